@@ -1,0 +1,855 @@
+// api.hip -- implementation of the C ABI declared in include/illuminant_hip.h.
+// Owns device memory behind opaque handles; validates arguments the way the
+// reference's host code does (same limits, same failure conditions) and turns
+// them into return codes that the C# wrapper rethrows as exceptions.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "internal.hpp"
+
+namespace {
+
+using namespace ilm;
+
+thread_local char g_last_error[512] = "";
+
+int32_t fail(int32_t code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return fail((int32_t)_e, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+    } while (0)
+
+enum : uint32_t {
+    kMagicCtx = 0x494C4D43u, kMagicEngine = 0x494C4D45u, kMagicSystem = 0x494C4D53u,
+    kMagicSdf = 0x494C4D44u, kMagicGBuffer = 0x494C4D47u, kMagicLightmap = 0x494C4D4Cu
+};
+
+struct Ctx {
+    uint32_t magic = kMagicCtx;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    // device staging for AoS <-> SoA conversion
+    void* staging = nullptr; size_t staging_bytes = 0;
+    // pinned ring for small asynchronous parameter uploads (light arrays)
+    static constexpr int kRing = 4;
+    void* pinned[kRing] = {}; size_t pinned_bytes[kRing] = {}; hipEvent_t pinned_ev[kRing] = {}; int ring_pos = 0;
+    IlmLightVertex* d_lights = nullptr; void* d_recs = nullptr; int light_cap = 0;
+    unsigned long long* d_stats = nullptr;
+};
+
+struct Engine {
+    uint32_t magic = kMagicEngine;
+    Ctx* ctx = nullptr;
+    int chunk_size = 0, slots = 0;
+    int64_t stride = 0;
+    float4* rnd = nullptr; int rw = 0, rh = 0;
+};
+
+struct Sdf {
+    uint32_t magic = kMagicSdf;
+    Ctx* ctx = nullptr;
+    uint2* texels = nullptr; int width = 0, height = 0, format = 0;
+};
+
+struct GBuffer {
+    uint32_t magic = kMagicGBuffer;
+    Ctx* ctx = nullptr;
+    void* texels = nullptr; int width = 0, height = 0, format = 0;
+};
+
+struct Lightmap {
+    uint32_t magic = kMagicLightmap;
+    Ctx* ctx = nullptr;
+    void* texels = nullptr; int width = 0, height = 0, format = 0; bool external = false;
+};
+
+struct System {
+    uint32_t magic = kMagicSystem;
+    Engine* engine = nullptr;
+    std::vector<float*> chunks;
+    float** d_table = nullptr; int table_cap = 0; bool table_dirty = true;
+    uint32_t* d_counts = nullptr; int counts_cap = 0;
+    Sdf* sdf = nullptr;
+    float4* ramp = nullptr; int ramp_w = 0, ramp_h = 0;
+    uint32_t* d_slots = nullptr; int slots_cap = 0; uint32_t* d_slot_count = nullptr;
+};
+
+template <typename T>
+T* from_handle(IlmHandle h, uint32_t magic) {
+    T* p = reinterpret_cast<T*>(static_cast<uintptr_t>(h));
+    if (p == nullptr || p->magic != magic)
+        return nullptr;
+    return p;
+}
+template <typename T>
+IlmHandle to_handle(T* p) { return static_cast<IlmHandle>(reinterpret_cast<uintptr_t>(p)); }
+
+size_t lightmap_texel_bytes(int format) {
+    return format == ILM_LIGHTMAP_FLOAT4 ? 16 : (format == ILM_LIGHTMAP_HALF4 ? 8 : 4);
+}
+
+int32_t ensure_staging(Ctx* c, size_t bytes) {
+    if (bytes <= c->staging_bytes)
+        return ILM_OK;
+    if (c->staging) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipFree(c->staging));
+        c->staging = nullptr; c->staging_bytes = 0;
+    }
+    size_t cap = bytes < (1u << 20) ? (1u << 20) : bytes;
+    HIP_TRY(hipMalloc(&c->staging, cap));
+    c->staging_bytes = cap;
+    return ILM_OK;
+}
+
+// copy a small host block to the device through the pinned ring (asynchronous)
+int32_t upload_small(Ctx* c, void* dst, const void* src, size_t bytes) {
+    const int slot = c->ring_pos;
+    c->ring_pos = (c->ring_pos + 1) % Ctx::kRing;
+    if (c->pinned_ev[slot] == nullptr)
+        HIP_TRY(hipEventCreateWithFlags(&c->pinned_ev[slot], hipEventDisableTiming));
+    else
+        HIP_TRY(hipEventSynchronize(c->pinned_ev[slot]));
+    if (c->pinned_bytes[slot] < bytes) {
+        if (c->pinned[slot]) HIP_TRY(hipHostFree(c->pinned[slot]));
+        c->pinned[slot] = nullptr; c->pinned_bytes[slot] = 0;
+        size_t cap = bytes < 65536 ? 65536 : bytes;
+        HIP_TRY(hipHostMalloc(&c->pinned[slot], cap, hipHostMallocDefault));
+        c->pinned_bytes[slot] = cap;
+    }
+    memcpy(c->pinned[slot], src, bytes);
+    HIP_TRY(hipMemcpyAsync(dst, c->pinned[slot], bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipEventRecord(c->pinned_ev[slot], c->stream));
+    return ILM_OK;
+}
+
+int32_t refresh_table(System* s) {
+    Ctx* c = s->engine->ctx;
+    const int n = (int)s->chunks.size();
+    if (n > s->table_cap) {
+        if (s->d_table) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(s->d_table)); s->d_table = nullptr; }
+        int cap = n < 64 ? 64 : n * 2;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_table), sizeof(float*) * (size_t)cap));
+        s->table_cap = cap;
+        s->table_dirty = true;
+    }
+    if (n > s->counts_cap) {
+        if (s->d_counts) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(s->d_counts)); s->d_counts = nullptr; }
+        int cap = n < 64 ? 64 : n * 2;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_counts), sizeof(uint32_t) * (size_t)cap));
+        HIP_TRY(hipMemsetAsync(s->d_counts, 0, sizeof(uint32_t) * (size_t)cap, c->stream));
+        s->counts_cap = cap;
+    }
+    if (s->table_dirty && n > 0) {
+        int32_t rc = upload_small(c, s->d_table, s->chunks.data(), sizeof(float*) * (size_t)n);
+        if (rc != ILM_OK) return rc;
+    }
+    s->table_dirty = false;
+    return ILM_OK;
+}
+
+int32_t validate_step(const System* s, const IlmStepDesc* d, int* first, int* count) {
+    const int n = (int)s->chunks.size();
+    if (d->OpCount < 0 || d->OpCount > ILM_MAX_OPS)
+        return fail(ILM_ERR_TOO_MANY, "OpCount %d outside [0, %d]", d->OpCount, ILM_MAX_OPS);
+    if (d->SpawnCount < 0 || d->SpawnCount > ILM_MAX_SPAWNS)
+        return fail(ILM_ERR_TOO_MANY, "SpawnCount %d outside [0, %d]", d->SpawnCount, ILM_MAX_SPAWNS);
+    if (d->UpdateMode < ILM_UPDATE_NONE || d->UpdateMode > ILM_UPDATE_ERASE)
+        return fail(ILM_ERR_INVALID_ARGUMENT, "unknown UpdateMode %d", d->UpdateMode);
+    for (int o = 0; o < d->OpCount; o++) {
+        const IlmTransformOp& op = d->Ops[o];
+        if (op.Type == ILM_OP_GRAVITY) {
+            // Transforms.cs:348-349: "Maximum number of attractors per instance is 16"
+            if (op.u.Gravity.AttractorCount > ILM_MAX_ATTRACTORS || op.u.Gravity.AttractorCount < 0)
+                return fail(ILM_ERR_TOO_MANY, "Maximum number of attractors per instance is %d", ILM_MAX_ATTRACTORS);
+        } else if (op.Type != ILM_OP_NOISE && op.Type != ILM_OP_FMA) {
+            return fail(ILM_ERR_INVALID_ARGUMENT, "unknown transform type %d", op.Type);
+        }
+    }
+    for (int k = 0; k < d->SpawnCount; k++) {
+        const IlmSpawnRecord& r = d->Spawns[k];
+        if (r.ChunkIndex < 0 || r.ChunkIndex >= n)
+            return fail(ILM_ERR_OUT_OF_RANGE, "spawn target chunk %d outside [0, %d)", r.ChunkIndex, n);
+        const float cs = r.Params.ChunkSizeAndIndices[0], first_i = r.Params.ChunkSizeAndIndices[1], last_i = r.Params.ChunkSizeAndIndices[2];
+        if ((int)cs != s->engine->chunk_size)
+            return fail(ILM_ERR_INVALID_ARGUMENT, "ChunkSizeAndIndices.x %g != engine chunk size %d", (double)cs, s->engine->chunk_size);
+        if (first_i < 0 || last_i >= (float)s->engine->slots)
+            return fail(ILM_ERR_OUT_OF_RANGE, "spawn range [%g, %g] outside the chunk", (double)first_i, (double)last_i);
+        if (r.Params.PositionConstantCount < 1.0f || r.Params.PositionConstantCount > (float)ILM_MAX_INLINE_POSITION_CONSTANTS)
+            return fail(ILM_ERR_OUT_OF_RANGE, "PositionConstantCount %g outside [1, %d]", (double)r.Params.PositionConstantCount,
+                        ILM_MAX_INLINE_POSITION_CONSTANTS);
+    }
+    if (d->UpdateMode == ILM_UPDATE_WITH_DISTANCE_FIELD && s->sdf == nullptr)
+        // ParticleSystem.cs:835-836
+        return fail(ILM_ERR_STATE, "UpdateWithDistanceField requires a distance field (ilm_system_set_distance_field)");
+    int f = d->FirstChunk, c = d->ChunkCount;
+    if (c < 0) { f = 0; c = n; }
+    if (f < 0 || f + c > n)
+        return fail(ILM_ERR_OUT_OF_RANGE, "chunk range [%d, %d) outside [0, %d)", f, f + c, n);
+    *first = f; *count = c;
+    return ILM_OK;
+}
+
+int32_t run_step(System* s, const IlmStepDesc* d) {
+    int first = 0, count = 0;
+    int32_t rc = validate_step(s, d, &first, &count);
+    if (rc != ILM_OK) return rc;
+    Engine* e = s->engine;
+    Ctx* c = e->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    rc = refresh_table(s);
+    if (rc != ILM_OK) return rc;
+    if (count == 0) return ILM_OK;
+    if (d->Flags & ILM_STEP_COUNT_LIVE)
+        HIP_TRY(hipMemsetAsync(s->d_counts, 0, sizeof(uint32_t) * (size_t)s->chunks.size(), c->stream));
+
+    StepLaunch a;
+    memcpy(&a.desc, d, sizeof(IlmStepDesc));
+    a.chunk_bases = s->d_table;
+    a.stride = e->stride;
+    a.chunk_size = e->chunk_size;
+    a.first_chunk = first;
+    a.chunk_count = count;
+    a.op_mask = 0;
+    for (int o = 0; o < d->OpCount; o++) a.op_mask |= 1u << d->Ops[o].Type;
+    a.rnd = e->rnd; a.rw = e->rw; a.rh = e->rh;
+    a.ramp = s->ramp; a.ramp_w = s->ramp_w; a.ramp_h = s->ramp_h;
+    a.sdf.texels = s->sdf ? s->sdf->texels : nullptr;
+    a.sdf.width = s->sdf ? s->sdf->width : 0;
+    a.sdf.height = s->sdf ? s->sdf->height : 0;
+    a.sdf.format = s->sdf ? s->sdf->format : ILM_SDF_UNORM16;
+    a.live_counts = s->d_counts;
+    HIP_TRY(launch_step(a, c->stream));
+    return ILM_OK;
+}
+
+int32_t copy_counts(System* s, uint32_t* out, int32_t capacity, int32_t saturate16) {
+    Ctx* c = s->engine->ctx;
+    const int n = (int)s->chunks.size();
+    if (capacity < n)
+        return fail(ILM_ERR_OUT_OF_RANGE, "capacity %d < chunk count %d", capacity, n);
+    if (n == 0) return ILM_OK;
+    HIP_TRY(hipMemcpyAsync(out, s->d_counts, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (saturate16)
+        for (int i = 0; i < n; i++)
+            if (out[i] > 65535u) out[i] = 65535u;   // 16-bit additive target, CountLiveParticles.fx:38 + ParticleEngine.cs:244-247
+    return ILM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t ilm_abi_version(void) { return ILM_ABI_VERSION; }
+const char* ilm_last_error(void) { return g_last_error; }
+
+int32_t ilm_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+// ---- context ------------------------------------------------------------------------------------
+
+int32_t ilm_ctx_create(int32_t device_id, IlmHandle* out_ctx) {
+    if (!out_ctx) return fail(ILM_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
+    *out_ctx = 0;
+    const int n = ilm_device_count();
+    if (n <= 0)
+        return fail(ILM_ERR_NO_DEVICE, "no HIP device visible: libilluminant_hip has no CPU fallback");
+    if (device_id < 0 || device_id >= n)
+        return fail(ILM_ERR_OUT_OF_RANGE, "device %d outside [0, %d)", device_id, n);
+    HIP_TRY(hipSetDevice(device_id));
+    Ctx* c = new (std::nothrow) Ctx();
+    if (!c) return fail(ILM_ERR_INVALID_ARGUMENT, "out of host memory");
+    c->device = device_id;
+    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&c->t0));
+    HIP_TRY(hipEventCreate(&c->t1));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_stats), 3 * sizeof(unsigned long long)));
+    *out_ctx = to_handle(c);
+    return ILM_OK;
+}
+
+int32_t ilm_ctx_destroy(IlmHandle h) {
+    Ctx* c = from_handle<Ctx>(h, kMagicCtx);
+    if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->staging) (void)hipFree(c->staging);
+    for (int i = 0; i < Ctx::kRing; i++) {
+        if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
+        if (c->pinned_ev[i]) (void)hipEventDestroy(c->pinned_ev[i]);
+    }
+    if (c->d_lights) (void)hipFree(c->d_lights);
+    if (c->d_recs) (void)hipFree(c->d_recs);
+    if (c->d_stats) (void)hipFree(c->d_stats);
+    (void)hipEventDestroy(c->t0);
+    (void)hipEventDestroy(c->t1);
+    (void)hipStreamDestroy(c->stream);
+    c->magic = 0;
+    delete c;
+    return ILM_OK;
+}
+
+int32_t ilm_ctx_sync(IlmHandle h) {
+    Ctx* c = from_handle<Ctx>(h, kMagicCtx);
+    if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ILM_OK;
+}
+
+int32_t ilm_ctx_stream(IlmHandle h, void** out_stream) {
+    Ctx* c = from_handle<Ctx>(h, kMagicCtx);
+    if (!c || !out_stream) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
+    *out_stream = reinterpret_cast<void*>(c->stream);
+    return ILM_OK;
+}
+
+int32_t ilm_timer_start(IlmHandle h) {
+    Ctx* c = from_handle<Ctx>(h, kMagicCtx);
+    if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
+    HIP_TRY(hipEventRecord(c->t0, c->stream));
+    return ILM_OK;
+}
+
+int32_t ilm_timer_stop(IlmHandle h, float* out_ms) {
+    Ctx* c = from_handle<Ctx>(h, kMagicCtx);
+    if (!c || !out_ms) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
+    HIP_TRY(hipEventRecord(c->t1, c->stream));
+    HIP_TRY(hipEventSynchronize(c->t1));
+    HIP_TRY(hipEventElapsedTime(out_ms, c->t0, c->t1));
+    return ILM_OK;
+}
+
+// ---- engine / system ------------------------------------------------------------------------------
+
+int32_t ilm_engine_create(IlmHandle hctx, int32_t chunk_size, const IlmFloat4* randomness, int32_t rw, int32_t rh, IlmHandle* out) {
+    Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);
+    if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
+    if (!out || !randomness) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = 0;
+    if (chunk_size < 4 || chunk_size > 4096)
+        return fail(ILM_ERR_OUT_OF_RANGE, "chunk_size %d outside [4, 4096]", chunk_size);
+    if (rw <= 0 || rh <= 0) return fail(ILM_ERR_INVALID_ARGUMENT, "bad randomness table size");
+    HIP_TRY(hipSetDevice(c->device));
+    Engine* e = new (std::nothrow) Engine();
+    if (!e) return fail(ILM_ERR_INVALID_ARGUMENT, "out of host memory");
+    e->ctx = c;
+    e->chunk_size = chunk_size;
+    e->slots = chunk_size * chunk_size;
+    e->stride = ((int64_t)e->slots + kSlotsPerBlock - 1) / kSlotsPerBlock * kSlotsPerBlock;
+    e->rw = rw; e->rh = rh;
+    const size_t bytes = sizeof(float4) * (size_t)rw * (size_t)rh;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->rnd), bytes));
+    HIP_TRY(hipMemcpy(e->rnd, randomness, bytes, hipMemcpyHostToDevice));
+    *out = to_handle(e);
+    return ILM_OK;
+}
+
+int32_t ilm_engine_destroy(IlmHandle h) {
+    Engine* e = from_handle<Engine>(h, kMagicEngine);
+    if (!e) return fail(ILM_ERR_INVALID_HANDLE, "not an engine handle");
+    (void)hipSetDevice(e->ctx->device);
+    (void)hipStreamSynchronize(e->ctx->stream);
+    if (e->rnd) (void)hipFree(e->rnd);
+    e->magic = 0;
+    delete e;
+    return ILM_OK;
+}
+
+int32_t ilm_system_create(IlmHandle hengine, IlmHandle* out) {
+    Engine* e = from_handle<Engine>(hengine, kMagicEngine);
+    if (!e) return fail(ILM_ERR_INVALID_HANDLE, "not an engine handle");
+    if (!out) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
+    System* s = new (std::nothrow) System();
+    if (!s) return fail(ILM_ERR_INVALID_ARGUMENT, "out of host memory");
+    s->engine = e;
+    *out = to_handle(s);
+    return ILM_OK;
+}
+
+int32_t ilm_system_destroy(IlmHandle h) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    Ctx* c = s->engine->ctx;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (float* p : s->chunks) (void)hipFree(p);
+    if (s->d_table) (void)hipFree(s->d_table);
+    if (s->d_counts) (void)hipFree(s->d_counts);
+    if (s->ramp) (void)hipFree(s->ramp);
+    if (s->d_slots) (void)hipFree(s->d_slots);
+    if (s->d_slot_count) (void)hipFree(s->d_slot_count);
+    s->magic = 0;
+    delete s;
+    return ILM_OK;
+}
+
+int32_t ilm_system_add_chunk(IlmHandle h, int32_t* out_index) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    Engine* e = s->engine;
+    HIP_TRY(hipSetDevice(e->ctx->device));
+    float* base = nullptr;
+    const size_t bytes = sizeof(float) * (size_t)kComponents * (size_t)e->stride;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&base), bytes));
+    HIP_TRY(hipMemsetAsync(base, 0, bytes, e->ctx->stream));
+    s->chunks.push_back(base);
+    s->table_dirty = true;
+    if (out_index) *out_index = (int32_t)s->chunks.size() - 1;
+    return ILM_OK;
+}
+
+int32_t ilm_system_remove_chunk(IlmHandle h, int32_t index) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (index < 0 || index >= (int)s->chunks.size())
+        return fail(ILM_ERR_OUT_OF_RANGE, "chunk %d outside [0, %d)", index, (int)s->chunks.size());
+    Ctx* c = s->engine->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipFree(s->chunks[(size_t)index]));
+    s->chunks.erase(s->chunks.begin() + index);
+    s->table_dirty = true;
+    return ILM_OK;
+}
+
+int32_t ilm_system_chunk_count(IlmHandle h, int32_t* out_count) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s || !out_count) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    *out_count = (int32_t)s->chunks.size();
+    return ILM_OK;
+}
+
+static int32_t check_plane_range(System* s, int32_t chunk, int32_t plane, int32_t first_slot, int32_t count) {
+    if (chunk < 0 || chunk >= (int)s->chunks.size())
+        return fail(ILM_ERR_OUT_OF_RANGE, "chunk %d outside [0, %d)", chunk, (int)s->chunks.size());
+    if (plane < ILM_PLANE_POSITION || plane > ILM_PLANE_RENDER_DATA)
+        return fail(ILM_ERR_INVALID_ARGUMENT, "unknown plane %d", plane);
+    if (first_slot < 0 || count < 0 || first_slot + count > s->engine->slots)
+        return fail(ILM_ERR_OUT_OF_RANGE, "slot range [%d, %d) outside [0, %d)", first_slot, first_slot + count, s->engine->slots);
+    return ILM_OK;
+}
+
+int32_t ilm_chunk_upload(IlmHandle h, int32_t chunk, int32_t plane, const IlmFloat4* src, int32_t first_slot, int32_t count) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (!src) return fail(ILM_ERR_INVALID_ARGUMENT, "src is NULL");
+    int32_t rc = check_plane_range(s, chunk, plane, first_slot, count);
+    if (rc != ILM_OK || count == 0) return rc;
+    Engine* e = s->engine; Ctx* c = e->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = sizeof(float4) * (size_t)count;
+    rc = ensure_staging(c, bytes);
+    if (rc != ILM_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(c->staging, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_aos_to_soa(reinterpret_cast<const float4*>(c->staging), s->chunks[(size_t)chunk] + (int64_t)plane * 4 * e->stride,
+                              e->stride, first_slot, count, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));   // staging is reused by the next call
+    return ILM_OK;
+}
+
+int32_t ilm_chunk_download(IlmHandle h, int32_t chunk, int32_t plane, IlmFloat4* dst, int32_t first_slot, int32_t count) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (!dst) return fail(ILM_ERR_INVALID_ARGUMENT, "dst is NULL");
+    int32_t rc = check_plane_range(s, chunk, plane, first_slot, count);
+    if (rc != ILM_OK || count == 0) return rc;
+    Engine* e = s->engine; Ctx* c = e->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = sizeof(float4) * (size_t)count;
+    rc = ensure_staging(c, bytes);
+    if (rc != ILM_OK) return rc;
+    HIP_TRY(launch_soa_to_aos(s->chunks[(size_t)chunk] + (int64_t)plane * 4 * e->stride, e->stride,
+                              reinterpret_cast<float4*>(c->staging), first_slot, count, c->stream));
+    HIP_TRY(hipMemcpyAsync(dst, c->staging, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ILM_OK;
+}
+
+int32_t ilm_chunk_device_ptr(IlmHandle h, int32_t chunk, int32_t component, void** out_ptr, int64_t* out_stride) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (chunk < 0 || chunk >= (int)s->chunks.size() || component < 0 || component >= kComponents)
+        return fail(ILM_ERR_OUT_OF_RANGE, "chunk/component out of range");
+    if (out_ptr) *out_ptr = s->chunks[(size_t)chunk] + (int64_t)component * s->engine->stride;
+    if (out_stride) *out_stride = s->engine->stride;
+    return ILM_OK;
+}
+
+int32_t ilm_system_set_distance_field(IlmHandle h, IlmHandle hsdf) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (hsdf == 0) { s->sdf = nullptr; return ILM_OK; }
+    Sdf* f = from_handle<Sdf>(hsdf, kMagicSdf);
+    if (!f) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle");
+    if (f->ctx != s->engine->ctx) return fail(ILM_ERR_INVALID_ARGUMENT, "distance field belongs to another context");
+    s->sdf = f;
+    return ILM_OK;
+}
+
+int32_t ilm_system_set_life_ramp(IlmHandle h, const IlmFloat4* texels, int32_t width, int32_t height) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    Ctx* c = s->engine->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (s->ramp) { HIP_TRY(hipFree(s->ramp)); s->ramp = nullptr; s->ramp_w = s->ramp_h = 0; }
+    if (!texels || width <= 0 || height <= 0) return ILM_OK;
+    const size_t bytes = sizeof(float4) * (size_t)width * (size_t)height;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->ramp), bytes));
+    HIP_TRY(hipMemcpy(s->ramp, texels, bytes, hipMemcpyHostToDevice));
+    s->ramp_w = width; s->ramp_h = height;
+    return ILM_OK;
+}
+
+int32_t ilm_system_step(IlmHandle h, const IlmStepDesc* desc) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (!desc) return fail(ILM_ERR_INVALID_ARGUMENT, "desc is NULL");
+    return run_step(s, desc);
+}
+
+static void init_single_pass(IlmStepDesc* d, int32_t chunk_index, const IlmParticleSystemUniforms* sys) {
+    memset(d, 0, sizeof(*d));
+    if (chunk_index < 0) { d->FirstChunk = 0; d->ChunkCount = -1; }
+    else { d->FirstChunk = chunk_index; d->ChunkCount = 1; }
+    if (sys) d->System = *sys;
+}
+
+int32_t ilm_spawn(IlmHandle h, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmSpawnParams* p) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (!p || chunk_index < 0) return fail(ILM_ERR_INVALID_ARGUMENT, "spawn needs parameters and a target chunk");
+    IlmStepDesc d;
+    init_single_pass(&d, chunk_index, sys);
+    d.SpawnCount = 1;
+    d.Spawns[0].ChunkIndex = chunk_index;
+    d.Spawns[0].Params = *p;
+    return run_step(s, &d);
+}
+
+int32_t ilm_gravity(IlmHandle h, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmGravityParams* p) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (!p || !sys) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
+    IlmStepDesc d;
+    init_single_pass(&d, chunk_index, sys);
+    d.OpCount = 1; d.Ops[0].Type = ILM_OP_GRAVITY; d.Ops[0].u.Gravity = *p;
+    return run_step(s, &d);
+}
+
+int32_t ilm_noise(IlmHandle h, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmNoiseParams* p) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (!p || !sys) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
+    IlmStepDesc d;
+    init_single_pass(&d, chunk_index, sys);
+    d.OpCount = 1; d.Ops[0].Type = ILM_OP_NOISE; d.Ops[0].u.Noise = *p;
+    return run_step(s, &d);
+}
+
+int32_t ilm_fma(IlmHandle h, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmFMAParams* p) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (!p || !sys) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
+    IlmStepDesc d;
+    init_single_pass(&d, chunk_index, sys);
+    d.OpCount = 1; d.Ops[0].Type = ILM_OP_FMA; d.Ops[0].u.FMA = *p;
+    return run_step(s, &d);
+}
+
+int32_t ilm_update(IlmHandle h, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmUpdateParams* p,
+                   const IlmDistanceFieldUniforms* df) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (!p || !sys) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
+    IlmStepDesc d;
+    init_single_pass(&d, chunk_index, sys);
+    d.Update = *p;
+    if (df) { d.DistanceField = *df; d.UpdateMode = ILM_UPDATE_WITH_DISTANCE_FIELD; }
+    else d.UpdateMode = ILM_UPDATE_POSITIONS;
+    return run_step(s, &d);
+}
+
+int32_t ilm_erase(IlmHandle h, int32_t chunk_index) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    IlmStepDesc d;
+    init_single_pass(&d, chunk_index, nullptr);
+    d.UpdateMode = ILM_UPDATE_ERASE;
+    return run_step(s, &d);
+}
+
+int32_t ilm_system_live_counts(IlmHandle h, uint32_t* out_counts, int32_t capacity, int32_t saturate16) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (!out_counts) return fail(ILM_ERR_INVALID_ARGUMENT, "out_counts is NULL");
+    Ctx* c = s->engine->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    int32_t rc = refresh_table(s);
+    if (rc != ILM_OK) return rc;
+    const int n = (int)s->chunks.size();
+    if (n > 0) {
+        HIP_TRY(hipMemsetAsync(s->d_counts, 0, sizeof(uint32_t) * (size_t)n, c->stream));
+        HIP_TRY(launch_count_live(s->d_table, s->engine->stride, n, s->d_counts, c->stream));
+    }
+    return copy_counts(s, out_counts, capacity, saturate16);
+}
+
+int32_t ilm_system_step_counts(IlmHandle h, uint32_t* out_counts, int32_t capacity, int32_t saturate16) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (!out_counts) return fail(ILM_ERR_INVALID_ARGUMENT, "out_counts is NULL");
+    HIP_TRY(hipSetDevice(s->engine->ctx->device));
+    if (s->d_counts == nullptr && !s->chunks.empty())
+        return fail(ILM_ERR_STATE, "no step with ILM_STEP_COUNT_LIVE has run");
+    return copy_counts(s, out_counts, capacity, saturate16);
+}
+
+int32_t ilm_chunk_live_slots(IlmHandle h, int32_t chunk, uint32_t* out_slots, int32_t capacity, int32_t* out_count) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (chunk < 0 || chunk >= (int)s->chunks.size())
+        return fail(ILM_ERR_OUT_OF_RANGE, "chunk %d outside [0, %d)", chunk, (int)s->chunks.size());
+    if (!out_count || capacity < 0 || (capacity > 0 && !out_slots)) return fail(ILM_ERR_INVALID_ARGUMENT, "bad output arguments");
+    Engine* e = s->engine; Ctx* c = e->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    if (s->slots_cap < e->slots) {
+        if (s->d_slots) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(s->d_slots)); s->d_slots = nullptr; }
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_slots), sizeof(uint32_t) * (size_t)e->slots));
+        s->slots_cap = e->slots;
+    }
+    if (!s->d_slot_count)
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_slot_count), sizeof(uint32_t)));
+    HIP_TRY(launch_live_slots(s->chunks[(size_t)chunk] + 3 * e->stride, e->slots, s->d_slots, (uint32_t)e->slots, s->d_slot_count, c->stream));
+    uint32_t n = 0;
+    HIP_TRY(hipMemcpyAsync(&n, s->d_slot_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *out_count = (int32_t)n;
+    const uint32_t m = n < (uint32_t)capacity ? n : (uint32_t)capacity;
+    if (m > 0) {
+        HIP_TRY(hipMemcpyAsync(out_slots, s->d_slots, sizeof(uint32_t) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return ILM_OK;
+}
+
+// ---- lighting resources -----------------------------------------------------------------------------
+
+int32_t ilm_sdf_create(IlmHandle hctx, int32_t w, int32_t ht, int32_t format, IlmHandle* out) {
+    Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);
+    if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
+    if (!out) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = 0;
+    // DistanceField.MaxSurfaceSize, SDF/DistanceField.cs:19
+    if (w <= 0 || ht <= 0 || w > 8192 || ht > 8192) return fail(ILM_ERR_OUT_OF_RANGE, "atlas %dx%d outside (0, 8192]", w, ht);
+    if (format != ILM_SDF_UNORM16 && format != ILM_SDF_FP16) return fail(ILM_ERR_INVALID_ARGUMENT, "unknown SDF format %d", format);
+    HIP_TRY(hipSetDevice(c->device));
+    Sdf* f = new (std::nothrow) Sdf();
+    if (!f) return fail(ILM_ERR_INVALID_ARGUMENT, "out of host memory");
+    f->ctx = c; f->width = w; f->height = ht; f->format = format;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f->texels), sizeof(uint2) * (size_t)w * (size_t)ht));
+    HIP_TRY(hipMemsetAsync(f->texels, 0, sizeof(uint2) * (size_t)w * (size_t)ht, c->stream));
+    *out = to_handle(f);
+    return ILM_OK;
+}
+
+int32_t ilm_sdf_upload(IlmHandle h, const uint16_t* texels) {
+    Sdf* f = from_handle<Sdf>(h, kMagicSdf);
+    if (!f) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle");
+    if (!texels) return fail(ILM_ERR_INVALID_ARGUMENT, "texels is NULL");
+    HIP_TRY(hipSetDevice(f->ctx->device));
+    HIP_TRY(hipMemcpyAsync(f->texels, texels, sizeof(uint2) * (size_t)f->width * (size_t)f->height, hipMemcpyHostToDevice, f->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(f->ctx->stream));
+    return ILM_OK;
+}
+
+int32_t ilm_sdf_destroy(IlmHandle h) {
+    Sdf* f = from_handle<Sdf>(h, kMagicSdf);
+    if (!f) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle");
+    (void)hipSetDevice(f->ctx->device);
+    (void)hipStreamSynchronize(f->ctx->stream);
+    if (f->texels) (void)hipFree(f->texels);
+    f->magic = 0;
+    delete f;
+    return ILM_OK;
+}
+
+int32_t ilm_gbuffer_create(IlmHandle hctx, int32_t w, int32_t ht, int32_t format, IlmHandle* out) {
+    Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);
+    if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
+    if (!out) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = 0;
+    if (w <= 0 || ht <= 0) return fail(ILM_ERR_OUT_OF_RANGE, "bad G-buffer size %dx%d", w, ht);
+    if (format != ILM_GBUFFER_FLOAT4 && format != ILM_GBUFFER_HALF4) return fail(ILM_ERR_INVALID_ARGUMENT, "unknown G-buffer format %d", format);
+    HIP_TRY(hipSetDevice(c->device));
+    GBuffer* g = new (std::nothrow) GBuffer();
+    if (!g) return fail(ILM_ERR_INVALID_ARGUMENT, "out of host memory");
+    g->ctx = c; g->width = w; g->height = ht; g->format = format;
+    const size_t bytes = (format == ILM_GBUFFER_FLOAT4 ? 16u : 8u) * (size_t)w * (size_t)ht;
+    HIP_TRY(hipMalloc(&g->texels, bytes));
+    HIP_TRY(hipMemsetAsync(g->texels, 0, bytes, c->stream));
+    *out = to_handle(g);
+    return ILM_OK;
+}
+
+int32_t ilm_gbuffer_upload(IlmHandle h, const void* texels) {
+    GBuffer* g = from_handle<GBuffer>(h, kMagicGBuffer);
+    if (!g) return fail(ILM_ERR_INVALID_HANDLE, "not a G-buffer handle");
+    if (!texels) return fail(ILM_ERR_INVALID_ARGUMENT, "texels is NULL");
+    HIP_TRY(hipSetDevice(g->ctx->device));
+    const size_t bytes = (g->format == ILM_GBUFFER_FLOAT4 ? 16u : 8u) * (size_t)g->width * (size_t)g->height;
+    HIP_TRY(hipMemcpyAsync(g->texels, texels, bytes, hipMemcpyHostToDevice, g->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+    return ILM_OK;
+}
+
+int32_t ilm_gbuffer_destroy(IlmHandle h) {
+    GBuffer* g = from_handle<GBuffer>(h, kMagicGBuffer);
+    if (!g) return fail(ILM_ERR_INVALID_HANDLE, "not a G-buffer handle");
+    (void)hipSetDevice(g->ctx->device);
+    (void)hipStreamSynchronize(g->ctx->stream);
+    if (g->texels) (void)hipFree(g->texels);
+    g->magic = 0;
+    delete g;
+    return ILM_OK;
+}
+
+int32_t ilm_lightmap_create(IlmHandle hctx, int32_t w, int32_t ht, int32_t format, void* external, IlmHandle* out) {
+    Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);
+    if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
+    if (!out) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = 0;
+    if (w <= 0 || ht <= 0) return fail(ILM_ERR_OUT_OF_RANGE, "bad lightmap size %dx%d", w, ht);
+    if (format < ILM_LIGHTMAP_FLOAT4 || format > ILM_LIGHTMAP_RGBA8) return fail(ILM_ERR_INVALID_ARGUMENT, "unknown lightmap format %d", format);
+    HIP_TRY(hipSetDevice(c->device));
+    Lightmap* m = new (std::nothrow) Lightmap();
+    if (!m) return fail(ILM_ERR_INVALID_ARGUMENT, "out of host memory");
+    m->ctx = c; m->width = w; m->height = ht; m->format = format;
+    if (external) {
+        m->texels = external;
+        m->external = true;
+    } else {
+        const size_t bytes = lightmap_texel_bytes(format) * (size_t)w * (size_t)ht;
+        HIP_TRY(hipMalloc(&m->texels, bytes));
+        HIP_TRY(hipMemsetAsync(m->texels, 0, bytes, c->stream));
+    }
+    *out = to_handle(m);
+    return ILM_OK;
+}
+
+int32_t ilm_lightmap_download(IlmHandle h, void* dst, int32_t first_row, int32_t row_count) {
+    Lightmap* m = from_handle<Lightmap>(h, kMagicLightmap);
+    if (!m) return fail(ILM_ERR_INVALID_HANDLE, "not a lightmap handle");
+    if (!dst) return fail(ILM_ERR_INVALID_ARGUMENT, "dst is NULL");
+    if (first_row < 0 || row_count < 0 || first_row + row_count > m->height)
+        return fail(ILM_ERR_OUT_OF_RANGE, "rows [%d, %d) outside [0, %d)", first_row, first_row + row_count, m->height);
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    const size_t row_bytes = lightmap_texel_bytes(m->format) * (size_t)m->width;
+    HIP_TRY(hipMemcpyAsync(dst, static_cast<const char*>(m->texels) + row_bytes * (size_t)first_row, row_bytes * (size_t)row_count,
+                           hipMemcpyDeviceToHost, m->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+    return ILM_OK;
+}
+
+int32_t ilm_lightmap_device_ptr(IlmHandle h, void** out_ptr) {
+    Lightmap* m = from_handle<Lightmap>(h, kMagicLightmap);
+    if (!m || !out_ptr) return fail(ILM_ERR_INVALID_HANDLE, "not a lightmap handle");
+    *out_ptr = m->texels;
+    return ILM_OK;
+}
+
+int32_t ilm_lightmap_destroy(IlmHandle h) {
+    Lightmap* m = from_handle<Lightmap>(h, kMagicLightmap);
+    if (!m) return fail(ILM_ERR_INVALID_HANDLE, "not a lightmap handle");
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    if (m->texels && !m->external) (void)hipFree(m->texels);
+    m->magic = 0;
+    delete m;
+    return ILM_OK;
+}
+
+int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, int32_t light_count, const IlmEnvironment* env,
+                                 const IlmDistanceFieldUniforms* df, IlmHandle hgbuffer, IlmHandle hsdf, const float ambient[4],
+                                 IlmHandle hlightmap, int32_t row_begin, int32_t row_end, IlmRenderStats* stats) {
+    Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);
+    if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
+    Lightmap* m = from_handle<Lightmap>(hlightmap, kMagicLightmap);
+    if (!m) return fail(ILM_ERR_INVALID_HANDLE, "not a lightmap handle");
+    GBuffer* g = nullptr; Sdf* f = nullptr;
+    if (hgbuffer) { g = from_handle<GBuffer>(hgbuffer, kMagicGBuffer); if (!g) return fail(ILM_ERR_INVALID_HANDLE, "not a G-buffer handle"); }
+    if (hsdf) { f = from_handle<Sdf>(hsdf, kMagicSdf); if (!f) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle"); }
+    if (!env || !df || !ambient) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (light_count < 0 || (light_count > 0 && !lights)) return fail(ILM_ERR_INVALID_ARGUMENT, "bad light array");
+    if (light_count > 65535) return fail(ILM_ERR_TOO_MANY, "at most 65535 lights per call");
+    if (m->ctx != c || (g && g->ctx != c) || (f && f->ctx != c)) return fail(ILM_ERR_INVALID_ARGUMENT, "resources belong to another context");
+    if (row_begin < 0 || row_end > m->height || row_begin > row_end)
+        return fail(ILM_ERR_OUT_OF_RANGE, "rows [%d, %d) outside [0, %d]", row_begin, row_end, m->height);
+    HIP_TRY(hipSetDevice(c->device));
+
+    if (light_count > c->light_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_lights) HIP_TRY(hipFree(c->d_lights));
+        if (c->d_recs) HIP_TRY(hipFree(c->d_recs));
+        c->d_lights = nullptr; c->d_recs = nullptr;
+        int cap = light_count < 256 ? 256 : light_count * 2;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_lights), sizeof(IlmLightVertex) * (size_t)cap));
+        HIP_TRY(hipMalloc(&c->d_recs, kLightRecBytes * (size_t)cap));
+        c->light_cap = cap;
+    }
+    if (light_count > 0) {
+        int32_t rc = upload_small(c, c->d_lights, lights, sizeof(IlmLightVertex) * (size_t)light_count);
+        if (rc != ILM_OK) return rc;
+        HIP_TRY(launch_prepare_lights(c->d_lights, light_count, *env, df->ConeAndMisc.x, c->d_recs, c->stream));
+    }
+
+    LightLaunch a;
+    a.lights = c->d_lights;
+    a.light_count = light_count;
+    a.env = *env;
+    a.df = *df;
+    a.gbuffer.texels = g ? g->texels : nullptr;
+    a.gbuffer.width = g ? g->width : 0; a.gbuffer.height = g ? g->height : 0; a.gbuffer.format = g ? g->format : 0;
+    a.sdf.texels = f ? f->texels : nullptr;
+    a.sdf.width = f ? f->width : 0; a.sdf.height = f ? f->height : 0; a.sdf.format = f ? f->format : ILM_SDF_UNORM16;
+    for (int i = 0; i < 4; i++) a.ambient[i] = ambient[i];
+    a.lightmap = m->texels; a.width = m->width; a.height = m->height; a.format = m->format;
+    a.row_begin = row_begin; a.row_end = row_end;
+    a.stats = nullptr;
+    if (stats) {
+        HIP_TRY(hipMemsetAsync(c->d_stats, 0, 3 * sizeof(unsigned long long), c->stream));
+        a.stats = c->d_stats;
+    }
+    HIP_TRY(launch_sphere_lights_prepared(a, c->d_recs, c->stream));
+    if (stats) {
+        unsigned long long host[3] = { 0, 0, 0 };
+        HIP_TRY(hipMemcpyAsync(host, c->d_stats, sizeof(host), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        stats->SdfSamples = host[0]; stats->PixelLightPairs = host[1]; stats->TracedPairs = host[2];
+    }
+    return ILM_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,73 @@
+// internal.hpp -- launch descriptors shared between the kernels (particles.hip,
+// lighting.hip) and the C-ABI implementation (api.hip).  Not part of the ABI.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/illuminant_hip.h"
+#include "hlsl_math.hpp"
+
+namespace ilm {
+
+// Component planes of one chunk, SoA, `stride` floats apart:
+//   0..3  x, y, z, life          (PositionAndLife)
+//   4..7  vx, vy, vz, category   (Velocity)
+//   8..11 attribute rgba         (Chunk.Color)
+//  12..15 render color rgba      (Chunk.RenderColor)
+//  16..19 render data            (Chunk.RenderData: size, rotation, speed, category)
+constexpr int kComponents = 20;
+constexpr int kSlotsPerThread = 4;         // widest variant; strides are padded for it
+constexpr int kDefaultStepSpt = 1;          // slots per thread of the step kernel (override: ILM_STEP_SPT=1|2|4)
+constexpr int kStepThreads = 256;
+constexpr int kSlotsPerBlock = kSlotsPerThread * kStepThreads;  // 1024; strides are padded to this
+
+struct StepLaunch {
+    IlmStepDesc desc;
+    float* const* chunk_bases;   // device table, one base pointer per chunk
+    int64_t stride;              // floats between component planes (multiple of kSlotsPerBlock)
+    int32_t chunk_size;
+    int32_t first_chunk, chunk_count;
+    uint32_t op_mask;            // bit t set when an op of type t is present
+    const float4* rnd; int32_t rw, rh;
+    const float4* ramp; int32_t ramp_w, ramp_h;
+    SdfView sdf;
+    uint32_t* live_counts;       // per chunk, zeroed by the caller when ILM_STEP_COUNT_LIVE
+};
+
+hipError_t launch_step(const StepLaunch& a, hipStream_t stream);
+
+// AoS float4 (device staging) <-> one SoA plane group (4 consecutive components)
+hipError_t launch_aos_to_soa(const float4* src, float* plane0, int64_t stride, int32_t first_slot, int32_t count, hipStream_t stream);
+hipError_t launch_soa_to_aos(const float* plane0, int64_t stride, float4* dst, int32_t first_slot, int32_t count, hipStream_t stream);
+
+// standalone liveness count over the life plane of each chunk (CountLiveParticles.fx)
+hipError_t launch_count_live(float* const* chunk_bases, int64_t stride, int32_t chunk_count, uint32_t* counts, hipStream_t stream);
+// ordered live-slot compaction of one chunk (ballot + prefix sum); *out_count is a device counter
+hipError_t launch_live_slots(const float* life, int32_t slots, uint32_t* out_slots, uint32_t capacity, uint32_t* out_count, hipStream_t stream);
+
+struct GBufferView {
+    const void* texels;
+    int32_t width, height, format;
+};
+
+struct LightLaunch {
+    const IlmLightVertex* lights;   // device
+    int32_t light_count;
+    IlmEnvironment env;
+    IlmDistanceFieldUniforms df;
+    GBufferView gbuffer;            // texels == nullptr => none
+    SdfView sdf;                    // texels == nullptr => none
+    float ambient[4];
+    void* lightmap; int32_t width, height, format;
+    int32_t row_begin, row_end;
+    unsigned long long* stats;      // device, 3 counters, or nullptr
+};
+
+constexpr size_t kLightRecBytes = 128;   // sizeof(LightRec) in lighting.hip
+// per-call preparation of the light records (footprint, cone config) into `recs` (device, count * kLightRecBytes)
+hipError_t launch_prepare_lights(const IlmLightVertex* lights, int count, const IlmEnvironment& env, float max_cone_radius,
+                                 void* recs, hipStream_t stream);
+hipError_t launch_sphere_lights_prepared(const LightLaunch& a, const void* recs, hipStream_t stream);
+
+}  // namespace ilm

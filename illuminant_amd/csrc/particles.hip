@@ -1,0 +1,843 @@
+// particles.hip -- ParticleEngine per-chunk state update for gfx950.
+//
+// One launch = one ParticleSystem.Update (Illuminant/Particles/ParticleSystem.cs:725-745):
+// the spawner pass, every active transform and the update pass are applied to a
+// slot in registers, in the reference's pass order, so a chunk streams through
+// HBM once (48 B read + 64 B written per live slot) instead of once per pass.
+// State is SoA; a thread owns 4 consecutive slots so every access is a 16-byte
+// load/store and a wave touches 1 KiB contiguous per instruction.
+//
+// HBM-bound integer/float streaming work: no MFMA, no LDS (no cross-slot reuse).
+#include <cstdlib>
+
+#include "internal.hpp"
+
+namespace ilm {
+
+// ---------------------------------------------------------------------------------------------
+// ParticleCommon.fxh:54-72 accessors
+// ---------------------------------------------------------------------------------------------
+ILM_DEV float dt_seconds(const IlmParticleSystemUniforms& s) { return s.GlobalSettings.x / kVelocityConstantScale; }
+
+// checkCategoryFilter, ParticleCommon.fxh:187-189
+ILM_DEV bool category_ok(float type, const float mm[2]) { return (type >= mm[0]) && (type <= mm[1]); }
+
+// randomCustom, RandomCommon.fxh:27-30 (POINT, WRAP)
+ILM_DEV float4 random_custom(const float4* __restrict__ rnd, int rw, int rh, float x, float y,
+                             float off_x, float off_y, float rate_x, float rate_y) {
+    const float texel_x = 1.0f / (float)rw, texel_y = 1.0f / (float)rh;
+    const float u = ((x * rate_x) + off_x) * texel_x;
+    const float v = ((y * rate_y) + off_y) * texel_y;
+    const int tx = wrap_index(floorf(u * (float)rw), rw);
+    const int ty = wrap_index(floorf(v * (float)rh), rh);
+    return rnd[ty * rw + tx];
+}
+
+// ---------------------------------------------------------------------------------------------
+// DistanceFunctionCommon.fxh -- area weights for FMA / Noise
+// ---------------------------------------------------------------------------------------------
+ILM_DEV float4 qmul(float4 q1, float4 q2) {
+    const f3 a = xyz(q2) * q1.w, b = xyz(q1) * q2.w, c = cross3(xyz(q1), xyz(q2));
+    const f3 s = (a + b) + c;
+    return mk4(s.x, s.y, s.z, q1.w * q2.w - dot3(xyz(q1), xyz(q2)));
+}
+ILM_DEV f3 rotate_local(f3 p, float r) {
+    // scalar AreaRotation promoted to float4(r,r,r,r) (FMA.fx:11,16-18)
+    const float4 rot = mk4(r, r, r, r);
+    const float4 r_c = mk4(r * -1.0f, r * -1.0f, r * -1.0f, r * 1.0f);
+    return xyz(qmul(rot, qmul(mk4(p.x, p.y, p.z, 0.0f), r_c)));
+}
+ILM_DEV float4 op_elongate(f3 p, f3 h) {
+    const f3 q = abs3(p) - h;
+    const f3 m = max03(q);
+    return mk4(sgn(p.x) * m.x, sgn(p.y) * m.y, sgn(p.z) * m.z, fminf(fmaxf(q.x, fmaxf(q.y, q.z)), 0.0f));
+}
+ILM_DEV float sd_octogon_prism(f3 p, float r, float h) {
+    const float kx = -0.9238795325f, ky = 0.3826834323f, kz = 0.4142135623f;
+    p = abs3(p);
+    const float d1 = fminf(kx * p.x + ky * p.y, 0.0f);
+    p.x -= 2.0f * d1 * kx;
+    p.y -= 2.0f * d1 * ky;
+    const float d2 = fminf(-kx * p.x + ky * p.y, 0.0f);
+    p.x -= 2.0f * d2 * -kx;
+    p.y -= 2.0f * d2 * ky;
+    p.x -= clampf(p.x, -kz * r, kz * r);
+    p.y -= r;
+    const float dx = sqrtf(p.x * p.x + p.y * p.y) * sgn(p.y);
+    const float dy = p.z - h;
+    const float mx = fmaxf(dx, 0.0f), my = fmaxf(dy, 0.0f);
+    return fminf(fmaxf(dx, dy), 0.0f) + sqrtf(mx * mx + my * my);
+}
+// evaluateByTypeId, DistanceFunctionCommon.fxh:170-187
+ILM_DEV float evaluate_area(int type_id, f3 wp, const IlmAreaParams& a) {
+    const int t = abs(type_id);
+    if (t < 1 || t > 5)
+        return 0.0f;
+    const f3 center = mk3(a.AreaCenter[0], a.AreaCenter[1], a.AreaCenter[2]);
+    const f3 size = mk3(a.AreaSize[0], a.AreaSize[1], a.AreaSize[2]);
+    const f3 p = rotate_local(wp - center, a.AreaRotation);
+    switch (t) {
+        case 1: {  // evaluateEllipsoid -> sdEllipsoid_improvedV2, :92-109
+            const float k0 = len3(mk3(p.x / size.x, p.y / size.y, p.z / size.z));
+            const float k1 = len3(mk3(p.x / (size.x * size.x), p.y / (size.y * size.y), p.z / (size.z * size.z)));
+            return (k0 < 1.0f) ? (k0 - 1.0f) * fminf(fminf(size.x, size.y), size.z) : k0 * (k0 - 1.0f) / k1;
+        }
+        case 2: {  // evaluateBox, :48-63
+            const f3 d = abs3(p) - size;
+            return fminf(fmaxf(d.x, fmaxf(d.y, d.z)), 0.0f) + len3(max03(d));
+        }
+        case 3: {  // evaluateCylinder -> sdCappedCylinder, :111-124
+            const float h = size.z, r = sqrtf(size.x * size.x + size.y * size.y);
+            const float dx = fabsf(sqrtf(p.x * p.x + p.y * p.y)) - r;
+            const float dy = fabsf(p.z) - h;
+            const float mx = fmaxf(dx, 0.0f), my = fmaxf(dy, 0.0f);
+            return fminf(fmaxf(dx, dy), 0.0f) + sqrtf(mx * mx + my * my);
+        }
+        case 4: {  // evaluateSpheroid, :65-75
+            const float min_size = fminf(size.x, fminf(size.y, size.z));
+            const float4 w = op_elongate(p, mk3(size.x - min_size, size.y - min_size, size.z - min_size));
+            return w.w + (len3(xyz(w)) - min_size);
+        }
+        default: {  // evaluateOctagon, :158-168
+            const float min_size = fminf(size.x, size.y);
+            const float4 w = op_elongate(p, mk3(size.x - min_size, size.y - min_size, 0.0f));
+            return w.w + sd_octogon_prism(xyz(w), min_size, size.z);
+        }
+    }
+}
+// computeWeight, FMA.fx:15-20 / Noise.fx:21-26
+ILM_DEV float compute_weight(const IlmAreaParams& a, f3 wp) {
+    const float distance = evaluate_area(a.AreaType, wp, a);
+    return (1.0f - sat(distance / a.AreaFalloff)) * a.Strength;
+}
+
+// ---------------------------------------------------------------------------------------------
+// transforms
+// ---------------------------------------------------------------------------------------------
+// PS_Gravity, Gravity.fx:12-61
+ILM_DEV void apply_gravity(float4& pos, float4& vel, const IlmParticleSystemUniforms& sys, const IlmGravityParams& p) {
+    if ((pos.w <= 0.0f) || !category_ok(vel.w, p.CategoryFilter))
+        return;
+    const float dt_ms = sys.GlobalSettings.x;
+    f3 acceleration = mk3(0.0f, 0.0f, 0.0f);
+    for (int i = 0; i < p.AttractorCount; i++) {
+        const f3 apos = mk3(p.AttractorPositions[i][0], p.AttractorPositions[i][1], p.AttractorPositions[i][2]);
+        const float radius = p.AttractorRadiusesAndStrengths[i][0];
+        const float strength = p.AttractorRadiusesAndStrengths[i][1];
+        const float type = p.AttractorRadiusesAndStrengths[i][2];
+        const f3 to_center = apos - xyz(pos);
+        float attraction;
+        if (type >= 0.5f) {
+            const float distance = len3(to_center);
+            attraction = 1.0f - sat(distance / radius);
+            if (type >= 1.5f)
+                attraction *= attraction;
+            attraction = attraction * dt_ms / kVelocityConstantScale;
+        } else {
+            float distance_squared = dot3(to_center, to_center) - radius;
+            distance_squared = fmaxf(distance_squared, 0.001f);
+            attraction = 1.0f / distance_squared;
+        }
+        acceleration = acceleration + ((norm3(to_center) * attraction) * strength);
+    }
+    const float maximum_acceleration = p.MaximumAcceleration * dt_ms / kVelocityConstantScale;
+    const float current_length = len3(acceleration);
+    if (current_length > maximum_acceleration)
+        acceleration = norm3(acceleration) * maximum_acceleration;
+    const float mv = sys.GlobalSettings.z;
+    vel.x = fminf(mv, vel.x + acceleration.x);
+    vel.y = fminf(mv, vel.y + acceleration.y);
+    vel.z = fminf(mv, vel.z + acceleration.z);
+}
+
+// PS_FMA, FMA.fx:22-51
+ILM_DEV void apply_fma(float4& pos, float4& vel, const IlmParticleSystemUniforms& sys, const IlmFMAParams& p) {
+    if ((pos.w <= 0.0f) || !category_ok(vel.w, p.Area.CategoryFilter))
+        return;
+    const float weight = compute_weight(p.Area, xyz(pos));
+    const float t = weight * sys.GlobalSettings.x / p.TimeDivisor;
+    const float4 np = lerp4(pos, add4(mul4(pos, ld4(p.PositionMultiply)), ld4(p.PositionAdd)), t);
+    const float4 nv = lerp4(vel, add4(mul4(vel, ld4(p.VelocityMultiply)), ld4(p.VelocityAdd)), t);
+    pos = np;
+    vel = nv;
+}
+
+ILM_DEV float4 noise_shape(float4 r, const IlmFloat4& offset, const IlmFloat4& minimum, const IlmFloat4& scale) {
+    const float4 d = add4(r, ld4(offset));
+    return mk4(sgn(d.x) * fmaxf(fabsf(d.x), minimum.x) * scale.x, sgn(d.y) * fmaxf(fabsf(d.y), minimum.y) * scale.y,
+               sgn(d.z) * fmaxf(fabsf(d.z), minimum.z) * scale.z, sgn(d.w) * fmaxf(fabsf(d.w), minimum.w) * scale.w);
+}
+
+// PS_Noise, Noise.fx:28-72 (no life check: dead slots go through the math, :40)
+ILM_DEV void apply_noise(float4& pos, float4& vel, float x, float y, const float4* __restrict__ rnd, int rw, int rh,
+                         const IlmParticleSystemUniforms& sys, const IlmNoiseParams& p) {
+    if (!category_ok(vel.w, p.Area.CategoryFilter))
+        return;
+    const float weight = compute_weight(p.Area, xyz(pos));
+    const float t = weight * sys.GlobalSettings.x / p.TimeDivisor;
+
+    const float rate_x = 1.0f / (float)rw, rate_y = 1.0f / (float)rh;  // rate = RandomnessTexel (Noise.fx:49-52)
+    const float4 p1 = random_custom(rnd, rw, rh, x, y, p.RandomnessOffset[0], p.RandomnessOffset[1], rate_x, rate_y);
+    const float4 p2 = random_custom(rnd, rw, rh, x, y, p.NextRandomnessOffset[0], p.NextRandomnessOffset[1], rate_x, rate_y);
+    const float4 v1 = random_custom(rnd, rw, rh, x + 2.0f, y + 1.0f, p.RandomnessOffset[0], p.RandomnessOffset[1], rate_x, rate_y);
+    const float4 v2 = random_custom(rnd, rw, rh, x + 2.0f, y + 1.0f, p.NextRandomnessOffset[0], p.NextRandomnessOffset[1], rate_x, rate_y);
+
+    const float4 position_delta = noise_shape(lerp4(p1, p2, p.FrequencyLerp), p.PositionOffset, p.PositionMinimum, p.PositionScale);
+    const float4 velocity_delta = noise_shape(lerp4(v1, v2, p.FrequencyLerp), p.VelocityOffset, p.VelocityMinimum, p.VelocityScale);
+
+    const float4 np = lerp4(pos, add4(pos, position_delta), t);
+    f3 nv;
+    if (p.ReplaceOldVelocity != 0.0f)
+        nv = mk3(lerp(vel.x, velocity_delta.x, weight), lerp(vel.y, velocity_delta.y, weight), lerp(vel.z, velocity_delta.z, weight));
+    else
+        nv = mk3(lerp(vel.x, vel.x + velocity_delta.x, t), lerp(vel.y, vel.y + velocity_delta.y, t), lerp(vel.z, vel.z + velocity_delta.z, t));
+    nv = nv + (norm3(xyz(vel)) * velocity_delta.w);
+    pos = np;
+    vel = mk4(nv.x, nv.y, nv.z, vel.w);
+}
+
+// ---------------------------------------------------------------------------------------------
+// spawner -- SpawnerCommon.fxh + PS_Spawn (SpawnParticles.fx:10-30)
+// ---------------------------------------------------------------------------------------------
+ILM_DEV f3 random_normal3(float rx, float ry) {
+    const float phi = rx * kPi * 2.0f;
+    const float costheta = (ry - 0.5f) * 2.0f;
+    const float theta = acosf(costheta);
+    float st, ct, sp, cp;
+    st = sinf(theta); ct = cosf(theta); sp = sinf(phi); cp = cosf(phi);
+    return mk3(st * cp, st * sp, ct);
+}
+
+// evaluateFormula, SpawnerCommon.fxh:59-104
+ILM_DEV float4 evaluate_formula(float4 origin, float4 constant, float4 scale, float4 offset, float4 randomness,
+                                float type, const float axis_mask[3]) {
+    const float4 type0 = add4(constant, mul4(add4(randomness, offset), scale));
+    const unsigned itype = (unsigned)fabsf(floorf(type));
+    if (itype == 1u || itype == 3u) {
+        f3 rn = random_normal3(randomness.x, randomness.y);
+        rn = norm3(mk3(rn.x * axis_mask[0], rn.y * axis_mask[1], rn.z * axis_mask[2]));
+        f3 circular = mk3(rn.x * randomness.z * scale.x, rn.y * randomness.z * scale.y, rn.z * randomness.z * scale.z);
+        f3 result;
+        if (itype == 3u) {
+            const float sqrt2 = 1.41421356237f;
+            const f3 edge = mk3(fabsf(offset.x), fabsf(offset.y), fabsf(offset.z));
+            result = mk3(clampf(offset.x * rn.x * sqrt2, -edge.x, edge.x), clampf(offset.y * rn.y * sqrt2, -edge.y, edge.y),
+                         clampf(offset.z * rn.z * sqrt2, -edge.z, edge.z));
+            result = result + (xyz(constant) + circular);
+        } else {
+            circular = circular + (rn * xyz(offset));
+            result = xyz(constant) + circular;
+        }
+        return mk4(result.x, result.y, result.z, type0.w);
+    }
+    if (itype == 2u) {
+        const f3 distance = xyz(constant) - xyz(origin);
+        const float ldistance = len3(distance);
+        if (ldistance < 0.1f)
+            return mk4(0.0f, 0.0f, 0.0f, constant.w);
+        const f3 direction = mk3(distance.x / ldistance, distance.y / ldistance, distance.z / ldistance);
+        const f3 random_speed = mk3(randomness.x * scale.x * direction.x, randomness.x * scale.y * direction.y, randomness.x * scale.z * direction.z);
+        const f3 s = random_speed + (xyz(offset) * direction);
+        return mk4(s.x, s.y, s.z, type0.w);
+    }
+    return type0;
+}
+
+ILM_DEV float4 mul_point(f3 v, const IlmMatrix& M) {
+    const float* m = M.m;
+    return mk4(v.x * m[0] + v.y * m[4] + v.z * m[8] + m[12], v.x * m[1] + v.y * m[5] + v.z * m[9] + m[13],
+               v.x * m[2] + v.y * m[6] + v.z * m[10] + m[14], v.x * m[3] + v.y * m[7] + v.z * m[11] + m[15]);
+}
+
+// Returns true when the slot was (re)written by the spawner.
+ILM_DEV bool spawn_slot(float4& pos, float4& vel, float4& attr, float x, float y,
+                        const float4* __restrict__ rnd, int rw, int rh, const IlmSpawnParams& p) {
+    const float index = x + (y * p.ChunkSizeAndIndices[0]);
+    if ((index < p.ChunkSizeAndIndices[1]) || (index > p.ChunkSizeAndIndices[2]))
+        return false;
+
+    const float ox = p.RandomnessOffset[0], oy = p.RandomnessOffset[1];
+    const float4 random1 = random_custom(rnd, rw, rh, fmodf(index, 8039.0f), 0.0f + fmodf(index, 57.0f), ox, oy, 1.0f, 1.0f);
+    float4 random2 = random_custom(rnd, rw, rh, fmodf(index, 6180.0f), 1.0f + fmodf(index, 4031.0f), ox, oy, 1.0f, 1.0f);
+    const float4 random3 = random_custom(rnd, rw, rh, fmodf(index, 2025.0f), 2.0f + fmodf(index, 65531.0f), ox, oy, 1.0f, 1.0f);
+    if (p.AlignVelocityAndPosition != 0.0f) {
+        random2.x = random1.x;
+        random2.y = random1.y;
+    }
+
+    int index1, index2;
+    float position_index_t;
+    const float relative_index = index - p.ChunkSizeAndIndices[1];
+    if (p.PolygonRate > 0.05f) {
+        const float position_index_f = (relative_index / p.PolygonRate) + p.ChunkSizeAndIndices[3];
+        const float divisor = p.PositionConstantCount;
+        float position_index_i;
+        position_index_t = modff(position_index_f, &position_index_i);
+        index1 = (int)fmodf(position_index_i, divisor);
+        if (p.PolygonLoop != 0.0f)
+            index2 = (int)fmodf(position_index_i + 1.0f, divisor);
+        else
+            index2 = (int)fminf((float)(index1 + 1), divisor - 1.0f);
+    } else {
+        index1 = index2 = (int)fmodf(relative_index + p.ChunkSizeAndIndices[3], p.PositionConstantCount);
+        position_index_t = 0.0f;
+    }
+    index1 = min(max(index1, 0), ILM_MAX_INLINE_POSITION_CONSTANTS - 1);
+    index2 = min(max(index2, 0), ILM_MAX_INLINE_POSITION_CONSTANTS - 1);
+
+    const float4 position1 = ld4(p.InlinePositionConstants[index1]), position2 = ld4(p.InlinePositionConstants[index2]);
+    const float4 position_constant = lerp4(position1, position2, position_index_t);
+    const float4 towards_next = sub4(position2, position1);
+
+    const float4 zero = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 temp_position = evaluate_formula(zero, position_constant, ld4(p.Configuration[0]), ld4(p.Configuration[1]),
+                                                  random1, p.FormulaTypes[0], p.AxisMask);
+    float4 new_position = mul_point(xyz(temp_position), p.PositionMatrix);
+    new_position.w = temp_position.w;
+
+    float4 temp_velocity = evaluate_formula(temp_position, ld4(p.Configuration[2]), ld4(p.Configuration[3]), ld4(p.Configuration[4]),
+                                            random2, p.FormulaTypes[1], p.AxisMask);
+    const float4 new_attributes = evaluate_formula(zero, ld4(p.Configuration[5]), ld4(p.Configuration[6]), ld4(p.Configuration[7]),
+                                                   random3, p.FormulaTypes[2], p.AxisMask);
+
+    const float towards_distance = sqrtf(towards_next.x * towards_next.x + towards_next.y * towards_next.y +
+                                         towards_next.z * towards_next.z + towards_next.w * towards_next.w);
+    if (towards_distance > 0.0001f) {
+        const float c = p.Configuration[8].x, s = p.Configuration[8].y, o = p.Configuration[8].z, r = random3.w;
+        const float towards_speed = evaluate_formula(zero, mk4(c, c, c, c), mk4(s, s, s, s), mk4(o, o, o, o), mk4(r, r, r, r),
+                                                     p.FormulaTypes[3], p.AxisMask).x;
+        temp_velocity = add4(temp_velocity, mk4((towards_next.x / towards_distance) * towards_speed, (towards_next.y / towards_distance) * towards_speed,
+                                                (towards_next.z / towards_distance) * towards_speed, (towards_next.w / towards_distance) * towards_speed));
+    }
+    float4 new_velocity = mul_point(xyz(temp_velocity), p.VelocityMatrix);
+    new_velocity.w = temp_velocity.w;
+
+    if (new_attributes.w < p.AttributeDiscardThreshold)
+        return false;
+    pos = new_position;
+    vel = new_velocity;
+    attr = new_attributes;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// update -- Bezier.fxh, UpdateCommon.fxh, UpdateParticleSystem*.fx
+// ---------------------------------------------------------------------------------------------
+// tForScaledBezier, Bezier.fxh:21-67
+ILM_DEV float t_for_scaled_bezier(const IlmFloat4& rc, float value, float& t) {
+    const float inv_divisor = rc.y;
+    const unsigned mode = (unsigned)fabsf(rc.w);
+    t = (value - rc.x) * fabsf(inv_divisor);
+    if (mode > 511u) {
+        t *= 2.0f;
+        t = (inv_divisor < 0.0f) ? (2.0f - fmodf(t, 2.0f)) : fmodf(t, 2.0f);
+        if (t > 1.0f)
+            t = 1.0f - (t - 1.0f);
+    } else if (mode > 255u) {
+        t = (inv_divisor < 0.0f) ? (1.0f - fmodf(t, 1.0f)) : fmodf(t, 1.0f);
+    } else {
+        t = (inv_divisor < 0.0f) ? (1.0f - sat(t)) : sat(t);
+    }
+    const unsigned m = mode % 256u;
+    if (m == 1u)
+        t = sinf(t * kPi * 0.5f);
+    else if (m == 2u)
+        t = t * t;
+    return rc.z;
+}
+// evaluateBezier1, Bezier.fxh:69-105
+ILM_DEV float bezier1(const IlmClampedBezier1& bz, float value) {
+    float t;
+    const float count = t_for_scaled_bezier(bz.RangeAndCount, value, t);
+    const float a = bz.ABCD.x, b = bz.ABCD.y, c = bz.ABCD.z, d = bz.ABCD.w;
+    if (count <= 1.5f) return a;
+    const float ab = lerp(a, b, t);
+    if (count <= 2.5f) return ab;
+    if (count <= 3.5f) return (t <= 0.0f) ? a : ((t >= 1.0f) ? c : b);
+    const float bc = lerp(b, c, t), cd = lerp(c, d, t);
+    return lerp(lerp(ab, bc, t), lerp(bc, cd, t), t);
+}
+// evaluateBezier4, Bezier.fxh:141-177
+ILM_DEV float4 bezier4(const IlmClampedBezier4& bz, float value) {
+    float t;
+    const float count = t_for_scaled_bezier(bz.RangeAndCount, value, t);
+    const float4 a = ld4(bz.A);
+    if (count <= 1.5f) return a;
+    const float4 b = ld4(bz.B);
+    const float4 ab = lerp4(a, b, t);
+    if (count <= 2.5f) return ab;
+    const float4 c = ld4(bz.C);
+    if (count <= 3.5f) return (t <= 0.0f) ? a : ((t >= 1.0f) ? c : b);
+    const float4 d = ld4(bz.D);
+    const float4 bc = lerp4(b, c, t), cd = lerp4(c, d, t);
+    return lerp4(lerp4(ab, bc, t), lerp4(bc, cd, t), t);
+}
+
+// applyFrictionAndMaximum, UpdateCommon.fxh:20-35
+ILM_DEV f3 friction_and_maximum(f3 velocity, const IlmParticleSystemUniforms& sys) {
+    float l = len3(velocity);
+    if (l <= 0.001f)
+        return mk3(0.0f, 0.0f, 0.0f);
+    const float mv = sys.GlobalSettings.z;
+    if (l > mv)
+        l = mv;
+    const float friction = l * sys.GlobalSettings.y;
+    l -= (friction * dt_seconds(sys));
+    l = clampf(l, 0.0f, mv);
+    return norm3(velocity) * l;
+}
+
+// computeRenderData, UpdateCommon.fxh:96-117
+ILM_DEV void render_data(float vx, float vy, float4 position, float4 velocity, float4 attributes,
+                         const IlmParticleSystemUniforms& sys, const IlmUpdateParams& p,
+                         const float4* __restrict__ ramp, int ramp_w, int ramp_h,
+                         float4& render_color, float4& rdata) {
+    if (position.w <= 0.0f) {
+        render_color = rdata = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+        return;
+    }
+    const float index = vx + (vy * 256.0f);  // reference quirk: 256 regardless of ChunkSize (:107)
+    const float velocity_length = fmaxf(len3(xyz(velocity)), 0.0001f);
+
+    float4 color = mul4(bezier4(p.ColorFromLife, position.w), bezier4(p.ColorFromVelocity, velocity_length));
+    if (p.LifeRampSettings.x != 0.0f) {
+        float u = (position.w - p.LifeRampSettings.y) / p.LifeRampSettings.z;
+        if (p.LifeRampSettings.x < 0.0f)
+            u = 1.0f - sat(u);
+        const float v = index / p.LifeRampSettings.w;
+        float4 texel = mk4(1.0f, 1.0f, 1.0f, 1.0f);
+        if (ramp != nullptr && ramp_w > 0 && ramp_h > 0) {
+            const int tx = min(max((int)floorf(u * (float)ramp_w), 0), ramp_w - 1);   // U CLAMP
+            const int ty = wrap_index(floorf(v * (float)ramp_h), ramp_h);             // V WRAP
+            texel = ramp[ty * ramp_w + tx];
+        }
+        color = lerp4(color, mul4(texel, color), sat(fabsf(p.LifeRampSettings.x)));
+    }
+
+    float4 rc = mul4(attributes, color);
+    rc.w = sat(rc.w);
+    rc.x *= rc.w; rc.y *= rc.w; rc.z *= rc.w;
+    render_color = rc;
+
+    // getRotationForVelocity, UpdateCommon.fxh:81-94
+    float rotation = 0.0f;
+    if (!((fabsf(velocity.x) < 0.01f) && (fabsf(velocity.y) < 0.01f))) {
+        rotation = atan2f(velocity.y, velocity.x);
+        if (rotation < 0.0f)
+            rotation += 2.0f * kPi;
+    }
+    rdata.x = bezier1(p.SizeFromLife, position.w) * bezier1(p.SizeFromVelocity, velocity_length);
+    rdata.y = (rotation * sys.AnimationRateAndRotationAndZToY.z) +
+              ((position.w * p.RotationFromLifeAndIndex[0]) + (index * p.RotationFromLifeAndIndex[1]));
+    rdata.z = velocity_length;
+    rdata.w = velocity.w;
+}
+
+// PS_Update, UpdateParticleSystem.fx:9-38 (live slot)
+ILM_DEV void update_positions(float4& pos, float4& vel, const IlmParticleSystemUniforms& sys) {
+    const f3 velocity = friction_and_maximum(xyz(vel), sys);
+    const float dts = dt_seconds(sys);
+    const float new_life = pos.w - (sys.GlobalSettings.w * dts);
+    if (new_life <= 0.0f) {
+        pos = vel = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+    } else {
+        pos = mk4(pos.x + velocity.x * dts, pos.y + velocity.y * dts, pos.z + velocity.z * dts, new_life);
+        vel = mk4(velocity.x, velocity.y, velocity.z, vel.w);
+    }
+}
+
+// estimateNormal4, VisualizeCommon.fxh:44-63
+template <int FMT>
+ILM_DEV f3 estimate_normal4(f3 position, const IlmDistanceFieldUniforms& df, const SdfView& sdf) {
+    const f3 texel = mk3(df.ConeAndMisc.w, df.StepAndMisc2.w, df.Extent.z / fmaxf(df.TextureSliceCount.w, 1.0f));
+    f3 result = mk3(0.0f, 0.0f, 0.0f);
+    const float W[4][3] = { { 1, -1, -1 }, { -1, -1, 1 }, { -1, 1, -1 }, { 1, 1, 1 } };
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const f3 w = mk3(W[i][0], W[i][1], W[i][2]);
+        const float s = sample_distance_field<FMT>(position + (w * texel), df, sdf);
+        result = result + (w * s);
+    }
+    return norm3(result);
+}
+
+// PS_Update, UpdateParticleSystemWithDistanceField.fx:29-147 (live slot)
+template <int FMT>
+ILM_DEV void update_with_distance_field(float4& pos, float4& vel, float x, float y, const IlmParticleSystemUniforms& sys,
+                                        const IlmDistanceFieldUniforms& df, const SdfView& sdf) {
+    const float4 zero = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float dts = dt_seconds(sys);
+    float new_life = pos.w - (sys.GlobalSettings.w * dts);
+    if (new_life <= 0.0f) {
+        pos = vel = zero;
+        return;
+    }
+    const float collision_distance = sys.CollisionSettings.z;
+    const float max_velocity = sys.GlobalSettings.z;
+    const f3 old_xyz = xyz(pos);
+    const f3 unit_vector = norm3(xyz(vel));
+    const f3 velocity = friction_and_maximum(xyz(vel), sys);
+    const f3 scaled_velocity = velocity * dts;
+
+    bool collided = false, escaping = false;
+    f3 collision_position = mk3(0.0f, 0.0f, 0.0f), new_position = old_xyz;
+    float4 new_velocity = zero;
+
+    const float initial_distance = sample_distance_field<FMT>(old_xyz, df, sdf);
+    const bool was_colliding = initial_distance < collision_distance;
+    float travel_distance = fmaxf(0.0f, fminf(initial_distance, len3(scaled_velocity)));
+    int step_count = 3;  // MAX_STEP_COUNT
+    if (was_colliding)
+        step_count = 1;
+    else if (travel_distance <= 0.001f)
+        step_count = 0;
+
+    for (int i = 0; i < step_count; i++) {
+        const f3 test_position = old_xyz + (unit_vector * travel_distance);
+        const float step_distance = sample_distance_field<FMT>(test_position, df, sdf);
+        if (step_distance < collision_distance) {
+            collided = true;
+            collision_position = test_position;
+        }
+        escaping = step_distance > initial_distance;
+        if (collided && !escaping) {
+            collision_position = test_position;
+            const float offset = clampf(step_distance + collision_distance, 0.05f, 16.0f);
+            travel_distance = fmaxf(0.0f, travel_distance - offset);
+        } else
+            step_count = 0;
+        if (travel_distance <= 0.001f)
+            step_count = 0;
+    }
+
+    if (collided) {
+        const bool bounce = vel.w <= 0.0f;
+        const bool redirect = was_colliding && !escaping;
+        f3 normal = mk3(0.0f, 0.0f, 0.0f);
+        if (bounce || redirect)
+            normal = estimate_normal4<FMT>(collision_position, df, sdf);
+        const float escape_speed = fminf(max_velocity, sys.CollisionSettings.x);
+        if (redirect) {
+            normal = normal * mk3(1.0f, 1.0f, 0.0f);  // ESCAPE_MASK
+            if (len3(normal) < 0.33f) {
+                const float a = (x / 67.0f) + (y / 13.0f);
+                normal = mk3(sinf(a), cosf(a), 0.0f);
+            }
+            const f3 nv = (norm3(normal) * escape_speed) * 0.33f;  // INITIAL_ESCAPE_SPEED
+            new_velocity = mk4(nv.x, nv.y, nv.z, 3.0f);           // BOUNCE_DELAY
+            new_position = old_xyz + (nv * dts);
+        } else if (bounce) {
+            const float d2 = 2.0f * dot3(normal, unit_vector);
+            f3 bounce_vector = ((normal - unit_vector) * d2) * -1.0f;
+            if (len3(bounce_vector) < 0.33f)
+                bounce_vector = unit_vector * -1.0f;
+            else
+                bounce_vector = norm3(bounce_vector);
+            new_position = collision_position;
+            const f3 nv = bounce_vector * fminf(max_velocity, len3(velocity) * sys.CollisionSettings.y);
+            new_velocity = mk4(nv.x, nv.y, nv.z, 3.0f);
+            new_life -= sys.CollisionSettings.w;
+        } else {
+            const float new_speed = fmaxf(len3(xyz(vel)) * 1.1f, escape_speed);  // ESCAPE_SPEED_ACCELERATION
+            const f3 nv = unit_vector * new_speed;
+            new_velocity = mk4(nv.x, nv.y, nv.z, 0.0f);
+            new_position = old_xyz + (unit_vector * travel_distance);
+        }
+    } else {
+        new_velocity = mk4(velocity.x, velocity.y, velocity.z, fmaxf(vel.w - 1.0f, 0.0f));
+        new_position = old_xyz + (unit_vector * travel_distance);
+    }
+    if (new_life <= 0.0f) {
+        new_position = mk3(0.0f, 0.0f, 0.0f);
+        new_velocity = zero;
+    }
+    pos = mk4(new_position.x, new_position.y, new_position.z, new_life);
+    vel = new_velocity;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the fused step kernel
+// ---------------------------------------------------------------------------------------------
+// SPT = slots per thread.  A thread owns SPT consecutive slots, so each component
+// plane is accessed with one SPT*4-byte load/store per thread (a wave covers
+// SPT*256 contiguous bytes per instruction).  All SPT values give fully coalesced
+// traffic; they trade bytes in flight per thread against register pressure.
+template <int SPT> struct VecIO;
+template <> struct VecIO<1> {
+    static ILM_DEV void load(const float* p, float (&v)[1]) { v[0] = *p; }
+    static ILM_DEV void store(float* p, const float (&v)[1]) { *p = v[0]; }
+};
+template <> struct VecIO<2> {
+    static ILM_DEV void load(const float* p, float (&v)[2]) { const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y; }
+    static ILM_DEV void store(float* p, const float (&v)[2]) { *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]); }
+};
+template <> struct VecIO<4> {
+    static ILM_DEV void load(const float* p, float (&v)[4]) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    static ILM_DEV void store(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+};
+
+template <int FMT, int SPT>
+__global__ __launch_bounds__(kStepThreads) void step_kernel(const StepLaunch a) {
+    const IlmStepDesc& d = a.desc;
+    const int chunk = a.first_chunk + (int)blockIdx.y;
+    float* __restrict__ base = a.chunk_bases[chunk];
+    const int64_t S = a.stride;
+    const int i0 = ((int)blockIdx.x * kStepThreads + (int)threadIdx.x) * SPT;
+    const int mode = d.UpdateMode;
+    const float4 zero = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+    float zeros[SPT];
+#pragma unroll
+    for (int j = 0; j < SPT; j++) zeros[j] = 0.0f;
+
+    float life[SPT];
+    VecIO<SPT>::load(base + 3 * S + i0, life);
+    bool any_live = false;
+#pragma unroll
+    for (int j = 0; j < SPT; j++) any_live = any_live || (life[j] > 0.0f);
+
+    // does a spawn record target one of this thread's slots?
+    bool spawn_here = false;
+    for (int s = 0; s < d.SpawnCount; s++) {
+        const IlmSpawnRecord& r = d.Spawns[s];
+        if (r.ChunkIndex == chunk) {
+            const float first = r.Params.ChunkSizeAndIndices[1], last = r.Params.ChunkSizeAndIndices[2];
+            if (((float)(i0 + SPT - 1) >= first) && ((float)i0 <= last))
+                spawn_here = true;
+        }
+    }
+    const bool has_noise = (a.op_mask & (1u << ILM_OP_NOISE)) != 0u;
+    const bool need_attr = (mode == ILM_UPDATE_POSITIONS) || (mode == ILM_UPDATE_WITH_DISTANCE_FIELD);
+    const bool full = (mode != ILM_UPDATE_ERASE) && (any_live || spawn_here || has_noise);
+
+    uint32_t live_after = 0;  // bit j: slot j alive after the step
+
+    if (mode == ILM_UPDATE_ERASE) {
+        // PS_Erase, UpdateParticleSystem.fx:40-49
+#pragma unroll
+        for (int c = 0; c < 8; c++) VecIO<SPT>::store(base + c * S + i0, zeros);
+#pragma unroll
+        for (int c = 12; c < 20; c++) VecIO<SPT>::store(base + c * S + i0, zeros);
+    } else if (!full) {
+        // every slot dead and nothing writes it: the update pass leaves the cleared target
+        // (UpdateHandler._BeforeDraw clears, ParticleTransform.cs:164-165; readStateOrDiscard discards)
+        if (mode != ILM_UPDATE_NONE) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) VecIO<SPT>::store(base + c * S + i0, zeros);
+#pragma unroll
+            for (int c = 12; c < 20; c++) VecIO<SPT>::store(base + c * S + i0, zeros);
+        }
+    } else {
+        float px[SPT], py[SPT], pz[SPT], vx[SPT], vy[SPT], vz[SPT], ct[SPT];
+        float ar[SPT], ag[SPT], ab[SPT], aa[SPT];
+        float cr[SPT], cg[SPT], cb[SPT], ca[SPT], dx[SPT], dy[SPT], dz[SPT], dw[SPT];
+        VecIO<SPT>::load(base + 0 * S + i0, px); VecIO<SPT>::load(base + 1 * S + i0, py); VecIO<SPT>::load(base + 2 * S + i0, pz);
+        VecIO<SPT>::load(base + 4 * S + i0, vx); VecIO<SPT>::load(base + 5 * S + i0, vy); VecIO<SPT>::load(base + 6 * S + i0, vz);
+        VecIO<SPT>::load(base + 7 * S + i0, ct);
+        if (need_attr || spawn_here) {
+            VecIO<SPT>::load(base + 8 * S + i0, ar); VecIO<SPT>::load(base + 9 * S + i0, ag);
+            VecIO<SPT>::load(base + 10 * S + i0, ab); VecIO<SPT>::load(base + 11 * S + i0, aa);
+        } else {
+#pragma unroll
+            for (int j = 0; j < SPT; j++) ar[j] = ag[j] = ab[j] = aa[j] = 0.0f;
+        }
+        bool spawned_any = false;
+
+        int sx = i0 % a.chunk_size, sy = i0 / a.chunk_size;
+#pragma unroll
+        for (int j = 0; j < SPT; j++) {
+            float4 pos = mk4(px[j], py[j], pz[j], life[j]);
+            float4 vel = mk4(vx[j], vy[j], vz[j], ct[j]);
+            float4 attr = mk4(ar[j], ag[j], ab[j], aa[j]);
+            const float fx = (float)sx, fy = (float)sy;
+
+            if (spawn_here) {
+                for (int s = 0; s < d.SpawnCount; s++) {
+                    if (d.Spawns[s].ChunkIndex == chunk) {
+                        if (spawn_slot(pos, vel, attr, fx, fy, a.rnd, a.rw, a.rh, d.Spawns[s].Params))
+                            spawned_any = true;
+                    }
+                }
+            }
+
+            for (int o = 0; o < d.OpCount; o++) {
+                const IlmTransformOp& op = d.Ops[o];
+                if (op.Type == ILM_OP_GRAVITY)
+                    apply_gravity(pos, vel, d.System, op.u.Gravity);
+                else if (op.Type == ILM_OP_NOISE)
+                    apply_noise(pos, vel, fx, fy, a.rnd, a.rw, a.rh, d.System, op.u.Noise);
+                else if (op.Type == ILM_OP_FMA)
+                    apply_fma(pos, vel, d.System, op.u.FMA);
+            }
+
+            float4 rc = zero, rd = zero;
+            if (need_attr) {
+                if (pos.w <= 0.0f) {
+                    pos = vel = zero;  // readStateOrDiscard: discard => cleared target
+                } else {
+                    if (mode == ILM_UPDATE_WITH_DISTANCE_FIELD)
+                        update_with_distance_field<FMT>(pos, vel, fx, fy, d.System, d.DistanceField, a.sdf);
+                    else
+                        update_positions(pos, vel, d.System);
+                    render_data(fx, fy, pos, vel, attr, d.System, d.Update, a.ramp, a.ramp_w, a.ramp_h, rc, rd);
+                }
+            }
+            cr[j] = rc.x; cg[j] = rc.y; cb[j] = rc.z; ca[j] = rc.w;
+            dx[j] = rd.x; dy[j] = rd.y; dz[j] = rd.z; dw[j] = rd.w;
+            px[j] = pos.x; py[j] = pos.y; pz[j] = pos.z; life[j] = pos.w;
+            vx[j] = vel.x; vy[j] = vel.y; vz[j] = vel.z; ct[j] = vel.w;
+            ar[j] = attr.x; ag[j] = attr.y; ab[j] = attr.z; aa[j] = attr.w;
+            if (pos.w > 0.0f)
+                live_after |= (1u << j);
+
+            if (++sx >= a.chunk_size) { sx = 0; sy++; }
+        }
+
+        VecIO<SPT>::store(base + 0 * S + i0, px); VecIO<SPT>::store(base + 1 * S + i0, py); VecIO<SPT>::store(base + 2 * S + i0, pz);
+        VecIO<SPT>::store(base + 3 * S + i0, life);
+        VecIO<SPT>::store(base + 4 * S + i0, vx); VecIO<SPT>::store(base + 5 * S + i0, vy); VecIO<SPT>::store(base + 6 * S + i0, vz);
+        VecIO<SPT>::store(base + 7 * S + i0, ct);
+        if (spawned_any) {
+            VecIO<SPT>::store(base + 8 * S + i0, ar); VecIO<SPT>::store(base + 9 * S + i0, ag);
+            VecIO<SPT>::store(base + 10 * S + i0, ab); VecIO<SPT>::store(base + 11 * S + i0, aa);
+        }
+        if (need_attr) {
+            VecIO<SPT>::store(base + 12 * S + i0, cr); VecIO<SPT>::store(base + 13 * S + i0, cg);
+            VecIO<SPT>::store(base + 14 * S + i0, cb); VecIO<SPT>::store(base + 15 * S + i0, ca);
+            VecIO<SPT>::store(base + 16 * S + i0, dx); VecIO<SPT>::store(base + 17 * S + i0, dy);
+            VecIO<SPT>::store(base + 18 * S + i0, dz); VecIO<SPT>::store(base + 19 * S + i0, dw);
+        }
+    }
+
+    if (!full && mode == ILM_UPDATE_NONE) {
+        // untouched slots keep their liveness when no update pass ran
+#pragma unroll
+        for (int j = 0; j < SPT; j++)
+            if (life[j] > 0.0f) live_after |= (1u << j);
+    }
+
+    if (d.Flags & ILM_STEP_COUNT_LIVE) {
+        // CountLiveParticles.fx: wave64 ballot + popcount, one atomic per wave
+        uint32_t n = 0;
+#pragma unroll
+        for (int j = 0; j < SPT; j++)
+            n += (uint32_t)__popcll(__ballot((live_after >> j) & 1u));
+        if ((threadIdx.x & 63) == 0 && n != 0)
+            atomicAdd(&a.live_counts[chunk], n);
+    }
+}
+
+static int g_step_spt = 0;   // 0 => take ILM_STEP_SPT from the environment (default 1)
+
+template <int SPT>
+static hipError_t launch_step_spt(const StepLaunch& a, hipStream_t stream) {
+    const dim3 grid((unsigned)(a.stride / (kStepThreads * SPT)), (unsigned)a.chunk_count, 1);
+    const dim3 block(kStepThreads, 1, 1);
+    if (a.sdf.format == ILM_SDF_FP16)
+        hipLaunchKernelGGL((step_kernel<ILM_SDF_FP16, SPT>), grid, block, 0, stream, a);
+    else
+        hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, SPT>), grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_step(const StepLaunch& a, hipStream_t stream) {
+    if (a.chunk_count <= 0)
+        return hipSuccess;
+    if (g_step_spt == 0) {
+        const char* e = getenv("ILM_STEP_SPT");
+        const int v = e ? atoi(e) : 0;
+        g_step_spt = (v == 1 || v == 2 || v == 4) ? v : kDefaultStepSpt;
+    }
+    switch (g_step_spt) {
+        case 4: return launch_step_spt<4>(a, stream);
+        case 2: return launch_step_spt<2>(a, stream);
+        default: return launch_step_spt<1>(a, stream);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// layout conversion: the reference API speaks AoS float4 (Spawn initializers, AutoReadback)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void aos_to_soa_kernel(const float4* __restrict__ src, float* __restrict__ plane0, int64_t stride,
+                                                          int first_slot, int count) {
+    const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (i >= count) return;
+    const float4 v = src[i];
+    float* p = plane0 + first_slot + i;
+    p[0] = v.x; p[stride] = v.y; p[2 * stride] = v.z; p[3 * stride] = v.w;
+}
+__global__ __launch_bounds__(256) void soa_to_aos_kernel(const float* __restrict__ plane0, int64_t stride, float4* __restrict__ dst,
+                                                          int first_slot, int count) {
+    const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (i >= count) return;
+    const float* p = plane0 + first_slot + i;
+    dst[i] = mk4(p[0], p[stride], p[2 * stride], p[3 * stride]);
+}
+hipError_t launch_aos_to_soa(const float4* src, float* plane0, int64_t stride, int32_t first_slot, int32_t count, hipStream_t stream) {
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(aos_to_soa_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, src, plane0, stride, first_slot, count);
+    return hipGetLastError();
+}
+hipError_t launch_soa_to_aos(const float* plane0, int64_t stride, float4* dst, int32_t first_slot, int32_t count, hipStream_t stream) {
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(soa_to_aos_kernel, dim3((count + 255) / 256), dim3(256), 0, stream, plane0, stride, dst, first_slot, count);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// liveness: standalone count + ordered live-slot compaction
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void count_live_kernel(float* const* __restrict__ bases, int64_t stride, uint32_t* __restrict__ counts) {
+    const int chunk = (int)blockIdx.y;
+    const float* life = bases[chunk] + 3 * stride;
+    const int i0 = ((int)blockIdx.x * 256 + (int)threadIdx.x) * 4;
+    const float4 l = *reinterpret_cast<const float4*>(life + i0);
+    uint32_t n = (uint32_t)__popcll(__ballot(l.x > 0.0f)) + (uint32_t)__popcll(__ballot(l.y > 0.0f)) +
+                 (uint32_t)__popcll(__ballot(l.z > 0.0f)) + (uint32_t)__popcll(__ballot(l.w > 0.0f));
+    if ((threadIdx.x & 63) == 0 && n != 0)
+        atomicAdd(&counts[chunk], n);
+}
+hipError_t launch_count_live(float* const* chunk_bases, int64_t stride, int32_t chunk_count, uint32_t* counts, hipStream_t stream) {
+    if (chunk_count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(count_live_kernel, dim3((unsigned)(stride / 1024), (unsigned)chunk_count), dim3(256), 0, stream, chunk_bases, stride, counts);
+    return hipGetLastError();
+}
+
+// Single workgroup of 1024 threads walks the chunk in 1024-slot tiles keeping a
+// running base, so the output is in ascending slot order (deterministic):
+// per-wave ballot -> popcount prefix inside the wave, LDS scan across the 16 waves.
+__global__ __launch_bounds__(1024) void live_slots_kernel(const float* __restrict__ life, int slots, uint32_t* __restrict__ out,
+                                                           uint32_t capacity, uint32_t* __restrict__ out_count) {
+    __shared__ uint32_t wave_counts[16];
+    __shared__ uint32_t running;
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    if (threadIdx.x == 0) running = 0;
+    __syncthreads();
+    for (int tile = 0; tile < slots; tile += 1024) {
+        const int i = tile + (int)threadIdx.x;
+        const bool alive = (i < slots) && (life[i] > 0.0f);
+        const unsigned long long mask = __ballot(alive);
+        const uint32_t prefix = (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_counts[wave] = (uint32_t)__popcll(mask);
+        __syncthreads();
+        uint32_t wave_base = running;
+        for (int w = 0; w < wave; w++) wave_base += wave_counts[w];
+        if (alive) {
+            const uint32_t dst = wave_base + prefix;
+            if (dst < capacity) out[dst] = (uint32_t)i;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t t = 0;
+            for (int w = 0; w < 16; w++) t += wave_counts[w];
+            running += t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out_count = running;
+}
+hipError_t launch_live_slots(const float* life, int32_t slots, uint32_t* out_slots, uint32_t capacity, uint32_t* out_count, hipStream_t stream) {
+    hipLaunchKernelGGL(live_slots_kernel, dim3(1), dim3(1024), 0, stream, life, slots, out_slots, capacity, out_count);
+    return hipGetLastError();
+}
+
+}  // namespace ilm

@@ -1,0 +1,336 @@
+"""ctypes binding of libilluminant_hip.so (include/illuminant_hip.h).
+
+This is the only way Python reaches the kernels: through the C ABI, exactly as
+the C# P/Invoke layer of INTEGRATION.md would.  There is no CPU fallback: if
+the library is missing or no GPU is visible, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libilluminant_hip.so")
+
+_lib = None
+
+
+class IlluminantError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("illuminant_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+# every symbol include/illuminant_hip.h declares: name -> (restype, argtypes)
+_H = abi.Handle
+_P = C.c_void_p
+_I = C.c_int32
+SYMBOLS = {
+    "ilm_abi_version": (_I, []),
+    "ilm_last_error": (C.c_char_p, []),
+    "ilm_device_count": (_I, []),
+    "ilm_ctx_create": (_I, [_I, C.POINTER(_H)]),
+    "ilm_ctx_destroy": (_I, [_H]),
+    "ilm_ctx_sync": (_I, [_H]),
+    "ilm_ctx_stream": (_I, [_H, C.POINTER(_P)]),
+    "ilm_timer_start": (_I, [_H]),
+    "ilm_timer_stop": (_I, [_H, C.POINTER(C.c_float)]),
+    "ilm_engine_create": (_I, [_H, _I, _P, _I, _I, C.POINTER(_H)]),
+    "ilm_engine_destroy": (_I, [_H]),
+    "ilm_system_create": (_I, [_H, C.POINTER(_H)]),
+    "ilm_system_destroy": (_I, [_H]),
+    "ilm_system_add_chunk": (_I, [_H, C.POINTER(_I)]),
+    "ilm_system_remove_chunk": (_I, [_H, _I]),
+    "ilm_system_chunk_count": (_I, [_H, C.POINTER(_I)]),
+    "ilm_chunk_upload": (_I, [_H, _I, _I, _P, _I, _I]),
+    "ilm_chunk_download": (_I, [_H, _I, _I, _P, _I, _I]),
+    "ilm_chunk_device_ptr": (_I, [_H, _I, _I, C.POINTER(_P), C.POINTER(C.c_int64)]),
+    "ilm_system_set_distance_field": (_I, [_H, _H]),
+    "ilm_system_set_life_ramp": (_I, [_H, _P, _I, _I]),
+    "ilm_system_step": (_I, [_H, _P]),
+    "ilm_spawn": (_I, [_H, _I, _P, _P]),
+    "ilm_gravity": (_I, [_H, _I, _P, _P]),
+    "ilm_noise": (_I, [_H, _I, _P, _P]),
+    "ilm_fma": (_I, [_H, _I, _P, _P]),
+    "ilm_update": (_I, [_H, _I, _P, _P, _P]),
+    "ilm_erase": (_I, [_H, _I]),
+    "ilm_system_live_counts": (_I, [_H, _P, _I, _I]),
+    "ilm_system_step_counts": (_I, [_H, _P, _I, _I]),
+    "ilm_chunk_live_slots": (_I, [_H, _I, _P, _I, C.POINTER(_I)]),
+    "ilm_sdf_create": (_I, [_H, _I, _I, _I, C.POINTER(_H)]),
+    "ilm_sdf_upload": (_I, [_H, _P]),
+    "ilm_sdf_destroy": (_I, [_H]),
+    "ilm_gbuffer_create": (_I, [_H, _I, _I, _I, C.POINTER(_H)]),
+    "ilm_gbuffer_upload": (_I, [_H, _P]),
+    "ilm_gbuffer_destroy": (_I, [_H]),
+    "ilm_lightmap_create": (_I, [_H, _I, _I, _I, _P, C.POINTER(_H)]),
+    "ilm_lightmap_download": (_I, [_H, _P, _I, _I]),
+    "ilm_lightmap_device_ptr": (_I, [_H, C.POINTER(_P)]),
+    "ilm_lightmap_destroy": (_I, [_H]),
+    "ilm_render_sphere_lights": (_I, [_H, _P, _I, _P, _P, _H, _H, _P, _H, _I, _I, _P]),
+}
+
+
+def lib():
+    """Load the shared library (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise IlluminantError(abi.ERR_NO_DEVICE, "%s not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                                  "(there is no CPU fallback)" % LIB_PATH)
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code):
+    if code != 0:
+        raise IlluminantError(code, lib().ilm_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    return int(lib().ilm_device_count())
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _byref(s):
+    return C.cast(C.byref(s), C.c_void_p) if s is not None else None
+
+
+class Context:
+    """One GPU + one HIP stream (ilm_ctx_*)."""
+
+    def __init__(self, device_id=0):
+        self.handle = abi.Handle(0)
+        check(lib().ilm_ctx_create(device_id, C.byref(self.handle)))
+        self.device_id = device_id
+
+    def sync(self):
+        check(lib().ilm_ctx_sync(self.handle))
+
+    def stream(self):
+        p = C.c_void_p()
+        check(lib().ilm_ctx_stream(self.handle, C.byref(p)))
+        return p.value
+
+    def timer_start(self):
+        check(lib().ilm_timer_start(self.handle))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        check(lib().ilm_timer_stop(self.handle, C.byref(ms)))
+        return float(ms.value)
+
+    def close(self):
+        if self.handle.value:
+            lib().ilm_ctx_destroy(self.handle)
+            self.handle = abi.Handle(0)
+
+
+class Engine:
+    """ilm_engine_*: chunk size + randomness table."""
+
+    def __init__(self, ctx, chunk_size, randomness):
+        rnd = np.ascontiguousarray(randomness, dtype=np.float32)
+        assert rnd.ndim == 3 and rnd.shape[2] == 4
+        self.ctx = ctx
+        self.chunk_size = int(chunk_size)
+        self.slots = self.chunk_size * self.chunk_size
+        self.randomness = rnd
+        self.handle = abi.Handle(0)
+        check(lib().ilm_engine_create(ctx.handle, chunk_size, _ptr(rnd), rnd.shape[1], rnd.shape[0], C.byref(self.handle)))
+
+    def close(self):
+        if self.handle.value:
+            lib().ilm_engine_destroy(self.handle)
+            self.handle = abi.Handle(0)
+
+
+class System:
+    """ilm_system_*: a table of chunks updated by ilm_system_step."""
+
+    def __init__(self, engine):
+        self.engine = engine
+        self.handle = abi.Handle(0)
+        check(lib().ilm_system_create(engine.handle, C.byref(self.handle)))
+
+    def add_chunk(self):
+        i = C.c_int32()
+        check(lib().ilm_system_add_chunk(self.handle, C.byref(i)))
+        return int(i.value)
+
+    def remove_chunk(self, index):
+        check(lib().ilm_system_remove_chunk(self.handle, index))
+
+    def chunk_count(self):
+        n = C.c_int32()
+        check(lib().ilm_system_chunk_count(self.handle, C.byref(n)))
+        return int(n.value)
+
+    def upload(self, chunk, plane, data, first_slot=0):
+        a = np.ascontiguousarray(data, dtype=np.float32).reshape(-1, 4)
+        check(lib().ilm_chunk_upload(self.handle, chunk, plane, _ptr(a), first_slot, a.shape[0]))
+
+    def download(self, chunk, plane, first_slot=0, count=None):
+        if count is None:
+            count = self.engine.slots - first_slot
+        out = np.empty((count, 4), dtype=np.float32)
+        check(lib().ilm_chunk_download(self.handle, chunk, plane, _ptr(out), first_slot, count))
+        return out
+
+    def device_ptr(self, chunk, component):
+        p = C.c_void_p()
+        stride = C.c_int64()
+        check(lib().ilm_chunk_device_ptr(self.handle, chunk, component, C.byref(p), C.byref(stride)))
+        return p.value, int(stride.value)
+
+    def set_distance_field(self, sdf):
+        check(lib().ilm_system_set_distance_field(self.handle, sdf.handle if sdf is not None else abi.Handle(0)))
+        self._sdf = sdf
+
+    def set_life_ramp(self, texels):
+        if texels is None:
+            check(lib().ilm_system_set_life_ramp(self.handle, None, 0, 0))
+            return
+        a = np.ascontiguousarray(texels, dtype=np.float32)
+        assert a.ndim == 3 and a.shape[2] == 4
+        check(lib().ilm_system_set_life_ramp(self.handle, _ptr(a), a.shape[1], a.shape[0]))
+
+    def step(self, desc):
+        check(lib().ilm_system_step(self.handle, _byref(desc)))
+
+    def spawn(self, chunk, sys, p):
+        check(lib().ilm_spawn(self.handle, chunk, _byref(sys), _byref(p)))
+
+    def gravity(self, chunk, sys, p):
+        check(lib().ilm_gravity(self.handle, chunk, _byref(sys), _byref(p)))
+
+    def noise(self, chunk, sys, p):
+        check(lib().ilm_noise(self.handle, chunk, _byref(sys), _byref(p)))
+
+    def fma(self, chunk, sys, p):
+        check(lib().ilm_fma(self.handle, chunk, _byref(sys), _byref(p)))
+
+    def update(self, chunk, sys, p, df=None):
+        check(lib().ilm_update(self.handle, chunk, _byref(sys), _byref(p), _byref(df)))
+
+    def erase(self, chunk):
+        check(lib().ilm_erase(self.handle, chunk))
+
+    def live_counts(self, saturate16=False):
+        n = self.chunk_count()
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        check(lib().ilm_system_live_counts(self.handle, _ptr(out), out.shape[0], 1 if saturate16 else 0))
+        return out[:n]
+
+    def step_counts(self, saturate16=False):
+        n = self.chunk_count()
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        check(lib().ilm_system_step_counts(self.handle, _ptr(out), out.shape[0], 1 if saturate16 else 0))
+        return out[:n]
+
+    def live_slots(self, chunk):
+        out = np.zeros(self.engine.slots, dtype=np.uint32)
+        n = C.c_int32()
+        check(lib().ilm_chunk_live_slots(self.handle, chunk, _ptr(out), out.shape[0], C.byref(n)))
+        return out[:n.value]
+
+    def close(self):
+        if self.handle.value:
+            lib().ilm_system_destroy(self.handle)
+            self.handle = abi.Handle(0)
+
+
+class DistanceFieldTexture:
+    """ilm_sdf_*: the RGBA16 atlas on the device."""
+
+    def __init__(self, ctx, texels, fmt=abi.SDF_UNORM16):
+        a = np.ascontiguousarray(texels, dtype=np.uint16)
+        assert a.ndim == 3 and a.shape[2] == 4
+        self.ctx = ctx
+        self.height, self.width = a.shape[0], a.shape[1]
+        self.format = fmt
+        self.handle = abi.Handle(0)
+        check(lib().ilm_sdf_create(ctx.handle, self.width, self.height, fmt, C.byref(self.handle)))
+        check(lib().ilm_sdf_upload(self.handle, _ptr(a)))
+
+    def upload(self, texels):
+        a = np.ascontiguousarray(texels, dtype=np.uint16)
+        assert a.shape == (self.height, self.width, 4)
+        check(lib().ilm_sdf_upload(self.handle, _ptr(a)))
+
+    def close(self):
+        if self.handle.value:
+            lib().ilm_sdf_destroy(self.handle)
+            self.handle = abi.Handle(0)
+
+
+class GBufferTexture:
+    def __init__(self, ctx, texels, fmt=abi.GBUFFER_FLOAT4):
+        dt = np.float32 if fmt == abi.GBUFFER_FLOAT4 else np.uint16
+        a = np.ascontiguousarray(texels, dtype=dt)
+        assert a.ndim == 3 and a.shape[2] == 4
+        self.ctx = ctx
+        self.height, self.width = a.shape[0], a.shape[1]
+        self.format = fmt
+        self.handle = abi.Handle(0)
+        check(lib().ilm_gbuffer_create(ctx.handle, self.width, self.height, fmt, C.byref(self.handle)))
+        check(lib().ilm_gbuffer_upload(self.handle, _ptr(a)))
+
+    def close(self):
+        if self.handle.value:
+            lib().ilm_gbuffer_destroy(self.handle)
+            self.handle = abi.Handle(0)
+
+
+_LM_DTYPE = {abi.LIGHTMAP_FLOAT4: (np.float32, 4), abi.LIGHTMAP_HALF4: (np.float16, 4), abi.LIGHTMAP_RGBA8: (np.uint8, 4)}
+
+
+class Lightmap:
+    def __init__(self, ctx, width, height, fmt=abi.LIGHTMAP_FLOAT4, external_ptr=None):
+        self.ctx = ctx
+        self.width, self.height, self.format = width, height, fmt
+        self.handle = abi.Handle(0)
+        check(lib().ilm_lightmap_create(ctx.handle, width, height, fmt, external_ptr, C.byref(self.handle)))
+
+    def download(self, first_row=0, row_count=None):
+        if row_count is None:
+            row_count = self.height - first_row
+        dt, ch = _LM_DTYPE[self.format]
+        out = np.empty((row_count, self.width, ch), dtype=dt)
+        check(lib().ilm_lightmap_download(self.handle, _ptr(out), first_row, row_count))
+        return out
+
+    def device_ptr(self):
+        p = C.c_void_p()
+        check(lib().ilm_lightmap_device_ptr(self.handle, C.byref(p)))
+        return p.value
+
+    def close(self):
+        if self.handle.value:
+            lib().ilm_lightmap_destroy(self.handle)
+            self.handle = abi.Handle(0)
+
+
+def render_sphere_lights(ctx, lights, env, df, gbuffer, sdf, ambient, lightmap, row_begin=0, row_end=None, want_stats=False):
+    """ilm_render_sphere_lights.  lights: ctypes array of abi.LightVertex (or None for zero lights)."""
+    if row_end is None:
+        row_end = lightmap.height
+    n = len(lights) if lights is not None else 0
+    amb = (C.c_float * 4)(*[float(x) for x in ambient])
+    stats = abi.RenderStats() if want_stats else None
+    check(lib().ilm_render_sphere_lights(
+        ctx.handle, C.cast(lights, C.c_void_p) if n else None, n, _byref(env), _byref(df),
+        gbuffer.handle if gbuffer is not None else abi.Handle(0),
+        sdf.handle if sdf is not None else abi.Handle(0),
+        C.cast(amb, C.c_void_p), lightmap.handle, row_begin, row_end, _byref(stats)))
+    return stats

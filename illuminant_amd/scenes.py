@@ -1,0 +1,411 @@
+"""Deterministic synthetic scenes of the shapes BASELINE.json names.
+
+Host-side input synthesis only (numpy): randomness tables, particle initial
+state, analytic SDF atlases, light lists and the parameter structs of each
+config.  Nothing here is on the hot path; the GPU work goes through
+illuminant_amd.native (the C ABI).  The generator is SplitMix64 -> uniform
+float, so seeds alone reproduce every input on the GPU box.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import abi
+
+_MASK = (1 << 64) - 1
+
+
+def splitmix64(seed, n):
+    """n uint64 draws of SplitMix64 seeded with `seed` (vectorised)."""
+    idx = (np.arange(1, n + 1, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)) + np.uint64(seed & _MASK)
+    z = idx
+    z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def uniform(seed, shape, lo=0.0, hi=1.0):
+    """float32 uniforms in [lo, hi) from the top 24 bits of SplitMix64."""
+    n = int(np.prod(shape))
+    with np.errstate(over="ignore"):
+        bits = splitmix64(seed, n)
+    u = (bits >> np.uint64(40)).astype(np.float64) / float(1 << 24)
+    return (lo + u * (hi - lo)).astype(np.float32).reshape(shape)
+
+
+def randomness_table(seed, width=abi.RANDOMNESS_WIDTH, height=abi.RANDOMNESS_HEIGHT):
+    """The 807x653 float4 table (ParticleEngine.cs:495-544); unseeded in the reference, so explicit here."""
+    return uniform(seed, (height, width, 4))
+
+
+# ---- particle-side parameter builders ------------------------------------------------------------------
+
+def system_uniforms(chunk_size, dt_seconds=1.0 / 60, friction=0.0, max_velocity=9999.0, life_decay=1.0,
+                    collision=(128.0, 0.0, 0.33, 0.0), size=(1.0, 1.0), rotation_from_velocity=False, z_to_y=0.0):
+    """Uniforms.ParticleSystem ctor, Uniforms.cs:207-235."""
+    u = abi.ParticleSystemUniforms()
+    u.GlobalSettings = abi.f4(np.float32(dt_seconds * 1000.0), friction, max_velocity, life_decay)
+    u.CollisionSettings = abi.f4(*collision)
+    u.TexelAndSize = abi.f4(1.0 / chunk_size, 1.0 / chunk_size, size[0], size[1])
+    u.AnimationRateAndRotationAndZToY = abi.f4(0, 0, 1.0 if rotation_from_velocity else 0.0, z_to_y)
+    return u
+
+
+def area_none(strength=1.0, category_filter=(-9999.0, 9999.0)):
+    """ParticleAreaTransform.SetParameters with Area == null (ParticleTransform.cs:294-318).
+    AreaFalloff is left at the effect default 0: distance/falloff = 0/0 = NaN, saturate(NaN) = 0."""
+    a = abi.AreaParams()
+    a.AreaType = 0
+    a.Strength = strength
+    a.AreaFalloff = 0.0
+    a.CategoryFilter[0], a.CategoryFilter[1] = category_filter
+    return a
+
+
+def area(type_id, center, size, falloff=1.0, rotation=0.0, strength=1.0, category_filter=(-9999.0, 9999.0)):
+    a = abi.AreaParams()
+    a.AreaType = type_id
+    a.Strength = strength
+    a.AreaFalloff = max(1.0, falloff)   # ParticleTransform.cs:301-302
+    a.AreaRotation = rotation
+    for i in range(3):
+        a.AreaCenter[i] = center[i]
+        a.AreaSize[i] = size[i]
+    a.CategoryFilter[0], a.CategoryFilter[1] = category_filter
+    return a
+
+
+def gravity_params(attractors, maximum_acceleration=8.0, category_filter=(0.0, 0.0)):
+    """attractors: [(position xyz, radius, strength, type)] ; Transforms.cs:347-365.
+    category_filter defaults to the effect default (0, 0): the reference never binds it for Gravity."""
+    g = abi.GravityParams()
+    g.AttractorCount = len(attractors)
+    g.MaximumAcceleration = maximum_acceleration
+    g.CategoryFilter[0], g.CategoryFilter[1] = category_filter
+    for i, (pos, radius, strength, typ) in enumerate(attractors[:abi.MAX_ATTRACTORS]):
+        for k in range(3):
+            g.AttractorPositions[i][k] = pos[k]
+        g.AttractorRadiusesAndStrengths[i][0] = radius
+        g.AttractorRadiusesAndStrengths[i][1] = strength
+        g.AttractorRadiusesAndStrengths[i][2] = float(typ)
+    return g
+
+
+def fma_params(area_params, cycles_per_second=10.0, position_add=(0, 0, 0), position_multiply=(1, 1, 1),
+               velocity_add=(0, 0, 0), velocity_multiply=(1, 1, 1)):
+    """FMA.SetParameters, Transforms.cs:38-45."""
+    p = abi.FMAParams()
+    p.Area = area_params
+    p.TimeDivisor = (1000.0 / cycles_per_second) if cycles_per_second is not None else -1.0
+    p.PositionAdd = abi.f4(*position_add, 0)
+    p.PositionMultiply = abi.f4(*position_multiply, 1)
+    p.VelocityAdd = abi.f4(*velocity_add, 0)
+    p.VelocityMultiply = abi.f4(*velocity_multiply, 1)
+    return p
+
+
+def noise_params(area_params, offsets, next_offsets, frequency_lerp, cycles_per_second=10.0, replace_old_velocity=True,
+                 position=((-0.5,) * 4, (0,) * 4, (0,) * 4), velocity=((-0.5,) * 3, (0,) * 3, (1,) * 3), speed=(-0.5, 0.0, 0.0)):
+    """Noise.SetParameters, Transforms.cs:243-268; defaults = Noise ctor (:192-204).
+    offsets = (CurrentU*253, CurrentV*127), next_offsets likewise."""
+    p = abi.NoiseParams()
+    p.Area = area_params
+    p.TimeDivisor = (1000.0 / cycles_per_second) if cycles_per_second is not None else -1.0
+    p.FrequencyLerp = frequency_lerp
+    p.ReplaceOldVelocity = 1.0 if replace_old_velocity else 0.0
+    p.RandomnessOffset[0], p.RandomnessOffset[1] = offsets
+    p.NextRandomnessOffset[0], p.NextRandomnessOffset[1] = next_offsets
+    p.PositionOffset, p.PositionMinimum, p.PositionScale = abi.f4(position[0]), abi.f4(position[1]), abi.f4(position[2])
+    p.VelocityOffset = abi.f4(*velocity[0], speed[0])
+    p.VelocityMinimum = abi.f4(*velocity[1], speed[1])
+    p.VelocityScale = abi.f4(*velocity[2], speed[2])
+    return p
+
+
+FORMULA_LINEAR, FORMULA_SPHERICAL, FORMULA_TOWARDS, FORMULA_RECTANGULAR = 0, 1, 2, 3
+
+
+def spawn_params(chunk_size, first, last, total_spawned, randomness_offset,
+                 position=((0, 0, 0), (1, 1, 1), (0, 0, 0), FORMULA_SPHERICAL),
+                 velocity=((0, 0, 0), (1, 1, 1), (0, 0, 0), FORMULA_SPHERICAL),
+                 life=(1.0, 0.0, 0.0), category=(0.0, 0.0, 0.0),
+                 color=((1, 1, 1, 1), (0, 0, 0, 0), (0, 0, 0, 0)), color_type=FORMULA_LINEAR,
+                 additional_positions=(), polygon_rate=None, polygon_loop=True, polygon_speed=(0.0, 0.0, 0.0),
+                 axis_mask=(1, 1, 1), align=False, alpha_discard_threshold=1.0,
+                 position_matrix=None, velocity_matrix=None):
+    """SpawnerBase.SetParameters + Spawner.SetParameters/GetChunkSizeAndIndices/BeginTick,
+    ParticleSpawner.cs:200-256, 319-403.  formula tuples are (constant, random scale, offset[, type])."""
+    p = abi.SpawnParams()
+    count = 1 + len(additional_positions)
+    assert count <= abi.MAX_INLINE_POSITION_CONSTANTS
+    rate = float(polygon_rate) if polygon_rate is not None else 0.0
+    if rate >= 1:
+        c = count - 1 if (not polygon_loop and count > 1) else count
+        w = math.fmod(np.float32(total_spawned / rate), float(c))
+    else:
+        w = total_spawned % count
+    p.ChunkSizeAndIndices[:] = [chunk_size, first, last, w]
+    p.Configuration[0] = abi.f4(*position[1], life[1])
+    p.Configuration[1] = abi.f4(*position[2], life[2])
+    p.Configuration[2] = abi.f4(*velocity[0], category[0])
+    p.Configuration[3] = abi.f4(*velocity[1], category[1])
+    p.Configuration[4] = abi.f4(*velocity[2], category[2])
+    p.Configuration[5] = abi.f4(*color[0])
+    p.Configuration[6] = abi.f4(*color[1])
+    p.Configuration[7] = abi.f4(*color[2])
+    p.Configuration[8] = abi.f4(polygon_speed[0], polygon_speed[1], polygon_speed[2], 0)
+    p.FormulaTypes[:] = [float(position[3]), float(velocity[3]), float(color_type), 0.0]
+    p.PositionMatrix = position_matrix if position_matrix is not None else abi.Matrix.identity()
+    p.VelocityMatrix = velocity_matrix if velocity_matrix is not None else abi.Matrix.identity()
+    p.AxisMask[:] = axis_mask
+    circular = position[3] in (FORMULA_SPHERICAL, FORMULA_RECTANGULAR) and velocity[3] in (FORMULA_SPHERICAL, FORMULA_RECTANGULAR)
+    p.AlignVelocityAndPosition = 1.0 if (align and circular) else 0.0
+    p.RandomnessOffset[0], p.RandomnessOffset[1] = randomness_offset
+    p.AttributeDiscardThreshold = np.float32(alpha_discard_threshold / 255.0)
+    p.PolygonRate = rate
+    p.PolygonLoop = 1.0 if polygon_loop else 0.0
+    p.PositionConstantCount = float(count)
+    p.InlinePositionConstants[0] = abi.f4(*position[0], life[0])
+    for i, ap in enumerate(additional_positions):
+        p.InlinePositionConstants[i + 1] = abi.f4(*ap, life[0])
+    return p
+
+
+def make_particles(seed, n, pos_lo=(0, 0, 0), pos_hi=(256, 256, 32), vel=60.0, life=(1.0, 6.0), dead_fraction=0.0,
+                   categories=(0.0,)):
+    """AoS float4 position/velocity/attribute planes of n slots."""
+    pos = np.zeros((n, 4), np.float32)
+    velo = np.zeros((n, 4), np.float32)
+    for k in range(3):
+        pos[:, k] = uniform(seed + 11 * k + 1, (n,), pos_lo[k], pos_hi[k])
+    pos[:, 3] = uniform(seed + 41, (n,), life[0], life[1])
+    velo[:, 0] = uniform(seed + 43, (n,), -vel, vel)
+    velo[:, 1] = uniform(seed + 47, (n,), -vel, vel)
+    velo[:, 2] = uniform(seed + 53, (n,), -vel * 0.25, vel * 0.25)
+    cat = uniform(seed + 59, (n,), 0.0, float(len(categories)))
+    velo[:, 3] = np.asarray(categories, np.float32)[np.minimum(cat.astype(np.int64), len(categories) - 1)]
+    attr = np.ones((n, 4), np.float32)
+    attr[:, :3] = uniform(seed + 61, (n, 3), 0.09, 0.39)
+    if dead_fraction > 0:
+        dead = uniform(seed + 67, (n,)) < dead_fraction
+        pos[dead] = 0
+        velo[dead] = 0
+    return pos, velo, attr
+
+
+# ---- distance field ------------------------------------------------------------------------------------
+
+class DistanceFieldLayout:
+    """Host mirror of the DistanceField ctor's atlas layout math (SDF/DistanceField.cs:43-122)."""
+    MAX_SURFACE_SIZE = 8192
+    PACKED_SLICE_COUNT = 3
+
+    def __init__(self, virtual_width, virtual_height, virtual_depth, requested_slice_count, requested_resolution=1.0,
+                 maximum_encoded_distance=128):
+        self.virtual_width, self.virtual_height, self.virtual_depth = virtual_width, virtual_height, float(virtual_depth)
+        self.maximum_encoded_distance = maximum_encoded_distance
+        rr = min(max(requested_resolution, 0.05), 1.0)
+        cw = int(round(virtual_width * rr))     # Python round == Math.Round (banker's)
+        ch = int(round(virtual_height * rr))
+        frac = (virtual_width / cw + virtual_height / ch) / 2
+        res = round(1.0 / frac, 3)
+        self.resolution = min(max(res, 0.05), 1.0)
+        self.slice_width = int(round(virtual_width * self.resolution))
+        self.slice_height = int(round(virtual_height * self.resolution))
+        max_x = self.MAX_SURFACE_SIZE // self.slice_width
+        max_y = self.MAX_SURFACE_SIZE // self.slice_height
+        max_slices = max_x * max_y * self.PACKED_SLICE_COUNT
+        sc = max(3, requested_slice_count)
+        sc = ((sc + 2) // 3) * 3
+        self.slice_count = min(sc, max_slices)
+        self.physical_slice_count = int(math.ceil(np.float32(self.slice_count) / np.float32(3)))
+        cols = min(max_x, self.physical_slice_count)
+        rows = min(max_y, max(int(math.ceil(np.float32(self.physical_slice_count) / np.float32(max_x))), 1))
+        while rows < cols and rows < max_y:
+            nr = rows + 1
+            nc = int(math.ceil(np.float32(self.physical_slice_count) / np.float32(nr)))
+            nr = min(nr, max_x)
+            nc = min(nc, max_y)
+            if nr * nc < self.physical_slice_count:
+                break
+            rows, cols = nr, nc
+        self.column_count, self.row_count = cols, rows
+        self.atlas_width, self.atlas_height = self.slice_width * cols, self.slice_height * rows
+
+    def slice_index_to_z(self, s, z_offset=0.0):
+        """SliceIndexToZ, LightingRenderer.DistanceField.cs:32-35."""
+        return float(np.float32(np.float32(s) / np.float32(max(1, self.slice_count))) * np.float32(self.virtual_depth) + np.float32(z_offset))
+
+    def uniforms(self, valid_slice_count=None, z_offset=0.0, max_cone_radius=24.0, power=1.0, step_limit=64,
+                 min_step_size=3.0, long_step_factor=1.0, packed1=True):
+        """Uniforms.DistanceField ctor (Uniforms.cs:90-110) + SetDistanceFieldParameters
+        (LightingRenderer.cs:1916-1939).  packed1=False leaves DistanceFieldPacked1 at zero, which is what the
+        reference's particle path does (only LightingRenderer ever sets it)."""
+        f = np.float32
+        u = abi.DistanceFieldUniforms()
+        valid = self.slice_count if valid_slice_count is None else min(valid_slice_count, self.slice_count)
+        slice_z = f(self.virtual_depth) / f(self.slice_count)
+        u.Extent = abi.f4(self.virtual_width, self.virtual_height, self.virtual_depth, self.maximum_encoded_distance)
+        u.TextureSliceCount = abi.f4(self.column_count, self.row_count, f(valid) * slice_z, self.slice_count)
+        u.TextureSliceAndTexelSize = abi.f4(f(1) / f(self.column_count), f(1) / f(self.row_count),
+                                            f(1) / f(self.virtual_width * self.column_count),
+                                            f(1) / f(self.virtual_height * self.row_count))
+        u.ConeAndMisc = abi.f4(max_cone_radius, z_offset, power, f(self.virtual_width / self.slice_width))
+        u.StepAndMisc2 = abi.f4(step_limit, min_step_size, long_step_factor, f(self.virtual_height / self.slice_height))
+        if packed1:
+            u.Packed1 = abi.f4((f(1) / max(f(0.0001), f(u.TextureSliceCount.x))) * (f(1) / f(3)),
+                               (f(1) / max(f(0.0001), f(u.Extent.z))) * f(u.TextureSliceCount.w),
+                               u.TextureSliceCount.z, min_step_size)
+        return u
+
+
+def _sd_ellipsoid(px, py, pz, size):
+    k0 = np.sqrt((px / size[0]) ** 2 + (py / size[1]) ** 2 + (pz / size[2]) ** 2)
+    k1 = np.sqrt((px / size[0] ** 2) ** 2 + (py / size[1] ** 2) ** 2 + (pz / size[2] ** 2) ** 2)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        outer = k0 * (k0 - 1.0) / k1
+    return np.where(k0 < 1.0, (k0 - 1.0) * min(size), outer)
+
+
+def _sd_box(px, py, pz, size):
+    dx, dy, dz = np.abs(px) - size[0], np.abs(py) - size[1], np.abs(pz) - size[2]
+    outside = np.sqrt(np.maximum(dx, 0) ** 2 + np.maximum(dy, 0) ** 2 + np.maximum(dz, 0) ** 2)
+    return np.minimum(np.maximum(dx, np.maximum(dy, dz)), 0.0) + outside
+
+
+def _sd_cylinder(px, py, pz, size):
+    r = math.hypot(size[0], size[1])
+    dx = np.sqrt(px * px + py * py) - r
+    dy = np.abs(pz) - size[2]
+    return np.minimum(np.maximum(dx, dy), 0.0) + np.sqrt(np.maximum(dx, 0) ** 2 + np.maximum(dy, 0) ** 2)
+
+
+_SD = {1: _sd_ellipsoid, 2: _sd_box, 3: _sd_cylinder}
+
+
+def build_sdf_atlas(layout, obstacles, z_offset=0.0, fmt=abi.SDF_UNORM16):
+    """Rasterise analytic obstructions [(type 1|2|3, center xyz, size xyz)] into the packed atlas the way
+    RenderDistanceFieldSliceTriplet does (LightingRenderer.DistanceField.cs:80-152, DistanceFunction.fx:33-80):
+    clear to encoded 0, MAX-blend encodeDistance(d) of every obstruction; texel RGBA = slices 3p..3p+3.
+    Returns (H, W, 4) uint16."""
+    L = layout
+    enc = np.zeros((L.atlas_height, L.atlas_width, 4), np.float32)
+    sx = L.virtual_width / L.slice_width
+    sy = L.virtual_height / L.slice_height
+    maxd = float(L.maximum_encoded_distance)
+    for p in range(L.physical_slice_count):
+        ox = (p % L.column_count) * L.slice_width
+        oy = (p // L.column_count) * L.slice_height
+        zs = [L.slice_index_to_z(3 * p + c, z_offset) for c in range(4)]
+        for (typ, center, size) in obstacles:
+            reach = max(size) + maxd + 4
+            x0 = max(int(math.floor((center[0] - reach) / sx)), 0)
+            x1 = min(int(math.ceil((center[0] + reach) / sx)) + 1, L.slice_width)
+            y0 = max(int(math.floor((center[1] - reach) / sy)), 0)
+            y1 = min(int(math.ceil((center[1] + reach) / sy)) + 1, L.slice_height)
+            if x0 >= x1 or y0 >= y1:
+                continue
+            wx = (np.arange(x0, x1, dtype=np.float32) * np.float32(sx))[None, :] - np.float32(center[0])
+            wy = (np.arange(y0, y1, dtype=np.float32) * np.float32(sy))[:, None] - np.float32(center[1])
+            for c in range(4):
+                d = _SD[typ](wx, wy, np.float32(zs[c] - center[2]), size)
+                e = np.float32(192.0 / 255.0) - d.astype(np.float32) / np.float32(maxd)
+                view = enc[oy + y0:oy + y1, ox + x0:ox + x1, c]
+                np.maximum(view, e, out=view)
+    enc = np.clip(enc, 0.0, 1.0)
+    if fmt == abi.SDF_FP16:
+        return enc.astype(np.float16).view(np.uint16)
+    return np.rint(enc * 65535.0).astype(np.uint16)
+
+
+def random_obstacles(seed, n, extent, size_lo=12.0, size_hi=70.0, z_hi=64.0):
+    cx = uniform(seed + 1, (n,), 0, extent[0])
+    cy = uniform(seed + 2, (n,), 0, extent[1])
+    sz = uniform(seed + 3, (n, 3), size_lo, size_hi)
+    typ = (uniform(seed + 4, (n,)) < 0.5)
+    out = []
+    for i in range(n):
+        h = float(min(sz[i, 2], z_hi))
+        out.append((1 if typ[i] else 2, (float(cx[i]), float(cy[i]), 0.0), (float(sz[i, 0]), float(sz[i, 1]), h)))
+    return out
+
+
+def simple_particles_obstacles(width=256.0, height=256.0):
+    """4 cylinders + 4 wall boxes in the pattern of TestGame Scenes/SimpleParticles.cs:255-284, scaled to the field."""
+    obs = []
+    for (fx, fy) in ((0.25, 0.25), (0.75, 0.25), (0.25, 0.75), (0.75, 0.75)):
+        obs.append((3, (width * fx, height * fy, 0.0), (width * 0.045, width * 0.045, 48.0)))
+    t = 6.0
+    obs.append((2, (width / 2, 0.0, 0.0), (width / 2, t, 64.0)))
+    obs.append((2, (width / 2, height, 0.0), (width / 2, t, 64.0)))
+    obs.append((2, (0.0, height / 2, 0.0), (t, height / 2, 64.0)))
+    obs.append((2, (width, height / 2, 0.0), (t, height / 2, 64.0)))
+    return obs
+
+
+# ---- lighting ---------------------------------------------------------------------------------------------
+
+def environment(ground_z=0.0, maximum_z=128.0, z_to_y=0.0, light_occlusion=0.0, render_scale=(1.0, 1.0),
+                gbuffer_size=None, viewport_scale=(1.0, 1.0), viewport_position=(0.0, 0.0), viewport_relative=False):
+    """ComputeUniforms (LightingRenderer.cs:691-701) + SetGBufferParameters (LightingRenderer.GBuffer.cs:520-534)."""
+    e = abi.Environment()
+    e.ZAndScale = abi.f4(ground_z, maximum_z, render_scale[0], render_scale[1])
+    inv = 0.0 if abs(z_to_y) <= 0.0001 else 1.0 / z_to_y
+    e.ZToY = abi.f4(z_to_y, inv, light_occlusion, 0)
+    if gbuffer_size is not None:
+        e.GBufferTexelSizeAndMisc = abi.f4(1.0 / gbuffer_size[0], 1.0 / gbuffer_size[1], viewport_scale[0], viewport_scale[1])
+    else:
+        e.GBufferTexelSizeAndMisc = abi.f4(0, 0, viewport_scale[0], viewport_scale[1])
+    e.ViewportPosition[0], e.ViewportPosition[1] = viewport_position
+    e.GBufferViewportRelative = 1.0 if viewport_relative else 0.0
+    return e
+
+
+def sphere_light(position, radius, ramp_length, color=(1, 1, 1, 1), opacity=1.0, intensity_scale=1.0, ramp_mode=0,
+                 casts_shadows=True, have_distance_field=True, ao_radius=0.0, ao_opacity=1.0, falloff_y=1.0,
+                 shadow_distance_falloff=None, shadow_filter=-1, specular=(0, 0, 0), specular_power=1.0):
+    """RenderSphereLightSource, LightingRenderer.cs:1193-1219."""
+    v = abi.LightVertex()
+    v.LightPosition1 = v.LightPosition2 = v.LightPosition3 = abi.f4(position[0], position[1], position[2], 0)
+    v.Color1 = abi.f4(color[0], color[1], color[2], np.float32(color[3]) * np.float32(opacity * intensity_scale))
+    v.Color2 = abi.f4(specular[0], specular[1], specular[2], specular_power)
+    v.LightProperties = abi.f4(radius, ramp_length, float(ramp_mode), 1.0 if (casts_shadows and have_distance_field) else 0.0)
+    v.MoreLightProperties = abi.f4(ao_radius, -99999.0 if shadow_distance_falloff is None else shadow_distance_falloff,
+                                   falloff_y, ao_opacity)
+    v.EvenMoreLightProperties = abi.f4(float(shadow_filter), 0, 0, 0)
+    return v
+
+
+def random_lights(seed, n, width, height, z=(8.0, 64.0), radius=24.0, ramp=(200.0, 550.0), **kw):
+    xs = uniform(seed + 1, (n,), 0, width)
+    ys = uniform(seed + 2, (n,), 0, height)
+    zs = uniform(seed + 3, (n,), z[0], z[1])
+    rs = uniform(seed + 4, (n,), ramp[0], ramp[1])
+    col = uniform(seed + 5, (n, 3), 0.2, 1.0)
+    arr = (abi.LightVertex * n)()
+    for i in range(n):
+        arr[i] = sphere_light((xs[i], ys[i], zs[i]), radius, rs[i], color=(col[i, 0], col[i, 1], col[i, 2], 1.0), **kw)
+    return arr
+
+
+def ground_plane_gbuffer(width, height, fmt=abi.GBUFFER_FLOAT4):
+    """G-buffer of a bare ground plane: texel (0.5, 1.0, 0, 1.0) <=> normal (0,0,1), z = 0
+    (GBufferShaderCommon.fxh:21-33 with encodeNormalSpherical, EnvironmentCommon.fxh:34-38)."""
+    g = np.empty((height, width, 4), np.float32)
+    g[...] = (0.5, 1.0, 0.0, 1.0)
+    if fmt == abi.GBUFFER_HALF4:
+        return g.astype(np.float16).view(np.uint16)
+    return g
+
+
+def encode_gbuffer(normal, relative_y, z, enable_shadows=True, fullbright=False):
+    """encodeGBufferSample, GBufferShaderCommon.fxh:10-35 (numpy, per texel arrays allowed)."""
+    nx = np.where(np.abs(normal[..., 0]) < 0.0001, 0.0001, normal[..., 0])
+    ex = (np.arctan2(normal[..., 1], nx) / np.pi + 1.0) * 0.5
+    ey = (normal[..., 2] + 1.0) * 0.5
+    sign = 1.0 if enable_shadows else -1.0
+    w = ((z + 1024.0) / 1024.0) * sign + (0.0 if enable_shadows else -1.0)
+    if fullbright:
+        w = np.full_like(ex, 99999.0)
+    return np.stack([ex, ey, np.broadcast_to(relative_y, ex.shape), np.broadcast_to(w, ex.shape)], axis=-1).astype(np.float32)

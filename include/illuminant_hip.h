@@ -1,0 +1,406 @@
+/*
+ * illuminant_hip.h -- C ABI of libilluminant_hip.so
+ *
+ * The drop-in boundary for the two data-parallel hot paths of sq/Illuminant on
+ * MI355X (gfx950): the ParticleEngine per-chunk state update and the
+ * LightingRenderer sphere-light SDF cone trace.  Everything here is plain C:
+ * POD structs whose byte layout is the reference's own uniform / vertex
+ * structs (so C# can pass them with `ref` / `fixed`), opaque handles for
+ * device memory, int32 return codes (0 = ok).
+ *
+ * All file:line citations are relative to the reference checkout
+ * (sq/Illuminant @ 2025-08-29).  The reference interface each entry point
+ * replaces is cited on the entry point.  INTEGRATION.md shows the P/Invoke
+ * declarations a maintainer of the reference would add.
+ *
+ * Threading: a context owns one HIP stream; calls on one context are
+ * asynchronous and ordered; callers serialise calls per context (this is what
+ * the reference's `lock (_UpdateParameterPool)` / issue-thread ordering gives,
+ * Illuminant/Particles/ParticleSystem.cs:681).  Host output buffers are valid
+ * after the call returns (download / count calls synchronise the stream).
+ */
+#ifndef ILLUMINANT_HIP_H
+#define ILLUMINANT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ILM_ABI_VERSION 1
+
+/* ---- return codes ------------------------------------------------------ */
+#define ILM_OK                    0
+#define ILM_ERR_INVALID_ARGUMENT  (-1)
+#define ILM_ERR_INVALID_HANDLE    (-2)
+#define ILM_ERR_OUT_OF_RANGE      (-3)
+#define ILM_ERR_TOO_MANY          (-4)   /* e.g. >16 attractors: Transforms.cs:348-349 */
+#define ILM_ERR_NO_DEVICE         (-5)
+#define ILM_ERR_STATE             (-6)   /* e.g. DF update without a bound field: ParticleSystem.cs:835-836 */
+/* positive values are hipError_t values passed through unchanged */
+
+typedef uint64_t IlmHandle;
+
+/* ---- POD mirrors of the reference's uniform structs -------------------- */
+
+typedef struct IlmFloat4 { float x, y, z, w; } IlmFloat4;
+
+/* XNA Matrix, row-major M11..M44; shaders use mul(rowVector, M)
+ * (Illuminant/Shaders/SpawnerCommon.fxh:166,179). */
+typedef struct IlmMatrix { float m[16]; } IlmMatrix;
+
+/* Uniforms.ParticleSystem -- Illuminant/Uniforms.cs:197-236,
+ * accessors Illuminant/Shaders/ParticleCommon.fxh:29-92. */
+typedef struct IlmParticleSystemUniforms {
+    IlmFloat4 GlobalSettings;     /* deltaTimeMilliseconds, friction, maximumVelocity, lifeDecayRate */
+    IlmFloat4 CollisionSettings;  /* escapeVelocity, bounceVelocityMultiplier, collisionDistance, collisionLifePenalty */
+    IlmFloat4 TexelAndSize;       /* 1/ChunkSize, 1/ChunkSize, Size.X, Size.Y */
+    IlmFloat4 AnimationRateAndRotationAndZToY; /* rate_x, rate_y, velocityRotation, zToY */
+} IlmParticleSystemUniforms;
+
+/* Uniforms.ClampedBezier1 / ClampedBezier4 -- Illuminant/Bezier.cs:433-441,588-599;
+ * shader side Illuminant/Shaders/Bezier.fxh:6-19. */
+typedef struct IlmClampedBezier1 { IlmFloat4 RangeAndCount, ABCD; } IlmClampedBezier1;
+typedef struct IlmClampedBezier4 { IlmFloat4 RangeAndCount, A, B, C, D; } IlmClampedBezier4;
+
+/* Uniforms.DistanceField -- Illuminant/Uniforms.cs:79-88 -- followed by the
+ * separately-bound DistanceFieldPacked1 (Illuminant/Lighting/LightingRenderer.cs:1933-1939,
+ * Illuminant/Shaders/DistanceFieldCommon.fxh:189-206). */
+typedef struct IlmDistanceFieldUniforms {
+    IlmFloat4 ConeAndMisc;              /* MaxConeRadius, DistanceFieldZOffset, OcclusionToOpacityPower, InvScaleFactorX */
+    IlmFloat4 TextureSliceAndTexelSize; /* 1/cols, 1/rows, 1/(virtualW*cols), 1/(virtualH*rows) */
+    IlmFloat4 StepAndMisc2;             /* StepLimit, MinimumLength, LongStepFactor, InvScaleFactorY */
+    IlmFloat4 TextureSliceCount;        /* cols, rows, validZ, sliceCount */
+    IlmFloat4 Extent;                   /* virtualW, virtualH, virtualDepth, maximumEncodedDistance */
+    IlmFloat4 Packed1;                  /* 1/(3*cols), sliceCount/extentZ, validZ, minStepSize */
+} IlmDistanceFieldUniforms;
+
+/* Uniforms.Environment -- Illuminant/Uniforms.cs:14-24 -- plus the G-buffer
+ * uniforms bound by SetGBufferParameters (Illuminant/Lighting/LightingRenderer.GBuffer.cs:520-534)
+ * and the view-transform values the pixel shader reads through
+ * GetViewportPosition()/GetViewportScale() (Illuminant/Shaders/LightCommon.fxh:27-33). */
+typedef struct IlmEnvironment {
+    IlmFloat4 ZAndScale;          /* GroundZ, MaximumZ, RenderScale.X, RenderScale.Y */
+    IlmFloat4 ZToY;               /* ZToYMultiplier, InvZToYMultiplier, LightOcclusion, unused */
+    IlmFloat4 GBufferTexelSizeAndMisc; /* 1/gbufW, 1/gbufH, ViewportScaleX, ViewportScaleY; xy==0 => no G-buffer */
+    float     ViewportPosition[2];
+    float     GBufferViewportRelative;
+    float     _pad0;
+} IlmEnvironment;
+
+/* LightVertex, 8 x float4, Pack=4 -- Illuminant/Vertices.cs:10-39; filled by
+ * RenderSphereLightSource, Illuminant/Lighting/LightingRenderer.cs:1193-1219. */
+typedef struct IlmLightVertex {
+    IlmFloat4 LightPosition1, LightPosition2, LightPosition3;
+    IlmFloat4 LightProperties;         /* radius, rampLength, rampMode, castsShadows */
+    IlmFloat4 MoreLightProperties;     /* aoRadius, shadowDistanceFalloff, falloffYFactor, aoOpacity */
+    IlmFloat4 EvenMoreLightProperties; /* shadowFilter, 0, rampOffset, rampRate */
+    IlmFloat4 Color1;                  /* rgb, a*opacity*intensityScale */
+    IlmFloat4 Color2;                  /* specular rgb, specular power */
+} IlmLightVertex;
+
+/* ---- particle transform parameters ------------------------------------- */
+
+/* ParticleAreaTransform.SetParameters -- Illuminant/Particles/ParticleTransform.cs:294-318. */
+typedef struct IlmAreaParams {
+    int32_t AreaType;             /* 0 none, 1 ellipsoid, 2 box, 3 cylinder, 4 spheroid, 5 octagon */
+    float   Strength;
+    float   AreaFalloff;
+    float   AreaRotation;
+    float   AreaCenter[3];  float _pad0;
+    float   AreaSize[3];    float _pad1;
+    float   CategoryFilter[2];    /* default (-9999, 9999) */
+    float   _pad2[2];
+} IlmAreaParams;
+
+#define ILM_MAX_ATTRACTORS 16     /* Illuminant/Shaders/Gravity.fx:3 */
+
+/* Gravity.SetParameters -- Illuminant/Particles/Transforms.cs:347-365; shader
+ * Illuminant/Shaders/Gravity.fx:5-10.  NOTE: Gravity derives from ParticleTransform,
+ * not ParticleAreaTransform, so the reference never binds CategoryFilter for it
+ * and the effect default (0,0) applies; the field is explicit here. */
+typedef struct IlmGravityParams {
+    int32_t AttractorCount;
+    float   MaximumAcceleration;
+    float   CategoryFilter[2];
+    float   AttractorPositions[ILM_MAX_ATTRACTORS][3];
+    float   AttractorRadiusesAndStrengths[ILM_MAX_ATTRACTORS][3]; /* radius, strength, type */
+} IlmGravityParams;
+
+/* FMA.SetParameters -- Illuminant/Particles/Transforms.cs:38-45; shader Illuminant/Shaders/FMA.fx:4-13. */
+typedef struct IlmFMAParams {
+    IlmAreaParams Area;
+    float     TimeDivisor;  float _pad[3];
+    IlmFloat4 PositionAdd, PositionMultiply;
+    IlmFloat4 VelocityAdd, VelocityMultiply;
+} IlmFMAParams;
+
+/* Noise.SetParameters -- Illuminant/Particles/Transforms.cs:243-268; shader Illuminant/Shaders/Noise.fx:5-19. */
+typedef struct IlmNoiseParams {
+    IlmAreaParams Area;
+    float     TimeDivisor;
+    float     FrequencyLerp;
+    float     ReplaceOldVelocity;
+    float     _pad;
+    float     RandomnessOffset[2];
+    float     NextRandomnessOffset[2];
+    IlmFloat4 PositionOffset, PositionMinimum, PositionScale;
+    IlmFloat4 VelocityOffset, VelocityMinimum, VelocityScale;
+} IlmNoiseParams;
+
+#define ILM_MAX_INLINE_POSITION_CONSTANTS 4   /* Illuminant/Shaders/SpawnerCommon.fxh:1 */
+
+/* SpawnerBase.SetParameters + Spawner.SetParameters --
+ * Illuminant/Particles/ParticleSpawner.cs:200-256,376-403; shader uniforms
+ * Illuminant/Shaders/SpawnerCommon.fxh:3-15. */
+typedef struct IlmSpawnParams {
+    float     ChunkSizeAndIndices[4];   /* chunkSize, first, last, positionIndexOffset */
+    IlmFloat4 Configuration[9];
+    float     FormulaTypes[4];
+    IlmMatrix PositionMatrix, VelocityMatrix;
+    float     AxisMask[3];
+    float     AlignVelocityAndPosition;
+    float     RandomnessOffset[2];
+    float     AttributeDiscardThreshold;  /* AlphaDiscardThreshold / 255 */
+    float     PolygonRate;
+    float     PolygonLoop;
+    float     PositionConstantCount;
+    float     _pad[2];
+    IlmFloat4 InlinePositionConstants[ILM_MAX_INLINE_POSITION_CONSTANTS];
+} IlmSpawnParams;
+
+/* Everything SetSystemUniforms (Illuminant/Particles/ParticleSystem.cs:547-575) and
+ * UpdateHandler._BeforeDraw (Illuminant/Particles/ParticleTransform.cs:84-168) bind
+ * for the Update pass. */
+typedef struct IlmUpdateParams {
+    IlmClampedBezier4 ColorFromLife, ColorFromVelocity;
+    IlmClampedBezier1 SizeFromLife, SizeFromVelocity;
+    float     RotationFromLifeAndIndex[2];   /* radians */
+    float     _pad[2];
+    IlmFloat4 LifeRampSettings;              /* strength, min, divisor, indexDivisor; x==0 => off */
+} IlmUpdateParams;
+
+enum {
+    ILM_OP_GRAVITY = 1,   /* technique Gravity, Illuminant/Shaders/Gravity.fx:12-61 */
+    ILM_OP_NOISE   = 2,   /* technique Noise,   Illuminant/Shaders/Noise.fx:28-72   */
+    ILM_OP_FMA     = 3    /* technique FMA,     Illuminant/Shaders/FMA.fx:15-51     */
+};
+
+typedef struct IlmTransformOp {
+    int32_t Type;
+    int32_t _pad[3];
+    union {
+        IlmGravityParams Gravity;
+        IlmNoiseParams   Noise;
+        IlmFMAParams     FMA;
+    } u;
+} IlmTransformOp;
+
+enum {
+    ILM_UPDATE_NONE                = 0,  /* transforms only */
+    ILM_UPDATE_POSITIONS           = 1,  /* technique UpdatePositions, UpdateParticleSystem.fx:9-38 */
+    ILM_UPDATE_WITH_DISTANCE_FIELD = 2,  /* technique UpdateWithDistanceField, UpdateParticleSystemWithDistanceField.fx:29-147 */
+    ILM_UPDATE_ERASE               = 3   /* technique Erase, UpdateParticleSystem.fx:40-49 */
+};
+
+#define ILM_MAX_OPS    4
+#define ILM_MAX_SPAWNS 2
+
+#define ILM_STEP_COUNT_LIVE  1u   /* also produce per-chunk live counts (CountLiveParticles.fx) */
+
+typedef struct IlmSpawnRecord {
+    int32_t        ChunkIndex;    /* index in the system's chunk table */
+    int32_t        _pad[3];
+    IlmSpawnParams Params;
+} IlmSpawnRecord;
+
+/* One ParticleSystem.Update's worth of GPU work (Illuminant/Particles/ParticleSystem.cs:725-745):
+ * spawns first, then for every chunk in [FirstChunk, FirstChunk+ChunkCount) each
+ * transform in order, then the update pass.  Executed as ONE kernel launch with
+ * every pass applied in registers; pass-ordering semantics are preserved per slot. */
+typedef struct IlmStepDesc {
+    int32_t  FirstChunk, ChunkCount;   /* ChunkCount < 0 => all chunks */
+    int32_t  OpCount, SpawnCount;
+    int32_t  UpdateMode;
+    uint32_t Flags;
+    int32_t  _pad[2];
+    IlmParticleSystemUniforms System;
+    IlmUpdateParams           Update;
+    IlmDistanceFieldUniforms  DistanceField;  /* used when UpdateMode == ILM_UPDATE_WITH_DISTANCE_FIELD */
+    IlmTransformOp            Ops[ILM_MAX_OPS];
+    IlmSpawnRecord            Spawns[ILM_MAX_SPAWNS];
+} IlmStepDesc;
+
+/* ---- formats ------------------------------------------------------------ */
+enum {
+    ILM_SDF_UNORM16 = 0,  /* SurfaceFormat.Rgba64, Illuminant/SDF/DistanceField.cs:22 */
+    ILM_SDF_FP16    = 1   /* same atlas, channels stored as IEEE half of the encoded value */
+};
+enum {
+    ILM_GBUFFER_FLOAT4 = 0, /* SurfaceFormat.Vector4     (Illuminant/GBuffer.cs:30-38) */
+    ILM_GBUFFER_HALF4  = 1  /* SurfaceFormat.HalfVector4 */
+};
+enum {
+    ILM_LIGHTMAP_FLOAT4 = 0, /* fp32 accumulation written unrounded (parity format) */
+    ILM_LIGHTMAP_HALF4  = 1, /* HalfVector4 lightmap, Illuminant/Lighting/LightingRenderer.cs:476-479 */
+    ILM_LIGHTMAP_RGBA8  = 2  /* SurfaceFormat.Color lightmap (low quality) */
+};
+
+/* Which particle attribute planes to move in upload / download. */
+enum {
+    ILM_PLANE_POSITION     = 0,  /* PositionAndLife  (xyz, life)      ParticleSystem.cs:73-146 */
+    ILM_PLANE_VELOCITY     = 1,  /* Velocity         (xyz, category)  */
+    ILM_PLANE_ATTRIBUTES   = 2,  /* Chunk.Color      (rgba)           ParticleSystem.cs:159 */
+    ILM_PLANE_RENDER_COLOR = 3,  /* Chunk.RenderColor (premultiplied) ParticleSystem.cs:160 */
+    ILM_PLANE_RENDER_DATA  = 4   /* Chunk.RenderData (size, rotation, speed, category) ParticleSystem.cs:161 */
+};
+
+/* ---- library / context -------------------------------------------------- */
+
+int32_t     ilm_abi_version(void);
+/* Last error text for the calling thread ("" if none). */
+const char* ilm_last_error(void);
+/* Number of visible HIP devices (0 when there is no GPU; never fails). */
+int32_t     ilm_device_count(void);
+
+/* One context per GPU.  Replaces the GraphicsDevice/RenderCoordinator the
+ * reference threads through ParticleEngine (Illuminant/Particles/ParticleEngine.cs:95-141)
+ * and LightingRenderer (Illuminant/Lighting/LightingRenderer.cs:486-560). */
+int32_t ilm_ctx_create(int32_t device_id, IlmHandle* out_ctx);
+int32_t ilm_ctx_destroy(IlmHandle ctx);
+/* Block until all work queued on the context has finished. */
+int32_t ilm_ctx_sync(IlmHandle ctx);
+/* Raw hipStream_t of the context (for interop with RCCL / torch streams). */
+int32_t ilm_ctx_stream(IlmHandle ctx, void** out_stream);
+
+/* GPU-side timers around a region of queued work (hipEvent pair on the context
+ * stream); elapsed time in milliseconds is returned by ilm_timer_stop after it
+ * synchronises on the stop event. */
+int32_t ilm_timer_start(IlmHandle ctx);
+int32_t ilm_timer_stop(IlmHandle ctx, float* out_ms);
+
+/* ---- particle engine ----------------------------------------------------- */
+
+/* ParticleEngine ctor: chunk size + the 807x653 float4 randomness table
+ * (Illuminant/Particles/ParticleEngine.cs:45-46,495-544).  The reference fills
+ * it from an unseeded RNG, so it is an explicit input here.  `randomness` is a
+ * host pointer to width*height float4 texels, row-major. */
+#define ILM_RANDOMNESS_WIDTH  807
+#define ILM_RANDOMNESS_HEIGHT 653
+int32_t ilm_engine_create(IlmHandle ctx, int32_t chunk_size,
+                          const IlmFloat4* randomness, int32_t rand_width, int32_t rand_height,
+                          IlmHandle* out_engine);
+int32_t ilm_engine_destroy(IlmHandle engine);
+
+/* ParticleSystem: a table of chunks of chunk_size^2 slots each
+ * (Illuminant/Particles/ParticleSystem.cs:148-240).  State is stored SoA, one
+ * buffer set per chunk, updated in place (the reference's Previous/Current
+ * ping-pong exists only to satisfy render-target hazards,
+ * ParticleSystem.cs:577-616). */
+int32_t ilm_system_create(IlmHandle engine, IlmHandle* out_system);
+int32_t ilm_system_destroy(IlmHandle system);
+/* CreateChunk (ParticleSystem.cs:349-384): appends a zero-filled chunk, returns its table index. */
+int32_t ilm_system_add_chunk(IlmHandle system, int32_t* out_chunk_index);
+/* Reap (ParticleLiveness.cs:120-129): removes the chunk at `chunk_index`; later chunks shift down by one. */
+int32_t ilm_system_remove_chunk(IlmHandle system, int32_t chunk_index);
+int32_t ilm_system_chunk_count(IlmHandle system, int32_t* out_count);
+
+/* ParticleSystem.Spawn(initializers) upload path (ParticleSpawning.cs:13-113) /
+ * AutoReadback (ParticleReadback.cs:21-71).  Host buffers are AoS float4,
+ * `count` slots starting at slot `first_slot`. */
+int32_t ilm_chunk_upload(IlmHandle system, int32_t chunk_index, int32_t plane,
+                         const IlmFloat4* src, int32_t first_slot, int32_t count);
+int32_t ilm_chunk_download(IlmHandle system, int32_t chunk_index, int32_t plane,
+                           IlmFloat4* dst, int32_t first_slot, int32_t count);
+/* Device pointer of one SoA component array of a chunk (component 0..19 =
+ * x,y,z,life, vx,vy,vz,category, attr rgba, renderColor rgba, renderData xyzw);
+ * `out_stride_floats` is the distance between component arrays.  For zero-copy
+ * consumers (RCCL all-gather of positions, renderers). */
+int32_t ilm_chunk_device_ptr(IlmHandle system, int32_t chunk_index, int32_t component,
+                             void** out_ptr, int64_t* out_stride_floats);
+
+/* Bind the distance field particles collide with
+ * (ParticleCollision.DistanceField, ParticleConfiguration.cs:20-24); 0 unbinds. */
+int32_t ilm_system_set_distance_field(IlmHandle system, IlmHandle sdf);
+/* Optional life ramp texture (ParticleSystem.cs:911-941): width*height float4, POINT, U clamp / V wrap. */
+int32_t ilm_system_set_life_ramp(IlmHandle system, const IlmFloat4* texels, int32_t width, int32_t height);
+
+/* The hot path.  Replaces RunSpawner + the UpdateChunk loop of
+ * ParticleSystem.Update (ParticleSystem.cs:725-745, 791-856): every RunTransform
+ * draw for every chunk becomes one launch. */
+int32_t ilm_system_step(IlmHandle system, const IlmStepDesc* desc);
+
+/* Single-pass entry points, one per reference technique (LoadMaterials.cs:387-522);
+ * chunk_index < 0 => every chunk.  Thin wrappers over ilm_system_step. */
+int32_t ilm_spawn  (IlmHandle system, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmSpawnParams* p);
+int32_t ilm_gravity(IlmHandle system, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmGravityParams* p);
+int32_t ilm_noise  (IlmHandle system, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmNoiseParams* p);
+int32_t ilm_fma    (IlmHandle system, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmFMAParams* p);
+int32_t ilm_update (IlmHandle system, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmUpdateParams* p,
+                    const IlmDistanceFieldUniforms* df /* NULL => UpdatePositions */);
+int32_t ilm_erase  (IlmHandle system, int32_t chunk_index);
+
+/* Liveness (CountLiveParticles.fx:5-40 + ProcessLivenessInfoData, ParticleEngine.cs:224-252):
+ * out_counts[i] = #{slots of chunk i with life > 0}; when saturate16 != 0 the
+ * value is min(count, 65535) exactly as the reference's 16-bit additive target decodes. */
+int32_t ilm_system_live_counts(IlmHandle system, uint32_t* out_counts, int32_t capacity, int32_t saturate16);
+
+/* Counts produced inside the last ilm_system_step that had ILM_STEP_COUNT_LIVE set
+ * (the ballot/popcount reduction fused into the update kernel); synchronises. */
+int32_t ilm_system_step_counts(IlmHandle system, uint32_t* out_counts, int32_t capacity, int32_t saturate16);
+
+/* Ordered live-slot list of one chunk (wave64 ballot + prefix sum): writes the
+ * ascending slot indices with life > 0 to `out_slots` (host, capacity entries)
+ * and their number to out_count.  Consumer: particle lights (ParticleLight.fx). */
+int32_t ilm_chunk_live_slots(IlmHandle system, int32_t chunk_index, uint32_t* out_slots, int32_t capacity, int32_t* out_count);
+
+/* ---- lighting ------------------------------------------------------------- */
+
+/* DistanceField atlas (Illuminant/SDF/DistanceField.cs:43-122): width x height
+ * texels of 4 x 16 bit, row-major; `texels` is a host pointer (DistanceField.Load
+ * layout, DistanceField.cs:178-213). */
+int32_t ilm_sdf_create(IlmHandle ctx, int32_t atlas_width, int32_t atlas_height, int32_t format, IlmHandle* out_sdf);
+int32_t ilm_sdf_upload(IlmHandle sdf, const uint16_t* texels);
+int32_t ilm_sdf_destroy(IlmHandle sdf);
+
+/* G-buffer (Illuminant/GBuffer.cs): width x height texels (encNormal.xy, relativeY, encodedZ). */
+int32_t ilm_gbuffer_create(IlmHandle ctx, int32_t width, int32_t height, int32_t format, IlmHandle* out_gbuffer);
+int32_t ilm_gbuffer_upload(IlmHandle gbuffer, const void* texels);
+int32_t ilm_gbuffer_destroy(IlmHandle gbuffer);
+
+/* Lightmap render target (BufferRing of lightmaps, LightingRenderer.cs:472-485).
+ * If external_device_ptr != NULL the lightmap aliases caller-owned device memory
+ * of width*height*bytes_per_texel bytes (e.g. a torch tensor that RCCL gathers). */
+int32_t ilm_lightmap_create(IlmHandle ctx, int32_t width, int32_t height, int32_t format,
+                            void* external_device_ptr, IlmHandle* out_lightmap);
+int32_t ilm_lightmap_download(IlmHandle lightmap, void* dst, int32_t first_row, int32_t row_count);
+int32_t ilm_lightmap_device_ptr(IlmHandle lightmap, void** out_ptr);
+int32_t ilm_lightmap_destroy(IlmHandle lightmap);
+
+typedef struct IlmRenderStats {
+    uint64_t SdfSamples;       /* sampleDistanceFieldEx calls executed (AO + cone-trace steps) */
+    uint64_t PixelLightPairs;  /* pixel x light pairs inside a light's raster footprint */
+    uint64_t TracedPairs;      /* pairs that ran the cone trace */
+} IlmRenderStats;
+
+/* The sphere-light pass of LightingRenderer.RenderLighting
+ * (Illuminant/Lighting/LightingRenderer.cs:1004-1169 + technique SphereLight,
+ * Illuminant/Shaders/SphereLight.fx:7-46): lightmap[row_begin..row_end) =
+ * ambient + sum over lights, in light order.  gbuffer == 0 => ground plane
+ * (LightCommon.fxh:130-141); sdf == 0 => no distance field.  `lights` is a host
+ * array.  stats may be NULL; when non-NULL the instrumented (counting) kernel
+ * variant runs and the call synchronises. */
+int32_t ilm_render_sphere_lights(IlmHandle ctx,
+                                 const IlmLightVertex* lights, int32_t light_count,
+                                 const IlmEnvironment* env,
+                                 const IlmDistanceFieldUniforms* df,
+                                 IlmHandle gbuffer, IlmHandle sdf,
+                                 const float ambient[4],
+                                 IlmHandle lightmap, int32_t row_begin, int32_t row_end,
+                                 IlmRenderStats* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ILLUMINANT_HIP_H */

@@ -1,0 +1,112 @@
+/*
+ * ilm_oracle.h -- CPU restatement of the reference's HLSL for the two hot paths.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is linked, imported or
+ * executed by the product path (illuminant_amd/, libilluminant_hip.so,
+ * libilluminant_host.so).  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py use it, and only as the checker / the timed
+ * CPU baseline.
+ *
+ * PARITY UNPINNED: the reference (sq/Illuminant, C# + HLSL) ships no tests,
+ * golden vectors or fixtures for these paths, and neither .NET nor fxc exists
+ * in the build container, so this restatement cannot be checked against the
+ * reference's own output.  It is pinned only by the substitute known-answer
+ * tests listed in DESIGN.md (values hand-derived from the cited reference
+ * lines; tests/test_oracle_kat.py).
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * the reference checkout).  HLSL semantics are made explicit:
+ *   saturate(x) = min(max(x,0),1) with NaN -> 0;  lerp(a,b,t) = a + (b-a)*t;
+ *   float % = fmodf (truncating);  normalize(v) = v / sqrt(dot(v,v));
+ *   POINT sample = floor(u*W) with WRAP = positive modulo, CLAMP = clamp;
+ *   LINEAR sample = texel centres at +0.5, fp32 weights;
+ *   unorm16 -> float = v / 65535.  No FMA contraction (-ffp-contract=off).
+ */
+#ifndef ILM_ORACLE_H
+#define ILM_ORACLE_H
+
+#include "../include/illuminant_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct OrcTexture {
+    const void* texels;
+    int32_t width, height;
+    int32_t format;          /* ILM_SDF_* / ILM_GBUFFER_* */
+} OrcTexture;
+
+/* particles: AoS float4 planes of one chunk (chunk_size^2 slots), updated in place */
+void orc_spawn(IlmFloat4* pos, IlmFloat4* vel, IlmFloat4* attr, int32_t chunk_size,
+               const IlmFloat4* rnd, int32_t rw, int32_t rh, const IlmSpawnParams* p);
+void orc_gravity(IlmFloat4* pos, IlmFloat4* vel, int32_t chunk_size,
+                 const IlmParticleSystemUniforms* sys, const IlmGravityParams* p);
+void orc_noise(IlmFloat4* pos, IlmFloat4* vel, int32_t chunk_size,
+               const IlmFloat4* rnd, int32_t rw, int32_t rh,
+               const IlmParticleSystemUniforms* sys, const IlmNoiseParams* p);
+void orc_fma(IlmFloat4* pos, IlmFloat4* vel, int32_t chunk_size,
+             const IlmParticleSystemUniforms* sys, const IlmFMAParams* p);
+void orc_update(IlmFloat4* pos, IlmFloat4* vel, const IlmFloat4* attr,
+                IlmFloat4* render_color, IlmFloat4* render_data, int32_t chunk_size,
+                const IlmParticleSystemUniforms* sys, const IlmUpdateParams* p,
+                const IlmFloat4* life_ramp, int32_t ramp_w, int32_t ramp_h,
+                const IlmDistanceFieldUniforms* df, const OrcTexture* sdf /* both NULL => UpdatePositions */);
+void orc_erase(IlmFloat4* pos, IlmFloat4* vel, IlmFloat4* render_color, IlmFloat4* render_data, int32_t chunk_size);
+uint32_t orc_count_live(const IlmFloat4* pos, int32_t slots, int32_t saturate16);
+
+/* one ParticleSystem.Update over a table of chunks; planes[c][0..4] = pos, vel, attr, rc, rd */
+void orc_step(IlmFloat4** planes, int32_t chunk_count, int32_t chunk_size,
+              const IlmFloat4* rnd, int32_t rw, int32_t rh,
+              const IlmFloat4* life_ramp, int32_t ramp_w, int32_t ramp_h,
+              const OrcTexture* sdf, const IlmStepDesc* desc, uint32_t* live_counts /* may be NULL */);
+
+/* bezier / distance field primitives exposed for known-answer tests */
+float orc_bezier1(const IlmClampedBezier1* b, float value);
+void  orc_bezier4(const IlmClampedBezier4* b, float value, IlmFloat4* out);
+float orc_sample_distance_field(const float pos[3], const IlmDistanceFieldUniforms* df, const OrcTexture* sdf);
+float orc_encode_distance(float distance, float max_encoded);
+float orc_decode_distance(float encoded, float max_encoded);
+float orc_evaluate_area(int32_t type_id, const float pos[3], const float center[3], const float size[3], float rotation);
+
+/* lighting */
+void orc_sample_gbuffer(float px, float py, const IlmEnvironment* env, const OrcTexture* gbuffer,
+                        float world_pos[3], float normal[3], int32_t* enable_shadows, int32_t* fullbright, float camera_pos[3]);
+void orc_render_sphere_lights(const IlmLightVertex* lights, int32_t light_count,
+                              const IlmEnvironment* env, const IlmDistanceFieldUniforms* df,
+                              const OrcTexture* gbuffer, const OrcTexture* sdf,
+                              const float ambient[4],
+                              IlmFloat4* lightmap, int32_t width, int32_t height,
+                              int32_t row_begin, int32_t row_end, IlmRenderStats* stats);
+
+/* host-side integer/layout logic */
+typedef struct OrcDistanceFieldLayout {
+    int32_t virtual_width, virtual_height;
+    float   virtual_depth;
+    double  resolution;
+    int32_t slice_width, slice_height, slice_count, physical_slice_count;
+    int32_t column_count, row_count, atlas_width, atlas_height;
+    int32_t maximum_encoded_distance;
+} OrcDistanceFieldLayout;
+void orc_distance_field_layout(int32_t virtual_width, int32_t virtual_height, float virtual_depth,
+                               int32_t requested_slice_count, double requested_resolution,
+                               int32_t maximum_encoded_distance, OrcDistanceFieldLayout* out);
+void orc_distance_field_uniforms(const OrcDistanceFieldLayout* l, int32_t valid_slice_count, float z_offset,
+                                 float max_cone_radius, float occlusion_to_opacity_power, int32_t step_limit,
+                                 float min_step_size, float long_step_factor, IlmDistanceFieldUniforms* out);
+
+/* SpawnerBase.BeginTick / EndTick + RunSpawner slot allocation */
+typedef struct OrcSpawnerState {
+    double  rate_error;
+    int32_t total_spawned;
+} OrcSpawnerState;
+int32_t orc_spawner_begin_tick(OrcSpawnerState* s, float min_rate, float max_rate, int32_t count_scale,
+                               double rng_draw, double delta_time_seconds, int32_t maximum_total /* <0 => none */);
+void    orc_spawner_end_tick(OrcSpawnerState* s, int32_t requested, int32_t actual);
+
+int32_t orc_num_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,218 @@
+"""ctypes front end of the CPU oracle (oracle/libilm_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by illuminant_amd/.  PARITY UNPINNED (see
+oracle/ilm_oracle.h and DESIGN.md).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from illuminant_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libilm_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    """Compile the C restatement with gcc (oracle/Makefile)."""
+    if force or not os.path.exists(_LIB_PATH) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
+            for f in ("ilm_oracle.c", "ilm_oracle.h")):
+        subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+    return _LIB_PATH
+
+
+class Texture(C.Structure):
+    _fields_ = [("texels", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("format", C.c_int32)]
+
+
+class DistanceFieldLayout(C.Structure):
+    _fields_ = [("virtual_width", C.c_int32), ("virtual_height", C.c_int32), ("virtual_depth", C.c_float),
+                ("resolution", C.c_double),
+                ("slice_width", C.c_int32), ("slice_height", C.c_int32), ("slice_count", C.c_int32),
+                ("physical_slice_count", C.c_int32), ("column_count", C.c_int32), ("row_count", C.c_int32),
+                ("atlas_width", C.c_int32), ("atlas_height", C.c_int32), ("maximum_encoded_distance", C.c_int32)]
+
+
+class SpawnerState(C.Structure):
+    _fields_ = [("rate_error", C.c_double), ("total_spawned", C.c_int32)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_bezier1.restype = C.c_float
+        _lib.orc_bezier1.argtypes = [C.c_void_p, C.c_float]
+        _lib.orc_sample_distance_field.restype = C.c_float
+        _lib.orc_encode_distance.restype = C.c_float
+        _lib.orc_encode_distance.argtypes = [C.c_float, C.c_float]
+        _lib.orc_decode_distance.restype = C.c_float
+        _lib.orc_decode_distance.argtypes = [C.c_float, C.c_float]
+        _lib.orc_evaluate_area.restype = C.c_float
+        _lib.orc_count_live.restype = C.c_uint32
+        _lib.orc_spawner_begin_tick.restype = C.c_int32
+        _lib.orc_spawner_begin_tick.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_int32, C.c_double, C.c_double, C.c_int32]
+        _lib.orc_distance_field_layout.argtypes = [C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_double, C.c_int32, C.c_void_p]
+        _lib.orc_distance_field_uniforms.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_float, C.c_int32,
+                                                     C.c_float, C.c_float, C.c_void_p]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _f4(a):
+    assert a.dtype == np.float32 and a.flags["C_CONTIGUOUS"] and a.shape[-1] == 4
+    return _p(a)
+
+
+def make_texture(arr, fmt):
+    """arr: (H, W, 4) uint16 (SDF / half G-buffer) or float32 (G-buffer)."""
+    assert arr.flags["C_CONTIGUOUS"] and arr.ndim == 3 and arr.shape[2] == 4
+    t = Texture(arr.ctypes.data, arr.shape[1], arr.shape[0], fmt)
+    t._keep = arr
+    return t
+
+
+def num_threads():
+    return int(lib().orc_num_threads())
+
+
+# ---- particles: planes are (slots, 4) float32 arrays, updated in place ---------------------------
+
+def spawn(pos, vel, attr, chunk_size, rnd, p):
+    lib().orc_spawn(_f4(pos), _f4(vel), _f4(attr), chunk_size, _f4(rnd), rnd.shape[1], rnd.shape[0], C.byref(p))
+
+
+def gravity(pos, vel, chunk_size, sys, p):
+    lib().orc_gravity(_f4(pos), _f4(vel), chunk_size, C.byref(sys), C.byref(p))
+
+
+def noise(pos, vel, chunk_size, rnd, sys, p):
+    lib().orc_noise(_f4(pos), _f4(vel), chunk_size, _f4(rnd), rnd.shape[1], rnd.shape[0], C.byref(sys), C.byref(p))
+
+
+def fma(pos, vel, chunk_size, sys, p):
+    lib().orc_fma(_f4(pos), _f4(vel), chunk_size, C.byref(sys), C.byref(p))
+
+
+def update(pos, vel, attr, rc, rd, chunk_size, sys, p, life_ramp=None, df=None, sdf=None):
+    rw = rh = 0
+    if life_ramp is not None:
+        rh, rw = life_ramp.shape[0], life_ramp.shape[1]
+    lib().orc_update(_f4(pos), _f4(vel), _f4(attr), _f4(rc), _f4(rd), chunk_size, C.byref(sys), C.byref(p),
+                     _p(life_ramp), rw, rh,
+                     C.byref(df) if df is not None else None, C.byref(sdf) if sdf is not None else None)
+
+
+def erase(pos, vel, rc, rd, chunk_size):
+    lib().orc_erase(_f4(pos), _f4(vel), _f4(rc), _f4(rd), chunk_size)
+
+
+def count_live(pos, saturate16=False):
+    return int(lib().orc_count_live(_f4(pos), pos.shape[0], 1 if saturate16 else 0))
+
+
+def step(chunks, chunk_size, rnd, desc, life_ramp=None, sdf=None, want_counts=False):
+    """chunks: list of dicts/tuples of 5 planes (pos, vel, attr, rc, rd) per chunk."""
+    n = len(chunks)
+    ptrs = (C.c_void_p * (n * 5))()
+    for c, planes in enumerate(chunks):
+        for k in range(5):
+            ptrs[c * 5 + k] = _f4(planes[k]).value
+    counts = np.zeros(n, dtype=np.uint32) if want_counts else None
+    rw = rh = 0
+    if life_ramp is not None:
+        rh, rw = life_ramp.shape[0], life_ramp.shape[1]
+    lib().orc_step(ptrs, n, chunk_size, _f4(rnd), rnd.shape[1], rnd.shape[0], _p(life_ramp), rw, rh,
+                   C.byref(sdf) if sdf is not None else None, C.byref(desc), _p(counts))
+    return counts
+
+
+# ---- primitives ------------------------------------------------------------------------------------
+
+def bezier1(b, value):
+    return float(lib().orc_bezier1(C.byref(b), C.c_float(value)))
+
+
+def bezier4(b, value):
+    out = abi.Float4()
+    lib().orc_bezier4(C.byref(b), C.c_float(value), C.byref(out))
+    return out.tuple()
+
+
+def sample_distance_field(pos, df, sdf):
+    a = (C.c_float * 3)(*[float(x) for x in pos])
+    return float(lib().orc_sample_distance_field(a, C.byref(df), C.byref(sdf)))
+
+
+def encode_distance(d, max_encoded):
+    return float(lib().orc_encode_distance(d, max_encoded))
+
+
+def decode_distance(e, max_encoded):
+    return float(lib().orc_decode_distance(e, max_encoded))
+
+
+def evaluate_area(type_id, pos, center, size, rotation):
+    mk = lambda v: (C.c_float * 3)(*[float(x) for x in v])
+    return float(lib().orc_evaluate_area(C.c_int32(type_id), mk(pos), mk(center), mk(size), C.c_float(rotation)))
+
+
+# ---- lighting --------------------------------------------------------------------------------------
+
+def sample_gbuffer(px, py, env, gbuffer=None):
+    wp = (C.c_float * 3)(); n = (C.c_float * 3)(); cam = (C.c_float * 3)()
+    es = C.c_int32(); fb = C.c_int32()
+    lib().orc_sample_gbuffer(C.c_float(px), C.c_float(py), C.byref(env),
+                             C.byref(gbuffer) if gbuffer is not None else None,
+                             wp, n, C.byref(es), C.byref(fb), cam)
+    return tuple(wp), tuple(n), bool(es.value), bool(fb.value), tuple(cam)
+
+
+def render_sphere_lights(lights, env, df, gbuffer, sdf, ambient, width, height, row_begin=0, row_end=None, want_stats=False):
+    """lights: ctypes array of abi.LightVertex.  Returns (lightmap (H, W, 4) float32, stats|None)."""
+    if row_end is None:
+        row_end = height
+    out = np.zeros((height, width, 4), dtype=np.float32)
+    amb = (C.c_float * 4)(*[float(x) for x in ambient])
+    stats = abi.RenderStats() if want_stats else None
+    lib().orc_render_sphere_lights(lights, len(lights), C.byref(env), C.byref(df),
+                                   C.byref(gbuffer) if gbuffer is not None else None,
+                                   C.byref(sdf) if sdf is not None else None,
+                                   amb, _f4(out), width, height, row_begin, row_end,
+                                   C.byref(stats) if stats is not None else None)
+    return out, stats
+
+
+# ---- host logic -------------------------------------------------------------------------------------
+
+def distance_field_layout(vw, vh, vdepth, requested_slices, resolution=1.0, max_encoded=128):
+    out = DistanceFieldLayout()
+    lib().orc_distance_field_layout(vw, vh, vdepth, requested_slices, resolution, max_encoded, C.byref(out))
+    return out
+
+
+def distance_field_uniforms(layout, valid_slice_count=None, z_offset=0.0, max_cone_radius=24.0, power=1.0,
+                            step_limit=64, min_step_size=3.0, long_step_factor=1.0):
+    out = abi.DistanceFieldUniforms()
+    if valid_slice_count is None:
+        valid_slice_count = layout.slice_count
+    lib().orc_distance_field_uniforms(C.byref(layout), valid_slice_count, z_offset, max_cone_radius, power,
+                                      step_limit, min_step_size, long_step_factor, C.byref(out))
+    return out
+
+
+def spawner_begin_tick(state, min_rate, max_rate, count_scale, rng_draw, dt, maximum_total=-1):
+    return int(lib().orc_spawner_begin_tick(C.byref(state), min_rate, max_rate, count_scale, rng_draw, dt, maximum_total))
+
+
+def spawner_end_tick(state, requested, actual):
+    lib().orc_spawner_end_tick(C.byref(state), requested, actual)

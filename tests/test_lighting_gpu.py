@@ -1,0 +1,141 @@
+"""Parity of the HIP sphere-light / SDF cone-trace pass (through the C ABI) against the CPU oracle."""
+import numpy as np
+import pytest
+
+from illuminant_amd import abi, native, scenes
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def small_scene(fmt=abi.SDF_UNORM16, n_lights=12, width=160, height=112, seed=5):
+    layout = scenes.DistanceFieldLayout(256, 192, 96.0, 12, 0.5, 128)
+    obstacles = scenes.random_obstacles(seed, 14, (256, 192), size_lo=8.0, size_hi=30.0, z_hi=40.0)
+    atlas = scenes.build_sdf_atlas(layout, obstacles, fmt=fmt)
+    dfu = layout.uniforms(max_cone_radius=24.0, power=0.7, step_limit=64, min_step_size=1.0, long_step_factor=0.5)
+    lights = scenes.random_lights(seed + 1, n_lights, width, height, z=(8.0, 48.0), radius=10.0, ramp=(40.0, 120.0))
+    return layout, atlas, dfu, lights, width, height
+
+
+def render_both(ctx, oracle, lights, env, dfu, gbuf_arr, gfmt, atlas, sfmt, ambient, width, height, lm_fmt=abi.LIGHTMAP_FLOAT4,
+                row_begin=0, row_end=None, want_stats=True):
+    sdf = native.DistanceFieldTexture(ctx, atlas, sfmt) if atlas is not None else None
+    gb = native.GBufferTexture(ctx, gbuf_arr, gfmt) if gbuf_arr is not None else None
+    lm = native.Lightmap(ctx, width, height, lm_fmt)
+    stats = native.render_sphere_lights(ctx, lights, env, dfu, gb, sdf, ambient, lm, row_begin, row_end, want_stats=want_stats)
+    got = lm.download()
+    otex = oracle.make_texture(atlas, sfmt) if atlas is not None else None
+    ogb = oracle.make_texture(gbuf_arr, gfmt) if gbuf_arr is not None else None
+    want, ostats = oracle.render_sphere_lights(lights, env, dfu, ogb, otex, ambient, width, height,
+                                               row_begin, height if row_end is None else row_end, want_stats=True)
+    lm.close()
+    if gb is not None:
+        gb.close()
+    if sdf is not None:
+        sdf.close()
+    return got, want, stats, ostats
+
+
+@pytest.mark.parametrize("sfmt", [abi.SDF_UNORM16, abi.SDF_FP16])
+def test_ground_plane_render_matches_oracle(ctx, oracle, sfmt):
+    layout, atlas, dfu, lights, w, h = small_scene(sfmt)
+    env = scenes.environment()
+    got, want, stats, ostats = render_both(ctx, oracle, lights, env, dfu, None, 0, atlas, sfmt, (0.05, 0.06, 0.07, 1.0), w, h)
+    # sample counts are integers: the trace visited exactly the same steps
+    assert (stats.SdfSamples, stats.PixelLightPairs, stats.TracedPairs) == (ostats.SdfSamples, ostats.PixelLightPairs, ostats.TracedPairs)
+    assert stats.SdfSamples > 10 * w * h
+    assert_close(got, want, "lightmap")
+    # the scene must contain both lit and shadowed pixels
+    assert (want[..., 3] > 1.5).mean() > 0.5
+
+
+def test_gbuffer_render_matches_oracle(ctx, oracle):
+    layout, atlas, dfu, lights, w, h = small_scene()
+    # a G-buffer with a tilted bump, raised ground, an unshadowed band and a fullbright band
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    nx = 0.3 * np.sin(xx / 9.0); ny = 0.3 * np.cos(yy / 7.0)
+    nz = np.sqrt(np.maximum(1.0 - nx * nx - ny * ny, 0.0))
+    normal = np.stack([nx, ny, nz], axis=-1)
+    z = 6.0 + 5.0 * np.sin(xx / 17.0) * np.cos(yy / 13.0)
+    g = scenes.encode_gbuffer(normal, 0.0, z)
+    g[10:20] = scenes.encode_gbuffer(normal[10:20], 0.0, z[10:20], enable_shadows=False)
+    g[30:34] = scenes.encode_gbuffer(normal[30:34], 0.0, z[30:34], fullbright=True)
+    g[40:44, :, :2] = 0.0   # zero normal: directional occlusion disabled
+    # lights with AO, specular, both falloff modes and a shadow filter
+    for i in range(len(lights)):
+        lights[i].MoreLightProperties.x = 12.0 if i % 2 else 0.0
+        lights[i].MoreLightProperties.w = 0.6
+        lights[i].Color2 = abi.f4(0.3, 0.2, 0.1, 8.0) if i % 3 == 0 else abi.f4(0, 0, 0, 1)
+        lights[i].LightProperties.z = float(i % 3)
+        lights[i].EvenMoreLightProperties.x = float((i % 4) - 1)
+    env = scenes.environment(gbuffer_size=(w, h), light_occlusion=40.0)
+    for gfmt, garr in ((abi.GBUFFER_FLOAT4, g), (abi.GBUFFER_HALF4, g.astype(np.float16).view(np.uint16))):
+        got, want, stats, ostats = render_both(ctx, oracle, lights, env, dfu, garr, gfmt, atlas, abi.SDF_UNORM16,
+                                               (0.0, 0.0, 0.0, 0.0), w, h)
+        assert (stats.SdfSamples, stats.PixelLightPairs, stats.TracedPairs) == (ostats.SdfSamples, ostats.PixelLightPairs, ostats.TracedPairs)
+        assert_close(got, want, "lightmap gbuffer fmt %d" % gfmt)
+        assert not got[30:34].any()            # fullbright pixels are discarded for every light
+
+
+def test_no_distance_field_and_25d_footprint(ctx, oracle):
+    w, h = 96, 80
+    lights = scenes.random_lights(9, 5, w, h, z=(4.0, 20.0), radius=6.0, ramp=(20.0, 40.0), falloff_y=0.5, have_distance_field=False)
+    env = scenes.environment(z_to_y=1.5)
+    dfu = abi.DistanceFieldUniforms()
+    dfu.StepAndMisc2 = abi.f4(64, 3, 1, 1)
+    got, want, stats, ostats = render_both(ctx, oracle, lights, env, dfu, None, 0, None, 0, (0.1, 0.1, 0.1, 1.0), w, h)
+    assert stats.SdfSamples == 0 == ostats.SdfSamples
+    assert stats.PixelLightPairs == ostats.PixelLightPairs
+    assert_close(got, want, "lightmap without distance field")
+    # FalloffYFactor < 1 makes the lit ellipse taller than the raster quad: the footprint clips it
+    assert (want[..., 3] == 1.0).any() and (want[..., 3] > 1.0).any()
+
+
+def test_light_at_pixel_without_field_is_fully_lit(ctx, oracle):
+    """KAT 5 of SURVEY 8c: inside the light radius opacity is 1 (LightCommon.fxh:208-209)."""
+    w = h = 32
+    lights = (abi.LightVertex * 1)(scenes.sphere_light((16.0, 16.0, 0.0), 8.0, 4.0, color=(0.25, 0.5, 1.0, 0.5),
+                                                       have_distance_field=False))
+    env = scenes.environment()
+    dfu = abi.DistanceFieldUniforms()
+    got, want, _, _ = render_both(ctx, oracle, lights, env, dfu, None, 0, None, 0, (0, 0, 0, 0), w, h)
+    assert np.allclose(got[16, 16], (0.125, 0.25, 0.5, 1.0), rtol=0, atol=1e-7)
+    assert_close(got, want, "single light")
+
+
+def test_strips_and_output_formats(ctx, oracle):
+    layout, atlas, dfu, lights, w, h = small_scene(n_lights=6)
+    env = scenes.environment()
+    amb = (0.02, 0.02, 0.02, 1.0)
+    sdf = native.DistanceFieldTexture(ctx, atlas)
+    full = native.Lightmap(ctx, w, h, abi.LIGHTMAP_FLOAT4)
+    native.render_sphere_lights(ctx, lights, env, dfu, None, sdf, amb, full)
+    ref = full.download()
+    # row strips (the multi-GPU screen split) tile the frame exactly
+    strips = native.Lightmap(ctx, w, h, abi.LIGHTMAP_FLOAT4)
+    for (a, b) in ((0, 37), (37, 64), (64, h)):
+        native.render_sphere_lights(ctx, lights, env, dfu, None, sdf, amb, strips, a, b)
+    assert np.array_equal(strips.download(), ref)
+    half = native.Lightmap(ctx, w, h, abi.LIGHTMAP_HALF4)
+    native.render_sphere_lights(ctx, lights, env, dfu, None, sdf, amb, half)
+    assert np.array_equal(half.download(), ref.astype(np.float16))
+    rgba = native.Lightmap(ctx, w, h, abi.LIGHTMAP_RGBA8)
+    native.render_sphere_lights(ctx, lights, env, dfu, None, sdf, amb, rgba)
+    assert np.array_equal(rgba.download(), np.rint(np.clip(ref, 0, 1) * 255.0).astype(np.uint8))
+    # zero lights: the ambient clear (LightingRenderer.cs:1013-1024)
+    native.render_sphere_lights(ctx, None, env, dfu, None, sdf, amb, full)
+    assert np.array_equal(full.download(), np.broadcast_to(np.asarray(amb, np.float32), (h, w, 4)))
+    for x in (full, strips, half, rgba, sdf):
+        x.close()
+
+
+def test_many_lights_exceed_one_tile_list(ctx, oracle):
+    """More lights than the LDS tile list holds (1024) are processed in batches, in light order."""
+    w, h = 48, 32
+    n = 1300
+    lights = scenes.random_lights(21, n, w, h, z=(4.0, 12.0), radius=2.0, ramp=(6.0, 14.0), have_distance_field=False)
+    env = scenes.environment()
+    dfu = abi.DistanceFieldUniforms()
+    got, want, stats, ostats = render_both(ctx, oracle, lights, env, dfu, None, 0, None, 0, (0, 0, 0, 0), w, h)
+    assert stats.PixelLightPairs == ostats.PixelLightPairs
+    assert_close(got, want, "1300 lights")
