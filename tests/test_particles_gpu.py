@@ -300,8 +300,8 @@ def test_fused_step_matches_pass_by_pass_oracle(ctx, oracle, rnd, cs, n_chunks, 
         upload_state(sysm, c, pos, vel, attr)
         chunks.append([pos.copy(), vel.copy(), attr.copy(), np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)])
     for it in range(3):
-        first = 1000 + it * 1093
-        d = build_step(cs, n_chunks, n_chunks - 1, first, first + 1092, with_df=dfu)
+        first = 1000 + it * 901
+        d = build_step(cs, n_chunks, n_chunks - 1, first, first + 900, with_df=dfu)
         sysm.step(d)
         want_counts = oracle.step(chunks, cs, rnd, d, sdf=otex, want_counts=True)
         got_counts = sysm.step_counts()
