@@ -1,0 +1,286 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the two hot paths on MI355X (contract: see the task's bench section).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one ParticleSystem.Update over the whole synthetic particle system (BASELINE.json configs[1]:
+1 M particles in 16 chunks of 256^2, Spawner + Gravity(4 attractors) + Noise + UpdatePositions, fp32).
+`value` = whole-job Mparticle-steps/s with all inputs resident in HBM.  With N > 1 every rank owns the same
+number of chunks (chunks never interact, ParticleSystem.cs:743-745): no data-path collective, weak scaling.
+The second hot path (sphere-light SDF cone trace) is measured after the timed particle region and reported
+in the same JSON line under "lighting" (1080p/64 lights and 4K/256 lights fp16; screen strips + RCCL
+all-gather of the lightmap when N > 1).
+
+The host side is the C++ mirror of the reference's ParticleSystem / LightingRenderer (illuminant_amd/host),
+calling the kernels only through the C ABI of include/illuminant_hip.h.  The CPU oracle is used solely for
+the "cpu_baseline" leg (rank 0, N == 1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+PARTICLE_BYTES_PER_SLOT = 112   # 48 B read (pos+life, vel+cat, attributes) + 64 B written (pos, vel, render colour, render data)
+SDF_SAMPLE_BYTES = 32           # one sampleDistanceFieldEx = 4 bilinear taps x 8 B RGBA16
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--chunks", type=int, default=16, help="uploaded 256^2 chunks per GPU (16 = 1 M particles)")
+    ap.add_argument("--chunk-size", type=int, default=256)
+    ap.add_argument("--light-frames", type=int, default=5)
+    ap.add_argument("--no-lighting", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+# ---- scenes ------------------------------------------------------------------------------------
+
+def build_particle_system(H, ctx, scenes, abi, chunk_size, n_chunks, rank):
+    """cfg2: n_chunks full chunks uploaded through Spawn(initializers) + a Spawner-fed chunk, Gravity x4 + Noise."""
+    rnd = scenes.randomness_table(7)
+    tp = H.ManualTimeProvider()
+    ecfg = H.ParticleEngineConfiguration(chunk_size)
+    ecfg.TimeProvider = tp
+    engine = H.ParticleEngine(ctx, ecfg, rnd)
+    cfg = H.ParticleSystemConfiguration()
+    cfg.Friction = 0.02
+    cfg.MaximumVelocity = 2048.0
+    cfg.LifeDecayPerSecond = 0.01           # nobody dies during the timed steps
+    col = H.ParticleColor()
+    col.OpacityFromLife = 2.5
+    cfg.Color = col
+    ps = H.ParticleSystem(engine, cfg)
+    n = chunk_size * chunk_size * n_chunks
+    pos, vel, attr = scenes.make_particles(1000 + rank, n, pos_lo=(0, 0, 0), pos_hi=(1920, 1080, 32), life=(50.0, 90.0))
+    ps.Spawn(n, pos, vel, attr)
+
+    sp = H.Spawner(11 + rank)
+    sp.MinRate = sp.MaxRate = 65536.0       # 1092 / 1093 slots per 1/60 s step through the RateError carry
+    f = H.Formula3(); f.Constant = [960, 540, 0]; f.RandomScale = [900, 450, 0]; f.Type = H.FormulaType.Spherical
+    sp.Position = f
+    g = H.Formula3(); g.RandomScale = [60, 60, 60]; g.Type = H.FormulaType.Spherical
+    sp.Velocity = g
+    life = H.Formula1(); life.Constant = 50.0; life.RandomScale = 2.7
+    sp.Life = life
+    gr = H.Gravity()
+    gr.MaximumAcceleration = 1024.0
+    atts = []
+    # radii / strengths in the pattern of TestGame Scenes/SimpleParticles.cs:164-180,372-398 at time 0
+    for (p, r, s) in (((400., 300., 0.), 70., 600.), ((1500., 300., 0.), 150., 900.), ((400., 800., 0.), 200., 1200.), ((1500., 800., 0.), 100., 1500.)):
+        a = H.Attractor(); a.Position = list(p); a.Radius = r; a.Strength = s; a.Type = H.AttractorType.Linear
+        atts.append(a)
+    gr.Attractors = atts
+    nz = H.Noise(3 + rank)                   # defaults of Transforms.cs:192-204, Interval 1000 ms
+    for t in (sp, gr, nz):
+        ps.AddTransform(t)
+    return dict(engine=engine, ps=ps, tp=tp, live=n, transforms=(sp, gr, nz), rnd=rnd, init=(pos, vel, attr))
+
+
+def build_lighting(H, ctx, scenes, abi, width, height, n_lights, resolution, world, sdf_fmt, external_ptr=0):
+    env = H.LightingEnvironment()
+    env.Ambient = [0.05, 0.05, 0.05, 1.0]
+    sc = width / 1920.0
+    xs = scenes.uniform(13, (n_lights,), 0, width); ys = scenes.uniform(14, (n_lights,), 0, height)
+    zs = scenes.uniform(15, (n_lights,), 8.0, 64.0); rs = scenes.uniform(16, (n_lights,), 200.0 * sc, 550.0 * sc)
+    cols = scenes.uniform(17, (n_lights, 3), 0.2, 1.0)
+    lights = []
+    for i in range(n_lights):
+        l = H.SphereLightSource()
+        l.Position = [float(xs[i]), float(ys[i]), float(zs[i])]
+        l.Radius = 24.0; l.RampLength = float(rs[i]); l.Color = [float(cols[i, 0]), float(cols[i, 1]), float(cols[i, 2]), 1.0]
+        lights.append(l)
+    env.Lights = lights
+    rc = H.RendererConfiguration(width, height)
+    q = H.RendererQualitySettings()           # the values every demo uses (Scenes/LightProbes.cs:113-118)
+    q.MinStepSize = 1.0; q.LongStepFactor = 0.5; q.MaxStepCount = 64; q.MaxConeRadius = 24.0; q.OcclusionToOpacityPower = 0.7
+    rc.DefaultQuality = q
+    renderer = H.LightingRenderer(ctx, rc, env, external_ptr)
+    field = H.DistanceField(ctx, world, world, 128.0, 32, resolution, 128, sdf_fmt)
+    layout = scenes.DistanceFieldLayout(world, world, 128.0, 32, resolution, 128)
+    assert (layout.atlas_width, layout.atlas_height) == (field.TextureWidth, field.TextureHeight)
+    atlas = scenes.build_sdf_atlas(layout, scenes.random_obstacles(11, 256, (world, world)), fmt=sdf_fmt)
+    field.Load(atlas)
+    renderer.DistanceField = field
+    return dict(renderer=renderer, env=env, field=field, atlas=atlas, layout=layout, width=width, height=height, n_lights=n_lights)
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_gpus = args.gpus
+    dist = None
+    torch = None
+    if world > 1 or os.environ.get("ILM_BENCH_FORCE_DIST"):
+        import torch as _torch
+        import torch.distributed as _dist
+        torch, dist = _torch, _dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from illuminant_amd import abi, native, scenes
+    from illuminant_amd import _host as H
+
+    if native.device_count() <= 0:
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    ctx = H.DeviceContext(local_rank)
+
+    def barrier():
+        ctx.Sync()
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.barrier()
+
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # ---- particles (the timed region of the contract) ------------------------------------------------------------
+    P = build_particle_system(H, ctx, scenes, abi, args.chunk_size, args.chunks, rank)
+    ps, tp = P["ps"], P["tp"]
+    dt = 1.0 / 60.0
+    frame = 0
+    for _ in range(args.warmup):
+        tp.Advance(dt); ps.Update(frame); frame += 1
+    barrier()
+    ctx.TimerStart()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        tp.Advance(dt); ps.Update(frame); frame += 1
+    gpu_ms = ctx.TimerStop()          # HIP events on the context stream around the K steps (also synchronises)
+    barrier()
+    wall = max_over_ranks(time.perf_counter() - t0)
+    live_slots = P["live"]            # slots carrying a live particle through every pass (the uploaded chunks)
+    spawned = sum(c.TotalSpawned for c in ps.Chunks[args.chunks:])
+    total_units = world * live_slots * args.steps
+    value = total_units / wall / 1e6
+    step_ms_gpu = gpu_ms / args.steps
+    achieved_gbs = live_slots * PARTICLE_BYTES_PER_SLOT / (step_ms_gpu * 1e-3) / 1e9
+
+    out = {
+        "metric": "Mparticle-steps/sec + lit Mpixels/sec (4K, 256 point lights) at 1/2/4/8 GPUs",
+        "value": round(value, 2),
+        "unit": "Mparticle-steps/s",
+        "n_gpus": n_gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(wall / args.steps * 1e3, 5),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "cfg2: %d particles/GPU in %d chunks of %d^2, Spawner(65536/s)+Gravity(4 attractors)+Noise+UpdatePositions"
+                               % (live_slots, args.chunks, args.chunk_size),
+                   "particles_per_gpu": live_slots, "spawned_per_gpu_in_run": int(spawned), "parallelism": "chunks sharded, %d rank(s)" % world},
+        "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "ilm::step_kernel (one ParticleSystem.Update = spawn-units launch + main launch)",
+                     "bytes_per_unit": PARTICLE_BYTES_PER_SLOT, "units_per_launch": live_slots,
+                     "launch_ms": round(step_ms_gpu, 5)},
+    }
+
+    # ---- lighting (second hot path; not part of the timed `value`) -------------------------------------------------
+    if not args.no_lighting:
+        lighting = {}
+        for name, (w, h, nl, res, wsize, fmt) in (("cfg3_1080p_64_lights_unorm16", (1920, 1080, 64, 0.25, 2048, abi.SDF_UNORM16)),
+                                                   ("cfg5_4k_256_lights_fp16", (3840, 2160, 256, 0.125, 4096, abi.SDF_FP16))):
+            # screen split into `world` row strips; with RCCL the lightmap lives in a torch tensor so
+            # the strips can be all-gathered in place over xGMI without a copy
+            rows = h // world
+            row_begin, row_end = rank * rows, (rank + 1) * rows if rank < world - 1 else h
+            full = strip = gather_buf = None
+            ext = 0
+            if dist is not None:
+                full = torch.zeros((h, w, 4), dtype=torch.float16, device="cuda")
+                gather_buf = torch.empty((world * rows, w, 4), dtype=torch.float16, device="cuda")
+                strip = full[row_begin:row_begin + rows]
+                ext = full.data_ptr()
+            L = build_lighting(H, ctx, scenes, abi, w, h, nl, res, wsize, fmt, ext)
+            r = L["renderer"]
+            stats = r.RenderLighting(1.0, row_begin, row_end, True)     # instrumented frame: exact SDF sample count
+            r.RenderLighting(1.0, row_begin, row_end, False)
+            barrier()
+            ctx.TimerStart()
+            t0 = time.perf_counter()
+            for _ in range(args.light_frames):
+                r.RenderLighting(1.0, row_begin, row_end, False)
+                if dist is not None:
+                    ctx.Sync()                                   # render stream -> RCCL stream hand-off
+                    dist.all_gather_into_tensor(gather_buf, strip)
+            gms = ctx.TimerStop()
+            barrier()
+            lwall = max_over_ranks(time.perf_counter() - t0)
+            samples = int(stats[0])
+            if dist is not None:
+                t = torch.tensor([samples], dtype=torch.float64, device="cuda")
+                dist.all_reduce(t)
+                samples_total = int(t.item())
+            else:
+                samples_total = samples
+            frame_ms = lwall / args.light_frames * 1e3
+            my_px = (row_end - row_begin) * w
+            alg_bytes = samples * SDF_SAMPLE_BYTES + my_px * 8 + nl * 128   # this rank's launch: SDF samples + ground-plane lightmap write (half4) + light records
+            kern_ms = gms / args.light_frames
+            lighting[name] = {
+                "lit_mpixels_per_s": round(w * h / (frame_ms * 1e-3) / 1e6, 2),
+                "ms_per_frame": round(frame_ms, 4),
+                "sdf_samples_per_frame": samples_total,
+                "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (kern_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                             "kernel": "ilm::sphere_lights_kernel", "bytes_per_unit": SDF_SAMPLE_BYTES,
+                             "units_per_launch": samples, "launch_ms": round(kern_ms, 4)},
+            }
+            del L
+        out["lighting"] = lighting
+        out["lit_mpixels_per_s"] = lighting["cfg5_4k_256_lights_fp16"]["lit_mpixels_per_s"]
+
+    # ---- CPU baseline: the oracle restatement on the host cores (rank 0, N == 1 only) -------------------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as orc
+        import ctypes as C
+        cs, nch = args.chunk_size, args.chunks
+        n = cs * cs
+        pos, vel, attr = P["init"]
+        chunks = []
+        for c in range(nch):
+            sl = slice(c * n, (c + 1) * n)
+            chunks.append([pos[sl].copy(), vel[sl].copy(), attr[sl].copy(), np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)])
+        chunks.append([np.zeros((n, 4), np.float32) for _ in range(5)])
+        d = abi.StepDesc.from_buffer_copy(ps.LastStepBytes())   # the very descriptor the GPU ran last
+        steps_done = 0
+        t0 = time.perf_counter()
+        while True:
+            orc.step(chunks, cs, P["rnd"], d)
+            steps_done += 1
+            el = time.perf_counter() - t0
+            if el > args.cpu_seconds or steps_done >= 200:
+                break
+        out["cpu_baseline"] = {"value": round(live_slots * steps_done / el / 1e6, 2), "unit": "Mparticle-steps/s",
+                               "cores": orc.num_threads(), "kind": "port",
+                               "sample": "%d steps of the same cfg2 system (oracle/ilm_oracle.c, OpenMP, %.1f s)" % (steps_done, el)}
+
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

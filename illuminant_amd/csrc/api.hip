@@ -42,6 +42,9 @@ struct Ctx {
     uint32_t magic = kMagicCtx;
     int device = 0;
     hipStream_t stream = nullptr;
+    // Spawn-range launches run on their own stream so their ~12 us single-wave latency overlaps the main launch.
+    hipStream_t spawn_stream = nullptr;
+    hipEvent_t ev_main = nullptr, ev_spawn = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // device staging for AoS <-> SoA conversion
     void* staging = nullptr; size_t staging_bytes = 0;
@@ -87,6 +90,8 @@ struct System {
     Sdf* sdf = nullptr;
     float4* ramp = nullptr; int ramp_w = 0, ramp_h = 0;
     uint32_t* d_slots = nullptr; int slots_cap = 0; uint32_t* d_slot_count = nullptr;
+    // asynchronous readback of the fused live counts
+    uint32_t* h_counts = nullptr; int h_counts_cap = 0; hipEvent_t counts_ev = nullptr; int counts_n = 0; bool counts_pending = false;
 };
 
 template <typename T>
@@ -151,8 +156,8 @@ int32_t refresh_table(System* s) {
     if (n > s->counts_cap) {
         if (s->d_counts) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(s->d_counts)); s->d_counts = nullptr; }
         int cap = n < 64 ? 64 : n * 2;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_counts), sizeof(uint32_t) * (size_t)cap));
-        HIP_TRY(hipMemsetAsync(s->d_counts, 0, sizeof(uint32_t) * (size_t)cap, c->stream));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_counts), sizeof(uint32_t) * (size_t)cap * kCountStride));
+        HIP_TRY(hipMemsetAsync(s->d_counts, 0, sizeof(uint32_t) * (size_t)cap * kCountStride, c->stream));
         s->counts_cap = cap;
     }
     if (s->table_dirty && n > 0) {
@@ -216,7 +221,7 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
     if (rc != ILM_OK) return rc;
     if (count == 0) return ILM_OK;
     if (d->Flags & ILM_STEP_COUNT_LIVE)
-        HIP_TRY(hipMemsetAsync(s->d_counts, 0, sizeof(uint32_t) * (size_t)s->chunks.size(), c->stream));
+        HIP_TRY(hipMemsetAsync(s->d_counts, 0, sizeof(uint32_t) * (size_t)s->chunks.size() * kCountStride, c->stream));
 
     StepLaunch a;
     memcpy(&a.desc, d, sizeof(IlmStepDesc));
@@ -234,7 +239,36 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
     a.sdf.height = s->sdf ? s->sdf->height : 0;
     a.sdf.format = s->sdf ? s->sdf->format : ILM_SDF_UNORM16;
     a.live_counts = s->d_counts;
-    HIP_TRY(launch_step(a, c->stream));
+    const int n_ranges = plan_step(a);
+    if (n_ranges > 0) {
+        // spawn stream: after everything queued so far on the main stream (the previous step's main launch wrote
+        // these slots; the counter memset above), concurrently with this step's main launch
+        HIP_TRY(hipEventRecord(c->ev_main, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->spawn_stream, c->ev_main, 0));
+        for (int k = 0; k < n_ranges; k++)
+            HIP_TRY(launch_step_spawn_range(a, k, c->spawn_stream));
+        HIP_TRY(hipEventRecord(c->ev_spawn, c->spawn_stream));
+    }
+    HIP_TRY(launch_step_main(a, c->stream));
+    if (n_ranges > 0)
+        // whatever follows on the main stream (next step, downloads, counts) sees the spawned slots
+        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_spawn, 0));
+    if (d->Flags & ILM_STEP_COUNT_LIVE) {
+        // queue the readback behind the kernel; ilm_system_poll_counts / ilm_system_step_counts pick it up
+        const int n = (int)s->chunks.size();
+        if (n > s->h_counts_cap) {
+            if (s->h_counts) HIP_TRY(hipHostFree(s->h_counts));
+            s->h_counts = nullptr;
+            int cap = n < 64 ? 64 : n * 2;
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_counts), sizeof(uint32_t) * (size_t)cap * kCountStride, hipHostMallocDefault));
+            s->h_counts_cap = cap;
+        }
+        if (!s->counts_ev) HIP_TRY(hipEventCreateWithFlags(&s->counts_ev, hipEventDisableTiming));
+        HIP_TRY(hipMemcpyAsync(s->h_counts, s->d_counts, sizeof(uint32_t) * (size_t)n * kCountStride, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipEventRecord(s->counts_ev, c->stream));
+        s->counts_n = n;
+        s->counts_pending = true;
+    }
     return ILM_OK;
 }
 
@@ -244,11 +278,13 @@ int32_t copy_counts(System* s, uint32_t* out, int32_t capacity, int32_t saturate
     if (capacity < n)
         return fail(ILM_ERR_OUT_OF_RANGE, "capacity %d < chunk count %d", capacity, n);
     if (n == 0) return ILM_OK;
-    HIP_TRY(hipMemcpyAsync(out, s->d_counts, sizeof(uint32_t) * (size_t)n, hipMemcpyDeviceToHost, c->stream));
+    std::vector<uint32_t> tmp((size_t)n * kCountStride);
+    HIP_TRY(hipMemcpyAsync(tmp.data(), s->d_counts, sizeof(uint32_t) * tmp.size(), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (saturate16)
-        for (int i = 0; i < n; i++)
-            if (out[i] > 65535u) out[i] = 65535u;   // 16-bit additive target, CountLiveParticles.fx:38 + ParticleEngine.cs:244-247
+    for (int i = 0; i < n; i++) {
+        const uint32_t v = tmp[(size_t)i * kCountStride];
+        out[i] = (saturate16 && v > 65535u) ? 65535u : v;   // 16-bit additive target, CountLiveParticles.fx:38 + ParticleEngine.cs:244-247
+    }
     return ILM_OK;
 }
 
@@ -283,6 +319,9 @@ int32_t ilm_ctx_create(int32_t device_id, IlmHandle* out_ctx) {
     if (!c) return fail(ILM_ERR_INVALID_ARGUMENT, "out of host memory");
     c->device = device_id;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->spawn_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_spawn, hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&c->t0));
     HIP_TRY(hipEventCreate(&c->t1));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_stats), 3 * sizeof(unsigned long long)));
@@ -305,6 +344,10 @@ int32_t ilm_ctx_destroy(IlmHandle h) {
     if (c->d_stats) (void)hipFree(c->d_stats);
     (void)hipEventDestroy(c->t0);
     (void)hipEventDestroy(c->t1);
+    (void)hipEventDestroy(c->ev_main);
+    (void)hipEventDestroy(c->ev_spawn);
+    (void)hipStreamSynchronize(c->spawn_stream);
+    (void)hipStreamDestroy(c->spawn_stream);
     (void)hipStreamDestroy(c->stream);
     c->magic = 0;
     delete c;
@@ -400,6 +443,8 @@ int32_t ilm_system_destroy(IlmHandle h) {
     if (s->ramp) (void)hipFree(s->ramp);
     if (s->d_slots) (void)hipFree(s->d_slots);
     if (s->d_slot_count) (void)hipFree(s->d_slot_count);
+    if (s->h_counts) (void)hipHostFree(s->h_counts);
+    if (s->counts_ev) (void)hipEventDestroy(s->counts_ev);
     s->magic = 0;
     delete s;
     return ILM_OK;
@@ -611,7 +656,7 @@ int32_t ilm_system_live_counts(IlmHandle h, uint32_t* out_counts, int32_t capaci
     if (rc != ILM_OK) return rc;
     const int n = (int)s->chunks.size();
     if (n > 0) {
-        HIP_TRY(hipMemsetAsync(s->d_counts, 0, sizeof(uint32_t) * (size_t)n, c->stream));
+        HIP_TRY(hipMemsetAsync(s->d_counts, 0, sizeof(uint32_t) * (size_t)n * kCountStride, c->stream));
         HIP_TRY(launch_count_live(s->d_table, s->engine->stride, n, s->d_counts, c->stream));
     }
     return copy_counts(s, out_counts, capacity, saturate16);
@@ -625,6 +670,26 @@ int32_t ilm_system_step_counts(IlmHandle h, uint32_t* out_counts, int32_t capaci
     if (s->d_counts == nullptr && !s->chunks.empty())
         return fail(ILM_ERR_STATE, "no step with ILM_STEP_COUNT_LIVE has run");
     return copy_counts(s, out_counts, capacity, saturate16);
+}
+
+int32_t ilm_system_poll_counts(IlmHandle h, uint32_t* out_counts, int32_t capacity, int32_t saturate16, int32_t* out_ready) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (!out_counts || !out_ready) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out_ready = 0;
+    if (!s->counts_pending) return fail(ILM_ERR_STATE, "no step with ILM_STEP_COUNT_LIVE is outstanding");
+    HIP_TRY(hipSetDevice(s->engine->ctx->device));
+    hipError_t q = hipEventQuery(s->counts_ev);
+    if (q == hipErrorNotReady) { (void)hipGetLastError(); return ILM_OK; }
+    if (q != hipSuccess) return fail((int32_t)q, "hipEventQuery failed: %s", hipGetErrorString(q));
+    if (capacity < s->counts_n) return fail(ILM_ERR_OUT_OF_RANGE, "capacity %d < %d", capacity, s->counts_n);
+    for (int i = 0; i < s->counts_n; i++) {
+        uint32_t v = s->h_counts[i * kCountStride];
+        out_counts[i] = (saturate16 && v > 65535u) ? 65535u : v;
+    }
+    s->counts_pending = false;
+    *out_ready = 1;
+    return ILM_OK;
 }
 
 int32_t ilm_chunk_live_slots(IlmHandle h, int32_t chunk, uint32_t* out_slots, int32_t capacity, int32_t* out_count) {

@@ -23,6 +23,12 @@ struct f3 { float x, y, z; };
 
 ILM_DEV float sat(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 ILM_DEV float lerp(float a, float b, float t) { return a + (b - a) * t; }
+// lerp with the multiply and the add rounded separately even when the translation unit allows FMA
+// contraction: used where the result is a life value (liveness must be bit-exact)
+ILM_DEV float lerp_exact(float a, float b, float t) {
+#pragma clang fp contract(off)
+    return a + (b - a) * t;
+}
 ILM_DEV float sgn(float x) { return (x > 0.0f) ? 1.0f : ((x < 0.0f) ? -1.0f : 0.0f); }
 ILM_DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 
@@ -45,6 +51,32 @@ ILM_DEV float4 mul4(float4 a, float4 b) { return mk4(a.x * b.x, a.y * b.y, a.z *
 ILM_DEV float4 lerp4(float4 a, float4 b, float t) { return mk4(lerp(a.x, b.x, t), lerp(a.y, b.y, t), lerp(a.z, b.z, t), lerp(a.w, b.w, t)); }
 ILM_DEV float4 ld4(const IlmFloat4& v) { return mk4(v.x, v.y, v.z, v.w); }
 ILM_DEV f3 xyz(float4 a) { return mk3(a.x, a.y, a.z); }
+
+// Approximate (about 1 ulp) reciprocal / rsqrt / sqrt: single VALU instructions.  Used only where
+// the result feeds neither a table index, a slot index nor a life value (see DESIGN.md "numerics");
+// everything index- or liveness-critical uses the IEEE operators above.
+ILM_DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+ILM_DEV float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+ILM_DEV float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+ILM_DEV float len3_fast(f3 a) { return fast_sqrt(dot3(a, a)); }
+ILM_DEV f3 norm3_fast(f3 a) { const float r = fast_rsq(dot3(a, a)); return mk3(a.x * r, a.y * r, a.z * r); }
+
+// positive modulo of an integer-valued float without integer division.  Domain: |t| < 2^23, which the
+// callers guarantee (randomness-table coordinates are bounded by the table offsets a*253, b*127 and the
+// per-index offsets < 65531).  q may be off by one after the reciprocal multiply; the remainder t - q*size is
+// exact in fp32 and is folded back into [0, size), so the result equals the integer modulo bit for bit.
+ILM_DEV int wrap_index_fast(float t, int size) {
+#pragma clang fp contract(off)
+    const float fs = (float)size;
+    const float q = floorf(t * fast_rcp(fs));
+    float r = t - q * fs;
+    r = (r < 0.0f) ? r + fs : r;
+    r = (r >= fs) ? r - fs : r;
+    return (int)r;
+}
+
+// sign(d) * m for m >= 0 (HLSL sign() is 0 at 0)
+ILM_DEV float sign_times(float d, float m) { return (d == 0.0f) ? 0.0f * m : copysignf(m, d); }
 
 // positive modulo of a float tap index (D3D WRAP addressing)
 ILM_DEV int wrap_index(float t, int size) {
@@ -84,6 +116,7 @@ ILM_DEV void sdf_unpack2(uint2 t, int pair, float& a, float& b) {
 
 template <int FORMAT>
 ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms& df, const SdfView& sdf) {
+#pragma clang fp contract(off)
     position.z -= df.ConeAndMisc.y;
     const float ex = df.Extent.x, ey = df.Extent.y, ez = df.Extent.z;
     const float cx = clampf(position.x, 0.0f, ex), cy = clampf(position.y, 0.0f, ey), cz = clampf(position.z, 0.0f, ez);

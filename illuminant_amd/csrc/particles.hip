@@ -25,11 +25,12 @@ ILM_DEV bool category_ok(float type, const float mm[2]) { return (type >= mm[0])
 // randomCustom, RandomCommon.fxh:27-30 (POINT, WRAP)
 ILM_DEV float4 random_custom(const float4* __restrict__ rnd, int rw, int rh, float x, float y,
                              float off_x, float off_y, float rate_x, float rate_y) {
+#pragma clang fp contract(off)   // table indices are bit-exact
     const float texel_x = 1.0f / (float)rw, texel_y = 1.0f / (float)rh;
     const float u = ((x * rate_x) + off_x) * texel_x;
     const float v = ((y * rate_y) + off_y) * texel_y;
-    const int tx = wrap_index(floorf(u * (float)rw), rw);
-    const int ty = wrap_index(floorf(v * (float)rh), rh);
+    const int tx = wrap_index_fast(floorf(u * (float)rw), rw);
+    const int ty = wrap_index_fast(floorf(v * (float)rh), rh);
     return rnd[ty * rw + tx];
 }
 
@@ -107,6 +108,7 @@ ILM_DEV float evaluate_area(int type_id, f3 wp, const IlmAreaParams& a) {
 }
 // computeWeight, FMA.fx:15-20 / Noise.fx:21-26
 ILM_DEV float compute_weight(const IlmAreaParams& a, f3 wp) {
+#pragma clang fp contract(off)
     const float distance = evaluate_area(a.AreaType, wp, a);
     return (1.0f - sat(distance / a.AreaFalloff)) * a.Strength;
 }
@@ -127,36 +129,43 @@ ILM_DEV void apply_gravity(float4& pos, float4& vel, const IlmParticleSystemUnif
         const float type = p.AttractorRadiusesAndStrengths[i][2];
         const f3 to_center = apos - xyz(pos);
         float attraction;
+        // velocities only: approximate rcp / rsq (no index or life value depends on them)
+        const float d2 = dot3(to_center, to_center);
+        const float inv_len = fast_rsq(d2);
         if (type >= 0.5f) {
-            const float distance = len3(to_center);
-            attraction = 1.0f - sat(distance / radius);
+            const float distance = d2 * inv_len;
+            attraction = 1.0f - sat(distance * fast_rcp(radius));
             if (type >= 1.5f)
                 attraction *= attraction;
-            attraction = attraction * dt_ms / kVelocityConstantScale;
+            attraction = attraction * dt_ms * (1.0f / kVelocityConstantScale);
         } else {
-            float distance_squared = dot3(to_center, to_center) - radius;
-            distance_squared = fmaxf(distance_squared, 0.001f);
-            attraction = 1.0f / distance_squared;
+            const float distance_squared = fmaxf(d2 - radius, 0.001f);
+            attraction = fast_rcp(distance_squared);
         }
-        acceleration = acceleration + ((norm3(to_center) * attraction) * strength);
+        acceleration = acceleration + (((to_center * inv_len) * attraction) * strength);
     }
     const float maximum_acceleration = p.MaximumAcceleration * dt_ms / kVelocityConstantScale;
-    const float current_length = len3(acceleration);
-    if (current_length > maximum_acceleration)
-        acceleration = norm3(acceleration) * maximum_acceleration;
+    const float a2 = dot3(acceleration, acceleration);
+    if (a2 > maximum_acceleration * maximum_acceleration)
+        acceleration = acceleration * (fast_rsq(a2) * maximum_acceleration);
     const float mv = sys.GlobalSettings.z;
     vel.x = fminf(mv, vel.x + acceleration.x);
     vel.y = fminf(mv, vel.y + acceleration.y);
     vel.z = fminf(mv, vel.z + acceleration.z);
 }
 
+ILM_DEV float fma_term_exact(float v, float m, float a) {
+#pragma clang fp contract(off)
+    return (v * m) + a;
+}
 // PS_FMA, FMA.fx:22-51
 ILM_DEV void apply_fma(float4& pos, float4& vel, const IlmParticleSystemUniforms& sys, const IlmFMAParams& p) {
     if ((pos.w <= 0.0f) || !category_ok(vel.w, p.Area.CategoryFilter))
         return;
     const float weight = compute_weight(p.Area, xyz(pos));
     const float t = weight * sys.GlobalSettings.x / p.TimeDivisor;
-    const float4 np = lerp4(pos, add4(mul4(pos, ld4(p.PositionMultiply)), ld4(p.PositionAdd)), t);
+    float4 np = lerp4(pos, add4(mul4(pos, ld4(p.PositionMultiply)), ld4(p.PositionAdd)), t);
+    np.w = lerp_exact(pos.w, fma_term_exact(pos.w, p.PositionMultiply.w, p.PositionAdd.w), t);   // life
     const float4 nv = lerp4(vel, add4(mul4(vel, ld4(p.VelocityMultiply)), ld4(p.VelocityAdd)), t);
     pos = np;
     vel = nv;
@@ -164,8 +173,8 @@ ILM_DEV void apply_fma(float4& pos, float4& vel, const IlmParticleSystemUniforms
 
 ILM_DEV float4 noise_shape(float4 r, const IlmFloat4& offset, const IlmFloat4& minimum, const IlmFloat4& scale) {
     const float4 d = add4(r, ld4(offset));
-    return mk4(sgn(d.x) * fmaxf(fabsf(d.x), minimum.x) * scale.x, sgn(d.y) * fmaxf(fabsf(d.y), minimum.y) * scale.y,
-               sgn(d.z) * fmaxf(fabsf(d.z), minimum.z) * scale.z, sgn(d.w) * fmaxf(fabsf(d.w), minimum.w) * scale.w);
+    return mk4(sign_times(d.x, fmaxf(fabsf(d.x), minimum.x)) * scale.x, sign_times(d.y, fmaxf(fabsf(d.y), minimum.y)) * scale.y,
+               sign_times(d.z, fmaxf(fabsf(d.z), minimum.z)) * scale.z, sign_times(d.w, fmaxf(fabsf(d.w), minimum.w)) * scale.w);
 }
 
 // PS_Noise, Noise.fx:28-72 (no life check: dead slots go through the math, :40)
@@ -185,13 +194,14 @@ ILM_DEV void apply_noise(float4& pos, float4& vel, float x, float y, const float
     const float4 position_delta = noise_shape(lerp4(p1, p2, p.FrequencyLerp), p.PositionOffset, p.PositionMinimum, p.PositionScale);
     const float4 velocity_delta = noise_shape(lerp4(v1, v2, p.FrequencyLerp), p.VelocityOffset, p.VelocityMinimum, p.VelocityScale);
 
-    const float4 np = lerp4(pos, add4(pos, position_delta), t);
+    float4 np = lerp4(pos, add4(pos, position_delta), t);
+    np.w = lerp_exact(pos.w, pos.w + position_delta.w, t);   // life
     f3 nv;
     if (p.ReplaceOldVelocity != 0.0f)
         nv = mk3(lerp(vel.x, velocity_delta.x, weight), lerp(vel.y, velocity_delta.y, weight), lerp(vel.z, velocity_delta.z, weight));
     else
         nv = mk3(lerp(vel.x, vel.x + velocity_delta.x, t), lerp(vel.y, vel.y + velocity_delta.y, t), lerp(vel.z, vel.z + velocity_delta.z, t));
-    nv = nv + (norm3(xyz(vel)) * velocity_delta.w);
+    nv = nv + (norm3_fast(xyz(vel)) * velocity_delta.w);
     pos = np;
     vel = mk4(nv.x, nv.y, nv.z, vel.w);
 }
@@ -375,8 +385,10 @@ ILM_DEV float4 bezier4(const IlmClampedBezier4& bz, float value) {
 
 // applyFrictionAndMaximum, UpdateCommon.fxh:20-35
 ILM_DEV f3 friction_and_maximum(f3 velocity, const IlmParticleSystemUniforms& sys) {
-    float l = len3(velocity);
-    if (l <= 0.001f)
+    const float l2 = dot3(velocity, velocity);
+    const float inv_l = fast_rsq(l2);
+    float l = l2 * inv_l;
+    if (!(l > 0.001f))
         return mk3(0.0f, 0.0f, 0.0f);
     const float mv = sys.GlobalSettings.z;
     if (l > mv)
@@ -384,7 +396,7 @@ ILM_DEV f3 friction_and_maximum(f3 velocity, const IlmParticleSystemUniforms& sy
     const float friction = l * sys.GlobalSettings.y;
     l -= (friction * dt_seconds(sys));
     l = clampf(l, 0.0f, mv);
-    return norm3(velocity) * l;
+    return velocity * (inv_l * l);
 }
 
 // computeRenderData, UpdateCommon.fxh:96-117
@@ -397,7 +409,7 @@ ILM_DEV void render_data(float vx, float vy, float4 position, float4 velocity, f
         return;
     }
     const float index = vx + (vy * 256.0f);  // reference quirk: 256 regardless of ChunkSize (:107)
-    const float velocity_length = fmaxf(len3(xyz(velocity)), 0.0001f);
+    const float velocity_length = fmaxf(len3_fast(xyz(velocity)), 0.0001f);
 
     float4 color = mul4(bezier4(p.ColorFromLife, position.w), bezier4(p.ColorFromVelocity, velocity_length));
     if (p.LifeRampSettings.x != 0.0f) {
@@ -421,7 +433,8 @@ ILM_DEV void render_data(float vx, float vy, float4 position, float4 velocity, f
 
     // getRotationForVelocity, UpdateCommon.fxh:81-94
     float rotation = 0.0f;
-    if (!((fabsf(velocity.x) < 0.01f) && (fabsf(velocity.y) < 0.01f))) {
+    // the angle is multiplied by getVelocityRotation(): skipping atan2 when that is 0 is exact
+    if ((sys.AnimationRateAndRotationAndZToY.z != 0.0f) && !((fabsf(velocity.x) < 0.01f) && (fabsf(velocity.y) < 0.01f))) {
         rotation = atan2f(velocity.y, velocity.x);
         if (rotation < 0.0f)
             rotation += 2.0f * kPi;
@@ -435,6 +448,7 @@ ILM_DEV void render_data(float vx, float vy, float4 position, float4 velocity, f
 
 // PS_Update, UpdateParticleSystem.fx:9-38 (live slot)
 ILM_DEV void update_positions(float4& pos, float4& vel, const IlmParticleSystemUniforms& sys) {
+#pragma clang fp contract(off)   // life arithmetic is bit-exact
     const f3 velocity = friction_and_maximum(xyz(vel), sys);
     const float dts = dt_seconds(sys);
     const float new_life = pos.w - (sys.GlobalSettings.w * dts);
@@ -449,6 +463,7 @@ ILM_DEV void update_positions(float4& pos, float4& vel, const IlmParticleSystemU
 // estimateNormal4, VisualizeCommon.fxh:44-63
 template <int FMT>
 ILM_DEV f3 estimate_normal4(f3 position, const IlmDistanceFieldUniforms& df, const SdfView& sdf) {
+#pragma clang fp contract(off)
     const f3 texel = mk3(df.ConeAndMisc.w, df.StepAndMisc2.w, df.Extent.z / fmaxf(df.TextureSliceCount.w, 1.0f));
     f3 result = mk3(0.0f, 0.0f, 0.0f);
     const float W[4][3] = { { 1, -1, -1 }, { -1, -1, 1 }, { -1, 1, -1 }, { 1, 1, 1 } };
@@ -465,6 +480,7 @@ ILM_DEV f3 estimate_normal4(f3 position, const IlmDistanceFieldUniforms& df, con
 template <int FMT>
 ILM_DEV void update_with_distance_field(float4& pos, float4& vel, float x, float y, const IlmParticleSystemUniforms& sys,
                                         const IlmDistanceFieldUniforms& df, const SdfView& sdf) {
+#pragma clang fp contract(off)   // discontinuous collision state machine + life arithmetic: keep IEEE-exact
     const float4 zero = mk4(0.0f, 0.0f, 0.0f, 0.0f);
     const float dts = dt_seconds(sys);
     float new_life = pos.w - (sys.GlobalSettings.w * dts);
@@ -558,200 +574,247 @@ ILM_DEV void update_with_distance_field(float4& pos, float4& vel, float x, float
 // ---------------------------------------------------------------------------------------------
 // the fused step kernel
 // ---------------------------------------------------------------------------------------------
-// SPT = slots per thread.  A thread owns SPT consecutive slots, so each component
-// plane is accessed with one SPT*4-byte load/store per thread (a wave covers
-// SPT*256 contiguous bytes per instruction).  All SPT values give fully coalesced
-// traffic; they trade bytes in flight per thread against register pressure.
-template <int SPT> struct VecIO;
-template <> struct VecIO<1> {
-    static ILM_DEV void load(const float* p, float (&v)[1]) { v[0] = *p; }
-    static ILM_DEV void store(float* p, const float (&v)[1]) { *p = v[0]; }
-};
-template <> struct VecIO<2> {
-    static ILM_DEV void load(const float* p, float (&v)[2]) { const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y; }
-    static ILM_DEV void store(float* p, const float (&v)[2]) { *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]); }
-};
-template <> struct VecIO<4> {
-    static ILM_DEV void load(const float* p, float (&v)[4]) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
-    static ILM_DEV void store(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+// Persistent, software-pipelined: every wave walks units of 64 consecutive slots (u, u + W, u + 2W, ...);
+// the 12 input loads of the next unit are issued before the current unit is computed, so HBM loads stay
+// in flight during the arithmetic (the chunk base pointers are cast to the global address space so the
+// compiler can use counted vmcnt waits instead of the flat-address vmcnt(0)).  One lane = one slot:
+// a wave reads/writes 256 contiguous bytes of each component plane per instruction.
+typedef float __attribute__((address_space(1))) gfloat;
+
+struct SlotIn {
+    float px, py, pz, life, vx, vy, vz, ct, ar, ag, ab, aa;
 };
 
-template <int FMT, int SPT>
-__global__ __launch_bounds__(kStepThreads) void step_kernel(const StepLaunch a) {
+template <bool ATTR>
+ILM_DEV SlotIn load_slot(const gfloat* base, int64_t S, int i) {
+    SlotIn s;
+    s.life = base[3 * S + i];
+    s.px = base[0 * S + i]; s.py = base[1 * S + i]; s.pz = base[2 * S + i];
+    s.vx = base[4 * S + i]; s.vy = base[5 * S + i]; s.vz = base[6 * S + i]; s.ct = base[7 * S + i];
+    if (ATTR) {
+        s.ar = base[8 * S + i]; s.ag = base[9 * S + i]; s.ab = base[10 * S + i]; s.aa = base[11 * S + i];
+    } else {
+        s.ar = s.ag = s.ab = s.aa = 0.0f;
+    }
+    return s;
+}
+
+// The launch descriptor lives in the kernarg segment (constant address space) and the per-unit body reads
+// every parameter through a pointer to it (s_load from a uniform address).  The persistent loop launders
+// that pointer through an empty asm each iteration: otherwise LICM hoists all ~150 scalar parameters out
+// of the loop, overflows the 102 SGPRs and spills them into VGPR lanes and scratch.
+typedef const StepLaunch __attribute__((address_space(4))) CStepLaunch;
+
+// DF: the update pass is UpdateWithDistanceField (pulls in the SDF sampler); SPAWN: spawn records present.
+// Both are compile-time so the common no-field / no-spawn step does not pay their registers.
+template <int FMT, bool DF, bool SPAWN>
+ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* base, int chunk, int i, int lane, int seg, SlotIn cur) {
+    const StepLaunch& a = *(const StepLaunch*)ap;
     const IlmStepDesc& d = a.desc;
-    const int chunk = a.first_chunk + (int)blockIdx.y;
-    float* __restrict__ base = a.chunk_bases[chunk];
     const int64_t S = a.stride;
-    const int i0 = ((int)blockIdx.x * kStepThreads + (int)threadIdx.x) * SPT;
     const int mode = d.UpdateMode;
+    const bool need_attr = (mode == ILM_UPDATE_POSITIONS) || (mode == ILM_UPDATE_WITH_DISTANCE_FIELD);
+    const bool has_noise = (a.op_mask & (1u << ILM_OP_NOISE)) != 0u;
     const float4 zero = mk4(0.0f, 0.0f, 0.0f, 0.0f);
-    float zeros[SPT];
-#pragma unroll
-    for (int j = 0; j < SPT; j++) zeros[j] = 0.0f;
 
-    float life[SPT];
-    VecIO<SPT>::load(base + 3 * S + i0, life);
-    bool any_live = false;
-#pragma unroll
-    for (int j = 0; j < SPT; j++) any_live = any_live || (life[j] > 0.0f);
-
-    // does a spawn record target one of this thread's slots?
     bool spawn_here = false;
-    for (int s = 0; s < d.SpawnCount; s++) {
-        const IlmSpawnRecord& r = d.Spawns[s];
-        if (r.ChunkIndex == chunk) {
-            const float first = r.Params.ChunkSizeAndIndices[1], last = r.Params.ChunkSizeAndIndices[2];
-            if (((float)(i0 + SPT - 1) >= first) && ((float)i0 <= last))
+    if constexpr (SPAWN) {
+        for (int s = 0; s < d.SpawnCount; s++) {
+            const IlmSpawnRecord& r = d.Spawns[s];
+            if (r.ChunkIndex == chunk && (float)i >= r.Params.ChunkSizeAndIndices[1] && (float)i <= r.Params.ChunkSizeAndIndices[2])
                 spawn_here = true;
         }
     }
-    const bool has_noise = (a.op_mask & (1u << ILM_OP_NOISE)) != 0u;
-    const bool need_attr = (mode == ILM_UPDATE_POSITIONS) || (mode == ILM_UPDATE_WITH_DISTANCE_FIELD);
-    const bool full = (mode != ILM_UPDATE_ERASE) && (any_live || spawn_here || has_noise);
-
-    uint32_t live_after = 0;  // bit j: slot j alive after the step
-
+    bool live_after = false;
     if (mode == ILM_UPDATE_ERASE) {
         // PS_Erase, UpdateParticleSystem.fx:40-49
 #pragma unroll
-        for (int c = 0; c < 8; c++) VecIO<SPT>::store(base + c * S + i0, zeros);
+        for (int c = 0; c < 8; c++) base[c * S + i] = 0.0f;
 #pragma unroll
-        for (int c = 12; c < 20; c++) VecIO<SPT>::store(base + c * S + i0, zeros);
-    } else if (!full) {
-        // every slot dead and nothing writes it: the update pass leaves the cleared target
+        for (int c = 12; c < 20; c++) base[c * S + i] = 0.0f;
+    } else if (!((cur.life > 0.0f) || spawn_here || has_noise)) {
+        // dead and nothing writes it: the update pass leaves the cleared target
         // (UpdateHandler._BeforeDraw clears, ParticleTransform.cs:164-165; readStateOrDiscard discards)
         if (mode != ILM_UPDATE_NONE) {
 #pragma unroll
-            for (int c = 0; c < 8; c++) VecIO<SPT>::store(base + c * S + i0, zeros);
+            for (int c = 0; c < 8; c++) base[c * S + i] = 0.0f;
 #pragma unroll
-            for (int c = 12; c < 20; c++) VecIO<SPT>::store(base + c * S + i0, zeros);
+            for (int c = 12; c < 20; c++) base[c * S + i] = 0.0f;
+        } else {
+            live_after = cur.life > 0.0f;   // untouched slots keep their liveness when no update pass ran
         }
     } else {
-        float px[SPT], py[SPT], pz[SPT], vx[SPT], vy[SPT], vz[SPT], ct[SPT];
-        float ar[SPT], ag[SPT], ab[SPT], aa[SPT];
-        float cr[SPT], cg[SPT], cb[SPT], ca[SPT], dx[SPT], dy[SPT], dz[SPT], dw[SPT];
-        VecIO<SPT>::load(base + 0 * S + i0, px); VecIO<SPT>::load(base + 1 * S + i0, py); VecIO<SPT>::load(base + 2 * S + i0, pz);
-        VecIO<SPT>::load(base + 4 * S + i0, vx); VecIO<SPT>::load(base + 5 * S + i0, vy); VecIO<SPT>::load(base + 6 * S + i0, vz);
-        VecIO<SPT>::load(base + 7 * S + i0, ct);
-        if (need_attr || spawn_here) {
-            VecIO<SPT>::load(base + 8 * S + i0, ar); VecIO<SPT>::load(base + 9 * S + i0, ag);
-            VecIO<SPT>::load(base + 10 * S + i0, ab); VecIO<SPT>::load(base + 11 * S + i0, aa);
-        } else {
-#pragma unroll
-            for (int j = 0; j < SPT; j++) ar[j] = ag[j] = ab[j] = aa[j] = 0.0f;
-        }
-        bool spawned_any = false;
+        float4 pos = mk4(cur.px, cur.py, cur.pz, cur.life);
+        float4 vel = mk4(cur.vx, cur.vy, cur.vz, cur.ct);
+        float4 attr = mk4(cur.ar, cur.ag, cur.ab, cur.aa);
+        // slot (x, y): the unit's first slot is divided on the scalar unit, lanes only fold the row wrap
+        const int cs = a.chunk_size;
+        const int row0 = __builtin_amdgcn_readfirstlane((seg * 64) / cs);
+        int sy = row0, sx = (seg * 64 - row0 * cs) + lane;
+        while (sx >= cs) { sx -= cs; sy++; }
+        const float fx = (float)sx, fy = (float)sy;
+        bool spawned = false;
 
-        int sx = i0 % a.chunk_size, sy = i0 / a.chunk_size;
-#pragma unroll
-        for (int j = 0; j < SPT; j++) {
-            float4 pos = mk4(px[j], py[j], pz[j], life[j]);
-            float4 vel = mk4(vx[j], vy[j], vz[j], ct[j]);
-            float4 attr = mk4(ar[j], ag[j], ab[j], aa[j]);
-            const float fx = (float)sx, fy = (float)sy;
-
+        if constexpr (SPAWN) {
             if (spawn_here) {
                 for (int s = 0; s < d.SpawnCount; s++) {
                     if (d.Spawns[s].ChunkIndex == chunk) {
                         if (spawn_slot(pos, vel, attr, fx, fy, a.rnd, a.rw, a.rh, d.Spawns[s].Params))
-                            spawned_any = true;
+                            spawned = true;
                     }
                 }
             }
-
-            for (int o = 0; o < d.OpCount; o++) {
-                const IlmTransformOp& op = d.Ops[o];
-                if (op.Type == ILM_OP_GRAVITY)
-                    apply_gravity(pos, vel, d.System, op.u.Gravity);
-                else if (op.Type == ILM_OP_NOISE)
-                    apply_noise(pos, vel, fx, fy, a.rnd, a.rw, a.rh, d.System, op.u.Noise);
-                else if (op.Type == ILM_OP_FMA)
-                    apply_fma(pos, vel, d.System, op.u.FMA);
-            }
-
-            float4 rc = zero, rd = zero;
-            if (need_attr) {
-                if (pos.w <= 0.0f) {
-                    pos = vel = zero;  // readStateOrDiscard: discard => cleared target
-                } else {
-                    if (mode == ILM_UPDATE_WITH_DISTANCE_FIELD)
-                        update_with_distance_field<FMT>(pos, vel, fx, fy, d.System, d.DistanceField, a.sdf);
-                    else
-                        update_positions(pos, vel, d.System);
-                    render_data(fx, fy, pos, vel, attr, d.System, d.Update, a.ramp, a.ramp_w, a.ramp_h, rc, rd);
-                }
-            }
-            cr[j] = rc.x; cg[j] = rc.y; cb[j] = rc.z; ca[j] = rc.w;
-            dx[j] = rd.x; dy[j] = rd.y; dz[j] = rd.z; dw[j] = rd.w;
-            px[j] = pos.x; py[j] = pos.y; pz[j] = pos.z; life[j] = pos.w;
-            vx[j] = vel.x; vy[j] = vel.y; vz[j] = vel.z; ct[j] = vel.w;
-            ar[j] = attr.x; ag[j] = attr.y; ab[j] = attr.z; aa[j] = attr.w;
-            if (pos.w > 0.0f)
-                live_after |= (1u << j);
-
-            if (++sx >= a.chunk_size) { sx = 0; sy++; }
         }
 
-        VecIO<SPT>::store(base + 0 * S + i0, px); VecIO<SPT>::store(base + 1 * S + i0, py); VecIO<SPT>::store(base + 2 * S + i0, pz);
-        VecIO<SPT>::store(base + 3 * S + i0, life);
-        VecIO<SPT>::store(base + 4 * S + i0, vx); VecIO<SPT>::store(base + 5 * S + i0, vy); VecIO<SPT>::store(base + 6 * S + i0, vz);
-        VecIO<SPT>::store(base + 7 * S + i0, ct);
-        if (spawned_any) {
-            VecIO<SPT>::store(base + 8 * S + i0, ar); VecIO<SPT>::store(base + 9 * S + i0, ag);
-            VecIO<SPT>::store(base + 10 * S + i0, ab); VecIO<SPT>::store(base + 11 * S + i0, aa);
+        for (int o = 0; o < d.OpCount; o++) {
+            const IlmTransformOp& op = d.Ops[o];
+            if (op.Type == ILM_OP_GRAVITY)
+                apply_gravity(pos, vel, d.System, op.u.Gravity);
+            else if (op.Type == ILM_OP_NOISE)
+                apply_noise(pos, vel, fx, fy, a.rnd, a.rw, a.rh, d.System, op.u.Noise);
+            else if (op.Type == ILM_OP_FMA)
+                apply_fma(pos, vel, d.System, op.u.FMA);
+        }
+
+        float4 rc = zero, rd = zero;
+        if (need_attr) {
+            if (pos.w <= 0.0f) {
+                pos = vel = zero;  // readStateOrDiscard: discard => cleared target
+            } else {
+                if constexpr (DF)
+                    update_with_distance_field<FMT>(pos, vel, fx, fy, d.System, d.DistanceField, a.sdf);
+                else
+                    update_positions(pos, vel, d.System);
+                render_data(fx, fy, pos, vel, attr, d.System, d.Update, a.ramp, a.ramp_w, a.ramp_h, rc, rd);
+            }
+        }
+        base[0 * S + i] = pos.x; base[1 * S + i] = pos.y; base[2 * S + i] = pos.z; base[3 * S + i] = pos.w;
+        base[4 * S + i] = vel.x; base[5 * S + i] = vel.y; base[6 * S + i] = vel.z; base[7 * S + i] = vel.w;
+        if (spawned) {
+            base[8 * S + i] = attr.x; base[9 * S + i] = attr.y; base[10 * S + i] = attr.z; base[11 * S + i] = attr.w;
         }
         if (need_attr) {
-            VecIO<SPT>::store(base + 12 * S + i0, cr); VecIO<SPT>::store(base + 13 * S + i0, cg);
-            VecIO<SPT>::store(base + 14 * S + i0, cb); VecIO<SPT>::store(base + 15 * S + i0, ca);
-            VecIO<SPT>::store(base + 16 * S + i0, dx); VecIO<SPT>::store(base + 17 * S + i0, dy);
-            VecIO<SPT>::store(base + 18 * S + i0, dz); VecIO<SPT>::store(base + 19 * S + i0, dw);
+            base[12 * S + i] = rc.x; base[13 * S + i] = rc.y; base[14 * S + i] = rc.z; base[15 * S + i] = rc.w;
+            base[16 * S + i] = rd.x; base[17 * S + i] = rd.y; base[18 * S + i] = rd.z; base[19 * S + i] = rd.w;
         }
+        live_after = pos.w > 0.0f;
     }
 
-    if (!full && mode == ILM_UPDATE_NONE) {
-        // untouched slots keep their liveness when no update pass ran
-#pragma unroll
-        for (int j = 0; j < SPT; j++)
-            if (life[j] > 0.0f) live_after |= (1u << j);
-    }
+    return live_after;
+}
 
-    if (d.Flags & ILM_STEP_COUNT_LIVE) {
-        // CountLiveParticles.fx: wave64 ballot + popcount, one atomic per wave
-        uint32_t n = 0;
-#pragma unroll
-        for (int j = 0; j < SPT; j++)
-            n += (uint32_t)__popcll(__ballot((live_after >> j) & 1u));
-        if ((threadIdx.x & 63) == 0 && n != 0)
-            atomicAdd(&a.live_counts[chunk], n);
+// One wave = one unit of 64 consecutive slots; the hardware dispatcher balances the waves.  (A persistent,
+// software-pipelined variant of this kernel measured 12-25 % slower: the body is a long dependent chain --
+// state loads, scalar parameter fetches, randomness gathers -- whose latency is hidden by wave occupancy,
+// not by prefetching; see DESIGN.md.)  MINW = minimum waves per SIMD requested from the register allocator.
+template <int FMT, bool DF, bool SPAWN, int MINW>
+__global__ __launch_bounds__(kStepThreads, MINW) void step_kernel(const StepLaunch a) {
+    __shared__ uint32_t wave_live[kStepThreads / 64];
+    CStepLaunch* ap = (CStepLaunch*)__builtin_amdgcn_kernarg_segment_ptr();
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const int u = a.unit_begin + (int)blockIdx.x * (kStepThreads / 64) + wave;
+    bool active = u < a.unit_end;
+    if constexpr (!SPAWN) {
+        // units holding a spawn range are processed by the SPAWN variant's launch
+        if ((u >= a.skip_begin[0] && u <= a.skip_end[0]) || (u >= a.skip_begin[1] && u <= a.skip_end[1]))
+            active = false;
+    }
+    bool live_after = false;
+    int chunk = 0;
+    if (active) {
+        const int chunk_rel = u / a.units_per_chunk;
+        const int seg = u - chunk_rel * a.units_per_chunk;
+        chunk = a.first_chunk + chunk_rel;
+        gfloat* base = (gfloat*)a.chunk_bases[chunk];
+        const int i = seg * 64 + lane;
+        const SlotIn cur = load_slot<true>(base, a.stride, i);
+        live_after = process_unit<FMT, DF, SPAWN>(ap, base, chunk, i, lane, seg, cur);
+    }
+    if (a.desc.Flags & ILM_STEP_COUNT_LIVE) {
+        // CountLiveParticles.fx: wave64 ballot + popcount, LDS sum over the block's waves, then ONE atomic per
+        // block on a per-chunk counter that sits on its own 128-byte line (per-wave atomics on one address
+        // serialise at ~11 ns each: 1024 of them per chunk made this step 7x slower).  The 4 units of a block
+        // always belong to one chunk (units_per_chunk is a multiple of 16; spawn launches stay inside one chunk).
+        const uint32_t n = (uint32_t)__popcll(__ballot(live_after));
+        if (lane == 0) wave_live[wave] = active ? n : 0u;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t total = wave_live[0] + wave_live[1] + wave_live[2] + wave_live[3];
+            const int first_unit = a.unit_begin + (int)blockIdx.x * (kStepThreads / 64);
+            const int c = a.first_chunk + first_unit / a.units_per_chunk;
+            if (total != 0)
+                atomicAdd(&a.live_counts[c * kCountStride], total);
+        }
     }
 }
 
-static int g_step_spt = 0;   // 0 => take ILM_STEP_SPT from the environment (default 1)
-
-template <int SPT>
-static hipError_t launch_step_spt(const StepLaunch& a, hipStream_t stream) {
-    const dim3 grid((unsigned)(a.stride / (kStepThreads * SPT)), (unsigned)a.chunk_count, 1);
-    const dim3 block(kStepThreads, 1, 1);
-    if (a.sdf.format == ILM_SDF_FP16)
-        hipLaunchKernelGGL((step_kernel<ILM_SDF_FP16, SPT>), grid, block, 0, stream, a);
-    else
-        hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, SPT>), grid, block, 0, stream, a);
+template <bool SPAWN>
+static hipError_t launch_step_variant(const StepLaunch& a, hipStream_t stream) {
+    const int units = a.unit_end - a.unit_begin;
+    if (units <= 0) return hipSuccess;
+    static int minw = -1;
+    if (minw < 0) {
+        const char* e = getenv("ILM_STEP_MINWAVES");
+        minw = e ? atoi(e) : kDefaultStepMinWaves;
+    }
+    const int waves_per_block = kStepThreads / 64;
+    const dim3 grid((unsigned)((units + waves_per_block - 1) / waves_per_block), 1, 1), block(kStepThreads, 1, 1);
+    if (a.desc.UpdateMode == ILM_UPDATE_WITH_DISTANCE_FIELD) {
+        if (a.sdf.format == ILM_SDF_FP16)
+            hipLaunchKernelGGL((step_kernel<ILM_SDF_FP16, true, SPAWN, 1>), grid, block, 0, stream, a);
+        else
+            hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, true, SPAWN, 1>), grid, block, 0, stream, a);
+    } else if (SPAWN) {
+        hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, false, SPAWN, 1>), grid, block, 0, stream, a);
+    } else {
+        switch (minw) {
+            case 8: hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, false, false, 8>), grid, block, 0, stream, a); break;
+            case 7: hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, false, false, 7>), grid, block, 0, stream, a); break;
+            case 6: hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, false, false, 6>), grid, block, 0, stream, a); break;
+            default: hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, false, false, 1>), grid, block, 0, stream, a); break;
+        }
+    }
     return hipGetLastError();
 }
 
-hipError_t launch_step(const StepLaunch& a, hipStream_t stream) {
-    if (a.chunk_count <= 0)
-        return hipSuccess;
-    if (g_step_spt == 0) {
-        const char* e = getenv("ILM_STEP_SPT");
-        const int v = e ? atoi(e) : 0;
-        g_step_spt = (v == 1 || v == 2 || v == 4) ? v : kDefaultStepSpt;
+// Fill the unit ranges of a launch descriptor: the whole [0, chunk_count * units_per_chunk) range for the main
+// launch and up to two spawn ranges (returned) that the SPAWN variant processes.
+int plan_step(StepLaunch& a) {
+    a.units_per_chunk = (int)(a.stride / 64);
+    a.unit_begin = 0;
+    a.unit_end = a.chunk_count * a.units_per_chunk;
+    for (int k = 0; k < 2; k++) { a.skip_begin[k] = 0; a.skip_end[k] = -1; }
+    int n_ranges = 0;
+    for (int s = 0; s < a.desc.SpawnCount; s++) {
+        const IlmSpawnRecord& r = a.desc.Spawns[s];
+        if (r.ChunkIndex < a.first_chunk || r.ChunkIndex >= a.first_chunk + a.chunk_count)
+            continue;
+        const int rel = r.ChunkIndex - a.first_chunk;
+        const int b0 = rel * a.units_per_chunk + (int)r.Params.ChunkSizeAndIndices[1] / 64;
+        const int b1 = rel * a.units_per_chunk + (int)r.Params.ChunkSizeAndIndices[2] / 64;
+        if (b1 < b0) continue;
+        if (n_ranges == 1 && b0 <= a.skip_end[0] + 1 && b1 >= a.skip_begin[0] - 1) {   // touching ranges: merge
+            a.skip_begin[0] = b0 < a.skip_begin[0] ? b0 : a.skip_begin[0];
+            a.skip_end[0] = b1 > a.skip_end[0] ? b1 : a.skip_end[0];
+        } else {
+            a.skip_begin[n_ranges] = b0; a.skip_end[n_ranges] = b1;
+            n_ranges++;
+        }
     }
-    switch (g_step_spt) {
-        case 4: return launch_step_spt<4>(a, stream);
-        case 2: return launch_step_spt<2>(a, stream);
-        default: return launch_step_spt<1>(a, stream);
-    }
+    return n_ranges;
+}
+
+// The SPAWN-variant launch over spawn range k of a planned descriptor.
+hipError_t launch_step_spawn_range(const StepLaunch& a, int k, hipStream_t stream) {
+    StepLaunch sp = a;
+    sp.unit_begin = a.skip_begin[k];
+    sp.unit_end = a.skip_end[k] + 1;
+    return launch_step_variant<true>(sp, stream);
+}
+
+// The main launch (every unit outside the spawn ranges).
+hipError_t launch_step_main(const StepLaunch& a, hipStream_t stream) {
+    return launch_step_variant<false>(a, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -787,14 +850,19 @@ hipError_t launch_soa_to_aos(const float* plane0, int64_t stride, float4* dst, i
 // liveness: standalone count + ordered live-slot compaction
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void count_live_kernel(float* const* __restrict__ bases, int64_t stride, uint32_t* __restrict__ counts) {
+    __shared__ uint32_t wave_live[4];
     const int chunk = (int)blockIdx.y;
     const float* life = bases[chunk] + 3 * stride;
     const int i0 = ((int)blockIdx.x * 256 + (int)threadIdx.x) * 4;
     const float4 l = *reinterpret_cast<const float4*>(life + i0);
-    uint32_t n = (uint32_t)__popcll(__ballot(l.x > 0.0f)) + (uint32_t)__popcll(__ballot(l.y > 0.0f)) +
-                 (uint32_t)__popcll(__ballot(l.z > 0.0f)) + (uint32_t)__popcll(__ballot(l.w > 0.0f));
-    if ((threadIdx.x & 63) == 0 && n != 0)
-        atomicAdd(&counts[chunk], n);
+    const uint32_t n = (uint32_t)__popcll(__ballot(l.x > 0.0f)) + (uint32_t)__popcll(__ballot(l.y > 0.0f)) +
+                       (uint32_t)__popcll(__ballot(l.z > 0.0f)) + (uint32_t)__popcll(__ballot(l.w > 0.0f));
+    if ((threadIdx.x & 63) == 0) wave_live[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = wave_live[0] + wave_live[1] + wave_live[2] + wave_live[3];
+        if (total != 0) atomicAdd(&counts[chunk * kCountStride], total);
+    }
 }
 hipError_t launch_count_live(float* const* chunk_bases, int64_t stride, int32_t chunk_count, uint32_t* counts, hipStream_t stream) {
     if (chunk_count <= 0) return hipSuccess;

@@ -1,0 +1,309 @@
+// bindings.cpp -- pybind11 glue exposing the C++ host mirror (illuminant_host.hpp) to Python as
+// illuminant_amd._host, with the reference's class and member names.  Test / bench plumbing only:
+// the product boundary is the C ABI underneath.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <cstring>
+
+#include "illuminant_host.hpp"
+
+namespace py = pybind11;
+using namespace Squared::Illuminant;
+using namespace Squared::Illuminant::Particles;
+using namespace Squared::Illuminant::Particles::Transforms;
+using namespace Squared::Illuminant::Lighting;
+
+using farray = py::array_t<float, py::array::c_style | py::array::forcecast>;
+
+static Vector2 v2(const std::vector<float>& v) { return Vector2{ v.at(0), v.at(1) }; }
+static Vector3 v3(const std::vector<float>& v) { return Vector3{ v.at(0), v.at(1), v.at(2) }; }
+static Vector4 v4(const std::vector<float>& v) { return Vector4{ v.at(0), v.at(1), v.at(2), v.at(3) }; }
+static std::vector<float> l2(const Vector2& v) { return { v.X, v.Y }; }
+static std::vector<float> l3(const Vector3& v) { return { v.X, v.Y, v.Z }; }
+static std::vector<float> l4(const Vector4& v) { return { v.X, v.Y, v.Z, v.W }; }
+
+// Vector-valued members are exposed as Python lists
+#define VEC_PROP(cls, name, N) \
+    .def_property(#name, [](const cls& o) { return l##N(o.name); }, [](cls& o, const std::vector<float>& v) { o.name = v##N(v); })
+
+PYBIND11_MODULE(_host, m) {
+    m.doc() = "C++ host mirror of Illuminant's ParticleSystem / LightingRenderer interface over libilluminant_hip.so";
+
+    py::register_exception<InvalidOperationException>(m, "InvalidOperationException", PyExc_RuntimeError);
+    py::register_exception<NativeException>(m, "NativeException", PyExc_RuntimeError);
+
+    py::class_<Xoshiro>(m, "Xoshiro").def(py::init<uint64_t>(), py::arg("seed") = 0x1234567ull)
+        .def("NextDouble", &Xoshiro::NextDouble).def("NextUInt64", &Xoshiro::NextUInt64);
+
+    py::class_<ITimeProvider>(m, "ITimeProvider");
+    py::class_<ManualTimeProvider, ITimeProvider>(m, "ManualTimeProvider").def(py::init<>())
+        .def_readwrite("Now", &ManualTimeProvider::Now).def("Advance", &ManualTimeProvider::Advance).def("Seconds", &ManualTimeProvider::Seconds);
+
+    py::class_<DeviceContext>(m, "DeviceContext").def(py::init<int>(), py::arg("deviceId") = 0)
+        .def("Sync", &DeviceContext::Sync).def("TimerStart", &DeviceContext::TimerStart).def("TimerStop", &DeviceContext::TimerStop)
+        .def_property_readonly("Handle", &DeviceContext::Handle);
+
+    py::class_<DistanceField>(m, "DistanceField")
+        .def(py::init<DeviceContext&, int, int, float, int, double, int, int>(), py::arg("ctx"), py::arg("virtualWidth"), py::arg("virtualHeight"),
+             py::arg("virtualDepth"), py::arg("requestedSliceCount"), py::arg("requestedResolution") = 1.0,
+             py::arg("maximumEncodedDistance") = 128, py::arg("format") = 0, py::keep_alive<1, 2>())
+        .def_readonly("VirtualWidth", &DistanceField::VirtualWidth).def_readonly("VirtualHeight", &DistanceField::VirtualHeight)
+        .def_readonly("VirtualDepth", &DistanceField::VirtualDepth).def_readonly("Resolution", &DistanceField::Resolution)
+        .def_readonly("SliceWidth", &DistanceField::SliceWidth).def_readonly("SliceHeight", &DistanceField::SliceHeight)
+        .def_readonly("SliceCount", &DistanceField::SliceCount).def_readonly("PhysicalSliceCount", &DistanceField::PhysicalSliceCount)
+        .def_readonly("ColumnCount", &DistanceField::ColumnCount).def_readonly("RowCount", &DistanceField::RowCount)
+        .def_readonly("TextureWidth", &DistanceField::TextureWidth).def_readonly("TextureHeight", &DistanceField::TextureHeight)
+        .def_readwrite("ZOffset", &DistanceField::ZOffset)
+        .def("Load", [](DistanceField& f, py::array_t<uint16_t, py::array::c_style | py::array::forcecast> a) {
+            if (a.size() != (py::ssize_t)f.TextureWidth * f.TextureHeight * 4) throw ArgumentException("atlas size mismatch");
+            f.Load(a.data());
+        })
+        .def("GetUniformsBytes", [](const DistanceField& f) { auto u = f.GetUniforms(); return py::bytes((const char*)&u, sizeof(u)); });
+
+    // ---- particles -------------------------------------------------------------------------------------------
+    py::class_<ParticleEngineConfiguration>(m, "ParticleEngineConfiguration").def(py::init<int>(), py::arg("chunkSize") = 256)
+        .def_readwrite("ChunkSize", &ParticleEngineConfiguration::ChunkSize)
+        .def_readwrite("TimeProvider", &ParticleEngineConfiguration::TimeProvider)
+        .def_readwrite("UpdatesPerSecond", &ParticleEngineConfiguration::UpdatesPerSecond)
+        .def_readwrite("MaximumUpdateDeltaTimeSeconds", &ParticleEngineConfiguration::MaximumUpdateDeltaTimeSeconds)
+        .def_readwrite("AccurateLivenessCounts", &ParticleEngineConfiguration::AccurateLivenessCounts);
+
+    py::class_<ParticleEngine>(m, "ParticleEngine")
+        .def(py::init([](DeviceContext& ctx, const ParticleEngineConfiguration& cfg, farray rnd) {
+            if (rnd.size() != (py::ssize_t)ParticleEngine::RandomnessTextureWidth * ParticleEngine::RandomnessTextureHeight * 4)
+                throw ArgumentException("randomness table must be 653 x 807 x 4 floats");
+            return new ParticleEngine(ctx, cfg, rnd.data());
+        }), py::keep_alive<1, 2>())
+        .def_readonly("Configuration", &ParticleEngine::Configuration);
+
+    py::class_<BezierF>(m, "BezierF").def(py::init<>())
+        .def_readwrite("Count", &BezierF::Count).def_readwrite("Mode", &BezierF::Mode)
+        .def_readwrite("MinValue", &BezierF::MinValue).def_readwrite("MaxValue", &BezierF::MaxValue)
+        .def_readwrite("A", &BezierF::A).def_readwrite("B", &BezierF::B).def_readwrite("C", &BezierF::C).def_readwrite("D", &BezierF::D);
+    py::class_<Bezier4>(m, "Bezier4").def(py::init<>())
+        .def_readwrite("Count", &Bezier4::Count).def_readwrite("Mode", &Bezier4::Mode)
+        .def_readwrite("MinValue", &Bezier4::MinValue).def_readwrite("MaxValue", &Bezier4::MaxValue)
+        VEC_PROP(Bezier4, A, 4) VEC_PROP(Bezier4, B, 4) VEC_PROP(Bezier4, C, 4) VEC_PROP(Bezier4, D, 4);
+
+    py::class_<ParticleCollision>(m, "ParticleCollision").def(py::init<>())
+        .def_readwrite("DistanceField", &ParticleCollision::Field)
+        .def_readwrite("DistanceFieldMaximumZ", &ParticleCollision::DistanceFieldMaximumZ)
+        .def_readwrite("Distance", &ParticleCollision::Distance).def_readwrite("LifePenalty", &ParticleCollision::LifePenalty)
+        .def_readwrite("EscapeVelocity", &ParticleCollision::EscapeVelocity)
+        .def_readwrite("BounceVelocityMultiplier", &ParticleCollision::BounceVelocityMultiplier);
+    py::class_<ParticleColor>(m, "ParticleColor").def(py::init<>())
+        .def_readwrite("OpacityFromLife", &ParticleColor::OpacityFromLife)
+        .def_readwrite("ColorFromLife", &ParticleColor::ColorFromLife).def_readwrite("ColorFromVelocity", &ParticleColor::ColorFromVelocity);
+    py::class_<ParticleSystemConfiguration>(m, "ParticleSystemConfiguration").def(py::init<>())
+        VEC_PROP(ParticleSystemConfiguration, Size, 2)
+        .def_readwrite("Friction", &ParticleSystemConfiguration::Friction)
+        .def_readwrite("MaximumVelocity", &ParticleSystemConfiguration::MaximumVelocity)
+        .def_readwrite("LifeDecayPerSecond", &ParticleSystemConfiguration::LifeDecayPerSecond)
+        .def_readwrite("Collision", &ParticleSystemConfiguration::Collision)
+        .def_readwrite("Color", &ParticleSystemConfiguration::Color)
+        .def_readwrite("SizeFromLife", &ParticleSystemConfiguration::SizeFromLife)
+        .def_readwrite("SizeFromVelocity", &ParticleSystemConfiguration::SizeFromVelocity)
+        .def_readwrite("RotationFromLife", &ParticleSystemConfiguration::RotationFromLife)
+        .def_readwrite("RotationFromIndex", &ParticleSystemConfiguration::RotationFromIndex)
+        .def_readwrite("RotationFromVelocity", &ParticleSystemConfiguration::RotationFromVelocity)
+        .def_readwrite("ZToY", &ParticleSystemConfiguration::ZToY)
+        .def_readwrite("TimeProvider", &ParticleSystemConfiguration::TimeProvider);
+
+    py::enum_<AreaType>(m, "AreaType").value("None_", AreaType::None).value("Ellipsoid", AreaType::Ellipsoid).value("Box", AreaType::Box)
+        .value("Cylinder", AreaType::Cylinder).value("Spheroid", AreaType::Spheroid).value("Octagon", AreaType::Octagon);
+    py::class_<TransformArea>(m, "TransformArea").def(py::init<>())
+        .def_readwrite("Type", &TransformArea::Type) VEC_PROP(TransformArea, Center, 3) VEC_PROP(TransformArea, Size, 3)
+        .def_readwrite("Falloff", &TransformArea::Falloff).def_readwrite("Rotation", &TransformArea::Rotation);
+
+    py::class_<ParticleTransform>(m, "ParticleTransform")
+        .def_readwrite("IsActive", &ParticleTransform::IsActive).def_readwrite("IsActive2", &ParticleTransform::IsActive2)
+        .def_readwrite("Label", &ParticleTransform::Label).def_property_readonly("IsValid", &ParticleTransform::IsValid)
+        .def("Reset", &ParticleTransform::Reset);
+    py::class_<ParticleAreaTransform, ParticleTransform>(m, "ParticleAreaTransform")
+        .def_readwrite("Strength", &ParticleAreaTransform::Strength)
+        .def_property("CategoryFilter", [](const ParticleAreaTransform& t) -> py::object { if (!t.CategoryFilter) return py::none(); return py::cast(l2(*t.CategoryFilter)); },
+                      [](ParticleAreaTransform& t, py::object v) { if (v.is_none()) t.CategoryFilter.reset(); else t.CategoryFilter = v2(v.cast<std::vector<float>>()); })
+        .def_readwrite("Area", &ParticleAreaTransform::Area);
+
+    py::class_<FMA::FMAParameters>(m, "FMAParameters").def(py::init<>()) VEC_PROP(FMA::FMAParameters, Add, 3) VEC_PROP(FMA::FMAParameters, Multiply, 3);
+    py::class_<FMA, ParticleAreaTransform>(m, "FMA").def(py::init<>())
+        .def_readwrite("CyclesPerSecond", &FMA::CyclesPerSecond)
+        .def_readwrite("Position", &FMA::Position).def_readwrite("Velocity", &FMA::Velocity);
+
+    py::class_<Noise::P4>(m, "NoiseParameters4").def(py::init<>()) VEC_PROP(Noise::P4, Offset, 4) VEC_PROP(Noise::P4, Minimum, 4) VEC_PROP(Noise::P4, Scale, 4);
+    py::class_<Noise::P3>(m, "NoiseParameters3").def(py::init<>()) VEC_PROP(Noise::P3, Offset, 3) VEC_PROP(Noise::P3, Minimum, 3) VEC_PROP(Noise::P3, Scale, 3);
+    py::class_<Noise::PF>(m, "NoiseParametersF").def(py::init<>())
+        .def_readwrite("Offset", &Noise::PF::Offset).def_readwrite("Minimum", &Noise::PF::Minimum).def_readwrite("Scale", &Noise::PF::Scale);
+    py::class_<Noise, ParticleAreaTransform>(m, "Noise").def(py::init<uint64_t>(), py::arg("seed") = 1)
+        .def_readwrite("CyclesPerSecond", &Noise::CyclesPerSecond)
+        .def_readwrite("Position", &Noise::Position).def_readwrite("Velocity", &Noise::Velocity).def_readwrite("Speed", &Noise::Speed)
+        .def_readwrite("Interval", &Noise::Interval).def_readwrite("ReplaceOldVelocity", &Noise::ReplaceOldVelocity)
+        .def_readonly("CurrentU", &Noise::CurrentU).def_readonly("CurrentV", &Noise::CurrentV)
+        .def_readonly("NextU", &Noise::NextU).def_readonly("NextV", &Noise::NextV);
+
+    py::enum_<AttractorType>(m, "AttractorType").value("Physical", AttractorType::Physical).value("Linear", AttractorType::Linear)
+        .value("Exponential", AttractorType::Exponential);
+    py::class_<Gravity::Attractor>(m, "Attractor").def(py::init<>())
+        VEC_PROP(Gravity::Attractor, Position, 3)
+        .def_readwrite("Radius", &Gravity::Attractor::Radius).def_readwrite("Strength", &Gravity::Attractor::Strength)
+        .def_readwrite("Type", &Gravity::Attractor::Type);
+    py::class_<Gravity, ParticleTransform>(m, "Gravity").def(py::init<>())
+        .def_readwrite("MaximumAcceleration", &Gravity::MaximumAcceleration)
+        .def_readwrite("Attractors", &Gravity::Attractors)
+        VEC_PROP(Gravity, CategoryFilter, 2);
+
+    py::enum_<FormulaType>(m, "FormulaType").value("Linear", FormulaType::Linear).value("Spherical", FormulaType::Spherical)
+        .value("Towards", FormulaType::Towards).value("Rectangular", FormulaType::Rectangular);
+    py::class_<Formula1>(m, "Formula1").def(py::init<>())
+        .def_readwrite("Constant", &Formula1::Constant).def_readwrite("RandomScale", &Formula1::RandomScale).def_readwrite("Offset", &Formula1::Offset);
+    py::class_<Formula3>(m, "Formula3").def(py::init<>())
+        VEC_PROP(Formula3, Constant, 3) VEC_PROP(Formula3, RandomScale, 3) VEC_PROP(Formula3, Offset, 3)
+        .def_readwrite("Type", &Formula3::Type);
+    py::class_<Formula4>(m, "Formula4").def(py::init<>())
+        VEC_PROP(Formula4, Constant, 4) VEC_PROP(Formula4, RandomScale, 4) VEC_PROP(Formula4, Offset, 4);
+
+    py::class_<SpawnerBase, ParticleTransform>(m, "SpawnerBase")
+        .def_readwrite("MinRate", &SpawnerBase::MinRate).def_readwrite("MaxRate", &SpawnerBase::MaxRate)
+        .def_readwrite("MaximumTotal", &SpawnerBase::MaximumTotal)
+        .def_readwrite("Position", &SpawnerBase::Position).def_readwrite("Velocity", &SpawnerBase::Velocity)
+        .def_readwrite("Life", &SpawnerBase::Life).def_readwrite("Category", &SpawnerBase::Category).def_readwrite("Color", &SpawnerBase::Color)
+        .def_readwrite("AlignVelocityAndPosition", &SpawnerBase::AlignVelocityAndPosition)
+        VEC_PROP(SpawnerBase, AxisMask, 3)
+        .def_readwrite("AlphaDiscardThreshold", &SpawnerBase::AlphaDiscardThreshold)
+        .def_readwrite("RateError", &SpawnerBase::RateError)
+        .def_property_readonly("TotalSpawned", &SpawnerBase::TotalSpawned)
+        .def("BeginTick", [](SpawnerBase& s, double now, double dt) { int n = 0; s.BeginTick(now, dt, n); return n; })
+        .def("EndTick", &SpawnerBase::EndTick);
+    py::class_<Spawner, SpawnerBase>(m, "Spawner").def(py::init<uint64_t>(), py::arg("seed") = 1)
+        .def_property("AdditionalPositions",
+                      [](const Spawner& s) { std::vector<std::vector<float>> r; for (auto& p : s.AdditionalPositions) r.push_back(l3(p)); return r; },
+                      [](Spawner& s, const std::vector<std::vector<float>>& v) { s.AdditionalPositions.clear(); for (auto& p : v) s.AdditionalPositions.push_back(v3(p)); })
+        .def_readwrite("PolygonRate", &Spawner::PolygonRate).def_readwrite("PolygonLoop", &Spawner::PolygonLoop)
+        .def_readwrite("VelocityAlongPolygon", &Spawner::VelocityAlongPolygon).def_readwrite("RatePerPosition", &Spawner::RatePerPosition);
+
+    py::class_<ParticleSystem::Chunk>(m, "Chunk")
+        .def_readonly("ID", &ParticleSystem::Chunk::ID).def_readonly("NextSpawnOffset", &ParticleSystem::Chunk::NextSpawnOffset)
+        .def_readonly("TotalSpawned", &ParticleSystem::Chunk::TotalSpawned)
+        .def_readonly("NoLongerASpawnTarget", &ParticleSystem::Chunk::NoLongerASpawnTarget)
+        .def_readonly("Count", &ParticleSystem::Chunk::Count).def_readonly("DeadFrameCount", &ParticleSystem::Chunk::DeadFrameCount);
+    py::class_<ParticleSystem::UpdateResult>(m, "UpdateResult")
+        .def_readonly("PerformedUpdate", &ParticleSystem::UpdateResult::PerformedUpdate)
+        .def_readonly("Timestamp", &ParticleSystem::UpdateResult::Timestamp);
+    py::class_<ParticleSystem>(m, "ParticleSystem")
+        .def(py::init<ParticleEngine&, const ParticleSystemConfiguration&>(), py::keep_alive<1, 2>())
+        .def_readwrite("Configuration", &ParticleSystem::Configuration)
+        .def_readonly("LiveCount", &ParticleSystem::LiveCount)
+        .def_property_readonly("Capacity", &ParticleSystem::Capacity)
+        .def_property_readonly("Chunks", &ParticleSystem::Chunks)
+        .def_readonly("TotalSpawnCount", &ParticleSystem::TotalSpawnCount)
+        .def_readwrite("DeadFrameThreshold", &ParticleSystem::DeadFrameThreshold)
+        .def_readwrite("BlockingLivenessReadback", &ParticleSystem::BlockingLivenessReadback)
+        .def_readonly("LastDeltaTimeSeconds", &ParticleSystem::LastDeltaTimeSeconds)
+        // Transforms list: the Python side keeps the objects alive (AddTransform keeps a reference)
+        .def("AddTransform", [](ParticleSystem& s, ParticleTransform* t) { s.Transforms.push_back(t); }, py::keep_alive<1, 2>())
+        .def("ClearTransforms", [](ParticleSystem& s) { s.Transforms.clear(); })
+        .def("Spawn", [](ParticleSystem& s, int count, farray pos, farray vel, py::object color) {
+            if (pos.size() < (py::ssize_t)count * 4 || vel.size() < (py::ssize_t)count * 4) throw ArgumentException("initializer arrays too small");
+            const IlmFloat4* c = nullptr;
+            farray carr;
+            if (!color.is_none()) { carr = color.cast<farray>(); c = (const IlmFloat4*)carr.data(); }
+            return s.Spawn(count, (const IlmFloat4*)pos.data(), (const IlmFloat4*)vel.data(), c);
+        }, py::arg("particleCount"), py::arg("positions"), py::arg("velocities"), py::arg("colors") = py::none())
+        .def("Update", &ParticleSystem::Update, py::arg("frameIndex"))
+        .def("UpdateMany", [](ParticleSystem& s, ManualTimeProvider& tp, int firstFrame, int count, double dt) {
+            // `count` Update calls, advancing the manual clock by dt before each (bench inner loop without Python in it)
+            for (int i = 0; i < count; i++) { tp.Advance(dt); s.Update(firstFrame + i); }
+        })
+        .def("Clear", &ParticleSystem::Clear)
+        .def("Readback", [](const ParticleSystem& s, int chunk, int plane) {
+            farray out({ (py::ssize_t)s.ChunkMaximumCount(), (py::ssize_t)4 });
+            s.Readback(chunk, plane, (IlmFloat4*)out.mutable_data());
+            return out;
+        })
+        .def_property_readonly("Handle", &ParticleSystem::Handle)
+        .def("LastStepBytes", [](const ParticleSystem& s) { return py::bytes((const char*)&s.LastStep(), sizeof(IlmStepDesc)); });
+
+    // ---- lighting ------------------------------------------------------------------------------------------------
+    py::class_<SphereLightSource>(m, "SphereLightSource").def(py::init<>())
+        VEC_PROP(SphereLightSource, Position, 3)
+        .def_readwrite("Radius", &SphereLightSource::Radius).def_readwrite("RampLength", &SphereLightSource::RampLength)
+        VEC_PROP(SphereLightSource, Color, 4)
+        .def_readwrite("Opacity", &SphereLightSource::Opacity)
+        .def_property("RampMode", [](const SphereLightSource& l) { return (int)l.RampMode; }, [](SphereLightSource& l, int v) { l.RampMode = (LightSourceRampMode)v; })
+        .def_readwrite("CastsShadows", &SphereLightSource::CastsShadows)
+        .def_readwrite("AmbientOcclusionRadius", &SphereLightSource::AmbientOcclusionRadius)
+        .def_readwrite("AmbientOcclusionOpacity", &SphereLightSource::AmbientOcclusionOpacity)
+        .def_readwrite("ShadowDistanceFalloff", &SphereLightSource::ShadowDistanceFalloff)
+        .def_readwrite("FalloffYFactor", &SphereLightSource::FalloffYFactor)
+        .def_readwrite("ShadowFilter", &SphereLightSource::ShadowFilter)
+        VEC_PROP(SphereLightSource, SpecularColor, 3)
+        .def_readwrite("SpecularPower", &SphereLightSource::SpecularPower);
+    py::class_<LightingEnvironment>(m, "LightingEnvironment").def(py::init<>())
+        .def_readwrite("Lights", &LightingEnvironment::Lights)
+        .def_readwrite("GroundZ", &LightingEnvironment::GroundZ).def_readwrite("MaximumZ", &LightingEnvironment::MaximumZ)
+        .def_readwrite("ZToYMultiplier", &LightingEnvironment::ZToYMultiplier)
+        VEC_PROP(LightingEnvironment, Ambient, 4);
+    py::class_<RendererQualitySettings>(m, "RendererQualitySettings").def(py::init<>())
+        .def_readwrite("MinStepSize", &RendererQualitySettings::MinStepSize).def_readwrite("LongStepFactor", &RendererQualitySettings::LongStepFactor)
+        .def_readwrite("MaxStepCount", &RendererQualitySettings::MaxStepCount).def_readwrite("MaxConeRadius", &RendererQualitySettings::MaxConeRadius)
+        .def_readwrite("ConeGrowthFactor", &RendererQualitySettings::ConeGrowthFactor)
+        .def_readwrite("OcclusionToOpacityPower", &RendererQualitySettings::OcclusionToOpacityPower);
+    py::class_<RendererConfiguration>(m, "RendererConfiguration").def(py::init<int, int>())
+        .def_readwrite("RenderWidth", &RendererConfiguration::RenderWidth).def_readwrite("RenderHeight", &RendererConfiguration::RenderHeight)
+        .def_readwrite("HighQuality", &RendererConfiguration::HighQuality).def_readwrite("TwoPointFiveD", &RendererConfiguration::TwoPointFiveD)
+        .def_readwrite("LightOcclusion", &RendererConfiguration::LightOcclusion)
+        VEC_PROP(RendererConfiguration, RenderScale, 2)
+        .def_readwrite("DefaultQuality", &RendererConfiguration::DefaultQuality)
+        .def_readwrite("FloatLightmap", &RendererConfiguration::FloatLightmap);
+    py::class_<LightingRenderer>(m, "LightingRenderer")
+        .def(py::init([](DeviceContext& ctx, const RendererConfiguration& cfg, LightingEnvironment* env, uintptr_t externalLightmap) {
+            return new LightingRenderer(ctx, cfg, env, reinterpret_cast<void*>(externalLightmap));
+        }), py::arg("ctx"), py::arg("configuration"), py::arg("environment"), py::arg("externalLightmap") = 0,
+             py::keep_alive<1, 2>(), py::keep_alive<1, 4>())
+        .def_readwrite("Configuration", &LightingRenderer::Configuration)
+        .def_property("DistanceField", py::cpp_function([](LightingRenderer& r) { return r.Field; }, py::return_value_policy::reference),
+                      py::cpp_function([](LightingRenderer& r, DistanceField* f) { r.Field = f; }, py::keep_alive<1, 2>()))
+        .def("SetGBuffer", [](LightingRenderer& r, py::object arr, int format) {
+            if (arr.is_none()) { r.SetGBuffer(nullptr, 0, 0, 0); return; }
+            py::array a = arr.cast<py::array>();
+            if (a.ndim() != 3 || a.shape(2) != 4) throw ArgumentException("G-buffer must be (H, W, 4)");
+            r.SetGBuffer(a.data(), (int)a.shape(1), (int)a.shape(0), format);
+        })
+        .def("RenderLighting", [](LightingRenderer& r, float intensityScale, int rowBegin, int rowEnd, bool wantStats) -> py::object {
+            if (!wantStats) { r.RenderLighting(intensityScale, rowBegin, rowEnd, nullptr); return py::none(); }
+            IlmRenderStats st{};
+            r.RenderLighting(intensityScale, rowBegin, rowEnd, &st);
+            return py::make_tuple(st.SdfSamples, st.PixelLightPairs, st.TracedPairs);
+        }, py::arg("intensityScale") = 1.0f, py::arg("rowBegin") = 0, py::arg("rowEnd") = -1, py::arg("wantStats") = false)
+        .def("RenderLightingMany", [](LightingRenderer& r, int count, float intensityScale, int rowBegin, int rowEnd) {
+            for (int i = 0; i < count; i++) r.RenderLighting(intensityScale, rowBegin, rowEnd, nullptr);
+        })
+        .def("ReadLightmap", [](const LightingRenderer& r, int firstRow, int rowCount) -> py::array {
+            const int w = r.Configuration.RenderWidth;
+            if (rowCount < 0) rowCount = r.Configuration.RenderHeight - firstRow;
+            if (r.LightmapFormat() == ILM_LIGHTMAP_FLOAT4) {
+                py::array_t<float> out({ (py::ssize_t)rowCount, (py::ssize_t)w, (py::ssize_t)4 });
+                r.ReadLightmap(out.mutable_data(), firstRow, rowCount);
+                return std::move(out);
+            } else if (r.LightmapFormat() == ILM_LIGHTMAP_HALF4) {
+                py::array_t<uint16_t> out({ (py::ssize_t)rowCount, (py::ssize_t)w, (py::ssize_t)4 });
+                r.ReadLightmap(out.mutable_data(), firstRow, rowCount);
+                return std::move(out);
+            }
+            py::array_t<uint8_t> out({ (py::ssize_t)rowCount, (py::ssize_t)w, (py::ssize_t)4 });
+            r.ReadLightmap(out.mutable_data(), firstRow, rowCount);
+            return std::move(out);
+        }, py::arg("firstRow") = 0, py::arg("rowCount") = -1)
+        .def_property_readonly("LightmapHandle", &LightingRenderer::Lightmap)
+        .def_property_readonly("LightmapFormat", &LightingRenderer::LightmapFormat)
+        .def("GetDistanceFieldUniformsBytes", [](const LightingRenderer& r) {
+            auto u = r.GetDistanceFieldUniforms(r.Configuration.DefaultQuality); return py::bytes((const char*)&u, sizeof(u)); })
+        .def("GetEnvironmentUniformsBytes", [](const LightingRenderer& r) { auto u = r.GetEnvironmentUniforms(); return py::bytes((const char*)&u, sizeof(u)); })
+        .def_static("PackSphereLightBytes", [](const SphereLightSource& l, float intensityScale, bool haveDF) -> py::object {
+            IlmLightVertex v;
+            if (!LightingRenderer::PackSphereLight(l, intensityScale, haveDF, v)) return py::none();
+            return py::bytes((const char*)&v, sizeof(v));
+        });
+}

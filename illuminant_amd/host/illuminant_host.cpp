@@ -1,0 +1,807 @@
+// illuminant_host.cpp -- host-side mirror of the reference's C# logic above the C ABI (see the header).
+#include "illuminant_host.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace Squared {
+namespace Illuminant {
+
+void ThrowIfFailed(int32_t code) {
+    if (code == ILM_OK)
+        return;
+    const char* msg = ilm_last_error();
+    throw NativeException(code, std::string("illuminant_hip error ") + std::to_string(code) + ": " + (msg ? msg : ""));
+}
+
+// ---- Xoshiro --------------------------------------------------------------------------------------------
+static uint64_t splitmix64(uint64_t& x) {
+    uint64_t z = (x += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+Xoshiro::Xoshiro(uint64_t seed) {
+    for (int i = 0; i < 4; i++) s[i] = splitmix64(seed);
+}
+static inline uint64_t rotl(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+uint64_t Xoshiro::NextUInt64() {
+    const uint64_t result = rotl(s[1] * 5, 7) * 9;
+    const uint64_t t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+    s[2] ^= t;
+    s[3] = rotl(s[3], 45);
+    return result;
+}
+double Xoshiro::NextDouble() { return (double)(NextUInt64() >> 11) * (1.0 / 9007199254740992.0); }
+
+// ---- DeviceContext ---------------------------------------------------------------------------------------
+DeviceContext::DeviceContext(int deviceId) { ThrowIfFailed(ilm_ctx_create(deviceId, &handle)); }
+DeviceContext::~DeviceContext() { if (handle) ilm_ctx_destroy(handle); }
+void DeviceContext::Sync() { ThrowIfFailed(ilm_ctx_sync(handle)); }
+void DeviceContext::TimerStart() { ThrowIfFailed(ilm_timer_start(handle)); }
+float DeviceContext::TimerStop() { float ms = 0; ThrowIfFailed(ilm_timer_stop(handle, &ms)); return ms; }
+
+// ---- DistanceField, SDF/DistanceField.cs:43-122 -------------------------------------------------------------
+static double RoundToEven(double v) { return std::nearbyint(v); }   // Math.Round: MidpointRounding.ToEven
+
+DistanceField::DistanceField(DeviceContext& ctx, int virtualWidth, int virtualHeight, float virtualDepth, int requestedSliceCount,
+                             double requestedResolution, int maximumEncodedDistance, int format) {
+    VirtualWidth = virtualWidth; VirtualHeight = virtualHeight; VirtualDepth = virtualDepth;
+    MaximumEncodedDistance = maximumEncodedDistance;
+    RequestedResolution = requestedResolution;
+    if (requestedResolution < 0.05) requestedResolution = 0.05;
+    else if (requestedResolution > 1) requestedResolution = 1;
+
+    const int candidateSliceWidth = (int)RoundToEven(VirtualWidth * requestedResolution);
+    const int candidateSliceHeight = (int)RoundToEven(VirtualHeight * requestedResolution);
+    const double fracX = (double)VirtualWidth / candidateSliceWidth, fracY = (double)VirtualHeight / candidateSliceHeight;
+    const double frac = (fracX + fracY) / 2;
+    double resolution = RoundToEven((1.0 / frac) * 1000.0) / 1000.0;   // Math.Round(x, 3)
+    if (resolution < 0.05) resolution = 0.05;
+    else if (resolution > 1) resolution = 1;
+    Resolution = resolution;
+
+    SliceWidth = (int)RoundToEven(VirtualWidth * Resolution);
+    SliceHeight = (int)RoundToEven(VirtualHeight * Resolution);
+    const int maxSlicesX = MaxSurfaceSize / SliceWidth, maxSlicesY = MaxSurfaceSize / SliceHeight;
+    const int maxSlices = maxSlicesX * maxSlicesY * PackedSliceCount;
+
+    int sliceCount = std::max(3, requestedSliceCount);
+    sliceCount = ((sliceCount + 2) / 3) * 3;
+    SliceCount = std::min(sliceCount, maxSlices);
+    PhysicalSliceCount = (int)std::ceil(SliceCount / (float)PackedSliceCount);
+
+    ColumnCount = std::min(maxSlicesX, PhysicalSliceCount);
+    RowCount = std::min(maxSlicesY, std::max((int)std::ceil(PhysicalSliceCount / (float)maxSlicesX), 1));
+    // "HACK: If the DF is going to be extremely wide but not tall, rebalance it" (:91-109)
+    while ((RowCount < ColumnCount) && (RowCount < maxSlicesY)) {
+        int newRowCount = RowCount + 1;
+        int newColumnCount = (int)std::ceil(PhysicalSliceCount / (float)newRowCount);
+        if (newRowCount > maxSlicesX) newRowCount = maxSlicesX;
+        if (newColumnCount > maxSlicesY) newColumnCount = maxSlicesY;
+        if ((newRowCount * newColumnCount) < PhysicalSliceCount) break;
+        RowCount = newRowCount;
+        ColumnCount = newColumnCount;
+    }
+    TextureWidth = SliceWidth * ColumnCount;
+    TextureHeight = SliceHeight * RowCount;
+    ThrowIfFailed(ilm_sdf_create(ctx.Handle(), TextureWidth, TextureHeight, format, &texture));
+}
+DistanceField::~DistanceField() { if (texture) ilm_sdf_destroy(texture); }
+
+void DistanceField::Load(const uint16_t* texels) {
+    ThrowIfFailed(ilm_sdf_upload(texture, texels));
+    ValidSliceCount = SliceCount;
+}
+
+IlmDistanceFieldUniforms DistanceField::GetUniforms() const {
+    IlmDistanceFieldUniforms u;
+    std::memset(&u, 0, sizeof(u));
+    u.Extent = { (float)VirtualWidth, (float)VirtualHeight, VirtualDepth, (float)MaximumEncodedDistance };   // GetExtent4
+    const float sliceZSize = VirtualDepth / SliceCount;
+    u.TextureSliceCount = { (float)ColumnCount, (float)RowCount, std::min(ValidSliceCount, SliceCount) * sliceZSize, (float)SliceCount };
+    u.TextureSliceAndTexelSize = { 1.0f / ColumnCount, 1.0f / RowCount, 1.0f / (VirtualWidth * ColumnCount), 1.0f / (VirtualHeight * RowCount) };
+    u.ConeAndMisc = { 0, 0, 0, (float)((double)VirtualWidth / SliceWidth) };
+    u.StepAndMisc2 = { 0, 0, 1, (float)((double)VirtualHeight / SliceHeight) };
+    return u;
+}
+
+namespace Particles {
+
+// ---- ParticleEngine ---------------------------------------------------------------------------------------
+ParticleEngine::ParticleEngine(DeviceContext& ctx, const ParticleEngineConfiguration& configuration, const float* randomnessTexels)
+    : Context(ctx), Configuration(configuration) {
+    ThrowIfFailed(ilm_engine_create(ctx.Handle(), configuration.ChunkSize, reinterpret_cast<const IlmFloat4*>(randomnessTexels),
+                                    RandomnessTextureWidth, RandomnessTextureHeight, &handle));
+}
+ParticleEngine::~ParticleEngine() { if (handle) ilm_engine_destroy(handle); }
+
+// ClampedBezier1(BezierF), Bezier.cs:442-460
+IlmClampedBezier1 MakeClampedBezier1(const std::optional<BezierF>& src) {
+    IlmClampedBezier1 r;
+    if (!src) { r.RangeAndCount = { 0, 1, 1, 0 }; r.ABCD = { 1, 1, 1, 1 }; return r; }   // ClampedBezier1.One
+    float range = src->MaxValue - src->MinValue;
+    if ((range == 0) || (src->Count <= 1)) range = 1;
+    r.RangeAndCount = { std::min(src->MinValue, src->MaxValue), 1.0f / range, (float)src->Count, (float)src->Mode };
+    r.ABCD = { src->A, src->B, src->C, src->D };
+    return r;
+}
+// ClampedBezier4(IBezier...), Bezier.cs:741-757
+IlmClampedBezier4 MakeClampedBezier4(const std::optional<Bezier4>& src) {
+    IlmClampedBezier4 r;
+    const IlmFloat4 one = { 1, 1, 1, 1 };
+    if (!src) { r.RangeAndCount = { 0, 1, 1, 0 }; r.A = r.B = r.C = r.D = one; return r; }   // ClampedBezier4.One
+    float range = src->MaxValue - src->MinValue;
+    if ((range == 0) || (src->Count <= 1)) range = 1;
+    r.RangeAndCount = { std::min(src->MinValue, src->MaxValue), 1.0f / range, (float)src->Count, (float)src->Mode };
+    auto cv = [](const Vector4& v) { return IlmFloat4{ v.X, v.Y, v.Z, v.W }; };
+    r.A = cv(src->A); r.B = cv(src->B); r.C = cv(src->C); r.D = cv(src->D);
+    return r;
+}
+
+namespace Transforms {
+
+// ParticleAreaTransform.SetParameters, ParticleTransform.cs:294-318
+void ParticleAreaTransform::FillArea(IlmAreaParams& a) const {
+    std::memset(&a, 0, sizeof(a));
+    if (Area) {
+        a.AreaType = (int)Area->Type;
+        a.AreaCenter[0] = Area->Center.X; a.AreaCenter[1] = Area->Center.Y; a.AreaCenter[2] = Area->Center.Z;
+        a.AreaSize[0] = Area->Size.X; a.AreaSize[1] = Area->Size.Y; a.AreaSize[2] = Area->Size.Z;
+        a.AreaFalloff = std::max(1.0f, Area->Falloff);
+        a.AreaRotation = Area->Rotation;
+    } else {
+        a.AreaType = 0;   // AreaFalloff stays at the effect default 0
+    }
+    a.Strength = Strength;
+    const Vector2 cf = CategoryFilter.value_or(Vector2{ -9999, 9999 });
+    a.CategoryFilter[0] = cf.X; a.CategoryFilter[1] = cf.Y;
+}
+
+// FMA.SetParameters, Transforms.cs:38-45
+bool FMA::FillOp(IlmTransformOp& op, double) {
+    std::memset(&op, 0, sizeof(op));
+    op.Type = ILM_OP_FMA;
+    IlmFMAParams& p = op.u.FMA;
+    FillArea(p.Area);
+    p.TimeDivisor = CyclesPerSecond ? (1000 / *CyclesPerSecond) : -1.0f;
+    p.PositionAdd = { Position.Add.X, Position.Add.Y, Position.Add.Z, 0 };
+    p.PositionMultiply = { Position.Multiply.X, Position.Multiply.Y, Position.Multiply.Z, 1 };
+    p.VelocityAdd = { Velocity.Add.X, Velocity.Add.Y, Velocity.Add.Z, 0 };
+    p.VelocityMultiply = { Velocity.Multiply.X, Velocity.Multiply.Y, Velocity.Multiply.Z, 1 };
+    return true;
+}
+
+// Noise, Transforms.cs:176-273
+Noise::Noise(uint64_t seed) : RNG(seed) { Reset(); }
+void Noise::CycleUVs() {
+    CurrentU = NextU; CurrentV = NextV;
+    NextU = RNG.NextDouble(); NextV = RNG.NextDouble();
+}
+void Noise::Reset() { LastUChangeWhen = 0; CycleUVs(); }
+void Noise::AutoCycleUV(float now, double intervalSecs, float& t) {
+    if (intervalSecs <= 0.01) { t = 0; return; }
+    double nextChangeWhen = LastUChangeWhen + intervalSecs;
+    if (now >= nextChangeWhen) {
+        const double elapsed = now - nextChangeWhen;
+        if (elapsed >= intervalSecs) LastUChangeWhen = now;
+        else LastUChangeWhen = nextChangeWhen;
+        nextChangeWhen = LastUChangeWhen + intervalSecs;
+        CycleUVs();
+    }
+    t = (float)((now - LastUChangeWhen) / intervalSecs);
+}
+bool Noise::FillOp(IlmTransformOp& op, double now) {
+    std::memset(&op, 0, sizeof(op));
+    op.Type = ILM_OP_NOISE;
+    IlmNoiseParams& p = op.u.Noise;
+    FillArea(p.Area);
+    p.TimeDivisor = CyclesPerSecond ? (1000 / *CyclesPerSecond) : -1.0f;
+    p.PositionOffset = { Position.Offset.X, Position.Offset.Y, Position.Offset.Z, Position.Offset.W };
+    p.PositionMinimum = { Position.Minimum.X, Position.Minimum.Y, Position.Minimum.Z, Position.Minimum.W };
+    p.PositionScale = { Position.Scale.X, Position.Scale.Y, Position.Scale.Z, Position.Scale.W };
+    p.VelocityOffset = { Velocity.Offset.X, Velocity.Offset.Y, Velocity.Offset.Z, Speed.Offset };
+    p.VelocityMinimum = { Velocity.Minimum.X, Velocity.Minimum.Y, Velocity.Minimum.Z, Speed.Minimum };
+    p.VelocityScale = { Velocity.Scale.X, Velocity.Scale.Y, Velocity.Scale.Z, Speed.Scale };
+    const double intervalSecs = Interval / (double)IntervalUnit;
+    float t;
+    AutoCycleUV((float)now, intervalSecs, t);
+    p.RandomnessOffset[0] = (float)(CurrentU * 253); p.RandomnessOffset[1] = (float)(CurrentV * 127);
+    p.NextRandomnessOffset[0] = (float)(NextU * 253); p.NextRandomnessOffset[1] = (float)(NextV * 127);
+    p.FrequencyLerp = t;
+    p.ReplaceOldVelocity = ReplaceOldVelocity ? 1.0f : 0.0f;
+    return true;
+}
+
+// Gravity.SetParameters, Transforms.cs:347-365
+bool Gravity::FillOp(IlmTransformOp& op, double) {
+    if ((int)Attractors.size() > MaxAttractors)
+        throw std::runtime_error("Maximum number of attractors per instance is " + std::to_string(MaxAttractors));
+    std::memset(&op, 0, sizeof(op));
+    op.Type = ILM_OP_GRAVITY;
+    IlmGravityParams& p = op.u.Gravity;
+    p.AttractorCount = (int)Attractors.size();
+    p.MaximumAcceleration = MaximumAcceleration;
+    p.CategoryFilter[0] = CategoryFilter.X; p.CategoryFilter[1] = CategoryFilter.Y;
+    for (size_t i = 0; i < Attractors.size(); i++) {
+        const Attractor& a = Attractors[i];
+        p.AttractorPositions[i][0] = a.Position.X; p.AttractorPositions[i][1] = a.Position.Y; p.AttractorPositions[i][2] = a.Position.Z;
+        p.AttractorRadiusesAndStrengths[i][0] = a.Radius;
+        p.AttractorRadiusesAndStrengths[i][1] = a.Strength;
+        p.AttractorRadiusesAndStrengths[i][2] = (float)(int)a.Type;
+    }
+    return true;
+}
+
+// ---- SpawnerBase, ParticleSpawner.cs:16-260 ---------------------------------------------------------------
+static IlmMatrix IdentityMatrix() {
+    IlmMatrix m;
+    std::memset(&m, 0, sizeof(m));
+    m.m[0] = m.m[5] = m.m[10] = m.m[15] = 1;
+    return m;
+}
+SpawnerBase::SpawnerBase(uint64_t seed) : PositionPostMatrix(IdentityMatrix()), VelocityPostMatrix(IdentityMatrix()), RNG(seed) {}
+
+void SpawnerBase::BeginTick(double, double deltaTimeSeconds, int& spawnCount) {
+    if (!IsActive || !IsActive2) {
+        RateError = 0;
+        spawnCount = 0;
+        return;
+    }
+    const int countScaler = CountScale();
+    float minRate = MinRate, maxRate = MaxRate;
+    if (minRate > maxRate)
+        minRate = maxRate;
+    double currentRate = ((RNG.NextDouble() * (maxRate - minRate)) + minRate) * countScaler * deltaTimeSeconds;
+    currentRate += RateError;
+    RateError = 0;
+    if (currentRate < 1) {
+        RateError = std::max(currentRate, 0.0);
+        spawnCount = 0;
+    } else {
+        spawnCount = (int)currentRate;
+        RateError = currentRate - spawnCount;
+    }
+    if (MaximumTotal) {
+        const int scaledTotal = *MaximumTotal * CountScale();
+        const int remaining = scaledTotal - totalSpawned;
+        if (spawnCount > remaining) {
+            spawnCount = remaining;
+            RateError = 0;
+        }
+    }
+}
+
+void SpawnerBase::EndTick(int requestedSpawnCount, int actualSpawnCount) {
+    RateError += requestedSpawnCount - actualSpawnCount;
+    totalSpawned += actualSpawnCount;
+}
+
+float SpawnerBase::EstimateMaximumLifeForNewParticle() const {
+    const float a = Life.Constant + (Life.Offset * Life.RandomScale);
+    const float b = Life.Constant - (Life.Offset * Life.RandomScale);
+    return std::max(a, b);
+}
+
+void SpawnerBase::FillSpawn(IlmSpawnParams& p, int chunkSize, double) {
+    std::memset(&p, 0, sizeof(p));
+    const double a = RNG.NextDouble(), b = RNG.NextDouble();
+    p.RandomnessOffset[0] = (float)(a * 253);
+    p.RandomnessOffset[1] = (float)(b * 127);
+    // GetChunkSizeAndIndices, :142-146 (w filled by the subclass)
+    p.ChunkSizeAndIndices[0] = (float)chunkSize;
+    p.ChunkSizeAndIndices[1] = (float)indexFirst;
+    p.ChunkSizeAndIndices[2] = (float)indexLast;
+    p.ChunkSizeAndIndices[3] = 0;
+    p.Configuration[0] = { Position.RandomScale.X, Position.RandomScale.Y, Position.RandomScale.Z, Life.RandomScale };
+    p.Configuration[1] = { Position.Offset.X, Position.Offset.Y, Position.Offset.Z, Life.Offset };
+    p.Configuration[2] = { Velocity.Constant.X, Velocity.Constant.Y, Velocity.Constant.Z, Category.Constant };
+    p.Configuration[3] = { Velocity.RandomScale.X, Velocity.RandomScale.Y, Velocity.RandomScale.Z, Category.RandomScale };
+    p.Configuration[4] = { Velocity.Offset.X, Velocity.Offset.Y, Velocity.Offset.Z, Category.Offset };
+    p.Configuration[5] = { Color.Constant.X, Color.Constant.Y, Color.Constant.Z, Color.Constant.W };
+    p.Configuration[6] = { Color.RandomScale.X, Color.RandomScale.Y, Color.RandomScale.Z, Color.RandomScale.W };
+    p.Configuration[7] = { Color.Offset.X, Color.Offset.Y, Color.Offset.Z, Color.Offset.W };
+    p.FormulaTypes[0] = (float)(int)Position.Type;
+    p.FormulaTypes[1] = (float)(int)Velocity.Type;
+    p.AlignVelocityAndPosition = (AlignVelocityAndPosition && Position.Circular() && Velocity.Circular()) ? 1.0f : 0.0f;
+    p.AxisMask[0] = AxisMask.X; p.AxisMask[1] = AxisMask.Y; p.AxisMask[2] = AxisMask.Z;
+    p.PositionMatrix = PositionPostMatrix;
+    p.VelocityMatrix = VelocityPostMatrix;
+    p.AttributeDiscardThreshold = AlphaDiscardThreshold / 255.0f;
+    // single-position defaults; Spawner overrides
+    p.PositionConstantCount = 1;
+    p.InlinePositionConstants[0] = { Position.Constant.X, Position.Constant.Y, Position.Constant.Z, Life.Constant };
+}
+
+// ---- Spawner, ParticleSpawner.cs:262-419 ------------------------------------------------------------------
+int Spawner::CountScale() const {
+    return std::max(RatePerPosition ? (int)AdditionalPositions.size() + (PolygonLoop ? 1 : 0) : 1, 1);
+}
+
+void Spawner::FillSpawn(IlmSpawnParams& p, int chunkSize, double now) {
+    SpawnerBase::FillSpawn(p, chunkSize, now);
+    int count = 1 + (int)AdditionalPositions.size();
+    if (count > MaxInlinePositions)
+        // the reference switches to SpawnFromPositionTexture here (:295-299); that technique is a "next" row
+        throw InvalidOperationException("more than 3 AdditionalPositions needs SpawnParticlesFromPositionTexture (not built yet)");
+    // GetChunkSizeAndIndices, :361-374
+    {
+        int c = count;
+        const float polygonRate = PolygonRate.value_or(0);
+        if (polygonRate >= 1) {
+            if (!PolygonLoop && (c > 1)) c -= 1;
+            p.ChunkSizeAndIndices[3] = std::fmod(totalSpawned / polygonRate, (float)c);
+        } else {
+            p.ChunkSizeAndIndices[3] = (float)(totalSpawned % c);
+        }
+    }
+    // BeginTick's Temp3, :338-346
+    for (int i = 0; (i < (int)AdditionalPositions.size()) && (i < MaxInlinePositions - 1); i++) {
+        const Vector3& ap = AdditionalPositions[(size_t)i];
+        p.InlinePositionConstants[i + 1] = { ap.X, ap.Y, ap.Z, Life.Constant };
+    }
+    p.PositionConstantCount = (float)count;
+    p.PolygonRate = PolygonRate.value_or(0);
+    p.PolygonLoop = PolygonLoop ? 1.0f : 0.0f;
+    // InitConfiguration, :393-403
+    p.Configuration[8] = { VelocityAlongPolygon.Constant, VelocityAlongPolygon.RandomScale, VelocityAlongPolygon.Offset, 0 };
+    p.FormulaTypes[3] = 0;
+}
+
+}  // namespace Transforms
+
+// ---- ParticleSystem ----------------------------------------------------------------------------------------
+ParticleSystem::ParticleSystem(ParticleEngine& engine, const ParticleSystemConfiguration& configuration)
+    : Engine(engine), Configuration(configuration) {
+    ThrowIfFailed(ilm_system_create(engine.Handle(), &handle));
+    std::memset(&lastStep, 0, sizeof(lastStep));
+}
+ParticleSystem::~ParticleSystem() { if (handle) ilm_system_destroy(handle); }
+
+// CreateChunk, ParticleSystem.cs:393-415
+int ParticleSystem::CreateChunk() {
+    if ((int)chunks.size() >= MaxChunkCount)
+        return -1;
+    int32_t index = -1;
+    ThrowIfFailed(ilm_system_add_chunk(handle, &index));
+    Chunk c;
+    c.ID = nextChunkId++;
+    chunks.push_back(c);
+    return (int)chunks.size() - 1;
+}
+
+// InitializeNewChunks, ParticleSpawning.cs:13-59
+int ParticleSystem::Spawn(int particleCount, const IlmFloat4* positions, const IlmFloat4* velocities, const IlmFloat4* colors) {
+    const int mc = ChunkMaximumCount();
+    const int numToSpawn = (int)std::ceil((double)particleCount / mc);
+    for (int i = 0; i < numToSpawn; i++) {
+        const int ci = CreateChunk();
+        if (ci < 0)
+            return 0;
+        const int offset = i * mc;
+        const int n = std::min(mc, particleCount - offset);
+        ThrowIfFailed(ilm_chunk_upload(handle, ci, ILM_PLANE_POSITION, positions + offset, 0, n));
+        ThrowIfFailed(ilm_chunk_upload(handle, ci, ILM_PLANE_VELOCITY, velocities + offset, 0, n));
+        if (colors)
+            ThrowIfFailed(ilm_chunk_upload(handle, ci, ILM_PLANE_ATTRIBUTES, colors + offset, 0, n));
+        Chunk& c = chunks[(size_t)ci];
+        c.TotalSpawned = mc;
+        c.Count = mc;
+        ProcessLatestLivenessInfo(c);
+        // ParticleSystem.Update adds new user chunks with NoLongerASpawnTarget = true (:690-697)
+        c.NoLongerASpawnTarget = true;
+        TotalSpawnCount += mc;
+    }
+    return numToSpawn * mc;
+}
+
+// ProcessLatestLivenessInfo, ParticleLiveness.cs:47-78
+void ParticleSystem::ProcessLatestLivenessInfo(Chunk& c) {
+    if (!c.Count)
+        return;
+    if (*c.Count <= 0) c.DeadFrameCount++;
+    else c.DeadFrameCount = 0;
+    if (c.DeadFrameCount >= DeadFrameThreshold)
+        if (std::find(chunksToReap.begin(), chunksToReap.end(), c.ID) == chunksToReap.end())
+            chunksToReap.push_back(c.ID);
+}
+
+// UpdateLiveCountAndReapDeadChunks, ParticleLiveness.cs:80-105 (+ the deferred readback of
+// LivenessDataReadbackWorkItem / ProcessLivenessInfoData, ParticleEngine.cs:224-252)
+void ParticleSystem::UpdateLiveCountAndReapDeadChunks() {
+    if (livenessPending) {
+        std::vector<uint32_t> counts(std::max<size_t>(livenessChunkIds.size(), 1));
+        int32_t ready = 0;
+        if (BlockingLivenessReadback) {
+            ThrowIfFailed(ilm_system_step_counts(handle, counts.data(), (int32_t)counts.size(), 1));
+            ready = 1;
+        } else {
+            // like the reference's deferred readback: take the counts when the GPU has produced them, never stall
+            ThrowIfFailed(ilm_system_poll_counts(handle, counts.data(), (int32_t)counts.size(), 1, &ready));
+        }
+        if (ready) {
+            for (size_t i = 0; i < livenessChunkIds.size(); i++)
+                for (Chunk& c : chunks)
+                    if (c.ID == livenessChunkIds[i]) {
+                        c.Count = (int)(counts[i] & 0xFFFF);   // ProcessLivenessInfoData: raw & 0xFFFF
+                        ProcessLatestLivenessInfo(c);
+                    }
+            livenessPending = false;
+        }
+    }
+    LiveCount = 0;
+    for (const Chunk& c : chunks) {
+        const int chunkCount = c.Count.value_or(0);
+        if (Engine.Configuration.AccurateLivenessCounts) LiveCount += chunkCount;
+        else LiveCount += (chunkCount > 0) ? 1 : 0;
+    }
+    for (int id : chunksToReap) {
+        for (size_t i = 0; i < chunks.size(); i++)
+            if (chunks[i].ID == id) {
+                // Reap, ParticleLiveness.cs:120-129
+                ThrowIfFailed(ilm_system_remove_chunk(handle, (int32_t)i));
+                chunks.erase(chunks.begin() + (long)i);
+                if (currentSpawnTarget == id) currentSpawnTarget = -1;
+                break;
+            }
+    }
+    chunksToReap.clear();
+}
+
+// PickTargetForSpawn, ParticleSpawning.cs:199-231: returns the chunk table index
+int ParticleSystem::PickTargetForSpawn(int count, bool& needClear, bool partialSpawnAllowed) {
+    int index = -1;
+    for (size_t i = 0; i < chunks.size(); i++)
+        if (chunks[i].ID == currentSpawnTarget) index = (int)i;
+    if (index >= 0) {
+        Chunk& chunk = chunks[(size_t)index];
+        const int free = ChunkMaximumCount() - chunk.NextSpawnOffset;
+        if (free < (partialSpawnAllowed ? 16 : count)) {
+            chunk.NoLongerASpawnTarget = true;
+            currentSpawnTarget = -1;
+            index = -1;
+        }
+    }
+    if (index < 0) {
+        index = CreateChunk();
+        if (index < 0) { needClear = false; return -1; }
+        currentSpawnTarget = chunks[(size_t)index].ID;
+        needClear = true;
+    } else {
+        needClear = false;
+    }
+    return index;
+}
+
+// RunSpawner, ParticleSpawning.cs:115-197
+bool ParticleSystem::RunSpawner(Transforms::SpawnerBase& spawner, double deltaTimeSeconds, double now, bool,
+                                std::vector<IlmSpawnRecord>& records) {
+    int spawnCount = 0, requestedSpawnCount = 0;
+    if (!spawner.IsValid())
+        return false;
+    spawner.BeginTick(now, deltaTimeSeconds, requestedSpawnCount);
+    if (requestedSpawnCount <= 0)
+        return false;
+    else if (requestedSpawnCount > ChunkMaximumCount())
+        spawnCount = ChunkMaximumCount();
+    else
+        spawnCount = requestedSpawnCount;
+
+    bool needClear;
+    const int ci = PickTargetForSpawn(spawnCount, needClear, spawner.PartialSpawnAllowed());
+    if (ci < 0)
+        return false;
+    Chunk& chunk = chunks[(size_t)ci];
+    const int free = ChunkMaximumCount() - chunk.NextSpawnOffset;
+    if (spawnCount > free) {
+        if (spawner.PartialSpawnAllowed()) spawnCount = free;
+        else return false;
+    }
+    const int first = chunk.NextSpawnOffset;
+    const int last = chunk.NextSpawnOffset + spawnCount - 1;
+    spawner.SetIndices(first, last);
+    chunk.NextSpawnOffset += spawnCount;
+    TotalSpawnCount += spawnCount;
+
+    spawner.EndTick(requestedSpawnCount, spawnCount);
+    chunk.TotalSpawned += spawnCount;
+    if (spawnCount > 0) {
+        chunk.DeadFrameCount = 0;
+        IlmSpawnRecord rec;
+        std::memset(&rec, 0, sizeof(rec));
+        rec.ChunkIndex = ci;
+        spawner.FillSpawn(rec.Params, Engine.Configuration.ChunkSize, now);
+        records.push_back(rec);
+    }
+    chunk.ApproximateMaximumLife = std::max(chunk.ApproximateMaximumLife, spawner.EstimateMaximumLifeForNewParticle());
+    return requestedSpawnCount > spawnCount;   // isPartialSpawn
+}
+
+// SetSystemUniforms (ParticleSystem.cs:547-575) + Uniforms.ParticleSystem ctor (Uniforms.cs:207-235)
+// + the rotation / life ramp / distance field binds of UpdateHandler._BeforeDraw (ParticleTransform.cs:144-161)
+void ParticleSystem::FillSystemUniforms(IlmStepDesc& d, double deltaTimeSeconds) const {
+    const ParticleSystemConfiguration& C = Configuration;
+    const int cs = Engine.Configuration.ChunkSize;
+    d.System.TexelAndSize = { 1.0f / cs, 1.0f / cs, C.Size.X, C.Size.Y };
+    d.System.GlobalSettings = { (float)(deltaTimeSeconds * 1000), C.Friction, C.MaximumVelocity, C.LifeDecayPerSecond };
+    if (C.Collision)
+        d.System.CollisionSettings = { C.Collision->EscapeVelocity, C.Collision->BounceVelocityMultiplier, C.Collision->Distance, C.Collision->LifePenalty };
+    else
+        d.System.CollisionSettings = { 0, 0, 0, 0 };
+    d.System.AnimationRateAndRotationAndZToY = { 0, 0, C.RotationFromVelocity ? 1.0f : 0.0f, C.ZToY };
+
+    const float o = C.Color.OpacityFromLife.value_or(0);
+    if (o != 0) {
+        d.Update.ColorFromLife.A = { 1, 1, 1, 0 };
+        d.Update.ColorFromLife.B = { 1, 1, 1, 1 };
+        d.Update.ColorFromLife.C = { 0, 0, 0, 0 };
+        d.Update.ColorFromLife.D = { 0, 0, 0, 0 };
+        d.Update.ColorFromLife.RangeAndCount = { 0, 1.0f / o, 2, 0 };
+    } else {
+        d.Update.ColorFromLife = MakeClampedBezier4(C.Color.ColorFromLife);
+    }
+    d.Update.ColorFromVelocity = MakeClampedBezier4(C.Color.ColorFromVelocity);
+    d.Update.SizeFromLife = MakeClampedBezier1(C.SizeFromLife);
+    d.Update.SizeFromVelocity = MakeClampedBezier1(C.SizeFromVelocity);
+    const float deg = 3.14159265358979323846f / 180.0f;   // MathHelper.ToRadians
+    d.Update.RotationFromLifeAndIndex[0] = C.RotationFromLife * deg;
+    d.Update.RotationFromLifeAndIndex[1] = C.RotationFromIndex * deg;
+    d.Update.LifeRampSettings = { 0, 0, 1, 1 };   // MaybeSetLifeRampParameters without a ramp, :936-939
+}
+
+void ParticleSystem::Launch(const IlmStepDesc& d) {
+    lastStep = d;
+    ThrowIfFailed(ilm_system_step(handle, &d));
+}
+
+// Update, ParticleSystem.cs:630-761
+ParticleSystem::UpdateResult ParticleSystem::Update(int frameIndex) {
+    ITimeProvider* tp = Configuration.TimeProvider ? Configuration.TimeProvider
+                        : (Engine.Configuration.TimeProvider ? Engine.Configuration.TimeProvider : &defaultTime);
+    const std::optional<double> lastUpdate = lastUpdateTimeSeconds;
+    const double updateError = updateErrorAccumulator;
+    updateErrorAccumulator = 0;
+    double now = tp->Seconds();
+    currentFrameIndex++;
+
+    if (lastFrameUpdated >= frameIndex)
+        throw InvalidOperationException("Cannot update twice in a single frame");
+
+    const std::optional<int>& ups = Engine.Configuration.UpdatesPerSecond;
+    const double maxDeltaTime = std::min(std::max(Engine.Configuration.MaximumUpdateDeltaTimeSeconds, (double)(1 / 200.0f)), 10.0);
+    const double tickUnit = 1.0 / std::min(std::max(ups.value_or(60), 5), 200);
+    double actualDeltaTimeSeconds = tickUnit;
+    if (lastUpdate)
+        actualDeltaTimeSeconds = std::min(now - *lastUpdate, maxDeltaTime);
+
+    if (ups && lastUpdate) {
+        actualDeltaTimeSeconds += updateError;
+        int tickCount = (int)std::floor(actualDeltaTimeSeconds / tickUnit);
+        if (tickCount < 0) tickCount = 0;
+        const double adjustedDeltaTime = tickCount * tickUnit;
+        updateErrorAccumulator = actualDeltaTimeSeconds - adjustedDeltaTime;
+        actualDeltaTimeSeconds = adjustedDeltaTime;
+        if ((actualDeltaTimeSeconds <= 0) && (currentFrameIndex > 1))
+            return UpdateResult{ false, (float)now };
+        lastUpdateTimeSeconds = now = *lastUpdate + adjustedDeltaTime;
+    } else {
+        lastUpdateTimeSeconds = now;
+    }
+    lastFrameUpdated = frameIndex;
+    actualDeltaTimeSeconds = std::min(actualDeltaTimeSeconds, maxDeltaTime);
+    LastDeltaTimeSeconds = actualDeltaTimeSeconds;
+
+    UpdateLiveCountAndReapDeadChunks();
+
+    if (isClearPending) {
+        // :702-714: Erase twice (idempotent) then reap everything
+        IlmStepDesc e;
+        std::memset(&e, 0, sizeof(e));
+        e.ChunkCount = -1;
+        e.UpdateMode = ILM_UPDATE_ERASE;
+        if (!chunks.empty()) Launch(e);
+        while (!chunks.empty()) {
+            ThrowIfFailed(ilm_system_remove_chunk(handle, (int32_t)chunks.size() - 1));
+            chunks.pop_back();
+        }
+        isClearPending = false;
+        TotalSpawnCount = 0;
+        currentSpawnTarget = -1;
+        livenessPending = false;
+    }
+
+    bool computingLiveness = false;
+    if (framesUntilNextLivenessCheck-- <= 0) {
+        framesUntilNextLivenessCheck = LivenessCheckInterval;
+        computingLiveness = true;
+    }
+
+    // spawners first (:725-741)
+    std::vector<IlmSpawnRecord> records;
+    for (Transforms::ParticleTransform* t : Transforms) {
+        if (!t->IsSpawner()) continue;
+        auto* s = static_cast<Transforms::SpawnerBase*>(t);
+        if (!s->IsActive || !s->IsActive2) continue;
+        const bool isPartialSpawn = RunSpawner(*s, actualDeltaTimeSeconds, now, false, records);
+        if (isPartialSpawn)
+            RunSpawner(*s, actualDeltaTimeSeconds, now, true, records);
+    }
+
+    // UpdateChunk (:791-856) for every chunk: transforms in list order, then exactly one update technique
+    std::vector<IlmTransformOp> ops;
+    for (Transforms::ParticleTransform* t : Transforms) {
+        const bool shouldSkip = !t->IsActive || !t->IsActive2 || t->IsSpawner() || !t->IsValid();
+        if (shouldSkip) continue;
+        IlmTransformOp op;
+        if (t->FillOp(op, now))
+            ops.push_back(op);
+    }
+
+    IlmStepDesc d;
+    std::memset(&d, 0, sizeof(d));
+    d.FirstChunk = 0;
+    d.ChunkCount = -1;
+    FillSystemUniforms(d, actualDeltaTimeSeconds);
+    int finalMode = ILM_UPDATE_POSITIONS;
+    if (Configuration.Collision && Configuration.Collision->Field) {
+        if (!Configuration.Collision->DistanceFieldMaximumZ)
+            throw InvalidOperationException("If a distance field is active, you must set DistanceFieldMaximumZ");
+        finalMode = ILM_UPDATE_WITH_DISTANCE_FIELD;
+        // ParticleTransform.cs:144-152: only Uniforms.DistanceField is bound; DistanceFieldPacked1 is never set on the
+        // particle effect in the reference and stays zero (the field collapses to its first slice).
+        d.DistanceField = Configuration.Collision->Field->GetUniforms();
+        ThrowIfFailed(ilm_system_set_distance_field(handle, Configuration.Collision->Field->Texture()));
+    }
+
+    // One launch when everything fits a descriptor; otherwise earlier launches carry the surplus spawn records
+    // and transforms (pass order is preserved: all spawns, then transforms in order, update last).
+    size_t spawnPos = 0, opPos = 0;
+    if (chunks.empty())
+        return UpdateResult{ true, (float)now };
+    for (;;) {
+        const size_t spawnsLeft = records.size() - spawnPos, opsLeft = ops.size() - opPos;
+        const bool lastLaunch = (spawnsLeft <= ILM_MAX_SPAWNS) && (opsLeft <= ILM_MAX_OPS);
+        IlmStepDesc cur = d;
+        if (spawnsLeft > ILM_MAX_SPAWNS) {
+            // surplus spawn records go alone, before any transform runs
+            cur.SpawnCount = ILM_MAX_SPAWNS;
+            for (int k = 0; k < ILM_MAX_SPAWNS; k++) cur.Spawns[k] = records[spawnPos + (size_t)k];
+            spawnPos += ILM_MAX_SPAWNS;
+            cur.UpdateMode = ILM_UPDATE_NONE;
+            Launch(cur);
+            continue;
+        }
+        cur.SpawnCount = (int)spawnsLeft;
+        for (size_t k = 0; k < spawnsLeft; k++) cur.Spawns[k] = records[spawnPos + k];
+        spawnPos = records.size();
+        const size_t nOps = std::min<size_t>(opsLeft, ILM_MAX_OPS);
+        cur.OpCount = (int)nOps;
+        for (size_t k = 0; k < nOps; k++) cur.Ops[k] = ops[opPos + k];
+        opPos += nOps;
+        if (lastLaunch) {
+            cur.UpdateMode = finalMode;
+            if (computingLiveness) cur.Flags |= ILM_STEP_COUNT_LIVE;
+            Launch(cur);
+            break;
+        }
+        cur.UpdateMode = ILM_UPDATE_NONE;
+        Launch(cur);
+    }
+    for (Chunk& c : chunks)
+        c.ApproximateMaximumLife -= Configuration.LifeDecayPerSecond * (float)actualDeltaTimeSeconds;
+
+    if (computingLiveness) {
+        // ComputeLiveness (:716-720, ParticleEngine.cs:282-386): counts are produced by the update launch itself
+        livenessPending = true;
+        livenessChunkIds.clear();
+        for (const Chunk& c : chunks) livenessChunkIds.push_back(c.ID);
+    }
+    return UpdateResult{ true, (float)now };
+}
+
+void ParticleSystem::Readback(int chunkIndex, int plane, IlmFloat4* dst) const {
+    ThrowIfFailed(ilm_chunk_download(handle, chunkIndex, plane, dst, 0, ChunkMaximumCount()));
+}
+
+}  // namespace Particles
+
+namespace Lighting {
+
+LightingRenderer::LightingRenderer(DeviceContext& ctx, const RendererConfiguration& configuration, LightingEnvironment* environment,
+                                   void* externalLightmap)
+    : Context(ctx), Configuration(configuration), Environment(environment) {
+    // lightmap format: HalfVector4 when HighQuality else Color (LightingRenderer.cs:476-479)
+    lightmapFormat = configuration.FloatLightmap ? ILM_LIGHTMAP_FLOAT4 : (configuration.HighQuality ? ILM_LIGHTMAP_HALF4 : ILM_LIGHTMAP_RGBA8);
+    ThrowIfFailed(ilm_lightmap_create(ctx.Handle(), configuration.RenderWidth, configuration.RenderHeight, lightmapFormat, externalLightmap, &lightmap));
+}
+LightingRenderer::~LightingRenderer() {
+    if (lightmap) ilm_lightmap_destroy(lightmap);
+    if (gbuffer) ilm_gbuffer_destroy(gbuffer);
+}
+
+void LightingRenderer::SetGBuffer(const void* texels, int width, int height, int format) {
+    if (gbuffer) { ilm_gbuffer_destroy(gbuffer); gbuffer = 0; }
+    if (!texels) return;
+    ThrowIfFailed(ilm_gbuffer_create(Context.Handle(), width, height, format, &gbuffer));
+    ThrowIfFailed(ilm_gbuffer_upload(gbuffer, texels));
+    gbufferWidth = width; gbufferHeight = height;
+}
+
+// RenderSphereLightSource, LightingRenderer.cs:1193-1219
+bool LightingRenderer::PackSphereLight(const SphereLightSource& l, float intensityScale, bool haveDistanceField, IlmLightVertex& v) {
+    if (l.Opacity <= 0.0f)
+        return false;
+    const IlmFloat4 pos = { l.Position.X, l.Position.Y, l.Position.Z, 0 };
+    v.LightPosition1 = v.LightPosition2 = v.LightPosition3 = pos;
+    v.Color1 = { l.Color.X, l.Color.Y, l.Color.Z, l.Color.W * (l.Opacity * intensityScale) };
+    v.Color2 = { l.SpecularColor.X, l.SpecularColor.Y, l.SpecularColor.Z, l.SpecularPower };
+    v.LightProperties = { l.Radius, l.RampLength, (float)(int)l.RampMode, (l.CastsShadows && haveDistanceField) ? 1.0f : 0.0f };
+    v.MoreLightProperties = { l.AmbientOcclusionRadius, l.ShadowDistanceFalloff.value_or(-99999.0f), l.FalloffYFactor, l.AmbientOcclusionOpacity };
+    v.EvenMoreLightProperties = { (float)l.ShadowFilter, 0, 0, 0 };
+    return true;
+}
+
+// SetDistanceFieldParameters, LightingRenderer.cs:1894-1940
+IlmDistanceFieldUniforms LightingRenderer::GetDistanceFieldUniforms(const RendererQualitySettings& q) const {
+    IlmDistanceFieldUniforms dfu;
+    if (!Field) {
+        std::memset(&dfu, 0, sizeof(dfu));
+        dfu.ConeAndMisc.w = 1; dfu.StepAndMisc2.w = 1;      // InvScaleFactorX/Y = 1
+        dfu.Extent.z = Environment->MaximumZ;
+        dfu.StepAndMisc2.x = (float)q.MaxStepCount;
+        dfu.StepAndMisc2.y = q.MinStepSize;
+        return dfu;                                          // DistanceFieldPacked1 = 0
+    }
+    dfu = Field->GetUniforms();
+    dfu.ConeAndMisc.x = q.MaxConeRadius;
+    dfu.ConeAndMisc.y = Field->ZOffset;
+    dfu.ConeAndMisc.z = q.OcclusionToOpacityPower;
+    dfu.StepAndMisc2.x = (float)q.MaxStepCount;
+    dfu.StepAndMisc2.y = q.MinStepSize;
+    dfu.StepAndMisc2.z = q.LongStepFactor;
+    dfu.Packed1 = { (float)((1.0f / std::max(0.0001f, dfu.TextureSliceCount.x)) * (1.0f / 3.0f)),
+                    (float)((1.0f / std::max(0.0001f, dfu.Extent.z)) * dfu.TextureSliceCount.w),
+                    dfu.TextureSliceCount.z, dfu.StepAndMisc2.y };
+    return dfu;
+}
+
+IlmEnvironment LightingRenderer::GetEnvironmentUniforms() const {
+    IlmEnvironment e;
+    std::memset(&e, 0, sizeof(e));
+    const float zToY = Configuration.TwoPointFiveD ? Environment->ZToYMultiplier : 0.0f;
+    e.ZAndScale = { Environment->GroundZ, Environment->MaximumZ, Configuration.RenderScale.X, Configuration.RenderScale.Y };
+    e.ZToY = { zToY, (std::fabs(zToY) <= 0.0001f) ? 0.0f : 1.0f / zToY, Configuration.LightOcclusion, 0 };   // Uniforms.cs:45-59
+    if (gbuffer)
+        e.GBufferTexelSizeAndMisc = { 1.0f / gbufferWidth, 1.0f / gbufferHeight, 1, 1 };
+    else
+        e.GBufferTexelSizeAndMisc = { 0, 0, 1, 1 };
+    return e;
+}
+
+// RenderLighting, LightingRenderer.cs:917-1191 (sphere lights only)
+void LightingRenderer::RenderLighting(float intensityScale, int rowBegin, int rowEnd, IlmRenderStats* stats) {
+    if (rowEnd < 0) rowEnd = Configuration.RenderHeight;
+    vertices.clear();
+    for (const SphereLightSource& l : Environment->Lights) {
+        IlmLightVertex v;
+        if (PackSphereLight(l, intensityScale, Field != nullptr, v))
+            vertices.push_back(v);
+    }
+    const IlmEnvironment env = GetEnvironmentUniforms();
+    const IlmDistanceFieldUniforms dfu = GetDistanceFieldUniforms(Configuration.DefaultQuality);
+    // clear colour: Ambient * intensityScale (:1013-1024)
+    const float ambient[4] = { Environment->Ambient.X * intensityScale, Environment->Ambient.Y * intensityScale,
+                               Environment->Ambient.Z * intensityScale, Environment->Ambient.W * intensityScale };
+    ThrowIfFailed(ilm_render_sphere_lights(Context.Handle(), vertices.empty() ? nullptr : vertices.data(), (int32_t)vertices.size(),
+                                           &env, &dfu, gbuffer, Field ? Field->Texture() : 0, ambient, lightmap, rowBegin, rowEnd, stats));
+}
+
+void LightingRenderer::ReadLightmap(void* dst, int firstRow, int rowCount) const {
+    ThrowIfFailed(ilm_lightmap_download(lightmap, dst, firstRow, rowCount));
+}
+
+}  // namespace Lighting
+}  // namespace Illuminant
+}  // namespace Squared

@@ -1,0 +1,484 @@
+// illuminant_host.hpp -- host-side mirror of the reference's C# interface for the two hot paths.
+//
+// The reference's host code is C# (.NET 4.8); no .NET toolchain exists in the build image, so the host
+// side above the C ABI is written in C++ with the reference's own class / member names, argument meaning
+// and error behaviour (exceptions with the same messages).  It uses ONLY include/illuminant_hip.h --
+// exactly what the C# P/Invoke layer of INTEGRATION.md would call -- and contains no device code.
+//
+// Mirrors (file:line relative to the reference checkout):
+//   Particles::ParticleEngine / ParticleEngineConfiguration   Illuminant/Particles/ParticleEngine.cs:24-141,616-696
+//   Particles::ParticleSystem (+Chunk, liveness, spawning)     Illuminant/Particles/ParticleSystem.cs:48-1072,
+//                                                              ParticleSpawning.cs:13-231, ParticleLiveness.cs:14-129
+//   Particles::Transforms::{Spawner,Gravity,Noise,FMA}         Illuminant/Particles/ParticleSpawner.cs:16-419, Transforms.cs:16-372
+//   DistanceField                                              Illuminant/SDF/DistanceField.cs:18-246
+//   Lighting::{LightingEnvironment,SphereLightSource,LightingRenderer,RendererQualitySettings}
+//                                                              Illuminant/Lighting/LightingEnvironment.cs:13-49, LightSource.cs:37-280,
+//                                                              LightingRenderer.cs:917-1219,1894-1940, LightingRenderer.Configuration.cs:254-291
+// Parameter<T> animation (bezier / named / expression parameters, Parameter.cs:190-485) is evaluated on the
+// CPU before upload in the reference; here every parameter is a plain value (out of scope).
+#pragma once
+
+#include <cstdint>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/illuminant_hip.h"
+
+namespace Squared {
+namespace Illuminant {
+
+struct Vector2 { float X = 0, Y = 0; };
+struct Vector3 { float X = 0, Y = 0, Z = 0; };
+struct Vector4 { float X = 0, Y = 0, Z = 0, W = 0; };
+
+// .NET exception types the reference throws on these paths
+struct InvalidOperationException : std::runtime_error { using std::runtime_error::runtime_error; };
+struct ArgumentException : std::invalid_argument { using std::invalid_argument::invalid_argument; };
+// anything the native layer reports (hipError_t or ILM_ERR_*)
+struct NativeException : std::runtime_error {
+    int Code;
+    NativeException(int code, const std::string& what) : std::runtime_error(what), Code(code) {}
+};
+void ThrowIfFailed(int32_t code);
+
+// Stand-in for Squared.CoreCLR.Xoshiro (Fracture, not in the reference tree): xoshiro256** seeded through
+// SplitMix64.  Every draw the reference makes from its RNG is an explicit value at the C ABI, so the
+// generator only has to be deterministic, not identical.
+class Xoshiro {
+public:
+    explicit Xoshiro(uint64_t seed = 0x1234567ull);
+    uint64_t NextUInt64();
+    double NextDouble();   // [0, 1)
+private:
+    uint64_t s[4];
+};
+
+struct ITimeProvider {
+    virtual ~ITimeProvider() {}
+    virtual double Seconds() = 0;
+};
+class ManualTimeProvider : public ITimeProvider {
+public:
+    double Now = 0;
+    double Seconds() override { return Now; }
+    void Advance(double dt) { Now += dt; }
+};
+
+// One GPU context (replaces the RenderCoordinator / GraphicsDevice the reference threads through)
+class DeviceContext {
+public:
+    explicit DeviceContext(int deviceId = 0);
+    ~DeviceContext();
+    DeviceContext(const DeviceContext&) = delete;
+    IlmHandle Handle() const { return handle; }
+    void Sync();
+    void TimerStart();
+    float TimerStop();
+private:
+    IlmHandle handle = 0;
+};
+
+// ---- SDF/DistanceField.cs ---------------------------------------------------------------------------
+class DistanceField {
+public:
+    static constexpr int MaxSurfaceSize = 8192;                    // :19
+    static constexpr int DefaultMaximumEncodedDistance = 128;      // :20
+    static constexpr int PackedSliceCount = 3;                     // LightingRenderer.PackedSliceCount
+
+    // ctor, :43-122 (layout math only; the atlas itself is uploaded with Load)
+    DistanceField(DeviceContext& ctx, int virtualWidth, int virtualHeight, float virtualDepth, int requestedSliceCount,
+                  double requestedResolution = 1, int maximumEncodedDistance = DefaultMaximumEncodedDistance,
+                  int format = ILM_SDF_UNORM16);
+    ~DistanceField();
+    DistanceField(const DistanceField&) = delete;
+
+    int VirtualWidth, VirtualHeight;
+    float VirtualDepth;
+    double Resolution, RequestedResolution;
+    int MaximumEncodedDistance;
+    int SliceWidth, SliceHeight, SliceCount, PhysicalSliceCount, ColumnCount, RowCount;
+    int TextureWidth, TextureHeight;
+    float ZOffset = 0;
+    int ValidSliceCount = 0;   // SliceInfo.ValidSliceCount
+
+    // Load, :196-213: raw RGBA16 atlas, 8 bytes per texel; marks every slice valid
+    void Load(const uint16_t* texels);
+    IlmHandle Texture() const { return texture; }
+    // Uniforms.DistanceField ctor, Uniforms.cs:90-110
+    IlmDistanceFieldUniforms GetUniforms() const;
+private:
+    IlmHandle texture = 0;
+};
+
+namespace Particles {
+
+class ParticleSystem;
+
+// ParticleEngine.cs:616-696
+struct ParticleEngineConfiguration {
+    int ChunkSize = 256;
+    ITimeProvider* TimeProvider = nullptr;
+    std::optional<int> UpdatesPerSecond;
+    double MaximumUpdateDeltaTimeSeconds = 1.0 / 20;
+    bool AccurateLivenessCounts = true;
+    explicit ParticleEngineConfiguration(int chunkSize = 256) : ChunkSize(chunkSize) {}
+};
+
+// ParticleEngine.cs:24-141
+class ParticleEngine {
+public:
+    static constexpr int RandomnessTextureWidth = 807, RandomnessTextureHeight = 653;   // :45-46
+    // The reference fills the randomness texture from an unseeded RNG (:495-544); it is an input here.
+    ParticleEngine(DeviceContext& ctx, const ParticleEngineConfiguration& configuration, const float* randomnessTexels);
+    ~ParticleEngine();
+    ParticleEngine(const ParticleEngine&) = delete;
+    DeviceContext& Context;
+    ParticleEngineConfiguration Configuration;
+    IlmHandle Handle() const { return handle; }
+private:
+    IlmHandle handle = 0;
+};
+
+// Bezier.cs BezierF / Bezier4 reduced to what ClampedBezier1/4 consume (Bezier.cs:442-460, 741-757)
+struct BezierF { int Count = 1; int Mode = 0; float MinValue = 0, MaxValue = 1; float A = 1, B = 1, C = 1, D = 1; };
+struct Bezier4 { int Count = 1; int Mode = 0; float MinValue = 0, MaxValue = 1; Vector4 A{1, 1, 1, 1}, B{1, 1, 1, 1}, C{1, 1, 1, 1}, D{1, 1, 1, 1}; };
+IlmClampedBezier1 MakeClampedBezier1(const std::optional<BezierF>& src);
+IlmClampedBezier4 MakeClampedBezier4(const std::optional<Bezier4>& src);
+
+// ParticleConfiguration.cs:13-39
+struct ParticleCollision {
+    DistanceField* Field = nullptr;                  // DistanceField
+    std::optional<float> DistanceFieldMaximumZ;
+    float Distance = 0.33f, LifePenalty = 0, EscapeVelocity = 128.0f, BounceVelocityMultiplier = 0.0f;
+};
+// ParticleConfiguration.cs ParticleColor
+struct ParticleColor {
+    std::optional<float> OpacityFromLife;
+    std::optional<Bezier4> ColorFromLife, ColorFromVelocity;
+};
+// ParticleConfiguration.cs:187-303 (the members the update path reads)
+struct ParticleSystemConfiguration {
+    Vector2 Size{1, 1};
+    float Friction = 0, MaximumVelocity = 9999.0f, LifeDecayPerSecond = 1;
+    std::optional<ParticleCollision> Collision;
+    ParticleColor Color;
+    std::optional<BezierF> SizeFromLife, SizeFromVelocity;
+    float RotationFromLife = 0, RotationFromIndex = 0;   // degrees
+    bool RotationFromVelocity = false;
+    float ZToY = 0;
+    ITimeProvider* TimeProvider = nullptr;
+};
+
+namespace Transforms {
+
+enum class AreaType { None = 0, Ellipsoid = 1, Box = 2, Cylinder = 3, Spheroid = 4, Octagon = 5 };
+struct TransformArea {   // ParticleTransform.cs TransformArea
+    AreaType Type = AreaType::None;
+    Vector3 Center, Size{1, 1, 1};
+    float Falloff = 1, Rotation = 0;
+};
+
+// ParticleTransform.cs:58-292
+class ParticleTransform {
+public:
+    virtual ~ParticleTransform() {}
+    bool IsActive = true, IsActive2 = true;
+    std::string Label;
+    virtual bool IsValid() const = 0;
+    virtual bool IsSpawner() const { return false; }
+    virtual void Reset() {}
+    // the SetParameters half that fills the native op (false => not representable as an op)
+    virtual bool FillOp(IlmTransformOp& op, double now) { (void)op; (void)now; return false; }
+};
+
+// ParticleTransform.cs:294-326
+class ParticleAreaTransform : public ParticleTransform {
+public:
+    float Strength = 1;
+    std::optional<Vector2> CategoryFilter;
+    std::optional<TransformArea> Area;
+    bool IsValid() const override { return true; }
+protected:
+    void FillArea(IlmAreaParams& a) const;
+};
+
+// Transforms.cs:16-50
+class FMA : public ParticleAreaTransform {
+public:
+    struct FMAParameters { Vector3 Add{0, 0, 0}, Multiply{1, 1, 1}; };
+    std::optional<float> CyclesPerSecond = 10.0f;
+    FMAParameters Position, Velocity;
+    bool FillOp(IlmTransformOp& op, double now) override;
+};
+
+// Transforms.cs:133-273
+class Noise : public ParticleAreaTransform {
+public:
+    static constexpr float IntervalUnit = 1000;
+    struct P4 { Vector4 Offset{-0.5f, -0.5f, -0.5f, -0.5f}, Minimum{0, 0, 0, 0}, Scale{0, 0, 0, 0}; };
+    struct P3 { Vector3 Offset{-0.5f, -0.5f, -0.5f}, Minimum{0, 0, 0}, Scale{1, 1, 1}; };
+    struct PF { float Offset = -0.5f, Minimum = 0, Scale = 0; };
+    std::optional<float> CyclesPerSecond = 10.0f;
+    P4 Position;
+    P3 Velocity;
+    PF Speed;
+    float Interval = IntervalUnit;   // milliseconds
+    bool ReplaceOldVelocity = true;
+    explicit Noise(uint64_t seed = 1);
+    void Reset() override;
+    bool FillOp(IlmTransformOp& op, double now) override;
+    double CurrentU = 0, CurrentV = 0, NextU = 0, NextV = 0;
+private:
+    void CycleUVs();
+    void AutoCycleUV(float now, double intervalSecs, float& t);
+    double LastUChangeWhen = 0;
+    Xoshiro RNG;
+};
+
+// Transforms.cs:275-372
+enum class AttractorType { Physical = 0, Linear = 1, Exponential = 2 };
+class Gravity : public ParticleTransform {
+public:
+    static constexpr int MaxAttractors = 16;
+    struct Attractor { Vector3 Position; float Radius = 1, Strength = 1; AttractorType Type = AttractorType::Linear; };
+    float MaximumAcceleration = 8;
+    std::vector<Attractor> Attractors;
+    // The reference never binds CategoryFilter for Gravity (it derives from ParticleTransform): the effect default
+    // (0, 0) applies, i.e. only category-0 particles are attracted.  Kept explicit so the quirk is visible.
+    Vector2 CategoryFilter{0, 0};
+    bool IsValid() const override { return !Attractors.empty(); }
+    bool FillOp(IlmTransformOp& op, double now) override;
+};
+
+enum class FormulaType { Linear = 0, Spherical = 1, Towards = 2, Rectangular = 3 };
+struct Formula1 { float Constant = 0, RandomScale = 0, Offset = 0; };
+struct Formula3 {
+    Vector3 Constant, RandomScale, Offset;
+    FormulaType Type = FormulaType::Linear;
+    bool Circular() const { return Type == FormulaType::Spherical || Type == FormulaType::Rectangular; }
+    static Formula3 UnitNormal() { Formula3 f; f.RandomScale = {1, 1, 1}; f.Type = FormulaType::Spherical; return f; }   // Formula.cs UnitNormal
+};
+struct Formula4 { Vector4 Constant{1, 1, 1, 1}, RandomScale, Offset; };
+
+// ParticleSpawner.cs:16-260
+class SpawnerBase : public ParticleTransform {
+public:
+    float MinRate = 0, MaxRate = 0;
+    std::optional<int> MaximumTotal;
+    Formula3 Position = Formula3::UnitNormal();
+    IlmMatrix PositionPostMatrix, VelocityPostMatrix;
+    bool AlignVelocityAndPosition = false;
+    Vector3 AxisMask{1, 1, 1};
+    Formula3 Velocity = Formula3::UnitNormal();
+    Formula1 Life{1, 0, 0};
+    Formula1 Category{0, 0, 0};
+    Formula4 Color;
+    float AlphaDiscardThreshold = 1;
+
+    explicit SpawnerBase(uint64_t seed = 1);
+    bool IsSpawner() const override { return true; }
+    bool IsValid() const override { return true; }
+    void Reset() override { RateError = 0; totalSpawned = 0; }
+    int TotalSpawned() const { return totalSpawned; }
+    double RateError = 0;
+
+    virtual bool PartialSpawnAllowed() const { return true; }
+    virtual int CountScale() const { return 1; }
+    // :152-189
+    virtual void BeginTick(double now, double deltaTimeSeconds, int& spawnCount);
+    // :191-194
+    void EndTick(int requestedSpawnCount, int actualSpawnCount);
+    void SetIndices(int first, int last) { indexFirst = first; indexLast = last; }
+    // :200-256
+    virtual void FillSpawn(IlmSpawnParams& p, int chunkSize, double now);
+    // :142-150
+    float EstimateMaximumLifeForNewParticle() const;
+protected:
+    int indexFirst = 0, indexLast = 0, totalSpawned = 0;
+    Xoshiro RNG;
+};
+
+// ParticleSpawner.cs:262-419
+class Spawner : public SpawnerBase {
+public:
+    static constexpr int MaxInlinePositions = 4;
+    std::vector<Vector3> AdditionalPositions;
+    std::optional<float> PolygonRate;
+    bool PolygonLoop = true;
+    Formula1 VelocityAlongPolygon{0, 0, 0};
+    bool RatePerPosition = true;
+    explicit Spawner(uint64_t seed = 1) : SpawnerBase(seed) {}
+    int CountScale() const override;
+    void FillSpawn(IlmSpawnParams& p, int chunkSize, double now) override;
+};
+
+}  // namespace Transforms
+
+// ParticleSystem.cs:48-1072 (update path), ParticleSpawning.cs, ParticleLiveness.cs
+class ParticleSystem {
+public:
+    static constexpr int MaxChunkCount = 64;             // ParticleSystem.cs:49
+    static constexpr int LivenessCheckInterval = 4;      // ParticleLiveness.cs:14
+    int DeadFrameThreshold = LivenessCheckInterval * 4;  // ParticleLiveness.cs:22
+    // true: wait for the liveness counts at the next Update (deterministic, for tests); false: poll them without
+    // stalling the stream, as the reference's LivenessDataReadbackWorkItem does (ParticleWorkItems.cs:98-135)
+    bool BlockingLivenessReadback = false;
+
+    struct Chunk {   // ParticleSystem.cs:148-240
+        int ID = 0;
+        int NextSpawnOffset = 0, TotalSpawned = 0;
+        bool NoLongerASpawnTarget = false;
+        float ApproximateMaximumLife = 0;
+        // LivenessInfo, ParticleLiveness.cs:24-28
+        std::optional<int> Count;
+        int DeadFrameCount = 0;
+    };
+    // UpdateResult, ParticleSystem.cs:51-71
+    struct UpdateResult { bool PerformedUpdate = false; float Timestamp = 0; };
+
+    ParticleSystem(ParticleEngine& engine, const ParticleSystemConfiguration& configuration);
+    ~ParticleSystem();
+    ParticleSystem(const ParticleSystem&) = delete;
+
+    ParticleEngine& Engine;
+    ParticleSystemConfiguration Configuration;
+    std::vector<Transforms::ParticleTransform*> Transforms;   // not owned
+    int LiveCount = 0;
+    int Capacity() const { return (int)chunks.size() * ChunkMaximumCount(); }
+    int ChunkMaximumCount() const { return Engine.Configuration.ChunkSize * Engine.Configuration.ChunkSize; }
+    const std::vector<Chunk>& Chunks() const { return chunks; }
+    long TotalSpawnCount = 0;
+
+    // Spawn(particleCount, initializers), ParticleSpawning.cs:61-113: whole new chunks filled from host arrays
+    // (position/velocity/color are float4 arrays of particleCount entries; color may be null => zeros).
+    int Spawn(int particleCount, const IlmFloat4* positions, const IlmFloat4* velocities, const IlmFloat4* colors);
+    // Update, ParticleSystem.cs:630-761.  frameIndex plays DeviceManager.FrameIndex.
+    UpdateResult Update(int frameIndex);
+    void Clear() { isClearPending = true; }   // ParticleSystem.cs:1000-1003
+    // AutoReadback / ReadbackResult (ParticleReadback.cs:21-71) reduced to a synchronous plane download
+    void Readback(int chunkIndex, int plane, IlmFloat4* dst) const;
+    IlmHandle Handle() const { return handle; }
+    // the descriptor of the last launch (tests compare it with the oracle's step)
+    const IlmStepDesc& LastStep() const { return lastStep; }
+    double LastDeltaTimeSeconds = 0;
+
+private:
+    bool RunSpawner(Transforms::SpawnerBase& spawner, double deltaTimeSeconds, double now, bool isSecondPass,
+                    std::vector<IlmSpawnRecord>& records);
+    int PickTargetForSpawn(int count, bool& needClear, bool partialSpawnAllowed);
+    int CreateChunk();
+    void UpdateLiveCountAndReapDeadChunks();
+    void ProcessLatestLivenessInfo(Chunk& c);
+    void FillSystemUniforms(IlmStepDesc& d, double deltaTimeSeconds) const;
+    void Launch(const IlmStepDesc& d);
+
+    IlmHandle handle = 0;
+    std::vector<Chunk> chunks;
+    std::vector<int> chunksToReap;   // chunk IDs
+    int nextChunkId = 1;
+    int currentSpawnTarget = -1;
+    int currentFrameIndex = 0;
+    int lastFrameUpdated = -1;
+    int framesUntilNextLivenessCheck = 0;
+    bool livenessPending = false;
+    std::vector<int> livenessChunkIds;   // chunk IDs in table order when the pending count was issued
+    std::optional<double> lastUpdateTimeSeconds;
+    double updateErrorAccumulator = 0;
+    bool isClearPending = false;
+    IlmStepDesc lastStep;
+    ManualTimeProvider defaultTime;
+};
+
+}  // namespace Particles
+
+namespace Lighting {
+
+enum class LightSourceRampMode { Linear = 0, Exponential = 1, Constant = 2 };       // LightSource.cs
+enum class LightShadowFilter { None = -1, ShadowsOnly = 1, NoShadowsOnly = 0 };   // as packed into EvenMoreLightProperties.x
+
+// LightSource.cs:37-280 (SphereLightSource)
+struct SphereLightSource {
+    Vector3 Position;
+    float Radius = 0, RampLength = 1;
+    Vector4 Color{1, 1, 1, 1};
+    float Opacity = 1;
+    LightSourceRampMode RampMode = LightSourceRampMode::Linear;
+    bool CastsShadows = true;
+    float AmbientOcclusionRadius = 0, AmbientOcclusionOpacity = 1;
+    std::optional<float> ShadowDistanceFalloff;
+    float FalloffYFactor = 1;
+    int ShadowFilter = -1;
+    Vector3 SpecularColor{0, 0, 0};
+    float SpecularPower = 1;
+};
+
+// LightingEnvironment.cs:13-49
+struct LightingEnvironment {
+    std::vector<SphereLightSource> Lights;
+    float GroundZ = 0, MaximumZ = 128, ZToYMultiplier = 0;
+    Vector4 Ambient{0, 0, 0, 1};
+};
+
+// LightingRenderer.Configuration.cs:254-291
+struct RendererQualitySettings {
+    float MinStepSize = 3.0f, LongStepFactor = 1.0f;
+    int MaxStepCount = 64;
+    float MaxConeRadius = 24, ConeGrowthFactor = 1.0f, OcclusionToOpacityPower = 1;
+};
+
+// LightingRenderer.Configuration.cs:13-250 (members the sphere-light pass reads)
+struct RendererConfiguration {
+    int RenderWidth, RenderHeight;
+    bool HighQuality = true;          // HalfVector4 lightmap (:206); false => Color
+    bool TwoPointFiveD = false;
+    float LightOcclusion = 0;
+    Vector2 RenderScale{1, 1};
+    RendererQualitySettings DefaultQuality;
+    bool FloatLightmap = false;       // extension: fp32 lightmap (parity format)
+    RendererConfiguration(int w, int h) : RenderWidth(w), RenderHeight(h) {}
+};
+
+// LightingRenderer.cs (RenderLighting path only)
+class LightingRenderer {
+public:
+    // externalLightmap: optional caller-owned device memory for the lightmap (e.g. a tensor RCCL all-gathers)
+    LightingRenderer(DeviceContext& ctx, const RendererConfiguration& configuration, LightingEnvironment* environment,
+                     void* externalLightmap = nullptr);
+    ~LightingRenderer();
+    LightingRenderer(const LightingRenderer&) = delete;
+
+    DeviceContext& Context;
+    RendererConfiguration Configuration;
+    LightingEnvironment* Environment;
+    DistanceField* Field = nullptr;       // DistanceField property, :594-607
+    // G-buffer: null => ground plane only
+    void SetGBuffer(const void* texels, int width, int height, int format);
+
+    // RenderLighting, :917-1191: clears to Ambient * intensityScale and adds every sphere light.
+    // [rowBegin, rowEnd) restricts the pass to a screen strip (multi-GPU split); rowEnd < 0 => whole frame.
+    void RenderLighting(float intensityScale = 1.0f, int rowBegin = 0, int rowEnd = -1, IlmRenderStats* stats = nullptr);
+    // lightmap readback (RenderedLighting.Resolve is out of scope)
+    void ReadLightmap(void* dst, int firstRow, int rowCount) const;
+    IlmHandle Lightmap() const { return lightmap; }
+    int LightmapFormat() const { return lightmapFormat; }
+
+    // RenderSphereLightSource, :1193-1219
+    static bool PackSphereLight(const SphereLightSource& l, float intensityScale, bool haveDistanceField, IlmLightVertex& v);
+    // SetDistanceFieldParameters, :1894-1940
+    IlmDistanceFieldUniforms GetDistanceFieldUniforms(const RendererQualitySettings& q) const;
+    // ComputeUniforms :691-701 + SetGBufferParameters LightingRenderer.GBuffer.cs:520-534
+    IlmEnvironment GetEnvironmentUniforms() const;
+
+private:
+    IlmHandle lightmap = 0, gbuffer = 0;
+    int lightmapFormat = ILM_LIGHTMAP_HALF4;
+    int gbufferWidth = 0, gbufferHeight = 0;
+    std::vector<IlmLightVertex> vertices;
+};
+
+}  // namespace Lighting
+}  // namespace Illuminant
+}  // namespace Squared

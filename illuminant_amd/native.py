@@ -58,6 +58,7 @@ SYMBOLS = {
     "ilm_erase": (_I, [_H, _I]),
     "ilm_system_live_counts": (_I, [_H, _P, _I, _I]),
     "ilm_system_step_counts": (_I, [_H, _P, _I, _I]),
+    "ilm_system_poll_counts": (_I, [_H, _P, _I, _I, C.POINTER(_I)]),
     "ilm_chunk_live_slots": (_I, [_H, _I, _P, _I, C.POINTER(_I)]),
     "ilm_sdf_create": (_I, [_H, _I, _I, _I, C.POINTER(_H)]),
     "ilm_sdf_upload": (_I, [_H, _P]),
@@ -237,6 +238,14 @@ class System:
         out = np.zeros(max(n, 1), dtype=np.uint32)
         check(lib().ilm_system_step_counts(self.handle, _ptr(out), out.shape[0], 1 if saturate16 else 0))
         return out[:n]
+
+    def poll_counts(self, saturate16=False):
+        """Non-blocking: returns the counts of the last counting step, or None while the GPU is still busy."""
+        n = self.chunk_count()
+        out = np.zeros(max(n, 1), dtype=np.uint32)
+        ready = C.c_int32()
+        check(lib().ilm_system_poll_counts(self.handle, _ptr(out), out.shape[0], 1 if saturate16 else 0, C.byref(ready)))
+        return out[:n] if ready.value else None
 
     def live_slots(self, chunk):
         out = np.zeros(self.engine.slots, dtype=np.uint32)

@@ -350,6 +350,11 @@ int32_t ilm_system_live_counts(IlmHandle system, uint32_t* out_counts, int32_t c
  * (the ballot/popcount reduction fused into the update kernel); synchronises. */
 int32_t ilm_system_step_counts(IlmHandle system, uint32_t* out_counts, int32_t capacity, int32_t saturate16);
 
+/* Non-blocking form (the reference reads liveness back a frame or more later through
+ * LivenessDataReadbackWorkItem, ParticleWorkItems.cs:98-135): *out_ready = 1 and the counts are
+ * written when the last counting step has finished on the GPU, else *out_ready = 0. */
+int32_t ilm_system_poll_counts(IlmHandle system, uint32_t* out_counts, int32_t capacity, int32_t saturate16, int32_t* out_ready);
+
 /* Ordered live-slot list of one chunk (wave64 ballot + prefix sum): writes the
  * ascending slot indices with life > 0 to `out_slots` (host, capacity entries)
  * and their number to out_count.  Consumer: particle lights (ParticleLight.fx). */

@@ -1,0 +1,82 @@
+"""Quick on-GPU timing probe of the two hot kernels (development aid, not the contract bench)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from illuminant_amd import abi, native, scenes
+
+def particles(ctx, cs=256, n_chunks=16, steps=50, spawn=True):
+    rnd = scenes.randomness_table(7)
+    eng = native.Engine(ctx, cs, rnd); sysm = native.System(eng)
+    n = cs * cs
+    for c in range(n_chunks):
+        sysm.add_chunk()
+        pos, vel, attr = scenes.make_particles(10 + c, n, pos_lo=(0, 0, 0), pos_hi=(1920, 1080, 32), life=(50.0, 90.0))
+        sysm.upload(c, abi.PLANE_POSITION, pos); sysm.upload(c, abi.PLANE_VELOCITY, vel); sysm.upload(c, abi.PLANE_ATTRIBUTES, attr)
+    tgt = sysm.add_chunk() if spawn else -1
+    d = abi.StepDesc(); d.FirstChunk, d.ChunkCount = 0, -1
+    d.System = scenes.system_uniforms(cs, friction=0.02, max_velocity=2048.0, life_decay=0.01)
+    d.Update = abi.UpdateParams.default(); d.UpdateMode = abi.UPDATE_POSITIONS
+    d.OpCount = 2
+    d.Ops[0].Type = abi.OP_GRAVITY
+    d.Ops[0].u.Gravity = scenes.gravity_params([((400., 300., 0.), 70., 600., 1), ((1500., 300., 0.), 150., 900., 1),
+                                                ((400., 800., 0.), 200., 1200., 1), ((1500., 800., 0.), 100., 1500., 1)], 1024.0)
+    d.Ops[1].Type = abi.OP_NOISE
+    d.Ops[1].u.Noise = scenes.noise_params(scenes.area_none(), (0.37 * 253, 0.81 * 127), (0.12 * 253, 0.55 * 127), 0.35)
+    import ctypes
+    descs = []
+    first = 0
+    for i in range(steps + 5):
+        dd = abi.StepDesc(); ctypes.memmove(ctypes.byref(dd), ctypes.byref(d), ctypes.sizeof(d))
+        if spawn:
+            dd.SpawnCount = 1; dd.Spawns[0].ChunkIndex = tgt
+            dd.Spawns[0].Params = scenes.spawn_params(cs, first, first + 1091, first, (0.42 * 253, 0.77 * 127),
+                position=((960, 540, 0), (900, 450, 0), (0, 0, 0), 1), velocity=((0, 0, 0), (60, 60, 60), (0, 0, 0), 1), life=(50.0, 2.7, 0))
+            first = (first + 1092) % (n - 1092)
+        descs.append(dd)
+    it = iter(descs)
+    def step():
+        sysm.step(next(it))
+    for _ in range(5): step()
+    ctx.sync()
+    t0 = time.perf_counter(); ctx.timer_start()
+    for _ in range(steps): step()
+    ms = ctx.timer_stop(); wall = (time.perf_counter() - t0) * 1e3
+    slots = n * (n_chunks + (1 if spawn else 0))
+    live = n * n_chunks
+    print("particles cs=%d chunks=%d: %.3f ms/step gpu (%.3f wall)  %.1f Mslot-steps/s  live-bytes %.2f TB/s" %
+          (cs, n_chunks, ms / steps, wall / steps, live * steps / ms / 1e3, live * 112 * steps / ms / 1e9))
+    sysm.close(); eng.close()
+
+def lighting(ctx, w=1920, h=1080, n_lights=64, res=0.25, frames=5, fmt=abi.SDF_UNORM16, world=2048):
+    layout = scenes.DistanceFieldLayout(world, world, 128.0, 32, res, 128)
+    t = time.time()
+    atlas = scenes.build_sdf_atlas(layout, scenes.random_obstacles(11, 256, (world, world)), fmt=fmt)
+    print("atlas %dx%d built in %.1fs" % (layout.atlas_width, layout.atlas_height, time.time() - t))
+    dfu = layout.uniforms(max_cone_radius=24.0, power=0.7, step_limit=64, min_step_size=1.0, long_step_factor=0.5)
+    sc = w / 1920.0
+    lights = scenes.random_lights(12, n_lights, w, h, z=(8.0, 64.0), radius=24.0, ramp=(200.0 * sc, 550.0 * sc))
+    env = scenes.environment()
+    sdf = native.DistanceFieldTexture(ctx, atlas, fmt)
+    lm = native.Lightmap(ctx, w, h, abi.LIGHTMAP_HALF4)
+    st = native.render_sphere_lights(ctx, lights, env, dfu, None, sdf, (0.05, 0.05, 0.05, 1), lm, want_stats=True)
+    ctx.sync()
+    ctx.timer_start()
+    for _ in range(frames):
+        native.render_sphere_lights(ctx, lights, env, dfu, None, sdf, (0.05, 0.05, 0.05, 1), lm)
+    ms = ctx.timer_stop() / frames
+    print("lighting %dx%d %d lights: %.3f ms/frame  %.1f Mpx/s  samples %.3g (%.1f/px) pairs %.3g traced %.3g  algorithmic %.2f TB/s" %
+          (w, h, n_lights, ms, w * h / ms / 1e3, st.SdfSamples, st.SdfSamples / (w * h), st.PixelLightPairs, st.TracedPairs,
+           (st.SdfSamples * 32 + w * h * 8) / ms / 1e9))
+    lm.close(); sdf.close()
+
+if __name__ == "__main__":
+    ctx = native.Context(0)
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what in ("all", "p"):
+        particles(ctx, 256, 16, 100, True)
+        particles(ctx, 256, 16, 100, False)
+        particles(ctx, 1024, 8, 20, False)
+    if what in ("all", "l"):
+        lighting(ctx, 1920, 1080, 64, 0.25)
+        lighting(ctx, 3840, 2160, 256, 0.125, frames=2, fmt=abi.SDF_FP16, world=4096)
+    ctx.close()

@@ -1,0 +1,69 @@
+// Micro-benchmark: what does the memory path allow for the particle step's access pattern?
+//   mode 0: 12 dword loads + 16 dword stores per lane (one slot per lane, SoA planes)       [the step kernel's pattern]
+//   mode 1: same bytes with 16-byte accesses (4 slots per lane)
+//   mode 2: AoS float4: 3 x 16 B loads + 4 x 16 B stores per slot (one slot per lane)
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+typedef float __attribute__((address_space(1))) gfloat;
+typedef float __attribute__((ext_vector_type(4))) vf4;
+typedef vf4 __attribute__((address_space(1))) gvf4;
+
+__global__ __launch_bounds__(256) void k_dword(float* b, long S, int alu) {
+    gfloat* base = (gfloat*)b;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    float v[12];
+#pragma unroll
+    for (int c = 0; c < 12; c++) v[c] = base[c * S + i];
+    float acc = 0;
+#pragma unroll
+    for (int c = 0; c < 12; c++) acc += v[c];
+    for (int k = 0; k < alu; k++) acc = acc * 1.0001f + 0.5f;
+#pragma unroll
+    for (int c = 0; c < 8; c++) base[c * S + i] = v[c] + acc;
+#pragma unroll
+    for (int c = 12; c < 20; c++) base[c * S + i] = acc;
+}
+__global__ __launch_bounds__(256) void k_x4(float* b, long S, int alu) {
+    gfloat* base = (gfloat*)b;
+    long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    vf4 v[12];
+#pragma unroll
+    for (int c = 0; c < 12; c++) v[c] = *(const gvf4*)(base + c * S + i);
+    float acc = 0;
+#pragma unroll
+    for (int c = 0; c < 12; c++) acc += v[c].x + v[c].y + v[c].z + v[c].w;
+    for (int k = 0; k < alu; k++) acc = acc * 1.0001f + 0.5f;
+#pragma unroll
+    for (int c = 0; c < 8; c++) { vf4 o = v[c]; o.x += acc; *(gvf4*)(base + c * S + i) = o; }
+#pragma unroll
+    for (int c = 12; c < 20; c++) { vf4 o = {acc, acc, acc, acc}; *(gvf4*)(base + c * S + i) = o; }
+}
+__global__ __launch_bounds__(256) void k_aos(float4* b, long N, int alu) {
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    float4 p = b[i], v = b[N + i], a = b[2 * N + i];
+    float acc = p.x + v.y + a.z;
+    for (int k = 0; k < alu; k++) acc = acc * 1.0001f + 0.5f;
+    b[i] = make_float4(p.x + acc, p.y, p.z, p.w); b[N + i] = make_float4(v.x + acc, v.y, v.z, v.w);
+    b[3 * N + i] = make_float4(acc, acc, acc, acc); b[4 * N + i] = make_float4(acc, acc, acc, acc);
+}
+int main(int argc, char** argv) {
+    long N = argc > 1 ? atol(argv[1]) : (1 << 20);
+    int alu = argc > 2 ? atoi(argv[2]) : 0;
+    float* d; CK(hipMalloc(&d, sizeof(float) * 20 * N)); CK(hipMemset(d, 0, sizeof(float) * 20 * N));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int mode = 0; mode < 3; mode++) {
+        const int reps = 50;
+        for (int r = 0; r < reps + 5; r++) {
+            if (r == 5) CK(hipEventRecord(e0));
+            if (mode == 0) hipLaunchKernelGGL(k_dword, dim3(N / 256), dim3(256), 0, 0, d, N, alu);
+            else if (mode == 1) hipLaunchKernelGGL(k_x4, dim3(N / 1024), dim3(256), 0, 0, d, N, alu);
+            else hipLaunchKernelGGL(k_aos, dim3(N / 256), dim3(256), 0, 0, (float4*)d, N, alu);
+        }
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+        printf("N=%ld alu=%d mode=%d: %.2f us  %.2f TB/s (112 B/slot)\n", N, alu, mode, ms * 1e3, N * 112.0 / ms / 1e9);
+    }
+    return 0;
+}
