@@ -131,7 +131,7 @@ def main():
         torch.cuda.set_device(local_rank)
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    from illuminant_amd import abi, native, scenes
+    from illuminant_amd import abi, native, scenes, sharding
     from illuminant_amd import _host as H
 
     if native.device_count() <= 0:
@@ -201,16 +201,14 @@ def main():
         lighting = {}
         for name, (w, h, nl, res, wsize, fmt) in (("cfg3_1080p_64_lights_unorm16", (1920, 1080, 64, 0.25, 2048, abi.SDF_UNORM16)),
                                                    ("cfg5_4k_256_lights_fp16", (3840, 2160, 256, 0.125, 4096, abi.SDF_FP16))):
-            # screen split into `world` row strips; with RCCL the lightmap lives in a torch tensor so
-            # the strips can be all-gathered in place over xGMI without a copy
-            rows = h // world
-            row_begin, row_end = rank * rows, (rank + 1) * rows if rank < world - 1 else h
-            full = strip = gather_buf = None
+            # screen split into `world` equal strips of whole 16-row tile bands (illuminant_amd/sharding.py);
+            # with RCCL the lightmap lives in a torch tensor so the strips are all-gathered in place over xGMI
+            R, strips = sharding.padded_row_strips(h, world)
+            row_begin, row_end = strips[rank]
+            full = None
             ext = 0
             if dist is not None:
-                full = torch.zeros((h, w, 4), dtype=torch.float16, device="cuda")
-                gather_buf = torch.empty((world * rows, w, 4), dtype=torch.float16, device="cuda")
-                strip = full[row_begin:row_begin + rows]
+                full = torch.zeros((world * R, w, 4), dtype=torch.float16, device="cuda")   # frame = first h rows
                 ext = full.data_ptr()
             L = build_lighting(H, ctx, scenes, abi, w, h, nl, res, wsize, fmt, ext)
             r = L["renderer"]
@@ -223,7 +221,7 @@ def main():
                 r.RenderLighting(1.0, row_begin, row_end, False)
                 if dist is not None:
                     ctx.Sync()                                   # render stream -> RCCL stream hand-off
-                    dist.all_gather_into_tensor(gather_buf, strip)
+                    sharding.all_gather_rows(full, strips, rank, dist)
             gms = ctx.TimerStop()
             barrier()
             lwall = max_over_ranks(time.perf_counter() - t0)

@@ -45,7 +45,15 @@ PYBIND11_MODULE(_host, m) {
         .def("Sync", &DeviceContext::Sync).def("TimerStart", &DeviceContext::TimerStart).def("TimerStop", &DeviceContext::TimerStop)
         .def_property_readonly("Handle", &DeviceContext::Handle);
 
+    py::class_<DistanceField::Layout>(m, "DistanceFieldLayout")
+        .def_readonly("Resolution", &DistanceField::Layout::Resolution)
+        .def_readonly("SliceWidth", &DistanceField::Layout::SliceWidth).def_readonly("SliceHeight", &DistanceField::Layout::SliceHeight)
+        .def_readonly("SliceCount", &DistanceField::Layout::SliceCount).def_readonly("PhysicalSliceCount", &DistanceField::Layout::PhysicalSliceCount)
+        .def_readonly("ColumnCount", &DistanceField::Layout::ColumnCount).def_readonly("RowCount", &DistanceField::Layout::RowCount)
+        .def_readonly("TextureWidth", &DistanceField::Layout::TextureWidth).def_readonly("TextureHeight", &DistanceField::Layout::TextureHeight);
     py::class_<DistanceField>(m, "DistanceField")
+        .def_static("ComputeLayout", &DistanceField::ComputeLayout, py::arg("virtualWidth"), py::arg("virtualHeight"),
+                    py::arg("requestedSliceCount"), py::arg("requestedResolution") = 1.0)
         .def(py::init<DeviceContext&, int, int, float, int, double, int, int>(), py::arg("ctx"), py::arg("virtualWidth"), py::arg("virtualHeight"),
              py::arg("virtualDepth"), py::arg("requestedSliceCount"), py::arg("requestedResolution") = 1.0,
              py::arg("maximumEncodedDistance") = 128, py::arg("format") = 0, py::keep_alive<1, 2>())
@@ -173,6 +181,7 @@ PYBIND11_MODULE(_host, m) {
         VEC_PROP(SpawnerBase, AxisMask, 3)
         .def_readwrite("AlphaDiscardThreshold", &SpawnerBase::AlphaDiscardThreshold)
         .def_readwrite("RateError", &SpawnerBase::RateError)
+        .def_readwrite("ScriptedDraws", &SpawnerBase::ScriptedDraws)
         .def_property_readonly("TotalSpawned", &SpawnerBase::TotalSpawned)
         .def("BeginTick", [](SpawnerBase& s, double now, double dt) { int n = 0; s.BeginTick(now, dt, n); return n; })
         .def("EndTick", &SpawnerBase::EndTick);

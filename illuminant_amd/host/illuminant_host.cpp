@@ -46,47 +46,59 @@ float DeviceContext::TimerStop() { float ms = 0; ThrowIfFailed(ilm_timer_stop(ha
 // ---- DistanceField, SDF/DistanceField.cs:43-122 -------------------------------------------------------------
 static double RoundToEven(double v) { return std::nearbyint(v); }   // Math.Round: MidpointRounding.ToEven
 
+// The layout half of the constructor (:56-109): pure integer / double arithmetic, no device.
+DistanceField::Layout DistanceField::ComputeLayout(int virtualWidth, int virtualHeight, int requestedSliceCount, double requestedResolution) {
+    Layout L;
+    if (requestedResolution < 0.05) requestedResolution = 0.05;
+    else if (requestedResolution > 1) requestedResolution = 1;
+
+    const int candidateSliceWidth = (int)RoundToEven(virtualWidth * requestedResolution);
+    const int candidateSliceHeight = (int)RoundToEven(virtualHeight * requestedResolution);
+    const double fracX = (double)virtualWidth / candidateSliceWidth, fracY = (double)virtualHeight / candidateSliceHeight;
+    const double frac = (fracX + fracY) / 2;
+    double resolution = RoundToEven((1.0 / frac) * 1000.0) / 1000.0;   // Math.Round(x, 3)
+    if (resolution < 0.05) resolution = 0.05;
+    else if (resolution > 1) resolution = 1;
+    L.Resolution = resolution;
+
+    L.SliceWidth = (int)RoundToEven(virtualWidth * L.Resolution);
+    L.SliceHeight = (int)RoundToEven(virtualHeight * L.Resolution);
+    const int maxSlicesX = MaxSurfaceSize / L.SliceWidth, maxSlicesY = MaxSurfaceSize / L.SliceHeight;
+    const int maxSlices = maxSlicesX * maxSlicesY * PackedSliceCount;
+
+    int sliceCount = std::max(3, requestedSliceCount);
+    sliceCount = ((sliceCount + 2) / 3) * 3;
+    L.SliceCount = std::min(sliceCount, maxSlices);
+    L.PhysicalSliceCount = (int)std::ceil(L.SliceCount / (float)PackedSliceCount);
+
+    L.ColumnCount = std::min(maxSlicesX, L.PhysicalSliceCount);
+    L.RowCount = std::min(maxSlicesY, std::max((int)std::ceil(L.PhysicalSliceCount / (float)maxSlicesX), 1));
+    // "HACK: If the DF is going to be extremely wide but not tall, rebalance it" (:91-109)
+    while ((L.RowCount < L.ColumnCount) && (L.RowCount < maxSlicesY)) {
+        int newRowCount = L.RowCount + 1;
+        int newColumnCount = (int)std::ceil(L.PhysicalSliceCount / (float)newRowCount);
+        if (newRowCount > maxSlicesX) newRowCount = maxSlicesX;
+        if (newColumnCount > maxSlicesY) newColumnCount = maxSlicesY;
+        if ((newRowCount * newColumnCount) < L.PhysicalSliceCount) break;
+        L.RowCount = newRowCount;
+        L.ColumnCount = newColumnCount;
+    }
+    L.TextureWidth = L.SliceWidth * L.ColumnCount;
+    L.TextureHeight = L.SliceHeight * L.RowCount;
+    return L;
+}
+
 DistanceField::DistanceField(DeviceContext& ctx, int virtualWidth, int virtualHeight, float virtualDepth, int requestedSliceCount,
                              double requestedResolution, int maximumEncodedDistance, int format) {
     VirtualWidth = virtualWidth; VirtualHeight = virtualHeight; VirtualDepth = virtualDepth;
     MaximumEncodedDistance = maximumEncodedDistance;
     RequestedResolution = requestedResolution;
-    if (requestedResolution < 0.05) requestedResolution = 0.05;
-    else if (requestedResolution > 1) requestedResolution = 1;
-
-    const int candidateSliceWidth = (int)RoundToEven(VirtualWidth * requestedResolution);
-    const int candidateSliceHeight = (int)RoundToEven(VirtualHeight * requestedResolution);
-    const double fracX = (double)VirtualWidth / candidateSliceWidth, fracY = (double)VirtualHeight / candidateSliceHeight;
-    const double frac = (fracX + fracY) / 2;
-    double resolution = RoundToEven((1.0 / frac) * 1000.0) / 1000.0;   // Math.Round(x, 3)
-    if (resolution < 0.05) resolution = 0.05;
-    else if (resolution > 1) resolution = 1;
-    Resolution = resolution;
-
-    SliceWidth = (int)RoundToEven(VirtualWidth * Resolution);
-    SliceHeight = (int)RoundToEven(VirtualHeight * Resolution);
-    const int maxSlicesX = MaxSurfaceSize / SliceWidth, maxSlicesY = MaxSurfaceSize / SliceHeight;
-    const int maxSlices = maxSlicesX * maxSlicesY * PackedSliceCount;
-
-    int sliceCount = std::max(3, requestedSliceCount);
-    sliceCount = ((sliceCount + 2) / 3) * 3;
-    SliceCount = std::min(sliceCount, maxSlices);
-    PhysicalSliceCount = (int)std::ceil(SliceCount / (float)PackedSliceCount);
-
-    ColumnCount = std::min(maxSlicesX, PhysicalSliceCount);
-    RowCount = std::min(maxSlicesY, std::max((int)std::ceil(PhysicalSliceCount / (float)maxSlicesX), 1));
-    // "HACK: If the DF is going to be extremely wide but not tall, rebalance it" (:91-109)
-    while ((RowCount < ColumnCount) && (RowCount < maxSlicesY)) {
-        int newRowCount = RowCount + 1;
-        int newColumnCount = (int)std::ceil(PhysicalSliceCount / (float)newRowCount);
-        if (newRowCount > maxSlicesX) newRowCount = maxSlicesX;
-        if (newColumnCount > maxSlicesY) newColumnCount = maxSlicesY;
-        if ((newRowCount * newColumnCount) < PhysicalSliceCount) break;
-        RowCount = newRowCount;
-        ColumnCount = newColumnCount;
-    }
-    TextureWidth = SliceWidth * ColumnCount;
-    TextureHeight = SliceHeight * RowCount;
+    const Layout L = ComputeLayout(virtualWidth, virtualHeight, requestedSliceCount, requestedResolution);
+    Resolution = L.Resolution;
+    SliceWidth = L.SliceWidth; SliceHeight = L.SliceHeight;
+    SliceCount = L.SliceCount; PhysicalSliceCount = L.PhysicalSliceCount;
+    ColumnCount = L.ColumnCount; RowCount = L.RowCount;
+    TextureWidth = L.TextureWidth; TextureHeight = L.TextureHeight;
     ThrowIfFailed(ilm_sdf_create(ctx.Handle(), TextureWidth, TextureHeight, format, &texture));
 }
 DistanceField::~DistanceField() { if (texture) ilm_sdf_destroy(texture); }
@@ -254,7 +266,7 @@ void SpawnerBase::BeginTick(double, double deltaTimeSeconds, int& spawnCount) {
     float minRate = MinRate, maxRate = MaxRate;
     if (minRate > maxRate)
         minRate = maxRate;
-    double currentRate = ((RNG.NextDouble() * (maxRate - minRate)) + minRate) * countScaler * deltaTimeSeconds;
+    double currentRate = ((NextRateDraw() * (maxRate - minRate)) + minRate) * countScaler * deltaTimeSeconds;
     currentRate += RateError;
     RateError = 0;
     if (currentRate < 1) {
@@ -272,6 +284,15 @@ void SpawnerBase::BeginTick(double, double deltaTimeSeconds, int& spawnCount) {
             RateError = 0;
         }
     }
+}
+
+double SpawnerBase::NextRateDraw() {
+    if (!ScriptedDraws.empty()) {
+        const double d = ScriptedDraws.front();
+        ScriptedDraws.erase(ScriptedDraws.begin());
+        return d;
+    }
+    return RNG.NextDouble();
 }
 
 void SpawnerBase::EndTick(int requestedSpawnCount, int actualSpawnCount) {

@@ -104,6 +104,14 @@ public:
     float ZOffset = 0;
     int ValidSliceCount = 0;   // SliceInfo.ValidSliceCount
 
+    // :56-109 on their own (no device): what the constructor computes before it allocates the atlas
+    struct Layout {
+        double Resolution = 1;
+        int SliceWidth = 0, SliceHeight = 0, SliceCount = 0, PhysicalSliceCount = 0, ColumnCount = 0, RowCount = 0;
+        int TextureWidth = 0, TextureHeight = 0;
+    };
+    static Layout ComputeLayout(int virtualWidth, int virtualHeight, int requestedSliceCount, double requestedResolution = 1);
+
     // Load, :196-213: raw RGBA16 atlas, 8 bytes per texel; marks every slice valid
     void Load(const uint16_t* texels);
     IlmHandle Texture() const { return texture; }
@@ -284,6 +292,9 @@ public:
     void Reset() override { RateError = 0; totalSpawned = 0; }
     int TotalSpawned() const { return totalSpawned; }
     double RateError = 0;
+    // The reference draws the rate from an unseeded RNG (ParticleSpawner.cs:165); draws queued here are consumed
+    // first, in order, so a test can replay the exact sequence a fixture was derived for.
+    std::vector<double> ScriptedDraws;
 
     virtual bool PartialSpawnAllowed() const { return true; }
     virtual int CountScale() const { return 1; }
@@ -297,6 +308,7 @@ public:
     // :142-150
     float EstimateMaximumLifeForNewParticle() const;
 protected:
+    double NextRateDraw();
     int indexFirst = 0, indexLast = 0, totalSpawned = 0;
     Xoshiro RNG;
 };

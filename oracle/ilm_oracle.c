@@ -272,12 +272,19 @@ static void gravity_slot(f4* pos, f4* vel, const IlmParticleSystemUniforms* sys,
     vel->w = old_velocity.w;
 }
 
+/* rows [y0, y1) of one chunk; the passes are slot-local, so a band of rows can be taken through the whole
+ * pass list on its own (orc_step) without changing any result */
+static void gravity_rows(IlmFloat4* pos, IlmFloat4* vel, int32_t chunk_size, int y0, int y1,
+                         const IlmParticleSystemUniforms* sys, const IlmGravityParams* p) {
+    for (int i = y0 * chunk_size; i < y1 * chunk_size; i++)
+        gravity_slot(&pos[i], &vel[i], sys, p);
+}
+
 void orc_gravity(IlmFloat4* pos, IlmFloat4* vel, int32_t chunk_size,
                  const IlmParticleSystemUniforms* sys, const IlmGravityParams* p) {
-    const int n = chunk_size * chunk_size;
     #pragma omp parallel for schedule(static)
-    for (int i = 0; i < n; i++)
-        gravity_slot(&pos[i], &vel[i], sys, p);
+    for (int y = 0; y < chunk_size; y++)
+        gravity_rows(pos, vel, chunk_size, y, y + 1, sys, p);
 }
 
 /* ---------------------------------------------------------------------------
@@ -293,12 +300,17 @@ static void fma_slot(f4* pos, f4* vel, const IlmParticleSystemUniforms* sys, con
     *vel = v4lerp(old_velocity, v4add(v4mul(old_velocity, p->VelocityMultiply), p->VelocityAdd), t);
 }
 
+static void fma_rows(IlmFloat4* pos, IlmFloat4* vel, int32_t chunk_size, int y0, int y1,
+                     const IlmParticleSystemUniforms* sys, const IlmFMAParams* p) {
+    for (int i = y0 * chunk_size; i < y1 * chunk_size; i++)
+        fma_slot(&pos[i], &vel[i], sys, p);
+}
+
 void orc_fma(IlmFloat4* pos, IlmFloat4* vel, int32_t chunk_size,
              const IlmParticleSystemUniforms* sys, const IlmFMAParams* p) {
-    const int n = chunk_size * chunk_size;
     #pragma omp parallel for schedule(static)
-    for (int i = 0; i < n; i++)
-        fma_slot(&pos[i], &vel[i], sys, p);
+    for (int y = 0; y < chunk_size; y++)
+        fma_rows(pos, vel, chunk_size, y, y + 1, sys, p);
 }
 
 /* ---------------------------------------------------------------------------
@@ -346,13 +358,20 @@ static void noise_slot(f4* pos, f4* vel, float x, float y, const f4* rnd, int rw
     *vel = v4(nv.x, nv.y, nv.z, old_velocity.w);
 }
 
+static void noise_rows(IlmFloat4* pos, IlmFloat4* vel, int32_t chunk_size, int y0, int y1,
+                       const IlmFloat4* rnd, int32_t rw, int32_t rh,
+                       const IlmParticleSystemUniforms* sys, const IlmNoiseParams* p) {
+    for (int y = y0; y < y1; y++)
+        for (int x = 0; x < chunk_size; x++)
+            noise_slot(&pos[y * chunk_size + x], &vel[y * chunk_size + x], (float)x, (float)y, rnd, rw, rh, sys, p);
+}
+
 void orc_noise(IlmFloat4* pos, IlmFloat4* vel, int32_t chunk_size,
                const IlmFloat4* rnd, int32_t rw, int32_t rh,
                const IlmParticleSystemUniforms* sys, const IlmNoiseParams* p) {
     #pragma omp parallel for schedule(static)
     for (int y = 0; y < chunk_size; y++)
-        for (int x = 0; x < chunk_size; x++)
-            noise_slot(&pos[y * chunk_size + x], &vel[y * chunk_size + x], (float)x, (float)y, rnd, rw, rh, sys, p);
+        noise_rows(pos, vel, chunk_size, y, y + 1, rnd, rw, rh, sys, p);
 }
 
 /* ---------------------------------------------------------------------------
@@ -484,14 +503,20 @@ static void spawn_slot(f4* pos, f4* vel, f4* attr, float x, float y,
     *attr = new_attributes;
 }
 
-void orc_spawn(IlmFloat4* pos, IlmFloat4* vel, IlmFloat4* attr, int32_t chunk_size,
-               const IlmFloat4* rnd, int32_t rw, int32_t rh, const IlmSpawnParams* p) {
-    #pragma omp parallel for schedule(static)
-    for (int y = 0; y < chunk_size; y++)
+static void spawn_rows(IlmFloat4* pos, IlmFloat4* vel, IlmFloat4* attr, int32_t chunk_size, int y0, int y1,
+                       const IlmFloat4* rnd, int32_t rw, int32_t rh, const IlmSpawnParams* p) {
+    for (int y = y0; y < y1; y++)
         for (int x = 0; x < chunk_size; x++) {
             int i = y * chunk_size + x;
             spawn_slot(&pos[i], &vel[i], &attr[i], (float)x, (float)y, rnd, rw, rh, p);
         }
+}
+
+void orc_spawn(IlmFloat4* pos, IlmFloat4* vel, IlmFloat4* attr, int32_t chunk_size,
+               const IlmFloat4* rnd, int32_t rw, int32_t rh, const IlmSpawnParams* p) {
+    #pragma omp parallel for schedule(static)
+    for (int y = 0; y < chunk_size; y++)
+        spawn_rows(pos, vel, attr, chunk_size, y, y + 1, rnd, rw, rh, p);
 }
 
 /* ---------------------------------------------------------------------------
@@ -890,13 +915,12 @@ static void update_df_slot(f4* pos, f4* vel, const f4* attr, f4* rc, f4* rd, flo
     *vel = new_velocity;
 }
 
-void orc_update(IlmFloat4* pos, IlmFloat4* vel, const IlmFloat4* attr,
-                IlmFloat4* render_color, IlmFloat4* render_data, int32_t chunk_size,
-                const IlmParticleSystemUniforms* sys, const IlmUpdateParams* p,
-                const IlmFloat4* life_ramp, int32_t ramp_w, int32_t ramp_h,
-                const IlmDistanceFieldUniforms* df, const OrcTexture* sdf) {
-    #pragma omp parallel for schedule(static)
-    for (int y = 0; y < chunk_size; y++)
+static void update_rows(IlmFloat4* pos, IlmFloat4* vel, const IlmFloat4* attr,
+                        IlmFloat4* render_color, IlmFloat4* render_data, int32_t chunk_size, int y0, int y1,
+                        const IlmParticleSystemUniforms* sys, const IlmUpdateParams* p,
+                        const IlmFloat4* life_ramp, int32_t ramp_w, int32_t ramp_h,
+                        const IlmDistanceFieldUniforms* df, const OrcTexture* sdf) {
+    for (int y = y0; y < y1; y++)
         for (int x = 0; x < chunk_size; x++) {
             int i = y * chunk_size + x;
             if (df && sdf)
@@ -906,6 +930,16 @@ void orc_update(IlmFloat4* pos, IlmFloat4* vel, const IlmFloat4* attr,
                 update_slot(&pos[i], &vel[i], &attr[i], &render_color[i], &render_data[i], (float)x, (float)y,
                             sys, p, life_ramp, ramp_w, ramp_h);
         }
+}
+
+void orc_update(IlmFloat4* pos, IlmFloat4* vel, const IlmFloat4* attr,
+                IlmFloat4* render_color, IlmFloat4* render_data, int32_t chunk_size,
+                const IlmParticleSystemUniforms* sys, const IlmUpdateParams* p,
+                const IlmFloat4* life_ramp, int32_t ramp_w, int32_t ramp_h,
+                const IlmDistanceFieldUniforms* df, const OrcTexture* sdf) {
+    #pragma omp parallel for schedule(static)
+    for (int y = 0; y < chunk_size; y++)
+        update_rows(pos, vel, attr, render_color, render_data, chunk_size, y, y + 1, sys, p, life_ramp, ramp_w, ramp_h, df, sdf);
 }
 
 /* PS_Erase, UpdateParticleSystem.fx:40-49 */
@@ -924,45 +958,59 @@ uint32_t orc_count_live(const IlmFloat4* pos, int32_t slots, int32_t saturate16)
     return n;
 }
 
-/* ParticleSystem.Update pass order, ParticleSystem.cs:725-745 + UpdateChunk :791-856 */
+/* ParticleSystem.Update pass order, ParticleSystem.cs:725-745 + UpdateChunk :791-856.
+ * Every pass is slot-local (a slot reads only its own previous state, the randomness table and the SDF),
+ * so the chunk table is cut into bands of rows and each band goes through spawn -> transforms -> update on
+ * its own: same per-slot pass order as the reference's chunk-at-a-time draws, one OpenMP region per step. */
 void orc_step(IlmFloat4** planes, int32_t chunk_count, int32_t chunk_size,
               const IlmFloat4* rnd, int32_t rw, int32_t rh,
               const IlmFloat4* life_ramp, int32_t ramp_w, int32_t ramp_h,
               const OrcTexture* sdf, const IlmStepDesc* desc, uint32_t* live_counts) {
-    for (int s = 0; s < desc->SpawnCount; s++) {
-        int c = desc->Spawns[s].ChunkIndex;
-        if (c < 0 || c >= chunk_count) continue;
-        orc_spawn(planes[c * 5 + 0], planes[c * 5 + 1], planes[c * 5 + 2], chunk_size, rnd, rw, rh, &desc->Spawns[s].Params);
-    }
     int first = desc->FirstChunk, count = desc->ChunkCount;
     if (count < 0) { first = 0; count = chunk_count; }
-    for (int c = first; c < first + count && c < chunk_count; c++) {
+    const int band = chunk_size >= 64 ? 16 : chunk_size;           /* rows per task */
+    const int bands = (chunk_size + band - 1) / band;
+    const int tasks = chunk_count * bands;
+    #pragma omp parallel for schedule(dynamic, 1)
+    for (int t = 0; t < tasks; t++) {
+        const int c = t / bands;
+        const int y0 = (t % bands) * band;
+        const int y1 = (y0 + band < chunk_size) ? y0 + band : chunk_size;
         IlmFloat4 *pos = planes[c * 5 + 0], *vel = planes[c * 5 + 1], *attr = planes[c * 5 + 2],
                   *rc = planes[c * 5 + 3], *rd = planes[c * 5 + 4];
+        /* spawners run first and may target chunks outside [first, first + count) */
+        for (int s = 0; s < desc->SpawnCount; s++)
+            if (desc->Spawns[s].ChunkIndex == c)
+                spawn_rows(pos, vel, attr, chunk_size, y0, y1, rnd, rw, rh, &desc->Spawns[s].Params);
+        if (c < first || c >= first + count)
+            continue;
         for (int o = 0; o < desc->OpCount; o++) {
             const IlmTransformOp* op = &desc->Ops[o];
             switch (op->Type) {
-                case ILM_OP_GRAVITY: orc_gravity(pos, vel, chunk_size, &desc->System, &op->u.Gravity); break;
-                case ILM_OP_NOISE:   orc_noise(pos, vel, chunk_size, rnd, rw, rh, &desc->System, &op->u.Noise); break;
-                case ILM_OP_FMA:     orc_fma(pos, vel, chunk_size, &desc->System, &op->u.FMA); break;
+                case ILM_OP_GRAVITY: gravity_rows(pos, vel, chunk_size, y0, y1, &desc->System, &op->u.Gravity); break;
+                case ILM_OP_NOISE:   noise_rows(pos, vel, chunk_size, y0, y1, rnd, rw, rh, &desc->System, &op->u.Noise); break;
+                case ILM_OP_FMA:     fma_rows(pos, vel, chunk_size, y0, y1, &desc->System, &op->u.FMA); break;
                 default: break;
             }
         }
         switch (desc->UpdateMode) {
             case ILM_UPDATE_POSITIONS:
-                orc_update(pos, vel, attr, rc, rd, chunk_size, &desc->System, &desc->Update, life_ramp, ramp_w, ramp_h, NULL, NULL);
+                update_rows(pos, vel, attr, rc, rd, chunk_size, y0, y1, &desc->System, &desc->Update, life_ramp, ramp_w, ramp_h, NULL, NULL);
                 break;
             case ILM_UPDATE_WITH_DISTANCE_FIELD:
-                orc_update(pos, vel, attr, rc, rd, chunk_size, &desc->System, &desc->Update, life_ramp, ramp_w, ramp_h, &desc->DistanceField, sdf);
+                update_rows(pos, vel, attr, rc, rd, chunk_size, y0, y1, &desc->System, &desc->Update, life_ramp, ramp_w, ramp_h, &desc->DistanceField, sdf);
                 break;
-            case ILM_UPDATE_ERASE:
-                orc_erase(pos, vel, rc, rd, chunk_size);
+            case ILM_UPDATE_ERASE: {   /* PS_Erase, UpdateParticleSystem.fx:40-49 */
+                size_t o = (size_t)y0 * (size_t)chunk_size, n = (size_t)(y1 - y0) * (size_t)chunk_size * sizeof(IlmFloat4);
+                memset(pos + o, 0, n); memset(vel + o, 0, n); memset(rc + o, 0, n); memset(rd + o, 0, n);
                 break;
+            }
             default: break;
         }
-        if (live_counts && (desc->Flags & ILM_STEP_COUNT_LIVE))
-            live_counts[c] = orc_count_live(pos, chunk_size * chunk_size, 0);
     }
+    if (live_counts && (desc->Flags & ILM_STEP_COUNT_LIVE))
+        for (int c = first; c < first + count && c < chunk_count; c++)
+            live_counts[c] = orc_count_live(planes[c * 5 + 0], chunk_size * chunk_size, 0);
 }
 
 /* ---------------------------------------------------------------------------
@@ -1358,6 +1406,14 @@ int32_t orc_spawner_begin_tick(OrcSpawnerState* s, float min_rate, float max_rat
 void orc_spawner_end_tick(OrcSpawnerState* s, int32_t requested, int32_t actual) {
     s->rate_error += requested - actual;
     s->total_spawned += actual;
+}
+
+void orc_set_num_threads(int32_t n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
 }
 
 int32_t orc_num_threads(void) {

@@ -105,6 +105,7 @@ int32_t orc_spawner_begin_tick(OrcSpawnerState* s, float min_rate, float max_rat
 void    orc_spawner_end_tick(OrcSpawnerState* s, int32_t requested, int32_t actual);
 
 int32_t orc_num_threads(void);
+void    orc_set_num_threads(int32_t n);
 
 #ifdef __cplusplus
 }

@@ -42,11 +42,29 @@ class SpawnerState(C.Structure):
     _fields_ = [("rate_error", C.c_double), ("total_spawned", C.c_int32)]
 
 
+def usable_cpus():
+    """Cores this process may actually run on: the affinity mask capped by the cgroup CPU quota.
+
+    A GPU box can show hundreds of logical cores while the container is limited to a few; an OpenMP team sized
+    by the former spends its time in oversubscribed barriers."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def lib():
     global _lib
     if _lib is None:
         build()
+        os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
         _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_set_num_threads(C.c_int32(int(os.environ.get("ILM_ORACLE_THREADS", usable_cpus()))))
         _lib.orc_bezier1.restype = C.c_float
         _lib.orc_bezier1.argtypes = [C.c_void_p, C.c_float]
         _lib.orc_sample_distance_field.restype = C.c_float

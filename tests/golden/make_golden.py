@@ -1,0 +1,407 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.json -- the substitute known-answer vectors that pin the CPU oracle.
+
+WHY "SUBSTITUTE".  sq/Illuminant ships no tests, golden vectors or fixtures for the two hot paths, its GPU
+code is HLSL that needs fxc + Direct3D, and its host code needs .NET 4.8 + Fracture + XNA/FNA: none of that
+can run in the build container, so the oracle (oracle/ilm_oracle.c, a restatement of the HLSL) cannot be checked
+against outputs of the reference itself ("parity unpinned").  What the reference DOES contain is a
+second, independent statement of some of the same arithmetic in C# -- CPU mirrors the engine uses on the host --
+plus pure integer/layout logic and closed-form identities.  This script restates THOSE (not the HLSL) in plain
+Python, one function per cited C# block, evaluates them on fixed inputs and writes inputs + expected outputs
+as data.  tests/test_oracle_kat.py then requires the oracle (and, on the GPU box, the HIP path) to reproduce
+them.  Two restatements written from two different sources agreeing is the strongest pin available here.
+
+Everything is float32-faithful where the C# is float (numpy.float32 arithmetic, one rounding per operation).
+All file:line citations are relative to the reference checkout.  The script needs nothing but numpy, does not
+read /root/reference, and is deterministic: re-running it must reproduce the committed JSON byte for byte.
+"""
+import json
+import math
+import os
+
+import numpy as np
+
+F = np.float32
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def f32(x):
+    return float(F(x))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 1. ClampedBezier1/4.Evaluate + tForScaledBezier -- Illuminant/Bezier.cs:461-490 (Bezier1), :759-832 (Bezier4)
+#    (the C# CPU mirror of Bezier.fxh:21-177, which is what the oracle restates)
+# ---------------------------------------------------------------------------------------------------------
+def cs_lerp(a, b, t):
+    # Arithmetic.Lerp (Fracture Squared.Util): a + (b - a) * t in float
+    return F(a) + (F(b) - F(a)) * F(t)
+
+
+def cs_saturate(t):
+    return F(min(max(F(t), F(0)), F(1)))
+
+
+def cs_wrap_exclusive(t, lo, hi):
+    # Arithmetic.WrapExclusive for t >= lo: t - floor((t-lo)/(hi-lo))*(hi-lo).  Vectors below keep t >= 0, where it
+    # coincides with HLSL's truncating `%` (Bezier.fxh:33-46); negative t is where the two differ and is left out.
+    d = F(hi) - F(lo)
+    return F(np.fmod(F(t) - F(lo), d)) + F(lo)
+
+
+def t_for_scaled_bezier(range_and_count, value):
+    min_value, inv_divisor, count, mode_f = [F(v) for v in range_and_count]
+    mode = int(mode_f)
+    repeating, bouncing = mode > 255, mode > 511
+    t = (F(value) - min_value) * F(abs(inv_divisor))
+    if bouncing:
+        t = t * F(2)
+        t = (F(2) - cs_wrap_exclusive(t, 0, 2)) if inv_divisor < 0 else cs_wrap_exclusive(t, 0, 2)
+        if t > 1:
+            t = F(1) - (t - F(1))
+    elif repeating:
+        t = (F(1) - cs_wrap_exclusive(t, 0, 1)) if inv_divisor < 0 else cs_wrap_exclusive(t, 0, 1)
+    else:
+        t = (F(1) - cs_saturate(t)) if inv_divisor < 0 else cs_saturate(t)
+    m = mode % 256
+    if m == 1:      # BezierTimeMode.Sine: (float)Math.Sin(t * Math.PI * 0.5) -- double sin, rounded once
+        t = F(math.sin(float(t) * math.pi * 0.5))
+    elif m == 2:    # BezierTimeMode.Exp
+        t = t * t
+    return int(count), F(t)
+
+
+def bezier_evaluate(range_and_count, a, b, c, d, value):
+    """a..d: scalars (ClampedBezier1) or 4-tuples (ClampedBezier4); returns a list of float."""
+    a, b, c, d = [np.atleast_1d(np.asarray(v, dtype=F)) for v in (a, b, c, d)]
+    count, t = t_for_scaled_bezier(range_and_count, value)
+    if count <= 1.5:
+        r = a
+    else:
+        ab = cs_lerp(a, b, t)
+        if count <= 2.5:
+            r = ab
+        elif count <= 3.5:   # "HACK: Shelf mode"
+            r = a if t <= 0 else (c if t >= 1 else b)
+        else:
+            bc = cs_lerp(b, c, t)
+            abbc = cs_lerp(ab, bc, t)
+            cd = cs_lerp(c, d, t)
+            bccd = cs_lerp(bc, cd, t)
+            r = cs_lerp(abbc, bccd, t)
+    return [float(x) for x in np.asarray(r, dtype=F)]
+
+
+def clamped_range(min_value, max_value, count, mode):
+    # ClampedBezier1 ctor, Bezier.cs:444-459: (min(minValue, maxValue), 1/range, Count, Mode); range 0 or Count<=1 -> 1
+    rng = F(max_value) - F(min_value)
+    if rng == 0 or count <= 1:
+        rng = F(1)
+    return [f32(min(min_value, max_value)), f32(F(1) / rng), float(count), float(mode)]
+
+
+def gen_bezier():
+    cases = []
+    values = [0.0, 0.125, 0.5, 0.75, 1.0, 1.5, 2.25, 3.0, 7.625]
+    a1, b1, c1, d1 = 0.25, 1.5, -0.75, 2.0
+    a4, b4, c4, d4 = (1.0, 0.5, 0.25, 0.0), (0.2, 0.9, 0.4, 1.0), (0.7, 0.1, 0.95, 0.5), (0.0, 0.3, 0.6, 1.0)
+    for count in (1, 2, 3, 4):
+        for mode in (0, 1, 2, 256, 257, 512, 514):
+            for (lo, hi) in ((0.0, 1.0), (0.5, 3.0), (3.0, 0.5)):
+                rc = clamped_range(lo, hi, count, mode)
+                for v in values:
+                    if v < min(lo, hi):
+                        continue       # keep t >= 0 (see cs_wrap_exclusive)
+                    cases.append({"kind": "bezier1", "range_and_count": rc, "abcd": [a1, b1, c1, d1], "value": v,
+                                  "expected": bezier_evaluate(rc, a1, b1, c1, d1, v)})
+                    cases.append({"kind": "bezier4", "range_and_count": rc, "a": list(a4), "b": list(b4), "c": list(c4),
+                                  "d": list(d4), "value": v, "expected": bezier_evaluate(rc, a4, b4, c4, d4, v)})
+    # the ColorFromLife curve SetSystemUniforms builds from OpacityFromLife = o (ParticleSystem.cs:554-563):
+    # A = (1,1,1,0), B = 1, RangeAndCount = (0, 1/o, 2, 0)  =>  alpha ramps 0 -> 1 over life in [0, o]
+    for o in (0.5, 2.5):
+        rc = [0.0, f32(F(1) / F(o)), 2.0, 0.0]
+        for v in (0.0, 0.1, 0.25, 1.0, 2.5, 40.0):
+            cases.append({"kind": "bezier4", "range_and_count": rc, "a": [1, 1, 1, 0], "b": [1, 1, 1, 1], "c": [1, 1, 1, 1],
+                          "d": [1, 1, 1, 1], "value": v, "expected": bezier_evaluate(rc, (1, 1, 1, 0), (1, 1, 1, 1), (1, 1, 1, 1), (1, 1, 1, 1), v)})
+    return {"source": "Illuminant/Bezier.cs:444-490,759-832 (C# CPU mirror of Bezier.fxh:21-177)", "tolerance": "rtol 1e-6 (Sine mode: C# uses double sin)", "cases": cases}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 2. DistanceField constructor -- Illuminant/SDF/DistanceField.cs:43-109 (pure integer / double layout math)
+# ---------------------------------------------------------------------------------------------------------
+def cs_round(x):
+    # Math.Round(double): round half to even -- Python's round() on a float does the same
+    return float(round(x))
+
+
+def distance_field_layout(vw, vh, requested_slices, requested_resolution):
+    max_surface, packed = 8192, 3           # DistanceField.cs:19, LightingRenderer.PackedSliceCount
+    rr = min(max(requested_resolution, 0.05), 1.0)
+    cw, ch = int(cs_round(vw * rr)), int(cs_round(vh * rr))
+    frac = (vw / cw + vh / ch) / 2
+    res = round(1.0 / frac, 3)              # Math.Round(x, 3); the cases below are exact at 3 digits
+    res = min(max(res, 0.05), 1.0)
+    sw, sh = int(cs_round(vw * res)), int(cs_round(vh * res))
+    mx, my = max_surface // sw, max_surface // sh
+    max_slices = mx * my * packed
+    sc = max(3, requested_slices)
+    sc = ((sc + 2) // 3) * 3
+    sc = min(sc, max_slices)
+    phys = int(math.ceil(sc / packed))
+    cols = min(mx, phys)
+    rows = min(my, max(int(math.ceil(phys / mx)), 1))
+    while rows < cols and rows < my:
+        nr = rows + 1
+        nc = int(math.ceil(phys / nr))
+        nr = min(nr, mx)
+        nc = min(nc, my)
+        if nr * nc < phys:
+            break
+        rows, cols = nr, nc
+    return {"resolution": res, "slice_width": sw, "slice_height": sh, "slice_count": sc, "physical_slice_count": phys,
+            "column_count": cols, "row_count": rows, "atlas_width": sw * cols, "atlas_height": sh * rows}
+
+
+def gen_layout():
+    cases = []
+    for (vw, vh, n, r) in ((512, 512, 32, 1.0),          # SURVEY 8c KAT: 33 slices, 11 physical, 3x4, 1536x2048
+                           (1920, 1080, 9, 0.25),         # TestGame Scenes/SimpleParticles.cs:216-219: 480x270, 2x2
+                           (256, 256, 9, 1.0),            # cfg1: 3 physical, 2x2, 512x512
+                           (2048, 2048, 32, 0.25),        # cfg3 field: 512x512 slices, 1536x2048 atlas
+                           (4096, 4096, 32, 0.125),       # cfg5 field
+                           (128, 128, 6, 0.5), (1024, 768, 1, 1.0), (640, 360, 64, 0.5), (8192, 8192, 16, 1.0),
+                           (300, 200, 24, 0.01), (1000, 1000, 7, 3.0)):
+        cases.append({"virtual_width": vw, "virtual_height": vh, "requested_slice_count": n, "requested_resolution": r,
+                      "expected": distance_field_layout(vw, vh, n, r)})
+    return {"source": "Illuminant/SDF/DistanceField.cs:43-109", "tolerance": "exact (resolution: 1e-12)", "cases": cases}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 3. SpawnerBase.BeginTick / EndTick + RunSpawner / PickTargetForSpawn slot allocation --
+#    Illuminant/Particles/ParticleSpawner.cs:152-194, ParticleSpawning.cs:115-231, ParticleSystem.cs:725-741
+#    RNG draws are explicit inputs (the reference's Xoshiro is unseeded).
+# ---------------------------------------------------------------------------------------------------------
+def begin_tick(state, min_rate, max_rate, count_scale, draw, dt, maximum_total):
+    min_rate, max_rate = f32(min_rate), f32(max_rate)
+    if min_rate > max_rate:
+        min_rate = max_rate
+    current = ((draw * (max_rate - min_rate)) + min_rate) * count_scale * dt
+    current += state["rate_error"]
+    state["rate_error"] = 0.0
+    if current < 1:
+        state["rate_error"] = max(current, 0.0)
+        count = 0
+    else:
+        count = int(current)
+        state["rate_error"] = current - count
+    if maximum_total is not None:
+        remaining = maximum_total * count_scale - state["total_spawned"]
+        if count > remaining:
+            count = remaining
+            state["rate_error"] = 0.0
+    return count
+
+
+def end_tick(state, requested, actual):
+    state["rate_error"] += requested - actual
+    state["total_spawned"] += actual
+
+
+def run_system_spawns(chunk_capacity, ticks, min_rate, max_rate, count_scale, dt, maximum_total, partial_allowed=True):
+    """One spawner, a fresh ParticleSystem; per tick returns the (chunk id, first, last) ranges RunSpawner issues
+    (second pass included, ParticleSystem.cs:732-740)."""
+    state = {"rate_error": 0.0, "total_spawned": 0}
+    chunks = {}          # id -> NextSpawnOffset
+    retired = set()
+    target = -1
+    next_id = 1
+    trace = []
+    for draws in ticks:
+        issued = []
+        passes = 0
+        while passes < 2:
+            draw = draws[passes]
+            requested = begin_tick(state, min_rate, max_rate, count_scale, draw, dt, maximum_total)
+            if requested <= 0:
+                break
+            count = min(requested, chunk_capacity)
+            # PickTargetForSpawn, ParticleSpawning.cs:199-231
+            if target != -1:
+                free = chunk_capacity - chunks[target]
+                if free < (16 if partial_allowed else count):
+                    retired.add(target)
+                    target = -1
+            if target == -1:
+                target = next_id
+                next_id += 1
+                chunks[target] = 0
+            free = chunk_capacity - chunks[target]
+            if count > free:
+                if partial_allowed:
+                    count = free
+                else:
+                    break
+            first = chunks[target]
+            last = first + count - 1
+            chunks[target] += count
+            end_tick(state, requested, count)
+            issued.append([target, first, last])
+            passes += 1
+            if not (requested > count):      # isPartialSpawn
+                break
+        trace.append({"draws": list(draws), "issued": issued, "rate_error_after": state["rate_error"], "total_spawned_after": state["total_spawned"]})
+    return trace
+
+
+def gen_spawner():
+    cases = []
+    # (a) BeginTick traces: cfg2's spawner, MinRate = MaxRate = 65536/s at dt = 1/60 => 1092 / 1093 through the RateError carry
+    st = {"rate_error": 0.0, "total_spawned": 0}
+    seq = []
+    for i in range(12):
+        n = begin_tick(st, 65536.0, 65536.0, 1, 0.5, 1.0 / 60.0, None)
+        end_tick(st, n, n)
+        seq.append({"draw": 0.5, "count": n, "rate_error_after": st["rate_error"], "total_spawned_after": st["total_spawned"]})
+    cases.append({"kind": "begin_tick", "min_rate": 65536.0, "max_rate": 65536.0, "count_scale": 1, "dt": 1.0 / 60.0, "maximum_total": None, "ticks": seq})
+    # (b) random rate in [min, max], low rates accumulate through RateError, MaximumTotal clamp
+    st = {"rate_error": 0.0, "total_spawned": 0}
+    seq = []
+    draws = [0.0, 0.999, 0.25, 0.5, 0.75, 0.125, 0.875, 0.0625, 0.3, 0.6, 0.9, 0.45, 0.05, 0.95]
+    for dr in draws:
+        n = begin_tick(st, 20.0, 240.0, 2, dr, 1.0 / 60.0, 25)
+        end_tick(st, n, n)
+        seq.append({"draw": dr, "count": n, "rate_error_after": st["rate_error"], "total_spawned_after": st["total_spawned"]})
+    cases.append({"kind": "begin_tick", "min_rate": 20.0, "max_rate": 240.0, "count_scale": 2, "dt": 1.0 / 60.0, "maximum_total": 25, "ticks": seq})
+    # (c) min > max is clamped to max (ParticleSpawner.cs:163-164)
+    st = {"rate_error": 0.0, "total_spawned": 0}
+    seq = []
+    for dr in (0.1, 0.9, 0.5):
+        n = begin_tick(st, 900.0, 300.0, 1, dr, 0.05, None)
+        end_tick(st, n, n)
+        seq.append({"draw": dr, "count": n, "rate_error_after": st["rate_error"], "total_spawned_after": st["total_spawned"]})
+    cases.append({"kind": "begin_tick", "min_rate": 900.0, "max_rate": 300.0, "count_scale": 1, "dt": 0.05, "maximum_total": None, "ticks": seq})
+    # (d) slot allocation across chunk roll-over: 64^2 chunks, 1500/tick => partial spawn + second pass + Free<16 rule
+    ticks = [(0.5, 0.5)] * 9
+    cases.append({"kind": "allocation", "chunk_capacity": 4096, "min_rate": 90000.0, "max_rate": 90000.0, "count_scale": 1, "dt": 1.0 / 60.0,
+                  "maximum_total": None, "trace": run_system_spawns(4096, ticks, 90000.0, 90000.0, 1, 1.0 / 60.0, None)})
+    ticks = [(0.2, 0.7), (0.9, 0.1), (0.4, 0.4), (0.99, 0.01), (0.6, 0.3), (0.5, 0.5), (0.05, 0.95), (0.8, 0.2)]
+    cases.append({"kind": "allocation", "chunk_capacity": 1024, "min_rate": 6000.0, "max_rate": 40000.0, "count_scale": 1, "dt": 1.0 / 60.0,
+                  "maximum_total": None, "trace": run_system_spawns(1024, ticks, 6000.0, 40000.0, 1, 1.0 / 60.0, None)})
+    return {"source": "Illuminant/Particles/ParticleSpawner.cs:152-194, ParticleSpawning.cs:115-231, ParticleSystem.cs:725-741",
+            "tolerance": "counts / slot indices exact; rate_error 1e-9", "cases": cases}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 4. Liveness decode -- CountLiveParticles.fx:38 (+1/65535 per live particle into a unorm16 channel, additive blend,
+#    saturating) and ProcessLivenessInfoData, ParticleEngine.cs:244-247 (count = raw & 0xFFFF)
+# ---------------------------------------------------------------------------------------------------------
+def gen_liveness():
+    cases = []
+    for live in (0, 1, 255, 4095, 4096, 65534, 65535, 65536, 70000, 1048576):
+        unorm = min(live, 65535)                 # additive blending saturates the 16-bit channel at 1.0
+        raw = (0xABCD << 16) | unorm             # the other Rg32 channel carries a flag: masked off by the decode
+        cases.append({"live_slots": live, "raw": raw, "expected_count": raw & 0xFFFF})
+    return {"source": "Illuminant/Shaders/CountLiveParticles.fx:5-40, Illuminant/Particles/ParticleEngine.cs:244-247", "tolerance": "exact", "cases": cases}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 5. Distance encoding -- DistanceFieldCommon.fxh:8,264-270: encode(d) = 192/255 - d/maxDist, decode(e) = (192/255 - e)*maxDist
+# ---------------------------------------------------------------------------------------------------------
+def gen_encoding():
+    cases = []
+    for max_d in (128.0, 256.0):
+        z = F(192.0) / F(255.0)
+        for d in (0.0, 1.0, -1.0, 17.5, -31.25, 96.0, -32.0):
+            e = z - F(d) / F(max_d)
+            cases.append({"distance": d, "max_distance": max_d, "encoded": float(e), "decoded": float((z - e) * F(max_d))})
+    return {"source": "Illuminant/Shaders/DistanceFieldCommon.fxh:8,264-270", "tolerance": "1e-6 absolute on encoded, 1e-4 on decoded", "cases": cases}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 6. G-buffer texel <-> world position / normal -- encode side GBufferShaderCommon.fxh:10-35 +
+#    encodeNormalSpherical EnvironmentCommon.fxh:34-38; decode side LightCommon.fxh:58-144, EnvironmentCommon.fxh:40-51.
+#    The expected values are the INPUTS of the encode (round trip), i.e. independent of the decode restatement --
+#    except for a fullbright texel, whose z is not recoverable: the decode zeroes it BEFORE the *1024 - 1024 rescale
+#    (LightCommon.fxh:91-99), so such a pixel reports z = -1024 (it is skipped by every light anyway).
+# ---------------------------------------------------------------------------------------------------------
+def encode_normal_spherical(n):
+    # float2(atan2(n.y, n.x) / PI, n.z) * 0.5 + 0.5
+    return [(math.atan2(n[1], n[0]) / math.pi) * 0.5 + 0.5, n[2] * 0.5 + 0.5]
+
+
+def gen_gbuffer():
+    cases = []
+    for normal, rel_y, z, shadows, fullbright in (((0.0, 0.0, 1.0), 0.0, 0.0, True, False),       # ground plane: texel (0.5, 1.0, 0, 1.0)
+                                                 ((0.0, 1.0, 0.0), -12.0, 12.0, True, False),      # front face of a height volume
+                                                 ((0.6, 0.0, 0.8), 3.0, 40.0, True, False),
+                                                 ((-0.48, 0.64, 0.6), 0.0, 0.0, False, False),     # shadows disabled at z = 0
+                                                 ((0.0, 0.0, 1.0), 0.0, 25.0, False, False),
+                                                 ((0.0, 0.0, 1.0), 0.0, 0.0, True, True)):         # fullbright
+        enc = encode_normal_spherical(normal)
+        if fullbright:
+            w = 99999.0
+        else:
+            w = ((z + 1024.0) / 1024.0) * (1 if shadows else -1) + (0 if shadows else -1)
+        cases.append({"texel": [enc[0], enc[1], rel_y, w], "pixel": [37.0, 21.0],
+                      "expected": {"normal": list(normal), "world_z": -1024.0 if fullbright else z, "world_xy": [37.0, 21.0 + rel_y],
+                                   "enable_shadows": bool(shadows and not fullbright), "fullbright": bool(fullbright)}})
+    return {"source": "Illuminant/Shaders/GBufferShaderCommon.fxh:10-35, EnvironmentCommon.fxh:34-51, LightCommon.fxh:58-144",
+            "tolerance": "1e-5 absolute on the normal, 2e-4 on world_z (the /1024 round trip)", "cases": cases}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# 7. Closed-form single-light / single-particle answers, derived by hand from the cited lines
+# ---------------------------------------------------------------------------------------------------------
+def gen_closed_form():
+    cases = []
+    # (a) light centred on the pixel, no distance field: distance 0 < radius => saturate(radius - distance) = 1 =>
+    #     opacity 1 (LightCommon.fxh:208-213); lightmap = ambient + rgb * a (SphereLight.fx:42-45), alpha += 1
+    cases.append({"kind": "light_at_pixel", "light": {"position": [8.0, 6.0, 0.0], "radius": 4.0, "ramp": 10.0, "color": [0.25, 0.5, 0.75, 0.5]},
+                  "ambient": [0.05, 0.06, 0.07, 1.0], "pixel": [8, 6], "expected": [0.05 + 0.125, 0.06 + 0.25, 0.07 + 0.375, 2.0]})
+    # (b) linear ramp on the ground plane, no field, light at height 0: at distance radius + k*ramp the opacity is (1 - k)
+    #     (normal factor: light in the plane => dot = 0 => pow(saturate(0.15/0.15), .85) = 1; LightCommon.fxh:154-214)
+    for k in (0.25, 0.5, 0.75):
+        d = 4.0 + k * 16.0
+        # (the pixel shader works at the integer VPOS, so pixel (x, y) shades world point (x, y): light on a pixel corner)
+        cases.append({"kind": "linear_ramp", "light": {"position": [4.0, 4.0, 0.0], "radius": 4.0, "ramp": 16.0, "color": [1.0, 1.0, 1.0, 1.0]},
+                      "ambient": [0.0, 0.0, 0.0, 1.0], "pixel": [4 + int(d), 4], "expected_rgb": 1.0 - k})
+    # (c) Gravity, one Linear attractor (Gravity.fx:36-60): a = normalize(c - p) * (1 - d/r) * dt * strength, capped by
+    #     MaximumAcceleration * dt; particle (100,100,0) v = 0, attractor (160,180,0) r = 200 strength 60, dt = 1/60:
+    #     d = 100, a = (.6,.8,0) * .5 * (1/60) * 60 = (.3,.4,0); cap 8/60 = .1333 => a = (.08, .10667, 0)
+    cases.append({"kind": "gravity_linear", "position": [100.0, 100.0, 0.0, 1.0], "velocity": [0.0, 0.0, 0.0, 0.0],
+                  "attractor": {"position": [160.0, 180.0, 0.0], "radius": 200.0, "strength": 60.0, "type": 1},
+                  "dt": 1.0 / 60.0, "maximum_acceleration": 8.0, "expected_velocity": [0.6 * 8.0 / 60.0, 0.8 * 8.0 / 60.0, 0.0, 0.0]})
+    cases.append({"kind": "gravity_linear", "position": [100.0, 100.0, 0.0, 1.0], "velocity": [1.0, -2.0, 0.5, 0.0],
+                  "attractor": {"position": [160.0, 180.0, 0.0], "radius": 200.0, "strength": 60.0, "type": 1},
+                  "dt": 1.0 / 60.0, "maximum_acceleration": 1024.0, "expected_velocity": [1.3, -1.6, 0.5, 0.0]})
+    # (d) UpdatePositions (UpdateParticleSystem.fx:9-38, UpdateCommon.fxh:20-35): v = (30, 40, 0) |v| = 50, friction .1,
+    #     dt = .1: l = 50 - 50*.1*.1 = 49.5 => v' = (29.7, 39.6, 0); p' = p + v'*dt; life' = life - decay*dt
+    cases.append({"kind": "update_positions", "position": [10.0, 20.0, 5.0, 2.0], "velocity": [30.0, 40.0, 0.0, 3.0],
+                  "dt": 0.1, "friction": 0.1, "max_velocity": 2048.0, "life_decay": 1.5,
+                  "expected_position": [12.97, 23.96, 5.0, 1.85], "expected_velocity": [29.7, 39.6, 0.0, 3.0]})
+    # life runs out => slot zeroed (UpdateParticleSystem.fx:28-35)
+    cases.append({"kind": "update_positions", "position": [10.0, 20.0, 5.0, 0.1], "velocity": [30.0, 40.0, 0.0, 3.0],
+                  "dt": 0.1, "friction": 0.1, "max_velocity": 2048.0, "life_decay": 1.5,
+                  "expected_position": [0.0, 0.0, 0.0, 0.0], "expected_velocity": [0.0, 0.0, 0.0, 0.0]})
+    # (e) FMA (FMA.fx:22-51, Transforms.cs:38-45): no area => weight = Strength; t = Strength * dtMs / (1000/cps);
+    #     Strength 1, dt 1/60 s, 10 cycles/s => t = 16.6667/100 = 1/6; v' = lerp(v, v*mul + add, t)
+    cases.append({"kind": "fma", "position": [6.0, 12.0, 0.0, 1.0], "velocity": [60.0, -30.0, 0.0, 0.0], "dt": 1.0 / 60.0, "strength": 1.0,
+                  "cycles_per_second": 10.0, "position_add": [6.0, 0.0, 0.0], "position_multiply": [1.0, 1.0, 1.0],
+                  "velocity_add": [0.0, 0.0, 0.0], "velocity_multiply": [0.4, 0.4, 1.0],
+                  "expected_position": [7.0, 12.0, 0.0, 1.0], "expected_velocity": [54.0, -27.0, 0.0, 0.0]})
+    return {"source": "hand-derived from the cited HLSL lines (see comments in make_golden.py)", "tolerance": "1e-5 relative", "cases": cases}
+
+
+def main():
+    out = {"bezier.json": gen_bezier(), "distance_field_layout.json": gen_layout(), "spawner.json": gen_spawner(),
+           "liveness.json": gen_liveness(), "distance_encoding.json": gen_encoding(), "gbuffer.json": gen_gbuffer(),
+           "closed_form.json": gen_closed_form()}
+    for name, doc in out.items():
+        with open(os.path.join(HERE, name), "w") as f:
+            json.dump(doc, f, indent=1, sort_keys=True)
+            f.write("\n")
+        print("%-28s %d cases" % (name, len(doc["cases"])))
+
+
+if __name__ == "__main__":
+    main()

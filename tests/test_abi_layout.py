@@ -1,0 +1,146 @@
+"""The drop-in boundary without a GPU: libilluminant_hip.so loads, exports every symbol include/illuminant_hip.h
+declares, the ctypes mirrors have the header's byte layout, and the product path fails loudly (no CPU fallback).
+No compute calls are made here; the parity tests proper are the `-m gpu` files.
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+from illuminant_amd import abi, native
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "illuminant_hip.h")
+
+# C struct name -> ctypes mirror
+STRUCTS = {
+    "IlmFloat4": abi.Float4, "IlmMatrix": abi.Matrix, "IlmParticleSystemUniforms": abi.ParticleSystemUniforms,
+    "IlmClampedBezier1": abi.ClampedBezier1, "IlmClampedBezier4": abi.ClampedBezier4,
+    "IlmDistanceFieldUniforms": abi.DistanceFieldUniforms, "IlmEnvironment": abi.Environment, "IlmLightVertex": abi.LightVertex,
+    "IlmAreaParams": abi.AreaParams, "IlmGravityParams": abi.GravityParams, "IlmFMAParams": abi.FMAParams,
+    "IlmNoiseParams": abi.NoiseParams, "IlmSpawnParams": abi.SpawnParams, "IlmUpdateParams": abi.UpdateParams,
+    "IlmTransformOp": abi.TransformOp, "IlmSpawnRecord": abi.SpawnRecord, "IlmStepDesc": abi.StepDesc, "IlmRenderStats": abi.RenderStats,
+}
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ilm_[a-z0-9_]+)\s*\(", text)))
+
+
+def declared_structs():
+    text = open(HEADER).read()
+    return sorted(set(re.findall(r"typedef struct (Ilm\w+)", text)))
+
+
+def test_header_declares_the_expected_surface():
+    fns = declared_functions()
+    assert len(fns) >= 40
+    for must in ("ilm_system_step", "ilm_render_sphere_lights", "ilm_spawn", "ilm_gravity", "ilm_noise", "ilm_fma", "ilm_update",
+                 "ilm_system_live_counts", "ilm_sdf_upload", "ilm_chunk_upload", "ilm_chunk_download", "ilm_last_error"):
+        assert must in fns
+
+
+def test_library_exports_every_declared_symbol():
+    handle = C.CDLL(native.LIB_PATH)
+    missing = [f for f in declared_functions() if not hasattr(handle, f)]
+    assert not missing, missing
+    # and the dynamic symbol table says the same (no accidental C++ mangling)
+    nm = subprocess.run(["nm", "-D", "--defined-only", native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = set(re.findall(r"\bT (ilm_\w+)", nm))
+    assert set(declared_functions()) <= exported
+
+
+def test_python_binding_covers_every_declared_symbol():
+    assert sorted(native.SYMBOLS) == declared_functions()
+    native.lib()   # binds restype / argtypes of every symbol: raises AttributeError if one is missing
+
+
+def test_every_struct_has_a_mirror():
+    assert sorted(STRUCTS) == declared_structs()
+
+
+def test_struct_layouts_match_the_c_header(tmp_path):
+    """Compile a probe against the header with gcc; compare sizeof and the offset of every field with ctypes."""
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "%s"' % HEADER, "int main(void) {"]
+    for cname, mirror in STRUCTS.items():
+        lines.append('  printf("%s sizeof %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ftype in mirror._fields_:
+            lines.append('  printf("%s %s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-std=c11", "-o", str(exe), str(src)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout
+    seen = 0
+    for line in out.splitlines():
+        cname, what, value = line.split()
+        mirror = STRUCTS[cname]
+        if what == "sizeof":
+            assert C.sizeof(mirror) == int(value), "sizeof(%s)" % cname
+        else:
+            assert getattr(mirror, what).offset == int(value), "%s.%s" % (cname, what)
+        seen += 1
+    assert seen > 120
+
+
+def test_reference_struct_sizes():
+    """The byte sizes the reference's own structs have (so C# can pass them by ref without marshalling)."""
+    assert C.sizeof(abi.LightVertex) == 128            # Vertices.cs:10-39: 8 x Vector4, Pack = 4
+    assert C.sizeof(abi.ParticleSystemUniforms) == 64   # Uniforms.cs:197-236: 4 x Vector4
+    assert C.sizeof(abi.ClampedBezier1) == 32           # Bezier.cs:433-441
+    assert C.sizeof(abi.ClampedBezier4) == 80           # Bezier.cs:588-599
+    assert C.sizeof(abi.DistanceFieldUniforms) == 96    # Uniforms.cs:79-88 (5 x Vector4) + DistanceFieldPacked1
+    assert C.sizeof(abi.Float4) == 16 and C.sizeof(abi.Matrix) == 64
+
+
+def test_constants_match_the_header():
+    text = open(HEADER).read()
+    defines = dict(re.findall(r"#define (ILM_\w+)\s+\(?(-?\d+)u?\)?", text))
+    assert int(defines["ILM_ABI_VERSION"]) == abi.ABI_VERSION == native.lib().ilm_abi_version()
+    assert int(defines["ILM_MAX_ATTRACTORS"]) == abi.MAX_ATTRACTORS == 16        # Gravity.fx:3
+    assert int(defines["ILM_MAX_INLINE_POSITION_CONSTANTS"]) == abi.MAX_INLINE_POSITION_CONSTANTS == 4
+    assert int(defines["ILM_MAX_OPS"]) == abi.MAX_OPS and int(defines["ILM_MAX_SPAWNS"]) == abi.MAX_SPAWNS
+    assert int(defines["ILM_RANDOMNESS_WIDTH"]) == 807 and int(defines["ILM_RANDOMNESS_HEIGHT"]) == 653   # ParticleEngine.cs:45-46
+    assert int(defines["ILM_ERR_NO_DEVICE"]) == abi.ERR_NO_DEVICE and int(defines["ILM_ERR_STATE"]) == abi.ERR_STATE
+
+
+def test_handles_are_validated_without_a_device():
+    lib = native.lib()
+    assert lib.ilm_ctx_sync(abi.Handle(0)) == abi.ERR_INVALID_HANDLE
+    assert b"context" in lib.ilm_last_error()
+    out = abi.Handle(0)
+    assert lib.ilm_system_create(abi.Handle(0), C.byref(out)) == abi.ERR_INVALID_HANDLE
+    assert lib.ilm_erase(abi.Handle(0), 0) == abi.ERR_INVALID_HANDLE
+
+
+@pytest.mark.skipif(native.device_count() > 0, reason="this box has a GPU")
+def test_no_gpu_means_a_loud_failure_not_a_cpu_fallback():
+    """Without a HIP device the product path refuses to run: ILM_ERR_NO_DEVICE from the C ABI, an exception from
+    the Python binding and from the C++ host mirror."""
+    lib = native.lib()
+    assert native.device_count() == 0
+    out = abi.Handle(0)
+    assert lib.ilm_ctx_create(0, C.byref(out)) == abi.ERR_NO_DEVICE
+    assert out.value == 0
+    assert b"no CPU fallback" in lib.ilm_last_error()
+    with pytest.raises(native.IlluminantError) as e:
+        native.Context(0)
+    assert e.value.code == abi.ERR_NO_DEVICE
+    from illuminant_amd import _host as H
+    with pytest.raises(Exception) as e2:
+        H.DeviceContext(0)
+    assert "no CPU fallback" in str(e2.value)
+
+
+def test_product_libraries_do_not_link_the_oracle():
+    """ldd of the product .so files: the oracle (test infrastructure) is not among their dependencies."""
+    libdir = os.path.join(ROOT, "illuminant_amd", "lib")
+    for name in os.listdir(libdir):
+        if name.endswith(".so"):
+            out = subprocess.run(["readelf", "-d", os.path.join(libdir, name)], capture_output=True, text=True, check=True).stdout
+            assert "ilm_oracle" not in out, name
