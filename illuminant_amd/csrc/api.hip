@@ -6,6 +6,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -42,9 +43,6 @@ struct Ctx {
     uint32_t magic = kMagicCtx;
     int device = 0;
     hipStream_t stream = nullptr;
-    // Spawn-range launches run on their own stream so their ~12 us single-wave latency overlaps the main launch.
-    hipStream_t spawn_stream = nullptr;
-    hipEvent_t ev_main = nullptr, ev_spawn = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // device staging for AoS <-> SoA conversion
     void* staging = nullptr; size_t staging_bytes = 0;
@@ -239,20 +237,7 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
     a.sdf.height = s->sdf ? s->sdf->height : 0;
     a.sdf.format = s->sdf ? s->sdf->format : ILM_SDF_UNORM16;
     a.live_counts = s->d_counts;
-    const int n_ranges = plan_step(a);
-    if (n_ranges > 0) {
-        // spawn stream: after everything queued so far on the main stream (the previous step's main launch wrote
-        // these slots; the counter memset above), concurrently with this step's main launch
-        HIP_TRY(hipEventRecord(c->ev_main, c->stream));
-        HIP_TRY(hipStreamWaitEvent(c->spawn_stream, c->ev_main, 0));
-        for (int k = 0; k < n_ranges; k++)
-            HIP_TRY(launch_step_spawn_range(a, k, c->spawn_stream));
-        HIP_TRY(hipEventRecord(c->ev_spawn, c->spawn_stream));
-    }
-    HIP_TRY(launch_step_main(a, c->stream));
-    if (n_ranges > 0)
-        // whatever follows on the main stream (next step, downloads, counts) sees the spawned slots
-        HIP_TRY(hipStreamWaitEvent(c->stream, c->ev_spawn, 0));
+    HIP_TRY(launch_step(a, c->stream));
     if (d->Flags & ILM_STEP_COUNT_LIVE) {
         // queue the readback behind the kernel; ilm_system_poll_counts / ilm_system_step_counts pick it up
         const int n = (int)s->chunks.size();
@@ -319,9 +304,6 @@ int32_t ilm_ctx_create(int32_t device_id, IlmHandle* out_ctx) {
     if (!c) return fail(ILM_ERR_INVALID_ARGUMENT, "out of host memory");
     c->device = device_id;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&c->spawn_stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming));
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_spawn, hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&c->t0));
     HIP_TRY(hipEventCreate(&c->t1));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_stats), 3 * sizeof(unsigned long long)));
@@ -344,10 +326,6 @@ int32_t ilm_ctx_destroy(IlmHandle h) {
     if (c->d_stats) (void)hipFree(c->d_stats);
     (void)hipEventDestroy(c->t0);
     (void)hipEventDestroy(c->t1);
-    (void)hipEventDestroy(c->ev_main);
-    (void)hipEventDestroy(c->ev_spawn);
-    (void)hipStreamSynchronize(c->spawn_stream);
-    (void)hipStreamDestroy(c->spawn_stream);
     (void)hipStreamDestroy(c->stream);
     c->magic = 0;
     delete c;

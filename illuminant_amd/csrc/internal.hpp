@@ -33,19 +33,16 @@ struct StepLaunch {
     const float4* ramp; int32_t ramp_w, ramp_h;
     SdfView sdf;
     uint32_t* live_counts;       // per chunk at index chunk * kCountStride, zeroed by the caller when ILM_STEP_COUNT_LIVE
-    // Work is cut into units of one wave (64 consecutive slots).  Spawn records touch a few hundred slots but
-    // their code (sin/cos/acos, formula switch) costs ~25 VGPRs, so the units that contain a spawn range run in
-    // their own small launch of the SPAWN variant and the main launch skips them.  Filled by launch_step.
+    // Work is cut into units of one wave (64 consecutive slots); unit = chunk_rel * units_per_chunk + segment.
+    // Filled by launch_step.
     int32_t units_per_chunk;     // stride / 64
-    int32_t unit_begin, unit_end;        // global unit range [begin, end) of this launch; unit = chunk_rel * units_per_chunk + segment
-    int32_t skip_begin[2], skip_end[2];  // main launch: global unit ranges [begin, end] to leave alone (end < begin => none)
+    int32_t unit_begin, unit_end;        // global unit range [begin, end) of this launch
+    int32_t unit_rotate, total_padded;   // block b starts at unit (b * 4 + unit_rotate) mod total_padded
 };
 
 // per-chunk live counters are kCountStride uint32 apart (one 128-byte line each)
 constexpr int kCountStride = 32;
-int plan_step(StepLaunch& a);                                                     // returns the number of spawn ranges (0..2)
-hipError_t launch_step_spawn_range(const StepLaunch& a, int k, hipStream_t stream);
-hipError_t launch_step_main(const StepLaunch& a, hipStream_t stream);
+hipError_t launch_step(StepLaunch& a, hipStream_t stream);
 
 // AoS float4 (device staging) <-> one SoA plane group (4 consecutive components)
 hipError_t launch_aos_to_soa(const float4* src, float* plane0, int64_t stride, int32_t first_slot, int32_t count, hipStream_t stream);

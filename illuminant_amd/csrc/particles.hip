@@ -259,6 +259,11 @@ ILM_DEV float4 mul_point(f3 v, const IlmMatrix& M) {
                v.x * m[2] + v.y * m[6] + v.z * m[10] + m[14], v.x * m[3] + v.y * m[7] + v.z * m[11] + m[15]);
 }
 
+// index % m for an integer-valued index in [0, 2^24) and a literal integer m: HLSL's float % is exact here, and so
+// is the integer remainder (which the compiler turns into a multiply-high); OCML's fmodf is a ~100-instruction loop.
+template <unsigned M>
+ILM_DEV float mod_const(float index) { return (float)((unsigned)index % M); }
+
 // Returns true when the slot was (re)written by the spawner.
 ILM_DEV bool spawn_slot(float4& pos, float4& vel, float4& attr, float x, float y,
                         const float4* __restrict__ rnd, int rw, int rh, const IlmSpawnParams& p) {
@@ -267,9 +272,9 @@ ILM_DEV bool spawn_slot(float4& pos, float4& vel, float4& attr, float x, float y
         return false;
 
     const float ox = p.RandomnessOffset[0], oy = p.RandomnessOffset[1];
-    const float4 random1 = random_custom(rnd, rw, rh, fmodf(index, 8039.0f), 0.0f + fmodf(index, 57.0f), ox, oy, 1.0f, 1.0f);
-    float4 random2 = random_custom(rnd, rw, rh, fmodf(index, 6180.0f), 1.0f + fmodf(index, 4031.0f), ox, oy, 1.0f, 1.0f);
-    const float4 random3 = random_custom(rnd, rw, rh, fmodf(index, 2025.0f), 2.0f + fmodf(index, 65531.0f), ox, oy, 1.0f, 1.0f);
+    const float4 random1 = random_custom(rnd, rw, rh, mod_const<8039u>(index), 0.0f + mod_const<57u>(index), ox, oy, 1.0f, 1.0f);
+    float4 random2 = random_custom(rnd, rw, rh, mod_const<6180u>(index), 1.0f + mod_const<4031u>(index), ox, oy, 1.0f, 1.0f);
+    const float4 random3 = random_custom(rnd, rw, rh, mod_const<2025u>(index), 2.0f + mod_const<65531u>(index), ox, oy, 1.0f, 1.0f);
     if (p.AlignVelocityAndPosition != 0.0f) {
         random2.x = random1.x;
         random2.y = random1.y;
@@ -289,7 +294,8 @@ ILM_DEV bool spawn_slot(float4& pos, float4& vel, float4& attr, float x, float y
         else
             index2 = (int)fminf((float)(index1 + 1), divisor - 1.0f);
     } else {
-        index1 = index2 = (int)fmodf(relative_index + p.ChunkSizeAndIndices[3], p.PositionConstantCount);
+        // integer-valued operands (slot index + TotalSpawned % count, 1..4 position constants): exact either way
+        index1 = index2 = wrap_index_fast(relative_index + p.ChunkSizeAndIndices[3], (int)p.PositionConstantCount);
         position_index_t = 0.0f;
     }
     index1 = min(max(index1, 0), ILM_MAX_INLINE_POSITION_CONSTANTS - 1);
@@ -585,14 +591,25 @@ struct SlotIn {
     float px, py, pz, life, vx, vy, vz, ct, ar, ag, ab, aa;
 };
 
+// Plane c of the unit: a UNIFORM pointer (chunk base + c * stride + first slot of the unit, all SGPR values) indexed
+// by the lane number alone, so every access is `global_load/store_dword v, v_lane_offset, s[base:base+1]` --
+// no per-plane 64-bit vector address arithmetic.
+// The empty asm pins the plane pointer in an SGPR pair: without it LLVM re-associates (ub + lane) + c * S and
+// falls back to a 64-bit vector multiply-add per access.
+ILM_DEV gfloat* plane(gfloat* ub, int64_t S, int c) {
+    gfloat* p = ub + (int64_t)c * S;
+    asm("" : "+s"(p));
+    return p;
+}
+
 template <bool ATTR>
-ILM_DEV SlotIn load_slot(const gfloat* base, int64_t S, int i) {
+ILM_DEV SlotIn load_slot(gfloat* ub, int64_t S, unsigned lane) {
     SlotIn s;
-    s.life = base[3 * S + i];
-    s.px = base[0 * S + i]; s.py = base[1 * S + i]; s.pz = base[2 * S + i];
-    s.vx = base[4 * S + i]; s.vy = base[5 * S + i]; s.vz = base[6 * S + i]; s.ct = base[7 * S + i];
+    s.life = plane(ub, S, 3)[lane];
+    s.px = plane(ub, S, 0)[lane]; s.py = plane(ub, S, 1)[lane]; s.pz = plane(ub, S, 2)[lane];
+    s.vx = plane(ub, S, 4)[lane]; s.vy = plane(ub, S, 5)[lane]; s.vz = plane(ub, S, 6)[lane]; s.ct = plane(ub, S, 7)[lane];
     if (ATTR) {
-        s.ar = base[8 * S + i]; s.ag = base[9 * S + i]; s.ab = base[10 * S + i]; s.aa = base[11 * S + i];
+        s.ar = plane(ub, S, 8)[lane]; s.ag = plane(ub, S, 9)[lane]; s.ab = plane(ub, S, 10)[lane]; s.aa = plane(ub, S, 11)[lane];
     } else {
         s.ar = s.ag = s.ab = s.aa = 0.0f;
     }
@@ -608,7 +625,7 @@ typedef const StepLaunch __attribute__((address_space(4))) CStepLaunch;
 // DF: the update pass is UpdateWithDistanceField (pulls in the SDF sampler); SPAWN: spawn records present.
 // Both are compile-time so the common no-field / no-spawn step does not pay their registers.
 template <int FMT, bool DF, bool SPAWN>
-ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* base, int chunk, int i, int lane, int seg, SlotIn cur) {
+ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* ub, int chunk, int i, unsigned lane, int seg, SlotIn cur) {
     const StepLaunch& a = *(const StepLaunch*)ap;
     const IlmStepDesc& d = a.desc;
     const int64_t S = a.stride;
@@ -629,17 +646,17 @@ ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* base, int chunk, int i, int l
     if (mode == ILM_UPDATE_ERASE) {
         // PS_Erase, UpdateParticleSystem.fx:40-49
 #pragma unroll
-        for (int c = 0; c < 8; c++) base[c * S + i] = 0.0f;
+        for (int c = 0; c < 8; c++) plane(ub, S, c)[lane] = 0.0f;
 #pragma unroll
-        for (int c = 12; c < 20; c++) base[c * S + i] = 0.0f;
+        for (int c = 12; c < 20; c++) plane(ub, S, c)[lane] = 0.0f;
     } else if (!((cur.life > 0.0f) || spawn_here || has_noise)) {
         // dead and nothing writes it: the update pass leaves the cleared target
         // (UpdateHandler._BeforeDraw clears, ParticleTransform.cs:164-165; readStateOrDiscard discards)
         if (mode != ILM_UPDATE_NONE) {
 #pragma unroll
-            for (int c = 0; c < 8; c++) base[c * S + i] = 0.0f;
+            for (int c = 0; c < 8; c++) plane(ub, S, c)[lane] = 0.0f;
 #pragma unroll
-            for (int c = 12; c < 20; c++) base[c * S + i] = 0.0f;
+            for (int c = 12; c < 20; c++) plane(ub, S, c)[lane] = 0.0f;
         } else {
             live_after = cur.life > 0.0f;   // untouched slots keep their liveness when no update pass ran
         }
@@ -650,7 +667,7 @@ ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* base, int chunk, int i, int l
         // slot (x, y): the unit's first slot is divided on the scalar unit, lanes only fold the row wrap
         const int cs = a.chunk_size;
         const int row0 = __builtin_amdgcn_readfirstlane((seg * 64) / cs);
-        int sy = row0, sx = (seg * 64 - row0 * cs) + lane;
+        int sy = row0, sx = (seg * 64 - row0 * cs) + (int)lane;
         while (sx >= cs) { sx -= cs; sy++; }
         const float fx = (float)sx, fy = (float)sy;
         bool spawned = false;
@@ -688,14 +705,14 @@ ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* base, int chunk, int i, int l
                 render_data(fx, fy, pos, vel, attr, d.System, d.Update, a.ramp, a.ramp_w, a.ramp_h, rc, rd);
             }
         }
-        base[0 * S + i] = pos.x; base[1 * S + i] = pos.y; base[2 * S + i] = pos.z; base[3 * S + i] = pos.w;
-        base[4 * S + i] = vel.x; base[5 * S + i] = vel.y; base[6 * S + i] = vel.z; base[7 * S + i] = vel.w;
+        plane(ub, S, 0)[lane] = pos.x; plane(ub, S, 1)[lane] = pos.y; plane(ub, S, 2)[lane] = pos.z; plane(ub, S, 3)[lane] = pos.w;
+        plane(ub, S, 4)[lane] = vel.x; plane(ub, S, 5)[lane] = vel.y; plane(ub, S, 6)[lane] = vel.z; plane(ub, S, 7)[lane] = vel.w;
         if (spawned) {
-            base[8 * S + i] = attr.x; base[9 * S + i] = attr.y; base[10 * S + i] = attr.z; base[11 * S + i] = attr.w;
+            plane(ub, S, 8)[lane] = attr.x; plane(ub, S, 9)[lane] = attr.y; plane(ub, S, 10)[lane] = attr.z; plane(ub, S, 11)[lane] = attr.w;
         }
         if (need_attr) {
-            base[12 * S + i] = rc.x; base[13 * S + i] = rc.y; base[14 * S + i] = rc.z; base[15 * S + i] = rc.w;
-            base[16 * S + i] = rd.x; base[17 * S + i] = rd.y; base[18 * S + i] = rd.z; base[19 * S + i] = rd.w;
+            plane(ub, S, 12)[lane] = rc.x; plane(ub, S, 13)[lane] = rc.y; plane(ub, S, 14)[lane] = rc.z; plane(ub, S, 15)[lane] = rc.w;
+            plane(ub, S, 16)[lane] = rd.x; plane(ub, S, 17)[lane] = rd.y; plane(ub, S, 18)[lane] = rd.z; plane(ub, S, 19)[lane] = rd.w;
         }
         live_after = pos.w > 0.0f;
     }
@@ -711,39 +728,43 @@ template <int FMT, bool DF, bool SPAWN, int MINW>
 __global__ __launch_bounds__(kStepThreads, MINW) void step_kernel(const StepLaunch a) {
     __shared__ uint32_t wave_live[kStepThreads / 64];
     CStepLaunch* ap = (CStepLaunch*)__builtin_amdgcn_kernarg_segment_ptr();
-    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
-    const int u = a.unit_begin + (int)blockIdx.x * (kStepThreads / 64) + wave;
-    bool active = u < a.unit_end;
-    if constexpr (!SPAWN) {
-        // units holding a spawn range are processed by the SPAWN variant's launch
-        if ((u >= a.skip_begin[0] && u <= a.skip_end[0]) || (u >= a.skip_begin[1] && u <= a.skip_end[1]))
-            active = false;
-    }
+    // the wave index is uniform by construction; saying so keeps the unit / chunk / base-pointer arithmetic on the
+    // scalar unit and lets every plane access use the SGPR-base + 32-bit lane-offset addressing form
+    const unsigned lane = threadIdx.x & 63u;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    // Blocks are rotated so that block 0 holds the first unit of the first spawn range: a spawning wave is a long
+    // dependent chain (randomness gathers, sin/cos/acos), so it has to start first to finish under the cover of
+    // the streaming waves instead of forming the tail of the launch.  unit_rotate is a multiple of 4.
+    int v = (int)blockIdx.x * (kStepThreads / 64) + a.unit_rotate;
+    const int total = a.unit_end - a.unit_begin;
+    if (v >= a.total_padded) v -= a.total_padded;
+    const int u = a.unit_begin + v + wave;
+    const bool active = (v + wave) < total;
     bool live_after = false;
     int chunk = 0;
     if (active) {
         const int chunk_rel = u / a.units_per_chunk;
         const int seg = u - chunk_rel * a.units_per_chunk;
         chunk = a.first_chunk + chunk_rel;
-        gfloat* base = (gfloat*)a.chunk_bases[chunk];
-        const int i = seg * 64 + lane;
-        const SlotIn cur = load_slot<true>(base, a.stride, i);
-        live_after = process_unit<FMT, DF, SPAWN>(ap, base, chunk, i, lane, seg, cur);
+        gfloat* ub = (gfloat*)a.chunk_bases[chunk] + seg * 64;     // first slot of the unit, plane 0 (uniform)
+        const int i = seg * 64 + (int)lane;
+        const SlotIn cur = load_slot<true>(ub, a.stride, lane);
+        live_after = process_unit<FMT, DF, SPAWN>(ap, ub, chunk, i, lane, seg, cur);
     }
     if (a.desc.Flags & ILM_STEP_COUNT_LIVE) {
         // CountLiveParticles.fx: wave64 ballot + popcount, LDS sum over the block's waves, then ONE atomic per
         // block on a per-chunk counter that sits on its own 128-byte line (per-wave atomics on one address
         // serialise at ~11 ns each: 1024 of them per chunk made this step 7x slower).  The 4 units of a block
-        // always belong to one chunk (units_per_chunk is a multiple of 16; spawn launches stay inside one chunk).
+        // always belong to one chunk (units_per_chunk is a multiple of 16 and the rotation a multiple of 4).
         const uint32_t n = (uint32_t)__popcll(__ballot(live_after));
         if (lane == 0) wave_live[wave] = active ? n : 0u;
         __syncthreads();
         if (threadIdx.x == 0) {
-            const uint32_t total = wave_live[0] + wave_live[1] + wave_live[2] + wave_live[3];
-            const int first_unit = a.unit_begin + (int)blockIdx.x * (kStepThreads / 64);
+            const uint32_t block_live = wave_live[0] + wave_live[1] + wave_live[2] + wave_live[3];
+            const int first_unit = a.unit_begin + v;
             const int c = a.first_chunk + first_unit / a.units_per_chunk;
-            if (total != 0)
-                atomicAdd(&a.live_counts[c * kCountStride], total);
+            if (block_live != 0)
+                atomicAdd(&a.live_counts[c * kCountStride], block_live);
         }
     }
 }
@@ -777,44 +798,29 @@ static hipError_t launch_step_variant(const StepLaunch& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// Fill the unit ranges of a launch descriptor: the whole [0, chunk_count * units_per_chunk) range for the main
-// launch and up to two spawn ranges (returned) that the SPAWN variant processes.
-int plan_step(StepLaunch& a) {
+// One launch per ParticleSystem.Update: the unit range covers every chunk of the step; when spawn records are
+// present the SPAWN variant runs (for every unit) and the grid is rotated to start at the first spawn range.
+hipError_t launch_step(StepLaunch& a, hipStream_t stream) {
     a.units_per_chunk = (int)(a.stride / 64);
     a.unit_begin = 0;
     a.unit_end = a.chunk_count * a.units_per_chunk;
-    for (int k = 0; k < 2; k++) { a.skip_begin[k] = 0; a.skip_end[k] = -1; }
-    int n_ranges = 0;
+    const int waves_per_block = kStepThreads / 64;
+    a.total_padded = (a.unit_end + waves_per_block - 1) / waves_per_block * waves_per_block;
+    a.unit_rotate = 0;
+    bool spawning = false;
     for (int s = 0; s < a.desc.SpawnCount; s++) {
         const IlmSpawnRecord& r = a.desc.Spawns[s];
         if (r.ChunkIndex < a.first_chunk || r.ChunkIndex >= a.first_chunk + a.chunk_count)
             continue;
-        const int rel = r.ChunkIndex - a.first_chunk;
-        const int b0 = rel * a.units_per_chunk + (int)r.Params.ChunkSizeAndIndices[1] / 64;
-        const int b1 = rel * a.units_per_chunk + (int)r.Params.ChunkSizeAndIndices[2] / 64;
-        if (b1 < b0) continue;
-        if (n_ranges == 1 && b0 <= a.skip_end[0] + 1 && b1 >= a.skip_begin[0] - 1) {   // touching ranges: merge
-            a.skip_begin[0] = b0 < a.skip_begin[0] ? b0 : a.skip_begin[0];
-            a.skip_end[0] = b1 > a.skip_end[0] ? b1 : a.skip_end[0];
-        } else {
-            a.skip_begin[n_ranges] = b0; a.skip_end[n_ranges] = b1;
-            n_ranges++;
+        if (r.Params.ChunkSizeAndIndices[2] < r.Params.ChunkSizeAndIndices[1])
+            continue;
+        if (!spawning) {
+            const int unit = (r.ChunkIndex - a.first_chunk) * a.units_per_chunk + (int)r.Params.ChunkSizeAndIndices[1] / 64;
+            a.unit_rotate = unit / waves_per_block * waves_per_block;
         }
+        spawning = true;
     }
-    return n_ranges;
-}
-
-// The SPAWN-variant launch over spawn range k of a planned descriptor.
-hipError_t launch_step_spawn_range(const StepLaunch& a, int k, hipStream_t stream) {
-    StepLaunch sp = a;
-    sp.unit_begin = a.skip_begin[k];
-    sp.unit_end = a.skip_end[k] + 1;
-    return launch_step_variant<true>(sp, stream);
-}
-
-// The main launch (every unit outside the spawn ranges).
-hipError_t launch_step_main(const StepLaunch& a, hipStream_t stream) {
-    return launch_step_variant<false>(a, stream);
+    return spawning ? launch_step_variant<true>(a, stream) : launch_step_variant<false>(a, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

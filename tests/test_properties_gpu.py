@@ -53,7 +53,10 @@ def test_cfg2_one_million_particles_properties(ctx):
     before = fused.live_counts()
     assert int(before[:n_chunks].sum()) == int((pos[:, 3] > 0).sum()) and before[n_chunks] == 0
 
-    # (1) chunk independence: ONE launch over the 17-chunk table == 17 single-chunk launches, bit for bit
+    # (1) chunk independence: ONE launch over the 17-chunk table == 17 single-chunk launches.  The 17-chunk launch
+    # carries a spawn record and runs the spawning instantiation of the kernel, the spawn-free single-chunk launches
+    # the plain one; the compiler contracts a*b+c differently in the two, so floats agree to rounding (1e-6) while
+    # everything liveness depends on (the life plane, fenced from contraction) is bit-exact.
     d = cfg2_step(cs, spawn_chunk=n_chunks, first=100, last=100 + 1092)
     for _ in range(3):
         fused.step(d)
@@ -68,7 +71,9 @@ def test_cfg2_one_million_particles_properties(ctx):
     for c in range(n_chunks + 1):
         for plane in (P, V, RC, RD):
             a, b = fused.download(c, plane), split.download(c, plane)
-            assert np.array_equal(a, b, equal_nan=True), "chunk %d plane %d differs between fused and per-chunk launches" % (c, plane)
+            if plane == P:
+                assert np.array_equal(a[:, 3], b[:, 3]), "chunk %d: life differs between fused and per-chunk launches" % c
+            assert_close(a, b, "chunk %d plane %d fused vs per-chunk launches" % (c, plane), rtol=2e-6, atol=1e-7)
         # (2) count checksum: fused ballot/popcount == standalone count kernel == count of the downloaded life plane
         life = fused.download(c, P)[:, 3]
         assert counts_fused[c] == int((life > 0).sum())
