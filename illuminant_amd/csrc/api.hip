@@ -92,6 +92,18 @@ struct System {
     uint32_t* h_counts = nullptr; int h_counts_cap = 0; hipEvent_t counts_ev = nullptr; int counts_n = 0; bool counts_pending = false;
 };
 
+SdfView make_sdf_view(const Sdf* f) {
+    SdfView v;
+    v.texels = f ? f->texels : nullptr;
+    v.width = f ? f->width : 0;
+    v.height = f ? f->height : 0;
+    v.format = f ? f->format : ILM_SDF_UNORM16;
+    v.wf = (float)v.width;
+    v.hf = (float)v.height;
+    v.inv_wf = v.width > 0 ? 1.0f / v.wf : 0.0f;
+    return v;
+}
+
 template <typename T>
 T* from_handle(IlmHandle h, uint32_t magic) {
     T* p = reinterpret_cast<T*>(static_cast<uintptr_t>(h));
@@ -232,11 +244,31 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
     for (int o = 0; o < d->OpCount; o++) a.op_mask |= 1u << d->Ops[o].Type;
     a.rnd = e->rnd; a.rw = e->rw; a.rh = e->rh;
     a.ramp = s->ramp; a.ramp_w = s->ramp_w; a.ramp_h = s->ramp_h;
-    a.sdf.texels = s->sdf ? s->sdf->texels : nullptr;
-    a.sdf.width = s->sdf ? s->sdf->width : 0;
-    a.sdf.height = s->sdf ? s->sdf->height : 0;
-    a.sdf.format = s->sdf ? s->sdf->format : ILM_SDF_UNORM16;
+    a.sdf = make_sdf_view(s->sdf);
     a.live_counts = s->d_counts;
+    {   // StepDerived: same float operations, same order, as the device code they replace
+        StepDerived& dv = a.derived;
+        std::memset(&dv, 0, sizeof(dv));
+        const float dt_ms = d->System.GlobalSettings.x;
+        dv.dt_s = dt_ms / kVelocityConstantScale;
+        dv.inv_rw = 1.0f / (float)e->rw;
+        dv.inv_rh = 1.0f / (float)e->rh;
+        dv.cs_shift = -1;
+        for (int b = 0; b < 31; b++)
+            if ((1 << b) == e->chunk_size) dv.cs_shift = b;
+        for (int o = 0; o < d->OpCount; o++) {
+            const IlmTransformOp& op = d->Ops[o];
+            if (op.Type == ILM_OP_GRAVITY) {
+                dv.op[o].max_accel = op.u.Gravity.MaximumAcceleration * dt_ms / kVelocityConstantScale;
+            } else if (op.Type == ILM_OP_NOISE || op.Type == ILM_OP_FMA) {
+                const IlmAreaParams& ar = (op.Type == ILM_OP_NOISE) ? op.u.Noise.Area : op.u.FMA.Area;
+                const float divisor = (op.Type == ILM_OP_NOISE) ? op.u.Noise.TimeDivisor : op.u.FMA.TimeDivisor;
+                const int t = ar.AreaType < 0 ? -ar.AreaType : ar.AreaType;
+                dv.op[o].area_none = (t < 1 || t > 5) ? 1 : 0;
+                dv.op[o].t = ar.Strength * dt_ms / divisor;
+            }
+        }
+    }
     HIP_TRY(launch_step(a, c->stream));
     if (d->Flags & ILM_STEP_COUNT_LIVE) {
         // queue the readback behind the kernel; ilm_system_poll_counts / ilm_system_step_counts pick it up
@@ -728,6 +760,25 @@ int32_t ilm_sdf_upload(IlmHandle h, const uint16_t* texels) {
     return ILM_OK;
 }
 
+int32_t ilm_sdf_sample(IlmHandle h, const IlmDistanceFieldUniforms* df, const float* positions, int32_t count, float* out_distances) {
+    Sdf* f = from_handle<Sdf>(h, kMagicSdf);
+    if (!f) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle");
+    if (!df || count < 0 || (count > 0 && (!positions || !out_distances))) return fail(ILM_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (count == 0) return ILM_OK;
+    Ctx* c = f->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t in_bytes = sizeof(float) * 3 * (size_t)count, out_bytes = sizeof(float) * (size_t)count;
+    int32_t rc = ensure_staging(c, in_bytes + out_bytes);
+    if (rc != ILM_OK) return rc;
+    float* d_in = static_cast<float*>(c->staging);
+    float* d_out = d_in + 3 * (size_t)count;
+    HIP_TRY(hipMemcpyAsync(d_in, positions, in_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_sdf_sample(make_sdf_view(f), *df, d_in, count, d_out, c->stream));
+    HIP_TRY(hipMemcpyAsync(out_distances, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ILM_OK;
+}
+
 int32_t ilm_sdf_destroy(IlmHandle h) {
     Sdf* f = from_handle<Sdf>(h, kMagicSdf);
     if (!f) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle");
@@ -875,8 +926,7 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
     a.df = *df;
     a.gbuffer.texels = g ? g->texels : nullptr;
     a.gbuffer.width = g ? g->width : 0; a.gbuffer.height = g ? g->height : 0; a.gbuffer.format = g ? g->format : 0;
-    a.sdf.texels = f ? f->texels : nullptr;
-    a.sdf.width = f ? f->width : 0; a.sdf.height = f ? f->height : 0; a.sdf.format = f ? f->format : ILM_SDF_UNORM16;
+    a.sdf = make_sdf_view(f);
     for (int i = 0; i < 4; i++) a.ambient[i] = ambient[i];
     a.lightmap = m->texels; a.width = m->width; a.height = m->height; a.format = m->format;
     a.row_begin = row_begin; a.row_end = row_end;

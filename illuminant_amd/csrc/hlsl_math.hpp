@@ -96,24 +96,45 @@ struct SdfView {
     const uint2* texels;   // one RGBA16 texel = 8 bytes
     int width, height;
     int format;            // ILM_SDF_UNORM16 / ILM_SDF_FP16
+    float wf, hf;          // (float)width, (float)height
+    float inv_wf;          // 1 / wf (seed of the exact integer wrap; any value within 1 ulp works)
 };
 
+// x / 65535 for an integer-valued x in [0, 65535], correctly rounded: one multiply by fl(1/65535) and one
+// Markstein correction step (two FMAs) instead of the ~10-instruction IEEE division sequence.  Equality with the
+// division for all 65536 inputs is checked on the device by tests/test_sdf_sample_gpu.py.
+ILM_DEV float unorm16_to_float(float x) {
+    const float r = 1.0f / 65535.0f;
+    const float q = x * r;
+    const float e = __builtin_fmaf(-q, 65535.0f, x);
+    return __builtin_fmaf(e, r, q);
+}
+
+// One 32-bit word holding the two channels of a texel that virtual slice 3k+m blends: low half = slice m's
+// channel, high half = the next one.  m = 0: (r,g)  1: (g,b)  2: (b,a).
+ILM_DEV uint32_t sdf_pair_word(uint2 t, int m) {
+    const uint32_t mid = __builtin_amdgcn_alignbit(t.y, t.x, 16);   // (g, b)
+    return (m == 0) ? t.x : ((m == 1) ? mid : t.y);
+}
+
 template <int FORMAT>
-ILM_DEV void sdf_unpack2(uint2 t, int pair, float& a, float& b) {
-    // pair 0: (r,g)  1: (g,b)  2: (b,a)
-    uint32_t lo, hi;
-    if (pair == 0) { lo = t.x & 0xFFFFu; hi = t.x >> 16; }
-    else if (pair == 1) { lo = t.x >> 16; hi = t.y & 0xFFFFu; }
-    else { lo = t.y & 0xFFFFu; hi = t.y >> 16; }
+ILM_DEV void sdf_unpack_word(uint32_t w, float& a, float& b) {
     if (FORMAT == ILM_SDF_FP16) {
-        a = __half2float(__ushort_as_half((unsigned short)lo));
-        b = __half2float(__ushort_as_half((unsigned short)hi));
+        a = __half2float(__ushort_as_half((unsigned short)(w & 0xFFFFu)));
+        b = __half2float(__ushort_as_half((unsigned short)(w >> 16)));
     } else {
-        a = (float)lo / 65535.0f;
-        b = (float)hi / 65535.0f;
+        a = unorm16_to_float((float)(w & 0xFFFFu));
+        b = unorm16_to_float((float)(w >> 16));
     }
 }
 
+// sampleDistanceFieldEx.  Same IEEE operations on every value the result depends on as the CPU oracle (the cone
+// trace's loop exits are discontinuous in this value, and the tests require the oracle's exact sample counts);
+// what is rewritten is the integer bookkeeping around them:
+//   floor(vslice / 3) and vslice % 3      -> multiply-shift on the integer slice number (exact for vslice < 65536)
+//   WRAP / CLAMP tap indices              -> exact float-reciprocal wrap (|index| < 2^23) and integer clamps
+//   distance to the volume                -> the sqrt is skipped when every lane of the wave is inside the volume
+//   unorm16 decode                        -> unorm16_to_float
 template <int FORMAT>
 ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms& df, const SdfView& sdf) {
 #pragma clang fp contract(off)
@@ -123,37 +144,50 @@ ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms&
     const f3 dtv = mk3(-fminf(position.x, 0.0f) + (fmaxf(position.x, ex) - ex),
                        -fminf(position.y, 0.0f) + (fmaxf(position.y, ey) - ey),
                        -fminf(position.z, 0.0f) + (fmaxf(position.z, ez) - ez));
-    const float distance_to_volume = len3(dtv);
+    const float d2 = dot3(dtv, dtv);
+    float distance_to_volume = 0.0f;                 // sqrt(+0) == +0: skipping it inside the volume is exact
+    if (__builtin_amdgcn_ballot_w64(d2 != 0.0f) != 0ull)
+        distance_to_volume = sqrtf(d2);
 
     const float slice_position = fminf(cz, df.Packed1.z) * df.Packed1.y;
     const float vslice = floorf(slice_position);
+    const uint32_t vi = (uint32_t)vslice;                    // 0 <= vslice < 65536
+    const uint32_t third = (vi * 0xAAABu) >> 17;             // vi / 3
+    const int m = (int)(vi - 3u * third);                    // vi % 3
 
-    const float column_index = floorf(vslice / 3.0f);
-    const float row_index = floorf(vslice * df.Packed1.x);
+    const float column_index = (float)third;                 // floor(vslice / 3)
+    const float row_index = floorf(vslice * df.Packed1.x);   // floor(vslice * invCols / 3): the reference's float form
     const float u = column_index * df.TextureSliceAndTexelSize.x + cx * df.TextureSliceAndTexelSize.z;
     const float v = row_index * df.TextureSliceAndTexelSize.y + cy * df.TextureSliceAndTexelSize.w;
 
     // LINEAR, U WRAP, V CLAMP, texel centres at +0.5
-    const float x = u * (float)sdf.width - 0.5f;
-    const float y = v * (float)sdf.height - 0.5f;
+    const float x = u * sdf.wf - 0.5f;
+    const float y = v * sdf.hf - 0.5f;
     const float x0f = floorf(x), y0f = floorf(y);
     const float fx = x - x0f, fy = y - y0f;
-    const int x0 = wrap_index(x0f, sdf.width), x1 = wrap_index(x0f + 1.0f, sdf.width);
-    int y0 = (int)y0f, y1 = (int)y0f + 1;
-    y0 = min(max(y0, 0), sdf.height - 1);
-    y1 = min(max(y1, 0), sdf.height - 1);
+    int x0;
+    {   // positive modulo of x0f by the atlas width; the remainder is exact in fp32, q may be off by one
+        const float q = floorf(x0f * sdf.inv_wf);
+        float r = x0f - q * sdf.wf;
+        r = (r < 0.0f) ? r + sdf.wf : r;
+        r = (r >= sdf.wf) ? r - sdf.wf : r;
+        x0 = (int)r;
+    }
+    int x1 = x0 + 1;
+    x1 = (x1 == sdf.width) ? 0 : x1;
+    const int yi = (int)y0f;
+    const int y0 = min(max(yi, 0), sdf.height - 1);
+    const int y1 = min(max(yi + 1, 0), sdf.height - 1);
 
-    const uint2* row0 = sdf.texels + (size_t)y0 * (size_t)sdf.width;
-    const uint2* row1 = sdf.texels + (size_t)y1 * (size_t)sdf.width;
-    const uint2 t00 = row0[x0], t10 = row0[x1], t01 = row1[x0], t11 = row1[x1];
+    const uint32_t r0 = (uint32_t)(y0 * sdf.width), r1 = (uint32_t)(y1 * sdf.width);
+    const uint2 t00 = sdf.texels[r0 + (uint32_t)x0], t10 = sdf.texels[r0 + (uint32_t)x1];
+    const uint2 t01 = sdf.texels[r1 + (uint32_t)x0], t11 = sdf.texels[r1 + (uint32_t)x1];
 
-    const float m = fmodf(vslice, 3.0f);
-    const int pair = (m >= 2.0f) ? 2 : ((m >= 1.0f) ? 1 : 0);
     float a00, b00, a10, b10, a01, b01, a11, b11;
-    sdf_unpack2<FORMAT>(t00, pair, a00, b00);
-    sdf_unpack2<FORMAT>(t10, pair, a10, b10);
-    sdf_unpack2<FORMAT>(t01, pair, a01, b01);
-    sdf_unpack2<FORMAT>(t11, pair, a11, b11);
+    sdf_unpack_word<FORMAT>(sdf_pair_word(t00, m), a00, b00);
+    sdf_unpack_word<FORMAT>(sdf_pair_word(t10, m), a10, b10);
+    sdf_unpack_word<FORMAT>(sdf_pair_word(t01, m), a01, b01);
+    sdf_unpack_word<FORMAT>(sdf_pair_word(t11, m), a11, b11);
     const float lo = lerp(lerp(a00, a10, fx), lerp(a01, a11, fx), fy);
     const float hi = lerp(lerp(b00, b10, fx), lerp(b01, b11, fx), fy);
     const float blended = lerp(lo, hi, slice_position - vslice);

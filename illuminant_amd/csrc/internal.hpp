@@ -22,8 +22,24 @@ constexpr int kStepThreads = 256;
 constexpr int kSlotsPerBlock = kSlotsPerThread * kStepThreads;  // 1024; strides are padded to this
 constexpr int kDefaultStepMinWaves = 1;   // __launch_bounds__ min waves/SIMD of the main step variant (override: ILM_STEP_MINWAVES=6|7|8)
 
+// Values every wave would otherwise recompute on the vector ALU from uniform inputs (gfx950 has no scalar float
+// unit): filled on the host with the SAME IEEE single-precision operations, in the same order, as the per-slot
+// code they replace, so the results are bit-identical (api.hip is compiled with -ffp-contract=off).
+struct StepDerived {
+    float dt_s;                  // getDeltaTimeSeconds: GlobalSettings.x / 1000            (ParticleCommon.fxh:54-56)
+    float inv_rw, inv_rh;        // RandomnessTexel = 1 / (807, 653)                         (RandomCommon.fxh:12-15)
+    int32_t cs_shift;            // log2(chunk_size) when it is a power of two, else -1
+    struct Op {
+        int32_t area_none;       // AreaType outside 1..5: evaluateByTypeId returns 0 => weight == Strength exactly
+        float   t;               // Noise / FMA with area_none: weight * dtMs / TimeDivisor
+        float   max_accel;       // Gravity: MaximumAcceleration * dtMs / 1000
+        int32_t _pad;
+    } op[ILM_MAX_OPS];
+};
+
 struct StepLaunch {
     IlmStepDesc desc;
+    StepDerived derived;
     float* const* chunk_bases;   // device table, one base pointer per chunk
     int64_t stride;              // floats between component planes (multiple of kSlotsPerBlock)
     int32_t chunk_size;
@@ -76,5 +92,7 @@ constexpr size_t kLightRecBytes = 128;   // sizeof(LightRec) in lighting.hip
 hipError_t launch_prepare_lights(const IlmLightVertex* lights, int count, const IlmEnvironment& env, float max_cone_radius,
                                  void* recs, hipStream_t stream);
 hipError_t launch_sphere_lights_prepared(const LightLaunch& a, const void* recs, hipStream_t stream);
+// sampleDistanceFieldEx at `count` positions (xyz triples) -- diagnostic entry point ilm_sdf_sample
+hipError_t launch_sdf_sample(const SdfView& sdf, const IlmDistanceFieldUniforms& df, const float* positions, int count, float* out, hipStream_t stream);
 
 }  // namespace ilm

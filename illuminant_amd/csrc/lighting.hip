@@ -330,6 +330,22 @@ __global__ __launch_bounds__(256) void sphere_lights_kernel(const LightLaunch a,
     }
 }
 
+template <int FMT>
+__global__ __launch_bounds__(256) void sdf_sample_kernel(SdfView sdf, IlmDistanceFieldUniforms df, const float* __restrict__ positions, int count,
+                                                          float* __restrict__ out) {
+    const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (i >= count) return;
+    out[i] = sample_distance_field<FMT>(mk3(positions[3 * i], positions[3 * i + 1], positions[3 * i + 2]), df, sdf);
+}
+
+hipError_t launch_sdf_sample(const SdfView& sdf, const IlmDistanceFieldUniforms& df, const float* positions, int count, float* out, hipStream_t stream) {
+    if (count <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((count + 255) / 256)), block(256);
+    if (sdf.format == ILM_SDF_FP16) hipLaunchKernelGGL(sdf_sample_kernel<ILM_SDF_FP16>, grid, block, 0, stream, sdf, df, positions, count, out);
+    else hipLaunchKernelGGL(sdf_sample_kernel<ILM_SDF_UNORM16>, grid, block, 0, stream, sdf, df, positions, count, out);
+    return hipGetLastError();
+}
+
 // device scratch for the prepared light records, owned by the caller (api.hip)
 hipError_t launch_prepare_lights(const IlmLightVertex* lights, int count, const IlmEnvironment& env, float max_cone_radius,
                                  void* recs, hipStream_t stream) {

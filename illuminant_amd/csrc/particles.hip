@@ -23,10 +23,9 @@ ILM_DEV float dt_seconds(const IlmParticleSystemUniforms& s) { return s.GlobalSe
 ILM_DEV bool category_ok(float type, const float mm[2]) { return (type >= mm[0]) && (type <= mm[1]); }
 
 // randomCustom, RandomCommon.fxh:27-30 (POINT, WRAP)
-ILM_DEV float4 random_custom(const float4* __restrict__ rnd, int rw, int rh, float x, float y,
+ILM_DEV float4 random_custom(const float4* __restrict__ rnd, int rw, int rh, float texel_x, float texel_y, float x, float y,
                              float off_x, float off_y, float rate_x, float rate_y) {
 #pragma clang fp contract(off)   // table indices are bit-exact
-    const float texel_x = 1.0f / (float)rw, texel_y = 1.0f / (float)rh;
     const float u = ((x * rate_x) + off_x) * texel_x;
     const float v = ((y * rate_y) + off_y) * texel_y;
     const int tx = wrap_index_fast(floorf(u * (float)rw), rw);
@@ -112,12 +111,25 @@ ILM_DEV float compute_weight(const IlmAreaParams& a, f3 wp) {
     const float distance = evaluate_area(a.AreaType, wp, a);
     return (1.0f - sat(distance / a.AreaFalloff)) * a.Strength;
 }
+// weight and time factor of an area transform.  Without an area evaluateByTypeId returns 0, so
+// weight = (1 - saturate(0 / falloff)) * Strength = Strength and t = Strength * dtMs / TimeDivisor are uniform:
+// both come from the host (StepDerived), computed with the same operations.
+ILM_DEV void area_weight_and_t(const IlmAreaParams& a, const StepDerived::Op& dv, f3 wp, float dt_ms, float time_divisor, float& weight, float& t) {
+#pragma clang fp contract(off)
+    if (dv.area_none) {
+        weight = a.Strength;
+        t = dv.t;
+    } else {
+        weight = compute_weight(a, wp);
+        t = weight * dt_ms / time_divisor;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // transforms
 // ---------------------------------------------------------------------------------------------
 // PS_Gravity, Gravity.fx:12-61
-ILM_DEV void apply_gravity(float4& pos, float4& vel, const IlmParticleSystemUniforms& sys, const IlmGravityParams& p) {
+ILM_DEV void apply_gravity(float4& pos, float4& vel, const IlmParticleSystemUniforms& sys, const IlmGravityParams& p, const StepDerived::Op& dv) {
     if ((pos.w <= 0.0f) || !category_ok(vel.w, p.CategoryFilter))
         return;
     const float dt_ms = sys.GlobalSettings.x;
@@ -144,7 +156,7 @@ ILM_DEV void apply_gravity(float4& pos, float4& vel, const IlmParticleSystemUnif
         }
         acceleration = acceleration + (((to_center * inv_len) * attraction) * strength);
     }
-    const float maximum_acceleration = p.MaximumAcceleration * dt_ms / kVelocityConstantScale;
+    const float maximum_acceleration = dv.max_accel;
     const float a2 = dot3(acceleration, acceleration);
     if (a2 > maximum_acceleration * maximum_acceleration)
         acceleration = acceleration * (fast_rsq(a2) * maximum_acceleration);
@@ -159,11 +171,11 @@ ILM_DEV float fma_term_exact(float v, float m, float a) {
     return (v * m) + a;
 }
 // PS_FMA, FMA.fx:22-51
-ILM_DEV void apply_fma(float4& pos, float4& vel, const IlmParticleSystemUniforms& sys, const IlmFMAParams& p) {
+ILM_DEV void apply_fma(float4& pos, float4& vel, const IlmParticleSystemUniforms& sys, const IlmFMAParams& p, const StepDerived::Op& dv) {
     if ((pos.w <= 0.0f) || !category_ok(vel.w, p.Area.CategoryFilter))
         return;
-    const float weight = compute_weight(p.Area, xyz(pos));
-    const float t = weight * sys.GlobalSettings.x / p.TimeDivisor;
+    float weight, t;
+    area_weight_and_t(p.Area, dv, xyz(pos), sys.GlobalSettings.x, p.TimeDivisor, weight, t);
     float4 np = lerp4(pos, add4(mul4(pos, ld4(p.PositionMultiply)), ld4(p.PositionAdd)), t);
     np.w = lerp_exact(pos.w, fma_term_exact(pos.w, p.PositionMultiply.w, p.PositionAdd.w), t);   // life
     const float4 nv = lerp4(vel, add4(mul4(vel, ld4(p.VelocityMultiply)), ld4(p.VelocityAdd)), t);
@@ -179,17 +191,17 @@ ILM_DEV float4 noise_shape(float4 r, const IlmFloat4& offset, const IlmFloat4& m
 
 // PS_Noise, Noise.fx:28-72 (no life check: dead slots go through the math, :40)
 ILM_DEV void apply_noise(float4& pos, float4& vel, float x, float y, const float4* __restrict__ rnd, int rw, int rh,
-                         const IlmParticleSystemUniforms& sys, const IlmNoiseParams& p) {
+                         const IlmParticleSystemUniforms& sys, const IlmNoiseParams& p, const StepDerived& sd, const StepDerived::Op& dv) {
     if (!category_ok(vel.w, p.Area.CategoryFilter))
         return;
-    const float weight = compute_weight(p.Area, xyz(pos));
-    const float t = weight * sys.GlobalSettings.x / p.TimeDivisor;
+    float weight, t;
+    area_weight_and_t(p.Area, dv, xyz(pos), sys.GlobalSettings.x, p.TimeDivisor, weight, t);
 
-    const float rate_x = 1.0f / (float)rw, rate_y = 1.0f / (float)rh;  // rate = RandomnessTexel (Noise.fx:49-52)
-    const float4 p1 = random_custom(rnd, rw, rh, x, y, p.RandomnessOffset[0], p.RandomnessOffset[1], rate_x, rate_y);
-    const float4 p2 = random_custom(rnd, rw, rh, x, y, p.NextRandomnessOffset[0], p.NextRandomnessOffset[1], rate_x, rate_y);
-    const float4 v1 = random_custom(rnd, rw, rh, x + 2.0f, y + 1.0f, p.RandomnessOffset[0], p.RandomnessOffset[1], rate_x, rate_y);
-    const float4 v2 = random_custom(rnd, rw, rh, x + 2.0f, y + 1.0f, p.NextRandomnessOffset[0], p.NextRandomnessOffset[1], rate_x, rate_y);
+    const float rate_x = sd.inv_rw, rate_y = sd.inv_rh;  // rate = RandomnessTexel (Noise.fx:49-52)
+    const float4 p1 = random_custom(rnd, rw, rh, rate_x, rate_y, x, y, p.RandomnessOffset[0], p.RandomnessOffset[1], rate_x, rate_y);
+    const float4 p2 = random_custom(rnd, rw, rh, rate_x, rate_y, x, y, p.NextRandomnessOffset[0], p.NextRandomnessOffset[1], rate_x, rate_y);
+    const float4 v1 = random_custom(rnd, rw, rh, rate_x, rate_y, x + 2.0f, y + 1.0f, p.RandomnessOffset[0], p.RandomnessOffset[1], rate_x, rate_y);
+    const float4 v2 = random_custom(rnd, rw, rh, rate_x, rate_y, x + 2.0f, y + 1.0f, p.NextRandomnessOffset[0], p.NextRandomnessOffset[1], rate_x, rate_y);
 
     const float4 position_delta = noise_shape(lerp4(p1, p2, p.FrequencyLerp), p.PositionOffset, p.PositionMinimum, p.PositionScale);
     const float4 velocity_delta = noise_shape(lerp4(v1, v2, p.FrequencyLerp), p.VelocityOffset, p.VelocityMinimum, p.VelocityScale);
@@ -266,15 +278,15 @@ ILM_DEV float mod_const(float index) { return (float)((unsigned)index % M); }
 
 // Returns true when the slot was (re)written by the spawner.
 ILM_DEV bool spawn_slot(float4& pos, float4& vel, float4& attr, float x, float y,
-                        const float4* __restrict__ rnd, int rw, int rh, const IlmSpawnParams& p) {
+                        const float4* __restrict__ rnd, int rw, int rh, float tx_, float ty_, const IlmSpawnParams& p) {
     const float index = x + (y * p.ChunkSizeAndIndices[0]);
     if ((index < p.ChunkSizeAndIndices[1]) || (index > p.ChunkSizeAndIndices[2]))
         return false;
 
     const float ox = p.RandomnessOffset[0], oy = p.RandomnessOffset[1];
-    const float4 random1 = random_custom(rnd, rw, rh, mod_const<8039u>(index), 0.0f + mod_const<57u>(index), ox, oy, 1.0f, 1.0f);
-    float4 random2 = random_custom(rnd, rw, rh, mod_const<6180u>(index), 1.0f + mod_const<4031u>(index), ox, oy, 1.0f, 1.0f);
-    const float4 random3 = random_custom(rnd, rw, rh, mod_const<2025u>(index), 2.0f + mod_const<65531u>(index), ox, oy, 1.0f, 1.0f);
+    const float4 random1 = random_custom(rnd, rw, rh, tx_, ty_, mod_const<8039u>(index), 0.0f + mod_const<57u>(index), ox, oy, 1.0f, 1.0f);
+    float4 random2 = random_custom(rnd, rw, rh, tx_, ty_, mod_const<6180u>(index), 1.0f + mod_const<4031u>(index), ox, oy, 1.0f, 1.0f);
+    const float4 random3 = random_custom(rnd, rw, rh, tx_, ty_, mod_const<2025u>(index), 2.0f + mod_const<65531u>(index), ox, oy, 1.0f, 1.0f);
     if (p.AlignVelocityAndPosition != 0.0f) {
         random2.x = random1.x;
         random2.y = random1.y;
@@ -363,10 +375,10 @@ ILM_DEV float t_for_scaled_bezier(const IlmFloat4& rc, float value, float& t) {
 }
 // evaluateBezier1, Bezier.fxh:69-105
 ILM_DEV float bezier1(const IlmClampedBezier1& bz, float value) {
+    const float a = bz.ABCD.x, b = bz.ABCD.y, c = bz.ABCD.z, d = bz.ABCD.w;
+    if (bz.RangeAndCount.z <= 1.5f) return a;   // constant curve (ClampedBezier1.One): t is not needed
     float t;
     const float count = t_for_scaled_bezier(bz.RangeAndCount, value, t);
-    const float a = bz.ABCD.x, b = bz.ABCD.y, c = bz.ABCD.z, d = bz.ABCD.w;
-    if (count <= 1.5f) return a;
     const float ab = lerp(a, b, t);
     if (count <= 2.5f) return ab;
     if (count <= 3.5f) return (t <= 0.0f) ? a : ((t >= 1.0f) ? c : b);
@@ -375,10 +387,10 @@ ILM_DEV float bezier1(const IlmClampedBezier1& bz, float value) {
 }
 // evaluateBezier4, Bezier.fxh:141-177
 ILM_DEV float4 bezier4(const IlmClampedBezier4& bz, float value) {
+    const float4 a = ld4(bz.A);
+    if (bz.RangeAndCount.z <= 1.5f) return a;   // constant curve (ClampedBezier4.One): t is not needed
     float t;
     const float count = t_for_scaled_bezier(bz.RangeAndCount, value, t);
-    const float4 a = ld4(bz.A);
-    if (count <= 1.5f) return a;
     const float4 b = ld4(bz.B);
     const float4 ab = lerp4(a, b, t);
     if (count <= 2.5f) return ab;
@@ -390,7 +402,7 @@ ILM_DEV float4 bezier4(const IlmClampedBezier4& bz, float value) {
 }
 
 // applyFrictionAndMaximum, UpdateCommon.fxh:20-35
-ILM_DEV f3 friction_and_maximum(f3 velocity, const IlmParticleSystemUniforms& sys) {
+ILM_DEV f3 friction_and_maximum(f3 velocity, const IlmParticleSystemUniforms& sys, float dts) {
     const float l2 = dot3(velocity, velocity);
     const float inv_l = fast_rsq(l2);
     float l = l2 * inv_l;
@@ -400,7 +412,7 @@ ILM_DEV f3 friction_and_maximum(f3 velocity, const IlmParticleSystemUniforms& sy
     if (l > mv)
         l = mv;
     const float friction = l * sys.GlobalSettings.y;
-    l -= (friction * dt_seconds(sys));
+    l -= (friction * dts);
     l = clampf(l, 0.0f, mv);
     return velocity * (inv_l * l);
 }
@@ -453,10 +465,9 @@ ILM_DEV void render_data(float vx, float vy, float4 position, float4 velocity, f
 }
 
 // PS_Update, UpdateParticleSystem.fx:9-38 (live slot)
-ILM_DEV void update_positions(float4& pos, float4& vel, const IlmParticleSystemUniforms& sys) {
+ILM_DEV void update_positions(float4& pos, float4& vel, const IlmParticleSystemUniforms& sys, float dts) {
 #pragma clang fp contract(off)   // life arithmetic is bit-exact
-    const f3 velocity = friction_and_maximum(xyz(vel), sys);
-    const float dts = dt_seconds(sys);
+    const f3 velocity = friction_and_maximum(xyz(vel), sys, dts);
     const float new_life = pos.w - (sys.GlobalSettings.w * dts);
     if (new_life <= 0.0f) {
         pos = vel = mk4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -484,11 +495,10 @@ ILM_DEV f3 estimate_normal4(f3 position, const IlmDistanceFieldUniforms& df, con
 
 // PS_Update, UpdateParticleSystemWithDistanceField.fx:29-147 (live slot)
 template <int FMT>
-ILM_DEV void update_with_distance_field(float4& pos, float4& vel, float x, float y, const IlmParticleSystemUniforms& sys,
+ILM_DEV void update_with_distance_field(float4& pos, float4& vel, float x, float y, const IlmParticleSystemUniforms& sys, float dts,
                                         const IlmDistanceFieldUniforms& df, const SdfView& sdf) {
 #pragma clang fp contract(off)   // discontinuous collision state machine + life arithmetic: keep IEEE-exact
     const float4 zero = mk4(0.0f, 0.0f, 0.0f, 0.0f);
-    const float dts = dt_seconds(sys);
     float new_life = pos.w - (sys.GlobalSettings.w * dts);
     if (new_life <= 0.0f) {
         pos = vel = zero;
@@ -498,7 +508,7 @@ ILM_DEV void update_with_distance_field(float4& pos, float4& vel, float x, float
     const float max_velocity = sys.GlobalSettings.z;
     const f3 old_xyz = xyz(pos);
     const f3 unit_vector = norm3(xyz(vel));
-    const f3 velocity = friction_and_maximum(xyz(vel), sys);
+    const f3 velocity = friction_and_maximum(xyz(vel), sys, dts);
     const f3 scaled_velocity = velocity * dts;
 
     bool collided = false, escaping = false;
@@ -666,7 +676,7 @@ ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* ub, int chunk, int i, unsigne
         float4 attr = mk4(cur.ar, cur.ag, cur.ab, cur.aa);
         // slot (x, y): the unit's first slot is divided on the scalar unit, lanes only fold the row wrap
         const int cs = a.chunk_size;
-        const int row0 = __builtin_amdgcn_readfirstlane((seg * 64) / cs);
+        const int row0 = (a.derived.cs_shift >= 0) ? ((seg * 64) >> a.derived.cs_shift) : __builtin_amdgcn_readfirstlane((seg * 64) / cs);
         int sy = row0, sx = (seg * 64 - row0 * cs) + (int)lane;
         while (sx >= cs) { sx -= cs; sy++; }
         const float fx = (float)sx, fy = (float)sy;
@@ -676,7 +686,7 @@ ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* ub, int chunk, int i, unsigne
             if (spawn_here) {
                 for (int s = 0; s < d.SpawnCount; s++) {
                     if (d.Spawns[s].ChunkIndex == chunk) {
-                        if (spawn_slot(pos, vel, attr, fx, fy, a.rnd, a.rw, a.rh, d.Spawns[s].Params))
+                        if (spawn_slot(pos, vel, attr, fx, fy, a.rnd, a.rw, a.rh, a.derived.inv_rw, a.derived.inv_rh, d.Spawns[s].Params))
                             spawned = true;
                     }
                 }
@@ -686,11 +696,11 @@ ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* ub, int chunk, int i, unsigne
         for (int o = 0; o < d.OpCount; o++) {
             const IlmTransformOp& op = d.Ops[o];
             if (op.Type == ILM_OP_GRAVITY)
-                apply_gravity(pos, vel, d.System, op.u.Gravity);
+                apply_gravity(pos, vel, d.System, op.u.Gravity, a.derived.op[o]);
             else if (op.Type == ILM_OP_NOISE)
-                apply_noise(pos, vel, fx, fy, a.rnd, a.rw, a.rh, d.System, op.u.Noise);
+                apply_noise(pos, vel, fx, fy, a.rnd, a.rw, a.rh, d.System, op.u.Noise, a.derived, a.derived.op[o]);
             else if (op.Type == ILM_OP_FMA)
-                apply_fma(pos, vel, d.System, op.u.FMA);
+                apply_fma(pos, vel, d.System, op.u.FMA, a.derived.op[o]);
         }
 
         float4 rc = zero, rd = zero;
@@ -699,9 +709,9 @@ ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* ub, int chunk, int i, unsigne
                 pos = vel = zero;  // readStateOrDiscard: discard => cleared target
             } else {
                 if constexpr (DF)
-                    update_with_distance_field<FMT>(pos, vel, fx, fy, d.System, d.DistanceField, a.sdf);
+                    update_with_distance_field<FMT>(pos, vel, fx, fy, d.System, a.derived.dt_s, d.DistanceField, a.sdf);
                 else
-                    update_positions(pos, vel, d.System);
+                    update_positions(pos, vel, d.System, a.derived.dt_s);
                 render_data(fx, fy, pos, vel, attr, d.System, d.Update, a.ramp, a.ramp_w, a.ramp_h, rc, rd);
             }
         }

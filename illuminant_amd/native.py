@@ -62,6 +62,7 @@ SYMBOLS = {
     "ilm_chunk_live_slots": (_I, [_H, _I, _P, _I, C.POINTER(_I)]),
     "ilm_sdf_create": (_I, [_H, _I, _I, _I, C.POINTER(_H)]),
     "ilm_sdf_upload": (_I, [_H, _P]),
+    "ilm_sdf_sample": (_I, [_H, _P, _P, _I, _P]),
     "ilm_sdf_destroy": (_I, [_H]),
     "ilm_gbuffer_create": (_I, [_H, _I, _I, _I, C.POINTER(_H)]),
     "ilm_gbuffer_upload": (_I, [_H, _P]),
@@ -271,6 +272,13 @@ class DistanceFieldTexture:
         self.handle = abi.Handle(0)
         check(lib().ilm_sdf_create(ctx.handle, self.width, self.height, fmt, C.byref(self.handle)))
         check(lib().ilm_sdf_upload(self.handle, _ptr(a)))
+
+    def sample(self, df, positions):
+        """ilm_sdf_sample: distances at (n, 3) float32 world positions."""
+        positions = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+        out = np.empty(positions.shape[0], dtype=np.float32)
+        check(lib().ilm_sdf_sample(self.handle, _byref(df), _ptr(positions), positions.shape[0], _ptr(out)))
+        return out
 
     def upload(self, texels):
         a = np.ascontiguousarray(texels, dtype=np.uint16)

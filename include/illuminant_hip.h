@@ -367,6 +367,11 @@ int32_t ilm_chunk_live_slots(IlmHandle system, int32_t chunk_index, uint32_t* ou
  * layout, DistanceField.cs:178-213). */
 int32_t ilm_sdf_create(IlmHandle ctx, int32_t atlas_width, int32_t atlas_height, int32_t format, IlmHandle* out_sdf);
 int32_t ilm_sdf_upload(IlmHandle sdf, const uint16_t* texels);
+/* sampleDistanceFieldEx (Illuminant/Shaders/DistanceFieldCommon.fxh:313-353) evaluated on the device at `count`
+ * world positions (host array of xyz triples); writes `count` distances to out_distances (host) and synchronises.
+ * Not on the reference's call path: it exposes the very sampler the particle collision and the cone trace use, so a
+ * host (or a test) can query the field the kernels see. */
+int32_t ilm_sdf_sample(IlmHandle sdf, const IlmDistanceFieldUniforms* df, const float* positions, int32_t count, float* out_distances);
 int32_t ilm_sdf_destroy(IlmHandle sdf);
 
 /* G-buffer (Illuminant/GBuffer.cs): width x height texels (encNormal.xy, relativeY, encodedZ). */

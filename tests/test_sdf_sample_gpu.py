@@ -1,0 +1,76 @@
+"""sampleDistanceFieldEx on the device (ilm_sdf_sample) against the oracle, BIT FOR BIT.
+
+The cone trace's loop exits are discontinuous in the sampled distance, and the renderer tests require the oracle's
+exact SDF sample counts, so the device sampler must reproduce every rounding of the restated HLSL arithmetic even
+though its integer bookkeeping (slice / 3, % 3, WRAP, unorm16 decode) is implemented differently.
+"""
+import numpy as np
+import pytest
+
+from illuminant_amd import abi, native, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def oracle_samples(oracle, positions, dfu, tex):
+    return np.array([oracle.sample_distance_field(p, dfu, tex) for p in positions], dtype=np.float32)
+
+
+def test_unorm16_decode_is_exact_for_every_code(ctx, oracle):
+    """All 65536 unorm16 values, read back at texel centres of slice 0 (weights 0: the sample is the texel itself):
+    the 3-instruction decode equals value / 65535 exactly."""
+    layout = scenes.DistanceFieldLayout(256, 256, 64.0, 3, 1.0)
+    assert (layout.atlas_width, layout.atlas_height) == (256, 256)
+    dfu = layout.uniforms()
+    atlas = np.zeros((256, 256, 4), np.uint16)
+    atlas[..., 0] = np.arange(65536, dtype=np.uint32).reshape(256, 256).astype(np.uint16)
+    atlas[..., 1] = atlas[..., 0][::-1, ::-1]
+    sdf = native.DistanceFieldTexture(ctx, atlas)
+    ys, xs = np.mgrid[0:256, 0:256]
+    pos = np.stack([xs + 0.5, ys + 0.5, np.zeros_like(xs, dtype=np.float64)], axis=-1).reshape(-1, 3).astype(np.float32)
+    got = sdf.sample(dfu, pos)
+    want = ((np.float32(192.0) / np.float32(255.0)) - (np.arange(65536, dtype=np.float32) / np.float32(65535.0))) * np.float32(128.0)
+    assert np.array_equal(got, want.astype(np.float32))
+    # the oracle agrees on a subsample (it is slow per call through ctypes)
+    idx = np.arange(0, 65536, 97)
+    assert np.array_equal(got[idx], oracle_samples(oracle, pos[idx], dfu, oracle.make_texture(atlas, abi.SDF_UNORM16)))
+    sdf.close()
+
+
+@pytest.mark.parametrize("fmt", [abi.SDF_UNORM16, abi.SDF_FP16])
+@pytest.mark.parametrize("packed1", [True, False])
+def test_random_positions_match_the_oracle_bit_for_bit(ctx, oracle, fmt, packed1):
+    """Multi-row atlas (U WRAP carries the column index past 1.0), every slice pair, positions inside, on the faces
+    of and outside the volume, negative z offsets."""
+    layout = scenes.DistanceFieldLayout(2048, 2048, 128.0, 32, 0.25)      # 512x512 slices, 3 x 4 atlas (cfg3 / cfg5 shape)
+    rng = np.random.default_rng(5)
+    atlas = rng.integers(0, 65536, size=(layout.atlas_height, layout.atlas_width, 4), dtype=np.uint16)
+    if fmt == abi.SDF_FP16:
+        atlas = rng.uniform(0.0, 1.5, size=atlas.shape).astype(np.float16).view(np.uint16)
+    dfu = layout.uniforms(z_offset=-3.0, packed1=packed1)
+    sdf = native.DistanceFieldTexture(ctx, atlas, fmt)
+    n = 6000
+    pos = np.empty((n, 3), np.float32)
+    pos[:, 0] = rng.uniform(-40.0, 2090.0, n)
+    pos[:, 1] = rng.uniform(-40.0, 2090.0, n)
+    pos[:, 2] = rng.uniform(-20.0, 140.0, n)
+    pos[:200] = np.round(pos[:200])                       # integer coordinates: taps exactly on texel boundaries
+    pos[200:260, 0] = 0.0; pos[260:320, 0] = 2048.0      # faces of the volume
+    pos[320:380, 2] = 128.0 - 3.0
+    got = sdf.sample(dfu, pos)
+    want = oracle_samples(oracle, pos, dfu, oracle.make_texture(atlas, fmt))
+    assert np.array_equal(got, want), "%d of %d samples differ" % (int((got != want).sum()), n)
+    sdf.close()
+
+
+def test_small_single_column_atlas(ctx, oracle):
+    layout = scenes.DistanceFieldLayout(100, 60, 30.0, 3, 1.0)             # 1 physical slice: 100 x 60 atlas, width not a power of two
+    rng = np.random.default_rng(9)
+    atlas = rng.integers(0, 65536, size=(layout.atlas_height, layout.atlas_width, 4), dtype=np.uint16)
+    dfu = layout.uniforms()
+    sdf = native.DistanceFieldTexture(ctx, atlas)
+    pos = np.stack([rng.uniform(-5, 105, 3000), rng.uniform(-5, 65, 3000), rng.uniform(-3, 33, 3000)], axis=-1).astype(np.float32)
+    got = sdf.sample(dfu, pos)
+    want = oracle_samples(oracle, pos, dfu, oracle.make_texture(atlas, abi.SDF_UNORM16))
+    assert np.array_equal(got, want)
+    sdf.close()

@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from illuminant_amd import abi, native, scenes
 
-def particles(ctx, cs=256, n_chunks=16, steps=50, spawn=True):
+def particles(ctx, cs=256, n_chunks=16, steps=50, spawn=True, ops="gn", update=True):
     rnd = scenes.randomness_table(7)
     eng = native.Engine(ctx, cs, rnd); sysm = native.System(eng)
     n = cs * cs
@@ -15,13 +15,21 @@ def particles(ctx, cs=256, n_chunks=16, steps=50, spawn=True):
     tgt = sysm.add_chunk() if spawn else -1
     d = abi.StepDesc(); d.FirstChunk, d.ChunkCount = 0, -1
     d.System = scenes.system_uniforms(cs, friction=0.02, max_velocity=2048.0, life_decay=0.01)
-    d.Update = abi.UpdateParams.default(); d.UpdateMode = abi.UPDATE_POSITIONS
-    d.OpCount = 2
-    d.Ops[0].Type = abi.OP_GRAVITY
-    d.Ops[0].u.Gravity = scenes.gravity_params([((400., 300., 0.), 70., 600., 1), ((1500., 300., 0.), 150., 900., 1),
-                                                ((400., 800., 0.), 200., 1200., 1), ((1500., 800., 0.), 100., 1500., 1)], 1024.0)
-    d.Ops[1].Type = abi.OP_NOISE
-    d.Ops[1].u.Noise = scenes.noise_params(scenes.area_none(), (0.37 * 253, 0.81 * 127), (0.12 * 253, 0.55 * 127), 0.35)
+    d.Update = abi.UpdateParams.default(); d.UpdateMode = abi.UPDATE_POSITIONS if update else abi.UPDATE_NONE
+    k = 0
+    for o in ops:
+        if o == "g":
+            d.Ops[k].Type = abi.OP_GRAVITY
+            d.Ops[k].u.Gravity = scenes.gravity_params([((400., 300., 0.), 70., 600., 1), ((1500., 300., 0.), 150., 900., 1),
+                                                        ((400., 800., 0.), 200., 1200., 1), ((1500., 800., 0.), 100., 1500., 1)], 1024.0)
+        elif o == "n":
+            d.Ops[k].Type = abi.OP_NOISE
+            d.Ops[k].u.Noise = scenes.noise_params(scenes.area_none(), (0.37 * 253, 0.81 * 127), (0.12 * 253, 0.55 * 127), 0.35)
+        elif o == "f":
+            d.Ops[k].Type = abi.OP_FMA
+            d.Ops[k].u.FMA = scenes.fma_params(scenes.area_none(), velocity_multiply=(0.99, 0.99, 1.0))
+        k += 1
+    d.OpCount = k
     import ctypes
     descs = []
     first = 0
@@ -43,8 +51,8 @@ def particles(ctx, cs=256, n_chunks=16, steps=50, spawn=True):
     ms = ctx.timer_stop(); wall = (time.perf_counter() - t0) * 1e3
     slots = n * (n_chunks + (1 if spawn else 0))
     live = n * n_chunks
-    print("particles cs=%d chunks=%d: %.3f ms/step gpu (%.3f wall)  %.1f Mslot-steps/s  live-bytes %.2f TB/s" %
-          (cs, n_chunks, ms / steps, wall / steps, live * steps / ms / 1e3, live * 112 * steps / ms / 1e9))
+    print("particles cs=%d chunks=%d ops=%r update=%d spawn=%d: %.4f ms/step gpu (%.3f wall)  %.1f Mslot-steps/s  live-bytes %.2f TB/s" %
+          (cs, n_chunks, ops, update, spawn, ms / steps, wall / steps, live * steps / ms / 1e3, live * 112 * steps / ms / 1e9))
     sysm.close(); eng.close()
 
 def lighting(ctx, w=1920, h=1080, n_lights=64, res=0.25, frames=5, fmt=abi.SDF_UNORM16, world=2048):
@@ -72,6 +80,9 @@ def lighting(ctx, w=1920, h=1080, n_lights=64, res=0.25, frames=5, fmt=abi.SDF_U
 if __name__ == "__main__":
     ctx = native.Context(0)
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what == "ablate":
+        for ops, upd in (("gn", True), ("g", True), ("n", True), ("", True), ("gn", False), ("", False), ("f", True)):
+            particles(ctx, 256, 16, 200, False, ops, upd)
     if what in ("all", "p"):
         particles(ctx, 256, 16, 100, True)
         particles(ctx, 256, 16, 100, False)

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output (tools/profile_bench.sh) into the small files committed under profiles/.
+
+    summarize_prof.py <raw dir> <summary dir> <tag>
+
+  <tag>_kernel_stats.csv   the rocprofv3 --stats per-kernel table (calls, total / average / min / max ns)
+  <tag>_pmc.csv            per kernel: average of every collected counter per dispatch
+  <tag>_summary.md         the few numbers bench.py's roofline object is checked against
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def find(root, suffix):
+    hits = sorted(glob.glob(os.path.join(root, "**", "*" + suffix), recursive=True))
+    return hits[0] if hits else None
+
+
+def short(name):
+    name = name.replace("void ", "")
+    return name.split("(")[0]
+
+
+def main():
+    raw, out, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    os.makedirs(out, exist_ok=True)
+    lines = ["# rocprofv3 summary `%s`" % tag, ""]
+
+    stats = find(os.path.join(raw, "stats"), "kernel_stats.csv")
+    kernel_avg = {}
+    if stats:
+        rows = list(csv.DictReader(open(stats)))
+        with open(os.path.join(out, "%s_kernel_stats.csv" % tag), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+            for r in rows:
+                w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+                kernel_avg[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]))
+        lines += ["## kernel trace (`rocprofv3 --kernel-trace --stats -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline`)", "",
+                  "| kernel | calls | average us | % of GPU time |", "|---|---|---|---|"]
+        for r in rows[:8]:
+            lines.append("| `%s` | %s | %.2f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
+        lines.append("")
+
+    # PMC passes
+    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    meta = {}
+    for path in sorted(glob.glob(os.path.join(raw, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
+        for r in csv.DictReader(open(path)):
+            k = short(r["Kernel_Name"])
+            a = agg[k][r["Counter_Name"]]
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+            meta[k] = (r["VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Workgroup_Size"])
+    if agg:
+        counters = sorted({c for k in agg for c in agg[k]})
+        with open(os.path.join(out, "%s_pmc.csv" % tag), "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["kernel", "dispatches", "vgpr", "sgpr", "lds", "workgroup"] + counters)
+            for k in sorted(agg):
+                n = max(v[0] for v in agg[k].values())
+                w.writerow([k, n] + list(meta[k]) + ["%.1f" % (agg[k][c][1] / agg[k][c][0]) if c in agg[k] else "" for c in counters])
+        lines += ["## PMC counters (average per dispatch; separate passes, `--kernel-trace --pmc <set>`)", ""]
+        for k in sorted(agg):
+            if "ilm::" not in k:
+                continue
+            c = {name: v[1] / v[0] for name, v in agg[k].items()}
+            lines.append("### `%s`  (VGPR %s, SGPR %s)" % (k, meta[k][0], meta[k][1]))
+            if "FETCH_SIZE" in c:
+                lines.append("* FETCH_SIZE %.1f KB per dispatch (raw); x2 for wide coalesced reads per MI355X_MICROARCH.md = %.2f MB" % (c["FETCH_SIZE"], c["FETCH_SIZE"] * 2 * 1024 / 1e6))
+            if "WRITE_SIZE" in c:
+                lines.append("* WRITE_SIZE %.1f KB per dispatch = %.2f MB" % (c["WRITE_SIZE"], c["WRITE_SIZE"] * 1024 / 1e6))
+            if "TCC_HIT_sum" in c and (c["TCC_HIT_sum"] + c.get("TCC_MISS_sum", 0)) > 0:
+                lines.append("* L2 hit rate %.1f %% (TCC_HIT %.0f, TCC_MISS %.0f)" % (100 * c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), c["TCC_HIT_sum"], c["TCC_MISS_sum"]))
+            if "SQ_WAVES" in c:
+                w_ = max(c["SQ_WAVES"], 1)
+                lines.append("* waves %.0f; per wave: VALU %.0f, SALU %.0f, SMEM %.0f; VALU busy %.0f quad-cycles per wave; wave cycles %.0f" %
+                             (c["SQ_WAVES"], c.get("SQ_INSTS_VALU", 0) / w_, c.get("SQ_INSTS_SALU", 0) / w_, c.get("SQ_INSTS_SMEM", 0) / w_,
+                              c.get("SQ_ACTIVE_INST_VALU", 0) / w_, c.get("SQ_WAVE_CYCLES", 0) / w_))
+            if "SQ_WAIT_ANY" in c and "SQ_ACTIVE_INST_ANY" in c:
+                lines.append("* SQ_WAIT_ANY %.3g, SQ_WAIT_INST_ANY %.3g, SQ_ACTIVE_INST_ANY %.3g (quad-cycles summed over waves)" %
+                             (c["SQ_WAIT_ANY"], c["SQ_WAIT_INST_ANY"], c["SQ_ACTIVE_INST_ANY"]))
+            lines.append("")
+    for name in ("bench_unprofiled.json", "bench_under_rocprof.json"):
+        p = os.path.join(out, name)
+        if os.path.exists(p):
+            try:
+                d = json.loads(open(p).read().strip().splitlines()[-1])
+                lines.append("* `%s`: value %.1f %s, ms_per_step %.5f, roofline.frac %.4f (launch_ms %.5f)" %
+                             (name, d["value"], d["unit"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["launch_ms"]))
+            except Exception as e:  # noqa: BLE001
+                lines.append("* `%s`: unreadable (%s)" % (name, e))
+    open(os.path.join(out, "%s_summary.md" % tag), "w").write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+
+
+if __name__ == "__main__":
+    main()
