@@ -112,9 +112,10 @@ ILM_DEV float unorm16_to_float(float x) {
 
 // One 32-bit word holding the two channels of a texel that virtual slice 3k+m blends: low half = slice m's
 // channel, high half = the next one.  m = 0: (r,g)  1: (g,b)  2: (b,a).
-ILM_DEV uint32_t sdf_pair_word(uint2 t, int m) {
-    const uint32_t mid = __builtin_amdgcn_alignbit(t.y, t.x, 16);   // (g, b)
-    return (m == 0) ? t.x : ((m == 1) ? mid : t.y);
+// Branch-free: the texel as a 64-bit value shifted right by 16 * m.
+ILM_DEV uint32_t sdf_pair_word(uint2 t, uint32_t m) {
+    const uint32_t w01 = __builtin_amdgcn_alignbit(t.y, t.x, (m & 1u) << 4);   // m = 0: (r,g)   m = 1: (g,b)
+    return (m >= 2u) ? t.y : w01;
 }
 
 template <int FORMAT>
@@ -146,14 +147,16 @@ ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms&
                        -fminf(position.z, 0.0f) + (fmaxf(position.z, ez) - ez));
     const float d2 = dot3(dtv, dtv);
     float distance_to_volume = 0.0f;                 // sqrt(+0) == +0: skipping it inside the volume is exact
-    if (__builtin_amdgcn_ballot_w64(d2 != 0.0f) != 0ull)
+    if (__builtin_amdgcn_ballot_w64(d2 != 0.0f) != 0ull) {
+        asm volatile("" ::: "memory");               // keep this a (wave-uniform) branch: if-conversion would run the sqrt every time
         distance_to_volume = sqrtf(d2);
+    }
 
     const float slice_position = fminf(cz, df.Packed1.z) * df.Packed1.y;
     const float vslice = floorf(slice_position);
     const uint32_t vi = (uint32_t)vslice;                    // 0 <= vslice < 65536
-    const uint32_t third = (vi * 0xAAABu) >> 17;             // vi / 3
-    const int m = (int)(vi - 3u * third);                    // vi % 3
+    const uint32_t third = __umul24(vi, 0xAAABu) >> 17;      // vi / 3 (24-bit multiply: full rate)
+    const uint32_t m = vi - 3u * third;                      // vi % 3
 
     const float column_index = (float)third;                 // floor(vslice / 3)
     const float row_index = floorf(vslice * df.Packed1.x);   // floor(vslice * invCols / 3): the reference's float form
@@ -179,9 +182,20 @@ ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms&
     const int y0 = min(max(yi, 0), sdf.height - 1);
     const int y1 = min(max(yi + 1, 0), sdf.height - 1);
 
-    const uint32_t r0 = (uint32_t)(y0 * sdf.width), r1 = (uint32_t)(y1 * sdf.width);
-    const uint2 t00 = sdf.texels[r0 + (uint32_t)x0], t10 = sdf.texels[r0 + (uint32_t)x1];
-    const uint2 t01 = sdf.texels[r1 + (uint32_t)x0], t11 = sdf.texels[r1 + (uint32_t)x1];
+    // byte offsets from the (uniform) atlas base: 32-bit lane offsets on an SGPR base pointer
+    // (atlas <= 8192^2 texels of 8 bytes = 2^29 bytes); one 24-bit multiply, the second row is the first + pitch
+    const uint32_t pitch = (uint32_t)sdf.width << 3;
+    const uint32_t r0 = __umul24((uint32_t)y0, pitch);
+    const uint32_t r1 = (y1 != y0) ? r0 + pitch : r0;
+    const uint32_t c0 = (uint32_t)x0 << 3, c1 = (uint32_t)x1 << 3;
+    typedef const char __attribute__((address_space(1))) gbyte;
+    typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
+    typedef const u32x2 __attribute__((address_space(1))) gtexel;
+    gbyte* base = (gbyte*)sdf.texels;
+    asm("" : "+s"(base));
+    const u32x2 q00 = *(gtexel*)(base + (r0 + c0)), q10 = *(gtexel*)(base + (r0 + c1));
+    const u32x2 q01 = *(gtexel*)(base + (r1 + c0)), q11 = *(gtexel*)(base + (r1 + c1));
+    const uint2 t00 = make_uint2(q00.x, q00.y), t10 = make_uint2(q10.x, q10.y), t01 = make_uint2(q01.x, q01.y), t11 = make_uint2(q11.x, q11.y);
 
     float a00, b00, a10, b10, a01, b01, a11, b11;
     sdf_unpack_word<FORMAT>(sdf_pair_word(t00, m), a00, b00);
