@@ -141,10 +141,17 @@ ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms&
 #pragma clang fp contract(off)
     position.z -= df.ConeAndMisc.y;
     const float ex = df.Extent.x, ey = df.Extent.y, ez = df.Extent.z;
-    const float cx = clampf(position.x, 0.0f, ex), cy = clampf(position.y, 0.0f, ey), cz = clampf(position.z, 0.0f, ez);
-    const f3 dtv = mk3(-fminf(position.x, 0.0f) + (fmaxf(position.x, ex) - ex),
-                       -fminf(position.y, 0.0f) + (fmaxf(position.y, ey) - ey),
-                       -fminf(position.z, 0.0f) + (fmaxf(position.z, ez) - ez));
+    // clamp3(position, 0, extent) as one median-of-three each.  The distance to the volume per axis,
+    // -min(p, 0) + (max(p, e) - e), equals |p - clamp(p, 0, e)| with the same single rounding in every case
+    // (p < 0: -p;  p > e: p - e;  inside: 0), and only its square is used.
+    // A NaN coordinate (normalize(0) upstream) behaves like 0 in the min/max form -- clamp gives 0 and both terms of
+    // the distance vanish -- so it is replaced by 0 up front and the two forms agree on every input.
+    position.x = (position.x != position.x) ? 0.0f : position.x;
+    position.y = (position.y != position.y) ? 0.0f : position.y;
+    position.z = (position.z != position.z) ? 0.0f : position.z;
+    const float cx = __builtin_amdgcn_fmed3f(position.x, 0.0f, ex), cy = __builtin_amdgcn_fmed3f(position.y, 0.0f, ey),
+                cz = __builtin_amdgcn_fmed3f(position.z, 0.0f, ez);
+    const f3 dtv = mk3(position.x - cx, position.y - cy, position.z - cz);
     const float d2 = dot3(dtv, dtv);
     float distance_to_volume = 0.0f;                 // sqrt(+0) == +0: skipping it inside the volume is exact
     if (__builtin_amdgcn_ballot_w64(d2 != 0.0f) != 0ull) {

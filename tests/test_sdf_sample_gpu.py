@@ -74,3 +74,20 @@ def test_small_single_column_atlas(ctx, oracle):
     want = oracle_samples(oracle, pos, dfu, oracle.make_texture(atlas, abi.SDF_UNORM16))
     assert np.array_equal(got, want)
     sdf.close()
+
+
+def test_non_finite_positions_follow_the_min_max_semantics(ctx, oracle):
+    """NaN coordinates reach the sampler in the particle path (normalize(0), UpdateParticleSystemWithDistanceField.fx);
+    the device's median-of-three clamp must treat them exactly like the restated min/max form does."""
+    layout = scenes.DistanceFieldLayout(256, 256, 64.0, 9, 1.0)
+    rng = np.random.default_rng(3)
+    atlas = rng.integers(0, 65536, size=(layout.atlas_height, layout.atlas_width, 4), dtype=np.uint16)
+    dfu = layout.uniforms()
+    sdf = native.DistanceFieldTexture(ctx, atlas)
+    nan, inf = np.float32(np.nan), np.float32(np.inf)
+    pos = np.array([[nan, 10, 5], [10, nan, 5], [10, 20, nan], [nan, nan, nan], [inf, 10, 5], [-inf, 10, 5], [10, 20, inf],
+                    [10, -inf, 5], [-0.0, -0.0, -0.0], [256.0, 256.0, 64.0]], dtype=np.float32)
+    got = sdf.sample(dfu, pos)
+    want = oracle_samples(oracle, pos, dfu, oracle.make_texture(atlas, abi.SDF_UNORM16))
+    assert np.array_equal(got, want, equal_nan=True), (got, want)
+    sdf.close()
