@@ -31,6 +31,22 @@ PARTICLE_BYTES_PER_SLOT = 112   # 48 B read (pos+life, vel+cat, attri
 SDF_SAMPLE_BYTES = 32           # one sampleDistanceFieldEx = 4 bilinear taps x 8 B RGBA16
 
 
+def profiled_traffic(kernel_prefix):
+    """HBM bytes per launch of a kernel from the newest committed rocprofv3 PMC summary (profiles/*_pmc.csv, written by
+    tools/profile_bench.sh on the SAME bench command): FETCH_SIZE x 2 + WRITE_SIZE, both in KB.  The x2 is the gfx950
+    FETCH_SIZE correction of MI355X_MICROARCH.md ("reports exactly half of the bytes of a wide coalesced streaming
+    read"), confirmed here on the step kernel's known 48 B/slot read.  Counters cannot be collected from inside the
+    timed run (rocprofv3 wraps the process), so the figure is carried over from the profile; None when absent."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.csv")))
+    for path in reversed(files):
+        for row in csv.DictReader(open(path)):
+            if row["kernel"].startswith(kernel_prefix) and row.get("FETCH_SIZE") and row.get("WRITE_SIZE"):
+                return {"bytes": (float(row["FETCH_SIZE"]) * 2.0 + float(row["WRITE_SIZE"])) * 1024.0, "source": os.path.basename(path)}
+    return None
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,6 +188,7 @@ def main():
     value = total_units / wall / 1e6
     step_ms_gpu = gpu_ms / args.steps
     achieved_gbs = live_slots * PARTICLE_BYTES_PER_SLOT / (step_ms_gpu * 1e-3) / 1e9
+    step_traffic = profiled_traffic("ilm::step_kernel<0, false, true")
 
     out = {
         "metric": "Mparticle-steps/sec + lit Mpixels/sec (4K, 256 point lights) at 1/2/4/8 GPUs",
@@ -190,8 +207,10 @@ def main():
                                % (live_slots, args.chunks, args.chunk_size),
                    "particles_per_gpu": live_slots, "spawned_per_gpu_in_run": int(spawned), "parallelism": "chunks sharded, %d rank(s)" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved_gbs / HBM_PEAK_GBS, 4), "traffic": None,
-                     "kernel": "ilm::step_kernel (one ParticleSystem.Update = spawn-units launch + main launch)",
+                     "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
+                     "traffic": round(step_traffic["bytes"]) if step_traffic else None,
+                     "traffic_source": ("profiles/%s: (FETCH_SIZE x 2 + WRITE_SIZE) KB per dispatch" % step_traffic["source"]) if step_traffic else None,
+                     "kernel": "ilm::step_kernel<UNORM16, no field, spawning> (one launch = one ParticleSystem.Update over every chunk)",
                      "bytes_per_unit": PARTICLE_BYTES_PER_SLOT, "units_per_launch": live_slots,
                      "launch_ms": round(step_ms_gpu, 5)},
     }

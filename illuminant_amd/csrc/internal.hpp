@@ -18,8 +18,15 @@ namespace ilm {
 //  16..19 render data            (Chunk.RenderData: size, rotation, speed, category)
 constexpr int kComponents = 20;
 constexpr int kSlotsPerThread = 4;         // widest variant; strides are padded for it
-constexpr int kStepThreads = 256;
-constexpr int kSlotsPerBlock = kSlotsPerThread * kStepThreads;  // 1024; strides are padded to this
+#ifndef ILM_STEP_THREADS
+#define ILM_STEP_THREADS 256
+#endif
+constexpr int kStepThreads = ILM_STEP_THREADS;
+constexpr int kSlotsPerBlock = 1024;       // strides are padded to this
+#ifndef ILM_STEP_UNITS
+#define ILM_STEP_UNITS 1
+#endif
+constexpr int kUnitsPerWave = ILM_STEP_UNITS;   // units (64 slots each) a wave loads up front and then processes in turn: 1, 2 or 4
 constexpr int kDefaultStepMinWaves = 1;   // __launch_bounds__ min waves/SIMD of the main step variant (override: ILM_STEP_MINWAVES=6|7|8)
 
 // Values every wave would otherwise recompute on the vector ALU from uniform inputs (gfx950 has no scalar float

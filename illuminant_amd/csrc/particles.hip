@@ -744,33 +744,47 @@ __global__ __launch_bounds__(kStepThreads, MINW) void step_kernel(const StepLaun
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     // Blocks are rotated so that block 0 holds the first unit of the first spawn range: a spawning wave is a long
     // dependent chain (randomness gathers, sin/cos/acos), so it has to start first to finish under the cover of
-    // the streaming waves instead of forming the tail of the launch.  unit_rotate is a multiple of 4.
-    int v = (int)blockIdx.x * (kStepThreads / 64) + a.unit_rotate;
+    // the streaming waves instead of forming the tail of the launch.  unit_rotate is a multiple of the units per block.
+    constexpr int K = kUnitsPerWave;
+    int v = (int)blockIdx.x * (kStepThreads / 64) * K + a.unit_rotate;      // first unit of the block
     const int total = a.unit_end - a.unit_begin;
     if (v >= a.total_padded) v -= a.total_padded;
-    const int u = a.unit_begin + v + wave;
-    const bool active = (v + wave) < total;
-    bool live_after = false;
-    int chunk = 0;
+    const int u = a.unit_begin + v + wave * K;                               // first of this wave's K consecutive units
+    // units_per_chunk is a multiple of 16 = (4 waves) x (K <= 4): the K units of a wave (and the whole block) lie in
+    // one chunk, and `total` is a multiple of 16, so the K units are active or inactive together
+    const bool active = (v + wave * K) < total;
+    uint32_t n_live = 0;
     if (active) {
         const int chunk_rel = u / a.units_per_chunk;
         const int seg = u - chunk_rel * a.units_per_chunk;
-        chunk = a.first_chunk + chunk_rel;
-        gfloat* ub = (gfloat*)a.chunk_bases[chunk] + seg * 64;     // first slot of the unit, plane 0 (uniform)
-        const int i = seg * 64 + (int)lane;
-        const SlotIn cur = load_slot<true>(ub, a.stride, lane);
-        live_after = process_unit<FMT, DF, SPAWN>(ap, ub, chunk, i, lane, seg, cur);
+        const int chunk = a.first_chunk + chunk_rel;
+        gfloat* ub = (gfloat*)a.chunk_bases[chunk] + seg * 64;     // first slot of the first unit, plane 0 (uniform)
+        // K > 1 issues the state loads of all K units before any arithmetic (K x 12 loads in flight per wave).  Measured
+        // on cfg2 ("experiments"): K = 1 26.1 us, K = 2 30.5 us, K = 4 36.5 us per step -- the extra
+        // registers cost more occupancy than the memory-level parallelism returns, so K = 1 ships.
+        SlotIn q[K];
+#pragma unroll
+        for (int j = 0; j < K; j++) q[j] = load_slot<true>(ub + j * 64, a.stride, lane);
+#pragma nounroll
+        for (int j = 0; j < K; j++) {
+            const SlotIn cur = q[0];
+#pragma unroll
+            for (int r = 0; r + 1 < K; r++) q[r] = q[r + 1];
+            const bool live_after = process_unit<FMT, DF, SPAWN>(ap, ub + j * 64, chunk, (seg + j) * 64 + (int)lane, lane, seg + j, cur);
+            n_live += (uint32_t)__popcll(__ballot(live_after));
+        }
     }
     if (a.desc.Flags & ILM_STEP_COUNT_LIVE) {
         // CountLiveParticles.fx: wave64 ballot + popcount, LDS sum over the block's waves, then ONE atomic per
         // block on a per-chunk counter that sits on its own 128-byte line (per-wave atomics on one address
         // serialise at ~11 ns each: 1024 of them per chunk made this step 7x slower).  The 4 units of a block
-        // always belong to one chunk (units_per_chunk is a multiple of 16 and the rotation a multiple of 4).
-        const uint32_t n = (uint32_t)__popcll(__ballot(live_after));
-        if (lane == 0) wave_live[wave] = active ? n : 0u;
+        // of a block always belong to one chunk (see above).
+        if (lane == 0) wave_live[wave] = n_live;
         __syncthreads();
         if (threadIdx.x == 0) {
-            const uint32_t block_live = wave_live[0] + wave_live[1] + wave_live[2] + wave_live[3];
+            uint32_t block_live = 0;
+#pragma unroll
+            for (int w = 0; w < kStepThreads / 64; w++) block_live += wave_live[w];
             const int first_unit = a.unit_begin + v;
             const int c = a.first_chunk + first_unit / a.units_per_chunk;
             if (block_live != 0)
@@ -788,8 +802,8 @@ static hipError_t launch_step_variant(const StepLaunch& a, hipStream_t stream) {
         const char* e = getenv("ILM_STEP_MINWAVES");
         minw = e ? atoi(e) : kDefaultStepMinWaves;
     }
-    const int waves_per_block = kStepThreads / 64;
-    const dim3 grid((unsigned)((units + waves_per_block - 1) / waves_per_block), 1, 1), block(kStepThreads, 1, 1);
+    const int units_per_block = (kStepThreads / 64) * kUnitsPerWave;
+    const dim3 grid((unsigned)((units + units_per_block - 1) / units_per_block), 1, 1), block(kStepThreads, 1, 1);
     if (a.desc.UpdateMode == ILM_UPDATE_WITH_DISTANCE_FIELD) {
         if (a.sdf.format == ILM_SDF_FP16)
             hipLaunchKernelGGL((step_kernel<ILM_SDF_FP16, true, SPAWN, 1>), grid, block, 0, stream, a);
@@ -814,7 +828,7 @@ hipError_t launch_step(StepLaunch& a, hipStream_t stream) {
     a.units_per_chunk = (int)(a.stride / 64);
     a.unit_begin = 0;
     a.unit_end = a.chunk_count * a.units_per_chunk;
-    const int waves_per_block = kStepThreads / 64;
+    const int waves_per_block = (kStepThreads / 64) * kUnitsPerWave;   // units per block
     a.total_padded = (a.unit_end + waves_per_block - 1) / waves_per_block * waves_per_block;
     a.unit_rotate = 0;
     bool spawning = false;

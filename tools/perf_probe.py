@@ -78,6 +78,8 @@ def lighting(ctx, w=1920, h=1080, n_lights=64, res=0.25, frames=5, fmt=abi.SDF_U
     lm.close(); sdf.close()
 
 if __name__ == "__main__":
+    if os.environ.get("ILM_HIP_LIB"):       # experiment builds of the library (block-size variants ...)
+        native.LIB_PATH = os.path.abspath(os.environ["ILM_HIP_LIB"])
     ctx = native.Context(0)
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
     if what == "ablate":
