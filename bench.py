@@ -175,6 +175,8 @@ def main():
     for _ in range(args.warmup):
         tp.Advance(dt); ps.Update(frame); frame += 1
     barrier()
+    spawner = P["transforms"][0]
+    spawned_before = int(spawner.TotalSpawned)      # the Spawner's own count (ps.TotalSpawnCount also counts the upload)
     ctx.TimerStart()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -182,12 +184,19 @@ def main():
     gpu_ms = ctx.TimerStop()          # HIP events on the context stream around the K steps (also synchronises)
     barrier()
     wall = max_over_ranks(time.perf_counter() - t0)
-    live_slots = P["live"]            # slots carrying a live particle through every pass (the uploaded chunks)
-    spawned = sum(c.TotalSpawned for c in ps.Chunks[args.chunks:])
-    total_units = world * live_slots * args.steps
+    spawned_after = int(spawner.TotalSpawned)
+    spawned = spawned_after
+    # Units = live particles taken through the whole pass list.  The uploaded particles live through every step
+    # (LifeDecay is tiny); the spawner adds 1092 / 1093 more per step (life 50 s), each updated from the step that
+    # spawns it on, so step k of the timed region carries uploaded + spawned_before + (k + 1) * rate live particles.
+    # Dead slots of the spawn-target chunks are streamed too but are NOT counted.
+    live_slots = P["live"]
+    spawn_steps = (spawned_after - spawned_before)
+    live_avg = live_slots + spawned_before + spawn_steps * (args.steps + 1) / (2.0 * args.steps)
+    total_units = world * live_avg * args.steps
     value = total_units / wall / 1e6
     step_ms_gpu = gpu_ms / args.steps
-    achieved_gbs = live_slots * PARTICLE_BYTES_PER_SLOT / (step_ms_gpu * 1e-3) / 1e9
+    achieved_gbs = live_avg * PARTICLE_BYTES_PER_SLOT / (step_ms_gpu * 1e-3) / 1e9
     step_traffic = profiled_traffic("ilm::step_kernel<0, false, true")
 
     out = {
@@ -205,13 +214,14 @@ def main():
         "data": "synthetic",
         "config": {"workload": "cfg2: %d particles/GPU in %d chunks of %d^2, Spawner(65536/s)+Gravity(4 attractors)+Noise+UpdatePositions"
                                % (live_slots, args.chunks, args.chunk_size),
-                   "particles_per_gpu": live_slots, "spawned_per_gpu_in_run": int(spawned), "parallelism": "chunks sharded, %d rank(s)" % world},
+                   "particles_per_gpu": live_slots, "spawned_per_gpu_in_run": int(spawned), "live_particles_per_step_avg": round(live_avg, 1),
+                   "chunks_at_end": len(ps.Chunks), "parallelism": "chunks sharded, %d rank(s)" % world},
         "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
                      "traffic": round(step_traffic["bytes"]) if step_traffic else None,
                      "traffic_source": ("profiles/%s: (FETCH_SIZE x 2 + WRITE_SIZE) KB per dispatch" % step_traffic["source"]) if step_traffic else None,
                      "kernel": "ilm::step_kernel<UNORM16, no field, spawning> (one launch = one ParticleSystem.Update over every chunk)",
-                     "bytes_per_unit": PARTICLE_BYTES_PER_SLOT, "units_per_launch": live_slots,
+                     "bytes_per_unit": PARTICLE_BYTES_PER_SLOT, "units_per_launch": round(live_avg, 1),
                      "launch_ms": round(step_ms_gpu, 5)},
     }
 
@@ -289,7 +299,7 @@ def main():
             el = time.perf_counter() - t0
             if el > args.cpu_seconds:
                 break
-        out["cpu_baseline"] = {"value": round(live_slots * steps_done / el / 1e6, 2), "unit": "Mparticle-steps/s",
+        out["cpu_baseline"] = {"value": round(live_slots * steps_done / el / 1e6, 2), "unit": "Mparticle-steps/s",   # spawned particles not counted here (< 1 % over the sample)
                                "cores": orc.num_threads(), "kind": "port",
                                "sample": "%d steps of the same cfg2 system (oracle/ilm_oracle.c, OpenMP, %.1f s)" % (steps_done, el)}
 

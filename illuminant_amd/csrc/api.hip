@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -44,6 +45,10 @@ struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr;
+    // Liveness counts leave through their own stream, so the device-to-host copy (a separate blit kernel on ROCm)
+    // never sits between two step launches on the compute stream.
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_step = nullptr;
     // device staging for AoS <-> SoA conversion
     void* staging = nullptr; size_t staging_bytes = 0;
     // pinned ring for small asynchronous parameter uploads (light arrays)
@@ -84,12 +89,16 @@ struct System {
     Engine* engine = nullptr;
     std::vector<float*> chunks;
     float** d_table = nullptr; int table_cap = 0; bool table_dirty = true;
-    uint32_t* d_counts = nullptr; int counts_cap = 0;
+    // Three counter regions of counts_cap * kCountStride words: 0 / 1 alternate between counting steps (the step kernel
+    // accumulates into one and zeroes the other for next time: no memset launch), 2 belongs to ilm_system_live_counts.
+    uint32_t* d_counts = nullptr; int counts_cap = 0; int count_parity = 0;
+    uint32_t* counts_region(int r) const { return d_counts + (size_t)r * (size_t)counts_cap * kCountStride; }
     Sdf* sdf = nullptr;
     float4* ramp = nullptr; int ramp_w = 0, ramp_h = 0;
     uint32_t* d_slots = nullptr; int slots_cap = 0; uint32_t* d_slot_count = nullptr;
     // asynchronous readback of the fused live counts
     uint32_t* h_counts = nullptr; int h_counts_cap = 0; hipEvent_t counts_ev = nullptr; int counts_n = 0; bool counts_pending = false;
+    bool counts_valid = false;   // h_counts holds (or is about to receive) the counts of the last counting step
 };
 
 SdfView make_sdf_view(const Sdf* f) {
@@ -166,8 +175,9 @@ int32_t refresh_table(System* s) {
     if (n > s->counts_cap) {
         if (s->d_counts) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(s->d_counts)); s->d_counts = nullptr; }
         int cap = n < 64 ? 64 : n * 2;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_counts), sizeof(uint32_t) * (size_t)cap * kCountStride));
-        HIP_TRY(hipMemsetAsync(s->d_counts, 0, sizeof(uint32_t) * (size_t)cap * kCountStride, c->stream));
+        if (s->counts_ev) HIP_TRY(hipEventSynchronize(s->counts_ev));   // an outstanding copy reads the old buffer
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_counts), sizeof(uint32_t) * 3 * (size_t)cap * kCountStride));
+        HIP_TRY(hipMemsetAsync(s->d_counts, 0, sizeof(uint32_t) * 3 * (size_t)cap * kCountStride, c->stream));
         s->counts_cap = cap;
     }
     if (s->table_dirty && n > 0) {
@@ -230,8 +240,11 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
     rc = refresh_table(s);
     if (rc != ILM_OK) return rc;
     if (count == 0) return ILM_OK;
-    if (d->Flags & ILM_STEP_COUNT_LIVE)
-        HIP_TRY(hipMemsetAsync(s->d_counts, 0, sizeof(uint32_t) * (size_t)s->chunks.size() * kCountStride, c->stream));
+    const bool counting = (d->Flags & ILM_STEP_COUNT_LIVE) != 0;
+    const int region = s->count_parity;
+    if (counting && s->counts_ev)
+        // this launch zeroes the region the previous counting step filled: its copy-out must have finished
+        HIP_TRY(hipStreamWaitEvent(c->stream, s->counts_ev, 0));
 
     StepLaunch a;
     memcpy(&a.desc, d, sizeof(IlmStepDesc));
@@ -245,7 +258,9 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
     a.rnd = e->rnd; a.rw = e->rw; a.rh = e->rh;
     a.ramp = s->ramp; a.ramp_w = s->ramp_w; a.ramp_h = s->ramp_h;
     a.sdf = make_sdf_view(s->sdf);
-    a.live_counts = s->d_counts;
+    a.live_counts = counting ? s->counts_region(region) : nullptr;
+    a.zero_counts = counting ? s->counts_region(region ^ 1) : nullptr;
+    a.zero_n = counting ? (int32_t)s->counts_cap : 0;   // every entry, so chunk-table growth after a shrink never meets stale counts
     {   // StepDerived: same float operations, same order, as the device code they replace
         StepDerived& dv = a.derived;
         std::memset(&dv, 0, sizeof(dv));
@@ -266,6 +281,17 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
                 const int t = ar.AreaType < 0 ? -ar.AreaType : ar.AreaType;
                 dv.op[o].area_none = (t < 1 || t > 5) ? 1 : 0;
                 dv.op[o].t = ar.Strength * dt_ms / divisor;
+                if (op.Type == ILM_OP_NOISE) {
+                    // Noise is the one transform without a life check (Noise.fx:40): a dead slot goes through
+                    // newLife = lerp(life, life + delta.w, t).  With PositionScale.w == 0 and every factor finite,
+                    // delta.w is +-0 and the lerp returns life unchanged, so the slot stays dead and the update pass
+                    // discards it whatever else Noise wrote: its arithmetic can be skipped.
+                    const IlmNoiseParams& np = op.u.Noise;
+                    const bool inert = (np.PositionScale.w == 0.0f) && std::isfinite(np.PositionOffset.w) && std::isfinite(np.PositionMinimum.w) &&
+                                       std::isfinite(ar.Strength) && std::isfinite(dt_ms) && std::isfinite(divisor) && (divisor != 0.0f) &&
+                                       std::isfinite(ar.AreaFalloff);
+                    if (!inert) dv.noise_may_revive = 1;
+                }
             }
         }
     }
@@ -281,22 +307,26 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
             s->h_counts_cap = cap;
         }
         if (!s->counts_ev) HIP_TRY(hipEventCreateWithFlags(&s->counts_ev, hipEventDisableTiming));
-        HIP_TRY(hipMemcpyAsync(s->h_counts, s->d_counts, sizeof(uint32_t) * (size_t)n * kCountStride, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipEventRecord(s->counts_ev, c->stream));
+        HIP_TRY(hipEventRecord(c->ev_step, c->stream));
+        HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_step, 0));
+        HIP_TRY(hipMemcpyAsync(s->h_counts, s->counts_region(region), sizeof(uint32_t) * (size_t)n * kCountStride, hipMemcpyDeviceToHost, c->copy_stream));
+        HIP_TRY(hipEventRecord(s->counts_ev, c->copy_stream));
         s->counts_n = n;
         s->counts_pending = true;
+        s->counts_valid = true;
+        s->count_parity ^= 1;
     }
     return ILM_OK;
 }
 
-int32_t copy_counts(System* s, uint32_t* out, int32_t capacity, int32_t saturate16) {
+int32_t copy_counts(System* s, const uint32_t* d_region, uint32_t* out, int32_t capacity, int32_t saturate16) {
     Ctx* c = s->engine->ctx;
     const int n = (int)s->chunks.size();
     if (capacity < n)
         return fail(ILM_ERR_OUT_OF_RANGE, "capacity %d < chunk count %d", capacity, n);
     if (n == 0) return ILM_OK;
     std::vector<uint32_t> tmp((size_t)n * kCountStride);
-    HIP_TRY(hipMemcpyAsync(tmp.data(), s->d_counts, sizeof(uint32_t) * tmp.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(tmp.data(), d_region, sizeof(uint32_t) * tmp.size(), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int i = 0; i < n; i++) {
         const uint32_t v = tmp[(size_t)i * kCountStride];
@@ -336,6 +366,8 @@ int32_t ilm_ctx_create(int32_t device_id, IlmHandle* out_ctx) {
     if (!c) return fail(ILM_ERR_INVALID_ARGUMENT, "out of host memory");
     c->device = device_id;
     HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&c->ev_step, hipEventDisableTiming));
     HIP_TRY(hipEventCreate(&c->t0));
     HIP_TRY(hipEventCreate(&c->t1));
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_stats), 3 * sizeof(unsigned long long)));
@@ -356,6 +388,9 @@ int32_t ilm_ctx_destroy(IlmHandle h) {
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_recs) (void)hipFree(c->d_recs);
     if (c->d_stats) (void)hipFree(c->d_stats);
+    (void)hipStreamSynchronize(c->copy_stream);
+    (void)hipStreamDestroy(c->copy_stream);
+    (void)hipEventDestroy(c->ev_step);
     (void)hipEventDestroy(c->t0);
     (void)hipEventDestroy(c->t1);
     (void)hipStreamDestroy(c->stream);
@@ -666,10 +701,10 @@ int32_t ilm_system_live_counts(IlmHandle h, uint32_t* out_counts, int32_t capaci
     if (rc != ILM_OK) return rc;
     const int n = (int)s->chunks.size();
     if (n > 0) {
-        HIP_TRY(hipMemsetAsync(s->d_counts, 0, sizeof(uint32_t) * (size_t)n * kCountStride, c->stream));
-        HIP_TRY(launch_count_live(s->d_table, s->engine->stride, n, s->d_counts, c->stream));
+        HIP_TRY(hipMemsetAsync(s->counts_region(2), 0, sizeof(uint32_t) * (size_t)n * kCountStride, c->stream));
+        HIP_TRY(launch_count_live(s->d_table, s->engine->stride, n, s->counts_region(2), c->stream));
     }
-    return copy_counts(s, out_counts, capacity, saturate16);
+    return copy_counts(s, s->counts_region(2), out_counts, capacity, saturate16);
 }
 
 int32_t ilm_system_step_counts(IlmHandle h, uint32_t* out_counts, int32_t capacity, int32_t saturate16) {
@@ -677,9 +712,15 @@ int32_t ilm_system_step_counts(IlmHandle h, uint32_t* out_counts, int32_t capaci
     if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
     if (!out_counts) return fail(ILM_ERR_INVALID_ARGUMENT, "out_counts is NULL");
     HIP_TRY(hipSetDevice(s->engine->ctx->device));
-    if (s->d_counts == nullptr && !s->chunks.empty())
+    if (!s->counts_valid)
         return fail(ILM_ERR_STATE, "no step with ILM_STEP_COUNT_LIVE has run");
-    return copy_counts(s, out_counts, capacity, saturate16);
+    if (capacity < s->counts_n) return fail(ILM_ERR_OUT_OF_RANGE, "capacity %d < %d", capacity, s->counts_n);
+    HIP_TRY(hipEventSynchronize(s->counts_ev));      // the copy-out queued behind the last counting step
+    for (int i = 0; i < s->counts_n; i++) {
+        const uint32_t v = s->h_counts[(size_t)i * kCountStride];
+        out_counts[i] = (saturate16 && v > 65535u) ? 65535u : v;
+    }
+    return ILM_OK;
 }
 
 int32_t ilm_system_poll_counts(IlmHandle h, uint32_t* out_counts, int32_t capacity, int32_t saturate16, int32_t* out_ready) {

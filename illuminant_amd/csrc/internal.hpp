@@ -36,6 +36,7 @@ struct StepDerived {
     float dt_s;                  // getDeltaTimeSeconds: GlobalSettings.x / 1000            (ParticleCommon.fxh:54-56)
     float inv_rw, inv_rh;        // RandomnessTexel = 1 / (807, 653)                         (RandomCommon.fxh:12-15)
     int32_t cs_shift;            // log2(chunk_size) when it is a power of two, else -1
+    int32_t noise_may_revive;    // some Noise op can change the life of a dead slot (see api.hip); 0 => dead slots skip the transforms
     struct Op {
         int32_t area_none;       // AreaType outside 1..5: evaluateByTypeId returns 0 => weight == Strength exactly
         float   t;               // Noise / FMA with area_none: weight * dtMs / TimeDivisor
@@ -55,7 +56,9 @@ struct StepLaunch {
     const float4* rnd; int32_t rw, rh;
     const float4* ramp; int32_t ramp_w, ramp_h;
     SdfView sdf;
-    uint32_t* live_counts;       // per chunk at index chunk * kCountStride, zeroed by the caller when ILM_STEP_COUNT_LIVE
+    uint32_t* live_counts;       // per chunk at index chunk * kCountStride; all zero on entry when ILM_STEP_COUNT_LIVE
+    uint32_t* zero_counts;       // the other counter region: zeroed by this launch for the next counting step
+    int32_t zero_n;
     // Work is cut into units of one wave (64 consecutive slots); unit = chunk_rel * units_per_chunk + segment.
     // Filled by launch_step.
     int32_t units_per_chunk;     // stride / 64

@@ -641,7 +641,9 @@ ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* ub, int chunk, int i, unsigne
     const int64_t S = a.stride;
     const int mode = d.UpdateMode;
     const bool need_attr = (mode == ILM_UPDATE_POSITIONS) || (mode == ILM_UPDATE_WITH_DISTANCE_FIELD);
-    const bool has_noise = (a.op_mask & (1u << ILM_OP_NOISE)) != 0u;
+    // Noise has no life check (Noise.fx:40): dead slots go through it.  That only matters when its result survives --
+    // no update pass follows (single-pass ilm_noise), or the op can bring a dead slot back to life (StepDerived).
+    const bool has_noise = ((a.op_mask & (1u << ILM_OP_NOISE)) != 0u) && ((mode == ILM_UPDATE_NONE) || (a.derived.noise_may_revive != 0));
     const float4 zero = mk4(0.0f, 0.0f, 0.0f, 0.0f);
 
     bool spawn_here = false;
@@ -779,6 +781,8 @@ __global__ __launch_bounds__(kStepThreads, MINW) void step_kernel(const StepLaun
         // block on a per-chunk counter that sits on its own 128-byte line (per-wave atomics on one address
         // serialise at ~11 ns each: 1024 of them per chunk made this step 7x slower).  The 4 units of a block
         // of a block always belong to one chunk (see above).
+        if (blockIdx.x == 0)
+            for (int i = (int)threadIdx.x; i < a.zero_n; i += kStepThreads) a.zero_counts[i * kCountStride] = 0u;
         if (lane == 0) wave_live[wave] = n_live;
         __syncthreads();
         if (threadIdx.x == 0) {

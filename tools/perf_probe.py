@@ -77,11 +77,45 @@ def lighting(ctx, w=1920, h=1080, n_lights=64, res=0.25, frames=5, fmt=abi.SDF_U
            (st.SdfSamples * 32 + w * h * 8) / ms / 1e9))
     lm.close(); sdf.close()
 
+def pcie(ctx):
+    """Host <-> device legs of the boundary (AoS float4 staging + SoA conversion included), for DESIGN.md."""
+    cs, n_chunks = 256, 16
+    n = cs * cs
+    rnd = scenes.randomness_table(7)
+    eng = native.Engine(ctx, cs, rnd); sysm = native.System(eng)
+    pos, vel, attr = scenes.make_particles(10, n * n_chunks)
+    for c in range(n_chunks):
+        sysm.add_chunk()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for c in range(n_chunks):
+        sl = slice(c * n, (c + 1) * n)
+        sysm.upload(c, abi.PLANE_POSITION, pos[sl]); sysm.upload(c, abi.PLANE_VELOCITY, vel[sl]); sysm.upload(c, abi.PLANE_ATTRIBUTES, attr[sl])
+    up = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for c in range(n_chunks):
+        for k in (abi.PLANE_POSITION, abi.PLANE_VELOCITY, abi.PLANE_RENDER_COLOR, abi.PLANE_RENDER_DATA):
+            sysm.download(c, k)
+    down = time.perf_counter() - t0
+    print("pcie particles: upload 3 planes of %d slots %.2f ms (%.1f GB/s), download 4 planes %.2f ms (%.1f GB/s)" %
+          (n * n_chunks, up * 1e3, n * n_chunks * 48 / up / 1e9, down * 1e3, n * n_chunks * 64 / down / 1e9))
+    sysm.close(); eng.close()
+    lm = native.Lightmap(ctx, 3840, 2160, abi.LIGHTMAP_HALF4)
+    lm.download()
+    t0 = time.perf_counter()
+    lm.download()
+    d = time.perf_counter() - t0
+    print("pcie lightmap: 4K half4 download %.2f ms (%.1f GB/s)" % (d * 1e3, 3840 * 2160 * 8 / d / 1e9))
+    lm.close()
+
+
 if __name__ == "__main__":
     if os.environ.get("ILM_HIP_LIB"):       # experiment builds of the library (block-size variants ...)
         native.LIB_PATH = os.path.abspath(os.environ["ILM_HIP_LIB"])
     ctx = native.Context(0)
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what == "pcie":
+        pcie(ctx)
     if what == "ablate":
         for ops, upd in (("gn", True), ("g", True), ("n", True), ("", True), ("gn", False), ("", False), ("f", True)):
             particles(ctx, 256, 16, 200, False, ops, upd)
