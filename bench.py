@@ -265,12 +265,14 @@ def main():
             my_px = (row_end - row_begin) * w
             alg_bytes = samples * SDF_SAMPLE_BYTES + my_px * 8 + nl * 128   # this rank's launch: SDF samples + ground-plane lightmap write (half4) + light records
             kern_ms = gms / args.light_frames
+            lt = profiled_traffic("ilm::sphere_lights_kernel<%d, false>" % (1 if fmt == abi.SDF_FP16 else 0)) if world == 1 else None
             lighting[name] = {
                 "lit_mpixels_per_s": round(w * h / (frame_ms * 1e-3) / 1e6, 2),
                 "ms_per_frame": round(frame_ms, 4),
                 "sdf_samples_per_frame": samples_total,
                 "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (kern_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": round(alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                             "frac": round(alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "traffic": round(lt["bytes"]) if lt else None,
                              "kernel": "ilm::sphere_lights_kernel", "bytes_per_unit": SDF_SAMPLE_BYTES,
                              "units_per_launch": samples, "launch_ms": round(kern_ms, 4)},
             }
