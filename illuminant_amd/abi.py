@@ -186,6 +186,26 @@ class StepDesc(C.Structure):
                 ("Ops", TransformOp * MAX_OPS), ("Spawns", SpawnRecord * MAX_SPAWNS)]
 
 
+OBSTRUCTION_ELLIPSOID, OBSTRUCTION_BOX, OBSTRUCTION_CYLINDER, OBSTRUCTION_SPHEROID, OBSTRUCTION_OCTAGON = 0, 1, 2, 3, 4
+DISTANCE_LIMIT = 520.0
+
+
+class Obstruction(C.Structure):
+    _fields_ = [("Center", f32 * 3), ("Type", i32), ("Size", f32 * 3), ("IsDynamic", i32), ("Orientation", f32 * 4)]
+
+
+class HeightVolume(C.Structure):
+    _fields_ = [("FirstVertex", i32), ("VertexCount", i32), ("ZBase", f32), ("Height", f32),
+                ("IsDynamic", i32), ("_pad", i32 * 3)]
+
+
+class DistanceFieldRenderDesc(C.Structure):
+    _fields_ = [("VirtualWidth", i32), ("VirtualHeight", i32), ("VirtualDepth", f32), ("ZOffset", f32),
+                ("SliceWidth", i32), ("SliceHeight", i32), ("SliceCount", i32), ("ColumnCount", i32),
+                ("RowCount", i32), ("MaximumEncodedDistance", f32), ("InvScaleFactorX", f32), ("InvScaleFactorY", f32),
+                ("DynamicFlagFilter", i32), ("_pad", i32 * 3)]
+
+
 class RenderStats(C.Structure):
     _fields_ = [("SdfSamples", C.c_uint64), ("PixelLightPairs", C.c_uint64), ("TracedPairs", C.c_uint64)]
 
@@ -202,4 +222,6 @@ EXPECTED_SIZES = {
     "IlmUpdateParams": (UpdateParams, 256), "IlmTransformOp": (TransformOp, 416),
     "IlmSpawnRecord": (SpawnRecord, 432), "IlmStepDesc": (StepDesc, 2976),
     "IlmRenderStats": (RenderStats, 24),
+    "IlmObstruction": (Obstruction, 48), "IlmHeightVolume": (HeightVolume, 32),
+    "IlmDistanceFieldRenderDesc": (DistanceFieldRenderDesc, 64),
 }

@@ -56,6 +56,8 @@ struct Ctx {
     void* pinned[kRing] = {}; size_t pinned_bytes[kRing] = {}; hipEvent_t pinned_ev[kRing] = {}; int ring_pos = 0;
     IlmLightVertex* d_lights = nullptr; void* d_recs = nullptr; int light_cap = 0;
     unsigned long long* d_stats = nullptr;
+    // parameter block of the distance-field generation pass (slice list, obstruction records, volumes, polygon vertices)
+    void* d_field_params = nullptr; size_t field_params_bytes = 0;
 };
 
 struct Engine {
@@ -388,6 +390,7 @@ int32_t ilm_ctx_destroy(IlmHandle h) {
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_recs) (void)hipFree(c->d_recs);
     if (c->d_stats) (void)hipFree(c->d_stats);
+    if (c->d_field_params) (void)hipFree(c->d_field_params);
     (void)hipStreamSynchronize(c->copy_stream);
     (void)hipStreamDestroy(c->copy_stream);
     (void)hipEventDestroy(c->ev_step);
@@ -828,6 +831,149 @@ int32_t ilm_sdf_destroy(IlmHandle h) {
     if (f->texels) (void)hipFree(f->texels);
     f->magic = 0;
     delete f;
+    return ILM_OK;
+}
+
+int32_t ilm_sdf_download(IlmHandle h, uint16_t* texels) {
+    Sdf* f = from_handle<Sdf>(h, kMagicSdf);
+    if (!f) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle");
+    if (!texels) return fail(ILM_ERR_INVALID_ARGUMENT, "texels is NULL");
+    HIP_TRY(hipSetDevice(f->ctx->device));
+    HIP_TRY(hipMemcpyAsync(texels, f->texels, sizeof(uint2) * (size_t)f->width * (size_t)f->height, hipMemcpyDeviceToHost, f->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(f->ctx->stream));
+    return ILM_OK;
+}
+
+int32_t ilm_sdf_device_ptr(IlmHandle h, void** out_ptr) {
+    Sdf* f = from_handle<Sdf>(h, kMagicSdf);
+    if (!f || !out_ptr) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle");
+    *out_ptr = f->texels;
+    return ILM_OK;
+}
+
+int32_t ilm_sdf_render_slices(IlmHandle h, IlmHandle hclear, const IlmDistanceFieldRenderDesc* d,
+                              const int32_t* first_virtual_slices, int32_t triplet_count,
+                              const IlmObstruction* obstructions, int32_t obstruction_count,
+                              const IlmHeightVolume* volumes, int32_t volume_count,
+                              const float* polygon_xy, int32_t polygon_vertex_count) {
+    Sdf* f = from_handle<Sdf>(h, kMagicSdf);
+    if (!f) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle");
+    Sdf* clr = nullptr;
+    if (hclear) {
+        clr = from_handle<Sdf>(hclear, kMagicSdf);
+        if (!clr) return fail(ILM_ERR_INVALID_HANDLE, "clear source is not a distance field handle");
+        if (clr->ctx != f->ctx || clr->width != f->width || clr->height != f->height || clr->format != f->format)
+            return fail(ILM_ERR_INVALID_ARGUMENT, "clear source must match the distance field (context, size, format)");
+        if (clr == f) return fail(ILM_ERR_INVALID_ARGUMENT, "clear source is the target itself");
+    }
+    if (!d) return fail(ILM_ERR_INVALID_ARGUMENT, "desc is NULL");
+    if (triplet_count < 0 || obstruction_count < 0 || volume_count < 0 || polygon_vertex_count < 0 ||
+        (triplet_count > 0 && !first_virtual_slices) || (obstruction_count > 0 && !obstructions) ||
+        (volume_count > 0 && (!volumes || !polygon_xy)))
+        return fail(ILM_ERR_INVALID_ARGUMENT, "bad array argument");
+    if (d->SliceWidth <= 0 || d->SliceHeight <= 0 || d->ColumnCount <= 0 || d->RowCount <= 0 || d->SliceCount <= 0 ||
+        d->VirtualWidth <= 0 || d->VirtualHeight <= 0 || !(d->MaximumEncodedDistance > 0.0f))
+        return fail(ILM_ERR_INVALID_ARGUMENT, "bad distance field layout");
+    if (d->SliceWidth * d->ColumnCount != f->width || d->SliceHeight * d->RowCount != f->height)
+        return fail(ILM_ERR_INVALID_ARGUMENT, "layout %dx%d slices of %dx%d does not match the %dx%d atlas",
+                    d->ColumnCount, d->RowCount, d->SliceWidth, d->SliceHeight, f->width, f->height);
+    if (obstruction_count > 65535) return fail(ILM_ERR_TOO_MANY, "at most 65535 obstructions per call");
+    const int physical_count = d->ColumnCount * d->RowCount;
+    for (int i = 0; i < triplet_count; i++) {
+        const int s = first_virtual_slices[i];
+        if (s < 0 || (s % 3) != 0 || s / 3 >= physical_count)
+            return fail(ILM_ERR_OUT_OF_RANGE, "first virtual slice %d is not a triplet start inside the atlas", s);
+    }
+    for (int i = 0; i < obstruction_count; i++)
+        if (obstructions[i].Type < ILM_OBSTRUCTION_ELLIPSOID || obstructions[i].Type > ILM_OBSTRUCTION_OCTAGON)
+            return fail(ILM_ERR_INVALID_ARGUMENT, "obstruction %d has unknown type %d", i, obstructions[i].Type);
+    for (int i = 0; i < volume_count; i++)
+        if (volumes[i].FirstVertex < 0 || volumes[i].VertexCount < 0 || volumes[i].FirstVertex + volumes[i].VertexCount > polygon_vertex_count)
+            return fail(ILM_ERR_OUT_OF_RANGE, "height volume %d vertex range outside the polygon array", i);
+    if (triplet_count == 0) return ILM_OK;
+    Ctx* c = f->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+
+    // the orthographic view transform maps [0, VirtualWidth * ColumnCount] onto the atlas width
+    // (RenderDistanceFieldSliceTriplet, LightingRenderer.DistanceField.cs:97-102): virtual units -> slice pixels
+    const float px_per_unit_x = (float)d->SliceWidth / (float)d->VirtualWidth;
+    const float px_per_unit_y = (float)d->SliceHeight / (float)d->VirtualHeight;
+    const bool filter = d->DynamicFlagFilter >= 0, want_dynamic = d->DynamicFlagFilter != 0;
+
+    std::vector<FieldObstruction> recs;
+    recs.reserve((size_t)obstruction_count);
+    for (int i = 0; i < obstruction_count; i++) {
+        const IlmObstruction& o = obstructions[i];
+        if (filter && ((o.IsDynamic != 0) != want_dynamic)) continue;   // BuildDistanceFieldDistanceFunctionBuffer, :321-322
+        FieldObstruction r;
+        r.cx = o.Center[0]; r.cy = o.Center[1]; r.cz = o.Center[2]; r.type = o.Type;
+        r.sx = o.Size[0]; r.sy = o.Size[1]; r.sz = o.Size[2]; r._pad = 0;
+        r.qx = o.Orientation[0]; r.qy = o.Orientation[1]; r.qz = o.Orientation[2]; r.qw = o.Orientation[3];
+        // DistanceFunctionVertexShader, DistanceFunction.fx:16-26
+        const float msize = fmaxf(fmaxf(fabsf(o.Size[0]), fabsf(o.Size[1])), fabsf(o.Size[2])) + d->MaximumEncodedDistance + 4.0f;
+        r.x0 = (o.Center[0] - msize) * px_per_unit_x; r.x1 = (o.Center[0] + msize) * px_per_unit_x;
+        r.y0 = (o.Center[1] - msize) * px_per_unit_y; r.y1 = (o.Center[1] + msize) * px_per_unit_y;
+        recs.push_back(r);
+    }
+    std::vector<FieldVolume> vols;
+    vols.reserve((size_t)volume_count);
+    for (int i = 0; i < volume_count; i++) {
+        const IlmHeightVolume& hv = volumes[i];
+        if (filter && ((hv.IsDynamic != 0) != want_dynamic)) continue;   // :205-206
+        if (hv.VertexCount < 1) continue;
+        const float* P = polygon_xy + 2 * (size_t)hv.FirstVertex;
+        float bx0 = P[0], bx1 = P[0], by0 = P[1], by1 = P[1];
+        for (int e = 1; e < hv.VertexCount; e++) {
+            bx0 = fminf(bx0, P[2 * e]); bx1 = fmaxf(bx1, P[2 * e]);
+            by0 = fminf(by0, P[2 * e + 1]); by1 = fmaxf(by1, P[2 * e + 1]);
+        }
+        FieldVolume v;
+        v.first_vertex = hv.FirstVertex; v.vertex_count = hv.VertexCount;
+        v.z0 = hv.ZBase; v.z1 = hv.ZBase + hv.Height;
+        // hv.Bounds.Expand(DistanceLimit, DistanceLimit), :216
+        v.x0 = (bx0 - ILM_DISTANCE_LIMIT) * px_per_unit_x; v.x1 = (bx1 + ILM_DISTANCE_LIMIT) * px_per_unit_x;
+        v.y0 = (by0 - ILM_DISTANCE_LIMIT) * px_per_unit_y; v.y1 = (by1 + ILM_DISTANCE_LIMIT) * px_per_unit_y;
+        vols.push_back(v);
+    }
+
+    // one parameter block: [slices | obstruction records | volumes | polygon vertices], 64-byte aligned sections
+    auto align64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
+    const size_t off_slices = 0;
+    const size_t off_recs = align64(off_slices + sizeof(int32_t) * (size_t)triplet_count);
+    const size_t off_vols = align64(off_recs + sizeof(FieldObstruction) * recs.size());
+    const size_t off_poly = align64(off_vols + sizeof(FieldVolume) * vols.size());
+    const size_t total = align64(off_poly + sizeof(float) * 2 * (size_t)(vols.empty() ? 0 : polygon_vertex_count));
+    if (total > c->field_params_bytes) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_field_params) HIP_TRY(hipFree(c->d_field_params));
+        c->d_field_params = nullptr; c->field_params_bytes = 0;
+        const size_t cap = total < 65536 ? 65536 : total * 2;
+        HIP_TRY(hipMalloc(&c->d_field_params, cap));
+        c->field_params_bytes = cap;
+    }
+    std::vector<unsigned char> block(total, 0);
+    memcpy(block.data() + off_slices, first_virtual_slices, sizeof(int32_t) * (size_t)triplet_count);
+    if (!recs.empty()) memcpy(block.data() + off_recs, recs.data(), sizeof(FieldObstruction) * recs.size());
+    if (!vols.empty()) {
+        memcpy(block.data() + off_vols, vols.data(), sizeof(FieldVolume) * vols.size());
+        memcpy(block.data() + off_poly, polygon_xy, sizeof(float) * 2 * (size_t)polygon_vertex_count);
+    }
+    int32_t rc = upload_small(c, c->d_field_params, block.data(), total);
+    if (rc != ILM_OK) return rc;
+
+    FieldLaunch a;
+    char* base = static_cast<char*>(c->d_field_params);
+    a.atlas = f->texels; a.clear_source = clr ? clr->texels : nullptr; a.atlas_w = f->width;
+    a.first_slices = reinterpret_cast<const int32_t*>(base + off_slices); a.triplet_count = triplet_count;
+    a.obstructions = reinterpret_cast<const FieldObstruction*>(base + off_recs); a.obstruction_count = (int32_t)recs.size();
+    a.volumes = reinterpret_cast<const FieldVolume*>(base + off_vols); a.volume_count = (int32_t)vols.size();
+    a.polygon_xy = reinterpret_cast<const float2*>(base + off_poly);
+    a.slice_w = d->SliceWidth; a.slice_h = d->SliceHeight; a.columns = d->ColumnCount;
+    a.virtual_w = d->VirtualWidth; a.virtual_h = d->VirtualHeight;
+    a.slice_count_f = (float)d->SliceCount < 1.0f ? 1.0f : (float)d->SliceCount;   // Math.Max(1, (float)SliceCount), :33
+    a.virtual_depth = d->VirtualDepth; a.z_offset = d->ZOffset; a.max_encoded = d->MaximumEncodedDistance;
+    a.inv_scale_x = d->InvScaleFactorX; a.inv_scale_y = d->InvScaleFactorY;
+    HIP_TRY(launch_render_slices(a, f->format, c->stream));
     return ILM_OK;
 }
 

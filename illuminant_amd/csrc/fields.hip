@@ -1,0 +1,188 @@
+// fields.hip -- distance-field atlas generation for gfx950.
+//
+// The reference rasterises one instanced quad per obstruction and slice triplet into the atlas
+// render target and lets the ROP MAX-blend the encoded distances
+// (Illuminant/Lighting/LightingRenderer.DistanceField.cs:80-152,347-400, techniques of
+// Illuminant/Shaders/DistanceFunction.fx:33-155 and Illuminant/Shaders/DistanceField.fx:101-115,
+// BlendFunction.Max in Illuminant/LoadMaterials.cs:164-176): every obstruction re-reads and re-writes
+// the 8-byte texel.  Here a 64x4-texel tile of one physical slice is one workgroup: wave 0 bins the
+// obstruction quads / height-volume boxes that touch the tile into an LDS list (wave64 ballot +
+// popcount), every lane walks the list with the record in SGPRs (readfirstlane index -> scalar loads),
+// keeps the four running maxima of its texel in registers and stores the texel once: the atlas is
+// written exactly once per pass (8 B / texel), a wave stores 512 contiguous bytes.
+//
+// Compiled with -ffp-contract=off: every operation rounds as in the CPU oracle, so the stored codes are
+// bit-identical to it.  No MFMA (per-texel scalar distance functions), HBM-write-bound by definition
+// (8 B per texel) and in practice ALU-bound on scenes with many overlapping obstructions.
+#include "internal.hpp"
+#include "distance_functions.hpp"
+
+namespace ilm {
+
+constexpr int kFieldTileW = 64, kFieldTileH = 4;
+constexpr int kFieldListCapacity = 2048;
+
+// evaluate* by LightObstructionType (LightObstruction.cs:10-16): Ellipsoid, Box, Cylinder, Spheroid, Octagon
+// are cases 1..5 of evaluateByTypeId (DistanceFunctionCommon.fxh:170-187)
+ILM_DEV float evaluate_obstruction(int type, f3 wp, const FieldObstruction& o) {
+    const f3 p = rotate_local_q(wp - mk3(o.cx, o.cy, o.cz), mk4(o.qx, o.qy, o.qz, o.qw));
+    return evaluate_shape(type + 1, p, mk3(o.sx, o.sy, o.sz));
+}
+
+// computeDistanceZ, DistanceField.fx:47-56
+ILM_DEV float compute_distance_z(float slice_z, float z0, float z1) {
+    if (slice_z >= z0) {
+        if (slice_z <= z1)
+            return fmaxf(slice_z - z1, z0 - slice_z);
+        return slice_z - z1;
+    }
+    return z0 - slice_z;
+}
+
+// finalEval, DistanceField.fx:58-73 (PolygonXyBias 1.5)
+ILM_DEV float final_eval(float z, float z0, float z1, float dist_xy_biased) {
+    const float distance_z = compute_distance_z(z, z0, z1);
+    if (dist_xy_biased <= 0.0f)
+        return (distance_z <= 0.0f) ? dist_xy_biased + distance_z : distance_z;
+    return fmaxf(dist_xy_biased, 0.0f) + fmaxf(distance_z, 0.0f);
+}
+
+// render-target write of one channel: saturate, then D3D float -> unorm16 (c * 65535 + 0.5, truncated) or the
+// IEEE half of the saturated value
+template <int FORMAT>
+ILM_DEV uint32_t store_channel(float enc) {
+    const float c = sat(enc);
+    if (FORMAT == ILM_SDF_FP16)
+        return (uint32_t)__half_as_ushort(__float2half_rn(c));
+    return (uint32_t)floorf(c * 65535.0f + 0.5f);
+}
+
+template <int FORMAT>
+__global__ __launch_bounds__(256) void render_slices_kernel(const FieldLaunch a) {
+    __shared__ uint16_t list[kFieldListCapacity];
+    __shared__ int list_count;
+
+    const int tiles_x = (a.slice_w + kFieldTileW - 1) / kFieldTileW;
+    const int tiles_y = (a.slice_h + kFieldTileH - 1) / kFieldTileH;
+    const int tiles_per_slice = tiles_x * tiles_y;
+    const int b = (int)blockIdx.x;
+    const int triplet = b / tiles_per_slice, tile = b - triplet * tiles_per_slice;
+    const int first = a.first_slices[triplet];
+    const int physical = first / 3;
+    const int col = physical % a.columns, row = physical / a.columns;
+    const int slice_x = col * a.slice_w, slice_y = row * a.slice_h;
+    const float vpx = -(float)(col * a.virtual_w), vpy = -(float)(row * a.virtual_h);
+
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const int tx0 = (tile % tiles_x) * kFieldTileW, ty0 = (tile / tiles_x) * kFieldTileH;
+    const int i = tx0 + lane, j = ty0 + wave;
+    const bool in_slice = (i < a.slice_w) && (j < a.slice_h);
+    const int ax = slice_x + i, ay = slice_y + j;
+
+    // SliceIndexToZ, LightingRenderer.DistanceField.cs:32-35
+    float slice_z[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        slice_z[k] = (((float)(first + k) / a.slice_count_f) * a.virtual_depth) + a.z_offset;
+
+    // getPositionXy, DistanceFunction.fx:28-31 (vpos = integer atlas pixel)
+    const float wx = ((float)ax * a.inv_scale_x) + vpx;
+    const float wy = ((float)ay * a.inv_scale_y) + vpy;
+    const float cxp = (float)i + 0.5f, cyp = (float)j + 0.5f;
+    const float tminx = (float)tx0 + 0.5f, tmaxx = (float)(tx0 + kFieldTileW - 1) + 0.5f;
+    const float tminy = (float)ty0 + 0.5f, tmaxy = (float)(ty0 + kFieldTileH - 1) + 0.5f;
+
+    float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;   // saturate() at the target floors every write at 0
+
+    // ---- analytic obstructions ----------------------------------------------------------------------
+    for (int batch = 0; batch < a.obstruction_count; batch += kFieldListCapacity) {
+        const int batch_n = min(kFieldListCapacity, a.obstruction_count - batch);
+        __syncthreads();
+        if (wave == 0) {
+            int base = 0;
+            for (int o0 = 0; o0 < batch_n; o0 += 64) {
+                const int oi = o0 + lane;
+                bool hit = false;
+                if (oi < batch_n) {
+                    const FieldObstruction& R = a.obstructions[batch + oi];
+                    hit = (R.x0 <= tmaxx) && (R.x1 > tminx) && (R.y0 <= tmaxy) && (R.y1 > tminy);
+                }
+                const unsigned long long m = __ballot(hit);
+                if (hit)
+                    list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)oi;
+                base += __popcll(m);
+            }
+            if (lane == 0) list_count = base;
+        }
+        __syncthreads();
+        const int n = list_count;
+        for (int k = 0; k < n; k++) {
+            const int oi = __builtin_amdgcn_readfirstlane((int)list[k]);
+            const FieldObstruction& R = a.obstructions[batch + oi];
+            // DistanceFunctionVertexShader's quad (DistanceFunction.fx:16-26): pixel centre inside [x0, x1) x [y0, y1)
+            if (!(in_slice && (cxp >= R.x0) && (cxp < R.x1) && (cyp >= R.y0) && (cyp < R.y1)))
+                continue;
+            const int type = R.type;
+            acc0 = fmaxf(acc0, kDistanceZero - (evaluate_obstruction(type, mk3(wx, wy, slice_z[0]), R) / a.max_encoded));
+            acc1 = fmaxf(acc1, kDistanceZero - (evaluate_obstruction(type, mk3(wx, wy, slice_z[1]), R) / a.max_encoded));
+            acc2 = fmaxf(acc2, kDistanceZero - (evaluate_obstruction(type, mk3(wx, wy, slice_z[2]), R) / a.max_encoded));
+            acc3 = fmaxf(acc3, kDistanceZero - (evaluate_obstruction(type, mk3(wx, wy, slice_z[3]), R) / a.max_encoded));
+        }
+    }
+
+    // ---- height volumes: DistanceToPolygon, DistanceField.fx:75-115 -------------------------------
+    for (int v = 0; v < a.volume_count; v++) {
+        const FieldVolume& V = a.volumes[v];
+        // whole-tile reject on the expanded bounds, then the per-pixel raster test
+        if (!((V.x0 <= tmaxx) && (V.x1 > tminx) && (V.y0 <= tmaxy) && (V.y1 > tminy)))
+            continue;
+        const bool covered = in_slice && (cxp >= V.x0) && (cxp < V.x1) && (cyp >= V.y0) && (cyp < V.y1);
+        // Inigo Quilez' sdPolygon (Fracture SDF2D.fxh sdPolygonInit / sdPolygonVertex): every edge exactly once
+        float dist_sq = 999999.0f, sign = 1.0f;
+        const float2* P = a.polygon_xy + V.first_vertex;
+        for (int e = 0; e < V.vertex_count; e++) {
+            const int nx = (e + 1 == V.vertex_count) ? 0 : e + 1;
+            const float2 vi = P[nx], vj = P[e];
+            const float ex = vj.x - vi.x, ey = vj.y - vi.y;
+            const float qx = wx - vi.x, qy = wy - vi.y;
+            const float t = clampf((qx * ex + qy * ey) / (ex * ex + ey * ey), 0.0f, 1.0f);
+            const float bx = qx - ex * t, by = qy - ey * t;
+            dist_sq = fminf(dist_sq, bx * bx + by * by);
+            const bool c0 = wy >= vi.y, c1 = wy < vj.y, c2 = (ex * qy) > (ey * qx);
+            if ((c0 && c1 && c2) || (!c0 && !c1 && !c2))
+                sign = -sign;
+        }
+        if (!covered)
+            continue;
+        const float dxy = (sqrtf(dist_sq) * sign) + 1.5f;
+        acc0 = fmaxf(acc0, kDistanceZero - (final_eval(slice_z[0], V.z0, V.z1, dxy) / a.max_encoded));
+        acc1 = fmaxf(acc1, kDistanceZero - (final_eval(slice_z[1], V.z0, V.z1, dxy) / a.max_encoded));
+        acc2 = fmaxf(acc2, kDistanceZero - (final_eval(slice_z[2], V.z0, V.z1, dxy) / a.max_encoded));
+        acc3 = fmaxf(acc3, kDistanceZero - (final_eval(slice_z[3], V.z0, V.z1, dxy) / a.max_encoded));
+    }
+
+    if (!in_slice)
+        return;
+    const size_t o = (size_t)ay * (size_t)a.atlas_w + (size_t)ax;
+    uint32_t c0 = store_channel<FORMAT>(acc0), c1 = store_channel<FORMAT>(acc1);
+    uint32_t c2 = store_channel<FORMAT>(acc2), c3 = store_channel<FORMAT>(acc3);
+    if (a.clear_source != nullptr) {
+        // ClearDistanceFieldSlice with the static texture (ClearDistanceField.fx:30-44), then BlendFunction.Max on the
+        // stored codes (non-negative halves order like their bit patterns)
+        const uint2 s = a.clear_source[o];
+        c0 = max(c0, s.x & 0xFFFFu); c1 = max(c1, s.x >> 16);
+        c2 = max(c2, s.y & 0xFFFFu); c3 = max(c3, s.y >> 16);
+    }
+    a.atlas[o] = make_uint2(c0 | (c1 << 16), c2 | (c3 << 16));
+}
+
+hipError_t launch_render_slices(const FieldLaunch& a, int format, hipStream_t stream) {
+    if (a.triplet_count <= 0 || a.slice_w <= 0 || a.slice_h <= 0) return hipSuccess;
+    const int tiles_x = (a.slice_w + kFieldTileW - 1) / kFieldTileW, tiles_y = (a.slice_h + kFieldTileH - 1) / kFieldTileH;
+    const dim3 grid((unsigned)(a.triplet_count * tiles_x * tiles_y)), block(256);
+    if (format == ILM_SDF_FP16) hipLaunchKernelGGL(render_slices_kernel<ILM_SDF_FP16>, grid, block, 0, stream, a);
+    else hipLaunchKernelGGL(render_slices_kernel<ILM_SDF_UNORM16>, grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace ilm

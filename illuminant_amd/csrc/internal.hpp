@@ -105,4 +105,30 @@ hipError_t launch_sphere_lights_prepared(const LightLaunch& a, const void* recs,
 // sampleDistanceFieldEx at `count` positions (xyz triples) -- diagnostic entry point ilm_sdf_sample
 hipError_t launch_sdf_sample(const SdfView& sdf, const IlmDistanceFieldUniforms& df, const float* positions, int count, float* out, hipStream_t stream);
 
+// ---- distance-field generation (fields.hip) ---------------------------------------------------------------
+// One obstruction as the kernel reads it: the DistanceFunctionVertex (Vertices.cs:105-141) plus its quad in slice
+// pixels, computed on the host with the oracle's operations (api.hip is compiled with -ffp-contract=off).
+struct FieldObstruction {
+    float cx, cy, cz; int32_t type;
+    float sx, sy, sz; int32_t _pad;
+    float qx, qy, qz, qw;
+    float x0, x1, y0, y1;       // raster bounds of DistanceFunctionVertexShader's quad, slice-local pixels
+};
+static_assert(sizeof(FieldObstruction) == 64, "FieldObstruction is one 64-byte record");
+struct FieldVolume {
+    int32_t first_vertex, vertex_count;
+    float z0, z1;               // zRange = (ZBase, ZBase + Height)
+    float x0, x1, y0, y1;       // hv.Bounds.Expand(DistanceLimit) in slice-local pixels
+};
+struct FieldLaunch {
+    uint2* atlas; const uint2* clear_source; int32_t atlas_w;
+    const int32_t* first_slices; int32_t triplet_count;     // device
+    const FieldObstruction* obstructions; int32_t obstruction_count;
+    const FieldVolume* volumes; int32_t volume_count;
+    const float2* polygon_xy;
+    int32_t slice_w, slice_h, columns, virtual_w, virtual_h;
+    float slice_count_f, virtual_depth, z_offset, max_encoded, inv_scale_x, inv_scale_y;
+};
+hipError_t launch_render_slices(const FieldLaunch& a, int format, hipStream_t stream);
+
 }  // namespace ilm

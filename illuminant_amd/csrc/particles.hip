@@ -11,6 +11,7 @@
 #include <cstdlib>
 
 #include "internal.hpp"
+#include "distance_functions.hpp"
 
 namespace ilm {
 
@@ -36,38 +37,6 @@ ILM_DEV float4 random_custom(const float4* __restrict__ rnd, int rw, int rh, flo
 // ---------------------------------------------------------------------------------------------
 // DistanceFunctionCommon.fxh -- area weights for FMA / Noise
 // ---------------------------------------------------------------------------------------------
-ILM_DEV float4 qmul(float4 q1, float4 q2) {
-    const f3 a = xyz(q2) * q1.w, b = xyz(q1) * q2.w, c = cross3(xyz(q1), xyz(q2));
-    const f3 s = (a + b) + c;
-    return mk4(s.x, s.y, s.z, q1.w * q2.w - dot3(xyz(q1), xyz(q2)));
-}
-ILM_DEV f3 rotate_local(f3 p, float r) {
-    // scalar AreaRotation promoted to float4(r,r,r,r) (FMA.fx:11,16-18)
-    const float4 rot = mk4(r, r, r, r);
-    const float4 r_c = mk4(r * -1.0f, r * -1.0f, r * -1.0f, r * 1.0f);
-    return xyz(qmul(rot, qmul(mk4(p.x, p.y, p.z, 0.0f), r_c)));
-}
-ILM_DEV float4 op_elongate(f3 p, f3 h) {
-    const f3 q = abs3(p) - h;
-    const f3 m = max03(q);
-    return mk4(sgn(p.x) * m.x, sgn(p.y) * m.y, sgn(p.z) * m.z, fminf(fmaxf(q.x, fmaxf(q.y, q.z)), 0.0f));
-}
-ILM_DEV float sd_octogon_prism(f3 p, float r, float h) {
-    const float kx = -0.9238795325f, ky = 0.3826834323f, kz = 0.4142135623f;
-    p = abs3(p);
-    const float d1 = fminf(kx * p.x + ky * p.y, 0.0f);
-    p.x -= 2.0f * d1 * kx;
-    p.y -= 2.0f * d1 * ky;
-    const float d2 = fminf(-kx * p.x + ky * p.y, 0.0f);
-    p.x -= 2.0f * d2 * -kx;
-    p.y -= 2.0f * d2 * ky;
-    p.x -= clampf(p.x, -kz * r, kz * r);
-    p.y -= r;
-    const float dx = sqrtf(p.x * p.x + p.y * p.y) * sgn(p.y);
-    const float dy = p.z - h;
-    const float mx = fmaxf(dx, 0.0f), my = fmaxf(dy, 0.0f);
-    return fminf(fmaxf(dx, dy), 0.0f) + sqrtf(mx * mx + my * my);
-}
 // evaluateByTypeId, DistanceFunctionCommon.fxh:170-187
 ILM_DEV float evaluate_area(int type_id, f3 wp, const IlmAreaParams& a) {
     const int t = abs(type_id);
@@ -76,34 +45,7 @@ ILM_DEV float evaluate_area(int type_id, f3 wp, const IlmAreaParams& a) {
     const f3 center = mk3(a.AreaCenter[0], a.AreaCenter[1], a.AreaCenter[2]);
     const f3 size = mk3(a.AreaSize[0], a.AreaSize[1], a.AreaSize[2]);
     const f3 p = rotate_local(wp - center, a.AreaRotation);
-    switch (t) {
-        case 1: {  // evaluateEllipsoid -> sdEllipsoid_improvedV2, :92-109
-            const float k0 = len3(mk3(p.x / size.x, p.y / size.y, p.z / size.z));
-            const float k1 = len3(mk3(p.x / (size.x * size.x), p.y / (size.y * size.y), p.z / (size.z * size.z)));
-            return (k0 < 1.0f) ? (k0 - 1.0f) * fminf(fminf(size.x, size.y), size.z) : k0 * (k0 - 1.0f) / k1;
-        }
-        case 2: {  // evaluateBox, :48-63
-            const f3 d = abs3(p) - size;
-            return fminf(fmaxf(d.x, fmaxf(d.y, d.z)), 0.0f) + len3(max03(d));
-        }
-        case 3: {  // evaluateCylinder -> sdCappedCylinder, :111-124
-            const float h = size.z, r = sqrtf(size.x * size.x + size.y * size.y);
-            const float dx = fabsf(sqrtf(p.x * p.x + p.y * p.y)) - r;
-            const float dy = fabsf(p.z) - h;
-            const float mx = fmaxf(dx, 0.0f), my = fmaxf(dy, 0.0f);
-            return fminf(fmaxf(dx, dy), 0.0f) + sqrtf(mx * mx + my * my);
-        }
-        case 4: {  // evaluateSpheroid, :65-75
-            const float min_size = fminf(size.x, fminf(size.y, size.z));
-            const float4 w = op_elongate(p, mk3(size.x - min_size, size.y - min_size, size.z - min_size));
-            return w.w + (len3(xyz(w)) - min_size);
-        }
-        default: {  // evaluateOctagon, :158-168
-            const float min_size = fminf(size.x, size.y);
-            const float4 w = op_elongate(p, mk3(size.x - min_size, size.y - min_size, 0.0f));
-            return w.w + sd_octogon_prism(xyz(w), min_size, size.z);
-        }
-    }
+    return evaluate_shape(t, p, size);
 }
 // computeWeight, FMA.fx:15-20 / Noise.fx:21-26
 ILM_DEV float compute_weight(const IlmAreaParams& a, f3 wp) {

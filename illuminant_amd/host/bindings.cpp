@@ -68,7 +68,35 @@ PYBIND11_MODULE(_host, m) {
             if (a.size() != (py::ssize_t)f.TextureWidth * f.TextureHeight * 4) throw ArgumentException("atlas size mismatch");
             f.Load(a.data());
         })
+        .def("Save", [](const DistanceField& f) {
+            py::array_t<uint16_t> out({ (py::ssize_t)f.TextureHeight, (py::ssize_t)f.TextureWidth, (py::ssize_t)4 });
+            f.Save(out.mutable_data());
+            return out;
+        })
+        .def("Invalidate", [](DistanceField& f) { f.Invalidate(); })
+        .def_property_readonly("ValidSliceCount", [](const DistanceField& f) { return f.Slices.ValidSliceCount; })
+        .def_property_readonly("InvalidSlices", [](const DistanceField& f) { return f.Slices.InvalidSlices; })
+        .def_property_readonly("IsFullyGenerated", &DistanceField::IsFullyGenerated)
+        .def_property_readonly("NeedsRasterize", &DistanceField::NeedsRasterize)
+        .def_property_readonly("TextureHandle", &DistanceField::Texture)
+        .def("ReadTexture", [](const DistanceField& f) {      // the atlas whatever its validity (tests)
+            py::array_t<uint16_t> out({ (py::ssize_t)f.TextureHeight, (py::ssize_t)f.TextureWidth, (py::ssize_t)4 });
+            ThrowIfFailed(ilm_sdf_download(f.Texture(), out.mutable_data()));
+            return out;
+        })
         .def("GetUniformsBytes", [](const DistanceField& f) { auto u = f.GetUniforms(); return py::bytes((const char*)&u, sizeof(u)); });
+    py::class_<DynamicDistanceField, DistanceField>(m, "DynamicDistanceField")
+        .def(py::init<DeviceContext&, int, int, float, int, double, int, int>(), py::arg("ctx"), py::arg("virtualWidth"), py::arg("virtualHeight"),
+             py::arg("virtualDepth"), py::arg("sliceCount"), py::arg("requestedResolution") = 1.0,
+             py::arg("maximumEncodedDistance") = 128, py::arg("format") = 0, py::keep_alive<1, 2>())
+        .def("Invalidate", [](DynamicDistanceField& f, bool invalidateStatic) { f.Invalidate(invalidateStatic); }, py::arg("invalidateStatic") = true)
+        .def_property_readonly("StaticValidSliceCount", [](const DynamicDistanceField& f) { return f.StaticSliceInfo.ValidSliceCount; })
+        .def_property_readonly("StaticInvalidSlices", [](const DynamicDistanceField& f) { return f.StaticSliceInfo.InvalidSlices; })
+        .def("ReadStaticTexture", [](const DynamicDistanceField& f) {
+            py::array_t<uint16_t> out({ (py::ssize_t)f.TextureHeight, (py::ssize_t)f.TextureWidth, (py::ssize_t)4 });
+            ThrowIfFailed(ilm_sdf_download(f.StaticTexture(), out.mutable_data()));
+            return out;
+        });
 
     // ---- particles -------------------------------------------------------------------------------------------
     py::class_<ParticleEngineConfiguration>(m, "ParticleEngineConfiguration").def(py::init<int>(), py::arg("chunkSize") = 256)
@@ -249,8 +277,32 @@ PYBIND11_MODULE(_host, m) {
         .def_readwrite("ShadowFilter", &SphereLightSource::ShadowFilter)
         VEC_PROP(SphereLightSource, SpecularColor, 3)
         .def_readwrite("SpecularPower", &SphereLightSource::SpecularPower);
+    py::class_<LightObstruction, std::shared_ptr<LightObstruction>>(m, "LightObstruction")
+        .def(py::init([](int type, const std::vector<float>& center, const std::vector<float>& radius, float rotation) {
+            return std::make_shared<LightObstruction>((LightObstructionType)type, v3(center), v3(radius), rotation);
+        }), py::arg("type"), py::arg("center") = std::vector<float>{0, 0, 0}, py::arg("radius") = std::vector<float>{0, 0, 0}, py::arg("rotation") = 0.0f)
+        .def_property("Type", [](const LightObstruction& o) { return (int)o.Type(); }, [](LightObstruction& o, int t) { o.SetType((LightObstructionType)t); })
+        .def_property("Center", [](const LightObstruction& o) { return l3(o.Center()); }, [](LightObstruction& o, const std::vector<float>& v) { o.SetCenter(v3(v)); })
+        .def_property("Size", [](const LightObstruction& o) { return l3(o.Size()); }, [](LightObstruction& o, const std::vector<float>& v) { o.SetSize(v3(v)); })
+        .def_property("Orientation", [](const LightObstruction& o) { return l4(o.Orientation()); }, [](LightObstruction& o, const std::vector<float>& v) { o.SetOrientation(v4(v)); })
+        .def_property("Rotation", &LightObstruction::Rotation, &LightObstruction::SetRotation)
+        .def_property("IsDynamic", &LightObstruction::IsDynamic, &LightObstruction::SetIsDynamic)
+        .def_readonly("IsValid", &LightObstruction::IsValid)
+        .def("VertexBytes", [](const LightObstruction& o) { auto v = o.Vertex(); return py::bytes((const char*)&v, sizeof(v)); });
+    py::class_<LightObstructionCollection>(m, "LightObstructionCollection")
+        .def("Add", &LightObstructionCollection::Add).def("RemoveAt", &LightObstructionCollection::RemoveAt)
+        .def("Clear", &LightObstructionCollection::Clear).def_property_readonly("Count", &LightObstructionCollection::Count)
+        .def("__len__", &LightObstructionCollection::Count)
+        .def("__getitem__", [](LightObstructionCollection& c, int i) { return c.Items.at(i); });
+    py::class_<HeightVolume>(m, "HeightVolume").def(py::init<>())
+        .def_property("Polygon", [](const HeightVolume& h) { std::vector<std::vector<float>> r; for (auto& p : h.Polygon) r.push_back(l2(p)); return r; },
+                      [](HeightVolume& h, const std::vector<std::vector<float>>& v) { h.Polygon.clear(); for (auto& p : v) h.Polygon.push_back(v2(p)); })
+        .def_readwrite("ZBase", &HeightVolume::ZBase).def_readwrite("Height", &HeightVolume::Height)
+        .def_readwrite("IsDynamic", &HeightVolume::IsDynamic).def_readwrite("IsObstruction", &HeightVolume::IsObstruction);
     py::class_<LightingEnvironment>(m, "LightingEnvironment").def(py::init<>())
         .def_readwrite("Lights", &LightingEnvironment::Lights)
+        .def_property_readonly("Obstructions", [](LightingEnvironment& e) -> LightObstructionCollection& { return e.Obstructions; }, py::return_value_policy::reference_internal)
+        .def_readwrite("HeightVolumes", &LightingEnvironment::HeightVolumes)
         .def_readwrite("GroundZ", &LightingEnvironment::GroundZ).def_readwrite("MaximumZ", &LightingEnvironment::MaximumZ)
         .def_readwrite("ZToYMultiplier", &LightingEnvironment::ZToYMultiplier)
         VEC_PROP(LightingEnvironment, Ambient, 4);
@@ -265,6 +317,7 @@ PYBIND11_MODULE(_host, m) {
         .def_readwrite("LightOcclusion", &RendererConfiguration::LightOcclusion)
         VEC_PROP(RendererConfiguration, RenderScale, 2)
         .def_readwrite("DefaultQuality", &RendererConfiguration::DefaultQuality)
+        .def_readwrite("MaximumFieldUpdatesPerFrame", &RendererConfiguration::MaximumFieldUpdatesPerFrame)
         .def_readwrite("FloatLightmap", &RendererConfiguration::FloatLightmap);
     py::class_<LightingRenderer>(m, "LightingRenderer")
         .def(py::init([](DeviceContext& ctx, const RendererConfiguration& cfg, LightingEnvironment* env, uintptr_t externalLightmap) {
@@ -280,6 +333,8 @@ PYBIND11_MODULE(_host, m) {
             if (a.ndim() != 3 || a.shape(2) != 4) throw ArgumentException("G-buffer must be (H, W, 4)");
             r.SetGBuffer(a.data(), (int)a.shape(1), (int)a.shape(0), format);
         })
+        .def("UpdateFields", &LightingRenderer::UpdateFields)
+        .def("InvalidateFields", &LightingRenderer::InvalidateFields, py::arg("invalidateDistanceField") = true)
         .def("RenderLighting", [](LightingRenderer& r, float intensityScale, int rowBegin, int rowEnd, bool wantStats) -> py::object {
             if (!wantStats) { r.RenderLighting(intensityScale, rowBegin, rowEnd, nullptr); return py::none(); }
             IlmRenderStats st{};

@@ -88,8 +88,14 @@ DistanceField::Layout DistanceField::ComputeLayout(int virtualWidth, int virtual
     return L;
 }
 
+bool SliceInfo::Contains(int index) const { return std::find(InvalidSlices.begin(), InvalidSlices.end(), index) != InvalidSlices.end(); }
+void SliceInfo::Remove(int index) {
+    auto it = std::find(InvalidSlices.begin(), InvalidSlices.end(), index);
+    if (it != InvalidSlices.end()) InvalidSlices.erase(it);
+}
+
 DistanceField::DistanceField(DeviceContext& ctx, int virtualWidth, int virtualHeight, float virtualDepth, int requestedSliceCount,
-                             double requestedResolution, int maximumEncodedDistance, int format) {
+                             double requestedResolution, int maximumEncodedDistance, int format) : context(ctx) {
     VirtualWidth = virtualWidth; VirtualHeight = virtualHeight; VirtualDepth = virtualDepth;
     MaximumEncodedDistance = maximumEncodedDistance;
     RequestedResolution = requestedResolution;
@@ -99,13 +105,72 @@ DistanceField::DistanceField(DeviceContext& ctx, int virtualWidth, int virtualHe
     SliceCount = L.SliceCount; PhysicalSliceCount = L.PhysicalSliceCount;
     ColumnCount = L.ColumnCount; RowCount = L.RowCount;
     TextureWidth = L.TextureWidth; TextureHeight = L.TextureHeight;
+    Format = format;
     ThrowIfFailed(ilm_sdf_create(ctx.Handle(), TextureWidth, TextureHeight, format, &texture));
+    NeedClear = true;
+    DistanceField::Invalidate();   // :120
 }
 DistanceField::~DistanceField() { if (texture) ilm_sdf_destroy(texture); }
 
+// Save, :183-194
+void DistanceField::Save(uint16_t* texels) const {
+    if (Slices.ValidSliceCount < SliceCount)
+        throw InvalidOperationException("The distance field must be fully valid");
+    ThrowIfFailed(ilm_sdf_download(texture, texels));
+}
+
+// Load, :196-213
 void DistanceField::Load(const uint16_t* texels) {
     ThrowIfFailed(ilm_sdf_upload(texture, texels));
-    ValidSliceCount = SliceCount;
+    Slices.InvalidSlices.clear();
+    Slices.ValidSliceCount = ((SliceCount + 2) / 3) * 3;
+}
+
+// Invalidate, :215-222
+void DistanceField::Invalidate() {
+    for (int i = 0; i < SliceCount; i++)
+        if (!Slices.Contains(i))
+            Slices.InvalidSlices.push_back(i);
+}
+
+IlmDistanceFieldRenderDesc DistanceField::GetRenderDesc(int dynamicFlagFilter) const {
+    IlmDistanceFieldRenderDesc d;
+    std::memset(&d, 0, sizeof(d));
+    d.VirtualWidth = VirtualWidth; d.VirtualHeight = VirtualHeight; d.VirtualDepth = VirtualDepth; d.ZOffset = ZOffset;
+    d.SliceWidth = SliceWidth; d.SliceHeight = SliceHeight; d.SliceCount = SliceCount;
+    d.ColumnCount = ColumnCount; d.RowCount = RowCount;
+    d.MaximumEncodedDistance = (float)MaximumEncodedDistance;
+    d.InvScaleFactorX = (float)((double)VirtualWidth / SliceWidth);      // Uniforms.cs:108-109
+    d.InvScaleFactorY = (float)((double)VirtualHeight / SliceHeight);
+    d.DynamicFlagFilter = dynamicFlagFilter;
+    return d;
+}
+
+// DynamicDistanceField, SDF/DistanceField.cs:248-321
+DynamicDistanceField::DynamicDistanceField(DeviceContext& ctx, int virtualWidth, int virtualHeight, float virtualDepth, int sliceCount,
+                                           double requestedResolution, int maximumEncodedDistance, int format)
+    : DistanceField(ctx, virtualWidth, virtualHeight, virtualDepth, sliceCount, requestedResolution, maximumEncodedDistance, format) {
+    ThrowIfFailed(ilm_sdf_create(ctx.Handle(), TextureWidth, TextureHeight, format, &staticTexture));
+    Invalidate(true);
+}
+DynamicDistanceField::~DynamicDistanceField() { if (staticTexture) ilm_sdf_destroy(staticTexture); }
+void DynamicDistanceField::Invalidate(bool invalidateStatic) {   // :270-277
+    for (int i = 0; i < SliceCount; i++) {
+        if (!Slices.Contains(i)) Slices.InvalidSlices.push_back(i);
+        if (invalidateStatic && !StaticSliceInfo.Contains(i)) StaticSliceInfo.InvalidSlices.push_back(i);
+    }
+}
+void DynamicDistanceField::ValidateSlice(int index, bool dynamic) {   // :279-285
+    if (dynamic) {
+        if (!StaticSliceInfo.Contains(index)) Slices.Remove(index);
+    } else
+        StaticSliceInfo.Remove(index);
+}
+void DynamicDistanceField::MarkValidSlice(int index, bool dynamic) {   // :287-292
+    if (dynamic)
+        Slices.ValidSliceCount = std::min(std::max(Slices.ValidSliceCount, index), StaticSliceInfo.ValidSliceCount);
+    else
+        StaticSliceInfo.ValidSliceCount = std::max(StaticSliceInfo.ValidSliceCount, index);
 }
 
 IlmDistanceFieldUniforms DistanceField::GetUniforms() const {
@@ -113,7 +178,7 @@ IlmDistanceFieldUniforms DistanceField::GetUniforms() const {
     std::memset(&u, 0, sizeof(u));
     u.Extent = { (float)VirtualWidth, (float)VirtualHeight, VirtualDepth, (float)MaximumEncodedDistance };   // GetExtent4
     const float sliceZSize = VirtualDepth / SliceCount;
-    u.TextureSliceCount = { (float)ColumnCount, (float)RowCount, std::min(ValidSliceCount, SliceCount) * sliceZSize, (float)SliceCount };
+    u.TextureSliceCount = { (float)ColumnCount, (float)RowCount, std::min(Slices.ValidSliceCount, SliceCount) * sliceZSize, (float)SliceCount };
     u.TextureSliceAndTexelSize = { 1.0f / ColumnCount, 1.0f / RowCount, 1.0f / (VirtualWidth * ColumnCount), 1.0f / (VirtualHeight * RowCount) };
     u.ConeAndMisc = { 0, 0, 0, (float)((double)VirtualWidth / SliceWidth) };
     u.StepAndMisc2 = { 0, 0, 1, (float)((double)VirtualHeight / SliceHeight) };
@@ -817,6 +882,132 @@ void LightingRenderer::RenderLighting(float intensityScale, int rowBegin, int ro
                                Environment->Ambient.Z * intensityScale, Environment->Ambient.W * intensityScale };
     ThrowIfFailed(ilm_render_sphere_lights(Context.Handle(), vertices.empty() ? nullptr : vertices.data(), (int32_t)vertices.size(),
                                            &env, &dfu, gbuffer, Field ? Field->Texture() : 0, ambient, lightmap, rowBegin, rowEnd, stats));
+}
+
+// ---- LightObstruction.cs ---------------------------------------------------------------------------------
+LightObstruction::LightObstruction(LightObstructionType t, Vector3 c, Vector3 radius, float rotation) : type(t), center(c), size(radius) {
+    SetRotation(rotation);
+}
+void LightObstruction::SetRotation(float value) {
+    shadowRotation = value;
+    // Quaternion.CreateFromAxisAngle(Vector3.UnitZ, angle): half = angle * 0.5f; (axis * sin(half), cos(half))
+    const float half = value * 0.5f;
+    SetOrientation({ 0.0f, 0.0f, (float)std::sin((double)half), (float)std::cos((double)half) });
+}
+IlmObstruction LightObstruction::Vertex() const {
+    IlmObstruction o;
+    o.Center[0] = center.X; o.Center[1] = center.Y; o.Center[2] = center.Z; o.Type = (int32_t)type;
+    o.Size[0] = size.X; o.Size[1] = size.Y; o.Size[2] = size.Z; o.IsDynamic = isDynamic ? 1 : 0;
+    o.Orientation[0] = orientation.X; o.Orientation[1] = orientation.Y; o.Orientation[2] = orientation.Z; o.Orientation[3] = orientation.W;
+    return o;
+}
+
+// AutoInvalidateDistanceField, LightingRenderer.cs:1977-2014
+void LightingRenderer::AutoInvalidateDistanceField() {
+    DynamicDistanceField* ddf = dynamic_cast<DynamicDistanceField*>(Field);
+    bool hasInvalidatedStatic = false, hasInvalidatedDynamic = false;
+    LightObstructionCollection& obstructions = Environment->Obstructions;
+    if (obstructions.IsInvalidDynamic) {
+        if (ddf) ddf->Invalidate(false);
+        hasInvalidatedDynamic = true;
+    }
+    if (obstructions.IsInvalid) {
+        Field->Invalidate();
+        hasInvalidatedStatic = true;
+    }
+    obstructions.IsInvalid = obstructions.IsInvalidDynamic = false;
+    for (auto& obs : obstructions.Items) {
+        if (obs->HasDynamicityChanged) {
+            obs->HasDynamicityChanged = false;
+            if (!hasInvalidatedStatic) {
+                hasInvalidatedStatic = hasInvalidatedDynamic = true;
+                Field->Invalidate();
+            }
+        }
+        if (!obs->IsValid) {
+            obs->IsValid = true;
+            if (ddf && obs->IsDynamic()) {
+                if (!hasInvalidatedDynamic) {
+                    hasInvalidatedDynamic = true;
+                    ddf->Invalidate(false);
+                }
+            } else if (!hasInvalidatedStatic) {
+                hasInvalidatedStatic = hasInvalidatedDynamic = true;
+                Field->Invalidate();
+            }
+        }
+    }
+}
+
+// RenderDistanceFieldPartition, LightingRenderer.DistanceField.cs:415-464.  The reference issues one render-target pass per
+// slice triplet; here the triplets of one partition go to the device as one ilm_sdf_render_slices call.
+int LightingRenderer::RenderDistanceFieldPartition(int dynamicFlagFilter) {
+    DynamicDistanceField* ddf = dynamic_cast<DynamicDistanceField*>(Field);
+    if (!ddf) dynamicFlagFilter = -1;
+    const bool isRenderingStatic = ddf && (dynamicFlagFilter == 0);
+    SliceInfo& sliceInfo = isRenderingStatic ? ddf->StaticSliceInfo : Field->Slices;
+    const IlmHandle renderTarget = isRenderingStatic ? ddf->StaticTexture() : Field->Texture();
+
+    int slicesToUpdate = std::min(Configuration.MaximumFieldUpdatesPerFrame, (int)sliceInfo.InvalidSlices.size());
+    if (slicesToUpdate <= 0)
+        return 0;
+
+    std::vector<int32_t> firstSlices;
+    while (slicesToUpdate > 0) {
+        if (sliceInfo.InvalidSlices.empty())
+            break;   // (the reference would index an empty list here when the count is not a multiple of 3)
+        const int slice = sliceInfo.InvalidSlices[0];
+        firstSlices.push_back(slice - (slice % DistanceField::PackedSliceCount));
+        // RenderDistanceFieldSliceTriplet, :137-148
+        const int first = firstSlices.back(), last = first + 2;
+        for (int i = first; i <= last; i++) {
+            if (ddf) ddf->ValidateSlice(i, dynamicFlagFilter == 1);
+            else Field->ValidateSlice(i);
+        }
+        if (ddf) ddf->MarkValidSlice(last + 1, dynamicFlagFilter == 1);
+        else Field->MarkValidSlice(last + 1);
+        slicesToUpdate -= 3;
+    }
+
+    std::vector<IlmObstruction> obstructions;
+    obstructions.reserve(Environment->Obstructions.Items.size());
+    for (const auto& o : Environment->Obstructions.Items)
+        obstructions.push_back(o->Vertex());
+    std::vector<IlmHeightVolume> volumes;
+    std::vector<float> polygon;
+    for (const HeightVolume& hv : Environment->HeightVolumes) {
+        IlmHeightVolume v;
+        std::memset(&v, 0, sizeof(v));
+        v.FirstVertex = (int32_t)(polygon.size() / 2); v.VertexCount = (int32_t)hv.Polygon.size();
+        v.ZBase = hv.ZBase; v.Height = hv.Height; v.IsDynamic = hv.IsDynamic ? 1 : 0;
+        for (const Vector2& p : hv.Polygon) { polygon.push_back(p.X); polygon.push_back(p.Y); }
+        volumes.push_back(v);
+    }
+    const IlmDistanceFieldRenderDesc desc = Field->GetRenderDesc(dynamicFlagFilter);
+    // ClearDistanceFieldSlice: the dynamic partition starts from the static texture (:117-119)
+    const IlmHandle clearSource = (ddf && dynamicFlagFilter == 1) ? ddf->StaticTexture() : 0;
+    Field->NeedClear = false;
+    ThrowIfFailed(ilm_sdf_render_slices(renderTarget, clearSource, &desc, firstSlices.data(), (int32_t)firstSlices.size(),
+                                        obstructions.empty() ? nullptr : obstructions.data(), (int32_t)obstructions.size(),
+                                        volumes.empty() ? nullptr : volumes.data(), (int32_t)volumes.size(),
+                                        polygon.empty() ? nullptr : polygon.data(), (int32_t)(polygon.size() / 2)));
+    return (int)firstSlices.size();
+}
+
+// UpdateFields, LightingRenderer.cs:1949-1975 (distance field half) + RenderDistanceField, LightingRenderer.DistanceField.cs:20-30
+int LightingRenderer::UpdateFields() {
+    if (!Field)
+        return 0;
+    AutoInvalidateDistanceField();
+    if (!Field->NeedsRasterize())
+        return 0;
+    int rendered = 0;
+    if (dynamic_cast<DynamicDistanceField*>(Field)) {
+        rendered += RenderDistanceFieldPartition(0);
+        rendered += RenderDistanceFieldPartition(1);
+    } else
+        rendered += RenderDistanceFieldPartition(-1);
+    return rendered;
 }
 
 void LightingRenderer::ReadLightmap(void* dst, int firstRow, int rowCount) const {

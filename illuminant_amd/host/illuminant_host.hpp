@@ -18,6 +18,7 @@
 // CPU before upload in the reference; here every parameter is a plain value (out of scope).
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <memory>
 #include <optional>
@@ -82,17 +83,25 @@ private:
 };
 
 // ---- SDF/DistanceField.cs ---------------------------------------------------------------------------
+// SliceInfo, :13-16
+struct SliceInfo {
+    int ValidSliceCount = 0;
+    std::vector<int> InvalidSlices;
+    bool Contains(int index) const;
+    void Remove(int index);
+};
+
 class DistanceField {
 public:
     static constexpr int MaxSurfaceSize = 8192;                    // :19
     static constexpr int DefaultMaximumEncodedDistance = 128;      // :20
     static constexpr int PackedSliceCount = 3;                     // LightingRenderer.PackedSliceCount
 
-    // ctor, :43-122 (layout math only; the atlas itself is uploaded with Load)
+    // ctor, :43-122: layout math + the atlas; every slice starts invalid (Invalidate(), :120)
     DistanceField(DeviceContext& ctx, int virtualWidth, int virtualHeight, float virtualDepth, int requestedSliceCount,
                   double requestedResolution = 1, int maximumEncodedDistance = DefaultMaximumEncodedDistance,
                   int format = ILM_SDF_UNORM16);
-    ~DistanceField();
+    virtual ~DistanceField();
     DistanceField(const DistanceField&) = delete;
 
     int VirtualWidth, VirtualHeight;
@@ -101,8 +110,10 @@ public:
     int MaximumEncodedDistance;
     int SliceWidth, SliceHeight, SliceCount, PhysicalSliceCount, ColumnCount, RowCount;
     int TextureWidth, TextureHeight;
+    int Format;
     float ZOffset = 0;
-    int ValidSliceCount = 0;   // SliceInfo.ValidSliceCount
+    bool NeedClear = true;
+    SliceInfo Slices;          // SliceInfo (:41)
 
     // :56-109 on their own (no device): what the constructor computes before it allocates the atlas
     struct Layout {
@@ -112,13 +123,48 @@ public:
     };
     static Layout ComputeLayout(int virtualWidth, int virtualHeight, int requestedSliceCount, double requestedResolution = 1);
 
+    // :125-137
+    virtual bool IsFullyGenerated() const { return (Slices.ValidSliceCount >= SliceCount) && Slices.InvalidSlices.empty(); }
+    virtual bool NeedsRasterize() const { return !Slices.InvalidSlices.empty(); }
+    // Save, :183-194: throws InvalidOperationException("The distance field must be fully valid")
+    virtual void Save(uint16_t* texels) const;
     // Load, :196-213: raw RGBA16 atlas, 8 bytes per texel; marks every slice valid
-    void Load(const uint16_t* texels);
+    virtual void Load(const uint16_t* texels);
+    // :215-231
+    virtual void Invalidate();
+    virtual void ValidateSlice(int index) { Slices.Remove(index); }
+    virtual void MarkValidSlice(int index) { Slices.ValidSliceCount = std::max(Slices.ValidSliceCount, index); }
+
     IlmHandle Texture() const { return texture; }
     // Uniforms.DistanceField ctor, Uniforms.cs:90-110
     IlmDistanceFieldUniforms GetUniforms() const;
-private:
+    // what RenderDistanceFieldSliceTriplet binds (LightingRenderer.DistanceField.cs:80-152)
+    IlmDistanceFieldRenderDesc GetRenderDesc(int dynamicFlagFilter) const;
+protected:
+    DeviceContext& context;
     IlmHandle texture = 0;
+};
+
+// DynamicDistanceField, SDF/DistanceField.cs:248-321: a static atlas for IsDynamic == false obstructions plus the
+// composite one (cleared from the static atlas, dynamic obstructions MAX-blended on top)
+class DynamicDistanceField : public DistanceField {
+public:
+    DynamicDistanceField(DeviceContext& ctx, int virtualWidth, int virtualHeight, float virtualDepth, int sliceCount,
+                         double requestedResolution = 1, int maximumEncodedDistance = DefaultMaximumEncodedDistance,
+                         int format = ILM_SDF_UNORM16);
+    ~DynamicDistanceField() override;
+    SliceInfo StaticSliceInfo;
+    IlmHandle StaticTexture() const { return staticTexture; }
+    void Invalidate() override { Invalidate(true); }
+    void Invalidate(bool invalidateStatic);
+    void ValidateSlice(int index, bool dynamic);
+    void MarkValidSlice(int index, bool dynamic);
+    void ValidateSlice(int index) override { ValidateSlice(index, false); ValidateSlice(index, true); }
+    void MarkValidSlice(int index) override { MarkValidSlice(index, false); MarkValidSlice(index, true); }
+    void Load(const uint16_t*) override { throw std::logic_error("NotImplementedException"); }    // :304-306
+    void Save(uint16_t*) const override { throw std::logic_error("NotImplementedException"); }   // :308-310
+private:
+    IlmHandle staticTexture = 0;
 };
 
 namespace Particles {
@@ -427,9 +473,63 @@ struct SphereLightSource {
     float SpecularPower = 1;
 };
 
+// LightObstruction.cs:10-140
+enum class LightObstructionType : short { Ellipsoid = 0, Box = 1, Cylinder = 2, Spheroid = 3, Octagon = 4 };
+class LightObstruction {
+public:
+    LightObstruction(LightObstructionType type, Vector3 center = {}, Vector3 radius = {}, float rotation = 0);
+    static LightObstruction Box(Vector3 center, Vector3 size, float rotation = 0) { return LightObstruction(LightObstructionType::Box, center, size, rotation); }
+    static LightObstruction Ellipsoid(Vector3 center, Vector3 size, float rotation = 0) { return LightObstruction(LightObstructionType::Ellipsoid, center, size, rotation); }
+    static LightObstruction Cylinder(Vector3 center, Vector3 size, float rotation = 0) { return LightObstruction(LightObstructionType::Cylinder, center, size, rotation); }
+    // every setter invalidates when the value changes (:38-91)
+    LightObstructionType Type() const { return type; }
+    void SetType(LightObstructionType v) { if (type != v) Invalidate(); type = v; }
+    Vector3 Center() const { return center; }
+    void SetCenter(Vector3 v) { if (v.X != center.X || v.Y != center.Y || v.Z != center.Z) Invalidate(); center = v; }
+    Vector3 Size() const { return size; }
+    void SetSize(Vector3 v) { if (v.X != size.X || v.Y != size.Y || v.Z != size.Z) Invalidate(); size = v; }
+    Vector4 Orientation() const { return orientation; }
+    void SetOrientation(Vector4 q) { if (q.X != orientation.X || q.Y != orientation.Y || q.Z != orientation.Z || q.W != orientation.W) Invalidate(); orientation = q; }
+    // Rotation setter, :94-103: Quaternion.CreateFromAxisAngle(Vector3.UnitZ, value)
+    std::optional<float> Rotation() const { return shadowRotation; }
+    void SetRotation(float value);
+    bool IsDynamic() const { return isDynamic; }
+    void SetIsDynamic(bool v) { if (isDynamic != v) HasDynamicityChanged = true; isDynamic = v; }
+    void Invalidate() { IsValid = false; }
+    bool IsValid = false, HasDynamicityChanged = true;
+    IlmObstruction Vertex() const;   // DistanceFunctionVertex (Vertices.cs:105-141) + type + dynamic flag
+private:
+    LightObstructionType type;
+    Vector3 center, size;
+    Vector4 orientation{0, 0, 0, 1};
+    std::optional<float> shadowRotation;
+    bool isDynamic = false;
+};
+
+// LightObstructionCollection, LightingEnvironment.cs:51-135
+class LightObstructionCollection {
+public:
+    bool IsInvalid = true, IsInvalidDynamic = true;
+    std::vector<std::shared_ptr<LightObstruction>> Items;
+    void Add(std::shared_ptr<LightObstruction> value) { (value->IsDynamic() ? IsInvalidDynamic : IsInvalid) = true; Items.push_back(std::move(value)); }
+    void RemoveAt(int index) { (Items.at(index)->IsDynamic() ? IsInvalidDynamic : IsInvalid) = true; Items.erase(Items.begin() + index); }
+    void Clear() { IsInvalid = true; Items.clear(); }
+    int Count() const { return (int)Items.size(); }
+};
+
+// HeightVolumeBase / SimpleHeightVolume, SDF/HeightVolume.cs:14-80 (the members the distance field pass reads)
+struct HeightVolume {
+    std::vector<Vector2> Polygon;
+    float ZBase = 0, Height = 0;
+    bool IsDynamic = true;      // :23
+    bool IsObstruction = true;
+};
+
 // LightingEnvironment.cs:13-49
 struct LightingEnvironment {
     std::vector<SphereLightSource> Lights;
+    LightObstructionCollection Obstructions;
+    std::vector<HeightVolume> HeightVolumes;
     float GroundZ = 0, MaximumZ = 128, ZToYMultiplier = 0;
     Vector4 Ambient{0, 0, 0, 1};
 };
@@ -449,6 +549,7 @@ struct RendererConfiguration {
     float LightOcclusion = 0;
     Vector2 RenderScale{1, 1};
     RendererQualitySettings DefaultQuality;
+    int MaximumFieldUpdatesPerFrame = 1;   // LightingRenderer.Configuration.cs:91
     bool FloatLightmap = false;       // extension: fp32 lightmap (parity format)
     RendererConfiguration(int w, int h) : RenderWidth(w), RenderHeight(h) {}
 };
@@ -469,6 +570,13 @@ public:
     // G-buffer: null => ground plane only
     void SetGBuffer(const void* texels, int width, int height, int format);
 
+    // InvalidateFields, :1942-1947
+    void InvalidateFields(bool invalidateDistanceField = true) { if (invalidateDistanceField && Field) Field->Invalidate(); }
+    // UpdateFields, :1949-1975 (distance field half): AutoInvalidateDistanceField (:1977-2014), then at most
+    // MaximumFieldUpdatesPerFrame slices of RenderDistanceField (LightingRenderer.DistanceField.cs:20-30,415-464).
+    // Returns the number of slice triplets rendered.
+    int UpdateFields();
+
     // RenderLighting, :917-1191: clears to Ambient * intensityScale and adds every sphere light.
     // [rowBegin, rowEnd) restricts the pass to a screen strip (multi-GPU split); rowEnd < 0 => whole frame.
     void RenderLighting(float intensityScale = 1.0f, int rowBegin = 0, int rowEnd = -1, IlmRenderStats* stats = nullptr);
@@ -485,6 +593,8 @@ public:
     IlmEnvironment GetEnvironmentUniforms() const;
 
 private:
+    void AutoInvalidateDistanceField();
+    int RenderDistanceFieldPartition(int dynamicFlagFilter /* -1 = null */);
     IlmHandle lightmap = 0, gbuffer = 0;
     int lightmapFormat = ILM_LIGHTMAP_HALF4;
     int gbufferWidth = 0, gbufferHeight = 0;

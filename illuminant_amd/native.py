@@ -64,6 +64,9 @@ SYMBOLS = {
     "ilm_sdf_upload": (_I, [_H, _P]),
     "ilm_sdf_sample": (_I, [_H, _P, _P, _I, _P]),
     "ilm_sdf_destroy": (_I, [_H]),
+    "ilm_sdf_download": (_I, [_H, _P]),
+    "ilm_sdf_device_ptr": (_I, [_H, C.POINTER(_P)]),
+    "ilm_sdf_render_slices": (_I, [_H, _H, _P, _P, _I, _P, _I, _P, _I, _P, _I]),
     "ilm_gbuffer_create": (_I, [_H, _I, _I, _I, C.POINTER(_H)]),
     "ilm_gbuffer_upload": (_I, [_H, _P]),
     "ilm_gbuffer_destroy": (_I, [_H]),
@@ -263,15 +266,38 @@ class System:
 class DistanceFieldTexture:
     """ilm_sdf_*: the RGBA16 atlas on the device."""
 
-    def __init__(self, ctx, texels, fmt=abi.SDF_UNORM16):
-        a = np.ascontiguousarray(texels, dtype=np.uint16)
-        assert a.ndim == 3 and a.shape[2] == 4
+    def __init__(self, ctx, texels=None, fmt=abi.SDF_UNORM16, size=None):
+        """texels: (H, W, 4) uint16 atlas to upload, or None with size=(width, height) for an empty (zeroed) atlas."""
         self.ctx = ctx
-        self.height, self.width = a.shape[0], a.shape[1]
         self.format = fmt
         self.handle = abi.Handle(0)
+        if texels is None:
+            self.width, self.height = int(size[0]), int(size[1])
+            check(lib().ilm_sdf_create(ctx.handle, self.width, self.height, fmt, C.byref(self.handle)))
+            return
+        a = np.ascontiguousarray(texels, dtype=np.uint16)
+        assert a.ndim == 3 and a.shape[2] == 4
+        self.height, self.width = a.shape[0], a.shape[1]
         check(lib().ilm_sdf_create(ctx.handle, self.width, self.height, fmt, C.byref(self.handle)))
         check(lib().ilm_sdf_upload(self.handle, _ptr(a)))
+
+    def download(self):
+        """ilm_sdf_download: the atlas as (H, W, 4) uint16."""
+        out = np.empty((self.height, self.width, 4), dtype=np.uint16)
+        check(lib().ilm_sdf_download(self.handle, _ptr(out)))
+        return out
+
+    def render_slices(self, desc, first_virtual_slices, obstructions=None, volumes=None, polygon_xy=None, clear_source=None):
+        """ilm_sdf_render_slices.  obstructions / volumes: ctypes arrays of abi.Obstruction / abi.HeightVolume (or None);
+        polygon_xy: (n, 2) float32."""
+        sl = np.ascontiguousarray(first_virtual_slices, dtype=np.int32)
+        no = len(obstructions) if obstructions is not None else 0
+        nv = len(volumes) if volumes is not None else 0
+        poly = np.ascontiguousarray(polygon_xy, dtype=np.float32).reshape(-1, 2) if polygon_xy is not None else np.zeros((0, 2), np.float32)
+        check(lib().ilm_sdf_render_slices(
+            self.handle, clear_source.handle if clear_source is not None else abi.Handle(0), _byref(desc),
+            _ptr(sl), sl.shape[0], C.cast(obstructions, C.c_void_p) if no else None, no,
+            C.cast(volumes, C.c_void_p) if nv else None, nv, _ptr(poly) if poly.shape[0] else None, poly.shape[0]))
 
     def sample(self, df, positions):
         """ilm_sdf_sample: distances at (n, 3) float32 world positions."""

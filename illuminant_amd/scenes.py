@@ -299,11 +299,13 @@ def build_sdf_atlas(layout, obstacles, z_offset=0.0, fmt=abi.SDF_UNORM16):
         oy = (p // L.column_count) * L.slice_height
         zs = [L.slice_index_to_z(3 * p + c, z_offset) for c in range(4)]
         for (typ, center, size) in obstacles:
+            # DistanceFunctionVertexShader's quad (DistanceFunction.fx:16-26): half-size max|size| + maxDistance + 4 around the
+            # centre; texel i is covered iff its centre i + 0.5 lies in [left, right) (in slice pixels)
             reach = max(size) + maxd + 4
-            x0 = max(int(math.floor((center[0] - reach) / sx)), 0)
-            x1 = min(int(math.ceil((center[0] + reach) / sx)) + 1, L.slice_width)
-            y0 = max(int(math.floor((center[1] - reach) / sy)), 0)
-            y1 = min(int(math.ceil((center[1] + reach) / sy)) + 1, L.slice_height)
+            x0 = max(int(math.ceil((center[0] - reach) / sx - 0.5)), 0)
+            x1 = min(int(math.ceil((center[0] + reach) / sx - 0.5)), L.slice_width)
+            y0 = max(int(math.ceil((center[1] - reach) / sy - 0.5)), 0)
+            y1 = min(int(math.ceil((center[1] + reach) / sy - 0.5)), L.slice_height)
             if x0 >= x1 or y0 >= y1:
                 continue
             wx = (np.arange(x0, x1, dtype=np.float32) * np.float32(sx))[None, :] - np.float32(center[0])
@@ -317,6 +319,72 @@ def build_sdf_atlas(layout, obstacles, z_offset=0.0, fmt=abi.SDF_UNORM16):
     if fmt == abi.SDF_FP16:
         return enc.astype(np.float16).view(np.uint16)
     return np.rint(enc * 65535.0).astype(np.uint16)
+
+
+def render_desc(layout, z_offset=0.0, dynamic_flag_filter=-1):
+    """IlmDistanceFieldRenderDesc of a layout: what RenderDistanceFieldSliceTriplet binds
+    (LightingRenderer.DistanceField.cs:80-152; inverse scale factors as in Uniforms.cs:108-109)."""
+    d = abi.DistanceFieldRenderDesc()
+    d.VirtualWidth, d.VirtualHeight, d.VirtualDepth, d.ZOffset = layout.virtual_width, layout.virtual_height, layout.virtual_depth, z_offset
+    d.SliceWidth, d.SliceHeight, d.SliceCount = layout.slice_width, layout.slice_height, layout.slice_count
+    d.ColumnCount, d.RowCount = layout.column_count, layout.row_count
+    d.MaximumEncodedDistance = float(layout.maximum_encoded_distance)
+    d.InvScaleFactorX = float(np.float32(layout.virtual_width / layout.slice_width))
+    d.InvScaleFactorY = float(np.float32(layout.virtual_height / layout.slice_height))
+    d.DynamicFlagFilter = dynamic_flag_filter
+    return d
+
+
+def obstruction_array(obstacles):
+    """[(LightObstructionType 0..4, center xyz, size xyz[, rotation about z in radians[, is_dynamic]])] ->
+    ctypes array of abi.Obstruction; Orientation = Quaternion.CreateFromAxisAngle(UnitZ, rotation)
+    (LightObstruction.Rotation setter, LightObstruction.cs:94-103)."""
+    arr = (abi.Obstruction * len(obstacles))()
+    for i, ob in enumerate(obstacles):
+        typ, center, size = ob[0], ob[1], ob[2]
+        rot = float(ob[3]) if len(ob) > 3 else 0.0
+        o = arr[i]
+        o.Type = int(typ)
+        o.IsDynamic = int(bool(ob[4])) if len(ob) > 4 else 0
+        for k in range(3):
+            o.Center[k] = float(center[k])
+            o.Size[k] = float(size[k])
+        half = np.float32(rot) * np.float32(0.5)
+        o.Orientation[0] = 0.0
+        o.Orientation[1] = 0.0
+        o.Orientation[2] = float(np.float32(math.sin(float(half))))
+        o.Orientation[3] = float(np.float32(math.cos(float(half))))
+    return arr
+
+
+def height_volume_arrays(volumes):
+    """[(polygon [(x, y), ...], z_base, height[, is_dynamic])] -> (ctypes array of abi.HeightVolume, (n, 2) float32 vertices)."""
+    arr = (abi.HeightVolume * len(volumes))()
+    verts = []
+    for i, hv in enumerate(volumes):
+        poly = hv[0]
+        arr[i].FirstVertex, arr[i].VertexCount = len(verts), len(poly)
+        arr[i].ZBase, arr[i].Height = float(hv[1]), float(hv[2])
+        arr[i].IsDynamic = int(bool(hv[3])) if len(hv) > 3 else 1     # HeightVolumeBase.IsDynamic defaults to true, HeightVolume.cs:23
+        verts.extend((float(x), float(y)) for (x, y) in poly)
+    return arr, np.asarray(verts, dtype=np.float32).reshape(-1, 2)
+
+
+def random_obstructions(seed, n, extent, size_lo=12.0, size_hi=70.0, z_hi=64.0, types=(0, 1, 2, 3, 4), rotate=True, dynamic_fraction=0.0):
+    """n random LightObstructions of every type with rotations, for obstruction_array()."""
+    cx = uniform(seed + 1, (n,), 0, extent[0])
+    cy = uniform(seed + 2, (n,), 0, extent[1])
+    cz = uniform(seed + 5, (n,), 0, z_hi * 0.5)
+    sz = uniform(seed + 3, (n, 3), size_lo, size_hi)
+    ty = uniform(seed + 4, (n,))
+    ro = uniform(seed + 6, (n,), -math.pi, math.pi)
+    dy = uniform(seed + 7, (n,))
+    out = []
+    for i in range(n):
+        t = types[min(int(ty[i] * len(types)), len(types) - 1)]
+        out.append((t, (float(cx[i]), float(cy[i]), float(cz[i])), (float(sz[i, 0]), float(sz[i, 1]), float(min(sz[i, 2], z_hi))),
+                    float(ro[i]) if rotate else 0.0, bool(dy[i] < dynamic_fraction)))
+    return out
 
 
 def random_obstacles(seed, n, extent, size_lo=12.0, size_hi=70.0, z_hi=64.0):

@@ -373,6 +373,63 @@ int32_t ilm_sdf_upload(IlmHandle sdf, const uint16_t* texels);
  * host (or a test) can query the field the kernels see. */
 int32_t ilm_sdf_sample(IlmHandle sdf, const IlmDistanceFieldUniforms* df, const float* positions, int32_t count, float* out_distances);
 int32_t ilm_sdf_destroy(IlmHandle sdf);
+/* DistanceField.Save (Illuminant/SDF/DistanceField.cs:178-194): the atlas bytes, 8 per texel, row-major. */
+int32_t ilm_sdf_download(IlmHandle sdf, uint16_t* texels);
+int32_t ilm_sdf_device_ptr(IlmHandle sdf, void** out_ptr);
+
+/* ---- distance field generation ------------------------------ */
+
+/* LightObstruction (Illuminant/Lighting/LightObstruction.cs:10-140): the DistanceFunctionVertex it packs
+ * (Center, Size, Orientation quaternion -- Illuminant/Vertices.cs:105-141) + Type + IsDynamic. */
+enum {
+    ILM_OBSTRUCTION_ELLIPSOID = 0, ILM_OBSTRUCTION_BOX = 1, ILM_OBSTRUCTION_CYLINDER = 2,
+    ILM_OBSTRUCTION_SPHEROID = 3, ILM_OBSTRUCTION_OCTAGON = 4
+};
+typedef struct IlmObstruction {
+    float   Center[3];      int32_t Type;        /* LightObstructionType */
+    float   Size[3];        int32_t IsDynamic;
+    float   Orientation[4];                      /* quaternion x, y, z, w */
+} IlmObstruction;
+
+/* HeightVolumeBase (Illuminant/SDF/HeightVolume.cs:14-80) as RenderDistanceFieldHeightVolumes consumes it
+ * (Illuminant/Lighting/LightingRenderer.DistanceField.cs:185-266): a polygon (a vertex range in the shared
+ * xy array handed to the call) extruded over [ZBase, ZBase + Height]. */
+typedef struct IlmHeightVolume {
+    int32_t FirstVertex, VertexCount;
+    float   ZBase, Height;
+    int32_t IsDynamic;
+    int32_t _pad[3];
+} IlmHeightVolume;
+
+#define ILM_DISTANCE_LIMIT 520.0f   /* LightingRenderer.DistanceLimit, Illuminant/Lighting/LightingRenderer.cs:316 */
+
+/* What RenderDistanceFieldSliceTriplet binds for a group of slice triplets
+ * (Illuminant/Lighting/LightingRenderer.DistanceField.cs:80-152): the atlas layout of the DistanceField
+ * constructor (Illuminant/SDF/DistanceField.cs:43-122) and SliceIndexToZ's inputs (:32-35). */
+typedef struct IlmDistanceFieldRenderDesc {
+    int32_t VirtualWidth, VirtualHeight;
+    float   VirtualDepth, ZOffset;
+    int32_t SliceWidth, SliceHeight, SliceCount, ColumnCount;
+    int32_t RowCount;
+    float   MaximumEncodedDistance;
+    float   InvScaleFactorX, InvScaleFactorY;    /* VirtualWidth / SliceWidth, VirtualHeight / SliceHeight (Uniforms.cs:108-109) */
+    int32_t DynamicFlagFilter;                   /* -1: every obstruction (plain DistanceField); 0: static only; 1: dynamic only */
+    int32_t _pad[3];
+} IlmDistanceFieldRenderDesc;
+
+/* RenderDistanceFieldPartition's inner loop (LightingRenderer.DistanceField.cs:415-464) for `triplet_count` slice
+ * triplets at once: for each first virtual slice s = first_virtual_slices[i] (a multiple of 3) the physical slice
+ * s / 3 is cleared -- to zero, or to the texels of `clear_source` (the DynamicDistanceField's static texture,
+ * ClearDistanceField.fx:30-44) -- and every obstruction / height volume passing the dynamic-flag filter is
+ * rasterised into it with the analytic distance functions of DistanceFunction.fx:33-115 (quad of half-size
+ * max|Size| + MaximumEncodedDistance + 4, :24-25) / DistanceField.fx:75-115, encoded (DistanceFieldCommon.fxh:264-266)
+ * and MAX-blended (LoadMaterials.cs:164-176); texel RGBA = virtual slices s .. s+3.
+ * `obstructions`, `volumes`, `polygon_xy` (x,y pairs) and `first_virtual_slices` are host arrays.  Asynchronous. */
+int32_t ilm_sdf_render_slices(IlmHandle sdf, IlmHandle clear_source, const IlmDistanceFieldRenderDesc* desc,
+                              const int32_t* first_virtual_slices, int32_t triplet_count,
+                              const IlmObstruction* obstructions, int32_t obstruction_count,
+                              const IlmHeightVolume* volumes, int32_t volume_count,
+                              const float* polygon_xy, int32_t polygon_vertex_count);
 
 /* G-buffer (Illuminant/GBuffer.cs): width x height texels (encNormal.xy, relativeY, encodedZ). */
 int32_t ilm_gbuffer_create(IlmHandle ctx, int32_t width, int32_t height, int32_t format, IlmHandle* out_gbuffer);

@@ -1408,6 +1408,8 @@ void orc_spawner_end_tick(OrcSpawnerState* s, int32_t requested, int32_t actual)
     s->total_spawned += actual;
 }
 
+#include "ilm_oracle_fields.c"
+
 void orc_set_num_threads(int32_t n) {
 #ifdef _OPENMP
     if (n > 0) omp_set_num_threads(n);

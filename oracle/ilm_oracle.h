@@ -104,6 +104,15 @@ int32_t orc_spawner_begin_tick(OrcSpawnerState* s, float min_rate, float max_rat
                                double rng_draw, double delta_time_seconds, int32_t maximum_total /* <0 => none */);
 void    orc_spawner_end_tick(OrcSpawnerState* s, int32_t requested, int32_t actual);
 
+/* distance-field generation, ilm_oracle_fields.c: renders the listed slice triplets into `atlas`
+ * (RGBA16 texels of SliceWidth*ColumnCount x SliceHeight*RowCount); clear_source may be NULL */
+void orc_render_distance_field_slices(uint16_t* atlas, int32_t format, const uint16_t* clear_source,
+                                      const IlmDistanceFieldRenderDesc* desc,
+                                      const int32_t* first_virtual_slices, int32_t triplet_count,
+                                      const IlmObstruction* obstructions, int32_t obstruction_count,
+                                      const IlmHeightVolume* volumes, int32_t volume_count,
+                                      const float* polygon_xy, int32_t polygon_vertex_count);
+
 int32_t orc_num_threads(void);
 void    orc_set_num_threads(int32_t n);
 

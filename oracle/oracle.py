@@ -21,7 +21,7 @@ def build(force=False):
     """Compile the C restatement with gcc (oracle/Makefile)."""
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-            for f in ("ilm_oracle.c", "ilm_oracle.h")):
+            for f in ("ilm_oracle.c", "ilm_oracle_fields.c", "ilm_oracle.h")):
         subprocess.run(["make", "-C", _HERE, "-s"], check=True)
     return _LIB_PATH
 
@@ -208,6 +208,22 @@ def render_sphere_lights(lights, env, df, gbuffer, sdf, ambient, width, height, 
                                    amb, _f4(out), width, height, row_begin, row_end,
                                    C.byref(stats) if stats is not None else None)
     return out, stats
+
+
+def render_distance_field_slices(atlas, fmt, desc, first_virtual_slices, obstructions=None, volumes=None, polygon_xy=None,
+                                 clear_source=None):
+    """orc_render_distance_field_slices: renders the listed slice triplets into `atlas` ((H, W, 4) uint16, in place)."""
+    assert atlas.dtype == np.uint16 and atlas.flags["C_CONTIGUOUS"] and atlas.shape[2] == 4
+    sl = np.ascontiguousarray(first_virtual_slices, dtype=np.int32)
+    no = len(obstructions) if obstructions is not None else 0
+    nv = len(volumes) if volumes is not None else 0
+    poly = np.ascontiguousarray(polygon_xy, dtype=np.float32).reshape(-1, 2) if polygon_xy is not None else np.zeros((0, 2), np.float32)
+    if clear_source is not None:
+        assert clear_source.dtype == np.uint16 and clear_source.shape == atlas.shape and clear_source.flags["C_CONTIGUOUS"]
+    lib().orc_render_distance_field_slices(_p(atlas), C.c_int32(fmt), _p(clear_source), C.byref(desc), _p(sl), C.c_int32(sl.shape[0]),
+                                           obstructions if no else None, C.c_int32(no), volumes if nv else None, C.c_int32(nv),
+                                           _p(poly) if poly.shape[0] else None, C.c_int32(poly.shape[0]))
+    return atlas
 
 
 # ---- host logic -------------------------------------------------------------------------------------

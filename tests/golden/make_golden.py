@@ -394,8 +394,72 @@ def gen_closed_form():
     return {"source": "hand-derived from the cited HLSL lines (see comments in make_golden.py)", "tolerance": "1e-5 relative", "cases": cases}
 
 
+# ---------------------------------------------------------------------------------------------------------
+# 8. Distance-field generation: closed-form stored codes of single obstructions / height volumes,
+#    derived by hand from DistanceFunctionCommon.fxh:48-124, DistanceField.fx:47-73 (finalEval, PolygonXyBias 1.5),
+#    encodeDistance (DistanceFieldCommon.fxh:264-266), SliceIndexToZ (LightingRenderer.DistanceField.cs:32-35) and the
+#    unorm16 render-target write.  Evaluated in float64; the oracle / HIP path must hit the code within +-1.
+# ---------------------------------------------------------------------------------------------------------
+def gen_distance_field_generation():
+    vw, vh, depth, slices, max_enc = 128, 128, 64.0, 9, 128.0     # resolution 1: texel (x, y) of a slice is world (x, y)
+
+    def code(distance):
+        enc = 192.0 / 255.0 - distance / max_enc
+        return int(math.floor(min(max(enc, 0.0), 1.0) * 65535.0 + 0.5))
+
+    def slice_z(k):
+        return k / float(slices) * depth
+
+    cases = []
+    # (a) axis-aligned box, centre (64,64,0) half-size (16,16,32): outside along x the distance is x - 64 - 16
+    #     (z = 0 and y = 64 are inside); inside, max(dx, dy, dz) = -16 at the centre column of slice 0
+    box = {"type": 1, "center": [64.0, 64.0, 0.0], "size": [16.0, 16.0, 32.0], "rotation": 0.0}
+    cases.append({"kind": "obstruction", "obstruction": box, "texel": [100, 64], "slice": 0, "expected_code": code(20.0), "distance": 20.0})
+    cases.append({"kind": "obstruction", "obstruction": box, "texel": [64, 64], "slice": 0, "expected_code": code(-16.0), "distance": -16.0})
+    #     slice 6 is z = 6/9*64 = 42.667: above the box top (32) by 10.667, laterally inside
+    cases.append({"kind": "obstruction", "obstruction": box, "texel": [64, 64], "slice": 6, "expected_code": code(slice_z(6) - 32.0), "distance": slice_z(6) - 32.0})
+    #     corner: outside in x by 12 and in y by 5 at z = 0 -> length((12,5,0)) = 13
+    cases.append({"kind": "obstruction", "obstruction": box, "texel": [92, 85], "slice": 0, "expected_code": code(13.0), "distance": 13.0})
+    # (b) sphere as a Spheroid of equal radii 10 at (40,50,0): |p - c| - r; texel (46,58) slice 0 -> 10 - 10 = 0 -> DISTANCE_ZERO
+    sph = {"type": 3, "center": [40.0, 50.0, 0.0], "size": [10.0, 10.0, 10.0], "rotation": 0.0}
+    cases.append({"kind": "obstruction", "obstruction": sph, "texel": [46, 58], "slice": 0, "expected_code": code(0.0), "distance": 0.0})
+    cases.append({"kind": "obstruction", "obstruction": sph, "texel": [70, 90], "slice": 0, "expected_code": code(40.0), "distance": 40.0})
+    #     slice 3 (z = 21.333) straight above the centre: 21.333 - 10
+    cases.append({"kind": "obstruction", "obstruction": sph, "texel": [40, 50], "slice": 3, "expected_code": code(slice_z(3) - 10.0), "distance": slice_z(3) - 10.0})
+    # (c) ellipsoid (improvedV2), inside branch (k0 < 1): (k0 - 1) * min(r); centre (64,64,0) radii (40,20,30), texel (84,64): k0 = .5
+    ell = {"type": 0, "center": [64.0, 64.0, 0.0], "size": [40.0, 20.0, 30.0], "rotation": 0.0}
+    cases.append({"kind": "obstruction", "obstruction": ell, "texel": [84, 64], "slice": 0, "expected_code": code(-10.0), "distance": -10.0})
+    #     outside on the x axis: k0 = x/rx, k1 = x/rx^2 -> k0 (k0 - 1) / k1 = (k0 - 1) rx = x - rx; texel (124,64): 60 - 40 = 20
+    cases.append({"kind": "obstruction", "obstruction": ell, "texel": [124, 64], "slice": 0, "expected_code": code(20.0), "distance": 20.0})
+    # (d) cylinder: radius = length(size.xy) = 5 for size (3,4,h) (DistanceFunctionCommon.fxh:122); texel 20 px off-axis, z inside
+    cyl = {"type": 2, "center": [30.0, 30.0, 0.0], "size": [3.0, 4.0, 48.0], "rotation": 0.0}
+    cases.append({"kind": "obstruction", "obstruction": cyl, "texel": [50, 30], "slice": 0, "expected_code": code(15.0), "distance": 15.0})
+    # (e) a box rotated by 90 degrees about z swaps its x / y half-sizes: half-size (30,6,32) rotated -> (6,30) footprint
+    rbox = {"type": 1, "center": [64.0, 64.0, 0.0], "size": [30.0, 6.0, 32.0], "rotation": math.pi / 2}
+    cases.append({"kind": "obstruction", "obstruction": rbox, "texel": [80, 64], "slice": 0, "expected_code": code(10.0), "distance": 10.0})
+    cases.append({"kind": "obstruction", "obstruction": rbox, "texel": [64, 104], "slice": 0, "expected_code": code(10.0), "distance": 10.0})
+    # (f) far texel: encoded distance < 0 saturates to code 0 at the render target
+    cases.append({"kind": "obstruction", "obstruction": cyl, "texel": [127, 127], "slice": 0, "expected_code": 0, "distance": math.hypot(97, 97) - 5.0})
+    # (g) height volume: square (32,32)-(96,96) over z in [0, 20].  finalEval: inside on xy and z -> (d_xy + 1.5) + d_z
+    sq = {"polygon": [[32.0, 32.0], [96.0, 32.0], [96.0, 96.0], [32.0, 96.0]], "z_base": 0.0, "height": 20.0}
+    zz = slice_z(1)     # 7.111: inside [0, 20]; distanceZ = max(z - 20, 0 - z) = -7.111
+    cases.append({"kind": "height_volume", "volume": sq, "texel": [64, 64], "slice": 1, "expected_code": code((-32.0 + 1.5) + max(zz - 20.0, -zz)),
+                  "distance": (-32.0 + 1.5) + max(zz - 20.0, -zz)})
+    #     outside on xy by 24 (+1.5 bias), z inside -> 25.5 + max(dz, 0) = 25.5
+    cases.append({"kind": "height_volume", "volume": sq, "texel": [120, 64], "slice": 1, "expected_code": code(25.5), "distance": 25.5})
+    #     inside on xy, above the top: slice 6 z = 42.667 -> just the z distance 22.667
+    cases.append({"kind": "height_volume", "volume": sq, "texel": [64, 64], "slice": 6, "expected_code": code(slice_z(6) - 20.0), "distance": slice_z(6) - 20.0})
+    #     outside on both: 25.5 + 22.667
+    cases.append({"kind": "height_volume", "volume": sq, "texel": [120, 64], "slice": 6, "expected_code": code(25.5 + slice_z(6) - 20.0), "distance": 25.5 + slice_z(6) - 20.0})
+    return {"source": "hand-derived from DistanceFunctionCommon.fxh:48-124, DistanceField.fx:47-73, DistanceFieldCommon.fxh:264-266, "
+                      "LightingRenderer.DistanceField.cs:32-35 (see comments in make_golden.py)",
+            "field": {"virtual_width": vw, "virtual_height": vh, "virtual_depth": depth, "requested_slices": slices, "resolution": 1.0,
+                      "maximum_encoded_distance": max_enc},
+            "tolerance": "+-1 unorm16 code (1.5e-5 of the encoded range, 0.002 world units)", "cases": cases}
+
+
 def main():
-    out = {"bezier.json": gen_bezier(), "distance_field_layout.json": gen_layout(), "spawner.json": gen_spawner(),
+    out = {"distance_field_generation.json": gen_distance_field_generation(), "bezier.json": gen_bezier(), "distance_field_layout.json": gen_layout(), "spawner.json": gen_spawner(),
            "liveness.json": gen_liveness(), "distance_encoding.json": gen_encoding(), "gbuffer.json": gen_gbuffer(),
            "closed_form.json": gen_closed_form()}
     for name, doc in out.items():

@@ -1,0 +1,115 @@
+"""Pins the oracle's distance-field generation (oracle/ilm_oracle_fields.c) without a GPU:
+closed-form fixture codes, an independent numpy rasteriser, and the pass's structural properties."""
+import numpy as np
+import pytest
+
+from illuminant_amd import abi, scenes
+from tests import fields_common as fc
+
+
+def render_oracle(oracle, layout, obs=None, vols=None, poly=None, slices=None, fmt=abi.SDF_UNORM16, flt=-1, clear_source=None, atlas=None):
+    if atlas is None:
+        atlas = np.zeros((layout.atlas_height, layout.atlas_width, 4), np.uint16)
+    d = scenes.render_desc(layout, dynamic_flag_filter=flt)
+    return oracle.render_distance_field_slices(atlas, fmt, d, fc.all_triplets(layout) if slices is None else slices, obs, vols, poly,
+                                               clear_source=clear_source)
+
+
+def test_closed_form_codes(oracle):
+    doc = fc.load_generation_fixture()
+    layout = fc.fixture_layout(doc)
+    assert (layout.slice_width, layout.slice_height, layout.slice_count) == (128, 128, 9)
+    for case in doc["cases"]:
+        obs, vols, poly = fc.fixture_case_inputs(case)
+        atlas = render_oracle(oracle, layout, obs, vols, poly)
+        got = fc.texel_of(atlas, layout, case["texel"][0], case["texel"][1], case["slice"])
+        assert abs(got - case["expected_code"]) <= 1, (case, got)
+
+
+def test_matches_independent_numpy_rasteriser(oracle):
+    """scenes.build_sdf_atlas (float64 numpy, written for the lighting tests) rasterises unrotated ellipsoids, boxes and
+    cylinders on its own; the two agree to one code."""
+    layout = scenes.DistanceFieldLayout(256, 192, 96.0, 12, 0.5, 128)
+    old = scenes.random_obstacles(5, 14, (256, 192), size_lo=8.0, size_hi=30.0, z_hi=40.0)
+    want = scenes.build_sdf_atlas(layout, old)
+    got = render_oracle(oracle, layout, scenes.obstruction_array([(t - 1, c, s) for (t, c, s) in old]))
+    diff = np.abs(got.astype(np.int64) - want.astype(np.int64))
+    assert diff.max() <= 1, int(diff.max())
+    assert (want > 0).mean() > 0.3
+
+
+def test_alpha_of_slice_is_red_of_next(oracle):
+    """A texel's RGBA holds virtual slices 3p..3p+3, so A of physical slice p == R of p+1 (SliceZ, DistanceFunction.fx:14)."""
+    layout, obs, volumes = fc.mixed_scene()
+    vols, poly = scenes.height_volume_arrays(volumes)
+    atlas = render_oracle(oracle, layout, scenes.obstruction_array(obs), vols, poly)
+    L = layout
+    for p in range(L.physical_slice_count - 1):
+        a = atlas[(p // L.column_count) * L.slice_height:(p // L.column_count + 1) * L.slice_height,
+                  (p % L.column_count) * L.slice_width:(p % L.column_count + 1) * L.slice_width, 3]
+        q = p + 1
+        r = atlas[(q // L.column_count) * L.slice_height:(q // L.column_count + 1) * L.slice_height,
+                  (q % L.column_count) * L.slice_width:(q % L.column_count + 1) * L.slice_width, 0]
+        assert np.array_equal(a, r)
+
+
+def test_max_blend_is_order_free_and_monotone(oracle):
+    layout, obs, volumes = fc.mixed_scene()
+    vols, poly = scenes.height_volume_arrays(volumes)
+    full = render_oracle(oracle, layout, scenes.obstruction_array(obs), vols, poly)
+    rev = render_oracle(oracle, layout, scenes.obstruction_array(obs[::-1]), vols, poly)
+    assert np.array_equal(full, rev)
+    fewer = render_oracle(oracle, layout, scenes.obstruction_array(obs[:10]))
+    assert (full >= fewer).all() and (full > fewer).any()
+    # per-obstruction renders MAX-combined == one render of all (BlendFunction.Max, LoadMaterials.cs:164-176)
+    acc = render_oracle(oracle, layout, None, vols, poly)
+    for o in obs:
+        acc = np.maximum(acc, render_oracle(oracle, layout, scenes.obstruction_array([o])))
+    assert np.array_equal(acc, full)
+
+
+def test_partial_update_touches_only_the_listed_triplets(oracle):
+    layout, obs, _ = fc.mixed_scene()
+    arr = scenes.obstruction_array(obs)
+    full = render_oracle(oracle, layout, arr)
+    sentinel = np.full_like(full, 7)
+    part = render_oracle(oracle, layout, arr, slices=[3], atlas=sentinel.copy())
+    L = layout
+    p = 1
+    ys = slice((p // L.column_count) * L.slice_height, (p // L.column_count + 1) * L.slice_height)
+    xs = slice((p % L.column_count) * L.slice_width, (p % L.column_count + 1) * L.slice_width)
+    assert np.array_equal(part[ys, xs], full[ys, xs])
+    mask = np.ones(full.shape[:2], bool)
+    mask[ys, xs] = False
+    assert (part[mask] == 7).all()
+
+
+def test_dynamic_field_is_static_clear_plus_dynamic_obstructions(oracle):
+    """DynamicDistanceField: the static partition renders IsDynamic == false, the dynamic one clears each slice to the
+    static texture and MAX-blends IsDynamic == true on top (LightingRenderer.DistanceField.cs:20-30,117-119)."""
+    layout, obs, volumes = fc.mixed_scene(dynamic_fraction=0.4)
+    vols, poly = scenes.height_volume_arrays(volumes)
+    arr = scenes.obstruction_array(obs)
+    assert 0 < sum(1 for o in obs if o[4]) < len(obs)
+    static = render_oracle(oracle, layout, arr, vols, poly, flt=0)
+    dynamic = render_oracle(oracle, layout, arr, vols, poly, flt=1, clear_source=static)
+    everything = render_oracle(oracle, layout, arr, vols, poly, flt=-1)
+    assert np.array_equal(dynamic, everything)
+    assert (static < everything).any()
+
+
+@pytest.mark.parametrize("fmt", [abi.SDF_UNORM16, abi.SDF_FP16])
+def test_generated_field_samples_back_the_analytic_distance(oracle, fmt):
+    """encode -> store -> sampleDistanceFieldEx round trip: the sampled distance of a generated sphere field is the analytic one
+    (within the quantisation of the format and the bilinear / slice interpolation of a curved function)."""
+    layout = scenes.DistanceFieldLayout(128, 128, 64.0, 16, 1.0, 128)
+    sph = [(abi.OBSTRUCTION_SPHEROID, (64.0, 64.0, 20.0), (18.0, 18.0, 18.0), 0.0)]
+    atlas = render_oracle(oracle, layout, scenes.obstruction_array(sph), fmt=fmt)
+    tex = oracle.make_texture(atlas, fmt)
+    dfu = layout.uniforms()
+    pts = scenes.uniform(3, (200, 3), 0.0, 1.0) * np.array([127.0, 127.0, 50.0], np.float32)
+    for p in pts:
+        want = float(np.linalg.norm(p - np.array([64.0, 64.0, 20.0]))) - 18.0
+        got = oracle.sample_distance_field(p, dfu, tex)
+        if want < 90.0:     # beyond ~96 the encoding saturates
+            assert abs(got - want) < (1.2 if fmt == abi.SDF_UNORM16 else 1.6), (p, got, want)

@@ -1,0 +1,155 @@
+"""LightingRenderer.UpdateFields on the host mirror (illuminant_amd/host): LightObstruction / HeightVolume lists, incremental slice
+updates, invalidation and the static / dynamic partitions of a DynamicDistanceField, checked against the oracle's render of the
+same obstructions."""
+import numpy as np
+import pytest
+
+from illuminant_amd import abi, scenes
+from tests import fields_common as fc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def H():
+    from illuminant_amd import _host
+    return _host
+
+
+@pytest.fixture(scope="module")
+def hctx(H):
+    return H.DeviceContext(0)
+
+
+def build(H, hctx, field_cls, obs, volumes, layout_args=(256, 192, 96.0, 12, 0.5), updates_per_frame=1):
+    env = H.LightingEnvironment()
+    items = []
+    for (t, c, s, rot, dyn) in obs:
+        o = H.LightObstruction(t, list(c), list(s), rot)
+        o.IsDynamic = dyn
+        env.Obstructions.Add(o)
+        items.append(o)
+    hvs = []
+    for (poly, zb, h, dyn) in volumes:
+        hv = H.HeightVolume()
+        hv.Polygon = [list(p) for p in poly]
+        hv.ZBase, hv.Height, hv.IsDynamic = zb, h, dyn
+        hvs.append(hv)
+    env.HeightVolumes = hvs
+    rc = H.RendererConfiguration(64, 48)
+    rc.MaximumFieldUpdatesPerFrame = updates_per_frame
+    r = H.LightingRenderer(hctx, rc, env)
+    f = field_cls(hctx, *layout_args)
+    r.DistanceField = f
+    return env, r, f, items
+
+
+def oracle_atlas(oracle, layout, obs, volumes, flt=-1, clear_source=None):
+    vols, poly = scenes.height_volume_arrays(volumes)
+    atlas = np.zeros((layout.atlas_height, layout.atlas_width, 4), np.uint16)
+    return oracle.render_distance_field_slices(atlas, abi.SDF_UNORM16, scenes.render_desc(layout, dynamic_flag_filter=flt),
+                                               fc.all_triplets(layout), scenes.obstruction_array(obs), vols, poly, clear_source=clear_source)
+
+
+def test_obstruction_vertex_packing(H):
+    o = H.LightObstruction(abi.OBSTRUCTION_BOX, [1, 2, 3], [4, 5, 6], 0.7)
+    got = abi.Obstruction.from_buffer_copy(o.VertexBytes())
+    want = scenes.obstruction_array([(abi.OBSTRUCTION_BOX, (1, 2, 3), (4, 5, 6), 0.7)])[0]
+    assert bytes(got) == bytes(want)
+
+
+def test_incremental_update_one_triplet_per_frame(H, hctx, oracle):
+    layout, obs, volumes = fc.mixed_scene()
+    env, r, f, _ = build(H, hctx, H.DistanceField, obs, volumes)
+    assert f.ValidSliceCount == 0 and f.InvalidSlices == list(range(layout.slice_count)) and f.NeedsRasterize
+    with pytest.raises(H.InvalidOperationException, match="The distance field must be fully valid"):
+        f.Save()
+    want = oracle_atlas(oracle, layout, obs, volumes)
+    frames = 0
+    while f.NeedsRasterize:
+        assert r.UpdateFields() == 1           # MaximumFieldUpdatesPerFrame = 1 -> one triplet (LightingRenderer.DistanceField.cs:427-463)
+        frames += 1
+        assert f.ValidSliceCount == 3 * frames      # MarkValidSlice(lastVirtualSliceIndex + 1), :144-147
+        # the uniforms expose only the valid part of the field (Uniforms.cs:96-100)
+        dfu = abi.DistanceFieldUniforms.from_buffer_copy(r.GetDistanceFieldUniformsBytes())
+        assert abs(dfu.TextureSliceCount.z - min(f.ValidSliceCount, layout.slice_count) * layout.virtual_depth / layout.slice_count) < 1e-4
+    assert frames == layout.slice_count // 3
+    assert f.IsFullyGenerated and r.UpdateFields() == 0
+    assert np.array_equal(f.Save(), want)
+
+
+def test_whole_field_in_one_frame_and_invalidate(H, hctx, oracle):
+    layout, obs, volumes = fc.mixed_scene()
+    env, r, f, items = build(H, hctx, H.DistanceField, obs, volumes, updates_per_frame=999)
+    assert r.UpdateFields() == layout.slice_count // 3
+    assert np.array_equal(f.Save(), oracle_atlas(oracle, layout, obs, volumes))
+    # moving an obstruction invalidates the field (LightObstruction.Center setter -> AutoInvalidateDistanceField)
+    assert r.UpdateFields() == 0
+    items[3].Center = [40.0, 60.0, 5.0]
+    obs2 = list(obs)
+    obs2[3] = (obs[3][0], (40.0, 60.0, 5.0), obs[3][2], obs[3][3], obs[3][4])
+    assert r.UpdateFields() == layout.slice_count // 3
+    assert np.array_equal(f.Save(), oracle_atlas(oracle, layout, obs2, volumes))
+    # removing one as well
+    env.Obstructions.RemoveAt(0)
+    assert r.UpdateFields() == layout.slice_count // 3
+    assert np.array_equal(f.Save(), oracle_atlas(oracle, layout, obs2[1:], volumes))
+
+
+def test_dynamic_distance_field_partitions(H, hctx, oracle):
+    layout, obs, volumes = fc.mixed_scene(dynamic_fraction=0.4)
+    env, r, f, items = build(H, hctx, H.DynamicDistanceField, obs, volumes, updates_per_frame=999)
+    n = layout.slice_count // 3
+    assert r.UpdateFields() == 2 * n            # static partition + dynamic partition
+    static_want = oracle_atlas(oracle, layout, obs, volumes, flt=0)
+    assert np.array_equal(f.ReadStaticTexture(), static_want)
+    assert np.array_equal(f.ReadTexture(), oracle_atlas(oracle, layout, obs, volumes, flt=-1))
+    assert f.IsFullyGenerated and f.StaticValidSliceCount >= layout.slice_count
+    # moving a dynamic obstruction re-renders only the dynamic partition; the static atlas is reused as the clear source
+    di = next(i for i, o in enumerate(obs) if o[4])
+    items[di].Center = [128.0, 96.0, 4.0]
+    obs2 = list(obs)
+    obs2[di] = (obs[di][0], (128.0, 96.0, 4.0), obs[di][2], obs[di][3], True)
+    assert r.UpdateFields() == n
+    assert f.StaticInvalidSlices == []
+    assert np.array_equal(f.ReadStaticTexture(), static_want)
+    assert np.array_equal(f.ReadTexture(), oracle_atlas(oracle, layout, obs2, volumes, flt=-1))
+    # moving a static one re-renders both
+    si = next(i for i, o in enumerate(obs) if not o[4])
+    items[si].Size = [9.0, 30.0, 12.0]
+    obs3 = list(obs2)
+    obs3[si] = (obs[si][0], obs[si][1], (9.0, 30.0, 12.0), obs[si][3], False)
+    assert r.UpdateFields() == 2 * n
+    assert np.array_equal(f.ReadTexture(), oracle_atlas(oracle, layout, obs3, volumes, flt=-1))
+
+
+def test_lit_frame_from_generated_field_matches_oracle(H, hctx, oracle):
+    """End to end on the host mirror: obstructions -> UpdateFields -> RenderLighting, against the oracle doing both steps."""
+    layout, obs, volumes = fc.mixed_scene()
+    env, r, f, _ = build(H, hctx, H.DistanceField, obs, volumes, updates_per_frame=999)
+    lights = []
+    for (x, y, z) in ((20.0, 12.0, 20.0), (50.0, 40.0, 30.0), (8.0, 44.0, 12.0)):
+        l = H.SphereLightSource()
+        l.Position = [x, y, z]; l.Radius = 6.0; l.RampLength = 60.0; l.Color = [0.9, 0.8, 0.7, 1.0]
+        lights.append(l)
+    env.Lights = lights
+    env.Ambient = [0.02, 0.02, 0.02, 1.0]
+    r.Configuration.FloatLightmap = True
+    rc = H.RendererConfiguration(64, 48)
+    rc.FloatLightmap = True
+    rc.MaximumFieldUpdatesPerFrame = 999
+    r2 = H.LightingRenderer(hctx, rc, env)
+    r2.DistanceField = f
+    r2.UpdateFields()
+    r2.RenderLighting()
+    got = r2.ReadLightmap()
+    atlas = oracle_atlas(oracle, layout, obs, volumes)
+    verts = (abi.LightVertex * 3)()
+    for i, l in enumerate(lights):
+        verts[i] = abi.LightVertex.from_buffer_copy(H.LightingRenderer.PackSphereLightBytes(l, 1.0, True))
+    dfu = abi.DistanceFieldUniforms.from_buffer_copy(r2.GetDistanceFieldUniformsBytes())
+    envu = abi.Environment.from_buffer_copy(r2.GetEnvironmentUniformsBytes())
+    want, _ = oracle.render_sphere_lights(verts, envu, dfu, None, oracle.make_texture(atlas, abi.SDF_UNORM16), (0.02, 0.02, 0.02, 1.0), 64, 48)
+    from tests.util import assert_close
+    assert_close(got, want, "lightmap")
+    assert (want[..., 3] > 1.5).any()
