@@ -122,14 +122,28 @@ def build_lighting(H, ctx, scenes, abi, width, height, n_lights, resolution, wor
     q = H.RendererQualitySettings()           # the values every demo uses (Scenes/LightProbes.cs:113-118)
     q.MinStepSize = 1.0; q.LongStepFactor = 0.5; q.MaxStepCount = 64; q.MaxConeRadius = 24.0; q.OcclusionToOpacityPower = 0.7
     rc.DefaultQuality = q
+    rc.MaximumFieldUpdatesPerFrame = 9999      # the whole field in one UpdateFields (the reference default of 1 slice / frame is an amortisation knob)
     renderer = H.LightingRenderer(ctx, rc, env, external_ptr)
     field = H.DistanceField(ctx, world, world, 128.0, 32, resolution, 128, sdf_fmt)
-    layout = scenes.DistanceFieldLayout(world, world, 128.0, 32, resolution, 128)
-    assert (layout.atlas_width, layout.atlas_height) == (field.TextureWidth, field.TextureHeight)
-    atlas = scenes.build_sdf_atlas(layout, scenes.random_obstacles(11, 256, (world, world)), fmt=sdf_fmt)
-    field.Load(atlas)
     renderer.DistanceField = field
-    return dict(renderer=renderer, env=env, field=field, atlas=atlas, layout=layout, width=width, height=height, n_lights=n_lights)
+    # the field is generated on the GPU from LightObstructions: 256 random ellipsoids / boxes, seed 11
+    for (typ, center, size) in scenes.random_obstacles(11, 256, (world, world)):
+        env.Obstructions.Add(H.LightObstruction(typ - 1, list(center), list(size), 0.0))
+    renderer.UpdateFields()
+    ctx.Sync()
+    gen_iters = 5
+    ctx.TimerStart()
+    for _ in range(gen_iters):
+        renderer.InvalidateFields()
+        renderer.UpdateFields()
+    gen_ms = ctx.TimerStop() / gen_iters
+    texels = field.PhysicalSliceCount * field.SliceWidth * field.SliceHeight     # texels one full generation writes (8 B each)
+    gen = {"ms_per_field": round(gen_ms, 4), "atlas": "%dx%d RGBA16 (%d slices of %dx%d)" % (field.TextureWidth, field.TextureHeight, field.SliceCount, field.SliceWidth, field.SliceHeight),
+           "obstructions": 256, "mtexels_per_s": round(texels / (gen_ms * 1e-3) / 1e6, 1),
+           "roofline": {"bound": "hbm", "achieved": round(texels * 8 / (gen_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(texels * 8 / (gen_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                        "kernel": "ilm::render_slices_kernel", "bytes_per_unit": 8, "units_per_launch": texels, "launch_ms": round(gen_ms, 4)}}
+    return dict(renderer=renderer, env=env, field=field, width=width, height=height, n_lights=n_lights, field_generation=gen)
 
 
 def main():
@@ -270,6 +284,7 @@ def main():
                 "lit_mpixels_per_s": round(w * h / (frame_ms * 1e-3) / 1e6, 2),
                 "ms_per_frame": round(frame_ms, 4),
                 "sdf_samples_per_frame": samples_total,
+                "field_generation": L["field_generation"],
                 "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (kern_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              "traffic": round(lt["bytes"]) if lt else None,

@@ -7,7 +7,7 @@ offsets against the C header by compiling a probe.
 """
 import ctypes as C
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 OK = 0
 ERR_INVALID_ARGUMENT = -1
@@ -24,7 +24,8 @@ MAX_SPAWNS = 2
 RANDOMNESS_WIDTH = 807
 RANDOMNESS_HEIGHT = 653
 
-OP_GRAVITY, OP_NOISE, OP_FMA = 1, 2, 3
+OP_GRAVITY, OP_NOISE, OP_FMA, OP_MATRIX_MULTIPLY, OP_SPATIAL_NOISE = 1, 2, 3, 4, 5
+SPAWN_INLINE, SPAWN_POSITION_BUFFER, SPAWN_FEEDBACK = 0, 1, 2
 UPDATE_NONE, UPDATE_POSITIONS, UPDATE_WITH_DISTANCE_FIELD, UPDATE_ERASE = 0, 1, 2, 3
 STEP_COUNT_LIVE = 1
 
@@ -166,8 +167,23 @@ class UpdateParams(C.Structure):
         return u
 
 
+class MatrixMultiplyParams(C.Structure):
+    _fields_ = [("Area", AreaParams), ("TimeDivisor", f32), ("_pad", f32 * 3), ("PositionMatrix", Matrix), ("VelocityMatrix", Matrix)]
+
+
+class SpatialNoiseParams(C.Structure):
+    _fields_ = [("Noise", NoiseParams), ("SpaceScale", f32 * 2), ("_pad", f32 * 2)]
+
+
+class FeedbackParams(C.Structure):
+    _fields_ = [("SourceSystem", Handle), ("SourceChunkIndex", i32), ("FeedbackSourceIndex", f32), ("InstanceMultiplier", f32),
+                ("SourceVelocityFactor", f32), ("AlignPositionConstant", f32), ("MultiplyLife", f32), ("MultiplyAttributeConstant", f32),
+                ("SourceLifeRange", f32 * 2), ("_pad", f32)]
+
+
 class _OpUnion(C.Union):
-    _fields_ = [("Gravity", GravityParams), ("Noise", NoiseParams), ("FMA", FMAParams)]
+    _fields_ = [("Gravity", GravityParams), ("Noise", NoiseParams), ("FMA", FMAParams),
+                ("MatrixMultiply", MatrixMultiplyParams), ("SpatialNoise", SpatialNoiseParams)]
 
 
 class TransformOp(C.Structure):
@@ -175,7 +191,7 @@ class TransformOp(C.Structure):
 
 
 class SpawnRecord(C.Structure):
-    _fields_ = [("ChunkIndex", i32), ("_pad", i32 * 3), ("Params", SpawnParams)]
+    _fields_ = [("ChunkIndex", i32), ("Kind", i32), ("_pad", i32 * 2), ("Params", SpawnParams), ("Feedback", FeedbackParams)]
 
 
 class StepDesc(C.Structure):
@@ -220,7 +236,9 @@ EXPECTED_SIZES = {
     "IlmGravityParams": (GravityParams, 400), "IlmFMAParams": (FMAParams, 144),
     "IlmNoiseParams": (NoiseParams, 192), "IlmSpawnParams": (SpawnParams, 416),
     "IlmUpdateParams": (UpdateParams, 256), "IlmTransformOp": (TransformOp, 416),
-    "IlmSpawnRecord": (SpawnRecord, 432), "IlmStepDesc": (StepDesc, 2976),
+    "IlmSpawnRecord": (SpawnRecord, 480), "IlmStepDesc": (StepDesc, 3072),
+    "IlmMatrixMultiplyParams": (MatrixMultiplyParams, 208), "IlmSpatialNoiseParams": (SpatialNoiseParams, 208),
+    "IlmFeedbackParams": (FeedbackParams, 48),
     "IlmRenderStats": (RenderStats, 24),
     "IlmObstruction": (Obstruction, 48), "IlmHeightVolume": (HeightVolume, 32),
     "IlmDistanceFieldRenderDesc": (DistanceFieldRenderDesc, 64),

@@ -66,6 +66,7 @@ struct Engine {
     int chunk_size = 0, slots = 0;
     int64_t stride = 0;
     float4* rnd = nullptr; int rw = 0, rh = 0;
+    uint2* rnd_lp = nullptr;   // LowPrecisionRandomnessTexture: the Rgba64 copy (ParticleEngine.cs:508-540)
 };
 
 struct Sdf {
@@ -98,6 +99,8 @@ struct System {
     Sdf* sdf = nullptr;
     float4* ramp = nullptr; int ramp_w = 0, ramp_h = 0;
     uint32_t* d_slots = nullptr; int slots_cap = 0; uint32_t* d_slot_count = nullptr;
+    // the Spawner's PositionBuffer per spawn record slot (ParticleSpawner.cs:301-353)
+    float4* spawn_positions[ILM_MAX_SPAWNS] = {}; int spawn_position_count[ILM_MAX_SPAWNS] = {}; int spawn_position_cap[ILM_MAX_SPAWNS] = {};
     // asynchronous readback of the fused live counts
     uint32_t* h_counts = nullptr; int h_counts_cap = 0; hipEvent_t counts_ev = nullptr; int counts_n = 0; bool counts_pending = false;
     bool counts_valid = false;   // h_counts holds (or is about to receive) the counts of the last counting step
@@ -204,7 +207,7 @@ int32_t validate_step(const System* s, const IlmStepDesc* d, int* first, int* co
             // Transforms.cs:348-349: "Maximum number of attractors per instance is 16"
             if (op.u.Gravity.AttractorCount > ILM_MAX_ATTRACTORS || op.u.Gravity.AttractorCount < 0)
                 return fail(ILM_ERR_TOO_MANY, "Maximum number of attractors per instance is %d", ILM_MAX_ATTRACTORS);
-        } else if (op.Type != ILM_OP_NOISE && op.Type != ILM_OP_FMA) {
+        } else if (op.Type != ILM_OP_NOISE && op.Type != ILM_OP_FMA && op.Type != ILM_OP_MATRIX_MULTIPLY && op.Type != ILM_OP_SPATIAL_NOISE) {
             return fail(ILM_ERR_INVALID_ARGUMENT, "unknown transform type %d", op.Type);
         }
     }
@@ -217,7 +220,25 @@ int32_t validate_step(const System* s, const IlmStepDesc* d, int* first, int* co
             return fail(ILM_ERR_INVALID_ARGUMENT, "ChunkSizeAndIndices.x %g != engine chunk size %d", (double)cs, s->engine->chunk_size);
         if (first_i < 0 || last_i >= (float)s->engine->slots)
             return fail(ILM_ERR_OUT_OF_RANGE, "spawn range [%g, %g] outside the chunk", (double)first_i, (double)last_i);
-        if (r.Params.PositionConstantCount < 1.0f || r.Params.PositionConstantCount > (float)ILM_MAX_INLINE_POSITION_CONSTANTS)
+        if (r.Kind == ILM_SPAWN_POSITION_BUFFER) {
+            if (s->spawn_position_count[k] < 1 || r.Params.PositionConstantCount != (float)s->spawn_position_count[k])
+                return fail(ILM_ERR_STATE, "spawn record %d: PositionConstantCount %g but %d positions bound (ilm_system_set_spawn_positions)",
+                            k, (double)r.Params.PositionConstantCount, s->spawn_position_count[k]);
+        } else if (r.Kind == ILM_SPAWN_FEEDBACK) {
+            const System* src = from_handle<System>(r.Feedback.SourceSystem, kMagicSystem);
+            if (!src) return fail(ILM_ERR_INVALID_HANDLE, "spawn record %d: feedback source is not a system handle", k);
+            // "FIXME: Support using the same system as a feedback input?" -- the reference refuses it (SpecialSpawners.cs:347-349)
+            if (src == s) return fail(ILM_ERR_INVALID_ARGUMENT, "spawn record %d: a system cannot feed back into itself", k);
+            if (src->engine != s->engine) return fail(ILM_ERR_INVALID_ARGUMENT, "spawn record %d: feedback source belongs to another engine", k);
+            if (r.Feedback.SourceChunkIndex < 0 || r.Feedback.SourceChunkIndex >= (int)src->chunks.size())
+                return fail(ILM_ERR_OUT_OF_RANGE, "spawn record %d: source chunk %d outside [0, %d)", k, r.Feedback.SourceChunkIndex, (int)src->chunks.size());
+            if (!(r.Feedback.InstanceMultiplier >= 1.0f))
+                return fail(ILM_ERR_INVALID_ARGUMENT, "spawn record %d: InstanceMultiplier %g < 1", k, (double)r.Feedback.InstanceMultiplier);
+        } else if (r.Kind != ILM_SPAWN_INLINE) {
+            return fail(ILM_ERR_INVALID_ARGUMENT, "spawn record %d: unknown kind %d", k, r.Kind);
+        }
+        if (r.Kind != ILM_SPAWN_POSITION_BUFFER &&
+            (r.Params.PositionConstantCount < 1.0f || r.Params.PositionConstantCount > (float)ILM_MAX_INLINE_POSITION_CONSTANTS))
             return fail(ILM_ERR_OUT_OF_RANGE, "PositionConstantCount %g outside [1, %d]", (double)r.Params.PositionConstantCount,
                         ILM_MAX_INLINE_POSITION_CONSTANTS);
     }
@@ -258,6 +279,14 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
     a.op_mask = 0;
     for (int o = 0; o < d->OpCount; o++) a.op_mask |= 1u << d->Ops[o].Type;
     a.rnd = e->rnd; a.rw = e->rw; a.rh = e->rh;
+    a.rnd_lp = e->rnd_lp;
+    for (int k = 0; k < ILM_MAX_SPAWNS; k++) {
+        a.spawn_positions[k] = s->spawn_positions[k];
+        a.spawn_position_count[k] = s->spawn_position_count[k];
+        a.source_base[k] = nullptr;
+        if (k < d->SpawnCount && d->Spawns[k].Kind == ILM_SPAWN_FEEDBACK)
+            a.source_base[k] = from_handle<System>(d->Spawns[k].Feedback.SourceSystem, kMagicSystem)->chunks[(size_t)d->Spawns[k].Feedback.SourceChunkIndex];
+    }
     a.ramp = s->ramp; a.ramp_w = s->ramp_w; a.ramp_h = s->ramp_h;
     a.sdf = make_sdf_view(s->sdf);
     a.live_counts = counting ? s->counts_region(region) : nullptr;
@@ -294,6 +323,12 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
                                        std::isfinite(ar.AreaFalloff);
                     if (!inert) dv.noise_may_revive = 1;
                 }
+            } else if (op.Type == ILM_OP_SPATIAL_NOISE) {
+                // same argument as Noise (no life check, Noise.fx:86): life' = lerp(life, life + (r.w + offset.w) * scale.w, t)
+                const IlmNoiseParams& np = op.u.SpatialNoise.Noise;
+                const bool inert = (np.PositionScale.w == 0.0f) && std::isfinite(np.PositionOffset.w) && std::isfinite(np.Area.Strength) &&
+                                   std::isfinite(dt_ms) && std::isfinite(np.TimeDivisor) && (np.TimeDivisor != 0.0f) && std::isfinite(np.Area.AreaFalloff);
+                if (!inert) dv.noise_may_revive = 1;
             }
         }
     }
@@ -453,6 +488,14 @@ int32_t ilm_engine_create(IlmHandle hctx, int32_t chunk_size, const IlmFloat4* r
     const size_t bytes = sizeof(float4) * (size_t)rw * (size_t)rh;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->rnd), bytes));
     HIP_TRY(hipMemcpy(e->rnd, randomness, bytes, hipMemcpyHostToDevice));
+    {   // new Rgba64(Vector4) per texel (ParticleEngine.cs:536-538): round-half-even of clamp(v, 0, 1) * 65535 per channel
+        std::vector<uint16_t> lp((size_t)rw * (size_t)rh * 4);
+        const float* f = reinterpret_cast<const float*>(randomness);
+        for (size_t i = 0; i < lp.size(); i++)
+            lp[i] = (uint16_t)nearbyintf(fminf(fmaxf(f[i], 0.0f), 1.0f) * 65535.0f);
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->rnd_lp), sizeof(uint2) * (size_t)rw * (size_t)rh));
+        HIP_TRY(hipMemcpy(e->rnd_lp, lp.data(), sizeof(uint2) * (size_t)rw * (size_t)rh, hipMemcpyHostToDevice));
+    }
     *out = to_handle(e);
     return ILM_OK;
 }
@@ -463,6 +506,7 @@ int32_t ilm_engine_destroy(IlmHandle h) {
     (void)hipSetDevice(e->ctx->device);
     (void)hipStreamSynchronize(e->ctx->stream);
     if (e->rnd) (void)hipFree(e->rnd);
+    if (e->rnd_lp) (void)hipFree(e->rnd_lp);
     e->magic = 0;
     delete e;
     return ILM_OK;
@@ -491,6 +535,8 @@ int32_t ilm_system_destroy(IlmHandle h) {
     if (s->ramp) (void)hipFree(s->ramp);
     if (s->d_slots) (void)hipFree(s->d_slots);
     if (s->d_slot_count) (void)hipFree(s->d_slot_count);
+    for (int k = 0; k < ILM_MAX_SPAWNS; k++)
+        if (s->spawn_positions[k]) (void)hipFree(s->spawn_positions[k]);
     if (s->h_counts) (void)hipHostFree(s->h_counts);
     if (s->counts_ev) (void)hipEventDestroy(s->counts_ev);
     s->magic = 0;
@@ -616,6 +662,30 @@ int32_t ilm_system_set_life_ramp(IlmHandle h, const IlmFloat4* texels, int32_t w
     return ILM_OK;
 }
 
+int32_t ilm_system_set_spawn_positions(IlmHandle h, int32_t slot, const IlmFloat4* positions, int32_t count) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (slot < 0 || slot >= ILM_MAX_SPAWNS) return fail(ILM_ERR_OUT_OF_RANGE, "spawn slot %d outside [0, %d)", slot, ILM_MAX_SPAWNS);
+    if (count < 0 || (count > 0 && !positions)) return fail(ILM_ERR_INVALID_ARGUMENT, "bad position list");
+    if (count > (1 << 20)) return fail(ILM_ERR_TOO_MANY, "at most %d positions", 1 << 20);
+    Ctx* c = s->engine->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    if (count > s->spawn_position_cap[slot]) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (s->spawn_positions[slot]) HIP_TRY(hipFree(s->spawn_positions[slot]));
+        s->spawn_positions[slot] = nullptr; s->spawn_position_cap[slot] = 0;
+        const int cap = (count + 127) / 128 * 128;     // EnsurePositionBufferExists, ParticleSpawner.cs:307
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->spawn_positions[slot]), sizeof(float4) * (size_t)cap));
+        s->spawn_position_cap[slot] = cap;
+    }
+    if (count > 0) {
+        int32_t rc = upload_small(c, s->spawn_positions[slot], positions, sizeof(float4) * (size_t)count);
+        if (rc != ILM_OK) return rc;
+    }
+    s->spawn_position_count[slot] = count;
+    return ILM_OK;
+}
+
 int32_t ilm_system_step(IlmHandle h, const IlmStepDesc* desc) {
     System* s = from_handle<System>(h, kMagicSystem);
     if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
@@ -669,6 +739,26 @@ int32_t ilm_fma(IlmHandle h, int32_t chunk_index, const IlmParticleSystemUniform
     IlmStepDesc d;
     init_single_pass(&d, chunk_index, sys);
     d.OpCount = 1; d.Ops[0].Type = ILM_OP_FMA; d.Ops[0].u.FMA = *p;
+    return run_step(s, &d);
+}
+
+int32_t ilm_matrix_multiply(IlmHandle h, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmMatrixMultiplyParams* p) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (!p || !sys) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
+    IlmStepDesc d;
+    init_single_pass(&d, chunk_index, sys);
+    d.OpCount = 1; d.Ops[0].Type = ILM_OP_MATRIX_MULTIPLY; d.Ops[0].u.MatrixMultiply = *p;
+    return run_step(s, &d);
+}
+
+int32_t ilm_spatial_noise(IlmHandle h, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmSpatialNoiseParams* p) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (!p || !sys) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
+    IlmStepDesc d;
+    init_single_pass(&d, chunk_index, sys);
+    d.OpCount = 1; d.Ops[0].Type = ILM_OP_SPATIAL_NOISE; d.Ops[0].u.SpatialNoise = *p;
     return run_step(s, &d);
 }
 

@@ -54,7 +54,11 @@ struct StepLaunch {
     int32_t first_chunk, chunk_count;
     uint32_t op_mask;            // bit t set when an op of type t is present
     const float4* rnd; int32_t rw, rh;
+    const uint2* rnd_lp;         // the Rgba64 copy of the randomness table (SpatialNoise; ParticleEngine.cs:508-540)
     const float4* ramp; int32_t ramp_w, ramp_h;
+    // extended spawn kinds (per spawn record slot): the Spawner's PositionBuffer and the feedback source chunk
+    const float4* spawn_positions[ILM_MAX_SPAWNS]; int32_t spawn_position_count[ILM_MAX_SPAWNS];
+    const float* source_base[ILM_MAX_SPAWNS];
     SdfView sdf;
     uint32_t* live_counts;       // per chunk at index chunk * kCountStride; all zero on entry when ILM_STEP_COUNT_LIVE
     uint32_t* zero_counts;       // the other counter region: zeroed by this launch for the next counting step

@@ -160,6 +160,80 @@ ILM_DEV void apply_noise(float4& pos, float4& vel, float x, float y, const float
     vel = mk4(nv.x, nv.y, nv.z, vel.w);
 }
 
+// mul3, ParticleCommon.fxh:183-196
+ILM_DEV float4 mul_point(f3 v, const IlmMatrix& M);
+ILM_DEV float4 mul3(float4 old_value, const IlmMatrix& mat, float w) {
+    const float4 temp = mul_point(xyz(old_value), mat);
+    if (w != 0.0f)
+        return mk4(temp.x / temp.w, temp.y / temp.w, temp.z / temp.w, old_value.w);
+    return mk4(temp.x, temp.y, temp.z, old_value.w);
+}
+
+// PS_MatrixMultiply, MatrixMultiply.fx:22-52
+ILM_DEV void apply_matrix_multiply(float4& pos, float4& vel, const IlmParticleSystemUniforms& sys, const IlmMatrixMultiplyParams& p) {
+#pragma clang fp contract(off)
+    if ((pos.w <= 0.0f) || !category_ok(vel.w, p.Area.CategoryFilter))
+        return;
+    const float time_scale = (p.TimeDivisor >= 0.0f) ? sys.GlobalSettings.x / p.TimeDivisor : 1.0f;
+    const float distance = evaluate_area(p.Area.AreaType, xyz(pos), p.Area);
+    const float w = ((1.0f - clampf(distance / p.Area.AreaFalloff, 0.0f, 1.0f)) * p.Area.Strength) * time_scale;
+    const float4 np = lerp4(pos, mul3(pos, p.PositionMatrix, 1.0f), w);
+    const float4 nv = lerp4(vel, mul3(vel, p.VelocityMatrix, 0.0f), w);
+    pos = np;
+    vel = nv;
+}
+
+// smoothRandomCustom, RandomCommon.fxh:36-39: bilinear, WRAP on both axes, on the Rgba64 copy of the randomness table
+ILM_DEV float4 smooth_random_custom(const uint2* __restrict__ lp, int rw, int rh, float texel_x, float texel_y, float x, float y,
+                                    float off_x, float off_y, float rate_x, float rate_y) {
+#pragma clang fp contract(off)
+    const float u = ((x * rate_x) + off_x) * texel_x;
+    const float v = ((y * rate_y) + off_y) * texel_y;
+    const float sx = u * (float)rw - 0.5f, sy = v * (float)rh - 0.5f;
+    const float x0f = floorf(sx), y0f = floorf(sy);
+    const float fx = sx - x0f, fy = sy - y0f;
+    const int x0 = wrap_index(x0f, rw), y0 = wrap_index(y0f, rh);
+    const int x1 = (x0 + 1 == rw) ? 0 : x0 + 1, y1 = (y0 + 1 == rh) ? 0 : y0 + 1;
+    const uint2 t00 = lp[y0 * rw + x0], t10 = lp[y0 * rw + x1], t01 = lp[y1 * rw + x0], t11 = lp[y1 * rw + x1];
+    float r[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const uint32_t w00 = (c < 2) ? t00.x : t00.y, w10 = (c < 2) ? t10.x : t10.y, w01 = (c < 2) ? t01.x : t01.y, w11 = (c < 2) ? t11.x : t11.y;
+        const int sh = (c & 1) * 16;
+        const float a = unorm16_to_float((float)((w00 >> sh) & 0xFFFFu)), b = unorm16_to_float((float)((w10 >> sh) & 0xFFFFu));
+        const float cc = unorm16_to_float((float)((w01 >> sh) & 0xFFFFu)), d = unorm16_to_float((float)((w11 >> sh) & 0xFFFFu));
+        r[c] = lerp(lerp(a, b, fx), lerp(cc, d, fx), fy);
+    }
+    return mk4(r[0], r[1], r[2], r[3]);
+}
+
+// PS_SpatialNoise, Noise.fx:74-116 (no life check, no Minimum shaping)
+ILM_DEV void apply_spatial_noise(float4& pos, float4& vel, const uint2* __restrict__ lp, int rw, int rh,
+                                 const IlmParticleSystemUniforms& sys, const IlmSpatialNoiseParams& sp, const StepDerived& sd) {
+#pragma clang fp contract(off)
+    const IlmNoiseParams& p = sp.Noise;
+    if (!category_ok(vel.w, p.Area.CategoryFilter))
+        return;
+    const float weight = compute_weight(p.Area, xyz(pos));
+    const float t = weight * sys.GlobalSettings.x / p.TimeDivisor;
+    const float rx = pos.x, ry = pos.y, sx = sp.SpaceScale[0], sy = sp.SpaceScale[1];
+    const float4 p1 = smooth_random_custom(lp, rw, rh, sd.inv_rw, sd.inv_rh, rx, ry, p.RandomnessOffset[0], p.RandomnessOffset[1], sx, sy);
+    const float4 p2 = smooth_random_custom(lp, rw, rh, sd.inv_rw, sd.inv_rh, rx, ry, p.NextRandomnessOffset[0], p.NextRandomnessOffset[1], sx, sy);
+    const float4 v1 = smooth_random_custom(lp, rw, rh, sd.inv_rw, sd.inv_rh, rx + 2.0f, ry + 1.0f, p.RandomnessOffset[0], p.RandomnessOffset[1], sx, sy);
+    const float4 v2 = smooth_random_custom(lp, rw, rh, sd.inv_rw, sd.inv_rh, rx + 2.0f, ry + 1.0f, p.NextRandomnessOffset[0], p.NextRandomnessOffset[1], sx, sy);
+    const float4 position_delta = mul4(add4(lerp4(p1, p2, p.FrequencyLerp), ld4(p.PositionOffset)), ld4(p.PositionScale));
+    const float4 velocity_delta = mul4(add4(lerp4(v1, v2, p.FrequencyLerp), ld4(p.VelocityOffset)), ld4(p.VelocityScale));
+    const float4 np = lerp4(pos, add4(pos, position_delta), t);
+    f3 nv;
+    if (p.ReplaceOldVelocity != 0.0f)
+        nv = mk3(lerp(vel.x, velocity_delta.x, weight), lerp(vel.y, velocity_delta.y, weight), lerp(vel.z, velocity_delta.z, weight));
+    else
+        nv = mk3(lerp(vel.x, vel.x + velocity_delta.x, t), lerp(vel.y, vel.y + velocity_delta.y, t), lerp(vel.z, vel.z + velocity_delta.z, t));
+    nv = nv + (norm3(xyz(vel)) * velocity_delta.w);
+    pos = np;
+    vel = mk4(nv.x, nv.y, nv.z, vel.w);
+}
+
 // ---------------------------------------------------------------------------------------------
 // spawner -- SpawnerCommon.fxh + PS_Spawn (SpawnParticles.fx:10-30)
 // ---------------------------------------------------------------------------------------------
@@ -218,24 +292,25 @@ ILM_DEV float4 mul_point(f3 v, const IlmMatrix& M) {
 template <unsigned M>
 ILM_DEV float mod_const(float index) { return (float)((unsigned)index % M); }
 
-// Returns true when the slot was (re)written by the spawner.
-ILM_DEV bool spawn_slot(float4& pos, float4& vel, float4& attr, float x, float y,
-                        const float4* __restrict__ rnd, int rw, int rh, float tx_, float ty_, const IlmSpawnParams& p) {
+// evaluateRandomForIndex, SpawnerCommon.fxh:106-117
+ILM_DEV void evaluate_random_for_index(const float4* __restrict__ rnd, int rw, int rh, float tx_, float ty_, float index, float ox, float oy,
+                                       float4& random1, float4& random2, float4& random3) {
+    random1 = random_custom(rnd, rw, rh, tx_, ty_, mod_const<8039u>(index), 0.0f + mod_const<57u>(index), ox, oy, 1.0f, 1.0f);
+    random2 = random_custom(rnd, rw, rh, tx_, ty_, mod_const<6180u>(index), 1.0f + mod_const<4031u>(index), ox, oy, 1.0f, 1.0f);
+    random3 = random_custom(rnd, rw, rh, tx_, ty_, mod_const<2025u>(index), 2.0f + mod_const<65531u>(index), ox, oy, 1.0f, 1.0f);
+}
+
+// Spawn_Stage1, SpawnerCommon.fxh:119-160: the slot test, the three random vectors and the position-constant indices
+ILM_DEV bool spawn_stage1(float x, float y, const float4* __restrict__ rnd, int rw, int rh, float tx_, float ty_, const IlmSpawnParams& p,
+                          float4& random1, float4& random2, float4& random3, int& index1, int& index2, float& position_index_t) {
     const float index = x + (y * p.ChunkSizeAndIndices[0]);
     if ((index < p.ChunkSizeAndIndices[1]) || (index > p.ChunkSizeAndIndices[2]))
         return false;
-
-    const float ox = p.RandomnessOffset[0], oy = p.RandomnessOffset[1];
-    const float4 random1 = random_custom(rnd, rw, rh, tx_, ty_, mod_const<8039u>(index), 0.0f + mod_const<57u>(index), ox, oy, 1.0f, 1.0f);
-    float4 random2 = random_custom(rnd, rw, rh, tx_, ty_, mod_const<6180u>(index), 1.0f + mod_const<4031u>(index), ox, oy, 1.0f, 1.0f);
-    const float4 random3 = random_custom(rnd, rw, rh, tx_, ty_, mod_const<2025u>(index), 2.0f + mod_const<65531u>(index), ox, oy, 1.0f, 1.0f);
+    evaluate_random_for_index(rnd, rw, rh, tx_, ty_, index, p.RandomnessOffset[0], p.RandomnessOffset[1], random1, random2, random3);
     if (p.AlignVelocityAndPosition != 0.0f) {
         random2.x = random1.x;
         random2.y = random1.y;
     }
-
-    int index1, index2;
-    float position_index_t;
     const float relative_index = index - p.ChunkSizeAndIndices[1];
     if (p.PolygonRate > 0.05f) {
         const float position_index_f = (relative_index / p.PolygonRate) + p.ChunkSizeAndIndices[3];
@@ -248,14 +323,16 @@ ILM_DEV bool spawn_slot(float4& pos, float4& vel, float4& attr, float x, float y
         else
             index2 = (int)fminf((float)(index1 + 1), divisor - 1.0f);
     } else {
-        // integer-valued operands (slot index + TotalSpawned % count, 1..4 position constants): exact either way
+        // integer-valued operands (slot index + TotalSpawned % count, the position count): exact either way
         index1 = index2 = wrap_index_fast(relative_index + p.ChunkSizeAndIndices[3], (int)p.PositionConstantCount);
         position_index_t = 0.0f;
     }
-    index1 = min(max(index1, 0), ILM_MAX_INLINE_POSITION_CONSTANTS - 1);
-    index2 = min(max(index2, 0), ILM_MAX_INLINE_POSITION_CONSTANTS - 1);
+    return true;
+}
 
-    const float4 position1 = ld4(p.InlinePositionConstants[index1]), position2 = ld4(p.InlinePositionConstants[index2]);
+// Spawn_Stage2, SpawnerCommon.fxh:162-190.  Returns false on the alpha discard.
+ILM_DEV bool spawn_stage2(float4 position1, float4 position2, float position_index_t, float4 random1, float4 random2, float4 random3,
+                          const IlmSpawnParams& p, float4& pos, float4& vel, float4& attr) {
     const float4 position_constant = lerp4(position1, position2, position_index_t);
     const float4 towards_next = sub4(position2, position1);
 
@@ -282,6 +359,99 @@ ILM_DEV bool spawn_slot(float4& pos, float4& vel, float4& attr, float x, float y
     float4 new_velocity = mul_point(xyz(temp_velocity), p.VelocityMatrix);
     new_velocity.w = temp_velocity.w;
 
+    if (new_attributes.w < p.AttributeDiscardThreshold)
+        return false;
+    pos = new_position;
+    vel = new_velocity;
+    attr = new_attributes;
+    return true;
+}
+
+// PS_Spawn, SpawnParticles.fx:10-30.  Returns true when the slot was (re)written by the spawner.
+ILM_DEV bool spawn_slot(float4& pos, float4& vel, float4& attr, float x, float y,
+                        const float4* __restrict__ rnd, int rw, int rh, float tx_, float ty_, const IlmSpawnParams& p) {
+    float4 random1, random2, random3;
+    int index1, index2;
+    float position_index_t;
+    if (!spawn_stage1(x, y, rnd, rw, rh, tx_, ty_, p, random1, random2, random3, index1, index2, position_index_t))
+        return false;
+    index1 = min(max(index1, 0), ILM_MAX_INLINE_POSITION_CONSTANTS - 1);
+    index2 = min(max(index2, 0), ILM_MAX_INLINE_POSITION_CONSTANTS - 1);
+    return spawn_stage2(ld4(p.InlinePositionConstants[index1]), ld4(p.InlinePositionConstants[index2]), position_index_t,
+                        random1, random2, random3, p, pos, vel, attr);
+}
+
+// tex2Dlod(PositionConstantSampler, index * PositionConstantTexel.x): POINT / CLAMP on the Spawner's PositionBuffer, whose width is
+// the count rounded up to a multiple of 128 and whose padding stays zero (ParticleSpawner.cs:301-314, SpawnParticles.fx:47-48)
+ILM_DEV float4 position_constant_fetch(const float4* __restrict__ positions, int count, int index) {
+#pragma clang fp contract(off)
+    const int width = (count + 127) / 128 * 128;
+    const float texel = 1.0f / (float)width;
+    const float u = (float)index * texel;
+    const int tx = min(max((int)floorf(u * (float)width), 0), width - 1);
+    return (tx < count) ? positions[tx] : mk4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// PS_SpawnFromPositionTexture, SpawnParticles.fx:32-52
+ILM_DEV bool spawn_slot_position_buffer(float4& pos, float4& vel, float4& attr, float x, float y, const float4* __restrict__ rnd, int rw, int rh,
+                                        float tx_, float ty_, const IlmSpawnParams& p, const float4* __restrict__ positions, int count) {
+    float4 random1, random2, random3;
+    int index1, index2;
+    float position_index_t;
+    if (!spawn_stage1(x, y, rnd, rw, rh, tx_, ty_, p, random1, random2, random3, index1, index2, position_index_t))
+        return false;
+    return spawn_stage2(position_constant_fetch(positions, count, index1), position_constant_fetch(positions, count, index2), position_index_t,
+                        random1, random2, random3, p, pos, vel, attr);
+}
+
+// PS_SpawnFeedback, SpawnParticles.fx:54-118.  `src` = plane 0 of the source chunk (same stride S and chunk size as the target:
+// SourceChunkSizeAndTexel = (size, 1/size, 1/size), ParticleTransform.cs:129-141).
+ILM_DEV bool spawn_slot_feedback(float4& pos, float4& vel, float4& attr, float x, float y, const float4* __restrict__ rnd, int rw, int rh,
+                                 float tx_, float ty_, const IlmSpawnParams& p, const IlmFeedbackParams& fb,
+                                 const float* __restrict__ src, int64_t S, int chunk_size) {
+#pragma clang fp contract(off)
+    const float index = x + (y * p.ChunkSizeAndIndices[0]);
+    if ((index < p.ChunkSizeAndIndices[1]) || (index > p.ChunkSizeAndIndices[2]))
+        return false;
+    const float size = (float)chunk_size, texel = 1.0f / (float)chunk_size;
+    const float source_index = ((index - p.ChunkSizeAndIndices[1]) / fb.InstanceMultiplier) + fb.FeedbackSourceIndex;
+    float source_y;
+    const float source_x = modff(source_index / size, &source_y) * size;
+    // readStateUv: POINT / CLAMP at uv = sourceXy * texel
+    const int tx = min(max((int)floorf((source_x * texel) * size), 0), chunk_size - 1);
+    const int ty = min(max((int)floorf((source_y * texel) * size), 0), chunk_size - 1);
+    const int si = ty * chunk_size + tx;
+    const float4 source_position = mk4(src[si], src[S + si], src[2 * S + si], src[3 * S + si]);
+    if ((source_position.w <= fb.SourceLifeRange[0]) || (source_position.w >= fb.SourceLifeRange[1]))
+        return false;
+    const float4 source_velocity = mk4(src[4 * S + si], src[5 * S + si], src[6 * S + si], src[7 * S + si]);
+    const float4 source_attributes = mk4(src[8 * S + si], src[9 * S + si], src[10 * S + si], src[11 * S + si]);
+
+    float4 random1, random2, random3;
+    evaluate_random_for_index(rnd, rw, rh, tx_, ty_, index, p.RandomnessOffset[0], p.RandomnessOffset[1], random1, random2, random3);
+
+    const float4 zero = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 position_constant = ld4(p.InlinePositionConstants[0]);
+    if (fb.AlignPositionConstant != 0.0f) {
+        position_constant.x += source_position.x; position_constant.y += source_position.y; position_constant.z += source_position.z;
+    }
+    const float4 temp_position = evaluate_formula(zero, position_constant, ld4(p.Configuration[0]), ld4(p.Configuration[1]),
+                                                  random1, p.FormulaTypes[0], p.AxisMask);
+    float4 attribute_constant = ld4(p.Configuration[5]);
+    if (fb.MultiplyAttributeConstant != 0.0f)
+        attribute_constant = mul4(attribute_constant, source_attributes);
+    float4 new_position = mul_point(xyz(temp_position), p.PositionMatrix);
+    new_position.w = temp_position.w;
+    if (fb.MultiplyLife != 0.0f)
+        new_position.w *= source_position.w;
+    float4 temp_velocity = evaluate_formula(temp_position, ld4(p.Configuration[2]), ld4(p.Configuration[3]), ld4(p.Configuration[4]),
+                                            random2, p.FormulaTypes[1], p.AxisMask);
+    temp_velocity = add4(temp_velocity, mk4(source_velocity.x * fb.SourceVelocityFactor, source_velocity.y * fb.SourceVelocityFactor,
+                                            source_velocity.z * fb.SourceVelocityFactor, source_velocity.w * fb.SourceVelocityFactor));
+    float4 new_velocity = mul_point(xyz(temp_velocity), p.VelocityMatrix);
+    new_velocity.w = temp_velocity.w;
+    const float4 new_attributes = evaluate_formula(temp_position, attribute_constant, ld4(p.Configuration[6]), ld4(p.Configuration[7]),
+                                                   random3, p.FormulaTypes[2], p.AxisMask);
     if (new_attributes.w < p.AttributeDiscardThreshold)
         return false;
     pos = new_position;
@@ -576,7 +746,7 @@ typedef const StepLaunch __attribute__((address_space(4))) CStepLaunch;
 
 // DF: the update pass is UpdateWithDistanceField (pulls in the SDF sampler); SPAWN: spawn records present.
 // Both are compile-time so the common no-field / no-spawn step does not pay their registers.
-template <int FMT, bool DF, bool SPAWN>
+template <int FMT, bool DF, bool SPAWN, bool EXT>
 ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* ub, int chunk, int i, unsigned lane, int seg, SlotIn cur) {
     const StepLaunch& a = *(const StepLaunch*)ap;
     const IlmStepDesc& d = a.desc;
@@ -585,7 +755,8 @@ ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* ub, int chunk, int i, unsigne
     const bool need_attr = (mode == ILM_UPDATE_POSITIONS) || (mode == ILM_UPDATE_WITH_DISTANCE_FIELD);
     // Noise has no life check (Noise.fx:40): dead slots go through it.  That only matters when its result survives --
     // no update pass follows (single-pass ilm_noise), or the op can bring a dead slot back to life (StepDerived).
-    const bool has_noise = ((a.op_mask & (1u << ILM_OP_NOISE)) != 0u) && ((mode == ILM_UPDATE_NONE) || (a.derived.noise_may_revive != 0));
+    const uint32_t noise_ops = EXT ? ((1u << ILM_OP_NOISE) | (1u << ILM_OP_SPATIAL_NOISE)) : (1u << ILM_OP_NOISE);
+    const bool has_noise = ((a.op_mask & noise_ops) != 0u) && ((mode == ILM_UPDATE_NONE) || (a.derived.noise_may_revive != 0));
     const float4 zero = mk4(0.0f, 0.0f, 0.0f, 0.0f);
 
     bool spawn_here = false;
@@ -630,7 +801,16 @@ ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* ub, int chunk, int i, unsigne
             if (spawn_here) {
                 for (int s = 0; s < d.SpawnCount; s++) {
                     if (d.Spawns[s].ChunkIndex == chunk) {
-                        if (spawn_slot(pos, vel, attr, fx, fy, a.rnd, a.rw, a.rh, a.derived.inv_rw, a.derived.inv_rh, d.Spawns[s].Params))
+                        bool wrote;
+                        if (EXT && d.Spawns[s].Kind == ILM_SPAWN_POSITION_BUFFER)
+                            wrote = spawn_slot_position_buffer(pos, vel, attr, fx, fy, a.rnd, a.rw, a.rh, a.derived.inv_rw, a.derived.inv_rh,
+                                                               d.Spawns[s].Params, a.spawn_positions[s], a.spawn_position_count[s]);
+                        else if (EXT && d.Spawns[s].Kind == ILM_SPAWN_FEEDBACK)
+                            wrote = spawn_slot_feedback(pos, vel, attr, fx, fy, a.rnd, a.rw, a.rh, a.derived.inv_rw, a.derived.inv_rh,
+                                                        d.Spawns[s].Params, d.Spawns[s].Feedback, a.source_base[s], S, cs);
+                        else
+                            wrote = spawn_slot(pos, vel, attr, fx, fy, a.rnd, a.rw, a.rh, a.derived.inv_rw, a.derived.inv_rh, d.Spawns[s].Params);
+                        if (wrote)
                             spawned = true;
                     }
                 }
@@ -645,6 +825,10 @@ ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* ub, int chunk, int i, unsigne
                 apply_noise(pos, vel, fx, fy, a.rnd, a.rw, a.rh, d.System, op.u.Noise, a.derived, a.derived.op[o]);
             else if (op.Type == ILM_OP_FMA)
                 apply_fma(pos, vel, d.System, op.u.FMA, a.derived.op[o]);
+            else if (EXT && op.Type == ILM_OP_MATRIX_MULTIPLY)
+                apply_matrix_multiply(pos, vel, d.System, op.u.MatrixMultiply);
+            else if (EXT && op.Type == ILM_OP_SPATIAL_NOISE)
+                apply_spatial_noise(pos, vel, a.rnd_lp, a.rw, a.rh, d.System, op.u.SpatialNoise, a.derived);
         }
 
         float4 rc = zero, rd = zero;
@@ -678,7 +862,7 @@ ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* ub, int chunk, int i, unsigne
 // software-pipelined variant of this kernel measured 12-25 % slower: the body is a long dependent chain --
 // state loads, scalar parameter fetches, randomness gathers -- whose latency is hidden by wave occupancy,
 // not by prefetching; see DESIGN.md.)  MINW = minimum waves per SIMD requested from the register allocator.
-template <int FMT, bool DF, bool SPAWN, int MINW>
+template <int FMT, bool DF, bool SPAWN, int MINW, bool EXT = false>
 __global__ __launch_bounds__(kStepThreads, MINW) void step_kernel(const StepLaunch a) {
     __shared__ uint32_t wave_live[kStepThreads / 64];
     CStepLaunch* ap = (CStepLaunch*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -714,7 +898,7 @@ __global__ __launch_bounds__(kStepThreads, MINW) void step_kernel(const StepLaun
             const SlotIn cur = q[0];
 #pragma unroll
             for (int r = 0; r + 1 < K; r++) q[r] = q[r + 1];
-            const bool live_after = process_unit<FMT, DF, SPAWN>(ap, ub + j * 64, chunk, (seg + j) * 64 + (int)lane, lane, seg + j, cur);
+            const bool live_after = process_unit<FMT, DF, SPAWN, EXT>(ap, ub + j * 64, chunk, (seg + j) * 64 + (int)lane, lane, seg + j, cur);
             n_live += (uint32_t)__popcll(__ballot(live_after));
         }
     }
@@ -739,10 +923,32 @@ __global__ __launch_bounds__(kStepThreads, MINW) void step_kernel(const StepLaun
     }
 }
 
+// The extended variant carries the rarely used techniques (MatrixMultiply, SpatialNoise, the position-buffer and feedback spawners) so
+// that the common variants do not pay their registers; it is always the spawning superset.
+static bool needs_extended_variant(const StepLaunch& a) {
+    if (a.op_mask & ((1u << ILM_OP_MATRIX_MULTIPLY) | (1u << ILM_OP_SPATIAL_NOISE))) return true;
+    for (int s = 0; s < a.desc.SpawnCount; s++)
+        if (a.desc.Spawns[s].Kind != ILM_SPAWN_INLINE) return true;
+    return false;
+}
+
 template <bool SPAWN>
 static hipError_t launch_step_variant(const StepLaunch& a, hipStream_t stream) {
     const int units = a.unit_end - a.unit_begin;
     if (units <= 0) return hipSuccess;
+    if (needs_extended_variant(a)) {
+        const int upb = (kStepThreads / 64) * kUnitsPerWave;
+        const dim3 g((unsigned)((units + upb - 1) / upb), 1, 1), b(kStepThreads, 1, 1);
+        if (a.desc.UpdateMode == ILM_UPDATE_WITH_DISTANCE_FIELD) {
+            if (a.sdf.format == ILM_SDF_FP16)
+                hipLaunchKernelGGL((step_kernel<ILM_SDF_FP16, true, true, 1, true>), g, b, 0, stream, a);
+            else
+                hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, true, true, 1, true>), g, b, 0, stream, a);
+        } else {
+            hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, false, true, 1, true>), g, b, 0, stream, a);
+        }
+        return hipGetLastError();
+    }
     static int minw = -1;
     if (minw < 0) {
         const char* e = getenv("ILM_STEP_MINWAVES");

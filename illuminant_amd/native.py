@@ -54,6 +54,9 @@ SYMBOLS = {
     "ilm_gravity": (_I, [_H, _I, _P, _P]),
     "ilm_noise": (_I, [_H, _I, _P, _P]),
     "ilm_fma": (_I, [_H, _I, _P, _P]),
+    "ilm_matrix_multiply": (_I, [_H, _I, _P, _P]),
+    "ilm_spatial_noise": (_I, [_H, _I, _P, _P]),
+    "ilm_system_set_spawn_positions": (_I, [_H, _I, _P, _I]),
     "ilm_update": (_I, [_H, _I, _P, _P, _P]),
     "ilm_erase": (_I, [_H, _I]),
     "ilm_system_live_counts": (_I, [_H, _P, _I, _I]),
@@ -224,6 +227,20 @@ class System:
 
     def fma(self, chunk, sys, p):
         check(lib().ilm_fma(self.handle, chunk, _byref(sys), _byref(p)))
+
+    def matrix_multiply(self, chunk, sys, p):
+        check(lib().ilm_matrix_multiply(self.handle, chunk, _byref(sys), _byref(p)))
+
+    def spatial_noise(self, chunk, sys, p):
+        check(lib().ilm_spatial_noise(self.handle, chunk, _byref(sys), _byref(p)))
+
+    def set_spawn_positions(self, slot, positions):
+        """ilm_system_set_spawn_positions: (n, 4) float32 (xyz, life) position constants of spawn record `slot`; None releases."""
+        if positions is None:
+            check(lib().ilm_system_set_spawn_positions(self.handle, slot, None, 0))
+            return
+        a = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 4)
+        check(lib().ilm_system_set_spawn_positions(self.handle, slot, _ptr(a), a.shape[0]))
 
     def update(self, chunk, sys, p, df=None):
         check(lib().ilm_update(self.handle, chunk, _byref(sys), _byref(p), _byref(df)))

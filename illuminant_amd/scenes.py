@@ -123,6 +123,65 @@ def noise_params(area_params, offsets, next_offsets, frequency_lerp, cycles_per_
     return p
 
 
+def matrix_multiply_params(area_params, position_matrix=None, velocity_matrix=None, cycles_per_second=10.0):
+    """MatrixMultiply.SetParameters, Transforms.cs:61-66."""
+    p = abi.MatrixMultiplyParams()
+    p.Area = area_params
+    p.TimeDivisor = (1000.0 / cycles_per_second) if cycles_per_second is not None else -1.0
+    p.PositionMatrix = position_matrix if position_matrix is not None else abi.Matrix.identity()
+    p.VelocityMatrix = velocity_matrix if velocity_matrix is not None else abi.Matrix.identity()
+    return p
+
+
+def spatial_noise_params(noise, space_scale=(1.0, 1.0)):
+    """SpatialNoise.SetParameters, Transforms.cs:288-293: SpaceScale uniform = 1 / scale."""
+    p = abi.SpatialNoiseParams()
+    p.Noise = noise
+    p.SpaceScale[0] = float(np.float32(1.0) / np.float32(space_scale[0]))
+    p.SpaceScale[1] = float(np.float32(1.0) / np.float32(space_scale[1]))
+    return p
+
+
+def position_buffer_spawn_params(chunk_size, first, last, total_spawned, randomness_offset, positions, life_constant=1.0, **kw):
+    """Spawner with more than 4 positions (technique SpawnParticlesFromPositionTexture): returns (SpawnParams, (n, 4) position list).
+    positions: [(x, y, z)] including the spawner's own Position.Constant first (ParticleSpawner.cs:319-353)."""
+    polygon_rate = kw.get("polygon_rate")
+    polygon_loop = kw.get("polygon_loop", True)
+    base = dict(kw)
+    base["position"] = (tuple(positions[0]),) + tuple(kw.get("position", ((0, 0, 0), (1, 1, 1), (0, 0, 0), FORMULA_SPHERICAL))[1:])
+    base["life"] = (life_constant,) + tuple(kw.get("life", (1.0, 0.0, 0.0))[1:])
+    p = spawn_params(chunk_size, first, last, total_spawned, randomness_offset, **base)
+    count = len(positions)
+    rate = float(polygon_rate) if polygon_rate is not None else 0.0
+    if rate >= 1:
+        c = count - 1 if (not polygon_loop and count > 1) else count
+        w = math.fmod(np.float32(total_spawned / rate), float(c))
+    else:
+        w = total_spawned % count
+    p.ChunkSizeAndIndices[3] = w
+    p.PositionConstantCount = float(count)
+    buf = np.zeros((count, 4), np.float32)
+    buf[:, :3] = np.asarray(positions, np.float32)
+    buf[:, 3] = life_constant
+    return p, buf
+
+
+def feedback_params(source_system_handle, source_chunk_index, source_index, instance_multiplier=1, source_velocity_factor=0.0,
+                    align_position_constant=True, multiply_life=False, multiply_color_constant=False, source_life_range=(0.0, 9999.0)):
+    """FeedbackSpawner.SetParameters, SpecialSpawners.cs:411-427 (defaults :262-300)."""
+    f = abi.FeedbackParams()
+    f.SourceSystem = source_system_handle
+    f.SourceChunkIndex = source_chunk_index
+    f.FeedbackSourceIndex = float(source_index)
+    f.InstanceMultiplier = float(instance_multiplier)
+    f.SourceVelocityFactor = source_velocity_factor
+    f.AlignPositionConstant = 1.0 if align_position_constant else 0.0
+    f.MultiplyLife = 1.0 if multiply_life else 0.0
+    f.MultiplyAttributeConstant = 1.0 if multiply_color_constant else 0.0
+    f.SourceLifeRange[0], f.SourceLifeRange[1] = source_life_range
+    return f
+
+
 FORMULA_LINEAR, FORMULA_SPHERICAL, FORMULA_TOWARDS, FORMULA_RECTANGULAR = 0, 1, 2, 3
 
 

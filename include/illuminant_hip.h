@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ILM_ABI_VERSION 1
+#define ILM_ABI_VERSION 2
 
 /* ---- return codes ------------------------------------------------------ */
 #define ILM_OK                    0
@@ -181,19 +181,40 @@ typedef struct IlmUpdateParams {
     IlmFloat4 LifeRampSettings;              /* strength, min, divisor, indexDivisor; x==0 => off */
 } IlmUpdateParams;
 
+/* MatrixMultiply.SetParameters -- Illuminant/Particles/Transforms.cs:61-66; shader
+ * Illuminant/Shaders/MatrixMultiply.fx:4-52 (mul3: Illuminant/Shaders/ParticleCommon.fxh:183-196). */
+typedef struct IlmMatrixMultiplyParams {
+    IlmAreaParams Area;
+    float     TimeDivisor;  float _pad[3];     /* 1000 / CyclesPerSecond, or -1 => timeScale 1 */
+    IlmMatrix PositionMatrix, VelocityMatrix;
+} IlmMatrixMultiplyParams;
+
+/* SpatialNoise.SetParameters -- Illuminant/Particles/Transforms.cs:275-300 on top of Noise's; shader
+ * Illuminant/Shaders/Noise.fx:17,74-116 (smoothRandomCustom: bilinear, WRAP, on the Rgba64 copy of the
+ * randomness table, Illuminant/Shaders/RandomCommon.fxh:7-15,36-39, Illuminant/Particles/ParticleEngine.cs:508-540). */
+typedef struct IlmSpatialNoiseParams {
+    IlmNoiseParams Noise;            /* PositionMinimum / VelocityMinimum are not read by this technique */
+    float     SpaceScale[2];         /* 1 / SpaceScale.X, 1 / SpaceScale.Y */
+    float     _pad[2];
+} IlmSpatialNoiseParams;
+
 enum {
-    ILM_OP_GRAVITY = 1,   /* technique Gravity, Illuminant/Shaders/Gravity.fx:12-61 */
-    ILM_OP_NOISE   = 2,   /* technique Noise,   Illuminant/Shaders/Noise.fx:28-72   */
-    ILM_OP_FMA     = 3    /* technique FMA,     Illuminant/Shaders/FMA.fx:15-51     */
+    ILM_OP_GRAVITY         = 1,   /* technique Gravity,        Illuminant/Shaders/Gravity.fx:12-61        */
+    ILM_OP_NOISE           = 2,   /* technique Noise,          Illuminant/Shaders/Noise.fx:28-72          */
+    ILM_OP_FMA             = 3,   /* technique FMA,            Illuminant/Shaders/FMA.fx:15-51            */
+    ILM_OP_MATRIX_MULTIPLY = 4,   /* technique MatrixMultiply, Illuminant/Shaders/MatrixMultiply.fx:22-52 */
+    ILM_OP_SPATIAL_NOISE   = 5    /* technique SpatialNoise,   Illuminant/Shaders/Noise.fx:74-116         */
 };
 
 typedef struct IlmTransformOp {
     int32_t Type;
     int32_t _pad[3];
     union {
-        IlmGravityParams Gravity;
-        IlmNoiseParams   Noise;
-        IlmFMAParams     FMA;
+        IlmGravityParams        Gravity;
+        IlmNoiseParams          Noise;
+        IlmFMAParams            FMA;
+        IlmMatrixMultiplyParams MatrixMultiply;
+        IlmSpatialNoiseParams   SpatialNoise;
     } u;
 } IlmTransformOp;
 
@@ -209,10 +230,33 @@ enum {
 
 #define ILM_STEP_COUNT_LIVE  1u   /* also produce per-chunk live counts (CountLiveParticles.fx) */
 
+enum {
+    ILM_SPAWN_INLINE           = 0,  /* technique SpawnParticles (<= 4 inline positions), SpawnParticles.fx:10-30 */
+    ILM_SPAWN_POSITION_BUFFER  = 1,  /* technique SpawnParticlesFromPositionTexture, SpawnParticles.fx:32-52: positions from
+                                        the list bound with ilm_system_set_spawn_positions */
+    ILM_SPAWN_FEEDBACK         = 2   /* technique SpawnFeedbackParticles, SpawnParticles.fx:54-118: one source particle of
+                                        another system's chunk per InstanceMultiplier new particles */
+};
+
+/* FeedbackSpawner.SetParameters (Illuminant/Particles/SpecialSpawners.cs:411-427) + the source chunk bound by
+ * UpdateHandler._BeforeDraw (Illuminant/Particles/ParticleTransform.cs:129-141, SourceChunkSizeAndTexel). */
+typedef struct IlmFeedbackParams {
+    IlmHandle SourceSystem;            /* system that owns the source chunk (same engine chunk size) */
+    int32_t   SourceChunkIndex;        /* index in the source system's chunk table */
+    float     FeedbackSourceIndex;     /* first source slot */
+    float     InstanceMultiplier;
+    float     SourceVelocityFactor;
+    float     AlignPositionConstant, MultiplyLife, MultiplyAttributeConstant;
+    float     SourceLifeRange[2];
+    float     _pad;
+} IlmFeedbackParams;
+
 typedef struct IlmSpawnRecord {
     int32_t        ChunkIndex;    /* index in the system's chunk table */
-    int32_t        _pad[3];
+    int32_t        Kind;          /* ILM_SPAWN_* */
+    int32_t        _pad[2];
     IlmSpawnParams Params;
+    IlmFeedbackParams Feedback;   /* read when Kind == ILM_SPAWN_FEEDBACK */
 } IlmSpawnRecord;
 
 /* One ParticleSystem.Update's worth of GPU work (Illuminant/Particles/ParticleSystem.cs:725-745):
@@ -326,6 +370,12 @@ int32_t ilm_system_set_distance_field(IlmHandle system, IlmHandle sdf);
 /* Optional life ramp texture (ParticleSystem.cs:911-941): width*height float4, POINT, U clamp / V wrap. */
 int32_t ilm_system_set_life_ramp(IlmHandle system, const IlmFloat4* texels, int32_t width, int32_t height);
 
+/* The Spawner's PositionBuffer texture (Illuminant/Particles/ParticleSpawner.cs:301-353): `count` (xyz, life) position
+ * constants for spawn record `spawn_slot` (0 .. ILM_MAX_SPAWNS-1) of this system, used by records of kind
+ * ILM_SPAWN_POSITION_BUFFER.  The reference pads the texture width to a multiple of 128 and addresses it with
+ * index * (1 / width), POINT / CLAMP; the same arithmetic is applied here.  count == 0 releases the list. */
+int32_t ilm_system_set_spawn_positions(IlmHandle system, int32_t spawn_slot, const IlmFloat4* positions, int32_t count);
+
 /* The hot path.  Replaces RunSpawner + the UpdateChunk loop of
  * ParticleSystem.Update (ParticleSystem.cs:725-745, 791-856): every RunTransform
  * draw for every chunk becomes one launch. */
@@ -337,6 +387,8 @@ int32_t ilm_spawn  (IlmHandle system, int32_t chunk_index, const IlmParticleSyst
 int32_t ilm_gravity(IlmHandle system, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmGravityParams* p);
 int32_t ilm_noise  (IlmHandle system, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmNoiseParams* p);
 int32_t ilm_fma    (IlmHandle system, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmFMAParams* p);
+int32_t ilm_matrix_multiply(IlmHandle system, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmMatrixMultiplyParams* p);
+int32_t ilm_spatial_noise  (IlmHandle system, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmSpatialNoiseParams* p);
 int32_t ilm_update (IlmHandle system, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmUpdateParams* p,
                     const IlmDistanceFieldUniforms* df /* NULL => UpdatePositions */);
 int32_t ilm_erase  (IlmHandle system, int32_t chunk_index);

@@ -958,6 +958,8 @@ uint32_t orc_count_live(const IlmFloat4* pos, int32_t slots, int32_t saturate16)
     return n;
 }
 
+#include "ilm_oracle_transforms.c"
+
 /* ParticleSystem.Update pass order, ParticleSystem.cs:725-745 + UpdateChunk :791-856.
  * Every pass is slot-local (a slot reads only its own previous state, the randomness table and the SDF),
  * so the chunk table is cut into bands of rows and each band goes through spawn -> transforms -> update on
@@ -966,6 +968,24 @@ void orc_step(IlmFloat4** planes, int32_t chunk_count, int32_t chunk_size,
               const IlmFloat4* rnd, int32_t rw, int32_t rh,
               const IlmFloat4* life_ramp, int32_t ramp_w, int32_t ramp_h,
               const OrcTexture* sdf, const IlmStepDesc* desc, uint32_t* live_counts) {
+    orc_step_ex(planes, chunk_count, chunk_size, rnd, rw, rh, life_ramp, ramp_w, ramp_h, sdf, desc, live_counts, NULL);
+}
+
+void orc_step_ex(IlmFloat4** planes, int32_t chunk_count, int32_t chunk_size,
+                 const IlmFloat4* rnd, int32_t rw, int32_t rh,
+                 const IlmFloat4* life_ramp, int32_t ramp_w, int32_t ramp_h,
+                 const OrcTexture* sdf, const IlmStepDesc* desc, uint32_t* live_counts, const OrcStepExtras* ex) {
+    static const OrcStepExtras no_extras;
+    if (!ex) ex = &no_extras;
+    /* SpatialNoise reads the Rgba64 copy of the randomness table */
+    uint16_t* lp_owned = NULL;
+    const uint16_t* lp = ex->low_precision_rnd;
+    for (int o = 0; o < desc->OpCount && !lp; o++)
+        if (desc->Ops[o].Type == ILM_OP_SPATIAL_NOISE) {
+            lp_owned = (uint16_t*)malloc(sizeof(uint16_t) * 4 * (size_t)rw * (size_t)rh);
+            orc_low_precision_randomness(rnd, rw * rh, lp_owned);
+            lp = lp_owned;
+        }
     int first = desc->FirstChunk, count = desc->ChunkCount;
     if (count < 0) { first = 0; count = chunk_count; }
     const int band = chunk_size >= 64 ? 16 : chunk_size;           /* rows per task */
@@ -981,7 +1001,7 @@ void orc_step(IlmFloat4** planes, int32_t chunk_count, int32_t chunk_size,
         /* spawners run first and may target chunks outside [first, first + count) */
         for (int s = 0; s < desc->SpawnCount; s++)
             if (desc->Spawns[s].ChunkIndex == c)
-                spawn_rows(pos, vel, attr, chunk_size, y0, y1, rnd, rw, rh, &desc->Spawns[s].Params);
+                spawn_record_rows(pos, vel, attr, chunk_size, y0, y1, rnd, rw, rh, &desc->Spawns[s], s, ex);
         if (c < first || c >= first + count)
             continue;
         for (int o = 0; o < desc->OpCount; o++) {
@@ -990,6 +1010,8 @@ void orc_step(IlmFloat4** planes, int32_t chunk_count, int32_t chunk_size,
                 case ILM_OP_GRAVITY: gravity_rows(pos, vel, chunk_size, y0, y1, &desc->System, &op->u.Gravity); break;
                 case ILM_OP_NOISE:   noise_rows(pos, vel, chunk_size, y0, y1, rnd, rw, rh, &desc->System, &op->u.Noise); break;
                 case ILM_OP_FMA:     fma_rows(pos, vel, chunk_size, y0, y1, &desc->System, &op->u.FMA); break;
+                case ILM_OP_MATRIX_MULTIPLY: matrix_multiply_rows(pos, vel, chunk_size, y0, y1, &desc->System, &op->u.MatrixMultiply); break;
+                case ILM_OP_SPATIAL_NOISE:   spatial_noise_rows(pos, vel, chunk_size, y0, y1, lp, rw, rh, &desc->System, &op->u.SpatialNoise); break;
                 default: break;
             }
         }
@@ -1011,6 +1033,7 @@ void orc_step(IlmFloat4** planes, int32_t chunk_count, int32_t chunk_size,
     if (live_counts && (desc->Flags & ILM_STEP_COUNT_LIVE))
         for (int c = first; c < first + count && c < chunk_count; c++)
             live_counts[c] = orc_count_live(planes[c * 5 + 0], chunk_size * chunk_size, 0);
+    free(lp_owned);
 }
 
 /* ---------------------------------------------------------------------------

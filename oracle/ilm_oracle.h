@@ -61,6 +61,27 @@ void orc_step(IlmFloat4** planes, int32_t chunk_count, int32_t chunk_size,
               const IlmFloat4* life_ramp, int32_t ramp_w, int32_t ramp_h,
               const OrcTexture* sdf, const IlmStepDesc* desc, uint32_t* live_counts /* may be NULL */);
 
+/* remaining particle techniques, ilm_oracle_transforms.c */
+void orc_matrix_multiply(IlmFloat4* pos, IlmFloat4* vel, int32_t chunk_size,
+                         const IlmParticleSystemUniforms* sys, const IlmMatrixMultiplyParams* p);
+void orc_low_precision_randomness(const IlmFloat4* rnd, int32_t count, uint16_t* out /* count * 4 */);
+void orc_spatial_noise(IlmFloat4* pos, IlmFloat4* vel, int32_t chunk_size, const uint16_t* low_precision_rnd, int32_t rw, int32_t rh,
+                       const IlmParticleSystemUniforms* sys, const IlmSpatialNoiseParams* p);
+/* what orc_step cannot find in the descriptor: the position lists of ILM_SPAWN_POSITION_BUFFER records and the planes of the
+ * source chunk of ILM_SPAWN_FEEDBACK records, per spawn record slot */
+typedef struct OrcStepExtras {
+    const IlmFloat4* spawn_positions[ILM_MAX_SPAWNS];
+    int32_t          spawn_position_count[ILM_MAX_SPAWNS];
+    const IlmFloat4* source_pos[ILM_MAX_SPAWNS];
+    const IlmFloat4* source_vel[ILM_MAX_SPAWNS];
+    const IlmFloat4* source_attr[ILM_MAX_SPAWNS];
+    const uint16_t*  low_precision_rnd;       /* optional: the Rgba64 randomness copy (computed per call when NULL) */
+} OrcStepExtras;
+void orc_step_ex(IlmFloat4** planes, int32_t chunk_count, int32_t chunk_size,
+                 const IlmFloat4* rnd, int32_t rw, int32_t rh,
+                 const IlmFloat4* life_ramp, int32_t ramp_w, int32_t ramp_h,
+                 const OrcTexture* sdf, const IlmStepDesc* desc, uint32_t* live_counts, const OrcStepExtras* extras);
+
 /* bezier / distance field primitives exposed for known-answer tests */
 float orc_bezier1(const IlmClampedBezier1* b, float value);
 void  orc_bezier4(const IlmClampedBezier4* b, float value, IlmFloat4* out);

@@ -21,7 +21,7 @@ def build(force=False):
     """Compile the C restatement with gcc (oracle/Makefile)."""
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-            for f in ("ilm_oracle.c", "ilm_oracle_fields.c", "ilm_oracle.h")):
+            for f in ("ilm_oracle.c", "ilm_oracle_fields.c", "ilm_oracle_transforms.c", "ilm_oracle.h")):
         subprocess.run(["make", "-C", _HERE, "-s"], check=True)
     return _LIB_PATH
 
@@ -130,6 +130,28 @@ def update(pos, vel, attr, rc, rd, chunk_size, sys, p, life_ramp=None, df=None, 
                      C.byref(df) if df is not None else None, C.byref(sdf) if sdf is not None else None)
 
 
+def matrix_multiply(pos, vel, chunk_size, sys, p):
+    lib().orc_matrix_multiply(_f4(pos), _f4(vel), chunk_size, C.byref(sys), C.byref(p))
+
+
+def low_precision_randomness(rnd):
+    """The Rgba64 copy of the randomness table (ParticleEngine.cs:536-538): (H, W, 4) uint16."""
+    out = np.empty(rnd.shape, dtype=np.uint16)
+    lib().orc_low_precision_randomness(_f4(rnd), C.c_int32(rnd.shape[0] * rnd.shape[1]), _p(out))
+    return out
+
+
+def spatial_noise(pos, vel, chunk_size, rnd, sys, p):
+    lp = low_precision_randomness(rnd)
+    lib().orc_spatial_noise(_f4(pos), _f4(vel), chunk_size, _p(lp), rnd.shape[1], rnd.shape[0], C.byref(sys), C.byref(p))
+
+
+class StepExtras(C.Structure):
+    _fields_ = [("spawn_positions", C.c_void_p * abi.MAX_SPAWNS), ("spawn_position_count", C.c_int32 * abi.MAX_SPAWNS),
+                ("source_pos", C.c_void_p * abi.MAX_SPAWNS), ("source_vel", C.c_void_p * abi.MAX_SPAWNS),
+                ("source_attr", C.c_void_p * abi.MAX_SPAWNS), ("low_precision_rnd", C.c_void_p)]
+
+
 def erase(pos, vel, rc, rd, chunk_size):
     lib().orc_erase(_f4(pos), _f4(vel), _f4(rc), _f4(rd), chunk_size)
 
@@ -138,8 +160,10 @@ def count_live(pos, saturate16=False):
     return int(lib().orc_count_live(_f4(pos), pos.shape[0], 1 if saturate16 else 0))
 
 
-def step(chunks, chunk_size, rnd, desc, life_ramp=None, sdf=None, want_counts=False):
-    """chunks: list of dicts/tuples of 5 planes (pos, vel, attr, rc, rd) per chunk."""
+def step(chunks, chunk_size, rnd, desc, life_ramp=None, sdf=None, want_counts=False, spawn_positions=None, feedback_sources=None):
+    """chunks: list of dicts/tuples of 5 planes (pos, vel, attr, rc, rd) per chunk.
+    spawn_positions: {spawn slot: (n, 4) float32} for ILM_SPAWN_POSITION_BUFFER records;
+    feedback_sources: {spawn slot: (pos, vel, attr) planes of the source chunk} for ILM_SPAWN_FEEDBACK records."""
     n = len(chunks)
     ptrs = (C.c_void_p * (n * 5))()
     for c, planes in enumerate(chunks):
@@ -149,8 +173,17 @@ def step(chunks, chunk_size, rnd, desc, life_ramp=None, sdf=None, want_counts=Fa
     rw = rh = 0
     if life_ramp is not None:
         rh, rw = life_ramp.shape[0], life_ramp.shape[1]
-    lib().orc_step(ptrs, n, chunk_size, _f4(rnd), rnd.shape[1], rnd.shape[0], _p(life_ramp), rw, rh,
-                   C.byref(sdf) if sdf is not None else None, C.byref(desc), _p(counts))
+    ex = StepExtras()
+    keep = []
+    for slot, a in (spawn_positions or {}).items():
+        a = np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 4)
+        keep.append(a)
+        ex.spawn_positions[slot] = a.ctypes.data
+        ex.spawn_position_count[slot] = a.shape[0]
+    for slot, (sp, sv, sa) in (feedback_sources or {}).items():
+        ex.source_pos[slot], ex.source_vel[slot], ex.source_attr[slot] = _f4(sp).value, _f4(sv).value, _f4(sa).value
+    lib().orc_step_ex(ptrs, n, chunk_size, _f4(rnd), rnd.shape[1], rnd.shape[0], _p(life_ramp), rw, rh,
+                      C.byref(sdf) if sdf is not None else None, C.byref(desc), _p(counts), C.byref(ex))
     return counts
 
 

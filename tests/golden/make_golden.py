@@ -458,8 +458,71 @@ def gen_distance_field_generation():
             "tolerance": "+-1 unorm16 code (1.5e-5 of the encoded range, 0.002 world units)", "cases": cases}
 
 
+# ---------------------------------------------------------------------------------------------------------
+# 9. Remaining particle techniques: closed forms derived by hand from MatrixMultiply.fx:22-52 + mul3
+#    (ParticleCommon.fxh:183-196), Noise.fx:74-116 (SpatialNoise), SpawnParticles.fx:32-118 (position texture, feedback)
+# ---------------------------------------------------------------------------------------------------------
+def gen_transforms_ext():
+    cases = []
+    dt = 1.0 / 60.0
+    w = (dt * 1000.0) / 100.0          # Strength 1, no area => weight 1; timeScale = dtMs / (1000 / 10 cycles per second)
+    # (a) translation by (5,-3,2) (row-vector convention: M41..M43) + velocity scaled by .5: lerp(p, p + T, w), lerp(v, .5 v, w);
+    #     life / category (w components) come back unchanged from mul3
+    T = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 5, -3, 2, 1]
+    S = [0.5, 0, 0, 0, 0, 0.5, 0, 0, 0, 0, 0.5, 0, 0, 0, 0, 1]
+    pos, vel = [10.0, 20.0, 30.0, 2.0], [6.0, -12.0, 3.0, 7.0]
+    cases.append({"kind": "matrix_multiply", "position": pos, "velocity": vel, "position_matrix": T, "velocity_matrix": S,
+                  "cycles_per_second": 10.0, "strength": 1.0, "dt": dt,
+                  "expected_position": [10.0 + 5 * w, 20.0 - 3 * w, 30.0 + 2 * w, 2.0],
+                  "expected_velocity": [6.0 * (1 - 0.5 * w), -12.0 * (1 - 0.5 * w), 3.0 * (1 - 0.5 * w), 7.0]})
+    # (b) M44 = 2: positions are divided by temp.w (w argument 1), velocities are not (w argument 0)
+    H2 = [1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 2]
+    cases.append({"kind": "matrix_multiply", "position": pos, "velocity": vel, "position_matrix": H2, "velocity_matrix": H2,
+                  "cycles_per_second": 10.0, "strength": 1.0, "dt": dt,
+                  "expected_position": [10.0 * (1 - 0.5 * w), 20.0 * (1 - 0.5 * w), 30.0 * (1 - 0.5 * w), 2.0],
+                  "expected_velocity": vel})
+    # (c) CyclesPerSecond == null => TimeDivisor -1 => timeScale 1: the weight is the Strength itself
+    cases.append({"kind": "matrix_multiply", "position": pos, "velocity": vel, "position_matrix": T, "velocity_matrix": S,
+                  "cycles_per_second": None, "strength": 0.25, "dt": dt,
+                  "expected_position": [10.0 + 5 * 0.25, 20.0 - 3 * 0.25, 30.0 + 2 * 0.25, 2.0],
+                  "expected_velocity": [6.0 * 0.875, -12.0 * 0.875, 3.0 * 0.875, 7.0]})
+    # (d) dead slots and filtered categories pass through untouched
+    cases.append({"kind": "matrix_multiply", "position": [1.0, 2.0, 3.0, 0.0], "velocity": vel, "position_matrix": T, "velocity_matrix": S,
+                  "cycles_per_second": 10.0, "strength": 1.0, "dt": dt, "expected_position": [1.0, 2.0, 3.0, 0.0], "expected_velocity": vel})
+    # (e) SpatialNoise on a constant randomness table c: every bilinear tap returns q = round(c * 65535) / 65535, so
+    #     positionDelta = (q + offset) * scale everywhere; t = 1/6; ReplaceOldVelocity => v' = lerp(v, vDelta, weight 1) + normalize(v) * delta.w
+    c = 0.75
+    q = round(c * 65535.0) / 65535.0
+    pd = [(q - 0.5) * 2.0, (q - 0.5) * 4.0, (q - 0.5) * 6.0]
+    vd = [(q - 0.5) * 10.0, (q - 0.5) * 20.0, (q - 0.5) * 30.0]
+    cases.append({"kind": "spatial_noise", "table_value": c, "position": [100.0, 50.0, 5.0, 3.0], "velocity": [3.0, 4.0, 0.0, 1.0],
+                  "position_scale": [2.0, 4.0, 6.0, 0.0], "velocity_scale": [10.0, 20.0, 30.0], "speed_scale": 5.0, "space_scale": [8.0, 8.0],
+                  "cycles_per_second": 10.0, "dt": dt, "replace_old_velocity": True,
+                  "expected_position": [100.0 + pd[0] * w, 50.0 + pd[1] * w, 5.0 + pd[2] * w, 3.0],
+                  "expected_velocity": [vd[0] + 0.6 * (q - 0.5) * 5.0, vd[1] + 0.8 * (q - 0.5) * 5.0, vd[2], 1.0]})
+    cases.append({"kind": "spatial_noise", "table_value": c, "position": [100.0, 50.0, 5.0, 3.0], "velocity": [3.0, 4.0, 0.0, 1.0],
+                  "position_scale": [2.0, 4.0, 6.0, 0.0], "velocity_scale": [10.0, 20.0, 30.0], "speed_scale": 0.0, "space_scale": [8.0, 8.0],
+                  "cycles_per_second": 10.0, "dt": dt, "replace_old_velocity": False,
+                  "expected_position": [100.0 + pd[0] * w, 50.0 + pd[1] * w, 5.0 + pd[2] * w, 3.0],
+                  "expected_velocity": [3.0 + vd[0] * w, 4.0 + vd[1] * w, 0.0 + vd[2] * w, 1.0]})
+    # (f) position texture: 6 positions, no polygon rate: slot first + k spawns at position (k + TotalSpawned % 6) % 6 exactly
+    #     (position scale / offset 0 => the constant itself; life constant 2.5)
+    positions = [[10.0 * i, 100.0 - i, 1.0 + i] for i in range(6)]
+    cases.append({"kind": "position_buffer", "positions": positions, "first": 40, "last": 52, "total_spawned": 15, "life": 2.5,
+                  "expected": [{"slot": 40 + k, "position": positions[(k + 15 % 6) % 6] + [2.5]} for k in range(13)]})
+    # (g) feedback: new particle k (slot first + k) reads source slot floor(k / InstanceMultiplier) + FeedbackSourceIndex, lands on the
+    #     source position (AlignPositionConstant, constant 0) and inherits SourceVelocityFactor * source velocity; sources outside
+    #     SourceLifeRange are skipped (the slot keeps its old contents)
+    cases.append({"kind": "feedback", "instance_multiplier": 3, "source_index": 20, "first": 100, "last": 111, "source_velocity_factor": 0.5,
+                  "source_life_range": [0.5, 9999.0], "dead_source_slots": [22],
+                  "expected_source_of_slot": {str(100 + k): 20 + k // 3 for k in range(12)}})
+    return {"source": "hand-derived from MatrixMultiply.fx:22-52, ParticleCommon.fxh:183-196, Noise.fx:74-116, RandomCommon.fxh:36-39, "
+                      "SpawnParticles.fx:32-118, ParticleSpawner.cs:301-367 (see comments in make_golden.py)",
+            "tolerance": "1e-5 relative", "cases": cases}
+
+
 def main():
-    out = {"distance_field_generation.json": gen_distance_field_generation(), "bezier.json": gen_bezier(), "distance_field_layout.json": gen_layout(), "spawner.json": gen_spawner(),
+    out = {"transforms_ext.json": gen_transforms_ext(), "distance_field_generation.json": gen_distance_field_generation(), "bezier.json": gen_bezier(), "distance_field_layout.json": gen_layout(), "spawner.json": gen_spawner(),
            "liveness.json": gen_liveness(), "distance_encoding.json": gen_encoding(), "gbuffer.json": gen_gbuffer(),
            "closed_form.json": gen_closed_form()}
     for name, doc in out.items():
