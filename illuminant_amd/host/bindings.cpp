@@ -179,6 +179,15 @@ PYBIND11_MODULE(_host, m) {
         .def_readonly("CurrentU", &Noise::CurrentU).def_readonly("CurrentV", &Noise::CurrentV)
         .def_readonly("NextU", &Noise::NextU).def_readonly("NextV", &Noise::NextV);
 
+    py::class_<SpatialNoise, Noise>(m, "SpatialNoise").def(py::init<uint64_t>(), py::arg("seed") = 1)
+        VEC_PROP(SpatialNoise, SpaceScale, 2);
+    py::class_<MatrixMultiply, ParticleAreaTransform>(m, "MatrixMultiply").def(py::init<>())
+        .def_readwrite("CyclesPerSecond", &MatrixMultiply::CyclesPerSecond)
+        .def_property("Position", [](const MatrixMultiply& t) { return std::vector<float>(t.Position.m, t.Position.m + 16); },
+                      [](MatrixMultiply& t, const std::vector<float>& v) { for (int i = 0; i < 16; i++) t.Position.m[i] = v.at((size_t)i); })
+        .def_property("Velocity", [](const MatrixMultiply& t) { return std::vector<float>(t.Velocity.m, t.Velocity.m + 16); },
+                      [](MatrixMultiply& t, const std::vector<float>& v) { for (int i = 0; i < 16; i++) t.Velocity.m[i] = v.at((size_t)i); });
+
     py::enum_<AttractorType>(m, "AttractorType").value("Physical", AttractorType::Physical).value("Linear", AttractorType::Linear)
         .value("Exponential", AttractorType::Exponential);
     py::class_<Gravity::Attractor>(m, "Attractor").def(py::init<>())
@@ -220,7 +229,20 @@ PYBIND11_MODULE(_host, m) {
         .def_readwrite("PolygonRate", &Spawner::PolygonRate).def_readwrite("PolygonLoop", &Spawner::PolygonLoop)
         .def_readwrite("VelocityAlongPolygon", &Spawner::VelocityAlongPolygon).def_readwrite("RatePerPosition", &Spawner::RatePerPosition);
 
+    py::class_<FeedbackSpawner, SpawnerBase>(m, "FeedbackSpawner").def(py::init<uint64_t>(), py::arg("seed") = 1)
+        .def_property("SourceSystem", py::cpp_function([](FeedbackSpawner& s) { return s.SourceSystem; }, py::return_value_policy::reference),
+                      py::cpp_function([](FeedbackSpawner& s, ParticleSystem* p) { s.SourceSystem = p; }, py::keep_alive<1, 2>()))
+        .def_readwrite("SlidingWindowSize", &FeedbackSpawner::SlidingWindowSize).def_readwrite("SlidingWindowMargin", &FeedbackSpawner::SlidingWindowMargin)
+        .def_readwrite("SpawnFromEntireWindow", &FeedbackSpawner::SpawnFromEntireWindow)
+        .def_readwrite("InstanceMultiplier", &FeedbackSpawner::InstanceMultiplier)
+        .def_readwrite("AlignPositionConstant", &FeedbackSpawner::AlignPositionConstant)
+        .def_readwrite("SourceVelocityFactor", &FeedbackSpawner::SourceVelocityFactor)
+        .def_readwrite("MultiplyLife", &FeedbackSpawner::MultiplyLife).def_readwrite("MultiplyColorConstant", &FeedbackSpawner::MultiplyColorConstant)
+        VEC_PROP(FeedbackSpawner, SourceLifeRange, 2);
+
     py::class_<ParticleSystem::Chunk>(m, "Chunk")
+        .def_readonly("IsFeedbackSource", &ParticleSystem::Chunk::IsFeedbackSource)
+        .def_readonly("TotalConsumedForFeedback", &ParticleSystem::Chunk::TotalConsumedForFeedback)
         .def_readonly("ID", &ParticleSystem::Chunk::ID).def_readonly("NextSpawnOffset", &ParticleSystem::Chunk::NextSpawnOffset)
         .def_readonly("TotalSpawned", &ParticleSystem::Chunk::TotalSpawned)
         .def_readonly("NoLongerASpawnTarget", &ParticleSystem::Chunk::NoLongerASpawnTarget)

@@ -409,9 +409,6 @@ int Spawner::CountScale() const {
 void Spawner::FillSpawn(IlmSpawnParams& p, int chunkSize, double now) {
     SpawnerBase::FillSpawn(p, chunkSize, now);
     int count = 1 + (int)AdditionalPositions.size();
-    if (count > MaxInlinePositions)
-        // the reference switches to SpawnFromPositionTexture here (:295-299); that technique is a "next" row
-        throw InvalidOperationException("more than 3 AdditionalPositions needs SpawnParticlesFromPositionTexture (not built yet)");
     // GetChunkSizeAndIndices, :361-374
     {
         int c = count;
@@ -434,6 +431,132 @@ void Spawner::FillSpawn(IlmSpawnParams& p, int chunkSize, double now) {
     // InitConfiguration, :393-403
     p.Configuration[8] = { VelocityAlongPolygon.Constant, VelocityAlongPolygon.RandomScale, VelocityAlongPolygon.Offset, 0 };
     p.FormulaTypes[3] = 0;
+}
+
+// GetMaterial (:295-299): SpawnFromPositionTexture once the inline constants no longer hold the positions; BeginTick's
+// Temp4 (:326-345) is the PositionBuffer content: (Position.Constant, life), then (AdditionalPositions[i], life)
+void Spawner::FillRecord(IlmSpawnRecord& rec, std::vector<IlmFloat4>& positions, int chunkSize, double now) {
+    positions.clear();
+    FillSpawn(rec.Params, chunkSize, now);
+    const int count = 1 + (int)AdditionalPositions.size();
+    if (count > MaxInlinePositions) {
+        rec.Kind = ILM_SPAWN_POSITION_BUFFER;
+        positions.push_back({ Position.Constant.X, Position.Constant.Y, Position.Constant.Z, Life.Constant });
+        for (const Vector3& ap : AdditionalPositions)
+            positions.push_back({ ap.X, ap.Y, ap.Z, Life.Constant });
+    } else {
+        rec.Kind = ILM_SPAWN_INLINE;
+    }
+}
+
+// ---- FeedbackSpawner, SpecialSpawners.cs:243-443 -----------------------------------------------------------
+void FeedbackSpawner::BeginTick(ParticleSystem& system, double now, double deltaTimeSeconds, int& spawnCount, int& sourceChunkIndex) {
+    if (InstanceMultiplier < 1)
+        InstanceMultiplier = 1;
+    spawnCount = 0;
+    sourceChunkIndex = -1;
+    currentFeedbackSource = -1;
+    if (!SourceSystem)
+        return;
+    // "FIXME: Support using the same system as a feedback input?" (:347-349)
+    if (SourceSystem == &system)
+        return;
+    SpawnerBase::BeginTick(now, deltaTimeSeconds, spawnCount);
+
+    if ((spawnCount < InstanceMultiplier) && !SpawnFromEntireWindow) {
+        AddError(spawnCount);
+        spawnCount = 0;
+        return;
+    }
+    const int instances = spawnCount / InstanceMultiplier;
+    const int rounded = instances * InstanceMultiplier;
+    if (rounded < spawnCount) {
+        if (rounded > 0) {
+            AddError(spawnCount - rounded);
+            spawnCount = rounded;
+        }
+    }
+    sourceChunkIndex = SourceSystem->PickSourceForFeedback(instances);
+    if (sourceChunkIndex < 0) {
+        spawnCount = 0;
+        return;
+    }
+    ParticleSystem::Chunk& sourceChunk = SourceSystem->ChunkAt(sourceChunkIndex);
+    const int windowSize = SlidingWindowSize.value_or(999999);
+    int availableForFeedback = sourceChunk.AvailableForFeedback();
+    if (sourceChunk.NoLongerASpawnTarget) {
+        const int currentWriteChunk = SourceSystem->GetCurrentSpawnTarget(false);
+        if (currentWriteChunk >= 0)
+            availableForFeedback += SourceSystem->ChunkAt(currentWriteChunk).AvailableForFeedback();
+    }
+    const int windowedAvailable = std::min(availableForFeedback, windowSize);
+    const int skipAmount = std::max(0, availableForFeedback - windowedAvailable);
+    sourceChunk.SkipFeedbackInput(skipAmount);
+    const int availableLessMargin = std::max(0, windowedAvailable - SlidingWindowMargin);
+    const int maximumPossibleSpawns = availableLessMargin * InstanceMultiplier;
+    spawnCount = std::min(spawnCount, maximumPossibleSpawns);
+    spawnCount = std::min(spawnCount, sourceChunk.AvailableForFeedback() * InstanceMultiplier);
+    currentFeedbackSource = sourceChunkIndex;
+    currentFeedbackSourceIndex = sourceChunk.FeedbackSourceIndex();
+    if (SpawnFromEntireWindow) {
+        const int sourceCount = std::max(spawnCount / InstanceMultiplier, 1);
+        const int maxOffset = availableLessMargin - sourceCount;
+        if (maxOffset > 1)
+            currentFeedbackSourceIndex += (int)(RNG.NextDouble() * maxOffset);   // RNG.Next(0, maxOffset)
+    }
+}
+
+// RunSpawner, ParticleSpawning.cs:159-166
+void FeedbackSpawner::OnSpawned(int spawnCount) {
+    if (currentFeedbackSource < 0 || !SourceSystem || SpawnFromEntireWindow)
+        return;
+    const int consumedCount = std::max(spawnCount / InstanceMultiplier, 1);
+    SourceSystem->ChunkAt(currentFeedbackSource).TotalConsumedForFeedback += consumedCount;
+}
+
+// SetParameters, :411-427
+void FeedbackSpawner::FillRecord(IlmSpawnRecord& rec, std::vector<IlmFloat4>& positions, int chunkSize, double now) {
+    positions.clear();
+    FillSpawn(rec.Params, chunkSize, now);
+    rec.Kind = ILM_SPAWN_FEEDBACK;
+    rec.Params.PositionConstantCount = 1;
+    rec.Params.InlinePositionConstants[0] = { Position.Constant.X, Position.Constant.Y, Position.Constant.Z, Life.Constant };
+    IlmFeedbackParams& f = rec.Feedback;
+    f.SourceSystem = SourceSystem->Handle();
+    f.SourceChunkIndex = currentFeedbackSource;
+    f.FeedbackSourceIndex = (float)currentFeedbackSourceIndex;
+    f.InstanceMultiplier = (float)InstanceMultiplier;
+    f.SourceVelocityFactor = SourceVelocityFactor;
+    f.AlignPositionConstant = AlignPositionConstant ? 1.0f : 0.0f;
+    f.MultiplyLife = MultiplyLife ? 1.0f : 0.0f;
+    f.MultiplyAttributeConstant = MultiplyColorConstant ? 1.0f : 0.0f;
+    f.SourceLifeRange[0] = SourceLifeRange.X; f.SourceLifeRange[1] = SourceLifeRange.Y;
+}
+
+// MatrixMultiply, Transforms.cs:52-71
+MatrixMultiply::MatrixMultiply() : Position(IdentityMatrix()), Velocity(IdentityMatrix()) {}
+bool MatrixMultiply::FillOp(IlmTransformOp& op, double) {
+    std::memset(&op, 0, sizeof(op));
+    op.Type = ILM_OP_MATRIX_MULTIPLY;
+    IlmMatrixMultiplyParams& p = op.u.MatrixMultiply;
+    FillArea(p.Area);
+    p.TimeDivisor = CyclesPerSecond ? (1000 / *CyclesPerSecond) : -1.0f;
+    p.PositionMatrix = Position;
+    p.VelocityMatrix = Velocity;
+    return true;
+}
+
+// SpatialNoise.SetParameters, Transforms.cs:288-293 on top of Noise's
+bool SpatialNoise::FillOp(IlmTransformOp& op, double now) {
+    IlmTransformOp base;
+    Noise::FillOp(base, now);
+    const IlmNoiseParams noise = base.u.Noise;
+    std::memset(&op, 0, sizeof(op));
+    op.Type = ILM_OP_SPATIAL_NOISE;
+    op.u.SpatialNoise.Noise = noise;
+    op.u.SpatialNoise.SpaceScale[0] = 1.0f / SpaceScale.X;
+    op.u.SpatialNoise.SpaceScale[1] = 1.0f / SpaceScale.Y;
+    return true;
 }
 
 }  // namespace Transforms
@@ -537,23 +660,25 @@ void ParticleSystem::UpdateLiveCountAndReapDeadChunks() {
 }
 
 // PickTargetForSpawn, ParticleSpawning.cs:199-231: returns the chunk table index
-int ParticleSystem::PickTargetForSpawn(int count, bool& needClear, bool partialSpawnAllowed) {
+int ParticleSystem::PickTargetForSpawn(bool feedback, int count, bool& needClear, bool partialSpawnAllowed) {
+    int& currentTarget = feedback ? currentFeedbackSpawnTarget : currentSpawnTarget;
     int index = -1;
     for (size_t i = 0; i < chunks.size(); i++)
-        if (chunks[i].ID == currentSpawnTarget) index = (int)i;
+        if (chunks[i].ID == currentTarget) index = (int)i;
     if (index >= 0) {
         Chunk& chunk = chunks[(size_t)index];
         const int free = ChunkMaximumCount() - chunk.NextSpawnOffset;
         if (free < (partialSpawnAllowed ? 16 : count)) {
             chunk.NoLongerASpawnTarget = true;
-            currentSpawnTarget = -1;
+            currentTarget = -1;
             index = -1;
         }
     }
     if (index < 0) {
         index = CreateChunk();
         if (index < 0) { needClear = false; return -1; }
-        currentSpawnTarget = chunks[(size_t)index].ID;
+        chunks[(size_t)index].IsFeedbackSource = feedback;
+        currentTarget = chunks[(size_t)index].ID;
         needClear = true;
     } else {
         needClear = false;
@@ -561,13 +686,32 @@ int ParticleSystem::PickTargetForSpawn(int count, bool& needClear, bool partialS
     return index;
 }
 
+// GetCurrentSpawnTarget / PickSourceForFeedback, ParticleSpawning.cs:233-265
+int ParticleSystem::GetCurrentSpawnTarget(bool feedback) const {
+    const int id = feedback ? currentFeedbackSpawnTarget : currentSpawnTarget;
+    for (size_t i = 0; i < chunks.size(); i++)
+        if (chunks[i].ID == id) return (int)i;
+    return -1;
+}
+int ParticleSystem::PickSourceForFeedback(int count) {
+    for (size_t i = 0; i < chunks.size(); i++) {
+        const Chunk& c = chunks[i];
+        if ((c.AvailableForFeedback() >= count / 2) && !c.IsFeedbackSource) {
+            currentFeedbackSource = c.ID;
+            return (int)i;
+        }
+    }
+    return -1;
+}
+
 // RunSpawner, ParticleSpawning.cs:115-197
 bool ParticleSystem::RunSpawner(Transforms::SpawnerBase& spawner, double deltaTimeSeconds, double now, bool,
-                                std::vector<IlmSpawnRecord>& records) {
+                                std::vector<IlmSpawnRecord>& records, std::vector<std::vector<IlmFloat4>>& recordPositions) {
     int spawnCount = 0, requestedSpawnCount = 0;
     if (!spawner.IsValid())
         return false;
-    spawner.BeginTick(now, deltaTimeSeconds, requestedSpawnCount);
+    int sourceChunkIndex = -1;
+    spawner.BeginTick(*this, now, deltaTimeSeconds, requestedSpawnCount, sourceChunkIndex);
     if (requestedSpawnCount <= 0)
         return false;
     else if (requestedSpawnCount > ChunkMaximumCount())
@@ -576,7 +720,7 @@ bool ParticleSystem::RunSpawner(Transforms::SpawnerBase& spawner, double deltaTi
         spawnCount = requestedSpawnCount;
 
     bool needClear;
-    const int ci = PickTargetForSpawn(spawnCount, needClear, spawner.PartialSpawnAllowed());
+    const int ci = PickTargetForSpawn(spawner.IsFeedback(), spawnCount, needClear, spawner.PartialSpawnAllowed());
     if (ci < 0)
         return false;
     Chunk& chunk = chunks[(size_t)ci];
@@ -590,6 +734,8 @@ bool ParticleSystem::RunSpawner(Transforms::SpawnerBase& spawner, double deltaTi
     spawner.SetIndices(first, last);
     chunk.NextSpawnOffset += spawnCount;
     TotalSpawnCount += spawnCount;
+    if (sourceChunkIndex >= 0)
+        spawner.OnSpawned(spawnCount);
 
     spawner.EndTick(requestedSpawnCount, spawnCount);
     chunk.TotalSpawned += spawnCount;
@@ -598,8 +744,10 @@ bool ParticleSystem::RunSpawner(Transforms::SpawnerBase& spawner, double deltaTi
         IlmSpawnRecord rec;
         std::memset(&rec, 0, sizeof(rec));
         rec.ChunkIndex = ci;
-        spawner.FillSpawn(rec.Params, Engine.Configuration.ChunkSize, now);
+        std::vector<IlmFloat4> positions;
+        spawner.FillRecord(rec, positions, Engine.Configuration.ChunkSize, now);
         records.push_back(rec);
+        recordPositions.push_back(std::move(positions));
     }
     chunk.ApproximateMaximumLife = std::max(chunk.ApproximateMaximumLife, spawner.EstimateMaximumLifeForNewParticle());
     return requestedSpawnCount > spawnCount;   // isPartialSpawn
@@ -694,7 +842,7 @@ ParticleSystem::UpdateResult ParticleSystem::Update(int frameIndex) {
         }
         isClearPending = false;
         TotalSpawnCount = 0;
-        currentSpawnTarget = -1;
+        currentSpawnTarget = currentFeedbackSpawnTarget = currentFeedbackSource = -1;
         livenessPending = false;
     }
 
@@ -706,14 +854,21 @@ ParticleSystem::UpdateResult ParticleSystem::Update(int frameIndex) {
 
     // spawners first (:725-741)
     std::vector<IlmSpawnRecord> records;
+    std::vector<std::vector<IlmFloat4>> recordPositions;
     for (Transforms::ParticleTransform* t : Transforms) {
         if (!t->IsSpawner()) continue;
         auto* s = static_cast<Transforms::SpawnerBase*>(t);
         if (!s->IsActive || !s->IsActive2) continue;
-        const bool isPartialSpawn = RunSpawner(*s, actualDeltaTimeSeconds, now, false, records);
+        const bool isPartialSpawn = RunSpawner(*s, actualDeltaTimeSeconds, now, false, records, recordPositions);
         if (isPartialSpawn)
-            RunSpawner(*s, actualDeltaTimeSeconds, now, true, records);
+            RunSpawner(*s, actualDeltaTimeSeconds, now, true, records, recordPositions);
     }
+    // the PositionBuffer of a position-texture record is bound to the record slot it will occupy in its launch
+    auto bindPositions = [&](int slot, size_t recordIndex) {
+        const std::vector<IlmFloat4>& pl = recordPositions[recordIndex];
+        if (!pl.empty())
+            ThrowIfFailed(ilm_system_set_spawn_positions(handle, slot, pl.data(), (int32_t)pl.size()));
+    };
 
     // UpdateChunk (:791-856) for every chunk: transforms in list order, then exactly one update technique
     std::vector<IlmTransformOp> ops;
@@ -753,14 +908,14 @@ ParticleSystem::UpdateResult ParticleSystem::Update(int frameIndex) {
         if (spawnsLeft > ILM_MAX_SPAWNS) {
             // surplus spawn records go alone, before any transform runs
             cur.SpawnCount = ILM_MAX_SPAWNS;
-            for (int k = 0; k < ILM_MAX_SPAWNS; k++) cur.Spawns[k] = records[spawnPos + (size_t)k];
+            for (int k = 0; k < ILM_MAX_SPAWNS; k++) { cur.Spawns[k] = records[spawnPos + (size_t)k]; bindPositions(k, spawnPos + (size_t)k); }
             spawnPos += ILM_MAX_SPAWNS;
             cur.UpdateMode = ILM_UPDATE_NONE;
             Launch(cur);
             continue;
         }
         cur.SpawnCount = (int)spawnsLeft;
-        for (size_t k = 0; k < spawnsLeft; k++) cur.Spawns[k] = records[spawnPos + k];
+        for (size_t k = 0; k < spawnsLeft; k++) { cur.Spawns[k] = records[spawnPos + k]; bindPositions((int)k, spawnPos + k); }
         spawnPos = records.size();
         const size_t nOps = std::min<size_t>(opsLeft, ILM_MAX_OPS);
         cur.OpCount = (int)nOps;

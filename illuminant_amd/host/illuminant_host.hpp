@@ -346,6 +346,21 @@ public:
     virtual int CountScale() const { return 1; }
     // :152-189
     virtual void BeginTick(double now, double deltaTimeSeconds, int& spawnCount);
+    // BeginTick as RunSpawner calls it (with the target system and the source chunk out-parameter, :152);
+    // sourceChunkIndex = index in the SOURCE system's chunk table, -1 when there is none
+    virtual void BeginTick(ParticleSystem& system, double now, double deltaTimeSeconds, int& spawnCount, int& sourceChunkIndex) {
+        (void)system; sourceChunkIndex = -1; BeginTick(now, deltaTimeSeconds, spawnCount);
+    }
+    // AddError, :196-198
+    void AddError(double amount) { RateError += amount; }
+    // fills the whole record (kind, params, feedback block); positions receives the PositionBuffer contents when the
+    // record is of kind ILM_SPAWN_POSITION_BUFFER
+    virtual void FillRecord(IlmSpawnRecord& rec, std::vector<IlmFloat4>& positions, int chunkSize, double now) {
+        positions.clear(); rec.Kind = ILM_SPAWN_INLINE; FillSpawn(rec.Params, chunkSize, now);
+    }
+    virtual bool IsFeedback() const { return false; }
+    // RunSpawner's consumed-count bookkeeping for feedback sources (ParticleSpawning.cs:159-166)
+    virtual void OnSpawned(int spawnCount) { (void)spawnCount; }
     // :191-194
     void EndTick(int requestedSpawnCount, int actualSpawnCount);
     void SetIndices(int first, int last) { indexFirst = first; indexLast = last; }
@@ -371,6 +386,48 @@ public:
     explicit Spawner(uint64_t seed = 1) : SpawnerBase(seed) {}
     int CountScale() const override;
     void FillSpawn(IlmSpawnParams& p, int chunkSize, double now) override;
+    // more than MaxInlinePositions positions => technique SpawnParticlesFromPositionTexture (GetMaterial, :295-299)
+    void FillRecord(IlmSpawnRecord& rec, std::vector<IlmFloat4>& positions, int chunkSize, double now) override;
+};
+
+// SpecialSpawners.cs:243-443
+class FeedbackSpawner : public SpawnerBase {
+public:
+    explicit FeedbackSpawner(uint64_t seed = 1) : SpawnerBase(seed) {}
+    ParticleSystem* SourceSystem = nullptr;       // ParticleSystemReference, resolved
+    std::optional<int> SlidingWindowSize;
+    int SlidingWindowMargin = 0;
+    bool SpawnFromEntireWindow = false;
+    int InstanceMultiplier = 1;
+    bool AlignPositionConstant = true;
+    float SourceVelocityFactor = 0.0f;
+    bool MultiplyLife = false, MultiplyColorConstant = false;
+    Vector2 SourceLifeRange{0, 9999};
+    bool IsFeedback() const override { return true; }
+    void Reset() override { SpawnerBase::Reset(); currentFeedbackSourceIndex = 0; currentFeedbackSource = -1; }
+    void BeginTick(ParticleSystem& system, double now, double deltaTimeSeconds, int& spawnCount, int& sourceChunkIndex) override;
+    void FillRecord(IlmSpawnRecord& rec, std::vector<IlmFloat4>& positions, int chunkSize, double now) override;
+    void OnSpawned(int spawnCount) override;
+private:
+    int currentFeedbackSource = -1;        // chunk table index in the source system
+    int currentFeedbackSourceIndex = 0;
+};
+
+// Transforms.cs:52-71
+class MatrixMultiply : public ParticleAreaTransform {
+public:
+    std::optional<float> CyclesPerSecond = 10.0f;
+    IlmMatrix Position, Velocity;
+    MatrixMultiply();
+    bool FillOp(IlmTransformOp& op, double now) override;
+};
+
+// Transforms.cs:275-300
+class SpatialNoise : public Noise {
+public:
+    Vector2 SpaceScale{1, 1};
+    explicit SpatialNoise(uint64_t seed = 1) : Noise(seed) {}
+    bool FillOp(IlmTransformOp& op, double now) override;
 };
 
 }  // namespace Transforms
@@ -389,6 +446,14 @@ public:
         int ID = 0;
         int NextSpawnOffset = 0, TotalSpawned = 0;
         bool NoLongerASpawnTarget = false;
+        bool IsFeedbackSource = false;                     // ParticleSystem.cs:164
+        int TotalConsumedForFeedback = 0;                  // :168
+        int AvailableForFeedback() const { return TotalSpawned - TotalConsumedForFeedback; }   // :170-174
+        int FeedbackSourceIndex() const { return TotalConsumedForFeedback; }                   // :175-179
+        void SkipFeedbackInput(int skipAmount) {           // :235-239
+            TotalConsumedForFeedback += skipAmount;
+            if (TotalConsumedForFeedback > TotalSpawned) TotalConsumedForFeedback = TotalSpawned;
+        }
         float ApproximateMaximumLife = 0;
         // LivenessInfo, ParticleLiveness.cs:24-28
         std::optional<int> Count;
@@ -419,14 +484,18 @@ public:
     // AutoReadback / ReadbackResult (ParticleReadback.cs:21-71) reduced to a synchronous plane download
     void Readback(int chunkIndex, int plane, IlmFloat4* dst) const;
     IlmHandle Handle() const { return handle; }
+    // PickSourceForFeedback / GetCurrentSpawnTarget, ParticleSpawning.cs:233-265 (chunk table indices, -1 = null)
+    int PickSourceForFeedback(int count);
+    int GetCurrentSpawnTarget(bool feedback) const;
+    Chunk& ChunkAt(int index) { return chunks.at((size_t)index); }
     // the descriptor of the last launch (tests compare it with the oracle's step)
     const IlmStepDesc& LastStep() const { return lastStep; }
     double LastDeltaTimeSeconds = 0;
 
 private:
     bool RunSpawner(Transforms::SpawnerBase& spawner, double deltaTimeSeconds, double now, bool isSecondPass,
-                    std::vector<IlmSpawnRecord>& records);
-    int PickTargetForSpawn(int count, bool& needClear, bool partialSpawnAllowed);
+                    std::vector<IlmSpawnRecord>& records, std::vector<std::vector<IlmFloat4>>& recordPositions);
+    int PickTargetForSpawn(bool feedback, int count, bool& needClear, bool partialSpawnAllowed);
     int CreateChunk();
     void UpdateLiveCountAndReapDeadChunks();
     void ProcessLatestLivenessInfo(Chunk& c);
@@ -437,7 +506,7 @@ private:
     std::vector<Chunk> chunks;
     std::vector<int> chunksToReap;   // chunk IDs
     int nextChunkId = 1;
-    int currentSpawnTarget = -1;
+    int currentSpawnTarget = -1, currentFeedbackSpawnTarget = -1, currentFeedbackSource = -1;   // chunk IDs
     int currentFrameIndex = 0;
     int lastFrameUpdated = -1;
     int framesUntilNextLivenessCheck = 0;

@@ -1,0 +1,160 @@
+"""The host mirror's remaining transforms / spawners (MatrixMultiply, SpatialNoise, Spawner with a position buffer,
+FeedbackSpawner -- SURVEY 8f-2) driving the extended step kernel, replayed descriptor by descriptor on the oracle."""
+import numpy as np
+import pytest
+
+from illuminant_amd import abi, scenes
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+P, V, A, RC, RD = abi.PLANE_POSITION, abi.PLANE_VELOCITY, abi.PLANE_ATTRIBUTES, abi.PLANE_RENDER_COLOR, abi.PLANE_RENDER_DATA
+
+
+@pytest.fixture(scope="module")
+def H():
+    from illuminant_amd import _host
+    return _host
+
+
+@pytest.fixture(scope="module")
+def hctx(H):
+    return H.DeviceContext(0)
+
+
+def make_engine(H, hctx, chunk_size, seed=7):
+    rnd = scenes.randomness_table(seed)
+    tp = H.ManualTimeProvider()
+    ecfg = H.ParticleEngineConfiguration(chunk_size)
+    ecfg.TimeProvider = tp
+    return H.ParticleEngine(hctx, ecfg, rnd), tp, rnd
+
+
+def empty_chunk(n):
+    return [np.zeros((n, 4), np.float32) for _ in range(5)]
+
+
+def compare_system(ps, chunks, rtol=2e-4, atol=2e-5):
+    assert len(ps.Chunks) == len(chunks)
+    live = 0
+    for ci in range(len(chunks)):
+        got = [ps.Readback(ci, k) for k in (P, V, A, RC, RD)]
+        want = chunks[ci]
+        assert np.array_equal(got[0][:, 3] > 0, want[0][:, 3] > 0), "chunk %d live mask" % ci
+        m = want[0][:, 3] > 0
+        live += int(m.sum())
+        for k, name in ((0, "position"), (1, "velocity"), (2, "attributes"), (3, "render color"), (4, "render data")):
+            assert_close(got[k][m], want[k][m], "chunk %d %s" % (ci, name), rtol=rtol, atol=atol)
+    return live
+
+
+def test_position_buffer_spawner_with_matrix_multiply_and_spatial_noise(H, hctx, oracle):
+    cs = 64
+    n = cs * cs
+    engine, tp, rnd = make_engine(H, hctx, cs)
+    cfg = H.ParticleSystemConfiguration()
+    cfg.Friction = 0.05; cfg.MaximumVelocity = 1024.0; cfg.LifeDecayPerSecond = 1.0
+    ps = H.ParticleSystem(engine, cfg)
+    sp = H.Spawner(5)
+    sp.MinRate = sp.MaxRate = 3000.0
+    sp.RatePerPosition = False
+    f = H.Formula3(); f.Constant = [100, 100, 0]; f.RandomScale = [4, 4, 1]; f.Type = H.FormulaType.Spherical
+    sp.Position = f
+    sp.AdditionalPositions = [[100.0 + 40.0 * i, 100.0 + 25.0 * (i % 3), float(i)] for i in range(1, 8)]      # 8 positions > 4 inline
+    sp.PolygonRate = 3.0
+    g = H.Formula3(); g.RandomScale = [30, 30, 5]; g.Type = H.FormulaType.Spherical
+    sp.Velocity = g
+    life = H.Formula1(); life.Constant = 1.0; life.RandomScale = 2.0
+    sp.Life = life
+    mm = H.MatrixMultiply()
+    mm.Strength = 0.5
+    c, s_ = np.cos(0.3), np.sin(0.3)
+    mm.Position = [c, s_, 0, 0, -s_, c, 0, 0, 0, 0, 1, 0, 3, -2, 0, 1]      # rotate about z + translate (row-vector convention)
+    mm.Velocity = [0.95, 0, 0, 0, 0, 0.95, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1]
+    sn = H.SpatialNoise(4)
+    sn.SpaceScale = [9.0, 5.0]
+    v3 = H.NoiseParameters3(); v3.Scale = [25.0, 25.0, 2.0]
+    sn.Velocity = v3
+    sn.ReplaceOldVelocity = False
+    for t in (sp, mm, sn):
+        ps.AddTransform(t)
+    chunks = []
+    for frame in range(10):
+        tp.Advance(1.0 / 60.0)
+        ps.Update(frame)
+        d = abi.StepDesc.from_buffer_copy(ps.LastStepBytes())
+        while len(chunks) < len(ps.Chunks):
+            chunks.append(empty_chunk(n))
+        extras = {}
+        for k in range(d.SpawnCount):
+            assert d.Spawns[k].Kind == abi.SPAWN_POSITION_BUFFER
+            buf = np.zeros((8, 4), np.float32)
+            buf[0] = [100, 100, 0, 1.0]
+            for i, ap in enumerate(sp.AdditionalPositions):
+                buf[i + 1] = list(ap) + [1.0]
+            extras[k] = buf
+        oracle.step(chunks, cs, rnd, d, spawn_positions=extras)
+    hctx.Sync()
+    assert 495 <= sp.TotalSpawned <= 500          # 3000/s over 10 steps of 1/60 s, up to the RateError carry
+    live = compare_system(ps, chunks)
+    assert live > 300
+
+
+def test_feedback_spawner_consumes_the_source_window(H, hctx, oracle):
+    cs = 32
+    n = cs * cs
+    engine, tp, rnd = make_engine(H, hctx, cs)
+    cfg = H.ParticleSystemConfiguration()
+    cfg.LifeDecayPerSecond = 0.5
+    src = H.ParticleSystem(engine, cfg)
+    dst = H.ParticleSystem(engine, cfg)
+    sp = H.Spawner(2)
+    sp.MinRate = sp.MaxRate = 1200.0                 # 20 per 1/60 s step
+    f = H.Formula3(); f.Constant = [200, 100, 5]; f.RandomScale = [50, 50, 0]; f.Type = H.FormulaType.Spherical
+    sp.Position = f
+    life = H.Formula1(); life.Constant = 3.0; life.RandomScale = 1.0
+    sp.Life = life
+    src.AddTransform(sp)
+    fb = H.FeedbackSpawner(6)
+    fb.SourceSystem = src
+    fb.MinRate = fb.MaxRate = 1800.0                 # 30 per step = 10 sources x InstanceMultiplier 3
+    fb.InstanceMultiplier = 3
+    fb.SourceVelocityFactor = 0.5
+    fb.MultiplyLife = True
+    pf = H.Formula3(); pf.Constant = [0, 0, 1]; pf.RandomScale = [2, 2, 0]; pf.Type = H.FormulaType.Spherical
+    fb.Position = pf
+    lf = H.Formula1(); lf.Constant = 0.5
+    fb.Life = lf
+    dst.AddTransform(fb)
+
+    src_chunks, dst_chunks = [], []
+    consumed = []
+    for frame in range(14):
+        tp.Advance(1.0 / 60.0)
+        src.Update(frame)
+        ds = abi.StepDesc.from_buffer_copy(src.LastStepBytes())
+        while len(src_chunks) < len(src.Chunks):
+            src_chunks.append(empty_chunk(n))
+        oracle.step(src_chunks, cs, rnd, ds)
+        dst.Update(frame)
+        if len(dst.Chunks) == 0:
+            continue
+        dd = abi.StepDesc.from_buffer_copy(dst.LastStepBytes())
+        while len(dst_chunks) < len(dst.Chunks):
+            dst_chunks.append(empty_chunk(n))
+        sources = {}
+        for k in range(dd.SpawnCount):
+            assert dd.Spawns[k].Kind == abi.SPAWN_FEEDBACK and dd.Spawns[k].Feedback.SourceSystem == src.Handle
+            sc = src_chunks[dd.Spawns[k].Feedback.SourceChunkIndex]
+            sources[k] = (sc[0], sc[1], sc[2])
+            consumed.append(int(dd.Spawns[k].Feedback.FeedbackSourceIndex))
+        oracle.step(dst_chunks, cs, rnd, dd, feedback_sources=sources)
+    hctx.Sync()
+    # the feedback source index walks forward by spawnCount / InstanceMultiplier per step (RunSpawner, ParticleSpawning.cs:159-166)
+    assert consumed == sorted(consumed) and len(set(consumed)) > 5
+    assert all(9 <= b - a <= 11 for a, b in zip(consumed, consumed[1:]))
+    assert consumed[-1] + 9 <= src.Chunks[0].TotalConsumedForFeedback <= consumed[-1] + 11
+    assert dst.Chunks[0].IsFeedbackSource and not src.Chunks[0].IsFeedbackSource
+    compare_system(src, src_chunks)
+    live = compare_system(dst, dst_chunks)
+    assert live > 100
