@@ -91,6 +91,10 @@ struct System {
     uint32_t magic = kMagicSystem;
     Engine* engine = nullptr;
     std::vector<float*> chunks;
+    // High-water mark per chunk: slots >= used[i] have never been written since the chunk was allocated (zero-filled) or
+    // erased, so every plane of theirs is zero and a step leaves them exactly as they are -- the launch skips their units.
+    // Raised by uploads and spawn ranges; a chunk whose device pointer was handed out is treated as fully used.
+    std::vector<int32_t> used;
     float** d_table = nullptr; int table_cap = 0; bool table_dirty = true;
     // Three counter regions of counts_cap * kCountStride words: 0 / 1 alternate between counting steps (the step kernel
     // accumulates into one and zeroes the other for next time: no memset launch), 2 belongs to ilm_system_live_counts.
@@ -278,6 +282,11 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
     a.chunk_count = count;
     a.op_mask = 0;
     for (int o = 0; o < d->OpCount; o++) a.op_mask |= 1u << d->Ops[o].Type;
+    for (int k = 0; k < d->SpawnCount; k++) {
+        const IlmSpawnRecord& r = d->Spawns[k];
+        if (r.Params.ChunkSizeAndIndices[2] >= r.Params.ChunkSizeAndIndices[1])
+            s->used[(size_t)r.ChunkIndex] = std::max(s->used[(size_t)r.ChunkIndex], (int32_t)r.Params.ChunkSizeAndIndices[2] + 1);
+    }
     a.rnd = e->rnd; a.rw = e->rw; a.rh = e->rh;
     a.rnd_lp = e->rnd_lp;
     for (int k = 0; k < ILM_MAX_SPAWNS; k++) {
@@ -332,7 +341,24 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
             }
         }
     }
+    // Units past a chunk's high-water mark are skipped -- unless a Noise-type op can write dead slots in this launch
+    // (no life check, Noise.fx:40 / :86: it moves even never-spawned slots when its result survives)
+    a.partial_count = 0;
+    {
+        const bool noise_op = (a.op_mask & ((1u << ILM_OP_NOISE) | (1u << ILM_OP_SPATIAL_NOISE))) != 0u;
+        const bool noise_touches_dead = noise_op && ((d->UpdateMode == ILM_UPDATE_NONE) || (a.derived.noise_may_revive != 0));
+        for (int ci = first; !noise_touches_dead && ci < first + count && a.partial_count < kMaxPartialChunks; ci++) {
+            const int used_units = (s->used[(size_t)ci] + 63) / 64;
+            if (used_units * 64 < e->slots) {
+                a.partial_chunk[a.partial_count] = ci;
+                a.partial_units[a.partial_count] = used_units;
+                a.partial_count++;
+            }
+        }
+    }
     HIP_TRY(launch_step(a, c->stream));
+    if (d->UpdateMode == ILM_UPDATE_ERASE)
+        for (int ci = first; ci < first + count; ci++) s->used[(size_t)ci] = 0;   // position, velocity and render planes are zero again
     if (d->Flags & ILM_STEP_COUNT_LIVE) {
         // queue the readback behind the kernel; ilm_system_poll_counts / ilm_system_step_counts pick it up
         const int n = (int)s->chunks.size();
@@ -554,6 +580,7 @@ int32_t ilm_system_add_chunk(IlmHandle h, int32_t* out_index) {
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&base), bytes));
     HIP_TRY(hipMemsetAsync(base, 0, bytes, e->ctx->stream));
     s->chunks.push_back(base);
+    s->used.push_back(0);
     s->table_dirty = true;
     if (out_index) *out_index = (int32_t)s->chunks.size() - 1;
     return ILM_OK;
@@ -569,6 +596,7 @@ int32_t ilm_system_remove_chunk(IlmHandle h, int32_t index) {
     HIP_TRY(hipStreamSynchronize(c->stream));
     HIP_TRY(hipFree(s->chunks[(size_t)index]));
     s->chunks.erase(s->chunks.begin() + index);
+    s->used.erase(s->used.begin() + index);
     s->table_dirty = true;
     return ILM_OK;
 }
@@ -602,6 +630,7 @@ int32_t ilm_chunk_upload(IlmHandle h, int32_t chunk, int32_t plane, const IlmFlo
     rc = ensure_staging(c, bytes);
     if (rc != ILM_OK) return rc;
     HIP_TRY(hipMemcpyAsync(c->staging, src, bytes, hipMemcpyHostToDevice, c->stream));
+    s->used[(size_t)chunk] = std::max(s->used[(size_t)chunk], first_slot + count);
     HIP_TRY(launch_aos_to_soa(reinterpret_cast<const float4*>(c->staging), s->chunks[(size_t)chunk] + (int64_t)plane * 4 * e->stride,
                               e->stride, first_slot, count, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));   // staging is reused by the next call
@@ -632,6 +661,7 @@ int32_t ilm_chunk_device_ptr(IlmHandle h, int32_t chunk, int32_t component, void
     if (chunk < 0 || chunk >= (int)s->chunks.size() || component < 0 || component >= kComponents)
         return fail(ILM_ERR_OUT_OF_RANGE, "chunk/component out of range");
     if (out_ptr) *out_ptr = s->chunks[(size_t)chunk] + (int64_t)component * s->engine->stride;
+    s->used[(size_t)chunk] = s->engine->slots;     // the caller may write through the pointer
     if (out_stride) *out_stride = s->engine->stride;
     return ILM_OK;
 }

@@ -45,6 +45,7 @@ struct StepDerived {
     } op[ILM_MAX_OPS];
 };
 
+constexpr int kMaxPartialChunks = 4;
 struct StepLaunch {
     IlmStepDesc desc;
     StepDerived derived;
@@ -60,6 +61,9 @@ struct StepLaunch {
     const float4* spawn_positions[ILM_MAX_SPAWNS]; int32_t spawn_position_count[ILM_MAX_SPAWNS];
     const float* source_base[ILM_MAX_SPAWNS];
     SdfView sdf;
+    // chunks whose tail has never been written (api.hip, System::used): units >= partial_units[i] of chunk partial_chunk[i]
+    // hold only zeros and are skipped; chunks not listed are processed whole
+    int32_t partial_count; int32_t partial_chunk[kMaxPartialChunks]; int32_t partial_units[kMaxPartialChunks];
     uint32_t* live_counts;       // per chunk at index chunk * kCountStride; all zero on entry when ILM_STEP_COUNT_LIVE
     uint32_t* zero_counts;       // the other counter region: zeroed by this launch for the next counting step
     int32_t zero_n;

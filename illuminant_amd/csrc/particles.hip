@@ -886,6 +886,11 @@ __global__ __launch_bounds__(kStepThreads, MINW) void step_kernel(const StepLaun
         const int chunk_rel = u / a.units_per_chunk;
         const int seg = u - chunk_rel * a.units_per_chunk;
         const int chunk = a.first_chunk + chunk_rel;
+        // never-written tail of a spawn-target chunk: all planes are zero and stay zero (scalar compares, uniform branch)
+        bool untouched = false;
+        for (int k = 0; k < a.partial_count; k++)
+            untouched = untouched || ((a.partial_chunk[k] == chunk) && (seg >= a.partial_units[k]));
+        if (!untouched) {
         gfloat* ub = (gfloat*)a.chunk_bases[chunk] + seg * 64;     // first slot of the first unit, plane 0 (uniform)
         // K > 1 issues the state loads of all K units before any arithmetic (K x 12 loads in flight per wave).  Measured
         // on cfg2 ("experiments"): K = 1 26.1 us, K = 2 30.5 us, K = 4 36.5 us per step -- the extra
@@ -900,6 +905,7 @@ __global__ __launch_bounds__(kStepThreads, MINW) void step_kernel(const StepLaun
             for (int r = 0; r + 1 < K; r++) q[r] = q[r + 1];
             const bool live_after = process_unit<FMT, DF, SPAWN, EXT>(ap, ub + j * 64, chunk, (seg + j) * 64 + (int)lane, lane, seg + j, cur);
             n_live += (uint32_t)__popcll(__ballot(live_after));
+        }
         }
     }
     if (a.desc.Flags & ILM_STEP_COUNT_LIVE) {
@@ -962,6 +968,8 @@ static hipError_t launch_step_variant(const StepLaunch& a, hipStream_t stream) {
         else
             hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, true, SPAWN, 1>), grid, block, 0, stream, a);
     } else if (SPAWN) {
+        // (bounding this variant to 7 / 8 waves per SIMD -- 72 / 64 VGPRs with 8 / 24 bytes of scratch in the cold spawn path --
+        // measured 3.5 % / 14 % SLOWER on cfg2: the step is VALU-issue-bound, not occupancy-bound; DESIGN.md "experiments")
         hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, false, SPAWN, 1>), grid, block, 0, stream, a);
     } else {
         switch (minw) {
