@@ -222,6 +222,11 @@ class DistanceFieldRenderDesc(C.Structure):
                 ("DynamicFlagFilter", i32), ("_pad", i32 * 3)]
 
 
+class ParticleLightParams(C.Structure):
+    _fields_ = [("LightProperties", Float4), ("MoreLightProperties", Float4), ("LightColor", Float4), ("LightSpecularColor", Float4),
+                ("StippleFactor", f32), ("_pad", f32 * 3)]
+
+
 class RenderStats(C.Structure):
     _fields_ = [("SdfSamples", C.c_uint64), ("PixelLightPairs", C.c_uint64), ("TracedPairs", C.c_uint64)]
 
@@ -240,6 +245,7 @@ EXPECTED_SIZES = {
     "IlmMatrixMultiplyParams": (MatrixMultiplyParams, 208), "IlmSpatialNoiseParams": (SpatialNoiseParams, 208),
     "IlmFeedbackParams": (FeedbackParams, 48),
     "IlmRenderStats": (RenderStats, 24),
+    "IlmParticleLightParams": (ParticleLightParams, 80),
     "IlmObstruction": (Obstruction, 48), "IlmHeightVolume": (HeightVolume, 32),
     "IlmDistanceFieldRenderDesc": (DistanceFieldRenderDesc, 64),
 }

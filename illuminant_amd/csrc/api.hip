@@ -56,6 +56,11 @@ struct Ctx {
     void* pinned[kRing] = {}; size_t pinned_bytes[kRing] = {}; hipEvent_t pinned_ev[kRing] = {}; int ring_pos = 0;
     IlmLightVertex* d_lights = nullptr; void* d_recs = nullptr; int light_cap = 0;
     unsigned long long* d_stats = nullptr;
+    // particle lights: records compacted on the device + their count, block counts, per-chunk quad counts
+    void* d_pl_recs = nullptr; int pl_cap = 0; int32_t* d_pl_count = nullptr; int32_t* d_pl_blocks = nullptr; int pl_blocks_cap = 0;
+    int32_t* d_pl_quads = nullptr; int pl_quads_cap = 0;
+    // light probes: positions | normals | values
+    float4* d_probes = nullptr; int probes_cap = 0;
     // parameter block of the distance-field generation pass (slice list, obstruction records, volumes, polygon vertices)
     void* d_field_params = nullptr; size_t field_params_bytes = 0;
 };
@@ -452,6 +457,11 @@ int32_t ilm_ctx_destroy(IlmHandle h) {
     if (c->d_recs) (void)hipFree(c->d_recs);
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_field_params) (void)hipFree(c->d_field_params);
+    if (c->d_pl_recs) (void)hipFree(c->d_pl_recs);
+    if (c->d_pl_count) (void)hipFree(c->d_pl_count);
+    if (c->d_pl_blocks) (void)hipFree(c->d_pl_blocks);
+    if (c->d_pl_quads) (void)hipFree(c->d_pl_quads);
+    if (c->d_probes) (void)hipFree(c->d_probes);
     (void)hipStreamSynchronize(c->copy_stream);
     (void)hipStreamDestroy(c->copy_stream);
     (void)hipEventDestroy(c->ev_step);
@@ -1192,6 +1202,166 @@ int32_t ilm_lightmap_destroy(IlmHandle h) {
     return ILM_OK;
 }
 
+namespace {
+// shared by the three light passes: resource checks + the launch descriptor
+int32_t fill_light_launch(Ctx* c, const IlmEnvironment* env, const IlmDistanceFieldUniforms* df, IlmHandle hgbuffer, IlmHandle hsdf,
+                          IlmHandle hlightmap, int32_t row_begin, int32_t row_end, LightLaunch* a) {
+    Lightmap* m = from_handle<Lightmap>(hlightmap, kMagicLightmap);
+    if (!m) return fail(ILM_ERR_INVALID_HANDLE, "not a lightmap handle");
+    GBuffer* g = nullptr; Sdf* f = nullptr;
+    if (hgbuffer) { g = from_handle<GBuffer>(hgbuffer, kMagicGBuffer); if (!g) return fail(ILM_ERR_INVALID_HANDLE, "not a G-buffer handle"); }
+    if (hsdf) { f = from_handle<Sdf>(hsdf, kMagicSdf); if (!f) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle"); }
+    if (!env || !df) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (m->ctx != c || (g && g->ctx != c) || (f && f->ctx != c)) return fail(ILM_ERR_INVALID_ARGUMENT, "resources belong to another context");
+    if (row_begin < 0 || row_end > m->height || row_begin > row_end)
+        return fail(ILM_ERR_OUT_OF_RANGE, "rows [%d, %d) outside [0, %d]", row_begin, row_end, m->height);
+    a->lights = nullptr; a->light_count = 0;
+    a->env = *env; a->df = *df;
+    a->gbuffer.texels = g ? g->texels : nullptr;
+    a->gbuffer.width = g ? g->width : 0; a->gbuffer.height = g ? g->height : 0; a->gbuffer.format = g ? g->format : 0;
+    a->sdf = make_sdf_view(f);
+    for (int i = 0; i < 4; i++) a->ambient[i] = 0.0f;
+    a->lightmap = m->texels; a->width = m->width; a->height = m->height; a->format = m->format;
+    a->row_begin = row_begin; a->row_end = row_end;
+    a->stats = nullptr; a->light_count_ptr = nullptr; a->accumulate = 0;
+    return ILM_OK;
+}
+}  // namespace
+
+int32_t ilm_render_particle_lights(IlmHandle hctx, IlmHandle hsystem, const int32_t* quad_counts, int32_t chunk_count,
+                                   const IlmParticleLightParams* params, const IlmEnvironment* env, const IlmDistanceFieldUniforms* df,
+                                   IlmHandle hgbuffer, IlmHandle hsdf, IlmHandle hlightmap, int32_t row_begin, int32_t row_end,
+                                   IlmRenderStats* stats) {
+    Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);
+    if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
+    System* s = from_handle<System>(hsystem, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (s->engine->ctx != c) return fail(ILM_ERR_INVALID_ARGUMENT, "the particle system belongs to another context");
+    if (!params) return fail(ILM_ERR_INVALID_ARGUMENT, "params is NULL");
+    // StippleReject (Fracture DitherCommon.fxh) is not in the reference tree: only "reject nothing" is defined here
+    if (!(params->StippleFactor >= 1.0f))
+        return fail(ILM_ERR_INVALID_ARGUMENT, "StippleFactor %g < 1 needs Fracture's StippleReject, which is outside the reference tree", (double)params->StippleFactor);
+    const int n = (int)s->chunks.size();
+    if (chunk_count < 0 || chunk_count > n) return fail(ILM_ERR_OUT_OF_RANGE, "chunk_count %d outside [0, %d]", chunk_count, n);
+    LightLaunch a;
+    int32_t rc = fill_light_launch(c, env, df, hgbuffer, hsdf, hlightmap, row_begin, row_end, &a);
+    if (rc != ILM_OK) return rc;
+    if (chunk_count == 0) return ILM_OK;
+    Engine* e = s->engine;
+    HIP_TRY(hipSetDevice(c->device));
+    rc = refresh_table(s);
+    if (rc != ILM_OK) return rc;
+
+    int64_t total = 0;
+    for (int i = 0; i < chunk_count; i++) {
+        const int q = quad_counts ? quad_counts[i] : e->slots;
+        if (q < 0 || q > e->slots) return fail(ILM_ERR_OUT_OF_RANGE, "quad_counts[%d] = %d outside [0, %d]", i, q, e->slots);
+        total += q;
+    }
+    if (total > (1 << 22)) return fail(ILM_ERR_TOO_MANY, "%lld particle lights in one call (limit %d)", (long long)total, 1 << 22);
+    if (total == 0) return ILM_OK;
+    const int blocks_per_chunk = (e->slots + 1023) / 1024;
+    const int blocks = chunk_count * blocks_per_chunk;
+    if ((int)total > c->pl_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_pl_recs) HIP_TRY(hipFree(c->d_pl_recs));
+        c->d_pl_recs = nullptr; c->pl_cap = 0;
+        const int cap = (int)total < 4096 ? 4096 : (int)total;
+        HIP_TRY(hipMalloc(&c->d_pl_recs, kLightRecBytes * (size_t)cap));
+        c->pl_cap = cap;
+    }
+    if (!c->d_pl_count) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_pl_count), sizeof(int32_t)));
+    if (blocks > c->pl_blocks_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_pl_blocks) HIP_TRY(hipFree(c->d_pl_blocks));
+        c->d_pl_blocks = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_pl_blocks), sizeof(int32_t) * (size_t)blocks * 2));
+        c->pl_blocks_cap = blocks * 2;
+    }
+    if (chunk_count > c->pl_quads_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_pl_quads) HIP_TRY(hipFree(c->d_pl_quads));
+        c->d_pl_quads = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_pl_quads), sizeof(int32_t) * (size_t)chunk_count * 2));
+        c->pl_quads_cap = chunk_count * 2;
+    }
+    if (quad_counts) {
+        rc = upload_small(c, c->d_pl_quads, quad_counts, sizeof(int32_t) * (size_t)chunk_count);
+        if (rc != ILM_OK) return rc;
+    }
+    ParticleLightLaunch pl;
+    pl.chunk_bases = s->d_table; pl.stride = e->stride; pl.chunk_count = chunk_count; pl.slots = e->slots;
+    pl.quad_counts = quad_counts ? c->d_pl_quads : nullptr;
+    pl.params = *params; pl.env = *env; pl.max_cone_radius = df->ConeAndMisc.x;
+    pl.block_counts = c->d_pl_blocks; pl.recs = c->d_pl_recs; pl.capacity = c->pl_cap; pl.out_count = c->d_pl_count;
+    HIP_TRY(launch_prepare_particle_lights(pl, c->stream));
+
+    a.light_count = 0;
+    a.light_count_ptr = c->d_pl_count;
+    a.accumulate = 1;
+    if (stats) {
+        HIP_TRY(hipMemsetAsync(c->d_stats, 0, 3 * sizeof(unsigned long long), c->stream));
+        a.stats = c->d_stats;
+    }
+    HIP_TRY(launch_sphere_lights_prepared(a, c->d_pl_recs, c->stream));
+    if (stats) {
+        unsigned long long host[3] = { 0, 0, 0 };
+        HIP_TRY(hipMemcpyAsync(host, c->d_stats, sizeof(host), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        stats->SdfSamples = host[0]; stats->PixelLightPairs = host[1]; stats->TracedPairs = host[2];
+    }
+    return ILM_OK;
+}
+
+int32_t ilm_render_light_probes(IlmHandle hctx, const IlmLightVertex* lights, int32_t light_count,
+                                const IlmFloat4* probe_positions, const IlmFloat4* probe_normals, int32_t probe_count,
+                                const IlmEnvironment* env, const IlmDistanceFieldUniforms* df, IlmHandle hsdf, IlmFloat4* out_values) {
+    Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);
+    if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
+    Sdf* f = nullptr;
+    if (hsdf) { f = from_handle<Sdf>(hsdf, kMagicSdf); if (!f) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle"); }
+    if (f && f->ctx != c) return fail(ILM_ERR_INVALID_ARGUMENT, "resources belong to another context");
+    if (!env || !df) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (light_count < 0 || (light_count > 0 && !lights)) return fail(ILM_ERR_INVALID_ARGUMENT, "bad light array");
+    if (probe_count < 0 || (probe_count > 0 && (!probe_positions || !probe_normals || !out_values))) return fail(ILM_ERR_INVALID_ARGUMENT, "bad probe arrays");
+    if (probe_count == 0) return ILM_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    if (light_count > c->light_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_lights) HIP_TRY(hipFree(c->d_lights));
+        if (c->d_recs) HIP_TRY(hipFree(c->d_recs));
+        c->d_lights = nullptr; c->d_recs = nullptr;
+        int cap = light_count < 256 ? 256 : light_count * 2;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_lights), sizeof(IlmLightVertex) * (size_t)cap));
+        HIP_TRY(hipMalloc(&c->d_recs, kLightRecBytes * (size_t)cap));
+        c->light_cap = cap;
+    }
+    if (light_count > 0) {
+        int32_t rc = upload_small(c, c->d_lights, lights, sizeof(IlmLightVertex) * (size_t)light_count);
+        if (rc != ILM_OK) return rc;
+        HIP_TRY(launch_prepare_lights(c->d_lights, light_count, *env, df->ConeAndMisc.x, c->d_recs, c->stream));
+    }
+    if (probe_count > c->probes_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_probes) HIP_TRY(hipFree(c->d_probes));
+        c->d_probes = nullptr;
+        const int cap = probe_count < 256 ? 256 : probe_count * 2;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_probes), sizeof(float4) * 3 * (size_t)cap));
+        c->probes_cap = cap;
+    }
+    float4* d_pos = c->d_probes;
+    float4* d_nrm = c->d_probes + c->probes_cap;
+    float4* d_val = c->d_probes + 2 * (size_t)c->probes_cap;
+    int32_t rc = upload_small(c, d_pos, probe_positions, sizeof(float4) * (size_t)probe_count);
+    if (rc != ILM_OK) return rc;
+    rc = upload_small(c, d_nrm, probe_normals, sizeof(float4) * (size_t)probe_count);
+    if (rc != ILM_OK) return rc;
+    HIP_TRY(launch_light_probes(c->d_recs, light_count, d_pos, d_nrm, probe_count, *env, *df, make_sdf_view(f), d_val, c->stream));
+    HIP_TRY(hipMemcpyAsync(out_values, d_val, sizeof(float4) * (size_t)probe_count, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ILM_OK;
+}
+
 int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, int32_t light_count, const IlmEnvironment* env,
                                  const IlmDistanceFieldUniforms* df, IlmHandle hgbuffer, IlmHandle hsdf, const float ambient[4],
                                  IlmHandle hlightmap, int32_t row_begin, int32_t row_end, IlmRenderStats* stats) {
@@ -1237,7 +1407,7 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
     for (int i = 0; i < 4; i++) a.ambient[i] = ambient[i];
     a.lightmap = m->texels; a.width = m->width; a.height = m->height; a.format = m->format;
     a.row_begin = row_begin; a.row_end = row_end;
-    a.stats = nullptr;
+    a.stats = nullptr; a.light_count_ptr = nullptr; a.accumulate = 0;
     if (stats) {
         HIP_TRY(hipMemsetAsync(c->d_stats, 0, 3 * sizeof(unsigned long long), c->stream));
         a.stats = c->d_stats;

@@ -103,6 +103,8 @@ struct LightLaunch {
     void* lightmap; int32_t width, height, format;
     int32_t row_begin, row_end;
     unsigned long long* stats;      // device, 3 counters, or nullptr
+    const int32_t* light_count_ptr; // device: when non-null the record count is read from here (particle lights are counted on the device)
+    int32_t accumulate;             // != 0: start from the lightmap's contents instead of `ambient` (additive blend onto an earlier pass)
 };
 
 constexpr size_t kLightRecBytes = 128;   // sizeof(LightRec) in lighting.hip
@@ -110,6 +112,22 @@ constexpr size_t kLightRecBytes = 128;   // sizeof(LightRec) in lighting.hip
 hipError_t launch_prepare_lights(const IlmLightVertex* lights, int count, const IlmEnvironment& env, float max_cone_radius,
                                  void* recs, hipStream_t stream);
 hipError_t launch_sphere_lights_prepared(const LightLaunch& a, const void* recs, hipStream_t stream);
+// Particle lights (ParticleLight.fx): ordered device-side compaction of the live, visible particles of every chunk into light
+// records.  block_counts: one int per 1024-slot block of every chunk (scratch); *out_count receives the record count.
+struct ParticleLightLaunch {
+    float* const* chunk_bases; int64_t stride; int32_t chunk_count, slots;
+    const int32_t* quad_counts;     // device, per chunk; nullptr => every slot
+    IlmParticleLightParams params;
+    IlmEnvironment env;
+    float max_cone_radius;
+    int32_t* block_counts;          // chunk_count * blocks_per_chunk
+    void* recs; int32_t capacity;   // LightRec array
+    int32_t* out_count;
+};
+hipError_t launch_prepare_particle_lights(const ParticleLightLaunch& a, hipStream_t stream);
+// Light probes (SphereLightProbe.fx): every prepared light record on every probe; values = float4 per probe (device)
+hipError_t launch_light_probes(const void* recs, int light_count, const float4* probe_positions, const float4* probe_normals, int probe_count,
+                               const IlmEnvironment& env, const IlmDistanceFieldUniforms& df, const SdfView& sdf, float4* values, hipStream_t stream);
 // sampleDistanceFieldEx at `count` positions (xyz triples) -- diagnostic entry point ilm_sdf_sample
 hipError_t launch_sdf_sample(const SdfView& sdf, const IlmDistanceFieldUniforms& df, const float* positions, int count, float* out, hipStream_t stream);
 

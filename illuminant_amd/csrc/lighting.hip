@@ -159,6 +159,84 @@ ILM_DEV float sphere_light_opacity(f3 shaded, f3 normal, const LightRec& L, floa
     return sat((normal_factor * distance_factor) + sat(L.radius - distance));
 }
 
+struct LightStats { unsigned long long samples = 0, pairs = 0, traced = 0; };
+
+// One light on one shaded point: SphereLightPixelShader (SphereLight.fx:7-46) after the raster test.  Returns false when the shader
+// discards (nothing is blended); otherwise the light's rgb contribution in (out_r, out_g, out_b).
+template <int FMT, bool STATS>
+ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment& env, const IlmDistanceFieldUniforms& df, const SdfView& sdf,
+                         bool have_sdf, LightStats& st, float& out_r, float& out_g, float& out_b) {
+    // checkShadowFilter, LightCommon.fxh:146-152
+    const bool filtered = (L.shadow_filter < 0.0f) ? false : ((L.shadow_filter > 0.5f) != P.enable_shadows);
+    if (P.fullbright || filtered)
+        return false;
+
+    const float casts = L.casts_shadows * (P.enable_shadows ? 1.0f : 0.0f);
+    const float distance_opacity = sphere_light_opacity(P.shaded, P.normal, L, env.ZToY.z);
+    const bool visible = (distance_opacity > 0.0f) && (P.shaded.x > -9999.0f);
+    if (!visible)
+        return false;
+
+    // computeAO, AOCommon.fxh:1-19 (aoRadius scaled by max(0, normal.z), SphereLightCore.fxh:78)
+    float ao_opacity = 1.0f;
+    const float ao_radius = L.ao_radius * fmaxf(0.0f, P.normal.z);
+    if ((ao_radius >= 0.5f) && have_sdf) {
+        const float distance = sample_distance_field<FMT>(mk3(P.shaded.x, P.shaded.y, P.shaded.z + P.normal.z * ao_radius), df, sdf);
+        if (STATS) st.samples++;
+        float r = 1.0f - sat(clampf(distance, 0.0f, ao_radius) / ao_radius);
+        r *= r;
+        r = 1.0f - r;
+        ao_opacity = (1.0f - L.ao_opacity) + (r * L.ao_opacity);
+    }
+    const float pre_trace = distance_opacity * ao_opacity;
+
+    // coneTrace, ConeTrace.fxh:148-191
+    float cone_opacity = 1.0f;
+    const bool trace = (casts != 0.0f) && (pre_trace >= (0.75f / 255.0f));
+    if (trace) {
+        if (STATS) st.traced++;
+        const f3 start = P.shaded + (P.normal * 1.6f);   // SELF_OCCLUSION_HACK
+        const f3 tv = mk3(L.cx, L.cy, L.cz) - start;
+        const float trace_length = len3(tv);
+        const f3 dir = mk3(tv.x / trace_length, tv.y / trace_length, tv.z / trace_length);
+        const float data_y = fmaxf(trace_length - L.radius, 1.0f);
+        float data_x = 0.5f;   // TRACE_INITIAL_OFFSET_PX
+        float data_z = 1.0f;
+        const float cfg_z = fmaxf(1.0f, df.Packed1.w);
+        float steps_remaining = df.StepAndMisc2.x;
+        float liveness = have_sdf ? 1.0f : 0.0f;
+        while (liveness > 0.0f) {
+            steps_remaining -= 1.0f;
+            const float s = sample_distance_field<FMT>(start + (dir * data_x), df, sdf);
+            if (STATS) st.samples++;
+            const float local_radius = fminf((L.cfg_y * data_x) + 0.33f, L.cfg_x);   // MIN_CONE_RADIUS
+            data_z = fminf(data_z, (s + 1.5f) / local_radius);                        // HACK_DISTANCE_OFFSET
+            data_x += fmaxf(fabsf(s) * df.StepAndMisc2.z, cfg_z);
+            liveness = steps_remaining * (sat(data_z - 0.075f) * sat(data_y - data_x));
+        }
+        const float visibility = fminf(data_z, steps_remaining / 2.0f);               // MAX_STEP_RAMP_WINDOW
+        cone_opacity = powf(sat(sat(visibility - 0.075f) / (0.95f - 0.075f)), df.ConeAndMisc.z);
+    }
+    const float opacity = pre_trace * cone_opacity;
+
+    // SphereLightPixelShader epilogue, SphereLight.fx:37-45.  The specular term is
+    // skipped when Color2.rgb == 0: it then contributes exactly 0 unless
+    // pow() produced inf/NaN (negative SpecularPower), which the reference does not guard.
+    float sr = 0.0f, sg = 0.0f, sb = 0.0f;
+    if (L.has_spec != 0.0f) {
+        const f3 light_direction = P.shaded - mk3(L.cx, L.cy, L.cz);
+        const f3 h = norm3(norm3(P.camera - P.shaded) - light_direction);
+        const float specularity = powf(sat(dot3(h, P.normal)), L.spec_power);
+        sr = L.spec_r * specularity * opacity;
+        sg = L.spec_g * specularity * opacity;
+        sb = L.spec_b * specularity * opacity;
+    }
+    out_r = (L.col_r * opacity) + sr;
+    out_g = (L.col_g * opacity) + sg;
+    out_b = (L.col_b * opacity) + sb;
+    return true;
+}
+
 constexpr int kTile = 16;
 constexpr int kListCapacity = 1024;
 
@@ -188,10 +266,27 @@ __global__ __launch_bounds__(256) void sphere_lights_kernel(const LightLaunch a,
     const bool have_sdf = (a.sdf.texels != nullptr) && (a.df.Extent.x > 0.0f);
 
     float acc_r = a.ambient[0], acc_g = a.ambient[1], acc_b = a.ambient[2], acc_a = a.ambient[3];
-    unsigned long long n_samples = 0, n_pairs = 0, n_traced = 0;
+    if (a.accumulate != 0 && in_image) {
+        // additive blend onto an earlier pass of the same frame (another light-type render state, LightingRenderer.cs:1100-1169)
+        const size_t o = (size_t)py * (size_t)a.width + (size_t)px;
+        if (a.format == ILM_LIGHTMAP_FLOAT4) {
+            const float4 v = reinterpret_cast<const float4*>(a.lightmap)[o];
+            acc_r = v.x; acc_g = v.y; acc_b = v.z; acc_a = v.w;
+        } else if (a.format == ILM_LIGHTMAP_HALF4) {
+            const uint2 v = reinterpret_cast<const uint2*>(a.lightmap)[o];
+            acc_r = __half2float(__ushort_as_half((unsigned short)(v.x & 0xFFFFu))); acc_g = __half2float(__ushort_as_half((unsigned short)(v.x >> 16)));
+            acc_b = __half2float(__ushort_as_half((unsigned short)(v.y & 0xFFFFu))); acc_a = __half2float(__ushort_as_half((unsigned short)(v.y >> 16)));
+        } else {
+            const uint32_t v = reinterpret_cast<const uint32_t*>(a.lightmap)[o];
+            acc_r = (float)(v & 0xFFu) / 255.0f; acc_g = (float)((v >> 8) & 0xFFu) / 255.0f;
+            acc_b = (float)((v >> 16) & 0xFFu) / 255.0f; acc_a = (float)(v >> 24) / 255.0f;
+        }
+    }
+    LightStats st;
+    const int light_count = (a.light_count_ptr != nullptr) ? __builtin_amdgcn_readfirstlane(*a.light_count_ptr) : a.light_count;
 
-    for (int batch = 0; batch < a.light_count; batch += kListCapacity) {
-        const int batch_n = min(kListCapacity, a.light_count - batch);
+    for (int batch = 0; batch < light_count; batch += kListCapacity) {
+        const int batch_n = min(kListCapacity, light_count - batch);
         __syncthreads();
         if (threadIdx.x == 0) list_count = 0;
         __syncthreads();
@@ -226,75 +321,13 @@ __global__ __launch_bounds__(256) void sphere_lights_kernel(const LightLaunch a,
                                               ((cxp >= L.fx0) && (cxp < L.fx3) && (cyp >= L.fy1) && (cyp < L.fy2)));
             if (!covered)
                 continue;
-            if (STATS) n_pairs++;
-            // checkShadowFilter, LightCommon.fxh:146-152
-            const bool filtered = (L.shadow_filter < 0.0f) ? false : ((L.shadow_filter > 0.5f) != P.enable_shadows);
-            if (P.fullbright || filtered)
+            if (STATS) st.pairs++;
+            float cr, cg, cb;
+            if (!shade_light<FMT, STATS>(P, L, a.env, a.df, a.sdf, have_sdf, st, cr, cg, cb))
                 continue;
-
-            const float casts = L.casts_shadows * (P.enable_shadows ? 1.0f : 0.0f);
-            const float distance_opacity = sphere_light_opacity(P.shaded, P.normal, L, a.env.ZToY.z);
-            const bool visible = (distance_opacity > 0.0f) && (P.shaded.x > -9999.0f);
-            if (!visible)
-                continue;
-
-            // computeAO, AOCommon.fxh:1-19 (aoRadius scaled by max(0, normal.z), SphereLightCore.fxh:78)
-            float ao_opacity = 1.0f;
-            const float ao_radius = L.ao_radius * fmaxf(0.0f, P.normal.z);
-            if ((ao_radius >= 0.5f) && have_sdf) {
-                const float distance = sample_distance_field<FMT>(mk3(P.shaded.x, P.shaded.y, P.shaded.z + P.normal.z * ao_radius), a.df, a.sdf);
-                if (STATS) n_samples++;
-                float r = 1.0f - sat(clampf(distance, 0.0f, ao_radius) / ao_radius);
-                r *= r;
-                r = 1.0f - r;
-                ao_opacity = (1.0f - L.ao_opacity) + (r * L.ao_opacity);
-            }
-            const float pre_trace = distance_opacity * ao_opacity;
-
-            // coneTrace, ConeTrace.fxh:148-191
-            float cone_opacity = 1.0f;
-            const bool trace = (casts != 0.0f) && (pre_trace >= (0.75f / 255.0f));
-            if (trace) {
-                if (STATS) n_traced++;
-                const f3 start = P.shaded + (P.normal * 1.6f);   // SELF_OCCLUSION_HACK
-                const f3 tv = mk3(L.cx, L.cy, L.cz) - start;
-                const float trace_length = len3(tv);
-                const f3 dir = mk3(tv.x / trace_length, tv.y / trace_length, tv.z / trace_length);
-                const float data_y = fmaxf(trace_length - L.radius, 1.0f);
-                float data_x = 0.5f;   // TRACE_INITIAL_OFFSET_PX
-                float data_z = 1.0f;
-                const float cfg_z = fmaxf(1.0f, a.df.Packed1.w);
-                float steps_remaining = a.df.StepAndMisc2.x;
-                float liveness = have_sdf ? 1.0f : 0.0f;
-                while (liveness > 0.0f) {
-                    steps_remaining -= 1.0f;
-                    const float s = sample_distance_field<FMT>(start + (dir * data_x), a.df, a.sdf);
-                    if (STATS) n_samples++;
-                    const float local_radius = fminf((L.cfg_y * data_x) + 0.33f, L.cfg_x);   // MIN_CONE_RADIUS
-                    data_z = fminf(data_z, (s + 1.5f) / local_radius);                        // HACK_DISTANCE_OFFSET
-                    data_x += fmaxf(fabsf(s) * a.df.StepAndMisc2.z, cfg_z);
-                    liveness = steps_remaining * (sat(data_z - 0.075f) * sat(data_y - data_x));
-                }
-                const float visibility = fminf(data_z, steps_remaining / 2.0f);               // MAX_STEP_RAMP_WINDOW
-                cone_opacity = powf(sat(sat(visibility - 0.075f) / (0.95f - 0.075f)), a.df.ConeAndMisc.z);
-            }
-            const float opacity = pre_trace * cone_opacity;
-
-            // SphereLightPixelShader epilogue, SphereLight.fx:37-45.  The specular term is
-            // skipped when Color2.rgb == 0: it then contributes exactly 0 unless
-            // pow() produced inf/NaN (negative SpecularPower), which the reference does not guard.
-            float sr = 0.0f, sg = 0.0f, sb = 0.0f;
-            if (L.has_spec != 0.0f) {
-                const f3 light_direction = P.shaded - mk3(L.cx, L.cy, L.cz);
-                const f3 h = norm3(norm3(P.camera - P.shaded) - light_direction);
-                const float specularity = powf(sat(dot3(h, P.normal)), L.spec_power);
-                sr = L.spec_r * specularity * opacity;
-                sg = L.spec_g * specularity * opacity;
-                sb = L.spec_b * specularity * opacity;
-            }
-            acc_r += (L.col_r * opacity) + sr;
-            acc_g += (L.col_g * opacity) + sg;
-            acc_b += (L.col_b * opacity) + sb;
+            acc_r += cr;
+            acc_g += cg;
+            acc_b += cb;
             acc_a += 1.0f;
         }
     }
@@ -318,16 +351,180 @@ __global__ __launch_bounds__(256) void sphere_lights_kernel(const LightLaunch a,
     if (STATS) {
         // wave reduce, one atomic per wave and counter
         for (int off = 32; off > 0; off >>= 1) {
-            n_samples += __shfl_down(n_samples, off);
-            n_pairs += __shfl_down(n_pairs, off);
-            n_traced += __shfl_down(n_traced, off);
+            st.samples += __shfl_down(st.samples, off);
+            st.pairs += __shfl_down(st.pairs, off);
+            st.traced += __shfl_down(st.traced, off);
         }
         if (lane == 0) {
-            atomicAdd(&a.stats[0], n_samples);
-            atomicAdd(&a.stats[1], n_pairs);
-            atomicAdd(&a.stats[2], n_traced);
+            atomicAdd(&a.stats[0], st.samples);
+            atomicAdd(&a.stats[1], st.pairs);
+            atomicAdd(&a.stats[2], st.traced);
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Particle lights -- ParticleLightVertexShader, ParticleLight.fx:16-83, for every slot below the chunk's quad count:
+// a light record is emitted iff life > 0 and the un-premultiplied render colour x LightColor has alpha > 0.
+// Two passes over 1024-slot blocks: counts, then an ordered emit (block base = sum of the counts before it; inside a
+// block: wave64 ballot + popcount prefix, wave bases through LDS), so the records come out in chunk / slot order --
+// the order the reference's instanced draw blends them in.
+// ---------------------------------------------------------------------------------------------
+constexpr int kPlBlock = 1024;
+
+ILM_DEV bool particle_emits_light(const ParticleLightLaunch& a, int chunk, int slot, float4& position, float4& light_color) {
+    const int quads = (a.quad_counts != nullptr) ? a.quad_counts[chunk] : a.slots;
+    if (slot >= quads || slot >= a.slots)
+        return false;
+    const float* base = a.chunk_bases[chunk];
+    const int64_t S = a.stride;
+    position = mk4(base[slot], base[S + slot], base[2 * S + slot], base[3 * S + slot]);
+    float4 rc = mk4(base[12 * S + slot], base[13 * S + slot], base[14 * S + slot], base[15 * S + slot]);   // Chunk.RenderColor
+    if (rc.w > 0.0f) {   // unpremultiply, :43-45
+        rc.x /= rc.w; rc.y /= rc.w; rc.z /= rc.w;
+    }
+    if (position.w <= 0.0f)
+        return false;
+    light_color = mul4(rc, ld4(a.params.LightColor));
+    return light_color.w > 0.0f;
+}
+
+__global__ __launch_bounds__(kPlBlock) void particle_light_count_kernel(const ParticleLightLaunch a, int blocks_per_chunk) {
+    __shared__ int wave_counts[kPlBlock / 64];
+    const int chunk = (int)blockIdx.x / blocks_per_chunk, blk = (int)blockIdx.x - chunk * blocks_per_chunk;
+    const int slot = blk * kPlBlock + (int)threadIdx.x;
+    float4 pos, col;
+    const bool emit = particle_emits_light(a, chunk, slot, pos, col);
+    const unsigned long long m = __ballot(emit);
+    if ((threadIdx.x & 63u) == 0u) wave_counts[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int w = 0; w < kPlBlock / 64; w++) n += wave_counts[w];
+        a.block_counts[blockIdx.x] = n;
+    }
+}
+
+__global__ __launch_bounds__(kPlBlock) void particle_light_emit_kernel(const ParticleLightLaunch a, int blocks_per_chunk) {
+    __shared__ int wave_counts[kPlBlock / 64];
+    __shared__ int partial[kPlBlock / 64];
+    __shared__ int block_base;
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    // exclusive prefix of the block counts before this block (a few thousand ints at most)
+    int sum = 0;
+    for (int i = (int)threadIdx.x; i < (int)blockIdx.x; i += kPlBlock) sum += a.block_counts[i];
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off);
+    if (lane == 0) partial[wave] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int b = 0;
+        for (int w = 0; w < kPlBlock / 64; w++) b += partial[w];
+        block_base = b;
+        if (blockIdx.x == gridDim.x - 1)
+            *a.out_count = min(b + a.block_counts[blockIdx.x], a.capacity);
+    }
+    const int chunk = (int)blockIdx.x / blocks_per_chunk, blk = (int)blockIdx.x - chunk * blocks_per_chunk;
+    const int slot = blk * kPlBlock + (int)threadIdx.x;
+    float4 pos, col;
+    const bool emit = particle_emits_light(a, chunk, slot, pos, col);
+    const unsigned long long m = __ballot(emit);
+    if (lane == 0) wave_counts[wave] = __popcll(m);
+    __syncthreads();
+    if (!emit)
+        return;
+    int index = block_base + __popcll(m & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; w++) index += wave_counts[w];
+    if (index >= a.capacity)
+        return;
+    const IlmParticleLightParams& P = a.params;
+    LightRec r;
+    r.cx = pos.x; r.cy = pos.y; r.cz = pos.z;
+    r.radius = P.LightProperties.x; r.ramp = P.LightProperties.y; r.falloff_mode = P.LightProperties.z; r.casts_shadows = P.LightProperties.w;
+    r.ao_radius = P.MoreLightProperties.x; r.shadow_falloff = P.MoreLightProperties.y; r.falloff_y = P.MoreLightProperties.z; r.ao_opacity = P.MoreLightProperties.w;
+    r.shadow_filter = -1.0f;                                                   // ParticleLightPixelShader has no shadow filter
+    r.col_r = col.x * col.w; r.col_g = col.y * col.w; r.col_b = col.z * col.w; // lightColor.rgb * lightColor.a, :113-116
+    r.spec_r = P.LightSpecularColor.x; r.spec_g = P.LightSpecularColor.y; r.spec_b = P.LightSpecularColor.z; r.spec_power = P.LightSpecularColor.w;
+    r.has_spec = ((r.spec_r != 0.0f) || (r.spec_g != 0.0f) || (r.spec_b != 0.0f)) ? 1.0f : 0.0f;
+    // the quad, :55-70: a plain rectangle (fx1 = fx0, fx2 = fx3 collapse the sphere light's cross shape onto it)
+    const float radius = P.LightProperties.x + P.LightProperties.y + 1.0f;
+    const float tlx = r.cx - radius, brx = r.cx + radius, bry = r.cy + radius;
+    float tly = r.cy - radius;
+    tly -= radius * a.env.ZToY.y;
+    tly -= r.cz * a.env.ZToY.x;
+    const float sx = a.env.GBufferTexelSizeAndMisc.z * a.env.ZAndScale.z, sy = a.env.GBufferTexelSizeAndMisc.w * a.env.ZAndScale.w;
+    r.fx0 = r.fx1 = (tlx - a.env.ViewportPosition[0]) * sx;
+    r.fx2 = r.fx3 = (brx - a.env.ViewportPosition[0]) * sx;
+    r.fy0 = r.fy1 = (tly - a.env.ViewportPosition[1]) * sy;
+    r.fy2 = r.fy3 = (bry - a.env.ViewportPosition[1]) * sy;
+    const float max_radius = clampf(r.radius, 0.33f, a.max_cone_radius);
+    r.cfg_x = max_radius;
+    r.cfg_y = max_radius / fmaxf(r.ramp, 16.0f) * 1.0f;
+    r._pad0 = r._pad1 = 0.0f;
+    reinterpret_cast<LightRec*>(a.recs)[index] = r;
+}
+
+hipError_t launch_prepare_particle_lights(const ParticleLightLaunch& a, hipStream_t stream) {
+    const int blocks_per_chunk = (a.slots + kPlBlock - 1) / kPlBlock;
+    const int blocks = a.chunk_count * blocks_per_chunk;
+    if (blocks <= 0) return hipMemsetAsync(a.out_count, 0, sizeof(int32_t), stream);
+    hipLaunchKernelGGL(particle_light_count_kernel, dim3(blocks), dim3(kPlBlock), 0, stream, a, blocks_per_chunk);
+    hipLaunchKernelGGL(particle_light_emit_kernel, dim3(blocks), dim3(kPlBlock), 0, stream, a, blocks_per_chunk);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------
+// Light probes -- SphereLightProbePixelShader, SphereLightProbe.fx:19-44: one lane per probe walks every light record
+// (uniform index -> scalar loads), fp32 accumulation in light order.
+// ---------------------------------------------------------------------------------------------
+template <int FMT>
+__global__ __launch_bounds__(64) void light_probes_kernel(const LightRec* __restrict__ recs, int light_count,
+                                                           const float4* __restrict__ probe_positions, const float4* __restrict__ probe_normals,
+                                                           int probe_count, IlmEnvironment env, IlmDistanceFieldUniforms df, SdfView sdf,
+                                                           float4* __restrict__ values) {
+    const int i = (int)blockIdx.x * 64 + (int)threadIdx.x;
+    const bool valid = i < probe_count;
+    const float4 pp = valid ? probe_positions[i] : mk4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float4 pn = valid ? probe_normals[i] : mk4(0.0f, 0.0f, 0.0f, 0.0f);
+    // sampleLightProbeBuffer, LightCommon.fxh:233-254
+    const float probe_opacity = pp.w;
+    Pixel P;
+    P.shaded = xyz(pp); P.normal = xyz(pn); P.camera = mk3(0.0f, 0.0f, 0.0f);
+    P.fullbright = false;
+    const bool have_sdf = (sdf.texels != nullptr) && (df.Extent.x > 0.0f);
+    float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f, acc_a = 0.0f;
+    LightStats st;
+    for (int k = 0; k < light_count; k++) {
+        LightRec L = recs[k];
+        if (!(valid && probe_opacity > 0.0f))
+            continue;
+        // lightProperties.w *= enableShadows (a float here, not the G-buffer's flag); no AO, no specular, no shadow filter (:33-42)
+        L.casts_shadows *= pn.w;
+        P.enable_shadows = true;
+        L.ao_radius = 0.0f; L.ao_opacity = 0.0f;
+        L.shadow_filter = -1.0f;
+        L.has_spec = 0.0f;
+        float cr, cg, cb;
+        if (!shade_light<FMT, false>(P, L, env, df, sdf, have_sdf, st, cr, cg, cb))
+            continue;
+        acc_r += cr * probe_opacity;
+        acc_g += cg * probe_opacity;
+        acc_b += cb * probe_opacity;
+        acc_a += 1.0f;
+    }
+    if (valid)
+        values[i] = mk4(acc_r, acc_g, acc_b, acc_a);
+}
+
+hipError_t launch_light_probes(const void* recs, int light_count, const float4* probe_positions, const float4* probe_normals, int probe_count,
+                               const IlmEnvironment& env, const IlmDistanceFieldUniforms& df, const SdfView& sdf, float4* values, hipStream_t stream) {
+    if (probe_count <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((probe_count + 63) / 64)), block(64);
+    const LightRec* r = reinterpret_cast<const LightRec*>(recs);
+    if (sdf.format == ILM_SDF_FP16)
+        hipLaunchKernelGGL(light_probes_kernel<ILM_SDF_FP16>, grid, block, 0, stream, r, light_count, probe_positions, probe_normals, probe_count, env, df, sdf, values);
+    else
+        hipLaunchKernelGGL(light_probes_kernel<ILM_SDF_UNORM16>, grid, block, 0, stream, r, light_count, probe_positions, probe_normals, probe_count, env, df, sdf, values);
+    return hipGetLastError();
 }
 
 template <int FMT>

@@ -78,6 +78,8 @@ SYMBOLS = {
     "ilm_lightmap_device_ptr": (_I, [_H, C.POINTER(_P)]),
     "ilm_lightmap_destroy": (_I, [_H]),
     "ilm_render_sphere_lights": (_I, [_H, _P, _I, _P, _P, _H, _H, _P, _H, _I, _I, _P]),
+    "ilm_render_particle_lights": (_I, [_H, _H, _P, _I, _P, _P, _P, _H, _H, _H, _I, _I, _P]),
+    "ilm_render_light_probes": (_I, [_H, _P, _I, _P, _P, _I, _P, _P, _H, _P]),
 }
 
 
@@ -394,3 +396,31 @@ def render_sphere_lights(ctx, lights, env, df, gbuffer, sdf, ambient, lightmap, 
         sdf.handle if sdf is not None else abi.Handle(0),
         C.cast(amb, C.c_void_p), lightmap.handle, row_begin, row_end, _byref(stats)))
     return stats
+
+
+def render_particle_lights(ctx, system, params, env, df, gbuffer, sdf, lightmap, quad_counts=None, chunk_count=None, row_begin=0, row_end=None,
+                           want_stats=False):
+    """ilm_render_particle_lights: one sphere light per live particle of `system`, added onto the lightmap's contents."""
+    if row_end is None:
+        row_end = lightmap.height
+    if chunk_count is None:
+        chunk_count = system.chunk_count()
+    q = np.ascontiguousarray(quad_counts, dtype=np.int32) if quad_counts is not None else None
+    stats = abi.RenderStats() if want_stats else None
+    check(lib().ilm_render_particle_lights(
+        ctx.handle, system.handle, _ptr(q) if q is not None else None, chunk_count, _byref(params), _byref(env), _byref(df),
+        gbuffer.handle if gbuffer is not None else abi.Handle(0), sdf.handle if sdf is not None else abi.Handle(0),
+        lightmap.handle, row_begin, row_end, _byref(stats)))
+    return stats
+
+
+def render_light_probes(ctx, lights, probe_positions, probe_normals, env, df, sdf):
+    """ilm_render_light_probes: (n, 4) float32 probe values (rgb sum, contributing light count)."""
+    n = len(lights) if lights is not None else 0
+    pp = np.ascontiguousarray(probe_positions, dtype=np.float32).reshape(-1, 4)
+    pn = np.ascontiguousarray(probe_normals, dtype=np.float32).reshape(-1, 4)
+    assert pp.shape == pn.shape
+    out = np.zeros_like(pp)
+    check(lib().ilm_render_light_probes(ctx.handle, C.cast(lights, C.c_void_p) if n else None, n, _ptr(pp), _ptr(pn), pp.shape[0],
+                                        _byref(env), _byref(df), sdf.handle if sdf is not None else abi.Handle(0), _ptr(out)))
+    return out

@@ -519,6 +519,42 @@ int32_t ilm_render_sphere_lights(IlmHandle ctx,
                                  IlmHandle lightmap, int32_t row_begin, int32_t row_end,
                                  IlmRenderStats* stats);
 
+/* ---- particle lights and light probes --------------------------------------------------------- */
+
+/* What _ParticleLightBatchSetup binds for a ParticleLightSource (Illuminant/Lighting/LightingRenderer.cs:769-790,
+ * Illuminant/Lighting/LightSource.cs:466-505) + the StippleFactor ParticleSystem.Render adds
+ * (Illuminant/Particles/ParticleSystem.cs:1023). */
+typedef struct IlmParticleLightParams {
+    IlmFloat4 LightProperties;      /* Template.Radius, RampLength, RampMode, CastsShadows && DistanceField */
+    IlmFloat4 MoreLightProperties;  /* aoRadius (0 when aoOpacity <= .001), shadowDistanceFalloff | -99999, falloffYFactor, saturate(aoOpacity) */
+    IlmFloat4 LightColor;           /* Template.Color */
+    IlmFloat4 LightSpecularColor;   /* Template.SpecularColor, SpecularPower */
+    float     StippleFactor;        /* must be >= 1: StippleReject is Fracture code outside the tree (DitherCommon.fxh) */
+    float     _pad[3];
+} IlmParticleLightParams;
+
+/* technique ParticleLight (Illuminant/Shaders/ParticleLight.fx:16-118): one sphere light per live particle of `system`
+ * (position from PositionAndLife, colour = un-premultiplied Chunk.RenderColor x LightColor), additively blended onto what the
+ * lightmap already holds -- RenderLighting draws it as one more light-type render state after the clear
+ * (LightingRenderer.cs:1126-1141).  quad_counts[i] = min(ChunkMaximumCount, chunk.TotalSpawned + 1) slots of chunk i take part
+ * (RenderChunk, ParticleSystem.cs:880); NULL => every slot.  The live particles are compacted on the device in chunk / slot
+ * order (wave64 ballot + prefix sum) into the same light records the sphere-light pass uses; nothing is read back. */
+int32_t ilm_render_particle_lights(IlmHandle ctx, IlmHandle system, const int32_t* quad_counts, int32_t chunk_count,
+                                   const IlmParticleLightParams* params,
+                                   const IlmEnvironment* env, const IlmDistanceFieldUniforms* df,
+                                   IlmHandle gbuffer, IlmHandle sdf,
+                                   IlmHandle lightmap, int32_t row_begin, int32_t row_end,
+                                   IlmRenderStats* stats);
+
+/* technique SphereLightProbe (Illuminant/Shaders/SphereLightProbe.fx:19-44) for `probe_count` probes
+ * (UpdateLightProbes, Illuminant/Lighting/LightingRenderer.LightProbes.cs:49-110): probe_positions[i] = (position, 1),
+ * probe_normals[i] = (normal or 0, enableShadows); out_values[i] = sum over lights of color.rgb * color.a * opacity, alpha =
+ * number of contributing lights.  Host arrays; synchronises (the reference reads the values back, :112-150). */
+int32_t ilm_render_light_probes(IlmHandle ctx, const IlmLightVertex* lights, int32_t light_count,
+                                const IlmFloat4* probe_positions, const IlmFloat4* probe_normals, int32_t probe_count,
+                                const IlmEnvironment* env, const IlmDistanceFieldUniforms* df, IlmHandle sdf,
+                                IlmFloat4* out_values);
+
 #ifdef __cplusplus
 }
 #endif

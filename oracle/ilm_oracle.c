@@ -1321,6 +1321,8 @@ void orc_render_sphere_lights(const IlmLightVertex* lights, int32_t light_count,
     }
 }
 
+#include "ilm_oracle_lights.c"
+
 /* ---------------------------------------------------------------------------
  * Host-side integer / layout logic
  * ------------------------------------------------------------------------- */

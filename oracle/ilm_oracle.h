@@ -100,6 +100,18 @@ void orc_render_sphere_lights(const IlmLightVertex* lights, int32_t light_count,
                               IlmFloat4* lightmap, int32_t width, int32_t height,
                               int32_t row_begin, int32_t row_end, IlmRenderStats* stats);
 
+/* particle lights and light probes, ilm_oracle_lights.c; the lightmap is accumulated into (additive blend) */
+void orc_render_particle_lights(IlmFloat4** planes, int32_t chunk_count, const int32_t* quad_counts,
+                                const IlmParticleLightParams* p,
+                                const IlmEnvironment* env, const IlmDistanceFieldUniforms* df,
+                                const OrcTexture* gbuffer, const OrcTexture* sdf,
+                                IlmFloat4* lightmap, int32_t width, int32_t height,
+                                int32_t row_begin, int32_t row_end, IlmRenderStats* stats);
+void orc_render_light_probes(const IlmLightVertex* lights, int32_t light_count,
+                             const IlmFloat4* probe_positions, const IlmFloat4* probe_normals, int32_t probe_count,
+                             const IlmEnvironment* env, const IlmDistanceFieldUniforms* df, const OrcTexture* sdf,
+                             IlmFloat4* out_values);
+
 /* host-side integer/layout logic */
 typedef struct OrcDistanceFieldLayout {
     int32_t virtual_width, virtual_height;

@@ -21,7 +21,7 @@ def build(force=False):
     """Compile the C restatement with gcc (oracle/Makefile)."""
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-            for f in ("ilm_oracle.c", "ilm_oracle_fields.c", "ilm_oracle_transforms.c", "ilm_oracle.h")):
+            for f in ("ilm_oracle.c", "ilm_oracle_fields.c", "ilm_oracle_transforms.c", "ilm_oracle_lights.c", "ilm_oracle.h")):
         subprocess.run(["make", "-C", _HERE, "-s"], check=True)
     return _LIB_PATH
 
@@ -257,6 +257,34 @@ def render_distance_field_slices(atlas, fmt, desc, first_virtual_slices, obstruc
                                            obstructions if no else None, C.c_int32(no), volumes if nv else None, C.c_int32(nv),
                                            _p(poly) if poly.shape[0] else None, C.c_int32(poly.shape[0]))
     return atlas
+
+
+def render_particle_lights(chunks, quad_counts, params, env, df, gbuffer, sdf, lightmap, row_begin=0, row_end=None, want_stats=False):
+    """orc_render_particle_lights: chunks = list of 5 planes per chunk; lightmap (H, W, 4) float32 is accumulated into, in place."""
+    n = len(chunks)
+    ptrs = (C.c_void_p * (n * 5))()
+    for c, planes in enumerate(chunks):
+        for k in range(5):
+            ptrs[c * 5 + k] = _f4(planes[k]).value
+    q = np.ascontiguousarray(quad_counts, dtype=np.int32)
+    h, w = lightmap.shape[0], lightmap.shape[1]
+    if row_end is None:
+        row_end = h
+    stats = abi.RenderStats() if want_stats else None
+    lib().orc_render_particle_lights(ptrs, C.c_int32(n), _p(q), C.byref(params), C.byref(env), C.byref(df),
+                                     C.byref(gbuffer) if gbuffer is not None else None, C.byref(sdf) if sdf is not None else None,
+                                     _f4(lightmap), C.c_int32(w), C.c_int32(h), C.c_int32(row_begin), C.c_int32(row_end),
+                                     C.byref(stats) if stats is not None else None)
+    return stats
+
+
+def render_light_probes(lights, probe_positions, probe_normals, env, df, sdf):
+    pp = np.ascontiguousarray(probe_positions, dtype=np.float32).reshape(-1, 4)
+    pn = np.ascontiguousarray(probe_normals, dtype=np.float32).reshape(-1, 4)
+    out = np.zeros_like(pp)
+    lib().orc_render_light_probes(lights, C.c_int32(len(lights) if lights is not None else 0), _f4(pp), _f4(pn), C.c_int32(pp.shape[0]),
+                                  C.byref(env), C.byref(df), C.byref(sdf) if sdf is not None else None, _f4(out))
+    return out
 
 
 # ---- host logic -------------------------------------------------------------------------------------

@@ -521,8 +521,54 @@ def gen_transforms_ext():
             "tolerance": "1e-5 relative", "cases": cases}
 
 
+# ---------------------------------------------------------------------------------------------------------
+# 10. Particle lights and light probes: closed forms from ParticleLight.fx:16-118, SphereLightProbe.fx:19-44,
+#     LightCommon.fxh:154-214 (no distance field => cone trace 1, no AO)
+# ---------------------------------------------------------------------------------------------------------
+def gen_lights_ext():
+    cases = []
+    # (a) a particle on the shaded pixel: distance 0 < radius => opacity 1.  Colour = (renderColor.rgb / renderColor.a, renderColor.a) *
+    #     LightColor, blended as rgb * a on top of what the lightmap holds; alpha counts the light (ParticleLight.fx:40-45,72,113-116)
+    rc = [0.2, 0.1, 0.05, 0.5]
+    lc = [1.0, 0.5, 2.0, 0.8]
+    un = [rc[0] / rc[3], rc[1] / rc[3], rc[2] / rc[3], rc[3]]
+    light = [un[i] * lc[i] for i in range(4)]
+    base = [0.05, 0.06, 0.07, 1.0]
+    cases.append({"kind": "particle_light", "particle": {"position": [8.0, 6.0, 0.0, 1.5], "render_color": rc}, "light_color": lc,
+                  "radius": 4.0, "ramp": 10.0, "lightmap_before": base, "pixel": [8, 6],
+                  "expected": [base[0] + light[0] * light[3], base[1] + light[1] * light[3], base[2] + light[2] * light[3], 2.0]})
+    # (b) the same particle dead (life 0), transparent (render alpha 0) or beyond the chunk's quad count: the lightmap keeps its contents
+    for why, part, quads in (("dead", {"position": [8.0, 6.0, 0.0, 0.0], "render_color": rc}, 64),
+                             ("transparent", {"position": [8.0, 6.0, 0.0, 1.5], "render_color": [0.2, 0.1, 0.05, 0.0]}, 64),
+                             ("beyond_quad_count", {"position": [8.0, 6.0, 0.0, 1.5], "render_color": rc}, 3)):
+        cases.append({"kind": "particle_light", "why": why, "particle": part, "slot": 5, "quad_count": quads, "light_color": lc,
+                      "radius": 4.0, "ramp": 10.0, "lightmap_before": base, "pixel": [8, 6], "expected": base})
+    # (c) linear ramp: ground plane (normal +z), particle in the plane => dot(light direction, normal) = 0 => normal factor 1;
+    #     at distance radius + k ramp the opacity is 1 - k (LightCommon.fxh:154-214)
+    for k in (0.25, 0.5):
+        d = 4.0 + k * 16.0
+        cases.append({"kind": "particle_light", "particle": {"position": [4.0, 4.0, 0.0, 1.0], "render_color": [1.0, 1.0, 1.0, 1.0]},
+                      "light_color": [1.0, 1.0, 1.0, 1.0], "radius": 4.0, "ramp": 16.0, "lightmap_before": [0.0, 0.0, 0.0, 1.0],
+                      "pixel": [4 + int(d), 4], "expected": [1.0 - k, 1.0 - k, 1.0 - k, 2.0]})
+    # (d) light probe without a normal (normal factor 1), 3 lights at distances inside the radius / mid-ramp / beyond the ramp:
+    #     value = sum colour.rgb * colour.a * opacity; alpha = number of lights that were not discarded (opacity 0 => discard)
+    probe = [100.0, 50.0, 10.0]
+    lights = [{"position": [100.0, 50.0, 12.0], "radius": 5.0, "ramp": 20.0, "color": [1.0, 0.0, 0.0, 0.5]},      # distance 2 < radius: 1
+              {"position": [115.0, 50.0, 10.0], "radius": 5.0, "ramp": 20.0, "color": [0.0, 1.0, 0.0, 1.0]},      # distance 15: 1 - 10/20 = .5
+              {"position": [100.0, 90.0, 10.0], "radius": 5.0, "ramp": 20.0, "color": [0.0, 0.0, 1.0, 1.0]}]      # distance 40 > 25: discarded
+    cases.append({"kind": "light_probe", "probe": {"position": probe, "normal": None, "enable_shadows": True}, "lights": lights,
+                  "expected": [0.5, 0.5, 0.0, 2.0]})
+    # (e) a probe facing away from the light (normal . direction to light = -1): normal factor = pow(saturate((-1 + .15) / .15), .85) = 0 => discarded
+    cases.append({"kind": "light_probe", "probe": {"position": probe, "normal": [-1.0, 0.0, 0.0], "enable_shadows": True}, "lights": [lights[1]],
+                  "expected": [0.0, 0.0, 0.0, 0.0]})
+    cases.append({"kind": "light_probe", "probe": {"position": probe, "normal": [1.0, 0.0, 0.0], "enable_shadows": True}, "lights": [lights[1]],
+                  "expected": [0.0, 0.5, 0.0, 1.0]})
+    return {"source": "hand-derived from ParticleLight.fx:16-118, SphereLightProbe.fx:19-44, LightCommon.fxh:154-254 (see comments in make_golden.py)",
+            "tolerance": "1e-5 relative", "cases": cases}
+
+
 def main():
-    out = {"transforms_ext.json": gen_transforms_ext(), "distance_field_generation.json": gen_distance_field_generation(), "bezier.json": gen_bezier(), "distance_field_layout.json": gen_layout(), "spawner.json": gen_spawner(),
+    out = {"lights_ext.json": gen_lights_ext(), "transforms_ext.json": gen_transforms_ext(), "distance_field_generation.json": gen_distance_field_generation(), "bezier.json": gen_bezier(), "distance_field_layout.json": gen_layout(), "spawner.json": gen_spawner(),
            "liveness.json": gen_liveness(), "distance_encoding.json": gen_encoding(), "gbuffer.json": gen_gbuffer(),
            "closed_form.json": gen_closed_form()}
     for name, doc in out.items():

@@ -23,6 +23,7 @@ STRUCTS = {
     "IlmNoiseParams": abi.NoiseParams, "IlmSpawnParams": abi.SpawnParams, "IlmUpdateParams": abi.UpdateParams,
     "IlmTransformOp": abi.TransformOp, "IlmSpawnRecord": abi.SpawnRecord, "IlmStepDesc": abi.StepDesc, "IlmRenderStats": abi.RenderStats,
     "IlmMatrixMultiplyParams": abi.MatrixMultiplyParams, "IlmSpatialNoiseParams": abi.SpatialNoiseParams, "IlmFeedbackParams": abi.FeedbackParams,
+    "IlmParticleLightParams": abi.ParticleLightParams,
     "IlmObstruction": abi.Obstruction, "IlmHeightVolume": abi.HeightVolume, "IlmDistanceFieldRenderDesc": abi.DistanceFieldRenderDesc,
 }
 
