@@ -299,6 +299,23 @@ PYBIND11_MODULE(_host, m) {
         .def_readwrite("ShadowFilter", &SphereLightSource::ShadowFilter)
         VEC_PROP(SphereLightSource, SpecularColor, 3)
         .def_readwrite("SpecularPower", &SphereLightSource::SpecularPower);
+    py::class_<ParticleLightSource>(m, "ParticleLightSource").def(py::init<>())
+        .def_readwrite("Template", &ParticleLightSource::Template)
+        .def_property("System", py::cpp_function([](ParticleLightSource& s) { return s.System; }, py::return_value_policy::reference),
+                      py::cpp_function([](ParticleLightSource& s, ParticleSystem* p) { s.System = p; }, py::keep_alive<1, 2>()))
+        .def_readwrite("IsActive", &ParticleLightSource::IsActive).def_readwrite("Enabled", &ParticleLightSource::Enabled)
+        .def_readwrite("StippleFactor", &ParticleLightSource::StippleFactor);
+    py::class_<LightProbe, std::shared_ptr<LightProbe>>(m, "LightProbe").def(py::init<>())
+        VEC_PROP(LightProbe, Position, 3)
+        .def_property("Normal", [](const LightProbe& p) -> py::object { if (!p.Normal) return py::none(); return py::cast(l3(*p.Normal)); },
+                      [](LightProbe& p, py::object v) { if (v.is_none()) p.Normal.reset(); else p.Normal = v3(v.cast<std::vector<float>>()); })
+        .def_readwrite("EnableShadows", &LightProbe::EnableShadows)
+        .def_property_readonly("Value", [](const LightProbe& p) { return l4(p.Value); })
+        .def_property_readonly("PreviousValue", [](const LightProbe& p) { return l4(p.PreviousValue); });
+    py::class_<LightProbeCollection>(m, "LightProbeCollection")
+        .def("Add", &LightProbeCollection::Add).def("Clear", &LightProbeCollection::Clear)
+        .def_property_readonly("Count", &LightProbeCollection::Count).def("__len__", &LightProbeCollection::Count)
+        .def("__getitem__", [](LightProbeCollection& c, int i) { return c.Items.at((size_t)i); });
     py::class_<LightObstruction, std::shared_ptr<LightObstruction>>(m, "LightObstruction")
         .def(py::init([](int type, const std::vector<float>& center, const std::vector<float>& radius, float rotation) {
             return std::make_shared<LightObstruction>((LightObstructionType)type, v3(center), v3(radius), rotation);
@@ -323,6 +340,7 @@ PYBIND11_MODULE(_host, m) {
         .def_readwrite("IsDynamic", &HeightVolume::IsDynamic).def_readwrite("IsObstruction", &HeightVolume::IsObstruction);
     py::class_<LightingEnvironment>(m, "LightingEnvironment").def(py::init<>())
         .def_readwrite("Lights", &LightingEnvironment::Lights)
+        .def_readwrite("ParticleLights", &LightingEnvironment::ParticleLights)
         .def_property_readonly("Obstructions", [](LightingEnvironment& e) -> LightObstructionCollection& { return e.Obstructions; }, py::return_value_policy::reference_internal)
         .def_readwrite("HeightVolumes", &LightingEnvironment::HeightVolumes)
         .def_readwrite("GroundZ", &LightingEnvironment::GroundZ).def_readwrite("MaximumZ", &LightingEnvironment::MaximumZ)
@@ -340,6 +358,7 @@ PYBIND11_MODULE(_host, m) {
         VEC_PROP(RendererConfiguration, RenderScale, 2)
         .def_readwrite("DefaultQuality", &RendererConfiguration::DefaultQuality)
         .def_readwrite("MaximumFieldUpdatesPerFrame", &RendererConfiguration::MaximumFieldUpdatesPerFrame)
+        .def_readwrite("MaximumLightProbeCount", &RendererConfiguration::MaximumLightProbeCount)
         .def_readwrite("FloatLightmap", &RendererConfiguration::FloatLightmap);
     py::class_<LightingRenderer>(m, "LightingRenderer")
         .def(py::init([](DeviceContext& ctx, const RendererConfiguration& cfg, LightingEnvironment* env, uintptr_t externalLightmap) {
@@ -356,6 +375,9 @@ PYBIND11_MODULE(_host, m) {
             r.SetGBuffer(a.data(), (int)a.shape(1), (int)a.shape(0), format);
         })
         .def("UpdateFields", &LightingRenderer::UpdateFields)
+        .def_property_readonly("Probes", [](LightingRenderer& r) -> LightProbeCollection& { return r.Probes; }, py::return_value_policy::reference_internal)
+        .def_static("PackParticleLightBytes", [](const ParticleLightSource& pls, bool haveDF) {
+            auto p = LightingRenderer::PackParticleLight(pls, haveDF); return py::bytes((const char*)&p, sizeof(p)); })
         .def("InvalidateFields", &LightingRenderer::InvalidateFields, py::arg("invalidateDistanceField") = true)
         .def("RenderLighting", [](LightingRenderer& r, float intensityScale, int rowBegin, int rowEnd, bool wantStats) -> py::object {
             if (!wantStats) { r.RenderLighting(intensityScale, rowBegin, rowEnd, nullptr); return py::none(); }

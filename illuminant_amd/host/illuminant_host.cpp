@@ -952,7 +952,7 @@ namespace Lighting {
 
 LightingRenderer::LightingRenderer(DeviceContext& ctx, const RendererConfiguration& configuration, LightingEnvironment* environment,
                                    void* externalLightmap)
-    : Context(ctx), Configuration(configuration), Environment(environment) {
+    : Context(ctx), Configuration(configuration), Environment(environment), Probes(configuration.MaximumLightProbeCount) {
     // lightmap format: HalfVector4 when HighQuality else Color (LightingRenderer.cs:476-479)
     lightmapFormat = configuration.FloatLightmap ? ILM_LIGHTMAP_FLOAT4 : (configuration.HighQuality ? ILM_LIGHTMAP_HALF4 : ILM_LIGHTMAP_RGBA8);
     ThrowIfFailed(ilm_lightmap_create(ctx.Handle(), configuration.RenderWidth, configuration.RenderHeight, lightmapFormat, externalLightmap, &lightmap));
@@ -1037,6 +1037,63 @@ void LightingRenderer::RenderLighting(float intensityScale, int rowBegin, int ro
                                Environment->Ambient.Z * intensityScale, Environment->Ambient.W * intensityScale };
     ThrowIfFailed(ilm_render_sphere_lights(Context.Handle(), vertices.empty() ? nullptr : vertices.data(), (int32_t)vertices.size(),
                                            &env, &dfu, gbuffer, Field ? Field->Texture() : 0, ambient, lightmap, rowBegin, rowEnd, stats));
+    // particle light sources: one more light-type render state each, blended on top (:1126-1141)
+    for (const ParticleLightSource& pls : Environment->ParticleLights) {
+        if (!pls.Enabled || !pls.IsActive || !pls.System)
+            continue;
+        const IlmParticleLightParams p = PackParticleLight(pls, Field != nullptr);
+        // RenderChunk, ParticleSystem.cs:880: quadCount = min(ChunkMaximumCount, chunk.TotalSpawned + 1)
+        std::vector<int32_t> quads;
+        for (const Particles::ParticleSystem::Chunk& c : pls.System->Chunks())
+            quads.push_back(std::min(pls.System->ChunkMaximumCount(), c.TotalSpawned + 1));
+        if (quads.empty())
+            continue;
+        IlmRenderStats ps{};
+        ThrowIfFailed(ilm_render_particle_lights(Context.Handle(), pls.System->Handle(), quads.data(), (int32_t)quads.size(), &p, &env, &dfu,
+                                                 gbuffer, Field ? Field->Texture() : 0, lightmap, rowBegin, rowEnd, stats ? &ps : nullptr));
+        if (stats) { stats->SdfSamples += ps.SdfSamples; stats->PixelLightPairs += ps.PixelLightPairs; stats->TracedPairs += ps.TracedPairs; }
+    }
+    if (Probes.Count() > 0)      // :1176-1182
+        UpdateLightProbes(intensityScale);
+}
+
+IlmParticleLightParams LightingRenderer::PackParticleLight(const ParticleLightSource& pls, bool haveDistanceField) {
+    const SphereLightSource& l = pls.Template;
+    IlmParticleLightParams p;
+    std::memset(&p, 0, sizeof(p));
+    p.LightProperties = { l.Radius, l.RampLength, (float)(int)l.RampMode, (l.CastsShadows && haveDistanceField) ? 1.0f : 0.0f };
+    p.MoreLightProperties = { l.AmbientOcclusionOpacity > 0.001 ? l.AmbientOcclusionRadius : 0.0f, l.ShadowDistanceFalloff.value_or(-99999.0f),
+                              l.FalloffYFactor, std::min(std::max(l.AmbientOcclusionOpacity, 0.0f), 1.0f) };
+    p.LightColor = { l.Color.X, l.Color.Y, l.Color.Z, l.Color.W };
+    p.LightSpecularColor = { l.SpecularColor.X, l.SpecularColor.Y, l.SpecularColor.Z, l.SpecularPower };
+    p.StippleFactor = pls.StippleFactor.value_or(1.0f);
+    return p;
+}
+
+// UpdateLightProbeTexture + UpdateLightProbes + LightProbeDownloadTask, LightingRenderer.LightProbes.cs:49-150.  The reference reads
+// the values back a frame later on a worker thread; here the call synchronises and the probes hold this frame's values.
+void LightingRenderer::UpdateLightProbes(float intensityScale) {
+    const int n = Probes.Count();
+    std::vector<IlmFloat4> positions((size_t)n), normals((size_t)n), values((size_t)n);
+    for (int i = 0; i < n; i++) {
+        const LightProbe& p = *Probes.Items[(size_t)i];
+        positions[(size_t)i] = { p.Position.X, p.Position.Y, p.Position.Z, 1.0f };
+        if (p.Normal) normals[(size_t)i] = { p.Normal->X, p.Normal->Y, p.Normal->Z, p.EnableShadows ? 1.0f : 0.0f };
+        else normals[(size_t)i] = { 0, 0, 0, p.EnableShadows ? 1.0f : 0.0f };
+    }
+    Probes.IsDirty = false;
+    const IlmEnvironment env = GetEnvironmentUniforms();
+    const IlmDistanceFieldUniforms dfu = GetDistanceFieldUniforms(Configuration.DefaultQuality);
+    // the light vertices of this frame were packed with intensityScale folded into Color1.a (RenderSphereLightSource, :1203)
+    ThrowIfFailed(ilm_render_light_probes(Context.Handle(), vertices.empty() ? nullptr : vertices.data(), (int32_t)vertices.size(),
+                                          positions.data(), normals.data(), n, &env, &dfu, Field ? Field->Texture() : 0, values.data()));
+    const float scaleFactor = 1.0f / intensityScale;     // LightProbeDownloadTask.ScaleFactor, LightingRenderer.cs:943
+    for (int i = 0; i < n; i++) {
+        LightProbe& p = *Probes.Items[(size_t)i];
+        p.PreviousValue = p.Value;
+        // the probe target is a HalfVector4: round through fp16 like the read-back does
+        p.Value = { values[(size_t)i].x * scaleFactor, values[(size_t)i].y * scaleFactor, values[(size_t)i].z * scaleFactor, values[(size_t)i].w * scaleFactor };
+    }
 }
 
 // ---- LightObstruction.cs ---------------------------------------------------------------------------------

@@ -542,6 +542,35 @@ struct SphereLightSource {
     float SpecularPower = 1;
 };
 
+// ParticleLightSource, LightSource.cs:466-505
+struct ParticleLightSource {
+    SphereLightSource Template;
+    Particles::ParticleSystem* System = nullptr;
+    bool IsActive = true, Enabled = true;
+    std::optional<float> StippleFactor;     // defaults to the system's (1): only >= 1 is supported (StippleReject is Fracture code)
+};
+
+// LightProbe / LightProbeCollection, LightProbe.cs:15-160
+struct LightProbe {
+    Vector3 Position;
+    std::optional<Vector3> Normal;
+    bool EnableShadows = true;
+    Vector4 PreviousValue, Value;
+};
+class LightProbeCollection {
+public:
+    explicit LightProbeCollection(int maximumCount) : MaximumCount(maximumCount) {}
+    const int MaximumCount;
+    bool IsDirty = false;
+    std::vector<std::shared_ptr<LightProbe>> Items;
+    void Add(std::shared_ptr<LightProbe> probe) {
+        if ((int)Items.size() >= MaximumCount) throw InvalidOperationException("List full");    // :32-33
+        Items.push_back(std::move(probe)); IsDirty = true;
+    }
+    void Clear() { Items.clear(); IsDirty = true; }
+    int Count() const { return (int)Items.size(); }
+};
+
 // LightObstruction.cs:10-140
 enum class LightObstructionType : short { Ellipsoid = 0, Box = 1, Cylinder = 2, Spheroid = 3, Octagon = 4 };
 class LightObstruction {
@@ -597,6 +626,7 @@ struct HeightVolume {
 // LightingEnvironment.cs:13-49
 struct LightingEnvironment {
     std::vector<SphereLightSource> Lights;
+    std::vector<ParticleLightSource> ParticleLights;   // ParticleLightSource entries of Lights in the reference (one render state each)
     LightObstructionCollection Obstructions;
     std::vector<HeightVolume> HeightVolumes;
     float GroundZ = 0, MaximumZ = 128, ZToYMultiplier = 0;
@@ -619,6 +649,7 @@ struct RendererConfiguration {
     Vector2 RenderScale{1, 1};
     RendererQualitySettings DefaultQuality;
     int MaximumFieldUpdatesPerFrame = 1;   // LightingRenderer.Configuration.cs:91
+    int MaximumLightProbeCount = 256;      // LightingRenderer.Configuration.cs
     bool FloatLightmap = false;       // extension: fp32 lightmap (parity format)
     RendererConfiguration(int w, int h) : RenderWidth(w), RenderHeight(h) {}
 };
@@ -636,6 +667,7 @@ public:
     RendererConfiguration Configuration;
     LightingEnvironment* Environment;
     DistanceField* Field = nullptr;       // DistanceField property, :594-607
+    LightProbeCollection Probes;          // :330
     // G-buffer: null => ground plane only
     void SetGBuffer(const void* texels, int width, int height, int format);
 
@@ -654,6 +686,8 @@ public:
     IlmHandle Lightmap() const { return lightmap; }
     int LightmapFormat() const { return lightmapFormat; }
 
+    // _ParticleLightBatchSetup, :769-790
+    static IlmParticleLightParams PackParticleLight(const ParticleLightSource& pls, bool haveDistanceField);
     // RenderSphereLightSource, :1193-1219
     static bool PackSphereLight(const SphereLightSource& l, float intensityScale, bool haveDistanceField, IlmLightVertex& v);
     // SetDistanceFieldParameters, :1894-1940
@@ -662,6 +696,7 @@ public:
     IlmEnvironment GetEnvironmentUniforms() const;
 
 private:
+    void UpdateLightProbes(float intensityScale);   // LightingRenderer.LightProbes.cs:49-150 (synchronous read-back)
     void AutoInvalidateDistanceField();
     int RenderDistanceFieldPartition(int dynamicFlagFilter /* -1 = null */);
     IlmHandle lightmap = 0, gbuffer = 0;

@@ -158,3 +158,73 @@ def test_feedback_spawner_consumes_the_source_window(H, hctx, oracle):
     compare_system(src, src_chunks)
     live = compare_system(dst, dst_chunks)
     assert live > 100
+
+
+def test_particle_light_source_and_probes_through_the_renderer(H, hctx, oracle):
+    """LightingEnvironment with a sphere light, a ParticleLightSource on a stepped system and two LightProbes: one RenderLighting call
+    produces the lightmap and the probe values; the oracle redoes it from the replayed particle state."""
+    cs, w, h = 32, 96, 64
+    n = cs * cs
+    engine, tp, rnd = make_engine(H, hctx, cs)
+    cfg = H.ParticleSystemConfiguration()
+    cfg.LifeDecayPerSecond = 0.5
+    col = H.ParticleColor(); col.OpacityFromLife = 2.0
+    cfg.Color = col
+    ps = H.ParticleSystem(engine, cfg)
+    sp = H.Spawner(8)
+    sp.MinRate = sp.MaxRate = 2400.0
+    f = H.Formula3(); f.Constant = [48, 32, 6]; f.RandomScale = [40, 26, 3]; f.Type = H.FormulaType.Spherical
+    sp.Position = f
+    life = H.Formula1(); life.Constant = 0.3; life.RandomScale = 2.0
+    sp.Life = life
+    c4 = H.Formula4(); c4.Constant = [0.9, 0.7, 0.5, 1.0]
+    sp.Color = c4
+    ps.AddTransform(sp)
+    chunks = []
+    for frame in range(5):
+        tp.Advance(1.0 / 60.0)
+        ps.Update(frame)
+        d = abi.StepDesc.from_buffer_copy(ps.LastStepBytes())
+        while len(chunks) < len(ps.Chunks):
+            chunks.append(empty_chunk(n))
+        oracle.step(chunks, cs, rnd, d)
+
+    env = H.LightingEnvironment()
+    env.Ambient = [0.03, 0.03, 0.03, 1.0]
+    l = H.SphereLightSource()
+    l.Position = [20.0, 12.0, 20.0]; l.Radius = 6.0; l.RampLength = 50.0; l.Color = [0.5, 0.6, 0.7, 1.0]
+    env.Lights = [l]
+    pls = H.ParticleLightSource()
+    t = H.SphereLightSource()
+    t.Radius = 1.5; t.RampLength = 14.0; t.Color = [1.0, 0.8, 0.6, 0.7]; t.AmbientOcclusionRadius = 4.0; t.AmbientOcclusionOpacity = 0.5
+    pls.Template = t
+    pls.System = ps
+    env.ParticleLights = [pls]
+    rc = H.RendererConfiguration(w, h)
+    rc.FloatLightmap = True
+    r = H.LightingRenderer(hctx, rc, env)
+    for (pos, nrm) in (([30.0, 20.0, 4.0], None), ([60.0, 40.0, 2.0], [0.0, 0.0, 1.0])):
+        p = H.LightProbe()
+        p.Position = pos
+        p.Normal = nrm
+        r.Probes.Add(p)
+    r.RenderLighting(0.5)       # intensityScale 0.5: folded into the sphere light's alpha and divided back out of the probe values
+    got = r.ReadLightmap()
+
+    dfu = abi.DistanceFieldUniforms.from_buffer_copy(r.GetDistanceFieldUniformsBytes())
+    envu = abi.Environment.from_buffer_copy(r.GetEnvironmentUniformsBytes())
+    verts = (abi.LightVertex * 1)()
+    verts[0] = abi.LightVertex.from_buffer_copy(H.LightingRenderer.PackSphereLightBytes(l, 0.5, False))
+    want, _ = oracle.render_sphere_lights(verts, envu, dfu, None, None, (0.015, 0.015, 0.015, 0.5), w, h)
+    params = abi.ParticleLightParams.from_buffer_copy(H.LightingRenderer.PackParticleLightBytes(pls, False))
+    assert params.MoreLightProperties.x == 4.0 and params.StippleFactor == 1.0
+    quads = [min(n, c.TotalSpawned + 1) for c in ps.Chunks]
+    oracle.render_particle_lights(chunks, quads, params, envu, dfu, None, None, want)
+    assert_close(got, want, "lightmap", rtol=2e-4, atol=2e-5)
+    assert (want[..., 3] > 2.0).any()
+    pp = np.asarray([[30.0, 20.0, 4.0, 1.0], [60.0, 40.0, 2.0, 1.0]], np.float32)
+    pn = np.asarray([[0, 0, 0, 1.0], [0, 0, 1.0, 1.0]], np.float32)
+    pv = oracle.render_light_probes(verts, pp, pn, envu, dfu, None) / 0.5
+    for i in range(2):
+        assert_close(np.asarray(r.Probes[i].Value), pv[i], "probe %d" % i)
+    assert pv[0][3] == 2.0      # one light reached the probe; alpha 1 / intensityScale
