@@ -227,6 +227,25 @@ class ParticleLightParams(C.Structure):
                 ("StippleFactor", f32), ("_pad", f32 * 3)]
 
 
+HDR_NONE, HDR_GAMMA_COMPRESS, HDR_TONE_MAP = 0, 1, 2
+
+
+class ReadbackDrawCall(C.Structure):
+    _fields_ = [("Position", f32 * 2), ("Scale", f32 * 2), ("TextureRegion", f32 * 4), ("Rotation", f32), ("SortOrder", f32),
+                ("MultiplyColor", C.c_uint8 * 4), ("_pad", i32)]
+
+
+class ReadbackParams(C.Structure):
+    _fields_ = [("Size", f32 * 2), ("TextureRegion", f32 * 4), ("AnimationRate", f32 * 2), ("ZToY", f32),
+                ("ColumnFromVelocity", i32), ("RowFromVelocity", i32), ("RotationFromVelocity", i32), ("SortedReadback", i32), ("_pad", i32)]
+
+
+class HDRConfiguration(C.Structure):
+    _fields_ = [("Mode", i32), ("InverseScaleFactor", f32), ("Offset", f32), ("Exposure", f32), ("Gamma", f32),
+                ("MiddleGray", f32), ("AverageLuminance", f32), ("MaximumLuminance", f32), ("WhitePoint", f32),
+                ("ResolveToSRGB", i32), ("DitheringStrength", i32), ("_pad", i32)]
+
+
 class RenderStats(C.Structure):
     _fields_ = [("SdfSamples", C.c_uint64), ("PixelLightPairs", C.c_uint64), ("TracedPairs", C.c_uint64)]
 
@@ -246,6 +265,7 @@ EXPECTED_SIZES = {
     "IlmFeedbackParams": (FeedbackParams, 48),
     "IlmRenderStats": (RenderStats, 24),
     "IlmParticleLightParams": (ParticleLightParams, 80),
+    "IlmReadbackDrawCall": (ReadbackDrawCall, 48), "IlmReadbackParams": (ReadbackParams, 56), "IlmHDRConfiguration": (HDRConfiguration, 48),
     "IlmObstruction": (Obstruction, 48), "IlmHeightVolume": (HeightVolume, 32),
     "IlmDistanceFieldRenderDesc": (DistanceFieldRenderDesc, 64),
 }

@@ -59,6 +59,9 @@ struct Ctx {
     // particle lights: records compacted on the device + their count, block counts, per-chunk quad counts
     void* d_pl_recs = nullptr; int pl_cap = 0; int32_t* d_pl_count = nullptr; int32_t* d_pl_blocks = nullptr; int pl_blocks_cap = 0;
     int32_t* d_pl_quads = nullptr; int pl_quads_cap = 0;
+    // particle read-back: draw-call records, total, block counts, per-chunk element counts
+    IlmReadbackDrawCall* d_rb = nullptr; int rb_cap = 0; int32_t* d_rb_count = nullptr; int32_t* d_rb_blocks = nullptr; int rb_blocks_cap = 0;
+    int32_t* d_rb_elems = nullptr; int rb_elems_cap = 0;
     // light probes: positions | normals | values
     float4* d_probes = nullptr; int probes_cap = 0;
     // parameter block of the distance-field generation pass (slice list, obstruction records, volumes, polygon vertices)
@@ -462,6 +465,10 @@ int32_t ilm_ctx_destroy(IlmHandle h) {
     if (c->d_pl_blocks) (void)hipFree(c->d_pl_blocks);
     if (c->d_pl_quads) (void)hipFree(c->d_pl_quads);
     if (c->d_probes) (void)hipFree(c->d_probes);
+    if (c->d_rb) (void)hipFree(c->d_rb);
+    if (c->d_rb_count) (void)hipFree(c->d_rb_count);
+    if (c->d_rb_blocks) (void)hipFree(c->d_rb_blocks);
+    if (c->d_rb_elems) (void)hipFree(c->d_rb_elems);
     (void)hipStreamSynchronize(c->copy_stream);
     (void)hipStreamDestroy(c->copy_stream);
     (void)hipEventDestroy(c->ev_step);
@@ -1359,6 +1366,110 @@ int32_t ilm_render_light_probes(IlmHandle hctx, const IlmLightVertex* lights, in
     HIP_TRY(launch_light_probes(c->d_recs, light_count, d_pos, d_nrm, probe_count, *env, *df, make_sdf_view(f), d_val, c->stream));
     HIP_TRY(hipMemcpyAsync(out_values, d_val, sizeof(float4) * (size_t)probe_count, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    return ILM_OK;
+}
+
+int32_t ilm_system_readback(IlmHandle hsystem, const int32_t* element_counts, int32_t chunk_count, const IlmReadbackParams* params,
+                            IlmReadbackDrawCall* out, int32_t capacity, int32_t* out_count) {
+    System* s = from_handle<System>(hsystem, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (!params || !out_count || capacity < 0 || (capacity > 0 && !out)) return fail(ILM_ERR_INVALID_ARGUMENT, "bad arguments");
+    *out_count = 0;
+    const int n = (int)s->chunks.size();
+    if (chunk_count < 0 || chunk_count > n) return fail(ILM_ERR_OUT_OF_RANGE, "chunk_count %d outside [0, %d]", chunk_count, n);
+    if (chunk_count == 0) return ILM_OK;
+    Engine* e = s->engine;
+    Ctx* c = e->ctx;
+    for (int i = 0; i < chunk_count; i++)
+        if (element_counts && (element_counts[i] < 0 || element_counts[i] > e->slots))
+            return fail(ILM_ERR_OUT_OF_RANGE, "element_counts[%d] = %d outside [0, %d]", i, element_counts[i], e->slots);
+    HIP_TRY(hipSetDevice(c->device));
+    int32_t rc = refresh_table(s);
+    if (rc != ILM_OK) return rc;
+    const int blocks = chunk_count * ((e->slots + 1023) / 1024);
+    if (capacity > c->rb_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_rb) HIP_TRY(hipFree(c->d_rb));
+        c->d_rb = nullptr; c->rb_cap = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_rb), sizeof(IlmReadbackDrawCall) * (size_t)capacity));
+        c->rb_cap = capacity;
+    }
+    if (!c->d_rb_count) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_rb_count), sizeof(int32_t)));
+    if (blocks > c->rb_blocks_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_rb_blocks) HIP_TRY(hipFree(c->d_rb_blocks));
+        c->d_rb_blocks = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_rb_blocks), sizeof(int32_t) * (size_t)blocks * 2));
+        c->rb_blocks_cap = blocks * 2;
+    }
+    if (chunk_count > c->rb_elems_cap) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_rb_elems) HIP_TRY(hipFree(c->d_rb_elems));
+        c->d_rb_elems = nullptr;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_rb_elems), sizeof(int32_t) * (size_t)chunk_count * 2));
+        c->rb_elems_cap = chunk_count * 2;
+    }
+    if (element_counts) {
+        rc = upload_small(c, c->d_rb_elems, element_counts, sizeof(int32_t) * (size_t)chunk_count);
+        if (rc != ILM_OK) return rc;
+    }
+    ReadbackLaunch a;
+    a.chunk_bases = s->d_table; a.stride = e->stride; a.chunk_count = chunk_count; a.slots = e->slots;
+    a.element_counts = element_counts ? c->d_rb_elems : nullptr;
+    a.params = *params;
+    // ParticleReadback.cs:100-112
+    a.region_w = params->TextureRegion[2] - params->TextureRegion[0];
+    a.region_h = params->TextureRegion[3] - params->TextureRegion[1];
+    a.frame_count_x = std::max((int)(1.0f / a.region_w), 1);
+    a.frame_count_y = std::max((int)(1.0f / a.region_h), 1);
+    a.max_angle_x = (2 * 3.14159265358979323846) / a.frame_count_x;
+    a.max_angle_y = (2 * 3.14159265358979323846) / a.frame_count_y;
+    a.block_counts = c->d_rb_blocks; a.out = c->d_rb; a.capacity = capacity; a.out_count = c->d_rb_count;
+    HIP_TRY(launch_readback(a, c->stream));
+    int32_t total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, c->d_rb_count, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *out_count = total;
+    const int n_copy = total < capacity ? total : capacity;
+    if (n_copy > 0) {
+        HIP_TRY(hipMemcpyAsync(out, c->d_rb, sizeof(IlmReadbackDrawCall) * (size_t)n_copy, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return ILM_OK;
+}
+
+int32_t ilm_resolve_lighting(IlmHandle hsrc, IlmHandle hdst, const IlmHDRConfiguration* hdr, int32_t row_begin, int32_t row_end) {
+    Lightmap* src = from_handle<Lightmap>(hsrc, kMagicLightmap);
+    Lightmap* dst = from_handle<Lightmap>(hdst, kMagicLightmap);
+    if (!src || !dst) return fail(ILM_ERR_INVALID_HANDLE, "not a lightmap handle");
+    if (!hdr) return fail(ILM_ERR_INVALID_ARGUMENT, "hdr is NULL");
+    if (src->ctx != dst->ctx || src->width != dst->width || src->height != dst->height)
+        return fail(ILM_ERR_INVALID_ARGUMENT, "source and destination must share context and size");
+    if (hdr->Mode < ILM_HDR_NONE || hdr->Mode > ILM_HDR_TONE_MAP) return fail(ILM_ERR_INVALID_ARGUMENT, "unknown HDR mode %d", hdr->Mode);
+    if (hdr->ResolveToSRGB != 0)
+        return fail(ILM_ERR_INVALID_ARGUMENT, "ResolveToSRGB needs Fracture's pLinearToPSRGB (sRGBCommon.fxh), which is outside the reference tree");
+    if (hdr->DitheringStrength != 0)
+        return fail(ILM_ERR_INVALID_ARGUMENT, "dithering needs Fracture's ApplyDither (DitherCommon.fxh), which is outside the reference tree");
+    if (row_begin < 0 || row_end > src->height || row_begin > row_end)
+        return fail(ILM_ERR_OUT_OF_RANGE, "rows [%d, %d) outside [0, %d]", row_begin, row_end, src->height);
+    Ctx* c = src->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    // clamps of SetGammaCompressionParameters / SetToneMappingParameters, IlluminantMaterials.cs:81-137
+    const float min_v = 1.0f / 256.0f, max_v = 99999.0f;
+    auto clamp = [](float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); };
+    ResolveLaunch a;
+    a.src = src->texels; a.src_format = src->format; a.dst = dst->texels; a.dst_format = dst->format;
+    a.width = src->width; a.row_begin = row_begin; a.row_end = row_end; a.mode = hdr->Mode;
+    a.inverse_scale = (hdr->InverseScaleFactor != 0.0f) ? hdr->InverseScaleFactor : 1.0f;     // LightingRenderer.cs:1468-1472
+    a.offset = hdr->Offset;
+    a.exposure_minus_one = clamp(hdr->Exposure, min_v, max_v) - 1.0f;
+    a.gamma_minus_one = clamp(hdr->Gamma, 0.1f, 4.0f) - 1.0f;
+    a.white_point = clamp(hdr->Mode == ILM_HDR_TONE_MAP ? hdr->WhitePoint : 1.0f, min_v, max_v);
+    a.middle_gray = clamp(hdr->MiddleGray, 0.0f, max_v);
+    a.average_luminance = clamp(hdr->AverageLuminance, min_v, max_v);
+    const float maximum_luminance = clamp(hdr->MaximumLuminance, min_v, max_v);
+    a.maximum_luminance_squared = maximum_luminance * maximum_luminance;
+    HIP_TRY(launch_resolve(a, c->stream));
     return ILM_OK;
 }
 

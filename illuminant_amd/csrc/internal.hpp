@@ -157,4 +157,25 @@ struct FieldLaunch {
 };
 hipError_t launch_render_slices(const FieldLaunch& a, int format, hipStream_t stream);
 
+// ---- output side (output.hip) ---------------------------------------------------------------------------------
+struct ReadbackLaunch {
+    float* const* chunk_bases; int64_t stride; int32_t chunk_count, slots;
+    const int32_t* element_counts;      // device, per chunk; nullptr => every slot
+    IlmReadbackParams params;
+    // derived on the host exactly as FillReadbackResult does before its loop (ParticleReadback.cs:100-112)
+    float region_w, region_h; int32_t frame_count_x, frame_count_y; double max_angle_x, max_angle_y;
+    int32_t* block_counts;
+    IlmReadbackDrawCall* out; int32_t capacity;
+    int32_t* out_count;
+};
+hipError_t launch_readback(const ReadbackLaunch& a, hipStream_t stream);
+
+struct ResolveLaunch {
+    const void* src; int32_t src_format;
+    void* dst; int32_t dst_format;
+    int32_t width, row_begin, row_end, mode;
+    float inverse_scale, offset, exposure_minus_one, gamma_minus_one, middle_gray, average_luminance, maximum_luminance_squared, white_point;
+};
+hipError_t launch_resolve(const ResolveLaunch& a, hipStream_t stream);
+
 }  // namespace ilm

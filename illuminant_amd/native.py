@@ -80,6 +80,8 @@ SYMBOLS = {
     "ilm_render_sphere_lights": (_I, [_H, _P, _I, _P, _P, _H, _H, _P, _H, _I, _I, _P]),
     "ilm_render_particle_lights": (_I, [_H, _H, _P, _I, _P, _P, _P, _H, _H, _H, _I, _I, _P]),
     "ilm_render_light_probes": (_I, [_H, _P, _I, _P, _P, _I, _P, _P, _H, _P]),
+    "ilm_system_readback": (_I, [_H, _P, _I, _P, _P, _I, C.POINTER(_I)]),
+    "ilm_resolve_lighting": (_I, [_H, _H, _P, _I, _I]),
 }
 
 
@@ -276,6 +278,19 @@ class System:
         check(lib().ilm_chunk_live_slots(self.handle, chunk, _ptr(out), out.shape[0], C.byref(n)))
         return out[:n.value]
 
+    def readback(self, params, element_counts=None, chunk_count=None, capacity=None):
+        """ilm_system_readback: (array of abi.ReadbackDrawCall for the live particles in chunk / slot order, total live count)."""
+        if chunk_count is None:
+            chunk_count = self.chunk_count()
+        if capacity is None:
+            capacity = max(1, chunk_count * self.engine.slots)
+        e = np.ascontiguousarray(element_counts, dtype=np.int32) if element_counts is not None else None
+        out = (abi.ReadbackDrawCall * capacity)()
+        n = C.c_int32()
+        check(lib().ilm_system_readback(self.handle, _ptr(e) if e is not None else None, chunk_count, _byref(params),
+                                        C.cast(out, C.c_void_p), capacity, C.byref(n)))
+        return out, int(n.value)
+
     def close(self):
         if self.handle.value:
             lib().ilm_system_destroy(self.handle)
@@ -424,3 +439,8 @@ def render_light_probes(ctx, lights, probe_positions, probe_normals, env, df, sd
     check(lib().ilm_render_light_probes(ctx.handle, C.cast(lights, C.c_void_p) if n else None, n, _ptr(pp), _ptr(pn), pp.shape[0],
                                         _byref(env), _byref(df), sdf.handle if sdf is not None else abi.Handle(0), _ptr(out)))
     return out
+
+
+def resolve_lighting(src, dst, hdr, row_begin=0, row_end=None):
+    """ilm_resolve_lighting: tone-map lightmap `src` into `dst` (same size, any formats)."""
+    check(lib().ilm_resolve_lighting(src.handle, dst.handle, _byref(hdr), row_begin, src.height if row_end is None else row_end))

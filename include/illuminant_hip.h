@@ -555,6 +555,60 @@ int32_t ilm_render_light_probes(IlmHandle ctx, const IlmLightVertex* lights, int
                                 const IlmEnvironment* env, const IlmDistanceFieldUniforms* df, IlmHandle sdf,
                                 IlmFloat4* out_values);
 
+/* ---- output side: particle read-back and lightmap resolve -------------------------------------- */
+
+/* The members of Fracture's BitmapDrawCall that FillReadbackResult writes per live particle
+ * (Illuminant/Particles/ParticleReadback.cs:73-167).  BitmapDrawCall itself is outside the reference tree. */
+typedef struct IlmReadbackDrawCall {
+    float   Position[2];        /* pAndL.X, pAndL.Y */
+    float   Scale[2];           /* pSize * renderData.x */
+    float   TextureRegion[4];   /* TopLeft.xy, BottomRight.xy (animation frame applied) */
+    float   Rotation;           /* RotationFromVelocity ? renderData.y % 2 pi : 0 */
+    float   SortOrder;          /* SortedReadback ? pAndL.Y + ZToY : 0 */
+    uint8_t MultiplyColor[4];   /* (byte)(renderColor * 255), R G B A */
+    int32_t _pad;
+} IlmReadbackDrawCall;
+
+/* What FillReadbackResult reads from ParticleSystemConfiguration / ParticleAppearance (:80-115): pSize and the texture region are
+ * resolved by the caller (they depend on the texture's size, which lives on the C# side). */
+typedef struct IlmReadbackParams {
+    float   Size[2];            /* pSize */
+    float   TextureRegion[4];   /* region: TopLeft.xy, BottomRight.xy; Bounds.Unit = (0,0,1,1) without a texture */
+    float   AnimationRate[2];
+    float   ZToY;
+    int32_t ColumnFromVelocity, RowFromVelocity, RotationFromVelocity, SortedReadback;
+    int32_t _pad;
+} IlmReadbackParams;
+
+/* MaybePerformReadback + FillReadbackResult (ParticleReadback.cs:21-167): instead of reading three whole float4 planes per chunk
+ * back and filtering on the CPU, the live particles are compacted on the device (chunk / slot order, wave64 ballot + prefix sum)
+ * straight into draw-call records and only those cross PCIe.  element_counts[i] = ceil(TotalSpawned / ChunkSize) * ChunkSize slots
+ * of chunk i are examined (:57-58); NULL => every slot.  Writes at most `capacity` records and the total to *out_count;
+ * synchronises. */
+int32_t ilm_system_readback(IlmHandle system, const int32_t* element_counts, int32_t chunk_count, const IlmReadbackParams* params,
+                            IlmReadbackDrawCall* out, int32_t capacity, int32_t* out_count);
+
+enum { ILM_HDR_NONE = 0, ILM_HDR_GAMMA_COMPRESS = 1, ILM_HDR_TONE_MAP = 2 };   /* HDRMode, LightingRenderer.HDR.cs:254-258 */
+
+/* HDRConfiguration (Illuminant/Lighting/LightingRenderer.HDR.cs:198-252) as LightingResolveHandler._Before binds it
+ * (Illuminant/Lighting/LightingRenderer.cs:1463-1520; clamps of IlluminantMaterials.cs:81-137 are applied by the library). */
+typedef struct IlmHDRConfiguration {
+    int32_t Mode;
+    float   InverseScaleFactor;     /* 0 => 1 */
+    float   Offset, Exposure, Gamma;
+    float   MiddleGray, AverageLuminance, MaximumLuminance;   /* GammaCompression */
+    float   WhitePoint;                                       /* ToneMapping */
+    int32_t ResolveToSRGB;          /* must be 0: pLinearToPSRGB is Fracture code (sRGBCommon.fxh, outside the tree) */
+    int32_t DitheringStrength;      /* must be 0: ApplyDither is Fracture code (DitherCommon.fxh) */
+    int32_t _pad;
+} IlmHDRConfiguration;
+
+/* RenderedLighting.Resolve without albedo, 1:1 (techniques ScreenSpaceLightingResolve / GammaCompressedLightingResolve /
+ * ToneMappedLightingResolve, Illuminant/Shaders/Resolve.fx:25-139 + HDR.fxh): dst[row_begin..row_end) = tone-mapped src, alpha 1.
+ * src and dst are lightmap handles of the same size (any formats; dst RGBA8 is the back-buffer case). */
+int32_t ilm_resolve_lighting(IlmHandle src_lightmap, IlmHandle dst_lightmap, const IlmHDRConfiguration* hdr,
+                             int32_t row_begin, int32_t row_end);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,7 @@
  */
 #include "ilm_oracle.h"
 
+#define _USE_MATH_DEFINES
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1322,6 +1323,7 @@ void orc_render_sphere_lights(const IlmLightVertex* lights, int32_t light_count,
 }
 
 #include "ilm_oracle_lights.c"
+#include "ilm_oracle_output.c"
 
 /* ---------------------------------------------------------------------------
  * Host-side integer / layout logic

@@ -112,6 +112,12 @@ void orc_render_light_probes(const IlmLightVertex* lights, int32_t light_count,
                              const IlmEnvironment* env, const IlmDistanceFieldUniforms* df, const OrcTexture* sdf,
                              IlmFloat4* out_values);
 
+/* output side, ilm_oracle_output.c */
+int32_t orc_fill_readback_result(IlmFloat4** planes, int32_t chunk_count, const int32_t* element_counts, int32_t slots,
+                                 const IlmReadbackParams* p, IlmReadbackDrawCall* out, int32_t capacity);
+void orc_resolve_lighting(const IlmFloat4* lightmap, int32_t width, int32_t height, const IlmHDRConfiguration* hdr,
+                          IlmFloat4* out, int32_t row_begin, int32_t row_end);
+
 /* host-side integer/layout logic */
 typedef struct OrcDistanceFieldLayout {
     int32_t virtual_width, virtual_height;

@@ -1,0 +1,115 @@
+/*
+ * ilm_oracle_output.c -- CPU restatement of the output-side callers: FillReadbackResult and the lightmap resolve.
+ * TEST INFRASTRUCTURE ONLY (see ilm_oracle.h).  PARITY UNPINNED.
+ * Textually included by ilm_oracle.c (shares its static helpers).
+ */
+
+/* FillReadbackResult, Illuminant/Particles/ParticleReadback.cs:73-167 -- this one is C# CPU code in the reference, restated line
+ * by line (float / double mix as C# evaluates it).  Returns the number of records written (chunk order, slot order). */
+int32_t orc_fill_readback_result(IlmFloat4** planes, int32_t chunk_count, const int32_t* element_counts, int32_t slots,
+                                 const IlmReadbackParams* p, IlmReadbackDrawCall* out, int32_t capacity) {
+    const float anim_abs_x = fabsf(p->AnimationRate[0]), anim_abs_y = fabsf(p->AnimationRate[1]);
+    const float region_w = p->TextureRegion[2] - p->TextureRegion[0], region_h = p->TextureRegion[3] - p->TextureRegion[1];   /* texSize = region.Size */
+    int frame_count_x = (int)(1.0f / region_w), frame_count_y = (int)(1.0f / region_h);
+    if (frame_count_x < 1) frame_count_x = 1;
+    if (frame_count_y < 1) frame_count_y = 1;
+    const double max_angle_x = (2 * M_PI) / frame_count_x, max_angle_y = (2 * M_PI) / frame_count_y;
+    const double vel_rotation = p->RotationFromVelocity ? 1.0 : 0.0;
+    int32_t result = 0;
+    for (int c = 0; c < chunk_count; c++) {
+        const IlmFloat4* position_and_life = planes[c * 5 + 0];
+        const IlmFloat4* render_color = planes[c * 5 + 3];
+        const IlmFloat4* render_data = planes[c * 5 + 4];
+        const int count = element_counts ? element_counts[c] : slots;
+        for (int i = 0; i < count && i < slots; i++) {
+            const f4 pl = position_and_life[i];
+            const float life = pl.w;
+            if (life <= 0.0f)
+                continue;
+            const f4 rd = render_data[i], rc = render_color[i];
+            const float sz = rd.x;
+            const float rot = fmodf(rd.y, (float)(2 * M_PI));
+            IlmReadbackDrawCall dc;
+            memset(&dc, 0, sizeof(dc));
+            for (int k = 0; k < 4; k++) dc.TextureRegion[k] = p->TextureRegion[k];
+            if ((frame_count_x > 1) || (frame_count_y > 1)) {
+                float fx = floorf(anim_abs_x * life), fy = floorf(anim_abs_y * life);
+                fy += (float)floor((double)rd.w);
+                if (p->ColumnFromVelocity) fx += (float)nearbyint(rot / max_angle_x);     /* Math.Round: half to even */
+                if (p->RowFromVelocity)    fy += (float)nearbyint(rot / max_angle_y);
+                fx = fmodf(fmaxf(0.0f, fx), (float)frame_count_x);
+                fy = h_clamp(fy, 0.0f, (float)(frame_count_y - 1));
+                if (p->AnimationRate[0] < 0.0f) fx = frame_count_x - fx;
+                if (p->AnimationRate[1] < 0.0f) fy = frame_count_y - fy;
+                const float ox = fx * region_w, oy = fy * region_h;
+                dc.TextureRegion[0] += ox; dc.TextureRegion[1] += oy; dc.TextureRegion[2] += ox; dc.TextureRegion[3] += oy;
+            }
+            dc.Position[0] = pl.x; dc.Position[1] = pl.y;
+            if (p->SortedReadback)
+                dc.SortOrder = pl.y + p->ZToY;
+            dc.Scale[0] = p->Size[0] * sz; dc.Scale[1] = p->Size[1] * sz;
+            dc.MultiplyColor[0] = (uint8_t)(int32_t)(rc.x * 255.0f);    /* (byte)(float): truncation */
+            dc.MultiplyColor[1] = (uint8_t)(int32_t)(rc.y * 255.0f);
+            dc.MultiplyColor[2] = (uint8_t)(int32_t)(rc.z * 255.0f);
+            dc.MultiplyColor[3] = (uint8_t)(int32_t)(rc.w * 255.0f);
+            dc.Rotation = (float)(vel_rotation * rot);
+            if (result < capacity)
+                out[result] = dc;
+            result++;
+        }
+    }
+    return result;
+}
+
+/* HDR.fxh:1-44 */
+static f4 gamma_compress(f4 color, float offset, float middle_gray, float average_luminance, float maximum_luminance_squared) {
+    f3 rgb = v3(fmaxf(color.x + offset, 0.0f), fmaxf(color.y + offset, 0.0f), fmaxf(color.z + offset, 0.0f));
+    float result_luminance = rgb.x * 0.299f + rgb.y * 0.587f + rgb.z * 0.114f;
+    float scaled_luminance = (result_luminance * middle_gray) / average_luminance;
+    float compressed_luminance = (scaled_luminance * (1.0f + (scaled_luminance / maximum_luminance_squared))) / (1.0f + scaled_luminance);
+    float rescale_factor = compressed_luminance / result_luminance;
+    return v4(rgb.x * rescale_factor, rgb.y * rescale_factor, rgb.z * rescale_factor, color.w);
+}
+static float uncharted2_tonemap1(float value) {
+    const float kA = 0.15f, kB = 0.50f, kC = 0.10f, kD = 0.20f, kE = 0.02f, kF = 0.30f;
+    return ((value * (kA * value + kC * kB) + kD * kE) / (value * (kA * value + kB) + kD * kF)) - kE / kF;
+}
+
+/* LightingResolvePixelShader / GammaCompressedLightingResolvePixelShader / ToneMappedLightingResolvePixelShader, Resolve.fx:62-139,
+ * with ResolveCommon (:25-40) at scale 1 (each output pixel reads its own lightmap texel); parameter clamps of
+ * SetGammaCompressionParameters / SetToneMappingParameters (IlluminantMaterials.cs:81-137). */
+void orc_resolve_lighting(const IlmFloat4* lightmap, int32_t width, int32_t height, const IlmHDRConfiguration* hdr,
+                          IlmFloat4* out, int32_t row_begin, int32_t row_end) {
+    const float min_v = 1.0f / 256.0f, max_v = 99999.0f;
+    const float inverse_scale = (hdr->InverseScaleFactor != 0.0f) ? hdr->InverseScaleFactor : 1.0f;
+    const float exposure = h_clamp(hdr->Exposure, min_v, max_v);
+    const float white_point = (hdr->Mode == ILM_HDR_TONE_MAP) ? h_clamp(hdr->WhitePoint, min_v, max_v) : h_clamp(1.0f, min_v, max_v);
+    const float gamma = h_clamp(hdr->Gamma, 0.1f, 4.0f);
+    const float exposure_minus_one = exposure - 1.0f, gamma_minus_one = gamma - 1.0f;
+    const float middle_gray = h_clamp(hdr->MiddleGray, 0.0f, max_v);
+    const float average_luminance = h_clamp(hdr->AverageLuminance, min_v, max_v);
+    const float maximum_luminance = h_clamp(hdr->MaximumLuminance, min_v, max_v);
+    const float maximum_luminance_squared = maximum_luminance * maximum_luminance;
+    if (row_begin < 0) row_begin = 0;
+    if (row_end > height) row_end = height;
+    #pragma omp parallel for schedule(static)
+    for (int y = row_begin; y < row_end; y++)
+        for (int x = 0; x < width; x++) {
+            const f4 color = lightmap[(size_t)y * (size_t)width + (size_t)x];
+            f4 r = v4(color.x * inverse_scale, color.y * inverse_scale, color.z * inverse_scale, 1.0f);   /* ResolveCommon */
+            if (hdr->Mode == ILM_HDR_GAMMA_COMPRESS) {
+                r = gamma_compress(r, hdr->Offset, middle_gray, average_luminance, maximum_luminance_squared);
+            } else if (hdr->Mode == ILM_HDR_TONE_MAP) {
+                f3 pre = v3(fmaxf(0.0f, r.x + hdr->Offset) * (exposure_minus_one + 1.0f), fmaxf(0.0f, r.y + hdr->Offset) * (exposure_minus_one + 1.0f),
+                            fmaxf(0.0f, r.z + hdr->Offset) * (exposure_minus_one + 1.0f));
+                const float w = uncharted2_tonemap1(white_point);
+                r = v4(uncharted2_tonemap1(pre.x) / w, uncharted2_tonemap1(pre.y) / w, uncharted2_tonemap1(pre.z) / w, r.w);
+                r.x = powf(r.x, gamma_minus_one + 1.0f); r.y = powf(r.y, gamma_minus_one + 1.0f); r.z = powf(r.z, gamma_minus_one + 1.0f);
+            } else {
+                r.x = fmaxf(0.0f, r.x + hdr->Offset); r.y = fmaxf(0.0f, r.y + hdr->Offset); r.z = fmaxf(0.0f, r.z + hdr->Offset);
+                r.x *= (exposure_minus_one + 1.0f); r.y *= (exposure_minus_one + 1.0f); r.z *= (exposure_minus_one + 1.0f);
+                r.x = powf(r.x, gamma_minus_one + 1.0f); r.y = powf(r.y, gamma_minus_one + 1.0f); r.z = powf(r.z, gamma_minus_one + 1.0f);
+            }
+            out[(size_t)y * (size_t)width + (size_t)x] = r;
+        }
+}

@@ -21,7 +21,7 @@ def build(force=False):
     """Compile the C restatement with gcc (oracle/Makefile)."""
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-            for f in ("ilm_oracle.c", "ilm_oracle_fields.c", "ilm_oracle_transforms.c", "ilm_oracle_lights.c", "ilm_oracle.h")):
+            for f in ("ilm_oracle.c", "ilm_oracle_fields.c", "ilm_oracle_transforms.c", "ilm_oracle_lights.c", "ilm_oracle_output.c", "ilm_oracle.h")):
         subprocess.run(["make", "-C", _HERE, "-s"], check=True)
     return _LIB_PATH
 
@@ -284,6 +284,31 @@ def render_light_probes(lights, probe_positions, probe_normals, env, df, sdf):
     out = np.zeros_like(pp)
     lib().orc_render_light_probes(lights, C.c_int32(len(lights) if lights is not None else 0), _f4(pp), _f4(pn), C.c_int32(pp.shape[0]),
                                   C.byref(env), C.byref(df), C.byref(sdf) if sdf is not None else None, _f4(out))
+    return out
+
+
+def fill_readback_result(chunks, params, element_counts=None, capacity=None):
+    """orc_fill_readback_result: (ctypes array of abi.ReadbackDrawCall, total)."""
+    n = len(chunks)
+    slots = chunks[0][0].shape[0]
+    ptrs = (C.c_void_p * (n * 5))()
+    for c, planes in enumerate(chunks):
+        for k in range(5):
+            ptrs[c * 5 + k] = _f4(planes[k]).value
+    e = np.ascontiguousarray(element_counts, dtype=np.int32) if element_counts is not None else None
+    if capacity is None:
+        capacity = n * slots
+    out = (abi.ReadbackDrawCall * capacity)()
+    lib().orc_fill_readback_result.restype = C.c_int32
+    total = lib().orc_fill_readback_result(ptrs, C.c_int32(n), _p(e), C.c_int32(slots), C.byref(params), out, C.c_int32(capacity))
+    return out, int(total)
+
+
+def resolve_lighting(lightmap, hdr, row_begin=0, row_end=None):
+    h, w = lightmap.shape[0], lightmap.shape[1]
+    out = np.zeros_like(lightmap)
+    lib().orc_resolve_lighting(_f4(lightmap), C.c_int32(w), C.c_int32(h), C.byref(hdr), _f4(out), C.c_int32(row_begin),
+                               C.c_int32(h if row_end is None else row_end))
     return out
 
 

@@ -567,8 +567,65 @@ def gen_lights_ext():
             "tolerance": "1e-5 relative", "cases": cases}
 
 
+# ---------------------------------------------------------------------------------------------------------
+# 11. Output side: FillReadbackResult (ParticleReadback.cs:73-167, C# CPU code) and the lightmap resolve
+#     (Resolve.fx:62-139, HDR.fxh, clamps of IlluminantMaterials.cs:81-137), evaluated by hand / in float64
+# ---------------------------------------------------------------------------------------------------------
+def gen_output_ext():
+    cases = []
+    two_pi = float(F(2 * math.pi))
+    # (a) one live particle, no animation frames (region = unit): bytes are truncated ((byte)(rc * 255)), scale = pSize * size,
+    #     rotation = renderData.y % 2 pi when RotationFromVelocity, SortOrder = y + ZToY when SortedReadback
+    cases.append({"kind": "readback", "params": {"size": [3.0, 2.0], "region": [0.0, 0.0, 1.0, 1.0], "animation_rate": [0.0, 0.0], "z_to_y": 0.5,
+                                                  "column_from_velocity": False, "row_from_velocity": False, "rotation_from_velocity": True, "sorted": True},
+                  "particles": [{"slot": 3, "position": [10.0, 20.0, 5.0, 1.3], "render_color": [0.5, 0.25, 1.0, 0.999], "render_data": [1.5, 7.0, 9.0, 0.0]}],
+                  "expected": [{"position": [10.0, 20.0], "scale": [4.5, 3.0], "region": [0.0, 0.0, 1.0, 1.0], "rotation": float(F(math.fmod(7.0, two_pi))),
+                                "sort_order": 20.5, "color": [127, 63, 255, 254]}]})
+    # (b) a 4 x 2 frame sheet (region .25 x .5): frame x = floor(|rate.x| * life) % 4, frame y = clamp(floor(renderData.w), 0, 1);
+    #     no RotationFromVelocity => rotation 0; unsorted => SortOrder 0; dead slots are skipped and the order is slot order
+    cases.append({"kind": "readback", "params": {"size": [1.0, 1.0], "region": [0.0, 0.0, 0.25, 0.5], "animation_rate": [2.0, 0.0], "z_to_y": 0.0,
+                                                  "column_from_velocity": False, "row_from_velocity": False, "rotation_from_velocity": False, "sorted": False},
+                  "particles": [{"slot": 9, "position": [1.0, 2.0, 0.0, 1.3], "render_color": [1.0, 1.0, 1.0, 1.0], "render_data": [2.0, 1.0, 0.0, 1.0]},
+                                {"slot": 4, "position": [5.0, 6.0, 0.0, 0.0], "render_color": [1.0, 1.0, 1.0, 1.0], "render_data": [1.0, 0.0, 0.0, 0.0]},
+                                {"slot": 2, "position": [7.0, 8.0, 0.0, 3.6], "render_color": [0.0, 0.0, 0.0, 0.0], "render_data": [1.0, 0.0, 0.0, 5.0]}],
+                  "expected": [{"position": [7.0, 8.0], "scale": [1.0, 1.0], "region": [0.75, 0.5, 1.0, 1.0], "rotation": 0.0, "sort_order": 0.0, "color": [0, 0, 0, 0]},
+                               {"position": [1.0, 2.0], "scale": [2.0, 2.0], "region": [0.5, 0.5, 0.75, 1.0], "rotation": 0.0, "sort_order": 0.0, "color": [255, 255, 255, 255]}]})
+    # (c) ColumnFromVelocity: + Math.Round(rot / (2 pi / 4)); rot = 4.0 -> 4 / 1.5708 = 2.546 -> 3; frame x = (0 + 3) % 4 = 3
+    cases.append({"kind": "readback", "params": {"size": [1.0, 1.0], "region": [0.0, 0.0, 0.25, 1.0], "animation_rate": [0.0, 0.0], "z_to_y": 0.0,
+                                                  "column_from_velocity": True, "row_from_velocity": False, "rotation_from_velocity": False, "sorted": False},
+                  "particles": [{"slot": 0, "position": [0.0, 0.0, 0.0, 1.0], "render_color": [1.0, 1.0, 1.0, 1.0], "render_data": [1.0, 4.0, 0.0, 0.0]}],
+                  "expected": [{"position": [0.0, 0.0], "scale": [1.0, 1.0], "region": [0.75, 0.0, 1.0, 1.0], "rotation": 0.0, "sort_order": 0.0, "color": [255, 255, 255, 255]}]})
+
+    texel = [0.5, 0.25, 1.0, 7.0]
+    # (d) HDRMode.None: rgb = pow(max(0, rgb * inverseScale + offset) * exposure, gamma), alpha 1
+    r = [max(0.0, v * 2.0 - 0.1) * 1.5 for v in texel[:3]]
+    cases.append({"kind": "resolve", "texel": texel, "hdr": {"mode": 0, "inverse_scale": 2.0, "offset": -0.1, "exposure": 1.5, "gamma": 2.0},
+                  "expected": [r[0] ** 2, r[1] ** 2, r[2] ** 2, 1.0]})
+    #     InverseScaleFactor 0 means 1 (LightingRenderer.cs:1468-1472); gamma is clamped to [.1, 4], exposure to [1/256, 99999]
+    r = [max(0.0, v) * (1.0 / 256.0) for v in texel[:3]]
+    cases.append({"kind": "resolve", "texel": texel, "hdr": {"mode": 0, "inverse_scale": 0.0, "offset": 0.0, "exposure": 0.0, "gamma": 9.0},
+                  "expected": [r[0] ** 4, r[1] ** 4, r[2] ** 4, 1.0]})
+    # (e) GammaCompress (HDR.fxh:11-18): L = dot(rgb, (.299,.587,.114)); s = L * middleGray / average; c = s (1 + s / max^2) / (1 + s); rgb *= c / L
+    rgb = [max(v * 1.0 + 0.05, 0.0) for v in texel[:3]]
+    L = rgb[0] * 0.299 + rgb[1] * 0.587 + rgb[2] * 0.114
+    sL = L * 0.6 / 0.4
+    cL = sL * (1 + sL / (2.0 * 2.0)) / (1 + sL)
+    cases.append({"kind": "resolve", "texel": texel, "hdr": {"mode": 1, "inverse_scale": 1.0, "offset": 0.05, "middle_gray": 0.6, "average_luminance": 0.4,
+                                                             "maximum_luminance": 2.0},
+                  "expected": [rgb[0] * cL / L, rgb[1] * cL / L, rgb[2] * cL / L, 1.0]})
+    # (f) ToneMap (Resolve.fx:113-139): Uncharted2(max(0, rgb + offset) * exposure) / Uncharted2(whitePoint), then gamma
+    def u2(v):
+        kA, kB, kC, kD, kE, kF = 0.15, 0.50, 0.10, 0.20, 0.02, 0.30
+        return ((v * (kA * v + kC * kB) + kD * kE) / (v * (kA * v + kB) + kD * kF)) - kE / kF
+    pre = [max(0.0, v * 1.0 + 0.0) * 2.0 for v in texel[:3]]
+    cases.append({"kind": "resolve", "texel": texel, "hdr": {"mode": 2, "inverse_scale": 1.0, "offset": 0.0, "exposure": 2.0, "gamma": 0.8, "white_point": 4.0},
+                  "expected": [(u2(pre[0]) / u2(4.0)) ** 0.8, (u2(pre[1]) / u2(4.0)) ** 0.8, (u2(pre[2]) / u2(4.0)) ** 0.8, 1.0]})
+    return {"source": "ParticleReadback.cs:73-167, Resolve.fx:25-139, HDR.fxh:1-44, IlluminantMaterials.cs:81-137, LightingRenderer.cs:1463-1520 "
+                      "(hand-evaluated; see comments in make_golden.py)", "tolerance": "1e-5 relative; colour bytes and record order exact", "cases": cases}
+
+
 def main():
-    out = {"lights_ext.json": gen_lights_ext(), "transforms_ext.json": gen_transforms_ext(), "distance_field_generation.json": gen_distance_field_generation(), "bezier.json": gen_bezier(), "distance_field_layout.json": gen_layout(), "spawner.json": gen_spawner(),
+    out = {"output_ext.json": gen_output_ext(), "lights_ext.json": gen_lights_ext(), "transforms_ext.json": gen_transforms_ext(), "distance_field_generation.json": gen_distance_field_generation(), "bezier.json": gen_bezier(), "distance_field_layout.json": gen_layout(), "spawner.json": gen_spawner(),
            "liveness.json": gen_liveness(), "distance_encoding.json": gen_encoding(), "gbuffer.json": gen_gbuffer(),
            "closed_form.json": gen_closed_form()}
     for name, doc in out.items():

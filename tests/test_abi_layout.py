@@ -24,6 +24,7 @@ STRUCTS = {
     "IlmTransformOp": abi.TransformOp, "IlmSpawnRecord": abi.SpawnRecord, "IlmStepDesc": abi.StepDesc, "IlmRenderStats": abi.RenderStats,
     "IlmMatrixMultiplyParams": abi.MatrixMultiplyParams, "IlmSpatialNoiseParams": abi.SpatialNoiseParams, "IlmFeedbackParams": abi.FeedbackParams,
     "IlmParticleLightParams": abi.ParticleLightParams,
+    "IlmReadbackDrawCall": abi.ReadbackDrawCall, "IlmReadbackParams": abi.ReadbackParams, "IlmHDRConfiguration": abi.HDRConfiguration,
     "IlmObstruction": abi.Obstruction, "IlmHeightVolume": abi.HeightVolume, "IlmDistanceFieldRenderDesc": abi.DistanceFieldRenderDesc,
 }
 
