@@ -132,7 +132,18 @@ PYBIND11_MODULE(_host, m) {
     py::class_<ParticleColor>(m, "ParticleColor").def(py::init<>())
         .def_readwrite("OpacityFromLife", &ParticleColor::OpacityFromLife)
         .def_readwrite("ColorFromLife", &ParticleColor::ColorFromLife).def_readwrite("ColorFromVelocity", &ParticleColor::ColorFromVelocity);
+    py::class_<ParticleAppearance>(m, "ParticleAppearance").def(py::init<>())
+        .def_property("TextureSize", [](const ParticleAppearance& a) -> py::object { if (!a.TextureSize) return py::none(); return py::cast(l2(*a.TextureSize)); },
+                      [](ParticleAppearance& a, py::object v) { if (v.is_none()) a.TextureSize.reset(); else a.TextureSize = v2(v.cast<std::vector<float>>()); })
+        VEC_PROP(ParticleAppearance, OffsetPx, 2)
+        .def_property("SizePx", [](const ParticleAppearance& a) -> py::object { if (!a.SizePx) return py::none(); return py::cast(l2(*a.SizePx)); },
+                      [](ParticleAppearance& a, py::object v) { if (v.is_none()) a.SizePx.reset(); else a.SizePx = v2(v.cast<std::vector<float>>()); })
+        VEC_PROP(ParticleAppearance, AnimationRate, 2)
+        .def_readwrite("RelativeSize", &ParticleAppearance::RelativeSize)
+        .def_readwrite("ColumnFromVelocity", &ParticleAppearance::ColumnFromVelocity).def_readwrite("RowFromVelocity", &ParticleAppearance::RowFromVelocity);
     py::class_<ParticleSystemConfiguration>(m, "ParticleSystemConfiguration").def(py::init<>())
+        .def_readwrite("Appearance", &ParticleSystemConfiguration::Appearance)
+        .def_readwrite("AutoReadback", &ParticleSystemConfiguration::AutoReadback).def_readwrite("SortedReadback", &ParticleSystemConfiguration::SortedReadback)
         VEC_PROP(ParticleSystemConfiguration, Size, 2)
         .def_readwrite("Friction", &ParticleSystemConfiguration::Friction)
         .def_readwrite("MaximumVelocity", &ParticleSystemConfiguration::MaximumVelocity)
@@ -276,6 +287,12 @@ PYBIND11_MODULE(_host, m) {
             for (int i = 0; i < count; i++) { tp.Advance(dt); s.Update(firstFrame + i); }
         })
         .def("Clear", &ParticleSystem::Clear)
+        .def("PerformReadback", [](const ParticleSystem& s) {
+            auto r = s.PerformReadback();
+            return py::bytes((const char*)r.data(), r.size() * sizeof(IlmReadbackDrawCall)); })
+        .def_property_readonly("ReadbackResultBytes", [](const ParticleSystem& s) {
+            return py::bytes((const char*)s.ReadbackResult.data(), s.ReadbackResult.size() * sizeof(IlmReadbackDrawCall)); })
+        .def("GetReadbackParamsBytes", [](const ParticleSystem& s) { auto p = s.GetReadbackParams(); return py::bytes((const char*)&p, sizeof(p)); })
         .def("Readback", [](const ParticleSystem& s, int chunk, int plane) {
             farray out({ (py::ssize_t)s.ChunkMaximumCount(), (py::ssize_t)4 });
             s.Readback(chunk, plane, (IlmFloat4*)out.mutable_data());
@@ -375,6 +392,32 @@ PYBIND11_MODULE(_host, m) {
             r.SetGBuffer(a.data(), (int)a.shape(1), (int)a.shape(0), format);
         })
         .def("UpdateFields", &LightingRenderer::UpdateFields)
+        .def("ResolveToArray", [](const LightingRenderer& r, py::object hdrBytes) {
+            // Resolve into a float4 target owned by the renderer's context, read it back (test / bench plumbing)
+            const int w = r.Configuration.RenderWidth, h = r.Configuration.RenderHeight;
+            IlmHandle target = 0;
+            ThrowIfFailed(ilm_lightmap_create(r.Context.Handle(), w, h, ILM_LIGHTMAP_FLOAT4, nullptr, &target));
+            IlmHDRConfiguration hdr; const IlmHDRConfiguration* hp = nullptr;
+            if (!hdrBytes.is_none()) {
+                std::string b = hdrBytes.cast<std::string>();
+                if (b.size() != sizeof(IlmHDRConfiguration)) { ilm_lightmap_destroy(target); throw ArgumentException("hdr must be an IlmHDRConfiguration"); }
+                std::memcpy(&hdr, b.data(), sizeof(hdr)); hp = &hdr;
+            }
+            py::array_t<float> out({ (py::ssize_t)h, (py::ssize_t)w, (py::ssize_t)4 });
+            try {
+                r.Resolve(target, hp);
+                ThrowIfFailed(ilm_lightmap_download(target, out.mutable_data(), 0, h));
+            } catch (...) { ilm_lightmap_destroy(target); throw; }
+            ilm_lightmap_destroy(target);
+            return out;
+        }, py::arg("hdr") = py::none())
+        .def("Resolve", [](const LightingRenderer& r, IlmHandle destination, py::object hdrBytes, int rowBegin, int rowEnd) {
+            if (hdrBytes.is_none()) { r.Resolve(destination, nullptr, rowBegin, rowEnd); return; }
+            std::string b = hdrBytes.cast<std::string>();
+            if (b.size() != sizeof(IlmHDRConfiguration)) throw ArgumentException("hdr must be an IlmHDRConfiguration");
+            IlmHDRConfiguration h; std::memcpy(&h, b.data(), sizeof(h));
+            r.Resolve(destination, &h, rowBegin, rowEnd);
+        }, py::arg("destination"), py::arg("hdr") = py::none(), py::arg("rowBegin") = 0, py::arg("rowEnd") = -1)
         .def_property_readonly("Probes", [](LightingRenderer& r) -> LightProbeCollection& { return r.Probes; }, py::return_value_policy::reference_internal)
         .def_static("PackParticleLightBytes", [](const ParticleLightSource& pls, bool haveDF) {
             auto p = LightingRenderer::PackParticleLight(pls, haveDF); return py::bytes((const char*)&p, sizeof(p)); })

@@ -933,6 +933,10 @@ ParticleSystem::UpdateResult ParticleSystem::Update(int frameIndex) {
     for (Chunk& c : chunks)
         c.ApproximateMaximumLife -= Configuration.LifeDecayPerSecond * (float)actualDeltaTimeSeconds;
 
+    if (Configuration.AutoReadback) {     // MaybePerformReadback(timestamp), ParticleSystem.cs:625-628
+        ReadbackTimestamp = (float)now;
+        ReadbackResult = PerformReadback();
+    }
     if (computingLiveness) {
         // ComputeLiveness (:716-720, ParticleEngine.cs:282-386): counts are produced by the update launch itself
         livenessPending = true;
@@ -940,6 +944,53 @@ ParticleSystem::UpdateResult ParticleSystem::Update(int frameIndex) {
         for (const Chunk& c : chunks) livenessChunkIds.push_back(c.ID);
     }
     return UpdateResult{ true, (float)now };
+}
+
+// the part of FillReadbackResult that runs before its loop, ParticleReadback.cs:80-115
+IlmReadbackParams ParticleSystem::GetReadbackParams() const {
+    IlmReadbackParams p;
+    std::memset(&p, 0, sizeof(p));
+    const ParticleAppearance& ap = Configuration.Appearance;
+    Vector2 pSize = Configuration.Size;
+    p.TextureRegion[0] = 0; p.TextureRegion[1] = 0; p.TextureRegion[2] = 1; p.TextureRegion[3] = 1;    // Bounds.Unit
+    if (ap.TextureSize) {
+        const Vector2 sizeF = *ap.TextureSize;
+        const Vector2 sz = ap.SizePx.value_or(sizeF);
+        // Bounds.FromPositionAndSize(OffsetPx / sizeF, SizePx / sizeF)
+        p.TextureRegion[0] = ap.OffsetPx.X / sizeF.X; p.TextureRegion[1] = ap.OffsetPx.Y / sizeF.Y;
+        p.TextureRegion[2] = p.TextureRegion[0] + sz.X / sizeF.X; p.TextureRegion[3] = p.TextureRegion[1] + sz.Y / sizeF.Y;
+        if (!ap.RelativeSize)
+            pSize = { Configuration.Size.X / sizeF.X, Configuration.Size.Y / sizeF.Y };
+    }
+    p.Size[0] = pSize.X; p.Size[1] = pSize.Y;
+    p.AnimationRate[0] = ap.AnimationRate.X; p.AnimationRate[1] = ap.AnimationRate.Y;
+    p.ZToY = Configuration.ZToY;
+    p.ColumnFromVelocity = ap.ColumnFromVelocity ? 1 : 0;
+    p.RowFromVelocity = ap.RowFromVelocity ? 1 : 0;
+    p.RotationFromVelocity = Configuration.RotationFromVelocity ? 1 : 0;
+    p.SortedReadback = Configuration.SortedReadback ? 1 : 0;
+    return p;
+}
+
+// MaybePerformReadback, ParticleReadback.cs:21-71
+std::vector<IlmReadbackDrawCall> ParticleSystem::PerformReadback() const {
+    std::vector<IlmReadbackDrawCall> result;
+    if (chunks.empty())
+        return result;
+    const int cs = Engine.Configuration.ChunkSize;
+    std::vector<int32_t> elements;
+    int maxTotalCount = 0;
+    for (const Chunk& c : chunks) {
+        const int rowCount = (int)std::ceil(c.TotalSpawned / (float)cs);   // :57
+        elements.push_back(std::min(rowCount * cs, ChunkMaximumCount()));
+        maxTotalCount += elements.back();
+    }
+    result.resize((size_t)std::max(maxTotalCount, 1));
+    const IlmReadbackParams p = GetReadbackParams();
+    int32_t total = 0;
+    ThrowIfFailed(ilm_system_readback(handle, elements.data(), (int32_t)elements.size(), &p, result.data(), (int32_t)result.size(), &total));
+    result.resize((size_t)total);
+    return result;
 }
 
 void ParticleSystem::Readback(int chunkIndex, int plane, IlmFloat4* dst) const {
@@ -1220,6 +1271,17 @@ int LightingRenderer::UpdateFields() {
     } else
         rendered += RenderDistanceFieldPartition(-1);
     return rendered;
+}
+
+void LightingRenderer::Resolve(IlmHandle destination, const IlmHDRConfiguration* hdr, int rowBegin, int rowEnd) const {
+    IlmHDRConfiguration plain;
+    if (!hdr) {      // hdr == null: InverseScaleFactor 1 and the material's default uniforms (exposure 1, gamma 1, offset 0)
+        std::memset(&plain, 0, sizeof(plain));
+        plain.Mode = ILM_HDR_NONE; plain.InverseScaleFactor = 1; plain.Exposure = 1; plain.Gamma = 1; plain.WhitePoint = 1;
+        hdr = &plain;
+    }
+    if (rowEnd < 0) rowEnd = Configuration.RenderHeight;
+    ThrowIfFailed(ilm_resolve_lighting(lightmap, destination, hdr, rowBegin, rowEnd));
 }
 
 void LightingRenderer::ReadLightmap(void* dst, int firstRow, int rowCount) const {

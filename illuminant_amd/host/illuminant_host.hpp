@@ -213,8 +213,20 @@ struct ParticleColor {
     std::optional<float> OpacityFromLife;
     std::optional<Bezier4> ColorFromLife, ColorFromVelocity;
 };
+// ParticleAppearance (ParticleConfiguration.cs:41-120): the members FillReadbackResult reads; the texture itself lives on the
+// C# side, only its size matters here
+struct ParticleAppearance {
+    std::optional<Vector2> TextureSize;    // Texture.Instance.Width / Height; unset => no texture
+    Vector2 OffsetPx{0, 0};
+    std::optional<Vector2> SizePx;
+    Vector2 AnimationRate{0, 0};
+    bool RelativeSize = true;
+    bool ColumnFromVelocity = false, RowFromVelocity = false;
+};
 // ParticleConfiguration.cs:187-303 (the members the update path reads)
 struct ParticleSystemConfiguration {
+    ParticleAppearance Appearance;
+    bool AutoReadback = false, SortedReadback = false;   // :277-283
     Vector2 Size{1, 1};
     float Friction = 0, MaximumVelocity = 9999.0f, LifeDecayPerSecond = 1;
     std::optional<ParticleCollision> Collision;
@@ -483,6 +495,12 @@ public:
     void Clear() { isClearPending = true; }   // ParticleSystem.cs:1000-1003
     // AutoReadback / ReadbackResult (ParticleReadback.cs:21-71) reduced to a synchronous plane download
     void Readback(int chunkIndex, int plane, IlmFloat4* dst) const;
+    // MaybePerformReadback + FillReadbackResult (ParticleReadback.cs:21-167): one draw-call record per live particle, chunk / slot
+    // order.  Update() refreshes ReadbackResult when Configuration.AutoReadback is set (the reference completes a Future).
+    std::vector<IlmReadbackDrawCall> PerformReadback() const;
+    IlmReadbackParams GetReadbackParams() const;
+    std::vector<IlmReadbackDrawCall> ReadbackResult;
+    float ReadbackTimestamp = 0;
     IlmHandle Handle() const { return handle; }
     // PickSourceForFeedback / GetCurrentSpawnTarget, ParticleSpawning.cs:233-265 (chunk table indices, -1 = null)
     int PickSourceForFeedback(int count);
@@ -681,8 +699,11 @@ public:
     // RenderLighting, :917-1191: clears to Ambient * intensityScale and adds every sphere light.
     // [rowBegin, rowEnd) restricts the pass to a screen strip (multi-GPU split); rowEnd < 0 => whole frame.
     void RenderLighting(float intensityScale = 1.0f, int rowBegin = 0, int rowEnd = -1, IlmRenderStats* stats = nullptr);
-    // lightmap readback (RenderedLighting.Resolve is out of scope)
     void ReadLightmap(void* dst, int firstRow, int rowCount) const;
+    // RenderedLighting.Resolve -> ResolveLighting without albedo (LightingRenderer.HDR.cs:99-151, LightingRenderer.cs:1537-1645):
+    // tone-maps the lightmap into `destination` (a lightmap handle of the same size; RGBA8 = the back buffer).  hdr == nullptr => the
+    // plain LightingResolve with exposure / gamma 1.
+    void Resolve(IlmHandle destination, const IlmHDRConfiguration* hdr = nullptr, int rowBegin = 0, int rowEnd = -1) const;
     IlmHandle Lightmap() const { return lightmap; }
     int LightmapFormat() const { return lightmapFormat; }
 

@@ -228,3 +228,70 @@ def test_particle_light_source_and_probes_through_the_renderer(H, hctx, oracle):
     for i in range(2):
         assert_close(np.asarray(r.Probes[i].Value), pv[i], "probe %d" % i)
     assert pv[0][3] == 2.0      # one light reached the probe; alpha 1 / intensityScale
+
+
+def test_auto_readback_and_resolve_through_the_host_mirror(H, hctx, oracle):
+    """Configuration.AutoReadback fills ReadbackResult on every Update (MaybePerformReadback); LightingRenderer.Resolve tone-maps the
+    frame.  Both against the oracle on the replayed state."""
+    from tests import output_common as oc
+    cs = 32
+    n = cs * cs
+    engine, tp, rnd = make_engine(H, hctx, cs)
+    cfg = H.ParticleSystemConfiguration()
+    cfg.LifeDecayPerSecond = 0.7
+    cfg.AutoReadback = True
+    cfg.SortedReadback = True
+    cfg.RotationFromVelocity = True
+    cfg.ZToY = 0.25
+    cfg.Size = [6.0, 4.0]
+    ap = H.ParticleAppearance()
+    ap.TextureSize = [256.0, 128.0]
+    ap.SizePx = [64.0, 64.0]
+    ap.AnimationRate = [3.0, 0.0]
+    ap.RelativeSize = False
+    cfg.Appearance = ap
+    ps = H.ParticleSystem(engine, cfg)
+    sp = H.Spawner(4)
+    sp.MinRate = sp.MaxRate = 3000.0
+    f = H.Formula3(); f.Constant = [100, 60, 3]; f.RandomScale = [80, 50, 2]; f.Type = H.FormulaType.Spherical
+    sp.Position = f
+    g = H.Formula3(); g.RandomScale = [50, 50, 0]; g.Type = H.FormulaType.Spherical
+    sp.Velocity = g
+    life = H.Formula1(); life.Constant = 0.03; life.RandomScale = 1.5
+    sp.Life = life
+    ps.AddTransform(sp)
+    chunks = []
+    for frame in range(6):
+        tp.Advance(1.0 / 60.0)
+        ps.Update(frame)
+        d = abi.StepDesc.from_buffer_copy(ps.LastStepBytes())
+        while len(chunks) < len(ps.Chunks):
+            chunks.append(empty_chunk(n))
+        oracle.step(chunks, cs, rnd, d)
+    params = abi.ReadbackParams.from_buffer_copy(ps.GetReadbackParamsBytes())
+    assert tuple(params.TextureRegion) == (0.0, 0.0, 0.25, 0.5) and abs(params.Size[0] - 6.0 / 256.0) < 1e-9
+    elems = [min(n, -(-c.TotalSpawned // cs) * cs) for c in ps.Chunks]
+    want, wn = oracle.fill_readback_result(chunks, params, element_counts=elems)
+    got = np.frombuffer(ps.ReadbackResultBytes, dtype=np.uint8).reshape(-1, 48)
+    assert got.shape[0] == wn and 100 < wn < 300           # some of the shortest-lived particles are already dead
+    w = np.frombuffer(want, dtype=np.uint8).reshape(-1, 48)[:wn]
+    assert np.array_equal(got[:, 40:44], w[:, 40:44])
+    assert_close(got[:, :40].copy().view(np.float32), w[:, :40].copy().view(np.float32), "draw calls", rtol=2e-4, atol=2e-4)
+
+    env = H.LightingEnvironment()
+    env.Ambient = [0.2, 0.1, 0.3, 1.0]
+    l = H.SphereLightSource()
+    l.Position = [40.0, 30.0, 15.0]; l.Radius = 8.0; l.RampLength = 60.0; l.Color = [2.0, 1.5, 1.0, 1.0]
+    env.Lights = [l]
+    rc = H.RendererConfiguration(96, 64)
+    r = H.LightingRenderer(hctx, rc, env)        # HighQuality: HalfVector4 lightmap
+    r.RenderLighting(1.0)
+    hdr = oc.hdr_configuration(abi.HDR_TONE_MAP, 1.0, 0.0, 1.2, 1.0 / 2.2, white_point=3.0)
+    got_img = r.ResolveToArray(bytes(hdr))
+    lit = r.ReadLightmap().view(np.float16).astype(np.float32)
+    want_img = oracle.resolve_lighting(np.ascontiguousarray(lit), hdr)
+    assert_close(got_img, want_img, "resolved frame")
+    assert 0.2 < float(want_img[30, 40, 0]) < 1.0
+    plain = r.ResolveToArray()                     # hdr == null: the lightmap itself, alpha forced to 1
+    assert_close(plain[..., :3], lit[..., :3], "plain resolve")
+    assert (plain[..., 3] == 1.0).all()
