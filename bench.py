@@ -57,6 +57,7 @@ def parse_args():
     ap.add_argument("--light-frames", type=int, default=5)
     ap.add_argument("--no-lighting", action="store_true")
     ap.add_argument("--no-cfg4", action="store_true", help="skip the 8 M-particle (cfg4 per-GPU share) measurement")
+    ap.add_argument("--no-next-rows", action="store_true", help="skip the SURVEY 8f measurements (read-back, particle lights, resolve)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -244,6 +245,22 @@ def main():
     # ---- cfg4's per-GPU share: 8 chunks of 1024^2 = 8 M particles, Gravity + Noise + UpdatePositions (no Spawner) ---------------
     # Not `value` (the contract's N = 1 workload is cfg2); reported because at this size the working set (0.9 GB) no longer fits
     # the Infinity Cache and the same kernel meets HBM.
+    next_rows = {}
+    if not args.no_next_rows:
+        # read-back: FillReadbackResult as an ordered device-side compaction; every live particle becomes a 48-byte
+        # draw-call record, so the wall time below is dominated by the PCIe copy of the records (pageable host memory)
+        ps.PerformReadback()
+        barrier()
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            rb = ps.PerformReadback()
+        rb_ms = (time.perf_counter() - t0) / reps * 1e3
+        n_rec = len(rb) // 48
+        next_rows["readback_cfg2"] = {"records": n_rec, "ms_per_readback_incl_pcie": round(rb_ms, 3),
+                                      "mrecords_per_s": round(n_rec / (rb_ms * 1e-3) / 1e6, 1), "host_gb_per_s": round(n_rec * 48 / (rb_ms * 1e-3) / 1e9, 2),
+                                      "note": "the reference copies 3 float4 planes per chunk (48 B per SLOT) and filters on the CPU"}
+        del rb
     cpu_init, cpu_rnd, cpu_desc_bytes = P["init"], P["rnd"], ps.LastStepBytes()
     if not args.no_cfg4:
         del P, ps, spawner          # free cfg2's chunks before the 0.9 GB system is built
@@ -324,6 +341,60 @@ def main():
             del L
         out["lighting"] = lighting
         out["lit_mpixels_per_s"] = lighting["cfg5_4k_256_lights_fp16"]["lit_mpixels_per_s"]
+
+        if not args.no_next_rows and world == 1:
+            # particle lights: 4 096 live particles of a 64^2 chunk lighting a 1080p frame through cfg3's field
+            L = build_lighting(H, ctx, scenes, abi, 1920, 1080, 0, 0.25, 2048, abi.SDF_UNORM16)
+            rnd = scenes.randomness_table(7)
+            ecfg = H.ParticleEngineConfiguration(64)
+            eng = H.ParticleEngine(ctx, ecfg, rnd)
+            pcfg = H.ParticleSystemConfiguration()
+            pcfg.LifeDecayPerSecond = 0.01
+            lsys = H.ParticleSystem(eng, pcfg)
+            pos, vel, attr = scenes.make_particles(91, 4096, pos_lo=(0, 0, 4), pos_hi=(1920, 1080, 48), life=(50.0, 90.0))
+            lsys.Spawn(4096, pos, vel, attr)
+            lsys.Update(0)                                   # one step so that RenderColor is populated
+            pls = H.ParticleLightSource()
+            tmpl = H.SphereLightSource()
+            tmpl.Radius = 4.0; tmpl.RampLength = 60.0; tmpl.Color = [1.0, 0.9, 0.8, 1.0]
+            pls.Template = tmpl
+            pls.System = lsys
+            L["env"].ParticleLights = [pls]
+            r = L["renderer"]
+            stats = r.RenderLighting(1.0, 0, -1, True)
+            ctx.Sync()
+            ctx.TimerStart()
+            frames = 3
+            for _ in range(frames):
+                r.RenderLighting(1.0, 0, -1, False)
+            pl_ms = ctx.TimerStop() / frames
+            alg = int(stats[0]) * SDF_SAMPLE_BYTES + 1920 * 1080 * 16 + 4096 * (32 + 128)
+            next_rows["particle_lights_1080p_4096"] = {
+                "ms_per_frame": round(pl_ms, 4), "lit_mpixels_per_s": round(1920 * 1080 / (pl_ms * 1e-3) / 1e6, 1), "lights": 4096,
+                "sdf_samples_per_frame": int(stats[0]), "pixel_light_pairs": int(stats[1]),
+                "roofline": {"bound": "hbm", "achieved": round(alg / (pl_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(alg / (pl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                             "kernel": "ilm::sphere_lights_kernel (accumulate, device-side light count) + particle_light_count/emit", "bytes_per_unit": SDF_SAMPLE_BYTES,
+                             "units_per_launch": int(stats[0]), "launch_ms": round(pl_ms, 4)}}
+            del L, r, lsys, eng, pls
+            # lightmap resolve: 4K HalfVector4 lightmap -> RGBA8, ToneMap; 8 B read + 4 B written per pixel
+            L = build_lighting(H, ctx, scenes, abi, 3840, 2160, 8, 0.125, 4096, abi.SDF_FP16)
+            r = L["renderer"]
+            r.RenderLighting(1.0, 0, -1, False)
+            hc = abi.HDRConfiguration()
+            hc.Mode, hc.InverseScaleFactor, hc.Exposure, hc.Gamma, hc.WhitePoint = abi.HDR_TONE_MAP, 1.0, 1.2, 1.0 / 2.2, 3.0
+            hdr = bytes(hc)
+            rs_ms = r.BenchResolve(hdr, abi.LIGHTMAP_RGBA8, 20)
+            px = 3840 * 2160
+            next_rows["resolve_4k_half4_to_rgba8"] = {
+                "ms_per_frame": round(rs_ms, 4), "mpixels_per_s": round(px / (rs_ms * 1e-3) / 1e6, 1),
+                "roofline": {"bound": "hbm", "achieved": round(px * 12 / (rs_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(px * 12 / (rs_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None, "kernel": "ilm::resolve_kernel",
+                             "bytes_per_unit": 12, "units_per_launch": px, "launch_ms": round(rs_ms, 4)}}
+            del L, r
+
+    if next_rows:
+        out["next_rows"] = next_rows
 
     # ---- CPU baseline: the oracle restatement on the host cores (rank 0, N == 1 only) -------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

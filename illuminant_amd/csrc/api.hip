@@ -1464,11 +1464,16 @@ int32_t ilm_resolve_lighting(IlmHandle hsrc, IlmHandle hdst, const IlmHDRConfigu
     a.offset = hdr->Offset;
     a.exposure_minus_one = clamp(hdr->Exposure, min_v, max_v) - 1.0f;
     a.gamma_minus_one = clamp(hdr->Gamma, 0.1f, 4.0f) - 1.0f;
-    a.white_point = clamp(hdr->Mode == ILM_HDR_TONE_MAP ? hdr->WhitePoint : 1.0f, min_v, max_v);
+    const float white_point = clamp(hdr->Mode == ILM_HDR_TONE_MAP ? hdr->WhitePoint : 1.0f, min_v, max_v);
+    {   // Uncharted2Tonemap1(WhitePoint), HDR.fxh:30-36
+        const float kA = 0.15f, kB = 0.50f, kC = 0.10f, kD = 0.20f, kE = 0.02f, kF = 0.30f;
+        const float w = ((white_point * (kA * white_point + kC * kB) + kD * kE) / (white_point * (kA * white_point + kB) + kD * kF)) - kE / kF;
+        a.inv_white = 1.0f / w;
+    }
     a.middle_gray = clamp(hdr->MiddleGray, 0.0f, max_v);
-    a.average_luminance = clamp(hdr->AverageLuminance, min_v, max_v);
+    a.inv_average_luminance = 1.0f / clamp(hdr->AverageLuminance, min_v, max_v);
     const float maximum_luminance = clamp(hdr->MaximumLuminance, min_v, max_v);
-    a.maximum_luminance_squared = maximum_luminance * maximum_luminance;
+    a.inv_maximum_luminance_squared = 1.0f / (maximum_luminance * maximum_luminance);
     HIP_TRY(launch_resolve(a, c->stream));
     return ILM_OK;
 }

@@ -139,48 +139,76 @@ ILM_DEV void store_lightmap_texel(void* texels, int format, size_t o, float4 c) 
     }
 }
 
-// Uncharted2Tonemap1, HDR.fxh:30-36
-ILM_DEV float uncharted2_tonemap1(float value) {
-    const float kA = 0.15f, kB = 0.50f, kC = 0.10f, kD = 0.20f, kE = 0.02f, kF = 0.30f;
-    return ((value * (kA * value + kC * kB) + kD * kE) / (value * (kA * value + kB) + kD * kF)) - kE / kF;
-}
+// pow(x, y) for x >= 0 as exp2(y * log2(x)): v_log_f32 / v_exp_f32 are 1-ulp hardware transcendentals, so the result is within a
+// few 1e-7 relative of powf for the exponents in use (gamma in [0.1, 4]) -- far inside the 1e-4 parity tolerance -- at 3 instructions
+// instead of OCML powf's ~40.  pow(0, y > 0) = exp2(-inf) = 0 as powf gives.
+ILM_DEV float pow_pos(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
 
-__global__ __launch_bounds__(256) void resolve_kernel(const ResolveLaunch a) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const size_t n = (size_t)(a.row_end - a.row_begin) * (size_t)a.width;
-    if (i >= n) return;
-    const size_t o = (size_t)a.row_begin * (size_t)a.width + i;
-    const float4 color = load_lightmap_texel(a.src, a.src_format, o);
+ILM_DEV float4 resolve_texel(const ResolveLaunch& a, float4 color) {
     // ResolveCommon, Resolve.fx:25-40 (scale 1: the pixel's own texel)
     float r = color.x * a.inverse_scale, g = color.y * a.inverse_scale, b = color.z * a.inverse_scale;
     if (a.mode == ILM_HDR_GAMMA_COMPRESS) {
         // GammaCompress, HDR.fxh:11-18
         r = fmaxf(r + a.offset, 0.0f); g = fmaxf(g + a.offset, 0.0f); b = fmaxf(b + a.offset, 0.0f);
         const float result_luminance = r * 0.299f + g * 0.587f + b * 0.114f;
-        const float scaled = (result_luminance * a.middle_gray) / a.average_luminance;
-        const float compressed = (scaled * (1.0f + (scaled / a.maximum_luminance_squared))) / (1.0f + scaled);
-        const float rescale = compressed / result_luminance;
+        const float scaled = (result_luminance * a.middle_gray) * a.inv_average_luminance;
+        const float compressed = (scaled * (1.0f + (scaled * a.inv_maximum_luminance_squared))) * fast_rcp(1.0f + scaled);
+        const float rescale = compressed * fast_rcp(result_luminance);
+        // 0 / 0 at a black pixel is NaN in the shader as well (compressedLuminance / resultLuminance)
         r *= rescale; g *= rescale; b *= rescale;
     } else if (a.mode == ILM_HDR_TONE_MAP) {
-        // ToneMappedLightingResolvePixelShader, Resolve.fx:113-139
-        const float e = a.exposure_minus_one + 1.0f, w = uncharted2_tonemap1(a.white_point), gm = a.gamma_minus_one + 1.0f;
-        r = powf(uncharted2_tonemap1(fmaxf(0.0f, r + a.offset) * e) / w, gm);
-        g = powf(uncharted2_tonemap1(fmaxf(0.0f, g + a.offset) * e) / w, gm);
-        b = powf(uncharted2_tonemap1(fmaxf(0.0f, b + a.offset) * e) / w, gm);
+        // ToneMappedLightingResolvePixelShader, Resolve.fx:113-139; Uncharted2Tonemap, HDR.fxh:38-44
+        const float kA = 0.15f, kB = 0.50f, kC = 0.10f, kD = 0.20f, kE = 0.02f, kF = 0.30f;
+        const float e = a.exposure_minus_one + 1.0f, gm = a.gamma_minus_one + 1.0f;
+        float v[3] = { fmaxf(0.0f, r + a.offset) * e, fmaxf(0.0f, g + a.offset) * e, fmaxf(0.0f, b + a.offset) * e };
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const float t = ((v[k] * (kA * v[k] + kC * kB) + kD * kE) * fast_rcp(v[k] * (kA * v[k] + kB) + kD * kF)) - kE / kF;
+            v[k] = pow_pos(t * a.inv_white, gm);
+        }
+        r = v[0]; g = v[1]; b = v[2];
     } else {
         // LightingResolvePixelShader, Resolve.fx:62-83
         const float e = a.exposure_minus_one + 1.0f, gm = a.gamma_minus_one + 1.0f;
-        r = powf(fmaxf(0.0f, r + a.offset) * e, gm);
-        g = powf(fmaxf(0.0f, g + a.offset) * e, gm);
-        b = powf(fmaxf(0.0f, b + a.offset) * e, gm);
+        r = pow_pos(fmaxf(0.0f, r + a.offset) * e, gm);
+        g = pow_pos(fmaxf(0.0f, g + a.offset) * e, gm);
+        b = pow_pos(fmaxf(0.0f, b + a.offset) * e, gm);
     }
-    store_lightmap_texel(a.dst, a.dst_format, o, mk4(r, g, b, 1.0f));
+    return mk4(r, g, b, 1.0f);
+}
+
+// Pure stream: 2 pixels per lane (16 B half4 loads, 8 B RGBA8 stores; a wave moves 1 KiB / 512 B per instruction).
+__global__ __launch_bounds__(256) void resolve_kernel(const ResolveLaunch a) {
+    const size_t pair = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n = (size_t)(a.row_end - a.row_begin) * (size_t)a.width;
+    const size_t i = pair * 2;
+    if (i >= n) return;
+    const size_t o = (size_t)a.row_begin * (size_t)a.width + i;
+    const bool two = (i + 1 < n) && ((o & 1) == 0);
+    if (two && a.src_format == ILM_LIGHTMAP_HALF4 && a.dst_format == ILM_LIGHTMAP_RGBA8) {
+        // the back-buffer case: one 16-byte load, one 8-byte store
+        const uint4 v = reinterpret_cast<const uint4*>(a.src)[o >> 1];
+        const float4 c0 = mk4(__half2float(__ushort_as_half((unsigned short)(v.x & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(v.x >> 16))),
+                              __half2float(__ushort_as_half((unsigned short)(v.y & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(v.y >> 16))));
+        const float4 c1 = mk4(__half2float(__ushort_as_half((unsigned short)(v.z & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(v.z >> 16))),
+                              __half2float(__ushort_as_half((unsigned short)(v.w & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(v.w >> 16))));
+        const float4 r0 = resolve_texel(a, c0), r1 = resolve_texel(a, c1);
+        uint2 out;
+        out.x = (uint32_t)rintf(sat(r0.x) * 255.0f) | ((uint32_t)rintf(sat(r0.y) * 255.0f) << 8) | ((uint32_t)rintf(sat(r0.z) * 255.0f) << 16) | (255u << 24);
+        out.y = (uint32_t)rintf(sat(r1.x) * 255.0f) | ((uint32_t)rintf(sat(r1.y) * 255.0f) << 8) | ((uint32_t)rintf(sat(r1.z) * 255.0f) << 16) | (255u << 24);
+        reinterpret_cast<uint2*>(a.dst)[o >> 1] = out;
+        return;
+    }
+    store_lightmap_texel(a.dst, a.dst_format, o, resolve_texel(a, load_lightmap_texel(a.src, a.src_format, o)));
+    if (i + 1 < n)
+        store_lightmap_texel(a.dst, a.dst_format, o + 1, resolve_texel(a, load_lightmap_texel(a.src, a.src_format, o + 1)));
 }
 
 hipError_t launch_resolve(const ResolveLaunch& a, hipStream_t stream) {
     const size_t n = (size_t)(a.row_end - a.row_begin) * (size_t)a.width;
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, a);
+    const size_t pairs = (n + 1) / 2;
+    hipLaunchKernelGGL(resolve_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 

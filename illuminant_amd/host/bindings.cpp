@@ -5,6 +5,7 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <algorithm>
 #include <cstring>
 
 #include "illuminant_host.hpp"
@@ -392,6 +393,23 @@ PYBIND11_MODULE(_host, m) {
             r.SetGBuffer(a.data(), (int)a.shape(1), (int)a.shape(0), format);
         })
         .def("UpdateFields", &LightingRenderer::UpdateFields)
+        .def("BenchResolve", [](LightingRenderer& r, const std::string& hdrBytes, int format, int iterations) {
+            // `iterations` resolves into a target of `format`, timed with the context's HIP events; returns ms per resolve
+            if (hdrBytes.size() != sizeof(IlmHDRConfiguration)) throw ArgumentException("hdr must be an IlmHDRConfiguration");
+            IlmHDRConfiguration hdr; std::memcpy(&hdr, hdrBytes.data(), sizeof(hdr));
+            IlmHandle target = 0;
+            ThrowIfFailed(ilm_lightmap_create(r.Context.Handle(), r.Configuration.RenderWidth, r.Configuration.RenderHeight, format, nullptr, &target));
+            float ms = 0;
+            try {
+                r.Resolve(target, &hdr);
+                r.Context.Sync();
+                r.Context.TimerStart();
+                for (int i = 0; i < iterations; i++) r.Resolve(target, &hdr);
+                ms = r.Context.TimerStop() / (float)std::max(iterations, 1);
+            } catch (...) { ilm_lightmap_destroy(target); throw; }
+            ilm_lightmap_destroy(target);
+            return ms;
+        })
         .def("ResolveToArray", [](const LightingRenderer& r, py::object hdrBytes) {
             // Resolve into a float4 target owned by the renderer's context, read it back (test / bench plumbing)
             const int w = r.Configuration.RenderWidth, h = r.Configuration.RenderHeight;

@@ -985,11 +985,12 @@ std::vector<IlmReadbackDrawCall> ParticleSystem::PerformReadback() const {
         elements.push_back(std::min(rowCount * cs, ChunkMaximumCount()));
         maxTotalCount += elements.back();
     }
-    result.resize((size_t)std::max(maxTotalCount, 1));
+    // ReadbackResultBuffer (:40-41): sized for every examined slot, not cleared ("FIXME: This is too slow")
+    std::unique_ptr<IlmReadbackDrawCall[]> buffer(new IlmReadbackDrawCall[(size_t)std::max(maxTotalCount, 1)]);
     const IlmReadbackParams p = GetReadbackParams();
     int32_t total = 0;
-    ThrowIfFailed(ilm_system_readback(handle, elements.data(), (int32_t)elements.size(), &p, result.data(), (int32_t)result.size(), &total));
-    result.resize((size_t)total);
+    ThrowIfFailed(ilm_system_readback(handle, elements.data(), (int32_t)elements.size(), &p, buffer.get(), std::max(maxTotalCount, 1), &total));
+    result.assign(buffer.get(), buffer.get() + total);
     return result;
 }
 
