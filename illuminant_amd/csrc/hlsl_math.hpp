@@ -130,13 +130,17 @@ ILM_DEV void sdf_unpack_word(uint32_t w, float& a, float& b) {
 }
 
 // sampleDistanceFieldEx.  Same IEEE operations on every value the result depends on as the CPU oracle (the cone
-// trace's loop exits are discontinuous in this value, and the tests require the oracle's exact sample counts);
-// what is rewritten is the integer bookkeeping around them:
+// trace's loop exits are discontinuous in this value, and the tests require the oracle's exact sample counts).  Multiply-adds are
+// FUSED exactly where the oracle calls fmaf (uv assembly, texel-space coordinates, the seven lerps, the decode): the HLSL leaves
+// that open and v_fma_f32 halves those chains.  What is rewritten is the integer bookkeeping around them:
 //   floor(vslice / 3) and vslice % 3      -> multiply-shift on the integer slice number (exact for vslice < 65536)
 //   WRAP / CLAMP tap indices              -> exact float-reciprocal wrap (|index| < 2^23) and integer clamps
 //   distance to the volume                -> the sqrt is skipped when every lane of the wave is inside the volume
 //   unorm16 decode                        -> unorm16_to_float
-template <int FORMAT>
+// CHECK_NAN = false: the caller guarantees finite coordinates (the cone trace hoists the test out of its loop).
+ILM_DEV float lerp_fused(float a, float b, float t) { return __builtin_fmaf(t, b - a, a); }
+
+template <int FORMAT, bool CHECK_NAN = true>
 ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms& df, const SdfView& sdf) {
 #pragma clang fp contract(off)
     position.z -= df.ConeAndMisc.y;
@@ -146,13 +150,15 @@ ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms&
     // (p < 0: -p;  p > e: p - e;  inside: 0), and only its square is used.
     // A NaN coordinate (normalize(0) upstream) behaves like 0 in the min/max form -- clamp gives 0 and both terms of
     // the distance vanish -- so it is replaced by 0 up front and the two forms agree on every input.
-    position.x = (position.x != position.x) ? 0.0f : position.x;
-    position.y = (position.y != position.y) ? 0.0f : position.y;
-    position.z = (position.z != position.z) ? 0.0f : position.z;
+    if (CHECK_NAN) {
+        position.x = (position.x != position.x) ? 0.0f : position.x;
+        position.y = (position.y != position.y) ? 0.0f : position.y;
+        position.z = (position.z != position.z) ? 0.0f : position.z;
+    }
     const float cx = __builtin_amdgcn_fmed3f(position.x, 0.0f, ex), cy = __builtin_amdgcn_fmed3f(position.y, 0.0f, ey),
                 cz = __builtin_amdgcn_fmed3f(position.z, 0.0f, ez);
     const f3 dtv = mk3(position.x - cx, position.y - cy, position.z - cz);
-    const float d2 = dot3(dtv, dtv);
+    const float d2 = __builtin_fmaf(dtv.z, dtv.z, __builtin_fmaf(dtv.y, dtv.y, dtv.x * dtv.x));
     float distance_to_volume = 0.0f;                 // sqrt(+0) == +0: skipping it inside the volume is exact
     if (__builtin_amdgcn_ballot_w64(d2 != 0.0f) != 0ull) {
         asm volatile("" ::: "memory");               // keep this a (wave-uniform) branch: if-conversion would run the sqrt every time
@@ -167,18 +173,21 @@ ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms&
 
     const float column_index = (float)third;                 // floor(vslice / 3)
     const float row_index = floorf(vslice * df.Packed1.x);   // floor(vslice * invCols / 3): the reference's float form
-    const float u = column_index * df.TextureSliceAndTexelSize.x + cx * df.TextureSliceAndTexelSize.z;
-    const float v = row_index * df.TextureSliceAndTexelSize.y + cy * df.TextureSliceAndTexelSize.w;
+    const float u = __builtin_fmaf(column_index, df.TextureSliceAndTexelSize.x, cx * df.TextureSliceAndTexelSize.z);
+    const float v = __builtin_fmaf(row_index, df.TextureSliceAndTexelSize.y, cy * df.TextureSliceAndTexelSize.w);
 
     // LINEAR, U WRAP, V CLAMP, texel centres at +0.5
-    const float x = u * sdf.wf - 0.5f;
-    const float y = v * sdf.hf - 0.5f;
+    const float x = __builtin_fmaf(u, sdf.wf, -0.5f);
+    const float y = __builtin_fmaf(v, sdf.hf, -0.5f);
     const float x0f = floorf(x), y0f = floorf(y);
     const float fx = x - x0f, fy = y - y0f;
+    // U WRAP is what folds physical slice p onto atlas column p % cols (u = p / cols + ... runs past 1 for every atlas row but
+    // the first, DistanceFieldCommon.fxh:303-311): a positive modulo of x0f by the atlas width.  q may be off by one after the
+    // reciprocal multiply; the remainder x0f - q * width is exact in fp32 and is folded back into [0, width).
     int x0;
-    {   // positive modulo of x0f by the atlas width; the remainder is exact in fp32, q may be off by one
+    {
         const float q = floorf(x0f * sdf.inv_wf);
-        float r = x0f - q * sdf.wf;
+        float r = __builtin_fmaf(-q, sdf.wf, x0f);
         r = (r < 0.0f) ? r + sdf.wf : r;
         r = (r >= sdf.wf) ? r - sdf.wf : r;
         x0 = (int)r;
@@ -209,11 +218,11 @@ ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms&
     sdf_unpack_word<FORMAT>(sdf_pair_word(t10, m), a10, b10);
     sdf_unpack_word<FORMAT>(sdf_pair_word(t01, m), a01, b01);
     sdf_unpack_word<FORMAT>(sdf_pair_word(t11, m), a11, b11);
-    const float lo = lerp(lerp(a00, a10, fx), lerp(a01, a11, fx), fy);
-    const float hi = lerp(lerp(b00, b10, fx), lerp(b01, b11, fx), fy);
-    const float blended = lerp(lo, hi, slice_position - vslice);
+    const float lo = lerp_fused(lerp_fused(a00, a10, fx), lerp_fused(a01, a11, fx), fy);
+    const float hi = lerp_fused(lerp_fused(b00, b10, fx), lerp_fused(b01, b11, fx), fy);
+    const float blended = lerp_fused(lo, hi, slice_position - vslice);
 
-    return (kDistanceZero - blended) * df.Extent.w + distance_to_volume;
+    return __builtin_fmaf(kDistanceZero - blended, df.Extent.w, distance_to_volume);
 }
 
 }  // namespace ilm

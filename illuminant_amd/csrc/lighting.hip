@@ -195,21 +195,27 @@ ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment
     const bool trace = (casts != 0.0f) && (pre_trace >= (0.75f / 255.0f));
     if (trace) {
         if (STATS) st.traced++;
-        const f3 start = P.shaded + (P.normal * 1.6f);   // SELF_OCCLUSION_HACK
+        f3 start = P.shaded + (P.normal * 1.6f);   // SELF_OCCLUSION_HACK
         const f3 tv = mk3(L.cx, L.cy, L.cz) - start;
         const float trace_length = len3(tv);
-        const f3 dir = mk3(tv.x / trace_length, tv.y / trace_length, tv.z / trace_length);
+        f3 dir = mk3(tv.x / trace_length, tv.y / trace_length, tv.z / trace_length);
         const float data_y = fmaxf(trace_length - L.radius, 1.0f);
         float data_x = 0.5f;   // TRACE_INITIAL_OFFSET_PX
         float data_z = 1.0f;
         const float cfg_z = fmaxf(1.0f, df.Packed1.w);
         float steps_remaining = df.StepAndMisc2.x;
         float liveness = have_sdf ? 1.0f : 0.0f;
+        // The sampler treats a NaN coordinate as 0.  start + dir * x is NaN for every x exactly when start or dir is (x stays
+        // finite), so the test is hoisted: such an axis becomes start = dir = 0 and the loop samples with CHECK_NAN = false.
+        if ((start.x != start.x) || (dir.x != dir.x)) { start.x = 0.0f; dir.x = 0.0f; }
+        if ((start.y != start.y) || (dir.y != dir.y)) { start.y = 0.0f; dir.y = 0.0f; }
+        if ((start.z != start.z) || (dir.z != dir.z)) { start.z = 0.0f; dir.z = 0.0f; }
         while (liveness > 0.0f) {
             steps_remaining -= 1.0f;
-            const float s = sample_distance_field<FMT>(start + (dir * data_x), df, sdf);
+            const f3 sp = mk3(__builtin_fmaf(dir.x, data_x, start.x), __builtin_fmaf(dir.y, data_x, start.y), __builtin_fmaf(dir.z, data_x, start.z));
+            const float s = sample_distance_field<FMT, false>(sp, df, sdf);
             if (STATS) st.samples++;
-            const float local_radius = fminf((L.cfg_y * data_x) + 0.33f, L.cfg_x);   // MIN_CONE_RADIUS
+            const float local_radius = fminf(__builtin_fmaf(L.cfg_y, data_x, 0.33f), L.cfg_x);   // MIN_CONE_RADIUS
             data_z = fminf(data_z, (s + 1.5f) / local_radius);                        // HACK_DISTANCE_OFFSET
             data_x += fmaxf(fabsf(s) * df.StepAndMisc2.z, cfg_z);
             liveness = steps_remaining * (sat(data_z - 0.075f) * sat(data_y - data_x));

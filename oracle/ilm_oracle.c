@@ -620,9 +620,15 @@ static inline void sdf_texel(const OrcTexture* t, int x, int y, float out[4]) {
 
 /* tex2Dlod on DistanceFieldTextureSampler: LINEAR min/mag, U WRAP, V CLAMP
  * (DistanceFieldCommon.fxh:273-281) */
+/* Multiply-adds of the SDF sampler and of the cone-trace step are FUSED (one rounding), in exactly the places where the HIP path
+ * issues v_fma_f32 / v_fmac_f32: the HLSL leaves this open (fxc emits mad / lrp for these expressions at will), so the restatement
+ * fixes it once for both sides; fmaf is exact by definition, which keeps the two bit-identical. */
+static inline float h_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+static inline float h_lerp_fused(float a, float b, float t) { return h_fma(t, b - a, a); }
+
 static void sdf_sample_linear(const OrcTexture* t, float u, float v, float out[4]) {
-    float x = u * (float)t->width - 0.5f;
-    float y = v * (float)t->height - 0.5f;
+    float x = h_fma(u, (float)t->width, -0.5f);
+    float y = h_fma(v, (float)t->height, -0.5f);
     float x0f = floorf(x), y0f = floorf(y);
     float fx = x - x0f, fy = y - y0f;
     int x0 = wrap_index(x0f, t->width), x1 = wrap_index(x0f + 1.0f, t->width);
@@ -633,9 +639,9 @@ static void sdf_sample_linear(const OrcTexture* t, float u, float v, float out[4
     sdf_texel(t, x0, y0, t00); sdf_texel(t, x1, y0, t10);
     sdf_texel(t, x0, y1, t01); sdf_texel(t, x1, y1, t11);
     for (int c = 0; c < 4; c++) {
-        float top = h_lerp(t00[c], t10[c], fx);
-        float bot = h_lerp(t01[c], t11[c], fx);
-        out[c] = h_lerp(top, bot, fy);
+        float top = h_lerp_fused(t00[c], t10[c], fx);
+        float bot = h_lerp_fused(t01[c], t11[c], fx);
+        out[c] = h_lerp_fused(top, bot, fy);
     }
 }
 
@@ -650,7 +656,7 @@ static float sample_distance_field_ex(f3 position, const IlmDistanceFieldUniform
     f3 dtv = v3(-fminf(position.x, 0.0f) + (fmaxf(position.x, extent.x) - extent.x),
                 -fminf(position.y, 0.0f) + (fmaxf(position.y, extent.y) - extent.y),
                 -fminf(position.z, 0.0f) + (fmaxf(position.z, extent.z) - extent.z));
-    float distance_to_volume = v3len(dtv);
+    float distance_to_volume = sqrtf(h_fma(dtv.z, dtv.z, h_fma(dtv.y, dtv.y, dtv.x * dtv.x)));
 
     float slice_position = fminf(clamped.z, df->Packed1.z) * df->Packed1.y;
     float virtual_slice_index = floorf(slice_position);
@@ -661,8 +667,8 @@ static float sample_distance_field_ex(f3 position, const IlmDistanceFieldUniform
     /* computeDistanceFieldSliceUv, DistanceFieldCommon.fxh:303-311 */
     float column_index = floorf(virtual_slice_index / 3.0f);
     float row_index = floorf(virtual_slice_index * df->Packed1.x);
-    float u = column_index * df->TextureSliceAndTexelSize.x + texel_u;
-    float v = row_index * df->TextureSliceAndTexelSize.y + texel_v;
+    float u = h_fma(column_index, df->TextureSliceAndTexelSize.x, texel_u);
+    float v = h_fma(row_index, df->TextureSliceAndTexelSize.y, texel_v);
 
     float packed[4];
     sdf_sample_linear(sdf, u, v, packed);
@@ -670,14 +676,14 @@ static float sample_distance_field_ex(f3 position, const IlmDistanceFieldUniform
     float mask_pattern_index = fmodf(virtual_slice_index, 3.0f);
     float subslice = slice_position - virtual_slice_index, blended;
     if (mask_pattern_index >= 2.0f)
-        blended = h_lerp(packed[2], packed[3], subslice);
+        blended = h_lerp_fused(packed[2], packed[3], subslice);
     else if (mask_pattern_index >= 1.0f)
-        blended = h_lerp(packed[1], packed[2], subslice);
+        blended = h_lerp_fused(packed[1], packed[2], subslice);
     else
-        blended = h_lerp(packed[0], packed[1], subslice);
+        blended = h_lerp_fused(packed[0], packed[1], subslice);
 
-    float decoded = (DISTANCE_ZERO - blended) * df->Extent.w;
-    return decoded + distance_to_volume;
+    /* decodeDistance(blended) + distanceToVolume */
+    return h_fma(DISTANCE_ZERO - blended, df->Extent.w, distance_to_volume);
 }
 
 float orc_sample_distance_field(const float pos[3], const IlmDistanceFieldUniforms* df, const OrcTexture* sdf) {
@@ -1215,10 +1221,10 @@ static float cone_trace(f3 light_center, float light_radius, float light_ramp, f
     while (liveness > 0.0f) {
         steps_remaining -= 1.0f;
         /* coneTraceAdvance, :76-85 */
-        f3 sp = v3add(shaded, v3scale(direction, data_x));
+        f3 sp = v3(h_fma(direction.x, data_x, shaded.x), h_fma(direction.y, data_x, shaded.y), h_fma(direction.z, data_x, shaded.z));
         float sample = sample_distance_field_ex(sp, df, sdf, ctr);
         /* coneTraceStep, :52-74 */
-        float local_sphere_radius = fminf((cfg_y * data_x) + 0.33f, cfg_x);
+        float local_sphere_radius = fminf(h_fma(cfg_y, data_x, 0.33f), cfg_x);
         float local_visibility = ((sample + 1.5f) / local_sphere_radius);
         data_z = fminf(data_z, local_visibility);
         data_x += fmaxf(fabsf(sample) * df->StepAndMisc2.z, cfg_z);

@@ -91,3 +91,26 @@ def test_non_finite_positions_follow_the_min_max_semantics(ctx, oracle):
     want = oracle_samples(oracle, pos, dfu, oracle.make_texture(atlas, abi.SDF_UNORM16))
     assert np.array_equal(got, want, equal_nan=True), (got, want)
     sdf.close()
+
+
+@pytest.mark.parametrize("fmt", [abi.SDF_UNORM16, abi.SDF_FP16])
+def test_multi_row_atlas_relies_on_the_u_wrap(ctx, oracle, fmt):
+    """The lighting configs' field: 33 slices in a 3 x 4 atlas.  u = physicalSlice / columns + ... runs past 1 for every atlas row but
+    the first, and it is the sampler's U WRAP that folds slice p onto column p % columns (DistanceFieldCommon.fxh:303-311): the
+    device's wrap arithmetic must agree with the oracle's on every row, at slice seams and at the volume's faces."""
+    layout = scenes.DistanceFieldLayout(2048, 2048, 128.0, 32, 0.25, 128)
+    assert (layout.column_count, layout.row_count, layout.slice_count) == (3, 4, 33)
+    atlas = scenes.build_sdf_atlas(layout, scenes.random_obstacles(11, 96, (2048, 2048)), fmt=fmt)
+    dfu = layout.uniforms(max_cone_radius=24.0, power=0.7, step_limit=64, min_step_size=1.0, long_step_factor=0.5)
+    sdf = native.DistanceFieldTexture(ctx, atlas, fmt)
+    n = 6000
+    pts = scenes.uniform(5, (n, 3), 0, 1) * np.array([2048, 2048, 128], np.float32)
+    # seams: x on slice borders (the left tap of texel 0 wraps to the previous column), z on slice boundaries, outside the volume
+    pts[:300, 0] = np.repeat(np.array([0.0, 0.5, 1.9, 2047.9, 2048.0, 2100.0], np.float32), 50)
+    pts[300:600, 2] = np.linspace(0.0, 128.0, 300, dtype=np.float32)
+    pts[600:700, 1] = np.linspace(-40.0, 2090.0, 100, dtype=np.float32)
+    got = sdf.sample(dfu, pts)
+    want = oracle_samples(oracle, pts, dfu, oracle.make_texture(atlas, fmt))
+    assert np.array_equal(got, want), "%d of %d samples differ" % (int((got != want).sum()), n)
+    assert np.unique((pts[:, 2] * 33 / 128).astype(int) // 3 // 3).size == 4      # all four atlas rows were visited
+    sdf.close()
