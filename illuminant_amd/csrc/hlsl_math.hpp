@@ -203,21 +203,22 @@ ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms&
     const uint32_t pitch = (uint32_t)sdf.width << 3;
     const uint32_t r0 = __umul24((uint32_t)y0, pitch);
     const uint32_t r1 = (y1 != y0) ? r0 + pitch : r0;
-    const uint32_t c0 = (uint32_t)x0 << 3, c1 = (uint32_t)x1 << 3;
+    // The two channels virtual slice 3k+m blends -- (r,g), (g,b) or (b,a) -- are the 4 bytes at offset 2m inside the 8-byte texel:
+    // one dword load per tap at that (2-byte aligned) address replaces the 8-byte load + funnel shift + select.
+    const uint32_t sub = m << 1;
+    const uint32_t c0 = ((uint32_t)x0 << 3) + sub, c1 = ((uint32_t)x1 << 3) + sub;
     typedef const char __attribute__((address_space(1))) gbyte;
-    typedef uint32_t __attribute__((ext_vector_type(2))) u32x2;
-    typedef const u32x2 __attribute__((address_space(1))) gtexel;
+    typedef const uint32_t __attribute__((address_space(1), aligned(2))) gword;
     gbyte* base = (gbyte*)sdf.texels;
     asm("" : "+s"(base));
-    const u32x2 q00 = *(gtexel*)(base + (r0 + c0)), q10 = *(gtexel*)(base + (r0 + c1));
-    const u32x2 q01 = *(gtexel*)(base + (r1 + c0)), q11 = *(gtexel*)(base + (r1 + c1));
-    const uint2 t00 = make_uint2(q00.x, q00.y), t10 = make_uint2(q10.x, q10.y), t01 = make_uint2(q01.x, q01.y), t11 = make_uint2(q11.x, q11.y);
+    const uint32_t w00 = *(gword*)(base + (r0 + c0)), w10 = *(gword*)(base + (r0 + c1));
+    const uint32_t w01 = *(gword*)(base + (r1 + c0)), w11 = *(gword*)(base + (r1 + c1));
 
     float a00, b00, a10, b10, a01, b01, a11, b11;
-    sdf_unpack_word<FORMAT>(sdf_pair_word(t00, m), a00, b00);
-    sdf_unpack_word<FORMAT>(sdf_pair_word(t10, m), a10, b10);
-    sdf_unpack_word<FORMAT>(sdf_pair_word(t01, m), a01, b01);
-    sdf_unpack_word<FORMAT>(sdf_pair_word(t11, m), a11, b11);
+    sdf_unpack_word<FORMAT>(w00, a00, b00);
+    sdf_unpack_word<FORMAT>(w10, a10, b10);
+    sdf_unpack_word<FORMAT>(w01, a01, b01);
+    sdf_unpack_word<FORMAT>(w11, a11, b11);
     const float lo = lerp_fused(lerp_fused(a00, a10, fx), lerp_fused(a01, a11, fx), fy);
     const float hi = lerp_fused(lerp_fused(b00, b10, fx), lerp_fused(b01, b11, fx), fy);
     const float blended = lerp_fused(lo, hi, slice_position - vslice);
