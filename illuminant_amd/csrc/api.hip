@@ -1210,6 +1210,15 @@ int32_t ilm_lightmap_destroy(IlmHandle h) {
 }
 
 namespace {
+// Block -> tile mapping of the light kernel.  Measured on MI355X (bench.py lighting, ms/frame cfg3 | cfg5): contiguous band of tiles
+// per XCD 2.02 | 29.0; tile rows round-robin over the XCDs 1.65 | 22.8; identity (consecutive tiles on consecutive XCDs) 1.59 | 23.1.
+// The banded mapping keeps each XCD's L2 on one part of the atlas but the lights are not spread evenly over the screen, so whole
+// XCDs idle while the busiest band finishes; the 25 MB atlas is L2 / Infinity-Cache resident either way.  Identity is the default.
+int light_tile_map() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ILM_LIGHT_TILE_MAP"); v = e ? atoi(e) : 2; }
+    return v;
+}
 // shared by the three light passes: resource checks + the launch descriptor
 int32_t fill_light_launch(Ctx* c, const IlmEnvironment* env, const IlmDistanceFieldUniforms* df, IlmHandle hgbuffer, IlmHandle hsdf,
                           IlmHandle hlightmap, int32_t row_begin, int32_t row_end, LightLaunch* a) {
@@ -1231,6 +1240,7 @@ int32_t fill_light_launch(Ctx* c, const IlmEnvironment* env, const IlmDistanceFi
     a->lightmap = m->texels; a->width = m->width; a->height = m->height; a->format = m->format;
     a->row_begin = row_begin; a->row_end = row_end;
     a->stats = nullptr; a->light_count_ptr = nullptr; a->accumulate = 0;
+    a->tile_map = light_tile_map();
     return ILM_OK;
 }
 }  // namespace
@@ -1524,6 +1534,7 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
     a.lightmap = m->texels; a.width = m->width; a.height = m->height; a.format = m->format;
     a.row_begin = row_begin; a.row_end = row_end;
     a.stats = nullptr; a.light_count_ptr = nullptr; a.accumulate = 0;
+    a.tile_map = light_tile_map();
     if (stats) {
         HIP_TRY(hipMemsetAsync(c->d_stats, 0, 3 * sizeof(unsigned long long), c->stream));
         a.stats = c->d_stats;

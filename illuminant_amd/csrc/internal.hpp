@@ -104,6 +104,7 @@ struct LightLaunch {
     int32_t row_begin, row_end;
     unsigned long long* stats;      // device, 3 counters, or nullptr
     const int32_t* light_count_ptr; // device: when non-null the record count is read from here (particle lights are counted on the device)
+    int32_t tile_map;               // block -> tile mapping: 0 contiguous band per XCD, 1 tile rows round-robin over the XCDs, 2 identity
     int32_t accumulate;             // != 0: start from the lightmap's contents instead of `ambient` (additive blend onto an earlier pass)
 };
 

@@ -251,13 +251,23 @@ __global__ __launch_bounds__(256) void sphere_lights_kernel(const LightLaunch a,
     __shared__ uint16_t list[kListCapacity];
     __shared__ int list_count;
 
-    // XCD-aware remap: the dispatcher places block b on XCD b % 8; give every XCD a
-    // contiguous band of tiles so neighbouring tiles (which walk the same SDF texels)
-    // share one L2.
+    // The dispatcher places block b on XCD b % 8.  Which tiles an XCD gets decides both its L2 locality and its share of the work
+    // (lights are not spread evenly): see light_tile_map() in api.hip for the measurements; identity (tile_map 2) is the default.
     const int nb = (int)gridDim.x;
     const int per_xcd = nb / 8;
     const int b = (int)blockIdx.x;
-    const int tile = (b % 8) * per_xcd + (b / 8);
+    int tile;
+    if (a.tile_map == 1) {
+        // tile rows dealt round-robin to the XCDs: row r -> XCD r % 8 (balances a frame whose lights cluster vertically)
+        const int xcd = b % 8, k = b / 8;                  // k-th block of this XCD
+        const int rows_here = (tiles_y - xcd + 7) / 8;     // rows r with r % 8 == xcd
+        const int r_local = k / tiles_x, cx_ = k - r_local * tiles_x;
+        tile = (r_local < rows_here) ? (r_local * 8 + xcd) * tiles_x + cx_ : tile_count;
+    } else if (a.tile_map == 2) {
+        tile = b;
+    } else {
+        tile = (b % 8) * per_xcd + (b / 8);
+    }
     if (tile >= tile_count)
         return;
     const int tx0 = (tile % tiles_x) * kTile, ty0 = a.row_begin + (tile / tiles_x) * kTile;
@@ -563,7 +573,8 @@ hipError_t launch_sphere_lights_prepared(const LightLaunch& a, const void* recs,
     if (rows <= 0 || a.width <= 0) return hipSuccess;
     const int tiles_x = (a.width + kTile - 1) / kTile, tiles_y = (rows + kTile - 1) / kTile;
     const int tile_count = tiles_x * tiles_y;
-    const int blocks = ((tile_count + 7) / 8) * 8;
+    int blocks = ((tile_count + 7) / 8) * 8;
+    if (a.tile_map == 1) blocks = ((tiles_y + 7) / 8) * tiles_x * 8;   // every XCD gets ceil(rows / 8) rows' worth of blocks
     const LightRec* r = reinterpret_cast<const LightRec*>(recs);
     const bool stats = a.stats != nullptr;
     const bool fp16 = a.sdf.format == ILM_SDF_FP16;
