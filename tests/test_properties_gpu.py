@@ -161,3 +161,87 @@ def test_cfg3_1080p_properties(ctx, oracle, cfg3_scene):
     assert np.abs(half[..., :3] - whole[..., :3]).mean() < 2e-3
     sdf16.close()
     sdf.close()
+
+
+def test_cfg4_share_eight_million_particles(ctx, oracle):
+    """cfg4's per-GPU share: 8 chunks of 1024^2 slots (8.4 M particles), Gravity + Noise + UpdatePositions.  One launch over the table ==
+    per-chunk launches (life bit-exact); live-count checksum; the oracle replays one whole 1 M-slot chunk."""
+    cs, n_chunks = 1024, 8
+    n = cs * cs
+    rnd = scenes.randomness_table(7)
+    eng = native.Engine(ctx, cs, rnd)
+    fused = native.System(eng)
+    split = native.System(eng)
+    d = cfg2_step(cs)
+    d.System = scenes.system_uniforms(cs, friction=0.02, max_velocity=2048.0, life_decay=4.0)
+    keep = {}
+    for c in range(n_chunks):
+        pos, vel, attr = scenes.make_particles(4000 + c, n, pos_lo=(0, 0, 0), pos_hi=(1920, 1080, 32), life=(0.01, 0.4), dead_fraction=0.05)
+        for s in (fused, split):
+            s.add_chunk()
+            s.upload(c, P, pos); s.upload(c, V, vel); s.upload(c, A, attr)
+        if c == 5:
+            keep = [pos.copy(), vel.copy(), attr.copy(), np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)]
+    steps = 2
+    for _ in range(steps):
+        fused.step(d)
+        for c in range(n_chunks):
+            dc = cfg2_step(cs)
+            dc.System = d.System
+            dc.FirstChunk, dc.ChunkCount = c, 1
+            split.step(dc)
+        oracle.step([keep], cs, rnd, _single_chunk(d))
+    counts = fused.step_counts()
+    total = 0
+    for c in range(n_chunks):
+        a, b = fused.download(c, P), split.download(c, P)
+        assert np.array_equal(a, b), "chunk %d: one launch vs per-chunk launches" % c       # same kernel variant: bit-equal
+        assert counts[c] == int((a[:, 3] > 0).sum())
+        total += int(counts[c])
+    assert np.array_equal(fused.live_counts(), counts) and 0 < total < n * n_chunks
+    # the oracle on chunk 5 (its 1 M slots through 2 steps)
+    got = [fused.download(5, k) for k in (P, V, A, RC, RD)]
+    assert np.array_equal(got[0][:, 3] > 0, keep[0][:, 3] > 0)
+    m = keep[0][:, 3] > 0
+    for k in (0, 1, 3, 4):
+        assert_close(got[k][m], keep[k][m], "cfg4 chunk 5 plane %d vs oracle" % k)
+    for s in (fused, split):
+        s.close()
+    eng.close()
+
+
+def _single_chunk(d):
+    import ctypes
+    c = abi.StepDesc()
+    ctypes.memmove(ctypes.byref(c), ctypes.byref(d), ctypes.sizeof(d))
+    c.FirstChunk, c.ChunkCount = 0, -1
+    return c
+
+
+def test_cfg5_4k_256_lights_fp16_properties(ctx, oracle):
+    """cfg5's frame: 3840 x 2160, 256 lights, fp16-sample field generated on the device from 256 obstructions.  8-strip invariance (the
+    8-GPU screen split), the oracle on an 8-row crop with exact SDF sample / pair / trace counts."""
+    w, h = 3840, 2160
+    layout = scenes.DistanceFieldLayout(4096, 4096, 128.0, 32, 0.125, 128)
+    obstacles = scenes.random_obstacles(11, 256, (4096, 4096))
+    sdf = native.DistanceFieldTexture(ctx, None, abi.SDF_FP16, size=(layout.atlas_width, layout.atlas_height))
+    sdf.render_slices(scenes.render_desc(layout), list(range(0, layout.slice_count, 3)), scenes.obstruction_array([(t - 1, c, s) for (t, c, s) in obstacles]))
+    atlas = sdf.download()
+    dfu = layout.uniforms(max_cone_radius=24.0, power=0.7, step_limit=64, min_step_size=1.0, long_step_factor=0.5)
+    lights = scenes.random_lights(13, 256, w, h, z=(8.0, 64.0), radius=24.0, ramp=(400.0, 1100.0))
+    env = scenes.environment()
+    ambient = (0.05, 0.05, 0.05, 1.0)
+    whole = render(ctx, lights, env, dfu, sdf, ambient, w, h)
+    assert np.isfinite(whole).all()
+    from illuminant_amd import sharding
+    assert np.array_equal(render(ctx, lights, env, dfu, sdf, ambient, w, h, strips=sharding.row_strips(h, 8)), whole)
+    b0, b1 = 1076, 1084
+    lm = native.Lightmap(ctx, w, h, abi.LIGHTMAP_FLOAT4)
+    stats = native.render_sphere_lights(ctx, lights, env, dfu, None, sdf, ambient, lm, b0, b1, want_stats=True)
+    lm.close()
+    want, ostats = oracle.render_sphere_lights(lights, env, dfu, None, oracle.make_texture(atlas, abi.SDF_FP16), ambient, w, h,
+                                               row_begin=b0, row_end=b1, want_stats=True)
+    assert (stats.SdfSamples, stats.PixelLightPairs, stats.TracedPairs) == (ostats.SdfSamples, ostats.PixelLightPairs, ostats.TracedPairs)
+    assert stats.SdfSamples > 5_000_000
+    assert_close(whole[b0:b1], want[b0:b1], "cfg5 crop vs oracle")
+    sdf.close()
