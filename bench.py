@@ -338,6 +338,27 @@ def main():
                              "kernel": "ilm::sphere_lights_kernel", "bytes_per_unit": SDF_SAMPLE_BYTES,
                              "units_per_launch": samples, "launch_ms": round(kern_ms, 4)},
             }
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                # the oracle on a bounded band of rows of the same frame (same generated field, same packed lights), on the host cores
+                from oracle import oracle as orc
+                atlas_host = L["field"].Save()
+                verts = (abi.LightVertex * nl)()
+                for i, lsrc in enumerate(L["env"].Lights):
+                    verts[i] = abi.LightVertex.from_buffer_copy(H.LightingRenderer.PackSphereLightBytes(lsrc, 1.0, True))
+                envu = abi.Environment.from_buffer_copy(r.GetEnvironmentUniformsBytes())
+                dfuu = abi.DistanceFieldUniforms.from_buffer_copy(r.GetDistanceFieldUniformsBytes())
+                tex = orc.make_texture(atlas_host, fmt)
+                rows, mid, budget = 4, h // 2, max(args.cpu_seconds / 3.0, 1.0)
+                t0 = time.perf_counter()
+                orc.render_sphere_lights(verts, envu, dfuu, None, tex, (0.05, 0.05, 0.05, 1.0), w, h, row_begin=mid, row_end=mid + rows)
+                el = time.perf_counter() - t0
+                if el < budget / 2:      # one more, larger band sized for the budget
+                    rows = int(min(max(rows * (budget / max(el, 1e-3)), rows), h // 2))
+                    t0 = time.perf_counter()
+                    orc.render_sphere_lights(verts, envu, dfuu, None, tex, (0.05, 0.05, 0.05, 1.0), w, h, row_begin=mid, row_end=mid + rows)
+                    el = time.perf_counter() - t0
+                lighting[name]["cpu_baseline"] = {"value": round(rows * w / el / 1e6, 4), "unit": "lit Mpixels/s", "cores": orc.num_threads(), "kind": "port",
+                                                  "sample": "%d rows x %d px around the frame's middle (oracle/ilm_oracle.c, OpenMP, %.1f s)" % (rows, w, el)}
             del L
         out["lighting"] = lighting
         out["lit_mpixels_per_s"] = lighting["cfg5_4k_256_lights_fp16"]["lit_mpixels_per_s"]
