@@ -212,7 +212,12 @@ class Obstruction(C.Structure):
 
 class HeightVolume(C.Structure):
     _fields_ = [("FirstVertex", i32), ("VertexCount", i32), ("ZBase", f32), ("Height", f32),
-                ("IsDynamic", i32), ("_pad", i32 * 3)]
+                ("IsDynamic", i32), ("TopFaceEnableShadows", i32), ("_pad", i32 * 2)]
+
+
+class GBufferRenderDesc(C.Structure):
+    _fields_ = [("ViewportPosition", f32 * 2), ("ViewportScale", f32 * 2), ("GroundZ", f32), ("RenderGroundPlane", i32),
+                ("EnableGroundShadows", i32), ("_pad", i32)]
 
 
 class DistanceFieldRenderDesc(C.Structure):
@@ -266,6 +271,7 @@ EXPECTED_SIZES = {
     "IlmRenderStats": (RenderStats, 24),
     "IlmParticleLightParams": (ParticleLightParams, 80),
     "IlmReadbackDrawCall": (ReadbackDrawCall, 48), "IlmReadbackParams": (ReadbackParams, 56), "IlmHDRConfiguration": (HDRConfiguration, 48),
+    "IlmGBufferRenderDesc": (GBufferRenderDesc, 32),
     "IlmObstruction": (Obstruction, 48), "IlmHeightVolume": (HeightVolume, 32),
     "IlmDistanceFieldRenderDesc": (DistanceFieldRenderDesc, 64),
 }

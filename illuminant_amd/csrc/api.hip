@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -1140,6 +1141,77 @@ int32_t ilm_gbuffer_upload(IlmHandle h, const void* texels) {
     const size_t bytes = (g->format == ILM_GBUFFER_FLOAT4 ? 16u : 8u) * (size_t)g->width * (size_t)g->height;
     HIP_TRY(hipMemcpyAsync(g->texels, texels, bytes, hipMemcpyHostToDevice, g->ctx->stream));
     HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+    return ILM_OK;
+}
+
+int32_t ilm_gbuffer_download(IlmHandle h, void* texels) {
+    GBuffer* g = from_handle<GBuffer>(h, kMagicGBuffer);
+    if (!g) return fail(ILM_ERR_INVALID_HANDLE, "not a G-buffer handle");
+    if (!texels) return fail(ILM_ERR_INVALID_ARGUMENT, "texels is NULL");
+    HIP_TRY(hipSetDevice(g->ctx->device));
+    const size_t bytes = (g->format == ILM_GBUFFER_FLOAT4 ? 16u : 8u) * (size_t)g->width * (size_t)g->height;
+    HIP_TRY(hipMemcpyAsync(texels, g->texels, bytes, hipMemcpyDeviceToHost, g->ctx->stream));
+    HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+    return ILM_OK;
+}
+
+int32_t ilm_gbuffer_render(IlmHandle h, const IlmGBufferRenderDesc* d, const IlmHeightVolume* volumes, int32_t volume_count,
+                           const float* polygon_xy, int32_t polygon_vertex_count) {
+    GBuffer* g = from_handle<GBuffer>(h, kMagicGBuffer);
+    if (!g) return fail(ILM_ERR_INVALID_HANDLE, "not a G-buffer handle");
+    if (!d) return fail(ILM_ERR_INVALID_ARGUMENT, "desc is NULL");
+    if (volume_count < 0 || polygon_vertex_count < 0 || (volume_count > 0 && (!volumes || !polygon_xy)))
+        return fail(ILM_ERR_INVALID_ARGUMENT, "bad array argument");
+    if (!(d->ViewportScale[0] > 0.0f) || !(d->ViewportScale[1] > 0.0f)) return fail(ILM_ERR_INVALID_ARGUMENT, "ViewportScale must be positive");
+    for (int i = 0; i < volume_count; i++)
+        if (volumes[i].FirstVertex < 0 || volumes[i].VertexCount < 0 || volumes[i].FirstVertex + volumes[i].VertexCount > polygon_vertex_count)
+            return fail(ILM_ERR_OUT_OF_RANGE, "height volume %d vertex range outside the polygon array", i);
+    Ctx* c = g->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    // RenderGBufferVolumes: OrderBy(hv => hv.ZBase + hv.Height) (stable), LightingRenderer.GBuffer.cs:210
+    std::vector<int> order;
+    for (int i = 0; i < volume_count; i++)
+        if (volumes[i].VertexCount >= 3) order.push_back(i);
+    std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+        return (volumes[x].ZBase + volumes[x].Height) < (volumes[y].ZBase + volumes[y].Height); });
+    std::vector<GBufferVolume> vols;
+    for (int i : order) {
+        const IlmHeightVolume& hv = volumes[i];
+        const float* P = polygon_xy + 2 * (size_t)hv.FirstVertex;
+        GBufferVolume v;
+        v.first_vertex = hv.FirstVertex; v.vertex_count = hv.VertexCount;
+        v.top = hv.ZBase + hv.Height; v.enable_shadows = hv.TopFaceEnableShadows;
+        v.x0 = v.x1 = P[0]; v.y0 = v.y1 = P[1];
+        for (int e = 1; e < hv.VertexCount; e++) {
+            v.x0 = fminf(v.x0, P[2 * e]); v.x1 = fmaxf(v.x1, P[2 * e]);
+            v.y0 = fminf(v.y0, P[2 * e + 1]); v.y1 = fmaxf(v.y1, P[2 * e + 1]);
+        }
+        vols.push_back(v);
+    }
+    auto align64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
+    const size_t off_poly = align64(sizeof(GBufferVolume) * vols.size());
+    const size_t total = align64(off_poly + sizeof(float) * 2 * (size_t)(vols.empty() ? 0 : polygon_vertex_count)) + 64;
+    if (total > c->field_params_bytes) {
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        if (c->d_field_params) HIP_TRY(hipFree(c->d_field_params));
+        c->d_field_params = nullptr; c->field_params_bytes = 0;
+        const size_t cap = total < 65536 ? 65536 : total * 2;
+        HIP_TRY(hipMalloc(&c->d_field_params, cap));
+        c->field_params_bytes = cap;
+    }
+    if (!vols.empty()) {
+        std::vector<unsigned char> block(total, 0);
+        memcpy(block.data(), vols.data(), sizeof(GBufferVolume) * vols.size());
+        memcpy(block.data() + off_poly, polygon_xy, sizeof(float) * 2 * (size_t)polygon_vertex_count);
+        int32_t rc = upload_small(c, c->d_field_params, block.data(), total);
+        if (rc != ILM_OK) return rc;
+    }
+    GBufferLaunch a;
+    a.texels = g->texels; a.width = g->width; a.height = g->height; a.format = g->format;
+    a.desc = *d;
+    a.volumes = reinterpret_cast<const GBufferVolume*>(c->d_field_params); a.volume_count = (int32_t)vols.size();
+    a.polygon_xy = reinterpret_cast<const float2*>(static_cast<char*>(c->d_field_params) + off_poly);
+    HIP_TRY(launch_render_gbuffer(a, c->stream));
     return ILM_OK;
 }
 

@@ -185,4 +185,64 @@ hipError_t launch_render_slices(const FieldLaunch& a, int format, hipStream_t st
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------
+// G-buffer generation, non-2.5D: RenderGBuffer (LightingRenderer.GBuffer.cs:127-219) = clear + ground plane + height-volume top
+// faces, lowest to highest, all with technique GroundPlane (GBuffer.fx:7-19,57-70).  One pass, one store per texel
+// (16 B float4 or 8 B half4): a pure HBM-write stream plus an edge loop for pixels inside a volume's bounding box.
+// ---------------------------------------------------------------------------------------------
+// encodeGBufferSample with normal (0, 0, 1), relativeY 0 (GBufferShaderCommon.fxh:10-35; encodeNormalSpherical, EnvironmentCommon.fxh:33-40)
+ILM_DEV float4 encode_gbuffer_up(float z, bool enable_shadows) {
+    const float nx = 0.0001f;                                          // |n.x| < 0.0001 => 0.0001
+    const float ex = ((atan2f(0.0f, nx) / kPi) + 1.0f) * 0.5f;
+    const float ey = (1.0f + 1.0f) * 0.5f;
+    const float w = (((z + 1024.0f) / 1024.0f) * (enable_shadows ? 1.0f : -1.0f)) + (enable_shadows ? 0.0f : -1.0f);
+    return mk4(ex, ey, 0.0f, w);
+}
+
+__global__ __launch_bounds__(256) void render_gbuffer_kernel(const GBufferLaunch a) {
+    const int i = (int)blockIdx.x * 64 + ((int)threadIdx.x & 63);
+    const int j = (int)blockIdx.y * 4 + ((int)threadIdx.x >> 6);
+    if (i >= a.width || j >= a.height) return;
+    const float wx = ((float)i + 0.5f) / a.desc.ViewportScale[0] + a.desc.ViewportPosition[0];
+    const float wy = ((float)j + 0.5f) / a.desc.ViewportScale[1] + a.desc.ViewportPosition[1];
+    const float ground_z = a.desc.GroundZ + (a.desc.RenderGroundPlane ? 0.0f : 99999.0f);
+    float4 texel = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (!(ground_z < a.desc.GroundZ))
+        texel = encode_gbuffer_up(ground_z, a.desc.EnableGroundShadows != 0);
+    for (int v = 0; v < a.volume_count; v++) {
+        const GBufferVolume& V = a.volumes[v];
+        if (!((wx >= V.x0) && (wx <= V.x1) && (wy >= V.y0) && (wy <= V.y1)))      // outside the polygon's bounds: no crossing can make it inside
+            continue;
+        const float2* P = a.polygon_xy + V.first_vertex;
+        bool inside = false;
+        for (int e = 0; e < V.vertex_count; e++) {
+            const int n = (e + 1 == V.vertex_count) ? 0 : e + 1;
+            const float2 pa = P[e], pb = P[n];
+            if ((pa.y > wy) != (pb.y > wy)) {
+                const float xi = ((pb.x - pa.x) * (wy - pa.y)) / (pb.y - pa.y) + pa.x;
+                if (wx < xi) inside = !inside;
+            }
+        }
+        if (!inside || (V.top < a.desc.GroundZ))
+            continue;
+        texel = encode_gbuffer_up(V.top, V.enable_shadows != 0);
+    }
+    const size_t o = (size_t)j * (size_t)a.width + (size_t)i;
+    if (a.format == ILM_GBUFFER_HALF4) {
+        uint2 h;
+        h.x = (uint32_t)__half_as_ushort(__float2half_rn(texel.x)) | ((uint32_t)__half_as_ushort(__float2half_rn(texel.y)) << 16);
+        h.y = (uint32_t)__half_as_ushort(__float2half_rn(texel.z)) | ((uint32_t)__half_as_ushort(__float2half_rn(texel.w)) << 16);
+        reinterpret_cast<uint2*>(a.texels)[o] = h;
+    } else {
+        reinterpret_cast<float4*>(a.texels)[o] = texel;
+    }
+}
+
+hipError_t launch_render_gbuffer(const GBufferLaunch& a, hipStream_t stream) {
+    if (a.width <= 0 || a.height <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((a.width + 63) / 64), (unsigned)((a.height + 3) / 4)), block(256);
+    hipLaunchKernelGGL(render_gbuffer_kernel, grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+
 }  // namespace ilm

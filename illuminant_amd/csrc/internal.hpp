@@ -158,6 +158,20 @@ struct FieldLaunch {
 };
 hipError_t launch_render_slices(const FieldLaunch& a, int format, hipStream_t stream);
 
+// G-buffer generation (fields.hip): volumes sorted by top height on the host, bounds of each polygon for the early reject
+struct GBufferVolume {
+    int32_t first_vertex, vertex_count;
+    float top; int32_t enable_shadows;
+    float x0, x1, y0, y1;
+};
+struct GBufferLaunch {
+    void* texels; int32_t width, height, format;
+    IlmGBufferRenderDesc desc;
+    const GBufferVolume* volumes; int32_t volume_count;
+    const float2* polygon_xy;
+};
+hipError_t launch_render_gbuffer(const GBufferLaunch& a, hipStream_t stream);
+
 // ---- output side (output.hip) ---------------------------------------------------------------------------------
 struct ReadbackLaunch {
     float* const* chunk_bases; int64_t stride; int32_t chunk_count, slots;

@@ -355,7 +355,8 @@ PYBIND11_MODULE(_host, m) {
         .def_property("Polygon", [](const HeightVolume& h) { std::vector<std::vector<float>> r; for (auto& p : h.Polygon) r.push_back(l2(p)); return r; },
                       [](HeightVolume& h, const std::vector<std::vector<float>>& v) { h.Polygon.clear(); for (auto& p : v) h.Polygon.push_back(v2(p)); })
         .def_readwrite("ZBase", &HeightVolume::ZBase).def_readwrite("Height", &HeightVolume::Height)
-        .def_readwrite("IsDynamic", &HeightVolume::IsDynamic).def_readwrite("IsObstruction", &HeightVolume::IsObstruction);
+        .def_readwrite("IsDynamic", &HeightVolume::IsDynamic).def_readwrite("IsObstruction", &HeightVolume::IsObstruction)
+        .def_readwrite("TopFaceEnableShadows", &HeightVolume::TopFaceEnableShadows);
     py::class_<LightingEnvironment>(m, "LightingEnvironment").def(py::init<>())
         .def_readwrite("Lights", &LightingEnvironment::Lights)
         .def_readwrite("ParticleLights", &LightingEnvironment::ParticleLights)
@@ -363,6 +364,7 @@ PYBIND11_MODULE(_host, m) {
         .def_readwrite("HeightVolumes", &LightingEnvironment::HeightVolumes)
         .def_readwrite("GroundZ", &LightingEnvironment::GroundZ).def_readwrite("MaximumZ", &LightingEnvironment::MaximumZ)
         .def_readwrite("ZToYMultiplier", &LightingEnvironment::ZToYMultiplier)
+        .def_readwrite("EnableGroundShadows", &LightingEnvironment::EnableGroundShadows)
         VEC_PROP(LightingEnvironment, Ambient, 4);
     py::class_<RendererQualitySettings>(m, "RendererQualitySettings").def(py::init<>())
         .def_readwrite("MinStepSize", &RendererQualitySettings::MinStepSize).def_readwrite("LongStepFactor", &RendererQualitySettings::LongStepFactor)
@@ -377,6 +379,8 @@ PYBIND11_MODULE(_host, m) {
         .def_readwrite("DefaultQuality", &RendererConfiguration::DefaultQuality)
         .def_readwrite("MaximumFieldUpdatesPerFrame", &RendererConfiguration::MaximumFieldUpdatesPerFrame)
         .def_readwrite("MaximumLightProbeCount", &RendererConfiguration::MaximumLightProbeCount)
+        .def_readwrite("EnableGBuffer", &RendererConfiguration::EnableGBuffer).def_readwrite("RenderGroundPlane", &RendererConfiguration::RenderGroundPlane)
+        .def_readwrite("HighQualityGBuffer", &RendererConfiguration::HighQualityGBuffer)
         .def_readwrite("FloatLightmap", &RendererConfiguration::FloatLightmap);
     py::class_<LightingRenderer>(m, "LightingRenderer")
         .def(py::init([](DeviceContext& ctx, const RendererConfiguration& cfg, LightingEnvironment* env, uintptr_t externalLightmap) {
@@ -393,6 +397,13 @@ PYBIND11_MODULE(_host, m) {
             r.SetGBuffer(a.data(), (int)a.shape(1), (int)a.shape(0), format);
         })
         .def("UpdateFields", &LightingRenderer::UpdateFields)
+        .def("RenderGBuffer", [](LightingRenderer& r, const std::vector<float>& pos, const std::vector<float>& scale) { r.RenderGBuffer(v2(pos), v2(scale)); },
+             py::arg("viewportPosition") = std::vector<float>{0, 0}, py::arg("viewportScale") = std::vector<float>{1, 1})
+        .def("ReadGBuffer", [](const LightingRenderer& r) {
+            py::array_t<float> out({ (py::ssize_t)r.Configuration.RenderHeight, (py::ssize_t)r.Configuration.RenderWidth, (py::ssize_t)4 });
+            if (!r.Configuration.HighQualityGBuffer) throw ArgumentException("ReadGBuffer reads the Vector4 format");
+            ThrowIfFailed(ilm_gbuffer_download(r.GBuffer(), out.mutable_data()));
+            return out; })
         .def("BenchResolve", [](LightingRenderer& r, const std::string& hdrBytes, int format, int iterations) {
             // `iterations` resolves into a target of `format`, timed with the context's HIP events; returns ms per resolve
             if (hdrBytes.size() != sizeof(IlmHDRConfiguration)) throw ArgumentException("hdr must be an IlmHDRConfiguration");

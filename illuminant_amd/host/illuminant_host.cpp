@@ -1243,7 +1243,7 @@ int LightingRenderer::RenderDistanceFieldPartition(int dynamicFlagFilter) {
         IlmHeightVolume v;
         std::memset(&v, 0, sizeof(v));
         v.FirstVertex = (int32_t)(polygon.size() / 2); v.VertexCount = (int32_t)hv.Polygon.size();
-        v.ZBase = hv.ZBase; v.Height = hv.Height; v.IsDynamic = hv.IsDynamic ? 1 : 0;
+        v.ZBase = hv.ZBase; v.Height = hv.Height; v.IsDynamic = hv.IsDynamic ? 1 : 0; v.TopFaceEnableShadows = hv.TopFaceEnableShadows ? 1 : 0;
         for (const Vector2& p : hv.Polygon) { polygon.push_back(p.X); polygon.push_back(p.Y); }
         volumes.push_back(v);
     }
@@ -1258,8 +1258,42 @@ int LightingRenderer::RenderDistanceFieldPartition(int dynamicFlagFilter) {
     return (int)firstSlices.size();
 }
 
-// UpdateFields, LightingRenderer.cs:1949-1975 (distance field half) + RenderDistanceField, LightingRenderer.DistanceField.cs:20-30
+// RenderGBuffer, LightingRenderer.GBuffer.cs:127-219
+void LightingRenderer::RenderGBuffer(Vector2 viewportPosition, Vector2 viewportScale) {
+    if (Configuration.TwoPointFiveD)
+        throw InvalidOperationException("the 2.5D G-buffer (front faces, billboards) is not built");
+    const int format = Configuration.HighQualityGBuffer ? ILM_GBUFFER_FLOAT4 : ILM_GBUFFER_HALF4;
+    if (!gbuffer || gbufferWidth != Configuration.RenderWidth || gbufferHeight != Configuration.RenderHeight) {   // EnsureGBuffer
+        if (gbuffer) { ilm_gbuffer_destroy(gbuffer); gbuffer = 0; }
+        ThrowIfFailed(ilm_gbuffer_create(Context.Handle(), Configuration.RenderWidth, Configuration.RenderHeight, format, &gbuffer));
+        gbufferWidth = Configuration.RenderWidth; gbufferHeight = Configuration.RenderHeight;
+    }
+    IlmGBufferRenderDesc d;
+    std::memset(&d, 0, sizeof(d));
+    d.ViewportPosition[0] = viewportPosition.X; d.ViewportPosition[1] = viewportPosition.Y;
+    d.ViewportScale[0] = viewportScale.X * Configuration.RenderScale.X;     // actualScaleFactor, :131
+    d.ViewportScale[1] = viewportScale.Y * Configuration.RenderScale.Y;
+    d.GroundZ = Environment->GroundZ;
+    d.RenderGroundPlane = Configuration.RenderGroundPlane ? 1 : 0;
+    d.EnableGroundShadows = Environment->EnableGroundShadows ? 1 : 0;
+    std::vector<IlmHeightVolume> volumes;
+    std::vector<float> polygon;
+    for (const HeightVolume& hv : Environment->HeightVolumes) {
+        IlmHeightVolume v;
+        std::memset(&v, 0, sizeof(v));
+        v.FirstVertex = (int32_t)(polygon.size() / 2); v.VertexCount = (int32_t)hv.Polygon.size();
+        v.ZBase = hv.ZBase; v.Height = hv.Height; v.IsDynamic = hv.IsDynamic ? 1 : 0; v.TopFaceEnableShadows = hv.TopFaceEnableShadows ? 1 : 0;
+        for (const Vector2& p : hv.Polygon) { polygon.push_back(p.X); polygon.push_back(p.Y); }
+        volumes.push_back(v);
+    }
+    ThrowIfFailed(ilm_gbuffer_render(gbuffer, &d, volumes.empty() ? nullptr : volumes.data(), (int32_t)volumes.size(),
+                                     polygon.empty() ? nullptr : polygon.data(), (int32_t)(polygon.size() / 2)));
+}
+
+// UpdateFields, LightingRenderer.cs:1949-1975 + RenderDistanceField, LightingRenderer.DistanceField.cs:20-30
 int LightingRenderer::UpdateFields() {
+    if (Configuration.EnableGBuffer)
+        RenderGBuffer();
     if (!Field)
         return 0;
     AutoInvalidateDistanceField();

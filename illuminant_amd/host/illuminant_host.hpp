@@ -639,6 +639,7 @@ struct HeightVolume {
     float ZBase = 0, Height = 0;
     bool IsDynamic = true;      // :23
     bool IsObstruction = true;
+    bool TopFaceEnableShadows = true;   // :18
 };
 
 // LightingEnvironment.cs:13-49
@@ -649,6 +650,7 @@ struct LightingEnvironment {
     std::vector<HeightVolume> HeightVolumes;
     float GroundZ = 0, MaximumZ = 128, ZToYMultiplier = 0;
     Vector4 Ambient{0, 0, 0, 1};
+    bool EnableGroundShadows = true;    // :41
 };
 
 // LightingRenderer.Configuration.cs:254-291
@@ -668,6 +670,9 @@ struct RendererConfiguration {
     RendererQualitySettings DefaultQuality;
     int MaximumFieldUpdatesPerFrame = 1;   // LightingRenderer.Configuration.cs:91
     int MaximumLightProbeCount = 256;      // LightingRenderer.Configuration.cs
+    bool EnableGBuffer = false;            // the mirror starts without one (SetGBuffer uploads, UpdateFields generates)
+    bool RenderGroundPlane = true;
+    bool HighQualityGBuffer = true;        // GBuffer format Vector4 (true) or HalfVector4, GBuffer.cs:30-38
     bool FloatLightmap = false;       // extension: fp32 lightmap (parity format)
     RendererConfiguration(int w, int h) : RenderWidth(w), RenderHeight(h) {}
 };
@@ -695,6 +700,10 @@ public:
     // MaximumFieldUpdatesPerFrame slices of RenderDistanceField (LightingRenderer.DistanceField.cs:20-30,415-464).
     // Returns the number of slice triplets rendered.
     int UpdateFields();
+    // RenderGBuffer, LightingRenderer.GBuffer.cs:127-219 (non-2.5D: ground plane + height-volume top faces); called by UpdateFields
+    // when Configuration.EnableGBuffer is set
+    void RenderGBuffer(Vector2 viewportPosition = {0, 0}, Vector2 viewportScale = {1, 1});
+    IlmHandle GBuffer() const { return gbuffer; }
 
     // RenderLighting, :917-1191: clears to Ambient * intensityScale and adds every sphere light.
     // [rowBegin, rowEnd) restricts the pass to a screen strip (multi-GPU split); rowEnd < 0 => whole frame.

@@ -73,6 +73,8 @@ SYMBOLS = {
     "ilm_gbuffer_create": (_I, [_H, _I, _I, _I, C.POINTER(_H)]),
     "ilm_gbuffer_upload": (_I, [_H, _P]),
     "ilm_gbuffer_destroy": (_I, [_H]),
+    "ilm_gbuffer_download": (_I, [_H, _P]),
+    "ilm_gbuffer_render": (_I, [_H, _P, _P, _I, _P, _I]),
     "ilm_lightmap_create": (_I, [_H, _I, _I, _I, _P, C.POINTER(_H)]),
     "ilm_lightmap_download": (_I, [_H, _P, _I, _I]),
     "ilm_lightmap_device_ptr": (_I, [_H, C.POINTER(_P)]),
@@ -352,16 +354,34 @@ class DistanceFieldTexture:
 
 
 class GBufferTexture:
-    def __init__(self, ctx, texels, fmt=abi.GBUFFER_FLOAT4):
+    def __init__(self, ctx, texels=None, fmt=abi.GBUFFER_FLOAT4, size=None):
+        """texels: (H, W, 4) array to upload, or None with size=(width, height) for an empty G-buffer to render into."""
         dt = np.float32 if fmt == abi.GBUFFER_FLOAT4 else np.uint16
-        a = np.ascontiguousarray(texels, dtype=dt)
-        assert a.ndim == 3 and a.shape[2] == 4
         self.ctx = ctx
-        self.height, self.width = a.shape[0], a.shape[1]
         self.format = fmt
         self.handle = abi.Handle(0)
+        if texels is None:
+            self.width, self.height = int(size[0]), int(size[1])
+            check(lib().ilm_gbuffer_create(ctx.handle, self.width, self.height, fmt, C.byref(self.handle)))
+            return
+        a = np.ascontiguousarray(texels, dtype=dt)
+        assert a.ndim == 3 and a.shape[2] == 4
+        self.height, self.width = a.shape[0], a.shape[1]
         check(lib().ilm_gbuffer_create(ctx.handle, self.width, self.height, fmt, C.byref(self.handle)))
         check(lib().ilm_gbuffer_upload(self.handle, _ptr(a)))
+
+    def render(self, desc, volumes=None, polygon_xy=None):
+        """ilm_gbuffer_render: ground plane + height-volume top faces."""
+        nv = len(volumes) if volumes is not None else 0
+        poly = np.ascontiguousarray(polygon_xy, dtype=np.float32).reshape(-1, 2) if polygon_xy is not None else np.zeros((0, 2), np.float32)
+        check(lib().ilm_gbuffer_render(self.handle, _byref(desc), C.cast(volumes, C.c_void_p) if nv else None, nv,
+                                       _ptr(poly) if poly.shape[0] else None, poly.shape[0]))
+
+    def download(self):
+        dt = np.float32 if self.format == abi.GBUFFER_FLOAT4 else np.uint16
+        out = np.empty((self.height, self.width, 4), dtype=dt)
+        check(lib().ilm_gbuffer_download(self.handle, _ptr(out)))
+        return out
 
     def close(self):
         if self.handle.value:

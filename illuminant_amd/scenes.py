@@ -394,6 +394,17 @@ def render_desc(layout, z_offset=0.0, dynamic_flag_filter=-1):
     return d
 
 
+def gbuffer_render_desc(ground_z=0.0, viewport_position=(0.0, 0.0), viewport_scale=(1.0, 1.0), render_ground_plane=True, enable_ground_shadows=True):
+    """What RenderGBuffer binds (LightingRenderer.GBuffer.cs:127-203)."""
+    d = abi.GBufferRenderDesc()
+    d.ViewportPosition[:] = viewport_position
+    d.ViewportScale[:] = viewport_scale
+    d.GroundZ = ground_z
+    d.RenderGroundPlane = int(render_ground_plane)
+    d.EnableGroundShadows = int(enable_ground_shadows)
+    return d
+
+
 def obstruction_array(obstacles):
     """[(LightObstructionType 0..4, center xyz, size xyz[, rotation about z in radians[, is_dynamic]])] ->
     ctypes array of abi.Obstruction; Orientation = Quaternion.CreateFromAxisAngle(UnitZ, rotation)
@@ -425,6 +436,7 @@ def height_volume_arrays(volumes):
         arr[i].FirstVertex, arr[i].VertexCount = len(verts), len(poly)
         arr[i].ZBase, arr[i].Height = float(hv[1]), float(hv[2])
         arr[i].IsDynamic = int(bool(hv[3])) if len(hv) > 3 else 1     # HeightVolumeBase.IsDynamic defaults to true, HeightVolume.cs:23
+        arr[i].TopFaceEnableShadows = int(bool(hv[4])) if len(hv) > 4 else 1   # :18
         verts.extend((float(x), float(y)) for (x, y) in poly)
     return arr, np.asarray(verts, dtype=np.float32).reshape(-1, 2)
 

@@ -450,7 +450,8 @@ typedef struct IlmHeightVolume {
     int32_t FirstVertex, VertexCount;
     float   ZBase, Height;
     int32_t IsDynamic;
-    int32_t _pad[3];
+    int32_t TopFaceEnableShadows;   /* HeightVolumeBase.TopFaceEnableShadows (:18), read by the G-buffer pass only */
+    int32_t _pad[2];
 } IlmHeightVolume;
 
 #define ILM_DISTANCE_LIMIT 520.0f   /* LightingRenderer.DistanceLimit, Illuminant/Lighting/LightingRenderer.cs:316 */
@@ -487,6 +488,29 @@ int32_t ilm_sdf_render_slices(IlmHandle sdf, IlmHandle clear_source, const IlmDi
 int32_t ilm_gbuffer_create(IlmHandle ctx, int32_t width, int32_t height, int32_t format, IlmHandle* out_gbuffer);
 int32_t ilm_gbuffer_upload(IlmHandle gbuffer, const void* texels);
 int32_t ilm_gbuffer_destroy(IlmHandle gbuffer);
+int32_t ilm_gbuffer_download(IlmHandle gbuffer, void* texels);
+
+/* What RenderGBuffer binds in its non-2.5D form (Illuminant/Lighting/LightingRenderer.GBuffer.cs:127-203): the view transform
+ * (Position = the pending field viewport position, Scale = viewportScale * RenderScale, :131-135) and the ground plane's inputs
+ * (RenderGroundPlane, :271-299). */
+typedef struct IlmGBufferRenderDesc {
+    float   ViewportPosition[2];
+    float   ViewportScale[2];
+    float   GroundZ;
+    int32_t RenderGroundPlane;        /* Configuration.RenderGroundPlane: false lifts the plane by 99999 (:280-286) */
+    int32_t EnableGroundShadows;      /* Environment.EnableGroundShadows */
+    int32_t _pad;
+} IlmGBufferRenderDesc;
+
+/* RenderGBuffer without TwoPointFiveD, billboards or user content: clear to transparent, the ground plane
+ * (technique GroundPlane, Illuminant/Shaders/GBuffer.fx:7-19,57-70) and the top face of every height volume drawn with the same
+ * material from the lowest to the highest (RenderGBufferVolumes, :205-219), encoded by encodeGBufferSample
+ * (Illuminant/Shaders/GBufferShaderCommon.fxh:10-35).  The top-face meshes come from Fracture's Geometry.Triangulate
+ * (SDF/HeightVolume.cs:126-133), which is outside the tree; a triangulation covers exactly the polygon's interior, so coverage
+ * is decided per pixel centre with an even-odd point-in-polygon test instead.  Host arrays; asynchronous. */
+int32_t ilm_gbuffer_render(IlmHandle gbuffer, const IlmGBufferRenderDesc* desc,
+                           const IlmHeightVolume* volumes, int32_t volume_count,
+                           const float* polygon_xy, int32_t polygon_vertex_count);
 
 /* Lightmap render target (BufferRing of lightmaps, LightingRenderer.cs:472-485).
  * If external_device_ptr != NULL the lightmap aliases caller-owned device memory

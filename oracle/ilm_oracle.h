@@ -152,6 +152,9 @@ void orc_render_distance_field_slices(uint16_t* atlas, int32_t format, const uin
                                       const IlmHeightVolume* volumes, int32_t volume_count,
                                       const float* polygon_xy, int32_t polygon_vertex_count);
 
+void orc_render_gbuffer(IlmFloat4* out, int32_t width, int32_t height, const IlmGBufferRenderDesc* desc,
+                        const IlmHeightVolume* volumes, int32_t volume_count, const float* polygon_xy);
+
 int32_t orc_num_threads(void);
 void    orc_set_num_threads(int32_t n);
 

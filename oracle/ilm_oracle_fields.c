@@ -200,3 +200,66 @@ void orc_render_distance_field_slices(uint16_t* atlas, int32_t format, const uin
         }
     }
 }
+
+
+/* ---------------------------------------------------------------------------
+ * G-buffer generation, non-2.5D (LightingRenderer.GBuffer.cs:127-219, GBuffer.fx:7-70, GBufferShaderCommon.fxh:10-35)
+ * ------------------------------------------------------------------------- */
+/* encodeNormalSpherical, EnvironmentCommon.fxh:33-40 */
+static void encode_normal_spherical(f3 n, float out[2]) {
+    if (fabsf(n.x) < 0.0001f)
+        n.x = 0.0001f;
+    out[0] = ((atan2f(n.y, n.x) / H_PI) + 1.0f) * 0.5f;
+    out[1] = (n.z + 1.0f) * 0.5f;
+}
+
+/* encodeGBufferSample, GBufferShaderCommon.fxh:10-35 (dead = false, fullbright = false on this path) */
+static f4 encode_gbuffer_sample(f3 normal, float relative_y, float z, int enable_shadows) {
+    float enc[2] = { 0.0f, 0.0f };
+    if ((normal.x != 0.0f) || (normal.y != 0.0f) || (normal.z != 0.0f))
+        encode_normal_spherical(normal, enc);
+    float w = (((z + 1024.0f) / 1024.0f) * (enable_shadows ? 1.0f : -1.0f)) + (enable_shadows ? 0.0f : -1.0f);
+    return v4(enc[0], enc[1], relative_y, w);
+}
+
+/* even-odd crossing test of a pixel centre against a polygon (coverage of any triangulation of its interior) */
+static int point_in_polygon(float px, float py, const float* P, int count) {
+    int inside = 0;
+    for (int e = 0; e < count; e++) {
+        const int n = (e + 1 == count) ? 0 : e + 1;
+        const float ax = P[2 * e], ay = P[2 * e + 1], bx = P[2 * n], by = P[2 * n + 1];
+        if ((ay > py) != (by > py)) {
+            const float xi = ((bx - ax) * (py - ay)) / (by - ay) + ax;
+            if (px < xi) inside = !inside;
+        }
+    }
+    return inside;
+}
+
+/* out: width * height float4 texels.  volumes must already be ordered lowest to highest top (OrderBy(ZBase + Height), :210). */
+void orc_render_gbuffer(IlmFloat4* out, int32_t width, int32_t height, const IlmGBufferRenderDesc* d,
+                        const IlmHeightVolume* volumes, int32_t volume_count, const float* polygon_xy) {
+    const float ground_z = d->GroundZ + (d->RenderGroundPlane ? 0.0f : 99999.0f);     /* RenderGroundPlane, :271-286 */
+    #pragma omp parallel for schedule(static)
+    for (int j = 0; j < height; j++)
+        for (int i = 0; i < width; i++) {
+            /* inverse of (position.xy - ViewportPosition) * ViewportScale (GroundPlaneVertexShader, GBuffer.fx:15) at the pixel centre */
+            const float wx = ((float)i + 0.5f) / d->ViewportScale[0] + d->ViewportPosition[0];
+            const float wy = ((float)j + 0.5f) / d->ViewportScale[1] + d->ViewportPosition[1];
+            f4 texel = v4(0, 0, 0, 0);                                  /* ClearBatch(Color.Transparent), :147-150 */
+            if (!(ground_z < d->GroundZ))                               /* GroundPlanePixelShader, GBuffer.fx:63-66 */
+                texel = encode_gbuffer_sample(v3(0, 0, 1), 0.0f, ground_z, d->EnableGroundShadows);
+            for (int v = 0; v < volume_count; v++) {
+                const IlmHeightVolume* hv = &volumes[v];
+                if (hv->VertexCount < 3)
+                    continue;
+                if (!point_in_polygon(wx, wy, polygon_xy + 2 * (size_t)hv->FirstVertex, hv->VertexCount))
+                    continue;
+                const float top = hv->ZBase + hv->Height;               /* Mesh3D: Position.Z = h2, HeightVolume.cs:115-122 */
+                if (top < d->GroundZ)
+                    continue;                                           /* discard */
+                texel = encode_gbuffer_sample(v3(0, 0, 1), 0.0f, top, hv->TopFaceEnableShadows);
+            }
+            out[(size_t)j * (size_t)width + (size_t)i] = texel;
+        }
+}

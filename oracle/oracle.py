@@ -312,6 +312,19 @@ def resolve_lighting(lightmap, hdr, row_begin=0, row_end=None):
     return out
 
 
+def render_gbuffer(width, height, desc, volumes=None, polygon_xy=None):
+    """orc_render_gbuffer: (H, W, 4) float32; volumes are sorted by top height here as RenderGBufferVolumes does."""
+    out = np.zeros((height, width, 4), np.float32)
+    nv = len(volumes) if volumes is not None else 0
+    order = sorted(range(nv), key=lambda i: np.float32(volumes[i].ZBase) + np.float32(volumes[i].Height))
+    sorted_vols = (abi.HeightVolume * max(nv, 1))()
+    for k, i in enumerate(order):
+        C.memmove(C.byref(sorted_vols[k]), C.byref(volumes[i]), C.sizeof(abi.HeightVolume))
+    poly = np.ascontiguousarray(polygon_xy, dtype=np.float32).reshape(-1, 2) if polygon_xy is not None else np.zeros((1, 2), np.float32)
+    lib().orc_render_gbuffer(_f4(out), C.c_int32(width), C.c_int32(height), C.byref(desc), sorted_vols, C.c_int32(nv), _p(poly))
+    return out
+
+
 # ---- host logic -------------------------------------------------------------------------------------
 
 def distance_field_layout(vw, vh, vdepth, requested_slices, resolution=1.0, max_encoded=128):

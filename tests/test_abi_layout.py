@@ -25,6 +25,7 @@ STRUCTS = {
     "IlmMatrixMultiplyParams": abi.MatrixMultiplyParams, "IlmSpatialNoiseParams": abi.SpatialNoiseParams, "IlmFeedbackParams": abi.FeedbackParams,
     "IlmParticleLightParams": abi.ParticleLightParams,
     "IlmReadbackDrawCall": abi.ReadbackDrawCall, "IlmReadbackParams": abi.ReadbackParams, "IlmHDRConfiguration": abi.HDRConfiguration,
+    "IlmGBufferRenderDesc": abi.GBufferRenderDesc,
     "IlmObstruction": abi.Obstruction, "IlmHeightVolume": abi.HeightVolume, "IlmDistanceFieldRenderDesc": abi.DistanceFieldRenderDesc,
 }
 

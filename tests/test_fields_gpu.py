@@ -124,3 +124,57 @@ def test_full_size_field_of_the_lighting_configs(ctx, oracle):
     # independent numpy rasteriser (the atlas the lighting bench uploaded before this pass existed)
     ref = scenes.build_sdf_atlas(layout, old)
     assert np.abs(got.astype(np.int64) - ref.astype(np.int64)).max() <= 1
+
+
+@pytest.mark.parametrize("fmt", [abi.GBUFFER_FLOAT4, abi.GBUFFER_HALF4])
+def test_gbuffer_generation_matches_oracle_and_feeds_the_light_pass(ctx, oracle, fmt):
+    w, h = 160, 112
+    volumes = [
+        ([(10, 10), (70, 14), (64, 60), (30, 40), (12, 70)], 0.0, 24.0, True, True),       # concave
+        ([(50, 30), (150, 30), (150, 100), (50, 100)], 6.0, 30.0, True, False),
+        ([(100, 5), (140, 12), (120, 40)], 0.0, 12.0, True, True),
+    ]
+    vols, poly = scenes.height_volume_arrays(volumes)
+    d = scenes.gbuffer_render_desc(ground_z=0.0, viewport_position=(4.0, -3.0), viewport_scale=(1.25, 1.25))
+    gb = native.GBufferTexture(ctx, None, fmt, size=(w, h))
+    gb.render(d, vols, poly)
+    got = gb.download()
+    want = oracle.render_gbuffer(w, h, d, vols, poly)
+    if fmt == abi.GBUFFER_HALF4:
+        assert np.array_equal(got, want.astype(np.float16).view(np.uint16))
+    else:
+        assert np.array_equal(got, want)
+    assert len(np.unique(want[..., 3])) == 4                 # ground + three tops are all visible
+    # the generated G-buffer drives the light pass like an uploaded one
+    layout = scenes.DistanceFieldLayout(256, 192, 96.0, 12, 0.5, 128)
+    atlas = scenes.build_sdf_atlas(layout, scenes.random_obstacles(5, 14, (256, 192), size_lo=8.0, size_hi=30.0, z_hi=40.0))
+    dfu = layout.uniforms(max_cone_radius=24.0, power=0.7, step_limit=64, min_step_size=1.0, long_step_factor=0.5)
+    lights = scenes.random_lights(6, 6, w, h, z=(30.0, 60.0), radius=10.0, ramp=(40.0, 120.0))
+    env = scenes.environment(gbuffer_size=(w, h))
+    sdf = native.DistanceFieldTexture(ctx, atlas)
+    lm = native.Lightmap(ctx, w, h, abi.LIGHTMAP_FLOAT4)
+    native.render_sphere_lights(ctx, lights, env, dfu, gb, sdf, (0.05, 0.05, 0.05, 1.0), lm)
+    lit = lm.download()
+    ogb = want if fmt == abi.GBUFFER_FLOAT4 else want.astype(np.float16).view(np.uint16)
+    ref, _ = oracle.render_sphere_lights(lights, env, dfu, oracle.make_texture(np.ascontiguousarray(ogb), fmt),
+                                         oracle.make_texture(atlas, abi.SDF_UNORM16), (0.05, 0.05, 0.05, 1.0), w, h)
+    from tests.util import assert_close
+    assert_close(lit, ref, "lightmap from the generated G-buffer")
+    for x in (lm, sdf, gb):
+        x.close()
+
+
+def test_generated_ground_plane_equals_the_no_gbuffer_path(ctx):
+    """A G-buffer holding only the ground plane at z = 0 decodes to exactly what sampleGBuffer assumes without one (LightCommon.fxh:130-141)."""
+    w, h = 96, 64
+    gb = native.GBufferTexture(ctx, None, abi.GBUFFER_FLOAT4, size=(w, h))
+    gb.render(scenes.gbuffer_render_desc(ground_z=0.0))
+    lights = scenes.random_lights(3, 5, w, h, z=(8.0, 40.0), radius=6.0, ramp=(30.0, 80.0))
+    dfu = scenes.DistanceFieldLayout(128, 128, 64.0, 6, 0.5).uniforms()
+    a = native.Lightmap(ctx, w, h, abi.LIGHTMAP_FLOAT4)
+    b = native.Lightmap(ctx, w, h, abi.LIGHTMAP_FLOAT4)
+    native.render_sphere_lights(ctx, lights, scenes.environment(gbuffer_size=(w, h)), dfu, gb, None, (0.1, 0.1, 0.1, 1.0), a)
+    native.render_sphere_lights(ctx, lights, scenes.environment(), dfu, None, None, (0.1, 0.1, 0.1, 1.0), b)
+    assert np.allclose(a.download(), b.download(), rtol=1e-6, atol=1e-7)
+    for x in (a, b, gb):
+        x.close()

@@ -113,3 +113,28 @@ def test_generated_field_samples_back_the_analytic_distance(oracle, fmt):
         got = oracle.sample_distance_field(p, dfu, tex)
         if want < 90.0:     # beyond ~96 the encoding saturates
             assert abs(got - want) < (1.2 if fmt == abi.SDF_UNORM16 else 1.6), (p, got, want)
+
+
+def test_gbuffer_ground_plane_and_volume_tops(oracle):
+    """RenderGBuffer, non-2.5D: the ground-plane texel is the fixture's (0.5, 1, 0, 1) (GBufferShaderCommon.fxh:21-33: normal +z,
+    relativeY 0, w = (z + 1024) / 1024); volume tops overwrite it lowest to highest; shadows disabled => w = -(z + 1024) / 1024 - 1."""
+    w, h = 64, 48
+    g = oracle.render_gbuffer(w, h, scenes.gbuffer_render_desc(ground_z=0.0))
+    assert np.allclose(g, np.broadcast_to(np.float32([0.5, 1.0, 0.0, 1.0]), g.shape), rtol=0, atol=1e-7)
+    vols, poly = scenes.height_volume_arrays([
+        ([(10, 10), (40, 10), (40, 30), (10, 30)], 0.0, 20.0, True, True),
+        ([(30, 20), (60, 20), (60, 44), (30, 44)], 5.0, 40.0, True, False),      # higher, shadows off: drawn last
+        ([(2, 36), (12, 36), (7, 46)], 0.0, 8.0, True, True)])
+    g = oracle.render_gbuffer(w, h, scenes.gbuffer_render_desc(ground_z=0.0), vols, poly)
+    assert np.allclose(g[15, 20], [0.5, 1.0, 0.0, (20.0 + 1024.0) / 1024.0])                     # inside the first box only
+    assert np.allclose(g[25, 35], [0.5, 1.0, 0.0, -((45.0 + 1024.0) / 1024.0) - 1.0])            # overlap: the higher volume wins
+    assert np.allclose(g[40, 7], [0.5, 1.0, 0.0, (8.0 + 1024.0) / 1024.0])                       # inside the triangle
+    assert np.allclose(g[2, 2], [0.5, 1.0, 0.0, 1.0])                                            # bare ground
+    # pixel (i, j) is covered iff its centre (i + .5, j + .5) is inside: column 9 is out, column 10 is in
+    assert np.allclose(g[15, 9], [0.5, 1.0, 0.0, 1.0]) and not np.allclose(g[15, 10], g[15, 9])
+    # the view transform: position 100,50 at scale 0.5 moves the first box to pixels ((10-100)*.5 ...): off screen; RenderGroundPlane off lifts the plane
+    g2 = oracle.render_gbuffer(w, h, scenes.gbuffer_render_desc(0.0, (100.0, 50.0), (0.5, 0.5), render_ground_plane=False), vols, poly)
+    assert np.allclose(g2, np.broadcast_to(np.float32([0.5, 1.0, 0.0, (99999.0 + 1024.0) / 1024.0]), g2.shape))
+    # ground shadows off
+    g3 = oracle.render_gbuffer(w, h, scenes.gbuffer_render_desc(3.0, enable_ground_shadows=False))
+    assert np.allclose(g3[0, 0], [0.5, 1.0, 0.0, -((3.0 + 1024.0) / 1024.0) - 1.0])

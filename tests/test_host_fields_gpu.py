@@ -153,3 +153,37 @@ def test_lit_frame_from_generated_field_matches_oracle(H, hctx, oracle):
     from tests.util import assert_close
     assert_close(got, want, "lightmap")
     assert (want[..., 3] > 1.5).any()
+
+
+def test_update_fields_generates_the_gbuffer_too(H, hctx, oracle):
+    """Configuration.EnableGBuffer: UpdateFields renders the G-buffer (ground plane + height-volume tops) before the distance field,
+    and RenderLighting then shades through it."""
+    layout, obs, volumes = fc.mixed_scene()
+    env, r0, f, _ = build(H, hctx, H.DistanceField, obs, volumes, updates_per_frame=999)
+    rc = H.RendererConfiguration(96, 64)
+    rc.FloatLightmap = True
+    rc.EnableGBuffer = True
+    rc.MaximumFieldUpdatesPerFrame = 999
+    r = H.LightingRenderer(hctx, rc, env)
+    r.DistanceField = f
+    r.UpdateFields()
+    vols, poly = scenes.height_volume_arrays([(p, zb, h, dyn, True) for (p, zb, h, dyn) in volumes])
+    want_g = oracle.render_gbuffer(96, 64, scenes.gbuffer_render_desc(ground_z=0.0), vols, poly)
+    assert np.array_equal(r.ReadGBuffer(), want_g)
+    assert len(np.unique(want_g[..., 3])) >= 2
+    l = H.SphereLightSource()
+    l.Position = [40.0, 30.0, 60.0]; l.Radius = 8.0; l.RampLength = 90.0; l.Color = [1.0, 0.9, 0.8, 1.0]
+    env.Lights = [l]
+    env.Ambient = [0.02, 0.02, 0.02, 1.0]
+    r.RenderLighting()
+    got = r.ReadLightmap()
+    verts = (abi.LightVertex * 1)()
+    verts[0] = abi.LightVertex.from_buffer_copy(H.LightingRenderer.PackSphereLightBytes(l, 1.0, True))
+    dfu = abi.DistanceFieldUniforms.from_buffer_copy(r.GetDistanceFieldUniformsBytes())
+    envu = abi.Environment.from_buffer_copy(r.GetEnvironmentUniformsBytes())
+    assert envu.GBufferTexelSizeAndMisc.x == np.float32(1.0 / 96)
+    atlas = oracle_atlas(oracle, layout, obs, volumes)
+    want, _ = oracle.render_sphere_lights(verts, envu, dfu, oracle.make_texture(want_g, abi.GBUFFER_FLOAT4),
+                                          oracle.make_texture(atlas, abi.SDF_UNORM16), (0.02, 0.02, 0.02, 1.0), 96, 64)
+    from tests.util import assert_close
+    assert_close(got, want, "lightmap through the generated G-buffer")
