@@ -304,6 +304,7 @@ PYBIND11_MODULE(_host, m) {
 
     // ---- lighting ------------------------------------------------------------------------------------------------
     py::class_<SphereLightSource>(m, "SphereLightSource").def(py::init<>())
+        .def_readwrite("SortKey", &SphereLightSource::SortKey)
         VEC_PROP(SphereLightSource, Position, 3)
         .def_readwrite("Radius", &SphereLightSource::Radius).def_readwrite("RampLength", &SphereLightSource::RampLength)
         VEC_PROP(SphereLightSource, Color, 4)

@@ -1077,9 +1077,14 @@ IlmEnvironment LightingRenderer::GetEnvironmentUniforms() const {
 void LightingRenderer::RenderLighting(float intensityScale, int rowBegin, int rowEnd, IlmRenderStats* stats) {
     if (rowEnd < 0) rowEnd = Configuration.RenderHeight;
     vertices.clear();
-    for (const SphereLightSource& l : Environment->Lights) {
+    // LightSorter (:2066-2096): SortKey first; blend mode, ramp texture and type are the same for every light of this pass.  The
+    // reference's sort is not stable for equal keys; a stable one keeps list order, which is one of its possible outcomes.
+    std::vector<const SphereLightSource*> sorted;
+    for (const SphereLightSource& l : Environment->Lights) sorted.push_back(&l);
+    std::stable_sort(sorted.begin(), sorted.end(), [](const SphereLightSource* x, const SphereLightSource* y) { return x->SortKey < y->SortKey; });
+    for (const SphereLightSource* l : sorted) {
         IlmLightVertex v;
-        if (PackSphereLight(l, intensityScale, Field != nullptr, v))
+        if (PackSphereLight(*l, intensityScale, Field != nullptr, v))
             vertices.push_back(v);
     }
     const IlmEnvironment env = GetEnvironmentUniforms();
@@ -1122,6 +1127,16 @@ IlmParticleLightParams LightingRenderer::PackParticleLight(const ParticleLightSo
     return p;
 }
 
+// float -> IEEE half (round to nearest even) -> float, for finite values inside the half range
+static float HalfRound(float f) {
+    if (!(std::fabs(f) < 65504.0f)) return f;
+    if (std::fabs(f) < 6.103515625e-05f)            // below 2^-14: subnormal halves, spacing 2^-24
+        return std::nearbyint(f * 16777216.0f) / 16777216.0f;
+    int e;
+    const float m = std::frexp(f, &e);              // f = m * 2^e, 0.5 <= |m| < 1: 11 significant bits
+    return std::ldexp(std::nearbyint(m * 2048.0f) / 2048.0f, e);
+}
+
 // UpdateLightProbeTexture + UpdateLightProbes + LightProbeDownloadTask, LightingRenderer.LightProbes.cs:49-150.  The reference reads
 // the values back a frame later on a worker thread; here the call synchronises and the probes hold this frame's values.
 void LightingRenderer::UpdateLightProbes(float intensityScale) {
@@ -1143,8 +1158,10 @@ void LightingRenderer::UpdateLightProbes(float intensityScale) {
     for (int i = 0; i < n; i++) {
         LightProbe& p = *Probes.Items[(size_t)i];
         p.PreviousValue = p.Value;
-        // the probe target is a HalfVector4: round through fp16 like the read-back does
-        p.Value = { values[(size_t)i].x * scaleFactor, values[(size_t)i].y * scaleFactor, values[(size_t)i].z * scaleFactor, values[(size_t)i].w * scaleFactor };
+        // the probe target is a HalfVector4 (LightProbes.cs:20,124-131): the read-back sees fp16 values (rounded once here; the reference's
+        // ROP rounds after every light)
+        p.Value = { HalfRound(values[(size_t)i].x) * scaleFactor, HalfRound(values[(size_t)i].y) * scaleFactor,
+                    HalfRound(values[(size_t)i].z) * scaleFactor, HalfRound(values[(size_t)i].w) * scaleFactor };
     }
 }
 

@@ -546,6 +546,7 @@ enum class LightShadowFilter { None = -1, ShadowsOnly = 1, NoShadowsOnly = 0 }; 
 
 // LightSource.cs:37-280 (SphereLightSource)
 struct SphereLightSource {
+    int SortKey = 0;          // LightSourceBase.SortKey: RenderLighting sorts by it first (LightSorter, LightingRenderer.cs:2066-2096)
     Vector3 Position;
     float Radius = 0, RampLength = 1;
     Vector4 Color{1, 1, 1, 1};
