@@ -7,7 +7,7 @@ offsets against the C header by compiling a probe.
 """
 import ctypes as C
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 OK = 0
 ERR_INVALID_ARGUMENT = -1
@@ -25,7 +25,7 @@ RANDOMNESS_WIDTH = 807
 RANDOMNESS_HEIGHT = 653
 
 OP_GRAVITY, OP_NOISE, OP_FMA, OP_MATRIX_MULTIPLY, OP_SPATIAL_NOISE = 1, 2, 3, 4, 5
-SPAWN_INLINE, SPAWN_POSITION_BUFFER, SPAWN_FEEDBACK = 0, 1, 2
+SPAWN_INLINE, SPAWN_POSITION_BUFFER, SPAWN_FEEDBACK, SPAWN_PATTERN = 0, 1, 2, 3
 UPDATE_NONE, UPDATE_POSITIONS, UPDATE_WITH_DISTANCE_FIELD, UPDATE_ERASE = 0, 1, 2, 3
 STEP_COUNT_LIVE = 1
 
@@ -181,6 +181,11 @@ class FeedbackParams(C.Structure):
                 ("SourceLifeRange", f32 * 2), ("_pad", f32)]
 
 
+class PatternParams(C.Structure):
+    _fields_ = [("StepWidthAndSizeScale", f32 * 4), ("YOffsetsAndCoordScale", f32 * 4), ("TexelOffsetAndMipBias", f32 * 4),
+                ("CenteringOffset", f32 * 2), ("MultiplyAttributeConstant", f32), ("_pad", f32)]
+
+
 class _OpUnion(C.Union):
     _fields_ = [("Gravity", GravityParams), ("Noise", NoiseParams), ("FMA", FMAParams),
                 ("MatrixMultiply", MatrixMultiplyParams), ("SpatialNoise", SpatialNoiseParams)]
@@ -191,7 +196,8 @@ class TransformOp(C.Structure):
 
 
 class SpawnRecord(C.Structure):
-    _fields_ = [("ChunkIndex", i32), ("Kind", i32), ("_pad", i32 * 2), ("Params", SpawnParams), ("Feedback", FeedbackParams)]
+    _fields_ = [("ChunkIndex", i32), ("Kind", i32), ("_pad", i32 * 2), ("Params", SpawnParams), ("Feedback", FeedbackParams),
+                ("Pattern", PatternParams)]
 
 
 class StepDesc(C.Structure):
@@ -265,9 +271,9 @@ EXPECTED_SIZES = {
     "IlmGravityParams": (GravityParams, 400), "IlmFMAParams": (FMAParams, 144),
     "IlmNoiseParams": (NoiseParams, 192), "IlmSpawnParams": (SpawnParams, 416),
     "IlmUpdateParams": (UpdateParams, 256), "IlmTransformOp": (TransformOp, 416),
-    "IlmSpawnRecord": (SpawnRecord, 480), "IlmStepDesc": (StepDesc, 3072),
+    "IlmSpawnRecord": (SpawnRecord, 544), "IlmStepDesc": (StepDesc, 3200),
     "IlmMatrixMultiplyParams": (MatrixMultiplyParams, 208), "IlmSpatialNoiseParams": (SpatialNoiseParams, 208),
-    "IlmFeedbackParams": (FeedbackParams, 48),
+    "IlmFeedbackParams": (FeedbackParams, 48), "IlmPatternParams": (PatternParams, 64),
     "IlmRenderStats": (RenderStats, 24),
     "IlmParticleLightParams": (ParticleLightParams, 80),
     "IlmReadbackDrawCall": (ReadbackDrawCall, 48), "IlmReadbackParams": (ReadbackParams, 56), "IlmHDRConfiguration": (HDRConfiguration, 48),

@@ -114,6 +114,8 @@ struct System {
     uint32_t* d_slots = nullptr; int slots_cap = 0; uint32_t* d_slot_count = nullptr;
     // the Spawner's PositionBuffer per spawn record slot (ParticleSpawner.cs:301-353)
     float4* spawn_positions[ILM_MAX_SPAWNS] = {}; int spawn_position_count[ILM_MAX_SPAWNS] = {}; int spawn_position_cap[ILM_MAX_SPAWNS] = {};
+    // the PatternSpawner's texture per spawn record slot, mip levels back to back (SpecialSpawners.cs:19-22)
+    float4* spawn_pattern[ILM_MAX_SPAWNS] = {}; int pattern_w[ILM_MAX_SPAWNS] = {}, pattern_h[ILM_MAX_SPAWNS] = {}, pattern_levels[ILM_MAX_SPAWNS] = {};
     // asynchronous readback of the fused live counts
     uint32_t* h_counts = nullptr; int h_counts_cap = 0; hipEvent_t counts_ev = nullptr; int counts_n = 0; bool counts_pending = false;
     bool counts_valid = false;   // h_counts holds (or is about to receive) the counts of the last counting step
@@ -247,6 +249,11 @@ int32_t validate_step(const System* s, const IlmStepDesc* d, int* first, int* co
                 return fail(ILM_ERR_OUT_OF_RANGE, "spawn record %d: source chunk %d outside [0, %d)", k, r.Feedback.SourceChunkIndex, (int)src->chunks.size());
             if (!(r.Feedback.InstanceMultiplier >= 1.0f))
                 return fail(ILM_ERR_INVALID_ARGUMENT, "spawn record %d: InstanceMultiplier %g < 1", k, (double)r.Feedback.InstanceMultiplier);
+        } else if (r.Kind == ILM_SPAWN_PATTERN) {
+            if (s->pattern_levels[k] < 1)
+                return fail(ILM_ERR_STATE, "spawn record %d: no pattern texture bound (ilm_system_set_spawn_pattern)", k);
+            if (!(r.Pattern.StepWidthAndSizeScale[1] >= 1.0f))
+                return fail(ILM_ERR_INVALID_ARGUMENT, "spawn record %d: ParticlesPerRow %g < 1", k, (double)r.Pattern.StepWidthAndSizeScale[1]);
         } else if (r.Kind != ILM_SPAWN_INLINE) {
             return fail(ILM_ERR_INVALID_ARGUMENT, "spawn record %d: unknown kind %d", k, r.Kind);
         }
@@ -302,6 +309,8 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
         a.spawn_positions[k] = s->spawn_positions[k];
         a.spawn_position_count[k] = s->spawn_position_count[k];
         a.source_base[k] = nullptr;
+        a.spawn_pattern[k] = s->spawn_pattern[k];
+        a.pattern_w[k] = s->pattern_w[k]; a.pattern_h[k] = s->pattern_h[k]; a.pattern_levels[k] = s->pattern_levels[k];
         if (k < d->SpawnCount && d->Spawns[k].Kind == ILM_SPAWN_FEEDBACK)
             a.source_base[k] = from_handle<System>(d->Spawns[k].Feedback.SourceSystem, kMagicSystem)->chunks[(size_t)d->Spawns[k].Feedback.SourceChunkIndex];
     }
@@ -581,6 +590,8 @@ int32_t ilm_system_destroy(IlmHandle h) {
     if (s->d_slot_count) (void)hipFree(s->d_slot_count);
     for (int k = 0; k < ILM_MAX_SPAWNS; k++)
         if (s->spawn_positions[k]) (void)hipFree(s->spawn_positions[k]);
+    for (int k = 0; k < ILM_MAX_SPAWNS; k++)
+        if (s->spawn_pattern[k]) (void)hipFree(s->spawn_pattern[k]);
     if (s->h_counts) (void)hipHostFree(s->h_counts);
     if (s->counts_ev) (void)hipEventDestroy(s->counts_ev);
     s->magic = 0;
@@ -731,6 +742,31 @@ int32_t ilm_system_set_spawn_positions(IlmHandle h, int32_t slot, const IlmFloat
         if (rc != ILM_OK) return rc;
     }
     s->spawn_position_count[slot] = count;
+    return ILM_OK;
+}
+
+int32_t ilm_system_set_spawn_pattern(IlmHandle h, int32_t slot, const IlmFloat4* texels, int32_t width, int32_t height, int32_t levels) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (slot < 0 || slot >= ILM_MAX_SPAWNS) return fail(ILM_ERR_OUT_OF_RANGE, "spawn slot %d outside [0, %d)", slot, ILM_MAX_SPAWNS);
+    if (levels < 0 || levels > 16) return fail(ILM_ERR_OUT_OF_RANGE, "%d mip levels outside [0, 16]", levels);
+    if (levels > 0 && (!texels || width < 1 || height < 1 || width > 16384 || height > 16384))
+        return fail(ILM_ERR_INVALID_ARGUMENT, "bad pattern texture (%d x %d)", width, height);
+    Ctx* c = s->engine->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));     // an earlier step may still read the old texture
+    if (s->spawn_pattern[slot]) HIP_TRY(hipFree(s->spawn_pattern[slot]));
+    s->spawn_pattern[slot] = nullptr;
+    s->pattern_w[slot] = s->pattern_h[slot] = s->pattern_levels[slot] = 0;
+    if (levels == 0) return ILM_OK;
+    size_t total = 0;
+    for (int l = 0, lw = width, lh = height; l < levels; l++) {
+        total += (size_t)lw * (size_t)lh;
+        lw = std::max(1, lw >> 1); lh = std::max(1, lh >> 1);
+    }
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->spawn_pattern[slot]), sizeof(float4) * total));
+    HIP_TRY(hipMemcpy(s->spawn_pattern[slot], texels, sizeof(float4) * total, hipMemcpyHostToDevice));
+    s->pattern_w[slot] = width; s->pattern_h[slot] = height; s->pattern_levels[slot] = levels;
     return ILM_OK;
 }
 

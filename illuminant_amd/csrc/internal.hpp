@@ -60,6 +60,8 @@ struct StepLaunch {
     // extended spawn kinds (per spawn record slot): the Spawner's PositionBuffer and the feedback source chunk
     const float4* spawn_positions[ILM_MAX_SPAWNS]; int32_t spawn_position_count[ILM_MAX_SPAWNS];
     const float* source_base[ILM_MAX_SPAWNS];
+    // PatternSpawner texture: mip levels back to back (ilm_system_set_spawn_pattern)
+    const float4* spawn_pattern[ILM_MAX_SPAWNS]; int32_t pattern_w[ILM_MAX_SPAWNS], pattern_h[ILM_MAX_SPAWNS], pattern_levels[ILM_MAX_SPAWNS];
     SdfView sdf;
     // chunks whose tail has never been written (api.hip, System::used): units >= partial_units[i] of chunk partial_chunk[i]
     // hold only zeros and are skipped; chunks not listed are processed whole
@@ -73,6 +75,8 @@ struct StepLaunch {
     int32_t unit_begin, unit_end;        // global unit range [begin, end) of this launch
     int32_t unit_rotate, total_padded;   // block b starts at unit (b * 4 + unit_rotate) mod total_padded
 };
+
+static_assert(sizeof(StepLaunch) <= 4096, "StepLaunch travels in the kernarg segment (4 KB)");
 
 // per-chunk live counters are kCountStride uint32 apart (one 128-byte line each)
 constexpr int kCountStride = 32;

@@ -460,6 +460,77 @@ ILM_DEV bool spawn_slot_feedback(float4& pos, float4& vel, float4& attr, float x
     return true;
 }
 
+// tex2Dlod(PatternSampler, float4(uv, 0, lod)): CLAMP, LINEAR min / mag, POINT mip (PatternSpawner.fx:11-19).  `tex` holds the mip
+// levels back to back (include/illuminant_hip.h, ilm_system_set_spawn_pattern); texel centres sit at integer + 0.5.
+ILM_DEV float4 pattern_fetch(const float4* __restrict__ tex, int w, int h, int levels, float u, float v, float lod) {
+#pragma clang fp contract(off)
+    const int level = min(max((int)floorf(lod + 0.5f), 0), levels - 1);
+    int lw = w, lh = h;
+    for (int l = 0; l < level; l++) {
+        tex += lw * lh;
+        lw = max(1, lw >> 1); lh = max(1, lh >> 1);
+    }
+    const float sx = u * (float)lw - 0.5f, sy = v * (float)lh - 0.5f;
+    const float x0f = floorf(sx), y0f = floorf(sy);
+    const float fx = sx - x0f, fy = sy - y0f;
+    // clamp in float first: u, v are unbounded below (the caller only rejects coordinates above 1)
+    const int x0 = (int)fminf(fmaxf(x0f, 0.0f), (float)(lw - 1)), x1 = (int)fminf(fmaxf(x0f + 1.0f, 0.0f), (float)(lw - 1));
+    const int y0 = (int)fminf(fmaxf(y0f, 0.0f), (float)(lh - 1)), y1 = (int)fminf(fmaxf(y0f + 1.0f, 0.0f), (float)(lh - 1));
+    const float4 t00 = tex[y0 * lw + x0], t10 = tex[y0 * lw + x1], t01 = tex[y1 * lw + x0], t11 = tex[y1 * lw + x1];
+    return lerp4(lerp4(t00, t10, fx), lerp4(t01, t11, fx), fy);
+}
+
+// PS_SpawnPattern, PatternSpawner.fx:21-97
+ILM_DEV bool spawn_slot_pattern(float4& pos, float4& vel, float4& attr, float x, float y, const float4* __restrict__ rnd, int rw, int rh,
+                                float tx_, float ty_, const IlmSpawnParams& p, const IlmPatternParams& pt,
+                                const float4* __restrict__ tex, int tw, int th, int levels) {
+#pragma clang fp contract(off)
+    const float index = x + (y * p.ChunkSizeAndIndices[0]);
+    if ((index < p.ChunkSizeAndIndices[1]) || (index > p.ChunkSizeAndIndices[2]))
+        return false;
+    const float relative_index = floorf(index - p.ChunkSizeAndIndices[1]);
+    const float particles_per_row = pt.StepWidthAndSizeScale[1];
+    // integer-valued operands below 2^24: the quotient's floor and the remainder are exact (HLSL's float %)
+    const float row = floorf(relative_index / particles_per_row);
+    float ix = floorf(relative_index - (particles_per_row * row)), iy = row;
+    iy += pt.YOffsetsAndCoordScale[0];
+    const float u = (ix * pt.StepWidthAndSizeScale[2]) + pt.TexelOffsetAndMipBias[0];
+    const float v = ((iy * pt.StepWidthAndSizeScale[3]) + pt.TexelOffsetAndMipBias[1]) + pt.YOffsetsAndCoordScale[1];
+    const float position_x = ix * pt.YOffsetsAndCoordScale[2] + pt.CenteringOffset[0];
+    const float position_y = iy * pt.YOffsetsAndCoordScale[3] + pt.CenteringOffset[1];
+    if ((u > 1.0f) || (v > 1.0f))
+        return false;
+    const float4 pattern_color = pattern_fetch(tex, tw, th, levels, u, v, pt.TexelOffsetAndMipBias[3]);
+
+    float4 random1, random2, random3;
+    evaluate_random_for_index(rnd, rw, rh, tx_, ty_, index, p.RandomnessOffset[0], p.RandomnessOffset[1], random1, random2, random3);
+
+    const float4 zero = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+    float4 temp_position = evaluate_formula(zero, ld4(p.InlinePositionConstants[0]), ld4(p.Configuration[0]), ld4(p.Configuration[1]),
+                                            random1, p.FormulaTypes[0], p.AxisMask);
+    temp_position.x += position_x;
+    temp_position.y += position_y;
+    float4 attribute_constant = pattern_color;
+    if (pt.MultiplyAttributeConstant != 0.0f)
+        attribute_constant = mul4(attribute_constant, ld4(p.Configuration[5]));
+    else
+        attribute_constant = add4(attribute_constant, ld4(p.Configuration[5]));
+    float4 new_position = mul_point(xyz(temp_position), p.PositionMatrix);
+    new_position.w = temp_position.w;
+    const float4 temp_velocity = evaluate_formula(temp_position, ld4(p.Configuration[2]), ld4(p.Configuration[3]), ld4(p.Configuration[4]),
+                                                  random2, p.FormulaTypes[1], p.AxisMask);
+    float4 new_velocity = mul_point(xyz(temp_velocity), p.VelocityMatrix);
+    new_velocity.w = temp_velocity.w;
+    const float4 new_attributes = evaluate_formula(temp_position, attribute_constant, ld4(p.Configuration[6]), ld4(p.Configuration[7]),
+                                                   random3, p.FormulaTypes[2], p.AxisMask);
+    if (new_attributes.w < p.AttributeDiscardThreshold)
+        return false;
+    pos = new_position;
+    vel = new_velocity;
+    attr = new_attributes;
+    return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // update -- Bezier.fxh, UpdateCommon.fxh, UpdateParticleSystem*.fx
 // ---------------------------------------------------------------------------------------------
@@ -808,6 +879,10 @@ ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* ub, int chunk, int i, unsigne
                         else if (EXT && d.Spawns[s].Kind == ILM_SPAWN_FEEDBACK)
                             wrote = spawn_slot_feedback(pos, vel, attr, fx, fy, a.rnd, a.rw, a.rh, a.derived.inv_rw, a.derived.inv_rh,
                                                         d.Spawns[s].Params, d.Spawns[s].Feedback, a.source_base[s], S, cs);
+                        else if (EXT && d.Spawns[s].Kind == ILM_SPAWN_PATTERN)
+                            wrote = spawn_slot_pattern(pos, vel, attr, fx, fy, a.rnd, a.rw, a.rh, a.derived.inv_rw, a.derived.inv_rh,
+                                                       d.Spawns[s].Params, d.Spawns[s].Pattern, a.spawn_pattern[s], a.pattern_w[s],
+                                                       a.pattern_h[s], a.pattern_levels[s]);
                         else
                             wrote = spawn_slot(pos, vel, attr, fx, fy, a.rnd, a.rw, a.rh, a.derived.inv_rw, a.derived.inv_rh, d.Spawns[s].Params);
                         if (wrote)

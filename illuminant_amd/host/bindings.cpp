@@ -252,6 +252,33 @@ PYBIND11_MODULE(_host, m) {
         .def_readwrite("MultiplyLife", &FeedbackSpawner::MultiplyLife).def_readwrite("MultiplyColorConstant", &FeedbackSpawner::MultiplyColorConstant)
         VEC_PROP(FeedbackSpawner, SourceLifeRange, 2);
 
+    py::class_<PatternSpawner, SpawnerBase>(m, "PatternSpawner").def(py::init<uint64_t>(), py::arg("seed") = 1)
+        .def_property("TextureTopLeftPx",
+                      [](const PatternSpawner& s) { return s.TextureTopLeftPx ? std::optional<std::vector<float>>(l2(*s.TextureTopLeftPx)) : std::nullopt; },
+                      [](PatternSpawner& s, const std::optional<std::vector<float>>& v) { s.TextureTopLeftPx = v ? std::optional<Vector2>(v2(*v)) : std::nullopt; })
+        .def_property("TextureSizePx",
+                      [](const PatternSpawner& s) { return s.TextureSizePx ? std::optional<std::vector<float>>(l2(*s.TextureSizePx)) : std::nullopt; },
+                      [](PatternSpawner& s, const std::optional<std::vector<float>>& v) { s.TextureSizePx = v ? std::optional<Vector2>(v2(*v)) : std::nullopt; })
+        .def_readwrite("MipBiasBase", &PatternSpawner::MipBiasBase).def_readwrite("WholeSpawn", &PatternSpawner::WholeSpawn)
+        .def_readwrite("InstantInitialSpawn", &PatternSpawner::InstantInitialSpawn)
+        .def_readwrite("MultiplyColorConstant", &PatternSpawner::MultiplyColorConstant)
+        .def_property("Divisor", &PatternSpawner::Divisor, &PatternSpawner::SetDivisor)
+        .def_property_readonly("ParticlesPerRow", &PatternSpawner::ParticlesPerRow)
+        .def_property_readonly("RowsPerInstance", &PatternSpawner::RowsPerInstance)
+        .def_property_readonly("ParticlesPerInstance", &PatternSpawner::ParticlesPerInstance)
+        .def_property_readonly("RowsSpawned", &PatternSpawner::RowsSpawned)
+        // levels: list of (h, w, 4) float32 arrays, level 0 first
+        .def("SetTexture", [](PatternSpawner& s, const std::vector<py::array_t<float, py::array::c_style | py::array::forcecast>>& levels) {
+            if (levels.empty()) { s.SetTexture(0, 0, 0, {}); return; }
+            std::vector<IlmFloat4> flat;
+            for (const auto& a : levels) {
+                if (a.ndim() != 3 || a.shape(2) != 4) throw std::invalid_argument("each level must be (h, w, 4) float32");
+                const IlmFloat4* p = reinterpret_cast<const IlmFloat4*>(a.data());
+                flat.insert(flat.end(), p, p + a.shape(0) * a.shape(1));
+            }
+            s.SetTexture((int)levels[0].shape(1), (int)levels[0].shape(0), (int)levels.size(), std::move(flat));
+        });
+
     py::class_<ParticleSystem::Chunk>(m, "Chunk")
         .def_readonly("IsFeedbackSource", &ParticleSystem::Chunk::IsFeedbackSource)
         .def_readonly("TotalConsumedForFeedback", &ParticleSystem::Chunk::TotalConsumedForFeedback)

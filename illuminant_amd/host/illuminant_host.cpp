@@ -334,6 +334,7 @@ void SpawnerBase::BeginTick(double, double deltaTimeSeconds, int& spawnCount) {
     double currentRate = ((NextRateDraw() * (maxRate - minRate)) + minRate) * countScaler * deltaTimeSeconds;
     currentRate += RateError;
     RateError = 0;
+    currentRate = AdjustCurrentRate(currentRate);
     if (currentRate < 1) {
         RateError = std::max(currentRate, 0.0);
         spawnCount = 0;
@@ -533,6 +534,105 @@ void FeedbackSpawner::FillRecord(IlmSpawnRecord& rec, std::vector<IlmFloat4>& po
     f.SourceLifeRange[0] = SourceLifeRange.X; f.SourceLifeRange[1] = SourceLifeRange.Y;
 }
 
+// ---- PatternSpawner, SpecialSpawners.cs:15-264 -----------------------------------------------------------
+// Arithmetic.NextPowerOfTwo lives in Fracture (not in the tree): smallest power of two >= v; 0 for v <= 0, which
+// BeginTick's `minCount <= 0` guard (:189-194) turns into "nothing to spawn"
+static int NextPowerOfTwo(int v) {
+    if (v <= 0) return 0;
+    int r = 1;
+    while (r < v) r <<= 1;
+    return r;
+}
+void PatternSpawner::SetTexture(int width, int height, int levels, std::vector<IlmFloat4> texels) {
+    size_t total = 0;
+    for (int l = 0, w = width, h = height; l < levels; l++) {
+        total += (size_t)w * (size_t)h;
+        w = std::max(1, w >> 1); h = std::max(1, h >> 1);
+    }
+    if (levels < 0 || (levels > 0 && (width < 1 || height < 1 || texels.size() != total)))
+        throw ArgumentException("texture levels do not match width x height");
+    texWidth = width; texHeight = height; texLevels = levels;
+    texData = std::move(texels);
+    texVersion++;
+}
+Vector2 PatternSpawner::DirectTextureSize() const {
+    Vector2 result{0, 0};
+    if (texLevels <= 0) return result;
+    result = Vector2{ (float)texWidth, (float)texHeight };
+    if (TextureSizePx) {
+        if (TextureSizePx->X > 0) result.X = TextureSizePx->X;
+        if (TextureSizePx->Y > 0) result.Y = TextureSizePx->Y;
+    }
+    if (TextureTopLeftPx) { result.X -= TextureTopLeftPx->X; result.Y -= TextureTopLeftPx->Y; }
+    return result;
+}
+int PatternSpawner::ParticlesPerRow() const { return NextPowerOfTwo((int)DirectTextureSize().X / divisor); }
+int PatternSpawner::RowsPerInstance() const { return NextPowerOfTwo((int)DirectTextureSize().Y / divisor); }
+
+// :141-160
+double PatternSpawner::AdjustCurrentRate(double rate) {
+    if (WholeSpawn && (totalSpawned == 0) && MaximumTotal && (*MaximumTotal > 0) && (rate >= 1) && InstantInitialSpawn) {
+        const double result = std::max((double)ParticlesPerInstance(), rate);
+        const double delta = rate - result;
+        RateError += delta;      // bias the error down so another instance does not follow immediately
+        return result;
+    }
+    return rate;
+}
+
+// :162-206
+void PatternSpawner::BeginTick(ParticleSystem&, double now, double deltaTimeSeconds, int& spawnCount, int& sourceChunkIndex) {
+    sourceChunkIndex = -1;
+    if (texLevels <= 0) { spawnCount = 0; return; }
+    SpawnerBase::BeginTick(now, deltaTimeSeconds, spawnCount);
+    const int minCount = WholeSpawn ? ParticlesPerInstance() : ParticlesPerRow();
+    if (minCount <= 0) { spawnCount = 0; return; }
+    const int requestedSpawnCount = spawnCount;
+    if (spawnCount < minCount) {
+        AddError(spawnCount);
+        spawnCount = 0;
+    } else {
+        spawnCount = (spawnCount / minCount) * minCount;
+        AddError(requestedSpawnCount - spawnCount);
+    }
+}
+
+// SetParameters, :208-256
+void PatternSpawner::FillRecord(IlmSpawnRecord& rec, std::vector<IlmFloat4>& positions, int chunkSize, double now) {
+    positions.clear();
+    FillSpawn(rec.Params, chunkSize, now);
+    rec.Kind = ILM_SPAWN_PATTERN;
+    const int rowsPerInstance = RowsPerInstance();
+    const int currentRow = WholeSpawn ? 0 : (rowsSpawned++) % rowsPerInstance;
+    if (WholeSpawn)
+        rowsSpawned = 0;
+    IlmPatternParams& p = rec.Pattern;
+    p.StepWidthAndSizeScale[0] = (float)divisor; p.StepWidthAndSizeScale[1] = (float)ParticlesPerRow();
+    p.StepWidthAndSizeScale[2] = divisor / (float)texWidth; p.StepWidthAndSizeScale[3] = divisor / (float)texHeight;
+    float baseX = 0, baseY = 0;
+    if (TextureTopLeftPx) {
+        baseX = TextureTopLeftPx->X / texWidth;
+        baseY = TextureTopLeftPx->Y / texHeight;
+    }
+    p.YOffsetsAndCoordScale[0] = (float)currentRow;
+    p.YOffsetsAndCoordScale[1] = (float)((currentRow * divisor) / texHeight);      // integer division in the reference (:237)
+    p.YOffsetsAndCoordScale[2] = (float)divisor; p.YOffsetsAndCoordScale[3] = (float)divisor;
+    p.TexelOffsetAndMipBias[0] = -0.5f / texWidth + baseX;
+    p.TexelOffsetAndMipBias[1] = -0.5f / texHeight + baseY;
+    p.TexelOffsetAndMipBias[2] = 0;
+    p.TexelOffsetAndMipBias[3] = (float)(std::log((double)divisor) / std::log(2.0)) + MipBiasBase;     // Math.Log(Divisor, 2)
+    const Vector2 size = DirectTextureSize();
+    p.CenteringOffset[0] = size.X * -0.5f; p.CenteringOffset[1] = size.Y * -0.5f;
+    p.MultiplyAttributeConstant = MultiplyColorConstant ? 1.0f : 0.0f;
+    rec.Params.PositionConstantCount = 1;
+    rec.Params.InlinePositionConstants[0] = { Position.Constant.X, Position.Constant.Y, Position.Constant.Z, Life.Constant };
+}
+
+void PatternSpawner::BindResources(ParticleSystem& system, int slot) {
+    if (system.PatternBound(slot, this, texVersion)) return;
+    ThrowIfFailed(ilm_system_set_spawn_pattern(system.Handle(), slot, texData.data(), texWidth, texHeight, texLevels));
+}
+
 // MatrixMultiply, Transforms.cs:52-71
 MatrixMultiply::MatrixMultiply() : Position(IdentityMatrix()), Velocity(IdentityMatrix()) {}
 bool MatrixMultiply::FillOp(IlmTransformOp& op, double) {
@@ -706,7 +806,8 @@ int ParticleSystem::PickSourceForFeedback(int count) {
 
 // RunSpawner, ParticleSpawning.cs:115-197
 bool ParticleSystem::RunSpawner(Transforms::SpawnerBase& spawner, double deltaTimeSeconds, double now, bool,
-                                std::vector<IlmSpawnRecord>& records, std::vector<std::vector<IlmFloat4>>& recordPositions) {
+                                std::vector<IlmSpawnRecord>& records, std::vector<std::vector<IlmFloat4>>& recordPositions,
+                                std::vector<Transforms::SpawnerBase*>& recordSpawners) {
     int spawnCount = 0, requestedSpawnCount = 0;
     if (!spawner.IsValid())
         return false;
@@ -748,6 +849,7 @@ bool ParticleSystem::RunSpawner(Transforms::SpawnerBase& spawner, double deltaTi
         spawner.FillRecord(rec, positions, Engine.Configuration.ChunkSize, now);
         records.push_back(rec);
         recordPositions.push_back(std::move(positions));
+        recordSpawners.push_back(&spawner);
     }
     chunk.ApproximateMaximumLife = std::max(chunk.ApproximateMaximumLife, spawner.EstimateMaximumLifeForNewParticle());
     return requestedSpawnCount > spawnCount;   // isPartialSpawn
@@ -855,19 +957,21 @@ ParticleSystem::UpdateResult ParticleSystem::Update(int frameIndex) {
     // spawners first (:725-741)
     std::vector<IlmSpawnRecord> records;
     std::vector<std::vector<IlmFloat4>> recordPositions;
+    std::vector<Transforms::SpawnerBase*> recordSpawners;
     for (Transforms::ParticleTransform* t : Transforms) {
         if (!t->IsSpawner()) continue;
         auto* s = static_cast<Transforms::SpawnerBase*>(t);
         if (!s->IsActive || !s->IsActive2) continue;
-        const bool isPartialSpawn = RunSpawner(*s, actualDeltaTimeSeconds, now, false, records, recordPositions);
+        const bool isPartialSpawn = RunSpawner(*s, actualDeltaTimeSeconds, now, false, records, recordPositions, recordSpawners);
         if (isPartialSpawn)
-            RunSpawner(*s, actualDeltaTimeSeconds, now, true, records, recordPositions);
+            RunSpawner(*s, actualDeltaTimeSeconds, now, true, records, recordPositions, recordSpawners);
     }
     // the PositionBuffer of a position-texture record is bound to the record slot it will occupy in its launch
     auto bindPositions = [&](int slot, size_t recordIndex) {
         const std::vector<IlmFloat4>& pl = recordPositions[recordIndex];
         if (!pl.empty())
             ThrowIfFailed(ilm_system_set_spawn_positions(handle, slot, pl.data(), (int32_t)pl.size()));
+        recordSpawners[recordIndex]->BindResources(*this, slot);
     };
 
     // UpdateChunk (:791-856) for every chunk: transforms in list order, then exactly one update technique

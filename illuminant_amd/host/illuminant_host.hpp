@@ -356,6 +356,8 @@ public:
 
     virtual bool PartialSpawnAllowed() const { return true; }
     virtual int CountScale() const { return 1; }
+    // :148-150
+    virtual double AdjustCurrentRate(double rate) { return rate; }
     // :152-189
     virtual void BeginTick(double now, double deltaTimeSeconds, int& spawnCount);
     // BeginTick as RunSpawner calls it (with the target system and the source chunk out-parameter, :152);
@@ -371,6 +373,8 @@ public:
         positions.clear(); rec.Kind = ILM_SPAWN_INLINE; FillSpawn(rec.Params, chunkSize, now);
     }
     virtual bool IsFeedback() const { return false; }
+    // device-side resources a record of this spawner needs in spawn record slot `slot` of `system` (the pattern texture)
+    virtual void BindResources(ParticleSystem& system, int slot) { (void)system; (void)slot; }
     // RunSpawner's consumed-count bookkeeping for feedback sources (ParticleSpawning.cs:159-166)
     virtual void OnSpawned(int spawnCount) { (void)spawnCount; }
     // :191-194
@@ -423,6 +427,39 @@ public:
 private:
     int currentFeedbackSource = -1;        // chunk table index in the source system
     int currentFeedbackSourceIndex = 0;
+};
+
+// SpecialSpawners.cs:15-264.  Texture = the mip levels as float4 texels (the reference's Texture2D comes from its texture loader).
+class PatternSpawner : public SpawnerBase {
+public:
+    explicit PatternSpawner(uint64_t seed = 1) : SpawnerBase(seed) {}
+    std::optional<Vector2> TextureTopLeftPx, TextureSizePx;
+    float MipBiasBase = -0.5f;
+    bool WholeSpawn = false, InstantInitialSpawn = true, MultiplyColorConstant = true;
+    int Divisor() const { return divisor; }
+    void SetDivisor(int v) { divisor = std::min(std::max(v, 1), 10); }          // Arithmetic.Clamp(value, 1, 10), :44-51
+    // `texels`: `levels` mip levels back to back, level l = max(1, width >> l) x max(1, height >> l)
+    void SetTexture(int width, int height, int levels, std::vector<IlmFloat4> texels);
+    int TextureWidth() const { return texWidth; }
+    int TextureHeight() const { return texHeight; }
+    int ParticlesPerRow() const;       // :111-115
+    int RowsPerInstance() const;       // :117-121
+    int ParticlesPerInstance() const { return ParticlesPerRow() * RowsPerInstance(); }
+    int RowsSpawned() const { return rowsSpawned; }
+    int CountScale() const override { return WholeSpawn ? ParticlesPerInstance() : ParticlesPerRow(); }
+    bool PartialSpawnAllowed() const override { return false; }
+    bool IsValid() const override { return texLevels > 0; }
+    void Reset() override { SpawnerBase::Reset(); rowsSpawned = 0; }
+    double AdjustCurrentRate(double rate) override;
+    void BeginTick(ParticleSystem& system, double now, double deltaTimeSeconds, int& spawnCount, int& sourceChunkIndex) override;
+    void FillRecord(IlmSpawnRecord& rec, std::vector<IlmFloat4>& positions, int chunkSize, double now) override;
+    void BindResources(ParticleSystem& system, int slot) override;
+private:
+    Vector2 DirectTextureSize() const;  // :76-97
+    int divisor = 1, rowsSpawned = 0;
+    int texWidth = 0, texHeight = 0, texLevels = 0;
+    uint64_t texVersion = 0;
+    std::vector<IlmFloat4> texData;
 };
 
 // Transforms.cs:52-71
@@ -509,10 +546,17 @@ public:
     // the descriptor of the last launch (tests compare it with the oracle's step)
     const IlmStepDesc& LastStep() const { return lastStep; }
     double LastDeltaTimeSeconds = 0;
+    // which pattern texture (owner, version) spawn record slot `slot` currently holds on the device; true = already bound
+    bool PatternBound(int slot, const void* owner, uint64_t version) {
+        if (boundPatternOwner[slot] == owner && boundPatternVersion[slot] == version) return true;
+        boundPatternOwner[slot] = owner; boundPatternVersion[slot] = version;
+        return false;
+    }
 
 private:
     bool RunSpawner(Transforms::SpawnerBase& spawner, double deltaTimeSeconds, double now, bool isSecondPass,
-                    std::vector<IlmSpawnRecord>& records, std::vector<std::vector<IlmFloat4>>& recordPositions);
+                    std::vector<IlmSpawnRecord>& records, std::vector<std::vector<IlmFloat4>>& recordPositions,
+                    std::vector<Transforms::SpawnerBase*>& recordSpawners);
     int PickTargetForSpawn(bool feedback, int count, bool& needClear, bool partialSpawnAllowed);
     int CreateChunk();
     void UpdateLiveCountAndReapDeadChunks();
@@ -535,6 +579,8 @@ private:
     bool isClearPending = false;
     IlmStepDesc lastStep;
     ManualTimeProvider defaultTime;
+    const void* boundPatternOwner[ILM_MAX_SPAWNS] = {};
+    uint64_t boundPatternVersion[ILM_MAX_SPAWNS] = {};
 };
 
 }  // namespace Particles

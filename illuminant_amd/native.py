@@ -57,6 +57,7 @@ SYMBOLS = {
     "ilm_matrix_multiply": (_I, [_H, _I, _P, _P]),
     "ilm_spatial_noise": (_I, [_H, _I, _P, _P]),
     "ilm_system_set_spawn_positions": (_I, [_H, _I, _P, _I]),
+    "ilm_system_set_spawn_pattern": (_I, [_H, _I, _P, _I, _I, _I]),
     "ilm_update": (_I, [_H, _I, _P, _P, _P]),
     "ilm_erase": (_I, [_H, _I]),
     "ilm_system_live_counts": (_I, [_H, _P, _I, _I]),
@@ -247,6 +248,19 @@ class System:
             return
         a = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 4)
         check(lib().ilm_system_set_spawn_positions(self.handle, slot, _ptr(a), a.shape[0]))
+
+    def set_spawn_pattern(self, slot, levels):
+        """ilm_system_set_spawn_pattern: `levels` = [level 0 (h, w, 4) float32, level 1 (max(1, h >> 1), max(1, w >> 1), 4), ...] of the
+        PatternSpawner texture of spawn record `slot`; None releases."""
+        if not levels:
+            check(lib().ilm_system_set_spawn_pattern(self.handle, slot, None, 0, 0, 0))
+            return
+        h, w = levels[0].shape[0], levels[0].shape[1]
+        for l, a in enumerate(levels):
+            if a.shape[:2] != (max(1, h >> l), max(1, w >> l)):
+                raise ValueError("mip level %d is %s, expected %s" % (l, a.shape[:2], (max(1, h >> l), max(1, w >> l))))
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.float32).reshape(-1, 4) for a in levels]))
+        check(lib().ilm_system_set_spawn_pattern(self.handle, slot, _ptr(flat), w, h, len(levels)))
 
     def update(self, chunk, sys, p, df=None):
         check(lib().ilm_update(self.handle, chunk, _byref(sys), _byref(p), _byref(df)))

@@ -182,6 +182,69 @@ def feedback_params(source_system_handle, source_chunk_index, source_index, inst
     return f
 
 
+def next_power_of_two(v):
+    """Arithmetic.NextPowerOfTwo (Fracture, not in the tree): the smallest power of two >= v; 0 for v <= 0 (PatternSpawner.BeginTick treats
+    a non-positive particle count as "nothing to spawn", SpecialSpawners.cs:189-194)."""
+    v = int(v)
+    if v <= 0:
+        return 0
+    return 1 << (v - 1).bit_length()
+
+
+def pattern_direct_texture_size(tex_w, tex_h, top_left_px=None, size_px=None):
+    """PatternSpawner.DirectTextureSize, SpecialSpawners.cs:76-97 (the top-left corner is subtracted even from an explicit size)."""
+    w, h = np.float32(tex_w), np.float32(tex_h)
+    if size_px is not None:
+        if size_px[0] > 0:
+            w = np.float32(size_px[0])
+        if size_px[1] > 0:
+            h = np.float32(size_px[1])
+    if top_left_px is not None:
+        w, h = np.float32(w - np.float32(top_left_px[0])), np.float32(h - np.float32(top_left_px[1]))
+    return w, h
+
+
+def pattern_counts(tex_w, tex_h, divisor=1, top_left_px=None, size_px=None):
+    """(ParticlesPerRow, RowsPerInstance) of a PatternSpawner, SpecialSpawners.cs:111-127: integer divisions, then NextPowerOfTwo."""
+    w, h = pattern_direct_texture_size(tex_w, tex_h, top_left_px, size_px)
+    return next_power_of_two(int(w) // divisor), next_power_of_two(int(h) // divisor)
+
+
+def pattern_params(tex_w, tex_h, divisor=1, current_row=0, top_left_px=None, size_px=None, mip_bias_base=-0.5,
+                   multiply_color_constant=True):
+    """PatternSpawner.SetParameters, SpecialSpawners.cs:208-256, in float32.  current_row = 0 for WholeSpawn, else
+    RowsSpawned % RowsPerInstance.  `(currentRow * Divisor) / tex.Height` is an INTEGER division in the reference (:237)."""
+    f = np.float32
+    per_row, _rows = pattern_counts(tex_w, tex_h, divisor, top_left_px, size_px)
+    p = abi.PatternParams()
+    p.StepWidthAndSizeScale[:] = [f(divisor), f(per_row), f(divisor) / f(tex_w), f(divisor) / f(tex_h)]
+    base_x = base_y = f(0)
+    if top_left_px is not None:
+        base_x, base_y = f(top_left_px[0]) / f(tex_w), f(top_left_px[1]) / f(tex_h)
+    p.YOffsetsAndCoordScale[:] = [f(current_row), f((current_row * divisor) // tex_h), f(divisor), f(divisor)]
+    p.TexelOffsetAndMipBias[:] = [f(-0.5) / f(tex_w) + base_x, f(-0.5) / f(tex_h) + base_y, f(0),
+                                  f(math.log(divisor) / math.log(2.0)) + f(mip_bias_base)]
+    dw, dh = pattern_direct_texture_size(tex_w, tex_h, top_left_px, size_px)
+    p.CenteringOffset[:] = [dw * f(-0.5), dh * f(-0.5)]
+    p.MultiplyAttributeConstant = 1.0 if multiply_color_constant else 0.0
+    return p
+
+
+def pattern_mip_chain(texels, levels=None):
+    """A synthetic mip chain for tests and benchmarks: 2x2 box filter (edge texels repeated for odd sizes).  The reference's chain comes
+    from its texture loader, which is not in the tree; the C ABI takes the levels as given."""
+    a = np.ascontiguousarray(texels, dtype=np.float32)
+    out = [a]
+    while (levels is None and (a.shape[0] > 1 or a.shape[1] > 1)) or (levels is not None and len(out) < levels):
+        h, w = a.shape[0], a.shape[1]
+        nh, nw = max(1, h >> 1), max(1, w >> 1)
+        ys0 = np.minimum(np.arange(nh) * 2, h - 1); ys1 = np.minimum(ys0 + 1, h - 1)
+        xs0 = np.minimum(np.arange(nw) * 2, w - 1); xs1 = np.minimum(xs0 + 1, w - 1)
+        a = ((a[ys0][:, xs0] + a[ys0][:, xs1] + a[ys1][:, xs0] + a[ys1][:, xs1]) * np.float32(0.25)).astype(np.float32)
+        out.append(a)
+    return out
+
+
 FORMULA_LINEAR, FORMULA_SPHERICAL, FORMULA_TOWARDS, FORMULA_RECTANGULAR = 0, 1, 2, 3
 
 

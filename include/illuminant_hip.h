@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ILM_ABI_VERSION 2
+#define ILM_ABI_VERSION 3
 
 /* ---- return codes ------------------------------------------------------ */
 #define ILM_OK                    0
@@ -234,8 +234,10 @@ enum {
     ILM_SPAWN_INLINE           = 0,  /* technique SpawnParticles (<= 4 inline positions), SpawnParticles.fx:10-30 */
     ILM_SPAWN_POSITION_BUFFER  = 1,  /* technique SpawnParticlesFromPositionTexture, SpawnParticles.fx:32-52: positions from
                                         the list bound with ilm_system_set_spawn_positions */
-    ILM_SPAWN_FEEDBACK         = 2   /* technique SpawnFeedbackParticles, SpawnParticles.fx:54-118: one source particle of
+    ILM_SPAWN_FEEDBACK         = 2,  /* technique SpawnFeedbackParticles, SpawnParticles.fx:54-118: one source particle of
                                         another system's chunk per InstanceMultiplier new particles */
+    ILM_SPAWN_PATTERN          = 3   /* technique SpawnPatternParticles, PatternSpawner.fx:21-97: one particle per Divisor x Divisor
+                                        block of the texture bound with ilm_system_set_spawn_pattern */
 };
 
 /* FeedbackSpawner.SetParameters (Illuminant/Particles/SpecialSpawners.cs:411-427) + the source chunk bound by
@@ -251,12 +253,24 @@ typedef struct IlmFeedbackParams {
     float     _pad;
 } IlmFeedbackParams;
 
+/* PatternSpawner.SetParameters (Illuminant/Particles/SpecialSpawners.cs:208-256); uniforms of
+ * Illuminant/Shaders/PatternSpawner.fx:6-9. */
+typedef struct IlmPatternParams {
+    float StepWidthAndSizeScale[4];    /* Divisor, ParticlesPerRow, Divisor / texWidth, Divisor / texHeight */
+    float YOffsetsAndCoordScale[4];    /* currentRow, currentRow * Divisor / texHeight, Divisor, Divisor */
+    float TexelOffsetAndMipBias[4];    /* -0.5 / texWidth + baseX, -0.5 / texHeight + baseY, 0, log2(Divisor) + MipBiasBase */
+    float CenteringOffset[2];          /* DirectTextureSize * -0.5 */
+    float MultiplyAttributeConstant;   /* != 0: pattern colour * Configuration[5], else + */
+    float _pad;
+} IlmPatternParams;
+
 typedef struct IlmSpawnRecord {
     int32_t        ChunkIndex;    /* index in the system's chunk table */
     int32_t        Kind;          /* ILM_SPAWN_* */
     int32_t        _pad[2];
     IlmSpawnParams Params;
     IlmFeedbackParams Feedback;   /* read when Kind == ILM_SPAWN_FEEDBACK */
+    IlmPatternParams  Pattern;    /* read when Kind == ILM_SPAWN_PATTERN */
 } IlmSpawnRecord;
 
 /* One ParticleSystem.Update's worth of GPU work (Illuminant/Particles/ParticleSystem.cs:725-745):
@@ -375,6 +389,15 @@ int32_t ilm_system_set_life_ramp(IlmHandle system, const IlmFloat4* texels, int3
  * ILM_SPAWN_POSITION_BUFFER.  The reference pads the texture width to a multiple of 128 and addresses it with
  * index * (1 / width), POINT / CLAMP; the same arithmetic is applied here.  count == 0 releases the list. */
 int32_t ilm_system_set_spawn_positions(IlmHandle system, int32_t spawn_slot, const IlmFloat4* positions, int32_t count);
+
+/* The PatternSpawner's texture (Illuminant/Particles/SpecialSpawners.cs:19-22,255; sampler PatternSampler,
+ * Illuminant/Shaders/PatternSpawner.fx:11-19: CLAMP, LINEAR min/mag, POINT mip) for spawn record `spawn_slot`, used by records of
+ * kind ILM_SPAWN_PATTERN.  `texels` holds `levels` mip levels back to back, level l being max(1, width >> l) x max(1, height >> l)
+ * float4 texels, row-major (the reference's mip chain comes from its texture loader, which is outside the tree: it is an explicit
+ * input here; levels == 1 is a texture without mips).  tex2Dlod's explicit LOD picks level clamp(floor(lod + 0.5), 0, levels - 1).
+ * levels == 0 releases the texture. */
+int32_t ilm_system_set_spawn_pattern(IlmHandle system, int32_t spawn_slot, const IlmFloat4* texels,
+                                     int32_t width, int32_t height, int32_t levels);
 
 /* The hot path.  Replaces RunSpawner + the UpdateChunk loop of
  * ParticleSystem.Update (ParticleSystem.cs:725-745, 791-856): every RunTransform

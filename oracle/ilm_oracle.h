@@ -67,7 +67,8 @@ void orc_matrix_multiply(IlmFloat4* pos, IlmFloat4* vel, int32_t chunk_size,
 void orc_low_precision_randomness(const IlmFloat4* rnd, int32_t count, uint16_t* out /* count * 4 */);
 void orc_spatial_noise(IlmFloat4* pos, IlmFloat4* vel, int32_t chunk_size, const uint16_t* low_precision_rnd, int32_t rw, int32_t rh,
                        const IlmParticleSystemUniforms* sys, const IlmSpatialNoiseParams* p);
-/* what orc_step cannot find in the descriptor: the position lists of ILM_SPAWN_POSITION_BUFFER records and the planes of the
+/* what orc_step cannot find in the descriptor: the position lists of ILM_SPAWN_POSITION_BUFFER records, the textures of
+ * ILM_SPAWN_PATTERN records and the planes of the
  * source chunk of ILM_SPAWN_FEEDBACK records, per spawn record slot */
 typedef struct OrcStepExtras {
     const IlmFloat4* spawn_positions[ILM_MAX_SPAWNS];
@@ -76,6 +77,8 @@ typedef struct OrcStepExtras {
     const IlmFloat4* source_vel[ILM_MAX_SPAWNS];
     const IlmFloat4* source_attr[ILM_MAX_SPAWNS];
     const uint16_t*  low_precision_rnd;       /* optional: the Rgba64 randomness copy (computed per call when NULL) */
+    const IlmFloat4* spawn_pattern[ILM_MAX_SPAWNS];       /* ILM_SPAWN_PATTERN: mip levels back to back */
+    int32_t          pattern_w[ILM_MAX_SPAWNS], pattern_h[ILM_MAX_SPAWNS], pattern_levels[ILM_MAX_SPAWNS];
 } OrcStepExtras;
 void orc_step_ex(IlmFloat4** planes, int32_t chunk_count, int32_t chunk_size,
                  const IlmFloat4* rnd, int32_t rw, int32_t rh,

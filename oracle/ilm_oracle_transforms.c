@@ -238,6 +238,75 @@ static void spawn_feedback_slot(f4* pos, f4* vel, f4* attr, float x, float y, co
     *pos = new_position; *vel = new_velocity; *attr = new_attributes;
 }
 
+/* tex2Dlod(PatternSampler, float4(uv, 0, lod)), PatternSpawner.fx:11-19,58-60: CLAMP addressing, LINEAR min / mag filter, POINT mip
+ * filter.  The explicit LOD picks the nearest level, floor(lod + 0.5) clamped to the chain; bilinear weights come from
+ * uv * size - 0.5 (texel centres at integer + 0.5).  The mip chain itself is an input (the reference's texture loader makes it). */
+static f4 pattern_fetch(const IlmFloat4* tex, int w, int h, int levels, float u, float v, float lod) {
+    int level = (int)floorf(lod + 0.5f);
+    if (level < 0) level = 0;
+    if (level > levels - 1) level = levels - 1;
+    int lw = w, lh = h;
+    for (int l = 0; l < level; l++) {
+        tex += lw * lh;
+        lw = lw >> 1; if (lw < 1) lw = 1;
+        lh = lh >> 1; if (lh < 1) lh = 1;
+    }
+    float sx = u * (float)lw - 0.5f, sy = v * (float)lh - 0.5f;
+    float x0f = floorf(sx), y0f = floorf(sy);
+    float fx = sx - x0f, fy = sy - y0f;
+    float x1f = x0f + 1.0f, y1f = y0f + 1.0f;
+    if (x0f < 0.0f) x0f = 0.0f; if (x0f > (float)(lw - 1)) x0f = (float)(lw - 1);
+    if (x1f < 0.0f) x1f = 0.0f; if (x1f > (float)(lw - 1)) x1f = (float)(lw - 1);
+    if (y0f < 0.0f) y0f = 0.0f; if (y0f > (float)(lh - 1)) y0f = (float)(lh - 1);
+    if (y1f < 0.0f) y1f = 0.0f; if (y1f > (float)(lh - 1)) y1f = (float)(lh - 1);
+    const int x0 = (int)x0f, x1 = (int)x1f, y0 = (int)y0f, y1 = (int)y1f;
+    return v4lerp(v4lerp(tex[y0 * lw + x0], tex[y0 * lw + x1], fx), v4lerp(tex[y1 * lw + x0], tex[y1 * lw + x1], fx), fy);
+}
+
+/* PS_SpawnPattern, PatternSpawner.fx:21-97 (the #if FNA nudge is off in the reference build, as in PS_Spawn) */
+static void spawn_pattern_slot(f4* pos, f4* vel, f4* attr, float x, float y, const f4* rnd, int rw, int rh,
+                               const IlmSpawnParams* p, const IlmPatternParams* pt, const IlmFloat4* tex, int tw, int th, int levels) {
+    const float* csi = p->ChunkSizeAndIndices;
+    float index = x + (y * csi[0]);
+    if ((index < csi[1]) || (index > csi[2]))
+        return;
+    float relative_index = floorf(index - csi[1]);
+    float particles_per_row = pt->StepWidthAndSizeScale[1];
+    float ix = floorf(fmodf(relative_index, particles_per_row)), iy = floorf(relative_index / particles_per_row);
+    iy += pt->YOffsetsAndCoordScale[0];
+    float u = (ix * pt->StepWidthAndSizeScale[2]) + pt->TexelOffsetAndMipBias[0];
+    float v = (iy * pt->StepWidthAndSizeScale[3]) + pt->TexelOffsetAndMipBias[1];
+    v += pt->YOffsetsAndCoordScale[1];
+    float position_x = ix * pt->YOffsetsAndCoordScale[2] + pt->CenteringOffset[0];
+    float position_y = iy * pt->YOffsetsAndCoordScale[3] + pt->CenteringOffset[1];
+    if ((u > 1.0f) || (v > 1.0f))
+        return;
+    f4 pattern_color = pattern_fetch(tex, tw, th, levels, u, v, pt->TexelOffsetAndMipBias[3]);
+
+    f4 random1, random2, random3;
+    evaluate_random_for_index(rnd, rw, rh, index, p->RandomnessOffset, &random1, &random2, &random3);
+
+    const f4 zero = v4(0, 0, 0, 0);
+    const f4* C = p->Configuration;
+    f4 temp_position = evaluate_formula(zero, p->InlinePositionConstants[0], C[0], C[1], random1, p->FormulaTypes[0], p->AxisMask);
+    temp_position.x += position_x;
+    temp_position.y += position_y;
+    f4 attribute_constant = pattern_color;
+    if (pt->MultiplyAttributeConstant != 0.0f)
+        attribute_constant = v4mul(attribute_constant, C[5]);
+    else
+        attribute_constant = v4add(attribute_constant, C[5]);
+    f4 new_position = mul_point(xyz(temp_position), &p->PositionMatrix);
+    new_position.w = temp_position.w;
+    f4 temp_velocity = evaluate_formula(temp_position, C[2], C[3], C[4], random2, p->FormulaTypes[1], p->AxisMask);
+    f4 new_velocity = mul_point(xyz(temp_velocity), &p->VelocityMatrix);
+    new_velocity.w = temp_velocity.w;
+    f4 new_attributes = evaluate_formula(temp_position, attribute_constant, C[6], C[7], random3, p->FormulaTypes[2], p->AxisMask);
+    if (new_attributes.w < p->AttributeDiscardThreshold)
+        return;
+    *pos = new_position; *vel = new_velocity; *attr = new_attributes;
+}
+
 /* spawn record dispatch over a band of rows (kinds: ILM_SPAWN_*) */
 static void spawn_record_rows(IlmFloat4* pos, IlmFloat4* vel, IlmFloat4* attr, int32_t chunk_size, int y0, int y1,
                               const IlmFloat4* rnd, int32_t rw, int32_t rh, const IlmSpawnRecord* r, int slot, const OrcStepExtras* ex) {
@@ -254,5 +323,8 @@ static void spawn_record_rows(IlmFloat4* pos, IlmFloat4* vel, IlmFloat4* attr, i
             else if (r->Kind == ILM_SPAWN_FEEDBACK)
                 spawn_feedback_slot(&pos[i], &vel[i], &attr[i], (float)x, (float)y, rnd, rw, rh, &r->Params, &r->Feedback,
                                     ex->source_pos[slot], ex->source_vel[slot], ex->source_attr[slot], chunk_size);
+            else if (r->Kind == ILM_SPAWN_PATTERN)
+                spawn_pattern_slot(&pos[i], &vel[i], &attr[i], (float)x, (float)y, rnd, rw, rh, &r->Params, &r->Pattern,
+                                   ex->spawn_pattern[slot], ex->pattern_w[slot], ex->pattern_h[slot], ex->pattern_levels[slot]);
         }
 }

@@ -149,7 +149,9 @@ def spatial_noise(pos, vel, chunk_size, rnd, sys, p):
 class StepExtras(C.Structure):
     _fields_ = [("spawn_positions", C.c_void_p * abi.MAX_SPAWNS), ("spawn_position_count", C.c_int32 * abi.MAX_SPAWNS),
                 ("source_pos", C.c_void_p * abi.MAX_SPAWNS), ("source_vel", C.c_void_p * abi.MAX_SPAWNS),
-                ("source_attr", C.c_void_p * abi.MAX_SPAWNS), ("low_precision_rnd", C.c_void_p)]
+                ("source_attr", C.c_void_p * abi.MAX_SPAWNS), ("low_precision_rnd", C.c_void_p),
+                ("spawn_pattern", C.c_void_p * abi.MAX_SPAWNS), ("pattern_w", C.c_int32 * abi.MAX_SPAWNS),
+                ("pattern_h", C.c_int32 * abi.MAX_SPAWNS), ("pattern_levels", C.c_int32 * abi.MAX_SPAWNS)]
 
 
 def erase(pos, vel, rc, rd, chunk_size):
@@ -160,10 +162,12 @@ def count_live(pos, saturate16=False):
     return int(lib().orc_count_live(_f4(pos), pos.shape[0], 1 if saturate16 else 0))
 
 
-def step(chunks, chunk_size, rnd, desc, life_ramp=None, sdf=None, want_counts=False, spawn_positions=None, feedback_sources=None):
+def step(chunks, chunk_size, rnd, desc, life_ramp=None, sdf=None, want_counts=False, spawn_positions=None, feedback_sources=None,
+         spawn_patterns=None):
     """chunks: list of dicts/tuples of 5 planes (pos, vel, attr, rc, rd) per chunk.
     spawn_positions: {spawn slot: (n, 4) float32} for ILM_SPAWN_POSITION_BUFFER records;
-    feedback_sources: {spawn slot: (pos, vel, attr) planes of the source chunk} for ILM_SPAWN_FEEDBACK records."""
+    feedback_sources: {spawn slot: (pos, vel, attr) planes of the source chunk} for ILM_SPAWN_FEEDBACK records;
+    spawn_patterns: {spawn slot: [level 0 (h, w, 4) float32, level 1, ...]} for ILM_SPAWN_PATTERN records."""
     n = len(chunks)
     ptrs = (C.c_void_p * (n * 5))()
     for c, planes in enumerate(chunks):
@@ -180,6 +184,11 @@ def step(chunks, chunk_size, rnd, desc, life_ramp=None, sdf=None, want_counts=Fa
         keep.append(a)
         ex.spawn_positions[slot] = a.ctypes.data
         ex.spawn_position_count[slot] = a.shape[0]
+    for slot, levels in (spawn_patterns or {}).items():
+        flat = np.ascontiguousarray(np.concatenate([np.asarray(l, dtype=np.float32).reshape(-1, 4) for l in levels]))
+        keep.append(flat)
+        ex.spawn_pattern[slot] = flat.ctypes.data
+        ex.pattern_h[slot], ex.pattern_w[slot], ex.pattern_levels[slot] = levels[0].shape[0], levels[0].shape[1], len(levels)
     for slot, (sp, sv, sa) in (feedback_sources or {}).items():
         ex.source_pos[slot], ex.source_vel[slot], ex.source_attr[slot] = _f4(sp).value, _f4(sv).value, _f4(sa).value
     lib().orc_step_ex(ptrs, n, chunk_size, _f4(rnd), rnd.shape[1], rnd.shape[0], _p(life_ramp), rw, rh,

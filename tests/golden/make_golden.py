@@ -516,8 +516,53 @@ def gen_transforms_ext():
     cases.append({"kind": "feedback", "instance_multiplier": 3, "source_index": 20, "first": 100, "last": 111, "source_velocity_factor": 0.5,
                   "source_life_range": [0.5, 9999.0], "dead_source_slots": [22],
                   "expected_source_of_slot": {str(100 + k): 20 + k // 3 for k in range(12)}})
+    # (h) PatternSpawner (PatternSpawner.fx:21-97, SpecialSpawners.cs:208-256).  With Linear formulas and zero random scales the new
+    #     particle k (slot first + k) of a whole spawn has indexXy = (k % perRow, k / perRow), sits at constant + indexXy * Divisor -
+    #     size / 2 and takes the texture colour at uv = indexXy * Divisor / size - 0.5 / size.  In texel space (u * w - 0.5) that is
+    #     indexXy * Divisor - 1 at level 0 -- the reference's half-texel offset lands one texel up and to the left of the pixel it
+    #     stands on; CLAMP repeats the first row / column.
+    def pattern_case(name, tex_w, tex_h, levels, level_used, divisor, current_row, count, color_constant, multiply, first=32):
+        lw, lh = max(1, tex_w >> level_used), max(1, tex_h >> level_used)
+        texel = lambda x, y: [10.0 * x + 5.0, 100.0 * y + 7.0, 0.5, 1.0]
+        chain = []
+        for l in range(levels):
+            w_, h_ = max(1, tex_w >> l), max(1, tex_h >> l)
+            if l == level_used:
+                chain.append([[texel(x, y) for x in range(w_)] for y in range(h_)])
+            else:
+                chain.append([[[999.0, 999.0, 999.0, 999.0] for x in range(w_)] for y in range(h_)])     # must not be read
+        npot = lambda v: 0 if v <= 0 else 1 << (v - 1).bit_length()
+        per_row = npot(tex_w // divisor)
+        constant, life = [100.0, 200.0, 5.0], 2.0
+        expected, rejected = [], []
+        for k in range(count):
+            ix, iy = k % per_row, k // per_row + current_row
+            u = ix * divisor / tex_w - 0.5 / tex_w
+            v = iy * divisor / tex_h - 0.5 / tex_h + (current_row * divisor) // tex_h
+            if u > 1 or v > 1:
+                rejected.append(first + k)
+                continue
+            # bilinear on the used level: the texel function is linear in x and y, so the filtered value is the function at the
+            # clamped sample position
+            sx = min(max(u * lw - 0.5, 0.0), lw - 1.0)
+            sy = min(max(v * lh - 0.5, 0.0), lh - 1.0)
+            colour = [10.0 * sx + 5.0, 100.0 * sy + 7.0, 0.5, 1.0]
+            attr = [c * k_ for c, k_ in zip(colour, color_constant)] if multiply else [c + k_ for c, k_ in zip(colour, color_constant)]
+            expected.append({"slot": first + k, "position": [constant[0] + ix * divisor - tex_w * 0.5, constant[1] + iy * divisor - tex_h * 0.5,
+                                                              constant[2], life], "attributes": attr})
+        return {"kind": "pattern", "name": name, "texture_levels": chain, "divisor": divisor, "current_row": current_row, "first": first,
+                "last": first + count - 1, "position_constant": constant, "life": life, "color_constant": color_constant, "multiply": multiply,
+                "expected": expected, "rejected_slots": rejected}
+    cases.append(pattern_case("whole 8x4", 8, 4, 1, 0, 1, 0, 32, [0.5, 2.0, 1.0, 1.0], True))
+    cases.append(pattern_case("row 2 of 8x4", 8, 4, 1, 0, 1, 2, 8, [0.5, 2.0, 1.0, 1.0], True, first=0))
+    # Divisor 2: LOD = log2(2) - 0.5 = 0.5 => nearest level 1 (4x4), additive colour constant
+    cases.append(pattern_case("divisor 2 reads mip 1", 8, 8, 2, 1, 2, 0, 16, [0.25, 0.0, 0.0, 0.0], False))
+    # 6 texels wide => 8 particles per row (next power of two); the 8th has u > 1 and is rejected, the 7th is one of the
+    # "garbage particles on the right" the shader comment mentions and survives
+    cases.append(pattern_case("npot 6x4", 6, 4, 1, 0, 1, 0, 32, [1.0, 1.0, 1.0, 1.0], True))
     return {"source": "hand-derived from MatrixMultiply.fx:22-52, ParticleCommon.fxh:183-196, Noise.fx:74-116, RandomCommon.fxh:36-39, "
-                      "SpawnParticles.fx:32-118, ParticleSpawner.cs:301-367 (see comments in make_golden.py)",
+                      "SpawnParticles.fx:32-118, ParticleSpawner.cs:301-367, PatternSpawner.fx:21-97, SpecialSpawners.cs:208-256 "
+                      "(see comments in make_golden.py)",
             "tolerance": "1e-5 relative", "cases": cases}
 
 

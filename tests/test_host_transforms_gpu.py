@@ -296,3 +296,90 @@ def test_auto_readback_and_resolve_through_the_host_mirror(H, hctx, oracle):
     plain = r.ResolveToArray()                     # hdr == null: the lightmap itself, alpha forced to 1
     assert_close(plain[..., :3], lit[..., :3], "plain resolve")
     assert (plain[..., 3] == 1.0).all()
+
+
+def replay_pattern(ps, sp, levels, chunks, cs, rnd, oracle):
+    d = abi.StepDesc.from_buffer_copy(ps.LastStepBytes())
+    while len(chunks) < len(ps.Chunks):
+        chunks.append(empty_chunk(cs * cs))
+    extras = {}
+    for k in range(d.SpawnCount):
+        assert d.Spawns[k].Kind == abi.SPAWN_PATTERN
+        extras[k] = levels
+    oracle.step(chunks, cs, rnd, d, spawn_patterns=extras)
+    return d
+
+
+def test_pattern_spawner_row_by_row(H, hctx, oracle):
+    """PatternSpawner (SpecialSpawners.cs:15-264) in incremental mode: one texture row of particles per ParticlesPerRow spawned,
+    RowsSpawned cycling through RowsPerInstance; the descriptors the mirror builds equal scenes.pattern_params (the float32
+    restatement of SetParameters) and the chunks equal the oracle's replay."""
+    cs = 32
+    engine, tp, rnd = make_engine(H, hctx, cs)
+    cfg = H.ParticleSystemConfiguration()
+    cfg.LifeDecayPerSecond = 0.25
+    ps = H.ParticleSystem(engine, cfg)
+    tw, th = 13, 6                                            # => 16 particles per row, 8 rows per instance
+    levels = scenes.pattern_mip_chain(scenes.uniform(77, (th, tw, 4), 0.2, 1.0))
+    sp = H.PatternSpawner(3)
+    sp.SetTexture(levels)
+    assert (sp.ParticlesPerRow, sp.RowsPerInstance, sp.ParticlesPerInstance) == (16, 8, 128) == scenes.pattern_counts(tw, th) + (128,)
+    sp.MinRate = sp.MaxRate = 61.0                            # x CountScale 16 x 1/60 s: a little over one row per step
+    f = H.Formula3(); f.Constant = [300, 200, 1]; f.RandomScale = [0.5, 0.5, 0]; f.Type = H.FormulaType.Spherical
+    sp.Position = f
+    life = H.Formula1(); life.Constant = 4.0
+    sp.Life = life
+    sp.MultiplyColorConstant = False
+    ps.AddTransform(sp)
+    chunks, rows_seen = [], []
+    for frame in range(12):
+        tp.Advance(1.0 / 60.0)
+        ps.Update(frame)
+        d = replay_pattern(ps, sp, levels, chunks, cs, rnd, oracle)
+        for k in range(d.SpawnCount):
+            rec = d.Spawns[k]
+            row = int(rec.Pattern.YOffsetsAndCoordScale[0])
+            rows_seen.append(row)
+            want = scenes.pattern_params(tw, th, 1, row, multiply_color_constant=False)
+            assert bytes(rec.Pattern) == bytes(want)
+            assert (rec.Params.ChunkSizeAndIndices[2] - rec.Params.ChunkSizeAndIndices[1] + 1) % 16 == 0     # whole rows only
+    hctx.Sync()
+    assert rows_seen == [r % 8 for r in range(len(rows_seen))] and len(rows_seen) >= 10
+    assert sp.TotalSpawned % 16 == 0 and sp.TotalSpawned >= 160
+    live = compare_system(ps, chunks)
+    assert 0 < live <= sp.TotalSpawned
+
+
+def test_pattern_spawner_whole_instances(H, hctx, oracle):
+    """WholeSpawn + InstantInitialSpawn (AdjustCurrentRate, SpecialSpawners.cs:141-160): a full instance on the first tick the spawner
+    runs, later instances only once the rate has accumulated ParticlesPerInstance; MaximumTotal counts instances."""
+    cs = 32
+    engine, tp, rnd = make_engine(H, hctx, cs)
+    ps = H.ParticleSystem(engine, H.ParticleSystemConfiguration())
+    tw, th = 16, 8
+    levels = scenes.pattern_mip_chain(scenes.uniform(78, (th, tw, 4), 0.2, 1.0))
+    sp = H.PatternSpawner(3)
+    sp.SetTexture(levels)
+    sp.Divisor = 2                                           # 8 x 4 = 32 particles per instance, colours from mip level 1
+    assert sp.Divisor == 2 and sp.ParticlesPerInstance == 32
+    sp.Divisor = 99
+    assert sp.Divisor == 10                                  # Arithmetic.Clamp(value, 1, 10)
+    sp.Divisor = 2
+    sp.WholeSpawn = True
+    sp.MaximumTotal = 3
+    sp.MinRate = sp.MaxRate = 6.0                            # x 32 x 1/60 = 3.2 per tick: ten ticks per instance
+    f = H.Formula3(); f.Constant = [300, 200, 1]; f.Type = H.FormulaType.Linear
+    sp.Position = f
+    ps.AddTransform(sp)
+    chunks, totals = [], []
+    for frame in range(40):
+        tp.Advance(1.0 / 60.0)
+        ps.Update(frame)
+        replay_pattern(ps, sp, levels, chunks, cs, rnd, oracle)
+        totals.append(sp.TotalSpawned)
+    hctx.Sync()
+    assert totals[0] == 32                                   # instant initial spawn
+    assert all(t % 32 == 0 for t in totals) and totals[-1] == 96 and totals[5] == 32     # MaximumTotal 3 instances, none early
+    assert sp.RowsSpawned == 0
+    live = compare_system(ps, chunks)
+    assert live == 96

@@ -24,7 +24,7 @@ def random_matrix(seed, scale=0.2, perspective=False):
     return abi.Matrix.from_rows(m.tolist())
 
 
-def run_both(ctx, oracle, cs, n_chunks, desc, seed=3, dead_fraction=0.2, spawn_positions=None):
+def run_both(ctx, oracle, cs, n_chunks, desc, seed=3, dead_fraction=0.2, spawn_positions=None, spawn_pattern=None):
     rnd = scenes.randomness_table(seed)
     eng = native.Engine(ctx, cs, rnd)
     sysm = native.System(eng)
@@ -39,9 +39,12 @@ def run_both(ctx, oracle, cs, n_chunks, desc, seed=3, dead_fraction=0.2, spawn_p
         chunks.append([pos.copy(), vel.copy(), attr.copy(), np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)])
     if spawn_positions is not None:
         sysm.set_spawn_positions(0, spawn_positions)
+    if spawn_pattern is not None:
+        sysm.set_spawn_pattern(0, spawn_pattern)
     desc.Flags = abi.STEP_COUNT_LIVE
     sysm.step(desc)
-    want_counts = oracle.step(chunks, cs, rnd, desc, want_counts=True, spawn_positions={0: spawn_positions} if spawn_positions is not None else None)
+    want_counts = oracle.step(chunks, cs, rnd, desc, want_counts=True, spawn_positions={0: spawn_positions} if spawn_positions is not None else None,
+                              spawn_patterns={0: spawn_pattern} if spawn_pattern is not None else None)
     got_counts = sysm.step_counts()
     got = [[sysm.download(c, pl) for pl in (P, V, A, RC, RD)] for c in range(n_chunks)]
     sysm.close(); eng.close()
@@ -165,6 +168,60 @@ def test_position_buffer_spawner_matches_oracle(ctx, oracle):
         d.Spawns[0].Params = p
         got, want, gc, wc = run_both(ctx, oracle, cs, 2, d, dead_fraction=0.6, spawn_positions=buf)
         compare(got, want, gc, wc)
+
+
+@pytest.mark.parametrize("divisor,top_left,size_px,multiply", [(1, None, None, True), (2, None, None, False), (3, (5, 3), (30, 18), True),
+                                                               (4, None, None, True)])
+def test_pattern_spawner_matches_oracle(ctx, oracle, divisor, top_left, size_px, multiply):
+    """PatternSpawner.fx:21-97 on a 37 x 23 texture with a full mip chain: whole-instance and single-row spawns, every Divisor's mip
+    level, a sub-rectangle, spherical position / velocity formulas, the alpha discard."""
+    cs = 64
+    tw, th = 37, 23
+    texels = scenes.uniform(900, (th, tw, 4), 0.0, 1.0)
+    texels[::5, ::7, 3] = 0.0          # some transparent pixels: rejected by the attribute discard threshold
+    levels = scenes.pattern_mip_chain(texels)
+    per_row, rows = scenes.pattern_counts(tw, th, divisor, top_left, size_px)
+    for current_row, count in ((0, per_row * rows), (min(2, rows - 1), per_row)):
+        first = 300
+        p = scenes.spawn_params(cs, first, first + count - 1, 0, (0.31 * 253, 0.58 * 127),
+                                position=((500, 400, 2), (3, 3, 1), (0, 0, 0), scenes.FORMULA_SPHERICAL),
+                                velocity=((1, 2, 3), (40, 40, 40), (0, 0, 0), scenes.FORMULA_SPHERICAL), life=(2.5, 1.5, 0.0),
+                                color=((0.9, 0.8, 0.7, 1.0) if multiply else (0.05, 0.0, 0.1, 0.0), (0.1, 0.1, 0.1, 0.0), (0, 0, 0, 0)),
+                                alpha_discard_threshold=8.0)
+        d = abi.StepDesc()
+        d.FirstChunk, d.ChunkCount = 0, -1
+        d.System = scenes.system_uniforms(cs)
+        d.Update = abi.UpdateParams.default()
+        d.UpdateMode = abi.UPDATE_POSITIONS
+        d.SpawnCount = 1
+        d.Spawns[0].ChunkIndex = 1
+        d.Spawns[0].Kind = abi.SPAWN_PATTERN
+        d.Spawns[0].Params = p
+        d.Spawns[0].Pattern = scenes.pattern_params(tw, th, divisor, current_row, top_left, size_px, multiply_color_constant=multiply)
+        got, want, gc, wc = run_both(ctx, oracle, cs, 2, d, dead_fraction=1.0, spawn_pattern=levels)
+        compare(got, want, gc, wc)
+        assert 0 < wc[1] <= count      # something spawned; transparent / out-of-texture particles did not
+
+
+def test_pattern_spawner_requires_a_texture(ctx):
+    cs = 16
+    eng = native.Engine(ctx, cs, scenes.randomness_table(7))
+    sysm = native.System(eng)
+    sysm.add_chunk()
+    d = tc.base_desc(1 / 60)
+    d.SpawnCount = 1
+    d.Spawns[0].Kind = abi.SPAWN_PATTERN
+    d.Spawns[0].Params = scenes.spawn_params(cs, 0, 31, 0, (1.0, 2.0))
+    d.Spawns[0].Pattern = scenes.pattern_params(8, 4)
+    with pytest.raises(native.IlluminantError) as e:
+        sysm.step(d)
+    assert e.value.code == abi.ERR_STATE
+    sysm.set_spawn_pattern(0, scenes.pattern_mip_chain(np.ones((4, 8, 4), np.float32), levels=1))
+    sysm.step(d)
+    sysm.set_spawn_pattern(0, None)
+    with pytest.raises(native.IlluminantError):
+        sysm.step(d)
+    sysm.close(); eng.close()
 
 
 def test_feedback_spawner_matches_oracle(ctx, oracle):

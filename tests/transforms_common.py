@@ -29,11 +29,12 @@ class OracleBackend:
     def __init__(self, oracle):
         self.orc = oracle
 
-    def run(self, desc, rnd, chunk, spawn_positions=None, source_chunk=None):
+    def run(self, desc, rnd, chunk, spawn_positions=None, source_chunk=None, spawn_pattern=None):
         planes = [chunk[0].copy(), chunk[1].copy(), chunk[2].copy(), np.zeros_like(chunk[0]), np.zeros_like(chunk[0])]
         fb = {0: source_chunk} if source_chunk is not None else None
         sp = {0: spawn_positions} if spawn_positions is not None else None
-        self.orc.step([planes], CS, rnd, desc, spawn_positions=sp, feedback_sources=fb)
+        pt = {0: spawn_pattern} if spawn_pattern is not None else None
+        self.orc.step([planes], CS, rnd, desc, spawn_positions=sp, feedback_sources=fb, spawn_patterns=pt)
         return planes
 
 
@@ -45,7 +46,7 @@ class GpuBackend:
         self.native = native
         self.ctx = ctx
 
-    def run(self, desc, rnd, chunk, spawn_positions=None, source_chunk=None):
+    def run(self, desc, rnd, chunk, spawn_positions=None, source_chunk=None, spawn_pattern=None):
         native = self.native
         eng = native.Engine(self.ctx, CS, rnd)
         sysm = native.System(eng)
@@ -62,6 +63,8 @@ class GpuBackend:
             desc.Spawns[0].Feedback.SourceChunkIndex = 0
         if spawn_positions is not None:
             sysm.set_spawn_positions(0, spawn_positions)
+        if spawn_pattern is not None:
+            sysm.set_spawn_pattern(0, spawn_pattern)
         sysm.step(desc)
         out = [sysm.download(0, p) for p in (abi.PLANE_POSITION, abi.PLANE_VELOCITY, abi.PLANE_ATTRIBUTES)]
         for x in (src, sysm, eng):
@@ -152,5 +155,28 @@ def check_case(case, backend):
                 continue
             assert_close(out[0][slot], [src_pos[source, 0], src_pos[source, 1], src_pos[source, 2], 1.5], "feedback position %d" % slot, rtol=1e-6)
             assert_close(out[1][slot][:3], src_vel[source, :3] * case["source_velocity_factor"], "feedback velocity %d" % slot, rtol=1e-6)
+    elif kind == "pattern":
+        d = base_desc(1.0 / 60.0)
+        levels = [np.asarray(l, np.float32) for l in case["texture_levels"]]
+        th, tw = levels[0].shape[0], levels[0].shape[1]
+        p = scenes.spawn_params(CS, case["first"], case["last"], 0, (0.2 * 253, 0.7 * 127),
+                                position=(tuple(case["position_constant"]), (0, 0, 0), (0, 0, 0), scenes.FORMULA_LINEAR),
+                                velocity=((0, 0, 0), (0, 0, 0), (0, 0, 0), scenes.FORMULA_LINEAR), life=(case["life"], 0.0, 0.0),
+                                color=(tuple(case["color_constant"]), (0, 0, 0, 0), (0, 0, 0, 0)))
+        d.SpawnCount = 1
+        d.Spawns[0].ChunkIndex = 0
+        d.Spawns[0].Kind = abi.SPAWN_PATTERN
+        d.Spawns[0].Params = p
+        d.Spawns[0].Pattern = scenes.pattern_params(tw, th, case["divisor"], case["current_row"], multiply_color_constant=case["multiply"])
+        old = filled([-1, -1, -1, 0])
+        old_attr = filled([9, 9, 9, 9])
+        out = backend.run(d, rnd, (old, filled([0, 0, 0, 0]), old_attr), spawn_pattern=levels)
+        for e in case["expected"]:
+            assert_close(out[0][e["slot"]], e["position"], "%s: position of slot %d" % (case["name"], e["slot"]), rtol=1e-6)
+            assert_close(out[2][e["slot"]], e["attributes"], "%s: attributes of slot %d" % (case["name"], e["slot"]), rtol=1e-5)
+        written = {e["slot"] for e in case["expected"]}
+        untouched = [i for i in range(CS * CS) if i not in written]
+        assert set(case["rejected_slots"]) <= set(untouched)
+        assert np.array_equal(out[0][untouched], old[untouched]) and np.array_equal(out[2][untouched], old_attr[untouched])
     else:
         raise AssertionError("unknown fixture kind %r" % kind)
