@@ -75,6 +75,7 @@ struct Engine {
     int chunk_size = 0, slots = 0;
     int64_t stride = 0;
     float4* rnd = nullptr; int rw = 0, rh = 0;
+    std::vector<float4> h_rnd;   // host copy: the uniform noise deltas are evaluated on the host (fill_noise_fast)
     uint2* rnd_lp = nullptr;   // LowPrecisionRandomnessTexture: the Rgba64 copy (ParticleEngine.cs:508-540)
 };
 
@@ -273,6 +274,108 @@ int32_t validate_step(const System* s, const IlmStepDesc* d, int* first, int* co
     return ILM_OK;
 }
 
+// The coordinate -> texel map of one axis of Noise's table lookups (randomCustom with rate = texel, RandomCommon.fxh:27-30,
+// Noise.fx:49-52), evaluated with the operations of particles.hip random_custom in the same order (this file is compiled with
+// -ffp-contract=off, like that function's fenced body).
+static float noise_axis_texel(float coordinate, float texel, float offset, int size) {
+    const float u = ((coordinate * texel) + offset) * texel;
+    return floorf(u * (float)size);
+}
+
+// Steps of one axis of the map over coordinates [0, last]: at most two (false otherwise, or when the texel values are too large
+// for exact integer arithmetic).  run k covers [flips[k-1], flips[k]) and reads the WRAPped texel index texels[k].
+static bool noise_axis_runs(float texel, float offset, int size, int last, int32_t flips[2], int32_t texels[3]) {
+    flips[0] = flips[1] = INT32_MAX;
+    texels[0] = texels[1] = texels[2] = 0;
+    int begin = 0;
+    for (int run = 0; run < 3; run++) {
+        const float value = noise_axis_texel((float)begin, texel, offset, size);
+        if (!(std::fabs(value) < 4194304.0f)) return false;      // also rejects NaN / infinity
+        const long long v = (long long)value;
+        texels[run] = (int32_t)(((v % size) + size) % size);    // WRAP addressing
+        if (noise_axis_texel((float)last, texel, offset, size) == value) return true;
+        if (run == 2) return false;                               // a third step
+        // smallest coordinate in (begin, last] whose texel differs: the map is monotone, so bisect
+        int lo = begin, hi = last;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) / 2;
+            if (noise_axis_texel((float)mid, texel, offset, size) == value) lo = mid; else hi = mid;
+        }
+        flips[run] = hi;
+        begin = hi;
+    }
+    return true;
+}
+
+static int run_of(const int32_t flips[2], int coordinate) { return (coordinate >= flips[0] ? 1 : 0) + (coordinate >= flips[1] ? 1 : 0); }
+
+static float host_lerp(float a, float b, float t) { return a + (b - a) * t; }
+// noise_shape of particles.hip (Noise.fx:53-60): sign(d) * max(|d|, minimum) * scale with HLSL's sign(0) = 0
+static float host_noise_shape(float r, float offset, float minimum, float scale) {
+    const float d = r + offset;
+    const float m = std::fmax(std::fabs(d), minimum);
+    return ((d == 0.0f) ? 0.0f * m : std::copysign(m, d)) * scale;
+}
+
+// StepDerived::NoiseFast for one Noise op (see internal.hpp).  Coordinates a chunk can ask for: x in [0, chunk_size + 1],
+// y in [0, chunk_size] (the second sample pair sits at (x + 2, y + 1)).  false when the fast path does not apply: a wave would span
+// several rows, or the runs of the two sample sets combine into more than three classes along an axis.
+static bool fill_noise_fast(StepDerived& dv, const IlmNoiseParams& p, int chunk_size, const std::vector<float4>& table, int rw, int rh) {
+    StepDerived::NoiseFast& nf = dv.noise;
+    if (chunk_size % 64 != 0 || chunk_size / 64 > 16 || table.empty()) return false;
+    int32_t xf[2][2], yf[2][2], tx[2][3], ty[2][3];
+    for (int s = 0; s < 2; s++) {
+        const float* off = (s == 0) ? p.RandomnessOffset : p.NextRandomnessOffset;
+        if (!noise_axis_runs(dv.inv_rw, off[0], rw, chunk_size + 1, xf[s], tx[s])) return false;
+        if (!noise_axis_runs(dv.inv_rh, off[1], rh, chunk_size, yf[s], ty[s])) return false;
+    }
+    // classes along an axis = the intervals between the steps of either sample set
+    auto merge = [](const int32_t a[2], const int32_t b[2], int32_t out[2]) {
+        int32_t all[4] = { a[0], a[1], b[0], b[1] };
+        std::sort(all, all + 4);
+        const int n = (int)(std::unique(all, all + 4) - all);
+        int m = 0;
+        for (int i = 0; i < n; i++)
+            if (all[i] != INT32_MAX) { if (m == 2) return false; out[m++] = all[i]; }
+        for (; m < 2; m++) out[m] = INT32_MAX;
+        return true;
+    };
+    int32_t xb[2];
+    if (!merge(xf[0], xf[1], xb) || !merge(yf[0], yf[1], nf.yb)) return false;
+    for (int w = 0; w < 16; w++) {
+        nf.wcode[w] = 0;
+        if (w * 64 >= chunk_size) continue;
+        const int x0 = w * 64;
+        bool usable = true;
+        for (int k = 0; k < 2; k++)
+            if (xb[k] != INT32_MAX && ((xb[k] > x0 && xb[k] <= x0 + 63) || (xb[k] > x0 + 2 && xb[k] <= x0 + 65))) usable = false;
+        nf.wcode[w] = (usable ? 16u : 0u) | (uint32_t)run_of(xb, x0) | ((uint32_t)run_of(xb, x0 + 2) << 2);
+    }
+    // one representative coordinate per class: its first
+    for (int yc = 0; yc < 3; yc++)
+        for (int xc = 0; xc < 3; xc++) {
+            const int x = (xc == 0) ? 0 : xb[xc - 1], y = (yc == 0) ? 0 : nf.yb[yc - 1];
+            float4 pd = make_float4(0, 0, 0, 0), vd = pd;
+            if (x != INT32_MAX && y != INT32_MAX) {
+                const float4 a = table[(size_t)ty[0][run_of(yf[0], y)] * (size_t)rw + (size_t)tx[0][run_of(xf[0], x)]];
+                const float4 b = table[(size_t)ty[1][run_of(yf[1], y)] * (size_t)rw + (size_t)tx[1][run_of(xf[1], x)]];
+                const float f = p.FrequencyLerp;
+                // class (yc, xc) read as the (x, y) pair gives positionDelta, read as the (x + 2, y + 1) pair velocityDelta
+                pd = make_float4(host_noise_shape(host_lerp(a.x, b.x, f), p.PositionOffset.x, p.PositionMinimum.x, p.PositionScale.x),
+                                 host_noise_shape(host_lerp(a.y, b.y, f), p.PositionOffset.y, p.PositionMinimum.y, p.PositionScale.y),
+                                 host_noise_shape(host_lerp(a.z, b.z, f), p.PositionOffset.z, p.PositionMinimum.z, p.PositionScale.z),
+                                 host_noise_shape(host_lerp(a.w, b.w, f), p.PositionOffset.w, p.PositionMinimum.w, p.PositionScale.w));
+                vd = make_float4(host_noise_shape(host_lerp(a.x, b.x, f), p.VelocityOffset.x, p.VelocityMinimum.x, p.VelocityScale.x),
+                                 host_noise_shape(host_lerp(a.y, b.y, f), p.VelocityOffset.y, p.VelocityMinimum.y, p.VelocityScale.y),
+                                 host_noise_shape(host_lerp(a.z, b.z, f), p.VelocityOffset.z, p.VelocityMinimum.z, p.VelocityScale.z),
+                                 host_noise_shape(host_lerp(a.w, b.w, f), p.VelocityOffset.w, p.VelocityMinimum.w, p.VelocityScale.w));
+            }
+            nf.position[yc][xc] = { pd.x, pd.y, pd.z, pd.w };
+            nf.velocity[yc][xc] = { vd.x, vd.y, vd.z, vd.w };
+        }
+    return true;
+}
+
 int32_t run_step(System* s, const IlmStepDesc* d) {
     int first = 0, count = 0;
     int32_t rc = validate_step(s, d, &first, &count);
@@ -329,6 +432,12 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
         dv.cs_shift = -1;
         for (int b = 0; b < 31; b++)
             if ((1 << b) == e->chunk_size) dv.cs_shift = b;
+        dv.noise.op = -1;
+        for (int o = 0; o < d->OpCount && dv.noise.op < 0; o++)
+            if (d->Ops[o].Type == ILM_OP_NOISE) {
+                if (fill_noise_fast(dv, d->Ops[o].u.Noise, e->chunk_size, e->h_rnd, e->rw, e->rh)) dv.noise.op = o;
+                else break;     // only the first Noise op is considered
+            }
         for (int o = 0; o < d->OpCount; o++) {
             const IlmTransformOp& op = d->Ops[o];
             if (op.Type == ILM_OP_GRAVITY) {
@@ -541,6 +650,7 @@ int32_t ilm_engine_create(IlmHandle hctx, int32_t chunk_size, const IlmFloat4* r
     const size_t bytes = sizeof(float4) * (size_t)rw * (size_t)rh;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->rnd), bytes));
     HIP_TRY(hipMemcpy(e->rnd, randomness, bytes, hipMemcpyHostToDevice));
+    e->h_rnd.assign(reinterpret_cast<const float4*>(randomness), reinterpret_cast<const float4*>(randomness) + (size_t)rw * (size_t)rh);
     {   // new Rgba64(Vector4) per texel (ParticleEngine.cs:536-538): round-half-even of clamp(v, 0, 1) * 65535 per channel
         std::vector<uint16_t> lp((size_t)rw * (size_t)rh * 4);
         const float* f = reinterpret_cast<const float*>(randomness);

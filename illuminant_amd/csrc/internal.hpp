@@ -37,6 +37,21 @@ struct StepDerived {
     float inv_rw, inv_rh;        // RandomnessTexel = 1 / (807, 653)                         (RandomCommon.fxh:12-15)
     int32_t cs_shift;            // log2(chunk_size) when it is a power of two, else -1
     int32_t noise_may_revive;    // some Noise op can change the life of a dead slot (see api.hip); 0 => dead slots skip the transforms
+    // Noise.fx:49-52 samples the randomness table at uv = ((xy * RandomnessTexel) + offset) * RandomnessTexel: the slot coordinate is
+    // scaled by the texel size TWICE, so the texel column only steps once per 807 slots along x (the row once per 653 along y) and
+    // a whole wave of 64 consecutive slots almost always reads ONE texel in each of the four lookups -- positionDelta and
+    // velocityDelta (Noise.fx:49-60) are then the same for all 64 slots.  The map coordinate -> texel index is monotone (a chain
+    // of monotone float operations), i.e. a step function; the host finds its steps with the same IEEE operations, evaluates the
+    // two deltas for every combination of runs (api.hip, fill_noise_fast) and the wave picks its pair with scalar integer code.
+    // A wave with a step inside it keeps the per-slot lookups.
+    struct NoiseFast {
+        int32_t op;              // index of the (first) Noise op this describes; -1: none / not applicable (then nothing else is read)
+        int32_t yb[2];           // rows where a sample's texel row steps (INT32_MAX: no such step): y class = #(yb <= row)
+        uint32_t wcode[16];      // per 64-slot column w of a chunk row: bit 4 = usable, bits 0-1 = x class of the (x, y) samples,
+                                 // bits 2-3 = x class of the (x + 2, y + 1) samples
+        IlmFloat4 position[3][3];   // positionDelta [y class of row][x class]
+        IlmFloat4 velocity[3][3];   // velocityDelta [y class of row + 1][x class]
+    } noise;
     struct Op {
         int32_t area_none;       // AreaType outside 1..5: evaluateByTypeId returns 0 => weight == Strength exactly
         float   t;               // Noise / FMA with area_none: weight * dtMs / TimeDivisor
@@ -72,6 +87,7 @@ struct StepLaunch {
     // Work is cut into units of one wave (64 consecutive slots); unit = chunk_rel * units_per_chunk + segment.
     // Filled by launch_step.
     int32_t units_per_chunk;     // stride / 64
+    int32_t upc_shift;           // log2(units_per_chunk) when it is a power of two, else -1
     int32_t unit_begin, unit_end;        // global unit range [begin, end) of this launch
     int32_t unit_rotate, total_padded;   // block b starts at unit (b * 4 + unit_rotate) mod total_padded
 };

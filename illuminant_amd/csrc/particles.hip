@@ -131,22 +131,40 @@ ILM_DEV float4 noise_shape(float4 r, const IlmFloat4& offset, const IlmFloat4& m
                sign_times(d.z, fmaxf(fabsf(d.z), minimum.z)) * scale.z, sign_times(d.w, fmaxf(fabsf(d.w), minimum.w)) * scale.w);
 }
 
+// The two noise vectors of a wave whose 64 slots read the same texel in each of the four table lookups
+// (StepDerived::NoiseFast): uniform values, held in SGPRs.
+struct NoiseDeltas {
+    bool valid;
+    float4 position, velocity;
+};
+
+// positionDelta / velocityDelta of Noise.fx:49-60 from the four table samples
+ILM_DEV void noise_deltas(float4 p1, float4 p2, float4 v1, float4 v2, const IlmNoiseParams& p, float4& position_delta, float4& velocity_delta) {
+    position_delta = noise_shape(lerp4(p1, p2, p.FrequencyLerp), p.PositionOffset, p.PositionMinimum, p.PositionScale);
+    velocity_delta = noise_shape(lerp4(v1, v2, p.FrequencyLerp), p.VelocityOffset, p.VelocityMinimum, p.VelocityScale);
+}
+
 // PS_Noise, Noise.fx:28-72 (no life check: dead slots go through the math, :40)
 ILM_DEV void apply_noise(float4& pos, float4& vel, float x, float y, const float4* __restrict__ rnd, int rw, int rh,
-                         const IlmParticleSystemUniforms& sys, const IlmNoiseParams& p, const StepDerived& sd, const StepDerived::Op& dv) {
+                         const IlmParticleSystemUniforms& sys, const IlmNoiseParams& p, const StepDerived& sd, const StepDerived::Op& dv,
+                         const NoiseDeltas& uniform) {
     if (!category_ok(vel.w, p.Area.CategoryFilter))
         return;
     float weight, t;
     area_weight_and_t(p.Area, dv, xyz(pos), sys.GlobalSettings.x, p.TimeDivisor, weight, t);
 
-    const float rate_x = sd.inv_rw, rate_y = sd.inv_rh;  // rate = RandomnessTexel (Noise.fx:49-52)
-    const float4 p1 = random_custom(rnd, rw, rh, rate_x, rate_y, x, y, p.RandomnessOffset[0], p.RandomnessOffset[1], rate_x, rate_y);
-    const float4 p2 = random_custom(rnd, rw, rh, rate_x, rate_y, x, y, p.NextRandomnessOffset[0], p.NextRandomnessOffset[1], rate_x, rate_y);
-    const float4 v1 = random_custom(rnd, rw, rh, rate_x, rate_y, x + 2.0f, y + 1.0f, p.RandomnessOffset[0], p.RandomnessOffset[1], rate_x, rate_y);
-    const float4 v2 = random_custom(rnd, rw, rh, rate_x, rate_y, x + 2.0f, y + 1.0f, p.NextRandomnessOffset[0], p.NextRandomnessOffset[1], rate_x, rate_y);
-
-    const float4 position_delta = noise_shape(lerp4(p1, p2, p.FrequencyLerp), p.PositionOffset, p.PositionMinimum, p.PositionScale);
-    const float4 velocity_delta = noise_shape(lerp4(v1, v2, p.FrequencyLerp), p.VelocityOffset, p.VelocityMinimum, p.VelocityScale);
+    float4 position_delta, velocity_delta;
+    if (uniform.valid) {
+        position_delta = uniform.position;
+        velocity_delta = uniform.velocity;
+    } else {
+        const float rate_x = sd.inv_rw, rate_y = sd.inv_rh;  // rate = RandomnessTexel (Noise.fx:49-52)
+        const float4 p1 = random_custom(rnd, rw, rh, rate_x, rate_y, x, y, p.RandomnessOffset[0], p.RandomnessOffset[1], rate_x, rate_y);
+        const float4 p2 = random_custom(rnd, rw, rh, rate_x, rate_y, x, y, p.NextRandomnessOffset[0], p.NextRandomnessOffset[1], rate_x, rate_y);
+        const float4 v1 = random_custom(rnd, rw, rh, rate_x, rate_y, x + 2.0f, y + 1.0f, p.RandomnessOffset[0], p.RandomnessOffset[1], rate_x, rate_y);
+        const float4 v2 = random_custom(rnd, rw, rh, rate_x, rate_y, x + 2.0f, y + 1.0f, p.NextRandomnessOffset[0], p.NextRandomnessOffset[1], rate_x, rate_y);
+        noise_deltas(p1, p2, v1, v2, p, position_delta, velocity_delta);
+    }
 
     float4 np = lerp4(pos, add4(pos, position_delta), t);
     np.w = lerp_exact(pos.w, pos.w + position_delta.w, t);   // life
@@ -158,6 +176,19 @@ ILM_DEV void apply_noise(float4& pos, float4& vel, float x, float y, const float
     nv = nv + (norm3_fast(xyz(vel)) * velocity_delta.w);
     pos = np;
     vel = mk4(nv.x, nv.y, nv.z, vel.w);
+}
+
+// The wave-uniform form of the four lookups (StepDerived::NoiseFast): (x0, row) = slot coordinates of the wave's first lane, the wave
+// covers x0 .. x0 + 63 of that row (chunk size a multiple of 64).  Scalar integer code only; the deltas arrive in SGPRs.
+ILM_DEV NoiseDeltas noise_prepare(const StepDerived::NoiseFast& nf, int x0, int row) {
+    NoiseDeltas out;
+    const uint32_t code = nf.wcode[x0 >> 6];
+    out.valid = (code & 16u) != 0u;
+    const int yc0 = ((row >= nf.yb[0]) ? 1 : 0) + ((row >= nf.yb[1]) ? 1 : 0);
+    const int yc1 = ((row + 1 >= nf.yb[0]) ? 1 : 0) + ((row + 1 >= nf.yb[1]) ? 1 : 0);
+    out.position = ld4(nf.position[yc0][code & 3u]);
+    out.velocity = ld4(nf.velocity[yc1][(code >> 2) & 3u]);
+    return out;
 }
 
 // mul3, ParticleCommon.fxh:183-196
@@ -818,7 +849,7 @@ typedef const StepLaunch __attribute__((address_space(4))) CStepLaunch;
 // DF: the update pass is UpdateWithDistanceField (pulls in the SDF sampler); SPAWN: spawn records present.
 // Both are compile-time so the common no-field / no-spawn step does not pay their registers.
 template <int FMT, bool DF, bool SPAWN, bool EXT>
-ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* ub, int chunk, int i, unsigned lane, int seg, SlotIn cur) {
+ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* ub, int chunk, int i, unsigned lane, int seg, SlotIn cur, const NoiseDeltas& noise) {
     const StepLaunch& a = *(const StepLaunch*)ap;
     const IlmStepDesc& d = a.desc;
     const int64_t S = a.stride;
@@ -897,7 +928,8 @@ ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* ub, int chunk, int i, unsigne
             if (op.Type == ILM_OP_GRAVITY)
                 apply_gravity(pos, vel, d.System, op.u.Gravity, a.derived.op[o]);
             else if (op.Type == ILM_OP_NOISE)
-                apply_noise(pos, vel, fx, fy, a.rnd, a.rw, a.rh, d.System, op.u.Noise, a.derived, a.derived.op[o]);
+                apply_noise(pos, vel, fx, fy, a.rnd, a.rw, a.rh, d.System, op.u.Noise, a.derived, a.derived.op[o],
+                            (o == a.derived.noise.op) ? noise : NoiseDeltas{ false, zero, zero });
             else if (op.Type == ILM_OP_FMA)
                 apply_fma(pos, vel, d.System, op.u.FMA, a.derived.op[o]);
             else if (EXT && op.Type == ILM_OP_MATRIX_MULTIPLY)
@@ -958,7 +990,8 @@ __global__ __launch_bounds__(kStepThreads, MINW) void step_kernel(const StepLaun
     const bool active = (v + wave * K) < total;
     uint32_t n_live = 0;
     if (active) {
-        const int chunk_rel = u / a.units_per_chunk;
+        // (a scalar integer division costs ~35 instructions per wave)
+        const int chunk_rel = (a.upc_shift >= 0) ? (u >> a.upc_shift) : (u / a.units_per_chunk);
         const int seg = u - chunk_rel * a.units_per_chunk;
         const int chunk = a.first_chunk + chunk_rel;
         // never-written tail of a spawn-target chunk: all planes are zero and stay zero (scalar compares, uniform branch)
@@ -978,7 +1011,15 @@ __global__ __launch_bounds__(kStepThreads, MINW) void step_kernel(const StepLaun
             const SlotIn cur = q[0];
 #pragma unroll
             for (int r = 0; r + 1 < K; r++) q[r] = q[r + 1];
-            const bool live_after = process_unit<FMT, DF, SPAWN, EXT>(ap, ub + j * 64, chunk, (seg + j) * 64 + (int)lane, lane, seg + j, cur);
+            NoiseDeltas noise;
+            noise.valid = false;
+            if (a.derived.noise.op >= 0) {
+                // first slot of the unit -> (x0, y): scalar; the unit lies in one row (chunk size a multiple of 64)
+                const int first = (seg + j) * 64;
+                const int row = (a.derived.cs_shift >= 0) ? (first >> a.derived.cs_shift) : (first / a.chunk_size);
+                noise = noise_prepare(((const StepLaunch*)ap)->derived.noise, first - row * a.chunk_size, row);
+            }
+            const bool live_after = process_unit<FMT, DF, SPAWN, EXT>(ap, ub + j * 64, chunk, (seg + j) * 64 + (int)lane, lane, seg + j, cur, noise);
             n_live += (uint32_t)__popcll(__ballot(live_after));
         }
         }
@@ -997,7 +1038,7 @@ __global__ __launch_bounds__(kStepThreads, MINW) void step_kernel(const StepLaun
 #pragma unroll
             for (int w = 0; w < kStepThreads / 64; w++) block_live += wave_live[w];
             const int first_unit = a.unit_begin + v;
-            const int c = a.first_chunk + first_unit / a.units_per_chunk;
+            const int c = a.first_chunk + ((a.upc_shift >= 0) ? (first_unit >> a.upc_shift) : (first_unit / a.units_per_chunk));
             if (block_live != 0)
                 atomicAdd(&a.live_counts[c * kCountStride], block_live);
         }
@@ -1061,6 +1102,9 @@ static hipError_t launch_step_variant(const StepLaunch& a, hipStream_t stream) {
 // present the SPAWN variant runs (for every unit) and the grid is rotated to start at the first spawn range.
 hipError_t launch_step(StepLaunch& a, hipStream_t stream) {
     a.units_per_chunk = (int)(a.stride / 64);
+    a.upc_shift = -1;
+    for (int b = 0; b < 31; b++)
+        if ((1 << b) == a.units_per_chunk) a.upc_shift = b;
     a.unit_begin = 0;
     a.unit_end = a.chunk_count * a.units_per_chunk;
     const int waves_per_block = (kStepThreads / 64) * kUnitsPerWave;   // units per block

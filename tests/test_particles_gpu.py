@@ -110,6 +110,43 @@ def test_noise_matches_oracle(ctx, oracle, rnd, replace):
     sysm.close(); eng.close()
 
 
+def noise_offset_with_step_at(coordinate, size, whole=5):
+    """A RandomnessOffset component that makes the table index floor(offset + c / size) step between coordinate - 1 and coordinate
+    (Noise.fx:49-52 scales the slot coordinate by the texel size twice, so the index moves one texel per `size` slots)."""
+    return float(whole) - (coordinate - 0.5) / size
+
+
+@pytest.mark.parametrize("cs,x_cur,x_next,y_cur,y_next", [
+    (128, 1, None, None, None), (128, 2, 3, None, None), (128, 63, 64, None, None), (128, 65, 66, 1, None), (128, 127, 128, 64, 65),
+    (128, 129, None, 127, 128), (128, None, 130, None, 129), (64, 62, 2, 63, 64), (256, 200, 100, 255, 3),
+    (1024, 300, 900, 500, 1000),        # 807 < 1024: the second set steps at 93 and 900 => three steps in a row, the wave-uniform path steps aside
+])
+def test_noise_texel_steps_inside_a_chunk(ctx, oracle, rnd, cs, x_cur, x_next, y_cur, y_next):
+    """The wave-uniform noise path (StepDerived::NoiseFast) against the per-slot oracle with the randomness-table index stepping at chosen
+    slot columns / rows: inside a wave, on wave boundaries, within the (+2, +1) shift of the second sample pair, and in both sample sets."""
+    n = cs * cs
+    pos, vel, attr = scenes.make_particles(310, n, dead_fraction=0.1)
+    su = scenes.system_uniforms(cs)
+    ox = lambda c, k: noise_offset_with_step_at(c, 807.0, k) if c is not None else k + 0.25
+    oy = lambda c, k: noise_offset_with_step_at(c, 653.0, k) if c is not None else k + 0.25
+    nz = scenes.noise_params(scenes.area_none(), (ox(x_cur, 5), oy(y_cur, 7)), (ox(x_next, 11), oy(y_next, 2)), 0.35,
+                             position=((-0.5,) * 4, (0.05,) * 4, (2.0, 2.0, 1.0, 0.0)),
+                             velocity=((-0.5,) * 3, (0.01,) * 3, (40.0, 40.0, 10.0)), speed=(-0.5, 0.0, 3.0))
+    eng, sysm = make_system(ctx, rnd, cs)
+    upload_state(sysm, 0, pos, vel, attr)
+    sysm.noise(0, su, nz)
+    got_p, got_v = sysm.download(0, P), sysm.download(0, V)
+    want_p, want_v = pos.copy(), vel.copy()
+    oracle.noise(want_p, want_v, cs, rnd, su, nz)
+    assert_close(got_p, want_p, "noise position")
+    assert_close(got_v, want_v, "noise velocity")
+    # the deltas really change across a chosen step (otherwise the test would not notice a wrong texel)
+    if x_cur is not None and 0 < x_cur < cs:
+        dx = (want_p.astype(np.float64) - pos).reshape(cs, cs, 4)[0, :, 0]
+        assert abs(dx[x_cur] - dx[x_cur - 1]) > 1e-4 * max(abs(dx[x_cur]), abs(dx[x_cur - 1]))
+    sysm.close(); eng.close()
+
+
 SPAWN_CASES = {
     "spherical": dict(position=((500, 300, 0), (900, 450, 0), (0, 0, 0), scenes.FORMULA_SPHERICAL),
                       velocity=((0, 0, 0), (60, 60, 60), (0, 0, 0), scenes.FORMULA_SPHERICAL),
