@@ -47,6 +47,18 @@ def profiled_traffic(kernel_prefix):
     return None
 
 
+def profiled_per_wave(kernel_prefix, column):
+    """Average of a per-dispatch SQ counter divided by SQ_WAVES from the newest committed PMC summary (same source and caveat as
+    profiled_traffic); None when absent."""
+    import csv
+    import glob
+    for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.csv")))):
+        for row in csv.DictReader(open(path)):
+            if row["kernel"].startswith(kernel_prefix) and row.get(column) and row.get("SQ_WAVES") and float(row["SQ_WAVES"]) > 0:
+                return {"value": float(row[column]) / float(row["SQ_WAVES"]), "source": os.path.basename(path)}
+    return None
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -141,11 +153,23 @@ def build_lighting(H, ctx, scenes, abi, width, height, n_lights, resolution, wor
         renderer.UpdateFields()
     gen_ms = ctx.TimerStop() / gen_iters
     texels = field.PhysicalSliceCount * field.SliceWidth * field.SliceHeight     # texels one full generation writes (8 B each)
+    # The field pass is arithmetic (one analytic distance function per covering obstruction, slice and texel; 8 B written per texel):
+    # its bound is vector-instruction issue, 256 CUs x 4 SIMDs x one wave64 instruction per 4 cycles at 2.4 GHz
+    # (MI355X_MICROARCH.md).  Instructions per wave come from the committed PMC profile of this same scene.
+    tiles = ((field.SliceWidth + 63) // 64) * ((field.SliceHeight + 3) // 4)
+    waves = field.PhysicalSliceCount * tiles * 4
+    valu = profiled_per_wave("ilm::render_slices_kernel<%d>" % (1 if sdf_fmt == abi.SDF_FP16 else 0), "SQ_INSTS_VALU")
+    issue_peak = 256 * 4 * 2.4e9 / 4.0 / 1e9          # G wave-instructions / s
+    issue = (waves * valu["value"] / (gen_ms * 1e-3) / 1e9) if valu else None
     gen = {"ms_per_field": round(gen_ms, 4), "atlas": "%dx%d RGBA16 (%d slices of %dx%d)" % (field.TextureWidth, field.TextureHeight, field.SliceCount, field.SliceWidth, field.SliceHeight),
            "obstructions": 256, "mtexels_per_s": round(texels / (gen_ms * 1e-3) / 1e6, 1),
-           "roofline": {"bound": "hbm", "achieved": round(texels * 8 / (gen_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(texels * 8 / (gen_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                        "kernel": "ilm::render_slices_kernel", "bytes_per_unit": 8, "units_per_launch": texels, "launch_ms": round(gen_ms, 4)}}
+           "hbm_write_gb_per_s": round(texels * 8 / (gen_ms * 1e-3) / 1e9, 1),
+           "roofline": {"bound": "valu", "achieved": round(issue, 1) if issue else None, "peak": round(issue_peak, 1), "unit": "G wave-instr/s",
+                        "frac": round(issue / issue_peak, 4) if issue else None,
+                        "kernel": "ilm::render_slices_kernel", "waves_per_launch": waves,
+                        "valu_instructions_per_wave": round(valu["value"], 1) if valu else None,
+                        "valu_source": ("profiles/%s: SQ_INSTS_VALU / SQ_WAVES" % valu["source"]) if valu else None,
+                        "launch_ms": round(gen_ms, 4)}}
     return dict(renderer=renderer, env=env, field=field, width=width, height=height, n_lights=n_lights, field_generation=gen)
 
 
