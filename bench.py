@@ -156,7 +156,7 @@ def build_lighting(H, ctx, scenes, abi, width, height, n_lights, resolution, wor
     # The field pass is arithmetic (one analytic distance function per covering obstruction, slice and texel; 8 B written per texel):
     # its bound is vector-instruction issue, 256 CUs x 4 SIMDs x one wave64 instruction per 4 cycles at 2.4 GHz
     # (MI355X_MICROARCH.md).  Instructions per wave come from the committed PMC profile of this same scene.
-    tiles = ((field.SliceWidth + 63) // 64) * ((field.SliceHeight + 3) // 4)
+    tiles = ((field.SliceWidth + 31) // 32) * ((field.SliceHeight + 7) // 8)     # one workgroup (4 waves) per 32 x 8 texels
     waves = field.PhysicalSliceCount * tiles * 4
     valu = profiled_per_wave("ilm::render_slices_kernel<%d>" % (1 if sdf_fmt == abi.SDF_FP16 else 0), "SQ_INSTS_VALU")
     issue_peak = 256 * 4 * 2.4e9 / 4.0 / 1e9          # G wave-instructions / s

@@ -376,6 +376,37 @@ static bool fill_noise_fast(StepDerived& dv, const IlmNoiseParams& p, int chunk_
     return true;
 }
 
+// Lower bound of an obstruction's distance function for the culling test of fields.hip.  p = rotateLocalPosition(world - centre, q)
+// has |p| = |q|^2 * e (e = |world - centre|).  Box, cylinder (radius |size.xy|, half height size.z), spheroid and octagon are exact
+// signed distances of a shape inside the ball of radius R around the centre, so f >= |p| - R everywhere (outside: the shape is no
+// nearer than its bounding ball; inside: the boundary is at most R - |p| away).  sdEllipsoid_improvedV2 = k0 (k0 - 1) / k1 (or
+// (k0 - 1) rmin inside) with k0 / k1 >= rmin and k0 >= |p| / rmax gives f >= (rmin / rmax) (|p| - rmax).  The margins (0.1 % on the
+// scale and on |q|^2, 0.05 units + 0.01 % on the radius) dwarf the rounding of the float evaluation; anything irregular -- a
+// non-unit quaternion, a non-positive or non-finite size -- switches the test off.
+static void fill_cull_bound(FieldObstruction& r) {
+    r.cull_inv_scale = 0.0f;
+    r.cull_radius = INFINITY;
+    r._pad2[0] = r._pad2[1] = 0.0f;
+    const double qn = (double)r.qx * r.qx + (double)r.qy * r.qy + (double)r.qz * r.qz + (double)r.qw * r.qw;
+    const double sx = r.sx, sy = r.sy, sz = r.sz;
+    if (!(std::fabs(qn - 1.0) <= 1e-3) || !(sx > 0 && sy > 0 && sz > 0) || !std::isfinite(sx + sy + sz)) return;
+    if (!std::isfinite((double)r.cx + r.cy + r.cz)) return;
+    double scale = 1.0, radius;
+    if (r.type == ILM_OBSTRUCTION_ELLIPSOID) {
+        const double rmax = std::max(sx, std::max(sy, sz)), rmin = std::min(sx, std::min(sy, sz));
+        scale = rmin / rmax;
+        radius = rmax;
+    } else if (r.type == ILM_OBSTRUCTION_OCTAGON) {
+        const double k = 1.0823922003;      // circumradius / apothem of a regular octagon
+        radius = std::sqrt(k * sx * k * sx + k * sy * k * sy + sz * sz);
+    } else {
+        radius = std::sqrt(sx * sx + sy * sy + sz * sz);
+    }
+    const double shrink = 1.0 - 1e-3;       // |q|^2 >= 1 - 1e-3
+    r.cull_inv_scale = (float)(1.0 / (scale * (1.0 - 1e-3) * shrink) * (1.0 + 1e-6));
+    r.cull_radius = (float)((radius * (1.0 + 1e-4) + 0.05) / shrink * (1.0 + 1e-6));
+}
+
 int32_t run_step(System* s, const IlmStepDesc* d) {
     int first = 0, count = 0;
     int32_t rc = validate_step(s, d, &first, &count);
@@ -1197,6 +1228,7 @@ int32_t ilm_sdf_render_slices(IlmHandle h, IlmHandle hclear, const IlmDistanceFi
         const float msize = fmaxf(fmaxf(fabsf(o.Size[0]), fabsf(o.Size[1])), fabsf(o.Size[2])) + d->MaximumEncodedDistance + 4.0f;
         r.x0 = (o.Center[0] - msize) * px_per_unit_x; r.x1 = (o.Center[0] + msize) * px_per_unit_x;
         r.y0 = (o.Center[1] - msize) * px_per_unit_y; r.y1 = (o.Center[1] + msize) * px_per_unit_y;
+        fill_cull_bound(r);
         recs.push_back(r);
     }
     std::vector<FieldVolume> vols;

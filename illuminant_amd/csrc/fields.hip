@@ -5,11 +5,12 @@
 // (Illuminant/Lighting/LightingRenderer.DistanceField.cs:80-152,347-400, techniques of
 // Illuminant/Shaders/DistanceFunction.fx:33-155 and Illuminant/Shaders/DistanceField.fx:101-115,
 // BlendFunction.Max in Illuminant/LoadMaterials.cs:164-176): every obstruction re-reads and re-writes
-// the 8-byte texel.  Here a 64x4-texel tile of one physical slice is one workgroup: wave 0 bins the
-// obstruction quads / height-volume boxes that touch the tile into an LDS list (wave64 ballot +
-// popcount), every lane walks the list with the record in SGPRs (readfirstlane index -> scalar loads),
-// keeps the four running maxima of its texel in registers and stores the texel once: the atlas is
-// written exactly once per pass (8 B / texel), a wave stores 512 contiguous bytes.
+// the 8-byte texel.  Here a 32x8-texel tile of one physical slice is one workgroup (four 8x8 waves): wave 0 bins the
+// obstruction quads / height-volume boxes that touch the tile into an LDS list (wave64 ballot + popcount), the
+// workgroup orders the list nearest-first, every lane walks it with the record in SGPRs (readfirstlane index ->
+// scalar loads), keeps the four running maxima of its texel in registers and stores the texel once: the atlas is
+// written exactly once per pass (8 B / texel).  An obstruction whose provable lower distance bound cannot raise
+// any covered texel of the wave is not evaluated at all (only the nearest surface survives a MAX blend).
 //
 // Compiled with -ffp-contract=off: every operation rounds as in the CPU oracle, so the stored codes are
 // bit-identical to it.  No MFMA (per-texel scalar distance functions), HBM-write-bound by definition
@@ -19,8 +20,11 @@
 
 namespace ilm {
 
-constexpr int kFieldTileW = 64, kFieldTileH = 4;
+// A workgroup covers 32 x 8 texels, each of its four waves an 8 x 8 square (lane = 8 * row + column): a compact footprint keeps the
+// per-texel quad-coverage tests and the culling decisions nearly wave-uniform (a 64 x 1 strip measured 47-60 % active lanes).
+constexpr int kFieldTileW = 32, kFieldTileH = 8;
 constexpr int kFieldListCapacity = 2048;
+constexpr int kFieldSortCapacity = 512;      // lists up to this length are ordered nearest-first
 
 // evaluate* by LightObstructionType (LightObstruction.cs:10-16): Ellipsoid, Box, Cylinder, Spheroid, Octagon
 // are cases 1..5 of evaluateByTypeId (DistanceFunctionCommon.fxh:170-187)
@@ -60,6 +64,8 @@ ILM_DEV uint32_t store_channel(float enc) {
 template <int FORMAT>
 __global__ __launch_bounds__(256) void render_slices_kernel(const FieldLaunch a) {
     __shared__ uint16_t list[kFieldListCapacity];
+    __shared__ float sort_key[kFieldSortCapacity];
+    __shared__ uint16_t sort_index[kFieldSortCapacity];
     __shared__ int list_count;
 
     const int tiles_x = (a.slice_w + kFieldTileW - 1) / kFieldTileW;
@@ -75,7 +81,7 @@ __global__ __launch_bounds__(256) void render_slices_kernel(const FieldLaunch a)
 
     const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
     const int tx0 = (tile % tiles_x) * kFieldTileW, ty0 = (tile / tiles_x) * kFieldTileH;
-    const int i = tx0 + lane, j = ty0 + wave;
+    const int i = tx0 + wave * 8 + (lane & 7), j = ty0 + (lane >> 3);
     const bool in_slice = (i < a.slice_w) && (j < a.slice_h);
     const int ax = slice_x + i, ay = slice_y + j;
 
@@ -95,6 +101,9 @@ __global__ __launch_bounds__(256) void render_slices_kernel(const FieldLaunch a)
     float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;   // saturate() at the target floors every write at 0
 
     // ---- analytic obstructions ----------------------------------------------------------------------
+    // tile centre in world units (for the nearest-first order of the list)
+    const float tcx = (((float)slice_x + (float)tx0 + 0.5f * (float)kFieldTileW) * a.inv_scale_x) + vpx;
+    const float tcy = (((float)slice_y + (float)ty0 + 0.5f * (float)kFieldTileH) * a.inv_scale_y) + vpy;
     for (int batch = 0; batch < a.obstruction_count; batch += kFieldListCapacity) {
         const int batch_n = min(kFieldListCapacity, a.obstruction_count - batch);
         __syncthreads();
@@ -116,11 +125,47 @@ __global__ __launch_bounds__(256) void render_slices_kernel(const FieldLaunch a)
         }
         __syncthreads();
         const int n = list_count;
+        // Nearest first (BlendFunction.Max does not care about the order): the sooner a texel's maximum is high, the more of the
+        // remaining obstructions the bound below rejects.  Rank sort by the distance of the tile centre to the bounding sphere,
+        // ties by list position; lists longer than the key buffer stay in index order.
+        const bool sorted = (n > 1) && (n <= kFieldSortCapacity);
+        if (sorted) {
+            for (int e = (int)threadIdx.x; e < n; e += 256) {
+                const FieldObstruction& R = a.obstructions[batch + list[e]];
+                const float dx = R.cx - tcx, dy = R.cy - tcy;
+                sort_key[e] = sqrtf(dx * dx + dy * dy) - ((R.cull_radius < 3.0e38f) ? R.cull_radius : 0.0f);
+            }
+            __syncthreads();
+            for (int e = (int)threadIdx.x; e < n; e += 256) {
+                const float key = sort_key[e];
+                int rank = 0;
+                for (int f = 0; f < n; f++) {
+                    const float other = sort_key[f];
+                    rank += ((other < key) || ((other == key) && (f < e))) ? 1 : 0;
+                }
+                sort_index[rank] = list[e];
+            }
+            __syncthreads();
+        }
+        const uint16_t* order = sorted ? sort_index : list;
+        const float z_low = fminf(slice_z[0], slice_z[3]), z_high = fmaxf(slice_z[0], slice_z[3]);
         for (int k = 0; k < n; k++) {
-            const int oi = __builtin_amdgcn_readfirstlane((int)list[k]);
+            const int oi = __builtin_amdgcn_readfirstlane((int)order[k]);
             const FieldObstruction& R = a.obstructions[batch + oi];
             // DistanceFunctionVertexShader's quad (DistanceFunction.fx:16-26): pixel centre inside [x0, x1) x [y0, y1)
-            if (!(in_slice && (cxp >= R.x0) && (cxp < R.x1) && (cyp >= R.y0) && (cyp < R.y1)))
+            const bool covered = in_slice && (cxp >= R.x0) && (cxp < R.x1) && (cyp >= R.y0) && (cyp < R.y1);
+            // Culling: every slice value of this obstruction is at most kDistanceZero - bound / max_encoded with
+            // bound = (e - cull_radius) / cull_inv_scale <= f (internal.hpp); if that cannot exceed the smallest of the four running
+            // maxima, MAX leaves the texel as it is.  Evaluate only when some covered lane can still change.
+            const float dx = wx - R.cx, dy = wy - R.cy;
+            const float dz = fmaxf(fmaxf(z_low - R.cz, R.cz - z_high), 0.0f);      // the four slices lie in [z_low, z_high]
+            const float e2 = (dx * dx + dy * dy) + dz * dz;
+            const float least = fminf(fminf(acc0, acc1), fminf(acc2, acc3));
+            const float reach = fmaxf(((kDistanceZero - least) * a.max_encoded) * R.cull_inv_scale + R.cull_radius, 0.0f);
+            const bool can_change = covered && !(e2 >= reach * reach);
+            if (__ballot(can_change) == 0ull)
+                continue;
+            if (!covered)
                 continue;
             const int type = R.type;
             acc0 = fmaxf(acc0, kDistanceZero - (evaluate_obstruction(type, mk3(wx, wy, slice_z[0]), R) / a.max_encoded));

@@ -160,8 +160,13 @@ struct FieldObstruction {
     float sx, sy, sz; int32_t _pad;
     float qx, qy, qz, qw;
     float x0, x1, y0, y1;       // raster bounds of DistanceFunctionVertexShader's quad, slice-local pixels
+    // Exact culling (fields.hip): with e = |world position - centre|, the distance function is provably >= (e - cull_radius) / cull_inv_scale
+    // (api.hip, fill_cull_bound: bounding sphere of the shape, safety margins for the float evaluation folded in).  An obstruction whose
+    // bound cannot beat a texel's current maximum is not evaluated; cull_radius = +infinity switches the test off.
+    float cull_inv_scale, cull_radius;
+    float _pad2[2];
 };
-static_assert(sizeof(FieldObstruction) == 64, "FieldObstruction is one 64-byte record");
+static_assert(sizeof(FieldObstruction) == 80, "FieldObstruction is one 80-byte record");
 struct FieldVolume {
     int32_t first_vertex, vertex_count;
     float z0, z1;               // zRange = (ZBase, ZBase + Height)
