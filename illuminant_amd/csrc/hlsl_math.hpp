@@ -75,6 +75,11 @@ ILM_DEV int wrap_index_fast(float t, int size) {
     return (int)r;
 }
 
+// pow(x, y) for x >= 0 as exp2(y * log2(x)): v_log_f32 / v_exp_f32 are 1-ulp hardware transcendentals, so the result is within
+// |y log2 x| * 2^-23 relative of powf (a few 1e-7 for the bases in [0, 1] and exponents in use) -- far inside the 1e-4 parity
+// tolerance -- at 3 instructions instead of OCML powf's ~160.  pow(0, y > 0) = exp2(-inf) = 0 as powf gives; pow(x, 0) = 1.
+ILM_DEV float pow_pos(float x, float y) { return (y == 0.0f) ? 1.0f : __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+
 // sign(d) * m for m >= 0 (HLSL sign() is 0 at 0)
 ILM_DEV float sign_times(float d, float m) { return (d == 0.0f) ? 0.0f * m : copysignf(m, d); }
 

@@ -148,7 +148,7 @@ ILM_DEV float sphere_light_opacity(f3 shaded, f3 normal, const LightRec& L, floa
     if ((normal.x != 0.0f) || (normal.y != 0.0f) || (normal.z != 0.0f)) {
         const f3 ln = mk3(d3.x / distance, d3.y / distance, d3.z / distance);
         const float d = dot3(ln * -1.0f, normal);
-        normal_factor = powf(sat((d + 0.15f) / 0.15f), 0.85f);   // DOT_OFFSET, DOT_RAMP_RANGE, DOT_EXPONENT
+        normal_factor = pow_pos(sat((d + 0.15f) / 0.15f), 0.85f);   // DOT_OFFSET, DOT_RAMP_RANGE, DOT_EXPONENT
     }
     if (L.falloff_mode >= 2.0f) {
         distance_factor = 1.0f - sat(distance - L.radius);
@@ -210,18 +210,22 @@ ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment
         if ((start.x != start.x) || (dir.x != dir.x)) { start.x = 0.0f; dir.x = 0.0f; }
         if ((start.y != start.y) || (dir.y != dir.y)) { start.y = 0.0f; dir.y = 0.0f; }
         if ((start.z != start.z) || (dir.z != dir.z)) { start.z = 0.0f; dir.z = 0.0f; }
+        // The light's cone configuration is read every iteration; with ~104 SGPRs live the compiler re-loads it from memory inside the
+        // loop (s_load + s_waitcnt per sample).  Two VGPRs keep it resident.
+        float cone_max_radius = L.cfg_x, cone_growth = L.cfg_y;
+        asm volatile("" : "+v"(cone_max_radius), "+v"(cone_growth));
         while (liveness > 0.0f) {
             steps_remaining -= 1.0f;
             const f3 sp = mk3(__builtin_fmaf(dir.x, data_x, start.x), __builtin_fmaf(dir.y, data_x, start.y), __builtin_fmaf(dir.z, data_x, start.z));
             const float s = sample_distance_field<FMT, false>(sp, df, sdf);
             if (STATS) st.samples++;
-            const float local_radius = fminf(__builtin_fmaf(L.cfg_y, data_x, 0.33f), L.cfg_x);   // MIN_CONE_RADIUS
+            const float local_radius = fminf(__builtin_fmaf(cone_growth, data_x, 0.33f), cone_max_radius);   // MIN_CONE_RADIUS
             data_z = fminf(data_z, (s + 1.5f) / local_radius);                        // HACK_DISTANCE_OFFSET
             data_x += fmaxf(fabsf(s) * df.StepAndMisc2.z, cfg_z);
             liveness = steps_remaining * (sat(data_z - 0.075f) * sat(data_y - data_x));
         }
         const float visibility = fminf(data_z, steps_remaining / 2.0f);               // MAX_STEP_RAMP_WINDOW
-        cone_opacity = powf(sat(sat(visibility - 0.075f) / (0.95f - 0.075f)), df.ConeAndMisc.z);
+        cone_opacity = pow_pos(sat(sat(visibility - 0.075f) / (0.95f - 0.075f)), df.ConeAndMisc.z);
     }
     const float opacity = pre_trace * cone_opacity;
 
@@ -232,7 +236,7 @@ ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment
     if (L.has_spec != 0.0f) {
         const f3 light_direction = P.shaded - mk3(L.cx, L.cy, L.cz);
         const f3 h = norm3(norm3(P.camera - P.shaded) - light_direction);
-        const float specularity = powf(sat(dot3(h, P.normal)), L.spec_power);
+        const float specularity = pow_pos(sat(dot3(h, P.normal)), L.spec_power);
         sr = L.spec_r * specularity * opacity;
         sg = L.spec_g * specularity * opacity;
         sb = L.spec_b * specularity * opacity;

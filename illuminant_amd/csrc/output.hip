@@ -139,10 +139,7 @@ ILM_DEV void store_lightmap_texel(void* texels, int format, size_t o, float4 c) 
     }
 }
 
-// pow(x, y) for x >= 0 as exp2(y * log2(x)): v_log_f32 / v_exp_f32 are 1-ulp hardware transcendentals, so the result is within a
-// few 1e-7 relative of powf for the exponents in use (gamma in [0.1, 4]) -- far inside the 1e-4 parity tolerance -- at 3 instructions
-// instead of OCML powf's ~40.  pow(0, y > 0) = exp2(-inf) = 0 as powf gives.
-ILM_DEV float pow_pos(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+// pow_pos: hlsl_math.hpp
 
 ILM_DEV float4 resolve_texel(const ResolveLaunch& a, float4 color) {
     // ResolveCommon, Resolve.fx:25-40 (scale 1: the pixel's own texel)
