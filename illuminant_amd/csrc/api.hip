@@ -10,7 +10,9 @@
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <mutex>
 #include <new>
+#include <unordered_map>
 #include <vector>
 
 #include "internal.hpp"
@@ -134,15 +136,38 @@ SdfView make_sdf_view(const Sdf* f) {
     return v;
 }
 
-template <typename T>
-T* from_handle(IlmHandle h, uint32_t magic) {
-    T* p = reinterpret_cast<T*>(static_cast<uintptr_t>(h));
-    if (p == nullptr || p->magic != magic)
-        return nullptr;
-    return p;
+// Handles are the object addresses, but an address is only trusted after it has been found in this table: a stale, foreign or
+// garbage handle is answered with ILM_ERR_INVALID_HANDLE instead of being dereferenced (the C# side owns handle lifetimes and can
+// hand in anything).  One mutex-protected lookup per entry point: ~50 ns against microseconds of launch cost.
+struct HandleRegistry {
+    std::mutex mutex;
+    std::unordered_map<uintptr_t, uint32_t> live;     // address -> magic of the object type
+};
+static HandleRegistry& handle_registry() {
+    static HandleRegistry* r = new HandleRegistry();  // never destroyed: entry points may run during process teardown
+    return *r;
 }
 template <typename T>
-IlmHandle to_handle(T* p) { return static_cast<IlmHandle>(reinterpret_cast<uintptr_t>(p)); }
+T* from_handle(IlmHandle h, uint32_t magic) {
+    HandleRegistry& r = handle_registry();
+    std::lock_guard<std::mutex> lock(r.mutex);
+    const auto it = r.live.find(static_cast<uintptr_t>(h));
+    if (it == r.live.end() || it->second != magic)
+        return nullptr;
+    return reinterpret_cast<T*>(static_cast<uintptr_t>(h));
+}
+template <typename T>
+IlmHandle to_handle(T* p) {
+    HandleRegistry& r = handle_registry();
+    std::lock_guard<std::mutex> lock(r.mutex);
+    r.live[reinterpret_cast<uintptr_t>(p)] = p->magic;
+    return static_cast<IlmHandle>(reinterpret_cast<uintptr_t>(p));
+}
+static void retire_handle(const void* p) {
+    HandleRegistry& r = handle_registry();
+    std::lock_guard<std::mutex> lock(r.mutex);
+    r.live.erase(reinterpret_cast<uintptr_t>(p));
+}
 
 size_t lightmap_texel_bytes(int format) {
     return format == ILM_LIGHTMAP_FLOAT4 ? 16 : (format == ILM_LIGHTMAP_HALF4 ? 8 : 4);
@@ -416,7 +441,11 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
     HIP_TRY(hipSetDevice(c->device));
     rc = refresh_table(s);
     if (rc != ILM_OK) return rc;
-    if (count == 0) return ILM_OK;
+    if (count == 0) {
+        // nothing to launch; a counting step over no chunks has produced its (empty) counts
+        if (d->Flags & ILM_STEP_COUNT_LIVE) { s->counts_n = 0; s->counts_pending = true; s->counts_valid = true; }
+        return ILM_OK;
+    }
     const bool counting = (d->Flags & ILM_STEP_COUNT_LIVE) != 0;
     const int region = s->count_parity;
     if (counting && s->counts_ev)
@@ -625,7 +654,7 @@ int32_t ilm_ctx_destroy(IlmHandle h) {
     (void)hipEventDestroy(c->t0);
     (void)hipEventDestroy(c->t1);
     (void)hipStreamDestroy(c->stream);
-    c->magic = 0;
+    retire_handle(c);
     delete c;
     return ILM_OK;
 }
@@ -701,7 +730,7 @@ int32_t ilm_engine_destroy(IlmHandle h) {
     (void)hipStreamSynchronize(e->ctx->stream);
     if (e->rnd) (void)hipFree(e->rnd);
     if (e->rnd_lp) (void)hipFree(e->rnd_lp);
-    e->magic = 0;
+    retire_handle(e);
     delete e;
     return ILM_OK;
 }
@@ -735,7 +764,7 @@ int32_t ilm_system_destroy(IlmHandle h) {
         if (s->spawn_pattern[k]) (void)hipFree(s->spawn_pattern[k]);
     if (s->h_counts) (void)hipHostFree(s->h_counts);
     if (s->counts_ev) (void)hipEventDestroy(s->counts_ev);
-    s->magic = 0;
+    retire_handle(s);
     delete s;
     return ILM_OK;
 }
@@ -1033,7 +1062,8 @@ int32_t ilm_system_step_counts(IlmHandle h, uint32_t* out_counts, int32_t capaci
     if (!s->counts_valid)
         return fail(ILM_ERR_STATE, "no step with ILM_STEP_COUNT_LIVE has run");
     if (capacity < s->counts_n) return fail(ILM_ERR_OUT_OF_RANGE, "capacity %d < %d", capacity, s->counts_n);
-    HIP_TRY(hipEventSynchronize(s->counts_ev));      // the copy-out queued behind the last counting step
+    if (s->counts_n > 0)
+        HIP_TRY(hipEventSynchronize(s->counts_ev));  // the copy-out queued behind the last counting step
     for (int i = 0; i < s->counts_n; i++) {
         const uint32_t v = s->h_counts[(size_t)i * kCountStride];
         out_counts[i] = (saturate16 && v > 65535u) ? 65535u : v;
@@ -1048,7 +1078,7 @@ int32_t ilm_system_poll_counts(IlmHandle h, uint32_t* out_counts, int32_t capaci
     *out_ready = 0;
     if (!s->counts_pending) return fail(ILM_ERR_STATE, "no step with ILM_STEP_COUNT_LIVE is outstanding");
     HIP_TRY(hipSetDevice(s->engine->ctx->device));
-    hipError_t q = hipEventQuery(s->counts_ev);
+    hipError_t q = (s->counts_n > 0) ? hipEventQuery(s->counts_ev) : hipSuccess;
     if (q == hipErrorNotReady) { (void)hipGetLastError(); return ILM_OK; }
     if (q != hipSuccess) return fail((int32_t)q, "hipEventQuery failed: %s", hipGetErrorString(q));
     if (capacity < s->counts_n) return fail(ILM_ERR_OUT_OF_RANGE, "capacity %d < %d", capacity, s->counts_n);
@@ -1144,7 +1174,7 @@ int32_t ilm_sdf_destroy(IlmHandle h) {
     (void)hipSetDevice(f->ctx->device);
     (void)hipStreamSynchronize(f->ctx->stream);
     if (f->texels) (void)hipFree(f->texels);
-    f->magic = 0;
+    retire_handle(f);
     delete f;
     return ILM_OK;
 }
@@ -1399,7 +1429,7 @@ int32_t ilm_gbuffer_destroy(IlmHandle h) {
     (void)hipSetDevice(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
     if (g->texels) (void)hipFree(g->texels);
-    g->magic = 0;
+    retire_handle(g);
     delete g;
     return ILM_OK;
 }
@@ -1454,7 +1484,7 @@ int32_t ilm_lightmap_destroy(IlmHandle h) {
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     if (m->texels && !m->external) (void)hipFree(m->texels);
-    m->magic = 0;
+    retire_handle(m);
     delete m;
     return ILM_OK;
 }

@@ -617,10 +617,11 @@ ILM_DEV float4 bezier4(const IlmClampedBezier4& bz, float value) {
 
 // applyFrictionAndMaximum, UpdateCommon.fxh:20-35
 ILM_DEV f3 friction_and_maximum(f3 velocity, const IlmParticleSystemUniforms& sys, float dts) {
-    const float l2 = dot3(velocity, velocity);
-    const float inv_l = fast_rsq(l2);
-    float l = l2 * inv_l;
-    if (!(l > 0.001f))
+    // v_sqrt_f32 / v_rcp_f32 (1 ulp; only velocities depend on them) behave like the reference's length() / normalize() at the
+    // edges: a NaN or infinite speed fails `l <= 0.001` and poisons the same components as dividing by it would
+    float l = len3_fast(velocity);
+    const float inv_l = fast_rcp(l);
+    if (l <= 0.001f)
         return mk3(0.0f, 0.0f, 0.0f);
     const float mv = sys.GlobalSettings.z;
     if (l > mv)
@@ -876,7 +877,7 @@ ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* ub, int chunk, int i, unsigne
         for (int c = 0; c < 8; c++) plane(ub, S, c)[lane] = 0.0f;
 #pragma unroll
         for (int c = 12; c < 20; c++) plane(ub, S, c)[lane] = 0.0f;
-    } else if (!((cur.life > 0.0f) || spawn_here || has_noise)) {
+    } else if ((cur.life <= 0.0f) && !spawn_here && !has_noise) {     // `<= 0` as the shaders test it: a NaN life is not dead
         // dead and nothing writes it: the update pass leaves the cleared target
         // (UpdateHandler._BeforeDraw clears, ParticleTransform.cs:164-165; readStateOrDiscard discards)
         if (mode != ILM_UPDATE_NONE) {

@@ -1,0 +1,201 @@
+"""Edge cases through the C ABI: empty systems and light lists, frames that do not fill whole tiles, descriptors at their limits, invalid
+handles and descriptor values, non-finite particle state.  Results are the oracle's; errors are the codes include/illuminant_hip.h documents."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from illuminant_amd import abi, native, scenes
+from tests.test_lighting_gpu import render_both, small_scene
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+P, V, A, RC, RD = abi.PLANE_POSITION, abi.PLANE_VELOCITY, abi.PLANE_ATTRIBUTES, abi.PLANE_RENDER_COLOR, abi.PLANE_RENDER_DATA
+
+
+def plain_desc(cs, mode=abi.UPDATE_POSITIONS):
+    d = abi.StepDesc()
+    d.FirstChunk, d.ChunkCount = 0, -1
+    d.System = scenes.system_uniforms(cs)
+    d.Update = abi.UpdateParams.default()
+    d.UpdateMode = mode
+    return d
+
+
+def test_system_without_chunks(ctx):
+    eng = native.Engine(ctx, 64, scenes.randomness_table(7))
+    sysm = native.System(eng)
+    assert sysm.chunk_count() == 0
+    d = plain_desc(64)
+    d.Flags = abi.STEP_COUNT_LIVE
+    sysm.step(d)                                   # nothing to do is not an error
+    assert len(sysm.step_counts()) == 0 and len(sysm.live_counts()) == 0
+    d.FirstChunk, d.ChunkCount = 0, 1              # but naming a chunk that is not there is
+    with pytest.raises(native.IlluminantError) as e:
+        sysm.step(d)
+    assert e.value.code == abi.ERR_OUT_OF_RANGE
+    with pytest.raises(native.IlluminantError):
+        sysm.download(0, P)
+    sysm.close(); eng.close()
+
+
+def test_all_dead_chunk_and_no_ops(ctx, oracle):
+    cs = 64
+    n = cs * cs
+    rnd = scenes.randomness_table(7)
+    eng = native.Engine(ctx, cs, rnd); sysm = native.System(eng)
+    sysm.add_chunk()
+    pos, vel, attr = scenes.make_particles(1, n, dead_fraction=1.0)
+    for pl, a in ((P, pos), (V, vel), (A, attr)):
+        sysm.upload(0, pl, a)
+    d = plain_desc(cs)
+    d.Flags = abi.STEP_COUNT_LIVE
+    sysm.step(d)
+    assert list(sysm.step_counts()) == [0]
+    for pl in (P, V, RC, RD):
+        assert not sysm.download(0, pl).any()
+    # transforms only, no ops: the state is left exactly as it is
+    pos2, vel2, attr2 = scenes.make_particles(2, n, dead_fraction=0.3)
+    for pl, a in ((P, pos2), (V, vel2), (A, attr2)):
+        sysm.upload(0, pl, a)
+    sysm.step(plain_desc(cs, abi.UPDATE_NONE))
+    assert np.array_equal(sysm.download(0, P), pos2) and np.array_equal(sysm.download(0, V), vel2)
+    sysm.close(); eng.close()
+
+
+def test_descriptor_at_its_limits(ctx, oracle):
+    """ILM_MAX_OPS transforms and ILM_MAX_SPAWNS spawn records in one launch, 16 attractors, on a chunk size that is not a multiple of 64."""
+    cs = 48
+    n = cs * cs
+    rnd = scenes.randomness_table(7)
+    eng = native.Engine(ctx, cs, rnd); sysm = native.System(eng)
+    chunks = []
+    for c in range(2):
+        sysm.add_chunk()
+        pos, vel, attr = scenes.make_particles(20 + c, n, dead_fraction=0.5)
+        for pl, a in ((P, pos), (V, vel), (A, attr)):
+            sysm.upload(c, pl, a)
+        chunks.append([pos.copy(), vel.copy(), attr.copy(), np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)])
+    d = plain_desc(cs)
+    d.OpCount = abi.MAX_OPS
+    att = [((float(20 + 13 * i), float(30 + 7 * i), float(i)), 40.0 + i, 100.0 + 20 * i, i % 3) for i in range(abi.MAX_ATTRACTORS)]
+    d.Ops[0].Type = abi.OP_GRAVITY; d.Ops[0].u.Gravity = scenes.gravity_params(att, 500.0)
+    d.Ops[1].Type = abi.OP_NOISE
+    d.Ops[1].u.Noise = scenes.noise_params(scenes.area_none(), (0.3 * 253, 0.6 * 127), (0.8 * 253, 0.1 * 127), 0.4)
+    d.Ops[2].Type = abi.OP_FMA
+    d.Ops[2].u.FMA = scenes.fma_params(scenes.area(2, (100, 100, 10), (60, 60, 30), falloff=20.0, rotation=0.3, strength=0.8), position_add=(1, 2, 0), velocity_multiply=(0.9, 0.9, 1))
+    d.Ops[3].Type = abi.OP_GRAVITY; d.Ops[3].u.Gravity = scenes.gravity_params(att[:1], 10.0)
+    d.SpawnCount = abi.MAX_SPAWNS
+    for k in range(abi.MAX_SPAWNS):
+        d.Spawns[k].ChunkIndex = k
+        d.Spawns[k].Params = scenes.spawn_params(cs, 100 * k, 100 * k + 300, 7 * k, (0.1 * 253 * (k + 1), 0.2 * 127))
+    d.Flags = abi.STEP_COUNT_LIVE
+    sysm.step(d)
+    want_counts = oracle.step(chunks, cs, rnd, d, want_counts=True)
+    assert np.array_equal(sysm.step_counts(), want_counts)
+    for c in range(2):
+        for k, pl in enumerate((P, V, A, RC, RD)):
+            got = sysm.download(c, pl)
+            if k == 0:
+                assert np.array_equal(got[:, 3] > 0, chunks[c][0][:, 3] > 0)
+            assert_close(got, chunks[c][k], "chunk %d plane %d" % (c, k))
+    # one more than the limits is refused
+    d.OpCount = abi.MAX_OPS + 1
+    with pytest.raises(native.IlluminantError):
+        sysm.step(d)
+    d.OpCount = 1
+    d.SpawnCount = abi.MAX_SPAWNS + 1
+    with pytest.raises(native.IlluminantError):
+        sysm.step(d)
+    sysm.close(); eng.close()
+
+
+def test_non_finite_particle_state_follows_the_oracle(ctx, oracle):
+    cs = 64
+    n = cs * cs
+    rnd = scenes.randomness_table(7)
+    pos, vel, attr = scenes.make_particles(5, n, dead_fraction=0.2)
+    pos[::97, 0] = np.nan; pos[5::89, 1] = np.inf; vel[7::83, 2] = -np.inf; vel[11::79, 0] = np.nan; pos[13::71, 3] = np.nan
+    eng = native.Engine(ctx, cs, rnd); sysm = native.System(eng)
+    sysm.add_chunk()
+    for pl, a in ((P, pos), (V, vel), (A, attr)):
+        sysm.upload(0, pl, a)
+    d = plain_desc(cs)
+    d.OpCount = 1
+    d.Ops[0].Type = abi.OP_GRAVITY
+    d.Ops[0].u.Gravity = scenes.gravity_params([((128., 128., 0.), 150., 60., 1)], 8.0)
+    d.Flags = abi.STEP_COUNT_LIVE
+    sysm.step(d)
+    chunk = [pos.copy(), vel.copy(), attr.copy(), np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)]
+    want_counts = oracle.step([chunk], cs, rnd, d, want_counts=True)
+    got_p = sysm.download(0, P)
+    # liveness (life > 0, false for NaN) is bit-exact even for the poisoned slots; NaNs sit in the same places
+    assert np.array_equal(sysm.step_counts(), want_counts)
+    assert np.array_equal(got_p[:, 3] > 0, chunk[0][:, 3] > 0)
+    assert np.array_equal(np.isnan(got_p), np.isnan(chunk[0]))
+    inf = np.isinf(chunk[0])
+    assert np.array_equal(np.isinf(got_p), inf) and np.array_equal(got_p[inf], chunk[0][inf])
+    fin = np.isfinite(chunk[0])
+    assert_close(np.where(fin, got_p, 0.0), np.where(fin, chunk[0], 0.0), "position")
+    sysm.close(); eng.close()
+
+
+@pytest.mark.parametrize("width,height", [(1, 1), (17, 5), (161, 113), (16, 16)])
+def test_frames_that_do_not_fill_whole_tiles(ctx, oracle, width, height):
+    layout, atlas, dfu, lights, _, _ = small_scene(n_lights=6)
+    lights = scenes.random_lights(9, 6, max(width, 64), max(height, 64), z=(8.0, 48.0), radius=10.0, ramp=(40.0, 120.0))
+    env = scenes.environment()
+    got, want, stats, ostats = render_both(ctx, oracle, lights, env, dfu, None, 0, atlas, abi.SDF_UNORM16, (0.1, 0.1, 0.1, 1.0), width, height)
+    assert (stats.SdfSamples, stats.PixelLightPairs, stats.TracedPairs) == (ostats.SdfSamples, ostats.PixelLightPairs, ostats.TracedPairs)
+    assert got.shape == want.shape == (height, width, 4)
+    assert_close(got, want, "lightmap %dx%d" % (width, height))
+
+
+def test_no_lights_and_lights_off_screen(ctx, oracle):
+    layout, atlas, dfu, lights, w, h = small_scene(n_lights=4)
+    env = scenes.environment()
+    ambient = (0.2, 0.3, 0.4, 1.0)
+    empty = (abi.LightVertex * 0)()
+    got, want, stats, ostats = render_both(ctx, oracle, empty, env, dfu, None, 0, atlas, abi.SDF_UNORM16, ambient, w, h)
+    assert stats.PixelLightPairs == ostats.PixelLightPairs == 0 and stats.SdfSamples == 0
+    assert np.array_equal(got, want) and np.allclose(got, np.asarray(ambient, np.float32))
+    far = scenes.random_lights(3, 5, w, h, z=(8.0, 48.0), radius=10.0, ramp=(40.0, 80.0))
+    for l in far:
+        l.LightPosition1.x += 5000.0; l.LightPosition2.x += 5000.0; l.LightPosition3.x += 5000.0
+    got, want, stats, ostats = render_both(ctx, oracle, far, env, dfu, None, 0, atlas, abi.SDF_UNORM16, ambient, w, h)
+    assert stats.PixelLightPairs == ostats.PixelLightPairs == 0
+    assert np.array_equal(got, want)
+
+
+def test_invalid_handles_and_arguments_are_reported(ctx):
+    lib = native.lib()
+    bogus = abi.Handle(0x1234)
+    out = abi.Handle(0)
+    assert lib.ilm_system_create(bogus, C.byref(out)) == abi.ERR_INVALID_HANDLE
+    assert lib.ilm_system_step(bogus, None) == abi.ERR_INVALID_HANDLE
+    assert lib.ilm_ctx_sync(bogus) == abi.ERR_INVALID_HANDLE
+    assert b"handle" in lib.ilm_last_error()
+    eng = native.Engine(ctx, 16, scenes.randomness_table(7))
+    sysm = native.System(eng)
+    assert lib.ilm_system_step(sysm.handle, None) == abi.ERR_INVALID_ARGUMENT
+    # a system handle where an engine handle is expected
+    assert lib.ilm_system_create(sysm.handle, C.byref(out)) == abi.ERR_INVALID_HANDLE
+    sysm.add_chunk()
+    d = plain_desc(16)
+    d.UpdateMode = 17
+    with pytest.raises(native.IlluminantError) as e:
+        sysm.step(d)
+    assert e.value.code == abi.ERR_INVALID_ARGUMENT
+    d = plain_desc(16)
+    d.OpCount = 1
+    d.Ops[0].Type = 99
+    with pytest.raises(native.IlluminantError):
+        sysm.step(d)
+    with pytest.raises(native.IlluminantError):
+        sysm.upload(0, P, np.zeros((16 * 16 + 1, 4), np.float32))       # more slots than the chunk has
+    with pytest.raises(native.IlluminantError):
+        native.Engine(ctx, 0, scenes.randomness_table(7))
+    sysm.close(); eng.close()
+    # a destroyed handle is dead
+    assert lib.ilm_system_step(sysm.handle, None) == abi.ERR_INVALID_HANDLE
