@@ -38,6 +38,18 @@ int32_t fail(int32_t code, const char* fmt, ...) {
             return fail((int32_t)_e, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
     } while (0)
 
+// Inside a create function, after the object has been registered: a failing HIP call destroys the half-built object (its
+// destroy entry point releases whatever was allocated so far; the error text of the failing call is kept) instead of leaking it.
+#define HIP_TRY_OR_DESTROY(expr, destroy_call)                                                 \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            const int32_t _rc = fail((int32_t)_e, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            (void)(destroy_call);                                                              \
+            return _rc;                                                                        \
+        }                                                                                      \
+    } while (0)
+
 enum : uint32_t {
     kMagicCtx = 0x494C4D43u, kMagicEngine = 0x494C4D45u, kMagicSystem = 0x494C4D53u,
     kMagicSdf = 0x494C4D44u, kMagicGBuffer = 0x494C4D47u, kMagicLightmap = 0x494C4D4Cu
@@ -65,6 +77,7 @@ struct Ctx {
     // particle read-back: draw-call records, total, block counts, per-chunk element counts
     IlmReadbackDrawCall* d_rb = nullptr; int rb_cap = 0; int32_t* d_rb_count = nullptr; int32_t* d_rb_blocks = nullptr; int rb_blocks_cap = 0;
     int32_t* d_rb_elems = nullptr; int rb_elems_cap = 0;
+    IlmReadbackDrawCall* h_rb = nullptr; size_t h_rb_cap = 0;    // pinned host buffer the read-back records land in
     // light probes: positions | normals | values
     float4* d_probes = nullptr; int probes_cap = 0;
     // parameter block of the distance-field generation pass (slice list, obstruction records, volumes, polygon vertices)
@@ -615,13 +628,14 @@ int32_t ilm_ctx_create(int32_t device_id, IlmHandle* out_ctx) {
     Ctx* c = new (std::nothrow) Ctx();
     if (!c) return fail(ILM_ERR_INVALID_ARGUMENT, "out of host memory");
     c->device = device_id;
-    HIP_TRY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    HIP_TRY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-    HIP_TRY(hipEventCreateWithFlags(&c->ev_step, hipEventDisableTiming));
-    HIP_TRY(hipEventCreate(&c->t0));
-    HIP_TRY(hipEventCreate(&c->t1));
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_stats), 3 * sizeof(unsigned long long)));
-    *out_ctx = to_handle(c);
+    const IlmHandle h = to_handle(c);
+    HIP_TRY_OR_DESTROY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), ilm_ctx_destroy(h));
+    HIP_TRY_OR_DESTROY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking), ilm_ctx_destroy(h));
+    HIP_TRY_OR_DESTROY(hipEventCreateWithFlags(&c->ev_step, hipEventDisableTiming), ilm_ctx_destroy(h));
+    HIP_TRY_OR_DESTROY(hipEventCreate(&c->t0), ilm_ctx_destroy(h));
+    HIP_TRY_OR_DESTROY(hipEventCreate(&c->t1), ilm_ctx_destroy(h));
+    HIP_TRY_OR_DESTROY(hipMalloc(reinterpret_cast<void**>(&c->d_stats), 3 * sizeof(unsigned long long)), ilm_ctx_destroy(h));
+    *out_ctx = h;
     return ILM_OK;
 }
 
@@ -648,12 +662,13 @@ int32_t ilm_ctx_destroy(IlmHandle h) {
     if (c->d_rb_count) (void)hipFree(c->d_rb_count);
     if (c->d_rb_blocks) (void)hipFree(c->d_rb_blocks);
     if (c->d_rb_elems) (void)hipFree(c->d_rb_elems);
-    (void)hipStreamSynchronize(c->copy_stream);
-    (void)hipStreamDestroy(c->copy_stream);
-    (void)hipEventDestroy(c->ev_step);
-    (void)hipEventDestroy(c->t0);
-    (void)hipEventDestroy(c->t1);
-    (void)hipStreamDestroy(c->stream);
+    if (c->h_rb) (void)hipHostFree(c->h_rb);
+    // (a context whose creation failed half-way has null members here)
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    if (c->ev_step) (void)hipEventDestroy(c->ev_step);
+    if (c->t0) (void)hipEventDestroy(c->t0);
+    if (c->t1) (void)hipEventDestroy(c->t1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     retire_handle(c);
     delete c;
     return ILM_OK;
@@ -708,18 +723,19 @@ int32_t ilm_engine_create(IlmHandle hctx, int32_t chunk_size, const IlmFloat4* r
     e->stride = ((int64_t)e->slots + kSlotsPerBlock - 1) / kSlotsPerBlock * kSlotsPerBlock;
     e->rw = rw; e->rh = rh;
     const size_t bytes = sizeof(float4) * (size_t)rw * (size_t)rh;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->rnd), bytes));
-    HIP_TRY(hipMemcpy(e->rnd, randomness, bytes, hipMemcpyHostToDevice));
+    const IlmHandle h = to_handle(e);
+    HIP_TRY_OR_DESTROY(hipMalloc(reinterpret_cast<void**>(&e->rnd), bytes), ilm_engine_destroy(h));
+    HIP_TRY_OR_DESTROY(hipMemcpy(e->rnd, randomness, bytes, hipMemcpyHostToDevice), ilm_engine_destroy(h));
     e->h_rnd.assign(reinterpret_cast<const float4*>(randomness), reinterpret_cast<const float4*>(randomness) + (size_t)rw * (size_t)rh);
     {   // new Rgba64(Vector4) per texel (ParticleEngine.cs:536-538): round-half-even of clamp(v, 0, 1) * 65535 per channel
         std::vector<uint16_t> lp((size_t)rw * (size_t)rh * 4);
         const float* f = reinterpret_cast<const float*>(randomness);
         for (size_t i = 0; i < lp.size(); i++)
             lp[i] = (uint16_t)nearbyintf(fminf(fmaxf(f[i], 0.0f), 1.0f) * 65535.0f);
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&e->rnd_lp), sizeof(uint2) * (size_t)rw * (size_t)rh));
-        HIP_TRY(hipMemcpy(e->rnd_lp, lp.data(), sizeof(uint2) * (size_t)rw * (size_t)rh, hipMemcpyHostToDevice));
+        HIP_TRY_OR_DESTROY(hipMalloc(reinterpret_cast<void**>(&e->rnd_lp), sizeof(uint2) * (size_t)rw * (size_t)rh), ilm_engine_destroy(h));
+        HIP_TRY_OR_DESTROY(hipMemcpy(e->rnd_lp, lp.data(), sizeof(uint2) * (size_t)rw * (size_t)rh, hipMemcpyHostToDevice), ilm_engine_destroy(h));
     }
-    *out = to_handle(e);
+    *out = h;
     return ILM_OK;
 }
 
@@ -1133,9 +1149,10 @@ int32_t ilm_sdf_create(IlmHandle hctx, int32_t w, int32_t ht, int32_t format, Il
     Sdf* f = new (std::nothrow) Sdf();
     if (!f) return fail(ILM_ERR_INVALID_ARGUMENT, "out of host memory");
     f->ctx = c; f->width = w; f->height = ht; f->format = format;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&f->texels), sizeof(uint2) * (size_t)w * (size_t)ht));
-    HIP_TRY(hipMemsetAsync(f->texels, 0, sizeof(uint2) * (size_t)w * (size_t)ht, c->stream));
-    *out = to_handle(f);
+    const IlmHandle h = to_handle(f);
+    HIP_TRY_OR_DESTROY(hipMalloc(reinterpret_cast<void**>(&f->texels), sizeof(uint2) * (size_t)w * (size_t)ht), ilm_sdf_destroy(h));
+    HIP_TRY_OR_DESTROY(hipMemsetAsync(f->texels, 0, sizeof(uint2) * (size_t)w * (size_t)ht, c->stream), ilm_sdf_destroy(h));
+    *out = h;
     return ILM_OK;
 }
 
@@ -1335,9 +1352,10 @@ int32_t ilm_gbuffer_create(IlmHandle hctx, int32_t w, int32_t ht, int32_t format
     if (!g) return fail(ILM_ERR_INVALID_ARGUMENT, "out of host memory");
     g->ctx = c; g->width = w; g->height = ht; g->format = format;
     const size_t bytes = (format == ILM_GBUFFER_FLOAT4 ? 16u : 8u) * (size_t)w * (size_t)ht;
-    HIP_TRY(hipMalloc(&g->texels, bytes));
-    HIP_TRY(hipMemsetAsync(g->texels, 0, bytes, c->stream));
-    *out = to_handle(g);
+    const IlmHandle h = to_handle(g);
+    HIP_TRY_OR_DESTROY(hipMalloc(&g->texels, bytes), ilm_gbuffer_destroy(h));
+    HIP_TRY_OR_DESTROY(hipMemsetAsync(g->texels, 0, bytes, c->stream), ilm_gbuffer_destroy(h));
+    *out = h;
     return ILM_OK;
 }
 
@@ -1445,15 +1463,16 @@ int32_t ilm_lightmap_create(IlmHandle hctx, int32_t w, int32_t ht, int32_t forma
     Lightmap* m = new (std::nothrow) Lightmap();
     if (!m) return fail(ILM_ERR_INVALID_ARGUMENT, "out of host memory");
     m->ctx = c; m->width = w; m->height = ht; m->format = format;
+    const IlmHandle h = to_handle(m);
     if (external) {
         m->texels = external;
         m->external = true;
     } else {
         const size_t bytes = lightmap_texel_bytes(format) * (size_t)w * (size_t)ht;
-        HIP_TRY(hipMalloc(&m->texels, bytes));
-        HIP_TRY(hipMemsetAsync(m->texels, 0, bytes, c->stream));
+        HIP_TRY_OR_DESTROY(hipMalloc(&m->texels, bytes), ilm_lightmap_destroy(h));
+        HIP_TRY_OR_DESTROY(hipMemsetAsync(m->texels, 0, bytes, c->stream), ilm_lightmap_destroy(h));
     }
-    *out = to_handle(m);
+    *out = h;
     return ILM_OK;
 }
 
@@ -1659,15 +1678,10 @@ int32_t ilm_render_light_probes(IlmHandle hctx, const IlmLightVertex* lights, in
     return ILM_OK;
 }
 
-int32_t ilm_system_readback(IlmHandle hsystem, const int32_t* element_counts, int32_t chunk_count, const IlmReadbackParams* params,
-                            IlmReadbackDrawCall* out, int32_t capacity, int32_t* out_count) {
-    System* s = from_handle<System>(hsystem, kMagicSystem);
-    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
-    if (!params || !out_count || capacity < 0 || (capacity > 0 && !out)) return fail(ILM_ERR_INVALID_ARGUMENT, "bad arguments");
-    *out_count = 0;
-    const int n = (int)s->chunks.size();
-    if (chunk_count < 0 || chunk_count > n) return fail(ILM_ERR_OUT_OF_RANGE, "chunk_count %d outside [0, %d]", chunk_count, n);
-    if (chunk_count == 0) return ILM_OK;
+// Compacts the live particles of the first chunk_count chunks into draw-call records in c->d_rb (device) and copies the first
+// min(total, capacity) of them into the context's pinned host buffer; *out_total = live particles found.
+static int32_t readback_to_pinned(System* s, const int32_t* element_counts, int32_t chunk_count, const IlmReadbackParams* params,
+                                  int32_t capacity, int32_t* out_total) {
     Engine* e = s->engine;
     Ctx* c = e->ctx;
     for (int i = 0; i < chunk_count; i++)
@@ -1719,12 +1733,63 @@ int32_t ilm_system_readback(IlmHandle hsystem, const int32_t* element_counts, in
     int32_t total = 0;
     HIP_TRY(hipMemcpyAsync(&total, c->d_rb_count, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    *out_count = total;
+    *out_total = total;
     const int n_copy = total < capacity ? total : capacity;
     if (n_copy > 0) {
-        HIP_TRY(hipMemcpyAsync(out, c->d_rb, sizeof(IlmReadbackDrawCall) * (size_t)n_copy, hipMemcpyDeviceToHost, c->stream));
+        // pinned destination: the records cross PCIe at DMA rate (a pageable destination goes through a bounce buffer and faults
+        // its pages in on first touch: 62 MB of records took 30 ms that way)
+        if ((size_t)n_copy > c->h_rb_cap) {
+            if (c->h_rb) HIP_TRY(hipHostFree(c->h_rb));
+            c->h_rb = nullptr; c->h_rb_cap = 0;
+            const size_t cap = (size_t)n_copy + (size_t)n_copy / 4 + 1024;
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_rb), sizeof(IlmReadbackDrawCall) * cap, hipHostMallocDefault));
+            c->h_rb_cap = cap;
+        }
+        HIP_TRY(hipMemcpyAsync(c->h_rb, c->d_rb, sizeof(IlmReadbackDrawCall) * (size_t)n_copy, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(hipStreamSynchronize(c->stream));
     }
+    return ILM_OK;
+}
+
+static int32_t readback_capacity(const System* s, const int32_t* element_counts, int32_t chunk_count) {
+    long long total = 0;
+    for (int i = 0; i < chunk_count; i++) total += element_counts ? (long long)std::max(element_counts[i], 0) : (long long)s->engine->slots;
+    return (int32_t)std::min<long long>(std::max<long long>(total, 1), INT32_MAX);
+}
+
+int32_t ilm_system_readback_view(IlmHandle hsystem, const int32_t* element_counts, int32_t chunk_count, const IlmReadbackParams* params,
+                                 const IlmReadbackDrawCall** out_records, int32_t* out_count) {
+    System* s = from_handle<System>(hsystem, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (!params || !out_count || !out_records) return fail(ILM_ERR_INVALID_ARGUMENT, "bad arguments");
+    *out_count = 0; *out_records = nullptr;
+    const int n = (int)s->chunks.size();
+    if (chunk_count < 0 || chunk_count > n) return fail(ILM_ERR_OUT_OF_RANGE, "chunk_count %d outside [0, %d]", chunk_count, n);
+    if (chunk_count == 0) return ILM_OK;
+    int32_t total = 0;
+    const int32_t rc = readback_to_pinned(s, element_counts, chunk_count, params, readback_capacity(s, element_counts, chunk_count), &total);
+    if (rc != ILM_OK) return rc;
+    *out_count = total;
+    *out_records = (total > 0) ? s->engine->ctx->h_rb : nullptr;
+    return ILM_OK;
+}
+
+int32_t ilm_system_readback(IlmHandle hsystem, const int32_t* element_counts, int32_t chunk_count, const IlmReadbackParams* params,
+                            IlmReadbackDrawCall* out, int32_t capacity, int32_t* out_count) {
+    System* s = from_handle<System>(hsystem, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (!params || !out_count || capacity < 0 || (capacity > 0 && !out)) return fail(ILM_ERR_INVALID_ARGUMENT, "bad arguments");
+    *out_count = 0;
+    const int n = (int)s->chunks.size();
+    if (chunk_count < 0 || chunk_count > n) return fail(ILM_ERR_OUT_OF_RANGE, "chunk_count %d outside [0, %d]", chunk_count, n);
+    if (chunk_count == 0) return ILM_OK;
+    int32_t total = 0;
+    const int32_t rc = readback_to_pinned(s, element_counts, chunk_count, params, capacity, &total);
+    if (rc != ILM_OK) return rc;
+    *out_count = total;
+    const int n_copy = total < capacity ? total : capacity;
+    if (n_copy > 0)
+        std::memcpy(out, s->engine->ctx->h_rb, sizeof(IlmReadbackDrawCall) * (size_t)n_copy);
     return ILM_OK;
 }
 

@@ -315,6 +315,13 @@ PYBIND11_MODULE(_host, m) {
             for (int i = 0; i < count; i++) { tp.Advance(dt); s.Update(firstFrame + i); }
         })
         .def("Clear", &ParticleSystem::Clear)
+        // (n, 12) float32 array over the pinned read-back buffer: no copy; valid until the next read-back on the context
+        .def("PerformReadbackView", [](const ParticleSystem& s) {
+            const ParticleSystem::ReadbackView v = s.PerformReadbackView();
+            constexpr py::ssize_t kFloats = sizeof(IlmReadbackDrawCall) / sizeof(float);
+            static const float kEmpty = 0.0f;
+            return py::array_t<float>({ (py::ssize_t)v.Count, kFloats }, { (py::ssize_t)sizeof(IlmReadbackDrawCall), (py::ssize_t)sizeof(float) },
+                                      v.Count ? reinterpret_cast<const float*>(v.Records) : &kEmpty, py::none()); })
         .def("PerformReadback", [](const ParticleSystem& s) {
             auto r = s.PerformReadback();
             return py::bytes((const char*)r.data(), r.size() * sizeof(IlmReadbackDrawCall)); })

@@ -1077,25 +1077,27 @@ IlmReadbackParams ParticleSystem::GetReadbackParams() const {
 }
 
 // MaybePerformReadback, ParticleReadback.cs:21-71
-std::vector<IlmReadbackDrawCall> ParticleSystem::PerformReadback() const {
-    std::vector<IlmReadbackDrawCall> result;
+ParticleSystem::ReadbackView ParticleSystem::PerformReadbackView() const {
+    ReadbackView view;
     if (chunks.empty())
-        return result;
+        return view;
     const int cs = Engine.Configuration.ChunkSize;
     std::vector<int32_t> elements;
-    int maxTotalCount = 0;
     for (const Chunk& c : chunks) {
         const int rowCount = (int)std::ceil(c.TotalSpawned / (float)cs);   // :57
         elements.push_back(std::min(rowCount * cs, ChunkMaximumCount()));
-        maxTotalCount += elements.back();
     }
-    // ReadbackResultBuffer (:40-41): sized for every examined slot, not cleared ("FIXME: This is too slow")
-    std::unique_ptr<IlmReadbackDrawCall[]> buffer(new IlmReadbackDrawCall[(size_t)std::max(maxTotalCount, 1)]);
+    // ReadbackResultBuffer (:40-41) is the context's pinned buffer: sized for every examined slot, reused, never cleared
     const IlmReadbackParams p = GetReadbackParams();
     int32_t total = 0;
-    ThrowIfFailed(ilm_system_readback(handle, elements.data(), (int32_t)elements.size(), &p, buffer.get(), std::max(maxTotalCount, 1), &total));
-    result.assign(buffer.get(), buffer.get() + total);
-    return result;
+    ThrowIfFailed(ilm_system_readback_view(handle, elements.data(), (int32_t)elements.size(), &p, &view.Records, &total));
+    view.Count = total;
+    return view;
+}
+
+std::vector<IlmReadbackDrawCall> ParticleSystem::PerformReadback() const {
+    const ReadbackView v = PerformReadbackView();
+    return std::vector<IlmReadbackDrawCall>(v.Records, v.Records + v.Count);
 }
 
 void ParticleSystem::Readback(int chunkIndex, int plane, IlmFloat4* dst) const {

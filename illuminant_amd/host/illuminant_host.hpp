@@ -535,6 +535,10 @@ public:
     // MaybePerformReadback + FillReadbackResult (ParticleReadback.cs:21-167): one draw-call record per live particle, chunk / slot
     // order.  Update() refreshes ReadbackResult when Configuration.AutoReadback is set (the reference completes a Future).
     std::vector<IlmReadbackDrawCall> PerformReadback() const;
+    // the same records where the native layer left them (page-locked host memory owned by the device context; valid until the
+    // next read-back on that context): ArraySegment<BitmapDrawCall> over the pooled buffer, ParticleReadback.cs:40-41,64-69
+    struct ReadbackView { const IlmReadbackDrawCall* Records = nullptr; int Count = 0; };
+    ReadbackView PerformReadbackView() const;
     IlmReadbackParams GetReadbackParams() const;
     std::vector<IlmReadbackDrawCall> ReadbackResult;
     float ReadbackTimestamp = 0;

@@ -84,6 +84,7 @@ SYMBOLS = {
     "ilm_render_particle_lights": (_I, [_H, _H, _P, _I, _P, _P, _P, _H, _H, _H, _I, _I, _P]),
     "ilm_render_light_probes": (_I, [_H, _P, _I, _P, _P, _I, _P, _P, _H, _P]),
     "ilm_system_readback": (_I, [_H, _P, _I, _P, _P, _I, C.POINTER(_I)]),
+    "ilm_system_readback_view": (_I, [_H, _P, _I, _P, C.POINTER(_P), C.POINTER(_I)]),
     "ilm_resolve_lighting": (_I, [_H, _H, _P, _I, _I]),
 }
 
@@ -306,6 +307,21 @@ class System:
         check(lib().ilm_system_readback(self.handle, _ptr(e) if e is not None else None, chunk_count, _byref(params),
                                         C.cast(out, C.c_void_p), capacity, C.byref(n)))
         return out, int(n.value)
+
+    def readback_view(self, params, element_counts=None, chunk_count=None):
+        """ilm_system_readback_view: (n, 12) float32 view of the draw-call records in the context's pinned buffer (valid until the next
+        read-back on the context) -- no host copy."""
+        if chunk_count is None:
+            chunk_count = self.chunk_count()
+        e = np.ascontiguousarray(element_counts, dtype=np.int32) if element_counts is not None else None
+        ptr = C.c_void_p()
+        n = C.c_int32()
+        check(lib().ilm_system_readback_view(self.handle, _ptr(e) if e is not None else None, chunk_count, _byref(params),
+                                             C.byref(ptr), C.byref(n)))
+        if n.value == 0:
+            return np.zeros((0, C.sizeof(abi.ReadbackDrawCall) // 4), np.float32)
+        buf = (C.c_float * (n.value * (C.sizeof(abi.ReadbackDrawCall) // 4))).from_address(ptr.value)
+        return np.frombuffer(buf, dtype=np.float32).reshape(n.value, -1)
 
     def close(self):
         if self.handle.value:

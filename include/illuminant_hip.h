@@ -40,6 +40,9 @@ extern "C" {
 #define ILM_ERR_STATE             (-6)   /* e.g. DF update without a bound field: ParticleSystem.cs:835-836 */
 /* positive values are hipError_t values passed through unchanged */
 
+/* Opaque object handles (contexts, engines, systems, textures).  Every entry point looks its handles up in a table of live
+ * objects first: a destroyed, foreign or garbage value returns ILM_ERR_INVALID_HANDLE, it is never dereferenced.  0 is never
+ * a valid handle.  A create call that fails releases everything it had allocated and leaves *out = 0. */
 typedef uint64_t IlmHandle;
 
 /* ---- POD mirrors of the reference's uniform structs -------------------- */
@@ -634,6 +637,11 @@ typedef struct IlmReadbackParams {
  * synchronises. */
 int32_t ilm_system_readback(IlmHandle system, const int32_t* element_counts, int32_t chunk_count, const IlmReadbackParams* params,
                             IlmReadbackDrawCall* out, int32_t capacity, int32_t* out_count);
+/* The same read-back without the last copy: the records stay in a page-locked host buffer owned by the system's context (the
+ * reference keeps a pooled ReadbackResultBuffer too, ParticleReadback.cs:40-41) and *out_records points at it; valid until the next
+ * read-back on that context or its destruction.  Capacity is every examined slot.  NULL when nothing is alive.  Synchronises. */
+int32_t ilm_system_readback_view(IlmHandle system, const int32_t* element_counts, int32_t chunk_count, const IlmReadbackParams* params,
+                                 const IlmReadbackDrawCall** out_records, int32_t* out_count);
 
 enum { ILM_HDR_NONE = 0, ILM_HDR_GAMMA_COMPRESS = 1, ILM_HDR_TONE_MAP = 2 };   /* HDRMode, LightingRenderer.HDR.cs:254-258 */
 

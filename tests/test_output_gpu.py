@@ -44,6 +44,11 @@ def test_readback_matches_oracle_record_for_record(ctx, oracle):
     got2, gn2 = sysm.readback(params, element_counts=elems, capacity=100)
     assert gn2 == gn
     assert np.array_equal(np.frombuffer(got2, dtype=np.uint8).reshape(-1, 48)[:100], g[:100])
+    # the zero-copy form: the same records, viewed in the context's pinned buffer
+    view = sysm.readback_view(params, element_counts=elems)
+    assert view.shape == (gn, 12) and np.array_equal(view.view(np.uint8).reshape(-1, 48), g)
+    # nothing examined -> nothing returned
+    assert sysm.readback_view(params, element_counts=[0, 0, 0]).shape[0] == 0
     sysm.close(); eng.close()
 
 
