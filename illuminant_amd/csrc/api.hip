@@ -474,6 +474,11 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
     a.chunk_count = count;
     a.op_mask = 0;
     for (int o = 0; o < d->OpCount; o++) a.op_mask |= 1u << d->Ops[o].Type;
+    // 20 planes x stride x 4 B per chunk against the 256 MB Infinity Cache (MI355X_MICROARCH.md): above it every plane streams
+    // through once per step and the non-temporal variant wins; below it the planes stay resident from one step to the next
+    a.streaming = ((size_t)count * (size_t)e->stride * kComponents * sizeof(float) > ((size_t)256 << 20)) ? 1 : 0;
+    static const int forced = [] { const char* v = getenv("ILM_STEP_STREAMING"); return v ? atoi(v) : -1; }();   // experiment switch
+    if (forced >= 0) a.streaming = forced;
     for (int k = 0; k < d->SpawnCount; k++) {
         const IlmSpawnRecord& r = d->Spawns[k];
         if (r.Params.ChunkSizeAndIndices[2] >= r.Params.ChunkSizeAndIndices[1])

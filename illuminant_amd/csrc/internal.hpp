@@ -69,6 +69,7 @@ struct StepLaunch {
     int32_t chunk_size;
     int32_t first_chunk, chunk_count;
     uint32_t op_mask;            // bit t set when an op of type t is present
+    int32_t streaming;           // != 0: the chunks of this launch do not fit the Infinity Cache -> non-temporal plane accesses
     const float4* rnd; int32_t rw, rh;
     const uint2* rnd_lp;         // the Rgba64 copy of the randomness table (SpatialNoise; ParticleEngine.cs:508-540)
     const float4* ramp; int32_t ramp_w, ramp_h;

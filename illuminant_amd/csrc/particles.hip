@@ -827,14 +827,25 @@ ILM_DEV gfloat* plane(gfloat* ub, int64_t S, int c) {
     return p;
 }
 
-template <bool ATTR>
+// STREAM: the launch's working set is larger than the Infinity Cache (api.hip decides), every plane is touched once per step: loads and
+// stores carry the non-temporal hint so they do not evict each other on the way through (tools/ubench/stream: 8.4 M slots 187 -> 170 us;
+// on a cache-resident working set the same hint costs 25 %, so small systems keep the default policy).
+template <bool STREAM>
+ILM_DEV float ld_plane(gfloat* p, unsigned lane) { return STREAM ? __builtin_nontemporal_load(p + lane) : p[lane]; }
+template <bool STREAM>
+ILM_DEV void st_plane(gfloat* p, unsigned lane, float v) {
+    if (STREAM) __builtin_nontemporal_store(v, p + lane);
+    else p[lane] = v;
+}
+
+template <bool ATTR, bool STREAM>
 ILM_DEV SlotIn load_slot(gfloat* ub, int64_t S, unsigned lane) {
     SlotIn s;
-    s.life = plane(ub, S, 3)[lane];
-    s.px = plane(ub, S, 0)[lane]; s.py = plane(ub, S, 1)[lane]; s.pz = plane(ub, S, 2)[lane];
-    s.vx = plane(ub, S, 4)[lane]; s.vy = plane(ub, S, 5)[lane]; s.vz = plane(ub, S, 6)[lane]; s.ct = plane(ub, S, 7)[lane];
+    s.life = ld_plane<STREAM>(plane(ub, S, 3), lane);
+    s.px = ld_plane<STREAM>(plane(ub, S, 0), lane); s.py = ld_plane<STREAM>(plane(ub, S, 1), lane); s.pz = ld_plane<STREAM>(plane(ub, S, 2), lane);
+    s.vx = ld_plane<STREAM>(plane(ub, S, 4), lane); s.vy = ld_plane<STREAM>(plane(ub, S, 5), lane); s.vz = ld_plane<STREAM>(plane(ub, S, 6), lane); s.ct = ld_plane<STREAM>(plane(ub, S, 7), lane);
     if (ATTR) {
-        s.ar = plane(ub, S, 8)[lane]; s.ag = plane(ub, S, 9)[lane]; s.ab = plane(ub, S, 10)[lane]; s.aa = plane(ub, S, 11)[lane];
+        s.ar = ld_plane<STREAM>(plane(ub, S, 8), lane); s.ag = ld_plane<STREAM>(plane(ub, S, 9), lane); s.ab = ld_plane<STREAM>(plane(ub, S, 10), lane); s.aa = ld_plane<STREAM>(plane(ub, S, 11), lane);
     } else {
         s.ar = s.ag = s.ab = s.aa = 0.0f;
     }
@@ -849,7 +860,7 @@ typedef const StepLaunch __attribute__((address_space(4))) CStepLaunch;
 
 // DF: the update pass is UpdateWithDistanceField (pulls in the SDF sampler); SPAWN: spawn records present.
 // Both are compile-time so the common no-field / no-spawn step does not pay their registers.
-template <int FMT, bool DF, bool SPAWN, bool EXT>
+template <int FMT, bool DF, bool SPAWN, bool EXT, bool STREAM>
 ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* ub, int chunk, int i, unsigned lane, int seg, SlotIn cur, const NoiseDeltas& noise) {
     const StepLaunch& a = *(const StepLaunch*)ap;
     const IlmStepDesc& d = a.desc;
@@ -874,17 +885,17 @@ ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* ub, int chunk, int i, unsigne
     if (mode == ILM_UPDATE_ERASE) {
         // PS_Erase, UpdateParticleSystem.fx:40-49
 #pragma unroll
-        for (int c = 0; c < 8; c++) plane(ub, S, c)[lane] = 0.0f;
+        for (int c = 0; c < 8; c++) st_plane<STREAM>(plane(ub, S, c), lane, 0.0f);
 #pragma unroll
-        for (int c = 12; c < 20; c++) plane(ub, S, c)[lane] = 0.0f;
+        for (int c = 12; c < 20; c++) st_plane<STREAM>(plane(ub, S, c), lane, 0.0f);
     } else if ((cur.life <= 0.0f) && !spawn_here && !has_noise) {     // `<= 0` as the shaders test it: a NaN life is not dead
         // dead and nothing writes it: the update pass leaves the cleared target
         // (UpdateHandler._BeforeDraw clears, ParticleTransform.cs:164-165; readStateOrDiscard discards)
         if (mode != ILM_UPDATE_NONE) {
 #pragma unroll
-            for (int c = 0; c < 8; c++) plane(ub, S, c)[lane] = 0.0f;
+            for (int c = 0; c < 8; c++) st_plane<STREAM>(plane(ub, S, c), lane, 0.0f);
 #pragma unroll
-            for (int c = 12; c < 20; c++) plane(ub, S, c)[lane] = 0.0f;
+            for (int c = 12; c < 20; c++) st_plane<STREAM>(plane(ub, S, c), lane, 0.0f);
         } else {
             live_after = cur.life > 0.0f;   // untouched slots keep their liveness when no update pass ran
         }
@@ -951,14 +962,14 @@ ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* ub, int chunk, int i, unsigne
                 render_data(fx, fy, pos, vel, attr, d.System, d.Update, a.ramp, a.ramp_w, a.ramp_h, rc, rd);
             }
         }
-        plane(ub, S, 0)[lane] = pos.x; plane(ub, S, 1)[lane] = pos.y; plane(ub, S, 2)[lane] = pos.z; plane(ub, S, 3)[lane] = pos.w;
-        plane(ub, S, 4)[lane] = vel.x; plane(ub, S, 5)[lane] = vel.y; plane(ub, S, 6)[lane] = vel.z; plane(ub, S, 7)[lane] = vel.w;
+        st_plane<STREAM>(plane(ub, S, 0), lane, pos.x); st_plane<STREAM>(plane(ub, S, 1), lane, pos.y); st_plane<STREAM>(plane(ub, S, 2), lane, pos.z); st_plane<STREAM>(plane(ub, S, 3), lane, pos.w);
+        st_plane<STREAM>(plane(ub, S, 4), lane, vel.x); st_plane<STREAM>(plane(ub, S, 5), lane, vel.y); st_plane<STREAM>(plane(ub, S, 6), lane, vel.z); st_plane<STREAM>(plane(ub, S, 7), lane, vel.w);
         if (spawned) {
-            plane(ub, S, 8)[lane] = attr.x; plane(ub, S, 9)[lane] = attr.y; plane(ub, S, 10)[lane] = attr.z; plane(ub, S, 11)[lane] = attr.w;
+            st_plane<STREAM>(plane(ub, S, 8), lane, attr.x); st_plane<STREAM>(plane(ub, S, 9), lane, attr.y); st_plane<STREAM>(plane(ub, S, 10), lane, attr.z); st_plane<STREAM>(plane(ub, S, 11), lane, attr.w);
         }
         if (need_attr) {
-            plane(ub, S, 12)[lane] = rc.x; plane(ub, S, 13)[lane] = rc.y; plane(ub, S, 14)[lane] = rc.z; plane(ub, S, 15)[lane] = rc.w;
-            plane(ub, S, 16)[lane] = rd.x; plane(ub, S, 17)[lane] = rd.y; plane(ub, S, 18)[lane] = rd.z; plane(ub, S, 19)[lane] = rd.w;
+            st_plane<STREAM>(plane(ub, S, 12), lane, rc.x); st_plane<STREAM>(plane(ub, S, 13), lane, rc.y); st_plane<STREAM>(plane(ub, S, 14), lane, rc.z); st_plane<STREAM>(plane(ub, S, 15), lane, rc.w);
+            st_plane<STREAM>(plane(ub, S, 16), lane, rd.x); st_plane<STREAM>(plane(ub, S, 17), lane, rd.y); st_plane<STREAM>(plane(ub, S, 18), lane, rd.z); st_plane<STREAM>(plane(ub, S, 19), lane, rd.w);
         }
         live_after = pos.w > 0.0f;
     }
@@ -970,7 +981,7 @@ ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* ub, int chunk, int i, unsigne
 // software-pipelined variant of this kernel measured 12-25 % slower: the body is a long dependent chain --
 // state loads, scalar parameter fetches, randomness gathers -- whose latency is hidden by wave occupancy,
 // not by prefetching; see DESIGN.md.)  MINW = minimum waves per SIMD requested from the register allocator.
-template <int FMT, bool DF, bool SPAWN, int MINW, bool EXT = false>
+template <int FMT, bool DF, bool SPAWN, int MINW, bool EXT = false, bool STREAM = false>
 __global__ __launch_bounds__(kStepThreads, MINW) void step_kernel(const StepLaunch a) {
     __shared__ uint32_t wave_live[kStepThreads / 64];
     CStepLaunch* ap = (CStepLaunch*)__builtin_amdgcn_kernarg_segment_ptr();
@@ -1006,7 +1017,7 @@ __global__ __launch_bounds__(kStepThreads, MINW) void step_kernel(const StepLaun
         // registers cost more occupancy than the memory-level parallelism returns, so K = 1 ships.
         SlotIn q[K];
 #pragma unroll
-        for (int j = 0; j < K; j++) q[j] = load_slot<true>(ub + j * 64, a.stride, lane);
+        for (int j = 0; j < K; j++) q[j] = load_slot<true, STREAM>(ub + j * 64, a.stride, lane);
 #pragma nounroll
         for (int j = 0; j < K; j++) {
             const SlotIn cur = q[0];
@@ -1020,7 +1031,7 @@ __global__ __launch_bounds__(kStepThreads, MINW) void step_kernel(const StepLaun
                 const int row = (a.derived.cs_shift >= 0) ? (first >> a.derived.cs_shift) : (first / a.chunk_size);
                 noise = noise_prepare(((const StepLaunch*)ap)->derived.noise, first - row * a.chunk_size, row);
             }
-            const bool live_after = process_unit<FMT, DF, SPAWN, EXT>(ap, ub + j * 64, chunk, (seg + j) * 64 + (int)lane, lane, seg + j, cur, noise);
+            const bool live_after = process_unit<FMT, DF, SPAWN, EXT, STREAM>(ap, ub + j * 64, chunk, (seg + j) * 64 + (int)lane, lane, seg + j, cur, noise);
             n_live += (uint32_t)__popcll(__ballot(live_after));
         }
         }
@@ -1084,6 +1095,8 @@ static hipError_t launch_step_variant(const StepLaunch& a, hipStream_t stream) {
             hipLaunchKernelGGL((step_kernel<ILM_SDF_FP16, true, SPAWN, 1>), grid, block, 0, stream, a);
         else
             hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, true, SPAWN, 1>), grid, block, 0, stream, a);
+    } else if (a.streaming) {
+        hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, false, SPAWN, 1, false, true>), grid, block, 0, stream, a);
     } else if (SPAWN) {
         // (bounding this variant to 7 / 8 waves per SIMD -- 72 / 64 VGPRs with 8 / 24 bytes of scratch in the cold spawn path --
         // measured 3.5 % / 14 % SLOWER on cfg2: the step is VALU-issue-bound, not occupancy-bound; DESIGN.md "experiments")

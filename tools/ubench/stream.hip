@@ -2,6 +2,7 @@
 //   mode 0: 12 dword loads + 16 dword stores per lane (one slot per lane, SoA planes)       [the step kernel's pattern]
 //   mode 1: same bytes with 16-byte accesses (4 slots per lane)
 //   mode 2: AoS float4: 3 x 16 B loads + 4 x 16 B stores per slot (one slot per lane)
+//   mode 3: mode 0 with non-temporal stores      mode 4: mode 0 with non-temporal loads and stores
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -24,6 +25,22 @@ __global__ __launch_bounds__(256) void k_dword(float* b, long S, int alu) {
     for (int c = 0; c < 8; c++) base[c * S + i] = v[c] + acc;
 #pragma unroll
     for (int c = 12; c < 20; c++) base[c * S + i] = acc;
+}
+template <bool NT_LOAD>
+__global__ __launch_bounds__(256) void k_dword_nt(float* b, long S, int alu) {
+    gfloat* base = (gfloat*)b;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    float v[12];
+#pragma unroll
+    for (int c = 0; c < 12; c++) v[c] = NT_LOAD ? __builtin_nontemporal_load(base + c * S + i) : base[c * S + i];
+    float acc = 0;
+#pragma unroll
+    for (int c = 0; c < 12; c++) acc += v[c];
+    for (int k = 0; k < alu; k++) acc = acc * 1.0001f + 0.5f;
+#pragma unroll
+    for (int c = 0; c < 8; c++) __builtin_nontemporal_store(v[c] + acc, base + c * S + i);
+#pragma unroll
+    for (int c = 12; c < 20; c++) __builtin_nontemporal_store(acc, base + c * S + i);
 }
 __global__ __launch_bounds__(256) void k_x4(float* b, long S, int alu) {
     gfloat* base = (gfloat*)b;
@@ -53,12 +70,14 @@ int main(int argc, char** argv) {
     int alu = argc > 2 ? atoi(argv[2]) : 0;
     float* d; CK(hipMalloc(&d, sizeof(float) * 20 * N)); CK(hipMemset(d, 0, sizeof(float) * 20 * N));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int mode = 0; mode < 3; mode++) {
+    for (int mode = 0; mode < 5; mode++) {
         const int reps = 50;
         for (int r = 0; r < reps + 5; r++) {
             if (r == 5) CK(hipEventRecord(e0));
             if (mode == 0) hipLaunchKernelGGL(k_dword, dim3(N / 256), dim3(256), 0, 0, d, N, alu);
             else if (mode == 1) hipLaunchKernelGGL(k_x4, dim3(N / 1024), dim3(256), 0, 0, d, N, alu);
+            else if (mode == 3) hipLaunchKernelGGL(k_dword_nt<false>, dim3(N / 256), dim3(256), 0, 0, d, N, alu);
+            else if (mode == 4) hipLaunchKernelGGL(k_dword_nt<true>, dim3(N / 256), dim3(256), 0, 0, d, N, alu);
             else hipLaunchKernelGGL(k_aos, dim3(N / 256), dim3(256), 0, 0, (float4*)d, N, alu);
         }
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
