@@ -341,6 +341,7 @@ def main():
             barrier()
             lwall = max_over_ranks(time.perf_counter() - t0)
             samples = int(stats[0])
+            pairs_local, traced_local = int(stats[1]), int(stats[2])
             if dist is not None:
                 t = torch.tensor([samples], dtype=torch.float64, device="cuda")
                 dist.all_reduce(t)
@@ -356,6 +357,7 @@ def main():
                 "lit_mpixels_per_s": round(w * h / (frame_ms * 1e-3) / 1e6, 2),
                 "ms_per_frame": round(frame_ms, 4),
                 "sdf_samples_per_frame": samples_total,
+                "pixel_light_pairs_this_rank": pairs_local, "traced_pairs_this_rank": traced_local,
                 "field_generation": L["field_generation"],
                 "roofline": {"bound": "hbm", "achieved": round(alg_bytes / (kern_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(alg_bytes / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),

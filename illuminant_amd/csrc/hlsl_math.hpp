@@ -170,7 +170,7 @@ ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms&
         distance_to_volume = sqrtf(d2);
     }
 
-    const float slice_position = fminf(cz, df.Packed1.z) * df.Packed1.y;
+    const float slice_position = (CHECK_NAN ? fminf(cz, df.Packed1.z) : __builtin_elementwise_minimum(cz, df.Packed1.z)) * df.Packed1.y;   // cz is finite
     const float vslice = floorf(slice_position);
     const uint32_t vi = (uint32_t)vslice;                    // 0 <= vslice < 65536
     const uint32_t third = __umul24(vi, 0xAAABu) >> 17;      // vi / 3 (24-bit multiply: full rate)

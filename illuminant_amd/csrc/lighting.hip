@@ -219,7 +219,8 @@ ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment
             const f3 sp = mk3(__builtin_fmaf(dir.x, data_x, start.x), __builtin_fmaf(dir.y, data_x, start.y), __builtin_fmaf(dir.z, data_x, start.z));
             const float s = sample_distance_field<FMT, false>(sp, df, sdf);
             if (STATS) st.samples++;
-            const float local_radius = fminf(__builtin_fmaf(cone_growth, data_x, 0.33f), cone_max_radius);   // MIN_CONE_RADIUS
+            // (both operands are finite: v_minimum3_f32 needs no canonicalising v_max in front of it, unlike IEEE minNum)
+            const float local_radius = __builtin_elementwise_minimum(__builtin_fmaf(cone_growth, data_x, 0.33f), cone_max_radius);   // MIN_CONE_RADIUS
             data_z = fminf(data_z, (s + 1.5f) / local_radius);                        // HACK_DISTANCE_OFFSET
             data_x += fmaxf(fabsf(s) * df.StepAndMisc2.z, cfg_z);
             liveness = steps_remaining * (sat(data_z - 0.075f) * sat(data_y - data_x));
@@ -337,8 +338,12 @@ __global__ __launch_bounds__(256) void sphere_lights_kernel(const LightLaunch a,
             const LightRec& L = recs[batch + li];
 
             // raster footprint: pixel centre inside the cross-shaped quad
-            const bool covered = in_image && (((cxp >= L.fx1) && (cxp < L.fx2) && (cyp >= L.fy0) && (cyp < L.fy3)) ||
-                                              ((cxp >= L.fx0) && (cxp < L.fx3) && (cyp >= L.fy1) && (cyp < L.fy2)));
+            // (all eight bounds fetched together and combined without short-circuits: as written with && / || the compiler issued
+            // eight dependent scalar loads, each behind its own wait and branch)
+            const float fx0 = L.fx0, fx1 = L.fx1, fx2 = L.fx2, fx3 = L.fx3, fy0 = L.fy0, fy1 = L.fy1, fy2 = L.fy2, fy3 = L.fy3;
+            const bool tall = (cxp >= fx1) & (cxp < fx2) & (cyp >= fy0) & (cyp < fy3);
+            const bool wide = (cxp >= fx0) & (cxp < fx3) & (cyp >= fy1) & (cyp < fy2);
+            const bool covered = in_image & (tall | wide);
             if (!covered)
                 continue;
             if (STATS) st.pairs++;
