@@ -89,6 +89,16 @@ class ClampedBezier1(C.Structure):
         # ClampedBezier1.One, Bezier.cs:434-437
         return ClampedBezier1(f4(0, 1, 1, 0), f4(1, 1, 1, 1))
 
+    @staticmethod
+    def constant(v):
+        # new ClampedBezier1(new BezierF(v)): one control point, Bezier.cs:439-460
+        return ClampedBezier1(f4(0, 1, 1, 0), f4(v, v, v, v))
+
+    @staticmethod
+    def linear(a, b, lo, hi):
+        # two control points a -> b over [lo, hi] (count 2, clamped range: RangeAndCount = (min, 1 / (max - min), count, mode))
+        return ClampedBezier1(f4(lo, 1.0 / max(hi - lo, 1e-6), 2, 0), f4(a, b, b, b))
+
 
 class ClampedBezier4(C.Structure):
     _fields_ = [("RangeAndCount", Float4), ("A", Float4), ("B", Float4), ("C", Float4), ("D", Float4)]
@@ -186,6 +196,16 @@ class PatternParams(C.Structure):
                 ("CenteringOffset", f32 * 2), ("MultiplyAttributeConstant", f32), ("_pad", f32)]
 
 
+BLEND_ALPHA, BLEND_ADDITIVE = 0, 1
+
+
+class RasterizeParams(C.Structure):
+    _fields_ = [("GlobalColor", Float4), ("BitmapTextureRegion", Float4), ("SizeFactorAndPosition", Float4), ("Scale", Float4),
+                ("ZFormula", Float4), ("ZConfiguration", Float4), ("RoundingPowerFromLife", ClampedBezier1),
+                ("RenderingOptions", f32 * 4), ("SystemSize", f32 * 2), ("ZToY", f32), ("StippleFactor", f32),
+                ("ViewportScale", f32 * 2), ("ViewportPosition", f32 * 2), ("BlendMode", i32), ("_pad", i32 * 3)]
+
+
 class _OpUnion(C.Union):
     _fields_ = [("Gravity", GravityParams), ("Noise", NoiseParams), ("FMA", FMAParams),
                 ("MatrixMultiply", MatrixMultiplyParams), ("SpatialNoise", SpatialNoiseParams)]
@@ -277,7 +297,7 @@ EXPECTED_SIZES = {
     "IlmRenderStats": (RenderStats, 24),
     "IlmParticleLightParams": (ParticleLightParams, 80),
     "IlmReadbackDrawCall": (ReadbackDrawCall, 48), "IlmReadbackParams": (ReadbackParams, 56), "IlmHDRConfiguration": (HDRConfiguration, 48),
-    "IlmGBufferRenderDesc": (GBufferRenderDesc, 32),
+    "IlmGBufferRenderDesc": (GBufferRenderDesc, 32), "IlmRasterizeParams": (RasterizeParams, 192),
     "IlmObstruction": (Obstruction, 48), "IlmHeightVolume": (HeightVolume, 32),
     "IlmDistanceFieldRenderDesc": (DistanceFieldRenderDesc, 64),
 }

@@ -74,6 +74,8 @@ struct Ctx {
     // particle lights: records compacted on the device + their count, block counts, per-chunk quad counts
     void* d_pl_recs = nullptr; int pl_cap = 0; int32_t* d_pl_count = nullptr; int32_t* d_pl_blocks = nullptr; int pl_blocks_cap = 0;
     int32_t* d_pl_quads = nullptr; int pl_quads_cap = 0;
+    RasterScratch raster;                                         // particle rasteriser buffers (raster.hip)
+    int32_t* d_raster_quads = nullptr; int raster_quads_cap = 0;
     // particle read-back: draw-call records, total, block counts, per-chunk element counts
     IlmReadbackDrawCall* d_rb = nullptr; int rb_cap = 0; int32_t* d_rb_count = nullptr; int32_t* d_rb_blocks = nullptr; int rb_blocks_cap = 0;
     int32_t* d_rb_elems = nullptr; int rb_elems_cap = 0;
@@ -662,6 +664,8 @@ int32_t ilm_ctx_destroy(IlmHandle h) {
     if (c->d_pl_count) (void)hipFree(c->d_pl_count);
     if (c->d_pl_blocks) (void)hipFree(c->d_pl_blocks);
     if (c->d_pl_quads) (void)hipFree(c->d_pl_quads);
+    free_raster_scratch(c->raster);
+    if (c->d_raster_quads) (void)hipFree(c->d_raster_quads);
     if (c->d_probes) (void)hipFree(c->d_probes);
     if (c->d_rb) (void)hipFree(c->d_rb);
     if (c->d_rb_count) (void)hipFree(c->d_rb_count);
@@ -1795,6 +1799,74 @@ int32_t ilm_system_readback(IlmHandle hsystem, const int32_t* element_counts, in
     const int n_copy = total < capacity ? total : capacity;
     if (n_copy > 0)
         std::memcpy(out, s->engine->ctx->h_rb, sizeof(IlmReadbackDrawCall) * (size_t)n_copy);
+    return ILM_OK;
+}
+
+int32_t ilm_lightmap_clear(IlmHandle h, const float rgba[4]) {
+    Lightmap* m = from_handle<Lightmap>(h, kMagicLightmap);
+    if (!m) return fail(ILM_ERR_INVALID_HANDLE, "not a lightmap handle");
+    if (!rgba) return fail(ILM_ERR_INVALID_ARGUMENT, "rgba is NULL");
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    HIP_TRY(launch_clear_target(m->texels, m->format, (size_t)m->width * (size_t)m->height, make_float4(rgba[0], rgba[1], rgba[2], rgba[3]), m->ctx->stream));
+    return ILM_OK;
+}
+
+int32_t ilm_render_particles(IlmHandle hsystem, const int32_t* quad_counts, int32_t chunk_count, const IlmRasterizeParams* params,
+                             IlmHandle htarget, uint64_t* out_stats) {
+    System* s = from_handle<System>(hsystem, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    Lightmap* m = from_handle<Lightmap>(htarget, kMagicLightmap);
+    if (!m) return fail(ILM_ERR_INVALID_HANDLE, "target is not a lightmap handle");
+    if (!params) return fail(ILM_ERR_INVALID_ARGUMENT, "params is NULL");
+    Engine* e = s->engine;
+    Ctx* c = e->ctx;
+    if (m->ctx != c) return fail(ILM_ERR_INVALID_ARGUMENT, "system and target belong to different contexts");
+    // Fracture code outside the reference tree (DitherCommon.fxh): not guessed
+    if (!(params->StippleFactor >= 1.0f))
+        return fail(ILM_ERR_INVALID_ARGUMENT, "StippleFactor %g < 1 needs Fracture's StippleReject, which is not part of the reference tree", (double)params->StippleFactor);
+    if (params->RenderingOptions[1] >= 0.5f)
+        return fail(ILM_ERR_INVALID_ARGUMENT, "DitheredOpacity needs Fracture's Dither64, which is not part of the reference tree");
+    if (params->BlendMode != ILM_BLEND_ALPHA && params->BlendMode != ILM_BLEND_ADDITIVE)
+        return fail(ILM_ERR_INVALID_ARGUMENT, "unknown blend mode %d", params->BlendMode);
+    const int n = (int)s->chunks.size();
+    if (chunk_count < 0 || chunk_count > n) return fail(ILM_ERR_OUT_OF_RANGE, "chunk_count %d outside [0, %d]", chunk_count, n);
+    if (out_stats) out_stats[0] = out_stats[1] = out_stats[2] = 0;
+    if (chunk_count == 0) return ILM_OK;
+    for (int i = 0; i < chunk_count; i++) {
+        const int q = quad_counts ? quad_counts[i] : e->slots;
+        if (q < 0 || q > e->slots) return fail(ILM_ERR_OUT_OF_RANGE, "quad_counts[%d] = %d outside [0, %d]", i, q, e->slots);
+    }
+    if ((long long)chunk_count * (long long)e->slots > (long long)INT32_MAX)
+        return fail(ILM_ERR_TOO_MANY, "%d chunks of %d slots exceed the 32-bit slot index of the sort key", chunk_count, e->slots);
+    if ((m->width + 15) / 16 > 65535 || (m->height + 15) / 16 > 65535) return fail(ILM_ERR_OUT_OF_RANGE, "target too large");
+    HIP_TRY(hipSetDevice(c->device));
+    int32_t rc = refresh_table(s);
+    if (rc != ILM_OK) return rc;
+    if (quad_counts) {
+        if (chunk_count > c->raster_quads_cap) {
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            if (c->d_raster_quads) HIP_TRY(hipFree(c->d_raster_quads));
+            c->d_raster_quads = nullptr; c->raster_quads_cap = 0;
+            HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_raster_quads), sizeof(int32_t) * (size_t)chunk_count * 2));
+            c->raster_quads_cap = chunk_count * 2;
+        }
+        rc = upload_small(c, c->d_raster_quads, quad_counts, sizeof(int32_t) * (size_t)chunk_count);
+        if (rc != ILM_OK) return rc;
+    }
+    RasterLaunch a;
+    std::memset(&a, 0, sizeof(a));
+    a.chunk_bases = s->d_table; a.stride = e->stride; a.chunk_count = chunk_count; a.slots = e->slots;
+    a.total_slots = chunk_count * e->slots;
+    a.quad_counts = quad_counts ? c->d_raster_quads : nullptr;
+    a.params = *params;
+    a.target = m->texels; a.format = m->format; a.width = m->width; a.height = m->height;
+    a.tiles_x = (m->width + 15) / 16; a.tiles_y = (m->height + 15) / 16;
+    a.count_shaded = out_stats ? 1 : 0;
+    unsigned long long stats[3] = { 0, 0, 0 };
+    bool too_many = false;
+    HIP_TRY(render_particles(a, c->raster, c->stream, out_stats ? stats : nullptr, &too_many));
+    if (too_many) return fail(ILM_ERR_TOO_MANY, "more than 2^28 (quad, tile) pairs: the quads are too large for this path");
+    if (out_stats) { out_stats[0] = stats[0]; out_stats[1] = stats[1]; out_stats[2] = stats[2]; }
     return ILM_OK;
 }
 

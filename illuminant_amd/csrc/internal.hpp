@@ -220,4 +220,27 @@ struct ResolveLaunch {
 };
 hipError_t launch_resolve(const ResolveLaunch& a, hipStream_t stream);
 
+// ---- particle rasterisation (raster.hip) ------------------------------------------------------------------------
+struct Sprite;
+struct RasterLaunch {
+    float* const* chunk_bases; int64_t stride; int32_t chunk_count, slots, total_slots;
+    const int32_t* quad_counts;         // device, per chunk; nullptr => every slot
+    IlmRasterizeParams params;
+    void* target; int32_t format, width, height, tiles_x, tiles_y;
+    int32_t count_shaded;               // != 0: count the fragments that were blended (statistics)
+    // scratch, filled by render_particles
+    Sprite* sprites; uint32_t* counts; uint32_t* offsets;
+    unsigned long long* keys; unsigned long long* sorted_keys; int64_t pair_count;
+    unsigned long long* stats;          // [0] live quads, [2] shaded pixels
+};
+// device buffers the rasteriser keeps between calls (owned by the context)
+struct RasterScratch {
+    void* sprites = nullptr; void* counts = nullptr; void* offsets = nullptr; void* keys = nullptr; void* sorted_keys = nullptr;
+    void* temp = nullptr; void* stats = nullptr;
+    size_t sprites_cap = 0, counts_cap = 0, offsets_cap = 0, keys_cap = 0, sorted_cap = 0, temp_cap = 0;
+};
+hipError_t render_particles(RasterLaunch& a, RasterScratch& s, hipStream_t stream, unsigned long long out_stats[3], bool* too_many);
+void free_raster_scratch(RasterScratch& s);
+hipError_t launch_clear_target(void* texels, int format, size_t n, float4 color, hipStream_t stream);
+
 }  // namespace ilm

@@ -1,0 +1,332 @@
+// raster.hip -- particle rasterisation for gfx950: technique RasterizeParticlesNoTexture
+// (Illuminant/Shaders/RasterizeParticleSystem.fx:61-163,228-241; ParticleSystem.Render / RenderChunk,
+// Illuminant/Particles/ParticleSystem.cs:876-1041).
+//
+// The reference draws one instanced quad per slot, chunk after chunk, and lets the ROP blend them in that order.  Blending is
+// order-dependent, so the order is kept: every live particle becomes a sprite record (the inverse of its affine map unit square ->
+// pixels), each (16 x 16 pixel tile, sprite) pair a 64-bit key (tile << 32 | global slot), the keys are radix-sorted (rocPRIM, a
+// plain library sort) and one workgroup per tile walks its run of keys in slot order: 256 sprites at a time through LDS, every
+// lane = one pixel, coverage + shading + blending in registers, the target texel read once and written once.
+//
+// Compiled with -ffp-contract=off: coverage is decided by the same IEEE operations as the CPU oracle.
+#include <cstring>
+
+#include "internal.hpp"
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+namespace ilm {
+
+constexpr int kRasterTile = 16;
+
+struct Sprite {
+    float cx, cy;               // centre, pixels
+    float i00, i01, i10, i11;   // unit = I * (pixel centre - centre)
+    float r, g, b, a;           // RenderColor * GlobalColor
+    float rounding;
+    uint32_t tiles_x, tiles_y;  // first | last << 16 tile column / row of the clipped bounding box
+    uint32_t _pad;
+};
+static_assert(sizeof(Sprite) == 56, "Sprite is 14 words");
+
+ILM_DEV float bezier1_raster(const IlmClampedBezier1& bz, float value);
+
+// tForScaledBezier + evaluateBezier1 (Bezier.fxh:21-105): same restatement as particles.hip / the oracle
+ILM_DEV float raster_t_for_scaled_bezier(const IlmFloat4& rc, float value, float& t) {
+    const float inv_divisor = rc.y;
+    const unsigned mode = (unsigned)fabsf(rc.w);
+    t = (value - rc.x) * fabsf(inv_divisor);
+    if (mode > 511u) {
+        t *= 2.0f;
+        t = (inv_divisor < 0.0f) ? (2.0f - fmodf(t, 2.0f)) : fmodf(t, 2.0f);
+        if (t > 1.0f)
+            t = 1.0f - (t - 1.0f);
+    } else if (mode > 255u) {
+        t = (inv_divisor < 0.0f) ? (1.0f - fmodf(t, 1.0f)) : fmodf(t, 1.0f);
+    } else {
+        t = (inv_divisor < 0.0f) ? (1.0f - sat(t)) : sat(t);
+    }
+    const unsigned m = mode % 256u;
+    if (m == 1u)
+        t = sinf(t * kPi * 0.5f);
+    else if (m == 2u)
+        t = t * t;
+    return rc.z;
+}
+ILM_DEV float bezier1_raster(const IlmClampedBezier1& bz, float value) {
+    const float a = bz.ABCD.x, b = bz.ABCD.y, c = bz.ABCD.z, d = bz.ABCD.w;
+    if (bz.RangeAndCount.z <= 1.5f) return a;
+    float t;
+    const float count = raster_t_for_scaled_bezier(bz.RangeAndCount, value, t);
+    const float ab = lerp(a, b, t);
+    if (count <= 2.5f) return ab;
+    if (count <= 3.5f) return (t <= 0.0f) ? a : ((t >= 1.0f) ? c : b);
+    const float bc = lerp(b, c, t), cd = lerp(c, d, t);
+    return lerp(lerp(ab, bc, t), lerp(bc, cd, t), t);
+}
+
+// VS_PosVelAttr, RasterizeParticleSystem.fx:61-148, for one slot: the sprite record and the number of tiles its clipped bounding
+// box touches (0: dead, degenerate or off-screen).
+__global__ __launch_bounds__(256) void raster_setup_kernel(const RasterLaunch a) {
+    const int g = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    bool live = false;
+    uint32_t count = 0;
+    if (g < a.total_slots) {
+        const int chunk = g / a.slots, slot = g - chunk * a.slots;
+        const int quads = a.quad_counts ? a.quad_counts[chunk] : a.slots;
+        const IlmRasterizeParams& p = a.params;
+        if (slot < quads) {
+            const float* base = a.chunk_bases[chunk];
+            const int64_t S = a.stride;
+            const float life = base[3 * S + slot];
+            if (!(life <= 0.0f)) {       // `life <= 0` rejects; a NaN life does not, as in the shader
+                const float px = base[slot], py = base[S + slot], pz = base[2 * S + slot];
+                const float rd_x = base[16 * S + slot], rd_y = base[17 * S + slot];
+                const float angle = fmodf(rd_y, 2.0f * kPi);
+                float sx = rd_x * p.SystemSize[0] * p.SizeFactorAndPosition.x;
+                float sy = rd_x * p.SystemSize[1] * p.SizeFactorAndPosition.y;
+                const float zf = fmaxf(0.0f, 1.0f + (pz * p.ZConfiguration.x));
+                sx *= zf; sy *= zf;
+                const float s = sinf(angle), c = cosf(angle);
+                const float display_x = (px * p.Scale.x) + p.SizeFactorAndPosition.z;
+                const float display_y = ((py - (pz * p.ZToY)) * p.Scale.y) + p.SizeFactorAndPosition.w;
+                Sprite sp;
+                sp.cx = (display_x - p.ViewportPosition[0]) * p.ViewportScale[0];
+                sp.cy = (display_y - p.ViewportPosition[1]) * p.ViewportScale[1];
+                const float kx = p.Scale.x * p.ViewportScale[0], ky = p.Scale.y * p.ViewportScale[1];
+                const float a00 = (c * sx) * kx, a01 = -(s * sy) * kx;
+                const float a10 = (s * sx) * ky, a11 = (c * sy) * ky;
+                const float det = (a00 * a11) - (a01 * a10);
+                if ((fabsf(det) > 0.0f) && isfinite(det) && isfinite(sp.cx) && isfinite(sp.cy)) {
+                    live = true;
+                    sp.i00 = a11 / det;  sp.i01 = -a01 / det;
+                    sp.i10 = -a10 / det; sp.i11 = a00 / det;
+                    const float ex = fabsf(a00) + fabsf(a01), ey = fabsf(a10) + fabsf(a11);
+                    sp.r = base[12 * S + slot] * p.GlobalColor.x; sp.g = base[13 * S + slot] * p.GlobalColor.y;
+                    sp.b = base[14 * S + slot] * p.GlobalColor.z; sp.a = base[15 * S + slot] * p.GlobalColor.w;
+                    sp.rounding = clampf(bezier1_raster(p.RoundingPowerFromLife, life), 0.001f, 1.0f);
+                    // pixel centres within the bounding box, one pixel of slack (the unit-square test decides), clipped to the target
+                    float fx0 = floorf(sp.cx - ex - 0.5f) - 1.0f, fx1 = ceilf(sp.cx + ex - 0.5f) + 1.0f;
+                    float fy0 = floorf(sp.cy - ey - 0.5f) - 1.0f, fy1 = ceilf(sp.cy + ey - 0.5f) + 1.0f;
+                    fx0 = fmaxf(fx0, 0.0f); fy0 = fmaxf(fy0, 0.0f);
+                    fx1 = fminf(fx1, (float)(a.width - 1)); fy1 = fminf(fy1, (float)(a.height - 1));
+                    sp.tiles_x = sp.tiles_y = 0u; sp._pad = 0u;
+                    if ((fx0 <= fx1) && (fy0 <= fy1)) {
+                        const uint32_t tx0 = (uint32_t)fx0 / kRasterTile, tx1 = (uint32_t)fx1 / kRasterTile;
+                        const uint32_t ty0 = (uint32_t)fy0 / kRasterTile, ty1 = (uint32_t)fy1 / kRasterTile;
+                        sp.tiles_x = tx0 | (tx1 << 16); sp.tiles_y = ty0 | (ty1 << 16);
+                        count = (tx1 - tx0 + 1u) * (ty1 - ty0 + 1u);
+                    }
+                    a.sprites[g] = sp;
+                }
+            }
+        }
+        a.counts[g] = count;
+    }
+    const unsigned long long m = __ballot(live);
+    if (((threadIdx.x & 63u) == 0u) && m != 0ull)
+        atomicAdd(&a.stats[0], (unsigned long long)__popcll(m));
+}
+
+// one key per (tile, sprite): tile << 32 | global slot -- sorting them lists every tile's sprites in chunk / slot order
+__global__ __launch_bounds__(256) void raster_emit_kernel(const RasterLaunch a) {
+    const int g = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (g >= a.total_slots) return;
+    const uint32_t count = a.counts[g];
+    if (count == 0u) return;
+    const Sprite& sp = a.sprites[g];
+    const uint32_t tx0 = sp.tiles_x & 0xFFFFu, tx1 = sp.tiles_x >> 16, ty0 = sp.tiles_y & 0xFFFFu, ty1 = sp.tiles_y >> 16;
+    unsigned long long* out = a.keys + a.offsets[g];
+    for (uint32_t ty = ty0; ty <= ty1; ty++)
+        for (uint32_t tx = tx0; tx <= tx1; tx++)
+            *out++ = ((unsigned long long)(ty * (uint32_t)a.tiles_x + tx) << 32) | (unsigned long long)(uint32_t)g;
+}
+
+template <int FORMAT>
+ILM_DEV float4 load_target(const void* texels, size_t o) {
+    if (FORMAT == ILM_LIGHTMAP_FLOAT4) return reinterpret_cast<const float4*>(texels)[o];
+    if (FORMAT == ILM_LIGHTMAP_HALF4) {
+        const uint2 v = reinterpret_cast<const uint2*>(texels)[o];
+        return mk4(__half2float(__ushort_as_half((unsigned short)(v.x & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(v.x >> 16))),
+                   __half2float(__ushort_as_half((unsigned short)(v.y & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(v.y >> 16))));
+    }
+    const uint32_t v = reinterpret_cast<const uint32_t*>(texels)[o];
+    return mk4((float)(v & 255u) / 255.0f, (float)((v >> 8) & 255u) / 255.0f, (float)((v >> 16) & 255u) / 255.0f, (float)(v >> 24) / 255.0f);
+}
+template <int FORMAT>
+ILM_DEV void store_target(void* texels, size_t o, float4 c) {
+    if (FORMAT == ILM_LIGHTMAP_FLOAT4) {
+        reinterpret_cast<float4*>(texels)[o] = c;
+    } else if (FORMAT == ILM_LIGHTMAP_HALF4) {
+        uint2 v;
+        v.x = (uint32_t)__half_as_ushort(__float2half_rn(c.x)) | ((uint32_t)__half_as_ushort(__float2half_rn(c.y)) << 16);
+        v.y = (uint32_t)__half_as_ushort(__float2half_rn(c.z)) | ((uint32_t)__half_as_ushort(__float2half_rn(c.w)) << 16);
+        reinterpret_cast<uint2*>(texels)[o] = v;
+    } else {
+        const uint32_t r = (uint32_t)rintf(sat(c.x) * 255.0f), g = (uint32_t)rintf(sat(c.y) * 255.0f);
+        const uint32_t b = (uint32_t)rintf(sat(c.z) * 255.0f), al = (uint32_t)rintf(sat(c.w) * 255.0f);
+        reinterpret_cast<uint32_t*>(texels)[o] = r | (g << 8) | (b << 16) | (al << 24);
+    }
+}
+
+// first index whose key is >= value
+ILM_DEV int64_t key_lower_bound(const unsigned long long* keys, int64_t n, unsigned long long value) {
+    int64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < value) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// PS_NoTexture + the blend, RasterizeParticleSystem.fx:150-163,228-241: one workgroup per tile, one lane per pixel
+template <int FORMAT>
+__global__ __launch_bounds__(256) void raster_tiles_kernel(const RasterLaunch a) {
+    __shared__ Sprite batch[256];
+    __shared__ int64_t range[2];
+    const int tile = (int)blockIdx.x;
+    const int tid = (int)threadIdx.x;
+    if (tid < 2)
+        range[tid] = key_lower_bound(a.sorted_keys, a.pair_count, (unsigned long long)(uint32_t)(tile + tid) << 32);
+    __syncthreads();
+    const int64_t begin = range[0], end = range[1];
+    if (begin == end) return;                               // uniform: no sprite touches this tile, the texels stay as they are
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const int x = tx * kRasterTile + (tid & 15), y = ty * kRasterTile + (tid >> 4);
+    const bool in_image = (x < a.width) && (y < a.height);
+    const size_t o = (size_t)y * (size_t)a.width + (size_t)x;
+    float4 dst = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (in_image) dst = load_target<FORMAT>(a.target, o);
+    const float pcx = (float)x + 0.5f, pcy = (float)y + 0.5f;
+    const bool rounded = a.params.RenderingOptions[0] != 0.0f;
+    const bool additive = a.params.BlendMode == ILM_BLEND_ADDITIVE;
+    uint32_t shaded = 0;
+    for (int64_t base = begin; base < end; base += 256) {
+        const int n = (int)((end - base < 256) ? (end - base) : 256);
+        __syncthreads();
+        if (tid < n)
+            batch[tid] = a.sprites[(uint32_t)(a.sorted_keys[base + tid] & 0xFFFFFFFFull)];
+        __syncthreads();
+        if (!in_image) continue;
+        for (int k = 0; k < n; k++) {
+            const Sprite& sp = batch[k];
+            const float dx = pcx - sp.cx, dy = pcy - sp.cy;
+            const float u = (sp.i00 * dx) + (sp.i01 * dy), v = (sp.i10 * dx) + (sp.i11 * dy);
+            if (!((u >= -1.0f) && (u < 1.0f) && (v >= -1.0f) && (v < 1.0f)))
+                continue;
+            float alpha = 1.0f;
+            if (rounded) {
+                // computeCircularAlpha
+                const float distance = sqrtf((u * u) + (v * v));
+                const float power = fmaxf(sp.rounding, 0.01f);
+                const float divisor = fmaxf(sat(1.0f - power), 0.001f);
+                const float distance_from_edge = sat(distance - power) / divisor;
+                alpha = sat(1.0f - pow_pos(distance_from_edge, power));
+            }
+            const float sr = sp.r * alpha, sg = sp.g * alpha, sb = sp.b * alpha, sa = sp.a * alpha;
+            if (sa <= 0.0f)                                 // `result.a <= (1 / 512)`: an integer division in the shader, i.e. <= 0
+                continue;
+            shaded++;
+            const float keep = additive ? 1.0f : (1.0f - sa);
+            dst.x = sr + (dst.x * keep); dst.y = sg + (dst.y * keep);
+            dst.z = sb + (dst.z * keep); dst.w = sa + (dst.w * keep);
+        }
+    }
+    if (in_image) store_target<FORMAT>(a.target, o, dst);
+    if (a.count_shaded) {
+        for (int off = 32; off > 0; off >>= 1) shaded += __shfl_down(shaded, off);
+        if (((tid & 63) == 0) && shaded != 0u) atomicAdd(&a.stats[2], (unsigned long long)shaded);
+    }
+}
+
+template <int FORMAT>
+__global__ __launch_bounds__(256) void clear_target_kernel(void* texels, size_t n, float4 c) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) store_target<FORMAT>(texels, i, c);
+}
+
+hipError_t launch_clear_target(void* texels, int format, size_t n, float4 color, hipStream_t stream) {
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (format == ILM_LIGHTMAP_FLOAT4) hipLaunchKernelGGL(clear_target_kernel<ILM_LIGHTMAP_FLOAT4>, grid, block, 0, stream, texels, n, color);
+    else if (format == ILM_LIGHTMAP_HALF4) hipLaunchKernelGGL(clear_target_kernel<ILM_LIGHTMAP_HALF4>, grid, block, 0, stream, texels, n, color);
+    else hipLaunchKernelGGL(clear_target_kernel<ILM_LIGHTMAP_RGBA8>, grid, block, 0, stream, texels, n, color);
+    return hipGetLastError();
+}
+
+#define RASTER_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
+
+static hipError_t grow(void** p, size_t* cap, size_t bytes, hipStream_t stream) {
+    if (bytes <= *cap) return hipSuccess;
+    RASTER_TRY(hipStreamSynchronize(stream));
+    if (*p) RASTER_TRY(hipFree(*p));
+    *p = nullptr; *cap = 0;
+    const size_t want = bytes + bytes / 4 + 4096;
+    RASTER_TRY(hipMalloc(p, want));
+    *cap = want;
+    return hipSuccess;
+}
+
+void free_raster_scratch(RasterScratch& s) {
+    void** ptrs[] = { &s.sprites, &s.counts, &s.offsets, &s.keys, &s.sorted_keys, &s.temp, &s.stats };
+    for (void** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
+    s.sprites_cap = s.counts_cap = s.offsets_cap = s.keys_cap = s.sorted_cap = s.temp_cap = 0;
+}
+
+// setup -> scan -> emit -> sort -> tiles.  One host synchronisation (the pair count sizes the key buffers).
+hipError_t render_particles(RasterLaunch& a, RasterScratch& s, hipStream_t stream, unsigned long long out_stats[3], bool* too_many) {
+    *too_many = false;
+    const size_t n = (size_t)a.total_slots;
+    RASTER_TRY(grow(&s.sprites, &s.sprites_cap, n * sizeof(Sprite), stream));
+    RASTER_TRY(grow(&s.counts, &s.counts_cap, n * sizeof(uint32_t), stream));
+    RASTER_TRY(grow(&s.offsets, &s.offsets_cap, n * sizeof(uint32_t), stream));
+    if (!s.stats) RASTER_TRY(hipMalloc(&s.stats, 4 * sizeof(unsigned long long)));
+    RASTER_TRY(hipMemsetAsync(s.stats, 0, 4 * sizeof(unsigned long long), stream));
+    a.sprites = static_cast<Sprite*>(s.sprites);
+    a.counts = static_cast<uint32_t*>(s.counts);
+    a.offsets = static_cast<uint32_t*>(s.offsets);
+    a.stats = static_cast<unsigned long long*>(s.stats);
+    const dim3 block(256), slot_grid((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL(raster_setup_kernel, slot_grid, block, 0, stream, a);
+    RASTER_TRY(hipGetLastError());
+    size_t scan_bytes = 0;
+    RASTER_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, a.counts, a.offsets, 0u, n, rocprim::plus<uint32_t>(), stream));
+    RASTER_TRY(grow(&s.temp, &s.temp_cap, scan_bytes, stream));
+    RASTER_TRY(rocprim::exclusive_scan(s.temp, scan_bytes, a.counts, a.offsets, 0u, n, rocprim::plus<uint32_t>(), stream));
+    uint32_t last[2] = { 0u, 0u };
+    RASTER_TRY(hipMemcpyAsync(&last[0], a.offsets + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    RASTER_TRY(hipMemcpyAsync(&last[1], a.counts + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    RASTER_TRY(hipStreamSynchronize(stream));
+    const unsigned long long pairs = (unsigned long long)last[0] + (unsigned long long)last[1];
+    // (the 32-bit scan would have wrapped long before this bound if it were exceeded: one pair per slot and tile, 2^28 keys = 2 GiB)
+    if (pairs > (1ull << 28)) { *too_many = true; return hipSuccess; }
+    a.pair_count = (int64_t)pairs;
+    if (pairs > 0) {
+        RASTER_TRY(grow(&s.keys, &s.keys_cap, pairs * sizeof(unsigned long long), stream));
+        RASTER_TRY(grow(&s.sorted_keys, &s.sorted_cap, pairs * sizeof(unsigned long long), stream));
+        a.keys = static_cast<unsigned long long*>(s.keys);
+        a.sorted_keys = static_cast<unsigned long long*>(s.sorted_keys);
+        hipLaunchKernelGGL(raster_emit_kernel, slot_grid, block, 0, stream, a);
+        RASTER_TRY(hipGetLastError());
+        int tile_bits = 1;
+        while ((1 << tile_bits) < a.tiles_x * a.tiles_y) tile_bits++;
+        size_t sort_bytes = 0;
+        RASTER_TRY(rocprim::radix_sort_keys(nullptr, sort_bytes, a.keys, a.sorted_keys, (size_t)pairs, 0u, (unsigned)(32 + tile_bits), stream));
+        RASTER_TRY(grow(&s.temp, &s.temp_cap, sort_bytes, stream));
+        RASTER_TRY(rocprim::radix_sort_keys(s.temp, sort_bytes, a.keys, a.sorted_keys, (size_t)pairs, 0u, (unsigned)(32 + tile_bits), stream));
+        const dim3 tile_grid((unsigned)(a.tiles_x * a.tiles_y));
+        if (a.format == ILM_LIGHTMAP_FLOAT4) hipLaunchKernelGGL(raster_tiles_kernel<ILM_LIGHTMAP_FLOAT4>, tile_grid, block, 0, stream, a);
+        else if (a.format == ILM_LIGHTMAP_HALF4) hipLaunchKernelGGL(raster_tiles_kernel<ILM_LIGHTMAP_HALF4>, tile_grid, block, 0, stream, a);
+        else hipLaunchKernelGGL(raster_tiles_kernel<ILM_LIGHTMAP_RGBA8>, tile_grid, block, 0, stream, a);
+        RASTER_TRY(hipGetLastError());
+    }
+    if (out_stats) {
+        unsigned long long h[4];
+        RASTER_TRY(hipMemcpyAsync(h, s.stats, sizeof(h), hipMemcpyDeviceToHost, stream));
+        RASTER_TRY(hipStreamSynchronize(stream));
+        out_stats[0] = h[0]; out_stats[1] = pairs; out_stats[2] = h[2];
+    }
+    return hipSuccess;
+}
+
+}  // namespace ilm

@@ -85,6 +85,8 @@ SYMBOLS = {
     "ilm_render_light_probes": (_I, [_H, _P, _I, _P, _P, _I, _P, _P, _H, _P]),
     "ilm_system_readback": (_I, [_H, _P, _I, _P, _P, _I, C.POINTER(_I)]),
     "ilm_system_readback_view": (_I, [_H, _P, _I, _P, C.POINTER(_P), C.POINTER(_I)]),
+    "ilm_render_particles": (_I, [_H, _P, _I, _P, _H, _P]),
+    "ilm_lightmap_clear": (_I, [_H, _P]),
     "ilm_resolve_lighting": (_I, [_H, _H, _P, _I, _I]),
 }
 
@@ -442,10 +444,27 @@ class Lightmap:
         check(lib().ilm_lightmap_device_ptr(self.handle, C.byref(p)))
         return p.value
 
+    def clear(self, rgba=(0.0, 0.0, 0.0, 0.0)):
+        """ilm_lightmap_clear"""
+        c = (C.c_float * 4)(*rgba)
+        check(lib().ilm_lightmap_clear(self.handle, c))
+
     def close(self):
         if self.handle.value:
             lib().ilm_lightmap_destroy(self.handle)
             self.handle = abi.Handle(0)
+
+
+def render_particles(system, params, target, quad_counts=None, chunk_count=None, want_stats=False):
+    """ilm_render_particles: blends the live particles of `system` onto the lightmap `target` in chunk / slot order.
+    Returns (live quads, (quad, tile) pairs, shaded pixels) when want_stats."""
+    if chunk_count is None:
+        chunk_count = system.chunk_count()
+    q = np.ascontiguousarray(quad_counts, dtype=np.int32) if quad_counts is not None else None
+    stats = (C.c_uint64 * 3)() if want_stats else None
+    check(lib().ilm_render_particles(system.handle, _ptr(q) if q is not None else None, chunk_count, _byref(params), target.handle,
+                                     C.cast(stats, C.c_void_p) if stats is not None else None))
+    return tuple(int(x) for x in stats) if want_stats else None
 
 
 def render_sphere_lights(ctx, lights, env, df, gbuffer, sdf, ambient, lightmap, row_begin=0, row_end=None, want_stats=False):

@@ -182,6 +182,33 @@ def feedback_params(source_system_handle, source_chunk_index, source_index, inst
     return f
 
 
+def rasterize_params(size=(1.0, 1.0), global_color=(1.0, 1.0, 1.0, 1.0), origin=(0.0, 0.0), scale=(1.0, 1.0), size_from_z=0.0, z_to_y=0.0,
+                     rounded=False, rounding_power=None, viewport_scale=(1.0, 1.0), viewport_position=(0.0, 0.0), blend=abi.BLEND_ALPHA,
+                     z_formula=(0.0, 0.0, 0.0, 0.0), stipple_factor=1.0):
+    """Uniforms.RasterizeParticleSystem for a system without a texture (Uniforms.cs:238-290) + what ParticleSystem.Render /
+    RenderHandler._BeforeDraw add (ParticleSystem.cs:254-271, 1023-1032).  global_color is Color.Global (NOT premultiplied: the ctor
+    does that); rounding_power: a ClampedBezier1 or None for the constant 0.8 (ParticleAppearance.RoundingPowerFromLife default)."""
+    p = abi.RasterizeParams()
+    gc = np.asarray(global_color, np.float32)
+    p.GlobalColor = abi.f4(gc[0] * gc[3], gc[1] * gc[3], gc[2] * gc[3], gc[3])
+    p.BitmapTextureRegion = abi.f4(0, 0, 1, 1)
+    p.SizeFactorAndPosition = abi.f4(1, 1, origin[0], origin[1])
+    p.Scale = abi.f4(scale[0], scale[1], 0, 0)
+    p.ZFormula = abi.f4(*z_formula)
+    p.ZConfiguration = abi.f4(size_from_z, 0, 0, 0)
+    if rounding_power is None:
+        rounding_power = abi.ClampedBezier1.constant(0.8)
+    p.RoundingPowerFromLife = rounding_power
+    p.RenderingOptions[:] = [1.0 if rounded else 0.0, 0.0, 0.0, 0.0]
+    p.SystemSize[:] = list(size)
+    p.ZToY = z_to_y
+    p.StippleFactor = stipple_factor
+    p.ViewportScale[:] = list(viewport_scale)
+    p.ViewportPosition[:] = list(viewport_position)
+    p.BlendMode = blend
+    return p
+
+
 def next_power_of_two(v):
     """Arithmetic.NextPowerOfTwo (Fracture, not in the tree): the smallest power of two >= v; 0 for v <= 0 (PatternSpawner.BeginTick treats
     a non-positive particle count as "nothing to spawn", SpecialSpawners.cs:189-194)."""

@@ -645,6 +645,48 @@ int32_t ilm_system_readback_view(IlmHandle system, const int32_t* element_counts
 
 enum { ILM_HDR_NONE = 0, ILM_HDR_GAMMA_COMPRESS = 1, ILM_HDR_TONE_MAP = 2 };   /* HDRMode, LightingRenderer.HDR.cs:254-258 */
 
+/* ---- particle rasterisation (technique RasterizeParticlesNoTexture) ------------------------------------------- */
+
+enum {
+    ILM_BLEND_ALPHA    = 0,  /* BlendState.AlphaBlend on premultiplied colour: dst = src + dst * (1 - src.a) */
+    ILM_BLEND_ADDITIVE = 1   /* BlendState.Additive-like (One, One): dst = src + dst */
+};
+
+/* What ParticleSystem.Render binds for the rasterise techniques: Uniforms.RasterizeParticleSystem (Illuminant/Uniforms.cs:238-290),
+ * RoundingPowerFromLife, RenderingOptions, StippleFactor (Illuminant/Particles/ParticleSystem.cs:943-1041, :254-271) and the bits of
+ * Uniforms.ParticleSystem the vertex shader reads (TexelAndSize.zw, ZToY).  The view transform -- Fracture's ViewTransformCommon.fxh,
+ * outside the tree -- is reduced to the default one of a render target: pixel = (display - ViewportPosition) * ViewportScale,
+ * pixel centres at +0.5; the depth formula is carried but unused (no depth buffer). */
+typedef struct IlmRasterizeParams {
+    IlmFloat4 GlobalColor;             /* Color.Global, premultiplied (Uniforms.cs:279-283) */
+    IlmFloat4 BitmapTextureRegion;     /* (0, 0, 1, 1) without a texture; not read by NoTexture */
+    IlmFloat4 SizeFactorAndPosition;   /* (1, 1, origin.xy) without a texture */
+    IlmFloat4 Scale;                   /* (scale.xy, 0, 0) */
+    IlmFloat4 ZFormula;
+    IlmFloat4 ZConfiguration;          /* (SizeFromZ, 0, 0, 0) */
+    IlmClampedBezier1 RoundingPowerFromLife;
+    float     RenderingOptions[4];     /* Rounded, DitheredOpacity (must be 0: Dither64 is Fracture code), column / row from velocity */
+    float     SystemSize[2];           /* System.TexelAndSize.zw = Configuration.Size */
+    float     ZToY;
+    float     StippleFactor;           /* must be >= 1 (StippleReject is Fracture code) */
+    float     ViewportScale[2], ViewportPosition[2];
+    int32_t   BlendMode;               /* ILM_BLEND_* */
+    int32_t   _pad[3];
+} IlmRasterizeParams;
+
+/* ParticleSystem.Render with technique RasterizeParticlesNoTexture (Illuminant/Shaders/RasterizeParticleSystem.fx:61-260,
+ * Illuminant/Particles/ParticleSystem.cs:876-1041): every live particle of the first chunk_count chunks becomes a rotated quad
+ * (VS_PosVelAttr) shaded by PS_NoTexture (colour x GlobalColor x computeCircularAlpha, discard at alpha <= 0 -- the shader's
+ * `1 / 512` is an integer division) and blended onto `target` (a lightmap object used as the render target) IN CHUNK / SLOT ORDER,
+ * as the instanced draws of RenderChunk do.  quad_counts[i] = min(ChunkMaximumCount, TotalSpawned + 1) slots of chunk i take part
+ * (NULL => every slot).  A pixel belongs to a quad when its centre maps to unit coordinates in [-1, 1) x [-1, 1) (the top-left rule
+ * of an axis-aligned quad, carried along with the rotation).  Sorted on the device by (16 x 16 tile, slot); nothing is read back.
+ * out_stats (may be NULL): [0] live quads, [1] (quad, tile) pairs, [2] shaded pixels (fragments not discarded). */
+int32_t ilm_render_particles(IlmHandle system, const int32_t* quad_counts, int32_t chunk_count, const IlmRasterizeParams* params,
+                             IlmHandle target, uint64_t* out_stats);
+/* Fill a lightmap / render target with one colour (the Clear before ParticleSystem.Render). */
+int32_t ilm_lightmap_clear(IlmHandle lightmap, const float rgba[4]);
+
 /* HDRConfiguration (Illuminant/Lighting/LightingRenderer.HDR.cs:198-252) as LightingResolveHandler._Before binds it
  * (Illuminant/Lighting/LightingRenderer.cs:1463-1520; clamps of IlluminantMaterials.cs:81-137 are applied by the library). */
 typedef struct IlmHDRConfiguration {

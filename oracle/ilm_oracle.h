@@ -120,6 +120,10 @@ int32_t orc_fill_readback_result(IlmFloat4** planes, int32_t chunk_count, const 
                                  const IlmReadbackParams* p, IlmReadbackDrawCall* out, int32_t capacity);
 void orc_resolve_lighting(const IlmFloat4* lightmap, int32_t width, int32_t height, const IlmHDRConfiguration* hdr,
                           IlmFloat4* out, int32_t row_begin, int32_t row_end);
+/* technique RasterizeParticlesNoTexture: blends the live particles of the chunks onto image (width * height float4) in chunk / slot
+ * order; stats (may be NULL): [0] live quads, [1] shaded pixels */
+void orc_render_particles(IlmFloat4** planes, int32_t chunk_count, const int32_t* quad_counts, int32_t slots,
+                          const IlmRasterizeParams* p, IlmFloat4* image, int32_t width, int32_t height, uint64_t* stats);
 
 /* host-side integer/layout logic */
 typedef struct OrcDistanceFieldLayout {

@@ -113,3 +113,102 @@ void orc_resolve_lighting(const IlmFloat4* lightmap, int32_t width, int32_t heig
             out[(size_t)y * (size_t)width + (size_t)x] = r;
         }
 }
+
+/* ---- particle rasterisation: technique RasterizeParticlesNoTexture ------------------------------------------------------------
+ * VS_PosVelAttr + PS_NoTexture, Illuminant/Shaders/RasterizeParticleSystem.fx:61-148,150-163,228-241, drawn one instanced quad per
+ * slot in chunk / slot order (RenderChunk, Illuminant/Particles/ParticleSystem.cs:876-908) with the blend state of the caller.
+ * The view transform (Fracture, not in the tree) is the default one of a render target: pixel = screen * ViewportScale with pixel
+ * centres at + 0.5; a pixel belongs to the quad when its centre maps to unit coordinates in [-1, 1) x [-1, 1).  No depth buffer.
+ * One sprite in pixel space: centre + the inverse of the affine map unit square -> pixels. */
+typedef struct OrcSprite {
+    float cx, cy;               /* centre, pixels */
+    float i00, i01, i10, i11;   /* unit = I * (pixel - centre) */
+    float ex, ey;               /* half extents of the bounding box, pixels */
+    f4 color;                   /* RenderColor * GlobalColor */
+    float rounding;
+    int live;
+} OrcSprite;
+
+static OrcSprite raster_sprite(f4 position, f4 render_data, f4 render_color, const IlmRasterizeParams* p) {
+    OrcSprite sp;
+    memset(&sp, 0, sizeof(sp));
+    const float life = position.w;
+    if (life <= 0.0f)                                     /* StippleReject: StippleFactor >= 1 rejects nothing */
+        return sp;
+    float angle = fmodf(render_data.y, (float)(2 * M_PI));
+    float sx = render_data.x * p->SystemSize[0] * p->SizeFactorAndPosition.x;
+    float sy = render_data.x * p->SystemSize[1] * p->SizeFactorAndPosition.y;
+    const float zf = fmaxf(0.0f, 1.0f + (position.z * p->ZConfiguration.x));
+    sx *= zf; sy *= zf;
+    const float s = sinf(angle), c = cosf(angle);
+    const float display_x = (position.x * p->Scale.x) + p->SizeFactorAndPosition.z;
+    const float display_y = ((position.y - (position.z * p->ZToY)) * p->Scale.y) + p->SizeFactorAndPosition.w;
+    sp.cx = (display_x - p->ViewportPosition[0]) * p->ViewportScale[0];
+    sp.cy = (display_y - p->ViewportPosition[1]) * p->ViewportScale[1];
+    /* rotatedCorner = (c ux sx - s uy sy, s ux sx + c uy sy) * Scale.xy, then * ViewportScale: pixel - centre = A * unit */
+    const float kx = p->Scale.x * p->ViewportScale[0], ky = p->Scale.y * p->ViewportScale[1];
+    const float a00 = (c * sx) * kx, a01 = -(s * sy) * kx;
+    const float a10 = (s * sx) * ky, a11 = (c * sy) * ky;
+    const float det = (a00 * a11) - (a01 * a10);
+    if (!(fabsf(det) > 0.0f) || !isfinite(det) || !isfinite(sp.cx) || !isfinite(sp.cy))
+        return sp;                                        /* degenerate quad: no pixel */
+    sp.i00 = a11 / det;  sp.i01 = -a01 / det;
+    sp.i10 = -a10 / det; sp.i11 = a00 / det;
+    sp.ex = fabsf(a00) + fabsf(a01);
+    sp.ey = fabsf(a10) + fabsf(a11);
+    sp.color = v4mul(render_color, p->GlobalColor);
+    sp.rounding = h_clamp(orc_bezier1(&p->RoundingPowerFromLife, life), 0.001f, 1.0f);
+    sp.live = 1;
+    return sp;
+}
+
+/* computeCircularAlpha, RasterizeParticleSystem.fx:150-163 */
+static float raster_circular_alpha(float u, float v, float rounding, float rounded) {
+    if (rounded == 0.0f)
+        return 1.0f;
+    const float distance = sqrtf((u * u) + (v * v));
+    const float power = fmaxf(rounding, 0.01f);
+    const float divisor = fmaxf(h_sat(1.0f - power), 0.001f);
+    const float distance_from_edge = h_sat(distance - power) / divisor;
+    return h_sat(1.0f - powf(distance_from_edge, power));
+}
+
+/* image: width * height float4, blended in place.  stats (may be NULL): live quads, shaded pixels. */
+void orc_render_particles(IlmFloat4** planes, int32_t chunk_count, const int32_t* quad_counts, int32_t slots,
+                          const IlmRasterizeParams* p, IlmFloat4* image, int32_t width, int32_t height, uint64_t* stats) {
+    uint64_t live = 0, shaded = 0;
+    for (int c = 0; c < chunk_count; c++) {
+        const int count = quad_counts ? quad_counts[c] : slots;
+        for (int i = 0; i < count && i < slots; i++) {
+            const OrcSprite sp = raster_sprite(planes[c * 5 + 0][i], planes[c * 5 + 4][i], planes[c * 5 + 3][i], p);
+            if (!sp.live)
+                continue;
+            live++;
+            /* pixel centres within the bounding box (one pixel of slack; the unit-square test decides) */
+            float fx0 = floorf(sp.cx - sp.ex - 0.5f) - 1.0f, fx1 = ceilf(sp.cx + sp.ex - 0.5f) + 1.0f;
+            float fy0 = floorf(sp.cy - sp.ey - 0.5f) - 1.0f, fy1 = ceilf(sp.cy + sp.ey - 0.5f) + 1.0f;
+            if (fx0 < 0.0f) fx0 = 0.0f; if (fy0 < 0.0f) fy0 = 0.0f;
+            if (fx1 > (float)(width - 1)) fx1 = (float)(width - 1);
+            if (fy1 > (float)(height - 1)) fy1 = (float)(height - 1);
+            if (!(fx0 <= fx1) || !(fy0 <= fy1))
+                continue;
+            for (int y = (int)fy0; y <= (int)fy1; y++)
+                for (int x = (int)fx0; x <= (int)fx1; x++) {
+                    const float dx = ((float)x + 0.5f) - sp.cx, dy = ((float)y + 0.5f) - sp.cy;
+                    const float u = (sp.i00 * dx) + (sp.i01 * dy), v = (sp.i10 * dx) + (sp.i11 * dy);
+                    if (!((u >= -1.0f) && (u < 1.0f) && (v >= -1.0f) && (v < 1.0f)))
+                        continue;
+                    const float alpha = raster_circular_alpha(u, v, sp.rounding, p->RenderingOptions[0]);
+                    const f4 src = v4scale(sp.color, alpha);
+                    if (src.w <= 0.0f)                    /* `result.a <= (1 / 512)`: integer division, i.e. <= 0 */
+                        continue;
+                    shaded++;
+                    f4* dst = &image[(size_t)y * (size_t)width + (size_t)x];
+                    const float keep = (p->BlendMode == ILM_BLEND_ADDITIVE) ? 1.0f : (1.0f - src.w);
+                    dst->x = src.x + (dst->x * keep); dst->y = src.y + (dst->y * keep);
+                    dst->z = src.z + (dst->z * keep); dst->w = src.w + (dst->w * keep);
+                }
+        }
+    }
+    if (stats) { stats[0] = live; stats[1] = shaded; }
+}

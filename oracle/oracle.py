@@ -313,6 +313,22 @@ def fill_readback_result(chunks, params, element_counts=None, capacity=None):
     return out, int(total)
 
 
+def render_particles(chunks, params, width, height, quad_counts=None, image=None):
+    """orc_render_particles: (image (h, w, 4) float32 blended in place / created black, (live quads, shaded pixels))."""
+    n = len(chunks)
+    slots = chunks[0][0].shape[0]
+    ptrs = (C.c_void_p * (n * 5))()
+    for c, planes in enumerate(chunks):
+        for k in range(5):
+            ptrs[c * 5 + k] = _f4(planes[k]).value
+    q = np.ascontiguousarray(quad_counts, dtype=np.int32) if quad_counts is not None else None
+    if image is None:
+        image = np.zeros((height, width, 4), np.float32)
+    stats = (C.c_uint64 * 2)()
+    lib().orc_render_particles(ptrs, C.c_int32(n), _p(q), C.c_int32(slots), C.byref(params), _f4(image), C.c_int32(width), C.c_int32(height), stats)
+    return image, (int(stats[0]), int(stats[1]))
+
+
 def resolve_lighting(lightmap, hdr, row_begin=0, row_end=None):
     h, w = lightmap.shape[0], lightmap.shape[1]
     out = np.zeros_like(lightmap)

@@ -669,8 +669,84 @@ def gen_output_ext():
                       "(hand-evaluated; see comments in make_golden.py)", "tolerance": "1e-5 relative; colour bytes and record order exact", "cases": cases}
 
 
+# ---------------------------------------------------------------------------------------------------------
+# 12. Particle rasterisation: closed forms from RasterizeParticleSystem.fx:61-163,228-241 (technique
+#     RasterizeParticlesNoTexture), Uniforms.cs:238-290.  Pixel (x, y) belongs to a quad when its centre (x + .5, y + .5) maps to
+#     unit coordinates in [-1, 1) x [-1, 1); blending is BlendState.AlphaBlend on premultiplied colour unless "additive".
+# ---------------------------------------------------------------------------------------------------------
+def gen_rasterize():
+    cases = []
+    clear = [0.1, 0.1, 0.1, 1.0]
+    over = lambda src, dst: [src[k] + dst[k] * (1.0 - src[3]) for k in range(4)]
+    add = lambda src, dst: [src[k] + dst[k] for k in range(4)]
+    sq = lambda x0, x1, y0, y1: [[x, y] for y in range(y0, y1 + 1) for x in range(x0, x1 + 1)]
+    # (a) axis-aligned square of half size 3 around (10, 8): centres with |d| < 3 => x 7..12, y 5..10
+    src = [0.2, 0.4, 0.6, 0.8]
+    cases.append({"name": "axis-aligned square", "width": 24, "height": 20, "clear": clear, "live_quads": 1, "shaded_pixels": 36,
+                  "particles": [{"slot": 5, "position": [10.0, 8.0, 0.0, 1.0], "size": 3.0, "rotation": 0.0, "color": src}],
+                  "pixels": [{"x": 7, "y": 5, "rgba": over(src, clear)}, {"x": 12, "y": 10, "rgba": over(src, clear)},
+                             {"x": 6, "y": 5, "rgba": clear}, {"x": 13, "y": 10, "rgba": clear}],
+                  "covered": sq(7, 12, 5, 10)})
+    # (b) the half-open rule: centre on a pixel-centre lattice point (10.5, 8.5) => d = x - 10 in [-3, 3): the left / top edge pixel
+    #     (d = -3) is in, the right / bottom one (d = +3) is out
+    cases.append({"name": "top-left rule", "width": 24, "height": 20, "clear": clear, "live_quads": 1, "shaded_pixels": 36,
+                  "particles": [{"slot": 0, "position": [10.5, 8.5, 0.0, 1.0], "size": 3.0, "rotation": 0.0, "color": src}],
+                  "pixels": [{"x": 7, "y": 5, "rgba": over(src, clear)}, {"x": 13, "y": 8, "rgba": clear}, {"x": 10, "y": 11, "rgba": clear}],
+                  "covered": sq(7, 12, 5, 10)})
+    # (c) rotation by pi / 2 swaps the extents: size (2, 1) * 2 = (4, 2) => 2 wide, 4 high half extents around (10.25, 8.25)
+    cases.append({"name": "quarter turn", "width": 24, "height": 20, "clear": clear, "live_quads": 1, "shaded_pixels": 32,
+                  "params": {"size": [2.0, 1.0]},
+                  "particles": [{"slot": 9, "position": [10.25, 8.25, 0.0, 1.0], "size": 2.0, "rotation": math.pi / 2, "color": src}],
+                  "pixels": [{"x": 8, "y": 4, "rgba": over(src, clear)}, {"x": 11, "y": 11, "rgba": over(src, clear)}, {"x": 7, "y": 8, "rgba": clear},
+                             {"x": 12, "y": 8, "rgba": clear}],
+                  "covered": sq(8, 11, 4, 11)})
+    # (d) draw order = slot order: half-transparent red (slot 3) under half-transparent green (slot 7)
+    red, green = [0.5, 0.0, 0.0, 0.5], [0.0, 0.5, 0.0, 0.5]
+    black = [0.0, 0.0, 0.0, 0.0]
+    two = [{"slot": 7, "position": [12.0, 10.0, 0.0, 1.0], "size": 3.0, "rotation": 0.0, "color": green},
+           {"slot": 3, "position": [10.0, 10.0, 0.0, 1.0], "size": 3.0, "rotation": 0.0, "color": red}]
+    cases.append({"name": "slot order under alpha blending", "width": 24, "height": 20, "clear": black, "live_quads": 2, "shaded_pixels": 72,
+                  "particles": two,
+                  "pixels": [{"x": 10, "y": 10, "rgba": over(green, over(red, black))}, {"x": 7, "y": 10, "rgba": red}, {"x": 14, "y": 10, "rgba": green}]})
+    cases.append({"name": "additive", "width": 24, "height": 20, "clear": black, "live_quads": 2, "shaded_pixels": 72,
+                  "params": {"additive": True}, "particles": two,
+                  "pixels": [{"x": 10, "y": 10, "rgba": add(green, add(red, black))}, {"x": 7, "y": 10, "rgba": red}]})
+    # (e) computeCircularAlpha with rounding power .5: alpha 1 up to distance .5, 1 - sqrt((d - .5) / .5) beyond, 0 from d = 1:
+    #     the quad's corners are discarded (alpha <= 0), so fewer pixels are shaded than covered
+    white = [1.0, 1.0, 1.0, 1.0]
+    a75 = 1.0 - math.sqrt(0.5)
+    cases.append({"name": "rounded", "width": 34, "height": 34, "clear": black, "live_quads": 1,
+                  "params": {"rounded": True, "rounding": 0.5},
+                  "particles": [{"slot": 1, "position": [16.5, 16.5, 0.0, 1.0], "size": 8.0, "rotation": 0.0, "color": white}],
+                  "pixels": [{"x": 16, "y": 16, "rgba": white}, {"x": 20, "y": 16, "rgba": white}, {"x": 22, "y": 16, "rgba": [a75] * 4},
+                             {"x": 23, "y": 23, "rgba": black}, {"x": 9, "y": 9, "rgba": black}]})
+    # (f) origin / scale / viewport / global colour: display = p * Scale + origin = (13, 11); pixel = (display - (1, 1)) * 2 = (24, 20);
+    #     half extent 1.5 * 2 * 2 = 6 px; GlobalColor (.5, 1, 1, .5) is premultiplied by the uniform's constructor
+    g = [0.5 * 0.5, 1.0 * 0.5, 1.0 * 0.5, 0.5]
+    cases.append({"name": "transforms and global colour", "width": 40, "height": 32, "clear": black, "live_quads": 1, "shaded_pixels": 144,
+                  "params": {"global_color": [0.5, 1.0, 1.0, 0.5], "origin": [3.0, 1.0], "scale": [2.0, 2.0], "viewport_scale": [2.0, 2.0],
+                             "viewport_position": [1.0, 1.0]},
+                  "particles": [{"slot": 2, "position": [5.0, 5.0, 0.0, 1.0], "size": 1.5, "rotation": 0.0, "color": white}],
+                  "pixels": [{"x": 18, "y": 14, "rgba": g}, {"x": 29, "y": 25, "rgba": g}, {"x": 17, "y": 14, "rgba": black}, {"x": 30, "y": 25, "rgba": black}],
+                  "covered": sq(18, 29, 14, 25)})
+    # (g) z: display.y = y - z * ZToY = 12 - 4 * .5 = 10; size * max(0, 1 + z * SizeFromZ) = 2 * (1 + 4 * .25) = 4
+    cases.append({"name": "z to y and size from z", "width": 24, "height": 20, "clear": black, "live_quads": 1, "shaded_pixels": 64,
+                  "params": {"z_to_y": 0.5, "size_from_z": 0.25},
+                  "particles": [{"slot": 4, "position": [10.0, 12.0, 4.0, 1.0], "size": 2.0, "rotation": 0.0, "color": white}],
+                  "pixels": [{"x": 6, "y": 6, "rgba": white}, {"x": 13, "y": 13, "rgba": white}, {"x": 10, "y": 14, "rgba": black}],
+                  "covered": sq(6, 13, 6, 13)})
+    # (h) dead particles and empty quads draw nothing; a transparent one is discarded per pixel (alpha <= 0)
+    cases.append({"name": "dead, empty, transparent", "width": 24, "height": 20, "clear": clear, "live_quads": 1, "shaded_pixels": 0,
+                  "particles": [{"slot": 0, "position": [10.0, 8.0, 0.0, 0.0], "size": 3.0, "rotation": 0.0, "color": white},
+                                {"slot": 1, "position": [10.0, 8.0, 0.0, 1.0], "size": 0.0, "rotation": 0.0, "color": white},
+                                {"slot": 2, "position": [10.0, 8.0, 0.0, 1.0], "size": 3.0, "rotation": 0.0, "color": [0.3, 0.3, 0.3, 0.0]}],
+                  "pixels": [{"x": 10, "y": 8, "rgba": clear}], "covered": []})
+    return {"source": "hand-derived from RasterizeParticleSystem.fx:61-163,228-241, Uniforms.cs:238-290 (see comments in make_golden.py)",
+            "tolerance": "1e-5 relative", "cases": cases}
+
+
 def main():
-    out = {"output_ext.json": gen_output_ext(), "lights_ext.json": gen_lights_ext(), "transforms_ext.json": gen_transforms_ext(), "distance_field_generation.json": gen_distance_field_generation(), "bezier.json": gen_bezier(), "distance_field_layout.json": gen_layout(), "spawner.json": gen_spawner(),
+    out = {"rasterize.json": gen_rasterize(), "output_ext.json": gen_output_ext(), "lights_ext.json": gen_lights_ext(), "transforms_ext.json": gen_transforms_ext(), "distance_field_generation.json": gen_distance_field_generation(), "bezier.json": gen_bezier(), "distance_field_layout.json": gen_layout(), "spawner.json": gen_spawner(),
            "liveness.json": gen_liveness(), "distance_encoding.json": gen_encoding(), "gbuffer.json": gen_gbuffer(),
            "closed_form.json": gen_closed_form()}
     for name, doc in out.items():

@@ -1,0 +1,132 @@
+"""Parity of the HIP particle rasteriser (ilm_render_particles: technique RasterizeParticlesNoTexture) with the CPU oracle."""
+import numpy as np
+import pytest
+
+from illuminant_amd import abi, native, scenes
+from tests import raster_common as rc
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+P, RCOL, RD = abi.PLANE_POSITION, abi.PLANE_RENDER_COLOR, abi.PLANE_RENDER_DATA
+
+
+@pytest.mark.parametrize("index", range(len(rc.load_cases())))
+def test_closed_form_case(ctx, index):
+    rc.check_case(rc.load_cases()[index], rc.GpuBackend(ctx))
+
+
+def random_chunks(seed, cs, n_chunks, width, height, size_hi, dead_fraction=0.3):
+    n = cs * cs
+    chunks = []
+    for c in range(n_chunks):
+        pos = np.zeros((n, 4), np.float32)
+        pos[:, 0] = scenes.uniform(seed + 10 * c, (n,), -20.0, width + 20.0)
+        pos[:, 1] = scenes.uniform(seed + 10 * c + 1, (n,), -20.0, height + 20.0)
+        pos[:, 2] = scenes.uniform(seed + 10 * c + 2, (n,), 0.0, 8.0)
+        pos[:, 3] = np.where(scenes.uniform(seed + 10 * c + 3, (n,)) < dead_fraction, 0.0, scenes.uniform(seed + 10 * c + 4, (n,), 0.1, 3.0))
+        a = scenes.uniform(seed + 10 * c + 5, (n,), 0.0, 1.0)
+        rgb = scenes.uniform(seed + 10 * c + 6, (n, 3), 0.0, 1.0)
+        col = np.concatenate([rgb * a[:, None], a[:, None]], axis=1).astype(np.float32)          # premultiplied, some fully transparent
+        col[::17, 3] = 0.0
+        rd = np.zeros((n, 4), np.float32)
+        rd[:, 0] = scenes.uniform(seed + 10 * c + 7, (n,), 0.0, size_hi)
+        rd[:, 1] = scenes.uniform(seed + 10 * c + 8, (n,), -7.0, 20.0)                           # rotation, beyond one turn both ways
+        chunks.append([pos, np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32), col, rd])
+    return chunks
+
+
+def render_gpu(ctx, chunks, cs, params, width, height, fmt, clear, quad_counts=None):
+    eng = native.Engine(ctx, cs, scenes.randomness_table(7))
+    sysm = native.System(eng)
+    for c, planes in enumerate(chunks):
+        sysm.add_chunk()
+        sysm.upload(c, P, planes[0]); sysm.upload(c, RCOL, planes[3]); sysm.upload(c, RD, planes[4])
+    lm = native.Lightmap(ctx, width, height, fmt)
+    lm.clear(clear)
+    stats = native.render_particles(sysm, params, lm, quad_counts=quad_counts, want_stats=True)
+    image = lm.download()
+    lm.close(); sysm.close(); eng.close()
+    return image, stats
+
+
+def compare_images(got, want, what, max_outliers):
+    """Coverage is decided by the same IEEE operations on both sides except sin / cos of the rotation (OCML vs libm, a 1e-7 relative
+    difference in the inverse map): a pixel centre within that distance of a rotated edge may fall on the other side.  Everything
+    else must agree to 1e-4; at most `max_outliers` pixels may differ by a whole fragment."""
+    err = np.abs(got.astype(np.float64) - want.astype(np.float64)).max(axis=-1)
+    tol = 1e-4 * np.maximum(1.0, np.abs(want).max(axis=-1))
+    bad = err > tol
+    assert int(bad.sum()) <= max_outliers, "%s: %d pixels differ (largest %.3g)" % (what, int(bad.sum()), float(err.max()))
+
+
+@pytest.mark.parametrize("rounded,blend", [(False, abi.BLEND_ALPHA), (True, abi.BLEND_ALPHA), (True, abi.BLEND_ADDITIVE)])
+def test_random_sprites_match_oracle(ctx, oracle, rounded, blend):
+    cs, n_chunks, w, h = 64, 3, 333, 197          # not multiples of the 16-pixel tile
+    chunks = random_chunks(40, cs, n_chunks, w, h, size_hi=14.0)
+    params = scenes.rasterize_params(size=(1.0, 0.6), global_color=(0.9, 0.8, 1.0, 0.7), origin=(3.0, -2.0), scale=(1.1, 0.9),
+                                     size_from_z=0.05, z_to_y=0.25, rounded=rounded,
+                                     rounding_power=abi.ClampedBezier1.linear(0.2, 0.9, 0.0, 3.0), viewport_scale=(1.0, 1.0),
+                                     viewport_position=(2.0, 1.0), blend=blend)
+    quads = [cs * cs, 3000, 17]
+    clear = (0.05, 0.1, 0.15, 0.2)
+    got, (live, pairs, shaded) = render_gpu(ctx, chunks, cs, params, w, h, abi.LIGHTMAP_FLOAT4, clear, quad_counts=quads)
+    want = np.zeros((h, w, 4), np.float32); want[:] = clear
+    want, (olive, oshaded) = oracle.render_particles(chunks, params, w, h, quad_counts=quads, image=want)
+    assert live == olive and live > 3000
+    assert abs(shaded - oshaded) <= 8 and shaded > 50 * live       # see compare_images
+    assert pairs >= live                                           # every on-screen quad touches at least one tile
+    compare_images(got, want, "float4 target", max_outliers=8)
+    # the picture is not trivial: most pixels were touched, by several sprites
+    assert (np.abs(want - np.asarray(clear, np.float32)).max(axis=-1) > 1e-3).mean() > 0.9
+
+
+@pytest.mark.parametrize("fmt,tol", [(abi.LIGHTMAP_HALF4, 2e-3), (abi.LIGHTMAP_RGBA8, 0.5 / 255 + 1e-6)])
+def test_half_and_byte_targets(ctx, oracle, fmt, tol):
+    """One pass over a cleared target: the only difference to the float4 target is the final conversion."""
+    cs, w, h = 32, 160, 96
+    chunks = random_chunks(70, cs, 1, w, h, size_hi=10.0)
+    params = scenes.rasterize_params(rounded=True)
+    got, _ = render_gpu(ctx, chunks, cs, params, w, h, fmt, (0.0, 0.0, 0.0, 0.0))
+    want, _ = oracle.render_particles(chunks, params, w, h)
+    if fmt == abi.LIGHTMAP_HALF4:
+        g = got.view(np.float16).astype(np.float32).reshape(h, w, 4)
+        assert (np.abs(g - want) > tol * np.maximum(1.0, np.abs(want))).sum() <= 8 * 4
+    else:
+        g = got.reshape(h, w, 4).astype(np.float32) / 255.0
+        assert (np.abs(g - np.clip(want, 0.0, 1.0)) > tol).sum() <= 8 * 4
+
+
+def test_large_sprites_and_many_tiles(ctx, oracle):
+    """Sprites hundreds of pixels across (each touches hundreds of tiles) over a field of small ones: the key count is dominated by
+    the large quads and the order between large and small sprites still holds."""
+    cs, w, h = 32, 640, 360
+    chunks = random_chunks(90, cs, 2, w, h, size_hi=6.0)
+    chunks[0][4][5::101, 0] = 150.0          # ten or so huge quads in between
+    params = scenes.rasterize_params(rounded=False)
+    got, (live, pairs, shaded) = render_gpu(ctx, chunks, cs, params, w, h, abi.LIGHTMAP_FLOAT4, (0, 0, 0, 0))
+    want, (olive, oshaded) = oracle.render_particles(chunks, params, w, h)
+    assert live == olive and pairs > 4 * live and abs(shaded - oshaded) <= 8
+    compare_images(got, want, "large sprites", max_outliers=8)
+
+
+def test_fracture_only_options_and_bad_arguments_are_refused(ctx):
+    eng = native.Engine(ctx, 16, scenes.randomness_table(7))
+    sysm = native.System(eng); sysm.add_chunk()
+    lm = native.Lightmap(ctx, 32, 32, abi.LIGHTMAP_FLOAT4)
+    p = scenes.rasterize_params(stipple_factor=0.5)
+    with pytest.raises(native.IlluminantError) as e:
+        native.render_particles(sysm, p, lm)
+    assert e.value.code == abi.ERR_INVALID_ARGUMENT and "Stipple" in str(e.value)
+    p = scenes.rasterize_params(); p.RenderingOptions[1] = 1.0
+    with pytest.raises(native.IlluminantError):
+        native.render_particles(sysm, p, lm)
+    p = scenes.rasterize_params(); p.BlendMode = 7
+    with pytest.raises(native.IlluminantError):
+        native.render_particles(sysm, p, lm)
+    with pytest.raises(native.IlluminantError):
+        native.render_particles(sysm, scenes.rasterize_params(), lm, quad_counts=[16 * 16 + 1])
+    # an empty system draws nothing and says so
+    empty = native.System(eng)
+    assert native.render_particles(empty, scenes.rasterize_params(), lm, want_stats=True) == (0, 0, 0)
+    lm.close(); empty.close(); sysm.close(); eng.close()
