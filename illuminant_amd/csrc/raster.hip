@@ -4,8 +4,8 @@
 //
 // The reference draws one instanced quad per slot, chunk after chunk, and lets the ROP blend them in that order.  Blending is
 // order-dependent, so the order is kept: every live particle becomes a sprite record (the inverse of its affine map unit square ->
-// pixels), each (16 x 16 pixel tile, sprite) pair a 64-bit key (tile << 32 | global slot), the keys are radix-sorted (rocPRIM, a
-// plain library sort) and one workgroup per tile walks its run of keys in slot order: 256 sprites at a time through LDS, every
+// pixels), each (16 x 16 pixel tile, sprite) pair a 64-bit key (tile << 32 | global slot), the keys are radix-sorted by tile (rocPRIM, a
+// plain library sort; stable, and the keys are emitted in slot order) and one workgroup per tile walks its run of keys in slot order: 256 sprites at a time through LDS, every
 // lane = one pixel, coverage + shading + blending in registers, the target texel read once and written once.
 //
 // Compiled with -ffp-contract=off: coverage is decided by the same IEEE operations as the CPU oracle.
@@ -20,15 +20,16 @@ namespace ilm {
 
 constexpr int kRasterTile = 16;
 
-struct Sprite {
+struct alignas(16) Sprite {
     float cx, cy;               // centre, pixels
+    float ex, ey;               // half extents of the bounding box, pixels (+ 1 pixel of slack): culling only
     float i00, i01, i10, i11;   // unit = I * (pixel centre - centre)
     float r, g, b, a;           // RenderColor * GlobalColor
     float rounding;
     uint32_t tiles_x, tiles_y;  // first | last << 16 tile column / row of the clipped bounding box
     uint32_t _pad;
 };
-static_assert(sizeof(Sprite) == 56, "Sprite is 14 words");
+static_assert(sizeof(Sprite) == 64, "Sprite is 16 words");
 
 ILM_DEV float bezier1_raster(const IlmClampedBezier1& bz, float value);
 
@@ -112,6 +113,7 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(const RasterLaunch a)
                     fx0 = fmaxf(fx0, 0.0f); fy0 = fmaxf(fy0, 0.0f);
                     fx1 = fminf(fx1, (float)(a.width - 1)); fy1 = fminf(fy1, (float)(a.height - 1));
                     sp.tiles_x = sp.tiles_y = 0u; sp._pad = 0u;
+                    sp.ex = ex + 1.0f; sp.ey = ey + 1.0f;
                     if ((fx0 <= fx1) && (fy0 <= fy1)) {
                         const uint32_t tx0 = (uint32_t)fx0 / kRasterTile, tx1 = (uint32_t)fx1 / kRasterTile;
                         const uint32_t ty0 = (uint32_t)fy0 / kRasterTile, ty1 = (uint32_t)fy1 / kRasterTile;
@@ -124,9 +126,11 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(const RasterLaunch a)
         }
         a.counts[g] = count;
     }
-    const unsigned long long m = __ballot(live);
-    if (((threadIdx.x & 63u) == 0u) && m != 0ull)
-        atomicAdd(&a.stats[0], (unsigned long long)__popcll(m));
+    if (a.count_shaded) {       // statistics only: 20 k same-address atomics serialise (~11 ns each)
+        const unsigned long long m = __ballot(live);
+        if (((threadIdx.x & 63u) == 0u) && m != 0ull)
+            atomicAdd(&a.stats[0], (unsigned long long)__popcll(m));
+    }
 }
 
 // one key per (tile, sprite): tile << 32 | global slot -- sorting them lists every tile's sprites in chunk / slot order
@@ -180,10 +184,16 @@ ILM_DEV int64_t key_lower_bound(const unsigned long long* keys, int64_t n, unsig
     return lo;
 }
 
-// PS_NoTexture + the blend, RasterizeParticleSystem.fx:150-163,228-241: one workgroup per tile, one lane per pixel
+// PS_NoTexture + the blend, RasterizeParticleSystem.fx:150-163,228-241: one workgroup per tile, one lane per pixel.
+// The tile's sprites come 256 at a time: thread t fetches sprite t of the batch into LDS and tests its bounding box against the four
+// 8 x 8 quadrants of the tile; a ballot + prefix count per quadrant turns that into four slot-ordered index lists, and wave q then
+// walks only the sprites that can touch its quadrant (for 8 x 8-pixel sprites about a third of the tile's), the next record
+// already in flight while the current one is shaded.
 template <int FORMAT>
 __global__ __launch_bounds__(256) void raster_tiles_kernel(const RasterLaunch a) {
     __shared__ Sprite batch[256];
+    __shared__ uint8_t list[4][256];
+    __shared__ int wave_count[4][4];          // [loader wave][quadrant]
     __shared__ int64_t range[2];
     const int tile = (int)blockIdx.x;
     const int tid = (int)threadIdx.x;
@@ -193,24 +203,61 @@ __global__ __launch_bounds__(256) void raster_tiles_kernel(const RasterLaunch a)
     const int64_t begin = range[0], end = range[1];
     if (begin == end) return;                               // uniform: no sprite touches this tile, the texels stay as they are
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
-    const int x = tx * kRasterTile + (tid & 15), y = ty * kRasterTile + (tid >> 4);
+    // each wave owns an 8 x 8 quadrant of the tile (lane = 8 * row + column)
+    const int wave = tid >> 6, lane = tid & 63;
+    const int qx = tx * kRasterTile + (wave & 1) * 8, qy = ty * kRasterTile + (wave >> 1) * 8;
+    const int x = qx + (lane & 7), y = qy + (lane >> 3);
     const bool in_image = (x < a.width) && (y < a.height);
     const size_t o = (size_t)y * (size_t)a.width + (size_t)x;
     float4 dst = mk4(0.0f, 0.0f, 0.0f, 0.0f);
     if (in_image) dst = load_target<FORMAT>(a.target, o);
     const float pcx = (float)x + 0.5f, pcy = (float)y + 0.5f;
+    const float tcx = (float)(tx * kRasterTile) + 4.0f, tcy = (float)(ty * kRasterTile) + 4.0f;     // centre of quadrant 0
     const bool rounded = a.params.RenderingOptions[0] != 0.0f;
     const bool additive = a.params.BlendMode == ILM_BLEND_ADDITIVE;
     uint32_t shaded = 0;
     for (int64_t base = begin; base < end; base += 256) {
         const int n = (int)((end - base < 256) ? (end - base) : 256);
+        __syncthreads();                                    // the previous batch has been consumed
+        bool hit[4] = { false, false, false, false };
+        if (tid < n) {
+            const Sprite sp = a.sprites[(uint32_t)(a.sorted_keys[base + tid] & 0xFFFFFFFFull)];
+            batch[tid] = sp;
+            // pixel centres of a quadrant lie within +-3.5 of its centre; ex / ey carry a pixel of slack
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float cx = tcx + (float)((q & 1) * 8), cy = tcy + (float)((q >> 1) * 8);
+                hit[q] = (fabsf(sp.cx - cx) - sp.ex <= 3.5f) && (fabsf(sp.cy - cy) - sp.ey <= 3.5f);
+            }
+        }
+        unsigned long long mask[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            mask[q] = __ballot(hit[q]);
+            if (lane == 0) wave_count[wave][q] = __popcll(mask[q]);
+        }
         __syncthreads();
-        if (tid < n)
-            batch[tid] = a.sprites[(uint32_t)(a.sorted_keys[base + tid] & 0xFFFFFFFFull)];
+        int total = 0;                                      // sprites on this wave's list
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            int before = 0, all = 0;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const int c = wave_count[w][q];
+                before += (w < wave) ? c : 0;
+                all += c;
+            }
+            if (hit[q])
+                list[q][before + __popcll(mask[q] & ((1ull << lane) - 1ull))] = (uint8_t)tid;
+            total = (q == wave) ? all : total;
+        }
         __syncthreads();
-        if (!in_image) continue;
-        for (int k = 0; k < n; k++) {
-            const Sprite& sp = batch[k];
+        total = __builtin_amdgcn_readfirstlane(total);
+        if (!in_image || total == 0) continue;
+        Sprite next = batch[list[wave][0]];
+        for (int k = 0; k < total; k++) {
+            const Sprite sp = next;
+            next = batch[list[wave][(k + 1 < total) ? k + 1 : k]];      // in flight while sp is shaded
             const float dx = pcx - sp.cx, dy = pcy - sp.cy;
             const float u = (sp.i00 * dx) + (sp.i01 * dy), v = (sp.i10 * dx) + (sp.i11 * dy);
             if (!((u >= -1.0f) && (u < 1.0f) && (v >= -1.0f) && (v < 1.0f)))
@@ -236,7 +283,7 @@ __global__ __launch_bounds__(256) void raster_tiles_kernel(const RasterLaunch a)
     if (in_image) store_target<FORMAT>(a.target, o, dst);
     if (a.count_shaded) {
         for (int off = 32; off > 0; off >>= 1) shaded += __shfl_down(shaded, off);
-        if (((tid & 63) == 0) && shaded != 0u) atomicAdd(&a.stats[2], (unsigned long long)shaded);
+        if ((lane == 0) && shaded != 0u) atomicAdd(&a.stats[2], (unsigned long long)shaded);
     }
 }
 
@@ -311,9 +358,11 @@ hipError_t render_particles(RasterLaunch& a, RasterScratch& s, hipStream_t strea
         int tile_bits = 1;
         while ((1 << tile_bits) < a.tiles_x * a.tiles_y) tile_bits++;
         size_t sort_bytes = 0;
-        RASTER_TRY(rocprim::radix_sort_keys(nullptr, sort_bytes, a.keys, a.sorted_keys, (size_t)pairs, 0u, (unsigned)(32 + tile_bits), stream));
+        // The keys are emitted in slot order (the scan runs over the slots), and a radix sort is stable: sorting on the tile bits
+        // alone leaves every tile's run in slot order -- two digit passes instead of six.
+        RASTER_TRY(rocprim::radix_sort_keys(nullptr, sort_bytes, a.keys, a.sorted_keys, (size_t)pairs, 32u, (unsigned)(32 + tile_bits), stream));
         RASTER_TRY(grow(&s.temp, &s.temp_cap, sort_bytes, stream));
-        RASTER_TRY(rocprim::radix_sort_keys(s.temp, sort_bytes, a.keys, a.sorted_keys, (size_t)pairs, 0u, (unsigned)(32 + tile_bits), stream));
+        RASTER_TRY(rocprim::radix_sort_keys(s.temp, sort_bytes, a.keys, a.sorted_keys, (size_t)pairs, 32u, (unsigned)(32 + tile_bits), stream));
         const dim3 tile_grid((unsigned)(a.tiles_x * a.tiles_y));
         if (a.format == ILM_LIGHTMAP_FLOAT4) hipLaunchKernelGGL(raster_tiles_kernel<ILM_LIGHTMAP_FLOAT4>, tile_grid, block, 0, stream, a);
         else if (a.format == ILM_LIGHTMAP_HALF4) hipLaunchKernelGGL(raster_tiles_kernel<ILM_LIGHTMAP_HALF4>, tile_grid, block, 0, stream, a);

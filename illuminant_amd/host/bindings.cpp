@@ -46,6 +46,18 @@ PYBIND11_MODULE(_host, m) {
         .def("Sync", &DeviceContext::Sync).def("TimerStart", &DeviceContext::TimerStart).def("TimerStop", &DeviceContext::TimerStop)
         .def_property_readonly("Handle", &DeviceContext::Handle);
 
+    py::class_<RenderTarget>(m, "RenderTarget")
+        .def(py::init<DeviceContext&, int, int, int>(), py::arg("ctx"), py::arg("width"), py::arg("height"), py::arg("format") = (int)ILM_LIGHTMAP_FLOAT4,
+             py::keep_alive<1, 2>())
+        .def_readonly("Width", &RenderTarget::Width).def_readonly("Height", &RenderTarget::Height).def_readonly("Format", &RenderTarget::Format)
+        .def("Clear", [](RenderTarget& t, const std::vector<float>& c) { t.Clear(Vector4{ c.at(0), c.at(1), c.at(2), c.at(3) }); })
+        // (height, width, 4) float32 for a float4 target; raw bytes reshaped by the caller otherwise
+        .def("Download", [](const RenderTarget& t) {
+            if (t.Format != ILM_LIGHTMAP_FLOAT4) throw std::invalid_argument("Download(): float4 targets only");
+            py::array_t<float> out({ (py::ssize_t)t.Height, (py::ssize_t)t.Width, (py::ssize_t)4 });
+            t.Download(out.mutable_data());
+            return out; });
+
     py::class_<DistanceField::Layout>(m, "DistanceFieldLayout")
         .def_readonly("Resolution", &DistanceField::Layout::Resolution)
         .def_readonly("SliceWidth", &DistanceField::Layout::SliceWidth).def_readonly("SliceHeight", &DistanceField::Layout::SliceHeight)
@@ -131,6 +143,7 @@ PYBIND11_MODULE(_host, m) {
         .def_readwrite("EscapeVelocity", &ParticleCollision::EscapeVelocity)
         .def_readwrite("BounceVelocityMultiplier", &ParticleCollision::BounceVelocityMultiplier);
     py::class_<ParticleColor>(m, "ParticleColor").def(py::init<>())
+        VEC_PROP(ParticleColor, Global, 4)
         .def_readwrite("OpacityFromLife", &ParticleColor::OpacityFromLife)
         .def_readwrite("ColorFromLife", &ParticleColor::ColorFromLife).def_readwrite("ColorFromVelocity", &ParticleColor::ColorFromVelocity);
     py::class_<ParticleAppearance>(m, "ParticleAppearance").def(py::init<>())
@@ -141,7 +154,9 @@ PYBIND11_MODULE(_host, m) {
                       [](ParticleAppearance& a, py::object v) { if (v.is_none()) a.SizePx.reset(); else a.SizePx = v2(v.cast<std::vector<float>>()); })
         VEC_PROP(ParticleAppearance, AnimationRate, 2)
         .def_readwrite("RelativeSize", &ParticleAppearance::RelativeSize)
-        .def_readwrite("ColumnFromVelocity", &ParticleAppearance::ColumnFromVelocity).def_readwrite("RowFromVelocity", &ParticleAppearance::RowFromVelocity);
+        .def_readwrite("ColumnFromVelocity", &ParticleAppearance::ColumnFromVelocity).def_readwrite("RowFromVelocity", &ParticleAppearance::RowFromVelocity)
+        .def_readwrite("Rounded", &ParticleAppearance::Rounded).def_readwrite("DitheredOpacity", &ParticleAppearance::DitheredOpacity)
+        .def_readwrite("RoundingPowerFromLife", &ParticleAppearance::RoundingPowerFromLife);
     py::class_<ParticleSystemConfiguration>(m, "ParticleSystemConfiguration").def(py::init<>())
         .def_readwrite("Appearance", &ParticleSystemConfiguration::Appearance)
         .def_readwrite("AutoReadback", &ParticleSystemConfiguration::AutoReadback).def_readwrite("SortedReadback", &ParticleSystemConfiguration::SortedReadback)
@@ -157,6 +172,9 @@ PYBIND11_MODULE(_host, m) {
         .def_readwrite("RotationFromIndex", &ParticleSystemConfiguration::RotationFromIndex)
         .def_readwrite("RotationFromVelocity", &ParticleSystemConfiguration::RotationFromVelocity)
         .def_readwrite("ZToY", &ParticleSystemConfiguration::ZToY)
+        .def_readwrite("StippleFactor", &ParticleSystemConfiguration::StippleFactor)
+        VEC_PROP(ParticleSystemConfiguration, ZFormula, 4)
+        .def_readwrite("SizeFromZ", &ParticleSystemConfiguration::SizeFromZ)
         .def_readwrite("TimeProvider", &ParticleSystemConfiguration::TimeProvider);
 
     py::enum_<AreaType>(m, "AreaType").value("None_", AreaType::None).value("Ellipsoid", AreaType::Ellipsoid).value("Box", AreaType::Box)
@@ -315,6 +333,22 @@ PYBIND11_MODULE(_host, m) {
             for (int i = 0; i < count; i++) { tp.Advance(dt); s.Update(firstFrame + i); }
         })
         .def("Clear", &ParticleSystem::Clear)
+        // Render(target, blendMode, origin, scale, viewportScale, viewportPosition, wantStats) -> (live quads, tile pairs, shaded pixels)
+        .def("Render", [](const ParticleSystem& s, RenderTarget& target, int blendMode, const std::vector<float>& origin, const std::vector<float>& scale,
+                          const std::vector<float>& viewportScale, const std::vector<float>& viewportPosition, bool wantStats) {
+            ParticleSystem::RenderParameters rp;
+            rp.Origin = v2(origin); rp.Scale = v2(scale);
+            const ParticleSystem::RenderStats st = s.Render(target, blendMode, &rp, v2(viewportScale), v2(viewportPosition), wantStats);
+            return py::make_tuple(st.LiveQuads, st.TilePairs, st.ShadedPixels);
+        }, py::arg("target"), py::arg("blendMode") = (int)ILM_BLEND_ALPHA, py::arg("origin") = std::vector<float>{0, 0},
+           py::arg("scale") = std::vector<float>{1, 1}, py::arg("viewportScale") = std::vector<float>{1, 1},
+           py::arg("viewportPosition") = std::vector<float>{0, 0}, py::arg("wantStats") = false)
+        .def("RasterizeParamsBytes", [](const ParticleSystem& s, int blendMode, const std::vector<float>& origin, const std::vector<float>& scale,
+                                        const std::vector<float>& viewportScale, const std::vector<float>& viewportPosition) {
+            ParticleSystem::RenderParameters rp;
+            rp.Origin = v2(origin); rp.Scale = v2(scale);
+            const IlmRasterizeParams p = s.GetRasterizeParams(blendMode, &rp, v2(viewportScale), v2(viewportPosition));
+            return py::bytes((const char*)&p, sizeof(p)); })
         // (n, 12) float32 array over the pinned read-back buffer: no copy; valid until the next read-back on the context
         .def("PerformReadbackView", [](const ParticleSystem& s) {
             const ParticleSystem::ReadbackView v = s.PerformReadbackView();

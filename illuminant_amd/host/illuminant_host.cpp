@@ -43,6 +43,16 @@ void DeviceContext::Sync() { ThrowIfFailed(ilm_ctx_sync(handle)); }
 void DeviceContext::TimerStart() { ThrowIfFailed(ilm_timer_start(handle)); }
 float DeviceContext::TimerStop() { float ms = 0; ThrowIfFailed(ilm_timer_stop(handle, &ms)); return ms; }
 
+RenderTarget::RenderTarget(DeviceContext& ctx, int width, int height, int format) : Width(width), Height(height), Format(format) {
+    ThrowIfFailed(ilm_lightmap_create(ctx.Handle(), width, height, format, nullptr, &handle));
+}
+RenderTarget::~RenderTarget() { if (handle) ilm_lightmap_destroy(handle); }
+void RenderTarget::Clear(Vector4 color) {
+    const float c[4] = { color.X, color.Y, color.Z, color.W };
+    ThrowIfFailed(ilm_lightmap_clear(handle, c));
+}
+void RenderTarget::Download(void* dst) const { ThrowIfFailed(ilm_lightmap_download(handle, dst, 0, Height)); }
+
 // ---- DistanceField, SDF/DistanceField.cs:43-122 -------------------------------------------------------------
 static double RoundToEven(double v) { return std::nearbyint(v); }   // Math.Round: MidpointRounding.ToEven
 
@@ -1098,6 +1108,50 @@ ParticleSystem::ReadbackView ParticleSystem::PerformReadbackView() const {
 std::vector<IlmReadbackDrawCall> ParticleSystem::PerformReadback() const {
     const ReadbackView v = PerformReadbackView();
     return std::vector<IlmReadbackDrawCall>(v.Records, v.Records + v.Count);
+}
+
+IlmRasterizeParams ParticleSystem::GetRasterizeParams(int blendMode, const RenderParameters* rp, Vector2 viewportScale, Vector2 viewportPosition) const {
+    IlmRasterizeParams p;
+    std::memset(&p, 0, sizeof(p));
+    const ParticleSystemConfiguration& C = Configuration;
+    if (C.Appearance.TextureSize)
+        throw InvalidOperationException("Render: only the NoTexture technique is bound (Appearance.Texture must be unset)");
+    const Vector2 origin = rp ? rp->Origin : Vector2{0, 0}, scale = rp ? rp->Scale : Vector2{1, 1};
+    p.BitmapTextureRegion = { 0, 0, 1, 1 };
+    p.SizeFactorAndPosition = { 1, 1, origin.X, origin.Y };
+    p.Scale = { scale.X, scale.Y, 0, 0 };
+    Vector4 g = C.Color.Global;
+    g.X *= g.W; g.Y *= g.W; g.Z *= g.W;
+    p.GlobalColor = { g.X, g.Y, g.Z, g.W };
+    p.ZFormula = { C.ZFormula.X, C.ZFormula.Y, C.ZFormula.Z, C.ZFormula.W };
+    p.ZConfiguration = { C.SizeFromZ, 0, 0, 0 };
+    p.RoundingPowerFromLife = MakeClampedBezier1(C.Appearance.RoundingPowerFromLife);
+    p.RenderingOptions[0] = C.Appearance.Rounded ? 1.0f : 0.0f;
+    p.RenderingOptions[1] = C.Appearance.DitheredOpacity ? 1.0f : 0.0f;
+    p.RenderingOptions[2] = C.Appearance.ColumnFromVelocity ? 1.0f : 0.0f;
+    p.RenderingOptions[3] = C.Appearance.RowFromVelocity ? 1.0f : 0.0f;
+    p.SystemSize[0] = C.Size.X; p.SystemSize[1] = C.Size.Y;
+    p.ZToY = C.ZToY;
+    p.StippleFactor = (rp && rp->StippleFactor) ? *rp->StippleFactor : C.StippleFactor;
+    p.ViewportScale[0] = viewportScale.X; p.ViewportScale[1] = viewportScale.Y;
+    p.ViewportPosition[0] = viewportPosition.X; p.ViewportPosition[1] = viewportPosition.Y;
+    p.BlendMode = blendMode;
+    return p;
+}
+
+ParticleSystem::RenderStats ParticleSystem::Render(RenderTarget& target, int blendMode, const RenderParameters* rp, Vector2 viewportScale,
+                                                   Vector2 viewportPosition, bool wantStats) const {
+    RenderStats st;
+    if (chunks.empty())
+        return st;
+    std::vector<int32_t> quads;
+    for (const Chunk& c : chunks)
+        quads.push_back(std::min(ChunkMaximumCount(), c.TotalSpawned + 1));      // RenderChunk, :880
+    const IlmRasterizeParams p = GetRasterizeParams(blendMode, rp, viewportScale, viewportPosition);
+    uint64_t stats[3] = { 0, 0, 0 };
+    ThrowIfFailed(ilm_render_particles(handle, quads.data(), (int32_t)quads.size(), &p, target.Handle(), wantStats ? stats : nullptr));
+    st.LiveQuads = stats[0]; st.TilePairs = stats[1]; st.ShadedPixels = stats[2];
+    return st;
 }
 
 void ParticleSystem::Readback(int chunkIndex, int plane, IlmFloat4* dst) const {

@@ -84,6 +84,23 @@ private:
 
 // ---- SDF/DistanceField.cs ---------------------------------------------------------------------------
 // SliceInfo, :13-16
+// A RenderTarget2D the particle rasteriser blends onto (ParticleSystem.Render draws into whatever target is bound): the native
+// lightmap object used as a plain colour target
+class RenderTarget {
+public:
+    RenderTarget(DeviceContext& ctx, int width, int height, int format = ILM_LIGHTMAP_FLOAT4);
+    ~RenderTarget();
+    RenderTarget(const RenderTarget&) = delete;
+    RenderTarget& operator=(const RenderTarget&) = delete;
+    void Clear(Vector4 color);
+    // float4 texels regardless of the storage format are NOT converted: `dst` receives width * height texels in the target's format
+    void Download(void* dst) const;
+    IlmHandle Handle() const { return handle; }
+    int Width, Height, Format;
+private:
+    IlmHandle handle = 0;
+};
+
 struct SliceInfo {
     int ValidSliceCount = 0;
     std::vector<int> InvalidSlices;
@@ -210,6 +227,7 @@ struct ParticleCollision {
 };
 // ParticleConfiguration.cs ParticleColor
 struct ParticleColor {
+    Vector4 Global{1, 1, 1, 1};                      // :146
     std::optional<float> OpacityFromLife;
     std::optional<Bezier4> ColorFromLife, ColorFromVelocity;
 };
@@ -222,6 +240,8 @@ struct ParticleAppearance {
     Vector2 AnimationRate{0, 0};
     bool RelativeSize = true;
     bool ColumnFromVelocity = false, RowFromVelocity = false;
+    bool Rounded = false, DitheredOpacity = false;                 // :72-77
+    BezierF RoundingPowerFromLife{1, 0, 0, 1, 0.8f, 0.8f, 0.8f, 0.8f};   // new BezierF(0.8f), :82
 };
 // ParticleConfiguration.cs:187-303 (the members the update path reads)
 struct ParticleSystemConfiguration {
@@ -235,6 +255,9 @@ struct ParticleSystemConfiguration {
     float RotationFromLife = 0, RotationFromIndex = 0;   // degrees
     bool RotationFromVelocity = false;
     float ZToY = 0;
+    float StippleFactor = 1.0f;                      // :248
+    Vector4 ZFormula{0, 0, 0, 0};                    // :282
+    float SizeFromZ = 0;                             // :287
     ITimeProvider* TimeProvider = nullptr;
 };
 
@@ -540,6 +563,16 @@ public:
     struct ReadbackView { const IlmReadbackDrawCall* Records = nullptr; int Count = 0; };
     ReadbackView PerformReadbackView() const;
     IlmReadbackParams GetReadbackParams() const;
+    // ParticleRenderParameters, ParticleConfiguration.cs:305-312
+    struct RenderParameters { Vector2 Origin{0, 0}, Scale{1, 1}; std::optional<float> StippleFactor; };
+    struct RenderStats { uint64_t LiveQuads = 0, TilePairs = 0, ShadedPixels = 0; };
+    // ParticleSystem.Render (ParticleSystem.cs:943-1041) for a system without Appearance.Texture: technique
+    // RasterizeParticlesNoTexture, every chunk in order with quadCount = min(ChunkMaximumCount, TotalSpawned + 1) (:880), blended onto
+    // `target` with blendMode (ILM_BLEND_*); viewportScale / viewportPosition play Fracture's ViewTransform.
+    RenderStats Render(RenderTarget& target, int blendMode = ILM_BLEND_ALPHA, const RenderParameters* renderParams = nullptr,
+                       Vector2 viewportScale = Vector2{1, 1}, Vector2 viewportPosition = Vector2{0, 0}, bool wantStats = false) const;
+    // Uniforms.RasterizeParticleSystem + RenderingOptions + StippleFactor as Render binds them (Uniforms.cs:238-290, ParticleSystem.cs:254-271,1023-1032)
+    IlmRasterizeParams GetRasterizeParams(int blendMode, const RenderParameters* renderParams, Vector2 viewportScale, Vector2 viewportPosition) const;
     std::vector<IlmReadbackDrawCall> ReadbackResult;
     float ReadbackTimestamp = 0;
     IlmHandle Handle() const { return handle; }
