@@ -301,8 +301,8 @@ def main():
         next_rows["rasterize_cfg2_1080p"] = {"ms_per_frame": round(rast_ms, 4), "live_quads": int(rstats[0]), "quad_tile_pairs": int(rstats[1]),
                                              "shaded_pixels": int(rstats[2]), "msprites_per_s": round(rstats[0] / (rast_ms * 1e-3) / 1e6, 1),
                                              "mfragments_per_s": round(rstats[2] / (rast_ms * 1e-3) / 1e6, 1),
-                                             "note": "setup + scan + key emit + 64-bit radix sort + one workgroup per 16 x 16 tile; "
-                                                     "ordered blending, the target read and written once"}
+                                             "note": "setup + scan + key emit + stable radix sort on the tile bits + one workgroup per 16 x 16 tile "
+                                                     "(crowded tiles in 2048-sprite segments, combined in order); ordered blending"}
         del target
     cpu_init, cpu_rnd, cpu_desc_bytes = P["init"], P["rnd"], ps.LastStepBytes()
     if not args.no_cfg4:

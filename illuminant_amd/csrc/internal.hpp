@@ -232,12 +232,17 @@ struct RasterLaunch {
     Sprite* sprites; uint32_t* counts; uint32_t* offsets;
     unsigned long long* keys; unsigned long long* sorted_keys; int64_t pair_count;
     unsigned long long* stats;          // [0] live quads, [2] shaded pixels
+    // per tile (tile_count + 1 entries where scanned): first key of the tile's run, number of segments the run is cut into, first
+    // work item of the tile, first partial-result slot of the tile (tiles with more than one segment only)
+    uint32_t* tile_begin; uint32_t* tile_segments; uint32_t* tile_first_item; uint32_t* tile_multi; uint32_t* tile_first_partial;
+    float* partials;                    // per partial slot: 256 x (premultiplied colour sum rgba, transmittance)
+    int32_t work_items;                 // upper bound of the work items (grid of the shading kernel)
 };
 // device buffers the rasteriser keeps between calls (owned by the context)
 struct RasterScratch {
     void* sprites = nullptr; void* counts = nullptr; void* offsets = nullptr; void* keys = nullptr; void* sorted_keys = nullptr;
-    void* temp = nullptr; void* stats = nullptr;
-    size_t sprites_cap = 0, counts_cap = 0, offsets_cap = 0, keys_cap = 0, sorted_cap = 0, temp_cap = 0;
+    void* temp = nullptr; void* stats = nullptr; void* tiles = nullptr; void* partials = nullptr;
+    size_t sprites_cap = 0, counts_cap = 0, offsets_cap = 0, keys_cap = 0, sorted_cap = 0, temp_cap = 0, tiles_cap = 0, partials_cap = 0;
 };
 hipError_t render_particles(RasterLaunch& a, RasterScratch& s, hipStream_t stream, unsigned long long out_stats[3], bool* too_many);
 void free_raster_scratch(RasterScratch& s);

@@ -184,8 +184,31 @@ ILM_DEV int64_t key_lower_bound(const unsigned long long* keys, int64_t n, unsig
     return lo;
 }
 
-// PS_NoTexture + the blend, RasterizeParticleSystem.fx:150-163,228-241: one workgroup per tile, one lane per pixel.
-// The tile's sprites come 256 at a time: thread t fetches sprite t of the batch into LDS and tests its bounding box against the four
+// A tile's run of keys is cut into segments of at most kRasterSegment sprites, one work item (workgroup) each: particle systems
+// cluster (attractors), and one workgroup walking the 50 000 sprites of the densest tile alone made the frame 5x longer than the
+// same number of sprites spread out.  `over` is associative -- a run of fragments acts on what lies beneath it as
+// dst' = C + T * dst with C the blended colour of the run over black and T the product of its (1 - alpha) -- so the segments of a
+// tile are shaded independently into (C, T) per pixel and combined in order afterwards (float rounding moves by an ulp or two
+// with the bracketing; blending is otherwise the same chain of operations).  Tiles with a single segment blend straight into the
+// target.
+constexpr int kRasterSegment = 2048;
+
+__global__ __launch_bounds__(256) void raster_tile_ranges_kernel(const RasterLaunch a) {
+    const int tile = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    const int tiles = a.tiles_x * a.tiles_y;
+    if (tile > tiles) return;
+    if (tile == tiles) { a.tile_begin[tile] = (uint32_t)a.pair_count; a.tile_segments[tile] = 0u; a.tile_multi[tile] = 0u; return; }
+    const int64_t begin = key_lower_bound(a.sorted_keys, a.pair_count, (unsigned long long)(uint32_t)tile << 32);
+    const int64_t end = key_lower_bound(a.sorted_keys, a.pair_count, (unsigned long long)(uint32_t)(tile + 1) << 32);
+    const uint32_t segments = (uint32_t)((end - begin + kRasterSegment - 1) / kRasterSegment);
+    a.tile_begin[tile] = (uint32_t)begin;
+    a.tile_segments[tile] = segments;
+    a.tile_multi[tile] = (segments > 1u) ? segments : 0u;
+}
+
+// PS_NoTexture + the blend, RasterizeParticleSystem.fx:150-163,228-241: one workgroup per work item (a tile, or a segment of a
+// crowded tile's run), one lane per pixel.
+// The sprites come 256 at a time: thread t fetches sprite t of the batch into LDS and tests its bounding box against the four
 // 8 x 8 quadrants of the tile; a ballot + prefix count per quadrant turns that into four slot-ordered index lists, and wave q then
 // walks only the sprites that can touch its quadrant (for 8 x 8-pixel sprites about a third of the tile's), the next record
 // already in flight while the current one is shaded.
@@ -194,14 +217,22 @@ __global__ __launch_bounds__(256) void raster_tiles_kernel(const RasterLaunch a)
     __shared__ Sprite batch[256];
     __shared__ uint8_t list[4][256];
     __shared__ int wave_count[4][4];          // [loader wave][quadrant]
-    __shared__ int64_t range[2];
-    const int tile = (int)blockIdx.x;
+    const int tiles = a.tiles_x * a.tiles_y;
+    const uint32_t item = blockIdx.x;
+    if (item >= a.tile_first_item[tiles]) return;           // the grid is an upper bound of the work items
+    // the tile this work item belongs to: last tile whose first item is <= item (tiles without sprites own no item)
+    int lo = 0, hi = tiles;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (a.tile_first_item[mid] <= item) lo = mid; else hi = mid;
+    }
+    const int tile = lo;
+    const uint32_t segment = item - a.tile_first_item[tile], segments = a.tile_segments[tile];
+    const int64_t run_begin = a.tile_begin[tile], run_end = a.tile_begin[tile + 1];
+    const int64_t begin = run_begin + (int64_t)segment * kRasterSegment;
+    const int64_t end = (begin + kRasterSegment < run_end) ? begin + kRasterSegment : run_end;
+    const bool direct = segments == 1u;
     const int tid = (int)threadIdx.x;
-    if (tid < 2)
-        range[tid] = key_lower_bound(a.sorted_keys, a.pair_count, (unsigned long long)(uint32_t)(tile + tid) << 32);
-    __syncthreads();
-    const int64_t begin = range[0], end = range[1];
-    if (begin == end) return;                               // uniform: no sprite touches this tile, the texels stay as they are
     const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
     // each wave owns an 8 x 8 quadrant of the tile (lane = 8 * row + column)
     const int wave = tid >> 6, lane = tid & 63;
@@ -210,7 +241,8 @@ __global__ __launch_bounds__(256) void raster_tiles_kernel(const RasterLaunch a)
     const bool in_image = (x < a.width) && (y < a.height);
     const size_t o = (size_t)y * (size_t)a.width + (size_t)x;
     float4 dst = mk4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (in_image) dst = load_target<FORMAT>(a.target, o);
+    float transmittance = 1.0f;
+    if (in_image && direct) dst = load_target<FORMAT>(a.target, o);
     const float pcx = (float)x + 0.5f, pcy = (float)y + 0.5f;
     const float tcx = (float)(tx * kRasterTile) + 4.0f, tcy = (float)(ty * kRasterTile) + 4.0f;     // centre of quadrant 0
     const bool rounded = a.params.RenderingOptions[0] != 0.0f;
@@ -278,13 +310,41 @@ __global__ __launch_bounds__(256) void raster_tiles_kernel(const RasterLaunch a)
             const float keep = additive ? 1.0f : (1.0f - sa);
             dst.x = sr + (dst.x * keep); dst.y = sg + (dst.y * keep);
             dst.z = sb + (dst.z * keep); dst.w = sa + (dst.w * keep);
+            transmittance *= keep;
         }
     }
-    if (in_image) store_target<FORMAT>(a.target, o, dst);
+    if (direct) {
+        if (in_image) store_target<FORMAT>(a.target, o, dst);
+    } else {
+        // (C, T) of this segment over black, lane-major so the combine pass reads it coalesced
+        float* out = a.partials + ((size_t)(a.tile_first_partial[tile] + segment) * 5u) * 256u;
+        out[tid] = dst.x; out[256 + tid] = dst.y; out[512 + tid] = dst.z; out[768 + tid] = dst.w; out[1024 + tid] = transmittance;
+    }
     if (a.count_shaded) {
         for (int off = 32; off > 0; off >>= 1) shaded += __shfl_down(shaded, off);
         if ((lane == 0) && shaded != 0u) atomicAdd(&a.stats[2], (unsigned long long)shaded);
     }
+}
+
+// crowded tiles: dst = C_j + T_j * dst for the segments j in order
+template <int FORMAT>
+__global__ __launch_bounds__(256) void raster_combine_kernel(const RasterLaunch a) {
+    const int tile = (int)blockIdx.x;
+    const uint32_t segments = a.tile_segments[tile];
+    if (segments <= 1u) return;
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tx = tile % a.tiles_x, ty = tile / a.tiles_x;
+    const int x = tx * kRasterTile + (wave & 1) * 8 + (lane & 7), y = ty * kRasterTile + (wave >> 1) * 8 + (lane >> 3);
+    if ((x >= a.width) || (y >= a.height)) return;
+    const size_t o = (size_t)y * (size_t)a.width + (size_t)x;
+    float4 dst = load_target<FORMAT>(a.target, o);
+    const float* part = a.partials + ((size_t)a.tile_first_partial[tile] * 5u) * 256u;
+    for (uint32_t j = 0; j < segments; j++, part += 5 * 256) {
+        const float t = part[1024 + tid];
+        dst.x = part[tid] + (dst.x * t); dst.y = part[256 + tid] + (dst.y * t);
+        dst.z = part[512 + tid] + (dst.z * t); dst.w = part[768 + tid] + (dst.w * t);
+    }
+    store_target<FORMAT>(a.target, o, dst);
 }
 
 template <int FORMAT>
@@ -315,9 +375,9 @@ static hipError_t grow(void** p, size_t* cap, size_t bytes, hipStream_t stream) 
 }
 
 void free_raster_scratch(RasterScratch& s) {
-    void** ptrs[] = { &s.sprites, &s.counts, &s.offsets, &s.keys, &s.sorted_keys, &s.temp, &s.stats };
+    void** ptrs[] = { &s.sprites, &s.counts, &s.offsets, &s.keys, &s.sorted_keys, &s.temp, &s.stats, &s.tiles, &s.partials };
     for (void** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
-    s.sprites_cap = s.counts_cap = s.offsets_cap = s.keys_cap = s.sorted_cap = s.temp_cap = 0;
+    s.sprites_cap = s.counts_cap = s.offsets_cap = s.keys_cap = s.sorted_cap = s.temp_cap = s.tiles_cap = s.partials_cap = 0;
 }
 
 // setup -> scan -> emit -> sort -> tiles.  One host synchronisation (the pair count sizes the key buffers).
@@ -363,10 +423,37 @@ hipError_t render_particles(RasterLaunch& a, RasterScratch& s, hipStream_t strea
         RASTER_TRY(rocprim::radix_sort_keys(nullptr, sort_bytes, a.keys, a.sorted_keys, (size_t)pairs, 32u, (unsigned)(32 + tile_bits), stream));
         RASTER_TRY(grow(&s.temp, &s.temp_cap, sort_bytes, stream));
         RASTER_TRY(rocprim::radix_sort_keys(s.temp, sort_bytes, a.keys, a.sorted_keys, (size_t)pairs, 32u, (unsigned)(32 + tile_bits), stream));
-        const dim3 tile_grid((unsigned)(a.tiles_x * a.tiles_y));
-        if (a.format == ILM_LIGHTMAP_FLOAT4) hipLaunchKernelGGL(raster_tiles_kernel<ILM_LIGHTMAP_FLOAT4>, tile_grid, block, 0, stream, a);
-        else if (a.format == ILM_LIGHTMAP_HALF4) hipLaunchKernelGGL(raster_tiles_kernel<ILM_LIGHTMAP_HALF4>, tile_grid, block, 0, stream, a);
-        else hipLaunchKernelGGL(raster_tiles_kernel<ILM_LIGHTMAP_RGBA8>, tile_grid, block, 0, stream, a);
+        // tile runs -> segments -> work items (two scans over the tiles; no host round trip: the grid is an upper bound)
+        const int tiles = a.tiles_x * a.tiles_y;
+        RASTER_TRY(grow(&s.tiles, &s.tiles_cap, (size_t)(tiles + 1) * 5 * sizeof(uint32_t), stream));
+        a.tile_begin = static_cast<uint32_t*>(s.tiles);
+        a.tile_segments = a.tile_begin + (tiles + 1);
+        a.tile_first_item = a.tile_segments + (tiles + 1);
+        a.tile_multi = a.tile_first_item + (tiles + 1);
+        a.tile_first_partial = a.tile_multi + (tiles + 1);
+        hipLaunchKernelGGL(raster_tile_ranges_kernel, dim3((unsigned)((tiles + 1 + 255) / 256)), block, 0, stream, a);
+        RASTER_TRY(hipGetLastError());
+        size_t tscan = 0;
+        RASTER_TRY(rocprim::exclusive_scan(nullptr, tscan, a.tile_segments, a.tile_first_item, 0u, (size_t)(tiles + 1), rocprim::plus<uint32_t>(), stream));
+        RASTER_TRY(grow(&s.temp, &s.temp_cap, tscan, stream));
+        RASTER_TRY(rocprim::exclusive_scan(s.temp, tscan, a.tile_segments, a.tile_first_item, 0u, (size_t)(tiles + 1), rocprim::plus<uint32_t>(), stream));
+        RASTER_TRY(rocprim::exclusive_scan(s.temp, tscan, a.tile_multi, a.tile_first_partial, 0u, (size_t)(tiles + 1), rocprim::plus<uint32_t>(), stream));
+        // sum over tiles of ceil(len / S) <= non-empty tiles + pairs / S; partial slots only for tiles with >= 2 segments: <= 2 pairs / S
+        a.work_items = (int32_t)std::min<unsigned long long>((unsigned long long)tiles + pairs / kRasterSegment + 1ull, 0x7FFFFFFFull);
+        const size_t partial_slots = (size_t)(2 * (pairs / kRasterSegment) + 2);
+        RASTER_TRY(grow(&s.partials, &s.partials_cap, partial_slots * 5 * 256 * sizeof(float), stream));
+        a.partials = static_cast<float*>(s.partials);
+        const dim3 item_grid((unsigned)a.work_items), tile_grid((unsigned)tiles);
+        if (a.format == ILM_LIGHTMAP_FLOAT4) {
+            hipLaunchKernelGGL(raster_tiles_kernel<ILM_LIGHTMAP_FLOAT4>, item_grid, block, 0, stream, a);
+            hipLaunchKernelGGL(raster_combine_kernel<ILM_LIGHTMAP_FLOAT4>, tile_grid, block, 0, stream, a);
+        } else if (a.format == ILM_LIGHTMAP_HALF4) {
+            hipLaunchKernelGGL(raster_tiles_kernel<ILM_LIGHTMAP_HALF4>, item_grid, block, 0, stream, a);
+            hipLaunchKernelGGL(raster_combine_kernel<ILM_LIGHTMAP_HALF4>, tile_grid, block, 0, stream, a);
+        } else {
+            hipLaunchKernelGGL(raster_tiles_kernel<ILM_LIGHTMAP_RGBA8>, item_grid, block, 0, stream, a);
+            hipLaunchKernelGGL(raster_combine_kernel<ILM_LIGHTMAP_RGBA8>, tile_grid, block, 0, stream, a);
+        }
         RASTER_TRY(hipGetLastError());
     }
     if (out_stats) {

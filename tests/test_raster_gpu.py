@@ -110,6 +110,28 @@ def test_large_sprites_and_many_tiles(ctx, oracle):
     compare_images(got, want, "large sprites", max_outliers=8)
 
 
+@pytest.mark.parametrize("blend", [abi.BLEND_ALPHA, abi.BLEND_ADDITIVE])
+def test_crowded_tiles_are_shaded_in_segments(ctx, oracle, blend):
+    """12 288 sprites inside a 40 x 40-pixel patch: the tiles under it hold thousands of sprites each, so their runs are cut into
+    segments, shaded independently as (colour, transmittance) and combined in order.  The result is the sequential blend."""
+    cs, w, h = 64, 128, 96
+    chunks = random_chunks(120, cs, 3, w, h, size_hi=5.0, dead_fraction=0.0)
+    for c, planes in enumerate(chunks):
+        planes[0][:, 0] = 40.0 + scenes.uniform(300 + c, (cs * cs,), 0.0, 40.0)
+        planes[0][:, 1] = 30.0 + scenes.uniform(310 + c, (cs * cs,), 0.0, 40.0)
+        planes[0][:, 2] = 0.0
+        planes[3][:] *= 0.15                       # faint sprites: thousands of layers still change the pixel
+    params = scenes.rasterize_params(rounded=True, blend=blend)
+    clear = (0.2, 0.1, 0.3, 1.0)
+    got, (live, pairs, shaded) = render_gpu(ctx, chunks, cs, params, w, h, abi.LIGHTMAP_FLOAT4, clear)
+    want = np.zeros((h, w, 4), np.float32); want[:] = clear
+    want, (olive, oshaded) = oracle.render_particles(chunks, params, w, h, image=want)
+    assert live == olive == 3 * cs * cs and abs(shaded - oshaded) <= 8
+    assert pairs / 9.0 > 2048                       # the ~9 tiles of the patch: more than one segment each
+    compare_images(got, want, "crowded tiles", max_outliers=8)
+    assert np.abs(want[50, 60] - np.asarray(clear, np.float32)).max() > 0.05
+
+
 def test_fracture_only_options_and_bad_arguments_are_refused(ctx):
     eng = native.Engine(ctx, 16, scenes.randomness_table(7))
     sysm = native.System(eng); sysm.add_chunk()
