@@ -7,7 +7,7 @@ offsets against the C header by compiling a probe.
 """
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 OK = 0
 ERR_INVALID_ARGUMENT = -1
@@ -197,13 +197,15 @@ class PatternParams(C.Structure):
 
 
 BLEND_ALPHA, BLEND_ADDITIVE = 0, 1
+BITMAP_NONE, BITMAP_POINT, BITMAP_LINEAR = 0, 1, 2
 
 
 class RasterizeParams(C.Structure):
     _fields_ = [("GlobalColor", Float4), ("BitmapTextureRegion", Float4), ("SizeFactorAndPosition", Float4), ("Scale", Float4),
                 ("ZFormula", Float4), ("ZConfiguration", Float4), ("RoundingPowerFromLife", ClampedBezier1),
                 ("RenderingOptions", f32 * 4), ("SystemSize", f32 * 2), ("ZToY", f32), ("StippleFactor", f32),
-                ("ViewportScale", f32 * 2), ("ViewportPosition", f32 * 2), ("BlendMode", i32), ("_pad", i32 * 3)]
+                ("ViewportScale", f32 * 2), ("ViewportPosition", f32 * 2), ("BlendMode", i32), ("BitmapFilter", i32),
+                ("AnimationRate", f32 * 2)]
 
 
 class _OpUnion(C.Union):

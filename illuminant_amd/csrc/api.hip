@@ -132,6 +132,7 @@ struct System {
     uint32_t* d_slots = nullptr; int slots_cap = 0; uint32_t* d_slot_count = nullptr;
     // the Spawner's PositionBuffer per spawn record slot (ParticleSpawner.cs:301-353)
     float4* spawn_positions[ILM_MAX_SPAWNS] = {}; int spawn_position_count[ILM_MAX_SPAWNS] = {}; int spawn_position_cap[ILM_MAX_SPAWNS] = {};
+    float4* bitmap = nullptr; int bitmap_w = 0, bitmap_h = 0;     // Appearance.Texture for the textured rasterise techniques
     // the PatternSpawner's texture per spawn record slot, mip levels back to back (SpecialSpawners.cs:19-22)
     float4* spawn_pattern[ILM_MAX_SPAWNS] = {}; int pattern_w[ILM_MAX_SPAWNS] = {}, pattern_h[ILM_MAX_SPAWNS] = {}, pattern_levels[ILM_MAX_SPAWNS] = {};
     // asynchronous readback of the fused live counts
@@ -787,6 +788,7 @@ int32_t ilm_system_destroy(IlmHandle h) {
         if (s->spawn_positions[k]) (void)hipFree(s->spawn_positions[k]);
     for (int k = 0; k < ILM_MAX_SPAWNS; k++)
         if (s->spawn_pattern[k]) (void)hipFree(s->spawn_pattern[k]);
+    if (s->bitmap) (void)hipFree(s->bitmap);
     if (s->h_counts) (void)hipHostFree(s->h_counts);
     if (s->counts_ev) (void)hipEventDestroy(s->counts_ev);
     retire_handle(s);
@@ -1802,6 +1804,24 @@ int32_t ilm_system_readback(IlmHandle hsystem, const int32_t* element_counts, in
     return ILM_OK;
 }
 
+int32_t ilm_system_set_bitmap(IlmHandle h, const IlmFloat4* texels, int32_t width, int32_t height) {
+    System* s = from_handle<System>(h, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (width < 0 || height < 0 || width > 16384 || height > 16384 || ((width > 0) != (height > 0)) || (width > 0 && !texels))
+        return fail(ILM_ERR_INVALID_ARGUMENT, "bad bitmap (%d x %d)", width, height);
+    Ctx* c = s->engine->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));     // an earlier render may still read the old bitmap
+    if (s->bitmap) HIP_TRY(hipFree(s->bitmap));
+    s->bitmap = nullptr; s->bitmap_w = s->bitmap_h = 0;
+    if (width == 0) return ILM_OK;
+    const size_t bytes = sizeof(float4) * (size_t)width * (size_t)height;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->bitmap), bytes));
+    HIP_TRY(hipMemcpy(s->bitmap, texels, bytes, hipMemcpyHostToDevice));
+    s->bitmap_w = width; s->bitmap_h = height;
+    return ILM_OK;
+}
+
 int32_t ilm_lightmap_clear(IlmHandle h, const float rgba[4]) {
     Lightmap* m = from_handle<Lightmap>(h, kMagicLightmap);
     if (!m) return fail(ILM_ERR_INVALID_HANDLE, "not a lightmap handle");
@@ -1828,6 +1848,13 @@ int32_t ilm_render_particles(IlmHandle hsystem, const int32_t* quad_counts, int3
         return fail(ILM_ERR_INVALID_ARGUMENT, "DitheredOpacity needs Fracture's Dither64, which is not part of the reference tree");
     if (params->BlendMode != ILM_BLEND_ALPHA && params->BlendMode != ILM_BLEND_ADDITIVE)
         return fail(ILM_ERR_INVALID_ARGUMENT, "unknown blend mode %d", params->BlendMode);
+    if (params->BitmapFilter < ILM_BITMAP_NONE || params->BitmapFilter > ILM_BITMAP_LINEAR)
+        return fail(ILM_ERR_INVALID_ARGUMENT, "unknown bitmap filter %d", params->BitmapFilter);
+    if (params->BitmapFilter != ILM_BITMAP_NONE) {
+        if (!s->bitmap) return fail(ILM_ERR_STATE, "textured technique without a bitmap (ilm_system_set_bitmap)");
+        const float rw = params->BitmapTextureRegion.z - params->BitmapTextureRegion.x, rh = params->BitmapTextureRegion.w - params->BitmapTextureRegion.y;
+        if (!(rw > 0.0f) || !(rh > 0.0f)) return fail(ILM_ERR_INVALID_ARGUMENT, "empty BitmapTextureRegion");
+    }
     const int n = (int)s->chunks.size();
     if (chunk_count < 0 || chunk_count > n) return fail(ILM_ERR_OUT_OF_RANGE, "chunk_count %d outside [0, %d]", chunk_count, n);
     if (out_stats) out_stats[0] = out_stats[1] = out_stats[2] = 0;
@@ -1862,6 +1889,7 @@ int32_t ilm_render_particles(IlmHandle hsystem, const int32_t* quad_counts, int3
     a.target = m->texels; a.format = m->format; a.width = m->width; a.height = m->height;
     a.tiles_x = (m->width + 15) / 16; a.tiles_y = (m->height + 15) / 16;
     a.count_shaded = out_stats ? 1 : 0;
+    a.bitmap = s->bitmap; a.bitmap_w = s->bitmap_w; a.bitmap_h = s->bitmap_h;
     unsigned long long stats[3] = { 0, 0, 0 };
     bool too_many = false;
     HIP_TRY(render_particles(a, c->raster, c->stream, out_stats ? stats : nullptr, &too_many));

@@ -228,8 +228,9 @@ struct RasterLaunch {
     IlmRasterizeParams params;
     void* target; int32_t format, width, height, tiles_x, tiles_y;
     int32_t count_shaded;               // != 0: count the fragments that were blended (statistics)
+    const float4* bitmap; int32_t bitmap_w, bitmap_h;      // Appearance.Texture, one level (ilm_system_set_bitmap)
     // scratch, filled by render_particles
-    Sprite* sprites; uint32_t* counts; uint32_t* offsets;
+    Sprite* sprites; uint32_t* counts; uint32_t* offsets; uint2* rects;
     unsigned long long* keys; unsigned long long* sorted_keys; int64_t pair_count;
     unsigned long long* stats;          // [0] live quads, [2] shaded pixels
     // per tile (tile_count + 1 entries where scanned): first key of the tile's run, number of segments the run is cut into, first
@@ -241,8 +242,8 @@ struct RasterLaunch {
 // device buffers the rasteriser keeps between calls (owned by the context)
 struct RasterScratch {
     void* sprites = nullptr; void* counts = nullptr; void* offsets = nullptr; void* keys = nullptr; void* sorted_keys = nullptr;
-    void* temp = nullptr; void* stats = nullptr; void* tiles = nullptr; void* partials = nullptr;
-    size_t sprites_cap = 0, counts_cap = 0, offsets_cap = 0, keys_cap = 0, sorted_cap = 0, temp_cap = 0, tiles_cap = 0, partials_cap = 0;
+    void* temp = nullptr; void* stats = nullptr; void* tiles = nullptr; void* partials = nullptr; void* rects = nullptr;
+    size_t sprites_cap = 0, counts_cap = 0, offsets_cap = 0, keys_cap = 0, sorted_cap = 0, temp_cap = 0, tiles_cap = 0, partials_cap = 0, rects_cap = 0;
 };
 hipError_t render_particles(RasterLaunch& a, RasterScratch& s, hipStream_t stream, unsigned long long out_stats[3], bool* too_many);
 void free_raster_scratch(RasterScratch& s);

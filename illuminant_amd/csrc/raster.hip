@@ -24,9 +24,9 @@ struct alignas(16) Sprite {
     float cx, cy;               // centre, pixels
     float ex, ey;               // half extents of the bounding box, pixels (+ 1 pixel of slack): culling only
     float i00, i01, i10, i11;   // unit = I * (pixel centre - centre)
-    float r, g, b, a;           // RenderColor * GlobalColor
+    float r, g, b, a;           // RenderColor (x GlobalColor for NoTexture; the textured pixel shaders apply it after the texel)
     float rounding;
-    uint32_t tiles_x, tiles_y;  // first | last << 16 tile column / row of the clipped bounding box
+    float frame_u, frame_v;     // frameTexCoord: offset of the animation frame inside the sheet
     uint32_t _pad;
 };
 static_assert(sizeof(Sprite) == 64, "Sprite is 16 words");
@@ -104,23 +104,42 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(const RasterLaunch a)
                     sp.i00 = a11 / det;  sp.i01 = -a01 / det;
                     sp.i10 = -a10 / det; sp.i11 = a00 / det;
                     const float ex = fabsf(a00) + fabsf(a01), ey = fabsf(a10) + fabsf(a11);
-                    sp.r = base[12 * S + slot] * p.GlobalColor.x; sp.g = base[13 * S + slot] * p.GlobalColor.y;
-                    sp.b = base[14 * S + slot] * p.GlobalColor.z; sp.a = base[15 * S + slot] * p.GlobalColor.w;
+                    const bool textured = p.BitmapFilter != ILM_BITMAP_NONE;
+                    sp.r = base[12 * S + slot]; sp.g = base[13 * S + slot]; sp.b = base[14 * S + slot]; sp.a = base[15 * S + slot];
+                    if (!textured) { sp.r *= p.GlobalColor.x; sp.g *= p.GlobalColor.y; sp.b *= p.GlobalColor.z; sp.a *= p.GlobalColor.w; }
                     sp.rounding = clampf(bezier1_raster(p.RoundingPowerFromLife, life), 0.001f, 1.0f);
+                    sp.frame_u = sp.frame_v = 0.0f;
+                    if (textured) {
+                        // frame selection, RasterizeParticleSystem.fx:112-139
+                        const float tex_w = p.BitmapTextureRegion.z - p.BitmapTextureRegion.x, tex_h = p.BitmapTextureRegion.w - p.BitmapTextureRegion.y;
+                        const float count_x = floorf(1.0f / tex_w), count_y = floorf(1.0f / tex_h);
+                        float fx = floorf(fabsf(p.AnimationRate[0]) * life), fy = floorf(fabsf(p.AnimationRate[1]) * life);
+                        const float max_angle_x = (2.0f * kPi) / count_x, max_angle_y = (2.0f * kPi) / count_y;
+                        fy += floorf(base[19 * S + slot]);
+                        if (p.RenderingOptions[2] != 0.0f) fx += rintf(angle / max_angle_x);      // HLSL round(): ties to even
+                        if (p.RenderingOptions[3] != 0.0f) fy += rintf(angle / max_angle_y);
+                        fx = fmodf(fmaxf(fx, 0.0f), count_x);
+                        fy = clampf(fy, 0.0f, count_y - 1.0f);
+                        if (p.AnimationRate[0] < 0.0f) fx = (count_x - fx) - 1.0f;
+                        if (p.AnimationRate[1] < 0.0f) fy = (count_y - fy) - 1.0f;
+                        sp.frame_u = fx * tex_w; sp.frame_v = fy * tex_h;
+                    }
                     // pixel centres within the bounding box, one pixel of slack (the unit-square test decides), clipped to the target
                     float fx0 = floorf(sp.cx - ex - 0.5f) - 1.0f, fx1 = ceilf(sp.cx + ex - 0.5f) + 1.0f;
                     float fy0 = floorf(sp.cy - ey - 0.5f) - 1.0f, fy1 = ceilf(sp.cy + ey - 0.5f) + 1.0f;
                     fx0 = fmaxf(fx0, 0.0f); fy0 = fmaxf(fy0, 0.0f);
                     fx1 = fminf(fx1, (float)(a.width - 1)); fy1 = fminf(fy1, (float)(a.height - 1));
-                    sp.tiles_x = sp.tiles_y = 0u; sp._pad = 0u;
+                    sp._pad = 0u;
                     sp.ex = ex + 1.0f; sp.ey = ey + 1.0f;
+                    uint2 rect = make_uint2(0u, 0u);
                     if ((fx0 <= fx1) && (fy0 <= fy1)) {
                         const uint32_t tx0 = (uint32_t)fx0 / kRasterTile, tx1 = (uint32_t)fx1 / kRasterTile;
                         const uint32_t ty0 = (uint32_t)fy0 / kRasterTile, ty1 = (uint32_t)fy1 / kRasterTile;
-                        sp.tiles_x = tx0 | (tx1 << 16); sp.tiles_y = ty0 | (ty1 << 16);
+                        rect = make_uint2(tx0 | (tx1 << 16), ty0 | (ty1 << 16));
                         count = (tx1 - tx0 + 1u) * (ty1 - ty0 + 1u);
                     }
                     a.sprites[g] = sp;
+                    a.rects[g] = rect;
                 }
             }
         }
@@ -139,8 +158,8 @@ __global__ __launch_bounds__(256) void raster_emit_kernel(const RasterLaunch a) 
     if (g >= a.total_slots) return;
     const uint32_t count = a.counts[g];
     if (count == 0u) return;
-    const Sprite& sp = a.sprites[g];
-    const uint32_t tx0 = sp.tiles_x & 0xFFFFu, tx1 = sp.tiles_x >> 16, ty0 = sp.tiles_y & 0xFFFFu, ty1 = sp.tiles_y >> 16;
+    const uint2 rect = a.rects[g];      // first | last << 16 tile column / row of the clipped bounding box
+    const uint32_t tx0 = rect.x & 0xFFFFu, tx1 = rect.x >> 16, ty0 = rect.y & 0xFFFFu, ty1 = rect.y >> 16;
     unsigned long long* out = a.keys + a.offsets[g];
     for (uint32_t ty = ty0; ty <= ty1; ty++)
         for (uint32_t tx = tx0; tx <= tx1; tx++)
@@ -172,6 +191,26 @@ ILM_DEV void store_target(void* texels, size_t o, float4 c) {
         const uint32_t b = (uint32_t)rintf(sat(c.z) * 255.0f), al = (uint32_t)rintf(sat(c.w) * 255.0f);
         reinterpret_cast<uint32_t*>(texels)[o] = r | (g << 8) | (b << 16) | (al << 24);
     }
+}
+
+// tex2D on a bitmap without mips: BitmapPointSampler (POINT, CLAMP) or BitmapSampler (LINEAR, CLAMP), texel centres at + 0.5
+ILM_DEV float4 bitmap_fetch(const float4* __restrict__ tex, int w, int h, float u, float v, int filter) {
+    if (filter == ILM_BITMAP_POINT) {
+        float xf = floorf(u * (float)w), yf = floorf(v * (float)h);
+        xf = (xf >= 0.0f) ? xf : 0.0f; xf = fminf(xf, (float)(w - 1));
+        yf = (yf >= 0.0f) ? yf : 0.0f; yf = fminf(yf, (float)(h - 1));
+        return tex[(int)yf * w + (int)xf];
+    }
+    const float sx = u * (float)w - 0.5f, sy = v * (float)h - 0.5f;
+    float x0f = floorf(sx), y0f = floorf(sy);
+    const float fx = sx - x0f, fy = sy - y0f;
+    float x1f = x0f + 1.0f, y1f = y0f + 1.0f;
+    x0f = (x0f >= 0.0f) ? x0f : 0.0f; x0f = fminf(x0f, (float)(w - 1));
+    x1f = (x1f >= 0.0f) ? x1f : 0.0f; x1f = fminf(x1f, (float)(w - 1));
+    y0f = (y0f >= 0.0f) ? y0f : 0.0f; y0f = fminf(y0f, (float)(h - 1));
+    y1f = (y1f >= 0.0f) ? y1f : 0.0f; y1f = fminf(y1f, (float)(h - 1));
+    const int x0 = (int)x0f, x1 = (int)x1f, y0 = (int)y0f, y1 = (int)y1f;
+    return lerp4(lerp4(tex[y0 * w + x0], tex[y0 * w + x1], fx), lerp4(tex[y1 * w + x0], tex[y1 * w + x1], fx), fy);
 }
 
 // first index whose key is >= value
@@ -247,6 +286,9 @@ __global__ __launch_bounds__(256) void raster_tiles_kernel(const RasterLaunch a)
     const float tcx = (float)(tx * kRasterTile) + 4.0f, tcy = (float)(ty * kRasterTile) + 4.0f;     // centre of quadrant 0
     const bool rounded = a.params.RenderingOptions[0] != 0.0f;
     const bool additive = a.params.BlendMode == ILM_BLEND_ADDITIVE;
+    const int filter = a.params.BitmapFilter;
+    const float region_x = a.params.BitmapTextureRegion.x, region_y = a.params.BitmapTextureRegion.y;
+    const float region_w = a.params.BitmapTextureRegion.z - region_x, region_h = a.params.BitmapTextureRegion.w - region_y;
     uint32_t shaded = 0;
     for (int64_t base = begin; base < end; base += 256) {
         const int n = (int)((end - base < 256) ? (end - base) : 256);
@@ -303,7 +345,16 @@ __global__ __launch_bounds__(256) void raster_tiles_kernel(const RasterLaunch a)
                 const float distance_from_edge = sat(distance - power) / divisor;
                 alpha = sat(1.0f - pow_pos(distance_from_edge, power));
             }
-            const float sr = sp.r * alpha, sg = sp.g * alpha, sb = sp.b * alpha, sa = sp.a * alpha;
+            float cr = sp.r, cg = sp.g, cb = sp.b, ca = sp.a;
+            if ((filter != ILM_BITMAP_NONE) && (ca > 0.0f)) {       // PS_Texture: `color.a > (1 / 512)`, an integer division
+                // texCoord = lerp(region.xy, region.zw, unit / 2 + 0.5) + frameTexCoord, interpolated over the quad
+                const float tu = (region_x + (region_w * ((u / 2.0f) + 0.5f))) + sp.frame_u;
+                const float tv = (region_y + (region_h * ((v / 2.0f) + 0.5f))) + sp.frame_v;
+                const float4 t = bitmap_fetch(a.bitmap, a.bitmap_w, a.bitmap_h, tu, tv, filter);
+                cr = (cr * t.x) * a.params.GlobalColor.x; cg = (cg * t.y) * a.params.GlobalColor.y;
+                cb = (cb * t.z) * a.params.GlobalColor.z; ca = (ca * t.w) * a.params.GlobalColor.w;
+            }
+            const float sr = cr * alpha, sg = cg * alpha, sb = cb * alpha, sa = ca * alpha;
             if (sa <= 0.0f)                                 // `result.a <= (1 / 512)`: an integer division in the shader, i.e. <= 0
                 continue;
             shaded++;
@@ -375,9 +426,9 @@ static hipError_t grow(void** p, size_t* cap, size_t bytes, hipStream_t stream) 
 }
 
 void free_raster_scratch(RasterScratch& s) {
-    void** ptrs[] = { &s.sprites, &s.counts, &s.offsets, &s.keys, &s.sorted_keys, &s.temp, &s.stats, &s.tiles, &s.partials };
+    void** ptrs[] = { &s.sprites, &s.counts, &s.offsets, &s.keys, &s.sorted_keys, &s.temp, &s.stats, &s.tiles, &s.partials, &s.rects };
     for (void** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
-    s.sprites_cap = s.counts_cap = s.offsets_cap = s.keys_cap = s.sorted_cap = s.temp_cap = s.tiles_cap = s.partials_cap = 0;
+    s.sprites_cap = s.counts_cap = s.offsets_cap = s.keys_cap = s.sorted_cap = s.temp_cap = s.tiles_cap = s.partials_cap = s.rects_cap = 0;
 }
 
 // setup -> scan -> emit -> sort -> tiles.  One host synchronisation (the pair count sizes the key buffers).
@@ -387,6 +438,8 @@ hipError_t render_particles(RasterLaunch& a, RasterScratch& s, hipStream_t strea
     RASTER_TRY(grow(&s.sprites, &s.sprites_cap, n * sizeof(Sprite), stream));
     RASTER_TRY(grow(&s.counts, &s.counts_cap, n * sizeof(uint32_t), stream));
     RASTER_TRY(grow(&s.offsets, &s.offsets_cap, n * sizeof(uint32_t), stream));
+    RASTER_TRY(grow(&s.rects, &s.rects_cap, n * sizeof(uint2), stream));
+    a.rects = static_cast<uint2*>(s.rects);
     if (!s.stats) RASTER_TRY(hipMalloc(&s.stats, 4 * sizeof(unsigned long long)));
     RASTER_TRY(hipMemsetAsync(s.stats, 0, 4 * sizeof(unsigned long long), stream));
     a.sprites = static_cast<Sprite*>(s.sprites);

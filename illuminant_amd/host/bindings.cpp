@@ -156,6 +156,7 @@ PYBIND11_MODULE(_host, m) {
         .def_readwrite("RelativeSize", &ParticleAppearance::RelativeSize)
         .def_readwrite("ColumnFromVelocity", &ParticleAppearance::ColumnFromVelocity).def_readwrite("RowFromVelocity", &ParticleAppearance::RowFromVelocity)
         .def_readwrite("Rounded", &ParticleAppearance::Rounded).def_readwrite("DitheredOpacity", &ParticleAppearance::DitheredOpacity)
+        .def_readwrite("Bilinear", &ParticleAppearance::Bilinear)
         .def_readwrite("RoundingPowerFromLife", &ParticleAppearance::RoundingPowerFromLife);
     py::class_<ParticleSystemConfiguration>(m, "ParticleSystemConfiguration").def(py::init<>())
         .def_readwrite("Appearance", &ParticleSystemConfiguration::Appearance)
@@ -343,6 +344,12 @@ PYBIND11_MODULE(_host, m) {
         }, py::arg("target"), py::arg("blendMode") = (int)ILM_BLEND_ALPHA, py::arg("origin") = std::vector<float>{0, 0},
            py::arg("scale") = std::vector<float>{1, 1}, py::arg("viewportScale") = std::vector<float>{1, 1},
            py::arg("viewportPosition") = std::vector<float>{0, 0}, py::arg("wantStats") = false)
+        // SetBitmap((h, w, 4) float32) / SetBitmap(None)
+        .def("SetBitmap", [](ParticleSystem& s, py::object texels) {
+            if (texels.is_none()) { s.SetBitmap(0, 0, nullptr); return; }
+            auto a = py::array_t<float, py::array::c_style | py::array::forcecast>::ensure(texels);
+            if (!a || a.ndim() != 3 || a.shape(2) != 4) throw std::invalid_argument("bitmap must be (h, w, 4) float32");
+            s.SetBitmap((int)a.shape(1), (int)a.shape(0), reinterpret_cast<const IlmFloat4*>(a.data())); })
         .def("RasterizeParamsBytes", [](const ParticleSystem& s, int blendMode, const std::vector<float>& origin, const std::vector<float>& scale,
                                         const std::vector<float>& viewportScale, const std::vector<float>& viewportPosition) {
             ParticleSystem::RenderParameters rp;

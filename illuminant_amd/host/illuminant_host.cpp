@@ -1114,11 +1114,28 @@ IlmRasterizeParams ParticleSystem::GetRasterizeParams(int blendMode, const Rende
     IlmRasterizeParams p;
     std::memset(&p, 0, sizeof(p));
     const ParticleSystemConfiguration& C = Configuration;
-    if (C.Appearance.TextureSize)
-        throw InvalidOperationException("Render: only the NoTexture technique is bound (Appearance.Texture must be unset)");
     const Vector2 origin = rp ? rp->Origin : Vector2{0, 0}, scale = rp ? rp->Scale : Vector2{1, 1};
-    p.BitmapTextureRegion = { 0, 0, 1, 1 };
-    p.SizeFactorAndPosition = { 1, 1, origin.X, origin.Y };
+    const ParticleAppearance& ap = C.Appearance;
+    if (ap.TextureSize) {
+        // Uniforms.RasterizeParticleSystem ctor, Uniforms.cs:252-277
+        const Vector2 texSize = *ap.TextureSize;
+        const Vector2 sizePx = ap.SizePx.value_or(texSize);
+        const Vector2 offset{ ap.OffsetPx.X / texSize.X, ap.OffsetPx.Y / texSize.Y };
+        const Vector2 size{ sizePx.X / texSize.X, sizePx.Y / texSize.Y };
+        p.BitmapTextureRegion = { offset.X, offset.Y, offset.X + size.X, offset.Y + size.Y };
+        if (ap.RelativeSize)
+            p.SizeFactorAndPosition = { sizePx.X * 0.5f, sizePx.Y * 0.5f, origin.X, origin.Y };
+        else
+            p.SizeFactorAndPosition = { 1, 1, origin.X, origin.Y };
+        p.BitmapFilter = ap.Bilinear ? ILM_BITMAP_LINEAR : ILM_BITMAP_POINT;      // material choice, ParticleSystem.cs:963-971
+    } else {
+        p.BitmapTextureRegion = { 0, 0, 1, 1 };
+        p.SizeFactorAndPosition = { 1, 1, origin.X, origin.Y };
+        p.BitmapFilter = ILM_BITMAP_NONE;
+    }
+    // System.AnimationRateAndRotationAndZToY.xy, Uniforms.cs:230-234
+    p.AnimationRate[0] = (ap.AnimationRate.X != 0) ? 1.0f / ap.AnimationRate.X : 0.0f;
+    p.AnimationRate[1] = (ap.AnimationRate.Y != 0) ? 1.0f / ap.AnimationRate.Y : 0.0f;
     p.Scale = { scale.X, scale.Y, 0, 0 };
     Vector4 g = C.Color.Global;
     g.X *= g.W; g.Y *= g.W; g.Z *= g.W;
@@ -1137,6 +1154,10 @@ IlmRasterizeParams ParticleSystem::GetRasterizeParams(int blendMode, const Rende
     p.ViewportPosition[0] = viewportPosition.X; p.ViewportPosition[1] = viewportPosition.Y;
     p.BlendMode = blendMode;
     return p;
+}
+
+void ParticleSystem::SetBitmap(int width, int height, const IlmFloat4* texels) {
+    ThrowIfFailed(ilm_system_set_bitmap(handle, texels, width, height));
 }
 
 ParticleSystem::RenderStats ParticleSystem::Render(RenderTarget& target, int blendMode, const RenderParameters* rp, Vector2 viewportScale,

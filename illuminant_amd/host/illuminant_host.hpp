@@ -241,6 +241,7 @@ struct ParticleAppearance {
     bool RelativeSize = true;
     bool ColumnFromVelocity = false, RowFromVelocity = false;
     bool Rounded = false, DitheredOpacity = false;                 // :72-77
+    bool Bilinear = true;                                          // :87
     BezierF RoundingPowerFromLife{1, 0, 0, 1, 0.8f, 0.8f, 0.8f, 0.8f};   // new BezierF(0.8f), :82
 };
 // ParticleConfiguration.cs:187-303 (the members the update path reads)
@@ -566,8 +567,11 @@ public:
     // ParticleRenderParameters, ParticleConfiguration.cs:305-312
     struct RenderParameters { Vector2 Origin{0, 0}, Scale{1, 1}; std::optional<float> StippleFactor; };
     struct RenderStats { uint64_t LiveQuads = 0, TilePairs = 0, ShadedPixels = 0; };
-    // ParticleSystem.Render (ParticleSystem.cs:943-1041) for a system without Appearance.Texture: technique
-    // RasterizeParticlesNoTexture, every chunk in order with quadCount = min(ChunkMaximumCount, TotalSpawned + 1) (:880), blended onto
+    // Appearance.Texture.Instance for the textured techniques: width x height float4 texels, one level (the native layer binds
+    // bitmaps without mips only); Appearance.TextureSize must say the same size
+    void SetBitmap(int width, int height, const IlmFloat4* texels);
+    // ParticleSystem.Render (ParticleSystem.cs:943-1041): technique RasterizeParticlesNoTexture, or TextureLinear / TexturePoint by
+    // Appearance.Bilinear when a texture is set (:963-971), every chunk in order with quadCount = min(ChunkMaximumCount, TotalSpawned + 1) (:880), blended onto
     // `target` with blendMode (ILM_BLEND_*); viewportScale / viewportPosition play Fracture's ViewTransform.
     RenderStats Render(RenderTarget& target, int blendMode = ILM_BLEND_ALPHA, const RenderParameters* renderParams = nullptr,
                        Vector2 viewportScale = Vector2{1, 1}, Vector2 viewportPosition = Vector2{0, 0}, bool wantStats = false) const;

@@ -87,6 +87,7 @@ SYMBOLS = {
     "ilm_system_readback_view": (_I, [_H, _P, _I, _P, C.POINTER(_P), C.POINTER(_I)]),
     "ilm_render_particles": (_I, [_H, _P, _I, _P, _H, _P]),
     "ilm_lightmap_clear": (_I, [_H, _P]),
+    "ilm_system_set_bitmap": (_I, [_H, _P, _I, _I]),
     "ilm_resolve_lighting": (_I, [_H, _H, _P, _I, _I]),
 }
 
@@ -251,6 +252,14 @@ class System:
             return
         a = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 4)
         check(lib().ilm_system_set_spawn_positions(self.handle, slot, _ptr(a), a.shape[0]))
+
+    def set_bitmap(self, texels):
+        """ilm_system_set_bitmap: (h, w, 4) float32 sprite sheet for the textured rasterise techniques; None releases."""
+        if texels is None:
+            check(lib().ilm_system_set_bitmap(self.handle, None, 0, 0))
+            return
+        a = np.ascontiguousarray(texels, dtype=np.float32)
+        check(lib().ilm_system_set_bitmap(self.handle, _ptr(a), a.shape[1], a.shape[0]))
 
     def set_spawn_pattern(self, slot, levels):
         """ilm_system_set_spawn_pattern: `levels` = [level 0 (h, w, 4) float32, level 1 (max(1, h >> 1), max(1, w >> 1), 4), ...] of the

@@ -184,28 +184,43 @@ def feedback_params(source_system_handle, source_chunk_index, source_index, inst
 
 def rasterize_params(size=(1.0, 1.0), global_color=(1.0, 1.0, 1.0, 1.0), origin=(0.0, 0.0), scale=(1.0, 1.0), size_from_z=0.0, z_to_y=0.0,
                      rounded=False, rounding_power=None, viewport_scale=(1.0, 1.0), viewport_position=(0.0, 0.0), blend=abi.BLEND_ALPHA,
-                     z_formula=(0.0, 0.0, 0.0, 0.0), stipple_factor=1.0):
-    """Uniforms.RasterizeParticleSystem for a system without a texture (Uniforms.cs:238-290) + what ParticleSystem.Render /
-    RenderHandler._BeforeDraw add (ParticleSystem.cs:254-271, 1023-1032).  global_color is Color.Global (NOT premultiplied: the ctor
-    does that); rounding_power: a ClampedBezier1 or None for the constant 0.8 (ParticleAppearance.RoundingPowerFromLife default)."""
+                     z_formula=(0.0, 0.0, 0.0, 0.0), stipple_factor=1.0, texture_size=None, offset_px=(0.0, 0.0), size_px=None,
+                     relative_size=True, bilinear=True, animation_rate=(0.0, 0.0), column_from_velocity=False, row_from_velocity=False):
+    """Uniforms.RasterizeParticleSystem (Uniforms.cs:238-290) + what ParticleSystem.Render / RenderHandler._BeforeDraw add
+    (ParticleSystem.cs:254-271, 963-1032).  global_color is Color.Global (NOT premultiplied: the ctor does that); rounding_power: a
+    ClampedBezier1 or None for the constant 0.8 (ParticleAppearance.RoundingPowerFromLife default).  texture_size = (w, h) of
+    Appearance.Texture or None (technique NoTexture); offset_px / size_px = the frame rectangle; animation_rate = Appearance.AnimationRate
+    (the uniform holds its reciprocal, Uniforms.cs:230-234)."""
+    f = np.float32
     p = abi.RasterizeParams()
     gc = np.asarray(global_color, np.float32)
     p.GlobalColor = abi.f4(gc[0] * gc[3], gc[1] * gc[3], gc[2] * gc[3], gc[3])
-    p.BitmapTextureRegion = abi.f4(0, 0, 1, 1)
-    p.SizeFactorAndPosition = abi.f4(1, 1, origin[0], origin[1])
+    if texture_size is not None:
+        tw, th = f(texture_size[0]), f(texture_size[1])
+        sw, sh = (f(size_px[0]), f(size_px[1])) if size_px is not None else (tw, th)
+        ox, oy = f(offset_px[0]) / tw, f(offset_px[1]) / th
+        p.BitmapTextureRegion = abi.f4(ox, oy, ox + sw / tw, oy + sh / th)
+        p.SizeFactorAndPosition = abi.f4(sw * f(0.5), sh * f(0.5), origin[0], origin[1]) if relative_size else abi.f4(1, 1, origin[0], origin[1])
+        p.BitmapFilter = abi.BITMAP_LINEAR if bilinear else abi.BITMAP_POINT
+    else:
+        p.BitmapTextureRegion = abi.f4(0, 0, 1, 1)
+        p.SizeFactorAndPosition = abi.f4(1, 1, origin[0], origin[1])
+        p.BitmapFilter = abi.BITMAP_NONE
     p.Scale = abi.f4(scale[0], scale[1], 0, 0)
     p.ZFormula = abi.f4(*z_formula)
     p.ZConfiguration = abi.f4(size_from_z, 0, 0, 0)
     if rounding_power is None:
         rounding_power = abi.ClampedBezier1.constant(0.8)
     p.RoundingPowerFromLife = rounding_power
-    p.RenderingOptions[:] = [1.0 if rounded else 0.0, 0.0, 0.0, 0.0]
+    p.RenderingOptions[:] = [1.0 if rounded else 0.0, 0.0, 1.0 if column_from_velocity else 0.0, 1.0 if row_from_velocity else 0.0]
     p.SystemSize[:] = list(size)
     p.ZToY = z_to_y
     p.StippleFactor = stipple_factor
     p.ViewportScale[:] = list(viewport_scale)
     p.ViewportPosition[:] = list(viewport_position)
     p.BlendMode = blend
+    p.AnimationRate[:] = [float(f(1.0) / f(animation_rate[0])) if animation_rate[0] != 0 else 0.0,
+                          float(f(1.0) / f(animation_rate[1])) if animation_rate[1] != 0 else 0.0]
     return p
 
 

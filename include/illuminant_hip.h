@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ILM_ABI_VERSION 3
+#define ILM_ABI_VERSION 4
 
 /* ---- return codes ------------------------------------------------------ */
 #define ILM_OK                    0
@@ -645,11 +645,16 @@ int32_t ilm_system_readback_view(IlmHandle system, const int32_t* element_counts
 
 enum { ILM_HDR_NONE = 0, ILM_HDR_GAMMA_COMPRESS = 1, ILM_HDR_TONE_MAP = 2 };   /* HDRMode, LightingRenderer.HDR.cs:254-258 */
 
-/* ---- particle rasterisation (technique RasterizeParticlesNoTexture) ------------------------------------------- */
+/* ---- particle rasterisation (techniques RasterizeParticlesNoTexture / TexturePoint / TextureLinear) -------------- */
 
 enum {
     ILM_BLEND_ALPHA    = 0,  /* BlendState.AlphaBlend on premultiplied colour: dst = src + dst * (1 - src.a) */
     ILM_BLEND_ADDITIVE = 1   /* BlendState.Additive-like (One, One): dst = src + dst */
+};
+enum {
+    ILM_BITMAP_NONE   = 0,   /* technique RasterizeParticlesNoTexture */
+    ILM_BITMAP_POINT  = 1,   /* technique RasterizeParticlesTexturePoint  (BitmapPointSampler: POINT, CLAMP) */
+    ILM_BITMAP_LINEAR = 2    /* technique RasterizeParticlesTextureLinear (BitmapSampler: LINEAR, CLAMP) */
 };
 
 /* What ParticleSystem.Render binds for the rasterise techniques: Uniforms.RasterizeParticleSystem (Illuminant/Uniforms.cs:238-290),
@@ -659,19 +664,20 @@ enum {
  * pixel centres at +0.5; the depth formula is carried but unused (no depth buffer). */
 typedef struct IlmRasterizeParams {
     IlmFloat4 GlobalColor;             /* Color.Global, premultiplied (Uniforms.cs:279-283) */
-    IlmFloat4 BitmapTextureRegion;     /* (0, 0, 1, 1) without a texture; not read by NoTexture */
-    IlmFloat4 SizeFactorAndPosition;   /* (1, 1, origin.xy) without a texture */
+    IlmFloat4 BitmapTextureRegion;     /* (offset, offset + size) / texture size; (0, 0, 1, 1) without a texture */
+    IlmFloat4 SizeFactorAndPosition;   /* (SizePx / 2 when RelativeSize and a texture is bound, else (1, 1); origin.xy) */
     IlmFloat4 Scale;                   /* (scale.xy, 0, 0) */
     IlmFloat4 ZFormula;
     IlmFloat4 ZConfiguration;          /* (SizeFromZ, 0, 0, 0) */
     IlmClampedBezier1 RoundingPowerFromLife;
-    float     RenderingOptions[4];     /* Rounded, DitheredOpacity (must be 0: Dither64 is Fracture code), column / row from velocity */
+    float     RenderingOptions[4];     /* Rounded, DitheredOpacity (must be 0: Dither64 is Fracture code), column / row (of the frame sheet) from velocity */
     float     SystemSize[2];           /* System.TexelAndSize.zw = Configuration.Size */
     float     ZToY;
     float     StippleFactor;           /* must be >= 1 (StippleReject is Fracture code) */
     float     ViewportScale[2], ViewportPosition[2];
     int32_t   BlendMode;               /* ILM_BLEND_* */
-    int32_t   _pad[3];
+    int32_t   BitmapFilter;            /* ILM_BITMAP_*: which technique; the bitmap is the one bound with ilm_system_set_bitmap */
+    float     AnimationRate[2];        /* System.AnimationRateAndRotationAndZToY.xy = 1 / Appearance.AnimationRate (0 when that is 0) */
 } IlmRasterizeParams;
 
 /* ParticleSystem.Render with technique RasterizeParticlesNoTexture (Illuminant/Shaders/RasterizeParticleSystem.fx:61-260,
@@ -684,6 +690,12 @@ typedef struct IlmRasterizeParams {
  * out_stats (may be NULL): [0] live quads, [1] (quad, tile) pairs, [2] shaded pixels (fragments not discarded). */
 int32_t ilm_render_particles(IlmHandle system, const int32_t* quad_counts, int32_t chunk_count, const IlmRasterizeParams* params,
                              IlmHandle target, uint64_t* out_stats);
+/* Appearance.Texture for the textured techniques (PS_Texture / PS_TexturePoint, RasterizeParticleSystem.fx:191-226; frame selection
+ * of VS_PosVelAttr, :112-139): width * height float4 texels, row-major, ONE level -- the reference samples with a mip filter whose
+ * level comes from screen-space derivatives (hardware-defined) over a chain its texture loader builds; a bitmap without mips is
+ * the case that is defined by the shader text alone.  The fragment is colour x texel x GlobalColor x computeCircularAlpha.
+ * width == 0 releases the bitmap. */
+int32_t ilm_system_set_bitmap(IlmHandle system, const IlmFloat4* texels, int32_t width, int32_t height);
 /* Fill a lightmap / render target with one colour (the Clear before ParticleSystem.Render). */
 int32_t ilm_lightmap_clear(IlmHandle lightmap, const float rgba[4]);
 

@@ -124,6 +124,10 @@ void orc_resolve_lighting(const IlmFloat4* lightmap, int32_t width, int32_t heig
  * order; stats (may be NULL): [0] live quads, [1] shaded pixels */
 void orc_render_particles(IlmFloat4** planes, int32_t chunk_count, const int32_t* quad_counts, int32_t slots,
                           const IlmRasterizeParams* p, IlmFloat4* image, int32_t width, int32_t height, uint64_t* stats);
+/* techniques RasterizeParticlesTexturePoint / TextureLinear on a bitmap without mips (p->BitmapFilter) */
+void orc_render_particles_textured(IlmFloat4** planes, int32_t chunk_count, const int32_t* quad_counts, int32_t slots,
+                                   const IlmRasterizeParams* p, const IlmFloat4* bitmap, int32_t bitmap_w, int32_t bitmap_h,
+                                   IlmFloat4* image, int32_t width, int32_t height, uint64_t* stats);
 
 /* host-side integer/layout logic */
 typedef struct OrcDistanceFieldLayout {

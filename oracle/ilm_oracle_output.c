@@ -124,10 +124,14 @@ typedef struct OrcSprite {
     float cx, cy;               /* centre, pixels */
     float i00, i01, i10, i11;   /* unit = I * (pixel - centre) */
     float ex, ey;               /* half extents of the bounding box, pixels */
-    f4 color;                   /* RenderColor * GlobalColor */
+    f4 color;                   /* RenderColor (x GlobalColor for NoTexture; the textured pixel shaders apply it after the texel) */
     float rounding;
+    float frame_u, frame_v;     /* frameTexCoord: offset of the animation frame inside the sheet */
     int live;
 } OrcSprite;
+
+/* HLSL round(): to nearest, ties to even */
+static float hlsl_round(float x) { return (float)nearbyint((double)x); }
 
 static OrcSprite raster_sprite(f4 position, f4 render_data, f4 render_color, const IlmRasterizeParams* p) {
     OrcSprite sp;
@@ -156,8 +160,23 @@ static OrcSprite raster_sprite(f4 position, f4 render_data, f4 render_color, con
     sp.i10 = -a10 / det; sp.i11 = a00 / det;
     sp.ex = fabsf(a00) + fabsf(a01);
     sp.ey = fabsf(a10) + fabsf(a11);
-    sp.color = v4mul(render_color, p->GlobalColor);
+    sp.color = (p->BitmapFilter == ILM_BITMAP_NONE) ? v4mul(render_color, p->GlobalColor) : render_color;
     sp.rounding = h_clamp(orc_bezier1(&p->RoundingPowerFromLife, life), 0.001f, 1.0f);
+    if (p->BitmapFilter != ILM_BITMAP_NONE) {
+        /* frame selection, RasterizeParticleSystem.fx:112-139 */
+        const float tex_w = p->BitmapTextureRegion.z - p->BitmapTextureRegion.x, tex_h = p->BitmapTextureRegion.w - p->BitmapTextureRegion.y;
+        const float count_x = floorf(1.0f / tex_w), count_y = floorf(1.0f / tex_h);
+        float fx = floorf(fabsf(p->AnimationRate[0]) * life), fy = floorf(fabsf(p->AnimationRate[1]) * life);
+        const float max_angle_x = (float)(2 * M_PI) / count_x, max_angle_y = (float)(2 * M_PI) / count_y;
+        fy += floorf(render_data.w);
+        if (p->RenderingOptions[2] != 0.0f) fx += hlsl_round(angle / max_angle_x);
+        if (p->RenderingOptions[3] != 0.0f) fy += hlsl_round(angle / max_angle_y);
+        fx = fmodf(fmaxf(fx, 0.0f), count_x);
+        fy = h_clamp(fy, 0.0f, count_y - 1.0f);
+        if (p->AnimationRate[0] < 0.0f) fx = (count_x - fx) - 1.0f;
+        if (p->AnimationRate[1] < 0.0f) fy = (count_y - fy) - 1.0f;
+        sp.frame_u = fx * tex_w; sp.frame_v = fy * tex_h;
+    }
     sp.live = 1;
     return sp;
 }
@@ -173,9 +192,43 @@ static float raster_circular_alpha(float u, float v, float rounding, float round
     return h_sat(1.0f - powf(distance_from_edge, power));
 }
 
-/* image: width * height float4, blended in place.  stats (may be NULL): live quads, shaded pixels. */
+/* tex2D on a bitmap without mips: BitmapPointSampler (POINT, CLAMP) or BitmapSampler (LINEAR, CLAMP), texel centres at + 0.5 */
+static f4 bitmap_fetch(const IlmFloat4* tex, int w, int h, float u, float v, int filter) {
+    if (filter == ILM_BITMAP_POINT) {
+        float xf = floorf(u * (float)w), yf = floorf(v * (float)h);
+        if (!(xf >= 0.0f)) xf = 0.0f; if (xf > (float)(w - 1)) xf = (float)(w - 1);
+        if (!(yf >= 0.0f)) yf = 0.0f; if (yf > (float)(h - 1)) yf = (float)(h - 1);
+        return tex[(int)yf * w + (int)xf];
+    }
+    const float sx = u * (float)w - 0.5f, sy = v * (float)h - 0.5f;
+    float x0f = floorf(sx), y0f = floorf(sy);
+    const float fx = sx - x0f, fy = sy - y0f;
+    float x1f = x0f + 1.0f, y1f = y0f + 1.0f;
+    if (!(x0f >= 0.0f)) x0f = 0.0f; if (x0f > (float)(w - 1)) x0f = (float)(w - 1);
+    if (!(x1f >= 0.0f)) x1f = 0.0f; if (x1f > (float)(w - 1)) x1f = (float)(w - 1);
+    if (!(y0f >= 0.0f)) y0f = 0.0f; if (y0f > (float)(h - 1)) y0f = (float)(h - 1);
+    if (!(y1f >= 0.0f)) y1f = 0.0f; if (y1f > (float)(h - 1)) y1f = (float)(h - 1);
+    const int x0 = (int)x0f, x1 = (int)x1f, y0 = (int)y0f, y1 = (int)y1f;
+    return v4lerp(v4lerp(tex[y0 * w + x0], tex[y0 * w + x1], fx), v4lerp(tex[y1 * w + x0], tex[y1 * w + x1], fx), fy);
+}
+
+/* image: width * height float4, blended in place.  stats (may be NULL): live quads, shaded pixels.
+ * bitmap (bitmap_w x bitmap_h float4, one level) is read when p->BitmapFilter != ILM_BITMAP_NONE. */
+void orc_render_particles_textured(IlmFloat4** planes, int32_t chunk_count, const int32_t* quad_counts, int32_t slots,
+                                   const IlmRasterizeParams* p, const IlmFloat4* bitmap, int32_t bitmap_w, int32_t bitmap_h,
+                                   IlmFloat4* image, int32_t width, int32_t height, uint64_t* stats);
+
 void orc_render_particles(IlmFloat4** planes, int32_t chunk_count, const int32_t* quad_counts, int32_t slots,
                           const IlmRasterizeParams* p, IlmFloat4* image, int32_t width, int32_t height, uint64_t* stats) {
+    orc_render_particles_textured(planes, chunk_count, quad_counts, slots, p, NULL, 0, 0, image, width, height, stats);
+}
+
+void orc_render_particles_textured(IlmFloat4** planes, int32_t chunk_count, const int32_t* quad_counts, int32_t slots,
+                                   const IlmRasterizeParams* p, const IlmFloat4* bitmap, int32_t bitmap_w, int32_t bitmap_h,
+                                   IlmFloat4* image, int32_t width, int32_t height, uint64_t* stats) {
+    const int textured = (p->BitmapFilter != ILM_BITMAP_NONE) && bitmap && bitmap_w > 0 && bitmap_h > 0;
+    const float region_x = p->BitmapTextureRegion.x, region_y = p->BitmapTextureRegion.y;
+    const float region_w = p->BitmapTextureRegion.z - p->BitmapTextureRegion.x, region_h = p->BitmapTextureRegion.w - p->BitmapTextureRegion.y;
     uint64_t live = 0, shaded = 0;
     for (int c = 0; c < chunk_count; c++) {
         const int count = quad_counts ? quad_counts[c] : slots;
@@ -199,7 +252,14 @@ void orc_render_particles(IlmFloat4** planes, int32_t chunk_count, const int32_t
                     if (!((u >= -1.0f) && (u < 1.0f) && (v >= -1.0f) && (v < 1.0f)))
                         continue;
                     const float alpha = raster_circular_alpha(u, v, sp.rounding, p->RenderingOptions[0]);
-                    const f4 src = v4scale(sp.color, alpha);
+                    f4 result = sp.color;
+                    if (textured && (result.w > 0.0f)) {       /* PS_Texture: `color.a > (1 / 512)`, an integer division */
+                        /* texCoord = lerp(region.xy, region.zw, unit / 2 + 0.5) + frameTexCoord, interpolated over the quad */
+                        const float tu = (region_x + (region_w * ((u / 2.0f) + 0.5f))) + sp.frame_u;
+                        const float tv = (region_y + (region_h * ((v / 2.0f) + 0.5f))) + sp.frame_v;
+                        result = v4mul(v4mul(result, bitmap_fetch(bitmap, bitmap_w, bitmap_h, tu, tv, p->BitmapFilter)), p->GlobalColor);
+                    }
+                    const f4 src = v4scale(result, alpha);
                     if (src.w <= 0.0f)                    /* `result.a <= (1 / 512)`: integer division, i.e. <= 0 */
                         continue;
                     shaded++;

@@ -313,8 +313,9 @@ def fill_readback_result(chunks, params, element_counts=None, capacity=None):
     return out, int(total)
 
 
-def render_particles(chunks, params, width, height, quad_counts=None, image=None):
-    """orc_render_particles: (image (h, w, 4) float32 blended in place / created black, (live quads, shaded pixels))."""
+def render_particles(chunks, params, width, height, quad_counts=None, image=None, bitmap=None):
+    """orc_render_particles(_textured): (image (h, w, 4) float32 blended in place / created black, (live quads, shaded pixels)).
+    bitmap: (h, w, 4) float32 sprite sheet for params.BitmapFilter != BITMAP_NONE."""
     n = len(chunks)
     slots = chunks[0][0].shape[0]
     ptrs = (C.c_void_p * (n * 5))()
@@ -325,7 +326,10 @@ def render_particles(chunks, params, width, height, quad_counts=None, image=None
     if image is None:
         image = np.zeros((height, width, 4), np.float32)
     stats = (C.c_uint64 * 2)()
-    lib().orc_render_particles(ptrs, C.c_int32(n), _p(q), C.c_int32(slots), C.byref(params), _f4(image), C.c_int32(width), C.c_int32(height), stats)
+    bm = np.ascontiguousarray(bitmap, dtype=np.float32) if bitmap is not None else None
+    lib().orc_render_particles_textured(ptrs, C.c_int32(n), _p(q), C.c_int32(slots), C.byref(params), _p(bm),
+                                        C.c_int32(bm.shape[1] if bm is not None else 0), C.c_int32(bm.shape[0] if bm is not None else 0),
+                                        _f4(image), C.c_int32(width), C.c_int32(height), stats)
     return image, (int(stats[0]), int(stats[1]))
 
 

@@ -741,7 +741,44 @@ def gen_rasterize():
                                 {"slot": 1, "position": [10.0, 8.0, 0.0, 1.0], "size": 0.0, "rotation": 0.0, "color": white},
                                 {"slot": 2, "position": [10.0, 8.0, 0.0, 1.0], "size": 3.0, "rotation": 0.0, "color": [0.3, 0.3, 0.3, 0.0]}],
                   "pixels": [{"x": 10, "y": 8, "rgba": clear}], "covered": []})
-    return {"source": "hand-derived from RasterizeParticleSystem.fx:61-163,228-241, Uniforms.cs:238-290 (see comments in make_golden.py)",
+    # (i) technique TexturePoint on a 4 x 2 bitmap: RelativeSize => SizeFactor = SizePx / 2 = (2, 1); RenderData.x = 4 => half extents
+    #     (8, 4) around (16, 12): a 16 x 8-pixel quad, each texel a 4 x 4-pixel block.  Fragment = colour x texel x GlobalColor.
+    texel = lambda i, j: [0.1 + 0.2 * i, 0.2 + 0.5 * j, 1.0 - 0.2 * i, 1.0]
+    bitmap = [[texel(i, j) for i in range(4)] for j in range(2)]
+    col = [0.5, 1.0, 0.5, 1.0]
+    mul = lambda a, b: [a[k] * b[k] for k in range(4)]
+    cases.append({"name": "point-sampled bitmap", "width": 32, "height": 24, "clear": black, "live_quads": 1, "shaded_pixels": 128,
+                  "bitmap": bitmap, "params": {"bilinear": False},
+                  "particles": [{"slot": 0, "position": [16.0, 12.0, 0.0, 1.0], "size": 4.0, "rotation": 0.0, "color": col}],
+                  "pixels": [{"x": 8, "y": 8, "rgba": mul(col, texel(0, 0))}, {"x": 11, "y": 11, "rgba": mul(col, texel(0, 0))},
+                             {"x": 12, "y": 8, "rgba": mul(col, texel(1, 0))}, {"x": 23, "y": 15, "rgba": mul(col, texel(3, 1))},
+                             {"x": 20, "y": 12, "rgba": mul(col, texel(3, 1))}, {"x": 7, "y": 8, "rgba": black}],
+                  "covered": sq(8, 23, 8, 15)})
+    # (j) frame sheet: an 8 x 2 bitmap of four 2 x 2 frames in a row (frame rectangle 2 x 2 px at offset 0): AnimationRate .5 => the
+    #     uniform is 2 => frame column floor(2 * life) % 4 = floor(2.6) = 2 for life 1.3; a negative rate plays the sheet backwards:
+    #     (4 - 2) - 1 = 1.  The quad (half extents SizePx / 2 * 3 = (3, 3)) shows texels (2 f, 0) .. (2 f + 1, 1) of frame f.
+    sheet = [[[0.1 * i, 0.3 + 0.4 * j, 0.05 * i * (j + 1), 1.0] for i in range(8)] for j in range(2)]
+    for (name, rate, frame) in (("frame from life", 0.5, 2), ("frame from life, reversed", -0.5, 1)):
+        cases.append({"name": name, "width": 24, "height": 20, "clear": black, "live_quads": 1, "shaded_pixels": 36,
+                      "bitmap": sheet, "params": {"bilinear": False, "size_px": [2.0, 2.0], "animation_rate": [rate, 0.0]},
+                      "particles": [{"slot": 3, "position": [10.0, 8.0, 0.0, 1.3], "size": 3.0, "rotation": 0.0, "color": white}],
+                      "pixels": [{"x": 7, "y": 5, "rgba": sheet[0][2 * frame]}, {"x": 12, "y": 5, "rgba": sheet[0][2 * frame + 1]},
+                                 {"x": 7, "y": 10, "rgba": sheet[1][2 * frame]}, {"x": 12, "y": 10, "rgba": sheet[1][2 * frame + 1]}]})
+    # (k) row of the sheet from RenderData.w (the particle's type): a 2 x 4 bitmap of two 2 x 2 frames stacked vertically
+    tall = [[[0.2 + 0.1 * i, 0.1 * j, 0.5, 1.0] for i in range(2)] for j in range(4)]
+    cases.append({"name": "row from the particle type", "width": 24, "height": 20, "clear": black, "live_quads": 1, "shaded_pixels": 36,
+                  "bitmap": tall, "params": {"bilinear": False, "size_px": [2.0, 2.0]},
+                  "particles": [{"slot": 1, "position": [10.0, 8.0, 0.0, 1.0], "size": 3.0, "rotation": 0.0, "color": white, "row": 1.0}],
+                  "pixels": [{"x": 7, "y": 5, "rgba": tall[2][0]}, {"x": 12, "y": 10, "rgba": tall[3][1]}]})
+    # (l) technique TextureLinear: a 2 x 1 bitmap black -> white; the pixel whose centre is the quad's centre has u = 0 => texCoord .5 =>
+    #     halfway between the two texel centres
+    ramp = [[[0.0, 0.0, 0.0, 1.0], [1.0, 1.0, 1.0, 1.0]]]
+    cases.append({"name": "bilinear bitmap", "width": 24, "height": 20, "clear": black, "live_quads": 1,
+                  "bitmap": ramp, "params": {"bilinear": True, "relative_size": False},
+                  "particles": [{"slot": 0, "position": [10.5, 8.5, 0.0, 1.0], "size": 4.0, "rotation": 0.0, "color": white}],
+                  "pixels": [{"x": 10, "y": 8, "rgba": [0.5, 0.5, 0.5, 1.0]}, {"x": 7, "y": 8, "rgba": [0.0, 0.0, 0.0, 1.0]},
+                             {"x": 13, "y": 8, "rgba": [1.0, 1.0, 1.0, 1.0]}, {"x": 11, "y": 8, "rgba": [0.75, 0.75, 0.75, 1.0]}]})
+    return {"source": "hand-derived from RasterizeParticleSystem.fx:61-163,191-241, Uniforms.cs:230-290 (see comments in make_golden.py)",
             "tolerance": "1e-5 relative", "cases": cases}
 
 

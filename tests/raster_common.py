@@ -23,7 +23,7 @@ def chunk_from_particles(particles, n=CS * CS):
         i = q["slot"]
         planes[0][i] = q["position"]
         planes[3][i] = q["color"]                       # RenderColor (premultiplied)
-        planes[4][i] = [q["size"], q["rotation"], 0.0, 0.0]
+        planes[4][i] = [q["size"], q["rotation"], 0.0, q.get("row", 0.0)]
     return planes
 
 
@@ -31,10 +31,10 @@ class OracleBackend:
     def __init__(self, oracle):
         self.orc = oracle
 
-    def render(self, chunks, params, width, height, clear):
+    def render(self, chunks, params, width, height, clear, bitmap=None):
         image = np.zeros((height, width, 4), np.float32)
         image[:] = np.asarray(clear, np.float32)
-        image, stats = self.orc.render_particles(chunks, params, width, height, image=image)
+        image, stats = self.orc.render_particles(chunks, params, width, height, image=image, bitmap=bitmap)
         return image, stats
 
 
@@ -43,7 +43,7 @@ class GpuBackend:
         from illuminant_amd import native
         self.native, self.ctx = native, ctx
 
-    def render(self, chunks, params, width, height, clear):
+    def render(self, chunks, params, width, height, clear, bitmap=None):
         native = self.native
         eng = native.Engine(self.ctx, int(round(chunks[0][0].shape[0] ** 0.5)), scenes.randomness_table(7))
         sysm = native.System(eng)
@@ -51,6 +51,8 @@ class GpuBackend:
             sysm.add_chunk()
             for pl, k in ((abi.PLANE_POSITION, 0), (abi.PLANE_RENDER_COLOR, 3), (abi.PLANE_RENDER_DATA, 4)):
                 sysm.upload(c, pl, planes[k])
+        if bitmap is not None:
+            sysm.set_bitmap(bitmap)
         lm = native.Lightmap(self.ctx, width, height, abi.LIGHTMAP_FLOAT4)
         lm.clear(clear)
         live, pairs, shaded = native.render_particles(sysm, params, lm, want_stats=True)
@@ -68,8 +70,14 @@ def check_case(case, backend):
                                      size_from_z=rp.get("size_from_z", 0.0), z_to_y=rp.get("z_to_y", 0.0), rounded=rp.get("rounded", False),
                                      rounding_power=abi.ClampedBezier1.constant(rp["rounding"]) if "rounding" in rp else None,
                                      viewport_scale=tuple(rp.get("viewport_scale", (1, 1))), viewport_position=tuple(rp.get("viewport_position", (0, 0))),
-                                     blend=abi.BLEND_ADDITIVE if rp.get("additive") else abi.BLEND_ALPHA)
-    image, (live, shaded) = backend.render(chunks, params, w, h, case.get("clear", [0, 0, 0, 0]))
+                                     blend=abi.BLEND_ADDITIVE if rp.get("additive") else abi.BLEND_ALPHA,
+                                     texture_size=(len(case["bitmap"][0]), len(case["bitmap"])) if "bitmap" in case else None,
+                                     offset_px=tuple(rp.get("offset_px", (0, 0))), size_px=tuple(rp["size_px"]) if "size_px" in rp else None,
+                                     relative_size=rp.get("relative_size", True), bilinear=rp.get("bilinear", True),
+                                     animation_rate=tuple(rp.get("animation_rate", (0, 0))),
+                                     column_from_velocity=rp.get("column_from_velocity", False), row_from_velocity=rp.get("row_from_velocity", False))
+    bitmap = np.asarray(case["bitmap"], np.float32) if "bitmap" in case else None
+    image, (live, shaded) = backend.render(chunks, params, w, h, case.get("clear", [0, 0, 0, 0]), bitmap=bitmap)
     assert live == case["live_quads"], case["name"]
     if "shaded_pixels" in case:
         assert shaded == case["shaded_pixels"], case["name"]

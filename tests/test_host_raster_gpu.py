@@ -64,9 +64,20 @@ def test_render_after_updates_matches_oracle(oracle):
     ps.Render(target, abi.BLEND_ADDITIVE, origin, scale, vscale, vpos, False)
     again = target.Download()
     assert (again >= got - 1e-6).all() and (again > got + 1e-3).mean() > 0.3
-    # a textured system is not bound (technique RasterizeParticlesTexture* needs the bitmap's mip chain and Fracture's samplers)
-    ap.TextureSize = [64.0, 64.0]
+    # a textured system: Appearance.Texture (8 x 8 frames of a 32 x 16 sheet), point sampled, frames from life
+    sheet = scenes.uniform(77, (16, 32, 4), 0.0, 1.0)
+    ap.TextureSize = [32.0, 16.0]; ap.SizePx = [8.0, 8.0]; ap.Bilinear = False; ap.AnimationRate = [0.5, 0.0]
     cfg.Appearance = ap
     ps.Configuration = cfg
-    with pytest.raises(RuntimeError):
-        ps.Render(target)
+    with pytest.raises(H.NativeException):
+        ps.Render(target)                              # ILM_ERR_STATE: no bitmap bound yet
+    ps.SetBitmap(sheet)
+    target.Clear(clear)
+    live2, _, shaded2 = ps.Render(target, abi.BLEND_ALPHA, origin, scale, vscale, vpos, True)
+    got2 = target.Download()
+    params2 = abi.RasterizeParams.from_buffer_copy(ps.RasterizeParamsBytes(abi.BLEND_ALPHA, origin, scale, vscale, vpos))
+    assert params2.BitmapFilter == abi.BITMAP_POINT and params2.AnimationRate[0] == 2.0 and params2.SizeFactorAndPosition.x == 4.0
+    want2 = np.zeros((h, w, 4), np.float32); want2[:] = clear
+    want2, (olive2, oshaded2) = oracle.render_particles(chunks, params2, w, h, quad_counts=quads, image=want2, bitmap=sheet)
+    assert live2 == olive2 and abs(shaded2 - oshaded2) <= 8
+    compare_images(got2, want2, "host render, textured", max_outliers=40)

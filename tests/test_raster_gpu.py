@@ -36,12 +36,14 @@ def random_chunks(seed, cs, n_chunks, width, height, size_hi, dead_fraction=0.3)
     return chunks
 
 
-def render_gpu(ctx, chunks, cs, params, width, height, fmt, clear, quad_counts=None):
+def render_gpu(ctx, chunks, cs, params, width, height, fmt, clear, quad_counts=None, bitmap=None):
     eng = native.Engine(ctx, cs, scenes.randomness_table(7))
     sysm = native.System(eng)
     for c, planes in enumerate(chunks):
         sysm.add_chunk()
         sysm.upload(c, P, planes[0]); sysm.upload(c, RCOL, planes[3]); sysm.upload(c, RD, planes[4])
+    if bitmap is not None:
+        sysm.set_bitmap(bitmap)
     lm = native.Lightmap(ctx, width, height, fmt)
     lm.clear(clear)
     stats = native.render_particles(sysm, params, lm, quad_counts=quad_counts, want_stats=True)
@@ -79,6 +81,41 @@ def test_random_sprites_match_oracle(ctx, oracle, rounded, blend):
     compare_images(got, want, "float4 target", max_outliers=8)
     # the picture is not trivial: most pixels were touched, by several sprites
     assert (np.abs(want - np.asarray(clear, np.float32)).max(axis=-1) > 1e-3).mean() > 0.9
+
+
+@pytest.mark.parametrize("bilinear,rate", [(False, (0.4, 0.0)), (True, (-0.7, 1.5)), (True, (0.0, -0.9))])
+def test_textured_sprites_match_oracle(ctx, oracle, bilinear, rate):
+    """Techniques TexturePoint / TextureLinear on a 32 x 16 sheet of 4 x 2 frames: frame column from life (both directions), row from
+    the particle type and from the rotation, RelativeSize, rounded corners on top of the texel."""
+    cs, w, h = 64, 320, 200
+    chunks = random_chunks(150, cs, 2, w, h, size_hi=2.5)
+    for c, planes in enumerate(chunks):
+        planes[4][:, 3] = np.floor(scenes.uniform(400 + c, (cs * cs,), -1.0, 3.0))       # RenderData.w: the type picks the row (clamped)
+    sheet = scenes.uniform(500, (16, 32, 4), 0.0, 1.0)
+    params = scenes.rasterize_params(global_color=(1.0, 0.9, 0.8, 0.9), rounded=True, texture_size=(32, 16), offset_px=(0.0, 0.0), size_px=(8.0, 8.0),
+                                     bilinear=bilinear, animation_rate=rate, column_from_velocity=bilinear, row_from_velocity=not bilinear)
+    got, (live, pairs, shaded) = render_gpu(ctx, chunks, cs, params, w, h, abi.LIGHTMAP_FLOAT4, (0.1, 0.1, 0.1, 1.0), bitmap=sheet)
+    want = np.zeros((h, w, 4), np.float32); want[:] = (0.1, 0.1, 0.1, 1.0)
+    want, (olive, oshaded) = oracle.render_particles(chunks, params, w, h, image=want, bitmap=sheet)
+    assert live == olive and live > 4000 and abs(shaded - oshaded) <= 8
+    # sin / cos (OCML vs libm) also move the texture coordinate of a POINT fetch across a texel edge now and then
+    compare_images(got, want, "textured", max_outliers=40 if not bilinear else 8)
+
+
+def test_textured_technique_needs_a_bitmap(ctx):
+    eng = native.Engine(ctx, 16, scenes.randomness_table(7))
+    sysm = native.System(eng); sysm.add_chunk()
+    lm = native.Lightmap(ctx, 32, 32, abi.LIGHTMAP_FLOAT4)
+    p = scenes.rasterize_params(texture_size=(8, 8))
+    with pytest.raises(native.IlluminantError) as e:
+        native.render_particles(sysm, p, lm)
+    assert e.value.code == abi.ERR_STATE
+    sysm.set_bitmap(np.ones((8, 8, 4), np.float32))
+    native.render_particles(sysm, p, lm)
+    sysm.set_bitmap(None)
+    with pytest.raises(native.IlluminantError):
+        native.render_particles(sysm, p, lm)
+    lm.close(); sysm.close(); eng.close()
 
 
 @pytest.mark.parametrize("fmt,tol", [(abi.LIGHTMAP_HALF4, 2e-3), (abi.LIGHTMAP_RGBA8, 0.5 / 255 + 1e-6)])
