@@ -383,6 +383,35 @@ def main():
                              "kernel": "ilm::sphere_lights_kernel", "bytes_per_unit": SDF_SAMPLE_BYTES,
                              "units_per_launch": samples, "launch_ms": round(kern_ms, 4)},
             }
+            if name.startswith("cfg5"):
+                # cfg5: + 16 M particles over the node = 2 chunks of 1024^2 per GPU stepped in the same frame (cfg2's
+                # transform list without the spawner); particle step and lit frame as two phases and as a whole, one stream
+                Q5 = build_particle_system(H, ctx, scenes, abi, 1024, 2, rank, with_spawner=False)
+                q5, q5tp = Q5["ps"], Q5["tp"]
+                for f5 in range(3):
+                    q5tp.Advance(1.0 / 60.0); q5.Update(f5)
+                barrier()
+                frames5 = max(args.light_frames, 3)
+                ctx.TimerStart()
+                for f5 in range(frames5):
+                    q5tp.Advance(1.0 / 60.0); q5.Update(3 + f5)
+                step5_ms = ctx.TimerStop() / frames5
+                barrier()
+                t5 = time.perf_counter()
+                for f5 in range(frames5):
+                    q5tp.Advance(1.0 / 60.0); q5.Update(3 + frames5 + f5)
+                    r.RenderLighting(1.0, row_begin, row_end, False)
+                    if dist is not None:
+                        ctx.Sync()
+                        sharding.all_gather_rows(full, strips, rank, dist)
+                barrier()
+                whole5 = max_over_ranks(time.perf_counter() - t5) / frames5 * 1e3
+                lighting[name]["with_particles"] = {
+                    "particles_per_gpu": Q5["live"], "particle_step_ms": round(step5_ms, 4),
+                    "particle_step_gb_per_s": round(Q5["live"] * PARTICLE_BYTES_PER_SLOT / (step5_ms * 1e-3) / 1e9, 1),
+                    "frame_ms_step_plus_lighting": round(whole5, 4),
+                    "lit_mpixels_per_s_with_particles": round(w * h / (whole5 * 1e-3) / 1e6, 2)}
+                del Q5, q5
             if rank == 0 and world == 1 and not args.no_cpu_baseline:
                 # the oracle on a bounded band of rows of the same frame (same generated field, same packed lights), on the host cores
                 from oracle import oracle as orc

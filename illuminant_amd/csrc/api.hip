@@ -359,9 +359,10 @@ static float host_noise_shape(float r, float offset, float minimum, float scale)
 }
 
 // StepDerived::NoiseFast for one Noise op (see internal.hpp).  Coordinates a chunk can ask for: x in [0, chunk_size + 1],
-// y in [0, chunk_size] (the second sample pair sits at (x + 2, y + 1)).  false when the fast path does not apply: a wave would span
-// several rows, or the runs of the two sample sets combine into more than three classes along an axis.
-static bool fill_noise_fast(StepDerived& dv, const IlmNoiseParams& p, int chunk_size, const std::vector<float4>& table, int rw, int rh) {
+// y in [0, chunk_size] (the second sample pair sits at (x + 2, y + 1)).  Up to 3 classes per axis the delta tables sit in the
+// NoiseFast block; up to 5 they take the place of the spawn records in `desc` (only when the launch has none).  false when the fast
+// path does not apply: a wave would span several rows, the runs of the two sample sets combine into more classes, or no room.
+static bool fill_noise_fast(StepDerived& dv, IlmStepDesc& desc, const IlmNoiseParams& p, int chunk_size, const std::vector<float4>& table, int rw, int rh) {
     StepDerived::NoiseFast& nf = dv.noise;
     if (chunk_size % 64 != 0 || chunk_size / 64 > 16 || table.empty()) return false;
     int32_t xf[2][2], yf[2][2], tx[2][3], ty[2][3];
@@ -370,31 +371,42 @@ static bool fill_noise_fast(StepDerived& dv, const IlmNoiseParams& p, int chunk_
         if (!noise_axis_runs(dv.inv_rw, off[0], rw, chunk_size + 1, xf[s], tx[s])) return false;
         if (!noise_axis_runs(dv.inv_rh, off[1], rh, chunk_size, yf[s], ty[s])) return false;
     }
-    // classes along an axis = the intervals between the steps of either sample set
-    auto merge = [](const int32_t a[2], const int32_t b[2], int32_t out[2]) {
+    // classes along an axis = the intervals between the steps of either sample set (at most 4 steps)
+    auto merge = [](const int32_t a[2], const int32_t b[2], int32_t out[4]) {
         int32_t all[4] = { a[0], a[1], b[0], b[1] };
         std::sort(all, all + 4);
         const int n = (int)(std::unique(all, all + 4) - all);
         int m = 0;
         for (int i = 0; i < n; i++)
-            if (all[i] != INT32_MAX) { if (m == 2) return false; out[m++] = all[i]; }
-        for (; m < 2; m++) out[m] = INT32_MAX;
-        return true;
+            if (all[i] != INT32_MAX) out[m++] = all[i];
+        const int steps = m;
+        for (; m < 4; m++) out[m] = INT32_MAX;
+        return steps;
     };
-    int32_t xb[2];
-    if (!merge(xf[0], xf[1], xb) || !merge(yf[0], yf[1], nf.yb)) return false;
+    auto class_of = [](const int32_t b[4], int coordinate) {
+        int c = 0;
+        for (int k = 0; k < 4; k++) c += (coordinate >= b[k]) ? 1 : 0;
+        return c;
+    };
+    int32_t xb[4];
+    const int xsteps = merge(xf[0], xf[1], xb), ysteps = merge(yf[0], yf[1], nf.yb);
+    const bool small = (xsteps <= 2) && (ysteps <= 2);
+    if (!small && desc.SpawnCount != 0) return false;        // the big tables need the spawn records' bytes
+    nf.classes = small ? 3 : kNoiseBigClasses;
     for (int w = 0; w < 16; w++) {
         nf.wcode[w] = 0;
         if (w * 64 >= chunk_size) continue;
         const int x0 = w * 64;
         bool usable = true;
-        for (int k = 0; k < 2; k++)
+        for (int k = 0; k < 4; k++)
             if (xb[k] != INT32_MAX && ((xb[k] > x0 && xb[k] <= x0 + 63) || (xb[k] > x0 + 2 && xb[k] <= x0 + 65))) usable = false;
-        nf.wcode[w] = (usable ? 16u : 0u) | (uint32_t)run_of(xb, x0) | ((uint32_t)run_of(xb, x0 + 2) << 2);
+        nf.wcode[w] = (usable ? 64u : 0u) | (uint32_t)class_of(xb, x0) | ((uint32_t)class_of(xb, x0 + 2) << 3);
     }
+    IlmFloat4* big = reinterpret_cast<IlmFloat4*>(&desc.Spawns[0]);
+    const int n = nf.classes;
     // one representative coordinate per class: its first
-    for (int yc = 0; yc < 3; yc++)
-        for (int xc = 0; xc < 3; xc++) {
+    for (int yc = 0; yc < n; yc++)
+        for (int xc = 0; xc < n; xc++) {
             const int x = (xc == 0) ? 0 : xb[xc - 1], y = (yc == 0) ? 0 : nf.yb[yc - 1];
             float4 pd = make_float4(0, 0, 0, 0), vd = pd;
             if (x != INT32_MAX && y != INT32_MAX) {
@@ -411,8 +423,9 @@ static bool fill_noise_fast(StepDerived& dv, const IlmNoiseParams& p, int chunk_
                                  host_noise_shape(host_lerp(a.z, b.z, f), p.VelocityOffset.z, p.VelocityMinimum.z, p.VelocityScale.z),
                                  host_noise_shape(host_lerp(a.w, b.w, f), p.VelocityOffset.w, p.VelocityMinimum.w, p.VelocityScale.w));
             }
-            nf.position[yc][xc] = { pd.x, pd.y, pd.z, pd.w };
-            nf.velocity[yc][xc] = { vd.x, vd.y, vd.z, vd.w };
+            const IlmFloat4 pdv = { pd.x, pd.y, pd.z, pd.w }, vdv = { vd.x, vd.y, vd.z, vd.w };
+            if (small) { nf.position[yc][xc] = pdv; nf.velocity[yc][xc] = vdv; }
+            else { big[yc * n + xc] = pdv; big[n * n + yc * n + xc] = vdv; }
         }
     return true;
 }
@@ -516,7 +529,7 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
         dv.noise.op = -1;
         for (int o = 0; o < d->OpCount && dv.noise.op < 0; o++)
             if (d->Ops[o].Type == ILM_OP_NOISE) {
-                if (fill_noise_fast(dv, d->Ops[o].u.Noise, e->chunk_size, e->h_rnd, e->rw, e->rh)) dv.noise.op = o;
+                if (fill_noise_fast(dv, a.desc, d->Ops[o].u.Noise, e->chunk_size, e->h_rnd, e->rw, e->rh)) dv.noise.op = o;
                 else break;     // only the first Noise op is considered
             }
         for (int o = 0; o < d->OpCount; o++) {

@@ -46,10 +46,12 @@ struct StepDerived {
     // A wave with a step inside it keeps the per-slot lookups.
     struct NoiseFast {
         int32_t op;              // index of the (first) Noise op this describes; -1: none / not applicable (then nothing else is read)
-        int32_t yb[2];           // rows where a sample's texel row steps (INT32_MAX: no such step): y class = #(yb <= row)
-        uint32_t wcode[16];      // per 64-slot column w of a chunk row: bit 4 = usable, bits 0-1 = x class of the (x, y) samples,
-                                 // bits 2-3 = x class of the (x + 2, y + 1) samples
-        IlmFloat4 position[3][3];   // positionDelta [y class of row][x class]
+        int32_t classes;         // classes per axis of the delta tables: 3 (tables below) or 5 (tables in the unused spawn records
+                                 // of the descriptor: chunk sizes above the table size, 807 x 653, step more often; see kNoiseBigTable)
+        int32_t yb[4];           // rows where a sample's texel row steps (INT32_MAX: no such step): y class = #(yb <= row)
+        uint32_t wcode[16];      // per 64-slot column w of a chunk row: bit 6 = usable, bits 0-2 = x class of the (x, y) samples,
+                                 // bits 3-5 = x class of the (x + 2, y + 1) samples
+        IlmFloat4 position[3][3];   // positionDelta [y class of row][x class]          (classes == 3)
         IlmFloat4 velocity[3][3];   // velocityDelta [y class of row + 1][x class]
     } noise;
     struct Op {
@@ -59,6 +61,11 @@ struct StepDerived {
         int32_t _pad;
     } op[ILM_MAX_OPS];
 };
+
+// With 5 classes per axis the two delta tables are 2 x 25 float4 = 800 bytes: more than the kernarg block has left, but a launch
+// without spawn records does not use desc.Spawns (2 x 544 bytes), so they live there: positionDelta[5][5] then velocityDelta[5][5].
+constexpr int kNoiseBigClasses = 5;
+static_assert(sizeof(IlmSpawnRecord) * ILM_MAX_SPAWNS >= 2 * kNoiseBigClasses * kNoiseBigClasses * sizeof(IlmFloat4), "noise tables fit the spawn records");
 
 constexpr int kMaxPartialChunks = 4;
 struct StepLaunch {

@@ -180,14 +180,25 @@ ILM_DEV void apply_noise(float4& pos, float4& vel, float x, float y, const float
 
 // The wave-uniform form of the four lookups (StepDerived::NoiseFast): (x0, row) = slot coordinates of the wave's first lane, the wave
 // covers x0 .. x0 + 63 of that row (chunk size a multiple of 64).  Scalar integer code only; the deltas arrive in SGPRs.
-ILM_DEV NoiseDeltas noise_prepare(const StepDerived::NoiseFast& nf, int x0, int row) {
+ILM_DEV NoiseDeltas noise_prepare(const StepDerived::NoiseFast& nf, const IlmStepDesc& desc, int x0, int row) {
     NoiseDeltas out;
     const uint32_t code = nf.wcode[x0 >> 6];
-    out.valid = (code & 16u) != 0u;
-    const int yc0 = ((row >= nf.yb[0]) ? 1 : 0) + ((row >= nf.yb[1]) ? 1 : 0);
-    const int yc1 = ((row + 1 >= nf.yb[0]) ? 1 : 0) + ((row + 1 >= nf.yb[1]) ? 1 : 0);
-    out.position = ld4(nf.position[yc0][code & 3u]);
-    out.velocity = ld4(nf.velocity[yc1][(code >> 2) & 3u]);
+    out.valid = (code & 64u) != 0u;
+    int yc0 = 0, yc1 = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        yc0 += (row >= nf.yb[k]) ? 1 : 0;
+        yc1 += (row + 1 >= nf.yb[k]) ? 1 : 0;
+    }
+    const int xc0 = (int)(code & 7u), xc1 = (int)((code >> 3) & 7u);
+    if (nf.classes == kNoiseBigClasses) {
+        const IlmFloat4* table = reinterpret_cast<const IlmFloat4*>(&desc.Spawns[0]);
+        out.position = ld4(table[yc0 * kNoiseBigClasses + xc0]);
+        out.velocity = ld4(table[kNoiseBigClasses * kNoiseBigClasses + yc1 * kNoiseBigClasses + xc1]);
+    } else {
+        out.position = ld4(nf.position[yc0][xc0]);
+        out.velocity = ld4(nf.velocity[yc1][xc1]);
+    }
     return out;
 }
 
@@ -1029,7 +1040,7 @@ __global__ __launch_bounds__(kStepThreads, MINW) void step_kernel(const StepLaun
                 // first slot of the unit -> (x0, y): scalar; the unit lies in one row (chunk size a multiple of 64)
                 const int first = (seg + j) * 64;
                 const int row = (a.derived.cs_shift >= 0) ? (first >> a.derived.cs_shift) : (first / a.chunk_size);
-                noise = noise_prepare(((const StepLaunch*)ap)->derived.noise, first - row * a.chunk_size, row);
+                noise = noise_prepare(((const StepLaunch*)ap)->derived.noise, ((const StepLaunch*)ap)->desc, first - row * a.chunk_size, row);
             }
             const bool live_after = process_unit<FMT, DF, SPAWN, EXT, STREAM>(ap, ub + j * 64, chunk, (seg + j) * 64 + (int)lane, lane, seg + j, cur, noise);
             n_live += (uint32_t)__popcll(__ballot(live_after));
