@@ -1,0 +1,109 @@
+"""Randomised parity sweep (not part of the test suite): many small lighting scenes and particle steps with fresh seeds, HIP path vs the
+CPU oracle; reports every scene whose integer statistics or liveness differ and the largest float error seen.
+    python tools/fuzz_parity.py [first_seed] [count]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from illuminant_amd import abi, native, scenes
+from oracle import oracle
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+ctx = native.Context(0)
+P, V, A, RC, RD = abi.PLANE_POSITION, abi.PLANE_VELOCITY, abi.PLANE_ATTRIBUTES, abi.PLANE_RENDER_COLOR, abi.PLANE_RENDER_DATA
+
+
+def rel_err(got, want):
+    got = np.asarray(got, np.float64); want = np.asarray(want, np.float64)
+    ok = np.isfinite(want) & np.isfinite(got)
+    if not ok.any():
+        return 0.0
+    scale = max(1.0, float(np.abs(want[ok]).max()))
+    return float((np.abs(got[ok] - want[ok]) / np.maximum(np.abs(want[ok]), 1e-4 * scale * 1e4 * 1e-4 + 1e-30 + 1e-4 * scale)).max())
+
+
+bad_light, bad_step, worst_l, worst_s = [], [], 0.0, 0.0
+worst_where = None
+for seed in range(first, first + count):
+    rng = np.random.default_rng(seed)
+    # ---- lighting: random field, lights, G-buffer normals, both SDF formats -------------------------------------------
+    w, h = int(rng.integers(33, 130)), int(rng.integers(17, 90))
+    fmt = abi.SDF_FP16 if seed % 2 else abi.SDF_UNORM16
+    layout = scenes.DistanceFieldLayout(256, 192, 96.0, int(rng.integers(3, 14)), 0.5, 128)
+    obstacles = scenes.random_obstacles(seed, int(rng.integers(1, 16)), (256, 192), size_lo=6.0, size_hi=34.0, z_hi=50.0)
+    atlas = scenes.build_sdf_atlas(layout, obstacles, fmt=fmt)
+    dfu = layout.uniforms(max_cone_radius=float(rng.uniform(4, 30)), power=float(rng.choice([0.5, 0.7, 1.0, 1.6])), step_limit=int(rng.integers(8, 80)),
+                          min_step_size=float(rng.uniform(0.5, 3.0)), long_step_factor=float(rng.uniform(0.3, 1.0)))
+    lights = scenes.random_lights(seed + 7, int(rng.integers(1, 20)), w, h, z=(2.0, 60.0), radius=float(rng.uniform(2, 30)), ramp=(20.0, 160.0))
+    env = scenes.environment()
+    sdf = native.DistanceFieldTexture(ctx, atlas, fmt)
+    lm = native.Lightmap(ctx, w, h, abi.LIGHTMAP_FLOAT4)
+    st = native.render_sphere_lights(ctx, lights, env, dfu, None, sdf, (0.05, 0.05, 0.05, 1.0), lm, want_stats=True)
+    got = lm.download()
+    want, ost = oracle.render_sphere_lights(lights, env, dfu, None, oracle.make_texture(atlas, fmt), (0.05, 0.05, 0.05, 1.0), w, h, 0, h, want_stats=True)
+    lm.close(); sdf.close()
+    e = float((np.abs(got - want) / np.maximum(np.abs(want), 1.0)).max())
+    worst_l = max(worst_l, e)
+    if (st.SdfSamples, st.PixelLightPairs, st.TracedPairs) != (ost.SdfSamples, ost.PixelLightPairs, ost.TracedPairs) or e > 1e-4:
+        bad_light.append((seed, (st.SdfSamples, st.PixelLightPairs, st.TracedPairs), (ost.SdfSamples, ost.PixelLightPairs, ost.TracedPairs), e))
+    # ---- particles: random op list, spawner, chunk size ---------------------------------------------------------------
+    cs = int(rng.choice([16, 48, 64, 128]))
+    n = cs * cs
+    rnd = scenes.randomness_table(seed % 5 + 1)
+    eng = native.Engine(ctx, cs, rnd); sysm = native.System(eng)
+    chunks = []
+    for c in range(2):
+        sysm.add_chunk()
+        pos, vel, attr = scenes.make_particles(seed * 3 + c, n, dead_fraction=float(rng.uniform(0, 0.8)), life=(0.01, 3.0))
+        for pl, a in ((P, pos), (V, vel), (A, attr)):
+            sysm.upload(c, pl, a)
+        chunks.append([pos.copy(), vel.copy(), attr.copy(), np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)])
+    d = abi.StepDesc(); d.FirstChunk, d.ChunkCount = 0, -1
+    d.System = scenes.system_uniforms(cs, friction=float(rng.uniform(0, 0.5)), max_velocity=float(rng.uniform(50, 3000)), life_decay=float(rng.uniform(0, 5)))
+    d.Update = abi.UpdateParams.default(); d.UpdateMode = abi.UPDATE_POSITIONS
+    k = 0
+    if rng.random() < 0.8:
+        att = [((float(rng.uniform(0, 256)), float(rng.uniform(0, 256)), float(rng.uniform(0, 32))), float(rng.uniform(10, 300)), float(rng.uniform(-500, 1500)),
+                int(rng.integers(0, 3))) for _ in range(int(rng.integers(1, 17)))]
+        d.Ops[k].Type = abi.OP_GRAVITY; d.Ops[k].u.Gravity = scenes.gravity_params(att, float(rng.uniform(1, 2000))); k += 1
+    if rng.random() < 0.8:
+        d.Ops[k].Type = abi.OP_NOISE
+        d.Ops[k].u.Noise = scenes.noise_params(scenes.area_none(), (float(rng.uniform(0, 253)), float(rng.uniform(0, 127))),
+                                               (float(rng.uniform(0, 253)), float(rng.uniform(0, 127))), float(rng.uniform(0, 1)),
+                                               replace_old_velocity=bool(rng.integers(0, 2)),
+                                               position=((-0.5,) * 4, (0.05,) * 4, (2.0, 2.0, 1.0, 0.0)), velocity=((-0.5,) * 3, (0.01,) * 3, (40.0, 40.0, 10.0)),
+                                               speed=(-0.5, 0.0, 3.0)); k += 1
+    d.OpCount = k
+    if rng.random() < 0.6:
+        first_slot = int(rng.integers(0, n - 40)); last = int(min(n - 1, first_slot + rng.integers(1, 600)))
+        d.SpawnCount = 1; d.Spawns[0].ChunkIndex = 1
+        d.Spawns[0].Params = scenes.spawn_params(cs, first_slot, last, int(rng.integers(0, 5000)), (float(rng.uniform(0, 253)), float(rng.uniform(0, 127))),
+                                                 position=((128, 128, 4), (90, 60, 4), (0, 0, 0), int(rng.choice([0, 1, 3]))),
+                                                 velocity=((0, 0, 0), (60, 60, 10), (0, 0, 0), int(rng.choice([0, 1, 2]))), life=(2.0, 2.0, 0.0))
+    d.Flags = abi.STEP_COUNT_LIVE
+    sysm.step(d)
+    want_counts = oracle.step(chunks, cs, rnd, d, want_counts=True)
+    got_counts = sysm.step_counts()
+    problem = not np.array_equal(got_counts, want_counts)
+    for c in range(2):
+        gp = sysm.download(c, P)
+        problem = problem or not np.array_equal(gp[:, 3] > 0, chunks[c][0][:, 3] > 0)
+        for kk, pl in enumerate((P, V, A, RC, RD)):
+            g = sysm.download(c, pl).astype(np.float64); wv = chunks[c][kk].astype(np.float64)
+            ok = np.isfinite(wv) & np.isfinite(g)
+            if ok.any():
+                scale = max(1.0, float(np.abs(wv[ok]).max()))
+                r = np.where(ok, np.abs(g - wv) / (np.abs(wv) + 1e-4 * scale), 0.0)
+                if float(r.max()) > worst_s:
+                    worst_s = float(r.max())
+                    i, j = np.unravel_index(int(np.argmax(r)), r.shape)
+                    worst_where = (seed, c, kk, int(i), int(j), float(g[i, j]), float(wv[i, j]), scale, cs, k, int(d.SpawnCount))
+    if problem:
+        bad_step.append((seed, list(got_counts), list(want_counts)))
+    sysm.close(); eng.close()
+print("seeds %d..%d" % (first, first + count - 1))
+print("lighting: %d scenes with differing statistics or > 1e-4 error; worst relative error %.3g" % (len(bad_light), worst_l))
+for b in bad_light[:10]: print("   ", b)
+print("particles: %d steps with differing live counts / liveness; worst error relative to (|want| + 1e-4 scale) %.3g" % (len(bad_step), worst_s))
+for b in bad_step[:10]: print("   ", b)
+print("worst particle element (seed, chunk, plane, slot, component, got, want, plane scale, chunk size, ops, spawns):", worst_where)
