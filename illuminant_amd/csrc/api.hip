@@ -58,6 +58,7 @@ enum : uint32_t {
 struct Ctx {
     uint32_t magic = kMagicCtx;
     int device = 0;
+    int children = 0;            // live engines / distance fields / G-buffers / lightmaps: the context cannot be destroyed under them
     hipStream_t stream = nullptr;
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // Liveness counts leave through their own stream, so the device-to-host copy (a separate blit kernel on ROCm)
@@ -89,6 +90,7 @@ struct Ctx {
 struct Engine {
     uint32_t magic = kMagicEngine;
     Ctx* ctx = nullptr;
+    int children = 0;            // live systems: the engine cannot be destroyed under them
     int chunk_size = 0, slots = 0;
     int64_t stride = 0;
     float4* rnd = nullptr; int rw = 0, rh = 0;
@@ -127,7 +129,7 @@ struct System {
     // accumulates into one and zeroes the other for next time: no memset launch), 2 belongs to ilm_system_live_counts.
     uint32_t* d_counts = nullptr; int counts_cap = 0; int count_parity = 0;
     uint32_t* counts_region(int r) const { return d_counts + (size_t)r * (size_t)counts_cap * kCountStride; }
-    Sdf* sdf = nullptr;
+    IlmHandle sdf_handle = 0;   // bound distance field: resolved through the handle table at every use (it may have been destroyed)
     float4* ramp = nullptr; int ramp_w = 0, ramp_h = 0;
     uint32_t* d_slots = nullptr; int slots_cap = 0; uint32_t* d_slot_count = nullptr;
     // the Spawner's PositionBuffer per spawn record slot (ParticleSpawner.cs:301-353)
@@ -304,7 +306,7 @@ int32_t validate_step(const System* s, const IlmStepDesc* d, int* first, int* co
             return fail(ILM_ERR_OUT_OF_RANGE, "PositionConstantCount %g outside [1, %d]", (double)r.Params.PositionConstantCount,
                         ILM_MAX_INLINE_POSITION_CONSTANTS);
     }
-    if (d->UpdateMode == ILM_UPDATE_WITH_DISTANCE_FIELD && s->sdf == nullptr)
+    if (d->UpdateMode == ILM_UPDATE_WITH_DISTANCE_FIELD && from_handle<Sdf>(s->sdf_handle, kMagicSdf) == nullptr)
         // ParticleSystem.cs:835-836
         return fail(ILM_ERR_STATE, "UpdateWithDistanceField requires a distance field (ilm_system_set_distance_field)");
     int f = d->FirstChunk, c = d->ChunkCount;
@@ -512,7 +514,7 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
             a.source_base[k] = from_handle<System>(d->Spawns[k].Feedback.SourceSystem, kMagicSystem)->chunks[(size_t)d->Spawns[k].Feedback.SourceChunkIndex];
     }
     a.ramp = s->ramp; a.ramp_w = s->ramp_w; a.ramp_h = s->ramp_h;
-    a.sdf = make_sdf_view(s->sdf);
+    a.sdf = make_sdf_view(from_handle<Sdf>(s->sdf_handle, kMagicSdf));
     a.live_counts = counting ? s->counts_region(region) : nullptr;
     a.zero_counts = counting ? s->counts_region(region ^ 1) : nullptr;
     a.zero_n = counting ? (int32_t)s->counts_cap : 0;   // every entry, so chunk-table growth after a shrink never meets stale counts
@@ -663,6 +665,8 @@ int32_t ilm_ctx_create(int32_t device_id, IlmHandle* out_ctx) {
 int32_t ilm_ctx_destroy(IlmHandle h) {
     Ctx* c = from_handle<Ctx>(h, kMagicCtx);
     if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
+    if (c->children > 0)
+        return fail(ILM_ERR_STATE, "%d object(s) of this context are still alive: destroy engines, fields, G-buffers and lightmaps first", c->children);
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     if (c->staging) (void)hipFree(c->staging);
@@ -741,6 +745,7 @@ int32_t ilm_engine_create(IlmHandle hctx, int32_t chunk_size, const IlmFloat4* r
     Engine* e = new (std::nothrow) Engine();
     if (!e) return fail(ILM_ERR_INVALID_ARGUMENT, "out of host memory");
     e->ctx = c;
+    c->children++;
     e->chunk_size = chunk_size;
     e->slots = chunk_size * chunk_size;
     e->stride = ((int64_t)e->slots + kSlotsPerBlock - 1) / kSlotsPerBlock * kSlotsPerBlock;
@@ -765,6 +770,8 @@ int32_t ilm_engine_create(IlmHandle hctx, int32_t chunk_size, const IlmFloat4* r
 int32_t ilm_engine_destroy(IlmHandle h) {
     Engine* e = from_handle<Engine>(h, kMagicEngine);
     if (!e) return fail(ILM_ERR_INVALID_HANDLE, "not an engine handle");
+    if (e->children > 0) return fail(ILM_ERR_STATE, "%d system(s) of this engine are still alive", e->children);
+    e->ctx->children--;
     (void)hipSetDevice(e->ctx->device);
     (void)hipStreamSynchronize(e->ctx->stream);
     if (e->rnd) (void)hipFree(e->rnd);
@@ -781,6 +788,7 @@ int32_t ilm_system_create(IlmHandle hengine, IlmHandle* out) {
     System* s = new (std::nothrow) System();
     if (!s) return fail(ILM_ERR_INVALID_ARGUMENT, "out of host memory");
     s->engine = e;
+    e->children++;
     *out = to_handle(s);
     return ILM_OK;
 }
@@ -789,6 +797,7 @@ int32_t ilm_system_destroy(IlmHandle h) {
     System* s = from_handle<System>(h, kMagicSystem);
     if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
     Ctx* c = s->engine->ctx;
+    s->engine->children--;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     for (float* p : s->chunks) (void)hipFree(p);
@@ -908,11 +917,11 @@ int32_t ilm_chunk_device_ptr(IlmHandle h, int32_t chunk, int32_t component, void
 int32_t ilm_system_set_distance_field(IlmHandle h, IlmHandle hsdf) {
     System* s = from_handle<System>(h, kMagicSystem);
     if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
-    if (hsdf == 0) { s->sdf = nullptr; return ILM_OK; }
+    if (hsdf == 0) { s->sdf_handle = 0; return ILM_OK; }
     Sdf* f = from_handle<Sdf>(hsdf, kMagicSdf);
     if (!f) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle");
     if (f->ctx != s->engine->ctx) return fail(ILM_ERR_INVALID_ARGUMENT, "distance field belongs to another context");
-    s->sdf = f;
+    s->sdf_handle = hsdf;
     return ILM_OK;
 }
 
@@ -1173,6 +1182,7 @@ int32_t ilm_sdf_create(IlmHandle hctx, int32_t w, int32_t ht, int32_t format, Il
     Sdf* f = new (std::nothrow) Sdf();
     if (!f) return fail(ILM_ERR_INVALID_ARGUMENT, "out of host memory");
     f->ctx = c; f->width = w; f->height = ht; f->format = format;
+    c->children++;
     const IlmHandle h = to_handle(f);
     HIP_TRY_OR_DESTROY(hipMalloc(reinterpret_cast<void**>(&f->texels), sizeof(uint2) * (size_t)w * (size_t)ht), ilm_sdf_destroy(h));
     HIP_TRY_OR_DESTROY(hipMemsetAsync(f->texels, 0, sizeof(uint2) * (size_t)w * (size_t)ht, c->stream), ilm_sdf_destroy(h));
@@ -1212,6 +1222,7 @@ int32_t ilm_sdf_sample(IlmHandle h, const IlmDistanceFieldUniforms* df, const fl
 int32_t ilm_sdf_destroy(IlmHandle h) {
     Sdf* f = from_handle<Sdf>(h, kMagicSdf);
     if (!f) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle");
+    f->ctx->children--;
     (void)hipSetDevice(f->ctx->device);
     (void)hipStreamSynchronize(f->ctx->stream);
     if (f->texels) (void)hipFree(f->texels);
@@ -1375,6 +1386,7 @@ int32_t ilm_gbuffer_create(IlmHandle hctx, int32_t w, int32_t ht, int32_t format
     GBuffer* g = new (std::nothrow) GBuffer();
     if (!g) return fail(ILM_ERR_INVALID_ARGUMENT, "out of host memory");
     g->ctx = c; g->width = w; g->height = ht; g->format = format;
+    c->children++;
     const size_t bytes = (format == ILM_GBUFFER_FLOAT4 ? 16u : 8u) * (size_t)w * (size_t)ht;
     const IlmHandle h = to_handle(g);
     HIP_TRY_OR_DESTROY(hipMalloc(&g->texels, bytes), ilm_gbuffer_destroy(h));
@@ -1468,6 +1480,7 @@ int32_t ilm_gbuffer_render(IlmHandle h, const IlmGBufferRenderDesc* d, const Ilm
 int32_t ilm_gbuffer_destroy(IlmHandle h) {
     GBuffer* g = from_handle<GBuffer>(h, kMagicGBuffer);
     if (!g) return fail(ILM_ERR_INVALID_HANDLE, "not a G-buffer handle");
+    g->ctx->children--;
     (void)hipSetDevice(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->stream);
     if (g->texels) (void)hipFree(g->texels);
@@ -1487,6 +1500,7 @@ int32_t ilm_lightmap_create(IlmHandle hctx, int32_t w, int32_t ht, int32_t forma
     Lightmap* m = new (std::nothrow) Lightmap();
     if (!m) return fail(ILM_ERR_INVALID_ARGUMENT, "out of host memory");
     m->ctx = c; m->width = w; m->height = ht; m->format = format;
+    c->children++;
     const IlmHandle h = to_handle(m);
     if (external) {
         m->texels = external;
@@ -1524,6 +1538,7 @@ int32_t ilm_lightmap_device_ptr(IlmHandle h, void** out_ptr) {
 int32_t ilm_lightmap_destroy(IlmHandle h) {
     Lightmap* m = from_handle<Lightmap>(h, kMagicLightmap);
     if (!m) return fail(ILM_ERR_INVALID_HANDLE, "not a lightmap handle");
+    m->ctx->children--;
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     if (m->texels && !m->external) (void)hipFree(m->texels);

@@ -42,7 +42,8 @@ extern "C" {
 
 /* Opaque object handles (contexts, engines, systems, textures).  Every entry point looks its handles up in a table of live
  * objects first: a destroyed, foreign or garbage value returns ILM_ERR_INVALID_HANDLE, it is never dereferenced.  0 is never
- * a valid handle.  A create call that fails releases everything it had allocated and leaves *out = 0. */
+ * a valid handle.  A create call that fails releases everything it had allocated and leaves *out = 0.  Parents outlive children:
+ * destroying a context (engine) that still has live objects (systems) returns ILM_ERR_STATE and destroys nothing. */
 typedef uint64_t IlmHandle;
 
 /* ---- POD mirrors of the reference's uniform structs -------------------- */

@@ -196,6 +196,28 @@ def test_invalid_handles_and_arguments_are_reported(ctx):
         sysm.upload(0, P, np.zeros((16 * 16 + 1, 4), np.float32))       # more slots than the chunk has
     with pytest.raises(native.IlluminantError):
         native.Engine(ctx, 0, scenes.randomness_table(7))
+    # parents outlive children: nothing is destroyed under a live object
+    assert lib.ilm_engine_destroy(eng.handle) == abi.ERR_STATE
+    assert lib.ilm_ctx_destroy(ctx.handle) == abi.ERR_STATE
+    h_sys = abi.Handle(sysm.handle.value)
     sysm.close(); eng.close()
     # a destroyed handle is dead
-    assert lib.ilm_system_step(sysm.handle, None) == abi.ERR_INVALID_HANDLE
+    assert lib.ilm_system_step(h_sys, None) == abi.ERR_INVALID_HANDLE
+
+
+def test_bound_distance_field_may_be_destroyed_first(ctx):
+    """The system keeps the field's handle, not its address: stepping with a destroyed field is an error, not a crash."""
+    from tests.test_particles_gpu import cfg1_field
+    eng = native.Engine(ctx, 16, scenes.randomness_table(7))
+    sysm = native.System(eng); sysm.add_chunk()
+    layout, atlas, dfu = cfg1_field()
+    sdf = native.DistanceFieldTexture(ctx, atlas, abi.SDF_UNORM16)
+    sysm.set_distance_field(sdf)
+    d = plain_desc(16, abi.UPDATE_WITH_DISTANCE_FIELD)
+    d.DistanceField = dfu
+    sysm.step(d)
+    sdf.close()
+    with pytest.raises(native.IlluminantError) as e:
+        sysm.step(d)
+    assert e.value.code == abi.ERR_STATE
+    sysm.close(); eng.close()
