@@ -75,6 +75,7 @@ struct Ctx {
     // particle lights: records compacted on the device + their count, block counts, per-chunk quad counts
     void* d_pl_recs = nullptr; int pl_cap = 0; int32_t* d_pl_count = nullptr; int32_t* d_pl_blocks = nullptr; int pl_blocks_cap = 0;
     int32_t* d_pl_quads = nullptr; int pl_quads_cap = 0;
+    float4* d_light_ramp = nullptr; int light_ramp_w = 0, light_ramp_h = 0;    // RampTexture of the light group being rendered
     RasterScratch raster;                                         // particle rasteriser buffers (raster.hip)
     int32_t* d_raster_quads = nullptr; int raster_quads_cap = 0;
     // particle read-back: draw-call records, total, block counts, per-chunk element counts
@@ -683,6 +684,7 @@ int32_t ilm_ctx_destroy(IlmHandle h) {
     if (c->d_pl_blocks) (void)hipFree(c->d_pl_blocks);
     if (c->d_pl_quads) (void)hipFree(c->d_pl_quads);
     free_raster_scratch(c->raster);
+    if (c->d_light_ramp) (void)hipFree(c->d_light_ramp);
     if (c->d_raster_quads) (void)hipFree(c->d_raster_quads);
     if (c->d_probes) (void)hipFree(c->d_probes);
     if (c->d_rb) (void)hipFree(c->d_rb);
@@ -1578,6 +1580,7 @@ int32_t fill_light_launch(Ctx* c, const IlmEnvironment* env, const IlmDistanceFi
     a->lightmap = m->texels; a->width = m->width; a->height = m->height; a->format = m->format;
     a->row_begin = row_begin; a->row_end = row_end;
     a->stats = nullptr; a->light_count_ptr = nullptr; a->accumulate = 0;
+    a->ramp = RampView{ nullptr, 0, 0 };      // particle lights have no ramp technique (LightingRenderer.cs:176-178)
     a->tile_map = light_tile_map();
     return ILM_OK;
 }
@@ -1711,7 +1714,8 @@ int32_t ilm_render_light_probes(IlmHandle hctx, const IlmLightVertex* lights, in
     if (rc != ILM_OK) return rc;
     rc = upload_small(c, d_nrm, probe_normals, sizeof(float4) * (size_t)probe_count);
     if (rc != ILM_OK) return rc;
-    HIP_TRY(launch_light_probes(c->d_recs, light_count, d_pos, d_nrm, probe_count, *env, *df, make_sdf_view(f), d_val, c->stream));
+    HIP_TRY(launch_light_probes(c->d_recs, light_count, d_pos, d_nrm, probe_count, *env, *df, make_sdf_view(f),
+                                RampView{ c->d_light_ramp, c->light_ramp_w, c->light_ramp_h }, d_val, c->stream));
     HIP_TRY(hipMemcpyAsync(out_values, d_val, sizeof(float4) * (size_t)probe_count, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return ILM_OK;
@@ -1850,6 +1854,26 @@ int32_t ilm_system_set_bitmap(IlmHandle h, const IlmFloat4* texels, int32_t widt
     return ILM_OK;
 }
 
+int32_t ilm_ctx_set_light_ramp(IlmHandle hctx, const IlmFloat4* texels, int32_t width, int32_t height) {
+    Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);
+    if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
+    if (width < 0 || height < 0 || width > 16384 || height > 16384 || ((width > 0) != (height > 0)) || (width > 0 && !texels))
+        return fail(ILM_ERR_INVALID_ARGUMENT, "bad ramp texture (%d x %d)", width, height);
+    const bool none = (width == 0) || (width == 1 && height == 1);
+    if (none && !c->d_light_ramp) return ILM_OK;  // nothing bound, nothing to unbind: no synchronisation
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->stream));     // an earlier pass may still read the old ramp
+    if (c->d_light_ramp) HIP_TRY(hipFree(c->d_light_ramp));
+    c->d_light_ramp = nullptr; c->light_ramp_w = c->light_ramp_h = 0;
+    // a 1 x 1 ramp is no ramp (LightingRenderer.cs:822-827)
+    if (width == 0 || (width == 1 && height == 1)) return ILM_OK;
+    const size_t bytes = sizeof(float4) * (size_t)width * (size_t)height;
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_light_ramp), bytes));
+    HIP_TRY(hipMemcpy(c->d_light_ramp, texels, bytes, hipMemcpyHostToDevice));
+    c->light_ramp_w = width; c->light_ramp_h = height;
+    return ILM_OK;
+}
+
 int32_t ilm_lightmap_clear(IlmHandle h, const float rgba[4]) {
     Lightmap* m = from_handle<Lightmap>(h, kMagicLightmap);
     if (!m) return fail(ILM_ERR_INVALID_HANDLE, "not a lightmap handle");
@@ -1976,7 +2000,7 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
     GBuffer* g = nullptr; Sdf* f = nullptr;
     if (hgbuffer) { g = from_handle<GBuffer>(hgbuffer, kMagicGBuffer); if (!g) return fail(ILM_ERR_INVALID_HANDLE, "not a G-buffer handle"); }
     if (hsdf) { f = from_handle<Sdf>(hsdf, kMagicSdf); if (!f) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle"); }
-    if (!env || !df || !ambient) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (!env || !df) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
     if (light_count < 0 || (light_count > 0 && !lights)) return fail(ILM_ERR_INVALID_ARGUMENT, "bad light array");
     if (light_count > 65535) return fail(ILM_ERR_TOO_MANY, "at most 65535 lights per call");
     if (m->ctx != c || (g && g->ctx != c) || (f && f->ctx != c)) return fail(ILM_ERR_INVALID_ARGUMENT, "resources belong to another context");
@@ -2008,10 +2032,12 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
     a.gbuffer.texels = g ? g->texels : nullptr;
     a.gbuffer.width = g ? g->width : 0; a.gbuffer.height = g ? g->height : 0; a.gbuffer.format = g ? g->format : 0;
     a.sdf = make_sdf_view(f);
-    for (int i = 0; i < 4; i++) a.ambient[i] = ambient[i];
+    for (int i = 0; i < 4; i++) a.ambient[i] = ambient ? ambient[i] : 0.0f;
     a.lightmap = m->texels; a.width = m->width; a.height = m->height; a.format = m->format;
     a.row_begin = row_begin; a.row_end = row_end;
-    a.stats = nullptr; a.light_count_ptr = nullptr; a.accumulate = 0;
+    a.stats = nullptr; a.light_count_ptr = nullptr;
+    a.accumulate = ambient ? 0 : 1;          // a further light group of the frame: added to what the lightmap holds
+    a.ramp = RampView{ c->d_light_ramp, c->light_ramp_w, c->light_ramp_h };
     a.tile_map = light_tile_map();
     if (stats) {
         HIP_TRY(hipMemsetAsync(c->d_stats, 0, 3 * sizeof(unsigned long long), c->stream));

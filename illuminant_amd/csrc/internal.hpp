@@ -120,6 +120,9 @@ struct GBufferView {
     int32_t width, height, format;
 };
 
+// RampTexture of the light group being rendered (technique SphereLightWithDistanceRamp, RampCommon.fxh); texels == nullptr => none
+struct RampView { const float4* texels; int32_t width, height; };
+
 struct LightLaunch {
     const IlmLightVertex* lights;   // device
     int32_t light_count;
@@ -134,6 +137,7 @@ struct LightLaunch {
     const int32_t* light_count_ptr; // device: when non-null the record count is read from here (particle lights are counted on the device)
     int32_t tile_map;               // block -> tile mapping: 0 contiguous band per XCD, 1 tile rows round-robin over the XCDs, 2 identity
     int32_t accumulate;             // != 0: start from the lightmap's contents instead of `ambient` (additive blend onto an earlier pass)
+    RampView ramp;
 };
 
 constexpr size_t kLightRecBytes = 128;   // sizeof(LightRec) in lighting.hip
@@ -156,7 +160,8 @@ struct ParticleLightLaunch {
 hipError_t launch_prepare_particle_lights(const ParticleLightLaunch& a, hipStream_t stream);
 // Light probes (SphereLightProbe.fx): every prepared light record on every probe; values = float4 per probe (device)
 hipError_t launch_light_probes(const void* recs, int light_count, const float4* probe_positions, const float4* probe_normals, int probe_count,
-                               const IlmEnvironment& env, const IlmDistanceFieldUniforms& df, const SdfView& sdf, float4* values, hipStream_t stream);
+                               const IlmEnvironment& env, const IlmDistanceFieldUniforms& df, const SdfView& sdf, const RampView& ramp, float4* values,
+                               hipStream_t stream);
 // sampleDistanceFieldEx at `count` positions (xyz triples) -- diagnostic entry point ilm_sdf_sample
 hipError_t launch_sdf_sample(const SdfView& sdf, const IlmDistanceFieldUniforms& df, const float* positions, int count, float* out, hipStream_t stream);
 

@@ -26,7 +26,7 @@ struct LightRec {
     float spec_r, spec_g, spec_b, shadow_falloff;
     float fx0, fx1, fx2, fx3;                   // raster footprint (screen px), see light_covers
     float fy0, fy1, fy2, fy3;
-    float cfg_x, cfg_y, _pad0, _pad1;           // createTraceConfig: maxRadius, radiusGrowthPerPixel
+    float cfg_x, cfg_y, ramp_offset, ramp_rate; // createTraceConfig: maxRadius, radiusGrowthPerPixel; EvenMoreLightProperties.zw
 };
 static_assert(sizeof(LightRec) == 128, "LightRec is one 128-byte record");
 
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(64) void prepare_lights_kernel(const IlmLightVertex
     const float max_radius = clampf(r.radius, 0.33f, max_cone_radius);
     r.cfg_x = max_radius;
     r.cfg_y = max_radius / fmaxf(r.ramp, 16.0f) * 1.0f;  // getConeGrowthFactor() == 1 (DistanceFieldCommon.fxh:233-236)
-    r._pad0 = r._pad1 = 0.0f;
+    r.ramp_offset = L.EvenMoreLightProperties.z; r.ramp_rate = L.EvenMoreLightProperties.w;
     out[i] = r;
 }
 
@@ -165,7 +165,7 @@ struct LightStats { unsigned long long samples = 0, pairs = 0, traced = 0; };
 // discards (nothing is blended); otherwise the light's rgb contribution in (out_r, out_g, out_b).
 template <int FMT, bool STATS>
 ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment& env, const IlmDistanceFieldUniforms& df, const SdfView& sdf,
-                         bool have_sdf, LightStats& st, float& out_r, float& out_g, float& out_b) {
+                         bool have_sdf, const RampView& ramp, LightStats& st, float& out_r, float& out_g, float& out_b) {
     // checkShadowFilter, LightCommon.fxh:146-152
     const bool filtered = (L.shadow_filter < 0.0f) ? false : ((L.shadow_filter > 0.5f) != P.enable_shadows);
     if (P.fullbright || filtered)
@@ -228,7 +228,27 @@ ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment
         const float visibility = fminf(data_z, steps_remaining / 2.0f);               // MAX_STEP_RAMP_WINDOW
         cone_opacity = pow_pos(sat(sat(visibility - 0.075f) / (0.95f - 0.075f)), df.ConeAndMisc.z);
     }
-    const float opacity = pre_trace * cone_opacity;
+    // SphereLightPixelEpilogue / ...WithRamp (SphereLightCore.fxh:83-119): with a ramp texture the opacity becomes a colour,
+    // SampleFromRamp2(preTraceOpacity, (angle + rampOffset) * rampRate).rgb * coneOpacity -- tex2Dlod level 0, LINEAR, U CLAMP, V WRAP
+    float opacity_r = pre_trace * cone_opacity, opacity_g = opacity_r, opacity_b = opacity_r;
+    if (ramp.texels != nullptr) {
+        const float angle = atan2f(P.shaded.y - L.cy, P.shaded.x - L.cx);
+        const float u = pre_trace, v = (angle + L.ramp_offset) * L.ramp_rate;
+        const int w = ramp.width, h = ramp.height;
+        const float sx = u * (float)w - 0.5f, sy = v * (float)h - 0.5f;
+        float x0f = floorf(sx);
+        const float y0f = floorf(sy);
+        const float fx = sx - x0f, fy = sy - y0f;
+        float x1f = x0f + 1.0f;
+        x0f = (x0f >= 0.0f) ? x0f : 0.0f; x0f = fminf(x0f, (float)(w - 1));
+        x1f = (x1f >= 0.0f) ? x1f : 0.0f; x1f = fminf(x1f, (float)(w - 1));
+        const int x0 = (int)x0f, x1 = (int)x1f;
+        const int y0 = wrap_index(y0f, h), y1 = wrap_index(y0f + 1.0f, h);
+        const float4 t00 = ramp.texels[y0 * w + x0], t10 = ramp.texels[y0 * w + x1], t01 = ramp.texels[y1 * w + x0], t11 = ramp.texels[y1 * w + x1];
+        opacity_r = lerp(lerp(t00.x, t10.x, fx), lerp(t01.x, t11.x, fx), fy) * cone_opacity;
+        opacity_g = lerp(lerp(t00.y, t10.y, fx), lerp(t01.y, t11.y, fx), fy) * cone_opacity;
+        opacity_b = lerp(lerp(t00.z, t10.z, fx), lerp(t01.z, t11.z, fx), fy) * cone_opacity;
+    }
 
     // SphereLightPixelShader epilogue, SphereLight.fx:37-45.  The specular term is
     // skipped when Color2.rgb == 0: it then contributes exactly 0 unless
@@ -238,13 +258,13 @@ ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment
         const f3 light_direction = P.shaded - mk3(L.cx, L.cy, L.cz);
         const f3 h = norm3(norm3(P.camera - P.shaded) - light_direction);
         const float specularity = pow_pos(sat(dot3(h, P.normal)), L.spec_power);
-        sr = L.spec_r * specularity * opacity;
-        sg = L.spec_g * specularity * opacity;
-        sb = L.spec_b * specularity * opacity;
+        sr = L.spec_r * specularity * opacity_r;
+        sg = L.spec_g * specularity * opacity_g;
+        sb = L.spec_b * specularity * opacity_b;
     }
-    out_r = (L.col_r * opacity) + sr;
-    out_g = (L.col_g * opacity) + sg;
-    out_b = (L.col_b * opacity) + sb;
+    out_r = (L.col_r * opacity_r) + sr;
+    out_g = (L.col_g * opacity_g) + sg;
+    out_b = (L.col_b * opacity_b) + sb;
     return true;
 }
 
@@ -348,7 +368,7 @@ __global__ __launch_bounds__(256) void sphere_lights_kernel(const LightLaunch a,
                 continue;
             if (STATS) st.pairs++;
             float cr, cg, cb;
-            if (!shade_light<FMT, STATS>(P, L, a.env, a.df, a.sdf, have_sdf, st, cr, cg, cb))
+            if (!shade_light<FMT, STATS>(P, L, a.env, a.df, a.sdf, have_sdf, a.ramp, st, cr, cg, cb))
                 continue;
             acc_r += cr;
             acc_g += cg;
@@ -484,7 +504,7 @@ __global__ __launch_bounds__(kPlBlock) void particle_light_emit_kernel(const Par
     const float max_radius = clampf(r.radius, 0.33f, a.max_cone_radius);
     r.cfg_x = max_radius;
     r.cfg_y = max_radius / fmaxf(r.ramp, 16.0f) * 1.0f;
-    r._pad0 = r._pad1 = 0.0f;
+    r.ramp_offset = r.ramp_rate = 0.0f;
     reinterpret_cast<LightRec*>(a.recs)[index] = r;
 }
 
@@ -505,7 +525,7 @@ template <int FMT>
 __global__ __launch_bounds__(64) void light_probes_kernel(const LightRec* __restrict__ recs, int light_count,
                                                            const float4* __restrict__ probe_positions, const float4* __restrict__ probe_normals,
                                                            int probe_count, IlmEnvironment env, IlmDistanceFieldUniforms df, SdfView sdf,
-                                                           float4* __restrict__ values) {
+                                                           RampView ramp, float4* __restrict__ values) {
     const int i = (int)blockIdx.x * 64 + (int)threadIdx.x;
     const bool valid = i < probe_count;
     const float4 pp = valid ? probe_positions[i] : mk4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -529,7 +549,7 @@ __global__ __launch_bounds__(64) void light_probes_kernel(const LightRec* __rest
         L.shadow_filter = -1.0f;
         L.has_spec = 0.0f;
         float cr, cg, cb;
-        if (!shade_light<FMT, false>(P, L, env, df, sdf, have_sdf, st, cr, cg, cb))
+        if (!shade_light<FMT, false>(P, L, env, df, sdf, have_sdf, ramp, st, cr, cg, cb))
             continue;
         acc_r += cr * probe_opacity;
         acc_g += cg * probe_opacity;
@@ -541,14 +561,15 @@ __global__ __launch_bounds__(64) void light_probes_kernel(const LightRec* __rest
 }
 
 hipError_t launch_light_probes(const void* recs, int light_count, const float4* probe_positions, const float4* probe_normals, int probe_count,
-                               const IlmEnvironment& env, const IlmDistanceFieldUniforms& df, const SdfView& sdf, float4* values, hipStream_t stream) {
+                               const IlmEnvironment& env, const IlmDistanceFieldUniforms& df, const SdfView& sdf, const RampView& ramp, float4* values,
+                               hipStream_t stream) {
     if (probe_count <= 0) return hipSuccess;
     const dim3 grid((unsigned)((probe_count + 63) / 64)), block(64);
     const LightRec* r = reinterpret_cast<const LightRec*>(recs);
     if (sdf.format == ILM_SDF_FP16)
-        hipLaunchKernelGGL(light_probes_kernel<ILM_SDF_FP16>, grid, block, 0, stream, r, light_count, probe_positions, probe_normals, probe_count, env, df, sdf, values);
+        hipLaunchKernelGGL(light_probes_kernel<ILM_SDF_FP16>, grid, block, 0, stream, r, light_count, probe_positions, probe_normals, probe_count, env, df, sdf, ramp, values);
     else
-        hipLaunchKernelGGL(light_probes_kernel<ILM_SDF_UNORM16>, grid, block, 0, stream, r, light_count, probe_positions, probe_normals, probe_count, env, df, sdf, values);
+        hipLaunchKernelGGL(light_probes_kernel<ILM_SDF_UNORM16>, grid, block, 0, stream, r, light_count, probe_positions, probe_normals, probe_count, env, df, sdf, ramp, values);
     return hipGetLastError();
 }
 

@@ -378,6 +378,16 @@ PYBIND11_MODULE(_host, m) {
         .def("LastStepBytes", [](const ParticleSystem& s) { return py::bytes((const char*)&s.LastStep(), sizeof(IlmStepDesc)); });
 
     // ---- lighting ------------------------------------------------------------------------------------------------
+    // RampTexture((h, w, 4) float32)
+    py::class_<RampTexture, std::shared_ptr<RampTexture>>(m, "RampTexture")
+        .def(py::init([](py::array_t<float, py::array::c_style | py::array::forcecast> a) {
+            if (a.ndim() != 3 || a.shape(2) != 4) throw std::invalid_argument("ramp texture must be (h, w, 4) float32");
+            auto t = std::make_shared<RampTexture>();
+            t->Width = (int)a.shape(1); t->Height = (int)a.shape(0);
+            const IlmFloat4* p = reinterpret_cast<const IlmFloat4*>(a.data());
+            t->Texels.assign(p, p + a.shape(0) * a.shape(1));
+            return t; }))
+        .def_readonly("Width", &RampTexture::Width).def_readonly("Height", &RampTexture::Height);
     py::class_<SphereLightSource>(m, "SphereLightSource").def(py::init<>())
         .def_readwrite("SortKey", &SphereLightSource::SortKey)
         VEC_PROP(SphereLightSource, Position, 3)
@@ -392,7 +402,9 @@ PYBIND11_MODULE(_host, m) {
         .def_readwrite("FalloffYFactor", &SphereLightSource::FalloffYFactor)
         .def_readwrite("ShadowFilter", &SphereLightSource::ShadowFilter)
         VEC_PROP(SphereLightSource, SpecularColor, 3)
-        .def_readwrite("SpecularPower", &SphereLightSource::SpecularPower);
+        .def_readwrite("SpecularPower", &SphereLightSource::SpecularPower)
+        .def_readwrite("TextureRef", &SphereLightSource::TextureRef)
+        .def_readwrite("RampOffset", &SphereLightSource::RampOffset).def_readwrite("RampRate", &SphereLightSource::RampRate);
     py::class_<ParticleLightSource>(m, "ParticleLightSource").def(py::init<>())
         .def_readwrite("Template", &ParticleLightSource::Template)
         .def_property("System", py::cpp_function([](ParticleLightSource& s) { return s.System; }, py::return_value_policy::reference),
@@ -454,6 +466,7 @@ PYBIND11_MODULE(_host, m) {
         VEC_PROP(RendererConfiguration, RenderScale, 2)
         .def_readwrite("DefaultQuality", &RendererConfiguration::DefaultQuality)
         .def_readwrite("MaximumFieldUpdatesPerFrame", &RendererConfiguration::MaximumFieldUpdatesPerFrame)
+        .def_readwrite("DefaultRampTexture", &RendererConfiguration::DefaultRampTexture)
         .def_readwrite("MaximumLightProbeCount", &RendererConfiguration::MaximumLightProbeCount)
         .def_readwrite("EnableGBuffer", &RendererConfiguration::EnableGBuffer).def_readwrite("RenderGroundPlane", &RendererConfiguration::RenderGroundPlane)
         .def_readwrite("HighQualityGBuffer", &RendererConfiguration::HighQualityGBuffer)

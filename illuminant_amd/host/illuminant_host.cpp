@@ -1213,7 +1213,9 @@ bool LightingRenderer::PackSphereLight(const SphereLightSource& l, float intensi
     v.Color2 = { l.SpecularColor.X, l.SpecularColor.Y, l.SpecularColor.Z, l.SpecularPower };
     v.LightProperties = { l.Radius, l.RampLength, (float)(int)l.RampMode, (l.CastsShadows && haveDistanceField) ? 1.0f : 0.0f };
     v.MoreLightProperties = { l.AmbientOcclusionRadius, l.ShadowDistanceFalloff.value_or(-99999.0f), l.FalloffYFactor, l.AmbientOcclusionOpacity };
-    v.EvenMoreLightProperties = { (float)l.ShadowFilter, 0, 0, 0 };
+    // RampOffsetForGPU / RampRateForGPU, LightSource.cs:97-98
+    v.EvenMoreLightProperties = { (float)l.ShadowFilter, 0, (float)-3.14159265358979323846 + l.RampOffset,
+                                  (float)(1.0 / (3.14159265358979323846 * 2) * l.RampRate) };
     return true;
 }
 
@@ -1263,18 +1265,39 @@ void LightingRenderer::RenderLighting(float intensityScale, int rowBegin, int ro
     std::vector<const SphereLightSource*> sorted;
     for (const SphereLightSource& l : Environment->Lights) sorted.push_back(&l);
     std::stable_sort(sorted.begin(), sorted.end(), [](const SphereLightSource* x, const SphereLightSource* y) { return x->SortKey < y->SortKey; });
+    // GetLightRenderState (:799-845): lights that share a ramp texture form one render state; the states are drawn one after the
+    // other onto the same target (additive), in the order their keys first appear
+    groupKeys.clear();
+    groups.clear();
     for (const SphereLightSource* l : sorted) {
         IlmLightVertex v;
-        if (PackSphereLight(*l, intensityScale, Field != nullptr, v))
-            vertices.push_back(v);
+        if (!PackSphereLight(*l, intensityScale, Field != nullptr, v))
+            continue;
+        const RampTexture* ramp = l->TextureRef ? l->TextureRef.get() : Configuration.DefaultRampTexture.get();
+        if (ramp && ((ramp->Width == 1 && ramp->Height == 1) || ramp->Width <= 0))
+            ramp = nullptr;                                   // a 1 x 1 ramp is no ramp (:822-827)
+        size_t g = 0;
+        while (g < groupKeys.size() && groupKeys[g] != ramp) g++;
+        if (g == groupKeys.size()) { groupKeys.push_back(ramp); groups.emplace_back(); }
+        groups[g].push_back(v);
+        vertices.push_back(v);
     }
     const IlmEnvironment env = GetEnvironmentUniforms();
     const IlmDistanceFieldUniforms dfu = GetDistanceFieldUniforms(Configuration.DefaultQuality);
     // clear colour: Ambient * intensityScale (:1013-1024)
     const float ambient[4] = { Environment->Ambient.X * intensityScale, Environment->Ambient.Y * intensityScale,
                                Environment->Ambient.Z * intensityScale, Environment->Ambient.W * intensityScale };
-    ThrowIfFailed(ilm_render_sphere_lights(Context.Handle(), vertices.empty() ? nullptr : vertices.data(), (int32_t)vertices.size(),
-                                           &env, &dfu, gbuffer, Field ? Field->Texture() : 0, ambient, lightmap, rowBegin, rowEnd, stats));
+    if (groups.empty()) { groupKeys.push_back(nullptr); groups.emplace_back(); }     // no lights: the clear still happens
+    if (stats) { stats->SdfSamples = stats->PixelLightPairs = stats->TracedPairs = 0; }
+    for (size_t g = 0; g < groups.size(); g++) {
+        BindRamp(groupKeys[g]);
+        IlmRenderStats gs{};
+        ThrowIfFailed(ilm_render_sphere_lights(Context.Handle(), groups[g].empty() ? nullptr : groups[g].data(), (int32_t)groups[g].size(),
+                                               &env, &dfu, gbuffer, Field ? Field->Texture() : 0, (g == 0) ? ambient : nullptr, lightmap, rowBegin, rowEnd,
+                                               stats ? &gs : nullptr));
+        if (stats) { stats->SdfSamples += gs.SdfSamples; stats->PixelLightPairs += gs.PixelLightPairs; stats->TracedPairs += gs.TracedPairs; }
+    }
+    BindRamp(nullptr);         // particle lights have no ramp technique (:176-178)
     // particle light sources: one more light-type render state each, blended on top (:1126-1141)
     for (const ParticleLightSource& pls : Environment->ParticleLights) {
         if (!pls.Enabled || !pls.IsActive || !pls.System)
@@ -1293,6 +1316,13 @@ void LightingRenderer::RenderLighting(float intensityScale, int rowBegin, int ro
     }
     if (Probes.Count() > 0)      // :1176-1182
         UpdateLightProbes(intensityScale);
+}
+
+// _LightBatchSetup binds the group's RampTexture (:764-766); the native layer keeps one per context
+void LightingRenderer::BindRamp(const RampTexture* ramp) {
+    if (ramp == boundRamp) return;
+    ThrowIfFailed(ilm_ctx_set_light_ramp(Context.Handle(), ramp ? ramp->Texels.data() : nullptr, ramp ? ramp->Width : 0, ramp ? ramp->Height : 0));
+    boundRamp = ramp;
 }
 
 IlmParticleLightParams LightingRenderer::PackParticleLight(const ParticleLightSource& pls, bool haveDistanceField) {
@@ -1332,9 +1362,20 @@ void LightingRenderer::UpdateLightProbes(float intensityScale) {
     Probes.IsDirty = false;
     const IlmEnvironment env = GetEnvironmentUniforms();
     const IlmDistanceFieldUniforms dfu = GetDistanceFieldUniforms(Configuration.DefaultQuality);
-    // the light vertices of this frame were packed with intensityScale folded into Color1.a (RenderSphereLightSource, :1203)
-    ThrowIfFailed(ilm_render_light_probes(Context.Handle(), vertices.empty() ? nullptr : vertices.data(), (int32_t)vertices.size(),
-                                          positions.data(), normals.data(), n, &env, &dfu, Field ? Field->Texture() : 0, values.data()));
+    // the light vertices of this frame were packed with intensityScale folded into Color1.a (RenderSphereLightSource, :1203); every
+    // render state draws its lights onto the probe target with its own probe material (with or without a ramp, :159-164): summed here
+    for (size_t g = 0; g < groups.size(); g++) {
+        if (groups[g].empty() && g > 0) continue;
+        BindRamp(groupKeys[g]);
+        std::vector<IlmFloat4> part((size_t)n);
+        ThrowIfFailed(ilm_render_light_probes(Context.Handle(), groups[g].empty() ? nullptr : groups[g].data(), (int32_t)groups[g].size(),
+                                              positions.data(), normals.data(), n, &env, &dfu, Field ? Field->Texture() : 0, part.data()));
+        for (int i = 0; i < n; i++) {
+            values[(size_t)i].x += part[(size_t)i].x; values[(size_t)i].y += part[(size_t)i].y;
+            values[(size_t)i].z += part[(size_t)i].z; values[(size_t)i].w += part[(size_t)i].w;
+        }
+    }
+    BindRamp(nullptr);
     const float scaleFactor = 1.0f / intensityScale;     // LightProbeDownloadTask.ScaleFactor, LightingRenderer.cs:943
     for (int i = 0; i < n; i++) {
         LightProbe& p = *Probes.Items[(size_t)i];

@@ -632,6 +632,13 @@ enum class LightSourceRampMode { Linear = 0, Exponential = 1, Constant = 2 };   
 enum class LightShadowFilter { None = -1, ShadowsOnly = 1, NoShadowsOnly = 0 };   // as packed into EvenMoreLightProperties.x
 
 // LightSource.cs:37-280 (SphereLightSource)
+// A light ramp texture (LightSource.TextureRef / RendererConfiguration.DefaultRampTexture): width x height float4 texels.  Lights are
+// grouped by the texture they share (LightTypeRenderStateKey.RampTexture, LightingRenderer.cs:50-83); a 1 x 1 ramp is no ramp (:822-827).
+struct RampTexture {
+    int Width = 0, Height = 0;
+    std::vector<IlmFloat4> Texels;
+};
+
 struct SphereLightSource {
     int SortKey = 0;          // LightSourceBase.SortKey: RenderLighting sorts by it first (LightSorter, LightingRenderer.cs:2066-2096)
     Vector3 Position;
@@ -646,6 +653,8 @@ struct SphereLightSource {
     int ShadowFilter = -1;
     Vector3 SpecularColor{0, 0, 0};
     float SpecularPower = 1;
+    std::shared_ptr<RampTexture> TextureRef;      // LightSource.TextureRef; null => Configuration.DefaultRampTexture
+    float RampOffset = 0, RampRate = 1;           // RampOffsetAndRate, LightSource.cs:90
 };
 
 // ParticleLightSource, LightSource.cs:466-505
@@ -762,6 +771,7 @@ struct RendererConfiguration {
     bool RenderGroundPlane = true;
     bool HighQualityGBuffer = true;        // GBuffer format Vector4 (true) or HalfVector4, GBuffer.cs:30-38
     bool FloatLightmap = false;       // extension: fp32 lightmap (parity format)
+    std::shared_ptr<RampTexture> DefaultRampTexture;   // LightingRenderer.Configuration.cs:78
     RendererConfiguration(int w, int h) : RenderWidth(w), RenderHeight(h) {}
 };
 
@@ -821,6 +831,11 @@ private:
     int lightmapFormat = ILM_LIGHTMAP_HALF4;
     int gbufferWidth = 0, gbufferHeight = 0;
     std::vector<IlmLightVertex> vertices;
+    // the light groups of the last RenderLighting (one per ramp texture) and the ramp currently bound on the context
+    std::vector<const RampTexture*> groupKeys;
+    std::vector<std::vector<IlmLightVertex>> groups;
+    const RampTexture* boundRamp = nullptr;
+    void BindRamp(const RampTexture* ramp);
 };
 
 }  // namespace Lighting

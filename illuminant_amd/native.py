@@ -87,6 +87,7 @@ SYMBOLS = {
     "ilm_system_readback_view": (_I, [_H, _P, _I, _P, C.POINTER(_P), C.POINTER(_I)]),
     "ilm_render_particles": (_I, [_H, _P, _I, _P, _H, _P]),
     "ilm_lightmap_clear": (_I, [_H, _P]),
+    "ilm_ctx_set_light_ramp": (_I, [_H, _P, _I, _I]),
     "ilm_system_set_bitmap": (_I, [_H, _P, _I, _I]),
     "ilm_resolve_lighting": (_I, [_H, _H, _P, _I, _I]),
 }
@@ -140,6 +141,14 @@ class Context:
         p = C.c_void_p()
         check(lib().ilm_ctx_stream(self.handle, C.byref(p)))
         return p.value
+
+    def set_light_ramp(self, texels):
+        """ilm_ctx_set_light_ramp: (h, w, 4) float32 RampTexture of the light group rendered next; None unbinds."""
+        if texels is None:
+            check(lib().ilm_ctx_set_light_ramp(self.handle, None, 0, 0))
+            return
+        a = np.ascontiguousarray(texels, dtype=np.float32)
+        check(lib().ilm_ctx_set_light_ramp(self.handle, _ptr(a), a.shape[1], a.shape[0]))
 
     def timer_start(self):
         check(lib().ilm_timer_start(self.handle))
@@ -477,17 +486,18 @@ def render_particles(system, params, target, quad_counts=None, chunk_count=None,
 
 
 def render_sphere_lights(ctx, lights, env, df, gbuffer, sdf, ambient, lightmap, row_begin=0, row_end=None, want_stats=False):
-    """ilm_render_sphere_lights.  lights: ctypes array of abi.LightVertex (or None for zero lights)."""
+    """ilm_render_sphere_lights.  lights: ctypes array of abi.LightVertex (or None for zero lights); ambient None = add this light
+    group to what the lightmap already holds."""
     if row_end is None:
         row_end = lightmap.height
     n = len(lights) if lights is not None else 0
-    amb = (C.c_float * 4)(*[float(x) for x in ambient])
+    amb = (C.c_float * 4)(*[float(x) for x in ambient]) if ambient is not None else None
     stats = abi.RenderStats() if want_stats else None
     check(lib().ilm_render_sphere_lights(
         ctx.handle, C.cast(lights, C.c_void_p) if n else None, n, _byref(env), _byref(df),
         gbuffer.handle if gbuffer is not None else abi.Handle(0),
         sdf.handle if sdf is not None else abi.Handle(0),
-        C.cast(amb, C.c_void_p), lightmap.handle, row_begin, row_end, _byref(stats)))
+        C.cast(amb, C.c_void_p) if amb is not None else None, lightmap.handle, row_begin, row_end, _byref(stats)))
     return stats
 
 

@@ -608,8 +608,8 @@ def environment(ground_z=0.0, maximum_z=128.0, z_to_y=0.0, light_occlusion=0.0, 
 
 def sphere_light(position, radius, ramp_length, color=(1, 1, 1, 1), opacity=1.0, intensity_scale=1.0, ramp_mode=0,
                  casts_shadows=True, have_distance_field=True, ao_radius=0.0, ao_opacity=1.0, falloff_y=1.0,
-                 shadow_distance_falloff=None, shadow_filter=-1, specular=(0, 0, 0), specular_power=1.0):
-    """RenderSphereLightSource, LightingRenderer.cs:1193-1219."""
+                 shadow_distance_falloff=None, shadow_filter=-1, specular=(0, 0, 0), specular_power=1.0, ramp_offset=0.0, ramp_rate=1.0):
+    """RenderSphereLightSource, LightingRenderer.cs:1193-1219; EvenMore.zw = RampOffsetForGPU, RampRateForGPU (LightSource.cs:97-98)."""
     v = abi.LightVertex()
     v.LightPosition1 = v.LightPosition2 = v.LightPosition3 = abi.f4(position[0], position[1], position[2], 0)
     v.Color1 = abi.f4(color[0], color[1], color[2], np.float32(color[3]) * np.float32(opacity * intensity_scale))
@@ -617,7 +617,8 @@ def sphere_light(position, radius, ramp_length, color=(1, 1, 1, 1), opacity=1.0,
     v.LightProperties = abi.f4(radius, ramp_length, float(ramp_mode), 1.0 if (casts_shadows and have_distance_field) else 0.0)
     v.MoreLightProperties = abi.f4(ao_radius, -99999.0 if shadow_distance_falloff is None else shadow_distance_falloff,
                                    falloff_y, ao_opacity)
-    v.EvenMoreLightProperties = abi.f4(float(shadow_filter), 0, 0, 0)
+    v.EvenMoreLightProperties = abi.f4(float(shadow_filter), 0, np.float32(-math.pi) + np.float32(ramp_offset),
+                                       np.float32(1.0 / (math.pi * 2) * ramp_rate))
     return v
 
 

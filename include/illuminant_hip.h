@@ -560,7 +560,11 @@ typedef struct IlmRenderStats {
  * ambient + sum over lights, in light order.  gbuffer == 0 => ground plane
  * (LightCommon.fxh:130-141); sdf == 0 => no distance field.  `lights` is a host
  * array.  stats may be NULL; when non-NULL the instrumented (counting) kernel
- * variant runs and the call synchronises. */
+ * variant runs and the call synchronises.
+ * ambient == NULL: the lights are ADDED to what the lightmap holds -- a further light group of the same frame (the reference draws
+ * one batch group per LightTypeRenderStateKey, e.g. per ramp texture, onto the same target, LightingRenderer.cs:1004-1169).
+ * With a ramp texture bound (ilm_ctx_set_light_ramp) the technique is SphereLightWithDistanceRamp (SphereLight.fx:48-86,
+ * SphereLightPixelEpilogueWithRamp, SphereLightCore.fxh:99-119). */
 int32_t ilm_render_sphere_lights(IlmHandle ctx,
                                  const IlmLightVertex* lights, int32_t light_count,
                                  const IlmEnvironment* env,
@@ -569,6 +573,12 @@ int32_t ilm_render_sphere_lights(IlmHandle ctx,
                                  const float ambient[4],
                                  IlmHandle lightmap, int32_t row_begin, int32_t row_end,
                                  IlmRenderStats* stats);
+
+/* LightSource.TextureRef / Configuration.DefaultRampTexture of the light group rendered by the FOLLOWING ilm_render_sphere_lights and
+ * ilm_render_light_probes calls (bound per group by _LightBatchSetup, Illuminant/Lighting/LightingRenderer.cs:764-766; sampler
+ * RampTextureSampler, Illuminant/Shaders/RampCommon.fxh:4-21: tex2Dlod level 0, LINEAR, U CLAMP, V WRAP): width * height float4 texels.
+ * width == 0 -- or a 1 x 1 texture, which the reference treats as none (:822-827) -- selects the techniques without a ramp. */
+int32_t ilm_ctx_set_light_ramp(IlmHandle ctx, const IlmFloat4* texels, int32_t width, int32_t height);
 
 /* ---- particle lights and light probes --------------------------------------------------------- */
 

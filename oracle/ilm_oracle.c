@@ -1262,6 +1262,41 @@ static int light_covers_pixel(const IlmLightVertex* L, const IlmEnvironment* env
     return 0;
 }
 
+/* The RampTexture of the light group being rendered (technique SphereLightWithDistanceRamp / SphereLightProbeWithDistanceRamp;
+ * bound per LightTypeRenderStateKey, Illuminant/Lighting/LightingRenderer.cs:764-766).  NULL: techniques SphereLight / SphereLightProbe. */
+static const IlmFloat4* g_light_ramp = NULL;
+static int g_light_ramp_w = 0, g_light_ramp_h = 0;
+void orc_set_light_ramp(const IlmFloat4* texels, int32_t width, int32_t height) {
+    g_light_ramp = (texels && width > 0 && height > 0) ? texels : NULL;
+    g_light_ramp_w = width; g_light_ramp_h = height;
+}
+
+/* SampleFromRamp2, RampCommon.fxh:4-21: tex2Dlod level 0, LINEAR, U CLAMP, V WRAP, texel centres at + 0.5 */
+static f4 sample_from_ramp2(float u, float v) {
+    const int w = g_light_ramp_w, h = g_light_ramp_h;
+    const float sx = u * (float)w - 0.5f, sy = v * (float)h - 0.5f;
+    float x0f = floorf(sx), y0f = floorf(sy);
+    const float fx = sx - x0f, fy = sy - y0f;
+    float x1f = x0f + 1.0f;
+    if (!(x0f >= 0.0f)) x0f = 0.0f; if (x0f > (float)(w - 1)) x0f = (float)(w - 1);
+    if (!(x1f >= 0.0f)) x1f = 0.0f; if (x1f > (float)(w - 1)) x1f = (float)(w - 1);
+    const int x0 = (int)x0f, x1 = (int)x1f;
+    const int y0 = wrap_index(y0f, h), y1 = wrap_index(y0f + 1.0f, h);
+    return v4lerp(v4lerp(g_light_ramp[y0 * w + x0], g_light_ramp[y0 * w + x1], fx),
+                  v4lerp(g_light_ramp[y1 * w + x0], g_light_ramp[y1 * w + x1], fx), fy);
+}
+
+/* SphereLightPixelEpilogue / ...WithRamp, SphereLightCore.fxh:83-119: the light's opacity per colour channel */
+static f3 sphere_light_epilogue(float pre_trace_opacity, float cone_opacity, f3 distance_to_center, f4 even_more) {
+    if (g_light_ramp == NULL) {
+        const float o = pre_trace_opacity * cone_opacity;
+        return v3(o, o, o);
+    }
+    const float angle = atan2f(distance_to_center.y, distance_to_center.x);
+    const f4 rgb = sample_from_ramp2(pre_trace_opacity, (angle + even_more.z) * even_more.w);
+    return v3(rgb.x * cone_opacity, rgb.y * cone_opacity, rgb.z * cone_opacity);
+}
+
 /* SphereLightPixelShader, SphereLight.fx:7-46, + additive blend onto the
  * ambient clear (LightingRenderer.cs:1013-1024) with fp32 accumulation */
 void orc_render_sphere_lights(const IlmLightVertex* lights, int32_t light_count,
@@ -1309,12 +1344,12 @@ void orc_render_sphere_lights(const IlmLightVertex* lights, int32_t light_count,
                 f3 start = v3add(shaded, v3scale(normal, 1.6f));
                 float cone_opacity = cone_trace(light_center, light_properties.x, light_properties.y, 1.0f, more.y,
                                                 start, df, sdf, trace_shadows, &ctr);
-                float opacity = pre_trace_opacity * cone_opacity;
+                const f3 opacity = sphere_light_epilogue(pre_trace_opacity, cone_opacity, v3sub(shaded, light_center), L->EvenMoreLightProperties);
 
                 float specularity = calc_sphere_light_specularity(camera, shaded, normal, light_center, L->Color2.w);
-                acc.x += (L->Color1.x * L->Color1.w * opacity) + (L->Color2.x * specularity * opacity);
-                acc.y += (L->Color1.y * L->Color1.w * opacity) + (L->Color2.y * specularity * opacity);
-                acc.z += (L->Color1.z * L->Color1.w * opacity) + (L->Color2.z * specularity * opacity);
+                acc.x += (L->Color1.x * L->Color1.w * opacity.x) + (L->Color2.x * specularity * opacity.x);
+                acc.y += (L->Color1.y * L->Color1.w * opacity.y) + (L->Color2.y * specularity * opacity.y);
+                acc.z += (L->Color1.z * L->Color1.w * opacity.z) + (L->Color2.z * specularity * opacity.z);
                 acc.w += 1.0f;
             }
             lightmap[(size_t)py * (size_t)width + (size_t)px] = acc;

@@ -94,6 +94,9 @@ float orc_decode_distance(float encoded, float max_encoded);
 float orc_evaluate_area(int32_t type_id, const float pos[3], const float center[3], const float size[3], float rotation);
 
 /* lighting */
+/* RampTexture of the light group rendered by the following orc_render_sphere_lights / orc_render_light_probes calls (width * height
+ * float4, kept by reference); NULL unbinds (techniques without a distance ramp) */
+void orc_set_light_ramp(const IlmFloat4* texels, int32_t width, int32_t height);
 void orc_sample_gbuffer(float px, float py, const IlmEnvironment* env, const OrcTexture* gbuffer,
                         float world_pos[3], float normal[3], int32_t* enable_shadows, int32_t* fullbright, float camera_pos[3]);
 void orc_render_sphere_lights(const IlmLightVertex* lights, int32_t light_count,

@@ -8,13 +8,14 @@
  */
 
 /* SphereLightPixelCore, SphereLightCore.fxh:122-158.  Returns 0 with *discarded = 1 when the shader discards. */
-static float sphere_light_pixel_core(f3 shaded, f3 normal, f3 light_center, f4 light_properties, f4 more,
-                                     const IlmEnvironment* env, const IlmDistanceFieldUniforms* df, const OrcTexture* sdf,
-                                     SdfCounter* ctr, uint64_t* traced, int* discarded) {
+static float sphere_light_pixel_core_ex(f3 shaded, f3 normal, f3 light_center, f4 light_properties, f4 more,
+                                        const IlmEnvironment* env, const IlmDistanceFieldUniforms* df, const OrcTexture* sdf,
+                                        SdfCounter* ctr, uint64_t* traced, int* discarded, float* pre_trace, float* cone) {
     /* SphereLightPixelPrologue, :58-81 */
     float distance_opacity = compute_sphere_light_opacity(shaded, normal, light_center, light_properties, more.z, env);
     int visible = (distance_opacity > 0.0f) && (shaded.x > -9999.0f);
     more.x *= fmaxf(0.0f, normal.z);
+    *pre_trace = *cone = 0.0f;
     if (!visible) {
         *discarded = 1;
         return 0.0f;
@@ -26,7 +27,14 @@ static float sphere_light_pixel_core(f3 shaded, f3 normal, f3 light_center, f4 l
     if (trace_shadows && traced) (*traced)++;
     f3 start = v3add(shaded, v3scale(normal, 1.6f));
     float cone_opacity = cone_trace(light_center, light_properties.x, light_properties.y, 1.0f, more.y, start, df, sdf, trace_shadows, ctr);
+    *pre_trace = pre_trace_opacity; *cone = cone_opacity;
     return pre_trace_opacity * cone_opacity;
+}
+static float sphere_light_pixel_core(f3 shaded, f3 normal, f3 light_center, f4 light_properties, f4 more,
+                                     const IlmEnvironment* env, const IlmDistanceFieldUniforms* df, const OrcTexture* sdf,
+                                     SdfCounter* ctr, uint64_t* traced, int* discarded) {
+    float pre, cone;
+    return sphere_light_pixel_core_ex(shaded, normal, light_center, light_properties, more, env, df, sdf, ctr, traced, discarded, &pre, &cone);
 }
 
 /* ParticleLightVertexShader's quad, ParticleLight.fx:16-83: a plain rectangle of half-size radius + ramp + 1 whose top edge is
@@ -144,13 +152,16 @@ void orc_render_light_probes(const IlmLightVertex* lights, int32_t light_count,
                 f4 more = L->MoreLightProperties;
                 more.x = more.w = 0.0f;             /* no AO on probes, SphereLightProbe.fx:36 */
                 int discarded;
-                float opacity = probe_opacity * sphere_light_pixel_core(shaded, normal, xyz(L->LightPosition1), light_properties, more,
-                                                                        env, df, sdf, &ctr, NULL, &discarded);
+                float pre, cone;
+                (void)sphere_light_pixel_core_ex(shaded, normal, xyz(L->LightPosition1), light_properties, more,
+                                                 env, df, sdf, &ctr, NULL, &discarded, &pre, &cone);
                 if (discarded)
                     continue;
-                acc.x += L->Color1.x * L->Color1.w * opacity;
-                acc.y += L->Color1.y * L->Color1.w * opacity;
-                acc.z += L->Color1.z * L->Color1.w * opacity;
+                /* opacity *= SphereLightPixelCore(...), or rgb = opacity * SphereLightPixelCoreWithRamp(...): SphereLightProbe.fx:39-44,67-71 */
+                const f3 core = sphere_light_epilogue(pre, cone, v3sub(shaded, xyz(L->LightPosition1)), L->EvenMoreLightProperties);
+                acc.x += L->Color1.x * L->Color1.w * (probe_opacity * core.x);
+                acc.y += L->Color1.y * L->Color1.w * (probe_opacity * core.y);
+                acc.z += L->Color1.z * L->Color1.w * (probe_opacity * core.z);
                 acc.w += 1.0f;
             }
         }

@@ -237,6 +237,22 @@ def sample_gbuffer(px, py, env, gbuffer=None):
     return tuple(wp), tuple(n), bool(es.value), bool(fb.value), tuple(cam)
 
 
+_ramp_keepalive = [None]
+
+
+def set_light_ramp(texels):
+    """orc_set_light_ramp: (h, w, 4) float32 RampTexture of the light group rendered by the following render_sphere_lights /
+    render_light_probes calls; None unbinds."""
+    # a 1 x 1 ramp is no ramp at all: GetLightRenderState, LightingRenderer.cs:822-827 (host logic, restated here)
+    if texels is None or (np.asarray(texels).shape[0] == 1 and np.asarray(texels).shape[1] == 1):
+        lib().orc_set_light_ramp(None, C.c_int32(0), C.c_int32(0))
+        _ramp_keepalive[0] = None
+        return
+    a = np.ascontiguousarray(texels, dtype=np.float32)
+    _ramp_keepalive[0] = a
+    lib().orc_set_light_ramp(_f4(a), C.c_int32(a.shape[1]), C.c_int32(a.shape[0]))
+
+
 def render_sphere_lights(lights, env, df, gbuffer, sdf, ambient, width, height, row_begin=0, row_end=None, want_stats=False):
     """lights: ctypes array of abi.LightVertex.  Returns (lightmap (H, W, 4) float32, stats|None)."""
     if row_end is None:

@@ -608,7 +608,25 @@ def gen_lights_ext():
                   "expected": [0.0, 0.0, 0.0, 0.0]})
     cases.append({"kind": "light_probe", "probe": {"position": probe, "normal": [1.0, 0.0, 0.0], "enable_shadows": True}, "lights": [lights[1]],
                   "expected": [0.0, 0.5, 0.0, 1.0]})
-    return {"source": "hand-derived from ParticleLight.fx:16-118, SphereLightProbe.fx:19-44, LightCommon.fxh:154-254 (see comments in make_golden.py)",
+    # (f) technique SphereLightProbeWithDistanceRamp (SphereLightProbe.fx:46-72, SphereLightPixelEpilogueWithRamp, SphereLightCore.fxh:99-119):
+    #     the opacity becomes SampleFromRamp2(preTraceOpacity, (angle + rampOffsetForGPU) * rampRateForGPU).rgb * coneOpacity.
+    #     A 2 x 1 ramp red -> blue read at u = preTraceOpacity = .5 (mid-ramp distance) is the midpoint of its two texels.
+    ramp_u = [[[1.0, 0.0, 0.0, 1.0], [0.0, 0.0, 1.0, 1.0]]]
+    cases.append({"kind": "light_probe", "probe": {"position": probe, "normal": None, "enable_shadows": True},
+                  "lights": [{"position": [115.0, 50.0, 10.0], "radius": 5.0, "ramp": 20.0, "color": [1.0, 1.0, 1.0, 1.0]}],
+                  "ramp_texture": ramp_u, "expected": [0.5, 0.0, 0.5, 1.0]})
+    #     A 1 x 4 ramp addressed by the angle around the light (V WRAP): the probe sits on the light's -x side, angle = atan2(0, -15) = pi;
+    #     RampOffsetForGPU = -pi + RampOffset, RampRateForGPU = RampRate / 2 pi => v = RampOffset / 2 pi; RampOffset = 2 pi * 0.375 => v * 4 - .5 = 1:
+    #     exactly row 1.  u = 1 (inside the radius) is clamped.
+    ramp_v = [[[0.1, 0.2, 0.3, 1.0]], [[0.9, 0.8, 0.7, 1.0]], [[0.4, 0.5, 0.6, 1.0]], [[0.0, 1.0, 0.0, 1.0]]]
+    cases.append({"kind": "light_probe", "probe": {"position": probe, "normal": None, "enable_shadows": True},
+                  "lights": [{"position": [115.0, 50.0, 10.0], "radius": 20.0, "ramp": 20.0, "color": [1.0, 1.0, 1.0, 0.5], "ramp_offset": 2 * math.pi * 0.375}],
+                  "ramp_texture": ramp_v, "expected": [0.45, 0.4, 0.35, 1.0]})
+    #     a 1 x 1 ramp is no ramp at all (LightingRenderer.cs:822-827): the plain technique's answer
+    cases.append({"kind": "light_probe", "probe": {"position": probe, "normal": None, "enable_shadows": True},
+                  "lights": [{"position": [115.0, 50.0, 10.0], "radius": 5.0, "ramp": 20.0, "color": [0.0, 1.0, 0.0, 1.0]}],
+                  "ramp_texture": [[[0.3, 0.3, 0.3, 1.0]]], "expected": [0.0, 0.5, 0.0, 1.0]})
+    return {"source": "hand-derived from ParticleLight.fx:16-118, SphereLightProbe.fx:19-72, SphereLightCore.fxh:99-119, RampCommon.fxh, LightCommon.fxh:154-254 (see comments in make_golden.py)",
             "tolerance": "1e-5 relative", "cases": cases}
 
 

@@ -48,8 +48,12 @@ class OracleBackend:
         self.orc.render_particle_lights([chunk], [quad_count], params, scenes.environment(), no_field_uniforms(), None, None, lm)
         return lm
 
-    def probes(self, lights, pp, pn):
-        return self.orc.render_light_probes(lights, pp, pn, scenes.environment(), no_field_uniforms(), None)
+    def probes(self, lights, pp, pn, ramp=None):
+        self.orc.set_light_ramp(ramp)
+        try:
+            return self.orc.render_light_probes(lights, pp, pn, scenes.environment(), no_field_uniforms(), None)
+        finally:
+            self.orc.set_light_ramp(None)
 
 
 class GpuBackend:
@@ -73,8 +77,12 @@ class GpuBackend:
             x.close()
         return out
 
-    def probes(self, lights, pp, pn):
-        return self.native.render_light_probes(self.ctx, lights, pp, pn, scenes.environment(), no_field_uniforms(), None)
+    def probes(self, lights, pp, pn, ramp=None):
+        self.ctx.set_light_ramp(ramp)
+        try:
+            return self.native.render_light_probes(self.ctx, lights, pp, pn, scenes.environment(), no_field_uniforms(), None)
+        finally:
+            self.ctx.set_light_ramp(None)
 
 
 def check_case(case, backend):
@@ -93,12 +101,14 @@ def check_case(case, backend):
     elif case["kind"] == "light_probe":
         lights = (abi.LightVertex * len(case["lights"]))()
         for i, l in enumerate(case["lights"]):
-            lights[i] = scenes.sphere_light(l["position"], l["radius"], l["ramp"], color=l["color"], casts_shadows=False)
+            lights[i] = scenes.sphere_light(l["position"], l["radius"], l["ramp"], color=l["color"], casts_shadows=False,
+                                            ramp_offset=l.get("ramp_offset", 0.0), ramp_rate=l.get("ramp_rate", 1.0))
         pr = case["probe"]
         pp = np.asarray([pr["position"] + [1.0]], np.float32)
         nrm = pr["normal"] if pr["normal"] is not None else [0.0, 0.0, 0.0]
         pn = np.asarray([nrm + [1.0 if pr["enable_shadows"] else 0.0]], np.float32)
-        out = backend.probes(lights, pp, pn)
-        assert_close(out[0], case["expected"], "light probe", rtol=1e-5)
+        ramp = np.asarray(case["ramp_texture"], np.float32) if "ramp_texture" in case else None
+        out = backend.probes(lights, pp, pn, ramp=ramp)
+        assert_close(out[0], case["expected"], "light probe", rtol=1e-5, atol=2e-6)
     else:
         raise AssertionError(case["kind"])

@@ -204,3 +204,52 @@ def test_reference_error_behaviour(H, hctx):
     tp.Advance(1 / 60)
     with pytest.raises(Exception, match="Maximum number of attractors"):              # Transforms.cs:348-349
         ps.Update(1)
+
+
+def test_lighting_renderer_groups_lights_by_ramp_texture(H, hctx, oracle):
+    """GetLightRenderState (LightingRenderer.cs:799-845): lights sharing a ramp texture form one render state; a light's TextureRef wins over
+    Configuration.DefaultRampTexture; a 1 x 1 ramp is no ramp.  Three groups on one frame: default ramp, own ramp, 1 x 1 ramp."""
+    w, h = 128, 80
+    env = H.LightingEnvironment()
+    env.Ambient = [0.02, 0.03, 0.04, 1.0]
+    ramp_a = scenes.uniform(61, (2, 6, 4), 0.0, 1.0)
+    ramp_b = scenes.uniform(62, (5, 3, 4), 0.0, 1.0)
+    ta, tb, t1 = H.RampTexture(ramp_a), H.RampTexture(ramp_b), H.RampTexture(np.full((1, 1, 4), 0.3, np.float32))
+    lv = scenes.random_lights(23, 9, w, h, z=(8.0, 40.0), radius=8.0, ramp=(40.0, 90.0))
+    lights, groups = [], {"a": [], "b": [], "none": []}
+    for i in range(len(lv)):
+        l = H.SphereLightSource()
+        l.Position = [lv[i].LightPosition1.x, lv[i].LightPosition1.y, lv[i].LightPosition1.z]
+        l.Radius = lv[i].LightProperties.x; l.RampLength = lv[i].LightProperties.y
+        l.Color = [lv[i].Color1.x, lv[i].Color1.y, lv[i].Color1.z, 1.0]
+        l.RampOffset = 0.3 * i; l.RampRate = 1.0 + 0.25 * i
+        key = ("a", "b", "none")[i % 3]
+        if key == "b":
+            l.TextureRef = tb
+        elif key == "none":
+            l.TextureRef = t1
+        lights.append(l)
+        groups[key].append(scenes.sphere_light(tuple(l.Position), l.Radius, l.RampLength, color=tuple(l.Color), ramp_offset=l.RampOffset, ramp_rate=l.RampRate,
+                                                have_distance_field=False))
+    env.Lights = lights
+    rc = H.RendererConfiguration(w, h)
+    rc.FloatLightmap = True
+    rc.DefaultRampTexture = ta
+    r = H.LightingRenderer(hctx, rc, env)
+    stats = r.RenderLighting(1.0, 0, -1, True)
+    got = r.ReadLightmap()
+    dfu = abi.DistanceFieldUniforms.from_buffer_copy(r.GetDistanceFieldUniformsBytes())
+    envu = abi.Environment.from_buffer_copy(r.GetEnvironmentUniformsBytes())
+    want = np.zeros((h, w, 4), np.float32)
+    totals = [0, 0, 0]
+    first = True
+    for key, ramp in (("a", ramp_a), ("b", ramp_b), ("none", None)):       # order of first appearance
+        arr = (abi.LightVertex * len(groups[key]))(*groups[key])
+        oracle.set_light_ramp(ramp)
+        part, st = oracle.render_sphere_lights(arr, envu, dfu, None, None, tuple(env.Ambient) if first else (0.0, 0.0, 0.0, 0.0), w, h, want_stats=True)
+        oracle.set_light_ramp(None)
+        want += part
+        totals = [totals[0] + st.SdfSamples, totals[1] + st.PixelLightPairs, totals[2] + st.TracedPairs]
+        first = False
+    assert_close(got, want, "three ramp groups")
+    assert [int(x) for x in stats] == totals

@@ -185,3 +185,39 @@ def test_stipple_factor_below_one_is_refused(ctx):
     assert e.value.code == abi.ERR_INVALID_ARGUMENT and "StippleReject" in str(e.value)
     for x in (lm, sysm, eng):
         x.close()
+
+
+def test_distance_ramp_technique_matches_oracle(ctx, oracle):
+    """Technique SphereLightWithDistanceRamp (SphereLight.fx:48-86): two light groups of one frame -- the first without a ramp texture
+    (clears to ambient), the second with an 8 x 4 RGBA ramp, random offsets / rates, added on top -- against the oracle doing the same."""
+    from tests.test_lighting_gpu import small_scene
+    layout, atlas, dfu, lights, w, h = small_scene(n_lights=10)
+    env = scenes.environment()
+    plain = scenes.random_lights(21, 5, w, h, z=(8.0, 48.0), radius=10.0, ramp=(40.0, 120.0))
+    ramped = (abi.LightVertex * 6)()
+    offs = scenes.uniform(31, (6,), -3.0, 3.0); rates = scenes.uniform(32, (6,), 0.5, 3.0)
+    xs = scenes.uniform(33, (6,), 0, w); ys = scenes.uniform(34, (6,), 0, h)
+    for i in range(6):
+        ramped[i] = scenes.sphere_light((float(xs[i]), float(ys[i]), 20.0), 12.0, 90.0, color=(0.9, 0.8, 1.0, 0.9), specular=(0.2, 0.1, 0.3), specular_power=6.0,
+                                        ramp_offset=float(offs[i]), ramp_rate=float(rates[i]))
+    ramp = scenes.uniform(35, (4, 8, 4), 0.0, 1.0)
+    ambient = (0.05, 0.06, 0.07, 1.0)
+    sdf = native.DistanceFieldTexture(ctx, atlas, abi.SDF_UNORM16)
+    lm = native.Lightmap(ctx, w, h, abi.LIGHTMAP_FLOAT4)
+    s1 = native.render_sphere_lights(ctx, plain, env, dfu, None, sdf, ambient, lm, want_stats=True)
+    ctx.set_light_ramp(ramp)
+    s2 = native.render_sphere_lights(ctx, ramped, env, dfu, None, sdf, None, lm, want_stats=True)      # ambient None: add to the lightmap
+    ctx.set_light_ramp(None)
+    got = lm.download()
+    otex = oracle.make_texture(atlas, abi.SDF_UNORM16)
+    want1, o1 = oracle.render_sphere_lights(plain, env, dfu, None, otex, ambient, w, h, want_stats=True)
+    oracle.set_light_ramp(ramp)
+    want2, o2 = oracle.render_sphere_lights(ramped, env, dfu, None, otex, (0.0, 0.0, 0.0, 0.0), w, h, want_stats=True)
+    oracle.set_light_ramp(None)
+    for a, b in ((s1, o1), (s2, o2)):
+        assert (a.SdfSamples, a.PixelLightPairs, a.TracedPairs) == (b.SdfSamples, b.PixelLightPairs, b.TracedPairs)
+    assert_close(got, want1 + want2, "two light groups")
+    # the ramp really colours the light: the ramped group is not grey although its lights are nearly white
+    lit = want2[..., 3] > 0.5
+    assert np.abs(want2[lit][:, 0] - want2[lit][:, 2]).mean() > 0.01
+    lm.close(); sdf.close()
