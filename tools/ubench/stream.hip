@@ -3,6 +3,8 @@
 //   mode 1: same bytes with 16-byte accesses (4 slots per lane)
 //   mode 2: AoS float4: 3 x 16 B loads + 4 x 16 B stores per slot (one slot per lane)
 //   mode 3: mode 0 with non-temporal stores      mode 4: mode 0 with non-temporal loads and stores
+//   mode 5: two units per wave, both units' loads issued before any arithmetic (half the waves, one generation at N = 1 M)
+//   mode 6: persistent waves (8 per SIMD), each walking units with the next unit's loads in flight during the arithmetic
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -42,6 +44,58 @@ __global__ __launch_bounds__(256) void k_dword_nt(float* b, long S, int alu) {
 #pragma unroll
     for (int c = 12; c < 20; c++) __builtin_nontemporal_store(acc, base + c * S + i);
 }
+__global__ __launch_bounds__(256) void k_two(float* b, long S, int alu) {
+    gfloat* base = (gfloat*)b;
+    const long i0 = ((long)blockIdx.x * 256 + (threadIdx.x & ~63u)) * 2 + (threadIdx.x & 63u);
+    float v[2][12];
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int c = 0; c < 12; c++) v[u][c] = base[c * S + i0 + u * 64];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        float acc = 0;
+#pragma unroll
+        for (int c = 0; c < 12; c++) acc += v[u][c];
+        for (int k = 0; k < alu; k++) acc = acc * 1.0001f + 0.5f;
+        const long i = i0 + u * 64;
+#pragma unroll
+        for (int c = 0; c < 8; c++) base[c * S + i] = v[u][c] + acc;
+#pragma unroll
+        for (int c = 12; c < 20; c++) base[c * S + i] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void k_persistent(float* b, long S, int alu, long units) {
+    gfloat* base = (gfloat*)b;
+    const long wave = (long)blockIdx.x * 4 + (threadIdx.x >> 6), waves = (long)gridDim.x * 4;
+    const unsigned lane = threadIdx.x & 63u;
+    float nxt[12];
+    long u = wave;
+    if (u < units) {
+#pragma unroll
+        for (int c = 0; c < 12; c++) nxt[c] = base[c * S + u * 64 + lane];
+    }
+    while (u < units) {
+        float v[12];
+#pragma unroll
+        for (int c = 0; c < 12; c++) v[c] = nxt[c];
+        const long un = u + waves;
+        if (un < units) {
+#pragma unroll
+            for (int c = 0; c < 12; c++) nxt[c] = base[c * S + un * 64 + lane];
+        }
+        float acc = 0;
+#pragma unroll
+        for (int c = 0; c < 12; c++) acc += v[c];
+        for (int k = 0; k < alu; k++) acc = acc * 1.0001f + 0.5f;
+        const long i = u * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < 8; c++) base[c * S + i] = v[c] + acc;
+#pragma unroll
+        for (int c = 12; c < 20; c++) base[c * S + i] = acc;
+        u = un;
+    }
+}
 __global__ __launch_bounds__(256) void k_x4(float* b, long S, int alu) {
     gfloat* base = (gfloat*)b;
     long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -70,7 +124,7 @@ int main(int argc, char** argv) {
     int alu = argc > 2 ? atoi(argv[2]) : 0;
     float* d; CK(hipMalloc(&d, sizeof(float) * 20 * N)); CK(hipMemset(d, 0, sizeof(float) * 20 * N));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int mode = 0; mode < 5; mode++) {
+    for (int mode = 0; mode < 7; mode++) {
         const int reps = 50;
         for (int r = 0; r < reps + 5; r++) {
             if (r == 5) CK(hipEventRecord(e0));
@@ -78,6 +132,8 @@ int main(int argc, char** argv) {
             else if (mode == 1) hipLaunchKernelGGL(k_x4, dim3(N / 1024), dim3(256), 0, 0, d, N, alu);
             else if (mode == 3) hipLaunchKernelGGL(k_dword_nt<false>, dim3(N / 256), dim3(256), 0, 0, d, N, alu);
             else if (mode == 4) hipLaunchKernelGGL(k_dword_nt<true>, dim3(N / 256), dim3(256), 0, 0, d, N, alu);
+            else if (mode == 5) hipLaunchKernelGGL(k_two, dim3(N / 512), dim3(256), 0, 0, d, N, alu);
+            else if (mode == 6) hipLaunchKernelGGL(k_persistent, dim3(256 * 8), dim3(256), 0, 0, d, N, alu, N / 64);
             else hipLaunchKernelGGL(k_aos, dim3(N / 256), dim3(256), 0, 0, (float4*)d, N, alu);
         }
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
