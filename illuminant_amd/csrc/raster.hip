@@ -12,6 +12,7 @@
 #include <cstring>
 
 #include "internal.hpp"
+#include "bezier.hpp"
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -30,42 +31,6 @@ struct alignas(16) Sprite {
     uint32_t _pad;
 };
 static_assert(sizeof(Sprite) == 64, "Sprite is 16 words");
-
-ILM_DEV float bezier1_raster(const IlmClampedBezier1& bz, float value);
-
-// tForScaledBezier + evaluateBezier1 (Bezier.fxh:21-105): same restatement as particles.hip / the oracle
-ILM_DEV float raster_t_for_scaled_bezier(const IlmFloat4& rc, float value, float& t) {
-    const float inv_divisor = rc.y;
-    const unsigned mode = (unsigned)fabsf(rc.w);
-    t = (value - rc.x) * fabsf(inv_divisor);
-    if (mode > 511u) {
-        t *= 2.0f;
-        t = (inv_divisor < 0.0f) ? (2.0f - fmodf(t, 2.0f)) : fmodf(t, 2.0f);
-        if (t > 1.0f)
-            t = 1.0f - (t - 1.0f);
-    } else if (mode > 255u) {
-        t = (inv_divisor < 0.0f) ? (1.0f - fmodf(t, 1.0f)) : fmodf(t, 1.0f);
-    } else {
-        t = (inv_divisor < 0.0f) ? (1.0f - sat(t)) : sat(t);
-    }
-    const unsigned m = mode % 256u;
-    if (m == 1u)
-        t = sinf(t * kPi * 0.5f);
-    else if (m == 2u)
-        t = t * t;
-    return rc.z;
-}
-ILM_DEV float bezier1_raster(const IlmClampedBezier1& bz, float value) {
-    const float a = bz.ABCD.x, b = bz.ABCD.y, c = bz.ABCD.z, d = bz.ABCD.w;
-    if (bz.RangeAndCount.z <= 1.5f) return a;
-    float t;
-    const float count = raster_t_for_scaled_bezier(bz.RangeAndCount, value, t);
-    const float ab = lerp(a, b, t);
-    if (count <= 2.5f) return ab;
-    if (count <= 3.5f) return (t <= 0.0f) ? a : ((t >= 1.0f) ? c : b);
-    const float bc = lerp(b, c, t), cd = lerp(c, d, t);
-    return lerp(lerp(ab, bc, t), lerp(bc, cd, t), t);
-}
 
 // VS_PosVelAttr, RasterizeParticleSystem.fx:61-148, for one slot: the sprite record and the number of tiles its clipped bounding
 // box touches (0: dead, degenerate or off-screen).
@@ -107,7 +72,7 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(const RasterLaunch a)
                     const bool textured = p.BitmapFilter != ILM_BITMAP_NONE;
                     sp.r = base[12 * S + slot]; sp.g = base[13 * S + slot]; sp.b = base[14 * S + slot]; sp.a = base[15 * S + slot];
                     if (!textured) { sp.r *= p.GlobalColor.x; sp.g *= p.GlobalColor.y; sp.b *= p.GlobalColor.z; sp.a *= p.GlobalColor.w; }
-                    sp.rounding = clampf(bezier1_raster(p.RoundingPowerFromLife, life), 0.001f, 1.0f);
+                    sp.rounding = clampf(bezier1(p.RoundingPowerFromLife, life), 0.001f, 1.0f);
                     sp.frame_u = sp.frame_v = 0.0f;
                     if (textured) {
                         // frame selection, RasterizeParticleSystem.fx:112-139
