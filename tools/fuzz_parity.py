@@ -101,7 +101,60 @@ for seed in range(first, first + count):
     if problem:
         bad_step.append((seed, list(got_counts), list(want_counts)))
     sysm.close(); eng.close()
+# ---- distance-field generation (exact culling!) and the particle rasteriser, every 4th seed (the oracle side is slower) ------------------
+bad_field, bad_raster, field_texels, raster_worst = [], [], 0, 0
+for seed in range(first, first + count, 4):
+    rng = np.random.default_rng(seed + 77777)
+    ext = (int(rng.integers(64, 300)), int(rng.integers(64, 240)))
+    layout = scenes.DistanceFieldLayout(ext[0], ext[1], float(rng.uniform(32, 128)), int(rng.integers(3, 16)), float(rng.choice([1.0, 0.5, 0.3, 0.25])), 128)
+    obs = scenes.random_obstructions(seed, int(rng.integers(1, 40)), ext, size_lo=float(rng.uniform(2, 10)), size_hi=float(rng.uniform(12, 90)), z_hi=float(rng.uniform(8, 80)))
+    arr = scenes.obstruction_array(obs)
+    fmt = abi.SDF_FP16 if seed % 8 < 4 else abi.SDF_UNORM16
+    d = scenes.render_desc(layout)
+    triplets = list(range(0, layout.slice_count, 3))
+    sdf = native.DistanceFieldTexture(ctx, None, fmt, size=(layout.atlas_width, layout.atlas_height))
+    sdf.render_slices(d, triplets, arr, None, None)
+    got = sdf.download(); sdf.close()
+    want = oracle.render_distance_field_slices(np.zeros((layout.atlas_height, layout.atlas_width, 4), np.uint16), fmt, d, triplets, arr, None, None)
+    field_texels += got.size
+    if not np.array_equal(got, want):
+        bad_field.append((seed, int((got != want).sum())))
+    # rasteriser: random sprites, sometimes a bitmap
+    cs, w, h = 32, int(rng.integers(40, 200)), int(rng.integers(30, 150))
+    n = cs * cs
+    pos = np.zeros((n, 4), np.float32)
+    pos[:, 0] = rng.uniform(-10, w + 10, n); pos[:, 1] = rng.uniform(-10, h + 10, n); pos[:, 2] = rng.uniform(0, 6, n)
+    pos[:, 3] = np.where(rng.random(n) < 0.3, 0.0, rng.uniform(0.1, 3.0, n))
+    a = rng.uniform(0, 1, n); rgb = rng.uniform(0, 1, (n, 3))
+    col = np.concatenate([rgb * a[:, None], a[:, None]], axis=1).astype(np.float32)
+    rd = np.zeros((n, 4), np.float32); rd[:, 0] = rng.uniform(0, 9, n); rd[:, 1] = rng.uniform(-7, 20, n); rd[:, 3] = np.floor(rng.uniform(-1, 3, n))
+    chunk = [pos, np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32), col, rd]
+    textured = bool(rng.integers(0, 2))
+    sheet = rng.uniform(0, 1, (8, 16, 4)).astype(np.float32) if textured else None
+    params = scenes.rasterize_params(size=(float(rng.uniform(0.3, 2)), float(rng.uniform(0.3, 2))), rounded=bool(rng.integers(0, 2)),
+                                     blend=int(rng.integers(0, 2)), z_to_y=float(rng.uniform(0, 1)), size_from_z=float(rng.uniform(0, 0.1)),
+                                     texture_size=(16, 8) if textured else None, size_px=(4.0, 4.0) if textured else None,
+                                     bilinear=bool(rng.integers(0, 2)), animation_rate=(float(rng.uniform(-2, 2)), float(rng.uniform(-2, 2))),
+                                     column_from_velocity=bool(rng.integers(0, 2)), row_from_velocity=bool(rng.integers(0, 2)))
+    eng = native.Engine(ctx, cs, scenes.randomness_table(1)); sysm = native.System(eng); sysm.add_chunk()
+    sysm.upload(0, P, pos); sysm.upload(0, RC, col); sysm.upload(0, RD, rd)
+    if textured: sysm.set_bitmap(sheet)
+    lm = native.Lightmap(ctx, w, h, abi.LIGHTMAP_FLOAT4); lm.clear((0.1, 0.2, 0.3, 1.0))
+    live, pairs, shaded = native.render_particles(sysm, params, lm, want_stats=True)
+    gimg = lm.download(); lm.close(); sysm.close(); eng.close()
+    wimg = np.zeros((h, w, 4), np.float32); wimg[:] = (0.1, 0.2, 0.3, 1.0)
+    wimg, (olive, oshaded) = oracle.render_particles([chunk], params, w, h, image=wimg, bitmap=sheet)
+    err = np.abs(gimg.astype(np.float64) - wimg).max(axis=-1)
+    outliers = int((err > 1e-4 * np.maximum(1.0, np.abs(wimg).max(axis=-1))).sum())
+    raster_worst = max(raster_worst, outliers)
+    if live != olive or outliers > (40 if textured else 8) or abs(shaded - oshaded) > 8:
+        bad_raster.append((seed, live, olive, shaded, oshaded, outliers, textured))
+
 print("seeds %d..%d" % (first, first + count - 1))
+print("field generation: %d scenes with differing codes of %d (%.1f M texel channels compared)" % (len(bad_field), len(range(first, first + count, 4)), field_texels / 1e6))
+for b in bad_field[:10]: print("   ", b)
+print("rasteriser: %d scenes out of bounds; most edge pixels that flipped in one frame: %d" % (len(bad_raster), raster_worst))
+for b in bad_raster[:10]: print("   ", b)
 print("lighting: %d scenes with differing statistics or > 1e-4 error; worst relative error %.3g" % (len(bad_light), worst_l))
 for b in bad_light[:10]: print("   ", b)
 print("particles: %d steps with differing live counts / liveness; worst error relative to (|want| + 1e-4 scale) %.3g" % (len(bad_step), worst_s))
