@@ -404,6 +404,7 @@ PYBIND11_MODULE(_host, m) {
         VEC_PROP(SphereLightSource, SpecularColor, 3)
         .def_readwrite("SpecularPower", &SphereLightSource::SpecularPower)
         .def_readwrite("TextureRef", &SphereLightSource::TextureRef)
+        .def_readwrite("Quality", &SphereLightSource::Quality)
         .def_readwrite("RampOffset", &SphereLightSource::RampOffset).def_readwrite("RampRate", &SphereLightSource::RampRate);
     py::class_<ParticleLightSource>(m, "ParticleLightSource").def(py::init<>())
         .def_readwrite("Template", &ParticleLightSource::Template)
@@ -454,7 +455,7 @@ PYBIND11_MODULE(_host, m) {
         .def_readwrite("ZToYMultiplier", &LightingEnvironment::ZToYMultiplier)
         .def_readwrite("EnableGroundShadows", &LightingEnvironment::EnableGroundShadows)
         VEC_PROP(LightingEnvironment, Ambient, 4);
-    py::class_<RendererQualitySettings>(m, "RendererQualitySettings").def(py::init<>())
+    py::class_<RendererQualitySettings, std::shared_ptr<RendererQualitySettings>>(m, "RendererQualitySettings").def(py::init<>())
         .def_readwrite("MinStepSize", &RendererQualitySettings::MinStepSize).def_readwrite("LongStepFactor", &RendererQualitySettings::LongStepFactor)
         .def_readwrite("MaxStepCount", &RendererQualitySettings::MaxStepCount).def_readwrite("MaxConeRadius", &RendererQualitySettings::MaxConeRadius)
         .def_readwrite("ConeGrowthFactor", &RendererQualitySettings::ConeGrowthFactor)

@@ -1265,9 +1265,10 @@ void LightingRenderer::RenderLighting(float intensityScale, int rowBegin, int ro
     std::vector<const SphereLightSource*> sorted;
     for (const SphereLightSource& l : Environment->Lights) sorted.push_back(&l);
     std::stable_sort(sorted.begin(), sorted.end(), [](const SphereLightSource* x, const SphereLightSource* y) { return x->SortKey < y->SortKey; });
-    // GetLightRenderState (:799-845): lights that share a ramp texture form one render state; the states are drawn one after the
-    // other onto the same target (additive), in the order their keys first appear
+    // GetLightRenderState (:799-845): lights that share a ramp texture and quality settings form one render state (BlendState is
+    // additive for every light here); the states are drawn one after the other onto the same target, in the order their keys first appear
     groupKeys.clear();
+    groupQuality.clear();
     groups.clear();
     for (const SphereLightSource* l : sorted) {
         IlmLightVertex v;
@@ -1276,9 +1277,10 @@ void LightingRenderer::RenderLighting(float intensityScale, int rowBegin, int ro
         const RampTexture* ramp = l->TextureRef ? l->TextureRef.get() : Configuration.DefaultRampTexture.get();
         if (ramp && ((ramp->Width == 1 && ramp->Height == 1) || ramp->Width <= 0))
             ramp = nullptr;                                   // a 1 x 1 ramp is no ramp (:822-827)
+        const RendererQualitySettings* quality = l->Quality.get();
         size_t g = 0;
-        while (g < groupKeys.size() && groupKeys[g] != ramp) g++;
-        if (g == groupKeys.size()) { groupKeys.push_back(ramp); groups.emplace_back(); }
+        while (g < groupKeys.size() && !(groupKeys[g] == ramp && groupQuality[g] == quality)) g++;
+        if (g == groupKeys.size()) { groupKeys.push_back(ramp); groupQuality.push_back(quality); groups.emplace_back(); }
         groups[g].push_back(v);
         vertices.push_back(v);
     }
@@ -1287,13 +1289,14 @@ void LightingRenderer::RenderLighting(float intensityScale, int rowBegin, int ro
     // clear colour: Ambient * intensityScale (:1013-1024)
     const float ambient[4] = { Environment->Ambient.X * intensityScale, Environment->Ambient.Y * intensityScale,
                                Environment->Ambient.Z * intensityScale, Environment->Ambient.W * intensityScale };
-    if (groups.empty()) { groupKeys.push_back(nullptr); groups.emplace_back(); }     // no lights: the clear still happens
+    if (groups.empty()) { groupKeys.push_back(nullptr); groupQuality.push_back(nullptr); groups.emplace_back(); }     // no lights: the clear still happens
     if (stats) { stats->SdfSamples = stats->PixelLightPairs = stats->TracedPairs = 0; }
     for (size_t g = 0; g < groups.size(); g++) {
         BindRamp(groupKeys[g]);
         IlmRenderStats gs{};
+        const IlmDistanceFieldUniforms gdfu = groupQuality[g] ? GetDistanceFieldUniforms(*groupQuality[g]) : dfu;     // SetDistanceFieldParameters(material, true, ltrs.Key.Quality), :792
         ThrowIfFailed(ilm_render_sphere_lights(Context.Handle(), groups[g].empty() ? nullptr : groups[g].data(), (int32_t)groups[g].size(),
-                                               &env, &dfu, gbuffer, Field ? Field->Texture() : 0, (g == 0) ? ambient : nullptr, lightmap, rowBegin, rowEnd,
+                                               &env, &gdfu, gbuffer, Field ? Field->Texture() : 0, (g == 0) ? ambient : nullptr, lightmap, rowBegin, rowEnd,
                                                stats ? &gs : nullptr));
         if (stats) { stats->SdfSamples += gs.SdfSamples; stats->PixelLightPairs += gs.PixelLightPairs; stats->TracedPairs += gs.TracedPairs; }
     }
@@ -1368,8 +1371,9 @@ void LightingRenderer::UpdateLightProbes(float intensityScale) {
         if (groups[g].empty() && g > 0) continue;
         BindRamp(groupKeys[g]);
         std::vector<IlmFloat4> part((size_t)n);
+        const IlmDistanceFieldUniforms gdfu = groupQuality[g] ? GetDistanceFieldUniforms(*groupQuality[g]) : dfu;
         ThrowIfFailed(ilm_render_light_probes(Context.Handle(), groups[g].empty() ? nullptr : groups[g].data(), (int32_t)groups[g].size(),
-                                              positions.data(), normals.data(), n, &env, &dfu, Field ? Field->Texture() : 0, part.data()));
+                                              positions.data(), normals.data(), n, &env, &gdfu, Field ? Field->Texture() : 0, part.data()));
         for (int i = 0; i < n; i++) {
             values[(size_t)i].x += part[(size_t)i].x; values[(size_t)i].y += part[(size_t)i].y;
             values[(size_t)i].z += part[(size_t)i].z; values[(size_t)i].w += part[(size_t)i].w;

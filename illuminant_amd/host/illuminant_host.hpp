@@ -639,6 +639,8 @@ struct RampTexture {
     std::vector<IlmFloat4> Texels;
 };
 
+struct RendererQualitySettings;
+
 struct SphereLightSource {
     int SortKey = 0;          // LightSourceBase.SortKey: RenderLighting sorts by it first (LightSorter, LightingRenderer.cs:2066-2096)
     Vector3 Position;
@@ -654,6 +656,7 @@ struct SphereLightSource {
     Vector3 SpecularColor{0, 0, 0};
     float SpecularPower = 1;
     std::shared_ptr<RampTexture> TextureRef;      // LightSource.TextureRef; null => Configuration.DefaultRampTexture
+    std::shared_ptr<RendererQualitySettings> Quality;   // LightSource.Quality (LightSource.cs:95); null => Configuration.DefaultQuality
     float RampOffset = 0, RampRate = 1;           // RampOffsetAndRate, LightSource.cs:90
 };
 
@@ -833,6 +836,7 @@ private:
     std::vector<IlmLightVertex> vertices;
     // the light groups of the last RenderLighting (one per ramp texture) and the ramp currently bound on the context
     std::vector<const RampTexture*> groupKeys;
+    std::vector<const RendererQualitySettings*> groupQuality;     // null => Configuration.DefaultQuality
     std::vector<std::vector<IlmLightVertex>> groups;
     const RampTexture* boundRamp = nullptr;
     void BindRamp(const RampTexture* ramp);

@@ -253,3 +253,47 @@ def test_lighting_renderer_groups_lights_by_ramp_texture(H, hctx, oracle):
         first = False
     assert_close(got, want, "three ramp groups")
     assert [int(x) for x in stats] == totals
+
+
+def test_lighting_renderer_groups_lights_by_quality(H, hctx, oracle):
+    """LightSource.Quality (LightSource.cs:95) is part of the render-state key: lights with their own quality settings are traced with
+    those (SetDistanceFieldParameters(material, true, key.Quality), LightingRenderer.cs:792), the others with Configuration.DefaultQuality."""
+    w, h = 128, 80
+    env = H.LightingEnvironment()
+    env.Ambient = [0.02, 0.03, 0.04, 1.0]
+    lv = scenes.random_lights(29, 8, w, h, z=(8.0, 40.0), radius=8.0, ramp=(40.0, 90.0))
+    coarse = H.RendererQualitySettings(); coarse.MinStepSize = 4.0; coarse.LongStepFactor = 1.0; coarse.MaxStepCount = 12; coarse.MaxConeRadius = 8.0
+    coarse.OcclusionToOpacityPower = 1.0
+    lights, packed = [], {"default": [], "coarse": []}
+    for i in range(len(lv)):
+        l = H.SphereLightSource()
+        l.Position = [lv[i].LightPosition1.x, lv[i].LightPosition1.y, lv[i].LightPosition1.z]
+        l.Radius = lv[i].LightProperties.x; l.RampLength = lv[i].LightProperties.y
+        l.Color = [lv[i].Color1.x, lv[i].Color1.y, lv[i].Color1.z, 1.0]
+        if i % 2:
+            l.Quality = coarse
+        lights.append(l)
+        packed["coarse" if i % 2 else "default"].append(scenes.sphere_light(tuple(l.Position), l.Radius, l.RampLength, color=tuple(l.Color)))
+    env.Lights = lights
+    rc = H.RendererConfiguration(w, h)
+    rc.FloatLightmap = True
+    q = H.RendererQualitySettings(); q.MinStepSize = 1.0; q.LongStepFactor = 0.5; q.MaxStepCount = 64; q.MaxConeRadius = 24.0; q.OcclusionToOpacityPower = 0.7
+    rc.DefaultQuality = q
+    r = H.LightingRenderer(hctx, rc, env)
+    field = H.DistanceField(hctx, 256, 256, 64.0, 9, 0.5)
+    layout = scenes.DistanceFieldLayout(256, 256, 64.0, 9, 0.5)
+    atlas = scenes.build_sdf_atlas(layout, scenes.random_obstacles(5, 10, (256, 256), 6.0, 24.0, 40.0))
+    field.Load(atlas)
+    r.DistanceField = field
+    stats = r.RenderLighting(1.0, 0, -1, True)
+    got = r.ReadLightmap()
+    envu = abi.Environment.from_buffer_copy(r.GetEnvironmentUniformsBytes())
+    tex = oracle.make_texture(atlas, abi.SDF_UNORM16)
+    dfu_default = layout.uniforms(power=0.7, min_step_size=1.0, long_step_factor=0.5, step_limit=64, max_cone_radius=24.0)
+    dfu_coarse = layout.uniforms(power=1.0, min_step_size=4.0, long_step_factor=1.0, step_limit=12, max_cone_radius=8.0)
+    a0 = (abi.LightVertex * len(packed["default"]))(*packed["default"]); a1 = (abi.LightVertex * len(packed["coarse"]))(*packed["coarse"])
+    want0, s0 = oracle.render_sphere_lights(a0, envu, dfu_default, None, tex, tuple(env.Ambient), w, h, want_stats=True)
+    want1, s1 = oracle.render_sphere_lights(a1, envu, dfu_coarse, None, tex, (0.0, 0.0, 0.0, 0.0), w, h, want_stats=True)
+    assert_close(got, want0 + want1, "two quality groups")
+    assert [int(x) for x in stats] == [s0.SdfSamples + s1.SdfSamples, s0.PixelLightPairs + s1.PixelLightPairs, s0.TracedPairs + s1.TracedPairs]
+    assert s1.SdfSamples < s0.SdfSamples          # the coarse group really traced with fewer, longer steps
