@@ -389,7 +389,7 @@ PYBIND11_MODULE(_host, m) {
             return t; }))
         .def_readonly("Width", &RampTexture::Width).def_readonly("Height", &RampTexture::Height);
     py::class_<SphereLightSource>(m, "SphereLightSource").def(py::init<>())
-        .def_readwrite("SortKey", &SphereLightSource::SortKey)
+        .def_readwrite("SortKey", &SphereLightSource::SortKey).def_readwrite("Enabled", &SphereLightSource::Enabled)
         VEC_PROP(SphereLightSource, Position, 3)
         .def_readwrite("Radius", &SphereLightSource::Radius).def_readwrite("RampLength", &SphereLightSource::RampLength)
         VEC_PROP(SphereLightSource, Color, 4)
@@ -406,6 +406,19 @@ PYBIND11_MODULE(_host, m) {
         .def_readwrite("TextureRef", &SphereLightSource::TextureRef)
         .def_readwrite("Quality", &SphereLightSource::Quality)
         .def_readwrite("RampOffset", &SphereLightSource::RampOffset).def_readwrite("RampRate", &SphereLightSource::RampRate);
+    py::class_<ReplicatedLight>(m, "ReplicatedLight").def(py::init<>())
+        VEC_PROP(ReplicatedLight, Position, 3)
+        .def_readwrite("Radius", &ReplicatedLight::Radius).def_readwrite("RampLength", &ReplicatedLight::RampLength)
+        .def_readwrite("SpecularPower", &ReplicatedLight::SpecularPower).def_readwrite("Opacity", &ReplicatedLight::Opacity)
+        .def_property("Color", [](const ReplicatedLight& l) -> py::object { if (!l.Color) return py::none(); return py::make_tuple(l.Color->X, l.Color->Y, l.Color->Z, l.Color->W); },
+                      [](ReplicatedLight& l, py::object v) { if (v.is_none()) { l.Color.reset(); return; } auto t = v.cast<std::vector<float>>(); l.Color = Vector4{t.at(0), t.at(1), t.at(2), t.at(3)}; })
+        .def_property("SpecularColor", [](const ReplicatedLight& l) -> py::object { if (!l.SpecularColor) return py::none(); return py::make_tuple(l.SpecularColor->X, l.SpecularColor->Y, l.SpecularColor->Z); },
+                      [](ReplicatedLight& l, py::object v) { if (v.is_none()) { l.SpecularColor.reset(); return; } auto t = v.cast<std::vector<float>>(); l.SpecularColor = Vector3{t.at(0), t.at(1), t.at(2)}; });
+    py::class_<LightSourceReplicator>(m, "LightSourceReplicator").def(py::init<>())
+        .def_readwrite("SortKey", &LightSourceReplicator::SortKey).def_readwrite("Enabled", &LightSourceReplicator::Enabled)
+        .def_readwrite("Template", &LightSourceReplicator::Template)
+        .def_readwrite("Lights", &LightSourceReplicator::Lights)
+        .def("Clear", &LightSourceReplicator::Clear).def("Add", &LightSourceReplicator::Add);
     py::class_<ParticleLightSource>(m, "ParticleLightSource").def(py::init<>())
         .def_readwrite("Template", &ParticleLightSource::Template)
         .def_property("System", py::cpp_function([](ParticleLightSource& s) { return s.System; }, py::return_value_policy::reference),
@@ -448,6 +461,7 @@ PYBIND11_MODULE(_host, m) {
         .def_readwrite("TopFaceEnableShadows", &HeightVolume::TopFaceEnableShadows);
     py::class_<LightingEnvironment>(m, "LightingEnvironment").def(py::init<>())
         .def_readwrite("Lights", &LightingEnvironment::Lights)
+        .def_readwrite("Replicators", &LightingEnvironment::Replicators)
         .def_readwrite("ParticleLights", &LightingEnvironment::ParticleLights)
         .def_property_readonly("Obstructions", [](LightingEnvironment& e) -> LightObstructionCollection& { return e.Obstructions; }, py::return_value_policy::reference_internal)
         .def_readwrite("HeightVolumes", &LightingEnvironment::HeightVolumes)
@@ -570,6 +584,9 @@ PYBIND11_MODULE(_host, m) {
         .def_property_readonly("LightmapFormat", &LightingRenderer::LightmapFormat)
         .def("GetDistanceFieldUniformsBytes", [](const LightingRenderer& r) {
             auto u = r.GetDistanceFieldUniforms(r.Configuration.DefaultQuality); return py::bytes((const char*)&u, sizeof(u)); })
+        .def("GetPackedLightVertices", [](const LightingRenderer& r) {
+            const auto& v = r.PackedLightVertices(); return py::bytes((const char*)v.data(), v.size() * sizeof(IlmLightVertex)); })
+        .def_property_readonly("LastLightCount", [](const LightingRenderer& r) { return r.PackedLightVertices().size(); })
         .def("GetEnvironmentUniformsBytes", [](const LightingRenderer& r) { auto u = r.GetEnvironmentUniforms(); return py::bytes((const char*)&u, sizeof(u)); })
         .def_static("PackSphereLightBytes", [](const SphereLightSource& l, float intensityScale, bool haveDF) -> py::object {
             IlmLightVertex v;

@@ -1261,28 +1261,62 @@ void LightingRenderer::RenderLighting(float intensityScale, int rowBegin, int ro
     if (rowEnd < 0) rowEnd = Configuration.RenderHeight;
     vertices.clear();
     // LightSorter (:2066-2096): SortKey first; blend mode, ramp texture and type are the same for every light of this pass.  The
-    // reference's sort is not stable for equal keys; a stable one keeps list order, which is one of its possible outcomes.
-    std::vector<const SphereLightSource*> sorted;
-    for (const SphereLightSource& l : Environment->Lights) sorted.push_back(&l);
-    std::stable_sort(sorted.begin(), sorted.end(), [](const SphereLightSource* x, const SphereLightSource* y) { return x->SortKey < y->SortKey; });
+    // reference's sort is not stable for equal keys; a stable one keeps list order, which is one of its possible outcomes
+    // (Lights before Replicators here, since the mirror holds them in two lists).
+    struct Entry { int sortKey; const SphereLightSource* sphere; const LightSourceReplicator* replicator; };
+    std::vector<Entry> sorted;
+    for (const SphereLightSource& l : Environment->Lights)
+        if (l.Enabled) sorted.push_back({ l.SortKey, &l, nullptr });
+    for (const LightSourceReplicator& r : Environment->Replicators)
+        if (r.Enabled) sorted.push_back({ r.SortKey, nullptr, &r });
+    std::stable_sort(sorted.begin(), sorted.end(), [](const Entry& x, const Entry& y) { return x.sortKey < y.sortKey; });
     // GetLightRenderState (:799-845): lights that share a ramp texture and quality settings form one render state (BlendState is
-    // additive for every light here); the states are drawn one after the other onto the same target, in the order their keys first appear
+    // additive for every light here); the states are drawn one after the other onto the same target, in the order their keys first appear.
+    // A replicator takes its state from its Template (:802).
     groupKeys.clear();
     groupQuality.clear();
     groups.clear();
-    for (const SphereLightSource* l : sorted) {
-        IlmLightVertex v;
-        if (!PackSphereLight(*l, intensityScale, Field != nullptr, v))
-            continue;
-        const RampTexture* ramp = l->TextureRef ? l->TextureRef.get() : Configuration.DefaultRampTexture.get();
+    auto groupFor = [&](const SphereLightSource& l) -> size_t {
+        const RampTexture* ramp = l.TextureRef ? l.TextureRef.get() : Configuration.DefaultRampTexture.get();
         if (ramp && ((ramp->Width == 1 && ramp->Height == 1) || ramp->Width <= 0))
             ramp = nullptr;                                   // a 1 x 1 ramp is no ramp (:822-827)
-        const RendererQualitySettings* quality = l->Quality.get();
+        const RendererQualitySettings* quality = l.Quality.get();
         size_t g = 0;
         while (g < groupKeys.size() && !(groupKeys[g] == ramp && groupQuality[g] == quality)) g++;
         if (g == groupKeys.size()) { groupKeys.push_back(ramp); groupQuality.push_back(quality); groups.emplace_back(); }
-        groups[g].push_back(v);
-        vertices.push_back(v);
+        return g;
+    };
+    for (const Entry& e : sorted) {
+        IlmLightVertex v;
+        if (e.sphere) {
+            if (!PackSphereLight(*e.sphere, intensityScale, Field != nullptr, v))
+                continue;
+            groups[groupFor(*e.sphere)].push_back(v);
+            vertices.push_back(v);
+            continue;
+        }
+        // RenderReplicatorLightSource (:1221-1255): the template's packed vertex with position / colour / radius / ramp length /
+        // specular replaced per placement; a placement whose final alpha is <= 0 is dropped
+        const SphereLightSource& t = e.replicator->Template;
+        SphereLightSource visible = t;
+        visible.Opacity = 1;                                  // the template's own Opacity only matters through the per-placement product
+        PackSphereLight(visible, intensityScale, Field != nullptr, v);
+        const size_t g = groupFor(t);
+        for (const ReplicatedLight& rl : e.replicator->Lights) {
+            const Vector4 color = rl.Color.value_or(t.Color);
+            const float alpha = color.W * (rl.Opacity.value_or(t.Opacity) * intensityScale);
+            if (alpha <= 0)
+                continue;
+            const Vector3 spec = rl.SpecularColor.value_or(t.SpecularColor);
+            const IlmFloat4 pos = { rl.Position.X, rl.Position.Y, rl.Position.Z, 0 };
+            v.LightPosition1 = v.LightPosition2 = v.LightPosition3 = pos;
+            v.Color1 = { color.X, color.Y, color.Z, alpha };
+            v.Color2 = { spec.X, spec.Y, spec.Z, rl.SpecularPower.value_or(t.SpecularPower) };
+            v.LightProperties.x = rl.Radius.value_or(t.Radius);
+            v.LightProperties.y = rl.RampLength.value_or(t.RampLength);
+            groups[g].push_back(v);
+            vertices.push_back(v);
+        }
     }
     const IlmEnvironment env = GetEnvironmentUniforms();
     const IlmDistanceFieldUniforms dfu = GetDistanceFieldUniforms(Configuration.DefaultQuality);

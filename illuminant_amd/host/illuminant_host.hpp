@@ -643,6 +643,7 @@ struct RendererQualitySettings;
 
 struct SphereLightSource {
     int SortKey = 0;          // LightSourceBase.SortKey: RenderLighting sorts by it first (LightSorter, LightingRenderer.cs:2066-2096)
+    bool Enabled = true;      // LightSourceBase.Enabled (LightSource.cs:42): disabled lights are skipped (LightingRenderer.cs:1062)
     Vector3 Position;
     float Radius = 0, RampLength = 1;
     Vector4 Color{1, 1, 1, 1};
@@ -658,6 +659,23 @@ struct SphereLightSource {
     std::shared_ptr<RampTexture> TextureRef;      // LightSource.TextureRef; null => Configuration.DefaultRampTexture
     std::shared_ptr<RendererQualitySettings> Quality;   // LightSource.Quality (LightSource.cs:95); null => Configuration.DefaultQuality
     float RampOffset = 0, RampRate = 1;           // RampOffsetAndRate, LightSource.cs:90
+};
+
+// ReplicatedLight / LightSourceReplicator, LightSource.cs:601-620: one template, many placements.  Each placement may override the
+// per-light values; everything else (ramp mode, shadows, AO, falloff, ramp texture, quality) comes from the template.
+struct ReplicatedLight {
+    Vector3 Position;
+    std::optional<float> Radius, RampLength, SpecularPower, Opacity;
+    std::optional<Vector4> Color;
+    std::optional<Vector3> SpecularColor;
+};
+struct LightSourceReplicator {
+    int SortKey = 0;
+    bool Enabled = true;
+    SphereLightSource Template;
+    std::vector<ReplicatedLight> Lights;
+    void Clear() { Lights.clear(); }
+    void Add(const ReplicatedLight& l) { Lights.push_back(l); }
 };
 
 // ParticleLightSource, LightSource.cs:466-505
@@ -745,6 +763,7 @@ struct HeightVolume {
 // LightingEnvironment.cs:13-49
 struct LightingEnvironment {
     std::vector<SphereLightSource> Lights;
+    std::vector<LightSourceReplicator> Replicators;    // LightSourceReplicator entries of Lights in the reference
     std::vector<ParticleLightSource> ParticleLights;   // ParticleLightSource entries of Lights in the reference (one render state each)
     LightObstructionCollection Obstructions;
     std::vector<HeightVolume> HeightVolumes;
@@ -825,6 +844,8 @@ public:
     IlmDistanceFieldUniforms GetDistanceFieldUniforms(const RendererQualitySettings& q) const;
     // ComputeUniforms :691-701 + SetGBufferParameters LightingRenderer.GBuffer.cs:520-534
     IlmEnvironment GetEnvironmentUniforms() const;
+    // the LightVertex stream of the last RenderLighting, in draw order (LightTypeRenderState.LightVertices)
+    const std::vector<IlmLightVertex>& PackedLightVertices() const { return vertices; }
 
 private:
     void UpdateLightProbes(float intensityScale);   // LightingRenderer.LightProbes.cs:49-150 (synchronous read-back)

@@ -297,3 +297,78 @@ def test_lighting_renderer_groups_lights_by_quality(H, hctx, oracle):
     assert_close(got, want0 + want1, "two quality groups")
     assert [int(x) for x in stats] == [s0.SdfSamples + s1.SdfSamples, s0.PixelLightPairs + s1.PixelLightPairs, s0.TracedPairs + s1.TracedPairs]
     assert s1.SdfSamples < s0.SdfSamples          # the coarse group really traced with fewer, longer steps
+
+
+def test_light_source_replicator_expands_the_template(H, hctx, oracle):
+    """LightSourceReplicator (LightSource.cs:601-620) draws its Template once per ReplicatedLight with the per-placement overrides
+    (RenderReplicatorLightSource, LightingRenderer.cs:1221-1255); placements whose alpha ends up <= 0 are dropped, disabled lights are
+    skipped (:1062), and SortKey orders replicators among the other lights."""
+    w, h = 144, 88
+    env = H.LightingEnvironment()
+    env.Ambient = [0.03, 0.03, 0.05, 1.0]
+    lv = scenes.random_lights(33, 14, w, h, z=(6.0, 36.0), radius=6.0, ramp=(30.0, 70.0))
+    rep = H.LightSourceReplicator()
+    rep.SortKey = -1                                  # ahead of the plain lights although it lives in its own list
+    t = rep.Template
+    t.Radius = 5.0; t.RampLength = 45.0; t.RampMode = 1; t.Opacity = 0.8; t.Color = [0.9, 0.7, 0.5, 1.0]
+    t.AmbientOcclusionRadius = 10.0; t.AmbientOcclusionOpacity = 0.6; t.FalloffYFactor = 1.5
+    t.SpecularColor = [0.2, 0.2, 0.3]; t.SpecularPower = 6.0
+    rep.Template = t
+    tkw = dict(ramp_mode=1, ao_radius=10.0, ao_opacity=0.6, falloff_y=1.5)
+    packed = []
+    for i in range(11):
+        rl = H.ReplicatedLight()
+        pos = (lv[i].LightPosition1.x, lv[i].LightPosition1.y, lv[i].LightPosition1.z)
+        rl.Position = list(pos)
+        radius, ramp, color, opacity, spec, power = 5.0, 45.0, (0.9, 0.7, 0.5, 1.0), 0.8, (0.2, 0.2, 0.3), 6.0
+        if i % 2:
+            radius = rl.Radius = 3.0 + i
+        if i % 3 == 0:
+            ramp = rl.RampLength = 60.0
+        if i % 4 == 1:
+            color = (lv[i].Color1.x, lv[i].Color1.y, lv[i].Color1.z, 0.9); rl.Color = list(color)
+        if i % 5 == 2:
+            spec = (0.5, 0.1, 0.1); rl.SpecularColor = list(spec); power = rl.SpecularPower = 12.0
+        if i == 4:
+            opacity = rl.Opacity = 0.0              # dropped: colour.W <= 0
+        if i == 6:
+            opacity = rl.Opacity = 0.35
+        rep.Add(rl)
+        if opacity > 0:
+            packed.append(scenes.sphere_light(pos, radius, ramp, color=color, opacity=opacity, specular=spec, specular_power=power, **tkw))
+    assert len(rep.Lights) == 11 and rep.Lights[1].Radius == 4.0 and rep.Lights[0].Radius is None and rep.Lights[0].Color is None
+    env.Replicators = [rep]
+    lights = []
+    for i in range(11, 14):
+        l = H.SphereLightSource()
+        l.Position = [lv[i].LightPosition1.x, lv[i].LightPosition1.y, lv[i].LightPosition1.z]
+        l.Radius = lv[i].LightProperties.x; l.RampLength = lv[i].LightProperties.y
+        l.Color = [lv[i].Color1.x, lv[i].Color1.y, lv[i].Color1.z, 1.0]
+        l.Enabled = i != 12
+        lights.append(l)
+        if l.Enabled:
+            packed.append(scenes.sphere_light(tuple(l.Position), l.Radius, l.RampLength, color=tuple(l.Color)))
+    env.Lights = lights
+    off = H.LightSourceReplicator(); off.Enabled = False; off.Add(H.ReplicatedLight())
+    env.Replicators = [rep, off]
+    rc = H.RendererConfiguration(w, h)
+    rc.FloatLightmap = True
+    q = H.RendererQualitySettings(); q.MinStepSize = 1.0; q.LongStepFactor = 0.5; q.MaxStepCount = 64; q.MaxConeRadius = 24.0; q.OcclusionToOpacityPower = 0.7
+    rc.DefaultQuality = q
+    r = H.LightingRenderer(hctx, rc, env)
+    field = H.DistanceField(hctx, 256, 256, 64.0, 9, 0.5)
+    layout = scenes.DistanceFieldLayout(256, 256, 64.0, 9, 0.5)
+    atlas = scenes.build_sdf_atlas(layout, scenes.random_obstacles(6, 10, (256, 256), 6.0, 24.0, 40.0))
+    field.Load(atlas)
+    r.DistanceField = field
+    stats = r.RenderLighting(1.0, 0, -1, True)
+    got = r.ReadLightmap()
+    assert r.LastLightCount == len(packed) == 12
+    dfu = abi.DistanceFieldUniforms.from_buffer_copy(r.GetDistanceFieldUniformsBytes())
+    envu = abi.Environment.from_buffer_copy(r.GetEnvironmentUniformsBytes())
+    arr = (abi.LightVertex * len(packed))(*packed)
+    assert bytes(r.GetPackedLightVertices()) == bytes(arr)       # the vertex stream itself, byte for byte and in draw order
+    want, wstats = oracle.render_sphere_lights(arr, envu, dfu, None, oracle.make_texture(atlas, abi.SDF_UNORM16), tuple(env.Ambient), w, h,
+                                               want_stats=True)
+    assert_close(got, want, "lightmap with a replicator")
+    assert tuple(int(x) for x in stats) == (wstats.SdfSamples, wstats.PixelLightPairs, wstats.TracedPairs)
