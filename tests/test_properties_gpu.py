@@ -245,3 +245,37 @@ def test_cfg5_4k_256_lights_fp16_properties(ctx, oracle):
     assert stats.SdfSamples > 5_000_000
     assert_close(whole[b0:b1], want[b0:b1], "cfg5 crop vs oracle")
     sdf.close()
+
+
+def test_largest_chunk_size_indexes_every_slot(ctx, oracle):
+    """ilm_engine_create's upper bound: one chunk of 4096^2 = 2^24 slots (the largest count a float slot index still holds exactly,
+    ChunkSizeAndIndices carries indices as floats; 268 MB per plane).  Gravity + Noise (64 units per row: the per-slot lookup path, not the
+    host-evaluated run tables) + UpdatePositions, and a spawn range that ends on the chunk's very last slot; the oracle replays the chunk."""
+    cs = 4096
+    n = cs * cs
+    rnd = scenes.randomness_table(7)
+    eng = native.Engine(ctx, cs, rnd)
+    with pytest.raises(native.IlluminantError):
+        native.Engine(ctx, cs + 1, rnd)
+    sysm = native.System(eng)
+    sysm.add_chunk()
+    pos, vel, attr = scenes.make_particles(77, n, pos_lo=(0, 0, 0), pos_hi=(1920, 1080, 32), life=(0.01, 0.4), dead_fraction=0.3)
+    pos[n - 5000:, 3] = 0.0                       # room for the spawner at the end of the chunk
+    sysm.upload(0, P, pos); sysm.upload(0, V, vel); sysm.upload(0, A, attr)
+    chunk = [pos, vel, attr, np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)]
+    d = cfg2_step(cs, spawn_chunk=0, first=n - 3000, last=n - 1)
+    d.System = scenes.system_uniforms(cs, friction=0.02, max_velocity=2048.0, life_decay=4.0)
+    sysm.step(d)
+    want_counts = oracle.step([chunk], cs, rnd, d, want_counts=True)
+    assert np.array_equal(sysm.step_counts(), want_counts)
+    got_p = sysm.download(0, P)
+    assert np.array_equal(got_p[:, 3] > 0, chunk[0][:, 3] > 0)
+    assert (got_p[n - 3000:, 3] > 0).all() and not (got_p[n - 5000:n - 3000, 3] > 0).any()
+    m = chunk[0][:, 3] > 0
+    assert_close(got_p[m], chunk[0][m], "4096^2 chunk: position/life")
+    del got_p
+    for k, pl in ((1, V), (3, RC), (4, RD)):
+        got = sysm.download(0, pl)
+        assert_close(got[m], chunk[k][m], "4096^2 chunk: plane %d" % k)
+        del got
+    sysm.close(); eng.close()
