@@ -143,7 +143,7 @@ struct System {
     bool counts_valid = false;   // h_counts holds (or is about to receive) the counts of the last counting step
 };
 
-SdfView make_sdf_view(const Sdf* f) {
+SdfView make_sdf_view(const Sdf* f, const IlmDistanceFieldUniforms* df) {
     SdfView v;
     v.texels = f ? f->texels : nullptr;
     v.width = f ? f->width : 0;
@@ -152,6 +152,17 @@ SdfView make_sdf_view(const Sdf* f) {
     v.wf = (float)v.width;
     v.hf = (float)v.height;
     v.inv_wf = v.width > 0 ? 1.0f / v.wf : 0.0f;
+    // The sampler's single-step U wrap needs every tap column below 2^22 (hlsl_math.hpp); the largest column these uniforms can produce
+    // is (floor(maxSlice) / 3 * sliceU + extentX * texelU) * width.  Anything at or above 2^20 (or not finite) keeps the two-fold wrap.
+    v.wrap_half = 0.0f;
+    if (df && v.width > 0) {
+        const double third_max = std::floor(std::fabs((double)df->Packed1.z * (double)df->Packed1.y)) / 3.0 + 1.0;
+        const double u_max = third_max * std::fabs((double)df->TextureSliceAndTexelSize.x) +
+                             std::fabs((double)df->Extent.x * (double)df->TextureSliceAndTexelSize.z) + 1.0;
+        const double x_max = u_max * (double)v.width;
+        if (x_max == x_max && x_max < 1048576.0)
+            v.wrap_half = 0.5f * v.inv_wf;
+    }
     return v;
 }
 
@@ -515,7 +526,7 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
             a.source_base[k] = from_handle<System>(d->Spawns[k].Feedback.SourceSystem, kMagicSystem)->chunks[(size_t)d->Spawns[k].Feedback.SourceChunkIndex];
     }
     a.ramp = s->ramp; a.ramp_w = s->ramp_w; a.ramp_h = s->ramp_h;
-    a.sdf = make_sdf_view(from_handle<Sdf>(s->sdf_handle, kMagicSdf));
+    a.sdf = make_sdf_view(from_handle<Sdf>(s->sdf_handle, kMagicSdf), &d->DistanceField);
     a.live_counts = counting ? s->counts_region(region) : nullptr;
     a.zero_counts = counting ? s->counts_region(region ^ 1) : nullptr;
     a.zero_n = counting ? (int32_t)s->counts_cap : 0;   // every entry, so chunk-table growth after a shrink never meets stale counts
@@ -1215,8 +1226,28 @@ int32_t ilm_sdf_sample(IlmHandle h, const IlmDistanceFieldUniforms* df, const fl
     float* d_in = static_cast<float*>(c->staging);
     float* d_out = d_in + 3 * (size_t)count;
     HIP_TRY(hipMemcpyAsync(d_in, positions, in_bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(launch_sdf_sample(make_sdf_view(f), *df, d_in, count, d_out, c->stream));
+    HIP_TRY(launch_sdf_sample(make_sdf_view(f, df), *df, d_in, count, d_out, c->stream));
     HIP_TRY(hipMemcpyAsync(out_distances, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ILM_OK;
+}
+
+int32_t ilm_debug_divide(IlmHandle hctx, const float* numerators, const float* denominators, int32_t count, float* out_fast, float* out_ieee) {
+    Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);
+    if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
+    if (count < 0 || (count > 0 && (!numerators || !denominators || !out_fast || !out_ieee))) return fail(ILM_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (count == 0) return ILM_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t bytes = sizeof(float) * (size_t)count;
+    int32_t rc = ensure_staging(c, 4 * bytes);
+    if (rc != ILM_OK) return rc;
+    float* d_n = static_cast<float*>(c->staging);
+    float* d_d = d_n + count; float* d_f = d_d + count; float* d_i = d_f + count;
+    HIP_TRY(hipMemcpyAsync(d_n, numerators, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(d_d, denominators, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_divide_probe(d_n, d_d, count, d_f, d_i, c->stream));
+    HIP_TRY(hipMemcpyAsync(out_fast, d_f, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out_ieee, d_i, bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return ILM_OK;
 }
@@ -1575,7 +1606,7 @@ int32_t fill_light_launch(Ctx* c, const IlmEnvironment* env, const IlmDistanceFi
     a->env = *env; a->df = *df;
     a->gbuffer.texels = g ? g->texels : nullptr;
     a->gbuffer.width = g ? g->width : 0; a->gbuffer.height = g ? g->height : 0; a->gbuffer.format = g ? g->format : 0;
-    a->sdf = make_sdf_view(f);
+    a->sdf = make_sdf_view(f, df);
     for (int i = 0; i < 4; i++) a->ambient[i] = 0.0f;
     a->lightmap = m->texels; a->width = m->width; a->height = m->height; a->format = m->format;
     a->row_begin = row_begin; a->row_end = row_end;
@@ -1714,7 +1745,7 @@ int32_t ilm_render_light_probes(IlmHandle hctx, const IlmLightVertex* lights, in
     if (rc != ILM_OK) return rc;
     rc = upload_small(c, d_nrm, probe_normals, sizeof(float4) * (size_t)probe_count);
     if (rc != ILM_OK) return rc;
-    HIP_TRY(launch_light_probes(c->d_recs, light_count, d_pos, d_nrm, probe_count, *env, *df, make_sdf_view(f),
+    HIP_TRY(launch_light_probes(c->d_recs, light_count, d_pos, d_nrm, probe_count, *env, *df, make_sdf_view(f, df),
                                 RampView{ c->d_light_ramp, c->light_ramp_w, c->light_ramp_h }, d_val, c->stream));
     HIP_TRY(hipMemcpyAsync(out_values, d_val, sizeof(float4) * (size_t)probe_count, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -2031,7 +2062,7 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
     a.df = *df;
     a.gbuffer.texels = g ? g->texels : nullptr;
     a.gbuffer.width = g ? g->width : 0; a.gbuffer.height = g ? g->height : 0; a.gbuffer.format = g ? g->format : 0;
-    a.sdf = make_sdf_view(f);
+    a.sdf = make_sdf_view(f, df);
     for (int i = 0; i < 4; i++) a.ambient[i] = ambient ? ambient[i] : 0.0f;
     a.lightmap = m->texels; a.width = m->width; a.height = m->height; a.format = m->format;
     a.row_begin = row_begin; a.row_end = row_end;

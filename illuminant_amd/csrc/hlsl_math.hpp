@@ -103,6 +103,7 @@ struct SdfView {
     int format;            // ILM_SDF_UNORM16 / ILM_SDF_FP16
     float wf, hf;          // (float)width, (float)height
     float inv_wf;          // 1 / wf (seed of the exact integer wrap; any value within 1 ulp works)
+    float wrap_half;       // 0.5 * inv_wf when every tap column this field can ask for stays below 2^20 (make_sdf_view), else 0
 };
 
 // x / 65535 for an integer-valued x in [0, 65535], correctly rounded: one multiply by fl(1/65535) and one
@@ -145,7 +146,25 @@ ILM_DEV void sdf_unpack_word(uint32_t w, float& a, float& b) {
 // CHECK_NAN = false: the caller guarantees finite coordinates (the cone trace hoists the test out of its loop).
 ILM_DEV float lerp_fused(float a, float b, float t) { return __builtin_fmaf(t, b - a, a); }
 
-template <int FORMAT, bool CHECK_NAN = true>
+// n / d, correctly rounded, for 2^-60 <= |d| <= 2^60 and |n| <= 2^60 (or zero / infinite / NaN): the instruction sequence the
+// compiler emits for an IEEE division without its two v_div_scale_f32 -- inside that range they do not scale (the scaled and
+// unscaled operands are the same bits, v_div_fmas_f32 applies no post-scale), so every intermediate is identical; v_div_fixup_f32
+// still patches the zero / infinite / NaN operands.  Checked against `/` on the device by tests/test_sdf_sample_gpu.py.
+ILM_DEV float div_no_scale(float n, float d) {
+    float y = __builtin_amdgcn_rcpf(d);
+    const float e = __builtin_fmaf(-d, y, 1.0f);
+    y = __builtin_fmaf(e, y, y);
+    float q = n * y;
+    float r = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(r, y, q);
+    r = __builtin_fmaf(-d, q, n);
+    q = __builtin_fmaf(r, y, q);
+    return __builtin_amdgcn_div_fixupf(q, d, n);
+}
+
+// INSIDE = true: the caller guarantees 0 <= position <= extent on every axis (after the z offset), so the clamp is the identity and
+// the distance to the volume is +0 -- the same values the general form computes there, without computing them.
+template <int FORMAT, bool CHECK_NAN = true, bool INSIDE = false>
 ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms& df, const SdfView& sdf) {
 #pragma clang fp contract(off)
     position.z -= df.ConeAndMisc.y;
@@ -160,21 +179,23 @@ ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms&
         position.y = (position.y != position.y) ? 0.0f : position.y;
         position.z = (position.z != position.z) ? 0.0f : position.z;
     }
-    const float cx = __builtin_amdgcn_fmed3f(position.x, 0.0f, ex), cy = __builtin_amdgcn_fmed3f(position.y, 0.0f, ey),
-                cz = __builtin_amdgcn_fmed3f(position.z, 0.0f, ez);
-    const f3 dtv = mk3(position.x - cx, position.y - cy, position.z - cz);
-    const float d2 = __builtin_fmaf(dtv.z, dtv.z, __builtin_fmaf(dtv.y, dtv.y, dtv.x * dtv.x));
+    float cx = position.x, cy = position.y, cz = position.z;
     float distance_to_volume = 0.0f;                 // sqrt(+0) == +0: skipping it inside the volume is exact
-    if (__builtin_amdgcn_ballot_w64(d2 != 0.0f) != 0ull) {
-        asm volatile("" ::: "memory");               // keep this a (wave-uniform) branch: if-conversion would run the sqrt every time
-        distance_to_volume = sqrtf(d2);
+    if (!INSIDE) {
+        cx = __builtin_amdgcn_fmed3f(position.x, 0.0f, ex); cy = __builtin_amdgcn_fmed3f(position.y, 0.0f, ey);
+        cz = __builtin_amdgcn_fmed3f(position.z, 0.0f, ez);
+        const f3 dtv = mk3(position.x - cx, position.y - cy, position.z - cz);
+        const float d2 = __builtin_fmaf(dtv.z, dtv.z, __builtin_fmaf(dtv.y, dtv.y, dtv.x * dtv.x));
+        if (__builtin_amdgcn_ballot_w64(d2 != 0.0f) != 0ull) {
+            asm volatile("" ::: "memory");               // keep this a (wave-uniform) branch: if-conversion would run the sqrt every time
+            distance_to_volume = sqrtf(d2);
+        }
     }
 
     const float slice_position = (CHECK_NAN ? fminf(cz, df.Packed1.z) : __builtin_elementwise_minimum(cz, df.Packed1.z)) * df.Packed1.y;   // cz is finite
     const float vslice = floorf(slice_position);
     const uint32_t vi = (uint32_t)vslice;                    // 0 <= vslice < 65536
     const uint32_t third = __umul24(vi, 0xAAABu) >> 17;      // vi / 3 (24-bit multiply: full rate)
-    const uint32_t m = vi - 3u * third;                      // vi % 3
 
     const float column_index = (float)third;                 // floor(vslice / 3)
     const float row_index = floorf(vslice * df.Packed1.x);   // floor(vslice * invCols / 3): the reference's float form
@@ -190,7 +211,12 @@ ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms&
     // the first, DistanceFieldCommon.fxh:303-311): a positive modulo of x0f by the atlas width.  q may be off by one after the
     // reciprocal multiply; the remainder x0f - q * width is exact in fp32 and is folded back into [0, width).
     int x0;
-    {
+    if (sdf.wrap_half > 0.0f) {
+        // (x0f + 0.5) / width is at least 0.5 / width away from every integer, and fl(x0f * inv_wf + 0.5 * inv_wf) is within
+        // (x0f + 0.5) / width * 2^-23 of it: for x0f < 2^22 the floor is the exact quotient and no fold is needed.  x0f >= -1 (u >= 0).
+        const float q = floorf(__builtin_fmaf(x0f, sdf.inv_wf, sdf.wrap_half));
+        x0 = (int)__builtin_fmaf(-q, sdf.wf, x0f);
+    } else {
         const float q = floorf(x0f * sdf.inv_wf);
         float r = __builtin_fmaf(-q, sdf.wf, x0f);
         r = (r < 0.0f) ? r + sdf.wf : r;
@@ -199,18 +225,22 @@ ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms&
     }
     int x1 = x0 + 1;
     x1 = (x1 == sdf.width) ? 0 : x1;
+    // V CLAMP: y0 = clamp(yi, 0, h - 1), y1 = clamp(yi + 1, 0, h - 1); y1 is the next row exactly when 0 <= yi < h - 1
     const int yi = (int)y0f;
-    const int y0 = min(max(yi, 0), sdf.height - 1);
-    const int y1 = min(max(yi + 1, 0), sdf.height - 1);
+    int y0;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(y0) : "v"(yi), "s"(sdf.height - 1));
+    const bool next_row = (uint32_t)yi < (uint32_t)(sdf.height - 1);
 
     // byte offsets from the (uniform) atlas base: 32-bit lane offsets on an SGPR base pointer
     // (atlas <= 8192^2 texels of 8 bytes = 2^29 bytes); one 24-bit multiply, the second row is the first + pitch
     const uint32_t pitch = (uint32_t)sdf.width << 3;
     const uint32_t r0 = __umul24((uint32_t)y0, pitch);
-    const uint32_t r1 = (y1 != y0) ? r0 + pitch : r0;
+    const uint32_t r1 = next_row ? r0 + pitch : r0;
     // The two channels virtual slice 3k+m blends -- (r,g), (g,b) or (b,a) -- are the 4 bytes at offset 2m inside the 8-byte texel:
     // one dword load per tap at that (2-byte aligned) address replaces the 8-byte load + funnel shift + select.
-    const uint32_t sub = m << 1;
+    // 2 * (vi % 3) = 2 * vi - 6 * third as one 24-bit multiply-add (the compiler's form was a quarter-rate 32-bit multiply by -3)
+    uint32_t sub;
+    asm("v_mad_i32_i24 %0, %1, -6, %2" : "=v"(sub) : "v"(third), "v"(vi << 1));
     const uint32_t c0 = ((uint32_t)x0 << 3) + sub, c1 = ((uint32_t)x1 << 3) + sub;
     typedef const char __attribute__((address_space(1))) gbyte;
     typedef const uint32_t __attribute__((address_space(1), aligned(2))) gword;

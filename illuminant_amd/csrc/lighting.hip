@@ -161,6 +161,34 @@ ILM_DEV float sphere_light_opacity(f3 shaded, f3 normal, const LightRec& L, floa
 
 struct LightStats { unsigned long long samples = 0, pairs = 0, traced = 0; };
 
+// The cone-trace loop (coneTraceAdvance + coneTraceStep, ConeTrace.fxh:52-85).  FAST: every sample of every active lane lies inside the
+// field's volume and the light's cone radius is of ordinary size (shade_light decides per wave) -- no clamp, no distance to the volume,
+// division without the range scaling.
+template <int FMT, bool STATS, bool FAST>
+ILM_DEV void cone_trace_loop(const f3& start, const f3& dir, float data_y, float cfg_z, float cone_growth, float cone_max_radius,
+                             const IlmDistanceFieldUniforms& df, const SdfView& sdf, float& data_x, float& data_z, float& steps_remaining,
+                             bool alive, LightStats& st) {
+    // liveness = stepsRemaining * (saturate(visibility - FULLY_SHADOWED) * saturate(length - position)) > 0 is, factor by factor,
+    // stepsRemaining > 0 && visibility > FULLY_SHADOWED && length > position: the smallest positive factors (ulp(0.075), ulp(0.5),
+    // 1) cannot underflow their product, and a NaN factor saturates to 0 and fails its compare alike.
+    while (alive) {
+        steps_remaining -= 1.0f;
+        const f3 sp = mk3(__builtin_fmaf(dir.x, data_x, start.x), __builtin_fmaf(dir.y, data_x, start.y), __builtin_fmaf(dir.z, data_x, start.z));
+        const float s = sample_distance_field<FMT, false, FAST>(sp, df, sdf);
+        if (STATS) st.samples++;
+        // (both operands are finite: v_minimum3_f32 needs no canonicalising v_max in front of it, unlike IEEE minNum)
+        const float local_radius = __builtin_elementwise_minimum(__builtin_fmaf(cone_growth, data_x, 0.33f), cone_max_radius);   // MIN_CONE_RADIUS
+        const float local_visibility = FAST ? div_no_scale(s + 1.5f, local_radius) : ((s + 1.5f) / local_radius);              // HACK_DISTANCE_OFFSET
+        // fminf / fmaxf as the bare instructions: the same minNum / maxNum result without the v_max x, x canonicalisation the
+        // compiler puts in front of each loop-carried operand (no signalling NaN can reach them)
+        asm("v_min_f32 %0, %0, %1" : "+v"(data_z) : "v"(local_visibility));
+        float step = fabsf(s) * df.StepAndMisc2.z;
+        asm("v_max_f32 %0, %0, %1" : "+v"(step) : "v"(cfg_z));
+        data_x += step;
+        alive = (steps_remaining > 0.0f) & (data_z > 0.075f) & (data_y > data_x);
+    }
+}
+
 // One light on one shaded point: SphereLightPixelShader (SphereLight.fx:7-46) after the raster test.  Returns false when the shader
 // discards (nothing is blended); otherwise the light's rgb contribution in (out_r, out_g, out_b).
 template <int FMT, bool STATS>
@@ -214,17 +242,21 @@ ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment
         // loop (s_load + s_waitcnt per sample).  Two VGPRs keep it resident.
         float cone_max_radius = L.cfg_x, cone_growth = L.cfg_y;
         asm volatile("" : "+v"(cone_max_radius), "+v"(cone_growth));
-        while (liveness > 0.0f) {
-            steps_remaining -= 1.0f;
-            const f3 sp = mk3(__builtin_fmaf(dir.x, data_x, start.x), __builtin_fmaf(dir.y, data_x, start.y), __builtin_fmaf(dir.z, data_x, start.z));
-            const float s = sample_distance_field<FMT, false>(sp, df, sdf);
-            if (STATS) st.samples++;
-            // (both operands are finite: v_minimum3_f32 needs no canonicalising v_max in front of it, unlike IEEE minNum)
-            const float local_radius = __builtin_elementwise_minimum(__builtin_fmaf(cone_growth, data_x, 0.33f), cone_max_radius);   // MIN_CONE_RADIUS
-            data_z = fminf(data_z, (s + 1.5f) / local_radius);                        // HACK_DISTANCE_OFFSET
-            data_x += fmaxf(fabsf(s) * df.StepAndMisc2.z, cfg_z);
-            liveness = steps_remaining * (sat(data_z - 0.075f) * sat(data_y - data_x));
-        }
+        // Fast loop when, for every tracing lane of the wave, the trace stays inside the field: samples lie on the segment start ->
+        // light centre, or (trace shorter than the minimum length 1) within 1 of start; both ends inside with a margin that covers
+        // that and the rounding of start + dir * x.  Plus the operand range div_no_scale needs (uniform per light / field).
+        const float zoff = df.ConeAndMisc.y;
+        const float mx = 0.0625f + df.Extent.x * 0x1p-16f, my = 0.0625f + df.Extent.y * 0x1p-16f, mz = 0.0625f + df.Extent.z * 0x1p-16f;
+        const bool ends_inside =
+            (start.x >= 1.0f + mx) & (start.x <= df.Extent.x - 1.0f - mx) & (L.cx >= mx) & (L.cx <= df.Extent.x - mx) &
+            (start.y >= 1.0f + my) & (start.y <= df.Extent.y - 1.0f - my) & (L.cy >= my) & (L.cy <= df.Extent.y - my) &
+            (start.z - zoff >= 1.0f + mz) & (start.z - zoff <= df.Extent.z - 1.0f - mz) & (L.cz - zoff >= mz) & (L.cz - zoff <= df.Extent.z - mz);
+        const bool ordinary = (L.cfg_x >= 0x1p-60f) & (L.cfg_x <= 0x1p60f) & (fabsf(df.Extent.w) <= 0x1p20f);
+        const bool alive = liveness > 0.0f;
+        if (ordinary && __builtin_amdgcn_ballot_w64(!ends_inside) == 0ull)
+            cone_trace_loop<FMT, STATS, true>(start, dir, data_y, cfg_z, cone_growth, cone_max_radius, df, sdf, data_x, data_z, steps_remaining, alive, st);
+        else
+            cone_trace_loop<FMT, STATS, false>(start, dir, data_y, cfg_z, cone_growth, cone_max_radius, df, sdf, data_x, data_z, steps_remaining, alive, st);
         const float visibility = fminf(data_z, steps_remaining / 2.0f);               // MAX_STEP_RAMP_WINDOW
         cone_opacity = pow_pos(sat(sat(visibility - 0.075f) / (0.95f - 0.075f)), df.ConeAndMisc.z);
     }
@@ -615,6 +647,20 @@ hipError_t launch_sphere_lights_prepared(const LightLaunch& a, const void* recs,
         if (fp16) hipLaunchKernelGGL((sphere_lights_kernel<ILM_SDF_FP16, false>), dim3(blocks), dim3(256), 0, stream, a, r, tiles_x, tiles_y, tile_count);
         else hipLaunchKernelGGL((sphere_lights_kernel<ILM_SDF_UNORM16, false>), dim3(blocks), dim3(256), 0, stream, a, r, tiles_x, tiles_y, tile_count);
     }
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void divide_probe_kernel(const float* __restrict__ n, const float* __restrict__ d, int count,
+                                                            float* __restrict__ out_fast, float* __restrict__ out_ieee) {
+    const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (i >= count) return;
+    out_fast[i] = div_no_scale(n[i], d[i]);
+    out_ieee[i] = n[i] / d[i];
+}
+
+hipError_t launch_divide_probe(const float* n, const float* d, int count, float* out_fast, float* out_ieee, hipStream_t stream) {
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(divide_probe_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, stream, n, d, count, out_fast, out_ieee);
     return hipGetLastError();
 }
 

@@ -67,6 +67,7 @@ SYMBOLS = {
     "ilm_sdf_create": (_I, [_H, _I, _I, _I, C.POINTER(_H)]),
     "ilm_sdf_upload": (_I, [_H, _P]),
     "ilm_sdf_sample": (_I, [_H, _P, _P, _I, _P]),
+    "ilm_debug_divide": (_I, [_H, _P, _P, _I, _P, _P]),
     "ilm_sdf_destroy": (_I, [_H]),
     "ilm_sdf_download": (_I, [_H, _P]),
     "ilm_sdf_device_ptr": (_I, [_H, C.POINTER(_P)]),
@@ -149,6 +150,15 @@ class Context:
             return
         a = np.ascontiguousarray(texels, dtype=np.float32)
         check(lib().ilm_ctx_set_light_ramp(self.handle, _ptr(a), a.shape[1], a.shape[0]))
+
+    def debug_divide(self, numerators, denominators):
+        """ilm_debug_divide: (the cone trace's unscaled division, the IEEE division) of the operand pairs, both evaluated on the device."""
+        n = np.ascontiguousarray(numerators, dtype=np.float32).ravel()
+        d = np.ascontiguousarray(denominators, dtype=np.float32).ravel()
+        assert n.shape == d.shape
+        fast = np.empty_like(n); ieee = np.empty_like(n)
+        check(lib().ilm_debug_divide(self.handle, _ptr(n), _ptr(d), n.shape[0], _ptr(fast), _ptr(ieee)))
+        return fast, ieee
 
     def timer_start(self):
         check(lib().ilm_timer_start(self.handle))

@@ -451,6 +451,12 @@ int32_t ilm_sdf_upload(IlmHandle sdf, const uint16_t* texels);
  * Not on the reference's call path: it exposes the very sampler the particle collision and the cone trace use, so a
  * host (or a test) can query the field the kernels see. */
 int32_t ilm_sdf_sample(IlmHandle sdf, const IlmDistanceFieldUniforms* df, const float* positions, int32_t count, float* out_distances);
+
+/* Diagnostic, like ilm_sdf_sample: the cone trace's in-volume loop divides (distance + HACK_DISTANCE_OFFSET) by the cone radius
+ * (ConeTrace.fxh:62) with an instruction sequence that skips the IEEE division's range scaling.  This evaluates that sequence
+ * (`out_fast`) and the plain IEEE division (`out_ieee`) for `count` operand pairs on the device, so a test can hold them
+ * bit-equal over the operand range the kernel admits (2^-60 <= |d| <= 2^60, |n| <= 2^60 or zero / infinite / NaN). */
+int32_t ilm_debug_divide(IlmHandle ctx, const float* numerators, const float* denominators, int32_t count, float* out_fast, float* out_ieee);
 int32_t ilm_sdf_destroy(IlmHandle sdf);
 /* DistanceField.Save (Illuminant/SDF/DistanceField.cs:178-194): the atlas bytes, 8 per texel, row-major. */
 int32_t ilm_sdf_download(IlmHandle sdf, uint16_t* texels);

@@ -114,3 +114,35 @@ def test_multi_row_atlas_relies_on_the_u_wrap(ctx, oracle, fmt):
     assert np.array_equal(got, want), "%d of %d samples differ" % (int((got != want).sum()), n)
     assert np.unique((pts[:, 2] * 33 / 128).astype(int) // 3 // 3).size == 4      # all four atlas rows were visited
     sdf.close()
+
+
+def test_cone_trace_division_equals_the_ieee_division(ctx):
+    """div_no_scale (hlsl_math.hpp) -- the division of the in-volume cone-trace loop, the compiler's IEEE sequence without its two
+    v_div_scale_f32 -- against `/` on the device, bit for bit: random mantissas over the exponent range the kernel admits
+    (2^-60 <= |d| <= 2^60, |n| <= 2^60), the cone-trace's own operand ranges, and zero / infinite / NaN numerators.  The CPU's
+    division (numpy float32) is the third witness."""
+    rng = np.random.default_rng(5)
+    n_parts, d_parts = [], []
+    # the loop's own operands: n = distance + 1.5 in about [-130, 130], d = cone radius in [0.33, 64]
+    n_parts.append(rng.uniform(-130.0, 130.0, 1 << 20).astype(np.float32)); d_parts.append(rng.uniform(0.33, 64.0, 1 << 20).astype(np.float32))
+    # numerators next to zero: (s + 1.5) cancels down to one ulp of 1.5
+    k = rng.integers(-64, 65, 1 << 16).astype(np.float32) * np.float32(2.0 ** -23)
+    n_parts.append(k); d_parts.append(rng.uniform(0.33, 24.0, 1 << 16).astype(np.float32))
+    # the whole admitted exponent range, random mantissas and signs
+    def wide(count, lo, hi):
+        m = rng.uniform(1.0, 2.0, count).astype(np.float32)
+        e = rng.integers(lo, hi + 1, count)
+        sgn = rng.choice(np.array([-1.0, 1.0], np.float32), count)
+        return (np.ldexp(m, e) * sgn).astype(np.float32)
+    n_parts.append(wide(1 << 20, -40, 59)); d_parts.append(wide(1 << 20, -60, 59))
+    # specials in the numerator (an fp16 atlas may hold inf / NaN texels), zero numerators
+    sp = np.array([0.0, -0.0, np.inf, -np.inf, np.nan], np.float32)
+    n_parts.append(np.repeat(sp, 64)); d_parts.append(np.tile(rng.uniform(0.33, 24.0, 64).astype(np.float32), 5))
+    n = np.concatenate(n_parts); d = np.concatenate(d_parts)
+    fast, ieee = ctx.debug_divide(n, d)
+    with np.errstate(all="ignore"):
+        cpu = (n / d).astype(np.float32)
+    same = (fast.view(np.uint32) == ieee.view(np.uint32)) | (np.isnan(fast) & np.isnan(ieee))
+    assert same.all(), "first difference: n=%r d=%r fast=%r ieee=%r" % (n[~same][0], d[~same][0], fast[~same][0], ieee[~same][0])
+    same_cpu = (ieee.view(np.uint32) == cpu.view(np.uint32)) | (np.isnan(ieee) & np.isnan(cpu))
+    assert same_cpu.all()
