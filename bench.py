@@ -28,6 +28,11 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 PARTICLE_BYTES_PER_SLOT = 112   # 48 B read (pos+life, vel+cat, attributes) + 64 B written (pos, vel, render colour, render data)
+# fp32 VALU issue: 256 CUs x 4 SIMD-32, one wave64 instruction per 2 cycles (MI355X_MICROARCH.md "Wave scheduling") at 2.4 GHz;
+# tools/ubench/valu (independent v_fma_f32 chains, 8 waves per SIMD) sustains 858 G/s -- the clock settles near 1.9 GHz under that load
+# (profiles/r01_valu_issue_calibration.md)
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0 / 1e9      # G wave-instructions / s
+VALU_ISSUE_CALIBRATED = 858.0
 SDF_SAMPLE_BYTES = 32           # one sampleDistanceFieldEx = 4 bilinear taps x 8 B RGBA16
 
 
@@ -160,13 +165,14 @@ def build_lighting(H, ctx, scenes, abi, width, height, n_lights, resolution, wor
     tiles = ((field.SliceWidth + 31) // 32) * ((field.SliceHeight + 7) // 8)     # one workgroup (4 waves) per 32 x 8 texels
     waves = field.PhysicalSliceCount * tiles * 4
     valu = profiled_per_wave("ilm::render_slices_kernel<%d>" % (1 if sdf_fmt == abi.SDF_FP16 else 0), "SQ_INSTS_VALU")
-    issue_peak = 256 * 4 * 2.4e9 / 4.0 / 1e9          # G wave-instructions / s
+    issue_peak = VALU_ISSUE_PEAK
     issue = (waves * valu["value"] / (gen_ms * 1e-3) / 1e9) if valu else None
     gen = {"ms_per_field": round(gen_ms, 4), "atlas": "%dx%d RGBA16 (%d slices of %dx%d)" % (field.TextureWidth, field.TextureHeight, field.SliceCount, field.SliceWidth, field.SliceHeight),
            "obstructions": 256, "mtexels_per_s": round(texels / (gen_ms * 1e-3) / 1e6, 1),
            "hbm_write_gb_per_s": round(texels * 8 / (gen_ms * 1e-3) / 1e9, 1),
            "roofline": {"bound": "valu", "achieved": round(issue, 1) if issue else None, "peak": round(issue_peak, 1), "unit": "G wave-instr/s",
                         "frac": round(issue / issue_peak, 4) if issue else None,
+                        "calibrated_peak": VALU_ISSUE_CALIBRATED, "calibrated_frac": round(issue / VALU_ISSUE_CALIBRATED, 4) if issue else None,
                         "kernel": "ilm::render_slices_kernel", "waves_per_launch": waves,
                         "valu_instructions_per_wave": round(valu["value"], 1) if valu else None,
                         "valu_source": ("profiles/%s: SQ_INSTS_VALU / SQ_WAVES" % valu["source"]) if valu else None,
@@ -370,7 +376,11 @@ def main():
             my_px = (row_end - row_begin) * w
             alg_bytes = samples * SDF_SAMPLE_BYTES + my_px * 8 + nl * 128   # this rank's launch: SDF samples + ground-plane lightmap write (half4) + light records
             kern_ms = gms / args.light_frames
-            lt = profiled_traffic("ilm::sphere_lights_kernel<%d, false>" % (1 if fmt == abi.SDF_FP16 else 0)) if world == 1 else None
+            kname = "ilm::sphere_lights_kernel<%d, false>" % (1 if fmt == abi.SDF_FP16 else 0)
+            lt = profiled_traffic(kname) if world == 1 else None
+            # the kernel's binding resource is VALU issue, not HBM (the atlas is cache-resident): wave-instructions of the committed PMC
+            # profile of this same frame / this run's launch time
+            lv = profiled_per_wave(kname, "SQ_INSTS_VALU") if world == 1 else None
             lighting[name] = {
                 "lit_mpixels_per_s": round(w * h / (frame_ms * 1e-3) / 1e6, 2),
                 "ms_per_frame": round(frame_ms, 4),
@@ -383,6 +393,15 @@ def main():
                              "kernel": "ilm::sphere_lights_kernel", "bytes_per_unit": SDF_SAMPLE_BYTES,
                              "units_per_launch": samples, "launch_ms": round(kern_ms, 4)},
             }
+            if lv:
+                waves_l = ((w + 15) // 16) * ((row_end - row_begin + 15) // 16) * 4
+                issue = waves_l * lv["value"] / (kern_ms * 1e-3) / 1e9
+                lighting[name]["valu_issue"] = {
+                    "bound": "valu", "achieved": round(issue, 1), "peak": round(VALU_ISSUE_PEAK, 1), "unit": "G wave-instr/s",
+                    "frac": round(issue / VALU_ISSUE_PEAK, 4), "calibrated_peak": VALU_ISSUE_CALIBRATED,
+                    "calibrated_frac": round(issue / VALU_ISSUE_CALIBRATED, 4), "waves_per_launch": waves_l,
+                    "valu_instructions_per_wave": round(lv["value"], 1), "valu_instructions_per_sdf_sample": round(waves_l * lv["value"] * 64 / max(samples, 1), 1),
+                    "valu_source": "profiles/%s: SQ_INSTS_VALU / SQ_WAVES" % lv["source"]}
             if name.startswith("cfg5"):
                 # cfg5: + 16 M particles over the node = 2 chunks of 1024^2 per GPU stepped in the same frame (cfg2's
                 # transform list without the spawner); particle step and lit frame as two phases and as a whole, one stream
