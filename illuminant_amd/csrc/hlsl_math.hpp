@@ -104,6 +104,7 @@ struct SdfView {
     float wf, hf;          // (float)width, (float)height
     float inv_wf;          // 1 / wf (seed of the exact integer wrap; any value within 1 ulp works)
     float wrap_half;       // 0.5 * inv_wf when every tap column this field can ask for stays below 2^20 (make_sdf_view), else 0
+    int pair_loads;        // launch the kernel variant that fetches a row's two taps with one 12-byte load (make_sdf_view: >= 3/16 texel per world unit)
 };
 
 // x / 65535 for an integer-valued x in [0, 65535], correctly rounded: one multiply by fl(1/65535) and one
@@ -164,7 +165,9 @@ ILM_DEV float div_no_scale(float n, float d) {
 
 // INSIDE = true: the caller guarantees 0 <= position <= extent on every axis (after the z offset), so the clamp is the identity and
 // the distance to the volume is +0 -- the same values the general form computes there, without computing them.
-template <int FORMAT, bool CHECK_NAN = true, bool INSIDE = false>
+// PAIR = true: the caller's kernel was chosen for a field dense enough for the paired tap loads (SdfView::pair_loads; a compile-time
+// choice, because carrying both load forms in the trace loop costs the coarse-field case 5 %).
+template <int FORMAT, bool CHECK_NAN = true, bool INSIDE = false, bool PAIR = false>
 ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms& df, const SdfView& sdf) {
 #pragma clang fp contract(off)
     position.z -= df.ConeAndMisc.y;
@@ -246,8 +249,21 @@ ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms&
     typedef const uint32_t __attribute__((address_space(1), aligned(2))) gword;
     gbyte* base = (gbyte*)sdf.texels;
     asm("" : "+s"(base));
-    const uint32_t w00 = *(gword*)(base + (r0 + c0)), w10 = *(gword*)(base + (r0 + c1));
-    const uint32_t w01 = *(gword*)(base + (r1 + c0)), w11 = *(gword*)(base + (r1 + c1));
+    // The right-hand tap is the next texel -- 8 bytes on -- unless U WRAP sends it to column 0.  When no lane of the wave wraps (all
+    // but the atlas' last column), ONE 12-byte load per row can fetch both taps.  Measured: where a wave's 64 samples
+    // spread over several texels the L1's per-address work dominates and two loads instead of four win 5-8 %; where they fall on
+    // one or two texels (coarse fields) the four narrow loads coalesce and the wide ones only add return traffic (+5 %).
+    // make_sdf_view picks by the field's texel density.
+    uint32_t w00, w10, w01, w11;
+    if (PAIR && __builtin_amdgcn_ballot_w64(x0 == sdf.width - 1) == 0ull) {
+        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+        typedef const u32x3 __attribute__((address_space(1), aligned(2))) gword3;
+        const u32x3 t0 = *(gword3*)(base + (r0 + c0)), t1 = *(gword3*)(base + (r1 + c0));
+        w00 = t0.x; w10 = t0.z; w01 = t1.x; w11 = t1.z;
+    } else {
+        w00 = *(gword*)(base + (r0 + c0)); w10 = *(gword*)(base + (r0 + c1));
+        w01 = *(gword*)(base + (r1 + c0)); w11 = *(gword*)(base + (r1 + c1));
+    }
 
     float a00, b00, a10, b10, a01, b01, a11, b11;
     sdf_unpack_word<FORMAT>(w00, a00, b00);

@@ -164,7 +164,7 @@ struct LightStats { unsigned long long samples = 0, pairs = 0, traced = 0; };
 // The cone-trace loop (coneTraceAdvance + coneTraceStep, ConeTrace.fxh:52-85).  FAST: every sample of every active lane lies inside the
 // field's volume and the light's cone radius is of ordinary size (shade_light decides per wave) -- no clamp, no distance to the volume,
 // division without the range scaling.
-template <int FMT, bool STATS, bool FAST>
+template <int FMT, bool STATS, bool FAST, bool PAIR>
 ILM_DEV void cone_trace_loop(const f3& start, const f3& dir, float data_y, float cfg_z, float cone_growth, float cone_max_radius,
                              const IlmDistanceFieldUniforms& df, const SdfView& sdf, float& data_x, float& data_z, float& steps_remaining,
                              bool alive, LightStats& st) {
@@ -174,7 +174,7 @@ ILM_DEV void cone_trace_loop(const f3& start, const f3& dir, float data_y, float
     while (alive) {
         steps_remaining -= 1.0f;
         const f3 sp = mk3(__builtin_fmaf(dir.x, data_x, start.x), __builtin_fmaf(dir.y, data_x, start.y), __builtin_fmaf(dir.z, data_x, start.z));
-        const float s = sample_distance_field<FMT, false, FAST>(sp, df, sdf);
+        const float s = sample_distance_field<FMT, false, FAST, PAIR>(sp, df, sdf);
         if (STATS) st.samples++;
         // (both operands are finite: v_minimum3_f32 needs no canonicalising v_max in front of it, unlike IEEE minNum)
         const float local_radius = __builtin_elementwise_minimum(__builtin_fmaf(cone_growth, data_x, 0.33f), cone_max_radius);   // MIN_CONE_RADIUS
@@ -191,7 +191,7 @@ ILM_DEV void cone_trace_loop(const f3& start, const f3& dir, float data_y, float
 
 // One light on one shaded point: SphereLightPixelShader (SphereLight.fx:7-46) after the raster test.  Returns false when the shader
 // discards (nothing is blended); otherwise the light's rgb contribution in (out_r, out_g, out_b).
-template <int FMT, bool STATS>
+template <int FMT, bool STATS, bool PAIR = false>
 ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment& env, const IlmDistanceFieldUniforms& df, const SdfView& sdf,
                          bool have_sdf, const RampView& ramp, LightStats& st, float& out_r, float& out_g, float& out_b) {
     // checkShadowFilter, LightCommon.fxh:146-152
@@ -254,9 +254,9 @@ ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment
         const bool ordinary = (L.cfg_x >= 0x1p-60f) & (L.cfg_x <= 0x1p60f) & (fabsf(df.Extent.w) <= 0x1p20f);
         const bool alive = liveness > 0.0f;
         if (ordinary && __builtin_amdgcn_ballot_w64(!ends_inside) == 0ull)
-            cone_trace_loop<FMT, STATS, true>(start, dir, data_y, cfg_z, cone_growth, cone_max_radius, df, sdf, data_x, data_z, steps_remaining, alive, st);
+            cone_trace_loop<FMT, STATS, true, PAIR>(start, dir, data_y, cfg_z, cone_growth, cone_max_radius, df, sdf, data_x, data_z, steps_remaining, alive, st);
         else
-            cone_trace_loop<FMT, STATS, false>(start, dir, data_y, cfg_z, cone_growth, cone_max_radius, df, sdf, data_x, data_z, steps_remaining, alive, st);
+            cone_trace_loop<FMT, STATS, false, PAIR>(start, dir, data_y, cfg_z, cone_growth, cone_max_radius, df, sdf, data_x, data_z, steps_remaining, alive, st);
         const float visibility = fminf(data_z, steps_remaining / 2.0f);               // MAX_STEP_RAMP_WINDOW
         cone_opacity = pow_pos(sat(sat(visibility - 0.075f) / (0.95f - 0.075f)), df.ConeAndMisc.z);
     }
@@ -303,7 +303,7 @@ ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment
 constexpr int kTile = 16;
 constexpr int kListCapacity = 1024;
 
-template <int FMT, bool STATS>
+template <int FMT, bool STATS, bool PAIR>
 __global__ __launch_bounds__(256) void sphere_lights_kernel(const LightLaunch a, const LightRec* __restrict__ recs, int tiles_x, int tiles_y, int tile_count) {
     __shared__ uint16_t list[kListCapacity];
     __shared__ int list_count;
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(256) void sphere_lights_kernel(const LightLaunch a,
                 continue;
             if (STATS) st.pairs++;
             float cr, cg, cb;
-            if (!shade_light<FMT, STATS>(P, L, a.env, a.df, a.sdf, have_sdf, a.ramp, st, cr, cg, cb))
+            if (!shade_light<FMT, STATS, PAIR>(P, L, a.env, a.df, a.sdf, have_sdf, a.ramp, st, cr, cg, cb))
                 continue;
             acc_r += cr;
             acc_g += cg;
@@ -640,13 +640,20 @@ hipError_t launch_sphere_lights_prepared(const LightLaunch& a, const void* recs,
     const LightRec* r = reinterpret_cast<const LightRec*>(recs);
     const bool stats = a.stats != nullptr;
     const bool fp16 = a.sdf.format == ILM_SDF_FP16;
-    if (stats) {
-        if (fp16) hipLaunchKernelGGL((sphere_lights_kernel<ILM_SDF_FP16, true>), dim3(blocks), dim3(256), 0, stream, a, r, tiles_x, tiles_y, tile_count);
-        else hipLaunchKernelGGL((sphere_lights_kernel<ILM_SDF_UNORM16, true>), dim3(blocks), dim3(256), 0, stream, a, r, tiles_x, tiles_y, tile_count);
-    } else {
-        if (fp16) hipLaunchKernelGGL((sphere_lights_kernel<ILM_SDF_FP16, false>), dim3(blocks), dim3(256), 0, stream, a, r, tiles_x, tiles_y, tile_count);
-        else hipLaunchKernelGGL((sphere_lights_kernel<ILM_SDF_UNORM16, false>), dim3(blocks), dim3(256), 0, stream, a, r, tiles_x, tiles_y, tile_count);
+    const dim3 grid(blocks), block(256);
+#define ILM_LAUNCH_LIGHTS(F, S, P) hipLaunchKernelGGL((sphere_lights_kernel<F, S, P>), grid, block, 0, stream, a, r, tiles_x, tiles_y, tile_count)
+    const int variant = (fp16 ? 4 : 0) | (stats ? 2 : 0) | (a.sdf.pair_loads ? 1 : 0);
+    switch (variant) {
+        case 0: ILM_LAUNCH_LIGHTS(ILM_SDF_UNORM16, false, false); break;
+        case 1: ILM_LAUNCH_LIGHTS(ILM_SDF_UNORM16, false, true); break;
+        case 2: ILM_LAUNCH_LIGHTS(ILM_SDF_UNORM16, true, false); break;
+        case 3: ILM_LAUNCH_LIGHTS(ILM_SDF_UNORM16, true, true); break;
+        case 4: ILM_LAUNCH_LIGHTS(ILM_SDF_FP16, false, false); break;
+        case 5: ILM_LAUNCH_LIGHTS(ILM_SDF_FP16, false, true); break;
+        case 6: ILM_LAUNCH_LIGHTS(ILM_SDF_FP16, true, false); break;
+        default: ILM_LAUNCH_LIGHTS(ILM_SDF_FP16, true, true); break;
     }
+#undef ILM_LAUNCH_LIGHTS
     return hipGetLastError();
 }
 
