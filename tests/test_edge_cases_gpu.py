@@ -221,3 +221,25 @@ def test_bound_distance_field_may_be_destroyed_first(ctx):
         sysm.step(d)
     assert e.value.code == abi.ERR_STATE
     sysm.close(); eng.close()
+
+
+@pytest.mark.parametrize("resolution", [1.0, 0.125])
+@pytest.mark.parametrize("sfmt", [abi.SDF_UNORM16, abi.SDF_FP16])
+def test_traces_along_the_fields_last_column_and_outside_it(ctx, oracle, sfmt, resolution):
+    """The frame covers the field exactly and lights sit on its right / bottom edge, above its top slice and outside it: traces run
+    along the atlas' last texel column (the right-hand tap wraps to column 0 -- the paired tap loads fall back to single ones), leave
+    the volume (distance-to-volume term, general trace loop) and mix with in-volume traces in one wave.  Both tap-load kernel variants
+    (texel density 1 and 1/8), both formats; integer statistics exact."""
+    w, h = 128, 96
+    layout = scenes.DistanceFieldLayout(w, h, 64.0, 9, resolution, 128)
+    obstacles = scenes.random_obstacles(31, 10, (w, h), size_lo=6.0, size_hi=20.0, z_hi=40.0)
+    atlas = scenes.build_sdf_atlas(layout, obstacles, fmt=sfmt)
+    dfu = layout.uniforms(max_cone_radius=16.0, power=0.7, step_limit=48, min_step_size=1.0, long_step_factor=0.5)
+    spots = [(127.9, 48.0, 30.0), (127.6, 5.0, 41.0), (64.0, 95.8, 30.0), (126.0, 94.0, 62.5), (140.0, 40.0, 20.0), (-9.0, 70.0, 12.0),
+             (60.0, 40.0, 80.0), (0.2, 0.3, 25.0), (64.0, 48.0, 10.0)]
+    lights = (abi.LightVertex * len(spots))(*[scenes.sphere_light(p, 6.0, 70.0 + 9.0 * i, color=(0.9, 0.8 - 0.05 * i, 0.5, 1.0)) for i, p in enumerate(spots)])
+    env = scenes.environment()
+    got, want, stats, ostats = render_both(ctx, oracle, lights, env, dfu, None, 0, atlas, sfmt, (0.02, 0.02, 0.02, 1.0), w, h)
+    assert (stats.SdfSamples, stats.PixelLightPairs, stats.TracedPairs) == (ostats.SdfSamples, ostats.PixelLightPairs, ostats.TracedPairs)
+    assert ostats.TracedPairs > 0.5 * ostats.PixelLightPairs > 0
+    assert_close(got, want, "lightmap with traces on and beyond the field's edges")
