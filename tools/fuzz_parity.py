@@ -81,6 +81,7 @@ for seed in range(first, first + count):
                                                  position=((128, 128, 4), (90, 60, 4), (0, 0, 0), int(rng.choice([0, 1, 3]))),
                                                  velocity=((0, 0, 0), (60, 60, 10), (0, 0, 0), int(rng.choice([0, 1, 2]))), life=(2.0, 2.0, 0.0))
     d.Flags = abi.STEP_COUNT_LIVE
+    inputs = [(c[0].copy(), c[1].copy()) for c in chunks]
     sysm.step(d)
     want_counts = oracle.step(chunks, cs, rnd, d, want_counts=True)
     got_counts = sysm.step_counts()
@@ -98,6 +99,21 @@ for seed in range(first, first + count):
                     worst_s = float(r.max())
                     i, j = np.unravel_index(int(np.argmax(r)), r.shape)
                     worst_where = (seed, c, kk, int(i), int(j), float(g[i, j]), float(wv[i, j]), scale, cs, k, int(d.SpawnCount))
+                    if os.environ.get("ILM_FUZZ_DUMP"):
+                        print("worst so far:", worst_where)
+                        print("  input position/life", inputs[c][0][i], "velocity", inputs[c][1][i])
+                        print("  got  P", sysm.download(c, P)[i], "V", sysm.download(c, V)[i])
+                        print("  want P", chunks[c][0][i], "V", chunks[c][1][i])
+                        for o in range(k):
+                            if d.Ops[o].Type == abi.OP_GRAVITY:
+                                gp_ = d.Ops[o].u.Gravity
+                                print("  gravity: count", gp_.AttractorCount, "max accel", gp_.MaximumAcceleration)
+                                for a_ in range(int(gp_.AttractorCount)):
+                                    ap = gp_.AttractorPositions[a_]; ar = gp_.AttractorRadiusesAndStrengths[a_]
+                                    dist = float(np.linalg.norm(np.array(list(ap)) - inputs[c][0][i][:3]))
+                                    print("    attractor", list(ap), "radius/strength/type", list(ar), "distance", dist)
+                            else:
+                                print("  op type", d.Ops[o].Type)
     if problem:
         bad_step.append((seed, list(got_counts), list(want_counts)))
     sysm.close(); eng.close()
