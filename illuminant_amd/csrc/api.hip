@@ -155,10 +155,10 @@ SdfView make_sdf_view(const Sdf* f, const IlmDistanceFieldUniforms* df) {
     // The sampler's single-step U wrap needs every tap column below 2^22 (hlsl_math.hpp); the largest column these uniforms can produce
     // is (floor(maxSlice) / 3 * sliceU + extentX * texelU) * width.  Anything at or above 2^20 (or not finite) keeps the two-fold wrap.
     v.wrap_half = 0.0f;
-    // An 8 x 8-pixel wave of the cone trace samples a patch about 8 world units wide: from 3/16 texel per unit on, that is more than
-    // one or two texels and the paired 12-byte tap loads pay off (hlsl_math.hpp)
-    v.pair_loads = (df && v.width > 0 && std::fabs(df->TextureSliceAndTexelSize.z) * v.wf >= 0.1875f) ? 1 : 0;
-    static const char* pair_env = getenv("ILM_SDF_PAIR_LOADS");      // "0" / "1" force the choice (measurements)
+    // ILM_SDF_PAIR_LOADS=1 selects the variant whose two taps of a row come from one 16-byte load (hlsl_math.hpp); measured r02: the
+    // texture path gets lighter (address unit 79 -> 56 % busy) but the kernel is bound by VALU issue, so it is 0-5 % slower: off by default
+    v.pair_loads = 0;
+    static const char* pair_env = getenv("ILM_SDF_PAIR_LOADS");
     if (pair_env && (pair_env[0] == '0' || pair_env[0] == '1')) v.pair_loads = pair_env[0] - '0';
     if (df && v.width > 0) {
         const double third_max = std::floor(std::fabs((double)df->Packed1.z * (double)df->Packed1.y)) / 3.0 + 1.0;

@@ -104,7 +104,7 @@ struct SdfView {
     float wf, hf;          // (float)width, (float)height
     float inv_wf;          // 1 / wf (seed of the exact integer wrap; any value within 1 ulp works)
     float wrap_half;       // 0.5 * inv_wf when every tap column this field can ask for stays below 2^20 (make_sdf_view), else 0
-    int pair_loads;        // launch the kernel variant that fetches a row's two taps with one 12-byte load (make_sdf_view: >= 3/16 texel per world unit)
+    int pair_loads;        // 1 (default): the kernel variant that fetches a row's two taps with one 16-byte load; 0 (ILM_SDF_PAIR_LOADS=0): four dword loads
 };
 
 // x / 65535 for an integer-valued x in [0, 65535], correctly rounded: one multiply by fl(1/65535) and one
@@ -165,9 +165,9 @@ ILM_DEV float div_no_scale(float n, float d) {
 
 // INSIDE = true: the caller guarantees 0 <= position <= extent on every axis (after the z offset), so the clamp is the identity and
 // the distance to the volume is +0 -- the same values the general form computes there, without computing them.
-// PAIR = true: the caller's kernel was chosen for a field dense enough for the paired tap loads (SdfView::pair_loads; a compile-time
-// choice, because carrying both load forms in the trace loop costs the coarse-field case 5 %).
-template <int FORMAT, bool CHECK_NAN = true, bool INSIDE = false, bool PAIR = false>
+// PAIR = true (the shipped form): a row's two taps come from one 16-byte load; false: one 2-byte-aligned dword load per tap (kept as the
+// A/B arm of tools/ab_pair.sh, SdfView::pair_loads).
+template <int FORMAT, bool CHECK_NAN = true, bool INSIDE = false, bool PAIR = true>
 ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms& df, const SdfView& sdf) {
 #pragma clang fp contract(off)
     position.z -= df.ConeAndMisc.y;
@@ -239,28 +239,46 @@ ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms&
     const uint32_t pitch = (uint32_t)sdf.width << 3;
     const uint32_t r0 = __umul24((uint32_t)y0, pitch);
     const uint32_t r1 = next_row ? r0 + pitch : r0;
-    // The two channels virtual slice 3k+m blends -- (r,g), (g,b) or (b,a) -- are the 4 bytes at offset 2m inside the 8-byte texel:
-    // one dword load per tap at that (2-byte aligned) address replaces the 8-byte load + funnel shift + select.
     // 2 * (vi % 3) = 2 * vi - 6 * third as one 24-bit multiply-add (the compiler's form was a quarter-rate 32-bit multiply by -3)
     uint32_t sub;
     asm("v_mad_i32_i24 %0, %1, -6, %2" : "=v"(sub) : "v"(third), "v"(vi << 1));
-    const uint32_t c0 = ((uint32_t)x0 << 3) + sub, c1 = ((uint32_t)x1 << 3) + sub;
     typedef const char __attribute__((address_space(1))) gbyte;
-    typedef const uint32_t __attribute__((address_space(1), aligned(2))) gword;
     gbyte* base = (gbyte*)sdf.texels;
     asm("" : "+s"(base));
-    // The right-hand tap is the next texel -- 8 bytes on -- unless U WRAP sends it to column 0.  When no lane of the wave wraps (all
-    // but the atlas' last column), ONE 12-byte load per row can fetch both taps.  Measured: where a wave's 64 samples
-    // spread over several texels the L1's per-address work dominates and two loads instead of four win 5-8 %; where they fall on
-    // one or two texels (coarse fields) the four narrow loads coalesce and the wide ones only add return traffic (+5 %).
-    // make_sdf_view picks by the field's texel density.
     uint32_t w00, w10, w01, w11;
-    if (PAIR && __builtin_amdgcn_ballot_w64(x0 == sdf.width - 1) == 0ull) {
-        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
-        typedef const u32x3 __attribute__((address_space(1), aligned(2))) gword3;
-        const u32x3 t0 = *(gword3*)(base + (r0 + c0)), t1 = *(gword3*)(base + (r1 + c0));
-        w00 = t0.x; w10 = t0.z; w01 = t1.x; w11 = t1.z;
+    if (PAIR) {
+        // What binds the cone trace is the texture path, not the ALUs (profiles/r02_summary.md: address unit 79 % busy, data return 92 %):
+        // a wave64 load costs the address unit its 16 quad-cycles whatever its width (tools/ubench/gather: dword, dwordx2 and dwordx4
+        // gathers all take the same time per instruction; only the misaligned 12-byte form is split and costs 3x).  The right-hand
+        // tap is the next texel -- 8 bytes on -- unless U WRAP sends it to column 0, so ONE 16-byte load per row fetches both taps'
+        // texels (8-byte aligned: no split) and a byte permute picks the channel pair of virtual slice 3k+m -- (r,g), (g,b) or (b,a),
+        // bytes 2m .. 2m+3 of the 8-byte texel: two loads per sample instead of four.  A wave with a lane on the atlas' last column
+        // (uniform test) loads the four texels separately.
+        // selector bytes (2m, 2m+1, 2m+2, 2m+3): 0x03020100 + 2m * 0x01010101 in two 24-bit-safe steps
+        uint32_t sel;
+        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(sel) : "v"(sub), "s"(0x010101u), "v"(0x03020100u));
+        sel += sub << 24;
+        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef const u32x2 __attribute__((address_space(1), aligned(8))) gtexel;
+        typedef const u32x4 __attribute__((address_space(1), aligned(8))) gtexel2;
+        const uint32_t c0 = (uint32_t)x0 << 3;
+        u32x4 t0, t1;
+        if (__builtin_amdgcn_ballot_w64(x0 == sdf.width - 1) == 0ull) {
+            t0 = *(gtexel2*)(base + (r0 + c0)); t1 = *(gtexel2*)(base + (r1 + c0));
+        } else {
+            const uint32_t c1 = (uint32_t)x1 << 3;
+            const u32x2 a = *(gtexel*)(base + (r0 + c0)), b = *(gtexel*)(base + (r0 + c1));
+            const u32x2 c = *(gtexel*)(base + (r1 + c0)), d = *(gtexel*)(base + (r1 + c1));
+            t0.x = a.x; t0.y = a.y; t0.z = b.x; t0.w = b.y;
+            t1.x = c.x; t1.y = c.y; t1.z = d.x; t1.w = d.y;
+        }
+        w00 = __builtin_amdgcn_perm(t0.y, t0.x, sel); w10 = __builtin_amdgcn_perm(t0.w, t0.z, sel);
+        w01 = __builtin_amdgcn_perm(t1.y, t1.x, sel); w11 = __builtin_amdgcn_perm(t1.w, t1.z, sel);
     } else {
+        // one dword load per tap at the channel pair's (2-byte aligned) offset inside the 8-byte texel
+        typedef const uint32_t __attribute__((address_space(1), aligned(2))) gword;
+        const uint32_t c0 = ((uint32_t)x0 << 3) + sub, c1 = ((uint32_t)x1 << 3) + sub;
         w00 = *(gword*)(base + (r0 + c0)); w10 = *(gword*)(base + (r0 + c1));
         w01 = *(gword*)(base + (r1 + c0)); w11 = *(gword*)(base + (r1 + c1));
     }

@@ -191,7 +191,7 @@ ILM_DEV void cone_trace_loop(const f3& start, const f3& dir, float data_y, float
 
 // One light on one shaded point: SphereLightPixelShader (SphereLight.fx:7-46) after the raster test.  Returns false when the shader
 // discards (nothing is blended); otherwise the light's rgb contribution in (out_r, out_g, out_b).
-template <int FMT, bool STATS, bool PAIR = false>
+template <int FMT, bool STATS, bool PAIR = true>
 ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment& env, const IlmDistanceFieldUniforms& df, const SdfView& sdf,
                          bool have_sdf, const RampView& ramp, LightStats& st, float& out_r, float& out_g, float& out_b) {
     // checkShadowFilter, LightCommon.fxh:146-152
