@@ -640,6 +640,33 @@ int32_t copy_counts(System* s, const uint32_t* d_region, uint32_t* out, int32_t 
 
 }  // namespace
 
+namespace ilm {
+int32_t api_fail(int32_t code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_last_error, sizeof(g_last_error), fmt, ap);
+    va_end(ap);
+    return code;
+}
+IlmHandle handle_register(const void* object, uint32_t magic) {
+    HandleRegistry& r = handle_registry();
+    std::lock_guard<std::mutex> lock(r.mutex);
+    r.live[reinterpret_cast<uintptr_t>(object)] = magic;
+    return static_cast<IlmHandle>(reinterpret_cast<uintptr_t>(object));
+}
+bool handle_is_live(IlmHandle h, uint32_t magic) {
+    HandleRegistry& r = handle_registry();
+    std::lock_guard<std::mutex> lock(r.mutex);
+    const auto it = r.live.find(static_cast<uintptr_t>(h));
+    return it != r.live.end() && it->second == magic;
+}
+void handle_retire(const void* object) { retire_handle(object); }
+int ctx_child_count(IlmHandle h) {
+    const Ctx* c = from_handle<Ctx>(h, kMagicCtx);
+    return c ? c->children : -1;
+}
+}  // namespace ilm
+
 extern "C" {
 
 int32_t ilm_abi_version(void) { return ILM_ABI_VERSION; }

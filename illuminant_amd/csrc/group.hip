@@ -1,0 +1,541 @@
+// group.hip -- multi-device groups: the ilm_group_* entry points of include/illuminant_hip.h.
+//
+// The reference is single-GPU (one GraphicsDevice; LightingRenderer.RenderLighting returns ONE lightmap per frame,
+// Illuminant/Lighting/LightingRenderer.cs:917-923,1004-1010; ParticleSystem chunks never interact,
+// Illuminant/Particles/ParticleSystem.cs:743-745).  This file is what lets a host keep those call sites while the frame's row
+// strips and the particle chunks live on the 8 GPUs of a node: a group owns one context per member, cuts a frame into equal
+// slots of whole 16-row tile bands, renders each strip with the single-device entry point on its member's stream and exchanges
+// the strips in place -- hipMemcpyPeerAsync fan-out over the xGMI mesh inside one process, ncclAllGather (RCCL) inside or across
+// processes.  Everything here is host code on top of the C ABI of api.hip; no kernel of its own.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1, which resolves to an already loaded copy -- PyTorch brings its own), so
+// the library loads and every single-device path works on a machine without it.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "internal.hpp"
+
+namespace {
+
+using namespace ilm;
+
+#define HIP_TRY(expr)                                                                                                          \
+    do {                                                                                                                       \
+        hipError_t _e = (expr);                                                                                                \
+        if (_e != hipSuccess)                                                                                                  \
+            return api_fail((int32_t)_e, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__);           \
+    } while (0)
+
+constexpr int kTileRows = 16;        // the sphere-light kernel works on 16 x 16 pixel tiles (lighting.hip)
+constexpr int kMaxMembers = 64;
+
+// ---- RCCL, bound lazily ------------------------------------------------------------------------------------------------------
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool ok = false;
+    char why[256] = "";
+};
+
+Rccl& rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+        for (const char* n : names) {
+            r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+            if (r.lib) break;
+        }
+        if (!r.lib) { snprintf(r.why, sizeof(r.why), "librccl.so not found: %s", dlerror()); return; }
+#define ILM_BIND(field, symbol)                                                                      \
+        r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.lib, symbol));                         \
+        if (!r.field) { snprintf(r.why, sizeof(r.why), "librccl.so lacks %s", symbol); return; }
+        ILM_BIND(GetUniqueId, "ncclGetUniqueId") ILM_BIND(CommInitRank, "ncclCommInitRank") ILM_BIND(CommInitAll, "ncclCommInitAll")
+        ILM_BIND(CommDestroy, "ncclCommDestroy") ILM_BIND(CommCount, "ncclCommCount") ILM_BIND(AllGather, "ncclAllGather")
+        ILM_BIND(GroupStart, "ncclGroupStart") ILM_BIND(GroupEnd, "ncclGroupEnd") ILM_BIND(GetErrorString, "ncclGetErrorString")
+#undef ILM_BIND
+        r.ok = true;
+    });
+    return r;
+}
+
+#define NCCL_TRY(expr)                                                                                                         \
+    do {                                                                                                                       \
+        ncclResult_t _r = (expr);                                                                                              \
+        if (_r != ncclSuccess)                                                                                                 \
+            return api_fail(ILM_ERR_STATE, "%s failed: %s (%s:%d)", #expr, rccl().GetErrorString(_r), __FILE__, __LINE__);     \
+    } while (0)
+
+struct Group {
+    uint32_t magic = kMagicGroup;
+    int n_local = 0, world = 0, first_rank = 0;
+    bool rank_mode = false;                 // one process per GPU: the group spans processes, exactly one local member
+    int children = 0;                       // live group lightmaps
+    std::vector<int> devices;
+    std::vector<IlmHandle> ctx;
+    std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> events;         // one per local member: "my pushes have been queued / finished" (peer fan-out)
+    std::vector<ncclComm_t> comms;          // one per local member once a communicator exists
+    bool duplicates = false;                // two members share a device (RCCL refuses that)
+    void* d_counts = nullptr; size_t counts_bytes = 0;     // scratch of ilm_group_live_counts (rank mode), on member 0's device
+};
+
+struct GroupLightmap {
+    uint32_t magic = kMagicGroupLightmap;
+    Group* group = nullptr;
+    int width = 0, height = 0, format = 0, slot_rows = 0;
+    size_t row_bytes = 0;
+    std::vector<void*> buffers;             // per local member: world * slot_rows rows
+    std::vector<IlmHandle> lightmaps;       // per local member: lightmap object aliasing the buffer
+};
+
+Group* group_from(IlmHandle h) { return handle_is_live(h, kMagicGroup) ? reinterpret_cast<Group*>(static_cast<uintptr_t>(h)) : nullptr; }
+GroupLightmap* glm_from(IlmHandle h) {
+    return handle_is_live(h, kMagicGroupLightmap) ? reinterpret_cast<GroupLightmap*>(static_cast<uintptr_t>(h)) : nullptr;
+}
+
+size_t texel_bytes(int format) { return format == ILM_LIGHTMAP_FLOAT4 ? 16 : (format == ILM_LIGHTMAP_HALF4 ? 8 : 4); }
+
+// padded equal slots: R rows each, a multiple of the tile height, world * R >= height
+int slot_rows_for(int height, int world) {
+    const int per = (height + world - 1) / world;
+    return (per + kTileRows - 1) / kTileRows * kTileRows;
+}
+
+int32_t make_members(Group* g) {
+    for (int i = 0; i < g->n_local; i++) {
+        IlmHandle c = 0;
+        const int32_t rc = ilm_ctx_create(g->devices[(size_t)i], &c);
+        if (rc != ILM_OK) return rc;
+        g->ctx.push_back(c);
+        void* s = nullptr;
+        const int32_t rs = ilm_ctx_stream(c, &s);
+        if (rs != ILM_OK) return rs;
+        g->streams.push_back(reinterpret_cast<hipStream_t>(s));
+        HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+        hipEvent_t e = nullptr;
+        HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        g->events.push_back(e);
+    }
+    for (int i = 0; i < g->n_local; i++)
+        for (int j = 0; j < i; j++)
+            if (g->devices[(size_t)i] == g->devices[(size_t)j]) g->duplicates = true;
+    // direct xGMI transfers between distinct local devices (already enabled / unsupported pairs are not errors: the copy then stages)
+    for (int i = 0; i < g->n_local; i++)
+        for (int j = 0; j < g->n_local; j++) {
+            const int a = g->devices[(size_t)i], b = g->devices[(size_t)j];
+            if (a == b) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) {
+                (void)hipSetDevice(a);
+                (void)hipDeviceEnablePeerAccess(b, 0);
+            }
+            (void)hipGetLastError();
+        }
+    return ILM_OK;
+}
+
+void release_group(Group* g) {
+    for (size_t i = 0; i < g->comms.size(); i++)
+        if (g->comms[i] && rccl().ok) {
+            (void)hipSetDevice(g->devices[i]);
+            (void)rccl().CommDestroy(g->comms[i]);
+        }
+    if (g->d_counts) { (void)hipSetDevice(g->devices[0]); (void)hipFree(g->d_counts); }
+    for (size_t i = 0; i < g->events.size(); i++) {
+        (void)hipSetDevice(g->devices[i]);
+        if (g->events[i]) (void)hipEventDestroy(g->events[i]);
+    }
+    for (IlmHandle c : g->ctx)
+        if (c) (void)ilm_ctx_destroy(c);
+    handle_retire(g);
+    delete g;
+}
+
+// the in-process communicator is created on first use (a group that only uses the peer fan-out never needs RCCL)
+int32_t ensure_comms(Group* g) {
+    if (!g->comms.empty()) return ILM_OK;
+    Rccl& r = rccl();
+    if (!r.ok) return api_fail(ILM_ERR_STATE, "RCCL is not available: %s", r.why);
+    if (g->rank_mode) return api_fail(ILM_ERR_STATE, "this group has no communicator");     // created by ilm_group_create_rank
+    if (g->duplicates)
+        return api_fail(ILM_ERR_INVALID_ARGUMENT, "RCCL needs one device per member; this group has several members on one device (use ILM_GATHER_PEER)");
+    std::vector<ncclComm_t> comms((size_t)g->n_local, nullptr);
+    NCCL_TRY(r.CommInitAll(comms.data(), g->n_local, g->devices.data()));
+    g->comms = comms;
+    return ILM_OK;
+}
+
+// In-place all-gather; see the header.  All work is stream-ordered on the members' context streams.
+int32_t all_gather(Group* g, void* const* buffers, size_t bytes, int gather) {
+    if (gather == ILM_GATHER_NONE || g->world == 1 || bytes == 0) return ILM_OK;
+    if (gather == ILM_GATHER_PEER) {
+        if (g->rank_mode)
+            return api_fail(ILM_ERR_INVALID_ARGUMENT, "ILM_GATHER_PEER needs every member in this process; a group that spans processes gathers with RCCL");
+        const int n = g->n_local;
+        // 1. nobody may overwrite a slot that its owner's earlier work (the previous frame's consumers) still reads, and nobody's push may
+        //    start before the destination has finished the work queued before this call: every stream waits for every other's "here" event
+        for (int i = 0; i < n; i++) {
+            HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+            HIP_TRY(hipEventRecord(g->events[(size_t)i], g->streams[(size_t)i]));
+        }
+        for (int i = 0; i < n; i++) {
+            HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+            for (int j = 0; j < n; j++)
+                if (j != i) HIP_TRY(hipStreamWaitEvent(g->streams[(size_t)i], g->events[(size_t)j], 0));
+        }
+        // 2. member i pushes its slot to the n - 1 others on its own stream: on a full xGMI mesh that is one transfer per link
+        for (int i = 0; i < n; i++) {
+            HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+            const size_t off = (size_t)(g->first_rank + i) * bytes;
+            for (int k = 1; k < n; k++) {
+                const int j = (i + k) % n;            // staggered destinations: no two members start on the same target
+                HIP_TRY(hipMemcpyPeerAsync(static_cast<char*>(buffers[j]) + off, g->devices[(size_t)j],
+                                           static_cast<const char*>(buffers[i]) + off, g->devices[(size_t)i], bytes, g->streams[(size_t)i]));
+            }
+            HIP_TRY(hipEventRecord(g->events[(size_t)i], g->streams[(size_t)i]));
+        }
+        // 3. a member's later work sees the whole frame: its stream waits for every push
+        for (int i = 0; i < n; i++) {
+            HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+            for (int j = 0; j < n; j++)
+                if (j != i) HIP_TRY(hipStreamWaitEvent(g->streams[(size_t)i], g->events[(size_t)j], 0));
+        }
+        return ILM_OK;
+    }
+    if (gather != ILM_GATHER_RCCL) return api_fail(ILM_ERR_INVALID_ARGUMENT, "unknown gather mode %d", gather);
+    const int32_t rc = ensure_comms(g);
+    if (rc != ILM_OK) return rc;
+    Rccl& r = rccl();
+    NCCL_TRY(r.GroupStart());
+    for (int i = 0; i < g->n_local; i++) {
+        HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+        char* buf = static_cast<char*>(buffers[i]);
+        // in place: the send buffer is this rank's slot of the receive buffer
+        NCCL_TRY(r.AllGather(buf + (size_t)(g->first_rank + i) * bytes, buf, bytes, ncclInt8, g->comms[(size_t)i], g->streams[(size_t)i]));
+    }
+    NCCL_TRY(r.GroupEnd());
+    return ILM_OK;
+}
+
+// Small host payloads (liveness counters, timings): rank r's `bytes` land at out + r * bytes on every process.  Members of this
+// process are copied; a group that spans processes stages its slot in device memory and all-gathers it with RCCL.  Synchronises.
+int32_t host_all_gather(Group* g, const void* local, void* out, size_t bytes) {
+    if (bytes == 0) return ILM_OK;
+    char* o = static_cast<char*>(out);
+    const size_t mine = (size_t)g->first_rank * bytes;
+    if (o + mine != local) memmove(o + mine, local, bytes * (size_t)g->n_local);
+    if (!(g->rank_mode && g->world > 1)) return ILM_OK;
+    const size_t total = bytes * (size_t)g->world;
+    HIP_TRY(hipSetDevice(g->devices[0]));
+    if (total > g->counts_bytes) {
+        if (g->d_counts) { HIP_TRY(hipStreamSynchronize(g->streams[0])); HIP_TRY(hipFree(g->d_counts)); g->d_counts = nullptr; g->counts_bytes = 0; }
+        const size_t cap = total < 4096 ? 4096 : total;
+        HIP_TRY(hipMalloc(&g->d_counts, cap));
+        g->counts_bytes = cap;
+    }
+    char* d = static_cast<char*>(g->d_counts);
+    HIP_TRY(hipMemcpyAsync(d + mine, o + mine, bytes, hipMemcpyHostToDevice, g->streams[0]));
+    void* bufs[1] = { g->d_counts };
+    const int32_t rc = all_gather(g, bufs, bytes, ILM_GATHER_RCCL);
+    if (rc != ILM_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(o, d, total, hipMemcpyDeviceToHost, g->streams[0]));
+    HIP_TRY(hipStreamSynchronize(g->streams[0]));
+    return ILM_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t ilm_group_create(const int32_t* device_ids, int32_t n, IlmHandle* out_group) {
+    if (!out_group) return api_fail(ILM_ERR_INVALID_ARGUMENT, "out_group is NULL");
+    *out_group = 0;
+    if (!device_ids || n < 1 || n > kMaxMembers) return api_fail(ILM_ERR_INVALID_ARGUMENT, "a group has 1 .. %d members", kMaxMembers);
+    const int visible = ilm_device_count();
+    if (visible <= 0) return api_fail(ILM_ERR_NO_DEVICE, "no HIP device visible: libilluminant_hip has no CPU fallback");
+    for (int i = 0; i < n; i++)
+        if (device_ids[i] < 0 || device_ids[i] >= visible)
+            return api_fail(ILM_ERR_OUT_OF_RANGE, "device %d outside [0, %d)", device_ids[i], visible);
+    Group* g = new (std::nothrow) Group();
+    if (!g) return api_fail(ILM_ERR_INVALID_ARGUMENT, "out of host memory");
+    g->n_local = n; g->world = n; g->first_rank = 0;
+    g->devices.assign(device_ids, device_ids + n);
+    handle_register(g, kMagicGroup);
+    const int32_t rc = make_members(g);
+    if (rc != ILM_OK) { release_group(g); return rc; }
+    *out_group = static_cast<IlmHandle>(reinterpret_cast<uintptr_t>(g));
+    return ILM_OK;
+}
+
+int32_t ilm_group_unique_id(void* out_id128) {
+    if (!out_id128) return api_fail(ILM_ERR_INVALID_ARGUMENT, "out_id128 is NULL");
+    static_assert(sizeof(ncclUniqueId) == 128, "the id travels as 128 bytes");
+    Rccl& r = rccl();
+    if (!r.ok) return api_fail(ILM_ERR_STATE, "RCCL is not available: %s", r.why);
+    ncclUniqueId id;
+    NCCL_TRY(r.GetUniqueId(&id));
+    memcpy(out_id128, &id, sizeof(id));
+    return ILM_OK;
+}
+
+int32_t ilm_group_create_rank(int32_t device_id, int32_t rank, int32_t world, const void* id128, IlmHandle* out_group) {
+    if (!out_group) return api_fail(ILM_ERR_INVALID_ARGUMENT, "out_group is NULL");
+    *out_group = 0;
+    if (!id128) return api_fail(ILM_ERR_INVALID_ARGUMENT, "id128 is NULL");
+    if (world < 1 || rank < 0 || rank >= world) return api_fail(ILM_ERR_OUT_OF_RANGE, "rank %d outside [0, %d)", rank, world);
+    const int visible = ilm_device_count();
+    if (visible <= 0) return api_fail(ILM_ERR_NO_DEVICE, "no HIP device visible: libilluminant_hip has no CPU fallback");
+    if (device_id < 0 || device_id >= visible) return api_fail(ILM_ERR_OUT_OF_RANGE, "device %d outside [0, %d)", device_id, visible);
+    Rccl& r = rccl();
+    if (!r.ok) return api_fail(ILM_ERR_STATE, "RCCL is not available: %s", r.why);
+    Group* g = new (std::nothrow) Group();
+    if (!g) return api_fail(ILM_ERR_INVALID_ARGUMENT, "out of host memory");
+    g->n_local = 1; g->world = world; g->first_rank = rank; g->rank_mode = true;
+    g->devices.assign(1, device_id);
+    handle_register(g, kMagicGroup);
+    int32_t rc = make_members(g);
+    if (rc != ILM_OK) { release_group(g); return rc; }
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    ncclComm_t comm = nullptr;
+    if (hipSetDevice(device_id) != hipSuccess) { release_group(g); return api_fail(ILM_ERR_STATE, "hipSetDevice(%d) failed", device_id); }
+    const ncclResult_t nr = r.CommInitRank(&comm, world, id, rank);      // collective over all `world` processes
+    if (nr != ncclSuccess) {
+        rc = api_fail(ILM_ERR_STATE, "ncclCommInitRank(rank %d of %d) failed: %s", rank, world, r.GetErrorString(nr));
+        release_group(g);
+        return rc;
+    }
+    g->comms.assign(1, comm);
+    *out_group = static_cast<IlmHandle>(reinterpret_cast<uintptr_t>(g));
+    return ILM_OK;
+}
+
+int32_t ilm_group_destroy(IlmHandle h) {
+    Group* g = group_from(h);
+    if (!g) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group handle");
+    if (g->children > 0) return api_fail(ILM_ERR_STATE, "%d group lightmap(s) are still alive", g->children);
+    // member contexts refuse to go while objects of theirs live: find that out before anything is torn down
+    for (int i = 0; i < g->n_local; i++) {
+        const int live = ctx_child_count(g->ctx[(size_t)i]);
+        if (live > 0)
+            return api_fail(ILM_ERR_STATE, "%d object(s) of member %d's context are still alive: destroy engines, fields, G-buffers and lightmaps first", live, i);
+    }
+    release_group(g);
+    return ILM_OK;
+}
+
+int32_t ilm_group_info(IlmHandle h, int32_t* out_local, int32_t* out_world, int32_t* out_first_rank, int32_t* out_comm_ranks) {
+    Group* g = group_from(h);
+    if (!g) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group handle");
+    if (out_local) *out_local = g->n_local;
+    if (out_world) *out_world = g->world;
+    if (out_first_rank) *out_first_rank = g->first_rank;
+    if (out_comm_ranks) {
+        *out_comm_ranks = 0;
+        if (!g->comms.empty()) {
+            int count = 0;
+            NCCL_TRY(rccl().CommCount(g->comms[0], &count));
+            *out_comm_ranks = count;
+        }
+    }
+    return ILM_OK;
+}
+
+int32_t ilm_group_ctx(IlmHandle h, int32_t local_index, IlmHandle* out_ctx) {
+    Group* g = group_from(h);
+    if (!g) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group handle");
+    if (!out_ctx) return api_fail(ILM_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
+    if (local_index < 0 || local_index >= g->n_local) return api_fail(ILM_ERR_OUT_OF_RANGE, "member %d outside [0, %d)", local_index, g->n_local);
+    *out_ctx = g->ctx[(size_t)local_index];
+    return ILM_OK;
+}
+
+int32_t ilm_group_sync(IlmHandle h) {
+    Group* g = group_from(h);
+    if (!g) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group handle");
+    for (int i = 0; i < g->n_local; i++) {
+        const int32_t rc = ilm_ctx_sync(g->ctx[(size_t)i]);
+        if (rc != ILM_OK) return rc;
+    }
+    return ILM_OK;
+}
+
+int32_t ilm_group_all_gather(IlmHandle h, void* const* buffers, uint64_t bytes_per_rank, int32_t gather) {
+    Group* g = group_from(h);
+    if (!g) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group handle");
+    if (!buffers) return api_fail(ILM_ERR_INVALID_ARGUMENT, "buffers is NULL");
+    for (int i = 0; i < g->n_local; i++)
+        if (!buffers[i]) return api_fail(ILM_ERR_INVALID_ARGUMENT, "buffers[%d] is NULL", i);
+    return all_gather(g, buffers, (size_t)bytes_per_rank, gather);
+}
+
+int32_t ilm_group_host_all_gather(IlmHandle h, const void* local, void* out_all, uint32_t bytes_per_rank) {
+    Group* g = group_from(h);
+    if (!g) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group handle");
+    if (!local || !out_all) return api_fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (bytes_per_rank > (1u << 20)) return api_fail(ILM_ERR_OUT_OF_RANGE, "host payloads are small (<= 1 MiB per rank): use ilm_group_all_gather for device buffers");
+    // every member's queued work is finished first: the call doubles as the barrier between timed regions
+    for (int i = 0; i < g->n_local; i++) {
+        const int32_t rc = ilm_ctx_sync(g->ctx[(size_t)i]);
+        if (rc != ILM_OK) return rc;
+    }
+    return host_all_gather(g, local, out_all, (size_t)bytes_per_rank);
+}
+
+int32_t ilm_group_lightmap_create(IlmHandle h, int32_t width, int32_t height, int32_t format, IlmHandle* out) {
+    Group* g = group_from(h);
+    if (!g) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group handle");
+    if (!out) return api_fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
+    *out = 0;
+    if (width <= 0 || height <= 0) return api_fail(ILM_ERR_OUT_OF_RANGE, "bad lightmap size %dx%d", width, height);
+    if (format < ILM_LIGHTMAP_FLOAT4 || format > ILM_LIGHTMAP_RGBA8) return api_fail(ILM_ERR_INVALID_ARGUMENT, "unknown lightmap format %d", format);
+    GroupLightmap* m = new (std::nothrow) GroupLightmap();
+    if (!m) return api_fail(ILM_ERR_INVALID_ARGUMENT, "out of host memory");
+    m->group = g; m->width = width; m->height = height; m->format = format;
+    m->slot_rows = slot_rows_for(height, g->world);
+    m->row_bytes = texel_bytes(format) * (size_t)width;
+    handle_register(m, kMagicGroupLightmap);
+    g->children++;
+    const IlmHandle self = static_cast<IlmHandle>(reinterpret_cast<uintptr_t>(m));
+    const size_t bytes = m->row_bytes * (size_t)m->slot_rows * (size_t)g->world;
+    for (int i = 0; i < g->n_local; i++) {
+        void* p = nullptr;
+        hipError_t e = hipSetDevice(g->devices[(size_t)i]);
+        if (e == hipSuccess) e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) e = hipMemsetAsync(p, 0, bytes, g->streams[(size_t)i]);
+        if (e != hipSuccess) {
+            if (p) (void)hipFree(p);
+            const int32_t rc = api_fail((int32_t)e, "group lightmap of %zu bytes on device %d: %s", bytes, g->devices[(size_t)i], hipGetErrorString(e));
+            (void)ilm_group_lightmap_destroy(self);
+            return rc;
+        }
+        m->buffers.push_back(p);
+        IlmHandle lm = 0;
+        const int32_t rc = ilm_lightmap_create(g->ctx[(size_t)i], width, m->slot_rows * g->world, format, p, &lm);
+        if (rc != ILM_OK) { (void)ilm_group_lightmap_destroy(self); return rc; }
+        m->lightmaps.push_back(lm);
+    }
+    *out = self;
+    return ILM_OK;
+}
+
+int32_t ilm_group_lightmap_destroy(IlmHandle h) {
+    GroupLightmap* m = glm_from(h);
+    if (!m) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group lightmap handle");
+    Group* g = m->group;
+    for (IlmHandle lm : m->lightmaps) (void)ilm_lightmap_destroy(lm);        // synchronises the member's stream
+    for (size_t i = 0; i < m->buffers.size(); i++) {
+        (void)hipSetDevice(g->devices[i]);
+        (void)hipStreamSynchronize(g->streams[i]);
+        (void)hipFree(m->buffers[i]);
+    }
+    g->children--;
+    handle_retire(m);
+    delete m;
+    return ILM_OK;
+}
+
+int32_t ilm_group_lightmap_member(IlmHandle h, int32_t local_index, IlmHandle* out_lightmap) {
+    GroupLightmap* m = glm_from(h);
+    if (!m) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group lightmap handle");
+    if (!out_lightmap) return api_fail(ILM_ERR_INVALID_ARGUMENT, "out_lightmap is NULL");
+    if (local_index < 0 || local_index >= m->group->n_local)
+        return api_fail(ILM_ERR_OUT_OF_RANGE, "member %d outside [0, %d)", local_index, m->group->n_local);
+    *out_lightmap = m->lightmaps[(size_t)local_index];
+    return ILM_OK;
+}
+
+int32_t ilm_group_lightmap_strip(IlmHandle h, int32_t rank, int32_t* out_row_begin, int32_t* out_row_end, int32_t* out_slot_rows) {
+    GroupLightmap* m = glm_from(h);
+    if (!m) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group lightmap handle");
+    if (rank < 0 || rank >= m->group->world) return api_fail(ILM_ERR_OUT_OF_RANGE, "rank %d outside [0, %d)", rank, m->group->world);
+    const int b = rank * m->slot_rows, e = (rank + 1) * m->slot_rows;
+    if (out_row_begin) *out_row_begin = b < m->height ? b : m->height;
+    if (out_row_end) *out_row_end = e < m->height ? e : m->height;
+    if (out_slot_rows) *out_slot_rows = m->slot_rows;
+    return ILM_OK;
+}
+
+int32_t ilm_group_lightmap_gather(IlmHandle h, int32_t gather) {
+    GroupLightmap* m = glm_from(h);
+    if (!m) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group lightmap handle");
+    return all_gather(m->group, m->buffers.data(), m->row_bytes * (size_t)m->slot_rows, gather);
+}
+
+int32_t ilm_group_render_sphere_lights(IlmHandle hgroup, const IlmLightVertex* lights, int32_t light_count, const IlmEnvironment* env,
+                                       const IlmDistanceFieldUniforms* df, const IlmHandle* gbuffers, const IlmHandle* sdfs,
+                                       const float ambient[4], IlmHandle hlightmap, int32_t gather, IlmRenderStats* stats) {
+    Group* g = group_from(hgroup);
+    if (!g) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group handle");
+    GroupLightmap* m = glm_from(hlightmap);
+    if (!m) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group lightmap handle");
+    if (m->group != g) return api_fail(ILM_ERR_INVALID_ARGUMENT, "the lightmap belongs to another group");
+    if (gather < ILM_GATHER_NONE || gather > ILM_GATHER_RCCL) return api_fail(ILM_ERR_INVALID_ARGUMENT, "unknown gather mode %d", gather);
+    if (stats) { stats->SdfSamples = 0; stats->PixelLightPairs = 0; stats->TracedPairs = 0; }
+    // every member's strip is queued before anything is waited for: the launches are asynchronous, the devices run concurrently
+    // (the instrumented variant synchronises per member; it is a diagnostic)
+    for (int i = 0; i < g->n_local; i++) {
+        int32_t b = 0, e = 0;
+        (void)ilm_group_lightmap_strip(hlightmap, g->first_rank + i, &b, &e, nullptr);
+        IlmRenderStats part = { 0, 0, 0 };
+        const int32_t rc = ilm_render_sphere_lights(g->ctx[(size_t)i], lights, light_count, env, df, gbuffers ? gbuffers[i] : 0, sdfs ? sdfs[i] : 0,
+                                                    ambient, m->lightmaps[(size_t)i], b, e, stats ? &part : nullptr);
+        if (rc != ILM_OK) return rc;
+        if (stats) { stats->SdfSamples += part.SdfSamples; stats->PixelLightPairs += part.PixelLightPairs; stats->TracedPairs += part.TracedPairs; }
+    }
+    return all_gather(g, m->buffers.data(), m->row_bytes * (size_t)m->slot_rows, gather);
+}
+
+int32_t ilm_group_live_counts(IlmHandle hgroup, const IlmHandle* systems, int32_t total_chunks, uint32_t* out_counts, int32_t capacity,
+                              int32_t saturate16) {
+    Group* g = group_from(hgroup);
+    if (!g) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group handle");
+    if (!systems || (!out_counts && total_chunks > 0)) return api_fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (total_chunks < 0 || capacity < total_chunks) return api_fail(ILM_ERR_OUT_OF_RANGE, "capacity %d < chunk count %d", capacity, total_chunks);
+    const int world = g->world;
+    const int per_rank = (total_chunks + world - 1) / world;
+    if (per_rank == 0) return ILM_OK;
+    // this process's slots of the table, rank-major: slot (r, k) = chunk k * world + r
+    std::vector<uint32_t> table((size_t)world * (size_t)per_rank, 0u);
+    std::vector<uint32_t> local((size_t)per_rank, 0u);
+    for (int i = 0; i < g->n_local; i++) {
+        const int rank = g->first_rank + i;
+        const int owned = (total_chunks - rank + world - 1) / world;          // chunks c < total with c % world == rank
+        int32_t have = 0;
+        int32_t rc = ilm_system_chunk_count(systems[i], &have);
+        if (rc != ILM_OK) return rc;
+        if (have != owned)
+            return api_fail(ILM_ERR_STATE, "rank %d holds %d chunks but owns %d of a table of %d (chunk c lives on rank c %% %d)", rank, have, owned,
+                            total_chunks, world);
+        if (owned > 0) {
+            rc = ilm_system_step_counts(systems[i], local.data(), per_rank, saturate16);
+            if (rc != ILM_OK) return rc;
+            memcpy(&table[(size_t)rank * (size_t)per_rank], local.data(), sizeof(uint32_t) * (size_t)owned);
+        }
+    }
+    if (g->rank_mode && world > 1) {
+        // the one exchange of the particle path: world * per_rank counters through RCCL
+        const int32_t rc = host_all_gather(g, &table[(size_t)g->first_rank * (size_t)per_rank], table.data(), sizeof(uint32_t) * (size_t)per_rank);
+        if (rc != ILM_OK) return rc;
+    }
+    for (int c = 0; c < total_chunks; c++)
+        out_counts[c] = table[(size_t)(c % world) * (size_t)per_rank + (size_t)(c / world)];
+    return ILM_OK;
+}
+
+}  // extern "C"

@@ -262,4 +262,14 @@ hipError_t render_particles(RasterLaunch& a, RasterScratch& s, hipStream_t strea
 void free_raster_scratch(RasterScratch& s);
 hipError_t launch_clear_target(void* texels, int format, size_t n, float4 color, hipStream_t stream);
 
+// ---- shared with group.hip (the multi-device layer sits on the C ABI of api.hip, inside the same library) -------------------------
+// thread-local error text + return code, as every entry point reports failures
+int32_t api_fail(int32_t code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+// the table of live handles (api.hip): objects of other translation units register under their own magic
+constexpr uint32_t kMagicGroup = 0x494C4752u, kMagicGroupLightmap = 0x494C474Cu;
+IlmHandle handle_register(const void* object, uint32_t magic);
+bool handle_is_live(IlmHandle h, uint32_t magic);
+void handle_retire(const void* object);
+int ctx_child_count(IlmHandle ctx);        // live objects of a context (-1: not a context)
+
 }  // namespace ilm

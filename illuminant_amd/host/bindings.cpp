@@ -43,6 +43,8 @@ PYBIND11_MODULE(_host, m) {
         .def_readwrite("Now", &ManualTimeProvider::Now).def("Advance", &ManualTimeProvider::Advance).def("Seconds", &ManualTimeProvider::Seconds);
 
     py::class_<DeviceContext>(m, "DeviceContext").def(py::init<int>(), py::arg("deviceId") = 0)
+        .def_static("FromHandle", [](IlmHandle member) { return new DeviceContext(DeviceContext::Borrowed{ member }); }, py::arg("memberContext"),
+                    "wrap a context owned by a multi-device group (ilm_group_ctx); it is not destroyed with this object")
         .def("Sync", &DeviceContext::Sync).def("TimerStart", &DeviceContext::TimerStart).def("TimerStop", &DeviceContext::TimerStop)
         .def_property_readonly("Handle", &DeviceContext::Handle);
 

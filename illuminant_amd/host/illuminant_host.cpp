@@ -38,7 +38,7 @@ double Xoshiro::NextDouble() { return (double)(NextUInt64() >> 11) * (1.0 / 9007
 
 // ---- DeviceContext ---------------------------------------------------------------------------------------
 DeviceContext::DeviceContext(int deviceId) { ThrowIfFailed(ilm_ctx_create(deviceId, &handle)); }
-DeviceContext::~DeviceContext() { if (handle) ilm_ctx_destroy(handle); }
+DeviceContext::~DeviceContext() { if (handle && owned) ilm_ctx_destroy(handle); }
 void DeviceContext::Sync() { ThrowIfFailed(ilm_ctx_sync(handle)); }
 void DeviceContext::TimerStart() { ThrowIfFailed(ilm_timer_start(handle)); }
 float DeviceContext::TimerStop() { float ms = 0; ThrowIfFailed(ilm_timer_stop(handle, &ms)); return ms; }

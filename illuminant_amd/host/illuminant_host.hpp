@@ -72,6 +72,9 @@ public:
 class DeviceContext {
 public:
     explicit DeviceContext(int deviceId = 0);
+    // a context owned by someone else -- a member of a multi-device group (ilm_group_ctx): used, never destroyed, by this object
+    struct Borrowed { IlmHandle handle; };
+    explicit DeviceContext(Borrowed member) : handle(member.handle), owned(false) {}
     ~DeviceContext();
     DeviceContext(const DeviceContext&) = delete;
     IlmHandle Handle() const { return handle; }
@@ -80,6 +83,7 @@ public:
     float TimerStop();
 private:
     IlmHandle handle = 0;
+    bool owned = true;
 };
 
 // ---- SDF/DistanceField.cs ---------------------------------------------------------------------------

@@ -91,6 +91,22 @@ SYMBOLS = {
     "ilm_ctx_set_light_ramp": (_I, [_H, _P, _I, _I]),
     "ilm_system_set_bitmap": (_I, [_H, _P, _I, _I]),
     "ilm_resolve_lighting": (_I, [_H, _H, _P, _I, _I]),
+    "ilm_group_create": (_I, [_P, _I, C.POINTER(_H)]),
+    "ilm_group_unique_id": (_I, [_P]),
+    "ilm_group_create_rank": (_I, [_I, _I, _I, _P, C.POINTER(_H)]),
+    "ilm_group_destroy": (_I, [_H]),
+    "ilm_group_info": (_I, [_H, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "ilm_group_ctx": (_I, [_H, _I, C.POINTER(_H)]),
+    "ilm_group_sync": (_I, [_H]),
+    "ilm_group_all_gather": (_I, [_H, _P, C.c_uint64, _I]),
+    "ilm_group_host_all_gather": (_I, [_H, _P, _P, C.c_uint32]),
+    "ilm_group_lightmap_create": (_I, [_H, _I, _I, _I, C.POINTER(_H)]),
+    "ilm_group_lightmap_member": (_I, [_H, _I, C.POINTER(_H)]),
+    "ilm_group_lightmap_strip": (_I, [_H, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "ilm_group_lightmap_gather": (_I, [_H, _I]),
+    "ilm_group_lightmap_destroy": (_I, [_H]),
+    "ilm_group_render_sphere_lights": (_I, [_H, _P, _I, _P, _P, _P, _P, _P, _H, _I, _P]),
+    "ilm_group_live_counts": (_I, [_H, _P, _I, _P, _I, _I]),
 }
 
 
@@ -130,9 +146,14 @@ def _byref(s):
 class Context:
     """One GPU + one HIP stream (ilm_ctx_*)."""
 
-    def __init__(self, device_id=0):
-        self.handle = abi.Handle(0)
-        check(lib().ilm_ctx_create(device_id, C.byref(self.handle)))
+    def __init__(self, device_id=0, borrowed_handle=None):
+        """borrowed_handle: a context owned by someone else (a group member, ilm_group_ctx): close() leaves it alone."""
+        self.owned = borrowed_handle is None
+        if borrowed_handle is not None:
+            self.handle = abi.Handle(int(borrowed_handle))
+        else:
+            self.handle = abi.Handle(0)
+            check(lib().ilm_ctx_create(device_id, C.byref(self.handle)))
         self.device_id = device_id
 
     def sync(self):
@@ -169,9 +190,9 @@ class Context:
         return float(ms.value)
 
     def close(self):
-        if self.handle.value:
+        if self.handle.value and self.owned:
             lib().ilm_ctx_destroy(self.handle)
-            self.handle = abi.Handle(0)
+        self.handle = abi.Handle(0)
 
 
 class Engine:
@@ -453,9 +474,14 @@ _LM_DTYPE = {abi.LIGHTMAP_FLOAT4: (np.float32, 4), abi.LIGHTMAP_HALF4: (np.float
 
 
 class Lightmap:
-    def __init__(self, ctx, width, height, fmt=abi.LIGHTMAP_FLOAT4, external_ptr=None):
+    def __init__(self, ctx, width, height, fmt=abi.LIGHTMAP_FLOAT4, external_ptr=None, borrowed_handle=None):
+        """borrowed_handle: a lightmap owned by someone else (a group lightmap's member): close() leaves it alone."""
         self.ctx = ctx
         self.width, self.height, self.format = width, height, fmt
+        self.owned = borrowed_handle is None
+        if borrowed_handle is not None:
+            self.handle = abi.Handle(int(borrowed_handle))
+            return
         self.handle = abi.Handle(0)
         check(lib().ilm_lightmap_create(ctx.handle, width, height, fmt, external_ptr, C.byref(self.handle)))
 
@@ -478,9 +504,132 @@ class Lightmap:
         check(lib().ilm_lightmap_clear(self.handle, c))
 
     def close(self):
-        if self.handle.value:
+        if self.handle.value and self.owned:
             lib().ilm_lightmap_destroy(self.handle)
+        self.handle = abi.Handle(0)
+
+
+GATHER_NONE, GATHER_PEER, GATHER_RCCL = 0, 1, 2
+
+
+class Group:
+    """ilm_group_*: the members of a multi-device group that live in this process.
+
+    Group([0, 1, ...])                                  one process drives the listed devices
+    Group.rank(device, rank, world, unique_id_bytes)    one process per GPU (unique_id from Group.unique_id() on rank 0)
+    """
+
+    def __init__(self, device_ids=None, _handle=None):
+        if _handle is not None:
+            self.handle = _handle
+        else:
+            ids = (C.c_int32 * len(device_ids))(*[int(d) for d in device_ids])
             self.handle = abi.Handle(0)
+            check(lib().ilm_group_create(C.cast(ids, C.c_void_p), len(device_ids), C.byref(self.handle)))
+        n, w, f, cr = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib().ilm_group_info(self.handle, C.byref(n), C.byref(w), C.byref(f), C.byref(cr)))
+        self.n_local, self.world, self.first_rank = int(n.value), int(w.value), int(f.value)
+        self.contexts = []
+        for i in range(self.n_local):
+            h = abi.Handle(0)
+            check(lib().ilm_group_ctx(self.handle, i, C.byref(h)))
+            self.contexts.append(Context(borrowed_handle=h.value))
+
+    @staticmethod
+    def unique_id():
+        buf = (C.c_uint8 * 128)()
+        check(lib().ilm_group_unique_id(C.cast(buf, C.c_void_p)))
+        return bytes(buf)
+
+    @classmethod
+    def rank(cls, device_id, rank, world, unique_id):
+        assert len(unique_id) == 128
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        h = abi.Handle(0)
+        check(lib().ilm_group_create_rank(device_id, rank, world, C.cast(buf, C.c_void_p), C.byref(h)))
+        return cls(_handle=h)
+
+    def comm_ranks(self):
+        """The rank count the RCCL communicator reports (0 while none has been created)."""
+        cr = C.c_int32()
+        check(lib().ilm_group_info(self.handle, None, None, None, C.byref(cr)))
+        return int(cr.value)
+
+    def sync(self):
+        check(lib().ilm_group_sync(self.handle))
+
+    def all_gather(self, device_ptrs, bytes_per_rank, gather):
+        ptrs = (C.c_void_p * self.n_local)(*[int(p) for p in device_ptrs])
+        check(lib().ilm_group_all_gather(self.handle, C.cast(ptrs, C.c_void_p), int(bytes_per_rank), gather))
+
+    def host_all_gather(self, local_bytes):
+        """ilm_group_host_all_gather: `local_bytes` = this process's slots (n_local equal slots); returns the `world` slots as a list of
+        bytes objects.  Also a barrier: every member's queued work has finished when it returns."""
+        assert len(local_bytes) % self.n_local == 0
+        per = len(local_bytes) // self.n_local
+        src = (C.c_uint8 * len(local_bytes)).from_buffer_copy(local_bytes)
+        dst = (C.c_uint8 * (per * self.world))()
+        check(lib().ilm_group_host_all_gather(self.handle, C.cast(src, C.c_void_p), C.cast(dst, C.c_void_p), per))
+        raw = bytes(dst)
+        return [raw[r * per:(r + 1) * per] for r in range(self.world)]
+
+    def live_counts(self, systems, total_chunks, saturate16=False):
+        hs = (abi.Handle * self.n_local)(*[s.handle.value for s in systems])
+        out = np.zeros(max(total_chunks, 1), dtype=np.uint32)
+        check(lib().ilm_group_live_counts(self.handle, C.cast(hs, C.c_void_p), total_chunks, _ptr(out), out.shape[0], 1 if saturate16 else 0))
+        return out[:total_chunks]
+
+    def render_sphere_lights(self, lights, env, df, gbuffers, sdfs, ambient, group_lightmap, gather=GATHER_PEER, want_stats=False):
+        """ilm_group_render_sphere_lights: every local member renders its strip, then the strips are gathered in place."""
+        n = len(lights) if lights is not None else 0
+        amb = (C.c_float * 4)(*[float(x) for x in ambient]) if ambient is not None else None
+        gb = (abi.Handle * self.n_local)(*[(g.handle.value if g is not None else 0) for g in gbuffers]) if gbuffers is not None else None
+        sd = (abi.Handle * self.n_local)(*[(s.handle.value if s is not None else 0) for s in sdfs]) if sdfs is not None else None
+        stats = abi.RenderStats() if want_stats else None
+        check(lib().ilm_group_render_sphere_lights(
+            self.handle, C.cast(lights, C.c_void_p) if n else None, n, _byref(env), _byref(df),
+            C.cast(gb, C.c_void_p) if gb is not None else None, C.cast(sd, C.c_void_p) if sd is not None else None,
+            C.cast(amb, C.c_void_p) if amb is not None else None, group_lightmap.handle, gather, _byref(stats)))
+        return stats
+
+    def close(self):
+        if self.handle.value:
+            check(lib().ilm_group_destroy(self.handle))
+            self.handle = abi.Handle(0)
+            self.contexts = []
+
+
+class GroupLightmap:
+    """ilm_group_lightmap_*: the composited lightmap of a group (one full-frame buffer per local member)."""
+
+    def __init__(self, group, width, height, fmt=abi.LIGHTMAP_FLOAT4):
+        self.group, self.width, self.height, self.format = group, width, height, fmt
+        self.handle = abi.Handle(0)
+        check(lib().ilm_group_lightmap_create(group.handle, width, height, fmt, C.byref(self.handle)))
+        b, e, r = C.c_int32(), C.c_int32(), C.c_int32()
+        self.strips = []
+        for rank in range(group.world):
+            check(lib().ilm_group_lightmap_strip(self.handle, rank, C.byref(b), C.byref(e), C.byref(r)))
+            self.strips.append((int(b.value), int(e.value)))
+        self.slot_rows = int(r.value)
+        self.members = []
+        for i in range(group.n_local):
+            h = abi.Handle(0)
+            check(lib().ilm_group_lightmap_member(self.handle, i, C.byref(h)))
+            self.members.append(Lightmap(group.contexts[i], width, self.slot_rows * group.world, fmt, borrowed_handle=h.value))
+
+    def gather(self, gather):
+        check(lib().ilm_group_lightmap_gather(self.handle, gather))
+
+    def download(self, local_index=0):
+        """The frame (first `height` rows) as local member `local_index` holds it."""
+        return self.members[local_index].download(0, self.height)
+
+    def close(self):
+        if self.handle.value:
+            check(lib().ilm_group_lightmap_destroy(self.handle))
+            self.handle = abi.Handle(0)
+            self.members = []
 
 
 def render_particles(system, params, target, quad_counts=None, chunk_count=None, want_stats=False):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ILM_ABI_VERSION 4
+#define ILM_ABI_VERSION 5
 
 /* ---- return codes ------------------------------------------------------ */
 #define ILM_OK                    0
@@ -734,6 +734,81 @@ typedef struct IlmHDRConfiguration {
  * src and dst are lightmap handles of the same size (any formats; dst RGBA8 is the back-buffer case). */
 int32_t ilm_resolve_lighting(IlmHandle src_lightmap, IlmHandle dst_lightmap, const IlmHDRConfiguration* hdr,
                              int32_t row_begin, int32_t row_end);
+
+/* ---- multi-device groups (SURVEY 8e / 8b "ilm_ctx_create(device_ids, n)") --------------------------------------------------------
+ *
+ * The reference renders on one GraphicsDevice.  A group is the MI355X-native extension that keeps its call sites unchanged while
+ * the work spreads over the GPUs of a node: the caller of LightingRenderer.RenderLighting (Illuminant/Lighting/LightingRenderer.cs:917-923)
+ * still gets ONE composited lightmap per frame (:1004-1010), the caller of ParticleSystem.Update (Illuminant/Particles/ParticleSystem.cs:630-761)
+ * still sees one liveness table.  Two shapes, same entry points afterwards:
+ *   - in-process: one host process drives n devices (ilm_group_create) -- the shape of a C# host;
+ *   - one process per GPU: every process creates its member with the same 128-byte id (ilm_group_unique_id on rank 0, handed to the
+ *     others by the launcher) -- the shape of `torchrun` / MPI jobs.
+ * Each member owns a context (ilm_group_ctx): replicated inputs -- the distance-field atlas, G-buffers, light ramps, randomness tables --
+ * are ordinary per-context objects the host creates in a loop over the members (the atlas is 25 MB; generating it per device is
+ * cheaper than broadcasting it).  Ranks number the members of the whole group: rank = first_rank + local index.
+ *
+ * Lighting: the frame is cut into `world` strips of whole 16-row tile bands, equal slots of R rows (world * R >= height); every member
+ * renders its strip into its own full-frame buffer and the strips are all-gathered IN PLACE, so every device ends with the composited
+ * frame.  Particles: chunks never interact (ParticleSystem.cs:743-745), chunk c lives on rank c % world as that member's chunk
+ * c / world; the per-step data path has no collective, only the per-chunk live counts are gathered (ilm_group_live_counts). */
+
+enum {
+    ILM_GATHER_NONE = 0,  /* strips stay where they were rendered (a host that reads every strip back itself) */
+    ILM_GATHER_PEER = 1,  /* in-process groups: every member pushes its strip to the n - 1 others with hipMemcpyPeerAsync -- one
+                             transfer per xGMI link, all links of the full mesh busy at once */
+    ILM_GATHER_RCCL = 2   /* ncclAllGather on the members' context streams (RCCL over xGMI; the only exchange between processes) */
+};
+
+/* In-process group over `n` devices (ids may repeat: several members on one device, which is how the exchange paths are tested on a
+ * one-GPU box; RCCL itself refuses duplicate devices).  Creates one context per member. */
+int32_t ilm_group_create(const int32_t* device_ids, int32_t n, IlmHandle* out_group);
+/* One-process-per-GPU group: rank 0 obtains `id` (128 bytes) from ilm_group_unique_id and the launcher hands it to every rank; all
+ * `world` processes then call ilm_group_create_rank collectively (it creates the RCCL communicator). */
+int32_t ilm_group_unique_id(void* out_id128);
+int32_t ilm_group_create_rank(int32_t device_id, int32_t rank, int32_t world, const void* id128, IlmHandle* out_group);
+/* Destroys the member contexts too; ILM_ERR_STATE while group lightmaps or objects of the member contexts are alive. */
+int32_t ilm_group_destroy(IlmHandle group);
+/* out_local = members in this process, out_world = members of the whole group, out_first_rank = rank of local member 0,
+ * out_comm_ranks = the rank count the RCCL communicator itself reports (ncclCommCount; 0 while no communicator exists). */
+int32_t ilm_group_info(IlmHandle group, int32_t* out_local, int32_t* out_world, int32_t* out_first_rank, int32_t* out_comm_ranks);
+int32_t ilm_group_ctx(IlmHandle group, int32_t local_index, IlmHandle* out_ctx);
+int32_t ilm_group_sync(IlmHandle group);
+
+/* In-place all-gather of device buffers: buffers[i] (on local member i's device) holds world * bytes_per_rank bytes and rank r's
+ * slot starts at r * bytes_per_rank; on return (stream-ordered on each member's context stream) every buffer holds every slot.
+ * This is the primitive under ilm_group_lightmap_gather; a host uses it directly for the optional Pos+Life all-gather of SURVEY 8e
+ * (planes from ilm_chunk_device_ptr) when a global consumer exists. */
+int32_t ilm_group_all_gather(IlmHandle group, void* const* buffers, uint64_t bytes_per_rank, int32_t gather);
+
+/* Small HOST payloads across the group (timings, counters; <= 1 MiB per rank): local = n_local * bytes_per_rank bytes, one slot per
+ * local member in member order; out_all receives world * bytes_per_rank bytes, rank r's slot at r * bytes_per_rank, identical on every
+ * process.  Waits for the members' queued work first, so it is also the barrier a host brackets a timed region with. */
+int32_t ilm_group_host_all_gather(IlmHandle group, const void* local, void* out_all, uint32_t bytes_per_rank);
+
+/* The composited lightmap of a group: one buffer of world * R rows per local member (the frame is its first `height` rows). */
+int32_t ilm_group_lightmap_create(IlmHandle group, int32_t width, int32_t height, int32_t format, IlmHandle* out_group_lightmap);
+/* The plain lightmap object (aliasing the member's buffer) that per-context calls -- particle lights, resolve, download -- take. */
+int32_t ilm_group_lightmap_member(IlmHandle group_lightmap, int32_t local_index, IlmHandle* out_lightmap);
+/* Rows [*out_row_begin, *out_row_end) of the frame that rank `rank` renders, and the slot height R. */
+int32_t ilm_group_lightmap_strip(IlmHandle group_lightmap, int32_t rank, int32_t* out_row_begin, int32_t* out_row_end, int32_t* out_slot_rows);
+int32_t ilm_group_lightmap_gather(IlmHandle group_lightmap, int32_t gather);
+int32_t ilm_group_lightmap_destroy(IlmHandle group_lightmap);
+
+/* ilm_render_sphere_lights for the whole group: every local member renders its strip (same lights, environment and uniforms;
+ * gbuffers / sdfs = one handle per local member, objects of that member's context, NULL / 0 as in the single-device call), then the
+ * strips are gathered.  stats (may be NULL) = sums over the local members. */
+int32_t ilm_group_render_sphere_lights(IlmHandle group, const IlmLightVertex* lights, int32_t light_count,
+                                       const IlmEnvironment* env, const IlmDistanceFieldUniforms* df,
+                                       const IlmHandle* gbuffers, const IlmHandle* sdfs, const float ambient[4],
+                                       IlmHandle group_lightmap, int32_t gather, IlmRenderStats* stats);
+
+/* Liveness table of a sharded particle system: systems[i] = local member i's system (chunk c of the table = chunk c / world of rank
+ * c % world); out_counts[c] = live count of chunk c from each member's last counting step, identical on every process (integers,
+ * bit-exact).  One small RCCL all-gather when the group spans processes, none otherwise.  Synchronises. */
+int32_t ilm_group_live_counts(IlmHandle group, const IlmHandle* systems, int32_t total_chunks, uint32_t* out_counts, int32_t capacity,
+                              int32_t saturate16);
+
 
 #ifdef __cplusplus
 }

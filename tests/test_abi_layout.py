@@ -142,6 +142,39 @@ def test_no_gpu_means_a_loud_failure_not_a_cpu_fallback():
     assert "no CPU fallback" in str(e2.value)
 
 
+def test_csharp_binding_is_generated_from_this_header():
+    """integration/IlluminantHip.cs (the P/Invoke file a maintainer drops into Illuminant/Native/) is what tools/gen_csharp_binding.py
+    makes of the header today: every declared function has its DllImport, every struct its mirror with the C size."""
+    p = subprocess.run(["python3", os.path.join(ROOT, "tools", "gen_csharp_binding.py"), "--check"], capture_output=True, text=True)
+    assert p.returncode == 0, p.stdout + p.stderr
+    cs = open(os.path.join(ROOT, "integration", "IlluminantHip.cs")).read()
+    imported = set(re.findall(r"public static extern \w+ (ilm_\w+) \(", cs))
+    assert imported == set(declared_functions())
+    for cname, mirror in STRUCTS.items():
+        if cname in ("IlmFloat4", "IlmMatrix", "IlmLightVertex"):      # the reference's own Vector4 / Matrix / LightVertex are used
+            continue
+        m = re.search(r"Size = (\d+)\)\]\s+public (?:unsafe )?struct %s \{" % cname, cs)
+        assert m and int(m.group(1)) == C.sizeof(mirror), cname
+
+
+def test_group_entry_points_validate_without_a_device():
+    """ilm_group_*: handles are looked up before anything else; without a GPU group creation is ILM_ERR_NO_DEVICE, never a fallback."""
+    lib = native.lib()
+    out = abi.Handle(0)
+    assert lib.ilm_group_sync(abi.Handle(0)) == abi.ERR_INVALID_HANDLE
+    assert lib.ilm_group_lightmap_gather(abi.Handle(12345), 1) == abi.ERR_INVALID_HANDLE
+    assert lib.ilm_group_lightmap_create(abi.Handle(0), 16, 16, 0, C.byref(out)) == abi.ERR_INVALID_HANDLE
+    assert lib.ilm_group_create(None, 0, C.byref(out)) == abi.ERR_INVALID_ARGUMENT
+    ids = (C.c_int32 * 2)(0, 1)
+    if native.device_count() == 0:
+        assert lib.ilm_group_create(C.cast(ids, C.c_void_p), 2, C.byref(out)) == abi.ERR_NO_DEVICE
+        assert out.value == 0 and b"no CPU fallback" in lib.ilm_last_error()
+        assert lib.ilm_group_create_rank(0, 0, 1, C.cast(ids, C.c_void_p), C.byref(out)) == abi.ERR_NO_DEVICE
+    # RCCL is bound at run time: the library itself does not depend on it
+    out_dyn = subprocess.run(["readelf", "-d", native.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "rccl" not in out_dyn
+
+
 def test_product_libraries_do_not_link_the_oracle():
     """ldd of the product .so files: the oracle (test infrastructure) is not among their dependencies."""
     libdir = os.path.join(ROOT, "illuminant_amd", "lib")

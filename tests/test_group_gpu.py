@@ -1,0 +1,225 @@
+"""Multi-device groups (ilm_group_*) on the GPU box.
+
+The box has ONE GPU, so the exchange paths run with several members on the same device: that executes the real strip
+rendering (the kernel, not the oracle), the in-place slot layout, the hipMemcpyPeerAsync fan-out with its event ordering and
+RCCL at world size 1 -- everything but the xGMI wire.  The frames must equal the single-context frame bit for bit (same kernel,
+same inputs, disjoint row ranges) and the oracle within the parity tolerance.
+"""
+import numpy as np
+import pytest
+
+from illuminant_amd import abi, native, scenes
+from tests.test_lighting_gpu import small_scene
+from tests.util import assert_close
+
+pytestmark = pytest.mark.gpu
+
+AMBIENT = (0.05, 0.06, 0.07, 1.0)
+
+
+def single_context_frame(ctx, lights, env, dfu, atlas, sfmt, w, h, lm_fmt=abi.LIGHTMAP_FLOAT4):
+    sdf = native.DistanceFieldTexture(ctx, atlas, sfmt)
+    lm = native.Lightmap(ctx, w, h, lm_fmt)
+    stats = native.render_sphere_lights(ctx, lights, env, dfu, None, sdf, AMBIENT, lm, want_stats=True)
+    frame = lm.download()
+    lm.close(); sdf.close()
+    return frame, stats
+
+
+def group_frame(devices, gather, lights, env, dfu, atlas, sfmt, w, h, lm_fmt=abi.LIGHTMAP_FLOAT4, want_stats=True):
+    g = native.Group(devices)
+    sdfs = [native.DistanceFieldTexture(c, atlas, sfmt) for c in g.contexts]      # replicated input: one per member
+    glm = native.GroupLightmap(g, w, h, lm_fmt)
+    stats = g.render_sphere_lights(lights, env, dfu, None, sdfs, AMBIENT, glm, gather, want_stats=want_stats)
+    g.sync()
+    frames = [glm.download(i) for i in range(g.n_local)]
+    info = dict(strips=glm.strips, slot_rows=glm.slot_rows, comm_ranks=g.comm_ranks(), world=g.world)
+    glm.close()
+    for s in sdfs:
+        s.close()
+    g.close()
+    return frames, stats, info
+
+
+@pytest.mark.parametrize("gather", [native.GATHER_NONE, native.GATHER_PEER, native.GATHER_RCCL])
+def test_group_of_one_equals_the_single_context_frame(ctx, oracle, gather):
+    layout, atlas, dfu, lights, w, h = small_scene()
+    env = scenes.environment()
+    want, wstats = single_context_frame(ctx, lights, env, dfu, atlas, abi.SDF_UNORM16, w, h)
+    frames, stats, info = group_frame([0], gather, lights, env, dfu, atlas, abi.SDF_UNORM16, w, h)
+    assert info["world"] == 1 and info["strips"] == [(0, h)] and info["slot_rows"] % 16 == 0 and info["slot_rows"] >= h
+    assert np.array_equal(frames[0], want)
+    assert (stats.SdfSamples, stats.PixelLightPairs, stats.TracedPairs) == (wstats.SdfSamples, wstats.PixelLightPairs, wstats.TracedPairs)
+    owant, ostats = oracle.render_sphere_lights(lights, env, dfu, None, oracle.make_texture(atlas, abi.SDF_UNORM16), AMBIENT, w, h, want_stats=True)
+    assert stats.SdfSamples == ostats.SdfSamples
+    assert_close(frames[0], owant, "group frame vs oracle")
+
+
+@pytest.mark.parametrize("members,fmt", [(2, abi.LIGHTMAP_FLOAT4), (3, abi.LIGHTMAP_HALF4), (8, abi.LIGHTMAP_FLOAT4)])
+def test_peer_fan_out_composites_the_frame_on_every_member(ctx, members, fmt):
+    """Several members on device 0: each renders its strip with the kernel, pushes it to the others; every member ends with
+    the whole frame, equal to the single-context frame (ragged last strip: 112 rows in slots of 64 / 48 / 16)."""
+    layout, atlas, dfu, lights, w, h = small_scene(abi.SDF_FP16)
+    env = scenes.environment()
+    want, wstats = single_context_frame(ctx, lights, env, dfu, atlas, abi.SDF_FP16, w, h, fmt)
+    frames, stats, info = group_frame([0] * members, native.GATHER_PEER, lights, env, dfu, atlas, abi.SDF_FP16, w, h, fmt)
+    strips = info["strips"]
+    assert len(strips) == members and strips[0][0] == 0 and max(e for _, e in strips) == h
+    assert all(b % 16 == 0 for b, _ in strips) and sum(e - b for b, e in strips) == h
+    assert members * info["slot_rows"] >= h
+    for i, f in enumerate(frames):
+        assert np.array_equal(f.view(np.uint8), want.view(np.uint8)), "member %d's composited frame differs" % i
+    assert (stats.SdfSamples, stats.PixelLightPairs, stats.TracedPairs) == (wstats.SdfSamples, wstats.PixelLightPairs, wstats.TracedPairs)
+
+
+def test_without_a_gather_every_member_holds_only_its_strip(ctx):
+    layout, atlas, dfu, lights, w, h = small_scene()
+    env = scenes.environment()
+    want, _ = single_context_frame(ctx, lights, env, dfu, atlas, abi.SDF_UNORM16, w, h)
+    frames, _, info = group_frame([0, 0], native.GATHER_NONE, lights, env, dfu, atlas, abi.SDF_UNORM16, w, h, want_stats=False)
+    for i, (b, e) in enumerate(info["strips"]):
+        assert np.array_equal(frames[i][b:e], want[b:e])
+        other = np.ones(h, bool); other[b:e] = False
+        assert not frames[i][other].any(), "rows outside member %d's strip were written" % i
+
+
+def test_rccl_refuses_members_that_share_a_device(ctx):
+    layout, atlas, dfu, lights, w, h = small_scene()
+    g = native.Group([0, 0])
+    glm = native.GroupLightmap(g, w, h)
+    with pytest.raises(native.IlluminantError) as e:
+        glm.gather(native.GATHER_RCCL)
+    assert e.value.code == abi.ERR_INVALID_ARGUMENT and "one device per member" in str(e.value)
+    glm.close(); g.close()
+
+
+def test_rank_group_of_world_size_one_runs_the_rccl_path(ctx):
+    """The one-process-per-GPU shape at world size 1: ncclCommInitRank, the in-place ncclAllGather on the context stream."""
+    layout, atlas, dfu, lights, w, h = small_scene()
+    env = scenes.environment()
+    want, _ = single_context_frame(ctx, lights, env, dfu, atlas, abi.SDF_UNORM16, w, h)
+    uid = native.Group.unique_id()
+    assert len(uid) == 128
+    g = native.Group.rank(0, 0, 1, uid)
+    assert (g.n_local, g.world, g.first_rank) == (1, 1, 0) and g.comm_ranks() == 1
+    sdf = native.DistanceFieldTexture(g.contexts[0], atlas, abi.SDF_UNORM16)
+    glm = native.GroupLightmap(g, w, h)
+    g.render_sphere_lights(lights, env, dfu, None, [sdf], AMBIENT, glm, native.GATHER_RCCL)
+    g.sync()
+    assert np.array_equal(glm.download(0), want)
+    glm.close(); sdf.close(); g.close()
+
+
+def test_rank_group_gather_modes_at_world_one_are_no_ops(ctx):
+    uid = native.Group.unique_id()
+    g = native.Group.rank(0, 0, 1, uid)
+    glm = native.GroupLightmap(g, 64, 48)
+    glm.gather(native.GATHER_NONE)
+    glm.gather(native.GATHER_RCCL)
+    glm.close(); g.close()
+
+
+def test_generic_all_gather_of_position_planes(ctx):
+    """SURVEY 8e's optional Pos+Life all-gather for a global consumer: 3 members, each fills its slot of a plane-shaped buffer."""
+    import ctypes as C
+    g = native.Group([0, 0, 0])
+    n = 4096
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    bufs = []
+    rng = np.random.default_rng(3)
+    slots = [rng.random(n, dtype=np.float32) for _ in range(3)]
+    for i in range(3):
+        p = C.c_void_p()
+        assert hip.hipMalloc(C.byref(p), 3 * n * 4) == 0
+        host = np.zeros(3 * n, np.float32)
+        host[i * n:(i + 1) * n] = slots[i]
+        assert hip.hipMemcpy(p, host.ctypes.data_as(C.c_void_p), host.nbytes, 1) == 0
+        bufs.append(p)
+    g.all_gather([b.value for b in bufs], n * 4, native.GATHER_PEER)
+    g.sync()
+    want = np.concatenate(slots)
+    for i in range(3):
+        host = np.empty(3 * n, np.float32)
+        assert hip.hipMemcpy(host.ctypes.data_as(C.c_void_p), bufs[i], host.nbytes, 2) == 0
+        assert np.array_equal(host, want)
+        hip.hipFree(bufs[i])
+    g.close()
+
+
+def test_group_live_counts_follow_chunk_mod_world(ctx, oracle):
+    """Chunks sharded chunk -> rank by c % world over two members; the gathered liveness table equals the single-system one
+    and the oracle's (integers, bit-exact)."""
+    cs, n_chunks = 32, 5
+    n = cs * cs
+    rnd = scenes.randomness_table(7)
+    pos, vel, attr = scenes.make_particles(42, n * n_chunks, dead_fraction=0.3)
+    d = abi.StepDesc()
+    d.FirstChunk, d.ChunkCount = 0, -1
+    d.System = scenes.system_uniforms(cs, friction=0.1, max_velocity=2048.0, life_decay=20.0)
+    d.Update = abi.UpdateParams.default()
+    d.OpCount = 1
+    d.Ops[0].Type = abi.OP_GRAVITY
+    d.Ops[0].u.Gravity = scenes.gravity_params([((128.0, 128.0, 0.0), 150.0, 60.0, 1)])
+    d.UpdateMode = abi.UPDATE_POSITIONS
+    d.Flags = abi.STEP_COUNT_LIVE
+
+    def fill(system, chunks):
+        for c in chunks:
+            k = system.add_chunk()
+            sl = slice(c * n, (c + 1) * n)
+            system.upload(k, abi.PLANE_POSITION, pos[sl]); system.upload(k, abi.PLANE_VELOCITY, vel[sl]); system.upload(k, abi.PLANE_ATTRIBUTES, attr[sl])
+
+    eng = native.Engine(ctx, cs, rnd)
+    whole = native.System(eng)
+    fill(whole, range(n_chunks))
+    whole.step(d)
+    want = whole.step_counts()
+    planes = [[pos[c * n:(c + 1) * n].copy(), vel[c * n:(c + 1) * n].copy(), attr[c * n:(c + 1) * n].copy(),
+               np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)] for c in range(n_chunks)]
+    assert np.array_equal(want, oracle.step(planes, cs, rnd, d, want_counts=True))
+    assert 0 < int(want.sum()) < n * n_chunks
+
+    g = native.Group([0, 0])
+    engines = [native.Engine(c, cs, rnd) for c in g.contexts]
+    systems = [native.System(e) for e in engines]
+    for r in range(2):
+        fill(systems[r], range(r, n_chunks, 2))
+        systems[r].step(d)
+    got = g.live_counts(systems, n_chunks)
+    assert got.dtype == np.uint32 and np.array_equal(got, want)
+    # the sharded chunks hold the same particles as the whole system's
+    for c in range(n_chunks):
+        assert np.array_equal(systems[c % 2].download(c // 2, abi.PLANE_POSITION), whole.download(c, abi.PLANE_POSITION))
+    # a table that does not match the sharding rule is refused
+    with pytest.raises(native.IlluminantError):
+        g.live_counts(systems, n_chunks + 2)
+    for s in systems + [whole]:
+        s.close()
+    for e in engines + [eng]:
+        e.close()
+    # the group cannot go while member objects live -- here everything is closed
+    g.close()
+
+
+def test_group_destroy_refuses_while_objects_live(ctx):
+    g = native.Group([0])
+    lm = native.Lightmap(g.contexts[0], 32, 32)
+    with pytest.raises(native.IlluminantError) as e:
+        g.close()
+    assert e.value.code == abi.ERR_STATE
+    lm.close()
+    g.close()
+
+
+def test_host_all_gather_is_the_barrier_and_the_small_exchange(ctx):
+    import struct
+    g = native.Group([0, 0, 0])
+    local = b"".join(struct.pack("<d", 1.5 * (i + 1)) for i in range(3))
+    slots = g.host_all_gather(local)
+    assert [struct.unpack("<d", b)[0] for b in slots] == [1.5, 3.0, 4.5]
+    g.close()
+    r = native.Group.rank(0, 0, 1, native.Group.unique_id())
+    assert r.host_all_gather(struct.pack("<d", 7.25)) == [struct.pack("<d", 7.25)]
+    r.close()

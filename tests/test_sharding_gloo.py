@@ -73,3 +73,14 @@ def test_world_size_2_over_gloo():
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (rank, out[-4000:])
         assert "rank %d ok" % rank in out
+
+
+def test_bench_refuses_a_rank_count_that_does_not_match_gpus():
+    """`--gpus N` must never be printed next to fewer ranks: with a launcher's WORLD_SIZE that disagrees the bench stops before
+    touching a device (VERDICT r01 #1)."""
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and "refusing to report a 2-GPU number from 1 rank" in (p.stderr + p.stdout)
+    assert '"n_gpus"' not in p.stdout
