@@ -171,6 +171,22 @@ SdfView make_sdf_view(const Sdf* f, const IlmDistanceFieldUniforms* df) {
     return v;
 }
 
+// The uniforms of a light / probe pass must describe the atlas that is bound: columns x slice width = atlas width, rows x slice height
+// = atlas height (DistanceField ctor, SDF/DistanceField.cs:91-109; slice size = virtual size / InvScaleFactor, Uniforms.cs:108-109).  The
+// sampler wraps / clamps its taps into the real atlas whatever the uniforms say, but a frame traced through mismatched uniforms is
+// garbage, so it is refused.  Uniforms that do not carry the information (zero / non-finite members, as the particle path leaves
+// them) are not judged.
+const char* field_uniforms_mismatch(const Sdf* f, const IlmDistanceFieldUniforms* df, char* text, size_t n) {
+    if (!f || !df) return nullptr;
+    const double cols = df->TextureSliceCount.x, rows = df->TextureSliceCount.y;
+    const double sw = (double)df->Extent.x / (double)df->ConeAndMisc.w, sh = (double)df->Extent.y / (double)df->StepAndMisc2.w;
+    if (!(cols >= 1 && rows >= 1 && sw >= 1 && sh >= 1) || !std::isfinite(cols * sw) || !std::isfinite(rows * sh)) return nullptr;
+    if (std::fabs(cols * sw - (double)f->width) <= 0.5 && std::fabs(rows * sh - (double)f->height) <= 0.5) return nullptr;
+    snprintf(text, n, "the distance-field uniforms describe a %.0f x %.0f atlas (%g x %g slices of %g x %g) but the bound field is %d x %d",
+             cols * sw, rows * sh, cols, rows, sw, sh, f->width, f->height);
+    return text;
+}
+
 // Handles are the object addresses, but an address is only trusted after it has been found in this table: a stale, foreign or
 // garbage handle is answered with ILM_ERR_INVALID_HANDLE instead of being dereferenced (the C# side owns handle lifetimes and can
 // hand in anything).  One mutex-protected lookup per entry point: ~50 ns against microseconds of launch cost.
@@ -505,6 +521,7 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
     a.chunk_bases = s->d_table;
     a.stride = e->stride;
     a.chunk_size = e->chunk_size;
+    a.slots = e->slots;
     a.first_chunk = first;
     a.chunk_count = count;
     a.op_mask = 0;
@@ -587,6 +604,9 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
     {
         const bool noise_op = (a.op_mask & ((1u << ILM_OP_NOISE) | (1u << ILM_OP_SPATIAL_NOISE))) != 0u;
         const bool noise_touches_dead = noise_op && ((d->UpdateMode == ILM_UPDATE_NONE) || (a.derived.noise_may_revive != 0));
+        // ... and such a launch may have brought never-written slots to life: from now on every slot of its chunks counts as used
+        // (a later step without the Noise op must age, update and count them like the reference does)
+        for (int ci = first; noise_touches_dead && ci < first + count; ci++) s->used[(size_t)ci] = e->slots;
         for (int ci = first; !noise_touches_dead && ci < first + count && a.partial_count < kMaxPartialChunks; ci++) {
             const int used_units = (s->used[(size_t)ci] + 63) / 64;
             if (used_units * 64 < e->slots) {
@@ -1143,7 +1163,7 @@ int32_t ilm_system_live_counts(IlmHandle h, uint32_t* out_counts, int32_t capaci
     const int n = (int)s->chunks.size();
     if (n > 0) {
         HIP_TRY(hipMemsetAsync(s->counts_region(2), 0, sizeof(uint32_t) * (size_t)n * kCountStride, c->stream));
-        HIP_TRY(launch_count_live(s->d_table, s->engine->stride, n, s->counts_region(2), c->stream));
+        HIP_TRY(launch_count_live(s->d_table, s->engine->stride, s->engine->slots, n, s->counts_region(2), c->stream));
     }
     return copy_counts(s, s->counts_region(2), out_counts, capacity, saturate16);
 }
@@ -1634,6 +1654,7 @@ int32_t fill_light_launch(Ctx* c, const IlmEnvironment* env, const IlmDistanceFi
     if (m->ctx != c || (g && g->ctx != c) || (f && f->ctx != c)) return fail(ILM_ERR_INVALID_ARGUMENT, "resources belong to another context");
     if (row_begin < 0 || row_end > m->height || row_begin > row_end)
         return fail(ILM_ERR_OUT_OF_RANGE, "rows [%d, %d) outside [0, %d]", row_begin, row_end, m->height);
+    { char why[256]; if (field_uniforms_mismatch(f, df, why, sizeof(why))) return fail(ILM_ERR_INVALID_ARGUMENT, "%s", why); }
     a->lights = nullptr; a->light_count = 0;
     a->env = *env; a->df = *df;
     a->gbuffer.texels = g ? g->texels : nullptr;
@@ -1745,6 +1766,7 @@ int32_t ilm_render_light_probes(IlmHandle hctx, const IlmLightVertex* lights, in
     if (!env || !df) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
     if (light_count < 0 || (light_count > 0 && !lights)) return fail(ILM_ERR_INVALID_ARGUMENT, "bad light array");
     if (probe_count < 0 || (probe_count > 0 && (!probe_positions || !probe_normals || !out_values))) return fail(ILM_ERR_INVALID_ARGUMENT, "bad probe arrays");
+    { char why[256]; if (field_uniforms_mismatch(f, df, why, sizeof(why))) return fail(ILM_ERR_INVALID_ARGUMENT, "%s", why); }
     if (probe_count == 0) return ILM_OK;
     HIP_TRY(hipSetDevice(c->device));
     if (light_count > c->light_cap) {
@@ -2067,6 +2089,7 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
     if (light_count < 0 || (light_count > 0 && !lights)) return fail(ILM_ERR_INVALID_ARGUMENT, "bad light array");
     if (light_count > 65535) return fail(ILM_ERR_TOO_MANY, "at most 65535 lights per call");
     if (m->ctx != c || (g && g->ctx != c) || (f && f->ctx != c)) return fail(ILM_ERR_INVALID_ARGUMENT, "resources belong to another context");
+    { char why[256]; if (field_uniforms_mismatch(f, df, why, sizeof(why))) return fail(ILM_ERR_INVALID_ARGUMENT, "%s", why); }
     if (row_begin < 0 || row_end > m->height || row_begin > row_end)
         return fail(ILM_ERR_OUT_OF_RANGE, "rows [%d, %d) outside [0, %d]", row_begin, row_end, m->height);
     HIP_TRY(hipSetDevice(c->device));

@@ -74,6 +74,7 @@ struct StepLaunch {
     float* const* chunk_bases;   // device table, one base pointer per chunk
     int64_t stride;              // floats between component planes (multiple of kSlotsPerBlock)
     int32_t chunk_size;
+    int32_t slots;               // chunk_size^2: lanes at or past it are stride padding (the stride is rounded up to 1024) and take no part
     int32_t first_chunk, chunk_count;
     uint32_t op_mask;            // bit t set when an op of type t is present
     int32_t streaming;           // != 0: the chunks of this launch do not fit the Infinity Cache -> non-temporal plane accesses
@@ -111,7 +112,7 @@ hipError_t launch_aos_to_soa(const float4* src, float* plane0, int64_t stride, i
 hipError_t launch_soa_to_aos(const float* plane0, int64_t stride, float4* dst, int32_t first_slot, int32_t count, hipStream_t stream);
 
 // standalone liveness count over the life plane of each chunk (CountLiveParticles.fx)
-hipError_t launch_count_live(float* const* chunk_bases, int64_t stride, int32_t chunk_count, uint32_t* counts, hipStream_t stream);
+hipError_t launch_count_live(float* const* chunk_bases, int64_t stride, int32_t slots, int32_t chunk_count, uint32_t* counts, hipStream_t stream);
 // ordered live-slot compaction of one chunk (ballot + prefix sum); *out_count is a device counter
 hipError_t launch_live_slots(const float* life, int32_t slots, uint32_t* out_slots, uint32_t capacity, uint32_t* out_count, hipStream_t stream);
 

@@ -251,7 +251,8 @@ ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment
             (start.x >= 1.0f + mx) & (start.x <= df.Extent.x - 1.0f - mx) & (L.cx >= mx) & (L.cx <= df.Extent.x - mx) &
             (start.y >= 1.0f + my) & (start.y <= df.Extent.y - 1.0f - my) & (L.cy >= my) & (L.cy <= df.Extent.y - my) &
             (start.z - zoff >= 1.0f + mz) & (start.z - zoff <= df.Extent.z - 1.0f - mz) & (L.cz - zoff >= mz) & (L.cz - zoff <= df.Extent.z - mz);
-        const bool ordinary = (L.cfg_x >= 0x1p-60f) & (L.cfg_x <= 0x1p60f) & (fabsf(df.Extent.w) <= 0x1p20f);
+        // (a negative light radius would make the trace longer than the distance to the light: samples would leave the start -> light segment)
+        const bool ordinary = (L.cfg_x >= 0x1p-60f) & (L.cfg_x <= 0x1p60f) & (fabsf(df.Extent.w) <= 0x1p20f) & (L.radius >= 0.0f);
         const bool alive = liveness > 0.0f;
         if (ordinary && __builtin_amdgcn_ballot_w64(!ends_inside) == 0ull)
             cone_trace_loop<FMT, STATS, true, PAIR>(start, dir, data_y, cfg_z, cone_growth, cone_max_radius, df, sdf, data_x, data_z, steps_remaining, alive, st);

@@ -4,8 +4,8 @@
 // the spawner pass, every active transform and the update pass are applied to a
 // slot in registers, in the reference's pass order, so a chunk streams through
 // HBM once (48 B read + 64 B written per live slot) instead of once per pass.
-// State is SoA; a thread owns 4 consecutive slots so every access is a 16-byte
-// load/store and a wave touches 1 KiB contiguous per instruction.
+// State is SoA; a wave owns 64 consecutive slots (one lane = one slot), so every
+// access is one dword per lane on an SGPR plane base: 256 contiguous bytes per instruction.
 //
 // HBM-bound integer/float streaming work: no MFMA, no LDS (no cross-slot reuse).
 #include <cstdlib>
@@ -71,7 +71,11 @@ ILM_DEV void area_weight_and_t(const IlmAreaParams& a, const StepDerived::Op& dv
 // ---------------------------------------------------------------------------------------------
 // transforms
 // ---------------------------------------------------------------------------------------------
-// PS_Gravity, Gravity.fx:12-61
+// PS_Gravity, Gravity.fx:12-61.  Every +, -, * rounds as the oracle's (this file is compiled with -ffp-contract=off like the rest of
+// the library), so d^2 and the type-0 branch's d^2 - radius are bit-identical to it.  normalize(toCenter), distance / radius and the
+// acceleration cap use v_rsq_f32 / v_rcp_f32 (1 ulp -- the accuracy Direct3D itself grants the reference's rcp / rsq / div): relative
+// error of each attractor's term <= 4e-7, velocities only.  -DILM_GRAVITY_EXACT builds the IEEE sqrt / division form, bit-identical to
+// the oracle, at +14 % step time on cfg2 and cfg4 (measured r02: 25.9 -> 29.3 us, 175 -> 201 us).
 ILM_DEV void apply_gravity(float4& pos, float4& vel, const IlmParticleSystemUniforms& sys, const IlmGravityParams& p, const StepDerived::Op& dv) {
     if ((pos.w <= 0.0f) || !category_ok(vel.w, p.CategoryFilter))
         return;
@@ -84,8 +88,8 @@ ILM_DEV void apply_gravity(float4& pos, float4& vel, const IlmParticleSystemUnif
         const float type = p.AttractorRadiusesAndStrengths[i][2];
         const f3 to_center = apos - xyz(pos);
         float attraction;
-        // velocities only: approximate rcp / rsq (no index or life value depends on them)
         const float d2 = dot3(to_center, to_center);
+#ifndef ILM_GRAVITY_EXACT
         const float inv_len = fast_rsq(d2);
         if (type >= 0.5f) {
             const float distance = d2 * inv_len;
@@ -94,15 +98,37 @@ ILM_DEV void apply_gravity(float4& pos, float4& vel, const IlmParticleSystemUnif
                 attraction *= attraction;
             attraction = attraction * dt_ms * (1.0f / kVelocityConstantScale);
         } else {
+            // the one place of this pass where an operand can cancel (d^2 - radius just above its 0.001 floor): the reference's own
+            // operations, IEEE division included (the attractor type is uniform: physical-type attractors pay, the others do not)
             const float distance_squared = fmaxf(d2 - radius, 0.001f);
-            attraction = fast_rcp(distance_squared);
+            attraction = 1.0f / distance_squared;
         }
         acceleration = acceleration + (((to_center * inv_len) * attraction) * strength);
+#else
+        const float distance = sqrtf(d2);
+        if (type >= 0.5f) {
+            attraction = 1.0f - sat(distance / radius);
+            if (type >= 1.5f)
+                attraction *= attraction;
+            attraction = attraction * dt_ms / kVelocityConstantScale;
+        } else {
+            const float distance_squared = fmaxf(d2 - radius, 0.001f);
+            attraction = 1.0f / distance_squared;
+        }
+        const f3 n = mk3(to_center.x / distance, to_center.y / distance, to_center.z / distance);
+        acceleration = acceleration + ((n * attraction) * strength);
+#endif
     }
     const float maximum_acceleration = dv.max_accel;
+#ifndef ILM_GRAVITY_EXACT
     const float a2 = dot3(acceleration, acceleration);
     if (a2 > maximum_acceleration * maximum_acceleration)
         acceleration = acceleration * (fast_rsq(a2) * maximum_acceleration);
+#else
+    const float current_length = len3(acceleration);
+    if (current_length > maximum_acceleration)
+        acceleration = mk3(acceleration.x / current_length, acceleration.y / current_length, acceleration.z / current_length) * maximum_acceleration;
+#endif
     const float mv = sys.GlobalSettings.z;
     vel.x = fminf(mv, vel.x + acceleration.x);
     vel.y = fminf(mv, vel.y + acceleration.y);
@@ -336,11 +362,18 @@ template <unsigned M>
 ILM_DEV float mod_const(float index) { return (float)((unsigned)index % M); }
 
 // evaluateRandomForIndex, SpawnerCommon.fxh:106-117
-ILM_DEV void evaluate_random_for_index(const float4* __restrict__ rnd, int rw, int rh, float tx_, float ty_, float index, float ox, float oy,
+ILM_DEV void evaluate_random_for_index(const float4* __restrict__ rnd, int rw, int rh, float tx_, float ty_, float index, const IlmSpawnParams& p,
                                        float4& random1, float4& random2, float4& random3) {
+    const float ox = p.RandomnessOffset[0], oy = p.RandomnessOffset[1];
     random1 = random_custom(rnd, rw, rh, tx_, ty_, mod_const<8039u>(index), 0.0f + mod_const<57u>(index), ox, oy, 1.0f, 1.0f);
     random2 = random_custom(rnd, rw, rh, tx_, ty_, mod_const<6180u>(index), 1.0f + mod_const<4031u>(index), ox, oy, 1.0f, 1.0f);
     random3 = random_custom(rnd, rw, rh, tx_, ty_, mod_const<2025u>(index), 2.0f + mod_const<65531u>(index), ox, oy, 1.0f, 1.0f);
+    // "The x and y element of random samples determines the normal" (:114-116): inside evaluateRandomForIndex, so the feedback and
+    // pattern spawners (SpawnParticles.fx:83, PatternSpawner.fx:63) align too
+    if (p.AlignVelocityAndPosition != 0.0f) {
+        random2.x = random1.x;
+        random2.y = random1.y;
+    }
 }
 
 // Spawn_Stage1, SpawnerCommon.fxh:119-160: the slot test, the three random vectors and the position-constant indices
@@ -349,11 +382,7 @@ ILM_DEV bool spawn_stage1(float x, float y, const float4* __restrict__ rnd, int 
     const float index = x + (y * p.ChunkSizeAndIndices[0]);
     if ((index < p.ChunkSizeAndIndices[1]) || (index > p.ChunkSizeAndIndices[2]))
         return false;
-    evaluate_random_for_index(rnd, rw, rh, tx_, ty_, index, p.RandomnessOffset[0], p.RandomnessOffset[1], random1, random2, random3);
-    if (p.AlignVelocityAndPosition != 0.0f) {
-        random2.x = random1.x;
-        random2.y = random1.y;
-    }
+    evaluate_random_for_index(rnd, rw, rh, tx_, ty_, index, p, random1, random2, random3);
     const float relative_index = index - p.ChunkSizeAndIndices[1];
     if (p.PolygonRate > 0.05f) {
         const float position_index_f = (relative_index / p.PolygonRate) + p.ChunkSizeAndIndices[3];
@@ -471,7 +500,7 @@ ILM_DEV bool spawn_slot_feedback(float4& pos, float4& vel, float4& attr, float x
     const float4 source_attributes = mk4(src[8 * S + si], src[9 * S + si], src[10 * S + si], src[11 * S + si]);
 
     float4 random1, random2, random3;
-    evaluate_random_for_index(rnd, rw, rh, tx_, ty_, index, p.RandomnessOffset[0], p.RandomnessOffset[1], random1, random2, random3);
+    evaluate_random_for_index(rnd, rw, rh, tx_, ty_, index, p, random1, random2, random3);
 
     const float4 zero = mk4(0.0f, 0.0f, 0.0f, 0.0f);
     float4 position_constant = ld4(p.InlinePositionConstants[0]);
@@ -546,7 +575,7 @@ ILM_DEV bool spawn_slot_pattern(float4& pos, float4& vel, float4& attr, float x,
     const float4 pattern_color = pattern_fetch(tex, tw, th, levels, u, v, pt.TexelOffsetAndMipBias[3]);
 
     float4 random1, random2, random3;
-    evaluate_random_for_index(rnd, rw, rh, tx_, ty_, index, p.RandomnessOffset[0], p.RandomnessOffset[1], random1, random2, random3);
+    evaluate_random_for_index(rnd, rw, rh, tx_, ty_, index, p, random1, random2, random3);
 
     const float4 zero = mk4(0.0f, 0.0f, 0.0f, 0.0f);
     float4 temp_position = evaluate_formula(zero, ld4(p.InlinePositionConstants[0]), ld4(p.Configuration[0]), ld4(p.Configuration[1]),
@@ -628,8 +657,11 @@ ILM_DEV void render_data(float vx, float vy, float4 position, float4 velocity, f
 
     // getRotationForVelocity, UpdateCommon.fxh:81-94
     float rotation = 0.0f;
-    // the angle is multiplied by getVelocityRotation(): skipping atan2 when that is 0 is exact
-    if ((sys.AnimationRateAndRotationAndZToY.z != 0.0f) && !((fabsf(velocity.x) < 0.01f) && (fabsf(velocity.y) < 0.01f))) {
+    // the angle is multiplied by getVelocityRotation(): skipping atan2 when that is 0 is exact for every finite or infinite velocity
+    // (the angle is finite); a NaN velocity (normalize(0) upstream) makes the angle NaN and NaN * 0 stays NaN
+    if (sys.AnimationRateAndRotationAndZToY.z == 0.0f) {
+        rotation = ((velocity.x != velocity.x) || (velocity.y != velocity.y)) ? __builtin_nanf("") : 0.0f;
+    } else if (!((fabsf(velocity.x) < 0.01f) && (fabsf(velocity.y) < 0.01f))) {
         rotation = atan2f(velocity.y, velocity.x);
         if (rotation < 0.0f)
             rotation += 2.0f * kPi;
@@ -844,6 +876,10 @@ ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* ub, int chunk, int i, unsigne
         }
     }
     bool live_after = false;
+    // Stride padding (chunk sizes whose square is not a multiple of 1024: 10, 16, 48 ...): not a slot of the chunk.  Noise has no life
+    // check, so without this a padding lane could be given a life, be updated and be counted (CountLiveParticles.fx counts ChunkSize^2 pixels).
+    if (i >= a.slots)
+        return false;
     if (mode == ILM_UPDATE_ERASE) {
         // PS_Erase, UpdateParticleSystem.fx:40-49
 #pragma unroll
@@ -1134,14 +1170,15 @@ hipError_t launch_soa_to_aos(const float* plane0, int64_t stride, float4* dst, i
 // ---------------------------------------------------------------------------------------------
 // liveness: standalone count + ordered live-slot compaction
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void count_live_kernel(float* const* __restrict__ bases, int64_t stride, uint32_t* __restrict__ counts) {
+__global__ __launch_bounds__(256) void count_live_kernel(float* const* __restrict__ bases, int64_t stride, int slots, uint32_t* __restrict__ counts) {
     __shared__ uint32_t wave_live[4];
     const int chunk = (int)blockIdx.y;
     const float* life = bases[chunk] + 3 * stride;
     const int i0 = ((int)blockIdx.x * 256 + (int)threadIdx.x) * 4;
     const float4 l = *reinterpret_cast<const float4*>(life + i0);
-    const uint32_t n = (uint32_t)__popcll(__ballot(l.x > 0.0f)) + (uint32_t)__popcll(__ballot(l.y > 0.0f)) +
-                       (uint32_t)__popcll(__ballot(l.z > 0.0f)) + (uint32_t)__popcll(__ballot(l.w > 0.0f));
+    // only the chunk's ChunkSize^2 slots are particles: the padding up to the stride is not counted
+    const uint32_t n = (uint32_t)__popcll(__ballot((i0 < slots) && (l.x > 0.0f))) + (uint32_t)__popcll(__ballot((i0 + 1 < slots) && (l.y > 0.0f))) +
+                       (uint32_t)__popcll(__ballot((i0 + 2 < slots) && (l.z > 0.0f))) + (uint32_t)__popcll(__ballot((i0 + 3 < slots) && (l.w > 0.0f)));
     if ((threadIdx.x & 63) == 0) wave_live[threadIdx.x >> 6] = n;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1149,9 +1186,9 @@ __global__ __launch_bounds__(256) void count_live_kernel(float* const* __restric
         if (total != 0) atomicAdd(&counts[chunk * kCountStride], total);
     }
 }
-hipError_t launch_count_live(float* const* chunk_bases, int64_t stride, int32_t chunk_count, uint32_t* counts, hipStream_t stream) {
+hipError_t launch_count_live(float* const* chunk_bases, int64_t stride, int32_t slots, int32_t chunk_count, uint32_t* counts, hipStream_t stream) {
     if (chunk_count <= 0) return hipSuccess;
-    hipLaunchKernelGGL(count_live_kernel, dim3((unsigned)(stride / 1024), (unsigned)chunk_count), dim3(256), 0, stream, chunk_bases, stride, counts);
+    hipLaunchKernelGGL(count_live_kernel, dim3((unsigned)(stride / 1024), (unsigned)chunk_count), dim3(256), 0, stream, chunk_bases, stride, slots, counts);
     return hipGetLastError();
 }
 

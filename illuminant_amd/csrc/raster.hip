@@ -397,6 +397,13 @@ void free_raster_scratch(RasterScratch& s) {
 }
 
 // setup -> scan -> emit -> sort -> tiles.  One host synchronisation (the pair count sizes the key buffers).
+struct SaturatingAdd {
+    __host__ __device__ uint32_t operator()(uint32_t x, uint32_t y) const {
+        const uint32_t sum = x + y;
+        return (sum < x) ? 0xFFFFFFFFu : sum;
+    }
+};
+
 hipError_t render_particles(RasterLaunch& a, RasterScratch& s, hipStream_t stream, unsigned long long out_stats[3], bool* too_many) {
     *too_many = false;
     const size_t n = (size_t)a.total_slots;
@@ -415,15 +422,16 @@ hipError_t render_particles(RasterLaunch& a, RasterScratch& s, hipStream_t strea
     hipLaunchKernelGGL(raster_setup_kernel, slot_grid, block, 0, stream, a);
     RASTER_TRY(hipGetLastError());
     size_t scan_bytes = 0;
-    RASTER_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, a.counts, a.offsets, 0u, n, rocprim::plus<uint32_t>(), stream));
+    // saturating addition (associative): a total beyond 32 bits reads 0xFFFFFFFF instead of wrapping below the bound checked next
+    RASTER_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, a.counts, a.offsets, 0u, n, SaturatingAdd(), stream));
     RASTER_TRY(grow(&s.temp, &s.temp_cap, scan_bytes, stream));
-    RASTER_TRY(rocprim::exclusive_scan(s.temp, scan_bytes, a.counts, a.offsets, 0u, n, rocprim::plus<uint32_t>(), stream));
+    RASTER_TRY(rocprim::exclusive_scan(s.temp, scan_bytes, a.counts, a.offsets, 0u, n, SaturatingAdd(), stream));
     uint32_t last[2] = { 0u, 0u };
     RASTER_TRY(hipMemcpyAsync(&last[0], a.offsets + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     RASTER_TRY(hipMemcpyAsync(&last[1], a.counts + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     RASTER_TRY(hipStreamSynchronize(stream));
     const unsigned long long pairs = (unsigned long long)last[0] + (unsigned long long)last[1];
-    // (the 32-bit scan would have wrapped long before this bound if it were exceeded: one pair per slot and tile, 2^28 keys = 2 GiB)
+    // (one pair per slot and tile; 2^28 keys = 2 GiB.  The scan saturates, so a wrapped total cannot slip under this bound.)
     if (pairs > (1ull << 28)) { *too_many = true; return hipSuccess; }
     a.pair_count = (int64_t)pairs;
     if (pairs > 0) {

@@ -115,10 +115,14 @@ void orc_spatial_noise(IlmFloat4* pos, IlmFloat4* vel, int32_t chunk_size, const
 }
 
 /* evaluateRandomForIndex, SpawnerCommon.fxh:106-117 */
-static void evaluate_random_for_index(const f4* rnd, int rw, int rh, float index, const float offset[2], f4* r1, f4* r2, f4* r3) {
+static void evaluate_random_for_index(const f4* rnd, int rw, int rh, float index, const float offset[2], float align_velocity_and_position,
+                                      f4* r1, f4* r2, f4* r3) {
     *r1 = random_custom(rnd, rw, rh, fmodf(index, 8039.0f), 0.0f + fmodf(index, 57.0f), offset, 1.0f, 1.0f);
     *r2 = random_custom(rnd, rw, rh, fmodf(index, 6180.0f), 1.0f + fmodf(index, 4031.0f), offset, 1.0f, 1.0f);
     *r3 = random_custom(rnd, rw, rh, fmodf(index, 2025.0f), 2.0f + fmodf(index, 65531.0f), offset, 1.0f, 1.0f);
+    /* "The x and y element of random samples determines the normal", :114-116 -- part of evaluateRandomForIndex, so every spawner
+     * technique that calls it (Spawn_Stage1, PS_SpawnFeedback SpawnParticles.fx:83, PS_SpawnPattern PatternSpawner.fx:63) aligns */
+    if (align_velocity_and_position != 0.0f) { r2->x = r1->x; r2->y = r1->y; }
 }
 
 /* tex2Dlod(PositionConstantSampler, index * PositionConstantTexel.x): POINT, CLAMP, on the Spawner's PositionBuffer whose
@@ -161,8 +165,7 @@ static void spawn_position_buffer_slot(f4* pos, f4* vel, f4* attr, float x, floa
     }
     /* Spawn_Stage2 (SpawnerCommon.fxh:162-190) on the two fetched constants */
     f4 random1, random2, random3;
-    evaluate_random_for_index(rnd, rw, rh, index, p->RandomnessOffset, &random1, &random2, &random3);
-    if (p->AlignVelocityAndPosition != 0.0f) { random2.x = random1.x; random2.y = random1.y; }
+    evaluate_random_for_index(rnd, rw, rh, index, p->RandomnessOffset, p->AlignVelocityAndPosition, &random1, &random2, &random3);
     f4 position1 = position_constant_fetch(positions, position_count, index1), position2 = position_constant_fetch(positions, position_count, index2);
     f4 position_constant = v4lerp(position1, position2, position_index_t);
     f4 towards_next = v4sub(position2, position1);
@@ -212,7 +215,7 @@ static void spawn_feedback_slot(f4* pos, f4* vel, f4* attr, float x, float y, co
         return;
 
     f4 random1, random2, random3;
-    evaluate_random_for_index(rnd, rw, rh, index, p->RandomnessOffset, &random1, &random2, &random3);
+    evaluate_random_for_index(rnd, rw, rh, index, p->RandomnessOffset, p->AlignVelocityAndPosition, &random1, &random2, &random3);
 
     const f4 zero = v4(0, 0, 0, 0);
     const f4* C = p->Configuration;
@@ -284,7 +287,7 @@ static void spawn_pattern_slot(f4* pos, f4* vel, f4* attr, float x, float y, con
     f4 pattern_color = pattern_fetch(tex, tw, th, levels, u, v, pt->TexelOffsetAndMipBias[3]);
 
     f4 random1, random2, random3;
-    evaluate_random_for_index(rnd, rw, rh, index, p->RandomnessOffset, &random1, &random2, &random3);
+    evaluate_random_for_index(rnd, rw, rh, index, p->RandomnessOffset, p->AlignVelocityAndPosition, &random1, &random2, &random3);
 
     const f4 zero = v4(0, 0, 0, 0);
     const f4* C = p->Configuration;

@@ -560,6 +560,15 @@ def gen_transforms_ext():
     # 6 texels wide => 8 particles per row (next power of two); the 8th has u > 1 and is rejected, the 7th is one of the
     # "garbage particles on the right" the shader comment mentions and survives
     cases.append(pattern_case("npot 6x4", 6, 4, 1, 0, 1, 0, 32, [1.0, 1.0, 1.0, 1.0], True))
+    # (i) AlignVelocityAndPosition lives INSIDE evaluateRandomForIndex (SpawnerCommon.fxh:106-117: "The x and y element of random samples
+    #     determines the normal": random2.xy = random1.xy), which PS_SpawnFeedback (SpawnParticles.fx:83) and PS_SpawnPattern
+    #     (PatternSpawner.fx:63) call like Spawn_Stage1 does.  With Spherical position and velocity formulas (constants 0, offsets 0) the new
+    #     position is n(random1.xy) * random1.z * scale and the velocity n(random2.xy) * random2.z * scale: aligned, the velocity of every
+    #     new particle points along its offset from the formula's centre -- whatever the randomness table holds.  (Unaligned they are
+    #     unrelated directions.)  The centre is the position constant, plus the pattern spawner's per-pixel offset.
+    cases.append({"kind": "aligned_spawn", "spawner": "feedback", "first": 64, "last": 64 + 95, "position_scale": 40.0, "velocity_scale": 9.0})
+    cases.append({"kind": "aligned_spawn", "spawner": "pattern", "first": 16, "last": 16 + 31, "position_scale": 40.0, "velocity_scale": 9.0,
+                  "texture_size": [8, 4], "position_constant": [100.0, 200.0, 5.0]})
     return {"source": "hand-derived from MatrixMultiply.fx:22-52, ParticleCommon.fxh:183-196, Noise.fx:74-116, RandomCommon.fxh:36-39, "
                       "SpawnParticles.fx:32-118, ParticleSpawner.cs:301-367, PatternSpawner.fx:21-97, SpecialSpawners.cs:208-256 "
                       "(see comments in make_golden.py)",

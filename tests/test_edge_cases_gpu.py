@@ -243,3 +243,68 @@ def test_traces_along_the_fields_last_column_and_outside_it(ctx, oracle, sfmt, r
     assert (stats.SdfSamples, stats.PixelLightPairs, stats.TracedPairs) == (ostats.SdfSamples, ostats.PixelLightPairs, ostats.TracedPairs)
     assert ostats.TracedPairs > 0.5 * ostats.PixelLightPairs > 0
     assert_close(got, want, "lightmap with traces on and beyond the field's edges")
+
+
+def reviving_noise():
+    """A Noise op whose life delta is not zero (PositionScale.w != 0): it has no life check (Noise.fx:40), so it gives dead -- and
+    never-written -- slots a life."""
+    return scenes.noise_params(scenes.area_none(), (0.3 * 253, 0.6 * 127), (0.8 * 253, 0.1 * 127), 0.4, cycles_per_second=10.0,
+                               position=((0.5,) * 4, (0,) * 4, (1.0, 1.0, 0.0, 4.0)))
+
+
+@pytest.mark.parametrize("cs", [10, 48])
+def test_stride_padding_is_not_a_particle(ctx, oracle, cs):
+    """Chunk sizes whose square is not a multiple of 64 / 1024 leave padding lanes behind the last slot (the plane stride is rounded
+    up).  A reviving Noise runs on every lane it is given: the padding must not come to life, be updated or be counted -- the
+    reference counts ChunkSize^2 pixels."""
+    n = cs * cs
+    rnd = scenes.randomness_table(7)
+    eng = native.Engine(ctx, cs, rnd); sysm = native.System(eng)
+    sysm.add_chunk()
+    chunk = [np.zeros((n, 4), np.float32) for _ in range(5)]      # an empty chunk: every slot dead
+    d = plain_desc(cs)
+    d.OpCount = 1
+    d.Ops[0].Type = abi.OP_NOISE; d.Ops[0].u.Noise = reviving_noise()
+    d.Flags = abi.STEP_COUNT_LIVE
+    for _ in range(2):
+        sysm.step(d)
+        want = oracle.step([chunk], cs, rnd, d, want_counts=True)
+        assert np.array_equal(sysm.step_counts(), want)
+        assert np.array_equal(sysm.live_counts(), want)
+    assert 0 < int(want[0]) <= n, "the noise must have revived slots (and no more than the chunk has)"
+    got = sysm.download(0, P)
+    assert np.array_equal(got[:, 3] > 0, chunk[0][:, 3] > 0)
+    assert_close(got, chunk[0], "revived particles", life_exact=True)
+    sysm.close(); eng.close()
+
+
+def test_slots_revived_past_the_high_water_mark_stay_in_the_step(ctx, oracle):
+    """A spawn-target chunk with a few spawned slots is skipped past its high-water mark -- until a reviving Noise has written every
+    slot.  The plain Update that follows must age, move and count the revived slots like the reference."""
+    cs = 64
+    n = cs * cs
+    rnd = scenes.randomness_table(7)
+    eng = native.Engine(ctx, cs, rnd); sysm = native.System(eng)
+    sysm.add_chunk()
+    chunk = [np.zeros((n, 4), np.float32) for _ in range(5)]
+    d = plain_desc(cs)
+    d.SpawnCount = 1
+    d.Spawns[0].ChunkIndex = 0
+    d.Spawns[0].Params = scenes.spawn_params(cs, 0, 99, 0, (0.1 * 253, 0.2 * 127))          # 100 of 4096 slots spawned
+    d.Flags = abi.STEP_COUNT_LIVE
+    sysm.step(d); oracle.step([chunk], cs, rnd, d)
+    # single-pass reviving noise over the chunk (UpdateMode none): touches dead and never-written slots
+    sysm.noise(0, scenes.system_uniforms(cs), reviving_noise())
+    oracle.noise(chunk[0], chunk[1], cs, rnd, scenes.system_uniforms(cs), reviving_noise())
+    revived = int((chunk[0][:, 3] > 0).sum())
+    assert revived > 1000, revived
+    # a plain step without the noise op
+    d2 = plain_desc(cs)
+    d2.Flags = abi.STEP_COUNT_LIVE
+    for _ in range(2):
+        sysm.step(d2)
+        want = oracle.step([chunk], cs, rnd, d2, want_counts=True)
+        assert np.array_equal(sysm.step_counts(), want), "revived slots past the high-water mark were skipped"
+    for k, pl in enumerate((P, V, RC, RD)):
+        assert_close(sysm.download(0, pl), chunk[(0, 1, 3, 4)[k]], "plane %d after the plain steps" % pl, life_exact=(k == 0))
+    sysm.close(); eng.close()

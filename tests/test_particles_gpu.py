@@ -60,7 +60,7 @@ def test_gravity_matches_oracle(ctx, oracle, rnd, chunk_size):
     got_p, got_v = sysm.download(0, P), sysm.download(0, V)
     want_p, want_v = pos.copy(), vel.copy()
     oracle.gravity(want_p, want_v, chunk_size, su, g)
-    assert_close(got_p, want_p, "gravity position")
+    assert_close(got_p, want_p, "gravity position", life_exact=True)
     assert_close(got_v, want_v, "gravity velocity")
     # category 1 is outside the (0,0) filter the reference leaves bound: untouched
     untouched = vel[:, 3] == 1.0
@@ -85,7 +85,7 @@ def test_fma_matches_oracle(ctx, oracle, rnd, area_type):
     got_p, got_v = sysm.download(0, P), sysm.download(0, V)
     want_p, want_v = pos.copy(), vel.copy()
     oracle.fma(want_p, want_v, cs, su, f)
-    assert_close(got_p, want_p, "fma position area %d" % area_type)
+    assert_close(got_p, want_p, "fma position area %d" % area_type, life_exact=True)
     assert_close(got_v, want_v, "fma velocity area %d" % area_type)
     sysm.close(); eng.close()
 
@@ -105,7 +105,7 @@ def test_noise_matches_oracle(ctx, oracle, rnd, replace):
     got_p, got_v = sysm.download(0, P), sysm.download(0, V)
     want_p, want_v = pos.copy(), vel.copy()
     oracle.noise(want_p, want_v, cs, rnd, su, nz)
-    assert_close(got_p, want_p, "noise position")
+    assert_close(got_p, want_p, "noise position", life_exact=True)
     assert_close(got_v, want_v, "noise velocity")
     sysm.close(); eng.close()
 
@@ -138,7 +138,7 @@ def test_noise_texel_steps_inside_a_chunk(ctx, oracle, rnd, cs, x_cur, x_next, y
     got_p, got_v = sysm.download(0, P), sysm.download(0, V)
     want_p, want_v = pos.copy(), vel.copy()
     oracle.noise(want_p, want_v, cs, rnd, su, nz)
-    assert_close(got_p, want_p, "noise position")
+    assert_close(got_p, want_p, "noise position", life_exact=True)
     assert_close(got_v, want_v, "noise velocity")
     # the deltas really change across a chosen step (otherwise the test would not notice a wrong texel)
     if x_cur is not None and 0 < x_cur < cs:
@@ -187,7 +187,7 @@ def test_spawn_matches_oracle(ctx, oracle, rnd, case):
     assert np.array_equal(changed_got, changed_want)
     assert not changed_got[:first].any() and not changed_got[last + 1:].any()
     for k, name in enumerate(("position", "velocity", "attributes")):
-        assert_close(got[k], want[k], "spawn %s (%s)" % (name, case))
+        assert_close(got[k], want[k], "spawn %s (%s)" % (name, case), life_exact=(k == 0))
     sysm.close(); eng.close()
 
 
@@ -232,7 +232,7 @@ def test_update_positions_matches_oracle(ctx, oracle, rnd, variant):
     assert np.array_equal(live_mask(got[0]), live_mask(want[0]))
     assert (want[0][:, 3] <= 0).sum() > n // 5
     for k, name in enumerate(("position", "velocity", "attributes", "render color", "render data")):
-        assert_close(got[k], want[k], "update %s v%d" % (name, variant))
+        assert_close(got[k], want[k], "update %s v%d" % (name, variant), life_exact=(k == 0))
     # dead slots are all-zero
     dead = ~live_mask(got[0])
     for k in (0, 1, 3, 4):
@@ -268,7 +268,7 @@ def test_update_with_distance_field_matches_oracle(ctx, oracle, rnd, fmt, packed
     # the collision state machine is discontinuous: a slot whose branch flipped because a distance sits within
     # float noise of a threshold would differ wholesale; none may (basic arithmetic is bit-identical by construction)
     for k, name in enumerate(("position", "velocity", "attributes", "render color", "render data")):
-        assert_close(got[k], want[k], "update-df %s" % name)
+        assert_close(got[k], want[k], "update-df %s" % name, life_exact=(k == 0))
     # the scene must exercise the collision branches
     bounced = (want[1][:, 3] == 3.0).sum()
     assert bounced > 20, bounced
@@ -348,7 +348,7 @@ def test_fused_step_matches_pass_by_pass_oracle(ctx, oracle, rnd, cs, n_chunks, 
         got = download_state(sysm, c)
         assert np.array_equal(live_mask(got[0]), live_mask(chunks[c][0]))
         for k, name in enumerate(("position", "velocity", "attributes", "render color", "render data")):
-            assert_close(got[k], chunks[c][k], "fused step chunk %d %s" % (c, name))
+            assert_close(got[k], chunks[c][k], "fused step chunk %d %s" % (c, name), life_exact=(k == 0))
     if sdf is not None:
         sdf.close()
     sysm.close(); eng.close()

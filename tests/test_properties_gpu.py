@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from illuminant_amd import abi, native, scenes
-from tests.util import assert_close
+from tests.util import assert_bits_equal, assert_close
 
 pytestmark = pytest.mark.gpu
 
@@ -36,7 +36,7 @@ def cfg2_step(cs, spawn_chunk=None, first=0, last=-1):
     return d
 
 
-def test_cfg2_one_million_particles_properties(ctx):
+def test_cfg2_one_million_particles_properties(ctx, oracle):
     cs, n_chunks = 256, 16
     n = cs * cs
     rnd = scenes.randomness_table(7)
@@ -53,13 +53,24 @@ def test_cfg2_one_million_particles_properties(ctx):
     before = fused.live_counts()
     assert int(before[:n_chunks].sum()) == int((pos[:, 3] > 0).sum()) and before[n_chunks] == 0
 
-    # (1) chunk independence: ONE launch over the 17-chunk table == 17 single-chunk launches.  The 17-chunk launch
-    # carries a spawn record and runs the spawning instantiation of the kernel, the spawn-free single-chunk launches
-    # the plain one; the compiler contracts a*b+c differently in the two, so floats agree to rounding (1e-6) while
-    # everything liveness depends on (the life plane, fenced from contraction) is bit-exact.
+    # (1) chunk independence: ONE launch over the 17-chunk table == 17 single-chunk launches, bit for bit.  The 17-chunk launch
+    # carries a spawn record and runs the spawning instantiation of the kernel, the spawn-free single-chunk launches the plain
+    # one: the same particle gets the same floats whichever variant steps it (no FMA contraction anywhere in the step).
+    # The oracle replays the spawn-target chunk and one full chunk through the same three steps.
     d = cfg2_step(cs, spawn_chunk=n_chunks, first=100, last=100 + 1092)
+    replay = {c: [pos[c * n:(c + 1) * n].copy(), vel[c * n:(c + 1) * n].copy(), attr[c * n:(c + 1) * n].copy(),
+                  np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)] for c in (3,)}
+    replay[n_chunks] = [np.zeros((n, 4), np.float32) for _ in range(5)]
     for _ in range(3):
         fused.step(d)
+        d3 = _single_chunk(d)
+        d3.SpawnCount = 0
+        oracle.step([replay[3]], cs, rnd, d3)
+        ds = _single_chunk(d)
+        ds.SpawnCount = 1
+        ds.Spawns[0] = d.Spawns[0]
+        ds.Spawns[0].ChunkIndex = 0
+        oracle.step([replay[n_chunks]], cs, rnd, ds)
         for c in range(n_chunks + 1):
             dc = cfg2_step(cs, spawn_chunk=n_chunks, first=100, last=100 + 1092)
             dc.FirstChunk, dc.ChunkCount = c, 1
@@ -71,9 +82,7 @@ def test_cfg2_one_million_particles_properties(ctx):
     for c in range(n_chunks + 1):
         for plane in (P, V, RC, RD):
             a, b = fused.download(c, plane), split.download(c, plane)
-            if plane == P:
-                assert np.array_equal(a[:, 3], b[:, 3]), "chunk %d: life differs between fused and per-chunk launches" % c
-            assert_close(a, b, "chunk %d plane %d fused vs per-chunk launches" % (c, plane), rtol=2e-6, atol=1e-7)
+            assert_bits_equal(a, b, "chunk %d plane %d fused vs per-chunk launches" % (c, plane))
         # (2) count checksum: fused ballot/popcount == standalone count kernel == count of the downloaded life plane
         life = fused.download(c, P)[:, 3]
         assert counts_fused[c] == int((life > 0).sum())
@@ -87,6 +96,14 @@ def test_cfg2_one_million_particles_properties(ctx):
     c0 = [fused.download(0, k) for k in (P, V, RC, RD)]
     dead = c0[0][:, 3] <= 0
     assert dead.any() and all(not plane[dead].any() for plane in c0)
+
+    # (2b) the oracle on the spawn-target chunk (the variant the bench's headline times) and on a full chunk, at full size
+    for c, want in replay.items():
+        got = [fused.download(c, k) for k in (P, V, A, RC, RD)]
+        assert counts_fused[c] == oracle.count_live(want[0])
+        for k, name in enumerate(("position", "velocity", "attributes", "render color", "render data")):
+            assert_close(got[k], want[k], "cfg2 chunk %d %s vs oracle" % (c, name), life_exact=(k == 0))
+    assert (replay[n_chunks][0][:, 3] > 0).sum() == 1093
 
     # (3) Erase is idempotent and total (UpdateParticleSystem.fx:40-49 run twice on Clear, ParticleSystem.cs:819-831)
     fused.erase(-1)
@@ -204,7 +221,7 @@ def test_cfg4_share_eight_million_particles(ctx, oracle):
     assert np.array_equal(got[0][:, 3] > 0, keep[0][:, 3] > 0)
     m = keep[0][:, 3] > 0
     for k in (0, 1, 3, 4):
-        assert_close(got[k][m], keep[k][m], "cfg4 chunk 5 plane %d vs oracle" % k)
+        assert_close(got[k][m], keep[k][m], "cfg4 chunk 5 plane %d vs oracle" % k, life_exact=(k == 0))
     for s in (fused, split):
         s.close()
     eng.close()

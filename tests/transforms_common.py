@@ -178,5 +178,49 @@ def check_case(case, backend):
         untouched = [i for i in range(CS * CS) if i not in written]
         assert set(case["rejected_slots"]) <= set(untouched)
         assert np.array_equal(out[0][untouched], old[untouched]) and np.array_equal(out[2][untouched], old_attr[untouched])
+    elif kind == "aligned_spawn":
+        n = CS * CS
+        first, last = case["first"], case["last"]
+        ps, vs = case["position_scale"], case["velocity_scale"]
+
+        def run(align):
+            d = base_desc(1.0 / 60.0)
+            constant = tuple(case.get("position_constant", (0.0, 0.0, 0.0)))
+            p = scenes.spawn_params(CS, first, last, 0, (0.2 * 253, 0.7 * 127),
+                                    position=(constant, (ps, ps, ps), (0, 0, 0), scenes.FORMULA_SPHERICAL),
+                                    velocity=((0, 0, 0), (vs, vs, vs), (0, 0, 0), scenes.FORMULA_SPHERICAL), life=(1.5, 0.0, 0.0), align=align)
+            d.SpawnCount = 1
+            d.Spawns[0].ChunkIndex = 0
+            d.Spawns[0].Params = p
+            old = filled([-1, -1, -1, 0])
+            if case["spawner"] == "feedback":
+                d.Spawns[0].Kind = abi.SPAWN_FEEDBACK
+                d.Spawns[0].Feedback = scenes.feedback_params(0, 0, 0, 1, 0.0, source_life_range=(0.5, 9999.0))
+                src_pos = filled([3.0, 4.0, 5.0, 2.0])
+                out = backend.run(d, rnd, (old, filled([0, 0, 0, 0]), filled([0, 0, 0, 0])),
+                                  source_chunk=(src_pos, filled([0, 0, 0, 0]), filled([1, 1, 1, 1])))
+                centre = np.tile(np.float32([3.0, 4.0, 5.0]), (n, 1))      # AlignPositionConstant: the constant (0) + the source's position
+            else:
+                tw, th = case["texture_size"]
+                d.Spawns[0].Kind = abi.SPAWN_PATTERN
+                d.Spawns[0].Pattern = scenes.pattern_params(tw, th, 1, 0, multiply_color_constant=True)
+                levels = [np.ones((th, tw, 4), np.float32)]
+                out = backend.run(d, rnd, (old, filled([0, 0, 0, 0]), filled([9, 9, 9, 9])), spawn_pattern=levels)
+                k = np.arange(n) - first
+                centre = np.zeros((n, 3), np.float32)
+                centre[:, 0] = constant[0] + (k % tw) - tw * 0.5
+                centre[:, 1] = constant[1] + (k // tw) - th * 0.5
+                centre[:, 2] = constant[2]
+            slots = np.arange(first, last + 1)
+            offset = out[0][slots, :3].astype(np.float64) - centre[slots]
+            velocity = out[1][slots, :3].astype(np.float64)
+            assert (out[0][slots, 3] == 1.5).all(), "every slot of the range spawned"
+            cosine = (offset * velocity).sum(axis=1) / np.maximum(np.linalg.norm(offset, axis=1) * np.linalg.norm(velocity, axis=1), 1e-30)
+            return cosine
+        aligned = run(True)
+        assert (aligned > 1.0 - 1e-5).all(), "%s spawner: velocity must point along the position offset when aligned (min cosine %.6f)" % (
+            case["spawner"], float(aligned.min()))
+        loose = run(False)
+        assert (loose < 0.99).mean() > 0.8, "unaligned directions are unrelated"
     else:
         raise AssertionError("unknown fixture kind %r" % kind)
