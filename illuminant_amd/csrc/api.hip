@@ -653,7 +653,7 @@ int32_t copy_counts(System* s, const uint32_t* d_region, uint32_t* out, int32_t 
     HIP_TRY(hipStreamSynchronize(c->stream));
     for (int i = 0; i < n; i++) {
         const uint32_t v = tmp[(size_t)i * kCountStride];
-        out[i] = (saturate16 && v > 65535u) ? 65535u : v;   // 16-bit additive target, CountLiveParticles.fx:38 + ParticleEngine.cs:244-247
+        out[i] = (saturate16 && v > ref::kLiveCountSaturation) ? ref::kLiveCountSaturation : v;   // 16-bit additive target, CountLiveParticles.fx:38 + ParticleEngine.cs:244-247
     }
     return ILM_OK;
 }
@@ -690,6 +690,15 @@ int ctx_child_count(IlmHandle h) {
 extern "C" {
 
 int32_t ilm_abi_version(void) { return ILM_ABI_VERSION; }
+
+int32_t ilm_debug_reference_constant(const char* key, double* out_value) {
+    if (!key || !out_value) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
+    for (int i = 0; i < ref::kTableSize; i++)
+        if (std::strcmp(ref::kTable[i].key, key) == 0) { *out_value = ref::kTable[i].value; return ILM_OK; }
+    return fail(ILM_ERR_OUT_OF_RANGE, "the kernels take no constant named '%s' from the reference", key);
+}
+int32_t ilm_debug_reference_constant_count(void) { return ref::kTableSize; }
+const char* ilm_debug_reference_constant_key(int32_t index) { return (index >= 0 && index < ref::kTableSize) ? ref::kTable[index].key : ""; }
 const char* ilm_last_error(void) { return g_last_error; }
 
 int32_t ilm_device_count(void) {
@@ -1180,7 +1189,7 @@ int32_t ilm_system_step_counts(IlmHandle h, uint32_t* out_counts, int32_t capaci
         HIP_TRY(hipEventSynchronize(s->counts_ev));  // the copy-out queued behind the last counting step
     for (int i = 0; i < s->counts_n; i++) {
         const uint32_t v = s->h_counts[(size_t)i * kCountStride];
-        out_counts[i] = (saturate16 && v > 65535u) ? 65535u : v;
+        out_counts[i] = (saturate16 && v > ref::kLiveCountSaturation) ? ref::kLiveCountSaturation : v;
     }
     return ILM_OK;
 }
@@ -1198,7 +1207,7 @@ int32_t ilm_system_poll_counts(IlmHandle h, uint32_t* out_counts, int32_t capaci
     if (capacity < s->counts_n) return fail(ILM_ERR_OUT_OF_RANGE, "capacity %d < %d", capacity, s->counts_n);
     for (int i = 0; i < s->counts_n; i++) {
         uint32_t v = s->h_counts[i * kCountStride];
-        out_counts[i] = (saturate16 && v > 65535u) ? 65535u : v;
+        out_counts[i] = (saturate16 && v > ref::kLiveCountSaturation) ? ref::kLiveCountSaturation : v;
     }
     s->counts_pending = false;
     *out_ready = 1;

@@ -240,7 +240,7 @@ ILM_DEV float4 encode_gbuffer_up(float z, bool enable_shadows) {
     const float nx = 0.0001f;                                          // |n.x| < 0.0001 => 0.0001
     const float ex = ((atan2f(0.0f, nx) / kPi) + 1.0f) * 0.5f;
     const float ey = (1.0f + 1.0f) * 0.5f;
-    const float w = (((z + 1024.0f) / 1024.0f) * (enable_shadows ? 1.0f : -1.0f)) + (enable_shadows ? 0.0f : -1.0f);
+    const float w = (((z + ref::kGBufferZOffset) / ref::kGBufferZScale) * (enable_shadows ? 1.0f : -1.0f)) + (enable_shadows ? 0.0f : -1.0f);
     return mk4(ex, ey, 0.0f, w);
 }
 

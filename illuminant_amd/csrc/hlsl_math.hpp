@@ -10,14 +10,15 @@
 #include <stdint.h>
 
 #include "../../include/illuminant_hip.h"
+#include "reference_constants.hpp"
 
 namespace ilm {
 
 #define ILM_DEV __device__ __forceinline__
 
-constexpr float kPi = 3.14159265358979323846f;      // ParticleCommon.fxh:23
-constexpr float kVelocityConstantScale = 1000.0f;   // ParticleCommon.fxh:24
-constexpr float kDistanceZero = 192.0f / 255.0f;    // DistanceFieldCommon.fxh:8
+using ref::kPi;                       // the reference's constants by name: reference_constants.hpp
+using ref::kVelocityConstantScale;
+using ref::kDistanceZero;
 
 struct f3 { float x, y, z; };
 

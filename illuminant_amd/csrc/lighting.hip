@@ -62,7 +62,7 @@ __global__ __launch_bounds__(64) void prepare_lights_kernel(const IlmLightVertex
     r.fy2 = ((lerp(tly, bry, mOne) - 0.0f) - env.ViewportPosition[1]) * sy;
     r.fy3 = ((lerp(tly, bry, 1.0f) - 0.0f) - env.ViewportPosition[1]) * sy;
 
-    const float max_radius = clampf(r.radius, 0.33f, max_cone_radius);
+    const float max_radius = clampf(r.radius, ref::kMinConeRadius, max_cone_radius);
     r.cfg_x = max_radius;
     r.cfg_y = max_radius / fmaxf(r.ramp, 16.0f) * 1.0f;  // getConeGrowthFactor() == 1 (DistanceFieldCommon.fxh:233-236)
     r.ramp_offset = L.EvenMoreLightProperties.z; r.ramp_rate = L.EvenMoreLightProperties.w;
@@ -118,8 +118,8 @@ ILM_DEV Pixel sample_gbuffer(float spx, float spy, const IlmEnvironment& env, co
             p.enable_shadows = false;
             p.fullbright = true;
         }
-        world_z *= 1024.0f;   // GBUFFER_Z_SCALE
-        world_z -= 1024.0f;   // GBUFFER_Z_OFFSET
+        world_z *= ref::kGBufferZScale;
+        world_z -= ref::kGBufferZOffset;
         spx /= rsx; spy /= rsy;
         p.camera = mk3(spx, spy, env.ZAndScale.y + 0.01f);
         p.shaded = mk3((spx + 0.0f) / vsx + env.ViewportPosition[0], (spy + relative_y) / vsy + env.ViewportPosition[1], world_z);
@@ -148,7 +148,7 @@ ILM_DEV float sphere_light_opacity(f3 shaded, f3 normal, const LightRec& L, floa
     if ((normal.x != 0.0f) || (normal.y != 0.0f) || (normal.z != 0.0f)) {
         const f3 ln = mk3(d3.x / distance, d3.y / distance, d3.z / distance);
         const float d = dot3(ln * -1.0f, normal);
-        normal_factor = pow_pos(sat((d + 0.15f) / 0.15f), 0.85f);   // DOT_OFFSET, DOT_RAMP_RANGE, DOT_EXPONENT
+        normal_factor = pow_pos(sat((d + ref::kDotOffset) / ref::kDotRampRange), ref::kDotExponent);
     }
     if (L.falloff_mode >= 2.0f) {
         distance_factor = 1.0f - sat(distance - L.radius);
@@ -177,15 +177,15 @@ ILM_DEV void cone_trace_loop(const f3& start, const f3& dir, float data_y, float
         const float s = sample_distance_field<FMT, false, FAST, PAIR>(sp, df, sdf);
         if (STATS) st.samples++;
         // (both operands are finite: v_minimum3_f32 needs no canonicalising v_max in front of it, unlike IEEE minNum)
-        const float local_radius = __builtin_elementwise_minimum(__builtin_fmaf(cone_growth, data_x, 0.33f), cone_max_radius);   // MIN_CONE_RADIUS
-        const float local_visibility = FAST ? div_no_scale(s + 1.5f, local_radius) : ((s + 1.5f) / local_radius);              // HACK_DISTANCE_OFFSET
+        const float local_radius = __builtin_elementwise_minimum(__builtin_fmaf(cone_growth, data_x, ref::kMinConeRadius), cone_max_radius);
+        const float local_visibility = FAST ? div_no_scale(s + ref::kHackDistanceOffset, local_radius) : ((s + ref::kHackDistanceOffset) / local_radius);
         // fminf / fmaxf as the bare instructions: the same minNum / maxNum result without the v_max x, x canonicalisation the
         // compiler puts in front of each loop-carried operand (no signalling NaN can reach them)
         asm("v_min_f32 %0, %0, %1" : "+v"(data_z) : "v"(local_visibility));
         float step = fabsf(s) * df.StepAndMisc2.z;
         asm("v_max_f32 %0, %0, %1" : "+v"(step) : "v"(cfg_z));
         data_x += step;
-        alive = (steps_remaining > 0.0f) & (data_z > 0.075f) & (data_y > data_x);
+        alive = (steps_remaining > 0.0f) & (data_z > ref::kFullyShadowedThreshold) & (data_y > data_x);
     }
 }
 
@@ -220,15 +220,15 @@ ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment
 
     // coneTrace, ConeTrace.fxh:148-191
     float cone_opacity = 1.0f;
-    const bool trace = (casts != 0.0f) && (pre_trace >= (0.75f / 255.0f));
+    const bool trace = (casts != 0.0f) && (pre_trace >= ref::kShadowOpacityThreshold);
     if (trace) {
         if (STATS) st.traced++;
-        f3 start = P.shaded + (P.normal * 1.6f);   // SELF_OCCLUSION_HACK
+        f3 start = P.shaded + (P.normal * ref::kSelfOcclusionHack);
         const f3 tv = mk3(L.cx, L.cy, L.cz) - start;
         const float trace_length = len3(tv);
         f3 dir = mk3(tv.x / trace_length, tv.y / trace_length, tv.z / trace_length);
         const float data_y = fmaxf(trace_length - L.radius, 1.0f);
-        float data_x = 0.5f;   // TRACE_INITIAL_OFFSET_PX
+        float data_x = ref::kTraceInitialOffsetPx;
         float data_z = 1.0f;
         const float cfg_z = fmaxf(1.0f, df.Packed1.w);
         float steps_remaining = df.StepAndMisc2.x;
@@ -258,8 +258,8 @@ ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment
             cone_trace_loop<FMT, STATS, true, PAIR>(start, dir, data_y, cfg_z, cone_growth, cone_max_radius, df, sdf, data_x, data_z, steps_remaining, alive, st);
         else
             cone_trace_loop<FMT, STATS, false, PAIR>(start, dir, data_y, cfg_z, cone_growth, cone_max_radius, df, sdf, data_x, data_z, steps_remaining, alive, st);
-        const float visibility = fminf(data_z, steps_remaining / 2.0f);               // MAX_STEP_RAMP_WINDOW
-        cone_opacity = pow_pos(sat(sat(visibility - 0.075f) / (0.95f - 0.075f)), df.ConeAndMisc.z);
+        const float visibility = fminf(data_z, steps_remaining / ref::kMaxStepRampWindow);
+        cone_opacity = pow_pos(sat(sat(visibility - ref::kFullyShadowedThreshold) / (ref::kUnshadowedThreshold - ref::kFullyShadowedThreshold)), df.ConeAndMisc.z);
     }
     // SphereLightPixelEpilogue / ...WithRamp (SphereLightCore.fxh:83-119): with a ramp texture the opacity becomes a colour,
     // SampleFromRamp2(preTraceOpacity, (angle + rampOffset) * rampRate).rgb * coneOpacity -- tex2Dlod level 0, LINEAR, U CLAMP, V WRAP
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(kPlBlock) void particle_light_emit_kernel(const Par
     r.fx2 = r.fx3 = (brx - a.env.ViewportPosition[0]) * sx;
     r.fy0 = r.fy1 = (tly - a.env.ViewportPosition[1]) * sy;
     r.fy2 = r.fy3 = (bry - a.env.ViewportPosition[1]) * sy;
-    const float max_radius = clampf(r.radius, 0.33f, a.max_cone_radius);
+    const float max_radius = clampf(r.radius, ref::kMinConeRadius, a.max_cone_radius);
     r.cfg_x = max_radius;
     r.cfg_y = max_radius / fmaxf(r.ramp, 16.0f) * 1.0f;
     r.ramp_offset = r.ramp_rate = 0.0f;

@@ -365,9 +365,9 @@ ILM_DEV float mod_const(float index) { return (float)((unsigned)index % M); }
 ILM_DEV void evaluate_random_for_index(const float4* __restrict__ rnd, int rw, int rh, float tx_, float ty_, float index, const IlmSpawnParams& p,
                                        float4& random1, float4& random2, float4& random3) {
     const float ox = p.RandomnessOffset[0], oy = p.RandomnessOffset[1];
-    random1 = random_custom(rnd, rw, rh, tx_, ty_, mod_const<8039u>(index), 0.0f + mod_const<57u>(index), ox, oy, 1.0f, 1.0f);
-    random2 = random_custom(rnd, rw, rh, tx_, ty_, mod_const<6180u>(index), 1.0f + mod_const<4031u>(index), ox, oy, 1.0f, 1.0f);
-    random3 = random_custom(rnd, rw, rh, tx_, ty_, mod_const<2025u>(index), 2.0f + mod_const<65531u>(index), ox, oy, 1.0f, 1.0f);
+    random1 = random_custom(rnd, rw, rh, tx_, ty_, mod_const<ref::kRandom1XModulus>(index), 0.0f + mod_const<ref::kRandom1YModulus>(index), ox, oy, 1.0f, 1.0f);
+    random2 = random_custom(rnd, rw, rh, tx_, ty_, mod_const<ref::kRandom2XModulus>(index), 1.0f + mod_const<ref::kRandom2YModulus>(index), ox, oy, 1.0f, 1.0f);
+    random3 = random_custom(rnd, rw, rh, tx_, ty_, mod_const<ref::kRandom3XModulus>(index), 2.0f + mod_const<ref::kRandom3YModulus>(index), ox, oy, 1.0f, 1.0f);
     // "The x and y element of random samples determines the normal" (:114-116): inside evaluateRandomForIndex, so the feedback and
     // pattern spawners (SpawnParticles.fx:83, PatternSpawner.fx:63) align too
     if (p.AlignVelocityAndPosition != 0.0f) {
@@ -632,7 +632,7 @@ ILM_DEV void render_data(float vx, float vy, float4 position, float4 velocity, f
         render_color = rdata = mk4(0.0f, 0.0f, 0.0f, 0.0f);
         return;
     }
-    const float index = vx + (vy * 256.0f);  // reference quirk: 256 regardless of ChunkSize (:107)
+    const float index = vx + (vy * ref::kRenderDataIndexRowPitch);  // reference quirk: 256 regardless of ChunkSize (:107)
     const float velocity_length = fmaxf(len3_fast(xyz(velocity)), 0.0001f);
 
     float4 color = mul4(bezier4(p.ColorFromLife, position.w), bezier4(p.ColorFromVelocity, velocity_length));
@@ -727,7 +727,7 @@ ILM_DEV void update_with_distance_field(float4& pos, float4& vel, float x, float
     const float initial_distance = sample_distance_field<FMT>(old_xyz, df, sdf);
     const bool was_colliding = initial_distance < collision_distance;
     float travel_distance = fmaxf(0.0f, fminf(initial_distance, len3(scaled_velocity)));
-    int step_count = 3;  // MAX_STEP_COUNT
+    int step_count = ref::kMaxStepCount;
     if (was_colliding)
         step_count = 1;
     else if (travel_distance <= 0.001f)
@@ -760,26 +760,26 @@ ILM_DEV void update_with_distance_field(float4& pos, float4& vel, float x, float
         const float escape_speed = fminf(max_velocity, sys.CollisionSettings.x);
         if (redirect) {
             normal = normal * mk3(1.0f, 1.0f, 0.0f);  // ESCAPE_MASK
-            if (len3(normal) < 0.33f) {
+            if (len3(normal) < ref::kNoNormalThreshold) {
                 const float a = (x / 67.0f) + (y / 13.0f);
                 normal = mk3(sinf(a), cosf(a), 0.0f);
             }
-            const f3 nv = (norm3(normal) * escape_speed) * 0.33f;  // INITIAL_ESCAPE_SPEED
-            new_velocity = mk4(nv.x, nv.y, nv.z, 3.0f);           // BOUNCE_DELAY
+            const f3 nv = (norm3(normal) * escape_speed) * ref::kInitialEscapeSpeed;
+            new_velocity = mk4(nv.x, nv.y, nv.z, ref::kBounceDelay);
             new_position = old_xyz + (nv * dts);
         } else if (bounce) {
             const float d2 = 2.0f * dot3(normal, unit_vector);
             f3 bounce_vector = ((normal - unit_vector) * d2) * -1.0f;
-            if (len3(bounce_vector) < 0.33f)
+            if (len3(bounce_vector) < ref::kNoNormalThreshold)
                 bounce_vector = unit_vector * -1.0f;
             else
                 bounce_vector = norm3(bounce_vector);
             new_position = collision_position;
             const f3 nv = bounce_vector * fminf(max_velocity, len3(velocity) * sys.CollisionSettings.y);
-            new_velocity = mk4(nv.x, nv.y, nv.z, 3.0f);
+            new_velocity = mk4(nv.x, nv.y, nv.z, ref::kBounceDelay);
             new_life -= sys.CollisionSettings.w;
         } else {
-            const float new_speed = fmaxf(len3(xyz(vel)) * 1.1f, escape_speed);  // ESCAPE_SPEED_ACCELERATION
+            const float new_speed = fmaxf(len3(xyz(vel)) * ref::kEscapeSpeedAcceleration, escape_speed);
             const f3 nv = unit_vector * new_speed;
             new_velocity = mk4(nv.x, nv.y, nv.z, 0.0f);
             new_position = old_xyz + (unit_vector * travel_distance);

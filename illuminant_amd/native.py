@@ -31,6 +31,9 @@ SYMBOLS = {
     "ilm_abi_version": (_I, []),
     "ilm_last_error": (C.c_char_p, []),
     "ilm_device_count": (_I, []),
+    "ilm_debug_reference_constant": (_I, [C.c_char_p, C.POINTER(C.c_double)]),
+    "ilm_debug_reference_constant_count": (_I, []),
+    "ilm_debug_reference_constant_key": (C.c_char_p, [_I]),
     "ilm_ctx_create": (_I, [_I, C.POINTER(_H)]),
     "ilm_ctx_destroy": (_I, [_H]),
     "ilm_ctx_sync": (_I, [_H]),
@@ -129,6 +132,17 @@ def lib():
 def check(code):
     if code != 0:
         raise IlluminantError(code, lib().ilm_last_error().decode("utf-8", "replace"))
+
+
+def reference_constants():
+    """{reference key: value} of every number the kernels take from the reference's text (csrc/reference_constants.hpp); no GPU needed."""
+    out = {}
+    for i in range(lib().ilm_debug_reference_constant_count()):
+        key = lib().ilm_debug_reference_constant_key(i)
+        v = C.c_double()
+        check(lib().ilm_debug_reference_constant(key, C.byref(v)))
+        out[key.decode()] = float(v.value)
+    return out
 
 
 def device_count():

@@ -326,6 +326,13 @@ const char* ilm_last_error(void);
 /* Number of visible HIP devices (0 when there is no GPU; never fails). */
 int32_t     ilm_device_count(void);
 
+/* The numbers the kernels take from the reference's text, by the reference's own names ("ConeTrace.fxh:FULLY_SHADOWED_THRESHOLD",
+ * "SpawnerCommon.fxh:randomOffset1.x modulus", ...; csrc/reference_constants.hpp).  Diagnostic, needs no GPU: tests/test_reference_pin.py
+ * compares every entry with the values tools/pin_reference_constants.py extracts from the reference sources. */
+int32_t     ilm_debug_reference_constant(const char* key, double* out_value);
+int32_t     ilm_debug_reference_constant_count(void);
+const char* ilm_debug_reference_constant_key(int32_t index);
+
 /* One context per GPU.  Replaces the GraphicsDevice/RenderCoordinator the
  * reference threads through ParticleEngine (Illuminant/Particles/ParticleEngine.cs:95-141)
  * and LightingRenderer (Illuminant/Lighting/LightingRenderer.cs:486-560). */

@@ -410,6 +410,9 @@ namespace Squared.Illuminant.Native {
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_abi_version ();
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern IntPtr ilm_last_error ();
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_device_count ();
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_debug_reference_constant (byte* key, double* outValue);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_debug_reference_constant_count ();
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern IntPtr ilm_debug_reference_constant_key (int index);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_ctx_create (int deviceId, ulong* outCtx);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_ctx_destroy (ulong ctx);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_ctx_sync (ulong ctx);

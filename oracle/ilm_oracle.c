@@ -21,7 +21,16 @@
 typedef struct { float x, y, z; } f3;
 typedef IlmFloat4 f4;
 
-#define H_PI 3.14159265358979323846f   /* ParticleCommon.fxh:23 (float literal) */
+#include "ilm_oracle_constants.h"
+
+/* value of the reference constant `key` as this restatement uses it (ilm_oracle_constants.h); 0 when unknown */
+int32_t orc_reference_constant(const char* key, double* out_value) {
+    for (size_t i = 0; i < sizeof(orc_reference_constants) / sizeof(orc_reference_constants[0]); i++)
+        if (strcmp(orc_reference_constants[i].key, key) == 0) { *out_value = orc_reference_constants[i].value; return 1; }
+    return 0;
+}
+int32_t orc_reference_constant_count(void) { return (int32_t)(sizeof(orc_reference_constants) / sizeof(orc_reference_constants[0])); }
+const char* orc_reference_constant_key(int32_t index) { return orc_reference_constants[index].key; }
 
 static inline float h_sat(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
 static inline float h_lerp(float a, float b, float t) { return a + (b - a) * t; }
@@ -96,7 +105,6 @@ static inline float half_to_float(uint16_t h) {
 /* ---------------------------------------------------------------------------
  * ParticleCommon.fxh accessors (ParticleCommon.fxh:29-92)
  * ------------------------------------------------------------------------- */
-#define VELOCITY_CONSTANT_SCALE 1000.0f
 static inline float sys_dt_seconds(const IlmParticleSystemUniforms* s) { return s->GlobalSettings.x / VELOCITY_CONSTANT_SCALE; }
 static inline float sys_dt(const IlmParticleSystemUniforms* s) { return s->GlobalSettings.x; }
 static inline float sys_friction(const IlmParticleSystemUniforms* s) { return s->GlobalSettings.y; }
@@ -438,9 +446,9 @@ static void spawn_slot(f4* pos, f4* vel, f4* attr, float x, float y,
         return; /* discard: target keeps its contents (RenderTargetUsage.PreserveContents, ParticleSystem.cs:106-111) */
 
     /* evaluateRandomForIndex, SpawnerCommon.fxh:106-117; random(xy) = randomCustom(xy, RandomnessOffset, 1) */
-    f4 random1 = random_custom(rnd, rw, rh, fmodf(index, 8039.0f), 0.0f + fmodf(index, 57.0f), p->RandomnessOffset, 1.0f, 1.0f);
-    f4 random2 = random_custom(rnd, rw, rh, fmodf(index, 6180.0f), 1.0f + fmodf(index, 4031.0f), p->RandomnessOffset, 1.0f, 1.0f);
-    f4 random3 = random_custom(rnd, rw, rh, fmodf(index, 2025.0f), 2.0f + fmodf(index, 65531.0f), p->RandomnessOffset, 1.0f, 1.0f);
+    f4 random1 = random_custom(rnd, rw, rh, fmodf(index, SP_RANDOM1_X_MODULUS), 0.0f + fmodf(index, SP_RANDOM1_Y_MODULUS), p->RandomnessOffset, 1.0f, 1.0f);
+    f4 random2 = random_custom(rnd, rw, rh, fmodf(index, SP_RANDOM2_X_MODULUS), 1.0f + fmodf(index, SP_RANDOM2_Y_MODULUS), p->RandomnessOffset, 1.0f, 1.0f);
+    f4 random3 = random_custom(rnd, rw, rh, fmodf(index, SP_RANDOM3_X_MODULUS), 2.0f + fmodf(index, SP_RANDOM3_Y_MODULUS), p->RandomnessOffset, 1.0f, 1.0f);
     if (p->AlignVelocityAndPosition != 0.0f) {
         random2.x = random1.x;
         random2.y = random1.y;
@@ -604,7 +612,6 @@ void orc_bezier4(const IlmClampedBezier4* b, float value, IlmFloat4* out) { *out
 /* ---------------------------------------------------------------------------
  * DistanceFieldCommon.fxh:264-353 -- encode/decode + sampleDistanceFieldEx
  * ------------------------------------------------------------------------- */
-#define DISTANCE_ZERO (192.0f / 255.0f)
 
 float orc_encode_distance(float distance, float max_encoded) { return DISTANCE_ZERO - (distance / max_encoded); }
 float orc_decode_distance(float encoded, float max_encoded) { return (DISTANCE_ZERO - encoded) * max_encoded; }
@@ -748,7 +755,7 @@ static void compute_render_data(float vx, float vy, f4 position, f4 velocity, f4
         *render_data = v4(0, 0, 0, 0);
         return;
     }
-    float index = vx + (vy * 256.0f); /* FIXME in the reference: hard-coded 256, UpdateCommon.fxh:107 */
+    float index = vx + (vy * RD_INDEX_ROW_PITCH); /* FIXME in the reference: hard-coded 256, UpdateCommon.fxh:107 */
     float velocity_length = fmaxf(v3len(xyz(velocity)), 0.0001f);
 
     /* getRampedColorForLifeValueAndIndex, UpdateCommon.fxh:66-79 */
@@ -804,11 +811,6 @@ static void update_slot(f4* pos, f4* vel, const f4* attr, f4* rc, f4* rd, float 
 }
 
 /* PS_Update, UpdateParticleSystemWithDistanceField.fx:29-147 */
-#define DF_MAX_STEP_COUNT 3
-#define DF_BOUNCE_DELAY 3.0f
-#define DF_NO_NORMAL_THRESHOLD 0.33f
-#define DF_INITIAL_ESCAPE_SPEED 0.33f
-#define DF_ESCAPE_SPEED_ACCELERATION 1.1f
 
 static void update_df_slot(f4* pos, f4* vel, const f4* attr, f4* rc, f4* rd, float x, float y,
                            const IlmParticleSystemUniforms* sys, const IlmUpdateParams* p,
@@ -961,7 +963,7 @@ uint32_t orc_count_live(const IlmFloat4* pos, int32_t slots, int32_t saturate16)
     uint32_t n = 0;
     for (int i = 0; i < slots; i++)
         if (pos[i].w > 0.0f) n++;
-    if (saturate16 && n > 65535u) n = 65535u;
+    if (saturate16 && n > LIVE_COUNT_SATURATION) n = LIVE_COUNT_SATURATION;
     return n;
 }
 
@@ -1072,8 +1074,6 @@ static void gbuffer_texel(const OrcTexture* g, int x, int y, float out[4]) {
 }
 
 /* sampleGBuffer, LightCommon.fxh:58-144 */
-#define GBUFFER_Z_SCALE 1024.0f
-#define GBUFFER_Z_OFFSET 1024.0f
 static f3 sample_gbuffer(float spx, float spy, const IlmEnvironment* env, const OrcTexture* g,
                          f3* world_position, f3* normal, int* enable_shadows, int* fullbright) {
     *enable_shadows = 1;
@@ -1148,7 +1148,7 @@ static float compute_normal_factor(f3 light_normal, f3 n) {
     if ((n.x == 0.0f) && (n.y == 0.0f) && (n.z == 0.0f))
         return 1.0f;
     float d = v3dot(v3scale(light_normal, -1.0f), n);
-    return powf(h_sat((d + 0.15f) / 0.15f), 0.85f);
+    return powf(h_sat((d + LC_DOT_OFFSET) / LC_DOT_RAMP_RANGE), LC_DOT_EXPONENT);
 }
 
 /* computeSphereLightOpacity, LightCommon.fxh:174-214 */
@@ -1206,11 +1206,11 @@ static float cone_trace(f3 light_center, float light_radius, float light_ramp, f
     float trace_length = v3len(trace_vector);
     f3 direction = v3(trace_vector.x / trace_length, trace_vector.y / trace_length, trace_vector.z / trace_length);
     float data_y = fmaxf(trace_length - light_radius, 1.0f);
-    float data_x = 0.5f;
+    float data_x = CT_TRACE_INITIAL_OFFSET_PX;
     float data_z = 1.0f;
 
     /* createTraceConfig, :128-146 */
-    float max_radius = h_clamp(light_radius, 0.33f, df->ConeAndMisc.x);
+    float max_radius = h_clamp(light_radius, CT_MIN_CONE_RADIUS, df->ConeAndMisc.x);
     float ramp_length = fmaxf(light_ramp, 16.0f);
     float radius_growth_per_pixel = max_radius / ramp_length * growth;
     float cfg_x = max_radius, cfg_y = radius_growth_per_pixel, cfg_z = fmaxf(1.0f, df->Packed1.w);
@@ -1224,17 +1224,17 @@ static float cone_trace(f3 light_center, float light_radius, float light_ramp, f
         f3 sp = v3(h_fma(direction.x, data_x, shaded.x), h_fma(direction.y, data_x, shaded.y), h_fma(direction.z, data_x, shaded.z));
         float sample = sample_distance_field_ex(sp, df, sdf, ctr);
         /* coneTraceStep, :52-74 */
-        float local_sphere_radius = fminf(h_fma(cfg_y, data_x, 0.33f), cfg_x);
-        float local_visibility = ((sample + 1.5f) / local_sphere_radius);
+        float local_sphere_radius = fminf(h_fma(cfg_y, data_x, CT_MIN_CONE_RADIUS), cfg_x);
+        float local_visibility = ((sample + CT_HACK_DISTANCE_OFFSET) / local_sphere_radius);
         data_z = fminf(data_z, local_visibility);
         data_x += fmaxf(fabsf(sample) * df->StepAndMisc2.z, cfg_z);
-        float step_liveness = h_sat(data_z - 0.075f) * h_sat(data_y - data_x);
+        float step_liveness = h_sat(data_z - CT_FULLY_SHADOWED_THRESHOLD) * h_sat(data_y - data_x);
         liveness = steps_remaining * step_liveness;
     }
 
-    float step_window_visibility = steps_remaining / 2.0f;
+    float step_window_visibility = steps_remaining / CT_MAX_STEP_RAMP_WINDOW;
     float visibility = fminf(data_z, step_window_visibility);
-    float final_result = powf(h_sat(h_sat(visibility - 0.075f) / (0.95f - 0.075f)), df->ConeAndMisc.z);
+    float final_result = powf(h_sat(h_sat(visibility - CT_FULLY_SHADOWED_THRESHOLD) / (CT_UNSHADOWED_THRESHOLD - CT_FULLY_SHADOWED_THRESHOLD)), df->ConeAndMisc.z);
     return enable ? final_result : 1.0f;
 }
 
@@ -1339,9 +1339,9 @@ void orc_render_sphere_lights(const IlmLightVertex* lights, int32_t light_count,
                 /* SphereLightPixelCore, SphereLightCore.fxh:122-158 */
                 float ao_opacity = compute_ao(shaded, normal, more, df, sdf, visible, &ctr);
                 float pre_trace_opacity = distance_opacity * ao_opacity;
-                int trace_shadows = visible && (light_properties.w != 0.0f) && (pre_trace_opacity >= (0.75f / 255.0f));
+                int trace_shadows = visible && (light_properties.w != 0.0f) && (pre_trace_opacity >= SL_SHADOW_OPACITY_THRESHOLD);
                 if (trace_shadows) total_traced++;
-                f3 start = v3add(shaded, v3scale(normal, 1.6f));
+                f3 start = v3add(shaded, v3scale(normal, SL_SELF_OCCLUSION_HACK));
                 float cone_opacity = cone_trace(light_center, light_properties.x, light_properties.y, 1.0f, more.y,
                                                 start, df, sdf, trace_shadows, &ctr);
                 const f3 opacity = sphere_light_epilogue(pre_trace_opacity, cone_opacity, v3sub(shaded, light_center), L->EvenMoreLightProperties);

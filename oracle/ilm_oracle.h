@@ -31,6 +31,12 @@
 extern "C" {
 #endif
 
+/* the numbers this restatement takes from the reference's text, by the reference's names (ilm_oracle_constants.h);
+ * tests/test_reference_pin.py compares them with the values extracted from the reference sources */
+int32_t orc_reference_constant(const char* key, double* out_value);
+int32_t orc_reference_constant_count(void);
+const char* orc_reference_constant_key(int32_t index);
+
 typedef struct OrcTexture {
     const void* texels;
     int32_t width, height;

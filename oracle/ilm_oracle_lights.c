@@ -23,9 +23,9 @@ static float sphere_light_pixel_core_ex(f3 shaded, f3 normal, f3 light_center, f
     *discarded = 0;
     float ao_opacity = compute_ao(shaded, normal, more, df, sdf, visible, ctr);
     float pre_trace_opacity = distance_opacity * ao_opacity;
-    int trace_shadows = visible && (light_properties.w != 0.0f) && (pre_trace_opacity >= (0.75f / 255.0f));
+    int trace_shadows = visible && (light_properties.w != 0.0f) && (pre_trace_opacity >= SL_SHADOW_OPACITY_THRESHOLD);
     if (trace_shadows && traced) (*traced)++;
-    f3 start = v3add(shaded, v3scale(normal, 1.6f));
+    f3 start = v3add(shaded, v3scale(normal, SL_SELF_OCCLUSION_HACK));
     float cone_opacity = cone_trace(light_center, light_properties.x, light_properties.y, 1.0f, more.y, start, df, sdf, trace_shadows, ctr);
     *pre_trace = pre_trace_opacity; *cone = cone_opacity;
     return pre_trace_opacity * cone_opacity;

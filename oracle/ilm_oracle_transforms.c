@@ -117,9 +117,9 @@ void orc_spatial_noise(IlmFloat4* pos, IlmFloat4* vel, int32_t chunk_size, const
 /* evaluateRandomForIndex, SpawnerCommon.fxh:106-117 */
 static void evaluate_random_for_index(const f4* rnd, int rw, int rh, float index, const float offset[2], float align_velocity_and_position,
                                       f4* r1, f4* r2, f4* r3) {
-    *r1 = random_custom(rnd, rw, rh, fmodf(index, 8039.0f), 0.0f + fmodf(index, 57.0f), offset, 1.0f, 1.0f);
-    *r2 = random_custom(rnd, rw, rh, fmodf(index, 6180.0f), 1.0f + fmodf(index, 4031.0f), offset, 1.0f, 1.0f);
-    *r3 = random_custom(rnd, rw, rh, fmodf(index, 2025.0f), 2.0f + fmodf(index, 65531.0f), offset, 1.0f, 1.0f);
+    *r1 = random_custom(rnd, rw, rh, fmodf(index, SP_RANDOM1_X_MODULUS), 0.0f + fmodf(index, SP_RANDOM1_Y_MODULUS), offset, 1.0f, 1.0f);
+    *r2 = random_custom(rnd, rw, rh, fmodf(index, SP_RANDOM2_X_MODULUS), 1.0f + fmodf(index, SP_RANDOM2_Y_MODULUS), offset, 1.0f, 1.0f);
+    *r3 = random_custom(rnd, rw, rh, fmodf(index, SP_RANDOM3_X_MODULUS), 2.0f + fmodf(index, SP_RANDOM3_Y_MODULUS), offset, 1.0f, 1.0f);
     /* "The x and y element of random samples determines the normal", :114-116 -- part of evaluateRandomForIndex, so every spawner
      * technique that calls it (Spawn_Stage1, PS_SpawnFeedback SpawnParticles.fx:83, PS_SpawnPattern PatternSpawner.fx:63) aligns */
     if (align_velocity_and_position != 0.0f) { r2->x = r1->x; r2->y = r1->y; }

@@ -158,6 +158,20 @@ def erase(pos, vel, rc, rd, chunk_size):
     lib().orc_erase(_f4(pos), _f4(vel), _f4(rc), _f4(rd), chunk_size)
 
 
+def reference_constants():
+    """{reference key: value} of every number the restatement takes from the reference's text (ilm_oracle_constants.h)."""
+    l = lib()
+    l.orc_reference_constant.argtypes = [C.c_char_p, C.POINTER(C.c_double)]
+    l.orc_reference_constant_key.restype = C.c_char_p
+    out = {}
+    for i in range(l.orc_reference_constant_count()):
+        key = l.orc_reference_constant_key(i)
+        v = C.c_double()
+        assert l.orc_reference_constant(key, C.byref(v)) == 1
+        out[key.decode()] = float(v.value)
+    return out
+
+
 def count_live(pos, saturate16=False):
     return int(lib().orc_count_live(_f4(pos), pos.shape[0], 1 if saturate16 else 0))
 

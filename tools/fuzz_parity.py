@@ -1,5 +1,7 @@
 """Randomised parity sweep (not part of the test suite): many small lighting scenes and particle steps with fresh seeds, HIP path vs the
-CPU oracle; reports every scene whose integer statistics or liveness differ and the largest float error seen.
+CPU oracle.  A seed FAILS (and the exit code is 1) when integer statistics, live counts or the liveness mask differ, when a life value is not
+bit-identical to the oracle's, or when a float is outside the criterion of tests/util.py: |got - want| <= 1e-4 |want| + 1e-5 * (largest |want|
+of the same component of the same plane).  The report also says how many elements needed the absolute floor at all (pure 1e-4 relative).
     python tools/fuzz_parity.py [first_seed] [count]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,6 +25,7 @@ def rel_err(got, want):
 
 
 bad_light, bad_step, worst_l, worst_s = [], [], 0.0, 0.0
+bad_float, floor_needed, elements_compared = [], 0, 0
 worst_where = None
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
@@ -89,8 +92,23 @@ for seed in range(first, first + count):
     for c in range(2):
         gp = sysm.download(c, P)
         problem = problem or not np.array_equal(gp[:, 3] > 0, chunks[c][0][:, 3] > 0)
+        if not np.array_equal(gp[:, 3].view(np.uint32), chunks[c][0][:, 3].view(np.uint32)):
+            nan_both = np.isnan(gp[:, 3]) & np.isnan(chunks[c][0][:, 3])
+            if not ((gp[:, 3].view(np.uint32) == chunks[c][0][:, 3].view(np.uint32)) | nan_both).all():
+                bad_float.append((seed, c, "life not bit-identical"))
         for kk, pl in enumerate((P, V, A, RC, RD)):
             g = sysm.download(c, pl).astype(np.float64); wv = chunks[c][kk].astype(np.float64)
+            # the suite's criterion (tests/util.py assert_close): per-component scale
+            comp_scale = np.where(np.isfinite(wv), np.abs(wv), 0.0).max(axis=0)
+            both_nan = np.isnan(g) & np.isnan(wv)
+            err_abs = np.abs(g - wv)
+            outside = ~(err_abs <= 1e-5 * comp_scale[None, :] + 1e-4 * np.abs(wv)) & ~both_nan
+            elements_compared += g.size
+            floor_needed += int((~(err_abs <= 1e-4 * np.abs(wv)) & ~both_nan).sum())
+            if outside.any():
+                i, j = np.argwhere(outside)[0]
+                bad_float.append((seed, c, "plane %d slot %d component %d: got %.9g want %.9g (component scale %.4g); %d element(s)"
+                                  % (kk, i, j, g[i, j], wv[i, j], comp_scale[j], int(outside.sum()))))
             ok = np.isfinite(wv) & np.isfinite(g)
             if ok.any():
                 scale = max(1.0, float(np.abs(wv[ok]).max()))
@@ -176,3 +194,10 @@ for b in bad_light[:10]: print("   ", b)
 print("particles: %d steps with differing live counts / liveness; worst error relative to (|want| + 1e-4 scale) %.3g" % (len(bad_step), worst_s))
 for b in bad_step[:10]: print("   ", b)
 print("worst particle element (seed, chunk, plane, slot, component, got, want, plane scale, chunk size, ops, spawns):", worst_where)
+print("particle floats: %d failures of the suite's criterion (1e-4 relative + 1e-5 x component scale, life bit-identical) in %.1f M elements; "
+      "%d elements (%.2g of all) are outside a PURE 1e-4 relative bound, i.e. needed the absolute floor" %
+      (len(bad_float), elements_compared / 1e6, floor_needed, floor_needed / max(elements_compared, 1)))
+for b in bad_float[:10]: print("   ", b)
+failed = bool(bad_field or bad_raster or bad_light or bad_step or bad_float)
+print("FUZZ %s" % ("FAILED" if failed else "PASSED"))
+sys.exit(1 if failed else 0)
