@@ -155,11 +155,36 @@ SdfView make_sdf_view(const Sdf* f, const IlmDistanceFieldUniforms* df) {
     // The sampler's single-step U wrap needs every tap column below 2^22 (hlsl_math.hpp); the largest column these uniforms can produce
     // is (floor(maxSlice) / 3 * sliceU + extentX * texelU) * width.  Anything at or above 2^20 (or not finite) keeps the two-fold wrap.
     v.wrap_half = 0.0f;
-    // ILM_SDF_PAIR_LOADS=1 selects the variant whose two taps of a row come from one 16-byte load (hlsl_math.hpp); measured r02: the
-    // texture path gets lighter (address unit 79 -> 56 % busy) but the kernel is bound by VALU issue, so it is 0-5 % slower: off by default
-    v.pair_loads = 0;
-    static const char* pair_env = getenv("ILM_SDF_PAIR_LOADS");
-    if (pair_env && (pair_env[0] == '0' || pair_env[0] == '1')) v.pair_loads = pair_env[0] - '0';
+    // The cone trace's in-volume sampler (hlsl_math.hpp, sample_inside_table) needs the uniforms to describe exactly this atlas as
+    // columns x rows whole slices with the reference's texel sizes (Uniforms.cs:90-110): then the U WRAP fold of a tap is decided by
+    // its slice alone.  Its box: every tap of a sample at least a sixteenth of a texel inside its slice in x and y (tap x0 >= 0,
+    // x0 + 1 <= sliceW - 1, likewise y), z between the offset and the last valid / tabulated slice.
+    v.table_slices = 0; v.columns = 1;
+    v.box_x0 = v.box_y0 = v.box_z0 = 1.0f; v.box_x1 = v.box_y1 = v.box_z1 = 0.0f;      // an empty box
+    static const bool table_off = [] { const char* e = getenv("ILM_SDF_TABLE"); return e && e[0] == '0'; }();     // A/B switch
+    if (df && v.width > 0 && !table_off) {
+        const double cols = df->TextureSliceCount.x, rows = df->TextureSliceCount.y, slices = df->TextureSliceCount.w;
+        const double isx = df->ConeAndMisc.w, isy = df->StepAndMisc2.w, ex = df->Extent.x, ey = df->Extent.y, ez = df->Extent.z;
+        const double sw = ex / isx, sh = ey / isy;
+        auto whole = [](double x) { return std::isfinite(x) && x >= 1.0 && x == std::floor(x); };
+        const bool consistent =
+            whole(cols) && whole(rows) && whole(slices) && whole(sw) && whole(sh) && slices <= kMaxTableSlices && cols <= 1024 &&
+            cols * sw == (double)v.width && rows * sh == (double)v.height && std::ceil(slices / 3.0) <= cols * rows &&
+            std::fabs((double)df->TextureSliceAndTexelSize.x * cols - 1.0) < 1e-6 && std::fabs((double)df->TextureSliceAndTexelSize.y * rows - 1.0) < 1e-6 &&
+            std::fabs((double)df->TextureSliceAndTexelSize.z * ex * cols - 1.0) < 1e-6 && std::fabs((double)df->TextureSliceAndTexelSize.w * ey * rows - 1.0) < 1e-6 &&
+            ez > 0 && std::isfinite(ez) && std::isfinite((double)df->ConeAndMisc.y) && df->Packed1.y > 0.0f && std::isfinite((double)df->Packed1.y) &&
+            df->Packed1.z > 0.0f && sw >= 4 && sh >= 4;
+        if (consistent) {
+            v.table_slices = (int)slices;
+            v.columns = (int)cols;
+            const double tx = 0.5625 * isx, ty = 0.5625 * isy;       // half a texel + 1/16, in world units
+            v.box_x0 = (float)tx; v.box_x1 = (float)(ex - tx);
+            v.box_y0 = (float)ty; v.box_y1 = (float)(ey - ty);
+            // slice_position = (z - zOffset) * Packed1.y must stay below the table's end and within [0, validZ]
+            const double zmax = std::min({ (double)df->Packed1.z, ez, (slices - 1e-3) / (double)df->Packed1.y });
+            v.box_z0 = df->ConeAndMisc.y; v.box_z1 = (float)((double)df->ConeAndMisc.y + zmax * (1.0 - 1e-6));
+        }
+    }
     if (df && v.width > 0) {
         const double third_max = std::floor(std::fabs((double)df->Packed1.z * (double)df->Packed1.y)) / 3.0 + 1.0;
         const double u_max = third_max * std::fabs((double)df->TextureSliceAndTexelSize.x) +
@@ -1289,6 +1314,28 @@ int32_t ilm_sdf_sample(IlmHandle h, const IlmDistanceFieldUniforms* df, const fl
     HIP_TRY(hipMemcpyAsync(d_in, positions, in_bytes, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(launch_sdf_sample(make_sdf_view(f, df), *df, d_in, count, d_out, c->stream));
     HIP_TRY(hipMemcpyAsync(out_distances, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return ILM_OK;
+}
+
+int32_t ilm_debug_sdf_sample_inside(IlmHandle h, const IlmDistanceFieldUniforms* df, const float* positions, int32_t count, float* out_distances,
+                                    int32_t* out_used_table) {
+    Sdf* f = from_handle<Sdf>(h, kMagicSdf);
+    if (!f) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle");
+    if (!df || count < 0 || (count > 0 && (!positions || !out_distances || !out_used_table))) return fail(ILM_ERR_INVALID_ARGUMENT, "bad arguments");
+    if (count == 0) return ILM_OK;
+    Ctx* c = f->ctx;
+    HIP_TRY(hipSetDevice(c->device));
+    const size_t in_bytes = sizeof(float) * 3 * (size_t)count, out_bytes = sizeof(float) * (size_t)count;
+    int32_t rc = ensure_staging(c, in_bytes + 2 * out_bytes);
+    if (rc != ILM_OK) return rc;
+    float* d_in = static_cast<float*>(c->staging);
+    float* d_out = d_in + 3 * (size_t)count;
+    int32_t* d_used = reinterpret_cast<int32_t*>(d_out + (size_t)count);
+    HIP_TRY(hipMemcpyAsync(d_in, positions, in_bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(launch_sdf_sample_inside(make_sdf_view(f, df), *df, d_in, count, d_out, d_used, c->stream));
+    HIP_TRY(hipMemcpyAsync(out_distances, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(out_used_table, d_used, out_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return ILM_OK;
 }

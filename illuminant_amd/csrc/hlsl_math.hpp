@@ -105,7 +105,13 @@ struct SdfView {
     float wf, hf;          // (float)width, (float)height
     float inv_wf;          // 1 / wf (seed of the exact integer wrap; any value within 1 ulp works)
     float wrap_half;       // 0.5 * inv_wf when every tap column this field can ask for stays below 2^20 (make_sdf_view), else 0
-    int pair_loads;        // 1 (default): the kernel variant that fetches a row's two taps with one 16-byte load; 0 (ILM_SDF_PAIR_LOADS=0): four dword loads
+    // The in-volume sampler of the cone trace (sample_inside_table below) works from a per-slice table in LDS.  table_slices = number
+    // of virtual slices (<= kMaxTableSlices) when the uniforms describe exactly this atlas as columns x rows whole slices
+    // (make_sdf_view checks it), else 0: the trace then always uses the general sampler.
+    int table_slices;
+    int columns;           // slices per atlas row (integer value of TextureSliceCount.x)
+    // world-space box inside which a SAMPLE position meets the table sampler's assumptions (InsideBox, make_sdf_view)
+    float box_x0, box_x1, box_y0, box_y1, box_z0, box_z1;
 };
 
 // x / 65535 for an integer-valued x in [0, 65535], correctly rounded: one multiply by fl(1/65535) and one
@@ -164,11 +170,8 @@ ILM_DEV float div_no_scale(float n, float d) {
     return __builtin_amdgcn_div_fixupf(q, d, n);
 }
 
-// INSIDE = true: the caller guarantees 0 <= position <= extent on every axis (after the z offset), so the clamp is the identity and
-// the distance to the volume is +0 -- the same values the general form computes there, without computing them.
-// PAIR = true (the shipped form): a row's two taps come from one 16-byte load; false: one 2-byte-aligned dword load per tap (kept as the
-// A/B arm of tools/ab_pair.sh, SdfView::pair_loads).
-template <int FORMAT, bool CHECK_NAN = true, bool INSIDE = false, bool PAIR = true>
+// The general form: any position (clamped to the volume, distance to the volume added), U WRAP / V CLAMP on the real atlas.
+template <int FORMAT, bool CHECK_NAN = true>
 ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms& df, const SdfView& sdf) {
 #pragma clang fp contract(off)
     position.z -= df.ConeAndMisc.y;
@@ -183,11 +186,10 @@ ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms&
         position.y = (position.y != position.y) ? 0.0f : position.y;
         position.z = (position.z != position.z) ? 0.0f : position.z;
     }
-    float cx = position.x, cy = position.y, cz = position.z;
     float distance_to_volume = 0.0f;                 // sqrt(+0) == +0: skipping it inside the volume is exact
-    if (!INSIDE) {
-        cx = __builtin_amdgcn_fmed3f(position.x, 0.0f, ex); cy = __builtin_amdgcn_fmed3f(position.y, 0.0f, ey);
-        cz = __builtin_amdgcn_fmed3f(position.z, 0.0f, ez);
+    const float cx = __builtin_amdgcn_fmed3f(position.x, 0.0f, ex), cy = __builtin_amdgcn_fmed3f(position.y, 0.0f, ey);
+    const float cz = __builtin_amdgcn_fmed3f(position.z, 0.0f, ez);
+    {
         const f3 dtv = mk3(position.x - cx, position.y - cy, position.z - cz);
         const float d2 = __builtin_fmaf(dtv.z, dtv.z, __builtin_fmaf(dtv.y, dtv.y, dtv.x * dtv.x));
         if (__builtin_amdgcn_ballot_w64(d2 != 0.0f) != 0ull) {
@@ -240,49 +242,18 @@ ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms&
     const uint32_t pitch = (uint32_t)sdf.width << 3;
     const uint32_t r0 = __umul24((uint32_t)y0, pitch);
     const uint32_t r1 = next_row ? r0 + pitch : r0;
-    // 2 * (vi % 3) = 2 * vi - 6 * third as one 24-bit multiply-add (the compiler's form was a quarter-rate 32-bit multiply by -3)
+    // The two channels virtual slice 3k+m blends -- (r,g), (g,b) or (b,a) -- are the 4 bytes at offset 2m inside the 8-byte texel:
+    // one dword load per tap at that (2-byte aligned) address (tools/ubench/gather: a 2-byte aligned dword gather costs the same as
+    // an aligned one).  2 * (vi % 3) = 2 * vi - 6 * third as one 24-bit multiply-add.
     uint32_t sub;
     asm("v_mad_i32_i24 %0, %1, -6, %2" : "=v"(sub) : "v"(third), "v"(vi << 1));
     typedef const char __attribute__((address_space(1))) gbyte;
+    typedef const uint32_t __attribute__((address_space(1), aligned(2))) gword;
     gbyte* base = (gbyte*)sdf.texels;
     asm("" : "+s"(base));
-    uint32_t w00, w10, w01, w11;
-    if (PAIR) {
-        // What binds the cone trace is the texture path, not the ALUs (profiles/r02_summary.md: address unit 79 % busy, data return 92 %):
-        // a wave64 load costs the address unit its 16 quad-cycles whatever its width (tools/ubench/gather: dword, dwordx2 and dwordx4
-        // gathers all take the same time per instruction; only the misaligned 12-byte form is split and costs 3x).  The right-hand
-        // tap is the next texel -- 8 bytes on -- unless U WRAP sends it to column 0, so ONE 16-byte load per row fetches both taps'
-        // texels (8-byte aligned: no split) and a byte permute picks the channel pair of virtual slice 3k+m -- (r,g), (g,b) or (b,a),
-        // bytes 2m .. 2m+3 of the 8-byte texel: two loads per sample instead of four.  A wave with a lane on the atlas' last column
-        // (uniform test) loads the four texels separately.
-        // selector bytes (2m, 2m+1, 2m+2, 2m+3): 0x03020100 + 2m * 0x01010101 in two 24-bit-safe steps
-        uint32_t sel;
-        asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(sel) : "v"(sub), "s"(0x010101u), "v"(0x03020100u));
-        sel += sub << 24;
-        typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        typedef const u32x2 __attribute__((address_space(1), aligned(8))) gtexel;
-        typedef const u32x4 __attribute__((address_space(1), aligned(8))) gtexel2;
-        const uint32_t c0 = (uint32_t)x0 << 3;
-        u32x4 t0, t1;
-        if (__builtin_amdgcn_ballot_w64(x0 == sdf.width - 1) == 0ull) {
-            t0 = *(gtexel2*)(base + (r0 + c0)); t1 = *(gtexel2*)(base + (r1 + c0));
-        } else {
-            const uint32_t c1 = (uint32_t)x1 << 3;
-            const u32x2 a = *(gtexel*)(base + (r0 + c0)), b = *(gtexel*)(base + (r0 + c1));
-            const u32x2 c = *(gtexel*)(base + (r1 + c0)), d = *(gtexel*)(base + (r1 + c1));
-            t0.x = a.x; t0.y = a.y; t0.z = b.x; t0.w = b.y;
-            t1.x = c.x; t1.y = c.y; t1.z = d.x; t1.w = d.y;
-        }
-        w00 = __builtin_amdgcn_perm(t0.y, t0.x, sel); w10 = __builtin_amdgcn_perm(t0.w, t0.z, sel);
-        w01 = __builtin_amdgcn_perm(t1.y, t1.x, sel); w11 = __builtin_amdgcn_perm(t1.w, t1.z, sel);
-    } else {
-        // one dword load per tap at the channel pair's (2-byte aligned) offset inside the 8-byte texel
-        typedef const uint32_t __attribute__((address_space(1), aligned(2))) gword;
-        const uint32_t c0 = ((uint32_t)x0 << 3) + sub, c1 = ((uint32_t)x1 << 3) + sub;
-        w00 = *(gword*)(base + (r0 + c0)); w10 = *(gword*)(base + (r0 + c1));
-        w01 = *(gword*)(base + (r1 + c0)); w11 = *(gword*)(base + (r1 + c1));
-    }
+    const uint32_t c0 = ((uint32_t)x0 << 3) + sub, c1 = ((uint32_t)x1 << 3) + sub;
+    const uint32_t w00 = *(gword*)(base + (r0 + c0)), w10 = *(gword*)(base + (r0 + c1));
+    const uint32_t w01 = *(gword*)(base + (r1 + c0)), w11 = *(gword*)(base + (r1 + c1));
 
     float a00, b00, a10, b10, a01, b01, a11, b11;
     sdf_unpack_word<FORMAT>(w00, a00, b00);
@@ -294,6 +265,109 @@ ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms&
     const float blended = lerp_fused(lo, hi, slice_position - vslice);
 
     return __builtin_fmaf(kDistanceZero - blended, df.Extent.w, distance_to_volume);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The cone trace's in-volume sampler.  What limits the trace loop is vector-instruction issue (profiles/r02_summary.md), and half
+// of the general sampler's instructions only find WHERE the four taps are.  Inside the box of SdfView (every tap of the sample lies in
+// the interior of one slice: no clamp, no U WRAP crossing, no V CLAMP, the right-hand tap is the next texel, the lower tap the next
+// row) everything that depends on the virtual slice number alone comes from a 16-byte table entry in LDS, built once per workgroup:
+//     column index (float), row index (the reference's float form), byte-permute selector of the channel pair, fold offset.
+// The FLOAT path that decides the taps and the weights is the oracle's, operation for operation (z - zOffset, * sliceCount / extentZ,
+// floor, the two fma of u / v, the two fma to texel space, floor, the three fractions), so taps, weights and result are bit-identical
+// to sample_distance_field's; the INTEGER path is: two float -> int conversions, one shift-add, one 24-bit multiply-add.
+// One 16-byte load per tap row (both taps' texels; 8-byte aligned, never split: tools/ubench/gather) + a byte permute per tap.
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxTableSlices = 256;
+struct __attribute__((aligned(16))) SliceEntry {
+    float column_index;   // floor(vslice / 3) as float
+    float row_index;      // floor(vslice * DistanceFieldPacked1.x): the reference's float form
+    uint32_t selector;    // v_perm_b32 selector of bytes 2m .. 2m+3 of the 8-byte texel, m = vslice % 3
+    uint32_t fold8;       // 8 * atlas width * (physical slice / columns): what U WRAP subtracts from the tap column, in bytes
+};
+
+// uniform values of the in-volume sampler (SGPRs)
+struct InsideConsts {
+    float z_offset, slice_scale;                    // DistanceFieldZOffset, sliceCount / extentZ
+    float tsx, tsy, tsz, tsw;                       // TextureSliceAndTexelSize
+    float wf, hf;                                   // atlas size
+    uint32_t pitch;                                 // atlas row pitch in bytes
+    float max_distance;                             // Extent.w
+};
+
+ILM_DEV InsideConsts make_inside_consts(const IlmDistanceFieldUniforms& df, const SdfView& sdf) {
+    InsideConsts c;
+    c.z_offset = df.ConeAndMisc.y; c.slice_scale = df.Packed1.y;
+    c.tsx = df.TextureSliceAndTexelSize.x; c.tsy = df.TextureSliceAndTexelSize.y; c.tsz = df.TextureSliceAndTexelSize.z; c.tsw = df.TextureSliceAndTexelSize.w;
+    c.wf = sdf.wf; c.hf = sdf.hf;
+    c.pitch = (uint32_t)sdf.width << 3;
+    c.max_distance = df.Extent.w;
+    return c;
+}
+
+// entry `vi` of the table (any thread of the workgroup; the caller synchronises)
+ILM_DEV SliceEntry make_slice_entry(uint32_t vi, const IlmDistanceFieldUniforms& df, const SdfView& sdf) {
+#pragma clang fp contract(off)
+    SliceEntry e;
+    const uint32_t third = vi / 3u, m = vi - 3u * third;
+    e.column_index = (float)third;
+    e.row_index = floorf((float)vi * df.Packed1.x);
+    e.selector = 0x03020100u + 0x02020202u * m;
+    e.fold8 = ((uint32_t)sdf.width << 3) * (third / (uint32_t)sdf.columns);
+    return e;
+}
+
+// the f16 halves of the permuted tap words feed the lerps directly: v_fma_mix_f32 converts its f16 sources exactly and rounds once,
+// i.e. it IS cvt + v_sub / v_fma -- without the eight conversions
+ILM_DEV float mix_sub_lo(uint32_t b, uint32_t a) { float d; asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(b), "v"(a)); return d; }
+ILM_DEV float mix_sub_hi(uint32_t b, uint32_t a) { float d; asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(b), "v"(a)); return d; }
+ILM_DEV float mix_fma_lo(float t, float d, uint32_t a) { float r; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(t), "v"(d), "v"(a)); return r; }
+ILM_DEV float mix_fma_hi(float t, float d, uint32_t a) { float r; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(t), "v"(d), "v"(a)); return r; }
+
+// Precondition (the caller's, per sample): position inside SdfView's box.  `table` = the workgroup's LDS table.
+template <int FORMAT>
+ILM_DEV float sample_inside_table(f3 position, const InsideConsts& c, const SdfView& sdf, const SliceEntry* table) {
+#pragma clang fp contract(off)
+    const float pz = position.z - c.z_offset;
+    const float slice_position = pz * c.slice_scale;          // min(clamp(z), validZ) is the identity inside the box
+    const float vslice = floorf(slice_position);
+    const SliceEntry e = table[(uint32_t)vslice];
+    const float u = __builtin_fmaf(e.column_index, c.tsx, position.x * c.tsz);
+    const float v = __builtin_fmaf(e.row_index, c.tsy, position.y * c.tsw);
+    const float x = __builtin_fmaf(u, c.wf, -0.5f);
+    const float y = __builtin_fmaf(v, c.hf, -0.5f);
+    const float x0f = floorf(x), y0f = floorf(y);
+    const float fx = x - x0f, fy = y - y0f, fz = slice_position - vslice;
+    // tap (x0, y0) of the atlas: column x0f - fold * width (U WRAP, decided by the slice alone inside the box), row y0f (no clamp)
+    const uint32_t column8 = ((uint32_t)(int)x0f << 3) - e.fold8;
+    uint32_t offset;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(offset) : "v"((uint32_t)(int)y0f), "s"(c.pitch), "v"(column8));
+    typedef const char __attribute__((address_space(1))) gbyte;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef const u32x4 __attribute__((address_space(1), aligned(8))) gtexel2;
+    gbyte* row0 = (gbyte*)sdf.texels;
+    gbyte* row1 = row0 + c.pitch;                     // uniform: the lower tap row is the same lane offset on a second SGPR base
+    asm("" : "+s"(row0));
+    asm("" : "+s"(row1));
+    const u32x4 t0 = *(gtexel2*)(row0 + offset), t1 = *(gtexel2*)(row1 + offset);
+    const uint32_t w00 = __builtin_amdgcn_perm(t0.y, t0.x, e.selector), w10 = __builtin_amdgcn_perm(t0.w, t0.z, e.selector);
+    const uint32_t w01 = __builtin_amdgcn_perm(t1.y, t1.x, e.selector), w11 = __builtin_amdgcn_perm(t1.w, t1.z, e.selector);
+    float lo0, lo1, hi0, hi1;
+    if (FORMAT == ILM_SDF_FP16) {
+        lo0 = mix_fma_lo(fx, mix_sub_lo(w10, w00), w00); hi0 = mix_fma_hi(fx, mix_sub_hi(w10, w00), w00);
+        lo1 = mix_fma_lo(fx, mix_sub_lo(w11, w01), w01); hi1 = mix_fma_hi(fx, mix_sub_hi(w11, w01), w01);
+    } else {
+        float a00, b00, a10, b10, a01, b01, a11, b11;
+        sdf_unpack_word<FORMAT>(w00, a00, b00);
+        sdf_unpack_word<FORMAT>(w10, a10, b10);
+        sdf_unpack_word<FORMAT>(w01, a01, b01);
+        sdf_unpack_word<FORMAT>(w11, a11, b11);
+        lo0 = lerp_fused(a00, a10, fx); hi0 = lerp_fused(b00, b10, fx);
+        lo1 = lerp_fused(a01, a11, fx); hi1 = lerp_fused(b01, b11, fx);
+    }
+    const float lo = lerp_fused(lo0, lo1, fy), hi = lerp_fused(hi0, hi1, fy);
+    const float blended = lerp_fused(lo, hi, fz);
+    return (kDistanceZero - blended) * c.max_distance;      // fma(x, maxDistance, +0): the distance to the volume is +0 inside it
 }
 
 }  // namespace ilm

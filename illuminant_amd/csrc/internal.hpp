@@ -165,6 +165,8 @@ hipError_t launch_light_probes(const void* recs, int light_count, const float4* 
                                hipStream_t stream);
 // sampleDistanceFieldEx at `count` positions (xyz triples) -- diagnostic entry point ilm_sdf_sample
 hipError_t launch_sdf_sample(const SdfView& sdf, const IlmDistanceFieldUniforms& df, const float* positions, int count, float* out, hipStream_t stream);
+hipError_t launch_sdf_sample_inside(const SdfView& sdf, const IlmDistanceFieldUniforms& df, const float* positions, int count, float* out, int32_t* used,
+                                    hipStream_t stream);
 hipError_t launch_divide_probe(const float* n, const float* d, int count, float* out_fast, float* out_ieee, hipStream_t stream);
 
 // ---- distance-field generation (fields.hip) ---------------------------------------------------------------

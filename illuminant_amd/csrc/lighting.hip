@@ -161,28 +161,63 @@ ILM_DEV float sphere_light_opacity(f3 shaded, f3 normal, const LightRec& L, floa
 
 struct LightStats { unsigned long long samples = 0, pairs = 0, traced = 0; };
 
+// What a trace needs besides the light: the field (general sampler) and, for the in-volume loop, its uniform constants and the
+// workgroup's slice table in LDS (table == nullptr: no in-volume loop -- light probes, fields the table cannot describe)
+struct TraceField {
+    const IlmDistanceFieldUniforms& df;
+    const SdfView& sdf;
+    const InsideConsts& inside;
+    const SliceEntry* table;
+};
+
 // The cone-trace loop (coneTraceAdvance + coneTraceStep, ConeTrace.fxh:52-85).  FAST: every sample of every active lane lies inside the
-// field's volume and the light's cone radius is of ordinary size (shade_light decides per wave) -- no clamp, no distance to the volume,
-// division without the range scaling.
-template <int FMT, bool STATS, bool FAST, bool PAIR>
+// box of the field's in-volume sampler and the light's cone radius is of ordinary size (shade_light decides per wave): the table
+// sampler, division without the range scaling, the step budget as a uniform counter.
+template <int FMT, bool STATS, bool FAST>
 ILM_DEV void cone_trace_loop(const f3& start, const f3& dir, float data_y, float cfg_z, float cone_growth, float cone_max_radius,
-                             const IlmDistanceFieldUniforms& df, const SdfView& sdf, float& data_x, float& data_z, float& steps_remaining,
-                             bool alive, LightStats& st) {
+                             const TraceField& F, float& data_x, float& data_z, float& steps_remaining, bool alive, LightStats& st) {
     // liveness = stepsRemaining * (saturate(visibility - FULLY_SHADOWED) * saturate(length - position)) > 0 is, factor by factor,
     // stepsRemaining > 0 && visibility > FULLY_SHADOWED && length > position: the smallest positive factors (ulp(0.075), ulp(0.5),
     // 1) cannot underflow their product, and a NaN factor saturates to 0 and fails its compare alike.
+    const float long_step = F.df.StepAndMisc2.z;
+    if (FAST) {
+        // Every lane enters with the same budget S (a uniform) and loses 1 per iteration: after k iterations a lane that is still
+        // in the loop holds S - k, exactly (S < 2^24: subtracting 1 from a positive float towards zero is exact, and the last step,
+        // which may cross zero, rounds once either way).  So `stepsRemaining > 0` is the scalar test k < S, and a lane's budget at its
+        // exit is S - (iterations it ran).
+        const float budget = steps_remaining;
+        const int most = (int)ceilf(budget);          // iterations k = 1 .. with S - k > 0 beforehand: k < S
+        int k = 0;
+        float ran = 0.0f;
+        while (alive) {
+            k++;
+            ran = (float)k;
+            const f3 sp = mk3(__builtin_fmaf(dir.x, data_x, start.x), __builtin_fmaf(dir.y, data_x, start.y), __builtin_fmaf(dir.z, data_x, start.z));
+            const float s = sample_inside_table<FMT>(sp, F.inside, F.sdf, F.table);
+            if (STATS) st.samples++;
+            const float local_radius = __builtin_elementwise_minimum(__builtin_fmaf(cone_growth, data_x, ref::kMinConeRadius), cone_max_radius);
+            const float local_visibility = div_no_scale(s + ref::kHackDistanceOffset, local_radius);
+            asm("v_min_f32 %0, %0, %1" : "+v"(data_z) : "v"(local_visibility));
+            float step = fabsf(s) * long_step;
+            asm("v_max_f32 %0, %0, %1" : "+v"(step) : "v"(cfg_z));
+            data_x += step;
+            alive = (k < most) & (data_z > ref::kFullyShadowedThreshold) & (data_y > data_x);
+        }
+        steps_remaining = budget - ran;
+        return;
+    }
     while (alive) {
         steps_remaining -= 1.0f;
         const f3 sp = mk3(__builtin_fmaf(dir.x, data_x, start.x), __builtin_fmaf(dir.y, data_x, start.y), __builtin_fmaf(dir.z, data_x, start.z));
-        const float s = sample_distance_field<FMT, false, FAST, PAIR>(sp, df, sdf);
+        const float s = sample_distance_field<FMT, false>(sp, F.df, F.sdf);
         if (STATS) st.samples++;
         // (both operands are finite: v_minimum3_f32 needs no canonicalising v_max in front of it, unlike IEEE minNum)
         const float local_radius = __builtin_elementwise_minimum(__builtin_fmaf(cone_growth, data_x, ref::kMinConeRadius), cone_max_radius);
-        const float local_visibility = FAST ? div_no_scale(s + ref::kHackDistanceOffset, local_radius) : ((s + ref::kHackDistanceOffset) / local_radius);
+        const float local_visibility = (s + ref::kHackDistanceOffset) / local_radius;
         // fminf / fmaxf as the bare instructions: the same minNum / maxNum result without the v_max x, x canonicalisation the
         // compiler puts in front of each loop-carried operand (no signalling NaN can reach them)
         asm("v_min_f32 %0, %0, %1" : "+v"(data_z) : "v"(local_visibility));
-        float step = fabsf(s) * df.StepAndMisc2.z;
+        float step = fabsf(s) * long_step;
         asm("v_max_f32 %0, %0, %1" : "+v"(step) : "v"(cfg_z));
         data_x += step;
         alive = (steps_remaining > 0.0f) & (data_z > ref::kFullyShadowedThreshold) & (data_y > data_x);
@@ -191,9 +226,11 @@ ILM_DEV void cone_trace_loop(const f3& start, const f3& dir, float data_y, float
 
 // One light on one shaded point: SphereLightPixelShader (SphereLight.fx:7-46) after the raster test.  Returns false when the shader
 // discards (nothing is blended); otherwise the light's rgb contribution in (out_r, out_g, out_b).
-template <int FMT, bool STATS, bool PAIR = true>
-ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment& env, const IlmDistanceFieldUniforms& df, const SdfView& sdf,
+template <int FMT, bool STATS>
+ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment& env, const TraceField& F,
                          bool have_sdf, const RampView& ramp, LightStats& st, float& out_r, float& out_g, float& out_b) {
+    const IlmDistanceFieldUniforms& df = F.df;
+    const SdfView& sdf = F.sdf;
     // checkShadowFilter, LightCommon.fxh:146-152
     const bool filtered = (L.shadow_filter < 0.0f) ? false : ((L.shadow_filter > 0.5f) != P.enable_shadows);
     if (P.fullbright || filtered)
@@ -242,22 +279,22 @@ ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment
         // loop (s_load + s_waitcnt per sample).  Two VGPRs keep it resident.
         float cone_max_radius = L.cfg_x, cone_growth = L.cfg_y;
         asm volatile("" : "+v"(cone_max_radius), "+v"(cone_growth));
-        // Fast loop when, for every tracing lane of the wave, the trace stays inside the field: samples lie on the segment start ->
-        // light centre, or (trace shorter than the minimum length 1) within 1 of start; both ends inside with a margin that covers
-        // that and the rounding of start + dir * x.  Plus the operand range div_no_scale needs (uniform per light / field).
-        const float zoff = df.ConeAndMisc.y;
+        // In-volume loop when, for every tracing lane of the wave, every sample lies in the box of the table sampler (SdfView): samples
+        // lie on the segment start -> light centre, or (trace shorter than the minimum length 1) within 1 of start; both ends inside
+        // with a margin that covers that and the rounding of start + dir * x.  Plus the operand range div_no_scale needs, a budget
+        // the uniform step counter can count, and a light whose trace does not overshoot it (uniform per light / field).
         const float mx = 0.0625f + df.Extent.x * 0x1p-16f, my = 0.0625f + df.Extent.y * 0x1p-16f, mz = 0.0625f + df.Extent.z * 0x1p-16f;
         const bool ends_inside =
-            (start.x >= 1.0f + mx) & (start.x <= df.Extent.x - 1.0f - mx) & (L.cx >= mx) & (L.cx <= df.Extent.x - mx) &
-            (start.y >= 1.0f + my) & (start.y <= df.Extent.y - 1.0f - my) & (L.cy >= my) & (L.cy <= df.Extent.y - my) &
-            (start.z - zoff >= 1.0f + mz) & (start.z - zoff <= df.Extent.z - 1.0f - mz) & (L.cz - zoff >= mz) & (L.cz - zoff <= df.Extent.z - mz);
-        // (a negative light radius would make the trace longer than the distance to the light: samples would leave the start -> light segment)
-        const bool ordinary = (L.cfg_x >= 0x1p-60f) & (L.cfg_x <= 0x1p60f) & (fabsf(df.Extent.w) <= 0x1p20f) & (L.radius >= 0.0f);
+            (start.x >= sdf.box_x0 + 1.0f + mx) & (start.x <= sdf.box_x1 - 1.0f - mx) & (L.cx >= sdf.box_x0 + mx) & (L.cx <= sdf.box_x1 - mx) &
+            (start.y >= sdf.box_y0 + 1.0f + my) & (start.y <= sdf.box_y1 - 1.0f - my) & (L.cy >= sdf.box_y0 + my) & (L.cy <= sdf.box_y1 - my) &
+            (start.z >= sdf.box_z0 + 1.0f + mz) & (start.z <= sdf.box_z1 - 1.0f - mz) & (L.cz >= sdf.box_z0 + mz) & (L.cz <= sdf.box_z1 - mz);
+        const bool ordinary = (F.table != nullptr) & (L.cfg_x >= 0x1p-60f) & (L.cfg_x <= 0x1p60f) & (df.Extent.w > 0.0f) & (df.Extent.w <= 0x1p20f) &
+                              (L.radius >= 0.0f) & (steps_remaining >= 0.0f) & (steps_remaining <= 0x1p23f);
         const bool alive = liveness > 0.0f;
-        if (ordinary && __builtin_amdgcn_ballot_w64(!ends_inside) == 0ull)
-            cone_trace_loop<FMT, STATS, true, PAIR>(start, dir, data_y, cfg_z, cone_growth, cone_max_radius, df, sdf, data_x, data_z, steps_remaining, alive, st);
+        if (ordinary && __builtin_amdgcn_ballot_w64(trace & !ends_inside) == 0ull)
+            cone_trace_loop<FMT, STATS, true>(start, dir, data_y, cfg_z, cone_growth, cone_max_radius, F, data_x, data_z, steps_remaining, alive, st);
         else
-            cone_trace_loop<FMT, STATS, false, PAIR>(start, dir, data_y, cfg_z, cone_growth, cone_max_radius, df, sdf, data_x, data_z, steps_remaining, alive, st);
+            cone_trace_loop<FMT, STATS, false>(start, dir, data_y, cfg_z, cone_growth, cone_max_radius, F, data_x, data_z, steps_remaining, alive, st);
         const float visibility = fminf(data_z, steps_remaining / ref::kMaxStepRampWindow);
         cone_opacity = pow_pos(sat(sat(visibility - ref::kFullyShadowedThreshold) / (ref::kUnshadowedThreshold - ref::kFullyShadowedThreshold)), df.ConeAndMisc.z);
     }
@@ -304,10 +341,11 @@ ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment
 constexpr int kTile = 16;
 constexpr int kListCapacity = 1024;
 
-template <int FMT, bool STATS, bool PAIR>
+template <int FMT, bool STATS>
 __global__ __launch_bounds__(256) void sphere_lights_kernel(const LightLaunch a, const LightRec* __restrict__ recs, int tiles_x, int tiles_y, int tile_count) {
     __shared__ uint16_t list[kListCapacity];
     __shared__ int list_count;
+    __shared__ SliceEntry slice_table[kMaxTableSlices];
 
     // The dispatcher places block b on XCD b % 8.  Which tiles an XCD gets decides both its L2 locality and its share of the work
     // (lights are not spread evenly): see light_tile_map() in api.hip for the measurements; identity (tile_map 2) is the default.
@@ -328,6 +366,12 @@ __global__ __launch_bounds__(256) void sphere_lights_kernel(const LightLaunch a,
     }
     if (tile >= tile_count)
         return;
+    // the in-volume sampler's per-slice table (hlsl_math.hpp): one entry per virtual slice, visible to the tile's waves after the
+    // first barrier of the light loop below
+    const int table_n = a.sdf.table_slices;
+    for (int i = (int)threadIdx.x; i < table_n; i += 256) slice_table[i] = make_slice_entry((uint32_t)i, a.df, a.sdf);
+    const InsideConsts inside = make_inside_consts(a.df, a.sdf);
+    const TraceField field = { a.df, a.sdf, inside, (table_n > 0) ? slice_table : nullptr };
     const int tx0 = (tile % tiles_x) * kTile, ty0 = a.row_begin + (tile / tiles_x) * kTile;
 
     const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
@@ -401,7 +445,7 @@ __global__ __launch_bounds__(256) void sphere_lights_kernel(const LightLaunch a,
                 continue;
             if (STATS) st.pairs++;
             float cr, cg, cb;
-            if (!shade_light<FMT, STATS, PAIR>(P, L, a.env, a.df, a.sdf, have_sdf, a.ramp, st, cr, cg, cb))
+            if (!shade_light<FMT, STATS>(P, L, a.env, field, have_sdf, a.ramp, st, cr, cg, cb))
                 continue;
             acc_r += cr;
             acc_g += cg;
@@ -571,6 +615,8 @@ __global__ __launch_bounds__(64) void light_probes_kernel(const LightRec* __rest
     const bool have_sdf = (sdf.texels != nullptr) && (df.Extent.x > 0.0f);
     float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f, acc_a = 0.0f;
     LightStats st;
+    const InsideConsts inside = make_inside_consts(df, sdf);
+    const TraceField field = { df, sdf, inside, nullptr };       // probes are few: the general sampler
     for (int k = 0; k < light_count; k++) {
         LightRec L = recs[k];
         if (!(valid && probe_opacity > 0.0f))
@@ -582,7 +628,7 @@ __global__ __launch_bounds__(64) void light_probes_kernel(const LightRec* __rest
         L.shadow_filter = -1.0f;
         L.has_spec = 0.0f;
         float cr, cg, cb;
-        if (!shade_light<FMT, false>(P, L, env, df, sdf, have_sdf, ramp, st, cr, cg, cb))
+        if (!shade_light<FMT, false>(P, L, env, field, have_sdf, ramp, st, cr, cg, cb))
             continue;
         acc_r += cr * probe_opacity;
         acc_g += cg * probe_opacity;
@@ -614,6 +660,33 @@ __global__ __launch_bounds__(256) void sdf_sample_kernel(SdfView sdf, IlmDistanc
     out[i] = sample_distance_field<FMT>(mk3(positions[3 * i], positions[3 * i + 1], positions[3 * i + 2]), df, sdf);
 }
 
+// the cone trace's in-volume sampler on caller-supplied positions (diagnostic entry point ilm_debug_sdf_sample_inside): positions inside
+// the sampler's box go through sample_inside_table exactly as the trace loop calls it (used = 1), the others through the general sampler
+template <int FMT>
+__global__ __launch_bounds__(256) void sdf_sample_inside_kernel(SdfView sdf, IlmDistanceFieldUniforms df, const float* __restrict__ positions, int count,
+                                                                 float* __restrict__ out, int32_t* __restrict__ used) {
+    __shared__ SliceEntry slice_table[kMaxTableSlices];
+    for (int i = (int)threadIdx.x; i < sdf.table_slices; i += 256) slice_table[i] = make_slice_entry((uint32_t)i, df, sdf);
+    __syncthreads();
+    const InsideConsts inside = make_inside_consts(df, sdf);
+    const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+    if (i >= count) return;
+    const f3 p = mk3(positions[3 * i], positions[3 * i + 1], positions[3 * i + 2]);
+    const bool in_box = (sdf.table_slices > 0) & (p.x >= sdf.box_x0) & (p.x <= sdf.box_x1) & (p.y >= sdf.box_y0) & (p.y <= sdf.box_y1) &
+                        (p.z >= sdf.box_z0) & (p.z <= sdf.box_z1);
+    used[i] = in_box ? 1 : 0;
+    out[i] = in_box ? sample_inside_table<FMT>(p, inside, sdf, slice_table) : sample_distance_field<FMT>(p, df, sdf);
+}
+
+hipError_t launch_sdf_sample_inside(const SdfView& sdf, const IlmDistanceFieldUniforms& df, const float* positions, int count, float* out, int32_t* used,
+                                    hipStream_t stream) {
+    if (count <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((count + 255) / 256)), block(256);
+    if (sdf.format == ILM_SDF_FP16) hipLaunchKernelGGL(sdf_sample_inside_kernel<ILM_SDF_FP16>, grid, block, 0, stream, sdf, df, positions, count, out, used);
+    else hipLaunchKernelGGL(sdf_sample_inside_kernel<ILM_SDF_UNORM16>, grid, block, 0, stream, sdf, df, positions, count, out, used);
+    return hipGetLastError();
+}
+
 hipError_t launch_sdf_sample(const SdfView& sdf, const IlmDistanceFieldUniforms& df, const float* positions, int count, float* out, hipStream_t stream) {
     if (count <= 0) return hipSuccess;
     const dim3 grid((unsigned)((count + 255) / 256)), block(256);
@@ -642,17 +715,13 @@ hipError_t launch_sphere_lights_prepared(const LightLaunch& a, const void* recs,
     const bool stats = a.stats != nullptr;
     const bool fp16 = a.sdf.format == ILM_SDF_FP16;
     const dim3 grid(blocks), block(256);
-#define ILM_LAUNCH_LIGHTS(F, S, P) hipLaunchKernelGGL((sphere_lights_kernel<F, S, P>), grid, block, 0, stream, a, r, tiles_x, tiles_y, tile_count)
-    const int variant = (fp16 ? 4 : 0) | (stats ? 2 : 0) | (a.sdf.pair_loads ? 1 : 0);
+#define ILM_LAUNCH_LIGHTS(F, S) hipLaunchKernelGGL((sphere_lights_kernel<F, S>), grid, block, 0, stream, a, r, tiles_x, tiles_y, tile_count)
+    const int variant = (fp16 ? 2 : 0) | (stats ? 1 : 0);
     switch (variant) {
-        case 0: ILM_LAUNCH_LIGHTS(ILM_SDF_UNORM16, false, false); break;
-        case 1: ILM_LAUNCH_LIGHTS(ILM_SDF_UNORM16, false, true); break;
-        case 2: ILM_LAUNCH_LIGHTS(ILM_SDF_UNORM16, true, false); break;
-        case 3: ILM_LAUNCH_LIGHTS(ILM_SDF_UNORM16, true, true); break;
-        case 4: ILM_LAUNCH_LIGHTS(ILM_SDF_FP16, false, false); break;
-        case 5: ILM_LAUNCH_LIGHTS(ILM_SDF_FP16, false, true); break;
-        case 6: ILM_LAUNCH_LIGHTS(ILM_SDF_FP16, true, false); break;
-        default: ILM_LAUNCH_LIGHTS(ILM_SDF_FP16, true, true); break;
+        case 0: ILM_LAUNCH_LIGHTS(ILM_SDF_UNORM16, false); break;
+        case 1: ILM_LAUNCH_LIGHTS(ILM_SDF_UNORM16, true); break;
+        case 2: ILM_LAUNCH_LIGHTS(ILM_SDF_FP16, false); break;
+        default: ILM_LAUNCH_LIGHTS(ILM_SDF_FP16, true); break;
     }
 #undef ILM_LAUNCH_LIGHTS
     return hipGetLastError();

@@ -70,6 +70,7 @@ SYMBOLS = {
     "ilm_sdf_create": (_I, [_H, _I, _I, _I, C.POINTER(_H)]),
     "ilm_sdf_upload": (_I, [_H, _P]),
     "ilm_sdf_sample": (_I, [_H, _P, _P, _I, _P]),
+    "ilm_debug_sdf_sample_inside": (_I, [_H, _P, _P, _I, _P, _P]),
     "ilm_debug_divide": (_I, [_H, _P, _P, _I, _P, _P]),
     "ilm_sdf_destroy": (_I, [_H]),
     "ilm_sdf_download": (_I, [_H, _P]),
@@ -436,6 +437,14 @@ class DistanceFieldTexture:
         out = np.empty(positions.shape[0], dtype=np.float32)
         check(lib().ilm_sdf_sample(self.handle, _byref(df), _ptr(positions), positions.shape[0], _ptr(out)))
         return out
+
+    def sample_inside(self, df, positions):
+        """ilm_debug_sdf_sample_inside: (distances, used_table) -- the cone trace's table-driven in-volume sampler where its precondition holds."""
+        positions = np.ascontiguousarray(positions, dtype=np.float32).reshape(-1, 3)
+        out = np.empty(positions.shape[0], dtype=np.float32)
+        used = np.zeros(positions.shape[0], dtype=np.int32)
+        check(lib().ilm_debug_sdf_sample_inside(self.handle, _byref(df), _ptr(positions), positions.shape[0], _ptr(out), _ptr(used)))
+        return out, used.astype(bool)
 
     def upload(self, texels):
         a = np.ascontiguousarray(texels, dtype=np.uint16)

@@ -459,6 +459,13 @@ int32_t ilm_sdf_upload(IlmHandle sdf, const uint16_t* texels);
  * host (or a test) can query the field the kernels see. */
 int32_t ilm_sdf_sample(IlmHandle sdf, const IlmDistanceFieldUniforms* df, const float* positions, int32_t count, float* out_distances);
 
+/* Diagnostic, like ilm_sdf_sample: the cone trace samples positions that lie well inside the field through a second, table-driven form of
+ * sampleDistanceFieldEx (csrc/hlsl_math.hpp, sample_inside_table).  This evaluates `count` positions the way the trace loop does:
+ * out_used_table[i] = 1 where position i met that form's precondition and went through it, 0 where the general form was used.  A test
+ * holds both bit-equal to the CPU restatement. */
+int32_t ilm_debug_sdf_sample_inside(IlmHandle sdf, const IlmDistanceFieldUniforms* df, const float* positions, int32_t count,
+                                    float* out_distances, int32_t* out_used_table);
+
 /* Diagnostic, like ilm_sdf_sample: the cone trace's in-volume loop divides (distance + HACK_DISTANCE_OFFSET) by the cone radius
  * (ConeTrace.fxh:62) with an instruction sequence that skips the IEEE division's range scaling.  This evaluates that sequence
  * (`out_fast`) and the plain IEEE division (`out_ieee`) for `count` operand pairs on the device, so a test can hold them

@@ -146,3 +146,67 @@ def test_cone_trace_division_equals_the_ieee_division(ctx):
     assert same.all(), "first difference: n=%r d=%r fast=%r ieee=%r" % (n[~same][0], d[~same][0], fast[~same][0], ieee[~same][0])
     same_cpu = (ieee.view(np.uint32) == cpu.view(np.uint32)) | (np.isnan(ieee) & np.isnan(cpu))
     assert same_cpu.all()
+
+
+# ---- the cone trace's table-driven in-volume sampler (hlsl_math.hpp, sample_inside_table) --------------------------------------
+
+@pytest.mark.parametrize("fmt", [abi.SDF_UNORM16, abi.SDF_FP16])
+@pytest.mark.parametrize("resolution,virtual", [(0.25, 2048), (0.125, 4096), (1.0, 256), (0.5, 300)])
+def test_in_volume_sampler_matches_the_oracle_bit_for_bit(ctx, oracle, fmt, resolution, virtual):
+    """The lighting configs' fields (cfg3: 1/4 texel per unit, cfg5: 1/8) and two small ones, random texels (every channel pair,
+    every atlas row), positions all over the volume and on the sampler's box faces.  Where the precondition holds the table form
+    runs (that must be nearly everywhere inside the volume); every result equals the oracle's bit for bit."""
+    layout = scenes.DistanceFieldLayout(virtual, virtual, 128.0, 32 if virtual > 1000 else 9, resolution, 128)
+    rng = np.random.default_rng(int(virtual + 1000 * resolution))
+    atlas = rng.integers(0, 65536, size=(layout.atlas_height, layout.atlas_width, 4), dtype=np.uint16)
+    if fmt == abi.SDF_FP16:
+        atlas = rng.uniform(0.0, 1.5, size=atlas.shape).astype(np.float16).view(np.uint16)
+        atlas.reshape(-1)[::977] = np.float16(3e-6).view(np.uint16)          # fp16 denormals: v_fma_mix_f32 must read them like v_cvt_f32_f16
+    dfu = layout.uniforms(z_offset=-3.0, max_cone_radius=24.0, power=0.7, step_limit=64, min_step_size=1.0, long_step_factor=0.5)
+    sdf = native.DistanceFieldTexture(ctx, atlas, fmt)
+    n = 8000
+    pos = np.empty((n, 3), np.float32)
+    pos[:, 0] = rng.uniform(-10.0, virtual + 10.0, n)
+    pos[:, 1] = rng.uniform(-10.0, virtual + 10.0, n)
+    pos[:, 2] = rng.uniform(-8.0, 130.0, n)
+    pos[:300] = np.round(pos[:300])                           # taps exactly on texel boundaries
+    isx = 1.0 / resolution
+    edge = np.float32([0.5 * isx, 0.5625 * isx, 0.6 * isx, virtual - 0.5625 * isx, virtual - 0.6 * isx, isx, virtual - isx])
+    pos[300:1000, 0] = np.tile(edge, 100)                     # the faces of the sampler's box
+    pos[1000:1700, 1] = np.tile(edge, 100)
+    pos[1700:2000, 2] = np.linspace(-3.0, 125.0, 300, dtype=np.float32)   # every slice boundary region
+    got, used = sdf.sample_inside(dfu, pos)
+    want = oracle_samples(oracle, pos, dfu, oracle.make_texture(atlas, fmt))
+    same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+    assert same.all(), "%d of %d samples differ (table form used for %d of them); first: %r got %r want %r" % (
+        int((~same).sum()), n, int(used[~same].sum()), pos[~same][0], got[~same][0], want[~same][0])
+    interior = (pos[:, 0] > isx) & (pos[:, 0] < virtual - isx) & (pos[:, 1] > isx) & (pos[:, 1] < virtual - isx) & (pos[:, 2] > -2.9) & (pos[:, 2] < 120.0)
+    assert used[interior].mean() > 0.99 and used.sum() > 0.5 * n
+    assert not used[(pos[:, 0] < 0) | (pos[:, 1] < 0) | (pos[:, 0] > virtual) | (pos[:, 1] > virtual)].any()
+    sdf.close()
+
+
+def test_in_volume_sampler_is_refused_for_uniforms_that_do_not_describe_the_atlas(ctx, oracle):
+    """Uniforms with a doubled slice count or texel size do not describe the bound atlas as whole slices: the table form is never
+    used (the general sampler wraps and clamps into the real atlas whatever the uniforms say) and the oracle still agrees."""
+    layout = scenes.DistanceFieldLayout(256, 256, 64.0, 9, 1.0)
+    rng = np.random.default_rng(4)
+    atlas = rng.integers(0, 65536, size=(layout.atlas_height, layout.atlas_width, 4), dtype=np.uint16)
+    sdf = native.DistanceFieldTexture(ctx, atlas)
+    pos = np.stack([rng.uniform(5, 250, 2000), rng.uniform(5, 250, 2000), rng.uniform(1, 60, 2000)], axis=-1).astype(np.float32)
+    good = layout.uniforms()
+    _, used = sdf.sample_inside(good, pos)
+    assert used.mean() > 0.9
+    for tweak in ("slices", "texel", "columns"):
+        bad = layout.uniforms()
+        if tweak == "slices":
+            bad.TextureSliceCount.w = 400.0           # more slices than the table holds
+        elif tweak == "texel":
+            bad.TextureSliceAndTexelSize.z *= 2.0     # texel size that is not 1 / (virtual width x columns)
+        else:
+            bad.TextureSliceCount.x = 3.0             # 3 columns of 256 != atlas width 512
+        got, used = sdf.sample_inside(bad, pos)
+        assert not used.any(), tweak
+        want = oracle_samples(oracle, pos, bad, oracle.make_texture(atlas, abi.SDF_UNORM16))
+        assert np.array_equal(got, want), tweak
+    sdf.close()
