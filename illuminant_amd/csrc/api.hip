@@ -1340,6 +1340,27 @@ int32_t ilm_debug_sdf_sample_inside(IlmHandle h, const IlmDistanceFieldUniforms*
     return ILM_OK;
 }
 
+int32_t ilm_debug_divide_by_constants(IlmHandle hctx, float* out_divisors, uint64_t* out_mismatches, int32_t capacity, int32_t* out_count) {
+    Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);
+    if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
+    if (!out_divisors || !out_mismatches || !out_count || capacity < 2) return fail(ILM_ERR_INVALID_ARGUMENT, "bad arguments");   // out_mismatches: 2 per divisor
+    HIP_TRY(hipSetDevice(c->device));
+    float pairs[2][2];
+    light_constant_divisors(pairs);
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(hipMemsetAsync(c->d_stats, 0, 2 * sizeof(unsigned long long), c->stream));
+        HIP_TRY(launch_divide_by_constant(pairs[i][0], pairs[i][1], c->d_stats, c->stream));
+        unsigned long long bad[2] = { 0, 0 };
+        HIP_TRY(hipMemcpyAsync(bad, c->d_stats, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        out_divisors[i] = pairs[i][0];
+        out_mismatches[2 * i] = bad[0];
+        out_mismatches[2 * i + 1] = bad[1];
+    }
+    *out_count = 2;
+    return ILM_OK;
+}
+
 int32_t ilm_debug_divide(IlmHandle hctx, const float* numerators, const float* denominators, int32_t count, float* out_fast, float* out_ieee) {
     Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);
     if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
@@ -1791,6 +1812,7 @@ int32_t ilm_render_particle_lights(IlmHandle hctx, IlmHandle hsystem, const int3
     pl.chunk_bases = s->d_table; pl.stride = e->stride; pl.chunk_count = chunk_count; pl.slots = e->slots;
     pl.quad_counts = quad_counts ? c->d_pl_quads : nullptr;
     pl.params = *params; pl.env = *env; pl.max_cone_radius = df->ConeAndMisc.x;
+    pl.gate = make_trace_gate(*df, a.sdf);
     pl.block_counts = c->d_pl_blocks; pl.recs = c->d_pl_recs; pl.capacity = c->pl_cap; pl.out_count = c->d_pl_count;
     HIP_TRY(launch_prepare_particle_lights(pl, c->stream));
 
@@ -1838,7 +1860,7 @@ int32_t ilm_render_light_probes(IlmHandle hctx, const IlmLightVertex* lights, in
     if (light_count > 0) {
         int32_t rc = upload_small(c, c->d_lights, lights, sizeof(IlmLightVertex) * (size_t)light_count);
         if (rc != ILM_OK) return rc;
-        HIP_TRY(launch_prepare_lights(c->d_lights, light_count, *env, df->ConeAndMisc.x, c->d_recs, c->stream));
+        HIP_TRY(launch_prepare_lights(c->d_lights, light_count, *env, *df, make_sdf_view(f, df), c->d_recs, c->stream));
     }
     if (probe_count > c->probes_cap) {
         HIP_TRY(hipStreamSynchronize(c->stream));
@@ -2163,7 +2185,7 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
     if (light_count > 0) {
         int32_t rc = upload_small(c, c->d_lights, lights, sizeof(IlmLightVertex) * (size_t)light_count);
         if (rc != ILM_OK) return rc;
-        HIP_TRY(launch_prepare_lights(c->d_lights, light_count, *env, df->ConeAndMisc.x, c->d_recs, c->stream));
+        HIP_TRY(launch_prepare_lights(c->d_lights, light_count, *env, *df, make_sdf_view(f, df), c->d_recs, c->stream));
     }
 
     LightLaunch a;

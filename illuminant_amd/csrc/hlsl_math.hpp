@@ -158,10 +158,15 @@ ILM_DEV float lerp_fused(float a, float b, float t) { return __builtin_fmaf(t, b
 // compiler emits for an IEEE division without its two v_div_scale_f32 -- inside that range they do not scale (the scaled and
 // unscaled operands are the same bits, v_div_fmas_f32 applies no post-scale), so every intermediate is identical; v_div_fixup_f32
 // still patches the zero / infinite / NaN operands.  Checked against `/` on the device by tests/test_sdf_sample_gpu.py.
-ILM_DEV float div_no_scale(float n, float d) {
+ILM_DEV float refined_rcp(float d) {
     float y = __builtin_amdgcn_rcpf(d);
     const float e = __builtin_fmaf(-d, y, 1.0f);
-    y = __builtin_fmaf(e, y, y);
+    return __builtin_fmaf(e, y, y);
+}
+// n / d given y = refined_rcp(d) -- or any y at least as close to 1 / d (the correctly rounded reciprocal): the two correction steps
+// land on the correctly rounded quotient, which is unique.  A divisor shared by several numerators (normalize) or fixed per light /
+// per kernel pays the three reciprocal instructions once.
+ILM_DEV float div_with_rcp(float n, float d, float y) {
     float q = n * y;
     float r = __builtin_fmaf(-d, q, n);
     q = __builtin_fmaf(r, y, q);
@@ -169,6 +174,7 @@ ILM_DEV float div_no_scale(float n, float d) {
     q = __builtin_fmaf(r, y, q);
     return __builtin_amdgcn_div_fixupf(q, d, n);
 }
+ILM_DEV float div_no_scale(float n, float d) { return div_with_rcp(n, d, refined_rcp(d)); }
 
 // The general form: any position (clamped to the volume, distance to the volume added), U WRAP / V CLAMP on the real atlas.
 template <int FORMAT, bool CHECK_NAN = true>

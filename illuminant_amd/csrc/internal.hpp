@@ -142,9 +142,17 @@ struct LightLaunch {
 };
 
 constexpr size_t kLightRecBytes = 128;   // sizeof(LightRec) in lighting.hip
-// per-call preparation of the light records (footprint, cone config) into `recs` (device, count * kLightRecBytes)
-hipError_t launch_prepare_lights(const IlmLightVertex* lights, int count, const IlmEnvironment& env, float max_cone_radius,
-                                 void* recs, hipStream_t stream);
+// What the in-volume trace loop asks of a light and the field, decided once per light by the prepare kernels (lighting.hip,
+// light_flags): the centre inside the table sampler's box (SdfView) with the margin for rounding, and a field whose encoded distance,
+// extent and step budget are in range.
+struct TraceGate {
+    float x0, x1, y0, y1, z0, z1;       // box of SdfView shrunk by the light-side margin; empty when the field has no table
+    float field_ok;
+};
+TraceGate make_trace_gate(const IlmDistanceFieldUniforms& df, const SdfView& sdf);
+// per-call preparation of the light records (footprint, cone config, trace flags) into `recs` (device, count * kLightRecBytes)
+hipError_t launch_prepare_lights(const IlmLightVertex* lights, int count, const IlmEnvironment& env, const IlmDistanceFieldUniforms& df,
+                                 const SdfView& sdf, void* recs, hipStream_t stream);
 hipError_t launch_sphere_lights_prepared(const LightLaunch& a, const void* recs, hipStream_t stream);
 // Particle lights (ParticleLight.fx): ordered device-side compaction of the live, visible particles of every chunk into light
 // records.  block_counts: one int per 1024-slot block of every chunk (scratch); *out_count receives the record count.
@@ -154,6 +162,7 @@ struct ParticleLightLaunch {
     IlmParticleLightParams params;
     IlmEnvironment env;
     float max_cone_radius;
+    TraceGate gate;                 // make_trace_gate of the frame's field
     int32_t* block_counts;          // chunk_count * blocks_per_chunk
     void* recs; int32_t capacity;   // LightRec array
     int32_t* out_count;
@@ -167,6 +176,8 @@ hipError_t launch_light_probes(const void* recs, int light_count, const float4* 
 hipError_t launch_sdf_sample(const SdfView& sdf, const IlmDistanceFieldUniforms& df, const float* positions, int count, float* out, hipStream_t stream);
 hipError_t launch_sdf_sample_inside(const SdfView& sdf, const IlmDistanceFieldUniforms& df, const float* positions, int count, float* out, int32_t* used,
                                     hipStream_t stream);
+hipError_t launch_divide_by_constant(float divisor, float reciprocal, unsigned long long* mismatches, hipStream_t stream);
+void light_constant_divisors(float out[2][2]);
 hipError_t launch_divide_probe(const float* n, const float* d, int count, float* out_fast, float* out_ieee, hipStream_t stream);
 
 // ---- distance-field generation (fields.hip) ---------------------------------------------------------------

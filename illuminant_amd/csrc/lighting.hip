@@ -22,29 +22,43 @@ struct LightRec {
     float cx, cy, cz, radius;
     float ramp, falloff_mode, casts_shadows, ao_radius;
     float falloff_y, ao_opacity, shadow_filter, spec_power;
-    float col_r, col_g, col_b, has_spec;        // Color1.rgb * Color1.a
-    float spec_r, spec_g, spec_b, shadow_falloff;
+    float col_r, col_g, col_b, flags;           // Color1.rgb * Color1.a; kLightHasSpecular | kLightFastTrace | kLightFastDivide (as a float)
+    float spec_r, spec_g, spec_b, ramp_rcp;     // refined_rcp(ramp) for the distance ramp's division when kLightFastDivide
     float fx0, fx1, fx2, fx3;                   // raster footprint (screen px), see light_covers
     float fy0, fy1, fy2, fy3;
     float cfg_x, cfg_y, ramp_offset, ramp_rate; // createTraceConfig: maxRadius, radiusGrowthPerPixel; EvenMoreLightProperties.zw
 };
 static_assert(sizeof(LightRec) == 128, "LightRec is one 128-byte record");
+constexpr int kLightHasSpecular = 1;    // Color2.rgb != 0
+constexpr int kLightFastTrace = 2;      // light + field admit the in-volume trace loop (uniform half of shade_light's test; see light_flags)
+constexpr int kLightFastDivide = 4;     // radius and ramp lie in the operand range of the unscaled division
+
+// What the in-volume trace loop asks of a light and the field, decided once per light (prepare kernels): the centre inside the table
+// sampler's box with the margin for rounding, a cone radius of ordinary size, a sane encoded distance, a trace that does not
+// overshoot the light (radius >= 0), a step budget the uniform counter can count.
+ILM_DEV int light_flags(const LightRec& r, const TraceGate& g) {
+    int f = 0;
+    if ((r.spec_r != 0.0f) || (r.spec_g != 0.0f) || (r.spec_b != 0.0f)) f |= kLightHasSpecular;
+    const bool inside = (r.cx >= g.x0) & (r.cx <= g.x1) & (r.cy >= g.y0) & (r.cy <= g.y1) & (r.cz >= g.z0) & (r.cz <= g.z1);
+    if (inside && (g.field_ok != 0.0f) && (r.cfg_x >= 0x1p-60f) && (r.cfg_x <= 0x1p60f) && (r.radius >= 0.0f)) f |= kLightFastTrace;
+    if ((r.ramp >= 0x1p-60f) && (r.ramp <= 0x1p60f) && (fabsf(r.radius) <= 0x1p59f)) f |= kLightFastDivide;
+    return f;
+}
 
 // SphereLightVertexShader (SphereLightCore.fxh:13-56) over the 12-vertex cut-corner
 // quad (FillSphereBuffer, LightingRenderer.cs:636-656) + createTraceConfig (ConeTrace.fxh:128-146)
 __global__ __launch_bounds__(64) void prepare_lights_kernel(const IlmLightVertex* __restrict__ lights, int count, IlmEnvironment env,
-                                                             float max_cone_radius, LightRec* __restrict__ out) {
+                                                             float max_cone_radius, TraceGate gate, LightRec* __restrict__ out) {
     const int i = (int)blockIdx.x * 64 + (int)threadIdx.x;
     if (i >= count) return;
     const IlmLightVertex L = lights[i];
     LightRec r;
     r.cx = L.LightPosition1.x; r.cy = L.LightPosition1.y; r.cz = L.LightPosition1.z;
     r.radius = L.LightProperties.x; r.ramp = L.LightProperties.y; r.falloff_mode = L.LightProperties.z; r.casts_shadows = L.LightProperties.w;
-    r.ao_radius = L.MoreLightProperties.x; r.shadow_falloff = L.MoreLightProperties.y; r.falloff_y = L.MoreLightProperties.z; r.ao_opacity = L.MoreLightProperties.w;
+    r.ao_radius = L.MoreLightProperties.x; r.falloff_y = L.MoreLightProperties.z; r.ao_opacity = L.MoreLightProperties.w;
     r.shadow_filter = L.EvenMoreLightProperties.x;
     r.col_r = L.Color1.x * L.Color1.w; r.col_g = L.Color1.y * L.Color1.w; r.col_b = L.Color1.z * L.Color1.w;
     r.spec_r = L.Color2.x; r.spec_g = L.Color2.y; r.spec_b = L.Color2.z; r.spec_power = L.Color2.w;
-    r.has_spec = ((L.Color2.x != 0.0f) || (L.Color2.y != 0.0f) || (L.Color2.z != 0.0f)) ? 1.0f : 0.0f;
 
     const float cOne = 1.0f / 7.0f, mOne = 6.0f / 7.0f;
     const float radius = L.LightProperties.x + L.LightProperties.y + 1.0f;
@@ -66,6 +80,9 @@ __global__ __launch_bounds__(64) void prepare_lights_kernel(const IlmLightVertex
     r.cfg_x = max_radius;
     r.cfg_y = max_radius / fmaxf(r.ramp, 16.0f) * 1.0f;  // getConeGrowthFactor() == 1 (DistanceFieldCommon.fxh:233-236)
     r.ramp_offset = L.EvenMoreLightProperties.z; r.ramp_rate = L.EvenMoreLightProperties.w;
+    const int flags = light_flags(r, gate);
+    r.flags = (float)flags;
+    r.ramp_rcp = (flags & kLightFastDivide) ? refined_rcp(r.ramp) : 0.0f;
     out[i] = r;
 }
 
@@ -80,7 +97,19 @@ ILM_DEV f3 decode_normal(float ex, float ey) {
 struct Pixel {
     f3 shaded, normal, camera;
     bool enable_shadows, fullbright;
+    // light-independent half of the in-volume trace test: the trace start (shaded + normal * SELF_OCCLUSION_HACK) lies in the table
+    // sampler's box with the start-side margin (set by trace_start_inside once per pixel)
+    bool start_inside;
 };
+
+// Samples lie on the segment start -> light centre, or (trace shorter than the minimum length 1) within 1 of start: the start must
+// keep 1 + the rounding margin from the box faces, the light centre (TraceGate, per light) the rounding margin alone.
+ILM_DEV bool trace_start_inside(const Pixel& P, const IlmDistanceFieldUniforms& df, const SdfView& sdf) {
+    const f3 start = P.shaded + (P.normal * ref::kSelfOcclusionHack);
+    const float mx = 1.0625f + df.Extent.x * 0x1p-16f, my = 1.0625f + df.Extent.y * 0x1p-16f, mz = 1.0625f + df.Extent.z * 0x1p-16f;
+    return (start.x >= sdf.box_x0 + mx) & (start.x <= sdf.box_x1 - mx) & (start.y >= sdf.box_y0 + my) & (start.y <= sdf.box_y1 - my) &
+           (start.z >= sdf.box_z0 + mz) & (start.z <= sdf.box_z1 - mz);
+}
 
 // sampleGBuffer, LightCommon.fxh:58-144
 ILM_DEV Pixel sample_gbuffer(float spx, float spy, const IlmEnvironment& env, const GBufferView& g) {
@@ -136,19 +165,32 @@ ILM_DEV Pixel sample_gbuffer(float spx, float spy, const IlmEnvironment& env, co
     return p;
 }
 
-// computeSphereLightOpacity + computeNormalFactor, LightCommon.fxh:154-214
-ILM_DEV float sphere_light_opacity(f3 shaded, f3 normal, const LightRec& L, float light_occlusion) {
-    f3 d3 = shaded - mk3(L.cx, L.cy, L.cz);
-    d3.y *= L.falloff_y;
-    const float distance = len3(d3);
-    float distance_factor = 1.0f - sat((distance - L.radius) / L.ramp);
+// computeSphereLightOpacity + computeNormalFactor, LightCommon.fxh:154-214.
+// SHARED: every divisor of this function lies in the operand range of the unscaled division (the caller's wave-uniform test):
+// the three divisions by `distance` share one refined reciprocal, the division by the light's ramp uses the one its record carries,
+// the division by DOT_RAMP_RANGE the constant's -- the same correctly rounded quotients as `/` (tests: ilm_debug_divide,
+// ilm_debug_divide_by_constant over all 2^32 numerators), 9 + 9 + 6 + 6 instructions instead of five 12-instruction sequences.
+constexpr float kDotRampRangeRcp = (float)(1.0 / (double)ref::kDotRampRange);
+constexpr float kVisibilityRange = ref::kUnshadowedThreshold - ref::kFullyShadowedThreshold;
+constexpr float kVisibilityRangeRcp = (float)(1.0 / (double)kVisibilityRange);
+template <bool SHARED>
+ILM_DEV float sphere_light_opacity(f3 d3, float distance, f3 normal, const LightRec& L, float light_occlusion) {
+    const float over = distance - L.radius;
+    float distance_factor = 1.0f - sat(SHARED ? div_with_rcp(over, L.ramp, L.ramp_rcp) : (over / L.ramp));
     if (light_occlusion > 0.0f)
         distance_factor *= 1.0f - sat(d3.z / light_occlusion);
     float normal_factor = 1.0f;
     if ((normal.x != 0.0f) || (normal.y != 0.0f) || (normal.z != 0.0f)) {
-        const f3 ln = mk3(d3.x / distance, d3.y / distance, d3.z / distance);
+        f3 ln;
+        if (SHARED) {
+            const float y = refined_rcp(distance);
+            ln = mk3(div_with_rcp(d3.x, distance, y), div_with_rcp(d3.y, distance, y), div_with_rcp(d3.z, distance, y));
+        } else {
+            ln = mk3(d3.x / distance, d3.y / distance, d3.z / distance);
+        }
         const float d = dot3(ln * -1.0f, normal);
-        normal_factor = pow_pos(sat((d + ref::kDotOffset) / ref::kDotRampRange), ref::kDotExponent);
+        const float ramped = SHARED ? div_with_rcp(d + ref::kDotOffset, ref::kDotRampRange, kDotRampRangeRcp) : ((d + ref::kDotOffset) / ref::kDotRampRange);
+        normal_factor = pow_pos(sat(ramped), ref::kDotExponent);
     }
     if (L.falloff_mode >= 2.0f) {
         distance_factor = 1.0f - sat(distance - L.radius);
@@ -237,7 +279,16 @@ ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment
         return false;
 
     const float casts = L.casts_shadows * (P.enable_shadows ? 1.0f : 0.0f);
-    const float distance_opacity = sphere_light_opacity(P.shaded, P.normal, L, env.ZToY.z);
+    const int light_flags_i = (int)L.flags;
+    f3 d3 = P.shaded - mk3(L.cx, L.cy, L.cz);
+    d3.y *= L.falloff_y;
+    const float distance = len3(d3);
+    // the shared-reciprocal divisions need distance (a divisor, and with the radius the ramp's numerator) inside their operand range:
+    // one wave-uniform test, the IEEE form otherwise
+    const bool divisors_ordinary = (distance >= 0x1p-60f) & (distance <= 0x1p59f);
+    const float distance_opacity = ((light_flags_i & kLightFastDivide) && __builtin_amdgcn_ballot_w64(!divisors_ordinary) == 0ull)
+                                       ? sphere_light_opacity<true>(d3, distance, P.normal, L, env.ZToY.z)
+                                       : sphere_light_opacity<false>(d3, distance, P.normal, L, env.ZToY.z);
     const bool visible = (distance_opacity > 0.0f) && (P.shaded.x > -9999.0f);
     if (!visible)
         return false;
@@ -263,40 +314,36 @@ ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment
         f3 start = P.shaded + (P.normal * ref::kSelfOcclusionHack);
         const f3 tv = mk3(L.cx, L.cy, L.cz) - start;
         const float trace_length = len3(tv);
-        f3 dir = mk3(tv.x / trace_length, tv.y / trace_length, tv.z / trace_length);
         const float data_y = fmaxf(trace_length - L.radius, 1.0f);
         float data_x = ref::kTraceInitialOffsetPx;
         float data_z = 1.0f;
         const float cfg_z = fmaxf(1.0f, df.Packed1.w);
         float steps_remaining = df.StepAndMisc2.x;
-        float liveness = have_sdf ? 1.0f : 0.0f;
-        // The sampler treats a NaN coordinate as 0.  start + dir * x is NaN for every x exactly when start or dir is (x stays
-        // finite), so the test is hoisted: such an axis becomes start = dir = 0 and the loop samples with CHECK_NAN = false.
-        if ((start.x != start.x) || (dir.x != dir.x)) { start.x = 0.0f; dir.x = 0.0f; }
-        if ((start.y != start.y) || (dir.y != dir.y)) { start.y = 0.0f; dir.y = 0.0f; }
-        if ((start.z != start.z) || (dir.z != dir.z)) { start.z = 0.0f; dir.z = 0.0f; }
+        const bool alive = have_sdf;
         // The light's cone configuration is read every iteration; with ~104 SGPRs live the compiler re-loads it from memory inside the
         // loop (s_load + s_waitcnt per sample).  Two VGPRs keep it resident.
         float cone_max_radius = L.cfg_x, cone_growth = L.cfg_y;
         asm volatile("" : "+v"(cone_max_radius), "+v"(cone_growth));
-        // In-volume loop when, for every tracing lane of the wave, every sample lies in the box of the table sampler (SdfView): samples
-        // lie on the segment start -> light centre, or (trace shorter than the minimum length 1) within 1 of start; both ends inside
-        // with a margin that covers that and the rounding of start + dir * x.  Plus the operand range div_no_scale needs, a budget
-        // the uniform step counter can count, and a light whose trace does not overshoot it (uniform per light / field).
-        const float mx = 0.0625f + df.Extent.x * 0x1p-16f, my = 0.0625f + df.Extent.y * 0x1p-16f, mz = 0.0625f + df.Extent.z * 0x1p-16f;
-        const bool ends_inside =
-            (start.x >= sdf.box_x0 + 1.0f + mx) & (start.x <= sdf.box_x1 - 1.0f - mx) & (L.cx >= sdf.box_x0 + mx) & (L.cx <= sdf.box_x1 - mx) &
-            (start.y >= sdf.box_y0 + 1.0f + my) & (start.y <= sdf.box_y1 - 1.0f - my) & (L.cy >= sdf.box_y0 + my) & (L.cy <= sdf.box_y1 - my) &
-            (start.z >= sdf.box_z0 + 1.0f + mz) & (start.z <= sdf.box_z1 - 1.0f - mz) & (L.cz >= sdf.box_z0 + mz) & (L.cz <= sdf.box_z1 - mz);
-        const bool ordinary = (F.table != nullptr) & (L.cfg_x >= 0x1p-60f) & (L.cfg_x <= 0x1p60f) & (df.Extent.w > 0.0f) & (df.Extent.w <= 0x1p20f) &
-                              (L.radius >= 0.0f) & (steps_remaining >= 0.0f) & (steps_remaining <= 0x1p23f);
-        const bool alive = liveness > 0.0f;
-        if (ordinary && __builtin_amdgcn_ballot_w64(trace & !ends_inside) == 0ull)
+        // In-volume loop when, for every tracing lane of the wave, every sample lies in the box of the table sampler: the light's half of
+        // the test was decided when its record was prepared (kLightFastTrace), the pixel's half once per pixel (start_inside); what is
+        // left per pair is a trace of ordinary length (a divisor of the unscaled division; > 0 also means a finite direction).
+        const bool pair_ok = P.start_inside & (trace_length >= 0x1p-60f);
+        if ((F.table != nullptr) && (light_flags_i & kLightFastTrace) && __builtin_amdgcn_ballot_w64(!pair_ok) == 0ull) {
+            const float y = refined_rcp(trace_length);
+            const f3 dir = mk3(div_with_rcp(tv.x, trace_length, y), div_with_rcp(tv.y, trace_length, y), div_with_rcp(tv.z, trace_length, y));
             cone_trace_loop<FMT, STATS, true>(start, dir, data_y, cfg_z, cone_growth, cone_max_radius, F, data_x, data_z, steps_remaining, alive, st);
-        else
+        } else {
+            f3 dir = mk3(tv.x / trace_length, tv.y / trace_length, tv.z / trace_length);
+            // The sampler treats a NaN coordinate as 0.  start + dir * x is NaN for every x exactly when start or dir is (x stays
+            // finite), so the test is hoisted: such an axis becomes start = dir = 0 and the loop samples with CHECK_NAN = false.
+            if ((start.x != start.x) || (dir.x != dir.x)) { start.x = 0.0f; dir.x = 0.0f; }
+            if ((start.y != start.y) || (dir.y != dir.y)) { start.y = 0.0f; dir.y = 0.0f; }
+            if ((start.z != start.z) || (dir.z != dir.z)) { start.z = 0.0f; dir.z = 0.0f; }
             cone_trace_loop<FMT, STATS, false>(start, dir, data_y, cfg_z, cone_growth, cone_max_radius, F, data_x, data_z, steps_remaining, alive, st);
+        }
         const float visibility = fminf(data_z, steps_remaining / ref::kMaxStepRampWindow);
-        cone_opacity = pow_pos(sat(sat(visibility - ref::kFullyShadowedThreshold) / (ref::kUnshadowedThreshold - ref::kFullyShadowedThreshold)), df.ConeAndMisc.z);
+        // (the numerator is a saturate: always inside the unscaled division's range; the divisor is a constant)
+        cone_opacity = pow_pos(sat(div_with_rcp(sat(visibility - ref::kFullyShadowedThreshold), kVisibilityRange, kVisibilityRangeRcp)), df.ConeAndMisc.z);
     }
     // SphereLightPixelEpilogue / ...WithRamp (SphereLightCore.fxh:83-119): with a ramp texture the opacity becomes a colour,
     // SampleFromRamp2(preTraceOpacity, (angle + rampOffset) * rampRate).rgb * coneOpacity -- tex2Dlod level 0, LINEAR, U CLAMP, V WRAP
@@ -324,7 +371,7 @@ ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment
     // skipped when Color2.rgb == 0: it then contributes exactly 0 unless
     // pow() produced inf/NaN (negative SpecularPower), which the reference does not guard.
     float sr = 0.0f, sg = 0.0f, sb = 0.0f;
-    if (L.has_spec != 0.0f) {
+    if (light_flags_i & kLightHasSpecular) {
         const f3 light_direction = P.shaded - mk3(L.cx, L.cy, L.cz);
         const f3 h = norm3(norm3(P.camera - P.shaded) - light_direction);
         const float specularity = pow_pos(sat(dot3(h, P.normal)), L.spec_power);
@@ -341,8 +388,18 @@ ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment
 constexpr int kTile = 16;
 constexpr int kListCapacity = 1024;
 
+// Six waves per SIMD (80 VGPRs, 28 bytes of scratch in the per-pair code): measured r02 against the allocator's own choice (93 VGPRs, five
+// waves) cfg5 11.55 -> 11.21 ms, cfg3 unchanged; seven / eight waves spill inside the trace loop and lose 3-6 % (tools/ab_lib.sh).
+#ifndef ILM_LIGHT_WAVES
+#define ILM_LIGHT_WAVES 6
+#endif
+#if ILM_LIGHT_WAVES > 0
+#define ILM_LIGHT_OCCUPANCY __attribute__((amdgpu_waves_per_eu(ILM_LIGHT_WAVES, ILM_LIGHT_WAVES)))
+#else
+#define ILM_LIGHT_OCCUPANCY
+#endif
 template <int FMT, bool STATS>
-__global__ __launch_bounds__(256) void sphere_lights_kernel(const LightLaunch a, const LightRec* __restrict__ recs, int tiles_x, int tiles_y, int tile_count) {
+__global__ __launch_bounds__(256) ILM_LIGHT_OCCUPANCY void sphere_lights_kernel(const LightLaunch a, const LightRec* __restrict__ recs, int tiles_x, int tiles_y, int tile_count) {
     __shared__ uint16_t list[kListCapacity];
     __shared__ int list_count;
     __shared__ SliceEntry slice_table[kMaxTableSlices];
@@ -379,7 +436,8 @@ __global__ __launch_bounds__(256) void sphere_lights_kernel(const LightLaunch a,
     const int py = ty0 + (wave >> 1) * 8 + (lane >> 3);
     const bool in_image = (px < a.width) && (py < a.row_end);
 
-    const Pixel P = sample_gbuffer((float)px, (float)py, a.env, a.gbuffer);
+    Pixel P = sample_gbuffer((float)px, (float)py, a.env, a.gbuffer);
+    P.start_inside = (table_n > 0) && trace_start_inside(P, a.df, a.sdf);
     const float cxp = (float)px + 0.5f, cyp = (float)py + 0.5f;
     const bool have_sdf = (a.sdf.texels != nullptr) && (a.df.Extent.x > 0.0f);
 
@@ -562,11 +620,10 @@ __global__ __launch_bounds__(kPlBlock) void particle_light_emit_kernel(const Par
     LightRec r;
     r.cx = pos.x; r.cy = pos.y; r.cz = pos.z;
     r.radius = P.LightProperties.x; r.ramp = P.LightProperties.y; r.falloff_mode = P.LightProperties.z; r.casts_shadows = P.LightProperties.w;
-    r.ao_radius = P.MoreLightProperties.x; r.shadow_falloff = P.MoreLightProperties.y; r.falloff_y = P.MoreLightProperties.z; r.ao_opacity = P.MoreLightProperties.w;
+    r.ao_radius = P.MoreLightProperties.x; r.falloff_y = P.MoreLightProperties.z; r.ao_opacity = P.MoreLightProperties.w;
     r.shadow_filter = -1.0f;                                                   // ParticleLightPixelShader has no shadow filter
     r.col_r = col.x * col.w; r.col_g = col.y * col.w; r.col_b = col.z * col.w; // lightColor.rgb * lightColor.a, :113-116
     r.spec_r = P.LightSpecularColor.x; r.spec_g = P.LightSpecularColor.y; r.spec_b = P.LightSpecularColor.z; r.spec_power = P.LightSpecularColor.w;
-    r.has_spec = ((r.spec_r != 0.0f) || (r.spec_g != 0.0f) || (r.spec_b != 0.0f)) ? 1.0f : 0.0f;
     // the quad, :55-70: a plain rectangle (fx1 = fx0, fx2 = fx3 collapse the sphere light's cross shape onto it)
     const float radius = P.LightProperties.x + P.LightProperties.y + 1.0f;
     const float tlx = r.cx - radius, brx = r.cx + radius, bry = r.cy + radius;
@@ -582,6 +639,9 @@ __global__ __launch_bounds__(kPlBlock) void particle_light_emit_kernel(const Par
     r.cfg_x = max_radius;
     r.cfg_y = max_radius / fmaxf(r.ramp, 16.0f) * 1.0f;
     r.ramp_offset = r.ramp_rate = 0.0f;
+    const int flags = light_flags(r, a.gate);
+    r.flags = (float)flags;
+    r.ramp_rcp = (flags & kLightFastDivide) ? refined_rcp(r.ramp) : 0.0f;
     reinterpret_cast<LightRec*>(a.recs)[index] = r;
 }
 
@@ -612,6 +672,7 @@ __global__ __launch_bounds__(64) void light_probes_kernel(const LightRec* __rest
     Pixel P;
     P.shaded = xyz(pp); P.normal = xyz(pn); P.camera = mk3(0.0f, 0.0f, 0.0f);
     P.fullbright = false;
+    P.start_inside = false;
     const bool have_sdf = (sdf.texels != nullptr) && (df.Extent.x > 0.0f);
     float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f, acc_a = 0.0f;
     LightStats st;
@@ -626,7 +687,7 @@ __global__ __launch_bounds__(64) void light_probes_kernel(const LightRec* __rest
         P.enable_shadows = true;
         L.ao_radius = 0.0f; L.ao_opacity = 0.0f;
         L.shadow_filter = -1.0f;
-        L.has_spec = 0.0f;
+        L.flags = (float)((int)L.flags & kLightFastDivide);     // no specular; probes use the general trace loop (no slice table here)
         float cr, cg, cb;
         if (!shade_light<FMT, false>(P, L, env, field, have_sdf, ramp, st, cr, cg, cb))
             continue;
@@ -696,10 +757,23 @@ hipError_t launch_sdf_sample(const SdfView& sdf, const IlmDistanceFieldUniforms&
 }
 
 // device scratch for the prepared light records, owned by the caller (api.hip)
-hipError_t launch_prepare_lights(const IlmLightVertex* lights, int count, const IlmEnvironment& env, float max_cone_radius,
-                                 void* recs, hipStream_t stream) {
+// the light-side half of the in-volume trace test (see light_flags)
+TraceGate make_trace_gate(const IlmDistanceFieldUniforms& df, const SdfView& sdf) {
+    TraceGate g;
+    const float mx = 0.0625f + df.Extent.x * 0x1p-16f, my = 0.0625f + df.Extent.y * 0x1p-16f, mz = 0.0625f + df.Extent.z * 0x1p-16f;
+    g.x0 = sdf.box_x0 + mx; g.x1 = sdf.box_x1 - mx;
+    g.y0 = sdf.box_y0 + my; g.y1 = sdf.box_y1 - my;
+    g.z0 = sdf.box_z0 + mz; g.z1 = sdf.box_z1 - mz;
+    const bool ok = (sdf.table_slices > 0) && (df.Extent.w > 0.0f) && (df.Extent.w <= 0x1p20f) && (df.Extent.x <= 0x1p20f) && (df.Extent.y <= 0x1p20f) &&
+                    (df.Extent.z <= 0x1p20f) && (df.StepAndMisc2.x >= 0.0f) && (df.StepAndMisc2.x <= 0x1p23f);
+    g.field_ok = ok ? 1.0f : 0.0f;
+    return g;
+}
+
+hipError_t launch_prepare_lights(const IlmLightVertex* lights, int count, const IlmEnvironment& env, const IlmDistanceFieldUniforms& df,
+                                 const SdfView& sdf, void* recs, hipStream_t stream) {
     if (count <= 0) return hipSuccess;
-    hipLaunchKernelGGL(prepare_lights_kernel, dim3((count + 63) / 64), dim3(64), 0, stream, lights, count, env, max_cone_radius,
+    hipLaunchKernelGGL(prepare_lights_kernel, dim3((count + 63) / 64), dim3(64), 0, stream, lights, count, env, df.ConeAndMisc.x, make_trace_gate(df, sdf),
                        reinterpret_cast<LightRec*>(recs));
     return hipGetLastError();
 }
@@ -733,6 +807,34 @@ __global__ __launch_bounds__(256) void divide_probe_kernel(const float* __restri
     if (i >= count) return;
     out_fast[i] = div_no_scale(n[i], d[i]);
     out_ieee[i] = n[i] / d[i];
+}
+
+// every one of the 2^32 float bit patterns as the numerator of a division by one constant: div_with_rcp with the constant's
+// host-computed reciprocal against `/` (proof by exhaustion for the two constant divisors of shade_light)
+__global__ __launch_bounds__(256) void divide_by_constant_kernel(float divisor, float reciprocal, unsigned long long* __restrict__ mismatches) {
+    const uint32_t first = ((uint32_t)blockIdx.x * 256u + (uint32_t)threadIdx.x) << 12;      // 2^20 threads x 4096 numerators
+    uint32_t bad_inside = 0, bad_outside = 0;
+    for (uint32_t k = 0; k < 4096u; k++) {
+        const float n = __uint_as_float(first + k);
+        const float a = div_with_rcp(n, divisor, reciprocal), b = n / divisor;
+        const bool differ = (__float_as_uint(a) != __float_as_uint(b)) && !((a != a) && (b != b));
+        // the range the unscaled division is specified for: 2^-60 <= |n| <= 2^60, or zero / infinite / NaN
+        const float m = fabsf(n);
+        const bool admitted = !(m < 0x1p-60f && m > 0.0f) && !(m > 0x1p60f && m < __builtin_inff());
+        bad_inside += (differ && admitted) ? 1u : 0u;
+        bad_outside += (differ && !admitted) ? 1u : 0u;
+    }
+    if (bad_inside) atomicAdd(&mismatches[0], (unsigned long long)bad_inside);
+    if (bad_outside) atomicAdd(&mismatches[1], (unsigned long long)bad_outside);
+}
+hipError_t launch_divide_by_constant(float divisor, float reciprocal, unsigned long long* mismatches, hipStream_t stream) {
+    hipLaunchKernelGGL(divide_by_constant_kernel, dim3(4096), dim3(256), 0, stream, divisor, reciprocal, mismatches);
+    return hipGetLastError();
+}
+// the (divisor, reciprocal) pairs shade_light uses
+void light_constant_divisors(float out[2][2]) {
+    out[0][0] = ref::kDotRampRange; out[0][1] = kDotRampRangeRcp;
+    out[1][0] = kVisibilityRange; out[1][1] = kVisibilityRangeRcp;
 }
 
 hipError_t launch_divide_probe(const float* n, const float* d, int count, float* out_fast, float* out_ieee, hipStream_t stream) {

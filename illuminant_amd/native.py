@@ -72,6 +72,7 @@ SYMBOLS = {
     "ilm_sdf_sample": (_I, [_H, _P, _P, _I, _P]),
     "ilm_debug_sdf_sample_inside": (_I, [_H, _P, _P, _I, _P, _P]),
     "ilm_debug_divide": (_I, [_H, _P, _P, _I, _P, _P]),
+    "ilm_debug_divide_by_constants": (_I, [_H, _P, _P, _I, C.POINTER(_I)]),
     "ilm_sdf_destroy": (_I, [_H]),
     "ilm_sdf_download": (_I, [_H, _P]),
     "ilm_sdf_device_ptr": (_I, [_H, C.POINTER(_P)]),
@@ -195,6 +196,12 @@ class Context:
         fast = np.empty_like(n); ieee = np.empty_like(n)
         check(lib().ilm_debug_divide(self.handle, _ptr(n), _ptr(d), n.shape[0], _ptr(fast), _ptr(ieee)))
         return fast, ieee
+
+    def debug_divide_by_constants(self):
+        """ilm_debug_divide_by_constants: [(divisor, mismatches among the numerators inside the admitted range, mismatches outside it)] over all 2^32 numerators."""
+        d = np.zeros(4, np.float32); bad = np.zeros(8, np.uint64); n = C.c_int32()
+        check(lib().ilm_debug_divide_by_constants(self.handle, _ptr(d), _ptr(bad), 4, C.byref(n)))
+        return [(float(d[i]), int(bad[2 * i]), int(bad[2 * i + 1])) for i in range(n.value)]
 
     def timer_start(self):
         check(lib().ilm_timer_start(self.handle))

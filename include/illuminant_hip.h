@@ -470,6 +470,13 @@ int32_t ilm_debug_sdf_sample_inside(IlmHandle sdf, const IlmDistanceFieldUniform
  * (ConeTrace.fxh:62) with an instruction sequence that skips the IEEE division's range scaling.  This evaluates that sequence
  * (`out_fast`) and the plain IEEE division (`out_ieee`) for `count` operand pairs on the device, so a test can hold them
  * bit-equal over the operand range the kernel admits (2^-60 <= |d| <= 2^60, |n| <= 2^60 or zero / infinite / NaN). */
+/* The light pass divides by two constants -- DOT_RAMP_RANGE (LightCommon.fxh:6) and UNSHADOWED_THRESHOLD - FULLY_SHADOWED_THRESHOLD
+ * (ConeTrace.fxh:19-20, :186) -- with the constants' reciprocals folded in at compile time.  This runs, for each of them, ALL 2^32
+ * float bit patterns as the numerator through that sequence and through the IEEE division and counts the results that differ:
+ * out_mismatches[2 i] for numerators inside the range the sequence is specified for (2^-60 <= |n| <= 2^60, zero, infinite, NaN -- the
+ * kernel's numerators are saturates and sums of unit-vector components), out_mismatches[2 i + 1] outside it, for divisor
+ * out_divisors[i]; *out_count divisors, out_mismatches holds 2 * capacity entries.  A test requires zero inside. */
+int32_t ilm_debug_divide_by_constants(IlmHandle ctx, float* out_divisors, uint64_t* out_mismatches, int32_t capacity, int32_t* out_count);
 int32_t ilm_debug_divide(IlmHandle ctx, const float* numerators, const float* denominators, int32_t count, float* out_fast, float* out_ieee);
 int32_t ilm_sdf_destroy(IlmHandle sdf);
 /* DistanceField.Save (Illuminant/SDF/DistanceField.cs:178-194): the atlas bytes, 8 per texel, row-major. */

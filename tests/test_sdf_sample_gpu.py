@@ -210,3 +210,12 @@ def test_in_volume_sampler_is_refused_for_uniforms_that_do_not_describe_the_atla
         want = oracle_samples(oracle, pos, bad, oracle.make_texture(atlas, abi.SDF_UNORM16))
         assert np.array_equal(got, want), tweak
     sdf.close()
+
+
+def test_divisions_by_the_light_pass_constants_are_exact_for_every_numerator(ctx):
+    """Proof by exhaustion: for DOT_RAMP_RANGE and (UNSHADOWED - FULLY_SHADOWED) the shared-reciprocal division of lighting.hip equals
+    `/` for every numerator bit pattern inside the range the unscaled division is specified for (2^-60 <= |n| <= 2^60, zero, infinite,
+    NaN; the kernel's numerators are a saturate and a sum of unit-vector components plus 0.15)."""
+    results = ctx.debug_divide_by_constants()
+    assert [round(d, 4) for d, _, _ in results] == [0.15, 0.875]
+    assert all(inside == 0 for _, inside, _ in results), results
