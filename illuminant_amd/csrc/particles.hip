@@ -810,36 +810,48 @@ struct SlotIn {
     float px, py, pz, life, vx, vy, vz, ct, ar, ag, ab, aa;
 };
 
-// Plane c of the unit: a UNIFORM pointer (chunk base + c * stride + first slot of the unit, all SGPR values) indexed
-// by the lane number alone, so every access is `global_load/store_dword v, v_lane_offset, s[base:base+1]` --
-// no per-plane 64-bit vector address arithmetic.
-// The empty asm pins the plane pointer in an SGPR pair: without it LLVM re-associates (ub + lane) + c * S and
-// falls back to a 64-bit vector multiply-add per access.
-ILM_DEV gfloat* plane(gfloat* ub, int64_t S, int c) {
-    gfloat* p = ub + (int64_t)c * S;
-    asm("" : "+s"(p));
-    return p;
+// The 20 planes of one unit through ONE buffer resource (the chunk's allocation) and one lane offset: plane c of the unit is
+// `buffer_load/store_dword v, v_lane_offset, s[rsrc], s_plane_offset offen` with s_plane_offset = (first slot + c * stride) * 4 in an
+// SGPR -- twenty 32-bit scalar adds per wave.  (The flat form, `global_load_dword v, v_lane_offset, s[base:base+1]`, needs a 64-bit
+// base per plane: 2 scalar instructions per plane, computed once for the loads and again for the stores -- 80 of the ~370 scalar
+// instructions a wave issued, and the scalar pipe, one instruction per cycle per CU against the four SIMDs' vector issue, is what
+// the step's issue phase is bound by: tools/ubench/salu.)
+struct UnitPlanes {
+    __amdgpu_buffer_rsrc_t rsrc;
+    uint32_t so[kComponents];
+};
+
+ILM_DEV UnitPlanes unit_planes(const float* chunk_base, int64_t stride, int first_slot) {
+    UnitPlanes u;
+    // raw buffer (stride 0), num_records = the chunk's bytes, DATA_FORMAT = 32 bits (0x00020000, the word gfx9 wants for untyped access)
+    u.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)chunk_base, 0, (int)(stride * (kComponents * 4)), 0x00020000);
+    const uint32_t s4 = (uint32_t)stride * 4u;
+    u.so[0] = (uint32_t)first_slot * 4u;
+#pragma unroll
+    for (int c = 1; c < kComponents; c++) u.so[c] = u.so[c - 1] + s4;
+    return u;
 }
 
 // STREAM: the launch's working set is larger than the Infinity Cache (api.hip decides), every plane is touched once per step: loads and
 // stores carry the non-temporal hint so they do not evict each other on the way through (tools/ubench/stream: 8.4 M slots 187 -> 170 us;
 // on a cache-resident working set the same hint costs 25 %, so small systems keep the default policy).
 template <bool STREAM>
-ILM_DEV float ld_plane(gfloat* p, unsigned lane) { return STREAM ? __builtin_nontemporal_load(p + lane) : p[lane]; }
+ILM_DEV float ld_plane(const UnitPlanes& u, int c, unsigned lane4) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(u.rsrc, (int)lane4, (int)u.so[c], STREAM ? 2 : 0));
+}
 template <bool STREAM>
-ILM_DEV void st_plane(gfloat* p, unsigned lane, float v) {
-    if (STREAM) __builtin_nontemporal_store(v, p + lane);
-    else p[lane] = v;
+ILM_DEV void st_plane(const UnitPlanes& u, int c, unsigned lane4, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), u.rsrc, (int)lane4, (int)u.so[c], STREAM ? 2 : 0);
 }
 
 template <bool ATTR, bool STREAM>
-ILM_DEV SlotIn load_slot(gfloat* ub, int64_t S, unsigned lane) {
+ILM_DEV SlotIn load_slot(const UnitPlanes& u, unsigned lane4) {
     SlotIn s;
-    s.life = ld_plane<STREAM>(plane(ub, S, 3), lane);
-    s.px = ld_plane<STREAM>(plane(ub, S, 0), lane); s.py = ld_plane<STREAM>(plane(ub, S, 1), lane); s.pz = ld_plane<STREAM>(plane(ub, S, 2), lane);
-    s.vx = ld_plane<STREAM>(plane(ub, S, 4), lane); s.vy = ld_plane<STREAM>(plane(ub, S, 5), lane); s.vz = ld_plane<STREAM>(plane(ub, S, 6), lane); s.ct = ld_plane<STREAM>(plane(ub, S, 7), lane);
+    s.life = ld_plane<STREAM>(u, 3, lane4);
+    s.px = ld_plane<STREAM>(u, 0, lane4); s.py = ld_plane<STREAM>(u, 1, lane4); s.pz = ld_plane<STREAM>(u, 2, lane4);
+    s.vx = ld_plane<STREAM>(u, 4, lane4); s.vy = ld_plane<STREAM>(u, 5, lane4); s.vz = ld_plane<STREAM>(u, 6, lane4); s.ct = ld_plane<STREAM>(u, 7, lane4);
     if (ATTR) {
-        s.ar = ld_plane<STREAM>(plane(ub, S, 8), lane); s.ag = ld_plane<STREAM>(plane(ub, S, 9), lane); s.ab = ld_plane<STREAM>(plane(ub, S, 10), lane); s.aa = ld_plane<STREAM>(plane(ub, S, 11), lane);
+        s.ar = ld_plane<STREAM>(u, 8, lane4); s.ag = ld_plane<STREAM>(u, 9, lane4); s.ab = ld_plane<STREAM>(u, 10, lane4); s.aa = ld_plane<STREAM>(u, 11, lane4);
     } else {
         s.ar = s.ag = s.ab = s.aa = 0.0f;
     }
@@ -855,10 +867,11 @@ typedef const StepLaunch __attribute__((address_space(4))) CStepLaunch;
 // DF: the update pass is UpdateWithDistanceField (pulls in the SDF sampler); SPAWN: spawn records present.
 // Both are compile-time so the common no-field / no-spawn step does not pay their registers.
 template <int FMT, bool DF, bool SPAWN, bool EXT, bool STREAM>
-ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* ub, int chunk, int i, unsigned lane, int seg, SlotIn cur, const NoiseDeltas& noise) {
+ILM_DEV bool process_unit(CStepLaunch* ap, const UnitPlanes& up, int chunk, int i, unsigned lane, int seg, SlotIn cur, const NoiseDeltas& noise) {
     const StepLaunch& a = *(const StepLaunch*)ap;
     const IlmStepDesc& d = a.desc;
     const int64_t S = a.stride;
+    const unsigned lane4 = lane * 4u;
     const int mode = d.UpdateMode;
     const bool need_attr = (mode == ILM_UPDATE_POSITIONS) || (mode == ILM_UPDATE_WITH_DISTANCE_FIELD);
     // Noise has no life check (Noise.fx:40): dead slots go through it.  That only matters when its result survives --
@@ -883,17 +896,17 @@ ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* ub, int chunk, int i, unsigne
     if (mode == ILM_UPDATE_ERASE) {
         // PS_Erase, UpdateParticleSystem.fx:40-49
 #pragma unroll
-        for (int c = 0; c < 8; c++) st_plane<STREAM>(plane(ub, S, c), lane, 0.0f);
+        for (int c = 0; c < 8; c++) st_plane<STREAM>(up, c, lane4, 0.0f);
 #pragma unroll
-        for (int c = 12; c < 20; c++) st_plane<STREAM>(plane(ub, S, c), lane, 0.0f);
+        for (int c = 12; c < 20; c++) st_plane<STREAM>(up, c, lane4, 0.0f);
     } else if ((cur.life <= 0.0f) && !spawn_here && !has_noise) {     // `<= 0` as the shaders test it: a NaN life is not dead
         // dead and nothing writes it: the update pass leaves the cleared target
         // (UpdateHandler._BeforeDraw clears, ParticleTransform.cs:164-165; readStateOrDiscard discards)
         if (mode != ILM_UPDATE_NONE) {
 #pragma unroll
-            for (int c = 0; c < 8; c++) st_plane<STREAM>(plane(ub, S, c), lane, 0.0f);
+            for (int c = 0; c < 8; c++) st_plane<STREAM>(up, c, lane4, 0.0f);
 #pragma unroll
-            for (int c = 12; c < 20; c++) st_plane<STREAM>(plane(ub, S, c), lane, 0.0f);
+            for (int c = 12; c < 20; c++) st_plane<STREAM>(up, c, lane4, 0.0f);
         } else {
             live_after = cur.life > 0.0f;   // untouched slots keep their liveness when no update pass ran
         }
@@ -960,14 +973,14 @@ ILM_DEV bool process_unit(CStepLaunch* ap, gfloat* ub, int chunk, int i, unsigne
                 render_data(fx, fy, pos, vel, attr, d.System, d.Update, a.ramp, a.ramp_w, a.ramp_h, rc, rd);
             }
         }
-        st_plane<STREAM>(plane(ub, S, 0), lane, pos.x); st_plane<STREAM>(plane(ub, S, 1), lane, pos.y); st_plane<STREAM>(plane(ub, S, 2), lane, pos.z); st_plane<STREAM>(plane(ub, S, 3), lane, pos.w);
-        st_plane<STREAM>(plane(ub, S, 4), lane, vel.x); st_plane<STREAM>(plane(ub, S, 5), lane, vel.y); st_plane<STREAM>(plane(ub, S, 6), lane, vel.z); st_plane<STREAM>(plane(ub, S, 7), lane, vel.w);
+        st_plane<STREAM>(up, 0, lane4, pos.x); st_plane<STREAM>(up, 1, lane4, pos.y); st_plane<STREAM>(up, 2, lane4, pos.z); st_plane<STREAM>(up, 3, lane4, pos.w);
+        st_plane<STREAM>(up, 4, lane4, vel.x); st_plane<STREAM>(up, 5, lane4, vel.y); st_plane<STREAM>(up, 6, lane4, vel.z); st_plane<STREAM>(up, 7, lane4, vel.w);
         if (spawned) {
-            st_plane<STREAM>(plane(ub, S, 8), lane, attr.x); st_plane<STREAM>(plane(ub, S, 9), lane, attr.y); st_plane<STREAM>(plane(ub, S, 10), lane, attr.z); st_plane<STREAM>(plane(ub, S, 11), lane, attr.w);
+            st_plane<STREAM>(up, 8, lane4, attr.x); st_plane<STREAM>(up, 9, lane4, attr.y); st_plane<STREAM>(up, 10, lane4, attr.z); st_plane<STREAM>(up, 11, lane4, attr.w);
         }
         if (need_attr) {
-            st_plane<STREAM>(plane(ub, S, 12), lane, rc.x); st_plane<STREAM>(plane(ub, S, 13), lane, rc.y); st_plane<STREAM>(plane(ub, S, 14), lane, rc.z); st_plane<STREAM>(plane(ub, S, 15), lane, rc.w);
-            st_plane<STREAM>(plane(ub, S, 16), lane, rd.x); st_plane<STREAM>(plane(ub, S, 17), lane, rd.y); st_plane<STREAM>(plane(ub, S, 18), lane, rd.z); st_plane<STREAM>(plane(ub, S, 19), lane, rd.w);
+            st_plane<STREAM>(up, 12, lane4, rc.x); st_plane<STREAM>(up, 13, lane4, rc.y); st_plane<STREAM>(up, 14, lane4, rc.z); st_plane<STREAM>(up, 15, lane4, rc.w);
+            st_plane<STREAM>(up, 16, lane4, rd.x); st_plane<STREAM>(up, 17, lane4, rd.y); st_plane<STREAM>(up, 18, lane4, rd.z); st_plane<STREAM>(up, 19, lane4, rd.w);
         }
         live_after = pos.w > 0.0f;
     }
@@ -1009,13 +1022,17 @@ __global__ __launch_bounds__(kStepThreads, MINW) void step_kernel(const StepLaun
         for (int k = 0; k < a.partial_count; k++)
             untouched = untouched || ((a.partial_chunk[k] == chunk) && (seg >= a.partial_units[k]));
         if (!untouched) {
-        gfloat* ub = (gfloat*)a.chunk_bases[chunk] + seg * 64;     // first slot of the first unit, plane 0 (uniform)
+        const float* chunk_base = a.chunk_bases[chunk];
+        const unsigned lane4 = lane * 4u;
+        UnitPlanes up[K];
+#pragma unroll
+        for (int j = 0; j < K; j++) up[j] = unit_planes(chunk_base, a.stride, (seg + j) * 64);
         // K > 1 issues the state loads of all K units before any arithmetic (K x 12 loads in flight per wave).  Measured
         // on cfg2 ("experiments"): K = 1 26.1 us, K = 2 30.5 us, K = 4 36.5 us per step -- the extra
         // registers cost more occupancy than the memory-level parallelism returns, so K = 1 ships.
         SlotIn q[K];
 #pragma unroll
-        for (int j = 0; j < K; j++) q[j] = load_slot<true, STREAM>(ub + j * 64, a.stride, lane);
+        for (int j = 0; j < K; j++) q[j] = load_slot<true, STREAM>(up[j], lane4);
 #pragma nounroll
         for (int j = 0; j < K; j++) {
             const SlotIn cur = q[0];
@@ -1029,7 +1046,7 @@ __global__ __launch_bounds__(kStepThreads, MINW) void step_kernel(const StepLaun
                 const int row = (a.derived.cs_shift >= 0) ? (first >> a.derived.cs_shift) : (first / a.chunk_size);
                 noise = noise_prepare(((const StepLaunch*)ap)->derived.noise, ((const StepLaunch*)ap)->desc, first - row * a.chunk_size, row);
             }
-            const bool live_after = process_unit<FMT, DF, SPAWN, EXT, STREAM>(ap, ub + j * 64, chunk, (seg + j) * 64 + (int)lane, lane, seg + j, cur, noise);
+            const bool live_after = process_unit<FMT, DF, SPAWN, EXT, STREAM>(ap, up[j], chunk, (seg + j) * 64 + (int)lane, lane, seg + j, cur, noise);
             n_live += (uint32_t)__popcll(__ballot(live_after));
         }
         }
