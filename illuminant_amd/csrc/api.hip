@@ -63,8 +63,6 @@ struct Ctx {
     hipEvent_t t0 = nullptr, t1 = nullptr;
     // Liveness counts leave through their own stream, so the device-to-host copy (a separate blit kernel on ROCm)
     // never sits between two step launches on the compute stream.
-    hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_step = nullptr;
     // device staging for AoS <-> SoA conversion
     void* staging = nullptr; size_t staging_bytes = 0;
     // pinned ring for small asynchronous parameter uploads (light arrays)
@@ -126,10 +124,12 @@ struct System {
     // Raised by uploads and spawn ranges; a chunk whose device pointer was handed out is treated as fully used.
     std::vector<int32_t> used;
     float** d_table = nullptr; int table_cap = 0; bool table_dirty = true;
-    // Three counter regions of counts_cap * kCountStride words: 0 / 1 alternate between counting steps (the step kernel
+    // Three counter regions of counts_cap * kCountStride 64-bit words: 0 / 1 alternate between counting steps (the step kernel
     // accumulates into one and zeroes the other for next time: no memset launch), 2 belongs to ilm_system_live_counts.
-    uint32_t* d_counts = nullptr; int counts_cap = 0; int count_parity = 0;
-    uint32_t* counts_region(int r) const { return d_counts + (size_t)r * (size_t)counts_cap * kCountStride; }
+    // Regions 0 and 1 hold kCountLines lines per chunk (internal.hpp), region 2 one.
+    unsigned long long* d_counts = nullptr; int counts_cap = 0; int count_parity = 0;
+    unsigned long long* counts_region(int r) const { return d_counts + (size_t)r * (size_t)counts_cap * kCountLines * kCountStride; }
+    static size_t counts_bytes(int cap) { return sizeof(unsigned long long) * (size_t)cap * kCountStride * (2 * kCountLines + 1); }
     IlmHandle sdf_handle = 0;   // bound distance field: resolved through the handle table at every use (it may have been destroyed)
     float4* ramp = nullptr; int ramp_w = 0, ramp_h = 0;
     uint32_t* d_slots = nullptr; int slots_cap = 0; uint32_t* d_slot_count = nullptr;
@@ -138,8 +138,12 @@ struct System {
     float4* bitmap = nullptr; int bitmap_w = 0, bitmap_h = 0;     // Appearance.Texture for the textured rasterise techniques
     // the PatternSpawner's texture per spawn record slot, mip levels back to back (SpecialSpawners.cs:19-22)
     float4* spawn_pattern[ILM_MAX_SPAWNS] = {}; int pattern_w[ILM_MAX_SPAWNS] = {}, pattern_h[ILM_MAX_SPAWNS] = {}, pattern_levels[ILM_MAX_SPAWNS] = {};
-    // asynchronous readback of the fused live counts
-    uint32_t* h_counts = nullptr; int h_counts_cap = 0; hipEvent_t counts_ev = nullptr; int counts_n = 0; bool counts_pending = false;
+    // The fused live counts arrive in page-locked host memory, written by the step kernel itself (internal.hpp, StepLaunch::host_counts):
+    // one word per chunk, sequence number << 32 | count.  A counting step over chunks [counts_first, counts_first + counts_span) is
+    // complete when each of their words carries its sequence number; chunks outside the range count zero.
+    unsigned long long* h_counts = nullptr; unsigned long long* h_counts_dev = nullptr; int h_counts_cap = 0;
+    uint32_t count_seq = 0; int counts_first = 0, counts_span = 0;
+    int counts_n = 0; bool counts_pending = false;
     bool counts_valid = false;   // h_counts holds (or is about to receive) the counts of the last counting step
 };
 
@@ -297,9 +301,17 @@ int32_t refresh_table(System* s) {
     if (n > s->counts_cap) {
         if (s->d_counts) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(s->d_counts)); s->d_counts = nullptr; }
         int cap = n < 64 ? 64 : n * 2;
-        if (s->counts_ev) HIP_TRY(hipEventSynchronize(s->counts_ev));   // an outstanding copy reads the old buffer
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_counts), sizeof(uint32_t) * 3 * (size_t)cap * kCountStride));
-        HIP_TRY(hipMemsetAsync(s->d_counts, 0, sizeof(uint32_t) * 3 * (size_t)cap * kCountStride, c->stream));
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_counts), System::counts_bytes(cap)));
+        HIP_TRY(hipMemsetAsync(s->d_counts, 0, System::counts_bytes(cap), c->stream));
+        // (the stream is idle here: no kernel can still publish into the old host table)
+        unsigned long long* old = s->h_counts;
+        unsigned long long* fresh = nullptr;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&fresh), sizeof(unsigned long long) * (size_t)cap, hipHostMallocMapped));
+        for (int i = 0; i < cap; i++) fresh[i] = (i < s->h_counts_cap && old) ? old[i] : 0ull;
+        if (old) HIP_TRY(hipHostFree(old));
+        s->h_counts = fresh;
+        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&s->h_counts_dev), fresh, 0));
+        s->h_counts_cap = cap;
         s->counts_cap = cap;
     }
     if (s->table_dirty && n > 0) {
@@ -521,6 +533,28 @@ static void fill_cull_bound(FieldObstruction& r) {
     r.cull_radius = (float)((radius * (1.0 + 1e-4) + 0.05) / shrink * (1.0 + 1e-6));
 }
 
+// (unsigned)fabsf(x) as the device converts (v_cvt_u32_f32 saturates: NaN and negatives give 0, 2^32 and above give 0xFFFFFFFF)
+static uint32_t device_float_to_uint(float x) {
+    if (!(x > 0.0f)) return 0u;
+    if (x >= 4294967296.0f) return 0xFFFFFFFFu;
+    return (uint32_t)x;
+}
+// The uniform decisions of tForScaledBezier / evaluateBezier1 / evaluateBezier4 (Bezier.fxh:21-177), taken here with the comparisons
+// the shader makes on RangeAndCount; layout in bezier.hpp.
+static uint32_t bezier_code(const IlmFloat4& rc) {
+    const float count = rc.z;
+    uint32_t cls = 3u;
+    if (count <= 1.5f) cls = 0u;
+    else if (count <= 2.5f) cls = 1u;
+    else if (count <= 3.5f) cls = 2u;
+    const uint32_t mode = device_float_to_uint(std::fabs(rc.w));
+    const uint32_t range = (mode > 511u) ? 2u : ((mode > 255u) ? 1u : 0u);
+    const uint32_t neg = (rc.y < 0.0f) ? 1u : 0u;
+    const uint32_t m = mode % 256u;
+    const uint32_t shaping = (m == 1u) ? 1u : ((m == 2u) ? 2u : 0u);
+    return cls | (range << 2) | (neg << 4) | (shaping << 5);
+}
+
 int32_t run_step(System* s, const IlmStepDesc* d) {
     int first = 0, count = 0;
     int32_t rc = validate_step(s, d, &first, &count);
@@ -537,9 +571,6 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
     }
     const bool counting = (d->Flags & ILM_STEP_COUNT_LIVE) != 0;
     const int region = s->count_parity;
-    if (counting && s->counts_ev)
-        // this launch zeroes the region the previous counting step filled: its copy-out must have finished
-        HIP_TRY(hipStreamWaitEvent(c->stream, s->counts_ev, 0));
 
     StepLaunch a;
     memcpy(&a.desc, d, sizeof(IlmStepDesc));
@@ -576,7 +607,10 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
     a.sdf = make_sdf_view(from_handle<Sdf>(s->sdf_handle, kMagicSdf), &d->DistanceField);
     a.live_counts = counting ? s->counts_region(region) : nullptr;
     a.zero_counts = counting ? s->counts_region(region ^ 1) : nullptr;
-    a.zero_n = counting ? (int32_t)s->counts_cap : 0;   // every entry, so chunk-table growth after a shrink never meets stale counts
+    a.zero_n = counting ? (int32_t)s->counts_cap * kCountLines : 0;   // every line, so chunk-table growth after a shrink never meets stale counts
+    if (counting && ++s->count_seq == 0u) s->count_seq = 1u;      // 0 is the table's initial content
+    a.host_counts = counting ? s->h_counts_dev : nullptr;
+    a.count_seq = s->count_seq;
     {   // StepDerived: same float operations, same order, as the device code they replace
         StepDerived& dv = a.derived;
         std::memset(&dv, 0, sizeof(dv));
@@ -587,6 +621,10 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
         dv.cs_shift = -1;
         for (int b = 0; b < 31; b++)
             if ((1 << b) == e->chunk_size) dv.cs_shift = b;
+        dv.bezier_codes = bezier_code(d->Update.ColorFromLife.RangeAndCount) | (bezier_code(d->Update.ColorFromVelocity.RangeAndCount) << 8) |
+                          (bezier_code(d->Update.SizeFromLife.RangeAndCount) << 16) | (bezier_code(d->Update.SizeFromVelocity.RangeAndCount) << 24);
+        dv.update_bits = ((d->Update.LifeRampSettings.x != 0.0f) ? 1u : 0u) | ((d->System.AnimationRateAndRotationAndZToY.z == 0.0f) ? 2u : 0u) |
+                         ((d->Update.LifeRampSettings.x < 0.0f) ? 4u : 0u);
         dv.noise.op = -1;
         for (int o = 0; o < d->OpCount && dv.noise.op < 0; o++)
             if (d->Ops[o].Type == ILM_OP_NOISE) {
@@ -645,21 +683,9 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
     if (d->UpdateMode == ILM_UPDATE_ERASE)
         for (int ci = first; ci < first + count; ci++) s->used[(size_t)ci] = 0;   // position, velocity and render planes are zero again
     if (d->Flags & ILM_STEP_COUNT_LIVE) {
-        // queue the readback behind the kernel; ilm_system_poll_counts / ilm_system_step_counts pick it up
-        const int n = (int)s->chunks.size();
-        if (n > s->h_counts_cap) {
-            if (s->h_counts) HIP_TRY(hipHostFree(s->h_counts));
-            s->h_counts = nullptr;
-            int cap = n < 64 ? 64 : n * 2;
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&s->h_counts), sizeof(uint32_t) * (size_t)cap * kCountStride, hipHostMallocDefault));
-            s->h_counts_cap = cap;
-        }
-        if (!s->counts_ev) HIP_TRY(hipEventCreateWithFlags(&s->counts_ev, hipEventDisableTiming));
-        HIP_TRY(hipEventRecord(c->ev_step, c->stream));
-        HIP_TRY(hipStreamWaitEvent(c->copy_stream, c->ev_step, 0));
-        HIP_TRY(hipMemcpyAsync(s->h_counts, s->counts_region(region), sizeof(uint32_t) * (size_t)n * kCountStride, hipMemcpyDeviceToHost, c->copy_stream));
-        HIP_TRY(hipEventRecord(s->counts_ev, c->copy_stream));
-        s->counts_n = n;
+        // the kernel publishes every chunk of its range itself; ilm_system_poll_counts / ilm_system_step_counts read the host table
+        s->counts_n = (int)s->chunks.size();
+        s->counts_first = first; s->counts_span = count;
         s->counts_pending = true;
         s->counts_valid = true;
         s->count_parity ^= 1;
@@ -667,7 +693,8 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
     return ILM_OK;
 }
 
-int32_t copy_counts(System* s, const uint32_t* d_region, uint32_t* out, int32_t capacity, int32_t saturate16) {
+int32_t copy_counts(System* s, const unsigned long long* d_region64, uint32_t* out, int32_t capacity, int32_t saturate16) {
+    const uint32_t* d_region = reinterpret_cast<const uint32_t*>(d_region64);
     Ctx* c = s->engine->ctx;
     const int n = (int)s->chunks.size();
     if (capacity < n)
@@ -751,8 +778,6 @@ int32_t ilm_ctx_create(int32_t device_id, IlmHandle* out_ctx) {
     c->device = device_id;
     const IlmHandle h = to_handle(c);
     HIP_TRY_OR_DESTROY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), ilm_ctx_destroy(h));
-    HIP_TRY_OR_DESTROY(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking), ilm_ctx_destroy(h));
-    HIP_TRY_OR_DESTROY(hipEventCreateWithFlags(&c->ev_step, hipEventDisableTiming), ilm_ctx_destroy(h));
     HIP_TRY_OR_DESTROY(hipEventCreate(&c->t0), ilm_ctx_destroy(h));
     HIP_TRY_OR_DESTROY(hipEventCreate(&c->t1), ilm_ctx_destroy(h));
     HIP_TRY_OR_DESTROY(hipMalloc(reinterpret_cast<void**>(&c->d_stats), 3 * sizeof(unsigned long long)), ilm_ctx_destroy(h));
@@ -790,8 +815,6 @@ int32_t ilm_ctx_destroy(IlmHandle h) {
     if (c->d_rb_elems) (void)hipFree(c->d_rb_elems);
     if (c->h_rb) (void)hipHostFree(c->h_rb);
     // (a context whose creation failed half-way has null members here)
-    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
-    if (c->ev_step) (void)hipEventDestroy(c->ev_step);
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -911,7 +934,6 @@ int32_t ilm_system_destroy(IlmHandle h) {
         if (s->spawn_pattern[k]) (void)hipFree(s->spawn_pattern[k]);
     if (s->bitmap) (void)hipFree(s->bitmap);
     if (s->h_counts) (void)hipHostFree(s->h_counts);
-    if (s->counts_ev) (void)hipEventDestroy(s->counts_ev);
     retire_handle(s);
     delete s;
     return ILM_OK;
@@ -1186,6 +1208,15 @@ int32_t ilm_erase(IlmHandle h, int32_t chunk_index) {
     return run_step(s, &d);
 }
 
+// Count of chunk i from the last counting step: chunks outside the step's range were not counted (zero); *ready goes false when the
+// chunk's word does not carry the step's sequence number yet.
+static uint32_t published_count(const System* s, int i, bool* ready) {
+    if (i < s->counts_first || i >= s->counts_first + s->counts_span) return 0u;
+    const unsigned long long w = __atomic_load_n(&s->h_counts[i], __ATOMIC_ACQUIRE);
+    if ((uint32_t)(w >> 32) != s->count_seq) { if (ready) *ready = false; return 0u; }
+    return (uint32_t)(w & 0xFFFFFFFFull);
+}
+
 int32_t ilm_system_live_counts(IlmHandle h, uint32_t* out_counts, int32_t capacity, int32_t saturate16) {
     System* s = from_handle<System>(h, kMagicSystem);
     if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
@@ -1197,7 +1228,7 @@ int32_t ilm_system_live_counts(IlmHandle h, uint32_t* out_counts, int32_t capaci
     const int n = (int)s->chunks.size();
     if (n > 0) {
         HIP_TRY(hipMemsetAsync(s->counts_region(2), 0, sizeof(uint32_t) * (size_t)n * kCountStride, c->stream));
-        HIP_TRY(launch_count_live(s->d_table, s->engine->stride, s->engine->slots, n, s->counts_region(2), c->stream));
+        HIP_TRY(launch_count_live(s->d_table, s->engine->stride, s->engine->slots, n, reinterpret_cast<uint32_t*>(s->counts_region(2)), c->stream));
     }
     return copy_counts(s, s->counts_region(2), out_counts, capacity, saturate16);
 }
@@ -1211,9 +1242,12 @@ int32_t ilm_system_step_counts(IlmHandle h, uint32_t* out_counts, int32_t capaci
         return fail(ILM_ERR_STATE, "no step with ILM_STEP_COUNT_LIVE has run");
     if (capacity < s->counts_n) return fail(ILM_ERR_OUT_OF_RANGE, "capacity %d < %d", capacity, s->counts_n);
     if (s->counts_n > 0)
-        HIP_TRY(hipEventSynchronize(s->counts_ev));  // the copy-out queued behind the last counting step
+        HIP_TRY(hipStreamSynchronize(s->engine->ctx->stream));   // the counting step has run: every chunk of its range is published
+    bool ready = true;
+    for (int i = 0; i < s->counts_n; i++) (void)published_count(s, i, &ready);
+    if (!ready) return fail(ILM_ERR_STATE, "the counting step finished without publishing every chunk's count");
     for (int i = 0; i < s->counts_n; i++) {
-        const uint32_t v = s->h_counts[(size_t)i * kCountStride];
+        const uint32_t v = published_count(s, i, nullptr);
         out_counts[i] = (saturate16 && v > ref::kLiveCountSaturation) ? ref::kLiveCountSaturation : v;
     }
     return ILM_OK;
@@ -1225,13 +1259,12 @@ int32_t ilm_system_poll_counts(IlmHandle h, uint32_t* out_counts, int32_t capaci
     if (!out_counts || !out_ready) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
     *out_ready = 0;
     if (!s->counts_pending) return fail(ILM_ERR_STATE, "no step with ILM_STEP_COUNT_LIVE is outstanding");
-    HIP_TRY(hipSetDevice(s->engine->ctx->device));
-    hipError_t q = (s->counts_n > 0) ? hipEventQuery(s->counts_ev) : hipSuccess;
-    if (q == hipErrorNotReady) { (void)hipGetLastError(); return ILM_OK; }
-    if (q != hipSuccess) return fail((int32_t)q, "hipEventQuery failed: %s", hipGetErrorString(q));
     if (capacity < s->counts_n) return fail(ILM_ERR_OUT_OF_RANGE, "capacity %d < %d", capacity, s->counts_n);
+    bool ready = true;
+    for (int i = 0; i < s->counts_n && ready; i++) (void)published_count(s, i, &ready);
+    if (!ready) return ILM_OK;      // like the reference's deferred readback: never stall
     for (int i = 0; i < s->counts_n; i++) {
-        uint32_t v = s->h_counts[i * kCountStride];
+        const uint32_t v = published_count(s, i, nullptr);
         out_counts[i] = (saturate16 && v > ref::kLiveCountSaturation) ? ref::kLiveCountSaturation : v;
     }
     s->counts_pending = false;
@@ -1360,6 +1393,8 @@ int32_t ilm_debug_divide_by_constants(IlmHandle hctx, float* out_divisors, uint6
     *out_count = 2;
     return ILM_OK;
 }
+
+int32_t ilm_debug_step_interpreter(int32_t interpreter) { return (int32_t)set_step_interpreter(interpreter); }
 
 int32_t ilm_debug_divide(IlmHandle hctx, const float* numerators, const float* denominators, int32_t count, float* out_fast, float* out_ieee) {
     Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);

@@ -37,6 +37,9 @@ struct StepDerived {
     float inv_rw, inv_rh;        // RandomnessTexel = 1 / (807, 653)                         (RandomCommon.fxh:12-15)
     int32_t cs_shift;            // log2(chunk_size) when it is a power of two, else -1
     int32_t noise_may_revive;    // some Noise op can change the life of a dead slot (see api.hip); 0 => dead slots skip the transforms
+    uint32_t bezier_codes;       // the uniform decisions of the update pass's four curves (bezier.hpp): byte 0 ColorFromLife, 1 ColorFromVelocity,
+                                 // 2 SizeFromLife, 3 SizeFromVelocity
+    uint32_t update_bits;        // bit 0: LifeRampSettings.x != 0 (life ramp on)   bit 1: getVelocityRotation() == 0   bit 2: LifeRampSettings.x < 0
     // Noise.fx:49-52 samples the randomness table at uv = ((xy * RandomnessTexel) + offset) * RandomnessTexel: the slot coordinate is
     // scaled by the texel size TWICE, so the texel column only steps once per 807 slots along x (the row once per 653 along y) and
     // a whole wave of 64 consecutive slots almost always reads ONE texel in each of the four lookups -- positionDelta and
@@ -90,9 +93,19 @@ struct StepLaunch {
     // chunks whose tail has never been written (api.hip, System::used): units >= partial_units[i] of chunk partial_chunk[i]
     // hold only zeros and are skipped; chunks not listed are processed whole
     int32_t partial_count; int32_t partial_chunk[kMaxPartialChunks]; int32_t partial_units[kMaxPartialChunks];
-    uint32_t* live_counts;       // per chunk at index chunk * kCountStride; all zero on entry when ILM_STEP_COUNT_LIVE
-    uint32_t* zero_counts;       // the other counter region: zeroed by this launch for the next counting step
-    int32_t zero_n;
+    // ILM_STEP_COUNT_LIVE: one 64-bit counter per chunk at index chunk * kCountStride (its own 128-byte line), all zero on entry:
+    // low word = live particles, high word = blocks of the chunk that have reported.  The block that completes a chunk publishes
+    // {count_seq, count} with ONE system-scope store into page-locked host memory, where ilm_system_poll_counts reads it: no copy,
+    // no event, no second stream (a record / wait pair on the stepping stream cost two ~7 us bubbles per counting step).
+    // A chunk owns kCountLines lines: line 0 collects the chunk, lines 1.. are buckets that the chunk's blocks are dealt over
+    // (block b of the chunk -> bucket b mod count_buckets), so that the ~4000 blocks of a 1024^2 chunk, which are resident at the
+    // same time, do not queue on one address; the block that completes a bucket carries its sum to line 0.
+    unsigned long long* live_counts;
+    unsigned long long* zero_counts;     // the other counter region: zeroed by this launch for the next counting step
+    unsigned long long* host_counts;     // device address of the page-locked table, one word per chunk: count_seq << 32 | count
+    uint32_t count_seq;
+    int32_t zero_n;                      // lines of the other region (capacity in chunks x kCountLines)
+    int32_t count_buckets;               // power of two <= kCountLines - 1 that divides the blocks per chunk
     // Work is cut into units of one wave (64 consecutive slots); unit = chunk_rel * units_per_chunk + segment.
     // Filled by launch_step.
     int32_t units_per_chunk;     // stride / 64
@@ -104,8 +117,10 @@ struct StepLaunch {
 static_assert(sizeof(StepLaunch) <= 4096, "StepLaunch travels in the kernarg segment (4 KB)");
 
 // per-chunk live counters are kCountStride uint32 apart (one 128-byte line each)
-constexpr int kCountStride = 32;
+constexpr int kCountStride = 16;     // in 64-bit words
+constexpr int kCountLines = 17;      // per chunk in the step kernels' counter regions: the chunk's line + 16 bucket lines
 hipError_t launch_step(StepLaunch& a, hipStream_t stream);
+int set_step_interpreter(int on);     // ilm_debug_step_interpreter: returns the previous setting
 
 // AoS float4 (device staging) <-> one SoA plane group (4 consecutive components)
 hipError_t launch_aos_to_soa(const float4* src, float* plane0, int64_t stride, int32_t first_slot, int32_t count, hipStream_t stream);

@@ -8,7 +8,10 @@
 // access is one dword per lane on an SGPR plane base: 256 contiguous bytes per instruction.
 //
 // HBM-bound integer/float streaming work: no MFMA, no LDS (no cross-slot reuse).
+#include <cmath>
+#include <cstddef>
 #include <cstdlib>
+#include <cstring>
 
 #include "internal.hpp"
 #include "distance_functions.hpp"
@@ -173,7 +176,7 @@ ILM_DEV void noise_deltas(float4 p1, float4 p2, float4 v1, float4 v2, const IlmN
 
 // PS_Noise, Noise.fx:28-72 (no life check: dead slots go through the math, :40)
 ILM_DEV void apply_noise(float4& pos, float4& vel, float x, float y, const float4* __restrict__ rnd, int rw, int rh,
-                         const IlmParticleSystemUniforms& sys, const IlmNoiseParams& p, const StepDerived& sd, const StepDerived::Op& dv,
+                         const IlmParticleSystemUniforms& sys, const IlmNoiseParams& p, float inv_rw, float inv_rh, const StepDerived::Op& dv,
                          const NoiseDeltas& uniform) {
     if (!category_ok(vel.w, p.Area.CategoryFilter))
         return;
@@ -185,7 +188,7 @@ ILM_DEV void apply_noise(float4& pos, float4& vel, float x, float y, const float
         position_delta = uniform.position;
         velocity_delta = uniform.velocity;
     } else {
-        const float rate_x = sd.inv_rw, rate_y = sd.inv_rh;  // rate = RandomnessTexel (Noise.fx:49-52)
+        const float rate_x = inv_rw, rate_y = inv_rh;  // rate = RandomnessTexel (Noise.fx:49-52)
         const float4 p1 = random_custom(rnd, rw, rh, rate_x, rate_y, x, y, p.RandomnessOffset[0], p.RandomnessOffset[1], rate_x, rate_y);
         const float4 p2 = random_custom(rnd, rw, rh, rate_x, rate_y, x, y, p.NextRandomnessOffset[0], p.NextRandomnessOffset[1], rate_x, rate_y);
         const float4 v1 = random_custom(rnd, rw, rh, rate_x, rate_y, x + 2.0f, y + 1.0f, p.RandomnessOffset[0], p.RandomnessOffset[1], rate_x, rate_y);
@@ -623,9 +626,10 @@ ILM_DEV f3 friction_and_maximum(f3 velocity, const IlmParticleSystemUniforms& sy
     return velocity * (inv_l * l);
 }
 
-// computeRenderData, UpdateCommon.fxh:96-117
+// computeRenderData, UpdateCommon.fxh:96-117.  `codes` / `bits`: the uniform decisions of the four curves, the life ramp and the
+// velocity rotation, taken on the host (StepDerived::bezier_codes / update_bits).
 ILM_DEV void render_data(float vx, float vy, float4 position, float4 velocity, float4 attributes,
-                         const IlmParticleSystemUniforms& sys, const IlmUpdateParams& p,
+                         const IlmParticleSystemUniforms& sys, const IlmUpdateParams& p, uint32_t codes, uint32_t bits,
                          const float4* __restrict__ ramp, int ramp_w, int ramp_h,
                          float4& render_color, float4& rdata) {
     if (position.w <= 0.0f) {
@@ -635,10 +639,10 @@ ILM_DEV void render_data(float vx, float vy, float4 position, float4 velocity, f
     const float index = vx + (vy * ref::kRenderDataIndexRowPitch);  // reference quirk: 256 regardless of ChunkSize (:107)
     const float velocity_length = fmaxf(len3_fast(xyz(velocity)), 0.0001f);
 
-    float4 color = mul4(bezier4(p.ColorFromLife, position.w), bezier4(p.ColorFromVelocity, velocity_length));
-    if (p.LifeRampSettings.x != 0.0f) {
+    float4 color = mul4(bezier4_coded(p.ColorFromLife, position.w, codes & 0xFFu), bezier4_coded(p.ColorFromVelocity, velocity_length, (codes >> 8) & 0xFFu));
+    if (bits & 1u) {    // p.LifeRampSettings.x != 0
         float u = (position.w - p.LifeRampSettings.y) / p.LifeRampSettings.z;
-        if (p.LifeRampSettings.x < 0.0f)
+        if (bits & 4u)  // p.LifeRampSettings.x < 0
             u = 1.0f - sat(u);
         const float v = index / p.LifeRampSettings.w;
         float4 texel = mk4(1.0f, 1.0f, 1.0f, 1.0f);
@@ -659,14 +663,14 @@ ILM_DEV void render_data(float vx, float vy, float4 position, float4 velocity, f
     float rotation = 0.0f;
     // the angle is multiplied by getVelocityRotation(): skipping atan2 when that is 0 is exact for every finite or infinite velocity
     // (the angle is finite); a NaN velocity (normalize(0) upstream) makes the angle NaN and NaN * 0 stays NaN
-    if (sys.AnimationRateAndRotationAndZToY.z == 0.0f) {
+    if (bits & 2u) {    // sys.AnimationRateAndRotationAndZToY.z == 0
         rotation = ((velocity.x != velocity.x) || (velocity.y != velocity.y)) ? __builtin_nanf("") : 0.0f;
     } else if (!((fabsf(velocity.x) < 0.01f) && (fabsf(velocity.y) < 0.01f))) {
         rotation = atan2f(velocity.y, velocity.x);
         if (rotation < 0.0f)
             rotation += 2.0f * kPi;
     }
-    rdata.x = bezier1(p.SizeFromLife, position.w) * bezier1(p.SizeFromVelocity, velocity_length);
+    rdata.x = bezier1_coded(p.SizeFromLife, position.w, (codes >> 16) & 0xFFu) * bezier1_coded(p.SizeFromVelocity, velocity_length, codes >> 24);
     rdata.y = (rotation * sys.AnimationRateAndRotationAndZToY.z) +
               ((position.w * p.RotationFromLifeAndIndex[0]) + (index * p.RotationFromLifeAndIndex[1]));
     rdata.z = velocity_length;
@@ -951,7 +955,7 @@ ILM_DEV bool process_unit(CStepLaunch* ap, const UnitPlanes& up, int chunk, int 
             if (op.Type == ILM_OP_GRAVITY)
                 apply_gravity(pos, vel, d.System, op.u.Gravity, a.derived.op[o]);
             else if (op.Type == ILM_OP_NOISE)
-                apply_noise(pos, vel, fx, fy, a.rnd, a.rw, a.rh, d.System, op.u.Noise, a.derived, a.derived.op[o],
+                apply_noise(pos, vel, fx, fy, a.rnd, a.rw, a.rh, d.System, op.u.Noise, a.derived.inv_rw, a.derived.inv_rh, a.derived.op[o],
                             (o == a.derived.noise.op) ? noise : NoiseDeltas{ false, zero, zero });
             else if (op.Type == ILM_OP_FMA)
                 apply_fma(pos, vel, d.System, op.u.FMA, a.derived.op[o]);
@@ -970,7 +974,7 @@ ILM_DEV bool process_unit(CStepLaunch* ap, const UnitPlanes& up, int chunk, int 
                     update_with_distance_field<FMT>(pos, vel, fx, fy, d.System, a.derived.dt_s, d.DistanceField, a.sdf);
                 else
                     update_positions(pos, vel, d.System, a.derived.dt_s);
-                render_data(fx, fy, pos, vel, attr, d.System, d.Update, a.ramp, a.ramp_w, a.ramp_h, rc, rd);
+                render_data(fx, fy, pos, vel, attr, d.System, d.Update, a.derived.bezier_codes, a.derived.update_bits, a.ramp, a.ramp_w, a.ramp_h, rc, rd);
             }
         }
         st_plane<STREAM>(up, 0, lane4, pos.x); st_plane<STREAM>(up, 1, lane4, pos.y); st_plane<STREAM>(up, 2, lane4, pos.z); st_plane<STREAM>(up, 3, lane4, pos.w);
@@ -986,6 +990,37 @@ ILM_DEV bool process_unit(CStepLaunch* ap, const UnitPlanes& up, int chunk, int 
     }
 
     return live_after;
+}
+
+// CountLiveParticles.fx for a block of the step kernels: LDS sum over the block's waves, ONE 64-bit atomic per block on a bucket
+// counter of its chunk (live particles in the low word, a ticket in the high word); the block that draws a bucket's last ticket
+// carries the bucket's sum to the chunk's counter the same way, and the one that completes the chunk stores the total, tagged with
+// the step's sequence number, straight into the host's table.  (Per-wave atomics on one address serialise at ~11 ns each: 1024 of
+// them per chunk made the step 7x slower; one per block on ONE address per chunk still queued 4096 deep on 1024^2 chunks.)  The
+// units of a block always belong to one chunk.
+ILM_DEV void publish_block_count(uint32_t* wave_live, uint32_t n_live, unsigned lane, int wave, bool block_in_range, int chunk, int block_in_chunk,
+                                 int blocks_per_chunk, int buckets, unsigned long long* live_counts, unsigned long long* zero_counts, int zero_n,
+                                 unsigned long long* host_counts, uint32_t seq) {
+    if (blockIdx.x == 0)
+        for (int i = (int)threadIdx.x; i < zero_n; i += kStepThreads) zero_counts[i * kCountStride] = 0ull;
+    if (lane == 0) wave_live[wave] = n_live;
+    __syncthreads();
+    if (threadIdx.x == 0 && block_in_range) {
+        uint32_t block_live = 0;
+#pragma unroll
+        for (int w = 0; w < kStepThreads / 64; w++) block_live += wave_live[w];
+        unsigned long long* lines = live_counts + (size_t)chunk * (kCountLines * kCountStride);
+        const int bucket = block_in_chunk & (buckets - 1);
+        const unsigned long long old = atomicAdd(&lines[(1 + bucket) * kCountStride], (1ull << 32) | (unsigned long long)block_live);
+        if ((int)(old >> 32) + 1 == blocks_per_chunk / buckets) {
+            const unsigned long long sum = (old & 0xFFFFFFFFull) + (unsigned long long)block_live;
+            const unsigned long long old2 = atomicAdd(&lines[0], (1ull << 32) | sum);
+            if ((int)(old2 >> 32) + 1 == buckets) {
+                const unsigned long long total = (old2 & 0xFFFFFFFFull) + sum;
+                __hip_atomic_store(&host_counts[chunk], ((unsigned long long)seq << 32) | (total & 0xFFFFFFFFull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
 // One wave = one unit of 64 consecutive slots; the hardware dispatcher balances the waves.  (A persistent,
@@ -1052,24 +1087,333 @@ __global__ __launch_bounds__(kStepThreads, MINW) void step_kernel(const StepLaun
         }
     }
     if (a.desc.Flags & ILM_STEP_COUNT_LIVE) {
-        // CountLiveParticles.fx: wave64 ballot + popcount, LDS sum over the block's waves, then ONE atomic per
-        // block on a per-chunk counter that sits on its own 128-byte line (per-wave atomics on one address
-        // serialise at ~11 ns each: 1024 of them per chunk made this step 7x slower).  The 4 units of a block
-        // of a block always belong to one chunk (see above).
-        if (blockIdx.x == 0)
-            for (int i = (int)threadIdx.x; i < a.zero_n; i += kStepThreads) a.zero_counts[i * kCountStride] = 0u;
-        if (lane == 0) wave_live[wave] = n_live;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t block_live = 0;
+        const int first_unit = a.unit_begin + v;
+        const int chunk_rel = (a.upc_shift >= 0) ? (first_unit >> a.upc_shift) : (first_unit / a.units_per_chunk);
+        constexpr int kUnitsPerBlock = (kStepThreads / 64) * K;
+        publish_block_count(wave_live, n_live, lane, wave, v < total, a.first_chunk + chunk_rel, (first_unit - chunk_rel * a.units_per_chunk) / kUnitsPerBlock,
+                            a.units_per_chunk / kUnitsPerBlock, a.count_buckets, a.live_counts, a.zero_counts, a.zero_n, a.host_counts, a.count_seq);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// the lean step kernel
+// ---------------------------------------------------------------------------------------------
+// step_kernel above interprets an arbitrary IlmStepDesc: per wave ~370 scalar-ALU instructions, ~70 scalar loads and ~60 branches next
+// to ~365 vector instructions.  The scalar pipe issues one instruction per cycle per CU against the four SIMDs' vector issue
+// (tools/ubench/salu: ~550 G/s against ~950 G/s), and every dependent scalar load the interpreter waits for is latency in the life of
+// a wave whose whole launch is only two to three wave generations long -- so on a cache-resident system (cfg2) the step's time
+// follows the scalar work, not the bytes.  step_lean_kernel runs the common shape of a step -- power-of-two chunk size >= 64,
+// UpdatePositions, Gravity / Noise (no area, wave-uniform deltas available) / FMA (no area) in any order, inline spawners, no life
+// ramp, no Noise that can revive a slot -- from a pre-digested descriptor (LeanStep, built by launch_step from the same StepLaunch):
+// every uniform decision arrives as an integer, the attractors as one 32-byte record each, the spawn ranges as unit ranges.  The
+// per-slot arithmetic is the interpreter's own (same functions or the same operations in the same order): ILM_STEP_LEAN=0 runs the
+// interpreter instead and tests/test_properties_gpu.py requires the two to agree bit for bit.
+struct LeanAttractor { float x, y, z, radius, strength, _p0, _p1, _p2; };
+constexpr int kLeanMaxAttractors = 8;
+struct LeanGravity {
+    int32_t count; uint32_t types;   // 2 bits per attractor: 0 physical (ars.z < 0.5), 1 linear, 2 squared (Gravity.fx:36-52)
+    float max_accel, _pad0;
+    float cat_lo, cat_hi, _pad1, _pad2;
+    LeanAttractor a[kLeanMaxAttractors];
+};
+union LeanOp {
+    LeanGravity gravity;
+    IlmNoiseParams noise;
+    IlmFMAParams fma;
+};
+struct LeanStep {
+    // decode
+    float* const* chunk_bases;
+    unsigned long long* live_counts; unsigned long long* zero_counts; unsigned long long* host_counts;
+    int64_t stride;
+    int32_t upc_shift, unit_rotate, total_padded, total_units;
+    int32_t first_chunk, cs_shift, zero_n; uint32_t flags;
+    uint32_t count_seq; int32_t count_buckets; int32_t _pad3[2];
+    int32_t partial_chunk[kMaxPartialChunks], partial_units[kMaxPartialChunks];     // unused entries: chunk -1
+    int32_t partial_count, op_count, spawn_count, _pad0;
+    int32_t op_type[ILM_MAX_OPS];
+    int32_t spawn_chunk[ILM_MAX_SPAWNS], spawn_unit_lo[ILM_MAX_SPAWNS], spawn_unit_hi[ILM_MAX_SPAWNS];   // segments of the target chunk a record touches
+    int32_t _pad1[2];
+    // update pass
+    float dt_s; uint32_t bezier_codes, update_bits; int32_t noise_op;
+    IlmParticleSystemUniforms sys;
+    IlmUpdateParams update;
+    // transforms
+    StepDerived::Op dop[ILM_MAX_OPS];
+    LeanOp op[ILM_MAX_OPS];
+    StepDerived::NoiseFast noise;
+    // spawners (inline kind only) -- or, in a launch without them, the 5 x 5 noise tables (kNoiseBigClasses)
+    const float4* rnd; int32_t rw, rh; float inv_rw, inv_rh; int32_t _pad2[2];
+    union {
+        IlmSpawnRecord spawns[ILM_MAX_SPAWNS];
+        IlmFloat4 noise_big[2 * kNoiseBigClasses * kNoiseBigClasses];
+    };
+};
+static_assert(sizeof(LeanStep) <= 4096, "LeanStep travels in the kernarg segment (4 KB)");
+
+// PS_Gravity with the attractor records and type codes of LeanGravity: the operations of apply_gravity, in its order
+ILM_DEV void apply_gravity_lean(float4& pos, float4& vel, const LeanGravity& g, float dt_ms, float mv) {
+    if ((pos.w <= 0.0f) || !((vel.w >= g.cat_lo) && (vel.w <= g.cat_hi)))
+        return;
+    f3 acceleration = mk3(0.0f, 0.0f, 0.0f);
+    const uint32_t types = g.types;
+    for (int i = 0; i < g.count; i++) {
+        const LeanAttractor A = g.a[i];
+        const uint32_t type = (types >> (2 * i)) & 3u;
+        const f3 to_center = mk3(A.x, A.y, A.z) - xyz(pos);
+        float attraction;
+        const float d2 = dot3(to_center, to_center);
+#ifndef ILM_GRAVITY_EXACT
+        const float inv_len = fast_rsq(d2);
+        if (type != 0u) {
+            const float distance = d2 * inv_len;
+            attraction = 1.0f - sat(distance * fast_rcp(A.radius));
+            if (type == 2u)
+                attraction *= attraction;
+            attraction = attraction * dt_ms * (1.0f / kVelocityConstantScale);
+        } else {
+            const float distance_squared = fmaxf(d2 - A.radius, 0.001f);
+            attraction = 1.0f / distance_squared;
+        }
+        acceleration = acceleration + (((to_center * inv_len) * attraction) * A.strength);
+#else
+        const float distance = sqrtf(d2);
+        if (type != 0u) {
+            attraction = 1.0f - sat(distance / A.radius);
+            if (type == 2u)
+                attraction *= attraction;
+            attraction = attraction * dt_ms / kVelocityConstantScale;
+        } else {
+            const float distance_squared = fmaxf(d2 - A.radius, 0.001f);
+            attraction = 1.0f / distance_squared;
+        }
+        const f3 n = mk3(to_center.x / distance, to_center.y / distance, to_center.z / distance);
+        acceleration = acceleration + ((n * attraction) * A.strength);
+#endif
+    }
+    const float maximum_acceleration = g.max_accel;
+#ifndef ILM_GRAVITY_EXACT
+    const float a2 = dot3(acceleration, acceleration);
+    if (a2 > maximum_acceleration * maximum_acceleration)
+        acceleration = acceleration * (fast_rsq(a2) * maximum_acceleration);
+#else
+    const float current_length = len3(acceleration);
+    if (current_length > maximum_acceleration)
+        acceleration = mk3(acceleration.x / current_length, acceleration.y / current_length, acceleration.z / current_length) * maximum_acceleration;
+#endif
+    vel.x = fminf(mv, vel.x + acceleration.x);
+    vel.y = fminf(mv, vel.y + acceleration.y);
+    vel.z = fminf(mv, vel.z + acceleration.z);
+}
+
+// noise_prepare on LeanStep: class counts as sign bits (2 scalar instructions per boundary), one table for both class counts
+ILM_DEV NoiseDeltas noise_prepare_lean(const LeanStep& a, int x0, int row) {
+    const StepDerived::NoiseFast& nf = a.noise;
+    NoiseDeltas out;
+    const uint32_t code = nf.wcode[x0 >> 6];
+    out.valid = (code & 64u) != 0u;
+    uint32_t yc0 = 0, yc1 = 0;
 #pragma unroll
-            for (int w = 0; w < kStepThreads / 64; w++) block_live += wave_live[w];
-            const int first_unit = a.unit_begin + v;
-            const int c = a.first_chunk + ((a.upc_shift >= 0) ? (first_unit >> a.upc_shift) : (first_unit / a.units_per_chunk));
-            if (block_live != 0)
-                atomicAdd(&a.live_counts[c * kCountStride], block_live);
+    for (int k = 0; k < 4; k++) {
+        const int b = nf.yb[k];                              // a row >= 0 or INT32_MAX
+        yc0 += (uint32_t)(b - 1 - row) >> 31;                // row >= b
+        yc1 += (uint32_t)(b - 2 - row) >> 31;                // row + 1 >= b
+    }
+    const uint32_t xc0 = code & 7u, xc1 = (code >> 3) & 7u;
+    const uint32_t n = (uint32_t)nf.classes;
+    const IlmFloat4* table = (n == (uint32_t)kNoiseBigClasses) ? a.noise_big : &nf.position[0][0];   // position[n][n] then velocity[n][n]
+    out.position = ld4(table[yc0 * n + xc0]);
+    out.velocity = ld4(table[n * n + yc1 * n + xc1]);
+    return out;
+}
+static_assert(offsetof(StepDerived::NoiseFast, velocity) == offsetof(StepDerived::NoiseFast, position) + 9 * sizeof(IlmFloat4), "velocity[3][3] follows position[3][3]");
+
+typedef const LeanStep __attribute__((address_space(4))) CLeanStep;
+
+template <bool SPAWN, bool STREAM>
+__global__ __launch_bounds__(kStepThreads) void step_lean_kernel(const LeanStep a_) {
+    __shared__ uint32_t wave_live[kStepThreads / 64];
+    const LeanStep& a = *(const LeanStep*)(CLeanStep*)__builtin_amdgcn_kernarg_segment_ptr();
+    const unsigned lane = threadIdx.x & 63u;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    int v = (int)blockIdx.x * (kStepThreads / 64) + a.unit_rotate;      // first unit of the block (rotation: see step_kernel)
+    if (v >= a.total_padded) v -= a.total_padded;
+    const int u = v + wave;
+    uint32_t n_live = 0;
+    if (u < a.total_units) {
+        const int chunk_rel = u >> a.upc_shift;
+        const int seg = u - (chunk_rel << a.upc_shift);
+        const int chunk = a.first_chunk + chunk_rel;
+        bool untouched = false;
+        if (a.partial_count != 0) {
+#pragma unroll
+            for (int k = 0; k < kMaxPartialChunks; k++)
+                untouched = untouched || ((a.partial_chunk[k] == chunk) && (seg >= a.partial_units[k]));
+        }
+        if (!untouched) {
+            const unsigned lane4 = lane * 4u;
+            const UnitPlanes up = unit_planes(a.chunk_bases[chunk], a.stride, seg * 64);
+            const SlotIn cur = load_slot<true, STREAM>(up, lane4);
+            // slot (x, y): the unit lies in one row (chunk size a multiple of 64)
+            const int first = seg * 64;
+            const int row = first >> a.cs_shift;
+            const int x0 = first - (row << a.cs_shift);
+            const float fx = (float)(x0 + (int)lane), fy = (float)row;
+            NoiseDeltas noise;
+            noise.valid = false;
+            if (a.noise_op >= 0)
+                noise = noise_prepare_lean(a, x0, row);
+
+            float4 pos = mk4(cur.px, cur.py, cur.pz, cur.life);
+            float4 vel = mk4(cur.vx, cur.vy, cur.vz, cur.ct);
+            float4 attr = mk4(cur.ar, cur.ag, cur.ab, cur.aa);
+            bool spawn_here = false, spawned = false;
+            if constexpr (SPAWN) {
+                for (int s = 0; s < a.spawn_count; s++) {
+                    if (a.spawn_chunk[s] == chunk && seg >= a.spawn_unit_lo[s] && seg <= a.spawn_unit_hi[s]) {
+                        const IlmSpawnRecord& r = a.spawns[s];
+                        const float fi = (float)(first + (int)lane);
+                        if (fi >= r.Params.ChunkSizeAndIndices[1] && fi <= r.Params.ChunkSizeAndIndices[2]) {
+                            spawn_here = true;
+                            if (spawn_slot(pos, vel, attr, fx, fy, a.rnd, a.rw, a.rh, a.inv_rw, a.inv_rh, r.Params))
+                                spawned = true;
+                        }
+                    }
+                }
+            }
+            // `<= 0` as the shaders test it: a NaN life is not dead.  A dead slot nothing writes keeps the cleared target's zeros.
+            const bool process = !(cur.life <= 0.0f) || spawn_here;
+            const float4 zero = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+            float4 rc = zero, rd = zero;
+            if (__ballot(process) != 0ull) {
+                if (process) {
+                    for (int o = 0; o < a.op_count; o++) {
+                        const int type = a.op_type[o];
+                        if (type == ILM_OP_GRAVITY)
+                            apply_gravity_lean(pos, vel, a.op[o].gravity, a.sys.GlobalSettings.x, a.sys.GlobalSettings.z);
+                        else if (type == ILM_OP_NOISE)
+                            apply_noise(pos, vel, fx, fy, a.rnd, a.rw, a.rh, a.sys, a.op[o].noise, a.inv_rw, a.inv_rh, a.dop[o],
+                                        (o == a.noise_op) ? noise : NoiseDeltas{ false, zero, zero });
+                        else
+                            apply_fma(pos, vel, a.sys, a.op[o].fma, a.dop[o]);
+                    }
+                    if (pos.w <= 0.0f) {
+                        pos = vel = zero;  // readStateOrDiscard: discard => cleared target
+                    } else {
+                        update_positions(pos, vel, a.sys, a.dt_s);
+                        render_data(fx, fy, pos, vel, attr, a.sys, a.update, a.bezier_codes, a.update_bits, nullptr, 0, 0, rc, rd);
+                    }
+                } else {
+                    pos = vel = zero;
+                }
+            } else {
+                pos = vel = zero;
+            }
+            st_plane<STREAM>(up, 0, lane4, pos.x); st_plane<STREAM>(up, 1, lane4, pos.y); st_plane<STREAM>(up, 2, lane4, pos.z); st_plane<STREAM>(up, 3, lane4, pos.w);
+            st_plane<STREAM>(up, 4, lane4, vel.x); st_plane<STREAM>(up, 5, lane4, vel.y); st_plane<STREAM>(up, 6, lane4, vel.z); st_plane<STREAM>(up, 7, lane4, vel.w);
+            if constexpr (SPAWN) {
+                if (spawned) {
+                    st_plane<STREAM>(up, 8, lane4, attr.x); st_plane<STREAM>(up, 9, lane4, attr.y); st_plane<STREAM>(up, 10, lane4, attr.z); st_plane<STREAM>(up, 11, lane4, attr.w);
+                }
+            }
+            st_plane<STREAM>(up, 12, lane4, rc.x); st_plane<STREAM>(up, 13, lane4, rc.y); st_plane<STREAM>(up, 14, lane4, rc.z); st_plane<STREAM>(up, 15, lane4, rc.w);
+            st_plane<STREAM>(up, 16, lane4, rd.x); st_plane<STREAM>(up, 17, lane4, rd.y); st_plane<STREAM>(up, 18, lane4, rd.z); st_plane<STREAM>(up, 19, lane4, rd.w);
+            n_live = (uint32_t)__popcll(__ballot(pos.w > 0.0f));
         }
     }
+    if (a.flags & ILM_STEP_COUNT_LIVE)
+        publish_block_count(wave_live, n_live, lane, wave, v < a.total_units, a.first_chunk + (v >> a.upc_shift),
+                            (v & ((1 << a.upc_shift) - 1)) / (kStepThreads / 64), (1 << a.upc_shift) / (kStepThreads / 64), a.count_buckets,
+                            a.live_counts, a.zero_counts, a.zero_n, a.host_counts, a.count_seq);
+}
+
+// LeanStep from a StepLaunch whose launch_step fields are filled; false when the step is not of the lean shape
+static bool build_lean_step(const StepLaunch& a, LeanStep& f) {
+    const IlmStepDesc& d = a.desc;
+    if (kUnitsPerWave != 1) return false;
+    if (d.UpdateMode != ILM_UPDATE_POSITIONS) return false;
+    if (a.derived.cs_shift < 6 || a.upc_shift < 0) return false;                   // power-of-two chunk size >= 64: no stride padding, a unit lies in one row
+    if ((int64_t)a.slots != a.stride) return false;
+    if (a.derived.noise_may_revive != 0) return false;
+    if (a.derived.update_bits & 1u) return false;                                   // life ramp
+    if (a.op_mask & ~((1u << ILM_OP_GRAVITY) | (1u << ILM_OP_NOISE) | (1u << ILM_OP_FMA))) return false;
+    memset(&f, 0, sizeof(f));
+    for (int o = 0; o < d.OpCount; o++) {
+        const IlmTransformOp& op = d.Ops[o];
+        f.op_type[o] = op.Type;
+        f.dop[o] = a.derived.op[o];
+        if (op.Type == ILM_OP_GRAVITY) {
+            const IlmGravityParams& g = op.u.Gravity;
+            if (g.AttractorCount > kLeanMaxAttractors) return false;
+            LeanGravity& l = f.op[o].gravity;
+            l.count = g.AttractorCount < 0 ? 0 : g.AttractorCount;
+            l.max_accel = a.derived.op[o].max_accel;
+            l.cat_lo = g.CategoryFilter[0]; l.cat_hi = g.CategoryFilter[1];
+            l.types = 0;
+            for (int i = 0; i < l.count; i++) {
+                l.a[i].x = g.AttractorPositions[i][0]; l.a[i].y = g.AttractorPositions[i][1]; l.a[i].z = g.AttractorPositions[i][2];
+                l.a[i].radius = g.AttractorRadiusesAndStrengths[i][0];
+                l.a[i].strength = g.AttractorRadiusesAndStrengths[i][1];
+                const float type = g.AttractorRadiusesAndStrengths[i][2];
+                l.types |= ((type >= 1.5f) ? 2u : ((type >= 0.5f) ? 1u : 0u)) << (2 * i);
+            }
+        } else if (op.Type == ILM_OP_NOISE) {
+            // the per-slot form of evaluateByTypeId stays with the interpreter; a second Noise op has no uniform deltas
+            if (!a.derived.op[o].area_none || a.derived.noise.op != o) return false;
+            f.op[o].noise = op.u.Noise;
+        } else {
+            if (!a.derived.op[o].area_none) return false;
+            f.op[o].fma = op.u.FMA;
+        }
+    }
+    f.op_count = d.OpCount;
+    f.noise_op = a.derived.noise.op;
+    f.noise = a.derived.noise;
+    f.spawn_count = 0;
+    for (int s = 0; s < ILM_MAX_SPAWNS; s++) { f.spawn_chunk[s] = -1; f.spawn_unit_lo[s] = 1; f.spawn_unit_hi[s] = 0; }
+    for (int s = 0; s < d.SpawnCount; s++) {
+        const IlmSpawnRecord& r = d.Spawns[s];
+        if (r.Kind != ILM_SPAWN_INLINE) return false;
+        f.spawns[s] = r;
+        f.spawn_chunk[s] = r.ChunkIndex;
+        const float first = r.Params.ChunkSizeAndIndices[1], last = r.Params.ChunkSizeAndIndices[2];
+        if (last >= first && last >= 0.0f) {      // (a NaN bound compares false: no lane can pass the per-lane test either)
+            const double lo = first < 0.0f ? 0.0 : std::floor((double)first), hi = std::floor((double)last);
+            const double max_unit = (double)(a.units_per_chunk - 1);
+            f.spawn_unit_lo[s] = (int32_t)std::fmin(lo / 64.0, max_unit + 1.0);
+            f.spawn_unit_hi[s] = (int32_t)std::fmin(hi / 64.0, max_unit);
+        }
+        f.spawn_count = s + 1;
+    }
+    if (d.SpawnCount == 0 && a.derived.noise.op >= 0 && a.derived.noise.classes == kNoiseBigClasses)
+        memcpy(f.noise_big, &d.Spawns[0], sizeof(f.noise_big));       // fill_noise_fast put the 5 x 5 tables there
+    f.chunk_bases = a.chunk_bases;
+    f.live_counts = a.live_counts; f.zero_counts = a.zero_counts; f.zero_n = a.zero_n; f.host_counts = a.host_counts; f.count_seq = a.count_seq; f.count_buckets = a.count_buckets;
+    f.stride = a.stride;
+    f.upc_shift = a.upc_shift; f.unit_rotate = a.unit_rotate; f.total_padded = a.total_padded; f.total_units = a.unit_end - a.unit_begin;
+    f.first_chunk = a.first_chunk; f.cs_shift = a.derived.cs_shift; f.flags = d.Flags;
+    f.partial_count = a.partial_count;
+    for (int k = 0; k < kMaxPartialChunks; k++) {
+        f.partial_chunk[k] = (k < a.partial_count) ? a.partial_chunk[k] : -1;
+        f.partial_units[k] = (k < a.partial_count) ? a.partial_units[k] : 0;
+    }
+    f.dt_s = a.derived.dt_s; f.bezier_codes = a.derived.bezier_codes; f.update_bits = a.derived.update_bits;
+    f.sys = d.System; f.update = d.Update;
+    f.rnd = a.rnd; f.rw = a.rw; f.rh = a.rh; f.inv_rw = a.derived.inv_rw; f.inv_rh = a.derived.inv_rh;
+    return true;
+}
+
+static hipError_t launch_lean_step(const LeanStep& f, bool spawning, bool streaming, hipStream_t stream) {
+    const int units_per_block = kStepThreads / 64;
+    const dim3 grid((unsigned)((f.total_units + units_per_block - 1) / units_per_block), 1, 1), block(kStepThreads, 1, 1);
+    if (spawning) {
+        if (streaming) hipLaunchKernelGGL((step_lean_kernel<true, true>), grid, block, 0, stream, f);
+        else hipLaunchKernelGGL((step_lean_kernel<true, false>), grid, block, 0, stream, f);
+    } else {
+        if (streaming) hipLaunchKernelGGL((step_lean_kernel<false, true>), grid, block, 0, stream, f);
+        else hipLaunchKernelGGL((step_lean_kernel<false, false>), grid, block, 0, stream, f);
+    }
+    return hipGetLastError();
 }
 
 // The extended variant carries the rarely used techniques (MatrixMultiply, SpatialNoise, the position-buffer and feedback spawners) so
@@ -1127,6 +1471,20 @@ static hipError_t launch_step_variant(const StepLaunch& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+static int g_step_interpreter = -1;      // -1: not decided yet (ILM_STEP_LEAN), 0: lean kernel where it applies, 1: interpreter always
+static bool step_interpreter_forced() {
+    if (g_step_interpreter < 0) {
+        const char* e = getenv("ILM_STEP_LEAN");
+        g_step_interpreter = (e && atoi(e) == 0) ? 1 : 0;
+    }
+    return g_step_interpreter != 0;
+}
+int set_step_interpreter(int on) {
+    const int before = step_interpreter_forced() ? 1 : 0;
+    g_step_interpreter = on ? 1 : 0;
+    return before;
+}
+
 // One launch per ParticleSystem.Update: the unit range covers every chunk of the step; when spawn records are
 // present the SPAWN variant runs (for every unit) and the grid is rotated to start at the first spawn range.
 hipError_t launch_step(StepLaunch& a, hipStream_t stream) {
@@ -1139,6 +1497,8 @@ hipError_t launch_step(StepLaunch& a, hipStream_t stream) {
     const int waves_per_block = (kStepThreads / 64) * kUnitsPerWave;   // units per block
     a.total_padded = (a.unit_end + waves_per_block - 1) / waves_per_block * waves_per_block;
     a.unit_rotate = 0;
+    a.count_buckets = 1;
+    while (a.count_buckets * 2 <= kCountLines - 1 && (a.units_per_chunk / waves_per_block) % (a.count_buckets * 2) == 0) a.count_buckets *= 2;
     bool spawning = false;
     for (int s = 0; s < a.desc.SpawnCount; s++) {
         const IlmSpawnRecord& r = a.desc.Spawns[s];
@@ -1151,6 +1511,11 @@ hipError_t launch_step(StepLaunch& a, hipStream_t stream) {
             a.unit_rotate = unit / waves_per_block * waves_per_block;
         }
         spawning = true;
+    }
+    if (!step_interpreter_forced() && a.unit_end > a.unit_begin) {
+        LeanStep f;
+        if (build_lean_step(a, f))
+            return launch_lean_step(f, spawning, a.streaming != 0, stream);
     }
     return spawning ? launch_step_variant<true>(a, stream) : launch_step_variant<false>(a, stream);
 }

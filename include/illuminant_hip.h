@@ -478,6 +478,11 @@ int32_t ilm_debug_sdf_sample_inside(IlmHandle sdf, const IlmDistanceFieldUniform
  * out_divisors[i]; *out_count divisors, out_mismatches holds 2 * capacity entries.  A test requires zero inside. */
 int32_t ilm_debug_divide_by_constants(IlmHandle ctx, float* out_divisors, uint64_t* out_mismatches, int32_t capacity, int32_t* out_count);
 int32_t ilm_debug_divide(IlmHandle ctx, const float* numerators, const float* denominators, int32_t count, float* out_fast, float* out_ieee);
+/* ilm_system_step runs a step of the common shape (power-of-two chunk size >= 64, UpdatePositions, Gravity / area-less Noise and FMA,
+ * inline spawners) through a kernel specialised for it and every other step through the kernel that interprets the descriptor; the
+ * per-slot arithmetic is the same.  interpreter != 0 forces the interpreting kernel for every later step of this process (0: the
+ * default choice) so that a test can hold the two bit-equal; returns the previous setting.  Environment: ILM_STEP_LEAN=0. */
+int32_t ilm_debug_step_interpreter(int32_t interpreter);
 int32_t ilm_sdf_destroy(IlmHandle sdf);
 /* DistanceField.Save (Illuminant/SDF/DistanceField.cs:178-194): the atlas bytes, 8 per texel, row-major. */
 int32_t ilm_sdf_download(IlmHandle sdf, uint16_t* texels);

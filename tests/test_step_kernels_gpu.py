@@ -1,0 +1,200 @@
+"""ilm_system_step has two kernels (csrc/particles.hip): the one that interprets an IlmStepDesc and the one specialised for the common
+shape of a step (power-of-two chunk size >= 64, UpdatePositions, Gravity / area-less Noise / area-less FMA, inline spawners).
+Which one runs is a launch decision, so the same step must give the same bits through both (ilm_debug_step_interpreter forces the
+interpreter) -- and both are held against the oracle.  Also covered: the curves' host-coded decisions (bezier.hpp) for every
+count class / range mode / shaping mode, and the live counts the kernels publish into host memory.
+"""
+import numpy as np
+import pytest
+
+from illuminant_amd import abi, native, scenes
+from tests.util import assert_bits_equal, assert_close
+
+pytestmark = pytest.mark.gpu
+
+P, V, A, RC, RD = abi.PLANE_POSITION, abi.PLANE_VELOCITY, abi.PLANE_ATTRIBUTES, abi.PLANE_RENDER_COLOR, abi.PLANE_RENDER_DATA
+PLANES = (P, V, A, RC, RD)
+
+
+def _bezier4(count, mode, lo=0.0, hi=3.0, negative=False):
+    inv = 1.0 / (hi - lo)
+    return abi.ClampedBezier4(abi.f4(lo, -inv if negative else inv, count, mode),
+                              abi.f4(1.0, 0.2, 0.1, 1.0), abi.f4(0.4, 0.9, 0.3, 0.8), abi.f4(0.1, 0.5, 1.0, 0.5), abi.f4(0.9, 0.1, 0.6, 0.2))
+
+
+def _bezier1(count, mode, lo=0.0, hi=50.0, negative=False):
+    inv = 1.0 / (hi - lo)
+    return abi.ClampedBezier1(abi.f4(lo, -inv if negative else inv, count, mode), abi.f4(0.5, 2.0, 1.25, 3.0))
+
+
+def _step(cs, shape):
+    d = abi.StepDesc()
+    d.FirstChunk, d.ChunkCount = 0, -1
+    d.System = scenes.system_uniforms(cs, friction=0.05, max_velocity=900.0, life_decay=4.0, rotation_from_velocity=shape.get("rotation", False))
+    d.Update = abi.UpdateParams.default()
+    if "curves" in shape:
+        count, mode, negative = shape["curves"]
+        d.Update.ColorFromLife = _bezier4(count, mode, 0.0, 2.5, negative)
+        d.Update.ColorFromVelocity = _bezier4(max(1, 5 - count), mode, 0.0, 120.0, not negative)
+        d.Update.SizeFromLife = _bezier1(count, mode, 0.0, 2.5, not negative)
+        d.Update.SizeFromVelocity = _bezier1(max(1, 5 - count), mode, 0.0, 120.0, negative)
+        d.Update.RotationFromLifeAndIndex[0], d.Update.RotationFromLifeAndIndex[1] = 0.7, 0.001
+    ops = shape["ops"]
+    d.OpCount = len(ops)
+    for o, kind in enumerate(ops):
+        if kind == "gravity":
+            d.Ops[o].Type = abi.OP_GRAVITY
+            d.Ops[o].u.Gravity = scenes.gravity_params([((60., 70., 0.), 40., 500., 0), ((200., 60., 10.), 90., 700., 1),
+                                                        ((100., 210., 0.), 120., 900., 2), ((220., 200., 5.), 3., 300., 0)][:shape.get("attractors", 4)],
+                                                       maximum_acceleration=shape.get("max_accel", 64.0))
+        elif kind == "noise":
+            d.Ops[o].Type = abi.OP_NOISE
+            d.Ops[o].u.Noise = scenes.noise_params(scenes.area_none(), (0.37 * 253, 0.81 * 127), (0.12 * 253, 0.55 * 127), 0.35,
+                                                   replace_old_velocity=shape.get("replace", True))
+        elif kind == "fma":
+            d.Ops[o].Type = abi.OP_FMA
+            d.Ops[o].u.FMA = scenes.fma_params(scenes.area_none(), position_add=(0.5, -0.25, 0.0), position_multiply=(1.001, 0.999, 1.0),
+                                               velocity_add=(0.0, 1.5, 0.0), velocity_multiply=(0.98, 0.97, 1.0))
+    d.UpdateMode = abi.UPDATE_POSITIONS
+    d.Flags = abi.STEP_COUNT_LIVE if shape.get("count", True) else 0
+    for s, (chunk, first, last) in enumerate(shape.get("spawns", ())):
+        d.Spawns[s].ChunkIndex = chunk
+        d.Spawns[s].Params = scenes.spawn_params(cs, first, last, 17 * s, (0.3 * 253, 0.6 * 127),
+                                                 position=((128, 128, 0), (100, 90, 4), (0, 0, 0), scenes.FORMULA_SPHERICAL),
+                                                 velocity=((0, 0, 0), (60, 60, 10), (0, 0, 0), scenes.FORMULA_SPHERICAL), life=(1.0, 2.0, 0.0))
+        d.SpawnCount = s + 1
+    return d
+
+
+SHAPES = {
+    "gravity+noise": dict(ops=("gravity", "noise")),
+    "gravity+noise+spawn": dict(ops=("gravity", "noise"), spawns=((2, 100, 1500),)),
+    "two spawn records, one past the used range": dict(ops=("noise", "gravity"), spawns=((2, 0, 63), (1, 4000, 4095))),
+    "update only, no counting": dict(ops=(), count=False),
+    "fma+gravity, one attractor": dict(ops=("fma", "gravity"), attractors=1, max_accel=2.0),
+    "noise adds to the velocity": dict(ops=("noise", "fma"), replace=False),
+    "rotation from velocity": dict(ops=("gravity",), rotation=True),
+    "curves linear / mirror": dict(ops=("gravity",), curves=(2, 512 + 1, False)),
+    "curves three-point / repeat / square": dict(ops=("gravity", "noise"), curves=(3, 256 + 2, True)),
+    "curves cubic / clamp / sine": dict(ops=("noise",), curves=(4, 1, True)),
+    "curves cubic / mirror": dict(ops=("gravity",), curves=(4, 600, False)),
+}
+
+
+@pytest.mark.parametrize("name", list(SHAPES))
+def test_both_step_kernels_agree_and_match_the_oracle(ctx, oracle, name):
+    shape = SHAPES[name]
+    cs, n_chunks, steps = 64, 3, 3
+    n = cs * cs
+    rnd = scenes.randomness_table(11)
+    eng = native.Engine(ctx, cs, rnd)
+    pos, vel, attr = scenes.make_particles(77, n * n_chunks, life=(0.02, 2.5), dead_fraction=0.2)
+    # chunk 2 is partly used (its tail has never been written): the kernels skip untouched units
+    used = [n, n, 1024]
+    systems = []
+    prev = native.lib().ilm_debug_step_interpreter(0)
+    try:
+        for interpreter in (0, 1):
+            native.lib().ilm_debug_step_interpreter(interpreter)
+            s = native.System(eng)
+            for c in range(n_chunks):
+                s.add_chunk()
+                sl = slice(c * n, c * n + used[c])
+                s.upload(c, P, pos[sl]); s.upload(c, V, vel[sl]); s.upload(c, A, attr[sl])
+            counts = []
+            for _ in range(steps):
+                d = _step(cs, shape)
+                s.step(d)
+                if d.Flags & abi.STEP_COUNT_LIVE:
+                    counts.append(s.step_counts().copy())
+            systems.append((s, counts))
+    finally:
+        native.lib().ilm_debug_step_interpreter(prev)
+    (lean, lean_counts), (interp, interp_counts) = systems
+    chunks = []
+    for c in range(n_chunks):
+        z = [np.zeros((n, 4), np.float32) for _ in range(5)]
+        z[0][:used[c]] = pos[c * n:c * n + used[c]]; z[1][:used[c]] = vel[c * n:c * n + used[c]]; z[2][:used[c]] = attr[c * n:c * n + used[c]]
+        chunks.append(z)
+    want_counts = []
+    for _ in range(steps):
+        d = _step(cs, shape)
+        got = oracle.step(chunks, cs, rnd, d, want_counts=bool(d.Flags & abi.STEP_COUNT_LIVE))
+        if d.Flags & abi.STEP_COUNT_LIVE:
+            want_counts.append(np.asarray(got).copy())
+    for a, b, w in zip(lean_counts, interp_counts, want_counts):
+        assert np.array_equal(a, b) and np.array_equal(a, w)
+    for c in range(n_chunks):
+        for k, plane in enumerate(PLANES):
+            a, b = lean.download(c, plane), interp.download(c, plane)
+            assert_bits_equal(a, b, "%s: chunk %d plane %d, specialised vs interpreting kernel" % (name, c, plane))
+            assert_close(a, chunks[c][k], "%s: chunk %d plane %d vs oracle" % (name, c, plane), life_exact=(plane == P))
+    assert np.array_equal(lean.live_counts(), interp.live_counts())
+    for s, _ in systems:
+        s.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("cs,n_chunks", [(1024, 2), (2048, 1)])
+def test_both_step_kernels_agree_on_large_chunks(ctx, cs, n_chunks):
+    """Chunks larger than the randomness table take the 5 x 5 noise tables; their ~4000+ blocks publish one count through the bucket lines."""
+    n = cs * cs
+    rnd = scenes.randomness_table(5)
+    eng = native.Engine(ctx, cs, rnd)
+    pos, vel, attr = scenes.make_particles(9, n, pos_hi=(1920, 1080, 32), life=(0.02, 1.0), dead_fraction=0.3)
+    out = []
+    prev = native.lib().ilm_debug_step_interpreter(0)
+    try:
+        for interpreter in (0, 1):
+            native.lib().ilm_debug_step_interpreter(interpreter)
+            s = native.System(eng)
+            for c in range(n_chunks):
+                s.add_chunk()
+                s.upload(c, P, np.roll(pos, c * 977, axis=0)); s.upload(c, V, vel); s.upload(c, A, attr)
+            for _ in range(2):
+                s.step(_step(cs, dict(ops=("gravity", "noise"))))
+            counts = s.step_counts().copy()
+            planes = [[s.download(c, k) for k in (P, V, RC, RD)] for c in range(n_chunks)]
+            assert np.array_equal(counts, s.live_counts())
+            for c in range(n_chunks):
+                assert counts[c] == int((planes[c][0][:, 3] > 0).sum())
+            out.append((counts, planes))
+            s.close()
+    finally:
+        native.lib().ilm_debug_step_interpreter(prev)
+    assert np.array_equal(out[0][0], out[1][0])
+    for c in range(n_chunks):
+        for k in range(4):
+            assert_bits_equal(out[0][1][c][k], out[1][1][c][k], "cs %d chunk %d plane %d, specialised vs interpreting kernel" % (cs, c, k))
+    eng.close()
+
+
+def test_counts_of_consecutive_counting_steps_do_not_mix(ctx):
+    """Each counting step publishes under its own sequence number; polling never returns a stale or half-written table."""
+    cs, n_chunks = 64, 5
+    n = cs * cs
+    rnd = scenes.randomness_table(3)
+    eng = native.Engine(ctx, cs, rnd)
+    s = native.System(eng)
+    pos, vel, attr = scenes.make_particles(21, n * n_chunks, life=(0.01, 0.4), dead_fraction=0.1)
+    for c in range(n_chunks):
+        s.add_chunk()
+        sl = slice(c * n, (c + 1) * n)
+        s.upload(c, P, pos[sl]); s.upload(c, V, vel[sl]); s.upload(c, A, attr[sl])
+    for i in range(40):
+        d = _step(cs, dict(ops=("gravity",)))
+        if i % 3 == 1:
+            d.FirstChunk, d.ChunkCount = 1, 3          # chunks outside a step's range count zero in that step
+        s.step(d)
+        counts = s.step_counts()
+        life = [int((s.download(c, P)[:, 3] > 0).sum()) for c in range(n_chunks)]
+        lo, hi = (1, 4) if i % 3 == 1 else (0, n_chunks)
+        for c in range(n_chunks):
+            assert counts[c] == (life[c] if lo <= c < hi else 0), (i, c)
+    # a burst of counting steps without reading in between: the last one's counts win
+    for _ in range(10):
+        s.step(_step(cs, dict(ops=("gravity",))))
+    counts = s.step_counts()
+    assert np.array_equal(counts, s.live_counts())
+    s.close()
+    eng.close()

@@ -11,7 +11,7 @@ import csv, glob, sys, collections
 rows = collections.OrderedDict()
 for f in glob.glob(sys.argv[1] + "/p/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "step_kernel" not in r["Kernel_Name"]: continue
+        if "step_kernel" not in r["Kernel_Name"] and "step_lean" not in r["Kernel_Name"]: continue
         rows.setdefault(int(r["Dispatch_Id"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
 ids = sorted(rows)
 names = ["update only", "gravity", "noise", "gravity+noise", "gravity+noise, no update"]

@@ -11,7 +11,7 @@ import csv, glob, sys
 rows = []
 for f in glob.glob(sys.argv[1] + "/p/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "step_kernel" in r["Kernel_Name"]:
+        if "step_kernel" in r["Kernel_Name"] or "step_lean" in r["Kernel_Name"]:
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
 rows.sort()
 names = ["update only", "gravity", "noise", "gravity+noise", "gravity+noise, no update"]
