@@ -21,6 +21,8 @@ namespace {
 
 using namespace ilm;
 
+constexpr int kPlanePad = 1088;    // floats (a multiple of 64: planes stay 256-byte aligned)
+
 thread_local char g_last_error[512] = "";
 
 int32_t fail(int32_t code, const char* fmt, ...) {
@@ -59,10 +61,26 @@ struct Ctx {
     uint32_t magic = kMagicCtx;
     int device = 0;
     int children = 0;            // live engines / distance fields / G-buffers / lightmaps: the context cannot be destroyed under them
-    hipStream_t stream = nullptr;
+    // Two streams.  Everything is ordered on `stream_`; ilm_system_step may put the second half of a large step's chunk range on `aux`
+    // (chunks never interact, ParticleSystem.cs:743-745: one half's launch tail is covered by the other half's launch, run_step).
+    // The halves are only joined when something else needs them: every entry point takes its stream from main(), which makes
+    // stream_ wait for what aux has queued and notes that aux must wait for stream_ before its next launch.  Back-to-back steps
+    // therefore cost no event at all (a record / wait pair is a ~7 us bubble on this runtime).
+    hipStream_t stream_ = nullptr, aux = nullptr;
+    hipEvent_t ev_main = nullptr, ev_aux = nullptr;
+    bool aux_pending = false;    // aux holds launches stream_ has not waited for
+    bool main_pending = true;    // stream_ holds work aux has not waited for
+    bool exported = false;       // ilm_ctx_stream handed stream_ to the caller, who may queue readers of the particle planes on it: no split
+    hipStream_t main() {
+        if (aux_pending) {
+            (void)hipEventRecord(ev_aux, aux);
+            (void)hipStreamWaitEvent(stream_, ev_aux, 0);
+            aux_pending = false;
+        }
+        main_pending = true;
+        return stream_;
+    }
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    // Liveness counts leave through their own stream, so the device-to-host copy (a separate blit kernel on ROCm)
-    // never sits between two step launches on the compute stream.
     // device staging for AoS <-> SoA conversion
     void* staging = nullptr; size_t staging_bytes = 0;
     // pinned ring for small asynchronous parameter uploads (light arrays)
@@ -91,7 +109,8 @@ struct Engine {
     Ctx* ctx = nullptr;
     int children = 0;            // live systems: the engine cannot be destroyed under them
     int chunk_size = 0, slots = 0;
-    int64_t stride = 0;
+    int64_t stride = 0;     // floats between the component planes of a chunk: span + kPlanePad
+    int32_t span = 0;       // slots rounded up to kSlotsPerBlock
     float4* rnd = nullptr; int rw = 0, rh = 0;
     std::vector<float4> h_rnd;   // host copy: the uniform noise deltas are evaluated on the host (fill_noise_fast)
     uint2* rnd_lp = nullptr;   // LowPrecisionRandomnessTexture: the Rgba64 copy (ParticleEngine.cs:508-540)
@@ -124,12 +143,16 @@ struct System {
     // Raised by uploads and spawn ranges; a chunk whose device pointer was handed out is treated as fully used.
     std::vector<int32_t> used;
     float** d_table = nullptr; int table_cap = 0; bool table_dirty = true;
-    // Three counter regions of counts_cap * kCountStride 64-bit words: 0 / 1 alternate between counting steps (the step kernel
-    // accumulates into one and zeroes the other for next time: no memset launch), 2 belongs to ilm_system_live_counts.
-    // Regions 0 and 1 hold kCountLines lines per chunk (internal.hpp), region 2 one.
+    // Five counter regions of 64-bit words.  Regions 0-3 belong to the step kernels, kCountLines lines per chunk (internal.hpp),
+    // index = parity * 2 + half: a counting launch of half h accumulates into (parity, h) and zeroes (parity ^ 1, h) for the next
+    // counting step -- no memset launch, and the two halves of a split step (run_step), which run on different streams, never touch
+    // each other's lines; a launch that is not split uses half 0 and zeroes both halves of the other parity (they are adjacent).
+    // Region 4, one line per chunk, belongs to ilm_system_live_counts.
     unsigned long long* d_counts = nullptr; int counts_cap = 0; int count_parity = 0;
     unsigned long long* counts_region(int r) const { return d_counts + (size_t)r * (size_t)counts_cap * kCountLines * kCountStride; }
-    static size_t counts_bytes(int cap) { return sizeof(unsigned long long) * (size_t)cap * kCountStride * (2 * kCountLines + 1); }
+    static size_t counts_bytes(int cap) { return sizeof(unsigned long long) * (size_t)cap * kCountStride * (4 * kCountLines + 1); }
+    // chunks [.., split_at) of a split step run on the context stream, [split_at, ..) on the second one; moved only after a join
+    int split_at = -1;
     IlmHandle sdf_handle = 0;   // bound distance field: resolved through the handle table at every use (it may have been destroyed)
     float4* ramp = nullptr; int ramp_w = 0, ramp_h = 0;
     uint32_t* d_slots = nullptr; int slots_cap = 0; uint32_t* d_slot_count = nullptr;
@@ -257,7 +280,7 @@ int32_t ensure_staging(Ctx* c, size_t bytes) {
     if (bytes <= c->staging_bytes)
         return ILM_OK;
     if (c->staging) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(c->main()));
         HIP_TRY(hipFree(c->staging));
         c->staging = nullptr; c->staging_bytes = 0;
     }
@@ -283,8 +306,8 @@ int32_t upload_small(Ctx* c, void* dst, const void* src, size_t bytes) {
         c->pinned_bytes[slot] = cap;
     }
     memcpy(c->pinned[slot], src, bytes);
-    HIP_TRY(hipMemcpyAsync(dst, c->pinned[slot], bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipEventRecord(c->pinned_ev[slot], c->stream));
+    HIP_TRY(hipMemcpyAsync(dst, c->pinned[slot], bytes, hipMemcpyHostToDevice, c->main()));
+    HIP_TRY(hipEventRecord(c->pinned_ev[slot], c->main()));
     return ILM_OK;
 }
 
@@ -292,17 +315,17 @@ int32_t refresh_table(System* s) {
     Ctx* c = s->engine->ctx;
     const int n = (int)s->chunks.size();
     if (n > s->table_cap) {
-        if (s->d_table) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(s->d_table)); s->d_table = nullptr; }
+        if (s->d_table) { HIP_TRY(hipStreamSynchronize(c->main())); HIP_TRY(hipFree(s->d_table)); s->d_table = nullptr; }
         int cap = n < 64 ? 64 : n * 2;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_table), sizeof(float*) * (size_t)cap));
         s->table_cap = cap;
         s->table_dirty = true;
     }
     if (n > s->counts_cap) {
-        if (s->d_counts) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(s->d_counts)); s->d_counts = nullptr; }
+        if (s->d_counts) { HIP_TRY(hipStreamSynchronize(c->main())); HIP_TRY(hipFree(s->d_counts)); s->d_counts = nullptr; }
         int cap = n < 64 ? 64 : n * 2;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_counts), System::counts_bytes(cap)));
-        HIP_TRY(hipMemsetAsync(s->d_counts, 0, System::counts_bytes(cap), c->stream));
+        HIP_TRY(hipMemsetAsync(s->d_counts, 0, System::counts_bytes(cap), c->main()));
         // (the stream is idle here: no kernel can still publish into the old host table)
         unsigned long long* old = s->h_counts;
         unsigned long long* fresh = nullptr;
@@ -555,6 +578,21 @@ static uint32_t bezier_code(const IlmFloat4& rc) {
     return cls | (range << 2) | (neg << 4) | (shaping << 5);
 }
 
+static int g_step_streams = -1;       // -1: not decided yet (ILM_STEP_STREAMS), else 1 or 2
+static int step_streams() {
+    if (g_step_streams < 0) {
+        const char* v = getenv("ILM_STEP_STREAMS");
+        g_step_streams = (v && atoi(v) == 1) ? 1 : 2;
+    }
+    return g_step_streams;
+}
+int set_step_streams_impl(int n) {
+    const int before = step_streams();
+    g_step_streams = (n == 1) ? 1 : 2;
+    return before;
+}
+constexpr int64_t kSplitMinUnits = 8192;      // half a million slots: below it the second launch costs more than the overlap returns
+
 int32_t run_step(System* s, const IlmStepDesc* d) {
     int first = 0, count = 0;
     int32_t rc = validate_step(s, d, &first, &count);
@@ -576,6 +614,7 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
     memcpy(&a.desc, d, sizeof(IlmStepDesc));
     a.chunk_bases = s->d_table;
     a.stride = e->stride;
+    a.span = e->span;
     a.chunk_size = e->chunk_size;
     a.slots = e->slots;
     a.first_chunk = first;
@@ -605,9 +644,9 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
     }
     a.ramp = s->ramp; a.ramp_w = s->ramp_w; a.ramp_h = s->ramp_h;
     a.sdf = make_sdf_view(from_handle<Sdf>(s->sdf_handle, kMagicSdf), &d->DistanceField);
-    a.live_counts = counting ? s->counts_region(region) : nullptr;
-    a.zero_counts = counting ? s->counts_region(region ^ 1) : nullptr;
-    a.zero_n = counting ? (int32_t)s->counts_cap * kCountLines : 0;   // every line, so chunk-table growth after a shrink never meets stale counts
+    a.live_counts = counting ? s->counts_region(region * 2) : nullptr;
+    a.zero_counts = counting ? s->counts_region((region ^ 1) * 2) : nullptr;
+    a.zero_n = counting ? 2 * (int32_t)s->counts_cap * kCountLines : 0;   // every line of both halves, so chunk-table growth after a shrink never meets stale counts
     if (counting && ++s->count_seq == 0u) s->count_seq = 1u;      // 0 is the table's initial content
     a.host_counts = counting ? s->h_counts_dev : nullptr;
     a.count_seq = s->count_seq;
@@ -679,7 +718,58 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
             }
         }
     }
-    HIP_TRY(launch_step(a, c->stream));
+    // Two streams for a large step.  A launch of this size is a few wave generations long, and back-to-back launches on one stream
+    // pay its ramp and its tail (the last waves run alone) plus the dispatch gap every time: ~7.7 us of the ~23 us a cfg2 step takes
+    // (tools/two_stream_probe.py: two 8-chunk launches in a row 31.2 us, one 16-chunk launch 23.5 us).  Chunks never interact, so
+    // the second half of the range goes to the context's second stream, where its launches overlap the first half's boundaries
+    // (22.4 us).  Nothing joins the streams between steps; Ctx::main() does when any other entry point needs the result.  Feedback
+    // spawners read other chunks, exported streams may carry readers this library cannot see: those steps stay on one stream.
+    int mid = -1;
+    if (step_streams() >= 2 && !c->exported && count >= 2 && (int64_t)count * (e->span / 64) >= kSplitMinUnits) {
+        bool reads_other_chunks = false;
+        for (int k = 0; k < d->SpawnCount; k++) reads_other_chunks = reads_other_chunks || (d->Spawns[k].Kind == ILM_SPAWN_FEEDBACK);
+        if (!reads_other_chunks) {
+            // balance the units that carry particles (a spawn-target chunk is mostly untouched)
+            int64_t total = 0, left = 0;
+            for (int ci = first; ci < first + count; ci++) total += (s->used[(size_t)ci] + 63) / 64 + 1;
+            mid = first + 1;
+            for (int ci = first; ci < first + count - 1; ci++) {
+                left += (s->used[(size_t)ci] + 63) / 64 + 1;
+                mid = ci + 1;
+                if (2 * left >= total) break;
+            }
+        }
+    }
+    if (mid < 0) {
+        HIP_TRY(launch_step(a, c->main()));
+    } else {
+        if (s->split_at != mid) { (void)c->main(); s->split_at = mid; }      // a chunk changes streams: join first
+        if (c->main_pending) {
+            HIP_TRY(hipEventRecord(c->ev_main, c->stream_));
+            HIP_TRY(hipStreamWaitEvent(c->aux, c->ev_main, 0));
+            c->main_pending = false;
+        }
+        StepLaunch b = a;
+        a.chunk_count = mid - first;
+        b.first_chunk = mid; b.chunk_count = first + count - mid;
+        if (counting) {
+            a.zero_n = b.zero_n = (int32_t)s->counts_cap * kCountLines;
+            b.live_counts = s->counts_region(region * 2 + 1);
+            b.zero_counts = s->counts_region((region ^ 1) * 2 + 1);
+        }
+        // the half that holds the spawn ranges first: its waves are the long ones
+        bool spawn_in_b = false;
+        for (int k = 0; k < d->SpawnCount; k++) spawn_in_b = spawn_in_b || (d->Spawns[k].ChunkIndex >= mid);
+        if (spawn_in_b) {
+            HIP_TRY(launch_step(b, c->aux));
+            c->aux_pending = true;
+            HIP_TRY(launch_step(a, c->stream_));
+        } else {
+            HIP_TRY(launch_step(a, c->stream_));
+            HIP_TRY(launch_step(b, c->aux));
+            c->aux_pending = true;
+        }
+    }
     if (d->UpdateMode == ILM_UPDATE_ERASE)
         for (int ci = first; ci < first + count; ci++) s->used[(size_t)ci] = 0;   // position, velocity and render planes are zero again
     if (d->Flags & ILM_STEP_COUNT_LIVE) {
@@ -701,8 +791,8 @@ int32_t copy_counts(System* s, const unsigned long long* d_region64, uint32_t* o
         return fail(ILM_ERR_OUT_OF_RANGE, "capacity %d < chunk count %d", capacity, n);
     if (n == 0) return ILM_OK;
     std::vector<uint32_t> tmp((size_t)n * kCountStride);
-    HIP_TRY(hipMemcpyAsync(tmp.data(), d_region, sizeof(uint32_t) * tmp.size(), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(tmp.data(), d_region, sizeof(uint32_t) * tmp.size(), hipMemcpyDeviceToHost, c->main()));
+    HIP_TRY(hipStreamSynchronize(c->main()));
     for (int i = 0; i < n; i++) {
         const uint32_t v = tmp[(size_t)i * kCountStride];
         out[i] = (saturate16 && v > ref::kLiveCountSaturation) ? ref::kLiveCountSaturation : v;   // 16-bit additive target, CountLiveParticles.fx:38 + ParticleEngine.cs:244-247
@@ -736,6 +826,11 @@ void handle_retire(const void* object) { retire_handle(object); }
 int ctx_child_count(IlmHandle h) {
     const Ctx* c = from_handle<Ctx>(h, kMagicCtx);
     return c ? c->children : -1;
+}
+int set_step_streams(int n) { return set_step_streams_impl(n); }
+hipStream_t ctx_stream_joined(IlmHandle h) {
+    Ctx* c = from_handle<Ctx>(h, kMagicCtx);
+    return c ? c->main() : nullptr;
 }
 }  // namespace ilm
 
@@ -777,7 +872,10 @@ int32_t ilm_ctx_create(int32_t device_id, IlmHandle* out_ctx) {
     if (!c) return fail(ILM_ERR_INVALID_ARGUMENT, "out of host memory");
     c->device = device_id;
     const IlmHandle h = to_handle(c);
-    HIP_TRY_OR_DESTROY(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), ilm_ctx_destroy(h));
+    HIP_TRY_OR_DESTROY(hipStreamCreateWithFlags(&c->stream_, hipStreamNonBlocking), ilm_ctx_destroy(h));
+    HIP_TRY_OR_DESTROY(hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking), ilm_ctx_destroy(h));
+    HIP_TRY_OR_DESTROY(hipEventCreateWithFlags(&c->ev_main, hipEventDisableTiming), ilm_ctx_destroy(h));
+    HIP_TRY_OR_DESTROY(hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming), ilm_ctx_destroy(h));
     HIP_TRY_OR_DESTROY(hipEventCreate(&c->t0), ilm_ctx_destroy(h));
     HIP_TRY_OR_DESTROY(hipEventCreate(&c->t1), ilm_ctx_destroy(h));
     HIP_TRY_OR_DESTROY(hipMalloc(reinterpret_cast<void**>(&c->d_stats), 3 * sizeof(unsigned long long)), ilm_ctx_destroy(h));
@@ -791,7 +889,8 @@ int32_t ilm_ctx_destroy(IlmHandle h) {
     if (c->children > 0)
         return fail(ILM_ERR_STATE, "%d object(s) of this context are still alive: destroy engines, fields, G-buffers and lightmaps first", c->children);
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->aux) (void)hipStreamSynchronize(c->aux);
+    if (c->stream_) (void)hipStreamSynchronize(c->stream_);
     if (c->staging) (void)hipFree(c->staging);
     for (int i = 0; i < Ctx::kRing; i++) {
         if (c->pinned[i]) (void)hipHostFree(c->pinned[i]);
@@ -817,7 +916,10 @@ int32_t ilm_ctx_destroy(IlmHandle h) {
     // (a context whose creation failed half-way has null members here)
     if (c->t0) (void)hipEventDestroy(c->t0);
     if (c->t1) (void)hipEventDestroy(c->t1);
-    if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->ev_main) (void)hipEventDestroy(c->ev_main);
+    if (c->ev_aux) (void)hipEventDestroy(c->ev_aux);
+    if (c->aux) (void)hipStreamDestroy(c->aux);
+    if (c->stream_) (void)hipStreamDestroy(c->stream_);
     retire_handle(c);
     delete c;
     return ILM_OK;
@@ -826,28 +928,29 @@ int32_t ilm_ctx_destroy(IlmHandle h) {
 int32_t ilm_ctx_sync(IlmHandle h) {
     Ctx* c = from_handle<Ctx>(h, kMagicCtx);
     if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->main()));
     return ILM_OK;
 }
 
 int32_t ilm_ctx_stream(IlmHandle h, void** out_stream) {
     Ctx* c = from_handle<Ctx>(h, kMagicCtx);
     if (!c || !out_stream) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
-    *out_stream = reinterpret_cast<void*>(c->stream);
+    c->exported = true;      // the caller may queue readers of the particle planes on it: from now on every step stays on this one stream
+    *out_stream = reinterpret_cast<void*>(c->main());
     return ILM_OK;
 }
 
 int32_t ilm_timer_start(IlmHandle h) {
     Ctx* c = from_handle<Ctx>(h, kMagicCtx);
     if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
-    HIP_TRY(hipEventRecord(c->t0, c->stream));
+    HIP_TRY(hipEventRecord(c->t0, c->main()));
     return ILM_OK;
 }
 
 int32_t ilm_timer_stop(IlmHandle h, float* out_ms) {
     Ctx* c = from_handle<Ctx>(h, kMagicCtx);
     if (!c || !out_ms) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
-    HIP_TRY(hipEventRecord(c->t1, c->stream));
+    HIP_TRY(hipEventRecord(c->t1, c->main()));
     HIP_TRY(hipEventSynchronize(c->t1));
     HIP_TRY(hipEventElapsedTime(out_ms, c->t0, c->t1));
     return ILM_OK;
@@ -870,7 +973,12 @@ int32_t ilm_engine_create(IlmHandle hctx, int32_t chunk_size, const IlmFloat4* r
     c->children++;
     e->chunk_size = chunk_size;
     e->slots = chunk_size * chunk_size;
-    e->stride = ((int64_t)e->slots + kSlotsPerBlock - 1) / kSlotsPerBlock * kSlotsPerBlock;
+    e->span = (int32_t)(((int64_t)e->slots + kSlotsPerBlock - 1) / kSlotsPerBlock * kSlotsPerBlock);
+    // Component planes a power of two apart land on the same memory channels: every wave of the step touches the same 256 bytes of
+    // 20 planes, and a bare copy of cfg2's planes runs 16 % faster once consecutive planes are offset by a kilobyte
+    // (tools/ubench/stream <slots> 0 <pad>: 1 M slots 18.9 -> 15.8 us).
+    static const int pad = [] { const char* v = getenv("ILM_PLANE_PAD"); return v ? atoi(v) : kPlanePad; }();
+    e->stride = (int64_t)e->span + (pad / 64) * 64;
     e->rw = rw; e->rh = rh;
     const size_t bytes = sizeof(float4) * (size_t)rw * (size_t)rh;
     const IlmHandle h = to_handle(e);
@@ -895,7 +1003,7 @@ int32_t ilm_engine_destroy(IlmHandle h) {
     if (e->children > 0) return fail(ILM_ERR_STATE, "%d system(s) of this engine are still alive", e->children);
     e->ctx->children--;
     (void)hipSetDevice(e->ctx->device);
-    (void)hipStreamSynchronize(e->ctx->stream);
+    (void)hipStreamSynchronize(e->ctx->main());
     if (e->rnd) (void)hipFree(e->rnd);
     if (e->rnd_lp) (void)hipFree(e->rnd_lp);
     retire_handle(e);
@@ -921,7 +1029,7 @@ int32_t ilm_system_destroy(IlmHandle h) {
     Ctx* c = s->engine->ctx;
     s->engine->children--;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    (void)hipStreamSynchronize(c->main());
     for (float* p : s->chunks) (void)hipFree(p);
     if (s->d_table) (void)hipFree(s->d_table);
     if (s->d_counts) (void)hipFree(s->d_counts);
@@ -947,7 +1055,7 @@ int32_t ilm_system_add_chunk(IlmHandle h, int32_t* out_index) {
     float* base = nullptr;
     const size_t bytes = sizeof(float) * (size_t)kComponents * (size_t)e->stride;
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&base), bytes));
-    HIP_TRY(hipMemsetAsync(base, 0, bytes, e->ctx->stream));
+    HIP_TRY(hipMemsetAsync(base, 0, bytes, e->ctx->main()));
     s->chunks.push_back(base);
     s->used.push_back(0);
     s->table_dirty = true;
@@ -962,7 +1070,7 @@ int32_t ilm_system_remove_chunk(IlmHandle h, int32_t index) {
         return fail(ILM_ERR_OUT_OF_RANGE, "chunk %d outside [0, %d)", index, (int)s->chunks.size());
     Ctx* c = s->engine->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->main()));
     HIP_TRY(hipFree(s->chunks[(size_t)index]));
     s->chunks.erase(s->chunks.begin() + index);
     s->used.erase(s->used.begin() + index);
@@ -998,11 +1106,11 @@ int32_t ilm_chunk_upload(IlmHandle h, int32_t chunk, int32_t plane, const IlmFlo
     const size_t bytes = sizeof(float4) * (size_t)count;
     rc = ensure_staging(c, bytes);
     if (rc != ILM_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(c->staging, src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->staging, src, bytes, hipMemcpyHostToDevice, c->main()));
     s->used[(size_t)chunk] = std::max(s->used[(size_t)chunk], first_slot + count);
     HIP_TRY(launch_aos_to_soa(reinterpret_cast<const float4*>(c->staging), s->chunks[(size_t)chunk] + (int64_t)plane * 4 * e->stride,
-                              e->stride, first_slot, count, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));   // staging is reused by the next call
+                              e->stride, first_slot, count, c->main()));
+    HIP_TRY(hipStreamSynchronize(c->main()));   // staging is reused by the next call
     return ILM_OK;
 }
 
@@ -1018,9 +1126,9 @@ int32_t ilm_chunk_download(IlmHandle h, int32_t chunk, int32_t plane, IlmFloat4*
     rc = ensure_staging(c, bytes);
     if (rc != ILM_OK) return rc;
     HIP_TRY(launch_soa_to_aos(s->chunks[(size_t)chunk] + (int64_t)plane * 4 * e->stride, e->stride,
-                              reinterpret_cast<float4*>(c->staging), first_slot, count, c->stream));
-    HIP_TRY(hipMemcpyAsync(dst, c->staging, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+                              reinterpret_cast<float4*>(c->staging), first_slot, count, c->main()));
+    HIP_TRY(hipMemcpyAsync(dst, c->staging, bytes, hipMemcpyDeviceToHost, c->main()));
+    HIP_TRY(hipStreamSynchronize(c->main()));
     return ILM_OK;
 }
 
@@ -1051,7 +1159,7 @@ int32_t ilm_system_set_life_ramp(IlmHandle h, const IlmFloat4* texels, int32_t w
     if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
     Ctx* c = s->engine->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipStreamSynchronize(c->main()));
     if (s->ramp) { HIP_TRY(hipFree(s->ramp)); s->ramp = nullptr; s->ramp_w = s->ramp_h = 0; }
     if (!texels || width <= 0 || height <= 0) return ILM_OK;
     const size_t bytes = sizeof(float4) * (size_t)width * (size_t)height;
@@ -1070,7 +1178,7 @@ int32_t ilm_system_set_spawn_positions(IlmHandle h, int32_t slot, const IlmFloat
     Ctx* c = s->engine->ctx;
     HIP_TRY(hipSetDevice(c->device));
     if (count > s->spawn_position_cap[slot]) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(c->main()));
         if (s->spawn_positions[slot]) HIP_TRY(hipFree(s->spawn_positions[slot]));
         s->spawn_positions[slot] = nullptr; s->spawn_position_cap[slot] = 0;
         const int cap = (count + 127) / 128 * 128;     // EnsurePositionBufferExists, ParticleSpawner.cs:307
@@ -1094,7 +1202,7 @@ int32_t ilm_system_set_spawn_pattern(IlmHandle h, int32_t slot, const IlmFloat4*
         return fail(ILM_ERR_INVALID_ARGUMENT, "bad pattern texture (%d x %d)", width, height);
     Ctx* c = s->engine->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));     // an earlier step may still read the old texture
+    HIP_TRY(hipStreamSynchronize(c->main()));     // an earlier step may still read the old texture
     if (s->spawn_pattern[slot]) HIP_TRY(hipFree(s->spawn_pattern[slot]));
     s->spawn_pattern[slot] = nullptr;
     s->pattern_w[slot] = s->pattern_h[slot] = s->pattern_levels[slot] = 0;
@@ -1227,10 +1335,10 @@ int32_t ilm_system_live_counts(IlmHandle h, uint32_t* out_counts, int32_t capaci
     if (rc != ILM_OK) return rc;
     const int n = (int)s->chunks.size();
     if (n > 0) {
-        HIP_TRY(hipMemsetAsync(s->counts_region(2), 0, sizeof(uint32_t) * (size_t)n * kCountStride, c->stream));
-        HIP_TRY(launch_count_live(s->d_table, s->engine->stride, s->engine->slots, n, reinterpret_cast<uint32_t*>(s->counts_region(2)), c->stream));
+        HIP_TRY(hipMemsetAsync(s->counts_region(4), 0, sizeof(uint32_t) * (size_t)n * kCountStride, c->main()));
+        HIP_TRY(launch_count_live(s->d_table, s->engine->stride, s->engine->span, s->engine->slots, n, reinterpret_cast<uint32_t*>(s->counts_region(4)), c->main()));
     }
-    return copy_counts(s, s->counts_region(2), out_counts, capacity, saturate16);
+    return copy_counts(s, s->counts_region(4), out_counts, capacity, saturate16);
 }
 
 int32_t ilm_system_step_counts(IlmHandle h, uint32_t* out_counts, int32_t capacity, int32_t saturate16) {
@@ -1242,7 +1350,7 @@ int32_t ilm_system_step_counts(IlmHandle h, uint32_t* out_counts, int32_t capaci
         return fail(ILM_ERR_STATE, "no step with ILM_STEP_COUNT_LIVE has run");
     if (capacity < s->counts_n) return fail(ILM_ERR_OUT_OF_RANGE, "capacity %d < %d", capacity, s->counts_n);
     if (s->counts_n > 0)
-        HIP_TRY(hipStreamSynchronize(s->engine->ctx->stream));   // the counting step has run: every chunk of its range is published
+        HIP_TRY(hipStreamSynchronize(s->engine->ctx->main()));   // the counting step has run: every chunk of its range is published
     bool ready = true;
     for (int i = 0; i < s->counts_n; i++) (void)published_count(s, i, &ready);
     if (!ready) return fail(ILM_ERR_STATE, "the counting step finished without publishing every chunk's count");
@@ -1281,21 +1389,21 @@ int32_t ilm_chunk_live_slots(IlmHandle h, int32_t chunk, uint32_t* out_slots, in
     Engine* e = s->engine; Ctx* c = e->ctx;
     HIP_TRY(hipSetDevice(c->device));
     if (s->slots_cap < e->slots) {
-        if (s->d_slots) { HIP_TRY(hipStreamSynchronize(c->stream)); HIP_TRY(hipFree(s->d_slots)); s->d_slots = nullptr; }
+        if (s->d_slots) { HIP_TRY(hipStreamSynchronize(c->main())); HIP_TRY(hipFree(s->d_slots)); s->d_slots = nullptr; }
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_slots), sizeof(uint32_t) * (size_t)e->slots));
         s->slots_cap = e->slots;
     }
     if (!s->d_slot_count)
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&s->d_slot_count), sizeof(uint32_t)));
-    HIP_TRY(launch_live_slots(s->chunks[(size_t)chunk] + 3 * e->stride, e->slots, s->d_slots, (uint32_t)e->slots, s->d_slot_count, c->stream));
+    HIP_TRY(launch_live_slots(s->chunks[(size_t)chunk] + 3 * e->stride, e->slots, s->d_slots, (uint32_t)e->slots, s->d_slot_count, c->main()));
     uint32_t n = 0;
-    HIP_TRY(hipMemcpyAsync(&n, s->d_slot_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(&n, s->d_slot_count, sizeof(uint32_t), hipMemcpyDeviceToHost, c->main()));
+    HIP_TRY(hipStreamSynchronize(c->main()));
     *out_count = (int32_t)n;
     const uint32_t m = n < (uint32_t)capacity ? n : (uint32_t)capacity;
     if (m > 0) {
-        HIP_TRY(hipMemcpyAsync(out_slots, s->d_slots, sizeof(uint32_t) * (size_t)m, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpyAsync(out_slots, s->d_slots, sizeof(uint32_t) * (size_t)m, hipMemcpyDeviceToHost, c->main()));
+        HIP_TRY(hipStreamSynchronize(c->main()));
     }
     return ILM_OK;
 }
@@ -1317,7 +1425,7 @@ int32_t ilm_sdf_create(IlmHandle hctx, int32_t w, int32_t ht, int32_t format, Il
     c->children++;
     const IlmHandle h = to_handle(f);
     HIP_TRY_OR_DESTROY(hipMalloc(reinterpret_cast<void**>(&f->texels), sizeof(uint2) * (size_t)w * (size_t)ht), ilm_sdf_destroy(h));
-    HIP_TRY_OR_DESTROY(hipMemsetAsync(f->texels, 0, sizeof(uint2) * (size_t)w * (size_t)ht, c->stream), ilm_sdf_destroy(h));
+    HIP_TRY_OR_DESTROY(hipMemsetAsync(f->texels, 0, sizeof(uint2) * (size_t)w * (size_t)ht, c->main()), ilm_sdf_destroy(h));
     *out = h;
     return ILM_OK;
 }
@@ -1327,8 +1435,8 @@ int32_t ilm_sdf_upload(IlmHandle h, const uint16_t* texels) {
     if (!f) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle");
     if (!texels) return fail(ILM_ERR_INVALID_ARGUMENT, "texels is NULL");
     HIP_TRY(hipSetDevice(f->ctx->device));
-    HIP_TRY(hipMemcpyAsync(f->texels, texels, sizeof(uint2) * (size_t)f->width * (size_t)f->height, hipMemcpyHostToDevice, f->ctx->stream));
-    HIP_TRY(hipStreamSynchronize(f->ctx->stream));
+    HIP_TRY(hipMemcpyAsync(f->texels, texels, sizeof(uint2) * (size_t)f->width * (size_t)f->height, hipMemcpyHostToDevice, f->ctx->main()));
+    HIP_TRY(hipStreamSynchronize(f->ctx->main()));
     return ILM_OK;
 }
 
@@ -1344,10 +1452,10 @@ int32_t ilm_sdf_sample(IlmHandle h, const IlmDistanceFieldUniforms* df, const fl
     if (rc != ILM_OK) return rc;
     float* d_in = static_cast<float*>(c->staging);
     float* d_out = d_in + 3 * (size_t)count;
-    HIP_TRY(hipMemcpyAsync(d_in, positions, in_bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(launch_sdf_sample(make_sdf_view(f, df), *df, d_in, count, d_out, c->stream));
-    HIP_TRY(hipMemcpyAsync(out_distances, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(d_in, positions, in_bytes, hipMemcpyHostToDevice, c->main()));
+    HIP_TRY(launch_sdf_sample(make_sdf_view(f, df), *df, d_in, count, d_out, c->main()));
+    HIP_TRY(hipMemcpyAsync(out_distances, d_out, out_bytes, hipMemcpyDeviceToHost, c->main()));
+    HIP_TRY(hipStreamSynchronize(c->main()));
     return ILM_OK;
 }
 
@@ -1365,11 +1473,11 @@ int32_t ilm_debug_sdf_sample_inside(IlmHandle h, const IlmDistanceFieldUniforms*
     float* d_in = static_cast<float*>(c->staging);
     float* d_out = d_in + 3 * (size_t)count;
     int32_t* d_used = reinterpret_cast<int32_t*>(d_out + (size_t)count);
-    HIP_TRY(hipMemcpyAsync(d_in, positions, in_bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(launch_sdf_sample_inside(make_sdf_view(f, df), *df, d_in, count, d_out, d_used, c->stream));
-    HIP_TRY(hipMemcpyAsync(out_distances, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(out_used_table, d_used, out_bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(d_in, positions, in_bytes, hipMemcpyHostToDevice, c->main()));
+    HIP_TRY(launch_sdf_sample_inside(make_sdf_view(f, df), *df, d_in, count, d_out, d_used, c->main()));
+    HIP_TRY(hipMemcpyAsync(out_distances, d_out, out_bytes, hipMemcpyDeviceToHost, c->main()));
+    HIP_TRY(hipMemcpyAsync(out_used_table, d_used, out_bytes, hipMemcpyDeviceToHost, c->main()));
+    HIP_TRY(hipStreamSynchronize(c->main()));
     return ILM_OK;
 }
 
@@ -1381,11 +1489,11 @@ int32_t ilm_debug_divide_by_constants(IlmHandle hctx, float* out_divisors, uint6
     float pairs[2][2];
     light_constant_divisors(pairs);
     for (int i = 0; i < 2; i++) {
-        HIP_TRY(hipMemsetAsync(c->d_stats, 0, 2 * sizeof(unsigned long long), c->stream));
-        HIP_TRY(launch_divide_by_constant(pairs[i][0], pairs[i][1], c->d_stats, c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_stats, 0, 2 * sizeof(unsigned long long), c->main()));
+        HIP_TRY(launch_divide_by_constant(pairs[i][0], pairs[i][1], c->d_stats, c->main()));
         unsigned long long bad[2] = { 0, 0 };
-        HIP_TRY(hipMemcpyAsync(bad, c->d_stats, sizeof(bad), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpyAsync(bad, c->d_stats, sizeof(bad), hipMemcpyDeviceToHost, c->main()));
+        HIP_TRY(hipStreamSynchronize(c->main()));
         out_divisors[i] = pairs[i][0];
         out_mismatches[2 * i] = bad[0];
         out_mismatches[2 * i + 1] = bad[1];
@@ -1395,6 +1503,7 @@ int32_t ilm_debug_divide_by_constants(IlmHandle hctx, float* out_divisors, uint6
 }
 
 int32_t ilm_debug_step_interpreter(int32_t interpreter) { return (int32_t)set_step_interpreter(interpreter); }
+int32_t ilm_debug_step_streams(int32_t streams) { return (int32_t)set_step_streams(streams); }
 
 int32_t ilm_debug_divide(IlmHandle hctx, const float* numerators, const float* denominators, int32_t count, float* out_fast, float* out_ieee) {
     Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);
@@ -1407,12 +1516,12 @@ int32_t ilm_debug_divide(IlmHandle hctx, const float* numerators, const float* d
     if (rc != ILM_OK) return rc;
     float* d_n = static_cast<float*>(c->staging);
     float* d_d = d_n + count; float* d_f = d_d + count; float* d_i = d_f + count;
-    HIP_TRY(hipMemcpyAsync(d_n, numerators, bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(d_d, denominators, bytes, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(launch_divide_probe(d_n, d_d, count, d_f, d_i, c->stream));
-    HIP_TRY(hipMemcpyAsync(out_fast, d_f, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(out_ieee, d_i, bytes, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(d_n, numerators, bytes, hipMemcpyHostToDevice, c->main()));
+    HIP_TRY(hipMemcpyAsync(d_d, denominators, bytes, hipMemcpyHostToDevice, c->main()));
+    HIP_TRY(launch_divide_probe(d_n, d_d, count, d_f, d_i, c->main()));
+    HIP_TRY(hipMemcpyAsync(out_fast, d_f, bytes, hipMemcpyDeviceToHost, c->main()));
+    HIP_TRY(hipMemcpyAsync(out_ieee, d_i, bytes, hipMemcpyDeviceToHost, c->main()));
+    HIP_TRY(hipStreamSynchronize(c->main()));
     return ILM_OK;
 }
 
@@ -1421,7 +1530,7 @@ int32_t ilm_sdf_destroy(IlmHandle h) {
     if (!f) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle");
     f->ctx->children--;
     (void)hipSetDevice(f->ctx->device);
-    (void)hipStreamSynchronize(f->ctx->stream);
+    (void)hipStreamSynchronize(f->ctx->main());
     if (f->texels) (void)hipFree(f->texels);
     retire_handle(f);
     delete f;
@@ -1433,8 +1542,8 @@ int32_t ilm_sdf_download(IlmHandle h, uint16_t* texels) {
     if (!f) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle");
     if (!texels) return fail(ILM_ERR_INVALID_ARGUMENT, "texels is NULL");
     HIP_TRY(hipSetDevice(f->ctx->device));
-    HIP_TRY(hipMemcpyAsync(texels, f->texels, sizeof(uint2) * (size_t)f->width * (size_t)f->height, hipMemcpyDeviceToHost, f->ctx->stream));
-    HIP_TRY(hipStreamSynchronize(f->ctx->stream));
+    HIP_TRY(hipMemcpyAsync(texels, f->texels, sizeof(uint2) * (size_t)f->width * (size_t)f->height, hipMemcpyDeviceToHost, f->ctx->main()));
+    HIP_TRY(hipStreamSynchronize(f->ctx->main()));
     return ILM_OK;
 }
 
@@ -1539,7 +1648,7 @@ int32_t ilm_sdf_render_slices(IlmHandle h, IlmHandle hclear, const IlmDistanceFi
     const size_t off_poly = align64(off_vols + sizeof(FieldVolume) * vols.size());
     const size_t total = align64(off_poly + sizeof(float) * 2 * (size_t)(vols.empty() ? 0 : polygon_vertex_count));
     if (total > c->field_params_bytes) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(c->main()));
         if (c->d_field_params) HIP_TRY(hipFree(c->d_field_params));
         c->d_field_params = nullptr; c->field_params_bytes = 0;
         const size_t cap = total < 65536 ? 65536 : total * 2;
@@ -1568,7 +1677,7 @@ int32_t ilm_sdf_render_slices(IlmHandle h, IlmHandle hclear, const IlmDistanceFi
     a.slice_count_f = (float)d->SliceCount < 1.0f ? 1.0f : (float)d->SliceCount;   // Math.Max(1, (float)SliceCount), :33
     a.virtual_depth = d->VirtualDepth; a.z_offset = d->ZOffset; a.max_encoded = d->MaximumEncodedDistance;
     a.inv_scale_x = d->InvScaleFactorX; a.inv_scale_y = d->InvScaleFactorY;
-    HIP_TRY(launch_render_slices(a, f->format, c->stream));
+    HIP_TRY(launch_render_slices(a, f->format, c->main()));
     return ILM_OK;
 }
 
@@ -1587,7 +1696,7 @@ int32_t ilm_gbuffer_create(IlmHandle hctx, int32_t w, int32_t ht, int32_t format
     const size_t bytes = (format == ILM_GBUFFER_FLOAT4 ? 16u : 8u) * (size_t)w * (size_t)ht;
     const IlmHandle h = to_handle(g);
     HIP_TRY_OR_DESTROY(hipMalloc(&g->texels, bytes), ilm_gbuffer_destroy(h));
-    HIP_TRY_OR_DESTROY(hipMemsetAsync(g->texels, 0, bytes, c->stream), ilm_gbuffer_destroy(h));
+    HIP_TRY_OR_DESTROY(hipMemsetAsync(g->texels, 0, bytes, c->main()), ilm_gbuffer_destroy(h));
     *out = h;
     return ILM_OK;
 }
@@ -1598,8 +1707,8 @@ int32_t ilm_gbuffer_upload(IlmHandle h, const void* texels) {
     if (!texels) return fail(ILM_ERR_INVALID_ARGUMENT, "texels is NULL");
     HIP_TRY(hipSetDevice(g->ctx->device));
     const size_t bytes = (g->format == ILM_GBUFFER_FLOAT4 ? 16u : 8u) * (size_t)g->width * (size_t)g->height;
-    HIP_TRY(hipMemcpyAsync(g->texels, texels, bytes, hipMemcpyHostToDevice, g->ctx->stream));
-    HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+    HIP_TRY(hipMemcpyAsync(g->texels, texels, bytes, hipMemcpyHostToDevice, g->ctx->main()));
+    HIP_TRY(hipStreamSynchronize(g->ctx->main()));
     return ILM_OK;
 }
 
@@ -1609,8 +1718,8 @@ int32_t ilm_gbuffer_download(IlmHandle h, void* texels) {
     if (!texels) return fail(ILM_ERR_INVALID_ARGUMENT, "texels is NULL");
     HIP_TRY(hipSetDevice(g->ctx->device));
     const size_t bytes = (g->format == ILM_GBUFFER_FLOAT4 ? 16u : 8u) * (size_t)g->width * (size_t)g->height;
-    HIP_TRY(hipMemcpyAsync(texels, g->texels, bytes, hipMemcpyDeviceToHost, g->ctx->stream));
-    HIP_TRY(hipStreamSynchronize(g->ctx->stream));
+    HIP_TRY(hipMemcpyAsync(texels, g->texels, bytes, hipMemcpyDeviceToHost, g->ctx->main()));
+    HIP_TRY(hipStreamSynchronize(g->ctx->main()));
     return ILM_OK;
 }
 
@@ -1651,7 +1760,7 @@ int32_t ilm_gbuffer_render(IlmHandle h, const IlmGBufferRenderDesc* d, const Ilm
     const size_t off_poly = align64(sizeof(GBufferVolume) * vols.size());
     const size_t total = align64(off_poly + sizeof(float) * 2 * (size_t)(vols.empty() ? 0 : polygon_vertex_count)) + 64;
     if (total > c->field_params_bytes) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(c->main()));
         if (c->d_field_params) HIP_TRY(hipFree(c->d_field_params));
         c->d_field_params = nullptr; c->field_params_bytes = 0;
         const size_t cap = total < 65536 ? 65536 : total * 2;
@@ -1670,7 +1779,7 @@ int32_t ilm_gbuffer_render(IlmHandle h, const IlmGBufferRenderDesc* d, const Ilm
     a.desc = *d;
     a.volumes = reinterpret_cast<const GBufferVolume*>(c->d_field_params); a.volume_count = (int32_t)vols.size();
     a.polygon_xy = reinterpret_cast<const float2*>(static_cast<char*>(c->d_field_params) + off_poly);
-    HIP_TRY(launch_render_gbuffer(a, c->stream));
+    HIP_TRY(launch_render_gbuffer(a, c->main()));
     return ILM_OK;
 }
 
@@ -1679,7 +1788,7 @@ int32_t ilm_gbuffer_destroy(IlmHandle h) {
     if (!g) return fail(ILM_ERR_INVALID_HANDLE, "not a G-buffer handle");
     g->ctx->children--;
     (void)hipSetDevice(g->ctx->device);
-    (void)hipStreamSynchronize(g->ctx->stream);
+    (void)hipStreamSynchronize(g->ctx->main());
     if (g->texels) (void)hipFree(g->texels);
     retire_handle(g);
     delete g;
@@ -1705,7 +1814,7 @@ int32_t ilm_lightmap_create(IlmHandle hctx, int32_t w, int32_t ht, int32_t forma
     } else {
         const size_t bytes = lightmap_texel_bytes(format) * (size_t)w * (size_t)ht;
         HIP_TRY_OR_DESTROY(hipMalloc(&m->texels, bytes), ilm_lightmap_destroy(h));
-        HIP_TRY_OR_DESTROY(hipMemsetAsync(m->texels, 0, bytes, c->stream), ilm_lightmap_destroy(h));
+        HIP_TRY_OR_DESTROY(hipMemsetAsync(m->texels, 0, bytes, c->main()), ilm_lightmap_destroy(h));
     }
     *out = h;
     return ILM_OK;
@@ -1720,8 +1829,8 @@ int32_t ilm_lightmap_download(IlmHandle h, void* dst, int32_t first_row, int32_t
     HIP_TRY(hipSetDevice(m->ctx->device));
     const size_t row_bytes = lightmap_texel_bytes(m->format) * (size_t)m->width;
     HIP_TRY(hipMemcpyAsync(dst, static_cast<const char*>(m->texels) + row_bytes * (size_t)first_row, row_bytes * (size_t)row_count,
-                           hipMemcpyDeviceToHost, m->ctx->stream));
-    HIP_TRY(hipStreamSynchronize(m->ctx->stream));
+                           hipMemcpyDeviceToHost, m->ctx->main()));
+    HIP_TRY(hipStreamSynchronize(m->ctx->main()));
     return ILM_OK;
 }
 
@@ -1737,7 +1846,7 @@ int32_t ilm_lightmap_destroy(IlmHandle h) {
     if (!m) return fail(ILM_ERR_INVALID_HANDLE, "not a lightmap handle");
     m->ctx->children--;
     (void)hipSetDevice(m->ctx->device);
-    (void)hipStreamSynchronize(m->ctx->stream);
+    (void)hipStreamSynchronize(m->ctx->main());
     if (m->texels && !m->external) (void)hipFree(m->texels);
     retire_handle(m);
     delete m;
@@ -1817,7 +1926,7 @@ int32_t ilm_render_particle_lights(IlmHandle hctx, IlmHandle hsystem, const int3
     const int blocks_per_chunk = (e->slots + 1023) / 1024;
     const int blocks = chunk_count * blocks_per_chunk;
     if ((int)total > c->pl_cap) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(c->main()));
         if (c->d_pl_recs) HIP_TRY(hipFree(c->d_pl_recs));
         c->d_pl_recs = nullptr; c->pl_cap = 0;
         const int cap = (int)total < 4096 ? 4096 : (int)total;
@@ -1826,14 +1935,14 @@ int32_t ilm_render_particle_lights(IlmHandle hctx, IlmHandle hsystem, const int3
     }
     if (!c->d_pl_count) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_pl_count), sizeof(int32_t)));
     if (blocks > c->pl_blocks_cap) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(c->main()));
         if (c->d_pl_blocks) HIP_TRY(hipFree(c->d_pl_blocks));
         c->d_pl_blocks = nullptr;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_pl_blocks), sizeof(int32_t) * (size_t)blocks * 2));
         c->pl_blocks_cap = blocks * 2;
     }
     if (chunk_count > c->pl_quads_cap) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(c->main()));
         if (c->d_pl_quads) HIP_TRY(hipFree(c->d_pl_quads));
         c->d_pl_quads = nullptr;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_pl_quads), sizeof(int32_t) * (size_t)chunk_count * 2));
@@ -1849,20 +1958,20 @@ int32_t ilm_render_particle_lights(IlmHandle hctx, IlmHandle hsystem, const int3
     pl.params = *params; pl.env = *env; pl.max_cone_radius = df->ConeAndMisc.x;
     pl.gate = make_trace_gate(*df, a.sdf);
     pl.block_counts = c->d_pl_blocks; pl.recs = c->d_pl_recs; pl.capacity = c->pl_cap; pl.out_count = c->d_pl_count;
-    HIP_TRY(launch_prepare_particle_lights(pl, c->stream));
+    HIP_TRY(launch_prepare_particle_lights(pl, c->main()));
 
     a.light_count = 0;
     a.light_count_ptr = c->d_pl_count;
     a.accumulate = 1;
     if (stats) {
-        HIP_TRY(hipMemsetAsync(c->d_stats, 0, 3 * sizeof(unsigned long long), c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_stats, 0, 3 * sizeof(unsigned long long), c->main()));
         a.stats = c->d_stats;
     }
-    HIP_TRY(launch_sphere_lights_prepared(a, c->d_pl_recs, c->stream));
+    HIP_TRY(launch_sphere_lights_prepared(a, c->d_pl_recs, c->main()));
     if (stats) {
         unsigned long long host[3] = { 0, 0, 0 };
-        HIP_TRY(hipMemcpyAsync(host, c->d_stats, sizeof(host), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpyAsync(host, c->d_stats, sizeof(host), hipMemcpyDeviceToHost, c->main()));
+        HIP_TRY(hipStreamSynchronize(c->main()));
         stats->SdfSamples = host[0]; stats->PixelLightPairs = host[1]; stats->TracedPairs = host[2];
     }
     return ILM_OK;
@@ -1883,7 +1992,7 @@ int32_t ilm_render_light_probes(IlmHandle hctx, const IlmLightVertex* lights, in
     if (probe_count == 0) return ILM_OK;
     HIP_TRY(hipSetDevice(c->device));
     if (light_count > c->light_cap) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(c->main()));
         if (c->d_lights) HIP_TRY(hipFree(c->d_lights));
         if (c->d_recs) HIP_TRY(hipFree(c->d_recs));
         c->d_lights = nullptr; c->d_recs = nullptr;
@@ -1895,10 +2004,10 @@ int32_t ilm_render_light_probes(IlmHandle hctx, const IlmLightVertex* lights, in
     if (light_count > 0) {
         int32_t rc = upload_small(c, c->d_lights, lights, sizeof(IlmLightVertex) * (size_t)light_count);
         if (rc != ILM_OK) return rc;
-        HIP_TRY(launch_prepare_lights(c->d_lights, light_count, *env, *df, make_sdf_view(f, df), c->d_recs, c->stream));
+        HIP_TRY(launch_prepare_lights(c->d_lights, light_count, *env, *df, make_sdf_view(f, df), c->d_recs, c->main()));
     }
     if (probe_count > c->probes_cap) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(c->main()));
         if (c->d_probes) HIP_TRY(hipFree(c->d_probes));
         c->d_probes = nullptr;
         const int cap = probe_count < 256 ? 256 : probe_count * 2;
@@ -1913,9 +2022,9 @@ int32_t ilm_render_light_probes(IlmHandle hctx, const IlmLightVertex* lights, in
     rc = upload_small(c, d_nrm, probe_normals, sizeof(float4) * (size_t)probe_count);
     if (rc != ILM_OK) return rc;
     HIP_TRY(launch_light_probes(c->d_recs, light_count, d_pos, d_nrm, probe_count, *env, *df, make_sdf_view(f, df),
-                                RampView{ c->d_light_ramp, c->light_ramp_w, c->light_ramp_h }, d_val, c->stream));
-    HIP_TRY(hipMemcpyAsync(out_values, d_val, sizeof(float4) * (size_t)probe_count, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+                                RampView{ c->d_light_ramp, c->light_ramp_w, c->light_ramp_h }, d_val, c->main()));
+    HIP_TRY(hipMemcpyAsync(out_values, d_val, sizeof(float4) * (size_t)probe_count, hipMemcpyDeviceToHost, c->main()));
+    HIP_TRY(hipStreamSynchronize(c->main()));
     return ILM_OK;
 }
 
@@ -1933,7 +2042,7 @@ static int32_t readback_to_pinned(System* s, const int32_t* element_counts, int3
     if (rc != ILM_OK) return rc;
     const int blocks = chunk_count * ((e->slots + 1023) / 1024);
     if (capacity > c->rb_cap) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(c->main()));
         if (c->d_rb) HIP_TRY(hipFree(c->d_rb));
         c->d_rb = nullptr; c->rb_cap = 0;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_rb), sizeof(IlmReadbackDrawCall) * (size_t)capacity));
@@ -1941,14 +2050,14 @@ static int32_t readback_to_pinned(System* s, const int32_t* element_counts, int3
     }
     if (!c->d_rb_count) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_rb_count), sizeof(int32_t)));
     if (blocks > c->rb_blocks_cap) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(c->main()));
         if (c->d_rb_blocks) HIP_TRY(hipFree(c->d_rb_blocks));
         c->d_rb_blocks = nullptr;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_rb_blocks), sizeof(int32_t) * (size_t)blocks * 2));
         c->rb_blocks_cap = blocks * 2;
     }
     if (chunk_count > c->rb_elems_cap) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(c->main()));
         if (c->d_rb_elems) HIP_TRY(hipFree(c->d_rb_elems));
         c->d_rb_elems = nullptr;
         HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_rb_elems), sizeof(int32_t) * (size_t)chunk_count * 2));
@@ -1970,10 +2079,10 @@ static int32_t readback_to_pinned(System* s, const int32_t* element_counts, int3
     a.max_angle_x = (2 * 3.14159265358979323846) / a.frame_count_x;
     a.max_angle_y = (2 * 3.14159265358979323846) / a.frame_count_y;
     a.block_counts = c->d_rb_blocks; a.out = c->d_rb; a.capacity = capacity; a.out_count = c->d_rb_count;
-    HIP_TRY(launch_readback(a, c->stream));
+    HIP_TRY(launch_readback(a, c->main()));
     int32_t total = 0;
-    HIP_TRY(hipMemcpyAsync(&total, c->d_rb_count, sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpyAsync(&total, c->d_rb_count, sizeof(int32_t), hipMemcpyDeviceToHost, c->main()));
+    HIP_TRY(hipStreamSynchronize(c->main()));
     *out_total = total;
     const int n_copy = total < capacity ? total : capacity;
     if (n_copy > 0) {
@@ -1986,8 +2095,8 @@ static int32_t readback_to_pinned(System* s, const int32_t* element_counts, int3
             HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&c->h_rb), sizeof(IlmReadbackDrawCall) * cap, hipHostMallocDefault));
             c->h_rb_cap = cap;
         }
-        HIP_TRY(hipMemcpyAsync(c->h_rb, c->d_rb, sizeof(IlmReadbackDrawCall) * (size_t)n_copy, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpyAsync(c->h_rb, c->d_rb, sizeof(IlmReadbackDrawCall) * (size_t)n_copy, hipMemcpyDeviceToHost, c->main()));
+        HIP_TRY(hipStreamSynchronize(c->main()));
     }
     return ILM_OK;
 }
@@ -2041,7 +2150,7 @@ int32_t ilm_system_set_bitmap(IlmHandle h, const IlmFloat4* texels, int32_t widt
         return fail(ILM_ERR_INVALID_ARGUMENT, "bad bitmap (%d x %d)", width, height);
     Ctx* c = s->engine->ctx;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));     // an earlier render may still read the old bitmap
+    HIP_TRY(hipStreamSynchronize(c->main()));     // an earlier render may still read the old bitmap
     if (s->bitmap) HIP_TRY(hipFree(s->bitmap));
     s->bitmap = nullptr; s->bitmap_w = s->bitmap_h = 0;
     if (width == 0) return ILM_OK;
@@ -2060,7 +2169,7 @@ int32_t ilm_ctx_set_light_ramp(IlmHandle hctx, const IlmFloat4* texels, int32_t 
     const bool none = (width == 0) || (width == 1 && height == 1);
     if (none && !c->d_light_ramp) return ILM_OK;  // nothing bound, nothing to unbind: no synchronisation
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipStreamSynchronize(c->stream));     // an earlier pass may still read the old ramp
+    HIP_TRY(hipStreamSynchronize(c->main()));     // an earlier pass may still read the old ramp
     if (c->d_light_ramp) HIP_TRY(hipFree(c->d_light_ramp));
     c->d_light_ramp = nullptr; c->light_ramp_w = c->light_ramp_h = 0;
     // a 1 x 1 ramp is no ramp (LightingRenderer.cs:822-827)
@@ -2077,7 +2186,7 @@ int32_t ilm_lightmap_clear(IlmHandle h, const float rgba[4]) {
     if (!m) return fail(ILM_ERR_INVALID_HANDLE, "not a lightmap handle");
     if (!rgba) return fail(ILM_ERR_INVALID_ARGUMENT, "rgba is NULL");
     HIP_TRY(hipSetDevice(m->ctx->device));
-    HIP_TRY(launch_clear_target(m->texels, m->format, (size_t)m->width * (size_t)m->height, make_float4(rgba[0], rgba[1], rgba[2], rgba[3]), m->ctx->stream));
+    HIP_TRY(launch_clear_target(m->texels, m->format, (size_t)m->width * (size_t)m->height, make_float4(rgba[0], rgba[1], rgba[2], rgba[3]), m->ctx->main()));
     return ILM_OK;
 }
 
@@ -2121,7 +2230,7 @@ int32_t ilm_render_particles(IlmHandle hsystem, const int32_t* quad_counts, int3
     if (rc != ILM_OK) return rc;
     if (quad_counts) {
         if (chunk_count > c->raster_quads_cap) {
-            HIP_TRY(hipStreamSynchronize(c->stream));
+            HIP_TRY(hipStreamSynchronize(c->main()));
             if (c->d_raster_quads) HIP_TRY(hipFree(c->d_raster_quads));
             c->d_raster_quads = nullptr; c->raster_quads_cap = 0;
             HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_raster_quads), sizeof(int32_t) * (size_t)chunk_count * 2));
@@ -2142,7 +2251,7 @@ int32_t ilm_render_particles(IlmHandle hsystem, const int32_t* quad_counts, int3
     a.bitmap = s->bitmap; a.bitmap_w = s->bitmap_w; a.bitmap_h = s->bitmap_h;
     unsigned long long stats[3] = { 0, 0, 0 };
     bool too_many = false;
-    HIP_TRY(render_particles(a, c->raster, c->stream, out_stats ? stats : nullptr, &too_many));
+    HIP_TRY(render_particles(a, c->raster, c->main(), out_stats ? stats : nullptr, &too_many));
     if (too_many) return fail(ILM_ERR_TOO_MANY, "more than 2^28 (quad, tile) pairs: the quads are too large for this path");
     if (out_stats) { out_stats[0] = stats[0]; out_stats[1] = stats[1]; out_stats[2] = stats[2]; }
     return ILM_OK;
@@ -2184,7 +2293,7 @@ int32_t ilm_resolve_lighting(IlmHandle hsrc, IlmHandle hdst, const IlmHDRConfigu
     a.inv_average_luminance = 1.0f / clamp(hdr->AverageLuminance, min_v, max_v);
     const float maximum_luminance = clamp(hdr->MaximumLuminance, min_v, max_v);
     a.inv_maximum_luminance_squared = 1.0f / (maximum_luminance * maximum_luminance);
-    HIP_TRY(launch_resolve(a, c->stream));
+    HIP_TRY(launch_resolve(a, c->main()));
     return ILM_OK;
 }
 
@@ -2208,7 +2317,7 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
     HIP_TRY(hipSetDevice(c->device));
 
     if (light_count > c->light_cap) {
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipStreamSynchronize(c->main()));
         if (c->d_lights) HIP_TRY(hipFree(c->d_lights));
         if (c->d_recs) HIP_TRY(hipFree(c->d_recs));
         c->d_lights = nullptr; c->d_recs = nullptr;
@@ -2220,7 +2329,7 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
     if (light_count > 0) {
         int32_t rc = upload_small(c, c->d_lights, lights, sizeof(IlmLightVertex) * (size_t)light_count);
         if (rc != ILM_OK) return rc;
-        HIP_TRY(launch_prepare_lights(c->d_lights, light_count, *env, *df, make_sdf_view(f, df), c->d_recs, c->stream));
+        HIP_TRY(launch_prepare_lights(c->d_lights, light_count, *env, *df, make_sdf_view(f, df), c->d_recs, c->main()));
     }
 
     LightLaunch a;
@@ -2239,14 +2348,14 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
     a.ramp = RampView{ c->d_light_ramp, c->light_ramp_w, c->light_ramp_h };
     a.tile_map = light_tile_map();
     if (stats) {
-        HIP_TRY(hipMemsetAsync(c->d_stats, 0, 3 * sizeof(unsigned long long), c->stream));
+        HIP_TRY(hipMemsetAsync(c->d_stats, 0, 3 * sizeof(unsigned long long), c->main()));
         a.stats = c->d_stats;
     }
-    HIP_TRY(launch_sphere_lights_prepared(a, c->d_recs, c->stream));
+    HIP_TRY(launch_sphere_lights_prepared(a, c->d_recs, c->main()));
     if (stats) {
         unsigned long long host[3] = { 0, 0, 0 };
-        HIP_TRY(hipMemcpyAsync(host, c->d_stats, sizeof(host), hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        HIP_TRY(hipMemcpyAsync(host, c->d_stats, sizeof(host), hipMemcpyDeviceToHost, c->main()));
+        HIP_TRY(hipStreamSynchronize(c->main()));
         stats->SdfSamples = host[0]; stats->PixelLightPairs = host[1]; stats->TracedPairs = host[2];
     }
     return ILM_OK;

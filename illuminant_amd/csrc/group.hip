@@ -87,7 +87,8 @@ struct Group {
     int children = 0;                       // live group lightmaps
     std::vector<int> devices;
     std::vector<IlmHandle> ctx;
-    std::vector<hipStream_t> streams;
+    // a member's context stream, joined with the context's second stepping stream (api.hip, Ctx::main) at every use
+    hipStream_t stream(size_t i) const { return ctx_stream_joined(ctx[i]); }
     std::vector<hipEvent_t> events;         // one per local member: "my pushes have been queued / finished" (peer fan-out)
     std::vector<ncclComm_t> comms;          // one per local member once a communicator exists
     bool duplicates = false;                // two members share a device (RCCL refuses that)
@@ -122,10 +123,6 @@ int32_t make_members(Group* g) {
         const int32_t rc = ilm_ctx_create(g->devices[(size_t)i], &c);
         if (rc != ILM_OK) return rc;
         g->ctx.push_back(c);
-        void* s = nullptr;
-        const int32_t rs = ilm_ctx_stream(c, &s);
-        if (rs != ILM_OK) return rs;
-        g->streams.push_back(reinterpret_cast<hipStream_t>(s));
         HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
         hipEvent_t e = nullptr;
         HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -191,12 +188,12 @@ int32_t all_gather(Group* g, void* const* buffers, size_t bytes, int gather) {
         //    start before the destination has finished the work queued before this call: every stream waits for every other's "here" event
         for (int i = 0; i < n; i++) {
             HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
-            HIP_TRY(hipEventRecord(g->events[(size_t)i], g->streams[(size_t)i]));
+            HIP_TRY(hipEventRecord(g->events[(size_t)i], g->stream((size_t)i)));
         }
         for (int i = 0; i < n; i++) {
             HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
             for (int j = 0; j < n; j++)
-                if (j != i) HIP_TRY(hipStreamWaitEvent(g->streams[(size_t)i], g->events[(size_t)j], 0));
+                if (j != i) HIP_TRY(hipStreamWaitEvent(g->stream((size_t)i), g->events[(size_t)j], 0));
         }
         // 2. member i pushes its slot to the n - 1 others on its own stream: on a full xGMI mesh that is one transfer per link
         for (int i = 0; i < n; i++) {
@@ -205,15 +202,15 @@ int32_t all_gather(Group* g, void* const* buffers, size_t bytes, int gather) {
             for (int k = 1; k < n; k++) {
                 const int j = (i + k) % n;            // staggered destinations: no two members start on the same target
                 HIP_TRY(hipMemcpyPeerAsync(static_cast<char*>(buffers[j]) + off, g->devices[(size_t)j],
-                                           static_cast<const char*>(buffers[i]) + off, g->devices[(size_t)i], bytes, g->streams[(size_t)i]));
+                                           static_cast<const char*>(buffers[i]) + off, g->devices[(size_t)i], bytes, g->stream((size_t)i)));
             }
-            HIP_TRY(hipEventRecord(g->events[(size_t)i], g->streams[(size_t)i]));
+            HIP_TRY(hipEventRecord(g->events[(size_t)i], g->stream((size_t)i)));
         }
         // 3. a member's later work sees the whole frame: its stream waits for every push
         for (int i = 0; i < n; i++) {
             HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
             for (int j = 0; j < n; j++)
-                if (j != i) HIP_TRY(hipStreamWaitEvent(g->streams[(size_t)i], g->events[(size_t)j], 0));
+                if (j != i) HIP_TRY(hipStreamWaitEvent(g->stream((size_t)i), g->events[(size_t)j], 0));
         }
         return ILM_OK;
     }
@@ -226,7 +223,7 @@ int32_t all_gather(Group* g, void* const* buffers, size_t bytes, int gather) {
         HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
         char* buf = static_cast<char*>(buffers[i]);
         // in place: the send buffer is this rank's slot of the receive buffer
-        NCCL_TRY(r.AllGather(buf + (size_t)(g->first_rank + i) * bytes, buf, bytes, ncclInt8, g->comms[(size_t)i], g->streams[(size_t)i]));
+        NCCL_TRY(r.AllGather(buf + (size_t)(g->first_rank + i) * bytes, buf, bytes, ncclInt8, g->comms[(size_t)i], g->stream((size_t)i)));
     }
     NCCL_TRY(r.GroupEnd());
     return ILM_OK;
@@ -243,18 +240,18 @@ int32_t host_all_gather(Group* g, const void* local, void* out, size_t bytes) {
     const size_t total = bytes * (size_t)g->world;
     HIP_TRY(hipSetDevice(g->devices[0]));
     if (total > g->counts_bytes) {
-        if (g->d_counts) { HIP_TRY(hipStreamSynchronize(g->streams[0])); HIP_TRY(hipFree(g->d_counts)); g->d_counts = nullptr; g->counts_bytes = 0; }
+        if (g->d_counts) { HIP_TRY(hipStreamSynchronize(g->stream((size_t)0))); HIP_TRY(hipFree(g->d_counts)); g->d_counts = nullptr; g->counts_bytes = 0; }
         const size_t cap = total < 4096 ? 4096 : total;
         HIP_TRY(hipMalloc(&g->d_counts, cap));
         g->counts_bytes = cap;
     }
     char* d = static_cast<char*>(g->d_counts);
-    HIP_TRY(hipMemcpyAsync(d + mine, o + mine, bytes, hipMemcpyHostToDevice, g->streams[0]));
+    HIP_TRY(hipMemcpyAsync(d + mine, o + mine, bytes, hipMemcpyHostToDevice, g->stream((size_t)0)));
     void* bufs[1] = { g->d_counts };
     const int32_t rc = all_gather(g, bufs, bytes, ILM_GATHER_RCCL);
     if (rc != ILM_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(o, d, total, hipMemcpyDeviceToHost, g->streams[0]));
-    HIP_TRY(hipStreamSynchronize(g->streams[0]));
+    HIP_TRY(hipMemcpyAsync(o, d, total, hipMemcpyDeviceToHost, g->stream((size_t)0)));
+    HIP_TRY(hipStreamSynchronize(g->stream((size_t)0)));
     return ILM_OK;
 }
 
@@ -417,7 +414,7 @@ int32_t ilm_group_lightmap_create(IlmHandle h, int32_t width, int32_t height, in
         void* p = nullptr;
         hipError_t e = hipSetDevice(g->devices[(size_t)i]);
         if (e == hipSuccess) e = hipMalloc(&p, bytes);
-        if (e == hipSuccess) e = hipMemsetAsync(p, 0, bytes, g->streams[(size_t)i]);
+        if (e == hipSuccess) e = hipMemsetAsync(p, 0, bytes, g->stream((size_t)i));
         if (e != hipSuccess) {
             if (p) (void)hipFree(p);
             const int32_t rc = api_fail((int32_t)e, "group lightmap of %zu bytes on device %d: %s", bytes, g->devices[(size_t)i], hipGetErrorString(e));
@@ -441,7 +438,7 @@ int32_t ilm_group_lightmap_destroy(IlmHandle h) {
     for (IlmHandle lm : m->lightmaps) (void)ilm_lightmap_destroy(lm);        // synchronises the member's stream
     for (size_t i = 0; i < m->buffers.size(); i++) {
         (void)hipSetDevice(g->devices[i]);
-        (void)hipStreamSynchronize(g->streams[i]);
+        (void)hipStreamSynchronize(g->stream((size_t)i));
         (void)hipFree(m->buffers[i]);
     }
     g->children--;

@@ -75,7 +75,8 @@ struct StepLaunch {
     IlmStepDesc desc;
     StepDerived derived;
     float* const* chunk_bases;   // device table, one base pointer per chunk
-    int64_t stride;              // floats between component planes (multiple of kSlotsPerBlock)
+    int64_t stride;              // floats between component planes: span + the engine's plane padding (api.hip, ilm_engine_create)
+    int32_t span;                // slots rounded up to kSlotsPerBlock: the units a launch walks per chunk are span / 64
     int32_t chunk_size;
     int32_t slots;               // chunk_size^2: lanes at or past it are stride padding (the stride is rounded up to 1024) and take no part
     int32_t first_chunk, chunk_count;
@@ -116,18 +117,21 @@ struct StepLaunch {
 
 static_assert(sizeof(StepLaunch) <= 4096, "StepLaunch travels in the kernarg segment (4 KB)");
 
-// per-chunk live counters are kCountStride uint32 apart (one 128-byte line each)
+// per-chunk live counters are kCountStride 64-bit words apart (one 128-byte line each)
 constexpr int kCountStride = 16;     // in 64-bit words
 constexpr int kCountLines = 17;      // per chunk in the step kernels' counter regions: the chunk's line + 16 bucket lines
 hipError_t launch_step(StepLaunch& a, hipStream_t stream);
 int set_step_interpreter(int on);     // ilm_debug_step_interpreter: returns the previous setting
+int set_step_streams(int n);          // ilm_debug_step_streams: 1 keeps every step on the context stream, 2 (default) lets large steps use two; returns the previous setting
+// the context's stream for work that is not a particle step: ordered after everything the context's second stepping stream holds (api.hip)
+hipStream_t ctx_stream_joined(IlmHandle ctx);
 
 // AoS float4 (device staging) <-> one SoA plane group (4 consecutive components)
 hipError_t launch_aos_to_soa(const float4* src, float* plane0, int64_t stride, int32_t first_slot, int32_t count, hipStream_t stream);
 hipError_t launch_soa_to_aos(const float* plane0, int64_t stride, float4* dst, int32_t first_slot, int32_t count, hipStream_t stream);
 
 // standalone liveness count over the life plane of each chunk (CountLiveParticles.fx)
-hipError_t launch_count_live(float* const* chunk_bases, int64_t stride, int32_t slots, int32_t chunk_count, uint32_t* counts, hipStream_t stream);
+hipError_t launch_count_live(float* const* chunk_bases, int64_t stride, int32_t span, int32_t slots, int32_t chunk_count, uint32_t* counts, hipStream_t stream);
 // ordered live-slot compaction of one chunk (ballot + prefix sum); *out_count is a device counter
 hipError_t launch_live_slots(const float* life, int32_t slots, uint32_t* out_slots, uint32_t capacity, uint32_t* out_count, hipStream_t stream);
 

@@ -1230,10 +1230,31 @@ static_assert(offsetof(StepDerived::NoiseFast, velocity) == offsetof(StepDerived
 
 typedef const LeanStep __attribute__((address_space(4))) CLeanStep;
 
+// The launch descriptor is written by the host into the kernarg ring just before the launch, so the first wave of every scalar cache
+// misses on each of its 64-byte lines all the way to memory -- and the step reads them one dependent phase after another (decode,
+// planes, noise tables, each transform, the update pass): a chain of ~20 serial misses at the head of every launch.  One load per
+// line, all in flight at once, turns the chain into a single miss; for every later wave they are ~60 cache hits the scalar pipe has
+// room for (tools/step_ab.py with 200 extra scalar instructions per wave: no change in step time).  Measured (r02): a one-chunk launch
+// 7.7 -> 6.0 us back to back (10.8 -> 8.3 us when it spawns), cfg2 without a spawner 24.0 -> 21.4 us per step.
+constexpr int kTouchBlocks = 512;
+#define ILM_T1(o) "s_load_dword %0, %1, " #o "\n"
+#define ILM_T4(o) ILM_T1(o) ILM_T1(o + 0x40) ILM_T1(o + 0x80) ILM_T1(o + 0xc0)
+#define ILM_T16(o) ILM_T4(o) ILM_T4(o + 0x100) ILM_T4(o + 0x200) ILM_T4(o + 0x300)
+ILM_DEV void touch_kernarg_lines() {
+    const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t sink;
+    asm volatile(ILM_T16(0x0) ILM_T16(0x400) ILM_T16(0x800) ILM_T1(0xc00) ILM_T1(0xc40) ILM_T1(0xc80) "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(sink) : "s"(kp) : "memory");
+}
+static_assert(sizeof(LeanStep) >= 0xc84 && sizeof(LeanStep) <= 0xcc0, "touch_kernarg_lines reads one dword of each 64-byte line of LeanStep");
+
 template <bool SPAWN, bool STREAM>
 __global__ __launch_bounds__(kStepThreads) void step_lean_kernel(const LeanStep a_) {
     __shared__ uint32_t wave_live[kStepThreads / 64];
     const LeanStep& a = *(const LeanStep*)(CLeanStep*)__builtin_amdgcn_kernarg_segment_ptr();
+    // (only the launch's first generation of blocks can be the first to read a line; for the others the loads would just load the
+    // scalar cache: one lookup per line per wave)
+    if (blockIdx.x < kTouchBlocks) touch_kernarg_lines();
     const unsigned lane = threadIdx.x & 63u;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     int v = (int)blockIdx.x * (kStepThreads / 64) + a.unit_rotate;      // first unit of the block (rotation: see step_kernel)
@@ -1333,7 +1354,7 @@ static bool build_lean_step(const StepLaunch& a, LeanStep& f) {
     if (kUnitsPerWave != 1) return false;
     if (d.UpdateMode != ILM_UPDATE_POSITIONS) return false;
     if (a.derived.cs_shift < 6 || a.upc_shift < 0) return false;                   // power-of-two chunk size >= 64: no stride padding, a unit lies in one row
-    if ((int64_t)a.slots != a.stride) return false;
+    if (a.slots != a.span) return false;
     if (a.derived.noise_may_revive != 0) return false;
     if (a.derived.update_bits & 1u) return false;                                   // life ramp
     if (a.op_mask & ~((1u << ILM_OP_GRAVITY) | (1u << ILM_OP_NOISE) | (1u << ILM_OP_FMA))) return false;
@@ -1488,7 +1509,7 @@ int set_step_interpreter(int on) {
 // One launch per ParticleSystem.Update: the unit range covers every chunk of the step; when spawn records are
 // present the SPAWN variant runs (for every unit) and the grid is rotated to start at the first spawn range.
 hipError_t launch_step(StepLaunch& a, hipStream_t stream) {
-    a.units_per_chunk = (int)(a.stride / 64);
+    a.units_per_chunk = a.span / 64;
     a.upc_shift = -1;
     for (int b = 0; b < 31; b++)
         if ((1 << b) == a.units_per_chunk) a.upc_shift = b;
@@ -1568,9 +1589,9 @@ __global__ __launch_bounds__(256) void count_live_kernel(float* const* __restric
         if (total != 0) atomicAdd(&counts[chunk * kCountStride], total);
     }
 }
-hipError_t launch_count_live(float* const* chunk_bases, int64_t stride, int32_t slots, int32_t chunk_count, uint32_t* counts, hipStream_t stream) {
+hipError_t launch_count_live(float* const* chunk_bases, int64_t stride, int32_t span, int32_t slots, int32_t chunk_count, uint32_t* counts, hipStream_t stream) {
     if (chunk_count <= 0) return hipSuccess;
-    hipLaunchKernelGGL(count_live_kernel, dim3((unsigned)(stride / 1024), (unsigned)chunk_count), dim3(256), 0, stream, chunk_bases, stride, slots, counts);
+    hipLaunchKernelGGL(count_live_kernel, dim3((unsigned)(span / 1024), (unsigned)chunk_count), dim3(256), 0, stream, chunk_bases, stride, slots, counts);
     return hipGetLastError();
 }
 

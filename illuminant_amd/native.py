@@ -12,7 +12,8 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libilluminant_hip.so")
+# ILM_HIP_LIB: a variant build of the same library for on-box A/B runs (tools/ab_build.sh)
+LIB_PATH = os.environ.get("ILM_HIP_LIB") or os.path.join(_HERE, "lib", "libilluminant_hip.so")
 
 _lib = None
 
@@ -73,6 +74,7 @@ SYMBOLS = {
     "ilm_debug_sdf_sample_inside": (_I, [_H, _P, _P, _I, _P, _P]),
     "ilm_debug_divide": (_I, [_H, _P, _P, _I, _P, _P]),
     "ilm_debug_step_interpreter": (_I, [_I]),
+    "ilm_debug_step_streams": (_I, [_I]),
     "ilm_debug_divide_by_constants": (_I, [_H, _P, _P, _I, C.POINTER(_I)]),
     "ilm_sdf_destroy": (_I, [_H]),
     "ilm_sdf_download": (_I, [_H, _P]),

@@ -483,6 +483,11 @@ int32_t ilm_debug_divide(IlmHandle ctx, const float* numerators, const float* de
  * per-slot arithmetic is the same.  interpreter != 0 forces the interpreting kernel for every later step of this process (0: the
  * default choice) so that a test can hold the two bit-equal; returns the previous setting.  Environment: ILM_STEP_LEAN=0. */
 int32_t ilm_debug_step_interpreter(int32_t interpreter);
+/* A step over at least two chunks and half a million slots puts the second half of its chunk range on a second stream of the context
+ * (chunks never interact, ParticleSystem.cs:743-745; every other entry point waits for both streams before it touches anything).
+ * streams == 1 keeps every later step of this process on the context stream, 2 restores the default; returns the previous setting.
+ * Environment: ILM_STEP_STREAMS=1.  A context whose stream was handed out by ilm_ctx_stream never splits. */
+int32_t ilm_debug_step_streams(int32_t streams);
 int32_t ilm_sdf_destroy(IlmHandle sdf);
 /* DistanceField.Save (Illuminant/SDF/DistanceField.cs:178-194): the atlas bytes, 8 per texel, row-major. */
 int32_t ilm_sdf_download(IlmHandle sdf, uint16_t* texels);

@@ -198,3 +198,92 @@ def test_counts_of_consecutive_counting_steps_do_not_mix(ctx):
     assert np.array_equal(counts, s.live_counts())
     s.close()
     eng.close()
+
+
+def test_two_stream_steps_equal_one_stream_steps(ctx):
+    """A step over >= 8192 units runs its two chunk halves on two streams that nothing joins between steps (api.hip, run_step);
+    every other entry point joins them first.  Interleave steps with uploads, downloads, standalone counts, a chunk removal and a
+    chunk added while the split is in force: the planes and counts equal the one-stream run's bit for bit."""
+    cs, n_chunks = 256, 16
+    n = cs * cs
+    rnd = scenes.randomness_table(13)
+    eng = native.Engine(ctx, cs, rnd)
+    pos, vel, attr = scenes.make_particles(31, n * 4, pos_hi=(1920, 1080, 32), life=(0.05, 3.0), dead_fraction=0.1)
+    patch = scenes.make_particles(32, 5000, pos_hi=(1920, 1080, 32), life=(0.5, 1.0))
+    shape = dict(ops=("gravity", "noise"), spawns=((16, 0, 2000),))
+    results = []
+    prev = native.lib().ilm_debug_step_streams(2)
+    try:
+        for streams in (2, 1):
+            native.lib().ilm_debug_step_streams(streams)
+            s = native.System(eng)
+            for c in range(n_chunks + 1):
+                s.add_chunk()
+            for c in range(n_chunks):
+                k = (c % 4) * n
+                s.upload(c, P, np.roll(pos[k:k + n], c * 131, axis=0)); s.upload(c, V, vel[k:k + n]); s.upload(c, A, attr[k:k + n])
+            log = []
+            for i in range(12):
+                d = _step(cs, shape)
+                if i % 4 != 1:
+                    d.Flags = 0
+                s.step(d)
+                if i % 4 == 1:
+                    log.append(s.step_counts().copy())
+                if i == 2:      # an upload into a chunk of the second half, right behind a step
+                    s.upload(11, P, patch[0], first_slot=777); s.upload(11, V, patch[1], first_slot=777)
+                if i == 3:      # a download of both halves right behind a step
+                    log.append(s.download(2, P).copy()); log.append(s.download(14, V).copy())
+                if i == 5:
+                    log.append(s.live_counts().copy())
+                if i == 6:      # the table shrinks: chunks 5.. move down one index, the halves are cut anew
+                    s.remove_chunk(4)
+                    shape = dict(ops=("gravity", "noise"), spawns=((15, 0, 2000),))
+                if i == 8:      # ... and grows again
+                    c_new = s.add_chunk()
+                    s.upload(c_new, P, pos[:n]); s.upload(c_new, V, vel[:n]); s.upload(c_new, A, attr[:n])
+            for c in range(s.chunk_count()):
+                for plane in PLANES:
+                    log.append(s.download(c, plane))
+            log.append(s.live_counts().copy())
+            results.append(log)
+            shape = dict(ops=("gravity", "noise"), spawns=((16, 0, 2000),))
+            s.close()
+    finally:
+        native.lib().ilm_debug_step_streams(prev)
+    two, one = results
+    assert len(two) == len(one)
+    for k, (a, b) in enumerate(zip(two, one)):
+        if a.dtype == np.float32:
+            assert_bits_equal(a, b, "log entry %d: two streams vs one" % k)
+        else:
+            assert np.array_equal(a, b), k
+    eng.close()
+
+
+def test_two_stream_steps_race_free_under_repetition(ctx, oracle):
+    """The same split step sequence many times over, reading a chunk of each half after every step: a missing join would show up as a
+    plane that is one step behind.  One chunk of each half is replayed by the oracle."""
+    cs, n_chunks = 256, 8
+    n = cs * cs
+    rnd = scenes.randomness_table(17)
+    eng = native.Engine(ctx, cs, rnd)
+    pos, vel, attr = scenes.make_particles(41, n, pos_hi=(1920, 1080, 32), life=(0.2, 3.0), dead_fraction=0.1)
+    s = native.System(eng)
+    for c in range(n_chunks):
+        s.add_chunk()
+        s.upload(c, P, np.roll(pos, c * 17, axis=0)); s.upload(c, V, vel); s.upload(c, A, attr)
+    shape = dict(ops=("gravity", "noise"))
+    replay = {c: [np.roll(pos, c * 17, axis=0).copy(), vel.copy(), attr.copy(), np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)] for c in (1, 6)}
+    for i in range(6):
+        d = _step(cs, shape)
+        s.step(d)
+        got = {c: s.download(c, P) for c in (1, 6)}
+        for c in (1, 6):
+            d1 = _step(cs, shape)
+            d1.FirstChunk, d1.ChunkCount = 0, 1
+            want_counts = oracle.step([replay[c]], cs, rnd, d1, want_counts=True)
+            assert_close(got[c], replay[c][0], "step %d chunk %d position vs oracle" % (i, c), life_exact=True)
+            assert s.step_counts()[c] == want_counts[0]
+    s.close()
+    eng.close()

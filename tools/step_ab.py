@@ -36,10 +36,16 @@ for (cs, chunks, spawner, blocks) in ((256, 16, True, 12), (256, 16, False, 12),
 for rnd in range(2):
     for tag in sys.argv[1:]:
         env = dict(os.environ)
-        env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "tools", "ab", tag) + ":" + env.get("LD_LIBRARY_PATH", "")
+        lib_tag = tag
+        if "@" in tag:      # <library tag>@VAR=value[,VAR=value]: the same library under different environment switches
+            lib_tag, settings = tag.split("@", 1)
+            for kv in settings.split(","):
+                k, v = kv.split("=", 1)
+                env[k] = v
+        env["LD_LIBRARY_PATH"] = os.path.join(ROOT, "tools", "ab", lib_tag) + ":" + env.get("LD_LIBRARY_PATH", "")
         out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True)
         for line in out.stdout.splitlines():
             if line.startswith("cs="):
-                print("%-8s %s" % (tag, line))
+                print("%-24s %s" % (tag, line))
         if out.returncode != 0:
             print(tag, "FAILED", out.stderr[-400:])

@@ -42,23 +42,3 @@ def run(parts, steps=300):
     return (time.perf_counter() - t0) / steps * 1e6
 
 
-a = native.Context(0); b = native.Context(0)
-e1, s1, d1 = make(a, 256, 16, 10, True)
-print("one stream, 16 + 1 chunks: %.2f us/step" % run([(a, s1, d1)]))
-e2, s2, d2 = make(a, 256, 8, 10, True)
-e3, s3, d3 = make(b, 256, 8, 50, False)
-print("two streams, 8 + 1 | 8 chunks: %.2f us/step" % run([(a, s2, d2), (b, s3, d3)]))
-e4, s4, d4 = make(a, 256, 8, 50, False)
-print("one stream, two launches 8 + 1 | 8: %.2f us/step" % run([(a, s2, d2), (a, s4, d4)]))
-# which part of the gain is the split, which the spawn-free variant on most of the chunks?
-e8, s8, d8 = make(a, 256, 16, 10, False)
-print("one stream, 16 chunks, no spawner: %.2f us/step" % run([(a, s8, d8)]))
-e9, s9, d9 = make(b, 256, 0, 10, True)
-print("two streams, 16 (no spawner) | spawn-target chunk alone: %.2f us/step" % run([(a, s8, d8), (b, s9, d9)]))
-e10, s10, d10 = make(a, 256, 8, 10, False)
-e11, s11, d11 = make(b, 256, 8, 50, False)
-print("two streams, 8 | 8, no spawner: %.2f us/step" % run([(a, s10, d10), (b, s11, d11)]))
-print("three launches on two streams, 8 | 8 + spawn-target chunk alone: %.2f us/step" % run([(a, s10, d10), (b, s11, d11), (b, s9, d9)]))
-e12, s12, d12 = make(a, 256, 10, 10, False)
-e13, s13, d13 = make(b, 256, 6, 50, True)
-print("two streams, 10 | 6 + 1: %.2f us/step" % run([(a, s12, d12), (b, s13, d13)]))

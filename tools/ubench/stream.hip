@@ -122,14 +122,16 @@ __global__ __launch_bounds__(256) void k_aos(float4* b, long N, int alu) {
 int main(int argc, char** argv) {
     long N = argc > 1 ? atol(argv[1]) : (1 << 20);
     int alu = argc > 2 ? atoi(argv[2]) : 0;
-    float* d; CK(hipMalloc(&d, sizeof(float) * 20 * N)); CK(hipMemset(d, 0, sizeof(float) * 20 * N));
+    const long pad = argc > 3 ? atol(argv[3]) : 0;        // floats added to the plane stride (planes a power of two apart share cache sets / channels)
+    const long S = N + pad;
+    float* d; CK(hipMalloc(&d, sizeof(float) * 20 * S)); CK(hipMemset(d, 0, sizeof(float) * 20 * S));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int mode = 0; mode < 7; mode++) {
         const int reps = 50;
         for (int r = 0; r < reps + 5; r++) {
             if (r == 5) CK(hipEventRecord(e0));
-            if (mode == 0) hipLaunchKernelGGL(k_dword, dim3(N / 256), dim3(256), 0, 0, d, N, alu);
-            else if (mode == 1) hipLaunchKernelGGL(k_x4, dim3(N / 1024), dim3(256), 0, 0, d, N, alu);
+            if (mode == 0) hipLaunchKernelGGL(k_dword, dim3(N / 256), dim3(256), 0, 0, d, S, alu);
+            else if (mode == 1) hipLaunchKernelGGL(k_x4, dim3(N / 1024), dim3(256), 0, 0, d, S, alu);
             else if (mode == 3) hipLaunchKernelGGL(k_dword_nt<false>, dim3(N / 256), dim3(256), 0, 0, d, N, alu);
             else if (mode == 4) hipLaunchKernelGGL(k_dword_nt<true>, dim3(N / 256), dim3(256), 0, 0, d, N, alu);
             else if (mode == 5) hipLaunchKernelGGL(k_two, dim3(N / 512), dim3(256), 0, 0, d, N, alu);
@@ -138,7 +140,7 @@ int main(int argc, char** argv) {
         }
         CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
-        printf("N=%ld alu=%d mode=%d: %.2f us  %.2f TB/s (112 B/slot)\n", N, alu, mode, ms * 1e3, N * 112.0 / ms / 1e9);
+        printf("N=%ld pad=%ld alu=%d mode=%d: %.2f us  %.2f TB/s (112 B/slot)\n", N, pad, alu, mode, ms * 1e3, N * 112.0 / ms / 1e9);
     }
     return 0;
 }
