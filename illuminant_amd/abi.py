@@ -276,7 +276,7 @@ class ReadbackParams(C.Structure):
 class HDRConfiguration(C.Structure):
     _fields_ = [("Mode", i32), ("InverseScaleFactor", f32), ("Offset", f32), ("Exposure", f32), ("Gamma", f32),
                 ("MiddleGray", f32), ("AverageLuminance", f32), ("MaximumLuminance", f32), ("WhitePoint", f32),
-                ("ResolveToSRGB", i32), ("DitheringStrength", i32), ("_pad", i32)]
+                ("ResolveToSRGB", i32), ("DitheringStrength", i32), ("AlbedoIsSRGB", i32)]
 
 
 class RenderStats(C.Structure):

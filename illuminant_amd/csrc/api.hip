@@ -1834,6 +1834,20 @@ int32_t ilm_lightmap_download(IlmHandle h, void* dst, int32_t first_row, int32_t
     return ILM_OK;
 }
 
+int32_t ilm_lightmap_upload(IlmHandle h, const void* src, int32_t first_row, int32_t row_count) {
+    Lightmap* m = from_handle<Lightmap>(h, kMagicLightmap);
+    if (!m) return fail(ILM_ERR_INVALID_HANDLE, "not a lightmap handle");
+    if (!src) return fail(ILM_ERR_INVALID_ARGUMENT, "src is NULL");
+    if (first_row < 0 || row_count < 0 || first_row + row_count > m->height)
+        return fail(ILM_ERR_OUT_OF_RANGE, "rows [%d, %d) outside [0, %d)", first_row, first_row + row_count, m->height);
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    const size_t row_bytes = lightmap_texel_bytes(m->format) * (size_t)m->width;
+    HIP_TRY(hipMemcpyAsync(static_cast<char*>(m->texels) + row_bytes * (size_t)first_row, src, row_bytes * (size_t)row_count,
+                           hipMemcpyHostToDevice, m->ctx->main()));
+    HIP_TRY(hipStreamSynchronize(m->ctx->main()));
+    return ILM_OK;
+}
+
 int32_t ilm_lightmap_device_ptr(IlmHandle h, void** out_ptr) {
     Lightmap* m = from_handle<Lightmap>(h, kMagicLightmap);
     if (!m || !out_ptr) return fail(ILM_ERR_INVALID_HANDLE, "not a lightmap handle");
@@ -2258,9 +2272,22 @@ int32_t ilm_render_particles(IlmHandle hsystem, const int32_t* quad_counts, int3
 }
 
 int32_t ilm_resolve_lighting(IlmHandle hsrc, IlmHandle hdst, const IlmHDRConfiguration* hdr, int32_t row_begin, int32_t row_end) {
+    return ilm_resolve_lighting_with_albedo(hsrc, 0, hdst, hdr, row_begin, row_end);
+}
+
+int32_t ilm_resolve_lighting_with_albedo(IlmHandle hsrc, IlmHandle halbedo, IlmHandle hdst, const IlmHDRConfiguration* hdr, int32_t row_begin, int32_t row_end) {
     Lightmap* src = from_handle<Lightmap>(hsrc, kMagicLightmap);
     Lightmap* dst = from_handle<Lightmap>(hdst, kMagicLightmap);
     if (!src || !dst) return fail(ILM_ERR_INVALID_HANDLE, "not a lightmap handle");
+    Lightmap* albedo = nullptr;
+    if (halbedo) {
+        albedo = from_handle<Lightmap>(halbedo, kMagicLightmap);
+        if (!albedo) return fail(ILM_ERR_INVALID_HANDLE, "albedo is not a texture (lightmap) handle");
+        if (albedo->ctx != src->ctx || albedo->width != src->width || albedo->height != src->height)
+            return fail(ILM_ERR_INVALID_ARGUMENT, "the albedo texture must share context and size with the lightmap (the resolve is texel for texel)");
+        if (hdr && hdr->AlbedoIsSRGB != 0)
+            return fail(ILM_ERR_INVALID_ARGUMENT, "AlbedoIsSRGB needs Fracture's pSRGBToPLinear (sRGBCommon.fxh), which is outside the reference tree");
+    }
     if (!hdr) return fail(ILM_ERR_INVALID_ARGUMENT, "hdr is NULL");
     if (src->ctx != dst->ctx || src->width != dst->width || src->height != dst->height)
         return fail(ILM_ERR_INVALID_ARGUMENT, "source and destination must share context and size");
@@ -2278,6 +2305,7 @@ int32_t ilm_resolve_lighting(IlmHandle hsrc, IlmHandle hdst, const IlmHDRConfigu
     auto clamp = [](float v, float lo, float hi) { return fminf(fmaxf(v, lo), hi); };
     ResolveLaunch a;
     a.src = src->texels; a.src_format = src->format; a.dst = dst->texels; a.dst_format = dst->format;
+    a.albedo = albedo ? albedo->texels : nullptr; a.albedo_format = albedo ? albedo->format : 0;
     a.width = src->width; a.row_begin = row_begin; a.row_end = row_end; a.mode = hdr->Mode;
     a.inverse_scale = (hdr->InverseScaleFactor != 0.0f) ? hdr->InverseScaleFactor : 1.0f;     // LightingRenderer.cs:1468-1472
     a.offset = hdr->Offset;

@@ -260,6 +260,7 @@ hipError_t launch_readback(const ReadbackLaunch& a, hipStream_t stream);
 struct ResolveLaunch {
     const void* src; int32_t src_format;
     void* dst; int32_t dst_format;
+    const void* albedo; int32_t albedo_format;      // the ...WithAlbedo techniques: the albedo texture, texel for texel (NULL: plain resolve)
     int32_t width, row_begin, row_end, mode;
     // uniform reciprocals are taken on the host (one rounding each; the per-pixel divisions they replace cost ~10 VALU instructions)
     float inverse_scale, offset, exposure_minus_one, gamma_minus_one, middle_gray, inv_average_luminance, inv_maximum_luminance_squared, inv_white;

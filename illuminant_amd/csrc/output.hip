@@ -2,7 +2,7 @@
 //   * particle read-back: FillReadbackResult (Illuminant/Particles/ParticleReadback.cs:73-167) as an ordered device-side
 //     compaction of the live particles into draw-call records (the reference copies three float4 planes per chunk to the host
 //     and filters there: 48 B/slot over PCIe; here 48 B per LIVE particle);
-//   * lightmap resolve: the LightingResolve techniques of Illuminant/Shaders/Resolve.fx:62-139 + HDR.fxh, a pure stream
+//   * lightmap resolve: the LightingResolve[WithAlbedo] techniques of Illuminant/Shaders/Resolve.fx:25-233 + HDR.fxh, a pure stream
 //     (8 B read + 4..16 B written per pixel): HBM-bound, no LDS, no MFMA.
 #include "internal.hpp"
 
@@ -141,9 +141,20 @@ ILM_DEV void store_lightmap_texel(void* texels, int format, size_t o, float4 c) 
 
 // pow_pos: hlsl_math.hpp
 
-ILM_DEV float4 resolve_texel(const ResolveLaunch& a, float4 color) {
-    // ResolveCommon, Resolve.fx:25-40 (scale 1: the pixel's own texel)
-    float r = color.x * a.inverse_scale, g = color.y * a.inverse_scale, b = color.z * a.inverse_scale;
+ILM_DEV float4 resolve_texel(const ResolveLaunch& a, float4 color, float4 albedo) {
+    float r, g, b, alpha;
+    if (a.albedo != nullptr) {
+        // ResolveWithAlbedoCommon, Resolve.fx:43-60 (AlbedoIsSRGB = 0): light *= InverseScaleFactor * 2, then
+        // lerp(albedo.rgb, albedo.rgb * light.rgb, saturate(light.a)); the alpha is the albedo's
+        const float k = a.inverse_scale * 2.0f;
+        const float t = sat(color.w * k);
+        r = lerp(albedo.x, albedo.x * (color.x * k), t); g = lerp(albedo.y, albedo.y * (color.y * k), t); b = lerp(albedo.z, albedo.z * (color.z * k), t);
+        alpha = albedo.w;
+    } else {
+        // ResolveCommon, Resolve.fx:25-40 (scale 1: the pixel's own texel)
+        r = color.x * a.inverse_scale; g = color.y * a.inverse_scale; b = color.z * a.inverse_scale;
+        alpha = 1.0f;
+    }
     if (a.mode == ILM_HDR_GAMMA_COMPRESS) {
         // GammaCompress, HDR.fxh:11-18
         r = fmaxf(r + a.offset, 0.0f); g = fmaxf(g + a.offset, 0.0f); b = fmaxf(b + a.offset, 0.0f);
@@ -154,7 +165,7 @@ ILM_DEV float4 resolve_texel(const ResolveLaunch& a, float4 color) {
         // 0 / 0 at a black pixel is NaN in the shader as well (compressedLuminance / resultLuminance)
         r *= rescale; g *= rescale; b *= rescale;
     } else if (a.mode == ILM_HDR_TONE_MAP) {
-        // ToneMappedLightingResolvePixelShader, Resolve.fx:113-139; Uncharted2Tonemap, HDR.fxh:38-44
+        // ToneMappedLightingResolve[WithAlbedo]PixelShader, Resolve.fx:113-139,209-233; Uncharted2Tonemap, HDR.fxh:38-44
         const float kA = 0.15f, kB = 0.50f, kC = 0.10f, kD = 0.20f, kE = 0.02f, kF = 0.30f;
         const float e = a.exposure_minus_one + 1.0f, gm = a.gamma_minus_one + 1.0f;
         float v[3] = { fmaxf(0.0f, r + a.offset) * e, fmaxf(0.0f, g + a.offset) * e, fmaxf(0.0f, b + a.offset) * e };
@@ -165,13 +176,13 @@ ILM_DEV float4 resolve_texel(const ResolveLaunch& a, float4 color) {
         }
         r = v[0]; g = v[1]; b = v[2];
     } else {
-        // LightingResolvePixelShader, Resolve.fx:62-83
+        // LightingResolve[WithAlbedo]PixelShader, Resolve.fx:62-83,141-158
         const float e = a.exposure_minus_one + 1.0f, gm = a.gamma_minus_one + 1.0f;
         r = pow_pos(fmaxf(0.0f, r + a.offset) * e, gm);
         g = pow_pos(fmaxf(0.0f, g + a.offset) * e, gm);
         b = pow_pos(fmaxf(0.0f, b + a.offset) * e, gm);
     }
-    return mk4(r, g, b, 1.0f);
+    return mk4(r, g, b, alpha);
 }
 
 // Pure stream: 2 pixels per lane (16 B half4 loads, 8 B RGBA8 stores; a wave moves 1 KiB / 512 B per instruction).
@@ -182,23 +193,32 @@ __global__ __launch_bounds__(256) void resolve_kernel(const ResolveLaunch a) {
     if (i >= n) return;
     const size_t o = (size_t)a.row_begin * (size_t)a.width + i;
     const bool two = (i + 1 < n) && ((o & 1) == 0);
-    if (two && a.src_format == ILM_LIGHTMAP_HALF4 && a.dst_format == ILM_LIGHTMAP_RGBA8) {
+    if (two && a.src_format == ILM_LIGHTMAP_HALF4 && a.dst_format == ILM_LIGHTMAP_RGBA8 && (a.albedo == nullptr || a.albedo_format == ILM_LIGHTMAP_RGBA8)) {
         // the back-buffer case: one 16-byte load, one 8-byte store
         const uint4 v = reinterpret_cast<const uint4*>(a.src)[o >> 1];
         const float4 c0 = mk4(__half2float(__ushort_as_half((unsigned short)(v.x & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(v.x >> 16))),
                               __half2float(__ushort_as_half((unsigned short)(v.y & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(v.y >> 16))));
         const float4 c1 = mk4(__half2float(__ushort_as_half((unsigned short)(v.z & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(v.z >> 16))),
                               __half2float(__ushort_as_half((unsigned short)(v.w & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(v.w >> 16))));
-        const float4 r0 = resolve_texel(a, c0), r1 = resolve_texel(a, c1);
+        float4 a0 = mk4(0.0f, 0.0f, 0.0f, 0.0f), a1 = a0;
+        if (a.albedo != nullptr) {       // a Color texture: one 8-byte load for the two texels
+            const uint2 av = reinterpret_cast<const uint2*>(a.albedo)[o >> 1];
+            a0 = mk4((float)(av.x & 0xFFu) / 255.0f, (float)((av.x >> 8) & 0xFFu) / 255.0f, (float)((av.x >> 16) & 0xFFu) / 255.0f, (float)(av.x >> 24) / 255.0f);
+            a1 = mk4((float)(av.y & 0xFFu) / 255.0f, (float)((av.y >> 8) & 0xFFu) / 255.0f, (float)((av.y >> 16) & 0xFFu) / 255.0f, (float)(av.y >> 24) / 255.0f);
+        }
+        const float4 r0 = resolve_texel(a, c0, a0), r1 = resolve_texel(a, c1, a1);
         uint2 out;
-        out.x = (uint32_t)rintf(sat(r0.x) * 255.0f) | ((uint32_t)rintf(sat(r0.y) * 255.0f) << 8) | ((uint32_t)rintf(sat(r0.z) * 255.0f) << 16) | (255u << 24);
-        out.y = (uint32_t)rintf(sat(r1.x) * 255.0f) | ((uint32_t)rintf(sat(r1.y) * 255.0f) << 8) | ((uint32_t)rintf(sat(r1.z) * 255.0f) << 16) | (255u << 24);
+        out.x = (uint32_t)rintf(sat(r0.x) * 255.0f) | ((uint32_t)rintf(sat(r0.y) * 255.0f) << 8) | ((uint32_t)rintf(sat(r0.z) * 255.0f) << 16) | ((uint32_t)rintf(sat(r0.w) * 255.0f) << 24);
+        out.y = (uint32_t)rintf(sat(r1.x) * 255.0f) | ((uint32_t)rintf(sat(r1.y) * 255.0f) << 8) | ((uint32_t)rintf(sat(r1.z) * 255.0f) << 16) | ((uint32_t)rintf(sat(r1.w) * 255.0f) << 24);
         reinterpret_cast<uint2*>(a.dst)[o >> 1] = out;
         return;
     }
-    store_lightmap_texel(a.dst, a.dst_format, o, resolve_texel(a, load_lightmap_texel(a.src, a.src_format, o)));
+    const float4 none = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+    store_lightmap_texel(a.dst, a.dst_format, o, resolve_texel(a, load_lightmap_texel(a.src, a.src_format, o),
+                                                                a.albedo ? load_lightmap_texel(a.albedo, a.albedo_format, o) : none));
     if (i + 1 < n)
-        store_lightmap_texel(a.dst, a.dst_format, o + 1, resolve_texel(a, load_lightmap_texel(a.src, a.src_format, o + 1)));
+        store_lightmap_texel(a.dst, a.dst_format, o + 1, resolve_texel(a, load_lightmap_texel(a.src, a.src_format, o + 1),
+                                                                        a.albedo ? load_lightmap_texel(a.albedo, a.albedo_format, o + 1) : none));
 }
 
 hipError_t launch_resolve(const ResolveLaunch& a, hipStream_t stream) {

@@ -1585,7 +1585,7 @@ int LightingRenderer::UpdateFields() {
     return rendered;
 }
 
-void LightingRenderer::Resolve(IlmHandle destination, const IlmHDRConfiguration* hdr, int rowBegin, int rowEnd) const {
+void LightingRenderer::Resolve(IlmHandle destination, const IlmHDRConfiguration* hdr, int rowBegin, int rowEnd, IlmHandle albedo) const {
     IlmHDRConfiguration plain;
     if (!hdr) {      // hdr == null: InverseScaleFactor 1 and the material's default uniforms (exposure 1, gamma 1, offset 0)
         std::memset(&plain, 0, sizeof(plain));
@@ -1593,7 +1593,7 @@ void LightingRenderer::Resolve(IlmHandle destination, const IlmHDRConfiguration*
         hdr = &plain;
     }
     if (rowEnd < 0) rowEnd = Configuration.RenderHeight;
-    ThrowIfFailed(ilm_resolve_lighting(lightmap, destination, hdr, rowBegin, rowEnd));
+    ThrowIfFailed(ilm_resolve_lighting_with_albedo(lightmap, albedo, destination, hdr, rowBegin, rowEnd));
 }
 
 void LightingRenderer::ReadLightmap(void* dst, int firstRow, int rowCount) const {

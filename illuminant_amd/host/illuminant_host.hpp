@@ -836,7 +836,8 @@ public:
     // RenderedLighting.Resolve -> ResolveLighting without albedo (LightingRenderer.HDR.cs:99-151, LightingRenderer.cs:1537-1645):
     // tone-maps the lightmap into `destination` (a lightmap handle of the same size; RGBA8 = the back buffer).  hdr == nullptr => the
     // plain LightingResolve with exposure / gamma 1.
-    void Resolve(IlmHandle destination, const IlmHDRConfiguration* hdr = nullptr, int rowBegin = 0, int rowEnd = -1) const;
+    // `albedo` != 0: the ...WithAlbedo techniques over a texture of the lightmap's size (ResolveLighting with albedo != null, :1549-1580).
+    void Resolve(IlmHandle destination, const IlmHDRConfiguration* hdr = nullptr, int rowBegin = 0, int rowEnd = -1, IlmHandle albedo = 0) const;
     IlmHandle Lightmap() const { return lightmap; }
     int LightmapFormat() const { return lightmapFormat; }
 

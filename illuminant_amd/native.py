@@ -99,6 +99,8 @@ SYMBOLS = {
     "ilm_ctx_set_light_ramp": (_I, [_H, _P, _I, _I]),
     "ilm_system_set_bitmap": (_I, [_H, _P, _I, _I]),
     "ilm_resolve_lighting": (_I, [_H, _H, _P, _I, _I]),
+    "ilm_resolve_lighting_with_albedo": (_I, [_H, _H, _H, _P, _I, _I]),
+    "ilm_lightmap_upload": (_I, [_H, _P, _I, _I]),
     "ilm_group_create": (_I, [_P, _I, C.POINTER(_H)]),
     "ilm_group_unique_id": (_I, [_P]),
     "ilm_group_create_rank": (_I, [_I, _I, _I, _P, C.POINTER(_H)]),
@@ -526,6 +528,12 @@ class Lightmap:
         check(lib().ilm_lightmap_download(self.handle, _ptr(out), first_row, row_count))
         return out
 
+    def upload(self, texels, first_row=0):
+        """ilm_lightmap_upload: rows of texels in the lightmap's own format (float32 x 4, float16 x 4 or uint8 x 4)."""
+        dt, ch = _LM_DTYPE[self.format]
+        a = np.ascontiguousarray(texels, dtype=dt).reshape(-1, self.width, ch)
+        check(lib().ilm_lightmap_upload(self.handle, _ptr(a), first_row, a.shape[0]))
+
     def device_ptr(self):
         p = C.c_void_p()
         check(lib().ilm_lightmap_device_ptr(self.handle, C.byref(p)))
@@ -721,6 +729,9 @@ def render_light_probes(ctx, lights, probe_positions, probe_normals, env, df, sd
     return out
 
 
-def resolve_lighting(src, dst, hdr, row_begin=0, row_end=None):
-    """ilm_resolve_lighting: tone-map lightmap `src` into `dst` (same size, any formats)."""
-    check(lib().ilm_resolve_lighting(src.handle, dst.handle, _byref(hdr), row_begin, src.height if row_end is None else row_end))
+def resolve_lighting(src, dst, hdr, row_begin=0, row_end=None, albedo=None):
+    """ilm_resolve_lighting[_with_albedo]: tone-map lightmap `src` into `dst` (same size, any formats); albedo: a Lightmap holding the albedo texture."""
+    if albedo is None:
+        check(lib().ilm_resolve_lighting(src.handle, dst.handle, _byref(hdr), row_begin, src.height if row_end is None else row_end))
+    else:
+        check(lib().ilm_resolve_lighting_with_albedo(src.handle, albedo.handle, dst.handle, _byref(hdr), row_begin, src.height if row_end is None else row_end))

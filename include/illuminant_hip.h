@@ -582,6 +582,9 @@ int32_t ilm_gbuffer_render(IlmHandle gbuffer, const IlmGBufferRenderDesc* desc,
 int32_t ilm_lightmap_create(IlmHandle ctx, int32_t width, int32_t height, int32_t format,
                             void* external_device_ptr, IlmHandle* out_lightmap);
 int32_t ilm_lightmap_download(IlmHandle lightmap, void* dst, int32_t first_row, int32_t row_count);
+/* Texture2D.SetData on rows [first_row, first_row + row_count) in the lightmap's own texel format (the albedo texture of the with-albedo
+ * resolve is such a texture). */
+int32_t ilm_lightmap_upload(IlmHandle lightmap, const void* src, int32_t first_row, int32_t row_count);
 int32_t ilm_lightmap_device_ptr(IlmHandle lightmap, void** out_ptr);
 int32_t ilm_lightmap_destroy(IlmHandle lightmap);
 
@@ -757,7 +760,7 @@ typedef struct IlmHDRConfiguration {
     float   WhitePoint;                                       /* ToneMapping */
     int32_t ResolveToSRGB;          /* must be 0: pLinearToPSRGB is Fracture code (sRGBCommon.fxh, outside the tree) */
     int32_t DitheringStrength;      /* must be 0: ApplyDither is Fracture code (DitherCommon.fxh) */
-    int32_t _pad;
+    int32_t AlbedoIsSRGB;           /* with-albedo resolve only; must be 0: pSRGBToPLinear is Fracture code (sRGBCommon.fxh) */
 } IlmHDRConfiguration;
 
 /* RenderedLighting.Resolve without albedo, 1:1 (techniques ScreenSpaceLightingResolve / GammaCompressedLightingResolve /
@@ -765,6 +768,13 @@ typedef struct IlmHDRConfiguration {
  * src and dst are lightmap handles of the same size (any formats; dst RGBA8 is the back-buffer case). */
 int32_t ilm_resolve_lighting(IlmHandle src_lightmap, IlmHandle dst_lightmap, const IlmHDRConfiguration* hdr,
                              int32_t row_begin, int32_t row_end);
+/* RenderedLighting.Resolve WITH albedo (LightingRenderer.ResolveLighting with `albedo != null`, Illuminant/Lighting/LightingRenderer.cs:1537-1580;
+ * techniques ScreenSpaceLightingResolveWithAlbedo / GammaCompressed... / ToneMapped..., Illuminant/Shaders/Resolve.fx:43-60,141-233), 1:1:
+ * light = src * (InverseScaleFactor * 2); rgb = lerp(albedo.rgb, albedo.rgb * light.rgb, saturate(light.a)); alpha = albedo.a; then the
+ * HDR mode as above.  `albedo` is a texture the size of the lightmap held in a lightmap object (RGBA8 = SurfaceFormat.Color is the
+ * usual case; upload with ilm_lightmap_upload); albedo == 0 is ilm_resolve_lighting.  Not bound: AlbedoIsSRGB, the LUT-blended technique. */
+int32_t ilm_resolve_lighting_with_albedo(IlmHandle src_lightmap, IlmHandle albedo, IlmHandle dst_lightmap, const IlmHDRConfiguration* hdr,
+                                         int32_t row_begin, int32_t row_end);
 
 /* ---- multi-device groups (SURVEY 8e / 8b "ilm_ctx_create(device_ids, n)") --------------------------------------------------------
  *

@@ -401,7 +401,7 @@ namespace Squared.Illuminant.Native {
         public float WhitePoint;
         public int ResolveToSRGB;
         public int DitheringStrength;
-        public int _pad;
+        public int AlbedoIsSRGB;
     }
 
     internal static unsafe class IlluminantHip {
@@ -465,6 +465,7 @@ namespace Squared.Illuminant.Native {
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_gbuffer_render (ulong gbuffer, IlmGBufferRenderDesc* desc, IlmHeightVolume* volumes, int volumeCount, float* polygonXy, int polygonVertexCount);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_lightmap_create (ulong ctx, int width, int height, int format, void* externalDevicePtr, ulong* outLightmap);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_lightmap_download (ulong lightmap, void* dst, int firstRow, int rowCount);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_lightmap_upload (ulong lightmap, void* src, int firstRow, int rowCount);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_lightmap_device_ptr (ulong lightmap, void** outPtr);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_lightmap_destroy (ulong lightmap);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_render_sphere_lights (ulong ctx, LightVertex* lights, int lightCount, IlmEnvironment* env, IlmDistanceFieldUniforms* df, ulong gbuffer, ulong sdf, float* ambient, ulong lightmap, int rowBegin, int rowEnd, IlmRenderStats* stats);
@@ -477,6 +478,7 @@ namespace Squared.Illuminant.Native {
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_system_set_bitmap (ulong system, Vector4* texels, int width, int height);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_lightmap_clear (ulong lightmap, float* rgba);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_resolve_lighting (ulong srcLightmap, ulong dstLightmap, IlmHDRConfiguration* hdr, int rowBegin, int rowEnd);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_resolve_lighting_with_albedo (ulong srcLightmap, ulong albedo, ulong dstLightmap, IlmHDRConfiguration* hdr, int rowBegin, int rowEnd);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_create (int* deviceIds, int n, ulong* outGroup);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_unique_id (void* outId128);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_create_rank (int deviceId, int rank, int world, void* id128, ulong* outGroup);

@@ -78,8 +78,17 @@ static float uncharted2_tonemap1(float value) {
 /* LightingResolvePixelShader / GammaCompressedLightingResolvePixelShader / ToneMappedLightingResolvePixelShader, Resolve.fx:62-139,
  * with ResolveCommon (:25-40) at scale 1 (each output pixel reads its own lightmap texel); parameter clamps of
  * SetGammaCompressionParameters / SetToneMappingParameters (IlluminantMaterials.cs:81-137). */
+void orc_resolve_lighting_with_albedo(const IlmFloat4* lightmap, const IlmFloat4* albedo, int32_t width, int32_t height, const IlmHDRConfiguration* hdr,
+                                      IlmFloat4* out, int32_t row_begin, int32_t row_end);
 void orc_resolve_lighting(const IlmFloat4* lightmap, int32_t width, int32_t height, const IlmHDRConfiguration* hdr,
                           IlmFloat4* out, int32_t row_begin, int32_t row_end) {
+    orc_resolve_lighting_with_albedo(lightmap, NULL, width, height, hdr, out, row_begin, row_end);
+}
+
+/* ... and LightingResolveWithAlbedoPixelShader / GammaCompressed... / ToneMapped... (Resolve.fx:141-233) when `albedo` is given:
+ * ResolveWithAlbedoCommon (:43-60) with AlbedoIsSRGB = 0, each output pixel reading its own texel of both textures. */
+void orc_resolve_lighting_with_albedo(const IlmFloat4* lightmap, const IlmFloat4* albedo_texels, int32_t width, int32_t height, const IlmHDRConfiguration* hdr,
+                                      IlmFloat4* out, int32_t row_begin, int32_t row_end) {
     const float min_v = 1.0f / 256.0f, max_v = 99999.0f;
     const float inverse_scale = (hdr->InverseScaleFactor != 0.0f) ? hdr->InverseScaleFactor : 1.0f;
     const float exposure = h_clamp(hdr->Exposure, min_v, max_v);
@@ -96,7 +105,18 @@ void orc_resolve_lighting(const IlmFloat4* lightmap, int32_t width, int32_t heig
     for (int y = row_begin; y < row_end; y++)
         for (int x = 0; x < width; x++) {
             const f4 color = lightmap[(size_t)y * (size_t)width + (size_t)x];
-            f4 r = v4(color.x * inverse_scale, color.y * inverse_scale, color.z * inverse_scale, 1.0f);   /* ResolveCommon */
+            f4 r;
+            if (albedo_texels) {
+                /* ResolveWithAlbedoCommon: light *= InverseScaleFactor * 2; lerp(albedo.rgb, albedo.rgb * light.rgb, saturate(light.a)) */
+                const f4 albedo = albedo_texels[(size_t)y * (size_t)width + (size_t)x];
+                const float k = inverse_scale * 2.0f;
+                const f4 light = v4(color.x * k, color.y * k, color.z * k, color.w * k);
+                const float t = h_clamp(light.w, 0.0f, 1.0f);
+                r = v4(albedo.x + (albedo.x * light.x - albedo.x) * t, albedo.y + (albedo.y * light.y - albedo.y) * t,
+                       albedo.z + (albedo.z * light.z - albedo.z) * t, albedo.w);
+            } else {
+                r = v4(color.x * inverse_scale, color.y * inverse_scale, color.z * inverse_scale, 1.0f);   /* ResolveCommon */
+            }
             if (hdr->Mode == ILM_HDR_GAMMA_COMPRESS) {
                 r = gamma_compress(r, hdr->Offset, middle_gray, average_luminance, maximum_luminance_squared);
             } else if (hdr->Mode == ILM_HDR_TONE_MAP) {

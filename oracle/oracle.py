@@ -363,11 +363,18 @@ def render_particles(chunks, params, width, height, quad_counts=None, image=None
     return image, (int(stats[0]), int(stats[1]))
 
 
-def resolve_lighting(lightmap, hdr, row_begin=0, row_end=None):
+def resolve_lighting(lightmap, hdr, row_begin=0, row_end=None, albedo=None):
+    """albedo: (h, w, 4) float32 texture for the ...WithAlbedo techniques (None: the plain resolve)."""
     h, w = lightmap.shape[0], lightmap.shape[1]
     out = np.zeros_like(lightmap)
-    lib().orc_resolve_lighting(_f4(lightmap), C.c_int32(w), C.c_int32(h), C.byref(hdr), _f4(out), C.c_int32(row_begin),
-                               C.c_int32(h if row_end is None else row_end))
+    if albedo is None:
+        lib().orc_resolve_lighting(_f4(lightmap), C.c_int32(w), C.c_int32(h), C.byref(hdr), _f4(out), C.c_int32(row_begin),
+                                   C.c_int32(h if row_end is None else row_end))
+    else:
+        albedo = np.ascontiguousarray(albedo, dtype=np.float32)
+        assert albedo.shape == lightmap.shape
+        lib().orc_resolve_lighting_with_albedo(_f4(lightmap), _f4(albedo), C.c_int32(w), C.c_int32(h), C.byref(hdr), _f4(out), C.c_int32(row_begin),
+                                               C.c_int32(h if row_end is None else row_end))
     return out
 
 

@@ -692,7 +692,33 @@ def gen_output_ext():
     pre = [max(0.0, v * 1.0 + 0.0) * 2.0 for v in texel[:3]]
     cases.append({"kind": "resolve", "texel": texel, "hdr": {"mode": 2, "inverse_scale": 1.0, "offset": 0.0, "exposure": 2.0, "gamma": 0.8, "white_point": 4.0},
                   "expected": [(u2(pre[0]) / u2(4.0)) ** 0.8, (u2(pre[1]) / u2(4.0)) ** 0.8, (u2(pre[2]) / u2(4.0)) ** 0.8, 1.0]})
-    return {"source": "ParticleReadback.cs:73-167, Resolve.fx:25-139, HDR.fxh:1-44, IlluminantMaterials.cs:81-137, LightingRenderer.cs:1463-1520 "
+    # (g) with albedo (ResolveWithAlbedoCommon, Resolve.fx:43-60): light = texel * (inverseScale * 2); rgb = lerp(albedo, albedo * light.rgb,
+    #     saturate(light.a)); alpha = albedo.a; then HDRMode.None.  light.a = 0.2 * 1.5 * 2 = 0.6
+    light_texel, albedo = [0.5, 0.25, 1.0, 0.2], [0.8, 0.4, 0.2, 0.5]
+    k = 1.5 * 2.0
+    t = min(max(light_texel[3] * k, 0.0), 1.0)
+    rgb = [a + (a * (l * k) - a) * t for a, l in zip(albedo[:3], light_texel[:3])]
+    r = [max(0.0, v + 0.05) * 1.2 for v in rgb]
+    cases.append({"kind": "resolve", "texel": light_texel, "albedo": albedo,
+                  "hdr": {"mode": 0, "inverse_scale": 1.5, "offset": 0.05, "exposure": 1.2, "gamma": 1.5},
+                  "expected": [r[0] ** 1.5, r[1] ** 1.5, r[2] ** 1.5, 0.5]})
+    #     light alpha above 1 saturates: rgb = albedo * light.rgb exactly; tone-mapped afterwards, alpha still the albedo's
+    light_texel, albedo = [0.5, 0.25, 1.0, 7.0], [0.8, 0.4, 0.2, 0.25]
+    rgb = [a * (l * 2.0) for a, l in zip(albedo[:3], light_texel[:3])]
+    pre = [max(0.0, v) * 2.0 for v in rgb]
+    cases.append({"kind": "resolve", "texel": light_texel, "albedo": albedo,
+                  "hdr": {"mode": 2, "inverse_scale": 1.0, "offset": 0.0, "exposure": 2.0, "gamma": 0.8, "white_point": 4.0},
+                  "expected": [(u2(pre[0]) / u2(4.0)) ** 0.8, (u2(pre[1]) / u2(4.0)) ** 0.8, (u2(pre[2]) / u2(4.0)) ** 0.8, 0.25]})
+    #     ... and gamma-compressed (GammaCompress keeps color.a, HDR.fxh:17): light alpha 0 leaves the albedo unlit
+    light_texel, albedo = [3.0, 3.0, 3.0, 0.0], [0.5, 0.25, 1.0, 0.75]
+    rgb = [max(v + 0.05, 0.0) for v in albedo[:3]]
+    L = rgb[0] * 0.299 + rgb[1] * 0.587 + rgb[2] * 0.114
+    sL = L * 0.6 / 0.4
+    cL = sL * (1 + sL / (2.0 * 2.0)) / (1 + sL)
+    cases.append({"kind": "resolve", "texel": light_texel, "albedo": albedo,
+                  "hdr": {"mode": 1, "inverse_scale": 1.0, "offset": 0.05, "middle_gray": 0.6, "average_luminance": 0.4, "maximum_luminance": 2.0},
+                  "expected": [rgb[0] * cL / L, rgb[1] * cL / L, rgb[2] * cL / L, 0.75]})
+    return {"source": "ParticleReadback.cs:73-167, Resolve.fx:25-233, HDR.fxh:1-44, IlluminantMaterials.cs:81-137, LightingRenderer.cs:1463-1580 "
                       "(hand-evaluated; see comments in make_golden.py)", "tolerance": "1e-5 relative; colour bytes and record order exact", "cases": cases}
 
 

@@ -48,8 +48,8 @@ class OracleBackend:
         recs, n = self.orc.fill_readback_result([chunk], params)
         return records_to_rows(recs, n)
 
-    def resolve(self, lightmap, hdr):
-        return self.orc.resolve_lighting(lightmap, hdr)
+    def resolve(self, lightmap, hdr, albedo=None):
+        return self.orc.resolve_lighting(lightmap, hdr, albedo=albedo)
 
 
 class GpuBackend:
@@ -69,16 +69,22 @@ class GpuBackend:
         sysm.close(); eng.close()
         return rows
 
-    def resolve(self, lightmap, hdr):
+    def resolve(self, lightmap, hdr, albedo=None):
         native = self.native
         h, w = lightmap.shape[:2]
         src = native.Lightmap(self.ctx, w, h, abi.LIGHTMAP_FLOAT4)
         # seed: a zero-light pass clears to `ambient`; the fixture lightmaps are constant
         native.render_sphere_lights(self.ctx, None, self.scenes.environment(), abi.DistanceFieldUniforms(), None, None, tuple(lightmap[0, 0]), src)
         dst = native.Lightmap(self.ctx, w, h, abi.LIGHTMAP_FLOAT4)
-        native.resolve_lighting(src, dst, hdr)
+        tex = None
+        if albedo is not None:
+            tex = native.Lightmap(self.ctx, w, h, abi.LIGHTMAP_FLOAT4)
+            tex.upload(albedo)
+        native.resolve_lighting(src, dst, hdr, albedo=tex)
         out = dst.download()
         src.close(); dst.close()
+        if tex is not None:
+            tex.close()
         return out
 
 
@@ -108,7 +114,11 @@ def check_case(case, backend):
         h = case["hdr"]
         hdr = hdr_configuration(h["mode"], h.get("inverse_scale", 1.0), h.get("offset", 0.0), h.get("exposure", 1.0), h.get("gamma", 1.0),
                                 h.get("middle_gray", 0.0), h.get("average_luminance", 0.0), h.get("maximum_luminance", 0.0), h.get("white_point", 1.0))
-        out = backend.resolve(lm, hdr)
+        albedo = None
+        if "albedo" in case:
+            albedo = np.zeros((4, 8, 4), np.float32)
+            albedo[:] = np.asarray(case["albedo"], np.float32)
+        out = backend.resolve(lm, hdr, albedo)
         assert_close(out[2, 5], case["expected"], "resolved texel", rtol=2e-5)
     else:
         raise AssertionError(case["kind"])

@@ -82,6 +82,49 @@ def test_resolve_matches_oracle_on_a_lit_frame(ctx, oracle, mode, fmt):
         x.close()
 
 
+@pytest.mark.parametrize("mode", [abi.HDR_NONE, abi.HDR_GAMMA_COMPRESS, abi.HDR_TONE_MAP])
+@pytest.mark.parametrize("albedo_fmt", [abi.LIGHTMAP_RGBA8, abi.LIGHTMAP_FLOAT4])
+def test_resolve_with_albedo_matches_oracle_on_a_lit_frame(ctx, oracle, mode, albedo_fmt):
+    """The ...WithAlbedo techniques (Resolve.fx:43-60,141-233): a lit half4 frame over a Color (or float) albedo texture, ragged width so the
+    two-texel fast path and the single-texel tail both run."""
+    w, h = 157, 96
+    layout = scenes.DistanceFieldLayout(256, 192, 96.0, 12, 0.5, 128)
+    atlas = scenes.build_sdf_atlas(layout, scenes.random_obstacles(5, 14, (256, 192), size_lo=8.0, size_hi=30.0, z_hi=40.0))
+    dfu = layout.uniforms(max_cone_radius=24.0, power=0.7, step_limit=64, min_step_size=1.0, long_step_factor=0.5)
+    lights = scenes.random_lights(6, 12, w, h, z=(8.0, 48.0), radius=10.0, ramp=(40.0, 120.0))
+    sdf = native.DistanceFieldTexture(ctx, atlas)
+    src = native.Lightmap(ctx, w, h, abi.LIGHTMAP_HALF4)
+    native.render_sphere_lights(ctx, lights, scenes.environment(), dfu, None, sdf, (0.05, 0.06, 0.07, 0.35), src)
+    lit = src.download().astype(np.float32)
+    texels = (scenes.uniform(91, (h, w, 4), 0.0, 1.0) * 255.0).astype(np.uint8)
+    tex = native.Lightmap(ctx, w, h, albedo_fmt)
+    if albedo_fmt == abi.LIGHTMAP_RGBA8:
+        tex.upload(texels)
+        albedo = texels.astype(np.float32) / np.float32(255.0)
+    else:
+        albedo = scenes.uniform(92, (h, w, 4), 0.0, 1.5).astype(np.float32)
+        tex.upload(albedo)
+    hdr = oc.hdr_configuration(mode, 0.75, 0.02, 1.3, 0.9, 0.5, 0.8, 3.0, 2.5)
+    dst = native.Lightmap(ctx, w, h, abi.LIGHTMAP_FLOAT4)
+    native.resolve_lighting(src, dst, hdr, albedo=tex)
+    want = oracle.resolve_lighting(np.ascontiguousarray(lit), hdr, albedo=albedo)
+    assert_close(dst.download(), want, "resolved frame with albedo")
+    dst8 = native.Lightmap(ctx, w, h, abi.LIGHTMAP_RGBA8)
+    native.resolve_lighting(src, dst8, hdr, albedo=tex)
+    want8 = np.rint(np.clip(want, 0.0, 1.0) * 255.0).astype(np.int32)
+    got8 = dst8.download().astype(np.int32)
+    assert np.abs(got8 - want8).max() <= 1
+    assert np.array_equal(got8[..., 3], want8[..., 3])          # the albedo's alpha goes straight through
+    # strips: rows outside stay untouched
+    dst.clear((0.0, 0.0, 0.0, 0.0))
+    native.resolve_lighting(src, dst, hdr, 16, 48, albedo=tex)
+    part = dst.download()
+    assert not part[:16].any() and not part[48:].any()
+    assert_close(part[16:48], want[16:48], "strip of the resolved frame with albedo")
+    for x in (dst8, dst, tex, src, sdf):
+        x.close()
+
+
 def test_fracture_only_options_are_refused(ctx):
     a = native.Lightmap(ctx, 8, 8, abi.LIGHTMAP_FLOAT4)
     b = native.Lightmap(ctx, 8, 8, abi.LIGHTMAP_FLOAT4)
@@ -90,4 +133,14 @@ def test_fracture_only_options_are_refused(ctx):
     with pytest.raises(native.IlluminantError) as e:
         native.resolve_lighting(a, b, hdr)
     assert e.value.code == abi.ERR_INVALID_ARGUMENT and "pLinearToPSRGB" in str(e.value)
-    a.close(); b.close()
+    hdr = oc.hdr_configuration()
+    hdr.AlbedoIsSRGB = 1
+    native.resolve_lighting(a, b, hdr)                      # only the with-albedo techniques read it
+    t = native.Lightmap(ctx, 8, 8, abi.LIGHTMAP_RGBA8)
+    with pytest.raises(native.IlluminantError) as e:
+        native.resolve_lighting(a, b, hdr, albedo=t)
+    assert e.value.code == abi.ERR_INVALID_ARGUMENT and "pSRGBToPLinear" in str(e.value)
+    small = native.Lightmap(ctx, 4, 8, abi.LIGHTMAP_RGBA8)
+    with pytest.raises(native.IlluminantError):
+        native.resolve_lighting(a, b, oc.hdr_configuration(), albedo=small)
+    a.close(); b.close(); t.close(); small.close()
