@@ -1244,7 +1244,7 @@ ILM_DEV void touch_kernarg_lines() {
     const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
     uint32_t sink;
     asm volatile(ILM_T16(0x0) ILM_T16(0x400) ILM_T16(0x800) ILM_T1(0xc00) ILM_T1(0xc40) ILM_T1(0xc80) "s_waitcnt lgkmcnt(0)"
-                 : "=&s"(sink) : "s"(kp) : "memory");
+                 : "=&s"(sink) : "s"(kp));
 }
 static_assert(sizeof(LeanStep) >= 0xc84 && sizeof(LeanStep) <= 0xcc0, "touch_kernarg_lines reads one dword of each 64-byte line of LeanStep");
 
@@ -1273,7 +1273,12 @@ __global__ __launch_bounds__(kStepThreads) void step_lean_kernel(const LeanStep 
         }
         if (!untouched) {
             const unsigned lane4 = lane * 4u;
-            const UnitPlanes up = unit_planes(a.chunk_bases[chunk], a.stride, seg * 64);
+            // the chunk table through the constant address space: a scalar load whatever the optimiser thinks may alias (behind the
+            // volatile asm of touch_kernarg_lines it would otherwise fetch the base with a VECTOR load and wrap every plane access in
+            // a waterfall loop over a "divergent" buffer resource: +160 vector instructions per wave); the table is written by a copy
+            // that precedes the launch on its stream and never during one
+            typedef float* const __attribute__((address_space(4))) CBase;
+            const UnitPlanes up = unit_planes(((CBase*)a.chunk_bases)[chunk], a.stride, seg * 64);
             const SlotIn cur = load_slot<true, STREAM>(up, lane4);
             // slot (x, y): the unit lies in one row (chunk size a multiple of 64)
             const int first = seg * 64;

@@ -35,7 +35,7 @@ dur = collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/p*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        if "sphere_lights" not in k and "step_kernel" not in k and "render_slices" not in k: continue
+        if "sphere_lights" not in k and "step_kernel" not in k and "step_lean" not in k and "render_slices" not in k: continue
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for f in glob.glob(sys.argv[1] + "/p1/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(f)):

@@ -4,7 +4,7 @@
     summarize_prof.py <raw dir> <summary dir> <tag>
 
   <tag>_kernel_stats.csv   the rocprofv3 --stats per-kernel table (calls, total / average / min / max ns)
-  <tag>_pmc.csv            per kernel: average of every collected counter per dispatch
+  <tag>_pmc.csv            per kernel: every collected counter of the kernel's MEDIAN dispatch
   <tag>_summary.md         the few numbers bench.py's roofline object is checked against
 """
 import collections
@@ -47,15 +47,20 @@ def main():
         lines.append("")
 
     # PMC passes
-    agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+    # Per kernel and counter the MEDIAN over its dispatches: a kernel name can carry launches of different scenes (the 4K kernel also
+    # runs one small frame in the bench's exchange check) and a mean over them describes none of them.
+    vals = collections.defaultdict(lambda: collections.defaultdict(list))
+    agg = collections.defaultdict(dict)
     meta = {}
     for path in sorted(glob.glob(os.path.join(raw, "pmc_*", "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(path)):
             k = short(r["Kernel_Name"])
-            a = agg[k][r["Counter_Name"]]
-            a[0] += 1
-            a[1] += float(r["Counter_Value"])
+            vals[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
             meta[k] = (r["VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"], r["Workgroup_Size"])
+    for k in vals:
+        for cname, v in vals[k].items():
+            v = sorted(v)
+            agg[k][cname] = [len(v), v[len(v) // 2] * len(v)]      # [dispatches, median x dispatches]: the code below divides
     if agg:
         counters = sorted({c for k in agg for c in agg[k]})
         with open(os.path.join(out, "%s_pmc.csv" % tag), "w", newline="") as f:
@@ -64,7 +69,7 @@ def main():
             for k in sorted(agg):
                 n = max(v[0] for v in agg[k].values())
                 w.writerow([k, n] + list(meta[k]) + ["%.1f" % (agg[k][c][1] / agg[k][c][0]) if c in agg[k] else "" for c in counters])
-        lines += ["## PMC counters (average per dispatch; separate passes, `--kernel-trace --pmc <set>`)", ""]
+        lines += ["## PMC counters (median dispatch of each kernel; separate passes, `--kernel-trace --pmc <set>`)", ""]
         for k in sorted(agg):
             if "ilm::" not in k:
                 continue
