@@ -1023,6 +1023,32 @@ ILM_DEV void publish_block_count(uint32_t* wave_live, uint32_t n_live, unsigned 
     }
 }
 
+// The launch descriptor is written by the host into the kernarg ring just before the launch, so the first wave of every scalar cache
+// misses on each of its 64-byte lines all the way to memory -- and the step reads them one dependent phase after another (decode,
+// planes, noise tables, each transform, the update pass): a chain of ~20 serial misses at the head of every launch.  One load per
+// line, all in flight at once, turns the chain into a single miss; for every later wave they are ~60 cache hits the scalar pipe has
+// room for (tools/step_ab.py with 200 extra scalar instructions per wave: no change in step time).  Measured (r02): a one-chunk launch
+// 7.7 -> 6.0 us back to back (10.8 -> 8.3 us when it spawns), cfg2 without a spawner 24.0 -> 21.4 us per step.
+constexpr int kTouchBlocks = 512;
+// The chunk table is read through the constant address space in both kernels: see step_lean_kernel.
+typedef float* const __attribute__((address_space(4))) CBase;
+#define ILM_T1(o) "s_load_dword %0, %1, " #o "\n"
+#define ILM_T4(o) ILM_T1(o) ILM_T1(o + 0x40) ILM_T1(o + 0x80) ILM_T1(o + 0xc0)
+#define ILM_T16(o) ILM_T4(o) ILM_T4(o + 0x100) ILM_T4(o + 0x200) ILM_T4(o + 0x300)
+ILM_DEV void touch_kernarg_lines_lean() {       // LeanStep: 51 lines
+    const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t sink;
+    asm volatile(ILM_T16(0x0) ILM_T16(0x400) ILM_T16(0x800) ILM_T1(0xc00) ILM_T1(0xc40) ILM_T1(0xc80) "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(sink) : "s"(kp));
+}
+ILM_DEV void touch_kernarg_lines_step() {       // StepLaunch: 63 lines
+    const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t sink;
+    asm volatile(ILM_T16(0x0) ILM_T16(0x400) ILM_T16(0x800) ILM_T4(0xc00) ILM_T4(0xd00) ILM_T4(0xe00) ILM_T1(0xf00) ILM_T1(0xf40) ILM_T1(0xf80)
+                 "s_waitcnt lgkmcnt(0)" : "=&s"(sink) : "s"(kp));
+}
+static_assert(sizeof(StepLaunch) >= 0xf84 && sizeof(StepLaunch) <= 0xfc0, "touch_kernarg_lines_step reads one dword of each 64-byte line of StepLaunch");
+
 // One wave = one unit of 64 consecutive slots; the hardware dispatcher balances the waves.  (A persistent,
 // software-pipelined variant of this kernel measured 12-25 % slower: the body is a long dependent chain --
 // state loads, scalar parameter fetches, randomness gathers -- whose latency is hidden by wave occupancy,
@@ -1031,6 +1057,7 @@ template <int FMT, bool DF, bool SPAWN, int MINW, bool EXT = false, bool STREAM 
 __global__ __launch_bounds__(kStepThreads, MINW) void step_kernel(const StepLaunch a) {
     __shared__ uint32_t wave_live[kStepThreads / 64];
     CStepLaunch* ap = (CStepLaunch*)__builtin_amdgcn_kernarg_segment_ptr();
+    if (blockIdx.x < kTouchBlocks) touch_kernarg_lines_step();
     // the wave index is uniform by construction; saying so keeps the unit / chunk / base-pointer arithmetic on the
     // scalar unit and lets every plane access use the SGPR-base + 32-bit lane-offset addressing form
     const unsigned lane = threadIdx.x & 63u;
@@ -1057,7 +1084,7 @@ __global__ __launch_bounds__(kStepThreads, MINW) void step_kernel(const StepLaun
         for (int k = 0; k < a.partial_count; k++)
             untouched = untouched || ((a.partial_chunk[k] == chunk) && (seg >= a.partial_units[k]));
         if (!untouched) {
-        const float* chunk_base = a.chunk_bases[chunk];
+        const float* chunk_base = ((CBase*)a.chunk_bases)[chunk];
         const unsigned lane4 = lane * 4u;
         UnitPlanes up[K];
 #pragma unroll
@@ -1229,24 +1256,8 @@ ILM_DEV NoiseDeltas noise_prepare_lean(const LeanStep& a, int x0, int row) {
 static_assert(offsetof(StepDerived::NoiseFast, velocity) == offsetof(StepDerived::NoiseFast, position) + 9 * sizeof(IlmFloat4), "velocity[3][3] follows position[3][3]");
 
 typedef const LeanStep __attribute__((address_space(4))) CLeanStep;
+static_assert(sizeof(LeanStep) >= 0xc84 && sizeof(LeanStep) <= 0xcc0, "touch_kernarg_lines_lean reads one dword of each 64-byte line of LeanStep");
 
-// The launch descriptor is written by the host into the kernarg ring just before the launch, so the first wave of every scalar cache
-// misses on each of its 64-byte lines all the way to memory -- and the step reads them one dependent phase after another (decode,
-// planes, noise tables, each transform, the update pass): a chain of ~20 serial misses at the head of every launch.  One load per
-// line, all in flight at once, turns the chain into a single miss; for every later wave they are ~60 cache hits the scalar pipe has
-// room for (tools/step_ab.py with 200 extra scalar instructions per wave: no change in step time).  Measured (r02): a one-chunk launch
-// 7.7 -> 6.0 us back to back (10.8 -> 8.3 us when it spawns), cfg2 without a spawner 24.0 -> 21.4 us per step.
-constexpr int kTouchBlocks = 512;
-#define ILM_T1(o) "s_load_dword %0, %1, " #o "\n"
-#define ILM_T4(o) ILM_T1(o) ILM_T1(o + 0x40) ILM_T1(o + 0x80) ILM_T1(o + 0xc0)
-#define ILM_T16(o) ILM_T4(o) ILM_T4(o + 0x100) ILM_T4(o + 0x200) ILM_T4(o + 0x300)
-ILM_DEV void touch_kernarg_lines() {
-    const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
-    uint32_t sink;
-    asm volatile(ILM_T16(0x0) ILM_T16(0x400) ILM_T16(0x800) ILM_T1(0xc00) ILM_T1(0xc40) ILM_T1(0xc80) "s_waitcnt lgkmcnt(0)"
-                 : "=&s"(sink) : "s"(kp));
-}
-static_assert(sizeof(LeanStep) >= 0xc84 && sizeof(LeanStep) <= 0xcc0, "touch_kernarg_lines reads one dword of each 64-byte line of LeanStep");
 
 template <bool SPAWN, bool STREAM>
 __global__ __launch_bounds__(kStepThreads) void step_lean_kernel(const LeanStep a_) {
@@ -1254,7 +1265,7 @@ __global__ __launch_bounds__(kStepThreads) void step_lean_kernel(const LeanStep 
     const LeanStep& a = *(const LeanStep*)(CLeanStep*)__builtin_amdgcn_kernarg_segment_ptr();
     // (only the launch's first generation of blocks can be the first to read a line; for the others the loads would just load the
     // scalar cache: one lookup per line per wave)
-    if (blockIdx.x < kTouchBlocks) touch_kernarg_lines();
+    if (blockIdx.x < kTouchBlocks) touch_kernarg_lines_lean();
     const unsigned lane = threadIdx.x & 63u;
     const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
     int v = (int)blockIdx.x * (kStepThreads / 64) + a.unit_rotate;      // first unit of the block (rotation: see step_kernel)
@@ -1277,7 +1288,6 @@ __global__ __launch_bounds__(kStepThreads) void step_lean_kernel(const LeanStep 
             // volatile asm of touch_kernarg_lines it would otherwise fetch the base with a VECTOR load and wrap every plane access in
             // a waterfall loop over a "divergent" buffer resource: +160 vector instructions per wave); the table is written by a copy
             // that precedes the launch on its stream and never during one
-            typedef float* const __attribute__((address_space(4))) CBase;
             const UnitPlanes up = unit_planes(((CBase*)a.chunk_bases)[chunk], a.stride, seg * 64);
             const SlotIn cur = load_slot<true, STREAM>(up, lane4);
             // slot (x, y): the unit lies in one row (chunk size a multiple of 64)
