@@ -287,3 +287,37 @@ def test_two_stream_steps_race_free_under_repetition(ctx, oracle):
             assert s.step_counts()[c] == want_counts[0]
     s.close()
     eng.close()
+
+
+def test_a_context_whose_stream_was_handed_out_steps_on_that_stream(ctx):
+    """ilm_ctx_stream gives the caller a stream to queue its own readers of the particle planes on, so such a context never uses its
+    second stream (api.hip, Ctx::exported): a kernel-free reader -- an async copy the TEST queues on the exported stream right behind
+    a large step, without any library call in between -- must see the stepped planes."""
+    import ctypes as C
+    cs, n_chunks = 256, 8
+    n = cs * cs
+    rnd = scenes.randomness_table(23)
+    own = native.Context(0)
+    stream = own.stream()
+    assert stream
+    eng = native.Engine(own, cs, rnd)
+    s = native.System(eng)
+    ref_eng = native.Engine(ctx, cs, rnd)
+    ref = native.System(ref_eng)
+    pos, vel, attr = scenes.make_particles(51, n, pos_hi=(1920, 1080, 32), life=(0.5, 3.0))
+    for sysm in (s, ref):
+        for c in range(n_chunks):
+            sysm.add_chunk()
+            sysm.upload(c, P, np.roll(pos, c * 29, axis=0)); sysm.upload(c, V, vel); sysm.upload(c, A, attr)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    ptr, stride = s.device_ptr(n_chunks - 1, 0)          # x plane of the last chunk: the half a split would put on the second stream
+    out = np.zeros(n, np.float32)
+    for _ in range(3):
+        d = _step(cs, dict(ops=("gravity", "noise"), count=False))
+        s.step(d); ref.step(d)
+        assert hip.hipMemcpyAsync(out.ctypes.data, ptr, n * 4, 2, stream) == 0         # 2 = hipMemcpyDeviceToHost
+        assert hip.hipStreamSynchronize(stream) == 0
+        assert_bits_equal(out, ref.download(n_chunks - 1, P)[:, 0], "x plane read on the exported stream right behind the step")
+    s.close(); eng.close(); ref.close(); ref_eng.close(); own.close()
