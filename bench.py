@@ -32,7 +32,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured
 PARTICLE_BYTES_PER_SLOT = 112   # 48 B read (pos+life, vel+cat, attributes) + 64 B written (pos, vel, render colour, render data)
 # fp32 VALU issue: 256 CUs x 4 SIMD-32, one wave64 instruction per 2 cycles (MI355X_MICROARCH.md "Wave scheduling") at 2.4 GHz;
 # tools/ubench/valu (independent v_fma_f32 chains, 8 waves per SIMD) sustains 858 G/s -- the clock settles near 1.9 GHz under that load
-# (profiles/r01_valu_issue_calibration.md)
+# (profiles/r01/r01_valu_issue_calibration.md)
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0 / 1e9      # G wave-instructions / s
 VALU_ISSUE_CALIBRATED = 858.0
 SDF_SAMPLE_BYTES = 32           # one sampleDistanceFieldEx = 4 bilinear taps x 8 B RGBA16
