@@ -839,13 +839,32 @@ ILM_DEV UnitPlanes unit_planes(const float* chunk_base, int64_t stride, int firs
 // STREAM: the launch's working set is larger than the Infinity Cache (api.hip decides), every plane is touched once per step: loads and
 // stores carry the non-temporal hint so they do not evict each other on the way through (tools/ubench/stream: 8.4 M slots 187 -> 170 us;
 // on a cache-resident working set the same hint costs 25 %, so small systems keep the default policy).
+// Cache policy bits of the plane accesses (buffer intrinsic aux word on gfx94x / gfx950: 1 = sc0, 2 = nt, 16 = sc1).
+// Stores of the cache-resident variant carry sc1: they write through the XCD's L2 instead of leaving dirty lines there.  Every L2 is
+// private to its XCD, so a kernel's release writes back whatever is still dirty before the next launch of the stream may start --
+// up to 8 x 4 MB after a cfg2 step, ~6 us during which nothing runs (per-wave timestamps, tools/step_trace_probe.py: the waves of a
+// 16-chunk launch span 17.5 us, back-to-back launches took 24).  The written planes are read next by another launch, on whichever XCD,
+// after an invalidate: keeping them in this L2 buys nothing.  tools/step_ab.py: cfg2 without a spawner 20.3 -> 17.5 us per step, with
+// 23.4 -> 22.0 (21.0 -> 19.4 / 24.5 -> 23.5 on one stream); sc0, nt, nt + sc1 and non-temporal loads all lose on a resident working set.
+#ifndef ILM_LD_AUX
+#define ILM_LD_AUX 0
+#endif
+#ifndef ILM_ST_AUX
+#define ILM_ST_AUX 16
+#endif
+#ifndef ILM_LD_AUX_STREAM
+#define ILM_LD_AUX_STREAM 2
+#endif
+#ifndef ILM_ST_AUX_STREAM
+#define ILM_ST_AUX_STREAM 2
+#endif
 template <bool STREAM>
 ILM_DEV float ld_plane(const UnitPlanes& u, int c, unsigned lane4) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(u.rsrc, (int)lane4, (int)u.so[c], STREAM ? 2 : 0));
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(u.rsrc, (int)lane4, (int)u.so[c], STREAM ? ILM_LD_AUX_STREAM : ILM_LD_AUX));
 }
 template <bool STREAM>
 ILM_DEV void st_plane(const UnitPlanes& u, int c, unsigned lane4, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), u.rsrc, (int)lane4, (int)u.so[c], STREAM ? 2 : 0);
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), u.rsrc, (int)lane4, (int)u.so[c], STREAM ? ILM_ST_AUX_STREAM : ILM_ST_AUX);
 }
 
 template <bool ATTR, bool STREAM>
@@ -1259,9 +1278,19 @@ typedef const LeanStep __attribute__((address_space(4))) CLeanStep;
 static_assert(sizeof(LeanStep) >= 0xc84 && sizeof(LeanStep) <= 0xcc0, "touch_kernarg_lines_lean reads one dword of each 64-byte line of LeanStep");
 
 
+#ifdef ILM_STEP_TRACE      // EXPERIMENT (tools/step_trace_probe.py): per-wave start / loaded / end times of the last launch, 100 MHz clock
+__device__ unsigned long long g_step_trace[3 * 131072];
+extern "C" int ilm_experiment_step_trace(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_trace), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
 template <bool SPAWN, bool STREAM>
 __global__ __launch_bounds__(kStepThreads) void step_lean_kernel(const LeanStep a_) {
     __shared__ uint32_t wave_live[kStepThreads / 64];
+#ifdef ILM_STEP_TRACE
+    const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long trace_t1 = trace_t0;
+#endif
     const LeanStep& a = *(const LeanStep*)(CLeanStep*)__builtin_amdgcn_kernarg_segment_ptr();
     // (only the launch's first generation of blocks can be the first to read a line; for the others the loads would just load the
     // scalar cache: one lookup per line per wave)
@@ -1303,6 +1332,10 @@ __global__ __launch_bounds__(kStepThreads) void step_lean_kernel(const LeanStep 
             float4 pos = mk4(cur.px, cur.py, cur.pz, cur.life);
             float4 vel = mk4(cur.vx, cur.vy, cur.vz, cur.ct);
             float4 attr = mk4(cur.ar, cur.ag, cur.ab, cur.aa);
+#ifdef ILM_STEP_TRACE
+            asm volatile("s_waitcnt vmcnt(0)");
+            trace_t1 = __builtin_amdgcn_s_memrealtime();
+#endif
             bool spawn_here = false, spawned = false;
             if constexpr (SPAWN) {
                 for (int s = 0; s < a.spawn_count; s++) {
@@ -1357,6 +1390,12 @@ __global__ __launch_bounds__(kStepThreads) void step_lean_kernel(const LeanStep 
             n_live = (uint32_t)__popcll(__ballot(pos.w > 0.0f));
         }
     }
+#ifdef ILM_STEP_TRACE
+    if (lane == 0) {
+        const unsigned w = (blockIdx.x * (kStepThreads / 64) + (unsigned)wave) & 131071u;
+        g_step_trace[3 * w] = trace_t0; g_step_trace[3 * w + 1] = trace_t1; g_step_trace[3 * w + 2] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     if (a.flags & ILM_STEP_COUNT_LIVE)
         publish_block_count(wave_live, n_live, lane, wave, v < a.total_units, a.first_chunk + (v >> a.upc_shift),
                             (v & ((1 << a.upc_shift) - 1)) / (kStepThreads / 64), (1 << a.upc_shift) / (kStepThreads / 64), a.count_buckets,
