@@ -18,8 +18,10 @@ namespace ilm {
 //  16..19 render data            (Chunk.RenderData: size, rotation, speed, category)
 constexpr int kComponents = 20;
 constexpr int kSlotsPerThread = 4;         // widest variant; strides are padded for it
+// 128-thread blocks: a block's slot is refilled when its slowest wave ends, and the spawning variant (74 VGPRs, 6 waves per SIMD) fills the
+// CU more evenly in pairs of waves than in fours (tools/step_ab.py r02: cfg2 with the spawner 22.1 -> 20.9 us per step, others unchanged)
 #ifndef ILM_STEP_THREADS
-#define ILM_STEP_THREADS 256
+#define ILM_STEP_THREADS 128
 #endif
 constexpr int kStepThreads = ILM_STEP_THREADS;
 constexpr int kSlotsPerBlock = 1024;       // strides are padded to this

@@ -1048,7 +1048,7 @@ ILM_DEV void publish_block_count(uint32_t* wave_live, uint32_t n_live, unsigned 
 // line, all in flight at once, turns the chain into a single miss; for every later wave they are ~60 cache hits the scalar pipe has
 // room for (tools/step_ab.py with 200 extra scalar instructions per wave: no change in step time).  Measured (r02): a one-chunk launch
 // 7.7 -> 6.0 us back to back (10.8 -> 8.3 us when it spawns), cfg2 without a spawner 24.0 -> 21.4 us per step.
-constexpr int kTouchBlocks = 512;
+constexpr int kTouchBlocks = 2048 / (kStepThreads / 64);      // the launch's first 2 048 waves
 // The chunk table is read through the constant address space in both kernels: see step_lean_kernel.
 typedef float* const __attribute__((address_space(4))) CBase;
 #define ILM_T1(o) "s_load_dword %0, %1, " #o "\n"
@@ -1481,12 +1481,15 @@ static bool build_lean_step(const StepLaunch& a, LeanStep& f) {
 static hipError_t launch_lean_step(const LeanStep& f, bool spawning, bool streaming, hipStream_t stream) {
     const int units_per_block = kStepThreads / 64;
     const dim3 grid((unsigned)((f.total_units + units_per_block - 1) / units_per_block), 1, 1), block(kStepThreads, 1, 1);
+    // experiment switch: resident waves per SIMD capped through dynamic LDS (blocks per CU); 0 = no cap
+    static const int occ = [] { const char* e = getenv("ILM_STEP_OCC"); return e ? atoi(e) : 0; }();
+    const unsigned lds = (occ > 0) ? (unsigned)(160 * 1024 / occ - 64) : 0u;
     if (spawning) {
-        if (streaming) hipLaunchKernelGGL((step_lean_kernel<true, true>), grid, block, 0, stream, f);
-        else hipLaunchKernelGGL((step_lean_kernel<true, false>), grid, block, 0, stream, f);
+        if (streaming) hipLaunchKernelGGL((step_lean_kernel<true, true>), grid, block, lds, stream, f);
+        else hipLaunchKernelGGL((step_lean_kernel<true, false>), grid, block, lds, stream, f);
     } else {
-        if (streaming) hipLaunchKernelGGL((step_lean_kernel<false, true>), grid, block, 0, stream, f);
-        else hipLaunchKernelGGL((step_lean_kernel<false, false>), grid, block, 0, stream, f);
+        if (streaming) hipLaunchKernelGGL((step_lean_kernel<false, true>), grid, block, lds, stream, f);
+        else hipLaunchKernelGGL((step_lean_kernel<false, false>), grid, block, lds, stream, f);
     }
     return hipGetLastError();
 }
