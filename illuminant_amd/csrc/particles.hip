@@ -1203,7 +1203,32 @@ ILM_DEV void apply_gravity_lean(float4& pos, float4& vel, const LeanGravity& g, 
         return;
     f3 acceleration = mk3(0.0f, 0.0f, 0.0f);
     const uint32_t types = g.types;
-    for (int i = 0; i < g.count; i++) {
+    int i = 0;
+#ifndef ILM_GRAVITY_EXACT
+    // Four attractors at a time while none of the four is of the physical type (the one with the IEEE division): their records come
+    // in together, every decision is a select on a uniform mask, so the four dependent chains (subtract, dot, rsq, rcp, ...) sit in
+    // one basic block and the scheduler interleaves them.  The same operations per attractor, the terms added in index order: the
+    // same bits as the loop below.  (A wave alone on its SIMD spent 1.24 us of its 3.4 in the transforms, one attractor after the
+    // other behind a scalar load each -- and that latency is what the head and the tail of every launch consist of.)
+    for (; i + 4 <= g.count && ((((types >> (2 * i)) | (types >> (2 * i + 1))) & 0x55u) == 0x55u); i += 4) {
+        f3 term[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const LeanAttractor A = g.a[i + k];
+            const bool squared = ((types >> (2 * (i + k))) & 2u) != 0u;
+            const f3 to_center = mk3(A.x, A.y, A.z) - xyz(pos);
+            const float d2 = dot3(to_center, to_center);
+            const float inv_len = fast_rsq(d2);
+            const float distance = d2 * inv_len;
+            float attraction = 1.0f - sat(distance * fast_rcp(A.radius));
+            attraction = squared ? attraction * attraction : attraction;
+            attraction = attraction * dt_ms * (1.0f / kVelocityConstantScale);
+            term[k] = ((to_center * inv_len) * attraction) * A.strength;
+        }
+        acceleration = (((acceleration + term[0]) + term[1]) + term[2]) + term[3];
+    }
+#endif
+    for (; i < g.count; i++) {
         const LeanAttractor A = g.a[i];
         const uint32_t type = (types >> (2 * i)) & 3u;
         const f3 to_center = mk3(A.x, A.y, A.z) - xyz(pos);
@@ -1279,7 +1304,7 @@ static_assert(sizeof(LeanStep) >= 0xc84 && sizeof(LeanStep) <= 0xcc0, "touch_ker
 
 
 #ifdef ILM_STEP_TRACE      // EXPERIMENT (tools/step_trace_probe.py): per-wave start / loaded / end times of the last launch, 100 MHz clock
-__device__ unsigned long long g_step_trace[3 * 131072];
+__device__ unsigned long long g_step_trace[5 * 131072];
 extern "C" int ilm_experiment_step_trace(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_step_trace), sizeof(unsigned long long) * (size_t)n);
 }
@@ -1289,7 +1314,7 @@ __global__ __launch_bounds__(kStepThreads) void step_lean_kernel(const LeanStep 
     __shared__ uint32_t wave_live[kStepThreads / 64];
 #ifdef ILM_STEP_TRACE
     const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
-    unsigned long long trace_t1 = trace_t0;
+    unsigned long long trace_t1 = trace_t0, trace_t2 = trace_t0, trace_t3 = trace_t0;
 #endif
     const LeanStep& a = *(const LeanStep*)(CLeanStep*)__builtin_amdgcn_kernarg_segment_ptr();
     // (only the launch's first generation of blocks can be the first to read a line; for the others the loads would just load the
@@ -1366,6 +1391,10 @@ __global__ __launch_bounds__(kStepThreads) void step_lean_kernel(const LeanStep 
                         else
                             apply_fma(pos, vel, a.sys, a.op[o].fma, a.dop[o]);
                     }
+#ifdef ILM_STEP_TRACE
+                    asm volatile("" : "+v"(pos.x), "+v"(vel.x));
+                    trace_t2 = __builtin_amdgcn_s_memrealtime();
+#endif
                     if (pos.w <= 0.0f) {
                         pos = vel = zero;  // readStateOrDiscard: discard => cleared target
                     } else {
@@ -1378,6 +1407,10 @@ __global__ __launch_bounds__(kStepThreads) void step_lean_kernel(const LeanStep 
             } else {
                 pos = vel = zero;
             }
+#ifdef ILM_STEP_TRACE
+            asm volatile("" : "+v"(pos.x), "+v"(rd.x), "+v"(rc.x));
+            trace_t3 = __builtin_amdgcn_s_memrealtime();
+#endif
             st_plane<STREAM>(up, 0, lane4, pos.x); st_plane<STREAM>(up, 1, lane4, pos.y); st_plane<STREAM>(up, 2, lane4, pos.z); st_plane<STREAM>(up, 3, lane4, pos.w);
             st_plane<STREAM>(up, 4, lane4, vel.x); st_plane<STREAM>(up, 5, lane4, vel.y); st_plane<STREAM>(up, 6, lane4, vel.z); st_plane<STREAM>(up, 7, lane4, vel.w);
             if constexpr (SPAWN) {
@@ -1393,7 +1426,8 @@ __global__ __launch_bounds__(kStepThreads) void step_lean_kernel(const LeanStep 
 #ifdef ILM_STEP_TRACE
     if (lane == 0) {
         const unsigned w = (blockIdx.x * (kStepThreads / 64) + (unsigned)wave) & 131071u;
-        g_step_trace[3 * w] = trace_t0; g_step_trace[3 * w + 1] = trace_t1; g_step_trace[3 * w + 2] = __builtin_amdgcn_s_memrealtime();
+        g_step_trace[5 * w] = trace_t0; g_step_trace[5 * w + 1] = trace_t1; g_step_trace[5 * w + 2] = __builtin_amdgcn_s_memrealtime();
+        g_step_trace[5 * w + 3] = trace_t2; g_step_trace[5 * w + 4] = trace_t3;
     }
 #endif
     if (a.flags & ILM_STEP_COUNT_LIVE)

@@ -16,9 +16,9 @@ for (cs, chunks, spawn) in ((256, 16, False), (256, 16, True), (256, 1, False)):
     for _ in range(30): s.step(d)
     a.sync()
     n_waves = (chunks + (1 if spawn else 0)) * (cs * cs // 64)
-    buf = np.zeros(3 * n_waves, np.uint64)
-    assert h.ilm_experiment_step_trace(buf.ctypes.data_as(C.c_void_p), C.c_int(3 * n_waves)) == 0
-    t = buf.reshape(-1, 3).astype(np.int64)
+    buf = np.zeros(5 * n_waves, np.uint64)
+    assert h.ilm_experiment_step_trace(buf.ctypes.data_as(C.c_void_p), C.c_int(5 * n_waves)) == 0
+    t = buf.reshape(-1, 5).astype(np.int64)
     t = t[t[:, 0] > 0]
     t0 = t[:, 0].min()
     start, loaded, end = (t[:, 0] - t0) * 0.01, (t[:, 1] - t0) * 0.01, (t[:, 2] - t0) * 0.01       # us
@@ -26,6 +26,9 @@ for (cs, chunks, spawn) in ((256, 16, False), (256, 16, True), (256, 1, False)):
     life = end - start
     print("   wave lifetime us: median %.2f  p10 %.2f  p90 %.2f  max %.2f ; loads arrive after median %.2f us (p90 %.2f)" %
           (np.median(life), np.percentile(life, 10), np.percentile(life, 90), life.max(), np.median(loaded - start), np.percentile(loaded - start, 90)))
+    ok = t[:, 3] > t[:, 0]
+    print("   phases (median us): entry -> loads %.2f | transforms %.2f | update + render data %.2f | stores + exit %.2f" %
+          (np.median(loaded - start), np.median((t[ok, 3] - t[ok, 1]) * 0.01), np.median((t[ok, 4] - t[ok, 3]) * 0.01), np.median((t[ok, 2] - t[ok, 4]) * 0.01)))
     print("   starts: p1 %.2f p25 %.2f p50 %.2f p75 %.2f p99 %.2f last %.2f" % tuple(np.percentile(start, [1, 25, 50, 75, 99, 100])))
     print("   ends:   p1 %.2f p25 %.2f p50 %.2f p75 %.2f p99 %.2f last %.2f" % tuple(np.percentile(end, [1, 25, 50, 75, 99, 100])))
     edges = np.arange(0.0, end.max() + 1.0, 1.0)
