@@ -1612,6 +1612,11 @@ int32_t ilm_sdf_render_slices(IlmHandle h, IlmHandle hclear, const IlmDistanceFi
         r.cx = o.Center[0]; r.cy = o.Center[1]; r.cz = o.Center[2]; r.type = o.Type;
         r.sx = o.Size[0]; r.sy = o.Size[1]; r.sz = o.Size[2]; r._pad = 0;
         r.qx = o.Orientation[0]; r.qy = o.Orientation[1]; r.qz = o.Orientation[2]; r.qw = o.Orientation[3];
+        // The identity quaternion (what an unrotated LightObstruction carries) turns rotateLocalPosition into two quaternion products
+        // of zeros and ones: 56 operations per evaluation whose result is the input, up to the sign of a zero component -- which no
+        // shape function can see (they take |p|, p * p, p / size or sgn(p) * ...).  Flagged here, skipped in fields.hip; a centre that
+        // is not finite keeps the products (inf * 0 is a NaN there).
+        r._pad = (r.qx == 0.0f && r.qy == 0.0f && r.qz == 0.0f && r.qw == 1.0f && std::isfinite(r.cx) && std::isfinite(r.cy) && std::isfinite(r.cz)) ? 1 : 0;
         // DistanceFunctionVertexShader, DistanceFunction.fx:16-26
         const float msize = fmaxf(fmaxf(fabsf(o.Size[0]), fabsf(o.Size[1])), fabsf(o.Size[2])) + d->MaximumEncodedDistance + 4.0f;
         r.x0 = (o.Center[0] - msize) * px_per_unit_x; r.x1 = (o.Center[0] + msize) * px_per_unit_x;

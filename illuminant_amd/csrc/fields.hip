@@ -29,7 +29,9 @@ constexpr int kFieldSortCapacity = 512;      // lists up to this length are orde
 // evaluate* by LightObstructionType (LightObstruction.cs:10-16): Ellipsoid, Box, Cylinder, Spheroid, Octagon
 // are cases 1..5 of evaluateByTypeId (DistanceFunctionCommon.fxh:170-187)
 ILM_DEV float evaluate_obstruction(int type, f3 wp, const FieldObstruction& o) {
-    const f3 p = rotate_local_q(wp - mk3(o.cx, o.cy, o.cz), mk4(o.qx, o.qy, o.qz, o.qw));
+    const f3 local = wp - mk3(o.cx, o.cy, o.cz);
+    // identity orientation (uniform flag set by the host): rotateLocalPosition returns its input up to the sign of zero components
+    const f3 p = (o._pad != 0) ? local : rotate_local_q(local, mk4(o.qx, o.qy, o.qz, o.qw));
     return evaluate_shape(type + 1, p, mk3(o.sx, o.sy, o.sz));
 }
 

@@ -58,6 +58,25 @@ def test_single_type_scenes(ctx, oracle, typ):
     assert np.array_equal(render_gpu(ctx, layout, arr), render_oracle(oracle, layout, arr))
 
 
+@pytest.mark.parametrize("fmt", [abi.SDF_UNORM16, abi.SDF_FP16])
+@pytest.mark.parametrize("typ", [abi.OBSTRUCTION_ELLIPSOID, abi.OBSTRUCTION_BOX, abi.OBSTRUCTION_CYLINDER, abi.OBSTRUCTION_SPHEROID,
+                                 abi.OBSTRUCTION_OCTAGON])
+def test_unrotated_obstructions_skip_the_rotation_exactly(ctx, oracle, typ, fmt):
+    """An identity orientation lets the kernel skip rotateLocalPosition (two quaternion products whose result is the input up to the
+    sign of zero components); the oracle always runs them.  Centres ON texel positions and on slice planes put exact zeros -- of
+    both signs -- into the local coordinates; one rotated and one negative-zero-quaternion obstruction keep the general path beside it."""
+    layout = scenes.DistanceFieldLayout(192, 128, 64.0, 8, 1.0, 128)        # resolution 1: world = pixel coordinate
+    obs = [(typ, (40.0, 32.0, 0.0), (18.0, 11.0, 9.0), 0.0), (typ, (97.0, 64.0, 16.0), (25.0, 25.0, 25.0), 0.0),
+           (typ, (150.0, 90.0, 32.0), (9.0, 30.0, 14.0), 0.0), (typ, (60.0, 100.0, 8.0), (14.0, 22.0, 10.0), 0.7),
+           (typ, (120.5, 20.25, 40.0), (12.0, 7.0, 20.0), 0.0)]
+    arr = scenes.obstruction_array(obs)
+    arr[4].Orientation[0] = -0.0; arr[4].Orientation[1] = -0.0; arr[4].Orientation[2] = -0.0      # still the identity (== 0 compares true)
+    got = render_gpu(ctx, layout, arr, fmt=fmt)
+    want = render_oracle(oracle, layout, arr, fmt=fmt)
+    assert np.array_equal(got, want), "%d texel channels differ" % int((got != want).sum())
+    assert (want > 0).mean() > 0.2
+
+
 def test_empty_scene_and_empty_slice_list(ctx, oracle):
     layout = scenes.DistanceFieldLayout(96, 64, 32.0, 6, 1.0, 128)
     assert (render_gpu(ctx, layout) == 0).all()

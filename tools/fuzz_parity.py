@@ -141,7 +141,8 @@ for seed in range(first, first + count, 4):
     rng = np.random.default_rng(seed + 77777)
     ext = (int(rng.integers(64, 300)), int(rng.integers(64, 240)))
     layout = scenes.DistanceFieldLayout(ext[0], ext[1], float(rng.uniform(32, 128)), int(rng.integers(3, 16)), float(rng.choice([1.0, 0.5, 0.3, 0.25])), 128)
-    obs = scenes.random_obstructions(seed, int(rng.integers(1, 40)), ext, size_lo=float(rng.uniform(2, 10)), size_hi=float(rng.uniform(12, 90)), z_hi=float(rng.uniform(8, 80)))
+    obs = scenes.random_obstructions(seed, int(rng.integers(1, 40)), ext, size_lo=float(rng.uniform(2, 10)), size_hi=float(rng.uniform(12, 90)), z_hi=float(rng.uniform(8, 80)),
+                                     rotate=bool((seed // 4) % 2))      # every other scene unrotated: the kernel skips identity rotations
     arr = scenes.obstruction_array(obs)
     fmt = abi.SDF_FP16 if seed % 8 < 4 else abi.SDF_UNORM16
     d = scenes.render_desc(layout)
