@@ -321,3 +321,50 @@ def test_a_context_whose_stream_was_handed_out_steps_on_that_stream(ctx):
         assert hip.hipStreamSynchronize(stream) == 0
         assert_bits_equal(out, ref.download(n_chunks - 1, P)[:, 0], "x plane read on the exported stream right behind the step")
     s.close(); eng.close(); ref.close(); ref_eng.close(); own.close()
+
+
+def test_consumers_of_a_split_step_see_both_halves(ctx):
+    """Read-back compaction, the rasteriser and the particle lights run on the context stream right behind a two-stream step: each must
+    see the planes of BOTH halves (Ctx::main joins them).  Same calls after one-stream steps give the reference bits."""
+    from tests import output_common as oc
+    import ctypes as C
+    from tests.lights_common import no_field_uniforms, particle_light_params
+    cs, n_chunks = 256, 8
+    n = cs * cs
+    rnd = scenes.randomness_table(29)
+    eng = native.Engine(ctx, cs, rnd)
+    pos, vel, attr = scenes.make_particles(61, n, pos_hi=(640, 360, 16), life=(0.5, 3.0), dead_fraction=0.97)
+    results = []
+    prev = native.lib().ilm_debug_step_streams(2)
+    try:
+        for streams in (2, 1):
+            native.lib().ilm_debug_step_streams(streams)
+            s = native.System(eng)
+            for c in range(n_chunks):
+                s.add_chunk()
+                s.upload(c, P, np.roll(pos, c * 37, axis=0)); s.upload(c, V, vel); s.upload(c, A, attr)
+            log = []
+            target = native.Lightmap(ctx, 640, 360, abi.LIGHTMAP_FLOAT4)
+            lit = native.Lightmap(ctx, 640, 360, abi.LIGHTMAP_FLOAT4)
+            for i in range(3):
+                s.step(_step(cs, dict(ops=("gravity", "noise"), count=False)))
+                recs, count = s.readback(oc.readback_params(size=(2.0, 2.0)))
+                log.append(np.frombuffer(recs, dtype=np.uint8)[:C.sizeof(abi.ReadbackDrawCall) * count].copy())
+                s.step(_step(cs, dict(ops=("gravity", "noise"), count=False)))
+                target.clear((0.0, 0.0, 0.0, 0.0))
+                native.render_particles(s, scenes.rasterize_params(size=(1.5, 1.5)), target)
+                log.append(target.download().copy())
+                s.step(_step(cs, dict(ops=("gravity", "noise"), count=False)))
+                lit.clear((0.0, 0.0, 0.0, 1.0))
+                native.render_particle_lights(ctx, s, particle_light_params(6.0, 20.0), scenes.environment(), no_field_uniforms(), None, None, lit)
+                log.append(lit.download().copy())
+            results.append(log)
+            target.close(); lit.close(); s.close()
+    finally:
+        native.lib().ilm_debug_step_streams(prev)
+    two, one = results
+    assert len(two) == len(one) == 9
+    for k, (a, b) in enumerate(zip(two, one)):
+        assert a.shape == b.shape and np.array_equal(a.view(np.uint8), b.view(np.uint8)), "output %d differs between two-stream and one-stream stepping" % k
+    assert two[0].size > 0 and two[1].any() and two[2].any()
+    eng.close()
