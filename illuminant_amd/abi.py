@@ -7,7 +7,7 @@ offsets against the C header by compiling a probe.
 """
 import ctypes as C
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 OK = 0
 ERR_INVALID_ARGUMENT = -1
@@ -248,6 +248,30 @@ class GBufferRenderDesc(C.Structure):
                 ("EnableGroundShadows", i32), ("_pad", i32)]
 
 
+class HeightVolumeVertex(C.Structure):
+    """HeightVolumeVertex, Illuminant/Vertices.cs:41-46 (Pack = 4)"""
+    _fields_ = [("Position", f32 * 3), ("Normal", f32 * 3), ("ZRange", f32 * 2), ("EnableShadows", f32)]
+
+
+class BillboardVertex(C.Structure):
+    """BillboardVertex, Illuminant/Vertices.cs:75-81 (Pack = 4)"""
+    _fields_ = [("ScreenPosition", f32 * 2), ("TexCoord", f32 * 2), ("WorldPosition", f32 * 3), ("Normal", f32 * 3),
+                ("DataScaleAndDynamicFlag", f32 * 2)]
+
+
+BILLBOARD_MASK, BILLBOARD_GBUFFER_DATA = 0, 1
+
+
+class BillboardRun(C.Structure):
+    _fields_ = [("Texture", Handle), ("FirstQuad", i32), ("QuadCount", i32), ("Type", i32), ("_pad", i32)]
+
+
+class GBufferMeshDesc(C.Structure):
+    _fields_ = [("ViewportPosition", f32 * 2), ("ViewportScale", f32 * 2), ("GroundZ", f32), ("ZToYMultiplier", f32),
+                ("RenderScale", f32 * 2), ("DistanceFieldExtentZ", f32), ("SelfOcclusionHack", f32), ("ZSelfOcclusionHack", f32),
+                ("TwoPointFiveD", i32), ("RenderGroundPlane", i32), ("EnableGroundShadows", i32), ("_pad", i32 * 2)]
+
+
 class DistanceFieldRenderDesc(C.Structure):
     _fields_ = [("VirtualWidth", i32), ("VirtualHeight", i32), ("VirtualDepth", f32), ("ZOffset", f32),
                 ("SliceWidth", i32), ("SliceHeight", i32), ("SliceCount", i32), ("ColumnCount", i32),
@@ -302,4 +326,6 @@ EXPECTED_SIZES = {
     "IlmGBufferRenderDesc": (GBufferRenderDesc, 32), "IlmRasterizeParams": (RasterizeParams, 192),
     "IlmObstruction": (Obstruction, 48), "IlmHeightVolume": (HeightVolume, 32),
     "IlmDistanceFieldRenderDesc": (DistanceFieldRenderDesc, 64),
+    "IlmHeightVolumeVertex": (HeightVolumeVertex, 36), "IlmBillboardVertex": (BillboardVertex, 48),
+    "IlmBillboardRun": (BillboardRun, 24), "IlmGBufferMeshDesc": (GBufferMeshDesc, 64),
 }

@@ -1788,6 +1788,89 @@ int32_t ilm_gbuffer_render(IlmHandle h, const IlmGBufferRenderDesc* d, const Ilm
     return ILM_OK;
 }
 
+int32_t ilm_gbuffer_render_meshes(IlmHandle h, const IlmGBufferMeshDesc* d,
+                                  const IlmHeightVolumeVertex* top_vertices, int32_t top_vertex_count,
+                                  const IlmHeightVolumeVertex* front_vertices, int32_t front_vertex_count,
+                                  const IlmBillboardVertex* billboard_vertices, int32_t billboard_vertex_count,
+                                  const IlmBillboardRun* runs, int32_t run_count) {
+    GBuffer* g = from_handle<GBuffer>(h, kMagicGBuffer);
+    if (!g) return fail(ILM_ERR_INVALID_HANDLE, "not a G-buffer handle");
+    if (!d) return fail(ILM_ERR_INVALID_ARGUMENT, "desc is NULL");
+    if (top_vertex_count < 0 || front_vertex_count < 0 || billboard_vertex_count < 0 || run_count < 0 ||
+        (top_vertex_count > 0 && !top_vertices) || (front_vertex_count > 0 && !front_vertices) ||
+        (billboard_vertex_count > 0 && !billboard_vertices) || (run_count > 0 && !runs))
+        return fail(ILM_ERR_INVALID_ARGUMENT, "bad array argument");
+    if ((top_vertex_count % 3) != 0 || (front_vertex_count % 3) != 0 || (billboard_vertex_count % 4) != 0)
+        return fail(ILM_ERR_INVALID_ARGUMENT, "triangle lists hold 3 vertices per triangle, billboards 4 per quad");
+    if (!(d->ViewportScale[0] > 0.0f) || !(d->ViewportScale[1] > 0.0f)) return fail(ILM_ERR_INVALID_ARGUMENT, "ViewportScale must be positive");
+    if (!d->TwoPointFiveD && front_vertex_count > 0)
+        return fail(ILM_ERR_INVALID_ARGUMENT, "front faces are only drawn with TwoPointFiveD (LightingRenderer.GBuffer.cs:160-167)");
+    if (d->TwoPointFiveD && (top_vertex_count > 0 || front_vertex_count > 0) && !(d->DistanceFieldExtentZ > 0.0f))
+        return fail(ILM_ERR_INVALID_ARGUMENT, "DistanceFieldExtentZ must be positive: the depth of a 2.5D vertex is z / DistanceFieldExtent.z");
+    Ctx* c = g->ctx;
+    // billboard quads in draw order: the mask batch is one layer below the g-data batch (:371-392)
+    std::vector<int4> quads;
+    std::vector<GBufferTex> textures((size_t)run_count);
+    for (int r = 0; r < run_count; r++) {
+        const IlmBillboardRun& run = runs[r];
+        if (run.Type != ILM_BILLBOARD_MASK && run.Type != ILM_BILLBOARD_GBUFFER_DATA)
+            return fail(ILM_ERR_INVALID_ARGUMENT, "billboard run %d: unknown type %d", r, run.Type);
+        if (run.FirstQuad < 0 || run.QuadCount < 0 || (int64_t)run.FirstQuad + run.QuadCount > billboard_vertex_count / 4)
+            return fail(ILM_ERR_OUT_OF_RANGE, "billboard run %d outside the vertex array", r);
+        GBufferTex t = { nullptr, 0, 0, 0, 0 };
+        if (run.Texture != 0) {
+            Lightmap* m = from_handle<Lightmap>(run.Texture, kMagicLightmap);
+            if (!m) return fail(ILM_ERR_INVALID_HANDLE, "billboard run %d: not a texture handle", r);
+            if (m->ctx != c) return fail(ILM_ERR_INVALID_ARGUMENT, "billboard run %d: the texture belongs to another context", r);
+            t.texels = m->texels; t.width = m->width; t.height = m->height; t.format = m->format;
+        }
+        textures[(size_t)r] = t;
+    }
+    for (int type = ILM_BILLBOARD_MASK; type <= ILM_BILLBOARD_GBUFFER_DATA; type++)
+        for (int r = 0; r < run_count; r++)
+            if (runs[r].Type == type)
+                for (int q = runs[r].FirstQuad; q < runs[r].FirstQuad + runs[r].QuadCount; q++)
+                    quads.push_back(make_int4(q, r, type == ILM_BILLBOARD_MASK ? 3 : 4, 0));
+    const int64_t prim_count = 2 + (int64_t)top_vertex_count / 3 + front_vertex_count / 3 + 2 * (int64_t)quads.size();
+    if (prim_count > (1 << 24)) return fail(ILM_ERR_TOO_MANY, "%lld triangles in one G-buffer frame", (long long)prim_count);
+    HIP_TRY(hipSetDevice(c->device));
+    auto align64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
+    const size_t off_front = align64(sizeof(IlmHeightVolumeVertex) * (size_t)top_vertex_count);
+    const size_t off_bb = align64(off_front + sizeof(IlmHeightVolumeVertex) * (size_t)front_vertex_count);
+    const size_t off_quads = align64(off_bb + sizeof(IlmBillboardVertex) * (size_t)billboard_vertex_count);
+    const size_t off_tex = align64(off_quads + sizeof(int4) * quads.size());
+    const size_t inputs = align64(off_tex + sizeof(GBufferTex) * textures.size()) + 64;
+    const size_t total = inputs + sizeof(GBufferPrim) * (size_t)prim_count;
+    if (total > c->field_params_bytes) {
+        HIP_TRY(hipStreamSynchronize(c->main()));
+        if (c->d_field_params) HIP_TRY(hipFree(c->d_field_params));
+        c->d_field_params = nullptr; c->field_params_bytes = 0;
+        const size_t cap = total < 65536 ? 65536 : total * 2;
+        HIP_TRY(hipMalloc(&c->d_field_params, cap));
+        c->field_params_bytes = cap;
+    }
+    std::vector<unsigned char> block(inputs, 0);
+    if (top_vertex_count) memcpy(block.data(), top_vertices, sizeof(IlmHeightVolumeVertex) * (size_t)top_vertex_count);
+    if (front_vertex_count) memcpy(block.data() + off_front, front_vertices, sizeof(IlmHeightVolumeVertex) * (size_t)front_vertex_count);
+    if (billboard_vertex_count) memcpy(block.data() + off_bb, billboard_vertices, sizeof(IlmBillboardVertex) * (size_t)billboard_vertex_count);
+    if (!quads.empty()) memcpy(block.data() + off_quads, quads.data(), sizeof(int4) * quads.size());
+    if (!textures.empty()) memcpy(block.data() + off_tex, textures.data(), sizeof(GBufferTex) * textures.size());
+    int32_t rc = upload_small(c, c->d_field_params, block.data(), inputs);
+    if (rc != ILM_OK) return rc;
+    char* base = static_cast<char*>(c->d_field_params);
+    GBufferMeshLaunch a;
+    a.texels = g->texels; a.width = g->width; a.height = g->height; a.format = g->format;
+    a.desc = *d;
+    a.top = reinterpret_cast<const IlmHeightVolumeVertex*>(base); a.top_triangles = top_vertex_count / 3;
+    a.front = reinterpret_cast<const IlmHeightVolumeVertex*>(base + off_front); a.front_triangles = front_vertex_count / 3;
+    a.billboards = reinterpret_cast<const IlmBillboardVertex*>(base + off_bb);
+    a.quads = reinterpret_cast<const int4*>(base + off_quads);
+    a.textures = reinterpret_cast<const GBufferTex*>(base + off_tex);
+    a.prims = reinterpret_cast<GBufferPrim*>(base + inputs); a.prim_count = (int32_t)prim_count;
+    HIP_TRY(launch_gbuffer_meshes(a, c->main()));
+    return ILM_OK;
+}
+
 int32_t ilm_gbuffer_destroy(IlmHandle h) {
     GBuffer* g = from_handle<GBuffer>(h, kMagicGBuffer);
     if (!g) return fail(ILM_ERR_INVALID_HANDLE, "not a G-buffer handle");

@@ -1,0 +1,268 @@
+// gbuffer.hip -- RenderGBuffer with the host's meshes: 2.5D height volumes (top + front faces under the depth test) and billboards
+// (ilm_gbuffer_render_meshes; Illuminant/Lighting/LightingRenderer.GBuffer.cs:102-478, Illuminant/Shaders/GBuffer.fx, GBufferBitmap.fx,
+// GBufferShaderCommon.fxh).  gfx950 only.
+//
+// The reference hands triangle lists to the Direct3D rasteriser, one draw call after the other into one render target with a 24-bit
+// depth buffer.  Here the whole frame is ONE pass over the pixels: a setup kernel runs the three vertex shaders and snaps every
+// triangle to the 1/256-pixel grid (one thread per triangle, records in draw order); the raster kernel gives every wave an 8 x 8 pixel
+// tile, walks the records in draw order with wave-uniform (scalar) loads, rejects a record against the tile with scalar compares, and
+// keeps each pixel's colour and depth in registers until its single store -- 16 B (or 8 B) written per texel, nothing read back, no
+// atomics, and the reference's draw order is the loop order.  Coverage is exact integer arithmetic (64-bit edge functions, top-left
+// rule), so a pixel belongs to exactly one of two triangles sharing an edge, as on the hardware.
+#include "internal.hpp"
+#include "hlsl_math.hpp"
+
+namespace ilm {
+
+namespace {
+
+constexpr int kGround = 0, kTop = 1, kFace = 2, kMask = 3, kGData = 4;
+
+// round-to-nearest onto the 1/256-pixel grid; positions are confined to +-2^30 so that edge functions fit 64 bits
+ILM_DEV int32_t snap(float s) {
+    double v = floor((double)s * 256.0 + 0.5);
+    if (!(v > -1073741824.0)) v = -1073741824.0;
+    if (v > 1073741824.0) v = 1073741824.0;
+    return (int32_t)v;
+}
+
+ILM_DEV int64_t edge(int32_t ax, int32_t ay, int32_t bx, int32_t by, int64_t px, int64_t py) {
+    return ((int64_t)bx - ax) * (py - ay) - ((int64_t)by - ay) * (px - ax);
+}
+
+// top-left rule on a clockwise triangle (y down): top edges run left to right, left edges run upwards
+ILM_DEV bool edge_owns(int32_t ax, int32_t ay, int32_t bx, int32_t by) { return (by < ay) || ((by == ay) && (bx > ax)); }
+
+ILM_DEV void finish(GBufferPrim& p, const float sx[3], const float sy[3]) {
+    for (int k = 0; k < 3; k++) { p.x[k] = snap(sx[k]); p.y[k] = snap(sy[k]); }
+    const int64_t area = edge(p.x[0], p.y[0], p.x[1], p.y[1], p.x[2], p.y[2]);
+    if (area == 0) { p.kind = -1; p.i0 = p.j0 = 1; p.i1 = p.j1 = 0; return; }
+    if (area < 0) {                                              // CullMode.None: the other winding is drawn too
+        int32_t t = p.x[1]; p.x[1] = p.x[2]; p.x[2] = t;
+        t = p.y[1]; p.y[1] = p.y[2]; p.y[2] = t;
+        for (int k = 0; k < kGBufferAttrs; k++) { const float f = p.a[1][k]; p.a[1][k] = p.a[2][k]; p.a[2][k] = f; }
+    }
+    const int32_t x0 = min(p.x[0], min(p.x[1], p.x[2])), x1 = max(p.x[0], max(p.x[1], p.x[2]));
+    const int32_t y0 = min(p.y[0], min(p.y[1], p.y[2])), y1 = max(p.y[0], max(p.y[1], p.y[2]));
+    // pixel centres 256 i + 128 inside [x0, x1]
+    p.i0 = (int32_t)(((int64_t)x0 - 128 + 255) >> 8); p.i1 = (int32_t)(((int64_t)x1 - 128) >> 8);
+    p.j0 = (int32_t)(((int64_t)y0 - 128 + 255) >> 8); p.j1 = (int32_t)(((int64_t)y1 - 128) >> 8);
+}
+
+// GroundPlaneVertexShader / HeightVolumeVertexShader / HeightVolumeFaceVertexShader, GBuffer.fx:7-55
+// attributes: 0-2 worldPosition, 3-5 normal, 6 enableShadows, 7 result.z, 8 dead
+ILM_DEV void volume_prim(GBufferPrim& p, int kind, const IlmHeightVolumeVertex& v0, const IlmHeightVolumeVertex& v1,
+                         const IlmHeightVolumeVertex& v2, const IlmGBufferMeshDesc& d) {
+    const IlmHeightVolumeVertex* v[3] = { &v0, &v1, &v2 };
+    float sx[3], sy[3];
+    p.kind = kind; p.texture = -1;
+    for (int k = 0; k < 3; k++) {
+        const float x = v[k]->Position[0], z = v[k]->Position[2];
+        float y = v[k]->Position[1];
+        for (int c = 0; c < kGBufferAttrs; c++) p.a[k][c] = 0.0f;
+        p.a[k][0] = x; p.a[k][1] = y; p.a[k][2] = z;
+        p.a[k][3] = v[k]->Normal[0]; p.a[k][4] = v[k]->Normal[1]; p.a[k][5] = v[k]->Normal[2];
+        p.a[k][6] = v[k]->EnableShadows;
+        if (kind == kGround) {
+            p.a[k][7] = 0.0f;
+            p.a[k][8] = (z < -9999.0f) ? 1.0f : 0.0f;
+        } else {
+            y -= d.ZToYMultiplier * z;
+            p.a[k][7] = z / d.DistanceFieldExtentZ;
+        }
+        sx[k] = (x - d.ViewportPosition[0]) * d.ViewportScale[0];
+        sy[k] = (y - d.ViewportPosition[1]) * d.ViewportScale[1];
+    }
+    finish(p, sx, sy);
+}
+
+// BillboardVertexShader, GBufferBitmap.fx:12-27 (POSITION0 carries two floats, Vertices.cs:89: position.z reads 0)
+// attributes: 0-2 worldPosition, 3-5 normal, 6-7 texCoord, 8 screenPosition.y, 9-10 dataScaleAndDynamicFlag
+ILM_DEV void billboard_prim(GBufferPrim& p, int kind, int texture, const IlmBillboardVertex& v0, const IlmBillboardVertex& v1,
+                            const IlmBillboardVertex& v2, const IlmGBufferMeshDesc& d) {
+    const IlmBillboardVertex* v[3] = { &v0, &v1, &v2 };
+    float sx[3], sy[3];
+    p.kind = kind; p.texture = texture;
+    for (int k = 0; k < 3; k++) {
+        for (int c = 0; c < kGBufferAttrs; c++) p.a[k][c] = 0.0f;
+        for (int c = 0; c < 3; c++) {
+            p.a[k][c] = v[k]->WorldPosition[c] + (d.SelfOcclusionHack * v[k]->Normal[c]);
+            p.a[k][3 + c] = v[k]->Normal[c];
+        }
+        p.a[k][6] = v[k]->TexCoord[0]; p.a[k][7] = v[k]->TexCoord[1];
+        p.a[k][8] = v[k]->ScreenPosition[1];
+        p.a[k][9] = v[k]->DataScaleAndDynamicFlag[0]; p.a[k][10] = v[k]->DataScaleAndDynamicFlag[1];
+        sx[k] = (v[k]->ScreenPosition[0] - d.ViewportPosition[0]) * d.ViewportScale[0];
+        sy[k] = (v[k]->ScreenPosition[1] - d.ViewportPosition[1]) * d.ViewportScale[1];
+    }
+    finish(p, sx, sy);
+}
+
+// encodeNormalSpherical, EnvironmentCommon.fxh:33-40; encodeGBufferSample, GBufferShaderCommon.fxh:10-35 (fullbright = false)
+ILM_DEV float4 encode_sample(f3 n, float relative_y, float z, bool dead, bool enable_shadows) {
+    if (dead)
+        return mk4(0.0f, 0.0f, -99999.0f, -99999.0f);
+    float ex = 0.0f, ey = 0.0f;
+    if ((n.x != 0.0f) || (n.y != 0.0f) || (n.z != 0.0f)) {
+        const float nx = (fabsf(n.x) < 0.0001f) ? 0.0001f : n.x;
+        ex = ((atan2f(n.y, nx) / kPi) + 1.0f) * 0.5f;
+        ey = (n.z + 1.0f) * 0.5f;
+    }
+    const float w = (((z + ref::kGBufferZOffset) / ref::kGBufferZScale) * (enable_shadows ? 1.0f : -1.0f)) + (enable_shadows ? 0.0f : -1.0f);
+    return mk4(ex, ey, relative_y, w);
+}
+
+// tex2D through the POINT / CLAMP sampler (LightingRenderer.GBuffer.cs:301-307); nothing bound reads (0, 0, 0, 1)
+ILM_DEV float4 sample_point(const GBufferTex* textures, int index, float u, float v) {
+    if (index < 0)
+        return mk4(0.0f, 0.0f, 0.0f, 1.0f);
+    const GBufferTex t = textures[index];
+    if (t.texels == nullptr)
+        return mk4(0.0f, 0.0f, 0.0f, 1.0f);
+    const float fx = floorf(u * (float)t.width), fy = floorf(v * (float)t.height);
+    const int x = !(fx >= 0.0f) ? 0 : ((fx > (float)(t.width - 1)) ? t.width - 1 : (int)fx);
+    const int y = !(fy >= 0.0f) ? 0 : ((fy > (float)(t.height - 1)) ? t.height - 1 : (int)fy);
+    const size_t o = (size_t)y * (size_t)t.width + (size_t)x;
+    if (t.format == ILM_LIGHTMAP_RGBA8) {
+        const uint32_t c = reinterpret_cast<const uint32_t*>(t.texels)[o];
+        return mk4((float)(c & 0xFFu) / 255.0f, (float)((c >> 8) & 0xFFu) / 255.0f, (float)((c >> 16) & 0xFFu) / 255.0f, (float)(c >> 24) / 255.0f);
+    }
+    if (t.format == ILM_LIGHTMAP_HALF4) {
+        const uint2 hh = reinterpret_cast<const uint2*>(t.texels)[o];
+        return mk4(__half2float(__ushort_as_half((unsigned short)(hh.x & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(hh.x >> 16))),
+                   __half2float(__ushort_as_half((unsigned short)(hh.y & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(hh.y >> 16))));
+    }
+    return reinterpret_cast<const float4*>(t.texels)[o];
+}
+
+}  // namespace
+
+// one thread per triangle of the frame, in draw order: [ground plane 2][top][front][billboard quads 2 each]
+__global__ __launch_bounds__(64) void gbuffer_setup_kernel(const GBufferMeshLaunch a) {
+    const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (t >= a.prim_count) return;
+    GBufferPrim p;
+    const IlmGBufferMeshDesc& d = a.desc;
+    const int quad_indices[6] = { 0, 1, 3, 1, 2, 3 };           // QuadIndices, LightingRenderer.cs:421-423
+    if (t < 2) {
+        // RenderGroundPlane, LightingRenderer.GBuffer.cs:271-299
+        const float gz = d.GroundZ + (d.RenderGroundPlane ? 0.0f : 99999.0f);
+        const float cx[4] = { -999999.0f, 999999.0f, 999999.0f, -999999.0f }, cy[4] = { -999999.0f, -999999.0f, 999999.0f, 999999.0f };
+        IlmHeightVolumeVertex g[3];
+        for (int k = 0; k < 3; k++) {
+            const int c = quad_indices[3 * t + k];
+            g[k].Position[0] = cx[c]; g[k].Position[1] = cy[c]; g[k].Position[2] = gz;
+            g[k].Normal[0] = 0.0f; g[k].Normal[1] = 0.0f; g[k].Normal[2] = 1.0f;
+            g[k].ZRange[0] = d.GroundZ; g[k].ZRange[1] = d.GroundZ;
+            g[k].EnableShadows = d.EnableGroundShadows ? 1.0f : 0.0f;
+        }
+        volume_prim(p, kGround, g[0], g[1], g[2], d);
+    } else if (t < 2 + a.top_triangles) {
+        const IlmHeightVolumeVertex* v = a.top + 3 * (size_t)(t - 2);
+        volume_prim(p, d.TwoPointFiveD ? kTop : kGround, v[0], v[1], v[2], d);
+    } else if (t < 2 + a.top_triangles + a.front_triangles) {
+        const IlmHeightVolumeVertex* v = a.front + 3 * (size_t)(t - 2 - a.top_triangles);
+        volume_prim(p, kFace, v[0], v[1], v[2], d);
+    } else {
+        const int b = t - 2 - a.top_triangles - a.front_triangles;
+        const int4 q = a.quads[b >> 1];                          // (quad, texture, kind, -)
+        const IlmBillboardVertex* v = a.billboards + 4 * (size_t)q.x;
+        const int* ix = quad_indices + 3 * (b & 1);
+        billboard_prim(p, q.z, q.y, v[ix[0]], v[ix[1]], v[ix[2]], d);
+    }
+    a.prims[t] = p;
+}
+
+// one wave per 8 x 8 pixel tile, four tiles (16 x 16 pixels) per workgroup
+__global__ __launch_bounds__(256) void gbuffer_meshes_kernel(const GBufferMeshLaunch a) {
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const int ti0 = (int)blockIdx.x * 16 + (wave & 1) * 8, tj0 = (int)blockIdx.y * 16 + (wave >> 1) * 8;   // wave-uniform
+    const int i = ti0 + (lane & 7), j = tj0 + (lane >> 3);
+    const int64_t px = 256 * (int64_t)i + 128, py = 256 * (int64_t)j + 128;
+    const IlmGBufferMeshDesc& d = a.desc;
+    float4 texel = mk4(0.0f, 0.0f, 0.0f, 0.0f);                  // ClearBatch(Color.Transparent, clearZ: 0), :147-150
+    uint32_t depth = 0;
+    const int tile_i0 = __builtin_amdgcn_readfirstlane(ti0), tile_j0 = __builtin_amdgcn_readfirstlane(tj0);
+    for (int t = 0; t < a.prim_count; t++) {
+        const GBufferPrim& p = a.prims[t];
+        if ((p.i1 < tile_i0) || (p.i0 > tile_i0 + 7) || (p.j1 < tile_j0) || (p.j0 > tile_j0 + 7))
+            continue;
+        const int64_t w0 = edge(p.x[1], p.y[1], p.x[2], p.y[2], px, py);
+        const int64_t w1 = edge(p.x[2], p.y[2], p.x[0], p.y[0], px, py);
+        const int64_t w2 = edge(p.x[0], p.y[0], p.x[1], p.y[1], px, py);
+        bool in = (w0 >= 0) && (w1 >= 0) && (w2 >= 0);
+        in = in && ((w0 != 0) || edge_owns(p.x[1], p.y[1], p.x[2], p.y[2]));
+        in = in && ((w1 != 0) || edge_owns(p.x[2], p.y[2], p.x[0], p.y[0]));
+        in = in && ((w2 != 0) || edge_owns(p.x[0], p.y[0], p.x[1], p.y[1]));
+        if (!in)
+            continue;
+        const double area = (double)(w0 + w1 + w2);
+        const float f1 = (float)((double)w1 / area), f2 = (float)((double)w2 / area);
+        auto at = [&](int k) { return (p.a[0][k] + (p.a[1][k] - p.a[0][k]) * f1) + (p.a[2][k] - p.a[0][k]) * f2; };
+        const float z = at(7);
+        if (!((z >= 0.0f) && (z <= 1.0f)))                       // clipped against the near / far plane (w = 1)
+            continue;
+        const f3 wp = mk3(at(0), at(1), at(2));
+        const f3 n = mk3(at(3), at(4), at(5));
+        float4 out;
+        const int kind = p.kind;
+        if (kind == kGround) {                                   // GroundPlanePixelShader, GBuffer.fx:57-70
+            if (wp.z < d.GroundZ) continue;
+            out = encode_sample(mk3(0.0f, 0.0f, 1.0f), 0.0f, wp.z, at(8) != 0.0f, at(6) > 0.5f);
+        } else if ((kind == kTop) || (kind == kFace)) {          // HeightVolumePixelShader :72-85 / HeightVolumeFacePixelShader :87-103
+            f3 bias = mk3(0.0f, 0.0f, d.ZSelfOcclusionHack);
+            if (kind == kFace) {
+                if (wp.z < d.GroundZ) continue;
+                bias = mk3(d.SelfOcclusionHack, d.SelfOcclusionHack, d.ZSelfOcclusionHack) * n;
+            }
+            const float relative_y = (((wp.z * d.ZToYMultiplier) * d.ViewportScale[0]) / d.RenderScale[0]) + bias.y;
+            out = encode_sample(n, relative_y, wp.z + bias.z, false, at(6) > 0.5f);
+            // DepthFormat.Depth24, CompareFunction.GreaterEqual with writes (LightingRenderer.cs:539-551)
+            const uint32_t d24 = (uint32_t)floor((double)z * 16777215.0 + 0.5);
+            if (!(d24 >= depth)) continue;
+            depth = d24;
+        } else {
+            const float4 data = sample_point(a.textures, p.texture, at(6), at(7));
+            const float data_scale = at(9);
+            if (kind == kMask) {                                 // MaskBillboardPixelShader, GBufferBitmap.fx:29-59
+                const float discard_threshold = 1.0f / 255.0f;
+                if ((data.w - discard_threshold) < 0.0f) continue;
+                const float relative_y = (wp.y - at(8)) * data_scale;
+                out = mk4((n.x / 2.0f) + 0.5f, (n.z / 2.0f) + 0.5f, relative_y,
+                          ((wp.z + ref::kGBufferZOffset) / ref::kGBufferZScale) * at(10));
+            } else if (kind == kGData) {                         // GDataBillboardPixelShader, GBufferBitmap.fx:61-113
+                const float discard_threshold = 127.0f / 255.0f;
+                if (data.w < discard_threshold) continue;
+                const float tx = (data.x - 0.5f) * 2.0f, ty = (data.y - 0.5f) * 2.0f;
+                const float tz = sqrtf(1.0f - (tx * tx + ty * ty));
+                const f3 world_normal = mk3((1.0f * tx + 0.0f * ty) + 0.0f * tz, (0.0f * tx + -1.0f * ty) + 0.0f * tz, (0.0f * tx + 0.0f * ty) + 1.0f * tz);
+                const f3 result_normal = norm3(world_normal);
+                const float effective_z = wp.z + (data.z * data_scale);
+                out = encode_sample(result_normal, effective_z * d.ZToYMultiplier, effective_z, false, true);
+            } else {
+                continue;                                        // a degenerate triangle's record (empty bounds: not reached)
+            }
+        }
+        texel = out;
+    }
+    if (i >= a.width || j >= a.height) return;
+    const size_t o = (size_t)j * (size_t)a.width + (size_t)i;
+    if (a.format == ILM_GBUFFER_HALF4) {
+        uint2 h;
+        h.x = (uint32_t)__half_as_ushort(__float2half_rn(texel.x)) | ((uint32_t)__half_as_ushort(__float2half_rn(texel.y)) << 16);
+        h.y = (uint32_t)__half_as_ushort(__float2half_rn(texel.z)) | ((uint32_t)__half_as_ushort(__float2half_rn(texel.w)) << 16);
+        reinterpret_cast<uint2*>(a.texels)[o] = h;
+    } else {
+        reinterpret_cast<float4*>(a.texels)[o] = texel;
+    }
+}
+
+hipError_t launch_gbuffer_meshes(const GBufferMeshLaunch& a, hipStream_t stream) {
+    if (a.width <= 0 || a.height <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gbuffer_setup_kernel, dim3((unsigned)((a.prim_count + 63) / 64)), dim3(64), 0, stream, a);
+    const dim3 grid((unsigned)((a.width + 15) / 16), (unsigned)((a.height + 15) / 16)), block(256);
+    hipLaunchKernelGGL(gbuffer_meshes_kernel, grid, block, 0, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace ilm

@@ -246,6 +246,28 @@ struct GBufferLaunch {
 };
 hipError_t launch_render_gbuffer(const GBufferLaunch& a, hipStream_t stream);
 
+// G-buffer from the host's meshes (gbuffer.hip): one record per triangle in draw order, written by the setup kernel and read
+// wave-uniformly by the raster kernel
+constexpr int kGBufferAttrs = 12;
+struct GBufferPrim {
+    int32_t x[3], y[3];           // 1/256-pixel positions, clockwise on the y-down screen
+    int32_t i0, i1, j0, j1;       // pixels whose centres the bounding box holds (inclusive; empty for a degenerate triangle)
+    int32_t kind, texture;        // pixel shader; index into the launch's texture table or -1
+    float a[3][kGBufferAttrs];    // per-vertex attributes
+};
+struct GBufferTex { const void* texels; int32_t width, height, format, _pad; };
+struct GBufferMeshLaunch {
+    void* texels; int32_t width, height, format;
+    IlmGBufferMeshDesc desc;
+    const IlmHeightVolumeVertex* top; int32_t top_triangles;
+    const IlmHeightVolumeVertex* front; int32_t front_triangles;
+    const IlmBillboardVertex* billboards;
+    const int4* quads;            // (quad, texture, kind, -) per billboard quad in draw order
+    const GBufferTex* textures;
+    GBufferPrim* prims; int32_t prim_count;
+};
+hipError_t launch_gbuffer_meshes(const GBufferMeshLaunch& a, hipStream_t stream);
+
 // ---- output side (output.hip) ---------------------------------------------------------------------------------
 struct ReadbackLaunch {
     float* const* chunk_bases; int64_t stride; int32_t chunk_count, slots;

@@ -85,6 +85,7 @@ SYMBOLS = {
     "ilm_gbuffer_destroy": (_I, [_H]),
     "ilm_gbuffer_download": (_I, [_H, _P]),
     "ilm_gbuffer_render": (_I, [_H, _P, _P, _I, _P, _I]),
+    "ilm_gbuffer_render_meshes": (_I, [_H, _P, _P, _I, _P, _I, _P, _I, _P, _I]),
     "ilm_lightmap_create": (_I, [_H, _I, _I, _I, _P, C.POINTER(_H)]),
     "ilm_lightmap_download": (_I, [_H, _P, _I, _I]),
     "ilm_lightmap_device_ptr": (_I, [_H, C.POINTER(_P)]),
@@ -492,6 +493,20 @@ class GBufferTexture:
         poly = np.ascontiguousarray(polygon_xy, dtype=np.float32).reshape(-1, 2) if polygon_xy is not None else np.zeros((0, 2), np.float32)
         check(lib().ilm_gbuffer_render(self.handle, _byref(desc), C.cast(volumes, C.c_void_p) if nv else None, nv,
                                        _ptr(poly) if poly.shape[0] else None, poly.shape[0]))
+
+    def render_meshes(self, desc, top=None, front=None, billboards=None, runs=()):
+        """ilm_gbuffer_render_meshes.  top / front: (n, 9) float32 rows of HeightVolumeVertex; billboards: (4 q, 12) float32 rows of
+        BillboardVertex; runs: (texture Lightmap | None, first_quad, quad_count, type) per run."""
+        def rows(a, n):
+            return np.ascontiguousarray(a, dtype=np.float32).reshape(-1, n) if a is not None else np.zeros((0, n), np.float32)
+        top, front, bb = rows(top, 9), rows(front, 9), rows(billboards, 12)
+        c_runs = (abi.BillboardRun * max(len(runs), 1))()
+        for r, (tex, first, count, kind) in enumerate(runs):
+            c_runs[r].Texture = tex.handle.value if tex is not None else 0
+            c_runs[r].FirstQuad, c_runs[r].QuadCount, c_runs[r].Type = first, count, kind
+        check(lib().ilm_gbuffer_render_meshes(self.handle, _byref(desc), _ptr(top) if len(top) else None, len(top),
+                                              _ptr(front) if len(front) else None, len(front), _ptr(bb) if len(bb) else None, len(bb),
+                                              C.cast(c_runs, C.c_void_p) if len(runs) else None, len(runs)))
 
     def download(self):
         dt = np.float32 if self.format == abi.GBUFFER_FLOAT4 else np.uint16

@@ -510,6 +510,155 @@ def gbuffer_render_desc(ground_z=0.0, viewport_position=(0.0, 0.0), viewport_sca
     return d
 
 
+def gbuffer_mesh_desc(ground_z=0.0, viewport_position=(0.0, 0.0), viewport_scale=(1.0, 1.0), z_to_y=0.0, render_scale=(1.0, 1.0),
+                      extent_z=128.0, self_occlusion_hack=0.0, z_self_occlusion_hack=0.0, two_point_five_d=True,
+                      render_ground_plane=True, enable_ground_shadows=True):
+    """What RenderGBuffer / _SetupGBufferGroundPlane bind (LightingRenderer.GBuffer.cs:102-157)."""
+    d = abi.GBufferMeshDesc()
+    d.ViewportPosition[:] = viewport_position
+    d.ViewportScale[:] = viewport_scale
+    d.GroundZ, d.ZToYMultiplier = ground_z, z_to_y
+    d.RenderScale[:] = render_scale
+    d.DistanceFieldExtentZ, d.SelfOcclusionHack, d.ZSelfOcclusionHack = extent_z, self_occlusion_hack, z_self_occlusion_hack
+    d.TwoPointFiveD, d.RenderGroundPlane, d.EnableGroundShadows = int(two_point_five_d), int(render_ground_plane), int(enable_ground_shadows)
+    return d
+
+
+def self_occlusion_hacks(resolution, virtual_depth, slice_count):
+    """ComputeSelfOcclusionHack / ComputeZSelfOcclusionHack, LightingRenderer.GBuffer.cs:62-80 (C# double / float arithmetic)."""
+    ratio_bias = max((1.0 / resolution) - 1.0, 0.0)
+    so = np.float32(0.5 + (ratio_bias ** 1.5) * 0.05)
+    slice_size = np.float32(virtual_depth) / np.float32(slice_count)
+    return float(so), float(max(np.float32(slice_size * np.float32(0.525)), np.float32(1.0)))
+
+
+def _segments_intersect(a0, a1, b0, b1):
+    """Proper-or-touching intersection of segments a and b (the role Geometry.LineIntersectPolygon's per-edge test plays in the
+    back-face hack of GetFrontFaceMesh3D; Fracture's exact routine is outside the reference tree)."""
+    la, lb = (a1[0] - a0[0], a1[1] - a0[1]), (b1[0] - b0[0], b1[1] - b0[1])
+    d = la[0] * lb[1] - la[1] * lb[0]
+    if d == 0.0:
+        return False
+    dx, dy = a0[0] - b0[0], a0[1] - b0[1]
+    r = (dy * lb[0] - dx * lb[1]) / d
+    t = (dy * la[0] - dx * la[1]) / d
+    return (0.0 <= r <= 1.0) and (0.0 <= t <= 1.0)
+
+
+def top_face_mesh(polygon, z_base, height, enable_shadows=True):
+    """SimpleHeightVolume.Mesh3D (HeightVolume.cs:106-133): a triangulation of the polygon at z = ZBase + Height with normal +z.
+    The reference triangulates with Fracture's Geometry.Triangulate; any triangulation covers the same interior -- this one clips
+    ears.  Returns (3 t, 9) float32 rows of HeightVolumeVertex."""
+    pts = [(float(np.float32(x)), float(np.float32(y))) for (x, y) in polygon]
+    area2 = sum(pts[i][0] * pts[(i + 1) % len(pts)][1] - pts[(i + 1) % len(pts)][0] * pts[i][1] for i in range(len(pts)))
+    idx = list(range(len(pts))) if area2 > 0 else list(range(len(pts) - 1, -1, -1))
+
+    def cross(o, a, b):
+        return (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0])
+    tris = []
+    guard = 0
+    while len(idx) > 3 and guard < 10000:
+        guard += 1
+        for k in range(len(idx)):
+            i0, i1, i2 = idx[k - 1], idx[k], idx[(k + 1) % len(idx)]
+            a, b, c = pts[i0], pts[i1], pts[i2]
+            if cross(a, b, c) <= 0:
+                continue
+            if any(cross(a, b, pts[j]) >= 0 and cross(b, c, pts[j]) >= 0 and cross(c, a, pts[j]) >= 0 for j in idx if j not in (i0, i1, i2)):
+                continue
+            tris.append((i0, i1, i2))
+            del idx[k]
+            break
+        else:
+            break
+    if len(idx) == 3:
+        tris.append(tuple(idx))
+    h1, h2 = np.float32(z_base), np.float32(z_base) + np.float32(height)
+    rows = [[pts[i][0], pts[i][1], h2, 0.0, 0.0, 1.0, h1, h2, 1.0 if enable_shadows else 0.0] for t in tris for i in t]
+    return np.asarray(rows, np.float32).reshape(-1, 9)
+
+
+def front_face_mesh(polygon, z_base, height, enable_shadows=True):
+    """SimpleHeightVolume.GetFrontFaceMesh3D (HeightVolume.cs:135-224): one quad per polygon edge from the top to the base, edges
+    whose start or end has polygon below it culled, normals as that function derives them.  (3 t, 9) float32 rows."""
+    pts = [(float(np.float32(x)), float(np.float32(y))) for (x, y) in polygon]
+    n = len(pts)
+    h1, h2 = float(np.float32(z_base)), float(np.float32(z_base) + np.float32(height))
+    es = 1.0 if enable_shadows else 0.0
+
+    def hits(p):
+        s0, s1 = (p[0], float(np.float32(p[1]) + np.float32(0.1))), (p[0], float(np.float32(p[1]) + np.float32(999.0)))
+        return any(_segments_intersect(s0, s1, pts[e], pts[(e + 1) % n]) for e in range(n))
+
+    def left_normal(d):
+        # Vector2.PerpendicularLeft() = (y, -x); Vector3.Normalize in float
+        v = np.asarray([d[1], -d[0], 0.0], np.float32)
+        l = np.sqrt(np.float32(v[0] * v[0] + v[1] * v[1]))
+        return [float(v[0] / l), float(v[1] / l), 0.0]
+    rows = []
+    for j in range(n):
+        prior, a, b = pts[(j - 1) % n], pts[j], pts[(j + 1) % n]
+        if hits(a) or hits(b):
+            continue
+        if a[1] == b[1]:
+            an = bn = [0.0, 1.0, 0.0]
+        else:
+            an = [0.0, 0.0, 0.0] if a == prior else left_normal((a[0] - prior[0], a[1] - prior[1]))
+            bn = [0.0, 0.0, 0.0] if b == a else left_normal((b[0] - a[0], b[1] - a[1]))
+        a_top, a_bot, b_top, b_bot = [a[0], a[1], h2], [a[0], a[1], h1], [b[0], b[1], h2], [b[0], b[1], h1]
+        for pos, nrm in ((a_top, an), (b_top, bn), (a_bot, an), (b_top, bn), (b_bot, bn), (a_bot, an)):
+            rows.append(pos + nrm + [h1, h2, es])
+    return np.asarray(rows, np.float32).reshape(-1, 9)
+
+
+def billboard_vertices(billboards, ground_z=0.0, z_to_y=0.0):
+    """The vertex loop of RenderGBufferBillboards (LightingRenderer.GBuffer.cs:411-475) for billboards given as dicts with the
+    Billboard struct's fields (Billboard.cs:9-86): screen_bounds ((x1, y1), (x2, y2)) | None, world_bounds ((x, y, z), (x, y, z)) |
+    None, world_elevation, world_offset, normal, cylinder_factor, data_scale, static_lighting_only, type, texture_bounds.
+    Returns (4 n, 12) float32 rows of BillboardVertex (TL, TR, BR, BL per billboard), in the order given (the caller sorts)."""
+    f = np.float32
+    rows = []
+    for b in billboards:
+        sb = b.get("screen_bounds")
+        wbv = b.get("world_bounds")
+        kind = b.get("type", abi.BILLBOARD_MASK)
+        normal1 = [f(c) for c in b.get("normal", (0.0, 1.0, 0.0))]
+        normal2 = list(normal1)
+        ds = b.get("data_scale")
+        dsf = (f(1.0) if ds is None else f(ds), f(-1.0) if b.get("static_lighting_only") else f(1.0))
+        sbv = [[f(0), f(0)], [f(0), f(0)]] if sb is None else [[f(sb[0][0]), f(sb[0][1])], [f(sb[1][0]), f(sb[1][1])]]
+        if wbv is not None:
+            wb = [[f(c) for c in wbv[0]], [f(c) for c in wbv[1]]]
+        else:
+            base_z = f(ground_z) * f(1)
+            x1, x2, y = sbv[0][0], sbv[1][0], sbv[1][1]
+            we = b.get("world_elevation")
+            h = f(sbv[1][1] - sbv[0][1]) if we is None else f(we)
+            z_scale = f(h / f(z_to_y)) if z_to_y > 0 else f(0)
+            if kind == abi.BILLBOARD_GBUFFER_DATA:
+                base_z = f(0) if we is None else f(we)
+                z_scale = f(0)
+            wb = [[x1, y, f(base_z + z_scale)], [x2, y, base_z]]
+        if sb is None and wbv is not None:
+            sbv = [[wb[0][0], f(wb[0][1] - f(wb[0][2] * f(z_to_y)))], [wb[1][0], f(wb[1][1] - f(wb[1][2] * f(z_to_y)))]]
+            max_z = max(wb[0][2], wb[1][2])
+            wb[0][2] = wb[1][2] = max_z
+        off = [f(c) for c in b.get("world_offset", (0.0, 0.0, 0.0))]
+        wb = [[f(wb[0][c] + off[c]) for c in range(3)], [f(wb[1][c] + off[c]) for c in range(3)]]
+        cf = f(b.get("cylinder_factor", 0.0))
+        if abs(cf) >= f(0.001):
+            normal1[0] = f(0) - f(f(0.9) * cf)
+            normal2[0] = f(0) + f(f(0.9) * cf)
+        tb = b.get("texture_bounds", ((0.0, 0.0), (1.0, 1.0)))
+        (tl, br) = ((f(tb[0][0]), f(tb[0][1])), (f(tb[1][0]), f(tb[1][1])))
+        (sx1, sy1), (sx2, sy2) = sbv
+        rows.append([sx1, sy1, tl[0], tl[1], wb[0][0], wb[0][1], wb[0][2], *normal1, *dsf])
+        rows.append([sx2, sy1, br[0], tl[1], wb[1][0], wb[0][1], wb[0][2], *normal2, *dsf])
+        rows.append([sx2, sy2, br[0], br[1], wb[1][0], wb[1][1], wb[1][2], *normal2, *dsf])
+        rows.append([sx1, sy2, tl[0], br[1], wb[0][0], wb[1][1], wb[1][2], *normal1, *dsf])
+    return np.asarray(rows, np.float32).reshape(-1, 12)
+
+
 def obstruction_array(obstacles):
     """[(LightObstructionType 0..4, center xyz, size xyz[, rotation about z in radians[, is_dynamic]])] ->
     ctypes array of abi.Obstruction; Orientation = Quaternion.CreateFromAxisAngle(UnitZ, rotation)

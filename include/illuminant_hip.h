@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define ILM_ABI_VERSION 5
+#define ILM_ABI_VERSION 6
 
 /* ---- return codes ------------------------------------------------------ */
 #define ILM_OK                    0
@@ -575,6 +575,79 @@ typedef struct IlmGBufferRenderDesc {
 int32_t ilm_gbuffer_render(IlmHandle gbuffer, const IlmGBufferRenderDesc* desc,
                            const IlmHeightVolume* volumes, int32_t volume_count,
                            const float* polygon_xy, int32_t polygon_vertex_count);
+
+/* ---- RenderGBuffer with the host's own meshes: 2.5D (top + front faces under a depth test) and billboards ------------------
+ * The reference's host builds triangle lists -- HeightVolume.Mesh3D / GetFrontFaceMesh3D (Illuminant/SDF/HeightVolume.cs:106-224)
+ * and the billboard quads of RenderGBufferBillboards (Illuminant/Lighting/LightingRenderer.GBuffer.cs:330-478) -- and hands them
+ * to the GPU; those builders stay host code, the arrays cross the boundary as they are. */
+
+/* HeightVolumeVertex, Illuminant/Vertices.cs:41-46 (Sequential, Pack = 4: 36 bytes) */
+typedef struct IlmHeightVolumeVertex {
+    float Position[3];
+    float Normal[3];
+    float ZRange[2];
+    float EnableShadows;
+} IlmHeightVolumeVertex;
+
+/* BillboardVertex, Illuminant/Vertices.cs:75-81 (Sequential, Pack = 4: 48 bytes) */
+typedef struct IlmBillboardVertex {
+    float ScreenPosition[2];
+    float TexCoord[2];
+    float WorldPosition[3];
+    float Normal[3];
+    float DataScaleAndDynamicFlag[2];
+} IlmBillboardVertex;
+
+enum {
+    ILM_BILLBOARD_MASK         = 0,  /* BillboardType.Mask        -> technique MaskBillboard  (GBufferBitmap.fx:29-59,115-122) */
+    ILM_BILLBOARD_GBUFFER_DATA = 1   /* BillboardType.GBufferData -> technique GDataBillboard (GBufferBitmap.fx:61-113,124-131) */
+};
+
+/* One PrimitiveDrawCall of RenderGBufferBillboards (LightingRenderer.GBuffer.cs:392-409): a run of quads sharing a texture and a
+ * type.  Texture = a lightmap-class texture of the same context (ilm_lightmap_create + ilm_lightmap_upload; RGBA8 = SurfaceFormat.Color,
+ * float4 / half4 accepted), sampled POINT / CLAMP (_SetTextureForGBufferBillboard, :301-307); 0 = no texture bound, which Direct3D 9
+ * samples as (0, 0, 0, 1) -- "the mask is an opaque rectangle" (Billboard.cs:93). */
+typedef struct IlmBillboardRun {
+    IlmHandle Texture;
+    int32_t   FirstQuad, QuadCount;   /* quads [FirstQuad, FirstQuad + QuadCount) of the vertex array, 4 vertices each (TL, TR, BR, BL) */
+    int32_t   Type;                   /* ILM_BILLBOARD_* */
+    int32_t   _pad;
+} IlmBillboardRun;
+
+/* What RenderGBuffer and _SetupGBufferGroundPlane bind (LightingRenderer.GBuffer.cs:102-157): the view transform, the Environment
+ * uniforms the three techniques read (Uniforms.cs:15-24: GroundZ, ZToYMultiplier, RenderScale), DistanceFieldExtent.z and the two
+ * self-occlusion hacks (ComputeSelfOcclusionHack / ComputeZSelfOcclusionHack, :62-80 -- host arithmetic, passed in). */
+typedef struct IlmGBufferMeshDesc {
+    float   ViewportPosition[2];
+    float   ViewportScale[2];
+    float   GroundZ;
+    float   ZToYMultiplier;
+    float   RenderScale[2];
+    float   DistanceFieldExtentZ;
+    float   SelfOcclusionHack;
+    float   ZSelfOcclusionHack;
+    int32_t TwoPointFiveD;            /* Configuration.TwoPointFiveD */
+    int32_t RenderGroundPlane;
+    int32_t EnableGroundShadows;
+    int32_t _pad[2];
+} IlmGBufferMeshDesc;
+
+/* RenderGBuffer (LightingRenderer.GBuffer.cs:127-203) in draw order -- clear (colour 0, depth 0); the ground plane; then
+ *   TwoPointFiveD = 1: every triangle of `top` with technique HeightVolume, then every triangle of `front` with technique
+ *     HeightVolumeFace (GBuffer.fx:21-55,72-103), both under DepthBufferFunction GreaterEqual with depth writes on a 24-bit depth
+ *     buffer, depth = z / DistanceFieldExtent.z (LightingRenderer.cs:539-551, GBuffer.cs:30-38; RenderTwoPointFiveDVolumes, :221-269 --
+ *     the caller concatenates the volumes' meshes in its OrderByDescending(ZBase + Height) order);
+ *   TwoPointFiveD = 0: every triangle of `top` with the ground plane's technique in the caller's OrderBy(ZBase + Height) order
+ *     (RenderGBufferVolumes, :205-219); `front` must be empty;
+ * then the billboard runs: all Mask runs in array order, then all GBufferData runs (layerIndex, layerIndex + 1, :371-392), no
+ * depth test.  Triangles cover a pixel when its centre is inside under the top-left rule on positions snapped to 1/256 pixel
+ * (both windings: CullMode.None); vertex attributes are interpolated with the barycentric weights of the snapped triangle;
+ * fragments whose depth leaves [0, 1] are clipped.  Host arrays; asynchronous. */
+int32_t ilm_gbuffer_render_meshes(IlmHandle gbuffer, const IlmGBufferMeshDesc* desc,
+                                  const IlmHeightVolumeVertex* top_vertices, int32_t top_vertex_count,
+                                  const IlmHeightVolumeVertex* front_vertices, int32_t front_vertex_count,
+                                  const IlmBillboardVertex* billboard_vertices, int32_t billboard_vertex_count,
+                                  const IlmBillboardRun* runs, int32_t run_count);
 
 /* Lightmap render target (BufferRing of lightmaps, LightingRenderer.cs:472-485).
  * If external_device_ptr != NULL the lightmap aliases caller-owned device memory

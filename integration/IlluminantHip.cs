@@ -1,6 +1,6 @@
 // IlluminantHip.cs -- P/Invoke layer of libilluminant_hip.so for sq/Illuminant (drop into Illuminant/Native/).
 // GENERATED from include/illuminant_hip.h by tools/gen_csharp_binding.py -- do not edit; the header carries the documentation
-// and the reference file:line each entry point replaces.  ABI version 5.
+// and the reference file:line each entry point replaces.  ABI version 6.
 //
 // Vector4 / Matrix are XNA's; LightVertex is Illuminant/Vertices.cs:10-39; the Uniforms.* structs of the reference
 // (Uniforms.cs:14-24,79-88,197-236; Bezier.cs:433-441,588-599) have the byte layout of the Ilm* mirrors below and can be passed
@@ -16,7 +16,7 @@ namespace Squared.Illuminant.Native {
     }
 
     public static class IlmConstants {
-        public const int ABI_VERSION = 5;
+        public const int ABI_VERSION = 6;
         public const int ERR_INVALID_ARGUMENT = -1;
         public const int ERR_INVALID_HANDLE = -2;
         public const int ERR_NO_DEVICE = -5;
@@ -62,6 +62,8 @@ namespace Squared.Illuminant.Native {
         public const int OBSTRUCTION_CYLINDER = 2;
         public const int OBSTRUCTION_SPHEROID = 3;
         public const int OBSTRUCTION_OCTAGON = 4;
+        public const int BILLBOARD_MASK = 0;
+        public const int BILLBOARD_GBUFFER_DATA = 1;
         public const int HDR_NONE = 0;
         public const int HDR_GAMMA_COMPRESS = 1;
         public const int HDR_TONE_MAP = 2;
@@ -327,6 +329,48 @@ namespace Squared.Illuminant.Native {
         public int _pad;
     }
 
+    [StructLayout(LayoutKind.Sequential, Pack = 4, Size = 36)]
+    public unsafe struct IlmHeightVolumeVertex {
+        public fixed float Position[3];
+        public fixed float Normal[3];
+        public fixed float ZRange[2];
+        public float EnableShadows;
+    }
+
+    [StructLayout(LayoutKind.Sequential, Pack = 4, Size = 48)]
+    public unsafe struct IlmBillboardVertex {
+        public fixed float ScreenPosition[2];
+        public fixed float TexCoord[2];
+        public fixed float WorldPosition[3];
+        public fixed float Normal[3];
+        public fixed float DataScaleAndDynamicFlag[2];
+    }
+
+    [StructLayout(LayoutKind.Sequential, Pack = 4, Size = 24)]
+    public struct IlmBillboardRun {
+        public ulong Texture;
+        public int FirstQuad;
+        public int QuadCount;
+        public int Type;
+        public int _pad;
+    }
+
+    [StructLayout(LayoutKind.Sequential, Pack = 4, Size = 64)]
+    public unsafe struct IlmGBufferMeshDesc {
+        public fixed float ViewportPosition[2];
+        public fixed float ViewportScale[2];
+        public float GroundZ;
+        public float ZToYMultiplier;
+        public fixed float RenderScale[2];
+        public float DistanceFieldExtentZ;
+        public float SelfOcclusionHack;
+        public float ZSelfOcclusionHack;
+        public int TwoPointFiveD;
+        public int RenderGroundPlane;
+        public int EnableGroundShadows;
+        public fixed int _pad[2];
+    }
+
     [StructLayout(LayoutKind.Sequential, Pack = 4, Size = 24)]
     public struct IlmRenderStats {
         public ulong SdfSamples;
@@ -463,6 +507,7 @@ namespace Squared.Illuminant.Native {
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_gbuffer_destroy (ulong gbuffer);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_gbuffer_download (ulong gbuffer, void* texels);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_gbuffer_render (ulong gbuffer, IlmGBufferRenderDesc* desc, IlmHeightVolume* volumes, int volumeCount, float* polygonXy, int polygonVertexCount);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_gbuffer_render_meshes (ulong gbuffer, IlmGBufferMeshDesc* desc, IlmHeightVolumeVertex* topVertices, int topVertexCount, IlmHeightVolumeVertex* frontVertices, int frontVertexCount, IlmBillboardVertex* billboardVertices, int billboardVertexCount, IlmBillboardRun* runs, int runCount);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_lightmap_create (ulong ctx, int width, int height, int format, void* externalDevicePtr, ulong* outLightmap);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_lightmap_download (ulong lightmap, void* dst, int firstRow, int rowCount);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_lightmap_upload (ulong lightmap, void* src, int firstRow, int rowCount);

@@ -1477,6 +1477,7 @@ void orc_spawner_end_tick(OrcSpawnerState* s, int32_t requested, int32_t actual)
 }
 
 #include "ilm_oracle_fields.c"
+#include "ilm_oracle_gbuffer.c"
 
 void orc_set_num_threads(int32_t n) {
 #ifdef _OPENMP

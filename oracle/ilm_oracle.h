@@ -175,6 +175,14 @@ void orc_render_distance_field_slices(uint16_t* atlas, int32_t format, const uin
 void orc_render_gbuffer(IlmFloat4* out, int32_t width, int32_t height, const IlmGBufferRenderDesc* desc,
                         const IlmHeightVolume* volumes, int32_t volume_count, const float* polygon_xy);
 
+/* RenderGBuffer with the host's meshes (2.5D top / front faces under the depth test, billboards): ilm_oracle_gbuffer.c.
+ * textures: one per run, texels NULL = nothing bound, format ILM_LIGHTMAP_*. */
+void orc_render_gbuffer_meshes(IlmFloat4* out, int32_t width, int32_t height, const IlmGBufferMeshDesc* desc,
+                               const IlmHeightVolumeVertex* top, int32_t top_count,
+                               const IlmHeightVolumeVertex* front, int32_t front_count,
+                               const IlmBillboardVertex* billboards, int32_t billboard_vertex_count,
+                               const IlmBillboardRun* runs, int32_t run_count, const OrcTexture* textures);
+
 int32_t orc_num_threads(void);
 void    orc_set_num_threads(int32_t n);
 

@@ -21,7 +21,7 @@ def build(force=False):
     """Compile the C restatement with gcc (oracle/Makefile)."""
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-            for f in ("ilm_oracle.c", "ilm_oracle_fields.c", "ilm_oracle_transforms.c", "ilm_oracle_lights.c", "ilm_oracle_output.c", "ilm_oracle.h")):
+            for f in ("ilm_oracle.c", "ilm_oracle_fields.c", "ilm_oracle_gbuffer.c", "ilm_oracle_transforms.c", "ilm_oracle_lights.c", "ilm_oracle_output.c", "ilm_oracle.h")):
         subprocess.run(["make", "-C", _HERE, "-s"], check=True)
     return _LIB_PATH
 
@@ -388,6 +388,33 @@ def render_gbuffer(width, height, desc, volumes=None, polygon_xy=None):
         C.memmove(C.byref(sorted_vols[k]), C.byref(volumes[i]), C.sizeof(abi.HeightVolume))
     poly = np.ascontiguousarray(polygon_xy, dtype=np.float32).reshape(-1, 2) if polygon_xy is not None else np.zeros((1, 2), np.float32)
     lib().orc_render_gbuffer(_f4(out), C.c_int32(width), C.c_int32(height), C.byref(desc), sorted_vols, C.c_int32(nv), _p(poly))
+    return out
+
+
+def render_gbuffer_meshes(width, height, desc, top=None, front=None, billboards=None, runs=(), textures=()):
+    """orc_render_gbuffer_meshes: (H, W, 4) float32.  top / front: (n, 9) float32 rows of HeightVolumeVertex; billboards: (4 q, 12)
+    float32 rows of BillboardVertex; runs: (first_quad, quad_count, type) per run; textures: one (h, w, 4) array (uint8 = Color,
+    float16, float32) or None per run."""
+    out = np.zeros((height, width, 4), np.float32)
+
+    def rows(a, n):
+        return np.ascontiguousarray(a, dtype=np.float32).reshape(-1, n) if a is not None else np.zeros((0, n), np.float32)
+    top, front, bb = rows(top, 9), rows(front, 9), rows(billboards, 12)
+    nr = len(runs)
+    c_runs = (abi.BillboardRun * max(nr, 1))()
+    c_tex = (Texture * max(nr, 1))()
+    keep = []
+    for r, (first, count, kind) in enumerate(runs):
+        c_runs[r].FirstQuad, c_runs[r].QuadCount, c_runs[r].Type = first, count, kind
+        t = textures[r] if r < len(textures) else None
+        if t is not None:
+            t = np.ascontiguousarray(t)
+            keep.append(t)
+            fmt = {np.dtype(np.uint8): abi.LIGHTMAP_RGBA8, np.dtype(np.float16): abi.LIGHTMAP_HALF4, np.dtype(np.float32): abi.LIGHTMAP_FLOAT4}[t.dtype]
+            c_tex[r] = Texture(t.ctypes.data, t.shape[1], t.shape[0], fmt)
+    lib().orc_render_gbuffer_meshes(_f4(out), C.c_int32(width), C.c_int32(height), C.byref(desc),
+                                    _p(top) if len(top) else None, C.c_int32(len(top)), _p(front) if len(front) else None, C.c_int32(len(front)),
+                                    _p(bb) if len(bb) else None, C.c_int32(len(bb)), c_runs, C.c_int32(nr), c_tex)
     return out
 
 

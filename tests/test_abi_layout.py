@@ -26,6 +26,8 @@ STRUCTS = {
     "IlmParticleLightParams": abi.ParticleLightParams,
     "IlmReadbackDrawCall": abi.ReadbackDrawCall, "IlmReadbackParams": abi.ReadbackParams, "IlmHDRConfiguration": abi.HDRConfiguration,
     "IlmGBufferRenderDesc": abi.GBufferRenderDesc,
+    "IlmHeightVolumeVertex": abi.HeightVolumeVertex, "IlmBillboardVertex": abi.BillboardVertex, "IlmBillboardRun": abi.BillboardRun,
+    "IlmGBufferMeshDesc": abi.GBufferMeshDesc,
     "IlmObstruction": abi.Obstruction, "IlmHeightVolume": abi.HeightVolume, "IlmDistanceFieldRenderDesc": abi.DistanceFieldRenderDesc,
 }
 
