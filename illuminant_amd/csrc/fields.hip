@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void render_gbuffer_kernel(const GBufferLaunch
     if (i >= a.width || j >= a.height) return;
     const float wx = ((float)i + 0.5f) / a.desc.ViewportScale[0] + a.desc.ViewportPosition[0];
     const float wy = ((float)j + 0.5f) / a.desc.ViewportScale[1] + a.desc.ViewportPosition[1];
-    const float ground_z = a.desc.GroundZ + (a.desc.RenderGroundPlane ? 0.0f : 99999.0f);
+    const float ground_z = a.desc.GroundZ + (a.desc.RenderGroundPlane ? 0.0f : ref::kGroundLift);
     float4 texel = mk4(0.0f, 0.0f, 0.0f, 0.0f);
     if (!(ground_z < a.desc.GroundZ))
         texel = encode_gbuffer_up(ground_z, a.desc.EnableGroundShadows != 0);

@@ -101,7 +101,7 @@ ILM_DEV void billboard_prim(GBufferPrim& p, int kind, int texture, const IlmBill
 // encodeNormalSpherical, EnvironmentCommon.fxh:33-40; encodeGBufferSample, GBufferShaderCommon.fxh:10-35 (fullbright = false)
 ILM_DEV float4 encode_sample(f3 n, float relative_y, float z, bool dead, bool enable_shadows) {
     if (dead)
-        return mk4(0.0f, 0.0f, -99999.0f, -99999.0f);
+        return mk4(0.0f, 0.0f, -ref::kDeadTexel, -ref::kDeadTexel);
     float ex = 0.0f, ey = 0.0f;
     if ((n.x != 0.0f) || (n.y != 0.0f) || (n.z != 0.0f)) {
         const float nx = (fabsf(n.x) < 0.0001f) ? 0.0001f : n.x;
@@ -146,8 +146,9 @@ __global__ __launch_bounds__(64) void gbuffer_setup_kernel(const GBufferMeshLaun
     const int quad_indices[6] = { 0, 1, 3, 1, 2, 3 };           // QuadIndices, LightingRenderer.cs:421-423
     if (t < 2) {
         // RenderGroundPlane, LightingRenderer.GBuffer.cs:271-299
-        const float gz = d.GroundZ + (d.RenderGroundPlane ? 0.0f : 99999.0f);
-        const float cx[4] = { -999999.0f, 999999.0f, 999999.0f, -999999.0f }, cy[4] = { -999999.0f, -999999.0f, 999999.0f, 999999.0f };
+        const float gz = d.GroundZ + (d.RenderGroundPlane ? 0.0f : ref::kGroundLift);
+        const float e = ref::kGroundHalfExtent;
+        const float cx[4] = { -e, e, e, -e }, cy[4] = { -e, -e, e, e };
         IlmHeightVolumeVertex g[3];
         for (int k = 0; k < 3; k++) {
             const int c = quad_indices[3 * t + k];
@@ -225,13 +226,13 @@ __global__ __launch_bounds__(256) void gbuffer_meshes_kernel(const GBufferMeshLa
             const float4 data = sample_point(a.textures, p.texture, at(6), at(7));
             const float data_scale = at(9);
             if (kind == kMask) {                                 // MaskBillboardPixelShader, GBufferBitmap.fx:29-59
-                const float discard_threshold = 1.0f / 255.0f;
+                const float discard_threshold = ref::kMaskDiscardNumerator / 255.0f;
                 if ((data.w - discard_threshold) < 0.0f) continue;
                 const float relative_y = (wp.y - at(8)) * data_scale;
                 out = mk4((n.x / 2.0f) + 0.5f, (n.z / 2.0f) + 0.5f, relative_y,
                           ((wp.z + ref::kGBufferZOffset) / ref::kGBufferZScale) * at(10));
             } else if (kind == kGData) {                         // GDataBillboardPixelShader, GBufferBitmap.fx:61-113
-                const float discard_threshold = 127.0f / 255.0f;
+                const float discard_threshold = ref::kGDataDiscardNumerator / 255.0f;
                 if (data.w < discard_threshold) continue;
                 const float tx = (data.x - 0.5f) * 2.0f, ty = (data.y - 0.5f) * 2.0f;
                 const float tz = sqrtf(1.0f - (tx * tx + ty * ty));

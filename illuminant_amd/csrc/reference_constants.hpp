@@ -46,6 +46,14 @@ constexpr float kRenderDataIndexRowPitch = 256.0f;
 // CountLiveParticles.fx:38 + ParticleEngine.cs:244-247: each live particle adds 1 / 65535 to a 16-bit target
 constexpr unsigned kLiveCountSaturation = 65535u;
 
+// G-buffer passes: GBufferBitmap.fx:40,72 (discard thresholds, numerators over 255); GBufferShaderCommon.fxh:14-18 (a dead texel);
+// LightingRenderer.GBuffer.cs:275-281 (the ground plane's quad and its lift when RenderGroundPlane is off)
+constexpr float kMaskDiscardNumerator = 1.0f;
+constexpr float kGDataDiscardNumerator = 127.0f;
+constexpr float kDeadTexel = 99999.0f;
+constexpr float kGroundHalfExtent = 999999.0f;
+constexpr float kGroundLift = 99999.0f;
+
 struct Entry { const char* key; double value; };
 constexpr Entry kTable[] = {
     { "ParticleCommon.fxh:PI", kPi }, { "DistanceFieldCommon.fxh:PI", kPi },
@@ -68,6 +76,11 @@ constexpr Entry kTable[] = {
     { "SpawnerCommon.fxh:randomOffset3.x modulus", kRandom3XModulus }, { "SpawnerCommon.fxh:randomOffset3.y modulus", kRandom3YModulus },
     { "UpdateCommon.fxh:computeRenderData index row pitch", kRenderDataIndexRowPitch },
     { "CountLiveParticles.fx:count increment denominator", kLiveCountSaturation },
+    { "GBufferBitmap.fx:mask discard threshold numerator", kMaskDiscardNumerator },
+    { "GBufferBitmap.fx:gdata discard threshold numerator", kGDataDiscardNumerator },
+    { "GBufferShaderCommon.fxh:dead texel value", kDeadTexel },
+    { "LightingRenderer.GBuffer.cs:ground plane half extent", kGroundHalfExtent },
+    { "LightingRenderer.GBuffer.cs:ground plane lift", kGroundLift },
     { "Gravity.fx:MAX_ATTRACTORS", ILM_MAX_ATTRACTORS },
     { "SpawnerCommon.fxh:MAX_INLINE_POSITION_CONSTANTS", ILM_MAX_INLINE_POSITION_CONSTANTS },
     { "ParticleEngine.cs:RandomnessTextureWidth", ILM_RANDOMNESS_WIDTH }, { "ParticleEngine.cs:RandomnessTextureHeight", ILM_RANDOMNESS_HEIGHT },

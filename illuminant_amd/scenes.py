@@ -611,6 +611,9 @@ def front_face_mesh(polygon, z_base, height, enable_shadows=True):
     return np.asarray(rows, np.float32).reshape(-1, 9)
 
 
+CYLINDER_NORMAL_FACTOR = 0.9      # LightingRenderer.GBuffer.cs:467-468 (pinned by tests/test_reference_pin.py)
+
+
 def billboard_vertices(billboards, ground_z=0.0, z_to_y=0.0):
     """The vertex loop of RenderGBufferBillboards (LightingRenderer.GBuffer.cs:411-475) for billboards given as dicts with the
     Billboard struct's fields (Billboard.cs:9-86): screen_bounds ((x1, y1), (x2, y2)) | None, world_bounds ((x, y, z), (x, y, z)) |
@@ -647,8 +650,8 @@ def billboard_vertices(billboards, ground_z=0.0, z_to_y=0.0):
         wb = [[f(wb[0][c] + off[c]) for c in range(3)], [f(wb[1][c] + off[c]) for c in range(3)]]
         cf = f(b.get("cylinder_factor", 0.0))
         if abs(cf) >= f(0.001):
-            normal1[0] = f(0) - f(f(0.9) * cf)
-            normal2[0] = f(0) + f(f(0.9) * cf)
+            normal1[0] = f(0) - f(f(CYLINDER_NORMAL_FACTOR) * cf)
+            normal2[0] = f(0) + f(f(CYLINDER_NORMAL_FACTOR) * cf)
         tb = b.get("texture_bounds", ((0.0, 0.0), (1.0, 1.0)))
         (tl, br) = ((f(tb[0][0]), f(tb[0][1])), (f(tb[1][0]), f(tb[1][1])))
         (sx1, sy1), (sx2, sy2) = sbv

@@ -47,6 +47,14 @@
 /* CountLiveParticles.fx:38 + ParticleEngine.cs:244-247: each live particle adds 1 / 65535 to a 16-bit target */
 #define LIVE_COUNT_SATURATION 65535u
 
+/* G-buffer passes: GBufferBitmap.fx:40,72 (discard thresholds, numerators over 255); GBufferShaderCommon.fxh:14-18 (a dead texel);
+ * LightingRenderer.GBuffer.cs:275-281 (the ground plane's quad and its lift when RenderGroundPlane is off) */
+#define GB_MASK_DISCARD_NUMERATOR 1.0f
+#define GB_GDATA_DISCARD_NUMERATOR 127.0f
+#define GB_DEAD_TEXEL 99999.0f
+#define GB_GROUND_HALF_EXTENT 999999.0f
+#define GB_GROUND_LIFT 99999.0f
+
 struct OrcReferenceConstant { const char* key; double value; };
 static const struct OrcReferenceConstant orc_reference_constants[] = {
     { "ParticleCommon.fxh:PI", H_PI }, { "DistanceFieldCommon.fxh:PI", H_PI },
@@ -69,6 +77,11 @@ static const struct OrcReferenceConstant orc_reference_constants[] = {
     { "SpawnerCommon.fxh:randomOffset3.x modulus", SP_RANDOM3_X_MODULUS }, { "SpawnerCommon.fxh:randomOffset3.y modulus", SP_RANDOM3_Y_MODULUS },
     { "UpdateCommon.fxh:computeRenderData index row pitch", RD_INDEX_ROW_PITCH },
     { "CountLiveParticles.fx:count increment denominator", LIVE_COUNT_SATURATION },
+    { "GBufferBitmap.fx:mask discard threshold numerator", GB_MASK_DISCARD_NUMERATOR },
+    { "GBufferBitmap.fx:gdata discard threshold numerator", GB_GDATA_DISCARD_NUMERATOR },
+    { "GBufferShaderCommon.fxh:dead texel value", GB_DEAD_TEXEL },
+    { "LightingRenderer.GBuffer.cs:ground plane half extent", GB_GROUND_HALF_EXTENT },
+    { "LightingRenderer.GBuffer.cs:ground plane lift", GB_GROUND_LIFT },
     { "Gravity.fx:MAX_ATTRACTORS", ILM_MAX_ATTRACTORS },
     { "SpawnerCommon.fxh:MAX_INLINE_POSITION_CONSTANTS", ILM_MAX_INLINE_POSITION_CONSTANTS },
     { "ParticleEngine.cs:RandomnessTextureWidth", ILM_RANDOMNESS_WIDTH }, { "ParticleEngine.cs:RandomnessTextureHeight", ILM_RANDOMNESS_HEIGHT },

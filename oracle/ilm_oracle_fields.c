@@ -239,7 +239,7 @@ static int point_in_polygon(float px, float py, const float* P, int count) {
 /* out: width * height float4 texels.  volumes must already be ordered lowest to highest top (OrderBy(ZBase + Height), :210). */
 void orc_render_gbuffer(IlmFloat4* out, int32_t width, int32_t height, const IlmGBufferRenderDesc* d,
                         const IlmHeightVolume* volumes, int32_t volume_count, const float* polygon_xy) {
-    const float ground_z = d->GroundZ + (d->RenderGroundPlane ? 0.0f : 99999.0f);     /* RenderGroundPlane, :271-286 */
+    const float ground_z = d->GroundZ + (d->RenderGroundPlane ? 0.0f : GB_GROUND_LIFT);     /* RenderGroundPlane, :271-286 */
     #pragma omp parallel for schedule(static)
     for (int j = 0; j < height; j++)
         for (int i = 0; i < width; i++) {

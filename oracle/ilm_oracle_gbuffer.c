@@ -117,7 +117,7 @@ static int gb_billboard_prim(GbPrim* p, int kind, int texture, const IlmBillboar
 /* encodeGBufferSample, GBufferShaderCommon.fxh:10-35 (fullbright = false) */
 static f4 gb_encode(f3 normal, float relative_y, float z, int dead, int enable_shadows) {
     if (dead)
-        return v4(0.0f, 0.0f, -99999.0f, -99999.0f);
+        return v4(0.0f, 0.0f, -GB_DEAD_TEXEL, -GB_DEAD_TEXEL);
     return encode_gbuffer_sample(normal, relative_y, z, enable_shadows);
 }
 
@@ -163,7 +163,7 @@ static int gb_shade(const GbPrim* p, float f1, float f2, const IlmGBufferMeshDes
     const f4 data = gb_sample((p->texture >= 0) ? &textures[p->texture] : NULL, gb_lerp(p, 6, f1, f2), gb_lerp(p, 7, f1, f2));
     const float data_scale = gb_lerp(p, 9, f1, f2);
     if (p->kind == GB_MASK) {                                     /* MaskBillboardPixelShader, GBufferBitmap.fx:29-59 */
-        const float discard_threshold = 1.0f / 255.0f;
+        const float discard_threshold = GB_MASK_DISCARD_NUMERATOR / 255.0f;
         if ((data.w - discard_threshold) < 0.0f) return 0;        /* clip() */
         const float relative_y = (wp.y - gb_lerp(p, 8, f1, f2)) * data_scale;
         *out = v4((n.x / 2.0f) + 0.5f, (n.z / 2.0f) + 0.5f, relative_y,
@@ -171,7 +171,7 @@ static int gb_shade(const GbPrim* p, float f1, float f2, const IlmGBufferMeshDes
         return 1;
     }
     /* GDataBillboardPixelShader, GBufferBitmap.fx:61-113 */
-    const float discard_threshold = 127.0f / 255.0f;
+    const float discard_threshold = GB_GDATA_DISCARD_NUMERATOR / 255.0f;
     if (data.w < discard_threshold) return 0;
     const float tx = (data.x - 0.5f) * 2.0f, ty = (data.y - 0.5f) * 2.0f;
     const float tz = sqrtf(1.0f - (tx * tx + ty * ty));
@@ -243,10 +243,11 @@ void orc_render_gbuffer_meshes(IlmFloat4* out, int32_t width, int32_t height, co
 
     /* RenderGroundPlane, :271-299 */
     {
-        const float lift = d->RenderGroundPlane ? 0.0f : 99999.0f;
+        const float lift = d->RenderGroundPlane ? 0.0f : GB_GROUND_LIFT;
         const float gz = d->GroundZ + lift;
         IlmHeightVolumeVertex g[4];
-        const float cx[4] = { -999999.0f, 999999.0f, 999999.0f, -999999.0f }, cy[4] = { -999999.0f, -999999.0f, 999999.0f, 999999.0f };
+        const float e = GB_GROUND_HALF_EXTENT;
+        const float cx[4] = { -e, e, e, -e }, cy[4] = { -e, -e, e, e };
         for (int k = 0; k < 4; k++) {
             g[k].Position[0] = cx[k]; g[k].Position[1] = cy[k]; g[k].Position[2] = gz;
             g[k].Normal[0] = 0.0f; g[k].Normal[1] = 0.0f; g[k].Normal[2] = 1.0f;

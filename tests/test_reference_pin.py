@@ -34,7 +34,7 @@ def f32(x):
 
 
 def test_fixture_covers_both_paths():
-    assert len(FIXTURE["defines"]) >= 30 and len(FIXTURE["literals"]) >= 20 and len(FIXTURE["structs"]) == 6
+    assert len(FIXTURE["defines"]) >= 30 and len(FIXTURE["literals"]) >= 20 and len(FIXTURE["structs"]) == 8
     for must in ("ConeTrace.fxh:FULLY_SHADOWED_THRESHOLD", "ConeTrace.fxh:MIN_CONE_RADIUS", "SphereLightCore.fxh:SELF_OCCLUSION_HACK",
                  "UpdateParticleSystemWithDistanceField.fx:BOUNCE_DELAY", "Gravity.fx:MAX_ATTRACTORS", "DistanceFieldCommon.fxh:DISTANCE_ZERO",
                  "SpawnerCommon.fxh:randomOffset3.y modulus", "CountLiveParticles.fx:count increment denominator"):
@@ -113,6 +113,7 @@ def test_header_defines_and_host_defaults():
     from illuminant_amd import scenes
     assert (scenes.FORMULA_LINEAR, scenes.FORMULA_SPHERICAL, scenes.FORMULA_TOWARDS, scenes.FORMULA_RECTANGULAR) == tuple(
         int(VALUES["SpawnerCommon.fxh:FormulaType_%s" % n]["value"]) for n in ("Linear", "Spherical", "Towards", "Rectangular"))
+    assert scenes.CYLINDER_NORMAL_FACTOR == VALUES["LightingRenderer.GBuffer.cs:cylinder normal factor"]["value"]
     # the C++ host mirror's defaults (RendererQualitySettings, ParticleSystem.MaxChunkCount, liveness bookkeeping)
     from illuminant_amd import _host as H
     q = H.RendererQualitySettings()
@@ -125,19 +126,27 @@ def test_header_defines_and_host_defaults():
 
 def test_pod_mirrors_have_the_references_field_order():
     """[StructLayout(Sequential)] structs of the reference vs the ctypes mirrors (whose offsets test_abi_layout.py checks against
-    the C header): same fields, same order, each a Vector4 = 16 bytes at offset 16 * index."""
+    the C header): same fields, same order, packed (Pack = 4: a VectorN is N floats at the running offset)."""
     by_name = {"IlmEnvironment": abi.Environment, "IlmDistanceFieldUniforms": abi.DistanceFieldUniforms,
                "IlmParticleSystemUniforms": abi.ParticleSystemUniforms, "IlmLightVertex": abi.LightVertex,
-               "IlmClampedBezier1": abi.ClampedBezier1, "IlmClampedBezier4": abi.ClampedBezier4}
+               "IlmClampedBezier1": abi.ClampedBezier1, "IlmClampedBezier4": abi.ClampedBezier4,
+               "IlmHeightVolumeVertex": abi.HeightVolumeVertex, "IlmBillboardVertex": abi.BillboardVertex}
+    sizes = {"Vector4": 16, "Vector3": 12, "Vector2": 8, "float": 4}
     for s in FIXTURE["structs"]:
         mirror = by_name[s["mirror"]]
         want = [f["name"] for f in s["fields"]]
-        assert all(f["type"] == "Vector4" for f in s["fields"]), s["struct"]
         got = [name for name, _ in mirror._fields_][:len(want)]
         assert got == want, (s["struct"], got, want)
-        for i, name in enumerate(want):
-            field = getattr(mirror, name)
-            assert (field.offset, field.size) == (16 * i, 16), (s["struct"], name)
+        offset = 0
+        for f in s["fields"]:
+            field = getattr(mirror, f["name"])
+            assert (field.offset, field.size) == (offset, sizes[f["type"]]), (s["struct"], f["name"])
+            offset += sizes[f["type"]]
+        if s["mirror"] in ("IlmHeightVolumeVertex", "IlmBillboardVertex"):
+            assert C.sizeof(mirror) == offset
+        else:
+            assert all(f["type"] == "Vector4" for f in s["fields"]), s["struct"]
     # the mirrors that stop where the reference struct stops
     assert C.sizeof(abi.ParticleSystemUniforms) == 64 and C.sizeof(abi.LightVertex) == 128
     assert C.sizeof(abi.ClampedBezier1) == 32 and C.sizeof(abi.ClampedBezier4) == 80
+    assert C.sizeof(abi.HeightVolumeVertex) == 36 and C.sizeof(abi.BillboardVertex) == 48

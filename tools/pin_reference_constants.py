@@ -63,6 +63,12 @@ LITERALS = [
     ("Illuminant/Lighting/LightingRenderer.Configuration.cs", "ConeGrowthFactor default", r"public float ConeGrowthFactor\s+= ([\d.]+)f?;"),
     ("Illuminant/Lighting/LightingRenderer.Configuration.cs", "OcclusionToOpacityPower default", r"public float OcclusionToOpacityPower = ([\d.]+)f?;"),
     ("Illuminant/Shaders/CountLiveParticles.fx", "count increment denominator", r"color = float4\(1\.0 / (\d+),"),
+    ("Illuminant/Shaders/GBufferBitmap.fx", "mask discard threshold numerator", r"MaskBillboardPixelShader[\s\S]*?discardThreshold = \(([\d.]+) / 255\.0\)"),
+    ("Illuminant/Shaders/GBufferBitmap.fx", "gdata discard threshold numerator", r"GDataBillboardPixelShader[\s\S]*?discardThreshold = \(([\d.]+) / 255\.0\)"),
+    ("Illuminant/Shaders/GBufferShaderCommon.fxh", "dead texel value", r"if \(dead\)[\s\S]*?0, 0,\s*-(\d+),"),
+    ("Illuminant/Lighting/LightingRenderer.GBuffer.cs", "ground plane half extent", r"var tl = new Vector3\(-(\d+),"),
+    ("Illuminant/Lighting/LightingRenderer.GBuffer.cs", "ground plane lift", r"var huge = new Vector3\(0, 0, (\d+)\)"),
+    ("Illuminant/Lighting/LightingRenderer.GBuffer.cs", "cylinder normal factor", r"normal1\.X = 0f - \(([\d.]+)f \* billboard\.CylinderFactor\)"),
 ]
 # (file, struct, ABI mirror) -- field ORDER of the [StructLayout(Sequential)] structs the ABI mirrors
 STRUCTS = [
@@ -72,6 +78,8 @@ STRUCTS = [
     ("Illuminant/Vertices.cs", "LightVertex", "IlmLightVertex"),
     ("Illuminant/Bezier.cs", "ClampedBezier1", "IlmClampedBezier1"),
     ("Illuminant/Bezier.cs", "ClampedBezier4", "IlmClampedBezier4"),
+    ("Illuminant/Vertices.cs", "HeightVolumeVertex", "IlmHeightVolumeVertex"),
+    ("Illuminant/Vertices.cs", "BillboardVertex", "IlmBillboardVertex"),
 ]
 
 
