@@ -1840,7 +1840,8 @@ int32_t ilm_gbuffer_render_meshes(IlmHandle h, const IlmGBufferMeshDesc* d,
     const size_t off_quads = align64(off_bb + sizeof(IlmBillboardVertex) * (size_t)billboard_vertex_count);
     const size_t off_tex = align64(off_quads + sizeof(int4) * quads.size());
     const size_t inputs = align64(off_tex + sizeof(GBufferTex) * textures.size()) + 64;
-    const size_t total = inputs + sizeof(GBufferPrim) * (size_t)prim_count;
+    const size_t off_bounds = inputs + align64(sizeof(GBufferPrim) * (size_t)prim_count);
+    const size_t total = off_bounds + sizeof(int4) * (size_t)prim_count;
     if (total > c->field_params_bytes) {
         HIP_TRY(hipStreamSynchronize(c->main()));
         if (c->d_field_params) HIP_TRY(hipFree(c->d_field_params));
@@ -1867,6 +1868,7 @@ int32_t ilm_gbuffer_render_meshes(IlmHandle h, const IlmGBufferMeshDesc* d,
     a.quads = reinterpret_cast<const int4*>(base + off_quads);
     a.textures = reinterpret_cast<const GBufferTex*>(base + off_tex);
     a.prims = reinterpret_cast<GBufferPrim*>(base + inputs); a.prim_count = (int32_t)prim_count;
+    a.bounds = reinterpret_cast<int4*>(base + off_bounds);
     HIP_TRY(launch_gbuffer_meshes(a, c->main()));
     return ILM_OK;
 }

@@ -4,10 +4,10 @@
 //
 // The reference hands triangle lists to the Direct3D rasteriser, one draw call after the other into one render target with a 24-bit
 // depth buffer.  Here the whole frame is ONE pass over the pixels: a setup kernel runs the three vertex shaders and snaps every
-// triangle to the 1/256-pixel grid (one thread per triangle, records in draw order); the raster kernel gives every wave an 8 x 8 pixel
-// tile, walks the records in draw order with wave-uniform (scalar) loads, rejects a record against the tile with scalar compares, and
-// keeps each pixel's colour and depth in registers until its single store -- 16 B (or 8 B) written per texel, nothing read back, no
-// atomics, and the reference's draw order is the loop order.  Coverage is exact integer arithmetic (64-bit edge functions, top-left
+// triangle to the 1/256-pixel grid (one thread per triangle, records in draw order); the raster kernel bins the records per 16 x 16
+// pixel tile into an ordered list in LDS, gives every wave an 8 x 8 quarter of the tile, walks the list with wave-uniform (scalar)
+// loads of the records, and keeps each pixel's colour and depth in registers until its single store -- 16 B (or 8 B) written per
+// texel, nothing read back, no atomics, and the reference's draw order is the loop order.  Coverage is exact integer arithmetic (64-bit edge functions, top-left
 // rule), so a pixel belongs to exactly one of two triangles sharing an edge, as on the hardware.
 #include "internal.hpp"
 #include "hlsl_math.hpp"
@@ -172,79 +172,112 @@ __global__ __launch_bounds__(64) void gbuffer_setup_kernel(const GBufferMeshLaun
         billboard_prim(p, q.z, q.y, v[ix[0]], v[ix[1]], v[ix[2]], d);
     }
     a.prims[t] = p;
+    a.bounds[t] = make_int4(p.i0, p.i1, p.j0, p.j1);
 }
 
-// one wave per 8 x 8 pixel tile, four tiles (16 x 16 pixels) per workgroup
+// One workgroup per 16 x 16 pixel tile, one wave per 8 x 8 quarter of it.  The workgroup first bins: 256 threads test 256 triangles'
+// pixel bounds against the tile at a time (one coalesced 16 B load each) and append the hits to a list in LDS IN DRAW ORDER (ballot +
+// popcount prefix within a wave, the waves' counts through LDS); then every wave walks the list -- typically tens of entries instead of
+// the frame's thousands -- with the record fetched through scalar loads.  A list that fills up is rasterised and refilled: the pixels'
+// state lives in registers across the rounds.
+constexpr int kBinCapacity = 4096;
+
 __global__ __launch_bounds__(256) void gbuffer_meshes_kernel(const GBufferMeshLaunch a) {
+    __shared__ int s_list[kBinCapacity];
+    __shared__ int s_count[4];
     const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
-    const int ti0 = (int)blockIdx.x * 16 + (wave & 1) * 8, tj0 = (int)blockIdx.y * 16 + (wave >> 1) * 8;   // wave-uniform
+    const int bi0 = (int)blockIdx.x * 16, bj0 = (int)blockIdx.y * 16;
+    const int ti0 = bi0 + (wave & 1) * 8, tj0 = bj0 + (wave >> 1) * 8;                                    // wave-uniform
     const int i = ti0 + (lane & 7), j = tj0 + (lane >> 3);
     const int64_t px = 256 * (int64_t)i + 128, py = 256 * (int64_t)j + 128;
     const IlmGBufferMeshDesc& d = a.desc;
     float4 texel = mk4(0.0f, 0.0f, 0.0f, 0.0f);                  // ClearBatch(Color.Transparent, clearZ: 0), :147-150
     uint32_t depth = 0;
     const int tile_i0 = __builtin_amdgcn_readfirstlane(ti0), tile_j0 = __builtin_amdgcn_readfirstlane(tj0);
-    for (int t = 0; t < a.prim_count; t++) {
-        const GBufferPrim& p = a.prims[t];
-        if ((p.i1 < tile_i0) || (p.i0 > tile_i0 + 7) || (p.j1 < tile_j0) || (p.j0 > tile_j0 + 7))
-            continue;
-        const int64_t w0 = edge(p.x[1], p.y[1], p.x[2], p.y[2], px, py);
-        const int64_t w1 = edge(p.x[2], p.y[2], p.x[0], p.y[0], px, py);
-        const int64_t w2 = edge(p.x[0], p.y[0], p.x[1], p.y[1], px, py);
-        bool in = (w0 >= 0) && (w1 >= 0) && (w2 >= 0);
-        in = in && ((w0 != 0) || edge_owns(p.x[1], p.y[1], p.x[2], p.y[2]));
-        in = in && ((w1 != 0) || edge_owns(p.x[2], p.y[2], p.x[0], p.y[0]));
-        in = in && ((w2 != 0) || edge_owns(p.x[0], p.y[0], p.x[1], p.y[1]));
-        if (!in)
-            continue;
-        const double area = (double)(w0 + w1 + w2);
-        const float f1 = (float)((double)w1 / area), f2 = (float)((double)w2 / area);
-        auto at = [&](int k) { return (p.a[0][k] + (p.a[1][k] - p.a[0][k]) * f1) + (p.a[2][k] - p.a[0][k]) * f2; };
-        const float z = at(7);
-        if (!((z >= 0.0f) && (z <= 1.0f)))                       // clipped against the near / far plane (w = 1)
-            continue;
-        const f3 wp = mk3(at(0), at(1), at(2));
-        const f3 n = mk3(at(3), at(4), at(5));
-        float4 out;
-        const int kind = p.kind;
-        if (kind == kGround) {                                   // GroundPlanePixelShader, GBuffer.fx:57-70
-            if (wp.z < d.GroundZ) continue;
-            out = encode_sample(mk3(0.0f, 0.0f, 1.0f), 0.0f, wp.z, at(8) != 0.0f, at(6) > 0.5f);
-        } else if ((kind == kTop) || (kind == kFace)) {          // HeightVolumePixelShader :72-85 / HeightVolumeFacePixelShader :87-103
-            f3 bias = mk3(0.0f, 0.0f, d.ZSelfOcclusionHack);
-            if (kind == kFace) {
-                if (wp.z < d.GroundZ) continue;
-                bias = mk3(d.SelfOcclusionHack, d.SelfOcclusionHack, d.ZSelfOcclusionHack) * n;
+    int next = 0;
+    while (next < a.prim_count) {
+        int len = 0;
+        while ((next < a.prim_count) && (len + 256 <= kBinCapacity)) {
+            const int t = next + (int)threadIdx.x;
+            bool hit = false;
+            if (t < a.prim_count) {
+                const int4 b = a.bounds[t];                      // (i0, i1, j0, j1)
+                hit = !((b.y < bi0) || (b.x > bi0 + 15) || (b.w < bj0) || (b.z > bj0 + 15));
             }
-            const float relative_y = (((wp.z * d.ZToYMultiplier) * d.ViewportScale[0]) / d.RenderScale[0]) + bias.y;
-            out = encode_sample(n, relative_y, wp.z + bias.z, false, at(6) > 0.5f);
-            // DepthFormat.Depth24, CompareFunction.GreaterEqual with writes (LightingRenderer.cs:539-551)
-            const uint32_t d24 = (uint32_t)floor((double)z * 16777215.0 + 0.5);
-            if (!(d24 >= depth)) continue;
-            depth = d24;
-        } else {
-            const float4 data = sample_point(a.textures, p.texture, at(6), at(7));
-            const float data_scale = at(9);
-            if (kind == kMask) {                                 // MaskBillboardPixelShader, GBufferBitmap.fx:29-59
-                const float discard_threshold = ref::kMaskDiscardNumerator / 255.0f;
-                if ((data.w - discard_threshold) < 0.0f) continue;
-                const float relative_y = (wp.y - at(8)) * data_scale;
-                out = mk4((n.x / 2.0f) + 0.5f, (n.z / 2.0f) + 0.5f, relative_y,
-                          ((wp.z + ref::kGBufferZOffset) / ref::kGBufferZScale) * at(10));
-            } else if (kind == kGData) {                         // GDataBillboardPixelShader, GBufferBitmap.fx:61-113
-                const float discard_threshold = ref::kGDataDiscardNumerator / 255.0f;
-                if (data.w < discard_threshold) continue;
-                const float tx = (data.x - 0.5f) * 2.0f, ty = (data.y - 0.5f) * 2.0f;
-                const float tz = sqrtf(1.0f - (tx * tx + ty * ty));
-                const f3 world_normal = mk3((1.0f * tx + 0.0f * ty) + 0.0f * tz, (0.0f * tx + -1.0f * ty) + 0.0f * tz, (0.0f * tx + 0.0f * ty) + 1.0f * tz);
-                const f3 result_normal = norm3(world_normal);
-                const float effective_z = wp.z + (data.z * data_scale);
-                out = encode_sample(result_normal, effective_z * d.ZToYMultiplier, effective_z, false, true);
-            } else {
-                continue;                                        // a degenerate triangle's record (empty bounds: not reached)
-            }
+            const uint64_t mask = __ballot(hit);
+            if (lane == 0) s_count[wave] = __popcll(mask);
+            __syncthreads();
+            int before = 0, total = 0;
+            for (int w = 0; w < 4; w++) { const int c = s_count[w]; total += c; if (w < wave) before += c; }
+            if (hit) s_list[len + before + __popcll(mask & ((1ull << lane) - 1ull))] = t;
+            len += total;
+            next += 256;
+            __syncthreads();
         }
-        texel = out;
+        for (int k = 0; k < len; k++) {
+            const int t = __builtin_amdgcn_readfirstlane(s_list[k]);
+            const GBufferPrim& p = a.prims[t];
+            if ((p.i1 < tile_i0) || (p.i0 > tile_i0 + 7) || (p.j1 < tile_j0) || (p.j0 > tile_j0 + 7))
+                continue;
+            const int64_t w0 = edge(p.x[1], p.y[1], p.x[2], p.y[2], px, py);
+            const int64_t w1 = edge(p.x[2], p.y[2], p.x[0], p.y[0], px, py);
+            const int64_t w2 = edge(p.x[0], p.y[0], p.x[1], p.y[1], px, py);
+            bool in = (w0 >= 0) && (w1 >= 0) && (w2 >= 0);
+            in = in && ((w0 != 0) || edge_owns(p.x[1], p.y[1], p.x[2], p.y[2]));
+            in = in && ((w1 != 0) || edge_owns(p.x[2], p.y[2], p.x[0], p.y[0]));
+            in = in && ((w2 != 0) || edge_owns(p.x[0], p.y[0], p.x[1], p.y[1]));
+            if (!in)
+                continue;
+            const double area = (double)(w0 + w1 + w2);
+            const float f1 = (float)((double)w1 / area), f2 = (float)((double)w2 / area);
+            auto at = [&](int k) { return (p.a[0][k] + (p.a[1][k] - p.a[0][k]) * f1) + (p.a[2][k] - p.a[0][k]) * f2; };
+            const float z = at(7);
+            if (!((z >= 0.0f) && (z <= 1.0f)))                       // clipped against the near / far plane (w = 1)
+                continue;
+            const f3 wp = mk3(at(0), at(1), at(2));
+            const f3 n = mk3(at(3), at(4), at(5));
+            float4 out;
+            const int kind = p.kind;
+            if (kind == kGround) {                                   // GroundPlanePixelShader, GBuffer.fx:57-70
+                if (wp.z < d.GroundZ) continue;
+                out = encode_sample(mk3(0.0f, 0.0f, 1.0f), 0.0f, wp.z, at(8) != 0.0f, at(6) > 0.5f);
+            } else if ((kind == kTop) || (kind == kFace)) {          // HeightVolumePixelShader :72-85 / HeightVolumeFacePixelShader :87-103
+                f3 bias = mk3(0.0f, 0.0f, d.ZSelfOcclusionHack);
+                if (kind == kFace) {
+                    if (wp.z < d.GroundZ) continue;
+                    bias = mk3(d.SelfOcclusionHack, d.SelfOcclusionHack, d.ZSelfOcclusionHack) * n;
+                }
+                const float relative_y = (((wp.z * d.ZToYMultiplier) * d.ViewportScale[0]) / d.RenderScale[0]) + bias.y;
+                out = encode_sample(n, relative_y, wp.z + bias.z, false, at(6) > 0.5f);
+                // DepthFormat.Depth24, CompareFunction.GreaterEqual with writes (LightingRenderer.cs:539-551)
+                const uint32_t d24 = (uint32_t)floor((double)z * 16777215.0 + 0.5);
+                if (!(d24 >= depth)) continue;
+                depth = d24;
+            } else {
+                const float4 data = sample_point(a.textures, p.texture, at(6), at(7));
+                const float data_scale = at(9);
+                if (kind == kMask) {                                 // MaskBillboardPixelShader, GBufferBitmap.fx:29-59
+                    const float discard_threshold = ref::kMaskDiscardNumerator / 255.0f;
+                    if ((data.w - discard_threshold) < 0.0f) continue;
+                    const float relative_y = (wp.y - at(8)) * data_scale;
+                    out = mk4((n.x / 2.0f) + 0.5f, (n.z / 2.0f) + 0.5f, relative_y,
+                              ((wp.z + ref::kGBufferZOffset) / ref::kGBufferZScale) * at(10));
+                } else if (kind == kGData) {                         // GDataBillboardPixelShader, GBufferBitmap.fx:61-113
+                    const float discard_threshold = ref::kGDataDiscardNumerator / 255.0f;
+                    if (data.w < discard_threshold) continue;
+                    const float tx = (data.x - 0.5f) * 2.0f, ty = (data.y - 0.5f) * 2.0f;
+                    const float tz = sqrtf(1.0f - (tx * tx + ty * ty));
+                    const f3 world_normal = mk3((1.0f * tx + 0.0f * ty) + 0.0f * tz, (0.0f * tx + -1.0f * ty) + 0.0f * tz, (0.0f * tx + 0.0f * ty) + 1.0f * tz);
+                    const f3 result_normal = norm3(world_normal);
+                    const float effective_z = wp.z + (data.z * data_scale);
+                    out = encode_sample(result_normal, effective_z * d.ZToYMultiplier, effective_z, false, true);
+                } else {
+                    continue;                                        // a degenerate triangle's record (empty bounds: not reached)
+                }
+            }
+            texel = out;
+        }
+        __syncthreads();                                        // the list is rewritten by the next round
     }
     if (i >= a.width || j >= a.height) return;
     const size_t o = (size_t)j * (size_t)a.width + (size_t)i;

@@ -265,6 +265,7 @@ struct GBufferMeshLaunch {
     const int4* quads;            // (quad, texture, kind, -) per billboard quad in draw order
     const GBufferTex* textures;
     GBufferPrim* prims; int32_t prim_count;
+    int4* bounds;                 // (i0, i1, j0, j1) per record: what the binning pass reads
 };
 hipError_t launch_gbuffer_meshes(const GBufferMeshLaunch& a, hipStream_t stream);
 
