@@ -2307,8 +2307,6 @@ int32_t ilm_render_particles(IlmHandle hsystem, const int32_t* quad_counts, int3
     // Fracture code outside the reference tree (DitherCommon.fxh): not guessed
     if (!(params->StippleFactor >= 1.0f))
         return fail(ILM_ERR_INVALID_ARGUMENT, "StippleFactor %g < 1 needs Fracture's StippleReject, which is not part of the reference tree", (double)params->StippleFactor);
-    if (params->RenderingOptions[1] >= 0.5f)
-        return fail(ILM_ERR_INVALID_ARGUMENT, "DitheredOpacity needs Fracture's Dither64, which is not part of the reference tree");
     if (params->BlendMode != ILM_BLEND_ALPHA && params->BlendMode != ILM_BLEND_ADDITIVE)
         return fail(ILM_ERR_INVALID_ARGUMENT, "unknown blend mode %d", params->BlendMode);
     if (params->BitmapFilter < ILM_BITMAP_NONE || params->BitmapFilter > ILM_BITMAP_LINEAR)

@@ -28,7 +28,7 @@ struct alignas(16) Sprite {
     float r, g, b, a;           // RenderColor (x GlobalColor for NoTexture; the textured pixel shaders apply it after the texel)
     float rounding;
     float frame_u, frame_v;     // frameTexCoord: offset of the animation frame inside the sheet
-    uint32_t _pad;
+    float dither_frame;         // floor(index % 4) of premultipliedToDithered; index = the slot (ParticleEngine.cs:476-478)
 };
 static_assert(sizeof(Sprite) == 64, "Sprite is 16 words");
 
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void raster_setup_kernel(const RasterLaunch a)
                     float fy0 = floorf(sp.cy - ey - 0.5f) - 1.0f, fy1 = ceilf(sp.cy + ey - 0.5f) + 1.0f;
                     fx0 = fmaxf(fx0, 0.0f); fy0 = fmaxf(fy0, 0.0f);
                     fx1 = fminf(fx1, (float)(a.width - 1)); fy1 = fminf(fy1, (float)(a.height - 1));
-                    sp._pad = 0u;
+                    sp.dither_frame = (float)(slot & 3);
                     sp.ex = ex + 1.0f; sp.ey = ey + 1.0f;
                     uint2 rect = make_uint2(0u, 0u);
                     if ((fx0 <= fx1) && (fy0 <= fy1)) {
@@ -250,6 +250,7 @@ __global__ __launch_bounds__(256) void raster_tiles_kernel(const RasterLaunch a)
     const float pcx = (float)x + 0.5f, pcy = (float)y + 0.5f;
     const float tcx = (float)(tx * kRasterTile) + 4.0f, tcy = (float)(ty * kRasterTile) + 4.0f;     // centre of quadrant 0
     const bool rounded = a.params.RenderingOptions[0] != 0.0f;
+    const bool dithered = a.params.RenderingOptions[1] >= 0.5f;
     const bool additive = a.params.BlendMode == ILM_BLEND_ADDITIVE;
     const int filter = a.params.BitmapFilter;
     const float region_x = a.params.BitmapTextureRegion.x, region_y = a.params.BitmapTextureRegion.y;
@@ -319,7 +320,20 @@ __global__ __launch_bounds__(256) void raster_tiles_kernel(const RasterLaunch a)
                 cr = (cr * t.x) * a.params.GlobalColor.x; cg = (cg * t.y) * a.params.GlobalColor.y;
                 cb = (cb * t.z) * a.params.GlobalColor.z; ca = (ca * t.w) * a.params.GlobalColor.w;
             }
-            const float sr = cr * alpha, sg = cg * alpha, sb = cb * alpha, sa = ca * alpha;
+            float sr = cr * alpha, sg = cg * alpha, sb = cb * alpha, sa = ca * alpha;
+            if (dithered) {
+                // premultipliedToDithered, RasterizeParticleSystem.fx:158-175, with Dither64 of Fracture's DitherCommon.fxh (outside the tree)
+                // = Jimenez' published frac(dot(float3(vpos, frame), uint3(33, 52, 25) / 64.0)); GET_VPOS = floor(vpos); every term is a
+                // multiple of 1/64 below 2^18, so the sum is exact in any order
+                const float dd = (((float)x * (33.0f / 64.0f)) + ((float)y * (52.0f / 64.0f))) + (sp.dither_frame * (25.0f / 64.0f));
+                const float d64 = dd - floorf(dd);
+                if ((sa <= d64) || (sa <= (ref::kDitherDiscardNumerator / 255.0f))) {
+                    sr = sg = sb = sa = 0.0f;
+                } else {
+                    const float al = fmaxf(sa, 0.0001f);
+                    sr = sr / al; sg = sg / al; sb = sb / al; sa = 1.0f;
+                }
+            }
             if (sa <= 0.0f)                                 // `result.a <= (1 / 512)`: an integer division in the shader, i.e. <= 0
                 continue;
             shaded++;

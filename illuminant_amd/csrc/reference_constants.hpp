@@ -54,6 +54,9 @@ constexpr float kDeadTexel = 99999.0f;
 constexpr float kGroundHalfExtent = 999999.0f;
 constexpr float kGroundLift = 99999.0f;
 
+// premultipliedToDithered, RasterizeParticleSystem.fx:161: discardThreshold = 6.0 / 255.0
+constexpr float kDitherDiscardNumerator = 6.0f;
+
 struct Entry { const char* key; double value; };
 constexpr Entry kTable[] = {
     { "ParticleCommon.fxh:PI", kPi }, { "DistanceFieldCommon.fxh:PI", kPi },
@@ -81,6 +84,7 @@ constexpr Entry kTable[] = {
     { "GBufferShaderCommon.fxh:dead texel value", kDeadTexel },
     { "LightingRenderer.GBuffer.cs:ground plane half extent", kGroundHalfExtent },
     { "LightingRenderer.GBuffer.cs:ground plane lift", kGroundLift },
+    { "RasterizeParticleSystem.fx:dither discard threshold numerator", kDitherDiscardNumerator },
     { "Gravity.fx:MAX_ATTRACTORS", ILM_MAX_ATTRACTORS },
     { "SpawnerCommon.fxh:MAX_INLINE_POSITION_CONSTANTS", ILM_MAX_INLINE_POSITION_CONSTANTS },
     { "ParticleEngine.cs:RandomnessTextureWidth", ILM_RANDOMNESS_WIDTH }, { "ParticleEngine.cs:RandomnessTextureHeight", ILM_RANDOMNESS_HEIGHT },

@@ -185,7 +185,7 @@ def feedback_params(source_system_handle, source_chunk_index, source_index, inst
 def rasterize_params(size=(1.0, 1.0), global_color=(1.0, 1.0, 1.0, 1.0), origin=(0.0, 0.0), scale=(1.0, 1.0), size_from_z=0.0, z_to_y=0.0,
                      rounded=False, rounding_power=None, viewport_scale=(1.0, 1.0), viewport_position=(0.0, 0.0), blend=abi.BLEND_ALPHA,
                      z_formula=(0.0, 0.0, 0.0, 0.0), stipple_factor=1.0, texture_size=None, offset_px=(0.0, 0.0), size_px=None,
-                     relative_size=True, bilinear=True, animation_rate=(0.0, 0.0), column_from_velocity=False, row_from_velocity=False):
+                     relative_size=True, bilinear=True, animation_rate=(0.0, 0.0), column_from_velocity=False, row_from_velocity=False, dithered_opacity=False):
     """Uniforms.RasterizeParticleSystem (Uniforms.cs:238-290) + what ParticleSystem.Render / RenderHandler._BeforeDraw add
     (ParticleSystem.cs:254-271, 963-1032).  global_color is Color.Global (NOT premultiplied: the ctor does that); rounding_power: a
     ClampedBezier1 or None for the constant 0.8 (ParticleAppearance.RoundingPowerFromLife default).  texture_size = (w, h) of
@@ -212,7 +212,7 @@ def rasterize_params(size=(1.0, 1.0), global_color=(1.0, 1.0, 1.0, 1.0), origin=
     if rounding_power is None:
         rounding_power = abi.ClampedBezier1.constant(0.8)
     p.RoundingPowerFromLife = rounding_power
-    p.RenderingOptions[:] = [1.0 if rounded else 0.0, 0.0, 1.0 if column_from_velocity else 0.0, 1.0 if row_from_velocity else 0.0]
+    p.RenderingOptions[:] = [1.0 if rounded else 0.0, 1.0 if dithered_opacity else 0.0, 1.0 if column_from_velocity else 0.0, 1.0 if row_from_velocity else 0.0]
     p.SystemSize[:] = list(size)
     p.ZToY = z_to_y
     p.StippleFactor = stipple_factor

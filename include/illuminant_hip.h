@@ -794,7 +794,8 @@ typedef struct IlmRasterizeParams {
     IlmFloat4 ZFormula;
     IlmFloat4 ZConfiguration;          /* (SizeFromZ, 0, 0, 0) */
     IlmClampedBezier1 RoundingPowerFromLife;
-    float     RenderingOptions[4];     /* Rounded, DitheredOpacity (must be 0: Dither64 is Fracture code), column / row (of the frame sheet) from velocity */
+    float     RenderingOptions[4];     /* Rounded, DitheredOpacity (premultipliedToDithered, RasterizeParticleSystem.fx:158-175, over Dither64 -- Fracture code outside the
+                                      * tree, restated from the function it publishes: Jimenez, SIGGRAPH 2014), column / row (of the frame sheet) from velocity */
     float     SystemSize[2];           /* System.TexelAndSize.zw = Configuration.Size */
     float     ZToY;
     float     StippleFactor;           /* must be >= 1 (StippleReject is Fracture code) */

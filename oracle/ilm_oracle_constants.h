@@ -55,6 +55,9 @@
 #define GB_GROUND_HALF_EXTENT 999999.0f
 #define GB_GROUND_LIFT 99999.0f
 
+/* premultipliedToDithered, RasterizeParticleSystem.fx:161: discardThreshold = 6.0 / 255.0 */
+#define RASTER_DITHER_DISCARD_NUMERATOR 6.0f
+
 struct OrcReferenceConstant { const char* key; double value; };
 static const struct OrcReferenceConstant orc_reference_constants[] = {
     { "ParticleCommon.fxh:PI", H_PI }, { "DistanceFieldCommon.fxh:PI", H_PI },
@@ -82,6 +85,7 @@ static const struct OrcReferenceConstant orc_reference_constants[] = {
     { "GBufferShaderCommon.fxh:dead texel value", GB_DEAD_TEXEL },
     { "LightingRenderer.GBuffer.cs:ground plane half extent", GB_GROUND_HALF_EXTENT },
     { "LightingRenderer.GBuffer.cs:ground plane lift", GB_GROUND_LIFT },
+    { "RasterizeParticleSystem.fx:dither discard threshold numerator", RASTER_DITHER_DISCARD_NUMERATOR },
     { "Gravity.fx:MAX_ATTRACTORS", ILM_MAX_ATTRACTORS },
     { "SpawnerCommon.fxh:MAX_INLINE_POSITION_CONSTANTS", ILM_MAX_INLINE_POSITION_CONSTANTS },
     { "ParticleEngine.cs:RandomnessTextureWidth", ILM_RANDOMNESS_WIDTH }, { "ParticleEngine.cs:RandomnessTextureHeight", ILM_RANDOMNESS_HEIGHT },

@@ -147,15 +147,26 @@ typedef struct OrcSprite {
     f4 color;                   /* RenderColor (x GlobalColor for NoTexture; the textured pixel shaders apply it after the texel) */
     float rounding;
     float frame_u, frame_v;     /* frameTexCoord: offset of the animation frame inside the sheet */
+    float dither_frame;         /* floor(index % 4) of premultipliedToDithered, index = the slot (ParticleEngine.cs:476-478) */
     int live;
 } OrcSprite;
 
 /* HLSL round(): to nearest, ties to even */
 static float hlsl_round(float x) { return (float)nearbyint((double)x); }
 
-static OrcSprite raster_sprite(f4 position, f4 render_data, f4 render_color, const IlmRasterizeParams* p) {
+/* Dither64 of Fracture's DitherCommon.fxh (Squared/RenderLib/Shaders, outside the reference tree, no pinned version), which restates
+ * the published function of J. Jimenez, "Next Generation Post Processing in Call of Duty: Advanced Warfare" (SIGGRAPH 2014):
+ * frac(dot(float3(Pos.xy, FrameIndexMod4), uint3(33, 52, 25) / 64.0)).  Every term is a multiple of 1/64 below 2^18, so the sum is
+ * exact in whatever order the dot product adds. */
+static float dither64(float x, float y, float frame_index_mod4) {
+    const float d = ((x * (33.0f / 64.0f)) + (y * (52.0f / 64.0f))) + (frame_index_mod4 * (25.0f / 64.0f));
+    return d - floorf(d);
+}
+
+static OrcSprite raster_sprite(f4 position, f4 render_data, f4 render_color, const IlmRasterizeParams* p, int slot) {
     OrcSprite sp;
     memset(&sp, 0, sizeof(sp));
+    sp.dither_frame = floorf(fmodf((float)slot, 4.0f));
     const float life = position.w;
     if (life <= 0.0f)                                     /* StippleReject: StippleFactor >= 1 rejects nothing */
         return sp;
@@ -253,7 +264,7 @@ void orc_render_particles_textured(IlmFloat4** planes, int32_t chunk_count, cons
     for (int c = 0; c < chunk_count; c++) {
         const int count = quad_counts ? quad_counts[c] : slots;
         for (int i = 0; i < count && i < slots; i++) {
-            const OrcSprite sp = raster_sprite(planes[c * 5 + 0][i], planes[c * 5 + 4][i], planes[c * 5 + 3][i], p);
+            const OrcSprite sp = raster_sprite(planes[c * 5 + 0][i], planes[c * 5 + 4][i], planes[c * 5 + 3][i], p, i);
             if (!sp.live)
                 continue;
             live++;
@@ -279,7 +290,16 @@ void orc_render_particles_textured(IlmFloat4** planes, int32_t chunk_count, cons
                         const float tv = (region_y + (region_h * ((v / 2.0f) + 0.5f))) + sp.frame_v;
                         result = v4mul(v4mul(result, bitmap_fetch(bitmap, bitmap_w, bitmap_h, tu, tv, p->BitmapFilter)), p->GlobalColor);
                     }
-                    const f4 src = v4scale(result, alpha);
+                    f4 src = v4scale(result, alpha);
+                    if (p->RenderingOptions[1] >= 0.5f) {       /* premultipliedToDithered, RasterizeParticleSystem.fx:158-175; GET_VPOS = floor(vpos) */
+                        const float discard_threshold = RASTER_DITHER_DISCARD_NUMERATOR / 255.0f;
+                        if ((src.w <= dither64((float)x, (float)y, sp.dither_frame)) || (src.w <= discard_threshold)) {
+                            src = v4(0, 0, 0, 0);
+                        } else {
+                            const float a = fmaxf(src.w, 0.0001f);
+                            src = v4(src.x / a, src.y / a, src.z / a, 1.0f);
+                        }
+                    }
                     if (src.w <= 0.0f)                    /* `result.a <= (1 / 512)`: integer division, i.e. <= 0 */
                         continue;
                     shaded++;

@@ -83,6 +83,29 @@ def test_random_sprites_match_oracle(ctx, oracle, rounded, blend):
     assert (np.abs(want - np.asarray(clear, np.float32)).max(axis=-1) > 1e-3).mean() > 0.9
 
 
+@pytest.mark.parametrize("rounded,textured", [(False, False), (True, False), (True, True)])
+def test_dithered_opacity_matches_oracle(ctx, oracle, rounded, textured):
+    """Appearance.DitheredOpacity (RenderingOptions.y): every technique ends in premultipliedToDithered -- fragments either vanish against
+    the 64-level ordered dither or become opaque; the threshold compare is exact arithmetic on both sides."""
+    cs, w, h = 64, 300, 180
+    chunks = random_chunks(77, cs, 2, w, h, size_hi=9.0)
+    sheet = scenes.uniform(501, (16, 32, 4), 0.0, 1.0) if textured else None
+    kw = dict(texture_size=(32, 16), offset_px=(0.0, 0.0), size_px=(8.0, 8.0), bilinear=True, animation_rate=(0.3, 0.0)) if textured else {}
+    params = scenes.rasterize_params(global_color=(0.9, 0.8, 1.0, 0.8), rounded=rounded, dithered_opacity=True,
+                                     rounding_power=abi.ClampedBezier1.linear(0.2, 0.9, 0.0, 3.0), **kw)
+    clear = (0.05, 0.1, 0.15, 0.2)
+    got, (live, pairs, shaded) = render_gpu(ctx, chunks, cs, params, w, h, abi.LIGHTMAP_FLOAT4, clear, bitmap=sheet)
+    want = np.zeros((h, w, 4), np.float32); want[:] = clear
+    want, (olive, oshaded) = oracle.render_particles(chunks, params, w, h, image=want, bitmap=sheet)
+    assert live == olive and live > 4000
+    # a fragment whose alpha sits within float noise of its dither level (pow / sin / cos differ in the last bits) may flip: whole pixels
+    assert abs(shaded - oshaded) <= 24 and shaded > 10 * live
+    compare_images(got, want, "dithered", max_outliers=24)
+    # dithered fragments are opaque: wherever a sprite was drawn, alpha is exactly 1
+    drawn = np.abs(want - np.asarray(clear, np.float32)).max(axis=-1) > 1e-6
+    assert drawn.mean() > 0.5 and np.all(want[drawn][:, 3] == 1.0)
+
+
 @pytest.mark.parametrize("bilinear,rate", [(False, (0.4, 0.0)), (True, (-0.7, 1.5)), (True, (0.0, -0.9))])
 def test_textured_sprites_match_oracle(ctx, oracle, bilinear, rate):
     """Techniques TexturePoint / TextureLinear on a 32 x 16 sheet of 4 x 2 frames: frame column from life (both directions), row from
@@ -177,9 +200,6 @@ def test_fracture_only_options_and_bad_arguments_are_refused(ctx):
     with pytest.raises(native.IlluminantError) as e:
         native.render_particles(sysm, p, lm)
     assert e.value.code == abi.ERR_INVALID_ARGUMENT and "Stipple" in str(e.value)
-    p = scenes.rasterize_params(); p.RenderingOptions[1] = 1.0
-    with pytest.raises(native.IlluminantError):
-        native.render_particles(sysm, p, lm)
     p = scenes.rasterize_params(); p.BlendMode = 7
     with pytest.raises(native.IlluminantError):
         native.render_particles(sysm, p, lm)

@@ -63,6 +63,7 @@ LITERALS = [
     ("Illuminant/Lighting/LightingRenderer.Configuration.cs", "ConeGrowthFactor default", r"public float ConeGrowthFactor\s+= ([\d.]+)f?;"),
     ("Illuminant/Lighting/LightingRenderer.Configuration.cs", "OcclusionToOpacityPower default", r"public float OcclusionToOpacityPower = ([\d.]+)f?;"),
     ("Illuminant/Shaders/CountLiveParticles.fx", "count increment denominator", r"color = float4\(1\.0 / (\d+),"),
+    ("Illuminant/Shaders/RasterizeParticleSystem.fx", "dither discard threshold numerator", r"premultipliedToDithered[\s\S]*?discardThreshold = \(([\d.]+) / 255\.0\)"),
     ("Illuminant/Shaders/GBufferBitmap.fx", "mask discard threshold numerator", r"MaskBillboardPixelShader[\s\S]*?discardThreshold = \(([\d.]+) / 255\.0\)"),
     ("Illuminant/Shaders/GBufferBitmap.fx", "gdata discard threshold numerator", r"GDataBillboardPixelShader[\s\S]*?discardThreshold = \(([\d.]+) / 255\.0\)"),
     ("Illuminant/Shaders/GBufferShaderCommon.fxh", "dead texel value", r"if \(dead\)[\s\S]*?0, 0,\s*-(\d+),"),
