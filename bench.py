@@ -57,13 +57,26 @@ def profiled_traffic(*kernel_prefixes):
     known 48 B/slot read.  Counters cannot be collected from inside the timed run (rocprofv3 wraps the process), so the figure is
     carried over from the profile; None when a kernel is absent from it."""
     rows, source = _newest_pmc_rows()
-    total = 0.0
+    total, lanes = 0.0, 0.0
     for prefix in kernel_prefixes:
         hit = [r for r in rows if r["kernel"].startswith(prefix) and r.get("FETCH_SIZE") and r.get("WRITE_SIZE")]
         if not hit:
             return None
         total += (float(hit[0]["FETCH_SIZE"]) * 2.0 + float(hit[0]["WRITE_SIZE"])) * 1024.0
-    return {"bytes": total, "source": source}
+        lanes += float(hit[0].get("SQ_WAVES") or 0.0) * 64.0
+    return {"bytes": total, "lanes": lanes, "source": source}
+
+
+def step_traffic_fields(t, units):
+    """The step kernels run one lane per slot, so the profile's bytes / (SQ_WAVES x 64) is the measured HBM traffic per slot-step of
+    the profiled launches; `traffic` = that figure x the units of THIS run's launch (the profiled run has fewer live slots than the
+    timed blocks end with), the profile's own numbers beside it."""
+    if not t or not t["lanes"]:
+        return {"traffic": None}
+    per = t["bytes"] / t["lanes"]
+    return {"traffic": round(per * units), "traffic_per_unit": round(per, 2),
+            "traffic_profiled": {"bytes_per_step": round(t["bytes"]), "slots_per_step": round(t["lanes"])},
+            "traffic_source": "profiles/%s: (FETCH_SIZE x 2 + WRITE_SIZE) KB / (SQ_WAVES x 64 slots) of the step's launches, x units_per_launch" % t["source"]}
 
 
 def profiled_per_wave(kernel_prefix, column):
@@ -362,8 +375,7 @@ def main():
                          "roofline_frac_max": round(max(b["gbs"] for b in blocks) / HBM_PEAK_GBS, 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
-                     "traffic": round(step_traffic["bytes"]) if step_traffic else None,
-                     "traffic_source": ("profiles/%s: (FETCH_SIZE x 2 + WRITE_SIZE) KB per dispatch" % step_traffic["source"]) if step_traffic else None,
+                     **step_traffic_fields(step_traffic, live_avg),
                      "kernel": "ilm::step_lean_kernel<spawning> + <no spawn> (one ParticleSystem.Update = two launches: the chunk range halved over the context's two streams)",
                      "bytes_per_unit": PARTICLE_BYTES_PER_SLOT, "units_per_launch": round(live_avg, 1),
                      "launch_ms": round(step_ms_gpu, 5)},
@@ -436,7 +448,7 @@ def main():
             "timed_blocks": {"blocks": len(b4), "steps_per_block": k4, "headline": "median block", "ms_per_step_min": round(b4[0][0] / k4 * 1e3, 5),
                              "ms_per_step_max": round(b4[-1][0] / k4 * 1e3, 5)},
             "roofline": {"bound": "hbm", "achieved": round(gbs4, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs4 / HBM_PEAK_GBS, 4),
-                         "traffic": None, "kernel": "ilm::step_lean_kernel<no spawn, streaming> (two launches per step: the chunk range halved over the context's two streams)", "bytes_per_unit": PARTICLE_BYTES_PER_SLOT,
+                         **step_traffic_fields(profiled_traffic("ilm::step_lean_kernel<false, true>"), Q["live"]), "kernel": "ilm::step_lean_kernel<no spawn, streaming> (two launches per step: the chunk range halved over the context's two streams)", "bytes_per_unit": PARTICLE_BYTES_PER_SLOT,
                          "units_per_launch": Q["live"], "launch_ms": round(g4 / k4, 5)}}
         del Q, qs
 
