@@ -26,6 +26,7 @@ def rel_err(got, want):
 
 bad_light, bad_step, worst_l, worst_s = [], [], 0.0, 0.0
 bad_float, floor_needed, elements_compared = [], 0, 0
+bad_gbuffer, gbuffer_texels = [], 0
 worst_where = None
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
@@ -170,7 +171,8 @@ for seed in range(first, first + count, 4):
                                      blend=int(rng.integers(0, 2)), z_to_y=float(rng.uniform(0, 1)), size_from_z=float(rng.uniform(0, 0.1)),
                                      texture_size=(16, 8) if textured else None, size_px=(4.0, 4.0) if textured else None,
                                      bilinear=bool(rng.integers(0, 2)), animation_rate=(float(rng.uniform(-2, 2)), float(rng.uniform(-2, 2))),
-                                     column_from_velocity=bool(rng.integers(0, 2)), row_from_velocity=bool(rng.integers(0, 2)))
+                                     column_from_velocity=bool(rng.integers(0, 2)), row_from_velocity=bool(rng.integers(0, 2)),
+                                     dithered_opacity=bool(rng.integers(0, 3) == 0))
     eng = native.Engine(ctx, cs, scenes.randomness_table(1)); sysm = native.System(eng); sysm.add_chunk()
     sysm.upload(0, P, pos); sysm.upload(0, RC, col); sysm.upload(0, RD, rd)
     if textured: sysm.set_bitmap(sheet)
@@ -185,7 +187,66 @@ for seed in range(first, first + count, 4):
     if live != olive or outliers > (40 if textured else 8) or abs(shaded - oshaded) > 8:
         bad_raster.append((seed, live, olive, shaded, oshaded, outliers, textured))
 
+    # ---- G-buffer from meshes: 2.5D volumes + billboards (every 2nd seed) ----------------------------------------------
+    if seed % 2 == 0:
+        gw, gh = int(rng.integers(40, 200)), int(rng.integers(30, 140))
+        k = float(rng.choice([0.0, 0.4, 0.6, 1.0]))
+        two = bool(rng.integers(0, 4) != 0)
+        vols = []
+        for v in range(int(rng.integers(1, 12))):
+            nv = int(rng.integers(3, 8))
+            ang = np.sort(rng.uniform(0, 2 * np.pi, nv)); rad = rng.uniform(4, 40, nv)
+            cx0, cy0 = rng.uniform(0, gw), rng.uniform(0, gh)
+            vols.append(([(float(np.float32(cx0 + rad[q] * np.cos(ang[q]))), float(np.float32(cy0 + rad[q] * np.sin(ang[q])))) for q in range(nv)],
+                         float(rng.uniform(-4, 10)), float(rng.uniform(1, 70)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))))
+        vols.sort(key=lambda t: (t[1] + t[2]) * (-1 if two else 1))
+        top = np.concatenate([scenes.top_face_mesh(t[0], t[1], t[2], t[3]) for t in vols])
+        front = np.concatenate([scenes.front_face_mesh(t[0], t[1], t[2], t[4]) for t in vols] + [np.zeros((0, 9), np.float32)]) if two else None
+        boards, kinds, texs, handles = [], [], [], []
+        for q in range(int(rng.integers(0, 7))):
+            kind = int(rng.integers(0, 2))
+            x, y = rng.uniform(-10, gw), rng.uniform(-10, gh)
+            bd = dict(screen_bounds=((x, y), (x + rng.uniform(2, 60), y + rng.uniform(2, 60))), type=kind, normal=tuple(rng.uniform(-1, 1, 3)),
+                      cylinder_factor=float(rng.choice([0.0, 0.5, 1.0])), data_scale=(None if rng.integers(0, 2) else float(rng.uniform(0.1, 6))),
+                      static_lighting_only=bool(rng.integers(0, 2)), world_offset=tuple(rng.uniform(-2, 2, 3)))
+            if kind == abi.BILLBOARD_GBUFFER_DATA: bd["world_elevation"] = float(rng.uniform(0, 30))
+            boards.append(bd); kinds.append(kind)
+            which = int(rng.integers(0, 4))
+            t = rng.uniform(0, 1, (int(rng.integers(1, 12)), int(rng.integers(1, 12)), 4))
+            t[..., :2] = 0.5 + (t[..., :2] - 0.5) * 0.7          # keep most tangent normals inside the unit disc; some NaNs stay
+            tex = None if which == 3 else (np.round(t * 255).astype(np.uint8) if which == 0 else t.astype(np.float16) if which == 1 else t.astype(np.float32))
+            texs.append(tex)
+            if tex is None:
+                handles.append(None)
+            else:
+                fm = {np.dtype(np.uint8): abi.LIGHTMAP_RGBA8, np.dtype(np.float16): abi.LIGHTMAP_HALF4, np.dtype(np.float32): abi.LIGHTMAP_FLOAT4}[tex.dtype]
+                hl = native.Lightmap(ctx, tex.shape[1], tex.shape[0], fm); hl.upload(tex); handles.append(hl)
+        bbv = scenes.billboard_vertices(boards, 0.0, k)
+        gd = scenes.gbuffer_mesh_desc(ground_z=float(rng.uniform(-2, 6)), viewport_position=tuple(rng.uniform(-8, 8, 2)), viewport_scale=tuple(rng.uniform(0.5, 2.0, 2)),
+                                      z_to_y=k, render_scale=tuple(rng.uniform(0.5, 2, 2)), extent_z=float(rng.uniform(16, 128)),
+                                      self_occlusion_hack=float(rng.uniform(0, 1)), z_self_occlusion_hack=float(rng.uniform(0, 3)), two_point_five_d=two,
+                                      render_ground_plane=bool(rng.integers(0, 5) != 0), enable_ground_shadows=bool(rng.integers(0, 2)))
+        gfmt = abi.GBUFFER_HALF4 if (seed // 2) % 2 else abi.GBUFFER_FLOAT4
+        gbt = native.GBufferTexture(ctx, None, gfmt, size=(gw, gh))
+        gbt.render_meshes(gd, top, front, bbv, [(handles[q], q, 1, kinds[q]) for q in range(len(kinds))])
+        ggot = gbt.download(); gbt.close()
+        for hl in handles:
+            if hl is not None: hl.close()
+        gwant = oracle.render_gbuffer_meshes(gw, gh, gd, top, front, bbv, [(q, 1, kinds[q]) for q in range(len(kinds))], texs)
+        if gfmt == abi.GBUFFER_HALF4:
+            ggot = ggot.view(np.float16).astype(np.float32); gwant = gwant.astype(np.float16).astype(np.float32); gtol = 2.0 ** -10
+        else:
+            gtol = 1e-6
+        gbuffer_texels += gw * gh
+        exact = np.array_equal(ggot[..., 1:], gwant[..., 1:], equal_nan=True) and np.array_equal(np.isnan(ggot[..., 0]), np.isnan(gwant[..., 0]))
+        d0 = np.abs(ggot[..., 0] - gwant[..., 0])
+        if not exact or (np.isfinite(d0).any() and np.nanmax(d0) > gtol):
+            bad_gbuffer.append((seed, gw, gh, two, len(vols), len(kinds), exact, float(np.nanmax(d0)) if np.isfinite(d0).any() else 0.0))
+
 print("seeds %d..%d" % (first, first + count - 1))
+print("G-buffer meshes: %d scenes with a differing texel of %d (%.2f M texels; channels 1-3 bit-equal, channel 0 within atan2's last bits)"
+      % (len(bad_gbuffer), len(range(first + (first % 2), first + count, 2)), gbuffer_texels / 1e6))
+for b in bad_gbuffer[:10]: print("   ", b)
 print("field generation: %d scenes with differing codes of %d (%.1f M texel channels compared)" % (len(bad_field), len(range(first, first + count, 4)), field_texels / 1e6))
 for b in bad_field[:10]: print("   ", b)
 print("rasteriser: %d scenes out of bounds; most edge pixels that flipped in one frame: %d" % (len(bad_raster), raster_worst))
@@ -199,6 +260,6 @@ print("particle floats: %d failures of the suite's criterion (1e-4 relative + 1e
       "%d elements (%.2g of all) are outside a PURE 1e-4 relative bound, i.e. needed the absolute floor" %
       (len(bad_float), elements_compared / 1e6, floor_needed, floor_needed / max(elements_compared, 1)))
 for b in bad_float[:10]: print("   ", b)
-failed = bool(bad_field or bad_raster or bad_light or bad_step or bad_float)
+failed = bool(bad_field or bad_raster or bad_light or bad_step or bad_float or bad_gbuffer)
 print("FUZZ %s" % ("FAILED" if failed else "PASSED"))
 sys.exit(1 if failed else 0)
