@@ -398,6 +398,12 @@ constexpr int kListCapacity = 1024;
 #else
 #define ILM_LIGHT_OCCUPANCY
 #endif
+#ifdef ILM_LIGHT_TRACE     // EXPERIMENT (tools/light_trace_probe.py): per-wave start / end of the last launch (100 MHz clock), tile and XCC / CU / SIMD
+__device__ unsigned long long g_light_trace[4 * 262144];
+extern "C" int ilm_experiment_light_trace(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_light_trace), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
 template <int FMT, bool STATS>
 __global__ __launch_bounds__(256) ILM_LIGHT_OCCUPANCY void sphere_lights_kernel(const LightLaunch a, const LightRec* __restrict__ recs, int tiles_x, int tiles_y, int tile_count) {
     __shared__ uint16_t list[kListCapacity];
@@ -406,6 +412,9 @@ __global__ __launch_bounds__(256) ILM_LIGHT_OCCUPANCY void sphere_lights_kernel(
 
     // The dispatcher places block b on XCD b % 8.  Which tiles an XCD gets decides both its L2 locality and its share of the work
     // (lights are not spread evenly): see light_tile_map() in api.hip for the measurements; identity (tile_map 2) is the default.
+#ifdef ILM_LIGHT_TRACE
+    const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     const int nb = (int)gridDim.x;
     const int per_xcd = nb / 8;
     const int b = (int)blockIdx.x;
@@ -528,6 +537,16 @@ __global__ __launch_bounds__(256) ILM_LIGHT_OCCUPANCY void sphere_lights_kernel(
         }
     }
 
+#ifdef ILM_LIGHT_TRACE
+    if (lane == 0) {
+        const unsigned w = ((unsigned)blockIdx.x * 4u + (unsigned)wave) & 262143u;
+        unsigned hw_id, xcc_id;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
+        g_light_trace[4 * w] = trace_t0; g_light_trace[4 * w + 1] = __builtin_amdgcn_s_memrealtime();
+        g_light_trace[4 * w + 2] = (unsigned long long)tile; g_light_trace[4 * w + 3] = ((unsigned long long)xcc_id << 32) | hw_id;
+    }
+#endif
     if (STATS) {
         // wave reduce, one atomic per wave and counter
         for (int off = 32; off > 0; off >>= 1) {

@@ -9,7 +9,7 @@ mkdir -p "$ROOT/tools/ab/$tag"
 if [ "$tag" = base ]; then make -s -j4; cp ../lib/libilluminant_hip.so "$ROOT/tools/ab/base/"; exit 0; fi
 src=$1; shift
 objs=""
-for o in particles lighting fields output raster api group; do
+for o in particles lighting fields gbuffer output raster api group; do
   if [ "$o.hip" = "$src" ]; then
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function "$@" -c $src -o /tmp/ab_${tag}_$o.o
     objs="$objs /tmp/ab_${tag}_$o.o"
