@@ -388,10 +388,13 @@ ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment
 constexpr int kTile = 16;
 constexpr int kListCapacity = 1024;
 
-// Six waves per SIMD (80 VGPRs, 28 bytes of scratch in the per-pair code): measured r02 against the allocator's own choice (93 VGPRs, five
-// waves) cfg5 11.55 -> 11.21 ms, cfg3 unchanged; seven / eight waves spill inside the trace loop and lose 3-6 % (tools/ab_lib.sh).
+// Seven waves per SIMD (72 VGPRs, 16 bytes of scratch in the per-pair code).  Measured with tools/ab_lib.sh on the final r02 kernel (the
+// table-driven sampler and the per-pair rewrite freed registers since the earlier sweep, when seven and eight waves spilled inside the
+// trace loop and lost 3-6 %): five waves (81 VGPRs, the allocator's own need, no scratch) cfg5 11.93 ms, six (80 VGPRs) 11.26, seven
+// 10.89, eight (64 VGPRs, 48 bytes of scratch) 10.93; cfg3 0.964-0.984 ms whatever the count (its occupancy over time is set by the
+// launch's tail).
 #ifndef ILM_LIGHT_WAVES
-#define ILM_LIGHT_WAVES 6
+#define ILM_LIGHT_WAVES 7
 #endif
 #if ILM_LIGHT_WAVES > 0
 #define ILM_LIGHT_OCCUPANCY __attribute__((amdgpu_waves_per_eu(ILM_LIGHT_WAVES, ILM_LIGHT_WAVES)))
