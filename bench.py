@@ -97,6 +97,7 @@ def parse_args():
     ap.add_argument("--chunks", type=int, default=16, help="uploaded 256^2 chunks per GPU (16 = 1 M particles)")
     ap.add_argument("--chunk-size", type=int, default=256)
     ap.add_argument("--light-frames", type=int, default=5)
+    ap.add_argument("--light-ms", type=float, default=60.0, help="GPU time a timed block of lit frames fills at least (0: exactly --light-frames)")
     ap.add_argument("--no-lighting", action="store_true")
     ap.add_argument("--no-cfg4", action="store_true", help="skip the 8 M-particle (cfg4 per-GPU share) measurement")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the SURVEY 8f measurements (read-back, particle lights, resolve)")
@@ -470,11 +471,18 @@ def main():
             L = build_lighting(H, ctx, scenes, abi, w, h, nl, res, wsize, fmt, ext)
             r = L["renderer"]
             stats = r.RenderLighting(1.0, row_begin, row_end, True)     # instrumented frame: exact SDF sample count
-            r.RenderLighting(1.0, row_begin, row_end, False)
+            # Frames per timed block: at least --light-frames, and enough to fill ~60 ms of GPU time -- a 1 ms frame timed over five
+            # launches sits on the clock ramp (cfg3: 1.00 ms per frame over 4 frames, 0.92 over 40, 0.89 over 400 on the same box)
+            barrier()
+            ctx.TimerStart()
+            for _ in range(2):
+                r.RenderLighting(1.0, row_begin, row_end, False)
+            est_ms = max(ctx.TimerStop() / 2.0, 1e-3)
+            light_frames = int(max_over_ranks(float(min(max(args.light_frames, int(np.ceil(args.light_ms / est_ms))), 120))))
             barrier()
             ctx.TimerStart()
             t0 = time.perf_counter()
-            for _ in range(args.light_frames):
+            for _ in range(light_frames):
                 r.RenderLighting(1.0, row_begin, row_end, False)
                 if glm is not None:
                     glm.gather(native.GATHER_RCCL)               # queued behind the strip on the same stream: no host hand-off
@@ -484,10 +492,10 @@ def main():
             samples = int(stats[0])
             pairs_local, traced_local = int(stats[1]), int(stats[2])
             samples_total = int(sum_over_ranks(samples))
-            frame_ms = lwall / args.light_frames * 1e3
+            frame_ms = lwall / light_frames * 1e3
             my_px = (row_end - row_begin) * w
             alg_bytes = samples * SDF_SAMPLE_BYTES + my_px * 8 + nl * 128   # this rank's launch: SDF samples + ground-plane lightmap write (half4) + light records
-            kern_ms = gms / args.light_frames
+            kern_ms = gms / light_frames
             kname = "ilm::sphere_lights_kernel<%d, false>" % (1 if fmt == abi.SDF_FP16 else 0)
             lt = profiled_traffic(kname) if world == 1 else None
             # the kernel's binding resource is VALU issue, not HBM (the atlas is cache-resident): wave-instructions of the committed PMC
@@ -497,7 +505,7 @@ def main():
             issue = (waves_l * lv["value"] / (kern_ms * 1e-3) / 1e9) if lv else None
             lighting[name] = {
                 "lit_mpixels_per_s": round(w * h / (frame_ms * 1e-3) / 1e6, 2),
-                "ms_per_frame": round(frame_ms, 4),
+                "ms_per_frame": round(frame_ms, 4), "timed_frames": light_frames,
                 "sdf_samples_per_frame": samples_total,
                 "pixel_light_pairs_this_rank": pairs_local, "traced_pairs_this_rank": traced_local,
                 "field_generation": L["field_generation"],

@@ -7,7 +7,7 @@ cd "$(cd "$(dirname "$0")/.." && pwd)"
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc_bound_${1:-x}
 rm -rf "$OUT"; mkdir -p "$OUT"
-CMD="python bench.py --steps 20 --warmup 2 --light-frames 1 --no-cpu-baseline --no-cfg4 --no-next-rows"
+CMD="python bench.py --steps 20 --warmup 2 --light-frames 1 --light-ms 0 --no-cpu-baseline --no-cfg4 --no-next-rows"
 i=0
 while read -r pass; do
   [ -z "$pass" ] && continue

@@ -5,7 +5,7 @@ cd "$(cd "$(dirname "$0")/.." && pwd)"
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc_light_${1:-x}
 rm -rf "$OUT"; mkdir -p "$OUT"
-rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES -d "$OUT/p" -o pmc -- python bench.py --steps 20 --warmup 2 --light-frames 1 --no-cpu-baseline --no-cfg4 --no-next-rows > "$OUT/log" 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES -d "$OUT/p" -o pmc -- python bench.py --steps 20 --warmup 2 --light-frames 1 --light-ms 0 --no-cpu-baseline --no-cfg4 --no-next-rows > "$OUT/log" 2>&1
 python - "$OUT" <<'PY'
 import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))

@@ -9,7 +9,7 @@ cd "$ROOT"
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc_sqc_light_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
-CMD="python bench.py --steps 20 --warmup 5 --blocks 3 --light-frames 2 --no-cpu-baseline --no-cfg4 --no-next-rows"
+CMD="python bench.py --steps 20 --warmup 5 --blocks 3 --light-frames 2 --light-ms 0 --no-cpu-baseline --no-cfg4 --no-next-rows"
 i=0
 for pass in "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE" "SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_DCACHE_MISSES_DUPLICATE" \
             "SQC_TC_REQ SQC_TC_INST_REQ SQC_TC_DATA_READ_REQ SQC_TC_STALL" "SQ_WAVES SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_IFETCH" "SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VALU SQ_INST_CYCLES_SALU SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_BRANCH SQ_INSTS_CBRANCH_TAKEN SQ_INSTS_SENDMSG SQ_INSTS_VSKIPPED SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_LDS"; do

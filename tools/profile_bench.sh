@@ -13,7 +13,7 @@ OUT=gpurun_out/prof_$TAG
 SUM=gpurun_out/profiles_$TAG
 rm -rf "$OUT" "$SUM"; mkdir -p "$OUT" "$SUM"
 BENCH="python bench.py --steps 200 --warmup 20 --no-cpu-baseline"
-SHORT="python bench.py --steps 40 --warmup 5 --light-frames 1 --no-cpu-baseline"
+SHORT="python bench.py --steps 40 --warmup 5 --light-frames 1 --light-ms 0 --no-cpu-baseline"
 
 # un-profiled reference line (never compare a profiled arm with an un-profiled one: the clocks differ)
 $BENCH > "$SUM/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"
