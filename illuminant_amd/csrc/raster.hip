@@ -216,8 +216,29 @@ __global__ __launch_bounds__(256) void raster_tile_ranges_kernel(const RasterLau
 // 8 x 8 quadrants of the tile; a ballot + prefix count per quadrant turns that into four slot-ordered index lists, and wave q then
 // walks only the sprites that can touch its quadrant (for 8 x 8-pixel sprites about a third of the tile's), the next record
 // already in flight while the current one is shaded.
+#ifdef ILM_RASTER_TRACE    // EXPERIMENT (tools/raster_trace_probe.py): per-workgroup start / end of the last launch (100 MHz clock), sprite count, segment
+__device__ unsigned long long g_raster_trace[4 * 131072];
+extern "C" int ilm_experiment_raster_trace(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_raster_trace), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
+// Eight waves per SIMD (64 VGPRs, no scratch once only the next sprite's geometry is prefetched).  Per-workgroup timestamps
+// (-DILM_RASTER_TRACE, tools/raster_trace_probe.py) showed 4.7 workgroups per CU in flight at 78 VGPRs and the pass waiting on LDS /
+// barriers rather than issuing: cfg2's frame 1.155 -> 1.062 ms (tools/ab_raster.sh).  Sprite records through scalar loads straight
+// from global memory instead of the LDS batch: 1.30 ms.
+#ifndef ILM_RASTER_WAVES
+#define ILM_RASTER_WAVES 8
+#endif
+#if ILM_RASTER_WAVES > 0
+#define ILM_RASTER_OCCUPANCY __attribute__((amdgpu_waves_per_eu(ILM_RASTER_WAVES, ILM_RASTER_WAVES)))
+#else
+#define ILM_RASTER_OCCUPANCY
+#endif
 template <int FORMAT>
-__global__ __launch_bounds__(256) void raster_tiles_kernel(const RasterLaunch a) {
+__global__ __launch_bounds__(256) ILM_RASTER_OCCUPANCY void raster_tiles_kernel(const RasterLaunch a) {
+#ifdef ILM_RASTER_TRACE
+    const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     __shared__ Sprite batch[256];
     __shared__ uint8_t list[4][256];
     __shared__ int wave_count[4][4];          // [loader wave][quadrant]
@@ -294,13 +315,25 @@ __global__ __launch_bounds__(256) void raster_tiles_kernel(const RasterLaunch a)
         __syncthreads();
         total = __builtin_amdgcn_readfirstlane(total);
         if (!in_image || total == 0) continue;
-        Sprite next = batch[list[wave][0]];
+        // a record = four 16-byte quads: (cx, cy, ex, ey) (i00, i01, i10, i11) (r, g, b, a) (rounding, frame u, v, dither frame).  The
+        // two geometry quads of the next sprite are in flight while this one is shaded; the other two are fetched only when some lane
+        // of the wave is covered
+        const float4* quads = reinterpret_cast<const float4*>(batch);
+        int cur = (int)list[wave][0];
+        float4 ng0 = quads[4 * cur], ng1 = quads[4 * cur + 1];
         for (int k = 0; k < total; k++) {
-            const Sprite sp = next;
-            next = batch[list[wave][(k + 1 < total) ? k + 1 : k]];      // in flight while sp is shaded
-            const float dx = pcx - sp.cx, dy = pcy - sp.cy;
-            const float u = (sp.i00 * dx) + (sp.i01 * dy), v = (sp.i10 * dx) + (sp.i11 * dy);
-            if (!((u >= -1.0f) && (u < 1.0f) && (v >= -1.0f) && (v < 1.0f)))
+            const float4 g0 = ng0, g1 = ng1;
+            const int here = cur;
+            cur = (int)list[wave][(k + 1 < total) ? k + 1 : k];
+            ng0 = quads[4 * cur]; ng1 = quads[4 * cur + 1];
+            const float dx = pcx - g0.x, dy = pcy - g0.y;
+            const float u = (g1.x * dx) + (g1.y * dy), v = (g1.z * dx) + (g1.w * dy);
+            const bool covered = (u >= -1.0f) && (u < 1.0f) && (v >= -1.0f) && (v < 1.0f);
+            if (__ballot(covered) == 0ull)
+                continue;
+            const float4 c0 = quads[4 * here + 2], c1 = quads[4 * here + 3];
+            struct { float r, g, b, a, rounding, frame_u, frame_v, dither_frame; } sp = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+            if (!covered)
                 continue;
             float alpha = 1.0f;
             if (rounded) {
@@ -354,6 +387,13 @@ __global__ __launch_bounds__(256) void raster_tiles_kernel(const RasterLaunch a)
         for (int off = 32; off > 0; off >>= 1) shaded += __shfl_down(shaded, off);
         if ((lane == 0) && shaded != 0u) atomicAdd(&a.stats[2], (unsigned long long)shaded);
     }
+#ifdef ILM_RASTER_TRACE
+    if (tid == 0) {
+        const unsigned w = item & 131071u;
+        g_raster_trace[4 * w] = trace_t0; g_raster_trace[4 * w + 1] = __builtin_amdgcn_s_memrealtime();
+        g_raster_trace[4 * w + 2] = (unsigned long long)(end - begin); g_raster_trace[4 * w + 3] = ((unsigned long long)segments << 32) | segment;
+    }
+#endif
 }
 
 // crowded tiles: dst = C_j + T_j * dst for the segments j in order
