@@ -123,6 +123,9 @@ def test_handles_are_validated_without_a_device():
     out = abi.Handle(0)
     assert lib.ilm_system_create(abi.Handle(0), C.byref(out)) == abi.ERR_INVALID_HANDLE
     assert lib.ilm_erase(abi.Handle(0), 0) == abi.ERR_INVALID_HANDLE
+    d = abi.GBufferMeshDesc()
+    assert lib.ilm_gbuffer_render_meshes(abi.Handle(0), C.byref(d), None, 0, None, 0, None, 0, None, 0) == abi.ERR_INVALID_HANDLE
+    assert b"G-buffer" in lib.ilm_last_error()
 
 
 @pytest.mark.skipif(native.device_count() > 0, reason="this box has a GPU")
