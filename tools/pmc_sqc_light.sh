@@ -1,6 +1,6 @@
 #!/bin/bash
 # Run ON THE GPU BOX: instruction-cache / scalar-cache counters of the light pass (bench lighting rows).
-#   tools/pmc_sqc.sh <tag> [library dir]      -> gpurun_out/pmc_sqc_light_<tag>.txt
+#   tools/pmc_sqc_light.sh <tag> [library dir]      -> gpurun_out/pmc_sqc_light_<tag>.txt
 set -u
 TAG=${1:-x}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
