@@ -104,6 +104,36 @@ def test_2p5d_scene_matches_oracle(ctx, oracle, fmt, seed):
     gb.close()
 
 
+def test_1080p_frame_of_2500_triangles_matches_oracle(ctx, oracle):
+    """The bench row's size (1920 x 1080, 256 volumes + 64 billboards): more triangles than one binning round holds per tile list
+    refill, tiles crossed by hundreds of records, volumes taller than the field (clipped tops)."""
+    w, h = 1920, 1080
+    _, top, front, bb, kinds = random_scene(21, w, h, n_volumes=256, n_billboards=64, z_to_y=0.6)
+    so, zso = scenes.self_occlusion_hacks(0.25, 128.0, 33)
+    d = scenes.gbuffer_mesh_desc(z_to_y=0.6, extent_z=48.0, self_occlusion_hack=so, z_self_occlusion_hack=zso)
+    texs = textures_for(21, kinds)
+    handles = []
+    for t in texs:
+        if t is None:
+            handles.append(None)
+            continue
+        fm = {np.dtype(np.uint8): abi.LIGHTMAP_RGBA8, np.dtype(np.float16): abi.LIGHTMAP_HALF4, np.dtype(np.float32): abi.LIGHTMAP_FLOAT4}[t.dtype]
+        lm = native.Lightmap(ctx, t.shape[1], t.shape[0], fm)
+        lm.upload(t)
+        handles.append(lm)
+    gb = native.GBufferTexture(ctx, None, abi.GBUFFER_FLOAT4, size=(w, h))
+    gb.render_meshes(d, top, front, bb, [(handles[q], q, 1, kinds[q]) for q in range(len(kinds))])
+    got = gb.download()
+    want = oracle.render_gbuffer_meshes(w, h, d, top, front, bb, [(q, 1, kinds[q]) for q in range(len(kinds))], texs)
+    compare(got, want, abi.GBUFFER_FLOAT4)
+    assert (len(top) + len(front)) // 3 + 2 * len(kinds) > 2000
+    assert (want[..., 2] > 1.0).mean() > 0.08                   # a tenth of the frame is volume surface
+    for x in handles:
+        if x is not None:
+            x.close()
+    gb.close()
+
+
 def test_non_2p5d_meshes_equal_the_polygon_entry_point(ctx, oracle):
     """ilm_gbuffer_render decides top-face coverage per pixel centre against the polygon; the mesh entry point rasterises a
     triangulation of it: same picture wherever no centre sits exactly on an edge (quarter-pixel vertices, unit scale)."""
