@@ -1,0 +1,40 @@
+"""bench.py's bookkeeping without a GPU: the committed PMC summary it quotes is parsed, the traffic figure is the profile's bytes per
+slot-step scaled to the run's units, and the contract's flags exist with defaults that finish within minutes."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_profiled_traffic_comes_from_the_newest_committed_summary():
+    rows, source = bench._newest_pmc_rows()
+    assert source is not None and source.endswith("_pmc.csv") and len(rows) > 10
+    t = bench.profiled_traffic("ilm::step_lean_kernel<true, false>", "ilm::step_lean_kernel<false, false>")
+    assert t is not None and t["lanes"] > 0
+    per = t["bytes"] / t["lanes"]
+    # one lane per slot: the measured HBM bytes per slot-step are the algorithmic 112 B (padding lanes of partial units pull it down a little)
+    assert 100.0 < per < 120.0
+    f = bench.step_traffic_fields(t, 2_000_000)
+    assert f["traffic"] == round(per * 2_000_000) and abs(f["traffic_per_unit"] - per) < 0.01
+    assert f["traffic_profiled"]["slots_per_step"] == round(t["lanes"])
+    assert bench.profiled_traffic("ilm::no_such_kernel") is None
+    assert bench.step_traffic_fields(None, 5) == {"traffic": None}
+
+
+def test_light_kernel_instruction_counts_are_in_the_summary():
+    for k in ("ilm::sphere_lights_kernel<0, false>", "ilm::sphere_lights_kernel<1, false>"):
+        v = bench.profiled_per_wave(k, "SQ_INSTS_VALU")
+        assert v is not None and v["value"] > 1000
+
+
+def test_contract_flags_and_defaults(monkeypatch):
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    a = bench.parse_args()
+    assert (a.gpus, a.steps, a.warmup) == (1, 200, 20)
+    assert a.light_ms == 60.0 and a.light_frames >= 1 and a.cpu_seconds <= 30
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    a = bench.parse_args()
+    assert (a.gpus, a.steps, a.warmup) == (8, 20, 5)
+    assert bench.PARTICLE_BYTES_PER_SLOT == 112 and bench.HBM_PEAK_GBS == 8000.0
