@@ -385,8 +385,13 @@ ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment
     return true;
 }
 
-constexpr int kTile = 16;
-constexpr int kListCapacity = 1024;
+// Tile edge in pixels: 16 = four waves per workgroup (one 8 x 8 quadrant each), 8 = one wave per workgroup (EXPERIMENT, -DILM_LIGHT_TILE=8)
+#ifndef ILM_LIGHT_TILE
+#define ILM_LIGHT_TILE 16
+#endif
+constexpr int kTile = ILM_LIGHT_TILE;
+constexpr int kLightThreads = (kTile / 8) * (kTile / 8) * 64;
+constexpr int kListCapacity = (kTile == 16) ? 1024 : 512;
 
 // Seven waves per SIMD (72 VGPRs, 16 bytes of scratch in the per-pair code).  Measured with tools/ab_lib.sh on the final r02 kernel (the
 // table-driven sampler and the per-pair rewrite freed registers since the earlier sweep, when seven and eight waves spilled inside the
@@ -408,7 +413,7 @@ extern "C" int ilm_experiment_light_trace(unsigned long long* out, int n) {
 }
 #endif
 template <int FMT, bool STATS>
-__global__ __launch_bounds__(256) ILM_LIGHT_OCCUPANCY void sphere_lights_kernel(const LightLaunch a, const LightRec* __restrict__ recs, int tiles_x, int tiles_y, int tile_count) {
+__global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_lights_kernel(const LightLaunch a, const LightRec* __restrict__ recs, int tiles_x, int tiles_y, int tile_count) {
     __shared__ uint16_t list[kListCapacity];
     __shared__ int list_count;
     __shared__ SliceEntry slice_table[kMaxTableSlices];
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(256) ILM_LIGHT_OCCUPANCY void sphere_lights_kernel(
     // the in-volume sampler's per-slice table (hlsl_math.hpp): one entry per virtual slice, visible to the tile's waves after the
     // first barrier of the light loop below
     const int table_n = a.sdf.table_slices;
-    for (int i = (int)threadIdx.x; i < table_n; i += 256) slice_table[i] = make_slice_entry((uint32_t)i, a.df, a.sdf);
+    for (int i = (int)threadIdx.x; i < table_n; i += kLightThreads) slice_table[i] = make_slice_entry((uint32_t)i, a.df, a.sdf);
     const InsideConsts inside = make_inside_consts(a.df, a.sdf);
     const TraceField field = { a.df, a.sdf, inside, (table_n > 0) ? slice_table : nullptr };
     const int tx0 = (tile % tiles_x) * kTile, ty0 = a.row_begin + (tile / tiles_x) * kTile;
@@ -542,7 +547,7 @@ __global__ __launch_bounds__(256) ILM_LIGHT_OCCUPANCY void sphere_lights_kernel(
 
 #ifdef ILM_LIGHT_TRACE
     if (lane == 0) {
-        const unsigned w = ((unsigned)blockIdx.x * 4u + (unsigned)wave) & 262143u;
+        const unsigned w = ((unsigned)blockIdx.x * (unsigned)(kLightThreads / 64) + (unsigned)wave) & 262143u;
         unsigned hw_id, xcc_id;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_id));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_id));
@@ -810,7 +815,7 @@ hipError_t launch_sphere_lights_prepared(const LightLaunch& a, const void* recs,
     const LightRec* r = reinterpret_cast<const LightRec*>(recs);
     const bool stats = a.stats != nullptr;
     const bool fp16 = a.sdf.format == ILM_SDF_FP16;
-    const dim3 grid(blocks), block(256);
+    const dim3 grid(blocks), block(kLightThreads);
 #define ILM_LAUNCH_LIGHTS(F, S) hipLaunchKernelGGL((sphere_lights_kernel<F, S>), grid, block, 0, stream, a, r, tiles_x, tiles_y, tile_count)
     const int variant = (fp16 ? 2 : 0) | (stats ? 1 : 0);
     switch (variant) {
