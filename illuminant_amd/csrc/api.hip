@@ -120,6 +120,14 @@ struct Sdf {
     uint32_t magic = kMagicSdf;
     Ctx* ctx = nullptr;
     uint2* texels = nullptr; int width = 0, height = 0, format = 0;
+    // The cone trace's view of the field (hlsl_math.hpp, SdfView::cells): built from the atlas on demand by ensure_sdf_cells and kept
+    // until the atlas changes (`version` is bumped by every entry point that writes it) or is described by other uniforms (the layout
+    // key).  A field whose device pointer was handed out (ilm_sdf_device_ptr) may change behind the library's back: its cells are
+    // rebuilt before every use.
+    void* cells = nullptr; size_t cells_bytes = 0;
+    uint64_t version = 1, cells_version = 0;
+    int cells_slices = 0, cells_columns = 0, cells_sw = 0, cells_sh = 0;
+    bool escaped = false;
 };
 
 struct GBuffer {
@@ -192,7 +200,10 @@ SdfView make_sdf_view(const Sdf* f, const IlmDistanceFieldUniforms* df) {
     if (df && v.width > 0 && !table_off) {
         const double cols = df->TextureSliceCount.x, rows = df->TextureSliceCount.y, slices = df->TextureSliceCount.w;
         const double isx = df->ConeAndMisc.w, isy = df->StepAndMisc2.w, ex = df->Extent.x, ey = df->Extent.y, ez = df->Extent.z;
-        const double sw = ex / isx, sh = ey / isy;
+        // ConeAndMisc.w is float(VirtualWidth / SliceWidth) (Uniforms.cs:108-109): for a resolution that is not a dyadic ratio the
+        // quotient misses the integer slice size by the float's rounding; the atlas size below decides whether the nearest integer is meant
+        auto nearest = [](double x) { const double r = std::floor(x + 0.5); return (std::fabs(x - r) <= 1e-6 * std::fmax(1.0, r)) ? r : x; };   // (a float's rounding: 6e-8; the box's 1/16-texel margin covers 1e-6 x 8192 texels)
+        const double sw = nearest(ex / isx), sh = nearest(ey / isy);
         auto whole = [](double x) { return std::isfinite(x) && x >= 1.0 && x == std::floor(x); };
         const bool consistent =
             whole(cols) && whole(rows) && whole(slices) && whole(sw) && whole(sh) && slices <= kMaxTableSlices && cols <= 1024 &&
@@ -201,7 +212,11 @@ SdfView make_sdf_view(const Sdf* f, const IlmDistanceFieldUniforms* df) {
             std::fabs((double)df->TextureSliceAndTexelSize.z * ex * cols - 1.0) < 1e-6 && std::fabs((double)df->TextureSliceAndTexelSize.w * ey * rows - 1.0) < 1e-6 &&
             ez > 0 && std::isfinite(ez) && std::isfinite((double)df->ConeAndMisc.y) && df->Packed1.y > 0.0f && std::isfinite((double)df->Packed1.y) &&
             df->Packed1.z > 0.0f && sw >= 4 && sh >= 4;
-        if (consistent) {
+        // the reference's float row index floor(vslice * Packed1.x) must name the atlas row the slice really lies in, for every slice
+        bool rows_agree = consistent;
+        for (int vi = 0; rows_agree && vi < (int)slices; vi++)
+            rows_agree = floorf((float)vi * df->Packed1.x) == (float)((vi / 3) / (int)cols);
+        if (consistent && rows_agree) {
             v.table_slices = (int)slices;
             v.columns = (int)cols;
             const double tx = 0.5625 * isx, ty = 0.5625 * isy;       // half a texel + 1/16, in world units
@@ -237,6 +252,40 @@ const char* field_uniforms_mismatch(const Sdf* f, const IlmDistanceFieldUniforms
     snprintf(text, n, "the distance-field uniforms describe a %.0f x %.0f atlas (%g x %g slices of %g x %g) but the bound field is %d x %d",
              cols * sw, rows * sh, cols, rows, sw, sh, f->width, f->height);
     return text;
+}
+
+// The view the cone trace launches with: make_sdf_view + the field's cell array, (re)built on `stream` when the atlas has changed since
+// the last build or is described by another layout.  Without cells (ILM_SDF_CELLS=0, a field past the 2 GiB the 32-bit cell offsets
+// reach, allocation failure) the view has no table and the trace uses the general sampler -- same results, slower.
+hipError_t make_trace_view(Sdf* f, const IlmDistanceFieldUniforms* df, hipStream_t stream, TraceSdfView* out) {
+    TraceSdfView v;
+    static_cast<SdfView&>(v) = make_sdf_view(f, df);
+    v.cells = nullptr; v.cells_bytes = 0; v.slice_w = 0; v.slice_h = 0;
+    if (v.table_slices > 0) {       // (make_sdf_view has checked that the uniforms tile the atlas in whole slices)
+        v.slice_w = v.width / v.columns;
+        v.slice_h = (int)std::floor((double)df->Extent.y / (double)df->StepAndMisc2.w + 0.5);
+    }
+    *out = v;
+    if (!f || v.table_slices <= 0) return hipSuccess;
+    static const bool cells_off = [] { const char* e = getenv("ILM_SDF_CELLS"); return e && e[0] == '0'; }();     // A/B switch
+    const size_t bytes = (size_t)v.table_slices * (size_t)v.slice_w * (size_t)v.slice_h * 16u;
+    auto no_table = [&]() { out->table_slices = 0; out->box_x0 = out->box_y0 = out->box_z0 = 1.0f; out->box_x1 = out->box_y1 = out->box_z1 = 0.0f; };
+    if (cells_off || bytes >= ((size_t)1 << 31)) { no_table(); return hipSuccess; }
+    const bool same_layout = f->cells && f->cells_slices == v.table_slices && f->cells_columns == v.columns && f->cells_sw == v.slice_w && f->cells_sh == v.slice_h;
+    if (!same_layout || f->escaped || f->cells_version != f->version) {
+        if (bytes > f->cells_bytes) {
+            if (f->cells) { (void)hipStreamSynchronize(stream); (void)hipFree(f->cells); f->cells = nullptr; f->cells_bytes = 0; }
+            if (hipMalloc(&f->cells, bytes) != hipSuccess) { (void)hipGetLastError(); f->cells = nullptr; no_table(); return hipSuccess; }
+            f->cells_bytes = bytes;
+        }
+        const hipError_t e = launch_build_sdf_cells(v, f->cells, stream);
+        if (e != hipSuccess) return e;
+        f->cells_slices = v.table_slices; f->cells_columns = v.columns; f->cells_sw = v.slice_w; f->cells_sh = v.slice_h;
+        f->cells_version = f->version;
+    }
+    out->cells = f->cells;
+    out->cells_bytes = (uint32_t)bytes;
+    return hipSuccess;
 }
 
 // Handles are the object addresses, but an address is only trusted after it has been found in this table: a stale, foreign or
@@ -1436,6 +1485,7 @@ int32_t ilm_sdf_upload(IlmHandle h, const uint16_t* texels) {
     if (!texels) return fail(ILM_ERR_INVALID_ARGUMENT, "texels is NULL");
     HIP_TRY(hipSetDevice(f->ctx->device));
     HIP_TRY(hipMemcpyAsync(f->texels, texels, sizeof(uint2) * (size_t)f->width * (size_t)f->height, hipMemcpyHostToDevice, f->ctx->main()));
+    f->version++;
     HIP_TRY(hipStreamSynchronize(f->ctx->main()));
     return ILM_OK;
 }
@@ -1474,7 +1524,9 @@ int32_t ilm_debug_sdf_sample_inside(IlmHandle h, const IlmDistanceFieldUniforms*
     float* d_out = d_in + 3 * (size_t)count;
     int32_t* d_used = reinterpret_cast<int32_t*>(d_out + (size_t)count);
     HIP_TRY(hipMemcpyAsync(d_in, positions, in_bytes, hipMemcpyHostToDevice, c->main()));
-    HIP_TRY(launch_sdf_sample_inside(make_sdf_view(f, df), *df, d_in, count, d_out, d_used, c->main()));
+    TraceSdfView view;
+    HIP_TRY(make_trace_view(f, df, c->main(), &view));
+    HIP_TRY(launch_sdf_sample_inside(view, *df, d_in, count, d_out, d_used, c->main()));
     HIP_TRY(hipMemcpyAsync(out_distances, d_out, out_bytes, hipMemcpyDeviceToHost, c->main()));
     HIP_TRY(hipMemcpyAsync(out_used_table, d_used, out_bytes, hipMemcpyDeviceToHost, c->main()));
     HIP_TRY(hipStreamSynchronize(c->main()));
@@ -1532,6 +1584,7 @@ int32_t ilm_sdf_destroy(IlmHandle h) {
     (void)hipSetDevice(f->ctx->device);
     (void)hipStreamSynchronize(f->ctx->main());
     if (f->texels) (void)hipFree(f->texels);
+    if (f->cells) (void)hipFree(f->cells);
     retire_handle(f);
     delete f;
     return ILM_OK;
@@ -1551,6 +1604,7 @@ int32_t ilm_sdf_device_ptr(IlmHandle h, void** out_ptr) {
     Sdf* f = from_handle<Sdf>(h, kMagicSdf);
     if (!f || !out_ptr) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle");
     *out_ptr = f->texels;
+    f->escaped = true;      // the caller may write the atlas: the trace's cell array is rebuilt before every use from now on
     return ILM_OK;
 }
 
@@ -1683,6 +1737,7 @@ int32_t ilm_sdf_render_slices(IlmHandle h, IlmHandle hclear, const IlmDistanceFi
     a.virtual_depth = d->VirtualDepth; a.z_offset = d->ZOffset; a.max_encoded = d->MaximumEncodedDistance;
     a.inv_scale_x = d->InvScaleFactorX; a.inv_scale_y = d->InvScaleFactorY;
     HIP_TRY(launch_render_slices(a, f->format, c->main()));
+    f->version++;
     return ILM_OK;
 }
 
@@ -1984,7 +2039,7 @@ int32_t fill_light_launch(Ctx* c, const IlmEnvironment* env, const IlmDistanceFi
     a->env = *env; a->df = *df;
     a->gbuffer.texels = g ? g->texels : nullptr;
     a->gbuffer.width = g ? g->width : 0; a->gbuffer.height = g ? g->height : 0; a->gbuffer.format = g ? g->format : 0;
-    a->sdf = make_sdf_view(f, df);
+    HIP_TRY(make_trace_view(f, df, c->main(), &a->sdf));
     for (int i = 0; i < 4; i++) a->ambient[i] = 0.0f;
     a->lightmap = m->texels; a->width = m->width; a->height = m->height; a->format = m->format;
     a->row_begin = row_begin; a->row_end = row_end;
@@ -2431,6 +2486,8 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
     if (row_begin < 0 || row_end > m->height || row_begin > row_end)
         return fail(ILM_ERR_OUT_OF_RANGE, "rows [%d, %d) outside [0, %d]", row_begin, row_end, m->height);
     HIP_TRY(hipSetDevice(c->device));
+    TraceSdfView trace_view;
+    HIP_TRY(make_trace_view(f, df, c->main(), &trace_view));
 
     if (light_count > c->light_cap) {
         HIP_TRY(hipStreamSynchronize(c->main()));
@@ -2445,7 +2502,7 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
     if (light_count > 0) {
         int32_t rc = upload_small(c, c->d_lights, lights, sizeof(IlmLightVertex) * (size_t)light_count);
         if (rc != ILM_OK) return rc;
-        HIP_TRY(launch_prepare_lights(c->d_lights, light_count, *env, *df, make_sdf_view(f, df), c->d_recs, c->main()));
+        HIP_TRY(launch_prepare_lights(c->d_lights, light_count, *env, *df, trace_view, c->d_recs, c->main()));
     }
 
     LightLaunch a;
@@ -2455,7 +2512,7 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
     a.df = *df;
     a.gbuffer.texels = g ? g->texels : nullptr;
     a.gbuffer.width = g ? g->width : 0; a.gbuffer.height = g ? g->height : 0; a.gbuffer.format = g ? g->format : 0;
-    a.sdf = make_sdf_view(f, df);
+    a.sdf = trace_view;
     for (int i = 0; i < 4; i++) a.ambient[i] = ambient ? ambient[i] : 0.0f;
     a.lightmap = m->texels; a.width = m->width; a.height = m->height; a.format = m->format;
     a.row_begin = row_begin; a.row_end = row_end;

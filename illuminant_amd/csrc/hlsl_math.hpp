@@ -113,6 +113,44 @@ struct SdfView {
     // world-space box inside which a SAMPLE position meets the table sampler's assumptions (InsideBox, make_sdf_view)
     float box_x0, box_x1, box_y0, box_y1, box_z0, box_z1;
 };
+// The cone trace's view: the in-volume sampler reads the field through its CELL array (api.hip make_trace_view, lighting.hip
+// build_sdf_cells_kernel): one 16-byte cell per (virtual slice, texel) holding the four bilinear taps of that texel's sample footprint,
+// each as the channel pair (slice v, slice v + 1) -- the eight values of one trilinear sample side by side.  Without cells
+// table_slices is 0.  (A separate type: the particle step's descriptor carries the plain view and has no room to spare.)
+struct TraceSdfView : SdfView {
+    const void* cells;
+    uint32_t cells_bytes;
+    int slice_w, slice_h;
+};
+
+// The texture path's own UNORM16 -> f32 conversion.  A typed buffer load (buffer_load_format_xy through a resource of DATA_FORMAT 16_16,
+// NUM_FORMAT unorm) returns float(code) / 65535 for both halves of the addressed 4-byte element -- correctly rounded for every one of the
+// 65 536 codes, at 2-byte aligned lane offsets too, at the price of an untyped dword load (tools/ubench/unorm.hip, profiles/
+// r03_typed_unorm16_loads.txt; on parity: tests/test_sdf_sample_gpu.py walks all codes through both samplers).  The channel pair of a tap
+// therefore arrives decoded: no byte permute, no conversions, no x / 65535 (unorm16_to_float below: 4 VALU instructions per channel,
+// 32 per sample).  The resource is uniform (4 SGPRs): raw addressing (stride 0), num_records = the atlas in bytes.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+extern "C" __device__ f32x2 ilm_llvm_buffer_load_format_xy(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.ptr.buffer.load.format.v2f32");
+// word 3 of a gfx9 buffer resource: DST_SEL_X = R (4), DST_SEL_Y = G (5), NUM_FORMAT unorm (0) [14:12], DATA_FORMAT 16_16 (5) [18:15]
+constexpr int kRsrcWord3Unorm16x2 = 4 | (5 << 3) | (0 << 12) | (5 << 15);
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+extern "C" __device__ f32x4 ilm_llvm_buffer_load_format_xyzw(__amdgpu_buffer_rsrc_t rsrc, int voffset, int soffset, int aux) __asm("llvm.amdgcn.raw.ptr.buffer.load.format.v4f32");
+// DST_SEL = R, G, B, A; NUM_FORMAT unorm; DATA_FORMAT 16_16_16_16 (12)
+constexpr int kRsrcWord3Unorm16x4 = 4 | (5 << 3) | (6 << 6) | (7 << 9) | (0 << 12) | (12 << 15);
+// a wave-uniform 64-bit value, said so explicitly (two v_readfirstlane_b32 when it sits in vector registers, nothing when it is scalar already)
+ILM_DEV uint64_t uniform_u64(uint64_t p) {
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)p) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(p >> 32)) << 32);
+}
+ILM_DEV __amdgpu_buffer_rsrc_t sdf_unorm_rsrc(const SdfView& sdf) {
+    // (the view is a kernel argument, i.e. uniform; said explicitly, because behind divergent control flow the backend otherwise
+    // tries to carry the resource through vector registers: "illegal VGPR to SGPR copy")
+    return __builtin_amdgcn_make_buffer_rsrc((void*)uniform_u64((uint64_t)sdf.texels), 0, __builtin_amdgcn_readfirstlane((sdf.width * sdf.height) << 3),
+                                             kRsrcWord3Unorm16x2);
+}
+
+ILM_DEV __amdgpu_buffer_rsrc_t sdf_cells_unorm_rsrc(const TraceSdfView& sdf) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)uniform_u64((uint64_t)sdf.cells), 0, __builtin_amdgcn_readfirstlane((int)sdf.cells_bytes), kRsrcWord3Unorm16x4);
+}
 
 // x / 65535 for an integer-valued x in [0, 65535], correctly rounded: one multiply by fl(1/65535) and one
 // Markstein correction step (two FMAs) instead of the ~10-instruction IEEE division sequence.  Equality with the
@@ -258,14 +296,21 @@ ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms&
     gbyte* base = (gbyte*)sdf.texels;
     asm("" : "+s"(base));
     const uint32_t c0 = ((uint32_t)x0 << 3) + sub, c1 = ((uint32_t)x1 << 3) + sub;
-    const uint32_t w00 = *(gword*)(base + (r0 + c0)), w10 = *(gword*)(base + (r0 + c1));
-    const uint32_t w01 = *(gword*)(base + (r1 + c0)), w11 = *(gword*)(base + (r1 + c1));
-
     float a00, b00, a10, b10, a01, b01, a11, b11;
-    sdf_unpack_word<FORMAT>(w00, a00, b00);
-    sdf_unpack_word<FORMAT>(w10, a10, b10);
-    sdf_unpack_word<FORMAT>(w01, a01, b01);
-    sdf_unpack_word<FORMAT>(w11, a11, b11);
+    if (FORMAT == ILM_SDF_UNORM16) {
+        // typed taps: the texture path decodes the channel pair (see sdf_unorm_rsrc)
+        const __amdgpu_buffer_rsrc_t rsrc = sdf_unorm_rsrc(sdf);
+        const f32x2 t00 = ilm_llvm_buffer_load_format_xy(rsrc, (int)(r0 + c0), 0, 0), t10 = ilm_llvm_buffer_load_format_xy(rsrc, (int)(r0 + c1), 0, 0);
+        const f32x2 t01 = ilm_llvm_buffer_load_format_xy(rsrc, (int)(r1 + c0), 0, 0), t11 = ilm_llvm_buffer_load_format_xy(rsrc, (int)(r1 + c1), 0, 0);
+        a00 = t00.x; b00 = t00.y; a10 = t10.x; b10 = t10.y; a01 = t01.x; b01 = t01.y; a11 = t11.x; b11 = t11.y;
+    } else {
+        const uint32_t w00 = *(gword*)(base + (r0 + c0)), w10 = *(gword*)(base + (r0 + c1));
+        const uint32_t w01 = *(gword*)(base + (r1 + c0)), w11 = *(gword*)(base + (r1 + c1));
+        sdf_unpack_word<FORMAT>(w00, a00, b00);
+        sdf_unpack_word<FORMAT>(w10, a10, b10);
+        sdf_unpack_word<FORMAT>(w01, a01, b01);
+        sdf_unpack_word<FORMAT>(w11, a11, b11);
+    }
     const float lo = lerp_fused(lerp_fused(a00, a10, fx), lerp_fused(a01, a11, fx), fy);
     const float hi = lerp_fused(lerp_fused(b00, b10, fx), lerp_fused(b01, b11, fx), fy);
     const float blended = lerp_fused(lo, hi, slice_position - vslice);
@@ -278,18 +323,22 @@ ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms&
 // of the general sampler's instructions only find WHERE the four taps are.  Inside the box of SdfView (every tap of the sample lies in
 // the interior of one slice: no clamp, no U WRAP crossing, no V CLAMP, the right-hand tap is the next texel, the lower tap the next
 // row) everything that depends on the virtual slice number alone comes from a 16-byte table entry in LDS, built once per workgroup:
-//     column index (float), row index (the reference's float form), byte-permute selector of the channel pair, fold offset.
+//     column index (float), row index (the reference's float form), and the offset of the slice's grid in the CELL array.
 // The FLOAT path that decides the taps and the weights is the oracle's, operation for operation (z - zOffset, * sliceCount / extentZ,
 // floor, the two fma of u / v, the two fma to texel space, floor, the three fractions), so taps, weights and result are bit-identical
 // to sample_distance_field's; the INTEGER path is: two float -> int conversions, one shift-add, one 24-bit multiply-add.
-// One 16-byte load per tap row (both taps' texels; 8-byte aligned, never split: tools/ubench/gather) + a byte permute per tap.
+// The taps themselves come from the cell array (SdfView::cells; r03): the atlas keeps the reference's packing, where the eight values of
+// a trilinear sample sit in four texels of two rows (two 16-byte loads + a byte permute per tap: the texture path's data return was
+// 78 % busy on cfg3, its address path 56 %); the cell array holds them side by side, so an fp16 sample is ONE 16-byte load with the
+// f16 pairs already in place, a unorm16 sample two 8-byte typed loads whose channels arrive decoded (see sdf_unorm_rsrc).
 // ---------------------------------------------------------------------------------------------
 constexpr int kMaxTableSlices = 256;
 struct __attribute__((aligned(16))) SliceEntry {
     float column_index;   // floor(vslice / 3) as float
     float row_index;      // floor(vslice * DistanceFieldPacked1.x): the reference's float form
-    uint32_t selector;    // v_perm_b32 selector of bytes 2m .. 2m+3 of the 8-byte texel, m = vslice % 3
-    uint32_t fold8;       // 8 * atlas width * (physical slice / columns): what U WRAP subtracts from the tap column, in bytes
+    uint32_t cell_off;    // byte offset (mod 2^32) that takes (atlas row y0, unfolded atlas column x0) of a tap to the slice's cell:
+                          // cell address = y0 * cell_pitch + 16 * x0 + cell_off
+    uint32_t pad;
 };
 
 // uniform values of the in-volume sampler (SGPRs)
@@ -297,29 +346,33 @@ struct InsideConsts {
     float z_offset, slice_scale;                    // DistanceFieldZOffset, sliceCount / extentZ
     float tsx, tsy, tsz, tsw;                       // TextureSliceAndTexelSize
     float wf, hf;                                   // atlas size
-    uint32_t pitch;                                 // atlas row pitch in bytes
+    uint32_t pitch;                                 // row pitch of the cell array in bytes (16 * slice width)
     float max_distance;                             // Extent.w
 };
 
-ILM_DEV InsideConsts make_inside_consts(const IlmDistanceFieldUniforms& df, const SdfView& sdf) {
+ILM_DEV InsideConsts make_inside_consts(const IlmDistanceFieldUniforms& df, const TraceSdfView& sdf) {
     InsideConsts c;
     c.z_offset = df.ConeAndMisc.y; c.slice_scale = df.Packed1.y;
     c.tsx = df.TextureSliceAndTexelSize.x; c.tsy = df.TextureSliceAndTexelSize.y; c.tsz = df.TextureSliceAndTexelSize.z; c.tsw = df.TextureSliceAndTexelSize.w;
     c.wf = sdf.wf; c.hf = sdf.hf;
-    c.pitch = (uint32_t)sdf.width << 3;
+    c.pitch = (uint32_t)sdf.slice_w << 4;
     c.max_distance = df.Extent.w;
     return c;
 }
 
 // entry `vi` of the table (any thread of the workgroup; the caller synchronises)
-ILM_DEV SliceEntry make_slice_entry(uint32_t vi, const IlmDistanceFieldUniforms& df, const SdfView& sdf) {
+ILM_DEV SliceEntry make_slice_entry(uint32_t vi, const IlmDistanceFieldUniforms& df, const TraceSdfView& sdf) {
 #pragma clang fp contract(off)
     SliceEntry e;
     const uint32_t third = vi / 3u, m = vi - 3u * third;
     e.column_index = (float)third;
     e.row_index = floorf((float)vi * df.Packed1.x);
-    e.selector = 0x03020100u + 0x02020202u * m;
-    e.fold8 = ((uint32_t)sdf.width << 3) * (third / (uint32_t)sdf.columns);
+    // Slice vi's cells form a slice_w x slice_h grid at cell index vi * slice_h * slice_w.  A tap's float path yields the atlas row
+    // y0 = row * slice_h + local y (row = physical slice / columns) and the UNFOLDED atlas column x0 = third * slice_w + local x
+    // (column_index = third, not third % columns: the U WRAP the table sampler used to fold is simply never applied).
+    const uint32_t row = third / (uint32_t)sdf.columns, sw = (uint32_t)sdf.slice_w, sh = (uint32_t)sdf.slice_h;
+    e.cell_off = 16u * sw * (sh * (vi - row) - third);
+    e.pad = m;
     return e;
 }
 
@@ -332,7 +385,7 @@ ILM_DEV float mix_fma_hi(float t, float d, uint32_t a) { float r; asm("v_fma_mix
 
 // Precondition (the caller's, per sample): position inside SdfView's box.  `table` = the workgroup's LDS table.
 template <int FORMAT>
-ILM_DEV float sample_inside_table(f3 position, const InsideConsts& c, const SdfView& sdf, const SliceEntry* table) {
+ILM_DEV float sample_inside_table(f3 position, const InsideConsts& c, const TraceSdfView& sdf, const SliceEntry* table) {
 #pragma clang fp contract(off)
     const float pz = position.z - c.z_offset;
     const float slice_position = pz * c.slice_scale;          // min(clamp(z), validZ) is the identity inside the box
@@ -344,32 +397,26 @@ ILM_DEV float sample_inside_table(f3 position, const InsideConsts& c, const SdfV
     const float y = __builtin_fmaf(v, c.hf, -0.5f);
     const float x0f = floorf(x), y0f = floorf(y);
     const float fx = x - x0f, fy = y - y0f, fz = slice_position - vslice;
-    // tap (x0, y0) of the atlas: column x0f - fold * width (U WRAP, decided by the slice alone inside the box), row y0f (no clamp)
-    const uint32_t column8 = ((uint32_t)(int)x0f << 3) - e.fold8;
+    // the sample's cell: row y0f, unfolded column x0f of the atlas (no clamp, no wrap inside the box), moved to the slice's grid
+    const uint32_t column16 = ((uint32_t)(int)x0f << 4) + e.cell_off;
     uint32_t offset;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(offset) : "v"((uint32_t)(int)y0f), "s"(c.pitch), "v"(column8));
-    typedef const char __attribute__((address_space(1))) gbyte;
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    typedef const u32x4 __attribute__((address_space(1), aligned(8))) gtexel2;
-    gbyte* row0 = (gbyte*)sdf.texels;
-    gbyte* row1 = row0 + c.pitch;                     // uniform: the lower tap row is the same lane offset on a second SGPR base
-    asm("" : "+s"(row0));
-    asm("" : "+s"(row1));
-    const u32x4 t0 = *(gtexel2*)(row0 + offset), t1 = *(gtexel2*)(row1 + offset);
-    const uint32_t w00 = __builtin_amdgcn_perm(t0.y, t0.x, e.selector), w10 = __builtin_amdgcn_perm(t0.w, t0.z, e.selector);
-    const uint32_t w01 = __builtin_amdgcn_perm(t1.y, t1.x, e.selector), w11 = __builtin_amdgcn_perm(t1.w, t1.z, e.selector);
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(offset) : "v"((uint32_t)(int)y0f), "s"(c.pitch), "v"(column16));
     float lo0, lo1, hi0, hi1;
     if (FORMAT == ILM_SDF_FP16) {
-        lo0 = mix_fma_lo(fx, mix_sub_lo(w10, w00), w00); hi0 = mix_fma_hi(fx, mix_sub_hi(w10, w00), w00);
-        lo1 = mix_fma_lo(fx, mix_sub_lo(w11, w01), w01); hi1 = mix_fma_hi(fx, mix_sub_hi(w11, w01), w01);
+        // ONE 16-byte load: (w00, w10, w01, w11), each word the f16 pair (slice v, slice v + 1) of a tap
+        typedef const char __attribute__((address_space(1))) gbyte;
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef const u32x4 __attribute__((address_space(1), aligned(16))) gcell;
+        gbyte* base = (gbyte*)uniform_u64((uint64_t)sdf.cells);
+        const u32x4 t = *(gcell*)(base + offset);
+        lo0 = mix_fma_lo(fx, mix_sub_lo(t.y, t.x), t.x); hi0 = mix_fma_hi(fx, mix_sub_hi(t.y, t.x), t.x);
+        lo1 = mix_fma_lo(fx, mix_sub_lo(t.w, t.z), t.z); hi1 = mix_fma_hi(fx, mix_sub_hi(t.w, t.z), t.z);
     } else {
-        float a00, b00, a10, b10, a01, b01, a11, b11;
-        sdf_unpack_word<FORMAT>(w00, a00, b00);
-        sdf_unpack_word<FORMAT>(w10, a10, b10);
-        sdf_unpack_word<FORMAT>(w01, a01, b01);
-        sdf_unpack_word<FORMAT>(w11, a11, b11);
-        lo0 = lerp_fused(a00, a10, fx); hi0 = lerp_fused(b00, b10, fx);
-        lo1 = lerp_fused(a01, a11, fx); hi1 = lerp_fused(b01, b11, fx);
+        // two typed loads (16_16_16_16 unorm): the upper tap row (a00, b00, a10, b10) and the lower one, decoded by the texture path
+        const __amdgpu_buffer_rsrc_t rsrc = sdf_cells_unorm_rsrc(sdf);
+        const f32x4 t0 = ilm_llvm_buffer_load_format_xyzw(rsrc, (int)offset, 0, 0), t1 = ilm_llvm_buffer_load_format_xyzw(rsrc, (int)offset + 8, 0, 0);
+        lo0 = lerp_fused(t0.x, t0.z, fx); hi0 = lerp_fused(t0.y, t0.w, fx);
+        lo1 = lerp_fused(t1.x, t1.z, fx); hi1 = lerp_fused(t1.y, t1.w, fx);
     }
     const float lo = lerp_fused(lo0, lo1, fy), hi = lerp_fused(hi0, hi1, fy);
     const float blended = lerp_fused(lo, hi, fz);

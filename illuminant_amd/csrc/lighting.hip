@@ -207,7 +207,7 @@ struct LightStats { unsigned long long samples = 0, pairs = 0, traced = 0; };
 // workgroup's slice table in LDS (table == nullptr: no in-volume loop -- light probes, fields the table cannot describe)
 struct TraceField {
     const IlmDistanceFieldUniforms& df;
-    const SdfView& sdf;
+    const TraceSdfView& sdf;
     const InsideConsts& inside;
     const SliceEntry* table;
 };
@@ -703,8 +703,11 @@ __global__ __launch_bounds__(64) void light_probes_kernel(const LightRec* __rest
     const bool have_sdf = (sdf.texels != nullptr) && (df.Extent.x > 0.0f);
     float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f, acc_a = 0.0f;
     LightStats st;
-    const InsideConsts inside = make_inside_consts(df, sdf);
-    const TraceField field = { df, sdf, inside, nullptr };       // probes are few: the general sampler
+    TraceSdfView trace_sdf;                                       // probes are few: the general sampler, no cell array
+    static_cast<SdfView&>(trace_sdf) = sdf;
+    trace_sdf.cells = nullptr; trace_sdf.cells_bytes = 0; trace_sdf.slice_w = 0; trace_sdf.slice_h = 0;
+    const InsideConsts inside = make_inside_consts(df, trace_sdf);
+    const TraceField field = { df, trace_sdf, inside, nullptr };
     for (int k = 0; k < light_count; k++) {
         LightRec L = recs[k];
         if (!(valid && probe_opacity > 0.0f))
@@ -751,7 +754,7 @@ __global__ __launch_bounds__(256) void sdf_sample_kernel(SdfView sdf, IlmDistanc
 // the cone trace's in-volume sampler on caller-supplied positions (diagnostic entry point ilm_debug_sdf_sample_inside): positions inside
 // the sampler's box go through sample_inside_table exactly as the trace loop calls it (used = 1), the others through the general sampler
 template <int FMT>
-__global__ __launch_bounds__(256) void sdf_sample_inside_kernel(SdfView sdf, IlmDistanceFieldUniforms df, const float* __restrict__ positions, int count,
+__global__ __launch_bounds__(256) void sdf_sample_inside_kernel(TraceSdfView sdf, IlmDistanceFieldUniforms df, const float* __restrict__ positions, int count,
                                                                  float* __restrict__ out, int32_t* __restrict__ used) {
     __shared__ SliceEntry slice_table[kMaxTableSlices];
     for (int i = (int)threadIdx.x; i < sdf.table_slices; i += 256) slice_table[i] = make_slice_entry((uint32_t)i, df, sdf);
@@ -763,15 +766,49 @@ __global__ __launch_bounds__(256) void sdf_sample_inside_kernel(SdfView sdf, Ilm
     const bool in_box = (sdf.table_slices > 0) & (p.x >= sdf.box_x0) & (p.x <= sdf.box_x1) & (p.y >= sdf.box_y0) & (p.y <= sdf.box_y1) &
                         (p.z >= sdf.box_z0) & (p.z <= sdf.box_z1);
     used[i] = in_box ? 1 : 0;
-    out[i] = in_box ? sample_inside_table<FMT>(p, inside, sdf, slice_table) : sample_distance_field<FMT>(p, df, sdf);
+    // positions outside the box keep the general sampler's value, which launch_sdf_sample_inside has already written to out[] (both
+    // samplers in one kernel make the backend carry the typed loads' scalar operands through a divergent phi: "illegal VGPR to SGPR copy")
+    // No divergent branch around the sampler either (its uniform operands -- tap row bases, the typed loads' resource -- are pinned to
+    // scalar registers): lanes outside the box sample the box's centre and drop the result.
+    const f3 q = in_box ? p : mk3(0.5f * (sdf.box_x0 + sdf.box_x1), 0.5f * (sdf.box_y0 + sdf.box_y1), 0.5f * (sdf.box_z0 + sdf.box_z1));
+    const float value = (sdf.table_slices > 0) ? sample_inside_table<FMT>(q, inside, sdf, slice_table) : 0.0f;
+    if (in_box) out[i] = value;
 }
 
-hipError_t launch_sdf_sample_inside(const SdfView& sdf, const IlmDistanceFieldUniforms& df, const float* positions, int count, float* out, int32_t* used,
+hipError_t launch_sdf_sample_inside(const TraceSdfView& sdf, const IlmDistanceFieldUniforms& df, const float* positions, int count, float* out, int32_t* used,
                                     hipStream_t stream) {
     if (count <= 0) return hipSuccess;
     const dim3 grid((unsigned)((count + 255) / 256)), block(256);
+    const hipError_t general = launch_sdf_sample(sdf, df, positions, count, out, stream);
+    if (general != hipSuccess) return general;
     if (sdf.format == ILM_SDF_FP16) hipLaunchKernelGGL(sdf_sample_inside_kernel<ILM_SDF_FP16>, grid, block, 0, stream, sdf, df, positions, count, out, used);
     else hipLaunchKernelGGL(sdf_sample_inside_kernel<ILM_SDF_UNORM16>, grid, block, 0, stream, sdf, df, positions, count, out, used);
+    return hipGetLastError();
+}
+
+// The cell array of a field (SdfView::cells): cell (v, y, x) = the four taps (x, y), (x + 1, y), (x, y + 1), (x + 1, y + 1) of virtual
+// slice v's grid, each as the 32-bit channel pair (slice v, slice v + 1) -- exactly the words sample_distance_field's taps would fetch
+// from the atlas for a sample whose floor coordinates are (x, y) in that slice (sdf_pair_word).  The last column / row of a slice
+// repeat their neighbour (never sampled: the table sampler's box keeps every tap inside the slice).  One thread per cell, 16-byte stores.
+__global__ __launch_bounds__(256) void build_sdf_cells_kernel(const uint2* __restrict__ atlas, int atlas_w, int slice_w, int slice_h, int columns, int slices,
+                                                               uint4* __restrict__ cells) {
+    const int x = (int)blockIdx.x * 256 + (int)threadIdx.x, y = (int)blockIdx.y, v = (int)blockIdx.z;
+    if (x >= slice_w) return;
+    const uint32_t third = (uint32_t)v / 3u, m = (uint32_t)v - 3u * third;
+    const int col = (int)(third % (uint32_t)columns), row = (int)(third / (uint32_t)columns);
+    const int ax0 = col * slice_w + x, ax1 = col * slice_w + min(x + 1, slice_w - 1);
+    const size_t r0 = (size_t)(row * slice_h + y) * (size_t)atlas_w, r1 = (size_t)(row * slice_h + min(y + 1, slice_h - 1)) * (size_t)atlas_w;
+    uint4 c;
+    c.x = sdf_pair_word(atlas[r0 + ax0], m); c.y = sdf_pair_word(atlas[r0 + ax1], m);
+    c.z = sdf_pair_word(atlas[r1 + ax0], m); c.w = sdf_pair_word(atlas[r1 + ax1], m);
+    cells[((size_t)v * (size_t)slice_h + (size_t)y) * (size_t)slice_w + (size_t)x] = c;
+}
+
+hipError_t launch_build_sdf_cells(const TraceSdfView& sdf, void* cells, hipStream_t stream) {
+    if (sdf.table_slices <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((sdf.slice_w + 255) / 256), (unsigned)sdf.slice_h, (unsigned)sdf.table_slices), block(256);
+    hipLaunchKernelGGL(build_sdf_cells_kernel, grid, block, 0, stream, sdf.texels, sdf.width, sdf.slice_w, sdf.slice_h, sdf.columns, sdf.table_slices,
+                       reinterpret_cast<uint4*>(cells));
     return hipGetLastError();
 }
 
