@@ -36,6 +36,12 @@ PARTICLE_BYTES_PER_SLOT = 112   # 48 B read (pos+life, vel+cat, attri
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 2.0 / 1e9      # G wave-instructions / s
 VALU_ISSUE_CALIBRATED = 858.0
 SDF_SAMPLE_BYTES = 32           # one sampleDistanceFieldEx = 4 bilinear taps x 8 B RGBA16
+# Work-based bound of the cone trace: VALU instructions one coneTraceStep + sampleDistanceFieldEx needs per SAMPLE.  The yardstick is
+# r02's loop (60; VERDICT r02 fixed it so that the fraction is comparable across rounds); the loop the shipped kernel runs is listed
+# beside it (lighting.hip cone_trace_loop<FAST>: 56 for fp16 fields, 52 for unorm16 ones since the cell array of r03).
+TRACE_INSTRUCTIONS_PER_SAMPLE = 60
+TRACE_LOOP_INSTRUCTIONS = {"fp16": 56, "unorm16": 52}
+INFINITY_CACHE_MB = 256
 
 
 def _newest_pmc_rows():
@@ -98,6 +104,8 @@ def parse_args():
     ap.add_argument("--chunk-size", type=int, default=256)
     ap.add_argument("--light-frames", type=int, default=5)
     ap.add_argument("--light-ms", type=float, default=60.0, help="GPU time a timed block of lit frames fills at least (0: exactly --light-frames)")
+    ap.add_argument("--sustain-s", type=float, default=5.5, help="GPU time the timed block of cfg5 frames fills at least (the longest GPU phase of the run: "
+                                                                 "a 5 s device-utilisation sampler sees it); 0: as --light-ms")
     ap.add_argument("--no-lighting", action="store_true")
     ap.add_argument("--no-cfg4", action="store_true", help="skip the 8 M-particle (cfg4 per-GPU share) measurement")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the SURVEY 8f measurements (read-back, particle lights, resolve)")
@@ -376,6 +384,10 @@ def main():
                          "roofline_frac_max": round(max(b["gbs"] for b in blocks) / HBM_PEAK_GBS, 4)},
         "roofline": {"bound": "hbm", "achieved": round(achieved_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved_gbs / HBM_PEAK_GBS, 4),
+                     # cfg2's state (80 B x slots of every chunk) is smaller than the 256 MiB Infinity Cache: this rate is L3 service, priced
+                     # against the HBM peak because that is the contract's roofline; the HBM-resident figure is `roofline_hbm_resident`
+                     # (cfg4's per-GPU share) and the knee is on file in profiles/r03_step_working_set_sweep.txt
+                     "resident": "infinity-cache (%.0f MB of particle state < %d MiB)" % (len(ps.Chunks) * args.chunk_size * args.chunk_size * 80 / 1e6, INFINITY_CACHE_MB),
                      **step_traffic_fields(step_traffic, live_avg),
                      "kernel": "ilm::step_lean_kernel<spawning> + <no spawn> (one ParticleSystem.Update = two launches: the chunk range halved over the context's two streams)",
                      "bytes_per_unit": PARTICLE_BYTES_PER_SLOT, "units_per_launch": round(live_avg, 1),
@@ -478,7 +490,8 @@ def main():
             for _ in range(2):
                 r.RenderLighting(1.0, row_begin, row_end, False)
             est_ms = max(ctx.TimerStop() / 2.0, 1e-3)
-            light_frames = int(max_over_ranks(float(min(max(args.light_frames, int(np.ceil(args.light_ms / est_ms))), 120))))
+            fill_ms = max(args.light_ms, args.sustain_s * 1e3) if (name.startswith("cfg5") and args.light_ms > 0) else args.light_ms
+            light_frames = int(max_over_ranks(float(min(max(args.light_frames, int(np.ceil(fill_ms / est_ms))), 1200))))
             barrier()
             ctx.TimerStart()
             t0 = time.perf_counter()
@@ -519,6 +532,14 @@ def main():
                              "valu_instructions_per_sdf_sample": round(waves_l * lv["value"] * 64 / max(samples, 1), 1) if lv else None,
                              "counter": ("profiles/%s: SQ_INSTS_VALU / SQ_WAVES" % lv["source"]) if lv else None,
                              "traffic": round(lt["bytes"]) if lt else None, "launch_ms": round(kern_ms, 4)},
+                # Issue-slot occupancy above counts whatever the kernel executes.  The WORK-based figure: S samples x the instructions a
+                # sample needs / 64 lanes, over the launch time, against the same nominal issue rate -- what fraction of the chip's
+                # vector issue went into necessary trace work (idle lanes, per-pair code and the launch tail all lower it).
+                "work_bound": {"bound": "valu", "unit": "G wave-instr/s", "peak": round(VALU_ISSUE_PEAK, 1),
+                               "instructions_per_sample": TRACE_INSTRUCTIONS_PER_SAMPLE,
+                               "useful_frac": round(samples * TRACE_INSTRUCTIONS_PER_SAMPLE / 64.0 / (kern_ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK, 4),
+                               "loop_instructions_per_sample_shipped": TRACE_LOOP_INSTRUCTIONS["fp16" if fmt == abi.SDF_FP16 else "unorm16"],
+                               "useful_frac_shipped_loop": round(samples * TRACE_LOOP_INSTRUCTIONS["fp16" if fmt == abi.SDF_FP16 else "unorm16"] / 64.0 / (kern_ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK, 4)},
                 # SURVEY 8d's figure for this path -- S samples x 32 B + pixels x 8 B + lights x 128 B over the launch time.  It prices
                 # cache-served tap bytes, so it is a sample rate: reported, without a fraction of the HBM peak (it exceeds it on cfg5).
                 "algorithmic_rate": {"value": round(alg_bytes / (kern_ms * 1e-3) / 1e9, 1), "unit": "GB/s", "bytes_per_unit": SDF_SAMPLE_BYTES,
@@ -600,7 +621,11 @@ def main():
         out["lighting"] = lighting
         out["lit_mpixels_per_s"] = lighting["cfg5_4k_256_lights_fp16"]["lit_mpixels_per_s"]
         # the second hot path's roofline next to the first one's, where the driver's `parsed` sees it
-        out["roofline_lighting"] = dict(lighting["cfg5_4k_256_lights_fp16"]["roofline"], workload="cfg5: 4K, 256 lights, fp16 samples")
+        l5 = lighting["cfg5_4k_256_lights_fp16"]
+        out["roofline_lighting"] = {"workload": "cfg5: 4K, 256 lights, fp16 samples", "bound": "valu", "achieved": l5["roofline"]["achieved"], "peak": l5["roofline"]["peak"],
+                                    "unit": "G wave-instr/s", "frac": l5["roofline"]["frac"], "useful_frac": l5["work_bound"]["useful_frac"],
+                                    "instructions_per_sample": TRACE_INSTRUCTIONS_PER_SAMPLE, "launch_ms": l5["roofline"]["launch_ms"],
+                                    "timed_frames": l5["timed_frames"], "sdf_samples_per_frame": l5["sdf_samples_per_frame"], "traffic": l5["roofline"]["traffic"]}
 
         if not args.no_next_rows and world == 1:
             # particle lights: 4 096 live particles of a 64^2 chunk lighting a 1080p frame through cfg3's field
@@ -721,6 +746,38 @@ def main():
         out["cpu_baseline"] = {"value": round(live_slots * steps_done / el / 1e6, 2), "unit": "Mparticle-steps/s",   # spawned particles not counted here (< 1 % over the sample)
                                "cores": orc.num_threads(), "kind": "port",
                                "sample": "%d steps of the same cfg2 system (oracle/ilm_oracle.c, OpenMP, %.1f s)" % (steps_done, el)}
+
+    # Why the CPU baseline is the oracle ("port") and not the reference on D3D WARP: probed, not assumed.
+    import platform
+    import shutil
+    probe = {"os": platform.system(), "tools_on_path": {t: bool(shutil.which(t)) for t in ("dotnet", "mono", "msbuild", "csc", "fxc", "dxc", "wine")}}
+    probe["warp_available"] = bool(probe["os"] == "Windows" and probe["tools_on_path"]["dotnet"])
+    probe["note"] = ("D3D WARP is a Windows component and the reference needs .NET + fxc + Fracture + FNA; none of it is on this box, "
+                     "so cpu_baseline.kind is \"port\" (oracle/, OpenMP)") if not probe["warp_available"] else "WARP could run here; the reference itself is still not shippable to the box"
+    out["warp_probe"] = probe
+
+    # The driver keeps the parsed keys and the LAST ~2000 characters of the line: the bulky rows go first, the two rooflines, the CPU
+    # baseline and a compact summary of both hot paths last.
+    tail_keys = ["cpu_baseline", "roofline", "roofline_hbm_resident", "roofline_lighting", "lit_mpixels_per_s", "summary"]
+    c4 = out.get("cfg4_share_8m_particles")
+    if c4:
+        out["roofline_hbm_resident"] = dict(c4["roofline"], workload="cfg4 per-GPU share: 8 chunks of 1024^2 = 8.4 M particles, 0.67 GB of state (> Infinity Cache)",
+                                            ms_per_step=c4["ms_per_step"], mparticle_steps_per_s=c4["mparticle_steps_per_s"])
+    summary = {"particles_cfg2": {"mparticle_steps_per_s": out["value"], "us_per_step": round(step_ms_gpu * 1e3, 2), "frac_of_hbm_peak": out["roofline"]["frac"],
+                                  "resident": "infinity-cache"}}
+    if c4:
+        summary["particles_cfg4_share"] = {"mparticle_steps_per_s": c4["mparticle_steps_per_s"], "us_per_step": round(c4["roofline"]["launch_ms"] * 1e3, 1),
+                                           "frac_of_hbm_peak": c4["roofline"]["frac"], "resident": "hbm"}
+    for key, short in (("cfg3_1080p_64_lights_unorm16", "lighting_cfg3"), ("cfg5_4k_256_lights_fp16", "lighting_cfg5")):
+        row = out.get("lighting", {}).get(key)
+        if row:
+            summary[short] = {"ms_per_frame": row["roofline"]["launch_ms"], "timed_frames": row["timed_frames"], "lit_mpixels_per_s": row["lit_mpixels_per_s"],
+                              "valu_issue_frac": row["roofline"]["frac"], "useful_frac_60_per_sample": row["work_bound"]["useful_frac"],
+                              "gsamples_per_s": row["algorithmic_rate"]["gsamples_per_s"]}
+    out["summary"] = summary
+    for k in tail_keys:
+        if k in out:
+            out[k] = out.pop(k)
 
     sys.stdout.flush()
     os.dup2(stdout_fd, 1)

@@ -2,6 +2,7 @@
 // Owns device memory behind opaque handles; validates arguments the way the
 // reference's host code does (same limits, same failure conditions) and turns
 // them into return codes that the C# wrapper rethrows as exceptions.
+#include <atomic>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -627,7 +628,9 @@ static uint32_t bezier_code(const IlmFloat4& rc) {
     return cls | (range << 2) | (neg << 4) | (shaping << 5);
 }
 
-static int g_step_streams = -1;       // -1: not decided yet (ILM_STEP_STREAMS), else 1 or 2
+// (process-wide diagnostic switch; atomic because two host threads may each step a context of their own.  A CONTEXT itself is
+// single-threaded: Ctx::main()'s stream hand-over state is not synchronised -- one thread per context at a time, include/illuminant_hip.h)
+static std::atomic<int> g_step_streams{-1};       // -1: not decided yet (ILM_STEP_STREAMS), else 1 or 2
 static int step_streams() {
     if (g_step_streams < 0) {
         const char* v = getenv("ILM_STEP_STREAMS");

@@ -231,13 +231,16 @@ __global__ __launch_bounds__(256) void gbuffer_meshes_kernel(const GBufferMeshLa
             const double area = (double)(w0 + w1 + w2);
             const float f1 = (float)((double)w1 / area), f2 = (float)((double)w2 / area);
             auto at = [&](int k) { return (p.a[0][k] + (p.a[1][k] - p.a[0][k]) * f1) + (p.a[2][k] - p.a[0][k]) * f2; };
-            const float z = at(7);
-            if (!((z >= 0.0f) && (z <= 1.0f)))                       // clipped against the near / far plane (w = 1)
+            // Clip against the near / far plane (w = 1).  Volumes only: a billboard's POSITION0 is a Vector2 (Vertices.cs:89), so
+            // BillboardVertexShader's result.z = position.z / DistanceFieldExtent.z is 0 and never clipped -- and attribute 7 of a
+            // billboard is TexCoord.y, which may leave [0, 1] (atlas sub-rectangles with a margin; the sampler clamps)
+            const int kind = p.kind;
+            const float z = ((kind == kMask) || (kind == kGData)) ? 0.0f : at(7);
+            if (!((z >= 0.0f) && (z <= 1.0f)))
                 continue;
             const f3 wp = mk3(at(0), at(1), at(2));
             const f3 n = mk3(at(3), at(4), at(5));
             float4 out;
-            const int kind = p.kind;
             if (kind == kGround) {                                   // GroundPlanePixelShader, GBuffer.fx:57-70
                 if (wp.z < d.GroundZ) continue;
                 out = encode_sample(mk3(0.0f, 0.0f, 1.0f), 0.0f, wp.z, at(8) != 0.0f, at(6) > 0.5f);

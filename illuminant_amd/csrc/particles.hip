@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <atomic>
 #include "internal.hpp"
 #include "distance_functions.hpp"
 #include "bezier.hpp"
@@ -1583,7 +1584,7 @@ static hipError_t launch_step_variant(const StepLaunch& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-static int g_step_interpreter = -1;      // -1: not decided yet (ILM_STEP_LEAN), 0: lean kernel where it applies, 1: interpreter always
+static std::atomic<int> g_step_interpreter{-1};      // (atomic: a process-wide switch read by every stepping thread)  -1: not decided yet (ILM_STEP_LEAN), 0: lean kernel where it applies, 1: interpreter always
 static bool step_interpreter_forced() {
     if (g_step_interpreter < 0) {
         const char* e = getenv("ILM_STEP_LEAN");

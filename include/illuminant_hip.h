@@ -16,7 +16,9 @@
  * Threading: a context owns one HIP stream; calls on one context are
  * asynchronous and ordered; callers serialise calls per context (this is what
  * the reference's `lock (_UpdateParameterPool)` / issue-thread ordering gives,
- * Illuminant/Particles/ParticleSystem.cs:681).  Host output buffers are valid
+ * Illuminant/Particles/ParticleSystem.cs:681).  Different contexts may be driven
+ * from different threads; the ilm_debug_* switches are process-wide (atomic) and
+ * change the behaviour of every context.  Host output buffers are valid
  * after the call returns (download / count calls synchronise the stream).
  */
 #ifndef ILLUMINANT_HIP_H
@@ -460,7 +462,8 @@ int32_t ilm_sdf_upload(IlmHandle sdf, const uint16_t* texels);
 int32_t ilm_sdf_sample(IlmHandle sdf, const IlmDistanceFieldUniforms* df, const float* positions, int32_t count, float* out_distances);
 
 /* Diagnostic, like ilm_sdf_sample: the cone trace samples positions that lie well inside the field through a second, table-driven form of
- * sampleDistanceFieldEx (csrc/hlsl_math.hpp, sample_inside_table).  This evaluates `count` positions the way the trace loop does:
+ * sampleDistanceFieldEx (csrc/hlsl_math.hpp, sample_inside_table) that reads the field's cell array (built from the atlas on demand and
+ * rebuilt when the atlas changes).  This evaluates `count` positions the way the trace loop does:
  * out_used_table[i] = 1 where position i met that form's precondition and went through it, 0 where the general form was used.  A test
  * holds both bit-equal to the CPU restatement. */
 int32_t ilm_debug_sdf_sample_inside(IlmHandle sdf, const IlmDistanceFieldUniforms* df, const float* positions, int32_t count,
@@ -470,6 +473,7 @@ int32_t ilm_debug_sdf_sample_inside(IlmHandle sdf, const IlmDistanceFieldUniform
  * (ConeTrace.fxh:62) with an instruction sequence that skips the IEEE division's range scaling.  This evaluates that sequence
  * (`out_fast`) and the plain IEEE division (`out_ieee`) for `count` operand pairs on the device, so a test can hold them
  * bit-equal over the operand range the kernel admits (2^-60 <= |d| <= 2^60, |n| <= 2^60 or zero / infinite / NaN). */
+int32_t ilm_debug_divide(IlmHandle ctx, const float* numerators, const float* denominators, int32_t count, float* out_fast, float* out_ieee);
 /* The light pass divides by two constants -- DOT_RAMP_RANGE (LightCommon.fxh:6) and UNSHADOWED_THRESHOLD - FULLY_SHADOWED_THRESHOLD
  * (ConeTrace.fxh:19-20, :186) -- with the constants' reciprocals folded in at compile time.  This runs, for each of them, ALL 2^32
  * float bit patterns as the numerator through that sequence and through the IEEE division and counts the results that differ:
@@ -477,7 +481,6 @@ int32_t ilm_debug_sdf_sample_inside(IlmHandle sdf, const IlmDistanceFieldUniform
  * kernel's numerators are saturates and sums of unit-vector components), out_mismatches[2 i + 1] outside it, for divisor
  * out_divisors[i]; *out_count divisors, out_mismatches holds 2 * capacity entries.  A test requires zero inside. */
 int32_t ilm_debug_divide_by_constants(IlmHandle ctx, float* out_divisors, uint64_t* out_mismatches, int32_t capacity, int32_t* out_count);
-int32_t ilm_debug_divide(IlmHandle ctx, const float* numerators, const float* denominators, int32_t count, float* out_fast, float* out_ieee);
 /* ilm_system_step runs a step of the common shape (power-of-two chunk size >= 64, UpdatePositions, Gravity / area-less Noise and FMA,
  * inline spawners) through a kernel specialised for it and every other step through the kernel that interprets the descriptor; the
  * per-slot arithmetic is the same.  interpreter != 0 forces the interpreting kernel for every later step of this process (0: the

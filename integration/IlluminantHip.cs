@@ -494,8 +494,8 @@ namespace Squared.Illuminant.Native {
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_sdf_upload (ulong sdf, ushort* texels);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_sdf_sample (ulong sdf, IlmDistanceFieldUniforms* df, float* positions, int count, float* outDistances);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_debug_sdf_sample_inside (ulong sdf, IlmDistanceFieldUniforms* df, float* positions, int count, float* outDistances, int* outUsedTable);
-        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_debug_divide_by_constants (ulong ctx, float* outDivisors, ulong* outMismatches, int capacity, int* outCount);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_debug_divide (ulong ctx, float* numerators, float* denominators, int count, float* outFast, float* outIeee);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_debug_divide_by_constants (ulong ctx, float* outDivisors, ulong* outMismatches, int capacity, int* outCount);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_debug_step_interpreter (int interpreter);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_debug_step_streams (int streams);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_sdf_destroy (ulong sdf);

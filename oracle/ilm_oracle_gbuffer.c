@@ -207,8 +207,12 @@ static void gb_draw(IlmFloat4* out, uint32_t* depth, int32_t width, int32_t heig
             float f1, f2;
             if (!gb_cover(p, (int)i, (int)j, &f1, &f2))
                 continue;
-            const float z = gb_lerp(p, 7, f1, f2);
-            if (!((z >= 0.0f) && (z <= 1.0f)))                    /* clipped against the near / far plane (w = 1) */
+            /* clipped against the near / far plane (w = 1) -- volumes only: BillboardVertex's POSITION0 is a Vector2 (Vertices.cs:89), so
+             * BillboardVertexShader's result.z = position.z / DistanceFieldExtent.z (GBufferBitmap.fx:12-27) is 0; attribute 7 of a
+             * billboard is TexCoord.y, which the CLAMP sampler, not the clipper, brings back into range */
+            const int is_billboard = (p->kind == GB_MASK) || (p->kind == GB_GDATA);
+            const float z = is_billboard ? 0.0f : gb_lerp(p, 7, f1, f2);
+            if (!((z >= 0.0f) && (z <= 1.0f)))
                 continue;
             f4 texel;
             if (!gb_shade(p, f1, f2, d, textures, &texel))

@@ -33,7 +33,7 @@ def random_scene(seed, w, h, n_volumes=14, n_billboards=10, z_to_y=0.6):
         d = dict(screen_bounds=((x, y), (x + 8 + b[k, 3] * 40, y + 8 + b[k, 4] * 50)), type=kind,
                  normal=(b[k, 5] - 0.5, b[k, 6], b[k, 7] * 0.5), cylinder_factor=(b[k, 8] if b[k, 9] < 0.5 else 0.0),
                  data_scale=(None if b[k, 10] < 0.3 else 0.25 + 4 * b[k, 10]), static_lighting_only=b[k, 11] < 0.3,
-                 world_offset=(0.0, 0.0, b[k, 12] * 4), texture_bounds=((0.0, 0.0), (1.0, 1.0)) if b[k, 13] < 0.5 else ((0.25, 0.1), (0.9, 1.2)))
+                 world_offset=(0.0, 0.0, b[k, 12] * 4), texture_bounds=((0.0, 0.0), (1.0, 1.0)) if b[k, 13] < 0.4 else (((0.25, 0.1), (0.9, 1.2)) if b[k, 13] < 0.7 else ((-0.4, -0.3), (1.5, 1.25))))
         if kind == abi.BILLBOARD_GBUFFER_DATA:
             d["world_elevation"] = b[k, 14] * 20
         if b[k, 15] < 0.3:
@@ -208,3 +208,24 @@ def test_mesh_entry_point_validates_its_arguments(ctx):
         gb.render_meshes(scenes.gbuffer_mesh_desc(), billboards=bb, runs=[(None, 0, 1, 7)])
     gb.render_meshes(scenes.gbuffer_mesh_desc(), tri)
     gb.close()
+
+
+def test_billboard_texture_bounds_outside_the_unit_square_are_clamped_not_clipped(ctx, oracle):
+    """A billboard's depth is 0 (BillboardVertex.POSITION0 is a Vector2): its fragments are never clipped against the near / far plane,
+    and TexCoord outside [0, 1] reads the clamped border texel (the closed form lives in tests/test_gbuffer_kat.py)."""
+    w, h = 48, 40
+    d = scenes.gbuffer_mesh_desc(two_point_five_d=True, z_to_y=1.0)
+    tex = np.zeros((2, 2, 4), np.uint8)
+    tex[..., 3] = [[255, 255], [255, 0]]
+    bb = scenes.billboard_vertices([dict(screen_bounds=((8.0, 4.0), (24.0, 36.0)), texture_bounds=((-0.5, -0.5), (1.5, 1.5)))], 0.0, 1.0)
+    lm = native.Lightmap(ctx, 2, 2, abi.LIGHTMAP_RGBA8)
+    lm.upload(tex)
+    gb = native.GBufferTexture(ctx, None, abi.GBUFFER_FLOAT4, size=(w, h))
+    gb.render_meshes(d, None, None, bb, [(lm, 0, 1, abi.BILLBOARD_MASK)])
+    got = gb.download()
+    want = oracle.render_gbuffer_meshes(w, h, d, billboards=bb, runs=[(0, 1, abi.BILLBOARD_MASK)], textures=[tex])
+    compare(got, want, abi.GBUFFER_FLOAT4)
+    ground = np.float32([0.5, 1.0, 0.0, 1.0])
+    drawn = ~np.all(got == ground, axis=-1)
+    assert drawn[4, 8] and drawn[35, 8] and drawn[4, 23] and not drawn[35, 23] and drawn.sum() == 16 * 32 - 8 * 16      # the transparent texel covers u, v >= 0.5: columns 16-23, rows 20-35
+    lm.close(); gb.close()

@@ -182,6 +182,29 @@ def test_mask_billboards(oracle):
     assert np.allclose(nx, -0.9 + 1.8 * (np.arange(16) + 0.5) / 16.0, atol=1e-5)
 
 
+def test_billboard_texture_bounds_outside_the_unit_square_are_clamped_not_clipped(oracle):
+    """BillboardVertex.POSITION0 is a Vector2 (Vertices.cs:89): BillboardVertexShader's depth is position.z / extent.z = 0, so a
+    billboard fragment is never clipped against the near / far plane, whatever its TexCoord; the sampler is POINT / CLAMP
+    (GBufferBitmap.fx).  TextureBounds (-0.5, -0.5)-(1.5, 1.5) over a 2 x 2 alpha texture whose four texels are opaque: the WHOLE
+    quad is drawn -- the outer ring reads the clamped border texels (the clip ran on attribute 7 = TexCoord.y)."""
+    w, h = 48, 40
+    d = scenes.gbuffer_mesh_desc(two_point_five_d=True, z_to_y=1.0)
+    tex = np.zeros((2, 2, 4), np.uint8)
+    tex[..., 3] = [[255, 255], [255, 0]]                      # bottom-right texel transparent
+    b = dict(screen_bounds=((8.0, 4.0), (24.0, 36.0)), texture_bounds=((-0.5, -0.5), (1.5, 1.5)))
+    bb = scenes.billboard_vertices([b], ground_z=0.0, z_to_y=1.0)
+    g = oracle.render_gbuffer_meshes(w, h, d, billboards=bb, runs=[(0, 1, abi.BILLBOARD_MASK)], textures=[tex])
+    drawn = ~np.all(g == GROUND, axis=-1)
+    # u = -0.5 + 2 (i + 0.5 - 8) / 16, v = -0.5 + 2 (j + 0.5 - 4) / 32; texel = clamp(floor(2 u), 0, 1): column 1 from u >= 0.5, row 1 from v >= 0.5
+    jj, ii = np.mgrid[0:h, 0:w]
+    u = -0.5 + 2.0 * (ii + 0.5 - 8.0) / 16.0
+    v = -0.5 + 2.0 * (jj + 0.5 - 4.0) / 32.0
+    inside = (ii >= 8) & (ii < 24) & (jj >= 4) & (jj < 36)
+    transparent = (np.clip(np.floor(2.0 * u), 0, 1) == 1) & (np.clip(np.floor(2.0 * v), 0, 1) == 1)
+    assert np.array_equal(drawn, inside & ~transparent)
+    assert drawn[4, 8] and drawn[35, 8] and drawn[4, 23]      # rows / columns with v < 0, v > 1, u > 1 are there
+
+
 def test_gdata_billboards_and_batch_order(oracle):
     """GDataBillboardPixelShader (GBufferBitmap.fx:61-113): alpha < 127/255 discards; (r, g) is a tangent-space normal, b * dataScale
     lifts z.  The mask batch sits one layer below the g-data batch whatever the run order (LightingRenderer.GBuffer.cs:371-392)."""
