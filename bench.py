@@ -255,6 +255,27 @@ def build_lighting(H, ctx, scenes, abi, width, height, n_lights, resolution, wor
     return dict(renderer=renderer, env=env, field=field, width=width, height=height, n_lights=n_lights, field_generation=gen)
 
 
+def build_collision_scene(H, ctx, scenes, abi):
+    """The field the demo the configs are modelled on collides its particles with (TestGame Scenes/SimpleParticles.cs:210-284): 1920 x 1080
+    x 64, 9 slices at resolution 1/4, maximumEncodedDistance 320; four cylinders of size 100-200 x 30 on a 32-pixel grid and four boxes
+    around the screen's edges, generated on the device through UpdateFields."""
+    env = H.LightingEnvironment()
+    rc = H.RendererConfiguration(64, 64)
+    rc.MaximumFieldUpdatesPerFrame = 9999
+    renderer = H.LightingRenderer(ctx, rc, env, 0)
+    field = H.DistanceField(ctx, 1920, 1080, 64.0, 9, 0.25, 320, abi.SDF_UNORM16)
+    renderer.DistanceField = field
+    r = scenes.uniform(23, (4, 3))
+    for i in range(4):
+        sz = 100.0 + 100.0 * float(r[i, 2])
+        env.Obstructions.Add(H.LightObstruction(2, [float(int(r[i, 0] * 61) * 32), float(int(r[i, 1] * 34) * 32), 0.0], [sz, sz, 30.0], 0.0))      # Cylinder
+    for center, size in (((0, -45, 0), (1920, 50, 60)), ((0, 1080 + 45, 0), (1920, 50, 60)), ((-45, 0, 0), (50, 1080, 60)), ((1920 + 45, 0, 0), (50, 1080, 60))):
+        env.Obstructions.Add(H.LightObstruction(1, [float(c) for c in center], [float(c) for c in size], 0.0))                                    # Box
+    renderer.UpdateFields()
+    ctx.Sync()
+    return dict(renderer=renderer, env=env, field=field)
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -297,6 +318,7 @@ def main():
         ctx = H.DeviceContext(local_rank)
 
     import struct
+    import ctypes as C_
 
     def barrier():
         """Device idle on every rank: hipStreamSynchronize of the context stream, then (N > 1) a collective that no rank leaves
@@ -431,6 +453,57 @@ def main():
                                              "note": "setup + scan + key emit + stable radix sort on the tile bits + one workgroup per 16 x 16 tile "
                                                      "(crowded tiles in 2048-sprite segments, combined in order); ordered blending"}
         del target
+    if not args.no_next_rows and world == 1:
+        # collision update: cfg2's particles (Gravity x4 + Noise, no spawner) stepped with UpdateWithDistanceField
+        # through the demo's own field, next to the same system stepped with UpdatePositions.  Unit of the roofline: 112 B per live
+        # slot-step + 32 B per sampleDistanceFieldEx call, the call count taken on the device (ilm_debug_step_sdf_samples).
+        scene = build_collision_scene(H, ctx, scenes, abi)
+        rows = {}
+        for label, collide in (("plain", False), ("collision", True)):
+            C = build_particle_system(H, ctx, scenes, abi, args.chunk_size, args.chunks, rank, with_spawner=False)
+            cs_, ctp = C["ps"], C["tp"]
+            if collide:
+                col = H.ParticleCollision()
+                col.DistanceField = scene["field"]
+                col.DistanceFieldMaximumZ = 256.0                         # SimpleParticles.cs:293
+                col.LifePenalty = 1.0                                     # :132-134
+                cfgc = cs_.Configuration
+                cfgc.Collision = col
+                cs_.Configuration = cfgc
+            fc = 0
+            for _ in range(10):
+                ctp.Advance(dt); cs_.Update(fc); fc += 1
+            samples_per_step = 0
+            if collide:
+                out_n = C_.c_uint64(0)
+                native.check(native.lib().ilm_debug_step_sdf_samples(ctx.Handle, 1, None))
+                ctp.Advance(dt); cs_.Update(fc); fc += 1
+                native.check(native.lib().ilm_debug_step_sdf_samples(ctx.Handle, 0, C_.byref(out_n)))
+                samples_per_step = int(out_n.value)
+            kc, blocks_c = 20, []
+            for _ in range(7):
+                barrier()
+                ctx.TimerStart()
+                for _ in range(kc):
+                    ctp.Advance(dt); cs_.Update(fc); fc += 1
+                blocks_c.append(ctx.TimerStop() / kc)
+            blocks_c.sort()
+            rows[label] = dict(ms=blocks_c[len(blocks_c) // 2], ms_min=blocks_c[0], samples=samples_per_step, live=C["live"], live_now=int(cs_.LiveCount) if hasattr(cs_, "LiveCount") else None)
+            del C, cs_
+        pl, co = rows["plain"], rows["collision"]
+        alg = co["live"] * PARTICLE_BYTES_PER_SLOT + co["samples"] * SDF_SAMPLE_BYTES
+        next_rows["collision_step_1m"] = {
+            "us_per_step": round(co["ms"] * 1e3, 2), "us_per_step_min": round(co["ms_min"] * 1e3, 2), "us_per_step_update_positions": round(pl["ms"] * 1e3, 2),
+            "ratio_to_plain_step": round(co["ms"] / pl["ms"], 3), "particles": co["live"], "sdf_samples_per_step": co["samples"],
+            "sdf_samples_per_particle": round(co["samples"] / max(co["live"], 1), 3),
+            "field": "1920x1080x64, 9 slices at 1/4 resolution, max encoded distance 320, 4 cylinders + 4 edge boxes (SimpleParticles.cs:210-284)",
+            "roofline": {"bound": "hbm", "achieved": round(alg / (co["ms"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(alg / (co["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "ilm::step_kernel<unorm16, DF> (interpreter; the collision update has no lean variant)",
+                         "bytes_per_unit": "112 B per live slot-step + 32 B per SDF sample", "units_per_launch": {"slots": co["live"], "sdf_samples": co["samples"]},
+                         "launch_ms": round(co["ms"], 5),
+                         "note": "the 0.8 MB field and cfg2's 84 MB of state are cache resident: priced against the HBM peak because that is the contract's roofline"}}
+        del scene
     cpu_init, cpu_rnd, cpu_desc_bytes = P["init"], P["rnd"], ps.LastStepBytes()
     if not args.no_cfg4:
         del P, ps, spawner          # free cfg2's chunks before the 0.9 GB system is built

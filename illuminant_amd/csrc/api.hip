@@ -1559,6 +1559,16 @@ int32_t ilm_debug_divide_by_constants(IlmHandle hctx, float* out_divisors, uint6
 
 int32_t ilm_debug_step_interpreter(int32_t interpreter) { return (int32_t)set_step_interpreter(interpreter); }
 int32_t ilm_debug_step_streams(int32_t streams) { return (int32_t)set_step_streams(streams); }
+int32_t ilm_debug_step_sdf_samples(IlmHandle hctx, int32_t enable, uint64_t* out_samples) {
+    Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);
+    if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(hipStreamSynchronize(c->main()));        // main() first joins the second stream
+    unsigned long long value = 0;
+    HIP_TRY(step_sdf_sample_counter(enable, &value));
+    if (out_samples) *out_samples = (uint64_t)value;
+    return ILM_OK;
+}
 
 int32_t ilm_debug_divide(IlmHandle hctx, const float* numerators, const float* denominators, int32_t count, float* out_fast, float* out_ieee) {
     Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);

@@ -691,6 +691,11 @@ ILM_DEV void update_positions(float4& pos, float4& vel, const IlmParticleSystemU
     }
 }
 
+// Diagnostic (ilm_debug_step_sdf_samples): how many sampleDistanceFieldEx calls the collision update makes -- the unit of its roofline
+// (bench.py collision_step_1m).  The flag is read by a scalar load; the counter costs nothing while it is off.
+__device__ unsigned long long g_step_sdf_samples;
+__device__ int g_step_count_sdf_samples;
+
 // estimateNormal4, VisualizeCommon.fxh:44-63
 template <int FMT>
 ILM_DEV f3 estimate_normal4(f3 position, const IlmDistanceFieldUniforms& df, const SdfView& sdf) {
@@ -710,7 +715,7 @@ ILM_DEV f3 estimate_normal4(f3 position, const IlmDistanceFieldUniforms& df, con
 // PS_Update, UpdateParticleSystemWithDistanceField.fx:29-147 (live slot)
 template <int FMT>
 ILM_DEV void update_with_distance_field(float4& pos, float4& vel, float x, float y, const IlmParticleSystemUniforms& sys, float dts,
-                                        const IlmDistanceFieldUniforms& df, const SdfView& sdf) {
+                                        const IlmDistanceFieldUniforms& df, const SdfView& sdf, int& samples) {
 #pragma clang fp contract(off)   // discontinuous collision state machine + life arithmetic: keep IEEE-exact
     const float4 zero = mk4(0.0f, 0.0f, 0.0f, 0.0f);
     float new_life = pos.w - (sys.GlobalSettings.w * dts);
@@ -730,6 +735,7 @@ ILM_DEV void update_with_distance_field(float4& pos, float4& vel, float x, float
     float4 new_velocity = zero;
 
     const float initial_distance = sample_distance_field<FMT>(old_xyz, df, sdf);
+    samples++;
     const bool was_colliding = initial_distance < collision_distance;
     float travel_distance = fmaxf(0.0f, fminf(initial_distance, len3(scaled_velocity)));
     int step_count = ref::kMaxStepCount;
@@ -741,6 +747,7 @@ ILM_DEV void update_with_distance_field(float4& pos, float4& vel, float x, float
     for (int i = 0; i < step_count; i++) {
         const f3 test_position = old_xyz + (unit_vector * travel_distance);
         const float step_distance = sample_distance_field<FMT>(test_position, df, sdf);
+        samples++;
         if (step_distance < collision_distance) {
             collided = true;
             collision_position = test_position;
@@ -760,8 +767,10 @@ ILM_DEV void update_with_distance_field(float4& pos, float4& vel, float x, float
         const bool bounce = vel.w <= 0.0f;
         const bool redirect = was_colliding && !escaping;
         f3 normal = mk3(0.0f, 0.0f, 0.0f);
-        if (bounce || redirect)
+        if (bounce || redirect) {
             normal = estimate_normal4<FMT>(collision_position, df, sdf);
+            samples += 4;
+        }
         const float escape_speed = fminf(max_velocity, sys.CollisionSettings.x);
         if (redirect) {
             normal = normal * mk3(1.0f, 1.0f, 0.0f);  // ESCAPE_MASK
@@ -913,6 +922,7 @@ ILM_DEV bool process_unit(CStepLaunch* ap, const UnitPlanes& up, int chunk, int 
         }
     }
     bool live_after = false;
+    int sdf_samples = 0;
     // Stride padding (chunk sizes whose square is not a multiple of 1024: 10, 16, 48 ...): not a slot of the chunk.  Noise has no life
     // check, so without this a padding lane could be given a life, be updated and be counted (CountLiveParticles.fx counts ChunkSize^2 pixels).
     if (i >= a.slots)
@@ -991,7 +1001,7 @@ ILM_DEV bool process_unit(CStepLaunch* ap, const UnitPlanes& up, int chunk, int 
                 pos = vel = zero;  // readStateOrDiscard: discard => cleared target
             } else {
                 if constexpr (DF)
-                    update_with_distance_field<FMT>(pos, vel, fx, fy, d.System, a.derived.dt_s, d.DistanceField, a.sdf);
+                    update_with_distance_field<FMT>(pos, vel, fx, fy, d.System, a.derived.dt_s, d.DistanceField, a.sdf, sdf_samples);
                 else
                     update_positions(pos, vel, d.System, a.derived.dt_s);
                 render_data(fx, fy, pos, vel, attr, d.System, d.Update, a.derived.bezier_codes, a.derived.update_bits, a.ramp, a.ramp_w, a.ramp_h, rc, rd);
@@ -1007,6 +1017,11 @@ ILM_DEV bool process_unit(CStepLaunch* ap, const UnitPlanes& up, int chunk, int 
             st_plane<STREAM>(up, 16, lane4, rd.x); st_plane<STREAM>(up, 17, lane4, rd.y); st_plane<STREAM>(up, 18, lane4, rd.z); st_plane<STREAM>(up, 19, lane4, rd.w);
         }
         live_after = pos.w > 0.0f;
+    }
+    if constexpr (DF) {
+        // diagnostic count (one atomic per lane: only ever on while bench.py takes the collision row's sample count)
+        if ((__builtin_amdgcn_readfirstlane(g_step_count_sdf_samples) != 0) && (sdf_samples != 0))
+            atomicAdd(&g_step_sdf_samples, (unsigned long long)sdf_samples);
     }
 
     return live_after;
@@ -1723,6 +1738,19 @@ __global__ __launch_bounds__(1024) void live_slots_kernel(const float* __restric
 hipError_t launch_live_slots(const float* life, int32_t slots, uint32_t* out_slots, uint32_t capacity, uint32_t* out_count, hipStream_t stream) {
     hipLaunchKernelGGL(live_slots_kernel, dim3(1), dim3(1024), 0, stream, life, slots, out_slots, capacity, out_count);
     return hipGetLastError();
+}
+
+// ilm_debug_step_sdf_samples: switch the count on / off and fetch-and-clear it (the caller has synchronised the device)
+hipError_t step_sdf_sample_counter(int enable, unsigned long long* out) {
+    unsigned long long value = 0, zero = 0;
+    hipError_t e = hipMemcpyFromSymbol(&value, HIP_SYMBOL(g_step_sdf_samples), sizeof(value));
+    if (e != hipSuccess) return e;
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_step_sdf_samples), &zero, sizeof(zero));
+    if (e != hipSuccess) return e;
+    const int flag = enable ? 1 : 0;
+    e = hipMemcpyToSymbol(HIP_SYMBOL(g_step_count_sdf_samples), &flag, sizeof(flag));
+    if (out) *out = value;
+    return e;
 }
 
 }  // namespace ilm

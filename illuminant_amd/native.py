@@ -75,6 +75,7 @@ SYMBOLS = {
     "ilm_debug_divide": (_I, [_H, _P, _P, _I, _P, _P]),
     "ilm_debug_step_interpreter": (_I, [_I]),
     "ilm_debug_step_streams": (_I, [_I]),
+    "ilm_debug_step_sdf_samples": (_I, [_H, _I, C.POINTER(C.c_uint64)]),
     "ilm_debug_divide_by_constants": (_I, [_H, _P, _P, _I, C.POINTER(_I)]),
     "ilm_sdf_destroy": (_I, [_H]),
     "ilm_sdf_download": (_I, [_H, _P]),

@@ -491,6 +491,12 @@ int32_t ilm_debug_step_interpreter(int32_t interpreter);
  * streams == 1 keeps every later step of this process on the context stream, 2 restores the default; returns the previous setting.
  * Environment: ILM_STEP_STREAMS=1.  A context whose stream was handed out by ilm_ctx_stream never splits. */
 int32_t ilm_debug_step_streams(int32_t streams);
+/* Diagnostic: the collision update (UpdateParticleSystemWithDistanceField.fx:29-147) is priced per sampleDistanceFieldEx call -- the
+ * field lookup at the particle, one per step of its sweep, four for a bounce / redirect normal (VisualizeCommon.fxh:44-63).  enable != 0
+ * makes every later ilm_system_step of this process that runs the collision update count those calls on the device; the call returns
+ * the count accumulated since the previous call in *out_samples (may be NULL) and clears it.  Synchronises the context.  The count
+ * costs one atomic per particle while it is on: for measurement runs only. */
+int32_t ilm_debug_step_sdf_samples(IlmHandle ctx, int32_t enable, uint64_t* out_samples);
 int32_t ilm_sdf_destroy(IlmHandle sdf);
 /* DistanceField.Save (Illuminant/SDF/DistanceField.cs:178-194): the atlas bytes, 8 per texel, row-major. */
 int32_t ilm_sdf_download(IlmHandle sdf, uint16_t* texels);
