@@ -19,6 +19,7 @@
 #include <new>
 #include <vector>
 
+#include <algorithm>
 #include "internal.hpp"
 
 namespace {
@@ -44,6 +45,8 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -66,7 +69,7 @@ Rccl& rccl() {
         if (!r.field) { snprintf(r.why, sizeof(r.why), "librccl.so lacks %s", symbol); return; }
         ILM_BIND(GetUniqueId, "ncclGetUniqueId") ILM_BIND(CommInitRank, "ncclCommInitRank") ILM_BIND(CommInitAll, "ncclCommInitAll")
         ILM_BIND(CommDestroy, "ncclCommDestroy") ILM_BIND(CommCount, "ncclCommCount") ILM_BIND(AllGather, "ncclAllGather")
-        ILM_BIND(GroupStart, "ncclGroupStart") ILM_BIND(GroupEnd, "ncclGroupEnd") ILM_BIND(GetErrorString, "ncclGetErrorString")
+        ILM_BIND(GroupStart, "ncclGroupStart") ILM_BIND(GroupEnd, "ncclGroupEnd") ILM_BIND(Send, "ncclSend") ILM_BIND(Recv, "ncclRecv") ILM_BIND(GetErrorString, "ncclGetErrorString")
 #undef ILM_BIND
         r.ok = true;
     });
@@ -100,6 +103,10 @@ struct GroupLightmap {
     Group* group = nullptr;
     int width = 0, height = 0, format = 0, slot_rows = 0;
     size_t row_bytes = 0;
+    // rows [begin[r], end[r]) rank r renders.  Default: the equal padded slots (one in-place all-gather).  ilm_group_lightmap_set_strips
+    // installs other contiguous strips of whole tile bands (cost-balanced ones): they are exchanged range by range (exchange_rows).
+    std::vector<int> begin, end;
+    bool equal_slots = true;
     std::vector<void*> buffers;             // per local member: world * slot_rows rows
     std::vector<IlmHandle> lightmaps;       // per local member: lightmap object aliasing the buffer
 };
@@ -227,6 +234,71 @@ int32_t all_gather(Group* g, void* const* buffers, size_t bytes, int gather) {
     }
     NCCL_TRY(r.GroupEnd());
     return ILM_OK;
+}
+
+// The exchange for strips of unequal size: rank r owns `bytes[r]` at `offset[r]` of every member's buffer and every other member needs
+// them.  Peer mode: as all_gather, every local member pushes its range to the others (one transfer per xGMI link).  RCCL: one group of
+// point-to-point transfers -- rank r sends its range to each of the world - 1 others and receives theirs in place; on the fully
+// connected xGMI mesh of one node that is again one transfer per link and direction, with no ring hop in between.
+int32_t exchange_ranges(Group* g, void* const* buffers, const std::vector<size_t>& offset, const std::vector<size_t>& bytes, int32_t gather) {
+    if (gather == ILM_GATHER_NONE || g->world == 1) return ILM_OK;
+    if (gather == ILM_GATHER_PEER) {
+        if (g->rank_mode) return api_fail(ILM_ERR_STATE, "ILM_GATHER_PEER needs every member in this process: use ILM_GATHER_RCCL");
+        const int n = g->n_local;
+        for (int i = 0; i < n; i++) {
+            HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+            HIP_TRY(hipEventRecord(g->events[(size_t)i], g->stream((size_t)i)));
+        }
+        for (int i = 0; i < n; i++) {
+            HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+            for (int j = 0; j < n; j++)
+                if (j != i) HIP_TRY(hipStreamWaitEvent(g->stream((size_t)i), g->events[(size_t)j], 0));
+        }
+        for (int i = 0; i < n; i++) {
+            HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+            const size_t off = offset[(size_t)(g->first_rank + i)], len = bytes[(size_t)(g->first_rank + i)];
+            for (int k = 1; k < n && len > 0; k++) {
+                const int j = (i + k) % n;
+                HIP_TRY(hipMemcpyPeerAsync(static_cast<char*>(buffers[j]) + off, g->devices[(size_t)j],
+                                           static_cast<const char*>(buffers[i]) + off, g->devices[(size_t)i], len, g->stream((size_t)i)));
+            }
+            HIP_TRY(hipEventRecord(g->events[(size_t)i], g->stream((size_t)i)));
+        }
+        for (int i = 0; i < n; i++) {
+            HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+            for (int j = 0; j < n; j++)
+                if (j != i) HIP_TRY(hipStreamWaitEvent(g->stream((size_t)i), g->events[(size_t)j], 0));
+        }
+        return ILM_OK;
+    }
+    if (gather != ILM_GATHER_RCCL) return api_fail(ILM_ERR_INVALID_ARGUMENT, "unknown gather mode %d", gather);
+    const int32_t rc = ensure_comms(g);
+    if (rc != ILM_OK) return rc;
+    Rccl& r = rccl();
+    NCCL_TRY(r.GroupStart());
+    for (int i = 0; i < g->n_local; i++) {
+        HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+        char* buf = static_cast<char*>(buffers[i]);
+        const int me = g->first_rank + i;
+        for (int k = 1; k < g->world; k++) {
+            const int to = (me + k) % g->world, from = (me - k + g->world) % g->world;      // staggered: no two ranks start on the same peer
+            if (bytes[(size_t)me] > 0) NCCL_TRY(r.Send(buf + offset[(size_t)me], bytes[(size_t)me], ncclInt8, to, g->comms[(size_t)i], g->stream((size_t)i)));
+            if (bytes[(size_t)from] > 0) NCCL_TRY(r.Recv(buf + offset[(size_t)from], bytes[(size_t)from], ncclInt8, from, g->comms[(size_t)i], g->stream((size_t)i)));
+        }
+    }
+    NCCL_TRY(r.GroupEnd());
+    return ILM_OK;
+}
+
+// the exchange of a group lightmap's strips: one in-place all-gather for the equal slots, range by range otherwise
+int32_t gather_lightmap(GroupLightmap* m, int32_t gather) {
+    if (m->equal_slots) return all_gather(m->group, m->buffers.data(), m->row_bytes * (size_t)m->slot_rows, gather);
+    std::vector<size_t> offset((size_t)m->group->world), bytes((size_t)m->group->world);
+    for (int r = 0; r < m->group->world; r++) {
+        offset[(size_t)r] = m->row_bytes * (size_t)m->begin[(size_t)r];
+        bytes[(size_t)r] = m->row_bytes * (size_t)(m->end[(size_t)r] - m->begin[(size_t)r]);
+    }
+    return exchange_ranges(m->group, m->buffers.data(), offset, bytes, gather);
 }
 
 // Small host payloads (liveness counters, timings): rank r's `bytes` land at out + r * bytes on every process.  Members of this
@@ -406,6 +478,10 @@ int32_t ilm_group_lightmap_create(IlmHandle h, int32_t width, int32_t height, in
     m->group = g; m->width = width; m->height = height; m->format = format;
     m->slot_rows = slot_rows_for(height, g->world);
     m->row_bytes = texel_bytes(format) * (size_t)width;
+    for (int r = 0; r < g->world; r++) {
+        m->begin.push_back(std::min(r * m->slot_rows, height));
+        m->end.push_back(std::min((r + 1) * m->slot_rows, height));
+    }
     handle_register(m, kMagicGroupLightmap);
     g->children++;
     const IlmHandle self = static_cast<IlmHandle>(reinterpret_cast<uintptr_t>(m));
@@ -461,17 +537,48 @@ int32_t ilm_group_lightmap_strip(IlmHandle h, int32_t rank, int32_t* out_row_beg
     GroupLightmap* m = glm_from(h);
     if (!m) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group lightmap handle");
     if (rank < 0 || rank >= m->group->world) return api_fail(ILM_ERR_OUT_OF_RANGE, "rank %d outside [0, %d)", rank, m->group->world);
-    const int b = rank * m->slot_rows, e = (rank + 1) * m->slot_rows;
-    if (out_row_begin) *out_row_begin = b < m->height ? b : m->height;
-    if (out_row_end) *out_row_end = e < m->height ? e : m->height;
+    if (out_row_begin) *out_row_begin = m->begin[(size_t)rank];
+    if (out_row_end) *out_row_end = m->end[(size_t)rank];
     if (out_slot_rows) *out_slot_rows = m->slot_rows;
+    return ILM_OK;
+}
+
+int32_t ilm_group_lightmap_set_strips(IlmHandle h, const int32_t* row_begins, const int32_t* row_ends) {
+    GroupLightmap* m = glm_from(h);
+    if (!m) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group lightmap handle");
+    const int world = m->group->world;
+    if (!row_begins || !row_ends) {                       // back to the equal slots
+        for (int r = 0; r < world; r++) {
+            m->begin[(size_t)r] = std::min(r * m->slot_rows, m->height);
+            m->end[(size_t)r] = std::min((r + 1) * m->slot_rows, m->height);
+        }
+        m->equal_slots = true;
+        return ILM_OK;
+    }
+    // contiguous, in rank order, whole tile bands (the last one may be ragged), covering the frame exactly
+    int at = 0;
+    for (int r = 0; r < world; r++) {
+        if (row_begins[r] != at || row_ends[r] < row_begins[r] || row_ends[r] > m->height)
+            return api_fail(ILM_ERR_INVALID_ARGUMENT, "strip %d = [%d, %d) does not continue at row %d of a %d-row frame", r, row_begins[r], row_ends[r], at, m->height);
+        if ((row_ends[r] % kTileRows) != 0 && row_ends[r] != m->height)
+            return api_fail(ILM_ERR_INVALID_ARGUMENT, "strip %d ends at row %d: strips are whole %d-row tile bands", r, row_ends[r], kTileRows);
+        at = row_ends[r];
+    }
+    if (at != m->height) return api_fail(ILM_ERR_INVALID_ARGUMENT, "the strips end at row %d of a %d-row frame", at, m->height);
+    bool equal = true;
+    for (int r = 0; r < world; r++) {
+        equal = equal && row_begins[r] == std::min(r * m->slot_rows, m->height) && row_ends[r] == std::min((r + 1) * m->slot_rows, m->height);
+        m->begin[(size_t)r] = row_begins[r];
+        m->end[(size_t)r] = row_ends[r];
+    }
+    m->equal_slots = equal;
     return ILM_OK;
 }
 
 int32_t ilm_group_lightmap_gather(IlmHandle h, int32_t gather) {
     GroupLightmap* m = glm_from(h);
     if (!m) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group lightmap handle");
-    return all_gather(m->group, m->buffers.data(), m->row_bytes * (size_t)m->slot_rows, gather);
+    return gather_lightmap(m, gather);
 }
 
 int32_t ilm_group_render_sphere_lights(IlmHandle hgroup, const IlmLightVertex* lights, int32_t light_count, const IlmEnvironment* env,
@@ -495,7 +602,7 @@ int32_t ilm_group_render_sphere_lights(IlmHandle hgroup, const IlmLightVertex* l
         if (rc != ILM_OK) return rc;
         if (stats) { stats->SdfSamples += part.SdfSamples; stats->PixelLightPairs += part.PixelLightPairs; stats->TracedPairs += part.TracedPairs; }
     }
-    return all_gather(g, m->buffers.data(), m->row_bytes * (size_t)m->slot_rows, gather);
+    return gather_lightmap(m, gather);
 }
 
 int32_t ilm_group_live_counts(IlmHandle hgroup, const IlmHandle* systems, int32_t total_chunks, uint32_t* out_counts, int32_t capacity,

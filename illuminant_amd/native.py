@@ -115,6 +115,7 @@ SYMBOLS = {
     "ilm_group_lightmap_create": (_I, [_H, _I, _I, _I, C.POINTER(_H)]),
     "ilm_group_lightmap_member": (_I, [_H, _I, C.POINTER(_H)]),
     "ilm_group_lightmap_strip": (_I, [_H, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
+    "ilm_group_lightmap_set_strips": (_I, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ilm_group_lightmap_gather": (_I, [_H, _I]),
     "ilm_group_lightmap_destroy": (_I, [_H]),
     "ilm_group_render_sphere_lights": (_I, [_H, _P, _I, _P, _P, _P, _P, _P, _H, _I, _P]),
@@ -674,6 +675,22 @@ class GroupLightmap:
             h = abi.Handle(0)
             check(lib().ilm_group_lightmap_member(self.handle, i, C.byref(h)))
             self.members.append(Lightmap(group.contexts[i], width, self.slot_rows * group.world, fmt, borrowed_handle=h.value))
+
+    def set_strips(self, strips=None):
+        """ilm_group_lightmap_set_strips: other contiguous strips of whole tile bands, one (begin, end) per rank (None: the equal slots)."""
+        if strips is None:
+            check(lib().ilm_group_lightmap_set_strips(self.handle, None, None))
+        else:
+            n = self.group.world
+            assert len(strips) == n
+            b = (C.c_int32 * n)(*[int(s[0]) for s in strips])
+            e = (C.c_int32 * n)(*[int(s[1]) for s in strips])
+            check(lib().ilm_group_lightmap_set_strips(self.handle, b, e))
+        bb, ee, r = C.c_int32(), C.c_int32(), C.c_int32()
+        self.strips = []
+        for rank in range(self.group.world):
+            check(lib().ilm_group_lightmap_strip(self.handle, rank, C.byref(bb), C.byref(ee), C.byref(r)))
+            self.strips.append((int(bb.value), int(ee.value)))
 
     def gather(self, gather):
         check(lib().ilm_group_lightmap_gather(self.handle, gather))

@@ -128,3 +128,24 @@ def all_gather_rows(full, strips, rank, dist):
         if e > b:
             dist.broadcast(full[b:e], src=r)
     return full
+
+
+def exchange_row_ranges(full, strips, rank, dist):
+    """The exchange csrc/group.hip exchange_ranges performs for UNEQUAL strips (ilm_group_lightmap_set_strips): rank r sends its rows
+    strips[r] to each of the world - 1 other ranks and receives theirs at their true rows -- point-to-point, staggered so that no two
+    ranks start on the same peer (peer k steps ahead / behind), one transfer per link and direction on a fully connected mesh."""
+    world = len(strips)
+    if dist is None or world == 1:
+        return full
+    b, e = strips[rank]
+    ops = []
+    for k in range(1, world):
+        to, frm = (rank + k) % world, (rank - k + world) % world
+        if e > b:
+            ops.append(dist.P2POp(dist.isend, full[b:e].contiguous(), to))
+        fb, fe = strips[frm]
+        if fe > fb:
+            ops.append(dist.P2POp(dist.irecv, full[fb:fe], frm))
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    return full

@@ -916,6 +916,12 @@ int32_t ilm_group_lightmap_create(IlmHandle group, int32_t width, int32_t height
 int32_t ilm_group_lightmap_member(IlmHandle group_lightmap, int32_t local_index, IlmHandle* out_lightmap);
 /* Rows [*out_row_begin, *out_row_end) of the frame that rank `rank` renders, and the slot height R. */
 int32_t ilm_group_lightmap_strip(IlmHandle group_lightmap, int32_t rank, int32_t* out_row_begin, int32_t* out_row_end, int32_t* out_slot_rows);
+/* Replaces the equal slots by other strips: row_begins[r], row_ends[r] for every rank r of the group (world entries each), contiguous in
+ * rank order, whole 16-row tile bands, covering [0, height) -- cost-balanced strips when the lights are unevenly spread (SURVEY 8e;
+ * the reference has one device and no such notion).  Every process of the group must install the same table.  Unequal strips are
+ * exchanged range by range at their true rows (ILM_GATHER_PEER: peer copies; ILM_GATHER_RCCL: one group of ncclSend / ncclRecv, one
+ * transfer per xGMI link and direction) instead of by the single in-place all-gather.  NULL, NULL restores the equal slots. */
+int32_t ilm_group_lightmap_set_strips(IlmHandle group_lightmap, const int32_t* row_begins, const int32_t* row_ends);
 int32_t ilm_group_lightmap_gather(IlmHandle group_lightmap, int32_t gather);
 int32_t ilm_group_lightmap_destroy(IlmHandle group_lightmap);
 

@@ -537,6 +537,7 @@ namespace Squared.Illuminant.Native {
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_lightmap_create (ulong group, int width, int height, int format, ulong* outGroupLightmap);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_lightmap_member (ulong groupLightmap, int localIndex, ulong* outLightmap);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_lightmap_strip (ulong groupLightmap, int rank, int* outRowBegin, int* outRowEnd, int* outSlotRows);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_lightmap_set_strips (ulong groupLightmap, int* rowBegins, int* rowEnds);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_lightmap_gather (ulong groupLightmap, int gather);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_lightmap_destroy (ulong groupLightmap);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_render_sphere_lights (ulong group, LightVertex* lights, int lightCount, IlmEnvironment* env, IlmDistanceFieldUniforms* df, ulong* gbuffers, ulong* sdfs, float* ambient, ulong groupLightmap, int gather, IlmRenderStats* stats);

@@ -93,6 +93,11 @@ def check_lighting(rank, world):
         full[b:e] = torch.from_numpy(part[b:e])
         sharding.all_gather_rows(full, strips, rank, dist)
         assert np.array_equal(full.numpy(), want), "gathered lightmap differs from the single-process frame"
+        # the same strips through the point-to-point range exchange bench.py's N > 1 frames use (group.hip exchange_ranges)
+        full2 = torch.zeros((h, w, 4), dtype=torch.float32)
+        full2[b:e] = torch.from_numpy(part[b:e])
+        sharding.exchange_row_ranges(full2, strips, rank, dist)
+        assert np.array_equal(full2.numpy(), want), "range exchange differs from the single-process frame"
 
 
 def main():

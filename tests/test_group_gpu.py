@@ -223,3 +223,53 @@ def test_host_all_gather_is_the_barrier_and_the_small_exchange(ctx):
     r = native.Group.rank(0, 0, 1, native.Group.unique_id())
     assert r.host_all_gather(struct.pack("<d", 7.25)) == [struct.pack("<d", 7.25)]
     r.close()
+
+
+@pytest.mark.parametrize("members,fmt", [(2, abi.LIGHTMAP_FLOAT4), (3, abi.LIGHTMAP_HALF4), (5, abi.LIGHTMAP_FLOAT4)])
+def test_cost_balanced_strips_are_exchanged_range_by_range(ctx, members, fmt):
+    """ilm_group_lightmap_set_strips with sharding.balanced_row_strips (unequal strips of whole tile bands): every member renders its strip
+    at its true rows, the ranges are pushed to the other members, and every member ends with the single-context frame bit for bit."""
+    from illuminant_amd import sharding
+    layout, atlas, dfu, lights, w, h = small_scene(abi.SDF_FP16)
+    env = scenes.environment()
+    want, wstats = single_context_frame(ctx, lights, env, dfu, atlas, abi.SDF_FP16, w, h, fmt)
+    g = native.Group([0] * members)
+    sdfs = [native.DistanceFieldTexture(c, atlas, abi.SDF_FP16) for c in g.contexts]
+    glm = native.GroupLightmap(g, w, h, fmt)
+    equal = list(glm.strips)
+    strips = sharding.balanced_row_strips(h, members, lights)
+    glm.set_strips(strips)
+    assert glm.strips == strips and strips[0][0] == 0 and strips[-1][1] == h and all(b % 16 == 0 for b, _ in strips)
+    stats = g.render_sphere_lights(lights, env, dfu, None, sdfs, AMBIENT, glm, native.GATHER_PEER, want_stats=True)
+    g.sync()
+    for i in range(members):
+        assert np.array_equal(glm.download(i).view(np.uint8), want.view(np.uint8)), "member %d's composited frame differs" % i
+    assert (stats.SdfSamples, stats.PixelLightPairs, stats.TracedPairs) == (wstats.SdfSamples, wstats.PixelLightPairs, wstats.TracedPairs)
+    # a table that does not tile the frame is refused; NULL restores the equal slots
+    bad = list(strips)
+    bad[-1] = (bad[-1][0], h - 1)
+    with pytest.raises(native.IlluminantError):
+        glm.set_strips(bad)
+    with pytest.raises(native.IlluminantError):
+        glm.set_strips([(b + 8, e) if i == 1 else (b, e) for i, (b, e) in enumerate(strips)])
+    glm.set_strips(None)
+    assert glm.strips == equal
+    glm.close()
+    for s in sdfs:
+        s.close()
+    g.close()
+
+
+def test_unequal_strips_over_rccl_at_world_one(ctx):
+    """The send / receive exchange with a communicator of one rank: nothing to send, the frame is the single-context frame."""
+    layout, atlas, dfu, lights, w, h = small_scene()
+    env = scenes.environment()
+    want, _ = single_context_frame(ctx, lights, env, dfu, atlas, abi.SDF_UNORM16, w, h)
+    g = native.Group([0])
+    sdf = native.DistanceFieldTexture(g.contexts[0], atlas, abi.SDF_UNORM16)
+    glm = native.GroupLightmap(g, w, h)
+    glm.set_strips([(0, h)])
+    g.render_sphere_lights(lights, env, dfu, None, [sdf], AMBIENT, glm, native.GATHER_RCCL)
+    g.sync()
+    assert np.array_equal(glm.download(0), want)
+    glm.close(); sdf.close(); g.close()
