@@ -1,0 +1,509 @@
+"""A second, independent reading of the two headline paths, written from the HLSL text alone ("Next" #6).
+
+    python tests/golden/second_reading.py            (build container; writes tests/golden/second_reading.npz)
+
+oracle/ restates the reference's shaders in C; the kernels are compared with it.  Both have one author, so a misreading of the HLSL
+would pass every parity test.  This file reads the same shaders AGAIN, in float32 numpy, without looking at oracle/ or csrc/ (it
+imports nothing from them): every function below cites the shader lines it transcribes and keeps their statement order and names.
+It cannot make parity "pinned" -- nothing here executes the reference either -- but it removes the single-reader risk on
+
+    L:  sampleGBuffer (no G-buffer bound) -> SphereLightPixelShader -> SphereLightPixelCore -> computeSphereLightOpacity / computeAO /
+        coneTrace -> sampleDistanceFieldEx, over a 64 x 48 frame with 4 lights, additive blend onto Ambient in light order;
+    P:  PS_Gravity -> PS_Noise -> PS_Update (+ computeRenderData) on the 4 096 slots of a 64^2 chunk.
+
+Every operation is rounded to float32 on its own (no fused multiply-adds: the HLSL leaves contraction open; oracle/ fuses in the
+sampler, which is why the test compares at 2e-6, not bit for bit).  Texture fetches follow Direct3D's rules as the shaders declare
+them: LINEAR / U WRAP / V CLAMP for the distance field, POINT for the randomness table, texel centres at +0.5, lerp(a, b, t) = a + (b - a) t
+first along x, then along y.  saturate(NaN) = 0, float % = fmod, sign(0) = 0.
+
+The inputs come from illuminant_amd.scenes (seeded generators and the C#-side uniform builders -- data, not shader code).  The fixture
+holds the outputs only; tests/test_second_reading.py regenerates the inputs from the same seeds and holds oracle/ to the fixture.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from illuminant_amd import abi, scenes   # noqa: E402
+
+F = np.float32
+PI = F(3.14159265358979323846)
+
+
+def saturate(x):
+    x = np.asarray(x, F)
+    return np.where(np.isnan(x), F(0), np.minimum(np.maximum(x, F(0)), F(1))).astype(F)
+
+
+def lerp(a, b, t):
+    return (a + (b - a) * t).astype(F)
+
+
+def length3(x, y, z):
+    return np.sqrt((x * x + y * y + z * z).astype(F)).astype(F)
+
+
+def f4(v):
+    return np.array([v.x, v.y, v.z, v.w], F)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# L: lighting
+# ---------------------------------------------------------------------------------------------------------------------
+
+class Field:
+    """DistanceFieldCommon.fxh:188-263: the uniform block and its accessors, by their HLSL names."""
+
+    def __init__(self, atlas_u16, dfu):
+        self.texture = (atlas_u16.astype(F) / F(65535.0)).astype(F)         # RGBA16 UNORM texels
+        self.height, self.width = atlas_u16.shape[:2]
+        self._ConeAndMisc, self._TextureSliceAndTexelSize = f4(dfu.ConeAndMisc), f4(dfu.TextureSliceAndTexelSize)
+        self._StepAndMisc2, self.TextureSliceCount, self.Extent = f4(dfu.StepAndMisc2), f4(dfu.TextureSliceCount), f4(dfu.Extent)
+        self.DistanceFieldPacked1 = f4(dfu.Packed1)
+        self.samples = 0
+
+    # getDistanceFieldZOffset ... getDistanceTexelSize, :204-260
+    def getDistanceFieldZOffset(self): return self._ConeAndMisc[1]
+    def getMaximumEncodedDistance(self): return self.Extent[3]
+    def getStepLimit(self): return self._StepAndMisc2[0]
+    def getMinStepSize(self): return self.DistanceFieldPacked1[3]
+    def getLongStepFactor(self): return self._StepAndMisc2[2]
+    def getMaxConeRadius(self): return self._ConeAndMisc[0]
+    def getConeGrowthFactor(self): return F(1.0)
+    def getOcclusionToOpacityPower(self): return self._ConeAndMisc[2]
+    def getDistanceSliceSize(self): return self._TextureSliceAndTexelSize[0:2]
+    def getDistanceTexelSize(self): return self._TextureSliceAndTexelSize[2:4]
+    def getMaximumValidZ(self): return self.DistanceFieldPacked1[2]                      # :294-296
+    def getInvSliceCountXTimesOneThird(self): return self.DistanceFieldPacked1[0]        # :298-300
+    def getZToSliceIndex(self): return self.DistanceFieldPacked1[1]                      # :302-304
+
+    def tex2Dlod(self, u, v):
+        """DistanceFieldTextureSampler, :274-281: LINEAR min / mag, AddressU WRAP, AddressV CLAMP, level 0."""
+        x = (u * F(self.width) - F(0.5)).astype(F)
+        y = (v * F(self.height) - F(0.5)).astype(F)
+        x0f, y0f = np.floor(x), np.floor(y)
+        fx, fy = (x - x0f).astype(F), (y - y0f).astype(F)
+        x0 = np.mod(x0f.astype(np.int64), self.width)
+        x1 = np.mod(x0f.astype(np.int64) + 1, self.width)
+        y0 = np.clip(y0f.astype(np.int64), 0, self.height - 1)
+        y1 = np.clip(y0f.astype(np.int64) + 1, 0, self.height - 1)
+        t = self.texture
+        top = lerp(t[y0, x0], t[y0, x1], fx[..., None])
+        bottom = lerp(t[y1, x0], t[y1, x1], fx[..., None])
+        return lerp(top, bottom, fy[..., None])
+
+    def sampleDistanceFieldEx(self, px, py, pz):
+        """DistanceFieldCommon.fxh:313-353, statement by statement."""
+        self.samples += int(np.size(px))
+        DISTANCE_ZERO = F(192.0) / F(255.0)                                                # :8
+        pz = (pz - self.getDistanceFieldZOffset()).astype(F)
+        ex, ey, ez = self.Extent[0], self.Extent[1], self.Extent[2]
+        cx, cy, cz = np.clip(px, F(0), ex), np.clip(py, F(0), ey), np.clip(pz, F(0), ez)  # clamp3(position, 0, extent)
+        # distanceToVolume3 = -min(position, 0) + (max(position, extent) - extent)
+        dx = (-np.minimum(px, F(0)) + (np.maximum(px, ex) - ex)).astype(F)
+        dy = (-np.minimum(py, F(0)) + (np.maximum(py, ey) - ey)).astype(F)
+        dz = (-np.minimum(pz, F(0)) + (np.maximum(pz, ez) - ez)).astype(F)
+        distanceToVolume = length3(dx, dy, dz)
+        slicePosition = (np.minimum(cz, self.getMaximumValidZ()) * self.getZToSliceIndex()).astype(F)
+        virtualSliceIndex = np.floor(slicePosition).astype(F)
+        texel = self.getDistanceTexelSize()
+        texelUvX, texelUvY = (cx * texel[0]).astype(F), (cy * texel[1]).astype(F)
+        # computeDistanceFieldSliceUv, :306-311
+        columnIndex = np.floor((virtualSliceIndex / F(3)).astype(F)).astype(F)
+        rowIndexF = (virtualSliceIndex * self.getInvSliceCountXTimesOneThird()).astype(F)
+        rowIndex = np.floor(rowIndexF).astype(F)
+        slice_size = self.getDistanceSliceSize()
+        u = ((columnIndex * slice_size[0]).astype(F) + texelUvX).astype(F)
+        v = ((rowIndex * slice_size[1]).astype(F) + texelUvY).astype(F)
+        packedSample = self.tex2Dlod(u, v)
+        maskPatternIndex = np.fmod(virtualSliceIndex, F(3))
+        subslice = (slicePosition - virtualSliceIndex).astype(F)
+        r, g, b, a = packedSample[..., 0], packedSample[..., 1], packedSample[..., 2], packedSample[..., 3]
+        blendedSample = np.where(maskPatternIndex >= 2, lerp(b, a, subslice), np.where(maskPatternIndex >= 1, lerp(g, b, subslice), lerp(r, g, subslice)))
+        decodedDistance = ((DISTANCE_ZERO - blendedSample).astype(F) * self.getMaximumEncodedDistance()).astype(F)      # decodeDistance, :268-270
+        return (decodedDistance + distanceToVolume).astype(F)
+
+
+def cone_trace(field, lightCenter, lightRamp, coneGrowthFactorAndDistanceFalloff, sx, sy, sz, enable):
+    """coneTrace, ConeTrace.fxh:148-191, over the arrays of shaded points (sx, sy, sz); `enable` per point."""
+    MIN_CONE_RADIUS, MAX_STEP_RAMP_WINDOW, TRACE_INITIAL_OFFSET_PX = F(0.33), F(2), F(0.5)
+    FULLY_SHADOWED_THRESHOLD, UNSHADOWED_THRESHOLD, HACK_DISTANCE_OFFSET = F(0.075), F(0.95), F(1.5)
+    # coneTraceInitialize, :37-50 (startAtEnd = false)
+    tx, ty, tz = (lightCenter[0] - sx).astype(F), (lightCenter[1] - sy).astype(F), (lightCenter[2] - sz).astype(F)
+    traceLength = length3(tx, ty, tz)
+    with np.errstate(all="ignore"):
+        dirx, diry, dirz = (tx / traceLength).astype(F), (ty / traceLength).astype(F), (tz / traceLength).astype(F)
+    data_y = np.maximum((traceLength - lightRamp[0]).astype(F), F(1))
+    data_x = np.full_like(sx, TRACE_INITIAL_OFFSET_PX)
+    data_z = np.full_like(sx, F(1.0))
+    # createTraceConfig, :128-146
+    maxRadius = np.clip(lightRamp[0], MIN_CONE_RADIUS, field.getMaxConeRadius())
+    rampLength = np.maximum(lightRamp[1], F(16))
+    radiusGrowthPerPixel = F(F(maxRadius / rampLength) * coneGrowthFactorAndDistanceFalloff[0])
+    config = (F(maxRadius), radiusGrowthPerPixel, np.maximum(F(1), field.getMinStepSize()), coneGrowthFactorAndDistanceFalloff[1])
+    stepsRemaining = np.full_like(sx, field.getStepLimit())
+    liveness = ((field.Extent[0] > 0) & enable).astype(F)
+    while True:
+        live = liveness > 0
+        if not live.any():
+            break
+        stepsRemaining[live] = (stepsRemaining[live] - F(1)).astype(F)
+        # coneTraceAdvance, :75-85
+        ox = (sx[live] + (dirx[live] * data_x[live]).astype(F)).astype(F)
+        oy = (sy[live] + (diry[live] * data_x[live]).astype(F)).astype(F)
+        oz = (sz[live] + (dirz[live] * data_x[live]).astype(F)).astype(F)
+        sample = field.sampleDistanceFieldEx(ox, oy, oz)
+        # coneTraceStep, :52-73
+        localSphereRadius = np.minimum(((config[1] * data_x[live]).astype(F) + MIN_CONE_RADIUS).astype(F), config[0])
+        localVisibility = ((sample + HACK_DISTANCE_OFFSET).astype(F) / localSphereRadius).astype(F)
+        data_z[live] = np.minimum(data_z[live], localVisibility)
+        step = np.maximum((np.abs(sample) * field.getLongStepFactor()).astype(F), config[2])
+        data_x[live] = (data_x[live] + step).astype(F)
+        stepLiveness = (saturate(data_z[live] - FULLY_SHADOWED_THRESHOLD) * saturate(data_y[live] - data_x[live])).astype(F)
+        liveness[live] = (stepsRemaining[live] * stepLiveness).astype(F)
+    # (if (stepsRemaining == 0) traceA.data.x = traceA.data.y: data.x is not read again)
+    stepWindowVisibility = (stepsRemaining / MAX_STEP_RAMP_WINDOW).astype(F)
+    visibility = np.minimum(data_z, stepWindowVisibility)
+    base = saturate((saturate(visibility - FULLY_SHADOWED_THRESHOLD) / F(UNSHADOWED_THRESHOLD - FULLY_SHADOWED_THRESHOLD)).astype(F))
+    finalResult = np.power(base, field.getOcclusionToOpacityPower()).astype(F)
+    return np.where(enable, finalResult, F(1.0)).astype(F)
+
+
+def compute_sphere_light_opacity(px, py, pz, nx, ny, nz, lightCenter, lightProperties, yDistanceFactor, lightOcclusion):
+    """computeSphereLightOpacity + computeNormalFactor(Ex), LightCommon.fxh:154-214."""
+    DOT_OFFSET, DOT_RAMP_RANGE, DOT_EXPONENT = F(0.15), F(0.15), F(0.85)
+    lightRadius, lightRampLength, falloffMode = lightProperties[0], lightProperties[1], lightProperties[2]
+    d3x, d3y, d3z = (px - lightCenter[0]).astype(F), (py - lightCenter[1]).astype(F), (pz - lightCenter[2]).astype(F)
+    d3y = (d3y * yDistanceFactor).astype(F)
+    distance = length3(d3x, d3y, d3z)
+    distanceFactor = (F(1) - saturate(((distance - lightRadius).astype(F) / lightRampLength).astype(F))).astype(F)
+    if lightOcclusion > 0:
+        distanceFactor = (distanceFactor * (F(1) - saturate((d3z / lightOcclusion).astype(F))).astype(F)).astype(F)
+    with np.errstate(all="ignore"):
+        lnx, lny, lnz = (d3x / distance).astype(F), (d3y / distance).astype(F), (d3z / distance).astype(F)
+    any_normal = (nx != 0) | (ny != 0) | (nz != 0)
+    d = ((((-lnx) * nx).astype(F) + ((-lny) * ny).astype(F)).astype(F) + ((-lnz) * nz).astype(F)).astype(F)
+    normalFactor = np.where(any_normal, np.power(saturate(((d + DOT_OFFSET).astype(F) / DOT_RAMP_RANGE).astype(F)), DOT_EXPONENT), F(1)).astype(F)
+    if falloffMode >= 2:
+        distanceFactor = (F(1) - saturate((distance - lightRadius).astype(F))).astype(F)
+        normalFactor = np.ones_like(normalFactor)
+    elif falloffMode >= 1:
+        distanceFactor = (distanceFactor * distanceFactor).astype(F)
+    return saturate(((normalFactor * distanceFactor).astype(F) + saturate((lightRadius - distance).astype(F))).astype(F)), distance
+
+
+def light_frame(atlas_u16, dfu, env, lights, ambient, width, height):
+    """One RenderLighting of the SphereLight technique without a G-buffer: ClearColor = Ambient, then every light's quad in order
+    with additive blending (LightingRenderer.cs:1004-1169)."""
+    field = Field(atlas_u16, dfu)
+    SELF_OCCLUSION_HACK, SHADOW_OPACITY_THRESHOLD = F(1.6), F(0.75) / F(255.0)          # SphereLightCore.fxh:10-11
+    ZAndScale, ZToY, GB = f4(env.ZAndScale), f4(env.ZToY), f4(env.GBufferTexelSizeAndMisc)
+    vp = np.array([env.ViewportPosition[0], env.ViewportPosition[1]], F)
+    assert GB[0] == 0 and GB[1] == 0, "this reading covers sampleGBuffer's else branch (no G-buffer)"
+    jj, ii = np.mgrid[0:height, 0:width]
+    vposx, vposy = ii.astype(F), jj.astype(F)                                             # GET_VPOS = floor(VPOS)
+    # sampleGBuffer, LightCommon.fxh:128-139
+    spx, spy = (vposx / ZAndScale[2]).astype(F), (vposy / ZAndScale[3]).astype(F)
+    camx, camy, camz = spx, spy, np.full_like(spx, F(ZAndScale[1] + F(0.01)))
+    wpx, wpy = ((spx / GB[2]).astype(F) + vp[0]).astype(F), ((spy / GB[3]).astype(F) + vp[1]).astype(F)
+    wpz = np.full_like(spx, ZAndScale[0])
+    nx, ny, nz = np.zeros_like(spx), np.zeros_like(spx), np.ones_like(spx)
+    out = np.empty((height, width, 4), F)
+    out[...] = np.asarray(ambient, F)
+    pairs = traced = 0
+    cxp, cyp = (vposx + F(0.5)).astype(F), (vposy + F(0.5)).astype(F)                    # pixel centres
+    for L in lights:
+        lightCenter = f4(L.LightPosition1)[:3]
+        lightProperties, more, evenMore = f4(L.LightProperties), f4(L.MoreLightProperties), f4(L.EvenMoreLightProperties)
+        color, specular = f4(L.Color1), f4(L.Color2)
+        # SphereLightVertexShader, SphereLightCore.fxh:13-56, over the 12 corner weights of FillSphereBuffer (LightingRenderer.cs:636-656)
+        radius = F(F(lightProperties[0] + lightProperties[1]) + F(1))
+        deltaY = F(radius - F(radius / more[2]))
+        r3 = np.array([radius, F(radius - F(deltaY / F(2.0)))], F)
+        tl, br = (lightCenter[:2] - r3).astype(F), (lightCenter[:2] + r3).astype(F)
+        radiusOffset, zOffset = F(radius * ZToY[1]), F(lightCenter[2] * ZToY[0])
+        cOne, mOne = F(1.0) / F(7.0), F(6.0) / F(7.0)
+        covered = np.zeros((height, width), bool)
+        for (u0, u1, v0, v1) in ((cOne, mOne, F(0), F(1)), (mOne, F(1), cOne, mOne), (F(0), cOne, cOne, mOne)):
+            def corner(u, v):
+                wx, wy = F(tl[0] + F(F(br[0] - tl[0]) * u)), F(tl[1] + F(F(br[1] - tl[1]) * v))
+                if v < 0.5:
+                    wy = F(F(wy - radiusOffset) - zOffset)
+                scale_x, scale_y = F(GB[2] * ZAndScale[2]), F(GB[3] * ZAndScale[3])
+                return F(F(wx - vp[0]) * scale_x), F(F(wy - vp[1]) * scale_y)
+            x0, y0 = corner(u0, v0)
+            x1, y1 = corner(u1, v1)
+            covered |= (cxp >= x0) & (cxp < x1) & (cyp >= y0) & (cyp < y1)                # pixel centre inside the rectangle
+        pairs += int(covered.sum())
+        # SphereLightPixelShader, SphereLight.fx:7-46 (no G-buffer: enableShadows = true, fullbright = false)
+        filt = evenMore[0]
+        if not (filt < 0) and ((filt > 0.5) != True):                                     # checkShadowFilter, LightCommon.fxh:146-152
+            continue
+        sel = covered
+        px_, py_, pz_ = wpx[sel], wpy[sel], wpz[sel]
+        nx_, ny_, nz_ = nx[sel], ny[sel], nz[sel]
+        # SphereLightPixelPrologue, SphereLightCore.fxh:58-81
+        distanceOpacity, _ = compute_sphere_light_opacity(px_, py_, pz_, nx_, ny_, nz_, lightCenter, lightProperties, more[2], ZToY[2])
+        visible = (distanceOpacity > 0) & (px_ > -9999)
+        aoRadius = (more[0] * np.maximum(F(0), nz_)).astype(F)
+        # computeAO, AOCommon.fxh:1-19
+        aoOpacity = np.ones_like(px_)
+        do_ao = (aoRadius >= 0.5) & (field.Extent[0] > 0) & visible
+        if do_ao.any():
+            dist = field.sampleDistanceFieldEx(px_[do_ao], py_[do_ao], (pz_[do_ao] + (nz_[do_ao] * aoRadius[do_ao]).astype(F)).astype(F))
+            clamped = np.clip(dist, F(0), aoRadius[do_ao])
+            res = (F(1) - saturate((clamped / aoRadius[do_ao]).astype(F))).astype(F)
+            res = (res * res).astype(F)
+            res = (F(1) - res).astype(F)
+            aoOpacity[do_ao] = (F(F(1) - more[3]) + (res * more[3]).astype(F)).astype(F)
+        preTraceOpacity = (distanceOpacity * aoOpacity).astype(F)
+        traceShadows = visible & (lightProperties[3] != 0) & (preTraceOpacity >= SHADOW_OPACITY_THRESHOLD)
+        traced += int(traceShadows.sum())
+        coneOpacity = cone_trace(field, lightCenter, lightProperties[0:2], (field.getConeGrowthFactor(), more[1]),
+                                 (px_ + (SELF_OCCLUSION_HACK * nx_).astype(F)).astype(F), (py_ + (SELF_OCCLUSION_HACK * ny_).astype(F)).astype(F),
+                                 (pz_ + (SELF_OCCLUSION_HACK * nz_).astype(F)).astype(F), traceShadows)
+        opacity = (preTraceOpacity * coneOpacity).astype(F)                               # SphereLightPixelEpilogue, :83-97
+        # CalcSphereLightSpecularity, LightCommon.fxh:216-226
+        ldx, ldy, ldz = (px_ - lightCenter[0]).astype(F), (py_ - lightCenter[1]).astype(F), (pz_ - lightCenter[2]).astype(F)
+        vx, vy, vz = (camx[sel] - px_).astype(F), (camy[sel] - py_).astype(F), (camz[sel] - pz_).astype(F)
+        vl = length3(vx, vy, vz)
+        hx, hy, hz = ((vx / vl).astype(F) - ldx).astype(F), ((vy / vl).astype(F) - ldy).astype(F), ((vz / vl).astype(F) - ldz).astype(F)
+        hl = length3(hx, hy, hz)
+        hx, hy, hz = (hx / hl).astype(F), (hy / hl).astype(F), (hz / hl).astype(F)
+        hdotn = (((hx * nx_).astype(F) + (hy * ny_).astype(F)).astype(F) + (hz * nz_).astype(F)).astype(F)
+        specularity = np.power(saturate(hdotn), specular[3]).astype(F)
+        contribution = np.empty(px_.shape + (4,), F)
+        for c in range(3):
+            contribution[:, c] = ((F(color[c] * color[3]) * opacity).astype(F) + ((specular[c] * specularity).astype(F) * opacity).astype(F)).astype(F)
+        contribution[:, 3] = F(1)
+        drawn = visible                                                                    # discard when !visible
+        target = out[sel]
+        target[drawn] = (target[drawn] + contribution[drawn]).astype(F)                    # BlendState: ONE, ONE
+        out[sel] = target
+    return out, (field.samples, pairs, traced)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# P: particles (one 64^2 chunk, slot = x + y * 64, VPOS = (x, y))
+# ---------------------------------------------------------------------------------------------------------------------
+
+class System:
+    def __init__(self, u):
+        self.GlobalSettings, self.CollisionSettings = f4(u.GlobalSettings), f4(u.CollisionSettings)
+        self.TexelAndSize, self.AnimationRateAndRotationAndZToY = f4(u.TexelAndSize), f4(u.AnimationRateAndRotationAndZToY)
+
+    VelocityConstantScale = F(1000)
+    def getDeltaTimeSeconds(self): return F(self.GlobalSettings[0] / self.VelocityConstantScale)       # ParticleCommon.fxh:60-62
+    def getDeltaTime(self): return self.GlobalSettings[0]
+    def getFriction(self): return self.GlobalSettings[1]
+    def getMaximumVelocity(self): return self.GlobalSettings[2]
+    def getLifeDecayRate(self): return self.GlobalSettings[3]
+    def getVelocityRotation(self): return self.AnimationRateAndRotationAndZToY[2]
+
+
+def normalize3(v):
+    with np.errstate(all="ignore"):
+        l = length3(v[:, 0], v[:, 1], v[:, 2])
+        return (v / l[:, None]).astype(F)
+
+
+def ps_gravity(sysu, g, position, velocity):
+    """PS_Gravity, Gravity.fx:12-61."""
+    newPosition, oldVelocity = position.copy(), velocity.copy()
+    cf = (F(g.CategoryFilter[0]), F(g.CategoryFilter[1]))
+    skip = (newPosition[:, 3] <= 0) | ~((oldVelocity[:, 3] >= cf[0]) & (oldVelocity[:, 3] <= cf[1]))
+    acceleration = np.zeros((position.shape[0], 3), F)
+    for i in range(g.AttractorCount):
+        apos = np.array(list(g.AttractorPositions[i]), F)
+        ars = np.array(list(g.AttractorRadiusesAndStrengths[i]), F)
+        toCenter = (apos[None, :] - newPosition[:, :3]).astype(F)
+        if ars[2] >= 0.5:
+            distance = length3(toCenter[:, 0], toCenter[:, 1], toCenter[:, 2])
+            attraction = (F(1) - saturate((distance / ars[0]).astype(F))).astype(F)
+            if ars[2] >= 1.5:
+                attraction = (attraction * attraction).astype(F)
+            attraction = ((attraction * sysu.getDeltaTime()).astype(F) / System.VelocityConstantScale).astype(F)
+        else:
+            dot = (((toCenter[:, 0] * toCenter[:, 0]).astype(F) + (toCenter[:, 1] * toCenter[:, 1]).astype(F)).astype(F) + (toCenter[:, 2] * toCenter[:, 2]).astype(F)).astype(F)
+            distanceSquared = np.maximum((dot - ars[0]).astype(F), F(0.001))
+            attraction = (F(1) / distanceSquared).astype(F)
+        newAccel = ((normalize3(toCenter) * attraction[:, None]).astype(F) * ars[1]).astype(F)
+        acceleration = (acceleration + newAccel).astype(F)
+    maximumAcceleration = F(F(F(g.MaximumAcceleration) * sysu.getDeltaTime()) / System.VelocityConstantScale)
+    currentLength = length3(acceleration[:, 0], acceleration[:, 1], acceleration[:, 2])
+    over = currentLength > maximumAcceleration
+    acceleration[over] = (normalize3(acceleration[over]) * maximumAcceleration).astype(F)
+    newVelocity = oldVelocity.copy()
+    newVelocity[:, :3] = np.minimum(sysu.getMaximumVelocity(), (oldVelocity[:, :3] + acceleration).astype(F))
+    newVelocity[skip] = oldVelocity[skip]
+    return newPosition, newVelocity
+
+
+def random_custom(table, xy, offset, rate, texel):
+    """randomCustom, RandomCommon.fxh:28-31, RandomnessSampler POINT / WRAP."""
+    h, w = table.shape[:2]
+    u = ((((xy[:, 0] * rate[0]).astype(F) + offset[0]).astype(F)) * texel[0]).astype(F)
+    v = ((((xy[:, 1] * rate[1]).astype(F) + offset[1]).astype(F)) * texel[1]).astype(F)
+    tx = np.mod(np.floor((u * F(w)).astype(F)).astype(np.int64), w)
+    ty = np.mod(np.floor((v * F(h)).astype(F)).astype(np.int64), h)
+    return table[ty, tx]
+
+
+def ps_noise(sysu, n, table, xy, position, velocity):
+    """PS_Noise, Noise.fx:28-72 with AreaType 0 (evaluateNone = 0, DistanceFunctionCommon.fxh:7-11)."""
+    oldPosition, oldVelocity = position, velocity
+    cf = (F(n.Area.CategoryFilter[0]), F(n.Area.CategoryFilter[1]))
+    passes = (oldVelocity[:, 3] >= cf[0]) & (oldVelocity[:, 3] <= cf[1])
+    with np.errstate(all="ignore"):
+        weight = F(F(F(1) - saturate(F(0) / F(n.Area.AreaFalloff))) * F(n.Area.Strength))       # computeWeight, :21-26
+    t = F(F(weight * sysu.getDeltaTime()) / F(n.TimeDivisor))
+    texel = (F(1.0) / F(table.shape[1]), F(1.0) / F(table.shape[0]))                       # RandomnessTexel
+    off, noff = (F(n.RandomnessOffset[0]), F(n.RandomnessOffset[1])), (F(n.NextRandomnessOffset[0]), F(n.NextRandomnessOffset[1]))
+    xy2 = (xy + np.array([2, 1], F)).astype(F)
+    randomP1, randomP2 = random_custom(table, xy, off, texel, texel), random_custom(table, xy, noff, texel, texel)
+    randomV1, randomV2 = random_custom(table, xy2, off, texel, texel), random_custom(table, xy2, noff, texel, texel)
+    fl = F(n.FrequencyLerp)
+    randomP, randomV = lerp(randomP1, randomP2, fl), lerp(randomV1, randomV2, fl)
+
+    def shaped(rnd, offset, minimum, scale):
+        delta = (rnd + f4(offset)[None, :]).astype(F)
+        delta = (np.sign(delta) * np.maximum(np.abs(delta), f4(minimum)[None, :])).astype(F)
+        return (delta * f4(scale)[None, :]).astype(F)
+    positionDelta = shaped(randomP, n.PositionOffset, n.PositionMinimum, n.PositionScale)
+    velocityDelta = shaped(randomV, n.VelocityOffset, n.VelocityMinimum, n.VelocityScale)
+    newPosition = lerp(oldPosition, (oldPosition + positionDelta).astype(F), t)
+    newVelocity = oldVelocity.copy()
+    if n.ReplaceOldVelocity != 0:
+        newVelocity[:, :3] = lerp(oldVelocity[:, :3], velocityDelta[:, :3], weight)
+    else:
+        newVelocity[:, :3] = lerp(oldVelocity[:, :3], (oldVelocity[:, :3] + velocityDelta[:, :3]).astype(F), t)
+    newVelocity[:, :3] = (newVelocity[:, :3] + (normalize3(oldVelocity[:, :3]) * velocityDelta[:, 3:4]).astype(F)).astype(F)
+    newPosition[~passes], newVelocity[~passes] = oldPosition[~passes], oldVelocity[~passes]
+    return newPosition, newVelocity
+
+
+def evaluate_bezier(rangeAndCount, abcd, value):
+    """tForScaledBezier + evaluateBezier{1,4}AtT, Bezier.fxh:22-64 and on, for the clamped, unshaped curves of up to two points this
+    fixture uses (count <= 2.5: a, or lerp(a, b, t))."""
+    rc = f4(rangeAndCount)
+    mode = int(abs(rc[3]))
+    assert mode == 0, "clamped, unshaped curves only"
+    t = ((value - rc[0]).astype(F) * F(abs(rc[1]))).astype(F)
+    t = (F(1) - saturate(t)).astype(F) if rc[1] < 0 else saturate(t)
+    count = rc[2]
+    assert count <= 2.5
+    a, b = abcd[0], abcd[1]
+    if count <= 1.5:
+        return np.broadcast_to(np.asarray(a, F), value.shape + np.shape(a)).astype(F)
+    return lerp(np.asarray(a, F), np.asarray(b, F), t[..., None] if np.ndim(a) else t)
+
+
+def ps_update(sysu, upd, xy, position, velocity, attributes):
+    """PS_Update, UpdateParticleSystem.fx:9-38 + applyFrictionAndMaximum / computeRenderData, UpdateCommon.fxh:20-36,97-117."""
+    n = position.shape[0]
+    newPosition, newVelocity = np.zeros((n, 4), F), np.zeros((n, 4), F)
+    renderColor, renderData = np.zeros((n, 4), F), np.zeros((n, 4), F)
+    alive = position[:, 3] > 0                                                              # readStateOrDiscard: dead slots keep the cleared target
+    oldPosition, oldVelocity = position[alive], velocity[alive]
+    # applyFrictionAndMaximum
+    l = length3(oldVelocity[:, 0], oldVelocity[:, 1], oldVelocity[:, 2])
+    tiny = l <= 0.001
+    l2 = np.minimum(l, sysu.getMaximumVelocity())
+    friction = (l2 * sysu.getFriction()).astype(F)
+    l2 = (l2 - (friction * sysu.getDeltaTimeSeconds()).astype(F)).astype(F)
+    l2 = np.clip(l2, F(0), sysu.getMaximumVelocity())
+    vel3 = (normalize3(oldVelocity[:, :3]) * l2[:, None]).astype(F)
+    vel3[tiny] = 0
+    scaledVelocity = (vel3 * sysu.getDeltaTimeSeconds()).astype(F)
+    newLife = (oldPosition[:, 3] - F(sysu.getLifeDecayRate() * sysu.getDeltaTimeSeconds())).astype(F)
+    np_, nv_ = np.zeros_like(oldPosition), np.zeros_like(oldVelocity)
+    lives = newLife > 0
+    np_[lives, :3] = (oldPosition[lives, :3] + scaledVelocity[lives]).astype(F)
+    np_[lives, 3] = newLife[lives]
+    nv_[lives, :3] = vel3[lives]
+    nv_[lives, 3] = oldVelocity[lives, 3]
+    # computeRenderData
+    vpos = xy[alive]
+    index = (vpos[:, 0] + (vpos[:, 1] * F(256)).astype(F)).astype(F)
+    velocityLength = np.maximum(length3(nv_[:, 0], nv_[:, 1], nv_[:, 2]), F(0.0001))
+    life = np_[:, 3]
+    color = (evaluate_bezier(upd.ColorFromLife.RangeAndCount, (f4(upd.ColorFromLife.A), f4(upd.ColorFromLife.B)), life) *
+             evaluate_bezier(upd.ColorFromVelocity.RangeAndCount, (f4(upd.ColorFromVelocity.A), f4(upd.ColorFromVelocity.B)), velocityLength)).astype(F)
+    assert f4(upd.LifeRampSettings)[0] == 0                                                 # getRampedColorForLifeValueAndIndex: no life ramp
+    rc = (attributes[alive] * color).astype(F)
+    rc[:, 3] = saturate(rc[:, 3])
+    rc[:, :3] = (rc[:, :3] * rc[:, 3:4]).astype(F)
+    size = (evaluate_bezier(upd.SizeFromLife.RangeAndCount, f4(upd.SizeFromLife.ABCD), life) *
+            evaluate_bezier(upd.SizeFromVelocity.RangeAndCount, f4(upd.SizeFromVelocity.ABCD), velocityLength)).astype(F)
+    # getRotationForVelocity, :82-95
+    still = (np.abs(nv_[:, 0]) < 0.01) & (np.abs(nv_[:, 1]) < 0.01)
+    angle = np.arctan2(nv_[:, 1], nv_[:, 0]).astype(F)
+    angle = np.where(angle < 0, (angle + F(F(2) * PI)).astype(F), angle)
+    angle = np.where(still, F(0), angle).astype(F)
+    rfl = (F(upd.RotationFromLifeAndIndex[0]), F(upd.RotationFromLifeAndIndex[1]))
+    rd = np.zeros_like(rc)
+    rd[:, 0] = size
+    rd[:, 1] = ((angle * sysu.getVelocityRotation()).astype(F) + ((life * rfl[0]).astype(F) + (index * rfl[1]).astype(F)).astype(F)).astype(F)
+    rd[:, 2] = velocityLength
+    rd[:, 3] = nv_[:, 3]
+    dead_now = ~lives                                                                        # computeRenderData: position.w <= 0 -> zeros
+    rc[dead_now], rd[dead_now] = 0, 0
+    newPosition[alive], newVelocity[alive], renderColor[alive], renderData[alive] = np_, nv_, rc, rd
+    return newPosition, newVelocity, renderColor, renderData
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the fixture's inputs (shared with tests/test_second_reading.py) and the generator
+# ---------------------------------------------------------------------------------------------------------------------
+
+def lighting_inputs():
+    w, h = 64, 48
+    layout = scenes.DistanceFieldLayout(128, 96, 64.0, 9, 0.5)
+    atlas = scenes.build_sdf_atlas(layout, scenes.random_obstacles(5, 7, (128, 96), 5.0, 16.0, 40.0))
+    dfu = layout.uniforms(power=0.7, min_step_size=1.0, long_step_factor=0.5)
+    lights = list(scenes.random_lights(21, 3, w, h, z=(6.0, 40.0), radius=5.0, ramp=(25.0, 70.0)))
+    lights.append(scenes.sphere_light((40.0, 20.0, 30.0), 4.0, 45.0, color=(0.9, 0.6, 0.3, 1.0), ao_radius=12.0, ao_opacity=0.8,
+                                      specular=(0.2, 0.3, 0.4), specular_power=6.0, falloff_y=1.5))
+    env = scenes.environment(maximum_z=64.0)
+    return dict(width=w, height=h, atlas=atlas, dfu=dfu, lights=lights, env=env, ambient=(0.04, 0.05, 0.06, 1.0))
+
+
+def particle_inputs():
+    cs = 64
+    n = cs * cs
+    pos, vel, attr = scenes.make_particles(77, n, pos_lo=(0, 0, 0), pos_hi=(256, 256, 32), dead_fraction=0.2, life=(0.005, 4.0))
+    rnd = scenes.randomness_table(9)
+    sysu = scenes.system_uniforms(cs, friction=0.15, max_velocity=90.0, life_decay=1.5, rotation_from_velocity=True)
+    g = scenes.gravity_params([((128.0, 100.0, 4.0), 90.0, 70.0, 1), ((30.0, 200.0, 0.0), 120.0, 40.0, 2), ((200.0, 40.0, 10.0), 15.0, 900.0, 0)],
+                              maximum_acceleration=6.0)
+    nz = scenes.noise_params(scenes.area_none(strength=0.8), (37.0 * 253 / 1000.0, 11.0 * 127 / 1000.0), (591.0 * 253 / 1000.0, 220.0 * 127 / 1000.0), 0.35,
+                             replace_old_velocity=False, position=((-0.5,) * 4, (0.05,) * 4, (3.0, 3.0, 1.0, 0.0)),
+                             velocity=((-0.5,) * 3, (0.1,) * 3, (20.0, 20.0, 5.0)), speed=(-0.5, 0.0, 2.0))
+    upd = abi.UpdateParams.default()
+    upd.RotationFromLifeAndIndex[0], upd.RotationFromLifeAndIndex[1] = 0.25, 0.001
+    return dict(chunk_size=cs, pos=pos, vel=vel, attr=attr, rnd=rnd, system=sysu, gravity=g, noise=nz, update=upd)
+
+
+def main():
+    L = lighting_inputs()
+    frame, (samples, pairs, traced) = light_frame(L["atlas"], L["dfu"], L["env"], L["lights"], L["ambient"], L["width"], L["height"])
+    P = particle_inputs()
+    cs = P["chunk_size"]
+    slots = np.arange(cs * cs)
+    xy = np.stack([(slots % cs).astype(F), (slots // cs).astype(F)], axis=1)
+    sysu = System(P["system"])
+    p1, v1 = ps_gravity(sysu, P["gravity"], P["pos"], P["vel"])
+    p2, v2 = ps_noise(sysu, P["noise"], P["rnd"], xy, p1, v1)
+    p3, v3, rc, rd = ps_update(sysu, P["update"], xy, p2, v2, P["attr"])
+    out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "second_reading.npz")
+    np.savez_compressed(out, lightmap=frame, light_counts=np.array([samples, pairs, traced], np.int64),
+                        after_gravity_velocity=v1, after_noise_position=p2, after_noise_velocity=v2,
+                        position=p3, velocity=v3, render_color=rc, render_data=rd)
+    print("wrote %s: %d SDF samples, %d pixel-light pairs, %d traced; %d live particles of %d" % (out, samples, pairs, traced, int((p3[:, 3] > 0).sum()), cs * cs))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,81 @@
+"""Holds oracle/ to the second, independent reading of the HLSL (tests/golden/second_reading.py -> second_reading.npz; CPU only).
+
+The fixture was computed in float32 numpy directly from the shader text (no fused multiply-adds, libm transcendentals); the oracle is
+the C restatement the kernels are compared with.  Integer results must agree exactly: the SDF sample / pixel-light pair / traced-pair
+counts of the lit frame, the liveness of every particle slot.  Floats agree to 2e-6 of the component's scale (the oracle fuses the
+sampler's multiply-adds where the device does; nothing else differs).  It does not pin parity -- neither side executes the reference --
+but a misreading shared by oracle and kernels would have to be made a third time, independently, to survive this test."""
+import importlib.util
+import os
+
+import numpy as np
+
+from illuminant_amd import abi
+from tests.util import assert_close
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+spec = importlib.util.spec_from_file_location("second_reading", os.path.join(HERE, "golden", "second_reading.py"))
+second = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(second)
+
+FIX = np.load(os.path.join(HERE, "golden", "second_reading.npz"))
+TOL = dict(rtol=2e-6, atol=2e-6)
+
+
+def test_lit_frame_of_the_second_reading(oracle):
+    L = second.lighting_inputs()
+    lights = (abi.LightVertex * len(L["lights"]))(*L["lights"])
+    tex = oracle.make_texture(L["atlas"], abi.SDF_UNORM16)
+    frame, stats = oracle.render_sphere_lights(lights, L["env"], L["dfu"], None, tex, L["ambient"], L["width"], L["height"], want_stats=True)
+    assert [int(stats.SdfSamples), int(stats.PixelLightPairs), int(stats.TracedPairs)] == [int(v) for v in FIX["light_counts"]]
+    # 2e-6 everywhere but where the trace ends within rounding of FULLY_SHADOWED_THRESHOLD: saturate(visibility - 0.075) cancels there and
+    # pow(., 0.7) amplifies what is left (two pixels of this frame, 2e-5 relative) -- those must still meet the north star's 1e-4
+    assert_close(frame, FIX["lightmap"], "oracle lightmap vs the second reading (north-star tolerance)")
+    err = np.abs(frame.astype(np.float64) - FIX["lightmap"]) - 2e-6 * np.abs(FIX["lightmap"]) - 2e-6 * np.abs(FIX["lightmap"]).reshape(-1, 4).max(axis=0)
+    assert (err > 0).sum() <= 12, "%d elements of the lightmap differ from the second reading by more than 2e-6" % int((err > 0).sum())
+    # the frame is a real one: most pixels lit by several lights, shadows present
+    assert (FIX["lightmap"][..., 3] >= 3.0).mean() > 0.5 and FIX["light_counts"][2] > 5000 and FIX["light_counts"][0] > 8 * FIX["light_counts"][2] // 2
+
+
+def test_particle_passes_of_the_second_reading(oracle):
+    P = second.particle_inputs()
+    cs = P["chunk_size"]
+    n = cs * cs
+
+    def desc(ops, mode):
+        d = abi.StepDesc()
+        d.FirstChunk, d.ChunkCount = 0, -1
+        d.System = P["system"]
+        d.Update = P["update"]
+        d.OpCount = len(ops)
+        for i, (typ, params) in enumerate(ops):
+            d.Ops[i].Type = typ
+            if typ == abi.OP_GRAVITY:
+                d.Ops[i].u.Gravity = params
+            else:
+                d.Ops[i].u.Noise = params
+        d.UpdateMode = mode
+        d.Flags = abi.STEP_COUNT_LIVE
+        return d
+
+    def fresh():
+        return [P["pos"].copy(), P["vel"].copy(), P["attr"].copy(), np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)]
+
+    # pass by pass, as the reference draws them (each technique reads the previous one's targets)
+    chunk = fresh()
+    oracle.step([chunk], cs, P["rnd"], desc([(abi.OP_GRAVITY, P["gravity"])], abi.UPDATE_NONE))
+    assert_close(chunk[1], FIX["after_gravity_velocity"], "velocity after PS_Gravity", **TOL)
+    oracle.step([chunk], cs, P["rnd"], desc([(abi.OP_NOISE, P["noise"])], abi.UPDATE_NONE))
+    assert_close(chunk[0], FIX["after_noise_position"], "position after PS_Noise", **TOL)
+    assert_close(chunk[1], FIX["after_noise_velocity"], "velocity after PS_Noise", **TOL)
+    # and the whole Update in one step
+    chunk = fresh()
+    counts = oracle.step([chunk], cs, P["rnd"], desc([(abi.OP_GRAVITY, P["gravity"]), (abi.OP_NOISE, P["noise"])], abi.UPDATE_POSITIONS), want_counts=True)
+    assert np.array_equal(chunk[0][:, 3] > 0, FIX["position"][:, 3] > 0), "liveness differs from the second reading"
+    assert int(counts[0]) == int((FIX["position"][:, 3] > 0).sum())
+    assert_close(chunk[0], FIX["position"], "PositionAndLife after PS_Update", **TOL)
+    assert_close(chunk[1], FIX["velocity"], "Velocity after PS_Update", **TOL)
+    assert_close(chunk[3], FIX["render_color"], "RenderColor", **TOL)
+    assert_close(chunk[4], FIX["render_data"], "RenderData", **TOL)
+    live = FIX["position"][:, 3] > 0
+    assert 0.5 < live.mean() < 0.9 and (P["pos"][:, 3] > 0).sum() > live.sum()          # some particles die in this step
