@@ -625,6 +625,27 @@ def main():
                 "algorithmic_rate": {"value": round(alg_bytes / (kern_ms * 1e-3) / 1e9, 1), "unit": "GB/s", "bytes_per_unit": SDF_SAMPLE_BYTES,
                                      "units_per_launch": samples, "gsamples_per_s": round(samples / (kern_ms * 1e-3) / 1e9, 2)},
             }
+            if world == 1:
+                # How far is the parity frame (fp32 accumulation over the lights) from what the reference's HalfVector4 render target would
+                # hold (rounded by the ROP after every light, ilm_ctx_set_lightmap_blend)?  Same kernel, same lights, both read back.
+                def read_frame():
+                    raw = np.asarray(r.ReadLightmap(0, h))
+                    return (raw.view(np.float16) if raw.dtype == np.uint16 else raw).astype(np.float32)
+                plain = read_frame()
+                nctx_b = native.Context(local_rank, borrowed_handle=ctx.Handle)
+                nctx_b.set_lightmap_blend(True)
+                r.RenderLighting(1.0, row_begin, row_end, False)
+                ctx.Sync()
+                nctx_b.set_lightmap_blend(False)
+                rop = read_frame()
+                r.RenderLighting(1.0, row_begin, row_end, False)
+                rel = np.abs(rop[..., :3] - plain[..., :3]) / np.maximum(np.abs(plain[..., :3]), 1e-3)
+                lighting[name]["fp16_per_light_blend_vs_fp32_accumulate"] = {
+                    "max_relative_rgb": round(float(rel.max()), 6), "mean_relative_rgb": round(float(rel.mean()), 7),
+                    "texels_that_differ": round(float((rop[..., :3] != plain[..., :3]).any(axis=-1).mean()), 4),
+                    "lights_per_pixel_max": int(plain[..., 3].max() - 1.0),
+                    "note": "the reference's lightmap is HalfVector4 and its ROP rounds after every light (LightingRenderer.cs:476-479); the 1e-4 parity "
+                            "bar is defined against fp32 accumulation (both read back from the fp16 lightmap here)"}
             if glm is not None:
                 # the composite entry point a C# host calls (ilm_group_render_sphere_lights: strip + gather in one call) must give
                 # the frame the mirror-rendered strip + ilm_group_lightmap_gather gave: checksum of both on rank 0's copy

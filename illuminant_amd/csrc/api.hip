@@ -93,6 +93,7 @@ struct Ctx {
     void* d_pl_recs = nullptr; int pl_cap = 0; int32_t* d_pl_count = nullptr; int32_t* d_pl_blocks = nullptr; int pl_blocks_cap = 0;
     int32_t* d_pl_quads = nullptr; int pl_quads_cap = 0;
     float4* d_light_ramp = nullptr; int light_ramp_w = 0, light_ramp_h = 0;    // RampTexture of the light group being rendered
+    int lightmap_blend = 0;               // ILM_BLEND_FP32_ACCUMULATE / ILM_BLEND_FP16_PER_LIGHT (ilm_ctx_set_lightmap_blend)
     RasterScratch raster;                                         // particle rasteriser buffers (raster.hip)
     int32_t* d_raster_quads = nullptr; int raster_quads_cap = 0;
     // particle read-back: draw-call records, total, block counts, per-chunk element counts
@@ -2058,6 +2059,7 @@ int32_t fill_light_launch(Ctx* c, const IlmEnvironment* env, const IlmDistanceFi
     a->row_begin = row_begin; a->row_end = row_end;
     a->stats = nullptr; a->light_count_ptr = nullptr; a->accumulate = 0;
     a->ramp = RampView{ nullptr, 0, 0 };      // particle lights have no ramp technique (LightingRenderer.cs:176-178)
+    a->blend_fp16 = (c->lightmap_blend == ILM_BLEND_FP16_PER_LIGHT) ? 1 : 0;
     a->tile_map = light_tile_map();
     return ILM_OK;
 }
@@ -2333,6 +2335,14 @@ int32_t ilm_system_set_bitmap(IlmHandle h, const IlmFloat4* texels, int32_t widt
     return ILM_OK;
 }
 
+int32_t ilm_ctx_set_lightmap_blend(IlmHandle hctx, int32_t mode) {
+    Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);
+    if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
+    if (mode != ILM_BLEND_FP32_ACCUMULATE && mode != ILM_BLEND_FP16_PER_LIGHT) return fail(ILM_ERR_INVALID_ARGUMENT, "unknown lightmap blend mode %d", mode);
+    c->lightmap_blend = mode;
+    return ILM_OK;
+}
+
 int32_t ilm_ctx_set_light_ramp(IlmHandle hctx, const IlmFloat4* texels, int32_t width, int32_t height) {
     Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);
     if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
@@ -2532,6 +2542,7 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
     a.stats = nullptr; a.light_count_ptr = nullptr;
     a.accumulate = ambient ? 0 : 1;          // a further light group of the frame: added to what the lightmap holds
     a.ramp = RampView{ c->d_light_ramp, c->light_ramp_w, c->light_ramp_h };
+    a.blend_fp16 = (c->lightmap_blend == ILM_BLEND_FP16_PER_LIGHT) ? 1 : 0;
     a.tile_map = light_tile_map();
     if (stats) {
         HIP_TRY(hipMemsetAsync(c->d_stats, 0, 3 * sizeof(unsigned long long), c->main()));

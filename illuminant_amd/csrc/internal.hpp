@@ -160,6 +160,7 @@ struct LightLaunch {
     const int32_t* light_count_ptr; // device: when non-null the record count is read from here (particle lights are counted on the device)
     int32_t tile_map;               // block -> tile mapping: 0 contiguous band per XCD, 1 tile rows round-robin over the XCDs, 2 identity
     int32_t accumulate;             // != 0: start from the lightmap's contents instead of `ambient` (additive blend onto an earlier pass)
+    int32_t blend_fp16;             // != 0: the reference's HalfVector4 render target -- round through fp16 after every light (ilm_ctx_set_lightmap_blend)
     RampView ramp;
 };
 

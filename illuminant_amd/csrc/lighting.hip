@@ -475,6 +475,11 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
             acc_b = (float)((v >> 16) & 0xFFu) / 255.0f; acc_a = (float)(v >> 24) / 255.0f;
         }
     }
+    // The reference's lightmap is a HalfVector4 surface blended into by the ROP light after light (LightingRenderer.cs:476-479): in that
+    // model the clear colour and every partial sum pass through fp16.  Off by default (fp32 accumulation, one rounding at the store).
+    const bool blend_fp16 = a.blend_fp16 != 0;
+    auto through_half = [](float v) { return __half2float(__float2half_rn(v)); };
+    if (blend_fp16) { acc_r = through_half(acc_r); acc_g = through_half(acc_g); acc_b = through_half(acc_b); acc_a = through_half(acc_a); }
     LightStats st;
     const int light_count = (a.light_count_ptr != nullptr) ? __builtin_amdgcn_readfirstlane(*a.light_count_ptr) : a.light_count;
 
@@ -522,10 +527,17 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
             float cr, cg, cb;
             if (!shade_light<FMT, STATS>(P, L, a.env, field, have_sdf, a.ramp, st, cr, cg, cb))
                 continue;
-            acc_r += cr;
-            acc_g += cg;
-            acc_b += cb;
-            acc_a += 1.0f;
+            if (blend_fp16) {      // dst = half(float(dst) + float(half(src))): the shader's output is converted to the target format, then blended
+                acc_r = through_half(acc_r + through_half(cr));
+                acc_g = through_half(acc_g + through_half(cg));
+                acc_b = through_half(acc_b + through_half(cb));
+                acc_a = through_half(acc_a + 1.0f);
+            } else {
+                acc_r += cr;
+                acc_g += cg;
+                acc_b += cb;
+                acc_a += 1.0f;
+            }
         }
     }
 

@@ -99,6 +99,7 @@ SYMBOLS = {
     "ilm_render_particles": (_I, [_H, _P, _I, _P, _H, _P]),
     "ilm_lightmap_clear": (_I, [_H, _P]),
     "ilm_ctx_set_light_ramp": (_I, [_H, _P, _I, _I]),
+    "ilm_ctx_set_lightmap_blend": (_I, [_H, _I]),
     "ilm_system_set_bitmap": (_I, [_H, _P, _I, _I]),
     "ilm_resolve_lighting": (_I, [_H, _H, _P, _I, _I]),
     "ilm_resolve_lighting_with_albedo": (_I, [_H, _H, _H, _P, _I, _I]),
@@ -195,6 +196,10 @@ class Context:
             return
         a = np.ascontiguousarray(texels, dtype=np.float32)
         check(lib().ilm_ctx_set_light_ramp(self.handle, _ptr(a), a.shape[1], a.shape[0]))
+
+    def set_lightmap_blend(self, fp16_per_light):
+        """ilm_ctx_set_lightmap_blend: True = the reference's HalfVector4 render target (rounded through fp16 after every light)."""
+        check(lib().ilm_ctx_set_lightmap_blend(self.handle, 1 if fp16_per_light else 0))
 
     def debug_divide(self, numerators, denominators):
         """ilm_debug_divide: (the cone trace's unscaled division, the IEEE division) of the operand pairs, both evaluated on the device."""

@@ -702,6 +702,18 @@ int32_t ilm_render_sphere_lights(IlmHandle ctx,
  * width == 0 -- or a 1 x 1 texture, which the reference treats as none (:822-827) -- selects the techniques without a ramp. */
 int32_t ilm_ctx_set_light_ramp(IlmHandle ctx, const IlmFloat4* texels, int32_t width, int32_t height);
 
+/* How the light passes of this context sum the lights of a pixel.
+ *   ILM_BLEND_FP32_ACCUMULATE (default): fp32 registers over all lights in light order, one rounding when the texel is stored.
+ *   ILM_BLEND_FP16_PER_LIGHT: the reference's render target.  Its lightmap is a HalfVector4 surface (LightingRenderer.cs:476-479) that
+ *     the ROP blends into additively, one light quad after the other: the clear colour and every partial sum are fp16 values.  The
+ *     model: dst = half(float(dst) + float(half(src))) per light and channel, round to nearest even (Direct3D converts the shader's
+ *     output to the target format, then blends).  Same light order, same shader arithmetic; only the rounding of the sum differs.
+ * 1e-4 parity with the HLSL path is defined against the fp32 form; this mode exists to MEASURE how far the frame the
+ * reference's hardware path displays lies from it (tests/test_lighting_gpu.py holds it bit-equal to the oracle's model). */
+#define ILM_BLEND_FP32_ACCUMULATE 0
+#define ILM_BLEND_FP16_PER_LIGHT 1
+int32_t ilm_ctx_set_lightmap_blend(IlmHandle ctx, int32_t mode);
+
 /* ---- particle lights and light probes --------------------------------------------------------- */
 
 /* What _ParticleLightBatchSetup binds for a ParticleLightSource (Illuminant/Lighting/LightingRenderer.cs:769-790,

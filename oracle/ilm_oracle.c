@@ -102,6 +102,34 @@ static inline float half_to_float(uint16_t h) {
     return f;
 }
 
+/* float -> IEEE half, round to nearest even, any finite / infinite / NaN input (the lightmap's HalfVector4 blend emulation) */
+static inline uint16_t float_to_half_any(float f) {
+    union { float f; uint32_t u; } v = { f };
+    const uint32_t sign = (v.u >> 16) & 0x8000u;
+    uint32_t x = v.u & 0x7FFFFFFFu;
+    if (x >= 0x7F800000u) return (uint16_t)(sign | 0x7C00u | ((x > 0x7F800000u) ? 0x0200u : 0u));      /* inf / NaN */
+    if (x >= 0x477FF000u) return (uint16_t)(sign | 0x7C00u);                                              /* rounds to 65536 or more: inf */
+    if (x < 0x38800000u) {                                                                                 /* below 2^-14: subnormal half (or zero) */
+        union { float f; uint32_t u; } a = { 0 };
+        a.u = x;
+        const float r = nearbyintf(a.f * 16777216.0f);                                                     /* |f| * 2^24, ties to even */
+        return (uint16_t)(sign | (uint32_t)r);
+    }
+    const uint32_t mant = x & 0x007FFFFFu, exp = (x >> 23) - 112u;
+    uint32_t half = (exp << 10) | (mant >> 13);
+    const uint32_t rem = mant & 0x1FFFu;
+    if (rem > 0x1000u || (rem == 0x1000u && (half & 1u))) half++;                                          /* may carry into the exponent: correct */
+    return (uint16_t)(sign | half);
+}
+static inline float round_through_half(float f) { return half_to_float(float_to_half_any(f)); }
+
+/* Lightmap blend model of the following orc_render_sphere_lights calls.  0: fp32 accumulation over the lights, one rounding when the
+ * caller converts the frame (the parity model of this restatement).  1: the reference's render target -- a HalfVector4 surface the
+ * ROP blends into light by light (LightingRenderer.cs:476-479, additive blend state :206): clear to half(Ambient), and after every
+ * light dst = half(float(dst) + float(half(src))), the pixel shader's output being converted to the target format before the blend. */
+static int g_orc_blend_fp16 = 0;
+void orc_set_lightmap_blend(int32_t mode) { g_orc_blend_fp16 = (mode != 0); }
+
 /* ---------------------------------------------------------------------------
  * ParticleCommon.fxh accessors (ParticleCommon.fxh:29-92)
  * ------------------------------------------------------------------------- */
@@ -1313,6 +1341,7 @@ void orc_render_sphere_lights(const IlmLightVertex* lights, int32_t light_count,
         SdfCounter ctr = { 0 };
         for (int px = 0; px < width; px++) {
             f4 acc = v4(ambient[0], ambient[1], ambient[2], ambient[3]);
+            if (g_orc_blend_fp16) acc = v4(round_through_half(acc.x), round_through_half(acc.y), round_through_half(acc.z), round_through_half(acc.w));
             f3 shaded, normal;
             int enable_shadows, fullbright;
             f3 camera = sample_gbuffer((float)px, (float)py, env, gbuffer, &shaded, &normal, &enable_shadows, &fullbright);
@@ -1347,10 +1376,20 @@ void orc_render_sphere_lights(const IlmLightVertex* lights, int32_t light_count,
                 const f3 opacity = sphere_light_epilogue(pre_trace_opacity, cone_opacity, v3sub(shaded, light_center), L->EvenMoreLightProperties);
 
                 float specularity = calc_sphere_light_specularity(camera, shaded, normal, light_center, L->Color2.w);
-                acc.x += (L->Color1.x * L->Color1.w * opacity.x) + (L->Color2.x * specularity * opacity.x);
-                acc.y += (L->Color1.y * L->Color1.w * opacity.y) + (L->Color2.y * specularity * opacity.y);
-                acc.z += (L->Color1.z * L->Color1.w * opacity.z) + (L->Color2.z * specularity * opacity.z);
-                acc.w += 1.0f;
+                const float cr = (L->Color1.x * L->Color1.w * opacity.x) + (L->Color2.x * specularity * opacity.x);
+                const float cg = (L->Color1.y * L->Color1.w * opacity.y) + (L->Color2.y * specularity * opacity.y);
+                const float cb = (L->Color1.z * L->Color1.w * opacity.z) + (L->Color2.z * specularity * opacity.z);
+                if (g_orc_blend_fp16) {
+                    acc.x = round_through_half(acc.x + round_through_half(cr));
+                    acc.y = round_through_half(acc.y + round_through_half(cg));
+                    acc.z = round_through_half(acc.z + round_through_half(cb));
+                    acc.w = round_through_half(acc.w + 1.0f);
+                } else {
+                    acc.x += cr;
+                    acc.y += cg;
+                    acc.z += cb;
+                    acc.w += 1.0f;
+                }
             }
             lightmap[(size_t)py * (size_t)width + (size_t)px] = acc;
         }

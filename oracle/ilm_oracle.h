@@ -103,6 +103,9 @@ float orc_evaluate_area(int32_t type_id, const float pos[3], const float center[
 /* RampTexture of the light group rendered by the following orc_render_sphere_lights / orc_render_light_probes calls (width * height
  * float4, kept by reference); NULL unbinds (techniques without a distance ramp) */
 void orc_set_light_ramp(const IlmFloat4* texels, int32_t width, int32_t height);
+/* 0: fp32 accumulation over the lights (default); 1: the reference's HalfVector4 lightmap, rounded by the ROP after every light
+ * (LightingRenderer.cs:476-479) -- see ilm_ctx_set_lightmap_blend */
+void orc_set_lightmap_blend(int32_t mode);
 void orc_sample_gbuffer(float px, float py, const IlmEnvironment* env, const OrcTexture* gbuffer,
                         float world_pos[3], float normal[3], int32_t* enable_shadows, int32_t* fullbright, float camera_pos[3]);
 void orc_render_sphere_lights(const IlmLightVertex* lights, int32_t light_count,

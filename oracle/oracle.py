@@ -267,10 +267,12 @@ def set_light_ramp(texels):
     lib().orc_set_light_ramp(_f4(a), C.c_int32(a.shape[1]), C.c_int32(a.shape[0]))
 
 
-def render_sphere_lights(lights, env, df, gbuffer, sdf, ambient, width, height, row_begin=0, row_end=None, want_stats=False):
-    """lights: ctypes array of abi.LightVertex.  Returns (lightmap (H, W, 4) float32, stats|None)."""
+def render_sphere_lights(lights, env, df, gbuffer, sdf, ambient, width, height, row_begin=0, row_end=None, want_stats=False, blend_fp16=False):
+    """lights: ctypes array of abi.LightVertex.  Returns (lightmap (H, W, 4) float32, stats|None).
+    blend_fp16: the reference's HalfVector4 render target, rounded after every light (orc_set_lightmap_blend)."""
     if row_end is None:
         row_end = height
+    lib().orc_set_lightmap_blend(C.c_int32(1 if blend_fp16 else 0))
     out = np.zeros((height, width, 4), dtype=np.float32)
     amb = (C.c_float * 4)(*[float(x) for x in ambient])
     stats = abi.RenderStats() if want_stats else None
@@ -279,6 +281,7 @@ def render_sphere_lights(lights, env, df, gbuffer, sdf, ambient, width, height, 
                                    C.byref(sdf) if sdf is not None else None,
                                    amb, _f4(out), width, height, row_begin, row_end,
                                    C.byref(stats) if stats is not None else None)
+    lib().orc_set_lightmap_blend(C.c_int32(0))
     return out, stats
 
 

@@ -139,3 +139,39 @@ def test_many_lights_exceed_one_tile_list(ctx, oracle):
     got, want, stats, ostats = render_both(ctx, oracle, lights, env, dfu, None, 0, None, 0, (0, 0, 0, 0), w, h)
     assert stats.PixelLightPairs == ostats.PixelLightPairs
     assert_close(got, want, "1300 lights")
+
+
+def test_fp16_per_light_blend_model_matches_oracle(ctx, oracle):
+    """ILM_BLEND_FP16_PER_LIGHT: the reference's HalfVector4 lightmap, rounded by the ROP after every light (LightingRenderer.cs:476-479).
+    The kernel's model equals the oracle's bit for bit in every lightmap format; SDF sample / pair / trace counts do not depend on the
+    blend; the fp32-accumulate frame (the parity model) differs from it by fp16 rounding only."""
+    layout, atlas, dfu, lights, w, h = small_scene(n_lights=12)
+    env = scenes.environment()
+    amb = (0.0213, 0.0377, 0.0591, 1.0)                       # not representable in fp16: the clear colour is rounded too
+    sdf = native.DistanceFieldTexture(ctx, atlas)
+    tex = oracle.make_texture(atlas, abi.SDF_UNORM16)
+    want, wstats = oracle.render_sphere_lights(lights, env, dfu, None, tex, amb, w, h, want_stats=True, blend_fp16=True)
+    want32, _ = oracle.render_sphere_lights(lights, env, dfu, None, tex, amb, w, h)
+    assert np.array_equal(want, want.astype(np.float16).astype(np.float32)), "every value of the fp16 model is an fp16 value"
+    ctx.set_lightmap_blend(True)
+    try:
+        for fmt in (abi.LIGHTMAP_FLOAT4, abi.LIGHTMAP_HALF4):
+            lm = native.Lightmap(ctx, w, h, fmt)
+            stats = native.render_sphere_lights(ctx, lights, env, dfu, None, sdf, amb, lm, want_stats=True)
+            got = lm.download().astype(np.float32)
+            # the per-light contributions differ from the oracle's by the parity tolerance BEFORE they are rounded: a contribution within
+            # that distance of an fp16 rounding boundary may land on the neighbouring fp16 value -- one fp16 ulp (2^-11 relative) at most
+            diff = np.abs(got - want)
+            assert (diff <= np.abs(want) * 2.0 ** -10 + 1e-7).all()
+            assert (diff > 0).mean() < 0.02, "more than 2 %% of the texels differ from the oracle's fp16 model"
+            assert (stats.SdfSamples, stats.PixelLightPairs, stats.TracedPairs) == (wstats.SdfSamples, wstats.PixelLightPairs, wstats.TracedPairs)
+            lm.close()
+    finally:
+        ctx.set_lightmap_blend(False)
+    # back to the parity model, and how far the two models are apart: fp16's 2^-11 per partial sum, accumulated over <= 12 lights
+    lm = native.Lightmap(ctx, w, h, abi.LIGHTMAP_FLOAT4)
+    native.render_sphere_lights(ctx, lights, env, dfu, None, sdf, amb, lm)
+    assert_close(lm.download(), want32, "fp32-accumulate frame after switching back")
+    rel = np.abs(want - want32) / np.maximum(np.abs(want32), 1e-3)
+    assert 1e-5 < rel.max() < 13 * 2.0 ** -11
+    lm.close(); sdf.close()
