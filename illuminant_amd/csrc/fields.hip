@@ -151,11 +151,21 @@ __global__ __launch_bounds__(256) void render_slices_kernel(const FieldLaunch a)
         }
         const uint16_t* order = sorted ? sort_index : list;
         const float z_low = fminf(slice_z[0], slice_z[3]), z_high = fmaxf(slice_z[0], slice_z[3]);
-        for (int k = 0; k < n; k++) {
+        // The record of list entry k, by value: five 16-byte scalar loads issued together (read field by field behind the raster test's
+        // short-circuits, the compiler fetched x0, x1, y0, y1, the centre, the bound and the orientation one dependent s_load after the
+        // other -- about ten scalar-cache round trips per obstruction and wave).  The NEXT entry's record is requested before this one is
+        // evaluated, so its latency hides behind the distance functions.
+        auto load_record = [&](int k) {
             const int oi = __builtin_amdgcn_readfirstlane((int)order[k]);
-            const FieldObstruction& R = a.obstructions[batch + oi];
+            return a.obstructions[batch + oi];
+        };
+        FieldObstruction next_record;
+        if (n > 0) next_record = load_record(0);
+        for (int k = 0; k < n; k++) {
+            const FieldObstruction R = next_record;
+            if (k + 1 < n) next_record = load_record(k + 1);
             // DistanceFunctionVertexShader's quad (DistanceFunction.fx:16-26): pixel centre inside [x0, x1) x [y0, y1)
-            const bool covered = in_slice && (cxp >= R.x0) && (cxp < R.x1) && (cyp >= R.y0) && (cyp < R.y1);
+            const bool covered = in_slice & (cxp >= R.x0) & (cxp < R.x1) & (cyp >= R.y0) & (cyp < R.y1);
             // Culling: every slice value of this obstruction is at most kDistanceZero - bound / max_encoded with
             // bound = (e - cull_radius) / cull_inv_scale <= f (internal.hpp); if that cannot exceed the smallest of the four running
             // maxima, MAX leaves the texel as it is.  Evaluate only when some covered lane can still change.

@@ -12,7 +12,8 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# ILM_HIP_LIB: a variant build of the same library for on-box A/B runs (tools/ab_build.sh)
+# ILM_HIP_LIB: a variant build of the same library for on-box A/B runs (tools/ab_build.sh).  Scripts that also drive the host mirror
+# (bench.py) point LD_LIBRARY_PATH at the same directory: mirror and binding must share ONE copy (two copies = two handle registries)
 LIB_PATH = os.environ.get("ILM_HIP_LIB") or os.path.join(_HERE, "lib", "libilluminant_hip.so")
 
 _lib = None
@@ -432,6 +433,18 @@ class DistanceFieldTexture:
         self.height, self.width = a.shape[0], a.shape[1]
         check(lib().ilm_sdf_create(ctx.handle, self.width, self.height, fmt, C.byref(self.handle)))
         check(lib().ilm_sdf_upload(self.handle, _ptr(a)))
+
+    def upload(self, texels):
+        """ilm_sdf_upload: replaces the atlas ((H, W, 4) uint16)."""
+        a = np.ascontiguousarray(texels, dtype=np.uint16)
+        assert a.shape == (self.height, self.width, 4)
+        check(lib().ilm_sdf_upload(self.handle, _ptr(a)))
+
+    def device_ptr(self):
+        """ilm_sdf_device_ptr: the atlas' device address (from then on the library assumes the caller may write it)."""
+        p = C.c_void_p()
+        check(lib().ilm_sdf_device_ptr(self.handle, C.byref(p)))
+        return p.value
 
     def download(self):
         """ilm_sdf_download: the atlas as (H, W, 4) uint16."""

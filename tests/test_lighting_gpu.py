@@ -175,3 +175,47 @@ def test_fp16_per_light_blend_model_matches_oracle(ctx, oracle):
     rel = np.abs(want - want32) / np.maximum(np.abs(want32), 1e-3)
     assert 1e-5 < rel.max() < 13 * 2.0 ** -11
     lm.close(); sdf.close()
+
+
+@pytest.mark.parametrize("sfmt", [abi.SDF_UNORM16, abi.SDF_FP16])
+def test_the_trace_follows_the_atlas_when_it_changes(ctx, oracle, sfmt):
+    """The cone trace reads the field through a cell array built from the atlas (hlsl_math.hpp, SdfView::cells).  Whatever writes the atlas
+    -- ilm_sdf_upload, ilm_sdf_render_slices, a caller holding the device pointer -- must reach the next frame: the frame after each
+    change equals the oracle's frame of the NEW field, with its exact SDF sample counts."""
+    layout, atlas_a, dfu, lights, w, h = small_scene(sfmt)
+    atlas_b = scenes.build_sdf_atlas(layout, scenes.random_obstacles(77, 9, (256, 192), size_lo=12.0, size_hi=40.0, z_hi=60.0), fmt=sfmt)
+    assert not np.array_equal(atlas_a, atlas_b)
+    env = scenes.environment()
+    amb = (0.03, 0.03, 0.03, 1.0)
+    sdf = native.DistanceFieldTexture(ctx, atlas_a, sfmt)
+    lm = native.Lightmap(ctx, w, h)
+
+    def check(atlas, what):
+        stats = native.render_sphere_lights(ctx, lights, env, dfu, None, sdf, amb, lm, want_stats=True)
+        want, ostats = oracle.render_sphere_lights(lights, env, dfu, None, oracle.make_texture(atlas, sfmt), amb, w, h, want_stats=True)
+        assert (stats.SdfSamples, stats.TracedPairs) == (ostats.SdfSamples, ostats.TracedPairs), what
+        assert_close(lm.download(), want, what)
+        return stats.SdfSamples
+
+    s_a = check(atlas_a, "first field")
+    sdf.upload(atlas_b)
+    s_b = check(atlas_b, "after ilm_sdf_upload")
+    assert s_a != s_b                                   # the two fields really trace differently
+    check(atlas_b, "unchanged field, cached cells")
+    # a field generated on the device, then regenerated with other obstructions
+    gen = native.DistanceFieldTexture(ctx, None, sfmt, size=(layout.atlas_width, layout.atlas_height))
+    desc = scenes.render_desc(layout)
+    triplets = list(range(0, layout.slice_count, 3))
+    for seed in (3, 4):
+        obs = scenes.obstruction_array(scenes.random_obstructions(seed, 8, (256, 192), 8.0, 30.0, 40.0))
+        gen.render_slices(desc, triplets, obs)
+        generated = gen.download()
+        stats = native.render_sphere_lights(ctx, lights, env, dfu, None, gen, amb, lm, want_stats=True)
+        want, ostats = oracle.render_sphere_lights(lights, env, dfu, None, oracle.make_texture(generated, sfmt), amb, w, h, want_stats=True)
+        assert stats.SdfSamples == ostats.SdfSamples, "after ilm_sdf_render_slices (seed %d)" % seed
+        assert_close(lm.download(), want, "after ilm_sdf_render_slices (seed %d)" % seed)
+    # a field whose device pointer was handed out is re-read before every frame
+    assert sdf.device_ptr() != 0
+    sdf.upload(atlas_a)
+    assert check(atlas_a, "after the pointer escaped") == s_a
+    gen.close(); lm.close(); sdf.close()

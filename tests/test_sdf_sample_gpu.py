@@ -151,7 +151,7 @@ def test_cone_trace_division_equals_the_ieee_division(ctx):
 # ---- the cone trace's table-driven in-volume sampler (hlsl_math.hpp, sample_inside_table) --------------------------------------
 
 @pytest.mark.parametrize("fmt", [abi.SDF_UNORM16, abi.SDF_FP16])
-@pytest.mark.parametrize("resolution,virtual", [(0.25, 2048), (0.125, 4096), (1.0, 256), (0.5, 300)])
+@pytest.mark.parametrize("resolution,virtual", [(0.25, 2048), (0.125, 4096), (1.0, 256), (0.5, 300), (0.3, 256)])   # 0.3: 77-texel slices, VirtualWidth / SliceWidth is not a float
 def test_in_volume_sampler_matches_the_oracle_bit_for_bit(ctx, oracle, fmt, resolution, virtual):
     """The lighting configs' fields (cfg3: 1/4 texel per unit, cfg5: 1/8) and two small ones, random texels (every channel pair,
     every atlas row), positions all over the volume and on the sampler's box faces.  Where the precondition holds the table form
@@ -170,7 +170,7 @@ def test_in_volume_sampler_matches_the_oracle_bit_for_bit(ctx, oracle, fmt, reso
     pos[:, 1] = rng.uniform(-10.0, virtual + 10.0, n)
     pos[:, 2] = rng.uniform(-8.0, 130.0, n)
     pos[:300] = np.round(pos[:300])                           # taps exactly on texel boundaries
-    isx = 1.0 / resolution
+    isx = virtual / layout.slice_width
     edge = np.float32([0.5 * isx, 0.5625 * isx, 0.6 * isx, virtual - 0.5625 * isx, virtual - 0.6 * isx, isx, virtual - isx])
     pos[300:1000, 0] = np.tile(edge, 100)                     # the faces of the sampler's box
     pos[1000:1700, 1] = np.tile(edge, 100)
