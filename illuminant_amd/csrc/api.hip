@@ -2449,21 +2449,25 @@ int32_t ilm_resolve_lighting_with_albedo(IlmHandle hsrc, IlmHandle halbedo, IlmH
     if (halbedo) {
         albedo = from_handle<Lightmap>(halbedo, kMagicLightmap);
         if (!albedo) return fail(ILM_ERR_INVALID_HANDLE, "albedo is not a texture (lightmap) handle");
-        if (albedo->ctx != src->ctx || albedo->width != src->width || albedo->height != src->height)
-            return fail(ILM_ERR_INVALID_ARGUMENT, "the albedo texture must share context and size with the lightmap (the resolve is texel for texel)");
+        if (albedo->ctx != src->ctx || albedo->width != src->width)
+            return fail(ILM_ERR_INVALID_ARGUMENT, "the albedo texture must share context and width with the lightmap (the resolve is texel for texel)");
         if (hdr && hdr->AlbedoIsSRGB != 0)
             return fail(ILM_ERR_INVALID_ARGUMENT, "AlbedoIsSRGB needs Fracture's pSRGBToPLinear (sRGBCommon.fxh), which is outside the reference tree");
     }
     if (!hdr) return fail(ILM_ERR_INVALID_ARGUMENT, "hdr is NULL");
-    if (src->ctx != dst->ctx || src->width != dst->width || src->height != dst->height)
-        return fail(ILM_ERR_INVALID_ARGUMENT, "source and destination must share context and size");
+    // Heights may differ: a group member's lightmap carries padding rows below the frame (world x slot rows, group.hip), the host's back
+    // buffer and albedo are frame-sized.  The rows resolved must exist in all of them.
+    if (src->ctx != dst->ctx || src->width != dst->width)
+        return fail(ILM_ERR_INVALID_ARGUMENT, "source and destination must share context and width");
+    int common_height = src->height < dst->height ? src->height : dst->height;
+    if (albedo && albedo->height < common_height) common_height = albedo->height;
     if (hdr->Mode < ILM_HDR_NONE || hdr->Mode > ILM_HDR_TONE_MAP) return fail(ILM_ERR_INVALID_ARGUMENT, "unknown HDR mode %d", hdr->Mode);
     if (hdr->ResolveToSRGB != 0)
         return fail(ILM_ERR_INVALID_ARGUMENT, "ResolveToSRGB needs Fracture's pLinearToPSRGB (sRGBCommon.fxh), which is outside the reference tree");
     if (hdr->DitheringStrength != 0)
         return fail(ILM_ERR_INVALID_ARGUMENT, "dithering needs Fracture's ApplyDither (DitherCommon.fxh), which is outside the reference tree");
-    if (row_begin < 0 || row_end > src->height || row_begin > row_end)
-        return fail(ILM_ERR_OUT_OF_RANGE, "rows [%d, %d) outside [0, %d]", row_begin, row_end, src->height);
+    if (row_begin < 0 || row_end > common_height || row_begin > row_end)
+        return fail(ILM_ERR_OUT_OF_RANGE, "rows [%d, %d) outside [0, %d] (the smallest of the textures' heights)", row_begin, row_end, common_height);
     Ctx* c = src->ctx;
     HIP_TRY(hipSetDevice(c->device));
     // clamps of SetGammaCompressionParameters / SetToneMappingParameters, IlluminantMaterials.cs:81-137

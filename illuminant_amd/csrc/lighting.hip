@@ -173,7 +173,12 @@ ILM_DEV Pixel sample_gbuffer(float spx, float spy, const IlmEnvironment& env, co
 constexpr float kDotRampRangeRcp = (float)(1.0 / (double)ref::kDotRampRange);
 constexpr float kVisibilityRange = ref::kUnshadowedThreshold - ref::kFullyShadowedThreshold;
 constexpr float kVisibilityRangeRcp = (float)(1.0 / (double)kVisibilityRange);
-template <bool SHARED>
+// FLAT (with SHARED only): every lane's normal has x = y = 0 (the ground plane, flat G-buffer texels; the caller's wave-uniform test).
+// dot(-lightNormal, normal) is then ((-ln.x * 0) + (-ln.y * 0)) + (-ln.z * normal.z) = -ln.z * normal.z exactly -- the two vanishing
+// products are signed zeros (all components are finite: SHARED's range test bounds `distance`, hence d3), and a zero added to the third
+// product leaves it unchanged (the sign of a zero RESULT may differ, which the following + DOT_OFFSET erases) -- so the x and y
+// components of lightNormal, two 6-instruction divisions, are never formed.
+template <bool SHARED, bool FLAT = false>
 ILM_DEV float sphere_light_opacity(f3 d3, float distance, f3 normal, const LightRec& L, float light_occlusion) {
     const float over = distance - L.radius;
     float distance_factor = 1.0f - sat(SHARED ? div_with_rcp(over, L.ramp, L.ramp_rcp) : (over / L.ramp));
@@ -181,14 +186,20 @@ ILM_DEV float sphere_light_opacity(f3 d3, float distance, f3 normal, const Light
         distance_factor *= 1.0f - sat(d3.z / light_occlusion);
     float normal_factor = 1.0f;
     if ((normal.x != 0.0f) || (normal.y != 0.0f) || (normal.z != 0.0f)) {
-        f3 ln;
-        if (SHARED) {
+        float d;
+        if (SHARED && FLAT) {
             const float y = refined_rcp(distance);
-            ln = mk3(div_with_rcp(d3.x, distance, y), div_with_rcp(d3.y, distance, y), div_with_rcp(d3.z, distance, y));
+            d = (div_with_rcp(d3.z, distance, y) * -1.0f) * normal.z;
         } else {
-            ln = mk3(d3.x / distance, d3.y / distance, d3.z / distance);
+            f3 ln;
+            if (SHARED) {
+                const float y = refined_rcp(distance);
+                ln = mk3(div_with_rcp(d3.x, distance, y), div_with_rcp(d3.y, distance, y), div_with_rcp(d3.z, distance, y));
+            } else {
+                ln = mk3(d3.x / distance, d3.y / distance, d3.z / distance);
+            }
+            d = dot3(ln * -1.0f, normal);
         }
-        const float d = dot3(ln * -1.0f, normal);
         const float ramped = SHARED ? div_with_rcp(d + ref::kDotOffset, ref::kDotRampRange, kDotRampRangeRcp) : ((d + ref::kDotOffset) / ref::kDotRampRange);
         normal_factor = pow_pos(sat(ramped), ref::kDotExponent);
     }
@@ -268,9 +279,10 @@ ILM_DEV void cone_trace_loop(const f3& start, const f3& dir, float data_y, float
 
 // One light on one shaded point: SphereLightPixelShader (SphereLight.fx:7-46) after the raster test.  Returns false when the shader
 // discards (nothing is blended); otherwise the light's rgb contribution in (out_r, out_g, out_b).
+// flat_normals: wave-uniform, every lane's normal has x = y = 0 (see sphere_light_opacity)
 template <int FMT, bool STATS>
 ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment& env, const TraceField& F,
-                         bool have_sdf, const RampView& ramp, LightStats& st, float& out_r, float& out_g, float& out_b) {
+                         bool have_sdf, const RampView& ramp, LightStats& st, float& out_r, float& out_g, float& out_b, bool flat_normals = false) {
     const IlmDistanceFieldUniforms& df = F.df;
     const SdfView& sdf = F.sdf;
     // checkShadowFilter, LightCommon.fxh:146-152
@@ -286,9 +298,10 @@ ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment
     // the shared-reciprocal divisions need distance (a divisor, and with the radius the ramp's numerator) inside their operand range:
     // one wave-uniform test, the IEEE form otherwise
     const bool divisors_ordinary = (distance >= 0x1p-60f) & (distance <= 0x1p59f);
-    const float distance_opacity = ((light_flags_i & kLightFastDivide) && __builtin_amdgcn_ballot_w64(!divisors_ordinary) == 0ull)
-                                       ? sphere_light_opacity<true>(d3, distance, P.normal, L, env.ZToY.z)
-                                       : sphere_light_opacity<false>(d3, distance, P.normal, L, env.ZToY.z);
+    const bool shared = (light_flags_i & kLightFastDivide) && __builtin_amdgcn_ballot_w64(!divisors_ordinary) == 0ull;
+    const float distance_opacity = shared ? (flat_normals ? sphere_light_opacity<true, true>(d3, distance, P.normal, L, env.ZToY.z)
+                                                          : sphere_light_opacity<true>(d3, distance, P.normal, L, env.ZToY.z))
+                                          : sphere_light_opacity<false>(d3, distance, P.normal, L, env.ZToY.z);
     const bool visible = (distance_opacity > 0.0f) && (P.shaded.x > -9999.0f);
     if (!visible)
         return false;
@@ -480,6 +493,9 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
     const bool blend_fp16 = a.blend_fp16 != 0;
     auto through_half = [](float v) { return __half2float(__float2half_rn(v)); };
     if (blend_fp16) { acc_r = through_half(acc_r); acc_g = through_half(acc_g); acc_b = through_half(acc_b); acc_a = through_half(acc_a); }
+    // wave-uniform: every pixel of this wave has a flat normal (no G-buffer, or ground / top-face texels): the normal factor needs one
+    // component of the light direction instead of three (sphere_light_opacity<.., FLAT>)
+    const bool flat_normals = __builtin_amdgcn_ballot_w64((P.normal.x != 0.0f) | (P.normal.y != 0.0f)) == 0ull;
     LightStats st;
     const int light_count = (a.light_count_ptr != nullptr) ? __builtin_amdgcn_readfirstlane(*a.light_count_ptr) : a.light_count;
 
@@ -495,14 +511,18 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
             int base = 0;
             for (int l0 = 0; l0 < batch_n; l0 += 64) {
                 const int li = l0 + lane;
-                bool hit = false;
+                bool hit = false, whole = false;
                 if (li < batch_n) {
                     const LightRec& R = recs[batch + li];
                     hit = (R.fx0 <= tmaxx) && (R.fx3 > tminx) && (R.fy0 <= tmaxy) && (R.fy3 > tminy);
+                    // the whole tile inside one of the footprint's two rectangles: every pixel centre passes the per-pixel test below (the
+                    // same comparisons, taken on the tile's extreme centres), so the walk skips it for this entry (bit 15)
+                    whole = ((tminx >= R.fx1) && (tmaxx < R.fx2) && (tminy >= R.fy0) && (tmaxy < R.fy3)) ||
+                            ((tminx >= R.fx0) && (tmaxx < R.fx3) && (tminy >= R.fy1) && (tmaxy < R.fy2));
                 }
                 const unsigned long long m = __ballot(hit);
                 if (hit)
-                    list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)li;
+                    list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(li | (whole ? 0x8000 : 0));
                 base += __popcll(m);
             }
             if (lane == 0) list_count = base;
@@ -511,21 +531,25 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
         const int n = list_count;
 
         for (int k = 0; k < n; k++) {
-            const int li = __builtin_amdgcn_readfirstlane((int)list[k]);
+            const int entry = __builtin_amdgcn_readfirstlane((int)list[k]);
+            const int li = entry & 0x7FFF;
             const LightRec& L = recs[batch + li];
 
-            // raster footprint: pixel centre inside the cross-shaped quad
-            // (all eight bounds fetched together and combined without short-circuits: as written with && / || the compiler issued
-            // eight dependent scalar loads, each behind its own wait and branch)
-            const float fx0 = L.fx0, fx1 = L.fx1, fx2 = L.fx2, fx3 = L.fx3, fy0 = L.fy0, fy1 = L.fy1, fy2 = L.fy2, fy3 = L.fy3;
-            const bool tall = (cxp >= fx1) & (cxp < fx2) & (cyp >= fy0) & (cyp < fy3);
-            const bool wide = (cxp >= fx0) & (cxp < fx3) & (cyp >= fy1) & (cyp < fy2);
-            const bool covered = in_image & (tall | wide);
+            bool covered = in_image;
+            if ((entry & 0x8000) == 0) {
+                // raster footprint: pixel centre inside the cross-shaped quad
+                // (all eight bounds fetched together and combined without short-circuits: as written with && / || the compiler issued
+                // eight dependent scalar loads, each behind its own wait and branch)
+                const float fx0 = L.fx0, fx1 = L.fx1, fx2 = L.fx2, fx3 = L.fx3, fy0 = L.fy0, fy1 = L.fy1, fy2 = L.fy2, fy3 = L.fy3;
+                const bool tall = (cxp >= fx1) & (cxp < fx2) & (cyp >= fy0) & (cyp < fy3);
+                const bool wide = (cxp >= fx0) & (cxp < fx3) & (cyp >= fy1) & (cyp < fy2);
+                covered = in_image & (tall | wide);
+            }
             if (!covered)
                 continue;
             if (STATS) st.pairs++;
             float cr, cg, cb;
-            if (!shade_light<FMT, STATS>(P, L, a.env, field, have_sdf, a.ramp, st, cr, cg, cb))
+            if (!shade_light<FMT, STATS>(P, L, a.env, field, have_sdf, a.ramp, st, cr, cg, cb, flat_normals))
                 continue;
             if (blend_fp16) {      // dst = half(float(dst) + float(half(src))): the shader's output is converted to the target format, then blended
                 acc_r = through_half(acc_r + through_half(cr));

@@ -1553,6 +1553,11 @@ static bool needs_extended_variant(const StepLaunch& a) {
     return false;
 }
 
+// Collision variants: six waves per SIMD (79 VGPRs, no scratch) 37.5-38.3 us on bench.py's collision row against 38.6-39.4 for the
+// allocator's own 86 VGPRs / five waves; seven (72 VGPRs, 24 B of scratch) 44.4, eight (64 VGPRs, 76 B) 55.2 (tools/ab_collision.sh)
+#ifndef ILM_DF_MINW
+#define ILM_DF_MINW 6
+#endif
 template <bool SPAWN>
 static hipError_t launch_step_variant(const StepLaunch& a, hipStream_t stream) {
     const int units = a.unit_end - a.unit_begin;
@@ -1578,10 +1583,11 @@ static hipError_t launch_step_variant(const StepLaunch& a, hipStream_t stream) {
     const int units_per_block = (kStepThreads / 64) * kUnitsPerWave;
     const dim3 grid((unsigned)((units + units_per_block - 1) / units_per_block), 1, 1), block(kStepThreads, 1, 1);
     if (a.desc.UpdateMode == ILM_UPDATE_WITH_DISTANCE_FIELD) {
+        // waves per SIMD requested for the collision variants (ILM_DF_MINW; measured in DESIGN 3.1)
         if (a.sdf.format == ILM_SDF_FP16)
-            hipLaunchKernelGGL((step_kernel<ILM_SDF_FP16, true, SPAWN, 1>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((step_kernel<ILM_SDF_FP16, true, SPAWN, ILM_DF_MINW>), grid, block, 0, stream, a);
         else
-            hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, true, SPAWN, 1>), grid, block, 0, stream, a);
+            hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, true, SPAWN, ILM_DF_MINW>), grid, block, 0, stream, a);
     } else if (a.streaming) {
         hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, false, SPAWN, 1, false, true>), grid, block, 0, stream, a);
     } else if (SPAWN) {

@@ -782,7 +782,9 @@ def render_light_probes(ctx, lights, probe_positions, probe_normals, env, df, sd
 
 def resolve_lighting(src, dst, hdr, row_begin=0, row_end=None, albedo=None):
     """ilm_resolve_lighting[_with_albedo]: tone-map lightmap `src` into `dst` (same size, any formats); albedo: a Lightmap holding the albedo texture."""
+    if row_end is None:
+        row_end = min(src.height, dst.height) if albedo is None else min(src.height, dst.height, albedo.height)
     if albedo is None:
-        check(lib().ilm_resolve_lighting(src.handle, dst.handle, _byref(hdr), row_begin, src.height if row_end is None else row_end))
+        check(lib().ilm_resolve_lighting(src.handle, dst.handle, _byref(hdr), row_begin, row_end))
     else:
-        check(lib().ilm_resolve_lighting_with_albedo(src.handle, albedo.handle, dst.handle, _byref(hdr), row_begin, src.height if row_end is None else row_end))
+        check(lib().ilm_resolve_lighting_with_albedo(src.handle, albedo.handle, dst.handle, _byref(hdr), row_begin, row_end))

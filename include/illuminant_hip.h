@@ -860,7 +860,9 @@ typedef struct IlmHDRConfiguration {
 
 /* RenderedLighting.Resolve without albedo, 1:1 (techniques ScreenSpaceLightingResolve / GammaCompressedLightingResolve /
  * ToneMappedLightingResolve, Illuminant/Shaders/Resolve.fx:25-139 + HDR.fxh): dst[row_begin..row_end) = tone-mapped src, alpha 1.
- * src and dst are lightmap handles of the same size (any formats; dst RGBA8 is the back-buffer case). */
+ * src and dst are lightmap handles of the same width (any formats; dst RGBA8 is the back-buffer case).  Heights may differ -- a group
+ * member's lightmap (ilm_group_lightmap_member) carries padding rows below the frame, a back buffer does not -- as long as the rows
+ * resolved exist in every texture involved. */
 int32_t ilm_resolve_lighting(IlmHandle src_lightmap, IlmHandle dst_lightmap, const IlmHDRConfiguration* hdr,
                              int32_t row_begin, int32_t row_end);
 /* RenderedLighting.Resolve WITH albedo (LightingRenderer.ResolveLighting with `albedo != null`, Illuminant/Lighting/LightingRenderer.cs:1537-1580;

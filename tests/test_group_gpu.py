@@ -273,3 +273,36 @@ def test_unequal_strips_over_rccl_at_world_one(ctx):
     g.sync()
     assert np.array_equal(glm.download(0), want)
     glm.close(); sdf.close(); g.close()
+
+
+def test_a_group_members_padded_lightmap_resolves_into_a_frame_sized_back_buffer(ctx, oracle):
+    """A member's lightmap is world x slot_rows rows tall (>= the frame); the host's back buffer and albedo are frame-sized.  The resolve
+    takes them as they are: rows [0, height) of the member equal the resolve of a frame-sized copy."""
+    layout, atlas, dfu, lights, w, h = small_scene()
+    env = scenes.environment()
+    g = native.Group([0, 0, 0])
+    sdfs = [native.DistanceFieldTexture(c, atlas, abi.SDF_UNORM16) for c in g.contexts]
+    glm = native.GroupLightmap(g, w, h, abi.LIGHTMAP_HALF4)
+    assert glm.members[0].height > h                       # 112 rows in three slots of 48
+    g.render_sphere_lights(lights, env, dfu, None, sdfs, AMBIENT, glm, native.GATHER_PEER)
+    g.sync()
+    hc = abi.HDRConfiguration()
+    hc.Mode, hc.InverseScaleFactor, hc.Exposure, hc.Gamma, hc.WhitePoint = abi.HDR_TONE_MAP, 1.0, 1.2, 1.0 / 2.2, 3.0
+    c0 = g.contexts[0]
+    back = native.Lightmap(c0, w, h, abi.LIGHTMAP_RGBA8)
+    albedo = native.Lightmap(c0, w, h, abi.LIGHTMAP_RGBA8)
+    albedo.upload(np.full((h, w, 4), 200, np.uint8))
+    native.resolve_lighting(glm.members[0], back, hc, albedo=albedo)
+    got = back.download()
+    frame = native.Lightmap(c0, w, h, abi.LIGHTMAP_HALF4)
+    frame.upload(glm.download(0))
+    want_lm = native.Lightmap(c0, w, h, abi.LIGHTMAP_RGBA8)
+    native.resolve_lighting(frame, want_lm, hc, albedo=albedo)
+    assert np.array_equal(got, want_lm.download())
+    with pytest.raises(native.IlluminantError):
+        native.resolve_lighting(glm.members[0], back, hc, 0, h + 1)            # rows past the back buffer
+    for x in (back, albedo, frame, want_lm, glm):
+        x.close()
+    for s in sdfs:
+        s.close()
+    g.close()
