@@ -389,18 +389,21 @@ ILM_DEV float sample_inside_table(f3 position, const InsideConsts& c, const Trac
 #pragma clang fp contract(off)
     const float pz = position.z - c.z_offset;
     const float slice_position = pz * c.slice_scale;          // min(clamp(z), validZ) is the identity inside the box
-    const float vslice = floorf(slice_position);
-    const SliceEntry e = table[(uint32_t)vslice];
+    // Inside the box slice_position, x and y are >= 0 (z >= the offset; every tap at least 1/16 texel inside its slice), so
+    //   floor(t)     = the truncating float -> int conversion, and
+    //   t - floor(t) = v_fract_f32(t): the subtraction is exact for every finite t and below 1 for t >= 0, where the instruction's
+    //                  clamp to 1 - 2^-24 never acts
+    // -- the oracle's floor / subtract / convert as two instructions per axis instead of three (r03).
+    const SliceEntry e = table[(uint32_t)slice_position];
     const float u = __builtin_fmaf(e.column_index, c.tsx, position.x * c.tsz);
     const float v = __builtin_fmaf(e.row_index, c.tsy, position.y * c.tsw);
     const float x = __builtin_fmaf(u, c.wf, -0.5f);
     const float y = __builtin_fmaf(v, c.hf, -0.5f);
-    const float x0f = floorf(x), y0f = floorf(y);
-    const float fx = x - x0f, fy = y - y0f, fz = slice_position - vslice;
-    // the sample's cell: row y0f, unfolded column x0f of the atlas (no clamp, no wrap inside the box), moved to the slice's grid
-    const uint32_t column16 = ((uint32_t)(int)x0f << 4) + e.cell_off;
+    const float fx = __builtin_amdgcn_fractf(x), fy = __builtin_amdgcn_fractf(y), fz = __builtin_amdgcn_fractf(slice_position);
+    // the sample's cell: row floor(y), unfolded column floor(x) of the atlas (no clamp, no wrap inside the box), moved to the slice's grid
+    const uint32_t column16 = ((uint32_t)(int)x << 4) + e.cell_off;
     uint32_t offset;
-    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(offset) : "v"((uint32_t)(int)y0f), "s"(c.pitch), "v"(column16));
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(offset) : "v"((uint32_t)(int)y), "s"(c.pitch), "v"(column16));
     float lo0, lo1, hi0, hi1;
     if (FORMAT == ILM_SDF_FP16) {
         // ONE 16-byte load: (w00, w10, w01, w11), each word the f16 pair (slice v, slice v + 1) of a tap

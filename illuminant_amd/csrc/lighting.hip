@@ -242,6 +242,9 @@ ILM_DEV void cone_trace_loop(const f3& start, const f3& dir, float data_y, float
         const int most = (int)ceilf(budget);          // iterations k = 1 .. with S - k > 0 beforehand: k < S
         int k = 0;
         float ran = 0.0f;
+        constexpr float kVisibilityGuard = 1.00000095367431640625f;      // 1 + 2^-20
+        float guard_z = data_z * kVisibilityGuard;
+        bool lit = data_z > ref::kFullyShadowedThreshold;
         while (alive) {
             k++;
             ran = (float)k;
@@ -249,12 +252,23 @@ ILM_DEV void cone_trace_loop(const f3& start, const f3& dir, float data_y, float
             const float s = sample_inside_table<FMT>(sp, F.inside, F.sdf, F.table);
             if (STATS) st.samples++;
             const float local_radius = __builtin_elementwise_minimum(__builtin_fmaf(cone_growth, data_x, ref::kMinConeRadius), cone_max_radius);
-            const float local_visibility = div_no_scale(s + ref::kHackDistanceOffset, local_radius);
-            asm("v_min_f32 %0, %0, %1" : "+v"(data_z) : "v"(local_visibility));
+            // visibility = min(visibility, n / r) with n = distance + HACK_DISTANCE_OFFSET (coneTraceStep, ConeTrace.fxh:62-63).  The quotient
+            // only matters when it is below the running minimum v, and away from obstacles it never is.  With g = fl(v (1 + 2^-20)), kept
+            // beside v: n >= fl(g r) implies n / r > v (the two roundings lose at most 2^-23 relative, r > 0, v > FULLY_SHADOWED_THRESHOLD
+            // while the lane is alive), hence RN(n / r) >= v and the minimum keeps v -- exactly.  When NO lane of the wave can lower its
+            // visibility the 11-instruction division is skipped (a multiply and a compare decide); a NaN fails the test and takes the
+            // division like everything else.  cfg5 10.65 -> 10.01 ms; cfg3 (four times the obstacle density, 2 x 2 texels per wave) unchanged.
+            const float n = s + ref::kHackDistanceOffset;
+            if (__builtin_amdgcn_ballot_w64(!(n >= guard_z * local_radius)) != 0ull) {
+                const float local_visibility = div_no_scale(n, local_radius);
+                asm("v_min_f32 %0, %0, %1" : "+v"(data_z) : "v"(local_visibility));
+                guard_z = data_z * kVisibilityGuard;
+                lit = data_z > ref::kFullyShadowedThreshold;       // (visibility changes here and nowhere else)
+            }
             float step = fabsf(s) * long_step;
             asm("v_max_f32 %0, %0, %1" : "+v"(step) : "v"(cfg_z));
             data_x += step;
-            alive = (k < most) & (data_z > ref::kFullyShadowedThreshold) & (data_y > data_x);
+            alive = (k < most) & lit & (data_y > data_x);
         }
         steps_remaining = budget - ran;
         return;
@@ -266,10 +280,15 @@ ILM_DEV void cone_trace_loop(const f3& start, const f3& dir, float data_y, float
         if (STATS) st.samples++;
         // (both operands are finite: v_minimum3_f32 needs no canonicalising v_max in front of it, unlike IEEE minNum)
         const float local_radius = __builtin_elementwise_minimum(__builtin_fmaf(cone_growth, data_x, ref::kMinConeRadius), cone_max_radius);
-        const float local_visibility = (s + ref::kHackDistanceOffset) / local_radius;
-        // fminf / fmaxf as the bare instructions: the same minNum / maxNum result without the v_max x, x canonicalisation the
-        // compiler puts in front of each loop-carried operand (no signalling NaN can reach them)
-        asm("v_min_f32 %0, %0, %1" : "+v"(data_z) : "v"(local_visibility));
+        // (the same exact skip of the division as in the in-volume loop; a cone radius that is not positive -- the general path admits
+        // any light -- always divides)
+        const float n = s + ref::kHackDistanceOffset;
+        if (__builtin_amdgcn_ballot_w64(!((n >= (data_z * 1.00000095367431640625f) * local_radius) & (local_radius > 0.0f) & (data_z > 0.0f))) != 0ull) {
+            const float local_visibility = n / local_radius;
+            // fminf / fmaxf as the bare instructions: the same minNum / maxNum result without the v_max x, x canonicalisation the
+            // compiler puts in front of each loop-carried operand (no signalling NaN can reach them)
+            asm("v_min_f32 %0, %0, %1" : "+v"(data_z) : "v"(local_visibility));
+        }
         float step = fabsf(s) * long_step;
         asm("v_max_f32 %0, %0, %1" : "+v"(step) : "v"(cfg_z));
         data_x += step;
