@@ -1685,6 +1685,10 @@ int32_t ilm_sdf_render_slices(IlmHandle h, IlmHandle hclear, const IlmDistanceFi
         // shape function can see (they take |p|, p * p, p / size or sgn(p) * ...).  Flagged here, skipped in fields.hip; a centre that
         // is not finite keeps the products (inf * 0 is a NaN there).
         r._pad = (r.qx == 0.0f && r.qy == 0.0f && r.qz == 0.0f && r.qw == 1.0f && std::isfinite(r.cx) && std::isfinite(r.cy) && std::isfinite(r.cz)) ? 1 : 0;
+        // bit 1: sizes and centre of ordinary magnitude (fields.hip: divisions by the sizes may share a refined reciprocal)
+        auto ordinary_size = [](float v) { return v >= 0x1p-10f && v <= 0x1p20f; };
+        if (ordinary_size(r.sx) && ordinary_size(r.sy) && ordinary_size(r.sz) && std::fabs(r.cx) <= 0x1p20f && std::fabs(r.cy) <= 0x1p20f && std::fabs(r.cz) <= 0x1p20f)
+            r._pad |= 2;
         // DistanceFunctionVertexShader, DistanceFunction.fx:16-26
         const float msize = fmaxf(fmaxf(fabsf(o.Size[0]), fabsf(o.Size[1])), fabsf(o.Size[2])) + d->MaximumEncodedDistance + 4.0f;
         r.x0 = (o.Center[0] - msize) * px_per_unit_x; r.x1 = (o.Center[0] + msize) * px_per_unit_x;

@@ -31,7 +31,7 @@ constexpr int kFieldSortCapacity = 512;      // lists up to this length are orde
 ILM_DEV float evaluate_obstruction(int type, f3 wp, const FieldObstruction& o) {
     const f3 local = wp - mk3(o.cx, o.cy, o.cz);
     // identity orientation (uniform flag set by the host): rotateLocalPosition returns its input up to the sign of zero components
-    const f3 p = (o._pad != 0) ? local : rotate_local_q(local, mk4(o.qx, o.qy, o.qz, o.qw));
+    const f3 p = ((o._pad & 1) != 0) ? local : rotate_local_q(local, mk4(o.qx, o.qy, o.qz, o.qw));
     return evaluate_shape(type + 1, p, mk3(o.sx, o.sy, o.sz));
 }
 
@@ -101,6 +101,15 @@ __global__ __launch_bounds__(256) void render_slices_kernel(const FieldLaunch a)
     const float tminy = (float)ty0 + 0.5f, tmaxy = (float)(ty0 + kFieldTileH - 1) + 0.5f;
 
     float acc0 = 0.0f, acc1 = 0.0f, acc2 = 0.0f, acc3 = 0.0f;   // saturate() at the target floors every write at 0
+    // distance / MaximumEncodedDistance (encodeDistance, DistanceFieldCommon.fxh:264-266): a uniform divisor of ordinary size shares one
+    // refined reciprocal (the same correctly rounded quotient); a distance beyond 2^60 takes the IEEE division
+    // "Ordinary magnitudes" (wave-uniform): every coordinate this wave hands to a distance function within 2^20, MaximumEncodedDistance in
+    // [2^-10, 2^20]; per record (api.hip, flag bit 1): sizes in [2^-10, 2^20], centre within 2^20.  Distances, quotients and residuals of
+    // the unscaled division then stay far inside the normal range (no operand needs v_div_scale's rescaling), and its result is the
+    // correctly rounded quotient -- `/`.  Anything else takes the IEEE division.
+    const bool ordinary_coordinates = (a.max_encoded >= 0x1p-10f) && (a.max_encoded <= 0x1p20f) &&
+        (__ballot(!((fabsf(wx) <= 0x1p20f) && (fabsf(wy) <= 0x1p20f) && (fabsf(slice_z[0]) <= 0x1p20f) && (fabsf(slice_z[3]) <= 0x1p20f))) == 0ull);
+    const float max_encoded_rcp = refined_rcp(a.max_encoded);
 
     // ---- analytic obstructions ----------------------------------------------------------------------
     // tile centre in world units (for the nearest-first order of the list)
@@ -180,10 +189,31 @@ __global__ __launch_bounds__(256) void render_slices_kernel(const FieldLaunch a)
             if (!covered)
                 continue;
             const int type = R.type;
-            acc0 = fmaxf(acc0, kDistanceZero - (evaluate_obstruction(type, mk3(wx, wy, slice_z[0]), R) / a.max_encoded));
-            acc1 = fmaxf(acc1, kDistanceZero - (evaluate_obstruction(type, mk3(wx, wy, slice_z[1]), R) / a.max_encoded));
-            acc2 = fmaxf(acc2, kDistanceZero - (evaluate_obstruction(type, mk3(wx, wy, slice_z[2]), R) / a.max_encoded));
-            acc3 = fmaxf(acc3, kDistanceZero - (evaluate_obstruction(type, mk3(wx, wy, slice_z[3]), R) / a.max_encoded));
+            float d[4];
+            if ((R._pad & 1) != 0) {
+                // unrotated (the common case): the four slices of the texel share x and y -- one evaluation with the xy work done once;
+                // bit 1 of the flag: the record's sizes are of ordinary magnitude (api.hip), and so are this wave's coordinates
+                const float pz[4] = { slice_z[0] - R.cz, slice_z[1] - R.cz, slice_z[2] - R.cz, slice_z[3] - R.cz };
+                if (((R._pad & 2) != 0) && ordinary_coordinates)
+                    evaluate_shape4<true>(type + 1, wx - R.cx, wy - R.cy, pz, mk3(R.sx, R.sy, R.sz), d);
+                else
+                    evaluate_shape4<false>(type + 1, wx - R.cx, wy - R.cy, pz, mk3(R.sx, R.sy, R.sz), d);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; k++) d[k] = evaluate_obstruction(type, mk3(wx, wy, slice_z[k]), R);
+            }
+            // encodeDistance: distance / MaximumEncodedDistance (DistanceFieldCommon.fxh:264-266), a uniform divisor
+            if (((R._pad & 2) != 0) && ordinary_coordinates) {
+                acc0 = fmaxf(acc0, kDistanceZero - div_with_rcp(d[0], a.max_encoded, max_encoded_rcp));
+                acc1 = fmaxf(acc1, kDistanceZero - div_with_rcp(d[1], a.max_encoded, max_encoded_rcp));
+                acc2 = fmaxf(acc2, kDistanceZero - div_with_rcp(d[2], a.max_encoded, max_encoded_rcp));
+                acc3 = fmaxf(acc3, kDistanceZero - div_with_rcp(d[3], a.max_encoded, max_encoded_rcp));
+            } else {
+                acc0 = fmaxf(acc0, kDistanceZero - (d[0] / a.max_encoded));
+                acc1 = fmaxf(acc1, kDistanceZero - (d[1] / a.max_encoded));
+                acc2 = fmaxf(acc2, kDistanceZero - (d[2] / a.max_encoded));
+                acc3 = fmaxf(acc3, kDistanceZero - (d[3] / a.max_encoded));
+            }
         }
     }
 

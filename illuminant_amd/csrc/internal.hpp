@@ -210,7 +210,7 @@ hipError_t launch_divide_probe(const float* n, const float* d, int count, float*
 // pixels, computed on the host with the oracle's operations (api.hip is compiled with -ffp-contract=off).
 struct FieldObstruction {
     float cx, cy, cz; int32_t type;
-    float sx, sy, sz; int32_t _pad;       // _pad: 1 when the orientation is the identity quaternion (api.hip): the rotation is skipped
+    float sx, sy, sz; int32_t _pad;       // flags (api.hip): bit 0 the orientation is the identity quaternion (the rotation is skipped), bit 1 sizes and centre of ordinary magnitude
     float qx, qy, qz, qw;
     float x0, x1, y0, y1;       // raster bounds of DistanceFunctionVertexShader's quad, slice-local pixels
     // Exact culling (fields.hip): with e = |world position - centre|, the distance function is provably >= (e - cull_radius) / cull_inv_scale
