@@ -12,7 +12,8 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof_$TAG
 SUM=gpurun_out/profiles_$TAG
 rm -rf "$OUT" "$SUM"; mkdir -p "$OUT" "$SUM"
-BENCH="python bench.py --steps 200 --warmup 20 --no-cpu-baseline"
+# the driver's exact command (kernel durations do not carry over between --steps 200 and --steps 20)
+BENCH="python bench.py --steps 20 --warmup 5"
 SHORT="python bench.py --steps 40 --warmup 5 --light-frames 1 --light-ms 0 --no-cpu-baseline"
 
 # un-profiled reference line (never compare a profiled arm with an un-profiled one: the clocks differ)
@@ -20,7 +21,7 @@ $BENCH > "$SUM/bench_unprofiled.json" 2> "$OUT/bench_unprofiled.err"
 
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o bench -- $BENCH > "$SUM/bench_under_rocprof.json" 2> "$OUT/stats.log"
 for pass in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" \
-            "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+            "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE" \
             "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_INST_LEVEL_VMEM"; do
   name=$(echo "$pass" | tr ' ' '+')
   rocprofv3 --kernel-trace --output-format csv --pmc $pass -d "$OUT/pmc_$name" -o pmc -- $SHORT > "$OUT/pmc_$name.json" 2> "$OUT/pmc_$name.log" || echo "pass $name failed" >> "$SUM/errors.txt"

@@ -40,7 +40,7 @@ def main():
             for r in rows:
                 w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
                 kernel_avg[short(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]))
-        lines += ["## kernel trace (`rocprofv3 --kernel-trace --stats -- python bench.py --steps 200 --warmup 20 --no-cpu-baseline`)", "",
+        lines += ["## kernel trace (`rocprofv3 --kernel-trace --stats -- python bench.py --steps 20 --warmup 5`, the driver's exact command; PMC passes: `--steps 40 --warmup 5 --light-frames 1 --light-ms 0 --no-cpu-baseline`)", "",
                   "| kernel | calls | average us | % of GPU time |", "|---|---|---|---|"]
         for r in rows[:8]:
             lines.append("| `%s` | %s | %.2f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
@@ -86,6 +86,9 @@ def main():
                 lines.append("* waves %.0f; per wave: VALU %.0f, SALU %.0f, SMEM %.0f; VALU busy %.0f quad-cycles per wave; wave cycles %.0f" %
                              (c["SQ_WAVES"], c.get("SQ_INSTS_VALU", 0) / w_, c.get("SQ_INSTS_SALU", 0) / w_, c.get("SQ_INSTS_SMEM", 0) / w_,
                               c.get("SQ_ACTIVE_INST_VALU", 0) / w_, c.get("SQ_WAVE_CYCLES", 0) / w_))
+            if c.get("SQ_THREAD_CYCLES_VALU") and c.get("SQ_ACTIVE_INST_VALU"):
+                lines.append("* lanes active per vector instruction: %.1f of 64 (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU)" %
+                             (c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"]))
             if "SQ_WAIT_ANY" in c and "SQ_ACTIVE_INST_ANY" in c:
                 lines.append("* SQ_WAIT_ANY %.3g, SQ_WAIT_INST_ANY %.3g, SQ_ACTIVE_INST_ANY %.3g (quad-cycles summed over waves)" %
                              (c["SQ_WAIT_ANY"], c["SQ_WAIT_INST_ANY"], c["SQ_ACTIVE_INST_ANY"]))
