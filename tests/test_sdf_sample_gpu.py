@@ -175,6 +175,12 @@ def test_in_volume_sampler_matches_the_oracle_bit_for_bit(ctx, oracle, fmt, reso
     pos[300:1000, 0] = np.tile(edge, 100)                     # the faces of the sampler's box
     pos[1000:1700, 1] = np.tile(edge, 100)
     pos[1700:2000, 2] = np.linspace(-3.0, 125.0, 300, dtype=np.float32)   # every slice boundary region
+    # the half texel before a slice's first column / row and after its last one (tap origin -1 and slice size - 1: the bordered cells,
+    # whose taps bleed into the neighbouring slice like the atlas'), the volume's faces and beyond, z at and past the last valid slice
+    rim = np.float32([0.0, 1e-3, 0.25 * isx, 0.49 * isx, 0.5 * isx, virtual, virtual - 1e-3, virtual - 0.25 * isx, virtual - 0.49 * isx, -1.0, virtual + 3.0])
+    pos[2000:2550, 0] = np.tile(rim, 50)
+    pos[2550:3100, 1] = np.tile(rim, 50)
+    pos[3100:3400, 2] = np.float32(rng.choice([-3.0, -3.0 + 1e-3, 124.9, 125.0, 125.0 + 1e-3, 127.0, 128.0, 140.0], 300))
     got, used = sdf.sample_inside(dfu, pos)
     want = oracle_samples(oracle, pos, dfu, oracle.make_texture(atlas, fmt))
     same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
