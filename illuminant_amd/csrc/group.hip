@@ -12,7 +12,13 @@
 // the library loads and every single-device path works on a machine without it.
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+// The handful of RCCL types the bindings below need, declared here instead of including <rccl/rccl.h>: the library is bound at run time,
+// so its headers are no build dependency either.  ABI facts of nccl.h 2.x / rccl.h: an opaque communicator pointer, a
+// 128-byte unique id passed by value, int-sized enums with ncclSuccess == 0 and ncclInt8 == 0.
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclInt8 = 0 } ncclDataType_t;
 
 #include <cstring>
 #include <mutex>
