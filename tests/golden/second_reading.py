@@ -9,7 +9,9 @@ It cannot make parity "pinned" -- nothing here executes the reference either -- 
 
     L:  sampleGBuffer (no G-buffer bound) -> SphereLightPixelShader -> SphereLightPixelCore -> computeSphereLightOpacity / computeAO /
         coneTrace -> sampleDistanceFieldEx, over a 64 x 48 frame with 4 lights, additive blend onto Ambient in light order;
-    P:  PS_Gravity -> PS_Noise -> PS_Update (+ computeRenderData) on the 4 096 slots of a 64^2 chunk.
+    P:  PS_Gravity -> PS_Noise -> PS_Update (+ computeRenderData) on the 4 096 slots of a 64^2 chunk; PS_FMA; PS_Spawn (Spawn_Stage1 /
+        Spawn_Stage2 / evaluateFormula: all four formula types, inline position constants with and without a polygon, matrices, the
+        alpha discard) into a range of 1 093 slots of a chunk that already holds particles.
 
 Every operation is rounded to float32 on its own (no fused multiply-adds: the HLSL leaves contraction open; oracle/ fuses in the
 sampler, which is why the test compares at 2e-6, not bit for bit).  Texture fetches follow Direct3D's rules as the shaders declare
@@ -455,6 +457,176 @@ def ps_update(sysu, upd, xy, position, velocity, attributes):
     return newPosition, newVelocity, renderColor, renderData
 
 
+def random_rate1(table, xy, offset):
+    """random(xy) = randomCustom(xy, RandomnessOffset, 1), RandomCommon.fxh:28-35 (POINT / WRAP)."""
+    h, w = table.shape[:2]
+    texel = (F(1.0) / F(w), F(1.0) / F(h))
+    return random_custom(table, xy, offset, (F(1), F(1)), texel)
+
+
+def evaluate_formula(origin, constant, scale, offset, randomness, ftype, AxisMask):
+    """evaluateFormula, SpawnerCommon.fxh:58-106; arrays of float4 rows, `ftype` one uniform."""
+    nonCircular = ((randomness + offset).astype(F) * scale).astype(F)
+    type0 = (constant + nonCircular).astype(F)
+    itype = int(abs(np.floor(F(ftype))))
+    if itype in (1, 3):                                      # FormulaType_Spherical, FormulaType_Rectangular
+        # generateRandomNormal3, :45-56
+        phi = ((randomness[:, 0] * PI).astype(F) * F(2)).astype(F)
+        costheta = ((randomness[:, 1] - F(0.5)).astype(F) * F(2)).astype(F)
+        theta = np.arccos(costheta).astype(F)
+        st, ct = np.sin(theta).astype(F), np.cos(theta).astype(F)
+        rn = np.stack([(st * np.cos(phi).astype(F)).astype(F), (st * np.sin(phi).astype(F)).astype(F), ct], axis=1)
+        randomNormal = normalize3((rn * AxisMask[None, :]).astype(F))
+        circular = ((randomNormal * randomness[:, 2:3]).astype(F) * scale[:, :3]).astype(F)
+        if itype == 3:
+            sqrt2 = F(1.41421356237)
+            edge = np.abs(offset[:, :3])
+            result = np.clip(((offset[:, :3] * randomNormal).astype(F) * sqrt2).astype(F), -edge, edge).astype(F)
+            result = (result + (constant[:, :3] + circular).astype(F)).astype(F)
+        else:
+            circular = (circular + (randomNormal * offset[:, :3]).astype(F)).astype(F)
+            result = (constant[:, :3] + circular).astype(F)
+        return np.concatenate([result, type0[:, 3:4]], axis=1).astype(F)
+    if itype == 2:                                           # FormulaType_Towards
+        distance = (constant[:, :3] - origin[:, :3]).astype(F)
+        ldistance = length3(distance[:, 0], distance[:, 1], distance[:, 2])
+        with np.errstate(all="ignore"):
+            direction = (distance / ldistance[:, None]).astype(F)
+        randomSpeed = ((randomness[:, 0:1] * scale[:, :3]).astype(F) * direction).astype(F)
+        fixedSpeed = (offset[:, :3] * direction).astype(F)
+        out = np.concatenate([(randomSpeed + fixedSpeed).astype(F), type0[:, 3:4]], axis=1).astype(F)
+        near = ldistance < 0.1
+        out[near] = np.concatenate([np.zeros((int(near.sum()), 3), F), constant[near, 3:4]], axis=1)
+        return out
+    return type0                                             # FormulaType_Linear / default
+
+
+def ps_spawn(sp, table, chunk_size, position, velocity, attributes):
+    """PS_Spawn, SpawnParticles.fx:10-32 = Spawn_Stage1 + Spawn_Stage2 (SpawnerCommon.fxh:121-189) for every slot of the chunk; slots outside
+    [ChunkSizeAndIndices.y, .z] and discarded ones keep their contents (the draw leaves the render targets alone)."""
+    cs = chunk_size
+    slots = np.arange(cs * cs)
+    xy = np.stack([(slots % cs).astype(F), (slots // cs).astype(F)], axis=1)
+    csi = np.array(list(sp.ChunkSizeAndIndices), F)
+    index = (xy[:, 0] + (xy[:, 1] * csi[0]).astype(F)).astype(F)
+    inside = ~((index < csi[1]) | (index > csi[2]))
+    idx = index[inside]
+    off = (F(sp.RandomnessOffset[0]), F(sp.RandomnessOffset[1]))
+    # evaluateRandomForIndex, :108-119
+    def rnd(a, b, c):
+        return random_rate1(table, np.stack([np.fmod(idx, F(a)), (F(b) + np.fmod(idx, F(c))).astype(F)], axis=1), off)
+    random1, random2, random3 = rnd(8039, 0, 57), rnd(6180, 1, 4031), rnd(2025, 2, 65531)
+    if sp.AlignVelocityAndPosition != 0:
+        random2 = random2.copy()
+        random2[:, :2] = random1[:, :2]
+    relativeIndex = (idx - csi[1]).astype(F)
+    count = F(sp.PositionConstantCount)
+    if F(sp.PolygonRate) > 0.05:
+        positionIndexF = ((relativeIndex / F(sp.PolygonRate)).astype(F) + csi[3]).astype(F)
+        positionIndexI = np.trunc(positionIndexF).astype(F)                        # modf
+        positionIndexT = (positionIndexF - positionIndexI).astype(F)
+        index1 = np.fmod(positionIndexI, count).astype(np.int64)                   # int index1 = float % float
+        if sp.PolygonLoop != 0:
+            index2 = np.fmod((positionIndexI + F(1)).astype(F), count).astype(np.int64)
+        else:
+            index2 = np.minimum(index1 + 1, int(count - 1))
+    else:
+        index1 = index2 = np.fmod((relativeIndex + csi[3]).astype(F), count).astype(np.int64)
+        positionIndexT = np.zeros_like(idx)
+    consts = np.array([[c.x, c.y, c.z, c.w] for c in sp.InlinePositionConstants], F)
+    position1, position2 = consts[index1], consts[index2]
+    positionConstant = lerp(position1, position2, positionIndexT[:, None])
+    towardsNext = (position2 - position1).astype(F)
+    cfg = np.array([[c.x, c.y, c.z, c.w] for c in sp.Configuration], F)
+    ft = np.array(list(sp.FormulaTypes), F)
+    axis = np.array(list(sp.AxisMask), F)
+    n = idx.shape[0]
+    rows = lambda v: np.broadcast_to(np.asarray(v, F), (n, 4))
+    zero4 = np.zeros((n, 4), F)
+    # Spawn_Stage2
+    tempPosition = evaluate_formula(zero4, positionConstant, rows(cfg[0]), rows(cfg[1]), random1, ft[0], axis)
+
+    def mul_row_vector(v3, m):                                                     # mul(float4(v, 1), M)
+        M = np.array(list(m.m), F).reshape(4, 4)
+        v4 = np.concatenate([v3, np.ones((v3.shape[0], 1), F)], axis=1)
+        out = np.zeros((v3.shape[0], 4), F)
+        for j in range(4):
+            acc = (v4[:, 0] * M[0, j]).astype(F)
+            for i in range(1, 4):
+                acc = (acc + (v4[:, i] * M[i, j]).astype(F)).astype(F)
+            out[:, j] = acc
+        return out
+    newPosition = mul_row_vector(tempPosition[:, :3], sp.PositionMatrix)
+    newPosition[:, 3] = tempPosition[:, 3]
+    tempVelocity = evaluate_formula(tempPosition, rows(cfg[2]), rows(cfg[3]), rows(cfg[4]), random2, ft[1], axis)
+    newAttributes = evaluate_formula(zero4, rows(cfg[5]), rows(cfg[6]), rows(cfg[7]), random3, ft[2], axis)
+    towardsDistance = np.sqrt((((towardsNext[:, 0] * towardsNext[:, 0]).astype(F) + (towardsNext[:, 1] * towardsNext[:, 1]).astype(F)).astype(F) +
+                               ((towardsNext[:, 2] * towardsNext[:, 2]).astype(F) + (towardsNext[:, 3] * towardsNext[:, 3]).astype(F)).astype(F)).astype(F)).astype(F)
+    far = towardsDistance > 0.0001
+    if far.any():
+        # float -> float4 promotion of Configuration[8].x/.y/.z and random3.w; only .x of the result is used
+        c8 = cfg[8]
+        speed = evaluate_formula(zero4, rows([c8[0]] * 4), rows([c8[1]] * 4), rows([c8[2]] * 4), np.repeat(random3[:, 3:4], 4, axis=1), ft[3], axis)[:, 0]
+        with np.errstate(all="ignore"):
+            add = (speed[:, None] * (towardsNext / towardsDistance[:, None]).astype(F)).astype(F)
+        tempVelocity = np.where(far[:, None], (tempVelocity + add).astype(F), tempVelocity)
+    newVelocity = mul_row_vector(tempVelocity[:, :3], sp.VelocityMatrix)
+    newVelocity[:, 3] = tempVelocity[:, 3]
+    keep = ~(newAttributes[:, 3] < F(sp.AttributeDiscardThreshold))                  # discard
+    outp, outv, outa = position.copy(), velocity.copy(), attributes.copy()
+    target = np.flatnonzero(inside)[keep]
+    outp[target], outv[target], outa[target] = newPosition[keep], newVelocity[keep], newAttributes[keep]
+    return outp, outv, outa
+
+
+def ps_fma(sysu, f, position, velocity):
+    """PS_FMA, FMA.fx:31-49 with AreaType 0."""
+    cf = (F(f.Area.CategoryFilter[0]), F(f.Area.CategoryFilter[1]))
+    skip = (position[:, 3] <= 0) | ~((velocity[:, 3] >= cf[0]) & (velocity[:, 3] <= cf[1]))
+    with np.errstate(all="ignore"):
+        weight = F(F(F(1) - saturate(F(0) / F(f.Area.AreaFalloff))) * F(f.Area.Strength))
+    t = F(F(weight * sysu.getDeltaTime()) / F(f.TimeDivisor))
+    newPosition = lerp(position, ((position * f4(f.PositionMultiply)[None, :]).astype(F) + f4(f.PositionAdd)[None, :]).astype(F), t)
+    newVelocity = lerp(velocity, ((velocity * f4(f.VelocityMultiply)[None, :]).astype(F) + f4(f.VelocityAdd)[None, :]).astype(F), t)
+    newPosition[skip], newVelocity[skip] = position[skip], velocity[skip]
+    return newPosition, newVelocity
+
+
+SPAWN_CASES = {
+    "spherical": dict(position=((120, 90, 2), (80, 60, 10), (3, 2, 1), scenes.FORMULA_SPHERICAL),
+                      velocity=((1, -2, 0.5), (40, 40, 40), (2, 2, 2), scenes.FORMULA_SPHERICAL), life=(3.3, 2.7, 0.1), align=True),
+    "linear_matrix": dict(position=((10, 20, 1), (50, 60, 4), (-0.5, -0.5, 0), scenes.FORMULA_LINEAR),
+                          velocity=((1, 2, 3), (30, 30, 5), (-0.5, -0.5, -0.5), scenes.FORMULA_LINEAR),
+                          life=(2.0, 1.0, 0.5), category=(1.0, 2.0, 0.0), color=((0.5, 0.4, 0.3, 0.2), (0.5, 0.6, 0.7, 0.8), (0, 0, 0, 0)),
+                          position_matrix=abi.Matrix.from_rows([[0.8, 0.6, 0, 0], [-0.6, 0.8, 0, 0], [0, 0, 1, 0], [5, -3, 2, 1]]),
+                          velocity_matrix=abi.Matrix.from_rows([[0, 1, 0, 0], [-1, 0, 0, 0], [0, 0, 2, 0], [0.5, 0.25, 0, 1]])),
+    "rectangular_towards": dict(position=((200, 200, 0), (40, 40, 0), (30, 20, 0), scenes.FORMULA_RECTANGULAR),
+                                velocity=((256, 256, 0), (20, 20, 20), (35, 35, 35), scenes.FORMULA_TOWARDS), axis_mask=(1, 1, 0)),
+    "polygon_discard": dict(position=((10, 10, 0), (3, 3, 0), (0, 0, 0), scenes.FORMULA_SPHERICAL),
+                            velocity=((0, 0, 0), (5, 5, 5), (0, 0, 0), scenes.FORMULA_SPHERICAL),
+                            additional_positions=((200, 10, 0), (200, 200, 5)), polygon_rate=7.0, polygon_loop=True, polygon_speed=(12.0, 6.0, 0.1),
+                            color=((1, 1, 1, 0.0), (0, 0, 0, 1.0), (0, 0, 0, 0)), alpha_discard_threshold=96.0),
+}
+
+
+def spawn_inputs(case):
+    cs = 64
+    pos, vel, attr = scenes.make_particles(400, cs * cs, dead_fraction=0.5)
+    sp = scenes.spawn_params(cs, 777, 777 + 1092, 31337, (0.42 * 253, 0.77 * 127), **SPAWN_CASES[case])
+    return dict(chunk_size=cs, pos=pos, vel=vel, attr=attr, rnd=scenes.randomness_table(9), spawn=sp)
+
+
+def fma_inputs():
+    P = particle_inputs()
+    f = abi.FMAParams()
+    f.Area = scenes.area_none(strength=0.6)
+    f.TimeDivisor = 250.0
+    f.PositionAdd, f.PositionMultiply = abi.f4(1.5, -2.0, 0.25, 0.0), abi.f4(0.98, 1.01, 1.0, 1.0)
+    f.VelocityAdd, f.VelocityMultiply = abi.f4(0.0, 9.8, 0.0, 0.0), abi.f4(0.9, 0.9, 0.5, 1.0)
+    P["fma"] = f
+    return P
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # the fixture's inputs (shared with tests/test_second_reading.py) and the generator
 # ---------------------------------------------------------------------------------------------------------------------
@@ -498,8 +670,15 @@ def main():
     p1, v1 = ps_gravity(sysu, P["gravity"], P["pos"], P["vel"])
     p2, v2 = ps_noise(sysu, P["noise"], P["rnd"], xy, p1, v1)
     p3, v3, rc, rd = ps_update(sysu, P["update"], xy, p2, v2, P["attr"])
+    extra = {}
+    for case in SPAWN_CASES:
+        S = spawn_inputs(case)
+        sp_, sv_, sa_ = ps_spawn(S["spawn"], S["rnd"], S["chunk_size"], S["pos"], S["vel"], S["attr"])
+        extra["spawn_%s_position" % case], extra["spawn_%s_velocity" % case], extra["spawn_%s_attributes" % case] = sp_, sv_, sa_
+    Pf = fma_inputs()
+    extra["after_fma_position"], extra["after_fma_velocity"] = ps_fma(System(Pf["system"]), Pf["fma"], Pf["pos"], Pf["vel"])
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "second_reading.npz")
-    np.savez_compressed(out, lightmap=frame, light_counts=np.array([samples, pairs, traced], np.int64),
+    np.savez_compressed(out, **extra, lightmap=frame, light_counts=np.array([samples, pairs, traced], np.int64),
                         after_gravity_velocity=v1, after_noise_position=p2, after_noise_velocity=v2,
                         position=p3, velocity=v3, render_color=rc, render_data=rd)
     print("wrote %s: %d SDF samples, %d pixel-light pairs, %d traced; %d live particles of %d" % (out, samples, pairs, traced, int((p3[:, 3] > 0).sum()), cs * cs))

@@ -79,3 +79,34 @@ def test_particle_passes_of_the_second_reading(oracle):
     assert_close(chunk[4], FIX["render_data"], "RenderData", **TOL)
     live = FIX["position"][:, 3] > 0
     assert 0.5 < live.mean() < 0.9 and (P["pos"][:, 3] > 0).sum() > live.sum()          # some particles die in this step
+
+
+import pytest
+
+
+@pytest.mark.parametrize("case", sorted(second.SPAWN_CASES))
+def test_spawn_of_the_second_reading(oracle, case):
+    """PS_Spawn: the same slots written (range, alpha discard), everything else untouched bit for bit, the written values within 2e-6."""
+    S = second.spawn_inputs(case)
+    pos, vel, attr = S["pos"].copy(), S["vel"].copy(), S["attr"].copy()
+    oracle.spawn(pos, vel, attr, S["chunk_size"], S["rnd"], S["spawn"])
+    want = [FIX["spawn_%s_%s" % (case, k)] for k in ("position", "velocity", "attributes")]
+    written = np.any(want[0] != S["pos"], axis=1) | np.any(want[1] != S["vel"], axis=1) | np.any(want[2] != S["attr"], axis=1)
+    got_written = np.any(pos != S["pos"], axis=1) | np.any(vel != S["vel"], axis=1) | np.any(attr != S["attr"], axis=1)
+    assert np.array_equal(written, got_written), "PS_Spawn wrote different slots than the second reading"
+    if case == "polygon_discard":
+        assert 100 < written.sum() < 1000          # the discard removes a real share of the range
+    else:
+        assert written.sum() == 1093
+    for got, w, name in zip((pos, vel, attr), want, ("position", "velocity", "attributes")):
+        assert np.array_equal(got[~written], w[~written])
+        assert_close(got, w, "PS_Spawn %s, %s" % (name, case), **TOL)
+
+
+def test_fma_of_the_second_reading(oracle):
+    P = second.fma_inputs()
+    pos, vel = P["pos"].copy(), P["vel"].copy()
+    oracle.fma(pos, vel, P["chunk_size"], P["system"], P["fma"])
+    assert_close(pos, FIX["after_fma_position"], "position after PS_FMA", **TOL)
+    assert_close(vel, FIX["after_fma_velocity"], "velocity after PS_FMA", **TOL)
+    assert np.abs(pos - P["pos"]).max() > 1e-3

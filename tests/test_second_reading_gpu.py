@@ -46,3 +46,43 @@ def test_particle_step_against_the_second_reading(ctx):
     for plane, key in ((abi.PLANE_POSITION, "position"), (abi.PLANE_VELOCITY, "velocity"), (abi.PLANE_RENDER_COLOR, "render_color"), (abi.PLANE_RENDER_DATA, "render_data")):
         assert_close(sysm.download(0, plane), FIX[key], "GPU %s vs the second reading" % key)
     sysm.close(); eng.close()
+
+
+def _system_with(ctx, cs, rnd, pos, vel, attr):
+    eng = native.Engine(ctx, cs, rnd)
+    sysm = native.System(eng)
+    sysm.add_chunk()
+    for plane, data in ((abi.PLANE_POSITION, pos), (abi.PLANE_VELOCITY, vel), (abi.PLANE_ATTRIBUTES, attr)):
+        sysm.upload(0, plane, data)
+    return eng, sysm
+
+
+@pytest.mark.parametrize("case", sorted(second.SPAWN_CASES))
+def test_spawn_against_the_second_reading(ctx, case):
+    S = second.spawn_inputs(case)
+    P = second.particle_inputs()
+    eng, sysm = _system_with(ctx, S["chunk_size"], S["rnd"], S["pos"], S["vel"], S["attr"])
+    sysm.spawn(0, P["system"], S["spawn"])
+    before = dict(position=S["pos"], velocity=S["vel"], attributes=S["attr"])
+    planes = dict(position=abi.PLANE_POSITION, velocity=abi.PLANE_VELOCITY, attributes=abi.PLANE_ATTRIBUTES)
+    want = {k: FIX["spawn_%s_%s" % (case, k)] for k in planes}
+    got = {k: sysm.download(0, planes[k]) for k in planes}
+    written = np.zeros(len(S["pos"]), bool)
+    got_written = np.zeros(len(S["pos"]), bool)
+    for k in planes:
+        written |= np.any(want[k] != before[k], axis=1)
+        got_written |= np.any(got[k] != before[k], axis=1)
+    assert np.array_equal(written, got_written), "the spawn kernel wrote different slots than the second reading"
+    for k in planes:
+        assert np.array_equal(got[k][~written], want[k][~written])
+        assert_close(got[k], want[k], "GPU PS_Spawn %s, %s vs the second reading" % (k, case))
+    sysm.close(); eng.close()
+
+
+def test_fma_against_the_second_reading(ctx):
+    P = second.fma_inputs()
+    eng, sysm = _system_with(ctx, P["chunk_size"], P["rnd"], P["pos"], P["vel"], P["attr"])
+    sysm.fma(0, P["system"], P["fma"])
+    assert_close(sysm.download(0, abi.PLANE_POSITION), FIX["after_fma_position"], "GPU position after PS_FMA vs the second reading")
+    assert_close(sysm.download(0, abi.PLANE_VELOCITY), FIX["after_fma_velocity"], "GPU velocity after PS_FMA vs the second reading")
+    sysm.close(); eng.close()
