@@ -11,7 +11,8 @@ It cannot make parity "pinned" -- nothing here executes the reference either -- 
         coneTrace -> sampleDistanceFieldEx, over a 64 x 48 frame with 4 lights, additive blend onto Ambient in light order;
     P:  PS_Gravity -> PS_Noise -> PS_Update (+ computeRenderData) on the 4 096 slots of a 64^2 chunk; PS_FMA; PS_Spawn (Spawn_Stage1 /
         Spawn_Stage2 / evaluateFormula: all four formula types, inline position constants with and without a polygon, matrices, the
-        alpha discard) into a range of 1 093 slots of a chunk that already holds particles.
+        alpha discard) into a range of 1 093 slots of a chunk that already holds particles; the collision update
+        (UpdateParticleSystemWithDistanceField.fx PS_Update + estimateNormal4) on 4 096 particles in the demo's field of cylinders and walls.
 
 Every operation is rounded to float32 on its own (no fused multiply-adds: the HLSL leaves contraction open; oracle/ fuses in the
 sampler, which is why the test compares at 2e-6, not bit for bit).  Texture fetches follow Direct3D's rules as the shaders declare
@@ -403,6 +404,163 @@ def evaluate_bezier(rangeAndCount, abcd, value):
     return lerp(np.asarray(a, F), np.asarray(b, F), t[..., None] if np.ndim(a) else t)
 
 
+def compute_render_data(sysu, upd, vpos, np_, nv_, attributes):
+    """computeRenderData, UpdateCommon.fxh:97-117 (+ getRotationForVelocity :82-95) for the slots that passed readStateOrDiscard."""
+    index = (vpos[:, 0] + (vpos[:, 1] * F(256)).astype(F)).astype(F)
+    velocityLength = np.maximum(length3(nv_[:, 0], nv_[:, 1], nv_[:, 2]), F(0.0001))
+    life = np_[:, 3]
+    color = (evaluate_bezier(upd.ColorFromLife.RangeAndCount, (f4(upd.ColorFromLife.A), f4(upd.ColorFromLife.B)), life) *
+             evaluate_bezier(upd.ColorFromVelocity.RangeAndCount, (f4(upd.ColorFromVelocity.A), f4(upd.ColorFromVelocity.B)), velocityLength)).astype(F)
+    assert f4(upd.LifeRampSettings)[0] == 0                                                 # getRampedColorForLifeValueAndIndex: no life ramp
+    rc = (attributes * color).astype(F)
+    rc[:, 3] = saturate(rc[:, 3])
+    rc[:, :3] = (rc[:, :3] * rc[:, 3:4]).astype(F)
+    size = (evaluate_bezier(upd.SizeFromLife.RangeAndCount, f4(upd.SizeFromLife.ABCD), life) *
+            evaluate_bezier(upd.SizeFromVelocity.RangeAndCount, f4(upd.SizeFromVelocity.ABCD), velocityLength)).astype(F)
+    # getRotationForVelocity, :82-95
+    still = (np.abs(nv_[:, 0]) < 0.01) & (np.abs(nv_[:, 1]) < 0.01)
+    with np.errstate(invalid="ignore"):
+        angle = np.arctan2(nv_[:, 1], nv_[:, 0]).astype(F)
+    angle = np.where(angle < 0, (angle + F(F(2) * PI)).astype(F), angle)
+    angle = np.where(still, F(0), angle).astype(F)
+    rfl = (F(upd.RotationFromLifeAndIndex[0]), F(upd.RotationFromLifeAndIndex[1]))
+    rd = np.zeros_like(rc)
+    rd[:, 0] = size
+    rd[:, 1] = ((angle * sysu.getVelocityRotation()).astype(F) + ((life * rfl[0]).astype(F) + (index * rfl[1]).astype(F)).astype(F)).astype(F)
+    rd[:, 2] = velocityLength
+    rd[:, 3] = nv_[:, 3]
+    dead_now = ~(np_[:, 3] > 0)                                                              # computeRenderData: position.w <= 0 -> zeros
+    rc[dead_now], rd[dead_now] = 0, 0
+    return rc, rd
+
+
+def apply_friction_and_maximum(sysu, velocity3):
+    """applyFrictionAndMaximum, UpdateCommon.fxh:20-36."""
+    l = length3(velocity3[:, 0], velocity3[:, 1], velocity3[:, 2])
+    tiny = l <= 0.001
+    l2 = np.minimum(l, sysu.getMaximumVelocity())
+    friction = (l2 * sysu.getFriction()).astype(F)
+    l2 = (l2 - (friction * sysu.getDeltaTimeSeconds()).astype(F)).astype(F)
+    l2 = np.clip(l2, F(0), sysu.getMaximumVelocity())
+    vel3 = (normalize3(velocity3) * l2[:, None]).astype(F)
+    vel3[tiny] = 0
+    return vel3
+
+
+def estimate_normal4(field, position):
+    """estimateNormal4, VisualizeCommon.fxh:44-63; VISUALIZE_TEXEL :9-16."""
+    texel = np.array([field._ConeAndMisc[3], field._StepAndMisc2[3], F(field.Extent[2] / max(field.TextureSliceCount[3], F(1)))], F)
+    result = np.zeros_like(position)
+    for weight in (np.array(w, F) for w in ((1, -1, -1), (-1, -1, 1), (-1, 1, -1), (1, 1, 1))):            # normalK.xyy, .yyx, .yxy, .xxx
+        p = (position + (weight * texel).astype(F)[None, :]).astype(F)
+        sample = field.sampleDistanceFieldEx(p[:, 0], p[:, 1], p[:, 2])
+        result = (result + (weight[None, :] * sample[:, None]).astype(F)).astype(F)
+    return normalize3(result)
+
+
+def ps_update_with_distance_field(sysu, upd, field, xy, position, velocity, attributes):
+    """PS_Update, UpdateParticleSystemWithDistanceField.fx:29-147, statement by statement over the slots that pass readStateOrDiscard."""
+    MAX_STEP_COUNT, BOUNCE_DELAY, NO_NORMAL_THRESHOLD = 3, F(3), F(0.33)
+    INITIAL_ESCAPE_SPEED, ESCAPE_SPEED_ACCELERATION = F(0.33), F(1.1)
+    collisionDistanceSetting = F(sysu.CollisionSettings[2])
+    n = position.shape[0]
+    outPosition, outVelocity = np.zeros((n, 4), F), np.zeros((n, 4), F)
+    outColor, outData = np.zeros((n, 4), F), np.zeros((n, 4), F)
+    alive = position[:, 3] > 0
+    oldPosition, oldVelocity, vpos = position[alive], velocity[alive], xy[alive]
+    m = oldPosition.shape[0]
+    dts = sysu.getDeltaTimeSeconds()
+    newLife = (oldPosition[:, 3] - F(sysu.getLifeDecayRate() * dts)).astype(F)
+    early = newLife <= 0                                                                     # everything 0, return
+    unitVector = normalize3(oldVelocity[:, :3])
+    velocity3 = apply_friction_and_maximum(sysu, oldVelocity[:, :3])
+    scaledVelocity = (velocity3 * dts).astype(F)
+    old3 = oldPosition[:, :3]
+    collided, escaping = np.zeros(m, bool), np.zeros(m, bool)
+    collisionPosition = np.zeros((m, 3), F)
+    initialDistance = field.sampleDistanceFieldEx(old3[:, 0], old3[:, 1], old3[:, 2])
+    wasColliding = initialDistance < collisionDistanceSetting
+    travelDistance = np.maximum(F(0), np.minimum(initialDistance, length3(scaledVelocity[:, 0], scaledVelocity[:, 1], scaledVelocity[:, 2])))
+    stepCount = np.full(m, MAX_STEP_COUNT)
+    stepCount[wasColliding] = 1
+    stepCount[~wasColliding & (travelDistance <= 0.001)] = 0
+    stepCount[early] = 0                                                                     # (returned above)
+    sampled = np.zeros(m, np.int64) + (~early)
+    for i in range(MAX_STEP_COUNT):
+        run = i < stepCount
+        if not run.any():
+            break
+        testPosition = (old3 + (travelDistance[:, None] * unitVector).astype(F)).astype(F)
+        with np.errstate(invalid="ignore"):
+            stepDistance = field.sampleDistanceFieldEx(testPosition[:, 0], testPosition[:, 1], testPosition[:, 2])
+        sampled += run
+        hit = run & (stepDistance < collisionDistanceSetting)
+        collided |= hit
+        collisionPosition[hit] = testPosition[hit]
+        escaping = np.where(run, stepDistance > initialDistance, escaping)
+        cont = run & collided & ~escaping
+        collisionPosition[cont] = testPosition[cont]
+        offset = np.clip((stepDistance + collisionDistanceSetting).astype(F), F(0.05), F(16))
+        travelDistance = np.where(cont, np.maximum(F(0), (travelDistance - offset).astype(F)), travelDistance).astype(F)
+        stepCount[run & ~cont] = 0
+        stepCount[run & (travelDistance <= 0.001)] = 0
+
+    newVelocity = np.zeros((m, 4), F)
+    newPosition = old3.copy()
+    bounce = oldVelocity[:, 3] <= 0
+    redirect = wasColliding & ~escaping
+    need_normal = collided & (bounce | redirect)
+    normal = np.zeros((m, 3), F)
+    if need_normal.any():
+        normal[need_normal] = estimate_normal4(field, collisionPosition[need_normal])
+        sampled[need_normal] += 4
+    escapeSpeed = np.minimum(sysu.getMaximumVelocity(), F(sysu.CollisionSettings[0]))
+    # redirect
+    r = collided & redirect
+    if r.any():
+        nr = (normal[r] * np.array([1, 1, 0], F)[None, :]).astype(F)                         # ESCAPE_MASK
+        weak = length3(nr[:, 0], nr[:, 1], nr[:, 2]) < NO_NORMAL_THRESHOLD
+        a = ((vpos[r, 0] / F(67)).astype(F) + (vpos[r, 1] / F(13)).astype(F)).astype(F)
+        nr[weak] = np.stack([np.sin(a).astype(F), np.cos(a).astype(F), np.zeros_like(a)], axis=1)[weak]
+        escapeVector = normalize3(nr)
+        nv = ((escapeVector * escapeSpeed).astype(F) * INITIAL_ESCAPE_SPEED).astype(F)
+        newVelocity[r] = np.concatenate([nv, np.full((nv.shape[0], 1), BOUNCE_DELAY, F)], axis=1)
+        newPosition[r] = (old3[r] + (nv * dts).astype(F)).astype(F)
+    # bounce
+    b = collided & ~redirect & bounce
+    if b.any():
+        nb, ub = normal[b], unitVector[b]
+        d = ((nb[:, 0] * ub[:, 0]).astype(F) + (nb[:, 1] * ub[:, 1]).astype(F)).astype(F)
+        d = (d + (nb[:, 2] * ub[:, 2]).astype(F)).astype(F)
+        bounceVector = -(((F(2) * d).astype(F))[:, None] * (nb - ub).astype(F)).astype(F)
+        weak = length3(bounceVector[:, 0], bounceVector[:, 1], bounceVector[:, 2]) < NO_NORMAL_THRESHOLD
+        bounceVector = np.where(weak[:, None], -ub, normalize3(bounceVector)).astype(F)
+        speed = np.minimum(sysu.getMaximumVelocity(), (length3(velocity3[b, 0], velocity3[b, 1], velocity3[b, 2]) * F(sysu.CollisionSettings[1])).astype(F))
+        newPosition[b] = collisionPosition[b]
+        newVelocity[b] = np.concatenate([(bounceVector * speed[:, None]).astype(F), np.full((nb.shape[0], 1), BOUNCE_DELAY, F)], axis=1)
+        newLife = newLife.copy()
+        newLife[b] = (newLife[b] - F(sysu.CollisionSettings[3])).astype(F)
+    # escaping: keep going (newVelocity.w stays 0)
+    e = collided & ~redirect & ~bounce
+    if e.any():
+        currentSpeed = length3(oldVelocity[e, 0], oldVelocity[e, 1], oldVelocity[e, 2])
+        newSpeed = np.maximum((currentSpeed * ESCAPE_SPEED_ACCELERATION).astype(F), escapeSpeed)
+        newVelocity[e, :3] = (unitVector[e] * newSpeed[:, None]).astype(F)
+        newPosition[e] = (old3[e] + (travelDistance[e, None] * unitVector[e]).astype(F)).astype(F)
+    # no collision
+    f = ~collided
+    newVelocity[f] = np.concatenate([velocity3[f], np.maximum((oldVelocity[f, 3] - F(1)).astype(F), F(0))[:, None]], axis=1)
+    newPosition[f] = (old3[f] + (travelDistance[f, None] * unitVector[f]).astype(F)).astype(F)
+    gone = early | (newLife <= 0)
+    newPosition[gone], newVelocity[gone] = 0, 0
+    resultPosition = np.concatenate([newPosition, newLife[:, None]], axis=1).astype(F)
+    resultPosition[early] = 0
+    rc, rd = compute_render_data(sysu, upd, vpos, resultPosition, newVelocity, attributes[alive])
+    rc[early], rd[early] = 0, 0
+    outPosition[alive], outVelocity[alive], outColor[alive], outData[alive] = resultPosition, newVelocity, rc, rd
+    return outPosition, outVelocity, outColor, outData, int(sampled.sum()), dict(collided=int(collided.sum()), redirected=int(r.sum()), bounced=int(b.sum()), escaping=int(e.sum()))
+
+
 def ps_update(sysu, upd, xy, position, velocity, attributes):
     """PS_Update, UpdateParticleSystem.fx:9-38 + applyFrictionAndMaximum / computeRenderData, UpdateCommon.fxh:20-36,97-117."""
     n = position.shape[0]
@@ -427,32 +585,7 @@ def ps_update(sysu, upd, xy, position, velocity, attributes):
     np_[lives, 3] = newLife[lives]
     nv_[lives, :3] = vel3[lives]
     nv_[lives, 3] = oldVelocity[lives, 3]
-    # computeRenderData
-    vpos = xy[alive]
-    index = (vpos[:, 0] + (vpos[:, 1] * F(256)).astype(F)).astype(F)
-    velocityLength = np.maximum(length3(nv_[:, 0], nv_[:, 1], nv_[:, 2]), F(0.0001))
-    life = np_[:, 3]
-    color = (evaluate_bezier(upd.ColorFromLife.RangeAndCount, (f4(upd.ColorFromLife.A), f4(upd.ColorFromLife.B)), life) *
-             evaluate_bezier(upd.ColorFromVelocity.RangeAndCount, (f4(upd.ColorFromVelocity.A), f4(upd.ColorFromVelocity.B)), velocityLength)).astype(F)
-    assert f4(upd.LifeRampSettings)[0] == 0                                                 # getRampedColorForLifeValueAndIndex: no life ramp
-    rc = (attributes[alive] * color).astype(F)
-    rc[:, 3] = saturate(rc[:, 3])
-    rc[:, :3] = (rc[:, :3] * rc[:, 3:4]).astype(F)
-    size = (evaluate_bezier(upd.SizeFromLife.RangeAndCount, f4(upd.SizeFromLife.ABCD), life) *
-            evaluate_bezier(upd.SizeFromVelocity.RangeAndCount, f4(upd.SizeFromVelocity.ABCD), velocityLength)).astype(F)
-    # getRotationForVelocity, :82-95
-    still = (np.abs(nv_[:, 0]) < 0.01) & (np.abs(nv_[:, 1]) < 0.01)
-    angle = np.arctan2(nv_[:, 1], nv_[:, 0]).astype(F)
-    angle = np.where(angle < 0, (angle + F(F(2) * PI)).astype(F), angle)
-    angle = np.where(still, F(0), angle).astype(F)
-    rfl = (F(upd.RotationFromLifeAndIndex[0]), F(upd.RotationFromLifeAndIndex[1]))
-    rd = np.zeros_like(rc)
-    rd[:, 0] = size
-    rd[:, 1] = ((angle * sysu.getVelocityRotation()).astype(F) + ((life * rfl[0]).astype(F) + (index * rfl[1]).astype(F)).astype(F)).astype(F)
-    rd[:, 2] = velocityLength
-    rd[:, 3] = nv_[:, 3]
-    dead_now = ~lives                                                                        # computeRenderData: position.w <= 0 -> zeros
-    rc[dead_now], rd[dead_now] = 0, 0
+    rc, rd = compute_render_data(sysu, upd, xy[alive], np_, nv_, attributes[alive])
     newPosition[alive], newVelocity[alive], renderColor[alive], renderData[alive] = np_, nv_, rc, rd
     return newPosition, newVelocity, renderColor, renderData
 
@@ -659,6 +792,27 @@ def particle_inputs():
     return dict(chunk_size=cs, pos=pos, vel=vel, attr=attr, rnd=rnd, system=sysu, gravity=g, noise=nz, update=upd)
 
 
+COLLISION_CASES = {
+    # the uniforms as the lighting path binds them / as the particle path does (DistanceFieldPacked1 left at zero: every lookup reads
+    # slice 0, ParticleSystem.cs SetDistanceFieldUniforms); with and without the bounce
+    "packed1_no_bounce": dict(packed1=True, bounce=0.0, seed=600),
+    "particle_path_bounce": dict(packed1=False, bounce=0.6, seed=601),
+}
+
+
+def collision_inputs(case):
+    c = COLLISION_CASES[case]
+    cs = 64
+    layout = scenes.DistanceFieldLayout(256, 256, 64.0, 9, 1.0, 128)
+    atlas = scenes.build_sdf_atlas(layout, scenes.simple_particles_obstacles())
+    pos, vel, attr = scenes.make_particles(c["seed"], cs * cs, pos_lo=(-20, -20, 0), pos_hi=(276, 276, 32), dead_fraction=0.1, life=(0.01, 6.0),
+                                           categories=(0.0, 2.0))
+    sysu = scenes.system_uniforms(cs, friction=0.1, max_velocity=2048.0, life_decay=1.2, collision=(128.0, c["bounce"], 0.33, 0.05))
+    upd = abi.UpdateParams.default()
+    upd.RotationFromLifeAndIndex[0], upd.RotationFromLifeAndIndex[1] = 0.5, 0.004
+    return dict(chunk_size=cs, atlas=atlas, dfu=layout.uniforms(packed1=c["packed1"]), pos=pos, vel=vel, attr=attr, system=sysu, update=upd)
+
+
 def main():
     L = lighting_inputs()
     frame, (samples, pairs, traced) = light_frame(L["atlas"], L["dfu"], L["env"], L["lights"], L["ambient"], L["width"], L["height"])
@@ -675,6 +829,13 @@ def main():
         S = spawn_inputs(case)
         sp_, sv_, sa_ = ps_spawn(S["spawn"], S["rnd"], S["chunk_size"], S["pos"], S["vel"], S["attr"])
         extra["spawn_%s_position" % case], extra["spawn_%s_velocity" % case], extra["spawn_%s_attributes" % case] = sp_, sv_, sa_
+    for case in COLLISION_CASES:
+        Cn = collision_inputs(case)
+        cp, cv, cc, cd, csamples, branches = ps_update_with_distance_field(System(Cn["system"]), Cn["update"], Field(Cn["atlas"], Cn["dfu"]), xy,
+                                                                            Cn["pos"], Cn["vel"], Cn["attr"])
+        for key, value in (("position", cp), ("velocity", cv), ("render_color", cc), ("render_data", cd), ("samples", np.array([csamples], np.int64))):
+            extra["collision_%s_%s" % (case, key)] = value
+        print("collision update, %s: %d lookups, %s" % (case, csamples, branches))
     Pf = fma_inputs()
     extra["after_fma_position"], extra["after_fma_velocity"] = ps_fma(System(Pf["system"]), Pf["fma"], Pf["pos"], Pf["vel"])
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "second_reading.npz")

@@ -110,3 +110,20 @@ def test_fma_of_the_second_reading(oracle):
     assert_close(pos, FIX["after_fma_position"], "position after PS_FMA", **TOL)
     assert_close(vel, FIX["after_fma_velocity"], "velocity after PS_FMA", **TOL)
     assert np.abs(pos - P["pos"]).max() > 1e-3
+
+
+@pytest.mark.parametrize("case", sorted(second.COLLISION_CASES))
+def test_collision_update_of_the_second_reading(oracle, case):
+    """UpdateWithDistanceField: the state machine is discontinuous (a lookup on the other side of a threshold changes a slot wholesale),
+    so agreement of every slot to 2e-6 means every branch decision of every particle agreed."""
+    Cn = second.collision_inputs(case)
+    cs = Cn["chunk_size"]
+    n = cs * cs
+    got = [Cn["pos"].copy(), Cn["vel"].copy(), Cn["attr"].copy(), np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)]
+    oracle.update(got[0], got[1], got[2], got[3], got[4], cs, Cn["system"], Cn["update"], df=Cn["dfu"], sdf=oracle.make_texture(Cn["atlas"], abi.SDF_UNORM16))
+    want = {k: FIX["collision_%s_%s" % (case, k)] for k in ("position", "velocity", "render_color", "render_data")}
+    assert np.array_equal(got[0][:, 3] > 0, want["position"][:, 3] > 0), "liveness differs from the second reading"
+    for k, key in ((0, "position"), (1, "velocity"), (3, "render_color"), (4, "render_data")):
+        assert_close(got[k], want[key], "collision update %s, %s" % (key, case), **TOL)
+    # the scene takes every branch: redirected and bounced particles carry BOUNCE_DELAY, escaping ones a zero velocity.w next to a speed
+    assert (want["velocity"][:, 3] == 3.0).sum() > 500

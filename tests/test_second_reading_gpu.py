@@ -86,3 +86,24 @@ def test_fma_against_the_second_reading(ctx):
     assert_close(sysm.download(0, abi.PLANE_POSITION), FIX["after_fma_position"], "GPU position after PS_FMA vs the second reading")
     assert_close(sysm.download(0, abi.PLANE_VELOCITY), FIX["after_fma_velocity"], "GPU velocity after PS_FMA vs the second reading")
     sysm.close(); eng.close()
+
+
+@pytest.mark.parametrize("case", sorted(second.COLLISION_CASES))
+def test_collision_update_against_the_second_reading(ctx, case):
+    import ctypes
+    Cn = second.collision_inputs(case)
+    cs = Cn["chunk_size"]
+    eng, sysm = _system_with(ctx, cs, second.particle_inputs()["rnd"], Cn["pos"], Cn["vel"], Cn["attr"])
+    sdf = native.DistanceFieldTexture(ctx, Cn["atlas"], abi.SDF_UNORM16)
+    sysm.set_distance_field(sdf)
+    native.check(native.lib().ilm_debug_step_sdf_samples(ctx.handle, 1, None))
+    sysm.update(0, Cn["system"], Cn["update"], df=Cn["dfu"])
+    lookups = ctypes.c_uint64(0)
+    native.check(native.lib().ilm_debug_step_sdf_samples(ctx.handle, 0, ctypes.byref(lookups)))
+    assert int(lookups.value) == int(FIX["collision_%s_samples" % case][0]), "sampleDistanceFieldEx calls differ from the second reading"
+    want = {k: FIX["collision_%s_%s" % (case, k)] for k in ("position", "velocity", "render_color", "render_data")}
+    got_pos = sysm.download(0, abi.PLANE_POSITION)
+    assert np.array_equal(got_pos[:, 3] > 0, want["position"][:, 3] > 0)
+    for plane, key in ((abi.PLANE_POSITION, "position"), (abi.PLANE_VELOCITY, "velocity"), (abi.PLANE_RENDER_COLOR, "render_color"), (abi.PLANE_RENDER_DATA, "render_data")):
+        assert_close(sysm.download(0, plane), want[key], "GPU collision update %s, %s vs the second reading" % (key, case))
+    sdf.close(); sysm.close(); eng.close()
