@@ -198,22 +198,57 @@ def compute_sphere_light_opacity(px, py, pz, nx, ny, nz, lightCenter, lightPrope
     return saturate(((normalFactor * distanceFactor).astype(F) + saturate((lightRadius - distance).astype(F))).astype(F)), distance
 
 
-def light_frame(atlas_u16, dfu, env, lights, ambient, width, height):
-    """One RenderLighting of the SphereLight technique without a G-buffer: ClearColor = Ambient, then every light's quad in order
-    with additive blending (LightingRenderer.cs:1004-1169)."""
+def light_frame(atlas_u16, dfu, env, lights, ambient, width, height, gbuffer=None):
+    """One RenderLighting of the SphereLight technique: ClearColor = Ambient, then every light's quad in order with additive blending
+    (LightingRenderer.cs:1004-1169).  gbuffer: None, or the (H, W, 4) float texture sampleGBuffer reads."""
     field = Field(atlas_u16, dfu)
     SELF_OCCLUSION_HACK, SHADOW_OPACITY_THRESHOLD = F(1.6), F(0.75) / F(255.0)          # SphereLightCore.fxh:10-11
     ZAndScale, ZToY, GB = f4(env.ZAndScale), f4(env.ZToY), f4(env.GBufferTexelSizeAndMisc)
     vp = np.array([env.ViewportPosition[0], env.ViewportPosition[1]], F)
-    assert GB[0] == 0 and GB[1] == 0, "this reading covers sampleGBuffer's else branch (no G-buffer)"
+    assert (gbuffer is not None) == bool(GB[0] != 0 or GB[1] != 0), "any(GBufferTexelSizeAndMisc.xy) selects sampleGBuffer's branch"
     jj, ii = np.mgrid[0:height, 0:width]
     vposx, vposy = ii.astype(F), jj.astype(F)                                             # GET_VPOS = floor(VPOS)
-    # sampleGBuffer, LightCommon.fxh:128-139
-    spx, spy = (vposx / ZAndScale[2]).astype(F), (vposy / ZAndScale[3]).astype(F)
-    camx, camy, camz = spx, spy, np.full_like(spx, F(ZAndScale[1] + F(0.01)))
-    wpx, wpy = ((spx / GB[2]).astype(F) + vp[0]).astype(F), ((spy / GB[3]).astype(F) + vp[1]).astype(F)
-    wpz = np.full_like(spx, ZAndScale[0])
-    nx, ny, nz = np.zeros_like(spx), np.zeros_like(spx), np.ones_like(spx)
+    enableShadows, fullbright = np.ones((height, width), bool), np.zeros((height, width), bool)
+    if gbuffer is None:
+        # sampleGBuffer, LightCommon.fxh:128-139
+        spx, spy = (vposx / ZAndScale[2]).astype(F), (vposy / ZAndScale[3]).astype(F)
+        camx, camy, camz = spx, spy, np.full_like(spx, F(ZAndScale[1] + F(0.01)))
+        wpx, wpy = ((spx / GB[2]).astype(F) + vp[0]).astype(F), ((spy / GB[3]).astype(F) + vp[1]).astype(F)
+        wpz = np.full_like(spx, ZAndScale[0])
+        nx, ny, nz = np.zeros_like(spx), np.zeros_like(spx), np.ones_like(spx)
+    else:
+        # sampleGBuffer, LightCommon.fxh:69-127
+        GBUFFER_Z_SCALE, GBUFFER_Z_OFFSET = F(1024), F(1024)
+        gh, gw = gbuffer.shape[:2]
+        sourceX, sourceY = vposx, vposy
+        if env.GBufferViewportRelative != 0:
+            sourceX, sourceY = ((sourceX / GB[2]).astype(F) + vp[0]).astype(F), ((sourceY / GB[3]).astype(F) + vp[1]).astype(F)
+        u, v = ((sourceX + F(0.5)).astype(F) * GB[0]).astype(F), ((sourceY + F(0.5)).astype(F) * GB[1]).astype(F)
+        # GBufferSampler: POINT, CLAMP
+        tx = np.clip(np.floor((u * F(gw)).astype(F)).astype(np.int64), 0, gw - 1)
+        ty = np.clip(np.floor((v * F(gh)).astype(F)).astype(np.int64), 0, gh - 1)
+        sample = gbuffer.astype(F)[ty, tx]
+        relativeY, worldZ = sample[..., 2], sample[..., 3].copy()
+        unshadowed = worldZ < 0
+        bright = ~unshadowed & (worldZ >= 9999)
+        worldZ = np.where(unshadowed, -((worldZ + F(1)).astype(F)), worldZ).astype(F)
+        worldZ[bright] = 0
+        enableShadows = ~(unshadowed | bright)
+        fullbright = bright
+        worldZ = ((worldZ * GBUFFER_Z_SCALE).astype(F) - GBUFFER_Z_OFFSET).astype(F)
+        spx, spy = (vposx / ZAndScale[2]).astype(F), (vposy / ZAndScale[3]).astype(F)
+        camx, camy, camz = spx, spy, np.full_like(spx, F(ZAndScale[1] + F(0.01)))
+        wpx = ((spx / GB[2]).astype(F) + vp[0]).astype(F)
+        wpy = (((spy + relativeY).astype(F) / GB[3]).astype(F) + vp[1]).astype(F)
+        wpz = worldZ
+        # decodeNormalSpherical, EnvironmentCommon.fxh:40-51
+        has_normal = (sample[..., 0] != 0) | (sample[..., 1] != 0)
+        angx, angy = ((sample[..., 0] * F(2)).astype(F) - F(1)).astype(F), ((sample[..., 1] * F(2)).astype(F) - F(1)).astype(F)
+        sth, cth = np.sin((angx * PI).astype(F)).astype(F), np.cos((angx * PI).astype(F)).astype(F)
+        phx = np.sqrt((F(1.0) - (angy * angy).astype(F)).astype(F)).astype(F)
+        nx = np.where(has_normal, (cth * phx).astype(F), F(0)).astype(F)
+        ny = np.where(has_normal, (sth * phx).astype(F), F(0)).astype(F)
+        nz = np.where(has_normal, angy, F(0)).astype(F)
     out = np.empty((height, width, 4), F)
     out[...] = np.asarray(ambient, F)
     pairs = traced = 0
@@ -241,11 +276,13 @@ def light_frame(atlas_u16, dfu, env, lights, ambient, width, height):
             x1, y1 = corner(u1, v1)
             covered |= (cxp >= x0) & (cxp < x1) & (cyp >= y0) & (cyp < y1)                # pixel centre inside the rectangle
         pairs += int(covered.sum())
-        # SphereLightPixelShader, SphereLight.fx:7-46 (no G-buffer: enableShadows = true, fullbright = false)
+        # SphereLightPixelShader, SphereLight.fx:7-46
         filt = evenMore[0]
-        if not (filt < 0) and ((filt > 0.5) != True):                                     # checkShadowFilter, LightCommon.fxh:146-152
+        filtered = np.zeros((height, width), bool) if filt < 0 else ((filt > 0.5) != enableShadows)     # checkShadowFilter, LightCommon.fxh:146-152
+        sel = covered & ~(fullbright | filtered)                                          # result = 0; discard
+        if not sel.any():
             continue
-        sel = covered
+        castsShadows = (lightProperties[3] != 0) & enableShadows[sel]                      # lightProperties.w *= enableShadows
         px_, py_, pz_ = wpx[sel], wpy[sel], wpz[sel]
         nx_, ny_, nz_ = nx[sel], ny[sel], nz[sel]
         # SphereLightPixelPrologue, SphereLightCore.fxh:58-81
@@ -263,7 +300,7 @@ def light_frame(atlas_u16, dfu, env, lights, ambient, width, height):
             res = (F(1) - res).astype(F)
             aoOpacity[do_ao] = (F(F(1) - more[3]) + (res * more[3]).astype(F)).astype(F)
         preTraceOpacity = (distanceOpacity * aoOpacity).astype(F)
-        traceShadows = visible & (lightProperties[3] != 0) & (preTraceOpacity >= SHADOW_OPACITY_THRESHOLD)
+        traceShadows = visible & castsShadows & (preTraceOpacity >= SHADOW_OPACITY_THRESHOLD)
         traced += int(traceShadows.sum())
         coneOpacity = cone_trace(field, lightCenter, lightProperties[0:2], (field.getConeGrowthFactor(), more[1]),
                                  (px_ + (SELF_OCCLUSION_HACK * nx_).astype(F)).astype(F), (py_ + (SELF_OCCLUSION_HACK * ny_).astype(F)).astype(F),
@@ -776,6 +813,34 @@ def lighting_inputs():
     return dict(width=w, height=h, atlas=atlas, dfu=dfu, lights=lights, env=env, ambient=(0.04, 0.05, 0.06, 1.0))
 
 
+def lighting_gbuffer_inputs():
+    """The same field under a G-buffer: tilted normals, raised and lowered ground, a band displaced in y (2.5D relativeY), an unshadowed
+    band, a fullbright band, a band without normal; lights with every falloff mode, both shadow filters, AO and specular; light
+    occlusion; the G-buffer larger than the frame and addressed viewport-relative from a scrolled viewport."""
+    L = lighting_inputs()
+    w, h = L["width"], L["height"]
+    gw, gh = w + 8, h + 8
+    yy, xx = np.mgrid[0:gh, 0:gw].astype(np.float32)
+    nx = 0.35 * np.sin(xx / 9.0); ny = 0.3 * np.cos(yy / 7.0)
+    nz = np.sqrt(np.maximum(1.0 - nx * nx - ny * ny, 0.0))
+    normal = np.stack([nx, ny, nz], axis=-1)
+    z = 6.0 + 5.0 * np.sin(xx / 17.0) * np.cos(yy / 13.0)
+    g = scenes.encode_gbuffer(normal, 0.0, z)
+    g[8:14] = scenes.encode_gbuffer(normal[8:14], 0.0, z[8:14], enable_shadows=False)
+    g[20:23] = scenes.encode_gbuffer(normal[20:23], 0.0, z[20:23], fullbright=True)
+    g[28:32, :, :2] = 0.0
+    g[36:42, :, 2] = -3.5
+    lights = L["lights"] + list(scenes.random_lights(23, 2, w, h, z=(10.0, 30.0), radius=6.0, ramp=(30.0, 60.0)))
+    for i, lv in enumerate(lights):
+        lv.MoreLightProperties.x = 10.0 if i % 2 else 0.0
+        lv.MoreLightProperties.w = 0.6
+        lv.Color2 = abi.f4(0.3, 0.2, 0.1, 8.0) if i % 3 == 0 else abi.f4(0, 0, 0, 1)
+        lv.LightProperties.z = float(i % 3)
+        lv.EvenMoreLightProperties.x = float((i % 4) - 1)
+    env = scenes.environment(maximum_z=64.0, gbuffer_size=(gw, gh), light_occlusion=40.0, viewport_position=(3.0, 2.0), viewport_relative=True)
+    return dict(width=w, height=h, atlas=L["atlas"], dfu=L["dfu"], lights=lights, env=env, ambient=(0.0, 0.01, 0.02, 0.0), gbuffer=g)
+
+
 def particle_inputs():
     cs = 64
     n = cs * cs
@@ -816,6 +881,9 @@ def collision_inputs(case):
 def main():
     L = lighting_inputs()
     frame, (samples, pairs, traced) = light_frame(L["atlas"], L["dfu"], L["env"], L["lights"], L["ambient"], L["width"], L["height"])
+    G = lighting_gbuffer_inputs()
+    gframe, gcounts = light_frame(G["atlas"], G["dfu"], G["env"], G["lights"], G["ambient"], G["width"], G["height"], gbuffer=G["gbuffer"])
+    print("lit frame under a G-buffer: %d SDF samples, %d pixel-light pairs, %d traced" % gcounts)
     P = particle_inputs()
     cs = P["chunk_size"]
     slots = np.arange(cs * cs)
@@ -839,7 +907,7 @@ def main():
     Pf = fma_inputs()
     extra["after_fma_position"], extra["after_fma_velocity"] = ps_fma(System(Pf["system"]), Pf["fma"], Pf["pos"], Pf["vel"])
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "second_reading.npz")
-    np.savez_compressed(out, **extra, lightmap=frame, light_counts=np.array([samples, pairs, traced], np.int64),
+    np.savez_compressed(out, **extra, lightmap_gbuffer=gframe, light_counts_gbuffer=np.array(gcounts, np.int64), lightmap=frame, light_counts=np.array([samples, pairs, traced], np.int64),
                         after_gravity_velocity=v1, after_noise_position=p2, after_noise_velocity=v2,
                         position=p3, velocity=v3, render_color=rc, render_data=rd)
     print("wrote %s: %d SDF samples, %d pixel-light pairs, %d traced; %d live particles of %d" % (out, samples, pairs, traced, int((p3[:, 3] > 0).sum()), cs * cs))

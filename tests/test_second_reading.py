@@ -127,3 +127,21 @@ def test_collision_update_of_the_second_reading(oracle, case):
         assert_close(got[k], want[key], "collision update %s, %s" % (key, case), **TOL)
     # the scene takes every branch: redirected and bounced particles carry BOUNCE_DELAY, escaping ones a zero velocity.w next to a speed
     assert (want["velocity"][:, 3] == 3.0).sum() > 500
+
+
+def test_lit_frame_under_a_gbuffer_of_the_second_reading(oracle):
+    """sampleGBuffer's G-buffer branch (viewport-relative addressing, the unshadowed / fullbright encodings, relativeY,
+    decodeNormalSpherical), the normal factor, light occlusion, both shadow filters, the three falloff modes, AO and specular."""
+    G = second.lighting_gbuffer_inputs()
+    lights = (abi.LightVertex * len(G["lights"]))(*G["lights"])
+    tex = oracle.make_texture(G["atlas"], abi.SDF_UNORM16)
+    gb = oracle.make_texture(G["gbuffer"], abi.GBUFFER_FLOAT4)
+    frame, stats = oracle.render_sphere_lights(lights, G["env"], G["dfu"], gb, tex, G["ambient"], G["width"], G["height"], want_stats=True)
+    assert [int(stats.SdfSamples), int(stats.PixelLightPairs), int(stats.TracedPairs)] == [int(v) for v in FIX["light_counts_gbuffer"]]
+    want = FIX["lightmap_gbuffer"]
+    assert np.array_equal(frame[..., 3], want[..., 3]), "the lights drawn per pixel (discards: fullbright, filter, distance) differ"
+    assert_close(frame, want, "oracle lightmap under a G-buffer vs the second reading (north-star tolerance)")
+    err = np.abs(frame.astype(np.float64) - want) - 2e-6 * np.abs(want) - 2e-6 * np.abs(want).reshape(-1, 4).max(axis=0)
+    assert (err > 0).sum() <= 12, "%d elements of the lightmap differ from the second reading by more than 2e-6" % int((err > 0).sum())
+    # the fullbright band (G-buffer rows 20..22 = frame rows 18..20 under the scrolled viewport) receives no light at all
+    assert not want[18:21, :, 3].any() and (want[..., 3] >= 2.0).mean() > 0.4

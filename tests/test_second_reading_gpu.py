@@ -107,3 +107,17 @@ def test_collision_update_against_the_second_reading(ctx, case):
     for plane, key in ((abi.PLANE_POSITION, "position"), (abi.PLANE_VELOCITY, "velocity"), (abi.PLANE_RENDER_COLOR, "render_color"), (abi.PLANE_RENDER_DATA, "render_data")):
         assert_close(sysm.download(0, plane), want[key], "GPU collision update %s, %s vs the second reading" % (key, case))
     sdf.close(); sysm.close(); eng.close()
+
+
+def test_lit_frame_under_a_gbuffer_against_the_second_reading(ctx):
+    G = second.lighting_gbuffer_inputs()
+    lights = (abi.LightVertex * len(G["lights"]))(*G["lights"])
+    sdf = native.DistanceFieldTexture(ctx, G["atlas"], abi.SDF_UNORM16)
+    gb = native.GBufferTexture(ctx, G["gbuffer"], abi.GBUFFER_FLOAT4)
+    lm = native.Lightmap(ctx, G["width"], G["height"])
+    stats = native.render_sphere_lights(ctx, lights, G["env"], G["dfu"], gb, sdf, G["ambient"], lm, want_stats=True)
+    assert [int(stats.SdfSamples), int(stats.PixelLightPairs), int(stats.TracedPairs)] == [int(v) for v in FIX["light_counts_gbuffer"]]
+    got = lm.download()
+    assert np.array_equal(got[..., 3], FIX["lightmap_gbuffer"][..., 3])
+    assert_close(got, FIX["lightmap_gbuffer"], "GPU lightmap under a G-buffer vs the second reading")
+    lm.close(); gb.close(); sdf.close()
