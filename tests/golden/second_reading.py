@@ -749,13 +749,93 @@ def ps_spawn(sp, table, chunk_size, position, velocity, attributes):
     return outp, outv, outa
 
 
+def _dot3(a, b):
+    return (((a[:, 0] * b[:, 0]).astype(F) + (a[:, 1] * b[:, 1]).astype(F)).astype(F) + (a[:, 2] * b[:, 2]).astype(F)).astype(F)
+
+
+def _cross3(a, b):
+    return np.stack([((a[:, 1] * b[:, 2]).astype(F) - (a[:, 2] * b[:, 1]).astype(F)).astype(F),
+                     ((a[:, 2] * b[:, 0]).astype(F) - (a[:, 0] * b[:, 2]).astype(F)).astype(F),
+                     ((a[:, 0] * b[:, 1]).astype(F) - (a[:, 1] * b[:, 0]).astype(F)).astype(F)], axis=1)
+
+
+def qmul(q1, q2):
+    """qmul, DistanceFunctionCommon.fxh:16-21: float4(q2.xyz * q1.w + q1.xyz * q2.w + cross(q1.xyz, q2.xyz), q1.w * q2.w - dot(q1.xyz, q2.xyz))."""
+    xyz = (((q2[:, :3] * q1[:, 3:4]).astype(F) + (q1[:, :3] * q2[:, 3:4]).astype(F)).astype(F) + _cross3(q1[:, :3], q2[:, :3])).astype(F)
+    w = ((q1[:, 3] * q2[:, 3]).astype(F) - _dot3(q1[:, :3], q2[:, :3])).astype(F)
+    return np.concatenate([xyz, w[:, None]], axis=1)
+
+
+def rotate_local_position(localPosition, rotation):
+    """rotateLocalPosition, :24-27."""
+    n = localPosition.shape[0]
+    rot = np.broadcast_to(np.asarray(rotation, F), (n, 4))
+    r_c = (rot * np.array([-1, -1, -1, 1], F)).astype(F)
+    return qmul(rot, qmul(np.concatenate([localPosition, np.zeros((n, 1), F)], axis=1), r_c))[:, :3]
+
+
+def op_elongate(p, h):
+    """opElongate, :43-46."""
+    q = (np.abs(p) - h[None, :]).astype(F)
+    return (np.sign(p) * np.maximum(q, F(0))).astype(F), np.minimum(np.maximum(q[:, 0], np.maximum(q[:, 1], q[:, 2])), F(0))
+
+
+def evaluate_by_type_id(typeId, worldPosition, center, size, rotation):
+    """evaluateByTypeId, :170-187, with evaluateEllipsoid / Box / Cylinder / Spheroid / Octagon (:48-168)."""
+    t = abs(int(typeId))
+    n = worldPosition.shape[0]
+    if t == 0 or t > 5:
+        return np.zeros(n, F)
+    center, size = np.asarray(center, F), np.asarray(size, F)
+    position = rotate_local_position((worldPosition - center[None, :]).astype(F), rotation)
+    if t == 1:                                                                              # sdEllipsoid_improvedV2
+        pr = (position / size[None, :]).astype(F)
+        prr = (position / (size * size).astype(F)[None, :]).astype(F)
+        k0, k1 = length3(pr[:, 0], pr[:, 1], pr[:, 2]), length3(prr[:, 0], prr[:, 1], prr[:, 2])
+        with np.errstate(all="ignore"):
+            return np.where(k0 < 1.0, ((k0 - F(1.0)).astype(F) * min(min(size[0], size[1]), size[2])).astype(F),
+                            ((k0 * (k0 - F(1.0)).astype(F)).astype(F) / k1).astype(F)).astype(F)
+    if t == 2:                                                                              # evaluateBox
+        d = (np.abs(position) - size[None, :]).astype(F)
+        m = np.maximum(d, F(0))
+        return (np.minimum(np.maximum(d[:, 0], np.maximum(d[:, 1], d[:, 2])), F(0)) + length3(m[:, 0], m[:, 1], m[:, 2])).astype(F)
+    if t == 3:                                                                              # sdCappedCylinder(position, size.z, length(size.xy))
+        h, r = size[2], F(np.sqrt(F(F(size[0] * size[0]) + F(size[1] * size[1]))))
+        lxy = np.sqrt(((position[:, 0] * position[:, 0]).astype(F) + (position[:, 1] * position[:, 1]).astype(F)).astype(F)).astype(F)
+        dx, dy = (np.abs(lxy) - r).astype(F), (np.abs(position[:, 2]) - h).astype(F)
+        mx, my = np.maximum(dx, F(0)), np.maximum(dy, F(0))
+        return (np.minimum(np.maximum(dx, dy), F(0)) + np.sqrt(((mx * mx).astype(F) + (my * my).astype(F)).astype(F)).astype(F)).astype(F)
+    if t == 4:                                                                              # evaluateSpheroid
+        minSize = min(size[0], min(size[1], size[2]))
+        w, ww = op_elongate(position, (size - minSize).astype(F))
+        return (ww + (length3(w[:, 0], w[:, 1], w[:, 2]) - minSize).astype(F)).astype(F)
+    # evaluateOctagon + sdOctogonPrism
+    minSize = min(size[0], size[1])
+    w, ww = op_elongate(position, np.array([size[0] - minSize, size[1] - minSize, 0], F))
+    kx, ky, kz = F(-0.9238795325), F(0.3826834323), F(0.4142135623)
+    p = np.abs(w)
+    r, h = minSize, size[2]
+    for (ax, ay) in ((kx, ky), (F(-kx), ky)):
+        dd = np.minimum(((ax * p[:, 0]).astype(F) + (ay * p[:, 1]).astype(F)).astype(F), F(0))
+        two = (F(2.0) * dd).astype(F)
+        p = np.stack([(p[:, 0] - (two * ax).astype(F)).astype(F), (p[:, 1] - (two * ay).astype(F)).astype(F), p[:, 2]], axis=1)
+    p = np.stack([(p[:, 0] - np.clip(p[:, 0], F(-kz * r), F(kz * r))).astype(F), (p[:, 1] - r).astype(F), p[:, 2]], axis=1)
+    dx = (np.sqrt(((p[:, 0] * p[:, 0]).astype(F) + (p[:, 1] * p[:, 1]).astype(F)).astype(F)).astype(F) * np.sign(p[:, 1])).astype(F)
+    dy = (p[:, 2] - h).astype(F)
+    mx, my = np.maximum(dx, F(0)), np.maximum(dy, F(0))
+    prism = (np.minimum(np.maximum(dx, dy), F(0)) + np.sqrt(((mx * mx).astype(F) + (my * my).astype(F)).astype(F)).astype(F)).astype(F)
+    return (ww + prism).astype(F)
+
+
 def ps_fma(sysu, f, position, velocity):
-    """PS_FMA, FMA.fx:31-49 with AreaType 0."""
+    """PS_FMA, FMA.fx:15-49: computeWeight through evaluateByTypeId (the scalar AreaRotation promotes to float4(r, r, r, r))."""
     cf = (F(f.Area.CategoryFilter[0]), F(f.Area.CategoryFilter[1]))
     skip = (position[:, 3] <= 0) | ~((velocity[:, 3] >= cf[0]) & (velocity[:, 3] <= cf[1]))
+    rot = F(f.Area.AreaRotation)
+    distance = evaluate_by_type_id(f.Area.AreaType, position[:, :3], list(f.Area.AreaCenter), list(f.Area.AreaSize), (rot, rot, rot, rot))
     with np.errstate(all="ignore"):
-        weight = F(F(F(1) - saturate(F(0) / F(f.Area.AreaFalloff))) * F(f.Area.Strength))
-    t = F(F(weight * sysu.getDeltaTime()) / F(f.TimeDivisor))
+        weight = ((F(1) - saturate((distance / F(f.Area.AreaFalloff)).astype(F))).astype(F) * F(f.Area.Strength)).astype(F)
+    t = ((weight * sysu.getDeltaTime()).astype(F) / F(f.TimeDivisor)).astype(F)[:, None]
     newPosition = lerp(position, ((position * f4(f.PositionMultiply)[None, :]).astype(F) + f4(f.PositionAdd)[None, :]).astype(F), t)
     newVelocity = lerp(velocity, ((velocity * f4(f.VelocityMultiply)[None, :]).astype(F) + f4(f.VelocityAdd)[None, :]).astype(F), t)
     newPosition[skip], newVelocity[skip] = position[skip], velocity[skip]
@@ -786,10 +866,11 @@ def spawn_inputs(case):
     return dict(chunk_size=cs, pos=pos, vel=vel, attr=attr, rnd=scenes.randomness_table(9), spawn=sp)
 
 
-def fma_inputs():
+def fma_inputs(area_type=0):
     P = particle_inputs()
     f = abi.FMAParams()
-    f.Area = scenes.area_none(strength=0.6)
+    f.Area = scenes.area_none(strength=0.6) if area_type == 0 else \
+        scenes.area(area_type, (120.0, 130.0, 10.0), (60.0, 45.0, 30.0), falloff=40.0, rotation=0.3, strength=0.8)
     f.TimeDivisor = 250.0
     f.PositionAdd, f.PositionMultiply = abi.f4(1.5, -2.0, 0.25, 0.0), abi.f4(0.98, 1.01, 1.0, 1.0)
     f.VelocityAdd, f.VelocityMultiply = abi.f4(0.0, 9.8, 0.0, 0.0), abi.f4(0.9, 0.9, 0.5, 1.0)
@@ -906,6 +987,10 @@ def main():
         print("collision update, %s: %d lookups, %s" % (case, csamples, branches))
     Pf = fma_inputs()
     extra["after_fma_position"], extra["after_fma_velocity"] = ps_fma(System(Pf["system"]), Pf["fma"], Pf["pos"], Pf["vel"])
+    for area_type in (1, 2, 3, 4, 5):
+        Pf = fma_inputs(area_type)
+        extra["after_fma_area%d_position" % area_type], extra["after_fma_area%d_velocity" % area_type] = \
+            ps_fma(System(Pf["system"]), Pf["fma"], Pf["pos"], Pf["vel"])
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "second_reading.npz")
     np.savez_compressed(out, **extra, lightmap_gbuffer=gframe, light_counts_gbuffer=np.array(gcounts, np.int64), lightmap=frame, light_counts=np.array([samples, pairs, traced], np.int64),
                         after_gravity_velocity=v1, after_noise_position=p2, after_noise_velocity=v2,

@@ -103,13 +103,18 @@ def test_spawn_of_the_second_reading(oracle, case):
         assert_close(got, w, "PS_Spawn %s, %s" % (name, case), **TOL)
 
 
-def test_fma_of_the_second_reading(oracle):
-    P = second.fma_inputs()
+@pytest.mark.parametrize("area_type", [0, 1, 2, 3, 4, 5])
+def test_fma_of_the_second_reading(oracle, area_type):
+    """PS_FMA with its weight from evaluateByTypeId: no area, then ellipsoid / box / cylinder / spheroid / octagon, rotated."""
+    P = second.fma_inputs(area_type)
+    key = "after_fma_" if area_type == 0 else "after_fma_area%d_" % area_type
     pos, vel = P["pos"].copy(), P["vel"].copy()
     oracle.fma(pos, vel, P["chunk_size"], P["system"], P["fma"])
-    assert_close(pos, FIX["after_fma_position"], "position after PS_FMA", **TOL)
-    assert_close(vel, FIX["after_fma_velocity"], "velocity after PS_FMA", **TOL)
-    assert np.abs(pos - P["pos"]).max() > 1e-3
+    assert_close(pos, FIX[key + "position"], "position after PS_FMA, area %d" % area_type, **TOL)
+    assert_close(vel, FIX[key + "velocity"], "velocity after PS_FMA, area %d" % area_type, **TOL)
+    live = P["pos"][:, 3] > 0
+    step = np.abs(FIX[key + "velocity"] - P["vel"])[live].max(axis=1)
+    assert step.max() > 1e-3 and (area_type == 0 or step.min() < 0.5 * step.max())          # the area weights the particles differently
 
 
 @pytest.mark.parametrize("case", sorted(second.COLLISION_CASES))

@@ -79,12 +79,14 @@ def test_spawn_against_the_second_reading(ctx, case):
     sysm.close(); eng.close()
 
 
-def test_fma_against_the_second_reading(ctx):
-    P = second.fma_inputs()
+@pytest.mark.parametrize("area_type", [0, 1, 2, 3, 4, 5])
+def test_fma_against_the_second_reading(ctx, area_type):
+    P = second.fma_inputs(area_type)
+    key = "after_fma_" if area_type == 0 else "after_fma_area%d_" % area_type
     eng, sysm = _system_with(ctx, P["chunk_size"], P["rnd"], P["pos"], P["vel"], P["attr"])
     sysm.fma(0, P["system"], P["fma"])
-    assert_close(sysm.download(0, abi.PLANE_POSITION), FIX["after_fma_position"], "GPU position after PS_FMA vs the second reading")
-    assert_close(sysm.download(0, abi.PLANE_VELOCITY), FIX["after_fma_velocity"], "GPU velocity after PS_FMA vs the second reading")
+    assert_close(sysm.download(0, abi.PLANE_POSITION), FIX[key + "position"], "GPU position after PS_FMA vs the second reading")
+    assert_close(sysm.download(0, abi.PLANE_VELOCITY), FIX[key + "velocity"], "GPU velocity after PS_FMA vs the second reading")
     sysm.close(); eng.close()
 
 
