@@ -2031,13 +2031,26 @@ int32_t ilm_lightmap_destroy(IlmHandle h) {
 }
 
 namespace {
-// Block -> tile mapping of the light kernel.  Measured on MI355X (bench.py lighting, ms/frame cfg3 | cfg5): contiguous band of tiles
-// per XCD 2.02 | 29.0; tile rows round-robin over the XCDs 1.65 | 22.8; identity (consecutive tiles on consecutive XCDs) 1.59 | 23.1.
-// The banded mapping keeps each XCD's L2 on one part of the atlas but the lights are not spread evenly over the screen, so whole
-// XCDs idle while the busiest band finishes; the 25 MB atlas is L2 / Infinity-Cache resident either way.  Identity is the default.
+// Block -> tile mapping of the light kernel (the dispatcher places block b on XCD b % 8; every XCD has its own L2).  Measured on MI355X,
+// bench.py lighting, ms / frame cfg3 | cfg5.  r01: (0) one contiguous band of tiles per XCD 2.02 | 29.0 -- each L2 stays on one part of
+// the field, but the lights are not spread evenly over the screen and whole XCDs idle while the busiest band finishes; (1) tile rows
+// round-robin over the XCDs 1.65 | 22.8; (2) identity, consecutive tiles on consecutive XCDs, 1.59 | 23.1 -- perfectly balanced, and an
+// XCD's tiles are every eighth of a row: no two of them are neighbours.  r03: (4) square groups of M x M tiles dealt round-robin to the
+// XCDs, each XCD walking its groups in turn: the tiles an XCD runs side by side lie side by side, their rays towards a light cross the
+// same cells and read the same light records, and with ~100 groups per XCD the balance holds.  Identity 0.623 | 9.41; M = 2 0.624 | 9.11,
+// 3 0.618 | 9.00, 4 0.632 | 9.06, 5 0.649 | 8.84, **6 0.618 | 8.78**, 7 0.630 | 8.88, 8 0.642 | 8.98, 10 0.664 | 9.19, 12 0.625 | 8.98,
+// 16 0.808 | 9.14 (tools/ab_tilemap.sh; small frames lose balance as the groups grow, large ones gain locality until the groups get
+// few).  Dealing a group row's groups out with the start rotated by the row (diagonal stripes) 0.636 | 8.93; whole group columns per
+// XCD, walked top to bottom, 0.70 | 8.72 (cfg5's 40 columns divide by 8, cfg3's 20 do not); tiles sorted heaviest first 0.70 | 9.96.
+// Default: 4 with M = 6.
 int light_tile_map() {
     static int v = -1;
-    if (v < 0) { const char* e = getenv("ILM_LIGHT_TILE_MAP"); v = e ? atoi(e) : 2; }
+    if (v < 0) { const char* e = getenv("ILM_LIGHT_TILE_MAP"); v = e ? atoi(e) : 4; }
+    return v;
+}
+int light_tile_macro() {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("ILM_LIGHT_TILE_MACRO"); v = e ? atoi(e) : 6; if (v < 1) v = 1; }
     return v;
 }
 // shared by the three light passes: resource checks + the launch descriptor
@@ -2065,6 +2078,7 @@ int32_t fill_light_launch(Ctx* c, const IlmEnvironment* env, const IlmDistanceFi
     a->ramp = RampView{ nullptr, 0, 0 };      // particle lights have no ramp technique (LightingRenderer.cs:176-178)
     a->blend_fp16 = (c->lightmap_blend == ILM_BLEND_FP16_PER_LIGHT) ? 1 : 0;
     a->tile_map = light_tile_map();
+    a->tile_macro = light_tile_macro();
     return ILM_OK;
 }
 }  // namespace
@@ -2552,6 +2566,7 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
     a.ramp = RampView{ c->d_light_ramp, c->light_ramp_w, c->light_ramp_h };
     a.blend_fp16 = (c->lightmap_blend == ILM_BLEND_FP16_PER_LIGHT) ? 1 : 0;
     a.tile_map = light_tile_map();
+    a.tile_macro = light_tile_macro();
     if (stats) {
         HIP_TRY(hipMemsetAsync(c->d_stats, 0, 3 * sizeof(unsigned long long), c->main()));
         a.stats = c->d_stats;

@@ -158,10 +158,12 @@ struct LightLaunch {
     int32_t row_begin, row_end;
     unsigned long long* stats;      // device, 3 counters, or nullptr
     const int32_t* light_count_ptr; // device: when non-null the record count is read from here (particle lights are counted on the device)
-    int32_t tile_map;               // block -> tile mapping: 0 contiguous band per XCD, 1 tile rows round-robin over the XCDs, 2 identity
+    int32_t tile_map;               // block -> tile mapping: 0 contiguous band per XCD, 1 tile rows round-robin over the XCDs, 2 identity,
+                                    // 4 groups of tile_macro x tile_macro tiles round-robin over the XCDs
     int32_t accumulate;             // != 0: start from the lightmap's contents instead of `ambient` (additive blend onto an earlier pass)
     int32_t blend_fp16;             // != 0: the reference's HalfVector4 render target -- round through fp16 after every light (ilm_ctx_set_lightmap_blend)
     RampView ramp;
+    int32_t tile_macro;             // tile_map 4: edge of the square groups of tiles dealt round-robin to the XCDs
 };
 
 constexpr size_t kLightRecBytes = 128;   // sizeof(LightRec) in lighting.hip

@@ -451,7 +451,7 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
     __shared__ SliceEntry slice_table[kMaxTableSlices];
 
     // The dispatcher places block b on XCD b % 8.  Which tiles an XCD gets decides both its L2 locality and its share of the work
-    // (lights are not spread evenly): see light_tile_map() in api.hip for the measurements; identity (tile_map 2) is the default.
+    // (lights are not spread evenly): see light_tile_map() in api.hip for the measurements; groups of 6 x 6 tiles (tile_map 4) are the default.
 #ifdef ILM_LIGHT_TRACE
     const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -467,6 +467,15 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
         tile = (r_local < rows_here) ? (r_local * 8 + xcd) * tiles_x + cx_ : tile_count;
     } else if (a.tile_map == 2) {
         tile = b;
+    } else if (a.tile_map == 4) {
+        // square groups of M x M tiles, dealt round-robin to the XCDs; an XCD walks its groups one after the other, so the tiles it
+        // runs side by side lie side by side (api.hip light_tile_map has the measurements)
+        const int M = a.tile_macro, MM = M * M;
+        const int xcd = b % 8, k = b / 8;
+        const int g = (k / MM) * 8 + xcd, t = k % MM;
+        const int mx = (tiles_x + M - 1) / M;
+        const int ty = (g / mx) * M + t / M, tx = (g % mx) * M + t % M;
+        tile = (tx < tiles_x && ty < tiles_y) ? ty * tiles_x + tx : tile_count;
     } else {
         tile = (b % 8) * per_xcd + (b / 8);
     }
@@ -904,6 +913,10 @@ hipError_t launch_sphere_lights_prepared(const LightLaunch& a, const void* recs,
     const int tile_count = tiles_x * tiles_y;
     int blocks = ((tile_count + 7) / 8) * 8;
     if (a.tile_map == 1) blocks = ((tiles_y + 7) / 8) * tiles_x * 8;   // every XCD gets ceil(rows / 8) rows' worth of blocks
+    if (a.tile_map == 4) {
+        const int M = a.tile_macro, groups = ((tiles_x + M - 1) / M) * ((tiles_y + M - 1) / M);
+        blocks = ((groups + 7) / 8) * 8 * M * M;
+    }
     const LightRec* r = reinterpret_cast<const LightRec*>(recs);
     const bool stats = a.stats != nullptr;
     const bool fp16 = a.sdf.format == ILM_SDF_FP16;
