@@ -2041,7 +2041,9 @@ namespace {
 // 3 0.618 | 9.00, 4 0.632 | 9.06, 5 0.649 | 8.84, **6 0.618 | 8.78**, 7 0.630 | 8.88, 8 0.642 | 8.98, 10 0.664 | 9.19, 12 0.625 | 8.98,
 // 16 0.808 | 9.14 (tools/ab_tilemap.sh; small frames lose balance as the groups grow, large ones gain locality until the groups get
 // few).  Dealing a group row's groups out with the start rotated by the row (diagonal stripes) 0.636 | 8.93; whole group columns per
-// XCD, walked top to bottom, 0.70 | 8.72 (cfg5's 40 columns divide by 8, cfg3's 20 do not); tiles sorted heaviest first 0.70 | 9.96.
+// XCD, walked top to bottom, 0.70 | 8.72 (cfg5's 40 columns divide by 8, cfg3's 20 do not); the eight groups in flight as a 4 x 2 block
+// of groups 0.618 | 9.00 against 0.611 | 8.74 beside it; groups dealt out heaviest first (one-workgroup cost + bitonic sort) 0.618 | 8.96
+// against 0.613 | 8.73; single tiles sorted heaviest first 0.70 | 9.96.  Every form of "balance first" lost to "neighbours together".
 // Default: 4 with M = 6.
 int light_tile_map() {
     static int v = -1;
