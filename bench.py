@@ -563,6 +563,11 @@ def main():
                 packed = [abi.LightVertex.from_buffer_copy(H.LightingRenderer.PackSphereLightBytes(lsrc, 1.0, True)) for lsrc in L["env"].Lights]
                 glm.set_strips(sharding.balanced_row_strips(h, world, packed))
                 row_begin, row_end = glm.strips[rank]
+            if group is None and os.environ.get("ILM_BENCH_STRIP"):
+                # EXPERIMENT (tools/ab_tilemap.sh): one GPU renders strip k of n equal bands only -- what a rank of an n-GPU frame launches
+                k_, n_ = (int(v) for v in os.environ["ILM_BENCH_STRIP"].split("/"))
+                band = (((h + 15) // 16 + n_ - 1) // n_) * 16
+                row_begin, row_end = min(h, k_ * band), min(h, (k_ + 1) * band)
             stats = r.RenderLighting(1.0, row_begin, row_end, True)     # instrumented frame: exact SDF sample count
             # Frames per timed block: at least --light-frames, and enough to fill ~60 ms of GPU time -- a 1 ms frame timed over five
             # launches sits on the clock ramp (cfg3: 1.00 ms per frame over 4 frames, 0.92 over 40, 0.89 over 400 on the same box)
