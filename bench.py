@@ -565,9 +565,15 @@ def main():
                 row_begin, row_end = glm.strips[rank]
             if group is None and os.environ.get("ILM_BENCH_STRIP"):
                 # EXPERIMENT (tools/ab_tilemap.sh): one GPU renders strip k of n equal bands only -- what a rank of an n-GPU frame launches
-                k_, n_ = (int(v) for v in os.environ["ILM_BENCH_STRIP"].split("/"))
-                band = (((h + 15) // 16 + n_ - 1) // n_) * 16
-                row_begin, row_end = min(h, k_ * band), min(h, (k_ + 1) * band)
+                spec = os.environ["ILM_BENCH_STRIP"]
+                k_, n_ = (int(v) for v in spec.split(":")[-1].split("/"))
+                if spec.startswith("balanced:"):        # the cost-balanced strips an n-rank run cuts (same call as below)
+                    from illuminant_amd import sharding
+                    packed = [abi.LightVertex.from_buffer_copy(H.LightingRenderer.PackSphereLightBytes(lsrc, 1.0, True)) for lsrc in L["env"].Lights]
+                    row_begin, row_end = sharding.balanced_row_strips(h, n_, packed)[k_]
+                else:
+                    band = (((h + 15) // 16 + n_ - 1) // n_) * 16
+                    row_begin, row_end = min(h, k_ * band), min(h, (k_ + 1) * band)
             stats = r.RenderLighting(1.0, row_begin, row_end, True)     # instrumented frame: exact SDF sample count
             # Frames per timed block: at least --light-frames, and enough to fill ~60 ms of GPU time -- a 1 ms frame timed over five
             # launches sits on the clock ramp (cfg3: 1.00 ms per frame over 4 frames, 0.92 over 40, 0.89 over 400 on the same box)
@@ -604,7 +610,7 @@ def main():
             issue = (waves_l * lv["value"] / (kern_ms * 1e-3) / 1e9) if lv else None
             lighting[name] = {
                 "lit_mpixels_per_s": round(w * h / (frame_ms * 1e-3) / 1e6, 2),
-                "ms_per_frame": round(frame_ms, 4), "timed_frames": light_frames,
+                "ms_per_frame": round(frame_ms, 4), "timed_frames": light_frames, "rows": [int(row_begin), int(row_end)],
                 "sdf_samples_per_frame": samples_total,
                 "pixel_light_pairs_this_rank": pairs_local, "traced_pairs_this_rank": traced_local,
                 "field_generation": L["field_generation"],
