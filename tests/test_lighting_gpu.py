@@ -219,3 +219,25 @@ def test_the_trace_follows_the_atlas_when_it_changes(ctx, oracle, sfmt):
     sdf.upload(atlas_a)
     assert check(atlas_a, "after the pointer escaped") == s_a
     gen.close(); lm.close(); sdf.close()
+
+
+@pytest.mark.parametrize("width,height,rows", [(96, 96, None), (97, 95, None), (112, 208, None), (193, 97, None), (16, 16, None), (5, 3, None),
+                                                (300, 220, (32, 176)), (208, 400, (96, 112)), (1, 1, None)])
+def test_every_pixel_of_any_frame_size_is_rendered_once(ctx, oracle, width, height, rows):
+    """The light pass deals its 16 x 16 tiles to the XCDs in groups of 6 x 6 (lighting.hip, tile_map 4): frames whose tile counts are
+    multiples of the group edge, one more, one less, smaller than a group, and strips that begin and end inside a group.  A tile rendered
+    twice would be harmless; one never rendered keeps the poison the lightmap is filled with."""
+    lights = scenes.random_lights(width * 1000 + height, 5, width, height, z=(8.0, 48.0), radius=10.0, ramp=(60.0, 200.0))
+    lights = (abi.LightVertex * len(lights))(*lights)
+    env = scenes.environment()
+    dfu = scenes.DistanceFieldLayout(64, 64, 32.0, 3, 1.0, 64).uniforms()
+    row_begin, row_end = rows if rows is not None else (0, height)
+    lm = native.Lightmap(ctx, width, height)
+    lm.upload(np.full((height, width, 4), -7.0, np.float32))
+    native.render_sphere_lights(ctx, lights, env, dfu, None, None, (0.1, 0.2, 0.3, 1.0), lm, row_begin, row_end)
+    got = lm.download()
+    want, _ = oracle.render_sphere_lights(lights, env, dfu, None, None, (0.1, 0.2, 0.3, 1.0), width, height, row_begin, row_end)
+    assert np.all(got[row_begin:row_end, :, 3] >= 1.0), "a pixel of the strip was not rendered"
+    assert_close(got[row_begin:row_end], want[row_begin:row_end], "lightmap %dx%d rows %d..%d" % (width, height, row_begin, row_end))
+    assert np.all(got[:row_begin] == -7.0) and np.all(got[row_end:] == -7.0), "rows outside the strip were written"
+    lm.close()
