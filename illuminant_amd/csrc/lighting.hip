@@ -425,13 +425,13 @@ constexpr int kTile = ILM_LIGHT_TILE;
 constexpr int kLightThreads = (kTile / 8) * (kTile / 8) * 64;
 constexpr int kListCapacity = (kTile == 16) ? 1024 : 512;
 
-// Seven waves per SIMD (72 VGPRs, 16 bytes of scratch in the per-pair code).  Measured with tools/ab_lib.sh on the final r02 kernel (the
-// table-driven sampler and the per-pair rewrite freed registers since the earlier sweep, when seven and eight waves spilled inside the
-// trace loop and lost 3-6 %): five waves (81 VGPRs, the allocator's own need, no scratch) cfg5 11.93 ms, six (80 VGPRs) 11.26, seven
-// 10.89, eight (64 VGPRs, 48 bytes of scratch) 10.93; cfg3 0.964-0.984 ms whatever the count (its occupancy over time is set by the
-// launch's tail).
+// Eight waves per SIMD (64 VGPRs; the fp16 kernel without scratch, the unorm16 one with 8 bytes outside the loop).  History, tools/ab_lib.sh:
+// r02, table-driven sampler: five waves (81 VGPRs, the allocator's own need) cfg5 11.93 ms, six 11.26, seven 10.89, eight (48 bytes of
+// scratch) 10.93.  r03, cell array + exact skips + tile groups: six 9.29, seven 8.82, eight 8.67 on cfg5 but 0.61 -> 0.66 on cfg3 (spills
+// in the per-pair code).  With the launch descriptor read where it is needed (the light loop below) the spills are gone:
+// seven 0.616 | 8.93, **eight 0.602 | 8.54**.
 #ifndef ILM_LIGHT_WAVES
-#define ILM_LIGHT_WAVES 7
+#define ILM_LIGHT_WAVES 8
 #endif
 #if ILM_LIGHT_WAVES > 0
 #define ILM_LIGHT_OCCUPANCY __attribute__((amdgpu_waves_per_eu(ILM_LIGHT_WAVES, ILM_LIGHT_WAVES)))
@@ -486,7 +486,6 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
     const int table_n = a.sdf.table_slices;
     for (int i = (int)threadIdx.x; i < table_n; i += kLightThreads) slice_table[i] = make_slice_entry((uint32_t)i, a.df, a.sdf);
     const InsideConsts inside = make_inside_consts(a.df, a.sdf);
-    const TraceField field = { a.df, a.sdf, inside, (table_n > 0) ? slice_table : nullptr };
     const int tx0 = (tile % tiles_x) * kTile, ty0 = a.row_begin + (tile / tiles_x) * kTile;
 
     const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
@@ -559,6 +558,17 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
         const int n = list_count;
 
         for (int k = 0; k < n; k++) {
+            // The launch descriptor lives in the kernarg segment.  Read through a pointer the compiler cannot see through, its fields are
+            // fetched (scalar-cache hits) where a pair needs them instead of being hoisted out of the light loop and held in SGPRs across
+            // the whole kernel: 32-42 scalar registers were spilled to vector lanes that way, now 2 -- by itself worth nothing (cfg5
+            // 8.82 -> 8.93 ms), but the vector registers it frees are what lets EIGHT waves per SIMD run without spilling in the loop.
+            typedef const LightLaunch __attribute__((address_space(4))) CLightLaunch;
+            CLightLaunch* ap = (CLightLaunch*)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ap));
+            const LightLaunch& A = *(const LightLaunch*)ap;
+            const TraceField field = { A.df, A.sdf, inside, (table_n > 0) ? slice_table : nullptr };
+            const IlmEnvironment& env_k = A.env;
+            const RampView& ramp_k = A.ramp;
             const int entry = __builtin_amdgcn_readfirstlane((int)list[k]);
             const int li = entry & 0x7FFF;
             const LightRec& L = recs[batch + li];
@@ -577,7 +587,7 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
                 continue;
             if (STATS) st.pairs++;
             float cr, cg, cb;
-            if (!shade_light<FMT, STATS>(P, L, a.env, field, have_sdf, a.ramp, st, cr, cg, cb, flat_normals))
+            if (!shade_light<FMT, STATS>(P, L, env_k, field, have_sdf, ramp_k, st, cr, cg, cb, flat_normals))
                 continue;
             if (blend_fp16) {      // dst = half(float(dst) + float(half(src))): the shader's output is converted to the target format, then blended
                 acc_r = through_half(acc_r + through_half(cr));
