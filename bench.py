@@ -601,7 +601,7 @@ def main():
             my_px = (row_end - row_begin) * w
             alg_bytes = samples * SDF_SAMPLE_BYTES + my_px * 8 + nl * 128   # this rank's launch: SDF samples + ground-plane lightmap write (half4) + light records
             kern_ms = gms / light_frames
-            kname = "ilm::sphere_lights_kernel<%d, false>" % (1 if fmt == abi.SDF_FP16 else 0)
+            kname = "ilm::sphere_lights_kernel<%d, false, false>" % (1 if fmt == abi.SDF_FP16 else 0)
             lt = profiled_traffic(kname) if world == 1 else None
             # the kernel's binding resource is VALU issue, not HBM (the atlas is cache-resident): wave-instructions of the committed PMC
             # profile of this same frame / this run's launch time

@@ -444,10 +444,14 @@ extern "C" int ilm_experiment_light_trace(unsigned long long* out, int n) {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_light_trace), sizeof(unsigned long long) * (size_t)n);
 }
 #endif
-template <int FMT, bool STATS>
+// WIDE_BIN: the tile list is built by all the workgroup's waves, 256 lights per round (frames of particle lights: thousands per tile);
+// otherwise by wave 0 alone, 64 per round, while the others wait -- a frame of a few hundred lights bins in 1-4 rounds either way, and
+// the wide form's extra code costs the sphere-light frames 1-2 % through register allocation, so it is its own instantiation.
+template <int FMT, bool STATS, bool WIDE_BIN>
 __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_lights_kernel(const LightLaunch a, const LightRec* __restrict__ recs, int tiles_x, int tiles_y, int tile_count) {
     __shared__ uint16_t list[kListCapacity];
     __shared__ int list_count;
+    __shared__ int bin_count[2][kLightThreads / 64];
     __shared__ SliceEntry slice_table[kMaxTableSlices];
 
     // The dispatcher places block b on XCD b % 8.  Which tiles an XCD gets decides both its L2 locality and its share of the work
@@ -528,6 +532,42 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
 
     for (int batch = 0; batch < light_count; batch += kListCapacity) {
         const int batch_n = min(kListCapacity, light_count - batch);
+        if constexpr (WIDE_BIN) {
+        __syncthreads();                                        // the previous batch's list has been walked
+        {
+            // ordered compaction of the lights whose footprint bounding box touches the tile: all the workgroup's threads test one light
+            // each per round (a frame of particle lights bins thousands per tile), the waves' counts meet in LDS, the list keeps light order
+            const float tminx = (float)tx0 + 0.5f, tmaxx = (float)(tx0 + kTile - 1) + 0.5f;
+            const float tminy = (float)ty0 + 0.5f, tmaxy = (float)(ty0 + kTile - 1) + 0.5f;
+            constexpr int kWaves = kLightThreads / 64;
+            int base = 0;
+            for (int l0 = 0; l0 < batch_n; l0 += kLightThreads) {
+                const int li = l0 + (int)threadIdx.x;
+                bool hit = false, whole = false;
+                if (li < batch_n) {
+                    const LightRec& R = recs[batch + li];
+                    const float4 fx = *reinterpret_cast<const float4*>(&R.fx0), fy = *reinterpret_cast<const float4*>(&R.fy0);
+                    hit = (fx.x <= tmaxx) && (fx.w > tminx) && (fy.x <= tmaxy) && (fy.w > tminy);
+                    // the whole tile inside one of the footprint's two rectangles: every pixel centre passes the per-pixel test below (the
+                    // same comparisons, taken on the tile's extreme centres), so the walk skips it for this entry (bit 15)
+                    whole = ((tminx >= fx.y) && (tmaxx < fx.z) && (tminy >= fy.x) && (tmaxy < fy.w)) ||
+                            ((tminx >= fx.x) && (tmaxx < fx.w) && (tminy >= fy.y) && (tmaxy < fy.z));
+                }
+                const unsigned long long m = __ballot(hit);
+                const int round = (l0 / kLightThreads) & 1;     // two sets of counters: a wave may be a round ahead of the slowest reader
+                if (lane == 0) bin_count[round][wave] = __popcll(m);
+                __syncthreads();
+                int before = 0, total = 0;
+#pragma unroll
+                for (int w = 0; w < kWaves; w++) { const int c = bin_count[round][w]; total += c; if (w < wave) before += c; }
+                if (hit)
+                    list[base + before + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(li | (whole ? 0x8000 : 0));
+                base += total;
+            }
+            if (threadIdx.x == 0) list_count = base;
+        }
+        __syncthreads();
+        } else {
         __syncthreads();
         if (threadIdx.x == 0) list_count = 0;
         __syncthreads();
@@ -555,6 +595,7 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
             if (lane == 0) list_count = base;
         }
         __syncthreads();
+        }
         const int n = list_count;
 
         for (int k = 0; k < n; k++) {
@@ -931,13 +972,19 @@ hipError_t launch_sphere_lights_prepared(const LightLaunch& a, const void* recs,
     const bool stats = a.stats != nullptr;
     const bool fp16 = a.sdf.format == ILM_SDF_FP16;
     const dim3 grid(blocks), block(kLightThreads);
-#define ILM_LAUNCH_LIGHTS(F, S) hipLaunchKernelGGL((sphere_lights_kernel<F, S>), grid, block, 0, stream, a, r, tiles_x, tiles_y, tile_count)
-    const int variant = (fp16 ? 2 : 0) | (stats ? 1 : 0);
+#define ILM_LAUNCH_LIGHTS(F, S, W) hipLaunchKernelGGL((sphere_lights_kernel<F, S, W>), grid, block, 0, stream, a, r, tiles_x, tiles_y, tile_count)
+    // device-side counts are particle lights: thousands
+    const bool wide = (a.light_count_ptr != nullptr) || (a.light_count > 512);
+    const int variant = (wide ? 4 : 0) | (fp16 ? 2 : 0) | (stats ? 1 : 0);
     switch (variant) {
-        case 0: ILM_LAUNCH_LIGHTS(ILM_SDF_UNORM16, false); break;
-        case 1: ILM_LAUNCH_LIGHTS(ILM_SDF_UNORM16, true); break;
-        case 2: ILM_LAUNCH_LIGHTS(ILM_SDF_FP16, false); break;
-        default: ILM_LAUNCH_LIGHTS(ILM_SDF_FP16, true); break;
+        case 0: ILM_LAUNCH_LIGHTS(ILM_SDF_UNORM16, false, false); break;
+        case 1: ILM_LAUNCH_LIGHTS(ILM_SDF_UNORM16, true, false); break;
+        case 2: ILM_LAUNCH_LIGHTS(ILM_SDF_FP16, false, false); break;
+        case 3: ILM_LAUNCH_LIGHTS(ILM_SDF_FP16, true, false); break;
+        case 4: ILM_LAUNCH_LIGHTS(ILM_SDF_UNORM16, false, true); break;
+        case 5: ILM_LAUNCH_LIGHTS(ILM_SDF_UNORM16, true, true); break;
+        case 6: ILM_LAUNCH_LIGHTS(ILM_SDF_FP16, false, true); break;
+        default: ILM_LAUNCH_LIGHTS(ILM_SDF_FP16, true, true); break;
     }
 #undef ILM_LAUNCH_LIGHTS
     return hipGetLastError();
