@@ -24,7 +24,7 @@ def test_profiled_traffic_comes_from_the_newest_committed_summary():
 
 
 def test_light_kernel_instruction_counts_are_in_the_summary():
-    for k in ("ilm::sphere_lights_kernel<0, false>", "ilm::sphere_lights_kernel<1, false>"):
+    for k in ("ilm::sphere_lights_kernel<0, false, false>", "ilm::sphere_lights_kernel<1, false, false>"):
         v = bench.profiled_per_wave(k, "SQ_INSTS_VALU")
         assert v is not None and v["value"] > 1000
 
