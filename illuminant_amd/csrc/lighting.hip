@@ -603,6 +603,7 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
             // fetched (scalar-cache hits) where a pair needs them instead of being hoisted out of the light loop and held in SGPRs across
             // the whole kernel: 32-42 scalar registers were spilled to vector lanes that way, now 2 -- by itself worth nothing (cfg5
             // 8.82 -> 8.93 ms), but the vector registers it frees are what lets EIGHT waves per SIMD run without spilling in the loop.
+            // (the descriptor is the kernel's FIRST parameter: offset 0 of the segment)
             typedef const LightLaunch __attribute__((address_space(4))) CLightLaunch;
             CLightLaunch* ap = (CLightLaunch*)__builtin_amdgcn_kernarg_segment_ptr();
             asm volatile("" : "+s"(ap));
