@@ -614,8 +614,8 @@ def main():
                 "sdf_samples_per_frame": samples_total,
                 "pixel_light_pairs_this_rank": pairs_local, "traced_pairs_this_rank": traced_local,
                 "field_generation": L["field_generation"],
-                # What binds the kernel, named by the counters (profiles/r02_summary.md): vector-instruction issue.  The 25 MB atlas is
-                # L2 / Infinity-Cache resident (L2 hit 99 %), HBM sees ~100 MB per frame.
+                # What binds the kernel, named by the counters (profiles/r03_summary.md): vector-instruction issue.  The trace reads the
+                # field's cell array (138 MB on cfg5) through L1 / L2 / Infinity Cache: L2 hit rate 98.6 %, ~0.2 GB per frame from beyond.
                 "roofline": {"bound": "valu", "achieved": round(issue, 1) if issue else None, "peak": round(VALU_ISSUE_PEAK, 1), "unit": "G wave-instr/s",
                              "frac": round(issue / VALU_ISSUE_PEAK, 4) if issue else None,
                              "calibrated_peak": VALU_ISSUE_CALIBRATED, "calibrated_frac": round(issue / VALU_ISSUE_CALIBRATED, 4) if issue else None,
