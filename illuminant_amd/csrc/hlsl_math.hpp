@@ -215,7 +215,13 @@ ILM_DEV float div_with_rcp(float n, float d, float y) {
 ILM_DEV float div_no_scale(float n, float d) { return div_with_rcp(n, d, refined_rcp(d)); }
 
 // The general form: any position (clamped to the volume, distance to the volume added), U WRAP / V CLAMP on the real atlas.
-template <int FORMAT, bool CHECK_NAN = true>
+// SLICE0: the uniforms as the reference's PARTICLE path binds them -- DistanceFieldPacked1 left at zero (ParticleSystem.cs
+// SetDistanceFieldUniforms): zToSliceIndex = 0 puts every lookup at slice position 0 * min(z, maximumValidZ) = 0, i.e. virtual
+// slice 0 (column 0, row 0, channel pair (r, g)) with a z weight of 0 -- the result is the bilinear fetch of channel r alone:
+// lerp(lo, hi, 0) = fma(0, hi - lo, lo) = lo for every finite lo, hi (up to the sign of a zero that `kDistanceZero - blended` does not
+// see).  The caller selects it when Packed1.y == 0 and Packed1.x, .z are finite; one channel per tap, three lerps instead of seven, no
+// slice arithmetic: a quarter of the sampler's instructions.
+template <int FORMAT, bool CHECK_NAN = true, bool SLICE0 = false>
 ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms& df, const SdfView& sdf) {
 #pragma clang fp contract(off)
     position.z -= df.ConeAndMisc.y;
@@ -242,15 +248,23 @@ ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms&
         }
     }
 
-    const float slice_position = (CHECK_NAN ? fminf(cz, df.Packed1.z) : __builtin_elementwise_minimum(cz, df.Packed1.z)) * df.Packed1.y;   // cz is finite
-    const float vslice = floorf(slice_position);
-    const uint32_t vi = (uint32_t)vslice;                    // 0 <= vslice < 65536
-    const uint32_t third = __umul24(vi, 0xAAABu) >> 17;      // vi / 3 (24-bit multiply: full rate)
-
-    const float column_index = (float)third;                 // floor(vslice / 3)
-    const float row_index = floorf(vslice * df.Packed1.x);   // floor(vslice * invCols / 3): the reference's float form
-    const float u = __builtin_fmaf(column_index, df.TextureSliceAndTexelSize.x, cx * df.TextureSliceAndTexelSize.z);
-    const float v = __builtin_fmaf(row_index, df.TextureSliceAndTexelSize.y, cy * df.TextureSliceAndTexelSize.w);
+    float slice_position = 0.0f, vslice = 0.0f;
+    uint32_t vi = 0u, third = 0u;
+    float u, v;
+    if (SLICE0) {
+        // column_index = row_index = 0: fma(0, size, t) = t for t >= +0
+        u = cx * df.TextureSliceAndTexelSize.z;
+        v = cy * df.TextureSliceAndTexelSize.w;
+    } else {
+        slice_position = (CHECK_NAN ? fminf(cz, df.Packed1.z) : __builtin_elementwise_minimum(cz, df.Packed1.z)) * df.Packed1.y;   // cz is finite
+        vslice = floorf(slice_position);
+        vi = (uint32_t)vslice;                                   // 0 <= vslice < 65536
+        third = __umul24(vi, 0xAAABu) >> 17;                     // vi / 3 (24-bit multiply: full rate)
+        const float column_index = (float)third;                 // floor(vslice / 3)
+        const float row_index = floorf(vslice * df.Packed1.x);   // floor(vslice * invCols / 3): the reference's float form
+        u = __builtin_fmaf(column_index, df.TextureSliceAndTexelSize.x, cx * df.TextureSliceAndTexelSize.z);
+        v = __builtin_fmaf(row_index, df.TextureSliceAndTexelSize.y, cy * df.TextureSliceAndTexelSize.w);
+    }
 
     // LINEAR, U WRAP, V CLAMP, texel centres at +0.5
     const float x = __builtin_fmaf(u, sdf.wf, -0.5f);
@@ -289,15 +303,20 @@ ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms&
     // The two channels virtual slice 3k+m blends -- (r,g), (g,b) or (b,a) -- are the 4 bytes at offset 2m inside the 8-byte texel:
     // one dword load per tap at that (2-byte aligned) address (tools/ubench/gather: a 2-byte aligned dword gather costs the same as
     // an aligned one).  2 * (vi % 3) = 2 * vi - 6 * third as one 24-bit multiply-add.
-    uint32_t sub;
-    asm("v_mad_i32_i24 %0, %1, -6, %2" : "=v"(sub) : "v"(third), "v"(vi << 1));
+    uint32_t sub = 0u;
+    if (!SLICE0) asm("v_mad_i32_i24 %0, %1, -6, %2" : "=v"(sub) : "v"(third), "v"(vi << 1));
     typedef const char __attribute__((address_space(1))) gbyte;
     typedef const uint32_t __attribute__((address_space(1), aligned(2))) gword;
     gbyte* base = (gbyte*)sdf.texels;
     asm("" : "+s"(base));
     const uint32_t c0 = ((uint32_t)x0 << 3) + sub, c1 = ((uint32_t)x1 << 3) + sub;
     float a00, b00, a10, b10, a01, b01, a11, b11;
-    if (FORMAT == ILM_SDF_UNORM16) {
+    if (SLICE0 && FORMAT == ILM_SDF_UNORM16) {
+        const __amdgpu_buffer_rsrc_t rsrc = sdf_unorm_rsrc(sdf);       // channel r of the four taps (the pair's second channel is not needed)
+        a00 = ilm_llvm_buffer_load_format_xy(rsrc, (int)(r0 + c0), 0, 0).x; a10 = ilm_llvm_buffer_load_format_xy(rsrc, (int)(r0 + c1), 0, 0).x;
+        a01 = ilm_llvm_buffer_load_format_xy(rsrc, (int)(r1 + c0), 0, 0).x; a11 = ilm_llvm_buffer_load_format_xy(rsrc, (int)(r1 + c1), 0, 0).x;
+        b00 = b10 = b01 = b11 = 0.0f;
+    } else if (FORMAT == ILM_SDF_UNORM16) {
         // typed taps: the texture path decodes the channel pair (see sdf_unorm_rsrc)
         const __amdgpu_buffer_rsrc_t rsrc = sdf_unorm_rsrc(sdf);
         const f32x2 t00 = ilm_llvm_buffer_load_format_xy(rsrc, (int)(r0 + c0), 0, 0), t10 = ilm_llvm_buffer_load_format_xy(rsrc, (int)(r0 + c1), 0, 0);
@@ -312,8 +331,11 @@ ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms&
         sdf_unpack_word<FORMAT>(w11, a11, b11);
     }
     const float lo = lerp_fused(lerp_fused(a00, a10, fx), lerp_fused(a01, a11, fx), fy);
-    const float hi = lerp_fused(lerp_fused(b00, b10, fx), lerp_fused(b01, b11, fx), fy);
-    const float blended = lerp_fused(lo, hi, slice_position - vslice);
+    float blended = lo;
+    if (!SLICE0) {
+        const float hi = lerp_fused(lerp_fused(b00, b10, fx), lerp_fused(b01, b11, fx), fy);
+        blended = lerp_fused(lo, hi, slice_position - vslice);
+    }
 
     return __builtin_fmaf(kDistanceZero - blended, df.Extent.w, distance_to_volume);
 }

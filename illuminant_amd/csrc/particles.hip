@@ -706,7 +706,7 @@ ILM_DEV f3 estimate_normal4(f3 position, const IlmDistanceFieldUniforms& df, con
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const f3 w = mk3(W[i][0], W[i][1], W[i][2]);
-        const float s = sample_distance_field<FMT>(position + (w * texel), df, sdf);
+        const float s = sample_distance_field<(FMT & 1), true, (FMT & 2) != 0>(position + (w * texel), df, sdf);
         result = result + (w * s);
     }
     return norm3(result);
@@ -734,7 +734,7 @@ ILM_DEV void update_with_distance_field(float4& pos, float4& vel, float x, float
     f3 collision_position = mk3(0.0f, 0.0f, 0.0f), new_position = old_xyz;
     float4 new_velocity = zero;
 
-    const float initial_distance = sample_distance_field<FMT>(old_xyz, df, sdf);
+    const float initial_distance = sample_distance_field<(FMT & 1), true, (FMT & 2) != 0>(old_xyz, df, sdf);
     samples++;
     const bool was_colliding = initial_distance < collision_distance;
     float travel_distance = fmaxf(0.0f, fminf(initial_distance, len3(scaled_velocity)));
@@ -746,7 +746,7 @@ ILM_DEV void update_with_distance_field(float4& pos, float4& vel, float x, float
 
     for (int i = 0; i < step_count; i++) {
         const f3 test_position = old_xyz + (unit_vector * travel_distance);
-        const float step_distance = sample_distance_field<FMT>(test_position, df, sdf);
+        const float step_distance = sample_distance_field<(FMT & 1), true, (FMT & 2) != 0>(test_position, df, sdf);
         samples++;
         if (step_distance < collision_distance) {
             collided = true;
@@ -1558,6 +1558,15 @@ static bool needs_extended_variant(const StepLaunch& a) {
 #ifndef ILM_DF_MINW
 #define ILM_DF_MINW 6
 #endif
+// The collision kernels' first template argument: the field's format, plus kFieldSlice0 when the uniforms put every lookup in virtual
+// slice 0 with a z weight of 0 (hlsl_math.hpp sample_distance_field<.., SLICE0>) -- what the reference's particle path binds.
+constexpr int kFieldSlice0 = 2;
+static_assert((ILM_SDF_UNORM16 | ILM_SDF_FP16) == 1, "the format is bit 0 of the collision kernels' first template argument");
+static bool field_is_slice0(const IlmDistanceFieldUniforms& df) {
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("ILM_DF_SLICE0"); enabled = e ? atoi(e) : 1; }
+    return enabled && (df.Packed1.y == 0.0f) && std::isfinite(df.Packed1.x) && std::isfinite(df.Packed1.z);
+}
 template <bool SPAWN>
 static hipError_t launch_step_variant(const StepLaunch& a, hipStream_t stream) {
     const int units = a.unit_end - a.unit_begin;
@@ -1566,10 +1575,12 @@ static hipError_t launch_step_variant(const StepLaunch& a, hipStream_t stream) {
         const int upb = (kStepThreads / 64) * kUnitsPerWave;
         const dim3 g((unsigned)((units + upb - 1) / upb), 1, 1), b(kStepThreads, 1, 1);
         if (a.desc.UpdateMode == ILM_UPDATE_WITH_DISTANCE_FIELD) {
-            if (a.sdf.format == ILM_SDF_FP16)
-                hipLaunchKernelGGL((step_kernel<ILM_SDF_FP16, true, true, 1, true>), g, b, 0, stream, a);
-            else
-                hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, true, true, 1, true>), g, b, 0, stream, a);
+            switch ((int)a.sdf.format | (field_is_slice0(a.desc.DistanceField) ? kFieldSlice0 : 0)) {
+                case ILM_SDF_FP16: hipLaunchKernelGGL((step_kernel<ILM_SDF_FP16, true, true, 1, true>), g, b, 0, stream, a); break;
+                case ILM_SDF_UNORM16: hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, true, true, 1, true>), g, b, 0, stream, a); break;
+                case ILM_SDF_FP16 | kFieldSlice0: hipLaunchKernelGGL((step_kernel<ILM_SDF_FP16 | kFieldSlice0, true, true, 1, true>), g, b, 0, stream, a); break;
+                default: hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16 | kFieldSlice0, true, true, 1, true>), g, b, 0, stream, a); break;
+            }
         } else {
             hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, false, true, 1, true>), g, b, 0, stream, a);
         }
@@ -1584,10 +1595,12 @@ static hipError_t launch_step_variant(const StepLaunch& a, hipStream_t stream) {
     const dim3 grid((unsigned)((units + units_per_block - 1) / units_per_block), 1, 1), block(kStepThreads, 1, 1);
     if (a.desc.UpdateMode == ILM_UPDATE_WITH_DISTANCE_FIELD) {
         // waves per SIMD requested for the collision variants (ILM_DF_MINW; measured in DESIGN 3.1)
-        if (a.sdf.format == ILM_SDF_FP16)
-            hipLaunchKernelGGL((step_kernel<ILM_SDF_FP16, true, SPAWN, ILM_DF_MINW>), grid, block, 0, stream, a);
-        else
-            hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, true, SPAWN, ILM_DF_MINW>), grid, block, 0, stream, a);
+        switch ((int)a.sdf.format | (field_is_slice0(a.desc.DistanceField) ? kFieldSlice0 : 0)) {
+            case ILM_SDF_FP16: hipLaunchKernelGGL((step_kernel<ILM_SDF_FP16, true, SPAWN, ILM_DF_MINW>), grid, block, 0, stream, a); break;
+            case ILM_SDF_UNORM16: hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, true, SPAWN, ILM_DF_MINW>), grid, block, 0, stream, a); break;
+            case ILM_SDF_FP16 | kFieldSlice0: hipLaunchKernelGGL((step_kernel<ILM_SDF_FP16 | kFieldSlice0, true, SPAWN, ILM_DF_MINW>), grid, block, 0, stream, a); break;
+            default: hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16 | kFieldSlice0, true, SPAWN, ILM_DF_MINW>), grid, block, 0, stream, a); break;
+        }
     } else if (a.streaming) {
         hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, false, SPAWN, 1, false, true>), grid, block, 0, stream, a);
     } else if (SPAWN) {

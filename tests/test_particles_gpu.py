@@ -246,7 +246,8 @@ def cfg1_field(fmt=abi.SDF_UNORM16, packed1=True):
     return layout, atlas, layout.uniforms(packed1=packed1)
 
 
-@pytest.mark.parametrize("fmt,packed1,bounce", [(abi.SDF_UNORM16, True, 0.0), (abi.SDF_UNORM16, False, 0.6), (abi.SDF_FP16, True, 0.6)])
+@pytest.mark.parametrize("fmt,packed1,bounce", [(abi.SDF_UNORM16, True, 0.0), (abi.SDF_UNORM16, False, 0.6), (abi.SDF_FP16, True, 0.6),
+                                                (abi.SDF_FP16, False, 0.0)])
 def test_update_with_distance_field_matches_oracle(ctx, oracle, rnd, fmt, packed1, bounce):
     cs = 64
     n = cs * cs
