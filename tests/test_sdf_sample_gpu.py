@@ -4,6 +4,8 @@ The cone trace's loop exits are discontinuous in the sampled distance, and the r
 exact SDF sample counts, so the device sampler must reproduce every rounding of the restated HLSL arithmetic even
 though its integer bookkeeping (slice / 3, % 3, WRAP, unorm16 decode) is implemented differently.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -187,7 +189,8 @@ def test_in_volume_sampler_matches_the_oracle_bit_for_bit(ctx, oracle, fmt, reso
     assert same.all(), "%d of %d samples differ (table form used for %d of them); first: %r got %r want %r" % (
         int((~same).sum()), n, int(used[~same].sum()), pos[~same][0], got[~same][0], want[~same][0])
     interior = (pos[:, 0] > isx) & (pos[:, 0] < virtual - isx) & (pos[:, 1] > isx) & (pos[:, 1] < virtual - isx) & (pos[:, 2] > -2.9) & (pos[:, 2] < 120.0)
-    assert used[interior].mean() > 0.99 and used.sum() > 0.5 * n
+    if os.environ.get("ILM_SDF_CELLS") != "0":               # (the experiment switch turns the table form off: the results above still agree)
+        assert used[interior].mean() > 0.99 and used.sum() > 0.5 * n
     assert not used[(pos[:, 0] < 0) | (pos[:, 1] < 0) | (pos[:, 0] > virtual) | (pos[:, 1] > virtual)].any()
     sdf.close()
 
