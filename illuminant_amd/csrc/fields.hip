@@ -63,8 +63,26 @@ ILM_DEV uint32_t store_channel(float enc) {
     return (uint32_t)floorf(c * 65535.0f + 0.5f);
 }
 
+#ifdef ILM_FIELD_TRACE     // EXPERIMENT (tools/field_trace_probe.py): per-workgroup start / end of the last launch (100 MHz clock), list length
+__device__ unsigned long long g_field_trace[4 * 65536];
+extern "C" int ilm_experiment_field_trace(unsigned long long* out, int n) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_field_trace), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
+#ifndef ILM_FIELD_WAVES
+#define ILM_FIELD_WAVES 0
+#endif
+#if ILM_FIELD_WAVES > 0
+#define ILM_FIELD_OCCUPANCY __attribute__((amdgpu_waves_per_eu(ILM_FIELD_WAVES, ILM_FIELD_WAVES)))
+#else
+#define ILM_FIELD_OCCUPANCY
+#endif
 template <int FORMAT>
-__global__ __launch_bounds__(256) void render_slices_kernel(const FieldLaunch a) {
+__global__ __launch_bounds__(256) ILM_FIELD_OCCUPANCY void render_slices_kernel(const FieldLaunch a) {
+#ifdef ILM_FIELD_TRACE
+    const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
+    int trace_n = 0, trace_evaluated = 0;
+#endif
     __shared__ uint16_t list[kFieldListCapacity];
     __shared__ float sort_key[kFieldSortCapacity];
     __shared__ uint16_t sort_index[kFieldSortCapacity];
@@ -136,6 +154,9 @@ __global__ __launch_bounds__(256) void render_slices_kernel(const FieldLaunch a)
         }
         __syncthreads();
         const int n = list_count;
+#ifdef ILM_FIELD_TRACE
+        trace_n += n;
+#endif
         // Nearest first (BlendFunction.Max does not care about the order): the sooner a texel's maximum is high, the more of the
         // remaining obstructions the bound below rejects.  Rank sort by the distance of the tile centre to the bounding sphere,
         // ties by list position; lists longer than the key buffer stay in index order.
@@ -186,6 +207,9 @@ __global__ __launch_bounds__(256) void render_slices_kernel(const FieldLaunch a)
             const bool can_change = covered && !(e2 >= reach * reach);
             if (__ballot(can_change) == 0ull)
                 continue;
+#ifdef ILM_FIELD_TRACE
+            trace_evaluated++;
+#endif
             if (!covered)
                 continue;
             const int type = R.type;
@@ -248,6 +272,12 @@ __global__ __launch_bounds__(256) void render_slices_kernel(const FieldLaunch a)
         acc3 = fmaxf(acc3, kDistanceZero - (final_eval(slice_z[3], V.z0, V.z1, dxy) / a.max_encoded));
     }
 
+#ifdef ILM_FIELD_TRACE
+    if (threadIdx.x == 0 && blockIdx.x < 65536u) {
+        g_field_trace[4 * blockIdx.x] = trace_t0; g_field_trace[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        g_field_trace[4 * blockIdx.x + 2] = (unsigned long long)trace_n; g_field_trace[4 * blockIdx.x + 3] = (unsigned long long)trace_evaluated;
+    }
+#endif
     if (!in_slice)
         return;
     const size_t o = (size_t)ay * (size_t)a.atlas_w + (size_t)ax;
