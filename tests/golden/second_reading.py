@@ -393,13 +393,15 @@ def random_custom(table, xy, offset, rate, texel):
 
 
 def ps_noise(sysu, n, table, xy, position, velocity):
-    """PS_Noise, Noise.fx:28-72 with AreaType 0 (evaluateNone = 0, DistanceFunctionCommon.fxh:7-11)."""
+    """PS_Noise, Noise.fx:28-72; computeWeight (:21-26) through evaluateByTypeId (AreaType 0: evaluateNone = 0)."""
     oldPosition, oldVelocity = position, velocity
     cf = (F(n.Area.CategoryFilter[0]), F(n.Area.CategoryFilter[1]))
     passes = (oldVelocity[:, 3] >= cf[0]) & (oldVelocity[:, 3] <= cf[1])
+    rot = F(n.Area.AreaRotation)
+    distance = evaluate_by_type_id(n.Area.AreaType, oldPosition[:, :3], list(n.Area.AreaCenter), list(n.Area.AreaSize), (rot, rot, rot, rot))
     with np.errstate(all="ignore"):
-        weight = F(F(F(1) - saturate(F(0) / F(n.Area.AreaFalloff))) * F(n.Area.Strength))       # computeWeight, :21-26
-    t = F(F(weight * sysu.getDeltaTime()) / F(n.TimeDivisor))
+        weight = ((F(1) - saturate((distance / F(n.Area.AreaFalloff)).astype(F))).astype(F) * F(n.Area.Strength)).astype(F)[:, None]
+    t = ((weight * sysu.getDeltaTime()).astype(F) / F(n.TimeDivisor)).astype(F)
     texel = (F(1.0) / F(table.shape[1]), F(1.0) / F(table.shape[0]))                       # RandomnessTexel
     off, noff = (F(n.RandomnessOffset[0]), F(n.RandomnessOffset[1])), (F(n.NextRandomnessOffset[0]), F(n.NextRandomnessOffset[1]))
     xy2 = (xy + np.array([2, 1], F)).astype(F)
@@ -866,6 +868,16 @@ def spawn_inputs(case):
     return dict(chunk_size=cs, pos=pos, vel=vel, attr=attr, rnd=scenes.randomness_table(9), spawn=sp)
 
 
+def noise_area_inputs():
+    """PS_Noise weighted by a rotated box, replacing the old velocity."""
+    P = particle_inputs()
+    P["noise"] = scenes.noise_params(scenes.area(2, (120.0, 130.0, 10.0), (70.0, 50.0, 40.0), falloff=60.0, rotation=0.5, strength=0.9),
+                                     (37.0 * 253 / 1000.0, 11.0 * 127 / 1000.0), (591.0 * 253 / 1000.0, 220.0 * 127 / 1000.0), 0.6,
+                                     replace_old_velocity=True, position=((-0.5,) * 4, (0.05,) * 4, (3.0, 3.0, 1.0, 0.0)),
+                                     velocity=((-0.5,) * 3, (0.1,) * 3, (20.0, 20.0, 5.0)), speed=(-0.5, 0.0, 2.0))
+    return P
+
+
 def fma_inputs(area_type=0):
     P = particle_inputs()
     f = abi.FMAParams()
@@ -985,6 +997,8 @@ def main():
         for key, value in (("position", cp), ("velocity", cv), ("render_color", cc), ("render_data", cd), ("samples", np.array([csamples], np.int64))):
             extra["collision_%s_%s" % (case, key)] = value
         print("collision update, %s: %d lookups, %s" % (case, csamples, branches))
+    Pn = noise_area_inputs()
+    extra["after_area_noise_position"], extra["after_area_noise_velocity"] = ps_noise(System(Pn["system"]), Pn["noise"], Pn["rnd"], xy, Pn["pos"], Pn["vel"])
     Pf = fma_inputs()
     extra["after_fma_position"], extra["after_fma_velocity"] = ps_fma(System(Pf["system"]), Pf["fma"], Pf["pos"], Pf["vel"])
     for area_type in (1, 2, 3, 4, 5):

@@ -150,3 +150,14 @@ def test_lit_frame_under_a_gbuffer_of_the_second_reading(oracle):
     assert (err > 0).sum() <= 12, "%d elements of the lightmap differ from the second reading by more than 2e-6" % int((err > 0).sum())
     # the fullbright band (G-buffer rows 20..22 = frame rows 18..20 under the scrolled viewport) receives no light at all
     assert not want[18:21, :, 3].any() and (want[..., 3] >= 2.0).mean() > 0.4
+
+
+def test_noise_under_an_area_of_the_second_reading(oracle):
+    """PS_Noise weighted by a rotated box (computeWeight through evaluateByTypeId), ReplaceOldVelocity on."""
+    P = second.noise_area_inputs()
+    pos, vel = P["pos"].copy(), P["vel"].copy()
+    oracle.noise(pos, vel, P["chunk_size"], P["rnd"], P["system"], P["noise"])
+    assert_close(pos, FIX["after_area_noise_position"], "position after PS_Noise under an area", **TOL)
+    assert_close(vel, FIX["after_area_noise_velocity"], "velocity after PS_Noise under an area", **TOL)
+    moved = np.abs(FIX["after_area_noise_position"] - P["pos"]).max(axis=1)
+    assert (moved > 1e-3).any() and (moved == 0).any()                         # inside the box's reach and beyond its falloff

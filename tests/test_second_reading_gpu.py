@@ -123,3 +123,12 @@ def test_lit_frame_under_a_gbuffer_against_the_second_reading(ctx):
     assert np.array_equal(got[..., 3], FIX["lightmap_gbuffer"][..., 3])
     assert_close(got, FIX["lightmap_gbuffer"], "GPU lightmap under a G-buffer vs the second reading")
     lm.close(); gb.close(); sdf.close()
+
+
+def test_noise_under_an_area_against_the_second_reading(ctx):
+    P = second.noise_area_inputs()
+    eng, sysm = _system_with(ctx, P["chunk_size"], P["rnd"], P["pos"], P["vel"], P["attr"])
+    sysm.noise(0, P["system"], P["noise"])
+    assert_close(sysm.download(0, abi.PLANE_POSITION), FIX["after_area_noise_position"], "GPU position after PS_Noise under an area vs the second reading")
+    assert_close(sysm.download(0, abi.PLANE_VELOCITY), FIX["after_area_noise_velocity"], "GPU velocity after PS_Noise under an area vs the second reading")
+    sysm.close(); eng.close()
