@@ -28,6 +28,7 @@ bad_light, bad_step, worst_l, worst_s = [], [], 0.0, 0.0
 bad_float, floor_needed, elements_compared = [], 0, 0
 bad_gbuffer, gbuffer_texels = [], 0
 worst_where = None
+bad_collision, collision_steps, collision_elements, collided_total = [], 0, 0, 0
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     # ---- lighting: random field, lights, G-buffer normals, both SDF formats -------------------------------------------
@@ -50,6 +51,43 @@ for seed in range(first, first + count):
     worst_l = max(worst_l, e)
     if (st.SdfSamples, st.PixelLightPairs, st.TracedPairs) != (ost.SdfSamples, ost.PixelLightPairs, ost.TracedPairs) or e > 1e-4:
         bad_light.append((seed, (st.SdfSamples, st.PixelLightPairs, st.TracedPairs), (ost.SdfSamples, ost.PixelLightPairs, ost.TracedPairs), e))
+    # ---- the collision update through this seed's field, every other seed: both formats, the uniforms as the lighting path binds
+    #      them and as the particle path does (DistanceFieldPacked1 = 0: the slice-0 form of the sampler) ------------------------------
+    if seed % 2 == 0:
+        crng = np.random.default_rng(seed + 424242)
+        ccs = 64
+        cn = ccs * ccs
+        cpos, cvel, cattr = scenes.make_particles(seed + 5, cn, pos_lo=(-16, -16, 0), pos_hi=(272, 208, 60), dead_fraction=float(crng.uniform(0, 0.3)),
+                                                  life=(0.01, 6.0), categories=(0.0, 2.0))
+        csu = scenes.system_uniforms(ccs, friction=float(crng.uniform(0, 0.3)), max_velocity=float(crng.choice([90.0, 2048.0])), life_decay=float(crng.uniform(0, 2)),
+                                     collision=(float(crng.uniform(30, 200)), float(crng.choice([0.0, 0.6, 1.2])), float(crng.uniform(0.1, 2.0)), float(crng.uniform(0, 0.2))))
+        cfmt = abi.SDF_FP16 if (seed // 2) % 2 else abi.SDF_UNORM16
+        catlas = atlas if cfmt == fmt else scenes.build_sdf_atlas(layout, obstacles, fmt=cfmt)
+        cdfu = layout.uniforms(packed1=bool((seed // 4) % 2))
+        cup = abi.UpdateParams.default()
+        ceng = native.Engine(ctx, ccs, scenes.randomness_table(3)); csys = native.System(ceng); csys.add_chunk()
+        csdf = native.DistanceFieldTexture(ctx, catlas, cfmt)
+        csys.set_distance_field(csdf)
+        for pl, data in ((P, cpos), (V, cvel), (A, cattr)):
+            csys.upload(0, pl, data)
+        csys.update(0, csu, cup, df=cdfu)
+        cwant = [cpos.copy(), cvel.copy(), cattr.copy(), np.zeros((cn, 4), np.float32), np.zeros((cn, 4), np.float32)]
+        oracle.update(cwant[0], cwant[1], cwant[2], cwant[3], cwant[4], ccs, csu, cup, df=cdfu, sdf=oracle.make_texture(catlas, cfmt))
+        collision_steps += 1
+        for kk, pl in enumerate((P, V, A, RC, RD)):
+            g = csys.download(0, pl).astype(np.float64); wv = cwant[kk].astype(np.float64)
+            if kk == 0:
+                if not np.array_equal(g[:, 3] > 0, wv[:, 3] > 0) or not np.array_equal(g[:, 3].astype(np.float32).view(np.uint32), wv[:, 3].astype(np.float32).view(np.uint32)):
+                    bad_collision.append((seed, "liveness / life not identical"))
+            comp_scale = np.where(np.isfinite(wv), np.abs(wv), 0.0).max(axis=0)
+            both_nan = np.isnan(g) & np.isnan(wv)
+            outside = ~(np.abs(g - wv) <= 1e-5 * comp_scale[None, :] + 1e-4 * np.abs(wv)) & ~both_nan
+            collision_elements += g.size
+            if outside.any():
+                i, j = np.argwhere(outside)[0]
+                bad_collision.append((seed, "plane %d slot %d component %d: got %.9g want %.9g; %d element(s)" % (kk, i, j, g[i, j], wv[i, j], int(outside.sum()))))
+        collided_total += int((cwant[1][:, 3] == 3.0).sum())
+        csdf.close(); csys.close(); ceng.close()
     # ---- particles: random op list, spawner, chunk size ---------------------------------------------------------------
     cs = int(rng.choice([16, 48, 64, 128]))
     n = cs * cs
@@ -253,6 +291,9 @@ print("rasteriser: %d scenes out of bounds; most edge pixels that flipped in one
 for b in bad_raster[:10]: print("   ", b)
 print("lighting: %d scenes with differing statistics or > 1e-4 error; worst relative error %.3g" % (len(bad_light), worst_l))
 for b in bad_light[:10]: print("   ", b)
+print("collision update: %d problems in %d steps (%.1f M elements; %d particles bounced or were redirected); liveness and life bit-identical, floats by the suite's criterion"
+      % (len(bad_collision), collision_steps, collision_elements / 1e6, collided_total))
+for b in bad_collision[:10]: print("   ", b)
 print("particles: %d steps with differing live counts / liveness; worst error relative to (|want| + 1e-4 scale) %.3g" % (len(bad_step), worst_s))
 for b in bad_step[:10]: print("   ", b)
 print("worst particle element (seed, chunk, plane, slot, component, got, want, plane scale, chunk size, ops, spawns):", worst_where)
@@ -260,6 +301,6 @@ print("particle floats: %d failures of the suite's criterion (1e-4 relative + 1e
       "%d elements (%.2g of all) are outside a PURE 1e-4 relative bound, i.e. needed the absolute floor" %
       (len(bad_float), elements_compared / 1e6, floor_needed, floor_needed / max(elements_compared, 1)))
 for b in bad_float[:10]: print("   ", b)
-failed = bool(bad_field or bad_raster or bad_light or bad_step or bad_float or bad_gbuffer)
+failed = bool(bad_field or bad_raster or bad_light or bad_step or bad_float or bad_gbuffer or bad_collision)
 print("FUZZ %s" % ("FAILED" if failed else "PASSED"))
 sys.exit(1 if failed else 0)
