@@ -2044,6 +2044,10 @@ namespace {
 // XCD, walked top to bottom, 0.70 | 8.72 (cfg5's 40 columns divide by 8, cfg3's 20 do not); the eight groups in flight as a 4 x 2 block
 // of groups 0.618 | 9.00 against 0.611 | 8.74 beside it; groups dealt out heaviest first (one-workgroup cost + bitonic sort) 0.618 | 8.96
 // against 0.613 | 8.73; single tiles sorted heaviest first 0.70 | 9.96.  Every form of "balance first" lost to "neighbours together".
+// On the eight-wave build the XCDs of a cfg3 frame end 12 % apart (tools/light_trace_probe.py), so the groups were also handed out
+// dynamically -- a workgroup draws a ticket on the XCD it runs on (XCC_ID), every run of M * M tickets opens the next group off a global
+// counter, idle XCDs complete the others' last runs; exact for any dispatch order, 88 light tests green -- 0.601 | 8.56 against
+// 0.600 | 8.53: nothing, and taken out again.
 // Default: 4 with M = 6.
 int light_tile_map() {
     static int v = -1;
