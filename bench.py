@@ -769,12 +769,21 @@ def main():
                 r.RenderLighting(1.0, 0, -1, False)
             pl_ms = ctx.TimerStop() / frames
             alg = int(stats[0]) * SDF_SAMPLE_BYTES + 1920 * 1080 * 16 + 4096 * (32 + 128)
+            # vector-instruction issue of the wide-binning instantiation of the light kernel in the committed PMC profile of this bench
+            plv = profiled_per_wave("ilm::sphere_lights_kernel<0, false, true>", "SQ_INSTS_VALU")
+            # waves of the launch: whole groups of 6 x 6 tiles (lighting.hip tile_map 4), four waves per tile -- what SQ_WAVES counted
+            pl_groups = ((120 + 5) // 6) * ((68 + 5) // 6)
+            pl_waves = ((pl_groups + 7) // 8) * 8 * 36 * 4
+            pl_issue = (pl_waves * plv["value"] / (pl_ms * 1e-3) / 1e9) if plv else None
             next_rows["particle_lights_1080p_4096"] = {
                 "ms_per_frame": round(pl_ms, 4), "lit_mpixels_per_s": round(1920 * 1080 / (pl_ms * 1e-3) / 1e6, 1), "lights": 4096,
                 "sdf_samples_per_frame": int(stats[0]), "pixel_light_pairs": int(stats[1]),
-                "roofline": {"bound": "valu", "achieved": None, "peak": round(VALU_ISSUE_PEAK, 1), "unit": "G wave-instr/s", "frac": None, "traffic": None,
-                             "kernel": "ilm::sphere_lights_kernel (accumulate, device-side light count) + particle_light_count/emit",
-                             "note": "same kernel as the sphere-light rows (VALU-issue-bound, cache-resident atlas); no PMC profile of this scene is committed",
+                "roofline": {"bound": "valu", "achieved": round(pl_issue, 1) if pl_issue else None, "peak": round(VALU_ISSUE_PEAK, 1), "unit": "G wave-instr/s",
+                             "frac": round(pl_issue / VALU_ISSUE_PEAK, 4) if pl_issue else None, "traffic": None,
+                             "calibrated_peak": VALU_ISSUE_CALIBRATED, "calibrated_frac": round(pl_issue / VALU_ISSUE_CALIBRATED, 4) if pl_issue else None,
+                             "kernel": "ilm::sphere_lights_kernel<unorm16, wide tile lists> (accumulate, device-side light count) + particle_light_count/emit",
+                             "valu_instructions_per_wave": round(plv["value"], 1) if plv else None,
+                             "counter": ("profiles/%s: SQ_INSTS_VALU / SQ_WAVES (the launch also contains the exit-only workgroups of partial tile groups)" % plv["source"]) if plv else None,
                              "launch_ms": round(pl_ms, 4)},
                 "algorithmic_rate": {"value": round(alg / (pl_ms * 1e-3) / 1e9, 1), "unit": "GB/s", "bytes_per_unit": SDF_SAMPLE_BYTES,
                                      "units_per_launch": int(stats[0])}}
