@@ -1,5 +1,5 @@
 """Quick on-GPU timing probe of the two hot kernels (development aid, not the contract bench)."""
-import sys, os, time
+import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from illuminant_amd import abi, native, scenes
@@ -30,6 +30,8 @@ def particles(ctx, cs=256, n_chunks=16, steps=50, spawn=True, ops="gn", update=T
             d.Ops[k].u.FMA = scenes.fma_params(scenes.area_none(), velocity_multiply=(0.99, 0.99, 1.0))
         k += 1
     d.OpCount = k
+    if os.environ.get("ILM_PROBE_COUNT"):        # what ParticleSystem.Update asks for every frame: the live count of every chunk
+        d.Flags = abi.STEP_COUNT_LIVE
     import ctypes
     descs = []
     first = 0
