@@ -362,6 +362,35 @@ int32_t upload_small(Ctx* c, void* dst, const void* src, size_t bytes) {
     return ILM_OK;
 }
 
+// The same ring, read in place: `src` is copied into a pinned slot and the slot's device-visible address is returned; the caller queues the
+// kernel that reads it on the context stream and then calls staged_small_done.  One device operation (and one dependent-launch gap)
+// less than upload_small + kernel: the lights of a frame are read once, by the one kernel that digests them.
+int32_t stage_small(Ctx* c, const void* src, size_t bytes, const void** device_visible, int* slot_out) {
+    const int slot = c->ring_pos;
+    c->ring_pos = (c->ring_pos + 1) % Ctx::kRing;
+    if (c->pinned_ev[slot] == nullptr)
+        HIP_TRY(hipEventCreateWithFlags(&c->pinned_ev[slot], hipEventDisableTiming));
+    else
+        HIP_TRY(hipEventSynchronize(c->pinned_ev[slot]));
+    if (c->pinned_bytes[slot] < bytes) {
+        if (c->pinned[slot]) HIP_TRY(hipHostFree(c->pinned[slot]));
+        c->pinned[slot] = nullptr; c->pinned_bytes[slot] = 0;
+        size_t cap = bytes < 65536 ? 65536 : bytes;
+        HIP_TRY(hipHostMalloc(&c->pinned[slot], cap, hipHostMallocDefault));
+        c->pinned_bytes[slot] = cap;
+    }
+    memcpy(c->pinned[slot], src, bytes);
+    void* dev = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dev, c->pinned[slot], 0));
+    *device_visible = dev;
+    *slot_out = slot;
+    return ILM_OK;
+}
+int32_t staged_small_done(Ctx* c, int slot) {
+    HIP_TRY(hipEventRecord(c->pinned_ev[slot], c->main()));
+    return ILM_OK;
+}
+
 int32_t refresh_table(System* s) {
     Ctx* c = s->engine->ctx;
     const int n = (int)s->chunks.size();
@@ -2551,9 +2580,21 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
         c->light_cap = cap;
     }
     if (light_count > 0) {
-        int32_t rc = upload_small(c, c->d_lights, lights, sizeof(IlmLightVertex) * (size_t)light_count);
-        if (rc != ILM_OK) return rc;
-        HIP_TRY(launch_prepare_lights(c->d_lights, light_count, *env, *df, trace_view, c->d_recs, c->main()));
+        static int in_place = -1;
+        if (in_place < 0) { const char* e = getenv("ILM_LIGHTS_IN_PLACE"); in_place = e ? atoi(e) : 1; }
+        if (in_place) {
+            // the vertices are read where the host left them (pinned ring): prepare_lights_kernel is their only reader
+            const void* staged = nullptr; int slot = 0;
+            int32_t rc = stage_small(c, lights, sizeof(IlmLightVertex) * (size_t)light_count, &staged, &slot);
+            if (rc != ILM_OK) return rc;
+            HIP_TRY(launch_prepare_lights(static_cast<const IlmLightVertex*>(staged), light_count, *env, *df, trace_view, c->d_recs, c->main()));
+            rc = staged_small_done(c, slot);
+            if (rc != ILM_OK) return rc;
+        } else {
+            int32_t rc = upload_small(c, c->d_lights, lights, sizeof(IlmLightVertex) * (size_t)light_count);
+            if (rc != ILM_OK) return rc;
+            HIP_TRY(launch_prepare_lights(c->d_lights, light_count, *env, *df, trace_view, c->d_recs, c->main()));
+        }
     }
 
     LightLaunch a;
