@@ -89,6 +89,9 @@ struct Ctx {
     void* pinned[kRing] = {}; size_t pinned_bytes[kRing] = {}; hipEvent_t pinned_ev[kRing] = {}; int ring_pos = 0;
     IlmLightVertex* d_lights = nullptr; void* d_recs = nullptr; int light_cap = 0;
     unsigned long long* d_stats = nullptr;
+    // light split (plan_light_split): the tiles' per-part sums and their tickets
+    float4* d_light_partials = nullptr; size_t light_partials_tiles = 0; uint32_t* d_light_tickets = nullptr; size_t light_tickets_cap = 0;
+    int light_split = 0;                  // ilm_ctx_set_light_split: 0 = chosen per launch, else 1 / 2 / 4 / 8
     // particle lights: records compacted on the device + their count, block counts, per-chunk quad counts
     void* d_pl_recs = nullptr; int pl_cap = 0; int32_t* d_pl_count = nullptr; int32_t* d_pl_blocks = nullptr; int pl_blocks_cap = 0;
     int32_t* d_pl_quads = nullptr; int pl_quads_cap = 0;
@@ -981,6 +984,8 @@ int32_t ilm_ctx_destroy(IlmHandle h) {
     if (c->d_lights) (void)hipFree(c->d_lights);
     if (c->d_recs) (void)hipFree(c->d_recs);
     if (c->d_stats) (void)hipFree(c->d_stats);
+    if (c->d_light_partials) (void)hipFree(c->d_light_partials);
+    if (c->d_light_tickets) (void)hipFree(c->d_light_tickets);
     if (c->d_field_params) (void)hipFree(c->d_field_params);
     if (c->d_pl_recs) (void)hipFree(c->d_pl_recs);
     if (c->d_pl_count) (void)hipFree(c->d_pl_count);
@@ -2088,6 +2093,59 @@ int light_tile_macro() {
     if (v < 0) { const char* e = getenv("ILM_LIGHT_TILE_MACRO"); v = e ? atoi(e) : 6; if (v < 1) v = 1; }
     return v;
 }
+// Light split: how many workgroups serve one tile of this launch (LightLaunch::split, lighting.hip).
+// A wave of the light pass lives as long as its pixels' lights take, one after the other (~0.5 ms on cfg5, ~0.15 on cfg3), and the chip
+// holds 8 192 of them: a launch of only a generation or two -- one rank's strip of a frame split over 8 GPUs is 16 320 waves on cfg5, 4 080
+// on cfg3 -- takes two wave lifetimes whatever its share of the work (r03: the eight strips of cfg5 summed to 11.9 ms for an 8.55 ms
+// frame).  With K workgroups per tile the same work is K times as many waves of 1/K the life; the result's bits do not depend on K
+// (kLightParts).  What a member costs on top (r04, tools/light_overhead_probe.py, tools/pmc_dispatches.sh): ~300 vector instructions
+// (+1.5 % of cfg5's at K = 4) but ~8 us of latency before its first pair (kernel arguments, the slice table, two barriers, the records
+// of its lights) and ~10 us for the meeting at the ticket, during which its slot issues nothing: whole frames lose (cfg5 8.8 -> 9.3 ms
+// at K = 2, 10.6 at 4), short launches gain up to K = 2 (cfg5's strips 1.65 -> 1.45 ms at most, 12.0 -> 10.8 ms summed) and nothing
+// beyond (K = 4: 1.56 | 11.4).  So: K = 2 for launches of at most ILM_LIGHT_SPLIT_WAVES waves (default 24 576: three device fills),
+// else 1.  ILM_LIGHT_SPLIT = 1 / 2 / 4 / 8 or ilm_ctx_set_light_split force it.
+int light_split_env() {
+    static const int v = [] { const char* e = getenv("ILM_LIGHT_SPLIT"); return e ? atoi(e) : 0; }();
+    return v;
+}
+int light_split_target_waves() {
+    static const int v = [] { const char* e = getenv("ILM_LIGHT_SPLIT_WAVES"); return e ? atoi(e) : 24576; }();
+    return v;
+}
+int32_t plan_light_split(Ctx* c, LightLaunch* a) {
+    a->split = 1; a->partials = nullptr; a->tickets = nullptr;
+    const int rows = a->row_end - a->row_begin;
+    if (rows <= 0 || a->width <= 0) return ILM_OK;
+    const int64_t tiles = (int64_t)((a->width + kLightTile - 1) / kLightTile) * (int64_t)((rows + kLightTile - 1) / kLightTile);
+    int k = c->light_split ? c->light_split : light_split_env();
+    if (k == 0) {
+        const int64_t waves = tiles * (kLightTileThreads / 64);
+        k = (waves <= (int64_t)light_split_target_waves()) ? 2 : 1;
+        if (a->light_count < 16) k = 1;          // a list this short has nothing to split
+    }
+    if (k != 1 && k != 2 && k != 4 && k != 8) k = 1;
+    // one list per tile (<= 1 024 lights; device-side counts are particle lights: thousands), and no per-light fp16 rounding chain
+    if (a->blend_fp16 || a->light_count_ptr != nullptr || a->light_count > 1024 || a->light_count <= 0) k = 1;
+    if (k == 1) return ILM_OK;
+    if ((size_t)tiles > c->light_partials_tiles) {
+        HIP_TRY(hipStreamSynchronize(c->main()));
+        if (c->d_light_partials) HIP_TRY(hipFree(c->d_light_partials));
+        c->d_light_partials = nullptr; c->light_partials_tiles = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_light_partials), (size_t)tiles * (size_t)kLightParts * (size_t)kLightTileThreads * sizeof(float4)));
+        c->light_partials_tiles = (size_t)tiles;
+    }
+    if ((size_t)tiles > c->light_tickets_cap) {
+        HIP_TRY(hipStreamSynchronize(c->main()));
+        if (c->d_light_tickets) HIP_TRY(hipFree(c->d_light_tickets));
+        c->d_light_tickets = nullptr; c->light_tickets_cap = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_light_tickets), (size_t)tiles * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(c->d_light_tickets, 0, (size_t)tiles * sizeof(uint32_t), c->main()));
+        c->light_tickets_cap = (size_t)tiles;
+    }
+    a->split = k; a->partials = c->d_light_partials; a->tickets = c->d_light_tickets;
+    return ILM_OK;
+}
+
 // shared by the three light passes: resource checks + the launch descriptor
 int32_t fill_light_launch(Ctx* c, const IlmEnvironment* env, const IlmDistanceFieldUniforms* df, IlmHandle hgbuffer, IlmHandle hsdf,
                           IlmHandle hlightmap, int32_t row_begin, int32_t row_end, LightLaunch* a) {
@@ -2114,6 +2172,7 @@ int32_t fill_light_launch(Ctx* c, const IlmEnvironment* env, const IlmDistanceFi
     a->blend_fp16 = (c->lightmap_blend == ILM_BLEND_FP16_PER_LIGHT) ? 1 : 0;
     a->tile_map = light_tile_map();
     a->tile_macro = light_tile_macro();
+    a->split = 1; a->partials = nullptr; a->tickets = nullptr;
     return ILM_OK;
 }
 }  // namespace
@@ -2396,6 +2455,15 @@ int32_t ilm_ctx_set_lightmap_blend(IlmHandle hctx, int32_t mode) {
     return ILM_OK;
 }
 
+int32_t ilm_ctx_set_light_split(IlmHandle hctx, int32_t workgroups) {
+    Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);
+    if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
+    if (workgroups != 0 && workgroups != 1 && workgroups != 2 && workgroups != 4 && workgroups != 8)
+        return fail(ILM_ERR_INVALID_ARGUMENT, "light split %d is not 0 (automatic), 1, 2, 4 or 8", workgroups);
+    c->light_split = workgroups;
+    return ILM_OK;
+}
+
 int32_t ilm_ctx_set_light_ramp(IlmHandle hctx, const IlmFloat4* texels, int32_t width, int32_t height) {
     Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);
     if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
@@ -2614,6 +2682,7 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
     a.blend_fp16 = (c->lightmap_blend == ILM_BLEND_FP16_PER_LIGHT) ? 1 : 0;
     a.tile_map = light_tile_map();
     a.tile_macro = light_tile_macro();
+    { const int32_t rc = plan_light_split(c, &a); if (rc != ILM_OK) return rc; }
     if (stats) {
         HIP_TRY(hipMemsetAsync(c->d_stats, 0, 3 * sizeof(unsigned long long), c->main()));
         a.stats = c->d_stats;

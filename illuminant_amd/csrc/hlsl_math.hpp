@@ -354,7 +354,10 @@ ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms&
 // 78 % busy on cfg3, its address path 56 %); the cell array holds them side by side, so an fp16 sample is ONE 16-byte load with the
 // f16 pairs already in place, a unorm16 sample two 8-byte typed loads whose channels arrive decoded (see sdf_unorm_rsrc).
 // ---------------------------------------------------------------------------------------------
-constexpr int kMaxTableSlices = 256;
+#ifndef ILM_MAX_TABLE_SLICES
+#define ILM_MAX_TABLE_SLICES 256
+#endif
+constexpr int kMaxTableSlices = ILM_MAX_TABLE_SLICES;
 struct __attribute__((aligned(16))) SliceEntry {
     float column_index;   // floor(vslice / 3) as float
     float row_index;      // floor(vslice * DistanceFieldPacked1.x): the reference's float form

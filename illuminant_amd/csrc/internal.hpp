@@ -164,7 +164,23 @@ struct LightLaunch {
     int32_t blend_fp16;             // != 0: the reference's HalfVector4 render target -- round through fp16 after every light (ilm_ctx_set_lightmap_blend)
     RampView ramp;
     int32_t tile_macro;             // tile_map 4: edge of the square groups of tiles dealt round-robin to the XCDs
+    // Light split (lighting.hip, "parts"): `split` workgroups serve one tile, each walking kLightParts / split consecutive parts of the
+    // tile's light list; their per-part sums meet in `partials` (float4 per pixel, tile-major, part, thread) and the workgroup that
+    // draws the tile's last ticket adds them up in part order.  split == 1: one workgroup per tile, nothing leaves the registers / LDS.
+    int32_t split;
+    float4* partials;               // device scratch of the context: tile_count * kLightParts * 256 float4 (split > 1)
+    uint32_t* tickets;              // device, one per tile, zero between launches (the last arriver resets its tile's)
 };
+// A tile's light list is summed in kLightParts consecutive parts (entries [p n / 8, (p + 1) n / 8) of a list of n), each part from zero in
+// light order, the parts added onto the clear colour in part order: the sum's bits depend on the tile and its list only, not on how
+// many workgroups computed the parts.
+constexpr int kLightParts = 8;
+// Tile edge of the light pass in pixels: 16 = four waves per workgroup (one 8 x 8 quadrant each), 8 = one wave per workgroup (EXPERIMENT, -DILM_LIGHT_TILE=8)
+#ifndef ILM_LIGHT_TILE
+#define ILM_LIGHT_TILE 16
+#endif
+constexpr int kLightTile = ILM_LIGHT_TILE;
+constexpr int kLightTileThreads = (kLightTile / 8) * (kLightTile / 8) * 64;
 
 constexpr size_t kLightRecBytes = 128;   // sizeof(LightRec) in lighting.hip
 // What the in-volume trace loop asks of a light and the field, decided once per light by the prepare kernels (lighting.hip,

@@ -417,13 +417,9 @@ ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment
     return true;
 }
 
-// Tile edge in pixels: 16 = four waves per workgroup (one 8 x 8 quadrant each), 8 = one wave per workgroup (EXPERIMENT, -DILM_LIGHT_TILE=8)
-#ifndef ILM_LIGHT_TILE
-#define ILM_LIGHT_TILE 16
-#endif
-constexpr int kTile = ILM_LIGHT_TILE;
-constexpr int kLightThreads = (kTile / 8) * (kTile / 8) * 64;
-constexpr int kListCapacity = (kTile == 16) ? 1024 : 512;
+constexpr int kTile = kLightTile;                   // internal.hpp
+constexpr int kLightThreads = kLightTileThreads;
+constexpr int kListCapacity = (kTile == 16) ? 1024 : 256;
 
 // Eight waves per SIMD (64 VGPRs; the fp16 kernel without scratch, the unorm16 one with 8 bytes outside the loop).  History, tools/ab_lib.sh:
 // r02, table-driven sampler: five waves (81 VGPRs, the allocator's own need) cfg5 11.93 ms, six 11.26, seven 10.89, eight (48 bytes of
@@ -433,8 +429,11 @@ constexpr int kListCapacity = (kTile == 16) ? 1024 : 512;
 #ifndef ILM_LIGHT_WAVES
 #define ILM_LIGHT_WAVES 8
 #endif
+#ifndef ILM_LIGHT_SGPRS
+#define ILM_LIGHT_SGPRS
+#endif
 #if ILM_LIGHT_WAVES > 0
-#define ILM_LIGHT_OCCUPANCY __attribute__((amdgpu_waves_per_eu(ILM_LIGHT_WAVES, ILM_LIGHT_WAVES)))
+#define ILM_LIGHT_OCCUPANCY __attribute__((amdgpu_waves_per_eu(ILM_LIGHT_WAVES, ILM_LIGHT_WAVES))) ILM_LIGHT_SGPRS
 #else
 #define ILM_LIGHT_OCCUPANCY
 #endif
@@ -453,15 +452,32 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
     __shared__ int list_count;
     __shared__ int bin_count[2][kLightThreads / 64];
     __shared__ SliceEntry slice_table[kMaxTableSlices];
+    __shared__ float4 tree[3][kLightThreads];       // the part sums waiting for their right-hand neighbours (levels 0-2 of the tree over 8 parts)
+    __shared__ int last_member;
 
     // The dispatcher places block b on XCD b % 8.  Which tiles an XCD gets decides both its L2 locality and its share of the work
     // (lights are not spread evenly): see light_tile_map() in api.hip for the measurements; groups of 6 x 6 tiles (tile_map 4) are the default.
 #ifdef ILM_LIGHT_TRACE
     const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    const int nb = (int)gridDim.x;
+    // Light split: a.split consecutive blocks of an XCD serve one tile (they share its L2: cells, light records, the tile's partial sums);
+    // b is the tile's block number as the maps below see it, `member` which of the tile's workgroups this is.
+    // (the launch descriptor through a pointer the compiler cannot see through -- see the light loop: what is read here is not kept
+    // in scalar registers across the kernel)
+    typedef const LightLaunch __attribute__((address_space(4))) CLightLaunch;
+    auto kernargs = []() -> const LightLaunch& {
+        CLightLaunch* ap = (CLightLaunch*)__builtin_amdgcn_kernarg_segment_ptr();      // the descriptor is the kernel's FIRST parameter: offset 0
+        asm volatile("" : "+s"(ap));
+        return *(const LightLaunch*)ap;
+    };
+    int member, nb, b;
+    {
+        const int split = a.split;
+        member = ((int)blockIdx.x / 8) % split;
+        nb = (int)gridDim.x / split;
+        b = (((int)blockIdx.x / 8) / split) * 8 + ((int)blockIdx.x % 8);
+    }
     const int per_xcd = nb / 8;
-    const int b = (int)blockIdx.x;
     int tile;
     if (a.tile_map == 1) {
         // tile rows dealt round-robin to the XCDs: row r -> XCD r % 8 (balances a frame whose lights cluster vertically)
@@ -502,36 +518,76 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
     const float cxp = (float)px + 0.5f, cyp = (float)py + 0.5f;
     const bool have_sdf = (a.sdf.texels != nullptr) && (a.df.Extent.x > 0.0f);
 
-    float acc_r = a.ambient[0], acc_g = a.ambient[1], acc_b = a.ambient[2], acc_a = a.ambient[3];
-    if (a.accumulate != 0 && in_image) {
-        // additive blend onto an earlier pass of the same frame (another light-type render state, LightingRenderer.cs:1100-1169)
-        const size_t o = (size_t)py * (size_t)a.width + (size_t)px;
-        if (a.format == ILM_LIGHTMAP_FLOAT4) {
-            const float4 v = reinterpret_cast<const float4*>(a.lightmap)[o];
-            acc_r = v.x; acc_g = v.y; acc_b = v.z; acc_a = v.w;
-        } else if (a.format == ILM_LIGHTMAP_HALF4) {
-            const uint2 v = reinterpret_cast<const uint2*>(a.lightmap)[o];
-            acc_r = __half2float(__ushort_as_half((unsigned short)(v.x & 0xFFFFu))); acc_g = __half2float(__ushort_as_half((unsigned short)(v.x >> 16)));
-            acc_b = __half2float(__ushort_as_half((unsigned short)(v.y & 0xFFFFu))); acc_a = __half2float(__ushort_as_half((unsigned short)(v.y >> 16)));
-        } else {
-            const uint32_t v = reinterpret_cast<const uint32_t*>(a.lightmap)[o];
-            acc_r = (float)(v & 0xFFu) / 255.0f; acc_g = (float)((v >> 8) & 0xFFu) / 255.0f;
-            acc_b = (float)((v >> 16) & 0xFFu) / 255.0f; acc_a = (float)(v >> 24) / 255.0f;
-        }
-    }
+    // What the lights are added to: the clear colour, or the lightmap's contents (additive blend onto an earlier pass of the same frame:
+    // another light-type render state, LightingRenderer.cs:1100-1169).  Read when it is needed -- at the end, where the tile's sum is
+    // added to it; in the fp16-per-light model at the start, where the chain of roundings begins.
     // The reference's lightmap is a HalfVector4 surface blended into by the ROP light after light (LightingRenderer.cs:476-479): in that
     // model the clear colour and every partial sum pass through fp16.  Off by default (fp32 accumulation, one rounding at the store).
-    const bool blend_fp16 = a.blend_fp16 != 0;
     auto through_half = [](float v) { return __half2float(__float2half_rn(v)); };
-    if (blend_fp16) { acc_r = through_half(acc_r); acc_g = through_half(acc_g); acc_b = through_half(acc_b); acc_a = through_half(acc_a); }
+    auto base_value = [&](const LightLaunch& A) -> float4 {
+        float4 v = mk4(A.ambient[0], A.ambient[1], A.ambient[2], A.ambient[3]);
+        if (A.accumulate != 0 && in_image) {
+            const size_t o = (size_t)py * (size_t)A.width + (size_t)px;
+            if (A.format == ILM_LIGHTMAP_FLOAT4) {
+                v = reinterpret_cast<const float4*>(A.lightmap)[o];
+            } else if (A.format == ILM_LIGHTMAP_HALF4) {
+                const uint2 h = reinterpret_cast<const uint2*>(A.lightmap)[o];
+                v = mk4(__half2float(__ushort_as_half((unsigned short)(h.x & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(h.x >> 16))),
+                        __half2float(__ushort_as_half((unsigned short)(h.y & 0xFFFFu))), __half2float(__ushort_as_half((unsigned short)(h.y >> 16))));
+            } else {
+                const uint32_t c = reinterpret_cast<const uint32_t*>(A.lightmap)[o];
+                v = mk4((float)(c & 0xFFu) / 255.0f, (float)((c >> 8) & 0xFFu) / 255.0f, (float)((c >> 16) & 0xFFu) / 255.0f, (float)(c >> 24) / 255.0f);
+            }
+        }
+        if (A.blend_fp16 != 0) v = mk4(through_half(v.x), through_half(v.y), through_half(v.z), through_half(v.w));
+        return v;
+    };
+    const bool blend_fp16 = a.blend_fp16 != 0;
+    // the running sum of the current part of the light list (the whole chain in the fp16-per-light model)
+    float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f, acc_a = 0.0f;
+    if (blend_fp16) { const float4 v = base_value(a); acc_r = v.x; acc_g = v.y; acc_b = v.z; acc_a = v.w; }
     // wave-uniform: every pixel of this wave has a flat normal (no G-buffer, or ground / top-face texels): the normal factor needs one
     // component of the light direction instead of three (sphere_light_opacity<.., FLAT>)
     const bool flat_normals = __builtin_amdgcn_ballot_w64((P.normal.x != 0.0f) | (P.normal.y != 0.0f)) == 0ull;
     LightStats st;
     const int light_count = (a.light_count_ptr != nullptr) ? __builtin_amdgcn_readfirstlane(*a.light_count_ptr) : a.light_count;
 
-    for (int batch = 0; batch < light_count; batch += kListCapacity) {
-        const int batch_n = min(kListCapacity, light_count - batch);
+    // ---- the order of the sum -------------------------------------------------------------------------------------------------------
+    // The reference adds the lights of a pixel in draw order through the ROP (LightingRenderer.cs:1149-1166 cuts the list into draws of
+    // 128 instances; SphereLight.fx:42-45 is what each adds).  Here the launch's light list is cut, BY LIGHT INDEX, into kLightParts parts
+    // (part p = lights [L p / 8, L (p + 1) / 8)); a pixel's contributions are summed part by part in light order, each part from zero,
+    // the part sums are combined as a balanced binary tree ((q0 + q1) + (q2 + q3)) + ((q4 + q5) + (q6 + q7)), and the tree's root is
+    // added to the base value.  That order depends on the light list and the pixel alone -- not on the tile grid (strips may start on
+    // any row), nor on how many workgroups serve a tile: with `split` = K of them, member m bins and walks the lights of its 8 / K parts
+    // only, its subtree's sum goes to memory, and the member that arrives last adds the K subtree sums (the tree's upper levels).
+    // (The fp16-per-light model is one chain of roundings in light order: no parts, split 1.)
+    int part, part_end;
+    {
+        const int parts_each = kLightParts / kernargs().split;        // split divides kLightParts
+        part = member * parts_each; part_end = part + parts_each;
+    }
+    const int light_lo = blend_fp16 ? 0 : (int)(((long long)light_count * part) / kLightParts);
+    const int light_hi = blend_fp16 ? light_count : (int)(((long long)light_count * part_end) / kLightParts);
+    const int part_first = part;
+    // closes the current part: its sum joins the tree (a sum whose index in the member's range is odd has its left-hand neighbour waiting
+    // one level down: left + right, then one level up), and the registers start the next part from zero
+    auto close_part = [&]() {
+        int r = part - part_first, level = 0;
+        while (r & 1) {
+            const float4 left = tree[level][threadIdx.x];
+            acc_r = left.x + acc_r; acc_g = left.y + acc_g; acc_b = left.z + acc_b; acc_a = left.w + acc_a;
+            level++; r >>= 1;
+        }
+        part++;
+        if (part < part_end) {
+            tree[level][threadIdx.x] = mk4(acc_r, acc_g, acc_b, acc_a);
+            acc_r = 0.0f; acc_g = 0.0f; acc_b = 0.0f; acc_a = 0.0f;
+        }       // else: the member's subtree is summed, its root stays in the registers
+    };
+    int part_bound = blend_fp16 ? 0x7FFFFFFF : (int)(((long long)light_count * (part + 1)) / kLightParts);   // first light of the next part
+
+    for (int batch = light_lo; batch < light_hi; batch += kListCapacity) {
+        const int batch_n = min(kListCapacity, light_hi - batch);
         if constexpr (WIDE_BIN) {
         __syncthreads();                                        // the previous batch's list has been walked
         {
@@ -596,6 +652,7 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
         }
         __syncthreads();
         }
+
         const int n = list_count;
 
         for (int k = 0; k < n; k++) {
@@ -604,15 +661,16 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
             // the whole kernel: 32-42 scalar registers were spilled to vector lanes that way, now 2 -- by itself worth nothing (cfg5
             // 8.82 -> 8.93 ms), but the vector registers it frees are what lets EIGHT waves per SIMD run without spilling in the loop.
             // (the descriptor is the kernel's FIRST parameter: offset 0 of the segment)
-            typedef const LightLaunch __attribute__((address_space(4))) CLightLaunch;
-            CLightLaunch* ap = (CLightLaunch*)__builtin_amdgcn_kernarg_segment_ptr();
-            asm volatile("" : "+s"(ap));
-            const LightLaunch& A = *(const LightLaunch*)ap;
+            const LightLaunch& A = kernargs();
             const TraceField field = { A.df, A.sdf, inside, (table_n > 0) ? slice_table : nullptr };
             const IlmEnvironment& env_k = A.env;
             const RampView& ramp_k = A.ramp;
             const int entry = __builtin_amdgcn_readfirstlane((int)list[k]);
             const int li = entry & 0x7FFF;
+            while (batch + li >= part_bound) {      // (never in the fp16-per-light model)
+                close_part();
+                part_bound = (int)(((long long)light_count * (part + 1)) / kLightParts);
+            }
             const LightRec& L = recs[batch + li];
 
             bool covered = in_image;
@@ -644,6 +702,57 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
             }
         }
     }
+    if (!blend_fp16) {
+        while (part < part_end) close_part();       // the parts behind the last listed light (empty ones add their zeros: the same additions whatever the split)
+    }
+
+    const int split = kernargs().split;
+    if (split > 1) {
+        // The tile's workgroups meet at its ticket.  Every member writes its subtree's sum and waits until the write is acknowledged
+        // (device-scope stores, sc1: written through this XCD's L2; s_waitcnt in every wave, then the barrier), thread 0 then draws
+        // the ticket (device-scope atomic); the member that draws the last one reads the sums back with device-scope loads -- no
+        // cache write-back or invalidate is involved, the light pass's L2 contents (the field's cells) stay where they are.
+#ifdef ILM_SPLIT_NO_COMBINE      // EXPERIMENT (timing only, wrong pixels): what the members cost without their meeting
+        goto tile_done;
+#endif
+        float* mine = reinterpret_cast<float*>(kernargs().partials + ((size_t)tile * (size_t)kLightParts + (size_t)member) * (size_t)kLightThreads + threadIdx.x);
+        __hip_atomic_store(mine + 0, acc_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 1, acc_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 2, acc_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(mine + 3, acc_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t* ticket = kernargs().tickets + tile;
+#ifdef ILM_SPLIT_FORMAL          // EXPERIMENT: the release / acquire the language asks for -- an L2 write-back and an L2 invalidate per workgroup
+            const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+#else
+            const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+            last_member = (t == (uint32_t)(split - 1)) ? 1 : 0;
+            if (t == (uint32_t)(split - 1)) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+        __syncthreads();
+        if (last_member == 0)
+            goto tile_done;
+        asm volatile("" ::: "memory");
+        const float* all = reinterpret_cast<const float*>(kernargs().partials + (size_t)tile * (size_t)kLightParts * (size_t)kLightThreads + threadIdx.x);
+        // the upper levels of the tree over the members' sums: ((m0 + m1) + (m2 + m3)) + ((m4 + m5) + (m6 + m7)), left operand first as in close_part
+        auto member_sum = [&](int m) -> float4 {
+            const float* q = all + (size_t)m * (size_t)kLightThreads * 4;
+            return mk4(__hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
+                       __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        };
+        auto add4 = [](const float4& l, const float4& r) { return mk4(l.x + r.x, l.y + r.y, l.z + r.z, l.w + r.w); };
+        float4 v = add4(member_sum(0), member_sum(1));
+        if (split >= 4) v = add4(v, add4(member_sum(2), member_sum(3)));
+        if (split == 8) v = add4(v, add4(add4(member_sum(4), member_sum(5)), add4(member_sum(6), member_sum(7))));
+        acc_r = v.x; acc_g = v.y; acc_b = v.z; acc_a = v.w;
+    }
+    if (!blend_fp16) {
+        const float4 v = base_value(kernargs());
+        acc_r = v.x + acc_r; acc_g = v.y + acc_g; acc_b = v.z + acc_b; acc_a = v.w + acc_a;
+    }
 
     if (in_image) {
         const size_t o = (size_t)py * (size_t)a.width + (size_t)px;
@@ -661,6 +770,7 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
         }
     }
 
+tile_done:
 #ifdef ILM_LIGHT_TRACE
     if (lane == 0) {
         const unsigned w = ((unsigned)blockIdx.x * (unsigned)(kLightThreads / 64) + (unsigned)wave) & 262143u;
@@ -972,7 +1082,7 @@ hipError_t launch_sphere_lights_prepared(const LightLaunch& a, const void* recs,
     const LightRec* r = reinterpret_cast<const LightRec*>(recs);
     const bool stats = a.stats != nullptr;
     const bool fp16 = a.sdf.format == ILM_SDF_FP16;
-    const dim3 grid(blocks), block(kLightThreads);
+    const dim3 grid(blocks * a.split), block(kLightThreads);
 #define ILM_LAUNCH_LIGHTS(F, S, W) hipLaunchKernelGGL((sphere_lights_kernel<F, S, W>), grid, block, 0, stream, a, r, tiles_x, tiles_y, tile_count)
     // device-side counts are particle lights: thousands
     const bool wide = (a.light_count_ptr != nullptr) || (a.light_count > 512);

@@ -101,6 +101,7 @@ SYMBOLS = {
     "ilm_lightmap_clear": (_I, [_H, _P]),
     "ilm_ctx_set_light_ramp": (_I, [_H, _P, _I, _I]),
     "ilm_ctx_set_lightmap_blend": (_I, [_H, _I]),
+    "ilm_ctx_set_light_split": (_I, [_H, _I]),
     "ilm_system_set_bitmap": (_I, [_H, _P, _I, _I]),
     "ilm_resolve_lighting": (_I, [_H, _H, _P, _I, _I]),
     "ilm_resolve_lighting_with_albedo": (_I, [_H, _H, _H, _P, _I, _I]),
@@ -201,6 +202,10 @@ class Context:
     def set_lightmap_blend(self, fp16_per_light):
         """ilm_ctx_set_lightmap_blend: True = the reference's HalfVector4 render target (rounded through fp16 after every light)."""
         check(lib().ilm_ctx_set_lightmap_blend(self.handle, 1 if fp16_per_light else 0))
+
+    def set_light_split(self, workgroups):
+        """ilm_ctx_set_light_split: workgroups per tile of the sphere-light launches (0 = chosen per launch, 1 / 2 / 4 / 8)."""
+        check(lib().ilm_ctx_set_light_split(self.handle, int(workgroups)))
 
     def debug_divide(self, numerators, denominators):
         """ilm_debug_divide: (the cone trace's unscaled division, the IEEE division) of the operand pairs, both evaluated on the device."""

@@ -714,6 +714,16 @@ int32_t ilm_ctx_set_light_ramp(IlmHandle ctx, const IlmFloat4* texels, int32_t w
 #define ILM_BLEND_FP16_PER_LIGHT 1
 int32_t ilm_ctx_set_lightmap_blend(IlmHandle ctx, int32_t mode);
 
+/* How many workgroups serve one 16 x 16 tile of this context's sphere-light launches ("light split").  The reference cuts a frame's
+ * light list into draws of 128 instances and the ROP adds them (Illuminant/Lighting/LightingRenderer.cs:1149-1166,
+ * Illuminant/Shaders/SphereLight.fx:42-45): the sum does not care who shaded which light.  Here a tile's list is summed in 8 fixed
+ * parts -- each part in light order, the parts onto the clear colour in part order -- and `workgroups` = 1, 2, 4 or 8 says how many
+ * workgroups share those parts; the lightmap's bits do not depend on it.  0 (default) = chosen per launch: 1 for launches that fill the
+ * device several times over (whole frames), more for short ones (one rank's strip of a frame split over 8 GPUs), where a launch would
+ * otherwise last two wave lifetimes whatever its share of the work.  Launches in the ILM_BLEND_FP16_PER_LIGHT model, of more than 1 024
+ * lights, or of particle lights always use 1. */
+int32_t ilm_ctx_set_light_split(IlmHandle ctx, int32_t workgroups);
+
 /* ---- particle lights and light probes --------------------------------------------------------- */
 
 /* What _ParticleLightBatchSetup binds for a ParticleLightSource (Illuminant/Lighting/LightingRenderer.cs:769-790,

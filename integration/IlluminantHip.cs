@@ -519,6 +519,7 @@ namespace Squared.Illuminant.Native {
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_render_sphere_lights (ulong ctx, LightVertex* lights, int lightCount, IlmEnvironment* env, IlmDistanceFieldUniforms* df, ulong gbuffer, ulong sdf, float* ambient, ulong lightmap, int rowBegin, int rowEnd, IlmRenderStats* stats);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_ctx_set_light_ramp (ulong ctx, Vector4* texels, int width, int height);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_ctx_set_lightmap_blend (ulong ctx, int mode);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_ctx_set_light_split (ulong ctx, int workgroups);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_render_particle_lights (ulong ctx, ulong system, int* quadCounts, int chunkCount, IlmParticleLightParams* @params, IlmEnvironment* env, IlmDistanceFieldUniforms* df, ulong gbuffer, ulong sdf, ulong lightmap, int rowBegin, int rowEnd, IlmRenderStats* stats);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_render_light_probes (ulong ctx, LightVertex* lights, int lightCount, Vector4* probePositions, Vector4* probeNormals, int probeCount, IlmEnvironment* env, IlmDistanceFieldUniforms* df, ulong sdf, Vector4* outValues);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_system_readback (ulong system, int* elementCounts, int chunkCount, IlmReadbackParams* @params, IlmReadbackDrawCall* @out, int capacity, int* outCount);

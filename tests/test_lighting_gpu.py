@@ -241,3 +241,57 @@ def test_every_pixel_of_any_frame_size_is_rendered_once(ctx, oracle, width, heig
     assert_close(got[row_begin:row_end], want[row_begin:row_end], "lightmap %dx%d rows %d..%d" % (width, height, row_begin, row_end))
     assert np.all(got[:row_begin] == -7.0) and np.all(got[row_end:] == -7.0), "rows outside the strip were written"
     lm.close()
+
+
+@pytest.mark.parametrize("sfmt", [abi.SDF_UNORM16, abi.SDF_FP16])
+def test_light_split_keeps_every_bit(ctx, oracle, sfmt):
+    """ilm_ctx_set_light_split: K workgroups per tile share the 8 parts of the light list; the lightmap's bits depend on the light list and
+    the pixel alone -- not on K, not on where a strip starts (tiles are anchored at row_begin), not on the lightmap's format rounding
+    order -- and the SDF-sample / pair / trace counts stay the oracle's.  Also a second light group added onto the first (ambient NULL:
+    the base value is the lightmap's contents) and a list shorter than the parts."""
+    layout, atlas, dfu, lights, w, h = small_scene(sfmt, n_lights=37, width=203, height=150)
+    env = scenes.environment()
+    ambient = (0.05, 0.06, 0.07, 1.0)
+    sdf = native.DistanceFieldTexture(ctx, atlas, sfmt)
+    want, ostats = oracle.render_sphere_lights(lights, env, dfu, None, oracle.make_texture(atlas, sfmt), ambient, w, h, want_stats=True)
+    few = (abi.LightVertex * 3)(*[lights[i] for i in (5, 6, 7)])
+
+    def frame(split, strips, fmt=abi.LIGHTMAP_FLOAT4, second_group=False):
+        ctx.set_light_split(split)
+        lm = native.Lightmap(ctx, w, h, fmt)
+        counts = [0, 0, 0]
+        for (b, e) in strips:
+            st = native.render_sphere_lights(ctx, lights, env, dfu, None, sdf, ambient, lm, b, e, want_stats=True)
+            counts = [counts[0] + st.SdfSamples, counts[1] + st.PixelLightPairs, counts[2] + st.TracedPairs]
+            if second_group:
+                native.render_sphere_lights(ctx, few, env, dfu, None, sdf, None, lm, b, e)
+        out = lm.download()
+        lm.close()
+        return out, tuple(counts)
+
+    try:
+        whole, counts = frame(1, [(0, h)])
+        assert counts == (ostats.SdfSamples, ostats.PixelLightPairs, ostats.TracedPairs)
+        assert_close(whole, want, "one workgroup per tile vs the oracle")
+        uneven = [(0, 7), (7, 100), (100, 101), (101, h)]
+        half_whole, _ = frame(1, [(0, h)], abi.LIGHTMAP_HALF4)
+        two_whole, _ = frame(1, [(0, h)], second_group=True)
+        assert not np.array_equal(two_whole, whole)
+        for split in (2, 4, 8, 0):
+            for strips in ([(0, h)], uneven):
+                got, c = frame(split, strips)
+                assert np.array_equal(got, whole), "split %d, strips %s" % (split, strips)
+                assert c == counts
+            assert np.array_equal(frame(split, uneven, abi.LIGHTMAP_HALF4)[0], half_whole)
+            assert np.array_equal(frame(split, uneven, second_group=True)[0], two_whole)
+        # the fp16-per-light model is one chain of roundings: the setting is ignored there
+        ctx.set_lightmap_blend(True)
+        a, _ = frame(1, [(0, h)], abi.LIGHTMAP_HALF4)
+        b, _ = frame(8, uneven, abi.LIGHTMAP_HALF4)
+        assert np.array_equal(a, b)
+    finally:
+        ctx.set_lightmap_blend(False)
+        ctx.set_light_split(0)
+        sdf.close()
+    with pytest.raises(native.IlluminantError):
+        ctx.set_light_split(3)
