@@ -92,6 +92,7 @@ struct Ctx {
     // light split (plan_light_split): the tiles' per-part sums and their tickets
     float4* d_light_partials = nullptr; size_t light_partials_tiles = 0; uint32_t* d_light_tickets = nullptr; size_t light_tickets_cap = 0;
     int light_split = 0;                  // ilm_ctx_set_light_split: 0 = chosen per launch, else 1 / 2 / 4 / 8
+    uint16_t* d_group_order = nullptr; int group_order_cap = 0;
     // particle lights: records compacted on the device + their count, block counts, per-chunk quad counts
     void* d_pl_recs = nullptr; int pl_cap = 0; int32_t* d_pl_count = nullptr; int32_t* d_pl_blocks = nullptr; int pl_blocks_cap = 0;
     int32_t* d_pl_quads = nullptr; int pl_quads_cap = 0;
@@ -986,6 +987,7 @@ int32_t ilm_ctx_destroy(IlmHandle h) {
     if (c->d_stats) (void)hipFree(c->d_stats);
     if (c->d_light_partials) (void)hipFree(c->d_light_partials);
     if (c->d_light_tickets) (void)hipFree(c->d_light_tickets);
+    if (c->d_group_order) (void)hipFree(c->d_group_order);
     if (c->d_field_params) (void)hipFree(c->d_field_params);
     if (c->d_pl_recs) (void)hipFree(c->d_pl_recs);
     if (c->d_pl_count) (void)hipFree(c->d_pl_count);
@@ -2093,17 +2095,21 @@ int light_tile_macro() {
     if (v < 0) { const char* e = getenv("ILM_LIGHT_TILE_MACRO"); v = e ? atoi(e) : 6; if (v < 1) v = 1; }
     return v;
 }
-// Light split: how many workgroups serve one tile of this launch (LightLaunch::split, lighting.hip).
+// Light split: how many workgroups serve a tile of this launch (LightLaunch::split / taper, lighting.hip).
 // A wave of the light pass lives as long as its pixels' lights take, one after the other (~0.5 ms on cfg5, ~0.15 on cfg3), and the chip
 // holds 8 192 of them: a launch of only a generation or two -- one rank's strip of a frame split over 8 GPUs is 16 320 waves on cfg5, 4 080
-// on cfg3 -- takes two wave lifetimes whatever its share of the work (r03: the eight strips of cfg5 summed to 11.9 ms for an 8.55 ms
-// frame).  With K workgroups per tile the same work is K times as many waves of 1/K the life; the result's bits do not depend on K
-// (kLightParts).  What a member costs on top (r04, tools/light_overhead_probe.py, tools/pmc_dispatches.sh): ~300 vector instructions
-// (+1.5 % of cfg5's at K = 4) but ~8 us of latency before its first pair (kernel arguments, the slice table, two barriers, the records
-// of its lights) and ~10 us for the meeting at the ticket, during which its slot issues nothing: whole frames lose (cfg5 8.8 -> 9.3 ms
-// at K = 2, 10.6 at 4), short launches gain up to K = 2 (cfg5's strips 1.65 -> 1.45 ms at most, 12.0 -> 10.8 ms summed) and nothing
-// beyond (K = 4: 1.56 | 11.4).  So: K = 2 for launches of at most ILM_LIGHT_SPLIT_WAVES waves (default 24 576: three device fills),
-// else 1.  ILM_LIGHT_SPLIT = 1 / 2 / 4 / 8 or ilm_ctx_set_light_split force it.
+// on cfg3 -- ends in a drain as long as a wave's life, during which the device empties (r03: the eight strips of cfg5 summed to 11.9 ms
+// for an 8.55 ms frame).  With K workgroups per tile the same work is K times as many waves of 1/K the life, and the result's bits do
+// not depend on K (kLightParts).  What a member costs (r04, tools/light_overhead_probe.py, tools/pmc_dispatches.sh): ~300 vector
+// instructions (+1.5 % of cfg5's at K = 4) -- and a slot that issues nothing while it is launched (the dispatcher starts ~0.5 G waves/s:
+// a frame of lights that touch nothing takes 0.13 ms at K = 1 and 0.5 ms at K = 8 with NO work in it), reads its arguments, bins, and
+// meets the others at the ticket: whole cfg5 frames 8.8 ms at K = 1, 9.1 at 2, 10.6 at 4, 11.5 at 8.  So the split is TAPERED: the
+// tiles an XCD starts first are served whole, later ones by 2, then 4, the last by 8 workgroups -- the drain is made of the shortest
+// waves, the overhead is paid on the part of the launch that needs it.  On cfg5's cost-balanced strips (one GPU standing in for each
+// of 8 ranks, tools/strip_probe.py): at most 1.65 ms and 12.0 ms summed untouched, 1.44 | 10.8 at K = 2 throughout, 1.34 | 10.2 tapered.
+//   chosen per launch: launches of at most one device fill split every tile (2 | 4 | 8 by halves), up to ILM_LIGHT_SPLIT_WAVES waves
+//   (default 24 576, three fills) the second half tapers 2 | 4 | 8, longer ones (whole frames) are not split.
+//   ILM_LIGHT_SPLIT = 1 / 2 / 4 / 8 or ilm_ctx_set_light_split force one K for every tile; ILM_LIGHT_TAPER = f1,f2,f3 forces the taper.
 int light_split_env() {
     static const int v = [] { const char* e = getenv("ILM_LIGHT_SPLIT"); return e ? atoi(e) : 0; }();
     return v;
@@ -2112,21 +2118,50 @@ int light_split_target_waves() {
     static const int v = [] { const char* e = getenv("ILM_LIGHT_SPLIT_WAVES"); return e ? atoi(e) : 24576; }();
     return v;
 }
+// ILM_LIGHT_TAPER = "f1,f2,f3": the fractions of an XCD's tiles from which on a tile is served by 2, 4 and 8 workgroups (1 = never)
+void light_taper_env(double f[3], bool* set) {
+    static double v[3]; static bool have = false;
+    static const bool once = [] {
+        const char* e = getenv("ILM_LIGHT_TAPER");
+        if (e && sscanf(e, "%lf,%lf,%lf", &v[0], &v[1], &v[2]) == 3) have = true;
+        return true;
+    }();
+    (void)once;
+    *set = have; f[0] = v[0]; f[1] = v[1]; f[2] = v[2];
+}
 int32_t plan_light_split(Ctx* c, LightLaunch* a) {
     a->split = 1; a->partials = nullptr; a->tickets = nullptr;
     const int rows = a->row_end - a->row_begin;
     if (rows <= 0 || a->width <= 0) return ILM_OK;
+    const int slots = light_block_slots(*a);
+    a->taper[0] = a->taper[1] = a->taper[2] = slots; a->taper_slots = slots;
     const int64_t tiles = (int64_t)((a->width + kLightTile - 1) / kLightTile) * (int64_t)((rows + kLightTile - 1) / kLightTile);
-    int k = c->light_split ? c->light_split : light_split_env();
-    if (k == 0) {
-        const int64_t waves = tiles * (kLightTileThreads / 64);
-        k = (waves <= (int64_t)light_split_target_waves()) ? 2 : 1;
-        if (a->light_count < 16) k = 1;          // a list this short has nothing to split
-    }
-    if (k != 1 && k != 2 && k != 4 && k != 8) k = 1;
     // one list per tile (<= 1 024 lights; device-side counts are particle lights: thousands), and no per-light fp16 rounding chain
-    if (a->blend_fp16 || a->light_count_ptr != nullptr || a->light_count > 1024 || a->light_count <= 0) k = 1;
+    if (a->blend_fp16 || a->light_count_ptr != nullptr || a->light_count > 1024 || a->light_count < 16) return ILM_OK;
+    int k = c->light_split ? c->light_split : light_split_env();
+    double f[3] = { 1.0, 1.0, 1.0 };
+    bool taper_set = false;
+    light_taper_env(f, &taper_set);
     if (k == 1) return ILM_OK;
+    if (k == 2 || k == 4 || k == 8) {
+        // every tile of the launch by k workgroups
+        f[0] = 0.0; f[1] = (k >= 4) ? 0.0 : 1.0; f[2] = (k == 8) ? 0.0 : 1.0;
+    } else if (!taper_set) {
+        // chosen per launch: short launches end tapered, whole frames are left alone
+        const int64_t waves = tiles * (kLightTileThreads / 64);
+        if (waves > (int64_t)light_split_target_waves()) return ILM_OK;
+        if (waves <= 8192) { f[0] = 0.0; f[1] = 0.5; f[2] = 0.75; }     // everything starts at once: the longest wave is the launch
+        else { f[0] = 0.5; f[1] = 0.75; f[2] = 0.875; }
+    }
+    int t[3];
+    for (int i = 0; i < 3; i++) {
+        double v = f[i] < 0.0 ? 0.0 : (f[i] > 1.0 ? 1.0 : f[i]);
+        t[i] = (int)(v * (double)slots + 0.5);
+        if (i > 0 && t[i] < t[i - 1]) t[i] = t[i - 1];
+    }
+    if (t[0] >= slots) return ILM_OK;
+    a->taper[0] = t[0]; a->taper[1] = t[1]; a->taper[2] = t[2];
+    a->split = (t[2] < slots) ? 8 : (t[1] < slots) ? 4 : 2;
     if ((size_t)tiles > c->light_partials_tiles) {
         HIP_TRY(hipStreamSynchronize(c->main()));
         if (c->d_light_partials) HIP_TRY(hipFree(c->d_light_partials));
@@ -2138,11 +2173,67 @@ int32_t plan_light_split(Ctx* c, LightLaunch* a) {
         HIP_TRY(hipStreamSynchronize(c->main()));
         if (c->d_light_tickets) HIP_TRY(hipFree(c->d_light_tickets));
         c->d_light_tickets = nullptr; c->light_tickets_cap = 0;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_light_tickets), (size_t)tiles * sizeof(uint32_t)));
-        HIP_TRY(hipMemsetAsync(c->d_light_tickets, 0, (size_t)tiles * sizeof(uint32_t), c->main()));
+        // (one ticket per tile and wave: the quadrants of a tile are delivered independently)
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_light_tickets), (size_t)tiles * (kLightTileThreads / 64) * sizeof(uint32_t)));
+        HIP_TRY(hipMemsetAsync(c->d_light_tickets, 0, (size_t)tiles * (kLightTileThreads / 64) * sizeof(uint32_t), c->main()));
         c->light_tickets_cap = (size_t)tiles;
     }
-    a->split = k; a->partials = c->d_light_partials; a->tickets = c->d_light_tickets;
+    a->partials = c->d_light_partials; a->tickets = c->d_light_tickets;
+    return ILM_OK;
+}
+
+// EXPERIMENT (ILM_LIGHT_GROUP_ORDER=1): the groups of tiles dealt out heaviest first -- a short launch's tail is the work that starts last.
+// Cost of a group = summed area of the lights' footprint boxes inside it (host arithmetic on the frame's light vertices).
+int light_group_order_env() {
+    static const int v = [] { const char* e = getenv("ILM_LIGHT_GROUP_ORDER"); return e ? atoi(e) : 0; }();
+    return v;
+}
+int32_t plan_group_order(Ctx* c, LightLaunch* a, const IlmLightVertex* lights, int light_count, int group_edge_px) {
+    a->group_order = nullptr;
+    if (!light_group_order_env() || a->tile_map != 4 || light_count <= 0) return ILM_OK;
+    const int rows = a->row_end - a->row_begin;
+    const int gx = (a->width + group_edge_px - 1) / group_edge_px, gy = (rows + group_edge_px - 1) / group_edge_px;
+    const int groups = gx * gy;
+    if (groups < 2 || groups > 65535) return ILM_OK;
+    std::vector<double> cost((size_t)groups, 0.0);
+    const float sx = a->env.GBufferTexelSizeAndMisc.z * a->env.ZAndScale.z, sy = a->env.GBufferTexelSizeAndMisc.w * a->env.ZAndScale.w;
+    for (int i = 0; i < light_count; i++) {
+        const IlmLightVertex& L = lights[i];
+        const double reach = (double)L.LightProperties.x + (double)L.LightProperties.y + 1.0;
+        const double x0 = ((double)L.LightPosition1.x - reach - a->env.ViewportPosition[0]) * sx, x1 = ((double)L.LightPosition1.x + reach - a->env.ViewportPosition[0]) * sx;
+        const double y0 = ((double)L.LightPosition1.y - reach - a->env.ViewportPosition[1]) * sy - a->row_begin, y1 = ((double)L.LightPosition1.y + reach - a->env.ViewportPosition[1]) * sy - a->row_begin;
+        if (!(x1 > x0) || !(y1 > y0)) continue;
+        const int ga = std::max(0, (int)std::floor(x0 / group_edge_px)), gb = std::min(gx - 1, (int)std::floor(x1 / group_edge_px));
+        const int gc = std::max(0, (int)std::floor(y0 / group_edge_px)), gd = std::min(gy - 1, (int)std::floor(y1 / group_edge_px));
+        for (int yy = gc; yy <= gd; yy++)
+            for (int xx = ga; xx <= gb; xx++) {
+                const double w = std::min(x1, (double)std::min((xx + 1) * group_edge_px, a->width)) - std::max(x0, (double)(xx * group_edge_px));
+                const double h = std::min(y1, (double)std::min((yy + 1) * group_edge_px, rows)) - std::max(y0, (double)(yy * group_edge_px));
+                if (w > 0 && h > 0) cost[(size_t)(yy * gx + xx)] += w * h;
+            }
+    }
+    std::vector<uint16_t> order((size_t)groups);
+    for (int g = 0; g < groups; g++) order[(size_t)g] = (uint16_t)g;
+    std::stable_sort(order.begin(), order.end(), [&](uint16_t l, uint16_t r) { return cost[l] > cost[r]; });
+    // dealt to the XCDs in a snake (0..7, 7..0): position p of the dealing order is read by XCD p % 8 as its (p / 8)-th group
+    std::vector<uint16_t> dealt((size_t)groups);
+    for (int p = 0; p < groups; p++) {
+        const int round = p / 8, slot = p % 8;
+        const int src = round * 8 + ((round & 1) ? 7 - slot : slot);
+        dealt[(size_t)p] = order[(size_t)std::min(src, groups - 1)];
+    }
+    // (the last, partial round of a snake may name a group twice and skip another: repair by a plain copy of that round)
+    { const int tail = (groups / 8) * 8; for (int p = tail; p < groups; p++) dealt[(size_t)p] = order[(size_t)p]; }
+    if (groups > c->group_order_cap) {
+        HIP_TRY(hipStreamSynchronize(c->main()));
+        if (c->d_group_order) HIP_TRY(hipFree(c->d_group_order));
+        c->d_group_order = nullptr; c->group_order_cap = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_group_order), sizeof(uint16_t) * (size_t)groups * 2));
+        c->group_order_cap = groups * 2;
+    }
+    const int32_t rc = upload_small(c, c->d_group_order, dealt.data(), sizeof(uint16_t) * (size_t)groups);
+    if (rc != ILM_OK) return rc;
+    a->group_order = c->d_group_order;
     return ILM_OK;
 }
 
@@ -2172,7 +2263,7 @@ int32_t fill_light_launch(Ctx* c, const IlmEnvironment* env, const IlmDistanceFi
     a->blend_fp16 = (c->lightmap_blend == ILM_BLEND_FP16_PER_LIGHT) ? 1 : 0;
     a->tile_map = light_tile_map();
     a->tile_macro = light_tile_macro();
-    a->split = 1; a->partials = nullptr; a->tickets = nullptr;
+    a->split = 1; a->partials = nullptr; a->tickets = nullptr; a->group_order = nullptr;
     return ILM_OK;
 }
 }  // namespace
@@ -2682,11 +2773,13 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
     a.blend_fp16 = (c->lightmap_blend == ILM_BLEND_FP16_PER_LIGHT) ? 1 : 0;
     a.tile_map = light_tile_map();
     a.tile_macro = light_tile_macro();
-    { const int32_t rc = plan_light_split(c, &a); if (rc != ILM_OK) return rc; }
     if (stats) {
         HIP_TRY(hipMemsetAsync(c->d_stats, 0, 3 * sizeof(unsigned long long), c->main()));
         a.stats = c->d_stats;
     }
+    a.split = 1; a.partials = nullptr; a.tickets = nullptr; a.group_order = nullptr;
+    { const int32_t rc = plan_light_split(c, &a); if (rc != ILM_OK) return rc; }
+    { const int32_t rc = plan_group_order(c, &a, lights, light_count, 16 * a.tile_macro); if (rc != ILM_OK) return rc; }
     HIP_TRY(launch_sphere_lights_prepared(a, c->d_recs, c->main()));
     if (stats) {
         unsigned long long host[3] = { 0, 0, 0 };

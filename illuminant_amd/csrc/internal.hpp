@@ -167,7 +167,12 @@ struct LightLaunch {
     // Light split (lighting.hip, "parts"): `split` workgroups serve one tile, each walking kLightParts / split consecutive parts of the
     // tile's light list; their per-part sums meet in `partials` (float4 per pixel, tile-major, part, thread) and the workgroup that
     // draws the tile's last ticket adds them up in part order.  split == 1: one workgroup per tile, nothing leaves the registers / LDS.
-    int32_t split;
+    const uint16_t* group_order;    // tile_map 4: the groups in the order they are dealt out (heaviest first), or nullptr: row-major
+    int32_t split;                  // the largest number of workgroups per tile in this launch (1: no split anywhere)
+    // Tapered split: of the `taper_slots` tiles an XCD is dealt (block slots, padding included), the first taper[0] are served by one
+    // workgroup each, those up to taper[1] by two, up to taper[2] by four, the rest by eight -- the work that starts last comes in the
+    // smallest pieces (guided self-scheduling, laid out in the grid).  No taper: taper[0..2] = taper_slots.
+    int32_t taper[3], taper_slots;
     float4* partials;               // device scratch of the context: tile_count * kLightParts * 256 float4 (split > 1)
     uint32_t* tickets;              // device, one per tile, zero between launches (the last arriver resets its tile's)
 };
@@ -195,6 +200,8 @@ TraceGate make_trace_gate(const IlmDistanceFieldUniforms& df, const SdfView& sdf
 hipError_t launch_prepare_lights(const IlmLightVertex* lights, int count, const IlmEnvironment& env, const IlmDistanceFieldUniforms& df,
                                  const SdfView& sdf, void* recs, hipStream_t stream);
 hipError_t launch_sphere_lights_prepared(const LightLaunch& a, const void* recs, hipStream_t stream);
+int light_block_slots(const LightLaunch& a);      // block slots per XCD of the tile kernel's launch over a's rows
+
 // Particle lights (ParticleLight.fx): ordered device-side compaction of the live, visible particles of every chunk into light
 // records.  block_counts: one int per 1024-slot block of every chunk (scratch); *out_count receives the record count.
 struct ParticleLightLaunch {

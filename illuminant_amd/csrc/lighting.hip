@@ -95,7 +95,11 @@ ILM_DEV f3 decode_normal(float ex, float ey) {
 }
 
 struct Pixel {
-    f3 shaded, normal, camera;
+    f3 shaded, normal;
+    // the camera position (sampleGBuffer's third output, read by the specular term alone) is a function of the pixel's coordinates:
+    // not kept per lane -- the pixel of lane l is (origin_x + (l & 7), origin_y + (l >> 3)), and shade_light forms it where a light has a
+    // specular colour (the same operations on the same values)
+    int origin_x, origin_y;
     bool enable_shadows, fullbright;
     // light-independent half of the in-volume trace test: the trace start (shaded + normal * SELF_OCCLUSION_HACK) lies in the table
     // sampler's box with the start-side margin (set by trace_start_inside once per pixel)
@@ -150,7 +154,6 @@ ILM_DEV Pixel sample_gbuffer(float spx, float spy, const IlmEnvironment& env, co
         world_z *= ref::kGBufferZScale;
         world_z -= ref::kGBufferZOffset;
         spx /= rsx; spy /= rsy;
-        p.camera = mk3(spx, spy, env.ZAndScale.y + 0.01f);
         p.shaded = mk3((spx + 0.0f) / vsx + env.ViewportPosition[0], (spy + relative_y) / vsy + env.ViewportPosition[1], world_z);
         if ((s.x != 0.0f) || (s.y != 0.0f))
             p.normal = decode_normal(s.x, s.y);
@@ -158,7 +161,6 @@ ILM_DEV Pixel sample_gbuffer(float spx, float spy, const IlmEnvironment& env, co
             p.normal = mk3(0.0f, 0.0f, 0.0f);
     } else {
         spx /= rsx; spy /= rsy;
-        p.camera = mk3(spx, spy, env.ZAndScale.y + 0.01f);
         p.shaded = mk3(spx / vsx + env.ViewportPosition[0], spy / vsy + env.ViewportPosition[1], env.ZAndScale.x);
         p.normal = mk3(0.0f, 0.0f, 1.0f);
     }
@@ -214,6 +216,44 @@ ILM_DEV float sphere_light_opacity(f3 d3, float distance, f3 normal, const Light
 
 struct LightStats { unsigned long long samples = 0, pairs = 0, traced = 0; };
 
+// The partial sums of a light split travel between workgroups (any XCD) as device-scope accesses: `sc1` stores are written through the
+// XCD's L2, `sc1` loads are served past the CU's L1 -- valid without cache write-backs or invalidates when BOTH sides use them
+// (MI355X_MICROARCH.md, "inter-workgroup visibility") -- as ONE 16-byte access per lane (a dword `sc1` store is a fabric write of its
+// own, ~6 x the time per byte).  Written as instructions: the compiler has no 16-byte device-scope access to offer.  The store is not
+// waited for here (the caller's `s_waitcnt vmcnt(0)` before the ticket is); the loads of a tile's sums are issued together and waited for.
+ILM_DEV void store_partial(float4* where, float r, float g, float b, float a) {
+    const f32x4 v = { r, g, b, a };
+    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(where), "v"(v) : "memory");
+}
+// K = 2 or 4 partial sums `stride` float4 apart, all requested before the first is waited for (for callers with registers to spare)
+template <int K>
+ILM_DEV void load_partials(const float4* first, size_t stride, float4 (&out)[K]) {
+    f32x4 v[K];
+    if constexpr (K == 2) {
+        asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]) : "v"(first), "v"(first + stride) : "memory");
+    } else if constexpr (K == 4) {
+        asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\t"
+                     "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                     : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3])
+                     : "v"(first), "v"(first + stride), "v"(first + 2 * stride), "v"(first + 3 * stride) : "memory");
+    }
+#pragma unroll
+    for (int i = 0; i < K; i++) out[i] = mk4(v[i].x, v[i].y, v[i].z, v[i].w);
+}
+// the sums of a tile's K = 2, 4 or 8 members, `stride` float4 apart, combined as the upper levels of the tree over the parts:
+// ((m0 + m1) + (m2 + m3)) + ((m4 + m5) + (m6 + m7)), left operand first as in close_part
+ILM_DEV float4 combine_partials(const float4* first, size_t stride, int count) {
+    auto add4 = [](const float4& l, const float4& r) { return mk4(l.x + r.x, l.y + r.y, l.z + r.z, l.w + r.w); };
+    if (count == 2) { float4 m[2]; load_partials<2>(first, stride, m); return add4(m[0], m[1]); }
+    if (count == 4) { float4 m[4]; load_partials<4>(first, stride, m); return add4(add4(m[0], m[1]), add4(m[2], m[3])); }
+    // (eight: two requests of four -- 32 registers of sums at once push the kernel's allocation into scratch)
+    float4 m[4], n[4];
+    load_partials<4>(first, stride, m);
+    const float4 lower = add4(add4(m[0], m[1]), add4(m[2], m[3]));
+    load_partials<4>(first + 4 * stride, stride, n);
+    return add4(lower, add4(add4(n[0], n[1]), add4(n[2], n[3])));
+}
 // What a trace needs besides the light: the field (general sampler) and, for the in-volume loop, its uniform constants and the
 // workgroup's slice table in LDS (table == nullptr: no in-volume loop -- light probes, fields the table cannot describe)
 struct TraceField {
@@ -405,7 +445,9 @@ ILM_DEV bool shade_light(const Pixel& P, const LightRec& L, const IlmEnvironment
     float sr = 0.0f, sg = 0.0f, sb = 0.0f;
     if (light_flags_i & kLightHasSpecular) {
         const f3 light_direction = P.shaded - mk3(L.cx, L.cy, L.cz);
-        const f3 h = norm3(norm3(P.camera - P.shaded) - light_direction);
+        const int l = (int)(threadIdx.x & 63u);
+        const f3 camera = mk3((float)(P.origin_x + (l & 7)) / env.ZAndScale.z, (float)(P.origin_y + (l >> 3)) / env.ZAndScale.w, env.ZAndScale.y + 0.01f);
+        const f3 h = norm3(norm3(camera - P.shaded) - light_direction);
         const float specularity = pow_pos(sat(dot3(h, P.normal)), L.spec_power);
         sr = L.spec_r * specularity * opacity_r;
         sg = L.spec_g * specularity * opacity_g;
@@ -453,14 +495,13 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
     __shared__ int bin_count[2][kLightThreads / 64];
     __shared__ SliceEntry slice_table[kMaxTableSlices];
     __shared__ float4 tree[3][kLightThreads];       // the part sums waiting for their right-hand neighbours (levels 0-2 of the tree over 8 parts)
-    __shared__ int last_member;
 
     // The dispatcher places block b on XCD b % 8.  Which tiles an XCD gets decides both its L2 locality and its share of the work
     // (lights are not spread evenly): see light_tile_map() in api.hip for the measurements; groups of 6 x 6 tiles (tile_map 4) are the default.
 #ifdef ILM_LIGHT_TRACE
     const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
-    // Light split: a.split consecutive blocks of an XCD serve one tile (they share its L2: cells, light records, the tile's partial sums);
+    // Light split: consecutive blocks of an XCD serve one tile (they share its L2: cells, light records, the tile's partial sums);
     // b is the tile's block number as the maps below see it, `member` which of the tile's workgroups this is.
     // (the launch descriptor through a pointer the compiler cannot see through -- see the light loop: what is read here is not kept
     // in scalar registers across the kernel)
@@ -470,12 +511,24 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
         asm volatile("" : "+s"(ap));
         return *(const LightLaunch*)ap;
     };
+    // Which of an XCD's block slots this is, and what it serves: slots [0, taper[0]) are whole tiles, the next 2 (taper[1] - taper[0]) the
+    // two members of a tile each, then four, then eight (tile_split): the launch ends in its smallest pieces.
+    auto tile_split = [&](int& slot, int& member) -> int {
+        const LightLaunch& A = kernargs();
+        const int k = (int)blockIdx.x / 8;
+        const int t0 = A.taper[0], t1 = A.taper[1], t2 = A.taper[2];
+        const int b1 = t0 + 2 * (t1 - t0), b2 = b1 + 4 * (t2 - t1);
+        if (k < t0) { slot = k; member = 0; return 1; }
+        if (k < b1) { slot = t0 + (k - t0) / 2; member = (k - t0) % 2; return 2; }
+        if (k < b2) { slot = t1 + (k - b1) / 4; member = (k - b1) % 4; return 4; }
+        slot = t2 + (k - b2) / 8; member = (k - b2) % 8; return 8;
+    };
     int member, nb, b;
     {
-        const int split = a.split;
-        member = ((int)blockIdx.x / 8) % split;
-        nb = (int)gridDim.x / split;
-        b = (((int)blockIdx.x / 8) / split) * 8 + ((int)blockIdx.x % 8);
+        int slot;
+        (void)tile_split(slot, member);
+        nb = a.taper_slots * 8;
+        b = slot * 8 + ((int)blockIdx.x % 8);
     }
     const int per_xcd = nb / 8;
     int tile;
@@ -492,8 +545,10 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
         // runs side by side lie side by side (api.hip light_tile_map has the measurements)
         const int M = a.tile_macro, MM = M * M;
         const int xcd = b % 8, k = b / 8;
-        const int g = (k / MM) * 8 + xcd, t = k % MM;
+        int g = (k / MM) * 8 + xcd;
+        const int t = k % MM;
         const int mx = (tiles_x + M - 1) / M;
+        if (a.group_order != nullptr && g < mx * ((tiles_y + M - 1) / M)) g = (int)a.group_order[g];
         const int ty = (g / mx) * M + t / M, tx = (g % mx) * M + t % M;
         tile = (tx < tiles_x && ty < tiles_y) ? ty * tiles_x + tx : tile_count;
     } else {
@@ -503,7 +558,11 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
         return;
     // the in-volume sampler's per-slice table (hlsl_math.hpp): one entry per virtual slice, visible to the tile's waves after the
     // first barrier of the light loop below
+#ifdef ILM_EXP_NO_TABLE            // EXPERIMENT (timing of the prologue only)
+    const int table_n = 0;
+#else
     const int table_n = a.sdf.table_slices;
+#endif
     for (int i = (int)threadIdx.x; i < table_n; i += kLightThreads) slice_table[i] = make_slice_entry((uint32_t)i, a.df, a.sdf);
     const InsideConsts inside = make_inside_consts(a.df, a.sdf);
     const int tx0 = (tile % tiles_x) * kTile, ty0 = a.row_begin + (tile / tiles_x) * kTile;
@@ -514,6 +573,7 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
     const bool in_image = (px < a.width) && (py < a.row_end);
 
     Pixel P = sample_gbuffer((float)px, (float)py, a.env, a.gbuffer);
+    P.origin_x = tx0 + (wave & 1) * 8; P.origin_y = ty0 + (wave >> 1) * 8;
     P.start_inside = (table_n > 0) && trace_start_inside(P, a.df, a.sdf);
     const float cxp = (float)px + 0.5f, cyp = (float)py + 0.5f;
     const bool have_sdf = (a.sdf.texels != nullptr) && (a.df.Extent.x > 0.0f);
@@ -563,7 +623,8 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
     // (The fp16-per-light model is one chain of roundings in light order: no parts, split 1.)
     int part, part_end;
     {
-        const int parts_each = kLightParts / kernargs().split;        // split divides kLightParts
+        int slot_, member_;
+        const int parts_each = kLightParts / tile_split(slot_, member_);
         part = member * parts_each; part_end = part + parts_each;
     }
     const int light_lo = blend_fp16 ? 0 : (int)(((long long)light_count * part) / kLightParts);
@@ -587,7 +648,11 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
     int part_bound = blend_fp16 ? 0x7FFFFFFF : (int)(((long long)light_count * (part + 1)) / kLightParts);   // first light of the next part
 
     for (int batch = light_lo; batch < light_hi; batch += kListCapacity) {
+#ifdef ILM_EXP_NO_BIN              // EXPERIMENT (timing of the prologue only): no light is looked at
+        const int batch_n = 0;
+#else
         const int batch_n = min(kListCapacity, light_hi - batch);
+#endif
         if constexpr (WIDE_BIN) {
         __syncthreads();                                        // the previous batch's list has been walked
         {
@@ -706,47 +771,29 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
         while (part < part_end) close_part();       // the parts behind the last listed light (empty ones add their zeros: the same additions whatever the split)
     }
 
-    const int split = kernargs().split;
+    int slot_end, member_end;
+    const int split = tile_split(slot_end, member_end);
     if (split > 1) {
-        // The tile's workgroups meet at its ticket.  Every member writes its subtree's sum and waits until the write is acknowledged
-        // (device-scope stores, sc1: written through this XCD's L2; s_waitcnt in every wave, then the barrier), thread 0 then draws
-        // the ticket (device-scope atomic); the member that draws the last one reads the sums back with device-scope loads -- no
-        // cache write-back or invalidate is involved, the light pass's L2 contents (the field's cells) stay where they are.
+        // The members of a tile meet at its tickets, wave by wave: the waves of a workgroup own a quadrant each, so quadrant q of member m
+        // only ever needs quadrant q of the other members -- no barrier, every wave leaves when ITS part is delivered.  A wave writes its
+        // subtree's sums (device-scope stores, sc1: written through this XCD's L2), waits until the write is acknowledged, draws the
+        // quadrant's ticket (device-scope atomic); the one that draws the last reads the K sums back with device-scope loads -- no cache
+        // write-back or invalidate is involved, the light pass's L2 contents (the field's cells) stay where they are.
 #ifdef ILM_SPLIT_NO_COMBINE      // EXPERIMENT (timing only, wrong pixels): what the members cost without their meeting
         goto tile_done;
 #endif
-        float* mine = reinterpret_cast<float*>(kernargs().partials + ((size_t)tile * (size_t)kLightParts + (size_t)member) * (size_t)kLightThreads + threadIdx.x);
-        __hip_atomic_store(mine + 0, acc_r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(mine + 1, acc_g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(mine + 2, acc_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(mine + 3, acc_a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float4* tile_sums = kernargs().partials + (size_t)tile * (size_t)kLightParts * (size_t)kLightThreads + threadIdx.x;
+        store_partial(tile_sums + (size_t)member_end * (size_t)kLightThreads, acc_r, acc_g, acc_b, acc_a);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t* ticket = kernargs().tickets + tile;
-#ifdef ILM_SPLIT_FORMAL          // EXPERIMENT: the release / acquire the language asks for -- an L2 write-back and an L2 invalidate per workgroup
-            const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-#else
-            const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#endif
-            last_member = (t == (uint32_t)(split - 1)) ? 1 : 0;
-            if (t == (uint32_t)(split - 1)) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-        }
-        __syncthreads();
-        if (last_member == 0)
+        uint32_t drawn = 0;
+        uint32_t* ticket = kernargs().tickets + (size_t)tile * (size_t)(kLightThreads / 64) + (size_t)wave;
+        if (lane == 0) drawn = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        drawn = (uint32_t)__builtin_amdgcn_readfirstlane((int)drawn);
+        if (drawn != (uint32_t)(split - 1))
             goto tile_done;
+        if (lane == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next launch
         asm volatile("" ::: "memory");
-        const float* all = reinterpret_cast<const float*>(kernargs().partials + (size_t)tile * (size_t)kLightParts * (size_t)kLightThreads + threadIdx.x);
-        // the upper levels of the tree over the members' sums: ((m0 + m1) + (m2 + m3)) + ((m4 + m5) + (m6 + m7)), left operand first as in close_part
-        auto member_sum = [&](int m) -> float4 {
-            const float* q = all + (size_t)m * (size_t)kLightThreads * 4;
-            return mk4(__hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                       __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        };
-        auto add4 = [](const float4& l, const float4& r) { return mk4(l.x + r.x, l.y + r.y, l.z + r.z, l.w + r.w); };
-        float4 v = add4(member_sum(0), member_sum(1));
-        if (split >= 4) v = add4(v, add4(member_sum(2), member_sum(3)));
-        if (split == 8) v = add4(v, add4(add4(member_sum(4), member_sum(5)), add4(member_sum(6), member_sum(7))));
+        const float4 v = combine_partials(tile_sums, (size_t)kLightThreads, split);
         acc_r = v.x; acc_g = v.y; acc_b = v.z; acc_a = v.w;
     }
     if (!blend_fp16) {
@@ -923,7 +970,7 @@ __global__ __launch_bounds__(64) void light_probes_kernel(const LightRec* __rest
     // sampleLightProbeBuffer, LightCommon.fxh:233-254
     const float probe_opacity = pp.w;
     Pixel P;
-    P.shaded = xyz(pp); P.normal = xyz(pn); P.camera = mk3(0.0f, 0.0f, 0.0f);
+    P.shaded = xyz(pp); P.normal = xyz(pn); P.origin_x = 0; P.origin_y = 0;      // (no specular term: SphereLightProbe.fx:33-42)
     P.fullbright = false;
     P.start_inside = false;
     const bool have_sdf = (sdf.texels != nullptr) && (df.Extent.x > 0.0f);
@@ -1068,9 +1115,10 @@ hipError_t launch_prepare_lights(const IlmLightVertex* lights, int count, const 
     return hipGetLastError();
 }
 
-hipError_t launch_sphere_lights_prepared(const LightLaunch& a, const void* recs, hipStream_t stream) {
+// block slots per XCD of a launch over `a`'s rows (each slot = one tile of the block -> tile map, padding included)
+int light_block_slots(const LightLaunch& a) {
     const int rows = a.row_end - a.row_begin;
-    if (rows <= 0 || a.width <= 0) return hipSuccess;
+    if (rows <= 0 || a.width <= 0) return 0;
     const int tiles_x = (a.width + kTile - 1) / kTile, tiles_y = (rows + kTile - 1) / kTile;
     const int tile_count = tiles_x * tiles_y;
     int blocks = ((tile_count + 7) / 8) * 8;
@@ -1079,10 +1127,24 @@ hipError_t launch_sphere_lights_prepared(const LightLaunch& a, const void* recs,
         const int M = a.tile_macro, groups = ((tiles_x + M - 1) / M) * ((tiles_y + M - 1) / M);
         blocks = ((groups + 7) / 8) * 8 * M * M;
     }
+    return blocks / 8;
+}
+
+hipError_t launch_sphere_lights_prepared(const LightLaunch& launch, const void* recs, hipStream_t stream) {
+    const int rows = launch.row_end - launch.row_begin;
+    if (rows <= 0 || launch.width <= 0) return hipSuccess;
+    LightLaunch a = launch;
+    const int tiles_x = (a.width + kTile - 1) / kTile, tiles_y = (rows + kTile - 1) / kTile;
+    const int tile_count = tiles_x * tiles_y;
+    const int slots = light_block_slots(a);
+    if (a.split <= 1) { a.split = 1; a.taper[0] = a.taper[1] = a.taper[2] = slots; a.taper_slots = slots; }     // one workgroup per tile throughout
+    const int t0 = a.taper[0], t1 = a.taper[1], t2 = a.taper[2];
+    if (a.taper_slots != slots || t0 < 0 || t0 > t1 || t1 > t2 || t2 > slots) return hipErrorInvalidValue;
+    const int per_xcd_blocks = t0 + 2 * (t1 - t0) + 4 * (t2 - t1) + 8 * (slots - t2);
     const LightRec* r = reinterpret_cast<const LightRec*>(recs);
     const bool stats = a.stats != nullptr;
     const bool fp16 = a.sdf.format == ILM_SDF_FP16;
-    const dim3 grid(blocks * a.split), block(kLightThreads);
+    const dim3 grid(per_xcd_blocks * 8), block(kLightThreads);
 #define ILM_LAUNCH_LIGHTS(F, S, W) hipLaunchKernelGGL((sphere_lights_kernel<F, S, W>), grid, block, 0, stream, a, r, tiles_x, tiles_y, tile_count)
     // device-side counts are particle lights: thousands
     const bool wide = (a.light_count_ptr != nullptr) || (a.light_count > 512);

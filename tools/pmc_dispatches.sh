@@ -10,7 +10,7 @@ rows = collections.OrderedDict()
 for p in glob.glob('/tmp/pmcd/**/*counter_collection.csv', recursive=True):
     for r in csv.DictReader(open(p)):
         k = r['Kernel_Name']
-        if 'sphere_lights' not in k: continue
+        if 'sphere_light' not in k: continue
         d = rows.setdefault(int(r['Dispatch_Id']), {})
         d[r['Counter_Name']] = d.get(r['Counter_Name'], 0.0) + float(r['Counter_Value'])
 for i, d in sorted(rows.items()):
