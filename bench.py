@@ -40,8 +40,11 @@ SDF_SAMPLE_BYTES = 32           # one sampleDistanceFieldEx = 4 bilin
 # r02's loop (60; VERDICT r02 fixed it so that the fraction is comparable across rounds); the loop the shipped kernel runs is listed
 # beside it (lighting.hip cone_trace_loop<FAST>: 56 for fp16 fields, 52 for unorm16 ones since the cell array of r03; 12 fewer in the
 # iterations whose visibility division is skipped).
-TRACE_INSTRUCTIONS_PER_SAMPLE = 60
+TRACE_INSTRUCTIONS_PER_SAMPLE = 60          # r02's yardstick, kept so that the fraction stays comparable across rounds
 TRACE_LOOP_INSTRUCTIONS = {"fp16": 56, "unorm16": 52}      # with the visibility division taken; 44 / 40 when the wave skips it
+# The loop the shipped kernel runs, weighted by how often a wave's iteration skips the division (82 % of them on cfg5, measured when the
+# skip went in): 0.82 x 44 + 0.18 x 56 and 0.82 x 40 + 0.18 x 52.  This is the PRIMARY work-based figure since r04.
+TRACE_LOOP_WEIGHTED = {"fp16": 46.0, "unorm16": 42.0}
 INFINITY_CACHE_MB = 256
 
 
@@ -201,7 +204,11 @@ def build_particle_system(H, ctx, scenes, abi, chunk_size, n_chunks, rank, with_
     return dict(engine=engine, ps=ps, tp=tp, live=n, transforms=(sp, gr, nz), rnd=rnd, init=(pos, vel, attr))
 
 
-def build_lighting(H, ctx, scenes, abi, width, height, n_lights, resolution, world, sdf_fmt, external_ptr=0):
+def build_lighting(H, ctx, scenes, abi, width, height, n_lights, resolution, world, sdf_fmt, external_ptr=0, plain_twin=False):
+    """The configured frame: EnableGBuffer is the reference's default (LightingRenderer.Configuration.cs:106) and SURVEY 8d defines cfg3 /
+    cfg5 with the ground-plane G-buffer (texel (0.5, 1, 0, 1), Vector4 = 16 B per pixel: highQualityGBuffer defaults to true,
+    Configuration.cs:178-188) -- UpdateFields renders it, every pixel goes through sampleGBuffer's texture branch (LightCommon.fxh:69-144).
+    plain_twin: a second renderer over the same environment and field WITHOUT a G-buffer (what r01-r03 timed), for the row beside it."""
     env = H.LightingEnvironment()
     env.Ambient = [0.05, 0.05, 0.05, 1.0]
     sc = width / 1920.0
@@ -220,20 +227,31 @@ def build_lighting(H, ctx, scenes, abi, width, height, n_lights, resolution, wor
     q.MinStepSize = 1.0; q.LongStepFactor = 0.5; q.MaxStepCount = 64; q.MaxConeRadius = 24.0; q.OcclusionToOpacityPower = 0.7
     rc.DefaultQuality = q
     rc.MaximumFieldUpdatesPerFrame = 9999      # the whole field in one UpdateFields (the reference default of 1 slice / frame is an amortisation knob)
+    rc.EnableGBuffer = True
     renderer = H.LightingRenderer(ctx, rc, env, external_ptr)
     field = H.DistanceField(ctx, world, world, 128.0, 32, resolution, 128, sdf_fmt)
     renderer.DistanceField = field
     # the field is generated on the GPU from LightObstructions: 256 random ellipsoids / boxes, seed 11
     for (typ, center, size) in scenes.random_obstacles(11, 256, (world, world)):
         env.Obstructions.Add(H.LightObstruction(typ - 1, list(center), list(size), 0.0))
-    renderer.UpdateFields()
+    renderer.UpdateFields()                    # the G-buffer (ground plane) and the whole field
     ctx.Sync()
+    renderer.Configuration.EnableGBuffer = False      # (the field's timing below is the field's alone; the G-buffer stays bound)
     gen_iters = 5
     ctx.TimerStart()
     for _ in range(gen_iters):
         renderer.InvalidateFields()
         renderer.UpdateFields()
     gen_ms = ctx.TimerStop() / gen_iters
+    renderer.Configuration.EnableGBuffer = True
+    plain = None
+    if plain_twin:
+        rc2 = H.RendererConfiguration(width, height)
+        rc2.DefaultQuality = q
+        rc2.MaximumFieldUpdatesPerFrame = 9999
+        rc2.EnableGBuffer = False
+        plain = H.LightingRenderer(ctx, rc2, env, 0)
+        plain.DistanceField = field
     texels = field.PhysicalSliceCount * field.SliceWidth * field.SliceHeight     # texels one full generation writes (8 B each)
     # The field pass is arithmetic (one analytic distance function per covering obstruction, slice and texel; 8 B written per texel):
     # its bound is vector-instruction issue, 256 CUs x 4 SIMDs x one wave64 instruction per 4 cycles at 2.4 GHz
@@ -253,7 +271,7 @@ def build_lighting(H, ctx, scenes, abi, width, height, n_lights, resolution, wor
                         "valu_instructions_per_wave": round(valu["value"], 1) if valu else None,
                         "valu_source": ("profiles/%s: SQ_INSTS_VALU / SQ_WAVES" % valu["source"]) if valu else None,
                         "launch_ms": round(gen_ms, 4)}}
-    return dict(renderer=renderer, env=env, field=field, width=width, height=height, n_lights=n_lights, field_generation=gen)
+    return dict(renderer=renderer, renderer_plain=plain, env=env, field=field, width=width, height=height, n_lights=n_lights, field_generation=gen)
 
 
 def build_collision_scene(H, ctx, scenes, abi):
@@ -503,7 +521,8 @@ def main():
                          "kernel": "ilm::step_kernel<unorm16, DF> (interpreter; the collision update has no lean variant)",
                          "bytes_per_unit": "112 B per live slot-step + 32 B per SDF sample", "units_per_launch": {"slots": co["live"], "sdf_samples": co["samples"]},
                          "launch_ms": round(co["ms"], 5),
-                         "note": "the 0.8 MB field and cfg2's 84 MB of state are cache resident: priced against the HBM peak because that is the contract's roofline"}}
+                         "resident": "infinity-cache (0.8 MB field + 84 MB of particle state < %d MiB)" % INFINITY_CACHE_MB,
+                         "note": "cache-served bytes priced against the HBM peak because that is the contract's roofline: read it like cfg2's fraction, not like cfg4's"}}
         del scene
     cpu_init, cpu_rnd, cpu_desc_bytes = P["init"], P["rnd"], ps.LastStepBytes()
     if not args.no_cfg4:
@@ -553,7 +572,7 @@ def main():
             if group is not None:
                 glm = native.GroupLightmap(group, w, h, abi.LIGHTMAP_HALF4)
                 ext = glm.members[0].device_ptr()
-            L = build_lighting(H, ctx, scenes, abi, w, h, nl, res, wsize, fmt, ext)
+            L = build_lighting(H, ctx, scenes, abi, w, h, nl, res, wsize, fmt, ext, plain_twin=(group is None))
             r = L["renderer"]
             if group is not None:
                 # cost-balanced strips: whole 16-row bands cut where the lights' raster footprints say the work is equal
@@ -599,21 +618,39 @@ def main():
             samples_total = int(sum_over_ranks(samples))
             frame_ms = lwall / light_frames * 1e3
             my_px = (row_end - row_begin) * w
-            alg_bytes = samples * SDF_SAMPLE_BYTES + my_px * 8 + nl * 128   # this rank's launch: SDF samples + ground-plane lightmap write (half4) + light records
+            # this rank's launch: SDF samples + the G-buffer texel of every pixel (Vector4) + lightmap write (half4) + light records
+            alg_bytes = samples * SDF_SAMPLE_BYTES + my_px * (16 + 8) + nl * 128
             kern_ms = gms / light_frames
+            without_gbuffer_ms = None
+            if L.get("renderer_plain") is not None:
+                rp = L["renderer_plain"]
+                n_plain = max(8, light_frames // 8)
+                for _ in range(2):
+                    rp.RenderLighting(1.0, row_begin, row_end, False)
+                ctx.TimerStart()
+                for _ in range(n_plain):
+                    rp.RenderLighting(1.0, row_begin, row_end, False)
+                without_gbuffer_ms = ctx.TimerStop() / n_plain
             kname = "ilm::sphere_lights_kernel<%d, false, false>" % (1 if fmt == abi.SDF_FP16 else 0)
             lt = profiled_traffic(kname) if world == 1 else None
             # the kernel's binding resource is VALU issue, not HBM (the atlas is cache-resident): wave-instructions of the committed PMC
             # profile of this same frame / this run's launch time
             lv = profiled_per_wave(kname, "SQ_INSTS_VALU") if world == 1 else None
-            waves_l = ((w + 15) // 16) * ((row_end - row_begin + 15) // 16) * 4
+            # the LAUNCHED grid (the profile's per-wave average is over SQ_WAVES, exit-only workgroups of partial tile groups included):
+            # groups of 6 x 6 tiles dealt to 8 XCDs, four waves per tile -- a whole frame is one workgroup per tile (lighting.hip)
+            tiles_x_l, tiles_y_l = (w + 15) // 16, (row_end - row_begin + 15) // 16
+            groups_l = ((tiles_x_l + 5) // 6) * ((tiles_y_l + 5) // 6)
+            waves_l = ((groups_l + 7) // 8) * 8 * 36 * 4
             issue = (waves_l * lv["value"] / (kern_ms * 1e-3) / 1e9) if lv else None
+            loop_w = TRACE_LOOP_WEIGHTED["fp16" if fmt == abi.SDF_FP16 else "unorm16"]
             lighting[name] = {
                 "lit_mpixels_per_s": round(w * h / (frame_ms * 1e-3) / 1e6, 2),
                 "ms_per_frame": round(frame_ms, 4), "timed_frames": light_frames, "rows": [int(row_begin), int(row_end)],
                 "sdf_samples_per_frame": samples_total,
                 "pixel_light_pairs_this_rank": pairs_local, "traced_pairs_this_rank": traced_local,
                 "field_generation": L["field_generation"],
+                "gbuffer": "ground plane rendered by UpdateFields, Vector4 (16 B per pixel), bound: every pixel decodes its texel (LightCommon.fxh:69-144)",
+                "without_gbuffer_ms": round(without_gbuffer_ms, 4) if without_gbuffer_ms else None,
                 # What binds the kernel, named by the counters (profiles/r03_summary.md): vector-instruction issue.  The trace reads the
                 # field's cell array (138 MB on cfg5) through L1 / L2 / Infinity Cache: L2 hit rate 98.6 %, ~0.2 GB per frame from beyond.
                 "roofline": {"bound": "valu", "achieved": round(issue, 1) if issue else None, "peak": round(VALU_ISSUE_PEAK, 1), "unit": "G wave-instr/s",
@@ -628,8 +665,9 @@ def main():
                 # sample needs / 64 lanes, over the launch time, against the same nominal issue rate -- what fraction of the chip's
                 # vector issue went into necessary trace work (idle lanes, per-pair code and the launch tail all lower it).
                 "work_bound": {"bound": "valu", "unit": "G wave-instr/s", "peak": round(VALU_ISSUE_PEAK, 1),
-                               "instructions_per_sample": TRACE_INSTRUCTIONS_PER_SAMPLE,
-                               "useful_frac": round(samples * TRACE_INSTRUCTIONS_PER_SAMPLE / 64.0 / (kern_ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK, 4),
+                               "instructions_per_sample": loop_w,
+                               "useful_frac": round(samples * loop_w / 64.0 / (kern_ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK, 4),
+                               "useful_frac_r02_yardstick": round(samples * TRACE_INSTRUCTIONS_PER_SAMPLE / 64.0 / (kern_ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK, 4),
                                "loop_instructions_per_sample_shipped": TRACE_LOOP_INSTRUCTIONS["fp16" if fmt == abi.SDF_FP16 else "unorm16"],
                                "useful_frac_shipped_loop": round(samples * TRACE_LOOP_INSTRUCTIONS["fp16" if fmt == abi.SDF_FP16 else "unorm16"] / 64.0 / (kern_ms * 1e-3) / 1e9 / VALU_ISSUE_PEAK, 4)},
                 # SURVEY 8d's figure for this path -- S samples x 32 B + pixels x 8 B + lights x 128 B over the launch time.  It prices
@@ -739,7 +777,8 @@ def main():
         l5 = lighting["cfg5_4k_256_lights_fp16"]
         out["roofline_lighting"] = {"workload": "cfg5: 4K, 256 lights, fp16 samples", "bound": "valu", "achieved": l5["roofline"]["achieved"], "peak": l5["roofline"]["peak"],
                                     "unit": "G wave-instr/s", "frac": l5["roofline"]["frac"], "useful_frac": l5["work_bound"]["useful_frac"],
-                                    "instructions_per_sample": TRACE_INSTRUCTIONS_PER_SAMPLE, "launch_ms": l5["roofline"]["launch_ms"],
+                                    "instructions_per_sample": l5["work_bound"]["instructions_per_sample"], "launch_ms": l5["roofline"]["launch_ms"],
+                                    "gbuffer": "bound (ground plane, Vector4)", "without_gbuffer_ms": l5["without_gbuffer_ms"],
                                     "timed_frames": l5["timed_frames"], "sdf_samples_per_frame": l5["sdf_samples_per_frame"], "traffic": l5["roofline"]["traffic"]}
 
         if not args.no_next_rows and world == 1:
@@ -914,7 +953,8 @@ def main():
         row = out.get("lighting", {}).get(key)
         if row:
             summary[short] = {"ms_per_frame": row["roofline"]["launch_ms"], "timed_frames": row["timed_frames"], "lit_mpixels_per_s": row["lit_mpixels_per_s"],
-                              "valu_issue_frac": row["roofline"]["frac"], "useful_frac_60_per_sample": row["work_bound"]["useful_frac"],
+                              "gbuffer": "bound", "without_gbuffer_ms": row["without_gbuffer_ms"],
+                              "valu_issue_frac": row["roofline"]["frac"], "useful_frac": row["work_bound"]["useful_frac"],
                               "gsamples_per_s": row["algorithmic_rate"]["gsamples_per_s"]}
     out["summary"] = summary
     for k in tail_keys:

@@ -128,10 +128,10 @@ def cfg3_scene():
     return w, h, layout, atlas, dfu, lights
 
 
-def render(ctx, lights, env, dfu, sdf, ambient, w, h, fmt=abi.LIGHTMAP_FLOAT4, strips=None):
+def render(ctx, lights, env, dfu, sdf, ambient, w, h, fmt=abi.LIGHTMAP_FLOAT4, strips=None, gbuffer=None):
     lm = native.Lightmap(ctx, w, h, fmt)
     for (b, e) in (strips or [(0, h)]):
-        native.render_sphere_lights(ctx, lights, env, dfu, None, sdf, ambient, lm, b, e)
+        native.render_sphere_lights(ctx, lights, env, dfu, gbuffer, sdf, ambient, lm, b, e)
     out = lm.download()
     lm.close()
     return out
@@ -139,45 +139,53 @@ def render(ctx, lights, env, dfu, sdf, ambient, w, h, fmt=abi.LIGHTMAP_FLOAT4, s
 
 def test_cfg3_1080p_properties(ctx, oracle, cfg3_scene):
     w, h, layout, atlas, dfu, lights = cfg3_scene
-    env = scenes.environment()
+    # the configured frame (RendererConfiguration.EnableGBuffer's default): the ground-plane G-buffer is bound, every pixel goes
+    # through sampleGBuffer's texture branch (LightCommon.fxh:69-144); Vector4 texels here, HalfVector4 in the cfg5 test
+    garr = scenes.ground_plane_gbuffer(w, h, abi.GBUFFER_FLOAT4)
+    gb = native.GBufferTexture(ctx, garr, abi.GBUFFER_FLOAT4)
+    env = scenes.environment(gbuffer_size=(w, h))
     ambient = (0.05, 0.05, 0.05, 1.0)
     sdf = native.DistanceFieldTexture(ctx, atlas)
-    whole = render(ctx, lights, env, dfu, sdf, ambient, w, h)
+    whole = render(ctx, lights, env, dfu, sdf, ambient, w, h, gbuffer=gb)
     assert np.isfinite(whole).all()
+    # (the generated ground plane reproduces the frame without a G-buffer: sampleGBuffer's else-branch)
+    assert_close(render(ctx, lights, scenes.environment(), dfu, sdf, ambient, w, h), whole, "no G-buffer vs the ground-plane G-buffer", rtol=1e-6, atol=1e-7)
 
     # (1) strip invariance: 8 strips (the 8-GPU split) == one launch, bit for bit
     from illuminant_amd import sharding
     strips = sharding.row_strips(h, 8)
-    assert np.array_equal(render(ctx, lights, env, dfu, sdf, ambient, w, h, strips=strips), whole)
+    assert np.array_equal(render(ctx, lights, env, dfu, sdf, ambient, w, h, strips=strips, gbuffer=gb), whole)
     uneven = [(0, 7), (7, 500), (500, 501), (501, h)]          # not tile aligned: still exact
-    assert np.array_equal(render(ctx, lights, env, dfu, sdf, ambient, w, h, strips=uneven), whole)
+    assert np.array_equal(render(ctx, lights, env, dfu, sdf, ambient, w, h, strips=uneven, gbuffer=gb), whole)
 
     # (2) additivity: lights [0,32) and [32,64) rendered apart sum to the whole frame (rgb and the alpha light count)
     n = len(lights)
     first = (abi.LightVertex * (n // 2))(*[lights[i] for i in range(n // 2)])
     second = (abi.LightVertex * (n - n // 2))(*[lights[i] for i in range(n // 2, n)])
     zero = (0.0, 0.0, 0.0, 0.0)
-    a = render(ctx, first, env, dfu, sdf, ambient, w, h)
-    b = render(ctx, second, env, dfu, sdf, zero, w, h)
+    a = render(ctx, first, env, dfu, sdf, ambient, w, h, gbuffer=gb)
+    b = render(ctx, second, env, dfu, sdf, zero, w, h, gbuffer=gb)
     assert_close(a + b, whole, "additivity over light subsets", rtol=1e-5, atol=1e-6)
     assert np.array_equal((a + b)[..., 3], whole[..., 3])      # alpha = 1 + number of contributing lights: exact integers
 
     # (3) no lights => the clear colour (Ambient * intensityScale, LightingRenderer.cs:1013-1024)
-    none = render(ctx, (abi.LightVertex * 0)(), env, dfu, sdf, ambient, w, h)
+    none = render(ctx, (abi.LightVertex * 0)(), env, dfu, sdf, ambient, w, h, gbuffer=gb)
     assert np.array_equal(none, np.broadcast_to(np.float32(ambient), none.shape))
 
     # (4) the oracle on a 24-row crop of the full-size frame (same lights, same 25 MB atlas)
     b0, b1 = 528, 552
-    want, _ = oracle.render_sphere_lights(lights, env, dfu, None, oracle.make_texture(atlas, abi.SDF_UNORM16), ambient, w, h, row_begin=b0, row_end=b1)
+    want, _ = oracle.render_sphere_lights(lights, env, dfu, oracle.make_texture(garr, abi.GBUFFER_FLOAT4), oracle.make_texture(atlas, abi.SDF_UNORM16),
+                                          ambient, w, h, row_begin=b0, row_end=b1)
     assert_close(whole[b0:b1], want[b0:b1], "cfg3 crop vs oracle")
 
     # (5) the fp16-sample variant of the same atlas (config 5's storage) stays within half precision of the unorm16 one
     atlas16 = scenes.build_sdf_atlas(layout, scenes.random_obstacles(11, 256, (2048, 2048)), fmt=abi.SDF_FP16)
     sdf16 = native.DistanceFieldTexture(ctx, atlas16, abi.SDF_FP16)
-    half = render(ctx, lights, env, dfu, sdf16, ambient, w, h)
+    half = render(ctx, lights, env, dfu, sdf16, ambient, w, h, gbuffer=gb)
     assert np.abs(half[..., :3] - whole[..., :3]).mean() < 2e-3
     sdf16.close()
     sdf.close()
+    gb.close()
 
 
 def test_cfg4_share_eight_million_particles(ctx, oracle):
@@ -246,17 +254,21 @@ def test_cfg5_4k_256_lights_fp16_properties(ctx, oracle):
     atlas = sdf.download()
     dfu = layout.uniforms(max_cone_radius=24.0, power=0.7, step_limit=64, min_step_size=1.0, long_step_factor=0.5)
     lights = scenes.random_lights(13, 256, w, h, z=(8.0, 64.0), radius=24.0, ramp=(400.0, 1100.0))
-    env = scenes.environment()
+    # the configured frame: the ground-plane G-buffer bound (HalfVector4 texels here, Vector4 in the cfg3 test)
+    garr = scenes.ground_plane_gbuffer(w, h, abi.GBUFFER_HALF4)
+    gb = native.GBufferTexture(ctx, garr, abi.GBUFFER_HALF4)
+    env = scenes.environment(gbuffer_size=(w, h))
     ambient = (0.05, 0.05, 0.05, 1.0)
-    whole = render(ctx, lights, env, dfu, sdf, ambient, w, h)
+    whole = render(ctx, lights, env, dfu, sdf, ambient, w, h, gbuffer=gb)
     assert np.isfinite(whole).all()
     from illuminant_amd import sharding
-    assert np.array_equal(render(ctx, lights, env, dfu, sdf, ambient, w, h, strips=sharding.row_strips(h, 8)), whole)
+    assert np.array_equal(render(ctx, lights, env, dfu, sdf, ambient, w, h, strips=sharding.row_strips(h, 8), gbuffer=gb), whole)
     b0, b1 = 1076, 1084
     lm = native.Lightmap(ctx, w, h, abi.LIGHTMAP_FLOAT4)
-    stats = native.render_sphere_lights(ctx, lights, env, dfu, None, sdf, ambient, lm, b0, b1, want_stats=True)
+    stats = native.render_sphere_lights(ctx, lights, env, dfu, gb, sdf, ambient, lm, b0, b1, want_stats=True)
     lm.close()
-    want, ostats = oracle.render_sphere_lights(lights, env, dfu, None, oracle.make_texture(atlas, abi.SDF_FP16), ambient, w, h,
+    gb.close()
+    want, ostats = oracle.render_sphere_lights(lights, env, dfu, oracle.make_texture(garr, abi.GBUFFER_HALF4), oracle.make_texture(atlas, abi.SDF_FP16), ambient, w, h,
                                                row_begin=b0, row_end=b1, want_stats=True)
     assert (stats.SdfSamples, stats.PixelLightPairs, stats.TracedPairs) == (ostats.SdfSamples, ostats.PixelLightPairs, ostats.TracedPairs)
     assert stats.SdfSamples > 5_000_000
