@@ -764,7 +764,9 @@ def sphere_light(position, radius, ramp_length, color=(1, 1, 1, 1), opacity=1.0,
     """RenderSphereLightSource, LightingRenderer.cs:1193-1219; EvenMore.zw = RampOffsetForGPU, RampRateForGPU (LightSource.cs:97-98)."""
     v = abi.LightVertex()
     v.LightPosition1 = v.LightPosition2 = v.LightPosition3 = abi.f4(position[0], position[1], position[2], 0)
-    v.Color1 = abi.f4(color[0], color[1], color[2], np.float32(color[3]) * np.float32(opacity * intensity_scale))
+    # color.W *= (lightSource.Opacity * intensityScale): float * float, then float *= float (found by tests/test_reference_uniforms.py: the
+    # product of the two factors had been formed in double)
+    v.Color1 = abi.f4(color[0], color[1], color[2], np.float32(color[3]) * (np.float32(opacity) * np.float32(intensity_scale)))
     v.Color2 = abi.f4(specular[0], specular[1], specular[2], specular_power)
     v.LightProperties = abi.f4(radius, ramp_length, float(ramp_mode), 1.0 if (casts_shadows and have_distance_field) else 0.0)
     v.MoreLightProperties = abi.f4(ao_radius, -99999.0 if shadow_distance_falloff is None else shadow_distance_falloff,

@@ -19,8 +19,11 @@ sampler, which is why the test compares at 2e-6, not bit for bit).  Texture fetc
 them: LINEAR / U WRAP / V CLAMP for the distance field, POINT for the randomness table, texel centres at +0.5, lerp(a, b, t) = a + (b - a) t
 first along x, then along y.  saturate(NaN) = 0, float % = fmod, sign(0) = 0.
 
-The inputs come from illuminant_amd.scenes (seeded generators and the C#-side uniform builders -- data, not shader code).  The fixture
-holds the outputs only; tests/test_second_reading.py regenerates the inputs from the same seeds and holds oracle/ to the fixture.
+The random inputs come from illuminant_amd.scenes' seeded generators (particle states, obstacle lists, light positions: data).  The
+uniform blocks and light vertices -- Uniforms.DistanceField, DistanceFieldPacked1, Uniforms.ParticleSystem, the Environment block,
+RenderSphereLightSource's LightVertex -- are built by tests/golden/reference_uniforms.py, a transcription of the C# lines of its own
+(r04: before, they came from scenes.py's builders, which oracle and kernels use too); tests/test_reference_uniforms.py holds the two to
+each other.  The fixture holds the outputs only; tests/test_second_reading.py regenerates the inputs and holds oracle/ to the fixture.
 """
 import os
 import sys
@@ -31,6 +34,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 from illuminant_amd import abi, scenes   # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import reference_uniforms as ref   # noqa: E402
+
+
+def random_lights(seed, n, width, height, z, radius, ramp):
+    """n sphere lights at seeded positions (scenes.uniform is the shared SplitMix64 generator: data), packed by reference_uniforms"""
+    xs = scenes.uniform(seed + 1, (n,), 0, width); ys = scenes.uniform(seed + 2, (n,), 0, height)
+    zs = scenes.uniform(seed + 3, (n,), z[0], z[1]); rs = scenes.uniform(seed + 4, (n,), ramp[0], ramp[1])
+    col = scenes.uniform(seed + 5, (n, 3), 0.2, 1.0)
+    return [ref.sphere_light_vertex((xs[i], ys[i], zs[i]), radius, rs[i], Color=(col[i, 0], col[i, 1], col[i, 2], 1.0)) for i in range(n)]
 
 F = np.float32
 PI = F(3.14159265358979323846)
@@ -898,11 +911,13 @@ def lighting_inputs():
     w, h = 64, 48
     layout = scenes.DistanceFieldLayout(128, 96, 64.0, 9, 0.5)
     atlas = scenes.build_sdf_atlas(layout, scenes.random_obstacles(5, 7, (128, 96), 5.0, 16.0, 40.0))
-    dfu = layout.uniforms(power=0.7, min_step_size=1.0, long_step_factor=0.5)
-    lights = list(scenes.random_lights(21, 3, w, h, z=(6.0, 40.0), radius=5.0, ramp=(25.0, 70.0)))
-    lights.append(scenes.sphere_light((40.0, 20.0, 30.0), 4.0, 45.0, color=(0.9, 0.6, 0.3, 1.0), ao_radius=12.0, ao_opacity=0.8,
-                                      specular=(0.2, 0.3, 0.4), specular_power=6.0, falloff_y=1.5))
-    env = scenes.environment(maximum_z=64.0)
+    field = ref.ReferenceDistanceField(128, 96, 64.0, 9, 0.5)
+    assert (field.TextureWidth, field.TextureHeight) == (layout.atlas_width, layout.atlas_height)
+    dfu = ref.distance_field_uniforms(field, OcclusionToOpacityPower=0.7, MinStepSize=1.0, LongStepFactor=0.5)
+    lights = random_lights(21, 3, w, h, z=(6.0, 40.0), radius=5.0, ramp=(25.0, 70.0))
+    lights.append(ref.sphere_light_vertex((40.0, 20.0, 30.0), 4.0, 45.0, Color=(0.9, 0.6, 0.3, 1.0), AmbientOcclusionRadius=12.0, AmbientOcclusionOpacity=0.8,
+                                          SpecularColor=(0.2, 0.3, 0.4), SpecularPower=6.0, FalloffYFactor=1.5))
+    env = ref.environment_uniforms(MaximumZ=64.0)
     return dict(width=w, height=h, atlas=atlas, dfu=dfu, lights=lights, env=env, ambient=(0.04, 0.05, 0.06, 1.0))
 
 
@@ -923,14 +938,14 @@ def lighting_gbuffer_inputs():
     g[20:23] = scenes.encode_gbuffer(normal[20:23], 0.0, z[20:23], fullbright=True)
     g[28:32, :, :2] = 0.0
     g[36:42, :, 2] = -3.5
-    lights = L["lights"] + list(scenes.random_lights(23, 2, w, h, z=(10.0, 30.0), radius=6.0, ramp=(30.0, 60.0)))
+    lights = L["lights"] + random_lights(23, 2, w, h, z=(10.0, 30.0), radius=6.0, ramp=(30.0, 60.0))
     for i, lv in enumerate(lights):
         lv.MoreLightProperties.x = 10.0 if i % 2 else 0.0
         lv.MoreLightProperties.w = 0.6
         lv.Color2 = abi.f4(0.3, 0.2, 0.1, 8.0) if i % 3 == 0 else abi.f4(0, 0, 0, 1)
         lv.LightProperties.z = float(i % 3)
         lv.EvenMoreLightProperties.x = float((i % 4) - 1)
-    env = scenes.environment(maximum_z=64.0, gbuffer_size=(gw, gh), light_occlusion=40.0, viewport_position=(3.0, 2.0), viewport_relative=True)
+    env = ref.environment_uniforms(MaximumZ=64.0, gbuffer_size=(gw, gh), LightOcclusion=40.0, ViewportPosition=(3.0, 2.0), GBufferViewportRelative=True)
     return dict(width=w, height=h, atlas=L["atlas"], dfu=L["dfu"], lights=lights, env=env, ambient=(0.0, 0.01, 0.02, 0.0), gbuffer=g)
 
 
@@ -939,7 +954,8 @@ def particle_inputs():
     n = cs * cs
     pos, vel, attr = scenes.make_particles(77, n, pos_lo=(0, 0, 0), pos_hi=(256, 256, 32), dead_fraction=0.2, life=(0.005, 4.0))
     rnd = scenes.randomness_table(9)
-    sysu = scenes.system_uniforms(cs, friction=0.15, max_velocity=90.0, life_decay=1.5, rotation_from_velocity=True)
+    sysu = ref.particle_system_uniforms(cs, 1.0 / 60, Friction=0.15, MaximumVelocity=90.0, LifeDecayPerSecond=1.5, RotationFromVelocity=True,
+                                        Collision=(128.0, 0.0, 0.33, 0.0))
     g = scenes.gravity_params([((128.0, 100.0, 4.0), 90.0, 70.0, 1), ((30.0, 200.0, 0.0), 120.0, 40.0, 2), ((200.0, 40.0, 10.0), 15.0, 900.0, 0)],
                               maximum_acceleration=6.0)
     nz = scenes.noise_params(scenes.area_none(strength=0.8), (37.0 * 253 / 1000.0, 11.0 * 127 / 1000.0), (591.0 * 253 / 1000.0, 220.0 * 127 / 1000.0), 0.35,
@@ -965,10 +981,12 @@ def collision_inputs(case):
     atlas = scenes.build_sdf_atlas(layout, scenes.simple_particles_obstacles())
     pos, vel, attr = scenes.make_particles(c["seed"], cs * cs, pos_lo=(-20, -20, 0), pos_hi=(276, 276, 32), dead_fraction=0.1, life=(0.01, 6.0),
                                            categories=(0.0, 2.0))
-    sysu = scenes.system_uniforms(cs, friction=0.1, max_velocity=2048.0, life_decay=1.2, collision=(128.0, c["bounce"], 0.33, 0.05))
+    sysu = ref.particle_system_uniforms(cs, 1.0 / 60, Friction=0.1, MaximumVelocity=2048.0, LifeDecayPerSecond=1.2, Collision=(128.0, c["bounce"], 0.33, 0.05))
     upd = abi.UpdateParams.default()
     upd.RotationFromLifeAndIndex[0], upd.RotationFromLifeAndIndex[1] = 0.5, 0.004
-    return dict(chunk_size=cs, atlas=atlas, dfu=layout.uniforms(packed1=c["packed1"]), pos=pos, vel=vel, attr=attr, system=sysu, update=upd)
+    field = ref.ReferenceDistanceField(256, 256, 64.0, 9, 1.0, 128)
+    assert (field.TextureWidth, field.TextureHeight) == (layout.atlas_width, layout.atlas_height)
+    return dict(chunk_size=cs, atlas=atlas, dfu=ref.distance_field_uniforms(field, set_packed1=c["packed1"]), pos=pos, vel=vel, attr=attr, system=sysu, update=upd)
 
 
 def main():
