@@ -120,6 +120,11 @@ class Environment(C.Structure):
                 ("ViewportPosition", f32 * 2), ("GBufferViewportRelative", f32), ("_pad0", f32)]
 
 
+class SdfTraceInfo(C.Structure):
+    _fields_ = [("CellBytes", C.c_uint64), ("CellRebuilds", C.c_uint64), ("CellSlicesRebuilt", C.c_uint64),
+                ("LastRebuiltSlices", i32), ("TableSlices", i32), ("RebuiltEveryFrame", i32), ("Reserved", i32)]
+
+
 class LightVertex(C.Structure):
     _fields_ = [("LightPosition1", Float4), ("LightPosition2", Float4), ("LightPosition3", Float4),
                 ("LightProperties", Float4), ("MoreLightProperties", Float4), ("EvenMoreLightProperties", Float4),

@@ -134,6 +134,19 @@ struct Sdf {
     uint64_t version = 1, cells_version = 0;
     int cells_slices = 0, cells_columns = 0, cells_sw = 0, cells_sh = 0;
     bool escaped = false;
+    // Which virtual slices of the atlas have been written since the cells were built (bit v of dirty[v / 64]; kMaxTableSlices = 256 bits;
+    // slices past that have no cells anyway).  The reference regenerates MaximumFieldUpdatesPerFrame = 1 slice triplet per frame
+    // (LightingRenderer.Configuration.cs:91, LightingRenderer.DistanceField.cs:415-464): the cells of slice v hold the channel pairs
+    // (v, v + 1), so a triplet [s, s + 3) invalidates the cells of slices s - 1 .. s + 2 -- 4 of cfg5's 33, not all 138 MB.
+    uint64_t dirty[4] = { ~0ull, ~0ull, ~0ull, ~0ull };
+    void mark_all_dirty() { for (uint64_t& w : dirty) w = ~0ull; version++; }
+    void mark_slices_dirty(int first, int count) {
+        for (int v = std::max(0, first - 1); v < first + count && v < 256; v++) dirty[v >> 6] |= 1ull << (v & 63);
+        version++;
+    }
+    // what the last light pass over this field found / did (ilm_sdf_trace_info)
+    uint64_t cell_rebuilds = 0, cell_slices_rebuilt = 0;
+    int last_rebuilt_slices = 0, last_table_slices = 0;
 };
 
 struct GBuffer {
@@ -278,14 +291,33 @@ hipError_t make_trace_view(Sdf* f, const IlmDistanceFieldUniforms* df, hipStream
     auto no_table = [&]() { out->table_slices = 0; out->box_x0 = out->box_y0 = out->box_z0 = 1.0f; out->box_x1 = out->box_y1 = out->box_z1 = 0.0f; };
     if (cells_off || bytes >= ((size_t)1 << 31)) { no_table(); return hipSuccess; }
     const bool same_layout = f->cells && f->cells_slices == v.table_slices && f->cells_columns == v.columns && f->cells_sw == v.slice_w && f->cells_sh == v.slice_h;
+    f->last_rebuilt_slices = 0; f->last_table_slices = v.table_slices;
     if (!same_layout || f->escaped || f->cells_version != f->version) {
         if (bytes > f->cells_bytes) {
             if (f->cells) { (void)hipStreamSynchronize(stream); (void)hipFree(f->cells); f->cells = nullptr; f->cells_bytes = 0; }
-            if (hipMalloc(&f->cells, bytes) != hipSuccess) { (void)hipGetLastError(); f->cells = nullptr; no_table(); return hipSuccess; }
+            if (hipMalloc(&f->cells, bytes) != hipSuccess) {
+                (void)hipGetLastError(); f->cells = nullptr; f->last_table_slices = 0;
+                static std::atomic<bool> said{false};
+                if (!said.exchange(true)) fprintf(stderr, "illuminant_hip: no memory for the %zu-byte cell array of a distance field: its light passes use the general sampler (slower)\n", bytes);
+                no_table(); return hipSuccess;
+            }
             f->cells_bytes = bytes;
+            f->mark_all_dirty();
         }
-        const hipError_t e = launch_build_sdf_cells(v, f->cells, stream);
-        if (e != hipSuccess) return e;
+        if (!same_layout || f->escaped) f->mark_all_dirty();
+        // the runs of slices written since the last build (everything, the first time and for an escaped atlas)
+        int v0 = 0;
+        while (v0 < v.table_slices) {
+            if (!((f->dirty[v0 >> 6] >> (v0 & 63)) & 1ull)) { v0++; continue; }
+            int v1 = v0;
+            while (v1 < v.table_slices && ((f->dirty[v1 >> 6] >> (v1 & 63)) & 1ull)) v1++;
+            const hipError_t e = launch_build_sdf_cells(v, f->cells, v0, v1 - v0, stream);
+            if (e != hipSuccess) return e;
+            f->last_rebuilt_slices += v1 - v0;
+            v0 = v1;
+        }
+        for (uint64_t& w : f->dirty) w = 0;
+        f->cell_rebuilds++; f->cell_slices_rebuilt += (uint64_t)f->last_rebuilt_slices;
         f->cells_slices = v.table_slices; f->cells_columns = v.columns; f->cells_sw = v.slice_w; f->cells_sh = v.slice_h;
         f->cells_version = f->version;
     }
@@ -1525,7 +1557,7 @@ int32_t ilm_sdf_upload(IlmHandle h, const uint16_t* texels) {
     if (!texels) return fail(ILM_ERR_INVALID_ARGUMENT, "texels is NULL");
     HIP_TRY(hipSetDevice(f->ctx->device));
     HIP_TRY(hipMemcpyAsync(f->texels, texels, sizeof(uint2) * (size_t)f->width * (size_t)f->height, hipMemcpyHostToDevice, f->ctx->main()));
-    f->version++;
+    f->mark_all_dirty();
     HIP_TRY(hipStreamSynchronize(f->ctx->main()));
     return ILM_OK;
 }
@@ -1654,7 +1686,26 @@ int32_t ilm_sdf_device_ptr(IlmHandle h, void** out_ptr) {
     Sdf* f = from_handle<Sdf>(h, kMagicSdf);
     if (!f || !out_ptr) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle");
     *out_ptr = f->texels;
-    f->escaped = true;      // the caller may write the atlas: the trace's cell array is rebuilt before every use from now on
+    f->escaped = true;      // the caller may write the atlas: the trace's cell array is rebuilt before every use from now on (until ilm_sdf_mark_dirty)
+    return ILM_OK;
+}
+
+int32_t ilm_sdf_mark_dirty(IlmHandle h, int32_t first_virtual_slice, int32_t slice_count) {
+    Sdf* f = from_handle<Sdf>(h, kMagicSdf);
+    if (!f) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle");
+    if (slice_count < 0 || first_virtual_slice < 0) return fail(ILM_ERR_OUT_OF_RANGE, "slices [%d, %d + %d)", first_virtual_slice, first_virtual_slice, slice_count);
+    if (slice_count == 0) f->mark_all_dirty(); else f->mark_slices_dirty(first_virtual_slice, slice_count);
+    f->escaped = false;     // the caller reports its writes from now on
+    return ILM_OK;
+}
+
+int32_t ilm_sdf_trace_info(IlmHandle h, IlmSdfTraceInfo* out) {
+    Sdf* f = from_handle<Sdf>(h, kMagicSdf);
+    if (!f || !out) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle");
+    out->CellBytes = (uint64_t)f->cells_bytes;
+    out->CellRebuilds = f->cell_rebuilds; out->CellSlicesRebuilt = f->cell_slices_rebuilt;
+    out->LastRebuiltSlices = f->last_rebuilt_slices; out->TableSlices = f->last_table_slices;
+    out->RebuiltEveryFrame = f->escaped ? 1 : 0; out->Reserved = 0;
     return ILM_OK;
 }
 
@@ -1791,7 +1842,7 @@ int32_t ilm_sdf_render_slices(IlmHandle h, IlmHandle hclear, const IlmDistanceFi
     a.virtual_depth = d->VirtualDepth; a.z_offset = d->ZOffset; a.max_encoded = d->MaximumEncodedDistance;
     a.inv_scale_x = d->InvScaleFactorX; a.inv_scale_y = d->InvScaleFactorY;
     HIP_TRY(launch_render_slices(a, f->format, c->main()));
-    f->version++;
+    for (int32_t i = 0; i < triplet_count; i++) f->mark_slices_dirty(first_virtual_slices[i], 3);
     return ILM_OK;
 }
 

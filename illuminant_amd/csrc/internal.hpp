@@ -223,7 +223,7 @@ hipError_t launch_light_probes(const void* recs, int light_count, const float4* 
 // sampleDistanceFieldEx at `count` positions (xyz triples) -- diagnostic entry point ilm_sdf_sample
 hipError_t launch_sdf_sample(const SdfView& sdf, const IlmDistanceFieldUniforms& df, const float* positions, int count, float* out, hipStream_t stream);
 // fills the cell array of the table sampler (sdf.table_slices x sdf.slice_h x sdf.slice_w cells of 16 bytes) from the atlas
-hipError_t launch_build_sdf_cells(const TraceSdfView& sdf, void* cells, hipStream_t stream);
+hipError_t launch_build_sdf_cells(const TraceSdfView& sdf, void* cells, int first_slice, int slice_count, hipStream_t stream);
 hipError_t launch_sdf_sample_inside(const TraceSdfView& sdf, const IlmDistanceFieldUniforms& df, const float* positions, int count, float* out, int32_t* used,
                                     hipStream_t stream);
 hipError_t launch_divide_by_constant(float divisor, float reciprocal, unsigned long long* mismatches, hipStream_t stream);

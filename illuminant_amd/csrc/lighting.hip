@@ -1063,9 +1063,9 @@ hipError_t launch_sdf_sample_inside(const TraceSdfView& sdf, const IlmDistanceFi
 // slice v's grid, each as the 32-bit channel pair (slice v, slice v + 1) -- exactly the words sample_distance_field's taps would fetch
 // from the atlas for a sample whose floor coordinates are (x, y) in that slice (sdf_pair_word).  The last column / row of a slice
 // repeat their neighbour (never sampled: the table sampler's box keeps every tap inside the slice).  One thread per cell, 16-byte stores.
-__global__ __launch_bounds__(256) void build_sdf_cells_kernel(const uint2* __restrict__ atlas, int atlas_w, int slice_w, int slice_h, int columns, int slices,
+__global__ __launch_bounds__(256) void build_sdf_cells_kernel(const uint2* __restrict__ atlas, int atlas_w, int slice_w, int slice_h, int columns, int first_slice,
                                                                uint4* __restrict__ cells) {
-    const int x = (int)blockIdx.x * 256 + (int)threadIdx.x, y = (int)blockIdx.y, v = (int)blockIdx.z;
+    const int x = (int)blockIdx.x * 256 + (int)threadIdx.x, y = (int)blockIdx.y, v = first_slice + (int)blockIdx.z;
     if (x >= slice_w) return;
     const uint32_t third = (uint32_t)v / 3u, m = (uint32_t)v - 3u * third;
     const int col = (int)(third % (uint32_t)columns), row = (int)(third / (uint32_t)columns);
@@ -1077,10 +1077,11 @@ __global__ __launch_bounds__(256) void build_sdf_cells_kernel(const uint2* __res
     cells[((size_t)v * (size_t)slice_h + (size_t)y) * (size_t)slice_w + (size_t)x] = c;
 }
 
-hipError_t launch_build_sdf_cells(const TraceSdfView& sdf, void* cells, hipStream_t stream) {
-    if (sdf.table_slices <= 0) return hipSuccess;
-    const dim3 grid((unsigned)((sdf.slice_w + 255) / 256), (unsigned)sdf.slice_h, (unsigned)sdf.table_slices), block(256);
-    hipLaunchKernelGGL(build_sdf_cells_kernel, grid, block, 0, stream, sdf.texels, sdf.width, sdf.slice_w, sdf.slice_h, sdf.columns, sdf.table_slices,
+// (re)builds the cells of virtual slices [first_slice, first_slice + slice_count)
+hipError_t launch_build_sdf_cells(const TraceSdfView& sdf, void* cells, int first_slice, int slice_count, hipStream_t stream) {
+    if (sdf.table_slices <= 0 || slice_count <= 0) return hipSuccess;
+    const dim3 grid((unsigned)((sdf.slice_w + 255) / 256), (unsigned)sdf.slice_h, (unsigned)slice_count), block(256);
+    hipLaunchKernelGGL(build_sdf_cells_kernel, grid, block, 0, stream, sdf.texels, sdf.width, sdf.slice_w, sdf.slice_h, sdf.columns, first_slice,
                        reinterpret_cast<uint4*>(cells));
     return hipGetLastError();
 }

@@ -81,6 +81,8 @@ SYMBOLS = {
     "ilm_sdf_destroy": (_I, [_H]),
     "ilm_sdf_download": (_I, [_H, _P]),
     "ilm_sdf_device_ptr": (_I, [_H, C.POINTER(_P)]),
+    "ilm_sdf_mark_dirty": (_I, [_H, _I, _I]),
+    "ilm_sdf_trace_info": (_I, [_H, C.POINTER(abi.SdfTraceInfo)]),
     "ilm_sdf_render_slices": (_I, [_H, _H, _P, _P, _I, _P, _I, _P, _I, _P, _I]),
     "ilm_gbuffer_create": (_I, [_H, _I, _I, _I, C.POINTER(_H)]),
     "ilm_gbuffer_upload": (_I, [_H, _P]),
@@ -450,6 +452,16 @@ class DistanceFieldTexture:
         p = C.c_void_p()
         check(lib().ilm_sdf_device_ptr(self.handle, C.byref(p)))
         return p.value
+
+    def mark_dirty(self, first_virtual_slice=0, slice_count=0):
+        """ilm_sdf_mark_dirty: the caller wrote those virtual slices through device_ptr() (slice_count 0: the whole atlas)."""
+        check(lib().ilm_sdf_mark_dirty(self.handle, first_virtual_slice, slice_count))
+
+    def trace_info(self):
+        """ilm_sdf_trace_info"""
+        info = abi.SdfTraceInfo()
+        check(lib().ilm_sdf_trace_info(self.handle, C.byref(info)))
+        return info
 
     def download(self):
         """ilm_sdf_download: the atlas as (H, W, 4) uint16."""

@@ -500,7 +500,30 @@ int32_t ilm_debug_step_sdf_samples(IlmHandle ctx, int32_t enable, uint64_t* out_
 int32_t ilm_sdf_destroy(IlmHandle sdf);
 /* DistanceField.Save (Illuminant/SDF/DistanceField.cs:178-194): the atlas bytes, 8 per texel, row-major. */
 int32_t ilm_sdf_download(IlmHandle sdf, uint16_t* texels);
+/* The atlas in device memory, for callers that write it themselves (a torch tensor view, another library's kernel).  The light passes
+ * read the field through a cell array derived from the atlas: once the pointer has been handed out the library cannot know
+ * when the atlas changes and re-derives ALL cells before every light pass (138 MB on a 512 x 512 x 33 field) -- until the caller takes
+ * over the bookkeeping with ilm_sdf_mark_dirty. */
 int32_t ilm_sdf_device_ptr(IlmHandle sdf, void** out_ptr);
+/* "I have written virtual slices [first_virtual_slice, first_virtual_slice + slice_count) of the atlas" (slice_count 0: all of it).  The
+ * next light pass re-derives the cells of those slices and their lower neighbour only -- the reference regenerates
+ * MaximumFieldUpdatesPerFrame = 1 slice triplet per frame (Illuminant/Lighting/LightingRenderer.Configuration.cs:91,
+ * LightingRenderer.DistanceField.cs:415-464) -- and from this call on the field is no longer re-derived before every pass:
+ * the caller reports its writes.  ilm_sdf_upload and ilm_sdf_render_slices do this bookkeeping themselves. */
+int32_t ilm_sdf_mark_dirty(IlmHandle sdf, int32_t first_virtual_slice, int32_t slice_count);
+/* What the light passes do with this field: the bytes of its cell array (0: none was built), how many virtual slices the last light pass
+ * re-derived and has a table for (TableSlices 0: the pass used the general sampler -- uniforms that do not tile the atlas, more than 256
+ * slices, cells past 2 GiB, or no memory for them: same results, about half the speed), and the running totals. */
+typedef struct IlmSdfTraceInfo {
+    uint64_t CellBytes;
+    uint64_t CellRebuilds;          /* light passes that re-derived at least one slice */
+    uint64_t CellSlicesRebuilt;     /* virtual slices re-derived in total */
+    int32_t  LastRebuiltSlices;
+    int32_t  TableSlices;
+    int32_t  RebuiltEveryFrame;     /* 1: the device pointer was handed out and ilm_sdf_mark_dirty has not been called since */
+    int32_t  Reserved;
+} IlmSdfTraceInfo;
+int32_t ilm_sdf_trace_info(IlmHandle sdf, IlmSdfTraceInfo* out);
 
 /* ---- distance field generation ------------------------------ */
 

@@ -283,6 +283,17 @@ namespace Squared.Illuminant.Native {
         public IlmSpawnRecord Spawns1;
     }
 
+    [StructLayout(LayoutKind.Sequential, Pack = 4, Size = 40)]
+    public struct IlmSdfTraceInfo {
+        public ulong CellBytes;
+        public ulong CellRebuilds;
+        public ulong CellSlicesRebuilt;
+        public int LastRebuiltSlices;
+        public int TableSlices;
+        public int RebuiltEveryFrame;
+        public int Reserved;
+    }
+
     [StructLayout(LayoutKind.Sequential, Pack = 4, Size = 48)]
     public unsafe struct IlmObstruction {
         public fixed float Center[3];
@@ -504,6 +515,8 @@ namespace Squared.Illuminant.Native {
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_sdf_destroy (ulong sdf);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_sdf_download (ulong sdf, ushort* texels);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_sdf_device_ptr (ulong sdf, void** outPtr);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_sdf_mark_dirty (ulong sdf, int firstVirtualSlice, int sliceCount);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_sdf_trace_info (ulong sdf, IlmSdfTraceInfo* @out);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_sdf_render_slices (ulong sdf, ulong clearSource, IlmDistanceFieldRenderDesc* desc, int* firstVirtualSlices, int tripletCount, IlmObstruction* obstructions, int obstructionCount, IlmHeightVolume* volumes, int volumeCount, float* polygonXy, int polygonVertexCount);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_gbuffer_create (ulong ctx, int width, int height, int format, ulong* outGbuffer);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_gbuffer_upload (ulong gbuffer, void* texels);

@@ -22,7 +22,7 @@ STRUCTS = {
     "IlmAreaParams": abi.AreaParams, "IlmGravityParams": abi.GravityParams, "IlmFMAParams": abi.FMAParams,
     "IlmNoiseParams": abi.NoiseParams, "IlmSpawnParams": abi.SpawnParams, "IlmUpdateParams": abi.UpdateParams,
     "IlmTransformOp": abi.TransformOp, "IlmSpawnRecord": abi.SpawnRecord, "IlmStepDesc": abi.StepDesc, "IlmRenderStats": abi.RenderStats,
-    "IlmMatrixMultiplyParams": abi.MatrixMultiplyParams, "IlmSpatialNoiseParams": abi.SpatialNoiseParams, "IlmFeedbackParams": abi.FeedbackParams, "IlmPatternParams": abi.PatternParams, "IlmRasterizeParams": abi.RasterizeParams,
+    "IlmMatrixMultiplyParams": abi.MatrixMultiplyParams, "IlmSdfTraceInfo": abi.SdfTraceInfo, "IlmSpatialNoiseParams": abi.SpatialNoiseParams, "IlmFeedbackParams": abi.FeedbackParams, "IlmPatternParams": abi.PatternParams, "IlmRasterizeParams": abi.RasterizeParams,
     "IlmParticleLightParams": abi.ParticleLightParams,
     "IlmReadbackDrawCall": abi.ReadbackDrawCall, "IlmReadbackParams": abi.ReadbackParams, "IlmHDRConfiguration": abi.HDRConfiguration,
     "IlmGBufferRenderDesc": abi.GBufferRenderDesc,

@@ -214,10 +214,37 @@ def test_the_trace_follows_the_atlas_when_it_changes(ctx, oracle, sfmt):
         want, ostats = oracle.render_sphere_lights(lights, env, dfu, None, oracle.make_texture(generated, sfmt), amb, w, h, want_stats=True)
         assert stats.SdfSamples == ostats.SdfSamples, "after ilm_sdf_render_slices (seed %d)" % seed
         assert_close(lm.download(), want, "after ilm_sdf_render_slices (seed %d)" % seed)
-    # a field whose device pointer was handed out is re-read before every frame
+    # ONE slice triplet regenerated (the reference's cadence: MaximumFieldUpdatesPerFrame = 1, LightingRenderer.Configuration.cs:91): the
+    # frame follows, and only the cells of that triplet and of the slice below it were re-derived (a cell of slice v holds the pairs (v, v + 1))
+    n_slices = layout.slice_count
+    assert gen.trace_info().TableSlices == n_slices and gen.trace_info().CellBytes > 0
+    obs = scenes.obstruction_array(scenes.random_obstructions(5, 8, (256, 192), 8.0, 30.0, 40.0))
+    for first in (0, 3, n_slices - 3):
+        before = gen.trace_info().CellSlicesRebuilt
+        gen.render_slices(desc, [first], obs)
+        generated = gen.download()
+        stats = native.render_sphere_lights(ctx, lights, env, dfu, None, gen, amb, lm, want_stats=True)
+        want, ostats = oracle.render_sphere_lights(lights, env, dfu, None, oracle.make_texture(generated, sfmt), amb, w, h, want_stats=True)
+        assert stats.SdfSamples == ostats.SdfSamples, "after one triplet (%d)" % first
+        assert_close(lm.download(), want, "after one triplet (%d)" % first)
+        info = gen.trace_info()
+        assert info.LastRebuiltSlices == (3 if first == 0 else 4) and info.CellSlicesRebuilt - before == info.LastRebuiltSlices
+        assert info.LastRebuiltSlices * 33 <= 4 * max(n_slices, 33) or n_slices < 33
+    native.render_sphere_lights(ctx, lights, env, dfu, None, gen, amb, lm)
+    assert gen.trace_info().LastRebuiltSlices == 0                     # nothing changed: the cells are kept
+    # a field whose device pointer was handed out is re-read before every frame ...
     assert sdf.device_ptr() != 0
     sdf.upload(atlas_a)
     assert check(atlas_a, "after the pointer escaped") == s_a
+    assert sdf.trace_info().RebuiltEveryFrame == 1 and sdf.trace_info().LastRebuiltSlices == n_slices
+    check(atlas_a, "escaped, unchanged")
+    assert sdf.trace_info().LastRebuiltSlices == n_slices
+    # ... until the caller reports its writes itself (ilm_sdf_mark_dirty)
+    sdf.mark_dirty(3, 3)
+    assert check(atlas_a, "after ilm_sdf_mark_dirty") == s_a
+    assert sdf.trace_info().RebuiltEveryFrame == 0 and sdf.trace_info().LastRebuiltSlices == 4
+    check(atlas_a, "reported, unchanged")
+    assert sdf.trace_info().LastRebuiltSlices == 0
     gen.close(); lm.close(); sdf.close()
 
 
