@@ -2136,14 +2136,13 @@ namespace {
 // counter, idle XCDs complete the others' last runs; exact for any dispatch order, 88 light tests green -- 0.601 | 8.56 against
 // 0.600 | 8.53: nothing, and taken out again.
 // Default: 4 with M = 6.
+// (function-local statics initialised by a lambda: thread-safe, contexts may be driven from different threads)
 int light_tile_map() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("ILM_LIGHT_TILE_MAP"); v = e ? atoi(e) : 4; }
+    static const int v = [] { const char* e = getenv("ILM_LIGHT_TILE_MAP"); return e ? atoi(e) : 4; }();
     return v;
 }
 int light_tile_macro() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("ILM_LIGHT_TILE_MACRO"); v = e ? atoi(e) : 6; if (v < 1) v = 1; }
+    static const int v = [] { const char* e = getenv("ILM_LIGHT_TILE_MACRO"); const int m = e ? atoi(e) : 6; return m < 1 ? 1 : m; }();
     return v;
 }
 // Light split: how many workgroups serve a tile of this launch (LightLaunch::split / taper, lighting.hip).
@@ -2790,8 +2789,7 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
         c->light_cap = cap;
     }
     if (light_count > 0) {
-        static int in_place = -1;
-        if (in_place < 0) { const char* e = getenv("ILM_LIGHTS_IN_PLACE"); in_place = e ? atoi(e) : 1; }
+        static const int in_place = [] { const char* e = getenv("ILM_LIGHTS_IN_PLACE"); return e ? atoi(e) : 1; }();
         if (in_place) {
             // the vertices are read where the host left them (pinned ring): prepare_lights_kernel is their only reader
             const void* staged = nullptr; int slot = 0;

@@ -1562,10 +1562,14 @@ static bool needs_extended_variant(const StepLaunch& a) {
 // slice 0 with a z weight of 0 (hlsl_math.hpp sample_distance_field<.., SLICE0>) -- what the reference's particle path binds.
 constexpr int kFieldSlice0 = 2;
 static_assert((ILM_SDF_UNORM16 | ILM_SDF_FP16) == 1, "the format is bit 0 of the collision kernels' first template argument");
-static bool field_is_slice0(const IlmDistanceFieldUniforms& df) {
-    static int enabled = -1;
-    if (enabled < 0) { const char* e = getenv("ILM_DF_SLICE0"); enabled = e ? atoi(e) : 1; }
-    return enabled && (df.Packed1.y == 0.0f) && std::isfinite(df.Packed1.x) && std::isfinite(df.Packed1.z);
+// The slice-0 sampler returns the bilinear fetch of channel r where the general one forms lerp(lo, hi, 0) = fma(0, hi - lo, lo): equal
+// for FINITE texels only, so it serves UNORM16 fields (every code is finite); an FP16 atlas uploaded through ilm_sdf_upload may hold
+// inf / NaN (hi = inf gives NaN in the general form and in the oracle) and keeps the general sampler.  The uniforms whose fma(0, ., .)
+// terms the slice-0 form drops (Packed1.x, .z, TextureSliceAndTexelSize.xy) must be finite for the same reason.
+static bool field_is_slice0(const IlmDistanceFieldUniforms& df, int format) {
+    static const int enabled = [] { const char* e = getenv("ILM_DF_SLICE0"); return e ? atoi(e) : 1; }();
+    return enabled && (format == ILM_SDF_UNORM16) && (df.Packed1.y == 0.0f) && std::isfinite(df.Packed1.x) && std::isfinite(df.Packed1.z) &&
+           std::isfinite(df.TextureSliceAndTexelSize.x) && std::isfinite(df.TextureSliceAndTexelSize.y);
 }
 template <bool SPAWN>
 static hipError_t launch_step_variant(const StepLaunch& a, hipStream_t stream) {
@@ -1575,7 +1579,7 @@ static hipError_t launch_step_variant(const StepLaunch& a, hipStream_t stream) {
         const int upb = (kStepThreads / 64) * kUnitsPerWave;
         const dim3 g((unsigned)((units + upb - 1) / upb), 1, 1), b(kStepThreads, 1, 1);
         if (a.desc.UpdateMode == ILM_UPDATE_WITH_DISTANCE_FIELD) {
-            switch ((int)a.sdf.format | (field_is_slice0(a.desc.DistanceField) ? kFieldSlice0 : 0)) {
+            switch ((int)a.sdf.format | (field_is_slice0(a.desc.DistanceField, (int)a.sdf.format) ? kFieldSlice0 : 0)) {
                 case ILM_SDF_FP16: hipLaunchKernelGGL((step_kernel<ILM_SDF_FP16, true, true, 1, true>), g, b, 0, stream, a); break;
                 case ILM_SDF_UNORM16: hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, true, true, 1, true>), g, b, 0, stream, a); break;
                 case ILM_SDF_FP16 | kFieldSlice0: hipLaunchKernelGGL((step_kernel<ILM_SDF_FP16 | kFieldSlice0, true, true, 1, true>), g, b, 0, stream, a); break;
@@ -1595,7 +1599,7 @@ static hipError_t launch_step_variant(const StepLaunch& a, hipStream_t stream) {
     const dim3 grid((unsigned)((units + units_per_block - 1) / units_per_block), 1, 1), block(kStepThreads, 1, 1);
     if (a.desc.UpdateMode == ILM_UPDATE_WITH_DISTANCE_FIELD) {
         // waves per SIMD requested for the collision variants (ILM_DF_MINW; measured in DESIGN 3.1)
-        switch ((int)a.sdf.format | (field_is_slice0(a.desc.DistanceField) ? kFieldSlice0 : 0)) {
+        switch ((int)a.sdf.format | (field_is_slice0(a.desc.DistanceField, (int)a.sdf.format) ? kFieldSlice0 : 0)) {
             case ILM_SDF_FP16: hipLaunchKernelGGL((step_kernel<ILM_SDF_FP16, true, SPAWN, ILM_DF_MINW>), grid, block, 0, stream, a); break;
             case ILM_SDF_UNORM16: hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, true, SPAWN, ILM_DF_MINW>), grid, block, 0, stream, a); break;
             case ILM_SDF_FP16 | kFieldSlice0: hipLaunchKernelGGL((step_kernel<ILM_SDF_FP16 | kFieldSlice0, true, SPAWN, ILM_DF_MINW>), grid, block, 0, stream, a); break;

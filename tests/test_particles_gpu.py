@@ -276,6 +276,41 @@ def test_update_with_distance_field_matches_oracle(ctx, oracle, rnd, fmt, packed
     sdf.close(); sysm.close(); eng.close()
 
 
+@pytest.mark.parametrize("packed1", [True, False])
+def test_update_with_distance_field_over_non_finite_fp16_texels(ctx, oracle, rnd, packed1):
+    """An FP16 atlas uploaded through ilm_sdf_upload may hold inf / NaN.  With the particle path's uniforms (DistanceFieldPacked1 = 0) the
+    general sampler forms lerp(lo, hi, 0) = fma(0, hi - lo, lo): NaN where hi is infinite, which a sampler that returns `lo` would miss --
+    FP16 fields therefore never take the slice-0 sampler (particles.hip field_is_slice0).  Kernel and oracle must agree slot by slot,
+    NaN for NaN."""
+    cs = 64
+    n = cs * cs
+    layout, atlas, dfu = cfg1_field(abi.SDF_FP16, packed1)
+    atlas = atlas.copy()
+    sw, sh = layout.slice_width, layout.slice_height
+    atlas[40:90, 60:120, 1] = 0x7C00                 # +inf in channel g (virtual slice 1) of physical slice 0: `hi` of every slice-0 lookup there
+    atlas[100:140, 30:70, 0] = 0xFC00                # -inf in channel r (virtual slice 0): `lo`
+    atlas[150:170, 150:200, :2] = 0x7E00             # NaN in both
+    assert sw >= 200 and sh >= 170
+    pos, vel, attr = scenes.make_particles(611, n, pos_lo=(0, 0, 0), pos_hi=(256, 256, 8), dead_fraction=0.05, life=(0.5, 6.0))
+    su = scenes.system_uniforms(cs, friction=0.1, max_velocity=2048.0, life_decay=1.2, collision=(128.0, 0.6, 0.33, 0.05))
+    up = update_params(1)
+    eng, sysm = make_system(ctx, rnd, cs)
+    sdf = native.DistanceFieldTexture(ctx, atlas, abi.SDF_FP16)
+    sysm.set_distance_field(sdf)
+    upload_state(sysm, 0, pos, vel, attr)
+    sysm.update(0, su, up, df=dfu)
+    got = download_state(sysm, 0)
+    want = [pos.copy(), vel.copy(), attr.copy(), np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)]
+    oracle.update(want[0], want[1], want[2], want[3], want[4], cs, su, up, df=dfu, sdf=oracle.make_texture(atlas, abi.SDF_FP16))
+    assert np.array_equal(np.isnan(got[0]), np.isnan(want[0])) and np.array_equal(np.isnan(got[1]), np.isnan(want[1]))
+    assert np.array_equal(live_mask(got[0]), live_mask(want[0]))
+    finite = np.isfinite(want[0]).all(axis=1) & np.isfinite(want[1]).all(axis=1)
+    assert 0.5 < finite.mean() < 1.0 or not packed1          # the patches were hit, and most of the chunk was not
+    for k, name in enumerate(("position", "velocity")):
+        assert_close(got[k][finite], want[k][finite], "update-df over non-finite texels: %s" % name, life_exact=(k == 0))
+    sdf.close(); sysm.close(); eng.close()
+
+
 def test_update_with_distance_field_requires_field(ctx, rnd):
     eng, sysm = make_system(ctx, rnd, 64)
     layout, atlas, dfu = cfg1_field()
