@@ -578,6 +578,25 @@ int32_t ilm_group_lightmap_set_strips(IlmHandle h, const int32_t* row_begins, co
         m->end[(size_t)r] = row_ends[r];
     }
     m->equal_slots = equal;
+    // One process per GPU: every rank sizes its ncclSend / ncclRecv from its own copy of the table, so two ranks with different tables
+    // would exchange mismatched byte counts (a hang, or rows in the wrong place).  The call is a collective there: the ranks compare a
+    // hash of the table (one 8-byte host all-gather, once per installation) and all fail with ILM_ERR_STATE if they disagree.
+    Group* g = m->group;
+    if (g->rank_mode && g->world > 1) {
+        uint64_t hash = 1469598103934665603ull;             // FNV-1a over (begin, end) in rank order
+        for (int r = 0; r < world; r++)
+            for (const int v : { m->begin[(size_t)r], m->end[(size_t)r] })
+                for (int b = 0; b < 4; b++) { hash ^= (uint64_t)((v >> (8 * b)) & 0xFF); hash *= 1099511628211ull; }
+        std::vector<uint64_t> all((size_t)world, 0);
+        all[(size_t)g->first_rank] = hash;
+        const int32_t rc = host_all_gather(g, &all[(size_t)g->first_rank], all.data(), sizeof(uint64_t));
+        if (rc != ILM_OK) return rc;
+        for (int r = 0; r < world; r++)
+            if (all[(size_t)r] != hash) {
+                ilm_group_lightmap_set_strips(h, nullptr, nullptr);       // (local: back to the equal slots every rank has)
+                return api_fail(ILM_ERR_STATE, "rank %d installed a different strip table than rank %d: every rank must pass the same strips", r, g->first_rank);
+            }
+    }
     return ILM_OK;
 }
 
