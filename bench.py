@@ -48,15 +48,35 @@ TRACE_LOOP_WEIGHTED = {"fp16": 46.0, "unorm16": 42.0}
 INFINITY_CACHE_MB = 256
 
 
+def kernel_sources_sha256():
+    """sha256 over the kernel sources (illuminant_amd/csrc/*.hip, *.hpp and the Makefile), in name order: what a PMC profile is a profile OF."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "illuminant_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.hpp")) + [os.path.join(d, "Makefile")]):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def _newest_pmc_rows():
     """Rows of the NEWEST committed rocprofv3 PMC summary (profiles/*_pmc.csv, written by tools/profile_bench.sh on the SAME bench
     command).  Only the newest file counts: a kernel that is missing from it (renamed, rewritten since) has no profile, and a figure
-    from an older round's kernel would be a wrong figure."""
+    from an older round's kernel would be a wrong figure.  Since r04 the summary carries the sha256 of the kernel sources it was taken
+    from (<tag>_pmc.meta.json): when the tree's sources differ -- a kernel was edited after the profile -- the profile is not used at all
+    (the per-wave instruction counts and traffic figures derived from it would describe another kernel) and the fractions read null."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.csv")))
     if not files:
         return [], None
+    meta = files[-1][:-4] + ".meta.json"
+    if os.path.exists(meta):
+        try:
+            if json.load(open(meta)).get("kernel_sources_sha256") != kernel_sources_sha256():
+                return [], os.path.basename(files[-1]) + " (stale: the kernel sources changed since)"
+        except (OSError, ValueError):
+            return [], None
     return list(csv.DictReader(open(files[-1]))), os.path.basename(files[-1])
 
 

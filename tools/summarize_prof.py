@@ -69,6 +69,11 @@ def main():
             for k in sorted(agg):
                 n = max(v[0] for v in agg[k].values())
                 w.writerow([k, n] + list(meta[k]) + ["%.1f" % (agg[k][c][1] / agg[k][c][0]) if c in agg[k] else "" for c in counters])
+        # what the counters are counters OF: bench.py uses the profile only while the tree's kernel sources hash to this
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        with open(os.path.join(out, "%s_pmc.meta.json" % tag), "w") as f:
+            json.dump({"kernel_sources_sha256": bench.kernel_sources_sha256(), "tag": tag}, f)
         lines += ["## PMC counters (median dispatch of each kernel; separate passes, `--kernel-trace --pmc <set>`)", ""]
         for k in sorted(agg):
             if "ilm::" not in k:
