@@ -602,6 +602,23 @@ def main():
                 packed = [abi.LightVertex.from_buffer_copy(H.LightingRenderer.PackSphereLightBytes(lsrc, 1.0, True)) for lsrc in L["env"].Lights]
                 glm.set_strips(sharding.balanced_row_strips(h, world, packed))
                 row_begin, row_end = glm.strips[rank]
+                # ... then re-cut from what the strips COST: two rounds of every rank timing its own strip (HIP events), the times
+                # all-gathered (every rank computes the same table: set_strips is a collective that checks it), new cuts at equal
+                # measured cost (sharding.rebalance_row_strips).  The footprint model cannot see the obstacle field.
+                strip_history = [{"strips": [list(s_) for s_ in glm.strips], "how": "footprint model"}]
+                for round_ in range(2):
+                    for _ in range(2):
+                        r.RenderLighting(1.0, row_begin, row_end, False)
+                    barrier()
+                    ctx.TimerStart()
+                    for _ in range(4):
+                        r.RenderLighting(1.0, row_begin, row_end, False)
+                    mine = ctx.TimerStop() / 4.0
+                    times = [struct.unpack("<d", b)[0] for b in group.host_all_gather(struct.pack("<d", mine))]
+                    strip_history[-1]["ms"] = [round(t, 4) for t in times]
+                    glm.set_strips(sharding.rebalance_row_strips(glm.strips, times, h))
+                    row_begin, row_end = glm.strips[rank]
+                    strip_history.append({"strips": [list(s_) for s_ in glm.strips], "how": "measured, round %d" % (round_ + 1)})
             if group is None and os.environ.get("ILM_BENCH_STRIP"):
                 # EXPERIMENT (tools/ab_tilemap.sh): one GPU renders strip k of n equal bands only -- what a rank of an n-GPU frame launches
                 spec = os.environ["ILM_BENCH_STRIP"]
@@ -666,6 +683,7 @@ def main():
             lighting[name] = {
                 "lit_mpixels_per_s": round(w * h / (frame_ms * 1e-3) / 1e6, 2),
                 "ms_per_frame": round(frame_ms, 4), "timed_frames": light_frames, "rows": [int(row_begin), int(row_end)],
+                "strip_balancing": strip_history if group is not None else None,
                 "sdf_samples_per_frame": samples_total,
                 "pixel_light_pairs_this_rank": pairs_local, "traced_pairs_this_rank": traced_local,
                 "field_generation": L["field_generation"],

@@ -109,6 +109,40 @@ def balanced_row_strips(height, world, lights, align=TILE_ROWS):
     return [(min(cuts[r] * align, height), min(cuts[r + 1] * align, height)) for r in range(world)]
 
 
+def rebalance_row_strips(strips, seconds, height, align=TILE_ROWS):
+    """The strips cut again from what they COST: `seconds[r]` = the time rank r's strip took (any unit).  The footprint model of
+    balanced_row_strips cannot see the obstacle field (a ray in the open takes a few long steps, one along a wall dozens) and leaves the
+    strips of cfg5 7-9 % apart; a frame or two of measured times bring them within ~2 %.  The cost of a row is taken as constant inside
+    its current strip (time / rows); the new cuts are where the cumulative cost passes r / world of the total, on `align`-row bands.
+    Every rank must pass the same `seconds` (gather them first): the table is part of the exchange protocol."""
+    world = len(strips)
+    assert len(seconds) == world
+    bands = (height + align - 1) // align
+    band_cost = np.zeros(bands, dtype=np.float64)
+    for (b, e), t in zip(strips, seconds):
+        rows = max(e - b, 0)
+        if rows == 0:
+            continue
+        per_row = max(float(t), 0.0) / rows
+        for band in range(b // align, (e + align - 1) // align):
+            r0, r1 = max(b, band * align), min(e, (band + 1) * align)
+            band_cost[band] += per_row * max(r1 - r0, 0)
+    if not (band_cost.sum() > 0):
+        return list(strips)
+    prefix = np.concatenate([[0.0], np.cumsum(band_cost)])
+    total = prefix[-1]
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r / world
+        b = int(np.searchsorted(prefix, target, side="left"))
+        if b > 0 and abs(prefix[b - 1] - target) <= abs(prefix[min(b, bands)] - target):
+            b -= 1
+        b = min(max(b, cuts[-1]), bands)
+        cuts.append(b)
+    cuts.append(bands)
+    return [(min(cuts[r] * align, height), min(cuts[r + 1] * align, height)) for r in range(world)]
+
+
 def all_gather_rows(full, strips, rank, dist):
     """In-place all-gather of row strips of `full` (a (H, W, C) torch tensor every rank holds; rank r has rendered
     rows strips[r]).  Equal strips use one all_gather_into_tensor straight into `full`; unequal strips are

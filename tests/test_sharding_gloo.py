@@ -45,6 +45,28 @@ def test_balanced_strips_follow_the_lights():
     assert bal[0][1] < eq[0][1]
 
 
+def test_strips_recut_from_measured_times():
+    """rebalance_row_strips: contiguous whole-band strips covering the frame, equal cost under the piecewise-constant model it assumes
+    (so a second pass with the model's own prediction changes nothing), strips that took longer get shorter."""
+    h, world = 2160, 8
+    strips = sharding.row_strips(h, world)
+    seconds = [1.0, 1.2, 1.3, 1.5, 1.6, 1.4, 1.1, 0.9]
+    cut = sharding.rebalance_row_strips(strips, seconds, h)
+    assert cut[0][0] == 0 and cut[-1][1] == h and all(a[1] == b[0] for a, b in zip(cut[:-1], cut[1:]))
+    assert all(b % 16 == 0 for b, _ in cut) and all(e > b for b, e in cut)
+    density = np.zeros(h)
+    for (b, e), t in zip(strips, seconds):
+        density[b:e] = t / (e - b)
+    predicted = [density[b:e].sum() for b, e in cut]
+    assert max(predicted) / min(predicted) < 1.08           # equal up to the 16-row granularity
+    assert (cut[4][1] - cut[4][0]) < (strips[4][1] - strips[4][0]) and (cut[7][1] - cut[7][0]) > (strips[7][1] - strips[7][0])
+    again = sharding.rebalance_row_strips(cut, predicted, h)
+    assert max(abs(a[0] - b[0]) for a, b in zip(again, cut)) <= 16
+    # degenerate inputs: no time measured, one rank
+    assert sharding.rebalance_row_strips(strips, [0.0] * world, h) == strips
+    assert sharding.rebalance_row_strips([(0, h)], [3.0], h) == [(0, h)]
+
+
 def test_chunk_ownership_is_a_partition():
     for n in (0, 1, 7, 16, 64):
         for world in (1, 2, 8):

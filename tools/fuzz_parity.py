@@ -43,8 +43,21 @@ for seed in range(first, first + count):
     env = scenes.environment()
     sdf = native.DistanceFieldTexture(ctx, atlas, fmt)
     lm = native.Lightmap(ctx, w, h, abi.LIGHTMAP_FLOAT4)
+    # (r04) the light split: chosen per launch / forced to 1, 2, 4, 8 workgroups per tile, and the frame in one launch or in three strips that
+    # start on arbitrary rows -- none of it may change a statistic, and the strips must reproduce the one-launch frame bit for bit
+    split = (0, 1, 2, 4, 8)[seed % 5]
+    ctx.set_light_split(split)
     st = native.render_sphere_lights(ctx, lights, env, dfu, None, sdf, (0.05, 0.05, 0.05, 1.0), lm, want_stats=True)
     got = lm.download()
+    if seed % 3 == 0:
+        cuts = sorted(set([0, h] + [int(v) for v in np.random.default_rng(seed + 99).integers(1, h, 2)]))
+        ctx.set_light_split((8, 0, 2, 4, 1)[seed % 5])
+        lm.clear()
+        for b0, b1 in zip(cuts[:-1], cuts[1:]):
+            native.render_sphere_lights(ctx, lights, env, dfu, None, sdf, (0.05, 0.05, 0.05, 1.0), lm, b0, b1)
+        if not np.array_equal(lm.download(), got):
+            bad_light.append((seed, "strips under another split differ from the one-launch frame", cuts))
+    ctx.set_light_split(0)
     want, ost = oracle.render_sphere_lights(lights, env, dfu, None, oracle.make_texture(atlas, fmt), (0.05, 0.05, 0.05, 1.0), w, h, 0, h, want_stats=True)
     lm.close(); sdf.close()
     e = float((np.abs(got - want) / np.maximum(np.abs(want), 1.0)).max())

@@ -84,10 +84,27 @@ def main():
             same_strips = bool(np.array_equal(ref.download(), whole_bits))
             print("%s split=%s whole %.4f ms   bits: whole %s, strips %s" % (name, split if split else "auto", t_whole, "equal" if same_whole else "DIFFER",
                                                                          "equal" if same_strips else "DIFFER"), flush=True)
+            def measure(table):
+                return [timed(ctx, lambda b=b, e=e: native.render_sphere_lights(ctx, lights, env, dfu, gb, sdf, ambient, lm, b, e), args.frames) for (b, e) in table]
+
+            def show(kind, table, ts):
+                print("%s split=%s %-9s strips: %s   max %.4f  sum %.4f  (whole / %d = %.4f)  rows %s" % (
+                    name, split if split else "auto", kind, " ".join("%.4f" % t for t in ts), max(ts), sum(ts), args.ranks, t_whole / args.ranks,
+                    " ".join(str(e - b) for (b, e) in table)), flush=True)
             for kind, table in tables.items():
-                ts = [timed(ctx, lambda b=b, e=e: native.render_sphere_lights(ctx, lights, env, dfu, gb, sdf, ambient, lm, b, e), args.frames) for (b, e) in table]
-                print("%s split=%s %-8s strips: %s   max %.4f  sum %.4f  (whole / %d = %.4f)" % (
-                    name, split if split else "auto", kind, " ".join("%.4f" % t for t in ts), max(ts), sum(ts), args.ranks, t_whole / args.ranks), flush=True)
+                ts = measure(table)
+                show(kind, table, ts)
+            # cost-balanced by MEASUREMENT: the footprint model's strips re-cut from the times just measured (what an N-rank run does
+            # with the ranks' own strip times, sharding.rebalance_row_strips), twice
+            table, ts = tables["balanced"], measure(tables["balanced"])
+            for round_ in (1, 2):
+                table = sharding.rebalance_row_strips(table, ts, h)
+                ts = measure(table)
+                show("measured%d" % round_, table, ts)
+            ref.clear()
+            for (b, e) in table:
+                native.render_sphere_lights(ctx, lights, env, dfu, gb, sdf, ambient, ref, b, e)
+            assert np.array_equal(ref.download(), whole_bits), "re-cut strips changed the frame"
         for x in (lm, ref, sdf):
             x.close()
         if gb is not None:
