@@ -92,7 +92,7 @@ struct Ctx {
     // light split (plan_light_split): the tiles' per-part sums and their tickets
     float4* d_light_partials = nullptr; size_t light_partials_tiles = 0; uint32_t* d_light_tickets = nullptr; size_t light_tickets_cap = 0;
     int light_split = 0;                  // ilm_ctx_set_light_split: 0 = chosen per launch, else 1 / 2 / 4 / 8
-    uint16_t* d_group_order = nullptr; int group_order_cap = 0;
+    uint16_t* d_group_order = nullptr; int group_order_cap = 0; uint64_t group_order_key = 0; int group_order_groups = 0;
     // particle lights: records compacted on the device + their count, block counts, per-chunk quad counts
     void* d_pl_recs = nullptr; int pl_cap = 0; int32_t* d_pl_count = nullptr; int32_t* d_pl_blocks = nullptr; int pl_blocks_cap = 0;
     int32_t* d_pl_quads = nullptr; int pl_quads_cap = 0;
@@ -2232,19 +2232,39 @@ int32_t plan_light_split(Ctx* c, LightLaunch* a) {
     return ILM_OK;
 }
 
-// EXPERIMENT (ILM_LIGHT_GROUP_ORDER=1): the groups of tiles dealt out heaviest first -- a short launch's tail is the work that starts last.
-// Cost of a group = summed area of the lights' footprint boxes inside it (host arithmetic on the frame's light vertices).
+// The groups of tiles dealt out heaviest first (r04).  Cost of a group = summed area of the lights' footprint boxes inside it (host
+// arithmetic on the frame's light vertices, redone only when the lights, the view or the rows change).  A whole cfg5 frame (920 groups):
+// 8.85 -> 8.69 ms, three A/B pairs on one box (-1.8 %); cfg3's 240 groups and the strips of either frame do not respond, so launches
+// of fewer than ILM_LIGHT_GROUP_ORDER_MIN groups (default 512) keep the row-major deal.  ILM_LIGHT_GROUP_ORDER=0 switches it off, =1 on
+// for every launch.  (r03 had measured "heaviest first" as a loss: that was single TILES sorted, which tears neighbours apart; whole
+// 6 x 6 groups keep the locality and only change which group an XCD takes next.)
 int light_group_order_env() {
-    static const int v = [] { const char* e = getenv("ILM_LIGHT_GROUP_ORDER"); return e ? atoi(e) : 0; }();
+    static const int v = [] { const char* e = getenv("ILM_LIGHT_GROUP_ORDER"); return e ? atoi(e) : -1; }();
+    return v;
+}
+int light_group_order_min() {
+    static const int v = [] { const char* e = getenv("ILM_LIGHT_GROUP_ORDER_MIN"); return e ? atoi(e) : 512; }();
     return v;
 }
 int32_t plan_group_order(Ctx* c, LightLaunch* a, const IlmLightVertex* lights, int light_count, int group_edge_px) {
     a->group_order = nullptr;
-    if (!light_group_order_env() || a->tile_map != 4 || light_count <= 0) return ILM_OK;
+    const int mode = light_group_order_env();
+    if (mode == 0 || a->tile_map != 4 || light_count <= 0) return ILM_OK;
     const int rows = a->row_end - a->row_begin;
     const int gx = (a->width + group_edge_px - 1) / group_edge_px, gy = (rows + group_edge_px - 1) / group_edge_px;
     const int groups = gx * gy;
-    if (groups < 2 || groups > 65535) return ILM_OK;
+    if (groups < 2 || groups > 65535 || (mode < 0 && groups < light_group_order_min())) return ILM_OK;
+    // the same lights over the same rows through the same view: the table on the device is still right
+    {
+        uint64_t key = 1469598103934665603ull;
+        auto mix = [&](const void* p, size_t n) { const unsigned char* b = static_cast<const unsigned char*>(p); for (size_t i = 0; i < n; i++) { key ^= b[i]; key *= 1099511628211ull; } };
+        mix(lights, sizeof(IlmLightVertex) * (size_t)light_count);
+        mix(&a->env, sizeof(a->env));
+        const int32_t geom[5] = { a->width, a->row_begin, a->row_end, group_edge_px, light_count };
+        mix(geom, sizeof(geom));
+        if (c->d_group_order && c->group_order_key == key && c->group_order_groups == groups) { a->group_order = c->d_group_order; return ILM_OK; }
+        c->group_order_key = key; c->group_order_groups = groups;
+    }
     std::vector<double> cost((size_t)groups, 0.0);
     const float sx = a->env.GBufferTexelSizeAndMisc.z * a->env.ZAndScale.z, sy = a->env.GBufferTexelSizeAndMisc.w * a->env.ZAndScale.w;
     for (int i = 0; i < light_count; i++) {
