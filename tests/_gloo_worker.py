@@ -100,6 +100,25 @@ def check_lighting(rank, world):
         assert np.array_equal(full2.numpy(), want), "range exchange differs from the single-process frame"
 
 
+    # bench.py's N > 1 path re-cuts the strips from what they cost: every rank times its own strip, the times are all-gathered, every
+    # rank computes the same table (sharding.rebalance_row_strips) -- here the "time" of a strip is the oracle's SDF-sample count over it
+    strips = sharding.balanced_row_strips(h, world, lights)
+    for _ in range(2):
+        b, e = strips[rank]
+        _, st = orc.render_sphere_lights(lights, env, dfu, None, tex, ambient, w, h, row_begin=b, row_end=e, want_stats=True)
+        mine = torch.tensor([float(st.SdfSamples)], dtype=torch.float64)
+        everyone = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(everyone, mine)
+        strips = sharding.rebalance_row_strips(strips, [float(t[0]) for t in everyone], h)
+        assert strips[0][0] == 0 and strips[-1][1] == h and all(strips[r][1] == strips[r + 1][0] for r in range(world - 1))
+    b, e = strips[rank]
+    part, _ = orc.render_sphere_lights(lights, env, dfu, None, tex, ambient, w, h, row_begin=b, row_end=e)
+    full3 = torch.zeros((h, w, 4), dtype=torch.float32)
+    full3[b:e] = torch.from_numpy(part[b:e])
+    sharding.exchange_row_ranges(full3, strips, rank, dist)
+    assert np.array_equal(full3.numpy(), want), "the frame over re-cut strips differs from the single-process frame"
+
+
 def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
