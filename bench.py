@@ -979,7 +979,7 @@ def main():
         out["config"]["workload"] = "cfg4: %d particles per GPU in 8 chunks of 1024^2 (64 M on 8 GPUs), Gravity(4 attractors)+Noise+UpdatePositions" % c4h["particles_per_gpu"]
         out["config"]["particles_per_gpu"] = c4h["particles_per_gpu"]
         out["config"]["parallelism"] = ("particles: chunk c on rank c mod %d, no data-path collective; lit frame: cost-balanced row strips of whole 16-row bands "
-                                        "(balanced_row_strips), range exchange over RCCL send/recv" % world)
+                                        "(balanced_row_strips, then re-cut twice from the ranks' measured strip times: rebalance_row_strips), range exchange over RCCL send/recv" % world)
 
     # The driver keeps the parsed keys and the LAST ~2000 characters of the line: the bulky rows go first, the two rooflines, the CPU
     # baseline and a compact summary of both hot paths last.
