@@ -7,7 +7,10 @@
 // is one workgroup: wave 0 bins the lights whose raster footprint touches the
 // tile into an LDS list (wave64 ballot + popcount, light order preserved), then
 // every thread decodes its G-buffer texel once and walks the list, accumulating
-// in fp32 registers and storing the lightmap texel once.
+// in fp32 registers and storing the lightmap texel once.  The sum runs over eight
+// index-defined parts of the light list combined as a tree, so that several
+// workgroups can share a tile without changing a bit (r04: "the order of the sum"
+// in sphere_lights_kernel; short launches end tapered, api.hip plan_light_split).
 //
 // Per-light constants (footprint rectangles, cone config, premultiplied colour)
 // are prepared once per call by prepare_lights_kernel and fetched through the

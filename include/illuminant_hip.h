@@ -742,9 +742,11 @@ int32_t ilm_ctx_set_lightmap_blend(IlmHandle ctx, int32_t mode);
  * Illuminant/Shaders/SphereLight.fx:42-45): the sum does not care who shaded which light.  Here a tile's list is summed in 8 fixed
  * parts -- each part in light order, the parts onto the clear colour in part order -- and `workgroups` = 1, 2, 4 or 8 says how many
  * workgroups share those parts; the lightmap's bits do not depend on it.  0 (default) = chosen per launch: 1 for launches that fill the
- * device several times over (whole frames), more for short ones (one rank's strip of a frame split over 8 GPUs), where a launch would
- * otherwise last two wave lifetimes whatever its share of the work.  Launches in the ILM_BLEND_FP16_PER_LIGHT model, of more than 1 024
- * lights, or of particle lights always use 1. */
+ * device several times over (whole frames); short ones (one rank's strip of a frame split over 8 GPUs, a small target), which would
+ * otherwise last two wave lifetimes whatever their share of the work, are TAPERED -- the tiles that start first are served whole, later
+ * ones by 2, then 4, the last by 8 workgroups, so that the launch drains in its smallest pieces.  A non-zero value
+ * serves every tile by that many.  Launches in the ILM_BLEND_FP16_PER_LIGHT model, of fewer than 16 or more than 1 024 lights, or of
+ * particle lights always use 1. */
 int32_t ilm_ctx_set_light_split(IlmHandle ctx, int32_t workgroups);
 
 /* ---- particle lights and light probes --------------------------------------------------------- */
