@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define ILM_ABI_VERSION 6
+/* 7 (r04): + ilm_ctx_set_light_split, ilm_sdf_mark_dirty, ilm_sdf_trace_info / IlmSdfTraceInfo; ilm_group_lightmap_set_strips became a
+ * collective with one process per GPU.  Nothing was removed or changed in layout since 6. */
+#define ILM_ABI_VERSION 7
 
 /* ---- return codes ------------------------------------------------------ */
 #define ILM_OK                    0

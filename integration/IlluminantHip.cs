@@ -1,6 +1,6 @@
 // IlluminantHip.cs -- P/Invoke layer of libilluminant_hip.so for sq/Illuminant (drop into Illuminant/Native/).
 // GENERATED from include/illuminant_hip.h by tools/gen_csharp_binding.py -- do not edit; the header carries the documentation
-// and the reference file:line each entry point replaces.  ABI version 6.
+// and the reference file:line each entry point replaces.  ABI version 7.
 //
 // Vector4 / Matrix are XNA's; LightVertex is Illuminant/Vertices.cs:10-39; the Uniforms.* structs of the reference
 // (Uniforms.cs:14-24,79-88,197-236; Bezier.cs:433-441,588-599) have the byte layout of the Ilm* mirrors below and can be passed
@@ -16,7 +16,7 @@ namespace Squared.Illuminant.Native {
     }
 
     public static class IlmConstants {
-        public const int ABI_VERSION = 6;
+        public const int ABI_VERSION = 7;
         public const int BLEND_FP16_PER_LIGHT = 1;
         public const int BLEND_FP32_ACCUMULATE = 0;
         public const int ERR_INVALID_ARGUMENT = -1;
