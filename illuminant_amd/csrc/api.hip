@@ -2145,6 +2145,18 @@ int light_tile_macro() {
     static const int v = [] { const char* e = getenv("ILM_LIGHT_TILE_MACRO"); const int m = e ? atoi(e) : 6; return m < 1 ? 1 : m; }();
     return v;
 }
+int light_split_target_waves();
+// ... and per launch: SHORT launches (at most ILM_LIGHT_SPLIT_WAVES tile-kernel waves: the ones that end tapered) are dealt in groups of
+// 4 x 4 tiles instead of 6 x 6 -- a strip of a 4K frame is 120 groups of 6 x 6, fifteen per XCD, and the XCDs end several per cent
+// apart; with 4 x 4 groups (264 of them) cfg5's eight cost-balanced strips take 10.0 ms summed instead of 10.3, 1.31 instead of 1.36
+// at most (3 x 3: 10.0 | 1.33, 2 x 2: 10.0 | 1.33; r04, tools/strip_probe.py).  Whole frames keep 6 (4: 8.86 against 8.69 ms).
+// ILM_LIGHT_TILE_MACRO, when set, is used for every launch.
+int light_tile_macro_for(int width, int rows) {
+    static const bool forced = getenv("ILM_LIGHT_TILE_MACRO") != nullptr;
+    if (forced || rows <= 0 || width <= 0) return light_tile_macro();
+    const int64_t waves = (int64_t)((width + kLightTile - 1) / kLightTile) * (int64_t)((rows + kLightTile - 1) / kLightTile) * (kLightTileThreads / 64);
+    return (waves <= (int64_t)light_split_target_waves()) ? 4 : light_tile_macro();
+}
 // Light split: how many workgroups serve a tile of this launch (LightLaunch::split / taper, lighting.hip).
 // A wave of the light pass lives as long as its pixels' lights take, one after the other (~0.5 ms on cfg5, ~0.15 on cfg3), and the chip
 // holds 8 192 of them: a launch of only a generation or two -- one rank's strip of a frame split over 8 GPUs is 16 320 waves on cfg5, 4 080
@@ -2156,7 +2168,7 @@ int light_tile_macro() {
 // meets the others at the ticket: whole cfg5 frames 8.8 ms at K = 1, 9.1 at 2, 10.6 at 4, 11.5 at 8.  So the split is TAPERED: the
 // tiles an XCD starts first are served whole, later ones by 2, then 4, the last by 8 workgroups -- the drain is made of the shortest
 // waves, the overhead is paid on the part of the launch that needs it.  On cfg5's cost-balanced strips (one GPU standing in for each
-// of 8 ranks, tools/strip_probe.py): at most 1.65 ms and 12.0 ms summed untouched, 1.44 | 10.8 at K = 2 throughout, 1.34 | 10.2 tapered.
+// of 8 ranks, tools/strip_probe.py): at most 1.65 ms and 12.0 ms summed untouched, 1.44 | 10.8 at K = 2 throughout, 1.36 | 10.3 tapered, 1.31 | 10.0 tapered in 4 x 4 groups.
 //   chosen per launch: launches of at most one device fill split every tile (2 | 4 | 8 by halves), up to ILM_LIGHT_SPLIT_WAVES waves
 //   (default 24 576, three fills) the second half tapers 2 | 4 | 8, longer ones (whole frames) are not split.
 //   ILM_LIGHT_SPLIT = 1 / 2 / 4 / 8 or ilm_ctx_set_light_split force one K for every tile; ILM_LIGHT_TAPER = f1,f2,f3 forces the taper.
@@ -2332,7 +2344,7 @@ int32_t fill_light_launch(Ctx* c, const IlmEnvironment* env, const IlmDistanceFi
     a->ramp = RampView{ nullptr, 0, 0 };      // particle lights have no ramp technique (LightingRenderer.cs:176-178)
     a->blend_fp16 = (c->lightmap_blend == ILM_BLEND_FP16_PER_LIGHT) ? 1 : 0;
     a->tile_map = light_tile_map();
-    a->tile_macro = light_tile_macro();
+    a->tile_macro = light_tile_macro_for(m->width, row_end - row_begin);
     a->split = 1; a->partials = nullptr; a->tickets = nullptr; a->group_order = nullptr;
     return ILM_OK;
 }
@@ -2841,7 +2853,7 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
     a.ramp = RampView{ c->d_light_ramp, c->light_ramp_w, c->light_ramp_h };
     a.blend_fp16 = (c->lightmap_blend == ILM_BLEND_FP16_PER_LIGHT) ? 1 : 0;
     a.tile_map = light_tile_map();
-    a.tile_macro = light_tile_macro();
+    a.tile_macro = light_tile_macro_for(m->width, row_end - row_begin);
     if (stats) {
         HIP_TRY(hipMemsetAsync(c->d_stats, 0, 3 * sizeof(unsigned long long), c->main()));
         a.stats = c->d_stats;
