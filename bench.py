@@ -234,6 +234,30 @@ def build_particle_system(H, ctx, scenes, abi, chunk_size, n_chunks, rank, with_
     return dict(engine=engine, ps=ps, tp=tp, live=n, transforms=(sp, gr, nz), rnd=rnd, init=(pos, vel, attr))
 
 
+def gbuffer_meshes_scene():
+    """SURVEY 8f-1's bench frame: 1080p, 256 height volumes (top + front faces) and 64 billboards, as the vertex arrays a host hands over
+    (float32 rows of HeightVolumeVertex / BillboardVertex).  Returns (desc, top, front, billboards)."""
+    from illuminant_amd import scenes
+    r16 = scenes.uniform(77, (256, 8))
+    tops, fronts = [], []
+    vols = []
+    for v in range(256):
+        cx, cy, rad = 40 + r16[v, 0] * 1840, 80 + r16[v, 1] * 960, 12 + r16[v, 2] * 50
+        nv = 4 + int(r16[v, 3] * 4)
+        ang = np.sort(scenes.uniform(770 + v, (nv,)) * 2 * np.pi)
+        vols.append(([(cx + rad * np.cos(a), cy + rad * np.sin(a)) for a in ang], r16[v, 4] * 8, 6 + r16[v, 5] * 70))
+    for poly, zb, hh in sorted(vols, key=lambda t: -(t[1] + t[2])):
+        tops.append(scenes.top_face_mesh(poly, zb, hh))
+        fronts.append(scenes.front_face_mesh(poly, zb, hh))
+    top, front = np.concatenate(tops), np.concatenate(fronts)
+    rb = scenes.uniform(78, (64, 4))
+    bbv = scenes.billboard_vertices([dict(screen_bounds=((rb[k, 0] * 1800, rb[k, 1] * 960), (rb[k, 0] * 1800 + 24 + rb[k, 2] * 60, rb[k, 1] * 960 + 40 + rb[k, 3] * 80)))
+                                     for k in range(64)], 0.0, 0.6)
+    so, zso = scenes.self_occlusion_hacks(0.25, 128.0, 33)
+    gd = scenes.gbuffer_mesh_desc(z_to_y=0.6, extent_z=128.0, self_occlusion_hack=so, z_self_occlusion_hack=zso)
+    return gd, np.ascontiguousarray(top, np.float32), np.ascontiguousarray(front, np.float32), np.ascontiguousarray(bbv, np.float32)
+
+
 def build_lighting(H, ctx, scenes, abi, width, height, n_lights, resolution, world, sdf_fmt, external_ptr=0, plain_twin=False):
     """The configured frame: EnableGBuffer is the reference's default (LightingRenderer.Configuration.cs:106) and SURVEY 8d defines cfg3 /
     cfg5 with the ground-plane G-buffer (texel (0.5, 1, 0, 1), Vector4 = 16 B per pixel: highQualityGBuffer defaults to true,
@@ -891,31 +915,15 @@ def main():
         if not args.no_next_rows and world == 1:
             # 2.5D G-buffer from the host's meshes: 1080p, 256 height volumes (top + front faces) and 64 billboards
             nctx = native.Context(local_rank, borrowed_handle=ctx.Handle)
-            r16 = scenes.uniform(77, (256, 8))
-            tops, fronts = [], []
-            vols = []
-            for v in range(256):
-                cx, cy, rad = 40 + r16[v, 0] * 1840, 80 + r16[v, 1] * 960, 12 + r16[v, 2] * 50
-                nv = 4 + int(r16[v, 3] * 4)
-                ang = np.sort(scenes.uniform(770 + v, (nv,)) * 2 * np.pi)
-                vols.append(([(cx + rad * np.cos(a), cy + rad * np.sin(a)) for a in ang], r16[v, 4] * 8, 6 + r16[v, 5] * 70))
-            for poly, zb, hh in sorted(vols, key=lambda t: -(t[1] + t[2])):
-                tops.append(scenes.top_face_mesh(poly, zb, hh))
-                fronts.append(scenes.front_face_mesh(poly, zb, hh))
-            top, front = np.concatenate(tops), np.concatenate(fronts)
-            rb = scenes.uniform(78, (64, 4))
-            bbv = scenes.billboard_vertices([dict(screen_bounds=((rb[k, 0] * 1800, rb[k, 1] * 960), (rb[k, 0] * 1800 + 24 + rb[k, 2] * 60, rb[k, 1] * 960 + 40 + rb[k, 3] * 80)))
-                                             for k in range(64)], 0.0, 0.6)
-            so, zso = scenes.self_occlusion_hacks(0.25, 128.0, 33)
-            gd = scenes.gbuffer_mesh_desc(z_to_y=0.6, extent_z=128.0, self_occlusion_hack=so, z_self_occlusion_hack=zso)
+            gd, top, front, bbv = gbuffer_meshes_scene()
             gbt = native.GBufferTexture(nctx, None, abi.GBUFFER_FLOAT4, size=(1920, 1080))
             gruns = [(None, 0, 64, abi.BILLBOARD_MASK)]
             gbt.render_meshes(gd, top, front, bbv, gruns)
             nctx.sync()
             nctx.timer_start()
-            for _ in range(10):
+            for _ in range(50):
                 gbt.render_meshes(gd, top, front, bbv, gruns)
-            gb_ms = nctx.timer_stop() / 10
+            gb_ms = nctx.timer_stop() / 50
             tris = 2 + len(top) // 3 + len(front) // 3 + 128
             px = 1920 * 1080
             next_rows["gbuffer_2p5d_1080p"] = {

@@ -377,8 +377,8 @@ int32_t ensure_staging(Ctx* c, size_t bytes) {
     return ILM_OK;
 }
 
-// copy a small host block to the device through the pinned ring (asynchronous)
-int32_t upload_small(Ctx* c, void* dst, const void* src, size_t bytes) {
+// the next slot of the pinned ring, free and at least `bytes` large: the caller fills *host and calls upload_small_commit
+int32_t upload_small_begin(Ctx* c, size_t bytes, void** host, int* slot_out) {
     const int slot = c->ring_pos;
     c->ring_pos = (c->ring_pos + 1) % Ctx::kRing;
     if (c->pinned_ev[slot] == nullptr)
@@ -392,10 +392,24 @@ int32_t upload_small(Ctx* c, void* dst, const void* src, size_t bytes) {
         HIP_TRY(hipHostMalloc(&c->pinned[slot], cap, hipHostMallocDefault));
         c->pinned_bytes[slot] = cap;
     }
-    memcpy(c->pinned[slot], src, bytes);
+    *host = c->pinned[slot];
+    *slot_out = slot;
+    return ILM_OK;
+}
+int32_t upload_small_commit(Ctx* c, void* dst, int slot, size_t bytes) {
     HIP_TRY(hipMemcpyAsync(dst, c->pinned[slot], bytes, hipMemcpyHostToDevice, c->main()));
     HIP_TRY(hipEventRecord(c->pinned_ev[slot], c->main()));
     return ILM_OK;
+}
+
+// copy a small host block to the device through the pinned ring (asynchronous)
+int32_t upload_small(Ctx* c, void* dst, const void* src, size_t bytes) {
+    void* host = nullptr;
+    int slot = -1;
+    const int32_t rc = upload_small_begin(c, bytes, &host, &slot);
+    if (rc != ILM_OK) return rc;
+    memcpy(host, src, bytes);
+    return upload_small_commit(c, dst, slot, bytes);
 }
 
 // The same ring, read in place: `src` is copied into a pinned slot and the slot's device-visible address is returned; the caller queues the
@@ -2001,7 +2015,16 @@ int32_t ilm_gbuffer_render_meshes(IlmHandle h, const IlmGBufferMeshDesc* d,
     const size_t off_tex = align64(off_quads + sizeof(int4) * quads.size());
     const size_t inputs = align64(off_tex + sizeof(GBufferTex) * textures.size()) + 64;
     const size_t off_bounds = inputs + align64(sizeof(GBufferPrim) * (size_t)prim_count);
-    const size_t total = off_bounds + sizeof(int4) * (size_t)prim_count;
+    // coarse bins: 64 x 64 pixel blocks, doubled until the blocks' lists (one slot per triangle each) fit the budget
+    int block_shift = 6;
+    auto blocks_at = [&](int shift) { return (size_t)((g->width + (1 << shift) - 1) >> shift) * (size_t)((g->height + (1 << shift) - 1) >> shift); };
+    while (blocks_at(block_shift) > 1 && blocks_at(block_shift) * (size_t)prim_count * sizeof(int32_t) > kGBufferBlockListBudget)
+        block_shift++;
+    const size_t block_count = blocks_at(block_shift);
+    const size_t off_verts = align64(off_bounds + sizeof(int4) * (size_t)prim_count);
+    const size_t off_block_count = align64(off_verts + 2 * sizeof(int4) * (size_t)prim_count);
+    const size_t off_block_list = align64(off_block_count + sizeof(int32_t) * block_count);
+    const size_t total = off_block_list + sizeof(int32_t) * block_count * (size_t)prim_count;
     if (total > c->field_params_bytes) {
         HIP_TRY(hipStreamSynchronize(c->main()));
         if (c->d_field_params) HIP_TRY(hipFree(c->d_field_params));
@@ -2010,13 +2033,17 @@ int32_t ilm_gbuffer_render_meshes(IlmHandle h, const IlmGBufferMeshDesc* d,
         HIP_TRY(hipMalloc(&c->d_field_params, cap));
         c->field_params_bytes = cap;
     }
-    std::vector<unsigned char> block(inputs, 0);
-    if (top_vertex_count) memcpy(block.data(), top_vertices, sizeof(IlmHeightVolumeVertex) * (size_t)top_vertex_count);
-    if (front_vertex_count) memcpy(block.data() + off_front, front_vertices, sizeof(IlmHeightVolumeVertex) * (size_t)front_vertex_count);
-    if (billboard_vertex_count) memcpy(block.data() + off_bb, billboard_vertices, sizeof(IlmBillboardVertex) * (size_t)billboard_vertex_count);
-    if (!quads.empty()) memcpy(block.data() + off_quads, quads.data(), sizeof(int4) * quads.size());
-    if (!textures.empty()) memcpy(block.data() + off_tex, textures.data(), sizeof(GBufferTex) * textures.size());
-    int32_t rc = upload_small(c, c->d_field_params, block.data(), inputs);
+    // the frame's inputs are gathered straight into a pinned slot of the ring (one host copy) and go to the device as one block
+    unsigned char* block = nullptr;
+    int slot = -1;
+    int32_t rc = upload_small_begin(c, inputs, reinterpret_cast<void**>(&block), &slot);
+    if (rc != ILM_OK) return rc;
+    if (top_vertex_count) memcpy(block, top_vertices, sizeof(IlmHeightVolumeVertex) * (size_t)top_vertex_count);
+    if (front_vertex_count) memcpy(block + off_front, front_vertices, sizeof(IlmHeightVolumeVertex) * (size_t)front_vertex_count);
+    if (billboard_vertex_count) memcpy(block + off_bb, billboard_vertices, sizeof(IlmBillboardVertex) * (size_t)billboard_vertex_count);
+    if (!quads.empty()) memcpy(block + off_quads, quads.data(), sizeof(int4) * quads.size());
+    if (!textures.empty()) memcpy(block + off_tex, textures.data(), sizeof(GBufferTex) * textures.size());
+    rc = upload_small_commit(c, c->d_field_params, slot, inputs);
     if (rc != ILM_OK) return rc;
     char* base = static_cast<char*>(c->d_field_params);
     GBufferMeshLaunch a;
@@ -2029,6 +2056,11 @@ int32_t ilm_gbuffer_render_meshes(IlmHandle h, const IlmGBufferMeshDesc* d,
     a.textures = reinterpret_cast<const GBufferTex*>(base + off_tex);
     a.prims = reinterpret_cast<GBufferPrim*>(base + inputs); a.prim_count = (int32_t)prim_count;
     a.bounds = reinterpret_cast<int4*>(base + off_bounds);
+    a.verts = reinterpret_cast<int4*>(base + off_verts);
+    a.block_shift = block_shift;
+    a.block_cols = (g->width + (1 << block_shift) - 1) >> block_shift; a.block_rows = (g->height + (1 << block_shift) - 1) >> block_shift;
+    a.block_count = reinterpret_cast<int32_t*>(base + off_block_count);
+    a.block_list = reinterpret_cast<int32_t*>(base + off_block_list);
     HIP_TRY(launch_gbuffer_meshes(a, c->main()));
     return ILM_OK;
 }

@@ -4,10 +4,12 @@
 //
 // The reference hands triangle lists to the Direct3D rasteriser, one draw call after the other into one render target with a 24-bit
 // depth buffer.  Here the whole frame is ONE pass over the pixels: a setup kernel runs the three vertex shaders and snaps every
-// triangle to the 1/256-pixel grid (one thread per triangle, records in draw order); the raster kernel bins the records per 16 x 16
-// pixel tile into an ordered list in LDS, gives every wave an 8 x 8 quarter of the tile, walks the list with wave-uniform (scalar)
-// loads of the records, and keeps each pixel's colour and depth in registers until its single store -- 16 B (or 8 B) written per
-// texel, nothing read back, no atomics, and the reference's draw order is the loop order.  Coverage is exact integer arithmetic (64-bit edge functions, top-left
+// triangle to the 1/256-pixel grid (one thread per triangle, records in draw order); a binning kernel lists, per 64 x 64 pixel block,
+// the triangles whose pixel bounds touch it; the raster kernel gives every wave an 8 x 8 pixel square, reads its block's list 64
+// entries at a time (one candidate per lane: bounds and vertices), and walks the candidates that touch the square in list order --
+// vertices out of the lanes' registers, attributes through wave-uniform (scalar) loads only for a triangle that covers a pixel -- and
+// keeps each pixel's colour and depth in registers until its single store: 16 B (or 8 B) written per texel, nothing read back, no
+// atomics, and the reference's draw order is the loop order.  Coverage is exact integer arithmetic (64-bit edge functions, top-left
 // rule), so a pixel belongs to exactly one of two triangles sharing an edge, as on the hardware.
 #include "internal.hpp"
 #include "hlsl_math.hpp"
@@ -30,12 +32,58 @@ ILM_DEV int64_t edge(int32_t ax, int32_t ay, int32_t bx, int32_t by, int64_t px,
     return ((int64_t)bx - ax) * (py - ay) - ((int64_t)by - ay) * (px - ax);
 }
 
+// a * b for numbers within 24 signed bits: the full-rate 24-bit multiplier's two halves instead of a 64 x 64 product
+ILM_DEV int64_t mul_i24(int32_t a, int32_t b) {
+    const int32_t a24 = (int32_t)((uint32_t)a << 8) >> 8, b24 = (int32_t)((uint32_t)b << 8) >> 8;
+    return (int64_t)a24 * (int64_t)b24;
+}
+
+// how the raster kernel decides a record's coverage (GBufferPrim::kind keeps the pixel shader; these ride above it in `verts`)
+constexpr int kShapeRect = 0x100;      // an axis-aligned rectangle whose pixels ARE its pixel bounds (the ground plane's two triangles as one record)
+constexpr int kShapeSmall = 0x200;     // every coordinate and every pixel centre of the frame within +-2^22: the edge functions' factors fit 24 bits
+
 // top-left rule on a clockwise triangle (y down): top edges run left to right, left edges run upwards
 ILM_DEV bool edge_owns(int32_t ax, int32_t ay, int32_t bx, int32_t by) { return (by < ay) || ((by == ay) && (bx > ax)); }
+
+// encodeNormalSpherical, EnvironmentCommon.fxh:33-40; encodeGBufferSample, GBufferShaderCommon.fxh:10-35 (fullbright = false)
+ILM_DEV void encode_normal(f3 n, float* ex, float* ey) {
+    *ex = 0.0f; *ey = 0.0f;
+    if ((n.x != 0.0f) || (n.y != 0.0f) || (n.z != 0.0f)) {
+        const float nx = (fabsf(n.x) < 0.0001f) ? 0.0001f : n.x;
+        *ex = ((atan2f(n.y, nx) / kPi) + 1.0f) * 0.5f;
+        *ey = (n.z + 1.0f) * 0.5f;
+    }
+}
+ILM_DEV float4 encode_sample(float ex, float ey, float relative_y, float z, bool dead, bool enable_shadows) {
+    if (dead)
+        return mk4(0.0f, 0.0f, -ref::kDeadTexel, -ref::kDeadTexel);
+    const float w = (((z + ref::kGBufferZOffset) / ref::kGBufferZScale) * (enable_shadows ? 1.0f : -1.0f)) + (enable_shadows ? 0.0f : -1.0f);
+    return mk4(ex, ey, relative_y, w);
+}
+
+constexpr int kFlatNormalBit = 16;                              // GBufferPrim::flat: enc_x / enc_y hold the triangle's encoded normal
+
+// An attribute with the same finite value v at the three vertices interpolates to (v + 0 f1) + 0 f2 = v + 0 at every covered pixel
+// (f1, f2 are finite and not negative there), whatever the weights: the raster kernel skips the weights for a triangle of such
+// attributes only -- the ground plane, every frame -- and takes a flat normal's encoding from here.
+ILM_DEV void finish_attributes(GBufferPrim& p) {
+    p.flat = 0; p.enc_x = 0.0f; p.enc_y = 0.0f;
+    for (int k = 0; k < kGBufferAttrs; k++) {
+        const uint32_t b0 = __float_as_uint(p.a[0][k]), b1 = __float_as_uint(p.a[1][k]), b2 = __float_as_uint(p.a[2][k]);
+        if ((b0 == b1) && (b0 == b2) && ((b0 & 0x7F800000u) != 0x7F800000u))
+            p.flat |= 1 << k;
+    }
+    if ((p.kind == kGround) || (((p.flat >> 3) & 7) == 7 && ((p.kind == kTop) || (p.kind == kFace)))) {
+        const f3 n = (p.kind == kGround) ? mk3(0.0f, 0.0f, 1.0f) : mk3(p.a[0][3] + 0.0f, p.a[0][4] + 0.0f, p.a[0][5] + 0.0f);
+        encode_normal(n, &p.enc_x, &p.enc_y);
+        p.flat |= 1 << kFlatNormalBit;
+    }
+}
 
 ILM_DEV void finish(GBufferPrim& p, const float sx[3], const float sy[3]) {
     for (int k = 0; k < 3; k++) { p.x[k] = snap(sx[k]); p.y[k] = snap(sy[k]); }
     const int64_t area = edge(p.x[0], p.y[0], p.x[1], p.y[1], p.x[2], p.y[2]);
+    p.flat = 0; p.enc_x = 0.0f; p.enc_y = 0.0f;
     if (area == 0) { p.kind = -1; p.i0 = p.j0 = 1; p.i1 = p.j1 = 0; return; }
     if (area < 0) {                                              // CullMode.None: the other winding is drawn too
         int32_t t = p.x[1]; p.x[1] = p.x[2]; p.x[2] = t;
@@ -47,6 +95,7 @@ ILM_DEV void finish(GBufferPrim& p, const float sx[3], const float sy[3]) {
     // pixel centres 256 i + 128 inside [x0, x1]
     p.i0 = (int32_t)(((int64_t)x0 - 128 + 255) >> 8); p.i1 = (int32_t)(((int64_t)x1 - 128) >> 8);
     p.j0 = (int32_t)(((int64_t)y0 - 128 + 255) >> 8); p.j1 = (int32_t)(((int64_t)y1 - 128) >> 8);
+    finish_attributes(p);
 }
 
 // GroundPlaneVertexShader / HeightVolumeVertexShader / HeightVolumeFaceVertexShader, GBuffer.fx:7-55
@@ -98,20 +147,6 @@ ILM_DEV void billboard_prim(GBufferPrim& p, int kind, int texture, const IlmBill
     finish(p, sx, sy);
 }
 
-// encodeNormalSpherical, EnvironmentCommon.fxh:33-40; encodeGBufferSample, GBufferShaderCommon.fxh:10-35 (fullbright = false)
-ILM_DEV float4 encode_sample(f3 n, float relative_y, float z, bool dead, bool enable_shadows) {
-    if (dead)
-        return mk4(0.0f, 0.0f, -ref::kDeadTexel, -ref::kDeadTexel);
-    float ex = 0.0f, ey = 0.0f;
-    if ((n.x != 0.0f) || (n.y != 0.0f) || (n.z != 0.0f)) {
-        const float nx = (fabsf(n.x) < 0.0001f) ? 0.0001f : n.x;
-        ex = ((atan2f(n.y, nx) / kPi) + 1.0f) * 0.5f;
-        ey = (n.z + 1.0f) * 0.5f;
-    }
-    const float w = (((z + ref::kGBufferZOffset) / ref::kGBufferZScale) * (enable_shadows ? 1.0f : -1.0f)) + (enable_shadows ? 0.0f : -1.0f);
-    return mk4(ex, ey, relative_y, w);
-}
-
 // tex2D through the POINT / CLAMP sampler (LightingRenderer.GBuffer.cs:301-307); nothing bound reads (0, 0, 0, 1)
 ILM_DEV float4 sample_point(const GBufferTex* textures, int index, float u, float v) {
     if (index < 0)
@@ -144,20 +179,31 @@ __global__ __launch_bounds__(64) void gbuffer_setup_kernel(const GBufferMeshLaun
     GBufferPrim p;
     const IlmGBufferMeshDesc& d = a.desc;
     const int quad_indices[6] = { 0, 1, 3, 1, 2, 3 };           // QuadIndices, LightingRenderer.cs:421-423
+    int shape = 0;
     if (t < 2) {
-        // RenderGroundPlane, LightingRenderer.GBuffer.cs:271-299
+        // RenderGroundPlane, LightingRenderer.GBuffer.cs:271-299: the quad's two triangles.  They carry the same attributes at every
+        // corner and share the diagonal, so together they cover -- under the top-left rule: left and top edge in, right and bottom edge
+        // out, every pixel of the diagonal in exactly one of them -- the pixels whose centres the snapped rectangle holds.  Record 0 is
+        // that rectangle (the raster kernel compares pixel indices instead of evaluating six edge functions with 2^30-sized corners
+        // under every pixel of every frame); record 1 is empty.
         const float gz = d.GroundZ + (d.RenderGroundPlane ? 0.0f : ref::kGroundLift);
         const float e = ref::kGroundHalfExtent;
         const float cx[4] = { -e, e, e, -e }, cy[4] = { -e, -e, e, e };
         IlmHeightVolumeVertex g[3];
         for (int k = 0; k < 3; k++) {
-            const int c = quad_indices[3 * t + k];
+            const int c = quad_indices[k];                       // corners 0, 1, 3: (x0, y0), (x1, y0), (x0, y1) of the rectangle
             g[k].Position[0] = cx[c]; g[k].Position[1] = cy[c]; g[k].Position[2] = gz;
             g[k].Normal[0] = 0.0f; g[k].Normal[1] = 0.0f; g[k].Normal[2] = 1.0f;
             g[k].ZRange[0] = d.GroundZ; g[k].ZRange[1] = d.GroundZ;
             g[k].EnableShadows = d.EnableGroundShadows ? 1.0f : 0.0f;
         }
         volume_prim(p, kGround, g[0], g[1], g[2], d);
+        const bool drawn = (t == 0) && (p.kind == kGround) && (p.x[0] == p.x[2]) && (p.y[0] == p.y[1]);
+        const int32_t x0 = p.x[0], x1 = p.x[1], y0 = p.y[0], y1 = p.y[2];
+        p.i0 = (int32_t)(((int64_t)x0 - 128 + 255) >> 8); p.i1 = (int32_t)(((int64_t)x1 - 128 + 255) >> 8) - 1;
+        p.j0 = (int32_t)(((int64_t)y0 - 128 + 255) >> 8); p.j1 = (int32_t)(((int64_t)y1 - 128 + 255) >> 8) - 1;
+        shape = kShapeRect;
+        if (!drawn || (p.i1 < p.i0) || (p.j1 < p.j0)) { p.kind = -1; p.i0 = p.j0 = 1; p.i1 = p.j1 = 0; shape = 0; }
     } else if (t < 2 + a.top_triangles) {
         const IlmHeightVolumeVertex* v = a.top + 3 * (size_t)(t - 2);
         volume_prim(p, d.TwoPointFiveD ? kTop : kGround, v[0], v[1], v[2], d);
@@ -173,92 +219,165 @@ __global__ __launch_bounds__(64) void gbuffer_setup_kernel(const GBufferMeshLaun
     }
     a.prims[t] = p;
     a.bounds[t] = make_int4(p.i0, p.i1, p.j0, p.j1);
+    a.verts[2 * (size_t)t] = make_int4(p.x[0], p.y[0], p.x[1], p.y[1]);
+    const int32_t reach = 1 << 22;
+    bool small = (a.width <= 16384) && (a.height <= 16384);
+    for (int k = 0; k < 3; k++)
+        small = small && (p.x[k] > -reach) && (p.x[k] < reach) && (p.y[k] > -reach) && (p.y[k] < reach);
+    if ((shape == 0) && small) shape = kShapeSmall;
+    a.verts[2 * (size_t)t + 1] = make_int4(p.x[2], p.y[2], (p.kind < 0) ? -1 : (p.kind | shape), p.texture);
 }
 
-// One workgroup per 16 x 16 pixel tile, one wave per 8 x 8 quarter of it.  The workgroup first bins: 256 threads test 256 triangles'
-// pixel bounds against the tile at a time (one coalesced 16 B load each) and append the hits to a list in LDS IN DRAW ORDER (ballot +
-// popcount prefix within a wave, the waves' counts through LDS); then every wave walks the list -- typically tens of entries instead of
-// the frame's thousands -- with the record fetched through scalar loads.  A list that fills up is rasterised and refilled: the pixels'
-// state lives in registers across the rounds.
-constexpr int kBinCapacity = 4096;
+// Binning, in draw order.  gbuffer_bin_kernel: one workgroup per BLOCK of pixels (64 x 64, or larger when the frame's triangle count
+// times its block count would outgrow the scratch budget) tests every triangle's pixel bounds against the block, 1024 per round (four
+// coalesced 16 B loads in flight per thread), and appends the hits to the block's list in global memory (ballot + popcount prefix
+// within a wave, the waves' counts through LDS).  gbuffer_meshes_kernel: one workgroup per 16 x 16 pixel tile, one wave per 8 x 8
+// quarter of it; each wave filters ITS BLOCK'S list -- tens to hundreds of entries instead of the frame's thousands -- by ballot, 64
+// candidates at a time, and walks the set bits.  No list in LDS, no barrier: a tile crossed by any number of triangles is the same loop.
+constexpr int kBinRound = 1024;                                 // candidates per round: 4 per thread
+
+// appends the round's hits (thread: candidates `wave * 256 + k * 64 + lane`, k = 0..3) behind `len` entries in draw order; returns the new length
+template <typename Put>
+ILM_DEV int append_hits(const bool (&hit)[4], int lane, int wave, int len, int* s_count, Put put) {
+    uint64_t mask[4];
+    int mine = 0;
+    for (int k = 0; k < 4; k++) { mask[k] = __ballot(hit[k]); mine += __popcll(mask[k]); }
+    if (lane == 0) s_count[wave] = mine;
+    __syncthreads();
+    int before = 0, total = 0;
+    for (int w = 0; w < 4; w++) { const int c = s_count[w]; total += c; if (w < wave) before += c; }
+    int pos = len + before;
+    for (int k = 0; k < 4; k++) {
+        if (hit[k]) put(pos + __popcll(mask[k] & ((1ull << lane) - 1ull)), k);
+        pos += __popcll(mask[k]);
+    }
+    __syncthreads();
+    return len + total;
+}
+
+__global__ __launch_bounds__(256) void gbuffer_bin_kernel(const GBufferMeshLaunch a) {
+    __shared__ int s_count[4];
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const int block = (int)blockIdx.x;
+    const int lo_i = (block % a.block_cols) << a.block_shift, lo_j = (block / a.block_cols) << a.block_shift;
+    const int hi_i = lo_i + (1 << a.block_shift) - 1, hi_j = lo_j + (1 << a.block_shift) - 1;
+    int* list = a.block_list + (size_t)block * (size_t)a.prim_count;
+    int len = 0;
+    for (int next = 0; next < a.prim_count; next += kBinRound) {
+        bool hit[4];
+        int t[4];
+        for (int k = 0; k < 4; k++) {
+            t[k] = next + wave * 256 + k * 64 + lane;
+            const int4 b = a.bounds[min(t[k], a.prim_count - 1)];     // (i0, i1, j0, j1); empty for a degenerate triangle
+            hit[k] = (t[k] < a.prim_count) && (b.x <= b.y) && (b.z <= b.w) && !((b.y < lo_i) || (b.x > hi_i) || (b.w < lo_j) || (b.z > hi_j));
+        }
+        len = append_hits(hit, lane, wave, len, s_count, [&](int at, int k) { list[at] = t[k]; });
+    }
+    if (threadIdx.x == 0) a.block_count[block] = len;
+}
 
 __global__ __launch_bounds__(256) void gbuffer_meshes_kernel(const GBufferMeshLaunch a) {
-    __shared__ int s_list[kBinCapacity];
-    __shared__ int s_count[4];
     const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
     const int bi0 = (int)blockIdx.x * 16, bj0 = (int)blockIdx.y * 16;
     const int ti0 = bi0 + (wave & 1) * 8, tj0 = bj0 + (wave >> 1) * 8;                                    // wave-uniform
     const int i = ti0 + (lane & 7), j = tj0 + (lane >> 3);
-    const int64_t px = 256 * (int64_t)i + 128, py = 256 * (int64_t)j + 128;
+    const int32_t px = 256 * i + 128, py = 256 * j + 128;     // the pixel's centre on the 1/256 grid (a frame side is below 2^22 pixels)
     const IlmGBufferMeshDesc& d = a.desc;
     float4 texel = mk4(0.0f, 0.0f, 0.0f, 0.0f);                  // ClearBatch(Color.Transparent, clearZ: 0), :147-150
     uint32_t depth = 0;
     const int tile_i0 = __builtin_amdgcn_readfirstlane(ti0), tile_j0 = __builtin_amdgcn_readfirstlane(tj0);
-    int next = 0;
-    while (next < a.prim_count) {
-        int len = 0;
-        while ((next < a.prim_count) && (len + 256 <= kBinCapacity)) {
-            const int t = next + (int)threadIdx.x;
-            bool hit = false;
-            if (t < a.prim_count) {
-                const int4 b = a.bounds[t];                      // (i0, i1, j0, j1)
-                hit = !((b.y < bi0) || (b.x > bi0 + 15) || (b.w < bj0) || (b.z > bj0 + 15));
+    const int block = (bj0 >> a.block_shift) * a.block_cols + (bi0 >> a.block_shift);
+    const int* candidates = a.block_list + (size_t)block * (size_t)a.prim_count;
+    const int candidate_count = a.block_count[block];
+    for (int next = 0; next < candidate_count; next += 64) {
+        // 64 candidates at a time, one per lane: its pixel bounds against this wave's 8 x 8 pixels and its vertices for the walk
+        const int mine = candidates[min(next + lane, candidate_count - 1)];
+        const int4 bounds = a.bounds[mine];
+        const int4 v01 = a.verts[2 * (size_t)mine], v2k = a.verts[2 * (size_t)mine + 1];
+        const bool hit = (next + lane < candidate_count) &&
+                         !((bounds.y < tile_i0) || (bounds.x > tile_i0 + 7) || (bounds.w < tile_j0) || (bounds.z > tile_j0 + 7));
+        uint64_t todo = __ballot(hit);
+        while (todo != 0) {                                      // draw order: the list's order, lane by lane
+            const int from = (int)__builtin_ctzll(todo);
+            todo &= todo - 1;
+            const int t = __builtin_amdgcn_readlane(mine, from);
+            const int32_t x0 = __builtin_amdgcn_readlane(v01.x, from), y0 = __builtin_amdgcn_readlane(v01.y, from);
+            const int32_t x1 = __builtin_amdgcn_readlane(v01.z, from), y1 = __builtin_amdgcn_readlane(v01.w, from);
+            const int32_t x2 = __builtin_amdgcn_readlane(v2k.x, from), y2 = __builtin_amdgcn_readlane(v2k.y, from);
+            const int kind_and_shape = __builtin_amdgcn_readlane(v2k.z, from), kind = kind_and_shape & 0xFF;
+            int64_t w1, w2;
+            bool in;
+            if (kind_and_shape & kShapeRect) {
+                in = (i >= __builtin_amdgcn_readlane(bounds.x, from)) && (i <= __builtin_amdgcn_readlane(bounds.y, from)) &&
+                     (j >= __builtin_amdgcn_readlane(bounds.z, from)) && (j <= __builtin_amdgcn_readlane(bounds.w, from));
+                w1 = 0; w2 = 0;                                  // its attributes are flat: no weights
+            } else {
+                int64_t w0;
+                if (kind_and_shape & kShapeSmall) {
+                    const int32_t qx0 = px - x0, qy0 = py - y0, qx1 = px - x1, qy1 = py - y1, qx2 = px - x2, qy2 = py - y2;
+                    w0 = mul_i24(x2 - x1, qy1) - mul_i24(y2 - y1, qx1);
+                    w1 = mul_i24(x0 - x2, qy2) - mul_i24(y0 - y2, qx2);
+                    w2 = mul_i24(x1 - x0, qy0) - mul_i24(y1 - y0, qx0);
+                } else {
+                    w0 = edge(x1, y1, x2, y2, px, py);
+                    w1 = edge(x2, y2, x0, y0, px, py);
+                    w2 = edge(x0, y0, x1, y1, px, py);
+                }
+                in = (w0 | w1 | w2) >= 0;
+                // a centre exactly on an edge belongs to the triangle that owns the edge: rare enough to ask the wave first
+                if (__any(in && ((w0 == 0) || (w1 == 0) || (w2 == 0)))) {
+                    in = in && ((w0 != 0) || edge_owns(x1, y1, x2, y2));
+                    in = in && ((w1 != 0) || edge_owns(x2, y2, x0, y0));
+                    in = in && ((w2 != 0) || edge_owns(x0, y0, x1, y1));
+                }
             }
-            const uint64_t mask = __ballot(hit);
-            if (lane == 0) s_count[wave] = __popcll(mask);
-            __syncthreads();
-            int before = 0, total = 0;
-            for (int w = 0; w < 4; w++) { const int c = s_count[w]; total += c; if (w < wave) before += c; }
-            if (hit) s_list[len + before + __popcll(mask & ((1ull << lane) - 1ull))] = t;
-            len += total;
-            next += 256;
-            __syncthreads();
-        }
-        for (int k = 0; k < len; k++) {
-            const int t = __builtin_amdgcn_readfirstlane(s_list[k]);
-            const GBufferPrim& p = a.prims[t];
-            if ((p.i1 < tile_i0) || (p.i0 > tile_i0 + 7) || (p.j1 < tile_j0) || (p.j0 > tile_j0 + 7))
-                continue;
-            const int64_t w0 = edge(p.x[1], p.y[1], p.x[2], p.y[2], px, py);
-            const int64_t w1 = edge(p.x[2], p.y[2], p.x[0], p.y[0], px, py);
-            const int64_t w2 = edge(p.x[0], p.y[0], p.x[1], p.y[1], px, py);
-            bool in = (w0 >= 0) && (w1 >= 0) && (w2 >= 0);
-            in = in && ((w0 != 0) || edge_owns(p.x[1], p.y[1], p.x[2], p.y[2]));
-            in = in && ((w1 != 0) || edge_owns(p.x[2], p.y[2], p.x[0], p.y[0]));
-            in = in && ((w2 != 0) || edge_owns(p.x[0], p.y[0], p.x[1], p.y[1]));
             if (!in)
                 continue;
-            const double area = (double)(w0 + w1 + w2);
-            const float f1 = (float)((double)w1 / area), f2 = (float)((double)w2 / area);
+            const GBufferPrim& p = a.prims[t];                  // wave-uniform: the attributes arrive through scalar loads
+            // the weights, unless every attribute this triangle's shader reads is flat (setup kernel)
+            const int flat = p.flat;
+            const int reads = (kind == kGround) ? 0x1C4 : (((kind == kTop) || (kind == kFace)) ? 0xFC : 0x7FF);
+            // interpolated as (a0 + (a1 - a0) f1) + (a2 - a0) f2; with every attribute flat the weights are left at 0 and the same
+            // expression returns a0 + 0, as the setup kernel's note on `flat` says (one branch per triangle, not one per attribute)
+            float f1 = 0.0f, f2 = 0.0f;
+            if ((~flat & reads) != 0) {
+                const double area = (double)edge(x0, y0, x1, y1, x2, y2);       // = w0 + w1 + w2 at every pixel (wave-uniform)
+                f1 = (float)((double)w1 / area); f2 = (float)((double)w2 / area);
+            }
             auto at = [&](int k) { return (p.a[0][k] + (p.a[1][k] - p.a[0][k]) * f1) + (p.a[2][k] - p.a[0][k]) * f2; };
             // Clip against the near / far plane (w = 1).  Volumes only: a billboard's POSITION0 is a Vector2 (Vertices.cs:89), so
             // BillboardVertexShader's result.z = position.z / DistanceFieldExtent.z is 0 and never clipped -- and attribute 7 of a
             // billboard is TexCoord.y, which may leave [0, 1] (atlas sub-rectangles with a margin; the sampler clamps)
-            const int kind = p.kind;
             const float z = ((kind == kMask) || (kind == kGData)) ? 0.0f : at(7);
             if (!((z >= 0.0f) && (z <= 1.0f)))
                 continue;
-            const f3 wp = mk3(at(0), at(1), at(2));
-            const f3 n = mk3(at(3), at(4), at(5));
             float4 out;
             if (kind == kGround) {                                   // GroundPlanePixelShader, GBuffer.fx:57-70
-                if (wp.z < d.GroundZ) continue;
-                out = encode_sample(mk3(0.0f, 0.0f, 1.0f), 0.0f, wp.z, at(8) != 0.0f, at(6) > 0.5f);
+                const float wz = at(2);
+                if (wz < d.GroundZ) continue;
+                out = encode_sample(p.enc_x, p.enc_y, 0.0f, wz, at(8) != 0.0f, at(6) > 0.5f);
             } else if ((kind == kTop) || (kind == kFace)) {          // HeightVolumePixelShader :72-85 / HeightVolumeFacePixelShader :87-103
+                const float wz = at(2);
+                const f3 n = mk3(at(3), at(4), at(5));
                 f3 bias = mk3(0.0f, 0.0f, d.ZSelfOcclusionHack);
                 if (kind == kFace) {
-                    if (wp.z < d.GroundZ) continue;
+                    if (wz < d.GroundZ) continue;
                     bias = mk3(d.SelfOcclusionHack, d.SelfOcclusionHack, d.ZSelfOcclusionHack) * n;
                 }
-                const float relative_y = (((wp.z * d.ZToYMultiplier) * d.ViewportScale[0]) / d.RenderScale[0]) + bias.y;
-                out = encode_sample(n, relative_y, wp.z + bias.z, false, at(6) > 0.5f);
+                const float relative_y = (((wz * d.ZToYMultiplier) * d.ViewportScale[0]) / d.RenderScale[0]) + bias.y;
+                float ex = p.enc_x, ey = p.enc_y;
+                if (((flat >> kFlatNormalBit) & 1) == 0)
+                    encode_normal(n, &ex, &ey);
+                out = encode_sample(ex, ey, relative_y, wz + bias.z, false, at(6) > 0.5f);
                 // DepthFormat.Depth24, CompareFunction.GreaterEqual with writes (LightingRenderer.cs:539-551)
                 const uint32_t d24 = (uint32_t)floor((double)z * 16777215.0 + 0.5);
                 if (!(d24 >= depth)) continue;
                 depth = d24;
             } else {
-                const float4 data = sample_point(a.textures, p.texture, at(6), at(7));
+                const float4 data = sample_point(a.textures, __builtin_amdgcn_readlane(v2k.w, from), at(6), at(7));
                 const float data_scale = at(9);
+                const f3 wp = mk3(at(0), at(1), at(2));
+                const f3 n = mk3(at(3), at(4), at(5));
                 if (kind == kMask) {                                 // MaskBillboardPixelShader, GBufferBitmap.fx:29-59
                     const float discard_threshold = ref::kMaskDiscardNumerator / 255.0f;
                     if ((data.w - discard_threshold) < 0.0f) continue;
@@ -273,14 +392,15 @@ __global__ __launch_bounds__(256) void gbuffer_meshes_kernel(const GBufferMeshLa
                     const f3 world_normal = mk3((1.0f * tx + 0.0f * ty) + 0.0f * tz, (0.0f * tx + -1.0f * ty) + 0.0f * tz, (0.0f * tx + 0.0f * ty) + 1.0f * tz);
                     const f3 result_normal = norm3(world_normal);
                     const float effective_z = wp.z + (data.z * data_scale);
-                    out = encode_sample(result_normal, effective_z * d.ZToYMultiplier, effective_z, false, true);
+                    float ex, ey;
+                    encode_normal(result_normal, &ex, &ey);
+                    out = encode_sample(ex, ey, effective_z * d.ZToYMultiplier, effective_z, false, true);
                 } else {
                     continue;                                        // a degenerate triangle's record (empty bounds: not reached)
                 }
             }
             texel = out;
         }
-        __syncthreads();                                        // the list is rewritten by the next round
     }
     if (i >= a.width || j >= a.height) return;
     const size_t o = (size_t)j * (size_t)a.width + (size_t)i;
@@ -297,6 +417,7 @@ __global__ __launch_bounds__(256) void gbuffer_meshes_kernel(const GBufferMeshLa
 hipError_t launch_gbuffer_meshes(const GBufferMeshLaunch& a, hipStream_t stream) {
     if (a.width <= 0 || a.height <= 0) return hipSuccess;
     hipLaunchKernelGGL(gbuffer_setup_kernel, dim3((unsigned)((a.prim_count + 63) / 64)), dim3(64), 0, stream, a);
+    hipLaunchKernelGGL(gbuffer_bin_kernel, dim3((unsigned)(a.block_cols * a.block_rows)), dim3(256), 0, stream, a);
     const dim3 grid((unsigned)((a.width + 15) / 16), (unsigned)((a.height + 15) / 16)), block(256);
     hipLaunchKernelGGL(gbuffer_meshes_kernel, grid, block, 0, stream, a);
     return hipGetLastError();

@@ -277,12 +277,14 @@ hipError_t launch_render_gbuffer(const GBufferLaunch& a, hipStream_t stream);
 
 // G-buffer from the host's meshes (gbuffer.hip): one record per triangle in draw order, written by the setup kernel and read
 // wave-uniformly by the raster kernel
-constexpr int kGBufferAttrs = 12;
+constexpr int kGBufferAttrs = 11;
 struct GBufferPrim {
     int32_t x[3], y[3];           // 1/256-pixel positions, clockwise on the y-down screen
     int32_t i0, i1, j0, j1;       // pixels whose centres the bounding box holds (inclusive; empty for a degenerate triangle)
     int32_t kind, texture;        // pixel shader; index into the launch's texture table or -1
     float a[3][kGBufferAttrs];    // per-vertex attributes
+    int32_t flat;                 // bit k: attribute k is the same finite number at the three vertices (interpolation returns a[0][k] + 0)
+    float enc_x, enc_y;           // the encoded normal of a ground / top / front-face triangle whose normal is flat
 };
 struct GBufferTex { const void* texels; int32_t width, height, format, _pad; };
 struct GBufferMeshLaunch {
@@ -294,8 +296,13 @@ struct GBufferMeshLaunch {
     const int4* quads;            // (quad, texture, kind, -) per billboard quad in draw order
     const GBufferTex* textures;
     GBufferPrim* prims; int32_t prim_count;
-    int4* bounds;                 // (i0, i1, j0, j1) per record: what the binning pass reads
+    int4* bounds;                 // (i0, i1, j0, j1) per record: what the binning passes read
+    int4* verts;                  // (x0, y0, x1, y1), (x2, y2, kind, texture) per record: what a wave's coverage test reads
+    int32_t block_shift, block_cols, block_rows;   // coarse bins: blocks of (1 << block_shift)^2 pixels, a multiple of the 16 x 16 tile
+    int32_t* block_count;         // [block_cols * block_rows]
+    int32_t* block_list;          // [block_cols * block_rows][prim_count] record indices in draw order
 };
+constexpr size_t kGBufferBlockListBudget = (size_t)256 << 20;   // bytes of block lists per frame before the blocks grow
 hipError_t launch_gbuffer_meshes(const GBufferMeshLaunch& a, hipStream_t stream);
 
 // ---- output side (output.hip) ---------------------------------------------------------------------------------

@@ -134,6 +134,34 @@ def test_1080p_frame_of_2500_triangles_matches_oracle(ctx, oracle):
     gb.close()
 
 
+def test_squares_crossed_by_thousands_of_triangles(ctx, oracle):
+    """6000 small top-face triangles heaped on a 40 x 40 pixel patch (and a few far away) of a 144 x 80 frame: the patch's 64 x 64
+    block list takes six binning rounds of 1024, every 8 x 8 square of the patch walks thousands of candidates 64 at a time, and the
+    depth test (heights drawn in no order) must still see every triangle in draw order."""
+    w, h = 144, 80
+    n = 6000
+    r = scenes.uniform(91, (n, 8))
+    rows = []
+    for t in range(n):
+        far = (t % 97) == 0
+        cx, cy = (100 + r[t, 0] * 40, 50 + r[t, 1] * 28) if far else (4 + r[t, 0] * 40, 4 + r[t, 1] * 40)
+        z = float(np.float32(2 + r[t, 2] * 60))
+        size = 2 + r[t, 3] * 14
+        ang = r[t, 4] * 2 * np.pi + np.array([0.0, 2.1 + r[t, 5], 4.2 + r[t, 6]])
+        for k in range(3):
+            rows.append([cx + size * np.cos(ang[k]), cy + size * np.sin(ang[k]), z, 0.0, 0.0, 1.0, 0.0, z, 1.0 if r[t, 7] < 0.8 else 0.0])
+    top = np.asarray(rows, np.float32)
+    so, zso = scenes.self_occlusion_hacks(0.5, 64.0, 12)
+    d = scenes.gbuffer_mesh_desc(z_to_y=0.25, extent_z=64.0, self_occlusion_hack=so, z_self_occlusion_hack=zso)
+    gb = native.GBufferTexture(ctx, None, abi.GBUFFER_FLOAT4, size=(w, h))
+    gb.render_meshes(d, top)
+    got = gb.download()
+    want = oracle.render_gbuffer_meshes(w, h, d, top)
+    compare(got, want, abi.GBUFFER_FLOAT4)
+    assert (want[:48, :48, 2] > 0.0).mean() > 0.5
+    gb.close()
+
+
 def test_non_2p5d_meshes_equal_the_polygon_entry_point(ctx, oracle):
     """ilm_gbuffer_render decides top-face coverage per pixel centre against the polygon; the mesh entry point rasterises a
     triangulation of it: same picture wherever no centre sits exactly on an edge (quarter-pixel vertices, unit scale)."""
