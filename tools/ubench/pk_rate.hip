@@ -1,4 +1,4 @@
-// Run ON THE GPU BOX (built in the build container: hipcc --offload-arch=gfx950 -O3 -o tools/probes/pk_rate_probe tools/probes/pk_rate_probe.hip).
+// Run ON THE GPU BOX (built in the build container: hipcc --offload-arch=gfx950 -O3 -o tools/ubench/pk_rate tools/ubench/pk_rate.hip).
 // Issue rate of v_fma_f32 against v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32 with eight waves per SIMD: does a packed f32 instruction
 // cost one issue slot (two results per slot) or two?
 #include <hip/hip_runtime.h>
