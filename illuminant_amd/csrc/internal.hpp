@@ -352,6 +352,7 @@ struct RasterScratch {
     void* sprites = nullptr; void* counts = nullptr; void* offsets = nullptr; void* keys = nullptr; void* sorted_keys = nullptr;
     void* temp = nullptr; void* stats = nullptr; void* tiles = nullptr; void* partials = nullptr; void* rects = nullptr;
     size_t sprites_cap = 0, counts_cap = 0, offsets_cap = 0, keys_cap = 0, sorted_cap = 0, temp_cap = 0, tiles_cap = 0, partials_cap = 0, rects_cap = 0;
+    unsigned long long* host_words = nullptr;    // pinned, device-visible: [0] the frame's pair count, [1..4] its statistics (written by kernels, read after a stream sync)
 };
 hipError_t render_particles(RasterLaunch& a, RasterScratch& s, hipStream_t stream, unsigned long long out_stats[3], bool* too_many);
 void free_raster_scratch(RasterScratch& s);

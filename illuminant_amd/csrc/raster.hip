@@ -210,6 +210,48 @@ __global__ __launch_bounds__(256) void raster_tile_ranges_kernel(const RasterLau
     a.tile_multi[tile] = (segments > 1u) ? segments : 0u;
 }
 
+// Exclusive prefix sums of tile_segments (-> the tile's first work item) and tile_multi (-> its first partial slot) over the tiles + 1
+// entries, both in ONE workgroup: a thread sums a run of consecutive tiles, the runs' sums are scanned across the workgroup (shuffles
+// within a wave, the sixteen waves' totals through LDS), the thread writes its run's prefixes.  (r03: two library scans = four launches
+// of ~5 us each for 8 161 numbers.)
+__global__ __launch_bounds__(1024) void raster_tile_scan_kernel(const RasterLaunch a) {
+    __shared__ uint32_t wave_sum[2][16];
+    const int count = a.tiles_x * a.tiles_y + 1;
+    const int per = (count + 1023) / 1024;
+    const int first = min((int)threadIdx.x * per, count), last = min(first + per, count);
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    // (eight tiles at a time with all sixteen loads in flight: one thread's run is a chain of dependent cache misses otherwise)
+    uint32_t s0 = 0u, s1 = 0u;
+    for (int base = first; base < last; base += 8) {
+        uint32_t x[8], y[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int i = min(base + k, count - 1); x[k] = a.tile_segments[i]; y[k] = a.tile_multi[i]; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { if (base + k < last) { s0 += x[k]; s1 += y[k]; } }
+    }
+    uint32_t i0 = s0, i1 = s1;                                   // inclusive scan of the runs' sums within the wave
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t t0 = __shfl_up(i0, off), t1 = __shfl_up(i1, off);
+        if (lane >= off) { i0 += t0; i1 += t1; }
+    }
+    if (lane == 63) { wave_sum[0][wave] = i0; wave_sum[1][wave] = i1; }
+    __syncthreads();
+    uint32_t e0 = i0 - s0, e1 = i1 - s1;
+    for (int w = 0; w < wave; w++) { e0 += wave_sum[0][w]; e1 += wave_sum[1][w]; }
+    for (int base = first; base < last; base += 8) {
+        uint32_t x[8], y[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { const int i = min(base + k, count - 1); x[k] = a.tile_segments[i]; y[k] = a.tile_multi[i]; }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (base + k < last) {
+                a.tile_first_item[base + k] = e0; e0 += x[k];
+                a.tile_first_partial[base + k] = e1; e1 += y[k];
+            }
+        }
+    }
+}
+
 // PS_NoTexture + the blend, RasterizeParticleSystem.fx:150-163,228-241: one workgroup per work item (a tile, or a segment of a
 // crowded tile's run), one lane per pixel.
 // The sprites come 256 at a time: thread t fetches sprite t of the batch into LDS and tests its bounding box against the four
@@ -448,9 +490,23 @@ void free_raster_scratch(RasterScratch& s) {
     void** ptrs[] = { &s.sprites, &s.counts, &s.offsets, &s.keys, &s.sorted_keys, &s.temp, &s.stats, &s.tiles, &s.partials, &s.rects };
     for (void** p : ptrs) { if (*p) (void)hipFree(*p); *p = nullptr; }
     s.sprites_cap = s.counts_cap = s.offsets_cap = s.keys_cap = s.sorted_cap = s.temp_cap = s.tiles_cap = s.partials_cap = s.rects_cap = 0;
+    if (s.host_words) (void)hipHostFree(s.host_words);
+    s.host_words = nullptr;
 }
 
-// setup -> scan -> emit -> sort -> tiles.  One host synchronisation (the pair count sizes the key buffers).
+// the frame's pair count (and, at the end, its statistics) reach the host through a pinned word the kernel writes: one stream
+// synchronisation, no staged device-to-host copies (two of them cost the r03 frame 55 us of idle device around 8 us of copying)
+__global__ void raster_total_kernel(const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ counts, size_t n, unsigned long long* host_word) {
+    *host_word = (unsigned long long)offsets[n - 1] + (unsigned long long)counts[n - 1];
+    __threadfence_system();
+}
+__global__ void raster_stats_kernel(const unsigned long long* __restrict__ stats, unsigned long long* host_words) {
+    for (int k = 0; k < 4; k++) host_words[k] = stats[k];
+    __threadfence_system();
+}
+
+// setup -> scan -> emit -> sort -> tiles.  One host synchronisation (the pair count sizes the key buffers): a one-thread kernel writes it to a
+// pinned word the host reads after the stream drains.
 struct SaturatingAdd {
     __host__ __device__ uint32_t operator()(uint32_t x, uint32_t y) const {
         const uint32_t sum = x + y;
@@ -480,11 +536,13 @@ hipError_t render_particles(RasterLaunch& a, RasterScratch& s, hipStream_t strea
     RASTER_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, a.counts, a.offsets, 0u, n, SaturatingAdd(), stream));
     RASTER_TRY(grow(&s.temp, &s.temp_cap, scan_bytes, stream));
     RASTER_TRY(rocprim::exclusive_scan(s.temp, scan_bytes, a.counts, a.offsets, 0u, n, SaturatingAdd(), stream));
-    uint32_t last[2] = { 0u, 0u };
-    RASTER_TRY(hipMemcpyAsync(&last[0], a.offsets + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-    RASTER_TRY(hipMemcpyAsync(&last[1], a.counts + (n - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    if (!s.host_words) RASTER_TRY(hipHostMalloc(reinterpret_cast<void**>(&s.host_words), 8 * sizeof(unsigned long long), hipHostMallocMapped));
+    unsigned long long* host_words_dev = nullptr;
+    RASTER_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&host_words_dev), s.host_words, 0));
+    hipLaunchKernelGGL(raster_total_kernel, dim3(1), dim3(1), 0, stream, a.offsets, a.counts, n, host_words_dev);
+    RASTER_TRY(hipGetLastError());
     RASTER_TRY(hipStreamSynchronize(stream));
-    const unsigned long long pairs = (unsigned long long)last[0] + (unsigned long long)last[1];
+    const unsigned long long pairs = s.host_words[0];
     // (one pair per slot and tile; 2^28 keys = 2 GiB.  The scan saturates, so a wrapped total cannot slip under this bound.)
     if (pairs > (1ull << 28)) { *too_many = true; return hipSuccess; }
     a.pair_count = (int64_t)pairs;
@@ -503,7 +561,7 @@ hipError_t render_particles(RasterLaunch& a, RasterScratch& s, hipStream_t strea
         RASTER_TRY(rocprim::radix_sort_keys(nullptr, sort_bytes, a.keys, a.sorted_keys, (size_t)pairs, 32u, (unsigned)(32 + tile_bits), stream));
         RASTER_TRY(grow(&s.temp, &s.temp_cap, sort_bytes, stream));
         RASTER_TRY(rocprim::radix_sort_keys(s.temp, sort_bytes, a.keys, a.sorted_keys, (size_t)pairs, 32u, (unsigned)(32 + tile_bits), stream));
-        // tile runs -> segments -> work items (two scans over the tiles; no host round trip: the grid is an upper bound)
+        // tile runs -> segments -> work items (both scans over the tiles in one workgroup; no host round trip: the grid is an upper bound)
         const int tiles = a.tiles_x * a.tiles_y;
         RASTER_TRY(grow(&s.tiles, &s.tiles_cap, (size_t)(tiles + 1) * 5 * sizeof(uint32_t), stream));
         a.tile_begin = static_cast<uint32_t*>(s.tiles);
@@ -513,11 +571,8 @@ hipError_t render_particles(RasterLaunch& a, RasterScratch& s, hipStream_t strea
         a.tile_first_partial = a.tile_multi + (tiles + 1);
         hipLaunchKernelGGL(raster_tile_ranges_kernel, dim3((unsigned)((tiles + 1 + 255) / 256)), block, 0, stream, a);
         RASTER_TRY(hipGetLastError());
-        size_t tscan = 0;
-        RASTER_TRY(rocprim::exclusive_scan(nullptr, tscan, a.tile_segments, a.tile_first_item, 0u, (size_t)(tiles + 1), rocprim::plus<uint32_t>(), stream));
-        RASTER_TRY(grow(&s.temp, &s.temp_cap, tscan, stream));
-        RASTER_TRY(rocprim::exclusive_scan(s.temp, tscan, a.tile_segments, a.tile_first_item, 0u, (size_t)(tiles + 1), rocprim::plus<uint32_t>(), stream));
-        RASTER_TRY(rocprim::exclusive_scan(s.temp, tscan, a.tile_multi, a.tile_first_partial, 0u, (size_t)(tiles + 1), rocprim::plus<uint32_t>(), stream));
+        hipLaunchKernelGGL(raster_tile_scan_kernel, dim3(1), dim3(1024), 0, stream, a);
+        RASTER_TRY(hipGetLastError());
         // sum over tiles of ceil(len / S) <= non-empty tiles + pairs / S; partial slots only for tiles with >= 2 segments: <= 2 pairs / S
         a.work_items = (int32_t)std::min<unsigned long long>((unsigned long long)tiles + pairs / kRasterSegment + 1ull, 0x7FFFFFFFull);
         const size_t partial_slots = (size_t)(2 * (pairs / kRasterSegment) + 2);
@@ -537,10 +592,10 @@ hipError_t render_particles(RasterLaunch& a, RasterScratch& s, hipStream_t strea
         RASTER_TRY(hipGetLastError());
     }
     if (out_stats) {
-        unsigned long long h[4];
-        RASTER_TRY(hipMemcpyAsync(h, s.stats, sizeof(h), hipMemcpyDeviceToHost, stream));
+        hipLaunchKernelGGL(raster_stats_kernel, dim3(1), dim3(1), 0, stream, static_cast<const unsigned long long*>(s.stats), host_words_dev + 1);
+        RASTER_TRY(hipGetLastError());
         RASTER_TRY(hipStreamSynchronize(stream));
-        out_stats[0] = h[0]; out_stats[1] = pairs; out_stats[2] = h[2];
+        out_stats[0] = s.host_words[1]; out_stats[1] = pairs; out_stats[2] = s.host_words[3];
     }
     return hipSuccess;
 }
