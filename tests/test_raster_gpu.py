@@ -192,6 +192,27 @@ def test_crowded_tiles_are_shaded_in_segments(ctx, oracle, blend):
     assert np.abs(want[50, 60] - np.asarray(clear, np.float32)).max() > 0.05
 
 
+def test_4k_frame_with_crowded_tiles_far_down_the_tile_table(ctx, oracle):
+    """3840 x 2160 = 32 400 tiles: the tile table's two prefix sums (first work item, first partial slot) run over 32 401 entries in one
+    workgroup, 32 per thread; a crowded patch near the frame's far corner (its tiles cut into segments) sits behind ~30 000 tiles of
+    scattered sprites, so a wrong prefix anywhere shifts its work items."""
+    cs, w, h = 64, 3840, 2160
+    chunks = random_chunks(140, cs, 3, w, h, size_hi=7.0, dead_fraction=0.1)
+    planes = chunks[2]
+    planes[0][:, 0] = 3500.0 + scenes.uniform(400, (cs * cs,), 0.0, 36.0)
+    planes[0][:, 1] = 2000.0 + scenes.uniform(401, (cs * cs,), 0.0, 36.0)
+    planes[0][:, 3] = 1.0
+    planes[3][:] *= 0.2
+    params = scenes.rasterize_params(rounded=True)
+    clear = (0.1, 0.2, 0.05, 1.0)
+    got, (live, pairs, shaded) = render_gpu(ctx, chunks, cs, params, w, h, abi.LIGHTMAP_FLOAT4, clear)
+    want = np.zeros((h, w, 4), np.float32); want[:] = clear
+    want, (olive, oshaded) = oracle.render_particles(chunks, params, w, h, image=want)
+    assert live == olive and abs(shaded - oshaded) <= 8
+    compare_images(got, want, "4K frame", max_outliers=8)
+    assert np.abs(want[2018, 3518] - np.asarray(clear, np.float32)).max() > 0.05 and pairs > live
+
+
 def test_fracture_only_options_and_bad_arguments_are_refused(ctx):
     eng = native.Engine(ctx, 16, scenes.randomness_table(7))
     sysm = native.System(eng); sysm.add_chunk()
