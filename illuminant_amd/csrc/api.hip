@@ -2018,7 +2018,9 @@ int32_t ilm_gbuffer_render_meshes(IlmHandle h, const IlmGBufferMeshDesc* d,
     // coarse bins: 64 x 64 pixel blocks, doubled until the blocks' lists (one slot per triangle each) fit the budget
     int block_shift = 6;
     auto blocks_at = [&](int shift) { return (size_t)((g->width + (1 << shift) - 1) >> shift) * (size_t)((g->height + (1 << shift) - 1) >> shift); };
-    while (blocks_at(block_shift) > 1 && blocks_at(block_shift) * (size_t)prim_count * sizeof(int32_t) > kGBufferBlockListBudget)
+    size_t budget = kGBufferBlockListBudget;
+    if (const char* e = getenv("ILM_GBUFFER_BLOCK_LIST_BYTES")) budget = (size_t)strtoull(e, nullptr, 10);      // (tests: the larger blocks without a million triangles)
+    while (blocks_at(block_shift) > 1 && blocks_at(block_shift) * (size_t)prim_count * sizeof(int32_t) > budget)
         block_shift++;
     const size_t block_count = blocks_at(block_shift);
     const size_t off_verts = align64(off_bounds + sizeof(int4) * (size_t)prim_count);

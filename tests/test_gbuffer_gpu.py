@@ -162,6 +162,24 @@ def test_squares_crossed_by_thousands_of_triangles(ctx, oracle):
     gb.close()
 
 
+@pytest.mark.parametrize("budget", [1 << 20, 60000, 1])
+def test_block_lists_over_larger_blocks_when_the_scratch_budget_is_small(ctx, oracle, budget, monkeypatch):
+    """The binning pass's blocks double from 64 x 64 pixels until blocks x triangles x 4 B fit the budget (256 MB by default): with the
+    budget turned down the same frame goes through 64-pixel blocks, 128-pixel blocks and one block for the whole frame -- same texels."""
+    w, h = 520, 300
+    z_to_y = 0.6
+    _, top, front, bb, kinds = random_scene(31, w, h, n_volumes=40, n_billboards=12, z_to_y=z_to_y)
+    so, zso = scenes.self_occlusion_hacks(0.5, 64.0, 12)
+    d = scenes.gbuffer_mesh_desc(z_to_y=z_to_y, extent_z=64.0, self_occlusion_hack=so, z_self_occlusion_hack=zso)
+    runs = [(None, q, 1, kinds[q]) for q in range(len(kinds))]
+    want = oracle.render_gbuffer_meshes(w, h, d, top, front, bb, [(q, 1, kinds[q]) for q in range(len(kinds))])
+    monkeypatch.setenv("ILM_GBUFFER_BLOCK_LIST_BYTES", str(budget))
+    gb = native.GBufferTexture(ctx, None, abi.GBUFFER_FLOAT4, size=(w, h))
+    gb.render_meshes(d, top, front, bb, runs)
+    compare(gb.download(), want, abi.GBUFFER_FLOAT4)
+    gb.close()
+
+
 def test_non_2p5d_meshes_equal_the_polygon_entry_point(ctx, oracle):
     """ilm_gbuffer_render decides top-face coverage per pixel centre against the polygon; the mesh entry point rasterises a
     triangulation of it: same picture wherever no centre sits exactly on an edge (quarter-pixel vertices, unit scale)."""
