@@ -13,16 +13,18 @@ from illuminant_amd import abi, scenes  # noqa: E402
 from illuminant_amd import _host as H  # noqa: E402
 
 ctx = H.DeviceContext(0)
-P = bench.build_particle_system(H, ctx, scenes, abi, 256, 16, 0)
+P = bench.build_particle_system(H, ctx, scenes, abi, 256, 16, 0, with_spawner=("--spawner" in sys.argv))      # without: a constant 1 048 576 particles
 ps, tp = P["ps"], P["tp"]
 f = 0
 for _ in range(25):
     tp.Advance(1 / 60); ps.Update(f); f += 1
 ctx.Sync()
-for K in (1, 5, 20, 80, 200):
+for K in (1, 5, 20, 80, 200, 800):
     rows = []
-    for _ in range(15):
+    for _ in range(9 if K > 100 else 15):
         ctx.Sync()
+        if "--idle" in sys.argv:
+            time.sleep(0.002)                      # a device that has been idle for 2 ms in front of every block
         ctx.TimerStart()
         t0 = time.perf_counter()
         for _ in range(K):
