@@ -172,6 +172,17 @@ def test_cfg3_1080p_properties(ctx, oracle, cfg3_scene):
     none = render(ctx, (abi.LightVertex * 0)(), env, dfu, sdf, ambient, w, h, gbuffer=gb)
     assert np.array_equal(none, np.broadcast_to(np.float32(ambient), none.shape))
 
+    # (3b) linearity in the lights' colours: every rgb of the frame is a sum of (Color1.rgb * Color1.a) x opacity products, so doubling
+    # every light's rgb doubles the frame over a black clear colour EXACTLY (a power of two passes through every product and sum
+    # unchanged in its mantissa), and leaves the alpha channel's light count alone
+    doubled = (abi.LightVertex * n)(*[lights[i] for i in range(n)])
+    for i in range(n):
+        doubled[i].Color1.x *= 2.0; doubled[i].Color1.y *= 2.0; doubled[i].Color1.z *= 2.0
+    once = render(ctx, lights, env, dfu, sdf, zero, w, h, gbuffer=gb)
+    twice = render(ctx, doubled, env, dfu, sdf, zero, w, h, gbuffer=gb)
+    assert np.array_equal(twice[..., :3], 2.0 * once[..., :3]) and np.array_equal(twice[..., 3], once[..., 3])
+    assert float(once[..., :3].max()) > 0.1
+
     # (4) the oracle on a 24-row crop of the full-size frame (same lights, same 25 MB atlas)
     b0, b1 = 528, 552
     want, _ = oracle.render_sphere_lights(lights, env, dfu, oracle.make_texture(garr, abi.GBUFFER_FLOAT4), oracle.make_texture(atlas, abi.SDF_UNORM16),
