@@ -66,7 +66,7 @@ constexpr int kFlatNormalBit = 16;                              // GBufferPrim::
 // An attribute with the same finite value v at the three vertices interpolates to (v + 0 f1) + 0 f2 = v + 0 at every covered pixel
 // (f1, f2 are finite and not negative there), whatever the weights: the raster kernel skips the weights for a triangle of such
 // attributes only -- the ground plane, every frame -- and takes a flat normal's encoding from here.
-ILM_DEV void finish_attributes(GBufferPrim& p) {
+ILM_DEV void finish_attributes(GBufferPrimSetup& p) {
     p.flat = 0; p.enc_x = 0.0f; p.enc_y = 0.0f;
     for (int k = 0; k < kGBufferAttrs; k++) {
         const uint32_t b0 = __float_as_uint(p.a[0][k]), b1 = __float_as_uint(p.a[1][k]), b2 = __float_as_uint(p.a[2][k]);
@@ -80,7 +80,7 @@ ILM_DEV void finish_attributes(GBufferPrim& p) {
     }
 }
 
-ILM_DEV void finish(GBufferPrim& p, const float sx[3], const float sy[3]) {
+ILM_DEV void finish(GBufferPrimSetup& p, const float sx[3], const float sy[3]) {
     for (int k = 0; k < 3; k++) { p.x[k] = snap(sx[k]); p.y[k] = snap(sy[k]); }
     const int64_t area = edge(p.x[0], p.y[0], p.x[1], p.y[1], p.x[2], p.y[2]);
     p.flat = 0; p.enc_x = 0.0f; p.enc_y = 0.0f;
@@ -100,7 +100,7 @@ ILM_DEV void finish(GBufferPrim& p, const float sx[3], const float sy[3]) {
 
 // GroundPlaneVertexShader / HeightVolumeVertexShader / HeightVolumeFaceVertexShader, GBuffer.fx:7-55
 // attributes: 0-2 worldPosition, 3-5 normal, 6 enableShadows, 7 result.z, 8 dead
-ILM_DEV void volume_prim(GBufferPrim& p, int kind, const IlmHeightVolumeVertex& v0, const IlmHeightVolumeVertex& v1,
+ILM_DEV void volume_prim(GBufferPrimSetup& p, int kind, const IlmHeightVolumeVertex& v0, const IlmHeightVolumeVertex& v1,
                          const IlmHeightVolumeVertex& v2, const IlmGBufferMeshDesc& d) {
     const IlmHeightVolumeVertex* v[3] = { &v0, &v1, &v2 };
     float sx[3], sy[3];
@@ -127,7 +127,7 @@ ILM_DEV void volume_prim(GBufferPrim& p, int kind, const IlmHeightVolumeVertex& 
 
 // BillboardVertexShader, GBufferBitmap.fx:12-27 (POSITION0 carries two floats, Vertices.cs:89: position.z reads 0)
 // attributes: 0-2 worldPosition, 3-5 normal, 6-7 texCoord, 8 screenPosition.y, 9-10 dataScaleAndDynamicFlag
-ILM_DEV void billboard_prim(GBufferPrim& p, int kind, int texture, const IlmBillboardVertex& v0, const IlmBillboardVertex& v1,
+ILM_DEV void billboard_prim(GBufferPrimSetup& p, int kind, int texture, const IlmBillboardVertex& v0, const IlmBillboardVertex& v1,
                             const IlmBillboardVertex& v2, const IlmGBufferMeshDesc& d) {
     const IlmBillboardVertex* v[3] = { &v0, &v1, &v2 };
     float sx[3], sy[3];
@@ -176,7 +176,7 @@ ILM_DEV float4 sample_point(const GBufferTex* textures, int index, float u, floa
 __global__ __launch_bounds__(64) void gbuffer_setup_kernel(const GBufferMeshLaunch a) {
     const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
     if (t >= a.prim_count) return;
-    GBufferPrim p;
+    GBufferPrimSetup p;
     const IlmGBufferMeshDesc& d = a.desc;
     const int quad_indices[6] = { 0, 1, 3, 1, 2, 3 };           // QuadIndices, LightingRenderer.cs:421-423
     int shape = 0;
@@ -217,7 +217,10 @@ __global__ __launch_bounds__(64) void gbuffer_setup_kernel(const GBufferMeshLaun
         const int* ix = quad_indices + 3 * (b & 1);
         billboard_prim(p, q.z, q.y, v[ix[0]], v[ix[1]], v[ix[2]], d);
     }
-    a.prims[t] = p;
+    GBufferPrim out;
+    for (int k = 0; k < kGBufferAttrs; k++) out.attr[k] = mk4(p.a[0][k], p.a[1][k] - p.a[0][k], p.a[2][k] - p.a[0][k], 0.0f);
+    out.flat = p.flat; out.enc_x = p.enc_x; out.enc_y = p.enc_y; out._pad = 0;
+    a.prims[t] = out;
     a.bounds[t] = make_int4(p.i0, p.i1, p.j0, p.j1);
     a.verts[2 * (size_t)t] = make_int4(p.x[0], p.y[0], p.x[1], p.y[1]);
     const int32_t reach = 1 << 22;
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(256) void gbuffer_meshes_kernel(const GBufferMeshLa
                 const double area = (double)edge(x0, y0, x1, y1, x2, y2);       // = w0 + w1 + w2 at every pixel (wave-uniform)
                 f1 = (float)((double)w1 / area); f2 = (float)((double)w2 / area);
             }
-            auto at = [&](int k) { return (p.a[0][k] + (p.a[1][k] - p.a[0][k]) * f1) + (p.a[2][k] - p.a[0][k]) * f2; };
+            auto at = [&](int k) { const float4 A = p.attr[k]; return (A.x + A.y * f1) + A.z * f2; };
             // Clip against the near / far plane (w = 1).  Volumes only: a billboard's POSITION0 is a Vector2 (Vertices.cs:89), so
             // BillboardVertexShader's result.z = position.z / DistanceFieldExtent.z is 0 and never clipped -- and attribute 7 of a
             // billboard is TexCoord.y, which may leave [0, 1] (atlas sub-rectangles with a margin; the sampler clamps)

@@ -278,13 +278,20 @@ hipError_t launch_render_gbuffer(const GBufferLaunch& a, hipStream_t stream);
 // G-buffer from the host's meshes (gbuffer.hip): one record per triangle in draw order, written by the setup kernel and read
 // wave-uniformly by the raster kernel
 constexpr int kGBufferAttrs = 11;
-struct GBufferPrim {
+// what the setup kernel works on (one triangle in draw order) ...
+struct GBufferPrimSetup {
     int32_t x[3], y[3];           // 1/256-pixel positions, clockwise on the y-down screen
     int32_t i0, i1, j0, j1;       // pixels whose centres the bounding box holds (inclusive; empty for a degenerate triangle)
     int32_t kind, texture;        // pixel shader; index into the launch's texture table or -1
     float a[3][kGBufferAttrs];    // per-vertex attributes
     int32_t flat;                 // bit k: attribute k is the same finite number at the three vertices (interpolation returns a[0][k] + 0)
     float enc_x, enc_y;           // the encoded normal of a ground / top / front-face triangle whose normal is flat
+};
+// ... and what it leaves for the raster kernel's scalar loads: per attribute (a0, a1 - a0, a2 - a0) side by side -- one 16-byte load and
+// no subtraction per attribute and covering triangle (the differences are the same IEEE operations, taken once)
+struct GBufferPrim {
+    float4 attr[kGBufferAttrs];
+    int32_t flat; float enc_x, enc_y; int32_t _pad;
 };
 struct GBufferTex { const void* texels; int32_t width, height, format, _pad; };
 struct GBufferMeshLaunch {
