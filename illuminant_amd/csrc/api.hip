@@ -2045,17 +2045,28 @@ int32_t ilm_gbuffer_render_meshes(IlmHandle h, const IlmGBufferMeshDesc* d,
     if (billboard_vertex_count) memcpy(block + off_bb, billboard_vertices, sizeof(IlmBillboardVertex) * (size_t)billboard_vertex_count);
     if (!quads.empty()) memcpy(block + off_quads, quads.data(), sizeof(int4) * quads.size());
     if (!textures.empty()) memcpy(block + off_tex, textures.data(), sizeof(GBufferTex) * textures.size());
-    rc = upload_small_commit(c, c->d_field_params, slot, inputs);
-    if (rc != ILM_OK) return rc;
+    // ... or is read by the setup kernel where it lies (the default: one device operation and one dependent-launch gap less; the
+    // vertices are read once, by the one kernel that digests them; ILM_GBUFFER_IN_PLACE=0 copies)
+    static const int in_place = [] { const char* e = getenv("ILM_GBUFFER_IN_PLACE"); return e ? atoi(e) : 1; }();
     char* base = static_cast<char*>(c->d_field_params);
+    const char* in = base;
+    if (in_place) {
+        void* dv = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(&dv, block, 0));
+        in = static_cast<const char*>(dv);
+    } else {
+        rc = upload_small_commit(c, c->d_field_params, slot, inputs);
+        if (rc != ILM_OK) return rc;
+    }
     GBufferMeshLaunch a;
     a.texels = g->texels; a.width = g->width; a.height = g->height; a.format = g->format;
     a.desc = *d;
-    a.top = reinterpret_cast<const IlmHeightVolumeVertex*>(base); a.top_triangles = top_vertex_count / 3;
-    a.front = reinterpret_cast<const IlmHeightVolumeVertex*>(base + off_front); a.front_triangles = front_vertex_count / 3;
-    a.billboards = reinterpret_cast<const IlmBillboardVertex*>(base + off_bb);
-    a.quads = reinterpret_cast<const int4*>(base + off_quads);
+    a.top = reinterpret_cast<const IlmHeightVolumeVertex*>(in); a.top_triangles = top_vertex_count / 3;
+    a.front = reinterpret_cast<const IlmHeightVolumeVertex*>(in + off_front); a.front_triangles = front_vertex_count / 3;
+    a.billboards = reinterpret_cast<const IlmBillboardVertex*>(in + off_bb);
+    a.quads = reinterpret_cast<const int4*>(in + off_quads);
     a.textures = reinterpret_cast<const GBufferTex*>(base + off_tex);
+    a.textures_in = in_place ? reinterpret_cast<const GBufferTex*>(in + off_tex) : nullptr; a.texture_count = (int32_t)textures.size();
     a.prims = reinterpret_cast<GBufferPrim*>(base + inputs); a.prim_count = (int32_t)prim_count;
     a.bounds = reinterpret_cast<int4*>(base + off_bounds);
     a.verts = reinterpret_cast<int4*>(base + off_verts);
@@ -2064,6 +2075,7 @@ int32_t ilm_gbuffer_render_meshes(IlmHandle h, const IlmGBufferMeshDesc* d,
     a.block_count = reinterpret_cast<int32_t*>(base + off_block_count);
     a.block_list = reinterpret_cast<int32_t*>(base + off_block_list);
     HIP_TRY(launch_gbuffer_meshes(a, c->main()));
+    if (in_place) return staged_small_done(c, slot);           // the slot is free again once the setup kernel has run
     return ILM_OK;
 }
 

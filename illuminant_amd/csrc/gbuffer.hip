@@ -175,6 +175,11 @@ ILM_DEV float4 sample_point(const GBufferTex* textures, int index, float u, floa
 // one thread per triangle of the frame, in draw order: [ground plane 2][top][front][billboard quads 2 each]
 __global__ __launch_bounds__(64) void gbuffer_setup_kernel(const GBufferMeshLaunch a) {
     const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    // (the vertex arrays and tables are read where the host left them -- a pinned slot -- when the call passes them in place; the
+    // texture table, which the raster kernel reads per billboard, moves to device memory here)
+    if (a.textures_in != nullptr)
+        for (int k = t; k < a.texture_count; k += (int)(gridDim.x * blockDim.x))
+            const_cast<GBufferTex*>(a.textures)[k] = a.textures_in[k];
     if (t >= a.prim_count) return;
     GBufferPrimSetup p;
     const IlmGBufferMeshDesc& d = a.desc;

@@ -301,7 +301,8 @@ struct GBufferMeshLaunch {
     const IlmHeightVolumeVertex* front; int32_t front_triangles;
     const IlmBillboardVertex* billboards;
     const int4* quads;            // (quad, texture, kind, -) per billboard quad in draw order
-    const GBufferTex* textures;
+    const GBufferTex* textures;   // device copy (read by the raster kernel)
+    const GBufferTex* textures_in; int32_t texture_count;   // where the setup kernel copies it from (the pinned slot), or nullptr
     GBufferPrim* prims; int32_t prim_count;
     int4* bounds;                 // (i0, i1, j0, j1) per record: what the binning passes read
     int4* verts;                  // (x0, y0, x1, y1), (x2, y2, kind, texture) per record: what a wave's coverage test reads
