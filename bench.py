@@ -931,9 +931,9 @@ def main():
                 "ms_per_frame": round(gb_ms, 4), "triangles": int(tris), "mpixels_per_s": round(px / (gb_ms * 1e-3) / 1e6, 1),
                 "roofline": {"bound": "hbm", "achieved": round(px * 16 / (gb_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": round(px * 16 / (gb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                             "kernel": "upload + ilm::gbuffer_setup_kernel + ilm::gbuffer_bin_kernel + ilm::gbuffer_meshes_kernel", "bytes_per_unit": 16, "units_per_launch": px,
+                             "kernel": "ilm::gbuffer_setup_kernel (reads the vertex arrays in the pinned ring) + ilm::gbuffer_bin_kernel + ilm::gbuffer_meshes_kernel", "bytes_per_unit": 16, "units_per_launch": px,
                              "launch_ms": round(gb_ms, 4),
-                             "note": "one 16 B store per texel is the algorithmic traffic; the frame is the upload of the vertex arrays (11 us), the setup and block-binning kernels (6 us each) and the raster kernel (40 us), which is bound by instruction issue (per-candidate scalar code and per-pixel shader arithmetic), not by the store: DESIGN 3.4"}}
+                             "note": "one 16 B store per texel is the algorithmic traffic; the frame is the setup kernel reading the vertex arrays where the host left them (11 us), the block-binning kernel (6 us) and the raster kernel (40 us), which is bound by instruction issue (per-candidate scalar code and per-pixel shader arithmetic), not by the store: DESIGN 3.4"}}
             gbt.close()
 
     if next_rows:
