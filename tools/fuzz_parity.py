@@ -137,6 +137,7 @@ for seed in range(first, first + count):
                                                  velocity=((0, 0, 0), (60, 60, 10), (0, 0, 0), int(rng.choice([0, 1, 2]))), life=(2.0, 2.0, 0.0))
     d.Flags = abi.STEP_COUNT_LIVE
     inputs = [(c[0].copy(), c[1].copy()) for c in chunks]
+    initial = [[a.copy() for a in c] for c in chunks]
     sysm.step(d)
     want_counts = oracle.step(chunks, cs, rnd, d, want_counts=True)
     got_counts = sysm.step_counts()
@@ -184,6 +185,20 @@ for seed in range(first, first + count):
                                     print("    attractor", list(ap), "radius/strength/type", list(ar), "distance", dist)
                             else:
                                 print("  op type", d.Ops[o].Type)
+                        # the same step without its ops (spawn + update only): is the difference there before the ops run?
+                        import copy
+                        d0 = copy.copy(d); d0.OpCount = 0
+                        sys0 = native.System(eng)
+                        ref0 = [[a.copy() for a in cc] for cc in initial]
+                        for cc in range(2):
+                            sys0.add_chunk()
+                            for pl_, a_ in ((P, initial[cc][0]), (V, initial[cc][1]), (A, initial[cc][2])):
+                                sys0.upload(cc, pl_, a_)
+                        sys0.step(d0)
+                        oracle.step(ref0, cs, rnd, d0)
+                        print("  without the ops: got  P", sys0.download(c, P)[i], "V", sys0.download(c, V)[i])
+                        print("  without the ops: want P", ref0[c][0][i], "V", ref0[c][1][i])
+                        sys0.close()
     if problem:
         bad_step.append((seed, list(got_counts), list(want_counts)))
     sysm.close(); eng.close()
