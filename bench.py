@@ -896,6 +896,32 @@ def main():
                 "algorithmic_rate": {"value": round(alg / (pl_ms * 1e-3) / 1e9, 1), "unit": "GB/s", "bytes_per_unit": SDF_SAMPLE_BYTES,
                                      "units_per_launch": int(stats[0])}}
             del L, r, lsys, eng, pls
+            # light probes: 256 probes under cfg3's 64 lights and field, one synchronous ilm_render_light_probes call
+            L = build_lighting(H, ctx, scenes, abi, 1920, 1080, 64, 0.25, 2048, abi.SDF_UNORM16)
+            r = L["renderer"]
+            pverts = (abi.LightVertex * 64)()
+            for i, lsrc in enumerate(L["env"].Lights):
+                pverts[i] = abi.LightVertex.from_buffer_copy(H.LightingRenderer.PackSphereLightBytes(lsrc, 1.0, True))
+            penv = abi.Environment.from_buffer_copy(r.GetEnvironmentUniformsBytes())
+            pdfu = abi.DistanceFieldUniforms.from_buffer_copy(r.GetDistanceFieldUniformsBytes())
+
+            class _ProbeSdf:      # the mirror's field, by handle
+                handle = abi.Handle(int(L["field"].TextureHandle))
+            pctx = native.Context(local_rank, borrowed_handle=ctx.Handle)
+            npr = 256
+            ppos = np.ones((npr, 4), np.float32)
+            ppos[:, 0] = scenes.uniform(5, (npr,), 0.0, 1920.0); ppos[:, 1] = scenes.uniform(6, (npr,), 0.0, 1080.0); ppos[:, 2] = scenes.uniform(7, (npr,), 0.0, 32.0)
+            pnrm = np.zeros((npr, 4), np.float32); pnrm[:, 2] = 1.0; pnrm[:, 3] = 1.0
+            for _ in range(5):
+                pv = native.render_light_probes(pctx, pverts, ppos, pnrm, penv, pdfu, _ProbeSdf)
+            t0 = time.perf_counter()
+            for _ in range(100):
+                pv = native.render_light_probes(pctx, pverts, ppos, pnrm, penv, pdfu, _ProbeSdf)
+            probe_us = (time.perf_counter() - t0) / 100 * 1e6
+            next_rows["light_probes_256_x_64_lights"] = {
+                "us_per_call": round(probe_us, 1), "probes": npr, "lights": 64, "lit_probe_light_pairs": int(pv[:, 3].sum()),
+                "note": "synchronous call on the host's clock: one pinned block in, prepare kernel, one wave per (64 probes, light), a sum in light order, values read from the same block (r03's one-lane-per-probe kernel with three uploads and a read-back: 1 207 us)"}
+            del L, r
             # lightmap resolve: 4K HalfVector4 lightmap -> RGBA8, ToneMap; 8 B read + 4 B written per pixel
             L = build_lighting(H, ctx, scenes, abi, 3840, 2160, 8, 0.125, 4096, abi.SDF_FP16)
             r = L["renderer"]

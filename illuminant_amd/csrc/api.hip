@@ -104,8 +104,8 @@ struct Ctx {
     IlmReadbackDrawCall* d_rb = nullptr; int rb_cap = 0; int32_t* d_rb_count = nullptr; int32_t* d_rb_blocks = nullptr; int rb_blocks_cap = 0;
     int32_t* d_rb_elems = nullptr; int rb_elems_cap = 0;
     IlmReadbackDrawCall* h_rb = nullptr; size_t h_rb_cap = 0;    // pinned host buffer the read-back records land in
-    // light probes: positions | normals | values
-    float4* d_probes = nullptr; int probes_cap = 0;
+    // light probes
+    float4* d_probe_pairs = nullptr; size_t probe_pairs_cap = 0;   // one contribution per (light, probe)
     // parameter block of the distance-field generation pass (slice list, obstruction records, volumes, polygon vertices)
     void* d_field_params = nullptr; size_t field_params_bytes = 0;
 };
@@ -1062,7 +1062,7 @@ int32_t ilm_ctx_destroy(IlmHandle h) {
     free_raster_scratch(c->raster);
     if (c->d_light_ramp) (void)hipFree(c->d_light_ramp);
     if (c->d_raster_quads) (void)hipFree(c->d_raster_quads);
-    if (c->d_probes) (void)hipFree(c->d_probes);
+    if (c->d_probe_pairs) (void)hipFree(c->d_probe_pairs);
     if (c->d_rb) (void)hipFree(c->d_rb);
     if (c->d_rb_count) (void)hipFree(c->d_rb_count);
     if (c->d_rb_blocks) (void)hipFree(c->d_rb_blocks);
@@ -2526,30 +2526,48 @@ int32_t ilm_render_light_probes(IlmHandle hctx, const IlmLightVertex* lights, in
         HIP_TRY(hipMalloc(&c->d_recs, kLightRecBytes * (size_t)cap));
         c->light_cap = cap;
     }
-    if (light_count > 0) {
-        int32_t rc = upload_small(c, c->d_lights, lights, sizeof(IlmLightVertex) * (size_t)light_count);
-        if (rc != ILM_OK) return rc;
-        HIP_TRY(launch_prepare_lights(c->d_lights, light_count, *env, *df, make_sdf_view(f, df), c->d_recs, c->main()));
-    }
-    if (probe_count > c->probes_cap) {
-        HIP_TRY(hipStreamSynchronize(c->main()));
-        if (c->d_probes) HIP_TRY(hipFree(c->d_probes));
-        c->d_probes = nullptr;
-        const int cap = probe_count < 256 ? 256 : probe_count * 2;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_probes), sizeof(float4) * 3 * (size_t)cap));
-        c->probes_cap = cap;
-    }
-    float4* d_pos = c->d_probes;
-    float4* d_nrm = c->d_probes + c->probes_cap;
-    float4* d_val = c->d_probes + 2 * (size_t)c->probes_cap;
-    int32_t rc = upload_small(c, d_pos, probe_positions, sizeof(float4) * (size_t)probe_count);
+    // One pinned block [lights | positions | normals | values]: the kernels read their inputs where it lies (each word once) and the
+    // last one writes the values into it -- no copy command on either side of the two kernels (r04; three uploads and a read-back before)
+    auto align64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
+    const size_t off_pos = align64(sizeof(IlmLightVertex) * (size_t)light_count);
+    const size_t off_nrm = off_pos + align64(sizeof(float4) * (size_t)probe_count);
+    const size_t off_val = off_nrm + align64(sizeof(float4) * (size_t)probe_count);
+    const size_t block_bytes = off_val + sizeof(float4) * (size_t)probe_count;
+    unsigned char* block = nullptr;
+    int slot = -1;
+    int32_t rc = upload_small_begin(c, block_bytes, reinterpret_cast<void**>(&block), &slot);
     if (rc != ILM_OK) return rc;
-    rc = upload_small(c, d_nrm, probe_normals, sizeof(float4) * (size_t)probe_count);
-    if (rc != ILM_OK) return rc;
+    if (light_count > 0) memcpy(block, lights, sizeof(IlmLightVertex) * (size_t)light_count);
+    memcpy(block + off_pos, probe_positions, sizeof(float4) * (size_t)probe_count);
+    memcpy(block + off_nrm, probe_normals, sizeof(float4) * (size_t)probe_count);
+    void* dv = nullptr;
+    HIP_TRY(hipHostGetDevicePointer(&dv, block, 0));
+    const char* in = static_cast<const char*>(dv);
+    if (light_count > 0)
+        HIP_TRY(launch_prepare_lights(reinterpret_cast<const IlmLightVertex*>(in), light_count, *env, *df, make_sdf_view(f, df), c->d_recs, c->main()));
+    const float4* d_pos = reinterpret_cast<const float4*>(in + off_pos);
+    const float4* d_nrm = reinterpret_cast<const float4*>(in + off_nrm);
+    float4* d_val = reinterpret_cast<float4*>(const_cast<char*>(in) + off_val);
+    // scratch for one contribution per (light, probe): the pairs are shaded side by side and added per probe in light order
+    float4* d_pairs = nullptr;
+    const size_t pair_count = (size_t)probe_count * (size_t)(light_count > 0 ? light_count : 0);
+    if (light_count > 1 && pair_count * sizeof(float4) <= ((size_t)256 << 20)) {
+        if (pair_count > c->probe_pairs_cap) {
+            HIP_TRY(hipStreamSynchronize(c->main()));
+            if (c->d_probe_pairs) HIP_TRY(hipFree(c->d_probe_pairs));
+            c->d_probe_pairs = nullptr; c->probe_pairs_cap = 0;
+            const size_t cap = pair_count < 65536 ? 65536 : pair_count + pair_count / 2;
+            if (hipMalloc(reinterpret_cast<void**>(&c->d_probe_pairs), sizeof(float4) * cap) == hipSuccess) c->probe_pairs_cap = cap;
+            else { (void)hipGetLastError(); c->d_probe_pairs = nullptr; }      // (the one-kernel form needs no scratch)
+        }
+        d_pairs = c->d_probe_pairs;
+    }
     HIP_TRY(launch_light_probes(c->d_recs, light_count, d_pos, d_nrm, probe_count, *env, *df, make_sdf_view(f, df),
-                                RampView{ c->d_light_ramp, c->light_ramp_w, c->light_ramp_h }, d_val, c->main()));
-    HIP_TRY(hipMemcpyAsync(out_values, d_val, sizeof(float4) * (size_t)probe_count, hipMemcpyDeviceToHost, c->main()));
+                                RampView{ c->d_light_ramp, c->light_ramp_w, c->light_ramp_h }, d_val, d_pairs, c->main()));
+    rc = staged_small_done(c, slot);
+    if (rc != ILM_OK) return rc;
     HIP_TRY(hipStreamSynchronize(c->main()));
+    memcpy(out_values, block + off_val, sizeof(float4) * (size_t)probe_count);
     return ILM_OK;
 }
 

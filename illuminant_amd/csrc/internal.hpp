@@ -218,7 +218,7 @@ struct ParticleLightLaunch {
 hipError_t launch_prepare_particle_lights(const ParticleLightLaunch& a, hipStream_t stream);
 // Light probes (SphereLightProbe.fx): every prepared light record on every probe; values = float4 per probe (device)
 hipError_t launch_light_probes(const void* recs, int light_count, const float4* probe_positions, const float4* probe_normals, int probe_count,
-                               const IlmEnvironment& env, const IlmDistanceFieldUniforms& df, const SdfView& sdf, const RampView& ramp, float4* values,
+                               const IlmEnvironment& env, const IlmDistanceFieldUniforms& df, const SdfView& sdf, const RampView& ramp, float4* values, float4* pairs,
                                hipStream_t stream);
 // sampleDistanceFieldEx at `count` positions (xyz triples) -- diagnostic entry point ilm_sdf_sample
 hipError_t launch_sdf_sample(const SdfView& sdf, const IlmDistanceFieldUniforms& df, const float* positions, int count, float* out, hipStream_t stream);

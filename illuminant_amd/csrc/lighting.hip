@@ -969,41 +969,61 @@ hipError_t launch_prepare_particle_lights(const ParticleLightLaunch& a, hipStrea
 // Light probes -- SphereLightProbePixelShader, SphereLightProbe.fx:19-44: one lane per probe walks every light record
 // (uniform index -> scalar loads), fp32 accumulation in light order.
 // ---------------------------------------------------------------------------------------------
+// r04: one WAVE per (block of 64 probes, light) instead of one lane walking every light (256 probes under 64 lights were four waves
+// tracing 64 lights one after the other: 1.2 ms of latency); the pair's contribution goes to scratch [light][probe] and a second kernel
+// adds a probe's contributions in light order -- the same additions in the same order.  `pairs` = nullptr: the one-kernel form (scratch
+// for probe_count x light_count contributions was not to be had).
+template <int FMT>
+ILM_DEV bool probe_light(const float4 pp, const float4 pn, LightRec L, const IlmEnvironment& env, const TraceField& field, bool have_sdf, const RampView& ramp,
+                         float& cr, float& cg, float& cb) {
+    Pixel P;
+    P.shaded = xyz(pp); P.normal = xyz(pn); P.origin_x = 0; P.origin_y = 0;      // (no specular term: SphereLightProbe.fx:33-42)
+    P.fullbright = false;
+    P.start_inside = false;
+    // lightProperties.w *= enableShadows (a float here, not the G-buffer's flag); no AO, no specular, no shadow filter (:33-42)
+    L.casts_shadows *= pn.w;
+    P.enable_shadows = true;
+    L.ao_radius = 0.0f; L.ao_opacity = 0.0f;
+    L.shadow_filter = -1.0f;
+    L.flags = (float)((int)L.flags & kLightFastDivide);     // no specular; probes use the general trace loop (no slice table here)
+    LightStats st;
+    return shade_light<FMT, false>(P, L, env, field, have_sdf, ramp, st, cr, cg, cb);
+}
+
 template <int FMT>
 __global__ __launch_bounds__(64) void light_probes_kernel(const LightRec* __restrict__ recs, int light_count,
                                                            const float4* __restrict__ probe_positions, const float4* __restrict__ probe_normals,
                                                            int probe_count, IlmEnvironment env, IlmDistanceFieldUniforms df, SdfView sdf,
-                                                           RampView ramp, float4* __restrict__ values) {
+                                                           RampView ramp, float4* __restrict__ values, float4* __restrict__ pairs) {
     const int i = (int)blockIdx.x * 64 + (int)threadIdx.x;
     const bool valid = i < probe_count;
     const float4 pp = valid ? probe_positions[i] : mk4(0.0f, 0.0f, 0.0f, 0.0f);
     const float4 pn = valid ? probe_normals[i] : mk4(0.0f, 0.0f, 0.0f, 0.0f);
     // sampleLightProbeBuffer, LightCommon.fxh:233-254
     const float probe_opacity = pp.w;
-    Pixel P;
-    P.shaded = xyz(pp); P.normal = xyz(pn); P.origin_x = 0; P.origin_y = 0;      // (no specular term: SphereLightProbe.fx:33-42)
-    P.fullbright = false;
-    P.start_inside = false;
     const bool have_sdf = (sdf.texels != nullptr) && (df.Extent.x > 0.0f);
-    float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f, acc_a = 0.0f;
-    LightStats st;
     TraceSdfView trace_sdf;                                       // probes are few: the general sampler, no cell array
     static_cast<SdfView&>(trace_sdf) = sdf;
     trace_sdf.cells = nullptr; trace_sdf.cells_bytes = 0; trace_sdf.slice_w = 0; trace_sdf.slice_h = 0;
     const InsideConsts inside = make_inside_consts(df, trace_sdf);
     const TraceField field = { df, trace_sdf, inside, nullptr };
+    if (pairs != nullptr) {
+        const int k = (int)blockIdx.y;                            // this wave's light
+        float cr = 0.0f, cg = 0.0f, cb = 0.0f;
+        bool lit = false;
+        if (valid && probe_opacity > 0.0f)
+            lit = probe_light<FMT>(pp, pn, recs[k], env, field, have_sdf, ramp, cr, cg, cb);
+        if (valid)
+            pairs[(size_t)k * (size_t)probe_count + (size_t)i] = lit ? mk4(cr * probe_opacity, cg * probe_opacity, cb * probe_opacity, 1.0f) : mk4(0.0f, 0.0f, 0.0f, 0.0f);
+        return;
+    }
+    float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f, acc_a = 0.0f;
     for (int k = 0; k < light_count; k++) {
-        LightRec L = recs[k];
+        const LightRec L = recs[k];
         if (!(valid && probe_opacity > 0.0f))
             continue;
-        // lightProperties.w *= enableShadows (a float here, not the G-buffer's flag); no AO, no specular, no shadow filter (:33-42)
-        L.casts_shadows *= pn.w;
-        P.enable_shadows = true;
-        L.ao_radius = 0.0f; L.ao_opacity = 0.0f;
-        L.shadow_filter = -1.0f;
-        L.flags = (float)((int)L.flags & kLightFastDivide);     // no specular; probes use the general trace loop (no slice table here)
         float cr, cg, cb;
-        if (!shade_light<FMT, false>(P, L, env, field, have_sdf, ramp, st, cr, cg, cb))
+        if (!probe_light<FMT>(pp, pn, L, env, field, have_sdf, ramp, cr, cg, cb))
             continue;
         acc_r += cr * probe_opacity;
         acc_g += cg * probe_opacity;
@@ -1014,16 +1034,32 @@ __global__ __launch_bounds__(64) void light_probes_kernel(const LightRec* __rest
         values[i] = mk4(acc_r, acc_g, acc_b, acc_a);
 }
 
+// a probe's contributions, added in light order (w = 1: the pair was lit and its products are added; w = 0: nothing is)
+__global__ __launch_bounds__(64) void light_probes_sum_kernel(const float4* __restrict__ pairs, int light_count, int probe_count, float4* __restrict__ values) {
+    const int i = (int)blockIdx.x * 64 + (int)threadIdx.x;
+    if (i >= probe_count) return;
+    float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f, acc_a = 0.0f;
+    for (int k = 0; k < light_count; k++) {
+        const float4 c = pairs[(size_t)k * (size_t)probe_count + (size_t)i];
+        if (c.w != 0.0f) { acc_r += c.x; acc_g += c.y; acc_b += c.z; acc_a += 1.0f; }
+    }
+    values[i] = mk4(acc_r, acc_g, acc_b, acc_a);
+}
+
 hipError_t launch_light_probes(const void* recs, int light_count, const float4* probe_positions, const float4* probe_normals, int probe_count,
                                const IlmEnvironment& env, const IlmDistanceFieldUniforms& df, const SdfView& sdf, const RampView& ramp, float4* values,
-                               hipStream_t stream) {
+                               float4* pairs, hipStream_t stream) {
     if (probe_count <= 0) return hipSuccess;
-    const dim3 grid((unsigned)((probe_count + 63) / 64)), block(64);
+    const bool by_pair = (pairs != nullptr) && (light_count > 1) && (light_count <= 65535);
+    const dim3 grid((unsigned)((probe_count + 63) / 64), by_pair ? (unsigned)light_count : 1u), block(64);
     const LightRec* r = reinterpret_cast<const LightRec*>(recs);
+    float4* p = by_pair ? pairs : nullptr;
     if (sdf.format == ILM_SDF_FP16)
-        hipLaunchKernelGGL(light_probes_kernel<ILM_SDF_FP16>, grid, block, 0, stream, r, light_count, probe_positions, probe_normals, probe_count, env, df, sdf, ramp, values);
+        hipLaunchKernelGGL(light_probes_kernel<ILM_SDF_FP16>, grid, block, 0, stream, r, light_count, probe_positions, probe_normals, probe_count, env, df, sdf, ramp, values, p);
     else
-        hipLaunchKernelGGL(light_probes_kernel<ILM_SDF_UNORM16>, grid, block, 0, stream, r, light_count, probe_positions, probe_normals, probe_count, env, df, sdf, ramp, values);
+        hipLaunchKernelGGL(light_probes_kernel<ILM_SDF_UNORM16>, grid, block, 0, stream, r, light_count, probe_positions, probe_normals, probe_count, env, df, sdf, ramp, values, p);
+    if (by_pair)
+        hipLaunchKernelGGL(light_probes_sum_kernel, dim3((unsigned)((probe_count + 63) / 64)), block, 0, stream, p, light_count, probe_count, values);
     return hipGetLastError();
 }
 
