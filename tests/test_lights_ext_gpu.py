@@ -150,10 +150,13 @@ def test_particle_lights_follow_the_particle_system(ctx, oracle):
         x.close()
 
 
-def test_light_probes_match_oracle(ctx, oracle):
+@pytest.mark.parametrize("n_lights", [9, 1, 0, 70])
+def test_light_probes_match_oracle(ctx, oracle, n_lights):
+    """9 / 70 lights: one wave per (64 probes, light) and the ordered sum (150 probes = three blocks, the last one ragged); one light: the
+    one-kernel form; no light: zeros."""
     atlas, dfu = small_field()
     env = scenes.environment()
-    lights = scenes.random_lights(8, 9, 256, 192, z=(8.0, 48.0), radius=10.0, ramp=(60.0, 160.0))
+    lights = scenes.random_lights(8, n_lights, 256, 192, z=(8.0, 48.0), radius=10.0, ramp=(60.0, 160.0))
     n = 150
     pp = np.ones((n, 4), np.float32)
     pp[:, 0] = scenes.uniform(1, (n,), 0, 256); pp[:, 1] = scenes.uniform(2, (n,), 0, 192); pp[:, 2] = scenes.uniform(3, (n,), 0, 40)
@@ -169,7 +172,9 @@ def test_light_probes_match_oracle(ctx, oracle):
     want = oracle.render_light_probes(lights, pp, pn, env, dfu, oracle.make_texture(atlas, abi.SDF_UNORM16))
     assert np.array_equal(got[:, 3], want[:, 3])         # the number of contributing lights per probe: exact
     assert_close(got, want, "probe values")
-    assert (want[:, 3] > 0).mean() > 0.5 and not want[::17].any()
+    assert not want[::17].any()
+    if n_lights >= 9:
+        assert (want[:, 3] > 0).mean() > 0.5
     sdf.close()
 
 
