@@ -1039,9 +1039,14 @@ __global__ __launch_bounds__(64) void light_probes_sum_kernel(const float4* __re
     const int i = (int)blockIdx.x * 64 + (int)threadIdx.x;
     if (i >= probe_count) return;
     float acc_r = 0.0f, acc_g = 0.0f, acc_b = 0.0f, acc_a = 0.0f;
-    for (int k = 0; k < light_count; k++) {
-        const float4 c = pairs[(size_t)k * (size_t)probe_count + (size_t)i];
-        if (c.w != 0.0f) { acc_r += c.x; acc_g += c.y; acc_b += c.z; acc_a += 1.0f; }
+    // (eight loads in flight; the additions stay one after the other, in light order)
+    for (int k0 = 0; k0 < light_count; k0 += 8) {
+        float4 c[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) c[u] = pairs[(size_t)min(k0 + u, light_count - 1) * (size_t)probe_count + (size_t)i];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+            if ((k0 + u < light_count) && (c[u].w != 0.0f)) { acc_r += c[u].x; acc_g += c[u].y; acc_b += c[u].z; acc_a += 1.0f; }
     }
     values[i] = mk4(acc_r, acc_g, acc_b, acc_a);
 }
