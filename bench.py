@@ -921,6 +921,27 @@ def main():
             next_rows["light_probes_256_x_64_lights"] = {
                 "us_per_call": round(probe_us, 1), "probes": npr, "lights": 64, "lit_probe_light_pairs": int(pv[:, 3].sum()),
                 "note": "synchronous call on the host's clock: one pinned block in, prepare kernel, one wave per (64 probes, light), a sum in light order, values read from the same block (r03's one-lane-per-probe kernel with three uploads and a read-back: 1 207 us)"}
+            # the reference's default cadence for a dynamic field: MaximumFieldUpdatesPerFrame = 1 slice triplet re-rendered per
+            # frame in front of the lit frame (LightingRenderer.Configuration.cs:91) -- cfg3's frame with and without it
+            r.Configuration.MaximumFieldUpdatesPerFrame = 1
+            dyn = {}
+            for tag in ("static", "one_triplet_per_frame"):
+                r.InvalidateFields(); r.Configuration.MaximumFieldUpdatesPerFrame = 9999; r.UpdateFields()
+                r.Configuration.MaximumFieldUpdatesPerFrame = 1
+                r.RenderLighting(1.0, 0, -1, False)
+                ctx.Sync()
+                ctx.TimerStart()
+                for k in range(44):                           # four passes over the field's eleven triplets
+                    if tag != "static":
+                        if k % 11 == 0:
+                            r.InvalidateFields()
+                        r.UpdateFields()
+                    r.RenderLighting(1.0, 0, -1, False)
+                dyn[tag] = ctx.TimerStop() / 44
+            next_rows["cfg3_frame_with_a_dynamic_field"] = {
+                "ms_per_frame": round(dyn["one_triplet_per_frame"], 4), "static_field_ms_per_frame": round(dyn["static"], 4),
+                "note": "one slice triplet (of eleven) re-rendered per frame + the cells of the four slices around it, then the lit frame; DESIGN 3.4"}
+            r.Configuration.MaximumFieldUpdatesPerFrame = 9999
             del L, r
             # lightmap resolve: 4K HalfVector4 lightmap -> RGBA8, ToneMap; 8 B read + 4 B written per pixel
             L = build_lighting(H, ctx, scenes, abi, 3840, 2160, 8, 0.125, 4096, abi.SDF_FP16)

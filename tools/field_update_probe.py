@@ -17,18 +17,24 @@ for name, (w, h, nl, res, world, fmt) in {"cfg3": (1920, 1080, 64, 0.25, 2048, a
     r.Configuration.MaximumFieldUpdatesPerFrame = 1
     r.Configuration.EnableGBuffer = False
     frames = 44                                     # four passes over the field's eleven triplets
-    for lit in (False, True):
-        r.InvalidateFields(); r.UpdateFields(); ctx.Sync()
+    for update, lit in ((True, False), (False, True), (True, True)):
+        r.Configuration.MaximumFieldUpdatesPerFrame = 9999
+        r.InvalidateFields(); r.UpdateFields()
+        r.Configuration.MaximumFieldUpdatesPerFrame = 1
+        if lit:
+            r.RenderLighting(1.0, 0, -1, False)
+        ctx.Sync()
         ctx.TimerStart()
         t0 = time.perf_counter()
         for k in range(frames):
-            if k % 11 == 0:
-                r.InvalidateFields()
-            r.UpdateFields()
+            if update:
+                if k % 11 == 0:
+                    r.InvalidateFields()
+                r.UpdateFields()
             if lit:
                 r.RenderLighting(1.0, 0, -1, False)
         host = (time.perf_counter() - t0) / frames
         ms = ctx.TimerStop() / frames
-        print("%s: one slice triplet per frame%s: %.4f ms per frame on the device's clock, host %.1f us per frame" % (
-            name, " + the lit frame" if lit else "", ms, host * 1e6))
+        print("%s: %s%s: %.4f ms per frame on the device's clock, host %.1f us per frame" % (
+            name, "one slice triplet per frame" if update else "static field", " + the lit frame" if lit else "", ms, host * 1e6))
     del L, r
