@@ -316,34 +316,66 @@ ILM_DEV float4 encode_gbuffer_up(float z, bool enable_shadows) {
     return mk4(ex, ey, 0.0f, w);
 }
 
+// A workgroup is a 64 x 4 pixel tile.  256 volumes at a time, thread t tests volume t's bounds against the TILE and the hits are
+// listed in LDS in the volumes' order (ballot + popcount prefix, the waves' counts through LDS); every pixel then walks the list --
+// a handful of volumes -- instead of comparing itself with every volume of the frame (r04: 256 volumes at 1080p 0.177 -> 0.027 ms, tools/gbuffer_polygon_probe.py).
 __global__ __launch_bounds__(256) void render_gbuffer_kernel(const GBufferLaunch a) {
-    const int i = (int)blockIdx.x * 64 + ((int)threadIdx.x & 63);
-    const int j = (int)blockIdx.y * 4 + ((int)threadIdx.x >> 6);
-    if (i >= a.width || j >= a.height) return;
+    __shared__ uint16_t s_list[256];
+    __shared__ int s_count[4];
+    const int lane = (int)threadIdx.x & 63, wave = (int)threadIdx.x >> 6;
+    const int i = (int)blockIdx.x * 64 + lane;
+    const int j = (int)blockIdx.y * 4 + wave;
+    const bool in_image = (i < a.width) && (j < a.height);
     const float wx = ((float)i + 0.5f) / a.desc.ViewportScale[0] + a.desc.ViewportPosition[0];
     const float wy = ((float)j + 0.5f) / a.desc.ViewportScale[1] + a.desc.ViewportPosition[1];
+    // the tile's extreme pixel centres in world units, by the same expression (either sign of the scale)
+    const float ex0 = ((float)((int)blockIdx.x * 64) + 0.5f) / a.desc.ViewportScale[0] + a.desc.ViewportPosition[0];
+    const float ex1 = ((float)((int)blockIdx.x * 64 + 63) + 0.5f) / a.desc.ViewportScale[0] + a.desc.ViewportPosition[0];
+    const float ey0 = ((float)((int)blockIdx.y * 4) + 0.5f) / a.desc.ViewportScale[1] + a.desc.ViewportPosition[1];
+    const float ey1 = ((float)((int)blockIdx.y * 4 + 3) + 0.5f) / a.desc.ViewportScale[1] + a.desc.ViewportPosition[1];
+    const float tx0 = fminf(ex0, ex1), tx1 = fmaxf(ex0, ex1), ty0 = fminf(ey0, ey1), ty1 = fmaxf(ey0, ey1);
+    // (a NaN anywhere makes the tile test unreliable: every volume is listed then, and the per-pixel test decides as before)
+    const bool tile_ordered = (tx0 <= tx1) && (ty0 <= ty1);
     const float ground_z = a.desc.GroundZ + (a.desc.RenderGroundPlane ? 0.0f : ref::kGroundLift);
     float4 texel = mk4(0.0f, 0.0f, 0.0f, 0.0f);
     if (!(ground_z < a.desc.GroundZ))
         texel = encode_gbuffer_up(ground_z, a.desc.EnableGroundShadows != 0);
-    for (int v = 0; v < a.volume_count; v++) {
-        const GBufferVolume& V = a.volumes[v];
-        if (!((wx >= V.x0) && (wx <= V.x1) && (wy >= V.y0) && (wy <= V.y1)))      // outside the polygon's bounds: no crossing can make it inside
-            continue;
-        const float2* P = a.polygon_xy + V.first_vertex;
-        bool inside = false;
-        for (int e = 0; e < V.vertex_count; e++) {
-            const int n = (e + 1 == V.vertex_count) ? 0 : e + 1;
-            const float2 pa = P[e], pb = P[n];
-            if ((pa.y > wy) != (pb.y > wy)) {
-                const float xi = ((pb.x - pa.x) * (wy - pa.y)) / (pb.y - pa.y) + pa.x;
-                if (wx < xi) inside = !inside;
-            }
+    for (int v0 = 0; v0 < a.volume_count; v0 += 256) {
+        const int mine = v0 + (int)threadIdx.x;
+        bool hit = false;
+        if (mine < a.volume_count) {
+            const GBufferVolume& V = a.volumes[mine];
+            hit = !tile_ordered || !((V.x1 < tx0) || (V.x0 > tx1) || (V.y1 < ty0) || (V.y0 > ty1));
         }
-        if (!inside || (V.top < a.desc.GroundZ))
-            continue;
-        texel = encode_gbuffer_up(V.top, V.enable_shadows != 0);
+        const unsigned long long m = __ballot(hit);
+        if (lane == 0) s_count[wave] = __popcll(m);
+        __syncthreads();
+        int before = 0, n = 0;
+        for (int w = 0; w < 4; w++) { const int c = s_count[w]; n += c; if (w < wave) before += c; }
+        if (hit) s_list[before + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)threadIdx.x;
+        __syncthreads();
+        for (int k = 0; k < n; k++) {
+            const int v = v0 + (int)s_list[k];
+            const GBufferVolume& V = a.volumes[v];
+            if (!((wx >= V.x0) && (wx <= V.x1) && (wy >= V.y0) && (wy <= V.y1)))      // outside the polygon's bounds: no crossing can make it inside
+                continue;
+            const float2* P = a.polygon_xy + V.first_vertex;
+            bool inside = false;
+            for (int e = 0; e < V.vertex_count; e++) {
+                const int nx = (e + 1 == V.vertex_count) ? 0 : e + 1;
+                const float2 pa = P[e], pb = P[nx];
+                if ((pa.y > wy) != (pb.y > wy)) {
+                    const float xi = ((pb.x - pa.x) * (wy - pa.y)) / (pb.y - pa.y) + pa.x;
+                    if (wx < xi) inside = !inside;
+                }
+            }
+            if (!inside || (V.top < a.desc.GroundZ))
+                continue;
+            texel = encode_gbuffer_up(V.top, V.enable_shadows != 0);
+        }
+        __syncthreads();                                        // the list is rewritten by the next batch
     }
+    if (!in_image) return;
     const size_t o = (size_t)j * (size_t)a.width + (size_t)i;
     if (a.format == ILM_GBUFFER_HALF4) {
         uint2 h;

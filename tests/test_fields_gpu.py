@@ -183,6 +183,29 @@ def test_gbuffer_generation_matches_oracle_and_feeds_the_light_pass(ctx, oracle,
         x.close()
 
 
+def test_gbuffer_generation_with_hundreds_of_volumes(ctx, oracle):
+    """600 overlapping volumes on a ragged 333 x 197 target: three batches of 256 through the tile lists, later volumes over earlier ones
+    in the array's order; a second view (scaled and shifted) moves every volume to other tiles."""
+    w, h = 333, 197
+    r = scenes.uniform(123, (600, 8))
+    volumes = []
+    for v in range(600):
+        cx, cy, rad = r[v, 0] * w, r[v, 1] * h, 4 + r[v, 2] * 30
+        nv = 3 + int(r[v, 3] * 5)
+        ang = np.sort(scenes.uniform(900 + v, (nv,)) * 2 * np.pi)
+        volumes.append(([(float(cx + rad * np.cos(a_)), float(cy + rad * np.sin(a_))) for a_ in ang], float(r[v, 4] * 8), float(2 + r[v, 5] * 60), True, bool(r[v, 6] < 0.7)))
+    vols, poly = scenes.height_volume_arrays(volumes)
+    for scale, position in (((1.0, 1.0), (0.0, 0.0)), ((1.5, 0.75), (-30.0, -20.0))):
+        d = scenes.gbuffer_render_desc(ground_z=0.0, viewport_position=position, viewport_scale=scale)
+        gb = native.GBufferTexture(ctx, None, abi.GBUFFER_FLOAT4, size=(w, h))
+        gb.render(d, vols, poly)
+        got = gb.download()
+        want = oracle.render_gbuffer(w, h, d, vols, poly)
+        assert np.array_equal(got, want)
+        assert len(np.unique(want[..., 3])) > 100
+        gb.close()
+
+
 def test_generated_ground_plane_equals_the_no_gbuffer_path(ctx):
     """A G-buffer holding only the ground plane at z = 0 decodes to exactly what sampleGBuffer assumes without one (LightCommon.fxh:130-141)."""
     w, h = 96, 64
