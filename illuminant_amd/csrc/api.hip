@@ -1835,6 +1835,15 @@ int32_t ilm_sdf_render_slices(IlmHandle h, IlmHandle hclear, const IlmDistanceFi
         // hv.Bounds.Expand(DistanceLimit, DistanceLimit), :216
         v.x0 = (bx0 - ILM_DISTANCE_LIMIT) * px_per_unit_x; v.x1 = (bx1 + ILM_DISTANCE_LIMIT) * px_per_unit_x;
         v.y0 = (by0 - ILM_DISTANCE_LIMIT) * px_per_unit_y; v.y1 = (by1 + ILM_DISTANCE_LIMIT) * px_per_unit_y;
+        // a circle around the polygon (centre of its bounds, the farthest vertex, rounded up): outside it a texel's distance to the
+        // polygon is at least its distance to the circle
+        const double ccx = 0.5 * ((double)bx0 + (double)bx1), ccy = 0.5 * ((double)by0 + (double)by1);
+        double rr = 0.0;
+        for (int e = 0; e < hv.VertexCount; e++) rr = std::max(rr, std::hypot((double)P[2 * e] - ccx, (double)P[2 * e + 1] - ccy));
+        v.cx = (float)ccx; v.cy = (float)ccy;
+        v.radius = (float)(rr * (1.0 + 1e-6) + 1e-3 + std::fabs(ccx - (double)(float)ccx) + std::fabs(ccy - (double)(float)ccy));
+        v.radius = std::nextafter(v.radius, INFINITY);          // (a NaN vertex leaves a NaN radius: the kernel never culls on it)
+        v._pad = 0.0f;
         vols.push_back(v);
     }
 

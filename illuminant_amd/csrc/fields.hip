@@ -248,6 +248,22 @@ __global__ __launch_bounds__(256) ILM_FIELD_OCCUPANCY void render_slices_kernel(
         if (!((V.x0 <= tmaxx) && (V.x1 > tminx) && (V.y0 <= tmaxy) && (V.y1 > tminy)))
             continue;
         const bool covered = in_slice && (cxp >= V.x0) && (cxp < V.x1) && (cyp >= V.y0) && (cyp < V.y1);
+        // Culling (r04; the reference rasterises the polygon's bounds expanded by DistanceLimit = 520 units, LightingRenderer.cs:316, but a
+        // texel farther than DISTANCE_ZERO x MaximumEncodedDistance from the volume encodes a value <= 0, which MAX over a target
+        // floored at 0 never keeps): outside the circle around the polygon the distance the shader computes is
+        //     min(distance to the polygon, sqrt(999999)) + 1.5 + max(dz, 0)  >=  min(|p - c| - radius, 999),
+        // so if that bound exceeds (DISTANCE_ZERO - the smallest of the four running maxima) x MaximumEncodedDistance by a unit -- far
+        // more than the roundings of the bound and of the encoding can move either side -- MAX leaves the texel as it is for all four
+        // slices.  The volume is evaluated only when some covered lane of the wave can still change.
+        {
+            const float ddx = wx - V.cx, ddy = wy - V.cy;
+            const float to_centre = sqrtf(ddx * ddx + ddy * ddy);
+            const float least = fminf(fminf(acc0, acc1), fminf(acc2, acc3));
+            const float need = fmaxf((kDistanceZero - least) * a.max_encoded + 1.0f, 1.0f);     // (the bound only speaks about texels outside the circle)
+            const bool cannot_change = (need <= 999.0f) && (a.max_encoded <= 65536.0f) && (to_centre >= need + V.radius);
+            if (__ballot(covered && !cannot_change) == 0ull)
+                continue;
+        }
         // Inigo Quilez' sdPolygon (Fracture SDF2D.fxh sdPolygonInit / sdPolygonVertex): every edge exactly once
         float dist_sq = 999999.0f, sign = 1.0f;
         const float2* P = a.polygon_xy + V.first_vertex;

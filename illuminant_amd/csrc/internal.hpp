@@ -249,6 +249,8 @@ struct FieldVolume {
     int32_t first_vertex, vertex_count;
     float z0, z1;               // zRange = (ZBase, ZBase + Height)
     float x0, x1, y0, y1;       // hv.Bounds.Expand(DistanceLimit) in slice-local pixels
+    float cx, cy, radius;       // a circle (world units) that holds the polygon, radius rounded up: the culling bound of fields.hip
+    float _pad;
 };
 struct FieldLaunch {
     uint2* atlas; const uint2* clear_source; int32_t atlas_w;

@@ -49,6 +49,31 @@ def test_every_type_matches_oracle_bit_for_bit(ctx, oracle, fmt, resolution):
     assert (want > 0).mean() > 0.3
 
 
+@pytest.mark.parametrize("fmt", [abi.SDF_UNORM16, abi.SDF_FP16])
+@pytest.mark.parametrize("max_encoded", [48.0, 128.0, 1400.0])
+def test_many_height_volumes_far_apart_match_oracle_bit_for_bit(ctx, oracle, fmt, max_encoded):
+    """70 small polygons (some concave, some degenerate: one vertex, two vertices) scattered over a 1024 x 768 world: most texels are
+    farther from most volumes than DISTANCE_ZERO x MaximumEncodedDistance, where the kernel culls a volume on the circle around its polygon
+    (the reference rasterises 520 units around each) -- every code must still be the oracle's, for a short reach, the usual one, and one
+    beyond sdPolygon's own distance cap (999: no culling there)."""
+    extent = (1024, 768)
+    layout = scenes.DistanceFieldLayout(extent[0], extent[1], 64.0, 6, 0.25, max_encoded)
+    r = scenes.uniform(321, (70, 8))
+    volumes = []
+    for v in range(70):
+        cx, cy, rad = r[v, 0] * extent[0], r[v, 1] * extent[1], 5 + r[v, 2] * 40
+        nv = 1 + (v % 7)                                     # 1 .. 7 vertices
+        ang = np.sort(scenes.uniform(1300 + v, (nv,)) * 2 * np.pi)
+        rr = rad * (0.4 + 0.6 * scenes.uniform(1400 + v, (nv,)))       # uneven radii: concave outlines
+        volumes.append(([(float(cx + rr[k] * np.cos(ang[k])), float(cy + rr[k] * np.sin(ang[k]))) for k in range(nv)],
+                        float(r[v, 4] * 20), float(2 + r[v, 5] * 50), bool(r[v, 6] < 0.5)))
+    vols, poly = scenes.height_volume_arrays(volumes)
+    got = render_gpu(ctx, layout, None, vols, poly, fmt=fmt)
+    want = render_oracle(oracle, layout, None, vols, poly, fmt=fmt)
+    assert np.array_equal(got, want), "%d texel channels differ" % int((got != want).sum())
+    assert 0.02 < (want > 0).mean()
+
+
 @pytest.mark.parametrize("typ", [abi.OBSTRUCTION_ELLIPSOID, abi.OBSTRUCTION_BOX, abi.OBSTRUCTION_CYLINDER, abi.OBSTRUCTION_SPHEROID,
                                  abi.OBSTRUCTION_OCTAGON])
 def test_single_type_scenes(ctx, oracle, typ):

@@ -203,7 +203,7 @@ for seed in range(first, first + count):
         bad_step.append((seed, list(got_counts), list(want_counts)))
     sysm.close(); eng.close()
 # ---- distance-field generation (exact culling!) and the particle rasteriser, every 4th seed (the oracle side is slower) ------------------
-bad_field, bad_raster, field_texels, raster_worst = [], [], 0, 0
+bad_field, bad_raster, field_texels, raster_worst, field_volume_scenes = [], [], 0, 0, 0
 for seed in range(first, first + count, 4):
     rng = np.random.default_rng(seed + 77777)
     ext = (int(rng.integers(64, 300)), int(rng.integers(64, 240)))
@@ -214,10 +214,25 @@ for seed in range(first, first + count, 4):
     fmt = abi.SDF_FP16 if seed % 8 < 4 else abi.SDF_UNORM16
     d = scenes.render_desc(layout)
     triplets = list(range(0, layout.slice_count, 3))
+    # every other scene also carries height volumes (DistanceToPolygon; the kernel culls a volume on the circle around its polygon) and a
+    # random MaximumEncodedDistance: short reaches cull most texel / volume pairs, long ones none
+    fvols, fpoly = None, None
+    if (seed // 4) % 2 == 1:
+        layout.maximum_encoded_distance = float(rng.choice([24.0, 64.0, 128.0, 300.0]))
+        d = scenes.render_desc(layout)
+        vlist = []
+        for _ in range(int(rng.integers(1, 30))):
+            cx, cy, rad = float(rng.uniform(0, ext[0])), float(rng.uniform(0, ext[1])), float(rng.uniform(2, 40))
+            nv = int(rng.integers(1, 8))
+            ang = np.sort(rng.uniform(0, 2 * np.pi, nv)); rr = rad * rng.uniform(0.3, 1.0, nv)
+            vlist.append(([(float(cx + rr[k] * np.cos(ang[k])), float(cy + rr[k] * np.sin(ang[k]))) for k in range(nv)],
+                          float(rng.uniform(0, 20)), float(rng.uniform(1, 60)), bool(rng.integers(0, 2))))
+        fvols, fpoly = scenes.height_volume_arrays(vlist)
+        field_volume_scenes += 1
     sdf = native.DistanceFieldTexture(ctx, None, fmt, size=(layout.atlas_width, layout.atlas_height))
-    sdf.render_slices(d, triplets, arr, None, None)
+    sdf.render_slices(d, triplets, arr, fvols, fpoly)
     got = sdf.download(); sdf.close()
-    want = oracle.render_distance_field_slices(np.zeros((layout.atlas_height, layout.atlas_width, 4), np.uint16), fmt, d, triplets, arr, None, None)
+    want = oracle.render_distance_field_slices(np.zeros((layout.atlas_height, layout.atlas_width, 4), np.uint16), fmt, d, triplets, arr, fvols, fpoly)
     field_texels += got.size
     if not np.array_equal(got, want):
         bad_field.append((seed, int((got != want).sum())))
@@ -313,7 +328,8 @@ print("seeds %d..%d" % (first, first + count - 1))
 print("G-buffer meshes: %d scenes with a differing texel of %d (%.2f M texels; channels 1-3 bit-equal, channel 0 within atan2's last bits)"
       % (len(bad_gbuffer), len(range(first + (first % 2), first + count, 2)), gbuffer_texels / 1e6))
 for b in bad_gbuffer[:10]: print("   ", b)
-print("field generation: %d scenes with differing codes of %d (%.1f M texel channels compared)" % (len(bad_field), len(range(first, first + count, 4)), field_texels / 1e6))
+print("field generation: %d scenes with differing codes of %d, %d of them with height volumes (%.1f M texel channels compared)" % (
+    len(bad_field), len(range(first, first + count, 4)), field_volume_scenes, field_texels / 1e6))
 for b in bad_field[:10]: print("   ", b)
 print("rasteriser: %d scenes out of bounds; most edge pixels that flipped in one frame: %d" % (len(bad_raster), raster_worst))
 for b in bad_raster[:10]: print("   ", b)
