@@ -242,11 +242,40 @@ __global__ __launch_bounds__(256) ILM_FIELD_OCCUPANCY void render_slices_kernel(
     }
 
     // ---- height volumes: DistanceToPolygon, DistanceField.fx:75-115 -------------------------------
-    for (int v = 0; v < a.volume_count; v++) {
+    // The tile's list first (wave 0, as for the obstructions): the volumes whose expanded bounds touch the tile AND whose circle is
+    // within the encoded reach of some texel of it -- the per-texel culling below at its most generous (running maxima of 0), taken at
+    // the tile's centre with the tile's half diagonal and one more unit of slack.  A frame of hundreds of volumes leaves a tile a handful.
+    const float tile_half_diagonal = 0.5f * sqrtf(((float)kFieldTileW * a.inv_scale_x) * ((float)kFieldTileW * a.inv_scale_x) +
+                                                   ((float)kFieldTileH * a.inv_scale_y) * ((float)kFieldTileH * a.inv_scale_y));
+    const float widest_need = kDistanceZero * a.max_encoded + 1.0f;
+    const bool volumes_cullable = (widest_need <= 999.0f) && (a.max_encoded <= 65536.0f);
+    for (int vbatch = 0; vbatch < a.volume_count; vbatch += kFieldListCapacity) {
+    const int vbatch_n = min(kFieldListCapacity, a.volume_count - vbatch);
+    __syncthreads();
+    if (wave == 0) {
+        int base = 0;
+        for (int o0 = 0; o0 < vbatch_n; o0 += 64) {
+            const int oi = o0 + lane;
+            bool hit = false;
+            if (oi < vbatch_n) {
+                const FieldVolume& V = a.volumes[vbatch + oi];
+                hit = (V.x0 <= tmaxx) && (V.x1 > tminx) && (V.y0 <= tmaxy) && (V.y1 > tminy);
+                const float ddx = V.cx - tcx, ddy = V.cy - tcy;
+                if (volumes_cullable && (sqrtf(ddx * ddx + ddy * ddy) - tile_half_diagonal - 1.0f >= widest_need + V.radius))
+                    hit = false;
+            }
+            const unsigned long long m = __ballot(hit);
+            if (hit)
+                list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)oi;
+            base += __popcll(m);
+        }
+        if (lane == 0) list_count = base;
+    }
+    __syncthreads();
+    const int vn = list_count;
+    for (int vk = 0; vk < vn; vk++) {
+        const int v = vbatch + __builtin_amdgcn_readfirstlane((int)list[vk]);
         const FieldVolume& V = a.volumes[v];
-        // whole-tile reject on the expanded bounds, then the per-pixel raster test
-        if (!((V.x0 <= tmaxx) && (V.x1 > tminx) && (V.y0 <= tmaxy) && (V.y1 > tminy)))
-            continue;
         const bool covered = in_slice && (cxp >= V.x0) && (cxp < V.x1) && (cyp >= V.y0) && (cyp < V.y1);
         // Culling (r04; the reference rasterises the polygon's bounds expanded by DistanceLimit = 520 units, LightingRenderer.cs:316, but a
         // texel farther than DISTANCE_ZERO x MaximumEncodedDistance from the volume encodes a value <= 0, which MAX over a target
@@ -286,6 +315,7 @@ __global__ __launch_bounds__(256) ILM_FIELD_OCCUPANCY void render_slices_kernel(
         acc1 = fmaxf(acc1, kDistanceZero - (final_eval(slice_z[1], V.z0, V.z1, dxy) / a.max_encoded));
         acc2 = fmaxf(acc2, kDistanceZero - (final_eval(slice_z[2], V.z0, V.z1, dxy) / a.max_encoded));
         acc3 = fmaxf(acc3, kDistanceZero - (final_eval(slice_z[3], V.z0, V.z1, dxy) / a.max_encoded));
+    }
     }
 
 #ifdef ILM_FIELD_TRACE
