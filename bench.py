@@ -813,11 +813,19 @@ def main():
                 whole5_dev = ctx.TimerStop() / frames5        # this rank's stream, HIP events (r04: the host-clock figure over three frames carried 0.3-0.5 ms of bracket)
                 barrier()
                 whole5 = max_over_ranks(time.perf_counter() - t5) / frames5 * 1e3
+                # the lit frame alone through the same loop (same frame count, same clock): what the step adds is the difference
+                barrier()
+                ctx.TimerStart()
+                for f5 in range(frames5):
+                    r.RenderLighting(1.0, row_begin, row_end, False)
+                    if glm is not None:
+                        glm.gather(native.GATHER_RCCL)
+                lit5_dev = ctx.TimerStop() / frames5
                 lighting[name]["with_particles"] = {
                     "particles_per_gpu": Q5["live"], "particle_step_ms": round(step5_ms, 4),
                     "particle_step_gb_per_s": round(Q5["live"] * PARTICLE_BYTES_PER_SLOT / (step5_ms * 1e-3) / 1e9, 1),
                     "frame_ms_step_plus_lighting": round(whole5, 4), "frame_ms_step_plus_lighting_device_clock": round(whole5_dev, 4),
-                    "timed_frames": frames5,
+                    "lit_frame_alone_same_loop_device_clock": round(lit5_dev, 4), "timed_frames": frames5,
                     "lit_mpixels_per_s_with_particles": round(w * h / (whole5 * 1e-3) / 1e6, 2)}
                 del Q5, q5
             if rank == 0 and world == 1 and not args.no_cpu_baseline:
