@@ -38,3 +38,15 @@ def test_contract_flags_and_defaults(monkeypatch):
     a = bench.parse_args()
     assert (a.gpus, a.steps, a.warmup) == (8, 20, 5)
     assert bench.PARTICLE_BYTES_PER_SLOT == 112 and bench.HBM_PEAK_GBS == 8000.0
+
+
+def test_the_mesh_gbuffer_scene_is_what_the_row_says():
+    """next_rows.gbuffer_2p5d_1080p: 256 height volumes (top + front faces) and 64 billboards as float32 vertex rows, 2 507 triangles with the
+    ground plane's two."""
+    import numpy as np
+    gd, top, front, bb = bench.gbuffer_meshes_scene()
+    assert top.dtype == np.float32 and front.dtype == np.float32 and bb.dtype == np.float32
+    assert top.shape[1] == 9 and front.shape[1] == 9 and bb.shape == (256, 12)
+    assert len(top) % 3 == 0 and len(front) % 3 == 0
+    assert 2 + len(top) // 3 + len(front) // 3 + 128 == 2507
+    assert gd.TwoPointFiveD != 0 and gd.DistanceFieldExtentZ == 128.0
