@@ -136,7 +136,7 @@ hipError_t launch_soa_to_aos(const float* plane0, int64_t stride, float4* dst, i
 // standalone liveness count over the life plane of each chunk (CountLiveParticles.fx)
 hipError_t launch_count_live(float* const* chunk_bases, int64_t stride, int32_t span, int32_t slots, int32_t chunk_count, uint32_t* counts, hipStream_t stream);
 // ordered live-slot compaction of one chunk (ballot + prefix sum); *out_count is a device counter
-hipError_t launch_live_slots(const float* life, int32_t slots, uint32_t* out_slots, uint32_t capacity, uint32_t* out_count, hipStream_t stream);
+hipError_t launch_live_slots(const float* life, int32_t slots, uint32_t* out_slots, uint32_t capacity, uint32_t* out_count, uint32_t* block_counts, hipStream_t stream);
 
 struct GBufferView {
     const void* texels;

@@ -411,6 +411,19 @@ def test_erase_and_live_bookkeeping(ctx, oracle, rnd):
     sysm.close(); eng.close()
 
 
+@pytest.mark.parametrize("cs,dead", [(256, 0.3), (48, 0.9), (1024, 0.5), (16, 0.0)])
+def test_live_slot_lists_of_whole_chunks(ctx, rnd, cs, dead):
+    """ilm_chunk_live_slots over 64 / 3 / 1024 / 1 blocks of 1024 slots (the last one ragged for 48^2): ascending slot order, exact."""
+    n = cs * cs
+    eng, sysm = make_system(ctx, rnd, cs, 1)
+    pos, vel, attr = scenes.make_particles(900 + cs, n, dead_fraction=dead)
+    upload_state(sysm, 0, pos, vel, attr)
+    want = np.nonzero(pos[:, 3] > 0)[0].astype(np.uint32)
+    assert np.array_equal(sysm.live_slots(0), want) and len(want) > 0
+    assert sysm.live_counts()[0] == len(want) or (cs == 256 and dead == 0.0)
+    sysm.close(); eng.close()
+
+
 def test_live_count_saturates_like_the_reference(ctx, rnd):
     """A full 256^2 chunk holds 65 536 live particles; the reference's 16-bit additive target decodes 65 535."""
     cs = 256
