@@ -142,6 +142,7 @@ def parse_args():
                                                                  "a 5 s device-utilisation sampler sees it); 0: as --light-ms")
     ap.add_argument("--no-lighting", action="store_true")
     ap.add_argument("--no-cfg4", action="store_true", help="skip the 8 M-particle (cfg4 per-GPU share) measurement")
+    ap.add_argument("--no-cfg4-64m", action="store_true", help="skip cfg4 whole on one GPU (64 chunks of 1024^2 = 67 M particles, 5.4 GB; N > 1: measured by rank 0 alone)")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the SURVEY 8f measurements (read-back, particle lights, resolve)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -189,10 +190,178 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+# ---- what the ranks of one job say to each other outside the data path -----------------------------------------------
+
+class Ranks:
+    """Barrier, max / sum / list over the ranks of the job: small host payloads through `group.host_all_gather` (ilm_group_host_all_gather,
+    one RCCL all-gather on the job's only communicator; bytes in, a list of `world` bytes objects out).  `group` None = one rank.  `sync`
+    drains this rank's device (hipStreamSynchronize of the context stream).  Everything the N > 1 record needs from the other ranks goes
+    through this class, so tests/_gloo_worker.py can run the record assembly at world 2 on CPU with a stand-in group."""
+
+    def __init__(self, group, rank, world, sync):
+        self.group, self.rank, self.world, self.sync = group, rank, world, sync
+
+    def barrier(self):
+        """Device idle on every rank, then (N > 1) a collective that no rank leaves before every rank has entered it."""
+        self.sync()
+        if self.group is not None:
+            self.group.host_all_gather(b"\0" * 8)
+
+    def doubles(self, x):
+        """x of every rank, in rank order (identical list on every rank)."""
+        import struct
+        if self.group is None:
+            return [float(x)]
+        return [struct.unpack("<d", b[:8])[0] for b in self.group.host_all_gather(struct.pack("<d", float(x)))]
+
+    def max(self, x):
+        return max(self.doubles(x))
+
+    def sum(self, x):
+        return sum(self.doubles(x))
+
+    def solo(self):
+        """The same interface for a phase ONE rank runs alone while the others wait at the next barrier."""
+        return Ranks(None, self.rank, 1, self.sync)
+
+
+def time_blocks(ctx, ranks, one_step, k, n_blocks):
+    """n_blocks timed blocks of EXACTLY k calls of one_step() each, every block between two barriers: [(wall seconds, max over ranks;
+    this rank's device milliseconds, HIP events on the context stream)], sorted by wall time."""
+    out = []
+    for _ in range(n_blocks):
+        ranks.barrier()
+        ctx.TimerStart()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            one_step()
+        g = ctx.TimerStop()
+        ranks.barrier()
+        out.append((ranks.max(time.perf_counter() - t0), g))
+    out.sort()
+    return out
+
+
+def particle_row(world_units, live_per_rank, k, blocks, kernel, traffic=None):
+    """A particle-step row from time_blocks(): median block; `world_units` = how many ranks' units the wall time covers."""
+    w, g = blocks[len(blocks) // 2]
+    gbs = live_per_rank * PARTICLE_BYTES_PER_SLOT / (g / k * 1e-3) / 1e9
+    return {"mparticle_steps_per_s": round(world_units * live_per_rank * k / w / 1e6, 1), "ms_per_step": round(w / k * 1e3, 5), "steps": k,
+            "particles_per_gpu": live_per_rank,
+            "timed_blocks": {"blocks": len(blocks), "steps_per_block": k, "headline": "median block", "ms_per_step_min": round(blocks[0][0] / k * 1e3, 5),
+                             "ms_per_step_max": round(blocks[-1][0] / k * 1e3, 5)},
+            "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                         **step_traffic_fields(traffic, live_per_rank), "kernel": kernel, "bytes_per_unit": PARTICLE_BYTES_PER_SLOT,
+                         "units_per_launch": live_per_rank, "launch_ms": round(g / k, 5)}}
+
+
+def balance_strips(glm, ranks, height, packed_lights, time_strip, rounds=2):
+    """The strips of an N-rank lit frame: whole 16-row bands cut where the lights' raster footprints say the work is equal
+    (sharding.balanced_row_strips; every rank computes the same table from the same packed lights), then re-cut `rounds` times from what
+    the strips COST: every rank times its own strip (time_strip(begin, end) -> ms), the times are all-gathered, every rank computes the
+    same new table (sharding.rebalance_row_strips) -- the footprint model cannot see the obstacle field.  glm.set_strips is a collective
+    that checks that the ranks agree (ilm_group_lightmap_set_strips).  Returns the history [{strips, how, ms}]."""
+    from illuminant_amd import sharding
+    glm.set_strips(sharding.balanced_row_strips(height, ranks.world, packed_lights))
+    history = [{"strips": [list(s_) for s_ in glm.strips], "how": "footprint model"}]
+    for round_ in range(rounds):
+        b, e = glm.strips[ranks.rank]
+        times = ranks.doubles(time_strip(b, e))
+        history[-1]["ms"] = [round(t, 4) for t in times]
+        glm.set_strips(sharding.rebalance_row_strips(glm.strips, times, height))
+        history.append({"strips": [list(s_) for s_ in glm.strips], "how": "measured, round %d" % (round_ + 1)})
+    return history
+
+
+def scaling_detail(world, share, share_solo, full_64m_solo, strong_64m, per_rank_rates, frames):
+    """The N > 1 line describes itself (VERDICT r04 #1c): every ratio names its denominator, and the denominators are measured by rank 0
+    ALONE in the same job (the other ranks wait at a barrier), so that no ratio divides across workloads or across boxes.
+      share          the headline row: 8 chunks of 1024^2 per rank, all ranks stepping together (aggregate over the job)
+      share_solo     the same 8 chunks stepped by rank 0 alone                               -> weak_vs_share
+      full_64m_solo  64 chunks of 1024^2 = cfg4 whole on rank 0's GPU alone                   -> strong_vs_one_gpu_64m
+      strong_64m     cfg4 whole sharded over the job: 64 / world chunks per rank (chunk c on rank c mod world), all ranks together
+      frames         per lit frame: this job's strips (per-rank ms, max, sum), the exchange alone, the composited frame, and the whole
+                     frame on rank 0's GPU alone."""
+    d = {"ranks": world,
+         "particles": {
+             "aggregate_mparticle_steps_per_s": share["mparticle_steps_per_s"],
+             "per_rank_mparticle_steps_per_s": [round(r, 1) for r in per_rank_rates],
+             "share_one_gpu_alone": {"workload": "8 chunks of 1024^2 on rank 0's GPU, the other ranks idle", "mparticle_steps_per_s": share_solo["mparticle_steps_per_s"],
+                                     "ms_per_step": share_solo["ms_per_step"]},
+             "weak_vs_share": round(share["mparticle_steps_per_s"] / (world * share_solo["mparticle_steps_per_s"]), 4),
+             "weak_vs_share_is": "aggregate of the job / (ranks x share_one_gpu_alone): 1.0 = no rank slows another"}}
+    if full_64m_solo and strong_64m:
+        d["particles"].update({
+            "one_gpu_64m": {"workload": full_64m_solo["workload"], "mparticle_steps_per_s": full_64m_solo["mparticle_steps_per_s"],
+                            "ms_per_step": full_64m_solo["ms_per_step"], "frac_of_hbm_peak": full_64m_solo["roofline"]["frac"]},
+            "sharded_64m": {"workload": strong_64m["workload"], "mparticle_steps_per_s": strong_64m["mparticle_steps_per_s"], "ms_per_step": strong_64m["ms_per_step"]},
+            "strong_vs_one_gpu_64m": round(strong_64m["mparticle_steps_per_s"] / full_64m_solo["mparticle_steps_per_s"], 4),
+            "strong_vs_one_gpu_64m_is": "64 M particles stepped by the job (64 / ranks chunks per rank) / the same 64 M on rank 0's GPU alone; the north star asks >= 6.4 at 8 ranks"})
+    d["frames"] = frames
+    return d
+
+
+def finalize_record(out, world, forced_dist, step_us_cfg2):
+    """The last stage of the record: with N > 1 the whole-job number is taken where the north star puts the scaling target -- 64 M particles
+    on 8 GPUs = cfg4's per-GPU share (8 chunks of 1024^2 per rank, HBM-resident) -- and N x cfg2 (cache-resident on every GPU) becomes the
+    secondary row; then the summary and the key order (the driver keeps the parsed keys and the LAST ~2000 characters of the line: bulky
+    rows first; the rooflines, the CPU baseline, the scaling block and a compact summary of both hot paths last).  Pure: dict in, dict out."""
+    c4h = out.get("cfg4_share_8m_particles")
+    if (world > 1 or forced_dist) and c4h:
+        out["cfg2_weak_row"] = {"mparticle_steps_per_s": out["value"], "ms_per_step": out["ms_per_step"], "roofline": out["roofline"],
+                                "workload": out["config"]["workload"], "timed_blocks": out.pop("timed_blocks")}
+        out["value"] = c4h["mparticle_steps_per_s"]
+        out["ms_per_step"] = c4h["ms_per_step"]
+        out["roofline"] = dict(c4h["roofline"], resident="hbm (0.67 GB of particle state per GPU > %d MiB Infinity Cache)" % INFINITY_CACHE_MB)
+        out["timed_blocks"] = c4h["timed_blocks"]
+        out["config"]["workload"] = "cfg4: %d particles per GPU in 8 chunks of 1024^2 (64 M on 8 GPUs), Gravity(4 attractors)+Noise+UpdatePositions" % c4h["particles_per_gpu"]
+        out["config"]["particles_per_gpu"] = c4h["particles_per_gpu"]
+        out["config"]["parallelism"] = ("particles: chunk c on rank c mod %d, no data-path collective; lit frame: cost-balanced row strips of whole 16-row bands "
+                                        "(balanced_row_strips, then re-cut twice from the ranks' measured strip times: rebalance_row_strips), range exchange over RCCL send/recv" % world)
+    tail_keys = ["cpu_baseline", "roofline", "roofline_hbm_resident", "cfg4_full_64m_one_gpu", "roofline_lighting", "lit_mpixels_per_s", "scaling_detail", "summary"]
+    c4 = out.get("cfg4_share_8m_particles")
+    if c4:
+        out["roofline_hbm_resident"] = dict(c4["roofline"], workload="cfg4 per-GPU share: 8 chunks of 1024^2 = 8.4 M particles, 0.67 GB of state (> Infinity Cache)",
+                                            ms_per_step=c4["ms_per_step"], mparticle_steps_per_s=c4["mparticle_steps_per_s"])
+    cfg2_row = out.get("cfg2_weak_row", {"mparticle_steps_per_s": out["value"], "roofline": out["roofline"]})
+    summary = {"particles_cfg2": {"mparticle_steps_per_s": cfg2_row["mparticle_steps_per_s"], "us_per_step": round(step_us_cfg2, 2),
+                                  "frac_of_hbm_peak": cfg2_row["roofline"]["frac"], "resident": "infinity-cache"}}
+    if c4:
+        summary["particles_cfg4_share"] = {"mparticle_steps_per_s": c4["mparticle_steps_per_s"], "us_per_step": round(c4["roofline"]["launch_ms"] * 1e3, 1),
+                                           "frac_of_hbm_peak": c4["roofline"]["frac"], "resident": "hbm"}
+    c64 = out.get("cfg4_full_64m_one_gpu")
+    if c64:
+        summary["particles_cfg4_64m_one_gpu"] = {"mparticle_steps_per_s": c64["mparticle_steps_per_s"], "ms_per_step": c64["ms_per_step"],
+                                                 "frac_of_hbm_peak": c64["roofline"]["frac"], "resident": "hbm"}
+    for key, short in (("cfg3_1080p_64_lights_unorm16", "lighting_cfg3"), ("cfg5_4k_256_lights_fp16", "lighting_cfg5")):
+        row = out.get("lighting", {}).get(key)
+        if row:
+            summary[short] = {"ms_per_frame": row["roofline"]["launch_ms"], "timed_frames": row["timed_frames"], "lit_mpixels_per_s": row["lit_mpixels_per_s"],
+                              "gbuffer": "bound", "without_gbuffer_ms": row["without_gbuffer_ms"], "verified_counts": row.get("verified_counts"),
+                              "valu_issue_frac": row["roofline"]["frac"], "useful_frac": row["work_bound"]["useful_frac"],
+                              "gsamples_per_s": row["algorithmic_rate"]["gsamples_per_s"]}
+    out["summary"] = summary
+    for k in tail_keys:
+        if k in out:
+            out[k] = out.pop(k)
+    return out
+
+
 # ---- scenes (SURVEY 8d) ------------------------------------------------------------------------------------
 
-def build_particle_system(H, ctx, scenes, abi, chunk_size, n_chunks, rank, with_spawner=True):
-    """cfg2: n_chunks full chunks uploaded through Spawn(initializers) + a Spawner-fed chunk, Gravity x4 + Noise."""
+CHUNK_1024_IMAGES = {}     # rank -> the eight 1024^2 chunk images of cfg4 (generated once per process: ~1 s of host time per image)
+
+
+def cfg4_images(scenes, rank):
+    if rank not in CHUNK_1024_IMAGES:
+        CHUNK_1024_IMAGES[rank] = scenes.make_particles(1000 + rank, 8 * 1024 * 1024, pos_lo=(0, 0, 0), pos_hi=(1920, 1080, 32), life=(50.0, 90.0))
+    return CHUNK_1024_IMAGES[rank]
+
+
+def build_particle_system(H, ctx, scenes, abi, chunk_size, n_chunks, rank, with_spawner=True, replicate_cfg4_images=False):
+    """cfg2: n_chunks full chunks uploaded through Spawn(initializers) + a Spawner-fed chunk, Gravity x4 + Noise.
+    replicate_cfg4_images (chunk_size 1024): chunk c holds image c mod 8 of the rank's eight cfg4 images, its particles moved by
+    (3, 2) x (c div 8) pixels -- 64 chunks without 64 s of host-side generation, no two chunks alike; one Spawn call per chunk."""
     rnd = scenes.randomness_table(7)
     tp = H.ManualTimeProvider()
     ecfg = H.ParticleEngineConfiguration(chunk_size)
@@ -208,8 +377,21 @@ def build_particle_system(H, ctx, scenes, abi, chunk_size, n_chunks, rank, with_
     cfg.Color = col
     ps = H.ParticleSystem(engine, cfg)
     n = chunk_size * chunk_size * n_chunks
-    pos, vel, attr = scenes.make_particles(1000 + rank, n, pos_lo=(0, 0, 0), pos_hi=(1920, 1080, 32), life=(50.0, 90.0))
-    ps.Spawn(n, pos, vel, attr)
+    if replicate_cfg4_images or (chunk_size == 1024 and n_chunks == 8):
+        pos, vel, attr = cfg4_images(scenes, rank)
+    else:
+        pos, vel, attr = scenes.make_particles(1000 + rank, n, pos_lo=(0, 0, 0), pos_hi=(1920, 1080, 32), life=(50.0, 90.0))
+    if replicate_cfg4_images:
+        assert chunk_size == 1024
+        mc = chunk_size * chunk_size
+        for c in range(n_chunks):
+            sl = slice((c % 8) * mc, (c % 8 + 1) * mc)
+            p = pos[sl].copy()
+            p[:, 0] += np.float32(3.0 * (c // 8)); p[:, 1] += np.float32(2.0 * (c // 8))
+            ps.Spawn(mc, p, np.ascontiguousarray(vel[sl]), np.ascontiguousarray(attr[sl]))
+        pos = vel = attr = None           # (the CPU baseline replays cfg2, never this system)
+    else:
+        ps.Spawn(n, pos, vel, attr)
     assert len(ps.Chunks) == n_chunks, "ParticleSystem.MaxChunkCount is 64 (ParticleSystem.cs:49): use a larger --chunk-size"
 
     sp = H.Spawner(11 + rank)
@@ -258,17 +440,19 @@ def gbuffer_meshes_scene():
     return gd, np.ascontiguousarray(top, np.float32), np.ascontiguousarray(front, np.float32), np.ascontiguousarray(bbv, np.float32)
 
 
-def build_lighting(H, ctx, scenes, abi, width, height, n_lights, resolution, world, sdf_fmt, external_ptr=0, plain_twin=False):
+def build_lighting(H, ctx, scenes, abi, width, height, n_lights, resolution, world, sdf_fmt, external_ptr=0, plain_twin=False, light_seed=12):
     """The configured frame: EnableGBuffer is the reference's default (LightingRenderer.Configuration.cs:106) and SURVEY 8d defines cfg3 /
     cfg5 with the ground-plane G-buffer (texel (0.5, 1, 0, 1), Vector4 = 16 B per pixel: highQualityGBuffer defaults to true,
     Configuration.cs:178-188) -- UpdateFields renders it, every pixel goes through sampleGBuffer's texture branch (LightCommon.fxh:69-144).
-    plain_twin: a second renderer over the same environment and field WITHOUT a G-buffer (what r01-r03 timed), for the row beside it."""
+    plain_twin: a second renderer over the same environment and field WITHOUT a G-buffer (what r01-r03 timed), for the row beside it.
+    light_seed: the lights are scenes.random_lights(light_seed, n_lights, width, height, ramp = (200, 550) x width / 1920) set on the mirror's
+    SphereLightSource objects -- with seed 12 (cfg3) / 13 (cfg5) the frames tests/golden/full_frame_bands.json pins band by band."""
     env = H.LightingEnvironment()
     env.Ambient = [0.05, 0.05, 0.05, 1.0]
     sc = width / 1920.0
-    xs = scenes.uniform(13, (n_lights,), 0, width); ys = scenes.uniform(14, (n_lights,), 0, height)
-    zs = scenes.uniform(15, (n_lights,), 8.0, 64.0); rs = scenes.uniform(16, (n_lights,), 200.0 * sc, 550.0 * sc)
-    cols = scenes.uniform(17, (n_lights, 3), 0.2, 1.0)
+    xs = scenes.uniform(light_seed + 1, (n_lights,), 0, width); ys = scenes.uniform(light_seed + 2, (n_lights,), 0, height)
+    zs = scenes.uniform(light_seed + 3, (n_lights,), 8.0, 64.0); rs = scenes.uniform(light_seed + 4, (n_lights,), 200.0 * sc, 550.0 * sc)
+    cols = scenes.uniform(light_seed + 5, (n_lights, 3), 0.2, 1.0)
     lights = []
     for i in range(n_lights):
         l = H.SphereLightSource()
@@ -393,22 +577,10 @@ def main():
     import struct
     import ctypes as C_
 
-    def barrier():
-        """Device idle on every rank: hipStreamSynchronize of the context stream, then (N > 1) a collective that no rank leaves
-        before every rank has entered it."""
-        ctx.Sync()
-        if group is not None:
-            group.host_all_gather(b"\0" * 8)
-
-    def max_over_ranks(x):
-        if group is None:
-            return x
-        return max(struct.unpack("<d", b)[0] for b in group.host_all_gather(struct.pack("<d", x)))
-
-    def sum_over_ranks(x):
-        if group is None:
-            return x
-        return sum(struct.unpack("<d", b)[0] for b in group.host_all_gather(struct.pack("<d", float(x))))
+    ranks = Ranks(group, rank, world, ctx.Sync)
+    barrier, max_over_ranks, sum_over_ranks = ranks.barrier, ranks.max, ranks.sum
+    forced_dist = bool(os.environ.get("ILM_BENCH_FORCE_DIST"))
+    multi = world > 1 or forced_dist        # the N > 1 shape of the record (ILM_BENCH_FORCE_DIST: the same code at world 1, for one-GPU boxes)
 
     # ---- particles (the timed region of the contract) ------------------------------------------------------------
     P = build_particle_system(H, ctx, scenes, abi, args.chunk_size, args.chunks, rank)
@@ -579,44 +751,80 @@ def main():
                          "note": "cache-served bytes priced against the HBM peak because that is the contract's roofline: read it like cfg2's fraction, not like cfg4's"}}
         del scene
     cpu_init, cpu_rnd, cpu_desc_bytes = P["init"], P["rnd"], ps.LastStepBytes()
+    scaling_particles = None
     if not args.no_cfg4:
         del P, ps, spawner          # free cfg2's chunks before the 0.9 GB system is built
+        stream_kernel = "ilm::step_lean_kernel<no spawn, streaming> (two launches per step: the chunk range halved over the context's two streams)"
+        stream_traffic = profiled_traffic("ilm::step_lean_kernel<false, true>")
+        k4 = args.steps if multi else 30      # N > 1: this row is the headline -> EXACTLY K steps per block
+
+        def stepper(S, warm):
+            """one_step() of system S after `warm` untimed steps: the first ~40 steps after a large upload run ~10 % slower (clocks settle),
+            and the rows report the steady state -- median block, the spread beside it"""
+            s_, tp_, f_ = S["ps"], S["tp"], [0]
+
+            def one():
+                tp_.Advance(dt); s_.Update(f_[0]); f_[0] += 1
+            for _ in range(warm):
+                one()
+            return one
+
         Q = build_particle_system(H, ctx, scenes, abi, 1024, 8, rank, with_spawner=False)
-        qs, qtp = Q["ps"], Q["tp"]
-        # 60 untimed steps, then 5 blocks of 30: the first ~40 steps after a 0.9 GB upload run ~10 % slower (clocks settle), and the
-        # row reports the steady state -- median block, the spread beside it
-        f4 = 0
-        for _ in range(60):
-            qtp.Advance(dt); qs.Update(f4); f4 += 1
-        k4 = args.steps if (world > 1 or os.environ.get("ILM_BENCH_FORCE_DIST")) else 30      # N > 1: this row is the headline -> EXACTLY K steps per block
-        b4 = []
-        for _ in range(5):
+        q_step = stepper(Q, 60)
+        share_solo = None
+        if multi:
+            # rank 0 alone first (the other ranks idle at the barrier): the denominator of scaling_detail.weak_vs_share
             barrier()
-            ctx.TimerStart()
-            t0 = time.perf_counter()
-            for _ in range(k4):
-                qtp.Advance(dt); qs.Update(f4); f4 += 1
-            g = ctx.TimerStop()
+            if rank == 0:
+                share_solo = particle_row(1, Q["live"], k4, time_blocks(ctx, ranks.solo(), q_step, k4, 5), stream_kernel, stream_traffic)
             barrier()
-            b4.append((max_over_ranks(time.perf_counter() - t0), g))
-        b4.sort()
-        w4, g4 = b4[len(b4) // 2]
-        gbs4 = Q["live"] * PARTICLE_BYTES_PER_SLOT / (g4 / k4 * 1e-3) / 1e9
-        out["cfg4_share_8m_particles"] = {
-            "mparticle_steps_per_s": round(world * Q["live"] * k4 / w4 / 1e6, 1), "ms_per_step": round(w4 / k4 * 1e3, 5), "steps": k4,
-            "particles_per_gpu": Q["live"],
-            "timed_blocks": {"blocks": len(b4), "steps_per_block": k4, "headline": "median block", "ms_per_step_min": round(b4[0][0] / k4 * 1e3, 5),
-                             "ms_per_step_max": round(b4[-1][0] / k4 * 1e3, 5)},
-            "roofline": {"bound": "hbm", "achieved": round(gbs4, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs4 / HBM_PEAK_GBS, 4),
-                         **step_traffic_fields(profiled_traffic("ilm::step_lean_kernel<false, true>"), Q["live"]), "kernel": "ilm::step_lean_kernel<no spawn, streaming> (two launches per step: the chunk range halved over the context's two streams)", "bytes_per_unit": PARTICLE_BYTES_PER_SLOT,
-                         "units_per_launch": Q["live"], "launch_ms": round(g4 / k4, 5)}}
-        del Q, qs
+        b4 = time_blocks(ctx, ranks, q_step, k4, 5)
+        out["cfg4_share_8m_particles"] = particle_row(world, Q["live"], k4, b4, stream_kernel, stream_traffic)
+        per_rank_rates = ranks.doubles(Q["live"] * k4 / (b4[len(b4) // 2][1] * 1e-3) / 1e6)      # each rank's own device clock
+        live_share = Q["live"]
+        del Q, q_step
+
+        # cfg4 WHOLE on one device: 64 chunks of 1024^2 = 67 M particles, the reference's own ceiling (MaxChunkCount = 64,
+        # ParticleSystem.cs:49), 5.4 GB of state -- the denominator of the north star's "x 6.4 from 1 to 8 GPUs at 64 M particles".
+        # N = 1: a row of the line.  N > 1: rank 0 measures it ALONE, in this job, before the ranks step their shards together.
+        full_64m = strong_64m = None
+        if not args.no_cfg4_64m:
+            k64 = args.steps
+            if rank == 0:
+                F = build_particle_system(H, ctx, scenes, abi, 1024, 64, rank, with_spawner=False, replicate_cfg4_images=True)
+                full_64m = particle_row(1, F["live"], k64, time_blocks(ctx, ranks.solo(), stepper(F, 20), k64, 5), stream_kernel, stream_traffic)
+                full_64m["workload"] = ("cfg4 whole on ONE GPU: 64 chunks of 1024^2 = %d particles (5.4 GB of state), Gravity(4 attractors)+Noise+UpdatePositions; "
+                                        "chunk c = image c mod 8 of the share's eight, moved by (3, 2) x (c div 8) px" % F["live"])
+                full_64m["roofline"]["resident"] = "hbm (5.4 GB of particle state)"
+                del F
+                out["cfg4_full_64m_one_gpu"] = full_64m
+            if multi:
+                barrier()
+                # ... then the same 64 M sharded over the job: chunk c on rank c mod world = 64 / world chunks per rank, no collective
+                n_mine = len(range(rank, 64, world))
+                if n_mine == 8:
+                    strong_64m = dict(out["cfg4_share_8m_particles"], workload="64 chunks of 1024^2 over %d ranks = the share row (8 chunks per rank)" % world)
+                else:
+                    S = build_particle_system(H, ctx, scenes, abi, 1024, n_mine, rank, with_spawner=False, replicate_cfg4_images=True)
+                    bs = time_blocks(ctx, ranks, stepper(S, 20), k64, 5)
+                    total_live = int(ranks.sum(S["live"]))
+                    strong_64m = particle_row(1, total_live, k64, bs, stream_kernel, None)
+                    strong_64m["particles_per_gpu"] = S["live"]
+                    strong_64m["roofline"] = None        # (the row's rate is the job's; per-GPU rooflines are the share row's and one_gpu_64m's)
+                    strong_64m["workload"] = "64 chunks of 1024^2 over %d rank(s): %d chunks on this rank, %d particles in the job" % (world, n_mine, total_live)
+                    del S
+        if multi:
+            share_solo = share_solo or out["cfg4_share_8m_particles"]
+            scaling_particles = dict(share=out["cfg4_share_8m_particles"], share_solo=share_solo, full_64m_solo=full_64m, strong_64m=strong_64m,
+                                     per_rank_rates=per_rank_rates)
 
     # ---- lighting (second hot path; not part of the timed `value`) -------------------------------------------------
     if not args.no_lighting:
         lighting = {}
-        for name, (w, h, nl, res, wsize, fmt) in (("cfg3_1080p_64_lights_unorm16", (1920, 1080, 64, 0.25, 2048, abi.SDF_UNORM16)),
-                                                   ("cfg5_4k_256_lights_fp16", (3840, 2160, 256, 0.125, 4096, abi.SDF_FP16))):
+        frames_scaling = {}
+        pinned = json.load(open(os.path.join(ROOT, "tests", "golden", "full_frame_bands.json")))      # the oracle's counts over the same two frames
+        for name, (w, h, nl, res, wsize, fmt, lseed, pin) in (("cfg3_1080p_64_lights_unorm16", (1920, 1080, 64, 0.25, 2048, abi.SDF_UNORM16, 12, "cfg3")),
+                                                               ("cfg5_4k_256_lights_fp16", (3840, 2160, 256, 0.125, 4096, abi.SDF_FP16, 13, "cfg5"))):
             # screen split into `world` equal strips of whole 16-row tile bands (SURVEY 8e); with N > 1 the frame lives in the group's
             # lightmap (every rank holds world * R rows, the frame is the first h) and the strips are all-gathered in place over xGMI
             # by ilm_group_lightmap_gather on the render stream itself
@@ -626,33 +834,23 @@ def main():
             if group is not None:
                 glm = native.GroupLightmap(group, w, h, abi.LIGHTMAP_HALF4)
                 ext = glm.members[0].device_ptr()
-            L = build_lighting(H, ctx, scenes, abi, w, h, nl, res, wsize, fmt, ext, plain_twin=(group is None))
+            L = build_lighting(H, ctx, scenes, abi, w, h, nl, res, wsize, fmt, ext, plain_twin=(group is None), light_seed=lseed)
             r = L["renderer"]
             if group is not None:
-                # cost-balanced strips: whole 16-row bands cut where the lights' raster footprints say the work is equal
-                # (sharding.balanced_row_strips; every rank computes the same table from the same packed lights), exchanged range by
-                # range at their true rows (ilm_group_lightmap_set_strips + ncclSend / ncclRecv, group.hip exchange_ranges)
-                from illuminant_amd import sharding
+                # cost-balanced strips, re-cut twice from what they cost (balance_strips above); exchanged range by range at their true
+                # rows (ilm_group_lightmap_set_strips + ncclSend / ncclRecv, group.hip exchange_ranges)
                 packed = [abi.LightVertex.from_buffer_copy(H.LightingRenderer.PackSphereLightBytes(lsrc, 1.0, True)) for lsrc in L["env"].Lights]
-                glm.set_strips(sharding.balanced_row_strips(h, world, packed))
-                row_begin, row_end = glm.strips[rank]
-                # ... then re-cut from what the strips COST: two rounds of every rank timing its own strip (HIP events), the times
-                # all-gathered (every rank computes the same table: set_strips is a collective that checks it), new cuts at equal
-                # measured cost (sharding.rebalance_row_strips).  The footprint model cannot see the obstacle field.
-                strip_history = [{"strips": [list(s_) for s_ in glm.strips], "how": "footprint model"}]
-                for round_ in range(2):
+
+                def time_strip(b_, e_, n_=4, sync=barrier):
                     for _ in range(2):
-                        r.RenderLighting(1.0, row_begin, row_end, False)
-                    barrier()
+                        r.RenderLighting(1.0, b_, e_, False)
+                    sync()
                     ctx.TimerStart()
-                    for _ in range(4):
-                        r.RenderLighting(1.0, row_begin, row_end, False)
-                    mine = ctx.TimerStop() / 4.0
-                    times = [struct.unpack("<d", b)[0] for b in group.host_all_gather(struct.pack("<d", mine))]
-                    strip_history[-1]["ms"] = [round(t, 4) for t in times]
-                    glm.set_strips(sharding.rebalance_row_strips(glm.strips, times, h))
-                    row_begin, row_end = glm.strips[rank]
-                    strip_history.append({"strips": [list(s_) for s_ in glm.strips], "how": "measured, round %d" % (round_ + 1)})
+                    for _ in range(n_):
+                        r.RenderLighting(1.0, b_, e_, False)
+                    return ctx.TimerStop() / n_
+                strip_history = balance_strips(glm, ranks, h, packed, time_strip)
+                row_begin, row_end = glm.strips[rank]
             if group is None and os.environ.get("ILM_BENCH_STRIP"):
                 # EXPERIMENT (tools/ab_tilemap.sh): one GPU renders strip k of n equal bands only -- what a rank of an n-GPU frame launches
                 spec = os.environ["ILM_BENCH_STRIP"]
@@ -688,6 +886,44 @@ def main():
             pairs_local, traced_local = int(stats[1]), int(stats[2])
             samples_total = int(sum_over_ranks(samples))
             frame_ms = lwall / light_frames * 1e3
+            # The timed frame IS the pinned frame: the instrumented launch's SDF-sample, pixel.light-pair and traced-pair
+            # totals over the job's strips must equal the CPU oracle's over the same frame (tests/golden/full_frame_bands.json, every
+            # 16-row band of it: tests/test_full_frame_bands_gpu.py) -- integer equality inside this run, or the run stops.
+            verified_counts = None
+            if not os.environ.get("ILM_BENCH_STRIP"):
+                got_counts = (samples_total, int(sum_over_ranks(pairs_local)), int(sum_over_ranks(traced_local)))
+                want_counts = (pinned[pin]["sdf_samples"], pinned[pin]["pairs"], pinned[pin]["traced"])
+                if got_counts != want_counts:
+                    raise SystemExit("bench.py: %s: the timed frame did (samples, pairs, traced) = %s but the oracle's pinned frame has %s" % (name, got_counts, want_counts))
+                verified_counts = True
+            frame_scaling = None
+            if glm is not None:
+                # the pieces of the composited frame, each alone: this job's strips (every rank its own, all at once), the exchange
+                # (events around the gathers only) and the WHOLE frame on rank 0's GPU alone (the other ranks wait) = the named
+                # denominator of speedup_vs_one_gpu_frame
+                n_s = int(max(8, min(light_frames, 200)))
+                strips_ms = ranks.doubles(time_strip(row_begin, row_end, n_s))
+                barrier()
+                ctx.TimerStart()
+                for _ in range(n_s):
+                    glm.gather(native.GATHER_RCCL)
+                exchange_ms = ranks.doubles(ctx.TimerStop() / n_s)
+                barrier()
+                one_gpu_ms = 0.0
+                if rank == 0:
+                    one_gpu_ms = time_strip(0, h, int(max(4, min(light_frames // 4, 40))), sync=ctx.Sync)
+                    r.RenderLighting(1.0, row_begin, row_end, False)
+                barrier()
+                glm.gather(native.GATHER_RCCL)        # (rank 0's copy of the other strips comes from their owners again)
+                one_gpu_ms = ranks.max(one_gpu_ms)
+                frame_scaling = {
+                    "strips": [list(s_) for s_ in glm.strips], "strip_ms": [round(t, 4) for t in strips_ms], "strip_ms_max": round(max(strips_ms), 4),
+                    "strip_ms_sum": round(sum(strips_ms), 4), "exchange_ms": round(max(exchange_ms), 4), "exchange_ms_per_rank": [round(t, 4) for t in exchange_ms],
+                    "exchange_is": "HIP events around back-to-back ilm_group_lightmap_gather calls alone (ncclSend / ncclRecv of the strips), max over ranks",
+                    "composited_frame_ms": round(frame_ms, 4), "composited_frame_is": "strip + gather per frame on one stream, wall clock, max over ranks",
+                    "one_gpu_frame_ms": round(one_gpu_ms, 4), "one_gpu_frame_is": "the whole frame rendered by rank 0's GPU alone in this job (the other ranks idle)",
+                    "share_ms": round(one_gpu_ms / world, 4), "speedup_vs_one_gpu_frame": round(one_gpu_ms / frame_ms, 3)}
+                frames_scaling[pin] = frame_scaling
             my_px = (row_end - row_begin) * w
             # this rank's launch: SDF samples + the G-buffer texel of every pixel (Vector4) + lightmap write (half4) + light records
             alg_bytes = samples * SDF_SAMPLE_BYTES + my_px * (16 + 8) + nl * 128
@@ -716,7 +952,10 @@ def main():
                 "lit_mpixels_per_s": round(w * h / (frame_ms * 1e-3) / 1e6, 2),
                 "ms_per_frame": round(frame_ms, 4), "timed_frames": light_frames, "rows": [int(row_begin), int(row_end)],
                 "strip_balancing": strip_history if group is not None else None,
-                "sdf_samples_per_frame": samples_total,
+                "sdf_samples_per_frame": samples_total, "verified_counts": verified_counts,
+                "verified_counts_is": ("the instrumented launch of THIS run: (SDF samples, pixel.light pairs, traced pairs) = the CPU oracle's totals over the same frame, "
+                                       "tests/golden/full_frame_bands.json[%s] = (%d, %d, %d)" % (pin, pinned[pin]["sdf_samples"], pinned[pin]["pairs"], pinned[pin]["traced"])) if verified_counts else None,
+                "scaling": frame_scaling,
                 "pixel_light_pairs_this_rank": pairs_local, "traced_pairs_this_rank": traced_local,
                 "field_generation": L["field_generation"],
                 "gbuffer": "ground plane rendered by UpdateFields, Vector4 (16 B per pixel), bound: every pixel decodes its texel (LightCommon.fxh:69-144)",
@@ -1033,45 +1272,11 @@ def main():
 
     if group is not None:
         out["config"]["rccl_communicator_ranks_per_rank"] = [struct.unpack("<i", b[:4])[0] for b in group.host_all_gather(struct.pack("<ii", comm_ranks, 0))]
-    c4h = out.get("cfg4_share_8m_particles")
-    if (world > 1 or os.environ.get("ILM_BENCH_FORCE_DIST")) and c4h:
-        # N > 1: the whole-job number is taken where the north star puts the scaling target -- 64 M particles on 8 GPUs = cfg4's per-GPU
-        # share (8 chunks of 1024^2 per rank, HBM-resident) -- and N x cfg2 (cache-resident on every GPU) becomes the secondary row.
-        out["cfg2_weak_row"] = {"mparticle_steps_per_s": out["value"], "ms_per_step": out["ms_per_step"], "roofline": out["roofline"],
-                                "workload": out["config"]["workload"], "timed_blocks": out.pop("timed_blocks")}
-        out["value"] = c4h["mparticle_steps_per_s"]
-        out["ms_per_step"] = c4h["ms_per_step"]
-        out["roofline"] = dict(c4h["roofline"], resident="hbm (0.67 GB of particle state per GPU > %d MiB Infinity Cache)" % INFINITY_CACHE_MB)
-        out["timed_blocks"] = c4h["timed_blocks"]
-        out["config"]["workload"] = "cfg4: %d particles per GPU in 8 chunks of 1024^2 (64 M on 8 GPUs), Gravity(4 attractors)+Noise+UpdatePositions" % c4h["particles_per_gpu"]
-        out["config"]["particles_per_gpu"] = c4h["particles_per_gpu"]
-        out["config"]["parallelism"] = ("particles: chunk c on rank c mod %d, no data-path collective; lit frame: cost-balanced row strips of whole 16-row bands "
-                                        "(balanced_row_strips, then re-cut twice from the ranks' measured strip times: rebalance_row_strips), range exchange over RCCL send/recv" % world)
-
-    # The driver keeps the parsed keys and the LAST ~2000 characters of the line: the bulky rows go first, the two rooflines, the CPU
-    # baseline and a compact summary of both hot paths last.
-    tail_keys = ["cpu_baseline", "roofline", "roofline_hbm_resident", "roofline_lighting", "lit_mpixels_per_s", "summary"]
-    c4 = out.get("cfg4_share_8m_particles")
-    if c4:
-        out["roofline_hbm_resident"] = dict(c4["roofline"], workload="cfg4 per-GPU share: 8 chunks of 1024^2 = 8.4 M particles, 0.67 GB of state (> Infinity Cache)",
-                                            ms_per_step=c4["ms_per_step"], mparticle_steps_per_s=c4["mparticle_steps_per_s"])
-    cfg2_row = out.get("cfg2_weak_row", {"mparticle_steps_per_s": out["value"], "roofline": out["roofline"]})
-    summary = {"particles_cfg2": {"mparticle_steps_per_s": cfg2_row["mparticle_steps_per_s"], "us_per_step": round(step_ms_gpu * 1e3, 2),
-                                  "frac_of_hbm_peak": cfg2_row["roofline"]["frac"], "resident": "infinity-cache"}}
-    if c4:
-        summary["particles_cfg4_share"] = {"mparticle_steps_per_s": c4["mparticle_steps_per_s"], "us_per_step": round(c4["roofline"]["launch_ms"] * 1e3, 1),
-                                           "frac_of_hbm_peak": c4["roofline"]["frac"], "resident": "hbm"}
-    for key, short in (("cfg3_1080p_64_lights_unorm16", "lighting_cfg3"), ("cfg5_4k_256_lights_fp16", "lighting_cfg5")):
-        row = out.get("lighting", {}).get(key)
-        if row:
-            summary[short] = {"ms_per_frame": row["roofline"]["launch_ms"], "timed_frames": row["timed_frames"], "lit_mpixels_per_s": row["lit_mpixels_per_s"],
-                              "gbuffer": "bound", "without_gbuffer_ms": row["without_gbuffer_ms"],
-                              "valu_issue_frac": row["roofline"]["frac"], "useful_frac": row["work_bound"]["useful_frac"],
-                              "gsamples_per_s": row["algorithmic_rate"]["gsamples_per_s"]}
-    out["summary"] = summary
-    for k in tail_keys:
-        if k in out:
-            out[k] = out.pop(k)
+    if multi and scaling_particles:
+        out["scaling_detail"] = scaling_detail(world, frames=(frames_scaling if not args.no_lighting else {}), **scaling_particles)
+        out["scaling_detail"]["note"] = ("the contract's top-level \"scaling\" stays the string \"weak\" (fixed work per GPU in the headline row); "
+                                         "this block carries the named ratios")
+    out = finalize_record(out, world, forced_dist, step_ms_gpu * 1e3)
 
     sys.stdout.flush()
     os.dup2(stdout_fd, 1)

@@ -552,51 +552,67 @@ int32_t ilm_group_lightmap_strip(IlmHandle h, int32_t rank, int32_t* out_row_beg
 int32_t ilm_group_lightmap_set_strips(IlmHandle h, const int32_t* row_begins, const int32_t* row_ends) {
     GroupLightmap* m = glm_from(h);
     if (!m) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group lightmap handle");
-    const int world = m->group->world;
-    if (!row_begins || !row_ends) {                       // back to the equal slots
-        for (int r = 0; r < world; r++) {
-            m->begin[(size_t)r] = std::min(r * m->slot_rows, m->height);
-            m->end[(size_t)r] = std::min((r + 1) * m->slot_rows, m->height);
-        }
-        m->equal_slots = true;
-        return ILM_OK;
-    }
-    // contiguous, in rank order, whole tile bands (the last one may be ragged), covering the frame exactly
-    int at = 0;
-    for (int r = 0; r < world; r++) {
-        if (row_begins[r] != at || row_ends[r] < row_begins[r] || row_ends[r] > m->height)
-            return api_fail(ILM_ERR_INVALID_ARGUMENT, "strip %d = [%d, %d) does not continue at row %d of a %d-row frame", r, row_begins[r], row_ends[r], at, m->height);
-        if ((row_ends[r] % kTileRows) != 0 && row_ends[r] != m->height)
-            return api_fail(ILM_ERR_INVALID_ARGUMENT, "strip %d ends at row %d: strips are whole %d-row tile bands", r, row_ends[r], kTileRows);
-        at = row_ends[r];
-    }
-    if (at != m->height) return api_fail(ILM_ERR_INVALID_ARGUMENT, "the strips end at row %d of a %d-row frame", at, m->height);
-    bool equal = true;
-    for (int r = 0; r < world; r++) {
-        equal = equal && row_begins[r] == std::min(r * m->slot_rows, m->height) && row_ends[r] == std::min((r + 1) * m->slot_rows, m->height);
-        m->begin[(size_t)r] = row_begins[r];
-        m->end[(size_t)r] = row_ends[r];
-    }
-    m->equal_slots = equal;
-    // One process per GPU: every rank sizes its ncclSend / ncclRecv from its own copy of the table, so two ranks with different tables
-    // would exchange mismatched byte counts (a hang, or rows in the wrong place).  The call is a collective there: the ranks compare a
-    // hash of the table (one 8-byte host all-gather, once per installation) and all fail with ILM_ERR_STATE if they disagree.
     Group* g = m->group;
-    if (g->rank_mode && g->world > 1) {
-        uint64_t hash = 1469598103934665603ull;             // FNV-1a over (begin, end) in rank order
+    const int world = g->world;
+    // 1. validate into a LOCAL verdict (nothing is installed yet, and nobody returns before the ranks have compared notes)
+    enum : uint64_t { kTableEqualSlots = 0x45515541u, kTableInvalid = 0x42414421u };        // sentinels of the cross-rank check below
+    const bool reset = !row_begins || !row_ends;           // NULL / NULL: back to the equal slots -- a collective like any other table
+    char why[192] = "";
+    bool valid = true;
+    if (!reset) {
+        // contiguous, in rank order, whole tile bands (the last one may be ragged), covering the frame exactly
+        int at = 0;
+        for (int r = 0; r < world && valid; r++) {
+            if (row_begins[r] != at || row_ends[r] < row_begins[r] || row_ends[r] > m->height) {
+                snprintf(why, sizeof(why), "strip %d = [%d, %d) does not continue at row %d of a %d-row frame", r, row_begins[r], row_ends[r], at, m->height);
+                valid = false;
+            } else if ((row_ends[r] % kTileRows) != 0 && row_ends[r] != m->height) {
+                snprintf(why, sizeof(why), "strip %d ends at row %d: strips are whole %d-row tile bands", r, row_ends[r], kTileRows);
+                valid = false;
+            }
+            at = row_ends[r];
+        }
+        if (valid && at != m->height) {
+            snprintf(why, sizeof(why), "the strips end at row %d of a %d-row frame", at, m->height);
+            valid = false;
+        }
+    }
+    // 2. One process per GPU: every rank sizes its ncclSend / ncclRecv from its own copy of the table, so two ranks with different tables
+    //    would exchange mismatched byte counts (a hang, or rows in the wrong place).  The call is ALWAYS a collective there:
+    //    every rank -- also one whose table is malformed, and one that resets to the equal slots -- enters the same 8-byte host all-gather
+    //    with a hash of what it was handed (FNV-1a over (begin, end) in rank order; a sentinel for "invalid" and one for "equal slots"),
+    //    and all ranks succeed or fail together.  (A bad handle cannot take part: it names no group.)
+    uint64_t hash = 1469598103934665603ull;
+    if (!valid) hash = kTableInvalid;
+    else if (reset) hash = kTableEqualSlots;
+    else
         for (int r = 0; r < world; r++)
-            for (const int v : { m->begin[(size_t)r], m->end[(size_t)r] })
+            for (const int v : { row_begins[r], row_ends[r] })
                 for (int b = 0; b < 4; b++) { hash ^= (uint64_t)((v >> (8 * b)) & 0xFF); hash *= 1099511628211ull; }
+    int disagree = -1, invalid_rank = valid ? -1 : g->first_rank;
+    if (g->rank_mode && world > 1) {
         std::vector<uint64_t> all((size_t)world, 0);
         all[(size_t)g->first_rank] = hash;
         const int32_t rc = host_all_gather(g, &all[(size_t)g->first_rank], all.data(), sizeof(uint64_t));
         if (rc != ILM_OK) return rc;
-        for (int r = 0; r < world; r++)
-            if (all[(size_t)r] != hash) {
-                ilm_group_lightmap_set_strips(h, nullptr, nullptr);       // (local: back to the equal slots every rank has)
-                return api_fail(ILM_ERR_STATE, "rank %d installed a different strip table than rank %d: every rank must pass the same strips", r, g->first_rank);
-            }
+        for (int r = 0; r < world; r++) {
+            if (all[(size_t)r] == kTableInvalid && invalid_rank < 0) invalid_rank = r;
+            if (all[(size_t)r] != hash && disagree < 0) disagree = r;
+        }
     }
+    // 3. all ranks reach the same verdict from the same gathered words; a failed installation leaves every rank's table as it was
+    if (!valid) return api_fail(ILM_ERR_INVALID_ARGUMENT, "%s", why);
+    if (invalid_rank >= 0) return api_fail(ILM_ERR_STATE, "rank %d was handed a malformed strip table: no rank installs one", invalid_rank);
+    if (disagree >= 0)
+        return api_fail(ILM_ERR_STATE, "rank %d installed a different strip table than rank %d: every rank must pass the same strips", disagree, g->first_rank);
+    bool equal = true;
+    for (int r = 0; r < world; r++) {
+        const int eb = std::min(r * m->slot_rows, m->height), ee = std::min((r + 1) * m->slot_rows, m->height);
+        m->begin[(size_t)r] = reset ? eb : row_begins[r];
+        m->end[(size_t)r] = reset ? ee : row_ends[r];
+        equal = equal && m->begin[(size_t)r] == eb && m->end[(size_t)r] == ee;
+    }
+    m->equal_slots = equal;
     return ILM_OK;
 }
 

@@ -970,8 +970,10 @@ int32_t ilm_group_lightmap_strip(IlmHandle group_lightmap, int32_t rank, int32_t
 /* Replaces the equal slots by other strips: row_begins[r], row_ends[r] for every rank r of the group (world entries each), contiguous in
  * rank order, whole 16-row tile bands, covering [0, height) -- cost-balanced strips when the lights are unevenly spread (SURVEY 8e;
  * the reference has one device and no such notion).  Every process of the group must install the same table: with one process per GPU
- * the call is a COLLECTIVE -- the ranks compare a hash of their tables (an 8-byte host all-gather) and all return ILM_ERR_STATE, back
- * on the equal slots, when they differ (each rank sizes its sends and receives from its own copy).  Unequal strips are
+ * the call is ALWAYS a COLLECTIVE (r05) -- every rank, also one that was handed a malformed table and one that resets to the equal slots
+ * with NULL, NULL, enters the same 8-byte host all-gather with a hash of its argument, and all ranks succeed or fail together: they return
+ * ILM_ERR_STATE (ILM_ERR_INVALID_ARGUMENT on the rank whose own table is malformed) and keep the table they had when the arguments differ
+ * or any of them is malformed (each rank sizes its sends and receives from its own copy).  Unequal strips are
  * exchanged range by range at their true rows (ILM_GATHER_PEER: peer copies; ILM_GATHER_RCCL: one group of ncclSend / ncclRecv, one
  * transfer per xGMI link and direction) instead of by the single in-place all-gather.  NULL, NULL restores the equal slots. */
 int32_t ilm_group_lightmap_set_strips(IlmHandle group_lightmap, const int32_t* row_begins, const int32_t* row_ends);

@@ -2,8 +2,9 @@
 
 Round 3's full-size oracle evidence was a 24-row crop of cfg3 and an 8-row crop of cfg5 -- 0.4 % of cfg5's 6.9 G cone-trace samples
 (ConeTrace.fxh:148-191); the rest of the frames was covered by strip invariance and additivity only.  This script runs
-oracle.render_sphere_lights over every band of both frames (the scenes of tests/test_properties_gpu.py: same seeds, the ground-plane
-G-buffer bound, cfg5's field generated by the ORACLE's field pass -- bit-identical to the device's, tests/test_fields_gpu.py) and
+oracle.render_sphere_lights over every band of both frames -- the frames bench.py TIMES since r05 (same light seeds, the ground-plane
+G-buffer bound as Vector4 texels, both fields generated from the 256 obstructions of seed 11 by the ORACLE's field pass, which is
+bit-identical to the device's, tests/test_fields_gpu.py; r04's cfg3 fixture used the numpy rasteriser scenes.build_sdf_atlas) -- and
 stores, per band, what a GPU test can hold the kernel to without the oracle's pixels travelling:
   * SDF-sample / pixel.light-pair / traced-pair counts (integers: exact),
   * the CRC-32 of the band's alpha plane (1 + the number of lights that contribute to each pixel: exact integers in fp32),
@@ -34,7 +35,10 @@ def scene(name):
     if name == "cfg3":
         w, h = 1920, 1080
         layout = scenes.DistanceFieldLayout(2048, 2048, 128.0, 32, 0.25)
-        atlas = scenes.build_sdf_atlas(layout, scenes.random_obstacles(11, 256, (2048, 2048)))
+        obstacles = scenes.random_obstacles(11, 256, (2048, 2048))
+        atlas = np.zeros((layout.atlas_height, layout.atlas_width, 4), np.uint16)
+        atlas = orc.render_distance_field_slices(atlas, abi.SDF_UNORM16, scenes.render_desc(layout), list(range(0, layout.slice_count, 3)),
+                                                 scenes.obstruction_array([(t - 1, c, s) for (t, c, s) in obstacles]))
         dfu = layout.uniforms(power=0.7, min_step_size=1.0, long_step_factor=0.5)
         lights = scenes.random_lights(12, 64, w, h)
         return w, h, dfu, lights, atlas, abi.SDF_UNORM16, scenes.ground_plane_gbuffer(w, h, abi.GBUFFER_FLOAT4), abi.GBUFFER_FLOAT4
@@ -46,7 +50,7 @@ def scene(name):
                                              scenes.obstruction_array([(t - 1, c, s) for (t, c, s) in obstacles]))
     dfu = layout.uniforms(max_cone_radius=24.0, power=0.7, step_limit=64, min_step_size=1.0, long_step_factor=0.5)
     lights = scenes.random_lights(13, 256, w, h, z=(8.0, 64.0), radius=24.0, ramp=(400.0, 1100.0))
-    return w, h, dfu, lights, atlas, abi.SDF_FP16, scenes.ground_plane_gbuffer(w, h, abi.GBUFFER_HALF4), abi.GBUFFER_HALF4
+    return w, h, dfu, lights, atlas, abi.SDF_FP16, scenes.ground_plane_gbuffer(w, h, abi.GBUFFER_FLOAT4), abi.GBUFFER_FLOAT4
 
 
 def bands_of(name):

@@ -8,7 +8,23 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
 
+def _profile_is_stale():
+    """The newest committed PMC summary carries the sha256 of the kernel sources it was taken from; between a kernel edit and the next
+    profiling run (tools/profile_round.sh on the GPU box) it describes ANOTHER kernel and bench.py must not quote it."""
+    rows, source = bench._newest_pmc_rows()
+    assert source is not None
+    if "stale" in source:
+        assert rows == [] and bench.profiled_traffic("ilm::step_lean_kernel<true, false>") is None
+        assert bench.profiled_per_wave("ilm::sphere_lights_kernel<0, false, false>", "SQ_INSTS_VALU") is None
+        assert bench.step_traffic_fields(None, 5) == {"traffic": None}
+        return True
+    return False
+
+
 def test_profiled_traffic_comes_from_the_newest_committed_summary():
+    if _profile_is_stale():
+        import pytest
+        pytest.skip("profiles/*_pmc.csv is older than the kernel sources: bench.py reports null fractions until the round's profile is committed")
     rows, source = bench._newest_pmc_rows()
     assert source is not None and source.endswith("_pmc.csv") and len(rows) > 10
     t = bench.profiled_traffic("ilm::step_lean_kernel<true, false>", "ilm::step_lean_kernel<false, false>")
@@ -24,6 +40,9 @@ def test_profiled_traffic_comes_from_the_newest_committed_summary():
 
 
 def test_light_kernel_instruction_counts_are_in_the_summary():
+    if _profile_is_stale():
+        import pytest
+        pytest.skip("stale profile (see above)")
     for k in ("ilm::sphere_lights_kernel<0, false, false>", "ilm::sphere_lights_kernel<1, false, false>"):
         v = bench.profiled_per_wave(k, "SQ_INSTS_VALU")
         assert v is not None and v["value"] > 1000

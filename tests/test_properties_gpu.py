@@ -246,6 +246,77 @@ def test_cfg4_share_eight_million_particles(ctx, oracle):
     eng.close()
 
 
+def test_cfg4_full_64m_particles_on_one_gpu(ctx, oracle):
+    """cfg4 whole, resident on ONE device: 64 chunks of 1024^2 slots = 67 M particles (the reference's own ceiling, MaxChunkCount = 64,
+    ParticleSystem.cs:49; 5.4 GB of state), Gravity + Noise + UpdatePositions -- the denominator of the north star's 1 -> 8 GPU scaling
+    target.  Chunks never interact (ParticleSystem.cs:743-745): the one launch over the 64-chunk table must equal, bit for bit, eight
+    launches of an 8-chunk system holding the same images (what one rank of the 8-GPU job steps); the live-count checksum over 64 chunks;
+    the oracle replays one whole chunk."""
+    cs, n_images, n_groups = 1024, 8, 8
+    n = cs * cs
+    rnd = scenes.randomness_table(7)
+    eng = native.Engine(ctx, cs, rnd)
+    big = native.System(eng)
+    small = native.System(eng)
+    d = cfg2_step(cs)
+    d.System = scenes.system_uniforms(cs, friction=0.02, max_velocity=2048.0, life_decay=4.0)
+    images = [scenes.make_particles(4100 + c, n, pos_lo=(0, 0, 0), pos_hi=(1920, 1080, 32), life=(0.01, 0.4), dead_fraction=0.05) for c in range(n_images)]
+
+    def image(g, c):
+        """group g's copy of image c: shifted, so that no two of the 64 chunks hold the same particles"""
+        pos, vel, attr = images[c]
+        p = pos.copy()
+        live = p[:, 3] > 0
+        p[live, 0] += np.float32(3.0 * g)
+        p[live, 1] += np.float32(2.0 * g)
+        return p, vel, attr
+
+    for c in range(n_images):
+        small.add_chunk()
+    for g in range(n_groups):
+        for c in range(n_images):
+            big.add_chunk()
+            p, v, a = image(g, c)
+            big.upload(g * n_images + c, P, p); big.upload(g * n_images + c, V, v); big.upload(g * n_images + c, A, a)
+    assert big.chunk_count() == 64
+    steps = 2
+    for _ in range(steps):
+        big.step(d)
+    counts = big.step_counts()
+    assert counts.shape[0] == 64
+    keep_g, keep_c = 5, 3
+    total = 0
+    for g in range(n_groups):
+        for c in range(n_images):
+            p, v, a = image(g, c)
+            small.upload(c, P, p); small.upload(c, V, v); small.upload(c, A, a)
+            if (g, c) == (keep_g, keep_c):
+                keep = [p.copy(), v.copy(), a.copy(), np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)]
+        for _ in range(steps):
+            small.step(d)
+        small_counts = small.step_counts()
+        for c in range(n_images):
+            k = g * n_images + c
+            a_, b_ = big.download(k, P), small.download(c, P)
+            assert np.array_equal(a_.view(np.uint32), b_.view(np.uint32)), "chunk %d of the 64-chunk launch vs chunk %d of an 8-chunk launch" % (k, c)
+            assert counts[k] == small_counts[c] == int((a_[:, 3] > 0).sum())
+            total += int(counts[k])
+        for plane in (V, RC, RD):      # one chunk per group through the other output planes
+            assert np.array_equal(big.download(g * n_images + g, plane).view(np.uint32), small.download(g, plane).view(np.uint32))
+    assert np.array_equal(big.live_counts(), counts) and 0 < total < 64 * n
+    for _ in range(steps):
+        oracle.step([keep], cs, rnd, _single_chunk(d))
+    k = keep_g * n_images + keep_c
+    got = [big.download(k, plane) for plane in (P, V, A, RC, RD)]
+    assert np.array_equal(got[0][:, 3] > 0, keep[0][:, 3] > 0)
+    m = keep[0][:, 3] > 0
+    for plane in (0, 1, 3, 4):
+        assert_close(got[plane][m], keep[plane][m], "cfg4 (64 M) chunk %d plane %d vs oracle" % (k, plane), life_exact=(plane == 0))
+    for s in (big, small):
+        s.close()
+    eng.close()
+
+
 def _single_chunk(d):
     import ctypes
     c = abi.StepDesc()

@@ -8,6 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from illuminant_amd import abi, native, scenes
 from oracle import oracle
+from tests import fuzz_scenes
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
@@ -32,14 +33,9 @@ bad_collision, collision_steps, collision_elements, collided_total = [], 0, 0, 0
 for seed in range(first, first + count):
     rng = np.random.default_rng(seed)
     # ---- lighting: random field, lights, G-buffer normals, both SDF formats -------------------------------------------
-    w, h = int(rng.integers(33, 130)), int(rng.integers(17, 90))
-    fmt = abi.SDF_FP16 if seed % 2 else abi.SDF_UNORM16
-    layout = scenes.DistanceFieldLayout(256, 192, 96.0, int(rng.integers(3, 14)), 0.5, 128)
-    obstacles = scenes.random_obstacles(seed, int(rng.integers(1, 16)), (256, 192), size_lo=6.0, size_hi=34.0, z_hi=50.0)
+    L_ = fuzz_scenes.draw_lighting(rng, seed)          # (tests/fuzz_scenes.py: the seed's draws, shared with tests/test_fuzz_regressions_gpu.py)
+    w, h, fmt, layout, obstacles, dfu, lights = L_["w"], L_["h"], L_["fmt"], L_["layout"], L_["obstacles"], L_["dfu"], L_["lights"]
     atlas = scenes.build_sdf_atlas(layout, obstacles, fmt=fmt)
-    dfu = layout.uniforms(max_cone_radius=float(rng.uniform(4, 30)), power=float(rng.choice([0.5, 0.7, 1.0, 1.6])), step_limit=int(rng.integers(8, 80)),
-                          min_step_size=float(rng.uniform(0.5, 3.0)), long_step_factor=float(rng.uniform(0.3, 1.0)))
-    lights = scenes.random_lights(seed + 7, int(rng.integers(1, 20)), w, h, z=(2.0, 60.0), radius=float(rng.uniform(2, 30)), ramp=(20.0, 160.0))
     env = scenes.environment()
     sdf = native.DistanceFieldTexture(ctx, atlas, fmt)
     lm = native.Lightmap(ctx, w, h, abi.LIGHTMAP_FLOAT4)
@@ -102,40 +98,14 @@ for seed in range(first, first + count):
         collided_total += int((cwant[1][:, 3] == 3.0).sum())
         csdf.close(); csys.close(); ceng.close()
     # ---- particles: random op list, spawner, chunk size ---------------------------------------------------------------
-    cs = int(rng.choice([16, 48, 64, 128]))
+    cs, rnd, chunks, d = fuzz_scenes.draw_particle_step(rng, seed)
     n = cs * cs
-    rnd = scenes.randomness_table(seed % 5 + 1)
+    k = int(d.OpCount)
     eng = native.Engine(ctx, cs, rnd); sysm = native.System(eng)
-    chunks = []
     for c in range(2):
         sysm.add_chunk()
-        pos, vel, attr = scenes.make_particles(seed * 3 + c, n, dead_fraction=float(rng.uniform(0, 0.8)), life=(0.01, 3.0))
-        for pl, a in ((P, pos), (V, vel), (A, attr)):
+        for pl, a in ((P, chunks[c][0]), (V, chunks[c][1]), (A, chunks[c][2])):
             sysm.upload(c, pl, a)
-        chunks.append([pos.copy(), vel.copy(), attr.copy(), np.zeros((n, 4), np.float32), np.zeros((n, 4), np.float32)])
-    d = abi.StepDesc(); d.FirstChunk, d.ChunkCount = 0, -1
-    d.System = scenes.system_uniforms(cs, friction=float(rng.uniform(0, 0.5)), max_velocity=float(rng.uniform(50, 3000)), life_decay=float(rng.uniform(0, 5)))
-    d.Update = abi.UpdateParams.default(); d.UpdateMode = abi.UPDATE_POSITIONS
-    k = 0
-    if rng.random() < 0.8:
-        att = [((float(rng.uniform(0, 256)), float(rng.uniform(0, 256)), float(rng.uniform(0, 32))), float(rng.uniform(10, 300)), float(rng.uniform(-500, 1500)),
-                int(rng.integers(0, 3))) for _ in range(int(rng.integers(1, 17)))]
-        d.Ops[k].Type = abi.OP_GRAVITY; d.Ops[k].u.Gravity = scenes.gravity_params(att, float(rng.uniform(1, 2000))); k += 1
-    if rng.random() < 0.8:
-        d.Ops[k].Type = abi.OP_NOISE
-        d.Ops[k].u.Noise = scenes.noise_params(scenes.area_none(), (float(rng.uniform(0, 253)), float(rng.uniform(0, 127))),
-                                               (float(rng.uniform(0, 253)), float(rng.uniform(0, 127))), float(rng.uniform(0, 1)),
-                                               replace_old_velocity=bool(rng.integers(0, 2)),
-                                               position=((-0.5,) * 4, (0.05,) * 4, (2.0, 2.0, 1.0, 0.0)), velocity=((-0.5,) * 3, (0.01,) * 3, (40.0, 40.0, 10.0)),
-                                               speed=(-0.5, 0.0, 3.0)); k += 1
-    d.OpCount = k
-    if rng.random() < 0.6:
-        first_slot = int(rng.integers(0, n - 40)); last = int(min(n - 1, first_slot + rng.integers(1, 600)))
-        d.SpawnCount = 1; d.Spawns[0].ChunkIndex = 1
-        d.Spawns[0].Params = scenes.spawn_params(cs, first_slot, last, int(rng.integers(0, 5000)), (float(rng.uniform(0, 253)), float(rng.uniform(0, 127))),
-                                                 position=((128, 128, 4), (90, 60, 4), (0, 0, 0), int(rng.choice([0, 1, 3]))),
-                                                 velocity=((0, 0, 0), (60, 60, 10), (0, 0, 0), int(rng.choice([0, 1, 2]))), life=(2.0, 2.0, 0.0))
-    d.Flags = abi.STEP_COUNT_LIVE
     inputs = [(c[0].copy(), c[1].copy()) for c in chunks]
     initial = [[a.copy() for a in c] for c in chunks]
     sysm.step(d)
