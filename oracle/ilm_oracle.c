@@ -1325,8 +1325,84 @@ static f3 sphere_light_epilogue(float pre_trace_opacity, float cone_opacity, f3 
     return v3(rgb.x * cone_opacity, rgb.y * cone_opacity, rgb.z * cone_opacity);
 }
 
-/* SphereLightPixelShader, SphereLight.fx:7-46, + additive blend onto the
+/* census hook (oracle/ilm_oracle_census.c, tools/open_ray_census.py): called for every traced pair after its march */
+typedef struct OrcTraceEvent {
+    int px, py, light;
+    f3 start, light_center;
+    float light_radius, light_ramp;
+    uint64_t samples;        /* SDF samples this pair's cone trace took */
+    float result;            /* coneTrace's return value */
+} OrcTraceEvent;
+typedef void (*OrcTraceHook)(void* user, const OrcTraceEvent* e);
+
+/* One row of SphereLightPixelShader, SphereLight.fx:7-46, + additive blend onto the
  * ambient clear (LightingRenderer.cs:1013-1024) with fp32 accumulation */
+static void sphere_lights_row(int py, const IlmLightVertex* lights, int32_t light_count,
+                              const IlmEnvironment* env, const IlmDistanceFieldUniforms* df,
+                              const OrcTexture* gbuffer, const OrcTexture* sdf, const float ambient[4],
+                              IlmFloat4* lightmap, int32_t width, SdfCounter* ctr, uint64_t* pairs, uint64_t* traced,
+                              OrcTraceHook hook, void* hook_user) {
+    for (int px = 0; px < width; px++) {
+        f4 acc = v4(ambient[0], ambient[1], ambient[2], ambient[3]);
+        if (g_orc_blend_fp16) acc = v4(round_through_half(acc.x), round_through_half(acc.y), round_through_half(acc.z), round_through_half(acc.w));
+        f3 shaded, normal;
+        int enable_shadows, fullbright;
+        f3 camera = sample_gbuffer((float)px, (float)py, env, gbuffer, &shaded, &normal, &enable_shadows, &fullbright);
+        for (int li = 0; li < light_count; li++) {
+            const IlmLightVertex* L = &lights[li];
+            if (!light_covers_pixel(L, env, (float)px + 0.5f, (float)py + 0.5f))
+                continue;
+            (*pairs)++;
+            if (fullbright || check_shadow_filter(L->EvenMoreLightProperties.x, enable_shadows))
+                continue; /* discard */
+
+            f4 light_properties = L->LightProperties;
+            light_properties.w *= (float)enable_shadows;
+            f4 more = L->MoreLightProperties;
+            f3 light_center = xyz(L->LightPosition1);
+
+            /* SphereLightPixelPrologue, SphereLightCore.fxh:58-81 */
+            float distance_opacity = compute_sphere_light_opacity(shaded, normal, light_center, light_properties, more.z, env);
+            int visible = (distance_opacity > 0.0f) && (shaded.x > -9999.0f);
+            more.x *= fmaxf(0.0f, normal.z);
+            if (!visible)
+                continue; /* discard */
+
+            /* SphereLightPixelCore, SphereLightCore.fxh:122-158 */
+            float ao_opacity = compute_ao(shaded, normal, more, df, sdf, visible, ctr);
+            float pre_trace_opacity = distance_opacity * ao_opacity;
+            int trace_shadows = visible && (light_properties.w != 0.0f) && (pre_trace_opacity >= SL_SHADOW_OPACITY_THRESHOLD);
+            if (trace_shadows) (*traced)++;
+            f3 start = v3add(shaded, v3scale(normal, SL_SELF_OCCLUSION_HACK));
+            const uint64_t samples_before = ctr->samples;
+            float cone_opacity = cone_trace(light_center, light_properties.x, light_properties.y, 1.0f, more.y,
+                                            start, df, sdf, trace_shadows, ctr);
+            if (hook && trace_shadows) {
+                OrcTraceEvent e = { px, py, li, start, light_center, light_properties.x, light_properties.y, ctr->samples - samples_before, cone_opacity };
+                hook(hook_user, &e);
+            }
+            const f3 opacity = sphere_light_epilogue(pre_trace_opacity, cone_opacity, v3sub(shaded, light_center), L->EvenMoreLightProperties);
+
+            float specularity = calc_sphere_light_specularity(camera, shaded, normal, light_center, L->Color2.w);
+            const float cr = (L->Color1.x * L->Color1.w * opacity.x) + (L->Color2.x * specularity * opacity.x);
+            const float cg = (L->Color1.y * L->Color1.w * opacity.y) + (L->Color2.y * specularity * opacity.y);
+            const float cb = (L->Color1.z * L->Color1.w * opacity.z) + (L->Color2.z * specularity * opacity.z);
+            if (g_orc_blend_fp16) {
+                acc.x = round_through_half(acc.x + round_through_half(cr));
+                acc.y = round_through_half(acc.y + round_through_half(cg));
+                acc.z = round_through_half(acc.z + round_through_half(cb));
+                acc.w = round_through_half(acc.w + 1.0f);
+            } else {
+                acc.x += cr;
+                acc.y += cg;
+                acc.z += cb;
+                acc.w += 1.0f;
+            }
+        }
+        if (lightmap) lightmap[(size_t)py * (size_t)width + (size_t)px] = acc;
+    }
+}
+
 void orc_render_sphere_lights(const IlmLightVertex* lights, int32_t light_count,
                               const IlmEnvironment* env, const IlmDistanceFieldUniforms* df,
                               const OrcTexture* gbuffer, const OrcTexture* sdf,
@@ -1339,61 +1415,11 @@ void orc_render_sphere_lights(const IlmLightVertex* lights, int32_t light_count,
     #pragma omp parallel for schedule(dynamic, 4) reduction(+:total_samples, total_pairs, total_traced)
     for (int py = row_begin; py < row_end; py++) {
         SdfCounter ctr = { 0 };
-        for (int px = 0; px < width; px++) {
-            f4 acc = v4(ambient[0], ambient[1], ambient[2], ambient[3]);
-            if (g_orc_blend_fp16) acc = v4(round_through_half(acc.x), round_through_half(acc.y), round_through_half(acc.z), round_through_half(acc.w));
-            f3 shaded, normal;
-            int enable_shadows, fullbright;
-            f3 camera = sample_gbuffer((float)px, (float)py, env, gbuffer, &shaded, &normal, &enable_shadows, &fullbright);
-            for (int li = 0; li < light_count; li++) {
-                const IlmLightVertex* L = &lights[li];
-                if (!light_covers_pixel(L, env, (float)px + 0.5f, (float)py + 0.5f))
-                    continue;
-                total_pairs++;
-                if (fullbright || check_shadow_filter(L->EvenMoreLightProperties.x, enable_shadows))
-                    continue; /* discard */
-
-                f4 light_properties = L->LightProperties;
-                light_properties.w *= (float)enable_shadows;
-                f4 more = L->MoreLightProperties;
-                f3 light_center = xyz(L->LightPosition1);
-
-                /* SphereLightPixelPrologue, SphereLightCore.fxh:58-81 */
-                float distance_opacity = compute_sphere_light_opacity(shaded, normal, light_center, light_properties, more.z, env);
-                int visible = (distance_opacity > 0.0f) && (shaded.x > -9999.0f);
-                more.x *= fmaxf(0.0f, normal.z);
-                if (!visible)
-                    continue; /* discard */
-
-                /* SphereLightPixelCore, SphereLightCore.fxh:122-158 */
-                float ao_opacity = compute_ao(shaded, normal, more, df, sdf, visible, &ctr);
-                float pre_trace_opacity = distance_opacity * ao_opacity;
-                int trace_shadows = visible && (light_properties.w != 0.0f) && (pre_trace_opacity >= SL_SHADOW_OPACITY_THRESHOLD);
-                if (trace_shadows) total_traced++;
-                f3 start = v3add(shaded, v3scale(normal, SL_SELF_OCCLUSION_HACK));
-                float cone_opacity = cone_trace(light_center, light_properties.x, light_properties.y, 1.0f, more.y,
-                                                start, df, sdf, trace_shadows, &ctr);
-                const f3 opacity = sphere_light_epilogue(pre_trace_opacity, cone_opacity, v3sub(shaded, light_center), L->EvenMoreLightProperties);
-
-                float specularity = calc_sphere_light_specularity(camera, shaded, normal, light_center, L->Color2.w);
-                const float cr = (L->Color1.x * L->Color1.w * opacity.x) + (L->Color2.x * specularity * opacity.x);
-                const float cg = (L->Color1.y * L->Color1.w * opacity.y) + (L->Color2.y * specularity * opacity.y);
-                const float cb = (L->Color1.z * L->Color1.w * opacity.z) + (L->Color2.z * specularity * opacity.z);
-                if (g_orc_blend_fp16) {
-                    acc.x = round_through_half(acc.x + round_through_half(cr));
-                    acc.y = round_through_half(acc.y + round_through_half(cg));
-                    acc.z = round_through_half(acc.z + round_through_half(cb));
-                    acc.w = round_through_half(acc.w + 1.0f);
-                } else {
-                    acc.x += cr;
-                    acc.y += cg;
-                    acc.z += cb;
-                    acc.w += 1.0f;
-                }
-            }
-            lightmap[(size_t)py * (size_t)width + (size_t)px] = acc;
-        }
+        uint64_t pairs = 0, traced = 0;
+        sphere_lights_row(py, lights, light_count, env, df, gbuffer, sdf, ambient, lightmap, width, &ctr, &pairs, &traced, NULL, NULL);
         total_samples += ctr.samples;
+        total_pairs += pairs;
+        total_traced += traced;
     }
     if (stats) {
         stats->SdfSamples = total_samples;
@@ -1402,6 +1428,7 @@ void orc_render_sphere_lights(const IlmLightVertex* lights, int32_t light_count,
     }
 }
 
+#include "ilm_oracle_census.c"
 #include "ilm_oracle_lights.c"
 #include "ilm_oracle_output.c"
 

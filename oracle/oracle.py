@@ -21,7 +21,7 @@ def build(force=False):
     """Compile the C restatement with gcc (oracle/Makefile)."""
     if force or not os.path.exists(_LIB_PATH) or any(
             os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(_LIB_PATH)
-            for f in ("ilm_oracle.c", "ilm_oracle_fields.c", "ilm_oracle_gbuffer.c", "ilm_oracle_transforms.c", "ilm_oracle_lights.c", "ilm_oracle_output.c", "ilm_oracle.h")):
+            for f in ("ilm_oracle.c", "ilm_oracle_fields.c", "ilm_oracle_gbuffer.c", "ilm_oracle_transforms.c", "ilm_oracle_lights.c", "ilm_oracle_output.c", "ilm_oracle_census.c", "ilm_oracle.h")):
         subprocess.run(["make", "-C", _HERE, "-s"], check=True)
     return _LIB_PATH
 
@@ -283,6 +283,29 @@ def render_sphere_lights(lights, env, df, gbuffer, sdf, ambient, width, height, 
                                    C.byref(stats) if stats is not None else None)
     lib().orc_set_lightmap_blend(C.c_int32(0))
     return out, stats
+
+
+class OpenRayCensus(C.Structure):
+    """OrcOpenRayCensus, oracle/ilm_oracle_census.c"""
+    _fields_ = [(n, C.c_uint64) for n in ("traced_pairs", "traced_samples", "result_one_pairs", "result_one_samples", "strict_pairs", "strict_samples",
+                                          "loose_pairs", "loose_samples", "violations", "wave_count", "wave_open", "wave_iterations", "wave_iterations_left",
+                                          "wave_open_samples", "dda_bricks")]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n, _ in self._fields_}
+
+
+def open_ray_census(lights, env, df, gbuffer, sdf, width, height, row_begin=0, row_end=None, brick_texels=8, census=None):
+    """orc_open_ray_census: marches every traced pair of rows [row_begin, row_end) like render_sphere_lights and counts the rays a table of
+    per-brick minimum distances PROVES open (analysis only: tools/open_ray_census.py).  Adds to `census` (a new one when None)."""
+    if row_end is None:
+        row_end = height
+    census = census if census is not None else OpenRayCensus()
+    n = len(lights) if lights is not None else 0
+    lib().orc_open_ray_census(C.cast(lights, C.c_void_p) if n else None, n, C.byref(env), C.byref(df),
+                              C.byref(gbuffer) if gbuffer is not None else None, C.byref(sdf), width, height, row_begin, row_end, brick_texels,
+                              C.byref(census))
+    return census
 
 
 def render_distance_field_slices(atlas, fmt, desc, first_virtual_slices, obstructions=None, volumes=None, polygon_xy=None,
