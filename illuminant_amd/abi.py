@@ -7,7 +7,7 @@ offsets against the C header by compiling a probe.
 """
 import ctypes as C
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 OK = 0
 ERR_INVALID_ARGUMENT = -1

@@ -3,6 +3,7 @@
 // reference's host code does (same limits, same failure conditions) and turns
 // them into return codes that the C# wrapper rethrows as exceptions.
 #include <atomic>
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -138,10 +139,14 @@ struct Sdf {
     // slices past that have no cells anyway).  The reference regenerates MaximumFieldUpdatesPerFrame = 1 slice triplet per frame
     // (LightingRenderer.Configuration.cs:91, LightingRenderer.DistanceField.cs:415-464): the cells of slice v hold the channel pairs
     // (v, v + 1), so a triplet [s, s + 3) invalidates the cells of slices s - 1 .. s + 2 -- 4 of cfg5's 33, not all 138 MB.
-    uint64_t dirty[4] = { ~0ull, ~0ull, ~0ull, ~0ull };
+    static constexpr int kDirtyWords = (kMaxTableSlices + 63) / 64;     // (sized by the build's table limit: -DILM_MAX_TABLE_SLICES may raise it)
+    uint64_t dirty[kDirtyWords];
+    Sdf() { for (uint64_t& w : dirty) w = ~0ull; }      // nothing has cells yet
     void mark_all_dirty() { for (uint64_t& w : dirty) w = ~0ull; version++; }
     void mark_slices_dirty(int first, int count) {
-        for (int v = std::max(0, first - 1); v < first + count && v < 256; v++) dirty[v >> 6] |= 1ull << (v & 63);
+        // (64-bit bounds: first + count of a caller's ilm_sdf_mark_dirty may not fit an int)
+        const int64_t lo = std::max<int64_t>(0, (int64_t)first - 1), hi = std::min<int64_t>((int64_t)first + (int64_t)count, (int64_t)kDirtyWords * 64);
+        for (int64_t v = lo; v < hi; v++) dirty[v >> 6] |= 1ull << (v & 63);
         version++;
     }
     // what the last light pass over this field found / did (ilm_sdf_trace_info)
@@ -159,6 +164,8 @@ struct Lightmap {
     uint32_t magic = kMagicLightmap;
     Ctx* ctx = nullptr;
     void* texels = nullptr; int width = 0, height = 0, format = 0; bool external = false;
+    // store-mode exchange of a group lightmap (lightmap_set_mirrors, group.hip): device array of the other members' buffers
+    void** d_mirrors = nullptr; int mirror_count = 0;
 };
 
 struct System {
@@ -1006,6 +1013,42 @@ hipStream_t ctx_stream_joined(IlmHandle h) {
     Ctx* c = from_handle<Ctx>(h, kMagicCtx);
     return c ? c->main() : nullptr;
 }
+const TraceApi& trace_api() {
+    static const TraceApi api = [] {
+        TraceApi t;
+        const char* e = getenv("ILM_TRACE");
+        if (!e || atoi(e) == 0) return t;
+        for (const char* name : { "librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so" }) {
+            void* lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            if (!lib) continue;
+            t.push = reinterpret_cast<int (*)(const char*)>(dlsym(lib, "roctxRangePushA"));
+            t.pop = reinterpret_cast<int (*)()>(dlsym(lib, "roctxRangePop"));
+            if (t.push && t.pop) { t.on = true; break; }
+        }
+        if (!t.on) fprintf(stderr, "libilluminant_hip: ILM_TRACE is set but no roctx library could be bound: no ranges\n");
+        return t;
+    }();
+    return api;
+}
+// Store-mode exchange (ILM_GATHER_STORE): every light pass into this lightmap also stores its texels at the same offsets of `count`
+// other buffers of the same size -- the other members' copies of a group's frame, addressable from this lightmap's device (peer access
+// / the same device).  count == 0 ends it.  Synchronises the lightmap's stream (the table may be in use by a queued launch).
+int32_t lightmap_set_mirrors(IlmHandle h, void* const* buffers, int count) {
+    Lightmap* m = from_handle<Lightmap>(h, kMagicLightmap);
+    if (!m) return fail(ILM_ERR_INVALID_HANDLE, "not a lightmap handle");
+    if (count < 0 || count > 64 || (count > 0 && !buffers)) return fail(ILM_ERR_INVALID_ARGUMENT, "bad mirror list");
+    HIP_TRY(hipSetDevice(m->ctx->device));
+    HIP_TRY(hipStreamSynchronize(m->ctx->main()));
+    if (count == 0) {
+        if (m->d_mirrors) HIP_TRY(hipFree(m->d_mirrors));
+        m->d_mirrors = nullptr; m->mirror_count = 0;
+        return ILM_OK;
+    }
+    if (!m->d_mirrors) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_mirrors), sizeof(void*) * 64));
+    HIP_TRY(hipMemcpy(m->d_mirrors, buffers, sizeof(void*) * (size_t)count, hipMemcpyHostToDevice));
+    m->mirror_count = count;
+    return ILM_OK;
+}
 }  // namespace ilm
 
 extern "C" {
@@ -1273,6 +1316,7 @@ static int32_t check_plane_range(System* s, int32_t chunk, int32_t plane, int32_
 }
 
 int32_t ilm_chunk_upload(IlmHandle h, int32_t chunk, int32_t plane, const IlmFloat4* src, int32_t first_slot, int32_t count) {
+    ILM_TRACE_RANGE("ilm_chunk_upload");
     System* s = from_handle<System>(h, kMagicSystem);
     if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
     if (!src) return fail(ILM_ERR_INVALID_ARGUMENT, "src is NULL");
@@ -1292,6 +1336,7 @@ int32_t ilm_chunk_upload(IlmHandle h, int32_t chunk, int32_t plane, const IlmFlo
 }
 
 int32_t ilm_chunk_download(IlmHandle h, int32_t chunk, int32_t plane, IlmFloat4* dst, int32_t first_slot, int32_t count) {
+    ILM_TRACE_RANGE("ilm_chunk_download");
     System* s = from_handle<System>(h, kMagicSystem);
     if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
     if (!dst) return fail(ILM_ERR_INVALID_ARGUMENT, "dst is NULL");
@@ -1396,6 +1441,7 @@ int32_t ilm_system_set_spawn_pattern(IlmHandle h, int32_t slot, const IlmFloat4*
 }
 
 int32_t ilm_system_step(IlmHandle h, const IlmStepDesc* desc) {
+    ILM_TRACE_RANGE("ilm_system_step");
     System* s = from_handle<System>(h, kMagicSystem);
     if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
     if (!desc) return fail(ILM_ERR_INVALID_ARGUMENT, "desc is NULL");
@@ -1410,6 +1456,7 @@ static void init_single_pass(IlmStepDesc* d, int32_t chunk_index, const IlmParti
 }
 
 int32_t ilm_spawn(IlmHandle h, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmSpawnParams* p) {
+    ILM_TRACE_RANGE("ilm_spawn");
     System* s = from_handle<System>(h, kMagicSystem);
     if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
     if (!p || chunk_index < 0) return fail(ILM_ERR_INVALID_ARGUMENT, "spawn needs parameters and a target chunk");
@@ -1422,6 +1469,7 @@ int32_t ilm_spawn(IlmHandle h, int32_t chunk_index, const IlmParticleSystemUnifo
 }
 
 int32_t ilm_gravity(IlmHandle h, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmGravityParams* p) {
+    ILM_TRACE_RANGE("ilm_gravity");
     System* s = from_handle<System>(h, kMagicSystem);
     if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
     if (!p || !sys) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -1432,6 +1480,7 @@ int32_t ilm_gravity(IlmHandle h, int32_t chunk_index, const IlmParticleSystemUni
 }
 
 int32_t ilm_noise(IlmHandle h, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmNoiseParams* p) {
+    ILM_TRACE_RANGE("ilm_noise");
     System* s = from_handle<System>(h, kMagicSystem);
     if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
     if (!p || !sys) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -1442,6 +1491,7 @@ int32_t ilm_noise(IlmHandle h, int32_t chunk_index, const IlmParticleSystemUnifo
 }
 
 int32_t ilm_fma(IlmHandle h, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmFMAParams* p) {
+    ILM_TRACE_RANGE("ilm_fma");
     System* s = from_handle<System>(h, kMagicSystem);
     if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
     if (!p || !sys) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -1452,6 +1502,7 @@ int32_t ilm_fma(IlmHandle h, int32_t chunk_index, const IlmParticleSystemUniform
 }
 
 int32_t ilm_matrix_multiply(IlmHandle h, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmMatrixMultiplyParams* p) {
+    ILM_TRACE_RANGE("ilm_matrix_multiply");
     System* s = from_handle<System>(h, kMagicSystem);
     if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
     if (!p || !sys) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -1462,6 +1513,7 @@ int32_t ilm_matrix_multiply(IlmHandle h, int32_t chunk_index, const IlmParticleS
 }
 
 int32_t ilm_spatial_noise(IlmHandle h, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmSpatialNoiseParams* p) {
+    ILM_TRACE_RANGE("ilm_spatial_noise");
     System* s = from_handle<System>(h, kMagicSystem);
     if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
     if (!p || !sys) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -1473,6 +1525,7 @@ int32_t ilm_spatial_noise(IlmHandle h, int32_t chunk_index, const IlmParticleSys
 
 int32_t ilm_update(IlmHandle h, int32_t chunk_index, const IlmParticleSystemUniforms* sys, const IlmUpdateParams* p,
                    const IlmDistanceFieldUniforms* df) {
+    ILM_TRACE_RANGE("ilm_update");
     System* s = from_handle<System>(h, kMagicSystem);
     if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
     if (!p || !sys) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -1485,6 +1538,7 @@ int32_t ilm_update(IlmHandle h, int32_t chunk_index, const IlmParticleSystemUnif
 }
 
 int32_t ilm_erase(IlmHandle h, int32_t chunk_index) {
+    ILM_TRACE_RANGE("ilm_erase");
     System* s = from_handle<System>(h, kMagicSystem);
     if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
     IlmStepDesc d;
@@ -1503,6 +1557,7 @@ static uint32_t published_count(const System* s, int i, bool* ready) {
 }
 
 int32_t ilm_system_live_counts(IlmHandle h, uint32_t* out_counts, int32_t capacity, int32_t saturate16) {
+    ILM_TRACE_RANGE("ilm_system_live_counts");
     System* s = from_handle<System>(h, kMagicSystem);
     if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
     if (!out_counts) return fail(ILM_ERR_INVALID_ARGUMENT, "out_counts is NULL");
@@ -1519,6 +1574,7 @@ int32_t ilm_system_live_counts(IlmHandle h, uint32_t* out_counts, int32_t capaci
 }
 
 int32_t ilm_system_step_counts(IlmHandle h, uint32_t* out_counts, int32_t capacity, int32_t saturate16) {
+    ILM_TRACE_RANGE("ilm_system_step_counts");
     System* s = from_handle<System>(h, kMagicSystem);
     if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
     if (!out_counts) return fail(ILM_ERR_INVALID_ARGUMENT, "out_counts is NULL");
@@ -1558,6 +1614,7 @@ int32_t ilm_system_poll_counts(IlmHandle h, uint32_t* out_counts, int32_t capaci
 }
 
 int32_t ilm_chunk_live_slots(IlmHandle h, int32_t chunk, uint32_t* out_slots, int32_t capacity, int32_t* out_count) {
+    ILM_TRACE_RANGE("ilm_chunk_live_slots");
     System* s = from_handle<System>(h, kMagicSystem);
     if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
     if (chunk < 0 || chunk >= (int)s->chunks.size())
@@ -1629,6 +1686,7 @@ int32_t ilm_sdf_create(IlmHandle hctx, int32_t w, int32_t ht, int32_t format, Il
 }
 
 int32_t ilm_sdf_upload(IlmHandle h, const uint16_t* texels) {
+    ILM_TRACE_RANGE("ilm_sdf_upload");
     Sdf* f = from_handle<Sdf>(h, kMagicSdf);
     if (!f) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle");
     if (!texels) return fail(ILM_ERR_INVALID_ARGUMENT, "texels is NULL");
@@ -1768,6 +1826,7 @@ int32_t ilm_sdf_destroy(IlmHandle h) {
 }
 
 int32_t ilm_sdf_download(IlmHandle h, uint16_t* texels) {
+    ILM_TRACE_RANGE("ilm_sdf_download");
     Sdf* f = from_handle<Sdf>(h, kMagicSdf);
     if (!f) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle");
     if (!texels) return fail(ILM_ERR_INVALID_ARGUMENT, "texels is NULL");
@@ -1809,6 +1868,7 @@ int32_t ilm_sdf_render_slices(IlmHandle h, IlmHandle hclear, const IlmDistanceFi
                               const IlmObstruction* obstructions, int32_t obstruction_count,
                               const IlmHeightVolume* volumes, int32_t volume_count,
                               const float* polygon_xy, int32_t polygon_vertex_count) {
+    ILM_TRACE_RANGE("ilm_sdf_render_slices");
     Sdf* f = from_handle<Sdf>(h, kMagicSdf);
     if (!f) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle");
     Sdf* clr = nullptr;
@@ -1971,6 +2031,7 @@ int32_t ilm_gbuffer_create(IlmHandle hctx, int32_t w, int32_t ht, int32_t format
 }
 
 int32_t ilm_gbuffer_upload(IlmHandle h, const void* texels) {
+    ILM_TRACE_RANGE("ilm_gbuffer_upload");
     GBuffer* g = from_handle<GBuffer>(h, kMagicGBuffer);
     if (!g) return fail(ILM_ERR_INVALID_HANDLE, "not a G-buffer handle");
     if (!texels) return fail(ILM_ERR_INVALID_ARGUMENT, "texels is NULL");
@@ -1994,6 +2055,7 @@ int32_t ilm_gbuffer_download(IlmHandle h, void* texels) {
 
 int32_t ilm_gbuffer_render(IlmHandle h, const IlmGBufferRenderDesc* d, const IlmHeightVolume* volumes, int32_t volume_count,
                            const float* polygon_xy, int32_t polygon_vertex_count) {
+    ILM_TRACE_RANGE("ilm_gbuffer_render");
     GBuffer* g = from_handle<GBuffer>(h, kMagicGBuffer);
     if (!g) return fail(ILM_ERR_INVALID_HANDLE, "not a G-buffer handle");
     if (!d) return fail(ILM_ERR_INVALID_ARGUMENT, "desc is NULL");
@@ -2057,6 +2119,7 @@ int32_t ilm_gbuffer_render_meshes(IlmHandle h, const IlmGBufferMeshDesc* d,
                                   const IlmHeightVolumeVertex* front_vertices, int32_t front_vertex_count,
                                   const IlmBillboardVertex* billboard_vertices, int32_t billboard_vertex_count,
                                   const IlmBillboardRun* runs, int32_t run_count) {
+    ILM_TRACE_RANGE("ilm_gbuffer_render_meshes");
     GBuffer* g = from_handle<GBuffer>(h, kMagicGBuffer);
     if (!g) return fail(ILM_ERR_INVALID_HANDLE, "not a G-buffer handle");
     if (!d) return fail(ILM_ERR_INVALID_ARGUMENT, "desc is NULL");
@@ -2207,6 +2270,7 @@ int32_t ilm_lightmap_create(IlmHandle hctx, int32_t w, int32_t ht, int32_t forma
 }
 
 int32_t ilm_lightmap_download(IlmHandle h, void* dst, int32_t first_row, int32_t row_count) {
+    ILM_TRACE_RANGE("ilm_lightmap_download");
     Lightmap* m = from_handle<Lightmap>(h, kMagicLightmap);
     if (!m) return fail(ILM_ERR_INVALID_HANDLE, "not a lightmap handle");
     if (!dst) return fail(ILM_ERR_INVALID_ARGUMENT, "dst is NULL");
@@ -2221,6 +2285,7 @@ int32_t ilm_lightmap_download(IlmHandle h, void* dst, int32_t first_row, int32_t
 }
 
 int32_t ilm_lightmap_upload(IlmHandle h, const void* src, int32_t first_row, int32_t row_count) {
+    ILM_TRACE_RANGE("ilm_lightmap_upload");
     Lightmap* m = from_handle<Lightmap>(h, kMagicLightmap);
     if (!m) return fail(ILM_ERR_INVALID_HANDLE, "not a lightmap handle");
     if (!src) return fail(ILM_ERR_INVALID_ARGUMENT, "src is NULL");
@@ -2248,6 +2313,7 @@ int32_t ilm_lightmap_destroy(IlmHandle h) {
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->main());
     if (m->texels && !m->external) (void)hipFree(m->texels);
+    if (m->d_mirrors) (void)hipFree(m->d_mirrors);
     retire_handle(m);
     delete m;
     return ILM_OK;
@@ -2360,12 +2426,21 @@ int32_t plan_light_split(Ctx* c, LightLaunch* a) {
     if (t[0] >= slots) return ILM_OK;
     a->taper[0] = t[0]; a->taper[1] = t[1]; a->taper[2] = t[2];
     a->split = (t[2] < slots) ? 8 : (t[1] < slots) ? 4 : 2;
-    if ((size_t)tiles > c->light_partials_tiles) {
+    // partial sums: one record of kLightParts x 256 float4 (32 KB) per SPLIT block slot of the launch -- (slots - taper[0]) x 8 XCDs -- not
+    // per tile (a forced split on a 4K frame asked for 1 GB).  When the device cannot give it the launch is not split: the
+    // frame is the same bits either way.
+    const size_t split_slots = (size_t)(slots - t[0]) * 8u;
+    if (split_slots > c->light_partials_tiles) {
         HIP_TRY(hipStreamSynchronize(c->main()));
         if (c->d_light_partials) HIP_TRY(hipFree(c->d_light_partials));
         c->d_light_partials = nullptr; c->light_partials_tiles = 0;
-        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&c->d_light_partials), (size_t)tiles * (size_t)kLightParts * (size_t)kLightTileThreads * sizeof(float4)));
-        c->light_partials_tiles = (size_t)tiles;
+        if (hipMalloc(reinterpret_cast<void**>(&c->d_light_partials), split_slots * (size_t)kLightParts * (size_t)kLightTileThreads * sizeof(float4)) != hipSuccess) {
+            (void)hipGetLastError();
+            c->d_light_partials = nullptr;
+            a->split = 1; a->taper[0] = a->taper[1] = a->taper[2] = slots;
+            return ILM_OK;
+        }
+        c->light_partials_tiles = split_slots;
     }
     if ((size_t)tiles > c->light_tickets_cap) {
         HIP_TRY(hipStreamSynchronize(c->main()));
@@ -2396,6 +2471,7 @@ int light_group_order_min() {
 }
 int32_t plan_group_order(Ctx* c, LightLaunch* a, const IlmLightVertex* lights, int light_count, int group_edge_px) {
     a->group_order = nullptr;
+    uint64_t pending_key = 0;
     const int mode = light_group_order_env();
     if (mode == 0 || a->tile_map != 4 || light_count <= 0) return ILM_OK;
     const int rows = a->row_end - a->row_begin;
@@ -2411,7 +2487,8 @@ int32_t plan_group_order(Ctx* c, LightLaunch* a, const IlmLightVertex* lights, i
         const int32_t geom[5] = { a->width, a->row_begin, a->row_end, group_edge_px, light_count };
         mix(geom, sizeof(geom));
         if (c->d_group_order && c->group_order_key == key && c->group_order_groups == groups) { a->group_order = c->d_group_order; return ILM_OK; }
-        c->group_order_key = key; c->group_order_groups = groups;
+        pending_key = key;       // committed below, once the table IS on the device (a failed upload left the key of a table that was not there)
+        c->group_order_groups = 0;
     }
     std::vector<double> cost((size_t)groups, 0.0);
     const float sx = a->env.GBufferTexelSizeAndMisc.z * a->env.ZAndScale.z, sy = a->env.GBufferTexelSizeAndMisc.w * a->env.ZAndScale.w;
@@ -2421,8 +2498,12 @@ int32_t plan_group_order(Ctx* c, LightLaunch* a, const IlmLightVertex* lights, i
         const double x0 = ((double)L.LightPosition1.x - reach - a->env.ViewportPosition[0]) * sx, x1 = ((double)L.LightPosition1.x + reach - a->env.ViewportPosition[0]) * sx;
         const double y0 = ((double)L.LightPosition1.y - reach - a->env.ViewportPosition[1]) * sy - a->row_begin, y1 = ((double)L.LightPosition1.y + reach - a->env.ViewportPosition[1]) * sy - a->row_begin;
         if (!(x1 > x0) || !(y1 > y0)) continue;
-        const int ga = std::max(0, (int)std::floor(x0 / group_edge_px)), gb = std::min(gx - 1, (int)std::floor(x1 / group_edge_px));
-        const int gc = std::max(0, (int)std::floor(y0 / group_edge_px)), gd = std::min(gy - 1, (int)std::floor(y1 / group_edge_px));
+        // (clamped to the launch's rectangle in double BEFORE the conversion: a huge or infinite radius must not reach the int cast)
+        const double cx0 = std::min(std::max(x0, 0.0), (double)a->width), cx1 = std::min(std::max(x1, 0.0), (double)a->width);
+        const double cy0 = std::min(std::max(y0, 0.0), (double)rows), cy1 = std::min(std::max(y1, 0.0), (double)rows);
+        if (!(cx1 > cx0) || !(cy1 > cy0)) continue;
+        const int ga = std::max(0, (int)std::floor(cx0 / group_edge_px)), gb = std::min(gx - 1, (int)std::floor(cx1 / group_edge_px));
+        const int gc = std::max(0, (int)std::floor(cy0 / group_edge_px)), gd = std::min(gy - 1, (int)std::floor(cy1 / group_edge_px));
         for (int yy = gc; yy <= gd; yy++)
             for (int xx = ga; xx <= gb; xx++) {
                 const double w = std::min(x1, (double)std::min((xx + 1) * group_edge_px, a->width)) - std::max(x0, (double)(xx * group_edge_px));
@@ -2451,6 +2532,7 @@ int32_t plan_group_order(Ctx* c, LightLaunch* a, const IlmLightVertex* lights, i
     }
     const int32_t rc = upload_small(c, c->d_group_order, dealt.data(), sizeof(uint16_t) * (size_t)groups);
     if (rc != ILM_OK) return rc;
+    c->group_order_key = pending_key; c->group_order_groups = groups;
     a->group_order = c->d_group_order;
     return ILM_OK;
 }
@@ -2482,14 +2564,17 @@ int32_t fill_light_launch(Ctx* c, const IlmEnvironment* env, const IlmDistanceFi
     a->tile_map = light_tile_map();
     a->tile_macro = light_tile_macro_for(m->width, row_end - row_begin);
     a->split = 1; a->partials = nullptr; a->tickets = nullptr; a->group_order = nullptr;
+    a->mirrors = m->d_mirrors; a->mirror_count = m->d_mirrors ? m->mirror_count : 0;
     return ILM_OK;
 }
 }  // namespace
+
 
 int32_t ilm_render_particle_lights(IlmHandle hctx, IlmHandle hsystem, const int32_t* quad_counts, int32_t chunk_count,
                                    const IlmParticleLightParams* params, const IlmEnvironment* env, const IlmDistanceFieldUniforms* df,
                                    IlmHandle hgbuffer, IlmHandle hsdf, IlmHandle hlightmap, int32_t row_begin, int32_t row_end,
                                    IlmRenderStats* stats) {
+    ILM_TRACE_RANGE("ilm_render_particle_lights");
     Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);
     if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
     System* s = from_handle<System>(hsystem, kMagicSystem);
@@ -2501,7 +2586,7 @@ int32_t ilm_render_particle_lights(IlmHandle hctx, IlmHandle hsystem, const int3
         return fail(ILM_ERR_INVALID_ARGUMENT, "StippleFactor %g < 1 needs Fracture's StippleReject, which is outside the reference tree", (double)params->StippleFactor);
     const int n = (int)s->chunks.size();
     if (chunk_count < 0 || chunk_count > n) return fail(ILM_ERR_OUT_OF_RANGE, "chunk_count %d outside [0, %d]", chunk_count, n);
-    LightLaunch a;
+    LightLaunch a = {};
     int32_t rc = fill_light_launch(c, env, df, hgbuffer, hsdf, hlightmap, row_begin, row_end, &a);
     if (rc != ILM_OK) return rc;
     if (chunk_count == 0) return ILM_OK;
@@ -2575,6 +2660,7 @@ int32_t ilm_render_particle_lights(IlmHandle hctx, IlmHandle hsystem, const int3
 int32_t ilm_render_light_probes(IlmHandle hctx, const IlmLightVertex* lights, int32_t light_count,
                                 const IlmFloat4* probe_positions, const IlmFloat4* probe_normals, int32_t probe_count,
                                 const IlmEnvironment* env, const IlmDistanceFieldUniforms* df, IlmHandle hsdf, IlmFloat4* out_values) {
+    ILM_TRACE_RANGE("ilm_render_light_probes");
     Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);
     if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
     Sdf* f = nullptr;
@@ -2722,6 +2808,7 @@ static int32_t readback_capacity(const System* s, const int32_t* element_counts,
 
 int32_t ilm_system_readback_view(IlmHandle hsystem, const int32_t* element_counts, int32_t chunk_count, const IlmReadbackParams* params,
                                  const IlmReadbackDrawCall** out_records, int32_t* out_count) {
+    ILM_TRACE_RANGE("ilm_system_readback_view");
     System* s = from_handle<System>(hsystem, kMagicSystem);
     if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
     if (!params || !out_count || !out_records) return fail(ILM_ERR_INVALID_ARGUMENT, "bad arguments");
@@ -2739,6 +2826,7 @@ int32_t ilm_system_readback_view(IlmHandle hsystem, const int32_t* element_count
 
 int32_t ilm_system_readback(IlmHandle hsystem, const int32_t* element_counts, int32_t chunk_count, const IlmReadbackParams* params,
                             IlmReadbackDrawCall* out, int32_t capacity, int32_t* out_count) {
+    ILM_TRACE_RANGE("ilm_system_readback");
     System* s = from_handle<System>(hsystem, kMagicSystem);
     if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
     if (!params || !out_count || capacity < 0 || (capacity > 0 && !out)) return fail(ILM_ERR_INVALID_ARGUMENT, "bad arguments");
@@ -2812,6 +2900,7 @@ int32_t ilm_ctx_set_light_ramp(IlmHandle hctx, const IlmFloat4* texels, int32_t 
 }
 
 int32_t ilm_lightmap_clear(IlmHandle h, const float rgba[4]) {
+    ILM_TRACE_RANGE("ilm_lightmap_clear");
     Lightmap* m = from_handle<Lightmap>(h, kMagicLightmap);
     if (!m) return fail(ILM_ERR_INVALID_HANDLE, "not a lightmap handle");
     if (!rgba) return fail(ILM_ERR_INVALID_ARGUMENT, "rgba is NULL");
@@ -2822,6 +2911,7 @@ int32_t ilm_lightmap_clear(IlmHandle h, const float rgba[4]) {
 
 int32_t ilm_render_particles(IlmHandle hsystem, const int32_t* quad_counts, int32_t chunk_count, const IlmRasterizeParams* params,
                              IlmHandle htarget, uint64_t* out_stats) {
+    ILM_TRACE_RANGE("ilm_render_particles");
     System* s = from_handle<System>(hsystem, kMagicSystem);
     if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
     Lightmap* m = from_handle<Lightmap>(htarget, kMagicLightmap);
@@ -2886,10 +2976,12 @@ int32_t ilm_render_particles(IlmHandle hsystem, const int32_t* quad_counts, int3
 }
 
 int32_t ilm_resolve_lighting(IlmHandle hsrc, IlmHandle hdst, const IlmHDRConfiguration* hdr, int32_t row_begin, int32_t row_end) {
+    ILM_TRACE_RANGE("ilm_resolve_lighting");
     return ilm_resolve_lighting_with_albedo(hsrc, 0, hdst, hdr, row_begin, row_end);
 }
 
 int32_t ilm_resolve_lighting_with_albedo(IlmHandle hsrc, IlmHandle halbedo, IlmHandle hdst, const IlmHDRConfiguration* hdr, int32_t row_begin, int32_t row_end) {
+    ILM_TRACE_RANGE("ilm_resolve_lighting_with_albedo");
     Lightmap* src = from_handle<Lightmap>(hsrc, kMagicLightmap);
     Lightmap* dst = from_handle<Lightmap>(hdst, kMagicLightmap);
     if (!src || !dst) return fail(ILM_ERR_INVALID_HANDLE, "not a lightmap handle");
@@ -2946,6 +3038,7 @@ int32_t ilm_resolve_lighting_with_albedo(IlmHandle hsrc, IlmHandle halbedo, IlmH
 int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, int32_t light_count, const IlmEnvironment* env,
                                  const IlmDistanceFieldUniforms* df, IlmHandle hgbuffer, IlmHandle hsdf, const float ambient[4],
                                  IlmHandle hlightmap, int32_t row_begin, int32_t row_end, IlmRenderStats* stats) {
+    ILM_TRACE_RANGE("ilm_render_sphere_lights");
     Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);
     if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
     Lightmap* m = from_handle<Lightmap>(hlightmap, kMagicLightmap);
@@ -2991,7 +3084,7 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
         }
     }
 
-    LightLaunch a;
+    LightLaunch a = {};
     a.lights = c->d_lights;
     a.light_count = light_count;
     a.env = *env;
@@ -3013,6 +3106,7 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
         a.stats = c->d_stats;
     }
     a.split = 1; a.partials = nullptr; a.tickets = nullptr; a.group_order = nullptr;
+    a.mirrors = m->d_mirrors; a.mirror_count = m->d_mirrors ? m->mirror_count : 0;      // store-mode exchange of a group lightmap
     { const int32_t rc = plan_light_split(c, &a); if (rc != ILM_OK) return rc; }
     { const int32_t rc = plan_group_order(c, &a, lights, light_count, 16 * a.tile_macro); if (rc != ILM_OK) return rc; }
     HIP_TRY(launch_sphere_lights_prepared(a, c->d_recs, c->main()));

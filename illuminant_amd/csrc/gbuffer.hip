@@ -195,20 +195,36 @@ __global__ __launch_bounds__(64) void gbuffer_setup_kernel(const GBufferMeshLaun
         const float e = ref::kGroundHalfExtent;
         const float cx[4] = { -e, e, e, -e }, cy[4] = { -e, -e, e, e };
         IlmHeightVolumeVertex g[3];
-        for (int k = 0; k < 3; k++) {
-            const int c = quad_indices[k];                       // corners 0, 1, 3: (x0, y0), (x1, y0), (x0, y1) of the rectangle
-            g[k].Position[0] = cx[c]; g[k].Position[1] = cy[c]; g[k].Position[2] = gz;
-            g[k].Normal[0] = 0.0f; g[k].Normal[1] = 0.0f; g[k].Normal[2] = 1.0f;
-            g[k].ZRange[0] = d.GroundZ; g[k].ZRange[1] = d.GroundZ;
-            g[k].EnableShadows = d.EnableGroundShadows ? 1.0f : 0.0f;
-        }
+        auto corners = [&](int first) {
+            for (int k = 0; k < 3; k++) {
+                const int c = quad_indices[first + k];           // triangle 0: corners 0, 1, 3 = (x0, y0), (x1, y0), (x0, y1) of the rectangle
+                g[k].Position[0] = cx[c]; g[k].Position[1] = cy[c]; g[k].Position[2] = gz;
+                g[k].Normal[0] = 0.0f; g[k].Normal[1] = 0.0f; g[k].Normal[2] = 1.0f;
+                g[k].ZRange[0] = d.GroundZ; g[k].ZRange[1] = d.GroundZ;
+                g[k].EnableShadows = d.EnableGroundShadows ? 1.0f : 0.0f;
+            }
+        };
+        corners(0);
         volume_prim(p, kGround, g[0], g[1], g[2], d);
-        const bool drawn = (t == 0) && (p.kind == kGround) && (p.x[0] == p.x[2]) && (p.y[0] == p.y[1]);
-        const int32_t x0 = p.x[0], x1 = p.x[1], y0 = p.y[0], y1 = p.y[2];
-        p.i0 = (int32_t)(((int64_t)x0 - 128 + 255) >> 8); p.i1 = (int32_t)(((int64_t)x1 - 128 + 255) >> 8) - 1;
-        p.j0 = (int32_t)(((int64_t)y0 - 128 + 255) >> 8); p.j1 = (int32_t)(((int64_t)y1 - 128 + 255) >> 8) - 1;
-        shape = kShapeRect;
-        if (!drawn || (p.i1 < p.i0) || (p.j1 < p.j0)) { p.kind = -1; p.i0 = p.j0 = 1; p.i1 = p.j1 = 0; shape = 0; }
+        // The rectangle from the extremes of the three snapped corners, whatever order finish() left them in (a negative ViewportScale on
+        // one axis mirrors the quad and swaps two vertices; on both axes it reverses left and right, top and bottom -- ADVICE r04: the
+        // equality test on fixed vertex slots then dropped the ground plane): an axis-aligned right triangle has exactly two x and two y.
+        const int32_t x0 = min(min(p.x[0], p.x[1]), p.x[2]), x1 = max(max(p.x[0], p.x[1]), p.x[2]);
+        const int32_t y0 = min(min(p.y[0], p.y[1]), p.y[2]), y1 = max(max(p.y[0], p.y[1]), p.y[2]);
+        bool axis_aligned = (x1 > x0) && (y1 > y0);
+        for (int k = 0; k < 3; k++) axis_aligned = axis_aligned && (p.x[k] == x0 || p.x[k] == x1) && (p.y[k] == y0 || p.y[k] == y1);
+        if ((p.kind == kGround) && axis_aligned) {
+            p.i0 = (int32_t)(((int64_t)x0 - 128 + 255) >> 8); p.i1 = (int32_t)(((int64_t)x1 - 128 + 255) >> 8) - 1;
+            p.j0 = (int32_t)(((int64_t)y0 - 128 + 255) >> 8); p.j1 = (int32_t)(((int64_t)y1 - 128 + 255) >> 8) - 1;
+            shape = kShapeRect;
+            if ((t != 0) || (p.i1 < p.i0) || (p.j1 < p.j0)) { p.kind = -1; p.i0 = p.j0 = 1; p.i1 = p.j1 = 0; shape = 0; }
+        } else if (p.kind == kGround) {
+            // not a rectangle the shortcut can describe (no transform of the reference produces this): the quad's two real triangles
+            corners(3 * t);
+            volume_prim(p, kGround, g[0], g[1], g[2], d);
+        } else if (t != 0) {
+            p.kind = -1; p.i0 = p.j0 = 1; p.i1 = p.j1 = 0;
+        }
     } else if (t < 2 + a.top_triangles) {
         const IlmHeightVolumeVertex* v = a.top + 3 * (size_t)(t - 2);
         volume_prim(p, d.TwoPointFiveD ? kTop : kGround, v[0], v[1], v[2], d);

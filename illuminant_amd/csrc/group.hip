@@ -101,6 +101,7 @@ struct Group {
     std::vector<hipEvent_t> events;         // one per local member: "my pushes have been queued / finished" (peer fan-out)
     std::vector<ncclComm_t> comms;          // one per local member once a communicator exists
     bool duplicates = false;                // two members share a device (RCCL refuses that)
+    bool peers_ok = true;                   // every pair of distinct local devices can address each other's memory (store mode needs it)
     void* d_counts = nullptr; size_t counts_bytes = 0;     // scratch of ilm_group_live_counts (rank mode), on member 0's device
 };
 
@@ -115,6 +116,7 @@ struct GroupLightmap {
     bool equal_slots = true;
     std::vector<void*> buffers;             // per local member: world * slot_rows rows
     std::vector<IlmHandle> lightmaps;       // per local member: lightmap object aliasing the buffer
+    bool store_mode = false;                // ILM_GATHER_STORE armed: every member's light passes also store into the other members' buffers
 };
 
 Group* group_from(IlmHandle h) { return handle_is_live(h, kMagicGroup) ? reinterpret_cast<Group*>(static_cast<uintptr_t>(h)) : nullptr; }
@@ -152,7 +154,10 @@ int32_t make_members(Group* g) {
             int can = 0;
             if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) {
                 (void)hipSetDevice(a);
-                (void)hipDeviceEnablePeerAccess(b, 0);
+                const hipError_t pe = hipDeviceEnablePeerAccess(b, 0);
+                if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) g->peers_ok = false;
+            } else {
+                g->peers_ok = false;
             }
             (void)hipGetLastError();
         }
@@ -296,8 +301,54 @@ int32_t exchange_ranges(Group* g, void* const* buffers, const std::vector<size_t
     return ILM_OK;
 }
 
+// Every local member's stream waits for everything queued on every other member's stream so far (events; nothing blocks the host).
+int32_t fence_members(Group* g) {
+    const int n = g->n_local;
+    if (n < 2) return ILM_OK;
+    for (int i = 0; i < n; i++) {
+        HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+        HIP_TRY(hipEventRecord(g->events[(size_t)i], g->stream((size_t)i)));
+    }
+    for (int i = 0; i < n; i++) {
+        HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+        for (int j = 0; j < n; j++)
+            if (j != i) HIP_TRY(hipStreamWaitEvent(g->stream((size_t)i), g->events[(size_t)j], 0));
+    }
+    return ILM_OK;
+}
+
+// ILM_GATHER_STORE (r05): the exchange disappears into the light kernel's epilogue.  Every member's lightmap object is handed the
+// buffers of the OTHER members (lightmap_set_mirrors): a light pass stores each texel of its strip at the same offset of every copy of
+// the frame -- its own and, through the peer mapping (hipDeviceEnablePeerAccess, make_members), the others' over xGMI: n stores of 8 B
+// per pixel and member instead of a copy phase behind the strip.  What is left of the "gather" is ordering: a member's later readers of
+// the frame wait for the other members' passes (fence_members).  In-process groups only: a buffer of another PROCESS is not addressable
+// here without an IPC mapping (not built; groups that span processes exchange with RCCL).
+int32_t set_store_mode(GroupLightmap* m, bool enable) {
+    Group* g = m->group;
+    if (enable == m->store_mode) return ILM_OK;
+    if (enable) {
+        if (g->rank_mode) return api_fail(ILM_ERR_STATE, "ILM_GATHER_STORE needs every member in this process (peer-mapped buffers): a group that spans processes gathers with RCCL");
+        if (!g->peers_ok) return api_fail(ILM_ERR_STATE, "ILM_GATHER_STORE needs peer access between every pair of the group's devices");
+    }
+    for (int i = 0; i < g->n_local; i++) {
+        std::vector<void*> others;
+        for (int j = 0; j < g->n_local && enable; j++)
+            if (j != i) others.push_back(m->buffers[(size_t)j]);
+        const int32_t rc = lightmap_set_mirrors(m->lightmaps[(size_t)i], others.data(), (int)others.size());
+        if (rc != ILM_OK) return rc;
+    }
+    m->store_mode = enable;
+    return ILM_OK;
+}
+
 // the exchange of a group lightmap's strips: one in-place all-gather for the equal slots, range by range otherwise
 int32_t gather_lightmap(GroupLightmap* m, int32_t gather) {
+    if (gather == ILM_GATHER_STORE) {
+        if (!m->store_mode) return api_fail(ILM_ERR_STATE, "ILM_GATHER_STORE: arm the group lightmap first (ilm_group_lightmap_store_mode)");
+        return fence_members(m->group);
+    }
+    if (m->store_mode && gather != ILM_GATHER_NONE)
+        return api_fail(ILM_ERR_STATE, "the group lightmap is in store mode: its members already hold every strip (gather with ILM_GATHER_STORE, or switch the mode off)");
     if (m->equal_slots) return all_gather(m->group, m->buffers.data(), m->row_bytes * (size_t)m->slot_rows, gather);
     std::vector<size_t> offset((size_t)m->group->world), bytes((size_t)m->group->world);
     for (int r = 0; r < m->group->world; r++) {
@@ -451,6 +502,7 @@ int32_t ilm_group_sync(IlmHandle h) {
 }
 
 int32_t ilm_group_all_gather(IlmHandle h, void* const* buffers, uint64_t bytes_per_rank, int32_t gather) {
+    ILM_TRACE_RANGE("ilm_group_all_gather");
     Group* g = group_from(h);
     if (!g) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group handle");
     if (!buffers) return api_fail(ILM_ERR_INVALID_ARGUMENT, "buffers is NULL");
@@ -460,6 +512,7 @@ int32_t ilm_group_all_gather(IlmHandle h, void* const* buffers, uint64_t bytes_p
 }
 
 int32_t ilm_group_host_all_gather(IlmHandle h, const void* local, void* out_all, uint32_t bytes_per_rank) {
+    ILM_TRACE_RANGE("ilm_group_host_all_gather");
     Group* g = group_from(h);
     if (!g) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group handle");
     if (!local || !out_all) return api_fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
@@ -517,6 +570,7 @@ int32_t ilm_group_lightmap_destroy(IlmHandle h) {
     GroupLightmap* m = glm_from(h);
     if (!m) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group lightmap handle");
     Group* g = m->group;
+    if (m->store_mode && m->lightmaps.size() == (size_t)g->n_local) (void)set_store_mode(m, false);
     for (IlmHandle lm : m->lightmaps) (void)ilm_lightmap_destroy(lm);        // synchronises the member's stream
     for (size_t i = 0; i < m->buffers.size(); i++) {
         (void)hipSetDevice(g->devices[i]);
@@ -550,6 +604,7 @@ int32_t ilm_group_lightmap_strip(IlmHandle h, int32_t rank, int32_t* out_row_beg
 }
 
 int32_t ilm_group_lightmap_set_strips(IlmHandle h, const int32_t* row_begins, const int32_t* row_ends) {
+    ILM_TRACE_RANGE("ilm_group_lightmap_set_strips");
     GroupLightmap* m = glm_from(h);
     if (!m) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group lightmap handle");
     Group* g = m->group;
@@ -617,21 +672,36 @@ int32_t ilm_group_lightmap_set_strips(IlmHandle h, const int32_t* row_begins, co
 }
 
 int32_t ilm_group_lightmap_gather(IlmHandle h, int32_t gather) {
+    ILM_TRACE_RANGE("ilm_group_lightmap_gather");
     GroupLightmap* m = glm_from(h);
     if (!m) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group lightmap handle");
     return gather_lightmap(m, gather);
 }
 
+int32_t ilm_group_lightmap_store_mode(IlmHandle h, int32_t enable) {
+    GroupLightmap* m = glm_from(h);
+    if (!m) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group lightmap handle");
+    return set_store_mode(m, enable != 0);
+}
+
 int32_t ilm_group_render_sphere_lights(IlmHandle hgroup, const IlmLightVertex* lights, int32_t light_count, const IlmEnvironment* env,
                                        const IlmDistanceFieldUniforms* df, const IlmHandle* gbuffers, const IlmHandle* sdfs,
                                        const float ambient[4], IlmHandle hlightmap, int32_t gather, IlmRenderStats* stats) {
+    ILM_TRACE_RANGE("ilm_group_render_sphere_lights");
     Group* g = group_from(hgroup);
     if (!g) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group handle");
     GroupLightmap* m = glm_from(hlightmap);
     if (!m) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group lightmap handle");
     if (m->group != g) return api_fail(ILM_ERR_INVALID_ARGUMENT, "the lightmap belongs to another group");
-    if (gather < ILM_GATHER_NONE || gather > ILM_GATHER_RCCL) return api_fail(ILM_ERR_INVALID_ARGUMENT, "unknown gather mode %d", gather);
+    if (gather < ILM_GATHER_NONE || gather > ILM_GATHER_STORE) return api_fail(ILM_ERR_INVALID_ARGUMENT, "unknown gather mode %d", gather);
     if (stats) { stats->SdfSamples = 0; stats->PixelLightPairs = 0; stats->TracedPairs = 0; }
+    // store mode: armed for this call when the host has not armed the lightmap itself; nobody's pass may write into a member's frame
+    // before that member's earlier readers of it are done (the fence in front), and the fence behind is the "gather"
+    const bool arm_here = (gather == ILM_GATHER_STORE) && !m->store_mode;
+    if (gather != ILM_GATHER_STORE && gather != ILM_GATHER_NONE && m->store_mode)
+        return api_fail(ILM_ERR_STATE, "the group lightmap is in store mode: gather with ILM_GATHER_STORE (or switch it off)");
+    if (arm_here) { const int32_t rc = set_store_mode(m, true); if (rc != ILM_OK) return rc; }
+    if (gather == ILM_GATHER_STORE) { const int32_t rc = fence_members(g); if (rc != ILM_OK) return rc; }
     // every member's strip is queued before anything is waited for: the launches are asynchronous, the devices run concurrently
     // (the instrumented variant synchronises per member; it is a diagnostic)
     for (int i = 0; i < g->n_local; i++) {
@@ -640,14 +710,17 @@ int32_t ilm_group_render_sphere_lights(IlmHandle hgroup, const IlmLightVertex* l
         IlmRenderStats part = { 0, 0, 0 };
         const int32_t rc = ilm_render_sphere_lights(g->ctx[(size_t)i], lights, light_count, env, df, gbuffers ? gbuffers[i] : 0, sdfs ? sdfs[i] : 0,
                                                     ambient, m->lightmaps[(size_t)i], b, e, stats ? &part : nullptr);
-        if (rc != ILM_OK) return rc;
+        if (rc != ILM_OK) { if (arm_here) (void)set_store_mode(m, false); return rc; }
         if (stats) { stats->SdfSamples += part.SdfSamples; stats->PixelLightPairs += part.PixelLightPairs; stats->TracedPairs += part.TracedPairs; }
     }
-    return gather_lightmap(m, gather);
+    const int32_t rc = gather_lightmap(m, gather);
+    if (arm_here) { const int32_t rc2 = set_store_mode(m, false); if (rc == ILM_OK && rc2 != ILM_OK) return rc2; }
+    return rc;
 }
 
 int32_t ilm_group_live_counts(IlmHandle hgroup, const IlmHandle* systems, int32_t total_chunks, uint32_t* out_counts, int32_t capacity,
                               int32_t saturate16) {
+    ILM_TRACE_RANGE("ilm_group_live_counts");
     Group* g = group_from(hgroup);
     if (!g) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group handle");
     if (!systems || (!out_counts && total_chunks > 0)) return api_fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");

@@ -128,6 +128,23 @@ int set_step_interpreter(int on);     // ilm_debug_step_interpreter: returns the
 int set_step_streams(int n);          // ilm_debug_step_streams: 1 keeps every step on the context stream, 2 (default) lets large steps use two; returns the previous setting
 // the context's stream for work that is not a particle step: ordered after everything the context's second stepping stream holds (api.hip)
 hipStream_t ctx_stream_joined(IlmHandle ctx);
+// Tracing ranges (the reference brackets every transform and light batch with RenderTrace.Marker,
+// Illuminant/Particles/ParticleSystem.cs:464-469, Illuminant/Lighting/LightingRenderer.cs:1123-1124).  ILM_TRACE=1: every data-path entry
+// point of the C ABI pushes a named roctx range for its duration (host side: what a call queues; the kernels of a range carry its
+// correlation in a rocprofv3 --marker-trace --kernel-trace run).  The roctx library is bound at run time like RCCL (dlopen of
+// librocprofiler-sdk-roctx.so.1, then libroctx64.so.4); off (the default) an entry point pays one predictable branch.
+struct TraceApi { int (*push)(const char*) = nullptr; int (*pop)() = nullptr; bool on = false; };
+const TraceApi& trace_api();
+struct TraceRange {
+    bool on;
+    explicit TraceRange(const char* name) : on(trace_api().on) { if (on) (void)trace_api().push(name); }
+    ~TraceRange() { if (on) (void)trace_api().pop(); }
+    TraceRange(const TraceRange&) = delete;
+    TraceRange& operator=(const TraceRange&) = delete;
+};
+#define ILM_TRACE_RANGE(name) ::ilm::TraceRange ilm_trace_range_(name)
+// store-mode exchange of a group lightmap: the light passes into `lightmap` also store at the same offsets of `count` other buffers (0: off)
+int32_t lightmap_set_mirrors(IlmHandle lightmap, void* const* buffers, int count);
 
 // AoS float4 (device staging) <-> one SoA plane group (4 consecutive components)
 hipError_t launch_aos_to_soa(const float4* src, float* plane0, int64_t stride, int32_t first_slot, int32_t count, hipStream_t stream);
@@ -175,6 +192,10 @@ struct LightLaunch {
     int32_t taper[3], taper_slots;
     float4* partials;               // device scratch of the context: tile_count * kLightParts * 256 float4 (split > 1)
     uint32_t* tickets;              // device, one per tile, zero between launches (the last arriver resets its tile's)
+    // Store-mode exchange of a group lightmap (ILM_GATHER_STORE, group.hip): the lightmap's texel is ALSO stored at the same offset of
+    // `mirror_count` other buffers -- the other members' copies of the frame, peer-mapped over xGMI -- so the strips need no gather phase.
+    void* const* mirrors;           // device array of mirror_count base pointers (nullptr / 0: an ordinary lightmap)
+    int32_t mirror_count;
 };
 // A tile's light list is summed in kLightParts consecutive parts (entries [p n / 8, (p + 1) n / 8) of a list of n), each part from zero in
 // light order, the parts added onto the clear colour in part order: the sum's bits depend on the tile and its list only, not on how

@@ -485,6 +485,13 @@ constexpr int kListCapacity = (kTile == 16) ? 1024 : 256;
 #ifndef ILM_LIGHT_SGPRS
 #define ILM_LIGHT_SGPRS
 #endif
+// circle cull (sphere_lights_kernel): the particle-light instantiation (WIDE) and the sphere-light ones, switchable for A/B builds
+#ifndef ILM_LIGHT_CIRCLE_CULL_WIDE
+#define ILM_LIGHT_CIRCLE_CULL_WIDE 1
+#endif
+#ifndef ILM_LIGHT_CIRCLE_CULL
+#define ILM_LIGHT_CIRCLE_CULL 0
+#endif
 #if ILM_LIGHT_WAVES > 0
 #define ILM_LIGHT_OCCUPANCY __attribute__((amdgpu_waves_per_eu(ILM_LIGHT_WAVES, ILM_LIGHT_WAVES))) ILM_LIGHT_SGPRS
 #else
@@ -506,6 +513,7 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
     __shared__ int bin_count[2][kLightThreads / 64];
     __shared__ SliceEntry slice_table[kMaxTableSlices];
     __shared__ float4 tree[3][kLightThreads];       // the part sums waiting for their right-hand neighbours (levels 0-2 of the tree over 8 parts)
+    __shared__ float4 wave_box[kLightThreads / 64];  // circle cull: (min x, max x, min y, max y) of the shaded points of each wave's 8 x 8 pixels
 
     // The dispatcher places block b on XCD b % 8.  Which tiles an XCD gets decides both its L2 locality and its share of the work
     // (lights are not spread evenly): see light_tile_map() in api.hip for the measurements; groups of 6 x 6 tiles (tile_map 4) are the default.
@@ -588,6 +596,44 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
     P.start_inside = (table_n > 0) && trace_start_inside(P, a.df, a.sdf);
     const float cxp = (float)px + 0.5f, cyp = (float)py + 0.5f;
     const bool have_sdf = (a.sdf.texels != nullptr) && (a.df.Extent.x > 0.0f);
+    // Circle cull (r05).  A light adds nothing to a point whose distance from its centre (y scaled by the light's falloffY) is at least
+    // radius + max(ramp, 1): computeSphereLightOpacity's distance factor and its saturate(radius - distance) term are both exactly 0
+    // there (LightCommon.fxh:174-214; every falloff mode), the shader discards.  The raster footprint is a square (particle lights) or a
+    // cut-corner square (sphere lights) around that circle: 21 % / 13 % of its pixels lie outside it.  Each wave publishes the xy bounding
+    // box of the SHADED POINTS of its 8 x 8 pixels (whatever the G-buffer made of them: no assumption about ZToY or relativeY), and the
+    // binning marks, per list entry, the waves whose box lies wholly outside the light's circle (4 bits of the 16-bit entry): those waves
+    // skip the entry on a scalar test, an entry no wave needs is not listed.  Not in the statistics variant, whose pair count is the
+    // raster footprint's (so that variant is also the reference the culled frames are held to, bit for bit).
+    constexpr bool kCircleCull = !STATS && (kTile == 16) && (WIDE_BIN ? (ILM_LIGHT_CIRCLE_CULL_WIDE != 0) : (ILM_LIGHT_CIRCLE_CULL != 0));
+    if constexpr (kCircleCull) {
+        const bool finite_xy = (fabsf(P.shaded.x) <= 0x1p100f) && (fabsf(P.shaded.y) <= 0x1p100f);
+        const float inf = __builtin_inff();
+        // (a lane outside the image shades nothing: neutral; a lane whose point is not finite opens the box to everything)
+        float lo_x = in_image ? (finite_xy ? P.shaded.x : -inf) : inf, hi_x = in_image ? (finite_xy ? P.shaded.x : inf) : -inf;
+        float lo_y = in_image ? (finite_xy ? P.shaded.y : -inf) : inf, hi_y = in_image ? (finite_xy ? P.shaded.y : inf) : -inf;
+        for (int off = 32; off > 0; off >>= 1) {
+            lo_x = fminf(lo_x, __shfl_xor(lo_x, off)); hi_x = fmaxf(hi_x, __shfl_xor(hi_x, off));
+            lo_y = fminf(lo_y, __shfl_xor(lo_y, off)); hi_y = fmaxf(hi_y, __shfl_xor(hi_y, off));
+        }
+        if (lane == 0) wave_box[wave] = mk4(lo_x, hi_x, lo_y, hi_y);      // read after the first barrier of the light loop
+    }
+    // the waves of the workgroup whose box lies wholly outside the circle of light R (bit w = wave w), by whoever bins R
+    auto culled_waves = [&](const LightRec& R) -> int {
+        if constexpr (!kCircleCull) return 0;
+        const float reach = R.radius + fmaxf(R.ramp, 1.0f), fy = fabsf(R.falloff_y);
+        // (a ramp that is not positive never fades; NaNs fail every comparison below: no cull)
+        const bool cullable = (R.ramp > 0.0f) & (R.radius >= 0.0f) & (reach <= 0x1p60f) & (fy <= 0x1p60f);
+        const float limit = reach * 1.0001f + 0.01f, limit2 = limit * limit;
+        int mask = 0;
+#pragma unroll 1      // (one box at a time: the pass runs with the pixel's whole state live, 64 registers)
+        for (int w = 0; w < kLightThreads / 64; w++) {
+            const float4 b = wave_box[w];
+            const float dx = fmaxf(fmaxf(b.x - R.cx, R.cx - b.y), 0.0f), dy = fmaxf(fmaxf(b.z - R.cy, R.cy - b.w), 0.0f) * fy;
+            if (cullable && (dx * dx + dy * dy >= limit2)) mask |= 1 << w;
+        }
+        return mask;
+    };
+    const int cull_bit = __builtin_amdgcn_readfirstlane(10 + wave);      // (uniform by construction; said so, so that the walk's test is scalar)
 
     // What the lights are added to: the clear colour, or the lightmap's contents (additive blend onto an earlier pass of the same frame:
     // another light-type render state, LightingRenderer.cs:1100-1169).  Read when it is needed -- at the end, where the tile's sum is
@@ -730,6 +776,15 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
         }
 
         const int n = list_count;
+        if constexpr (kCircleCull) {
+            // the cull bits of the LISTED lights only (the binning looks at every light of the launch -- thousands of particle lights per
+            // tile, of which a few dozen are listed: computing the bits there cost more than the skipped entries gave back)
+            for (int t = (int)threadIdx.x; t < n; t += kLightThreads) {
+                const int e = (int)list[t];
+                list[t] = (uint16_t)(e | (culled_waves(recs[batch + (e & 0x3FF)]) << 10));
+            }
+            __syncthreads();
+        }
 
         for (int k = 0; k < n; k++) {
             // The launch descriptor lives in the kernarg segment.  Read through a pointer the compiler cannot see through, its fields are
@@ -742,7 +797,9 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
             const IlmEnvironment& env_k = A.env;
             const RampView& ramp_k = A.ramp;
             const int entry = __builtin_amdgcn_readfirstlane((int)list[k]);
-            const int li = entry & 0x7FFF;
+            const int li = entry & (kCircleCull ? 0x3FF : 0x7FFF);
+            if (kCircleCull && ((entry >> cull_bit) & 1))      // this wave's points are outside the light's circle (see culled_waves): a scalar test
+                continue;
             while (batch + li >= part_bound) {      // (never in the fp16-per-light model)
                 close_part();
                 part_bound = (int)(((long long)light_count * (part + 1)) / kLightParts);
@@ -793,7 +850,10 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
 #ifdef ILM_SPLIT_NO_COMBINE      // EXPERIMENT (timing only, wrong pixels): what the members cost without their meeting
         goto tile_done;
 #endif
-        float4* tile_sums = kernargs().partials + (size_t)tile * (size_t)kLightParts * (size_t)kLightThreads + threadIdx.x;
+        // (scratch is indexed by the tile's place among the SPLIT block slots of the launch -- slot - taper[0] of this XCD -- not by the tile:
+        // the untapered head of a launch needs none, api.hip plan_light_split sizes it so)
+        const size_t split_slot = (size_t)(slot_end - kernargs().taper[0]) * 8u + (size_t)((int)blockIdx.x % 8);
+        float4* tile_sums = kernargs().partials + split_slot * (size_t)kLightParts * (size_t)kLightThreads + threadIdx.x;
         store_partial(tile_sums + (size_t)member_end * (size_t)kLightThreads, acc_r, acc_g, acc_b, acc_a);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         uint32_t drawn = 0;
@@ -814,18 +874,28 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
 
     if (in_image) {
         const size_t o = (size_t)py * (size_t)a.width + (size_t)px;
-        if (a.format == ILM_LIGHTMAP_FLOAT4) {
-            reinterpret_cast<float4*>(a.lightmap)[o] = mk4(acc_r, acc_g, acc_b, acc_a);
-        } else if (a.format == ILM_LIGHTMAP_HALF4) {
-            uint2 v;
-            v.x = (uint32_t)__half_as_ushort(__float2half_rn(acc_r)) | ((uint32_t)__half_as_ushort(__float2half_rn(acc_g)) << 16);
-            v.y = (uint32_t)__half_as_ushort(__float2half_rn(acc_b)) | ((uint32_t)__half_as_ushort(__float2half_rn(acc_a)) << 16);
-            reinterpret_cast<uint2*>(a.lightmap)[o] = v;
-        } else {
+        // the texel, once; then wherever it goes: the lightmap, and in store mode the same offset of every other member's copy of the
+        // frame (peer-mapped; 8 x 8 pixels of a wave are eight 64-byte runs of half4 texels)
+        const float4 v32 = mk4(acc_r, acc_g, acc_b, acc_a);
+        uint2 v16 = make_uint2(0u, 0u);
+        uint32_t v8 = 0u;
+        if (a.format == ILM_LIGHTMAP_HALF4) {
+            v16.x = (uint32_t)__half_as_ushort(__float2half_rn(acc_r)) | ((uint32_t)__half_as_ushort(__float2half_rn(acc_g)) << 16);
+            v16.y = (uint32_t)__half_as_ushort(__float2half_rn(acc_b)) | ((uint32_t)__half_as_ushort(__float2half_rn(acc_a)) << 16);
+        } else if (a.format != ILM_LIGHTMAP_FLOAT4) {
             const uint32_t r = (uint32_t)rintf(sat(acc_r) * 255.0f), g = (uint32_t)rintf(sat(acc_g) * 255.0f);
             const uint32_t bl = (uint32_t)rintf(sat(acc_b) * 255.0f), al = (uint32_t)rintf(sat(acc_a) * 255.0f);
-            reinterpret_cast<uint32_t*>(a.lightmap)[o] = r | (g << 8) | (bl << 16) | (al << 24);
+            v8 = r | (g << 8) | (bl << 16) | (al << 24);
         }
+        auto store_texel = [&](void* base) {
+            if (a.format == ILM_LIGHTMAP_FLOAT4) reinterpret_cast<float4*>(base)[o] = v32;
+            else if (a.format == ILM_LIGHTMAP_HALF4) reinterpret_cast<uint2*>(base)[o] = v16;
+            else reinterpret_cast<uint32_t*>(base)[o] = v8;
+        };
+        store_texel(a.lightmap);
+        const LightLaunch& A = kernargs();
+        const int mirror_count = A.mirror_count;
+        for (int m = 0; m < mirror_count; m++) store_texel(A.mirrors[m]);
     }
 
 tile_done:

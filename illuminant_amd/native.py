@@ -122,6 +122,7 @@ SYMBOLS = {
     "ilm_group_lightmap_strip": (_I, [_H, _I, C.POINTER(_I), C.POINTER(_I), C.POINTER(_I)]),
     "ilm_group_lightmap_set_strips": (_I, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ilm_group_lightmap_gather": (_I, [_H, _I]),
+    "ilm_group_lightmap_store_mode": (_I, [_H, _I]),
     "ilm_group_lightmap_destroy": (_I, [_H]),
     "ilm_group_render_sphere_lights": (_I, [_H, _P, _I, _P, _P, _P, _P, _P, _H, _I, _P]),
     "ilm_group_live_counts": (_I, [_H, _P, _I, _P, _I, _I]),
@@ -602,7 +603,7 @@ class Lightmap:
         self.handle = abi.Handle(0)
 
 
-GATHER_NONE, GATHER_PEER, GATHER_RCCL = 0, 1, 2
+GATHER_NONE, GATHER_PEER, GATHER_RCCL, GATHER_STORE = 0, 1, 2, 3
 
 
 class Group:
@@ -729,6 +730,11 @@ class GroupLightmap:
 
     def gather(self, gather):
         check(lib().ilm_group_lightmap_gather(self.handle, gather))
+
+    def store_mode(self, enable=True):
+        """ilm_group_lightmap_store_mode: while armed, every light pass into a member's lightmap also stores into the other members' copies
+        of the frame; gather(GATHER_STORE) is then the fence that replaces the exchange."""
+        check(lib().ilm_group_lightmap_store_mode(self.handle, 1 if enable else 0))
 
     def download(self, local_index=0):
         """The frame (first `height` rows) as local member `local_index` holds it."""

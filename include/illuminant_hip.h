@@ -30,9 +30,10 @@
 extern "C" {
 #endif
 
-/* 7 (r04): + ilm_ctx_set_light_split, ilm_sdf_mark_dirty, ilm_sdf_trace_info / IlmSdfTraceInfo; ilm_group_lightmap_set_strips became a
+/* 8 (r05): + ilm_group_lightmap_store_mode, ILM_GATHER_STORE.
+ * 7 (r04): + ilm_ctx_set_light_split, ilm_sdf_mark_dirty, ilm_sdf_trace_info / IlmSdfTraceInfo; ilm_group_lightmap_set_strips became a
  * collective with one process per GPU.  Nothing was removed or changed in layout since 6. */
-#define ILM_ABI_VERSION 7
+#define ILM_ABI_VERSION 8
 
 /* ---- return codes ------------------------------------------------------ */
 #define ILM_OK                    0
@@ -932,7 +933,10 @@ enum {
     ILM_GATHER_NONE = 0,  /* strips stay where they were rendered (a host that reads every strip back itself) */
     ILM_GATHER_PEER = 1,  /* in-process groups: every member pushes its strip to the n - 1 others with hipMemcpyPeerAsync -- one
                              transfer per xGMI link, all links of the full mesh busy at once */
-    ILM_GATHER_RCCL = 2   /* ncclAllGather on the members' context streams (RCCL over xGMI; the only exchange between processes) */
+    ILM_GATHER_RCCL = 2,  /* ncclAllGather on the members' context streams (RCCL over xGMI; the only exchange between processes) */
+    ILM_GATHER_STORE = 3  /* in-process groups (r05): no copy phase at all -- the light kernel's final store writes every texel of a member's
+                             strip at the same offset of EVERY member's copy of the frame (the others' buffers peer-mapped over xGMI:
+                             n stores of 8 B per pixel), so the exchange overlaps the strip; what remains of the gather is a fence */
 };
 
 /* In-process group over `n` devices (ids may repeat: several members on one device, which is how the exchange paths are tested on a
@@ -978,6 +982,15 @@ int32_t ilm_group_lightmap_strip(IlmHandle group_lightmap, int32_t rank, int32_t
  * transfer per xGMI link and direction) instead of by the single in-place all-gather.  NULL, NULL restores the equal slots. */
 int32_t ilm_group_lightmap_set_strips(IlmHandle group_lightmap, const int32_t* row_begins, const int32_t* row_ends);
 int32_t ilm_group_lightmap_gather(IlmHandle group_lightmap, int32_t gather);
+/* Arms (enable != 0) or disarms the store-mode exchange: while armed, EVERY light pass into a member's lightmap (ilm_render_sphere_lights,
+ * ilm_render_particle_lights through ilm_group_lightmap_member's handle) also stores its texels into the other members' copies of the frame, and
+ * ilm_group_lightmap_gather(ILM_GATHER_STORE) is the fence that orders each member's later readers behind the other members' passes --
+ * call it after the strips of a frame, and again in front of the next frame's strips when readers of the old frame may still be queued
+ * (a pass overwrites the other members' copies as it runs).  ilm_group_render_sphere_lights(..., ILM_GATHER_STORE) does all of this
+ * itself for one call.  ILM_ERR_STATE for groups that span processes (their buffers are not peer-mapped here: RCCL) or without peer
+ * access between the devices.  Synchronises the members' streams.  The reference has one device and one lightmap
+ * (Illuminant/Lighting/LightingRenderer.cs:1004-1010): every member still ends with that one composited frame. */
+int32_t ilm_group_lightmap_store_mode(IlmHandle group_lightmap, int32_t enable);
 int32_t ilm_group_lightmap_destroy(IlmHandle group_lightmap);
 
 /* ilm_render_sphere_lights for the whole group: every local member renders its strip (same lights, environment and uniforms;

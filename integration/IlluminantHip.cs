@@ -1,6 +1,6 @@
 // IlluminantHip.cs -- P/Invoke layer of libilluminant_hip.so for sq/Illuminant (drop into Illuminant/Native/).
 // GENERATED from include/illuminant_hip.h by tools/gen_csharp_binding.py -- do not edit; the header carries the documentation
-// and the reference file:line each entry point replaces.  ABI version 7.
+// and the reference file:line each entry point replaces.  ABI version 8.
 //
 // Vector4 / Matrix are XNA's; LightVertex is Illuminant/Vertices.cs:10-39; the Uniforms.* structs of the reference
 // (Uniforms.cs:14-24,79-88,197-236; Bezier.cs:433-441,588-599) have the byte layout of the Ilm* mirrors below and can be passed
@@ -16,7 +16,7 @@ namespace Squared.Illuminant.Native {
     }
 
     public static class IlmConstants {
-        public const int ABI_VERSION = 7;
+        public const int ABI_VERSION = 8;
         public const int BLEND_FP16_PER_LIGHT = 1;
         public const int BLEND_FP32_ACCUMULATE = 0;
         public const int ERR_INVALID_ARGUMENT = -1;
@@ -77,6 +77,7 @@ namespace Squared.Illuminant.Native {
         public const int GATHER_NONE = 0;
         public const int GATHER_PEER = 1;
         public const int GATHER_RCCL = 2;
+        public const int GATHER_STORE = 3;
     }
 
     [StructLayout(LayoutKind.Sequential, Pack = 4, Size = 64)]
@@ -556,6 +557,7 @@ namespace Squared.Illuminant.Native {
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_lightmap_strip (ulong groupLightmap, int rank, int* outRowBegin, int* outRowEnd, int* outSlotRows);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_lightmap_set_strips (ulong groupLightmap, int* rowBegins, int* rowEnds);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_lightmap_gather (ulong groupLightmap, int gather);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_lightmap_store_mode (ulong groupLightmap, int enable);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_lightmap_destroy (ulong groupLightmap);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_render_sphere_lights (ulong group, LightVertex* lights, int lightCount, IlmEnvironment* env, IlmDistanceFieldUniforms* df, ulong* gbuffers, ulong* sdfs, float* ambient, ulong groupLightmap, int gather, IlmRenderStats* stats);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_live_counts (ulong group, ulong* systems, int totalChunks, uint* outCounts, int capacity, int saturate16);

@@ -1,7 +1,8 @@
 """Worker of tests/test_fuzz_regressions_gpu.py: runs in its own process so that a VARIANT build of the library can be loaded
 (ILM_HIP_LIB, here illuminant_amd/lib/libilluminant_hip_gravity_exact.so = particles.hip compiled with -DILM_GRAVITY_EXACT: Gravity's IEEE
-sqrt / division form).  Replays the particle step of a fuzz seed from the ORACLE's post-spawn state (so the device and the oracle start
-from the same bits), without its spawner, and prints one JSON line about one slot of chunk 1.
+sqrt / division form).  Replays the TRANSFORMS of a fuzz seed's particle step (its Gravity op; UpdateMode = ILM_UPDATE_NONE -- the Update
+pass has divisions of its own and is not what the variant changes) from the ORACLE's post-spawn state, so the device and the oracle start
+from the same bits, and prints one JSON line about one slot of chunk 1 and about the chunk.
     ILM_HIP_LIB=... python tests/_variant_worker.py <seed> <slot>"""
 import copy
 import json
@@ -38,7 +39,7 @@ def device_step(ctx, cs, rnd, chunks, d):
     sysm.step(d)
     got = [[sysm.download(c, plane) for plane in (abi.PLANE_POSITION, abi.PLANE_VELOCITY, abi.PLANE_ATTRIBUTES, abi.PLANE_RENDER_COLOR, abi.PLANE_RENDER_DATA)]
            for c in range(len(chunks))]
-    counts = sysm.step_counts()
+    counts = sysm.step_counts() if (int(d.Flags) & abi.STEP_COUNT_LIVE) else None
     sysm.close(); eng.close()
     return got, counts
 
@@ -46,6 +47,8 @@ def device_step(ctx, cs, rnd, chunks, d):
 def main():
     seed, slot = int(sys.argv[1]), int(sys.argv[2])
     cs, rnd, chunks, d0 = post_spawn_state(seed)
+    d0.UpdateMode = abi.UPDATE_NONE
+    d0.Flags = 0
     ctx = native.Context(0)
     got, _ = device_step(ctx, cs, rnd, chunks, d0)
     want = [[a.copy() for a in c] for c in chunks]

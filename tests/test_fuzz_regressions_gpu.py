@@ -10,7 +10,8 @@ as named tests that assert what is actually true of them:
     the step has an attractor of the physical type whose radius all but cancels the particle's squared distance
     (Gravity.fx:44-47: strength / max(d^2 - radius, 0.001)), so the reference's own formula amplifies the last bit of a coordinate;
   * from the oracle's OWN post-spawn state (same bits in) the shipped kernel meets the criterion on every element, and the
-    -DILM_GRAVITY_EXACT build (Gravity's IEEE sqrt / division form) reproduces the oracle's velocity of that slot bit for bit.
+    -DILM_GRAVITY_EXACT build (Gravity's IEEE sqrt / division form) reproduces the oracle's Gravity pass bit for bit, on that slot and
+    on every live slot of the chunk.
 """
 import copy
 import itertools
@@ -122,7 +123,8 @@ def test_fuzz_miss_is_an_ulp_of_the_spawn_formula_in_front_of_the_references_own
 
 @pytest.mark.parametrize("seed,slot", [(c[0], c[1]) for c in CASES])
 def test_exact_gravity_build_reproduces_the_oracle_from_the_oracles_inputs(seed, slot):
-    """The -DILM_GRAVITY_EXACT variant (built beside the shipped library by csrc/Makefile) in a process of its own."""
+    """The -DILM_GRAVITY_EXACT variant (built beside the shipped library by csrc/Makefile) in a process of its own: the step's Gravity op
+    alone (ILM_UPDATE_NONE) on the oracle's post-spawn state."""
     assert os.path.exists(EXACT_LIB), "build the variant: make -C illuminant_amd/csrc (the Makefile's default goal builds both)"
     env = dict(os.environ, ILM_HIP_LIB=EXACT_LIB)
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_variant_worker.py"), str(seed), str(slot)], env=env, capture_output=True, text=True, timeout=600)

@@ -275,3 +275,22 @@ def test_billboard_texture_bounds_outside_the_unit_square_are_clamped_not_clippe
     drawn = ~np.all(got == ground, axis=-1)
     assert drawn[4, 8] and drawn[35, 8] and drawn[4, 23] and not drawn[35, 23] and drawn.sum() == 16 * 32 - 8 * 16      # the transparent texel covers u, v >= 0.5: columns 16-23, rows 20-35
     lm.close(); gb.close()
+
+
+@pytest.mark.parametrize("scale", [(-1.0, 1.0), (1.0, -1.25), (-1.125, -1.0)])
+def test_ground_plane_survives_a_mirrored_view(ctx, oracle, scale):
+    """a negative ViewportScale on one axis makes the rasteriser's set-up swap two vertices of the ground quad's first triangle,
+    on both axes it reverses the rectangle's corners; the rectangle shortcut looked at fixed vertex slots and dropped the ground plane
+    (every texel stayed zero).  The rectangle is now taken from the extremes of the snapped corners: the frame must equal the oracle's,
+    which rasterises the quad's two triangles."""
+    w, h = 96, 72
+    top = scenes.top_face_mesh([(-40.0, -30.0), (-10.0, -30.0), (-10.0, -5.0), (-40.0, -5.0)], 0.0, 12.0)
+    d = scenes.gbuffer_mesh_desc(ground_z=2.0, viewport_position=(-48.0 if scale[0] > 0 else 48.0, -36.0 if scale[1] > 0 else 36.0), viewport_scale=scale,
+                                 z_to_y=0.0, extent_z=64.0, two_point_five_d=False)
+    gb = native.GBufferTexture(ctx, None, abi.GBUFFER_FLOAT4, size=(w, h))
+    gb.render_meshes(d, top, None, None, [])
+    got = gb.download()
+    want = oracle.render_gbuffer_meshes(w, h, d, top, None, None, [])
+    compare(got, want, abi.GBUFFER_FLOAT4)
+    assert (want[..., 3] != 0).mean() > 0.9, "the ground plane covers the frame"
+    gb.close()

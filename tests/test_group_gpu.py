@@ -306,3 +306,78 @@ def test_a_group_members_padded_lightmap_resolves_into_a_frame_sized_back_buffer
     for s in sdfs:
         s.close()
     g.close()
+
+
+@pytest.mark.parametrize("members,fmt,balanced", [(2, abi.LIGHTMAP_FLOAT4, False), (3, abi.LIGHTMAP_HALF4, True), (5, abi.LIGHTMAP_HALF4, False),
+                                                   (8, abi.LIGHTMAP_RGBA8, True)])
+def test_store_mode_composites_the_frame_without_a_gather(ctx, members, fmt, balanced):
+    """ILM_GATHER_STORE (r05): the light kernel's final store writes each member's strip into EVERY member's copy of the frame (the other
+    members' buffers through the mirror table; on this one-GPU box the members share a device, on a node the buffers are peer-mapped
+    over xGMI), so no copy phase follows the strips.  Every member must end with the single-context frame bit for bit -- equal slots and
+    cost-balanced strips, all three lightmap formats, the composite call and the host-driven form (armed lightmap, per-member render
+    calls, gather(STORE) as the fence), a second light group accumulated on top, and particle lights through the member handles."""
+    from illuminant_amd import sharding
+    layout, atlas, dfu, lights, w, h = small_scene(abi.SDF_FP16, n_lights=24, width=176, height=160)
+    env = scenes.environment()
+    want, wstats = single_context_frame(ctx, lights, env, dfu, atlas, abi.SDF_FP16, w, h, fmt)
+    g = native.Group([0] * members)
+    sdfs = [native.DistanceFieldTexture(c, atlas, abi.SDF_FP16) for c in g.contexts]
+    glm = native.GroupLightmap(g, w, h, fmt)
+    if balanced:
+        glm.set_strips(sharding.balanced_row_strips(h, members, lights))
+    try:
+        # 1. the composite call arms the mode for its own duration
+        stats = g.render_sphere_lights(lights, env, dfu, None, sdfs, AMBIENT, glm, native.GATHER_STORE, want_stats=True)
+        g.sync()
+        assert (stats.SdfSamples, stats.PixelLightPairs, stats.TracedPairs) == (wstats.SdfSamples, wstats.PixelLightPairs, wstats.TracedPairs)
+        for i in range(members):
+            assert np.array_equal(glm.download(i).view(np.uint8), want.view(np.uint8)), "composite call: member %d's frame differs" % i
+        # ... and leaves it disarmed: the next plain strip stays on its member
+        for m in glm.members:
+            m.clear()
+        g.sync()
+        b, e = glm.strips[0]
+        native.render_sphere_lights(g.contexts[0], lights, env, dfu, None, sdfs[0], AMBIENT, glm.members[0], b, e)
+        g.sync()
+        if members > 1:
+            assert not glm.download(1)[b:e].any(), "a disarmed lightmap stored into another member"
+        with pytest.raises(native.IlluminantError):
+            glm.gather(native.GATHER_STORE)                      # not armed
+        # 2. host-driven: armed lightmap, every member renders its own strip, the fence is the gather; then a second light group on top
+        glm.store_mode(True)
+        few = (abi.LightVertex * 3)(*[lights[i] for i in (2, 9, 17)])
+        for group_lights, ambient in ((lights, AMBIENT), (few, None)):
+            glm.gather(native.GATHER_STORE)                      # (readers of the previous pass are done before anybody overwrites)
+            for i in range(members):
+                b, e = glm.strips[i]
+                native.render_sphere_lights(g.contexts[i], group_lights, env, dfu, None, sdfs[i], ambient, glm.members[i], b, e)
+            glm.gather(native.GATHER_STORE)
+        g.sync()
+        lm = native.Lightmap(ctx, w, h, fmt)
+        sdf0 = native.DistanceFieldTexture(ctx, atlas, abi.SDF_FP16)
+        native.render_sphere_lights(ctx, lights, env, dfu, None, sdf0, AMBIENT, lm)
+        native.render_sphere_lights(ctx, few, env, dfu, None, sdf0, None, lm)
+        want2 = lm.download()
+        lm.close(); sdf0.close()
+        assert not np.array_equal(want2, want)
+        for i in range(members):
+            assert np.array_equal(glm.download(i).view(np.uint8), want2.view(np.uint8)), "host-driven store mode: member %d's frame differs" % i
+        with pytest.raises(native.IlluminantError):
+            glm.gather(native.GATHER_PEER)                       # an armed lightmap has nothing to copy
+            g.render_sphere_lights(lights, env, dfu, None, sdfs, AMBIENT, glm, native.GATHER_PEER)
+        glm.store_mode(False)
+    finally:
+        glm.close()
+        for s in sdfs:
+            s.close()
+        g.close()
+
+
+def test_store_mode_is_refused_where_buffers_are_not_peer_mapped(ctx):
+    uid = native.Group.unique_id()
+    g = native.Group.rank(0, 0, 1, uid)
+    glm = native.GroupLightmap(g, 64, 48)
+    with pytest.raises(native.IlluminantError) as e:
+        glm.store_mode(True)
+    assert e.value.code == abi.ERR_STATE and "spans processes" in str(e.value)
+    glm.close(); g.close()

@@ -322,3 +322,70 @@ def test_light_split_keeps_every_bit(ctx, oracle, sfmt):
         sdf.close()
     with pytest.raises(native.IlluminantError):
         ctx.set_light_split(3)
+
+
+@pytest.mark.parametrize("sfmt", [abi.SDF_UNORM16, abi.SDF_FP16])
+def test_circle_cull_keeps_every_bit(ctx, oracle, sfmt):
+    """r05: waves whose shaded points lie outside a light's circle (radius + max(ramp, 1), y scaled by falloffY) skip the light, entries no
+    wave of a tile needs are not listed (lighting.hip, culled_waves).  The instrumented variant does not cull (its pair count is the raster
+    footprint's): the plain frame must equal it bit for bit -- small lights on a frame of many tiles, a G-buffer whose relativeY and z
+    move the shaded points off their pixels under a 2.5D footprint, falloffY != 1, the three falloff modes, ramps below 1 and not
+    positive, a light far outside the frame -- and the instrumented counts stay the oracle's.  Particle lights (the wide-binning
+    instantiation) the same way."""
+    from tests import lights_common as lc
+    layout, atlas, dfu, _, w, h = small_scene(sfmt, width=211, height=157)
+    sdf = native.DistanceFieldTexture(ctx, atlas, sfmt)
+    otex = oracle.make_texture(atlas, sfmt)
+    ambient = (0.05, 0.06, 0.07, 1.0)
+    L = []
+    xs, ys = scenes.uniform(61, (40,), -20, w + 20), scenes.uniform(62, (40,), -20, h + 20)
+    for i in range(40):
+        kw = dict(ramp_mode=i % 3, falloff_y=(1.0, 0.6, 2.5, -1.5)[i % 4], casts_shadows=(i % 5 != 0))
+        ramp = (22.0, 9.0, 0.4, 35.0, 0.0, -3.0, 14.0)[i % 7]
+        L.append(scenes.sphere_light((xs[i], ys[i], 4.0 + i), (3.0, 0.0, 7.5)[i % 3], ramp, color=(0.9, 0.5 + 0.01 * i, 0.3, 1.0), **kw))
+    L.append(scenes.sphere_light((-5000.0, 80.0, 10.0), 4.0, 30.0))
+    lights = (abi.LightVertex * len(L))(*L)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    nx = 0.3 * np.sin(xx / 9.0); ny = 0.3 * np.cos(yy / 7.0)
+    normal = np.stack([nx, ny, np.sqrt(np.maximum(1.0 - nx * nx - ny * ny, 0.0))], axis=-1)
+    z = 6.0 + 5.0 * np.sin(xx / 17.0) * np.cos(yy / 13.0)
+    g = scenes.encode_gbuffer(normal, 9.0 * np.sin(xx / 23.0), z)          # relativeY moves the shaded point up to 9 px off its pixel
+    gb = native.GBufferTexture(ctx, g, abi.GBUFFER_FLOAT4)
+    ogb = oracle.make_texture(g, abi.GBUFFER_FLOAT4)
+    try:
+        for env, gbuf, ogbuf in ((scenes.environment(), None, None), (scenes.environment(gbuffer_size=(w, h), z_to_y=0.4), gb, ogb)):
+            frames = []
+            for want_stats in (True, False):
+                lm = native.Lightmap(ctx, w, h, abi.LIGHTMAP_FLOAT4)
+                st = native.render_sphere_lights(ctx, lights, env, dfu, gbuf, sdf, ambient, lm, want_stats=want_stats)
+                frames.append(lm.download())
+                lm.close()
+                if want_stats:
+                    _, ost = oracle.render_sphere_lights(lights, env, dfu, ogbuf, otex, ambient, w, h, want_stats=True)
+                    assert (st.SdfSamples, st.PixelLightPairs, st.TracedPairs) == (ost.SdfSamples, ost.PixelLightPairs, ost.TracedPairs)
+            assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32)), "the culled frame differs from the instrumented one"
+            assert (frames[0][..., 3] > 1.5).mean() > 0.05 and (frames[0][..., 3] == 1.0).mean() > 0.2       # lit and unlit pixels both
+        # particle lights: 600 lights of reach 3 + 18 on the same frame
+        cs = 32
+        n = cs * cs
+        pos, vel, attr = scenes.make_particles(91, n, pos_lo=(0, 0, 2), pos_hi=(w, h, 30), dead_fraction=0.4)
+        rc = scenes.uniform(92, (n, 4), 0.2, 1.0).astype(np.float32)
+        rc[:, :3] *= rc[:, 3:4]
+        eng = native.Engine(ctx, cs, scenes.randomness_table(7))
+        sysm = native.System(eng)
+        sysm.add_chunk()
+        sysm.upload(0, abi.PLANE_POSITION, pos); sysm.upload(0, abi.PLANE_RENDER_COLOR, rc)
+        for fy in (1.0, 0.7):
+            params = lc.particle_light_params(3.0, 18.0, (1.0, 0.9, 0.8, 1.0), casts_shadows=True, falloff_y=fy)
+            frames = []
+            for want_stats in (True, False):
+                lm = native.Lightmap(ctx, w, h, abi.LIGHTMAP_FLOAT4)
+                native.render_sphere_lights(ctx, None, scenes.environment(), dfu, None, sdf, ambient, lm)
+                native.render_particle_lights(ctx, sysm, params, scenes.environment(), dfu, None, sdf, lm, want_stats=want_stats)
+                frames.append(lm.download())
+                lm.close()
+            assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32)), "particle lights: the culled frame differs (falloffY %g)" % fy
+            assert (frames[0][..., 3] > 2.5).any()
+        sysm.close(); eng.close()
+    finally:
+        gb.close(); sdf.close()
