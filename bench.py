@@ -119,14 +119,11 @@ def profiled_per_wave(kernel_prefix, column):
     return None
 
 
-def light_launch_waves(width, rows):
-    """Waves of a one-workgroup-per-tile launch of the light kernel over `rows` rows: whole groups of M x M 16-pixel tiles dealt to the 8
-    XCDs (lighting.hip tile_map 4; M = ILM_LIGHT_TILE_MACRO, default 6), four waves per tile -- what SQ_WAVES counts, exit-only
-    workgroups of partial groups included."""
-    m = max(1, int(os.environ.get("ILM_LIGHT_TILE_MACRO", "6")))
-    tiles_x, tiles_y = (width + 15) // 16, (rows + 15) // 16
-    groups = ((tiles_x + m - 1) // m) * ((tiles_y + m - 1) // m)
-    return ((groups + 7) // 8) * 8 * m * m * 4
+def light_launch_waves(native_ctx):
+    """Waves of the context's last light-pass launch, from the library itself (ilm_debug_last_light_launch: workgroups of four waves, exit-only
+    workgroups of partial tile groups and the members of split tiles included -- what SQ_WAVES counts).  r04 re-derived the grid here and
+    was wrong for strips (tile groups of 4 x 4, tapered split: ADVICE r04)."""
+    return native_ctx.last_light_launch()[0] * 4
 
 
 def parse_args():
@@ -945,7 +942,7 @@ def main():
             lv = profiled_per_wave(kname, "SQ_INSTS_VALU") if world == 1 else None
             # the LAUNCHED grid (the profile's per-wave average is over SQ_WAVES, exit-only workgroups of partial tile groups included):
             # groups of 6 x 6 tiles dealt to 8 XCDs, four waves per tile -- a whole frame is one workgroup per tile (lighting.hip)
-            waves_l = light_launch_waves(w, row_end - row_begin)
+            waves_l = light_launch_waves(native.Context(local_rank, borrowed_handle=ctx.Handle))
             issue = (waves_l * lv["value"] / (kern_ms * 1e-3) / 1e9) if lv else None
             loop_w = TRACE_LOOP_WEIGHTED["fp16" if fmt == abi.SDF_FP16 else "unorm16"]
             lighting[name] = {
@@ -1131,7 +1128,7 @@ def main():
             # vector-instruction issue of the wide-binning instantiation of the light kernel in the committed PMC profile of this bench
             plv = profiled_per_wave("ilm::sphere_lights_kernel<0, false, true>", "SQ_INSTS_VALU")
             # waves of the launch: whole groups of 6 x 6 tiles (lighting.hip tile_map 4), four waves per tile -- what SQ_WAVES counted
-            pl_waves = light_launch_waves(1920, 1080)
+            pl_waves = light_launch_waves(native.Context(local_rank, borrowed_handle=ctx.Handle))
             pl_issue = (pl_waves * plv["value"] / (pl_ms * 1e-3) / 1e9) if plv else None
             next_rows["particle_lights_1080p_4096"] = {
                 "ms_per_frame": round(pl_ms, 4), "lit_mpixels_per_s": round(1920 * 1080 / (pl_ms * 1e-3) / 1e6, 1), "lights": 4096,

@@ -91,6 +91,7 @@ struct Ctx {
     IlmLightVertex* d_lights = nullptr; void* d_recs = nullptr; int light_cap = 0;
     unsigned long long* d_stats = nullptr;
     // light split (plan_light_split): the tiles' per-part sums and their tickets
+    int last_light_blocks = 0, last_light_split = 1, last_light_macro = 0;       // the last tile-kernel launch (ilm_debug_last_light_launch)
     float4* d_light_partials = nullptr; size_t light_partials_tiles = 0; uint32_t* d_light_tickets = nullptr; size_t light_tickets_cap = 0;
     int light_split = 0;                  // ilm_ctx_set_light_split: 0 = chosen per launch, else 1 / 2 / 4 / 8
     uint16_t* d_group_order = nullptr; int group_order_cap = 0; uint64_t group_order_key = 0; int group_order_groups = 0;
@@ -1781,6 +1782,15 @@ int32_t ilm_debug_divide_by_constants(IlmHandle hctx, float* out_divisors, uint6
 
 int32_t ilm_debug_step_interpreter(int32_t interpreter) { return (int32_t)set_step_interpreter(interpreter); }
 int32_t ilm_debug_step_streams(int32_t streams) { return (int32_t)set_step_streams(streams); }
+int32_t ilm_debug_last_light_launch(IlmHandle hctx, int32_t* out_workgroups, int32_t* out_split, int32_t* out_tile_macro) {
+    Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);
+    if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
+    if (out_workgroups) *out_workgroups = c->last_light_blocks;
+    if (out_split) *out_split = c->last_light_split;
+    if (out_tile_macro) *out_tile_macro = c->last_light_macro;
+    return ILM_OK;
+}
+
 int32_t ilm_debug_step_sdf_samples(IlmHandle hctx, int32_t enable, uint64_t* out_samples) {
     Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);
     if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
@@ -2647,6 +2657,7 @@ int32_t ilm_render_particle_lights(IlmHandle hctx, IlmHandle hsystem, const int3
         HIP_TRY(hipMemsetAsync(c->d_stats, 0, 3 * sizeof(unsigned long long), c->main()));
         a.stats = c->d_stats;
     }
+    c->last_light_blocks = light_launch_blocks(a); c->last_light_split = a.split; c->last_light_macro = (a.tile_map == 4) ? a.tile_macro : 0;
     HIP_TRY(launch_sphere_lights_prepared(a, c->d_pl_recs, c->main()));
     if (stats) {
         unsigned long long host[3] = { 0, 0, 0 };
@@ -3109,6 +3120,7 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
     a.mirrors = m->d_mirrors; a.mirror_count = m->d_mirrors ? m->mirror_count : 0;      // store-mode exchange of a group lightmap
     { const int32_t rc = plan_light_split(c, &a); if (rc != ILM_OK) return rc; }
     { const int32_t rc = plan_group_order(c, &a, lights, light_count, 16 * a.tile_macro); if (rc != ILM_OK) return rc; }
+    c->last_light_blocks = light_launch_blocks(a); c->last_light_split = a.split; c->last_light_macro = (a.tile_map == 4) ? a.tile_macro : 0;
     HIP_TRY(launch_sphere_lights_prepared(a, c->d_recs, c->main()));
     if (stats) {
         unsigned long long host[3] = { 0, 0, 0 };

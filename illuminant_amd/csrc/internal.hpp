@@ -221,6 +221,7 @@ TraceGate make_trace_gate(const IlmDistanceFieldUniforms& df, const SdfView& sdf
 hipError_t launch_prepare_lights(const IlmLightVertex* lights, int count, const IlmEnvironment& env, const IlmDistanceFieldUniforms& df,
                                  const SdfView& sdf, void* recs, hipStream_t stream);
 hipError_t launch_sphere_lights_prepared(const LightLaunch& a, const void* recs, hipStream_t stream);
+int light_launch_blocks(const LightLaunch& a);    // workgroups of the tile kernel's launch for a (split / taper included)
 int light_block_slots(const LightLaunch& a);      // block slots per XCD of the tile kernel's launch over a's rows
 
 // Particle lights (ParticleLight.fx): ordered device-side compaction of the live, visible particles of every chunk into light

@@ -1253,6 +1253,14 @@ int light_block_slots(const LightLaunch& a) {
     return blocks / 8;
 }
 
+// workgroups the tile kernel is launched with for `a` (split and taper as planned; what SQ_WAVES / 4 of the launch counts)
+int light_launch_blocks(const LightLaunch& a) {
+    const int slots = light_block_slots(a);
+    if (slots <= 0) return 0;
+    if (a.split <= 1) return slots * 8;
+    return (a.taper[0] + 2 * (a.taper[1] - a.taper[0]) + 4 * (a.taper[2] - a.taper[1]) + 8 * (slots - a.taper[2])) * 8;
+}
+
 hipError_t launch_sphere_lights_prepared(const LightLaunch& launch, const void* recs, hipStream_t stream) {
     const int rows = launch.row_end - launch.row_begin;
     if (rows <= 0 || launch.width <= 0) return hipSuccess;

@@ -77,6 +77,7 @@ SYMBOLS = {
     "ilm_debug_step_interpreter": (_I, [_I]),
     "ilm_debug_step_streams": (_I, [_I]),
     "ilm_debug_step_sdf_samples": (_I, [_H, _I, C.POINTER(C.c_uint64)]),
+    "ilm_debug_last_light_launch": (_I, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ilm_debug_divide_by_constants": (_I, [_H, _P, _P, _I, C.POINTER(_I)]),
     "ilm_sdf_destroy": (_I, [_H]),
     "ilm_sdf_download": (_I, [_H, _P]),
@@ -209,6 +210,12 @@ class Context:
     def set_light_split(self, workgroups):
         """ilm_ctx_set_light_split: workgroups per tile of the sphere-light launches (0 = chosen per launch, 1 / 2 / 4 / 8)."""
         check(lib().ilm_ctx_set_light_split(self.handle, int(workgroups)))
+
+    def last_light_launch(self):
+        """ilm_debug_last_light_launch: (workgroups, largest split, tile-group edge) of the context's last light-pass launch."""
+        wg, sp, mc = C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib().ilm_debug_last_light_launch(self.handle, C.byref(wg), C.byref(sp), C.byref(mc)))
+        return int(wg.value), int(sp.value), int(mc.value)
 
     def debug_divide(self, numerators, denominators):
         """ilm_debug_divide: (the cone trace's unscaled division, the IEEE division) of the operand pairs, both evaluated on the device."""

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-/* 8 (r05): + ilm_group_lightmap_store_mode, ILM_GATHER_STORE.
+/* 8 (r05): + ilm_group_lightmap_store_mode, ILM_GATHER_STORE, ilm_debug_last_light_launch.
  * 7 (r04): + ilm_ctx_set_light_split, ilm_sdf_mark_dirty, ilm_sdf_trace_info / IlmSdfTraceInfo; ilm_group_lightmap_set_strips became a
  * collective with one process per GPU.  Nothing was removed or changed in layout since 6. */
 #define ILM_ABI_VERSION 8
@@ -500,6 +500,11 @@ int32_t ilm_debug_step_streams(int32_t streams);
  * the count accumulated since the previous call in *out_samples (may be NULL) and clears it.  Synchronises the context.  The count
  * costs one atomic per particle while it is on: for measurement runs only. */
 int32_t ilm_debug_step_sdf_samples(IlmHandle ctx, int32_t enable, uint64_t* out_samples);
+/* The grid of the context's last light-pass launch (sphere or particle lights): workgroups of 256 threads (four waves each; exit-only
+ * workgroups of partial tile groups included -- what a profiler's wave count sees), the largest number of workgroups per tile (light
+ * split; 1 = none) and the edge of the tile groups dealt to the XCDs (0: another block -> tile map).  Measurement scripts price per-wave
+ * counters with it instead of re-deriving the launch (r05). */
+int32_t ilm_debug_last_light_launch(IlmHandle ctx, int32_t* out_workgroups, int32_t* out_split, int32_t* out_tile_macro);
 int32_t ilm_sdf_destroy(IlmHandle sdf);
 /* DistanceField.Save (Illuminant/SDF/DistanceField.cs:178-194): the atlas bytes, 8 per texel, row-major. */
 int32_t ilm_sdf_download(IlmHandle sdf, uint16_t* texels);

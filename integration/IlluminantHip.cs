@@ -513,6 +513,7 @@ namespace Squared.Illuminant.Native {
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_debug_step_interpreter (int interpreter);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_debug_step_streams (int streams);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_debug_step_sdf_samples (ulong ctx, int enable, ulong* outSamples);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_debug_last_light_launch (ulong ctx, int* outWorkgroups, int* outSplit, int* outTileMacro);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_sdf_destroy (ulong sdf);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_sdf_download (ulong sdf, ushort* texels);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_sdf_device_ptr (ulong sdf, void** outPtr);

@@ -29,3 +29,19 @@ def ctx():
     c = native.Context(0)
     yield c
     c.close()
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """What the float criterion was asked to forgive in this session (tests/util.py CENSUS): printed, and written where ILM_TOLERANCE_CENSUS
+    names a file (the GPU box: gpurun_out/..., copied to profiles/ and committed)."""
+    from tests import util
+    if not util.CENSUS:
+        return
+    report = util.census_report()
+    path = os.environ.get("ILM_TOLERANCE_CENSUS")
+    if path:
+        with open(path, "w") as f:
+            f.write(report + "\n")
+    terminalreporter.write_line("")
+    for line in report.splitlines()[-1:]:
+        terminalreporter.write_line(line)

@@ -1,8 +1,55 @@
 """Shared helpers of the parity tests."""
 import numpy as np
 
+import re
+
 RTOL = 1e-4   # north_star: 1e-4 relative float tolerance
 ATOL = 1e-5   # absolute floor, as a fraction of the SAME component's scale (see assert_close)
+
+# Census of what the criterion was asked to forgive (VERDICT r04 #5b): per kind of comparison (the `what` label with its numbers
+# blanked) and per component, how many elements were compared, how many of them are outside a PURE 1e-4 relative bound -- i.e. needed
+# the absolute floor -- and the smallest floor (as a fraction of the component's scale) that would still have passed.  Written at the
+# end of a session by tests/conftest.py (profiles/r05_tolerance_census.txt is one such run on the GPU box).
+CENSUS = {}
+
+
+def _census_add(what, err, want, scale, rtol, both_nan):
+    # (numbers blanked -- seeds, chunk indices, sizes -- except the plane index, which is what the census is by)
+    key = re.sub(r"\d+(\.\d+)?", "#", re.sub(r"plane (\d)", lambda m: "plane " + "abcdefghij"[int(m.group(1))], what)).strip() or "(unlabelled)"
+    key = re.sub(r"plane ([a-j])\b", lambda m: "plane %d" % "abcdefghij".index(m.group(1)), key)
+    scale = np.broadcast_to(np.asarray(scale, np.float64), want.shape[-1:] if (want.ndim >= 2 and want.shape[-1] <= 4) else ())
+    comps = want.shape[-1] if (want.ndim >= 2 and want.shape[-1] <= 4) else 1
+    e2 = err.reshape(-1, comps)
+    w2 = np.abs(want).reshape(-1, comps)
+    ok2 = ~both_nan.reshape(-1, comps) & np.isfinite(e2)
+    row = CENSUS.setdefault(key, {"calls": 0, "components": comps, "elements": np.zeros(comps, np.int64), "needed_floor": np.zeros(comps, np.int64),
+                                  "least_floor": np.zeros(comps, np.float64), "worst_pure_relative": np.zeros(comps, np.float64)})
+    if row["components"] != comps:
+        return
+    row["calls"] += 1
+    over = np.where(ok2, e2 - rtol * w2, 0.0)                       # what the relative term leaves uncovered
+    sc = np.maximum(np.asarray(scale, np.float64).reshape(-1) if comps > 1 else np.full(1, float(np.max(scale)) if np.size(scale) else 0.0), 1e-300)
+    row["elements"] += ok2.sum(axis=0)
+    row["needed_floor"] += (over > 0).sum(axis=0)
+    row["least_floor"] = np.maximum(row["least_floor"], (np.maximum(over, 0.0) / sc).max(axis=0) if e2.size else 0.0)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        rel = np.where(ok2 & (w2 > 0), e2 / w2, 0.0)
+    row["worst_pure_relative"] = np.maximum(row["worst_pure_relative"], rel.max(axis=0) if e2.size else 0.0)
+
+
+def census_report():
+    lines = ["# tolerance census: criterion |got - want| <= %g |want| + atol x (largest |want| of the same component); atol = %g unless a test passes its own" % (RTOL, ATOL),
+             "# per kind of comparison and component: elements compared | outside a PURE %g relative bound (needed the floor) | smallest floor that passes (fraction of the component's scale) | worst pure relative error" % RTOL]
+    tot_e = tot_f = 0
+    for key in sorted(CENSUS):
+        r = CENSUS[key]
+        lines.append("%s   (%d call(s))" % (key, r["calls"]))
+        for c in range(r["components"]):
+            lines.append("    component %d: %12d | %10d (%.2e) | %.3e | %.3e" % (c, r["elements"][c], r["needed_floor"][c], r["needed_floor"][c] / max(r["elements"][c], 1),
+                                                                              r["least_floor"][c], r["worst_pure_relative"][c]))
+            tot_e += int(r["elements"][c]); tot_f += int(r["needed_floor"][c])
+    lines.append("# total: %d elements, %d needed the floor (%.2e)" % (tot_e, tot_f, tot_f / max(tot_e, 1)))
+    return "\n".join(lines)
 
 
 def assert_bits_equal(got, want, what=""):
@@ -39,6 +86,10 @@ def assert_close(got, want, what="", rtol=RTOL, atol=ATOL, scale=None, life_exac
             scale = float(finite.max()) if finite.size else 0.0
     both_nan = np.isnan(got) & np.isnan(want)
     err = np.abs(got - want)
+    try:
+        _census_add(what, err, want, scale, rtol, both_nan)
+    except Exception:        # (the census must never fail a test)
+        pass
     tol = atol * np.asarray(scale, np.float64) + rtol * np.abs(want)
     bad = ~(err <= tol) & ~both_nan
     if bad.any():
