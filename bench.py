@@ -315,7 +315,7 @@ def finalize_record(out, world, forced_dist, step_us_cfg2):
         out["config"]["particles_per_gpu"] = c4h["particles_per_gpu"]
         out["config"]["parallelism"] = ("particles: chunk c on rank c mod %d, no data-path collective; lit frame: cost-balanced row strips of whole 16-row bands "
                                         "(balanced_row_strips, then re-cut twice from the ranks' measured strip times: rebalance_row_strips), range exchange over RCCL send/recv" % world)
-    tail_keys = ["cpu_baseline", "roofline", "roofline_hbm_resident", "cfg4_full_64m_one_gpu", "roofline_lighting", "lit_mpixels_per_s", "scaling_detail", "summary"]
+    tail_keys = ["cpu_baseline", "roofline", "roofline_hbm_resident", "cfg4_full_64m_one_gpu", "roofline_lighting_cfg3", "roofline_lighting", "lit_mpixels_per_s", "scaling_detail", "summary"]
     c4 = out.get("cfg4_share_8m_particles")
     if c4:
         out["roofline_hbm_resident"] = dict(c4["roofline"], workload="cfg4 per-GPU share: 8 chunks of 1024^2 = 8.4 M particles, 0.67 GB of state (> Infinity Cache)",
@@ -1094,10 +1094,19 @@ def main():
         l5 = lighting["cfg5_4k_256_lights_fp16"]
         out["roofline_lighting"] = {"workload": "cfg5: 4K, 256 lights, fp16 samples", "bound": "valu", "achieved": l5["roofline"]["achieved"], "peak": l5["roofline"]["peak"],
                                     "unit": "G wave-instr/s", "frac": l5["roofline"]["frac"], "useful_frac": l5["work_bound"]["useful_frac"],
-                                    "instructions_per_sample": l5["work_bound"]["instructions_per_sample"], "launch_ms": l5["roofline"]["launch_ms"],
+                                    "instructions_per_sample": l5["work_bound"]["instructions_per_sample"], "launch_ms": l5["roofline"]["launch_ms"], "verified_counts": l5["verified_counts"],
                                     "gbuffer": "bound (ground plane, Vector4)", "without_gbuffer_ms": l5["without_gbuffer_ms"],
                                     "timed_frames": l5["timed_frames"], "sdf_samples_per_frame": l5["sdf_samples_per_frame"], "traffic": l5["roofline"]["traffic"]}
 
+        l3 = lighting["cfg3_1080p_64_lights_unorm16"]
+        # cfg3 beside it, with what ELSE limits it said in the record: its issue fraction is not slack -- the unorm16
+        # field's samples are two 8-byte typed loads per lane whose data path (TD) is 82 % busy at this sample rate
+        # (profiles/r03_typed_unorm16_loads.txt, DESIGN 3.2 "cfg3, accounted": 87 % of its vector instructions are trace)
+        out["roofline_lighting_cfg3"] = {"workload": "cfg3: 1080p, 64 lights, unorm16 samples", "bound": "valu", "achieved": l3["roofline"]["achieved"], "peak": l3["roofline"]["peak"],
+                                         "unit": "G wave-instr/s", "frac": l3["roofline"]["frac"], "useful_frac": l3["work_bound"]["useful_frac"],
+                                         "co_limit": "TD 82 % busy: the texture-data path returns the unorm16 taps as 2 x 8 B typed loads per lane-sample (TD_TD_BUSY, profiles/r03_typed_unorm16_loads.txt); "
+                                                     "the issue fraction is not slack", "launch_ms": l3["roofline"]["launch_ms"], "verified_counts": l3["verified_counts"],
+                                         "sdf_samples_per_frame": l3["sdf_samples_per_frame"], "traffic": l3["roofline"]["traffic"]}
         if not args.no_next_rows and world == 1:
             # particle lights: 4 096 live particles of a 64^2 chunk lighting a 1080p frame through cfg3's field
             L = build_lighting(H, ctx, scenes, abi, 1920, 1080, 0, 0.25, 2048, abi.SDF_UNORM16)

@@ -26,7 +26,7 @@ import pytest
 from illuminant_amd import abi
 from tests import _variant_worker as vw
 from tests import fuzz_scenes
-from tests.util import ATOL, RTOL, assert_bits_equal, assert_close
+from tests.util import ATOL, ATOL_TIGHT, RTOL, assert_bits_equal, assert_close
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -37,11 +37,12 @@ CASES = [(1222260, 4913, (154.30, 147.45, 0.85), 280.08, 150.59),
          (1223153, 2180, (120.94, 116.24, 12.75), 188.54, -12.33)]
 
 
-def outside_criterion(got, want):
-    """element mask of the suite's criterion (tests/util.py assert_close), per-component scale"""
+def outside_criterion(got, want, plane):
+    """element mask of the suite's criterion (tests/util.py assert_close), per-component scale; the floor is the velocity plane's or the tight one"""
     g, w = np.asarray(got, np.float64), np.asarray(want, np.float64)
     scale = np.where(np.isfinite(w), np.abs(w), 0.0).max(axis=0)
-    return ~(np.abs(g - w) <= ATOL * scale[None, :] + RTOL * np.abs(w)) & ~(np.isnan(g) & np.isnan(w))
+    atol = ATOL if plane == 1 else ATOL_TIGHT
+    return ~(np.abs(g - w) <= atol * scale[None, :] + RTOL * np.abs(w)) & ~(np.isnan(g) & np.isnan(w))
 
 
 @pytest.mark.parametrize("seed,slot,apos,aradius,astrength", CASES)
@@ -71,7 +72,7 @@ def test_fuzz_miss_is_an_ulp_of_the_spawn_formula_in_front_of_the_references_own
     outside = set()
     for c in range(2):
         for k in range(5):
-            for (i, j) in np.argwhere(outside_criterion(got[c][k], want[c][k])):
+            for (i, j) in np.argwhere(outside_criterion(got[c][k], want[c][k], k)):
                 outside.add((c, k, int(i), int(j)))
     assert outside <= {(1, 1, slot, 2)}, outside
 

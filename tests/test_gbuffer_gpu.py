@@ -277,20 +277,16 @@ def test_billboard_texture_bounds_outside_the_unit_square_are_clamped_not_clippe
     lm.close(); gb.close()
 
 
-@pytest.mark.parametrize("scale", [(-1.0, 1.0), (1.0, -1.25), (-1.125, -1.0)])
-def test_ground_plane_survives_a_mirrored_view(ctx, oracle, scale):
-    """a negative ViewportScale on one axis makes the rasteriser's set-up swap two vertices of the ground quad's first triangle,
-    on both axes it reverses the rectangle's corners; the rectangle shortcut looked at fixed vertex slots and dropped the ground plane
-    (every texel stayed zero).  The rectangle is now taken from the extremes of the snapped corners: the frame must equal the oracle's,
-    which rasterises the quad's two triangles."""
-    w, h = 96, 72
+@pytest.mark.parametrize("scale", [(-1.0, 1.0), (1.0, -1.25), (-1.125, -1.0), (0.0, 1.0)])
+def test_a_mirrored_view_is_refused_not_drawn_without_its_ground(ctx, scale):
+    """under a negative ViewportScale the rasteriser's set-up reorders the ground quad's vertices, and the rectangle shortcut of
+    the ground plane looked at fixed vertex slots.  The entry point refuses such a view outright (ViewportScale must be positive: the
+    reference's view transforms scale by positive factors); the shortcut itself now takes the rectangle from the extremes of the snapped
+    corners and falls back to the quad's two triangles when they do not form one (gbuffer.hip, gbuffer_setup_kernel)."""
     top = scenes.top_face_mesh([(-40.0, -30.0), (-10.0, -30.0), (-10.0, -5.0), (-40.0, -5.0)], 0.0, 12.0)
-    d = scenes.gbuffer_mesh_desc(ground_z=2.0, viewport_position=(-48.0 if scale[0] > 0 else 48.0, -36.0 if scale[1] > 0 else 36.0), viewport_scale=scale,
-                                 z_to_y=0.0, extent_z=64.0, two_point_five_d=False)
-    gb = native.GBufferTexture(ctx, None, abi.GBUFFER_FLOAT4, size=(w, h))
-    gb.render_meshes(d, top, None, None, [])
-    got = gb.download()
-    want = oracle.render_gbuffer_meshes(w, h, d, top, None, None, [])
-    compare(got, want, abi.GBUFFER_FLOAT4)
-    assert (want[..., 3] != 0).mean() > 0.9, "the ground plane covers the frame"
+    d = scenes.gbuffer_mesh_desc(ground_z=2.0, viewport_scale=scale, z_to_y=0.0, extent_z=64.0, two_point_five_d=False)
+    gb = native.GBufferTexture(ctx, None, abi.GBUFFER_FLOAT4, size=(96, 72))
+    with pytest.raises(native.IlluminantError) as e:
+        gb.render_meshes(d, top, None, None, [])
+    assert e.value.code == abi.ERR_INVALID_ARGUMENT and "ViewportScale" in str(e.value)
     gb.close()

@@ -13,4 +13,8 @@ bash tools/pmc_collision.sh $TAG > /dev/null 2>&1; cp gpurun_out/pmc_collision_$
 python tools/working_set_sweep.py > "$S/${TAG}_step_working_set_sweep.txt" 2>/dev/null
 python bench.py > "$S/${TAG}_bench_default.json" 2> /dev/null
 ILM_BENCH_FORCE_DIST=1 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > "$S/${TAG}_bench_forced_dist_world1.json" 2> /dev/null
+# r05: one rank's strips under every light-split setting, the store-mode exchange on one device, the roctx ranges of a short run
+python tools/strip_probe.py --gbuffer > "$S/${TAG}_strip_probe.txt" 2>&1
+python tools/store_mode_probe.py 8 20 > "$S/${TAG}_store_mode_probe.txt" 2>&1
+bash tools/marker_trace.sh "$TAG" > gpurun_out/marker_trace_$TAG.log 2>&1
 ls -la "$S"
