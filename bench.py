@@ -335,6 +335,7 @@ def finalize_record(out, world, forced_dist, step_us_cfg2):
         if row:
             summary[short] = {"ms_per_frame": row["roofline"]["launch_ms"], "timed_frames": row["timed_frames"], "lit_mpixels_per_s": row["lit_mpixels_per_s"],
                               "gbuffer": "bound", "without_gbuffer_ms": row["without_gbuffer_ms"], "verified_counts": row.get("verified_counts"),
+                              "two_frames_in_flight_ms": (row.get("two_frames_in_flight") or {}).get("ms_per_frame"),
                               "valu_issue_frac": row["roofline"]["frac"], "useful_frac": row["work_bound"]["useful_frac"],
                               "gsamples_per_s": row["algorithmic_rate"]["gsamples_per_s"]}
     out["summary"] = summary
@@ -935,6 +936,41 @@ def main():
                 for _ in range(n_plain):
                     rp.RenderLighting(1.0, row_begin, row_end, False)
                 without_gbuffer_ms = ctx.TimerStop() / n_plain
+            # Two frames in flight (r05).  The reference keeps a ring of lightmaps because frame N + 1 is built while frame N renders
+            # (BufferRing, LightingRenderer.cs:472-485).  A launch on one stream starts when the previous one has drained; rendering alternate
+            # frames on a SIBLING context (ilm_ctx_create_sibling: own stream and lightmap, the SAME field, read through the library's
+            # cross-context ordering) lets the next frame's first waves fill the slots the previous frame's drain leaves empty.  Same frames,
+            # same bits (tests/test_frames_in_flight_gpu.py); N frames between two barriers, wall clock.  Reported BESIDE ms_per_frame, which
+            # stays the one-stream figure.
+            two_in_flight = None
+            if group is None:
+                sib = abi.Handle(0)
+                native.check(native.lib().ilm_ctx_create_sibling(abi.Handle(int(ctx.Handle)), C_.byref(sib)))
+                ctx2 = H.DeviceContext.FromHandle(sib.value)
+                rc2 = H.RendererConfiguration(w, h)
+                rc2.DefaultQuality = r.Configuration.DefaultQuality
+                rc2.MaximumFieldUpdatesPerFrame = 9999
+                rc2.EnableGBuffer = True
+                r2 = H.LightingRenderer(ctx2, rc2, L["env"], 0)
+                r2.DistanceField = L["field"]                       # owned by the first context, read by both
+                r2.UpdateFields()                                   # (its own ground-plane G-buffer; the field is valid already)
+                for _ in range(2):
+                    r2.RenderLighting(1.0, row_begin, row_end, False)
+                ctx2.Sync(); barrier()
+                t0 = time.perf_counter()
+                for i_ in range(light_frames):
+                    (r2 if (i_ & 1) else r).RenderLighting(1.0, row_begin, row_end, False)
+                ctx.Sync(); ctx2.Sync()
+                two_ms = (time.perf_counter() - t0) / light_frames * 1e3
+                same_bits = bool(np.array_equal(np.asarray(r.ReadLightmap(row_begin, row_end - row_begin)), np.asarray(r2.ReadLightmap(row_begin, row_end - row_begin))))
+                two_in_flight = {"ms_per_frame": round(two_ms, 4), "lit_mpixels_per_s": round(w * h / (two_ms * 1e-3) / 1e6, 2), "timed_frames": light_frames,
+                                 "vs_one_stream": round(two_ms / frame_ms, 4), "frames_bit_equal": same_bits,
+                                 "how": "alternate frames on two sibling contexts (ilm_ctx_create_sibling): own streams and lightmaps, one field; wall clock over the block"}
+                del r2
+                import gc as gc_
+                gc_.collect()
+                if native.lib().ilm_ctx_destroy(sib) != 0:
+                    print("bench.py: the sibling context still has live objects: %s" % native.lib().ilm_last_error().decode(), file=sys.stderr)
             kname = "ilm::sphere_lights_kernel<%d, false, false>" % (1 if fmt == abi.SDF_FP16 else 0)
             lt = profiled_traffic(kname) if world == 1 else None
             # the kernel's binding resource is VALU issue, not HBM (the atlas is cache-resident): wave-instructions of the committed PMC
@@ -952,7 +988,7 @@ def main():
                 "sdf_samples_per_frame": samples_total, "verified_counts": verified_counts,
                 "verified_counts_is": ("the instrumented launch of THIS run: (SDF samples, pixel.light pairs, traced pairs) = the CPU oracle's totals over the same frame, "
                                        "tests/golden/full_frame_bands.json[%s] = (%d, %d, %d)" % (pin, pinned[pin]["sdf_samples"], pinned[pin]["pairs"], pinned[pin]["traced"])) if verified_counts else None,
-                "scaling": frame_scaling,
+                "scaling": frame_scaling, "two_frames_in_flight": two_in_flight,
                 "pixel_light_pairs_this_rank": pairs_local, "traced_pairs_this_rank": traced_local,
                 "field_generation": L["field_generation"],
                 "gbuffer": "ground plane rendered by UpdateFields, Vector4 (16 B per pixel), bound: every pixel decodes its texel (LightCommon.fxh:69-144)",

@@ -62,6 +62,10 @@ enum : uint32_t {
 struct Ctx {
     uint32_t magic = kMagicCtx;
     int device = 0;
+    // Sibling contexts (ilm_ctx_create_sibling, r05): contexts of one device that keep several frames in flight -- own stream, own scratch,
+    // own lightmaps -- and may READ each other's distance fields and G-buffers in the light passes (Shared below orders those reads
+    // against the owner's writes).  `family` = the address the first of them had; 0 = no siblings.
+    uintptr_t family = 0;
     int children = 0;            // live engines / distance fields / G-buffers / lightmaps: the context cannot be destroyed under them
     // Two streams.  Everything is ordered on `stream_`; ilm_system_step may put the second half of a large step's chunk range on `aux`
     // (chunks never interact, ParticleSystem.cs:743-745: one half's launch tail is covered by the other half's launch, run_step).
@@ -124,9 +128,63 @@ struct Engine {
     uint2* rnd_lp = nullptr;   // LowPrecisionRandomnessTexture: the Rgba64 copy (ParticleEngine.cs:508-540)
 };
 
+// A distance field or G-buffer that sibling contexts read (light passes on another context's stream).  Every WRITE to it happens on its
+// owner's stream (uploads, generation, the field's cell rebuild); a foreign read is ordered behind them by an event recorded on the
+// owner's stream when the read is queued, and the owner's later writes wait for the foreign reads' events.  Nothing here costs an
+// object that only its owner uses a call.
+struct Shared {
+    hipEvent_t owner_ev = nullptr;                                   // "everything the owner has queued so far"
+    std::vector<std::pair<Ctx*, hipEvent_t>> readers;                // per foreign context: its last queued read
+    std::vector<bool> pending;
+    void release() {
+        if (owner_ev) (void)hipEventDestroy(owner_ev);
+        for (auto& r : readers) (void)hipEventDestroy(r.second);
+        owner_ev = nullptr; readers.clear(); pending.clear();
+    }
+};
+// the owner is about to write: its stream waits for the sibling contexts' queued reads
+inline hipError_t shared_before_write(Shared& sh, Ctx* owner) {
+#ifdef ILM_EXP_NO_SHARED_ORDER      // EXPERIMENT (negative control of tests/test_frames_in_flight_gpu.py: without the ordering the test must fail)
+    return hipSuccess;
+#endif
+    for (size_t i = 0; i < sh.readers.size(); i++)
+        if (sh.pending[i]) {
+            const hipError_t e = hipStreamWaitEvent(owner->main(), sh.readers[i].second, 0);
+            if (e != hipSuccess) return e;
+            sh.pending[i] = false;
+        }
+    return hipSuccess;
+}
+// `reader` (a sibling of the owner) is about to queue a read on its own stream: behind whatever the owner has queued
+inline hipError_t shared_before_read(Shared& sh, Ctx* owner, Ctx* reader) {
+#ifdef ILM_EXP_NO_SHARED_ORDER
+    return hipSuccess;
+#endif
+    if (!sh.owner_ev) { const hipError_t e = hipEventCreateWithFlags(&sh.owner_ev, hipEventDisableTiming); if (e != hipSuccess) return e; }
+    hipError_t e = hipEventRecord(sh.owner_ev, owner->main());
+    if (e != hipSuccess) return e;
+    return hipStreamWaitEvent(reader->main(), sh.owner_ev, 0);
+}
+// ... and has queued it
+inline hipError_t shared_after_read(Shared& sh, Ctx* reader) {
+    size_t i = 0;
+    while (i < sh.readers.size() && sh.readers[i].first != reader) i++;
+    if (i == sh.readers.size()) {
+        hipEvent_t ev = nullptr;
+        const hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+        sh.readers.emplace_back(reader, ev); sh.pending.push_back(false);
+    }
+    const hipError_t e = hipEventRecord(sh.readers[i].second, reader->main());
+    if (e == hipSuccess) sh.pending[i] = true;
+    return e;
+}
+inline bool siblings(const Ctx* a, const Ctx* b) { return a == b || (a->family != 0 && a->family == b->family && a->device == b->device); }
+
 struct Sdf {
     uint32_t magic = kMagicSdf;
     Ctx* ctx = nullptr;
+    Shared shared;
     uint2* texels = nullptr; int width = 0, height = 0, format = 0;
     // The cone trace's view of the field (hlsl_math.hpp, SdfView::cells): built from the atlas on demand by ensure_sdf_cells and kept
     // until the atlas changes (`version` is bumped by every entry point that writes it) or is described by other uniforms (the layout
@@ -158,6 +216,7 @@ struct Sdf {
 struct GBuffer {
     uint32_t magic = kMagicGBuffer;
     Ctx* ctx = nullptr;
+    Shared shared;
     void* texels = nullptr; int width = 0, height = 0, format = 0;
 };
 
@@ -301,8 +360,15 @@ hipError_t make_trace_view(Sdf* f, const IlmDistanceFieldUniforms* df, hipStream
     const bool same_layout = f->cells && f->cells_slices == v.table_slices && f->cells_columns == v.columns && f->cells_sw == v.slice_w && f->cells_sh == v.slice_h;
     f->last_rebuilt_slices = 0; f->last_table_slices = v.table_slices;
     if (!same_layout || f->escaped || f->cells_version != f->version) {
+        // (the rebuild WRITES the cells: on the owner's stream -- `stream` is the owner's whoever asks, see borrowed_trace_view -- and
+        // behind the sibling contexts' queued reads)
+        { const hipError_t e = shared_before_write(f->shared, f->ctx); if (e != hipSuccess) return e; }
         if (bytes > f->cells_bytes) {
-            if (f->cells) { (void)hipStreamSynchronize(stream); (void)hipFree(f->cells); f->cells = nullptr; f->cells_bytes = 0; }
+            if (f->cells) {
+                (void)hipStreamSynchronize(stream);
+                for (auto& r : f->shared.readers) (void)hipEventSynchronize(r.second);       // sibling contexts still tracing through the old array
+                (void)hipFree(f->cells); f->cells = nullptr; f->cells_bytes = 0;
+            }
             if (hipMalloc(&f->cells, bytes) != hipSuccess) {
                 (void)hipGetLastError(); f->cells = nullptr; f->last_table_slices = 0;
                 static std::atomic<bool> said{false};
@@ -331,6 +397,22 @@ hipError_t make_trace_view(Sdf* f, const IlmDistanceFieldUniforms* df, hipStream
     }
     out->cells = f->cells;
     out->cells_bytes = (uint32_t)bytes;
+    return hipSuccess;
+}
+
+// The field (and G-buffer) of a light pass of context `c`: its own, or a sibling context's (ilm_ctx_create_sibling).  A borrowed field's
+// cells are (re)built on ITS OWNER's stream, then c's stream is ordered behind everything the owner has queued; after the pass has been
+// queued, light_pass_queued() leaves the marks the owner's next write waits for.
+hipError_t borrowed_trace_view(Ctx* c, Sdf* f, GBuffer* g, const IlmDistanceFieldUniforms* df, TraceSdfView* out) {
+    hipError_t e = make_trace_view(f, df, f ? f->ctx->main() : c->main(), out);
+    if (e != hipSuccess) return e;
+    if (f && f->ctx != c) { e = shared_before_read(f->shared, f->ctx, c); if (e != hipSuccess) return e; }
+    if (g && g->ctx != c) { e = shared_before_read(g->shared, g->ctx, c); if (e != hipSuccess) return e; }
+    return hipSuccess;
+}
+hipError_t light_pass_queued(Ctx* c, Sdf* f, GBuffer* g) {
+    if (f && f->ctx != c) { const hipError_t e = shared_after_read(f->shared, c); if (e != hipSuccess) return e; }
+    if (g && g->ctx != c) { const hipError_t e = shared_after_read(g->shared, c); if (e != hipSuccess) return e; }
     return hipSuccess;
 }
 
@@ -1101,6 +1183,20 @@ int32_t ilm_ctx_create(int32_t device_id, IlmHandle* out_ctx) {
     return ILM_OK;
 }
 
+int32_t ilm_ctx_create_sibling(IlmHandle hctx, IlmHandle* out_ctx) {
+    if (!out_ctx) return fail(ILM_ERR_INVALID_ARGUMENT, "out_ctx is NULL");
+    *out_ctx = 0;
+    Ctx* c = from_handle<Ctx>(hctx, kMagicCtx);
+    if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
+    IlmHandle h = 0;
+    const int32_t rc = ilm_ctx_create(c->device, &h);
+    if (rc != ILM_OK) return rc;
+    if (c->family == 0) c->family = reinterpret_cast<uintptr_t>(c);
+    from_handle<Ctx>(h, kMagicCtx)->family = c->family;
+    *out_ctx = h;
+    return ILM_OK;
+}
+
 int32_t ilm_ctx_destroy(IlmHandle h) {
     Ctx* c = from_handle<Ctx>(h, kMagicCtx);
     if (!c) return fail(ILM_ERR_INVALID_HANDLE, "not a context handle");
@@ -1692,6 +1788,7 @@ int32_t ilm_sdf_upload(IlmHandle h, const uint16_t* texels) {
     if (!f) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle");
     if (!texels) return fail(ILM_ERR_INVALID_ARGUMENT, "texels is NULL");
     HIP_TRY(hipSetDevice(f->ctx->device));
+    HIP_TRY(shared_before_write(f->shared, f->ctx));      // sibling contexts' queued reads first
     HIP_TRY(hipMemcpyAsync(f->texels, texels, sizeof(uint2) * (size_t)f->width * (size_t)f->height, hipMemcpyHostToDevice, f->ctx->main()));
     f->mark_all_dirty();
     HIP_TRY(hipStreamSynchronize(f->ctx->main()));
@@ -1828,6 +1925,8 @@ int32_t ilm_sdf_destroy(IlmHandle h) {
     f->ctx->children--;
     (void)hipSetDevice(f->ctx->device);
     (void)hipStreamSynchronize(f->ctx->main());
+    for (auto& r : f->shared.readers) (void)hipEventSynchronize(r.second);      // sibling contexts' light passes still reading it
+    f->shared.release();
     if (f->texels) (void)hipFree(f->texels);
     if (f->cells) (void)hipFree(f->cells);
     retire_handle(f);
@@ -1916,6 +2015,7 @@ int32_t ilm_sdf_render_slices(IlmHandle h, IlmHandle hclear, const IlmDistanceFi
     if (triplet_count == 0) return ILM_OK;
     Ctx* c = f->ctx;
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(shared_before_write(f->shared, c));           // sibling contexts' queued reads of the atlas / cells first
 
     // the orthographic view transform maps [0, VirtualWidth * ColumnCount] onto the atlas width
     // (RenderDistanceFieldSliceTriplet, LightingRenderer.DistanceField.cs:97-102): virtual units -> slice pixels
@@ -2046,6 +2146,7 @@ int32_t ilm_gbuffer_upload(IlmHandle h, const void* texels) {
     if (!g) return fail(ILM_ERR_INVALID_HANDLE, "not a G-buffer handle");
     if (!texels) return fail(ILM_ERR_INVALID_ARGUMENT, "texels is NULL");
     HIP_TRY(hipSetDevice(g->ctx->device));
+    HIP_TRY(shared_before_write(g->shared, g->ctx));
     const size_t bytes = (g->format == ILM_GBUFFER_FLOAT4 ? 16u : 8u) * (size_t)g->width * (size_t)g->height;
     HIP_TRY(hipMemcpyAsync(g->texels, texels, bytes, hipMemcpyHostToDevice, g->ctx->main()));
     HIP_TRY(hipStreamSynchronize(g->ctx->main()));
@@ -2077,6 +2178,7 @@ int32_t ilm_gbuffer_render(IlmHandle h, const IlmGBufferRenderDesc* d, const Ilm
             return fail(ILM_ERR_OUT_OF_RANGE, "height volume %d vertex range outside the polygon array", i);
     Ctx* c = g->ctx;
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(shared_before_write(g->shared, c));
     // RenderGBufferVolumes: OrderBy(hv => hv.ZBase + hv.Height) (stable), LightingRenderer.GBuffer.cs:210
     std::vector<int> order;
     for (int i = 0; i < volume_count; i++)
@@ -2171,6 +2273,7 @@ int32_t ilm_gbuffer_render_meshes(IlmHandle h, const IlmGBufferMeshDesc* d,
     const int64_t prim_count = 2 + (int64_t)top_vertex_count / 3 + front_vertex_count / 3 + 2 * (int64_t)quads.size();
     if (prim_count > (1 << 24)) return fail(ILM_ERR_TOO_MANY, "%lld triangles in one G-buffer frame", (long long)prim_count);
     HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(shared_before_write(g->shared, c));
     auto align64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
     const size_t off_front = align64(sizeof(IlmHeightVolumeVertex) * (size_t)top_vertex_count);
     const size_t off_bb = align64(off_front + sizeof(IlmHeightVolumeVertex) * (size_t)front_vertex_count);
@@ -2248,6 +2351,8 @@ int32_t ilm_gbuffer_destroy(IlmHandle h) {
     g->ctx->children--;
     (void)hipSetDevice(g->ctx->device);
     (void)hipStreamSynchronize(g->ctx->main());
+    for (auto& r : g->shared.readers) (void)hipEventSynchronize(r.second);
+    g->shared.release();
     if (g->texels) (void)hipFree(g->texels);
     retire_handle(g);
     delete g;
@@ -2556,7 +2661,8 @@ int32_t fill_light_launch(Ctx* c, const IlmEnvironment* env, const IlmDistanceFi
     if (hgbuffer) { g = from_handle<GBuffer>(hgbuffer, kMagicGBuffer); if (!g) return fail(ILM_ERR_INVALID_HANDLE, "not a G-buffer handle"); }
     if (hsdf) { f = from_handle<Sdf>(hsdf, kMagicSdf); if (!f) return fail(ILM_ERR_INVALID_HANDLE, "not a distance field handle"); }
     if (!env || !df) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
-    if (m->ctx != c || (g && g->ctx != c) || (f && f->ctx != c)) return fail(ILM_ERR_INVALID_ARGUMENT, "resources belong to another context");
+    // (the lightmap is written: the context's own; the field and the G-buffer are read: the context's or a sibling's)
+    if (m->ctx != c || (g && !siblings(g->ctx, c)) || (f && !siblings(f->ctx, c))) return fail(ILM_ERR_INVALID_ARGUMENT, "resources belong to another context");
     if (row_begin < 0 || row_end > m->height || row_begin > row_end)
         return fail(ILM_ERR_OUT_OF_RANGE, "rows [%d, %d) outside [0, %d]", row_begin, row_end, m->height);
     { char why[256]; if (field_uniforms_mismatch(f, df, why, sizeof(why))) return fail(ILM_ERR_INVALID_ARGUMENT, "%s", why); }
@@ -2564,7 +2670,8 @@ int32_t fill_light_launch(Ctx* c, const IlmEnvironment* env, const IlmDistanceFi
     a->env = *env; a->df = *df;
     a->gbuffer.texels = g ? g->texels : nullptr;
     a->gbuffer.width = g ? g->width : 0; a->gbuffer.height = g ? g->height : 0; a->gbuffer.format = g ? g->format : 0;
-    HIP_TRY(make_trace_view(f, df, c->main(), &a->sdf));
+    HIP_TRY(hipSetDevice(c->device));
+    HIP_TRY(borrowed_trace_view(c, f, g, df, &a->sdf));
     for (int i = 0; i < 4; i++) a->ambient[i] = 0.0f;
     a->lightmap = m->texels; a->width = m->width; a->height = m->height; a->format = m->format;
     a->row_begin = row_begin; a->row_end = row_end;
@@ -2659,6 +2766,7 @@ int32_t ilm_render_particle_lights(IlmHandle hctx, IlmHandle hsystem, const int3
     }
     c->last_light_blocks = light_launch_blocks(a); c->last_light_split = a.split; c->last_light_macro = (a.tile_map == 4) ? a.tile_macro : 0;
     HIP_TRY(launch_sphere_lights_prepared(a, c->d_pl_recs, c->main()));
+    HIP_TRY(light_pass_queued(c, hsdf ? from_handle<Sdf>(hsdf, kMagicSdf) : nullptr, hgbuffer ? from_handle<GBuffer>(hgbuffer, kMagicGBuffer) : nullptr));
     if (stats) {
         unsigned long long host[3] = { 0, 0, 0 };
         HIP_TRY(hipMemcpyAsync(host, c->d_stats, sizeof(host), hipMemcpyDeviceToHost, c->main()));
@@ -3060,13 +3168,14 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
     if (!env || !df) return fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
     if (light_count < 0 || (light_count > 0 && !lights)) return fail(ILM_ERR_INVALID_ARGUMENT, "bad light array");
     if (light_count > 65535) return fail(ILM_ERR_TOO_MANY, "at most 65535 lights per call");
-    if (m->ctx != c || (g && g->ctx != c) || (f && f->ctx != c)) return fail(ILM_ERR_INVALID_ARGUMENT, "resources belong to another context");
+    // (the lightmap is written: the context's own; the field and the G-buffer are read: the context's or a sibling's, ilm_ctx_create_sibling)
+    if (m->ctx != c || (g && !siblings(g->ctx, c)) || (f && !siblings(f->ctx, c))) return fail(ILM_ERR_INVALID_ARGUMENT, "resources belong to another context");
     { char why[256]; if (field_uniforms_mismatch(f, df, why, sizeof(why))) return fail(ILM_ERR_INVALID_ARGUMENT, "%s", why); }
     if (row_begin < 0 || row_end > m->height || row_begin > row_end)
         return fail(ILM_ERR_OUT_OF_RANGE, "rows [%d, %d) outside [0, %d]", row_begin, row_end, m->height);
     HIP_TRY(hipSetDevice(c->device));
     TraceSdfView trace_view;
-    HIP_TRY(make_trace_view(f, df, c->main(), &trace_view));
+    HIP_TRY(borrowed_trace_view(c, f, g, df, &trace_view));
 
     if (light_count > c->light_cap) {
         HIP_TRY(hipStreamSynchronize(c->main()));
@@ -3122,6 +3231,7 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
     { const int32_t rc = plan_group_order(c, &a, lights, light_count, 16 * a.tile_macro); if (rc != ILM_OK) return rc; }
     c->last_light_blocks = light_launch_blocks(a); c->last_light_split = a.split; c->last_light_macro = (a.tile_map == 4) ? a.tile_macro : 0;
     HIP_TRY(launch_sphere_lights_prepared(a, c->d_recs, c->main()));
+    HIP_TRY(light_pass_queued(c, f, g));
     if (stats) {
         unsigned long long host[3] = { 0, 0, 0 };
         HIP_TRY(hipMemcpyAsync(host, c->d_stats, sizeof(host), hipMemcpyDeviceToHost, c->main()));

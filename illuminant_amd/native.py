@@ -37,6 +37,7 @@ SYMBOLS = {
     "ilm_debug_reference_constant_count": (_I, []),
     "ilm_debug_reference_constant_key": (C.c_char_p, [_I]),
     "ilm_ctx_create": (_I, [_I, C.POINTER(_H)]),
+    "ilm_ctx_create_sibling": (_I, [_H, C.POINTER(_H)]),
     "ilm_ctx_destroy": (_I, [_H]),
     "ilm_ctx_sync": (_I, [_H]),
     "ilm_ctx_stream": (_I, [_H, C.POINTER(_P)]),
@@ -189,6 +190,15 @@ class Context:
 
     def sync(self):
         check(lib().ilm_ctx_sync(self.handle))
+
+    def sibling(self):
+        """ilm_ctx_create_sibling: another context on this device for a further frame in flight (own stream, scratch, lightmaps); its light
+        passes may read this context's distance fields and G-buffers."""
+        c = Context.__new__(Context)
+        c.owned, c.device_id = True, self.device_id
+        c.handle = abi.Handle(0)
+        check(lib().ilm_ctx_create_sibling(self.handle, C.byref(c.handle)))
+        return c
 
     def stream(self):
         p = C.c_void_p()

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-/* 8 (r05): + ilm_group_lightmap_store_mode, ILM_GATHER_STORE, ilm_debug_last_light_launch.
+/* 8 (r05): + ilm_group_lightmap_store_mode, ILM_GATHER_STORE, ilm_debug_last_light_launch, ilm_ctx_create_sibling.
  * 7 (r04): + ilm_ctx_set_light_split, ilm_sdf_mark_dirty, ilm_sdf_trace_info / IlmSdfTraceInfo; ilm_group_lightmap_set_strips became a
  * collective with one process per GPU.  Nothing was removed or changed in layout since 6. */
 #define ILM_ABI_VERSION 8
@@ -342,6 +342,16 @@ const char* ilm_debug_reference_constant_key(int32_t index);
  * reference threads through ParticleEngine (Illuminant/Particles/ParticleEngine.cs:95-141)
  * and LightingRenderer (Illuminant/Lighting/LightingRenderer.cs:486-560). */
 int32_t ilm_ctx_create(int32_t device_id, IlmHandle* out_ctx);
+/* A second (third, ...) context on the device of `ctx` for FRAMES IN FLIGHT (r05).  The reference keeps a ring of lightmaps
+ * (BufferRing, Illuminant/Lighting/LightingRenderer.cs:472-485) because frame N + 1 is built while frame N renders; here a launch on a
+ * context's stream starts when the previous launch of that stream has drained, so a host that wants the next frame's first waves to fill
+ * the slots the previous frame's tail leaves empty renders alternate frames on sibling contexts: each has its own stream, scratch and
+ * lightmaps, and -- unlike unrelated contexts -- the light passes of one (ilm_render_sphere_lights, ilm_render_particle_lights) may READ
+ * the distance fields and G-buffers of another.  The library orders those reads against the owner's writes (uploads, ilm_sdf_render_slices,
+ * ilm_gbuffer_render*, the field's cell rebuild -- all of which run on the OWNER's stream) with events, nothing blocks the host; writes
+ * the library cannot see (ilm_sdf_device_ptr) are the host's to order.  Sibling contexts that share objects are driven from one thread.
+ * Destroy like any context. */
+int32_t ilm_ctx_create_sibling(IlmHandle ctx, IlmHandle* out_ctx);
 int32_t ilm_ctx_destroy(IlmHandle ctx);
 /* Block until all work queued on the context has finished. */
 int32_t ilm_ctx_sync(IlmHandle ctx);

@@ -472,6 +472,7 @@ namespace Squared.Illuminant.Native {
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_debug_reference_constant_count ();
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern IntPtr ilm_debug_reference_constant_key (int index);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_ctx_create (int deviceId, ulong* outCtx);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_ctx_create_sibling (ulong ctx, ulong* outCtx);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_ctx_destroy (ulong ctx);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_ctx_sync (ulong ctx);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_ctx_stream (ulong ctx, void** outStream);
