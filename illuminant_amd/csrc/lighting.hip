@@ -804,6 +804,9 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
                 close_part();
                 part_bound = (int)(((long long)light_count * (part + 1)) / kLightParts);
             }
+            // (r05: fetching the whole 128-byte record at once for the wide-binning walk -- two 64-byte scalar loads, one wait instead of
+            // seven -- was measured a loss like r04's hot / cold record on cfg3: particle lights 1.035 / 1.055 -> 1.071 / 1.088 ms; the 32
+            // scalar registers it holds spill 40 more to vector lanes)
             const LightRec& L = recs[batch + li];
 
             bool covered = in_image;
