@@ -49,12 +49,15 @@ INFINITY_CACHE_MB = 256
 
 
 def kernel_sources_sha256():
-    """sha256 over the kernel sources (illuminant_amd/csrc/*.hip, *.hpp and the Makefile), in name order: what a PMC profile is a profile OF."""
+    """sha256 over the sources a PMC profile is a profile OF, in name order: every csrc/*.hip that contains device code (`__global__`:
+    the kernels, and api.hip, which also plans their launches), every csrc/*.hpp and the Makefile.  group.hip is host code over the C ABI
+    (no kernel, no launch of its own): an edit there does not change what a counter counted (r05)."""
     import glob
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "illuminant_amd", "csrc")
-    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.hpp")) + [os.path.join(d, "Makefile")]):
+    hips = [f for f in glob.glob(os.path.join(d, "*.hip")) if b"__global__" in open(f, "rb").read()]
+    for f in sorted(hips + glob.glob(os.path.join(d, "*.hpp")) + [os.path.join(d, "Makefile")]):
         h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
     return h.hexdigest()
 

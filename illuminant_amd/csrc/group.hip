@@ -335,7 +335,11 @@ int32_t set_store_mode(GroupLightmap* m, bool enable) {
         for (int j = 0; j < g->n_local && enable; j++)
             if (j != i) others.push_back(m->buffers[(size_t)j]);
         const int32_t rc = lightmap_set_mirrors(m->lightmaps[(size_t)i], others.data(), (int)others.size());
-        if (rc != ILM_OK) return rc;
+        if (rc != ILM_OK) {
+            // (never half-armed: a member that stores into the others while they do not would leave frames that differ by member)
+            for (int j = 0; j <= i && enable; j++) (void)lightmap_set_mirrors(m->lightmaps[(size_t)j], nullptr, 0);
+            return rc;
+        }
     }
     m->store_mode = enable;
     return ILM_OK;

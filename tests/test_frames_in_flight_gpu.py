@@ -135,3 +135,60 @@ def test_frames_in_flight_over_a_field_that_changes_every_frame(ctx, sfmt):
             for x in extra:
                 x.close()
             a.close()
+
+
+def test_frames_in_flight_under_a_gbuffer_that_changes_every_frame(ctx):
+    """The same for the G-buffer: the owner re-renders it (ilm_gbuffer_render: ground plane + height volumes whose heights change with the
+    frame; first a decoy, then the frame's own) in front of every frame, owner and sibling alternate, nothing synchronises until the end."""
+    layout, dfu, lights, w, h = heavy_scene()
+    frames = 6
+    desc = scenes.gbuffer_render_desc(0.0)
+
+    def volumes(k):
+        r = scenes.uniform(900 + k, (40, 5))
+        vols = []
+        for v in range(40):
+            cx, cy, rad = 60 + r[v, 0] * (w - 120), 60 + r[v, 1] * (h - 120), 20 + r[v, 2] * 60
+            vols.append(([(cx - rad, cy - rad), (cx + rad, cy - rad), (cx + rad, cy + rad), (cx - rad, cy + rad)], 0.0, 4.0 + 40.0 * r[v, 3], True, True))
+        return scenes.height_volume_arrays(vols)
+
+    env = scenes.environment(gbuffer_size=(w, h))
+    field_set = heavy_obstructions(0)
+    want = []
+    ref_field = native.DistanceFieldTexture(ctx, None, abi.SDF_UNORM16, size=(layout.atlas_width, layout.atlas_height))
+    ref_field.render_slices(scenes.render_desc(layout), list(range(0, layout.slice_count, 3)), field_set)
+    ref_gb = native.GBufferTexture(ctx, None, abi.GBUFFER_FLOAT4, size=(w, h))
+    ref_lm = native.Lightmap(ctx, w, h)
+    for k in range(frames):
+        ref_gb.render(desc, *volumes(k))
+        native.render_sphere_lights(ctx, lights, env, dfu, ref_gb, ref_field, AMBIENT, ref_lm)
+        want.append(ref_lm.download())
+    for x in (ref_lm, ref_gb, ref_field):
+        x.close()
+    assert not np.array_equal(want[0], want[1])
+    for pad in (0, 1):
+        a = native.Context(0)
+        extra = [native.Context(0) for _ in range(pad)]
+        b = a.sibling()
+        field = native.DistanceFieldTexture(a, None, abi.SDF_UNORM16, size=(layout.atlas_width, layout.atlas_height))
+        field.render_slices(scenes.render_desc(layout), list(range(0, layout.slice_count, 3)), field_set)
+        gb = native.GBufferTexture(a, None, abi.GBUFFER_FLOAT4, size=(w, h))
+        ring = [[native.Lightmap(c, w, h) for _ in range((frames + 1) // 2)] for c in (a, b)]
+        try:
+            for k in range(frames):
+                gb.render(desc, *volumes(50 + k))
+                gb.render(desc, *volumes(k))
+                native.render_sphere_lights((a, b)[k & 1], lights, env, dfu, gb, field, AMBIENT, ring[k & 1][k // 2])
+            a.sync(); b.sync()
+            for k in range(frames):
+                got = ring[k & 1][k // 2].download()
+                assert np.array_equal(got.view(np.uint32), want[k].view(np.uint32)), "frame %d (context %s, arrangement %d) saw another G-buffer" % (k, "ab"[k & 1], pad)
+        finally:
+            for lms in ring:
+                for lm in lms:
+                    lm.close()
+            gb.close(); field.close()
+            b.close()
+            for x in extra:
+                x.close()
+            a.close()

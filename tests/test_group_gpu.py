@@ -364,7 +364,38 @@ def test_store_mode_composites_the_frame_without_a_gather(ctx, members, fmt, bal
             assert np.array_equal(glm.download(i).view(np.uint8), want2.view(np.uint8)), "host-driven store mode: member %d's frame differs" % i
         with pytest.raises(native.IlluminantError):
             glm.gather(native.GATHER_PEER)                       # an armed lightmap has nothing to copy
+        with pytest.raises(native.IlluminantError):
             g.render_sphere_lights(lights, env, dfu, None, sdfs, AMBIENT, glm, native.GATHER_PEER)
+        # 3. particle lights on top, through the member handles (replicated particle state; the accumulate pass is mirrored like any other)
+        from tests import lights_common as lc
+        cs = 16
+        pos, vel, attr = scenes.make_particles(44, cs * cs, pos_lo=(0, 0, 2), pos_hi=(w, h, 30), dead_fraction=0.3)
+        rc = scenes.uniform(45, (cs * cs, 4), 0.3, 1.0).astype(np.float32); rc[:, :3] *= rc[:, 3:4]
+        params = lc.particle_light_params(3.0, 26.0, (1.0, 0.9, 0.8, 1.0), casts_shadows=True)
+        systems = []
+        for c in list(g.contexts) + [ctx]:
+            eng = native.Engine(c, cs, scenes.randomness_table(7))
+            sysm = native.System(eng); sysm.add_chunk()
+            sysm.upload(0, abi.PLANE_POSITION, pos); sysm.upload(0, abi.PLANE_RENDER_COLOR, rc)
+            systems.append((eng, sysm))
+        glm.gather(native.GATHER_STORE)
+        for i in range(members):
+            b, e = glm.strips[i]
+            native.render_particle_lights(g.contexts[i], systems[i][1], params, env, dfu, None, sdfs[i], glm.members[i], row_begin=b, row_end=e)
+        glm.gather(native.GATHER_STORE)
+        g.sync()
+        lm = native.Lightmap(ctx, w, h, fmt)
+        sdf0 = native.DistanceFieldTexture(ctx, atlas, abi.SDF_FP16)
+        native.render_sphere_lights(ctx, lights, env, dfu, None, sdf0, AMBIENT, lm)
+        native.render_sphere_lights(ctx, few, env, dfu, None, sdf0, None, lm)
+        native.render_particle_lights(ctx, systems[-1][1], params, env, dfu, None, sdf0, lm)
+        want3 = lm.download()
+        lm.close(); sdf0.close()
+        assert not np.array_equal(want3, want2)
+        for i in range(members):
+            assert np.array_equal(glm.download(i).view(np.uint8), want3.view(np.uint8)), "particle lights in store mode: member %d's frame differs" % i
+        for eng, sysm in systems:
+            sysm.close(); eng.close()
         glm.store_mode(False)
     finally:
         glm.close()
