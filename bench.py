@@ -924,6 +924,42 @@ def main():
                     "composited_frame_ms": round(frame_ms, 4), "composited_frame_is": "strip + gather per frame on one stream, wall clock, max over ranks",
                     "one_gpu_frame_ms": round(one_gpu_ms, 4), "one_gpu_frame_is": "the whole frame rendered by rank 0's GPU alone in this job (the other ranks idle)",
                     "share_ms": round(one_gpu_ms / world, 4), "speedup_vs_one_gpu_frame": round(one_gpu_ms / frame_ms, 3)}
+                # The same frames with the exchange PIPELINED (r05, ILM_GATHER_ASYNC): a ring of two group lightmaps (the reference's
+                # BufferRing); the exchange of frame N runs on the member's second stream while its context stream renders the strip of
+                # frame N + 1 into the other lightmap.  Reported beside the serial composited frame; a failure here is recorded, not fatal.
+                try:
+                    glm_b = native.GroupLightmap(group, w, h, abi.LIGHTMAP_HALF4)
+                    glm_b.set_strips(glm.strips)
+                    rc_b = H.RendererConfiguration(w, h)
+                    rc_b.DefaultQuality = r.Configuration.DefaultQuality
+                    rc_b.MaximumFieldUpdatesPerFrame = 9999
+                    rc_b.EnableGBuffer = True
+                    r_b = H.LightingRenderer(ctx, rc_b, L["env"], glm_b.members[0].device_ptr())
+                    r_b.DistanceField = L["field"]
+                    r_b.UpdateFields()
+                    ring_ = ((r, glm), (r_b, glm_b))
+                    mode_ = native.GATHER_RCCL | native.GATHER_ASYNC
+                    for i_ in range(4):
+                        rr_, gg_ = ring_[i_ & 1]
+                        gg_.wait(); rr_.RenderLighting(1.0, row_begin, row_end, False); gg_.gather(mode_)
+                    glm.wait(); glm_b.wait(); barrier()
+                    t0 = time.perf_counter()
+                    for i_ in range(light_frames):
+                        rr_, gg_ = ring_[i_ & 1]
+                        gg_.wait()                                  # the exchange queued on this lightmap two frames ago
+                        rr_.RenderLighting(1.0, row_begin, row_end, False)
+                        gg_.gather(mode_)
+                    glm.wait(); glm_b.wait(); barrier()
+                    pipe_ms = max_over_ranks(time.perf_counter() - t0) / light_frames * 1e3
+                    same_ = bool(np.array_equal(glm.download(0).view(np.uint16), glm_b.download(0).view(np.uint16)))
+                    frame_scaling["pipelined_exchange"] = {
+                        "composited_frame_ms": round(pipe_ms, 4), "vs_serial": round(pipe_ms / frame_ms, 4), "speedup_vs_one_gpu_frame": round(one_gpu_ms / pipe_ms, 3),
+                        "both_lightmaps_hold_the_same_frame": same_,
+                        "how": "ring of two group lightmaps; ilm_group_lightmap_gather(RCCL | ILM_GATHER_ASYNC) on the member's second stream, ilm_group_lightmap_wait in front of a lightmap's reuse"}
+                    del ring_, rr_, gg_, r_b
+                    glm_b.close()
+                except Exception as e_:      # noqa: BLE001 -- the serial figures above stand
+                    frame_scaling["pipelined_exchange"] = {"error": "%s: %s" % (type(e_).__name__, e_)}
                 frames_scaling[pin] = frame_scaling
             my_px = (row_end - row_begin) * w
             # this rank's launch: SDF samples + the G-buffer texel of every pixel (Vector4) + lightmap write (half4) + light records

@@ -103,6 +103,11 @@ struct Group {
     bool duplicates = false;                // two members share a device (RCCL refuses that)
     bool peers_ok = true;                   // every pair of distinct local devices can address each other's memory (store mode needs it)
     void* d_counts = nullptr; size_t counts_bytes = 0;     // scratch of ilm_group_live_counts (rank mode), on member 0's device
+    // ILM_GATHER_ASYNC: a second stream per local member that carries the exchanges, so that the member's context stream can go on with
+    // the next frame's strip (created on first use); its own scratch events for the peer fan-out
+    std::vector<hipStream_t> xstream;
+    std::vector<hipEvent_t> xfork, xevents;
+    hipStream_t exchange_stream(size_t i, bool async) const { return async ? xstream[i] : stream(i); }
 };
 
 struct GroupLightmap {
@@ -117,6 +122,8 @@ struct GroupLightmap {
     std::vector<void*> buffers;             // per local member: world * slot_rows rows
     std::vector<IlmHandle> lightmaps;       // per local member: lightmap object aliasing the buffer
     bool store_mode = false;                // ILM_GATHER_STORE armed: every member's light passes also store into the other members' buffers
+    std::vector<hipEvent_t> xdone;          // ILM_GATHER_ASYNC: per local member, "the exchange queued last has finished" (ilm_group_lightmap_wait)
+    std::vector<bool> xpending;
 };
 
 Group* group_from(IlmHandle h) { return handle_is_live(h, kMagicGroup) ? reinterpret_cast<Group*>(static_cast<uintptr_t>(h)) : nullptr; }
@@ -170,6 +177,12 @@ void release_group(Group* g) {
             (void)hipSetDevice(g->devices[i]);
             (void)rccl().CommDestroy(g->comms[i]);
         }
+    for (size_t i = 0; i < g->xstream.size(); i++) {
+        (void)hipSetDevice(g->devices[i]);
+        if (g->xstream[i]) { (void)hipStreamSynchronize(g->xstream[i]); (void)hipStreamDestroy(g->xstream[i]); }
+        if (i < g->xfork.size() && g->xfork[i]) (void)hipEventDestroy(g->xfork[i]);
+        if (i < g->xevents.size() && g->xevents[i]) (void)hipEventDestroy(g->xevents[i]);
+    }
     if (g->d_counts) { (void)hipSetDevice(g->devices[0]); (void)hipFree(g->d_counts); }
     for (size_t i = 0; i < g->events.size(); i++) {
         (void)hipSetDevice(g->devices[i]);
@@ -196,8 +209,10 @@ int32_t ensure_comms(Group* g) {
 }
 
 // In-place all-gather; see the header.  All work is stream-ordered on the members' context streams.
-int32_t all_gather(Group* g, void* const* buffers, size_t bytes, int gather) {
+int32_t all_gather(Group* g, void* const* buffers, size_t bytes, int gather, bool async = false) {
     if (gather == ILM_GATHER_NONE || g->world == 1 || bytes == 0) return ILM_OK;
+    std::vector<hipEvent_t>& events = async ? g->xevents : g->events;
+    auto S = [&](size_t i) { return g->exchange_stream(i, async); };
     if (gather == ILM_GATHER_PEER) {
         if (g->rank_mode)
             return api_fail(ILM_ERR_INVALID_ARGUMENT, "ILM_GATHER_PEER needs every member in this process; a group that spans processes gathers with RCCL");
@@ -206,12 +221,12 @@ int32_t all_gather(Group* g, void* const* buffers, size_t bytes, int gather) {
         //    start before the destination has finished the work queued before this call: every stream waits for every other's "here" event
         for (int i = 0; i < n; i++) {
             HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
-            HIP_TRY(hipEventRecord(g->events[(size_t)i], g->stream((size_t)i)));
+            HIP_TRY(hipEventRecord(events[(size_t)i], S((size_t)i)));
         }
         for (int i = 0; i < n; i++) {
             HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
             for (int j = 0; j < n; j++)
-                if (j != i) HIP_TRY(hipStreamWaitEvent(g->stream((size_t)i), g->events[(size_t)j], 0));
+                if (j != i) HIP_TRY(hipStreamWaitEvent(S((size_t)i), events[(size_t)j], 0));
         }
         // 2. member i pushes its slot to the n - 1 others on its own stream: on a full xGMI mesh that is one transfer per link
         for (int i = 0; i < n; i++) {
@@ -220,15 +235,15 @@ int32_t all_gather(Group* g, void* const* buffers, size_t bytes, int gather) {
             for (int k = 1; k < n; k++) {
                 const int j = (i + k) % n;            // staggered destinations: no two members start on the same target
                 HIP_TRY(hipMemcpyPeerAsync(static_cast<char*>(buffers[j]) + off, g->devices[(size_t)j],
-                                           static_cast<const char*>(buffers[i]) + off, g->devices[(size_t)i], bytes, g->stream((size_t)i)));
+                                           static_cast<const char*>(buffers[i]) + off, g->devices[(size_t)i], bytes, S((size_t)i)));
             }
-            HIP_TRY(hipEventRecord(g->events[(size_t)i], g->stream((size_t)i)));
+            HIP_TRY(hipEventRecord(events[(size_t)i], S((size_t)i)));
         }
         // 3. a member's later work sees the whole frame: its stream waits for every push
         for (int i = 0; i < n; i++) {
             HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
             for (int j = 0; j < n; j++)
-                if (j != i) HIP_TRY(hipStreamWaitEvent(g->stream((size_t)i), g->events[(size_t)j], 0));
+                if (j != i) HIP_TRY(hipStreamWaitEvent(S((size_t)i), events[(size_t)j], 0));
         }
         return ILM_OK;
     }
@@ -241,7 +256,7 @@ int32_t all_gather(Group* g, void* const* buffers, size_t bytes, int gather) {
         HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
         char* buf = static_cast<char*>(buffers[i]);
         // in place: the send buffer is this rank's slot of the receive buffer
-        NCCL_TRY(r.AllGather(buf + (size_t)(g->first_rank + i) * bytes, buf, bytes, ncclInt8, g->comms[(size_t)i], g->stream((size_t)i)));
+        NCCL_TRY(r.AllGather(buf + (size_t)(g->first_rank + i) * bytes, buf, bytes, ncclInt8, g->comms[(size_t)i], S((size_t)i)));
     }
     NCCL_TRY(r.GroupEnd());
     return ILM_OK;
@@ -251,19 +266,21 @@ int32_t all_gather(Group* g, void* const* buffers, size_t bytes, int gather) {
 // them.  Peer mode: as all_gather, every local member pushes its range to the others (one transfer per xGMI link).  RCCL: one group of
 // point-to-point transfers -- rank r sends its range to each of the world - 1 others and receives theirs in place; on the fully
 // connected xGMI mesh of one node that is again one transfer per link and direction, with no ring hop in between.
-int32_t exchange_ranges(Group* g, void* const* buffers, const std::vector<size_t>& offset, const std::vector<size_t>& bytes, int32_t gather) {
+int32_t exchange_ranges(Group* g, void* const* buffers, const std::vector<size_t>& offset, const std::vector<size_t>& bytes, int32_t gather, bool async = false) {
     if (gather == ILM_GATHER_NONE || g->world == 1) return ILM_OK;
+    std::vector<hipEvent_t>& events = async ? g->xevents : g->events;
+    auto S = [&](size_t i) { return g->exchange_stream(i, async); };
     if (gather == ILM_GATHER_PEER) {
         if (g->rank_mode) return api_fail(ILM_ERR_STATE, "ILM_GATHER_PEER needs every member in this process: use ILM_GATHER_RCCL");
         const int n = g->n_local;
         for (int i = 0; i < n; i++) {
             HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
-            HIP_TRY(hipEventRecord(g->events[(size_t)i], g->stream((size_t)i)));
+            HIP_TRY(hipEventRecord(events[(size_t)i], S((size_t)i)));
         }
         for (int i = 0; i < n; i++) {
             HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
             for (int j = 0; j < n; j++)
-                if (j != i) HIP_TRY(hipStreamWaitEvent(g->stream((size_t)i), g->events[(size_t)j], 0));
+                if (j != i) HIP_TRY(hipStreamWaitEvent(S((size_t)i), events[(size_t)j], 0));
         }
         for (int i = 0; i < n; i++) {
             HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
@@ -271,14 +288,14 @@ int32_t exchange_ranges(Group* g, void* const* buffers, const std::vector<size_t
             for (int k = 1; k < n && len > 0; k++) {
                 const int j = (i + k) % n;
                 HIP_TRY(hipMemcpyPeerAsync(static_cast<char*>(buffers[j]) + off, g->devices[(size_t)j],
-                                           static_cast<const char*>(buffers[i]) + off, g->devices[(size_t)i], len, g->stream((size_t)i)));
+                                           static_cast<const char*>(buffers[i]) + off, g->devices[(size_t)i], len, S((size_t)i)));
             }
-            HIP_TRY(hipEventRecord(g->events[(size_t)i], g->stream((size_t)i)));
+            HIP_TRY(hipEventRecord(events[(size_t)i], S((size_t)i)));
         }
         for (int i = 0; i < n; i++) {
             HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
             for (int j = 0; j < n; j++)
-                if (j != i) HIP_TRY(hipStreamWaitEvent(g->stream((size_t)i), g->events[(size_t)j], 0));
+                if (j != i) HIP_TRY(hipStreamWaitEvent(S((size_t)i), events[(size_t)j], 0));
         }
         return ILM_OK;
     }
@@ -293,8 +310,8 @@ int32_t exchange_ranges(Group* g, void* const* buffers, const std::vector<size_t
         const int me = g->first_rank + i;
         for (int k = 1; k < g->world; k++) {
             const int to = (me + k) % g->world, from = (me - k + g->world) % g->world;      // staggered: no two ranks start on the same peer
-            if (bytes[(size_t)me] > 0) NCCL_TRY(r.Send(buf + offset[(size_t)me], bytes[(size_t)me], ncclInt8, to, g->comms[(size_t)i], g->stream((size_t)i)));
-            if (bytes[(size_t)from] > 0) NCCL_TRY(r.Recv(buf + offset[(size_t)from], bytes[(size_t)from], ncclInt8, from, g->comms[(size_t)i], g->stream((size_t)i)));
+            if (bytes[(size_t)me] > 0) NCCL_TRY(r.Send(buf + offset[(size_t)me], bytes[(size_t)me], ncclInt8, to, g->comms[(size_t)i], S((size_t)i)));
+            if (bytes[(size_t)from] > 0) NCCL_TRY(r.Recv(buf + offset[(size_t)from], bytes[(size_t)from], ncclInt8, from, g->comms[(size_t)i], S((size_t)i)));
         }
     }
     NCCL_TRY(r.GroupEnd());
@@ -346,20 +363,82 @@ int32_t set_store_mode(GroupLightmap* m, bool enable) {
 }
 
 // the exchange of a group lightmap's strips: one in-place all-gather for the equal slots, range by range otherwise
+// the second stream (and its events) of every local member, for ILM_GATHER_ASYNC
+int32_t ensure_exchange_streams(Group* g) {
+    if (!g->xstream.empty()) return ILM_OK;
+    for (int i = 0; i < g->n_local; i++) {
+        HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+        hipStream_t st = nullptr; hipEvent_t a = nullptr, b = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+        g->xstream.push_back(st); g->xfork.push_back(a); g->xevents.push_back(b);
+    }
+    return ILM_OK;
+}
+
 int32_t gather_lightmap(GroupLightmap* m, int32_t gather) {
+    Group* g = m->group;
+    const bool async = (gather & ILM_GATHER_ASYNC) != 0;
+    gather &= ~ILM_GATHER_ASYNC;
     if (gather == ILM_GATHER_STORE) {
+        if (async) return api_fail(ILM_ERR_INVALID_ARGUMENT, "ILM_GATHER_STORE has no exchange to move to another stream");
         if (!m->store_mode) return api_fail(ILM_ERR_STATE, "ILM_GATHER_STORE: arm the group lightmap first (ilm_group_lightmap_store_mode)");
-        return fence_members(m->group);
+        return fence_members(g);
     }
     if (m->store_mode && gather != ILM_GATHER_NONE)
         return api_fail(ILM_ERR_STATE, "the group lightmap is in store mode: its members already hold every strip (gather with ILM_GATHER_STORE, or switch the mode off)");
-    if (m->equal_slots) return all_gather(m->group, m->buffers.data(), m->row_bytes * (size_t)m->slot_rows, gather);
-    std::vector<size_t> offset((size_t)m->group->world), bytes((size_t)m->group->world);
-    for (int r = 0; r < m->group->world; r++) {
-        offset[(size_t)r] = m->row_bytes * (size_t)m->begin[(size_t)r];
-        bytes[(size_t)r] = m->row_bytes * (size_t)(m->end[(size_t)r] - m->begin[(size_t)r]);
+    if (async) {
+        // ILM_GATHER_ASYNC (r05): the exchange of THIS frame runs on the members' exchange streams, behind what their context streams have
+        // queued so far (the strip), and the context streams go on -- with the next frame's strip into ANOTHER group lightmap.  Nobody may
+        // touch this lightmap again before ilm_group_lightmap_wait.
+        if (gather != ILM_GATHER_PEER && gather != ILM_GATHER_RCCL) return api_fail(ILM_ERR_INVALID_ARGUMENT, "ILM_GATHER_ASYNC goes with ILM_GATHER_PEER or ILM_GATHER_RCCL");
+        const int32_t rc = ensure_exchange_streams(g);
+        if (rc != ILM_OK) return rc;
+        if (m->xdone.empty())
+            for (int i = 0; i < g->n_local; i++) {
+                HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+                hipEvent_t e = nullptr;
+                HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                m->xdone.push_back(e); m->xpending.push_back(false);
+            }
+        for (int i = 0; i < g->n_local; i++) {
+            HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+            HIP_TRY(hipEventRecord(g->xfork[(size_t)i], g->stream((size_t)i)));
+            HIP_TRY(hipStreamWaitEvent(g->xstream[(size_t)i], g->xfork[(size_t)i], 0));
+        }
     }
-    return exchange_ranges(m->group, m->buffers.data(), offset, bytes, gather);
+    int32_t rc;
+    if (m->equal_slots) {
+        rc = all_gather(g, m->buffers.data(), m->row_bytes * (size_t)m->slot_rows, gather, async);
+    } else {
+        std::vector<size_t> offset((size_t)g->world), bytes((size_t)g->world);
+        for (int r = 0; r < g->world; r++) {
+            offset[(size_t)r] = m->row_bytes * (size_t)m->begin[(size_t)r];
+            bytes[(size_t)r] = m->row_bytes * (size_t)(m->end[(size_t)r] - m->begin[(size_t)r]);
+        }
+        rc = exchange_ranges(g, m->buffers.data(), offset, bytes, gather, async);
+    }
+    if (rc != ILM_OK) return rc;
+    if (async)
+        for (int i = 0; i < g->n_local; i++) {
+            HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+            HIP_TRY(hipEventRecord(m->xdone[(size_t)i], g->xstream[(size_t)i]));
+            m->xpending[(size_t)i] = true;
+        }
+    return ILM_OK;
+}
+
+// every member's context stream waits for the exchange queued last on this lightmap (nothing blocks the host)
+int32_t wait_lightmap_exchange(GroupLightmap* m) {
+    Group* g = m->group;
+    for (size_t i = 0; i < m->xpending.size(); i++)
+        if (m->xpending[i]) {
+            HIP_TRY(hipSetDevice(g->devices[i]));
+            HIP_TRY(hipStreamWaitEvent(g->stream(i), m->xdone[i], 0));
+            m->xpending[i] = false;
+        }
+    return ILM_OK;
 }
 
 // Small host payloads (liveness counters, timings): rank r's `bytes` land at out + r * bytes on every process.  Members of this
@@ -501,6 +580,7 @@ int32_t ilm_group_sync(IlmHandle h) {
     for (int i = 0; i < g->n_local; i++) {
         const int32_t rc = ilm_ctx_sync(g->ctx[(size_t)i]);
         if (rc != ILM_OK) return rc;
+        if ((size_t)i < g->xstream.size()) { HIP_TRY(hipSetDevice(g->devices[(size_t)i])); HIP_TRY(hipStreamSynchronize(g->xstream[(size_t)i])); }
     }
     return ILM_OK;
 }
@@ -521,10 +601,12 @@ int32_t ilm_group_host_all_gather(IlmHandle h, const void* local, void* out_all,
     if (!g) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group handle");
     if (!local || !out_all) return api_fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
     if (bytes_per_rank > (1u << 20)) return api_fail(ILM_ERR_OUT_OF_RANGE, "host payloads are small (<= 1 MiB per rank): use ilm_group_all_gather for device buffers");
-    // every member's queued work is finished first: the call doubles as the barrier between timed regions
+    // every member's queued work is finished first: the call doubles as the barrier between timed regions (the exchange streams of
+    // ILM_GATHER_ASYNC included: one communicator never has two operations in flight on two streams)
     for (int i = 0; i < g->n_local; i++) {
         const int32_t rc = ilm_ctx_sync(g->ctx[(size_t)i]);
         if (rc != ILM_OK) return rc;
+        if ((size_t)i < g->xstream.size()) { HIP_TRY(hipSetDevice(g->devices[(size_t)i])); HIP_TRY(hipStreamSynchronize(g->xstream[(size_t)i])); }
     }
     return host_all_gather(g, local, out_all, (size_t)bytes_per_rank);
 }
@@ -575,6 +657,8 @@ int32_t ilm_group_lightmap_destroy(IlmHandle h) {
     if (!m) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group lightmap handle");
     Group* g = m->group;
     if (m->store_mode && m->lightmaps.size() == (size_t)g->n_local) (void)set_store_mode(m, false);
+    for (size_t i = 0; i < g->xstream.size(); i++) { (void)hipSetDevice(g->devices[i]); (void)hipStreamSynchronize(g->xstream[i]); }
+    for (hipEvent_t e : m->xdone) if (e) (void)hipEventDestroy(e);
     for (IlmHandle lm : m->lightmaps) (void)ilm_lightmap_destroy(lm);        // synchronises the member's stream
     for (size_t i = 0; i < m->buffers.size(); i++) {
         (void)hipSetDevice(g->devices[i]);
@@ -682,6 +766,13 @@ int32_t ilm_group_lightmap_gather(IlmHandle h, int32_t gather) {
     return gather_lightmap(m, gather);
 }
 
+int32_t ilm_group_lightmap_wait(IlmHandle h) {
+    ILM_TRACE_RANGE("ilm_group_lightmap_wait");
+    GroupLightmap* m = glm_from(h);
+    if (!m) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group lightmap handle");
+    return wait_lightmap_exchange(m);
+}
+
 int32_t ilm_group_lightmap_store_mode(IlmHandle h, int32_t enable) {
     GroupLightmap* m = glm_from(h);
     if (!m) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group lightmap handle");
@@ -697,8 +788,10 @@ int32_t ilm_group_render_sphere_lights(IlmHandle hgroup, const IlmLightVertex* l
     GroupLightmap* m = glm_from(hlightmap);
     if (!m) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group lightmap handle");
     if (m->group != g) return api_fail(ILM_ERR_INVALID_ARGUMENT, "the lightmap belongs to another group");
-    if (gather < ILM_GATHER_NONE || gather > ILM_GATHER_STORE) return api_fail(ILM_ERR_INVALID_ARGUMENT, "unknown gather mode %d", gather);
+    if ((gather & ~ILM_GATHER_ASYNC) < ILM_GATHER_NONE || (gather & ~ILM_GATHER_ASYNC) > ILM_GATHER_STORE) return api_fail(ILM_ERR_INVALID_ARGUMENT, "unknown gather mode %d", gather);
     if (stats) { stats->SdfSamples = 0; stats->PixelLightPairs = 0; stats->TracedPairs = 0; }
+    // (a lightmap whose last exchange was asynchronous: the strips about to be rendered into it wait for that exchange)
+    { const int32_t rc = wait_lightmap_exchange(m); if (rc != ILM_OK) return rc; }
     // store mode: armed for this call when the host has not armed the lightmap itself; nobody's pass may write into a member's frame
     // before that member's earlier readers of it are done (the fence in front), and the fence behind is the "gather"
     const bool arm_here = (gather == ILM_GATHER_STORE) && !m->store_mode;

@@ -125,6 +125,7 @@ SYMBOLS = {
     "ilm_group_lightmap_set_strips": (_I, [_H, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "ilm_group_lightmap_gather": (_I, [_H, _I]),
     "ilm_group_lightmap_store_mode": (_I, [_H, _I]),
+    "ilm_group_lightmap_wait": (_I, [_H]),
     "ilm_group_lightmap_destroy": (_I, [_H]),
     "ilm_group_render_sphere_lights": (_I, [_H, _P, _I, _P, _P, _P, _P, _P, _H, _I, _P]),
     "ilm_group_live_counts": (_I, [_H, _P, _I, _P, _I, _I]),
@@ -621,6 +622,7 @@ class Lightmap:
 
 
 GATHER_NONE, GATHER_PEER, GATHER_RCCL, GATHER_STORE = 0, 1, 2, 3
+GATHER_ASYNC = 0x100        # flag: the exchange on the members' second streams (GroupLightmap.wait orders later work behind it)
 
 
 class Group:
@@ -747,6 +749,10 @@ class GroupLightmap:
 
     def gather(self, gather):
         check(lib().ilm_group_lightmap_gather(self.handle, gather))
+
+    def wait(self):
+        """ilm_group_lightmap_wait: the members' context streams wait for the asynchronous exchange queued last (no host block)."""
+        check(lib().ilm_group_lightmap_wait(self.handle))
 
     def store_mode(self, enable=True):
         """ilm_group_lightmap_store_mode: while armed, every light pass into a member's lightmap also stores into the other members' copies

@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-/* 8 (r05): + ilm_group_lightmap_store_mode, ILM_GATHER_STORE, ilm_debug_last_light_launch, ilm_ctx_create_sibling.
+/* 8 (r05): + ilm_group_lightmap_store_mode, ILM_GATHER_STORE, ilm_debug_last_light_launch, ilm_ctx_create_sibling,
+ * ILM_GATHER_ASYNC + ilm_group_lightmap_wait.
  * 7 (r04): + ilm_ctx_set_light_split, ilm_sdf_mark_dirty, ilm_sdf_trace_info / IlmSdfTraceInfo; ilm_group_lightmap_set_strips became a
  * collective with one process per GPU.  Nothing was removed or changed in layout since 6. */
 #define ILM_ABI_VERSION 8
@@ -949,6 +950,9 @@ enum {
     ILM_GATHER_PEER = 1,  /* in-process groups: every member pushes its strip to the n - 1 others with hipMemcpyPeerAsync -- one
                              transfer per xGMI link, all links of the full mesh busy at once */
     ILM_GATHER_RCCL = 2,  /* ncclAllGather on the members' context streams (RCCL over xGMI; the only exchange between processes) */
+    ILM_GATHER_ASYNC = 0x100, /* flag, OR'ed onto ILM_GATHER_PEER / ILM_GATHER_RCCL (r05): the exchange runs on a second stream of every member,
+                             behind the strip just queued, and the member's context stream goes on -- with the next frame's strip into ANOTHER
+                             group lightmap (a ring of two, the reference's BufferRing).  ilm_group_lightmap_wait orders later work behind it. */
     ILM_GATHER_STORE = 3  /* in-process groups (r05): no copy phase at all -- the light kernel's final store writes every texel of a member's
                              strip at the same offset of EVERY member's copy of the frame (the others' buffers peer-mapped over xGMI:
                              n stores of 8 B per pixel), so the exchange overlaps the strip; what remains of the gather is a fence */
@@ -997,6 +1001,11 @@ int32_t ilm_group_lightmap_strip(IlmHandle group_lightmap, int32_t rank, int32_t
  * transfer per xGMI link and direction) instead of by the single in-place all-gather.  NULL, NULL restores the equal slots. */
 int32_t ilm_group_lightmap_set_strips(IlmHandle group_lightmap, const int32_t* row_begins, const int32_t* row_ends);
 int32_t ilm_group_lightmap_gather(IlmHandle group_lightmap, int32_t gather);
+/* After ilm_group_lightmap_gather(..., mode | ILM_GATHER_ASYNC): every member's context stream waits for that exchange (stream-ordered,
+ * nothing blocks the host).  Call it before anything reads the composited frame and before the lightmap is rendered into again
+ * (ilm_group_render_sphere_lights does it itself); a no-op when no asynchronous exchange is pending.  A host keeps two group lightmaps
+ * and alternates: strip N + 1 is rendered while strip N travels.  ilm_group_sync / ilm_group_host_all_gather drain the exchange streams too. */
+int32_t ilm_group_lightmap_wait(IlmHandle group_lightmap);
 /* Arms (enable != 0) or disarms the store-mode exchange: while armed, EVERY light pass into a member's lightmap (ilm_render_sphere_lights,
  * ilm_render_particle_lights through ilm_group_lightmap_member's handle) also stores its texels into the other members' copies of the frame, and
  * ilm_group_lightmap_gather(ILM_GATHER_STORE) is the fence that orders each member's later readers behind the other members' passes --

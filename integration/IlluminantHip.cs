@@ -77,6 +77,7 @@ namespace Squared.Illuminant.Native {
         public const int GATHER_NONE = 0;
         public const int GATHER_PEER = 1;
         public const int GATHER_RCCL = 2;
+        public const int GATHER_ASYNC = 256;
         public const int GATHER_STORE = 3;
     }
 
@@ -559,6 +560,7 @@ namespace Squared.Illuminant.Native {
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_lightmap_strip (ulong groupLightmap, int rank, int* outRowBegin, int* outRowEnd, int* outSlotRows);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_lightmap_set_strips (ulong groupLightmap, int* rowBegins, int* rowEnds);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_lightmap_gather (ulong groupLightmap, int gather);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_lightmap_wait (ulong groupLightmap);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_lightmap_store_mode (ulong groupLightmap, int enable);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_lightmap_destroy (ulong groupLightmap);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_render_sphere_lights (ulong group, LightVertex* lights, int lightCount, IlmEnvironment* env, IlmDistanceFieldUniforms* df, ulong* gbuffers, ulong* sdfs, float* ambient, ulong groupLightmap, int gather, IlmRenderStats* stats);

@@ -49,6 +49,8 @@ def main():
     cs, rnd, chunks, d0 = post_spawn_state(seed)
     d0.UpdateMode = abi.UPDATE_NONE
     d0.Flags = 0
+    assert d0.Ops[0].Type == abi.OP_GRAVITY
+    d0.OpCount = 1                                   # the Gravity op alone (a Noise op behind it is not what the variant changes)
     ctx = native.Context(0)
     got, _ = device_step(ctx, cs, rnd, chunks, d0)
     want = [[a.copy() for a in c] for c in chunks]

@@ -412,3 +412,68 @@ def test_store_mode_is_refused_where_buffers_are_not_peer_mapped(ctx):
         glm.store_mode(True)
     assert e.value.code == abi.ERR_STATE and "spans processes" in str(e.value)
     glm.close(); g.close()
+
+
+@pytest.mark.parametrize("members,balanced", [(2, False), (3, True), (5, True)])
+def test_asynchronous_exchange_over_a_ring_of_two_lightmaps(ctx, members, balanced):
+    """ILM_GATHER_ASYNC (r05): the exchange of frame N runs on the members' second streams while their context streams render the strips of
+    frame N + 1 into the OTHER lightmap of a ring of two (the reference's BufferRing, LightingRenderer.cs:472-485).  Six frames with six
+    light sets, nothing synchronised except ilm_group_lightmap_wait in front of a lightmap's reuse: every member's copy of every frame
+    equals the single-context frame bit for bit (peer copies on one device; the RCCL form of the same calls at world 1)."""
+    from illuminant_amd import sharding
+    layout, atlas, dfu, _, w, h = small_scene(abi.SDF_UNORM16, width=240, height=176)
+    env = scenes.environment()
+    frames = 6
+    light_sets = [scenes.random_lights(300 + k, 10 + 3 * k, w, h, z=(8.0, 48.0), radius=10.0, ramp=(40.0, 140.0)) for k in range(frames)]
+    want = []
+    for k in range(frames):
+        f, _ = single_context_frame(ctx, light_sets[k], env, dfu, atlas, abi.SDF_UNORM16, w, h, abi.LIGHTMAP_HALF4)
+        want.append(f)
+    assert not np.array_equal(want[0], want[2])
+    g = native.Group([0] * members)
+    sdfs = [native.DistanceFieldTexture(c, atlas, abi.SDF_UNORM16) for c in g.contexts]
+    ring = [native.GroupLightmap(g, w, h, abi.LIGHTMAP_HALF4) for _ in range(2)]
+    if balanced:
+        for glm in ring:
+            glm.set_strips(sharding.balanced_row_strips(h, members, light_sets[0]))
+    try:
+        def check(k):
+            glm = ring[k & 1]
+            glm.wait()
+            for i in range(members):
+                assert np.array_equal(glm.download(i).view(np.uint16), want[k].view(np.uint16)), "frame %d, member %d" % (k, i)
+        for k in range(frames):
+            if k >= 2:
+                check(k - 2)
+            g.render_sphere_lights(light_sets[k], env, dfu, None, sdfs, AMBIENT, ring[k & 1], native.GATHER_PEER | native.GATHER_ASYNC)
+        check(frames - 2); check(frames - 1)
+        # the flag goes with a copying mode only
+        with pytest.raises(native.IlluminantError):
+            ring[0].gather(native.GATHER_STORE | native.GATHER_ASYNC)
+        with pytest.raises(native.IlluminantError):
+            ring[0].gather(native.GATHER_NONE | native.GATHER_ASYNC)
+    finally:
+        g.sync()
+        for glm in ring:
+            glm.close()
+        for s in sdfs:
+            s.close()
+        g.close()
+
+
+def test_asynchronous_rccl_exchange_at_world_one(ctx):
+    layout, atlas, dfu, lights, w, h = small_scene()
+    env = scenes.environment()
+    want, _ = single_context_frame(ctx, lights, env, dfu, atlas, abi.SDF_UNORM16, w, h)
+    g = native.Group.rank(0, 0, 1, native.Group.unique_id())
+    sdf = native.DistanceFieldTexture(g.contexts[0], atlas, abi.SDF_UNORM16)
+    ring = [native.GroupLightmap(g, w, h) for _ in range(2)]
+    for k in range(4):
+        g.render_sphere_lights(lights, env, dfu, None, [sdf], AMBIENT, ring[k & 1], native.GATHER_RCCL | native.GATHER_ASYNC)
+    for glm in ring:
+        glm.wait()
+        assert np.array_equal(glm.download(0), want)
+    g.host_all_gather(b"\0" * 8)          # the barrier drains the exchange streams too
+    for glm in ring:
+        glm.close()
+    sdf.close(); g.close()
