@@ -126,6 +126,17 @@ struct Engine {
     float4* rnd = nullptr; int rw = 0, rh = 0;
     std::vector<float4> h_rnd;   // host copy: the uniform noise deltas are evaluated on the host (fill_noise_fast)
     uint2* rnd_lp = nullptr;   // LowPrecisionRandomnessTexture: the Rgba64 copy (ParticleEngine.cs:508-540)
+    // Chunk pool (r05).  The reference's engine keeps its released buffer sets for reuse (AvailableBuffers / DiscardedBuffers, at most
+    // SpareBufferCount = 20 spares: ParticleEngine.cs:53-58,145-170,402-419) because creating a render target in the middle of a frame is
+    // expensive; so is hipMalloc: a Spawner that fills a 256^2 chunk every 60 steps paid ~70 us for the 61st (tools/host_cost_probe_cfg2.py).
+    // Chunks are carved out of slabs of up to 8 (64 MB at most; one for the large chunk sizes), zero-filled on the context stream when a
+    // slab is allocated and again when a chunk comes back; `spare` holds the ready ones.  Slabs live until the engine is destroyed,
+    // except single-chunk slabs beyond kSpareChunks spares, which are freed when they come back.
+    static constexpr int kSpareChunks = 20;
+    struct Slab { float* base; int chunks; };
+    std::vector<Slab> slabs;
+    std::vector<float*> spare;
+    size_t chunk_bytes() const { return sizeof(float) * (size_t)kComponents * (size_t)stride; }
 };
 
 // A distance field or G-buffer that sibling contexts read (light passes on another context's stream).  Every WRITE to it happens on its
@@ -1314,6 +1325,37 @@ int32_t ilm_engine_create(IlmHandle hctx, int32_t chunk_size, const IlmFloat4* r
     return ILM_OK;
 }
 
+// a zero-filled chunk of the engine's pool (zeroing is stream-ordered on the context stream, as its first use will be)
+static int32_t acquire_chunk(Engine* e, float** out) {
+    if (e->spare.empty()) {
+        const size_t bytes = e->chunk_bytes();
+        const int k = (int)std::min<size_t>(8, std::max<size_t>(1, ((size_t)64 << 20) / bytes));
+        float* base = nullptr;
+        hipError_t err = hipMalloc(reinterpret_cast<void**>(&base), bytes * (size_t)k);
+        int got = k;
+        if (err != hipSuccess && k > 1) { (void)hipGetLastError(); got = 1; err = hipMalloc(reinterpret_cast<void**>(&base), bytes); }
+        if (err != hipSuccess) return fail((int32_t)err, "a particle chunk of %zu bytes: %s", bytes, hipGetErrorString(err));
+        HIP_TRY(hipMemsetAsync(base, 0, bytes * (size_t)got, e->ctx->main()));
+        e->slabs.push_back(Engine::Slab{ base, got });
+        for (int i = got - 1; i >= 0; i--) e->spare.push_back(base + (size_t)i * (bytes / sizeof(float)));
+    }
+    *out = e->spare.back();
+    e->spare.pop_back();
+    return ILM_OK;
+}
+// a chunk nobody reads any more (the caller has drained the context stream) goes back: zeroed for its next owner
+static void release_chunk(Engine* e, float* chunk) {
+    if ((int)e->spare.size() >= Engine::kSpareChunks)
+        for (size_t i = 0; i < e->slabs.size(); i++)
+            if (e->slabs[i].base == chunk && e->slabs[i].chunks == 1) {      // beyond the spare limit a chunk with a slab of its own is freed
+                (void)hipFree(chunk);
+                e->slabs.erase(e->slabs.begin() + (long)i);
+                return;
+            }
+    (void)hipMemsetAsync(chunk, 0, e->chunk_bytes(), e->ctx->main());
+    e->spare.push_back(chunk);
+}
+
 int32_t ilm_engine_destroy(IlmHandle h) {
     Engine* e = from_handle<Engine>(h, kMagicEngine);
     if (!e) return fail(ILM_ERR_INVALID_HANDLE, "not an engine handle");
@@ -1323,6 +1365,7 @@ int32_t ilm_engine_destroy(IlmHandle h) {
     (void)hipStreamSynchronize(e->ctx->main());
     if (e->rnd) (void)hipFree(e->rnd);
     if (e->rnd_lp) (void)hipFree(e->rnd_lp);
+    for (const Engine::Slab& slab : e->slabs) (void)hipFree(slab.base);
     retire_handle(e);
     delete e;
     return ILM_OK;
@@ -1347,7 +1390,7 @@ int32_t ilm_system_destroy(IlmHandle h) {
     s->engine->children--;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->main());
-    for (float* p : s->chunks) (void)hipFree(p);
+    for (float* p : s->chunks) release_chunk(s->engine, p);
     if (s->d_table) (void)hipFree(s->d_table);
     if (s->d_counts) (void)hipFree(s->d_counts);
     if (s->ramp) (void)hipFree(s->ramp);
@@ -1370,9 +1413,7 @@ int32_t ilm_system_add_chunk(IlmHandle h, int32_t* out_index) {
     Engine* e = s->engine;
     HIP_TRY(hipSetDevice(e->ctx->device));
     float* base = nullptr;
-    const size_t bytes = sizeof(float) * (size_t)kComponents * (size_t)e->stride;
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&base), bytes));
-    HIP_TRY(hipMemsetAsync(base, 0, bytes, e->ctx->main()));
+    { const int32_t rc = acquire_chunk(e, &base); if (rc != ILM_OK) return rc; }
     s->chunks.push_back(base);
     s->used.push_back(0);
     s->table_dirty = true;
@@ -1388,7 +1429,7 @@ int32_t ilm_system_remove_chunk(IlmHandle h, int32_t index) {
     Ctx* c = s->engine->ctx;
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipStreamSynchronize(c->main()));
-    HIP_TRY(hipFree(s->chunks[(size_t)index]));
+    release_chunk(s->engine, s->chunks[(size_t)index]);
     s->chunks.erase(s->chunks.begin() + index);
     s->used.erase(s->used.begin() + index);
     s->table_dirty = true;

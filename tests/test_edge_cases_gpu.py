@@ -308,3 +308,42 @@ def test_slots_revived_past_the_high_water_mark_stay_in_the_step(ctx, oracle):
     for k, pl in enumerate((P, V, RC, RD)):
         assert_close(sysm.download(0, pl), chunk[(0, 1, 3, 4)[k]], "plane %d after the plain steps" % pl, life_exact=(k == 0))
     sysm.close(); eng.close()
+
+
+def test_chunks_come_from_the_engines_pool_zero_filled(ctx):
+    """r05: chunks are carved out of slabs and recycled through the engine's pool (the reference keeps its released buffer sets for reuse,
+    ParticleEngine.cs:145-170,402-419).  A recycled chunk must be indistinguishable from a new one -- every plane zero --, chunks of one
+    slab must not overlap, and systems of one engine share the pool."""
+    import numpy as np
+    from illuminant_amd import abi, native, scenes
+    cs = 32
+    n = cs * cs
+    eng = native.Engine(ctx, cs, scenes.randomness_table(7))
+    a, b = native.System(eng), native.System(eng)
+    marks = {}
+    for k in range(11):                      # more than one slab of 8
+        s = a if k % 2 == 0 else b
+        idx = s.add_chunk()
+        for plane in range(5):
+            assert not s.download(s.chunk_count() - 1, plane).any(), "a fresh chunk is not zero"
+        fill = np.full((n, 4), float(k + 1), np.float32)
+        for plane in (abi.PLANE_POSITION, abi.PLANE_VELOCITY, abi.PLANE_ATTRIBUTES, abi.PLANE_RENDER_COLOR, abi.PLANE_RENDER_DATA):
+            s.upload(s.chunk_count() - 1, plane, fill + plane)
+        marks[(id(s), s.chunk_count() - 1)] = float(k + 1)
+    for (sid, c), v in marks.items():        # nobody's chunk was overwritten by a neighbour's upload
+        s = a if sid == id(a) else b
+        for plane in range(5):
+            assert (s.download(c, plane) == v + plane).all()
+    # recycle: remove three chunks of a, add five to b -- the first three come back from the pool
+    for _ in range(3):
+        a.remove_chunk(0)
+    for _ in range(5):
+        b.add_chunk()
+        for plane in range(5):
+            assert not b.download(b.chunk_count() - 1, plane).any(), "a recycled chunk is not zero"
+    a.close()                                # its chunks go back too
+    c2 = native.System(eng)
+    for _ in range(4):
+        c2.add_chunk()
+        assert not c2.download(c2.chunk_count() - 1, abi.PLANE_POSITION).any()
+    c2.close(); b.close(); eng.close()
