@@ -26,6 +26,7 @@ def rel_err(got, want):
 
 
 bad_light, bad_step, worst_l, worst_s = [], [], 0.0, 0.0
+group_scenes = 0
 bad_float, floor_needed, elements_compared = [], 0, 0
 bad_gbuffer, gbuffer_texels = [], 0
 worst_where = None
@@ -54,6 +55,40 @@ for seed in range(first, first + count):
         if not np.array_equal(lm.download(), got):
             bad_light.append((seed, "strips under another split differ from the one-launch frame", cuts))
     ctx.set_light_split(0)
+    # (r05) every 6th scene also through a GROUP of 2-4 members on this device under one of the exchange modes -- peer copies, the
+    # store mode (the kernel's final store into every member's copy), the asynchronous exchange over a ring of two lightmaps, and a
+    # sibling context reading the first one's field: every copy of the frame must equal the one-launch frame bit for bit
+    if seed % 6 == 0:
+        grng = np.random.default_rng(seed + 31337)
+        members = int(grng.integers(2, 5))
+        mode = int(grng.integers(0, 4))
+        group_scenes += 1
+        if mode == 3:
+            sib = ctx.sibling()
+            lm2 = native.Lightmap(sib, w, h, abi.LIGHTMAP_FLOAT4)
+            native.render_sphere_lights(sib, lights, env, dfu, None, sdf, (0.05, 0.05, 0.05, 1.0), lm2)
+            if not np.array_equal(lm2.download(), got):
+                bad_light.append((seed, "a sibling context's frame through the borrowed field differs"))
+            lm2.close(); sib.close()
+        else:
+            g = native.Group([0] * members)
+            gsdfs = [native.DistanceFieldTexture(c, atlas, fmt) for c in g.contexts]
+            ring = [native.GroupLightmap(g, w, h, abi.LIGHTMAP_FLOAT4) for _ in range(2 if mode == 2 else 1)]
+            gather = (native.GATHER_PEER, native.GATHER_STORE, native.GATHER_PEER | native.GATHER_ASYNC)[mode]
+            for k in range(len(ring) * 2):
+                g.render_sphere_lights(lights, env, dfu, None, gsdfs, (0.05, 0.05, 0.05, 1.0), ring[k % len(ring)], gather)
+            for glm in ring:
+                glm.wait()
+            g.sync()
+            for glm in ring:
+                for i in range(members):
+                    if not np.array_equal(glm.download(i), got):
+                        bad_light.append((seed, "group of %d, exchange mode %d: member %d's frame differs" % (members, mode, i)))
+            for glm in ring:
+                glm.close()
+            for x in gsdfs:
+                x.close()
+            g.close()
     want, ost = oracle.render_sphere_lights(lights, env, dfu, None, oracle.make_texture(atlas, fmt), (0.05, 0.05, 0.05, 1.0), w, h, 0, h, want_stats=True)
     lm.close(); sdf.close()
     e = float((np.abs(got - want) / np.maximum(np.abs(want), 1.0)).max())
@@ -303,7 +338,7 @@ print("field generation: %d scenes with differing codes of %d, %d of them with h
 for b in bad_field[:10]: print("   ", b)
 print("rasteriser: %d scenes out of bounds; most edge pixels that flipped in one frame: %d" % (len(bad_raster), raster_worst))
 for b in bad_raster[:10]: print("   ", b)
-print("lighting: %d scenes with differing statistics or > 1e-4 error; worst relative error %.3g" % (len(bad_light), worst_l))
+print("lighting: %d scenes with differing statistics or > 1e-4 error; worst relative error %.3g (%d of the scenes also through a group / a sibling context: peer, store, asynchronous exchange)" % (len(bad_light), worst_l, group_scenes))
 for b in bad_light[:10]: print("   ", b)
 print("collision update: %d problems in %d steps (%.1f M elements; %d particles bounced or were redirected); liveness and life bit-identical, floats by the suite's criterion"
       % (len(bad_collision), collision_steps, collision_elements / 1e6, collided_total))
