@@ -555,6 +555,11 @@ def main():
 
     if native.device_count() <= 0:
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    one_gpu_stand_in = bool(os.environ.get("ILM_BENCH_ONE_GPU"))
+    if one_gpu_stand_in:
+        # TEST HOOK (tests/test_two_ranks_one_gpu.py): every rank on device 0, the exchange through tests/fake_rccl.cpp (ILM_RCCL_LIB) -- the
+        # whole N > 1 branch executed at world size > 1 on the build box's one GPU.  The record says so; its numbers mean nothing.
+        local_rank = 0
     if local_rank >= native.device_count():
         raise SystemExit("bench.py: rank %d wants GPU %d but this box has %d GPU(s)" % (rank, local_rank, native.device_count()))
 
@@ -642,6 +647,8 @@ def main():
                    "particles_per_gpu": live_slots, "spawned_per_gpu_in_run": int(spawned), "live_particles_per_step_avg": round(live_avg, 1),
                    "chunks_at_end": len(ps.Chunks), "parallelism": "chunks sharded, %d rank(s)" % world,
                    "ranks": world, "rccl_communicator_ranks": comm_ranks,
+                   **({"one_gpu_stand_in": "ILM_BENCH_ONE_GPU: every rank on device 0 behind a stand-in for RCCL -- a functional run of the N > 1 branch, NOT a measurement"}
+                      if one_gpu_stand_in else {}),
                    "lightmap_exchange": ("ilm_group_lightmap_gather (RCCL all-gather in place, csrc/group.hip)" if group is not None else "none (one GPU)")},
         "timed_blocks": {"blocks": n_blocks, "steps_per_block": args.steps, "headline": "median block",
                          "value_min": round(by_value[0]["value"], 2), "value_median": round(med["value"], 2), "value_max": round(by_value[-1]["value"], 2),

@@ -20,6 +20,7 @@ typedef struct { char internal[128]; } ncclUniqueId;
 typedef enum { ncclSuccess = 0 } ncclResult_t;
 typedef enum { ncclInt8 = 0 } ncclDataType_t;
 
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -64,10 +65,13 @@ Rccl& rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char* names[] = { "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+        // ILM_RCCL_LIB: another library with the same eleven entry points -- tests/fake_rccl.cpp, the shared-memory stand-in that lets
+        // several rank processes share the build box's ONE GPU (RCCL itself refuses that); never set in production
+        const char* override_path = getenv("ILM_RCCL_LIB");
+        const char* names[] = { override_path ? override_path : "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
         for (const char* n : names) {
             r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-            if (r.lib) break;
+            if (r.lib || override_path) break;
         }
         if (!r.lib) { snprintf(r.why, sizeof(r.why), "librccl.so not found: %s", dlerror()); return; }
 #define ILM_BIND(field, symbol)                                                                      \
