@@ -142,6 +142,7 @@ def parse_args():
                                                                  "a 5 s device-utilisation sampler sees it); 0: as --light-ms")
     ap.add_argument("--no-lighting", action="store_true")
     ap.add_argument("--no-cfg4", action="store_true", help="skip the 8 M-particle (cfg4 per-GPU share) measurement")
+    ap.add_argument("--no-store-mode-row", action="store_true", help="N > 1: skip the store-mode frames (IPC-mapped buffers of the other ranks) of scaling_detail")
     ap.add_argument("--no-cfg4-64m", action="store_true", help="skip cfg4 whole on one GPU (64 chunks of 1024^2 = 67 M particles, 5.4 GB; N > 1: measured by rank 0 alone)")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the SURVEY 8f measurements (read-back, particle lights, resolve)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -967,6 +968,42 @@ def main():
                     glm_b.close()
                 except Exception as e_:      # noqa: BLE001 -- the serial figures above stand
                     frame_scaling["pipelined_exchange"] = {"error": "%s: %s" % (type(e_).__name__, e_)}
+                # The same frames with NO copy phase (r05, ILM_GATHER_STORE across processes): every rank maps the other ranks' buffers
+                # through IPC handles (a collective: every rank arms or none does) and the light kernel's final store writes its strip
+                # into every rank's copy over xGMI while the strip runs; what is left of the exchange is the fence (an 8-byte collective)
+                # in front of the strips (readers of the old frame) and behind them.  Recorded beside the serial figures; not fatal.
+                if not args.no_store_mode_row:
+                    try:
+                        for m_ in glm.members:
+                            m_.clear()
+                        glm.store_mode(True)
+                        try:
+                            for _ in range(3):
+                                glm.gather(native.GATHER_STORE); r.RenderLighting(1.0, row_begin, row_end, False); glm.gather(native.GATHER_STORE)
+                            ctx.Sync(); barrier()
+                            t0 = time.perf_counter()
+                            for _ in range(light_frames):
+                                glm.gather(native.GATHER_STORE)
+                                r.RenderLighting(1.0, row_begin, row_end, False)
+                                glm.gather(native.GATHER_STORE)
+                            ctx.Sync(); barrier()
+                            store_ms = max_over_ranks(time.perf_counter() - t0) / light_frames * 1e3
+                            store_strip_ms = ranks.doubles(time_strip(row_begin, row_end, n_s))
+                            glm.gather(native.GATHER_STORE); ctx.Sync(); barrier()
+                            stored_ = glm.download(0).view(np.uint16).copy()
+                        finally:
+                            glm.store_mode(False)
+                        r.RenderLighting(1.0, row_begin, row_end, False)
+                        glm.gather(native.GATHER_RCCL); ctx.Sync(); barrier()
+                        same_ = bool(ranks.sum(0.0 if np.array_equal(stored_, glm.download(0).view(np.uint16)) else 1.0) == 0.0)
+                        frame_scaling["store_mode"] = {
+                            "composited_frame_ms": round(store_ms, 4), "vs_serial": round(store_ms / frame_ms, 4), "speedup_vs_one_gpu_frame": round(one_gpu_ms / store_ms, 3),
+                            "strip_ms_max": round(max(store_strip_ms), 4), "strip_ms": [round(t, 4) for t in store_strip_ms],
+                            "every_rank_holds_the_frame_of_the_rccl_exchange": same_,
+                            "how": "ilm_group_lightmap_store_mode (IPC-mapped buffers of the other ranks); per frame: fence, strip with mirror stores, fence (ilm_group_lightmap_gather(ILM_GATHER_STORE))"}
+                        del stored_
+                    except Exception as e_:      # noqa: BLE001 -- the serial figures above stand
+                        frame_scaling["store_mode"] = {"error": "%s: %s" % (type(e_).__name__, e_)}
                 frames_scaling[pin] = frame_scaling
             my_px = (row_end - row_begin) * w
             # this rank's launch: SDF samples + the G-buffer texel of every pixel (Vector4) + lightmap write (half4) + light records

@@ -67,6 +67,7 @@ struct Ctx {
     // against the owner's writes).  `family` = the address the first of them had; 0 = no siblings.
     uintptr_t family = 0;
     int children = 0;            // live engines / distance fields / G-buffers / lightmaps: the context cannot be destroyed under them
+    std::vector<struct Lightmap*> mirrored;      // this context's lightmaps with an armed store-mode table (lightmap_set_mirrors), for their aliases
     // Two streams.  Everything is ordered on `stream_`; ilm_system_step may put the second half of a large step's chunk range on `aux`
     // (chunks never interact, ParticleSystem.cs:743-745: one half's launch tail is covered by the other half's launch, run_step).
     // The halves are only joined when something else needs them: every entry point takes its stream from main(), which makes
@@ -1133,6 +1134,8 @@ int32_t lightmap_set_mirrors(IlmHandle h, void* const* buffers, int count) {
     if (count < 0 || count > 64 || (count > 0 && !buffers)) return fail(ILM_ERR_INVALID_ARGUMENT, "bad mirror list");
     HIP_TRY(hipSetDevice(m->ctx->device));
     HIP_TRY(hipStreamSynchronize(m->ctx->main()));
+    std::vector<Lightmap*>& armed = m->ctx->mirrored;
+    armed.erase(std::remove(armed.begin(), armed.end(), m), armed.end());
     if (count == 0) {
         if (m->d_mirrors) HIP_TRY(hipFree(m->d_mirrors));
         m->d_mirrors = nullptr; m->mirror_count = 0;
@@ -1141,7 +1144,21 @@ int32_t lightmap_set_mirrors(IlmHandle h, void* const* buffers, int count) {
     if (!m->d_mirrors) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_mirrors), sizeof(void*) * 64));
     HIP_TRY(hipMemcpy(m->d_mirrors, buffers, sizeof(void*) * (size_t)count, hipMemcpyHostToDevice));
     m->mirror_count = count;
+    armed.push_back(m);
     return ILM_OK;
+}
+
+// The store-mode table a light pass into `m` uses.  The table belongs to the BUFFER, not to the handle: a lightmap object that aliases an
+// armed lightmap's texels on the same context (ilm_lightmap_create with external_device_ptr = ilm_lightmap_device_ptr of a group
+// lightmap's member: what a host that wraps the group's buffer in its own renderer does, the host mirror among them) renders the same
+// frame on the same stream, and a strip rendered through it that stayed at home would leave every other member with a hole.
+static const Lightmap* mirror_table_of(const Lightmap* m) {
+    if (m->d_mirrors && m->mirror_count > 0) return m;
+    if (m->external)
+        for (const Lightmap* e : m->ctx->mirrored)
+            // (a member's object is slot_rows * world rows tall, the frame and its alias may be shorter: same base, same pitch)
+            if (e->texels == m->texels && e->width == m->width && m->height <= e->height && e->format == m->format && e->d_mirrors && e->mirror_count > 0) return e;
+    return nullptr;
 }
 }  // namespace ilm
 
@@ -2470,6 +2487,7 @@ int32_t ilm_lightmap_destroy(IlmHandle h) {
     (void)hipStreamSynchronize(m->ctx->main());
     if (m->texels && !m->external) (void)hipFree(m->texels);
     if (m->d_mirrors) (void)hipFree(m->d_mirrors);
+    m->ctx->mirrored.erase(std::remove(m->ctx->mirrored.begin(), m->ctx->mirrored.end(), m), m->ctx->mirrored.end());
     retire_handle(m);
     delete m;
     return ILM_OK;
@@ -2722,7 +2740,7 @@ int32_t fill_light_launch(Ctx* c, const IlmEnvironment* env, const IlmDistanceFi
     a->tile_map = light_tile_map();
     a->tile_macro = light_tile_macro_for(m->width, row_end - row_begin);
     a->split = 1; a->partials = nullptr; a->tickets = nullptr; a->group_order = nullptr;
-    a->mirrors = m->d_mirrors; a->mirror_count = m->d_mirrors ? m->mirror_count : 0;
+    { const Lightmap* t = mirror_table_of(m); a->mirrors = t ? t->d_mirrors : nullptr; a->mirror_count = t ? t->mirror_count : 0; }
     return ILM_OK;
 }
 }  // namespace
@@ -3267,7 +3285,7 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
         a.stats = c->d_stats;
     }
     a.split = 1; a.partials = nullptr; a.tickets = nullptr; a.group_order = nullptr;
-    a.mirrors = m->d_mirrors; a.mirror_count = m->d_mirrors ? m->mirror_count : 0;      // store-mode exchange of a group lightmap
+    { const Lightmap* t = mirror_table_of(m); a.mirrors = t ? t->d_mirrors : nullptr; a.mirror_count = t ? t->mirror_count : 0; }      // store-mode exchange of a group lightmap
     { const int32_t rc = plan_light_split(c, &a); if (rc != ILM_OK) return rc; }
     { const int32_t rc = plan_group_order(c, &a, lights, light_count, 16 * a.tile_macro); if (rc != ILM_OK) return rc; }
     c->last_light_blocks = light_launch_blocks(a); c->last_light_split = a.split; c->last_light_macro = (a.tile_map == 4) ? a.tile_macro : 0;

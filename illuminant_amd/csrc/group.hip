@@ -126,6 +126,7 @@ struct GroupLightmap {
     std::vector<void*> buffers;             // per local member: world * slot_rows rows
     std::vector<IlmHandle> lightmaps;       // per local member: lightmap object aliasing the buffer
     bool store_mode = false;                // ILM_GATHER_STORE armed: every member's light passes also store into the other members' buffers
+    std::vector<void*> ipc_peers;           // store mode of a group that spans processes: the other ranks' buffers, IPC-mapped (hipIpcOpenMemHandle)
     std::vector<hipEvent_t> xdone;          // ILM_GATHER_ASYNC: per local member, "the exchange queued last has finished" (ilm_group_lightmap_wait)
     std::vector<bool> xpending;
 };
@@ -322,8 +323,20 @@ int32_t exchange_ranges(Group* g, void* const* buffers, const std::vector<size_t
     return ILM_OK;
 }
 
+int32_t host_all_gather(Group* g, const void* local, void* out, size_t bytes);
+int32_t ensure_counts_scratch(Group* g, size_t total);
+
 // Every local member's stream waits for everything queued on every other member's stream so far (events; nothing blocks the host).
+// A group that spans processes has no common events: there the fence is an 8-byte in-place all-gather on the context streams -- a rank's
+// collective cannot complete before every rank has started its own, which its stream does only after the work queued in front of it.
 int32_t fence_members(Group* g) {
+    if (g->rank_mode) {
+        if (g->world < 2) return ILM_OK;
+        const int32_t rc = ensure_counts_scratch(g, 8u * (size_t)g->world);
+        if (rc != ILM_OK) return rc;
+        void* bufs[1] = { g->d_counts };
+        return all_gather(g, bufs, 8, ILM_GATHER_RCCL);
+    }
     const int n = g->n_local;
     if (n < 2) return ILM_OK;
     for (int i = 0; i < n; i++) {
@@ -342,15 +355,64 @@ int32_t fence_members(Group* g) {
 // buffers of the OTHER members (lightmap_set_mirrors): a light pass stores each texel of its strip at the same offset of every copy of
 // the frame -- its own and, through the peer mapping (hipDeviceEnablePeerAccess, make_members), the others' over xGMI: n stores of 8 B
 // per pixel and member instead of a copy phase behind the strip.  What is left of the "gather" is ordering: a member's later readers of
-// the frame wait for the other members' passes (fence_members).  In-process groups only: a buffer of another PROCESS is not addressable
-// here without an IPC mapping (not built; groups that span processes exchange with RCCL).
+// the frame wait for the other members' passes (fence_members).  A group that spans processes maps the other ranks' buffers through IPC
+// handles instead (below) and fences with an 8-byte collective.
 int32_t set_store_mode(GroupLightmap* m, bool enable) {
     Group* g = m->group;
     if (enable == m->store_mode) return ILM_OK;
-    if (enable) {
-        if (g->rank_mode) return api_fail(ILM_ERR_STATE, "ILM_GATHER_STORE needs every member in this process (peer-mapped buffers): a group that spans processes gathers with RCCL");
-        if (!g->peers_ok) return api_fail(ILM_ERR_STATE, "ILM_GATHER_STORE needs peer access between every pair of the group's devices");
+    if (g->rank_mode) {
+        // One process per GPU: the other ranks' buffers are mapped into this process through IPC handles (hipIpcGetMemHandle of the own
+        // buffer, the 64-byte handles all-gathered, hipIpcOpenMemHandle of the others': the mapping RCCL's own peer transport uses).  A
+        // COLLECTIVE, like set_strips: every rank arms or nobody does.
+        const int world = g->world, me = g->first_rank;
+        HIP_TRY(hipSetDevice(g->devices[0]));
+        if (!enable) {
+            int32_t rc = lightmap_set_mirrors(m->lightmaps[0], nullptr, 0);          // (drains this rank's stream: its stores into the others are done)
+            for (void* p : m->ipc_peers) if (p) (void)hipIpcCloseMemHandle(p);
+            m->ipc_peers.clear();
+            m->store_mode = false;
+            // nobody frees a buffer another rank may still be storing into: all ranks have drained and unmapped when this returns
+            uint64_t token = 0; std::vector<uint64_t> all((size_t)world, 0);
+            const int32_t rb = host_all_gather(g, &token, all.data(), sizeof(uint64_t));
+            return rc != ILM_OK ? rc : rb;
+        }
+        static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle travels as 64 bytes");
+        std::vector<hipIpcMemHandle_t> handles((size_t)world);
+        hipIpcMemHandle_t mine;
+        uint64_t ok = 1;
+        if (world > 1 && hipIpcGetMemHandle(&mine, m->buffers[0]) != hipSuccess) { (void)hipGetLastError(); ok = 0; memset(&mine, 0, sizeof(mine)); }
+        if (world > 1) {
+            handles[(size_t)me] = mine;
+            const int32_t rc = host_all_gather(g, &handles[(size_t)me], handles.data(), sizeof(hipIpcMemHandle_t));
+            if (rc != ILM_OK) return rc;
+        }
+        std::vector<void*> peers;
+        for (int r = 0; r < world && ok; r++) {
+            if (r == me) continue;
+            void* p = nullptr;
+            if (hipIpcOpenMemHandle(&p, handles[(size_t)r], hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); ok = 0; break; }
+            peers.push_back(p);
+        }
+        // every rank learns whether every rank could map every buffer
+        std::vector<uint64_t> verdicts((size_t)world, 0);
+        verdicts[(size_t)me] = ok;
+        if (world > 1) {
+            const int32_t rc = host_all_gather(g, &verdicts[(size_t)me], verdicts.data(), sizeof(uint64_t));
+            if (rc != ILM_OK) { for (void* p : peers) (void)hipIpcCloseMemHandle(p); return rc; }
+        }
+        int failed = -1;
+        for (int r = 0; r < world; r++) if (!verdicts[(size_t)r] && failed < 0) failed = r;
+        if (failed >= 0) {
+            for (void* p : peers) (void)hipIpcCloseMemHandle(p);
+            return api_fail(ILM_ERR_STATE, "ILM_GATHER_STORE: rank %d could not map the other ranks' lightmaps through IPC handles: no rank arms the mode", failed);
+        }
+        const int32_t rc = lightmap_set_mirrors(m->lightmaps[0], peers.data(), (int)peers.size());
+        if (rc != ILM_OK) { for (void* p : peers) (void)hipIpcCloseMemHandle(p); return rc; }
+        m->ipc_peers = peers;
+        m->store_mode = true;
+        return ILM_OK;
     }
+    if (enable && !g->peers_ok) return api_fail(ILM_ERR_STATE, "ILM_GATHER_STORE needs peer access between every pair of the group's devices");
     for (int i = 0; i < g->n_local; i++) {
         std::vector<void*> others;
         for (int j = 0; j < g->n_local && enable; j++)
@@ -445,6 +507,18 @@ int32_t wait_lightmap_exchange(GroupLightmap* m) {
     return ILM_OK;
 }
 
+// device scratch of the small collectives (member 0's device)
+int32_t ensure_counts_scratch(Group* g, size_t total) {
+    HIP_TRY(hipSetDevice(g->devices[0]));
+    if (total > g->counts_bytes) {
+        if (g->d_counts) { HIP_TRY(hipStreamSynchronize(g->stream((size_t)0))); HIP_TRY(hipFree(g->d_counts)); g->d_counts = nullptr; g->counts_bytes = 0; }
+        const size_t cap = total < 4096 ? 4096 : total;
+        HIP_TRY(hipMalloc(&g->d_counts, cap));
+        g->counts_bytes = cap;
+    }
+    return ILM_OK;
+}
+
 // Small host payloads (liveness counters, timings): rank r's `bytes` land at out + r * bytes on every process.  Members of this
 // process are copied; a group that spans processes stages its slot in device memory and all-gathers it with RCCL.  Synchronises.
 int32_t host_all_gather(Group* g, const void* local, void* out, size_t bytes) {
@@ -454,13 +528,7 @@ int32_t host_all_gather(Group* g, const void* local, void* out, size_t bytes) {
     if (o + mine != local) memmove(o + mine, local, bytes * (size_t)g->n_local);
     if (!(g->rank_mode && g->world > 1)) return ILM_OK;
     const size_t total = bytes * (size_t)g->world;
-    HIP_TRY(hipSetDevice(g->devices[0]));
-    if (total > g->counts_bytes) {
-        if (g->d_counts) { HIP_TRY(hipStreamSynchronize(g->stream((size_t)0))); HIP_TRY(hipFree(g->d_counts)); g->d_counts = nullptr; g->counts_bytes = 0; }
-        const size_t cap = total < 4096 ? 4096 : total;
-        HIP_TRY(hipMalloc(&g->d_counts, cap));
-        g->counts_bytes = cap;
-    }
+    { const int32_t rc = ensure_counts_scratch(g, total); if (rc != ILM_OK) return rc; }
     char* d = static_cast<char*>(g->d_counts);
     HIP_TRY(hipMemcpyAsync(d + mine, o + mine, bytes, hipMemcpyHostToDevice, g->stream((size_t)0)));
     void* bufs[1] = { g->d_counts };

@@ -953,7 +953,7 @@ enum {
     ILM_GATHER_ASYNC = 0x100, /* flag, OR'ed onto ILM_GATHER_PEER / ILM_GATHER_RCCL (r05): the exchange runs on a second stream of every member,
                              behind the strip just queued, and the member's context stream goes on -- with the next frame's strip into ANOTHER
                              group lightmap (a ring of two, the reference's BufferRing).  ilm_group_lightmap_wait orders later work behind it. */
-    ILM_GATHER_STORE = 3  /* in-process groups (r05): no copy phase at all -- the light kernel's final store writes every texel of a member's
+    ILM_GATHER_STORE = 3  /* (r05; in-process groups through peer access, groups that span processes through IPC-mapped buffers): no copy phase at all -- the light kernel's final store writes every texel of a member's
                              strip at the same offset of EVERY member's copy of the frame (the others' buffers peer-mapped over xGMI:
                              n stores of 8 B per pixel), so the exchange overlaps the strip; what remains of the gather is a fence */
 };
@@ -1011,8 +1011,13 @@ int32_t ilm_group_lightmap_wait(IlmHandle group_lightmap);
  * ilm_group_lightmap_gather(ILM_GATHER_STORE) is the fence that orders each member's later readers behind the other members' passes --
  * call it after the strips of a frame, and again in front of the next frame's strips when readers of the old frame may still be queued
  * (a pass overwrites the other members' copies as it runs).  ilm_group_render_sphere_lights(..., ILM_GATHER_STORE) does all of this
- * itself for one call.  ILM_ERR_STATE for groups that span processes (their buffers are not peer-mapped here: RCCL) or without peer
- * access between the devices.  Synchronises the members' streams.  The reference has one device and one lightmap
+ * itself for one call.  In-process groups need peer access between their devices (ILM_ERR_STATE otherwise).  For a group that spans
+ * processes the call is a COLLECTIVE (arming and disarming alike; destroying an armed lightmap disarms it): every rank exports its buffer
+ * as an IPC handle (hipIpcGetMemHandle), the handles are all-gathered, every rank maps the others' (hipIpcOpenMemHandle) -- and either
+ * every rank arms or none does (ILM_ERR_STATE on all); the fence of ILM_GATHER_STORE is then an 8-byte collective on the context streams.
+ * The table follows the BUFFER: a lightmap object the host made around a member's texels on the member's context (ilm_lightmap_create
+ * with external_device_ptr = ilm_lightmap_device_ptr(member)) is mirrored exactly like the member handle itself.
+ * Synchronises the members' streams.  The reference has one device and one lightmap
  * (Illuminant/Lighting/LightingRenderer.cs:1004-1010): every member still ends with that one composited frame. */
 int32_t ilm_group_lightmap_store_mode(IlmHandle group_lightmap, int32_t enable);
 int32_t ilm_group_lightmap_destroy(IlmHandle group_lightmap);

@@ -84,6 +84,26 @@ def main():
     g.sync()
     for x in ring:
         assert np.array_equal(x.download(0).view(np.uint16), want.view(np.uint16)), "rank %d: asynchronous exchange" % rank
+    # 2b. the store mode across processes: the other ranks' buffers mapped through IPC handles, the kernel's final store writes this
+    #     rank's strip into every rank's copy, the fence is a tiny collective; composite call and host-driven form, then disarmed
+    for m in glm.members:
+        m.clear()
+    g.sync(); g.host_all_gather(b"\0" * 8)
+    g.render_sphere_lights(lights, env, dfu, None, [sdf], AMBIENT, glm, native.GATHER_STORE)
+    g.sync(); g.host_all_gather(b"\0" * 8)
+    assert np.array_equal(glm.download(0).view(np.uint16), want.view(np.uint16)), "rank %d: store mode, composite call" % rank
+    glm.store_mode(True)
+    for m in glm.members:
+        m.clear()
+    g.sync(); g.host_all_gather(b"\0" * 8)
+    b, e = glm.strips[rank]
+    for _ in range(3):
+        glm.gather(native.GATHER_STORE)
+        native.render_sphere_lights(c, lights, env, dfu, None, sdf, AMBIENT, glm.members[0], b, e)
+        glm.gather(native.GATHER_STORE)
+    g.sync(); g.host_all_gather(b"\0" * 8)
+    assert np.array_equal(glm.download(0).view(np.uint16), want.view(np.uint16)), "rank %d: store mode, host-driven" % rank
+    glm.store_mode(False)
     # 3. ilm_group_lightmap_set_strips is ALWAYS a collective: ranks that disagree, a rank with a malformed table, a rank that resets while the
     #    others install -- every rank fails (nobody hangs, nobody installs), the table stays what it was
     before = native_strips(glm)

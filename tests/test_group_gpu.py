@@ -346,13 +346,18 @@ def test_store_mode_composites_the_frame_without_a_gather(ctx, members, fmt, bal
         # 2. host-driven: armed lightmap, every member renders its own strip, the fence is the gather; then a second light group on top
         glm.store_mode(True)
         few = (abi.LightVertex * 3)(*[lights[i] for i in (2, 9, 17)])
+        # (the second group of member 0 goes through an ALIAS of its buffer -- a lightmap object of the host's own around
+        # ilm_lightmap_device_ptr, what a renderer that wraps the group's buffer holds: the store-mode table follows the buffer)
+        alias = native.Lightmap(g.contexts[0], w, h, fmt, external_ptr=glm.members[0].device_ptr())
         for group_lights, ambient in ((lights, AMBIENT), (few, None)):
             glm.gather(native.GATHER_STORE)                      # (readers of the previous pass are done before anybody overwrites)
             for i in range(members):
                 b, e = glm.strips[i]
-                native.render_sphere_lights(g.contexts[i], group_lights, env, dfu, None, sdfs[i], ambient, glm.members[i], b, e)
+                target = alias if (i == 0 and ambient is None) else glm.members[i]
+                native.render_sphere_lights(g.contexts[i], group_lights, env, dfu, None, sdfs[i], ambient, target, b, e)
             glm.gather(native.GATHER_STORE)
         g.sync()
+        alias.close()
         lm = native.Lightmap(ctx, w, h, fmt)
         sdf0 = native.DistanceFieldTexture(ctx, atlas, abi.SDF_FP16)
         native.render_sphere_lights(ctx, lights, env, dfu, None, sdf0, AMBIENT, lm)
@@ -404,14 +409,21 @@ def test_store_mode_composites_the_frame_without_a_gather(ctx, members, fmt, bal
         g.close()
 
 
-def test_store_mode_is_refused_where_buffers_are_not_peer_mapped(ctx):
-    uid = native.Group.unique_id()
-    g = native.Group.rank(0, 0, 1, uid)
-    glm = native.GroupLightmap(g, 64, 48)
-    with pytest.raises(native.IlluminantError) as e:
-        glm.store_mode(True)
-    assert e.value.code == abi.ERR_STATE and "spans processes" in str(e.value)
-    glm.close(); g.close()
+def test_store_mode_of_a_rank_group_at_world_one(ctx):
+    """A group that spans processes arms the store mode through IPC handles of the ranks' buffers (a collective; world sizes 2 and 3 on this
+    GPU: tests/test_two_ranks_one_gpu.py); with one rank there is nobody to map and the frame is simply the rank's own."""
+    layout, atlas, dfu, lights, w, h = small_scene()
+    env = scenes.environment()
+    want, _ = single_context_frame(ctx, lights, env, dfu, atlas, abi.SDF_UNORM16, w, h)
+    g = native.Group.rank(0, 0, 1, native.Group.unique_id())
+    sdf = native.DistanceFieldTexture(g.contexts[0], atlas, abi.SDF_UNORM16)
+    glm = native.GroupLightmap(g, w, h)
+    glm.store_mode(True)
+    g.render_sphere_lights(lights, env, dfu, None, [sdf], AMBIENT, glm, native.GATHER_STORE)
+    g.sync()
+    assert np.array_equal(glm.download(0), want)
+    glm.store_mode(False)
+    glm.close(); sdf.close(); g.close()
 
 
 @pytest.mark.parametrize("members,balanced", [(2, False), (3, True), (5, True)])

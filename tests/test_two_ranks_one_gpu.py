@@ -75,3 +75,4 @@ def test_bench_runs_its_whole_n_gpu_branch_at_two_ranks(fake_rccl):
         fs = sd["frames"][pin]
         assert len(fs["strip_ms"]) == 2 and fs["strip_ms_max"] >= max(fs["strip_ms"]) - 1e-9 and fs["exchange_ms"] > 0 and fs["one_gpu_frame_ms"] > 0
         assert fs["pipelined_exchange"].get("both_lightmaps_hold_the_same_frame") is True, fs["pipelined_exchange"]
+        assert fs["store_mode"].get("every_rank_holds_the_frame_of_the_rccl_exchange") is True and fs["store_mode"]["composited_frame_ms"] > 0, fs["store_mode"]
