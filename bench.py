@@ -995,11 +995,16 @@ def main():
                             glm.store_mode(False)
                         r.RenderLighting(1.0, row_begin, row_end, False)
                         glm.gather(native.GATHER_RCCL); ctx.Sync(); barrier()
-                        same_ = bool(ranks.sum(0.0 if np.array_equal(stored_, glm.download(0).view(np.uint16)) else 1.0) == 0.0)
+                        now_ = glm.download(0).view(np.uint16)
+                        bad_rows_ = np.nonzero((stored_.reshape(h, -1) != now_.reshape(h, -1)).any(axis=1))[0]
+                        rows_differing_ = [[int(v) for v in t] for t in zip(ranks.doubles(float(len(bad_rows_))), ranks.doubles(float(bad_rows_[0]) if len(bad_rows_) else -1.0),
+                                                                          ranks.doubles(float(bad_rows_[-1]) if len(bad_rows_) else -1.0),
+                                                                          ranks.doubles(float((stored_ != now_).sum())))]
+                        same_ = bool(ranks.sum(0.0 if np.array_equal(stored_, now_) else 1.0) == 0.0)
                         frame_scaling["store_mode"] = {
                             "composited_frame_ms": round(store_ms, 4), "vs_serial": round(store_ms / frame_ms, 4), "speedup_vs_one_gpu_frame": round(one_gpu_ms / store_ms, 3),
                             "strip_ms_max": round(max(store_strip_ms), 4), "strip_ms": [round(t, 4) for t in store_strip_ms],
-                            "every_rank_holds_the_frame_of_the_rccl_exchange": same_,
+                            "every_rank_holds_the_frame_of_the_rccl_exchange": same_, "rows_differing_per_rank_count_first_last_elements": rows_differing_,
                             "how": "ilm_group_lightmap_store_mode (IPC-mapped buffers of the other ranks); per frame: fence, strip with mirror stores, fence (ilm_group_lightmap_gather(ILM_GATHER_STORE))"}
                         del stored_
                     except Exception as e_:      # noqa: BLE001 -- the serial figures above stand

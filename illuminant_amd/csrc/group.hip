@@ -107,6 +107,10 @@ struct Group {
     bool duplicates = false;                // two members share a device (RCCL refuses that)
     bool peers_ok = true;                   // every pair of distinct local devices can address each other's memory (store mode needs it)
     void* d_counts = nullptr; size_t counts_bytes = 0;     // scratch of ilm_group_live_counts (rank mode), on member 0's device
+    // IPC mappings of other ranks' buffers whose group lightmap is gone: unmapped when the GROUP goes, not before (set_store_mode)
+    std::vector<void*> ipc_retired;
+    std::vector<void*> ipc_decoys;          // (ILM_EXP_IPC_BOGUS_MAPPING, the proof's negative control)
+    uint32_t ipc_proofs = 0;                // serial number of prove_ipc_mappings (the same on every rank: a collective)
     // ILM_GATHER_ASYNC: a second stream per local member that carries the exchanges, so that the member's context stream can go on with
     // the next frame's strip (created on first use); its own scratch events for the peer fan-out
     std::vector<hipStream_t> xstream;
@@ -177,6 +181,12 @@ int32_t make_members(Group* g) {
 }
 
 void release_group(Group* g) {
+    if (!g->ipc_retired.empty()) {
+        (void)hipSetDevice(g->devices[0]);
+        for (void* p : g->ipc_retired) if (p) (void)hipIpcCloseMemHandle(p);
+        g->ipc_retired.clear();
+    }
+    for (void* p : g->ipc_decoys) { (void)hipSetDevice(g->devices[0]); (void)hipFree(p); }
     for (size_t i = 0; i < g->comms.size(); i++)
         if (g->comms[i] && rccl().ok) {
             (void)hipSetDevice(g->devices[i]);
@@ -351,6 +361,50 @@ int32_t fence_members(Group* g) {
     return ILM_OK;
 }
 
+// Proof that every mapping made by hipIpcOpenMemHandle addresses the buffer it was exported for (a collective, once per group lightmap,
+// after every rank has mapped every buffer): rank r writes a 16-byte stamp { serial, r } into slot r of the first and of the last
+// 16 * world bytes of EVERY other rank's buffer through its mapping, and every rank then finds all the stamps in its own buffer -- or
+// nobody arms.  A mapping that resolves elsewhere (seen once this round, set_store_mode) would otherwise show as a frame with holes, or
+// as a memory fault in the middle of a frame.  The bytes under the stamps are saved and put back.
+int32_t prove_ipc_mappings(GroupLightmap* m, const std::vector<void*>& peers) {
+    Group* g = m->group;
+    const int world = g->world, me = g->first_rank;
+    const size_t bytes = m->row_bytes * (size_t)m->slot_rows * (size_t)world, span = 16u * (size_t)world;
+    if (bytes < 2 * span) return ILM_OK;                                   // (a frame that small has no room for the proof; it has no holes to hide either)
+    char* own = static_cast<char*>(m->buffers[0]);
+    const size_t at[2] = { 0, bytes - span };
+    std::vector<unsigned char> saved(2 * span), seen(2 * span);
+    uint64_t token = 0; std::vector<uint64_t> all((size_t)world, 0);
+    HIP_TRY(hipStreamSynchronize(g->stream(0)));
+    for (int k = 0; k < 2; k++) HIP_TRY(hipMemcpy(saved.data() + (size_t)k * span, own + at[k], span, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 2; k++) HIP_TRY(hipMemset(own + at[k], 0, span));
+    { const int32_t rc = host_all_gather(g, &token, all.data(), sizeof(uint64_t)); if (rc != ILM_OK) return rc; }      // everybody's slots are blank
+    const uint32_t serial = ++g->ipc_proofs;
+    const uint32_t stamp[4] = { 0x494c4d00u, serial, (uint32_t)me, ~serial ^ (uint32_t)me };
+    uint64_t ok = 1;
+    for (void* p : peers)
+        for (int k = 0; k < 2 && ok; k++)
+            if (hipMemcpy(static_cast<char*>(p) + at[k] + 16u * (size_t)me, stamp, 16, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); ok = 0; }
+    { const int32_t rc = host_all_gather(g, &token, all.data(), sizeof(uint64_t)); if (rc != ILM_OK) return rc; }      // everybody has stamped
+    for (int k = 0; k < 2; k++) HIP_TRY(hipMemcpy(seen.data() + (size_t)k * span, own + at[k], span, hipMemcpyDeviceToHost));
+    int missing = -1;
+    for (int k = 0; k < 2; k++)
+        for (int r = 0; r < world; r++) {
+            if (r == me) continue;
+            const uint32_t want[4] = { 0x494c4d00u, serial, (uint32_t)r, ~serial ^ (uint32_t)r };
+            if (memcmp(seen.data() + (size_t)k * span + 16u * (size_t)r, want, 16) != 0 && missing < 0) missing = r;
+        }
+    if (missing >= 0) ok = 0;
+    std::vector<uint64_t> verdicts((size_t)world, 0);
+    verdicts[(size_t)me] = ok;
+    { const int32_t rc = host_all_gather(g, &verdicts[(size_t)me], verdicts.data(), sizeof(uint64_t)); if (rc != ILM_OK) return rc; }
+    for (int k = 0; k < 2; k++) HIP_TRY(hipMemcpy(own + at[k], saved.data() + (size_t)k * span, span, hipMemcpyHostToDevice));
+    for (int r = 0; r < world; r++)
+        if (!verdicts[(size_t)r])
+            return api_fail(ILM_ERR_STATE, "ILM_GATHER_STORE: the IPC mappings do not address the ranks' lightmaps (rank %d did not find every other rank's stamp in its buffer): no rank arms the mode", r);
+    return ILM_OK;
+}
+
 // ILM_GATHER_STORE (r05): the exchange disappears into the light kernel's epilogue.  Every member's lightmap object is handed the
 // buffers of the OTHER members (lightmap_set_mirrors): a light pass stores each texel of its strip at the same offset of every copy of
 // the frame -- its own and, through the peer mapping (hipDeviceEnablePeerAccess, make_members), the others' over xGMI: n stores of 8 B
@@ -368,46 +422,66 @@ int32_t set_store_mode(GroupLightmap* m, bool enable) {
         HIP_TRY(hipSetDevice(g->devices[0]));
         if (!enable) {
             int32_t rc = lightmap_set_mirrors(m->lightmaps[0], nullptr, 0);          // (drains this rank's stream: its stores into the others are done)
-            for (void* p : m->ipc_peers) if (p) (void)hipIpcCloseMemHandle(p);
-            m->ipc_peers.clear();
-            m->store_mode = false;
-            // nobody frees a buffer another rank may still be storing into: all ranks have drained and unmapped when this returns
+            m->store_mode = false;                                                   // (the mappings stay: see below)
+            // nobody frees a buffer another rank may still be storing into: all ranks have drained when this returns
             uint64_t token = 0; std::vector<uint64_t> all((size_t)world, 0);
             const int32_t rb = host_all_gather(g, &token, all.data(), sizeof(uint64_t));
             return rc != ILM_OK ? rc : rb;
         }
+        // The mappings are made ONCE per group lightmap (the buffers never move) and live until the GROUP is destroyed: re-arming reuses
+        // them, and a destroyed lightmap hands them to Group::ipc_retired instead of unmapping.  Measured reason (r05, ROCm 7.2, four rank
+        // processes): after hipIpcCloseMemHandle, the next large hipMalloc of the process lands in the address range the mapping had, and
+        // a handle exported for THAT allocation resolved to another buffer in the importing ranks (their stores went elsewhere, then
+        // faulted) -- deterministic with bench.py's second lit frame, gone with no unmap in between.
         static_assert(sizeof(hipIpcMemHandle_t) == 64, "the handle travels as 64 bytes");
+        const bool mapped = world > 1 && m->ipc_peers.size() == (size_t)(world - 1);
         std::vector<hipIpcMemHandle_t> handles((size_t)world);
         hipIpcMemHandle_t mine;
         uint64_t ok = 1;
-        if (world > 1 && hipIpcGetMemHandle(&mine, m->buffers[0]) != hipSuccess) { (void)hipGetLastError(); ok = 0; memset(&mine, 0, sizeof(mine)); }
-        if (world > 1) {
+        std::vector<void*> peers = m->ipc_peers;
+        if (world > 1 && !mapped) {
+            peers.clear();
+            if (hipIpcGetMemHandle(&mine, m->buffers[0]) != hipSuccess) { (void)hipGetLastError(); ok = 0; memset(&mine, 0, sizeof(mine)); }
             handles[(size_t)me] = mine;
             const int32_t rc = host_all_gather(g, &handles[(size_t)me], handles.data(), sizeof(hipIpcMemHandle_t));
             if (rc != ILM_OK) return rc;
-        }
-        std::vector<void*> peers;
-        for (int r = 0; r < world && ok; r++) {
-            if (r == me) continue;
-            void* p = nullptr;
-            if (hipIpcOpenMemHandle(&p, handles[(size_t)r], hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); ok = 0; break; }
-            peers.push_back(p);
+            for (int r = 0; r < world && ok; r++) {
+                if (r == me) continue;
+                void* p = nullptr;
+                if (hipIpcOpenMemHandle(&p, handles[(size_t)r], hipIpcMemLazyEnablePeerAccess) != hipSuccess) { (void)hipGetLastError(); ok = 0; break; }
+                peers.push_back(p);
+            }
         }
         // every rank learns whether every rank could map every buffer
         std::vector<uint64_t> verdicts((size_t)world, 0);
         verdicts[(size_t)me] = ok;
         if (world > 1) {
             const int32_t rc = host_all_gather(g, &verdicts[(size_t)me], verdicts.data(), sizeof(uint64_t));
-            if (rc != ILM_OK) { for (void* p : peers) (void)hipIpcCloseMemHandle(p); return rc; }
+            if (rc != ILM_OK) { if (!mapped) for (void* p : peers) g->ipc_retired.push_back(p); return rc; }
         }
         int failed = -1;
         for (int r = 0; r < world; r++) if (!verdicts[(size_t)r] && failed < 0) failed = r;
         if (failed >= 0) {
-            for (void* p : peers) (void)hipIpcCloseMemHandle(p);
+            if (!mapped) for (void* p : peers) g->ipc_retired.push_back(p);
             return api_fail(ILM_ERR_STATE, "ILM_GATHER_STORE: rank %d could not map the other ranks' lightmaps through IPC handles: no rank arms the mode", failed);
         }
+        if (!mapped && world > 1) {
+            // NEGATIVE CONTROL of the proof below (tests/test_two_ranks_one_gpu.py): rank 0's first mapping addresses memory of its own
+            if (ok && me == 0 && !peers.empty() && getenv("ILM_EXP_IPC_BOGUS_MAPPING")) {
+                void* elsewhere = nullptr;
+                if (hipMalloc(&elsewhere, m->row_bytes * (size_t)m->slot_rows * (size_t)world) == hipSuccess) {
+                    g->ipc_retired.push_back(peers[0]); g->ipc_decoys.push_back(elsewhere); peers[0] = elsewhere;
+                }
+            }
+            const int32_t rc = prove_ipc_mappings(m, peers);
+            if (rc != ILM_OK) {
+                for (void* p : peers)
+                    if (std::find(g->ipc_decoys.begin(), g->ipc_decoys.end(), p) == g->ipc_decoys.end()) g->ipc_retired.push_back(p);
+                return rc;
+            }
+        }
         const int32_t rc = lightmap_set_mirrors(m->lightmaps[0], peers.data(), (int)peers.size());
-        if (rc != ILM_OK) { for (void* p : peers) (void)hipIpcCloseMemHandle(p); return rc; }
+        if (rc != ILM_OK) { if (!mapped) for (void* p : peers) g->ipc_retired.push_back(p); return rc; }
         m->ipc_peers = peers;
         m->store_mode = true;
         return ILM_OK;
@@ -729,6 +803,8 @@ int32_t ilm_group_lightmap_destroy(IlmHandle h) {
     if (!m) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group lightmap handle");
     Group* g = m->group;
     if (m->store_mode && m->lightmaps.size() == (size_t)g->n_local) (void)set_store_mode(m, false);
+    for (void* p : m->ipc_peers) g->ipc_retired.push_back(p);
+    m->ipc_peers.clear();
     for (size_t i = 0; i < g->xstream.size(); i++) { (void)hipSetDevice(g->devices[i]); (void)hipStreamSynchronize(g->xstream[i]); }
     for (hipEvent_t e : m->xdone) if (e) (void)hipEventDestroy(e);
     for (IlmHandle lm : m->lightmaps) (void)ilm_lightmap_destroy(lm);        // synchronises the member's stream

@@ -1015,6 +1015,10 @@ int32_t ilm_group_lightmap_wait(IlmHandle group_lightmap);
  * processes the call is a COLLECTIVE (arming and disarming alike; destroying an armed lightmap disarms it): every rank exports its buffer
  * as an IPC handle (hipIpcGetMemHandle), the handles are all-gathered, every rank maps the others' (hipIpcOpenMemHandle) -- and either
  * every rank arms or none does (ILM_ERR_STATE on all); the fence of ILM_GATHER_STORE is then an 8-byte collective on the context streams.
+ * The mappings are made once per group lightmap, PROVEN before anybody arms (every rank writes a stamp through each of its mappings
+ * and finds every other rank's stamp in its own buffer; the bytes underneath are restored) and kept until the GROUP is destroyed --
+ * disarming, re-arming and destroying the lightmap unmap nothing (unmapping and re-exporting inside one process was measured to
+ * resolve handles to the wrong buffer on ROCm 7.2: DESIGN.md section 5).
  * The table follows the BUFFER: a lightmap object the host made around a member's texels on the member's context (ilm_lightmap_create
  * with external_device_ptr = ilm_lightmap_device_ptr(member)) is mirrored exactly like the member handle itself.
  * Synchronises the members' streams.  The reference has one device and one lightmap

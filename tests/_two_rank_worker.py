@@ -104,6 +104,39 @@ def main():
     g.sync(); g.host_all_gather(b"\0" * 8)
     assert np.array_equal(glm.download(0).view(np.uint16), want.view(np.uint16)), "rank %d: store mode, host-driven" % rank
     glm.store_mode(False)
+    # 2c. arming PROVES the mappings (every rank finds every other rank's stamp in its own buffer) -- negative control: rank 0 of the
+    #     library is told to address memory of its own instead of rank 1's buffer; EVERY rank must refuse, nobody arms, the buffer is
+    #     left as it was; a lightmap made afterwards arms, and the first one re-arms on the mappings it already has
+    glm2 = native.GroupLightmap(g, w, h, abi.LIGHTMAP_HALF4)
+    glm2.members[0].upload(want)
+    os.environ["ILM_EXP_IPC_BOGUS_MAPPING"] = "1"
+    try:
+        glm2.store_mode(True)
+        raise SystemExit("rank %d: armed over a mapping that addresses other memory" % rank)
+    except native.IlluminantError as refusal:
+        assert refusal.code == abi.ERR_STATE and "stamp" in str(refusal), refusal
+    del os.environ["ILM_EXP_IPC_BOGUS_MAPPING"]
+    assert np.array_equal(glm2.download(0).view(np.uint16), want.view(np.uint16)), "rank %d: the proof left its stamps in the frame" % rank
+    with_error = None
+    try:
+        glm2.gather(native.GATHER_STORE)
+    except native.IlluminantError as refusal:
+        with_error = refusal
+    assert with_error is not None and with_error.code == abi.ERR_STATE              # not armed
+    glm2.store_mode(True)                                                            # the same lightmap, mapped afresh: fine now
+    assert np.array_equal(glm2.download(0).view(np.uint16), want.view(np.uint16))
+    glm2.store_mode(False)
+    glm2.close()
+    glm.store_mode(True)
+    for m in glm.members:
+        m.clear()
+    g.sync(); g.host_all_gather(b"\0" * 8)
+    glm.gather(native.GATHER_STORE)
+    native.render_sphere_lights(c, lights, env, dfu, None, sdf, AMBIENT, glm.members[0], b, e)
+    glm.gather(native.GATHER_STORE)
+    g.sync(); g.host_all_gather(b"\0" * 8)
+    assert np.array_equal(glm.download(0).view(np.uint16), want.view(np.uint16)), "rank %d: store mode, re-armed" % rank
+    glm.store_mode(False)
     # 3. ilm_group_lightmap_set_strips is ALWAYS a collective: ranks that disagree, a rank with a malformed table, a rank that resets while the
     #    others install -- every rank fails (nobody hangs, nobody installs), the table stays what it was
     before = native_strips(glm)
