@@ -142,6 +142,8 @@ def parse_args():
                                                                  "a 5 s device-utilisation sampler sees it); 0: as --light-ms")
     ap.add_argument("--no-lighting", action="store_true")
     ap.add_argument("--no-cfg4", action="store_true", help="skip the 8 M-particle (cfg4 per-GPU share) measurement")
+    ap.add_argument("--optional-rows-timeout", type=int, default=300, help="N > 1: seconds the optional frames of scaling_detail (pipelined exchange, store mode) may take "
+                    "before a watchdog prints the record without them and ends the job with status 0")
     ap.add_argument("--no-store-mode-row", action="store_true", help="N > 1: skip the store-mode frames (IPC-mapped buffers of the other ranks) of scaling_detail")
     ap.add_argument("--no-cfg4-64m", action="store_true", help="skip cfg4 whole on one GPU (64 chunks of 1024^2 = 67 M particles, 5.4 GB; N > 1: measured by rank 0 alone)")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the SURVEY 8f measurements (read-back, particle lights, resolve)")
@@ -352,6 +354,131 @@ def finalize_record(out, world, forced_dist, step_us_cfg2):
 # ---- scenes ------------------------------------------------------------------------------------
 
 CHUNK_1024_IMAGES = {}     # rank -> the eight 1024^2 chunk images of cfg4 (generated once per process: ~1 s of host time per image)
+
+
+def exchange_variant_rows(v):
+    """The OPTIONAL frames of scaling_detail (N > 1): the composited frame with the exchange pipelined (ILM_GATHER_ASYNC) and with no copy
+    phase at all (ILM_GATHER_STORE across processes), beside the serial strip + RCCL exchange that the record's figures are.  `v`: what
+    the lit frame's block of main() had in hand (a namespace).  They run LAST, under a watchdog (run_optional_rows): nothing measured
+    before them depends on them, and a hang in them costs the record these rows only.  Returns {"pipelined_exchange": .., "store_mode": ..}."""
+    H, native, abi, args = v.H, v.native, v.abi, v.args
+    ctx, group, glm, r, L, ranks = v.ctx, v.group, v.glm, v.r, v.L, v.ranks
+    w, h, row_begin, row_end, light_frames, n_s, frame_ms, one_gpu_ms = v.w, v.h, v.row_begin, v.row_end, v.light_frames, v.n_s, v.frame_ms, v.one_gpu_ms
+    barrier, max_over_ranks = ranks.barrier, ranks.max
+    frame_scaling = {}
+    if os.environ.get("ILM_BENCH_HANG_OPTIONAL") and ranks.rank == ranks.world - 1:      # TEST HOOK (tests/test_two_ranks_one_gpu.py): the last rank never arrives
+        time.sleep(1e6)
+
+    def time_strip(b_, e_, n_=4, sync=barrier):
+        for _ in range(2):
+            r.RenderLighting(1.0, b_, e_, False)
+        sync()
+        ctx.TimerStart()
+        for _ in range(n_):
+            r.RenderLighting(1.0, b_, e_, False)
+        return ctx.TimerStop() / n_
+    # The same frames with the exchange PIPELINED (r05, ILM_GATHER_ASYNC): a ring of two group lightmaps (the reference's
+    # BufferRing); the exchange of frame N runs on the member's second stream while its context stream renders the strip of
+    # frame N + 1 into the other lightmap.  Reported beside the serial composited frame; a failure here is recorded, not fatal.
+    try:
+        glm_b = native.GroupLightmap(group, w, h, abi.LIGHTMAP_HALF4)
+        glm_b.set_strips(glm.strips)
+        rc_b = H.RendererConfiguration(w, h)
+        rc_b.DefaultQuality = r.Configuration.DefaultQuality
+        rc_b.MaximumFieldUpdatesPerFrame = 9999
+        rc_b.EnableGBuffer = True
+        r_b = H.LightingRenderer(ctx, rc_b, L["env"], glm_b.members[0].device_ptr())
+        r_b.DistanceField = L["field"]
+        r_b.UpdateFields()
+        ring_ = ((r, glm), (r_b, glm_b))
+        mode_ = native.GATHER_RCCL | native.GATHER_ASYNC
+        for i_ in range(4):
+            rr_, gg_ = ring_[i_ & 1]
+            gg_.wait(); rr_.RenderLighting(1.0, row_begin, row_end, False); gg_.gather(mode_)
+        glm.wait(); glm_b.wait(); barrier()
+        t0 = time.perf_counter()
+        for i_ in range(light_frames):
+            rr_, gg_ = ring_[i_ & 1]
+            gg_.wait()                                  # the exchange queued on this lightmap two frames ago
+            rr_.RenderLighting(1.0, row_begin, row_end, False)
+            gg_.gather(mode_)
+        glm.wait(); glm_b.wait(); barrier()
+        pipe_ms = max_over_ranks(time.perf_counter() - t0) / light_frames * 1e3
+        same_ = bool(np.array_equal(glm.download(0).view(np.uint16), glm_b.download(0).view(np.uint16)))
+        frame_scaling["pipelined_exchange"] = {
+            "composited_frame_ms": round(pipe_ms, 4), "vs_serial": round(pipe_ms / frame_ms, 4), "speedup_vs_one_gpu_frame": round(one_gpu_ms / pipe_ms, 3),
+            "both_lightmaps_hold_the_same_frame": same_,
+            "how": "ring of two group lightmaps; ilm_group_lightmap_gather(RCCL | ILM_GATHER_ASYNC) on the member's second stream, ilm_group_lightmap_wait in front of a lightmap's reuse"}
+        del ring_, rr_, gg_, r_b
+        glm_b.close()
+    except Exception as e_:      # noqa: BLE001 -- the serial figures above stand
+        frame_scaling["pipelined_exchange"] = {"error": "%s: %s" % (type(e_).__name__, e_)}
+    # The same frames with NO copy phase (r05, ILM_GATHER_STORE across processes): every rank maps the other ranks' buffers
+    # through IPC handles (a collective: every rank arms or none does) and the light kernel's final store writes its strip
+    # into every rank's copy over xGMI while the strip runs; what is left of the exchange is the fence (an 8-byte collective)
+    # in front of the strips (readers of the old frame) and behind them.  Recorded beside the serial figures; not fatal.
+    if not args.no_store_mode_row:
+        try:
+            for m_ in glm.members:
+                m_.clear()
+            glm.store_mode(True)
+            try:
+                for _ in range(3):
+                    glm.gather(native.GATHER_STORE); r.RenderLighting(1.0, row_begin, row_end, False); glm.gather(native.GATHER_STORE)
+                ctx.Sync(); barrier()
+                t0 = time.perf_counter()
+                for _ in range(light_frames):
+                    glm.gather(native.GATHER_STORE)
+                    r.RenderLighting(1.0, row_begin, row_end, False)
+                    glm.gather(native.GATHER_STORE)
+                ctx.Sync(); barrier()
+                store_ms = max_over_ranks(time.perf_counter() - t0) / light_frames * 1e3
+                store_strip_ms = ranks.doubles(time_strip(row_begin, row_end, n_s))
+                glm.gather(native.GATHER_STORE); ctx.Sync(); barrier()
+                stored_ = glm.download(0).view(np.uint16).copy()
+            finally:
+                glm.store_mode(False)
+            r.RenderLighting(1.0, row_begin, row_end, False)
+            glm.gather(native.GATHER_RCCL); ctx.Sync(); barrier()
+            now_ = glm.download(0).view(np.uint16)
+            bad_rows_ = np.nonzero((stored_.reshape(h, -1) != now_.reshape(h, -1)).any(axis=1))[0]
+            rows_differing_ = [[int(v) for v in t] for t in zip(ranks.doubles(float(len(bad_rows_))), ranks.doubles(float(bad_rows_[0]) if len(bad_rows_) else -1.0),
+                                                              ranks.doubles(float(bad_rows_[-1]) if len(bad_rows_) else -1.0),
+                                                              ranks.doubles(float((stored_ != now_).sum())))]
+            same_ = bool(ranks.sum(0.0 if np.array_equal(stored_, now_) else 1.0) == 0.0)
+            frame_scaling["store_mode"] = {
+                "composited_frame_ms": round(store_ms, 4), "vs_serial": round(store_ms / frame_ms, 4), "speedup_vs_one_gpu_frame": round(one_gpu_ms / store_ms, 3),
+                "strip_ms_max": round(max(store_strip_ms), 4), "strip_ms": [round(t, 4) for t in store_strip_ms],
+                "every_rank_holds_the_frame_of_the_rccl_exchange": same_, "rows_differing_per_rank_count_first_last_elements": rows_differing_,
+                "how": "ilm_group_lightmap_store_mode (IPC-mapped buffers of the other ranks); per frame: fence, strip with mirror stores, fence (ilm_group_lightmap_gather(ILM_GATHER_STORE))"}
+            del stored_
+        except Exception as e_:      # noqa: BLE001 -- the serial figures above stand
+            frame_scaling["store_mode"] = {"error": "%s: %s" % (type(e_).__name__, e_)}
+    return frame_scaling
+
+
+def run_optional_rows(deferred, frames_scaling, timeout_s, rank, emit_fallback, barrier):
+    """deferred: [(pin, namespace)] -- exchange_variant_rows for each, merged into frames_scaling[pin].  A watchdog THREAD (the main thread
+    may sit inside a collective) ends the job cleanly when they have not finished in timeout_s: rank 0 prints the record assembled WITHOUT
+    them (emit_fallback), every rank leaves with status 0 -- the hardware run's figures survive a hang in an optional row."""
+    import threading
+    done = threading.Event()
+
+    def watchdog():
+        if done.wait(timeout_s):
+            return
+        try:
+            if rank == 0:
+                emit_fallback()
+        finally:
+            os._exit(0)
+    t = threading.Thread(target=watchdog, daemon=True)
+    t.start()
+    for pin, v in deferred:
+        frames_scaling[pin].update(exchange_variant_rows(v))
+    v = None
+    barrier()               # EVERY rank is through: a rank that finished while another hangs waits here, under its own watchdog
+    done.set()
 
 
 def cfg4_images(scenes, rank):
@@ -831,6 +958,7 @@ def main():
     if not args.no_lighting:
         lighting = {}
         frames_scaling = {}
+        deferred_rows, kept_alive = [], []
         pinned = json.load(open(os.path.join(ROOT, "tests", "golden", "full_frame_bands.json")))      # the oracle's counts over the same two frames
         for name, (w, h, nl, res, wsize, fmt, lseed, pin) in (("cfg3_1080p_64_lights_unorm16", (1920, 1080, 64, 0.25, 2048, abi.SDF_UNORM16, 12, "cfg3")),
                                                                ("cfg5_4k_256_lights_fp16", (3840, 2160, 256, 0.125, 4096, abi.SDF_FP16, 13, "cfg5"))):
@@ -932,83 +1060,10 @@ def main():
                     "composited_frame_ms": round(frame_ms, 4), "composited_frame_is": "strip + gather per frame on one stream, wall clock, max over ranks",
                     "one_gpu_frame_ms": round(one_gpu_ms, 4), "one_gpu_frame_is": "the whole frame rendered by rank 0's GPU alone in this job (the other ranks idle)",
                     "share_ms": round(one_gpu_ms / world, 4), "speedup_vs_one_gpu_frame": round(one_gpu_ms / frame_ms, 3)}
-                # The same frames with the exchange PIPELINED (r05, ILM_GATHER_ASYNC): a ring of two group lightmaps (the reference's
-                # BufferRing); the exchange of frame N runs on the member's second stream while its context stream renders the strip of
-                # frame N + 1 into the other lightmap.  Reported beside the serial composited frame; a failure here is recorded, not fatal.
-                try:
-                    glm_b = native.GroupLightmap(group, w, h, abi.LIGHTMAP_HALF4)
-                    glm_b.set_strips(glm.strips)
-                    rc_b = H.RendererConfiguration(w, h)
-                    rc_b.DefaultQuality = r.Configuration.DefaultQuality
-                    rc_b.MaximumFieldUpdatesPerFrame = 9999
-                    rc_b.EnableGBuffer = True
-                    r_b = H.LightingRenderer(ctx, rc_b, L["env"], glm_b.members[0].device_ptr())
-                    r_b.DistanceField = L["field"]
-                    r_b.UpdateFields()
-                    ring_ = ((r, glm), (r_b, glm_b))
-                    mode_ = native.GATHER_RCCL | native.GATHER_ASYNC
-                    for i_ in range(4):
-                        rr_, gg_ = ring_[i_ & 1]
-                        gg_.wait(); rr_.RenderLighting(1.0, row_begin, row_end, False); gg_.gather(mode_)
-                    glm.wait(); glm_b.wait(); barrier()
-                    t0 = time.perf_counter()
-                    for i_ in range(light_frames):
-                        rr_, gg_ = ring_[i_ & 1]
-                        gg_.wait()                                  # the exchange queued on this lightmap two frames ago
-                        rr_.RenderLighting(1.0, row_begin, row_end, False)
-                        gg_.gather(mode_)
-                    glm.wait(); glm_b.wait(); barrier()
-                    pipe_ms = max_over_ranks(time.perf_counter() - t0) / light_frames * 1e3
-                    same_ = bool(np.array_equal(glm.download(0).view(np.uint16), glm_b.download(0).view(np.uint16)))
-                    frame_scaling["pipelined_exchange"] = {
-                        "composited_frame_ms": round(pipe_ms, 4), "vs_serial": round(pipe_ms / frame_ms, 4), "speedup_vs_one_gpu_frame": round(one_gpu_ms / pipe_ms, 3),
-                        "both_lightmaps_hold_the_same_frame": same_,
-                        "how": "ring of two group lightmaps; ilm_group_lightmap_gather(RCCL | ILM_GATHER_ASYNC) on the member's second stream, ilm_group_lightmap_wait in front of a lightmap's reuse"}
-                    del ring_, rr_, gg_, r_b
-                    glm_b.close()
-                except Exception as e_:      # noqa: BLE001 -- the serial figures above stand
-                    frame_scaling["pipelined_exchange"] = {"error": "%s: %s" % (type(e_).__name__, e_)}
-                # The same frames with NO copy phase (r05, ILM_GATHER_STORE across processes): every rank maps the other ranks' buffers
-                # through IPC handles (a collective: every rank arms or none does) and the light kernel's final store writes its strip
-                # into every rank's copy over xGMI while the strip runs; what is left of the exchange is the fence (an 8-byte collective)
-                # in front of the strips (readers of the old frame) and behind them.  Recorded beside the serial figures; not fatal.
-                if not args.no_store_mode_row:
-                    try:
-                        for m_ in glm.members:
-                            m_.clear()
-                        glm.store_mode(True)
-                        try:
-                            for _ in range(3):
-                                glm.gather(native.GATHER_STORE); r.RenderLighting(1.0, row_begin, row_end, False); glm.gather(native.GATHER_STORE)
-                            ctx.Sync(); barrier()
-                            t0 = time.perf_counter()
-                            for _ in range(light_frames):
-                                glm.gather(native.GATHER_STORE)
-                                r.RenderLighting(1.0, row_begin, row_end, False)
-                                glm.gather(native.GATHER_STORE)
-                            ctx.Sync(); barrier()
-                            store_ms = max_over_ranks(time.perf_counter() - t0) / light_frames * 1e3
-                            store_strip_ms = ranks.doubles(time_strip(row_begin, row_end, n_s))
-                            glm.gather(native.GATHER_STORE); ctx.Sync(); barrier()
-                            stored_ = glm.download(0).view(np.uint16).copy()
-                        finally:
-                            glm.store_mode(False)
-                        r.RenderLighting(1.0, row_begin, row_end, False)
-                        glm.gather(native.GATHER_RCCL); ctx.Sync(); barrier()
-                        now_ = glm.download(0).view(np.uint16)
-                        bad_rows_ = np.nonzero((stored_.reshape(h, -1) != now_.reshape(h, -1)).any(axis=1))[0]
-                        rows_differing_ = [[int(v) for v in t] for t in zip(ranks.doubles(float(len(bad_rows_))), ranks.doubles(float(bad_rows_[0]) if len(bad_rows_) else -1.0),
-                                                                          ranks.doubles(float(bad_rows_[-1]) if len(bad_rows_) else -1.0),
-                                                                          ranks.doubles(float((stored_ != now_).sum())))]
-                        same_ = bool(ranks.sum(0.0 if np.array_equal(stored_, now_) else 1.0) == 0.0)
-                        frame_scaling["store_mode"] = {
-                            "composited_frame_ms": round(store_ms, 4), "vs_serial": round(store_ms / frame_ms, 4), "speedup_vs_one_gpu_frame": round(one_gpu_ms / store_ms, 3),
-                            "strip_ms_max": round(max(store_strip_ms), 4), "strip_ms": [round(t, 4) for t in store_strip_ms],
-                            "every_rank_holds_the_frame_of_the_rccl_exchange": same_, "rows_differing_per_rank_count_first_last_elements": rows_differing_,
-                            "how": "ilm_group_lightmap_store_mode (IPC-mapped buffers of the other ranks); per frame: fence, strip with mirror stores, fence (ilm_group_lightmap_gather(ILM_GATHER_STORE))"}
-                        del stored_
-                    except Exception as e_:      # noqa: BLE001 -- the serial figures above stand
-                        frame_scaling["store_mode"] = {"error": "%s: %s" % (type(e_).__name__, e_)}
+                # The optional frames (pipelined exchange, store mode between processes) run LAST, under a watchdog: exchange_variant_rows
+                import types as types_
+                deferred_rows.append((pin, types_.SimpleNamespace(H=H, native=native, abi=abi, args=args, ctx=ctx, group=group, glm=glm, r=r, L=L, ranks=ranks, w=w, h=h,
+                                                                  row_begin=row_begin, row_end=row_end, light_frames=light_frames, n_s=n_s, frame_ms=frame_ms, one_gpu_ms=one_gpu_ms)))
                 frames_scaling[pin] = frame_scaling
             my_px = (row_end - row_begin) * w
             # this rank's launch: SDF samples + the G-buffer texel of every pixel (Vector4) + lightmap write (half4) + light records
@@ -1209,9 +1264,11 @@ def main():
                     el = time.perf_counter() - t0
                 lighting[name]["cpu_baseline"] = {"value": round(rows * w / el / 1e6, 4), "unit": "lit Mpixels/s", "cores": orc.num_threads(), "kind": "port",
                                                   "sample": "%d rows x %d px around the frame's middle (oracle/ilm_oracle.c, OpenMP, %.1f s)" % (rows, w, el)}
-            del L, r
-            if glm is not None:
+            if glm is not None and deferred_rows and deferred_rows[-1][1].glm is glm:
+                kept_alive.append((L, r, glm))          # (the optional rows at the end render with them)
+            elif glm is not None:
                 glm.close()
+            del L, r
         out["lighting"] = lighting
         out["lit_mpixels_per_s"] = lighting["cfg5_4k_256_lights_fp16"]["lit_mpixels_per_s"]
         # the second hot path's roofline next to the first one's, where the driver's `parsed` sees it
@@ -1402,17 +1459,35 @@ def main():
 
     if group is not None:
         out["config"]["rccl_communicator_ranks_per_rank"] = [struct.unpack("<i", b[:4])[0] for b in group.host_all_gather(struct.pack("<ii", comm_ranks, 0))]
-    if multi and scaling_particles:
-        out["scaling_detail"] = scaling_detail(world, frames=(frames_scaling if not args.no_lighting else {}), **scaling_particles)
-        out["scaling_detail"]["note"] = ("the contract's top-level \"scaling\" stays the string \"weak\" (fixed work per GPU in the headline row); "
-                                         "this block carries the named ratios")
-    out = finalize_record(out, world, forced_dist, step_ms_gpu * 1e3)
+    import copy
 
-    sys.stdout.flush()
-    os.dup2(stdout_fd, 1)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    os.dup2(2, 1)
+    def assemble(optional_rows_note=None):
+        o = copy.deepcopy(out)
+        if multi and scaling_particles:
+            o["scaling_detail"] = scaling_detail(world, frames=(copy.deepcopy(frames_scaling) if not args.no_lighting else {}), **scaling_particles)
+            o["scaling_detail"]["note"] = ("the contract's top-level \"scaling\" stays the string \"weak\" (fixed work per GPU in the headline row); "
+                                           "this block carries the named ratios")
+            if optional_rows_note:
+                o["scaling_detail"]["optional_rows"] = optional_rows_note
+        return finalize_record(o, world, forced_dist, step_ms_gpu * 1e3)
+
+    def emit(o):
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
+        if rank == 0:
+            print(json.dumps(o), flush=True)
+        os.dup2(2, 1)
+
+    if not args.no_lighting and deferred_rows:
+        # every figure above is in hand: the record as it stands is the fallback a watchdog prints if an optional row hangs
+        fallback = assemble("pipelined_exchange / store_mode did not finish within %d s: the record was printed without them" % args.optional_rows_timeout)
+        run_optional_rows(deferred_rows, frames_scaling, args.optional_rows_timeout, rank, lambda: emit(fallback), ranks.barrier)
+        deferred_rows.clear()
+        while kept_alive:
+            L_, r_, g_ = kept_alive.pop()
+            del L_, r_
+            g_.close()
+    emit(assemble())
     if group is not None:
         import gc
         del ctx

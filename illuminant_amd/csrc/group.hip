@@ -362,7 +362,8 @@ int32_t fence_members(Group* g) {
 }
 
 // Proof that every mapping made by hipIpcOpenMemHandle addresses the buffer it was exported for (a collective, once per group lightmap,
-// after every rank has mapped every buffer): rank r writes a 16-byte stamp { serial, r } into slot r of the first and of the last
+// after every rank has mapped every buffer): rank r stores (a one-lane kernel: the access the mirror stores will use) a 16-byte stamp
+// { serial, r } into slot r of the first and of the last
 // 16 * world bytes of EVERY other rank's buffer through its mapping, and every rank then finds all the stamps in its own buffer -- or
 // nobody arms.  A mapping that resolves elsewhere (seen once this round, set_store_mode) would otherwise show as a frame with holes, or
 // as a memory fault in the middle of a frame.  The bytes under the stamps are saved and put back.
@@ -384,7 +385,8 @@ int32_t prove_ipc_mappings(GroupLightmap* m, const std::vector<void*>& peers) {
     uint64_t ok = 1;
     for (void* p : peers)
         for (int k = 0; k < 2 && ok; k++)
-            if (hipMemcpy(static_cast<char*>(p) + at[k] + 16u * (size_t)me, stamp, 16, hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); ok = 0; }
+            if (launch_stamp16(static_cast<char*>(p) + at[k] + 16u * (size_t)me, stamp, g->stream(0)) != hipSuccess) { (void)hipGetLastError(); ok = 0; }
+    if (hipStreamSynchronize(g->stream(0)) != hipSuccess) { (void)hipGetLastError(); ok = 0; }
     { const int32_t rc = host_all_gather(g, &token, all.data(), sizeof(uint64_t)); if (rc != ILM_OK) return rc; }      // everybody has stamped
     for (int k = 0; k < 2; k++) HIP_TRY(hipMemcpy(seen.data() + (size_t)k * span, own + at[k], span, hipMemcpyDeviceToHost));
     int missing = -1;

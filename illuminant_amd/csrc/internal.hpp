@@ -243,6 +243,7 @@ hipError_t launch_light_probes(const void* recs, int light_count, const float4* 
                                const IlmEnvironment& env, const IlmDistanceFieldUniforms& df, const SdfView& sdf, const RampView& ramp, float4* values, float4* pairs,
                                hipStream_t stream);
 // sampleDistanceFieldEx at `count` positions (xyz triples) -- diagnostic entry point ilm_sdf_sample
+hipError_t launch_stamp16(void* where, const uint32_t stamp[4], hipStream_t stream);      // 16 bytes stored by a kernel (output.hip)
 hipError_t launch_sdf_sample(const SdfView& sdf, const IlmDistanceFieldUniforms& df, const float* positions, int count, float* out, hipStream_t stream);
 // fills the cell array of the table sampler (sdf.table_slices x sdf.slice_h x sdf.slice_w cells of 16 bytes) from the atlas
 hipError_t launch_build_sdf_cells(const TraceSdfView& sdf, void* cells, int first_slice, int slice_count, hipStream_t stream);

@@ -229,4 +229,13 @@ hipError_t launch_resolve(const ResolveLaunch& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// Sixteen bytes written by the DEVICE at `where` (group.hip, prove_ipc_mappings: the proof goes through the same kind of access the
+// store mode's mirror stores use -- a kernel's store through the mapping -- not through a copy engine).
+__global__ void stamp16_kernel(uint4* where, uint4 stamp) { *where = stamp; }
+
+hipError_t launch_stamp16(void* where, const uint32_t stamp[4], hipStream_t stream) {
+    hipLaunchKernelGGL(stamp16_kernel, dim3(1), dim3(1), 0, stream, static_cast<uint4*>(where), make_uint4(stamp[0], stamp[1], stamp[2], stamp[3]));
+    return hipGetLastError();
+}
+
 }  // namespace ilm

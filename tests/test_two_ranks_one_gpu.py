@@ -76,3 +76,22 @@ def test_bench_runs_its_whole_n_gpu_branch_at_two_ranks(fake_rccl):
         assert len(fs["strip_ms"]) == 2 and fs["strip_ms_max"] >= max(fs["strip_ms"]) - 1e-9 and fs["exchange_ms"] > 0 and fs["one_gpu_frame_ms"] > 0
         assert fs["pipelined_exchange"].get("both_lightmaps_hold_the_same_frame") is True, fs["pipelined_exchange"]
         assert fs["store_mode"].get("every_rank_holds_the_frame_of_the_rccl_exchange") is True and fs["store_mode"]["composited_frame_ms"] > 0, fs["store_mode"]
+
+
+def test_a_hang_in_an_optional_row_costs_the_record_that_row_only(fake_rccl):
+    """bench.py runs the optional frames of scaling_detail (pipelined exchange, store mode) LAST and under a watchdog thread: with the last
+    rank stuck in front of them (ILM_BENCH_HANG_OPTIONAL, a test hook) the other rank blocks in the first collective, the watchdog fires,
+    rank 0 prints the record as it stood -- every mandatory figure, the count checks, the serial composited frames -- with a note, and
+    every rank leaves with status 0."""
+    env = dict(os.environ, ILM_RCCL_LIB=fake_rccl, ILM_BENCH_ONE_GPU="1", ILM_BENCH_HANG_OPTIONAL="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--light-frames", "2", "--light-ms", "0",
+                        "--sustain-s", "0", "--no-cfg4-64m", "--optional-rows-timeout", "8"], env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    sd = d["scaling_detail"]
+    assert "did not finish" in sd["optional_rows"]
+    for pin in ("cfg3", "cfg5"):
+        assert sd["frames"][pin]["composited_frame_ms"] > 0 and "store_mode" not in sd["frames"][pin] and "pipelined_exchange" not in sd["frames"][pin]
+    assert d["lighting"]["cfg5_4k_256_lights_fp16"]["verified_counts"] is True and d["value"] > 0
