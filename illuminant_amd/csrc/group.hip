@@ -363,8 +363,7 @@ int32_t fence_members(Group* g) {
 
 // Proof that every mapping made by hipIpcOpenMemHandle addresses the buffer it was exported for (a collective, once per group lightmap,
 // after every rank has mapped every buffer): rank r stores (a one-lane kernel: the access the mirror stores will use) a 16-byte stamp
-// { serial, r } into slot r of the first and of the last
-// 16 * world bytes of EVERY other rank's buffer through its mapping, and every rank then finds all the stamps in its own buffer -- or
+// { serial, r } into slot r of the first and of the last 16 * world bytes of EVERY other rank's buffer through its mapping, and every rank then finds all the stamps in its own buffer -- or
 // nobody arms.  A mapping that resolves elsewhere (seen once this round, set_store_mode) would otherwise show as a frame with holes, or
 // as a memory fault in the middle of a frame.  The bytes under the stamps are saved and put back.
 int32_t prove_ipc_mappings(GroupLightmap* m, const std::vector<void*>& peers) {
@@ -373,7 +372,7 @@ int32_t prove_ipc_mappings(GroupLightmap* m, const std::vector<void*>& peers) {
     const size_t bytes = m->row_bytes * (size_t)m->slot_rows * (size_t)world, span = 16u * (size_t)world;
     if (bytes < 2 * span) return ILM_OK;                                   // (a frame that small has no room for the proof; it has no holes to hide either)
     char* own = static_cast<char*>(m->buffers[0]);
-    const size_t at[2] = { 0, bytes - span };
+    const size_t at[2] = { 0, (bytes - span) & ~(size_t)15 };             // (16-byte stores: aligned)
     std::vector<unsigned char> saved(2 * span), seen(2 * span);
     uint64_t token = 0; std::vector<uint64_t> all((size_t)world, 0);
     HIP_TRY(hipStreamSynchronize(g->stream(0)));
