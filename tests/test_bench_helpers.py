@@ -69,3 +69,28 @@ def test_the_mesh_gbuffer_scene_is_what_the_row_says():
     assert len(top) % 3 == 0 and len(front) % 3 == 0
     assert 2 + len(top) // 3 + len(front) // 3 + 128 == 2507
     assert gd.TwoPointFiveD != 0 and gd.DistanceFieldExtentZ == 128.0
+
+
+def test_optional_rows_merge_and_the_watchdog_prints_the_fallback():
+    """bench.run_optional_rows (N > 1): the optional frames are merged into scaling_detail's frames when they finish; when they do not, a
+    watchdog THREAD has rank 0 print the record as it stood and ends the process with status 0 (the main thread may be stuck in a
+    collective, so nothing may depend on it returning)."""
+    import subprocess
+    import sys
+    import types
+    calls = []
+    frames = {"cfg3": {"composited_frame_ms": 1.0}}
+    old = bench.exchange_variant_rows
+    bench.exchange_variant_rows = lambda v: {"store_mode": {"composited_frame_ms": v.x}}
+    try:
+        bench.run_optional_rows([("cfg3", types.SimpleNamespace(x=0.5))], frames, 30, 0, lambda: calls.append("fallback"), lambda: calls.append("barrier"))
+    finally:
+        bench.exchange_variant_rows = old
+    assert frames == {"cfg3": {"composited_frame_ms": 1.0, "store_mode": {"composited_frame_ms": 0.5}}} and calls == ["barrier"]
+    code = ("import sys, time, types; sys.path.insert(0, %r); import bench\n"
+            "bench.exchange_variant_rows = lambda v: time.sleep(1e6)\n"
+            "bench.run_optional_rows([('cfg3', types.SimpleNamespace())], {'cfg3': {}}, 1, int(sys.argv[1]), lambda: print('FALLBACK', flush=True), lambda: None)\n"
+            "print('NOT REACHED')\n") % ROOT
+    for rank, want in ((0, "FALLBACK\n"), (1, "")):
+        p = subprocess.run([sys.executable, "-c", code, str(rank)], capture_output=True, text=True, timeout=120)
+        assert p.returncode == 0 and p.stdout == want, (rank, p.stdout, p.stderr[-2000:])

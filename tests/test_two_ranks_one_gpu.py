@@ -26,7 +26,7 @@ def fake_rccl(tmp_path_factory):
     return out
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_a_group_that_spans_processes_composites_the_frame_on_every_rank(fake_rccl, world):
     idfile = os.path.join(tempfile.mkdtemp(), "id")
     env = dict(os.environ, ILM_RCCL_LIB=fake_rccl, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
