@@ -410,7 +410,7 @@ def test_store_mode_composites_the_frame_without_a_gather(ctx, members, fmt, bal
 
 
 def test_store_mode_of_a_rank_group_at_world_one(ctx):
-    """A group that spans processes arms the store mode through IPC handles of the ranks' buffers (a collective; world sizes 2 and 3 on this
+    """A group that spans processes arms the store mode through IPC handles of the ranks' buffers (a collective; world sizes 2, 3 and 8 on this
     GPU: tests/test_two_ranks_one_gpu.py); with one rank there is nobody to map and the frame is simply the rank's own."""
     layout, atlas, dfu, lights, w, h = small_scene()
     env = scenes.environment()
