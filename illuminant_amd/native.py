@@ -756,7 +756,8 @@ class GroupLightmap:
 
     def store_mode(self, enable=True):
         """ilm_group_lightmap_store_mode: while armed, every light pass into a member's lightmap also stores into the other members' copies
-        of the frame; gather(GATHER_STORE) is then the fence that replaces the exchange."""
+        of the frame; gather(GATHER_STORE) is then the fence that replaces the exchange.  For a group that spans processes the call is a
+        COLLECTIVE (arming and disarming): the ranks' buffers are mapped through IPC handles, proven, and every rank arms or none."""
         check(lib().ilm_group_lightmap_store_mode(self.handle, 1 if enable else 0))
 
     def download(self, local_index=0):
