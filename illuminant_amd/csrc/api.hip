@@ -1125,6 +1125,16 @@ const TraceApi& trace_api() {
     }();
     return api;
 }
+// every lightmap of the process that holds a store-mode table, whatever its context (mirror_table_of: aliases from OTHER contexts)
+static std::mutex g_armed_mutex;
+static std::vector<Lightmap*> g_armed;
+static std::atomic<int> g_armed_count{0};
+static void forget_armed(const Lightmap* m) {
+    std::lock_guard<std::mutex> lock(g_armed_mutex);
+    g_armed.erase(std::remove(g_armed.begin(), g_armed.end(), m), g_armed.end());
+    g_armed_count.store((int)g_armed.size(), std::memory_order_release);
+}
+
 // Store-mode exchange (ILM_GATHER_STORE): every light pass into this lightmap also stores its texels at the same offsets of `count`
 // other buffers of the same size -- the other members' copies of a group's frame, addressable from this lightmap's device (peer access
 // / the same device).  count == 0 ends it.  Synchronises the lightmap's stream (the table may be in use by a queued launch).
@@ -1136,6 +1146,7 @@ int32_t lightmap_set_mirrors(IlmHandle h, void* const* buffers, int count) {
     HIP_TRY(hipStreamSynchronize(m->ctx->main()));
     std::vector<Lightmap*>& armed = m->ctx->mirrored;
     armed.erase(std::remove(armed.begin(), armed.end(), m), armed.end());
+    forget_armed(m);
     if (count == 0) {
         if (m->d_mirrors) HIP_TRY(hipFree(m->d_mirrors));
         m->d_mirrors = nullptr; m->mirror_count = 0;
@@ -1145,6 +1156,11 @@ int32_t lightmap_set_mirrors(IlmHandle h, void* const* buffers, int count) {
     HIP_TRY(hipMemcpy(m->d_mirrors, buffers, sizeof(void*) * (size_t)count, hipMemcpyHostToDevice));
     m->mirror_count = count;
     armed.push_back(m);
+    {
+        std::lock_guard<std::mutex> lock(g_armed_mutex);
+        g_armed.push_back(m);
+        g_armed_count.store((int)g_armed.size(), std::memory_order_release);
+    }
     return ILM_OK;
 }
 
@@ -1152,13 +1168,29 @@ int32_t lightmap_set_mirrors(IlmHandle h, void* const* buffers, int count) {
 // armed lightmap's texels on the same context (ilm_lightmap_create with external_device_ptr = ilm_lightmap_device_ptr of a group
 // lightmap's member: what a host that wraps the group's buffer in its own renderer does, the host mirror among them) renders the same
 // frame on the same stream, and a strip rendered through it that stayed at home would leave every other member with a hole.
-static const Lightmap* mirror_table_of(const Lightmap* m) {
+// `*foreign` = true: `m` aliases the texels of a lightmap ANOTHER context holds armed (a sibling's renderer around a group member's
+// buffer, say).  Its passes run on a stream the group's fence does not cover and would not be mirrored: the callers refuse.
+static const Lightmap* mirror_table_of(const Lightmap* m, bool* foreign) {
+    *foreign = false;
     if (m->d_mirrors && m->mirror_count > 0) return m;
-    if (m->external)
-        for (const Lightmap* e : m->ctx->mirrored)
-            // (a member's object is slot_rows * world rows tall, the frame and its alias may be shorter: same base, same pitch)
-            if (e->texels == m->texels && e->width == m->width && m->height <= e->height && e->format == m->format && e->d_mirrors && e->mirror_count > 0) return e;
+    if (!m->external || g_armed_count.load(std::memory_order_acquire) == 0) return nullptr;
+    for (const Lightmap* e : m->ctx->mirrored)
+        // (a member's object is slot_rows * world rows tall, the frame and its alias may be shorter: same base, same pitch)
+        if (e->texels == m->texels && e->width == m->width && m->height <= e->height && e->format == m->format && e->d_mirrors && e->mirror_count > 0) return e;
+    std::lock_guard<std::mutex> lock(g_armed_mutex);
+    for (const Lightmap* e : g_armed)
+        if (e->texels == m->texels && e->ctx != m->ctx) *foreign = true;
     return nullptr;
+}
+// (both light-pass entry points)
+static int32_t set_launch_mirrors(const Lightmap* m, LightLaunch* a) {
+    bool foreign = false;
+    const Lightmap* t = mirror_table_of(m, &foreign);
+    if (foreign)
+        return fail(ILM_ERR_STATE, "the lightmap aliases the buffer of a group lightmap member that ANOTHER context holds in store mode: a pass from here "
+                                   "would not be mirrored into the other members' frames (render through the member's context, or disarm the mode)");
+    a->mirrors = t ? t->d_mirrors : nullptr; a->mirror_count = t ? t->mirror_count : 0;
+    return ILM_OK;
 }
 }  // namespace ilm
 
@@ -2488,6 +2520,7 @@ int32_t ilm_lightmap_destroy(IlmHandle h) {
     if (m->texels && !m->external) (void)hipFree(m->texels);
     if (m->d_mirrors) (void)hipFree(m->d_mirrors);
     m->ctx->mirrored.erase(std::remove(m->ctx->mirrored.begin(), m->ctx->mirrored.end(), m), m->ctx->mirrored.end());
+    forget_armed(m);
     retire_handle(m);
     delete m;
     return ILM_OK;
@@ -2740,7 +2773,7 @@ int32_t fill_light_launch(Ctx* c, const IlmEnvironment* env, const IlmDistanceFi
     a->tile_map = light_tile_map();
     a->tile_macro = light_tile_macro_for(m->width, row_end - row_begin);
     a->split = 1; a->partials = nullptr; a->tickets = nullptr; a->group_order = nullptr;
-    { const Lightmap* t = mirror_table_of(m); a->mirrors = t ? t->d_mirrors : nullptr; a->mirror_count = t ? t->mirror_count : 0; }
+    { const int32_t rc = set_launch_mirrors(m, a); if (rc != ILM_OK) return rc; }
     return ILM_OK;
 }
 }  // namespace
@@ -3285,7 +3318,7 @@ int32_t ilm_render_sphere_lights(IlmHandle hctx, const IlmLightVertex* lights, i
         a.stats = c->d_stats;
     }
     a.split = 1; a.partials = nullptr; a.tickets = nullptr; a.group_order = nullptr;
-    { const Lightmap* t = mirror_table_of(m); a.mirrors = t ? t->d_mirrors : nullptr; a.mirror_count = t ? t->mirror_count : 0; }      // store-mode exchange of a group lightmap
+    { const int32_t rc = set_launch_mirrors(m, &a); if (rc != ILM_OK) return rc; }      // store-mode exchange of a group lightmap
     { const int32_t rc = plan_light_split(c, &a); if (rc != ILM_OK) return rc; }
     { const int32_t rc = plan_group_order(c, &a, lights, light_count, 16 * a.tile_macro); if (rc != ILM_OK) return rc; }
     c->last_light_blocks = light_launch_blocks(a); c->last_light_split = a.split; c->last_light_macro = (a.tile_map == 4) ? a.tile_macro : 0;

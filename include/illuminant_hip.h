@@ -1020,7 +1020,8 @@ int32_t ilm_group_lightmap_wait(IlmHandle group_lightmap);
  * disarming, re-arming and destroying the lightmap unmap nothing (unmapping and re-exporting inside one process was measured to
  * resolve handles to the wrong buffer on ROCm 7.2: DESIGN.md section 5).
  * The table follows the BUFFER: a lightmap object the host made around a member's texels on the member's context (ilm_lightmap_create
- * with external_device_ptr = ilm_lightmap_device_ptr(member)) is mirrored exactly like the member handle itself.
+ * with external_device_ptr = ilm_lightmap_device_ptr(member)) is mirrored exactly like the member handle itself; such an object on ANOTHER
+ * context (a sibling's) is refused by the light passes with ILM_ERR_STATE while the mode is armed (its stream is outside the fence).
  * Synchronises the members' streams.  The reference has one device and one lightmap
  * (Illuminant/Lighting/LightingRenderer.cs:1004-1010): every member still ends with that one composited frame. */
 int32_t ilm_group_lightmap_store_mode(IlmHandle group_lightmap, int32_t enable);

@@ -358,6 +358,14 @@ def test_store_mode_composites_the_frame_without_a_gather(ctx, members, fmt, bal
             glm.gather(native.GATHER_STORE)
         g.sync()
         alias.close()
+        # ... but an alias held by ANOTHER context (a sibling's renderer around the member's buffer) is refused while the mode is armed:
+        # its passes would run on a stream the fence does not cover and would reach nobody else's frame
+        sib = g.contexts[0].sibling()
+        foreign = native.Lightmap(sib, w, h, fmt, external_ptr=glm.members[0].device_ptr())
+        with pytest.raises(native.IlluminantError) as refusal:
+            native.render_sphere_lights(sib, few, env, dfu, None, sdfs[0], None, foreign, *glm.strips[0])
+        assert refusal.value.code == abi.ERR_STATE and "ANOTHER context" in str(refusal.value)
+        foreign.close(); sib.close()
         lm = native.Lightmap(ctx, w, h, fmt)
         sdf0 = native.DistanceFieldTexture(ctx, atlas, abi.SDF_FP16)
         native.render_sphere_lights(ctx, lights, env, dfu, None, sdf0, AMBIENT, lm)
