@@ -169,6 +169,13 @@ def test_group_entry_points_validate_without_a_device():
     assert lib.ilm_group_sync(abi.Handle(0)) == abi.ERR_INVALID_HANDLE
     assert lib.ilm_group_lightmap_gather(abi.Handle(12345), 1) == abi.ERR_INVALID_HANDLE
     assert lib.ilm_group_lightmap_create(abi.Handle(0), 16, 16, 0, C.byref(out)) == abi.ERR_INVALID_HANDLE
+    # the entry points of r05: store mode, the asynchronous exchange's wait, sibling contexts, the launch diagnostics
+    assert lib.ilm_group_lightmap_store_mode(abi.Handle(0), 1) == abi.ERR_INVALID_HANDLE
+    assert lib.ilm_group_lightmap_store_mode(abi.Handle(987654321), 0) == abi.ERR_INVALID_HANDLE
+    assert lib.ilm_group_lightmap_wait(abi.Handle(0)) == abi.ERR_INVALID_HANDLE
+    assert lib.ilm_ctx_create_sibling(abi.Handle(0), C.byref(out)) == abi.ERR_INVALID_HANDLE and out.value == 0
+    n = C.c_int32(7)
+    assert lib.ilm_debug_last_light_launch(abi.Handle(0), C.byref(n), C.byref(n), C.byref(n)) == abi.ERR_INVALID_HANDLE
     assert lib.ilm_group_create(None, 0, C.byref(out)) == abi.ERR_INVALID_ARGUMENT
     ids = (C.c_int32 * 2)(0, 1)
     if native.device_count() == 0:
