@@ -45,6 +45,32 @@ def main():
         for r in rows[:8]:
             lines.append("| `%s` | %s | %.2f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3, r["Percentage"]))
         lines.append("")
+        # The light pass is also launched two at a time (bench.py's two_frames_in_flight row: alternate frames on sibling contexts): a
+        # launch that shares the device with another light-pass launch takes about twice as long and says nothing about the kernel.  The
+        # averages bench.py's ms_per_frame / roofline_lighting are to be checked against are those of the launches that ran ALONE.
+        trace = find(os.path.join(raw, "stats"), "kernel_trace.csv")
+        if trace:
+            light = []
+            for r in csv.DictReader(open(trace)):
+                if "sphere_lights_kernel" in r["Kernel_Name"]:
+                    light.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"]), int(r["Grid_Size_X"])))
+            light.sort()
+            alone, shared = collections.defaultdict(list), collections.defaultdict(list)
+            for i, (b, e, name, grid) in enumerate(light):
+                overlap = 0
+                for j in range(max(0, i - 4), min(len(light), i + 5)):
+                    if j != i:
+                        overlap = max(overlap, min(e, light[j][1]) - max(b, light[j][0]))
+                (shared if overlap > 0.05 * (e - b) else alone)[(name, grid)].append(e - b)
+            lines += ["### light-pass launches, alone on the device vs sharing it with another light-pass launch (frames in flight)", "",
+                      "| kernel | grid (threads) | alone: calls | alone: average us | alone: median us | overlapped: calls | overlapped: average us |", "|---|---|---|---|---|---|---|"]
+            for key in sorted(set(alone) | set(shared), key=lambda k: -sum(alone.get(k, [])) - sum(shared.get(k, []))):
+                a, o = sorted(alone.get(key, [])), shared.get(key, [])
+                if len(a) + len(o) < 8:
+                    continue
+                lines.append("| `%s` | %d | %d | %s | %s | %d | %s |" % (key[0], key[1], len(a), ("%.2f" % (sum(a) / len(a) / 1e3)) if a else "-",
+                                                                 ("%.2f" % (a[len(a) // 2] / 1e3)) if a else "-", len(o), ("%.2f" % (sum(o) / len(o) / 1e3)) if o else "-"))
+            lines.append("")
 
     # PMC passes
     # Per kernel and counter the MEDIAN over its dispatches: a kernel name can carry launches of different scenes (the 4K kernel also
