@@ -688,6 +688,10 @@ def main():
         # TEST HOOK (tests/test_two_ranks_one_gpu.py): every rank on device 0, the exchange through tests/fake_rccl.cpp (ILM_RCCL_LIB) -- the
         # whole N > 1 branch executed at world size > 1 on the build box's one GPU.  The record says so; its numbers mean nothing.
         local_rank = 0
+    if local_rank >= native.device_count() and native.device_count() == 1 and (os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")):
+        # a launcher that hands every rank ONE visible GPU of its own: that GPU is device 0 here (two ranks that were handed the SAME
+        # physical GPU are refused below by RCCL itself: it will not build a communicator with a device twice)
+        local_rank = 0
     if local_rank >= native.device_count():
         raise SystemExit("bench.py: rank %d wants GPU %d but this box has %d GPU(s)" % (rank, local_rank, native.device_count()))
 
