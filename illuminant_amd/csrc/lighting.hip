@@ -294,14 +294,6 @@ ILM_DEV void cone_trace_loop(const f3& start, const f3& dir, float data_y, float
             const f3 sp = mk3(__builtin_fmaf(dir.x, data_x, start.x), __builtin_fmaf(dir.y, data_x, start.y), __builtin_fmaf(dir.z, data_x, start.z));
             const float s = sample_inside_table<FMT>(sp, F.inside, F.sdf, F.table);
             if (STATS) st.samples++;
-#ifdef ILM_EXP_EXTRA_A             // EXPERIMENT (timing only): four more instructions of the fast class (add / sub / mul / fmac) per sample
-            { float dummy = data_x;
-              asm volatile("v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1\n v_add_f32 %0, %0, %1" : "+v"(dummy) : "v"(s)); }
-#endif
-#ifdef ILM_EXP_EXTRA_B             // EXPERIMENT (timing only): four more instructions of the other class (fract / cvt / min / shifts / mix)
-            { float dummy = data_x;
-              asm volatile("v_fract_f32 %0, %0\n v_fract_f32 %0, %0\n v_fract_f32 %0, %0\n v_fract_f32 %0, %0" : "+v"(dummy)); }
-#endif
             const float local_radius = __builtin_elementwise_minimum(__builtin_fmaf(cone_growth, data_x, ref::kMinConeRadius), cone_max_radius);
             // visibility = min(visibility, n / r) with n = distance + HACK_DISTANCE_OFFSET (coneTraceStep, ConeTrace.fxh:62-63).  The quotient
             // only matters when it is below the running minimum v, and away from obstacles it never is.  With g = fl(v (1 + 2^-20)), kept
