@@ -129,6 +129,77 @@ def light_launch_waves(native_ctx):
     return native_ctx.last_light_launch()[0] * 4
 
 
+class CollectiveLog:
+    """The ordered list of collectives a run issues: every call of a group entry point that ends in RCCL traffic is
+    noted here BEFORE it is issued -- phase, entry point, what it puts on the wire, bytes per rank -- with consecutive identical calls
+    folded into one line with a count.  With N > 1 every NEW line also goes to stderr at once (flushed), so that a hang on hardware is
+    located by the last line of the log; `bench.py --dry-collectives` walks the whole N > 1 branch once at minimal repetition and prints
+    the list (profiles/r06_collective_schedule.txt).  Host-side bookkeeping only: nothing here touches the data path."""
+
+    def __init__(self):
+        self.lines, self.echo, self.rank, self._phase = [], False, 0, "start-up"
+
+    def phase(self, name):
+        self._phase = name
+
+    def add(self, entry_point, wire, bytes_per_rank):
+        key = (self._phase, entry_point, wire, int(bytes_per_rank))
+        if self.lines and self.lines[-1][0] == key:
+            self.lines[-1][1] += 1
+            return
+        self.lines.append([key, 1])
+        if self.echo:
+            print("[collective %4d r%d] %s | %s | %s | %d B/rank" % (len(self.lines), self.rank, key[0], key[1], key[2], key[3]), file=sys.stderr, flush=True)
+
+    def table(self):
+        out = ["# seq | phase | entry point | on the wire | bytes per rank | consecutive calls"]
+        for i, (key, n) in enumerate(self.lines):
+            out.append("%4d | %s | %s | %s | %d | x%d" % (i + 1, key[0], key[1], key[2], key[3], n))
+        return out
+
+
+COLLECTIVES = CollectiveLog()
+
+
+def log_group_collectives(native, world):
+    """Wrap the bindings' methods that issue collectives so that every call is noted in COLLECTIVES first (see CollectiveLog)."""
+    def wrap(cls, name, describe):
+        orig = getattr(cls, name)
+
+        def logged(self, *a, **k):
+            d = describe(self, *a, **k)
+            if d is not None:
+                COLLECTIVES.add(*d)
+            return orig(self, *a, **k)
+        setattr(cls, name, logged)
+    G, L = native.Group, native.GroupLightmap
+
+    def lightmap_exchange(glm, mode):
+        base = mode & ~native.GATHER_ASYNC
+        row = glm.width * {0: 16, 1: 8, 2: 4}[glm.format]
+        asy = " on the exchange stream" if (mode & native.GATHER_ASYNC) else ""
+        if base == native.GATHER_STORE:
+            return ("ilm_group_lightmap_gather(STORE)", "fence: ncclAllGather", 8)
+        if base == native.GATHER_RCCL:
+            equal = all(glm.strips[r] == (min(r * glm.slot_rows, glm.height), min((r + 1) * glm.slot_rows, glm.height)) for r in range(world))
+            if equal:
+                return ("ilm_group_lightmap_gather(RCCL)", "ncclAllGather in place" + asy, glm.slot_rows * row)
+            b, e = glm.strips[glm.group.first_rank]
+            return ("ilm_group_lightmap_gather(RCCL)", "ncclGroup of %d ncclSend + %d ncclRecv (strips)%s" % (world - 1, world - 1, asy), (e - b) * row)
+        return None
+    wrap(G, "host_all_gather", lambda self, b: ("ilm_group_host_all_gather", "hipMemcpy H2D + ncclAllGather + hipMemcpy D2H, stream sync", len(b) // self.n_local))
+    wrap(G, "live_counts", lambda self, systems, total, saturate16=False: ("ilm_group_live_counts", "stream sync + ncclAllGather of the per-chunk counts", 4 * ((total + world - 1) // world)))
+    wrap(G, "gather_chunks", lambda self, src, dst, total, first=0, count=4, gather=2:
+         ("ilm_group_gather_chunks(components %d..%d)" % (first, first + count - 1), "ncclGroup of %d x (ncclSend + ncclRecv), one per owned chunk and peer" % (((total + world - 1) // world) * (world - 1)),
+          ((total + world - 1) // world) * count * int(dst[0].device_ptr(0, 0)[1]) * 4))
+    wrap(G, "render_sphere_lights", lambda self, lights, env, df, gb, sdfs, amb, glm, gather=1, want_stats=False: lightmap_exchange(glm, gather) and
+         ("ilm_group_render_sphere_lights -> " + lightmap_exchange(glm, gather)[0], lightmap_exchange(glm, gather)[1], lightmap_exchange(glm, gather)[2]))
+    wrap(L, "gather", lambda self, mode: lightmap_exchange(self, mode))
+    wrap(L, "set_strips", lambda self, strips=None: ("ilm_group_lightmap_set_strips", "ncclAllGather of the table's hash (host payload)", 8))
+    wrap(L, "store_mode", lambda self, enable=True: ("ilm_group_lightmap_store_mode(%d)" % (1 if enable else 0),
+                                                      "arming: ncclAllGather of 64 B IPC handles, of 8 B verdicts, 3 x 8 B of the stamp proof (first arming of a lightmap); disarming: one 8 B ncclAllGather", 64))
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -149,9 +220,16 @@ def parse_args():
     ap.add_argument("--no-next-rows", action="store_true", help="skip the SURVEY 8f measurements (read-back, particle lights, resolve)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dry-collectives", action="store_true", help="N > 1 (or ILM_BENCH_FORCE_DIST): walk the whole branch once at minimal repetition and print the ordered list of "
+                    "collectives with their byte counts instead of the record (profiles/r06_collective_schedule.txt)")
+    ap.add_argument("--no-particle-collective-rows", action="store_true", help="N > 1: skip the particle rows with collectives (live counts, Pos+Life all-gather)")
     ap.add_argument("--blocks", type=int, default=0, help="timed K-step blocks (0: as many as fill ~50 ms of GPU time, 3..15); "
                                                           "the headline is the median block, min / max are reported beside it")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.dry_collectives:
+        args.steps, args.warmup, args.blocks, args.light_frames, args.light_ms, args.sustain_s = 5, 0, 1, 1, 0.0, 0.0
+        args.no_cpu_baseline = args.no_next_rows = True
+    return args
 
 
 def exchange_unique_id(native, rank, world):
@@ -249,11 +327,13 @@ def particle_row(world_units, live_per_rank, k, blocks, kernel, traffic=None):
     """A particle-step row from time_blocks(): median block; `world_units` = how many ranks' units the wall time covers."""
     w, g = blocks[len(blocks) // 2]
     gbs = live_per_rank * PARTICLE_BYTES_PER_SLOT / (g / k * 1e-3) / 1e9
+    gbs_wall = live_per_rank * PARTICLE_BYTES_PER_SLOT / (w / k) / 1e9      # the same bytes over ms_per_step (wall clock, max over ranks, barriers included)
     return {"mparticle_steps_per_s": round(world_units * live_per_rank * k / w / 1e6, 1), "ms_per_step": round(w / k * 1e3, 5), "steps": k,
             "particles_per_gpu": live_per_rank,
             "timed_blocks": {"blocks": len(blocks), "steps_per_block": k, "headline": "median block", "ms_per_step_min": round(blocks[0][0] / k * 1e3, 5),
                              "ms_per_step_max": round(blocks[-1][0] / k * 1e3, 5)},
             "roofline": {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+                         "frac_from_ms_per_step": round(gbs_wall / HBM_PEAK_GBS, 4),
                          **step_traffic_fields(traffic, live_per_rank), "kernel": kernel, "bytes_per_unit": PARTICLE_BYTES_PER_SLOT,
                          "units_per_launch": live_per_rank, "launch_ms": round(g / k, 5)}}
 
@@ -276,7 +356,7 @@ def balance_strips(glm, ranks, height, packed_lights, time_strip, rounds=2):
     return history
 
 
-def scaling_detail(world, share, share_solo, full_64m_solo, strong_64m, per_rank_rates, frames):
+def scaling_detail(world, share, share_solo, full_64m_solo, strong_64m, per_rank_rates, frames, collective_rows=None):
     """The N > 1 line describes itself (VERDICT r04 #1c): every ratio names its denominator, and the denominators are measured by rank 0
     ALONE in the same job (the other ranks wait at a barrier), so that no ratio divides across workloads or across boxes.
       share          the headline row: 8 chunks of 1024^2 per rank, all ranks stepping together (aggregate over the job)
@@ -300,17 +380,26 @@ def scaling_detail(world, share, share_solo, full_64m_solo, strong_64m, per_rank
             "sharded_64m": {"workload": strong_64m["workload"], "mparticle_steps_per_s": strong_64m["mparticle_steps_per_s"], "ms_per_step": strong_64m["ms_per_step"]},
             "strong_vs_one_gpu_64m": round(strong_64m["mparticle_steps_per_s"] / full_64m_solo["mparticle_steps_per_s"], 4),
             "strong_vs_one_gpu_64m_is": "64 M particles stepped by the job (64 / ranks chunks per rank) / the same 64 M on rank 0's GPU alone; the north star asks >= 6.4 at 8 ranks"})
+    if collective_rows:
+        # BASELINE config 4 / SURVEY 8e row P: the step WITH the collectives the path has, beside the communication-free figure above
+        for key in ("with_live_counts", "with_position_all_gather"):
+            if key in collective_rows:
+                row = collective_rows[key]
+                if "mparticle_steps_per_s" in row:
+                    row = dict(row, vs_without_collectives=round(row["mparticle_steps_per_s"] / share["mparticle_steps_per_s"], 4))
+                d["particles"][key] = row
     d["frames"] = frames
     return d
 
 
-def finalize_record(out, world, forced_dist, step_us_cfg2):
+def finalize_record(out, world, forced_dist, step_us_cfg2, collective_rows=None):
     """The last stage of the record: with N > 1 the whole-job number is taken where the north star puts the scaling target -- 64 M particles
     on 8 GPUs = cfg4's per-GPU share (8 chunks of 1024^2 per rank, HBM-resident) -- and N x cfg2 (cache-resident on every GPU) becomes the
     secondary row; then the summary and the key order (the driver keeps the parsed keys and the LAST ~2000 characters of the line: bulky
     rows first; the rooflines, the CPU baseline, the scaling block and a compact summary of both hot paths last).  Pure: dict in, dict out."""
     c4h = out.get("cfg4_share_8m_particles")
-    if (world > 1 or forced_dist) and c4h:
+    multi = world > 1 or forced_dist
+    if multi and c4h:
         out["cfg2_weak_row"] = {"mparticle_steps_per_s": out["value"], "ms_per_step": out["ms_per_step"], "roofline": out["roofline"],
                                 "workload": out["config"]["workload"], "timed_blocks": out.pop("timed_blocks")}
         out["value"] = c4h["mparticle_steps_per_s"]
@@ -319,14 +408,43 @@ def finalize_record(out, world, forced_dist, step_us_cfg2):
         out["timed_blocks"] = c4h["timed_blocks"]
         out["config"]["workload"] = "cfg4: %d particles per GPU in 8 chunks of 1024^2 (64 M on 8 GPUs), Gravity(4 attractors)+Noise+UpdatePositions" % c4h["particles_per_gpu"]
         out["config"]["particles_per_gpu"] = c4h["particles_per_gpu"]
-        out["config"]["parallelism"] = ("particles: chunk c on rank c mod %d, no data-path collective; lit frame: cost-balanced row strips of whole 16-row bands "
+        out["config"]["parallelism"] = ("particles: chunk c on rank c mod %d; lit frame: cost-balanced row strips of whole 16-row bands "
                                         "(balanced_row_strips, then re-cut twice from the ranks' measured strip times: rebalance_row_strips), range exchange over RCCL send/recv" % world)
+        # BASELINE config 4 is "per-chunk update + RCCL all-gather": when the rows with the collectives were measured (they run last, under
+        # the watchdog), the headline is the step WITH the live-count all-gather of every liveness interval (ParticleLiveness.cs:14,
+        # ParticleEngine.cs:282-386); the communication-free figure stays beside it.  Otherwise the headline says that it has no collective.
+        wl = (collective_rows or {}).get("with_live_counts") or {}
+        out["value_without_collectives"] = c4h["mparticle_steps_per_s"]
+        if "mparticle_steps_per_s" in wl:
+            out["value"] = wl["mparticle_steps_per_s"]
+            out["ms_per_step"] = wl["ms_per_step"]
+            out["timed_blocks"] = wl["timed_blocks"]
+            out["roofline"] = dict(wl["roofline"], resident=out["roofline"]["resident"])
+            out["config"]["collective_in_the_timed_steps"] = ("ilm_group_live_counts (one small RCCL all-gather of the per-chunk counts) after every counting step: "
+                                                              "%s call(s) in the %d timed steps of a block" % (wl.get("live_count_calls_per_block"), wl["steps"]))
+        else:
+            out["config"]["collective_in_the_timed_steps"] = "none: the rows with collectives (scaling_detail.particles) did not finish; `value` is the communication-free step"
+    c64h = out.get("cfg4_full_64m_one_gpu")
+    if not multi and c64h:
+        # N = 1 (VERDICT r05 #1c): the north star's particle target is defined at 64 M particles (ParticleSystem.cs:49: 64 chunks), the
+        # size at which the state (5.4 GB) is HBM-resident -- that row is `value`; cfg2 (84 MB, Infinity-Cache-resident) stays beside it.
+        out["cfg2_cache_resident"] = {"mparticle_steps_per_s": out["value"], "ms_per_step": out["ms_per_step"], "roofline": out["roofline"],
+                                      "workload": out["config"]["workload"], "timed_blocks": out.pop("timed_blocks"),
+                                      "live_particles_per_step_avg": out["config"].pop("live_particles_per_step_avg", None),
+                                      "spawned_in_run": out["config"].pop("spawned_per_gpu_in_run", None), "chunks_at_end": out["config"].pop("chunks_at_end", None)}
+        out["value"] = c64h["mparticle_steps_per_s"]
+        out["ms_per_step"] = c64h["ms_per_step"]
+        out["roofline"] = c64h["roofline"]
+        out["timed_blocks"] = c64h["timed_blocks"]
+        out["config"]["workload"] = "cfg4-64M on one GPU: " + c64h["workload"].split(": ", 1)[1]
+        out["config"]["particles_per_gpu"] = c64h["particles_per_gpu"]
+        out["config"]["parallelism"] = "one GPU: 64 chunks in one launch pair per step (the chunk range halved over the context's two streams)"
     tail_keys = ["cpu_baseline", "roofline", "roofline_hbm_resident", "cfg4_full_64m_one_gpu", "roofline_lighting_cfg3", "roofline_lighting", "lit_mpixels_per_s", "scaling_detail", "summary"]
     c4 = out.get("cfg4_share_8m_particles")
     if c4:
         out["roofline_hbm_resident"] = dict(c4["roofline"], workload="cfg4 per-GPU share: 8 chunks of 1024^2 = 8.4 M particles, 0.67 GB of state (> Infinity Cache)",
                                             ms_per_step=c4["ms_per_step"], mparticle_steps_per_s=c4["mparticle_steps_per_s"])
-    cfg2_row = out.get("cfg2_weak_row", {"mparticle_steps_per_s": out["value"], "roofline": out["roofline"]})
+    cfg2_row = out.get("cfg2_weak_row") or out.get("cfg2_cache_resident") or {"mparticle_steps_per_s": out["value"], "roofline": out["roofline"]}
     summary = {"particles_cfg2": {"mparticle_steps_per_s": cfg2_row["mparticle_steps_per_s"], "us_per_step": round(step_us_cfg2, 2),
                                   "frac_of_hbm_peak": cfg2_row["roofline"]["frac"], "resident": "infinity-cache"}}
     if c4:
@@ -366,8 +484,6 @@ def exchange_variant_rows(v):
     w, h, row_begin, row_end, light_frames, n_s, frame_ms, one_gpu_ms = v.w, v.h, v.row_begin, v.row_end, v.light_frames, v.n_s, v.frame_ms, v.one_gpu_ms
     barrier, max_over_ranks = ranks.barrier, ranks.max
     frame_scaling = {}
-    if os.environ.get("ILM_BENCH_HANG_OPTIONAL") and ranks.rank == ranks.world - 1:      # TEST HOOK (tests/test_two_ranks_one_gpu.py): the last rank never arrives
-        time.sleep(1e6)
 
     def time_strip(b_, e_, n_=4, sync=barrier):
         for _ in range(2):
@@ -457,8 +573,115 @@ def exchange_variant_rows(v):
     return frame_scaling
 
 
-def run_optional_rows(deferred, frames_scaling, timeout_s, rank, emit_fallback, barrier):
-    """deferred: [(pin, namespace)] -- exchange_variant_rows for each, merged into frames_scaling[pin].  A watchdog THREAD (the main thread
+class SystemHandle:
+    """A mirror ParticleSystem (illuminant_amd/host) as the ctypes bindings of the group entry points want it: something with .handle."""
+
+    def __init__(self, abi, handle):
+        self.handle = abi.Handle(int(handle))
+
+
+def step_counted_live(ps):
+    """Did the ParticleSystem.Update just issued carry ILM_STEP_COUNT_LIVE?  (IlmStepDesc.Flags at byte 20 of the descriptor the mirror
+    launched last: the mirror counts every LivenessCheckInterval-th frame, ParticleLiveness.cs:14,80-105, fused into the update launch.)"""
+    import struct
+    return bool(struct.unpack_from("<I", ps.LastStepBytes(), 20)[0] & 1)
+
+
+def particle_collective_rows(v):
+    """The N > 1 particle rows WITH the collectives of the path (BASELINE config 4: "per-chunk update + RCCL all-gather"):
+      with_live_counts          cfg4's per-GPU share stepped as in the headline block, and after every step that counted live particles
+                                (the reference's liveness interval) ilm_group_live_counts: the whole table, identical on every rank,
+                                through one small RCCL all-gather -- inside the timed steps.  The table is checked (every chunk 1024^2 live).
+      with_position_all_gather  the same steps, each followed by ilm_group_gather_chunks of Pos+Life (components 0..3: 16 B per slot, 134 MB
+                                per rank at 8 chunks of 1024^2) into every rank's gathered system -- what a global consumer (particle lights,
+                                host readback) needs; the exchange alone by HIP events beside it; a checksum of every rank's first chunk
+                                is compared with the owner's.
+    They run LAST under the watchdog (run_optional_rows).  Returns {"with_live_counts": .., "with_position_all_gather": ..}."""
+    import struct
+    import zlib
+    H, native, abi, scenes, args = v.H, v.native, v.abi, v.scenes, v.args
+    ctx, group, ranks, rank, world = v.ctx, v.group, v.ranks, v.rank, v.world
+    dt, k = 1.0 / 60.0, v.k
+    rows = {}
+    Q = build_particle_system(H, ctx, scenes, abi, 1024, 8, rank, with_spawner=False)
+    ps, tp, frame = Q["ps"], Q["tp"], [0]
+    sysh = SystemHandle(abi, ps.Handle)
+    total = 8 * world
+    state = {"calls": 0, "table": None}
+
+    def plain():
+        tp.Advance(dt); ps.Update(frame[0]); frame[0] += 1
+
+    def with_counts():
+        plain()
+        if step_counted_live(ps):
+            state["table"] = group.live_counts([sysh], total)
+            state["calls"] += 1
+    for _ in range(20):
+        plain()
+    try:
+        COLLECTIVES.phase("particles: cfg4 share + ilm_group_live_counts at every counting step")
+        n_blocks = 5
+        blocks = time_blocks(ctx, ranks, with_counts, k, n_blocks)
+        row = particle_row(world, Q["live"], k, blocks, v.kernel, v.traffic)
+        table = state["table"]
+        ok = table is not None and len(table) == total and bool((table == 1024 * 1024).all())
+        row.update({"live_count_calls_per_block": round(state["calls"] / float(n_blocks), 2),
+                    "live_count_table": {"chunks": total, "every_chunk_live": 1024 * 1024, "bit_exact_on_every_rank": bool(ranks.sum(0.0 if ok else 1.0) == 0.0)} if table is not None else None,
+                    "collective": "ilm_group_live_counts: ilm_system_step_counts of the rank's chunks (synchronises the stream), one RCCL all-gather of %d B per rank, the table in chunk order" % (4 * 8),
+                    "is": "the headline block's steps with the liveness table gathered after every counting step (every 5th Update of the mirror, as the reference's FramesUntilNextLivenessCheck)"})
+        rows["with_live_counts"] = row
+    except Exception as e_:      # noqa: BLE001 -- the communication-free figure stands
+        rows["with_live_counts"] = {"error": "%s: %s" % (type(e_).__name__, e_)}
+    try:
+        COLLECTIVES.phase("particles: cfg4 share + ilm_group_gather_chunks(Pos+Life) after every step")
+        nctx = native.Context(v.local_rank, borrowed_handle=ctx.Handle)
+        geng = native.Engine(nctx, 1024, Q["rnd"])
+        gsys = native.System(geng)
+        for _ in range(total):
+            gsys.add_chunk()
+
+        def with_gather():
+            plain()
+            group.gather_chunks([sysh], [gsys], total, 0, 4, native.GATHER_RCCL)
+        for _ in range(2):
+            with_gather()
+        blocks = time_blocks(ctx, ranks, with_gather, k, 3)
+        row = particle_row(world, Q["live"], k, blocks, v.kernel, None)
+        ranks.barrier()
+        n_x = max(3, min(k, 10))
+        ctx.TimerStart()
+        for _ in range(n_x):
+            group.gather_chunks([sysh], [gsys], total, 0, 4, native.GATHER_RCCL)
+        x_ms = ranks.doubles(ctx.TimerStop() / n_x)
+        ranks.barrier()
+        # every rank's copy of chunk (r, 0) = table chunk r against its owner's planes: CRC32 of the first 65 536 Pos+Life slots
+        own = np.zeros((65536, 4), np.float32)
+        import ctypes as C_
+        native.check(native.lib().ilm_chunk_download(sysh.handle, 0, abi.PLANE_POSITION, own.ctypes.data_as(C_.c_void_p), 0, 65536))
+        crcs = [struct.unpack("<Q", b)[0] for b in group.host_all_gather(struct.pack("<Q", zlib.crc32(own.tobytes())))]
+        same = all(zlib.crc32(np.ascontiguousarray(gsys.download(r, abi.PLANE_POSITION, 0, 65536)).tobytes()) == crcs[r] for r in range(world))
+        per_rank_bytes = 8 * 4 * int(gsys.device_ptr(0, 0)[1]) * 4          # chunks x components x stride (floats) x 4 B
+        row.update({"exchange_ms": round(max(x_ms), 4), "exchange_ms_per_rank": [round(t, 4) for t in x_ms],
+                    "exchange_is": "HIP events around back-to-back ilm_group_gather_chunks calls alone, max over ranks",
+                    "bytes_sent_per_rank_and_peer": per_rank_bytes, "bytes_received_per_rank": per_rank_bytes * (world - 1),
+                    "egress_gb_per_s_per_rank": round(per_rank_bytes * (world - 1) / (max(x_ms) * 1e-3) / 1e9, 1) if world > 1 else None,
+                    "gathered_chunks_match_their_owners": bool(ranks.sum(0.0 if same else 1.0) == 0.0),
+                    "collective": "ilm_group_gather_chunks(components 0..3 = Pos+Life, ILM_GATHER_RCCL): one group of %d ncclSend + %d ncclRecv of %d B per rank and call, chunk planes to chunk planes (no packing)"
+                                  % (8 * (world - 1), 8 * (world - 1), per_rank_bytes // 8),
+                    "is": "the same steps, each followed by the Pos+Life all-gather a global consumer needs (SURVEY 8e: optional; reported with and without)"})
+        row["roofline"] = None       # (the row's time is the exchange's, not the step kernel's)
+        rows["with_position_all_gather"] = row
+        gsys.close(); geng.close()
+    except Exception as e_:      # noqa: BLE001
+        rows["with_position_all_gather"] = {"error": "%s: %s" % (type(e_).__name__, e_)}
+    del Q, ps
+    return rows
+
+
+def run_optional_rows(deferred, frames_scaling, timeout_s, rank, emit_fallback, barrier, particle_rows=None, hang_rank=False):
+    """particle_rows: (namespace, dict) -- particle_collective_rows(namespace) merged into dict, first (they decide the headline).
+    deferred: [(pin, namespace)] -- exchange_variant_rows for each, merged into frames_scaling[pin].  A watchdog THREAD (the main thread
     may sit inside a collective) ends the job cleanly when they have not finished in timeout_s: rank 0 prints the record assembled WITHOUT
     them (emit_fallback), every rank leaves with status 0 -- the hardware run's figures survive a hang in an optional row."""
     import threading
@@ -474,7 +697,12 @@ def run_optional_rows(deferred, frames_scaling, timeout_s, rank, emit_fallback, 
             os._exit(0)
     t = threading.Thread(target=watchdog, daemon=True)
     t.start()
+    if os.environ.get("ILM_BENCH_HANG_OPTIONAL") and hang_rank:      # TEST HOOK (tests/test_two_ranks_one_gpu.py): the last rank never arrives
+        time.sleep(1e6)
+    if particle_rows is not None:
+        particle_rows[1].update(particle_collective_rows(particle_rows[0]))
     for pin, v in deferred:
+        COLLECTIVES.phase("lit frame %s: optional exchange variants (pipelined, store mode)" % pin)
         frames_scaling[pin].update(exchange_variant_rows(v))
     v = None
     barrier()               # EVERY rank is through: a rank that finished while another hangs waits here, under its own watchdog
@@ -704,6 +932,8 @@ def main():
         # runtime, and a process that has initialised /opt/rocm's runtime (this library) cannot initialise a second one
         # (tools/hip_runtime_order_probe.py: "No HIP GPUs are available").  torchrun is only the launcher; rank 0 hands the 128-byte
         # RCCL id to the other ranks of the node through a file keyed by the launcher's pid.
+        log_group_collectives(native, world)
+        COLLECTIVES.rank, COLLECTIVES.echo = rank, (world > 1 and rank in (0, world - 1)) or bool(os.environ.get("ILM_BENCH_LOG_COLLECTIVES"))
         group = native.Group.rank(local_rank, rank, world, exchange_unique_id(native, rank, world))
         comm_ranks = group.comm_ranks()
         if comm_ranks != n_gpus:
@@ -721,6 +951,7 @@ def main():
     multi = world > 1 or forced_dist        # the N > 1 shape of the record (ILM_BENCH_FORCE_DIST: the same code at world 1, for one-GPU boxes)
 
     # ---- particles (the timed region of the contract) ------------------------------------------------------------
+    COLLECTIVES.phase("particles: cfg2, all ranks (barriers and max-over-ranks of the timed blocks)")
     P = build_particle_system(H, ctx, scenes, abi, args.chunk_size, args.chunks, rank)
     ps, tp = P["ps"], P["tp"]
     dt = 1.0 / 60.0
@@ -891,6 +1122,7 @@ def main():
                          "note": "cache-served bytes priced against the HBM peak because that is the contract's roofline: read it like cfg2's fraction, not like cfg4's"}}
         del scene
     cpu_init, cpu_rnd, cpu_desc_bytes = P["init"], P["rnd"], ps.LastStepBytes()
+    cfg4_desc_bytes = None
     scaling_particles = None
     if not args.no_cfg4:
         del P, ps, spawner          # free cfg2's chunks before the 0.9 GB system is built
@@ -909,6 +1141,7 @@ def main():
                 one()
             return one
 
+        COLLECTIVES.phase("particles: cfg4 share (8 chunks of 1024^2 per rank), communication-free steps")
         Q = build_particle_system(H, ctx, scenes, abi, 1024, 8, rank, with_spawner=False)
         q_step = stepper(Q, 60)
         share_solo = None
@@ -928,11 +1161,13 @@ def main():
         # ParticleSystem.cs:49), 5.4 GB of state -- the denominator of the north star's "x 6.4 from 1 to 8 GPUs at 64 M particles".
         # N = 1: a row of the line.  N > 1: rank 0 measures it ALONE, in this job, before the ranks step their shards together.
         full_64m = strong_64m = None
+        COLLECTIVES.phase("particles: cfg4 whole (64 M) on rank 0 alone, then sharded over the job")
         if not args.no_cfg4_64m:
             k64 = args.steps
             if rank == 0:
                 F = build_particle_system(H, ctx, scenes, abi, 1024, 64, rank, with_spawner=False, replicate_cfg4_images=True)
                 full_64m = particle_row(1, F["live"], k64, time_blocks(ctx, ranks.solo(), stepper(F, 20), k64, 5), stream_kernel, stream_traffic)
+                cfg4_desc_bytes = F["ps"].LastStepBytes()
                 full_64m["workload"] = ("cfg4 whole on ONE GPU: 64 chunks of 1024^2 = %d particles (5.4 GB of state), Gravity(4 attractors)+Noise+UpdatePositions; "
                                         "chunk c = image c mod 8 of the share's eight, moved by (3, 2) x (c div 8) px" % F["live"])
                 full_64m["roofline"]["resident"] = "hbm (5.4 GB of particle state)"
@@ -972,6 +1207,7 @@ def main():
             glm = None
             ext = 0
             row_begin, row_end = 0, h
+            COLLECTIVES.phase("lit frame %s: strips, exchange, composited frame" % pin)
             if group is not None:
                 glm = native.GroupLightmap(group, w, h, abi.LIGHTMAP_HALF4)
                 ext = glm.members[0].device_ptr()
@@ -1209,9 +1445,11 @@ def main():
                 glm2.close()
                 del ref_frame
             if name.startswith("cfg5"):
-                # cfg5: + 16 M particles over the node = 2 chunks of 1024^2 per GPU stepped in the same frame (cfg2's
-                # transform list without the spawner); particle step and lit frame as two phases and as a whole, one stream
-                Q5 = build_particle_system(H, ctx, scenes, abi, 1024, 2, rank, with_spawner=False)
+                # cfg5: + 16 M particles = 16 chunks of 1024^2 stepped in the same frame (cfg2's transform list without the
+                # spawner): ALL of them at N = 1 (VERDICT r05 #1d), 16 / N per rank otherwise; particle step and lit frame as two phases
+                # and as a whole, one stream
+                n5 = len(range(rank, 16, world))              # 16 chunks of 1024^2 = the config's 16 M particles: all of them at N = 1, chunk c on rank c mod N otherwise
+                Q5 = build_particle_system(H, ctx, scenes, abi, 1024, n5, rank, with_spawner=False, replicate_cfg4_images=True)
                 q5, q5tp = Q5["ps"], Q5["tp"]
                 for f5 in range(3):
                     q5tp.Advance(1.0 / 60.0); q5.Update(f5)
@@ -1241,7 +1479,9 @@ def main():
                         glm.gather(native.GATHER_RCCL)
                 lit5_dev = ctx.TimerStop() / frames5
                 lighting[name]["with_particles"] = {
-                    "particles_per_gpu": Q5["live"], "particle_step_ms": round(step5_ms, 4),
+                    "particles_per_gpu": Q5["live"], "chunks_per_gpu": n5, "particles_in_the_job": int(sum_over_ranks(Q5["live"])),
+                    "is": "cfg5's 16 M particles (16 chunks of 1024^2, chunk c on rank c mod %d) stepped in the same frame as the lit frame: two phases and the whole, one stream" % world,
+                    "particle_step_ms": round(step5_ms, 4),
                     "particle_step_gb_per_s": round(Q5["live"] * PARTICLE_BYTES_PER_SLOT / (step5_ms * 1e-3) / 1e9, 1),
                     "frame_ms_step_plus_lighting": round(whole5, 4), "frame_ms_step_plus_lighting_device_clock": round(whole5_dev, 4),
                     "lit_frame_alone_same_loop_device_clock": round(lit5_dev, 4), "timed_frames": frames5,
@@ -1446,11 +1686,32 @@ def main():
             orc.step(chunks, cs, cpu_rnd, d)
             steps_done += 1
             el = time.perf_counter() - t0
-            if el > args.cpu_seconds:
+            if el > (args.cpu_seconds / 3.0 if cfg4_desc_bytes is not None else args.cpu_seconds):
                 break
-        out["cpu_baseline"] = {"value": round(live_slots * steps_done / el / 1e6, 2), "unit": "Mparticle-steps/s",   # spawned particles not counted here (< 1 % over the sample)
-                               "cores": orc.num_threads(), "kind": "port",
-                               "sample": "%d steps of the same cfg2 system (oracle/ilm_oracle.c, OpenMP, %.1f s)" % (steps_done, el)}
+        cfg2_cpu = {"value": round(live_slots * steps_done / el / 1e6, 2), "unit": "Mparticle-steps/s",   # spawned particles not counted here (< 1 % over the sample)
+                    "cores": orc.num_threads(), "kind": "port",
+                    "sample": "%d steps of the same cfg2 system (oracle/ilm_oracle.c, OpenMP, %.1f s)" % (steps_done, el)}
+        out["cpu_baseline"] = cfg2_cpu
+        if cfg4_desc_bytes is not None:
+            # the headline workload is cfg4 (64 chunks of 1024^2): its bounded sample = 2 of the 64 chunks (images 0 and 1 of the share's
+            # eight, 2.1 M particles) through the very descriptor the GPU ran last (Gravity x 4 + Noise + UpdatePositions)
+            p4, v4, a4 = cfg4_images(scenes, rank)
+            m4 = 1024 * 1024
+            chunks4 = [[p4[c * m4:(c + 1) * m4].copy(), v4[c * m4:(c + 1) * m4].copy(), a4[c * m4:(c + 1) * m4].copy(), np.zeros((m4, 4), np.float32), np.zeros((m4, 4), np.float32)]
+                       for c in range(2)]
+            d4 = abi.StepDesc.from_buffer_copy(cfg4_desc_bytes)
+            d4.FirstChunk, d4.ChunkCount = 0, -1
+            steps4 = 0
+            t0 = time.perf_counter()
+            while True:
+                orc.step(chunks4, 1024, cpu_rnd, d4)
+                steps4 += 1
+                el4 = time.perf_counter() - t0
+                if el4 > args.cpu_seconds:
+                    break
+            out["cpu_baseline"] = {"value": round(2 * m4 * steps4 / el4 / 1e6, 2), "unit": "Mparticle-steps/s", "cores": orc.num_threads(), "kind": "port",
+                                   "sample": "%d steps of 2 of cfg4's 64 chunks of 1024^2 (2.1 M particles, Gravity x 4 + Noise + UpdatePositions; oracle/ilm_oracle.c, OpenMP, %.1f s)" % (steps4, el4)}
+            out["cpu_baseline_cfg2"] = cfg2_cpu
 
     # Why the CPU baseline is the oracle ("port") and not the reference on D3D WARP: probed, not assumed.
     import platform
@@ -1465,15 +1726,18 @@ def main():
         out["config"]["rccl_communicator_ranks_per_rank"] = [struct.unpack("<i", b[:4])[0] for b in group.host_all_gather(struct.pack("<ii", comm_ranks, 0))]
     import copy
 
+    collective_rows = {}
+
     def assemble(optional_rows_note=None):
         o = copy.deepcopy(out)
         if multi and scaling_particles:
-            o["scaling_detail"] = scaling_detail(world, frames=(copy.deepcopy(frames_scaling) if not args.no_lighting else {}), **scaling_particles)
+            o["scaling_detail"] = scaling_detail(world, frames=(copy.deepcopy(frames_scaling) if not args.no_lighting else {}),
+                                                 collective_rows=copy.deepcopy(collective_rows), **scaling_particles)
             o["scaling_detail"]["note"] = ("the contract's top-level \"scaling\" stays the string \"weak\" (fixed work per GPU in the headline row); "
                                            "this block carries the named ratios")
             if optional_rows_note:
                 o["scaling_detail"]["optional_rows"] = optional_rows_note
-        return finalize_record(o, world, forced_dist, step_ms_gpu * 1e3)
+        return finalize_record(o, world, forced_dist, step_ms_gpu * 1e3, copy.deepcopy(collective_rows))
 
     def emit(o):
         sys.stdout.flush()
@@ -1482,16 +1746,34 @@ def main():
             print(json.dumps(o), flush=True)
         os.dup2(2, 1)
 
-    if not args.no_lighting and deferred_rows:
+    particle_rows = None
+    if multi and scaling_particles and not args.no_particle_collective_rows:
+        import types as types_
+        particle_rows = (types_.SimpleNamespace(H=H, native=native, abi=abi, scenes=scenes, args=args, ctx=ctx, group=group, ranks=ranks, rank=rank, world=world,
+                                                local_rank=local_rank, k=args.steps, kernel=stream_kernel, traffic=stream_traffic), collective_rows)
+    if args.no_lighting:
+        deferred_rows, frames_scaling, kept_alive = [], {}, []
+    if deferred_rows or particle_rows:
         # every figure above is in hand: the record as it stands is the fallback a watchdog prints if an optional row hangs
-        fallback = assemble("pipelined_exchange / store_mode did not finish within %d s: the record was printed without them" % args.optional_rows_timeout)
-        run_optional_rows(deferred_rows, frames_scaling, args.optional_rows_timeout, rank, lambda: emit(fallback), ranks.barrier)
+        fallback = assemble("the rows with particle collectives / pipelined_exchange / store_mode did not finish within %d s: the record was printed without "
+                            "(some of) them" % args.optional_rows_timeout)
+        run_optional_rows(deferred_rows, frames_scaling, args.optional_rows_timeout, rank, lambda: emit(fallback), ranks.barrier,
+                          particle_rows=particle_rows, hang_rank=(rank == world - 1))
         deferred_rows.clear()
         while kept_alive:
             L_, r_, g_ = kept_alive.pop()
             del L_, r_
             g_.close()
-    emit(assemble())
+    if args.dry_collectives:
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
+        if rank == 0:
+            print("# bench.py --gpus %d --dry-collectives: every collective of the N > 1 branch in issue order (rank 0's view; %d rank(s)%s)"
+                  % (n_gpus, world, ", ILM_BENCH_ONE_GPU stand-in" if one_gpu_stand_in else ""))
+            print("\n".join(COLLECTIVES.table()), flush=True)
+        os.dup2(2, 1)
+    else:
+        emit(assemble())
     if group is not None:
         import gc
         del ctx

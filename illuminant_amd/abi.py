@@ -7,7 +7,7 @@ offsets against the C header by compiling a probe.
 """
 import ctypes as C
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 OK = 0
 ERR_INVALID_ARGUMENT = -1

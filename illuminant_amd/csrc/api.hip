@@ -1104,6 +1104,20 @@ int ctx_child_count(IlmHandle h) {
     return c ? c->children : -1;
 }
 int set_step_streams(int n) { return set_step_streams_impl(n); }
+// ilm_group_gather_chunks (group.hip): one chunk of a system as the exchange sees it -- base of component 0, the stride between the
+// component planes, the chunk's slot count and the context it lives on.  `written`: the caller is about to overwrite planes of the
+// chunk, so every slot counts as used from now on (a later step must not skip units as never-written).
+int32_t system_chunk_view(IlmHandle system, int chunk, bool written, float** out_base, int64_t* out_stride, int32_t* out_chunk_size, IlmHandle* out_ctx) {
+    System* s = from_handle<System>(system, kMagicSystem);
+    if (!s) return fail(ILM_ERR_INVALID_HANDLE, "not a system handle");
+    if (chunk < 0 || chunk >= (int)s->chunks.size()) return fail(ILM_ERR_OUT_OF_RANGE, "chunk %d outside [0, %d)", chunk, (int)s->chunks.size());
+    if (out_base) *out_base = s->chunks[(size_t)chunk];
+    if (out_stride) *out_stride = s->engine->stride;
+    if (out_chunk_size) *out_chunk_size = s->engine->chunk_size;
+    if (out_ctx) *out_ctx = to_handle(s->engine->ctx);
+    if (written) s->used[(size_t)chunk] = s->engine->slots;
+    return ILM_OK;
+}
 hipStream_t ctx_stream_joined(IlmHandle h) {
     Ctx* c = from_handle<Ctx>(h, kMagicCtx);
     return c ? c->main() : nullptr;

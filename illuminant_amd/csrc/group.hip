@@ -375,21 +375,26 @@ int32_t prove_ipc_mappings(GroupLightmap* m, const std::vector<void*>& peers) {
     const size_t at[2] = { 0, (bytes - span) & ~(size_t)15 };             // (16-byte stores: aligned)
     std::vector<unsigned char> saved(2 * span), seen(2 * span);
     uint64_t token = 0; std::vector<uint64_t> all((size_t)world, 0);
-    HIP_TRY(hipStreamSynchronize(g->stream(0)));
-    for (int k = 0; k < 2; k++) HIP_TRY(hipMemcpy(saved.data() + (size_t)k * span, own + at[k], span, hipMemcpyDeviceToHost));
-    for (int k = 0; k < 2; k++) HIP_TRY(hipMemset(own + at[k], 0, span));
+    // From here to the last collective a LOCAL failure (a copy, a memset, the stamping kernel) never returns: it folds into this rank's
+    // verdict word and the rank keeps walking the same three all-gathers as the others -- a rank that left early would pair its next
+    // collective with the wrong one of its peers and hang them.
+    uint64_t ok = 1;
+    auto soft = [&ok](hipError_t e) { if (e != hipSuccess) { (void)hipGetLastError(); ok = 0; } };
+    soft(hipStreamSynchronize(g->stream(0)));
+    for (int k = 0; k < 2; k++) soft(hipMemcpy(saved.data() + (size_t)k * span, own + at[k], span, hipMemcpyDeviceToHost));
+    const bool have_saved = ok != 0;
+    for (int k = 0; k < 2 && ok; k++) soft(hipMemset(own + at[k], 0, span));
     { const int32_t rc = host_all_gather(g, &token, all.data(), sizeof(uint64_t)); if (rc != ILM_OK) return rc; }      // everybody's slots are blank
     const uint32_t serial = ++g->ipc_proofs;
     const uint32_t stamp[4] = { 0x494c4d00u, serial, (uint32_t)me, ~serial ^ (uint32_t)me };
-    uint64_t ok = 1;
     for (void* p : peers)
         for (int k = 0; k < 2 && ok; k++)
-            if (launch_stamp16(static_cast<char*>(p) + at[k] + 16u * (size_t)me, stamp, g->stream(0)) != hipSuccess) { (void)hipGetLastError(); ok = 0; }
-    if (hipStreamSynchronize(g->stream(0)) != hipSuccess) { (void)hipGetLastError(); ok = 0; }
+            soft(launch_stamp16(static_cast<char*>(p) + at[k] + 16u * (size_t)me, stamp, g->stream(0)));
+    soft(hipStreamSynchronize(g->stream(0)));
     { const int32_t rc = host_all_gather(g, &token, all.data(), sizeof(uint64_t)); if (rc != ILM_OK) return rc; }      // everybody has stamped
-    for (int k = 0; k < 2; k++) HIP_TRY(hipMemcpy(seen.data() + (size_t)k * span, own + at[k], span, hipMemcpyDeviceToHost));
+    for (int k = 0; k < 2 && ok; k++) soft(hipMemcpy(seen.data() + (size_t)k * span, own + at[k], span, hipMemcpyDeviceToHost));
     int missing = -1;
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < 2 && ok; k++)
         for (int r = 0; r < world; r++) {
             if (r == me) continue;
             const uint32_t want[4] = { 0x494c4d00u, serial, (uint32_t)r, ~serial ^ (uint32_t)r };
@@ -399,7 +404,9 @@ int32_t prove_ipc_mappings(GroupLightmap* m, const std::vector<void*>& peers) {
     std::vector<uint64_t> verdicts((size_t)world, 0);
     verdicts[(size_t)me] = ok;
     { const int32_t rc = host_all_gather(g, &verdicts[(size_t)me], verdicts.data(), sizeof(uint64_t)); if (rc != ILM_OK) return rc; }
-    for (int k = 0; k < 2; k++) HIP_TRY(hipMemcpy(own + at[k], saved.data() + (size_t)k * span, span, hipMemcpyHostToDevice));
+    if (have_saved)
+        for (int k = 0; k < 2; k++)
+            if (hipMemcpy(own + at[k], saved.data() + (size_t)k * span, span, hipMemcpyHostToDevice) != hipSuccess) (void)hipGetLastError();
     for (int r = 0; r < world; r++)
         if (!verdicts[(size_t)r])
             return api_fail(ILM_ERR_STATE, "ILM_GATHER_STORE: the IPC mappings do not address the ranks' lightmaps (rank %d did not find every other rank's stamp in its buffer): no rank arms the mode", r);
@@ -506,15 +513,29 @@ int32_t set_store_mode(GroupLightmap* m, bool enable) {
 // the exchange of a group lightmap's strips: one in-place all-gather for the equal slots, range by range otherwise
 // the second stream (and its events) of every local member, for ILM_GATHER_ASYNC
 int32_t ensure_exchange_streams(Group* g) {
-    if (!g->xstream.empty()) return ILM_OK;
-    for (int i = 0; i < g->n_local; i++) {
-        HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+    if (g->xstream.size() == (size_t)g->n_local) return ILM_OK;
+    // built aside and installed whole: after a partial failure the group has none, not a table shorter than n_local
+    std::vector<hipStream_t> streams; std::vector<hipEvent_t> forks, events;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < g->n_local && e == hipSuccess; i++) {
         hipStream_t st = nullptr; hipEvent_t a = nullptr, b = nullptr;
-        HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&a, hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&b, hipEventDisableTiming));
-        g->xstream.push_back(st); g->xfork.push_back(a); g->xevents.push_back(b);
+        e = hipSetDevice(g->devices[(size_t)i]);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&a, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&b, hipEventDisableTiming);
+        streams.push_back(st); forks.push_back(a); events.push_back(b);
     }
+    if (e != hipSuccess) {
+        for (size_t i = 0; i < streams.size(); i++) {
+            (void)hipSetDevice(g->devices[i]);
+            if (streams[i]) (void)hipStreamDestroy(streams[i]);
+            if (forks[i]) (void)hipEventDestroy(forks[i]);
+            if (events[i]) (void)hipEventDestroy(events[i]);
+        }
+        (void)hipGetLastError();
+        return api_fail((int32_t)e, "exchange streams of the group: %s", hipGetErrorString(e));
+    }
+    g->xstream.swap(streams); g->xfork.swap(forks); g->xevents.swap(events);
     return ILM_OK;
 }
 
@@ -611,6 +632,111 @@ int32_t host_all_gather(Group* g, const void* local, void* out, size_t bytes) {
     if (rc != ILM_OK) return rc;
     HIP_TRY(hipMemcpyAsync(o, d, total, hipMemcpyDeviceToHost, g->stream((size_t)0)));
     HIP_TRY(hipStreamSynchronize(g->stream((size_t)0)));
+    return ILM_OK;
+}
+
+
+// ilm_group_gather_chunks: the sharded particle state made whole.  Chunk c of the table lives on rank c % world as chunk c / world of
+// that member's source system; afterwards chunk c of every member's `gathered` system holds `count` consecutive component planes of it.
+// The planes of a chunk are contiguous (count * stride floats), so a chunk travels as ONE range straight from the owner's planes into
+// the destination's planes -- no pack, no unpack.  Peer mode: the owner pushes to the n - 1 others (one transfer per xGMI link and
+// chunk).  RCCL: one group of ncclSend / ncclRecv, rank r sends each of its chunks to every other rank and receives theirs in place,
+// peers staggered as in exchange_ranges; several transfers between one pair match in issue order (chunk order on both sides).
+struct ChunkRange { char* base; size_t bytes; };
+int32_t gather_chunks(Group* g, const IlmHandle* sources, const IlmHandle* gathered, int total_chunks, int first, int count, int32_t gather) {
+    const int world = g->world, n = g->n_local;
+    if (total_chunks == 0) return ILM_OK;
+    // every local member's view of its own chunks and of the whole table, validated before anything is queued
+    std::vector<std::vector<ChunkRange>> src((size_t)n), dst((size_t)n);
+    int64_t stride0 = 0; int32_t size0 = 0;
+    for (int i = 0; i < n; i++) {
+        const int rank = g->first_rank + i;
+        const int owned = (total_chunks - rank + world - 1) / world;
+        int32_t have = 0;
+        int32_t rc = ilm_system_chunk_count(sources[i], &have);
+        if (rc != ILM_OK) return rc;
+        if (have != owned)
+            return api_fail(ILM_ERR_STATE, "rank %d holds %d chunks but owns %d of a table of %d (chunk c lives on rank c %% %d)", rank, have, owned, total_chunks, world);
+        rc = ilm_system_chunk_count(gathered[i], &have);
+        if (rc != ILM_OK) return rc;
+        if (have != total_chunks)
+            return api_fail(ILM_ERR_STATE, "rank %d's gathered system has %d chunks, the table has %d", rank, have, total_chunks);
+        for (int pass = 0; pass < 2; pass++) {
+            const IlmHandle sys = pass ? gathered[i] : sources[i];
+            const int chunks = pass ? total_chunks : owned;
+            for (int k = 0; k < chunks; k++) {
+                float* base = nullptr; int64_t stride = 0; int32_t size = 0; IlmHandle ctx = 0;
+                rc = system_chunk_view(sys, k, pass != 0, &base, &stride, &size, &ctx);
+                if (rc != ILM_OK) return rc;
+                if (ctx != g->ctx[(size_t)i])
+                    return api_fail(ILM_ERR_INVALID_ARGUMENT, "the %s system of member %d lives on another context than the member's", pass ? "gathered" : "source", i);
+                if (stride0 == 0) { stride0 = stride; size0 = size; }
+                if (stride != stride0 || size != size0)
+                    return api_fail(ILM_ERR_INVALID_ARGUMENT, "the systems' engines differ in chunk size (%d / %d): one chunk geometry per table", size, size0);
+                ChunkRange r = { reinterpret_cast<char*>(base + (int64_t)first * stride), sizeof(float) * (size_t)count * (size_t)stride };
+                (pass ? dst : src)[(size_t)i].push_back(r);
+            }
+        }
+    }
+    auto S = [&](size_t i) { return g->stream(i); };
+    // a member's own chunks: device-local copies into its gathered system
+    for (int i = 0; i < n; i++) {
+        HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+        const int rank = g->first_rank + i;
+        for (size_t k = 0; k < src[(size_t)i].size(); k++) {
+            const ChunkRange& from = src[(size_t)i][k]; const ChunkRange& to = dst[(size_t)i][k * (size_t)world + (size_t)rank];
+            if (to.base != from.base) HIP_TRY(hipMemcpyAsync(to.base, from.base, from.bytes, hipMemcpyDeviceToDevice, S((size_t)i)));
+        }
+    }
+    if (gather == ILM_GATHER_NONE || world == 1) return ILM_OK;
+    if (gather == ILM_GATHER_PEER) {
+        if (g->rank_mode) return api_fail(ILM_ERR_STATE, "ILM_GATHER_PEER needs every member in this process: use ILM_GATHER_RCCL");
+        // as all_gather: nobody pushes into a member before the work that member queued earlier (readers of the old table) is done
+        for (int i = 0; i < n; i++) {
+            HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+            HIP_TRY(hipEventRecord(g->events[(size_t)i], S((size_t)i)));
+        }
+        for (int i = 0; i < n; i++) {
+            HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+            for (int j = 0; j < n; j++)
+                if (j != i) HIP_TRY(hipStreamWaitEvent(S((size_t)i), g->events[(size_t)j], 0));
+        }
+        for (int i = 0; i < n; i++) {
+            HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+            for (size_t k = 0; k < src[(size_t)i].size(); k++)
+                for (int step = 1; step < n; step++) {
+                    const int j = (i + step) % n;
+                    const ChunkRange& from = src[(size_t)i][k]; const ChunkRange& to = dst[(size_t)j][k * (size_t)world + (size_t)(g->first_rank + i)];
+                    HIP_TRY(hipMemcpyPeerAsync(to.base, g->devices[(size_t)j], from.base, g->devices[(size_t)i], from.bytes, S((size_t)i)));
+                }
+            HIP_TRY(hipEventRecord(g->events[(size_t)i], S((size_t)i)));
+        }
+        for (int i = 0; i < n; i++) {
+            HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+            for (int j = 0; j < n; j++)
+                if (j != i) HIP_TRY(hipStreamWaitEvent(S((size_t)i), g->events[(size_t)j], 0));
+        }
+        return ILM_OK;
+    }
+    if (gather != ILM_GATHER_RCCL) return api_fail(ILM_ERR_INVALID_ARGUMENT, "ilm_group_gather_chunks exchanges with ILM_GATHER_PEER or ILM_GATHER_RCCL (mode %d)", gather);
+    const int32_t rc = ensure_comms(g);
+    if (rc != ILM_OK) return rc;
+    Rccl& r = rccl();
+    NCCL_TRY(r.GroupStart());
+    for (int i = 0; i < n; i++) {
+        HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+        const int me = g->first_rank + i;
+        for (int step = 1; step < world; step++) {
+            const int to = (me + step) % world, from = (me - step + world) % world;
+            for (const ChunkRange& c : src[(size_t)i]) NCCL_TRY(r.Send(c.base, c.bytes, ncclInt8, to, g->comms[(size_t)i], S((size_t)i)));
+            const int theirs = (total_chunks - from + world - 1) / world;
+            for (int k = 0; k < theirs; k++) {
+                const ChunkRange& c = dst[(size_t)i][(size_t)k * (size_t)world + (size_t)from];
+                NCCL_TRY(r.Recv(c.base, c.bytes, ncclInt8, from, g->comms[(size_t)i], S((size_t)i)));
+            }
+        }
+    }
+    NCCL_TRY(r.GroupEnd());
     return ILM_OK;
 }
 
@@ -950,18 +1076,30 @@ int32_t ilm_group_render_sphere_lights(IlmHandle hgroup, const IlmLightVertex* l
     if (gather == ILM_GATHER_STORE) { const int32_t rc = fence_members(g); if (rc != ILM_OK) return rc; }
     // every member's strip is queued before anything is waited for: the launches are asynchronous, the devices run concurrently
     // (the instrumented variant synchronises per member; it is a diagnostic)
-    for (int i = 0; i < g->n_local; i++) {
+    int32_t strip_rc = ILM_OK;
+    for (int i = 0; i < g->n_local && strip_rc == ILM_OK; i++) {
         int32_t b = 0, e = 0;
         (void)ilm_group_lightmap_strip(hlightmap, g->first_rank + i, &b, &e, nullptr);
         IlmRenderStats part = { 0, 0, 0 };
-        const int32_t rc = ilm_render_sphere_lights(g->ctx[(size_t)i], lights, light_count, env, df, gbuffers ? gbuffers[i] : 0, sdfs ? sdfs[i] : 0,
-                                                    ambient, m->lightmaps[(size_t)i], b, e, stats ? &part : nullptr);
-        if (rc != ILM_OK) { if (arm_here) (void)set_store_mode(m, false); return rc; }
-        if (stats) { stats->SdfSamples += part.SdfSamples; stats->PixelLightPairs += part.PixelLightPairs; stats->TracedPairs += part.TracedPairs; }
+        strip_rc = ilm_render_sphere_lights(g->ctx[(size_t)i], lights, light_count, env, df, gbuffers ? gbuffers[i] : 0, sdfs ? sdfs[i] : 0,
+                                            ambient, m->lightmaps[(size_t)i], b, e, stats ? &part : nullptr);
+        if (strip_rc == ILM_OK && stats) { stats->SdfSamples += part.SdfSamples; stats->PixelLightPairs += part.PixelLightPairs; stats->TracedPairs += part.TracedPairs; }
     }
+    if (strip_rc != ILM_OK && !(g->rank_mode && g->world > 1)) {
+        if (arm_here) (void)set_store_mode(m, false);
+        return strip_rc;
+    }
+    // One process per GPU: the other ranks cannot know that this rank's strip failed -- they are on their way into the exchange (or the
+    // fence of the store mode) and, when the call armed the mode itself, into the disarming collective behind it.  A failing rank walks
+    // the SAME sequence (its rows of the frame are whatever the buffer held) and reports its error afterwards; leaving early would pair
+    // its next collective with the wrong one of its peers and hang them.
+    char strip_why[512];
+    if (strip_rc != ILM_OK) snprintf(strip_why, sizeof(strip_why), "%s", ilm_last_error());
     const int32_t rc = gather_lightmap(m, gather);
-    if (arm_here) { const int32_t rc2 = set_store_mode(m, false); if (rc == ILM_OK && rc2 != ILM_OK) return rc2; }
-    return rc;
+    int32_t rc2 = ILM_OK;
+    if (arm_here) rc2 = set_store_mode(m, false);
+    if (strip_rc != ILM_OK) return api_fail(strip_rc, "%s", strip_why);
+    return rc != ILM_OK ? rc : rc2;
 }
 
 int32_t ilm_group_live_counts(IlmHandle hgroup, const IlmHandle* systems, int32_t total_chunks, uint32_t* out_counts, int32_t capacity,
@@ -1001,5 +1139,18 @@ int32_t ilm_group_live_counts(IlmHandle hgroup, const IlmHandle* systems, int32_
         out_counts[c] = table[(size_t)(c % world) * (size_t)per_rank + (size_t)(c / world)];
     return ILM_OK;
 }
+
+int32_t ilm_group_gather_chunks(IlmHandle hgroup, const IlmHandle* sources, const IlmHandle* gathered, int32_t total_chunks, int32_t first_component,
+                                int32_t component_count, int32_t gather) {
+    ILM_TRACE_RANGE("ilm_group_gather_chunks");
+    Group* g = group_from(hgroup);
+    if (!g) return api_fail(ILM_ERR_INVALID_HANDLE, "not a group handle");
+    if (!sources || !gathered) return api_fail(ILM_ERR_INVALID_ARGUMENT, "NULL argument");
+    if (total_chunks < 0) return api_fail(ILM_ERR_OUT_OF_RANGE, "total_chunks %d", total_chunks);
+    if (first_component < 0 || component_count < 1 || first_component + component_count > kComponents)
+        return api_fail(ILM_ERR_OUT_OF_RANGE, "components [%d, %d) outside [0, %d)", first_component, first_component + component_count, kComponents);
+    return gather_chunks(g, sources, gathered, total_chunks, first_component, component_count, gather);
+}
+
 
 }  // extern "C"

@@ -400,5 +400,7 @@ IlmHandle handle_register(const void* object, uint32_t magic);
 bool handle_is_live(IlmHandle h, uint32_t magic);
 void handle_retire(const void* object);
 int ctx_child_count(IlmHandle ctx);        // live objects of a context (-1: not a context)
+// one chunk of a system for the chunk exchange (api.hip): base of component 0, stride between component planes (floats), chunk size, owning context
+int32_t system_chunk_view(IlmHandle system, int chunk, bool written, float** out_base, int64_t* out_stride, int32_t* out_chunk_size, IlmHandle* out_ctx);
 
 }  // namespace ilm

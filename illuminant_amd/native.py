@@ -129,6 +129,7 @@ SYMBOLS = {
     "ilm_group_lightmap_destroy": (_I, [_H]),
     "ilm_group_render_sphere_lights": (_I, [_H, _P, _I, _P, _P, _P, _P, _P, _H, _I, _P]),
     "ilm_group_live_counts": (_I, [_H, _P, _I, _P, _I, _I]),
+    "ilm_group_gather_chunks": (_I, [_H, _P, _P, _I, _I, _I, _I]),
 }
 
 
@@ -691,6 +692,15 @@ class Group:
         out = np.zeros(max(total_chunks, 1), dtype=np.uint32)
         check(lib().ilm_group_live_counts(self.handle, C.cast(hs, C.c_void_p), total_chunks, _ptr(out), out.shape[0], 1 if saturate16 else 0))
         return out[:total_chunks]
+
+    def gather_chunks(self, sources, gathered, total_chunks, first_component=0, component_count=4, gather=GATHER_RCCL):
+        """ilm_group_gather_chunks: components [first, first + count) of every chunk of the sharded table land in chunk c of every local
+        member's `gathered` system (Pos+Life by default).  sources / gathered: one System (or anything with .handle, or a raw handle) per
+        local member.  Stream-ordered; a collective when the group spans processes."""
+        def handles(xs):
+            return (abi.Handle * self.n_local)(*[int(getattr(getattr(x, "handle", x), "value", getattr(x, "handle", x))) for x in xs])
+        check(lib().ilm_group_gather_chunks(self.handle, C.cast(handles(sources), C.c_void_p), C.cast(handles(gathered), C.c_void_p), int(total_chunks),
+                                            int(first_component), int(component_count), int(gather)))
 
     def render_sphere_lights(self, lights, env, df, gbuffers, sdfs, ambient, group_lightmap, gather=GATHER_PEER, want_stats=False):
         """ilm_group_render_sphere_lights: every local member renders its strip, then the strips are gathered in place."""

@@ -30,11 +30,13 @@
 extern "C" {
 #endif
 
-/* 8 (r05): + ilm_group_lightmap_store_mode, ILM_GATHER_STORE, ilm_debug_last_light_launch, ilm_ctx_create_sibling,
+/* 9 (r06): + ilm_group_gather_chunks (the sharded particle state made whole on every member: Pos+Life for global consumers, Pos+Life
+ * and RenderColor for particle lights across ranks).  Nothing removed or changed in layout.
+ * 8 (r05): + ilm_group_lightmap_store_mode, ILM_GATHER_STORE, ilm_debug_last_light_launch, ilm_ctx_create_sibling,
  * ILM_GATHER_ASYNC + ilm_group_lightmap_wait.
  * 7 (r04): + ilm_ctx_set_light_split, ilm_sdf_mark_dirty, ilm_sdf_trace_info / IlmSdfTraceInfo; ilm_group_lightmap_set_strips became a
  * collective with one process per GPU.  Nothing was removed or changed in layout since 6. */
-#define ILM_ABI_VERSION 8
+#define ILM_ABI_VERSION 9
 
 /* ---- return codes ------------------------------------------------------ */
 #define ILM_OK                    0
@@ -1040,6 +1042,22 @@ int32_t ilm_group_render_sphere_lights(IlmHandle group, const IlmLightVertex* li
  * bit-exact).  One small RCCL all-gather when the group spans processes, none otherwise.  Synchronises. */
 int32_t ilm_group_live_counts(IlmHandle group, const IlmHandle* systems, int32_t total_chunks, uint32_t* out_counts, int32_t capacity,
                               int32_t saturate16);
+
+/* The sharded particle state made whole ("optional all-gather of Pos+Life, 16 B/slot, only when a global consumer
+ * exists -- particle lights, host readback").  sources[i] = local member i's system (chunk c of the table = chunk c / world of rank
+ * c % world, as for ilm_group_live_counts); gathered[i] = an ordinary system on the SAME member's context whose engine has the same
+ * chunk size and which holds total_chunks chunks (ilm_system_add_chunk).  After the call (stream-ordered on the members' context
+ * streams, nothing blocks the host) components [first_component, first_component + component_count) of chunk c of every gathered
+ * system are those of chunk c of the table: 0..3 = Pos+Life (ParticleSystem.cs:73-146 PositionAndLife), 12..15 = RenderColor (what
+ * ParticleLight.fx:16-83 reads beside the position).  The planes of a chunk are contiguous, so a chunk travels as one range from the
+ * owner's planes into the destination's planes, no packing: ILM_GATHER_PEER (in-process groups) = hipMemcpyPeerAsync to each other
+ * member; ILM_GATHER_RCCL = one group of ncclSend / ncclRecv per call; ILM_GATHER_NONE = only each member's own chunks are copied over.
+ * Every other component of the gathered system is left as it is.  Any consumer that takes a system handle then sees the whole table in
+ * chunk order: ilm_render_particle_lights(ctx, gathered, ...) lights a member's strip with EVERY rank's particles, in the order -- and
+ * therefore with the bits -- of the one-context frame.  A collective when the group spans processes: every rank calls it with the same
+ * total_chunks, components and mode. */
+int32_t ilm_group_gather_chunks(IlmHandle group, const IlmHandle* sources, const IlmHandle* gathered, int32_t total_chunks,
+                                int32_t first_component, int32_t component_count, int32_t gather);
 
 
 #ifdef __cplusplus

@@ -1,6 +1,6 @@
 // IlluminantHip.cs -- P/Invoke layer of libilluminant_hip.so for sq/Illuminant (drop into Illuminant/Native/).
 // GENERATED from include/illuminant_hip.h by tools/gen_csharp_binding.py -- do not edit; the header carries the documentation
-// and the reference file:line each entry point replaces.  ABI version 8.
+// and the reference file:line each entry point replaces.  ABI version 9.
 //
 // Vector4 / Matrix are XNA's; LightVertex is Illuminant/Vertices.cs:10-39; the Uniforms.* structs of the reference
 // (Uniforms.cs:14-24,79-88,197-236; Bezier.cs:433-441,588-599) have the byte layout of the Ilm* mirrors below and can be passed
@@ -16,7 +16,7 @@ namespace Squared.Illuminant.Native {
     }
 
     public static class IlmConstants {
-        public const int ABI_VERSION = 8;
+        public const int ABI_VERSION = 9;
         public const int BLEND_FP16_PER_LIGHT = 1;
         public const int BLEND_FP32_ACCUMULATE = 0;
         public const int ERR_INVALID_ARGUMENT = -1;
@@ -565,6 +565,7 @@ namespace Squared.Illuminant.Native {
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_lightmap_destroy (ulong groupLightmap);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_render_sphere_lights (ulong group, LightVertex* lights, int lightCount, IlmEnvironment* env, IlmDistanceFieldUniforms* df, ulong* gbuffers, ulong* sdfs, float* ambient, ulong groupLightmap, int gather, IlmRenderStats* stats);
         [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_live_counts (ulong group, ulong* systems, int totalChunks, uint* outCounts, int capacity, int saturate16);
+        [DllImport(Lib, CallingConvention = CallingConvention.Cdecl)] public static extern int ilm_group_gather_chunks (ulong group, ulong* sources, ulong* gathered, int totalChunks, int firstComponent, int componentCount, int gather);
 
         public static void Check (int code) {
             if (code == 0) return;

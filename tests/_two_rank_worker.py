@@ -169,6 +169,43 @@ def main():
     everyone = g.host_all_gather(counts.astype("<u4").tobytes())
     assert all(b == everyone[0] for b in everyone), "the ranks hold different liveness tables"
     assert 0 < int(counts.sum()) < total_chunks * cs * cs
+    # 5. particle lights across ranks (SURVEY 8f-3 + 8e row P): chunk ch lives on rank ch % world; ilm_group_gather_chunks makes Pos+Life and
+    #    RenderColor whole in every rank's gathered system (one group of ncclSend / ncclRecv per call), the rank lights ITS strip with EVERY
+    #    rank's particles, the strips are exchanged: every rank holds the frame one context renders from the whole table, bit for bit
+    from tests import lights_common as lc
+    from tests.test_lights_ext_gpu import particle_scene, small_field
+    pw, ph, pcs, pchunks = 160, 112, 16, 5
+    patlas, pdfu = small_field()
+    penv = scenes.environment()
+    chunks = particle_scene(pcs, pchunks, pw, ph)
+    pparams = lc.particle_light_params(3.0, 30.0, (0.9, 0.8, 0.7, 0.6), casts_shadows=True)
+    peng = native.Engine(c, pcs, scenes.randomness_table(7))
+    whole, mine_, gathered = native.System(peng), native.System(peng), native.System(peng)
+    for ch in range(pchunks):
+        for target in ([whole] + ([mine_] if ch % world == rank else [])):
+            k = target.add_chunk()
+            target.upload(k, abi.PLANE_POSITION, chunks[ch][0]); target.upload(k, abi.PLANE_RENDER_COLOR, chunks[ch][3])
+        gathered.add_chunk()
+    psdf = native.DistanceFieldTexture(c, patlas)
+    plm = native.Lightmap(c, pw, ph, abi.LIGHTMAP_FLOAT4)
+    native.render_sphere_lights(c, None, penv, pdfu, None, psdf, AMBIENT, plm)
+    pst = native.render_particle_lights(c, whole, pparams, penv, pdfu, None, psdf, plm, want_stats=True)
+    pwant = plm.download()
+    plm.close()
+    pglm = native.GroupLightmap(g, pw, ph, abi.LIGHTMAP_FLOAT4)
+    g.gather_chunks([mine_], [gathered], pchunks, 0, 4, native.GATHER_RCCL)
+    g.gather_chunks([mine_], [gathered], pchunks, 12, 4, native.GATHER_RCCL)
+    pb, pe = pglm.strips[rank]
+    native.render_sphere_lights(c, None, penv, pdfu, None, psdf, AMBIENT, pglm.members[0], pb, pe)
+    ps_ = native.render_particle_lights(c, gathered, pparams, penv, pdfu, None, psdf, pglm.members[0], row_begin=pb, row_end=pe, want_stats=True)
+    pglm.gather(native.GATHER_RCCL)
+    g.sync()
+    assert np.array_equal(pglm.download(0), pwant), "rank %d: particle lights across ranks" % rank
+    for ch in range(pchunks):
+        assert np.array_equal(gathered.download(ch, abi.PLANE_POSITION), chunks[ch][0]) and np.array_equal(gathered.download(ch, abi.PLANE_RENDER_COLOR), chunks[ch][3])
+    pairs = sum(struct.unpack("<Q", b)[0] for b in g.host_all_gather(struct.pack("<Q", ps_.PixelLightPairs)))
+    assert pairs == pst.PixelLightPairs and pairs > 1000, (pairs, pst.PixelLightPairs)
+    pglm.close(); psdf.close(); whole.close(); mine_.close(); gathered.close(); peng.close()
     sysm.close(); eng.close()
     glm_b.close(); glm.close(); sdf.close(); g.close()
     print("rank %d of %d ok" % (rank, world))

@@ -497,3 +497,80 @@ def test_asynchronous_rccl_exchange_at_world_one(ctx):
     for glm in ring:
         glm.close()
     sdf.close(); g.close()
+
+
+@pytest.mark.parametrize("members,gather", [(2, native.GATHER_PEER), (3, native.GATHER_PEER), (1, native.GATHER_RCCL)])
+def test_gather_chunks_lights_every_strip_with_every_ranks_particles(ctx, members, gather):
+    """cfg5 joins P and L and chunk c lives on rank c % world: a member's strip sees only its own chunks' particles as
+    lights until the table is made whole.  ilm_group_gather_chunks moves Pos+Life and RenderColor of every chunk into every member's
+    gathered system (chunk order = table order), ilm_render_particle_lights over that system lights the member's strip, the strips are
+    exchanged: every member's frame equals the single-context particle-light frame BIT FOR BIT (same records in the same order)."""
+    from tests import lights_common as lc
+    from tests.test_lights_ext_gpu import particle_scene, small_field
+    w, h, cs, n_chunks = 160, 112, 16, 5
+    atlas, dfu = small_field()
+    env = scenes.environment()
+    chunks = particle_scene(cs, n_chunks, w, h)
+    params = lc.particle_light_params(3.0, 30.0, (0.9, 0.8, 0.7, 0.6), casts_shadows=True)
+    rnd = scenes.randomness_table(7)
+
+    def fill(system, which):
+        for c in which:
+            k = system.add_chunk()
+            system.upload(k, abi.PLANE_POSITION, chunks[c][0]); system.upload(k, abi.PLANE_RENDER_COLOR, chunks[c][3])
+
+    # the one-context frame
+    eng = native.Engine(ctx, cs, rnd)
+    whole = native.System(eng)
+    fill(whole, range(n_chunks))
+    sdf = native.DistanceFieldTexture(ctx, atlas)
+    lm = native.Lightmap(ctx, w, h, abi.LIGHTMAP_FLOAT4)
+    native.render_sphere_lights(ctx, None, env, dfu, None, sdf, AMBIENT, lm)
+    st = native.render_particle_lights(ctx, whole, params, env, dfu, None, sdf, lm, want_stats=True)
+    want = lm.download()
+    assert st.PixelLightPairs > 1000
+    for x in (lm, sdf, whole, eng):
+        x.close()
+
+    g = native.Group([0] * members) if gather == native.GATHER_PEER else native.Group.rank(0, 0, 1, native.Group.unique_id())
+    engines = [native.Engine(c, cs, rnd) for c in g.contexts]
+    sources = [native.System(e) for e in engines]
+    gathered = [native.System(e) for e in engines]
+    for r in range(members):
+        fill(sources[r], range(r, n_chunks, members))
+        for _ in range(n_chunks):
+            gathered[r].add_chunk()
+    sdfs = [native.DistanceFieldTexture(c, atlas) for c in g.contexts]
+    glm = native.GroupLightmap(g, w, h, abi.LIGHTMAP_FLOAT4)
+    try:
+        g.gather_chunks(sources, gathered, n_chunks, 0, 4, gather)          # Pos+Life
+        g.gather_chunks(sources, gathered, n_chunks, 12, 4, gather)         # RenderColor
+        total = 0
+        for i, c in enumerate(g.contexts):
+            b, e = glm.strips[i]
+            native.render_sphere_lights(c, None, env, dfu, None, sdfs[i], AMBIENT, glm.members[i], b, e)
+            s_ = native.render_particle_lights(c, gathered[i], params, env, dfu, None, sdfs[i], glm.members[i], row_begin=b, row_end=e, want_stats=True)
+            total += s_.PixelLightPairs
+        glm.gather(gather)
+        g.sync()
+        assert total == st.PixelLightPairs
+        for i in range(members):
+            assert np.array_equal(glm.download(i), want), "member %d" % i
+            for c in range(n_chunks):     # the gathered planes are the owners' planes
+                assert np.array_equal(gathered[i].download(c, abi.PLANE_POSITION), chunks[c][0])
+                assert np.array_equal(gathered[i].download(c, abi.PLANE_RENDER_COLOR), chunks[c][3])
+                assert not gathered[i].download(c, abi.PLANE_VELOCITY).any()           # components outside the range stay as they were
+        # a table that does not match the sharding rule, a gathered system of the wrong size and a bad component range are refused
+        with pytest.raises(native.IlluminantError):
+            g.gather_chunks(sources, gathered, n_chunks + 1, 0, 4, gather)
+        if members > 1:
+            with pytest.raises(native.IlluminantError):
+                g.gather_chunks(sources, sources, n_chunks, 0, 4, gather)
+        with pytest.raises(native.IlluminantError):
+            g.gather_chunks(sources, gathered, n_chunks, 18, 4, gather)
+    finally:
+        g.sync()
+        glm.close()
+        for x in sdfs + sources + gathered + engines:
+            x.close()
+        g.close()

@@ -51,7 +51,7 @@ def test_bench_runs_its_whole_n_gpu_branch_at_two_ranks(fake_rccl):
     the instrumented counts summed over the ranks equal the oracle's totals for the whole frames, the composite call and the pipelined
     exchange reproduce the frame, and the line carries the self-describing scaling block."""
     env = dict(os.environ, ILM_RCCL_LIB=fake_rccl, ILM_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--light-frames", "2", "--light-ms", "0",
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--light-frames", "2", "--light-ms", "0",
                         "--sustain-s", "0"], env=env, capture_output=True, text=True, timeout=1500)
     assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
@@ -59,8 +59,15 @@ def test_bench_runs_its_whole_n_gpu_branch_at_two_ranks(fake_rccl):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["ranks"] == 2 and d["config"]["rccl_communicator_ranks"] == 2
     assert d["config"]["rccl_communicator_ranks_per_rank"] == [2, 2] and "one_gpu_stand_in" in d["config"]
-    assert d["config"]["workload"].startswith("cfg4") and d["value"] == d["cfg4_share_8m_particles"]["mparticle_steps_per_s"] > 0
     sd = d["scaling_detail"]
+    # r06: the rows with the collectives BASELINE config 4 names run last under the watchdog; the headline is the step WITH the live-count
+    # all-gather, the communication-free figure beside it; the liveness table is bit-exact on every rank (every chunk of 1024^2 live) and
+    # every rank's gathered Pos+Life planes are their owners'
+    wl, wg = sd["particles"]["with_live_counts"], sd["particles"]["with_position_all_gather"]
+    assert d["config"]["workload"].startswith("cfg4") and d["value"] == wl["mparticle_steps_per_s"] > 0, wl
+    assert d["value_without_collectives"] == d["cfg4_share_8m_particles"]["mparticle_steps_per_s"] > 0 and "ilm_group_live_counts" in d["config"]["collective_in_the_timed_steps"]
+    assert wl["live_count_table"] == {"chunks": 16, "every_chunk_live": 1048576, "bit_exact_on_every_rank": True} and wl["live_count_calls_per_block"] >= 0.2, wl
+    assert wg["gathered_chunks_match_their_owners"] is True and wg["exchange_ms"] > 0 and wg["bytes_received_per_rank"] >= 8 * 4 * 1024 * 1024 * 4, wg
     assert sd["ranks"] == 2 and len(sd["particles"]["per_rank_mparticle_steps_per_s"]) == 2
     assert sd["particles"]["strong_vs_one_gpu_64m"] > 0 and sd["particles"]["weak_vs_share"] > 0
     assert sd["particles"]["sharded_64m"]["workload"].startswith("64 chunks of 1024^2 over 2 rank(s): 32 chunks")
@@ -92,6 +99,28 @@ def test_a_hang_in_an_optional_row_costs_the_record_that_row_only(fake_rccl):
     d = json.loads(lines[0])
     sd = d["scaling_detail"]
     assert "did not finish" in sd["optional_rows"]
+    assert "with_live_counts" not in sd["particles"] and d["value"] == d["value_without_collectives"] == d["cfg4_share_8m_particles"]["mparticle_steps_per_s"]
+    assert d["config"]["collective_in_the_timed_steps"].startswith("none")
     for pin in ("cfg3", "cfg5"):
         assert sd["frames"][pin]["composited_frame_ms"] > 0 and "store_mode" not in sd["frames"][pin] and "pipelined_exchange" not in sd["frames"][pin]
     assert d["lighting"]["cfg5_4k_256_lights_fp16"]["verified_counts"] is True and d["value"] > 0
+
+
+def test_the_collective_schedule_of_the_n_gpu_branch_is_printed_in_issue_order(fake_rccl):
+    """`bench.py --gpus 2 --dry-collectives` walks the whole N > 1 branch once and prints every collective in issue order with its bytes
+    (profiles/r06_collective_schedule.txt is this list at world 8): the two particle collectives, the strip tables, the lightmap exchanges,
+    the store mode's arming -- and the optional phase comes last."""
+    env = dict(os.environ, ILM_RCCL_LIB=fake_rccl, ILM_BENCH_ONE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-collectives", "--no-cfg4-64m"], env=env, capture_output=True, text=True, timeout=1500)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-3000:])
+    rows = [ln.split(" | ") for ln in p.stdout.splitlines() if " | " in ln and not ln.startswith("#")]
+    assert len(rows) > 20 and not any(ln.startswith("{") for ln in p.stdout.splitlines())
+    entry = [r[2] for r in rows]
+    for name in ("ilm_group_host_all_gather", "ilm_group_live_counts", "ilm_group_gather_chunks(components 0..3)", "ilm_group_lightmap_set_strips", "ilm_group_lightmap_gather(RCCL)",
+                 "ilm_group_lightmap_gather(STORE)", "ilm_group_lightmap_store_mode(1)"):
+        assert name in entry, name
+    assert [int(r[0]) for r in rows] == list(range(1, len(rows) + 1))
+    first_optional = min(i for i, r in enumerate(rows) if r[2] == "ilm_group_live_counts")
+    assert all("optional" not in r[1] and "ilm_group_live_counts" not in r[1] for r in rows[:first_optional])
+    chunks = [r for r in rows if r[2].startswith("ilm_group_gather_chunks")]
+    assert all(int(r[4]) >= 8 * 4 * 1024 * 1024 * 4 for r in chunks)
