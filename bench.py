@@ -1497,16 +1497,20 @@ def main():
                 envu = abi.Environment.from_buffer_copy(r.GetEnvironmentUniformsBytes())
                 dfuu = abi.DistanceFieldUniforms.from_buffer_copy(r.GetDistanceFieldUniformsBytes())
                 tex = orc.make_texture(atlas_host, fmt)
-                rows, mid, budget = 4, h // 2, max(args.cpu_seconds / 3.0, 1.0)
-                t0 = time.perf_counter()
-                orc.render_sphere_lights(verts, envu, dfuu, None, tex, (0.05, 0.05, 0.05, 1.0), w, h, row_begin=mid, row_end=mid + rows)
-                el = time.perf_counter() - t0
-                if el < budget / 2:      # one more, larger band sized for the budget
-                    rows = int(min(max(rows * (budget / max(el, 1e-3)), rows), h // 2))
+                # a band of rows around the frame's middle, grown until the oracle works on it for at least ~2.5 s (the 0.2 s / 1.1 s
+                # samples of r05 were order-of-magnitude only); the band's SDF samples are counted by the oracle itself, so the CPU's rate is
+                # stated per sample too -- the frames differ 5 x in samples per pixel, the CPU's sample rate should not
+                rows, mid, want_s = 4, h // 2, max(2.5, min(args.cpu_seconds / 3.0, 6.0))
+                while True:
+                    rows = int(min(rows, h // 2))
                     t0 = time.perf_counter()
-                    orc.render_sphere_lights(verts, envu, dfuu, None, tex, (0.05, 0.05, 0.05, 1.0), w, h, row_begin=mid, row_end=mid + rows)
+                    _, ost = orc.render_sphere_lights(verts, envu, dfuu, None, tex, (0.05, 0.05, 0.05, 1.0), w, h, row_begin=mid - rows // 2, row_end=mid - rows // 2 + rows, want_stats=True)
                     el = time.perf_counter() - t0
+                    if el >= want_s or rows >= h // 2:
+                        break
+                    rows = int(np.ceil(rows * min(max(1.25 * want_s / max(el, 1e-3), 1.5), 64.0)))
                 lighting[name]["cpu_baseline"] = {"value": round(rows * w / el / 1e6, 4), "unit": "lit Mpixels/s", "cores": orc.num_threads(), "kind": "port",
+                                                  "msamples_per_s": round(int(ost.SdfSamples) / el / 1e6, 1), "sdf_samples_in_sample": int(ost.SdfSamples),
                                                   "sample": "%d rows x %d px around the frame's middle (oracle/ilm_oracle.c, OpenMP, %.1f s)" % (rows, w, el)}
             if glm is not None and deferred_rows and deferred_rows[-1][1].glm is glm:
                 kept_alive.append((L, r, glm))          # (the optional rows at the end render with them)
