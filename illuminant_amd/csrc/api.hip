@@ -204,6 +204,9 @@ struct Sdf {
     // rebuilt before every use.
     void* cells = nullptr; size_t cells_bytes = 0;
     uint64_t version = 1, cells_version = 0;
+    // The particle path's cells (SdfView::cells0, r06): channel r of the four taps of every slice-0 lookup, built on demand by
+    // ensure_slice0_cells for the lean collision step and kept until the atlas changes (same versioning as `cells`).
+    void* cells0 = nullptr; size_t cells0_bytes = 0; uint64_t cells0_version = 0;
     int cells_slices = 0, cells_columns = 0, cells_sw = 0, cells_sh = 0;
     bool escaped = false;
     // Which virtual slices of the atlas have been written since the cells were built (bit v of dirty[v / 64]; kMaxTableSlices = 256 bits;
@@ -288,6 +291,7 @@ SdfView make_sdf_view(const Sdf* f, const IlmDistanceFieldUniforms* df) {
     // The sampler's single-step U wrap needs every tap column below 2^22 (hlsl_math.hpp); the largest column these uniforms can produce
     // is (floor(maxSlice) / 3 * sliceU + extentX * texelU) * width.  Anything at or above 2^20 (or not finite) keeps the two-fold wrap.
     v.wrap_half = 0.0f;
+    v.cells0 = nullptr;        // (run_step binds the slice-0 cells for the lean collision step)
     // The cone trace's in-volume sampler (hlsl_math.hpp, sample_inside_table) needs the uniforms to describe exactly this atlas as
     // columns x rows whole slices with the reference's texel sizes (Uniforms.cs:90-110): then the U WRAP fold of a tap is decided by
     // its slice alone.  Its box: every tap of a sample at least a sixteenth of a texel inside its slice in x and y (tap x0 >= 0,
@@ -847,6 +851,26 @@ int set_step_streams_impl(int n) {
 }
 constexpr int64_t kSplitMinUnits = 8192;      // half a million slots: below it the second launch costs more than the overlap returns
 
+// The slice-0 cells of a UNORM16 field for the lean collision step (hlsl_math.hpp SdfView::cells0): (re)built on the context stream when
+// the atlas has changed since the last build -- or before every use for an atlas whose device pointer was handed out.  16 us for the
+// demo's 960 x 540 atlas; a field generated once costs it once.  Returns nullptr (the four-tap form) when there is no memory for them.
+static const void* ensure_slice0_cells(Sdf* f, Ctx* c) {
+    const size_t bytes = sizeof(uint2) * (size_t)f->width * (size_t)(f->height + 1);
+    if (f->width <= 0 || f->height <= 0 || ((uint64_t)f->width * (uint64_t)(f->height + 1)) >= ((uint64_t)1 << 28)) return nullptr;     // 32-bit byte offsets
+    if (f->cells0 && f->cells0_bytes == bytes && f->cells0_version == f->version && !f->escaped) return f->cells0;
+    // (only a rebuild needs the context stream, joined with the second stepping stream: both halves of a split step see the new cells.
+    // Taking it for every step would join the two streams every step -- 14 us per cfg2 step, measured)
+    const hipStream_t stream = c->main();
+    if (f->cells0_bytes != bytes) {
+        if (f->cells0) { (void)hipStreamSynchronize(stream); (void)hipFree(f->cells0); f->cells0 = nullptr; f->cells0_bytes = 0; }
+        if (hipMalloc(&f->cells0, bytes) != hipSuccess) { (void)hipGetLastError(); f->cells0 = nullptr; return nullptr; }
+        f->cells0_bytes = bytes;
+    }
+    if (launch_build_slice0_cells(f->texels, f->width, f->height, f->cells0, stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    f->cells0_version = f->version;
+    return f->cells0;
+}
+
 int32_t run_step(System* s, const IlmStepDesc* d) {
     int first = 0, count = 0;
     int32_t rc = validate_step(s, d, &first, &count);
@@ -878,8 +902,7 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
     // 20 planes x stride x 4 B per chunk against the 256 MB Infinity Cache (MI355X_MICROARCH.md): above it every plane streams
     // through once per step and the non-temporal variant wins; below it the planes stay resident from one step to the next
     a.streaming = ((size_t)count * (size_t)e->stride * kComponents * sizeof(float) > ((size_t)256 << 20)) ? 1 : 0;
-    static const int forced = [] { const char* v = getenv("ILM_STEP_STREAMING"); return v ? atoi(v) : -1; }();   // experiment switch
-    if (forced >= 0) a.streaming = forced;
+    if (const char* v = getenv("ILM_STEP_STREAMING")) a.streaming = atoi(v) != 0 ? 1 : 0;      // experiment / test switch, read per step
     for (int k = 0; k < d->SpawnCount; k++) {
         const IlmSpawnRecord& r = d->Spawns[k];
         if (r.Params.ChunkSizeAndIndices[2] >= r.Params.ChunkSizeAndIndices[1])
@@ -897,7 +920,11 @@ int32_t run_step(System* s, const IlmStepDesc* d) {
             a.source_base[k] = from_handle<System>(d->Spawns[k].Feedback.SourceSystem, kMagicSystem)->chunks[(size_t)d->Spawns[k].Feedback.SourceChunkIndex];
     }
     a.ramp = s->ramp; a.ramp_w = s->ramp_w; a.ramp_h = s->ramp_h;
-    a.sdf = make_sdf_view(from_handle<Sdf>(s->sdf_handle, kMagicSdf), &d->DistanceField);
+    {
+        Sdf* field = from_handle<Sdf>(s->sdf_handle, kMagicSdf);
+        a.sdf = make_sdf_view(field, &d->DistanceField);
+        if (field && step_wants_slice0_cells(*d, field->format)) a.sdf.cells0 = ensure_slice0_cells(field, c);
+    }
     a.live_counts = counting ? s->counts_region(region * 2) : nullptr;
     a.zero_counts = counting ? s->counts_region((region ^ 1) * 2) : nullptr;
     a.zero_n = counting ? 2 * (int32_t)s->counts_cap * kCountLines : 0;   // every line of both halves, so chunk-table growth after a shrink never meets stale counts
@@ -2033,6 +2060,7 @@ int32_t ilm_sdf_destroy(IlmHandle h) {
     f->shared.release();
     if (f->texels) (void)hipFree(f->texels);
     if (f->cells) (void)hipFree(f->cells);
+    if (f->cells0) (void)hipFree(f->cells0);
     retire_handle(f);
     delete f;
     return ILM_OK;

@@ -112,6 +112,13 @@ struct SdfView {
     int columns;           // slices per atlas row (integer value of TextureSliceCount.x)
     // world-space box inside which a SAMPLE position meets the table sampler's assumptions (InsideBox, make_sdf_view)
     float box_x0, box_x1, box_y0, box_y1, box_z0, box_z1;
+    // The particle path's cells (r06; api.hip ensure_slice0_cells, particles.hip build_slice0_cells_kernel): for a UNORM16 field sampled
+    // through the slice-0 sampler (DistanceFieldPacked1 = 0: every lookup is the bilinear fetch of channel r of virtual slice 0), one
+    // 8-byte cell per (wrapped tap column x0, tap row yi + 1) holding channel r of the FOUR taps -- (x0, y0), (x1, y0), (x0, y1), (x1, y1)
+    // with the U WRAP of x1 and the V CLAMP of y0 / y1 folded in -- so that a sample is ONE typed 16_16_16_16 load instead of four
+    // 16_16 ones.  Four divergent gathers per lookup are what bounds the collision step -- the texture path serves a wave's 64 scattered
+    // addresses one at a time: cfg4's share 369 -> 245 us, cfg2 36 -> 29 us (tools/collision_probe.py).  nullptr: none (the four-tap form).
+    const void* cells0;
 };
 // The cone trace's view: the in-volume sampler reads the field through its CELL array (api.hip make_trace_view, lighting.hip
 // build_sdf_cells_kernel): one 16-byte cell per (virtual slice, texel) holding the four bilinear taps of that texel's sample footprint,
@@ -148,6 +155,9 @@ ILM_DEV __amdgpu_buffer_rsrc_t sdf_unorm_rsrc(const SdfView& sdf) {
                                              kRsrcWord3Unorm16x2);
 }
 
+ILM_DEV __amdgpu_buffer_rsrc_t sdf_cells0_rsrc(const SdfView& sdf) {     // (width x (height + 1) cells of 8 bytes)
+    return __builtin_amdgcn_make_buffer_rsrc((void*)uniform_u64((uint64_t)sdf.cells0), 0, __builtin_amdgcn_readfirstlane((sdf.width * (sdf.height + 1)) << 3), 4 | (5 << 3) | (6 << 6) | (7 << 9) | (0 << 12) | (12 << 15));
+}
 ILM_DEV __amdgpu_buffer_rsrc_t sdf_cells_unorm_rsrc(const TraceSdfView& sdf) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)uniform_u64((uint64_t)sdf.cells), 0, __builtin_amdgcn_readfirstlane((int)sdf.cells_bytes), kRsrcWord3Unorm16x4);
 }
@@ -221,9 +231,10 @@ ILM_DEV float div_no_scale(float n, float d) { return div_with_rcp(n, d, refined
 // lerp(lo, hi, 0) = fma(0, hi - lo, lo) = lo for every finite lo, hi (up to the sign of a zero that `kDistanceZero - blended` does not
 // see).  The caller selects it when Packed1.y == 0 and Packed1.x, .z are finite; one channel per tap, three lerps instead of seven, no
 // slice arithmetic: a quarter of the sampler's instructions.
-template <int FORMAT, bool CHECK_NAN = true, bool SLICE0 = false>
+template <int FORMAT, bool CHECK_NAN = true, bool SLICE0 = false, bool CELLS0 = false>
 ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms& df, const SdfView& sdf) {
 #pragma clang fp contract(off)
+    static_assert(!CELLS0 || (SLICE0 && FORMAT == ILM_SDF_UNORM16), "the slice-0 cells serve the slice-0 sampler of a UNORM16 field");
     position.z -= df.ConeAndMisc.y;
     const float ex = df.Extent.x, ey = df.Extent.y, ez = df.Extent.z;
     // clamp3(position, 0, extent) as one median-of-three each.  The distance to the volume per axis,
@@ -311,7 +322,25 @@ ILM_DEV float sample_distance_field(f3 position, const IlmDistanceFieldUniforms&
     asm("" : "+s"(base));
     const uint32_t c0 = ((uint32_t)x0 << 3) + sub, c1 = ((uint32_t)x1 << 3) + sub;
     float a00, b00, a10, b10, a01, b01, a11, b11;
-    if (SLICE0 && FORMAT == ILM_SDF_UNORM16) {
+    if (CELLS0) {
+        // one cell = channel r of the four taps, wrap and clamp folded in at build time: row yi + 1 (yi = -1 .. height - 1), column x0
+#ifndef ILM_CELLS0_UNTYPED
+        // ONE typed load (16_16_16_16 unorm): the four channels arrive decoded by the texture path, as the 16_16 taps do (sdf_unorm_rsrc)
+        const f32x4 t = ilm_llvm_buffer_load_format_xyzw(sdf_cells0_rsrc(sdf), (int)(__umul24((uint32_t)(yi + 1), pitch) + ((uint32_t)x0 << 3)), 0, 0);
+        a00 = t.x; a10 = t.y; a01 = t.z; a11 = t.w;
+#else
+        // (A/B: an untyped 8-byte load and the exact decode on the vector ALU -- unorm16_to_float is the texture path's conversion bit for
+        // bit; 2-3 % slower on both sizes of tools/collision_probe.py)
+        typedef const char __attribute__((address_space(1))) gbyte0;
+        typedef uint32_t u32x2c __attribute__((ext_vector_type(2)));
+        typedef const u32x2c __attribute__((address_space(1), aligned(8))) gcell0;
+        gbyte0* cbase = (gbyte0*)uniform_u64((uint64_t)sdf.cells0);
+        const u32x2c t = *(gcell0*)(cbase + (__umul24((uint32_t)(yi + 1), pitch) + ((uint32_t)x0 << 3)));
+        a00 = unorm16_to_float((float)(t.x & 0xFFFFu)); a10 = unorm16_to_float((float)(t.x >> 16));
+        a01 = unorm16_to_float((float)(t.y & 0xFFFFu)); a11 = unorm16_to_float((float)(t.y >> 16));
+#endif
+        b00 = b10 = b01 = b11 = 0.0f;
+    } else if (SLICE0 && FORMAT == ILM_SDF_UNORM16) {
         const __amdgpu_buffer_rsrc_t rsrc = sdf_unorm_rsrc(sdf);       // channel r of the four taps (the pair's second channel is not needed)
         a00 = ilm_llvm_buffer_load_format_xy(rsrc, (int)(r0 + c0), 0, 0).x; a10 = ilm_llvm_buffer_load_format_xy(rsrc, (int)(r0 + c1), 0, 0).x;
         a01 = ilm_llvm_buffer_load_format_xy(rsrc, (int)(r1 + c0), 0, 0).x; a11 = ilm_llvm_buffer_load_format_xy(rsrc, (int)(r1 + c1), 0, 0).x;

@@ -124,6 +124,9 @@ constexpr int kCountStride = 16;     // in 64-bit words
 constexpr int kCountLines = 17;      // per chunk in the step kernels' counter regions: the chunk's line + 16 bucket lines
 hipError_t launch_step(StepLaunch& a, hipStream_t stream);
 hipError_t step_sdf_sample_counter(int enable, unsigned long long* out);   // ilm_debug_step_sdf_samples
+// the slice-0 cells of a UNORM16 field (SdfView::cells0): does this step's collision update use them, and their build
+bool step_wants_slice0_cells(const IlmStepDesc& d, int format);
+hipError_t launch_build_slice0_cells(const uint2* texels, int width, int height, void* cells, hipStream_t stream);
 int set_step_interpreter(int on);     // ilm_debug_step_interpreter: returns the previous setting
 int set_step_streams(int n);          // ilm_debug_step_streams: 1 keeps every step on the context stream, 2 (default) lets large steps use two; returns the previous setting
 // the context's stream for work that is not a particle step: ordered after everything the context's second stepping stream holds (api.hip)

@@ -706,7 +706,7 @@ ILM_DEV f3 estimate_normal4(f3 position, const IlmDistanceFieldUniforms& df, con
 #pragma unroll
     for (int i = 0; i < 4; i++) {
         const f3 w = mk3(W[i][0], W[i][1], W[i][2]);
-        const float s = sample_distance_field<(FMT & 1), true, (FMT & 2) != 0>(position + (w * texel), df, sdf);
+        const float s = sample_distance_field<(FMT & 1), true, (FMT & 2) != 0, (FMT & 4) != 0>(position + (w * texel), df, sdf);
         result = result + (w * s);
     }
     return norm3(result);
@@ -1452,11 +1452,378 @@ __global__ __launch_bounds__(kStepThreads) void step_lean_kernel(const LeanStep 
                             a.live_counts, a.zero_counts, a.zero_n, a.host_counts, a.count_seq);
 }
 
+// ---------------------------------------------------------------------------------------------
+// the lean collision step (r06) -- UpdateParticleSystemWithDistanceField.fx:29-147 on the lean descriptor
+// ---------------------------------------------------------------------------------------------
+// The collision update is two things in one shader.  EVERY live particle samples the field where it is and where it is going (the
+// first iteration of the sweep): two dependent lookups, the same for all lanes.  A particle whose first sweep lookup lands inside an
+// obstacle (14 % of them on the demo's field) goes on: up to two more sweep lookups, estimateNormal4 (four more), the bounce / redirect
+// / escape arithmetic -- about as many vector instructions again as the whole rest of the step, run by a wave for its few such lanes
+// (the interpreter's step_kernel<.., DF>: 1 071 instructions per wave at 39.4 of 64 lanes, profiles/r06_collision_step.txt).
+// Here a wave walks K consecutive units in three phases.
+//   A  per unit: load, spawn, transforms, the common path at full width.  The lanes that collided are PARKED -- their state after the
+//      transforms and the two distances already sampled, eleven words, in a ring of 128 entries the wave owns in LDS (no barrier: the
+//      ring is private to the wave).  The unit's position and velocity stay in registers; nothing is stored yet.
+//   L  whenever 64 are parked, and once more after the last unit: the parked particles, one per lane, through the rest of the reference
+//      update (df_long: the operations of update_with_distance_field behind its first lookup); the results go back into
+//      the same ring entries.
+//   B  per unit: the parked lanes take their results from the ring, then computeRenderData and all sixteen stores at FULL width.
+// So the long path runs at 64 lanes -- or, for the remainder, at whatever K units leave -- instead of at ~9 lanes once per unit, and
+// every plane of a unit is still written by ONE full-width store (a first form of this kernel stored the finished lanes at once and
+// the parked ones later, from the long pass: two partial writes per line, and cfg4's share took 507-597 us against the interpreter's
+// 394 -- masked and scattered 4-byte stores cost a read-modify-write each once the line has left the L2).
+// A ring that would overflow (more than 128 of a wave's K x 64 particles colliding) is not waited for: that unit's parked lanes take the
+// long path in place, as the interpreter does.
+struct LeanStepDf {
+    LeanStep base;
+    IlmDistanceFieldUniforms df;
+    SdfView sdf;
+};
+static_assert(sizeof(LeanStepDf) <= 4096, "LeanStepDf travels in the kernarg segment (4 KB)");
+static_assert(sizeof(LeanStepDf) > 0xd40 && sizeof(LeanStepDf) <= 0xe00, "touch_kernarg_lines_lean_df reads one dword of each 64-byte line of LeanStepDf");
+ILM_DEV void touch_kernarg_lines_lean_df() {       // LeanStepDf: 54 .. 56 lines
+    const auto kp = __builtin_amdgcn_kernarg_segment_ptr();
+    uint32_t sink;
+    asm volatile(ILM_T16(0x0) ILM_T16(0x400) ILM_T16(0x800) ILM_T4(0xc00) ILM_T1(0xd00) ILM_T1(0xd40) "s_waitcnt lgkmcnt(0)"
+                 : "=&s"(sink) : "s"(kp));
+}
+typedef const LeanStepDf __attribute__((address_space(4))) CLeanStepDf;
+
+constexpr int kDfRing = 128;                     // parked particles per wave
+struct DfParked { float px[kDfRing], py[kDfRing], pz[kDfRing], life[kDfRing], vx[kDfRing], vy[kDfRing], vz[kDfRing], ct[kDfRing], d0[kDfRing], d1[kDfRing]; uint32_t slot[kDfRing]; };   // slot: bit 31 = d1 is the first iteration's lookup
+
+// The common path of PS_Update (distance field) for a live slot (life > 0 on entry): everything a particle needs that meets no obstacle.
+// The reference samples the field at the particle (initial_distance) and then at old + unit * travel with travel = max(0, min(
+// initial_distance, |velocity| dt)) -- two DEPENDENT lookups.  Away from obstacles travel IS |velocity| dt, known before any lookup: both
+// positions are sampled at once, and when min() did pick |velocity| dt (bit for bit) the second sample is the sweep's first
+// step_distance -- same position, same bits.  Returns 0 when the particle is finished (position and velocity final; zeros for one that
+// died); 1 when it must go on with the sweep's first iteration still to do (travel is not |velocity| dt: it sits at or inside an
+// obstacle); 2 when the first iteration is done and collided (step_distance valid).  For 1 and 2 position and velocity are left as they
+// came: the caller parks them for df_long.  Same operations in the same order as update_with_distance_field takes on these paths
+// (tests/test_step_kernels_gpu.py holds the kernels bit-equal, sample counts included).
+template <int FMT>
+ILM_DEV int df_common_path(float4& pos, float4& vel, const IlmParticleSystemUniforms& sys, float dts, const IlmDistanceFieldUniforms& df, const SdfView& sdf, int& samples,
+                           float& initial_distance, float& step_distance) {
+#pragma clang fp contract(off)
+    const float4 zero = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float new_life = pos.w - (sys.GlobalSettings.w * dts);
+    initial_distance = step_distance = 0.0f;
+    if (new_life <= 0.0f) {
+        pos = vel = zero;
+        return 0;
+    }
+    const float collision_distance = sys.CollisionSettings.z;
+    const f3 old_xyz = xyz(pos);
+    const f3 unit_vector = norm3(xyz(vel));
+    const f3 velocity = friction_and_maximum(xyz(vel), sys, dts);
+    const f3 scaled_velocity = velocity * dts;
+    const float reach = len3(scaled_velocity);
+    const f3 ahead = old_xyz + (unit_vector * reach);
+    initial_distance = sample_distance_field<(FMT & 1), true, (FMT & 2) != 0, (FMT & 4) != 0>(old_xyz, df, sdf);
+    step_distance = sample_distance_field<(FMT & 1), true, (FMT & 2) != 0, (FMT & 4) != 0>(ahead, df, sdf);        // (independent of the first: both in flight together)
+    samples++;
+    const bool was_colliding = initial_distance < collision_distance;
+    const float travel_distance = fmaxf(0.0f, fminf(initial_distance, reach));
+    if (__builtin_bit_cast(uint32_t, travel_distance) != __builtin_bit_cast(uint32_t, reach))
+        return 1;                                                 // the sweep starts somewhere else than `ahead`
+    if (was_colliding || !(travel_distance <= 0.001f)) {          // step_count 1 or MAX_STEP_COUNT: the sweep's first iteration runs, at `ahead`
+        samples++;
+        if (step_distance < collision_distance)
+            return 2;
+    }
+    pos = mk4(ahead.x, ahead.y, ahead.z, new_life);
+    vel = mk4(velocity.x, velocity.y, velocity.z, fmaxf(vel.w - 1.0f, 0.0f));
+    return 0;
+}
+
+// The rest of PS_Update (distance field) for a parked particle: update_with_distance_field with its first lookup (initial_distance) given
+// and, when `first_done`, the first iteration's lookup (step_distance0) too.  Operation for operation the function above -- the uniform
+// values and the vectors that depend on the inputs alone (unit vector, velocity after friction, travel distance) are formed again by
+// the same operations.
+template <int FMT>
+ILM_DEV void df_long(float4& pos, float4& vel, float x, float y, float initial_distance, float step_distance0, bool first_done,
+                     const IlmParticleSystemUniforms& sys, float dts, const IlmDistanceFieldUniforms& df, const SdfView& sdf, int& samples) {
+#pragma clang fp contract(off)
+    const float4 zero = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+    float new_life = pos.w - (sys.GlobalSettings.w * dts);
+    const float collision_distance = sys.CollisionSettings.z;
+    const float max_velocity = sys.GlobalSettings.z;
+    const f3 old_xyz = xyz(pos);
+    const f3 unit_vector = norm3(xyz(vel));
+    const f3 velocity = friction_and_maximum(xyz(vel), sys, dts);
+    const f3 scaled_velocity = velocity * dts;
+
+    bool collided = false, escaping = false;
+    f3 collision_position = mk3(0.0f, 0.0f, 0.0f), new_position = old_xyz;
+    float4 new_velocity = zero;
+
+    const bool was_colliding = initial_distance < collision_distance;
+    float travel_distance = fmaxf(0.0f, fminf(initial_distance, len3(scaled_velocity)));
+    int step_count = ref::kMaxStepCount;
+    if (was_colliding)
+        step_count = 1;
+    else if (travel_distance <= 0.001f)
+        step_count = 0;
+
+    for (int i = 0; i < step_count; i++) {
+        const f3 test_position = old_xyz + (unit_vector * travel_distance);
+        float step_distance = step_distance0;
+        if (!(first_done && i == 0)) {
+            step_distance = sample_distance_field<(FMT & 1), true, (FMT & 2) != 0, (FMT & 4) != 0>(test_position, df, sdf);
+            samples++;
+        }
+        if (step_distance < collision_distance) {
+            collided = true;
+            collision_position = test_position;
+        }
+        escaping = step_distance > initial_distance;
+        if (collided && !escaping) {
+            collision_position = test_position;
+            const float offset = clampf(step_distance + collision_distance, 0.05f, 16.0f);
+            travel_distance = fmaxf(0.0f, travel_distance - offset);
+        } else
+            step_count = 0;
+        if (travel_distance <= 0.001f)
+            step_count = 0;
+    }
+
+    if (collided) {
+        const bool bounce = vel.w <= 0.0f;
+        const bool redirect = was_colliding && !escaping;
+        f3 normal = mk3(0.0f, 0.0f, 0.0f);
+        if (bounce || redirect) {
+            normal = estimate_normal4<FMT>(collision_position, df, sdf);
+            samples += 4;
+        }
+        const float escape_speed = fminf(max_velocity, sys.CollisionSettings.x);
+        if (redirect) {
+            normal = normal * mk3(1.0f, 1.0f, 0.0f);  // ESCAPE_MASK
+            if (len3(normal) < ref::kNoNormalThreshold) {
+                const float a = (x / 67.0f) + (y / 13.0f);
+                normal = mk3(sinf(a), cosf(a), 0.0f);
+            }
+            const f3 nv = (norm3(normal) * escape_speed) * ref::kInitialEscapeSpeed;
+            new_velocity = mk4(nv.x, nv.y, nv.z, ref::kBounceDelay);
+            new_position = old_xyz + (nv * dts);
+        } else if (bounce) {
+            const float d2 = 2.0f * dot3(normal, unit_vector);
+            f3 bounce_vector = ((normal - unit_vector) * d2) * -1.0f;
+            if (len3(bounce_vector) < ref::kNoNormalThreshold)
+                bounce_vector = unit_vector * -1.0f;
+            else
+                bounce_vector = norm3(bounce_vector);
+            new_position = collision_position;
+            const f3 nv = bounce_vector * fminf(max_velocity, len3(velocity) * sys.CollisionSettings.y);
+            new_velocity = mk4(nv.x, nv.y, nv.z, ref::kBounceDelay);
+            new_life -= sys.CollisionSettings.w;
+        } else {
+            const float new_speed = fmaxf(len3(xyz(vel)) * ref::kEscapeSpeedAcceleration, escape_speed);
+            const f3 nv = unit_vector * new_speed;
+            new_velocity = mk4(nv.x, nv.y, nv.z, 0.0f);
+            new_position = old_xyz + (unit_vector * travel_distance);
+        }
+    } else {
+        new_velocity = mk4(velocity.x, velocity.y, velocity.z, fmaxf(vel.w - 1.0f, 0.0f));
+        new_position = old_xyz + (unit_vector * travel_distance);
+    }
+    if (new_life <= 0.0f) {
+        new_position = mk3(0.0f, 0.0f, 0.0f);
+        new_velocity = zero;
+    }
+    pos = mk4(new_position.x, new_position.y, new_position.z, new_life);
+    vel = new_velocity;
+}
+
+template <int FMT, bool SPAWN, bool STREAM, int K>
+__global__ __launch_bounds__(kStepThreads) void step_lean_df_kernel(const LeanStepDf a_) {
+    static_assert(K == 1 || K == 2 || K == 4, "units per wave");
+    __shared__ uint32_t wave_live[kStepThreads / 64];
+    __shared__ DfParked parked_all[kStepThreads / 64];
+    const LeanStepDf& A = *(const LeanStepDf*)(CLeanStepDf*)__builtin_amdgcn_kernarg_segment_ptr();
+    const LeanStep& a = A.base;
+    if (blockIdx.x < kTouchBlocks / K) touch_kernarg_lines_lean_df();
+    const unsigned lane = threadIdx.x & 63u;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    DfParked& parked = parked_all[wave];
+    constexpr int kUnitsPerBlock = (kStepThreads / 64) * K;
+    int v = (int)blockIdx.x * kUnitsPerBlock + a.unit_rotate;           // first unit of the block (rotation: see step_kernel; a multiple of kUnitsPerBlock)
+    if (v >= a.total_padded) v -= a.total_padded;
+    const int u0 = v + wave * K;                                        // this wave's K consecutive units: one chunk (units per chunk is a multiple of kUnitsPerBlock)
+    uint32_t n_live = 0;
+    int sdf_samples = 0;
+    const float4 zero = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (u0 < a.total_units) {
+        const int chunk_rel = u0 >> a.upc_shift;
+        const int seg0 = u0 - (chunk_rel << a.upc_shift);
+        const int chunk = a.first_chunk + chunk_rel;
+        int seg_end = 1 << a.upc_shift;                                 // units of this chunk that hold particles
+        if (a.partial_count != 0) {
+#pragma unroll
+            for (int k = 0; k < kMaxPartialChunks; k++)
+                if (a.partial_chunk[k] == chunk) seg_end = min(seg_end, a.partial_units[k]);
+        }
+        const int units = max(0, min(K, seg_end - seg0));               // (past seg_end: the never-written tail of a spawn-target chunk, zeros that stay zeros)
+        float* const chunk_base = ((CBase*)a.chunk_bases)[chunk];
+        const unsigned lane4 = lane * 4u;
+        const unsigned long long lanes_below = (1ull << lane) - 1ull;
+        // what a unit keeps in registers between phase A and phase B, and where its parked lanes sit in the ring
+        float4 hp0 = zero, hp1 = zero, hp2 = zero, hp3 = zero, hv0 = zero, hv1 = zero, hv2 = zero, hv3 = zero;
+        unsigned long long pm0 = 0ull, pm1 = 0ull, pm2 = 0ull, pm3 = 0ull;
+        uint32_t pb0 = 0, pb1 = 0, pb2 = 0, pb3 = 0;
+        uint32_t pending = 0, done = 0;                                 // ring entries [0, pending) hold parked particles, [0, done) their results
+
+        // the parked particles [first, first + count), count <= 64, one per lane: the rest of the reference's update, results in place
+        auto long_pass = [&](uint32_t first, uint32_t count) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (lane < count) {
+                const uint32_t e = first + lane;
+                float4 pos = mk4(parked.px[e], parked.py[e], parked.pz[e], parked.life[e]);
+                float4 vel = mk4(parked.vx[e], parked.vy[e], parked.vz[e], parked.ct[e]);
+                const uint32_t tagged = parked.slot[e];
+                const int slot = (int)(tagged & 0x7FFFFFFFu);
+                const int sy = slot >> a.cs_shift;
+                const float fx = (float)(slot - (sy << a.cs_shift)), fy = (float)sy;
+                df_long<FMT>(pos, vel, fx, fy, parked.d0[e], parked.d1[e], (tagged >> 31) != 0u, a.sys, a.dt_s, A.df, A.sdf, sdf_samples);
+                parked.px[e] = pos.x; parked.py[e] = pos.y; parked.pz[e] = pos.z; parked.life[e] = pos.w;
+                parked.vx[e] = vel.x; parked.vy[e] = vel.y; parked.vz[e] = vel.z; parked.ct[e] = vel.w;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        };
+
+        // ---- phase A ----
+#pragma nounroll
+        for (int j = 0; j < units; j++) {
+            const int seg = seg0 + j;
+            const UnitPlanes up = unit_planes(chunk_base, a.stride, seg * 64);
+            const SlotIn cur = load_slot<true, STREAM>(up, lane4);
+            const int first = seg * 64;
+            const int row = first >> a.cs_shift;
+            const int x0 = first - (row << a.cs_shift);
+            const float fx = (float)(x0 + (int)lane), fy = (float)row;
+            NoiseDeltas noise;
+            noise.valid = false;
+            if (a.noise_op >= 0)
+                noise = noise_prepare_lean(a, x0, row);
+            float4 pos = mk4(cur.px, cur.py, cur.pz, cur.life);
+            float4 vel = mk4(cur.vx, cur.vy, cur.vz, cur.ct);
+            float4 attr = mk4(cur.ar, cur.ag, cur.ab, cur.aa);
+            bool spawn_here = false, spawned = false;
+            if constexpr (SPAWN) {
+                for (int s = 0; s < a.spawn_count; s++) {
+                    if (a.spawn_chunk[s] == chunk && seg >= a.spawn_unit_lo[s] && seg <= a.spawn_unit_hi[s]) {
+                        const IlmSpawnRecord& r = a.spawns[s];
+                        const float fi = (float)(first + (int)lane);
+                        if (fi >= r.Params.ChunkSizeAndIndices[1] && fi <= r.Params.ChunkSizeAndIndices[2]) {
+                            spawn_here = true;
+                            if (spawn_slot(pos, vel, attr, fx, fy, a.rnd, a.rw, a.rh, a.inv_rw, a.inv_rh, r.Params))
+                                spawned = true;
+                        }
+                    }
+                }
+            }
+            const bool process = !(cur.life <= 0.0f) || spawn_here;
+            int parking = 0;
+            float d0 = 0.0f, d1 = 0.0f;
+            if (__ballot(process) != 0ull) {
+                if (process) {
+                    for (int o = 0; o < a.op_count; o++) {
+                        const int type = a.op_type[o];
+                        if (type == ILM_OP_GRAVITY)
+                            apply_gravity_lean(pos, vel, a.op[o].gravity, a.sys.GlobalSettings.x, a.sys.GlobalSettings.z);
+                        else if (type == ILM_OP_NOISE)
+                            apply_noise(pos, vel, fx, fy, a.rnd, a.rw, a.rh, a.sys, a.op[o].noise, a.inv_rw, a.inv_rh, a.dop[o],
+                                        (o == a.noise_op) ? noise : NoiseDeltas{ false, zero, zero });
+                        else
+                            apply_fma(pos, vel, a.sys, a.op[o].fma, a.dop[o]);
+                    }
+                    if (pos.w <= 0.0f)
+                        pos = vel = zero;  // readStateOrDiscard: discard => cleared target
+                    else
+                        parking = df_common_path<FMT>(pos, vel, a.sys, a.dt_s, A.df, A.sdf, sdf_samples, d0, d1);
+                } else {
+                    pos = vel = zero;
+                }
+            } else {
+                pos = vel = zero;
+            }
+            if constexpr (SPAWN) {
+                if (spawned) {      // (phase B reads the attributes back from the planes)
+                    st_plane<STREAM>(up, 8, lane4, attr.x); st_plane<STREAM>(up, 9, lane4, attr.y); st_plane<STREAM>(up, 10, lane4, attr.z); st_plane<STREAM>(up, 11, lane4, attr.w);
+                }
+            }
+            const bool park = parking != 0;
+            unsigned long long park_mask = __ballot(park);
+            const uint32_t n_park = (uint32_t)__popcll(park_mask);
+            if (n_park != 0u && pending + n_park > (uint32_t)kDfRing) {
+                // no room in the ring: these lanes take the long path here, as the interpreter's kernel does
+                if (park) df_long<FMT>(pos, vel, fx, fy, d0, d1, parking == 2, a.sys, a.dt_s, A.df, A.sdf, sdf_samples);
+                park_mask = 0ull;
+            } else if (n_park != 0u) {
+                if (park) {
+                    const uint32_t e = pending + (uint32_t)__popcll(park_mask & lanes_below);
+                    parked.px[e] = pos.x; parked.py[e] = pos.y; parked.pz[e] = pos.z; parked.life[e] = pos.w;
+                    parked.vx[e] = vel.x; parked.vy[e] = vel.y; parked.vz[e] = vel.z; parked.ct[e] = vel.w;
+                    parked.d0[e] = d0; parked.d1[e] = d1; parked.slot[e] = (uint32_t)(first + (int)lane) | ((parking == 2) ? 0x80000000u : 0u);
+                }
+            }
+            if (K == 1 || j == 0) { hp0 = pos; hv0 = vel; pm0 = park_mask; pb0 = pending; }
+            else if (K == 2 || j == 1) { hp1 = pos; hv1 = vel; pm1 = park_mask; pb1 = pending; }
+            else if (j == 2) { hp2 = pos; hv2 = vel; pm2 = park_mask; pb2 = pending; }
+            else { hp3 = pos; hv3 = vel; pm3 = park_mask; pb3 = pending; }
+            pending += (uint32_t)__popcll(park_mask);
+            if (pending - done >= 64u) { long_pass(done, 64u); done += 64u; }
+        }
+        // ---- phase L: what is still parked ----
+        while (done < pending) {
+            const uint32_t count = min(64u, pending - done);
+            long_pass(done, count);
+            done += count;
+        }
+        // ---- phase B ----
+        if constexpr (SPAWN) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the attributes stored for slots spawned in this launch are read back below
+#pragma nounroll
+        for (int j = 0; j < units; j++) {
+            const int seg = seg0 + j;
+            const UnitPlanes up = unit_planes(chunk_base, a.stride, seg * 64);
+            const float4 attr = mk4(ld_plane<STREAM>(up, 8, lane4), ld_plane<STREAM>(up, 9, lane4), ld_plane<STREAM>(up, 10, lane4), ld_plane<STREAM>(up, 11, lane4));
+            float4 pos, vel; unsigned long long pm; uint32_t pb;
+            if (K == 1 || j == 0) { pos = hp0; vel = hv0; pm = pm0; pb = pb0; }
+            else if (K == 2 || j == 1) { pos = hp1; vel = hv1; pm = pm1; pb = pb1; }
+            else if (j == 2) { pos = hp2; vel = hv2; pm = pm2; pb = pb2; }
+            else { pos = hp3; vel = hv3; pm = pm3; pb = pb3; }
+            if ((pm >> lane) & 1ull) {
+                const uint32_t e = pb + (uint32_t)__popcll(pm & lanes_below);
+                pos = mk4(parked.px[e], parked.py[e], parked.pz[e], parked.life[e]);
+                vel = mk4(parked.vx[e], parked.vy[e], parked.vz[e], parked.ct[e]);
+            }
+            const int first = seg * 64;
+            const int row = first >> a.cs_shift;
+            const float fx = (float)(first - (row << a.cs_shift) + (int)lane), fy = (float)row;
+            float4 rc = zero, rd = zero;
+            if (__ballot(pos.w > 0.0f) != 0ull)
+                render_data(fx, fy, pos, vel, attr, a.sys, a.update, a.bezier_codes, a.update_bits, nullptr, 0, 0, rc, rd);
+            st_plane<STREAM>(up, 0, lane4, pos.x); st_plane<STREAM>(up, 1, lane4, pos.y); st_plane<STREAM>(up, 2, lane4, pos.z); st_plane<STREAM>(up, 3, lane4, pos.w);
+            st_plane<STREAM>(up, 4, lane4, vel.x); st_plane<STREAM>(up, 5, lane4, vel.y); st_plane<STREAM>(up, 6, lane4, vel.z); st_plane<STREAM>(up, 7, lane4, vel.w);
+            st_plane<STREAM>(up, 12, lane4, rc.x); st_plane<STREAM>(up, 13, lane4, rc.y); st_plane<STREAM>(up, 14, lane4, rc.z); st_plane<STREAM>(up, 15, lane4, rc.w);
+            st_plane<STREAM>(up, 16, lane4, rd.x); st_plane<STREAM>(up, 17, lane4, rd.y); st_plane<STREAM>(up, 18, lane4, rd.z); st_plane<STREAM>(up, 19, lane4, rd.w);
+            n_live += (uint32_t)__popcll(__ballot(pos.w > 0.0f));
+        }
+    }
+    if ((__builtin_amdgcn_readfirstlane(g_step_count_sdf_samples) != 0) && (sdf_samples != 0))
+        atomicAdd(&g_step_sdf_samples, (unsigned long long)sdf_samples);
+    if (a.flags & ILM_STEP_COUNT_LIVE)
+        publish_block_count(wave_live, n_live, lane, wave, v < a.total_units, a.first_chunk + (v >> a.upc_shift),
+                            (v & ((1 << a.upc_shift) - 1)) / kUnitsPerBlock, (1 << a.upc_shift) / kUnitsPerBlock, a.count_buckets,
+                            a.live_counts, a.zero_counts, a.zero_n, a.host_counts, a.count_seq);
+}
+
 // LeanStep from a StepLaunch whose launch_step fields are filled; false when the step is not of the lean shape
 static bool build_lean_step(const StepLaunch& a, LeanStep& f) {
     const IlmStepDesc& d = a.desc;
     if (kUnitsPerWave != 1) return false;
-    if (d.UpdateMode != ILM_UPDATE_POSITIONS) return false;
+    if (d.UpdateMode != ILM_UPDATE_POSITIONS && d.UpdateMode != ILM_UPDATE_WITH_DISTANCE_FIELD) return false;   // (the collision update: launch_lean_df_step adds the field)
     if (a.derived.cs_shift < 6 || a.upc_shift < 0) return false;                   // power-of-two chunk size >= 64: no stride padding, a unit lies in one row
     if (a.slots != a.span) return false;
     if (a.derived.noise_may_revive != 0) return false;
@@ -1544,6 +1911,88 @@ static hipError_t launch_lean_step(const LeanStep& f, bool spawning, bool stream
     return hipGetLastError();
 }
 
+// The collision kernels' first template argument: the field's format, plus kFieldSlice0 when the uniforms put every lookup in virtual
+// slice 0 with a z weight of 0 (hlsl_math.hpp sample_distance_field<.., SLICE0>) -- what the reference's particle path binds.
+constexpr int kFieldSlice0 = 2;
+constexpr int kFieldCells0 = 4;      // ... plus the slice-0 cells (SdfView::cells0): one load per lookup (lean collision kernel only)
+static_assert((ILM_SDF_UNORM16 | ILM_SDF_FP16) == 1, "the format is bit 0 of the collision kernels' first template argument");
+// The slice-0 sampler returns the bilinear fetch of channel r where the general one forms lerp(lo, hi, 0) = fma(0, hi - lo, lo): equal
+// for FINITE texels only, so it serves UNORM16 fields (every code is finite); an FP16 atlas uploaded through ilm_sdf_upload may hold
+// inf / NaN (hi = inf gives NaN in the general form and in the oracle) and keeps the general sampler.  The uniforms whose fma(0, ., .)
+// terms the slice-0 form drops (Packed1.x, .z, TextureSliceAndTexelSize.xy) must be finite for the same reason.
+static bool field_is_slice0(const IlmDistanceFieldUniforms& df, int format) {
+    static const int enabled = [] { const char* e = getenv("ILM_DF_SLICE0"); return e ? atoi(e) : 1; }();
+    return enabled && (format == ILM_SDF_UNORM16) && (df.Packed1.y == 0.0f) && std::isfinite(df.Packed1.x) && std::isfinite(df.Packed1.z) &&
+           std::isfinite(df.TextureSliceAndTexelSize.x) && std::isfinite(df.TextureSliceAndTexelSize.y);
+}
+// SdfView::cells0 from the atlas: cell (x0, yr) = channel r of the taps (x0, y0), (x1, y0), (x0, y1), (x1, y1) of a bilinear fetch whose
+// upper-left tap is column x0 (already wrapped) of row yi = yr - 1 -- x1 = x0 + 1 with U WRAP, y0 = clamp(yi), y1 = the next row exactly
+// when 0 <= yi < height - 1: the integer bookkeeping of sample_distance_field, done once per texel instead of once per lookup.
+__global__ __launch_bounds__(256) void build_slice0_cells_kernel(const uint2* __restrict__ texels, int width, int height, uint2* __restrict__ cells) {
+    const int x0 = (int)blockIdx.x * 256 + (int)threadIdx.x, yr = (int)blockIdx.y;
+    if (x0 >= width) return;
+    const int yi = yr - 1;
+    const int y0 = min(max(yi, 0), height - 1);
+    const int y1 = ((uint32_t)yi < (uint32_t)(height - 1)) ? y0 + 1 : y0;
+    const int x1 = (x0 + 1 == width) ? 0 : x0 + 1;
+    const uint32_t r00 = texels[(size_t)y0 * width + x0].x & 0xFFFFu, r10 = texels[(size_t)y0 * width + x1].x & 0xFFFFu;
+    const uint32_t r01 = texels[(size_t)y1 * width + x0].x & 0xFFFFu, r11 = texels[(size_t)y1 * width + x1].x & 0xFFFFu;
+    cells[(size_t)yr * width + x0] = make_uint2(r00 | (r10 << 16), r01 | (r11 << 16));
+}
+hipError_t launch_build_slice0_cells(const uint2* texels, int width, int height, void* cells, hipStream_t stream) {
+    hipLaunchKernelGGL(build_slice0_cells_kernel, dim3((unsigned)((width + 255) / 256), (unsigned)(height + 1)), dim3(256), 0, stream, texels, width, height, static_cast<uint2*>(cells));
+    return hipGetLastError();
+}
+static bool step_interpreter_forced();
+bool step_wants_slice0_cells(const IlmStepDesc& d, int format) {
+    const char* e = getenv("ILM_DF_CELLS0");            // A/B switch, read per step: 0 = the four-tap form
+    if (e && atoi(e) == 0) return false;
+    const char* lean = getenv("ILM_DF_LEAN");
+    if ((lean && atoi(lean) == 0) || step_interpreter_forced()) return false;
+    return d.UpdateMode == ILM_UPDATE_WITH_DISTANCE_FIELD && format == ILM_SDF_UNORM16 && field_is_slice0(d.DistanceField, format);
+}
+
+// The lean collision step.  K = units per wave: the more units a wave walks, the fuller its long passes run -- and the longer it lives, so
+// a launch of few waves (cfg2: 16 384 units) takes the smaller K (tools/ab_collision.sh; ILM_DF_UNITS overrides).
+template <int FMT, bool SPAWN>
+static hipError_t launch_lean_df_variant(const LeanStepDf& f, int k, bool streaming, const dim3& grid, hipStream_t stream) {
+    const dim3 block(kStepThreads, 1, 1);
+    if (streaming) hipLaunchKernelGGL((step_lean_df_kernel<FMT, SPAWN, true, 4>), grid, block, 0, stream, f);
+    else if (k == 4) hipLaunchKernelGGL((step_lean_df_kernel<FMT, SPAWN, false, 4>), grid, block, 0, stream, f);
+    else if (k == 2) hipLaunchKernelGGL((step_lean_df_kernel<FMT, SPAWN, false, 2>), grid, block, 0, stream, f);
+    else hipLaunchKernelGGL((step_lean_df_kernel<FMT, SPAWN, false, 1>), grid, block, 0, stream, f);
+    return hipGetLastError();
+}
+static hipError_t launch_lean_df_step(LeanStepDf& f, const StepLaunch& a, bool spawning, hipStream_t stream) {
+    const char* forced_env = getenv("ILM_DF_UNITS");                  // (read per launch: an A/B and test switch)
+    const int forced_k = forced_env ? atoi(forced_env) : 0;
+    const bool streaming = a.streaming != 0;
+    int k = (forced_k == 1 || forced_k == 2 || forced_k == 4) ? forced_k : ((f.base.total_units >= 65536) ? 4 : 2);
+    if (streaming) k = 4;
+    const int upb = (kStepThreads / 64) * k;                            // units per block
+    while (k > 1 && (a.units_per_chunk % ((kStepThreads / 64) * k)) != 0) k >>= 1;       // (units per chunk is a power of two >= 64: never taken)
+    // the grid's bookkeeping for blocks of upb units (launch_step laid it out for blocks of kStepThreads / 64)
+    f.base.total_padded = (f.base.total_units + upb - 1) / upb * upb;
+    f.base.unit_rotate = f.base.unit_rotate / upb * upb;
+    int buckets = 1;
+    while (buckets * 2 <= kCountLines - 1 && (a.units_per_chunk / upb) % (buckets * 2) == 0) buckets *= 2;
+    f.base.count_buckets = buckets;
+    const dim3 grid((unsigned)(f.base.total_padded / upb), 1, 1);
+    int fmt = (int)a.sdf.format | (field_is_slice0(a.desc.DistanceField, (int)a.sdf.format) ? kFieldSlice0 : 0);
+    if (fmt == (ILM_SDF_UNORM16 | kFieldSlice0) && a.sdf.cells0 != nullptr) fmt |= kFieldCells0;
+    switch (fmt) {
+        case ILM_SDF_UNORM16 | kFieldSlice0 | kFieldCells0:
+            return spawning ? launch_lean_df_variant<ILM_SDF_UNORM16 | kFieldSlice0 | kFieldCells0, true>(f, k, streaming, grid, stream)
+                            : launch_lean_df_variant<ILM_SDF_UNORM16 | kFieldSlice0 | kFieldCells0, false>(f, k, streaming, grid, stream);
+        case ILM_SDF_FP16: return spawning ? launch_lean_df_variant<ILM_SDF_FP16, true>(f, k, streaming, grid, stream) : launch_lean_df_variant<ILM_SDF_FP16, false>(f, k, streaming, grid, stream);
+        case ILM_SDF_UNORM16: return spawning ? launch_lean_df_variant<ILM_SDF_UNORM16, true>(f, k, streaming, grid, stream) : launch_lean_df_variant<ILM_SDF_UNORM16, false>(f, k, streaming, grid, stream);
+        case ILM_SDF_FP16 | kFieldSlice0: return spawning ? launch_lean_df_variant<ILM_SDF_FP16 | kFieldSlice0, true>(f, k, streaming, grid, stream)
+                                                          : launch_lean_df_variant<ILM_SDF_FP16 | kFieldSlice0, false>(f, k, streaming, grid, stream);
+        default: return spawning ? launch_lean_df_variant<ILM_SDF_UNORM16 | kFieldSlice0, true>(f, k, streaming, grid, stream)
+                                 : launch_lean_df_variant<ILM_SDF_UNORM16 | kFieldSlice0, false>(f, k, streaming, grid, stream);
+    }
+}
+
 // The extended variant carries the rarely used techniques (MatrixMultiply, SpatialNoise, the position-buffer and feedback spawners) so
 // that the common variants do not pay their registers; it is always the spawning superset.
 static bool needs_extended_variant(const StepLaunch& a) {
@@ -1558,19 +2007,6 @@ static bool needs_extended_variant(const StepLaunch& a) {
 #ifndef ILM_DF_MINW
 #define ILM_DF_MINW 6
 #endif
-// The collision kernels' first template argument: the field's format, plus kFieldSlice0 when the uniforms put every lookup in virtual
-// slice 0 with a z weight of 0 (hlsl_math.hpp sample_distance_field<.., SLICE0>) -- what the reference's particle path binds.
-constexpr int kFieldSlice0 = 2;
-static_assert((ILM_SDF_UNORM16 | ILM_SDF_FP16) == 1, "the format is bit 0 of the collision kernels' first template argument");
-// The slice-0 sampler returns the bilinear fetch of channel r where the general one forms lerp(lo, hi, 0) = fma(0, hi - lo, lo): equal
-// for FINITE texels only, so it serves UNORM16 fields (every code is finite); an FP16 atlas uploaded through ilm_sdf_upload may hold
-// inf / NaN (hi = inf gives NaN in the general form and in the oracle) and keeps the general sampler.  The uniforms whose fma(0, ., .)
-// terms the slice-0 form drops (Packed1.x, .z, TextureSliceAndTexelSize.xy) must be finite for the same reason.
-static bool field_is_slice0(const IlmDistanceFieldUniforms& df, int format) {
-    static const int enabled = [] { const char* e = getenv("ILM_DF_SLICE0"); return e ? atoi(e) : 1; }();
-    return enabled && (format == ILM_SDF_UNORM16) && (df.Packed1.y == 0.0f) && std::isfinite(df.Packed1.x) && std::isfinite(df.Packed1.z) &&
-           std::isfinite(df.TextureSliceAndTexelSize.x) && std::isfinite(df.TextureSliceAndTexelSize.y);
-}
 template <bool SPAWN>
 static hipError_t launch_step_variant(const StepLaunch& a, hipStream_t stream) {
     const int units = a.unit_end - a.unit_begin;
@@ -1664,9 +2100,20 @@ hipError_t launch_step(StepLaunch& a, hipStream_t stream) {
         spawning = true;
     }
     if (!step_interpreter_forced() && a.unit_end > a.unit_begin) {
-        LeanStep f;
-        if (build_lean_step(a, f))
-            return launch_lean_step(f, spawning, a.streaming != 0, stream);
+        if (a.desc.UpdateMode == ILM_UPDATE_WITH_DISTANCE_FIELD) {
+            const char* lean_env = getenv("ILM_DF_LEAN");                 // A/B switch, read per launch: 0 = the interpreter
+            const bool lean_df = !(lean_env && atoi(lean_env) == 0);
+            LeanStepDf f;
+            if (lean_df && build_lean_step(a, f.base)) {
+                f.df = a.desc.DistanceField;
+                f.sdf = a.sdf;
+                return launch_lean_df_step(f, a, spawning, stream);
+            }
+        } else {
+            LeanStep f;
+            if (build_lean_step(a, f))
+                return launch_lean_step(f, spawning, a.streaming != 0, stream);
+        }
     }
     return spawning ? launch_step_variant<true>(a, stream) : launch_step_variant<false>(a, stream);
 }

@@ -135,6 +135,180 @@ def test_both_step_kernels_agree_and_match_the_oracle(ctx, oracle, name):
     eng.close()
 
 
+@pytest.mark.parametrize("fmt,packed1,units,spawn,cells", [(abi.SDF_UNORM16, False, 1, False, True), (abi.SDF_UNORM16, False, 2, True, True), (abi.SDF_UNORM16, False, 4, False, True),
+                                                            (abi.SDF_UNORM16, False, 2, True, False), (abi.SDF_UNORM16, False, 4, False, False),
+                                                            (abi.SDF_UNORM16, True, 2, False, True), (abi.SDF_UNORM16, True, 4, True, True), (abi.SDF_FP16, False, 2, False, True),
+                                                            (abi.SDF_FP16, True, 4, True, True), (abi.SDF_FP16, True, 1, True, True)])
+def test_the_lean_collision_step_equals_the_interpreter_bit_for_bit(ctx, oracle, fmt, packed1, units, spawn, cells):
+    """Row a10 (UpdateParticleSystemWithDistanceField.fx:29-147) has a kernel of its own since r06 (step_lean_df_kernel: the common path
+    at full width, the particles that collided parked in the wave's LDS ring and taken through the reference's whole update 64 at a time).
+    It must give the interpreter's bits -- planes and live counts -- for 1, 2 and 4 units per wave, both field formats, the particle path's
+    uniforms (DistanceFieldPacked1 = 0: the slice-0 sampler, through the one-load cells of a UNORM16 field and through its four taps) and the
+    general ones, with a spawner feeding a partly used chunk and a life penalty that kills some of the bouncing particles; both are held
+    against the oracle."""
+    import os
+    from tests.test_particles_gpu import cfg1_field
+    cs, n_chunks, steps = 64, 3, 3
+    n = cs * cs
+    rnd = scenes.randomness_table(11)
+    eng = native.Engine(ctx, cs, rnd)
+    layout, atlas, dfu = cfg1_field(fmt, packed1)
+    sdf = native.DistanceFieldTexture(ctx, atlas, fmt)
+    pos, vel, attr = scenes.make_particles(78, n * n_chunks, pos_lo=(-20, -20, 0), pos_hi=(276, 276, 32), life=(0.02, 2.5), dead_fraction=0.2, categories=(0.0, 2.0))
+    used = [n, n, 1024]
+
+    def step_desc():
+        d = _step(cs, dict(ops=("gravity", "noise"), spawns=((2, 900, 2400),) if spawn else ()))
+        d.System = scenes.system_uniforms(cs, friction=0.05, max_velocity=900.0, life_decay=4.0, collision=(128.0, 0.6, 0.33, 0.4))
+        d.UpdateMode = abi.UPDATE_WITH_DISTANCE_FIELD
+        d.DistanceField = dfu
+        return d
+    systems = []
+    prev = native.lib().ilm_debug_step_interpreter(0)
+    os.environ["ILM_DF_UNITS"] = str(units)
+    os.environ["ILM_DF_CELLS0"] = "1" if cells else "0"
+    try:
+        for interpreter in (0, 1):
+            native.lib().ilm_debug_step_interpreter(interpreter)
+            s = native.System(eng)
+            s.set_distance_field(sdf)
+            for c in range(n_chunks):
+                s.add_chunk()
+                sl = slice(c * n, c * n + used[c])
+                s.upload(c, P, pos[sl]); s.upload(c, V, vel[sl]); s.upload(c, A, attr[sl])
+            counts = []
+            for _ in range(steps):
+                s.step(step_desc())
+                counts.append(s.step_counts().copy())
+            systems.append((s, counts))
+    finally:
+        native.lib().ilm_debug_step_interpreter(prev)
+        del os.environ["ILM_DF_UNITS"], os.environ["ILM_DF_CELLS0"]
+    (lean, lean_counts), (interp, interp_counts) = systems
+    chunks = []
+    for c in range(n_chunks):
+        z = [np.zeros((n, 4), np.float32) for _ in range(5)]
+        z[0][:used[c]] = pos[c * n:c * n + used[c]]; z[1][:used[c]] = vel[c * n:c * n + used[c]]; z[2][:used[c]] = attr[c * n:c * n + used[c]]
+        chunks.append(z)
+    otex = oracle.make_texture(atlas, fmt)
+    want_counts = [np.asarray(oracle.step(chunks, cs, rnd, step_desc(), sdf=otex, want_counts=True)).copy() for _ in range(steps)]
+    for a, b, w in zip(lean_counts, interp_counts, want_counts):
+        assert np.array_equal(a, b) and np.array_equal(a, w), (a, b, w)
+    for c in range(n_chunks):
+        for k, plane in enumerate(PLANES):
+            a, b = lean.download(c, plane), interp.download(c, plane)
+            assert_bits_equal(a, b, "collision step: chunk %d plane %d, lean vs interpreting kernel" % (c, plane))
+            assert_close(a, chunks[c][k], "collision step: chunk %d plane %d vs oracle" % (c, plane), life_exact=(plane == P))
+    bounced = sum(int((chunks[c][1][:, 3] == 3.0).sum()) for c in range(n_chunks))
+    assert bounced > 50, bounced                     # the scene exercises the long path (BOUNCE_DELAY in the velocity's w)
+    assert np.array_equal(lean.live_counts(), interp.live_counts())
+    for s, _ in systems:
+        s.close()
+    sdf.close(); eng.close()
+
+
+def test_the_slice0_cells_follow_the_field(ctx):
+    """The one-load cells of the lean collision step are derived from the atlas: an atlas uploaded anew, regenerated slices and an atlas
+    whose device pointer was handed out (it may change behind the library's back: rebuilt before every use) must all be seen by the next
+    step.  Lean == interpreter after every change, and the change itself moves particles."""
+    import ctypes as C
+    from tests.test_particles_gpu import cfg1_field
+    cs = 64
+    n = cs * cs
+    rnd = scenes.randomness_table(11)
+    eng = native.Engine(ctx, cs, rnd)
+    layout, atlas, dfu = cfg1_field(abi.SDF_UNORM16, False)
+    other = np.ascontiguousarray(atlas[::-1, ::-1]).copy()                  # another field of the same shape
+    pos, vel, attr = scenes.make_particles(79, n, pos_lo=(-20, -20, 0), pos_hi=(276, 276, 32), life=(0.5, 2.5), categories=(0.0, 2.0))
+    sdfs = [native.DistanceFieldTexture(ctx, atlas, abi.SDF_UNORM16) for _ in range(2)]
+    systems = []
+    prev = native.lib().ilm_debug_step_interpreter(0)
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+
+    def step(s):
+        d = _step(cs, dict(ops=("gravity",)))
+        d.System = scenes.system_uniforms(cs, friction=0.05, max_velocity=900.0, life_decay=0.1, collision=(128.0, 0.6, 0.33, 0.0))
+        d.UpdateMode = abi.UPDATE_WITH_DISTANCE_FIELD
+        d.DistanceField = dfu
+        s.step(d)
+    try:
+        for interpreter in (0, 1):
+            s = native.System(eng)
+            s.set_distance_field(sdfs[interpreter])
+            s.add_chunk()
+            s.upload(0, P, pos); s.upload(0, V, vel); s.upload(0, A, attr)
+            systems.append(s)
+        snapshots = []
+        for phase in range(4):
+            for interpreter, s in enumerate(systems):
+                native.lib().ilm_debug_step_interpreter(interpreter)
+                if phase == 1:
+                    sdfs[interpreter].upload(other)                           # ilm_sdf_upload: the version moves
+                if phase == 2:                                                # the pointer escapes, the atlas is overwritten behind the library's back
+                    ptr = sdfs[interpreter].device_ptr()
+                    ctx.sync()
+                    assert hip.hipMemcpy(ptr, atlas.ctypes.data, atlas.nbytes, 1) == 0
+                step(s); step(s)
+            a, b = [systems[0].download(0, k) for k in (P, V)], [systems[1].download(0, k) for k in (P, V)]
+            for k in range(2):
+                assert_bits_equal(a[k], b[k], "phase %d plane %d, lean (slice-0 cells) vs interpreting kernel" % (phase, k))
+            snapshots.append(a[1].copy())
+        bounced = [(v[:, 3] == 3.0) for v in snapshots]
+        assert bounced[0].sum() > 50 and (bounced[1] != bounced[0]).any() and (bounced[2] != bounced[1]).any()
+    finally:
+        native.lib().ilm_debug_step_interpreter(prev)
+    for s in systems:
+        s.close()
+    for f in sdfs:
+        f.close()
+    eng.close()
+
+
+def test_the_lean_collision_step_on_large_chunks_and_many_collisions(ctx):
+    """1024^2 chunks (the streaming variant's shape, 4 units per wave, the counts through the bucket lines) over a field in which a third of
+    the particles sit inside obstacles: long passes of 64 run in the middle of a wave's walk, the ring wraps.  Lean == interpreter."""
+    import os
+    from tests.test_particles_gpu import cfg1_field
+    cs = 1024
+    n = cs * cs
+    rnd = scenes.randomness_table(5)
+    eng = native.Engine(ctx, cs, rnd)
+    layout, atlas, dfu = cfg1_field(abi.SDF_UNORM16, False)
+    sdf = native.DistanceFieldTexture(ctx, atlas)
+    pos, vel, attr = scenes.make_particles(9, n, pos_lo=(20, 20, 0), pos_hi=(236, 236, 24), life=(0.02, 1.0), dead_fraction=0.3)
+    out = []
+    prev = native.lib().ilm_debug_step_interpreter(0)
+    try:
+        for interpreter, streaming in ((0, "0"), (0, "1"), (1, "0")):
+            native.lib().ilm_debug_step_interpreter(interpreter)
+            os.environ["ILM_STEP_STREAMING"] = streaming          # (the non-temporal variant is a launch decision by size: forced here)
+            s = native.System(eng)
+            s.set_distance_field(sdf)
+            s.add_chunk()
+            s.upload(0, P, pos); s.upload(0, V, vel); s.upload(0, A, attr)
+            for _ in range(2):
+                d = _step(cs, dict(ops=("gravity", "noise")))
+                d.System = scenes.system_uniforms(cs, friction=0.05, max_velocity=900.0, life_decay=4.0, collision=(128.0, 0.6, 0.33, 0.4))
+                d.UpdateMode = abi.UPDATE_WITH_DISTANCE_FIELD
+                d.DistanceField = dfu
+                s.step(d)
+            counts = s.step_counts().copy()
+            planes = [s.download(0, k) for k in (P, V, RC, RD)]
+            assert counts[0] == int((planes[0][:, 3] > 0).sum()) and np.array_equal(counts, s.live_counts())
+            out.append((counts, planes))
+            s.close()
+    finally:
+        native.lib().ilm_debug_step_interpreter(prev)
+        os.environ.pop("ILM_STEP_STREAMING", None)
+    for other in (0, 1):
+        assert np.array_equal(out[other][0], out[2][0])
+        for k in range(4):
+            assert_bits_equal(out[other][1][k], out[2][1][k], "1024^2 collision step plane %d, lean (variant %d) vs interpreting kernel" % (k, other))
+    assert (out[2][1][1][:, 3] == 3.0).mean() > 0.02
+    sdf.close(); eng.close()
+
+
 @pytest.mark.parametrize("cs,n_chunks", [(1024, 2), (2048, 1)])
 def test_both_step_kernels_agree_on_large_chunks(ctx, cs, n_chunks):
     """Chunks larger than the randomness table take the 5 x 5 noise tables; their ~4000+ blocks publish one count through the bucket lines."""

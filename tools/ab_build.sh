@@ -11,7 +11,7 @@ src=$1; shift
 objs=""
 for o in particles lighting fields gbuffer output raster api group; do
   if [ "$o.hip" = "$src" ]; then
-    case $o in lighting|fields|raster) noslp=-fno-slp-vectorize;; *) noslp=;; esac      # as the Makefile
+    case $o in particles|lighting|fields|raster) noslp=-fno-slp-vectorize;; *) noslp=;; esac      # as the Makefile
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC -Wall -Wno-unused-function $noslp "$@" -c $src -o /tmp/ab_${tag}_$o.o
     objs="$objs /tmp/ab_${tag}_$o.o"
   else objs="$objs $o.o"; fi

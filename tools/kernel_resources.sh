@@ -4,7 +4,7 @@
 cd "$(cd "$(dirname "$0")/.." && pwd)/illuminant_amd/csrc"
 f=$1; shift
 extra=""
-case $f in lighting|fields|raster) extra="-fno-slp-vectorize";; esac
+case $f in particles|lighting|fields|raster) extra="-fno-slp-vectorize";; esac
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fPIC $extra "$@" -Rpass-analysis=kernel-resource-usage -c $f.hip -o /tmp/kr_$f.o 2>&1 | \
   python3 -c "
 import re, sys, subprocess
