@@ -1070,56 +1070,88 @@ def main():
                                                      "(crowded tiles in 2048-sprite segments, combined in order); ordered blending"}
         del target
     if not args.no_next_rows and world == 1:
-        # collision update: cfg2's particles (Gravity x4 + Noise, no spawner) stepped with UpdateWithDistanceField
-        # through the demo's own field, next to the same system stepped with UpdatePositions.  Unit of the roofline: 112 B per live
-        # slot-step + 32 B per sampleDistanceFieldEx call, the call count taken on the device (ilm_debug_step_sdf_samples).
+        # collision update (UpdateParticleSystemWithDistanceField.fx:29-147): Gravity x 4 + Noise (no spawner) stepped with
+        # UpdateWithDistanceField through the demo's own field, next to the same system stepped with UpdatePositions -- cfg2's particles
+        # (1 M in 16 chunks of 256^2, cache-resident) and cfg4's per-GPU share (8.4 M in 8 chunks of 1024^2, 0.67 GB: HBM-resident).  Unit of
+        # the roofline: 112 B per live slot-step + 32 B per sampleDistanceFieldEx call, the call count taken on the device
+        # (ilm_debug_step_sdf_samples).  Since r06 the update runs in a kernel of its own (step_lean_df_kernel, particles.hip); the
+        # interpreting kernel's time (ILM_DF_LEAN=0, a launch decision read per step) is taken beside it in the same run.
         scene = build_collision_scene(H, ctx, scenes, abi)
-        rows = {}
-        for label, collide in (("plain", False), ("collision", True)):
-            C = build_particle_system(H, ctx, scenes, abi, args.chunk_size, args.chunks, rank, with_spawner=False)
-            cs_, ctp = C["ps"], C["tp"]
+
+        def collision_system(cs_c, n_c, collide):
+            C = build_particle_system(H, ctx, scenes, abi, cs_c, n_c, rank, with_spawner=False)
             if collide:
                 col = H.ParticleCollision()
                 col.DistanceField = scene["field"]
                 col.DistanceFieldMaximumZ = 256.0                         # SimpleParticles.cs:293
                 col.LifePenalty = 1.0                                     # :132-134
-                cfgc = cs_.Configuration
+                cfgc = C["ps"].Configuration
                 cfgc.Collision = col
-                cs_.Configuration = cfgc
-            fc = 0
-            for _ in range(10):
-                ctp.Advance(dt); cs_.Update(fc); fc += 1
-            samples_per_step = 0
-            if collide:
-                out_n = C_.c_uint64(0)
-                native.check(native.lib().ilm_debug_step_sdf_samples(ctx.Handle, 1, None))
-                ctp.Advance(dt); cs_.Update(fc); fc += 1
-                native.check(native.lib().ilm_debug_step_sdf_samples(ctx.Handle, 0, C_.byref(out_n)))
-                samples_per_step = int(out_n.value)
-            kc, blocks_c = 20, []
-            for _ in range(7):
+                C["ps"].Configuration = cfgc
+            return C
+
+        def time_collision_steps(C, fc, kc=20, n=7):
+            cs_, ctp, blocks_c = C["ps"], C["tp"], []
+            for _ in range(n):
                 barrier()
                 ctx.TimerStart()
                 for _ in range(kc):
-                    ctp.Advance(dt); cs_.Update(fc); fc += 1
+                    ctp.Advance(dt); cs_.Update(fc[0]); fc[0] += 1
                 blocks_c.append(ctx.TimerStop() / kc)
             blocks_c.sort()
-            rows[label] = dict(ms=blocks_c[len(blocks_c) // 2], ms_min=blocks_c[0], samples=samples_per_step, live=C["live"], live_now=int(cs_.LiveCount) if hasattr(cs_, "LiveCount") else None)
-            del C, cs_
-        pl, co = rows["plain"], rows["collision"]
-        alg = co["live"] * PARTICLE_BYTES_PER_SLOT + co["samples"] * SDF_SAMPLE_BYTES
-        next_rows["collision_step_1m"] = {
-            "us_per_step": round(co["ms"] * 1e3, 2), "us_per_step_min": round(co["ms_min"] * 1e3, 2), "us_per_step_update_positions": round(pl["ms"] * 1e3, 2),
-            "ratio_to_plain_step": round(co["ms"] / pl["ms"], 3), "particles": co["live"], "sdf_samples_per_step": co["samples"],
-            "sdf_samples_per_particle": round(co["samples"] / max(co["live"], 1), 3),
-            "field": "1920x1080x64, 9 slices at 1/4 resolution, max encoded distance 320, 4 cylinders + 4 edge boxes (SimpleParticles.cs:210-284)",
-            "roofline": {"bound": "hbm", "achieved": round(alg / (co["ms"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(alg / (co["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                         "kernel": "ilm::step_kernel<unorm16, DF> (interpreter; the collision update has no lean variant)",
-                         "bytes_per_unit": "112 B per live slot-step + 32 B per SDF sample", "units_per_launch": {"slots": co["live"], "sdf_samples": co["samples"]},
-                         "launch_ms": round(co["ms"], 5),
-                         "resident": "infinity-cache (0.8 MB field + 84 MB of particle state < %d MiB)" % INFINITY_CACHE_MB,
-                         "note": "cache-served bytes priced against the HBM peak because that is the contract's roofline: read it like cfg2's fraction, not like cfg4's"}}
+            return blocks_c
+        for key, cs_c, n_c, resident in (("collision_step_1m", args.chunk_size, args.chunks, "infinity-cache (0.8 MB field + 84 MB of particle state < %d MiB)" % INFINITY_CACHE_MB),
+                                         ("collision_step_8m", 1024, 8, "hbm (0.67 GB of particle state per step > %d MiB Infinity Cache; the 4 MB field and its cells stay in the L2 / Infinity Cache)" % INFINITY_CACHE_MB)):
+            if key == "collision_step_8m" and args.no_cfg4:
+                continue
+            rows = {}
+            for label, collide, env_ in (("plain", False, None), ("collision", True, None), ("interpreter", True, {"ILM_DF_LEAN": "0"})):
+                for k_, v_ in (env_ or {}).items():
+                    os.environ[k_] = v_
+                try:
+                    C = collision_system(cs_c, n_c, collide)
+                    fc = [0]
+                    for _ in range(10):
+                        C["tp"].Advance(dt); C["ps"].Update(fc[0]); fc[0] += 1
+                    samples_per_step = 0
+                    if collide:
+                        out_n = C_.c_uint64(0)
+                        native.check(native.lib().ilm_debug_step_sdf_samples(ctx.Handle, 1, None))
+                        C["tp"].Advance(dt); C["ps"].Update(fc[0]); fc[0] += 1
+                        native.check(native.lib().ilm_debug_step_sdf_samples(ctx.Handle, 0, C_.byref(out_n)))
+                        samples_per_step = int(out_n.value)
+                    blocks_c = time_collision_steps(C, fc, n=(7 if label != "interpreter" else 3))
+                    rows[label] = dict(ms=blocks_c[len(blocks_c) // 2], ms_min=blocks_c[0], samples=samples_per_step, live=C["live"])
+                    del C
+                finally:
+                    for k_ in (env_ or {}):
+                        os.environ.pop(k_, None)
+            pl, co, it = rows["plain"], rows["collision"], rows["interpreter"]
+            alg = co["live"] * PARTICLE_BYTES_PER_SLOT + co["samples"] * SDF_SAMPLE_BYTES
+            units_k = 4 if key == "collision_step_8m" else 2
+            kname = "ilm::step_lean_df_kernel<6, false, %s, %d>" % ("true" if key == "collision_step_8m" else "false", units_k)
+            ct = profiled_traffic(kname)
+            lanes_c = None
+            for row_ in _newest_pmc_rows()[0]:
+                if row_["kernel"].startswith(kname) and row_.get("SQ_THREAD_CYCLES_VALU") and row_.get("SQ_ACTIVE_INST_VALU") and float(row_["SQ_ACTIVE_INST_VALU"]) > 0:
+                    lanes_c = round(float(row_["SQ_THREAD_CYCLES_VALU"]) / float(row_["SQ_ACTIVE_INST_VALU"]), 1)
+            next_rows[key] = {
+                "us_per_step": round(co["ms"] * 1e3, 2), "us_per_step_min": round(co["ms_min"] * 1e3, 2), "us_per_step_update_positions": round(pl["ms"] * 1e3, 2),
+                "us_per_step_interpreting_kernel": round(it["ms"] * 1e3, 2), "vs_interpreting_kernel": round(co["ms"] / it["ms"], 3),
+                "ratio_to_plain_step": round(co["ms"] / pl["ms"], 3), "particles": co["live"], "sdf_samples_per_step": co["samples"],
+                "sdf_samples_per_particle": round(co["samples"] / max(co["live"], 1), 3), "sample_counts_equal_the_interpreting_kernels": bool(co["samples"] == it["samples"]),
+                "field": "1920x1080x64, 9 slices at 1/4 resolution, max encoded distance 320, 4 cylinders + 4 edge boxes (SimpleParticles.cs:210-284)",
+                "lanes_active_per_valu_instruction": lanes_c,
+                "roofline": {"bound": "hbm", "achieved": round(alg / (co["ms"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": round(alg / (co["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": round(ct["bytes"]) if ct else None,
+                             "traffic_source": ("profiles/%s: FETCH_SIZE x 2 + WRITE_SIZE of the step's launches (two per step)" % ct["source"]) if ct else None,
+                             "kernel": "ilm::step_lean_df_kernel<unorm16 | slice 0 | cells, %d units per wave%s> (two launches per step: the chunk range halved over the context's two streams)"
+                                       % (units_k, ", streaming" if key == "collision_step_8m" else ""),
+                             "bytes_per_unit": "112 B per live slot-step + 32 B per SDF sample (SURVEY 8d: 4 taps x 8 B; the kernel fetches ONE 8-byte cell per sample)",
+                             "units_per_launch": {"slots": co["live"], "sdf_samples": co["samples"]},
+                             "launch_ms": round(co["ms"], 5), "resident": resident,
+                             "note": ("cache-served bytes priced against the HBM peak because that is the contract's roofline: read it like cfg2's fraction" if key == "collision_step_1m"
+                                      else "the particle planes stream from HBM (112 B per slot); the samples' 32 B each are L2 / Infinity-Cache service priced against the HBM peak")}}
         del scene
     cpu_init, cpu_rnd, cpu_desc_bytes = P["init"], P["rnd"], ps.LastStepBytes()
     cfg4_desc_bytes = None
@@ -1502,11 +1534,11 @@ def main():
                 # stated per sample too -- the frames differ 5 x in samples per pixel, the CPU's sample rate should not
                 rows, mid, want_s = 4, h // 2, max(2.5, min(args.cpu_seconds / 3.0, 6.0))
                 while True:
-                    rows = int(min(rows, h // 2))
+                    rows = int(min(rows, h))                # (cfg3's whole frame is ~1.5 s of 16 cores: then the sample is the frame)
                     t0 = time.perf_counter()
                     _, ost = orc.render_sphere_lights(verts, envu, dfuu, None, tex, (0.05, 0.05, 0.05, 1.0), w, h, row_begin=mid - rows // 2, row_end=mid - rows // 2 + rows, want_stats=True)
                     el = time.perf_counter() - t0
-                    if el >= want_s or rows >= h // 2:
+                    if el >= want_s or rows >= h:
                         break
                     rows = int(np.ceil(rows * min(max(1.25 * want_s / max(el, 1e-3), 1.5), 64.0)))
                 lighting[name]["cpu_baseline"] = {"value": round(rows * w / el / 1e6, 4), "unit": "lit Mpixels/s", "cores": orc.num_threads(), "kind": "port",

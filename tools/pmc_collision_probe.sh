@@ -8,9 +8,9 @@ OUT=gpurun_out/pmc_collision_probe_${1:-x}
 SIZES=${2:-1m}
 rm -rf "$OUT"; mkdir -p "$OUT"
 CMD="python tools/collision_probe.py --sizes $SIZES --reps 2 --steps 10"
-rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS -d "$OUT/p1" -o pmc -- $CMD > "$OUT/p1.txt" 2> "$OUT/p1.log"
-rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_WR SQ_WAIT_ANY -d "$OUT/p2" -o pmc -- $CMD > "$OUT/p2.txt" 2> "$OUT/p2.log"
-rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d "$OUT/p3" -o pmc -- $CMD > "$OUT/p3.txt" 2> "$OUT/p3.log"
+timeout 240 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVE_CYCLES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS -d "$OUT/p1" -o pmc -- $CMD > "$OUT/p1.txt" 2> "$OUT/p1.log"
+timeout 240 rocprofv3 --kernel-trace --output-format csv --pmc SQ_WAVES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VMEM_WR SQ_WAIT_ANY -d "$OUT/p2" -o pmc -- $CMD > "$OUT/p2.txt" 2> "$OUT/p2.log"
+timeout 240 rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE WRITE_SIZE TCC_HIT_sum TCC_MISS_sum -d "$OUT/p3" -o pmc -- $CMD > "$OUT/p3.txt" 2> "$OUT/p3.log"
 python - "$OUT" <<'PY' > "$OUT/summary.txt" 2>&1
 import csv, glob, sys, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
