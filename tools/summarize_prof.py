@@ -107,7 +107,12 @@ def main():
             c = {name: v[1] / v[0] for name, v in agg[k].items()}
             lines.append("### `%s`  (VGPR %s, SGPR %s)" % (k, meta[k][0], meta[k][1]))
             if "FETCH_SIZE" in c:
-                lines.append("* FETCH_SIZE %.1f KB per dispatch (raw); x2 for wide coalesced reads per MI355X_MICROARCH.md = %.2f MB" % (c["FETCH_SIZE"], c["FETCH_SIZE"] * 2 * 1024 / 1e6))
+                if "raster_tiles_kernel" in k:
+                    # 64-byte sprite records gathered by index are tallied at their size, the 8-byte keys at half (profiles/r06_fetch_size_calibration.txt)
+                    lines.append("* FETCH_SIZE %.1f KB per dispatch (raw) = %.2f MB; this kernel gathers 64-byte records (tallied x 1) and streams 8-byte keys "
+                                 "(x 1/2): NOT doubled (profiles/r06_fetch_size_calibration.txt; r03-r05 doubled it and read 2.06 x the records)" % (c["FETCH_SIZE"], c["FETCH_SIZE"] * 1024 / 1e6))
+                else:
+                    lines.append("* FETCH_SIZE %.1f KB per dispatch (raw); x2 for wide coalesced reads per MI355X_MICROARCH.md = %.2f MB" % (c["FETCH_SIZE"], c["FETCH_SIZE"] * 2 * 1024 / 1e6))
             if "WRITE_SIZE" in c:
                 lines.append("* WRITE_SIZE %.1f KB per dispatch = %.2f MB" % (c["WRITE_SIZE"], c["WRITE_SIZE"] * 1024 / 1e6))
             if "TCC_HIT_sum" in c and (c["TCC_HIT_sum"] + c.get("TCC_MISS_sum", 0)) > 0:
