@@ -64,7 +64,7 @@ struct Ctx {
     int device = 0;
     // Sibling contexts (ilm_ctx_create_sibling, r05): contexts of one device that keep several frames in flight -- own stream, own scratch,
     // own lightmaps -- and may READ each other's distance fields and G-buffers in the light passes (Shared below orders those reads
-    // against the owner's writes).  `family` = the address the first of them had; 0 = no siblings.
+    // against the owner's writes).  `family` = a process-wide serial number the first sibling call hands out; 0 = no siblings.
     uintptr_t family = 0;
     int children = 0;            // live engines / distance fields / G-buffers / lightmaps: the context cannot be destroyed under them
     std::vector<struct Lightmap*> mirrored;      // this context's lightmaps with an armed store-mode table (lightmap_set_mirrors), for their aliases
@@ -131,8 +131,8 @@ struct Engine {
     // SpareBufferCount = 20 spares: ParticleEngine.cs:53-58,145-170,402-419) because creating a render target in the middle of a frame is
     // expensive; so is hipMalloc: a Spawner that fills a 256^2 chunk every 60 steps paid ~70 us for the 61st (tools/host_cost_probe_cfg2.py).
     // Chunks are carved out of slabs of up to 8 (64 MB at most; one for the large chunk sizes), zero-filled on the context stream when a
-    // slab is allocated and again when a chunk comes back; `spare` holds the ready ones.  Slabs live until the engine is destroyed,
-    // except single-chunk slabs beyond kSpareChunks spares, which are freed when they come back.
+    // slab is allocated and again when a chunk comes back; `spare` holds the ready ones.  Beyond kSpareChunks spares a slab whose chunks are
+    // ALL spare is freed (release_chunk); the rest live until the engine is destroyed.
     static constexpr int kSpareChunks = 20;
     struct Slab { float* base; int chunks; };
     std::vector<Slab> slabs;
@@ -1292,7 +1292,10 @@ int32_t ilm_ctx_create_sibling(IlmHandle hctx, IlmHandle* out_ctx) {
     IlmHandle h = 0;
     const int32_t rc = ilm_ctx_create(c->device, &h);
     if (rc != ILM_OK) return rc;
-    if (c->family == 0) c->family = reinterpret_cast<uintptr_t>(c);
+    // (a process-wide serial, not the first context's address: the heap may hand a destroyed context's address to an unrelated one, whose
+    // siblings would then have joined the survivors of the old family -- ADVICE r05)
+    static std::atomic<uintptr_t> next_family{1};
+    if (c->family == 0) c->family = next_family.fetch_add(1);
     from_handle<Ctx>(h, kMagicCtx)->family = c->family;
     *out_ctx = h;
     return ILM_OK;
@@ -1433,17 +1436,29 @@ static int32_t acquire_chunk(Engine* e, float** out) {
     e->spare.pop_back();
     return ILM_OK;
 }
-// a chunk nobody reads any more (the caller has drained the context stream) goes back: zeroed for its next owner
+// A chunk nobody reads any more (the caller has drained the context stream) goes back, zeroed for its next owner.  Beyond kSpareChunks
+// spares the pool gives memory back, as the reference discards buffers beyond SpareBufferCount (ParticleEngine.cs:402-419): a slab ALL
+// of whose chunks are spare is freed, so a destroyed 64-chunk system of 1024^2 (5 GB) does not stay pinned behind a live engine
+// (r05 only ever freed one-chunk slabs).
 static void release_chunk(Engine* e, float* chunk) {
-    if ((int)e->spare.size() >= Engine::kSpareChunks)
-        for (size_t i = 0; i < e->slabs.size(); i++)
-            if (e->slabs[i].base == chunk && e->slabs[i].chunks == 1) {      // beyond the spare limit a chunk with a slab of its own is freed
-                (void)hipFree(chunk);
-                e->slabs.erase(e->slabs.begin() + (long)i);
-                return;
-            }
     (void)hipMemsetAsync(chunk, 0, e->chunk_bytes(), e->ctx->main());
     e->spare.push_back(chunk);
+    const size_t chunk_floats = e->chunk_bytes() / sizeof(float);
+    while ((int)e->spare.size() > Engine::kSpareChunks) {
+        size_t victim = e->slabs.size();
+        for (size_t i = 0; i < e->slabs.size() && victim == e->slabs.size(); i++) {
+            const float* lo = e->slabs[i].base; const float* hi = lo + (size_t)e->slabs[i].chunks * chunk_floats;
+            int spare_here = 0;
+            for (const float* p : e->spare) spare_here += (p >= lo && p < hi) ? 1 : 0;
+            if (spare_here == e->slabs[i].chunks) victim = i;
+        }
+        if (victim == e->slabs.size()) break;               // every slab still has a chunk in use: nothing can go yet
+        const float* lo = e->slabs[victim].base; const float* hi = lo + (size_t)e->slabs[victim].chunks * chunk_floats;
+        e->spare.erase(std::remove_if(e->spare.begin(), e->spare.end(), [&](const float* p) { return p >= lo && p < hi; }), e->spare.end());
+        (void)hipStreamSynchronize(e->ctx->main());        // (the zero-fills queued on its chunks)
+        (void)hipFree(e->slabs[victim].base);
+        e->slabs.erase(e->slabs.begin() + (long)victim);
+    }
 }
 
 int32_t ilm_engine_destroy(IlmHandle h) {

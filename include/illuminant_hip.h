@@ -1024,6 +1024,9 @@ int32_t ilm_group_lightmap_wait(IlmHandle group_lightmap);
  * The table follows the BUFFER: a lightmap object the host made around a member's texels on the member's context (ilm_lightmap_create
  * with external_device_ptr = ilm_lightmap_device_ptr(member)) is mirrored exactly like the member handle itself; such an object on ANOTHER
  * context (a sibling's) is refused by the light passes with ILM_ERR_STATE while the mode is armed (its stream is outside the fence).
+ * ONLY the light passes are mirrored: ilm_lightmap_clear, ilm_lightmap_upload, ilm_render_particles and ilm_resolve_lighting into an armed
+ * member (or an alias of its texels) write THAT member's copy alone -- the members' frames stay equal only if every member makes the same
+ * call (a host that clears or uploads per frame does it on every member, as it creates the replicated inputs).
  * Synchronises the members' streams.  The reference has one device and one lightmap
  * (Illuminant/Lighting/LightingRenderer.cs:1004-1010): every member still ends with that one composited frame. */
 int32_t ilm_group_lightmap_store_mode(IlmHandle group_lightmap, int32_t enable);

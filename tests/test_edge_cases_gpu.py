@@ -347,3 +347,38 @@ def test_chunks_come_from_the_engines_pool_zero_filled(ctx):
         c2.add_chunk()
         assert not c2.download(c2.chunk_count() - 1, abi.PLANE_POSITION).any()
     c2.close(); b.close(); eng.close()
+
+
+def test_the_chunk_pool_gives_memory_back_beyond_its_spares(ctx):
+    """ParticleEngine keeps at most SpareBufferCount = 20 discarded buffers (ParticleEngine.cs:402-419).  The pool carves chunks from slabs
+    of up to eight: r05 only ever freed one-chunk slabs, so destroying a large system pinned all of its memory behind a live engine
+    (ADVICE r05).  Remove 40 chunks of 256^2 (5 slabs of 42 MB): the device's free memory must come back but for at most the 20 spares
+    and the slabs that still hold a chunk in use."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(), C.c_size_t()
+
+    def free_bytes():
+        ctx.sync()
+        assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+        return int(free.value)
+    cs = 256
+    eng = native.Engine(ctx, cs, scenes.randomness_table(3))
+    sysm = native.System(eng)
+    before = free_bytes()
+    for _ in range(41):
+        sysm.add_chunk()
+    chunk_bytes = (before - free_bytes()) / 48.0          # 41 chunks come out of 6 slabs of 8
+    assert 5.0e6 < chunk_bytes < 5.6e6                    # 20 planes x (65 536 + padding) floats
+    for _ in range(40):
+        sysm.remove_chunk(sysm.chunk_count() - 1)
+    held = before - free_bytes()
+    # one slab holds the chunk still in use (8 chunks), the spares are at most 20 chunks + the slab granularity
+    assert held <= (8 + 20 + 8) * chunk_bytes * 1.02, (held / chunk_bytes)
+    assert held >= 8 * chunk_bytes * 0.98
+    # the spares are reused: the same chunks come back without a new allocation
+    mid = free_bytes()
+    for _ in range(16):
+        sysm.add_chunk()
+    assert free_bytes() >= mid - 8 * chunk_bytes * 1.02
+    sysm.close(); eng.close()
