@@ -1589,11 +1589,20 @@ def main():
             r = L["renderer"]
             stats = r.RenderLighting(1.0, 0, -1, True)
             ctx.Sync()
-            ctx.TimerStart()
-            frames = 3
-            for _ in range(frames):
+            # (r06: the row follows seconds of CPU-only work -- the lighting cpu_baseline legs -- and three frames after one warm-up frame were
+            # timed on a device still at its idle clocks: 1.30-1.34 ms where the same library gives 1.04.  Warm for >= 40 frames, then the
+            # median of seven blocks of ten.)
+            for _ in range(40):
                 r.RenderLighting(1.0, 0, -1, False)
-            pl_ms = ctx.TimerStop() / frames
+            ctx.Sync()
+            frames, pl_blocks = 10, []
+            for _ in range(7):
+                ctx.TimerStart()
+                for _ in range(frames):
+                    r.RenderLighting(1.0, 0, -1, False)
+                pl_blocks.append(ctx.TimerStop() / frames)
+            pl_blocks.sort()
+            pl_ms = pl_blocks[len(pl_blocks) // 2]
             alg = int(stats[0]) * SDF_SAMPLE_BYTES + 1920 * 1080 * 16 + 4096 * (32 + 128)
             # vector-instruction issue of the wide-binning instantiation of the light kernel in the committed PMC profile of this bench
             plv = profiled_per_wave("ilm::sphere_lights_kernel<0, false, true>", "SQ_INSTS_VALU")
@@ -1601,7 +1610,9 @@ def main():
             pl_waves = light_launch_waves(native.Context(local_rank, borrowed_handle=ctx.Handle))
             pl_issue = (pl_waves * plv["value"] / (pl_ms * 1e-3) / 1e9) if plv else None
             next_rows["particle_lights_1080p_4096"] = {
-                "ms_per_frame": round(pl_ms, 4), "lit_mpixels_per_s": round(1920 * 1080 / (pl_ms * 1e-3) / 1e6, 1), "lights": 4096,
+                "ms_per_frame": round(pl_ms, 4), "ms_per_frame_min": round(pl_blocks[0], 4), "ms_per_frame_max": round(pl_blocks[-1], 4),
+                "timed_blocks": {"blocks": len(pl_blocks), "frames_per_block": frames, "headline": "median block"},
+                "lit_mpixels_per_s": round(1920 * 1080 / (pl_ms * 1e-3) / 1e6, 1), "lights": 4096,
                 "sdf_samples_per_frame": int(stats[0]), "pixel_light_pairs": int(stats[1]),
                 "roofline": {"bound": "valu", "achieved": round(pl_issue, 1) if pl_issue else None, "peak": round(VALU_ISSUE_PEAK, 1), "unit": "G wave-instr/s",
                              "frac": round(pl_issue / VALU_ISSUE_PEAK, 4) if pl_issue else None, "traffic": None,
