@@ -625,7 +625,14 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
         }
         return mask;
     };
-    const int cull_bit = __builtin_amdgcn_readfirstlane(10 + wave);      // (uniform by construction; said so, so that the walk's test is scalar)
+    // Entry layout of the LDS list: the light's index within the batch, the four cull bits above it, bit 15 = the tile lies wholly inside
+    // the footprint.  The wide binning with the cull (r06, BIG): a batch holds up to 4 096 lights -- 12 index bits, the cull bits above,
+    // no bit 15 (the walk always takes the per-pixel footprint test) -- and ends early when another round of 256 lights might not fit the
+    // list: 4 096 particle lights were four batches of 1 024, four lists of ten entries with the tile's waves meeting at the end of each;
+    // one list of forty, one meeting: 0.991 -> 0.978 ms per frame, the same bits (tools/particle_lights_ab.py, profiles/r06_lane_queue_ab.txt).
+    constexpr bool BIG = WIDE_BIN && kCircleCull;
+    constexpr int kCullShift = BIG ? 12 : 10, kIndexMask = (1 << kCullShift) - 1;
+    const int cull_bit = __builtin_amdgcn_readfirstlane(kCullShift + wave);      // (uniform by construction; said so, so that the walk's test is scalar)
 
     // What the lights are added to: the clear colour, or the lightmap's contents (additive blend onto an earlier pass of the same frame:
     // another light-type render state, LightingRenderer.cs:1100-1169).  Read when it is needed -- at the end, where the tile's sum is
@@ -696,11 +703,11 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
     };
     int part_bound = blend_fp16 ? 0x7FFFFFFF : (int)(((long long)light_count * (part + 1)) / kLightParts);   // first light of the next part
 
-    for (int batch = light_lo; batch < light_hi; batch += kListCapacity) {
+    for (int batch = light_lo, batch_step = kListCapacity; batch < light_hi; batch += batch_step) {
 #ifdef ILM_EXP_NO_BIN              // EXPERIMENT (timing of the prologue only): no light is looked at
-        const int batch_n = 0;
+        int batch_n = 0;
 #else
-        const int batch_n = min(kListCapacity, light_hi - batch);
+        int batch_n = min(BIG ? 4096 : kListCapacity, light_hi - batch);
 #endif
         if constexpr (WIDE_BIN) {
         __syncthreads();                                        // the previous batch's list has been walked
@@ -710,8 +717,8 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
             const float tminx = (float)tx0 + 0.5f, tmaxx = (float)(tx0 + kTile - 1) + 0.5f;
             const float tminy = (float)ty0 + 0.5f, tmaxy = (float)(ty0 + kTile - 1) + 0.5f;
             constexpr int kWaves = kLightThreads / 64;
-            int base = 0;
-            for (int l0 = 0; l0 < batch_n; l0 += kLightThreads) {
+            int base = 0, l0 = 0;
+            for (; l0 < batch_n && (!BIG || base + kLightThreads <= kListCapacity); l0 += kLightThreads) {
                 const int li = l0 + (int)threadIdx.x;
                 bool hit = false, whole = false;
                 if (li < batch_n) {
@@ -731,9 +738,11 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
 #pragma unroll
                 for (int w = 0; w < kWaves; w++) { const int c = bin_count[round][w]; total += c; if (w < wave) before += c; }
                 if (hit)
-                    list[base + before + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(li | (whole ? 0x8000 : 0));
+                    list[base + before + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(li | ((whole && !BIG) ? 0x8000 : 0));
                 base += total;
             }
+            // (the batch ends where the binning stopped: `base` is the same in every thread, so is l0)
+            if constexpr (BIG) { batch_n = min(batch_n, l0); batch_step = (batch_n > 0) ? batch_n : 4096; }
             if (threadIdx.x == 0) list_count = base;
         }
         __syncthreads();
@@ -773,7 +782,7 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
             // tile, of which a few dozen are listed: computing the bits there cost more than the skipped entries gave back)
             for (int t = (int)threadIdx.x; t < n; t += kLightThreads) {
                 const int e = (int)list[t];
-                list[t] = (uint16_t)(e | (culled_waves(recs[batch + (e & 0x3FF)]) << 10));
+                list[t] = (uint16_t)(e | (culled_waves(recs[batch + (e & kIndexMask)]) << kCullShift));
             }
             __syncthreads();
         }
@@ -789,7 +798,7 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
             const IlmEnvironment& env_k = A.env;
             const RampView& ramp_k = A.ramp;
             const int entry = __builtin_amdgcn_readfirstlane((int)list[k]);
-            const int li = entry & (kCircleCull ? 0x3FF : 0x7FFF);
+            const int li = entry & (kCircleCull ? kIndexMask : 0x7FFF);
             if (kCircleCull && ((entry >> cull_bit) & 1))      // this wave's points are outside the light's circle (see culled_waves): a scalar test
                 continue;
             while (batch + li >= part_bound) {      // (never in the fp16-per-light model)
@@ -802,7 +811,7 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
             const LightRec& L = recs[batch + li];
 
             bool covered = in_image;
-            if ((entry & 0x8000) == 0) {
+            if (BIG || (entry & 0x8000) == 0) {
                 // raster footprint: pixel centre inside the cross-shaped quad
                 // (all eight bounds fetched together and combined without short-circuits: as written with && / || the compiler issued
                 // eight dependent scalar loads, each behind its own wait and branch)

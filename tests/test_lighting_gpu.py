@@ -389,3 +389,55 @@ def test_circle_cull_keeps_every_bit(ctx, oracle, sfmt):
         sysm.close(); eng.close()
     finally:
         gb.close(); sdf.close()
+
+
+@pytest.mark.gpu
+def test_crowded_tiles_end_their_batches_early(ctx, oracle):
+    """The wide binning's batches (r06): up to 4 096 lights each, ended early when another binning round of 256 lights might not fit the
+    tile's 1 024-entry list (lighting.hip, BIG).  Two chunks of 64^2 slots, ~4 900 live particle lights: the first chunk's crowd around
+    one spot -- the tiles there list well over a thousand of them, so their batches end after a few rounds while the other tiles' run
+    to 4 096 -- the second's are spread over the frame.  The plain frame must equal the instrumented one (batches of 1 024, no cull)
+    bit for bit, and the instrumented counts are the oracle's."""
+    from tests import lights_common as lc
+    layout, atlas, dfu, _, w, h = small_scene(abi.SDF_UNORM16, width=200, height=144)
+    sdf = native.DistanceFieldTexture(ctx, atlas, abi.SDF_UNORM16)
+    otex = oracle.make_texture(atlas, abi.SDF_UNORM16)
+    ambient = (0.05, 0.06, 0.07, 1.0)
+    cs = 64
+    n = cs * cs
+    chunks = []
+    for c, (lo, hi) in enumerate((((70, 50, 2), (120, 90, 30)), ((0, 0, 2), (w, h, 30)))):
+        pos, vel, attr = scenes.make_particles(191 + c, n, pos_lo=lo, pos_hi=hi, dead_fraction=0.4)
+        rc = scenes.uniform(192 + c, (n, 4), 0.2, 1.0).astype(np.float32)
+        rc[:, :3] *= rc[:, 3:4]
+        chunks.append([pos, vel, attr, rc, np.zeros((n, 4), np.float32)])
+    eng = native.Engine(ctx, cs, scenes.randomness_table(7))
+    sysm = native.System(eng)
+    for c, planes in enumerate(chunks):
+        sysm.add_chunk()
+        sysm.upload(c, abi.PLANE_POSITION, planes[0]); sysm.upload(c, abi.PLANE_RENDER_COLOR, planes[3])
+    params = lc.particle_light_params(2.0, 9.0, (1.0, 0.9, 0.8, 0.05), casts_shadows=True)
+    env = scenes.environment()
+    frames = []
+    try:
+        for want_stats in (True, False):
+            lm = native.Lightmap(ctx, w, h, abi.LIGHTMAP_FLOAT4)
+            native.render_sphere_lights(ctx, None, env, dfu, None, sdf, ambient, lm)
+            st = native.render_particle_lights(ctx, sysm, params, env, dfu, None, sdf, lm, want_stats=want_stats)
+            frames.append(lm.download())
+            lm.close()
+            if want_stats:
+                want = np.empty((h, w, 4), np.float32)
+                want[...] = np.asarray(ambient, np.float32)
+                ost = oracle.render_particle_lights(chunks, [n, n], params, env, dfu, None, otex, want, want_stats=True)
+                assert (st.SdfSamples, st.PixelLightPairs, st.TracedPairs) == (ost.SdfSamples, ost.PixelLightPairs, ost.TracedPairs)
+        assert np.array_equal(frames[0].view(np.uint32), frames[1].view(np.uint32)), "the frame of early-ended batches differs from the instrumented one"
+        # the tile of pixels (96..111, 64..79) lists every live light whose square footprint (half edge radius + ramp + 1 = 12) touches it:
+        # far more than one list's worth, so its first batch cannot run to 4 096 lights
+        p0 = chunks[0][0]
+        listed = (p0[:, 3] > 0) & (p0[:, 0] > 96 - 12) & (p0[:, 0] < 112 + 12) & (p0[:, 1] > 64 - 12) & (p0[:, 1] < 80 + 12)
+        assert int(listed.sum()) > 1300, int(listed.sum())
+        assert frames[0][..., 3].max() > 60.0, frames[0][..., 3].max()
+        assert_close(frames[0], want, "lightmap")
+    finally:
+        sysm.close(); eng.close(); sdf.close()
