@@ -41,9 +41,9 @@ SDF_SAMPLE_BYTES = 32           # one sampleDistanceFieldEx = 4 bilin
 # beside it (lighting.hip cone_trace_loop<FAST>: 56 for fp16 fields, 52 for unorm16 ones since the cell array of r03; 12 fewer in the
 # iterations whose visibility division is skipped).
 TRACE_INSTRUCTIONS_PER_SAMPLE = 60          # r02's yardstick, kept so that the fraction stays comparable across rounds
-TRACE_LOOP_INSTRUCTIONS = {"fp16": 56, "unorm16": 52}      # with the visibility division taken; 44 / 40 when the wave skips it
+TRACE_LOOP_INSTRUCTIONS = {"fp16": 56, "unorm16": 52}      # with the visibility division taken; 44 / 40 when the wave skips it (docs/experiments.md 3.2)
 # The loop the shipped kernel runs, weighted by how often a wave's iteration skips the division (82 % of them on cfg5, measured when the
-# skip went in): 0.82 x 44 + 0.18 x 56 and 0.82 x 40 + 0.18 x 52.  This is the PRIMARY work-based figure since r04.
+# skip went in, docs/experiments.md 3.2): 0.82 x 44 + 0.18 x 56 and 0.82 x 40 + 0.18 x 52.  This is the PRIMARY work-based figure since r04.
 TRACE_LOOP_WEIGHTED = {"fp16": 46.0, "unorm16": 42.0}
 INFINITY_CACHE_MB = 256
 
@@ -1562,7 +1562,7 @@ def main():
         l3 = lighting["cfg3_1080p_64_lights_unorm16"]
         # cfg3 beside it, with what ELSE limits it said in the record: its issue fraction is not slack -- the unorm16
         # field's samples are two 8-byte typed loads per lane whose data path (TD) is 82 % busy at this sample rate
-        # (profiles/r03_typed_unorm16_loads.txt, DESIGN 3.2 "cfg3, accounted": 87 % of its vector instructions are trace)
+        # (profiles/r03_typed_unorm16_loads.txt, docs/experiments.md 3.2 "cfg3, accounted": 87 % of its vector instructions are trace)
         out["roofline_lighting_cfg3"] = {"workload": "cfg3: 1080p, 64 lights, unorm16 samples", "bound": "valu", "achieved": l3["roofline"]["achieved"], "peak": l3["roofline"]["peak"],
                                          "unit": "G wave-instr/s", "frac": l3["roofline"]["frac"], "useful_frac": l3["work_bound"]["useful_frac"],
                                          "co_limit": "TD 82 % busy: the texture-data path returns the unorm16 taps as 2 x 8 B typed loads per lane-sample (TD_TD_BUSY, profiles/r03_typed_unorm16_loads.txt); "
@@ -1668,7 +1668,7 @@ def main():
                 dyn[tag] = ctx.TimerStop() / 44
             next_rows["cfg3_frame_with_a_dynamic_field"] = {
                 "ms_per_frame": round(dyn["one_triplet_per_frame"], 4), "static_field_ms_per_frame": round(dyn["static"], 4),
-                "note": "one slice triplet (of eleven) re-rendered per frame + the cells of the four slices around it, then the lit frame; DESIGN 3.4"}
+                "note": "one slice triplet (of eleven) re-rendered per frame + the cells of the four slices around it, then the lit frame; docs/experiments.md 3.4"}
             r.Configuration.MaximumFieldUpdatesPerFrame = 9999
             del L, r
             # lightmap resolve: 4K HalfVector4 lightmap -> RGBA8, ToneMap; 8 B read + 4 B written per pixel
@@ -1708,7 +1708,7 @@ def main():
                              "frac": round(px * 16 / (gb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                              "kernel": "ilm::gbuffer_setup_kernel (reads the vertex arrays in the pinned ring) + ilm::gbuffer_bin_kernel + ilm::gbuffer_meshes_kernel", "bytes_per_unit": 16, "units_per_launch": px,
                              "launch_ms": round(gb_ms, 4),
-                             "note": "one 16 B store per texel is the algorithmic traffic; the frame is the setup kernel reading the vertex arrays where the host left them (11 us), the block-binning kernel (6 us) and the raster kernel (40 us), which is bound by instruction issue (per-candidate scalar code and per-pixel shader arithmetic), not by the store: DESIGN 3.4"}}
+                             "note": "one 16 B store per texel is the algorithmic traffic; the frame is the setup kernel reading the vertex arrays where the host left them (11 us), the block-binning kernel (6 us) and the raster kernel (40 us), which is bound by instruction issue (per-candidate scalar code and per-pixel shader arithmetic), not by the store: docs/experiments.md 3.4"}}
             gbt.close()
 
     if next_rows:

@@ -226,7 +226,7 @@ ILM_DEV float div_no_scale(float n, float d) { return div_with_rcp(n, d, refined
 
 // The general form: any position (clamped to the volume, distance to the volume added), U WRAP / V CLAMP on the real atlas.
 // SLICE0: the uniforms as the reference's PARTICLE path binds them -- DistanceFieldPacked1 left at zero (ParticleSystem.cs
-// SetDistanceFieldUniforms): zToSliceIndex = 0 puts every lookup at slice position 0 * min(z, maximumValidZ) = 0, i.e. virtual
+// SetDistanceFieldUniforms; docs/experiments.md 1): zToSliceIndex = 0 puts every lookup at slice position 0 * min(z, maximumValidZ) = 0, i.e. virtual
 // slice 0 (column 0, row 0, channel pair (r, g)) with a z weight of 0 -- the result is the bilinear fetch of channel r alone:
 // lerp(lo, hi, 0) = fma(0, hi - lo, lo) = lo for every finite lo, hi (up to the sign of a zero that `kDistanceZero - blended` does not
 // see).  The caller selects it when Packed1.y == 0 and Packed1.x, .z are finite; one channel per tap, three lerps instead of seven, no

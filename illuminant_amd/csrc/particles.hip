@@ -2034,7 +2034,7 @@ static hipError_t launch_step_variant(const StepLaunch& a, hipStream_t stream) {
     const int units_per_block = (kStepThreads / 64) * kUnitsPerWave;
     const dim3 grid((unsigned)((units + units_per_block - 1) / units_per_block), 1, 1), block(kStepThreads, 1, 1);
     if (a.desc.UpdateMode == ILM_UPDATE_WITH_DISTANCE_FIELD) {
-        // waves per SIMD requested for the collision variants (ILM_DF_MINW; measured in DESIGN 3.1)
+        // waves per SIMD requested for the collision variants (ILM_DF_MINW; measured in docs/experiments.md 3.1)
         switch ((int)a.sdf.format | (field_is_slice0(a.desc.DistanceField, (int)a.sdf.format) ? kFieldSlice0 : 0)) {
             case ILM_SDF_FP16: hipLaunchKernelGGL((step_kernel<ILM_SDF_FP16, true, SPAWN, ILM_DF_MINW>), grid, block, 0, stream, a); break;
             case ILM_SDF_UNORM16: hipLaunchKernelGGL((step_kernel<ILM_SDF_UNORM16, true, SPAWN, ILM_DF_MINW>), grid, block, 0, stream, a); break;

@@ -522,7 +522,7 @@ int32_t ilm_sdf_destroy(IlmHandle sdf);
 /* DistanceField.Save (Illuminant/SDF/DistanceField.cs:178-194): the atlas bytes, 8 per texel, row-major. */
 int32_t ilm_sdf_download(IlmHandle sdf, uint16_t* texels);
 /* The atlas in device memory, for callers that write it themselves (a torch tensor view, another library's kernel).  The light passes
- * read the field through a cell array derived from the atlas: once the pointer has been handed out the library cannot know
+ * read the field through a cell array derived from the atlas (docs/experiments.md 2): once the pointer has been handed out the library cannot know
  * when the atlas changes and re-derives ALL cells before every light pass (138 MB on a 512 x 512 x 33 field) -- until the caller takes
  * over the bookkeeping with ilm_sdf_mark_dirty. */
 int32_t ilm_sdf_device_ptr(IlmHandle sdf, void** out_ptr);
@@ -753,7 +753,7 @@ int32_t ilm_ctx_set_light_ramp(IlmHandle ctx, const IlmFloat4* texels, int32_t w
  *     model: dst = half(float(dst) + float(half(src))) per light and channel, round to nearest even (Direct3D converts the shader's
  *     output to the target format, then blends).  Same light order, same shader arithmetic; only the rounding of the sum differs.
  * 1e-4 parity with the HLSL path is defined against the fp32 form; this mode exists to MEASURE how far the frame the
- * reference's hardware path displays lies from it (tests/test_lighting_gpu.py holds it bit-equal to the oracle's model). */
+ * reference's hardware path displays lies from it (docs/experiments.md 3.2; tests/test_lighting_gpu.py holds it bit-equal to the oracle's model). */
 #define ILM_BLEND_FP32_ACCUMULATE 0
 #define ILM_BLEND_FP16_PER_LIGHT 1
 int32_t ilm_ctx_set_lightmap_blend(IlmHandle ctx, int32_t mode);
@@ -765,7 +765,7 @@ int32_t ilm_ctx_set_lightmap_blend(IlmHandle ctx, int32_t mode);
  * workgroups share those parts; the lightmap's bits do not depend on it.  0 (default) = chosen per launch: 1 for launches that fill the
  * device several times over (whole frames); short ones (one rank's strip of a frame split over 8 GPUs, a small target), which would
  * otherwise last two wave lifetimes whatever their share of the work, are TAPERED -- the tiles that start first are served whole, later
- * ones by 2, then 4, the last by 8 workgroups, so that the launch drains in its smallest pieces.  A non-zero value
+ * ones by 2, then 4, the last by 8 workgroups, so that the launch drains in its smallest pieces (docs/experiments.md 3.2).  A non-zero value
  * serves every tile by that many.  Launches in the ILM_BLEND_FP16_PER_LIGHT model, of fewer than 16 or more than 1 024 lights, or of
  * particle lights always use 1. */
 int32_t ilm_ctx_set_light_split(IlmHandle ctx, int32_t workgroups);

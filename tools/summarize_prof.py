@@ -72,6 +72,23 @@ def main():
                                                                  ("%.2f" % (a[len(a) // 2] / 1e3)) if a else "-", len(o), ("%.2f" % (sum(o) / len(o) / 1e3)) if o else "-"))
             lines.append("")
 
+        # The step kernels by grid: one kernel name carries cfg2's steps, cfg4's share, cfg4 whole (the N = 1 headline since r06) and cfg5's
+        # 16 M particles; a step is TWO launches (the chunk range halved over the context's two streams) that run side by side, so a
+        # launch lasts about as long as the step it belongs to.  bench.py's roofline.launch_ms is to be checked against the row of its grid.
+        if trace:
+            steps_by_grid = collections.defaultdict(list)
+            for r in csv.DictReader(open(trace)):
+                if "step_lean" in r["Kernel_Name"] or "step_kernel" in r["Kernel_Name"]:
+                    steps_by_grid[(short(r["Kernel_Name"]), int(r["Grid_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            lines += ["### step launches by grid (a step = two launches side by side on the context's two streams)", "",
+                      "| kernel | grid (threads) | slots per launch | calls | average us | median us |", "|---|---|---|---|---|---|"]
+            for key in sorted(steps_by_grid, key=lambda k: -sum(steps_by_grid[k])):
+                v = sorted(steps_by_grid[key])
+                if len(v) < 8:
+                    continue
+                lines.append("| `%s` | %d | %d | %d | %.2f | %.2f |" % (key[0], key[1], key[1], len(v), sum(v) / len(v) / 1e3, v[len(v) // 2] / 1e3))
+            lines.append("")
+
     # PMC passes
     # Per kernel and counter the MEDIAN over its dispatches: a kernel name can carry launches of different scenes (the 4K kernel also
     # runs one small frame in the bench's exchange check) and a mean over them describes none of them.
