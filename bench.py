@@ -1519,6 +1519,34 @@ def main():
                     "lit_frame_alone_same_loop_device_clock": round(lit5_dev, 4), "timed_frames": frames5,
                     "lit_mpixels_per_s_with_particles": round(w * h / (whole5 * 1e-3) / 1e6, 2)}
                 del Q5, q5
+                if group is None and world == 1:
+                    # (r06) The same frame with the two phases SIDE BY SIDE: ParticleSystem.Update and RenderLighting of a frame share nothing
+                    # (the particles light nothing here), the step is HBM-bound and the cone trace issue-bound, so a host that keeps the
+                    # particle system on a SIBLING context (ilm_ctx_create_sibling: streams of its own) lets the step run under the lit
+                    # frame.  Same steps, same frames, same bits (each context's work is ordered as before); wall clock over the block,
+                    # both contexts drained.  Reported BESIDE the one-stream figure.
+                    import gc as gc5_
+                    sib5 = abi.Handle(0)
+                    native.check(native.lib().ilm_ctx_create_sibling(abi.Handle(int(ctx.Handle)), C_.byref(sib5)))
+                    ctx5 = H.DeviceContext.FromHandle(sib5.value)
+                    Q5b = build_particle_system(H, ctx5, scenes, abi, 1024, n5, rank, with_spawner=False, replicate_cfg4_images=True)
+                    for f5 in range(3):
+                        Q5b["tp"].Advance(1.0 / 60.0); Q5b["ps"].Update(f5)
+                        r.RenderLighting(1.0, row_begin, row_end, False)
+                    ctx5.Sync(); ctx.Sync()
+                    t5 = time.perf_counter()
+                    for f5 in range(frames5):
+                        Q5b["tp"].Advance(1.0 / 60.0); Q5b["ps"].Update(3 + f5)
+                        r.RenderLighting(1.0, row_begin, row_end, False)
+                    ctx5.Sync(); ctx.Sync()
+                    side5 = (time.perf_counter() - t5) / frames5 * 1e3
+                    lighting[name]["with_particles"]["step_beside_the_lit_frame"] = {
+                        "frame_ms": round(side5, 4), "vs_one_stream": round(side5 / whole5, 4), "lit_mpixels_per_s": round(w * h / (side5 * 1e-3) / 1e6, 2), "timed_frames": frames5,
+                        "how": "the particle system lives on a sibling context (ilm_ctx_create_sibling: its own streams): the 16 M-particle step runs under the lit frame; wall clock over the block, both contexts drained"}
+                    del Q5b
+                    gc5_.collect()
+                    if native.lib().ilm_ctx_destroy(sib5) != 0:
+                        print("bench.py: the particle sibling context still has live objects: %s" % native.lib().ilm_last_error().decode(), file=sys.stderr)
             if rank == 0 and world == 1 and not args.no_cpu_baseline:
                 # the oracle on a bounded band of rows of the same frame (same generated field, same packed lights), on the host cores
                 from oracle import oracle as orc

@@ -557,13 +557,25 @@ int32_t gather_lightmap(GroupLightmap* m, int32_t gather) {
         if (gather != ILM_GATHER_PEER && gather != ILM_GATHER_RCCL) return api_fail(ILM_ERR_INVALID_ARGUMENT, "ILM_GATHER_ASYNC goes with ILM_GATHER_PEER or ILM_GATHER_RCCL");
         const int32_t rc = ensure_exchange_streams(g);
         if (rc != ILM_OK) return rc;
-        if (m->xdone.empty())
-            for (int i = 0; i < g->n_local; i++) {
-                HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
+        if (m->xdone.size() != (size_t)g->n_local) {
+            // (built aside and installed whole, like the exchange streams: never a table shorter than n_local)
+            std::vector<hipEvent_t> done;
+            hipError_t err = hipSuccess;
+            for (int i = 0; i < g->n_local && err == hipSuccess; i++) {
                 hipEvent_t e = nullptr;
-                HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-                m->xdone.push_back(e); m->xpending.push_back(false);
+                err = hipSetDevice(g->devices[(size_t)i]);
+                if (err == hipSuccess) err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+                done.push_back(e);
             }
+            if (err != hipSuccess) {
+                for (size_t i = 0; i < done.size(); i++)
+                    if (done[i]) { (void)hipSetDevice(g->devices[i]); (void)hipEventDestroy(done[i]); }
+                (void)hipGetLastError();
+                return api_fail((int32_t)err, "exchange events of the group lightmap: %s", hipGetErrorString(err));
+            }
+            m->xdone.swap(done);
+            m->xpending.assign((size_t)g->n_local, false);
+        }
         for (int i = 0; i < g->n_local; i++) {
             HIP_TRY(hipSetDevice(g->devices[(size_t)i]));
             HIP_TRY(hipEventRecord(g->xfork[(size_t)i], g->stream((size_t)i)));

@@ -31,7 +31,13 @@ bad_float, floor_needed, elements_compared = [], 0, 0
 bad_gbuffer, gbuffer_texels = [], 0
 worst_where = None
 bad_collision, collision_steps, collision_elements, collided_total = [], 0, 0, 0
+bad_plight, particle_light_scenes, particle_light_pairs, worst_pl = [], 0, 0, 0.0
+import time as _time
+_t0, _budget = _time.time(), float(os.environ.get("ILM_FUZZ_SECONDS", "0") or 0)      # (a sweep under a time limit: stop drawing seeds, report what was done)
 for seed in range(first, first + count):
+    if _budget > 0 and _time.time() - _t0 > _budget:
+        count = seed - first
+        break
     rng = np.random.default_rng(seed)
     # ---- lighting: random field, lights, G-buffer normals, both SDF formats -------------------------------------------
     L_ = fuzz_scenes.draw_lighting(rng, seed)          # (tests/fuzz_scenes.py: the seed's draws, shared with tests/test_fuzz_regressions_gpu.py)
@@ -90,6 +96,52 @@ for seed in range(first, first + count):
                 x.close()
             g.close()
     want, ost = oracle.render_sphere_lights(lights, env, dfu, None, oracle.make_texture(atlas, fmt), (0.05, 0.05, 0.05, 1.0), w, h, 0, h, want_stats=True)
+    # (r06) every 4th scene: PARTICLE lights over the same field (ParticleLight.fx:16-118) -- 1-3 chunks of 16^2 .. 64^2 slots, some of them
+    # crowded onto one spot so that a tile's list overflows a batch (lighting.hip, BIG), random template (radius, ramp, falloff, AO,
+    # specular, shadows), quad counts that cut chunks short.  The plain launch (cull, batches of 4 096) must equal the instrumented one
+    # (no cull, batches of 1 024) bit for bit; counts and floats against the oracle.
+    if seed % 4 == 1:
+        from tests import lights_common as lc
+        prng = np.random.default_rng(seed + 777)
+        pcs = int(prng.choice([16, 32, 64])); pn = pcs * pcs
+        pchunks, pquads = [], []
+        for c in range(int(prng.integers(1, 4))):
+            crowd = bool(prng.integers(0, 2))
+            cx_, cy_ = float(prng.uniform(0, w)), float(prng.uniform(0, h))
+            lo = (cx_ - 20, cy_ - 15, 1) if crowd else (-10, -10, 1)
+            hi = (cx_ + 20, cy_ + 15, 25) if crowd else (w + 10, h + 10, 40)
+            ppos, pvel, pattr = scenes.make_particles(seed * 7 + c, pn, pos_lo=lo, pos_hi=hi, dead_fraction=float(prng.uniform(0, 0.5)))
+            prc = scenes.uniform(seed * 11 + c, (pn, 4), 0.0, 1.0).astype(np.float32)
+            prc[:, :3] *= prc[:, 3:4]
+            prc[scenes.uniform(seed * 13 + c, (pn,)) < 0.1, 3] = 0.0
+            pchunks.append([ppos, pvel, pattr, prc, np.zeros((pn, 4), np.float32)])
+            pquads.append(int(prng.integers(1, pn + 1)) if prng.integers(0, 3) == 0 else pn)
+        pparams = lc.particle_light_params(float(prng.uniform(1, 6)), float(prng.uniform(4, 40)), (1.0, 0.9, 0.8, float(prng.uniform(0.02, 1.0))),
+                                           casts_shadows=bool(prng.integers(0, 4) != 0), ao_radius=float(prng.choice([0.0, 5.0])), ao_opacity=float(prng.uniform(0, 1)),
+                                           falloff_y=float(prng.choice([1.0, 0.6, 2.0])), spec=tuple(prng.uniform(0, 0.4, 3)) if prng.integers(0, 3) == 0 else (0, 0, 0),
+                                           spec_power=float(prng.uniform(1, 4)), ramp_mode=int(prng.integers(0, 3)))
+        peng = native.Engine(ctx, pcs, scenes.randomness_table(7)); psys = native.System(peng)
+        for c, planes in enumerate(pchunks):
+            psys.add_chunk()
+            psys.upload(c, P, planes[0]); psys.upload(c, RC, planes[3])
+        pframes, pst = [], None
+        for want_stats in (True, False):
+            plm = native.Lightmap(ctx, w, h, abi.LIGHTMAP_FLOAT4)
+            native.render_sphere_lights(ctx, None, env, dfu, None, sdf, (0.05, 0.06, 0.07, 1.0), plm)
+            r_ = native.render_particle_lights(ctx, psys, pparams, env, dfu, None, sdf, plm, quad_counts=pquads, want_stats=want_stats)
+            if want_stats: pst = r_
+            pframes.append(plm.download()); plm.close()
+        pwant = np.empty((h, w, 4), np.float32); pwant[...] = np.asarray((0.05, 0.06, 0.07, 1.0), np.float32)
+        post = oracle.render_particle_lights(pchunks, pquads, pparams, env, dfu, None, oracle.make_texture(atlas, fmt), pwant, want_stats=True)
+        particle_light_scenes += 1
+        particle_light_pairs += int(post.PixelLightPairs)
+        pe = float((np.abs(pframes[0] - pwant) / np.maximum(np.abs(pwant), 1.0)).max())
+        worst_pl = max(worst_pl, pe)
+        if not np.array_equal(pframes[0].view(np.uint32), pframes[1].view(np.uint32)):
+            bad_plight.append((seed, "the plain frame differs from the instrumented one"))
+        if (pst.SdfSamples, pst.PixelLightPairs, pst.TracedPairs) != (post.SdfSamples, post.PixelLightPairs, post.TracedPairs) or pe > 1e-4:
+            bad_plight.append((seed, (pst.SdfSamples, pst.PixelLightPairs, pst.TracedPairs), (post.SdfSamples, post.PixelLightPairs, post.TracedPairs), pe))
+        psys.close(); peng.close()
     lm.close(); sdf.close()
     e = float((np.abs(got - want) / np.maximum(np.abs(want), 1.0)).max())
     worst_l = max(worst_l, e)
@@ -340,6 +392,9 @@ print("rasteriser: %d scenes out of bounds; most edge pixels that flipped in one
 for b in bad_raster[:10]: print("   ", b)
 print("lighting: %d scenes with differing statistics or > 1e-4 error; worst relative error %.3g (%d of the scenes also through a group / a sibling context: peer, store, asynchronous exchange)" % (len(bad_light), worst_l, group_scenes))
 for b in bad_light[:10]: print("   ", b)
+print("particle lights: %d scenes with differing statistics, > 1e-4 error or a plain frame that is not the instrumented one, of %d (%.1f M pixel.light pairs); worst relative error %.3g"
+      % (len(bad_plight), particle_light_scenes, particle_light_pairs / 1e6, worst_pl))
+for b in bad_plight[:10]: print("   ", b)
 print("collision update: %d problems in %d steps (%.1f M elements; %d particles bounced or were redirected); liveness and life bit-identical, floats by the suite's criterion"
       % (len(bad_collision), collision_steps, collision_elements / 1e6, collided_total))
 for b in bad_collision[:10]: print("   ", b)
@@ -350,6 +405,6 @@ print("particle floats: %d failures of the suite's criterion (1e-4 relative + 1e
       "%d elements (%.2g of all) are outside a PURE 1e-4 relative bound, i.e. needed the absolute floor" %
       (len(bad_float), elements_compared / 1e6, floor_needed, floor_needed / max(elements_compared, 1)))
 for b in bad_float[:10]: print("   ", b)
-failed = bool(bad_field or bad_raster or bad_light or bad_step or bad_float or bad_gbuffer or bad_collision)
+failed = bool(bad_field or bad_raster or bad_light or bad_step or bad_float or bad_gbuffer or bad_collision or bad_plight)
 print("FUZZ %s" % ("FAILED" if failed else "PASSED"))
 sys.exit(1 if failed else 0)
