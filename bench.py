@@ -1629,11 +1629,13 @@ def main():
             # (r06: the row follows seconds of CPU-only work -- the lighting cpu_baseline legs -- and three frames after one warm-up frame were
             # timed on a device still at its idle clocks: 1.30-1.34 ms where the same library gives 1.04.  Warm for >= 40 frames, then the
             # median of seven blocks of ten.)
-            for _ in range(40):
+            # (under the profiling flags -- --light-ms 0 -- two warm-up frames and one block of three: every frame here is also an ambient-only
+            # launch of the SPHERE-light kernel, and 110 of those made it the median dispatch of that kernel in the PMC summary)
+            for _ in range(40 if args.light_ms > 0 else 2):
                 r.RenderLighting(1.0, 0, -1, False)
             ctx.Sync()
-            frames, pl_blocks = 10, []
-            for _ in range(7):
+            frames, pl_blocks = (10 if args.light_ms > 0 else 3), []
+            for _ in range(7 if args.light_ms > 0 else 1):
                 ctx.TimerStart()
                 for _ in range(frames):
                     r.RenderLighting(1.0, 0, -1, False)

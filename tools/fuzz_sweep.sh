@@ -1,5 +1,6 @@
 #!/bin/bash
-# Run ON THE GPU BOX: tools/fuzz_parity.py over fresh seeds in parallel processes (the sweep is bound by the CPU oracle).
+# Run ON THE GPU BOX: tools/fuzz_parity.py over fresh seeds in parallel processes (the sweep is bound by the CPU oracle).  AT MOST 8 processes:
+# from 16 per GPU on, kernels now and then read stale memory behind a completed copy (profiles/r06_memcpy_order_under_oversubscription.txt).
 #   tools/fuzz_sweep.sh <first_seed> <seeds_per_process> <processes> <tag> [seconds per process: stop drawing seeds after that]   ->  gpurun_out/fuzz_<tag>/p<i>.txt + summary.txt
 set -u
 cd "$(cd "$(dirname "$0")/.." && pwd)"
@@ -14,6 +15,7 @@ t1=$(date +%s)
 {
   echo "tools/fuzz_sweep.sh $first $per $procs: seeds $first..$((first + per * procs - 1)) in $procs processes, $((t1 - t0)) s, library $(sha256sum illuminant_amd/lib/libilluminant_hip.so | cut -c1-16), git $(cat .git_head 2>/dev/null)"
   grep -h "FUZZ" "$out"/p*.txt | sort | uniq -c
+  [ "$procs" -gt 8 ] && echo "NOTE: with more than 8 processes on one GPU kernels now and then read stale memory behind a completed copy (profiles/r06_memcpy_order_under_oversubscription.txt): re-run reported seeds alone"
   echo "seeds done: $(grep -h "^seeds " "$out"/p*.txt | awk '{split($2, a, "[.][.]"); n += a[2] - a[1] + 1} END {print n}')"
   python3 - "$out" <<'PY'
 import glob, re, sys
