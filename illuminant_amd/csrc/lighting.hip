@@ -18,7 +18,6 @@
 // The cone trace is a chain of dependent SDF fetches: latency-bound, served by
 // L1/L2/MALL (the 25 MB atlas is cache resident); no MFMA (no dense contraction).
 #include "internal.hpp"
-#include <type_traits>
 
 namespace ilm {
 
@@ -501,12 +500,7 @@ extern "C" int ilm_experiment_light_trace(unsigned long long* out, int n) {
 // the wide form's extra code costs the sphere-light frames 1-2 % through register allocation, so it is its own instantiation.
 template <int FMT, bool STATS, bool WIDE_BIN>
 __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_lights_kernel(const LightLaunch a, const LightRec* __restrict__ recs, int tiles_x, int tiles_y, int tile_count) {
-    // (the wide binning with the circle cull -- BIG, below -- keeps 32-bit entries: 12 index bits, 4 cull bits, bit 16 = the tile lies wholly
-    // inside the footprint; 768 of them are 1 KB more than the 1 024 16-bit ones and still leave eight workgroups per CU their LDS)
-    constexpr bool kWideEntries = !STATS && (kLightTile == 16) && WIDE_BIN && (ILM_LIGHT_CIRCLE_CULL_WIDE != 0);
-    constexpr int kListEntries = kWideEntries ? 768 : kListCapacity;
-    using ListEntry = typename std::conditional<kWideEntries, uint32_t, uint16_t>::type;
-    __shared__ ListEntry list[kListEntries];
+    __shared__ uint16_t list[kListCapacity];
     __shared__ int list_count;
     __shared__ int bin_count[2][kLightThreads / 64];
     __shared__ SliceEntry slice_table[kMaxTableSlices];
@@ -631,16 +625,13 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
         }
         return mask;
     };
-    // Entry layout of the LDS list: the light's index within the batch, the four cull bits above it, then the bit "the tile lies wholly
-    // inside the footprint" (bit 15 of the 16-bit entries, 16 of the 32-bit ones).  The wide binning with the cull (r06, BIG): a batch holds
-    // up to 4 096 lights -- 12 index bits -- and ends early when another round of 256 lights might not fit the list: 4 096 particle lights
-    // were four batches of 1 024, four lists of ten entries with the tile's waves meeting at the end of each; one list of forty, one
-    // meeting: 0.991 -> 0.978 ms per frame with 16-bit entries that had no room for the whole-tile bit (+9 % vector instructions: every
-    // entry took the per-pixel footprint test), the same bits (tools/particle_lights_ab.py, profiles/r06_lane_queue_ab.txt).
+    // Entry layout of the LDS list: the light's index within the batch, the four cull bits above it, bit 15 = the tile lies wholly inside
+    // the footprint.  The wide binning with the cull (r06, BIG): a batch holds up to 4 096 lights -- 12 index bits, the cull bits above,
+    // no bit 15 (the walk always takes the per-pixel footprint test) -- and ends early when another round of 256 lights might not fit the
+    // list: 4 096 particle lights were four batches of 1 024, four lists of ten entries with the tile's waves meeting at the end of each;
+    // one list of forty, one meeting: 0.991 -> 0.978 ms per frame, the same bits (tools/particle_lights_ab.py, profiles/r06_lane_queue_ab.txt).
     constexpr bool BIG = WIDE_BIN && kCircleCull;
-    static_assert(BIG == kWideEntries, "the 32-bit entries belong to the batches of 4 096");
     constexpr int kCullShift = BIG ? 12 : 10, kIndexMask = (1 << kCullShift) - 1;
-    constexpr uint32_t kWholeBit = BIG ? 0x10000u : 0x8000u;
     const int cull_bit = __builtin_amdgcn_readfirstlane(kCullShift + wave);      // (uniform by construction; said so, so that the walk's test is scalar)
 
     // What the lights are added to: the clear colour, or the lightmap's contents (additive blend onto an earlier pass of the same frame:
@@ -712,11 +703,11 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
     };
     int part_bound = blend_fp16 ? 0x7FFFFFFF : (int)(((long long)light_count * (part + 1)) / kLightParts);   // first light of the next part
 
-    for (int batch = light_lo, batch_step = kListEntries; batch < light_hi; batch += batch_step) {
+    for (int batch = light_lo, batch_step = kListCapacity; batch < light_hi; batch += batch_step) {
 #ifdef ILM_EXP_NO_BIN              // EXPERIMENT (timing of the prologue only): no light is looked at
         int batch_n = 0;
 #else
-        int batch_n = min(BIG ? 4096 : kListEntries, light_hi - batch);
+        int batch_n = min(BIG ? 4096 : kListCapacity, light_hi - batch);
 #endif
         if constexpr (WIDE_BIN) {
         __syncthreads();                                        // the previous batch's list has been walked
@@ -727,7 +718,7 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
             const float tminy = (float)ty0 + 0.5f, tmaxy = (float)(ty0 + kTile - 1) + 0.5f;
             constexpr int kWaves = kLightThreads / 64;
             int base = 0, l0 = 0;
-            for (; l0 < batch_n && (!BIG || base + kLightThreads <= kListEntries); l0 += kLightThreads) {
+            for (; l0 < batch_n && (!BIG || base + kLightThreads <= kListCapacity); l0 += kLightThreads) {
                 const int li = l0 + (int)threadIdx.x;
                 bool hit = false, whole = false;
                 if (li < batch_n) {
@@ -747,7 +738,7 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
 #pragma unroll
                 for (int w = 0; w < kWaves; w++) { const int c = bin_count[round][w]; total += c; if (w < wave) before += c; }
                 if (hit)
-                    list[base + before + __popcll(m & ((1ull << lane) - 1ull))] = (ListEntry)((uint32_t)li | (whole ? kWholeBit : 0u));
+                    list[base + before + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(li | ((whole && !BIG) ? 0x8000 : 0));
                 base += total;
             }
             // (the batch ends where the binning stopped: `base` is the same in every thread, so is l0)
@@ -777,7 +768,7 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
                 }
                 const unsigned long long m = __ballot(hit);
                 if (hit)
-                    list[base + __popcll(m & ((1ull << lane) - 1ull))] = (ListEntry)((uint32_t)li | (whole ? kWholeBit : 0u));
+                    list[base + __popcll(m & ((1ull << lane) - 1ull))] = (uint16_t)(li | (whole ? 0x8000 : 0));
                 base += __popcll(m);
             }
             if (lane == 0) list_count = base;
@@ -791,7 +782,7 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
             // tile, of which a few dozen are listed: computing the bits there cost more than the skipped entries gave back)
             for (int t = (int)threadIdx.x; t < n; t += kLightThreads) {
                 const int e = (int)list[t];
-                list[t] = (ListEntry)(e | (culled_waves(recs[batch + (e & kIndexMask)]) << kCullShift));
+                list[t] = (uint16_t)(e | (culled_waves(recs[batch + (e & kIndexMask)]) << kCullShift));
             }
             __syncthreads();
         }
@@ -820,7 +811,7 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
             const LightRec& L = recs[batch + li];
 
             bool covered = in_image;
-            if ((entry & (int)kWholeBit) == 0) {
+            if (BIG || (entry & 0x8000) == 0) {
                 // raster footprint: pixel centre inside the cross-shaped quad
                 // (all eight bounds fetched together and combined without short-circuits: as written with && / || the compiler issued
                 // eight dependent scalar loads, each behind its own wait and branch)
