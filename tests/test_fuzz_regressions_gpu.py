@@ -1,14 +1,15 @@
 """The particle steps of the 24 000-seed sweeps that fell outside the suite's own float criterion -- r04's two
 (profiles/r04_fuzz_24000_seeds_final_kernels.txt: seeds 1222260 and 1223153, V.z of one newborn particle each, 7e-4 and 1.7e-4 relative) and
 r05's one (profiles/r05_fuzz_24000_seeds_head.txt: seed 1405703, V.y of a newborn particle, 9e-4 relative; d^2 - radius = 0.19 of d^2 = 288),
-r06's one (profiles/r06_fuzz_33381_seeds_6500000.txt: seed 6533961, V.y and V.z of a newborn particle, 1.1e-2 and 2e-4 relative; the same family) --
+r06's two (profiles/r06_fuzz_33381_seeds_6500000.txt: seed 6533961, V.y and V.z of a newborn particle, 1.1e-2 and 2e-4 relative;
+profiles/r06_fuzz_32000_seeds_6700000_8_processes.txt: seed 6726686, V.x, 2.5e-4 relative, d^2 - radius = 1.6 of d^2 = 146; the same family) --
 as named tests that assert what is actually true of them:
 
   * the step's integers are exact: live counts, the liveness of every slot, every life value bit for bit;
   * every float of the step except that one velocity component meets the criterion (1e-4 relative + 1e-5 of the component's scale);
-  * the newborn particle's POSITION is within 2 ulp of the oracle's (OCML's sin / cos / acos against glibc's in the spawn formula,
-    SpawnerCommon.fxh:47-57);
-  * its velocity lies inside the envelope the ORACLE ITSELF produces when its own post-spawn position is moved by +-2 ulp per coordinate:
+  * the newborn particle's POSITION and velocity after spawn + Update alone are within 2 ulp of the oracle's (3 for the last seed's V.z:
+    OCML's sin / cos / acos against glibc's in the spawn formula, SpawnerCommon.fxh:47-57);
+  * its velocity lies inside the envelope the ORACLE ITSELF produces when its own post-spawn position is moved by +-2 (3) ulp per coordinate:
     the step has an attractor of the physical type whose radius all but cancels the particle's squared distance
     (Gravity.fx:44-47: strength / max(d^2 - radius, 0.001)), so the reference's own formula amplifies the last bit of a coordinate;
   * from the oracle's OWN post-spawn state (same bits in) the shipped kernel meets the criterion on every element, and the
@@ -35,11 +36,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 EXACT_LIB = os.path.join(ROOT, "illuminant_amd", "lib", "libilluminant_hip_gravity_exact.so")
 
 # (seed, slot of chunk 1, velocity component(s) -- the first is the one the cancellation amplifies most --, the physical attractor in front of
-# the cancellation: position, radius, strength)
-CASES = [(1222260, 4913, (2,), (154.30, 147.45, 0.85), 280.08, 150.59),
-         (1223153, 2180, (2,), (120.94, 116.24, 12.75), 188.54, -12.33),
-         (1405703, 12779, (1,), (67.33, 170.43, 16.95), 287.52, 43.68),
-         (6533961, 2231, (1, 2, 0), (153.23, 120.27, 4.55), 231.17, -38.28)]
+# the cancellation: position, radius, strength, and how many ulp the spawn formula + Update alone leave between device and oracle: 2, or
+# 3 for the last seed's V.z)
+CASES = [(1222260, 4913, (2,), (154.30, 147.45, 0.85), 280.08, 150.59, 2),
+         (1223153, 2180, (2,), (120.94, 116.24, 12.75), 188.54, -12.33, 2),
+         (1405703, 12779, (1,), (67.33, 170.43, 16.95), 287.52, 43.68, 2),
+         (6533961, 2231, (1, 2, 0), (153.23, 120.27, 4.55), 231.17, -38.28, 2),
+         (6726686, 1194, (0,), (106.13, 145.52, 1.90), 144.15, -23.01, 3)]
 
 
 def outside_criterion(got, want, plane):
@@ -50,8 +53,8 @@ def outside_criterion(got, want, plane):
     return ~(np.abs(g - w) <= atol * scale[None, :] + RTOL * np.abs(w)) & ~(np.isnan(g) & np.isnan(w))
 
 
-@pytest.mark.parametrize("seed,slot,comps,apos,aradius,astrength", CASES)
-def test_fuzz_miss_is_an_ulp_of_the_spawn_formula_in_front_of_the_references_own_cancellation(ctx, oracle, seed, slot, comps, apos, aradius, astrength):
+@pytest.mark.parametrize("seed,slot,comps,apos,aradius,astrength,ulps", CASES)
+def test_fuzz_miss_is_an_ulp_of_the_spawn_formula_in_front_of_the_references_own_cancellation(ctx, oracle, seed, slot, comps, apos, aradius, astrength, ulps):
     comp = comps[0]
     cs, rnd, chunks, d = fuzz_scenes.particle_step_of_seed(seed)
     # the replay IS the step the sweep reported: its spawn range holds the slot, its op list starts with a Gravity that has that attractor
@@ -90,12 +93,12 @@ def test_fuzz_miss_is_an_ulp_of_the_spawn_formula_in_front_of_the_references_own
     oracle.step(want_plain, cs, rnd, d_plain)
     for plane in (0, 1):
         gp, wp = got_plain[1][plane][slot, :3], want_plain[1][plane][slot, :3]
-        assert (np.abs(gp.astype(np.float64) - wp.astype(np.float64)) <= 2.0 * np.spacing(np.abs(wp)).astype(np.float64)).all(), (plane, gp, wp)
+        assert (np.abs(gp.astype(np.float64) - wp.astype(np.float64)) <= float(ulps) * np.spacing(np.abs(wp)).astype(np.float64)).all(), (plane, gp, wp)
     # (in the full step its position then carries the velocity's difference x dt on top of that)
     dt = float(d.System.GlobalSettings.x) / 1000.0
     gp, wp = got[1][0][slot, :3].astype(np.float64), want[1][0][slot, :3].astype(np.float64)
     dv = np.abs(got[1][1][slot, :3].astype(np.float64) - want[1][1][slot, :3].astype(np.float64))
-    assert (np.abs(gp - wp) <= 3.0 * np.spacing(np.abs(want[1][0][slot, :3])).astype(np.float64) + dv * dt * 1.01).all(), (gp, wp, dv * dt)
+    assert (np.abs(gp - wp) <= (ulps + 1.0) * np.spacing(np.abs(want[1][0][slot, :3])).astype(np.float64) + dv * dt * 1.01).all(), (gp, wp, dv * dt)
     # ... in front of the cancellation the note describes: d^2 - radius is a small fraction of d^2
     cs_, rnd_, spawned, d0 = vw.post_spawn_state(seed)
     p0 = spawned[1][0][slot, :3].astype(np.float64)
@@ -103,7 +106,7 @@ def test_fuzz_miss_is_an_ulp_of_the_spawn_formula_in_front_of_the_references_own
     assert 0.0 < d2 - aradius < 0.12 * d2, (d2, aradius)
     # ... and its velocity inside the envelope of the oracle's own answers for +-2 ulp of its post-spawn position
     lo, hi = np.full(3, np.inf), np.full(3, -np.inf)
-    for signs in itertools.product((-2, -1, 0, 1, 2), repeat=3):
+    for signs in itertools.product(tuple(range(-ulps, ulps + 1)), repeat=3):
         trial = [[a.copy() for a in c] for c in spawned]
         for axis, s in enumerate(signs):
             trial[1][0][slot, axis] += np.float32(s) * np.spacing(np.abs(trial[1][0][slot, axis]))
