@@ -26,6 +26,53 @@ def rel_err(got, want):
 
 
 bad_light, bad_step, worst_l, worst_s = [], [], 0.0, 0.0
+explained = []          # (seed, slot, components): float misses that ARE the reference's own cancellation (see cancellation_explains)
+
+
+def cancellation_explains(seed, cs, rnd, d, got, failing):
+    """r06: is every float of this seed's step that fell outside the criterion the known family -- velocity / position of a particle BORN in
+    this step, beside a physical attractor of the step's Gravity whose radius all but cancels the particle's squared distance
+    (Gravity.fx:44-47: strength / max(d^2 - radius, 0.001)), with the device's velocity INSIDE the envelope of the oracle's own answers
+    for +-3 ulp of its own post-spawn position (the spawn formula's sin / cos / acos differ by that much between OCML and glibc)?
+    The same facts tests/test_fuzz_regressions_gpu.py asserts of the named seeds.  failing: {(chunk, plane, slot, component)}."""
+    import copy, itertools
+    from tests import _variant_worker as vw
+    if not failing or d.SpawnCount != 1 or d.OpCount < 1 or d.Ops[0].Type != abi.OP_GRAVITY:
+        return None
+    sp = d.Spawns[0].Params
+    slots = {f[2] for f in failing}
+    if len(slots) != 1 or any(f[0] != 1 or f[1] not in (0, 1, 4) or f[3] > 2 for f in failing):      # one slot of chunk 1: position, velocity (and the render data made of it)
+        return None
+    slot = slots.pop()
+    if not (sp.ChunkSizeAndIndices[1] <= slot <= sp.ChunkSizeAndIndices[2]):
+        return None
+    cs_, rnd_, spawned, d0 = vw.post_spawn_state(seed)
+    p0 = spawned[1][0][slot, :3].astype(np.float64)
+    g = d.Ops[0].u.Gravity
+    near = False
+    for k_ in range(int(g.AttractorCount)):
+        ar = g.AttractorRadiusesAndStrengths[k_]
+        if ar[2] < 0.5:
+            d2 = float(((np.array(list(g.AttractorPositions[k_])[:3], np.float64) - p0) ** 2).sum())
+            near = near or (0.0 < d2 - float(ar[0]) < 0.12 * d2)
+    if not near:
+        return None
+    lo, hi = np.full(3, np.inf), np.full(3, -np.inf)
+    for signs in itertools.product(range(-3, 4), repeat=3):
+        trial = [[a.copy() for a in c] for c in spawned]
+        for axis, sg in enumerate(signs):
+            trial[1][0][slot, axis] += np.float32(sg) * np.spacing(np.abs(trial[1][0][slot, axis]))
+        one = [trial[1]]
+        d1 = copy.copy(d0); d1.FirstChunk, d1.ChunkCount = 0, -1
+        oracle.step(one, cs, rnd, d1)
+        v = one[0][1][slot, :3].astype(np.float64)
+        lo, hi = np.minimum(lo, v), np.maximum(hi, v)
+    gv = got[1][1][slot, :3].astype(np.float64)
+    slack = 1e-4 * np.maximum(np.abs(lo), np.abs(hi)) + 1e-6
+    if not ((gv >= lo - slack) & (gv <= hi + slack)).all():
+        return None
+    return (seed, int(slot), sorted({(f[1], f[3]) for f in failing}))
+
 group_scenes = 0
 bad_float, floor_needed, elements_compared = [], 0, 0
 bad_gbuffer, gbuffer_texels = [], 0
@@ -199,6 +246,7 @@ for seed in range(first, first + count):
     want_counts = oracle.step(chunks, cs, rnd, d, want_counts=True)
     got_counts = sysm.step_counts()
     problem = not np.array_equal(got_counts, want_counts)
+    seed_failing, seed_bad_float, seed_got = set(), [], [[None] * 5, [None] * 5]
     for c in range(2):
         gp = sysm.download(c, P)
         problem = problem or not np.array_equal(gp[:, 3] > 0, chunks[c][0][:, 3] > 0)
@@ -207,7 +255,8 @@ for seed in range(first, first + count):
             if not ((gp[:, 3].view(np.uint32) == chunks[c][0][:, 3].view(np.uint32)) | nan_both).all():
                 bad_float.append((seed, c, "life not bit-identical"))
         for kk, pl in enumerate((P, V, A, RC, RD)):
-            g = sysm.download(c, pl).astype(np.float64); wv = chunks[c][kk].astype(np.float64)
+            g32 = sysm.download(c, pl); seed_got[c][kk] = g32
+            g = g32.astype(np.float64); wv = chunks[c][kk].astype(np.float64)
             # the suite's criterion (tests/util.py assert_close): per-component scale
             comp_scale = np.where(np.isfinite(wv), np.abs(wv), 0.0).max(axis=0)
             both_nan = np.isnan(g) & np.isnan(wv)
@@ -217,8 +266,10 @@ for seed in range(first, first + count):
             floor_needed += int((~(err_abs <= 1e-4 * np.abs(wv)) & ~both_nan).sum())
             if outside.any():
                 i, j = np.argwhere(outside)[0]
-                bad_float.append((seed, c, "plane %d slot %d component %d: got %.9g want %.9g (component scale %.4g); %d element(s)"
-                                  % (kk, i, j, g[i, j], wv[i, j], comp_scale[j], int(outside.sum()))))
+                seed_bad_float.append((seed, c, "plane %d slot %d component %d: got %.9g want %.9g (component scale %.4g); %d element(s)"
+                                       % (kk, i, j, g[i, j], wv[i, j], comp_scale[j], int(outside.sum()))))
+                for (ii, jj) in np.argwhere(outside)[:64]:
+                    seed_failing.add((c, kk, int(ii), int(jj)))
             ok = np.isfinite(wv) & np.isfinite(g)
             if ok.any():
                 scale = max(1.0, float(np.abs(wv[ok]).max()))
@@ -258,6 +309,17 @@ for seed in range(first, first + count):
                         sys0.close()
     if problem:
         bad_step.append((seed, list(got_counts), list(want_counts)))
+    if seed_bad_float:
+        why = None
+        if not problem and len(seed_failing) < 64 and not any("life" in str(b[2]) for b in bad_float if b[0] == seed):
+            try:
+                why = cancellation_explains(seed, cs, rnd, d, [[np.asarray(a) for a in cc] for cc in seed_got], seed_failing)
+            except Exception as e_:      # noqa: BLE001 -- an analysis that cannot run explains nothing
+                why = None
+        if why is not None:
+            explained.append(why)
+        else:
+            bad_float.extend(seed_bad_float)
     sysm.close(); eng.close()
 # ---- distance-field generation (exact culling!) and the particle rasteriser, every 4th seed (the oracle side is slower) ------------------
 bad_field, bad_raster, field_texels, raster_worst, field_volume_scenes = [], [], 0, 0, 0
@@ -405,6 +467,9 @@ print("particle floats: %d failures of the suite's criterion (1e-4 relative + 1e
       "%d elements (%.2g of all) are outside a PURE 1e-4 relative bound, i.e. needed the absolute floor" %
       (len(bad_float), elements_compared / 1e6, floor_needed, floor_needed / max(elements_compared, 1)))
 for b in bad_float[:10]: print("   ", b)
+print("explained by the reference's own cancellation (a newborn particle beside a physical attractor with 0 < d^2 - radius < 0.12 d^2, the device's velocity inside "
+      "the oracle's envelope for +-3 ulp of its own post-spawn position; not failures): %d" % len(explained))
+for b in explained[:10]: print("   ", b)
 failed = bool(bad_field or bad_raster or bad_light or bad_step or bad_float or bad_gbuffer or bad_collision or bad_plight)
 print("FUZZ %s" % ("FAILED" if failed else "PASSED"))
 sys.exit(1 if failed else 0)

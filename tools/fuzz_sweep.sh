@@ -36,6 +36,8 @@ for f in sorted(glob.glob(sys.argv[1] + "/p*.txt")):
     if m: problems += int(m.group(1)); tot["particle elements (M)"] += float(m.group(2)); tot["particle elements that needed the absolute floor"] += int(m.group(3))
     m = re.search(r"particle lights: (\d+) scenes .*? of (\d+) \(([\d.]+) M pixel", t)
     if m: problems += int(m.group(1)); tot["particle-light scenes"] = tot.get("particle-light scenes", 0) + int(m.group(2)); tot["particle-light pairs (M)"] = tot.get("particle-light pairs (M)", 0.0) + float(m.group(3))
+    m = re.search(r"not failures\): (\d+)", t)
+    if m: tot["float misses explained by the reference's own cancellation"] = tot.get("float misses explained by the reference's own cancellation", 0) + int(m.group(1))
     m = re.search(r"field generation: (\d+) scenes with differing codes of (\d+)", t)
     if m: problems += int(m.group(1)); tot["field scenes"] += int(m.group(2))
     m = re.search(r"G-buffer meshes: (\d+) scenes with a differing texel of (\d+)", t)
