@@ -122,6 +122,39 @@ def profiled_per_wave(kernel_prefix, column):
     return None
 
 
+def calibrate_hbm_copy(native, device, ctx, gib=1, reps=6):
+    """What THIS box's HBM gives a plain copy: `gib` GiB device-to-device on the context's stream (hipMemcpyAsync: the runtime's copy kernel), bytes
+    read + bytes written over the time between two HIP events around `reps` copies.  No kernel of this library is involved; buffers are far
+    larger than the 256 MiB Infinity Cache."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    n = int(gib) << 30
+    a, b = C.c_void_p(), C.c_void_p()
+    ctx.Sync()
+    cal = native.Context(device)          # a context of its own: handing out a context's stream changes how that context steps (one stream)
+    stream = cal.stream()
+    if hip.hipMalloc(C.byref(a), C.c_size_t(n)) != 0 or hip.hipMalloc(C.byref(b), C.c_size_t(n)) != 0:
+        cal.close()
+        raise RuntimeError("hipMalloc of the calibration buffers failed")
+    try:
+        hip.hipMemsetAsync(a, 1, C.c_size_t(n), C.c_void_p(stream)); hip.hipMemsetAsync(b, 2, C.c_size_t(n), C.c_void_p(stream))
+        for _ in range(2):
+            hip.hipMemcpyAsync(b, a, C.c_size_t(n), 3, C.c_void_p(stream))          # 3 = hipMemcpyDeviceToDevice
+        cal.sync()
+        cal.timer_start()
+        for _ in range(reps):
+            hip.hipMemcpyAsync(b, a, C.c_size_t(n), 3, C.c_void_p(stream))
+        ms = cal.timer_stop() / reps
+    finally:
+        cal.sync()
+        hip.hipFree(a); hip.hipFree(b)
+        cal.close()
+    rate = 2.0 * n / (ms * 1e-3) / 1e9
+    return {"copy_gb_per_s": round(rate, 1), "frac_of_spec": round(rate / HBM_PEAK_GBS, 4), "gib_per_copy": gib, "copies": reps, "ms_per_copy": round(ms, 4),
+            "is": "hipMemcpyAsync device-to-device of %d GiB on the context's stream, read + written bytes over HIP events around %d copies "
+                  "(this box, this run; MI355X_MICROARCH.md quotes 6.29 TB/s for a float4 copy kernel against the 8 TB/s spec)" % (gib, reps)}
+
+
 def light_launch_waves(native_ctx):
     """Waves of the context's last light-pass launch, from the library itself (ilm_debug_last_light_launch: workgroups of four waves, exit-only
     workgroups of partial tile groups and the members of split tiles included -- what SQ_WAVES counts).  r04 re-derived the grid here and
@@ -1813,6 +1846,24 @@ def main():
     import copy
 
     collective_rows = {}
+
+    # ---- the box's own HBM rate beside the spec figure ("a calibration run ... the calibrated number next to the spec number") ----
+    if rank == 0 and not args.dry_collectives:
+        try:
+            cal = calibrate_hbm_copy(native, local_rank, ctx)
+            out["hbm_calibration"] = cal
+            for key in ("roofline", "roofline_hbm_resident"):
+                rf = out.get(key)
+                if isinstance(rf, dict) and rf.get("bound") == "hbm" and rf.get("achieved"):
+                    rf["calibrated_peak"] = cal["copy_gb_per_s"]
+                    rf["calibrated_frac"] = round(rf["achieved"] / cal["copy_gb_per_s"], 4)
+            for key in ("cfg4_full_64m_one_gpu", "cfg4_share_8m_particles"):
+                rf = (out.get(key) or {}).get("roofline")
+                if isinstance(rf, dict) and rf.get("achieved"):
+                    rf["calibrated_peak"] = cal["copy_gb_per_s"]
+                    rf["calibrated_frac"] = round(rf["achieved"] / cal["copy_gb_per_s"], 4)
+        except Exception as e_:      # noqa: BLE001 -- a calibration that cannot run leaves the spec-based fractions as they are
+            out["hbm_calibration"] = {"error": "%s: %s" % (type(e_).__name__, e_)}
 
     def assemble(optional_rows_note=None):
         o = copy.deepcopy(out)
