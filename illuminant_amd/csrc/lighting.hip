@@ -474,6 +474,10 @@ constexpr int kListCapacity = (kTile == 16) ? 1024 : 256;
 #ifndef ILM_LIGHT_WAVES
 #define ILM_LIGHT_WAVES 8
 #endif
+// the wave-level skip of uncovered list entries (sphere_lights_kernel's walk): 1 = the wide-binning instantiations, 2 = all, 0 = none
+#ifndef ILM_WAVE_SKIP
+#define ILM_WAVE_SKIP 1
+#endif
 #ifndef ILM_LIGHT_SGPRS
 #define ILM_LIGHT_SGPRS
 #endif
@@ -820,6 +824,15 @@ __global__ __launch_bounds__(kLightThreads) ILM_LIGHT_OCCUPANCY void sphere_ligh
                 const bool wide = (cxp >= fx0) & (cxp < fx3) & (cyp >= fy1) & (cyp < fy2);
                 covered = in_image & (tall | wide);
             }
+            // (r06) A wave NONE of whose lanes the entry covers leaves on a scalar branch.  Without it such a wave runs the head of the
+            // pair code masked off -- the compiler only branches around blocks it finds long enough -- ~31 vector instructions per
+            // list entry on the particle-light frame (the tile lists a light whose footprint misses this quadrant, and the cull's box
+            // test did not catch it): 468 M -> 429 M vector instructions per launch, **0.979 -> 0.931 ms per frame**
+            // (profiles/r06_particle_lights_wave_skip_ab.txt).  On the sphere-light instantiations (ILM_WAVE_SKIP=2) it changes nothing
+            // -- cfg3 0.625 / 0.625 -> 0.625 / 0.622, cfg5 8.691 / 8.695 -> 8.701 / 8.704 ms -- their lists are short and their lights
+            // large: the branch is paid by every entry and almost never taken.
+            if ((WIDE_BIN ? (ILM_WAVE_SKIP >= 1) : (ILM_WAVE_SKIP >= 2)) && __builtin_amdgcn_ballot_w64(covered) == 0ull)
+                continue;
             if (!covered)
                 continue;
             if (STATS) st.pairs++;
